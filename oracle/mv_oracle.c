@@ -1,0 +1,392 @@
+/*
+ * mv_oracle.c -- CPU ORACLE for the ColPali late-interaction hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under morphik-core_amd/ may include, link
+ * or call this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker.
+ *
+ * Each function restates, in plain scalar C, the arithmetic of one reference
+ * symbol (paths relative to /root/reference):
+ *
+ *   orc_sign_pack        core/utils/fast_ops.py:191-227 (Python fallback),
+ *                        morphik_rust/src/binary_ops.rs:81-136 (v > 0.0, MSB first)
+ *   orc_hamming          morphik_rust/src/binary_ops.rs:238-264, fast_ops.py:230-239
+ *   orc_maxsim_binary    SQL max_sim(bit[],bit[]) core/vector_store/multi_vector_store.py:285-313
+ *   orc_maxsim_f32/bf16  colpali_engine v0.3.13 score_multi_vector, called at
+ *                        core/vector_store/fast_multivector_store.py:553-555
+ *                        (third-party, not vendored; published algorithm =
+ *                        einsum("bnd,csd->bcns").max(3).sum(2) in fp32 on zero-padded
+ *                        batches; in-container twin transformers
+ *                        models/colpali/processing_colpali.py:208 `score_retrieval`)
+ *   orc_topk             torch.topk(scores, k) fast_multivector_store.py:556 and
+ *                        "ORDER BY similarity DESC LIMIT k" multi_vector_store.py:759;
+ *                        ties are unspecified upstream -> we define (score desc, id asc)
+ *   orc_fde_*            fixed_dimensional_encoding 0.1.0 (C++ ext, SOURCE ABSENT from the
+ *                        snapshot; config at fast_multivector_store.py:325-331, call sites
+ *                        :447-449,:521).  PARITY UNPINNED: restated from the published
+ *                        MUVERA algorithm (Dhulipala et al. 2024; google graph-mining
+ *                        sketching/point_cloud/fixed_dimensional_encoding.cc) with our own
+ *                        counter-based RNG for the projection matrices.
+ *   orc_synth_*          not a reference function: the synthetic corpus generator of
+ *                        SURVEY.md section 8(d), restated so the CPU can regenerate any page
+ *                        the GPU generated.
+ *
+ * Pinning status (see tests/test_oracle_golden.py):
+ *   sign_pack / hamming : pinned against the reference's own Python fallback
+ *                         (imported from /root/reference by oracle/gen_golden.py) and the
+ *                         Rust unit-test known answers.
+ *   float MaxSim        : pinned against transformers' score_retrieval (same einsum) --
+ *                         the reference itself has no test of this boundary.
+ *   binary MaxSim       : pinned against the reference test's known answers
+ *                         (core/tests/unit/test_multivector.py:214-256 -> 1.0 / 0.0).
+ *   FDE                 : PARITY UNPINNED (no source, no tests upstream).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ bf16 */
+
+ORC_API uint16_t orc_f32_to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u); /* quiet NaN */
+  u += 0x7fffu + ((u >> 16) & 1u); /* round to nearest even */
+  return (uint16_t)(u >> 16);
+}
+
+ORC_API float orc_bf16_to_f32(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+ORC_API void orc_f32_to_bf16_n(const float* in, int64_t n, uint16_t* out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = orc_f32_to_bf16(in[i]);
+}
+
+ORC_API void orc_bf16_to_f32_n(const uint16_t* in, int64_t n, float* out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = orc_bf16_to_f32(in[i]);
+}
+
+/* -------------------------------------------------------------- philox4x32-10 */
+
+static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+ORC_API void orc_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
+  philox4x32_10(ctr, key, out);
+}
+
+/* ------------------------------------------------------ synthetic generator */
+/*
+ * Row (unit, row) of stream `seed`, dim 128 (any multiple of 4):
+ *   for chunk c in [0, dim/4): w = philox(ctr=(unit_lo, unit_hi, row, c), key=(seed_lo, seed_hi))
+ *   x[4c+j] = sum of the 4 bytes of w[j] - 510           (Irwin-Hall(4), integer, mean 0)
+ *   ss = sum x^2 (integer)                                (ss == 0 -> x[0] = 1, ss = 1)
+ *   y[i] = bf16_rne( (float)( (double)x[i] / sqrt((double)ss) ) )
+ * Every step is exact integer arithmetic or a correctly-rounded IEEE operation, so the
+ * GPU generator (csrc/mv_synth.hip) is required to reproduce it bit for bit.
+ */
+ORC_API void orc_synth_rows(uint64_t seed, uint64_t unit, int32_t row0, int32_t n_rows, int32_t dim,
+                            uint16_t* out /* n_rows x dim bf16 */) {
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  int32_t* x = (int32_t*)malloc(sizeof(int32_t) * (size_t)dim);
+  for (int32_t r = 0; r < n_rows; ++r) {
+    int64_t ss = 0;
+    for (int32_t c = 0; c < dim / 4; ++c) {
+      uint32_t ctr[4] = {(uint32_t)unit, (uint32_t)(unit >> 32), (uint32_t)(row0 + r), (uint32_t)c};
+      uint32_t w[4];
+      philox4x32_10(ctr, key, w);
+      for (int j = 0; j < 4; ++j) {
+        int32_t v = (int32_t)(w[j] & 0xff) + (int32_t)((w[j] >> 8) & 0xff) + (int32_t)((w[j] >> 16) & 0xff) +
+                    (int32_t)(w[j] >> 24) - 510;
+        x[4 * c + j] = v;
+        ss += (int64_t)v * v;
+      }
+    }
+    if (ss == 0) { x[0] = 1; ss = 1; }
+    double nrm = sqrt((double)ss);
+    for (int32_t i = 0; i < dim; ++i) {
+      float y = (float)((double)x[i] / nrm);
+      out[(size_t)r * dim + i] = orc_f32_to_bf16(y);
+    }
+  }
+  free(x);
+}
+
+/* ------------------------------------------------------------ sign pack (A4) */
+/* fast_ops.py:218-227 / binary_ops.rs:81-136: bit = v > 0.0 (0, -0, NaN -> 0), MSB first,
+ * ceil(d/8) bytes per row, tail bits left-aligned. */
+ORC_API void orc_sign_pack(const float* x, int64_t n_rows, int32_t d, uint8_t* out) {
+  int32_t nb = (d + 7) / 8;
+  for (int64_t r = 0; r < n_rows; ++r) {
+    const float* row = x + r * d;
+    uint8_t* o = out + r * nb;
+    memset(o, 0, (size_t)nb);
+    for (int32_t i = 0; i < d; ++i)
+      if (row[i] > 0.0f) o[i >> 3] |= (uint8_t)(1u << (7 - (i & 7)));
+  }
+}
+
+/* binary_ops.rs:238-264: sum of popcount(a[i]^b[i]). */
+ORC_API int64_t orc_hamming(const uint8_t* a, const uint8_t* b, int64_t n_bytes) {
+  int64_t h = 0;
+  for (int64_t i = 0; i < n_bytes; ++i) h += __builtin_popcount((unsigned)(a[i] ^ b[i]));
+  return h;
+}
+
+/* ------------------------------------------------------- binary MaxSim (A5) */
+/* SQL max_sim (multi_vector_store.py:285-313):
+ *   COALESCE( SUM_q MAX_d ( 1.0 - bit_count(d # q)::float / greatest(bit_length(q),1)::float ), 0.0 )
+ * doc: n_doc rows of nbytes; query: n_q rows of nbytes; bit_length = 8*nbytes.
+ * An empty doc gives an empty CROSS JOIN -> no groups -> SUM over nothing -> NULL -> 0.0. */
+ORC_API double orc_maxsim_binary(const uint8_t* doc, int32_t n_doc, const uint8_t* q, int32_t n_q, int32_t nbytes) {
+  if (n_doc <= 0 || n_q <= 0) return 0.0;
+  double bitlen = (double)(nbytes * 8 > 1 ? nbytes * 8 : 1);
+  double total = 0.0;
+  for (int32_t i = 0; i < n_q; ++i) {
+    double best = -INFINITY;
+    for (int32_t j = 0; j < n_doc; ++j) {
+      double sim = 1.0 - (double)orc_hamming(q + (size_t)i * nbytes, doc + (size_t)j * nbytes, nbytes) / bitlen;
+      if (sim > best) best = sim;
+    }
+    total += best;
+  }
+  return total;
+}
+
+/* ------------------------------------------------------- float MaxSim (A7) */
+/*
+ * One (query, page) score of score_multi_vector:
+ *   S = q @ p^T  (fp32),  score = sum_i max_j S[i][j].
+ * Zero-padding semantics (pad_sequence(padding_value=0) over a batch of pages):
+ * if the page has fewer rows than the longest page of its batch (`pad_to`), the batch
+ * tensor carries all-zero rows for it, each scoring exactly 0 against every query row, so
+ * every per-token max is clamped to >= 0.  pad_to <= n_rows means "no padding row exists".
+ * A page with 0 rows and no padding scores 0 (empty max is not reachable upstream; we define 0).
+ */
+ORC_API float orc_maxsim_f32(const float* q, int32_t n_q, const float* p, int32_t n_rows, int32_t d, int32_t pad_to) {
+  float total = 0.0f;
+  int clamp = pad_to > n_rows;
+  for (int32_t i = 0; i < n_q; ++i) {
+    float best = clamp ? 0.0f : -INFINITY;
+    for (int32_t j = 0; j < n_rows; ++j) {
+      float acc = 0.0f;
+      for (int32_t k = 0; k < d; ++k) acc += q[(size_t)i * d + k] * p[(size_t)j * d + k];
+      if (acc > best) best = acc;
+    }
+    if (best == -INFINITY) best = 0.0f;
+    total += best;
+  }
+  return total;
+}
+
+/* bf16 storage variant: upcast to fp32 first (fast_multivector_store.py:736,774 upcasts at load). */
+ORC_API float orc_maxsim_bf16(const uint16_t* q, int32_t n_q, const uint16_t* p, int32_t n_rows, int32_t d,
+                              int32_t pad_to) {
+  float* qf = (float*)malloc(sizeof(float) * (size_t)(n_q > 0 ? n_q : 1) * d);
+  float* pf = (float*)malloc(sizeof(float) * (size_t)(n_rows > 0 ? n_rows : 1) * d);
+  orc_bf16_to_f32_n(q, (int64_t)n_q * d, qf);
+  orc_bf16_to_f32_n(p, (int64_t)n_rows * d, pf);
+  float s = orc_maxsim_f32(qf, n_q, pf, n_rows, d, pad_to);
+  free(qf);
+  free(pf);
+  return s;
+}
+
+/* Score a fixed-stride bf16 slab: page i occupies rows [i*stride, i*stride+n_rows[i]). */
+ORC_API void orc_maxsim_bf16_slab(const uint16_t* q, int32_t n_q, const uint16_t* slab, const int32_t* n_rows,
+                                  int64_t n_pages, int32_t stride, int32_t d, int32_t pad_to, float* out) {
+  for (int64_t i = 0; i < n_pages; ++i)
+    out[i] = orc_maxsim_bf16(q, n_q, slab + (size_t)i * stride * d, n_rows ? n_rows[i] : stride, d, pad_to);
+}
+
+/* -------------------------------------------------------------------- top-k */
+typedef struct { float s; int64_t id; } orc_pair;
+
+static int pair_cmp(const void* a, const void* b) {
+  const orc_pair* x = (const orc_pair*)a;
+  const orc_pair* y = (const orc_pair*)b;
+  if (x->s > y->s) return -1;
+  if (x->s < y->s) return 1;
+  return (x->id > y->id) - (x->id < y->id);
+}
+
+/* Largest-k, sorted, ties by ascending id; -inf scores (masked pages) are never returned.
+ * Returns the number written (<= k). */
+ORC_API int64_t orc_topk(const float* scores, const int64_t* ids /* nullable */, int64_t n, int64_t k, float* out_s,
+                         int64_t* out_id) {
+  orc_pair* v = (orc_pair*)malloc(sizeof(orc_pair) * (size_t)(n > 0 ? n : 1));
+  int64_t m = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (scores[i] == -INFINITY || scores[i] != scores[i]) continue;
+    v[m].s = scores[i];
+    v[m].id = ids ? ids[i] : i;
+    ++m;
+  }
+  qsort(v, (size_t)m, sizeof(orc_pair), pair_cmp);
+  if (k > m) k = m;
+  for (int64_t i = 0; i < k; ++i) { out_s[i] = v[i].s; out_id[i] = v[i].id; }
+  free(v);
+  return k;
+}
+
+/* ---------------------------------------------------------------------- FDE */
+/*
+ * MUVERA fixed dimensional encoding, configuration of fast_multivector_store.py:325-331:
+ *   dimension=128, num_repetitions=20, num_simhash_projections=5, projection_dimension=16,
+ *   projection_type=AMS_SKETCH; query encoding = SUM per partition, document encoding =
+ *   AVERAGE per partition (empty partition -> zeros; fill_empty_partitions not set upstream).
+ * Per repetition r (seed + r):
+ *   sketch[j]   = sum_k x[k] * G_r[k][j]                j < n_simhash      (Gaussian hyperplanes)
+ *   partition   = gray-code index of the bits (sketch[j] > 0)  (AppendToGrayCode upstream)
+ *   proj[c]     = (1/sqrt(proj_dim)) * sum_{i : h_r(i)=c} s_r(i) * x[i]     (AMS sketch)
+ *   out[r][partition][:] += proj            (doc: divided by the partition's point count)
+ * Arithmetic contract shared with the HIP kernels (so partitions agree bit for bit):
+ *   sketch is an fp32 fmaf chain over k ascending starting from 0.0f; proj is fp32 adds of
+ *   +-x[i] over i ascending followed by one multiply by the fp32 scale.
+ * RNG (ours; upstream's std::mt19937 stream is not reproducible without its sources):
+ *   G_r[k][j]: philox(ctr=(k, j, r, 0x47), key=seed) and philox(ctr=(k, j, r, 0x48), key=seed)
+ *              -> 8 words -> 16 u16 halves, first 12 summed: g = (sum - 6*65535) / 65536  (Irwin-Hall(12))
+ *   h_r(i), s_r(i): w = philox(ctr=(i, 0, r, 0x41), key=seed); h = w[0] % proj_dim; s = (w[1] & 1) ? +1 : -1
+ */
+typedef struct {
+  int32_t dimension;
+  int32_t num_repetitions;
+  int32_t num_simhash_projections;
+  int32_t projection_dimension;
+  uint64_t seed;
+} orc_fde_config;
+
+ORC_API int64_t orc_fde_output_dim(const orc_fde_config* c) {
+  return (int64_t)c->num_repetitions * (1 << c->num_simhash_projections) * c->projection_dimension;
+}
+
+ORC_API void orc_fde_matrices(const orc_fde_config* c, float* G /* [rep][dim][nsh] */, int32_t* H /* [rep][dim] */,
+                              float* S /* [rep][dim] */) {
+  uint32_t key[2] = {(uint32_t)c->seed, (uint32_t)(c->seed >> 32)};
+  for (int32_t r = 0; r < c->num_repetitions; ++r) {
+    for (int32_t k = 0; k < c->dimension; ++k) {
+      for (int32_t j = 0; j < c->num_simhash_projections; ++j) {
+        uint32_t ctr[4] = {(uint32_t)k, (uint32_t)j, (uint32_t)r, 0x47u};
+        uint32_t w[8];
+        philox4x32_10(ctr, key, w);
+        ctr[3] = 0x48u;
+        philox4x32_10(ctr, key, w + 4);
+        int32_t sum = 0;
+        for (int t = 0; t < 6; ++t) sum += (int32_t)(w[t] & 0xffff) + (int32_t)(w[t] >> 16);
+        G[((size_t)r * c->dimension + k) * c->num_simhash_projections + j] =
+            (float)(sum - 6 * 65535) * (1.0f / 65536.0f);
+      }
+      uint32_t ctr[4] = {(uint32_t)k, 0u, (uint32_t)r, 0x41u};
+      uint32_t w[4];
+      philox4x32_10(ctr, key, w);
+      H[(size_t)r * c->dimension + k] = (int32_t)(w[0] % (uint32_t)c->projection_dimension);
+      S[(size_t)r * c->dimension + k] = (w[1] & 1u) ? 1.0f : -1.0f;
+    }
+  }
+}
+
+static uint32_t gray_append(uint32_t g, uint32_t bit) { return (g << 1) + (bit ^ (g & 1u)); }
+
+/* is_query != 0: SUM encoding; else AVERAGE. x: n_rows x dimension fp32. out: orc_fde_output_dim floats. */
+ORC_API void orc_fde_encode(const orc_fde_config* c, const float* x, int32_t n_rows, int32_t is_query, float* out) {
+  int32_t D = c->dimension, R = c->num_repetitions, NS = c->num_simhash_projections, PD = c->projection_dimension;
+  int32_t NP = 1 << NS;
+  int64_t od = orc_fde_output_dim(c);
+  float* G = (float*)malloc(sizeof(float) * (size_t)R * D * NS);
+  int32_t* H = (int32_t*)malloc(sizeof(int32_t) * (size_t)R * D);
+  float* S = (float*)malloc(sizeof(float) * (size_t)R * D);
+  int32_t* cnt = (int32_t*)calloc((size_t)R * NP, sizeof(int32_t));
+  float* proj = (float*)malloc(sizeof(float) * (size_t)PD);
+  orc_fde_matrices(c, G, H, S);
+  memset(out, 0, sizeof(float) * (size_t)od);
+  float scale = 1.0f / sqrtf((float)PD);
+  for (int32_t r = 0; r < R; ++r) {
+    const float* Gr = G + (size_t)r * D * NS;
+    for (int32_t p = 0; p < n_rows; ++p) {
+      const float* row = x + (size_t)p * D;
+      uint32_t part = 0;
+      for (int32_t j = 0; j < NS; ++j) {
+        float acc = 0.0f;
+        for (int32_t k = 0; k < D; ++k) acc = fmaf(row[k], Gr[(size_t)k * NS + j], acc);
+        part = gray_append(part, acc > 0.0f ? 1u : 0u);
+      }
+      for (int32_t t = 0; t < PD; ++t) proj[t] = 0.0f;
+      for (int32_t i = 0; i < D; ++i) proj[H[(size_t)r * D + i]] += S[(size_t)r * D + i] * row[i];
+      float* o = out + ((size_t)r * NP + part) * PD;
+      for (int32_t t = 0; t < PD; ++t) o[t] += proj[t] * scale;
+      cnt[(size_t)r * NP + part] += 1;
+    }
+    if (!is_query) {
+      for (int32_t b = 0; b < NP; ++b) {
+        int32_t n = cnt[(size_t)r * NP + b];
+        if (n > 1) {
+          float* o = out + ((size_t)r * NP + b) * PD;
+          for (int32_t t = 0; t < PD; ++t) o[t] = o[t] / (float)n;
+        }
+      }
+    }
+  }
+  free(G); free(H); free(S); free(cnt); free(proj);
+}
+
+/* Partition ids only (exactness check of the simhash stage): out[rep][row]. */
+ORC_API void orc_fde_partitions(const orc_fde_config* c, const float* x, int32_t n_rows, int32_t* out) {
+  int32_t D = c->dimension, R = c->num_repetitions, NS = c->num_simhash_projections;
+  float* G = (float*)malloc(sizeof(float) * (size_t)R * D * NS);
+  int32_t* H = (int32_t*)malloc(sizeof(int32_t) * (size_t)R * D);
+  float* S = (float*)malloc(sizeof(float) * (size_t)R * D);
+  orc_fde_matrices(c, G, H, S);
+  for (int32_t r = 0; r < R; ++r) {
+    const float* Gr = G + (size_t)r * D * NS;
+    for (int32_t p = 0; p < n_rows; ++p) {
+      const float* row = x + (size_t)p * D;
+      uint32_t part = 0;
+      for (int32_t j = 0; j < NS; ++j) {
+        float acc = 0.0f;
+        for (int32_t k = 0; k < D; ++k) acc = fmaf(row[k], Gr[(size_t)k * NS + j], acc);
+        part = gray_append(part, acc > 0.0f ? 1u : 0u);
+      }
+      out[(size_t)r * n_rows + p] = (int32_t)part;
+    }
+  }
+  free(G); free(H); free(S);
+}
+
+/* Coarse score of the FDE stage (A9): TurboPuffer ANN with distance_metric="cosine_distance"
+ * (fast_multivector_store.py:497,526-532) ranks by cosine; for a fixed query that is
+ * dot(q, d) / |d|.  The slab stores bf16(d); use_cosine == 0 gives the plain MUVERA dot. */
+ORC_API void orc_fde_coarse_scores(const float* qf, const uint16_t* dslab, int64_t n_pages, int64_t dim,
+                                   int32_t use_cosine, float* out) {
+  for (int64_t p = 0; p < n_pages; ++p) {
+    const uint16_t* d = dslab + (size_t)p * dim;
+    double dot = 0.0, nn = 0.0;
+    for (int64_t i = 0; i < dim; ++i) {
+      double v = (double)orc_bf16_to_f32(d[i]);
+      dot += (double)qf[i] * v;
+      nn += v * v;
+    }
+    if (use_cosine) out[p] = nn > 0.0 ? (float)(dot / sqrt(nn)) : 0.0f;
+    else out[p] = (float)dot;
+  }
+}

@@ -1,0 +1,218 @@
+"""Pin the CPU oracle against everything the reference offers for this path.
+
+Golden fixtures under tests/golden/ were produced by oracle/gen_golden.py from the reference's
+own importable code (core/utils/fast_ops.py) and from transformers' score_retrieval (the
+in-container twin of colpali_engine.score_multi_vector).  Known answers are quoted from the
+reference's tests with file:line.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+# ---------------------------------------------------------------- A4 sign pack
+def test_sign_pack_matches_reference_fast_ops(golden_dir):
+    g = _load(golden_dir, "sign_pack.npz")
+    for ci in range(int(g["n_cases"])):
+        x, packed, bools = g[f"x{ci}"], g[f"packed{ci}"], g[f"bools{ci}"]
+        got = orc.sign_pack(x)
+        assert got.dtype == np.uint8 and got.shape == packed.shape
+        assert np.array_equal(got, packed), f"case {ci}"
+        assert np.array_equal(orc.sign_pack_np(x), packed), f"case {ci} (numpy)"
+        d = x.shape[1]
+        assert np.array_equal(np.unpackbits(got, axis=-1)[:, :d].astype(bool), bools)
+
+
+def test_sign_pack_reference_unit_test_case(golden_dir):
+    # core/tests/unit/test_multivector.py:94-109: [[0.1,-0.2,0.3],[-0.1,0.2,-0.3]] -> "101", "010"
+    got = orc.sign_pack(np.array([[0.1, -0.2, 0.3], [-0.1, 0.2, -0.3]], np.float32))
+    assert [format(b >> 5, "03b") for b in got[:, 0]] == ["101", "010"]
+    g = _load(golden_dir, "sign_pack.npz")
+    assert g["bools_ref_test"].tolist() == [[True, False, True], [False, True, False]]
+
+
+def test_sign_pack_rust_known_answers():
+    # morphik_rust/src/binary_ops.rs:309-320 -> 0b10100101 (MSB first)
+    assert orc.sign_pack(np.array([1, -1, 1, -1, -1, 1, -1, 1], np.float32))[0, 0] == 0b10100101
+    # binary_ops.rs:298-306: zero maps to 0
+    bits = np.unpackbits(orc.sign_pack(np.array([1.0, -0.5, 0.1, -2.0, 0.0, 3.0, -1.0, 0.5], np.float32)))[:8]
+    assert bits.astype(bool).tolist() == [True, False, True, False, False, True, False, True]
+
+
+def test_hamming_matches_reference(golden_dir):
+    g = _load(golden_dir, "hamming.npz")
+    for a, b, hd in zip(g["a"], g["b"], g["hd"]):
+        assert orc.hamming(a, b) == hd
+    assert [orc.hamming(g["q"], y) for y in g["b"]] == g["batch"].tolist()
+    # binary_ops.rs:322-334
+    assert orc.hamming(bytes([0b11110000, 0b10101010]), bytes([0b11110000, 0b01010101])) == 8
+
+
+# ---------------------------------------------------------------- A5 binary MaxSim
+def test_binary_maxsim_reference_known_ranking():
+    # core/tests/unit/test_multivector.py:214-256: doc1 = 3 x (+1*64, -1*64), doc2 = negation,
+    # query = 1 x (+1*64, -1*64) -> ranking [doc1, doc2]; SQL scores are exactly 1.0 and 0.0.
+    half = np.concatenate([np.ones(64), -np.ones(64)]).astype(np.float32)
+    doc1 = orc.sign_pack(np.stack([half] * 3))
+    doc2 = orc.sign_pack(np.stack([-half] * 3))
+    q = orc.sign_pack(half[None])
+    assert orc.maxsim_binary(doc1, q) == 1.0
+    assert orc.maxsim_binary(doc2, q) == 0.0
+
+
+def test_binary_maxsim_identity_with_pm1_gemm():
+    # SURVEY 8(a) A5 identity: max_sim = 0.5*Q + (1/256) * sum_q max_d (s_q . s_d), s = 2b-1
+    rng = np.random.default_rng(3)
+    docs = rng.standard_normal((5, 37, 128)).astype(np.float32)
+    q = rng.standard_normal((9, 128)).astype(np.float32)
+    qb = orc.sign_pack(q)
+    sq = np.where(q > 0, 1.0, -1.0)
+    for d in docs:
+        sd = np.where(d > 0, 1.0, -1.0)
+        ident = 0.5 * q.shape[0] + (sq @ sd.T).max(1).sum() / 256.0
+        assert orc.maxsim_binary(orc.sign_pack(d), qb) == ident
+    vec = orc.maxsim_binary_np(np.stack([orc.sign_pack(d) for d in docs]), qb)
+    assert vec.tolist() == [orc.maxsim_binary(orc.sign_pack(d), qb) for d in docs]
+
+
+def test_binary_maxsim_empty():
+    q = orc.sign_pack(np.ones((2, 128), np.float32))
+    assert orc.maxsim_binary(np.zeros((0, 16), np.uint8), q) == 0.0  # COALESCE(..., 0.0)
+
+
+# ---------------------------------------------------------------- A7 float MaxSim
+def test_float_maxsim_matches_score_retrieval(golden_dir):
+    g = _load(golden_dir, "maxsim_float.npz")
+    for ci in range(int(g["n_cases"])):
+        q, slab, n_rows, pad_to, want = (g[f"{k}{ci}"] for k in ("q", "slab", "n_rows", "pad_to", "scores"))
+        got = np.array([orc.maxsim_f32(q, slab[i, : n_rows[i]], int(pad_to[i])) for i in range(slab.shape[0])], np.float32)
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-6, err_msg=f"case {ci}")
+        # numpy restatement (the bench's CPU baseline) agrees too
+        got_np = np.concatenate(
+            [
+                orc.maxsim_float_np(q, slab[j : j + 128], n_rows[j : j + 128], pad_to=int(pad_to[j]))
+                for j in range(0, slab.shape[0], 128)
+            ]
+        )
+        np.testing.assert_allclose(got_np, want, rtol=2e-6, atol=2e-6, err_msg=f"case {ci} numpy")
+
+
+def test_float_maxsim_bf16_path_and_torch_formulation():
+    q = orc.synth_rows(4321, 0, 0, 32)
+    pages = orc.synth_pages(1234, 0, 6, 48)
+    a = orc.maxsim_bf16_slab(q, pages)
+    b = orc.maxsim_float_np(orc.bf16_to_f32(q), orc.bf16_to_f32(pages))
+    c = orc.maxsim_float_torch(orc.bf16_to_f32(q), orc.bf16_to_f32(pages))
+    np.testing.assert_allclose(a, b, rtol=1e-6)
+    np.testing.assert_allclose(a, c, rtol=1e-6)
+
+
+def test_float_maxsim_zero_query_row_contributes_zero():
+    rng = np.random.default_rng(0)
+    p = rng.standard_normal((10, 128)).astype(np.float32)
+    q = rng.standard_normal((4, 128)).astype(np.float32)
+    q0 = np.concatenate([q, np.zeros((3, 128), np.float32)])
+    assert orc.maxsim_f32(q0, p) == pytest.approx(orc.maxsim_f32(q, p), rel=1e-7)
+
+
+# ---------------------------------------------------------------- top-k tie rule
+def test_topk_order_and_ties():
+    s = np.array([1.0, 3.0, 3.0, -np.inf, 2.0, 3.0, np.nan], np.float32)
+    sc, ids = orc.topk(s, 4)
+    assert ids.tolist() == [1, 2, 5, 4] and sc.tolist() == [3.0, 3.0, 3.0, 2.0]
+    sc, ids = orc.topk(s, 100)  # k may exceed N; masked (-inf) rows never come back
+    assert ids.tolist() == [1, 2, 5, 4, 0]
+    import torch
+
+    r = np.random.default_rng(5).standard_normal(1000).astype(np.float32)
+    tv, ti = torch.topk(torch.from_numpy(r), 17)  # reference: torch.topk (fast_multivector_store.py:556)
+    sc, ids = orc.topk(r, 17)
+    assert ids.tolist() == ti.tolist() and sc.tolist() == tv.tolist()
+
+
+# ---------------------------------------------------------------- bf16 + generator
+def test_bf16_rounding_matches_torch():
+    import torch
+
+    rng = np.random.default_rng(1)
+    x = np.concatenate(
+        [rng.standard_normal(5000).astype(np.float32) * 10.0 ** rng.integers(-20, 20, 5000), np.array([0.0, -0.0, np.inf, -np.inf, 1.0039062, 1.00390625, 3.3895314e38], np.float32)]
+    ).astype(np.float32)
+    want = torch.from_numpy(x).bfloat16().view(torch.int16).numpy().view(np.uint16)
+    assert np.array_equal(orc.f32_to_bf16(x), want)
+    assert np.array_equal(orc.f32_to_bf16_np(x), want)
+    assert np.array_equal(orc.bf16_to_f32(want), torch.from_numpy(x).bfloat16().float().numpy())
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors, philox4x32-10
+    assert orc.philox([0, 0, 0, 0], [0, 0]).tolist() == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert orc.philox([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2).tolist() == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert orc.philox([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]).tolist() == [
+        0xD16CFE09,
+        0x94FDCCEB,
+        0x5001E420,
+        0x24126EA1,
+    ]
+
+
+def test_synth_rows_are_unit_norm_and_addressable():
+    a = orc.synth_rows(1234, 7, 0, 64)
+    b = orc.synth_rows(1234, 7, 10, 5)
+    assert np.array_equal(a[10:15], b)  # any (page,row) regenerates independently
+    n = np.linalg.norm(orc.bf16_to_f32(a), axis=1)
+    assert np.all(np.abs(n - 1.0) < 5e-3)
+    assert not np.array_equal(a, orc.synth_rows(1235, 7, 0, 64))
+    m = orc.bf16_to_f32(orc.synth_rows(1, 0, 0, 2048)).mean()
+    assert abs(m) < 2e-3
+
+
+# ---------------------------------------------------------------- FDE (parity unpinned upstream)
+def test_fde_structural_invariants():
+    cfg = orc.FdeConfig.reference_default()
+    assert cfg.output_dim == 10240  # 20 x 32 x 16 (fast_multivector_store.py:325-331)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((50, 128)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    fq = orc.fde_encode(cfg, x, True)
+    fd = orc.fde_encode(cfg, x, False)
+    assert fq.shape == (10240,) and fd.shape == (10240,)
+    # permutation invariance over rows (up to fp32 summation order)
+    perm = rng.permutation(50)
+    np.testing.assert_allclose(orc.fde_encode(cfg, x[perm], True), fq, rtol=0, atol=1e-5)
+    # query encoding is additive over disjoint row sets
+    np.testing.assert_allclose(orc.fde_encode(cfg, x[:20], True) + orc.fde_encode(cfg, x[20:], True), fq, atol=1e-5)
+    # doc = per-partition mean: sum-encoding divided by partition counts
+    parts = orc.fde_partitions(cfg, x)
+    assert parts.min() >= 0 and parts.max() < 32
+    fq3, fd3 = fq.reshape(20, 32, 16), fd.reshape(20, 32, 16)
+    for r in range(20):
+        cnt = np.bincount(parts[r], minlength=32)
+        for b in range(32):
+            if cnt[b] == 0:
+                assert not fd3[r, b].any() and not fq3[r, b].any()
+            else:
+                np.testing.assert_allclose(fd3[r, b], fq3[r, b] / cnt[b], rtol=1e-6, atol=1e-7)
+    G, H, S = orc.fde_matrices(cfg)
+    assert H.min() >= 0 and H.max() < 16 and set(np.unique(S)) == {-1.0, 1.0}
+    assert abs(G.mean()) < 0.05 and 0.9 < G.std() < 1.1
+
+
+def test_fde_dot_tracks_maxsim():
+    cfg = orc.FdeConfig.reference_default()
+    q = orc.bf16_to_f32(orc.synth_rows(4321, 0, 0, 32))
+    pages = orc.bf16_to_f32(orc.synth_pages(1234, 0, 40, 64))
+    # plant a near-copy of the query in page 3
+    pages[3, :32] = q
+    fq = orc.fde_encode(cfg, q, True)
+    fds = np.stack([orc.fde_encode(cfg, p, False) for p in pages])
+    coarse = orc.fde_coarse_scores(fq, orc.f32_to_bf16(fds), use_cosine=False)
+    exact = orc.maxsim_float_np(q, pages)
+    assert int(np.argmax(coarse)) == 3 == int(np.argmax(exact))
