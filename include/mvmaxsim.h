@@ -1,0 +1,191 @@
+/*
+ * mvmaxsim.h -- C ABI of libmvmaxsim.so, the MI355X (gfx950) late-interaction retrieval engine.
+ *
+ * Flat C, caller-owned host buffers, library-owned device memory, no C++/torch types.
+ * Every entry point returns 0 on success or a negative mv_status; mv_last_error() returns a
+ * thread-local message for the last failure on the calling thread.
+ *
+ * Each function names the reference interface it replaces (paths relative to the
+ * morphik-core checkout).  The reference has no FFI for this path today -- scoring lives in a
+ * PostgreSQL SQL function, a third-party torch einsum and an un-vendored C++ extension -- so
+ * these are the entry points a ctypes binding inside core/vector_store/ would bind
+ * (INTEGRATION.md shows that binding).
+ */
+#ifndef MVMAXSIM_H
+#define MVMAXSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MV_API __attribute__((visibility("default")))
+
+typedef enum {
+  MV_OK = 0,
+  MV_ERR_INVALID = -1,   /* bad argument */
+  MV_ERR_HIP = -2,       /* HIP runtime error (message has the hipError string) */
+  MV_ERR_NOMEM = -3,     /* device or host allocation failed */
+  MV_ERR_CAPACITY = -4,  /* slab full */
+  MV_ERR_STATE = -5,     /* feature not enabled on this index */
+  MV_ERR_IO = -6         /* save/load failure */
+} mv_status;
+
+typedef enum { MV_F32 = 0, MV_BF16 = 1 } mv_dtype;
+
+/* Scoring modes of mv_query_topk / mv_score_all. */
+typedef enum {
+  MV_MODE_FLOAT = 0,          /* exact float MaxSim over every page (score_multi_vector semantics) */
+  MV_MODE_BINARY = 1,         /* sign-bit MaxSim == SQL max_sim(bit[],bit[]) */
+  MV_MODE_FDE_THEN_FLOAT = 2, /* FDE coarse top-n_coarse -> exact float rerank (FastMultiVectorStore) */
+  MV_MODE_FDE_ONLY = 3        /* coarse FDE scores only (the TurboPuffer ANN stage) */
+} mv_mode;
+
+/* Index feature flags (mv_config.flags). */
+enum {
+  MV_WITH_FLOAT = 1,  /* bf16 page slab (262 144 B / 1024-patch page) */
+  MV_WITH_BINARY = 2, /* sign-bit slab   ( 16 384 B / page)            */
+  MV_WITH_FDE = 4     /* bf16 FDE slab   ( 20 480 B / page)            */
+};
+
+/* fixed_dimensional_encoding.FixedDimensionalEncodingConfig as constructed at
+ * core/vector_store/fast_multivector_store.py:325-331 (AMS_SKETCH projection, query=SUM,
+ * document=AVERAGE). */
+typedef struct {
+  int32_t dimension;               /* 128 */
+  int32_t num_repetitions;         /* 20  */
+  int32_t num_simhash_projections; /* 5   */
+  int32_t projection_dimension;    /* 16  */
+  uint64_t seed;                   /* 1   */
+} mv_fde_config;
+
+typedef struct {
+  int32_t dim;            /* embedding width; must be 128 */
+  int32_t stride_rows;    /* patch rows reserved per page (multiple of 16), e.g. 1024 or 1040 */
+  int64_t capacity_pages; /* pages the slabs are sized for (fixed at create) */
+  int32_t device;         /* HIP device ordinal */
+  int32_t flags;          /* MV_WITH_* */
+  int64_t id_base;        /* global page id of local page 0 (row-sharded corpora: rank r passes r*N/R) */
+  mv_fde_config fde;      /* used when flags & MV_WITH_FDE */
+} mv_config;
+
+/* Per-call timing and accounting, filled when a non-NULL pointer is passed. Times are HIP-event
+ * durations on the index's stream (the stream the kernels were launched on). */
+typedef struct {
+  float score_kernel_ms;  /* the page-scan kernel(s) only */
+  float topk_ms;          /* selection kernels */
+  float total_device_ms;  /* first launch .. last kernel */
+  int32_t score_launches; /* kernel launches that make up score_kernel_ms */
+  int32_t reserved;
+  int64_t pages_scored;   /* pages whose embeddings were read (masked pages excluded) */
+  int64_t bytes_scanned;  /* algorithmic bytes: pages_scored * rows * row_bytes */
+} mv_query_stats;
+
+typedef struct mv_index mv_index;
+
+/* Tunables for mv_index_set_option. */
+typedef enum {
+  MV_OPT_MAXSIM_VARIANT = 1, /* float kernel variant id; -1 = default */
+  MV_OPT_FDE_COARSE_N = 2,   /* candidates kept by the FDE stage (reference: min(10*k, 75)) ; 0 = reference rule */
+  MV_OPT_FDE_COSINE = 3,     /* 1 = rank coarse stage by cosine (TurboPuffer cosine_distance, reference), 0 = dot */
+  MV_OPT_PAD_SEMANTICS = 4   /* 0 = max over a page's own rows only; 1 = reference rerank batch rule
+                                (pad_to = longest candidate of the batch of 128 => clamp at 0) */
+} mv_option;
+
+MV_API const char* mv_last_error(void);
+MV_API const char* mv_version(void);
+MV_API int mv_device_count(void);
+
+/* Lifecycle.  Replaces MultiVectorStore.initialize() (core/vector_store/multi_vector_store.py:186-327:
+ * table + max_sim function creation) and FastMultiVectorStore.__init__ (fast_multivector_store.py:296-338). */
+MV_API int mv_index_create(const mv_config* cfg, mv_index** out);
+MV_API void mv_index_destroy(mv_index* ix);
+MV_API int mv_index_set_option(mv_index* ix, int option, int64_t value);
+MV_API int64_t mv_index_size(const mv_index* ix);     /* pages appended so far (including tombstoned) */
+MV_API int64_t mv_index_capacity(const mv_index* ix);
+
+/* Append pages.  `emb` is a HOST buffer of sum(n_rows) rows x dim, pages back to back (ragged),
+ * dtype MV_F32 or MV_BF16.  doc_ordinals[i] >= 0 is the caller's dense document number used by
+ * the doc_ids filter.  The call fills every enabled slab (bf16 rows, sign bits, FDE) on the GPU.
+ * Replaces store_embeddings' device-independent work: MultiVectorStore._binary_quantize +
+ * INSERT (multi_vector_store.py:681-699,963-979) and FastMultiVectorStore's
+ * fde.generate_document_encoding + np.save (fast_multivector_store.py:447-449,673-707).
+ * Returns the local id of the first appended page in *out_first_page. */
+MV_API int mv_index_add(mv_index* ix, const void* emb, int dtype, const int32_t* n_rows, int64_t n_pages,
+                        const int32_t* doc_ordinals, int64_t* out_first_page);
+/* Same, `emb` is a DEVICE pointer on the index's device (encoder output stays on the GPU). */
+MV_API int mv_index_add_device(mv_index* ix, const void* d_emb, int dtype, const int32_t* n_rows, int64_t n_pages,
+                               const int32_t* doc_ordinals, int64_t* out_first_page);
+
+/* Tombstone every page of a document / one page.  Replaces
+ * delete_chunks_by_document_id (multi_vector_store.py:921-951). Returns pages removed in *out_n. */
+MV_API int mv_index_remove_doc(mv_index* ix, int32_t doc_ordinal, int64_t* out_n);
+MV_API int mv_index_remove_page(mv_index* ix, int64_t page);
+
+/* Read back bf16 rows of pages [page0, page0+n) (stride_rows x dim each) to a host buffer. */
+MV_API int mv_index_read_pages(mv_index* ix, int64_t page0, int64_t n_pages, void* out_bf16);
+/* Overwrite rows [row0,row0+n) of one page with host bf16 data (test/bench: planted neighbours).
+ * Only the float slab is touched. */
+MV_API int mv_index_write_rows(mv_index* ix, int64_t page, int32_t row0, int32_t n, const void* bf16_rows);
+/* Synthetic corpus: append n_pages pages of n_rows rows generated ON THE DEVICE by the
+ * counter-based generator (key=seed, counter=(unit,row,chunk)); unit of page i = first_unit + i.
+ * Bit-identical to oracle/mv_oracle.c:orc_synth_rows. doc ordinal of page i = (first_unit+i) / pages_per_doc. */
+MV_API int mv_index_fill_synthetic(mv_index* ix, uint64_t seed, uint64_t first_unit, int64_t n_pages, int32_t n_rows,
+                                   int32_t pages_per_doc);
+/* Host helper: the same generator for queries (n_rows x 128 bf16 to a host buffer, computed on the GPU). */
+MV_API int mv_synth_rows(int device, uint64_t seed, uint64_t unit, int32_t n_rows, void* out_bf16);
+
+/* Top-k query.  Replaces the scoring half of MultiVectorStore.query_similar
+ * (multi_vector_store.py:721-763: quantise query -> SQL max_sim -> ORDER BY similarity DESC LIMIT k)
+ * for MV_MODE_BINARY and of FastMultiVectorStore.query_similar (fast_multivector_store.py:504-556:
+ * fde.generate_query_encoding -> ANN -> score_multi_vector -> torch.topk) for the other modes.
+ *   q           host buffer, n_q_rows x dim, MV_F32 or MV_BF16
+ *   allow_bits  optional bitmap over doc ordinals (bit set = allowed), n_allow_words 32-bit words;
+ *               NULL = no doc_ids filter
+ *   out_scores  k floats, out_ids k int64 (GLOBAL page ids = id_base + local), *out_n = results (<= k)
+ * Order: score descending, ties by ascending id (upstream order under ties is unspecified). */
+MV_API int mv_query_topk(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int32_t k, int mode,
+                         const uint32_t* allow_bits, int64_t n_allow_words, float* out_scores, int64_t* out_ids,
+                         int32_t* out_n, mv_query_stats* stats);
+/* Same selection, results left on the device (for the RCCL all-gather of per-shard top-k):
+ * d_out_scores/d_out_ids are DEVICE buffers of k entries, padded with (-inf, -1).  stream = the
+ * hipStream_t to order against (NULL = index stream: the call returns after the kernels finished;
+ * with a stream it only enqueues, unless stats != NULL, which waits for the event timings). */
+MV_API int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int32_t k, int mode,
+                                const uint32_t* allow_bits, int64_t n_allow_words, float* d_out_scores,
+                                int64_t* d_out_ids, void* stream, mv_query_stats* stats);
+/* Score every page (no selection): out_scores[size] floats on the host; masked pages get -inf.
+ * For MV_MODE_FDE_* this returns the coarse scores. */
+MV_API int mv_score_all(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int mode,
+                        const uint32_t* allow_bits, int64_t n_allow_words, float* out_scores, mv_query_stats* stats);
+/* Exact float MaxSim of an explicit candidate list (local page ids). pad_to as in MV_OPT_PAD_SEMANTICS=1
+ * (0 = none).  Replaces processor.score_multi_vector(...) at fast_multivector_store.py:553-555. */
+MV_API int mv_score_candidates(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const int32_t* cand,
+                               int32_t n_cand, int32_t pad_to, float* out_scores, mv_query_stats* stats);
+
+/* Stateless helpers (host in, host out, computed on `device`).
+ * mv_sign_pack replaces fast_ops.binary_quantize_packed (core/utils/fast_ops.py:191-227 ->
+ * morphik_rust binary_quantize_batch_packed, src/binary_ops.rs:148-222): bit = v > 0, MSB first. */
+MV_API int mv_sign_pack(int device, const float* x, int64_t n_rows, int32_t d, uint8_t* out);
+/* mv_hamming_batch replaces fast_ops.hamming_distance_batch (fast_ops.py:242-248, binary_ops.rs:267-292). */
+MV_API int mv_hamming_batch(int device, const uint8_t* query, const uint8_t* cands, int64_t n_cands, int32_t n_bytes,
+                            int32_t* out);
+/* mv_fde_encode replaces fde.generate_query_encoding / generate_document_encoding
+ * (fast_multivector_store.py:521 / :447-449).  out has mv_fde_output_dim(cfg) floats. */
+MV_API int64_t mv_fde_output_dim(const mv_fde_config* cfg);
+MV_API int mv_fde_encode(int device, const mv_fde_config* cfg, const float* x, int32_t n_rows, int32_t is_query,
+                         float* out);
+
+/* Calibration: stream-read `bytes` of device memory `iters` times, returns average GB/s (measured peak
+ * for the roofline denominator next to the 8 TB/s datasheet figure). */
+MV_API int mv_calibrate_read_bw(int device, int64_t bytes, int32_t iters, double* out_gbps);
+
+/* Persistence ("checkpoint" of the HBM index): raw slabs + metadata in one file. */
+MV_API int mv_index_save(mv_index* ix, const char* path);
+MV_API int mv_index_load(const char* path, int32_t device, mv_index** out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVMAXSIM_H */

@@ -1,0 +1,135 @@
+"""ctypes binding of libmvmaxsim.so (include/mvmaxsim.h).
+
+There is NO CPU fallback: if the HIP library is missing or no MI355X is visible, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libmvmaxsim.so")
+_CSRC = os.path.join(_HERE, "csrc")
+
+
+class MvError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libmvmaxsim error {status}: {message}")
+        self.status = status
+
+
+def library_path() -> str:
+    return _LIB
+
+
+def build_library(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", _CSRC, "-s", "clean"])
+    subprocess.check_call(["make", "-C", _CSRC, "-s", "-j8"])
+    return _LIB
+
+
+class FdeConfigC(C.Structure):
+    _fields_ = [
+        ("dimension", C.c_int32),
+        ("num_repetitions", C.c_int32),
+        ("num_simhash_projections", C.c_int32),
+        ("projection_dimension", C.c_int32),
+        ("seed", C.c_uint64),
+    ]
+
+
+class ConfigC(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int32),
+        ("stride_rows", C.c_int32),
+        ("capacity_pages", C.c_int64),
+        ("device", C.c_int32),
+        ("flags", C.c_int32),
+        ("id_base", C.c_int64),
+        ("fde", FdeConfigC),
+    ]
+
+
+class QueryStatsC(C.Structure):
+    _fields_ = [
+        ("score_kernel_ms", C.c_float),
+        ("topk_ms", C.c_float),
+        ("total_device_ms", C.c_float),
+        ("score_launches", C.c_int32),
+        ("reserved", C.c_int32),
+        ("pages_scored", C.c_int64),
+        ("bytes_scanned", C.c_int64),
+    ]
+
+
+MV_F32, MV_BF16 = 0, 1
+MV_MODE_FLOAT, MV_MODE_BINARY, MV_MODE_FDE_THEN_FLOAT, MV_MODE_FDE_ONLY = 0, 1, 2, 3
+MV_WITH_FLOAT, MV_WITH_BINARY, MV_WITH_FDE = 1, 2, 4
+MV_OPT_MAXSIM_VARIANT, MV_OPT_FDE_COARSE_N, MV_OPT_FDE_COSINE, MV_OPT_PAD_SEMANTICS = 1, 2, 3, 4
+
+# every symbol include/mvmaxsim.h declares (tests check the .so exports all of them)
+EXPORTS = [
+    "mv_last_error", "mv_version", "mv_device_count", "mv_index_create", "mv_index_destroy", "mv_index_set_option",
+    "mv_index_size", "mv_index_capacity", "mv_index_add", "mv_index_add_device", "mv_index_remove_doc",
+    "mv_index_remove_page", "mv_index_read_pages", "mv_index_write_rows", "mv_index_fill_synthetic", "mv_synth_rows",
+    "mv_query_topk", "mv_query_topk_device", "mv_score_all", "mv_score_candidates", "mv_sign_pack", "mv_hamming_batch",
+    "mv_fde_output_dim", "mv_fde_encode", "mv_calibrate_read_bw", "mv_index_save", "mv_index_load",
+]
+
+_lock = threading.Lock()
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libmvmaxsim.so (built in-tree by csrc/Makefile). Raises if it is missing."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(_LIB):
+            raise MvError(-2, f"{_LIB} not found: build it with morphik_core_amd.build_library() "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(_LIB)
+        vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
+        L.mv_last_error.restype = C.c_char_p
+        L.mv_version.restype = C.c_char_p
+        L.mv_device_count.restype = C.c_int
+        L.mv_index_create.argtypes = [C.POINTER(ConfigC), C.POINTER(vp)]
+        L.mv_index_destroy.argtypes = [vp]
+        L.mv_index_destroy.restype = None
+        L.mv_index_set_option.argtypes = [vp, C.c_int, i64]
+        L.mv_index_size.argtypes = [vp]
+        L.mv_index_size.restype = i64
+        L.mv_index_capacity.argtypes = [vp]
+        L.mv_index_capacity.restype = i64
+        L.mv_index_add.argtypes = [vp, vp, C.c_int, vp, i64, vp, C.POINTER(i64)]
+        L.mv_index_add_device.argtypes = [vp, vp, C.c_int, vp, i64, vp, C.POINTER(i64)]
+        L.mv_index_remove_doc.argtypes = [vp, i32, C.POINTER(i64)]
+        L.mv_index_remove_page.argtypes = [vp, i64]
+        L.mv_index_read_pages.argtypes = [vp, i64, i64, vp]
+        L.mv_index_write_rows.argtypes = [vp, i64, i32, i32, vp]
+        L.mv_index_fill_synthetic.argtypes = [vp, u64, u64, i64, i32, i32]
+        L.mv_synth_rows.argtypes = [C.c_int, u64, u64, i32, vp]
+        L.mv_query_topk.argtypes = [vp, vp, C.c_int, i32, i32, C.c_int, vp, i64, vp, vp, C.POINTER(i32), C.POINTER(QueryStatsC)]
+        L.mv_query_topk_device.argtypes = [vp, vp, C.c_int, i32, i32, C.c_int, vp, i64, vp, vp, vp, C.POINTER(QueryStatsC)]
+        L.mv_score_all.argtypes = [vp, vp, C.c_int, i32, C.c_int, vp, i64, vp, C.POINTER(QueryStatsC)]
+        L.mv_score_candidates.argtypes = [vp, vp, C.c_int, i32, vp, i32, i32, vp, C.POINTER(QueryStatsC)]
+        L.mv_sign_pack.argtypes = [C.c_int, vp, i64, i32, vp]
+        L.mv_hamming_batch.argtypes = [C.c_int, vp, vp, i64, i32, vp]
+        L.mv_fde_output_dim.argtypes = [C.POINTER(FdeConfigC)]
+        L.mv_fde_output_dim.restype = i64
+        L.mv_fde_encode.argtypes = [C.c_int, C.POINTER(FdeConfigC), vp, i32, i32, vp]
+        L.mv_calibrate_read_bw.argtypes = [C.c_int, i64, i32, C.POINTER(C.c_double)]
+        L.mv_index_save.argtypes = [vp, C.c_char_p]
+        L.mv_index_load.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+        _lib = L
+        return L
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise MvError(status, (lib().mv_last_error() or b"").decode("utf-8", "replace"))

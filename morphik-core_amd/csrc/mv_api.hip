@@ -1,0 +1,1089 @@
+// mv_api.hip -- the C ABI of libmvmaxsim.so (include/mvmaxsim.h) over the HIP kernels.
+//
+// One mv_index = one GPU's shard of the corpus: a page-contiguous bf16 slab
+// [capacity][stride_rows][128], optionally a sign-bit slab [capacity][stride_rows][16 B] and an FDE
+// slab [capacity][out_dim] bf16, plus per-page metadata (valid rows, document ordinal).  All device
+// memory is allocated once at create: at 1M x 1024 x 128 bf16 the slab is 262 GB of the 288 GB HBM,
+// so there is no room for growth-by-copy.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "mv_common.h"
+
+namespace mv {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  set_error("HIP error %d (%s) at %s:%d in %s", (int)e, hipGetErrorString(e), file, line, what);
+  return e == hipErrorOutOfMemory ? MV_ERR_NOMEM : MV_ERR_HIP;
+}
+
+static uint16_t host_f32_to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static float host_bf16_to_f32(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+__global__ void add_scores_kernel(float* dst, const float* src, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+__global__ void ids64_to_32_kernel(const int64_t* in, int32_t* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (int32_t)in[i];
+}
+
+}  // namespace mv
+
+using namespace mv;
+
+constexpr int kMaxQRowsPerPass = 64;  // 4 MFMA row tiles held in VGPRs
+constexpr int kMaxCand = 65536;
+
+struct mv_index {
+  mv_config cfg{};
+  hipStream_t stream = nullptr;
+  // slabs
+  uint16_t* slab = nullptr;
+  uint8_t* bits = nullptr;
+  uint16_t* fde = nullptr;
+  float* fde_inv_norm = nullptr;
+  int32_t* d_n_rows = nullptr;
+  int32_t* d_doc_ord = nullptr;
+  std::vector<int32_t> h_n_rows, h_doc_ord;
+  int64_t size = 0;
+  bool ragged = false;      // some page has n_rows != stride
+  bool tombstones = false;  // some page is deleted
+  FdeTables fde_t;
+  // per-query workspace
+  float* d_scores = nullptr;   // [capacity]
+  float* d_scores2 = nullptr;  // [capacity] (second accumulator for > 64 query rows)
+  void* d_topk_ws = nullptr;
+  size_t topk_ws_bytes = 0;
+  uint16_t* d_q = nullptr;     // bf16 query, padded
+  float* d_qf32 = nullptr;     // fp32 query rows (FDE encode input)
+  uint8_t* d_qbits = nullptr;
+  float* d_qfde = nullptr;
+  int64_t* d_qoff = nullptr;   // [2] row offsets for the query "page"
+  uint32_t* d_allow = nullptr;
+  int64_t allow_cap_words = 0;
+  float* d_out_s = nullptr;    // [kTopkMaxDeviceK]
+  int64_t* d_out_id = nullptr;
+  int32_t* d_cand = nullptr;   // [kMaxCand]
+  float* d_cand_scores = nullptr;
+  int q_rows_cap = 0;
+  hipEvent_t ev[6] = {};
+  std::mutex mu;
+  // options
+  int maxsim_variant = -1;
+  int64_t fde_coarse_n = 0;
+  int fde_cosine = 1;
+  int pad_semantics = -1;  // -1: mode default (reference batch rule for FDE_THEN_FLOAT / candidates, none for full scan)
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    (void)hipGetDevice(&prev);
+    if (prev != dev) (void)hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (prev >= 0 && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+int ensure_query_cap(mv_index* ix, int n_rows) {
+  const int padded = ((n_rows + 15) / 16) * 16;
+  if (padded <= ix->q_rows_cap) return MV_OK;
+  const int cap = std::max(padded, 256);
+  if (ix->d_q) (void)hipFree(ix->d_q);
+  if (ix->d_qf32) (void)hipFree(ix->d_qf32);
+  if (ix->d_qbits) (void)hipFree(ix->d_qbits);
+  ix->d_q = nullptr; ix->d_qf32 = nullptr; ix->d_qbits = nullptr;
+  MV_HIP(hipMalloc(&ix->d_q, (size_t)cap * kDim * 2));
+  MV_HIP(hipMalloc(&ix->d_qf32, (size_t)cap * kDim * 4));
+  MV_HIP(hipMalloc(&ix->d_qbits, (size_t)cap * kSignBytes));
+  ix->q_rows_cap = cap;
+  return MV_OK;
+}
+
+// Upload the query in every representation the mode needs.  Returns padded row count.
+int upload_query(mv_index* ix, const void* q, int q_dtype, int n_q, bool want_bf16, bool want_f32, bool want_bits) {
+  int rc = ensure_query_cap(ix, n_q);
+  if (rc) return rc;
+  const int padded = ((n_q + 15) / 16) * 16;
+  std::vector<float> f((size_t)n_q * kDim);
+  if (q_dtype == MV_F32) {
+    memcpy(f.data(), q, f.size() * 4);
+  } else {
+    const uint16_t* h = (const uint16_t*)q;
+    for (size_t i = 0; i < f.size(); ++i) f[i] = host_bf16_to_f32(h[i]);
+  }
+  if (want_bf16) {
+    std::vector<uint16_t> b((size_t)padded * kDim, 0);
+    if (q_dtype == MV_BF16) memcpy(b.data(), q, (size_t)n_q * kDim * 2);
+    else for (size_t i = 0; i < f.size(); ++i) b[i] = host_f32_to_bf16(f[i]);
+    MV_HIP(hipMemcpyAsync(ix->d_q, b.data(), b.size() * 2, hipMemcpyHostToDevice, ix->stream));
+    MV_HIP(hipStreamSynchronize(ix->stream));  // b goes out of scope
+  }
+  if (want_f32 || want_bits) {
+    MV_HIP(hipMemcpyAsync(ix->d_qf32, f.data(), f.size() * 4, hipMemcpyHostToDevice, ix->stream));
+    if (want_bits) {
+      rc = launch_sign_pack_f32(ix->d_qf32, n_q, kDim, ix->d_qbits, ix->stream);
+      if (rc) return rc;
+    }
+    MV_HIP(hipStreamSynchronize(ix->stream));
+  }
+  return MV_OK;
+}
+
+int upload_allow(mv_index* ix, const uint32_t* allow_bits, int64_t n_words, const uint32_t** d_allow) {
+  *d_allow = nullptr;
+  if (!allow_bits) return MV_OK;
+  if (n_words < 0) { set_error("negative allow bitmap length"); return MV_ERR_INVALID; }
+  const int64_t need = std::max<int64_t>(n_words, 1);
+  if (need > ix->allow_cap_words) {
+    if (ix->d_allow) (void)hipFree(ix->d_allow);
+    ix->d_allow = nullptr;
+    MV_HIP(hipMalloc(&ix->d_allow, (size_t)need * 4));
+    ix->allow_cap_words = need;
+  }
+  if (n_words > 0) MV_HIP(hipMemcpyAsync(ix->d_allow, allow_bits, (size_t)n_words * 4, hipMemcpyHostToDevice, ix->stream));
+  *d_allow = ix->d_allow;
+  return MV_OK;
+}
+
+struct ScanResult {
+  const float* d_scores = nullptr;  // per work item
+  int64_t n = 0;
+  const int32_t* d_ids_map = nullptr;  // work item -> local page (candidate list) or null
+  int launches = 0;
+  int64_t pages = 0;
+  int64_t bytes = 0;
+};
+
+int64_t count_allowed_rows(const mv_index* ix, const uint32_t* allow_bits, int64_t n_words, int64_t* pages_out) {
+  // algorithmic accounting on the host metadata (exact): pages that are read and their valid rows
+  int64_t rows = 0, pages = 0;
+  const bool filt = allow_bits != nullptr;
+  if (!filt && !ix->tombstones && !ix->ragged) {
+    *pages_out = ix->size;
+    return ix->size * (int64_t)ix->cfg.stride_rows;
+  }
+  for (int64_t p = 0; p < ix->size; ++p) {
+    const int32_t o = ix->h_doc_ord[p];
+    if (o < 0) continue;
+    if (filt && ((int64_t)o >= n_words * 32 || !((allow_bits[o >> 5] >> (o & 31)) & 1u))) continue;
+    ++pages;
+    rows += ix->h_n_rows[p];
+  }
+  *pages_out = pages;
+  return rows;
+}
+
+int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_words, const int32_t* d_cand, int64_t n_items,
+               int32_t pad_to, float* d_out, int* launches) {
+  const bool need_meta = ix->tombstones || d_allow != nullptr;
+  const int padded = ((n_q + 15) / 16) * 16;
+  int done = 0, pass = 0;
+  while (done < padded) {
+    const int rows = std::min(padded - done, kMaxQRowsPerPass);
+    MaxsimArgs a{};
+    a.slab = ix->slab;
+    a.n_rows = ix->ragged ? ix->d_n_rows : nullptr;
+    a.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
+    a.allow = d_allow;
+    a.n_allow_bits = n_allow_words * 32;
+    a.cand = d_cand;
+    a.q = ix->d_q + (size_t)done * kDim;
+    a.scores = pass == 0 ? d_out : ix->d_scores2;
+    a.n = n_items;
+    a.stride = ix->cfg.stride_rows;
+    a.q_tiles = rows / 16;
+    a.pad_to = pad_to;
+    int rc = launch_maxsim_bf16(a, ix->maxsim_variant, ix->stream);
+    if (rc) return rc;
+    ++*launches;
+    if (pass > 0) {
+      hipLaunchKernelGGL(add_scores_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, ix->stream, d_out,
+                         (const float*)ix->d_scores2, n_items);
+    }
+    done += rows;
+    ++pass;
+  }
+  return MV_OK;
+}
+
+// Core of every query entry point: leaves per-item scores on the device.
+int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const uint32_t* allow_bits, int64_t n_words,
+             int64_t want_coarse, ScanResult* out, mv_query_stats* st) {
+  if (!q || n_q <= 0) { set_error("query must have at least one row"); return MV_ERR_INVALID; }
+  if (q_dtype != MV_F32 && q_dtype != MV_BF16) { set_error("bad query dtype %d", q_dtype); return MV_ERR_INVALID; }
+  const bool want_float = mode == MV_MODE_FLOAT || mode == MV_MODE_FDE_THEN_FLOAT;
+  const bool want_fde = mode == MV_MODE_FDE_THEN_FLOAT || mode == MV_MODE_FDE_ONLY;
+  const bool want_bin = mode == MV_MODE_BINARY;
+  if (!want_float && !want_fde && !want_bin) { set_error("unknown mode %d", mode); return MV_ERR_INVALID; }
+  if (want_float && !(ix->cfg.flags & MV_WITH_FLOAT)) { set_error("index has no float slab (MV_WITH_FLOAT)"); return MV_ERR_STATE; }
+  if (want_bin && !(ix->cfg.flags & MV_WITH_BINARY)) { set_error("index has no sign-bit slab (MV_WITH_BINARY)"); return MV_ERR_STATE; }
+  if (want_fde && !(ix->cfg.flags & MV_WITH_FDE)) { set_error("index has no FDE slab (MV_WITH_FDE)"); return MV_ERR_STATE; }
+
+  int rc = upload_query(ix, q, q_dtype, n_q, want_float, want_fde, want_bin);
+  if (rc) return rc;
+  const uint32_t* d_allow = nullptr;
+  rc = upload_allow(ix, allow_bits, n_words, &d_allow);
+  if (rc) return rc;
+  const bool need_meta = ix->tombstones || d_allow != nullptr;
+  const int64_t n = ix->size;
+  int64_t pages = 0;
+  const int64_t rows = st ? count_allowed_rows(ix, allow_bits, n_words, &pages) : 0;  // accounting only
+
+  MV_HIP(hipEventRecord(ix->ev[0], ix->stream));
+  out->launches = 0;
+  if (mode == MV_MODE_FLOAT) {
+    rc = float_scan(ix, n_q, d_allow, n_words, nullptr, n, 0 /* full scan: no padding rows exist */, ix->d_scores,
+                    &out->launches);
+    if (rc) return rc;
+    out->d_scores = ix->d_scores; out->n = n; out->d_ids_map = nullptr;
+    out->pages = pages; out->bytes = rows * (int64_t)kRowBytes;
+  } else if (mode == MV_MODE_BINARY) {
+    BinaryArgs b{};
+    b.bits = ix->bits; b.n_rows = ix->ragged ? ix->d_n_rows : nullptr; b.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
+    b.allow = d_allow; b.n_allow_bits = n_words * 32; b.qbits = ix->d_qbits; b.scores = ix->d_scores; b.n = n;
+    b.stride = ix->cfg.stride_rows; b.n_q = n_q;
+    rc = launch_maxsim_binary(b, ix->stream);
+    if (rc) return rc;
+    out->launches = 1;
+    out->d_scores = ix->d_scores; out->n = n; out->d_ids_map = nullptr;
+    out->pages = pages; out->bytes = rows * (int64_t)kSignBytes;
+  } else {
+    // FDE: encode the query (SUM), scan the FDE slab
+    const int64_t off[2] = {0, n_q};
+    MV_HIP(hipMemcpyAsync(ix->d_qoff, off, sizeof(off), hipMemcpyHostToDevice, ix->stream));
+    FdeEncodeArgs e{};
+    e.x_f32 = ix->d_qf32; e.row_offsets = ix->d_qoff; e.n_pages = 1; e.is_query = 1; e.out_f32 = ix->d_qfde;
+    rc = launch_fde_encode(ix->fde_t, e, ix->stream);
+    if (rc) return rc;
+    FdeScanArgs s{};
+    s.fde = ix->fde; s.inv_norm = ix->fde_cosine ? ix->fde_inv_norm : nullptr; s.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
+    s.allow = d_allow; s.n_allow_bits = n_words * 32; s.q = ix->d_qfde; s.scores = ix->d_scores; s.n = n;
+    s.out_dim = ix->fde_t.out_dim;
+    rc = launch_fde_scan(s, ix->stream);
+    if (rc) return rc;
+    out->launches = 2;
+    out->pages = pages; out->bytes = pages * ix->fde_t.out_dim * 2;
+    if (mode == MV_MODE_FDE_ONLY) {
+      out->d_scores = ix->d_scores; out->n = n; out->d_ids_map = nullptr;
+    } else {
+      // coarse top-n -> candidate list -> exact rerank
+      int64_t nc = std::min<int64_t>(std::min<int64_t>(want_coarse, n), kTopkMaxDeviceK);
+      if (nc < 1) nc = 1;
+      rc = launch_topk(ix->d_scores, n, (int32_t)nc, nullptr, 0, ix->d_topk_ws, ix->d_out_s, ix->d_out_id, ix->stream);
+      if (rc) return rc;
+      std::vector<int64_t> cand64((size_t)nc);
+      MV_HIP(hipMemcpyAsync(cand64.data(), ix->d_out_id, (size_t)nc * 8, hipMemcpyDeviceToHost, ix->stream));
+      MV_HIP(hipStreamSynchronize(ix->stream));
+      std::vector<int32_t> cand;
+      int32_t longest = 0;
+      int64_t cand_rows = 0;
+      for (int64_t i = 0; i < nc; ++i)
+        if (cand64[i] >= 0) {
+          cand.push_back((int32_t)cand64[i]);
+          longest = std::max(longest, ix->h_n_rows[cand64[i]]);
+          cand_rows += ix->h_n_rows[cand64[i]];
+        }
+      out->n = (int64_t)cand.size();
+      out->d_ids_map = ix->d_cand;
+      out->d_scores = ix->d_cand_scores;
+      if (!cand.empty()) {
+        MV_HIP(hipMemcpyAsync(ix->d_cand, cand.data(), cand.size() * 4, hipMemcpyHostToDevice, ix->stream));
+        // reference rule: pad_sequence over the rerank batch (<=128 pages): shorter pages see zero rows
+        const int pad_sem = ix->pad_semantics < 0 ? 1 : ix->pad_semantics;
+        rc = float_scan(ix, n_q, nullptr, 0, ix->d_cand, out->n, pad_sem ? longest : 0, ix->d_cand_scores, &out->launches);
+        if (rc) return rc;
+        MV_HIP(hipStreamSynchronize(ix->stream));  // cand goes out of scope
+      }
+      out->bytes += cand_rows * (int64_t)kRowBytes;
+    }
+  }
+  MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
+  if (st) {
+    memset(st, 0, sizeof(*st));
+    st->score_launches = out->launches;
+    st->pages_scored = out->pages;
+    st->bytes_scanned = out->bytes;
+  }
+  return MV_OK;
+}
+
+int finish_stats(mv_index* ix, mv_query_stats* st, bool had_topk) {
+  if (!st) return MV_OK;
+  MV_HIP(hipEventSynchronize(ix->ev[had_topk ? 2 : 1]));
+  MV_HIP(hipEventElapsedTime(&st->score_kernel_ms, ix->ev[0], ix->ev[1]));
+  if (had_topk) {
+    MV_HIP(hipEventElapsedTime(&st->topk_ms, ix->ev[1], ix->ev[2]));
+    MV_HIP(hipEventElapsedTime(&st->total_device_ms, ix->ev[0], ix->ev[2]));
+  } else {
+    st->total_device_ms = st->score_kernel_ms;
+  }
+  return MV_OK;
+}
+
+int64_t coarse_n_for(const mv_index* ix, int k) {
+  // reference: top_k = min(10 * k, 75)  (fast_multivector_store.py:529)
+  if (ix->fde_coarse_n > 0) return ix->fde_coarse_n;
+  return std::min<int64_t>(10LL * k, 75);
+}
+
+// Host selection for k beyond the device kernel's limit.
+void host_topk(const std::vector<float>& s, const std::vector<int32_t>* ids_map, int64_t id_base, int64_t k,
+               std::vector<float>* os, std::vector<int64_t>* oi) {
+  std::vector<std::pair<float, int64_t>> v;
+  v.reserve(s.size());
+  for (size_t i = 0; i < s.size(); ++i)
+    if (s[i] == s[i] && s[i] != -INFINITY) v.emplace_back(s[i] + 0.0f, ids_map ? (int64_t)(*ids_map)[i] : (int64_t)i);
+  auto cmp = [](const std::pair<float, int64_t>& a, const std::pair<float, int64_t>& b) {
+    return a.first > b.first || (a.first == b.first && a.second < b.second);
+  };
+  const size_t kk = std::min<size_t>((size_t)k, v.size());
+  std::partial_sort(v.begin(), v.begin() + kk, v.end(), cmp);
+  os->resize(kk);
+  oi->resize(kk);
+  for (size_t i = 0; i < kk; ++i) { (*os)[i] = v[i].first; (*oi)[i] = id_base + v[i].second; }
+}
+
+int add_pages_common(mv_index* ix, const void* d_src, int dtype, const int32_t* n_rows, int64_t n_pages,
+                     const int32_t* doc_ordinals, int64_t total_rows, int64_t* out_first) {
+  // d_src: device rows [total_rows][128] of dtype; scatter into the slab and derive the other slabs.
+  const int64_t first = ix->size;
+  std::vector<int64_t> off((size_t)n_pages + 1);
+  off[0] = 0;
+  for (int64_t i = 0; i < n_pages; ++i) off[i + 1] = off[i] + n_rows[i];
+  int64_t* d_off = nullptr;
+  MV_HIP(hipMalloc(&d_off, off.size() * 8));
+  int rc = MV_OK;
+  do {
+    if (hipMemcpyAsync(d_off, off.data(), off.size() * 8, hipMemcpyHostToDevice, ix->stream) != hipSuccess) { rc = MV_ERR_HIP; set_error("H2D of row offsets failed"); break; }
+    const int32_t stride = ix->cfg.stride_rows;
+    uint16_t* slab_dst = nullptr;
+    uint16_t* tmp_slab = nullptr;
+    if (ix->cfg.flags & MV_WITH_FLOAT) {
+      slab_dst = ix->slab + (size_t)first * stride * kDim;
+    } else {
+      // no float slab kept: still need fixed-stride bf16 rows as the source of the sign bits
+      if (hipMalloc(&tmp_slab, (size_t)n_pages * stride * kRowBytes) != hipSuccess) { rc = MV_ERR_NOMEM; set_error("out of device memory staging %lld pages", (long long)n_pages); break; }
+      slab_dst = tmp_slab;
+    }
+    rc = launch_scatter_rows(d_src, dtype, d_off, n_pages, stride, slab_dst, ix->stream);
+    if (!rc && (ix->cfg.flags & MV_WITH_BINARY)) {
+      // sign bits come from the bf16 image: bf16 RNE preserves sign and zero-ness of every fp32 value
+      // that is not an fp32 subnormal rounding to zero; fp32 inputs are packed from the fp32 rows below.
+      uint8_t* bdst = ix->bits + (size_t)first * stride * kSignBytes;
+      if (dtype == MV_BF16) {
+        rc = launch_sign_pack_bf16_rows(slab_dst, n_pages * (int64_t)stride, bdst, ix->stream);
+      } else {
+        // exact fp32 rule (v > 0.0f): pack the ragged fp32 rows, then scatter 16-byte rows
+        uint8_t* tmp_bits = nullptr;
+        if (hipMalloc(&tmp_bits, (size_t)std::max<int64_t>(total_rows, 1) * kSignBytes) != hipSuccess) { rc = MV_ERR_NOMEM; set_error("out of device memory"); }
+        if (!rc) rc = launch_sign_pack_f32((const float*)d_src, total_rows, kDim, tmp_bits, ix->stream);
+        if (!rc) {
+          (void)hipMemsetAsync(bdst, 0, (size_t)n_pages * stride * kSignBytes, ix->stream);
+          for (int64_t i = 0; i < n_pages && !rc; ++i)
+            if (n_rows[i] > 0 && hipMemcpyAsync(bdst + (size_t)i * stride * kSignBytes, tmp_bits + (size_t)off[i] * kSignBytes,
+                                                (size_t)n_rows[i] * kSignBytes, hipMemcpyDeviceToDevice, ix->stream) != hipSuccess) {
+              rc = MV_ERR_HIP; set_error("D2D of sign rows failed");
+            }
+        }
+        (void)hipStreamSynchronize(ix->stream);
+        if (tmp_bits) (void)hipFree(tmp_bits);
+      }
+    }
+    if (!rc && (ix->cfg.flags & MV_WITH_FDE)) {
+      FdeEncodeArgs e{};
+      int32_t* d_nr = nullptr;
+      if (dtype == MV_F32) {
+        e.x_f32 = (const float*)d_src; e.row_offsets = d_off;
+      } else {
+        if (hipMalloc(&d_nr, (size_t)n_pages * 4) != hipSuccess) { rc = MV_ERR_NOMEM; set_error("out of device memory"); }
+        if (!rc) (void)hipMemcpyAsync(d_nr, n_rows, (size_t)n_pages * 4, hipMemcpyHostToDevice, ix->stream);
+        e.x_bf16 = slab_dst; e.n_rows = d_nr; e.stride = stride;
+      }
+      e.n_pages = n_pages; e.is_query = 0;
+      e.out_bf16 = ix->fde + (size_t)first * ix->fde_t.out_dim;
+      e.out_inv_norm = ix->fde_inv_norm + first;
+      if (!rc) rc = launch_fde_encode(ix->fde_t, e, ix->stream);
+      (void)hipStreamSynchronize(ix->stream);
+      if (d_nr) (void)hipFree(d_nr);
+    }
+    (void)hipStreamSynchronize(ix->stream);
+    if (tmp_slab) (void)hipFree(tmp_slab);
+  } while (0);
+  (void)hipStreamSynchronize(ix->stream);
+  (void)hipFree(d_off);
+  if (rc) return rc;
+  // metadata
+  for (int64_t i = 0; i < n_pages; ++i) {
+    ix->h_n_rows[first + i] = n_rows[i];
+    ix->h_doc_ord[first + i] = doc_ordinals ? doc_ordinals[i] : 0;
+    if (n_rows[i] != ix->cfg.stride_rows) ix->ragged = true;
+    if (doc_ordinals && doc_ordinals[i] < 0) ix->tombstones = true;
+  }
+  MV_HIP(hipMemcpy(ix->d_n_rows + first, ix->h_n_rows.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice));
+  MV_HIP(hipMemcpy(ix->d_doc_ord + first, ix->h_doc_ord.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice));
+  ix->size += n_pages;
+  if (out_first) *out_first = first;
+  return MV_OK;
+}
+
+int validate_add(mv_index* ix, const void* emb, int dtype, const int32_t* n_rows, int64_t n_pages, int64_t* total_rows) {
+  if (!ix || (!emb && n_pages > 0) || (!n_rows && n_pages > 0) || n_pages < 0) { set_error("mv_index_add: null argument"); return MV_ERR_INVALID; }
+  if (dtype != MV_F32 && dtype != MV_BF16) { set_error("mv_index_add: bad dtype %d", dtype); return MV_ERR_INVALID; }
+  if (ix->size + n_pages > ix->cfg.capacity_pages) {
+    set_error("slab full: %lld + %lld > capacity %lld", (long long)ix->size, (long long)n_pages, (long long)ix->cfg.capacity_pages);
+    return MV_ERR_CAPACITY;
+  }
+  int64_t t = 0;
+  for (int64_t i = 0; i < n_pages; ++i) {
+    if (n_rows[i] < 0 || n_rows[i] > ix->cfg.stride_rows) {
+      set_error("page %lld has %d rows; stride_rows is %d", (long long)i, n_rows[i], ix->cfg.stride_rows);
+      return MV_ERR_INVALID;
+    }
+    t += n_rows[i];
+  }
+  *total_rows = t;
+  return MV_OK;
+}
+
+}  // namespace
+
+// =================================================================================== C ABI
+extern "C" {
+
+const char* mv_last_error(void) { return g_err.c_str(); }
+const char* mv_version(void) { return "mvmaxsim 0.1 (gfx950)"; }
+
+int mv_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void mv_index_destroy(mv_index* ix) {
+  if (!ix) return;
+  DeviceGuard g(ix->cfg.device);
+  if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+  void* ptrs[] = {ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
+                  ix->d_topk_ws, ix->d_q, ix->d_qf32, ix->d_qbits, ix->d_qfde, ix->d_qoff, ix->d_allow, ix->d_out_s,
+                  ix->d_out_id, ix->d_cand, ix->d_cand_scores};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  fde_tables_destroy(&ix->fde_t);
+  for (auto& e : ix->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (ix->stream) (void)hipStreamDestroy(ix->stream);
+  delete ix;
+}
+
+int mv_index_create(const mv_config* cfg, mv_index** out) {
+  if (!cfg || !out) { set_error("mv_index_create: null argument"); return MV_ERR_INVALID; }
+  *out = nullptr;
+  if (cfg->dim != kDim) { set_error("dim must be 128 (got %d)", cfg->dim); return MV_ERR_INVALID; }
+  if (cfg->stride_rows < 16 || cfg->stride_rows % 16) { set_error("stride_rows must be a positive multiple of 16 (got %d)", cfg->stride_rows); return MV_ERR_INVALID; }
+  if (cfg->capacity_pages < 1 || cfg->capacity_pages > 0x7fffffffLL) { set_error("capacity_pages out of range"); return MV_ERR_INVALID; }
+  if (!(cfg->flags & (MV_WITH_FLOAT | MV_WITH_BINARY | MV_WITH_FDE))) { set_error("flags select no slab"); return MV_ERR_INVALID; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device available (libmvmaxsim requires an MI355X / gfx950 GPU)"); return MV_ERR_HIP; }
+  if (cfg->device < 0 || cfg->device >= ndev) { set_error("device %d out of range (have %d)", cfg->device, ndev); return MV_ERR_INVALID; }
+  DeviceGuard g(cfg->device);
+  mv_index* ix = new (std::nothrow) mv_index();
+  if (!ix) { set_error("host allocation failed"); return MV_ERR_NOMEM; }
+  ix->cfg = *cfg;
+  const int64_t cap = cfg->capacity_pages;
+  const size_t rows = (size_t)cap * cfg->stride_rows;
+  int rc = MV_OK;
+  auto alloc = [&](void** p, size_t bytes, const char* what) {
+    if (rc) return;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+      set_error("hipMalloc of %zu bytes for %s failed: %s", bytes, what, hipGetErrorString(e));
+      rc = MV_ERR_NOMEM;
+      *p = nullptr;
+    }
+  };
+  if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); rc = MV_ERR_HIP; }
+  for (auto& e : ix->ev)
+    if (!rc && hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); rc = MV_ERR_HIP; }
+  if (cfg->flags & MV_WITH_FLOAT) alloc((void**)&ix->slab, rows * kRowBytes, "bf16 page slab");
+  if (cfg->flags & MV_WITH_BINARY) alloc((void**)&ix->bits, rows * kSignBytes, "sign-bit slab");
+  if (!rc && (cfg->flags & MV_WITH_FDE)) {
+    rc = fde_tables_create(cfg->fde, &ix->fde_t);
+    alloc((void**)&ix->fde, (size_t)cap * ix->fde_t.out_dim * 2, "FDE slab");
+    alloc((void**)&ix->fde_inv_norm, (size_t)cap * 4, "FDE norms");
+    alloc((void**)&ix->d_qfde, (size_t)std::max<int64_t>(ix->fde_t.out_dim, 1) * 4, "query FDE");
+  }
+  alloc((void**)&ix->d_n_rows, (size_t)cap * 4, "row counts");
+  alloc((void**)&ix->d_doc_ord, (size_t)cap * 4, "doc ordinals");
+  alloc((void**)&ix->d_scores, (size_t)cap * 4, "scores");
+  alloc((void**)&ix->d_scores2, (size_t)cap * 4, "scores2");
+  ix->topk_ws_bytes = topk_ws_bytes(cap, kTopkMaxDeviceK);
+  alloc(&ix->d_topk_ws, ix->topk_ws_bytes, "top-k workspace");
+  alloc((void**)&ix->d_out_s, (size_t)kTopkMaxDeviceK * 4, "top-k scores");
+  alloc((void**)&ix->d_out_id, (size_t)kTopkMaxDeviceK * 8, "top-k ids");
+  alloc((void**)&ix->d_cand, (size_t)kMaxCand * 4, "candidates");
+  alloc((void**)&ix->d_cand_scores, (size_t)kMaxCand * 4, "candidate scores");
+  alloc((void**)&ix->d_qoff, 16, "query offsets");
+  if (!rc) {
+    ix->h_n_rows.assign((size_t)cap, 0);
+    ix->h_doc_ord.assign((size_t)cap, -1);
+    rc = ensure_query_cap(ix, 64);
+  }
+  if (rc) {
+    std::string keep = g_err;
+    mv_index_destroy(ix);
+    g_err = keep;
+    return rc;
+  }
+  *out = ix;
+  return MV_OK;
+}
+
+int mv_index_set_option(mv_index* ix, int option, int64_t value) {
+  if (!ix) { set_error("null index"); return MV_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(ix->mu);
+  switch (option) {
+    case MV_OPT_MAXSIM_VARIANT: ix->maxsim_variant = (int)value; return MV_OK;
+    case MV_OPT_FDE_COARSE_N:
+      if (value < 0 || value > kTopkMaxDeviceK) { set_error("FDE_COARSE_N must be 0..%d", kTopkMaxDeviceK); return MV_ERR_INVALID; }
+      ix->fde_coarse_n = value; return MV_OK;
+    case MV_OPT_FDE_COSINE: ix->fde_cosine = value ? 1 : 0; return MV_OK;
+    case MV_OPT_PAD_SEMANTICS: ix->pad_semantics = (int)value; return MV_OK;
+    default: set_error("unknown option %d", option); return MV_ERR_INVALID;
+  }
+}
+
+int64_t mv_index_size(const mv_index* ix) { return ix ? ix->size : 0; }
+int64_t mv_index_capacity(const mv_index* ix) { return ix ? ix->cfg.capacity_pages : 0; }
+
+int mv_index_add_device(mv_index* ix, const void* d_emb, int dtype, const int32_t* n_rows, int64_t n_pages,
+                        const int32_t* doc_ordinals, int64_t* out_first_page) {
+  int64_t total = 0;
+  int rc = validate_add(ix, d_emb, dtype, n_rows, n_pages, &total);
+  if (rc) return rc;
+  if (n_pages == 0) { if (out_first_page) *out_first_page = ix->size; return MV_OK; }
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->cfg.device);
+  return add_pages_common(ix, d_emb, dtype, n_rows, n_pages, doc_ordinals, total, out_first_page);
+}
+
+int mv_index_add(mv_index* ix, const void* emb, int dtype, const int32_t* n_rows, int64_t n_pages,
+                 const int32_t* doc_ordinals, int64_t* out_first_page) {
+  int64_t total = 0;
+  int rc = validate_add(ix, emb, dtype, n_rows, n_pages, &total);
+  if (rc) return rc;
+  if (n_pages == 0) { if (out_first_page) *out_first_page = ix->size; return MV_OK; }
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->cfg.device);
+  // stage in chunks so the staging buffer stays <= ~1 GiB
+  const size_t esz = dtype == MV_F32 ? 4 : 2;
+  const int64_t first = ix->size;
+  int64_t p = 0;
+  int64_t row_base = 0;
+  while (p < n_pages) {
+    int64_t q = p, rows = 0;
+    while (q < n_pages && (q == p || (size_t)(rows + n_rows[q]) * kDim * esz <= ((size_t)1 << 30))) rows += n_rows[q++];
+    void* d_stage = nullptr;
+    MV_HIP(hipMalloc(&d_stage, std::max<size_t>((size_t)rows * kDim * esz, 16)));
+    hipError_t e = hipMemcpy(d_stage, (const char*)emb + (size_t)row_base * kDim * esz, (size_t)rows * kDim * esz, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d_stage); return hip_fail(e, "H2D of embeddings", __FILE__, __LINE__); }
+    rc = add_pages_common(ix, d_stage, dtype, n_rows + p, q - p, doc_ordinals ? doc_ordinals + p : nullptr, rows, nullptr);
+    (void)hipFree(d_stage);
+    if (rc) return rc;
+    row_base += rows;
+    p = q;
+  }
+  if (out_first_page) *out_first_page = first;
+  return MV_OK;
+}
+
+int mv_index_remove_page(mv_index* ix, int64_t page) {
+  if (!ix || page < 0 || page >= ix->size) { set_error("page out of range"); return MV_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->cfg.device);
+  ix->h_doc_ord[page] = -1;
+  ix->tombstones = true;
+  MV_HIP(hipMemcpy(ix->d_doc_ord + page, &ix->h_doc_ord[page], 4, hipMemcpyHostToDevice));
+  return MV_OK;
+}
+
+int mv_index_remove_doc(mv_index* ix, int32_t doc_ordinal, int64_t* out_n) {
+  if (!ix || doc_ordinal < 0) { set_error("bad doc ordinal"); return MV_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->cfg.device);
+  int64_t n = 0, lo = -1, hi = -1;
+  for (int64_t p = 0; p < ix->size; ++p)
+    if (ix->h_doc_ord[p] == doc_ordinal) {
+      ix->h_doc_ord[p] = -1;
+      if (lo < 0) lo = p;
+      hi = p;
+      ++n;
+    }
+  if (n) {
+    ix->tombstones = true;
+    MV_HIP(hipMemcpy(ix->d_doc_ord + lo, ix->h_doc_ord.data() + lo, (size_t)(hi - lo + 1) * 4, hipMemcpyHostToDevice));
+  }
+  if (out_n) *out_n = n;
+  return MV_OK;
+}
+
+int mv_index_read_pages(mv_index* ix, int64_t page0, int64_t n_pages, void* out_bf16) {
+  if (!ix || !out_bf16 || page0 < 0 || n_pages < 0 || page0 + n_pages > ix->size) { set_error("read_pages: range"); return MV_ERR_INVALID; }
+  if (!(ix->cfg.flags & MV_WITH_FLOAT)) { set_error("index has no float slab"); return MV_ERR_STATE; }
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->cfg.device);
+  const size_t pb = (size_t)ix->cfg.stride_rows * kRowBytes;
+  MV_HIP(hipMemcpy(out_bf16, (const char*)ix->slab + (size_t)page0 * pb, (size_t)n_pages * pb, hipMemcpyDeviceToHost));
+  return MV_OK;
+}
+
+int mv_index_write_rows(mv_index* ix, int64_t page, int32_t row0, int32_t n, const void* bf16_rows) {
+  if (!ix || !bf16_rows || page < 0 || page >= ix->size || row0 < 0 || n < 0 || row0 + n > ix->cfg.stride_rows) { set_error("write_rows: range"); return MV_ERR_INVALID; }
+  if (!(ix->cfg.flags & MV_WITH_FLOAT)) { set_error("index has no float slab"); return MV_ERR_STATE; }
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->cfg.device);
+  char* dst = (char*)ix->slab + ((size_t)page * ix->cfg.stride_rows + row0) * kRowBytes;
+  MV_HIP(hipMemcpy(dst, bf16_rows, (size_t)n * kRowBytes, hipMemcpyHostToDevice));
+  return MV_OK;
+}
+
+int mv_index_fill_synthetic(mv_index* ix, uint64_t seed, uint64_t first_unit, int64_t n_pages, int32_t n_rows,
+                            int32_t pages_per_doc) {
+  if (!ix || n_pages < 0 || n_rows < 0 || n_rows > ix->cfg.stride_rows) { set_error("fill_synthetic: bad argument"); return MV_ERR_INVALID; }
+  if (!(ix->cfg.flags & MV_WITH_FLOAT)) { set_error("fill_synthetic needs MV_WITH_FLOAT"); return MV_ERR_STATE; }
+  if (ix->size + n_pages > ix->cfg.capacity_pages) { set_error("slab full"); return MV_ERR_CAPACITY; }
+  if (pages_per_doc < 1) pages_per_doc = 1;
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->cfg.device);
+  const int64_t first = ix->size;
+  const int32_t stride = ix->cfg.stride_rows;
+  uint16_t* dst = ix->slab + (size_t)first * stride * kDim;
+  int rc = launch_synth_rows(dst, seed, first_unit, n_pages, n_rows, stride, ix->stream);
+  if (rc) return rc;
+  if (ix->cfg.flags & MV_WITH_BINARY) {
+    rc = launch_sign_pack_bf16_rows(dst, n_pages * (int64_t)stride, ix->bits + (size_t)first * stride * kSignBytes, ix->stream);
+    if (rc) return rc;
+  }
+  for (int64_t i = 0; i < n_pages; ++i) {
+    ix->h_n_rows[first + i] = n_rows;
+    ix->h_doc_ord[first + i] = (int32_t)((first_unit + (uint64_t)i) / (uint64_t)pages_per_doc);
+  }
+  if (n_rows != stride) ix->ragged = true;
+  MV_HIP(hipMemcpyAsync(ix->d_n_rows + first, ix->h_n_rows.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice, ix->stream));
+  MV_HIP(hipMemcpyAsync(ix->d_doc_ord + first, ix->h_doc_ord.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice, ix->stream));
+  if (ix->cfg.flags & MV_WITH_FDE) {
+    FdeEncodeArgs e{};
+    e.x_bf16 = dst; e.n_rows = ix->d_n_rows + first; e.stride = stride; e.n_pages = n_pages; e.is_query = 0;
+    e.out_bf16 = ix->fde + (size_t)first * ix->fde_t.out_dim;
+    e.out_inv_norm = ix->fde_inv_norm + first;
+    // grid.x limit: chunk launches
+    int64_t done = 0;
+    while (done < n_pages && !rc) {
+      const int64_t c = std::min<int64_t>(n_pages - done, 1 << 20);
+      FdeEncodeArgs ec = e;
+      ec.x_bf16 = dst + (size_t)done * stride * kDim; ec.n_rows = e.n_rows + done; ec.n_pages = c;
+      ec.out_bf16 = e.out_bf16 + (size_t)done * ix->fde_t.out_dim; ec.out_inv_norm = e.out_inv_norm + done;
+      rc = launch_fde_encode(ix->fde_t, ec, ix->stream);
+      done += c;
+    }
+    if (rc) return rc;
+  }
+  MV_HIP(hipStreamSynchronize(ix->stream));
+  ix->size += n_pages;
+  return MV_OK;
+}
+
+int mv_synth_rows(int device, uint64_t seed, uint64_t unit, int32_t n_rows, void* out_bf16) {
+  if (!out_bf16 || n_rows < 1) { set_error("mv_synth_rows: bad argument"); return MV_ERR_INVALID; }
+  DeviceGuard g(device);
+  uint16_t* d = nullptr;
+  MV_HIP(hipMalloc(&d, (size_t)n_rows * kRowBytes));
+  int rc = launch_synth_rows(d, seed, unit, 1, n_rows, n_rows, nullptr);
+  if (!rc) {
+    hipError_t e = hipMemcpy(out_bf16, d, (size_t)n_rows * kRowBytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = hip_fail(e, "D2H", __FILE__, __LINE__);
+  }
+  (void)hipFree(d);
+  return rc;
+}
+
+static int query_common(mv_index* ix, const void* q, int q_dtype, int32_t n_q, int32_t k, int mode,
+                        const uint32_t* allow_bits, int64_t n_words, float* h_scores, int64_t* h_ids, int32_t* out_n,
+                        float* d_scores_out, int64_t* d_ids_out, void* user_stream, mv_query_stats* st) {
+  if (!ix) { set_error("null index"); return MV_ERR_INVALID; }
+  if (k < 0) { set_error("k must be >= 0"); return MV_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->cfg.device);
+  if (out_n) *out_n = 0;
+  const bool to_device = d_scores_out != nullptr;
+  if (to_device && k > kTopkMaxDeviceK) { set_error("device-output top-k supports k <= %d", kTopkMaxDeviceK); return MV_ERR_INVALID; }
+  if (user_stream) {  // order our stream behind the caller's
+    MV_HIP(hipEventRecord(ix->ev[3], (hipStream_t)user_stream));
+    MV_HIP(hipStreamWaitEvent(ix->stream, ix->ev[3], 0));
+  }
+  if (k == 0 || ix->size == 0) {
+    if (to_device) {
+      std::vector<float> s((size_t)std::max(k, 1), -INFINITY);
+      std::vector<int64_t> id((size_t)std::max(k, 1), -1);
+      if (k > 0) {
+        MV_HIP(hipMemcpy(d_scores_out, s.data(), (size_t)k * 4, hipMemcpyHostToDevice));
+        MV_HIP(hipMemcpy(d_ids_out, id.data(), (size_t)k * 8, hipMemcpyHostToDevice));
+      }
+    }
+    if (st) memset(st, 0, sizeof(*st));
+    return MV_OK;
+  }
+  ScanResult r;
+  int rc = run_scan(ix, q, q_dtype, n_q, mode, allow_bits, n_words, coarse_n_for(ix, k), &r, st);
+  if (rc) return rc;
+  const int64_t id_base = ix->cfg.id_base;
+  if (r.n == 0) {
+    if (to_device) {
+      std::vector<float> s((size_t)k, -INFINITY);
+      std::vector<int64_t> id((size_t)k, -1);
+      MV_HIP(hipMemcpy(d_scores_out, s.data(), (size_t)k * 4, hipMemcpyHostToDevice));
+      MV_HIP(hipMemcpy(d_ids_out, id.data(), (size_t)k * 8, hipMemcpyHostToDevice));
+    }
+    return finish_stats(ix, st, false);
+  }
+  if (k <= kTopkMaxDeviceK) {
+    float* ds = to_device ? d_scores_out : ix->d_out_s;
+    int64_t* di = to_device ? d_ids_out : ix->d_out_id;
+    rc = launch_topk(r.d_scores, r.n, k, r.d_ids_map, id_base, ix->d_topk_ws, ds, di, ix->stream);
+    if (rc) return rc;
+    MV_HIP(hipEventRecord(ix->ev[2], ix->stream));
+    if (to_device) {
+      if (user_stream) {  // caller's stream waits for our result
+        MV_HIP(hipStreamWaitEvent((hipStream_t)user_stream, ix->ev[2], 0));
+      } else {
+        MV_HIP(hipStreamSynchronize(ix->stream));
+      }
+      return st ? finish_stats(ix, st, true) : MV_OK;
+    }
+    std::vector<float> s((size_t)k);
+    std::vector<int64_t> id((size_t)k);
+    MV_HIP(hipMemcpyAsync(s.data(), ds, (size_t)k * 4, hipMemcpyDeviceToHost, ix->stream));
+    MV_HIP(hipMemcpyAsync(id.data(), di, (size_t)k * 8, hipMemcpyDeviceToHost, ix->stream));
+    MV_HIP(hipStreamSynchronize(ix->stream));
+    int32_t n = 0;
+    while (n < k && id[n] >= 0) ++n;
+    memcpy(h_scores, s.data(), (size_t)n * 4);
+    memcpy(h_ids, id.data(), (size_t)n * 8);
+    if (out_n) *out_n = n;
+    return finish_stats(ix, st, true);
+  }
+  // k beyond the device selection kernel: copy the score vector and select on the host
+  std::vector<float> s((size_t)r.n);
+  MV_HIP(hipMemcpyAsync(s.data(), r.d_scores, (size_t)r.n * 4, hipMemcpyDeviceToHost, ix->stream));
+  std::vector<int32_t> map;
+  if (r.d_ids_map) {
+    map.resize((size_t)r.n);
+    MV_HIP(hipMemcpyAsync(map.data(), r.d_ids_map, (size_t)r.n * 4, hipMemcpyDeviceToHost, ix->stream));
+  }
+  MV_HIP(hipStreamSynchronize(ix->stream));
+  std::vector<float> os;
+  std::vector<int64_t> oi;
+  host_topk(s, r.d_ids_map ? &map : nullptr, id_base, k, &os, &oi);
+  memcpy(h_scores, os.data(), os.size() * 4);
+  memcpy(h_ids, oi.data(), oi.size() * 8);
+  if (out_n) *out_n = (int32_t)os.size();
+  return finish_stats(ix, st, false);
+}
+
+int mv_query_topk(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int32_t k, int mode,
+                  const uint32_t* allow_bits, int64_t n_allow_words, float* out_scores, int64_t* out_ids, int32_t* out_n,
+                  mv_query_stats* stats) {
+  if (k > 0 && (!out_scores || !out_ids)) { set_error("null output buffer"); return MV_ERR_INVALID; }
+  return query_common(ix, q, q_dtype, n_q_rows, k, mode, allow_bits, n_allow_words, out_scores, out_ids, out_n, nullptr,
+                      nullptr, nullptr, stats);
+}
+
+int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int32_t k, int mode,
+                         const uint32_t* allow_bits, int64_t n_allow_words, float* d_out_scores, int64_t* d_out_ids,
+                         void* stream, mv_query_stats* stats) {
+  if (k < 1 || !d_out_scores || !d_out_ids) { set_error("mv_query_topk_device: k >= 1 and device buffers required"); return MV_ERR_INVALID; }
+  return query_common(ix, q, q_dtype, n_q_rows, k, mode, allow_bits, n_allow_words, nullptr, nullptr, nullptr, d_out_scores,
+                      d_out_ids, stream, stats);
+}
+
+int mv_score_all(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int mode, const uint32_t* allow_bits,
+                 int64_t n_allow_words, float* out_scores, mv_query_stats* stats) {
+  if (!ix || !out_scores) { set_error("null argument"); return MV_ERR_INVALID; }
+  if (mode == MV_MODE_FDE_THEN_FLOAT) mode = MV_MODE_FDE_ONLY;
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->cfg.device);
+  if (ix->size == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return MV_OK; }
+  ScanResult r;
+  int rc = run_scan(ix, q, q_dtype, n_q_rows, mode, allow_bits, n_allow_words, 0, &r, stats);
+  if (rc) return rc;
+  MV_HIP(hipMemcpyAsync(out_scores, r.d_scores, (size_t)r.n * 4, hipMemcpyDeviceToHost, ix->stream));
+  MV_HIP(hipStreamSynchronize(ix->stream));
+  return finish_stats(ix, stats, false);
+}
+
+int mv_score_candidates(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const int32_t* cand, int32_t n_cand,
+                        int32_t pad_to, float* out_scores, mv_query_stats* stats) {
+  if (!ix || !q || !cand || !out_scores || n_cand < 0 || n_cand > kMaxCand || n_q_rows < 1) { set_error("score_candidates: bad argument"); return MV_ERR_INVALID; }
+  if (!(ix->cfg.flags & MV_WITH_FLOAT)) { set_error("index has no float slab"); return MV_ERR_STATE; }
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->cfg.device);
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (n_cand == 0) return MV_OK;
+  int64_t rows = 0;
+  for (int i = 0; i < n_cand; ++i) {
+    if (cand[i] < 0 || cand[i] >= ix->size) { set_error("candidate %d out of range", cand[i]); return MV_ERR_INVALID; }
+    rows += ix->h_n_rows[cand[i]];
+  }
+  int rc = upload_query(ix, q, q_dtype, n_q_rows, true, false, false);
+  if (rc) return rc;
+  MV_HIP(hipMemcpyAsync(ix->d_cand, cand, (size_t)n_cand * 4, hipMemcpyHostToDevice, ix->stream));
+  MV_HIP(hipEventRecord(ix->ev[0], ix->stream));
+  int launches = 0;
+  // tombstones are NOT applied here: the caller named the pages explicitly
+  const bool keep = ix->tombstones;
+  ix->tombstones = false;
+  rc = float_scan(ix, n_q_rows, nullptr, 0, ix->d_cand, n_cand, pad_to, ix->d_cand_scores, &launches);
+  ix->tombstones = keep;
+  if (rc) return rc;
+  MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
+  MV_HIP(hipMemcpyAsync(out_scores, ix->d_cand_scores, (size_t)n_cand * 4, hipMemcpyDeviceToHost, ix->stream));
+  MV_HIP(hipStreamSynchronize(ix->stream));
+  if (stats) {
+    stats->score_launches = launches;
+    stats->pages_scored = n_cand;
+    stats->bytes_scanned = rows * (int64_t)kRowBytes;
+  }
+  return finish_stats(ix, stats, false);
+}
+
+int mv_sign_pack(int device, const float* x, int64_t n_rows, int32_t d, uint8_t* out) {
+  if (!x || !out || n_rows < 0 || d < 1) { set_error("mv_sign_pack: bad argument"); return MV_ERR_INVALID; }
+  if (n_rows == 0) return MV_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device available"); return MV_ERR_HIP; }
+  DeviceGuard g(device);
+  const size_t nb = (size_t)((d + 7) / 8);
+  float* dx = nullptr;
+  uint8_t* dout = nullptr;
+  MV_HIP(hipMalloc(&dx, (size_t)n_rows * d * 4));
+  hipError_t e = hipMalloc(&dout, (size_t)n_rows * nb);
+  if (e != hipSuccess) { (void)hipFree(dx); return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+  int rc = MV_OK;
+  e = hipMemcpy(dx, x, (size_t)n_rows * d * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) rc = hip_fail(e, "H2D", __FILE__, __LINE__);
+  if (!rc) rc = launch_sign_pack_f32(dx, n_rows, d, dout, nullptr);
+  if (!rc) {
+    e = hipMemcpy(out, dout, (size_t)n_rows * nb, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = hip_fail(e, "D2H", __FILE__, __LINE__);
+  }
+  (void)hipFree(dx);
+  (void)hipFree(dout);
+  return rc;
+}
+
+int mv_hamming_batch(int device, const uint8_t* query, const uint8_t* cands, int64_t n_cands, int32_t n_bytes, int32_t* out) {
+  if (!query || (!cands && n_cands) || !out || n_cands < 0 || n_bytes < 1) { set_error("mv_hamming_batch: bad argument"); return MV_ERR_INVALID; }
+  if (n_cands == 0) return MV_OK;
+  DeviceGuard g(device);
+  uint8_t *dq = nullptr, *dc = nullptr;
+  int32_t* dout = nullptr;
+  MV_HIP(hipMalloc(&dq, (size_t)n_bytes));
+  MV_HIP(hipMalloc(&dc, (size_t)n_cands * n_bytes));
+  MV_HIP(hipMalloc(&dout, (size_t)n_cands * 4));
+  int rc = MV_OK;
+  if (hipMemcpy(dq, query, (size_t)n_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(dc, cands, (size_t)n_cands * n_bytes, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D failed"); rc = MV_ERR_HIP; }
+  if (!rc) rc = launch_hamming_batch(dq, dc, n_cands, n_bytes, dout, nullptr);
+  if (!rc && hipMemcpy(out, dout, (size_t)n_cands * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H failed"); rc = MV_ERR_HIP; }
+  (void)hipFree(dq); (void)hipFree(dc); (void)hipFree(dout);
+  return rc;
+}
+
+int64_t mv_fde_output_dim(const mv_fde_config* c) {
+  if (!c) return 0;
+  return (int64_t)c->num_repetitions * (1LL << c->num_simhash_projections) * c->projection_dimension;
+}
+
+int mv_fde_encode(int device, const mv_fde_config* cfg, const float* x, int32_t n_rows, int32_t is_query, float* out) {
+  if (!cfg || !x || !out || n_rows < 0) { set_error("mv_fde_encode: bad argument"); return MV_ERR_INVALID; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device available"); return MV_ERR_HIP; }
+  DeviceGuard g(device);
+  FdeTables t;
+  int rc = fde_tables_create(*cfg, &t);
+  if (rc) return rc;
+  float *dx = nullptr, *dout = nullptr;
+  int64_t* doff = nullptr;
+  const int64_t off[2] = {0, n_rows};
+  if (hipMalloc(&dx, std::max<size_t>((size_t)n_rows * kDim * 4, 16)) != hipSuccess || hipMalloc(&dout, (size_t)t.out_dim * 4) != hipSuccess ||
+      hipMalloc(&doff, 16) != hipSuccess) { set_error("out of device memory"); rc = MV_ERR_NOMEM; }
+  if (!rc && (hipMemcpy(dx, x, (size_t)n_rows * kDim * 4, hipMemcpyHostToDevice) != hipSuccess ||
+              hipMemcpy(doff, off, 16, hipMemcpyHostToDevice) != hipSuccess)) { set_error("H2D failed"); rc = MV_ERR_HIP; }
+  if (!rc) {
+    FdeEncodeArgs e{};
+    e.x_f32 = dx; e.row_offsets = doff; e.n_pages = 1; e.is_query = is_query; e.out_f32 = dout;
+    rc = launch_fde_encode(t, e, nullptr);
+  }
+  if (!rc && hipMemcpy(out, dout, (size_t)t.out_dim * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H failed"); rc = MV_ERR_HIP; }
+  if (dx) (void)hipFree(dx);
+  if (dout) (void)hipFree(dout);
+  if (doff) (void)hipFree(doff);
+  fde_tables_destroy(&t);
+  return rc;
+}
+
+int mv_calibrate_read_bw(int device, int64_t bytes, int32_t iters, double* out_gbps) {
+  if (!out_gbps || bytes < (1 << 20) || iters < 1) { set_error("calibrate: bad argument"); return MV_ERR_INVALID; }
+  DeviceGuard g(device);
+  void* buf = nullptr;
+  float* sink = nullptr;
+  MV_HIP(hipMalloc(&buf, (size_t)bytes));
+  MV_HIP(hipMalloc(&sink, 4));
+  (void)hipMemset(buf, 1, (size_t)bytes);
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  int rc = launch_read_bw(buf, bytes, sink, nullptr);  // warm-up
+  (void)hipEventRecord(a, nullptr);
+  for (int i = 0; i < iters && !rc; ++i) rc = launch_read_bw(buf, bytes, sink, nullptr);
+  (void)hipEventRecord(b, nullptr);
+  (void)hipEventSynchronize(b);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, a, b);
+  *out_gbps = ms > 0 ? (double)bytes * iters / (ms * 1e-3) / 1e9 : 0.0;
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  (void)hipFree(buf);
+  (void)hipFree(sink);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------- persistence
+struct SaveHeader {
+  char magic[8];
+  mv_config cfg;
+  int64_t size;
+  int64_t fde_out_dim;
+};
+
+int mv_index_save(mv_index* ix, const char* path) {
+  if (!ix || !path) { set_error("save: null argument"); return MV_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->cfg.device);
+  FILE* f = fopen(path, "wb");
+  if (!f) { set_error("cannot open %s for writing", path); return MV_ERR_IO; }
+  SaveHeader h{};
+  memcpy(h.magic, "MVIDX001", 8);
+  h.cfg = ix->cfg;
+  h.size = ix->size;
+  h.fde_out_dim = ix->fde_t.out_dim;
+  int rc = MV_OK;
+  auto wr = [&](const void* p, size_t n) { if (!rc && n && fwrite(p, 1, n, f) != n) { set_error("short write to %s", path); rc = MV_ERR_IO; } };
+  wr(&h, sizeof(h));
+  wr(ix->h_n_rows.data(), (size_t)ix->size * 4);
+  wr(ix->h_doc_ord.data(), (size_t)ix->size * 4);
+  std::vector<char> buf((size_t)64 << 20);
+  auto dump = [&](const void* d, size_t bytes) {
+    size_t off = 0;
+    while (!rc && off < bytes) {
+      const size_t n = std::min(buf.size(), bytes - off);
+      if (hipMemcpy(buf.data(), (const char*)d + off, n, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H failed during save"); rc = MV_ERR_HIP; break; }
+      wr(buf.data(), n);
+      off += n;
+    }
+  };
+  const size_t rows = (size_t)ix->size * ix->cfg.stride_rows;
+  if (ix->cfg.flags & MV_WITH_FLOAT) dump(ix->slab, rows * kRowBytes);
+  if (ix->cfg.flags & MV_WITH_BINARY) dump(ix->bits, rows * kSignBytes);
+  if (ix->cfg.flags & MV_WITH_FDE) {
+    dump(ix->fde, (size_t)ix->size * ix->fde_t.out_dim * 2);
+    dump(ix->fde_inv_norm, (size_t)ix->size * 4);
+  }
+  if (fclose(f) != 0 && !rc) { set_error("close failed for %s", path); rc = MV_ERR_IO; }
+  return rc;
+}
+
+int mv_index_load(const char* path, int32_t device, mv_index** out) {
+  if (!path || !out) { set_error("load: null argument"); return MV_ERR_INVALID; }
+  *out = nullptr;
+  FILE* f = fopen(path, "rb");
+  if (!f) { set_error("cannot open %s", path); return MV_ERR_IO; }
+  SaveHeader h{};
+  if (fread(&h, 1, sizeof(h), f) != sizeof(h) || memcmp(h.magic, "MVIDX001", 8) != 0) { fclose(f); set_error("%s is not an mv index file", path); return MV_ERR_IO; }
+  h.cfg.device = device;
+  mv_index* ix = nullptr;
+  int rc = mv_index_create(&h.cfg, &ix);
+  if (rc) { fclose(f); return rc; }
+  DeviceGuard g(device);
+  auto rd = [&](void* p, size_t n) { if (!rc && n && fread(p, 1, n, f) != n) { set_error("short read from %s", path); rc = MV_ERR_IO; } };
+  rd(ix->h_n_rows.data(), (size_t)h.size * 4);
+  rd(ix->h_doc_ord.data(), (size_t)h.size * 4);
+  std::vector<char> buf((size_t)64 << 20);
+  auto fill = [&](void* d, size_t bytes) {
+    size_t off = 0;
+    while (!rc && off < bytes) {
+      const size_t n = std::min(buf.size(), bytes - off);
+      rd(buf.data(), n);
+      if (!rc && hipMemcpy((char*)d + off, buf.data(), n, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D failed during load"); rc = MV_ERR_HIP; }
+      off += n;
+    }
+  };
+  const size_t rows = (size_t)h.size * h.cfg.stride_rows;
+  if (h.cfg.flags & MV_WITH_FLOAT) fill(ix->slab, rows * kRowBytes);
+  if (h.cfg.flags & MV_WITH_BINARY) fill(ix->bits, rows * kSignBytes);
+  if (h.cfg.flags & MV_WITH_FDE) {
+    fill(ix->fde, (size_t)h.size * ix->fde_t.out_dim * 2);
+    fill(ix->fde_inv_norm, (size_t)h.size * 4);
+  }
+  fclose(f);
+  if (!rc) {
+    ix->size = h.size;
+    for (int64_t p = 0; p < h.size; ++p) {
+      if (ix->h_n_rows[p] != h.cfg.stride_rows) ix->ragged = true;
+      if (ix->h_doc_ord[p] < 0) ix->tombstones = true;
+    }
+    if (h.size && (hipMemcpy(ix->d_n_rows, ix->h_n_rows.data(), (size_t)h.size * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                   hipMemcpy(ix->d_doc_ord, ix->h_doc_ord.data(), (size_t)h.size * 4, hipMemcpyHostToDevice) != hipSuccess)) { set_error("H2D of metadata failed"); rc = MV_ERR_HIP; }
+  }
+  if (rc) { std::string keep = g_err; mv_index_destroy(ix); g_err = keep; return rc; }
+  *out = ix;
+  return MV_OK;
+}
+
+}  // extern "C"

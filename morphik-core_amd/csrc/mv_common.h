@@ -1,0 +1,126 @@
+// mv_common.h -- shared declarations of libmvmaxsim's translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "mvmaxsim.h"
+
+namespace mv {
+
+constexpr int kDim = 128;            // embedding width (ColPali/ColQwen head)
+constexpr int kRowBytes = kDim * 2;  // one bf16 patch row
+constexpr int kTileRows = 16;        // patch rows per MFMA tile (N of mfma_f32_16x16x32_bf16)
+constexpr int kTileBytes = kTileRows * kRowBytes;  // 4 KiB
+constexpr int kSignBytes = kDim / 8;               // 16 B packed sign row
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define MV_HIP(expr)                                                         \
+  do {                                                                       \
+    hipError_t _e = (expr);                                                  \
+    if (_e != hipSuccess) return ::mv::hip_fail(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+// ---------------------------------------------------------------- float MaxSim (mv_maxsim.hip)
+struct MaxsimArgs {
+  const uint16_t* slab;     // [pages][stride][128] bf16
+  const int32_t* n_rows;    // valid rows per page (nullable -> stride)
+  const int32_t* doc_ord;   // doc ordinal per page, <0 = tombstoned (nullable)
+  const uint32_t* allow;    // bitmap over doc ordinals (nullable -> all)
+  int64_t n_allow_bits;
+  const int32_t* cand;      // candidate page list (nullable -> pages 0..n-1)
+  const uint16_t* q;        // [q_rows_padded][128] bf16, zero padded to a multiple of 16 rows
+  float* scores;            // [n] one score per work item; -inf for masked pages
+  int64_t n;                // work items
+  int32_t stride;           // rows per page slot
+  int32_t q_tiles;          // q_rows_padded / 16 (1..4)
+  int32_t pad_to;           // zero-padding clamp: pages with n_rows < pad_to clamp each token max at 0
+};
+// variant: -1 default; see DESIGN.md "Kernel variants".
+int launch_maxsim_bf16(const MaxsimArgs& a, int variant, hipStream_t s);
+const char* maxsim_variant_name(int variant);
+int maxsim_default_variant();
+
+// ---------------------------------------------------------------- selection (mv_topk.hip)
+// keys: order-preserving 64-bit (score desc, local index asc). ws must hold topk_ws_bytes(n,k).
+size_t topk_ws_bytes(int64_t n, int32_t k);
+constexpr int kTopkMaxDeviceK = 1024;
+// d_ids_map: optional int32 map from work index to local page id (candidate lists); id_base added on output.
+int launch_topk(const float* d_scores, int64_t n, int32_t k, const int32_t* d_ids_map, int64_t id_base, void* ws,
+                float* d_out_scores, int64_t* d_out_ids, hipStream_t s);
+
+// ---------------------------------------------------------------- synthetic generator (mv_synth.hip)
+int launch_synth_rows(uint16_t* d_out, uint64_t seed, uint64_t first_unit, int64_t n_units, int32_t n_rows,
+                      int32_t stride_rows, hipStream_t s);
+
+// ---------------------------------------------------------------- binary path (mv_binary.hip)
+int launch_sign_pack_f32(const float* d_x, int64_t n_rows, int32_t d, uint8_t* d_out, hipStream_t s);
+// pack bf16 slab rows [n_pages*stride][128] -> [n_pages*stride][16 B]
+int launch_sign_pack_bf16_rows(const uint16_t* d_rows, int64_t n_rows, uint8_t* d_out, hipStream_t s);
+struct BinaryArgs {
+  const uint8_t* bits;     // [pages][stride][16]
+  const int32_t* n_rows;
+  const int32_t* doc_ord;
+  const uint32_t* allow;
+  int64_t n_allow_bits;
+  const uint8_t* qbits;    // [n_q][16]
+  float* scores;           // Q - sum_q min_d hamming / 128, exact in fp32; -inf masked
+  int64_t n;
+  int32_t stride;
+  int32_t n_q;
+};
+int launch_maxsim_binary(const BinaryArgs& a, hipStream_t s);
+int launch_hamming_batch(const uint8_t* d_q, const uint8_t* d_c, int64_t n, int32_t n_bytes, int32_t* d_out,
+                         hipStream_t s);
+
+// ---------------------------------------------------------------- FDE (mv_fde.hip)
+struct FdeTables {           // device copies of the projection tables of one mv_fde_config
+  mv_fde_config cfg{};
+  float* G = nullptr;        // [rep][dim][nsh]
+  int32_t* H = nullptr;      // [rep][dim]
+  float* S = nullptr;        // [rep][dim]
+  int64_t out_dim = 0;
+};
+void fde_host_tables(const mv_fde_config& c, float* G, int32_t* H, float* S);
+int fde_tables_create(const mv_fde_config& c, FdeTables* t);
+void fde_tables_destroy(FdeTables* t);
+// Encode pages: x rows are fp32 [sum rows][128] (x_f32) or bf16 slab pages (x_bf16 with stride);
+// out_f32 (nullable) [n_pages][out_dim] fp32, out_bf16 (nullable) [n_pages][out_dim] bf16,
+// out_inv_norm (nullable) [n_pages] = 1/|bf16(fde)|.
+struct FdeEncodeArgs {
+  const float* x_f32;        // ragged fp32 rows (row_offsets gives the start row of each page) or null
+  const uint16_t* x_bf16;    // fixed-stride bf16 slab pages or null
+  const int64_t* row_offsets;// [n_pages+1] for x_f32 (nullable when n_pages==1 -> 0,n_rows0)
+  const int32_t* n_rows;     // per page rows (for x_bf16; nullable -> stride)
+  int32_t stride;
+  int64_t n_pages;
+  int32_t is_query;
+  float* out_f32;
+  uint16_t* out_bf16;
+  float* out_inv_norm;
+};
+int launch_fde_encode(const FdeTables& t, const FdeEncodeArgs& a, hipStream_t s);
+struct FdeScanArgs {
+  const uint16_t* fde;      // [pages][out_dim] bf16
+  const float* inv_norm;    // [pages] (nullable -> dot)
+  const int32_t* doc_ord;
+  const uint32_t* allow;
+  int64_t n_allow_bits;
+  const float* q;           // [out_dim] fp32
+  float* scores;            // [n]
+  int64_t n;
+  int64_t out_dim;
+};
+int launch_fde_scan(const FdeScanArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- misc device helpers
+int launch_f32_to_bf16(const float* d_in, uint16_t* d_out, int64_t n, hipStream_t s);
+int launch_read_bw(const void* d_buf, int64_t bytes, float* d_sink, hipStream_t s);
+// scatter ragged bf16/f32 rows into the fixed-stride slab (zero-filling the tail of each page slot)
+int launch_scatter_rows(const void* d_src, int dtype, const int64_t* d_row_offsets, int64_t n_pages, int32_t stride,
+                        uint16_t* d_slab_pages, hipStream_t s);
+
+}  // namespace mv

@@ -1,0 +1,393 @@
+// mv_fde.hip -- MUVERA fixed dimensional encoding (FDE) and the coarse scan over FDE vectors.
+//
+// Replaces the un-vendored C++ extension `fixed_dimensional_encoding` as the reference uses it:
+//   config          core/vector_store/fast_multivector_store.py:325-331
+//                   (dimension=128, num_repetitions=20, num_simhash_projections=5,
+//                    projection_dimension=16, projection_type=AMS_SKETCH)
+//   doc encoding    fde.generate_document_encoding(...)   fast_multivector_store.py:447-449  (AVERAGE)
+//   query encoding  fde.generate_query_encoding(...)      fast_multivector_store.py:521      (SUM)
+//   coarse ranking  TurboPuffer ANN over the FDE vectors, cosine distance
+//                   fast_multivector_store.py:497,526-532   -> here an exact scan, dot * 1/|d|.
+// The extension's sources are absent from the reference snapshot; the algorithm is restated from
+// the MUVERA paper / graph-mining fixed_dimensional_encoding.cc and pinned only against our own
+// oracle (oracle/mv_oracle.c, "PARITY UNPINNED").
+//
+// Arithmetic contract (shared with the oracle so SimHash partitions agree bit for bit):
+//   sketch_j = fp32 fmaf chain over k ascending from 0.0f
+//   proj_c   = fp32 sum over i ascending of (+-x_i) for h(i)=c, then * scale
+// Bucket sums over the rows of a partition use LDS float atomics: order-dependent in the last bits,
+// compared with a tolerance (no discontinuity downstream).
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "mv_common.h"
+
+namespace mv {
+namespace {
+
+constexpr int kRowsPerPass = 64;
+constexpr int kMaxNS = 6;
+constexpr int kMaxPD = 16;
+
+void philox_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+struct EncArgs {
+  const float* x_f32;
+  const uint16_t* x_bf16;
+  const int64_t* row_offsets;
+  const int32_t* n_rows;
+  int32_t stride;
+  int32_t is_query;
+  // tables
+  const float* G;        // [R][128][NS]
+  const int32_t* order;  // [R][128] input dims sorted by (bucket, dim)
+  const float* sgn;      // [R][128] sign of order[m]
+  const int32_t* bstart; // [R][PD+1]
+  int32_t R, NS, PD;
+  float scale;
+  int64_t out_dim;
+  float* out_f32;
+  uint16_t* out_bf16;
+  float* out_inv_norm;
+};
+
+// One block per page; 4 waves split the repetitions; 64 rows staged per pass, transposed in LDS.
+__global__ __launch_bounds__(256) void fde_encode_kernel(EncArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xT = reinterpret_cast<float*>(smem);                     // [128][64]
+  float* acc = xT + kDim * kRowsPerPass;                          // [R][NP][PD]
+  const int NP = 1 << a.NS;
+  int32_t* cnt = reinterpret_cast<int32_t*>(acc + a.out_dim);     // [R][NP]
+  float* red = reinterpret_cast<float*>(cnt + a.R * NP);          // [4]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t page = blockIdx.x;
+
+  int64_t r0 = 0;
+  int32_t nr;
+  if (a.x_f32) {
+    r0 = a.row_offsets[page];
+    nr = (int32_t)(a.row_offsets[page + 1] - r0);
+  } else {
+    nr = a.n_rows ? a.n_rows[page] : a.stride;
+    r0 = page * (int64_t)a.stride;
+  }
+
+  for (int i = threadIdx.x; i < (int)a.out_dim; i += 256) acc[i] = 0.0f;
+  for (int i = threadIdx.x; i < a.R * NP; i += 256) cnt[i] = 0;
+
+  for (int p0 = 0; p0 < nr; p0 += kRowsPerPass) {
+    __syncthreads();  // previous pass done with xT; also orders the zero-fill above
+    // stage rows p0..p0+63 transposed: thread -> (row = i / 32, 4 dims)
+    for (int i = threadIdx.x; i < kRowsPerPass * (kDim / 4); i += 256) {
+      const int row = i >> 5, c4 = (i & 31) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p0 + row < nr) {
+        const int64_t e = (r0 + p0 + row) * kDim + c4;
+        if (a.x_f32) {
+          v = *reinterpret_cast<const float4*>(a.x_f32 + e);
+        } else {
+          const uint2 h = *reinterpret_cast<const uint2*>(a.x_bf16 + e);
+          v.x = bf16_to_f32((uint16_t)(h.x & 0xffff)); v.y = bf16_to_f32((uint16_t)(h.x >> 16));
+          v.z = bf16_to_f32((uint16_t)(h.y & 0xffff)); v.w = bf16_to_f32((uint16_t)(h.y >> 16));
+        }
+      }
+      xT[(c4 + 0) * kRowsPerPass + row] = v.x;
+      xT[(c4 + 1) * kRowsPerPass + row] = v.y;
+      xT[(c4 + 2) * kRowsPerPass + row] = v.z;
+      xT[(c4 + 3) * kRowsPerPass + row] = v.w;
+    }
+    __syncthreads();
+    const bool valid = p0 + lane < nr;
+    for (int r = wave; r < a.R; r += 4) {
+      // ---- SimHash: NS fmaf chains over k ascending
+      float sk[kMaxNS];
+#pragma unroll
+      for (int j = 0; j < kMaxNS; ++j) sk[j] = 0.0f;
+      const float* Gr = a.G + (size_t)r * kDim * a.NS;
+      for (int k = 0; k < kDim; ++k) {
+        const float x = xT[k * kRowsPerPass + lane];
+#pragma unroll
+        for (int j = 0; j < kMaxNS; ++j)
+          if (j < a.NS) sk[j] = __builtin_fmaf(x, Gr[k * a.NS + j], sk[j]);
+      }
+      uint32_t part = 0;
+#pragma unroll
+      for (int j = 0; j < kMaxNS; ++j)
+        if (j < a.NS) part = (part << 1) + ((sk[j] > 0.0f ? 1u : 0u) ^ (part & 1u));  // AppendToGrayCode
+      // ---- AMS projection, bucket by bucket (members in ascending input dim)
+      float pj[kMaxPD];
+      const int32_t* ord = a.order + (size_t)r * kDim;
+      const float* sg = a.sgn + (size_t)r * kDim;
+      const int32_t* bs = a.bstart + (size_t)r * (a.PD + 1);
+#pragma unroll
+      for (int c = 0; c < kMaxPD; ++c) {
+        pj[c] = 0.0f;
+        if (c < a.PD) {
+          const int m1 = bs[c + 1];
+          for (int m = bs[c]; m < m1; ++m) pj[c] = __builtin_fmaf(sg[m], xT[ord[m] * kRowsPerPass + lane], pj[c]);
+          pj[c] *= a.scale;
+        }
+      }
+      if (valid) {
+        float* dst = acc + ((size_t)r * NP + part) * a.PD;
+#pragma unroll
+        for (int c = 0; c < kMaxPD; ++c)
+          if (c < a.PD) atomicAdd(&dst[c], pj[c]);
+        atomicAdd(&cnt[r * NP + part], 1);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- finish: AVERAGE for documents, write fp32 / bf16, inverse norm of the bf16 image
+  float nn = 0.0f;
+  for (int i = threadIdx.x; i < (int)a.out_dim; i += 256) {
+    float v = acc[i];
+    if (!a.is_query) {
+      const int n = cnt[i / a.PD];
+      if (n > 1) v = v / (float)n;
+    }
+    if (a.out_f32) a.out_f32[page * a.out_dim + i] = v;
+    const uint16_t h = f32_to_bf16_rne(v);
+    if (a.out_bf16) a.out_bf16[page * a.out_dim + i] = h;
+    const float vb = bf16_to_f32(h);
+    nn += vb * vb;
+  }
+  if (a.out_inv_norm) {
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) nn += __shfl_xor(nn, s);
+    if (lane == 0) red[wave] = nn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float t = (red[0] + red[1]) + (red[2] + red[3]);
+      a.out_inv_norm[page] = t > 0.0f ? 1.0f / sqrtf(t) : 0.0f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ coarse scan
+struct ScanArgs {
+  const uint16_t* fde;
+  const float* inv_norm;
+  const int32_t* doc_ord;
+  const uint32_t* allow;
+  int64_t n_allow_bits;
+  const float* q;
+  float* scores;
+  int64_t n;
+  int32_t out_dim;
+};
+
+// Persistent waves: each lane keeps its slice of the query FDE in registers (ITERS x 8 floats) and
+// streams pages; one page = ITERS coalesced 1 KiB wave loads.  out_dim = ITERS * 512.
+template <int ITERS>
+__global__ __launch_bounds__(256) void fde_scan_kernel(ScanArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  float q[ITERS][8];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const float4 lo = *reinterpret_cast<const float4*>(a.q + it * 512 + lane * 8);
+    const float4 hi = *reinterpret_cast<const float4*>(a.q + it * 512 + lane * 8 + 4);
+    q[it][0] = lo.x; q[it][1] = lo.y; q[it][2] = lo.z; q[it][3] = lo.w;
+    q[it][4] = hi.x; q[it][5] = hi.y; q[it][6] = hi.z; q[it][7] = hi.w;
+  }
+  for (int64_t p = wave; p < a.n; p += nwaves) {
+    bool m = false;
+    if (a.doc_ord) {
+      const int32_t o = a.doc_ord[p];
+      m = o < 0 || (a.allow && ((int64_t)o >= a.n_allow_bits || ((a.allow[o >> 5] >> (o & 31)) & 1u) == 0u));
+    }
+    if (m) {
+      if (lane == 0) a.scores[p] = -INFINITY;
+      continue;
+    }
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+    const u32x4* row = reinterpret_cast<const u32x4*>(a.fde + p * (int64_t)a.out_dim) + lane;
+    float acc = 0.0f;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const u32x4 v = __builtin_nontemporal_load(row + it * 64);
+      const uint32_t w[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc = __builtin_fmaf(__uint_as_float(w[k] << 16), q[it][2 * k], acc);
+        acc = __builtin_fmaf(__uint_as_float(w[k] & 0xffff0000u), q[it][2 * k + 1], acc);
+      }
+    }
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) acc += __shfl_xor(acc, s);
+    if (lane == 0) a.scores[p] = a.inv_norm ? acc * a.inv_norm[p] : acc;
+  }
+}
+
+// generic fallback for out_dim not a multiple of 512 or too large for registers
+__global__ __launch_bounds__(256) void fde_scan_generic_kernel(ScanArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (p >= a.n) return;
+  if (a.doc_ord) {
+    const int32_t o = a.doc_ord[p];
+    if (o < 0 || (a.allow && ((int64_t)o >= a.n_allow_bits || ((a.allow[o >> 5] >> (o & 31)) & 1u) == 0u))) {
+      if (lane == 0) a.scores[p] = -INFINITY;
+      return;
+    }
+  }
+  const uint16_t* row = a.fde + p * (int64_t)a.out_dim;
+  float acc = 0.0f;
+  for (int i = lane; i < a.out_dim; i += 64) acc = __builtin_fmaf(bf16_to_f32(row[i]), a.q[i], acc);
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) acc += __shfl_xor(acc, s);
+  if (lane == 0) a.scores[p] = a.inv_norm ? acc * a.inv_norm[p] : acc;
+}
+
+struct FdeDeviceExtra {  // bucket-sorted projection tables
+  int32_t* order = nullptr;
+  float* sgn = nullptr;
+  int32_t* bstart = nullptr;
+};
+
+}  // namespace
+
+// Projection tables; mirrors oracle/mv_oracle.c:orc_fde_matrices (spec in that file's FDE comment).
+void fde_host_tables(const mv_fde_config& c, float* G, int32_t* H, float* S) {
+  const uint32_t key[2] = {(uint32_t)c.seed, (uint32_t)(c.seed >> 32)};
+  for (int32_t r = 0; r < c.num_repetitions; ++r)
+    for (int32_t k = 0; k < c.dimension; ++k) {
+      for (int32_t j = 0; j < c.num_simhash_projections; ++j) {
+        uint32_t ctr[4] = {(uint32_t)k, (uint32_t)j, (uint32_t)r, 0x47u};
+        uint32_t w[8];
+        philox_host(ctr, key, w);
+        ctr[3] = 0x48u;
+        philox_host(ctr, key, w + 4);
+        int32_t sum = 0;
+        for (int t = 0; t < 6; ++t) sum += (int32_t)(w[t] & 0xffff) + (int32_t)(w[t] >> 16);
+        G[((size_t)r * c.dimension + k) * c.num_simhash_projections + j] = (float)(sum - 6 * 65535) * (1.0f / 65536.0f);
+      }
+      uint32_t ctr[4] = {(uint32_t)k, 0u, (uint32_t)r, 0x41u};
+      uint32_t w[4];
+      philox_host(ctr, key, w);
+      H[(size_t)r * c.dimension + k] = (int32_t)(w[0] % (uint32_t)c.projection_dimension);
+      S[(size_t)r * c.dimension + k] = (w[1] & 1u) ? 1.0f : -1.0f;
+    }
+}
+
+int fde_tables_create(const mv_fde_config& c, FdeTables* t) {
+  if (c.dimension != kDim || c.num_repetitions < 1 || c.num_simhash_projections < 1 ||
+      c.num_simhash_projections > kMaxNS || c.projection_dimension < 1 || c.projection_dimension > kMaxPD) {
+    set_error("unsupported FDE config: dimension must be 128, 1<=simhash<=%d, 1<=projection_dimension<=%d", kMaxNS, kMaxPD);
+    return MV_ERR_INVALID;
+  }
+  const int R = c.num_repetitions, D = c.dimension, NS = c.num_simhash_projections, PD = c.projection_dimension;
+  t->cfg = c;
+  t->out_dim = (int64_t)R * (1 << NS) * PD;
+  std::vector<float> G((size_t)R * D * NS), S((size_t)R * D), sg((size_t)R * D);
+  std::vector<int32_t> H((size_t)R * D), ord((size_t)R * D), bs((size_t)R * (PD + 1));
+  fde_host_tables(c, G.data(), H.data(), S.data());
+  for (int r = 0; r < R; ++r) {
+    int m = 0;
+    for (int b = 0; b < PD; ++b) {
+      bs[(size_t)r * (PD + 1) + b] = m;
+      for (int i = 0; i < D; ++i)
+        if (H[(size_t)r * D + i] == b) {
+          ord[(size_t)r * D + m] = i;
+          sg[(size_t)r * D + m] = S[(size_t)r * D + i];
+          ++m;
+        }
+    }
+    bs[(size_t)r * (PD + 1) + PD] = m;
+  }
+  // one allocation: G | H | S | order | sgn | bstart
+  const size_t bytes = G.size() * 4 + H.size() * 4 + S.size() * 4 + ord.size() * 4 + sg.size() * 4 + bs.size() * 4;
+  char* d = nullptr;
+  MV_HIP(hipMalloc(&d, bytes));
+  size_t off = 0;
+  auto put = [&](const void* src, size_t n) -> void* {
+    void* p = d + off;
+    (void)hipMemcpy(p, src, n, hipMemcpyHostToDevice);
+    off += n;
+    return p;
+  };
+  t->G = (float*)put(G.data(), G.size() * 4);
+  t->H = (int32_t*)put(H.data(), H.size() * 4);
+  t->S = (float*)put(S.data(), S.size() * 4);
+  // the bucket-sorted tables live behind S; their offsets are recomputed in launch_fde_encode
+  put(ord.data(), ord.size() * 4);
+  put(sg.data(), sg.size() * 4);
+  put(bs.data(), bs.size() * 4);
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
+void fde_tables_destroy(FdeTables* t) {
+  if (t->G) (void)hipFree(t->G);
+  t->G = nullptr;
+  t->H = nullptr;
+  t->S = nullptr;
+}
+
+int launch_fde_encode(const FdeTables& t, const FdeEncodeArgs& a, hipStream_t s) {
+  if (a.n_pages <= 0) return MV_OK;
+  const int R = t.cfg.num_repetitions, D = t.cfg.dimension, NS = t.cfg.num_simhash_projections,
+            PD = t.cfg.projection_dimension;
+  EncArgs k{};
+  k.x_f32 = a.x_f32; k.x_bf16 = a.x_bf16; k.row_offsets = a.row_offsets; k.n_rows = a.n_rows;
+  k.stride = a.stride; k.is_query = a.is_query;
+  k.G = t.G;
+  const char* after_S = reinterpret_cast<const char*>(t.S) + (size_t)R * D * 4;
+  k.order = reinterpret_cast<const int32_t*>(after_S);
+  k.sgn = reinterpret_cast<const float*>(after_S + (size_t)R * D * 4);
+  k.bstart = reinterpret_cast<const int32_t*>(after_S + (size_t)R * D * 8);
+  k.R = R; k.NS = NS; k.PD = PD;
+  k.scale = 1.0f / sqrtf((float)PD);
+  k.out_dim = t.out_dim;
+  k.out_f32 = a.out_f32; k.out_bf16 = a.out_bf16; k.out_inv_norm = a.out_inv_norm;
+  const size_t lds = (size_t)kDim * kRowsPerPass * 4 + (size_t)t.out_dim * 4 + (size_t)R * (1 << NS) * 4 + 16;
+  if (lds > 160 * 1024) {
+    set_error("FDE config needs %zu B of LDS (> 160 KiB)", lds);
+    return MV_ERR_INVALID;
+  }
+  MV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fde_encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)lds));
+  hipLaunchKernelGGL(fde_encode_kernel, dim3((unsigned)a.n_pages), dim3(256), lds, s, k);
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
+int launch_fde_scan(const FdeScanArgs& a, hipStream_t s) {
+  if (a.n <= 0) return MV_OK;
+  ScanArgs k{a.fde, a.inv_norm, a.doc_ord, a.allow, a.n_allow_bits, a.q, a.scores, a.n, (int32_t)a.out_dim};
+  const int grid = 256 * 2;  // 2 blocks/CU x 4 waves, persistent
+  if (a.out_dim == 10240) {
+    hipLaunchKernelGGL((fde_scan_kernel<20>), dim3(grid), dim3(256), 0, s, k);
+  } else if (a.out_dim == 5120) {
+    hipLaunchKernelGGL((fde_scan_kernel<10>), dim3(grid), dim3(256), 0, s, k);
+  } else {
+    hipLaunchKernelGGL(fde_scan_generic_kernel, dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, s, k);
+  }
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
+}  // namespace mv

@@ -1,0 +1,378 @@
+// mv_maxsim.hip -- fused float MaxSim page scan for gfx950 (MI355X).
+//
+// Replaces processor.score_multi_vector(...) (colpali_engine v0.3.13, called at
+// core/vector_store/fast_multivector_store.py:553-555): per page
+//     S[Q x P] = Qm[Q x 128] . Pg^T[128 x P]   (bf16 x bf16 -> fp32 on MFMA)
+//     score    = sum_q max_p S[q][p]
+// The reference materialises S (einsum), then max, then sum -- three kernels and a (Q x P) fp32
+// intermediate per page.  Here one kernel streams each 256-byte patch row from HBM exactly once,
+// keeps the running row-max in the MFMA accumulator layout and writes ONE float per page.
+//
+// The scan is HBM-bound (32 flop/byte at Q=32 against a ~315 flop/byte ridge): the kernel's job is
+// to keep >= 32 KiB per CU in flight with perfectly coalesced reads; MFMA time is ~10% of the
+// memory time.  Bytes per page = n_rows * 256.
+//
+// MFMA operand mapping (v_mfma_f32_16x16x32_bf16, D = A.B + C):
+//   A = query tile   : lane l holds Q[m*16 + (l&15)][32j + 8(l>>4) .. +8)      (loop invariant, VGPRs)
+//   B = page tile^T  : lane l holds P[16t + (l&15)][32j + 8(l>>4) .. +8)       (streamed)
+//   D[row = 4(l>>4)+i][col = l&15] -> query row 16m+4(l>>4)+i, patch 16t+(l&15)
+// so the max over patches is an elementwise max over tiles t followed by ONE 16-lane butterfly.
+//
+// Variants (MV_OPT_MAXSIM_VARIANT; measured table in DESIGN.md):
+//   0  direct-to-VGPR loads, one wave per page, 3-tile register ring
+//   1  direct-to-VGPR loads, four waves per page (tiles interleaved), LDS cross-wave max
+//   2  LDS-DMA (global_load_lds_dwordx4) into a wave-private 4-slot ring, XOR-swizzled rows,
+//      ds_read_b128 fragments, one wave per page
+//   3  as 2 with four waves per page
+//   4/5  as 0/1 with non-temporal loads
+#include "mv_common.h"
+
+namespace mv {
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kMaxQTiles = 4;
+
+struct KArgs {
+  const char* slab;
+  const int32_t* n_rows;
+  const int32_t* doc_ord;
+  const uint32_t* allow;
+  int64_t n_allow_bits;
+  const int32_t* cand;
+  const uint16_t* q;
+  float* scores;
+  int64_t n;
+  int32_t stride;
+  int32_t pad_to;
+};
+
+__device__ __forceinline__ bool page_masked(const KArgs& a, int64_t page) {
+  if (!a.doc_ord) return false;
+  int32_t o = a.doc_ord[page];
+  if (o < 0) return true;
+  if (!a.allow) return false;
+  if ((int64_t)o >= a.n_allow_bits) return true;
+  return ((a.allow[o >> 5] >> (o & 31)) & 1u) == 0u;
+}
+
+__device__ __forceinline__ float group16_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 1));
+  v = fmaxf(v, __shfl_xor(v, 2));
+  v = fmaxf(v, __shfl_xor(v, 4));
+  v = fmaxf(v, __shfl_xor(v, 8));
+  return v;
+}
+
+template <int MT>
+__device__ __forceinline__ void load_query(const uint16_t* q, int r, int g, bf16x8 (&a)[MT][4]) {
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[m][j] = *reinterpret_cast<const bf16x8*>(q + (m * 16 + r) * kDim + j * 32 + g * 8);
+}
+
+// One 16-patch tile against MT query tiles; running elementwise max in mx.
+template <int MT>
+__device__ __forceinline__ void tile_mfma(const bf16x8 (&a)[MT][4], const bf16x8 (&b)[4], f32x4 (&mx)[MT], bool mask_cols,
+                                          bool col_valid) {
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][j], b[j], acc, 0, 0, 0);
+    if (mask_cols && !col_valid) acc = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mx[m][i] = fmaxf(mx[m][i], acc[i]);
+  }
+}
+
+// Lane-level finish for ONE wave that saw all of the page's tiles: returns the page score in every lane.
+template <int MT>
+__device__ __forceinline__ float finish_wave(const f32x4 (&mx)[MT], bool clamp) {
+  float total = 0.f;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = group16_max(mx[m][i]);
+      if (clamp) v = fmaxf(v, 0.f);
+      if (v == -INFINITY) v = 0.f;
+      total += v;
+    }
+  total += __shfl_xor(total, 16);
+  total += __shfl_xor(total, 32);
+  return total;
+}
+
+// Cross-wave finish for four waves that split one page's tiles. red: 4 x 64 floats of LDS.
+template <int MT>
+__device__ __forceinline__ void finish_block(const f32x4 (&mx)[MT], bool clamp, float* red, int wave, int lane,
+                                             float* out) {
+  const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = group16_max(mx[m][i]);
+      if (r == 0) red[wave * 64 + m * 16 + g * 4 + i] = v;
+    }
+  __syncthreads();
+  if (wave == 0) {
+    float v = 0.f;
+    if (lane < MT * 16) {
+      v = fmaxf(fmaxf(red[lane], red[64 + lane]), fmaxf(red[128 + lane], red[192 + lane]));
+      if (clamp) v = fmaxf(v, 0.f);
+      if (v == -INFINITY) v = 0.f;
+    }
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s);
+    if (lane == 0) *out = v;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// Variants 0/1/4/5: direct global -> VGPR fragment loads (64 contiguous bytes per row per instruction).
+template <int MT, int WPP, bool NT>
+__global__ __launch_bounds__(256) void maxsim_direct_kernel(KArgs a) {
+  constexpr int PF = 3;  // register ring depth (tiles in flight per wave = PF-1 .. PF)
+  __shared__ float red[256];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t item = (WPP == 1) ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
+  if (item >= a.n) return;
+  const int64_t page = a.cand ? (int64_t)a.cand[item] : item;
+  if (page_masked(a, page)) {
+    if (lane == 0 && (WPP == 1 || wave == 0)) a.scores[item] = -INFINITY;
+    return;
+  }
+  const int nr = a.n_rows ? a.n_rows[page] : a.stride;
+  const int ntiles = (nr + kTileRows - 1) / kTileRows;
+  const bool clamp = a.pad_to > nr;
+
+  bf16x8 qa[MT][4];
+  load_query<MT>(a.q, r, g, qa);
+
+  f32x4 mx[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) mx[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+
+  const char* base = a.slab + (size_t)page * (size_t)a.stride * kRowBytes + r * kRowBytes + g * 16;
+  const int t0 = (WPP == 1) ? 0 : wave;
+  const int ntw = (ntiles - t0 + WPP - 1) / WPP;  // tiles owned by this wave (may be <= 0)
+
+  bf16x8 buf[PF][4];
+  auto load_tile = [&](bf16x8(&b)[4], int it) {
+    const char* tp = base + (size_t)(t0 + it * WPP) * kTileBytes;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16x8* p = reinterpret_cast<const bf16x8*>(tp + j * 64);
+      b[j] = NT ? __builtin_nontemporal_load(p) : *p;
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < PF - 1; ++i)
+    if (i < ntw) load_tile(buf[i], i);
+
+  for (int it0 = 0; it0 < ntw; it0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int it = it0 + u;
+      if (it < ntw) {
+        if (it + PF - 1 < ntw) load_tile(buf[(u + PF - 1) % PF], it + PF - 1);
+        const int t = t0 + it * WPP;
+        const bool partial = (t + 1) * kTileRows > nr;
+        tile_mfma<MT>(qa, buf[u], mx, partial, t * kTileRows + r < nr);
+      }
+    }
+  }
+
+  if (WPP == 1) {
+    float s = finish_wave<MT>(mx, clamp);
+    if (lane == 0) a.scores[item] = s;
+  } else {
+    finish_block<MT>(mx, clamp, red, wave, lane, &a.scores[item]);
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// Variants 2/3: LDS-DMA into a wave-private ring.  No barrier: a wave only ever reads what it
+// DMA'd itself, ordered by its own counted s_waitcnt vmcnt.
+//
+// LDS image of a tile (4 KiB): row-major 16 rows x 256 B, 16-byte chunk c of row w stored at chunk
+// position c ^ w (XOR swizzle) so that the ds_read_b128 fragment reads (16 rows, same logical chunk)
+// hit 16 distinct 16-byte bank slots.  The DMA writes LDS linearly (M0 base + lane*16), so the
+// swizzle is applied to the per-lane GLOBAL source address (same involution both sides); every DMA
+// instruction still reads 4 whole rows = 1 KiB contiguous from HBM.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int MT, int WPP, int D>
+__global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
+  // one __shared__ object only (a second one makes hipcc drain vmcnt before every ds_read)
+  __shared__ __attribute__((aligned(16))) char lds[4 * D * kTileBytes + 1024];
+  float* red = reinterpret_cast<float*>(lds + 4 * D * kTileBytes);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t item = (WPP == 1) ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
+  if (item >= a.n) return;
+  const int64_t page = a.cand ? (int64_t)a.cand[item] : item;
+  if (page_masked(a, page)) {
+    if (lane == 0 && (WPP == 1 || wave == 0)) a.scores[item] = -INFINITY;
+    return;
+  }
+  const int nr = a.n_rows ? a.n_rows[page] : a.stride;
+  const int ntiles = (nr + kTileRows - 1) / kTileRows;
+  const bool clamp = a.pad_to > nr;
+
+  f32x4 mx[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) mx[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+
+  const int t0 = (WPP == 1) ? 0 : wave;
+  const int ntw = (ntiles - t0 + WPP - 1) / WPP;
+  const char* pbase = a.slab + (size_t)page * (size_t)a.stride * kRowBytes;
+  char* ring = lds + wave * (D * kTileBytes);
+
+  // DMA source offsets: instruction i covers rows 4i..4i+3; lane -> row 4i+(lane>>4), position lane&15.
+  int src_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int w = i * 4 + (lane >> 4);
+    src_off[i] = w * kRowBytes + (((lane & 15) ^ w) << 4) - i * 1024;
+  }
+  // fragment read offsets: row r, logical chunk 4j+g at position (4j+g)^r
+  int rd_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rd_off[j] = r * kRowBytes + (((j * 4 + g) ^ r) << 4);
+
+  // The DMA is issued from inline asm: hipcc's waitcnt pass otherwise drains vmcnt(0) in front of
+  // every ds_read that may alias an in-flight LDS-DMA, which serialises the ring.  One statement per
+  // tile: M0 = wave-uniform LDS slot address; the instruction offset (applied to BOTH the global and
+  // the LDS address) walks the four 1 KiB pieces, so src_off[i] carries -i*1024 to compensate.
+  // s_nop 4 covers SALU-write -> VMEM-read of the base SGPRs and the M0 write -> LDS-DMA hazard.
+  auto issue = [&](int it) {
+    const char* tp = pbase + (size_t)(t0 + it * WPP) * kTileBytes;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
+    const uint64_t tpu = ((uint64_t)hi << 32) | lo;
+    const uint32_t slot = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + (it % D) * kTileBytes));
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %6\n\t"
+        "global_load_lds_dwordx4 %2, %6 offset:1024\n\t"
+        "global_load_lds_dwordx4 %3, %6 offset:2048\n\t"
+        "global_load_lds_dwordx4 %4, %6 offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src_off[0]), "v"(src_off[1]), "v"(src_off[2]), "v"(src_off[3]), "s"(slot), "s"(tpu)
+        : "memory");
+  };
+
+#pragma unroll
+  for (int i = 0; i < D - 1; ++i)
+    if (i < ntw) issue(i);
+
+  // Query fragments are loaded AFTER the prologue DMAs were issued and pinned (made "used") here, so
+  // hipcc waits for them once, before the loop.  Left to itself it defers the wait to the first MFMA
+  // inside the loop, where its counted vmcnt(7..0) ladder drains our DMA ring on every iteration.
+  bf16x8 qa[MT][4];
+  load_query<MT>(a.q, r, g, qa);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(qa[m][j]));
+
+  for (int it = 0; it < ntw; ++it) {
+    if (it + D - 1 < ntw) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // WAR: last reads of the slot being refilled
+      issue(it + D - 1);
+      wait_vmcnt<4 * (D - 1)>();
+    } else {
+      const int left = ntw - 1 - it;  // tiles still allowed in flight
+      if (left >= 2) wait_vmcnt<8>();
+      else if (left == 1) wait_vmcnt<4>();
+      else wait_vmcnt<0>();
+    }
+    const char* slot = ring + (it % D) * kTileBytes;
+    bf16x8 b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(slot + rd_off[j]);
+    const int t = t0 + it * WPP;
+    const bool partial = (t + 1) * kTileRows > nr;
+    tile_mfma<MT>(qa, b, mx, partial, t * kTileRows + r < nr);
+  }
+
+  if (WPP == 1) {
+    float s = finish_wave<MT>(mx, clamp);
+    if (lane == 0) a.scores[item] = s;
+  } else {
+    finish_block<MT>(mx, clamp, red, wave, lane, &a.scores[item]);
+  }
+}
+
+template <int MT>
+int launch_mt(const KArgs& k, int variant, hipStream_t s) {
+  const int64_t n = k.n;
+  if (n <= 0) return MV_OK;
+  dim3 block(256);
+  switch (variant) {
+    case 0: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 1, false>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
+    case 1: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 4, false>), dim3((unsigned)n), block, 0, s, k); break;
+    case 2: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 1, 4>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
+    case 3: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4>), dim3((unsigned)n), block, 0, s, k); break;
+    case 4: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 1, true>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
+    case 5: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 4, true>), dim3((unsigned)n), block, 0, s, k); break;
+    default: set_error("unknown maxsim variant %d", variant); return MV_ERR_INVALID;
+  }
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
+}  // namespace
+
+int maxsim_default_variant() { return 0; }
+
+const char* maxsim_variant_name(int v) {
+  switch (v) {
+    case 0: return "direct_wpp1";
+    case 1: return "direct_wpp4";
+    case 2: return "ldsdma_wpp1_d4";
+    case 3: return "ldsdma_wpp4_d4";
+    case 4: return "direct_wpp1_nt";
+    case 5: return "direct_wpp4_nt";
+    default: return "?";
+  }
+}
+
+int launch_maxsim_bf16(const MaxsimArgs& a, int variant, hipStream_t s) {
+  if (variant < 0) variant = maxsim_default_variant();
+  if (a.q_tiles < 1 || a.q_tiles > kMaxQTiles) {
+    set_error("q_tiles=%d out of range (1..%d)", a.q_tiles, kMaxQTiles);
+    return MV_ERR_INVALID;
+  }
+  if (a.n > 0x7fffffffLL) {
+    set_error("too many work items for one launch: %lld", (long long)a.n);
+    return MV_ERR_INVALID;
+  }
+  KArgs k{reinterpret_cast<const char*>(a.slab), a.n_rows, a.doc_ord, a.allow, a.n_allow_bits, a.cand, a.q, a.scores,
+          a.n, a.stride, a.pad_to};
+  switch (a.q_tiles) {
+    case 1: return launch_mt<1>(k, variant, s);
+    case 2: return launch_mt<2>(k, variant, s);
+    case 3: return launch_mt<3>(k, variant, s);
+    default: return launch_mt<4>(k, variant, s);
+  }
+}
+
+}  // namespace mv

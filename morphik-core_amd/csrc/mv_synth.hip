@@ -1,0 +1,179 @@
+// mv_synth.hip -- on-device synthetic corpus generator: any (unit,row) of the corpus
+// is a pure function of (seed, unit, row), so a 262 GB slab is produced shard by shard on the GPU
+// and the CPU oracle (oracle/mv_oracle.c:orc_synth_rows) regenerates any page it wants to check.
+// Spec (must stay bit-identical to the oracle):
+//   w = philox4x32-10(ctr=(unit_lo, unit_hi, row, chunk), key=(seed_lo, seed_hi)),  chunk = dim/4 index
+//   x[4*chunk+j] = byte-sum(w[j]) - 510 ; ss = sum x^2 (exact integer)
+//   y = bf16_rne( (float)( (double)x / sqrt((double)ss) ) )
+// Also holds the small utility kernels (fp32->bf16, ragged scatter, read-bandwidth calibration).
+#include "mv_common.h"
+
+namespace mv {
+namespace {
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// One wave = two rows (32 lanes x 4 dims each).  dim fixed at 128.
+__global__ __launch_bounds__(256) void synth_rows_kernel(uint16_t* out, uint64_t seed, uint64_t first_unit,
+                                                         int64_t n_units, int32_t n_rows, int32_t stride_rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t total_rows = n_units * (int64_t)stride_rows;
+  const int64_t grow = wave * 2 + (lane >> 5);  // global row index in the slab region
+  if (grow >= total_rows) return;
+  const int64_t ui = grow / stride_rows;
+  const int32_t row = (int32_t)(grow - ui * stride_rows);
+  const int chunk = lane & 31;
+  uint2 packed = make_uint2(0u, 0u);
+  if (row < n_rows) {  // wave-uniform per half; rows >= n_rows are zero filled
+    const uint64_t unit = first_unit + (uint64_t)ui;
+    uint32_t w[4];
+    philox4x32_10((uint32_t)unit, (uint32_t)(unit >> 32), (uint32_t)row, (uint32_t)chunk, (uint32_t)seed,
+                  (uint32_t)(seed >> 32), w);
+    int32_t x[4];
+    int32_t ss = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      x[j] = (int32_t)(w[j] & 0xff) + (int32_t)((w[j] >> 8) & 0xff) + (int32_t)((w[j] >> 16) & 0xff) + (int32_t)(w[j] >> 24) - 510;
+      ss += x[j] * x[j];
+    }
+#pragma unroll
+    for (int s = 1; s < 32; s <<= 1) ss += __shfl_xor(ss, s);  // stays inside the 32-lane half
+    if (ss == 0) {
+      if (chunk == 0) x[0] = 1;
+      ss = 1;
+    }
+    const double nrm = sqrt((double)ss);
+    uint16_t h[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = f32_to_bf16_rne((float)((double)x[j] / nrm));
+    packed.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+    packed.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+  }
+  *reinterpret_cast<uint2*>(out + grow * kDim + chunk * 4) = packed;
+}
+
+__global__ void f32_to_bf16_kernel(const float* in, uint16_t* out, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const float4 v = *reinterpret_cast<const float4*>(in + i);
+    uint2 p;
+    p.x = (uint32_t)f32_to_bf16_rne(v.x) | ((uint32_t)f32_to_bf16_rne(v.y) << 16);
+    p.y = (uint32_t)f32_to_bf16_rne(v.z) | ((uint32_t)f32_to_bf16_rne(v.w) << 16);
+    *reinterpret_cast<uint2*>(out + i) = p;
+  } else {
+    for (int64_t j = i; j < n; ++j) out[j] = f32_to_bf16_rne(in[j]);
+  }
+}
+
+// One block per page: copy/convert rows [off[p], off[p+1]) into slab page p, zero the tail.
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const void* src, int dtype, const int64_t* off, int32_t stride,
+                                                           uint16_t* slab) {
+  const int64_t p = blockIdx.x;
+  const int64_t r0 = off[p];
+  const int32_t nr = (int32_t)(off[p + 1] - r0);
+  uint16_t* dst = slab + p * (int64_t)stride * kDim;
+  const int total = stride * (kDim / 4);  // 4 elements per thread-step
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int row = i / (kDim / 4), c4 = i % (kDim / 4);
+    uint2 v = make_uint2(0u, 0u);
+    if (row < nr) {
+      const int64_t e = (r0 + row) * kDim + c4 * 4;
+      if (dtype == MV_BF16) {
+        v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(src) + e);
+      } else {
+        const float4 f = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + e);
+        v.x = (uint32_t)f32_to_bf16_rne(f.x) | ((uint32_t)f32_to_bf16_rne(f.y) << 16);
+        v.y = (uint32_t)f32_to_bf16_rne(f.z) | ((uint32_t)f32_to_bf16_rne(f.w) << 16);
+      }
+    }
+    *reinterpret_cast<uint2*>(dst + (int64_t)row * kDim + c4 * 4) = v;
+  }
+}
+
+// Read-bandwidth calibration: grid-stride 16 B loads, xor-reduce into a sink so nothing is elided.
+__global__ __launch_bounds__(256) void read_bw_kernel(const uint4* buf, int64_t n16, float* sink) {
+  uint32_t acc = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const uint4 a = buf[i], b = buf[i + stride], c = buf[i + 2 * stride], d = buf[i + 3 * stride];
+    acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+  }
+  for (; i < n16; i += stride) {
+    const uint4 a = buf[i];
+    acc ^= a.x ^ a.y ^ a.z ^ a.w;
+  }
+  if (acc == 0x9e3779b9u) *sink = 1.0f;  // practically never; keeps the loads alive
+}
+
+}  // namespace
+
+int launch_synth_rows(uint16_t* d_out, uint64_t seed, uint64_t first_unit, int64_t n_units, int32_t n_rows,
+                      int32_t stride_rows, hipStream_t s) {
+  if (n_units <= 0) return MV_OK;
+  const int64_t total_rows = n_units * (int64_t)stride_rows;
+  const int64_t waves = (total_rows + 1) / 2;
+  // at most 2^31-1 blocks per launch: 4 waves per block
+  const int64_t max_rows_per_launch = (int64_t)0x7fffff00 * 8;
+  int64_t done = 0;
+  (void)waves;
+  while (done < n_units) {
+    int64_t units = n_units - done;
+    const int64_t max_units = max_rows_per_launch / stride_rows;
+    if (units > max_units) units = max_units;
+    const int64_t rows = units * (int64_t)stride_rows;
+    const int64_t blocks = ((rows + 1) / 2 + 3) / 4;
+    hipLaunchKernelGGL(synth_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                       d_out + done * (int64_t)stride_rows * kDim, seed, first_unit + (uint64_t)done, units, n_rows,
+                       stride_rows);
+    done += units;
+  }
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
+int launch_f32_to_bf16(const float* d_in, uint16_t* d_out, int64_t n, hipStream_t s) {
+  if (n <= 0) return MV_OK;
+  const int64_t threads = (n + 3) / 4;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_in, d_out, n);
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
+int launch_scatter_rows(const void* d_src, int dtype, const int64_t* d_row_offsets, int64_t n_pages, int32_t stride,
+                        uint16_t* d_slab_pages, hipStream_t s) {
+  if (n_pages <= 0) return MV_OK;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)n_pages), dim3(256), 0, s, d_src, dtype, d_row_offsets, stride,
+                     d_slab_pages);
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
+int launch_read_bw(const void* d_buf, int64_t bytes, float* d_sink, hipStream_t s) {
+  hipLaunchKernelGGL(read_bw_kernel, dim3(256 * 8), dim3(256), 0, s, reinterpret_cast<const uint4*>(d_buf), bytes / 16,
+                     d_sink);
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
+}  // namespace mv

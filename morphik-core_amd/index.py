@@ -1,0 +1,325 @@
+"""MvIndex -- Python face of one mv_index (one GPU's shard of the page corpus).
+
+Thin: argument normalisation (numpy / torch / list -> contiguous host buffers) and ctypes calls.
+All scoring happens in libmvmaxsim.so on the MI355X; nothing here computes a score.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Any, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import (
+    MV_BF16,
+    MV_F32,
+    MV_MODE_BINARY,
+    MV_MODE_FDE_ONLY,
+    MV_MODE_FDE_THEN_FLOAT,
+    MV_MODE_FLOAT,
+    MV_WITH_BINARY,
+    MV_WITH_FDE,
+    MV_WITH_FLOAT,
+    ConfigC,
+    FdeConfigC,
+    QueryStatsC,
+    check,
+    lib,
+)
+
+MODES = {"float": MV_MODE_FLOAT, "binary": MV_MODE_BINARY, "fde_then_float": MV_MODE_FDE_THEN_FLOAT, "fde": MV_MODE_FDE_ONLY}
+
+
+@dataclass
+class FdeConfig:
+    """fixed_dimensional_encoding.FixedDimensionalEncodingConfig as built at
+    core/vector_store/fast_multivector_store.py:325-331."""
+
+    dimension: int = 128
+    num_repetitions: int = 20
+    num_simhash_projections: int = 5
+    projection_dimension: int = 16
+    seed: int = 1
+
+    def to_c(self) -> FdeConfigC:
+        return FdeConfigC(self.dimension, self.num_repetitions, self.num_simhash_projections, self.projection_dimension, self.seed)
+
+    @property
+    def output_dim(self) -> int:
+        return self.num_repetitions * (1 << self.num_simhash_projections) * self.projection_dimension
+
+
+@dataclass
+class QueryStats:
+    score_kernel_ms: float = 0.0
+    topk_ms: float = 0.0
+    total_device_ms: float = 0.0
+    score_launches: int = 0
+    pages_scored: int = 0
+    bytes_scanned: int = 0
+
+    @classmethod
+    def from_c(cls, s: QueryStatsC) -> "QueryStats":
+        return cls(s.score_kernel_ms, s.topk_ms, s.total_device_ms, s.score_launches, s.pages_scored, s.bytes_scanned)
+
+
+def _to_host(x: Any) -> np.ndarray:
+    """ndarray / torch.Tensor (any device, incl. bfloat16) / list -> numpy array on the host."""
+    if isinstance(x, np.ndarray):
+        return x
+    if hasattr(x, "detach") and hasattr(x, "cpu"):  # torch.Tensor without importing torch here
+        t = x.detach()
+        if str(t.dtype) == "torch.bfloat16":
+            import torch
+
+            return t.cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+        return t.cpu().numpy()
+    if isinstance(x, (list, tuple)) and len(x) and hasattr(x[0], "detach"):
+        return np.stack([_to_host(t) for t in x])
+    return np.asarray(x)
+
+
+def as_rows(x: Any) -> Tuple[np.ndarray, int]:
+    """-> (C-contiguous [n,128] array, dtype code).  uint16 arrays are taken as bf16 bit patterns."""
+    a = _to_host(x)
+    if a.dtype == np.uint16:
+        a = np.ascontiguousarray(a)
+        code = MV_BF16
+    else:
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        code = MV_F32
+    if a.ndim == 1:
+        a = a[None, :]
+    if a.ndim != 2 or a.shape[1] != 128:
+        raise ValueError(f"expected rows of width 128, got shape {a.shape}")
+    return a, code
+
+
+def allow_bitmap(allowed_ordinals: Optional[Iterable[int]], n_docs_hint: int = 0) -> Optional[np.ndarray]:
+    """Bitmap over dense document ordinals for the doc_ids filter (None = no filter)."""
+    if allowed_ordinals is None:
+        return None
+    ords = np.fromiter((int(o) for o in allowed_ordinals), dtype=np.int64)
+    n = int(max(ords.max() + 1 if ords.size else 0, n_docs_hint, 1))
+    bits = np.zeros((n + 31) // 32, np.uint32)
+    if ords.size:
+        np.bitwise_or.at(bits, ords >> 5, (np.uint32(1) << (ords & 31).astype(np.uint32)))
+    return bits
+
+
+class MvIndex:
+    def __init__(
+        self,
+        capacity_pages: int,
+        stride_rows: int = 1024,
+        device: int = 0,
+        with_float: bool = True,
+        with_binary: bool = False,
+        with_fde: bool = False,
+        fde: Optional[FdeConfig] = None,
+        id_base: int = 0,
+    ):
+        self.fde_config = fde or FdeConfig()
+        flags = (MV_WITH_FLOAT if with_float else 0) | (MV_WITH_BINARY if with_binary else 0) | (MV_WITH_FDE if with_fde else 0)
+        cfg = ConfigC(128, int(stride_rows), int(capacity_pages), int(device), flags, int(id_base), self.fde_config.to_c())
+        h = C.c_void_p()
+        check(lib().mv_index_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.stride_rows = int(stride_rows)
+        self.device = int(device)
+        self.id_base = int(id_base)
+        self.flags = flags
+
+    # -- lifecycle
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().mv_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        return int(lib().mv_index_size(self._h))
+
+    @property
+    def capacity(self) -> int:
+        return int(lib().mv_index_capacity(self._h))
+
+    def set_option(self, option: int, value: int) -> None:
+        check(lib().mv_index_set_option(self._h, option, int(value)))
+
+    # -- build
+    def add(self, pages: Sequence[Any], doc_ordinals: Optional[Sequence[int]] = None) -> int:
+        """Append pages (each [n_rows_i,128]; fp32 or bf16-as-uint16). Returns the first local page id."""
+        if len(pages) == 0:
+            return len(self)
+        arrs, codes = zip(*(as_rows(p) if np.size(p) else (np.zeros((0, 128), np.float32), MV_F32) for p in pages))
+        code = MV_BF16 if all(c == MV_BF16 for c in codes) else MV_F32
+        if code == MV_F32 and any(c == MV_BF16 for c in codes):
+            arrs = [(a.astype(np.uint32) << 16).view(np.float32) if c == MV_BF16 else a for a, c in zip(arrs, codes)]
+        n_rows = np.array([a.shape[0] for a in arrs], np.int32)
+        flat = np.ascontiguousarray(np.concatenate(arrs, axis=0)) if n_rows.sum() else np.zeros((1, 128), arrs[0].dtype)
+        ords = None if doc_ordinals is None else np.ascontiguousarray(doc_ordinals, dtype=np.int32)
+        first = C.c_int64()
+        check(
+            lib().mv_index_add(
+                self._h, flat.ctypes.data, code, n_rows.ctypes.data, len(arrs), None if ords is None else ords.ctypes.data, C.byref(first)
+            )
+        )
+        return int(first.value)
+
+    def add_device(self, d_ptr: int, dtype_code: int, n_rows: Sequence[int], doc_ordinals: Optional[Sequence[int]] = None) -> int:
+        """Append pages whose rows already sit in device memory (encoder output): d_ptr = device address
+        of sum(n_rows) x 128 rows."""
+        nr = np.ascontiguousarray(n_rows, dtype=np.int32)
+        ords = None if doc_ordinals is None else np.ascontiguousarray(doc_ordinals, dtype=np.int32)
+        first = C.c_int64()
+        check(lib().mv_index_add_device(self._h, C.c_void_p(d_ptr), dtype_code, nr.ctypes.data, len(nr), None if ords is None else ords.ctypes.data, C.byref(first)))
+        return int(first.value)
+
+    def fill_synthetic(self, seed: int, first_unit: int, n_pages: int, n_rows: Optional[int] = None, pages_per_doc: int = 1) -> None:
+        check(lib().mv_index_fill_synthetic(self._h, seed, first_unit, n_pages, self.stride_rows if n_rows is None else n_rows, pages_per_doc))
+
+    def write_rows(self, page: int, row0: int, rows_bf16: np.ndarray) -> None:
+        r = np.ascontiguousarray(rows_bf16, dtype=np.uint16)
+        check(lib().mv_index_write_rows(self._h, page, row0, r.shape[0], r.ctypes.data))
+
+    def read_pages(self, page0: int, n_pages: int) -> np.ndarray:
+        out = np.empty((n_pages, self.stride_rows, 128), np.uint16)
+        check(lib().mv_index_read_pages(self._h, page0, n_pages, out.ctypes.data))
+        return out
+
+    def remove_doc(self, doc_ordinal: int) -> int:
+        n = C.c_int64()
+        check(lib().mv_index_remove_doc(self._h, doc_ordinal, C.byref(n)))
+        return int(n.value)
+
+    def remove_page(self, page: int) -> None:
+        check(lib().mv_index_remove_page(self._h, page))
+
+    # -- query
+    def query(self, q: Any, k: int, mode: str = "float", allow: Optional[np.ndarray] = None, want_stats: bool = False):
+        """-> (scores[n] float32, ids[n] int64 global page ids[, QueryStats]); n <= k."""
+        qa, code = as_rows(q)
+        k = int(k)
+        scores = np.empty(max(k, 1), np.float32)
+        ids = np.empty(max(k, 1), np.int64)
+        n = C.c_int32()
+        st = QueryStatsC()
+        ab = None if allow is None else np.ascontiguousarray(allow, dtype=np.uint32)
+        check(
+            lib().mv_query_topk(
+                self._h, qa.ctypes.data, code, qa.shape[0], k, MODES[mode], None if ab is None else ab.ctypes.data,
+                0 if ab is None else ab.size, scores.ctypes.data, ids.ctypes.data, C.byref(n), C.byref(st) if want_stats else None,
+            )
+        )
+        res = (scores[: n.value].copy(), ids[: n.value].copy())
+        return res + (QueryStats.from_c(st),) if want_stats else res
+
+    def query_device(self, q: Any, k: int, d_scores_ptr: int, d_ids_ptr: int, mode: str = "float", allow: Optional[np.ndarray] = None,
+                     stream: int = 0, want_stats: bool = False) -> Optional[QueryStats]:
+        """Top-k left in caller-provided DEVICE buffers (k floats / k int64), padded with (-inf, -1)."""
+        qa, code = as_rows(q)
+        ab = None if allow is None else np.ascontiguousarray(allow, dtype=np.uint32)
+        st = QueryStatsC()
+        check(
+            lib().mv_query_topk_device(
+                self._h, qa.ctypes.data, code, qa.shape[0], int(k), MODES[mode], None if ab is None else ab.ctypes.data,
+                0 if ab is None else ab.size, C.c_void_p(d_scores_ptr), C.c_void_p(d_ids_ptr), C.c_void_p(stream) if stream else None,
+                C.byref(st) if want_stats else None,
+            )
+        )
+        return QueryStats.from_c(st) if want_stats else None
+
+    def score_all(self, q: Any, mode: str = "float", allow: Optional[np.ndarray] = None, want_stats: bool = False):
+        qa, code = as_rows(q)
+        out = np.empty(max(len(self), 1), np.float32)
+        st = QueryStatsC()
+        ab = None if allow is None else np.ascontiguousarray(allow, dtype=np.uint32)
+        check(
+            lib().mv_score_all(
+                self._h, qa.ctypes.data, code, qa.shape[0], MODES[mode], None if ab is None else ab.ctypes.data,
+                0 if ab is None else ab.size, out.ctypes.data, C.byref(st) if want_stats else None,
+            )
+        )
+        out = out[: len(self)]
+        return (out, QueryStats.from_c(st)) if want_stats else out
+
+    def score_candidates(self, q: Any, cand: Sequence[int], pad_to: int = 0) -> np.ndarray:
+        qa, code = as_rows(q)
+        c = np.ascontiguousarray(cand, dtype=np.int32)
+        out = np.empty(max(c.size, 1), np.float32)
+        check(lib().mv_score_candidates(self._h, qa.ctypes.data, code, qa.shape[0], c.ctypes.data, c.size, int(pad_to), out.ctypes.data, None))
+        return out[: c.size]
+
+    # -- persistence
+    def save(self, path: str) -> None:
+        check(lib().mv_index_save(self._h, path.encode()))
+
+    @classmethod
+    def load(cls, path: str, device: int = 0) -> "MvIndex":
+        h = C.c_void_p()
+        check(lib().mv_index_load(path.encode(), device, C.byref(h)))
+        self = cls.__new__(cls)
+        self._h = h
+        self.device = device
+        # re-read geometry through the C ABI is not exposed; the header is small, parse it here
+        import struct
+
+        with open(path, "rb") as f:
+            hdr = f.read(8 + C.sizeof(ConfigC))
+        cfg = ConfigC.from_buffer_copy(hdr[8:])
+        self.stride_rows = cfg.stride_rows
+        self.id_base = cfg.id_base
+        self.flags = cfg.flags
+        self.fde_config = FdeConfig(cfg.fde.dimension, cfg.fde.num_repetitions, cfg.fde.num_simhash_projections, cfg.fde.projection_dimension, cfg.fde.seed)
+        del struct
+        return self
+
+
+# ------------------------------------------------------------------ stateless helpers
+def sign_pack(x: Any, device: int = 0) -> np.ndarray:
+    """fast_ops.binary_quantize_packed on the GPU: [n,d] fp32 -> [n, ceil(d/8)] uint8 (MSB first)."""
+    a = np.ascontiguousarray(_to_host(x), dtype=np.float32)
+    if a.ndim == 1:
+        a = a[None, :]
+    out = np.empty((a.shape[0], (a.shape[1] + 7) // 8), np.uint8)
+    check(lib().mv_sign_pack(device, a.ctypes.data, a.shape[0], a.shape[1], out.ctypes.data))
+    return out
+
+
+def hamming_batch(query: bytes, cands: Sequence[bytes], device: int = 0) -> List[int]:
+    q = np.frombuffer(bytes(query), np.uint8)
+    c = np.frombuffer(b"".join(bytes(x) for x in cands), np.uint8)
+    if any(len(x) != q.size for x in cands):
+        raise ValueError("All candidates must have the same length as query")  # binary_ops.rs:277-284
+    out = np.empty(max(len(cands), 1), np.int32)
+    check(lib().mv_hamming_batch(device, q.ctypes.data, c.ctypes.data if len(cands) else None, len(cands), q.size, out.ctypes.data))
+    return out[: len(cands)].tolist()
+
+
+def fde_encode(x: Any, cfg: Optional[FdeConfig] = None, is_query: bool = False, device: int = 0) -> np.ndarray:
+    cfg = cfg or FdeConfig()
+    a = np.ascontiguousarray(_to_host(x), dtype=np.float32)
+    out = np.empty(cfg.output_dim, np.float32)
+    cc = cfg.to_c()
+    check(lib().mv_fde_encode(device, C.byref(cc), a.ctypes.data, a.shape[0], 1 if is_query else 0, out.ctypes.data))
+    return out
+
+
+def synth_rows(seed: int, unit: int, n_rows: int, device: int = 0) -> np.ndarray:
+    out = np.empty((n_rows, 128), np.uint16)
+    check(lib().mv_synth_rows(device, seed, unit, n_rows, out.ctypes.data))
+    return out
+
+
+def calibrate_read_bw(bytes_: int = 8 << 30, iters: int = 5, device: int = 0) -> float:
+    g = C.c_double()
+    check(lib().mv_calibrate_read_bw(device, bytes_, iters, C.byref(g)))
+    return float(g.value)

@@ -1,0 +1,84 @@
+"""Row-sharded corpus over N ranks (one process per GPU) -- SURVEY.md section 8(e).
+
+Rank r owns the contiguous page range shard_range(n_total, r, R); its MvIndex is created with
+id_base = lo so local results already carry GLOBAL page ids.  A query is broadcast by the host
+(every rank receives the same (Q,128) array), each rank scans its own slab, and the only
+exchange is one all-gather of k (score, id) pairs per rank -- RCCL over xGMI on the GPUs
+(torch.distributed backend "nccl"), gloo in the CPU tests.  120 bytes per rank at k=10: pure
+latency, no bandwidth term; no embedding ever crosses a link.
+
+The reference has no distributed code at all; this is the one collective we add.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+
+def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced: the first (n_total % world) ranks get one extra page."""
+    base, rem = divmod(int(n_total), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def merge_topk(scores, ids, k: int):
+    """scores/ids: [R, kk] tensors of per-shard results, each row sorted (score desc, id asc) and padded
+    with (-inf, -1); shards in rank order own ascending id ranges.  Returns the global top-k in the same
+    order.  A stable descending sort keeps (rank, position) order among equal scores, which IS
+    ascending id order, so ties resolve exactly as on a single index."""
+    import torch
+
+    s = scores.reshape(-1)
+    i = ids.reshape(-1)
+    order = torch.sort(s, descending=True, stable=True).indices[:k]
+    ms, mi = s[order], i[order]
+    keep = mi >= 0
+    return ms[keep], mi[keep]
+
+
+def allgather_topk(local_scores, local_ids, k: int, group=None):
+    """local_*: [kk] tensors on this rank (cuda for nccl/RCCL, cpu for gloo). Every rank returns the merged top-k."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    if world == 1:
+        return merge_topk(local_scores[None], local_ids[None], k)
+    gs = torch.empty((world,) + tuple(local_scores.shape), dtype=local_scores.dtype, device=local_scores.device)
+    gi = torch.empty((world,) + tuple(local_ids.shape), dtype=local_ids.dtype, device=local_ids.device)
+    dist.all_gather_into_tensor(gs, local_scores.contiguous(), group=group)
+    dist.all_gather_into_tensor(gi, local_ids.contiguous(), group=group)
+    return merge_topk(gs, gi, k)
+
+
+class ShardedSearcher:
+    """Wraps a per-rank search function.  `local_topk(q, k)` must return two tensors of exactly k entries
+    (padded with -inf / -1) on the collective's device; on the GPU it is MvIndex.query_device writing
+    into torch-owned cuda buffers, in the CPU tests an oracle-backed stand-in."""
+
+    def __init__(self, local_topk: Callable, group=None):
+        self.local_topk = local_topk
+        self.group = group
+
+    def query(self, q, k: int):
+        s, i = self.local_topk(q, k)
+        return allgather_topk(s, i, k, self.group)
+
+
+def make_gpu_local_topk(index, device=None, mode: str = "float", collect_stats: Optional[list] = None):
+    """Adapter: MvIndex -> local_topk over torch cuda buffers (no host round trip of the results)."""
+    import torch
+
+    dev = torch.device("cuda", index.device) if device is None else device
+    bufs = {}
+
+    def local_topk(q, k):
+        if k not in bufs:
+            bufs[k] = (torch.empty(k, dtype=torch.float32, device=dev), torch.empty(k, dtype=torch.int64, device=dev))
+        s, i = bufs[k]
+        st = index.query_device(q, k, s.data_ptr(), i.data_ptr(), mode=mode, want_stats=collect_stats is not None)
+        if collect_stats is not None:
+            collect_stats.append(st)
+        return s, i
+
+    return local_topk

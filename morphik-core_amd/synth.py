@@ -1,0 +1,83 @@
+"""Synthetic workload helpers shared by tests and bench.
+
+The corpus itself is generated on the GPU (csrc/mv_synth.hip); this module holds the small
+host-side pieces: fp32->bf16 rounding, queries' planted neighbours, recall.
+No scoring happens here.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+SEED_CORPUS = 1234
+SEED_QUERIES = 4321
+SEED_PLANTED = 99
+
+
+def f32_to_bf16(x: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even fp32 -> bf16 bit patterns (uint16)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    nan = (u & 0x7FFFFFFF) > 0x7F800000
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    if nan.any():
+        r[nan] = ((u[nan] >> 16) | 0x40).astype(np.uint16)
+    return r
+
+
+def bf16_to_f32(u: np.ndarray) -> np.ndarray:
+    u = np.ascontiguousarray(u, dtype=np.uint16)
+    return (u.astype(np.uint32) << 16).view(np.float32).reshape(u.shape)
+
+
+def planted_rows(q_bf16: np.ndarray, rank: int, rng: np.random.Generator, n_ranks: int = 10) -> np.ndarray:
+    """Rows to plant in a page so it becomes the query's rank-`rank` neighbour:
+    normalize(q_row + sigma_rank * noise), sigma rising 0.05 .. 0.5 with rank -> a unique, well
+    separated exact top-n_ranks (background per-token max of 1024 random unit vectors ~ 0.3)."""
+    q = bf16_to_f32(q_bf16)
+    sigma = 0.05 + (0.5 - 0.05) * rank / max(n_ranks - 1, 1)
+    noise = rng.standard_normal(q.shape).astype(np.float32) / np.sqrt(q.shape[1])
+    v = q + sigma * noise
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    return f32_to_bf16(v)
+
+
+def planted_spec(queries_bf16: Sequence[np.ndarray], n_pages_total: int, stride_rows: int, n_ranks: int = 10,
+                 seed: int = SEED_PLANTED) -> List[Tuple[int, int, int, int, np.ndarray]]:
+    """[(query_idx, rank, GLOBAL page id, first_row, rows_bf16)] -- a pure function of its arguments, so every
+    rank of a sharded run and the CPU checker derive the same overrides."""
+    plan = planted_plan(len(queries_bf16), n_pages_total, n_ranks, seed)
+    out = []
+    for qi, q in enumerate(queries_bf16):
+        for r in range(n_ranks):
+            rng = np.random.default_rng([seed, qi, r])
+            nq = q.shape[0]
+            row0 = int(rng.integers(0, max(stride_rows - nq, 0) + 1))
+            rows = planted_rows(q, r, rng, n_ranks)[: stride_rows - row0]
+            out.append((qi, r, int(plan[qi, r]), row0, rows))
+    return out
+
+
+def plant_neighbours(index, spec, page_lo: int = 0, page_hi: int = None) -> int:
+    """Write the overrides of `spec` whose global page falls in [page_lo, page_hi) into `index`
+    (local page = global - page_lo).  Returns the number of pages written."""
+    n = 0
+    for _qi, _r, page, row0, rows in spec:
+        if page < page_lo or (page_hi is not None and page >= page_hi):
+            continue
+        index.write_rows(page - page_lo, row0, rows)
+        n += 1
+    return n
+
+
+def planted_plan(n_queries: int, n_pages_total: int, n_ranks: int = 10, seed: int = SEED_PLANTED) -> np.ndarray:
+    """Global page ids chosen for planting, [n_queries, n_ranks] -- identical on every rank of a sharded run."""
+    rng = np.random.default_rng(seed)
+    return rng.choice(n_pages_total, size=n_queries * n_ranks, replace=False).reshape(n_queries, n_ranks)
+
+
+def recall_at_k(got_ids: Sequence[int], want_ids: Sequence[int]) -> float:
+    want = set(int(i) for i in want_ids)
+    if not want:
+        return 1.0
+    return len(want & set(int(i) for i in got_ids)) / float(len(want))

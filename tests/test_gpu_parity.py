@@ -1,0 +1,393 @@
+"""GPU parity tests: every HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs (and against the committed golden fixtures).  Bars: bit-exact for integer/byte/index
+work; <= 1e-3 relative (north_star) for float scores -- observed ~1e-6.
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc  # noqa: E402  (checker only)
+
+RTOL = 1e-3  # north_star tolerance for float MaxSim
+
+
+@pytest.fixture(scope="module")
+def mv():
+    import morphik_core_amd as m
+
+    assert os.path.exists(m.library_path()), "libmvmaxsim.so missing: the HIP path must be the one that runs"
+    from morphik_core_amd import _lib
+
+    assert _lib.lib().mv_device_count() >= 1, "no MI355X visible"
+    return m
+
+
+def _idx(mv, **kw):
+    from morphik_core_amd.index import MvIndex
+
+    return MvIndex(**kw)
+
+
+def _assert_topk_matches(got_s, got_i, want_s, want_i, rtol=RTOL):
+    assert len(got_i) == len(want_i)
+    np.testing.assert_allclose(got_s, want_s, rtol=rtol, atol=1e-6)
+    # ids equal where oracle scores are separated by more than the tolerance; equal as sets otherwise
+    assert set(got_i.tolist()) == set(want_i.tolist())
+    sep = np.abs(np.diff(want_s)) > 2 * rtol * np.abs(want_s[:-1]).max() if len(want_s) > 1 else np.array([])
+    if len(want_s) > 1 and sep.all():
+        assert got_i.tolist() == want_i.tolist()
+
+
+# ------------------------------------------------------------------ generator
+def test_synth_generator_bit_identical_to_oracle(mv):
+    from morphik_core_amd.index import synth_rows
+
+    ix = _idx(mv, capacity_pages=16, stride_rows=64)
+    ix.fill_synthetic(1234, 5, 9, n_rows=50)
+    got = ix.read_pages(0, 9)
+    want = np.zeros_like(got)
+    want[:, :50] = orc.synth_pages(1234, 5, 9, 50)
+    assert np.array_equal(got, want)
+    assert np.array_equal(synth_rows(4321, 3, 32), orc.synth_rows(4321, 3, 0, 32))
+    ix.close()
+
+
+# ------------------------------------------------------------------ float MaxSim
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+def test_float_maxsim_all_variants_small(mv, variant):
+    from morphik_core_amd import _lib
+
+    ix = _idx(mv, capacity_pages=512, stride_rows=64)
+    ix.fill_synthetic(1234, 0, 301)
+    ix.set_option(_lib.MV_OPT_MAXSIM_VARIANT, variant)
+    pages = ix.read_pages(0, 301)
+    for nq in (32, 7, 48):
+        q = orc.synth_rows(4321, nq, 0, nq)
+        want = orc.maxsim_bf16_slab(q, pages)
+        got = ix.score_all(q)
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-6)
+        assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()  # expected ~1e-6
+        gs, gi = ix.query(q, 10)
+        ws, wi = orc.topk(want, 10)
+        _assert_topk_matches(gs, gi, ws, wi)
+    ix.close()
+
+
+@pytest.mark.parametrize("nq", [1, 16, 17, 32, 64, 65, 100])
+def test_float_maxsim_1024_patches_query_lengths(mv, nq):
+    ix = _idx(mv, capacity_pages=64, stride_rows=1024)
+    ix.fill_synthetic(1234, 100, 40)
+    pages = ix.read_pages(0, 40)
+    q = orc.synth_rows(4321, 1000 + nq, 0, nq)
+    want = orc.maxsim_float_np(orc.bf16_to_f32(q), orc.bf16_to_f32(pages))
+    got = ix.score_all(q)
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6)
+    ix.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_float_maxsim_ragged_pages(mv, variant):
+    """Ragged pages through mv_index_add: rows beyond n_rows never count (pad_to = 0)."""
+    from morphik_core_amd import _lib
+
+    lens = [0, 1, 15, 16, 17, 31, 32, 33, 47, 48, 63, 64, 5, 64, 20]
+    pages = [orc.synth_rows(77, i, 0, n) if n else np.zeros((0, 128), np.uint16) for i, n in enumerate(lens)]
+    ix = _idx(mv, capacity_pages=32, stride_rows=64)
+    ix.set_option(_lib.MV_OPT_MAXSIM_VARIANT, variant)
+    ix.add(pages)
+    q = orc.synth_rows(4321, 9, 0, 21)
+    want = np.array([orc.maxsim_bf16(q, p) for p in pages], np.float32)
+    got = ix.score_all(q)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-6)
+    # zero-padding clamp of score_multi_vector: candidates scored as ONE batch pad to the longest
+    cand = [1, 4, 11, 12]
+    pad_to = max(lens[c] for c in cand)
+    want_c = np.array([orc.maxsim_bf16(q, pages[c], pad_to) for c in cand], np.float32)
+    np.testing.assert_allclose(ix.score_candidates(q, cand, pad_to), want_c, rtol=RTOL, atol=1e-6)
+    ix.close()
+
+
+def test_float_maxsim_golden_score_retrieval(mv, golden_dir):
+    """Against transformers' score_retrieval outputs (tests/golden/maxsim_float.npz)."""
+    g = np.load(os.path.join(golden_dir, "maxsim_float.npz"))
+    for ci in range(int(g["n_cases"])):
+        q, slab, n_rows, pad_to, want = (g[f"{k}{ci}"] for k in ("q", "slab", "n_rows", "pad_to", "scores"))
+        stride = ((slab.shape[1] + 15) // 16) * 16
+        ix = _idx(mv, capacity_pages=slab.shape[0], stride_rows=stride)
+        ix.add([slab[i, : n_rows[i]] for i in range(slab.shape[0])])
+        for j in range(0, slab.shape[0], 128):  # the reference pads per batch of 128
+            cand = list(range(j, min(j + 128, slab.shape[0])))
+            got = ix.score_candidates(q, cand, int(pad_to[j]))
+            # fp32 fixtures are rounded to bf16 on upload: |ds| <= Q * 2^-8 worst case, typically 1e-3 relative
+            exact = np.array_equal(orc.bf16_to_f32(orc.f32_to_bf16(slab)), slab)
+            np.testing.assert_allclose(got, want[cand], rtol=RTOL if exact else 5e-3, atol=1e-5 if exact else 2e-2)
+        ix.close()
+
+
+def test_doc_filter_and_tombstones(mv):
+    from morphik_core_amd.index import allow_bitmap
+
+    ix = _idx(mv, capacity_pages=256, stride_rows=32)
+    ix.fill_synthetic(1234, 0, 200, pages_per_doc=4)  # 50 docs of 4 pages
+    pages = ix.read_pages(0, 200)
+    q = orc.synth_rows(4321, 0, 0, 32)
+    full = orc.maxsim_bf16_slab(q, pages)
+    allowed = [3, 7, 8, 40]
+    bm = allow_bitmap(allowed, 50)
+    got = ix.score_all(q, allow=bm)
+    mask = np.isin(np.arange(200) // 4, allowed)
+    assert np.all(np.isneginf(got[~mask]))
+    np.testing.assert_allclose(got[mask], full[mask], rtol=RTOL)
+    s, i = ix.query(q, 50, allow=bm)
+    assert len(i) == 16 and set(i.tolist()) <= set(np.nonzero(mask)[0].tolist())  # results subset of the filter
+    ws, wi = orc.topk(np.where(mask, full, -np.inf), 50)
+    _assert_topk_matches(s, i, ws, wi)
+    # delete document 7 -> its pages disappear (delete_chunks_by_document_id)
+    assert ix.remove_doc(7) == 4
+    s, i = ix.query(q, 50, allow=bm)
+    assert len(i) == 12 and not (set(i.tolist()) & {28, 29, 30, 31})
+    s, i = ix.query(q, 300)  # k > N, no filter
+    assert len(i) == 196
+    ix.close()
+
+
+def test_topk_ties_k_edge_cases_and_large_k(mv):
+    ix = _idx(mv, capacity_pages=6000, stride_rows=16)
+    base = [orc.synth_rows(5, i, 0, 16) for i in range(40)]
+    pages = [base[i % 40] for i in range(5000)]  # every page duplicated 125 times -> massive ties
+    ix.add(pages)
+    q = orc.synth_rows(4321, 1, 0, 8)
+    sc = ix.score_all(q)
+    want = np.array([orc.maxsim_bf16(q, p) for p in base], np.float32)
+    np.testing.assert_allclose(sc[:40], want, rtol=RTOL)
+    assert np.array_equal(sc, np.tile(sc[:40], 125))  # identical pages -> bit-identical scores
+    for k in (1, 10, 130, 1024, 1500, 6000):
+        s, i = ix.query(q, k)
+        ws, wi = orc.topk(sc, k)
+        assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist()  # (score desc, id asc) exactly
+    s, i = ix.query(q, 0)
+    assert len(i) == 0
+    ix.close()
+    empty = _idx(mv, capacity_pages=4, stride_rows=16)
+    s, i = empty.query(q, 5)
+    assert len(i) == 0  # empty store (test_multivector.py:205-211)
+    empty.close()
+
+
+def test_self_retrieval_ranks_first(mv):
+    """core/tests/unit/test_multivector.py:166-181: querying with a stored page's own embedding ranks
+    it first, scores non-increasing."""
+    ix = _idx(mv, capacity_pages=128, stride_rows=32)
+    ix.fill_synthetic(1234, 0, 100)
+    page = ix.read_pages(17, 1)[0]
+    s, i = ix.query(page, 5)
+    assert i[0] == 17 and np.all(np.diff(s) <= 0)
+    assert s[0] == pytest.approx(32.0, rel=2e-2)  # 32 unit rows matching themselves
+    ix.close()
+
+
+def test_logical_shards_equal_single_index(mv):
+    """Row-sharding invariance: R shards with id_base offsets + merge == one index."""
+    N, stride = 960, 32
+    one = _idx(mv, capacity_pages=N, stride_rows=stride)
+    one.fill_synthetic(1234, 0, N)
+    q = orc.synth_rows(4321, 2, 0, 32)
+    s1, i1 = one.query(q, 10)
+    for R in (2, 4, 8):
+        per = N // R
+        parts = []
+        for r in range(R):
+            sh = _idx(mv, capacity_pages=per, stride_rows=stride, id_base=r * per)
+            sh.fill_synthetic(1234, r * per, per)
+            parts.append(sh.query(q, 10))
+            sh.close()
+        s = np.concatenate([p[0] for p in parts])
+        i = np.concatenate([p[1] for p in parts])
+        ms, mi = orc.topk(s, 10, ids=i)
+        assert mi.tolist() == i1.tolist() and ms.tolist() == s1.tolist()
+    one.close()
+
+
+def test_planted_neighbours_recall_and_sampled_parity_midsize(mv):
+    """20k pages x 1024 patches (5.2 GB): recall@10 == 1.0 on planted neighbours; sampled oracle parity."""
+    from morphik_core_amd import synth
+
+    N, stride = 20000, 1024
+    ix = _idx(mv, capacity_pages=N, stride_rows=stride)
+    ix.fill_synthetic(synth.SEED_CORPUS, 0, N)
+    queries = [orc.synth_rows(synth.SEED_QUERIES, qi, 0, 32) for qi in range(4)]
+    spec = synth.planted_spec(queries, N, stride)
+    assert synth.plant_neighbours(ix, spec) == 40
+    rng = np.random.default_rng(0)
+    sample = np.sort(rng.choice(N, 64, replace=False))
+    for qi, q in enumerate(queries):
+        s, i = ix.query(q, 10)
+        planted = [p for (qq, r, p, _, _) in spec if qq == qi]
+        assert i.tolist() == planted  # rank order by construction (sigma rises with rank)
+        assert synth.recall_at_k(i, planted) == 1.0
+        # oracle on planted + sampled pages, regenerated on the CPU with the same overrides
+        full = ix.score_all(q)
+        check = sorted(set(sample.tolist()) | set(planted))
+        for p in check:
+            page = orc.synth_rows(synth.SEED_CORPUS, p, 0, stride)
+            for (qq, r, pp, row0, rows) in spec:
+                if pp == p:
+                    page[row0 : row0 + rows.shape[0]] = rows
+            want = orc.maxsim_float_np(orc.bf16_to_f32(q), orc.bf16_to_f32(page)[None])[0]
+            assert abs(full[p] - want) <= RTOL * abs(want)
+    ix.close()
+
+
+# ------------------------------------------------------------------ binary path
+def test_sign_pack_matches_reference_golden(mv, golden_dir):
+    from morphik_core_amd.index import sign_pack
+
+    g = np.load(os.path.join(golden_dir, "sign_pack.npz"))
+    for ci in range(int(g["n_cases"])):
+        assert np.array_equal(sign_pack(g[f"x{ci}"]), g[f"packed{ci}"]), f"case {ci}"
+    # morphik_rust/src/binary_ops.rs:309-320
+    assert sign_pack(np.array([1, -1, 1, -1, -1, 1, -1, 1], np.float32))[0, 0] == 0b10100101
+
+
+def test_hamming_batch_matches_reference_golden(mv, golden_dir):
+    from morphik_core_amd.index import hamming_batch
+
+    g = np.load(os.path.join(golden_dir, "hamming.npz"))
+    assert hamming_batch(bytes(g["q"]), [bytes(x) for x in g["b"]]) == g["batch"].tolist()
+    assert hamming_batch(bytes([0xF0, 0xAA]), [bytes([0xF0, 0x55])]) == [8]  # binary_ops.rs:322-334
+    with pytest.raises(ValueError):
+        hamming_batch(b"ab", [b"abc"])
+
+
+def test_binary_maxsim_exact_vs_sql_restatement(mv):
+    lens = [64, 1, 0, 33, 64, 17, 64, 64, 5]
+    rng = np.random.default_rng(4)
+    pages = [rng.standard_normal((n, 128)).astype(np.float32) for n in lens]
+    pages[4][3, :7] = 0.0  # zeros quantise to 0 bits
+    ix = _idx(mv, capacity_pages=16, stride_rows=64, with_float=False, with_binary=True)
+    ix.add(pages)
+    for nq in (1, 9, 32, 40):
+        q = rng.standard_normal((nq, 128)).astype(np.float32)
+        want = np.array([orc.maxsim_binary(orc.sign_pack(p) if len(p) else np.zeros((0, 16), np.uint8), orc.sign_pack(q)) for p in pages])
+        got = ix.score_all(q, mode="binary")
+        assert got.astype(np.float64).tolist() == want.tolist()  # integer arithmetic: exact
+        s, i = ix.query(q, 4, mode="binary")
+        ws, wi = orc.topk(want.astype(np.float32), 4)
+        assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist()
+    ix.close()
+
+
+def test_binary_maxsim_reference_known_ranking(mv):
+    """core/tests/unit/test_multivector.py:214-256 -> doc1 first with 1.0, doc2 0.0."""
+    half = np.concatenate([np.ones(64), -np.ones(64)]).astype(np.float32)
+    ix = _idx(mv, capacity_pages=4, stride_rows=16, with_float=True, with_binary=True)
+    ix.add([np.stack([half] * 3), np.stack([-half] * 3)])
+    s, i = ix.query(half[None], 2, mode="binary")
+    assert i.tolist() == [0, 1] and s.tolist() == [1.0, 0.0]
+    ix.close()
+
+
+def test_binary_maxsim_synthetic_slab_1024(mv):
+    ix = _idx(mv, capacity_pages=64, stride_rows=1024, with_binary=True)
+    ix.fill_synthetic(1234, 0, 48)
+    pages = ix.read_pages(0, 48)
+    q = orc.synth_rows(4321, 0, 0, 32)
+    bits = np.stack([orc.sign_pack(orc.bf16_to_f32(p)) for p in pages])
+    want = orc.maxsim_binary_np(bits, orc.sign_pack(orc.bf16_to_f32(q)))
+    got = ix.score_all(q, mode="binary")
+    assert got.astype(np.float64).tolist() == want.tolist()
+    ix.close()
+
+
+# ------------------------------------------------------------------ FDE
+def test_fde_encode_matches_oracle(mv):
+    from morphik_core_amd.index import FdeConfig, fde_encode
+
+    cfg = FdeConfig()
+    ocfg = orc.FdeConfig.reference_default()
+    assert cfg.output_dim == 10240
+    for n in (1, 32, 63, 64, 65, 200):
+        x = orc.bf16_to_f32(orc.synth_rows(9, n, 0, n))
+        x[0, :5] *= 3.7  # not unit norm, not bf16-exact
+        for is_q in (True, False):
+            got = fde_encode(x, cfg, is_query=is_q)
+            want = orc.fde_encode(ocfg, x, is_q)
+            # partitions agree bit for bit (same fmaf chain) -> the support of the vectors is identical
+            assert np.array_equal(got != 0, want != 0)
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+def test_fde_coarse_scan_and_pipeline(mv):
+    from morphik_core_amd import _lib, synth
+
+    N, stride = 600, 64
+    ix = _idx(mv, capacity_pages=N, stride_rows=stride, with_fde=True)
+    ix.fill_synthetic(1234, 0, N)
+    q = orc.synth_rows(4321, 0, 0, 32)
+    spec = synth.planted_spec([q], N, stride, n_ranks=5)
+    # plant BEFORE the FDE slab is built: rebuild by re-adding planted pages is not needed here,
+    # so build a second index from host pages instead
+    pages = ix.read_pages(0, N)
+    for (_, _, p, row0, rows) in spec:
+        pages[p, row0 : row0 + rows.shape[0]] = rows
+    ix.close()
+    ix = _idx(mv, capacity_pages=N, stride_rows=stride, with_fde=True)
+    ix.add(list(pages))
+    ocfg = orc.FdeConfig.reference_default()
+    qf = orc.bf16_to_f32(q)
+    fq = orc.fde_encode(ocfg, qf, True)
+    fds = np.stack([orc.fde_encode(ocfg, orc.bf16_to_f32(p), False) for p in pages])
+    for cosine in (1, 0):
+        ix.set_option(_lib.MV_OPT_FDE_COSINE, cosine)
+        want = orc.fde_coarse_scores(fq, orc.f32_to_bf16(fds), use_cosine=bool(cosine))
+        got = ix.score_all(q, mode="fde")
+        np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4)
+    # coarse -> exact rerank: the planted pages come back on top with their exact scores
+    ix.set_option(_lib.MV_OPT_FDE_COSINE, 1)
+    s, i = ix.query(q, 5, mode="fde_then_float")
+    exact = orc.maxsim_float_np(qf, orc.bf16_to_f32(pages))
+    planted = [p for (_, _, p, _, _) in spec]
+    assert i.tolist() == planted
+    np.testing.assert_allclose(s, exact[planted], rtol=RTOL)
+    ix.close()
+
+
+# ------------------------------------------------------------------ persistence
+def test_save_load_roundtrip(mv, tmp_path):
+    from morphik_core_amd.index import MvIndex
+
+    ix = _idx(mv, capacity_pages=64, stride_rows=32, with_binary=True, with_fde=True)
+    ix.fill_synthetic(1234, 0, 50, pages_per_doc=5)
+    ix.remove_doc(2)
+    q = orc.synth_rows(4321, 0, 0, 32)
+    before = {m: ix.query(q, 7, mode=m) for m in ("float", "binary", "fde_then_float")}
+    path = str(tmp_path / "ix.mv")
+    ix.save(path)
+    ix.close()
+    ix2 = MvIndex.load(path)
+    assert len(ix2) == 50
+    for m, (s, i) in before.items():
+        s2, i2 = ix2.query(q, 7, mode=m)
+        assert i2.tolist() == i.tolist() and s2.tolist() == s.tolist()
+    ix2.close()
+
+
+def test_errors_are_loud(mv):
+    from morphik_core_amd import MvError
+
+    with pytest.raises(MvError):
+        _idx(mv, capacity_pages=4, stride_rows=20)  # not a multiple of 16
+    ix = _idx(mv, capacity_pages=2, stride_rows=16)
+    with pytest.raises(MvError):
+        ix.add([np.zeros((17, 128), np.float32)])  # longer than the stride
+    ix.add([np.ones((3, 128), np.float32)] * 2)
+    with pytest.raises(MvError):
+        ix.add([np.ones((3, 128), np.float32)])  # slab full
+    with pytest.raises(MvError):
+        ix.query(np.ones((2, 128), np.float32), 1, mode="binary")  # slab not enabled
+    ix.close()

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""A/B of the float MaxSim kernel variants (and the binary / FDE scans) in ONE process, interleaved
+rounds, HIP-event kernel times from the library's own stats.  Writes JSON to stdout / a file."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pages", type=int, default=100_000)
+    ap.add_argument("--patches", type=int, default=1024)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--variants", default="0,1,2,3,4,5")
+    ap.add_argument("--qtokens", default="32")
+    ap.add_argument("--aux", action="store_true", help="also time binary and FDE scans (smaller corpus)")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    from morphik_core_amd import _lib
+    from morphik_core_amd.index import MvIndex, calibrate_read_bw, synth_rows
+
+    res = {"pages": a.pages, "patches": a.patches, "float": {}, "calib_read_gbps": calibrate_read_bw(4 << 30, 10)}
+    ix = MvIndex(capacity_pages=a.pages, stride_rows=a.patches)
+    ix.fill_synthetic(1234, 0, a.pages)
+    nbytes = a.pages * a.patches * 256
+    variants = [int(v) for v in a.variants.split(",")]
+    for qt in [int(x) for x in a.qtokens.split(",")]:
+        q = synth_rows(4321, 0, qt)
+        times = {v: [] for v in variants}
+        ref = None
+        for r in range(a.rounds + 1):
+            for v in variants:
+                ix.set_option(_lib.MV_OPT_MAXSIM_VARIANT, v)
+                s, i, st = ix.query(q, 10, want_stats=True)
+                if ref is None:
+                    ref = (s, i)
+                assert i.tolist() == ref[1].tolist() and np.allclose(s, ref[0], rtol=1e-5), f"variant {v} disagrees"
+                if r:  # round 0 = warm-up
+                    times[v].append((st.score_kernel_ms, st.topk_ms))
+        for v in variants:
+            k = np.array([t[0] for t in times[v]])
+            res["float"][f"q{qt}_v{v}"] = {
+                "kernel_ms_med": float(np.median(k)), "kernel_ms_min": float(k.min()),
+                "GBps_med": nbytes / np.median(k) / 1e6, "GBps_best": nbytes / k.min() / 1e6,
+                "topk_ms_med": float(np.median([t[1] for t in times[v]])),
+            }
+            print(f"q={qt} variant {v}: {np.median(k):.3f} ms  {nbytes/np.median(k)/1e6:.0f} GB/s (best {nbytes/k.min()/1e6:.0f})  topk {np.median([t[1] for t in times[v]]):.3f} ms", flush=True)
+    ix.close()
+    if a.aux:
+        n = min(a.pages, 200_000)
+        ix = MvIndex(capacity_pages=n, stride_rows=a.patches, with_float=True, with_binary=True, with_fde=True)
+        import time
+        t0 = time.time()
+        ix.fill_synthetic(1234, 0, n)
+        res["fill_with_binary_fde_s"] = time.time() - t0
+        res["fill_pages"] = n
+        q = synth_rows(4321, 0, 32)
+        for mode, per_page in (("binary", a.patches * 16), ("fde", 10240 * 2), ("fde_then_float", 10240 * 2)):
+            ts = []
+            for r in range(a.rounds + 1):
+                s, i, st = ix.query(q, 10, mode=mode, want_stats=True)
+                if r:
+                    ts.append(st.score_kernel_ms)
+            res[mode] = {"kernel_ms_med": float(np.median(ts)), "GBps_med": n * per_page / np.median(ts) / 1e6, "pages_per_s": n / np.median(ts) * 1e3}
+            print(f"{mode}: {np.median(ts):.3f} ms  {n*per_page/np.median(ts)/1e6:.0f} GB/s  {n/np.median(ts)*1e3/1e6:.1f} M pages/s", flush=True)
+        ix.close()
+    js = json.dumps(res, indent=1)
+    if a.out:
+        os.makedirs(os.path.dirname(a.out), exist_ok=True)
+        open(a.out, "w").write(js)
+    print(js)
+
+
+if __name__ == "__main__":
+    main()
