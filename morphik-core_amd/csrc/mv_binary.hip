@@ -11,6 +11,8 @@
 //
 // The scan reads 16 B per patch row (16 KiB per 1024-patch page) and does 9 VALU ops per
 // (query row, patch): it sits close to the crossover of the HBM and VALU rooflines.
+#include <algorithm>
+
 #include "mv_common.h"
 
 namespace mv {
@@ -139,9 +141,14 @@ __global__ void hamming_batch_kernel(const uint8_t* q, const uint8_t* c, int64_t
 }  // namespace
 
 int launch_sign_pack_f32(const float* d_x, int64_t n_rows, int32_t d, uint8_t* d_out, hipStream_t s) {
-  const int64_t total = n_rows * ((d + 7) / 8);
-  if (total <= 0) return MV_OK;
-  hipLaunchKernelGGL(sign_pack_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_x, n_rows, d, d_out);
+  const int64_t nb = (d + 7) / 8;
+  if (n_rows * nb <= 0) return MV_OK;
+  const int64_t rows_per = std::max<int64_t>(((int64_t)1 << 31) / nb, 1);  // < 2^32 work-items per launch
+  for (int64_t r = 0; r < n_rows; r += rows_per) {
+    const int64_t m = std::min(rows_per, n_rows - r);
+    hipLaunchKernelGGL(sign_pack_f32_kernel, dim3((unsigned)((m * nb + 255) / 256)), dim3(256), 0, s, d_x + r * d, m, d,
+                       d_out + r * nb);
+  }
   MV_HIP(hipGetLastError());
   return MV_OK;
 }
@@ -151,7 +158,7 @@ int launch_sign_pack_bf16_rows(const uint16_t* d_rows, int64_t n_rows, uint8_t* 
   int64_t done = 0;
   while (done < words) {  // keep each launch under 2^31 blocks
     int64_t w = words - done;
-    const int64_t cap = (int64_t)0x7fffff00 * 256;
+    const int64_t cap = (int64_t)1 << 31;  // work-items per launch must stay below 2^32
     if (w > cap) w = cap;
     hipLaunchKernelGGL(sign_pack_bf16_kernel, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, s, d_rows + done * 32, w,
                        reinterpret_cast<uint32_t*>(d_out) + done);
@@ -165,6 +172,7 @@ int launch_maxsim_binary(const BinaryArgs& a, hipStream_t s) {
   if (a.n <= 0) return MV_OK;
   BArgs k{reinterpret_cast<const uint4*>(a.bits), a.n_rows, a.doc_ord, a.allow, a.n_allow_bits,
           reinterpret_cast<const uint4*>(a.qbits), a.scores, a.n, a.stride, a.n_q};
+  if (a.n > ((int64_t)1 << 25)) { set_error("binary scan: more than 2^25 pages per launch is not supported"); return MV_ERR_INVALID; }
   hipLaunchKernelGGL(maxsim_binary_kernel, dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, s, k);
   MV_HIP(hipGetLastError());
   return MV_OK;

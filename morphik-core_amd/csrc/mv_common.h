@@ -42,7 +42,7 @@ struct MaxsimArgs {
 // variant: -1 default; see DESIGN.md "Kernel variants".
 int launch_maxsim_bf16(const MaxsimArgs& a, int variant, hipStream_t s);
 const char* maxsim_variant_name(int variant);
-int maxsim_default_variant();
+int maxsim_default_variant(int stride_rows);
 
 // ---------------------------------------------------------------- selection (mv_topk.hip)
 // keys: order-preserving 64-bit (score desc, local index asc). ws must hold topk_ws_bytes(n,k).

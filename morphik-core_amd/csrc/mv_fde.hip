@@ -384,6 +384,7 @@ int launch_fde_scan(const FdeScanArgs& a, hipStream_t s) {
   } else if (a.out_dim == 5120) {
     hipLaunchKernelGGL((fde_scan_kernel<10>), dim3(grid), dim3(256), 0, s, k);
   } else {
+    if (a.n > ((int64_t)1 << 25)) { set_error("generic FDE scan: more than 2^25 pages per launch is not supported"); return MV_ERR_INVALID; }
     hipLaunchKernelGGL(fde_scan_generic_kernel, dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, s, k);
   }
   MV_HIP(hipGetLastError());

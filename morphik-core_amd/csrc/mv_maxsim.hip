@@ -25,6 +25,8 @@
 //      ds_read_b128 fragments, one wave per page
 //   3  as 2 with four waves per page
 //   4/5  as 0/1 with non-temporal loads
+#include <algorithm>
+
 #include "mv_common.h"
 
 namespace mv {
@@ -47,6 +49,7 @@ struct KArgs {
   int64_t n;
   int32_t stride;
   int32_t pad_to;
+  int64_t page0;  // first page of this launch when there is no candidate list
 };
 
 __device__ __forceinline__ bool page_masked(const KArgs& a, int64_t page) {
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256) void maxsim_direct_kernel(KArgs a) {
   const int r = lane & 15, g = lane >> 4;
   const int64_t item = (WPP == 1) ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
   if (item >= a.n) return;
-  const int64_t page = a.cand ? (int64_t)a.cand[item] : item;
+  const int64_t page = a.cand ? (int64_t)a.cand[item] : a.page0 + item;
   if (page_masked(a, page)) {
     if (lane == 0 && (WPP == 1 || wave == 0)) a.scores[item] = -INFINITY;
     return;
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
   const int r = lane & 15, g = lane >> 4;
   const int64_t item = (WPP == 1) ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
   if (item >= a.n) return;
-  const int64_t page = a.cand ? (int64_t)a.cand[item] : item;
+  const int64_t page = a.cand ? (int64_t)a.cand[item] : a.page0 + item;
   if (page_masked(a, page)) {
     if (lane == 0 && (WPP == 1 || wave == 0)) a.scores[item] = -INFINITY;
     return;
@@ -322,18 +325,27 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
 }
 
 template <int MT>
-int launch_mt(const KArgs& k, int variant, hipStream_t s) {
-  const int64_t n = k.n;
-  if (n <= 0) return MV_OK;
+int launch_mt(const KArgs& k0, int variant, hipStream_t s) {
+  if (k0.n <= 0) return MV_OK;
   dim3 block(256);
-  switch (variant) {
-    case 0: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 1, false>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
-    case 1: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 4, false>), dim3((unsigned)n), block, 0, s, k); break;
-    case 2: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 1, 4>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
-    case 3: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4>), dim3((unsigned)n), block, 0, s, k); break;
-    case 4: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 1, true>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
-    case 5: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 4, true>), dim3((unsigned)n), block, 0, s, k); break;
-    default: set_error("unknown maxsim variant %d", variant); return MV_ERR_INVALID;
+  // a launch's work-item count must stay below 2^32: at most 2^22 pages per launch (x256 or x64 threads)
+  constexpr int64_t kChunk = (int64_t)1 << 22;
+  for (int64_t off = 0; off < k0.n; off += kChunk) {
+    KArgs k = k0;
+    k.n = std::min(kChunk, k0.n - off);
+    k.scores = k0.scores + off;
+    if (k0.cand) k.cand = k0.cand + off;
+    else k.page0 = k0.page0 + off;
+    const int64_t n = k.n;
+    switch (variant) {
+      case 0: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 1, false>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
+      case 1: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 4, false>), dim3((unsigned)n), block, 0, s, k); break;
+      case 2: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 1, 4>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
+      case 3: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4>), dim3((unsigned)n), block, 0, s, k); break;
+      case 4: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 1, true>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
+      case 5: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 4, true>), dim3((unsigned)n), block, 0, s, k); break;
+      default: set_error("unknown maxsim variant %d", variant); return MV_ERR_INVALID;
+    }
   }
   MV_HIP(hipGetLastError());
   return MV_OK;
@@ -341,7 +353,10 @@ int launch_mt(const KArgs& k, int variant, hipStream_t s) {
 
 }  // namespace
 
-int maxsim_default_variant() { return 0; }
+// Measured on MI355X (profiles/variants_r1.json, 100k pages x 1024 patches, Q=32): LDS-DMA ring with four
+// waves per page 6.47 TB/s > direct loads 6.2-6.4 TB/s > non-temporal direct 5.9-6.0 TB/s.  Short pages
+// (< 16 tiles) cannot feed four waves, so they take the wave-per-page form.
+int maxsim_default_variant(int stride_rows) { return stride_rows >= 256 ? 3 : 2; }
 
 const char* maxsim_variant_name(int v) {
   switch (v) {
@@ -356,7 +371,7 @@ const char* maxsim_variant_name(int v) {
 }
 
 int launch_maxsim_bf16(const MaxsimArgs& a, int variant, hipStream_t s) {
-  if (variant < 0) variant = maxsim_default_variant();
+  if (variant < 0) variant = maxsim_default_variant(a.stride);
   if (a.q_tiles < 1 || a.q_tiles > kMaxQTiles) {
     set_error("q_tiles=%d out of range (1..%d)", a.q_tiles, kMaxQTiles);
     return MV_ERR_INVALID;
@@ -366,7 +381,7 @@ int launch_maxsim_bf16(const MaxsimArgs& a, int variant, hipStream_t s) {
     return MV_ERR_INVALID;
   }
   KArgs k{reinterpret_cast<const char*>(a.slab), a.n_rows, a.doc_ord, a.allow, a.n_allow_bits, a.cand, a.q, a.scores,
-          a.n, a.stride, a.pad_to};
+          a.n, a.stride, a.pad_to, 0};
   switch (a.q_tiles) {
     case 1: return launch_mt<1>(k, variant, s);
     case 2: return launch_mt<2>(k, variant, s);

@@ -6,6 +6,8 @@
 //   x[4*chunk+j] = byte-sum(w[j]) - 510 ; ss = sum x^2 (exact integer)
 //   y = bf16_rne( (float)( (double)x / sqrt((double)ss) ) )
 // Also holds the small utility kernels (fp32->bf16, ragged scatter, read-bandwidth calibration).
+#include <algorithm>
+
 #include "mv_common.h"
 
 namespace mv {
@@ -131,16 +133,12 @@ __global__ __launch_bounds__(256) void read_bw_kernel(const uint4* buf, int64_t 
 int launch_synth_rows(uint16_t* d_out, uint64_t seed, uint64_t first_unit, int64_t n_units, int32_t n_rows,
                       int32_t stride_rows, hipStream_t s) {
   if (n_units <= 0) return MV_OK;
-  const int64_t total_rows = n_units * (int64_t)stride_rows;
-  const int64_t waves = (total_rows + 1) / 2;
-  // at most 2^31-1 blocks per launch: 4 waves per block
-  const int64_t max_rows_per_launch = (int64_t)0x7fffff00 * 8;
+  // A launch's total work-item count must stay below 2^32 (32-bit AQL grid): 32 threads per row,
+  // so at most 2^26 rows per launch.
+  const int64_t max_units = std::max<int64_t>(((int64_t)1 << 26) / stride_rows, 1);
   int64_t done = 0;
-  (void)waves;
   while (done < n_units) {
-    int64_t units = n_units - done;
-    const int64_t max_units = max_rows_per_launch / stride_rows;
-    if (units > max_units) units = max_units;
+    const int64_t units = std::min(n_units - done, max_units);
     const int64_t rows = units * (int64_t)stride_rows;
     const int64_t blocks = ((rows + 1) / 2 + 3) / 4;
     hipLaunchKernelGGL(synth_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
@@ -154,8 +152,11 @@ int launch_synth_rows(uint16_t* d_out, uint64_t seed, uint64_t first_unit, int64
 
 int launch_f32_to_bf16(const float* d_in, uint16_t* d_out, int64_t n, hipStream_t s) {
   if (n <= 0) return MV_OK;
-  const int64_t threads = (n + 3) / 4;
-  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_in, d_out, n);
+  const int64_t per = (int64_t)1 << 32;  // elements per launch (2^30 threads x 4)
+  for (int64_t o = 0; o < n; o += per) {
+    const int64_t m = std::min(per, n - o);
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)(((m + 3) / 4 + 255) / 256)), dim3(256), 0, s, d_in + o, d_out + o, m);
+  }
   MV_HIP(hipGetLastError());
   return MV_OK;
 }
