@@ -44,11 +44,12 @@ def allgather_topk(local_scores, local_ids, k: int, group=None):
     world = dist.get_world_size(group)
     if world == 1:
         return merge_topk(local_scores[None], local_ids[None], k)
-    gs = torch.empty((world,) + tuple(local_scores.shape), dtype=local_scores.dtype, device=local_scores.device)
-    gi = torch.empty((world,) + tuple(local_ids.shape), dtype=local_ids.dtype, device=local_ids.device)
-    dist.all_gather_into_tensor(gs, local_scores.contiguous(), group=group)
-    dist.all_gather_into_tensor(gi, local_ids.contiguous(), group=group)
-    return merge_topk(gs, gi, k)
+    kk = local_scores.numel()
+    gs = torch.empty(world * kk, dtype=local_scores.dtype, device=local_scores.device)  # rank-major concatenation
+    gi = torch.empty(world * kk, dtype=local_ids.dtype, device=local_ids.device)
+    dist.all_gather_into_tensor(gs, local_scores.contiguous().view(-1), group=group)
+    dist.all_gather_into_tensor(gi, local_ids.contiguous().view(-1), group=group)
+    return merge_topk(gs.view(world, kk), gi.view(world, kk), k)
 
 
 class ShardedSearcher:

@@ -1,0 +1,297 @@
+"""BaseVectorStore plugins backed by the MI355X index -- the drop-in boundary of SURVEY.md 8(b).
+
+  MI355XMultiVectorStore      drop-in for core/vector_store/multi_vector_store.py:MultiVectorStore
+                              (scores = SQL max_sim on sign bits; mode "binary")
+  MI355XFastMultiVectorStore  drop-in for core/vector_store/fast_multivector_store.py:FastMultiVectorStore
+                              (FDE coarse top min(10k,75) -> exact float MaxSim rerank; mode "fde_then_float")
+  either can run mode "float": exact float MaxSim over the WHOLE corpus (no coarse stage) -- what the
+  HBM-resident slab makes affordable (1 M pages in ~40 ms on one GPU).
+
+Signatures, return shapes and error conventions follow the reference:
+  store_embeddings -> (True, ["{document_id}-{chunk_number}", ...], metrics)   multi_vector_store.py:623-719
+  query_similar    -> List[DocumentChunk] sorted by score desc, embedding=[]     multi_vector_store.py:721-817
+  get_chunks_by_id -> score 0.0                                                  multi_vector_store.py:824-919
+  delete_chunks_by_document_id -> bool, False on error                           multi_vector_store.py:921-951
+  initialize() -> bool, never raises                                             multi_vector_store.py:186-327
+Scoring is done by libmvmaxsim.so only; this file is bookkeeping (ids, payloads, filters).
+"""
+from __future__ import annotations
+
+import asyncio
+import json
+import logging
+import threading
+import time
+from typing import Any, Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .models import BaseVectorStore, DocumentChunk, build_store_metrics
+
+logger = logging.getLogger(__name__)
+
+
+def _embedding_rows(e: Any) -> np.ndarray:
+    """ndarray / torch.Tensor (any device) / list -> C-contiguous [n,128] fp32 or uint16(bf16)
+    (multi_vector_store.py:334-337 and fast_multivector_store.py:515-518 accept the same inputs)."""
+    from .index import _to_host
+
+    a = _to_host(e)
+    if a.dtype != np.uint16:
+        a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim == 1:
+        a = a[None, :]
+    if a.ndim != 2 or a.shape[1] != 128:
+        raise ValueError(f"multi-vector embedding must be [n, 128]; got {a.shape}")
+    return a
+
+
+class MI355XMultiVectorStore(BaseVectorStore):
+    backend_name = "mi355x"
+    default_mode = "binary"
+
+    def __init__(
+        self,
+        capacity_pages: int = 1_000_000,
+        stride_rows: int = 1040,  # ColPali-v1.2: 1024 patches + 6 prompt rows -> 1030, padded to a multiple of 16
+        device: int = 0,
+        mode: Optional[str] = None,
+        storage: Any = None,
+        id_base: int = 0,
+        index_factory: Optional[Callable[..., Any]] = None,
+        fde_coarse_n: int = 0,
+        **_ignored: Any,
+    ):
+        self.capacity_pages = int(capacity_pages)
+        self.stride_rows = int(stride_rows)
+        self.device = int(device)
+        self.mode = mode or self.default_mode
+        if self.mode not in ("binary", "float", "fde_then_float"):
+            raise ValueError(f"unknown mode {self.mode}")
+        self.storage = storage  # callers reach for .storage (document_service.py:1570-1575)
+        self.id_base = int(id_base)
+        self.fde_coarse_n = int(fde_coarse_n)
+        self._index_factory = index_factory
+        self._index = None
+        self._lock = threading.RLock()
+        # payload table: page -> (document_id, chunk_number, content, metadata_json, app_id)
+        self._rows: Dict[int, Tuple[str, int, str, str, Optional[str]]] = {}
+        self._page_of: Dict[Tuple[str, int], int] = {}
+        self._doc_ord: Dict[str, int] = {}
+        self._doc_app: Dict[int, Optional[str]] = {}
+        self._doc_pages: Dict[str, List[int]] = {}
+        self._last_store_metrics: Dict[str, Any] = {}
+        self.last_query_timing: Dict[str, float] = {}
+
+    # ------------------------------------------------------------------ lifecycle
+    def _make_index(self):
+        if self._index_factory is not None:
+            return self._index_factory(capacity_pages=self.capacity_pages, stride_rows=self.stride_rows, device=self.device,
+                                       id_base=self.id_base, mode=self.mode)
+        from .index import MvIndex  # HIP-only: raises MvError when libmvmaxsim.so or the GPU is missing
+
+        ix = MvIndex(
+            capacity_pages=self.capacity_pages, stride_rows=self.stride_rows, device=self.device, id_base=self.id_base,
+            with_float=self.mode in ("float", "fde_then_float"), with_binary=self.mode == "binary",
+            with_fde=self.mode == "fde_then_float",
+        )
+        if self.fde_coarse_n:
+            from ._lib import MV_OPT_FDE_COARSE_N
+
+            ix.set_option(MV_OPT_FDE_COARSE_N, self.fde_coarse_n)
+        return ix
+
+    def initialize(self) -> bool:
+        """Allocate the HBM slabs. Returns False on failure, never raises (multi_vector_store.py:325-327)."""
+        try:
+            with self._lock:
+                if self._index is None:
+                    self._index = self._make_index()
+            logger.info("%s initialized successfully", type(self).__name__)
+            return True
+        except Exception as e:  # noqa: BLE001
+            logger.error("Error initializing %s: %s", type(self).__name__, e)
+            return False
+
+    def close(self) -> None:
+        with self._lock:
+            if self._index is not None:
+                try:
+                    self._index.close()
+                except Exception as e:  # noqa: BLE001
+                    logger.error("Error closing index: %s", e)
+                self._index = None
+
+    def _require_index(self):
+        if self._index is None:
+            with self._lock:
+                if self._index is None:
+                    self._index = self._make_index()
+        return self._index
+
+    # ------------------------------------------------------------------ store
+    def _store_sync(self, valid: List[DocumentChunk], embs: List[np.ndarray], app_id: Optional[str]) -> List[str]:
+        ix = self._require_index()
+        with self._lock:
+            ords = []
+            for c in valid:
+                o = self._doc_ord.get(c.document_id)
+                if o is None:
+                    o = len(self._doc_ord)
+                    self._doc_ord[c.document_id] = o
+                    self._doc_app[o] = app_id
+                ords.append(o)
+            # upsert: an existing (document_id, chunk_number) is replaced (FastMultiVectorStore upserts by id)
+            for c in valid:
+                old = self._page_of.pop((c.document_id, c.chunk_number), None)
+                if old is not None:
+                    ix.remove_page(old - self.id_base)
+                    self._rows.pop(old, None)
+                    if old in self._doc_pages.get(c.document_id, []):
+                        self._doc_pages[c.document_id].remove(old)
+            first = ix.add(embs, ords) + self.id_base
+            ids = []
+            for i, c in enumerate(valid):
+                page = first + i
+                self._rows[page] = (c.document_id, int(c.chunk_number), c.content, json.dumps(c.metadata or {}), app_id)
+                self._page_of[(c.document_id, int(c.chunk_number))] = page
+                self._doc_pages.setdefault(c.document_id, []).append(page)
+                ids.append(f"{c.document_id}-{c.chunk_number}")
+            return ids
+
+    async def store_embeddings(self, chunks: List[DocumentChunk], app_id: Optional[str] = None) -> Tuple[bool, List[str], Dict[str, Any]]:
+        valid: List[DocumentChunk] = []
+        for chunk in chunks:
+            if not hasattr(chunk, "embedding") or chunk.embedding is None:
+                logger.error(f"Missing embeddings for chunk {chunk.document_id}-{chunk.chunk_number}")
+                continue
+            valid.append(chunk)
+        if not valid:
+            self._last_store_metrics = build_store_metrics(
+                chunk_payload_backend="memory", multivector_backend=self.backend_name, vector_store_backend=self.backend_name
+            )
+            return True, [], self._last_store_metrics
+        embs = [_embedding_rows(c.embedding) for c in valid]
+        for c, e in zip(valid, embs):
+            if e.shape[0] > self.stride_rows:
+                raise ValueError(
+                    f"chunk {c.document_id}-{c.chunk_number} has {e.shape[0]} vectors; this store was created with "
+                    f"stride_rows={self.stride_rows}"
+                )
+        t0 = time.perf_counter()
+        ids = await asyncio.to_thread(self._store_sync, valid, embs, app_id)
+        dt = time.perf_counter() - t0
+        self._last_store_metrics = build_store_metrics(
+            chunk_payload_backend="memory", multivector_backend=self.backend_name, vector_store_backend=self.backend_name,
+            multivector_upload_s=dt, multivector_objects=len(ids), multivector_bytes=int(sum(e.shape[0] for e in embs)) * 256,
+            vector_store_write_s=dt, vector_store_rows=len(ids),
+        )
+        return True, ids, self._last_store_metrics
+
+    # ------------------------------------------------------------------ query
+    def _allow_for(self, doc_ids: Optional[List[str]], app_id: Optional[str]):
+        """doc_ids falsy => no filter (multi_vector_store.py:754). Returns (bitmap or None, empty?)."""
+        from .index import allow_bitmap
+
+        ords = None
+        if doc_ids:
+            ords = [self._doc_ord[d] for d in doc_ids if d in self._doc_ord]
+        if app_id is not None and self._filter_by_app:
+            base = range(len(self._doc_ord)) if ords is None else ords
+            ords = [o for o in base if self._doc_app.get(o) == app_id]
+        if ords is None:
+            return None, False
+        if not ords:
+            return None, True
+        return allow_bitmap(ords, len(self._doc_ord)), False
+
+    _filter_by_app = False  # MultiVectorStore.query_similar ignores app_id (multi_vector_store.py:721-763)
+
+    def _query_sync(self, q: np.ndarray, k: int, allow) -> Tuple[np.ndarray, np.ndarray]:
+        ix = self._require_index()
+        t0 = time.perf_counter()
+        s, i = ix.query(q, k, mode=self.mode, allow=allow)
+        self.last_query_timing = {"vector_search_s": time.perf_counter() - t0}
+        return s, i
+
+    async def query_similar(
+        self,
+        query_embedding: Any,
+        k: int,
+        doc_ids: Optional[List[str]] = None,
+        app_id: Optional[str] = None,
+        skip_image_content: bool = False,
+    ) -> List[DocumentChunk]:
+        q = _embedding_rows(query_embedding)
+        with self._lock:
+            allow, empty = self._allow_for(doc_ids, app_id)
+        if empty or k <= 0:
+            return []
+        scores, pages = await asyncio.to_thread(self._query_sync, q, int(k), allow)  # exceptions propagate (:819-822)
+        out: List[DocumentChunk] = []
+        with self._lock:
+            for s, p in zip(scores.tolist(), pages.tolist()):
+                row = self._rows.get(int(p))
+                if row is None:
+                    continue  # deleted between scan and lookup
+                doc_id, chunk_no, content, meta_json, _app = row
+                out.append(DocumentChunk(document_id=doc_id, chunk_number=chunk_no, content=content, embedding=[],
+                                         metadata=json.loads(meta_json) if meta_json else {}, score=float(s)))
+        return out
+
+    async def get_chunks_by_id(self, chunk_identifiers: List[Tuple[str, int]], app_id: Optional[str] = None,
+                               skip_image_content: bool = False) -> List[DocumentChunk]:
+        if not chunk_identifiers:
+            return []
+        out = []
+        with self._lock:
+            for doc_id, chunk_no in dict.fromkeys((d, int(c)) for d, c in chunk_identifiers):
+                page = self._page_of.get((doc_id, chunk_no))
+                if page is None:
+                    continue
+                _d, _c, content, meta_json, _app = self._rows[page]
+                out.append(DocumentChunk(document_id=doc_id, chunk_number=chunk_no, content=content, embedding=[],
+                                         metadata=json.loads(meta_json) if meta_json else {}, score=0.0))
+        return out
+
+    async def delete_chunks_by_document_id(self, document_id: str, app_id: Optional[str] = None) -> bool:
+        try:
+            with self._lock:
+                o = self._doc_ord.get(document_id)
+                if o is None:
+                    return True  # DELETE of nothing succeeds
+                ix = self._require_index()
+                ix.remove_doc(o)
+                for page in self._doc_pages.pop(document_id, []):
+                    row = self._rows.pop(page, None)
+                    if row is not None:
+                        self._page_of.pop((row[0], row[1]), None)
+                # the ordinal stays reserved (its pages are tombstoned in the slab)
+            logger.info(f"Deleted all chunks for document {document_id} from {self.backend_name} store")
+            return True
+        except Exception as e:  # noqa: BLE001
+            logger.error(f"Error deleting chunks for document {document_id}: {e}")
+            return False
+
+    # ------------------------------------------------------------------ introspection
+    def __len__(self) -> int:
+        return len(self._rows)
+
+
+class MI355XFastMultiVectorStore(MI355XMultiVectorStore):
+    """Drop-in for FastMultiVectorStore: FDE coarse stage + exact float rerank, per-app namespaces
+    (fast_multivector_store.py:504-607; `self.ns(app_id)` :526)."""
+
+    default_mode = "fde_then_float"
+    _filter_by_app = True
+
+
+def create_store(provider: str, **kw: Any) -> MI355XMultiVectorStore:
+    """Factory for core/services_init.py: [multivector_store] provider = "mi355x" | "mi355x_fast" | "mi355x_float"."""
+    if provider == "mi355x":
+        return MI355XMultiVectorStore(**kw)
+    if provider == "mi355x_fast":
+        return MI355XFastMultiVectorStore(**kw)
+    if provider == "mi355x_float":
+        return MI355XMultiVectorStore(mode="float", **kw)
+    raise ValueError(f"unknown MI355X multivector provider {provider!r}")

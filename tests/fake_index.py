@@ -1,0 +1,70 @@
+"""Oracle-backed stand-in for MvIndex, for CPU tests of the HOST logic only (store bookkeeping,
+sharded merge).  Test infrastructure: lives under tests/, never imported by the product."""
+import numpy as np
+
+from oracle import oracle as orc
+
+
+class OracleIndex:
+    def __init__(self, capacity_pages, stride_rows, device=0, id_base=0, mode="float", **_):
+        self.capacity, self.stride_rows, self.id_base, self.mode = capacity_pages, stride_rows, id_base, mode
+        self.pages, self.ords, self.alive = [], [], []
+
+    def __len__(self):
+        return len(self.pages)
+
+    def add(self, pages, doc_ordinals=None):
+        first = len(self.pages)
+        if first + len(pages) > self.capacity:
+            raise RuntimeError("slab full")
+        for i, p in enumerate(pages):
+            p = np.asarray(p)
+            f = orc.bf16_to_f32(p) if p.dtype == np.uint16 else np.asarray(p, np.float32).reshape(-1, 128)
+            self.pages.append(f)
+            self.ords.append(0 if doc_ordinals is None else int(doc_ordinals[i]))
+            self.alive.append(True)
+        return first
+
+    def remove_page(self, page):
+        self.alive[page] = False
+
+    def remove_doc(self, o):
+        n = 0
+        for i, x in enumerate(self.ords):
+            if x == o and self.alive[i]:
+                self.alive[i] = False
+                n += 1
+        return n
+
+    def _mask(self, allow):
+        m = np.array(self.alive, bool)
+        if allow is not None:
+            o = np.array(self.ords)
+            ok = (o < allow.size * 32) & (((allow[np.minimum(o >> 5, allow.size - 1)] >> (o & 31).astype(np.uint32)) & 1) == 1)
+            m &= ok
+        return m
+
+    def score_all(self, q, mode=None, allow=None):
+        mode = mode or self.mode
+        q = np.asarray(q)
+        qf = orc.bf16_to_f32(q) if q.dtype == np.uint16 else np.asarray(q, np.float32)
+        out = np.full(len(self.pages), -np.inf, np.float32)
+        m = self._mask(allow)
+        for i, p in enumerate(self.pages):
+            if not m[i]:
+                continue
+            if mode == "binary":
+                out[i] = orc.maxsim_binary(orc.sign_pack(p) if len(p) else np.zeros((0, 16), np.uint8), orc.sign_pack(qf))
+            else:
+                pb = orc.bf16_to_f32(orc.f32_to_bf16(p))
+                qb = orc.bf16_to_f32(orc.f32_to_bf16(qf))
+                out[i] = orc.maxsim_f32(qb, pb)
+        return out
+
+    def query(self, q, k, mode=None, allow=None, want_stats=False):
+        s = self.score_all(q, mode, allow)
+        sc, ids = orc.topk(s, k)
+        return sc, ids + self.id_base
+
+    def close(self):
+        pass

@@ -1,0 +1,97 @@
+"""N>1 path on CPU: world_size-2 (and 3) gloo process groups; each rank owns a row shard served by an
+oracle-backed index; the all-gather + merge must equal the single-index top-k including ties."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from morphik_core_amd import sharded
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _corpus(n, rows=8):
+    from oracle import oracle as orc
+
+    base = [orc.synth_rows(5, i, 0, rows) for i in range(12)]
+    # duplicates -> exact score ties across shards
+    return [base[i % 12] if i % 3 else orc.synth_rows(6, i, 0, rows) for i in range(n)]
+
+
+def _worker(rank, world, port, n_total, k, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    from tests.fake_index import OracleIndex
+
+    lo, hi = sharded.shard_range(n_total, rank, world)
+    pages = _corpus(n_total)[lo:hi]
+    ix = OracleIndex(capacity_pages=max(hi - lo, 1), stride_rows=8, id_base=lo)
+    ix.add(pages)
+
+    def local_topk(q, kk):
+        s, i = ix.query(q, kk)
+        ps = np.full(kk, -np.inf, np.float32)
+        pi = np.full(kk, -1, np.int64)
+        ps[: len(s)] = s
+        pi[: len(i)] = i
+        return torch.from_numpy(ps), torch.from_numpy(pi)
+
+    searcher = sharded.ShardedSearcher(local_topk)
+    q = orc.synth_rows(4321, 0, 0, 6)
+    s, i = searcher.query(q, k)
+    out_q.put((rank, s.numpy().tolist(), i.numpy().tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total,k", [(2, 41, 10), (3, 50, 7), (2, 3, 10)])
+def test_sharded_topk_equals_single_index(world, n_total, k):
+    from oracle import oracle as orc
+    from tests.fake_index import OracleIndex
+
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, k, out_q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out_q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    one = OracleIndex(capacity_pages=n_total, stride_rows=8)
+    one.add(_corpus(n_total))
+    ws, wi = one.query(orc.synth_rows(4321, 0, 0, 6), k)
+    for _rank, s, i in results:  # every rank holds the same merged answer
+        assert i == wi.tolist() and s == ws.tolist()
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 1000, 1_000_000):
+        for w in (1, 2, 3, 8):
+            spans = [sharded.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_merge_topk_tie_rule():
+    s = torch.tensor([[3.0, 2.0, float("-inf")], [3.0, 3.0, 1.0]])
+    i = torch.tensor([[4, 1, -1], [10, 12, 11]])
+    ms, mi = sharded.merge_topk(s, i, 4)
+    assert mi.tolist() == [4, 10, 12, 1] and ms.tolist() == [3.0, 3.0, 3.0, 2.0]
+    ms, mi = sharded.merge_topk(s, i, 10)
+    assert mi.tolist() == [4, 10, 12, 1, 11]

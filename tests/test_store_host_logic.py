@@ -1,0 +1,59 @@
+"""CPU tests of the store's HOST logic (ids, payloads, filters, metrics, async surface) with an
+oracle-backed index injected; the same scenarios run on the real GPU index in test_gpu_store.py."""
+import numpy as np
+import pytest
+
+from morphik_core_amd.store import MI355XFastMultiVectorStore, MI355XMultiVectorStore, create_store
+from tests import store_scenarios as sc
+from tests.fake_index import OracleIndex
+
+
+def _store(cls=MI355XMultiVectorStore, **kw):
+    s = cls(capacity_pages=64, stride_rows=32, index_factory=OracleIndex, **kw)
+    assert s.initialize() is True
+    return s
+
+
+@pytest.mark.parametrize("scenario", sc.ALL, ids=lambda f: f.__name__)
+@pytest.mark.parametrize("mode", ["binary", "float"])
+def test_reference_store_scenarios(scenario, mode):
+    sc.run(scenario(_store(mode=mode)))
+
+
+def test_known_ranking_binary_scores_exact():
+    sc.run(sc.scenario_known_ranking(_store(mode="binary"), exact_binary=True))
+    sc.run(sc.scenario_known_ranking(_store(mode="float"), exact_binary=False))
+
+
+def test_initialize_never_raises_and_is_loud_without_gpu():
+    s = MI355XMultiVectorStore(capacity_pages=4, stride_rows=16)  # real index: no GPU in the CPU container
+    import torch
+
+    if not torch.cuda.is_available():
+        assert s.initialize() is False  # returns False, never raises (multi_vector_store.py:325-327)
+        with pytest.raises(Exception):
+            sc.run(s.query_similar(np.ones((2, 128), np.float32), k=1))  # no CPU fallback: query raises
+
+
+def test_fast_store_filters_by_app_namespace():
+    s = _store(MI355XFastMultiVectorStore, mode="float")
+    rng = np.random.default_rng(0)
+    a = sc.make_chunks(rng, n_docs=1, chunks_per_doc=2)
+    b = [c.model_copy(update={"document_id": "other"}) for c in sc.make_chunks(rng, n_docs=1, chunks_per_doc=2)]
+    sc.run(s.store_embeddings(a, app_id="app-a"))
+    sc.run(s.store_embeddings(b, app_id="app-b"))
+    res = sc.run(s.query_similar(a[0].embedding, k=10, app_id="app-b"))
+    assert {r.document_id for r in res} == {"other"}
+    assert len(sc.run(s.query_similar(a[0].embedding, k=10))) == 4
+
+
+def test_too_many_vectors_is_an_error_and_factory():
+    s = _store(mode="float")
+    from morphik_core_amd.models import DocumentChunk
+
+    with pytest.raises(ValueError):
+        sc.run(s.store_embeddings([DocumentChunk(document_id="d", chunk_number=0, content="", embedding=np.ones((33, 128), np.float32))]))
+    assert isinstance(create_store("mi355x_fast", capacity_pages=4), MI355XFastMultiVectorStore)
+    assert create_store("mi355x_float", capacity_pages=4).mode == "float"
+    with pytest.raises(ValueError):
+        create_store("postgres")
