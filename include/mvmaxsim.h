@@ -39,14 +39,16 @@ typedef enum {
   MV_MODE_FLOAT = 0,          /* exact float MaxSim over every page (score_multi_vector semantics) */
   MV_MODE_BINARY = 1,         /* sign-bit MaxSim == SQL max_sim(bit[],bit[]) */
   MV_MODE_FDE_THEN_FLOAT = 2, /* FDE coarse top-n_coarse -> exact float rerank (FastMultiVectorStore) */
-  MV_MODE_FDE_ONLY = 3        /* coarse FDE scores only (the TurboPuffer ANN stage) */
+  MV_MODE_FDE_ONLY = 3,       /* coarse FDE scores only (the TurboPuffer ANN stage) */
+  MV_MODE_FLOAT_FP8 = 4       /* exact float MaxSim over the e4m3 slab (BASELINE configs[4]; 128 B / patch row) */
 } mv_mode;
 
 /* Index feature flags (mv_config.flags). */
 enum {
   MV_WITH_FLOAT = 1,  /* bf16 page slab (262 144 B / 1024-patch page) */
   MV_WITH_BINARY = 2, /* sign-bit slab   ( 16 384 B / page)            */
-  MV_WITH_FDE = 4     /* bf16 FDE slab   ( 20 480 B / page)            */
+  MV_WITH_FDE = 4,    /* bf16 FDE slab   ( 20 480 B / page)            */
+  MV_WITH_FP8 = 8     /* e4m3 page slab  (131 072 B / page) + one power-of-two scale per page */
 };
 
 /* fixed_dimensional_encoding.FixedDimensionalEncodingConfig as constructed at
@@ -89,8 +91,10 @@ typedef enum {
   MV_OPT_MAXSIM_VARIANT = 1, /* float kernel variant id; -1 = default */
   MV_OPT_FDE_COARSE_N = 2,   /* candidates kept by the FDE stage (reference: min(10*k, 75)) ; 0 = reference rule */
   MV_OPT_FDE_COSINE = 3,     /* 1 = rank coarse stage by cosine (TurboPuffer cosine_distance, reference), 0 = dot */
-  MV_OPT_PAD_SEMANTICS = 4   /* 0 = max over a page's own rows only; 1 = reference rerank batch rule
+  MV_OPT_PAD_SEMANTICS = 4,  /* 0 = max over a page's own rows only; 1 = reference rerank batch rule
                                 (pad_to = longest candidate of the batch of 128 => clamp at 0) */
+  MV_OPT_BINARY_VARIANT = 5, /* sign-bit scan: 0 = popcount on the VALU, 1 = FP4 MFMA (default); same integers */
+  MV_OPT_FDE_SCAN_VARIANT = 6 /* FDE coarse scan: 0 = query in registers, 1 = query in LDS (default) */
 } mv_option;
 
 MV_API const char* mv_last_error(void);
@@ -128,9 +132,15 @@ MV_API int mv_index_read_pages(mv_index* ix, int64_t page0, int64_t n_pages, voi
 /* Overwrite rows [row0,row0+n) of one page with host bf16 data (test/bench: planted neighbours).
  * Only the float slab is touched. */
 MV_API int mv_index_write_rows(mv_index* ix, int64_t page, int32_t row0, int32_t n, const void* bf16_rows);
+/* Overwrite one whole page from HOST bf16 rows (n_rows x 128) and refresh every enabled slab (bf16, sign bits,
+ * FDE, fp8).  The update path of a re-embedded page; also how bench/tests plant neighbours on any slab mix. */
+MV_API int mv_index_replace_page(mv_index* ix, int64_t page, const void* bf16_rows, int32_t n_rows);
+/* Read back e4m3 codes (stride_rows x 128 bytes per page) and the per-page 2^-e scales. */
+MV_API int mv_index_read_fp8(mv_index* ix, int64_t page0, int64_t n_pages, void* out_codes, float* out_inv_scale);
 /* Synthetic corpus: append n_pages pages of n_rows rows generated ON THE DEVICE by the
  * counter-based generator (key=seed, counter=(unit,row,chunk)); unit of page i = first_unit + i.
- * Bit-identical to oracle/mv_oracle.c:orc_synth_rows. doc ordinal of page i = (first_unit+i) / pages_per_doc. */
+ * Bit-identical to oracle/mv_oracle.c:orc_synth_rows. doc ordinal of page i = (first_unit+i) / pages_per_doc.
+ * Without MV_WITH_FLOAT the bf16 image is staged in chunks and only its derivatives (bits / FDE / fp8) are kept. */
 MV_API int mv_index_fill_synthetic(mv_index* ix, uint64_t seed, uint64_t first_unit, int64_t n_pages, int32_t n_rows,
                                    int32_t pages_per_doc);
 /* Host helper: the same generator for queries (n_rows x 128 bf16 to a host buffer, computed on the GPU). */

@@ -67,15 +67,15 @@ class QueryStatsC(C.Structure):
 
 
 MV_F32, MV_BF16 = 0, 1
-MV_MODE_FLOAT, MV_MODE_BINARY, MV_MODE_FDE_THEN_FLOAT, MV_MODE_FDE_ONLY = 0, 1, 2, 3
-MV_WITH_FLOAT, MV_WITH_BINARY, MV_WITH_FDE = 1, 2, 4
-MV_OPT_MAXSIM_VARIANT, MV_OPT_FDE_COARSE_N, MV_OPT_FDE_COSINE, MV_OPT_PAD_SEMANTICS = 1, 2, 3, 4
+MV_MODE_FLOAT, MV_MODE_BINARY, MV_MODE_FDE_THEN_FLOAT, MV_MODE_FDE_ONLY, MV_MODE_FLOAT_FP8 = 0, 1, 2, 3, 4
+MV_WITH_FLOAT, MV_WITH_BINARY, MV_WITH_FDE, MV_WITH_FP8 = 1, 2, 4, 8
+MV_OPT_MAXSIM_VARIANT, MV_OPT_FDE_COARSE_N, MV_OPT_FDE_COSINE, MV_OPT_PAD_SEMANTICS, MV_OPT_BINARY_VARIANT, MV_OPT_FDE_SCAN_VARIANT = 1, 2, 3, 4, 5, 6
 
 # every symbol include/mvmaxsim.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "mv_last_error", "mv_version", "mv_device_count", "mv_index_create", "mv_index_destroy", "mv_index_set_option",
     "mv_index_size", "mv_index_capacity", "mv_index_add", "mv_index_add_device", "mv_index_remove_doc",
-    "mv_index_remove_page", "mv_index_read_pages", "mv_index_write_rows", "mv_index_fill_synthetic", "mv_synth_rows",
+    "mv_index_remove_page", "mv_index_read_pages", "mv_index_write_rows", "mv_index_replace_page", "mv_index_read_fp8", "mv_index_fill_synthetic", "mv_synth_rows",
     "mv_query_topk", "mv_query_topk_device", "mv_score_all", "mv_score_candidates", "mv_sign_pack", "mv_hamming_batch",
     "mv_fde_output_dim", "mv_fde_encode", "mv_calibrate_read_bw", "mv_index_save", "mv_index_load",
 ]
@@ -112,6 +112,8 @@ def lib() -> C.CDLL:
         L.mv_index_remove_page.argtypes = [vp, i64]
         L.mv_index_read_pages.argtypes = [vp, i64, i64, vp]
         L.mv_index_write_rows.argtypes = [vp, i64, i32, i32, vp]
+        L.mv_index_replace_page.argtypes = [vp, i64, vp, i32]
+        L.mv_index_read_fp8.argtypes = [vp, i64, i64, vp, vp]
         L.mv_index_fill_synthetic.argtypes = [vp, u64, u64, i64, i32, i32]
         L.mv_synth_rows.argtypes = [C.c_int, u64, u64, i32, vp]
         L.mv_query_topk.argtypes = [vp, vp, C.c_int, i32, i32, C.c_int, vp, i64, vp, vp, C.POINTER(i32), C.POINTER(QueryStatsC)]

@@ -73,6 +73,8 @@ struct mv_index {
   uint8_t* bits = nullptr;
   uint16_t* fde = nullptr;
   float* fde_inv_norm = nullptr;
+  uint8_t* slab8 = nullptr;      // e4m3 page slab [capacity][stride][128]
+  float* inv_scale8 = nullptr;   // [capacity] 2^-e per page
   int32_t* d_n_rows = nullptr;
   int32_t* d_doc_ord = nullptr;
   std::vector<int32_t> h_n_rows, h_doc_ord;
@@ -88,6 +90,10 @@ struct mv_index {
   uint16_t* d_q = nullptr;     // bf16 query, padded
   float* d_qf32 = nullptr;     // fp32 query rows (FDE encode input)
   uint8_t* d_qbits = nullptr;
+  float* d_qpop = nullptr;     // popc per query row (binary MFMA scan)
+  uint8_t* d_q8hi = nullptr;   // e4m3 query rows, two-term split (fp8 scan)
+  uint8_t* d_q8lo = nullptr;
+  float* d_q8fac = nullptr;    // 2^-s per query row
   float* d_qfde = nullptr;
   int64_t* d_qoff = nullptr;   // [2] row offsets for the query "page"
   uint32_t* d_allow = nullptr;
@@ -101,6 +107,8 @@ struct mv_index {
   std::mutex mu;
   // options
   int maxsim_variant = -1;
+  int binary_variant = -1;
+  int fde_scan_variant = -1;
   int64_t fde_coarse_n = 0;
   int fde_cosine = 1;
   int pad_semantics = -1;  // -1: mode default (reference batch rule for FDE_THEN_FLOAT / candidates, none for full scan)
@@ -128,16 +136,26 @@ int ensure_query_cap(mv_index* ix, int n_rows) {
   if (ix->d_q) (void)hipFree(ix->d_q);
   if (ix->d_qf32) (void)hipFree(ix->d_qf32);
   if (ix->d_qbits) (void)hipFree(ix->d_qbits);
-  ix->d_q = nullptr; ix->d_qf32 = nullptr; ix->d_qbits = nullptr;
+  if (ix->d_qpop) (void)hipFree(ix->d_qpop);
+  if (ix->d_q8hi) (void)hipFree(ix->d_q8hi);
+  if (ix->d_q8lo) (void)hipFree(ix->d_q8lo);
+  if (ix->d_q8fac) (void)hipFree(ix->d_q8fac);
+  ix->d_q = nullptr; ix->d_qf32 = nullptr; ix->d_qbits = nullptr; ix->d_qpop = nullptr;
+  ix->d_q8hi = nullptr; ix->d_q8lo = nullptr; ix->d_q8fac = nullptr;
   MV_HIP(hipMalloc(&ix->d_q, (size_t)cap * kDim * 2));
   MV_HIP(hipMalloc(&ix->d_qf32, (size_t)cap * kDim * 4));
   MV_HIP(hipMalloc(&ix->d_qbits, (size_t)cap * kSignBytes));
+  MV_HIP(hipMalloc(&ix->d_qpop, (size_t)cap * 4));
+  MV_HIP(hipMalloc(&ix->d_q8hi, (size_t)cap * kDim));
+  MV_HIP(hipMalloc(&ix->d_q8lo, (size_t)cap * kDim));
+  MV_HIP(hipMalloc(&ix->d_q8fac, (size_t)cap * 4));
   ix->q_rows_cap = cap;
   return MV_OK;
 }
 
 // Upload the query in every representation the mode needs.  Returns padded row count.
-int upload_query(mv_index* ix, const void* q, int q_dtype, int n_q, bool want_bf16, bool want_f32, bool want_bits) {
+int upload_query(mv_index* ix, const void* q, int q_dtype, int n_q, bool want_bf16, bool want_f32, bool want_bits,
+                 bool want_fp8 = false) {
   int rc = ensure_query_cap(ix, n_q);
   if (rc) return rc;
   const int padded = ((n_q + 15) / 16) * 16;
@@ -155,10 +173,14 @@ int upload_query(mv_index* ix, const void* q, int q_dtype, int n_q, bool want_bf
     MV_HIP(hipMemcpyAsync(ix->d_q, b.data(), b.size() * 2, hipMemcpyHostToDevice, ix->stream));
     MV_HIP(hipStreamSynchronize(ix->stream));  // b goes out of scope
   }
-  if (want_f32 || want_bits) {
+  if (want_f32 || want_bits || want_fp8) {
     MV_HIP(hipMemcpyAsync(ix->d_qf32, f.data(), f.size() * 4, hipMemcpyHostToDevice, ix->stream));
     if (want_bits) {
       rc = launch_sign_pack_f32(ix->d_qf32, n_q, kDim, ix->d_qbits, ix->stream);
+      if (rc) return rc;
+    }
+    if (want_fp8) {
+      rc = launch_fp8_query_prep(ix->d_qf32, n_q, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->stream);
       if (rc) return rc;
     }
     MV_HIP(hipStreamSynchronize(ix->stream));
@@ -243,20 +265,41 @@ int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_w
   return MV_OK;
 }
 
+// Exact float MaxSim over the e4m3 slab (all query rows in passes of 64 inside the launcher).
+int fp8_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_words, const int32_t* d_cand, int64_t n_items,
+             int32_t pad_to, float* d_out, int* launches) {
+  const bool need_meta = ix->tombstones || d_allow != nullptr;
+  Fp8ScanArgs a{};
+  a.slab = ix->slab8; a.inv_scale = ix->inv_scale8;
+  a.n_rows = ix->ragged ? ix->d_n_rows : nullptr;
+  a.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
+  a.allow = d_allow; a.n_allow_bits = n_allow_words * 32; a.cand = d_cand;
+  a.qhi = ix->d_q8hi; a.qlo = ix->d_q8lo; a.qfac = ix->d_q8fac; a.n_q = n_q;
+  a.scores = d_out; a.n = n_items; a.stride = ix->cfg.stride_rows; a.pad_to = pad_to;
+  int rc = launch_maxsim_fp8(a, ix->stream);
+  if (rc) return rc;
+  *launches += (((n_q + 15) / 16) * 16 + 63) / 64;
+  return MV_OK;
+}
+
 // Core of every query entry point: leaves per-item scores on the device.
 int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const uint32_t* allow_bits, int64_t n_words,
              int64_t want_coarse, ScanResult* out, mv_query_stats* st) {
   if (!q || n_q <= 0) { set_error("query must have at least one row"); return MV_ERR_INVALID; }
   if (q_dtype != MV_F32 && q_dtype != MV_BF16) { set_error("bad query dtype %d", q_dtype); return MV_ERR_INVALID; }
-  const bool want_float = mode == MV_MODE_FLOAT || mode == MV_MODE_FDE_THEN_FLOAT;
   const bool want_fde = mode == MV_MODE_FDE_THEN_FLOAT || mode == MV_MODE_FDE_ONLY;
   const bool want_bin = mode == MV_MODE_BINARY;
-  if (!want_float && !want_fde && !want_bin) { set_error("unknown mode %d", mode); return MV_ERR_INVALID; }
+  // the rerank stage of FDE_THEN_FLOAT uses the bf16 slab when the index has one, else the fp8 slab
+  const bool rerank_fp8 = mode == MV_MODE_FDE_THEN_FLOAT && !(ix->cfg.flags & MV_WITH_FLOAT) && (ix->cfg.flags & MV_WITH_FP8);
+  const bool want_fp8 = mode == MV_MODE_FLOAT_FP8 || rerank_fp8;
+  const bool want_float = mode == MV_MODE_FLOAT || (mode == MV_MODE_FDE_THEN_FLOAT && !rerank_fp8);
+  if (!want_float && !want_fde && !want_bin && !want_fp8) { set_error("unknown mode %d", mode); return MV_ERR_INVALID; }
   if (want_float && !(ix->cfg.flags & MV_WITH_FLOAT)) { set_error("index has no float slab (MV_WITH_FLOAT)"); return MV_ERR_STATE; }
+  if (want_fp8 && !(ix->cfg.flags & MV_WITH_FP8)) { set_error("index has no fp8 slab (MV_WITH_FP8)"); return MV_ERR_STATE; }
   if (want_bin && !(ix->cfg.flags & MV_WITH_BINARY)) { set_error("index has no sign-bit slab (MV_WITH_BINARY)"); return MV_ERR_STATE; }
   if (want_fde && !(ix->cfg.flags & MV_WITH_FDE)) { set_error("index has no FDE slab (MV_WITH_FDE)"); return MV_ERR_STATE; }
 
-  int rc = upload_query(ix, q, q_dtype, n_q, want_float, want_fde, want_bin);
+  int rc = upload_query(ix, q, q_dtype, n_q, want_float, want_fde, want_bin, want_fp8);
   if (rc) return rc;
   const uint32_t* d_allow = nullptr;
   rc = upload_allow(ix, allow_bits, n_words, &d_allow);
@@ -274,12 +317,17 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
     if (rc) return rc;
     out->d_scores = ix->d_scores; out->n = n; out->d_ids_map = nullptr;
     out->pages = pages; out->bytes = rows * (int64_t)kRowBytes;
+  } else if (mode == MV_MODE_FLOAT_FP8) {
+    rc = fp8_scan(ix, n_q, d_allow, n_words, nullptr, n, 0, ix->d_scores, &out->launches);
+    if (rc) return rc;
+    out->d_scores = ix->d_scores; out->n = n; out->d_ids_map = nullptr;
+    out->pages = pages; out->bytes = rows * (int64_t)kDim;
   } else if (mode == MV_MODE_BINARY) {
     BinaryArgs b{};
     b.bits = ix->bits; b.n_rows = ix->ragged ? ix->d_n_rows : nullptr; b.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
-    b.allow = d_allow; b.n_allow_bits = n_words * 32; b.qbits = ix->d_qbits; b.scores = ix->d_scores; b.n = n;
+    b.allow = d_allow; b.n_allow_bits = n_words * 32; b.qbits = ix->d_qbits; b.qpop_rw = ix->d_qpop; b.qpop = ix->d_qpop; b.scores = ix->d_scores; b.n = n;
     b.stride = ix->cfg.stride_rows; b.n_q = n_q;
-    rc = launch_maxsim_binary(b, ix->stream);
+    rc = launch_maxsim_binary(b, ix->binary_variant, ix->stream);
     if (rc) return rc;
     out->launches = 1;
     out->d_scores = ix->d_scores; out->n = n; out->d_ids_map = nullptr;
@@ -296,7 +344,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
     s.fde = ix->fde; s.inv_norm = ix->fde_cosine ? ix->fde_inv_norm : nullptr; s.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
     s.allow = d_allow; s.n_allow_bits = n_words * 32; s.q = ix->d_qfde; s.scores = ix->d_scores; s.n = n;
     s.out_dim = ix->fde_t.out_dim;
-    rc = launch_fde_scan(s, ix->stream);
+    rc = launch_fde_scan(s, ix->fde_scan_variant, ix->stream);
     if (rc) return rc;
     out->launches = 2;
     out->pages = pages; out->bytes = pages * ix->fde_t.out_dim * 2;
@@ -327,11 +375,12 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
         MV_HIP(hipMemcpyAsync(ix->d_cand, cand.data(), cand.size() * 4, hipMemcpyHostToDevice, ix->stream));
         // reference rule: pad_sequence over the rerank batch (<=128 pages): shorter pages see zero rows
         const int pad_sem = ix->pad_semantics < 0 ? 1 : ix->pad_semantics;
-        rc = float_scan(ix, n_q, nullptr, 0, ix->d_cand, out->n, pad_sem ? longest : 0, ix->d_cand_scores, &out->launches);
+        rc = rerank_fp8 ? fp8_scan(ix, n_q, nullptr, 0, ix->d_cand, out->n, pad_sem ? longest : 0, ix->d_cand_scores, &out->launches)
+                        : float_scan(ix, n_q, nullptr, 0, ix->d_cand, out->n, pad_sem ? longest : 0, ix->d_cand_scores, &out->launches);
         if (rc) return rc;
         MV_HIP(hipStreamSynchronize(ix->stream));  // cand goes out of scope
       }
-      out->bytes += cand_rows * (int64_t)kRowBytes;
+      out->bytes += cand_rows * (int64_t)(rerank_fp8 ? kDim : kRowBytes);
     }
   }
   MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
@@ -443,6 +492,15 @@ int add_pages_common(mv_index* ix, const void* d_src, int dtype, const int32_t* 
       (void)hipStreamSynchronize(ix->stream);
       if (d_nr) (void)hipFree(d_nr);
     }
+    if (!rc && (ix->cfg.flags & MV_WITH_FP8)) {
+      int32_t* d_nr8 = nullptr;
+      if (hipMalloc(&d_nr8, (size_t)n_pages * 4) != hipSuccess) { rc = MV_ERR_NOMEM; set_error("out of device memory"); }
+      if (!rc) (void)hipMemcpyAsync(d_nr8, n_rows, (size_t)n_pages * 4, hipMemcpyHostToDevice, ix->stream);
+      if (!rc) rc = launch_quantize_pages_fp8(slab_dst, d_nr8, stride, n_pages, ix->slab8 + (size_t)first * stride * kDim,
+                                              ix->inv_scale8 + first, ix->stream);
+      (void)hipStreamSynchronize(ix->stream);
+      if (d_nr8) (void)hipFree(d_nr8);
+    }
     (void)hipStreamSynchronize(ix->stream);
     if (tmp_slab) (void)hipFree(tmp_slab);
   } while (0);
@@ -500,8 +558,8 @@ void mv_index_destroy(mv_index* ix) {
   if (!ix) return;
   DeviceGuard g(ix->cfg.device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-  void* ptrs[] = {ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
-                  ix->d_topk_ws, ix->d_q, ix->d_qf32, ix->d_qbits, ix->d_qfde, ix->d_qoff, ix->d_allow, ix->d_out_s,
+  void* ptrs[] = {ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
+                  ix->d_topk_ws, ix->d_q, ix->d_qf32, ix->d_qbits, ix->d_qpop, ix->d_qfde, ix->d_qoff, ix->d_allow, ix->d_out_s,
                   ix->d_out_id, ix->d_cand, ix->d_cand_scores};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -518,7 +576,7 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   if (cfg->dim != kDim) { set_error("dim must be 128 (got %d)", cfg->dim); return MV_ERR_INVALID; }
   if (cfg->stride_rows < 16 || cfg->stride_rows % 16) { set_error("stride_rows must be a positive multiple of 16 (got %d)", cfg->stride_rows); return MV_ERR_INVALID; }
   if (cfg->capacity_pages < 1 || cfg->capacity_pages > 0x7fffffffLL) { set_error("capacity_pages out of range"); return MV_ERR_INVALID; }
-  if (!(cfg->flags & (MV_WITH_FLOAT | MV_WITH_BINARY | MV_WITH_FDE))) { set_error("flags select no slab"); return MV_ERR_INVALID; }
+  if (!(cfg->flags & (MV_WITH_FLOAT | MV_WITH_BINARY | MV_WITH_FDE | MV_WITH_FP8))) { set_error("flags select no slab"); return MV_ERR_INVALID; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device available (libmvmaxsim requires an MI355X / gfx950 GPU)"); return MV_ERR_HIP; }
   if (cfg->device < 0 || cfg->device >= ndev) { set_error("device %d out of range (have %d)", cfg->device, ndev); return MV_ERR_INVALID; }
@@ -542,7 +600,11 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   for (auto& e : ix->ev)
     if (!rc && hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); rc = MV_ERR_HIP; }
   if (cfg->flags & MV_WITH_FLOAT) alloc((void**)&ix->slab, rows * kRowBytes, "bf16 page slab");
-  if (cfg->flags & MV_WITH_BINARY) alloc((void**)&ix->bits, rows * kSignBytes, "sign-bit slab");
+  if (cfg->flags & MV_WITH_FP8) {
+    alloc((void**)&ix->slab8, rows * kDim + 4096, "fp8 page slab");  // +4 KiB: the scan DMAs whole 4 KiB pieces
+    alloc((void**)&ix->inv_scale8, (size_t)cap * 4, "fp8 page scales");
+  }
+  if (cfg->flags & MV_WITH_BINARY) alloc((void**)&ix->bits, rows * kSignBytes + 4096, "sign-bit slab");  // +4 KiB: the scan DMAs whole 1 KiB pieces
   if (!rc && (cfg->flags & MV_WITH_FDE)) {
     rc = fde_tables_create(cfg->fde, &ix->fde_t);
     alloc((void**)&ix->fde, (size_t)cap * ix->fde_t.out_dim * 2, "FDE slab");
@@ -585,6 +647,8 @@ int mv_index_set_option(mv_index* ix, int option, int64_t value) {
       ix->fde_coarse_n = value; return MV_OK;
     case MV_OPT_FDE_COSINE: ix->fde_cosine = value ? 1 : 0; return MV_OK;
     case MV_OPT_PAD_SEMANTICS: ix->pad_semantics = (int)value; return MV_OK;
+    case MV_OPT_BINARY_VARIANT: ix->binary_variant = (int)value; return MV_OK;
+    case MV_OPT_FDE_SCAN_VARIANT: ix->fde_scan_variant = (int)value; return MV_OK;
     default: set_error("unknown option %d", option); return MV_ERR_INVALID;
   }
 }
@@ -683,23 +747,44 @@ int mv_index_write_rows(mv_index* ix, int64_t page, int32_t row0, int32_t n, con
   return MV_OK;
 }
 
+// Derive every enabled non-float slab of pages [first, first+n) from their fixed-stride bf16 image `src`
+// (the float slab itself, or a staging buffer).  d_nr = device row counts of those pages.
+static int derive_slabs_from_bf16(mv_index* ix, const uint16_t* src, int64_t first, int64_t n, const int32_t* d_nr) {
+  const int32_t stride = ix->cfg.stride_rows;
+  int rc = MV_OK;
+  if (ix->cfg.flags & MV_WITH_BINARY) {
+    rc = launch_sign_pack_bf16_rows(src, n * (int64_t)stride, ix->bits + (size_t)first * stride * kSignBytes, ix->stream);
+    if (rc) return rc;
+  }
+  if (ix->cfg.flags & MV_WITH_FP8) {
+    rc = launch_quantize_pages_fp8(src, d_nr, stride, n, ix->slab8 + (size_t)first * stride * kDim, ix->inv_scale8 + first,
+                                   ix->stream);
+    if (rc) return rc;
+  }
+  if (ix->cfg.flags & MV_WITH_FDE) {
+    int64_t done = 0;
+    while (done < n && !rc) {  // grid.x limit: chunk launches
+      const int64_t c = std::min<int64_t>(n - done, 1 << 20);
+      FdeEncodeArgs e{};
+      e.x_bf16 = src + (size_t)done * stride * kDim; e.n_rows = d_nr + done; e.stride = stride; e.n_pages = c; e.is_query = 0;
+      e.out_bf16 = ix->fde + (size_t)(first + done) * ix->fde_t.out_dim;
+      e.out_inv_norm = ix->fde_inv_norm + first + done;
+      rc = launch_fde_encode(ix->fde_t, e, ix->stream);
+      done += c;
+    }
+  }
+  return rc;
+}
+
 int mv_index_fill_synthetic(mv_index* ix, uint64_t seed, uint64_t first_unit, int64_t n_pages, int32_t n_rows,
                             int32_t pages_per_doc) {
   if (!ix || n_pages < 0 || n_rows < 0 || n_rows > ix->cfg.stride_rows) { set_error("fill_synthetic: bad argument"); return MV_ERR_INVALID; }
-  if (!(ix->cfg.flags & MV_WITH_FLOAT)) { set_error("fill_synthetic needs MV_WITH_FLOAT"); return MV_ERR_STATE; }
   if (ix->size + n_pages > ix->cfg.capacity_pages) { set_error("slab full"); return MV_ERR_CAPACITY; }
   if (pages_per_doc < 1) pages_per_doc = 1;
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->cfg.device);
   const int64_t first = ix->size;
   const int32_t stride = ix->cfg.stride_rows;
-  uint16_t* dst = ix->slab + (size_t)first * stride * kDim;
-  int rc = launch_synth_rows(dst, seed, first_unit, n_pages, n_rows, stride, ix->stream);
-  if (rc) return rc;
-  if (ix->cfg.flags & MV_WITH_BINARY) {
-    rc = launch_sign_pack_bf16_rows(dst, n_pages * (int64_t)stride, ix->bits + (size_t)first * stride * kSignBytes, ix->stream);
-    if (rc) return rc;
-  }
   for (int64_t i = 0; i < n_pages; ++i) {
     ix->h_n_rows[first + i] = n_rows;
     ix->h_doc_ord[first + i] = (int32_t)((first_unit + (uint64_t)i) / (uint64_t)pages_per_doc);
@@ -707,25 +792,64 @@ int mv_index_fill_synthetic(mv_index* ix, uint64_t seed, uint64_t first_unit, in
   if (n_rows != stride) ix->ragged = true;
   MV_HIP(hipMemcpyAsync(ix->d_n_rows + first, ix->h_n_rows.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice, ix->stream));
   MV_HIP(hipMemcpyAsync(ix->d_doc_ord + first, ix->h_doc_ord.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice, ix->stream));
-  if (ix->cfg.flags & MV_WITH_FDE) {
-    FdeEncodeArgs e{};
-    e.x_bf16 = dst; e.n_rows = ix->d_n_rows + first; e.stride = stride; e.n_pages = n_pages; e.is_query = 0;
-    e.out_bf16 = ix->fde + (size_t)first * ix->fde_t.out_dim;
-    e.out_inv_norm = ix->fde_inv_norm + first;
-    // grid.x limit: chunk launches
-    int64_t done = 0;
-    while (done < n_pages && !rc) {
-      const int64_t c = std::min<int64_t>(n_pages - done, 1 << 20);
-      FdeEncodeArgs ec = e;
-      ec.x_bf16 = dst + (size_t)done * stride * kDim; ec.n_rows = e.n_rows + done; ec.n_pages = c;
-      ec.out_bf16 = e.out_bf16 + (size_t)done * ix->fde_t.out_dim; ec.out_inv_norm = e.out_inv_norm + done;
-      rc = launch_fde_encode(ix->fde_t, ec, ix->stream);
-      done += c;
-    }
-    if (rc) return rc;
+  const bool has_float = (ix->cfg.flags & MV_WITH_FLOAT) != 0;
+  // without a float slab the bf16 image is staged chunk by chunk (<= 512 MiB) and only its derivatives are kept
+  const int64_t chunk = has_float ? n_pages : std::max<int64_t>(1, ((int64_t)512 << 20) / ((int64_t)stride * kRowBytes));
+  uint16_t* stage = nullptr;
+  if (!has_float && n_pages > 0) MV_HIP(hipMalloc(&stage, (size_t)std::min(chunk, n_pages) * stride * kRowBytes));
+  int rc = MV_OK;
+  for (int64_t done = 0; done < n_pages && !rc; done += chunk) {
+    const int64_t c = std::min(chunk, n_pages - done);
+    uint16_t* dst = has_float ? ix->slab + (size_t)(first + done) * stride * kDim : stage;
+    rc = launch_synth_rows(dst, seed, first_unit + (uint64_t)done, c, n_rows, stride, ix->stream);
+    if (!rc) rc = derive_slabs_from_bf16(ix, dst, first + done, c, ix->d_n_rows + first + done);
+    if (!has_float && hipStreamSynchronize(ix->stream) != hipSuccess && !rc) { set_error("fill_synthetic: stream error"); rc = MV_ERR_HIP; }
   }
-  MV_HIP(hipStreamSynchronize(ix->stream));
+  hipError_t e = hipStreamSynchronize(ix->stream);
+  if (stage) (void)hipFree(stage);
+  if (rc) return rc;
+  if (e != hipSuccess) return hip_fail(e, "fill_synthetic", __FILE__, __LINE__);
   ix->size += n_pages;
+  return MV_OK;
+}
+
+// Overwrite one whole page from host bf16 rows and refresh every slab (bench/test: planted neighbours on any
+// combination of slabs; also the update path of a re-embedded page).
+int mv_index_replace_page(mv_index* ix, int64_t page, const void* bf16_rows, int32_t n_rows) {
+  if (!ix || !bf16_rows || page < 0 || page >= ix->size || n_rows < 0 || n_rows > ix->cfg.stride_rows) { set_error("replace_page: bad argument"); return MV_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->cfg.device);
+  const int32_t stride = ix->cfg.stride_rows;
+  const bool has_float = (ix->cfg.flags & MV_WITH_FLOAT) != 0;
+  uint16_t* dst = has_float ? ix->slab + (size_t)page * stride * kDim : nullptr;
+  uint16_t* stage = nullptr;
+  if (!has_float) { MV_HIP(hipMalloc(&stage, (size_t)stride * kRowBytes)); dst = stage; }
+  int rc = MV_OK;
+  hipError_t e = hipMemsetAsync(dst, 0, (size_t)stride * kRowBytes, ix->stream);
+  if (e == hipSuccess && n_rows > 0) e = hipMemcpyAsync(dst, bf16_rows, (size_t)n_rows * kRowBytes, hipMemcpyHostToDevice, ix->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);  // the host buffer may be pageable
+  if (e != hipSuccess) rc = hip_fail(e, "replace_page upload", __FILE__, __LINE__);
+  if (!rc) {
+    ix->h_n_rows[page] = n_rows;
+    if (n_rows != stride) ix->ragged = true;
+    e = hipMemcpyAsync(ix->d_n_rows + page, &ix->h_n_rows[page], 4, hipMemcpyHostToDevice, ix->stream);
+    if (e != hipSuccess) rc = hip_fail(e, "replace_page metadata", __FILE__, __LINE__);
+  }
+  if (!rc) rc = derive_slabs_from_bf16(ix, dst, page, 1, ix->d_n_rows + page);
+  (void)hipStreamSynchronize(ix->stream);
+  if (stage) (void)hipFree(stage);
+  return rc;
+}
+
+// Read back the e4m3 codes (stride_rows x 128 bytes per page) and 2^-e scales of pages [page0, page0+n).
+int mv_index_read_fp8(mv_index* ix, int64_t page0, int64_t n_pages, void* out_codes, float* out_inv_scale) {
+  if (!ix || !out_codes || !out_inv_scale || page0 < 0 || n_pages < 0 || page0 + n_pages > ix->size) { set_error("read_fp8: range"); return MV_ERR_INVALID; }
+  if (!(ix->cfg.flags & MV_WITH_FP8)) { set_error("index has no fp8 slab"); return MV_ERR_STATE; }
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->cfg.device);
+  const size_t pb = (size_t)ix->cfg.stride_rows * kDim;
+  MV_HIP(hipMemcpy(out_codes, ix->slab8 + (size_t)page0 * pb, (size_t)n_pages * pb, hipMemcpyDeviceToHost));
+  MV_HIP(hipMemcpy(out_inv_scale, ix->inv_scale8 + page0, (size_t)n_pages * 4, hipMemcpyDeviceToHost));
   return MV_OK;
 }
 
@@ -860,7 +984,8 @@ int mv_score_all(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int
 int mv_score_candidates(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const int32_t* cand, int32_t n_cand,
                         int32_t pad_to, float* out_scores, mv_query_stats* stats) {
   if (!ix || !q || !cand || !out_scores || n_cand < 0 || n_cand > kMaxCand || n_q_rows < 1) { set_error("score_candidates: bad argument"); return MV_ERR_INVALID; }
-  if (!(ix->cfg.flags & MV_WITH_FLOAT)) { set_error("index has no float slab"); return MV_ERR_STATE; }
+  const bool use_fp8 = !(ix->cfg.flags & MV_WITH_FLOAT);
+  if (use_fp8 && !(ix->cfg.flags & MV_WITH_FP8)) { set_error("index has neither a float nor an fp8 slab"); return MV_ERR_STATE; }
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->cfg.device);
   if (stats) memset(stats, 0, sizeof(*stats));
@@ -870,7 +995,7 @@ int mv_score_candidates(mv_index* ix, const void* q, int q_dtype, int32_t n_q_ro
     if (cand[i] < 0 || cand[i] >= ix->size) { set_error("candidate %d out of range", cand[i]); return MV_ERR_INVALID; }
     rows += ix->h_n_rows[cand[i]];
   }
-  int rc = upload_query(ix, q, q_dtype, n_q_rows, true, false, false);
+  int rc = upload_query(ix, q, q_dtype, n_q_rows, !use_fp8, false, false, use_fp8);
   if (rc) return rc;
   MV_HIP(hipMemcpyAsync(ix->d_cand, cand, (size_t)n_cand * 4, hipMemcpyHostToDevice, ix->stream));
   MV_HIP(hipEventRecord(ix->ev[0], ix->stream));
@@ -878,7 +1003,8 @@ int mv_score_candidates(mv_index* ix, const void* q, int q_dtype, int32_t n_q_ro
   // tombstones are NOT applied here: the caller named the pages explicitly
   const bool keep = ix->tombstones;
   ix->tombstones = false;
-  rc = float_scan(ix, n_q_rows, nullptr, 0, ix->d_cand, n_cand, pad_to, ix->d_cand_scores, &launches);
+  rc = use_fp8 ? fp8_scan(ix, n_q_rows, nullptr, 0, ix->d_cand, n_cand, pad_to, ix->d_cand_scores, &launches)
+               : float_scan(ix, n_q_rows, nullptr, 0, ix->d_cand, n_cand, pad_to, ix->d_cand_scores, &launches);
   ix->tombstones = keep;
   if (rc) return rc;
   MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
@@ -887,7 +1013,7 @@ int mv_score_candidates(mv_index* ix, const void* q, int q_dtype, int32_t n_q_ro
   if (stats) {
     stats->score_launches = launches;
     stats->pages_scored = n_cand;
-    stats->bytes_scanned = rows * (int64_t)kRowBytes;
+    stats->bytes_scanned = rows * (int64_t)(use_fp8 ? kDim : kRowBytes);
   }
   return finish_stats(ix, stats, false);
 }
@@ -1009,7 +1135,7 @@ int mv_index_save(mv_index* ix, const char* path) {
   FILE* f = fopen(path, "wb");
   if (!f) { set_error("cannot open %s for writing", path); return MV_ERR_IO; }
   SaveHeader h{};
-  memcpy(h.magic, "MVIDX001", 8);
+  memcpy(h.magic, "MVIDX002", 8);
   h.cfg = ix->cfg;
   h.size = ix->size;
   h.fde_out_dim = ix->fde_t.out_dim;
@@ -1035,6 +1161,10 @@ int mv_index_save(mv_index* ix, const char* path) {
     dump(ix->fde, (size_t)ix->size * ix->fde_t.out_dim * 2);
     dump(ix->fde_inv_norm, (size_t)ix->size * 4);
   }
+  if (ix->cfg.flags & MV_WITH_FP8) {
+    dump(ix->slab8, rows * kDim);
+    dump(ix->inv_scale8, (size_t)ix->size * 4);
+  }
   if (fclose(f) != 0 && !rc) { set_error("close failed for %s", path); rc = MV_ERR_IO; }
   return rc;
 }
@@ -1045,7 +1175,7 @@ int mv_index_load(const char* path, int32_t device, mv_index** out) {
   FILE* f = fopen(path, "rb");
   if (!f) { set_error("cannot open %s", path); return MV_ERR_IO; }
   SaveHeader h{};
-  if (fread(&h, 1, sizeof(h), f) != sizeof(h) || memcmp(h.magic, "MVIDX001", 8) != 0) { fclose(f); set_error("%s is not an mv index file", path); return MV_ERR_IO; }
+  if (fread(&h, 1, sizeof(h), f) != sizeof(h) || memcmp(h.magic, "MVIDX002", 8) != 0) { fclose(f); set_error("%s is not an mv index file", path); return MV_ERR_IO; }
   h.cfg.device = device;
   mv_index* ix = nullptr;
   int rc = mv_index_create(&h.cfg, &ix);
@@ -1070,6 +1200,10 @@ int mv_index_load(const char* path, int32_t device, mv_index** out) {
   if (h.cfg.flags & MV_WITH_FDE) {
     fill(ix->fde, (size_t)h.size * ix->fde_t.out_dim * 2);
     fill(ix->fde_inv_norm, (size_t)h.size * 4);
+  }
+  if (h.cfg.flags & MV_WITH_FP8) {
+    fill(ix->slab8, rows * kDim);
+    fill(ix->inv_scale8, (size_t)h.size * 4);
   }
   fclose(f);
   if (!rc) {

@@ -70,6 +70,7 @@ struct BArgs {
   int64_t n;
   int32_t stride;
   int32_t n_q;
+  const float* qpop;  // [n_q padded to 16] popc of each query row as float, -1 for padding rows (MFMA variant)
 };
 
 __device__ __forceinline__ bool masked(const BArgs& a, int64_t page) {
@@ -129,6 +130,192 @@ __global__ __launch_bounds__(256) void maxsim_binary_kernel(BArgs a) {
   if (lane == 0) a.scores[page] = (float)a.n_q - (float)total * (1.0f / 128.0f);
 }
 
+// ------------------------------------------------------------------------------ binary MaxSim on the matrix cores
+// The same integer result as the popcount kernel above, computed by v_mfma_scale_f32_16x16x128_f8f6f4 with
+// FP4 (e2m1) operands -- the whole K=128 bit row in ONE MFMA per 16 query rows x 16 patch rows:
+//   A (query bits q)  : nibble = q ? +1.0 (0x2) : -1.0 (0xA)
+//   B (page bits d)   : nibble = d ?  0.5 (0x1) :  0.0 (0x0)          block scales = 2^0
+//   D[q][d] = sum_k A.B = popc(q & d) - popc(d) / 2        (multiples of 0.5, |D| <= 64: exact in fp32)
+//   hamming(q, d) = popc(q) + popc(d) - 2 popc(q & d) = popc(q) - 2 D[q][d]
+//   min_d hamming = popc(q) - 2 max_d D[q][d]
+// so the row-max over patches is the same elementwise-max-then-butterfly as the float kernel.
+// K-slot mapping (any bijection works as long as A and B agree): lane (r = l&15, g = l>>4) holds, for row r,
+// nibble n of operand dword i = bit (4n + g) of the row's little-endian dword i  =>  B_i = (w_i >> g) & 0x11111111:
+// 4 shifts + 4 ands expand a 16-byte row; the MFMA pipe (2 x ~22 cycles per tile at Q=32) and the VALU
+// (~16 ops per tile) stay below the HBM time of a 256-byte tile.
+// Data movement: one wave per page; 1 KiB (64 rows) per global_load_lds_dwordx4 into a wave-private ring,
+// ds_read_b128 with 4-lane broadcast (rows r = 0..15 hit 64 distinct banks).  16 KiB per 1024-patch page.
+using i32x8 = __attribute__((ext_vector_type(8))) int;
+using f32x4b = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kBinSlotRows = 64;                       // rows per DMA instruction
+constexpr int kBinSlotBytes = kBinSlotRows * kSignBytes;  // 1 KiB
+
+template <int N>
+__device__ __forceinline__ void bin_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// max over the 16 lanes of a DPP row (lanes with equal l>>4), result in every lane: rotate-by-8/4/2/1 within
+// the row (v_max_f32_dpp row_ror) -- no LDS traffic, unlike __shfl_xor (ds_bpermute).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float bin_group16_max(float v) {
+  v = fmaxf(v, dpp_mov<0x128>(v));  // row_ror:8
+  v = fmaxf(v, dpp_mov<0x124>(v));  // row_ror:4
+  v = fmaxf(v, dpp_mov<0x122>(v));  // row_ror:2
+  v = fmaxf(v, dpp_mov<0x121>(v));  // row_ror:1
+  return v;
+}
+
+struct BMArgs {
+  BArgs b;
+  int32_t accumulate;  // add to scores[] (second and later query passes)
+};
+
+template <int MT, int D>
+__global__ __launch_bounds__(256) void maxsim_binary_mfma_kernel(BMArgs args) {
+  const BArgs& a = args.b;
+  __shared__ __attribute__((aligned(16))) char lds[4 * D * kBinSlotBytes];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t page = (int64_t)blockIdx.x * 4 + wave;
+  if (page >= a.n) return;
+  if (masked(a, page)) {
+    if (lane == 0) a.scores[page] = -INFINITY;
+    return;
+  }
+  const int nr = a.n_rows ? a.n_rows[page] : a.stride;
+  if (nr <= 0 || a.n_q <= 0) {
+    if (lane == 0 && !args.accumulate) a.scores[page] = 0.0f;  // COALESCE(SUM over nothing, 0.0)
+    return;
+  }
+  const int ntiles = (nr + 15) >> 4;
+  const int nslots = (nr + kBinSlotRows - 1) / kBinSlotRows;
+  const char* pbase = reinterpret_cast<const char*>(a.bits) + (size_t)page * (size_t)a.stride * kSignBytes;
+  char* ring = lds + wave * (D * kBinSlotBytes);
+  const int src_off = lane * 16;
+
+  auto issue = [&](int it) {
+    const char* tp = pbase + (size_t)it * kBinSlotBytes;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
+    const uint64_t tpu = ((uint64_t)hi << 32) | lo;
+    const uint32_t slot = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + (it % D) * kBinSlotBytes));
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src_off), "s"(slot), "s"(tpu)
+        : "memory");
+  };
+
+#pragma unroll
+  for (int i = 0; i < D - 1; ++i)
+    if (i < nslots) issue(i);
+
+  // query operand (loop invariant) and popc(q) of the rows this lane finishes; loaded after the prologue
+  // DMAs and pinned so the compiler's own vmcnt waits are all in front of the loop.
+  i32x8 qa[MT];
+  float qpop[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const uint4 qv = a.q[m * 16 + r];  // qbits is zero padded to a multiple of 16 rows
+    const float4 pc = *reinterpret_cast<const float4*>(a.qpop + m * 16 + g * 4);  // popc(q row), -1 = padding row
+    const uint32_t w[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qa[m][i] = (int)(0xAAAAAAAAu - (((w[i] >> g) & 0x11111111u) << 3));
+#pragma unroll
+    for (int i = 4; i < 8; ++i) qa[m][i] = 0;
+    qpop[m][0] = pc.x; qpop[m][1] = pc.y; qpop[m][2] = pc.z; qpop[m][3] = pc.w;
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      asm volatile("" : "+v"(qa[m][i]));
+      asm volatile("" : "+v"(qpop[m][i]));
+    }
+  }
+
+  f32x4b mx[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) mx[m] = f32x4b{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+
+  for (int it = 0; it < nslots; ++it) {
+    if (it + D - 1 < nslots) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // WAR: last reads of the slot being refilled
+      issue(it + D - 1);
+      bin_wait_vmcnt<D - 1>();
+    } else {
+      const int left = nslots - 1 - it;  // slots still allowed in flight
+      if (left >= 4) bin_wait_vmcnt<4>();
+      else if (left == 3) bin_wait_vmcnt<3>();
+      else if (left == 2) bin_wait_vmcnt<2>();
+      else if (left == 1) bin_wait_vmcnt<1>();
+      else bin_wait_vmcnt<0>();
+    }
+    const char* slot = ring + (it % D) * kBinSlotBytes;
+    auto tile = [&](const uint4& wv, bool col_valid) {
+      i32x8 b;
+      b[0] = (int)((wv.x >> g) & 0x11111111u);
+      b[1] = (int)((wv.y >> g) & 0x11111111u);
+      b[2] = (int)((wv.z >> g) & 0x11111111u);
+      b[3] = (int)((wv.w >> g) & 0x11111111u);
+      b[4] = 0; b[5] = 0; b[6] = 0; b[7] = 0;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        f32x4b acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(qa[m], b, acc, 4 /* A fp4 */, 4 /* B fp4 */, 0, 0x7f7f7f7f, 0,
+                                                               0x7f7f7f7f);
+        if (!col_valid) acc = f32x4b{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mx[m][i] = fmaxf(mx[m][i], acc[i]);
+      }
+    };
+    if ((it + 1) * kBinSlotRows <= nr) {  // whole slot valid (wave-uniform): 4 reads in flight, no column masks
+      uint4 wv[4];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) wv[tt] = *reinterpret_cast<const uint4*>(slot + (tt * 16 + r) * kSignBytes);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) tile(wv[tt], true);
+    } else {
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int t = it * 4 + tt;
+        if (t < ntiles) {  // wave-uniform
+          const uint4 wv = *reinterpret_cast<const uint4*>(slot + (tt * 16 + r) * kSignBytes);
+          tile(wv, t * 16 + r < nr);
+        }
+      }
+    }
+  }
+
+  // min_d hamming of query row (16m + 4g + i) = popc(q) - 2 max_d D; integers <= 128, exact in fp32
+  float ham = 0.f;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = bin_group16_max(mx[m][i]);
+      if (qpop[m][i] >= 0.f) ham += qpop[m][i] - 2.0f * v;
+    }
+  ham += __shfl_xor(ham, 16);
+  ham += __shfl_xor(ham, 32);
+  if (lane == 0) {
+    const float part = (float)a.n_q - ham * (1.0f / 128.0f);
+    a.scores[page] = args.accumulate ? a.scores[page] + part : part;
+  }
+}
+
 __global__ void hamming_batch_kernel(const uint8_t* q, const uint8_t* c, int64_t n, int32_t nb, int32_t* out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -168,12 +355,56 @@ int launch_sign_pack_bf16_rows(const uint16_t* d_rows, int64_t n_rows, uint8_t* 
   return MV_OK;
 }
 
-int launch_maxsim_binary(const BinaryArgs& a, hipStream_t s) {
+// popc(q row) as float for rows < n_q, -1 for the padding rows up to `padded`; also zero-fills the padding bit rows
+__global__ void binary_qprep_kernel(uint4* qbits, int n_q, int padded, float* qpop) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= padded) return;
+  if (i < n_q) {
+    const uint4 v = qbits[i];
+    qpop[i] = (float)(__popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w));
+  } else {
+    qbits[i] = make_uint4(0u, 0u, 0u, 0u);
+    qpop[i] = -1.0f;
+  }
+}
+
+template <int MT>
+static void launch_binary_mfma(const BArgs& k, int accumulate, hipStream_t s) {
+  BMArgs m{k, accumulate};
+  hipLaunchKernelGGL((maxsim_binary_mfma_kernel<MT, 6>), dim3((unsigned)((k.n + 3) / 4)), dim3(256), 0, s, m);
+}
+
+int launch_maxsim_binary(const BinaryArgs& a, int variant, hipStream_t s) {
   if (a.n <= 0) return MV_OK;
   BArgs k{reinterpret_cast<const uint4*>(a.bits), a.n_rows, a.doc_ord, a.allow, a.n_allow_bits,
-          reinterpret_cast<const uint4*>(a.qbits), a.scores, a.n, a.stride, a.n_q};
+          reinterpret_cast<const uint4*>(a.qbits), a.scores, a.n, a.stride, a.n_q, a.qpop};
   if (a.n > ((int64_t)1 << 25)) { set_error("binary scan: more than 2^25 pages per launch is not supported"); return MV_ERR_INVALID; }
-  hipLaunchKernelGGL(maxsim_binary_kernel, dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, s, k);
+  if (variant < 0) variant = 1;
+  if (variant == 0 || a.n_q <= 0) {
+    hipLaunchKernelGGL(maxsim_binary_kernel, dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, s, k);
+  } else if (variant == 1) {
+    if (!a.qpop) { set_error("binary MFMA scan needs the qpop workspace"); return MV_ERR_INVALID; }
+    const int padded = ((a.n_q + 15) / 16) * 16;
+    hipLaunchKernelGGL(binary_qprep_kernel, dim3((unsigned)((padded + 63) / 64)), dim3(64), 0, s,
+                       reinterpret_cast<uint4*>(const_cast<uint8_t*>(a.qbits)), a.n_q, padded, a.qpop_rw);
+    // query rows in passes of <= 64 (4 MFMA row tiles); later passes accumulate into scores[]
+    for (int q0 = 0, pass = 0; q0 < a.n_q; q0 += 64, ++pass) {
+      BArgs kp = k;
+      kp.q = k.q + q0;
+      kp.qpop = k.qpop + q0;
+      kp.n_q = std::min(64, a.n_q - q0);
+      const int mt = (kp.n_q + 15) / 16;
+      switch (mt) {
+        case 1: launch_binary_mfma<1>(kp, pass > 0, s); break;
+        case 2: launch_binary_mfma<2>(kp, pass > 0, s); break;
+        case 3: launch_binary_mfma<3>(kp, pass > 0, s); break;
+        default: launch_binary_mfma<4>(kp, pass > 0, s); break;
+      }
+    }
+  } else {
+    set_error("unknown binary variant %d", variant);
+    return MV_ERR_INVALID;
+  }
   MV_HIP(hipGetLastError());
   return MV_OK;
 }

@@ -66,13 +66,16 @@ struct BinaryArgs {
   const int32_t* doc_ord;
   const uint32_t* allow;
   int64_t n_allow_bits;
-  const uint8_t* qbits;    // [n_q][16]
+  const uint8_t* qbits;    // [n_q][16]; MFMA variant: buffer padded to a multiple of 16 rows (zero-filled by the launch)
+  float* qpop_rw;          // [n_q padded to 16] workspace: popc per query row (MFMA variant)
+  const float* qpop;       // same buffer, read side
   float* scores;           // Q - sum_q min_d hamming / 128, exact in fp32; -inf masked
   int64_t n;
   int32_t stride;
   int32_t n_q;
 };
-int launch_maxsim_binary(const BinaryArgs& a, hipStream_t s);
+// variant: 0 = popcount (VALU), 1 = FP4 MFMA (default, -1)
+int launch_maxsim_binary(const BinaryArgs& a, int variant, hipStream_t s);
 int launch_hamming_batch(const uint8_t* d_q, const uint8_t* d_c, int64_t n, int32_t n_bytes, int32_t* d_out,
                          hipStream_t s);
 
@@ -114,7 +117,33 @@ struct FdeScanArgs {
   int64_t n;
   int64_t out_dim;
 };
-int launch_fde_scan(const FdeScanArgs& a, hipStream_t s);
+// variant: 0 = query in registers (persistent waves), 1 = query in LDS (default, -1)
+int launch_fde_scan(const FdeScanArgs& a, int variant, hipStream_t s);
+
+// ---------------------------------------------------------------- fp8 path (mv_fp8.hip)
+// quantise fixed-stride bf16 pages -> e4m3 codes + one power-of-two scale per page (inv_scale = 2^-e)
+int launch_quantize_pages_fp8(const uint16_t* d_src_pages, const int32_t* d_n_rows, int32_t stride, int64_t n_pages,
+                              uint8_t* d_dst, float* d_inv_scale, hipStream_t s);
+// fp32 query rows -> two-term e4m3 split (hi, lo*16) + 2^-s per row; buffers padded to a multiple of 16 rows
+int launch_fp8_query_prep(const float* d_q_f32, int n_q, uint8_t* d_hi, uint8_t* d_lo, float* d_fac, hipStream_t s);
+struct Fp8ScanArgs {
+  const uint8_t* slab;      // [pages][stride][128] e4m3fn
+  const float* inv_scale;   // [pages]
+  const int32_t* n_rows;
+  const int32_t* doc_ord;
+  const uint32_t* allow;
+  int64_t n_allow_bits;
+  const int32_t* cand;
+  const uint8_t* qhi;
+  const uint8_t* qlo;
+  const float* qfac;
+  int32_t n_q;
+  float* scores;
+  int64_t n;
+  int32_t stride;
+  int32_t pad_to;
+};
+int launch_maxsim_fp8(const Fp8ScanArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- misc device helpers
 int launch_f32_to_bf16(const float* d_in, uint16_t* d_out, int64_t n, hipStream_t s);

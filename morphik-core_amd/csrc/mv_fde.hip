@@ -242,6 +242,60 @@ __global__ __launch_bounds__(256) void fde_scan_kernel(ScanArgs a) {
   }
 }
 
+// v2 coarse scan: the query FDE lives in LDS (40 KiB at 10 240 dims), not in 160 VGPRs per lane, so a wave
+// needs only the registers of one page's loads (ITERS x 16 B per lane, all issued before the first use) and
+// 16 waves fit a CU: 16 x 20 KiB = 320 KiB of HBM reads in flight per CU.  A 512-thread block stages the
+// query once and then streams `pages_per_block` pages, one page per wave at a time.
+// LDS image of the query: chunk (it, half) of lane l at ((it*2 + half)*64 + l)*16 B -> the two ds_read_b128
+// per load are 16-byte strided across lanes (conflict-free).
+template <int ITERS>
+__global__ __launch_bounds__(512) void fde_scan_lds_kernel(ScanArgs a, int pages_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float qs[];
+  for (int i = threadIdx.x; i < ITERS * 128; i += 512) {  // float4 index in the source order
+    const int it = i >> 7, rem = i & 127, l = rem >> 1, half = rem & 1;
+    const float4 v = *reinterpret_cast<const float4*>(a.q + (size_t)i * 4);
+    *reinterpret_cast<float4*>(qs + ((size_t)((it * 2 + half) * 64 + l)) * 4) = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t page0 = (int64_t)blockIdx.x * pages_per_block;
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+  for (int j = wave; j < pages_per_block; j += 8) {
+    const int64_t p = page0 + j;
+    if (p >= a.n) break;
+    bool m = false;
+    if (a.doc_ord) {
+      const int32_t o = a.doc_ord[p];
+      m = o < 0 || (a.allow && ((int64_t)o >= a.n_allow_bits || ((a.allow[o >> 5] >> (o & 31)) & 1u) == 0u));
+    }
+    if (m) {
+      if (lane == 0) a.scores[p] = -INFINITY;
+      continue;
+    }
+    const u32x4* row = reinterpret_cast<const u32x4*>(a.fde + p * (int64_t)a.out_dim) + lane;
+    u32x4 v[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) v[it] = row[it * 64];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const float4 qlo = *reinterpret_cast<const float4*>(qs + ((it * 2 + 0) * 64 + lane) * 4);
+      const float4 qhi = *reinterpret_cast<const float4*>(qs + ((it * 2 + 1) * 64 + lane) * 4);
+      const float qq[8] = {qlo.x, qlo.y, qlo.z, qlo.w, qhi.x, qhi.y, qhi.z, qhi.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc[k] = __builtin_fmaf(__uint_as_float(v[it][k] << 16), qq[2 * k], acc[k]);
+        acc[k] = __builtin_fmaf(__uint_as_float(v[it][k] & 0xffff0000u), qq[2 * k + 1], acc[k]);
+      }
+    }
+    float t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) t += __shfl_xor(t, sft);
+    if (lane == 0) a.scores[p] = a.inv_norm ? t * a.inv_norm[p] : t;
+  }
+}
+
 // generic fallback for out_dim not a multiple of 512 or too large for registers
 __global__ __launch_bounds__(256) void fde_scan_generic_kernel(ScanArgs a) {
   const int lane = threadIdx.x & 63;
@@ -375,11 +429,28 @@ int launch_fde_encode(const FdeTables& t, const FdeEncodeArgs& a, hipStream_t s)
   return MV_OK;
 }
 
-int launch_fde_scan(const FdeScanArgs& a, hipStream_t s) {
+template <int ITERS>
+static int launch_fde_scan_lds(const ScanArgs& k, hipStream_t s) {
+  const int ppb = 64;  // pages per block: the 40 KiB query staging is amortised over 1.3 MB of page reads
+  const size_t lds = (size_t)ITERS * 512 * 4;
+  MV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fde_scan_lds_kernel<ITERS>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((fde_scan_lds_kernel<ITERS>), dim3((unsigned)((k.n + ppb - 1) / ppb)), dim3(512), lds, s, k, ppb);
+  return MV_OK;
+}
+
+int launch_fde_scan(const FdeScanArgs& a, int variant, hipStream_t s) {
   if (a.n <= 0) return MV_OK;
   ScanArgs k{a.fde, a.inv_norm, a.doc_ord, a.allow, a.n_allow_bits, a.q, a.scores, a.n, (int32_t)a.out_dim};
   const int grid = 256 * 2;  // 2 blocks/CU x 4 waves, persistent
-  if (a.out_dim == 10240) {
+  if (variant < 0) variant = 1;
+  if (a.out_dim == 10240 && variant == 1) {
+    int rc = launch_fde_scan_lds<20>(k, s);
+    if (rc) return rc;
+  } else if (a.out_dim == 5120 && variant == 1) {
+    int rc = launch_fde_scan_lds<10>(k, s);
+    if (rc) return rc;
+  } else if (a.out_dim == 10240) {
     hipLaunchKernelGGL((fde_scan_kernel<20>), dim3(grid), dim3(256), 0, s, k);
   } else if (a.out_dim == 5120) {
     hipLaunchKernelGGL((fde_scan_kernel<10>), dim3(grid), dim3(256), 0, s, k);

@@ -1,0 +1,436 @@
+// mv_fp8.hip -- float MaxSim over an FP8 (OCP e4m3fn) page slab on the CDNA4 block-scaled matrix cores.
+//
+// BASELINE.json configs[4]: "fp8 (e4m3) patch embeddings on CDNA4 fp8 MFMA ... recall@10 vs bf16 reference".
+// Same scoring rule as mv_maxsim.hip (score_multi_vector, core/vector_store/fast_multivector_store.py:553-555)
+// on a slab that costs 128 B per patch row instead of 256 B: the scan is HBM-bound, so halving the bytes
+// doubles pages/s.  The reference has no fp8 path; the checker is oracle/mv_oracle.c:orc_maxsim_fp8 (same
+// quantised operands, fp32/fp64 arithmetic) and, for quality, recall@10 against the bf16 scores.
+//
+// Quantisation (bit-exact with the oracle: pure integer / exact power-of-two arithmetic):
+//   page   : one power-of-two scale 2^e per page, e = floor(log2(448 / amax(page)));  code = e4m3_rne(x * 2^e)
+//   query  : per row a power-of-two scale 2^s (amax -> [224, 448]) and a TWO-TERM split
+//              hi = e4m3_rne(x 2^s),  lo = e4m3_rne((x 2^s - hi) * 16)          (|residual| <= ulp/2 <= 16)
+//            so the query side carries ~8 significant bits (bf16 class); the MFMA pair
+//              acc  = Ahi . B            (block scale 2^0)
+//              acc += Alo . B * 2^-4     (E8M0 block scale 123 on the A operand)
+//            costs two of the ~18% utilised MFMA slots per tile.
+//   score  = 2^-e_page * sum_rows 2^-s_row * max_patch acc[row][patch]          (positive scales commute with max)
+//
+// MFMA: v_mfma_scale_f32_16x16x128_f8f6f4 (cbsz = blgp = 0: e4m3 x e4m3), K = 128 in one instruction:
+// lane (r = l&15, g = l>>4) holds row r's bytes [16g, 16g+16) and [64+16g, 64+16g+16) -- any K-slot bijection is
+// valid as long as A and B agree, and this one makes the LDS reads conflict-free (below).
+//
+// Data movement (as mv_maxsim.hip variant 3): four waves per page, each wave owns every 4th 4 KiB piece (32 rows)
+// and moves it with four global_load_lds_dwordx4 (8 whole rows = 1 KiB contiguous per instruction) into a
+// wave-private 4-slot LDS ring; counted vmcnt, no barrier in the loop.  LDS image: 16-byte chunk c of row w at
+// chunk position c ^ (w & 7) of that row (swizzle applied to the per-lane global source address); the
+// ds_read_b128 fragment reads (chunk g+4h of rows r) then hit 16 distinct 16-byte columns per 16-lane group.
+#include <algorithm>
+
+#include "mv_common.h"
+
+namespace mv {
+namespace {
+
+using i32x8 = __attribute__((ext_vector_type(8))) int;
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kF8RowBytes = kDim;                    // 128
+constexpr int kF8SlotRows = 32;                      // rows per ring slot (2 MFMA tiles)
+constexpr int kF8SlotBytes = kF8SlotRows * kF8RowBytes;  // 4 KiB
+
+// ---------------------------------------------------------------- e4m3fn codec (mirrors oracle/mv_oracle.c)
+__host__ __device__ __forceinline__ uint32_t f32_bits(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __float_as_uint(f);
+#else
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return u;
+#endif
+}
+__host__ __device__ __forceinline__ float bits_f32(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __uint_as_float(u);
+#else
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+#endif
+}
+
+// v finite, |v| arbitrary: round to nearest even e4m3fn, saturating at +-448.
+__device__ __forceinline__ uint32_t e4m3_encode(float v) {
+  const uint32_t u = __float_as_uint(v);
+  const uint32_t sign = (u >> 24) & 0x80u;
+  const uint32_t a = u & 0x7fffffffu;
+  if (a > 0x7f800000u) return sign | 0x7fu;  // NaN
+  if (a >= 0x43e80000u) return sign | 0x7eu;  // |v| >= 464 rounds past 448 -> saturate (also inf)
+  int e = (int)(a >> 23) - 127;
+  if (e < -6) e = -6;
+  const float q = rintf(__uint_as_float(a) * __uint_as_float((uint32_t)(127 + 3 - e) << 23));  // exact scaling, RNE
+  int qi = (int)q;
+  if (qi == 16) { qi = 8; e += 1; }
+  uint32_t code = (e == -6 && qi < 8) ? (uint32_t)qi : (uint32_t)(((e + 7) << 3) | (qi - 8));
+  if (code > 0x7eu) code = 0x7eu;
+  return sign | code;
+}
+__device__ __forceinline__ float e4m3_decode(uint32_t c) {
+  const uint32_t E = (c >> 3) & 15u, M = c & 7u;
+  const float mag = E == 0 ? (float)M * 0.001953125f /* 2^-9 */ : (float)(8u + M) * __uint_as_float((E + 127u - 10u) << 23);
+  return (c & 0x80u) ? -mag : mag;
+}
+// floor(log2(448 / amax)) for amax > 0 given as fp32 bits; 0 for amax == 0.  Clamped to +-100.
+__device__ __forceinline__ int pow2_scale_exp(uint32_t amax_bits) {
+  if ((amax_bits & 0x7fffffffu) == 0u) return 0;
+  const int ea = (int)((amax_bits >> 23) & 0xffu) - 127;
+  const uint32_t mant = amax_bits & 0x7fffffu;
+  int e = 8 - ea - (mant > 0x600000u ? 1 : 0);  // 448 = 1.75 * 2^8
+  if (e > 100) e = 100;
+  if (e < -100) e = -100;
+  return e;
+}
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((uint32_t)(127 + e) << 23); }
+
+// ---------------------------------------------------------------- page quantisation (ingest side)
+// One block per page.  src = fixed-stride bf16 slab pages; rows >= n_rows become zero codes.
+__global__ __launch_bounds__(256) void quantize_pages_kernel(const uint16_t* src, const int32_t* n_rows, int32_t stride,
+                                                             uint8_t* dst, float* inv_scale) {
+  __shared__ uint32_t red[4];
+  const int64_t page = blockIdx.x;
+  const int nr = n_rows ? n_rows[page] : stride;
+  const uint16_t* sp = src + (size_t)page * stride * kDim;
+  uint8_t* dp = dst + (size_t)page * stride * kDim;
+  const int n8 = nr * (kDim / 8);  // 16-byte chunks of valid data
+  uint32_t amax = 0;
+  for (int i = threadIdx.x; i < n8; i += 256) {
+    const uint4 v = reinterpret_cast<const uint4*>(sp)[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t lo = w[k] & 0x7fffu, hi = (w[k] >> 16) & 0x7fffu;
+      // finite magnitudes order like integers; NaN/inf rows are not expected in embeddings (clamped below)
+      amax = max(amax, max(lo, hi));
+    }
+  }
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, s));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  amax = max(max(red[0], red[1]), max(red[2], red[3]));
+  if (amax > 0x7f7fu) amax = 0x7f7fu;  // inf/NaN guard: largest finite bf16
+  const int e = pow2_scale_exp(amax << 16);
+  const float sc = pow2f(e);
+  if (threadIdx.x == 0) inv_scale[page] = pow2f(-e);
+  const int tot8 = stride * (kDim / 8);
+  for (int i = threadIdx.x; i < tot8; i += 256) {
+    uint2 out = make_uint2(0u, 0u);
+    if (i < n8) {
+      const uint4 v = reinterpret_cast<const uint4*>(sp)[i];
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      uint32_t c[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        c[2 * k] = e4m3_encode(__uint_as_float(w[k] << 16) * sc);
+        c[2 * k + 1] = e4m3_encode(__uint_as_float(w[k] & 0xffff0000u) * sc);
+      }
+      out.x = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+      out.y = c[4] | (c[5] << 8) | (c[6] << 16) | (c[7] << 24);
+    }
+    reinterpret_cast<uint2*>(dp)[i] = out;
+  }
+}
+
+// ---------------------------------------------------------------- query preparation
+// q: [n_q][128] fp32.  Writes hi/lo e4m3 rows (zero for the padding rows up to `padded`) and 2^-s per row (0 = padding).
+__global__ __launch_bounds__(64) void fp8_query_prep_kernel(const float* q, int n_q, int padded, uint8_t* hi, uint8_t* lo,
+                                                            float* row_factor) {
+  const int row = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (row >= padded) return;
+  if (row >= n_q) {
+    reinterpret_cast<uint16_t*>(hi + (size_t)row * kDim)[lane] = 0;
+    reinterpret_cast<uint16_t*>(lo + (size_t)row * kDim)[lane] = 0;
+    if (lane == 0) row_factor[row] = 0.0f;
+    return;
+  }
+  const float x0 = q[(size_t)row * kDim + 2 * lane], x1 = q[(size_t)row * kDim + 2 * lane + 1];
+  uint32_t amax = max(__float_as_uint(x0) & 0x7fffffffu, __float_as_uint(x1) & 0x7fffffffu);
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, s));
+  if (amax > 0x7f7fffffu) amax = 0x7f7fffffu;
+  const int e = pow2_scale_exp(amax);
+  const float sc = pow2f(e);
+  uint32_t ch[2], cl[2];
+  const float xs[2] = {x0 * sc, x1 * sc};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    ch[k] = e4m3_encode(xs[k]);
+    const float res = xs[k] - e4m3_decode(ch[k]);  // exact: both are multiples of the hi ulp's sub-grid within fp32
+    cl[k] = e4m3_encode(res * 16.0f);
+  }
+  reinterpret_cast<uint16_t*>(hi + (size_t)row * kDim)[lane] = (uint16_t)(ch[0] | (ch[1] << 8));
+  reinterpret_cast<uint16_t*>(lo + (size_t)row * kDim)[lane] = (uint16_t)(cl[0] | (cl[1] << 8));
+  if (lane == 0) row_factor[row] = pow2f(-e);
+}
+
+// ---------------------------------------------------------------- the scan
+struct F8Args {
+  const uint8_t* slab;      // [pages][stride][128] e4m3
+  const float* inv_scale;   // [pages]
+  const int32_t* n_rows;
+  const int32_t* doc_ord;
+  const uint32_t* allow;
+  int64_t n_allow_bits;
+  const int32_t* cand;
+  const uint8_t* qhi;       // [padded][128]
+  const uint8_t* qlo;
+  const float* qfac;        // [padded] 2^-s_row, 0 for padding rows
+  float* scores;
+  int64_t n;
+  int32_t stride;
+  int32_t pad_to;
+  int64_t page0;
+  int32_t accumulate;
+};
+
+__device__ __forceinline__ bool f8_masked(const F8Args& a, int64_t page) {
+  if (!a.doc_ord) return false;
+  const int32_t o = a.doc_ord[page];
+  if (o < 0) return true;
+  if (!a.allow) return false;
+  if ((int64_t)o >= a.n_allow_bits) return true;
+  return ((a.allow[o >> 5] >> (o & 31)) & 1u) == 0u;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float f8_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float f8_group16_max(float v) {
+  v = fmaxf(v, f8_dpp<0x128>(v));
+  v = fmaxf(v, f8_dpp<0x124>(v));
+  v = fmaxf(v, f8_dpp<0x122>(v));
+  v = fmaxf(v, f8_dpp<0x121>(v));
+  return v;
+}
+
+template <int N>
+__device__ __forceinline__ void f8_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int MT, int D>
+__global__ __launch_bounds__(256) void maxsim_fp8_kernel(F8Args a) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * D * kF8SlotBytes + 1024];
+  float* red = reinterpret_cast<float*>(lds + 4 * D * kF8SlotBytes);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t item = blockIdx.x;
+  if (item >= a.n) return;
+  const int64_t page = a.cand ? (int64_t)a.cand[item] : a.page0 + item;
+  if (f8_masked(a, page)) {
+    if (threadIdx.x == 0) a.scores[item] = -INFINITY;
+    return;
+  }
+  const int nr = a.n_rows ? a.n_rows[page] : a.stride;
+  const int ntiles = (nr + 15) >> 4;
+  const int nslots = (nr + kF8SlotRows - 1) / kF8SlotRows;
+  const bool clamp = a.pad_to > nr;
+  const int nsw = (nslots - wave + 3) / 4;  // slots owned by this wave (may be <= 0)
+  const char* pbase = reinterpret_cast<const char*>(a.slab) + (size_t)page * (size_t)a.stride * kF8RowBytes;
+  char* ring = lds + wave * (D * kF8SlotBytes);
+
+  // DMA source offsets: instruction i covers rows 8i..8i+7 of the slot; lane -> LDS row 8i + (lane>>3), chunk
+  // position lane&7, which must receive logical chunk (lane&7) ^ (row&7).
+  int src_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int w = i * 8 + (lane >> 3);
+    src_off[i] = w * kF8RowBytes + ((((lane & 7) ^ (w & 7))) << 4) - i * 1024;
+  }
+  // fragment read offsets within a 16-row tile: logical chunk g + 4h of row r
+  int rd_off[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) rd_off[h] = r * kF8RowBytes + (((g + 4 * h) ^ (r & 7)) << 4);
+
+  auto issue = [&](int it) {
+    const char* tp = pbase + (size_t)(wave + it * 4) * kF8SlotBytes;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
+    const uint64_t tpu = ((uint64_t)hi << 32) | lo;
+    const uint32_t slot = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + (it % D) * kF8SlotBytes));
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %6\n\t"
+        "global_load_lds_dwordx4 %2, %6 offset:1024\n\t"
+        "global_load_lds_dwordx4 %3, %6 offset:2048\n\t"
+        "global_load_lds_dwordx4 %4, %6 offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src_off[0]), "v"(src_off[1]), "v"(src_off[2]), "v"(src_off[3]), "s"(slot), "s"(tpu)
+        : "memory");
+  };
+
+#pragma unroll
+  for (int i = 0; i < D - 1; ++i)
+    if (i < nsw) issue(i);
+
+  // query operands (loop invariant), loaded after the prologue DMAs and pinned (see mv_maxsim.hip)
+  i32x8 ah[MT], al[MT];
+  float fac[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const size_t ro = (size_t)(m * 16 + r) * kF8RowBytes;
+    const i32x4 h0 = *reinterpret_cast<const i32x4*>(a.qhi + ro + g * 16);
+    const i32x4 h1 = *reinterpret_cast<const i32x4*>(a.qhi + ro + 64 + g * 16);
+    const i32x4 l0 = *reinterpret_cast<const i32x4*>(a.qlo + ro + g * 16);
+    const i32x4 l1 = *reinterpret_cast<const i32x4*>(a.qlo + ro + 64 + g * 16);
+    const float4 f = *reinterpret_cast<const float4*>(a.qfac + m * 16 + g * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[m][i] = h0[i]; ah[m][4 + i] = h1[i];
+      al[m][i] = l0[i]; al[m][4 + i] = l1[i];
+    }
+    fac[m][0] = f.x; fac[m][1] = f.y; fac[m][2] = f.z; fac[m][3] = f.w;
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      asm volatile("" : "+v"(ah[m][i]));
+      asm volatile("" : "+v"(al[m][i]));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(fac[m][i]));
+  }
+
+  f32x4 mx[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) mx[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+
+  for (int it = 0; it < nsw; ++it) {
+    if (it + D - 1 < nsw) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // WAR: last reads of the slot being refilled
+      issue(it + D - 1);
+      f8_wait_vmcnt<4 * (D - 1)>();
+    } else {
+      const int left = nsw - 1 - it;
+      if (left >= 2) f8_wait_vmcnt<8>();
+      else if (left == 1) f8_wait_vmcnt<4>();
+      else f8_wait_vmcnt<0>();
+    }
+    const char* slot = ring + (it % D) * kF8SlotBytes;
+    const int t0 = (wave + it * 4) * 2;  // first 16-row tile of this slot
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int t = t0 + tt;
+      if (t < ntiles) {  // wave-uniform
+        const i32x4 b0 = *reinterpret_cast<const i32x4*>(slot + tt * 2048 + rd_off[0]);
+        const i32x4 b1 = *reinterpret_cast<const i32x4*>(slot + tt * 2048 + rd_off[1]);
+        i32x8 b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { b[i] = b0[i]; b[4 + i] = b1[i]; }
+        const bool col_valid = t * 16 + r < nr;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ah[m], b, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(al[m], b, acc, 0, 0, 0, 0x7b7b7b7b /* 2^-4 */, 0, 0x7f7f7f7f);
+          if (!col_valid) acc = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) mx[m][i] = fmaxf(mx[m][i], acc[i]);
+        }
+      }
+    }
+  }
+
+  // cross-wave max, then per-row factors, sum, page scale
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = f8_group16_max(mx[m][i]);
+      if (r == 0) red[wave * 64 + m * 16 + g * 4 + i] = v;
+    }
+  __syncthreads();
+  if (wave == 0) {
+    float v = 0.f;
+    if (lane < MT * 16) {
+      v = fmaxf(fmaxf(red[lane], red[64 + lane]), fmaxf(red[128 + lane], red[192 + lane]));
+      if (clamp) v = fmaxf(v, 0.f);
+      if (v == -INFINITY) v = 0.f;
+      v *= a.qfac[lane];
+    }
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s);
+    if (lane == 0) {
+      const float part = v * a.inv_scale[page];
+      a.scores[item] = a.accumulate ? a.scores[item] + part : part;
+    }
+  }
+}
+
+template <int MT>
+int launch_f8_mt(const F8Args& k0, hipStream_t s) {
+  constexpr int64_t kChunk = (int64_t)1 << 22;  // work-item count per launch stays below 2^32
+  for (int64_t off = 0; off < k0.n; off += kChunk) {
+    F8Args k = k0;
+    k.n = std::min(kChunk, k0.n - off);
+    k.scores = k0.scores + off;
+    if (k0.cand) k.cand = k0.cand + off;
+    else k.page0 = k0.page0 + off;
+    hipLaunchKernelGGL((maxsim_fp8_kernel<MT, 4>), dim3((unsigned)k.n), dim3(256), 0, s, k);
+  }
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
+}  // namespace
+
+int launch_quantize_pages_fp8(const uint16_t* d_src_pages, const int32_t* d_n_rows, int32_t stride, int64_t n_pages,
+                              uint8_t* d_dst, float* d_inv_scale, hipStream_t s) {
+  int64_t done = 0;
+  while (done < n_pages) {
+    const int64_t c = std::min<int64_t>(n_pages - done, (int64_t)1 << 22);
+    hipLaunchKernelGGL(quantize_pages_kernel, dim3((unsigned)c), dim3(256), 0, s, d_src_pages + (size_t)done * stride * kDim,
+                       d_n_rows ? d_n_rows + done : nullptr, stride, d_dst + (size_t)done * stride * kDim, d_inv_scale + done);
+    done += c;
+  }
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
+int launch_fp8_query_prep(const float* d_q_f32, int n_q, uint8_t* d_hi, uint8_t* d_lo, float* d_fac, hipStream_t s) {
+  const int padded = ((n_q + 15) / 16) * 16;
+  hipLaunchKernelGGL(fp8_query_prep_kernel, dim3((unsigned)padded), dim3(64), 0, s, d_q_f32, n_q, padded, d_hi, d_lo, d_fac);
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
+int launch_maxsim_fp8(const Fp8ScanArgs& a, hipStream_t s) {
+  if (a.n <= 0) return MV_OK;
+  const int padded = ((a.n_q + 15) / 16) * 16;
+  for (int q0 = 0, pass = 0; q0 < padded; q0 += 64, ++pass) {
+    const int mt = std::min(4, (padded - q0) / 16);
+    F8Args k{a.slab, a.inv_scale, a.n_rows, a.doc_ord, a.allow, a.n_allow_bits, a.cand,
+             a.qhi + (size_t)q0 * kDim, a.qlo + (size_t)q0 * kDim, a.qfac + q0, a.scores, a.n, a.stride, a.pad_to, 0, pass > 0};
+    int rc;
+    switch (mt) {
+      case 1: rc = launch_f8_mt<1>(k, s); break;
+      case 2: rc = launch_f8_mt<2>(k, s); break;
+      case 3: rc = launch_f8_mt<3>(k, s); break;
+      default: rc = launch_f8_mt<4>(k, s); break;
+    }
+    if (rc) return rc;
+  }
+  return MV_OK;
+}
+
+}  // namespace mv

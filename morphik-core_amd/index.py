@@ -19,9 +19,11 @@ from ._lib import (
     MV_MODE_FDE_ONLY,
     MV_MODE_FDE_THEN_FLOAT,
     MV_MODE_FLOAT,
+    MV_MODE_FLOAT_FP8,
     MV_WITH_BINARY,
     MV_WITH_FDE,
     MV_WITH_FLOAT,
+    MV_WITH_FP8,
     ConfigC,
     FdeConfigC,
     QueryStatsC,
@@ -29,7 +31,8 @@ from ._lib import (
     lib,
 )
 
-MODES = {"float": MV_MODE_FLOAT, "binary": MV_MODE_BINARY, "fde_then_float": MV_MODE_FDE_THEN_FLOAT, "fde": MV_MODE_FDE_ONLY}
+MODES = {"float": MV_MODE_FLOAT, "binary": MV_MODE_BINARY, "fde_then_float": MV_MODE_FDE_THEN_FLOAT, "fde": MV_MODE_FDE_ONLY,
+         "float_fp8": MV_MODE_FLOAT_FP8}
 
 
 @dataclass
@@ -120,9 +123,11 @@ class MvIndex:
         with_fde: bool = False,
         fde: Optional[FdeConfig] = None,
         id_base: int = 0,
+        with_fp8: bool = False,
     ):
         self.fde_config = fde or FdeConfig()
-        flags = (MV_WITH_FLOAT if with_float else 0) | (MV_WITH_BINARY if with_binary else 0) | (MV_WITH_FDE if with_fde else 0)
+        flags = ((MV_WITH_FLOAT if with_float else 0) | (MV_WITH_BINARY if with_binary else 0) | (MV_WITH_FDE if with_fde else 0)
+                 | (MV_WITH_FP8 if with_fp8 else 0))
         cfg = ConfigC(128, int(stride_rows), int(capacity_pages), int(device), flags, int(id_base), self.fde_config.to_c())
         h = C.c_void_p()
         check(lib().mv_index_create(C.byref(cfg), C.byref(h)))
@@ -189,6 +194,18 @@ class MvIndex:
     def write_rows(self, page: int, row0: int, rows_bf16: np.ndarray) -> None:
         r = np.ascontiguousarray(rows_bf16, dtype=np.uint16)
         check(lib().mv_index_write_rows(self._h, page, row0, r.shape[0], r.ctypes.data))
+
+    def replace_page(self, page: int, rows_bf16: np.ndarray) -> None:
+        """Overwrite one whole page from host bf16 rows and refresh every enabled slab."""
+        r = np.ascontiguousarray(rows_bf16, dtype=np.uint16).reshape(-1, 128)
+        check(lib().mv_index_replace_page(self._h, page, r.ctypes.data, r.shape[0]))
+
+    def read_fp8(self, page0: int, n_pages: int) -> Tuple[np.ndarray, np.ndarray]:
+        """-> (e4m3 codes [n, stride_rows, 128] uint8, per-page inverse scales [n] float32)."""
+        codes = np.empty((n_pages, self.stride_rows, 128), np.uint8)
+        inv = np.empty(n_pages, np.float32)
+        check(lib().mv_index_read_fp8(self._h, page0, n_pages, codes.ctypes.data, inv.ctypes.data))
+        return codes, inv
 
     def read_pages(self, page0: int, n_pages: int) -> np.ndarray:
         out = np.empty((n_pages, self.stride_rows, 128), np.uint16)

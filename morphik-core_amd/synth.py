@@ -70,6 +70,23 @@ def plant_neighbours(index, spec, page_lo: int = 0, page_hi: int = None) -> int:
     return n
 
 
+def plant_neighbours_any(index, spec, corpus_seed: int, n_rows: int, page_lo: int = 0, page_hi: int = None) -> int:
+    """As plant_neighbours, for an index with ANY slab mix (fp8-only, bits-only, ...): the page is regenerated
+    by the device generator (C ABI mv_synth_rows, same key as fill_synthetic), the planted rows are overwritten
+    on the host and the whole page is replaced, which refreshes every slab."""
+    from .index import synth_rows
+
+    n = 0
+    for _qi, _r, page, row0, rows in spec:
+        if page < page_lo or (page_hi is not None and page >= page_hi):
+            continue
+        pg = synth_rows(corpus_seed, page, n_rows, device=index.device)
+        pg[row0 : row0 + rows.shape[0]] = rows
+        index.replace_page(page - page_lo, pg)
+        n += 1
+    return n
+
+
 def planted_plan(n_queries: int, n_pages_total: int, n_ranks: int = 10, seed: int = SEED_PLANTED) -> np.ndarray:
     """Global page ids chosen for planting, [n_queries, n_ranks] -- identical on every rank of a sharded run."""
     rng = np.random.default_rng(seed)

@@ -390,3 +390,105 @@ ORC_API void orc_fde_coarse_scores(const float* qf, const uint16_t* dslab, int64
     else out[p] = (float)dot;
   }
 }
+
+/* ------------------------------------------------------------------ fp8 (OCP e4m3fn) path
+ *
+ * Not a reference function: BASELINE.json configs[4] ("fp8 (e4m3) patch embeddings ... recall@10 vs bf16
+ * reference").  The scoring rule is still score_multi_vector's (fast_multivector_store.py:553-555); this
+ * restates the QUANTISER the HIP library uses (morphik-core_amd/csrc/mv_fp8.hip) and scores the same quantised
+ * operands in fp32/fp64 so the GPU kernel can be checked for arithmetic (not quantisation) differences.
+ * Every scaling below is by an exact power of two; the only roundings are the e4m3 RNE steps.
+ */
+static uint32_t orc_f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static float orc_bits_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+ORC_API uint8_t orc_e4m3_encode(float v) {
+  const uint32_t u = orc_f32_bits(v);
+  const uint32_t sign = (u >> 24) & 0x80u;
+  const uint32_t a = u & 0x7fffffffu;
+  if (a > 0x7f800000u) return (uint8_t)(sign | 0x7fu);
+  if (a >= 0x43e80000u) return (uint8_t)(sign | 0x7eu); /* >= 464 -> saturate at 448 */
+  int e = (int)(a >> 23) - 127;
+  if (e < -6) e = -6;
+  const float q = rintf(orc_bits_f32(a) * orc_bits_f32((uint32_t)(127 + 3 - e) << 23));
+  int qi = (int)q;
+  if (qi == 16) { qi = 8; e += 1; }
+  uint32_t code = (e == -6 && qi < 8) ? (uint32_t)qi : (uint32_t)(((e + 7) << 3) | (qi - 8));
+  if (code > 0x7eu) code = 0x7eu;
+  return (uint8_t)(sign | code);
+}
+
+ORC_API float orc_e4m3_decode(uint8_t c) {
+  const uint32_t E = (c >> 3) & 15u, M = c & 7u;
+  const float mag = E == 0 ? (float)M * 0.001953125f : (float)(8u + M) * orc_bits_f32((E + 127u - 10u) << 23);
+  return (c & 0x80u) ? -mag : mag;
+}
+
+static int orc_pow2_scale_exp(uint32_t amax_bits) { /* floor(log2(448 / amax)) */
+  if ((amax_bits & 0x7fffffffu) == 0u) return 0;
+  const int ea = (int)((amax_bits >> 23) & 0xffu) - 127;
+  const uint32_t mant = amax_bits & 0x7fffffu;
+  int e = 8 - ea - (mant > 0x600000u ? 1 : 0);
+  if (e > 100) e = 100;
+  if (e < -100) e = -100;
+  return e;
+}
+static float orc_pow2f(int e) { return orc_bits_f32((uint32_t)(127 + e) << 23); }
+
+/* page: bf16 rows [n_rows][128] -> codes [stride][128] (rows >= n_rows zero) + inverse scale 2^-e */
+ORC_API void orc_quantize_page_fp8(const uint16_t* rows, int32_t n_rows, int32_t stride, uint8_t* codes, float* inv_scale) {
+  uint32_t amax = 0;
+  for (int64_t i = 0; i < (int64_t)n_rows * 128; ++i) {
+    const uint32_t m = rows[i] & 0x7fffu;
+    if (m > amax) amax = m;
+  }
+  if (amax > 0x7f7fu) amax = 0x7f7fu;
+  const int e = orc_pow2_scale_exp(amax << 16);
+  const float sc = orc_pow2f(e);
+  *inv_scale = orc_pow2f(-e);
+  memset(codes, 0, (size_t)stride * 128);
+  for (int64_t i = 0; i < (int64_t)n_rows * 128; ++i) codes[i] = orc_e4m3_encode(orc_bf16_to_f32(rows[i]) * sc);
+}
+
+/* query: fp32 rows [n_q][128] -> hi, lo codes and 2^-s per row */
+ORC_API void orc_fp8_query_prep(const float* q, int32_t n_q, uint8_t* hi, uint8_t* lo, float* fac) {
+  for (int32_t r = 0; r < n_q; ++r) {
+    uint32_t amax = 0;
+    for (int k = 0; k < 128; ++k) {
+      const uint32_t m = orc_f32_bits(q[(size_t)r * 128 + k]) & 0x7fffffffu;
+      if (m > amax) amax = m;
+    }
+    if (amax > 0x7f7fffffu) amax = 0x7f7fffffu;
+    const int e = orc_pow2_scale_exp(amax);
+    const float sc = orc_pow2f(e);
+    for (int k = 0; k < 128; ++k) {
+      const float xs = q[(size_t)r * 128 + k] * sc;
+      const uint8_t ch = orc_e4m3_encode(xs);
+      const float res = xs - orc_e4m3_decode(ch);
+      hi[(size_t)r * 128 + k] = ch;
+      lo[(size_t)r * 128 + k] = orc_e4m3_encode(res * 16.0f);
+    }
+    fac[r] = orc_pow2f(-e);
+  }
+}
+
+/* score of one quantised page against a prepared query: fp64 accumulation of the same operands */
+ORC_API float orc_maxsim_fp8(const uint8_t* qhi, const uint8_t* qlo, const float* qfac, int32_t n_q, const uint8_t* codes,
+                             int32_t n_rows, float inv_scale, int32_t pad_to) {
+  double total = 0.0;
+  for (int32_t i = 0; i < n_q; ++i) {
+    double best = -INFINITY;
+    for (int32_t p = 0; p < n_rows; ++p) {
+      double acc = 0.0;
+      for (int k = 0; k < 128; ++k) {
+        const double a = (double)orc_e4m3_decode(qhi[(size_t)i * 128 + k]) + (double)orc_e4m3_decode(qlo[(size_t)i * 128 + k]) * 0.0625;
+        acc += a * (double)orc_e4m3_decode(codes[(size_t)p * 128 + k]);
+      }
+      if (acc > best) best = acc;
+    }
+    if (pad_to > n_rows && best < 0.0) best = 0.0;
+    if (best == -INFINITY) best = 0.0;
+    total += best * (double)qfac[i];
+  }
+  return (float)(total * (double)inv_scale);
+}

@@ -79,6 +79,14 @@ def lib() -> C.CDLL:
         L.orc_fde_encode.argtypes = [C.POINTER(FdeConfig), vp, i32, i32, vp]
         L.orc_fde_partitions.argtypes = [C.POINTER(FdeConfig), vp, i32, vp]
         L.orc_fde_coarse_scores.argtypes = [vp, vp, i64, i64, i32, vp]
+        L.orc_e4m3_encode.argtypes = [f32]
+        L.orc_e4m3_encode.restype = C.c_uint8
+        L.orc_e4m3_decode.argtypes = [C.c_uint8]
+        L.orc_e4m3_decode.restype = f32
+        L.orc_quantize_page_fp8.argtypes = [vp, i32, i32, vp, vp]
+        L.orc_fp8_query_prep.argtypes = [vp, i32, vp, vp, vp]
+        L.orc_maxsim_fp8.argtypes = [vp, vp, vp, i32, vp, i32, f32, i32]
+        L.orc_maxsim_fp8.restype = f32
         _lib = L
     return _lib
 
@@ -287,3 +295,55 @@ def fde_coarse_scores(q_fde, d_slab_u16, use_cosine: bool = True) -> np.ndarray:
     out = np.empty(d.shape[0], np.float32)
     lib().orc_fde_coarse_scores(_p(q), _p(d), d.shape[0], d.shape[1], 1 if use_cosine else 0, _p(out))
     return out
+
+
+# --------------------------------------------------------------------------- fp8 (e4m3fn) path
+def e4m3_encode(x) -> np.ndarray:
+    x = _c(x, np.float32)
+    return np.array([lib().orc_e4m3_encode(float(v)) for v in x.ravel()], np.uint8).reshape(x.shape)
+
+
+def e4m3_decode(c) -> np.ndarray:
+    c = _c(c, np.uint8)
+    lut = np.array([lib().orc_e4m3_decode(i) for i in range(256)], np.float32)
+    return lut[c]
+
+
+def quantize_page_fp8(rows_bf16, stride: int) -> Tuple[np.ndarray, float]:
+    """bf16 rows [n,128] -> (codes [stride,128] uint8, inverse scale 2^-e)."""
+    r = _c(rows_bf16, np.uint16).reshape(-1, 128)
+    codes = np.empty((stride, 128), np.uint8)
+    inv = C.c_float()
+    lib().orc_quantize_page_fp8(_p(r), r.shape[0], stride, _p(codes), C.byref(inv))
+    return codes, float(inv.value)
+
+
+def fp8_query_prep(q_f32):
+    q = _c(q_f32, np.float32).reshape(-1, 128)
+    hi = np.empty(q.shape, np.uint8)
+    lo = np.empty(q.shape, np.uint8)
+    fac = np.empty(q.shape[0], np.float32)
+    lib().orc_fp8_query_prep(_p(q), q.shape[0], _p(hi), _p(lo), _p(fac))
+    return hi, lo, fac
+
+
+def maxsim_fp8(q_f32, codes, n_rows: int, inv_scale: float, pad_to: int = 0) -> float:
+    hi, lo, fac = fp8_query_prep(q_f32)
+    c = _c(codes, np.uint8)
+    return float(lib().orc_maxsim_fp8(_p(hi), _p(lo), _p(fac), hi.shape[0], _p(c), int(n_rows), float(inv_scale), int(pad_to)))
+
+
+def maxsim_fp8_np(q_f32, codes_pages, inv_scales, n_rows=None) -> np.ndarray:
+    """Vectorised: codes_pages [N,P,128] uint8, inv_scales [N] -> scores [N] (fp64 accumulation, same operands)."""
+    hi, lo, fac = fp8_query_prep(q_f32)
+    a = e4m3_decode(hi).astype(np.float64) + e4m3_decode(lo).astype(np.float64) * 0.0625
+    lut = np.array([lib().orc_e4m3_decode(i) for i in range(256)], np.float64)
+    out = np.empty(len(codes_pages), np.float64)
+    for i, pg in enumerate(codes_pages):
+        nr = pg.shape[0] if n_rows is None else int(n_rows[i])
+        if nr == 0:
+            out[i] = 0.0
+            continue
+        s = lut[pg[:nr]] @ a.T  # [nr, Q]
+        out[i] = float((s.max(axis=0) * fac.astype(np.float64)).sum() * float(inv_scales[i]))
+    return out.astype(np.float32)

@@ -264,14 +264,28 @@ def test_hamming_batch_matches_reference_golden(mv, golden_dir):
         hamming_batch(b"ab", [b"abc"])
 
 
-def test_binary_maxsim_exact_vs_sql_restatement(mv):
-    lens = [64, 1, 0, 33, 64, 17, 64, 64, 5]
+BINARY_VARIANTS = [0, 1]  # 0 = popcount on the VALU, 1 = FP4 MFMA (default); identical integers required
+
+
+def _set_binary_variant(ix, variant):
+    from morphik_core_amd import _lib
+
+    ix.set_option(_lib.MV_OPT_BINARY_VARIANT, variant)
+
+
+@pytest.mark.parametrize("variant", BINARY_VARIANTS)
+@pytest.mark.parametrize("stride", [64, 80, 208])
+def test_binary_maxsim_exact_vs_sql_restatement(mv, variant, stride):
+    lens = [64, 1, 0, 33, 64, 17, 64, 64, 5, stride, stride - 1, stride - 15, 16, 48]
     rng = np.random.default_rng(4)
     pages = [rng.standard_normal((n, 128)).astype(np.float32) for n in lens]
     pages[4][3, :7] = 0.0  # zeros quantise to 0 bits
-    ix = _idx(mv, capacity_pages=16, stride_rows=64, with_float=False, with_binary=True)
+    pages[5][:, :] = -1.0  # all-zero bit rows
+    pages[6][:, :] = 1.0   # all-one bit rows
+    ix = _idx(mv, capacity_pages=len(lens), stride_rows=stride, with_float=False, with_binary=True)  # last page ends the slab
+    _set_binary_variant(ix, variant)
     ix.add(pages)
-    for nq in (1, 9, 32, 40):
+    for nq in (1, 9, 16, 32, 40, 64, 70, 130):
         q = rng.standard_normal((nq, 128)).astype(np.float32)
         want = np.array([orc.maxsim_binary(orc.sign_pack(p) if len(p) else np.zeros((0, 16), np.uint8), orc.sign_pack(q)) for p in pages])
         got = ix.score_all(q, mode="binary")
@@ -282,25 +296,51 @@ def test_binary_maxsim_exact_vs_sql_restatement(mv):
     ix.close()
 
 
-def test_binary_maxsim_reference_known_ranking(mv):
+@pytest.mark.parametrize("variant", BINARY_VARIANTS)
+def test_binary_maxsim_reference_known_ranking(mv, variant):
     """core/tests/unit/test_multivector.py:214-256 -> doc1 first with 1.0, doc2 0.0."""
     half = np.concatenate([np.ones(64), -np.ones(64)]).astype(np.float32)
     ix = _idx(mv, capacity_pages=4, stride_rows=16, with_float=True, with_binary=True)
+    _set_binary_variant(ix, variant)
     ix.add([np.stack([half] * 3), np.stack([-half] * 3)])
     s, i = ix.query(half[None], 2, mode="binary")
     assert i.tolist() == [0, 1] and s.tolist() == [1.0, 0.0]
     ix.close()
 
 
-def test_binary_maxsim_synthetic_slab_1024(mv):
+@pytest.mark.parametrize("variant", BINARY_VARIANTS)
+def test_binary_maxsim_synthetic_slab_1024(mv, variant):
     ix = _idx(mv, capacity_pages=64, stride_rows=1024, with_binary=True)
+    _set_binary_variant(ix, variant)
     ix.fill_synthetic(1234, 0, 48)
     pages = ix.read_pages(0, 48)
-    q = orc.synth_rows(4321, 0, 0, 32)
     bits = np.stack([orc.sign_pack(orc.bf16_to_f32(p)) for p in pages])
-    want = orc.maxsim_binary_np(bits, orc.sign_pack(orc.bf16_to_f32(q)))
-    got = ix.score_all(q, mode="binary")
-    assert got.astype(np.float64).tolist() == want.tolist()
+    for nq in (32, 20):
+        q = orc.synth_rows(4321, 0, 0, nq)
+        want = orc.maxsim_binary_np(bits, orc.sign_pack(orc.bf16_to_f32(q)))
+        got = ix.score_all(q, mode="binary")
+        assert got.astype(np.float64).tolist() == want.tolist()
+    ix.close()
+
+
+def test_binary_variants_agree_with_filter_and_tombstones_midsize(mv):
+    """Both sign-bit kernels over 20 k ragged pages with a doc filter and tombstones: identical vectors."""
+    n = 20_000
+    ix = _idx(mv, capacity_pages=n, stride_rows=1024, with_binary=True)
+    ix.fill_synthetic(1234, 0, n, n_rows=1000, pages_per_doc=7)
+    for d in (3, 11, 500):
+        ix.remove_doc(d)
+    from morphik_core_amd.index import allow_bitmap
+
+    allow = allow_bitmap([d for d in range(0, n // 7 + 1) if d % 3 != 1])
+    q = orc.synth_rows(4321, 1, 0, 32)
+    outs = []
+    for v in BINARY_VARIANTS:
+        _set_binary_variant(ix, v)
+        outs.append((ix.score_all(q, mode="binary", allow=allow), ix.query(q, 10, mode="binary", allow=allow)))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert outs[0][1][1].tolist() == outs[1][1][1].tolist() and outs[0][1][0].tolist() == outs[1][1][0].tolist()
+    assert np.isinf(outs[0][0]).sum() > n // 4  # the filter really masked pages
     ix.close()
 
 
@@ -357,15 +397,87 @@ def test_fde_coarse_scan_and_pipeline(mv):
     ix.close()
 
 
+# ------------------------------------------------------------------ fp8 (e4m3) slab
+def test_fp8_quantizer_bit_exact_vs_oracle(mv):
+    ix = _idx(mv, capacity_pages=40, stride_rows=64, with_fp8=True)
+    ix.fill_synthetic(1234, 0, 30, n_rows=50)
+    rng = np.random.default_rng(5)
+    extra = [rng.standard_normal((n, 128)).astype(np.float32) * s for n, s in ((64, 1.0), (1, 1e-3), (0, 1.0), (33, 40.0), (7, 1e-6))]
+    ix.add(extra)
+    pages = ix.read_pages(0, 35)
+    codes, inv = ix.read_fp8(0, 35)
+    lens = [50] * 30 + [64, 1, 0, 33, 7]
+    for p in range(35):
+        wc, wi = orc.quantize_page_fp8(pages[p, : lens[p]], 64)
+        assert np.array_equal(codes[p], wc), p
+        assert inv[p] == np.float32(wi), p
+    ix.close()
+
+
+@pytest.mark.parametrize("stride,nrows", [(1024, 1024), (1024, 1000), (64, 50), (48, 48), (16, 5)])
+def test_fp8_maxsim_matches_oracle_on_same_codes(mv, stride, nrows):
+    n = 24
+    ix = _idx(mv, capacity_pages=n, stride_rows=stride, with_float=True, with_fp8=True)
+    ix.fill_synthetic(1234, 0, n, n_rows=nrows)
+    codes, inv = ix.read_fp8(0, n)
+    for nq in (1, 17, 32, 64, 80):
+        q = orc.bf16_to_f32(orc.synth_rows(4321, nq, 0, nq))
+        q[0, :9] *= 2.5  # not unit norm
+        want = orc.maxsim_fp8_np(q, codes, inv, n_rows=[nrows] * n)
+        got = ix.score_all(q, mode="float_fp8")
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-6)
+        # quality: fp8 scores track the bf16 scores (3 mantissa bits on the page side; averaged over 128 dims)
+        ref = ix.score_all(q, mode="float")
+        assert np.max(np.abs(got - ref) / np.abs(ref)) < 3e-2
+    ix.close()
+
+
+def test_fp8_only_index_ragged_filter_candidates_and_pipeline(mv):
+    from morphik_core_amd import _lib, synth
+    from morphik_core_amd.index import allow_bitmap
+
+    N, stride, nrows = 3000, 64, 60
+    ix = _idx(mv, capacity_pages=N, stride_rows=stride, with_float=False, with_fp8=True, with_fde=True, with_binary=True)
+    ix.fill_synthetic(1234, 0, N, n_rows=nrows, pages_per_doc=4)  # staged in chunks: no float slab
+    q_bf = orc.synth_rows(4321, 0, 0, 32)
+    spec = synth.planted_spec([q_bf], N, nrows, n_ranks=5)
+    assert synth.plant_neighbours_any(ix, spec, 1234, nrows) == 5
+    planted = [p for (_, _, p, _, _) in spec]
+    q = orc.bf16_to_f32(q_bf)
+    codes, inv = ix.read_fp8(0, N)
+    want = orc.maxsim_fp8_np(q, codes, inv, n_rows=[nrows] * N)
+    got = ix.score_all(q_bf, mode="float_fp8")
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-6)
+    s, i = ix.query(q_bf, 5, mode="float_fp8")
+    assert i.tolist() == planted  # recall@5 = 1.0 against the exact (bf16) planted ranking
+    # coarse -> rerank on the fp8 slab
+    s2, i2 = ix.query(q_bf, 5, mode="fde_then_float")
+    assert i2.tolist() == planted
+    np.testing.assert_allclose(s2, s, rtol=1e-5)
+    # explicit candidates on the fp8 slab
+    cand = [planted[0], 17, planted[3], 2999]
+    np.testing.assert_allclose(ix.score_candidates(q_bf, cand), want[cand], rtol=RTOL)
+    # doc filter + tombstone
+    ix.remove_doc(planted[0] // 4)
+    allow = allow_bitmap([d for d in range(N // 4 + 1) if d != planted[1] // 4])
+    s3, i3 = ix.query(q_bf, 3, mode="float_fp8", allow=allow)
+    assert i3.tolist() == planted[2:5]
+    # the binary slab was refreshed by replace_page too
+    bits = np.stack([orc.sign_pack(orc.bf16_to_f32(synth_page)) for synth_page in [orc.synth_rows(1234, 5, 0, nrows)]])
+    gb = ix.score_all(q_bf, mode="binary")
+    assert float(gb[5]) == orc.maxsim_binary(bits[0], orc.sign_pack(q))
+    ix.close()
+
+
 # ------------------------------------------------------------------ persistence
 def test_save_load_roundtrip(mv, tmp_path):
     from morphik_core_amd.index import MvIndex
 
-    ix = _idx(mv, capacity_pages=64, stride_rows=32, with_binary=True, with_fde=True)
+    ix = _idx(mv, capacity_pages=64, stride_rows=32, with_binary=True, with_fde=True, with_fp8=True)
     ix.fill_synthetic(1234, 0, 50, pages_per_doc=5)
     ix.remove_doc(2)
     q = orc.synth_rows(4321, 0, 0, 32)
-    before = {m: ix.query(q, 7, mode=m) for m in ("float", "binary", "fde_then_float")}
+    before = {m: ix.query(q, 7, mode=m) for m in ("float", "binary", "fde_then_float", "float_fp8")}
     path = str(tmp_path / "ix.mv")
     ix.save(path)
     ix.close()

@@ -216,3 +216,38 @@ def test_fde_dot_tracks_maxsim():
     coarse = orc.fde_coarse_scores(fq, orc.f32_to_bf16(fds), use_cosine=False)
     exact = orc.maxsim_float_np(q, pages)
     assert int(np.argmax(coarse)) == 3 == int(np.argmax(exact))
+
+
+# ------------------------------------------------------------------ fp8 (e4m3fn) oracle pieces
+def test_e4m3_codec_matches_torch_float8():
+    """The quantiser both sides use is OCP e4m3fn with RNE and saturation at 448 -- pinned against
+    torch.float8_e4m3fn (an independent implementation) on 200k values incl. ties, subnormals and the clamp."""
+    import torch
+
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal(200_000) * np.exp(rng.standard_normal(200_000) * 3)).astype(np.float32)
+    x = np.concatenate([x, np.array([0.0, -0.0, 448.0, 464.0, 1e9, -1e9, 2.0**-9, 2.0**-10, 1.5 * 2.0**-9, 17.0, 18.0, 19.0], np.float32)])
+    ref = torch.from_numpy(np.clip(x, -448, 448)).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    assert np.array_equal(orc.e4m3_encode(x), ref)
+    codes = np.arange(256, dtype=np.uint8)
+    finite = (codes & 0x7F) != 0x7F
+    want = torch.from_numpy(codes).view(torch.float8_e4m3fn).float().numpy()
+    assert np.array_equal(orc.e4m3_decode(codes)[finite], want[finite])
+
+
+def test_fp8_quantised_scores_track_fp32_scores():
+    q = orc.bf16_to_f32(orc.synth_rows(4321, 0, 0, 32))
+    pages = orc.synth_pages(1234, 0, 6, 96)
+    codes, inv = zip(*(orc.quantize_page_fp8(p, 96) for p in pages))
+    for c, iv in zip(codes, inv):
+        assert 224.0 < np.abs(orc.e4m3_decode(c)).max() <= 448.0  # power-of-two scale puts amax in (224, 448]
+        assert np.log2(iv) == np.round(np.log2(iv))
+    got = orc.maxsim_fp8_np(q, np.stack(codes), np.array(inv, np.float32))
+    one = np.array([orc.maxsim_fp8(q, codes[i], 96, inv[i]) for i in range(6)], np.float32)
+    np.testing.assert_allclose(got, one, rtol=1e-6)
+    ref = orc.maxsim_float_np(q, orc.bf16_to_f32(pages))
+    assert np.max(np.abs(got - ref) / np.abs(ref)) < 3e-2
+    # two-term query split: hi + lo/16 reproduces the scaled query to ~2^-7 of its row maximum
+    hi, lo, fac = orc.fp8_query_prep(q)
+    rec = (orc.e4m3_decode(hi) + orc.e4m3_decode(lo) / 16.0) * fac[:, None]
+    assert np.max(np.abs(rec - q) / np.abs(q).max(axis=1, keepdims=True)) < 2.0**-7

@@ -53,21 +53,30 @@ def main():
     ix.close()
     if a.aux:
         n = min(a.pages, 200_000)
-        ix = MvIndex(capacity_pages=n, stride_rows=a.patches, with_float=True, with_binary=True, with_fde=True)
+        ix = MvIndex(capacity_pages=n, stride_rows=a.patches, with_float=True, with_binary=True, with_fde=True, with_fp8=True)
         import time
         t0 = time.time()
         ix.fill_synthetic(1234, 0, n)
-        res["fill_with_binary_fde_s"] = time.time() - t0
+        res["fill_all_slabs_s"] = time.time() - t0
         res["fill_pages"] = n
         q = synth_rows(4321, 0, 32)
-        for mode, per_page in (("binary", a.patches * 16), ("fde", 10240 * 2), ("fde_then_float", 10240 * 2)):
+        runs = [("binary_v0_popcount", "binary", a.patches * 16, (_lib.MV_OPT_BINARY_VARIANT, 0)),
+                ("binary_v1_fp4mfma", "binary", a.patches * 16, (_lib.MV_OPT_BINARY_VARIANT, 1)),
+                ("fde_v0_regs", "fde", 10240 * 2, (_lib.MV_OPT_FDE_SCAN_VARIANT, 0)),
+                ("fde_v1_lds", "fde", 10240 * 2, (_lib.MV_OPT_FDE_SCAN_VARIANT, 1)),
+                ("float_fp8", "float_fp8", a.patches * 128, None),
+                ("float_bf16", "float", a.patches * 256, None)]
+        for name, mode, per_page, opt in runs:
+            if opt:
+                ix.set_option(*opt)
             ts = []
             for r in range(a.rounds + 1):
                 s, i, st = ix.query(q, 10, mode=mode, want_stats=True)
                 if r:
                     ts.append(st.score_kernel_ms)
-            res[mode] = {"kernel_ms_med": float(np.median(ts)), "GBps_med": n * per_page / np.median(ts) / 1e6, "pages_per_s": n / np.median(ts) * 1e3}
-            print(f"{mode}: {np.median(ts):.3f} ms  {n*per_page/np.median(ts)/1e6:.0f} GB/s  {n/np.median(ts)*1e3/1e6:.1f} M pages/s", flush=True)
+            res[name] = {"kernel_ms_med": float(np.median(ts)), "GBps_med": n * per_page / np.median(ts) / 1e6, "pages_per_s": n / np.median(ts) * 1e3,
+                         "top": i[:3].tolist()}
+            print(f"{name}: {np.median(ts):.3f} ms  {n*per_page/np.median(ts)/1e6:.0f} GB/s  {n/np.median(ts)*1e3/1e6:.1f} M pages/s", flush=True)
         ix.close()
     js = json.dumps(res, indent=1)
     if a.out:
