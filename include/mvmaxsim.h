@@ -93,8 +93,9 @@ typedef enum {
   MV_OPT_FDE_COSINE = 3,     /* 1 = rank coarse stage by cosine (TurboPuffer cosine_distance, reference), 0 = dot */
   MV_OPT_PAD_SEMANTICS = 4,  /* 0 = max over a page's own rows only; 1 = reference rerank batch rule
                                 (pad_to = longest candidate of the batch of 128 => clamp at 0) */
-  MV_OPT_BINARY_VARIANT = 5, /* sign-bit scan: 0 = popcount on the VALU, 1 = FP4 MFMA (default); same integers */
-  MV_OPT_FDE_SCAN_VARIANT = 6 /* FDE coarse scan: 0 = query in registers, 1 = query in LDS (default) */
+  MV_OPT_BINARY_VARIANT = 5, /* sign-bit scan: 0 = popcount on the VALU, 1 = FP4 MFMA, 2/3/4 = FP4 MFMA with in-place bit operands and an
+                                8/16/4-slot ring (4 = default); all produce the same integers */
+  MV_OPT_FDE_SCAN_VARIANT = 6 /* FDE coarse scan: 0 = wave per page (default), 1 = query in LDS, 2 = workgroup per page */
 } mv_option;
 
 MV_API const char* mv_last_error(void);

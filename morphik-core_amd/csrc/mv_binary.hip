@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void maxsim_binary_mfma_kernel(BMArgs args) {
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %2\n\t"
         "s_nop 4\n\t"
-        "global_load_lds_dwordx4 %1, %3\n\t"
+        "global_load_lds_dwordx4 %1, %3 nt\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(src_off), "s"(slot), "s"(tpu)
@@ -355,6 +355,170 @@ int launch_sign_pack_bf16_rows(const uint16_t* d_rows, int64_t n_rows, uint8_t* 
   return MV_OK;
 }
 
+// Variant 2: the same MFMA with 9 instead of 16 VALU ops per tile (the 1-wave-per-page scan is VALU-issue bound:
+// a wave64 VALU op occupies its SIMD for 4 cycles).  Lane (r, g) takes dword g of row r (ds_read_b32) and feeds
+// its 32 bits as the lane's 32 FP4 K-slots WITHOUT moving three of every four bits:
+//     B_0 = w & 0x11111111  -> nibble 0x1 = 0.5      A slot magnitude 2.0   (product 1)
+//     B_1 = w & 0x22222222  -> nibble 0x2 = 1.0      A slot magnitude 1.0
+//     B_2 = w & 0x44444444  -> nibble 0x4 = 2.0      A slot magnitude 0.5
+//     B_3 = (w >> 1) & 0x44444444  (bit 3 of a nibble is the FP4 sign: it has to move)   A magnitude 0.5
+// so D[q][d] = sum_k (2 q_k - 1) d_k = 2 popc(q & d) - popc(d)  and  hamming = popc(q) - D.
+// The running max takes two tiles per v_max3_f32.
+template <int MT, int D>
+__global__ __launch_bounds__(256) void maxsim_binary_mfma2_kernel(BMArgs args) {
+  const BArgs& a = args.b;
+  __shared__ __attribute__((aligned(16))) char lds[4 * D * kBinSlotBytes];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t page = (int64_t)blockIdx.x * 4 + wave;
+  if (page >= a.n) return;
+  if (masked(a, page)) {
+    if (lane == 0) a.scores[page] = -INFINITY;
+    return;
+  }
+  const int nr = a.n_rows ? a.n_rows[page] : a.stride;
+  if (nr <= 0 || a.n_q <= 0) {
+    if (lane == 0 && !args.accumulate) a.scores[page] = 0.0f;
+    return;
+  }
+  const int ntiles = (nr + 15) >> 4;
+  const int nslots = (nr + kBinSlotRows - 1) / kBinSlotRows;
+  const char* pbase = reinterpret_cast<const char*>(a.bits) + (size_t)page * (size_t)a.stride * kSignBytes;
+  char* ring = lds + wave * (D * kBinSlotBytes);
+  const int src_off = lane * 16;
+  const int rd_off = r * kSignBytes + g * 4;
+
+  auto issue = [&](int it) {
+    const char* tp = pbase + (size_t)it * kBinSlotBytes;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
+    const uint64_t tpu = ((uint64_t)hi << 32) | lo;
+    const uint32_t slot = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + (it % D) * kBinSlotBytes));
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %3 nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src_off), "s"(slot), "s"(tpu)
+        : "memory");
+  };
+
+#pragma unroll
+  for (int i = 0; i < D - 1; ++i)
+    if (i < nslots) issue(i);
+
+  i32x8 qa[MT];
+  float qpop[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const uint32_t w = reinterpret_cast<const uint32_t*>(a.q + m * 16 + r)[g];
+    const float4 pc = *reinterpret_cast<const float4*>(a.qpop + m * 16 + g * 4);
+    qa[m][0] = (int)(0xCCCCCCCCu - ((w & 0x11111111u) << 3));         // +-2.0
+    qa[m][1] = (int)(0xAAAAAAAAu - (((w >> 1) & 0x11111111u) << 3));  // +-1.0
+    qa[m][2] = (int)(0x99999999u - (((w >> 2) & 0x11111111u) << 3));  // +-0.5
+    qa[m][3] = (int)(0x99999999u - (((w >> 3) & 0x11111111u) << 3));  // +-0.5
+#pragma unroll
+    for (int i = 4; i < 8; ++i) qa[m][i] = 0;
+    qpop[m][0] = pc.x; qpop[m][1] = pc.y; qpop[m][2] = pc.z; qpop[m][3] = pc.w;
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      asm volatile("" : "+v"(qa[m][i]));
+      asm volatile("" : "+v"(qpop[m][i]));
+    }
+  }
+
+  f32x4b mx[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) mx[m] = f32x4b{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+
+  auto expand = [&](uint32_t w) {
+    i32x8 b;
+    b[0] = (int)(w & 0x11111111u);
+    b[1] = (int)(w & 0x22222222u);
+    b[2] = (int)(w & 0x44444444u);
+    b[3] = (int)((w >> 1) & 0x44444444u);
+    b[4] = 0; b[5] = 0; b[6] = 0; b[7] = 0;
+    return b;
+  };
+  auto mma = [&](const i32x8& qam, const i32x8& b) {
+    f32x4b acc = {0.f, 0.f, 0.f, 0.f};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(qam, b, acc, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  };
+
+  // Main loop: full 64-row slots only (no column masks, no divergent register assignment); a ragged tail slot is
+  // handled after the loop, when every DMA has landed.
+  const int nfull = nr / kBinSlotRows;
+  for (int it = 0; it < nfull; ++it) {
+    if (it + D - 1 < nslots) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // WAR: last reads of the slot being refilled
+      issue(it + D - 1);
+      bin_wait_vmcnt<D - 1>();
+    } else {
+      const int left = nslots - 1 - it;  // slots still allowed in flight (conservative ladder)
+      if (left >= 4 && D > 4) bin_wait_vmcnt<4>();
+      else if (left >= 2) bin_wait_vmcnt<2>();
+      else if (left == 1) bin_wait_vmcnt<1>();
+      else bin_wait_vmcnt<0>();
+    }
+    const char* slot = ring + (it % D) * kBinSlotBytes + rd_off;
+    uint32_t w[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) w[tt] = *reinterpret_cast<const uint32_t*>(slot + tt * 256);
+#pragma unroll
+    for (int tp = 0; tp < 4; tp += 2) {
+      const i32x8 b0 = expand(w[tp]), b1 = expand(w[tp + 1]);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const f32x4b c0 = mma(qa[m], b0), c1 = mma(qa[m], b1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mx[m][i] = fmaxf(fmaxf(mx[m][i], c0[i]), c1[i]);
+      }
+    }
+  }
+  if (nfull < nslots) {  // ragged tail: 1..4 tiles of the last slot, the final tile possibly partial
+    bin_wait_vmcnt<0>();
+    const char* slot = ring + (nfull % D) * kBinSlotBytes + rd_off;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const int t = nfull * 4 + tt;
+      if (t < ntiles) {  // wave-uniform
+        const i32x8 b = expand(*reinterpret_cast<const uint32_t*>(slot + tt * 256));
+        const bool col_valid = t * 16 + r < nr;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          f32x4b c = mma(qa[m], b);
+          if (!col_valid) c = f32x4b{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) mx[m][i] = fmaxf(mx[m][i], c[i]);
+        }
+      }
+    }
+  }
+
+  float ham = 0.f;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = bin_group16_max(mx[m][i]);
+      if (qpop[m][i] >= 0.f) ham += qpop[m][i] - v;
+    }
+  ham += __shfl_xor(ham, 16);
+  ham += __shfl_xor(ham, 32);
+  if (lane == 0) {
+    const float part = (float)a.n_q - ham * (1.0f / 128.0f);
+    a.scores[page] = args.accumulate ? a.scores[page] + part : part;
+  }
+}
+
 // popc(q row) as float for rows < n_q, -1 for the padding rows up to `padded`; also zero-fills the padding bit rows
 __global__ void binary_qprep_kernel(uint4* qbits, int n_q, int padded, float* qpop) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -369,9 +533,15 @@ __global__ void binary_qprep_kernel(uint4* qbits, int n_q, int padded, float* qp
 }
 
 template <int MT>
-static void launch_binary_mfma(const BArgs& k, int accumulate, hipStream_t s) {
+static void launch_binary_mfma(const BArgs& k, int accumulate, int variant, hipStream_t s) {
   BMArgs m{k, accumulate};
-  hipLaunchKernelGGL((maxsim_binary_mfma_kernel<MT, 6>), dim3((unsigned)((k.n + 3) / 4)), dim3(256), 0, s, m);
+  const dim3 grid((unsigned)((k.n + 3) / 4)), block(256);
+  switch (variant) {
+    case 1: hipLaunchKernelGGL((maxsim_binary_mfma_kernel<MT, 6>), grid, block, 0, s, m); break;
+    case 3: hipLaunchKernelGGL((maxsim_binary_mfma2_kernel<MT, 16>), grid, block, 0, s, m); break;
+    case 4: hipLaunchKernelGGL((maxsim_binary_mfma2_kernel<MT, 4>), grid, block, 0, s, m); break;
+    default: hipLaunchKernelGGL((maxsim_binary_mfma2_kernel<MT, 8>), grid, block, 0, s, m); break;
+  }
 }
 
 int launch_maxsim_binary(const BinaryArgs& a, int variant, hipStream_t s) {
@@ -379,10 +549,10 @@ int launch_maxsim_binary(const BinaryArgs& a, int variant, hipStream_t s) {
   BArgs k{reinterpret_cast<const uint4*>(a.bits), a.n_rows, a.doc_ord, a.allow, a.n_allow_bits,
           reinterpret_cast<const uint4*>(a.qbits), a.scores, a.n, a.stride, a.n_q, a.qpop};
   if (a.n > ((int64_t)1 << 25)) { set_error("binary scan: more than 2^25 pages per launch is not supported"); return MV_ERR_INVALID; }
-  if (variant < 0) variant = 1;
+  if (variant < 0) variant = 4;  // measured (200k pages x 1024): 408 M pages/s (4-slot ring) > 390 (8) > 295 (16) > 345 (v1) > 48 (popcount)
   if (variant == 0 || a.n_q <= 0) {
     hipLaunchKernelGGL(maxsim_binary_kernel, dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, s, k);
-  } else if (variant == 1) {
+  } else if (variant >= 1 && variant <= 4) {
     if (!a.qpop) { set_error("binary MFMA scan needs the qpop workspace"); return MV_ERR_INVALID; }
     const int padded = ((a.n_q + 15) / 16) * 16;
     hipLaunchKernelGGL(binary_qprep_kernel, dim3((unsigned)((padded + 63) / 64)), dim3(64), 0, s,
@@ -395,10 +565,10 @@ int launch_maxsim_binary(const BinaryArgs& a, int variant, hipStream_t s) {
       kp.n_q = std::min(64, a.n_q - q0);
       const int mt = (kp.n_q + 15) / 16;
       switch (mt) {
-        case 1: launch_binary_mfma<1>(kp, pass > 0, s); break;
-        case 2: launch_binary_mfma<2>(kp, pass > 0, s); break;
-        case 3: launch_binary_mfma<3>(kp, pass > 0, s); break;
-        default: launch_binary_mfma<4>(kp, pass > 0, s); break;
+        case 1: launch_binary_mfma<1>(kp, pass > 0, variant, s); break;
+        case 2: launch_binary_mfma<2>(kp, pass > 0, variant, s); break;
+        case 3: launch_binary_mfma<3>(kp, pass > 0, variant, s); break;
+        default: launch_binary_mfma<4>(kp, pass > 0, variant, s); break;
       }
     }
   } else {

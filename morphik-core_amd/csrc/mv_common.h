@@ -74,7 +74,8 @@ struct BinaryArgs {
   int32_t stride;
   int32_t n_q;
 };
-// variant: 0 = popcount (VALU), 1 = FP4 MFMA (default, -1)
+// variant: 0 = popcount (VALU), 1 = FP4 MFMA (16 VALU ops/tile), 2 = FP4 MFMA with in-place bit operands (9 VALU
+// ops/tile, 8-slot ring), 3 / 4 = variant 2 with a 16- / 4-slot ring (4 = default, -1)
 int launch_maxsim_binary(const BinaryArgs& a, int variant, hipStream_t s);
 int launch_hamming_batch(const uint8_t* d_q, const uint8_t* d_c, int64_t n, int32_t n_bytes, int32_t* d_out,
                          hipStream_t s);
@@ -117,7 +118,7 @@ struct FdeScanArgs {
   int64_t n;
   int64_t out_dim;
 };
-// variant: 0 = query in registers (persistent waves), 1 = query in LDS (default, -1)
+// variant: 0 = query in registers, one wave per page, nt loads (default, -1), 1 = query in LDS, 2 = workgroup-cooperative
 int launch_fde_scan(const FdeScanArgs& a, int variant, hipStream_t s);
 
 // ---------------------------------------------------------------- fp8 path (mv_fp8.hip)

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void fde_encode_kernel(EncArgs a) {
     }
     __syncthreads();
     const bool valid = p0 + lane < nr;
-    for (int r = wave; r < a.R; r += 4) {
+    for (int r = blockIdx.y * 4 + wave; r < a.R; r += 4 * gridDim.y) {
       // ---- SimHash: NS fmaf chains over k ascending
       float sk[kMaxNS];
 #pragma unroll
@@ -159,9 +159,13 @@ __global__ __launch_bounds__(256) void fde_encode_kernel(EncArgs a) {
     }
   }
   __syncthreads();
-  // ---- finish: AVERAGE for documents, write fp32 / bf16, inverse norm of the bf16 image
+  // ---- finish: AVERAGE for documents, write fp32 / bf16, inverse norm of the bf16 image.
+  // With the repetitions split over blockIdx.y (latency form used for the single query page) a block writes only
+  // the slices of its own repetitions; the norm is then not produced (queries do not need it).
   float nn = 0.0f;
+  const int rep_elems = NP * a.PD;
   for (int i = threadIdx.x; i < (int)a.out_dim; i += 256) {
+    if (gridDim.y > 1 && ((i / rep_elems) >> 2) % (int)gridDim.y != (int)blockIdx.y) continue;
     float v = acc[i];
     if (!a.is_query) {
       const int n = cnt[i / a.PD];
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256) void fde_encode_kernel(EncArgs a) {
     const float vb = bf16_to_f32(h);
     nn += vb * vb;
   }
-  if (a.out_inv_norm) {
+  if (a.out_inv_norm && gridDim.y == 1) {
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) nn += __shfl_xor(nn, s);
     if (lane == 0) red[wave] = nn;
@@ -293,6 +297,95 @@ __global__ __launch_bounds__(512) void fde_scan_lds_kernel(ScanArgs a, int pages
 #pragma unroll
     for (int sft = 1; sft < 64; sft <<= 1) t += __shfl_xor(t, sft);
     if (lane == 0) a.scores[p] = a.inv_norm ? t * a.inv_norm[p] : t;
+  }
+}
+
+// v2 coarse scan: a 256-thread workgroup walks pages TOGETHER (wave w owns 1 KiB chunks w, w+4, ... of every page),
+// so the number of concurrent DRAM streams is the number of workgroups, not waves, and consecutive workgroups read
+// consecutive 20 KiB pages.  Each wave keeps only its quarter of the query FDE in registers (CH x 8 floats), and two
+// pages of loads in flight (double buffer).  Per-page partial sums are reduced inside the wave with DPP row rotates +
+// readlane, parked in LDS, and combined in a fixed order (deterministic) once per batch of 16 pages.
+template <int CTRL>
+__device__ __forceinline__ float fde_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+template <int CH>  // out_dim = CH * 2048
+__global__ __launch_bounds__(256) void fde_scan_coop_kernel(ScanArgs a) {
+  constexpr int NB = 16;
+  __shared__ float part[2][NB][4];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t G = gridDim.x, b = blockIdx.x;
+  if (b >= a.n) return;
+  const int64_t n_my = (a.n - b + G - 1) / G;
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+  float q[CH][8];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const float* qp = a.q + (size_t)(wave + 4 * c) * 512 + lane * 8;
+    const float4 lo = *reinterpret_cast<const float4*>(qp);
+    const float4 hi = *reinterpret_cast<const float4*>(qp + 4);
+    q[c][0] = lo.x; q[c][1] = lo.y; q[c][2] = lo.z; q[c][3] = lo.w;
+    q[c][4] = hi.x; q[c][5] = hi.y; q[c][6] = hi.z; q[c][7] = hi.w;
+  }
+
+  auto load = [&](u32x4 (&v)[CH], int64_t i) {
+    const u32x4* row = reinterpret_cast<const u32x4*>(a.fde + (b + i * G) * (int64_t)a.out_dim) + wave * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) v[c] = row[c * 256];
+  };
+  auto dot = [&](const u32x4 (&v)[CH]) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc[k] = __builtin_fmaf(__uint_as_float(v[c][k] << 16), q[c][2 * k], acc[k]);
+        acc[k] = __builtin_fmaf(__uint_as_float(v[c][k] & 0xffff0000u), q[c][2 * k + 1], acc[k]);
+      }
+    float t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    t += fde_dpp<0x128>(t);  // row_ror:8
+    t += fde_dpp<0x124>(t);
+    t += fde_dpp<0x122>(t);
+    t += fde_dpp<0x121>(t);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 48));
+    return (r0 + r1) + (r2 + r3);
+  };
+  auto finalize = [&](int64_t k) {  // wave 0: pages k*NB .. of this workgroup
+    const int64_t ii = k * NB + lane;
+    if (wave == 0 && lane < NB && ii < n_my) {
+      const int64_t p = b + ii * G;
+      bool m = false;
+      if (a.doc_ord) {
+        const int32_t o = a.doc_ord[p];
+        m = o < 0 || (a.allow && ((int64_t)o >= a.n_allow_bits || ((a.allow[o >> 5] >> (o & 31)) & 1u) == 0u));
+      }
+      const float* pp = part[k & 1][lane];
+      const float t = (pp[0] + pp[1]) + (pp[2] + pp[3]);
+      a.scores[p] = m ? -INFINITY : (a.inv_norm ? t * a.inv_norm[p] : t);
+    }
+  };
+
+  u32x4 va[CH], vb[CH];
+  load(va, 0);
+  for (int64_t i = 0; i < n_my; i += 2) {
+    if (i + 1 < n_my) load(vb, i + 1);
+    const float ta = dot(va);
+    if (lane == 0) part[(i / NB) & 1][i % NB][wave] = ta;
+    if (i + 2 < n_my) load(va, i + 2);
+    if (i + 1 < n_my) {
+      const float tb = dot(vb);
+      if (lane == 0) part[((i + 1) / NB) & 1][(i + 1) % NB][wave] = tb;
+    }
+    if ((i + 2) % NB == 0 || i + 2 >= n_my) {
+      __syncthreads();
+      finalize(i / NB);
+    }
   }
 }
 
@@ -424,7 +517,9 @@ int launch_fde_encode(const FdeTables& t, const FdeEncodeArgs& a, hipStream_t s)
   }
   MV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fde_encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)lds));
-  hipLaunchKernelGGL(fde_encode_kernel, dim3((unsigned)a.n_pages), dim3(256), lds, s, k);
+  // few pages (the query): split the repetitions over blockIdx.y so each wave runs one repetition (latency form)
+  const unsigned ysplit = (a.n_pages <= 8 && !a.out_inv_norm && R >= 8) ? (unsigned)((R + 3) / 4) : 1u;
+  hipLaunchKernelGGL(fde_encode_kernel, dim3((unsigned)a.n_pages, ysplit), dim3(256), lds, s, k);
   MV_HIP(hipGetLastError());
   return MV_OK;
 }
@@ -443,8 +538,17 @@ int launch_fde_scan(const FdeScanArgs& a, int variant, hipStream_t s) {
   if (a.n <= 0) return MV_OK;
   ScanArgs k{a.fde, a.inv_norm, a.doc_ord, a.allow, a.n_allow_bits, a.q, a.scores, a.n, (int32_t)a.out_dim};
   const int grid = 256 * 2;  // 2 blocks/CU x 4 waves, persistent
-  if (variant < 0) variant = 1;
-  if (a.out_dim == 10240 && variant == 1) {
+  if (variant < 0) variant = 0;  // measured: 6.87 TB/s (wave per page, nt loads) vs 6.1 for the LDS / cooperative forms
+  if (variant == 2 && a.out_dim % 2048 == 0 && a.out_dim / 2048 <= 5 && a.out_dim >= 2048) {
+    const int wg = 256 * 4;  // 4 workgroups per CU, persistent
+    switch ((int)(a.out_dim / 2048)) {
+      case 1: hipLaunchKernelGGL((fde_scan_coop_kernel<1>), dim3(wg), dim3(256), 0, s, k); break;
+      case 2: hipLaunchKernelGGL((fde_scan_coop_kernel<2>), dim3(wg), dim3(256), 0, s, k); break;
+      case 3: hipLaunchKernelGGL((fde_scan_coop_kernel<3>), dim3(wg), dim3(256), 0, s, k); break;
+      case 4: hipLaunchKernelGGL((fde_scan_coop_kernel<4>), dim3(wg), dim3(256), 0, s, k); break;
+      default: hipLaunchKernelGGL((fde_scan_coop_kernel<5>), dim3(wg), dim3(256), 0, s, k); break;
+    }
+  } else if (a.out_dim == 10240 && variant == 1) {
     int rc = launch_fde_scan_lds<20>(k, s);
     if (rc) return rc;
   } else if (a.out_dim == 5120 && variant == 1) {

@@ -25,6 +25,7 @@
 //      ds_read_b128 fragments, one wave per page
 //   3  as 2 with four waves per page
 //   4/5  as 0/1 with non-temporal loads
+//   6/7  as 3/2 with non-temporal LDS-DMA
 #include <algorithm>
 
 #include "mv_common.h"
@@ -215,7 +216,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int MT, int WPP, int D>
+template <int MT, int WPP, int D, bool NT = false>
 __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
   // one __shared__ object only (a second one makes hipcc drain vmcnt before every ds_read)
   __shared__ __attribute__((aligned(16))) char lds[4 * D * kTileBytes + 1024];
@@ -268,18 +269,33 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
     const uint32_t slot = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + (it % D) * kTileBytes));
     uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %5\n\t"
-        "s_nop 4\n\t"
-        "global_load_lds_dwordx4 %1, %6\n\t"
-        "global_load_lds_dwordx4 %2, %6 offset:1024\n\t"
-        "global_load_lds_dwordx4 %3, %6 offset:2048\n\t"
-        "global_load_lds_dwordx4 %4, %6 offset:3072\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(src_off[0]), "v"(src_off[1]), "v"(src_off[2]), "v"(src_off[3]), "s"(slot), "s"(tpu)
-        : "memory");
+    if (NT) {  // non-temporal: the page stream is read once; do not let it displace the query / metadata in L2
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %5\n\t"
+          "s_nop 4\n\t"
+          "global_load_lds_dwordx4 %1, %6 nt\n\t"
+          "global_load_lds_dwordx4 %2, %6 offset:1024 nt\n\t"
+          "global_load_lds_dwordx4 %3, %6 offset:2048 nt\n\t"
+          "global_load_lds_dwordx4 %4, %6 offset:3072 nt\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src_off[0]), "v"(src_off[1]), "v"(src_off[2]), "v"(src_off[3]), "s"(slot), "s"(tpu)
+          : "memory");
+    } else {
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %5\n\t"
+          "s_nop 4\n\t"
+          "global_load_lds_dwordx4 %1, %6\n\t"
+          "global_load_lds_dwordx4 %2, %6 offset:1024\n\t"
+          "global_load_lds_dwordx4 %3, %6 offset:2048\n\t"
+          "global_load_lds_dwordx4 %4, %6 offset:3072\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src_off[0]), "v"(src_off[1]), "v"(src_off[2]), "v"(src_off[3]), "s"(slot), "s"(tpu)
+          : "memory");
+    }
   };
 
 #pragma unroll
@@ -344,6 +360,8 @@ int launch_mt(const KArgs& k0, int variant, hipStream_t s) {
       case 3: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4>), dim3((unsigned)n), block, 0, s, k); break;
       case 4: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 1, true>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
       case 5: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 4, true>), dim3((unsigned)n), block, 0, s, k); break;
+      case 6: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true>), dim3((unsigned)n), block, 0, s, k); break;
+      case 7: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 1, 4, true>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
       default: set_error("unknown maxsim variant %d", variant); return MV_ERR_INVALID;
     }
   }
@@ -353,10 +371,11 @@ int launch_mt(const KArgs& k0, int variant, hipStream_t s) {
 
 }  // namespace
 
-// Measured on MI355X (profiles/variants_r1.json, 100k pages x 1024 patches, Q=32): LDS-DMA ring with four
-// waves per page 6.47 TB/s > direct loads 6.2-6.4 TB/s > non-temporal direct 5.9-6.0 TB/s.  Short pages
-// (< 16 tiles) cannot feed four waves, so they take the wave-per-page form.
-int maxsim_default_variant(int stride_rows) { return stride_rows >= 256 ? 3 : 2; }
+// Measured on MI355X (profiles/r1/variants_r1*.json, 100-200k pages x 1024 patches, Q=32): non-temporal LDS-DMA ring
+// with four waves per page 7.34 TB/s > the same with one wave per page 7.08 > default-policy LDS-DMA 6.53 / 6.37 >
+// direct loads 6.2-6.4 TB/s > non-temporal direct 5.9-6.0 TB/s.  Short pages (< 16 tiles) cannot feed four waves,
+// so they take the wave-per-page form.
+int maxsim_default_variant(int stride_rows) { return stride_rows >= 256 ? 6 : 7; }
 
 const char* maxsim_variant_name(int v) {
   switch (v) {
@@ -366,6 +385,8 @@ const char* maxsim_variant_name(int v) {
     case 3: return "ldsdma_wpp4_d4";
     case 4: return "direct_wpp1_nt";
     case 5: return "direct_wpp4_nt";
+    case 6: return "ldsdma_wpp4_d4_nt";
+    case 7: return "ldsdma_wpp1_d4_nt";
     default: return "?";
   }
 }

@@ -58,7 +58,7 @@ def test_synth_generator_bit_identical_to_oracle(mv):
 
 
 # ------------------------------------------------------------------ float MaxSim
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_float_maxsim_all_variants_small(mv, variant):
     from morphik_core_amd import _lib
 
@@ -90,7 +90,7 @@ def test_float_maxsim_1024_patches_query_lengths(mv, nq):
     ix.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7])
 def test_float_maxsim_ragged_pages(mv, variant):
     """Ragged pages through mv_index_add: rows beyond n_rows never count (pad_to = 0)."""
     from morphik_core_amd import _lib
@@ -264,7 +264,7 @@ def test_hamming_batch_matches_reference_golden(mv, golden_dir):
         hamming_batch(b"ab", [b"abc"])
 
 
-BINARY_VARIANTS = [0, 1]  # 0 = popcount on the VALU, 1 = FP4 MFMA (default); identical integers required
+BINARY_VARIANTS = [0, 1, 2, 3, 4]  # 0 = popcount on the VALU, 1..4 = FP4 MFMA forms (4 = default); identical integers required
 
 
 def _set_binary_variant(ix, variant):
@@ -338,8 +338,9 @@ def test_binary_variants_agree_with_filter_and_tombstones_midsize(mv):
     for v in BINARY_VARIANTS:
         _set_binary_variant(ix, v)
         outs.append((ix.score_all(q, mode="binary", allow=allow), ix.query(q, 10, mode="binary", allow=allow)))
-    assert np.array_equal(outs[0][0], outs[1][0])
-    assert outs[0][1][1].tolist() == outs[1][1][1].tolist() and outs[0][1][0].tolist() == outs[1][1][0].tolist()
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][0], o[0])
+        assert outs[0][1][1].tolist() == o[1][1].tolist() and outs[0][1][0].tolist() == o[1][0].tolist()
     assert np.isinf(outs[0][0]).sum() > n // 4  # the filter really masked pages
     ix.close()
 
@@ -428,7 +429,7 @@ def test_fp8_maxsim_matches_oracle_on_same_codes(mv, stride, nrows):
         np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-6)
         # quality: fp8 scores track the bf16 scores (3 mantissa bits on the page side; averaged over 128 dims)
         ref = ix.score_all(q, mode="float")
-        assert np.max(np.abs(got - ref) / np.abs(ref)) < 3e-2
+        assert np.all(np.abs(got - ref) <= 3e-2 * np.abs(ref) + 5e-3 * nq)
     ix.close()
 
 

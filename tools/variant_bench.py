@@ -62,8 +62,12 @@ def main():
         q = synth_rows(4321, 0, 32)
         runs = [("binary_v0_popcount", "binary", a.patches * 16, (_lib.MV_OPT_BINARY_VARIANT, 0)),
                 ("binary_v1_fp4mfma", "binary", a.patches * 16, (_lib.MV_OPT_BINARY_VARIANT, 1)),
+                ("binary_v2_fp4mfma_lean_d8", "binary", a.patches * 16, (_lib.MV_OPT_BINARY_VARIANT, 2)),
+                ("binary_v3_fp4mfma_lean_d16", "binary", a.patches * 16, (_lib.MV_OPT_BINARY_VARIANT, 3)),
+                ("binary_v4_fp4mfma_lean_d4", "binary", a.patches * 16, (_lib.MV_OPT_BINARY_VARIANT, 4)),
                 ("fde_v0_regs", "fde", 10240 * 2, (_lib.MV_OPT_FDE_SCAN_VARIANT, 0)),
                 ("fde_v1_lds", "fde", 10240 * 2, (_lib.MV_OPT_FDE_SCAN_VARIANT, 1)),
+                ("fde_v2_coop", "fde", 10240 * 2, (_lib.MV_OPT_FDE_SCAN_VARIANT, 2)),
                 ("float_fp8", "float_fp8", a.patches * 128, None),
                 ("float_bf16", "float", a.patches * 256, None)]
         for name, mode, per_page, opt in runs:
