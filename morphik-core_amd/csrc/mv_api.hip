@@ -94,6 +94,8 @@ struct mv_index {
   uint8_t* d_q8hi = nullptr;   // e4m3 query rows, two-term split (fp8 scan)
   uint8_t* d_q8lo = nullptr;
   float* d_q8fac = nullptr;    // 2^-s per query row
+  uint16_t* d_bq = nullptr;    // [512][128] bf16 query block of the batched scan
+  float* d_bscores = nullptr;  // [32][capacity] per-query score vectors of the batched scan (lazily allocated)
   float* d_qfde = nullptr;
   int64_t* d_qoff = nullptr;   // [2] row offsets for the query "page"
   uint32_t* d_allow = nullptr;
@@ -558,7 +560,7 @@ void mv_index_destroy(mv_index* ix) {
   if (!ix) return;
   DeviceGuard g(ix->cfg.device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-  void* ptrs[] = {ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
+  void* ptrs[] = {ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
                   ix->d_topk_ws, ix->d_q, ix->d_qf32, ix->d_qbits, ix->d_qpop, ix->d_qfde, ix->d_qoff, ix->d_allow, ix->d_out_s,
                   ix->d_out_id, ix->d_cand, ix->d_cand_scores};
   for (void* p : ptrs)
@@ -599,7 +601,7 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); rc = MV_ERR_HIP; }
   for (auto& e : ix->ev)
     if (!rc && hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); rc = MV_ERR_HIP; }
-  if (cfg->flags & MV_WITH_FLOAT) alloc((void**)&ix->slab, rows * kRowBytes, "bf16 page slab");
+  if (cfg->flags & MV_WITH_FLOAT) alloc((void**)&ix->slab, rows * kRowBytes + 16384, "bf16 page slab");  // +16 KiB: the batched scan DMAs whole 16 KiB chunks
   if (cfg->flags & MV_WITH_FP8) {
     alloc((void**)&ix->slab8, rows * kDim + 4096, "fp8 page slab");  // +4 KiB: the scan DMAs whole 4 KiB pieces
     alloc((void**)&ix->inv_scale8, (size_t)cap * 4, "fp8 page scales");
@@ -964,6 +966,94 @@ int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_r
   if (k < 1 || !d_out_scores || !d_out_ids) { set_error("mv_query_topk_device: k >= 1 and device buffers required"); return MV_ERR_INVALID; }
   return query_common(ix, q, q_dtype, n_q_rows, k, mode, allow_bits, n_allow_words, nullptr, nullptr, nullptr, d_out_scores,
                       d_out_ids, stream, stats);
+}
+
+int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, int32_t k, int mode,
+                        const uint32_t* allow_bits, int64_t n_allow_words, float* out_scores, int64_t* out_ids,
+                        int32_t* out_n, mv_query_stats* stats) {
+  if (!ix || !q || n_queries < 1 || n_q_rows < 1 || k < 0 || !out_n || (k > 0 && (!out_scores || !out_ids))) { set_error("mv_query_topk_batch: bad argument"); return MV_ERR_INVALID; }
+  if (q_dtype != MV_F32 && q_dtype != MV_BF16) { set_error("bad query dtype %d", q_dtype); return MV_ERR_INVALID; }
+  const size_t esz = q_dtype == MV_F32 ? 4 : 2;
+  const int rpq = ((n_q_rows + 15) / 16) * 16;
+  mv_query_stats total{};
+  // anything but the exact float scan (and queries longer than one 512-row group) runs query by query
+  if (mode != MV_MODE_FLOAT || rpq > 512 || k > kTopkMaxDeviceK || k == 0) {
+    for (int32_t b = 0; b < n_queries; ++b) {
+      mv_query_stats st{};
+      int rc = query_common(ix, (const char*)q + (size_t)b * n_q_rows * kDim * esz, q_dtype, n_q_rows, k, mode, allow_bits, n_allow_words,
+                            out_scores ? out_scores + (size_t)b * k : nullptr, out_ids ? out_ids + (size_t)b * k : nullptr, out_n + b, nullptr,
+                            nullptr, nullptr, stats ? &st : nullptr);
+      if (rc) return rc;
+      total.score_kernel_ms += st.score_kernel_ms; total.topk_ms += st.topk_ms; total.total_device_ms += st.total_device_ms;
+      total.score_launches += st.score_launches; total.pages_scored += st.pages_scored; total.bytes_scanned += st.bytes_scanned;
+    }
+    if (stats) *stats = total;
+    return MV_OK;
+  }
+  if (!(ix->cfg.flags & MV_WITH_FLOAT)) { set_error("index has no float slab (MV_WITH_FLOAT)"); return MV_ERR_STATE; }
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->cfg.device);
+  for (int32_t b = 0; b < n_queries; ++b) out_n[b] = 0;
+  if (ix->size == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return MV_OK; }
+  const int group = std::min(512 / rpq, 32);
+  if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)512 * kRowBytes));
+  if (!ix->d_bscores) {
+    hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->cfg.capacity_pages * 4);
+    if (e != hipSuccess) { ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->cfg.capacity_pages * 4); return MV_ERR_NOMEM; }
+  }
+  const uint32_t* d_allow = nullptr;
+  int rc = upload_allow(ix, allow_bits, n_allow_words, &d_allow);
+  if (rc) return rc;
+  const bool need_meta = ix->tombstones || d_allow != nullptr;
+  const int64_t n = ix->size;
+  int64_t pages = 0;
+  const int64_t rows = stats ? count_allowed_rows(ix, allow_bits, n_allow_words, &pages) : 0;
+  std::vector<uint16_t> hq((size_t)512 * kDim);
+  std::vector<float> hs((size_t)k);
+  std::vector<int64_t> hi((size_t)k);
+  for (int32_t b0 = 0; b0 < n_queries; b0 += group) {
+    const int nb = std::min(group, n_queries - b0);
+    std::fill(hq.begin(), hq.end(), (uint16_t)0);
+    for (int b = 0; b < nb; ++b) {
+      const char* src = (const char*)q + (size_t)(b0 + b) * n_q_rows * kDim * esz;
+      uint16_t* dst = hq.data() + (size_t)b * rpq * kDim;
+      if (q_dtype == MV_BF16) memcpy(dst, src, (size_t)n_q_rows * kRowBytes);
+      else for (size_t i = 0; i < (size_t)n_q_rows * kDim; ++i) dst[i] = host_f32_to_bf16(((const float*)src)[i]);
+    }
+    MV_HIP(hipMemcpyAsync(ix->d_bq, hq.data(), hq.size() * 2, hipMemcpyHostToDevice, ix->stream));
+    MV_HIP(hipEventRecord(ix->ev[0], ix->stream));
+    BatchArgs a{};
+    a.slab = ix->slab; a.n_rows = ix->ragged ? ix->d_n_rows : nullptr; a.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
+    a.allow = d_allow; a.n_allow_bits = n_allow_words * 32; a.q = ix->d_bq; a.scores = ix->d_bscores; a.n = n;
+    a.score_stride = ix->cfg.capacity_pages; a.stride = ix->cfg.stride_rows; a.n_queries = nb; a.rows_per_query = rpq;
+    rc = launch_maxsim_batch(a, ix->stream);
+    if (rc) return rc;
+    MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
+    for (int b = 0; b < nb; ++b) {
+      rc = launch_topk(ix->d_bscores + (size_t)b * ix->cfg.capacity_pages, n, k, nullptr, ix->cfg.id_base, ix->d_topk_ws, ix->d_out_s,
+                       ix->d_out_id, ix->stream);
+      if (rc) return rc;
+      MV_HIP(hipMemcpyAsync(hs.data(), ix->d_out_s, (size_t)k * 4, hipMemcpyDeviceToHost, ix->stream));
+      MV_HIP(hipMemcpyAsync(hi.data(), ix->d_out_id, (size_t)k * 8, hipMemcpyDeviceToHost, ix->stream));
+      MV_HIP(hipStreamSynchronize(ix->stream));
+      int32_t m = 0;
+      while (m < k && hi[m] >= 0) ++m;
+      memcpy(out_scores + (size_t)(b0 + b) * k, hs.data(), (size_t)m * 4);
+      memcpy(out_ids + (size_t)(b0 + b) * k, hi.data(), (size_t)m * 8);
+      out_n[b0 + b] = m;
+    }
+    MV_HIP(hipEventRecord(ix->ev[2], ix->stream));
+    if (stats) {
+      MV_HIP(hipEventSynchronize(ix->ev[2]));
+      float ms_scan = 0, ms_sel = 0;
+      MV_HIP(hipEventElapsedTime(&ms_scan, ix->ev[0], ix->ev[1]));
+      MV_HIP(hipEventElapsedTime(&ms_sel, ix->ev[1], ix->ev[2]));
+      total.score_kernel_ms += ms_scan; total.topk_ms += ms_sel; total.total_device_ms += ms_scan + ms_sel;
+      total.score_launches += 1; total.pages_scored += pages * nb; total.bytes_scanned += rows * (int64_t)kRowBytes;
+    }
+  }
+  if (stats) *stats = total;
+  return MV_OK;
 }
 
 int mv_score_all(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int mode, const uint32_t* allow_bits,

@@ -1,0 +1,246 @@
+// mv_batch.hip -- float MaxSim of a BATCH of queries in one pass over the bf16 page slab.
+//
+// Same scoring rule as mv_maxsim.hip (score_multi_vector, core/vector_store/fast_multivector_store.py:553-555; its
+// first argument is already a LIST of queries: einsum("bnd,csd->bcns")), for B queries at once.  One query is
+// HBM-bound (32 flop/byte); every extra query re-uses the page bytes already on the CU, so B queries cost one slab
+// read and the scan moves towards the bf16 MFMA roof: M = B x Q query rows against each 16-patch tile.  At
+// M = 512 (16 queries of 32 tokens) a page is 8192 MFMAs (134 MFLOP) per 262 144 B = 512 flop/byte, past the
+// ~315 flop/byte ridge.
+//
+// Work split (the opposite of the single-query kernel): the M rows are split over the four waves of a workgroup
+// (MTW 16-row tiles per wave, A fragments resident in VGPRs for the whole launch), and every wave multiplies EVERY
+// patch tile -- so page tiles are staged ONCE per workgroup in LDS and read by all four waves:
+//   * ring of S chunks x 16 KiB (4 tiles); wave w DMAs tile w of each chunk (4 x global_load_lds_dwordx4, the
+//     XOR-swizzled image of mv_maxsim.hip), non-temporal;
+//   * per chunk: counted s_waitcnt vmcnt for the own DMA, ONE s_barrier (chunk landed for everyone + previous chunk
+//     released), issue of chunk c+S-1, then 4 tiles x (4 ds_read_b128 + MTW x 4 MFMA + MTW x 4 v_max);
+//   * the MFMAs of a tile are issued K-quarter-major over MTW independent accumulators (no dependent back-to-back
+//     MFMA on one accumulator).
+// Workgroups are persistent (grid = 2 per CU): the query fragments are loaded once, pages are taken round-robin.
+// Per page the row maxima go through LDS and thread b sums the rows of query b: scores[b][page].
+#include <algorithm>
+
+#include "mv_common.h"
+
+namespace mv {
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kChunkTiles = 4;
+constexpr int kChunkBytes = kChunkTiles * kTileBytes;  // 16 KiB
+
+struct BKArgs {
+  const char* slab;
+  const int32_t* n_rows;
+  const int32_t* doc_ord;
+  const uint32_t* allow;
+  int64_t n_allow_bits;
+  const uint16_t* q;  // [4 * MTW * 16][128] bf16, zero padded
+  float* scores;      // [n_queries][score_stride]
+  int64_t n;
+  int64_t score_stride;
+  int64_t page0;
+  int32_t stride;
+  int32_t n_queries;
+  int32_t rows_per_query;  // multiple of 16
+};
+
+__device__ __forceinline__ bool bk_masked(const BKArgs& a, int64_t page) {
+  if (!a.doc_ord) return false;
+  const int32_t o = a.doc_ord[page];
+  if (o < 0) return true;
+  if (!a.allow) return false;
+  if ((int64_t)o >= a.n_allow_bits) return true;
+  return ((a.allow[o >> 5] >> (o & 31)) & 1u) == 0u;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float bk_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float bk_group16_max(float v) {
+  v = fmaxf(v, bk_dpp<0x128>(v));
+  v = fmaxf(v, bk_dpp<0x124>(v));
+  v = fmaxf(v, bk_dpp<0x122>(v));
+  v = fmaxf(v, bk_dpp<0x121>(v));
+  return v;
+}
+
+template <int N>
+__device__ __forceinline__ void bk_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void bk_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int MTW, int S>
+__global__ __launch_bounds__(256, 2) void maxsim_batch_kernel(BKArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[S * kChunkBytes + 64 * MTW * 4];
+  float* red = reinterpret_cast<float*>(lds + S * kChunkBytes);  // [64 * MTW] row maxima of the current page
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+
+  // query fragments of this wave's MTW row tiles (resident for the whole launch)
+  bf16x8 qa[MTW][4];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      qa[m][j] = *reinterpret_cast<const bf16x8*>(a.q + ((size_t)(wave * MTW + m) * 16 + r) * kDim + j * 32 + g * 8);
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(qa[m][j]));
+
+  // DMA source offsets (as mv_maxsim.hip): instruction i covers rows 4i..4i+3 of the tile
+  int src_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int w = i * 4 + (lane >> 4);
+    src_off[i] = w * kRowBytes + (((lane & 15) ^ w) << 4) - i * 1024;
+  }
+  int rd_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rd_off[j] = r * kRowBytes + (((j * 4 + g) ^ r) << 4);
+
+  for (int64_t item = blockIdx.x; item < a.n; item += gridDim.x) {
+    const int64_t page = a.page0 + item;
+    if (bk_masked(a, page)) {  // block-uniform
+      if ((int)threadIdx.x < a.n_queries) a.scores[(size_t)threadIdx.x * a.score_stride + item] = -INFINITY;
+      continue;
+    }
+    const int nr = a.n_rows ? a.n_rows[page] : a.stride;
+    if (nr <= 0) {
+      if ((int)threadIdx.x < a.n_queries) a.scores[(size_t)threadIdx.x * a.score_stride + item] = 0.0f;
+      continue;
+    }
+    const int ntiles = (nr + kTileRows - 1) / kTileRows;
+    const int nchunks = (ntiles + kChunkTiles - 1) / kChunkTiles;
+    const char* pbase = a.slab + (size_t)page * (size_t)a.stride * kRowBytes;
+
+    // wave w moves tile w of chunk c (always issued: the slab is padded, rows past n_rows are never consumed)
+    auto issue = [&](int c) {
+      const char* tp = pbase + (size_t)(c * kChunkTiles + wave) * kTileBytes;
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
+      const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
+      const uint64_t tpu = ((uint64_t)hi << 32) | lo;
+      const uint32_t slot = __builtin_amdgcn_readfirstlane(
+          (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + (c % S) * kChunkBytes + wave * kTileBytes));
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %5\n\t"
+          "s_nop 4\n\t"
+          "global_load_lds_dwordx4 %1, %6 nt\n\t"
+          "global_load_lds_dwordx4 %2, %6 offset:1024 nt\n\t"
+          "global_load_lds_dwordx4 %3, %6 offset:2048 nt\n\t"
+          "global_load_lds_dwordx4 %4, %6 offset:3072 nt\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src_off[0]), "v"(src_off[1]), "v"(src_off[2]), "v"(src_off[3]), "s"(slot), "s"(tpu)
+          : "memory");
+    };
+
+#pragma unroll
+    for (int c = 0; c < S - 1; ++c)
+      if (c < nchunks) issue(c);
+
+    f32x4 mx[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) mx[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+
+    for (int c = 0; c < nchunks; ++c) {
+      // own DMA of chunk c landed: chunks c+1 .. min(c+S-2, nchunks-1) may stay in flight
+      const int ahead = min(S - 2, nchunks - 1 - c);
+      if (ahead >= 2) bk_wait_vmcnt<8>();
+      else if (ahead == 1) bk_wait_vmcnt<4>();
+      else bk_wait_vmcnt<0>();
+      bk_barrier();  // chunk c visible to all four waves; everyone is done reading chunk c-1
+      if (c + S - 1 < nchunks) issue(c + S - 1);
+      const char* chunk = lds + (c % S) * kChunkBytes;
+#pragma unroll
+      for (int tt = 0; tt < kChunkTiles; ++tt) {
+        const int t = c * kChunkTiles + tt;
+        if (t < ntiles) {  // block-uniform
+          bf16x8 b[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(chunk + tt * kTileBytes + rd_off[j]);
+          f32x4 acc[MTW];
+#pragma unroll
+          for (int m = 0; m < MTW; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[m][j], b[j], acc[m], 0, 0, 0);
+          if ((t + 1) * kTileRows > nr) {  // partial last tile: mask the columns past n_rows
+            const bool col_valid = t * kTileRows + r < nr;
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+              if (!col_valid) acc[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+          }
+#pragma unroll
+          for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mx[m][i] = fmaxf(mx[m][i], acc[m][i]);
+        }
+      }
+    }
+
+    // row maxima -> LDS -> one thread per query sums its rows
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = bk_group16_max(mx[m][i]);
+        if (r == 0) red[(wave * MTW + m) * 16 + g * 4 + i] = v;
+      }
+    __syncthreads();
+    if ((int)threadIdx.x < a.n_queries) {
+      const float* rp = red + (size_t)threadIdx.x * a.rows_per_query;
+      float sum = 0.f;
+      for (int i = 0; i < a.rows_per_query; ++i) sum += rp[i];
+      a.scores[(size_t)threadIdx.x * a.score_stride + item] = sum;
+    }
+    // the next page's first bk_barrier() orders these reads of red[] before its rewrite
+  }
+}
+
+template <int MTW>
+int launch_batch_mtw(const BKArgs& k, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((maxsim_batch_kernel<MTW, 4>), dim3((unsigned)grid), dim3(256), 0, s, k);
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
+}  // namespace
+
+int batch_rows_capacity() { return 512; }
+
+int launch_maxsim_batch(const BatchArgs& a, hipStream_t s) {
+  if (a.n <= 0 || a.n_queries <= 0) return MV_OK;
+  if (a.rows_per_query < 16 || a.rows_per_query % 16) { set_error("batch scan: rows_per_query must be a positive multiple of 16"); return MV_ERR_INVALID; }
+  const int rows = a.n_queries * a.rows_per_query;
+  if (rows > 512 || a.n_queries > 256) { set_error("batch scan: %d query rows exceed the 512-row group", rows); return MV_ERR_INVALID; }
+  BKArgs k{reinterpret_cast<const char*>(a.slab), a.n_rows, a.doc_ord, a.allow, a.n_allow_bits, a.q, a.scores, a.n,
+           a.score_stride, 0, a.stride, a.n_queries, a.rows_per_query};
+  static int ncu = 0;  // CUs of the (single-architecture) node's GPUs, queried once
+  if (ncu == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+    else ncu = 256;
+  }
+  const int grid = (int)std::min<int64_t>(a.n, (int64_t)ncu * 2);
+  const int mtw = rows <= 64 ? 1 : rows <= 128 ? 2 : rows <= 256 ? 4 : 8;
+  switch (mtw) {
+    case 1: return launch_batch_mtw<1>(k, grid, s);
+    case 2: return launch_batch_mtw<2>(k, grid, s);
+    case 4: return launch_batch_mtw<4>(k, grid, s);
+    default: return launch_batch_mtw<8>(k, grid, s);
+  }
+}
+
+}  // namespace mv

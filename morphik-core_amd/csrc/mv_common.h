@@ -44,6 +44,23 @@ int launch_maxsim_bf16(const MaxsimArgs& a, int variant, hipStream_t s);
 const char* maxsim_variant_name(int variant);
 int maxsim_default_variant(int stride_rows);
 
+// ---------------------------------------------------------------- batched float MaxSim (mv_batch.hip)
+struct BatchArgs {
+  const uint16_t* slab;
+  const int32_t* n_rows;
+  const int32_t* doc_ord;
+  const uint32_t* allow;
+  int64_t n_allow_bits;
+  const uint16_t* q;        // [512][128] bf16: query b occupies rows [b*rows_per_query, (b+1)*rows_per_query), zero padded
+  float* scores;            // [n_queries][score_stride]
+  int64_t n;                // pages 0..n-1
+  int64_t score_stride;
+  int32_t stride;
+  int32_t n_queries;
+  int32_t rows_per_query;   // multiple of 16; n_queries * rows_per_query <= 512
+};
+int launch_maxsim_batch(const BatchArgs& a, hipStream_t s);
+
 // ---------------------------------------------------------------- selection (mv_topk.hip)
 // keys: order-preserving 64-bit (score desc, local index asc). ws must hold topk_ws_bytes(n,k).
 size_t topk_ws_bytes(int64_t n, int32_t k);

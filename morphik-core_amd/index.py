@@ -239,6 +239,31 @@ class MvIndex:
         res = (scores[: n.value].copy(), ids[: n.value].copy())
         return res + (QueryStats.from_c(st),) if want_stats else res
 
+    def query_batch(self, queries: Sequence[Any], k: int, mode: str = "float", allow: Optional[np.ndarray] = None,
+                    want_stats: bool = False):
+        """Top-k of several queries in one slab pass.  -> list of (scores, ids) per query [, QueryStats].
+        Queries may have different lengths: they are zero-padded to the longest (a zero row contributes 0)."""
+        rows = [as_rows(q) for q in queries]
+        nmax = max(a.shape[0] for a, _ in rows)
+        code = MV_BF16 if all(c == MV_BF16 for _, c in rows) else MV_F32
+        blk = np.zeros((len(rows), nmax, 128), np.uint16 if code == MV_BF16 else np.float32)
+        for i, (a, c) in enumerate(rows):
+            blk[i, : a.shape[0]] = a if c == code else (a.astype(np.uint32) << 16).view(np.float32)
+        k = int(k)
+        scores = np.empty((len(rows), max(k, 1)), np.float32)
+        ids = np.empty((len(rows), max(k, 1)), np.int64)
+        n = np.zeros(len(rows), np.int32)
+        st = QueryStatsC()
+        ab = None if allow is None else np.ascontiguousarray(allow, dtype=np.uint32)
+        check(
+            lib().mv_query_topk_batch(
+                self._h, blk.ctypes.data, code, len(rows), nmax, k, MODES[mode], None if ab is None else ab.ctypes.data,
+                0 if ab is None else ab.size, scores.ctypes.data, ids.ctypes.data, n.ctypes.data, C.byref(st) if want_stats else None,
+            )
+        )
+        res = [(scores[i, : n[i]].copy(), ids[i, : n[i]].copy()) for i in range(len(rows))]
+        return (res, QueryStats.from_c(st)) if want_stats else res
+
     def query_device(self, q: Any, k: int, d_scores_ptr: int, d_ids_ptr: int, mode: str = "float", allow: Optional[np.ndarray] = None,
                      stream: int = 0, want_stats: bool = False) -> Optional[QueryStats]:
         """Top-k left in caller-provided DEVICE buffers (k floats / k int64), padded with (-inf, -1)."""

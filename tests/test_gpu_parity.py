@@ -398,6 +398,45 @@ def test_fde_coarse_scan_and_pipeline(mv):
     ix.close()
 
 
+# ------------------------------------------------------------------ batched queries (one slab pass, MFMA-bound form)
+@pytest.mark.parametrize("stride,nrows", [(1024, 1024), (1024, 1000), (208, 200), (64, 50), (16, 7)])
+def test_batched_queries_equal_single_queries_and_oracle(mv, stride, nrows):
+    from morphik_core_amd.index import allow_bitmap
+
+    n = 700 if stride < 1024 else 300
+    ix = _idx(mv, capacity_pages=n, stride_rows=stride)  # the last page ends the slab (16 KiB DMA pad)
+    ix.fill_synthetic(1234, 0, n, n_rows=nrows, pages_per_doc=3)
+    ix.remove_doc(5)
+    allow = allow_bitmap([d for d in range(n // 3 + 1) if d % 4 != 2])
+    pages = orc.bf16_to_f32(ix.read_pages(0, n)[:, :nrows])
+    for lens in ([32], [32, 32, 32], [32] * 16, [32] * 20, [20, 32, 1, 17], [64] * 8, [16] * 32, [48] * 11, [100, 30]):
+        qs = [orc.synth_rows(4321, 10 + j, 0, L) for j, L in enumerate(lens)]
+        for al in (None, allow):
+            got = ix.query_batch(qs, 7, allow=al)
+            assert len(got) == len(qs)
+            for q, (s, i) in zip(qs, got):
+                ws, wi = ix.query(q, 7, allow=al)
+                assert i.tolist() == wi.tolist()
+                np.testing.assert_allclose(s, ws, rtol=1e-5)
+        # against the oracle (no filter): exact float MaxSim per query
+        got = ix.query_batch(qs, 5)
+        for q, (s, i) in zip(qs[:3], got[:3]):
+            want = orc.maxsim_float_np(orc.bf16_to_f32(q), pages)
+            want[15:18] = -np.inf  # doc 5 was tombstoned (pages 15..17)
+            ws, wi = orc.topk(want, 5)
+            _assert_topk_matches(s, i, ws, wi)
+    # other modes are served query by query through the same entry point
+    ix.close()
+    ix = _idx(mv, capacity_pages=64, stride_rows=32, with_binary=True)
+    ix.fill_synthetic(1234, 0, 64)
+    qs = [orc.synth_rows(4321, j, 0, 32) for j in range(3)]
+    got = ix.query_batch(qs, 4, mode="binary")
+    for q, (s, i) in zip(qs, got):
+        ws, wi = ix.query(q, 4, mode="binary")
+        assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist()
+    ix.close()
+
+
 # ------------------------------------------------------------------ fp8 (e4m3) slab
 def test_fp8_quantizer_bit_exact_vs_oracle(mv):
     ix = _idx(mv, capacity_pages=40, stride_rows=64, with_fp8=True)
