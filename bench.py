@@ -77,6 +77,65 @@ def cpu_baseline(sample_pages_u16, q_u16, budget_s=20.0):
     }
 
 
+def aux_paths(args, device):
+    """Quick, separately sized measurements of the other hot-path kernels (same HIP-event method, a smaller
+    corpus with every slab enabled): sign-bit MaxSim (SQL max_sim semantics), fp8 slab, FDE coarse scan and the
+    batched-query MFMA form.  Reported next to the headline number, never mixed into `value`."""
+    from morphik_core_amd import synth
+    from morphik_core_amd.index import MvIndex, synth_rows
+
+    n = args.aux_pages
+    ix = MvIndex(capacity_pages=n, stride_rows=((args.patches + 15) // 16) * 16, device=device, with_float=True, with_binary=True,
+                 with_fde=True, with_fp8=True)
+    ix.fill_synthetic(synth.SEED_CORPUS, 0, n, n_rows=args.patches)
+    qs = [synth_rows(synth.SEED_QUERIES, qi, args.qtokens, device=device) for qi in range(N_QUERIES)]
+    spec = synth.planted_spec(qs, n, args.patches, n_ranks=N_PLANTED)
+    synth.plant_neighbours_any(ix, spec, synth.SEED_CORPUS, args.patches)
+    res = {"pages": n, "note": "kernel-only HIP-event times, median of 5; recall@10 against the planted exact top-10"}
+    per_page = {"binary": args.patches * 16, "float_fp8": args.patches * 128, "fde": 10240 * 2, "float": args.patches * 256}
+    for mode in ("binary", "float_fp8", "fde", "float"):
+        ms = []
+        for r in range(6):
+            _s, _i, st = ix.query(qs[r % N_QUERIES], K, mode=mode, want_stats=True)
+            if r:
+                ms.append(st.score_kernel_ms)
+        m = float(np.median(ms))
+        ent = {"kernel_ms": round(m, 4), "pages_per_s": round(n / m * 1e3, 1), "GBps": round(n * per_page[mode] / m / 1e6, 1),
+               "frac_hbm_8TBps": round(n * per_page[mode] / m / 1e6 / HBM_PEAK_GBPS, 4), "bytes_per_page": per_page[mode]}
+        if mode in ("float_fp8", "float"):
+            rec = []
+            for qi in range(N_QUERIES):
+                _s, ids = ix.query(qs[qi], K, mode=mode)
+                rec.append(synth.recall_at_k(ids.tolist(), [p for (qq, _r, p, _a, _b) in spec if qq == qi]))
+            ent["recall_at_10"] = float(np.mean(rec))
+        res[mode] = ent
+    # FDE coarse top-1000 -> exact rerank (configs[3] pipeline) : recall of the planted top-10
+    from morphik_core_amd import _lib as L
+
+    ix.set_option(L.MV_OPT_FDE_COARSE_N, 1000)
+    rec, ms = [], []
+    for qi in range(N_QUERIES):
+        _s, ids, st = ix.query(qs[qi], K, mode="fde_then_float", want_stats=True)
+        ms.append(st.total_device_ms)
+        rec.append(synth.recall_at_k(ids.tolist(), [p for (qq, _r, p, _a, _b) in spec if qq == qi]))
+    res["fde_top1000_then_float"] = {"device_ms": round(float(np.median(ms)), 4), "pages_per_s": round(n / float(np.median(ms)) * 1e3, 1),
+                                     "recall_at_10": float(np.mean(rec))}
+    # batched queries: B x 32 tokens per slab pass
+    res["batched_float"] = {}
+    for B in (4, 16):
+        ms = []
+        for r in range(4):
+            _o, st = ix.query_batch(qs[:B], K, want_stats=True)
+            if r:
+                ms.append(st.score_kernel_ms)
+        m = float(np.median(ms))
+        tf = 2.0 * B * args.qtokens * args.patches * 128 * n / m / 1e9
+        res["batched_float"][f"B{B}"] = {"kernel_ms": round(m, 4), "query_pages_per_s": round(B * n / m * 1e3, 1), "TFLOPs": round(tf, 1),
+                                         "frac_mfma_bf16_2500TF": round(tf / 2500.0, 4), "GBps": round(n * per_page["float"] / m / 1e6, 1)}
+    ix.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +148,11 @@ def main():
     ap.add_argument("--cpu-sample-pages", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--no-aux", action="store_true", help="skip the secondary kernels' quick measurements (aux_paths)")
+    ap.add_argument("--aux-pages", type=int, default=200_000)
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="collective backend for N>1 (nccl == RCCL; gloo + MV_BENCH_SINGLE_DEVICE=1 lets N ranks share one GPU to "
+                         "exercise the multi-rank path on a 1-GPU box -- a functional check, not a measurement)")
     args = ap.parse_args()
 
     import torch
@@ -103,11 +167,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the product path is HIP-only (no CPU fallback)")
+    single_device = os.environ.get("MV_BENCH_SINGLE_DEVICE") == "1"
+    if single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend="gloo")
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collective payloads live
 
     import morphik_core_amd as mca
     from morphik_core_amd import _lib, sharded, synth
@@ -119,6 +190,8 @@ def main():
     # ---- size the shard to the HBM that is actually free
     free_b, total_b = torch.cuda.mem_get_info(dev)
     reserve = 6 << 30
+    if single_device:
+        free_b = free_b // world  # the ranks share one GPU
     fit = max(int((free_b - reserve) // (page_bytes + 64)), 1)
     if args.scaling == "strong":
         n_total = args.pages
@@ -128,7 +201,7 @@ def main():
     else:
         n_total = min(args.pages, fit) * world
     if world > 1:  # agree on the smallest feasible corpus
-        t = torch.tensor([n_total], dtype=torch.int64, device=dev)
+        t = torch.tensor([n_total], dtype=torch.int64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         n_total = int(t.item())
     lo, hi = sharded.shard_range(n_total, rank, world)
@@ -154,7 +227,13 @@ def main():
     log(f"[rank {rank}] corpus generated + planted in {time.time()-t0:.1f}s")
 
     stats = []
-    local_topk = sharded.make_gpu_local_topk(ix, dev, "float", collect_stats=stats)
+    gpu_topk = sharded.make_gpu_local_topk(ix, dev, "float", collect_stats=stats)
+    if args.backend == "nccl":
+        local_topk = gpu_topk
+    else:
+        def local_topk(q, k):  # gloo: the k (score, id) pairs go through host memory
+            s, i = gpu_topk(q, k)
+            return s.cpu(), i.cpu()
     searcher = sharded.ShardedSearcher(local_topk)
 
     def step(i):
@@ -181,7 +260,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -191,7 +270,7 @@ def main():
     kms = np.array([s.score_kernel_ms for s in stats if s is not None and s.score_kernel_ms > 0])
     bytes_per_launch = n_local * args.patches * PAGE_ROW_BYTES  # algorithmic: every valid patch row read once
     if world > 1:  # report the slowest rank's kernel
-        t = torch.tensor([float(kms.mean()) if kms.size else 0.0], dtype=torch.float64, device=dev)
+        t = torch.tensor([float(kms.mean()) if kms.size else 0.0], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         k_ms = float(t.item())
     else:
@@ -297,6 +376,11 @@ def main():
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
     ix.close()
+    if out is not None and world == 1 and not args.no_aux:
+        try:
+            out["aux_paths"] = aux_paths(args, local_rank)
+        except Exception as e:  # the headline number must survive a failure of the side measurements
+            out["aux_paths"] = {"error": repr(e)}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
