@@ -123,6 +123,12 @@ MV_API int mv_index_add(mv_index* ix, const void* emb, int dtype, const int32_t*
 MV_API int mv_index_add_device(mv_index* ix, const void* d_emb, int dtype, const int32_t* n_rows, int64_t n_pages,
                                const int32_t* doc_ordinals, int64_t* out_first_page);
 
+/* Append pages given only their packed sign rows (sum(n_rows) x 16 bytes, MSB first) -- the import path for an
+ * existing MultiVectorStore table (BIT(128)[] column, multi_vector_store.py:248).  The index must have been created
+ * with flags == MV_WITH_BINARY (floats cannot be recovered from sign bits). */
+MV_API int mv_index_add_bits(mv_index* ix, const uint8_t* bits, const int32_t* n_rows, int64_t n_pages,
+                             const int32_t* doc_ordinals, int64_t* out_first_page);
+
 /* Tombstone every page of a document / one page.  Replaces
  * delete_chunks_by_document_id (multi_vector_store.py:921-951). Returns pages removed in *out_n. */
 MV_API int mv_index_remove_doc(mv_index* ix, int32_t doc_ordinal, int64_t* out_n);

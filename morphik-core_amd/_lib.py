@@ -74,7 +74,7 @@ MV_OPT_MAXSIM_VARIANT, MV_OPT_FDE_COARSE_N, MV_OPT_FDE_COSINE, MV_OPT_PAD_SEMANT
 # every symbol include/mvmaxsim.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "mv_last_error", "mv_version", "mv_device_count", "mv_index_create", "mv_index_destroy", "mv_index_set_option",
-    "mv_index_size", "mv_index_capacity", "mv_index_add", "mv_index_add_device", "mv_index_remove_doc",
+    "mv_index_size", "mv_index_capacity", "mv_index_add", "mv_index_add_device", "mv_index_add_bits", "mv_index_remove_doc",
     "mv_index_remove_page", "mv_index_read_pages", "mv_index_write_rows", "mv_index_replace_page", "mv_index_read_fp8", "mv_index_fill_synthetic", "mv_synth_rows",
     "mv_query_topk", "mv_query_topk_device", "mv_query_topk_batch", "mv_score_all", "mv_score_candidates", "mv_sign_pack", "mv_hamming_batch",
     "mv_fde_output_dim", "mv_fde_encode", "mv_calibrate_read_bw", "mv_index_save", "mv_index_load",
@@ -108,6 +108,7 @@ def lib() -> C.CDLL:
         L.mv_index_capacity.restype = i64
         L.mv_index_add.argtypes = [vp, vp, C.c_int, vp, i64, vp, C.POINTER(i64)]
         L.mv_index_add_device.argtypes = [vp, vp, C.c_int, vp, i64, vp, C.POINTER(i64)]
+        L.mv_index_add_bits.argtypes = [vp, vp, vp, i64, vp, C.POINTER(i64)]
         L.mv_index_remove_doc.argtypes = [vp, i32, C.POINTER(i64)]
         L.mv_index_remove_page.argtypes = [vp, i64]
         L.mv_index_read_pages.argtypes = [vp, i64, i64, vp]

@@ -699,6 +699,46 @@ int mv_index_add(mv_index* ix, const void* emb, int dtype, const int32_t* n_rows
   return MV_OK;
 }
 
+// Append pages given only their packed sign rows (16 B per row, MSB first): the import path for an existing
+// MultiVectorStore table (BIT(128)[] column, core/vector_store/multi_vector_store.py:248) -- floats cannot be
+// recovered from it, so the index must carry the sign-bit slab only.
+int mv_index_add_bits(mv_index* ix, const uint8_t* bits, const int32_t* n_rows, int64_t n_pages, const int32_t* doc_ordinals,
+                      int64_t* out_first_page) {
+  if (!ix || (!bits && n_pages > 0) || (!n_rows && n_pages > 0) || n_pages < 0) { set_error("mv_index_add_bits: null argument"); return MV_ERR_INVALID; }
+  if (ix->cfg.flags != MV_WITH_BINARY) { set_error("mv_index_add_bits needs an index with MV_WITH_BINARY only (floats are not recoverable from sign bits)"); return MV_ERR_STATE; }
+  if (ix->size + n_pages > ix->cfg.capacity_pages) { set_error("slab full"); return MV_ERR_CAPACITY; }
+  const int32_t stride = ix->cfg.stride_rows;
+  for (int64_t i = 0; i < n_pages; ++i)
+    if (n_rows[i] < 0 || n_rows[i] > stride) { set_error("page %lld has %d rows; stride_rows is %d", (long long)i, n_rows[i], stride); return MV_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->cfg.device);
+  const int64_t first = ix->size;
+  std::vector<uint8_t> img((size_t)std::min<int64_t>(n_pages, 4096) * stride * kSignBytes);
+  int64_t src_row = 0;
+  for (int64_t p0 = 0; p0 < n_pages; p0 += 4096) {  // fixed-stride image of up to 4096 pages per copy
+    const int64_t c = std::min<int64_t>(4096, n_pages - p0);
+    std::fill(img.begin(), img.begin() + (size_t)c * stride * kSignBytes, (uint8_t)0);
+    for (int64_t i = 0; i < c; ++i) {
+      memcpy(img.data() + (size_t)i * stride * kSignBytes, bits + (size_t)src_row * kSignBytes, (size_t)n_rows[p0 + i] * kSignBytes);
+      src_row += n_rows[p0 + i];
+    }
+    MV_HIP(hipMemcpy(ix->bits + (size_t)(first + p0) * stride * kSignBytes, img.data(), (size_t)c * stride * kSignBytes, hipMemcpyHostToDevice));
+  }
+  for (int64_t i = 0; i < n_pages; ++i) {
+    ix->h_n_rows[first + i] = n_rows[i];
+    ix->h_doc_ord[first + i] = doc_ordinals ? doc_ordinals[i] : 0;
+    if (n_rows[i] != stride) ix->ragged = true;
+    if (doc_ordinals && doc_ordinals[i] < 0) ix->tombstones = true;
+  }
+  if (n_pages) {
+    MV_HIP(hipMemcpy(ix->d_n_rows + first, ix->h_n_rows.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice));
+    MV_HIP(hipMemcpy(ix->d_doc_ord + first, ix->h_doc_ord.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice));
+  }
+  ix->size += n_pages;
+  if (out_first_page) *out_first_page = first;
+  return MV_OK;
+}
+
 int mv_index_remove_page(mv_index* ix, int64_t page) {
   if (!ix || page < 0 || page >= ix->size) { set_error("page out of range"); return MV_ERR_INVALID; }
   std::lock_guard<std::mutex> lk(ix->mu);

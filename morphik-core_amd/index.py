@@ -179,6 +179,16 @@ class MvIndex:
         )
         return int(first.value)
 
+    def add_bits(self, pages_bits: Sequence[np.ndarray], doc_ordinals: Optional[Sequence[int]] = None) -> int:
+        """Append pages given as packed sign rows [(P_i,16) uint8] (import of BIT(128)[] rows; binary-only index)."""
+        arrs = [np.ascontiguousarray(p, dtype=np.uint8).reshape(-1, 16) for p in pages_bits]
+        n_rows = np.array([a.shape[0] for a in arrs], np.int32)
+        flat = np.ascontiguousarray(np.concatenate(arrs, 0)) if n_rows.sum() else np.zeros((1, 16), np.uint8)
+        ords = None if doc_ordinals is None else np.ascontiguousarray(doc_ordinals, dtype=np.int32)
+        first = C.c_int64()
+        check(lib().mv_index_add_bits(self._h, flat.ctypes.data, n_rows.ctypes.data, len(arrs), None if ords is None else ords.ctypes.data, C.byref(first)))
+        return int(first.value)
+
     def add_device(self, d_ptr: int, dtype_code: int, n_rows: Sequence[int], doc_ordinals: Optional[Sequence[int]] = None) -> int:
         """Append pages whose rows already sit in device memory (encoder output): d_ptr = device address
         of sum(n_rows) x 128 rows."""

@@ -46,6 +46,14 @@ def _embedding_rows(e: Any) -> np.ndarray:
     return a
 
 
+def _device_tensor(e: Any, device_index: int):
+    """The embedding itself when it is a torch tensor resident on the index's GPU ([n,128], bf16 or fp32), else None."""
+    if hasattr(e, "is_cuda") and getattr(e, "is_cuda") and e.device.index == device_index and e.dim() == 2 and e.shape[1] == 128:
+        if str(e.dtype) in ("torch.bfloat16", "torch.float32"):
+            return e
+    return None
+
+
 class MI355XMultiVectorStore(BaseVectorStore):
     backend_name = "mi355x"
     default_mode = "binary"
@@ -66,7 +74,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         self.stride_rows = int(stride_rows)
         self.device = int(device)
         self.mode = mode or self.default_mode
-        if self.mode not in ("binary", "float", "fde_then_float"):
+        if self.mode not in ("binary", "float", "fde_then_float", "float_fp8"):
             raise ValueError(f"unknown mode {self.mode}")
         self.storage = storage  # callers reach for .storage (document_service.py:1570-1575)
         self.id_base = int(id_base)
@@ -93,7 +101,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         ix = MvIndex(
             capacity_pages=self.capacity_pages, stride_rows=self.stride_rows, device=self.device, id_base=self.id_base,
             with_float=self.mode in ("float", "fde_then_float"), with_binary=self.mode == "binary",
-            with_fde=self.mode == "fde_then_float",
+            with_fde=self.mode == "fde_then_float", with_fp8=self.mode == "float_fp8",
         )
         if self.fde_coarse_n:
             from ._lib import MV_OPT_FDE_COARSE_N
@@ -149,7 +157,19 @@ class MI355XMultiVectorStore(BaseVectorStore):
                     self._rows.pop(old, None)
                     if old in self._doc_pages.get(c.document_id, []):
                         self._doc_pages[c.document_id].remove(old)
-            first = ix.add(embs, ords) + self.id_base
+            if embs and all(not isinstance(e, np.ndarray) for e in embs):
+                # ingest-side fusion: encoder output already on this GPU -> one D2D pass fills
+                # every slab (mv_index_add_device); no D2H -> fp32 -> H2D round trip
+                import torch
+
+                from ._lib import MV_BF16, MV_F32
+
+                code = MV_BF16 if all(e.dtype == torch.bfloat16 for e in embs) else MV_F32
+                flat = torch.cat([e if code == MV_BF16 else e.to(torch.float32) for e in embs], 0).contiguous()
+                torch.cuda.current_stream(flat.device).synchronize()  # the library orders on its own stream
+                first = ix.add_device(flat.data_ptr(), code, [int(e.shape[0]) for e in embs], ords) + self.id_base
+            else:
+                first = ix.add([e if isinstance(e, np.ndarray) else _embedding_rows(e) for e in embs], ords) + self.id_base
             ids = []
             for i, c in enumerate(valid):
                 page = first + i
@@ -171,7 +191,9 @@ class MI355XMultiVectorStore(BaseVectorStore):
                 chunk_payload_backend="memory", multivector_backend=self.backend_name, vector_store_backend=self.backend_name
             )
             return True, [], self._last_store_metrics
-        embs = [_embedding_rows(c.embedding) for c in valid]
+        use_dev = self._index_factory is None
+        embs = [(_device_tensor(c.embedding, self.device) if use_dev else None) for c in valid]
+        embs = [e if e is not None else _embedding_rows(c.embedding) for c, e in zip(valid, embs)]
         for c, e in zip(valid, embs):
             if e.shape[0] > self.stride_rows:
                 raise ValueError(

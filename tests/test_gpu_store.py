@@ -1,4 +1,6 @@
 """The reference's store scenarios on the REAL MI355X index (through libmvmaxsim.so)."""
+import asyncio
+
 import numpy as np
 import pytest
 
@@ -54,3 +56,76 @@ def test_gpu_store_matches_oracle_backed_store():
         else:
             np.testing.assert_allclose([r.score for r in rg], [r.score for r in ro], rtol=1e-3)
         g.close()
+
+
+# ------------------------------------------------------------------ ingest-side fusion and importers
+def test_encoder_output_stays_on_the_gpu_and_self_retrieval():
+    """Tiny random-init ColPali architecture on cuda -> bf16 rows stay on the device -> mv_index_add_device fills the
+    slab; the same pages ingested through the reference's float32-ndarray contract give identical scores."""
+    import io
+
+    import torch
+    from PIL import Image
+
+    from morphik_core_amd.embedding import MI355XColpaliEmbeddingModel
+    from morphik_core_amd.models import Chunk, DocumentChunk
+    from morphik_core_amd.store import MI355XMultiVectorStore
+
+    emb = MI355XColpaliEmbeddingModel(preset="tiny", device="cuda:0", batch_size=4)
+    rng = np.random.default_rng(3)
+
+    def png(i):
+        buf = io.BytesIO()
+        Image.fromarray(rng.integers(0, 255, (32, 32, 3), dtype=np.uint8)).save(buf, format="PNG")
+        return buf.getvalue()
+
+    chunks = [Chunk(content="", metadata={"is_image": True, "_image_bytes": png(i)}) for i in range(9)]
+    rows, n_rows = asyncio.run(emb.embed_for_ingestion_device(chunks))
+    assert rows.is_cuda and rows.dtype == torch.bfloat16 and sum(n_rows) == rows.shape[0]
+    host = asyncio.run(emb.embed_for_ingestion(chunks))
+    stride = ((max(n_rows) + 15) // 16) * 16
+    dev_store = MI355XMultiVectorStore(capacity_pages=16, stride_rows=stride, mode="float")
+    host_store = MI355XMultiVectorStore(capacity_pages=16, stride_rows=stride, mode="float")
+    assert dev_store.initialize() and host_store.initialize()
+    o = 0
+    dchunks, hchunks = [], []
+    for i, n in enumerate(n_rows):
+        dchunks.append(DocumentChunk(document_id=f"d{i // 3}", content=f"p{i}", embedding=rows[o : o + n], chunk_number=i % 3, metadata={}))
+        hchunks.append(DocumentChunk(document_id=f"d{i // 3}", content=f"p{i}", embedding=host[i], chunk_number=i % 3, metadata={}))
+        o += n
+    ok, ids, metrics = asyncio.run(dev_store.store_embeddings(dchunks))
+    assert ok and len(ids) == 9 and metrics["vector_store_rows"] == 9
+    asyncio.run(host_store.store_embeddings(hchunks))
+    for i in (0, 4, 8):
+        got = asyncio.run(dev_store.query_similar(rows[sum(n_rows[:i]) : sum(n_rows[: i + 1])], k=3))
+        want = asyncio.run(host_store.query_similar(host[i], k=3))
+        assert got[0].content == f"p{i}"  # self-retrieval ranks first (test_multivector.py:166-181)
+        assert [c.content for c in got] == [c.content for c in want]
+        np.testing.assert_allclose([c.score for c in got], [c.score for c in want], rtol=1e-3)
+    dev_store.close()
+    host_store.close()
+
+
+def test_import_of_bit128_rows_equals_index_built_from_floats():
+    from morphik_core_amd import formats
+    from morphik_core_amd.index import MvIndex
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(9)
+    pages = [rng.standard_normal((n, 128)).astype(np.float32) for n in (64, 3, 40, 64, 17)]
+    a = MvIndex(capacity_pages=8, stride_rows=64, with_float=False, with_binary=True)
+    a.add(pages, [0, 0, 1, 2, 2])
+    # what the Postgres table holds: BIT(128) strings per patch row
+    rows = [["".join("1" if v > 0 else "0" for v in r) for r in p] for p in pages]
+    b = MvIndex(capacity_pages=8, stride_rows=64, with_float=False, with_binary=True)
+    b.add_bits([formats.bit_rows_to_packed(r) for r in rows], [0, 0, 1, 2, 2])
+    q = rng.standard_normal((32, 128)).astype(np.float32)
+    sa, sb = a.score_all(q, mode="binary"), b.score_all(q, mode="binary")
+    assert sa.tolist() == sb.tolist()
+    want = [orc.maxsim_binary(orc.sign_pack(p), orc.sign_pack(q)) for p in pages]
+    assert sb.astype(np.float64).tolist() == want
+    c = MvIndex(capacity_pages=8, stride_rows=64)  # float index: bits alone are not enough
+    with pytest.raises(Exception):
+        c.add_bits([formats.bit_rows_to_packed(rows[0])])
+    for ix in (a, b, c):
+        ix.close()
