@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--cpu-sample-pages", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--workload", choices=["float", "fp8", "binary", "fde_fp8"], default="float",
+                    help="float = BASELINE configs[2] (the headline, default); fp8 = e4m3 slab (configs[4]); binary = sign-bit "
+                         "max_sim (MultiVectorStore); fde_fp8 = FDE coarse top-1000 -> exact fp8 rerank (configs[3] shard shape)")
     ap.add_argument("--no-aux", action="store_true", help="skip the secondary kernels' quick measurements (aux_paths)")
     ap.add_argument("--aux-pages", type=int, default=200_000)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -185,7 +188,14 @@ def main():
     from morphik_core_amd.index import MvIndex, synth_rows
 
     stride = ((args.patches + 15) // 16) * 16
-    page_bytes = stride * PAGE_ROW_BYTES
+    WL = {
+        "float": dict(mode="float", flags=dict(with_float=True), row_bytes=256, dtype="bf16", resident=stride * 256),
+        "fp8": dict(mode="float_fp8", flags=dict(with_float=False, with_fp8=True), row_bytes=128, dtype="fp8_e4m3", resident=stride * 128 + 4),
+        "binary": dict(mode="binary", flags=dict(with_float=False, with_binary=True), row_bytes=16, dtype="u1 (sign bits)", resident=stride * 16),
+        "fde_fp8": dict(mode="fde_then_float", flags=dict(with_float=False, with_fp8=True, with_fde=True), row_bytes=None, dtype="bf16 FDE + fp8_e4m3",
+                        resident=stride * 128 + 20480 + 8),
+    }[args.workload]
+    page_bytes = WL["resident"]
 
     # ---- size the shard to the HBM that is actually free
     free_b, total_b = torch.cuda.mem_get_info(dev)
@@ -216,18 +226,24 @@ def main():
         log(f"[rank 0] calibration: streaming read {measured_peak:.0f} GB/s")
 
     t0 = time.time()
-    ix = MvIndex(capacity_pages=n_local, stride_rows=stride, device=local_rank, id_base=lo)
+    ix = MvIndex(capacity_pages=n_local, stride_rows=stride, device=local_rank, id_base=lo, **WL["flags"])
     if args.variant >= 0:
         ix.set_option(_lib.MV_OPT_MAXSIM_VARIANT, args.variant)
+    if args.workload == "fde_fp8":
+        ix.set_option(_lib.MV_OPT_FDE_COARSE_N, 1000)
     ix.fill_synthetic(synth.SEED_CORPUS, lo, n_local, n_rows=args.patches)
     queries = [synth_rows(synth.SEED_QUERIES, qi, args.qtokens, device=local_rank) for qi in range(N_QUERIES)]
     spec = synth.planted_spec(queries, n_total, args.patches, n_ranks=N_PLANTED)
-    synth.plant_neighbours(ix, spec, lo, hi)
+    if args.workload == "float":
+        synth.plant_neighbours(ix, spec, lo, hi)
+    else:
+        synth.plant_neighbours_any(ix, spec, synth.SEED_CORPUS, args.patches, lo, hi)
+    MODE = WL["mode"]
     torch.cuda.synchronize()
     log(f"[rank {rank}] corpus generated + planted in {time.time()-t0:.1f}s")
 
     stats = []
-    gpu_topk = sharded.make_gpu_local_topk(ix, dev, "float", collect_stats=stats)
+    gpu_topk = sharded.make_gpu_local_topk(ix, dev, MODE, collect_stats=stats)
     if args.backend == "nccl":
         local_topk = gpu_topk
     else:
@@ -239,7 +255,7 @@ def main():
     def step(i):
         q = queries[i % N_QUERIES]
         if world == 1:
-            s, ids, st = ix.query(q, K, want_stats=True)
+            s, ids, st = ix.query(q, K, mode=MODE, want_stats=True)
             stats.append(st)
             return s, ids
         s, ids = searcher.query(q, K)
@@ -268,7 +284,10 @@ def main():
 
     # ---- roofline of the dominant kernel (the page scan), from HIP events recorded in the timed region
     kms = np.array([s.score_kernel_ms for s in stats if s is not None and s.score_kernel_ms > 0])
-    bytes_per_launch = n_local * args.patches * PAGE_ROW_BYTES  # algorithmic: every valid patch row read once
+    if args.workload == "fde_fp8":  # coarse scan of every FDE vector + exact rerank of 1000 candidates
+        bytes_per_launch = n_local * 20480 + min(1000, n_local) * args.patches * 128
+    else:
+        bytes_per_launch = n_local * args.patches * WL["row_bytes"]  # algorithmic: every valid patch row read once
     if world > 1:  # report the slowest rank's kernel
         t = torch.tensor([float(kms.mean()) if kms.size else 0.0], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -280,7 +299,7 @@ def main():
     # ---- parity inside the bench (outside the timed region): recall@10 and sampled oracle scores
     recall = []
     for qi in range(N_QUERIES):
-        s, ids = step(qi) if world > 1 else ix.query(queries[qi], K)
+        s, ids = step(qi) if world > 1 else ix.query(queries[qi], K, mode=MODE)
         ids = ids.tolist() if hasattr(ids, "tolist") else list(ids)
         planted = [p for (qq, r, p, _, _) in spec if qq == qi]
         recall.append(synth.recall_at_k(ids, planted))
@@ -303,14 +322,16 @@ def main():
                 traffic = None
         roofline = {
             "bound": "hbm",
-            "kernel": "maxsim_bf16 page scan (variant %s)" % (args.variant if args.variant >= 0 else "default"),
+            "kernel": {"float": "maxsim_ldsdma_kernel (bf16 page scan, variant %s)" % (args.variant if args.variant >= 0 else "default: nt LDS-DMA"),
+                       "fp8": "maxsim_fp8_kernel (e4m3 page scan, MX-scaled MFMA)", "binary": "maxsim_binary_mfma2_kernel (sign-bit scan, FP4 MFMA)",
+                       "fde_fp8": "fde_scan_kernel + top-1000 + maxsim_fp8_kernel rerank (whole device span)"}[args.workload],
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "measured_read_peak": None if measured_peak is None else round(measured_peak, 1),
             "frac_of_measured_peak": None if not measured_peak else round(achieved / measured_peak, 4),
-            "traffic": traffic,
+            "traffic": traffic if args.workload == "float" else None,
             "traffic_source": traffic_src,
             "bytes_per_launch": bytes_per_launch,
             "kernel_ms_avg": round(k_ms, 4),
@@ -319,7 +340,7 @@ def main():
         }
         cpu = None
         max_rel = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "float":
             from oracle import oracle as orc  # checker / baseline only
 
             ns = min(args.cpu_sample_pages, n_local)
@@ -343,7 +364,11 @@ def main():
             if not gen_ok:
                 sys.exit("bench.py: device-generated corpus differs from the oracle generator")
         out = {
-            "metric": "MaxSim pages scored/sec (exact top-10, 1 query of %d tokens per step)" % args.qtokens,
+            "metric": {"float": "MaxSim pages scored/sec (exact top-10, 1 query of %d tokens per step)",
+                       "fp8": "MaxSim pages scored/sec on the fp8 (e4m3) slab (exact top-10 of the quantised corpus, 1 query of %d tokens per step)",
+                       "binary": "sign-bit max_sim pages scored/sec (SQL max_sim semantics, top-10, 1 query of %d tokens per step)",
+                       "fde_fp8": "pages searched/sec: FDE coarse scan -> top-1000 -> exact fp8 MaxSim rerank -> top-10 (1 query of %d tokens per step)"}[args.workload]
+            % args.qtokens,
             "value": round(value, 1),
             "unit": "pages/s",
             "n_gpus": world,
@@ -353,10 +378,13 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": WL["dtype"],
             "data": "synthetic (on-device counter-based generator, L2-normalised bf16 rows, planted neighbours)",
             "config": {
-                "workload": "BASELINE configs[2]: %d pre-embedded pages x %d patches x 128-d bf16, MaxSim-only, corpus row-sharded over %d GPU(s)"
+                "workload": {"float": "BASELINE configs[2]: %d pre-embedded pages x %d patches x 128-d bf16, MaxSim-only, corpus row-sharded over %d GPU(s)",
+                             "fp8": "BASELINE configs[4] shape: %d pre-embedded pages x %d patches x 128-d fp8 e4m3 (quantised from the bf16 corpus), MaxSim-only, row-sharded over %d GPU(s)",
+                             "binary": "MultiVectorStore shape: %d pages x %d patches x BIT(128), sign-bit max_sim, row-sharded over %d GPU(s)",
+                             "fde_fp8": "BASELINE configs[3] shard shape: %d pages x %d patches, FDE(10240) coarse top-1000 -> exact fp8 rerank, row-sharded over %d GPU(s)"}[args.workload]
                 % (n_total, args.patches, world),
                 "pages_total": n_total,
                 "pages_per_gpu": n_local,
