@@ -176,12 +176,14 @@ MV_API int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_
  * fast_multivector_store.py:553-555 passes [query_embedding]; a serving process batches concurrent requests).
  *   q          host buffer, n_queries x n_q_rows x dim (every query padded to n_q_rows with zero rows -- a zero
  *              query row contributes exactly 0, the reference's own padding rule)
+ *   allow_bits n_allow_words words shared by all queries (allow_per_query = 0) or n_queries bitmaps of n_allow_words
+ *              words back to back (allow_per_query = 1: every request keeps its own doc_ids / auth filter)
  *   out_*      n_queries x k entries (row b = results of query b), out_n[b] = results of query b
  * MV_MODE_FLOAT runs the batched MFMA kernel (up to 512 query rows per slab pass: B x Q flop/byte); the other
  * modes are served query by query.  stats sum over the passes. */
 MV_API int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, int32_t k,
-                               int mode, const uint32_t* allow_bits, int64_t n_allow_words, float* out_scores,
-                               int64_t* out_ids, int32_t* out_n, mv_query_stats* stats);
+                               int mode, const uint32_t* allow_bits, int64_t n_allow_words, int32_t allow_per_query,
+                               float* out_scores, int64_t* out_ids, int32_t* out_n, mv_query_stats* stats);
 /* Score every page (no selection): out_scores[size] floats on the host; masked pages get -inf.
  * For MV_MODE_FDE_* this returns the coarse scores. */
 MV_API int mv_score_all(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int mode,

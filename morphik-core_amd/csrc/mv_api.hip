@@ -1009,8 +1009,8 @@ int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_r
 }
 
 int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, int32_t k, int mode,
-                        const uint32_t* allow_bits, int64_t n_allow_words, float* out_scores, int64_t* out_ids,
-                        int32_t* out_n, mv_query_stats* stats) {
+                        const uint32_t* allow_bits, int64_t n_allow_words, int32_t allow_per_query, float* out_scores,
+                        int64_t* out_ids, int32_t* out_n, mv_query_stats* stats) {
   if (!ix || !q || n_queries < 1 || n_q_rows < 1 || k < 0 || !out_n || (k > 0 && (!out_scores || !out_ids))) { set_error("mv_query_topk_batch: bad argument"); return MV_ERR_INVALID; }
   if (q_dtype != MV_F32 && q_dtype != MV_BF16) { set_error("bad query dtype %d", q_dtype); return MV_ERR_INVALID; }
   const size_t esz = q_dtype == MV_F32 ? 4 : 2;
@@ -1020,7 +1020,8 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
   if (mode != MV_MODE_FLOAT || rpq > 512 || k > kTopkMaxDeviceK || k == 0) {
     for (int32_t b = 0; b < n_queries; ++b) {
       mv_query_stats st{};
-      int rc = query_common(ix, (const char*)q + (size_t)b * n_q_rows * kDim * esz, q_dtype, n_q_rows, k, mode, allow_bits, n_allow_words,
+      const uint32_t* ab = (allow_bits && allow_per_query) ? allow_bits + (size_t)b * n_allow_words : allow_bits;
+      int rc = query_common(ix, (const char*)q + (size_t)b * n_q_rows * kDim * esz, q_dtype, n_q_rows, k, mode, ab, n_allow_words,
                             out_scores ? out_scores + (size_t)b * k : nullptr, out_ids ? out_ids + (size_t)b * k : nullptr, out_n + b, nullptr,
                             nullptr, nullptr, stats ? &st : nullptr);
       if (rc) return rc;
@@ -1041,13 +1042,16 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
     hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->cfg.capacity_pages * 4);
     if (e != hipSuccess) { ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->cfg.capacity_pages * 4); return MV_ERR_NOMEM; }
   }
+  const bool per_query = allow_bits && allow_per_query;
   const uint32_t* d_allow = nullptr;
-  int rc = upload_allow(ix, allow_bits, n_allow_words, &d_allow);
+  // per-query bitmaps: all n_queries x n_allow_words words are uploaded once; a group reads its slice
+  int rc = upload_allow(ix, allow_bits, per_query ? n_allow_words * (int64_t)n_queries : n_allow_words, &d_allow);
   if (rc) return rc;
   const bool need_meta = ix->tombstones || d_allow != nullptr;
   const int64_t n = ix->size;
   int64_t pages = 0;
-  const int64_t rows = stats ? count_allowed_rows(ix, allow_bits, n_allow_words, &pages) : 0;
+  // accounting: with per-query filters every live page is read (a page is skipped only when no query may see it)
+  const int64_t rows = stats ? count_allowed_rows(ix, per_query ? nullptr : allow_bits, n_allow_words, &pages) : 0;
   std::vector<uint16_t> hq((size_t)512 * kDim);
   std::vector<float> hs((size_t)k);
   std::vector<int64_t> hi((size_t)k);
@@ -1064,7 +1068,8 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
     MV_HIP(hipEventRecord(ix->ev[0], ix->stream));
     BatchArgs a{};
     a.slab = ix->slab; a.n_rows = ix->ragged ? ix->d_n_rows : nullptr; a.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
-    a.allow = d_allow; a.n_allow_bits = n_allow_words * 32; a.q = ix->d_bq; a.scores = ix->d_bscores; a.n = n;
+    a.allow = per_query ? d_allow + (size_t)b0 * n_allow_words : d_allow; a.n_allow_bits = n_allow_words * 32;
+    a.allow_stride_bits = per_query ? n_allow_words * 32 : 0; a.q = ix->d_bq; a.scores = ix->d_bscores; a.n = n;
     a.score_stride = ix->cfg.capacity_pages; a.stride = ix->cfg.stride_rows; a.n_queries = nb; a.rows_per_query = rpq;
     rc = launch_maxsim_batch(a, ix->stream);
     if (rc) return rc;

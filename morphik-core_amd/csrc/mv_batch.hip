@@ -45,13 +45,14 @@ struct BKArgs {
   int32_t stride;
   int32_t n_queries;
   int32_t rows_per_query;  // multiple of 16
+  int64_t allow_stride_bits;  // 0: one bitmap shared by all queries; > 0: query b filters with allow + b * stride/32
 };
 
 __device__ __forceinline__ bool bk_masked(const BKArgs& a, int64_t page) {
   if (!a.doc_ord) return false;
   const int32_t o = a.doc_ord[page];
   if (o < 0) return true;
-  if (!a.allow) return false;
+  if (!a.allow || a.allow_stride_bits) return false;  // per-query bitmaps are applied when the scores are written
   if ((int64_t)o >= a.n_allow_bits) return true;
   return ((a.allow[o >> 5] >> (o & 31)) & 1u) == 0u;
 }
@@ -203,6 +204,11 @@ __global__ __launch_bounds__(256, 2) void maxsim_batch_kernel(BKArgs a) {
       const float* rp = red + (size_t)threadIdx.x * a.rows_per_query;
       float sum = 0.f;
       for (int i = 0; i < a.rows_per_query; ++i) sum += rp[i];
+      if (a.allow && a.allow_stride_bits) {  // this query's own doc_ids filter
+        const int32_t o = a.doc_ord[page];
+        const uint32_t* ab = a.allow + (size_t)threadIdx.x * (size_t)(a.allow_stride_bits >> 5);
+        if ((int64_t)o >= a.n_allow_bits || ((ab[o >> 5] >> (o & 31)) & 1u) == 0u) sum = -INFINITY;
+      }
       a.scores[(size_t)threadIdx.x * a.score_stride + item] = sum;
     }
     // the next page's first bk_barrier() orders these reads of red[] before its rewrite
@@ -226,7 +232,7 @@ int launch_maxsim_batch(const BatchArgs& a, hipStream_t s) {
   const int rows = a.n_queries * a.rows_per_query;
   if (rows > 512 || a.n_queries > 256) { set_error("batch scan: %d query rows exceed the 512-row group", rows); return MV_ERR_INVALID; }
   BKArgs k{reinterpret_cast<const char*>(a.slab), a.n_rows, a.doc_ord, a.allow, a.n_allow_bits, a.q, a.scores, a.n,
-           a.score_stride, 0, a.stride, a.n_queries, a.rows_per_query};
+           a.score_stride, 0, a.stride, a.n_queries, a.rows_per_query, a.allow_stride_bits};
   static int ncu = 0;  // CUs of the (single-architecture) node's GPUs, queried once
   if (ncu == 0) {
     int dev = 0, v = 0;

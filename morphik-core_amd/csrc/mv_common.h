@@ -58,6 +58,7 @@ struct BatchArgs {
   int32_t stride;
   int32_t n_queries;
   int32_t rows_per_query;   // multiple of 16; n_queries * rows_per_query <= 512
+  int64_t allow_stride_bits;  // 0 = `allow` is shared; else query b uses allow + b * allow_stride_bits / 32 (n_allow_bits each)
 };
 int launch_maxsim_batch(const BatchArgs& a, hipStream_t s);
 

@@ -26,6 +26,7 @@
 //   3  as 2 with four waves per page
 //   4/5  as 0/1 with non-temporal loads
 //   6/7  as 3/2 with non-temporal LDS-DMA
+//   8..11 ring-depth probes of 6/7 (D = 3, 2, 6 with four waves per page; D = 8 with one)
 #include <algorithm>
 
 #include "mv_common.h"
@@ -362,6 +363,10 @@ int launch_mt(const KArgs& k0, int variant, hipStream_t s) {
       case 5: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 4, true>), dim3((unsigned)n), block, 0, s, k); break;
       case 6: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true>), dim3((unsigned)n), block, 0, s, k); break;
       case 7: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 1, 4, true>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
+      case 8: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 3, true>), dim3((unsigned)n), block, 0, s, k); break;
+      case 9: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 2, true>), dim3((unsigned)n), block, 0, s, k); break;
+      case 10: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 6, true>), dim3((unsigned)n), block, 0, s, k); break;
+      case 11: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 1, 8, true>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
       default: set_error("unknown maxsim variant %d", variant); return MV_ERR_INVALID;
     }
   }
@@ -387,6 +392,10 @@ const char* maxsim_variant_name(int v) {
     case 5: return "direct_wpp4_nt";
     case 6: return "ldsdma_wpp4_d4_nt";
     case 7: return "ldsdma_wpp1_d4_nt";
+    case 8: return "ldsdma_wpp4_d3_nt";
+    case 9: return "ldsdma_wpp4_d2_nt";
+    case 10: return "ldsdma_wpp4_d6_nt";
+    case 11: return "ldsdma_wpp1_d8_nt";
     default: return "?";
   }
 }

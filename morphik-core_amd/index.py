@@ -250,9 +250,11 @@ class MvIndex:
         return res + (QueryStats.from_c(st),) if want_stats else res
 
     def query_batch(self, queries: Sequence[Any], k: int, mode: str = "float", allow: Optional[np.ndarray] = None,
-                    want_stats: bool = False):
+                    want_stats: bool = False, allows: Optional[Sequence[Optional[np.ndarray]]] = None, n_docs: int = 0):
         """Top-k of several queries in one slab pass.  -> list of (scores, ids) per query [, QueryStats].
-        Queries may have different lengths: they are zero-padded to the longest (a zero row contributes 0)."""
+        Queries may have different lengths: they are zero-padded to the longest (a zero row contributes 0).
+        `allow` = one doc bitmap for all queries; `allows` = one bitmap (or None = everything) PER query
+        (pass n_docs = number of document ordinals in use so an unfiltered query's all-ones bitmap covers them)."""
         rows = [as_rows(q) for q in queries]
         nmax = max(a.shape[0] for a, _ in rows)
         code = MV_BF16 if all(c == MV_BF16 for _, c in rows) else MV_F32
@@ -264,11 +266,26 @@ class MvIndex:
         ids = np.empty((len(rows), max(k, 1)), np.int64)
         n = np.zeros(len(rows), np.int32)
         st = QueryStatsC()
-        ab = None if allow is None else np.ascontiguousarray(allow, dtype=np.uint32)
+        per_query = 0
+        n_words = 0
+        if allows is not None and any(a is not None for a in allows):
+            if len(allows) != len(rows):
+                raise ValueError("allows must have one entry per query")
+            n_words = max(max(int(np.size(a)) for a in allows if a is not None), (int(n_docs) + 31) // 32, 1)
+            ab = np.zeros((len(rows), n_words), np.uint32)
+            for i, a in enumerate(allows):
+                if a is None:
+                    ab[i] = 0xFFFFFFFF  # no filter for this query
+                else:
+                    ab[i, : np.size(a)] = np.asarray(a, dtype=np.uint32)
+            per_query = 1
+        else:
+            ab = None if allow is None else np.ascontiguousarray(allow, dtype=np.uint32)
+            n_words = 0 if ab is None else ab.size
         check(
             lib().mv_query_topk_batch(
                 self._h, blk.ctypes.data, code, len(rows), nmax, k, MODES[mode], None if ab is None else ab.ctypes.data,
-                0 if ab is None else ab.size, scores.ctypes.data, ids.ctypes.data, n.ctypes.data, C.byref(st) if want_stats else None,
+                n_words, per_query, scores.ctypes.data, ids.ctypes.data, n.ctypes.data, C.byref(st) if want_stats else None,
             )
         )
         res = [(scores[i, : n[i]].copy(), ids[i, : n[i]].copy()) for i in range(len(rows))]

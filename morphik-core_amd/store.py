@@ -68,6 +68,8 @@ class MI355XMultiVectorStore(BaseVectorStore):
         id_base: int = 0,
         index_factory: Optional[Callable[..., Any]] = None,
         fde_coarse_n: int = 0,
+        batch_window_ms: float = 0.0,
+        max_batch: int = 16,
         **_ignored: Any,
     ):
         self.capacity_pages = int(capacity_pages)
@@ -80,6 +82,13 @@ class MI355XMultiVectorStore(BaseVectorStore):
         self.id_base = int(id_base)
         self.fde_coarse_n = int(fde_coarse_n)
         self._index_factory = index_factory
+        # request coalescing (mode "float" only): concurrent query_similar calls arriving within batch_window_ms are
+        # scored in ONE slab pass by the batched MFMA kernel, each keeping its own doc_ids filter and k
+        self.batch_window_s = float(batch_window_ms) / 1e3
+        self.max_batch = int(max_batch)
+        self._pending: List[Tuple[np.ndarray, int, Any, Any]] = []
+        self._flush_handle = None
+        self.coalesced_batches: List[int] = []  # sizes of the batches actually issued (introspection / tests)
         self._index = None
         self._lock = threading.RLock()
         # payload table: page -> (document_id, chunk_number, content, metadata_json, app_id)
@@ -236,6 +245,51 @@ class MI355XMultiVectorStore(BaseVectorStore):
         self.last_query_timing = {"vector_search_s": time.perf_counter() - t0}
         return s, i
 
+    # -- request coalescing
+    def _batch_sync(self, items: List[Tuple[np.ndarray, int, Any, Any]]):
+        ix = self._require_index()
+        kmax = max(k for _q, k, _a, _f in items)
+        allows = [a for _q, _k, a, _f in items]
+        with self._lock:
+            n_docs = len(self._doc_ord)
+        t0 = time.perf_counter()
+        res = ix.query_batch([q for q, _k, _a, _f in items], kmax, mode="float", allows=allows if any(a is not None for a in allows) else None,
+                             n_docs=n_docs)
+        self.last_query_timing = {"vector_search_s": time.perf_counter() - t0, "batched_queries": len(items)}
+        return [(s[:k], i[:k]) for (s, i), (_q, k, _a, _f) in zip(res, items)]
+
+    def _flush(self) -> None:
+        items, self._pending = self._pending, []
+        if self._flush_handle is not None:
+            self._flush_handle.cancel()
+            self._flush_handle = None
+        if not items:
+            return
+        self.coalesced_batches.append(len(items))
+
+        async def run():
+            try:
+                outs = await asyncio.to_thread(self._batch_sync, items)
+                for (_q, _k, _a, fut), out in zip(items, outs):
+                    if not fut.done():
+                        fut.set_result(out)
+            except Exception as e:  # noqa: BLE001 -- every waiter sees the failure (query errors propagate)
+                for _q, _k, _a, fut in items:
+                    if not fut.done():
+                        fut.set_exception(e)
+
+        asyncio.ensure_future(run())
+
+    async def _coalesced_query(self, q: np.ndarray, k: int, allow) -> Tuple[np.ndarray, np.ndarray]:
+        loop = asyncio.get_running_loop()
+        fut = loop.create_future()
+        self._pending.append((q, k, allow, fut))
+        if len(self._pending) >= self.max_batch:
+            self._flush()
+        elif self._flush_handle is None:
+            self._flush_handle = loop.call_later(self.batch_window_s, self._flush)
+        return await fut
+
     async def query_similar(
         self,
         query_embedding: Any,
@@ -249,7 +303,10 @@ class MI355XMultiVectorStore(BaseVectorStore):
             allow, empty = self._allow_for(doc_ids, app_id)
         if empty or k <= 0:
             return []
-        scores, pages = await asyncio.to_thread(self._query_sync, q, int(k), allow)  # exceptions propagate (:819-822)
+        if self.batch_window_s > 0 and self.mode == "float":
+            scores, pages = await self._coalesced_query(q, int(k), allow)
+        else:
+            scores, pages = await asyncio.to_thread(self._query_sync, q, int(k), allow)  # exceptions propagate (:819-822)
         out: List[DocumentChunk] = []
         with self._lock:
             for s, p in zip(scores.tolist(), pages.tolist()):

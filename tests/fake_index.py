@@ -66,5 +66,12 @@ class OracleIndex:
         sc, ids = orc.topk(s, k)
         return sc, ids + self.id_base
 
+    def query_batch(self, queries, k, mode=None, allow=None, want_stats=False, allows=None, n_docs=0):
+        out = []
+        for j, q in enumerate(queries):
+            a = allow if allows is None else allows[j]
+            out.append(self.query(q, k, mode, None if a is None else np.asarray(a, np.uint32)))
+        return out
+
     def close(self):
         pass

@@ -425,6 +425,15 @@ def test_batched_queries_equal_single_queries_and_oracle(mv, stride, nrows):
             want[15:18] = -np.inf  # doc 5 was tombstoned (pages 15..17)
             ws, wi = orc.topk(want, 5)
             _assert_topk_matches(s, i, ws, wi)
+    # per-query doc filters in one pass: every request keeps its own doc_ids bitmap (None = unfiltered)
+    qs = [orc.synth_rows(4321, 40 + j, 0, 32) for j in range(6)]
+    n_docs = n // 3 + 1
+    allows = [None, allow_bitmap([1, 2, 3]), allow, allow_bitmap(range(0, n_docs, 2)), None, allow_bitmap([n_docs - 1])]
+    got = ix.query_batch(qs, 6, allows=allows, n_docs=n_docs)
+    for q, al, (s, i) in zip(qs, allows, got):
+        ws, wi = ix.query(q, 6, allow=al)
+        assert i.tolist() == wi.tolist()
+        np.testing.assert_allclose(s, ws, rtol=1e-5)
     # other modes are served query by query through the same entry point
     ix.close()
     ix = _idx(mv, capacity_pages=64, stride_rows=32, with_binary=True)

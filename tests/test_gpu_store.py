@@ -129,3 +129,24 @@ def test_import_of_bit128_rows_equals_index_built_from_floats():
         c.add_bits([formats.bit_rows_to_packed(rows[0])])
     for ix in (a, b, c):
         ix.close()
+
+
+def test_request_coalescing_on_the_real_index():
+    from tests import store_scenarios as sc2
+
+    rng = np.random.default_rng(2)
+    chunks = sc2.make_chunks(rng, n_docs=5, chunks_per_doc=4)
+    plain, fused = _store("float"), _store("float")
+    fused.batch_window_s, fused.max_batch = 0.05, 8
+    sc2.run(plain.store_embeddings(chunks))
+    sc2.run(fused.store_embeddings(chunks))
+    reqs = [(chunks[i].embedding, 1 + i % 5, None if i % 3 else [chunks[i].document_id, chunks[1].document_id]) for i in range(13)]
+
+    async def fire(store):
+        return await asyncio.gather(*(store.query_similar(q, k=k, doc_ids=d) for q, k, d in reqs))
+
+    want, got = sc2.run(fire(plain)), sc2.run(fire(fused))
+    assert fused.coalesced_batches == [8, 5]
+    for w, g in zip(want, got):
+        assert [(c.document_id, c.chunk_number) for c in g] == [(c.document_id, c.chunk_number) for c in w]
+        np.testing.assert_allclose([c.score for c in g], [c.score for c in w], rtol=1e-5)

@@ -57,3 +57,29 @@ def test_too_many_vectors_is_an_error_and_factory():
     assert create_store("mi355x_float", capacity_pages=4).mode == "float"
     with pytest.raises(ValueError):
         create_store("postgres")
+
+
+def test_concurrent_requests_are_coalesced_into_one_batched_scan():
+    """batch_window_ms > 0: concurrent query_similar calls (different k, different doc_ids filters) ride one
+    mv_query_topk_batch pass and each gets exactly what a lone call would have returned."""
+    import asyncio
+
+    rng = np.random.default_rng(2)
+    chunks = sc.make_chunks(rng, n_docs=4, chunks_per_doc=3)
+    plain = _store(mode="float")
+    fused = _store(mode="float", batch_window_ms=20.0, max_batch=8)
+    sc.run(plain.store_embeddings(chunks))
+    sc.run(fused.store_embeddings(chunks))
+    reqs = [(chunks[i].embedding, 1 + i % 4, None if i % 3 else [chunks[i].document_id, chunks[0].document_id]) for i in range(11)]
+
+    async def fire(store):
+        return await asyncio.gather(*(store.query_similar(q, k=k, doc_ids=d) for q, k, d in reqs))
+
+    want = sc.run(fire(plain))
+    got = sc.run(fire(fused))
+    assert fused.coalesced_batches == [8, 3]  # 11 concurrent requests: one full batch, one flushed by the window
+    for w, g, (_q, k, d) in zip(want, got, reqs):
+        assert [(c.document_id, c.chunk_number) for c in g] == [(c.document_id, c.chunk_number) for c in w]
+        assert [c.score for c in g] == [c.score for c in w] and len(g) <= k
+        if d:
+            assert {c.document_id for c in g} <= set(d)
