@@ -111,6 +111,7 @@ struct mv_index {
   int maxsim_variant = -1;
   int binary_variant = -1;
   int fde_scan_variant = -1;
+  int batch_variant = 0;
   int64_t fde_coarse_n = 0;
   int fde_cosine = 1;
   int pad_semantics = -1;  // -1: mode default (reference batch rule for FDE_THEN_FLOAT / candidates, none for full scan)
@@ -601,7 +602,7 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); rc = MV_ERR_HIP; }
   for (auto& e : ix->ev)
     if (!rc && hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); rc = MV_ERR_HIP; }
-  if (cfg->flags & MV_WITH_FLOAT) alloc((void**)&ix->slab, rows * kRowBytes + 16384, "bf16 page slab");  // +16 KiB: the batched scan DMAs whole 16 KiB chunks
+  if (cfg->flags & MV_WITH_FLOAT) alloc((void**)&ix->slab, rows * kRowBytes + 32768, "bf16 page slab");  // +32 KiB: the batched scans DMA whole 16 / 32 KiB chunks
   if (cfg->flags & MV_WITH_FP8) {
     alloc((void**)&ix->slab8, rows * kDim + 4096, "fp8 page slab");  // +4 KiB: the scan DMAs whole 4 KiB pieces
     alloc((void**)&ix->inv_scale8, (size_t)cap * 4, "fp8 page scales");
@@ -651,6 +652,7 @@ int mv_index_set_option(mv_index* ix, int option, int64_t value) {
     case MV_OPT_PAD_SEMANTICS: ix->pad_semantics = (int)value; return MV_OK;
     case MV_OPT_BINARY_VARIANT: ix->binary_variant = (int)value; return MV_OK;
     case MV_OPT_FDE_SCAN_VARIANT: ix->fde_scan_variant = (int)value; return MV_OK;
+    case MV_OPT_BATCH_VARIANT: ix->batch_variant = (int)value; return MV_OK;
     default: set_error("unknown option %d", option); return MV_ERR_INVALID;
   }
 }
@@ -1071,6 +1073,7 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
     a.allow = per_query ? d_allow + (size_t)b0 * n_allow_words : d_allow; a.n_allow_bits = n_allow_words * 32;
     a.allow_stride_bits = per_query ? n_allow_words * 32 : 0; a.q = ix->d_bq; a.scores = ix->d_bscores; a.n = n;
     a.score_stride = ix->cfg.capacity_pages; a.stride = ix->cfg.stride_rows; a.n_queries = nb; a.rows_per_query = rpq;
+    a.variant = ix->batch_variant;
     rc = launch_maxsim_batch(a, ix->stream);
     if (rc) return rc;
     MV_HIP(hipEventRecord(ix->ev[1], ix->stream));

@@ -59,6 +59,7 @@ struct BatchArgs {
   int32_t n_queries;
   int32_t rows_per_query;   // multiple of 16; n_queries * rows_per_query <= 512
   int64_t allow_stride_bits;  // 0 = `allow` is shared; else query b uses allow + b * allow_stride_bits / 32 (n_allow_bits each)
+  int32_t variant;          // 0 = 16x16x32 MFMA, 4 waves / workgroup; 1 = 32x32x16 MFMA, 8 waves / workgroup (> 128 rows)
 };
 int launch_maxsim_batch(const BatchArgs& a, hipStream_t s);
 

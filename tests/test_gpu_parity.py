@@ -399,12 +399,15 @@ def test_fde_coarse_scan_and_pipeline(mv):
 
 
 # ------------------------------------------------------------------ batched queries (one slab pass, MFMA-bound form)
+@pytest.mark.parametrize("bvariant", [0, 1])  # 16x16x32 / 4 waves, 32x32x16 / 8 waves
 @pytest.mark.parametrize("stride,nrows", [(1024, 1024), (1024, 1000), (208, 200), (64, 50), (16, 7)])
-def test_batched_queries_equal_single_queries_and_oracle(mv, stride, nrows):
+def test_batched_queries_equal_single_queries_and_oracle(mv, stride, nrows, bvariant):
+    from morphik_core_amd import _lib
     from morphik_core_amd.index import allow_bitmap
 
     n = 700 if stride < 1024 else 300
-    ix = _idx(mv, capacity_pages=n, stride_rows=stride)  # the last page ends the slab (16 KiB DMA pad)
+    ix = _idx(mv, capacity_pages=n, stride_rows=stride)  # the last page ends the slab (DMA pad)
+    ix.set_option(_lib.MV_OPT_BATCH_VARIANT, bvariant)
     ix.fill_synthetic(1234, 0, n, n_rows=nrows, pages_per_doc=3)
     ix.remove_doc(5)
     allow = allow_bitmap([d for d in range(n // 3 + 1) if d % 4 != 2])
@@ -515,6 +518,33 @@ def test_fp8_only_index_ragged_filter_candidates_and_pipeline(mv):
     bits = np.stack([orc.sign_pack(orc.bf16_to_f32(synth_page)) for synth_page in [orc.synth_rows(1234, 5, 0, nrows)]])
     gb = ix.score_all(q_bf, mode="binary")
     assert float(gb[5]) == orc.maxsim_binary(bits[0], orc.sign_pack(q))
+    ix.close()
+
+
+def test_concurrent_threads_on_one_index_get_their_own_answers(mv):
+    """The API server handles requests concurrently (to_thread): calls on one mv_index are serialised inside the
+    library (one stream + one workspace per index); every caller must still see exactly its own result."""
+    import threading
+
+    ix = _idx(mv, capacity_pages=4096, stride_rows=64, with_binary=True)
+    ix.fill_synthetic(1234, 0, 4096)
+    qs = [orc.synth_rows(4321, j, 0, 32) for j in range(8)]
+    want = [(ix.query(q, 5), ix.query(q, 5, mode="binary")) for q in qs]
+    errs = []
+
+    def worker(j):
+        try:
+            for _ in range(20):
+                a, b = ix.query(qs[j], 5), ix.query(qs[j], 5, mode="binary")
+                assert a[1].tolist() == want[j][0][1].tolist() and a[0].tolist() == want[j][0][0].tolist()
+                assert b[1].tolist() == want[j][1][1].tolist() and b[0].tolist() == want[j][1][0].tolist()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(j,)) for j in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[:2]
     ix.close()
 
 

@@ -52,7 +52,8 @@ def main():
             print(f"q={qt} variant {v}: {np.median(k):.3f} ms  {nbytes/np.median(k)/1e6:.0f} GB/s (best {nbytes/k.min()/1e6:.0f})  topk {np.median([t[1] for t in times[v]]):.3f} ms", flush=True)
     # batched queries: one slab pass for B queries of 32 tokens (HBM-bound -> MFMA-bound as B grows)
     res["batch"] = {}
-    for B in (1, 2, 4, 8, 16):
+    for bv, B in [(0, 1), (0, 2), (0, 4), (0, 8), (0, 16), (1, 8), (1, 16)]:
+        ix.set_option(_lib.MV_OPT_BATCH_VARIANT, bv)
         qs = [synth_rows(4321, j, 32) for j in range(B)]
         ts = []
         for r in range(a.rounds + 1):
@@ -61,8 +62,8 @@ def main():
                 ts.append(st.score_kernel_ms)
         ms = float(np.median(ts))
         flops = 2.0 * B * 32 * a.patches * 128 * a.pages
-        res["batch"][f"B{B}"] = {"kernel_ms_med": ms, "GBps": nbytes / ms / 1e6, "TFLOPs": flops / ms / 1e9, "query_pages_per_s": B * a.pages / ms * 1e3}
-        print(f"batch B={B}: {ms:.3f} ms  {nbytes/ms/1e6:.0f} GB/s  {flops/ms/1e9:.0f} TFLOP/s  {B*a.pages/ms*1e3/1e6:.1f} M query-pages/s", flush=True)
+        res["batch"][f"v{bv}_B{B}"] = {"kernel_ms_med": ms, "GBps": nbytes / ms / 1e6, "TFLOPs": flops / ms / 1e9, "query_pages_per_s": B * a.pages / ms * 1e3}
+        print(f"batch v{bv} B={B}: {ms:.3f} ms  {nbytes/ms/1e6:.0f} GB/s  {flops/ms/1e9:.0f} TFLOP/s  {B*a.pages/ms*1e3/1e6:.1f} M query-pages/s", flush=True)
     ix.close()
     if a.aux:
         n = min(a.pages, 200_000)
