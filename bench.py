@@ -77,7 +77,7 @@ def cpu_baseline(sample_pages_u16, q_u16, budget_s=20.0):
     }
 
 
-def aux_paths(args, device):
+def aux_paths(args, device, mfma_peak=None):
     """Quick, separately sized measurements of the other hot-path kernels (same HIP-event method, a smaller
     corpus with every slab enabled): sign-bit MaxSim (SQL max_sim semantics), fp8 slab, FDE coarse scan and the
     batched-query MFMA form.  Reported next to the headline number, never mixed into `value`."""
@@ -131,7 +131,9 @@ def aux_paths(args, device):
         m = float(np.median(ms))
         tf = 2.0 * B * args.qtokens * args.patches * 128 * n / m / 1e9
         res["batched_float"][f"B{B}"] = {"kernel_ms": round(m, 4), "query_pages_per_s": round(B * n / m * 1e3, 1), "TFLOPs": round(tf, 1),
-                                         "frac_mfma_bf16_2500TF": round(tf / 2500.0, 4), "GBps": round(n * per_page["float"] / m / 1e6, 1)}
+                                         "frac_mfma_bf16_2500TF": round(tf / 2500.0, 4),
+                                         "frac_of_measured_mfma_peak": None if not mfma_peak else round(tf / mfma_peak, 4),
+                                         "GBps": round(n * per_page["float"] / m / 1e6, 1)}
     ix.close()
     return res
 
@@ -218,12 +220,16 @@ def main():
     n_local = hi - lo
     log(f"[rank {rank}] HBM free {free_b/2**30:.1f} GiB of {total_b/2**30:.1f}; corpus {n_total} pages, shard [{lo},{hi}) = {n_local*page_bytes/1e9:.1f} GB")
 
-    measured_peak = None
+    measured_peak = measured_mfma = None
     if rank == 0 and world == 1:
         from morphik_core_amd.index import calibrate_read_bw
 
-        measured_peak = calibrate_read_bw(4 << 30, 10, device=local_rank)  # plain 16 B/lane streaming read
-        log(f"[rank 0] calibration: streaming read {measured_peak:.0f} GB/s")
+        from morphik_core_amd.index import calibrate
+
+        grid_stride_peak = calibrate_read_bw(4 << 30, 10, device=local_rank)  # grid-stride 16 B/lane read (the PMC calibration kernel)
+        measured_peak = calibrate("read_nt", 8 << 30, 10, device=local_rank)   # contiguous 16 KiB pieces, nt loads, no arithmetic
+        measured_mfma = calibrate("mfma_bf16", 0, 5, device=local_rank)
+        log(f"[rank 0] calibration: nt streaming read {measured_peak:.0f} GB/s (grid-stride read {grid_stride_peak:.0f}); bf16 MFMA {measured_mfma:.0f} TFLOP/s")
 
     t0 = time.time()
     ix = MvIndex(capacity_pages=n_local, stride_rows=stride, device=local_rank, id_base=lo, **WL["flags"])
@@ -331,6 +337,7 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "measured_read_peak": None if measured_peak is None else round(measured_peak, 1),
             "frac_of_measured_peak": None if not measured_peak else round(achieved / measured_peak, 4),
+            "measured_mfma_bf16_tflops": None if not measured_mfma else round(measured_mfma, 1),
             "traffic": traffic if args.workload == "float" else None,
             "traffic_source": traffic_src,
             "bytes_per_launch": bytes_per_launch,
@@ -406,7 +413,7 @@ def main():
     ix.close()
     if out is not None and world == 1 and not args.no_aux:
         try:
-            out["aux_paths"] = aux_paths(args, local_rank)
+            out["aux_paths"] = aux_paths(args, local_rank, measured_mfma)
         except Exception as e:  # the headline number must survive a failure of the side measurements
             out["aux_paths"] = {"error": repr(e)}
     if world > 1:

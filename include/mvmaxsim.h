@@ -211,6 +211,13 @@ MV_API int mv_fde_encode(int device, const mv_fde_config* cfg, const float* x, i
  * for the roofline denominator next to the 8 TB/s datasheet figure). */
 MV_API int mv_calibrate_read_bw(int device, int64_t bytes, int32_t iters, double* out_gbps);
 
+/* Measured peaks for the roofline denominators, taken in the same process as the measurement:
+ *   MV_CAL_READ_NT    streams `bytes` of device memory `iters` times in contiguous 16 KiB pieces with non-temporal
+ *                     loads (the scan kernels' access pattern, no arithmetic)            -> *out in GB/s
+ *   MV_CAL_MFMA_BF16  register-only v_mfma_f32_16x16x32_bf16 chains on every CU        -> *out in TFLOP/s */
+enum { MV_CAL_READ_NT = 1, MV_CAL_MFMA_BF16 = 2 };
+MV_API int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out);
+
 /* Persistence ("checkpoint" of the HBM index): raw slabs + metadata in one file. */
 MV_API int mv_index_save(mv_index* ix, const char* path);
 MV_API int mv_index_load(const char* path, int32_t device, mv_index** out);

@@ -71,6 +71,7 @@ MV_MODE_FLOAT, MV_MODE_BINARY, MV_MODE_FDE_THEN_FLOAT, MV_MODE_FDE_ONLY, MV_MODE
 MV_WITH_FLOAT, MV_WITH_BINARY, MV_WITH_FDE, MV_WITH_FP8 = 1, 2, 4, 8
 MV_OPT_MAXSIM_VARIANT, MV_OPT_FDE_COARSE_N, MV_OPT_FDE_COSINE, MV_OPT_PAD_SEMANTICS, MV_OPT_BINARY_VARIANT, MV_OPT_FDE_SCAN_VARIANT = 1, 2, 3, 4, 5, 6
 MV_OPT_BATCH_VARIANT = 7
+MV_CAL_READ_NT, MV_CAL_MFMA_BF16 = 1, 2
 
 # every symbol include/mvmaxsim.h declares (tests check the .so exports all of them)
 EXPORTS = [
@@ -78,7 +79,7 @@ EXPORTS = [
     "mv_index_size", "mv_index_capacity", "mv_index_add", "mv_index_add_device", "mv_index_add_bits", "mv_index_remove_doc",
     "mv_index_remove_page", "mv_index_read_pages", "mv_index_write_rows", "mv_index_replace_page", "mv_index_read_fp8", "mv_index_fill_synthetic", "mv_synth_rows",
     "mv_query_topk", "mv_query_topk_device", "mv_query_topk_batch", "mv_score_all", "mv_score_candidates", "mv_sign_pack", "mv_hamming_batch",
-    "mv_fde_output_dim", "mv_fde_encode", "mv_calibrate_read_bw", "mv_index_save", "mv_index_load",
+    "mv_fde_output_dim", "mv_fde_encode", "mv_calibrate_read_bw", "mv_calibrate", "mv_index_save", "mv_index_load",
 ]
 
 _lock = threading.Lock()
@@ -129,6 +130,7 @@ def lib() -> C.CDLL:
         L.mv_fde_output_dim.restype = i64
         L.mv_fde_encode.argtypes = [C.c_int, C.POINTER(FdeConfigC), vp, i32, i32, vp]
         L.mv_calibrate_read_bw.argtypes = [C.c_int, i64, i32, C.POINTER(C.c_double)]
+        L.mv_calibrate.argtypes = [C.c_int, C.c_int, i64, i32, C.POINTER(C.c_double)]
         L.mv_index_save.argtypes = [vp, C.c_char_p]
         L.mv_index_load.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
         _lib = L

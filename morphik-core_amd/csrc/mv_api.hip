@@ -1258,6 +1258,53 @@ int mv_calibrate_read_bw(int device, int64_t bytes, int32_t iters, double* out_g
   return rc;
 }
 
+int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out) {
+  if (!out || iters < 1) { set_error("calibrate: bad argument"); return MV_ERR_INVALID; }
+  DeviceGuard g(device);
+  float* sink = nullptr;
+  MV_HIP(hipMalloc(&sink, 4));
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  int rc = MV_OK;
+  float ms = 0;
+  if (what == MV_CAL_READ_NT) {
+    if (bytes < (1 << 24)) { set_error("calibrate: need >= 16 MiB"); rc = MV_ERR_INVALID; }
+    void* buf = nullptr;
+    if (!rc && hipMalloc(&buf, (size_t)bytes) != hipSuccess) { set_error("calibrate: out of memory"); rc = MV_ERR_NOMEM; }
+    if (!rc) {
+      (void)hipMemset(buf, 1, (size_t)bytes);
+      rc = launch_read_bw_nt(buf, bytes, sink, nullptr);
+      (void)hipEventRecord(a, nullptr);
+      for (int i = 0; i < iters && !rc; ++i) rc = launch_read_bw_nt(buf, bytes, sink, nullptr);
+      (void)hipEventRecord(b, nullptr);
+      (void)hipEventSynchronize(b);
+      (void)hipEventElapsedTime(&ms, a, b);
+      *out = ms > 0 ? (double)(bytes / 16384 * 16384) * iters / (ms * 1e-3) / 1e9 : 0.0;  // GB/s
+    }
+    if (buf) (void)hipFree(buf);
+  } else if (what == MV_CAL_MFMA_BF16) {
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+    const int blocks = ncu * 2, loop = 4096;  // 8 waves / CU
+    rc = launch_mfma_peak(blocks, 64, sink, nullptr);
+    (void)hipEventRecord(a, nullptr);
+    for (int i = 0; i < iters && !rc; ++i) rc = launch_mfma_peak(blocks, loop, sink, nullptr);
+    (void)hipEventRecord(b, nullptr);
+    (void)hipEventSynchronize(b);
+    (void)hipEventElapsedTime(&ms, a, b);
+    const double flops = (double)blocks * 4 * loop * 8 * (2.0 * 16 * 16 * 32) * iters;
+    *out = ms > 0 ? flops / (ms * 1e-3) / 1e12 : 0.0;  // TFLOP/s
+  } else {
+    set_error("calibrate: unknown measurement %d", what);
+    rc = MV_ERR_INVALID;
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  (void)hipFree(sink);
+  return rc;
+}
+
 // ---------------------------------------------------------------------------------- persistence
 struct SaveHeader {
   char magic[8];

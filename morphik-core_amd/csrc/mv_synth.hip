@@ -128,7 +128,61 @@ __global__ __launch_bounds__(256) void read_bw_kernel(const uint4* buf, int64_t 
   if (acc == 0x9e3779b9u) *sink = 1.0f;  // practically never; keeps the loads alive
 }
 
+// Streaming form of the same calibration: every wave reads whole contiguous 16 KiB pieces (16 non-temporal 1 KiB
+// wave-loads in flight), consecutive waves take consecutive pieces -- the access pattern of the scan kernels without
+// any arithmetic.  This is the "measured HBM peak" the rooflines are also quoted against.
+__global__ __launch_bounds__(256) void read_bw_nt_kernel(const uint4* buf, int64_t n_pieces, float* sink) {
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  uint32_t acc = 0;
+  for (int64_t p = wave; p < n_pieces; p += nwaves) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(buf) + p * 1024 + lane;
+    u32x4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + i * 64);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc ^= v[i][0] ^ v[i][1] ^ v[i][2] ^ v[i][3];
+  }
+  if (acc == 0x9e3779b9u) *sink = 1.0f;
+}
+
+// MFMA calibration: register-only chains of v_mfma_f32_16x16x32_bf16 (8 independent accumulators per wave).
+__global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, float* sink) {
+  using bf16x8 = __attribute__((ext_vector_type(8))) short;
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  bf16x8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = (short)(0x3f80 + threadIdx.x + i); b[i] = (short)(0x3f00 + i); }
+  f32x4 acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; it += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j], 0, 0, 0);
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+  if (t == 1.2345f) *sink = t;
+}
+
 }  // namespace
+
+int launch_read_bw_nt(const void* d_buf, int64_t bytes, float* d_sink, hipStream_t s) {
+  hipLaunchKernelGGL(read_bw_nt_kernel, dim3(256 * 4), dim3(256), 0, s, reinterpret_cast<const uint4*>(d_buf), bytes / 16384, d_sink);
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
+int launch_mfma_peak(int blocks, int iters, float* d_sink, hipStream_t s) {
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3((unsigned)blocks), dim3(256), 0, s, iters, d_sink);
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
 
 int launch_synth_rows(uint16_t* d_out, uint64_t seed, uint64_t first_unit, int64_t n_units, int32_t n_rows,
                       int32_t stride_rows, hipStream_t s) {

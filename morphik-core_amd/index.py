@@ -392,3 +392,10 @@ def calibrate_read_bw(bytes_: int = 8 << 30, iters: int = 5, device: int = 0) ->
     g = C.c_double()
     check(lib().mv_calibrate_read_bw(device, bytes_, iters, C.byref(g)))
     return float(g.value)
+
+
+def calibrate(what: str, bytes_: int = 8 << 30, iters: int = 5, device: int = 0) -> float:
+    """Measured peaks (same process as the measurement): "read_nt" -> GB/s, "mfma_bf16" -> TFLOP/s."""
+    g = C.c_double()
+    check(lib().mv_calibrate(device, {"read_nt": _lib.MV_CAL_READ_NT, "mfma_bf16": _lib.MV_CAL_MFMA_BF16}[what], bytes_, iters, C.byref(g)))
+    return float(g.value)
