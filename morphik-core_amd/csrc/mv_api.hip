@@ -1038,7 +1038,9 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
   DeviceGuard g(ix->cfg.device);
   for (int32_t b = 0; b < n_queries; ++b) out_n[b] = 0;
   if (ix->size == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return MV_OK; }
-  const int group = std::min(512 / rpq, 32);
+  const int group_rows = ix->batch_variant == 2 ? 384 : 512;  // variant 2: 6 row tiles per wave (pipelined kernel)
+  if (rpq > group_rows) { set_error("query of %d rows exceeds the %d-row group of batch variant %d", rpq, group_rows, ix->batch_variant); return MV_ERR_INVALID; }
+  const int group = std::min(group_rows / rpq, 32);
   if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)512 * kRowBytes));
   if (!ix->d_bscores) {
     hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->cfg.capacity_pages * 4);

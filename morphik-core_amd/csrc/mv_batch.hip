@@ -216,6 +216,197 @@ __global__ __launch_bounds__(256, 2) void maxsim_batch_kernel(BKArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Two-stage software pipeline of the 16x16x32 form (variant 2): MTW <= 6 row tiles per wave (384 rows per workgroup)
+// leave registers for a STATIC ping-pong of both the page fragments and the accumulators:
+//     tile t   : MFMAs into acc[t & 1]   (K-quarter-major, MTW independent chains)
+//     meanwhile: ds_read of tile t+1's fragments into b[(t + 1) & 1]      (LDS latency off the MFMA path)
+//                v_max of tile t-1 out of acc[(t - 1) & 1], a quarter after each K-quarter of MFMAs
+// The barrier that publishes chunk c+1 sits in front of the LAST tile of chunk c (its fragments are already in
+// registers), which also releases chunk c's slot for chunk c+S: all S slots are in flight.
+template <int MTW, int S>
+__global__ __launch_bounds__(256, 2) void maxsim_batch_pipe_kernel(BKArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[S * kChunkBytes + 64 * MTW * 4];
+  float* red = reinterpret_cast<float*>(lds + S * kChunkBytes);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+
+  bf16x8 qa[MTW][4];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      qa[m][j] = *reinterpret_cast<const bf16x8*>(a.q + ((size_t)(wave * MTW + m) * 16 + r) * kDim + j * 32 + g * 8);
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(qa[m][j]));
+
+  int src_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int w = i * 4 + (lane >> 4);
+    src_off[i] = w * kRowBytes + (((lane & 15) ^ w) << 4) - i * 1024;
+  }
+  int rd_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rd_off[j] = r * kRowBytes + (((j * 4 + g) ^ r) << 4);
+
+  for (int64_t item = blockIdx.x; item < a.n; item += gridDim.x) {
+    const int64_t page = a.page0 + item;
+    if (bk_masked(a, page)) {
+      if ((int)threadIdx.x < a.n_queries) a.scores[(size_t)threadIdx.x * a.score_stride + item] = -INFINITY;
+      continue;
+    }
+    const int nr = a.n_rows ? a.n_rows[page] : a.stride;
+    if (nr <= 0) {
+      if ((int)threadIdx.x < a.n_queries) a.scores[(size_t)threadIdx.x * a.score_stride + item] = 0.0f;
+      continue;
+    }
+    const int ntiles = (nr + kTileRows - 1) / kTileRows;
+    const int nchunks = (ntiles + kChunkTiles - 1) / kChunkTiles;
+    const int nfull = nr / (kChunkTiles * kTileRows);  // chunks whose 64 rows are all valid
+    const char* pbase = a.slab + (size_t)page * (size_t)a.stride * kRowBytes;
+
+    auto issue = [&](int c) {
+      const char* tp = pbase + (size_t)(c * kChunkTiles + wave) * kTileBytes;
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
+      const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
+      const uint64_t tpu = ((uint64_t)hi << 32) | lo;
+      const uint32_t slot = __builtin_amdgcn_readfirstlane(
+          (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + (c % S) * kChunkBytes + wave * kTileBytes));
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %5\n\t"
+          "s_nop 4\n\t"
+          "global_load_lds_dwordx4 %1, %6 nt\n\t"
+          "global_load_lds_dwordx4 %2, %6 offset:1024 nt\n\t"
+          "global_load_lds_dwordx4 %3, %6 offset:2048 nt\n\t"
+          "global_load_lds_dwordx4 %4, %6 offset:3072 nt\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src_off[0]), "v"(src_off[1]), "v"(src_off[2]), "v"(src_off[3]), "s"(slot), "s"(tpu)
+          : "memory");
+    };
+    auto frags = [&](bf16x8 (&b)[4], int c, int tt) {
+      const char* tp = lds + (c % S) * kChunkBytes + tt * kTileBytes;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(tp + rd_off[j]);
+    };
+
+#pragma unroll
+    for (int c = 0; c < S; ++c)
+      if (c < nchunks) issue(c);
+
+    f32x4 mx[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) mx[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+
+    {
+      const int ahead = min(S - 1, nchunks - 1);
+      if (ahead >= 3) bk_wait_vmcnt<12>();
+      else if (ahead == 2) bk_wait_vmcnt<8>();
+      else if (ahead == 1) bk_wait_vmcnt<4>();
+      else bk_wait_vmcnt<0>();
+      bk_barrier();
+    }
+    bf16x8 b[2][4];
+    f32x4 acc[2][MTW];
+    frags(b[0], 0, 0);
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) acc[1][m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // "tile -1": max-neutral
+
+    for (int c = 0; c < nfull; ++c) {
+#pragma unroll
+      for (int tt = 0; tt < kChunkTiles; ++tt) {
+        constexpr int kQuarter = (MTW + 3) / 4;  // v_max groups of the previous tile per K-quarter
+        const int cur = tt & 1, prv = cur ^ 1;
+        if (tt < kChunkTiles - 1) {
+          frags(b[prv], c, tt + 1);
+        } else if (c + 1 < nchunks) {
+          const int ahead = min(S - 2, nchunks - 2 - c);
+          if (ahead >= 2) bk_wait_vmcnt<8>();
+          else if (ahead == 1) bk_wait_vmcnt<4>();
+          else bk_wait_vmcnt<0>();
+          bk_barrier();
+          if (c + S < nchunks) issue(c + S);
+          frags(b[prv], c + 1, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int m = 0; m < MTW; ++m) {
+            const f32x4 cin = j == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[cur][m];
+            acc[cur][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[m][j], b[cur][j], cin, 0, 0, 0);
+          }
+          // a quarter of the previous tile's running-max work rides behind this K-quarter's MFMAs
+#pragma unroll
+          for (int m = j * kQuarter; m < (j + 1) * kQuarter && m < MTW; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mx[m][i] = fmaxf(mx[m][i], acc[prv][m][i]);
+        }
+        // MTW = 6 only (measured): pin the issue order -- fragment reads first, then one VALU behind every MFMA --
+        // which also keeps the register allocation under 256 (it spills without); smaller MTW schedule better freely
+        if (MTW == 6) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+          for (int i = 0; i < MTW * 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          }
+        }
+      }
+    }
+    // drain: the last full tile's accumulators (tile index 4*nfull - 1 used buffer 1; with nfull == 0 it is the neutral init)
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mx[m][i] = fmaxf(mx[m][i], acc[1][m][i]);
+    if (nfull < nchunks) {  // ragged tail chunk (its tile 0 is already in b[0]); every DMA has landed
+#pragma unroll
+      for (int tt = 0; tt < kChunkTiles; ++tt) {
+        const int t = nfull * kChunkTiles + tt;
+        if (t < ntiles) {  // block-uniform
+          if (tt > 0) frags(b[0], nfull, tt);
+          const bool col_valid = t * kTileRows + r < nr;
+#pragma unroll
+          for (int m = 0; m < MTW; ++m) {
+            f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[m][j], b[0][j], c4, 0, 0, 0);
+            if (!col_valid) c4 = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mx[m][i] = fmaxf(mx[m][i], c4[i]);
+          }
+        }
+      }
+    }
+
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = bk_group16_max(mx[m][i]);
+        if (r == 0) red[(wave * MTW + m) * 16 + g * 4 + i] = v;
+      }
+    __syncthreads();
+    if ((int)threadIdx.x < a.n_queries) {
+      const float* rp = red + (size_t)threadIdx.x * a.rows_per_query;
+      float sum = 0.f;
+      for (int i = 0; i < a.rows_per_query; ++i) sum += rp[i];
+      if (a.allow && a.allow_stride_bits) {
+        const int32_t o = a.doc_ord[page];
+        const uint32_t* ab = a.allow + (size_t)threadIdx.x * (size_t)(a.allow_stride_bits >> 5);
+        if ((int64_t)o >= a.n_allow_bits || ((ab[o >> 5] >> (o & 31)) & 1u) == 0u) sum = -INFINITY;
+      }
+      a.scores[(size_t)threadIdx.x * a.score_stride + item] = sum;
+    }
+    __syncthreads();  // red[] and the ring are rewritten by the next page's prologue / first tiles
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // 32x32x16 form: eight waves per workgroup (one workgroup per CU), RB blocks of 32 query rows per wave
 // (8 x RB x 32 <= 512 rows), page tiles of 32 patches.  Every staged tile is read by eight waves instead of four,
 // the ring is one per CU (4 x 32 KiB chunks, 96 KiB in flight), and the larger MFMA shape has the higher ceiling
@@ -397,6 +588,19 @@ int launch_maxsim_batch(const BatchArgs& a, hipStream_t s) {
     return MV_OK;
   }
   const int grid = (int)std::min<int64_t>(a.n, (int64_t)ncu * 2);
+  if (a.variant == 2 && rows <= 384) {  // pipelined 16x16x32 form
+    const int mtw6 = (rows + 63) / 64;
+    switch (mtw6) {
+      case 1: hipLaunchKernelGGL((maxsim_batch_pipe_kernel<1, 4>), dim3((unsigned)grid), dim3(256), 0, s, k); break;
+      case 2: hipLaunchKernelGGL((maxsim_batch_pipe_kernel<2, 4>), dim3((unsigned)grid), dim3(256), 0, s, k); break;
+      case 3: hipLaunchKernelGGL((maxsim_batch_pipe_kernel<3, 4>), dim3((unsigned)grid), dim3(256), 0, s, k); break;
+      case 4: hipLaunchKernelGGL((maxsim_batch_pipe_kernel<4, 4>), dim3((unsigned)grid), dim3(256), 0, s, k); break;
+      case 5: hipLaunchKernelGGL((maxsim_batch_pipe_kernel<5, 4>), dim3((unsigned)grid), dim3(256), 0, s, k); break;
+      default: hipLaunchKernelGGL((maxsim_batch_pipe_kernel<6, 4>), dim3((unsigned)grid), dim3(256), 0, s, k); break;
+    }
+    MV_HIP(hipGetLastError());
+    return MV_OK;
+  }
   const int mtw = rows <= 64 ? 1 : rows <= 128 ? 2 : rows <= 256 ? 4 : 8;
   switch (mtw) {
     case 1: return launch_batch_mtw<1>(k, grid, s);

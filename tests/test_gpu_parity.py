@@ -399,7 +399,7 @@ def test_fde_coarse_scan_and_pipeline(mv):
 
 
 # ------------------------------------------------------------------ batched queries (one slab pass, MFMA-bound form)
-@pytest.mark.parametrize("bvariant", [0, 1])  # 16x16x32 / 4 waves, 32x32x16 / 8 waves
+@pytest.mark.parametrize("bvariant", [0, 1, 2])  # 16x16x32 / 4 waves, 32x32x16 / 8 waves, pipelined 16x16x32 (384-row groups)
 @pytest.mark.parametrize("stride,nrows", [(1024, 1024), (1024, 1000), (208, 200), (64, 50), (16, 7)])
 def test_batched_queries_equal_single_queries_and_oracle(mv, stride, nrows, bvariant):
     from morphik_core_amd import _lib

@@ -52,7 +52,7 @@ def main():
             print(f"q={qt} variant {v}: {np.median(k):.3f} ms  {nbytes/np.median(k)/1e6:.0f} GB/s (best {nbytes/k.min()/1e6:.0f})  topk {np.median([t[1] for t in times[v]]):.3f} ms", flush=True)
     # batched queries: one slab pass for B queries of 32 tokens (HBM-bound -> MFMA-bound as B grows)
     res["batch"] = {}
-    for bv, B in [(0, 1), (0, 2), (0, 4), (0, 8), (0, 16), (1, 8), (1, 16)]:
+    for bv, B in [(0, 1), (0, 2), (0, 4), (0, 8), (0, 16), (1, 16), (2, 4), (2, 6), (2, 8), (2, 10), (2, 12), (0, 10), (0, 12)]:
         ix.set_option(_lib.MV_OPT_BATCH_VARIANT, bv)
         qs = [synth_rows(4321, j, 32) for j in range(B)]
         ts = []
