@@ -26,26 +26,7 @@ __device__ __forceinline__ float unordered_f32(uint32_t o) {
   return __uint_as_float(u);
 }
 
-// keys_in == nullptr: build keys from scores[base .. base+n).  Invalid (-inf / NaN / out of range) -> 0.
-__global__ __launch_bounds__(kThreads) void topk_level_kernel(const float* scores, const uint64_t* keys_in, int64_t n,
-                                                              int kk, uint64_t* keys_out) {
-  __shared__ uint64_t sk[kChunk];
-  const int64_t base = (int64_t)blockIdx.x * kChunk;
-  for (int i = threadIdx.x; i < kChunk; i += kThreads) {
-    const int64_t gi = base + i;
-    uint64_t key = 0;
-    if (gi < n) {
-      if (keys_in) {
-        key = keys_in[gi];
-      } else {
-        const float s = scores[gi] + 0.0f;  // -0 -> +0 so equal scores tie on index
-        if (s == s && s != -INFINITY) key = ((uint64_t)ordered_u32(s) << 32) | (uint32_t)(~(uint32_t)gi);
-      }
-    }
-    sk[i] = key;
-  }
-  __syncthreads();
-  // bitonic sort, descending
+__device__ __forceinline__ void bitonic_sort_desc(uint64_t* sk) {
   for (int size = 2; size <= kChunk; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       for (int t = threadIdx.x; t < kChunk / 2; t += kThreads) {
@@ -59,22 +40,144 @@ __global__ __launch_bounds__(kThreads) void topk_level_kernel(const float* score
       __syncthreads();
     }
   }
-  for (int i = threadIdx.x; i < kk; i += kThreads) keys_out[(int64_t)blockIdx.x * kk + i] = sk[i];
 }
 
-__global__ void topk_decode_kernel(const uint64_t* keys, int k, const int32_t* ids_map, int64_t id_base, float* out_s,
-                                   int64_t* out_id) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= k) return;
-  const uint64_t key = keys[i];
-  if (key == 0) {
-    out_s[i] = -INFINITY;
-    out_id[i] = -1;
+struct TopkOut {  // only read by the final (single-block) level: decode fused into it
+  const int32_t* ids_map;
+  int64_t id_base;
+  float* out_s;
+  int64_t* out_id;
+  int32_t k;
+};
+
+// One level of the selection.  A block owns `sub` consecutive chunks of 2048 keys: each is bitonic-sorted in LDS and
+// its best kk survive into a second LDS array, which is sorted once more when sub > 1 (sub * kk <= 2048).  Fewer,
+// fatter blocks mean fewer LEVELS -- the selection is launch-latency bound (~20 us per dependent launch), not
+// bandwidth bound -- and the last level writes (score, id) itself instead of a separate decode launch:
+// 1 M pages, k = 10: 2 launches (was 4).
+// keys_in == nullptr: build keys from scores[base .. base+n).  Invalid (-inf / NaN / out of range) -> 0.
+__global__ __launch_bounds__(kThreads) void topk_level_kernel(const float* scores, const uint64_t* keys_in, int64_t n,
+                                                              int kk, uint64_t* keys_out, int sub, int final, TopkOut o) {
+  __shared__ uint64_t sk[kChunk];
+  __shared__ uint64_t best[kChunk];
+  int nbest = 0;
+  for (int sc = 0; sc < sub; ++sc) {
+    const int64_t base = ((int64_t)blockIdx.x * sub + sc) * kChunk;
+    if (sc > 0 && base >= n) break;  // block-uniform
+    for (int i = threadIdx.x; i < kChunk; i += kThreads) {
+      const int64_t gi = base + i;
+      uint64_t key = 0;
+      if (gi < n) {
+        if (keys_in) {
+          key = keys_in[gi];
+        } else {
+          const float s = scores[gi] + 0.0f;  // -0 -> +0 so equal scores tie on index
+          if (s == s && s != -INFINITY) key = ((uint64_t)ordered_u32(s) << 32) | (uint32_t)(~(uint32_t)gi);
+        }
+      }
+      sk[i] = key;
+    }
+    __syncthreads();
+    bitonic_sort_desc(sk);
+    if (sub > 1) {
+      for (int i = threadIdx.x; i < kk; i += kThreads) best[nbest + i] = sk[i];
+      nbest += kk;
+      __syncthreads();
+    }
+  }
+  if (sub > 1) {
+    for (int i = threadIdx.x; i < kChunk; i += kThreads) sk[i] = i < nbest ? best[i] : 0;
+    __syncthreads();
+    bitonic_sort_desc(sk);
+  }
+  if (!final) {
+    for (int i = threadIdx.x; i < kk; i += kThreads) keys_out[(int64_t)blockIdx.x * kk + i] = sk[i];
     return;
   }
-  const uint32_t idx = ~(uint32_t)(key & 0xffffffffu);
-  out_s[i] = unordered_f32((uint32_t)(key >> 32));
-  out_id[i] = id_base + (ids_map ? (int64_t)ids_map[idx] : (int64_t)idx);
+  for (int i = threadIdx.x; i < o.k; i += kThreads) {
+    const uint64_t key = sk[i];
+    if (key == 0) {
+      o.out_s[i] = -INFINITY;
+      o.out_id[i] = -1;
+    } else {
+      const uint32_t idx = ~(uint32_t)(key & 0xffffffffu);
+      o.out_s[i] = unordered_f32((uint32_t)(key >> 32));
+      o.out_id[i] = o.id_base + (o.ids_map ? (int64_t)o.ids_map[idx] : (int64_t)idx);
+    }
+  }
+}
+
+// Small k (<= 32): no sort at all.  Every thread keeps its 8 * SUB keys in registers; each of the kk rounds finds the
+// block maximum (thread-local max -> DPP row max -> 16 row maxima through LDS, read back by everyone) and the owner
+// retires its key.  One barrier per round, ~0.3 us per round, instead of a 66-stage bitonic network (~20-40 us):
+// 1 M pages, k = 10: 2 launches of a few microseconds each.
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp_u64(uint64_t v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, false);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t umax64(uint64_t a, uint64_t b) { return a > b ? a : b; }
+
+template <int SUB>
+__global__ __launch_bounds__(kThreads) void topk_extract_kernel(const float* scores, const uint64_t* keys_in, int64_t n, int kk,
+                                                                uint64_t* keys_out, int final, TopkOut o) {
+  __shared__ uint64_t rowmax[2][16];
+  __shared__ uint64_t winners[32];
+  constexpr int NK = 8 * SUB;
+  uint64_t key[NK];
+  const int64_t base = (int64_t)blockIdx.x * SUB * kChunk;
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    const int64_t gi = base + threadIdx.x + (int64_t)j * kThreads;
+    uint64_t k64 = 0;
+    if (gi < n) {
+      if (keys_in) {
+        k64 = keys_in[gi];
+      } else {
+        const float s = scores[gi] + 0.0f;
+        if (s == s && s != -INFINITY) k64 = ((uint64_t)ordered_u32(s) << 32) | (uint32_t)(~(uint32_t)gi);
+      }
+    }
+    key[j] = k64;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = 0; r < kk; ++r) {
+    uint64_t m = key[0];
+#pragma unroll
+    for (int j = 1; j < NK; ++j) m = umax64(m, key[j]);
+    m = umax64(m, dpp_u64<0x128>(m));  // row_ror 8/4/2/1: maximum of the 16-lane row in every lane
+    m = umax64(m, dpp_u64<0x124>(m));
+    m = umax64(m, dpp_u64<0x122>(m));
+    m = umax64(m, dpp_u64<0x121>(m));
+    if ((lane & 15) == 0) rowmax[r & 1][wave * 4 + (lane >> 4)] = m;
+    __syncthreads();
+    uint64_t w = rowmax[r & 1][0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) w = umax64(w, rowmax[r & 1][i]);
+    if (threadIdx.x == 0) winners[r] = w;
+    if (w != 0) {  // keys are unique: exactly one thread retires it
+#pragma unroll
+      for (int j = 0; j < NK; ++j)
+        if (key[j] == w) key[j] = 0;
+    }
+  }
+  __syncthreads();
+  if (!final) {
+    for (int i = threadIdx.x; i < kk; i += kThreads) keys_out[(int64_t)blockIdx.x * kk + i] = winners[i];
+    return;
+  }
+  for (int i = threadIdx.x; i < o.k; i += kThreads) {
+    const uint64_t k64 = winners[i];
+    if (k64 == 0) {
+      o.out_s[i] = -INFINITY;
+      o.out_id[i] = -1;
+    } else {
+      const uint32_t idx = ~(uint32_t)(k64 & 0xffffffffu);
+      o.out_s[i] = unordered_f32((uint32_t)(k64 >> 32));
+      o.out_id[i] = o.id_base + (o.ids_map ? (int64_t)o.ids_map[idx] : (int64_t)idx);
+    }
+  }
 }
 
 inline int64_t nblocks(int64_t n) { return (n + kChunk - 1) / kChunk; }
@@ -102,22 +205,39 @@ int launch_topk(const float* d_scores, int64_t n, int32_t k, const int32_t* d_id
   uint64_t* bufA = reinterpret_cast<uint64_t*>(ws);
   const int64_t l1 = nblocks(n > 0 ? n : 1) * (int64_t)k;
   uint64_t* bufB = bufA + (l1 + kChunk);
+  const TopkOut out{d_ids_map, id_base, d_out_scores, d_out_ids, k};
+  // Intermediate levels run one 2048-key chunk per block (full parallelism); as soon as the survivors fit one block
+  // looping over <= max_sub chunks (sub * k <= 2048 best-of-chunk keys), that block finishes the selection.
+  const int max_sub = std::min<int>(k <= 32 ? 4 : 8, std::max(1, kChunk / k));  // extraction form: <= 32 keys per thread
+  auto pick_sub = [&](int64_t cur) {
+    if (cur <= (int64_t)kChunk * max_sub) return (int)std::max<int64_t>(1, (cur + kChunk - 1) / kChunk);
+    return 1;
+  };
   int64_t cur_n = n > 0 ? n : 0;
-  int64_t blocks = nblocks(cur_n > 0 ? cur_n : 1);
-  hipLaunchKernelGGL(topk_level_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, s, d_scores, (const uint64_t*)nullptr,
-                     cur_n, (int)k, bufA);
-  cur_n = blocks * k;
-  uint64_t* in = bufA;
-  uint64_t* out = bufB;
-  while (blocks > 1) {
-    blocks = nblocks(cur_n);
-    hipLaunchKernelGGL(topk_level_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, s, (const float*)nullptr,
-                       (const uint64_t*)in, cur_n, (int)k, out);
+  const float* sc = d_scores;
+  const uint64_t* in = nullptr;
+  uint64_t* outk = bufA;
+  while (true) {
+    const int sub = pick_sub(cur_n);
+    const int64_t per_block = (int64_t)kChunk * sub;
+    const int64_t blocks = std::max<int64_t>(1, (cur_n + per_block - 1) / per_block);
+    const int final = blocks == 1;
+    if (k <= 32) {
+      switch (sub) {
+        case 1: hipLaunchKernelGGL((topk_extract_kernel<1>), dim3((unsigned)blocks), dim3(kThreads), 0, s, sc, in, cur_n, (int)k, outk, final, out); break;
+        case 2: hipLaunchKernelGGL((topk_extract_kernel<2>), dim3((unsigned)blocks), dim3(kThreads), 0, s, sc, in, cur_n, (int)k, outk, final, out); break;
+        case 3: case 4: hipLaunchKernelGGL((topk_extract_kernel<4>), dim3((unsigned)blocks), dim3(kThreads), 0, s, sc, in, cur_n, (int)k, outk, final, out); break;
+        default: hipLaunchKernelGGL((topk_extract_kernel<8>), dim3((unsigned)blocks), dim3(kThreads), 0, s, sc, in, cur_n, (int)k, outk, final, out); break;
+      }
+    } else {
+      hipLaunchKernelGGL(topk_level_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, s, sc, in, cur_n, (int)k, outk, sub, final, out);
+    }
+    if (final) break;
     cur_n = blocks * k;
-    uint64_t* t = in; in = out; out = t;
+    sc = nullptr;
+    in = outk;
+    outk = (outk == bufA) ? bufB : bufA;
   }
-  hipLaunchKernelGGL(topk_decode_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, s, (const uint64_t*)in, (int)k,
-                     d_ids_map, id_base, d_out_scores, d_out_ids);
   MV_HIP(hipGetLastError());
   return MV_OK;
 }
