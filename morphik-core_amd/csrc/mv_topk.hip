@@ -16,6 +16,7 @@ namespace {
 
 constexpr int kChunk = 2048;
 constexpr int kThreads = 256;
+constexpr size_t kRadixTailBytes = 4096 * 8 + 2048 * 4 + 64;  // survivors + histogram + state (radix path, k > 32)
 
 __device__ __forceinline__ uint32_t ordered_u32(float f) {
   uint32_t u = __float_as_uint(f);
@@ -180,6 +181,71 @@ __global__ __launch_bounds__(kThreads) void topk_extract_kernel(const float* sco
   }
 }
 
+// Large k (> 32) over many scores: radix threshold instead of a 2048/k-per-level sort cascade (k = 1000 over 1.25 M FDE
+// scores took ~10 dependent bitonic levels, ~0.5 ms).  Three histogram passes over the order-preserving 32-bit keys
+// (11 + 11 + 10 bits, the bin choice stays on the device) give the exact k-th key T; one compaction pass collects
+// every key >= T (all ties included) as 64-bit (key, ~index) words; a single block sorts those <= 4096 survivors, so
+// order and the lowest-index tie rule are exactly those of the cascade.  More than 4096 survivors (masses of equal
+// scores) fall back to the cascade.
+struct RadixState {
+  uint32_t prefix_val;
+  uint32_t prefix_mask;
+  uint32_t k_remaining;
+  uint32_t count;  // compaction counter
+};
+constexpr int kRadixBins = 2048;
+constexpr int kRadixCap = 4096;
+
+__global__ __launch_bounds__(256) void radix_hist_kernel(const float* scores, int64_t n, int shift, int nbits, const RadixState* st,
+                                                         uint32_t* hist) {
+  __shared__ uint32_t h[kRadixBins];
+  for (int i = threadIdx.x; i < kRadixBins; i += 256) h[i] = 0;
+  __syncthreads();
+  const uint32_t pm = st->prefix_mask, pv = st->prefix_val, bm = (1u << nbits) - 1u;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float s = scores[i] + 0.0f;
+    if (s == s && s != -INFINITY) {
+      const uint32_t key = ordered_u32(s);
+      if ((key & pm) == pv) atomicAdd(&h[(key >> shift) & bm], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kRadixBins; i += 256)
+    if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+// one wave: walk the bins from the top until the cumulative count reaches k_remaining; fix those bits of the threshold
+__global__ void radix_pick_kernel(uint32_t* hist, int nbits, int shift, RadixState* st) {
+  if (threadIdx.x == 0) {
+    const int nb = 1 << nbits;
+    uint32_t kr = st->k_remaining, cum = 0;
+    int b = nb - 1;
+    for (; b > 0; --b) {
+      if (cum + hist[b] >= kr) break;
+      cum += hist[b];
+    }
+    st->k_remaining = kr - cum;  // still needed inside bin b (bin 0 absorbs a k beyond the number of valid scores)
+    st->prefix_val |= (uint32_t)b << shift;
+    st->prefix_mask |= ((1u << nbits) - 1u) << shift;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kRadixBins; i += blockDim.x) hist[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void radix_compact_kernel(const float* scores, int64_t n, RadixState* st, uint64_t* out) {
+  const uint32_t T = st->prefix_val;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float s = scores[i] + 0.0f;
+    if (s == s && s != -INFINITY) {
+      const uint32_t key = ordered_u32(s);
+      if (key >= T) {
+        const uint32_t pos = atomicAdd(&st->count, 1u);
+        if (pos < kRadixCap) out[pos] = ((uint64_t)key << 32) | (uint32_t)(~(uint32_t)i);
+      }
+    }
+  }
+}
+
 inline int64_t nblocks(int64_t n) { return (n + kChunk - 1) / kChunk; }
 
 }  // namespace
@@ -189,7 +255,7 @@ size_t topk_ws_bytes(int64_t n, int32_t k) {
   if (k > kTopkMaxDeviceK) k = kTopkMaxDeviceK;
   // two ping-pong key buffers sized for the first level's survivors (+ one chunk of slack)
   const int64_t l1 = nblocks(n > 0 ? n : 1) * (int64_t)k;
-  return (size_t)(2 * (l1 + kChunk)) * sizeof(uint64_t);
+  return (size_t)(2 * (l1 + kChunk)) * sizeof(uint64_t) + kRadixTailBytes;
 }
 
 int launch_topk(const float* d_scores, int64_t n, int32_t k, const int32_t* d_ids_map, int64_t id_base, void* ws,
@@ -217,6 +283,34 @@ int launch_topk(const float* d_scores, int64_t n, int32_t k, const int32_t* d_id
   const float* sc = d_scores;
   const uint64_t* in = nullptr;
   uint64_t* outk = bufA;
+  if (k > 32 && cur_n > 2 * kChunk) {
+    // radix threshold + compaction; workspace tail: [survivors 4096 x u64][hist 2048 x u32][state]
+    char* tail = reinterpret_cast<char*>(ws) + topk_ws_bytes(n, k) - kRadixTailBytes;
+    uint64_t* surv = reinterpret_cast<uint64_t*>(tail);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(tail + kRadixCap * 8);
+    RadixState* st = reinterpret_cast<RadixState*>(tail + kRadixCap * 8 + kRadixBins * 4);
+    const RadixState init{0u, 0u, (uint32_t)k, 0u};
+    MV_HIP(hipMemsetAsync(hist, 0, kRadixBins * 4, s));
+    MV_HIP(hipMemcpyAsync(st, &init, sizeof(init), hipMemcpyHostToDevice, s));
+    const int grid = (int)std::min<int64_t>((cur_n + 255) / 256, 256 * 8);
+    const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+    for (int p = 0; p < 3; ++p) {
+      hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)grid), dim3(256), 0, s, sc, cur_n, shifts[p], bits[p], (const RadixState*)st, hist);
+      hipLaunchKernelGGL(radix_pick_kernel, dim3(1), dim3(256), 0, s, hist, bits[p], shifts[p], st);
+    }
+    hipLaunchKernelGGL(radix_compact_kernel, dim3((unsigned)grid), dim3(256), 0, s, sc, cur_n, st, surv);
+    RadixState fin{};
+    MV_HIP(hipMemcpyAsync(&fin, st, sizeof(fin), hipMemcpyDeviceToHost, s));
+    MV_HIP(hipStreamSynchronize(s));
+    if (fin.count <= (uint32_t)kRadixCap) {
+      const int sub = (int)std::max<uint32_t>(1u, (fin.count + kChunk - 1) / kChunk);
+      hipLaunchKernelGGL(topk_level_kernel, dim3(1), dim3(kThreads), 0, s, (const float*)nullptr, (const uint64_t*)surv, (int64_t)fin.count,
+                         (int)k, outk, sub, 1, out);
+      MV_HIP(hipGetLastError());
+      return MV_OK;
+    }
+    // too many ties at the threshold: fall through to the sort cascade
+  }
   while (true) {
     const int sub = pick_sub(cur_n);
     const int64_t per_block = (int64_t)kChunk * sub;

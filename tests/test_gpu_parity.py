@@ -179,6 +179,38 @@ def test_topk_ties_k_edge_cases_and_large_k(mv):
     empty.close()
 
 
+def test_large_k_radix_selection_matches_oracle_order(mv):
+    """k > 32 over many distinct scores takes the radix-threshold path (3 histogram passes + compaction + one sort);
+    result and order must be exactly the oracle's (score desc, id asc), also through a filter, for k around the
+    survivor capacity, and for k beyond the number of live pages."""
+    from morphik_core_amd.index import allow_bitmap
+
+    n = 30_000
+    ix = _idx(mv, capacity_pages=n, stride_rows=16, with_binary=True)
+    ix.fill_synthetic(1234, 0, n, pages_per_doc=3)
+    ix.remove_doc(77)
+    q = orc.synth_rows(4321, 2, 0, 16)
+    allow = allow_bitmap([d for d in range(n // 3 + 1) if d % 5 != 0])
+    for al in (None, allow):
+        sc = ix.score_all(q, allow=al)
+        for k in (33, 100, 1000, 1024):
+            s, i = ix.query(q, k, allow=al)
+            ws, wi = orc.topk(sc, k)
+            assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist()
+    # sign-bit scores: a handful of distinct values -> the survivors overflow and the sort cascade takes over
+    sb = ix.score_all(q, mode="binary")
+    for k in (64, 1000):
+        s, i = ix.query(q, k, mode="binary")
+        ws, wi = orc.topk(sb, k)
+        assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist()
+    # k larger than the live pages of a narrow filter
+    narrow = allow_bitmap([1, 2, 3])
+    s, i = ix.query(q, 500, allow=narrow)
+    ws, wi = orc.topk(ix.score_all(q, allow=narrow), 500)
+    assert len(i) == 9 and i.tolist() == wi.tolist()
+    ix.close()
+
+
 def test_self_retrieval_ranks_first(mv):
     """core/tests/unit/test_multivector.py:166-181: querying with a stored page's own embedding ranks
     it first, scores non-increasing."""
