@@ -519,6 +519,149 @@ __global__ __launch_bounds__(256) void maxsim_binary_mfma2_kernel(BMArgs args) {
   }
 }
 
+// Variant 5: persistent waves with ONE continuous DMA stream across pages (fixed-size, unfiltered corpora only: every
+// page has S = stride/64 full slots, no metadata reads on the issue path).  Wave w takes pages w, w+W, w+2W, ...; the
+// ring keeps D-1 slots in flight across page boundaries, so the per-page prologue bubble, the query-operand reload and
+// the block launch of variant 4 disappear; a page's finish (DPP max + score store) runs under the next page's loads.
+template <int MT, int D>
+__global__ __launch_bounds__(256) void maxsim_binary_stream_kernel(BMArgs args) {
+  const BArgs& a = args.b;
+  __shared__ __attribute__((aligned(16))) char lds[4 * D * kBinSlotBytes];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t W = (int64_t)gridDim.x * 4;
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + wave;
+  if (w0 >= a.n) return;
+  const int S = a.stride / kBinSlotRows;            // slots per page (stride % 64 == 0)
+  const int64_t npages = (a.n - w0 + W - 1) / W;    // pages of this wave
+  const int64_t T = npages * S;                     // slots of this wave
+  char* ring = lds + wave * (D * kBinSlotBytes);
+  const int src_off = lane * 16;
+  const int rd_off = r * kSignBytes + g * 4;
+  const char* bits = reinterpret_cast<const char*>(a.bits);
+  const size_t page_bytes = (size_t)a.stride * kSignBytes;
+
+  // issue cursor (page ordinal j, slot s) advances one slot per call
+  int64_t ij = 0;
+  int is = 0;
+  int islot = 0;
+  auto issue_next = [&]() {
+    const char* tp = bits + (size_t)(w0 + ij * W) * page_bytes + (size_t)is * kBinSlotBytes;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
+    const uint64_t tpu = ((uint64_t)hi << 32) | lo;
+    const uint32_t slot = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + islot * kBinSlotBytes));
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %3 nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src_off), "s"(slot), "s"(tpu)
+        : "memory");
+    if (++is == S) { is = 0; ++ij; }
+    if (++islot == D) islot = 0;
+  };
+
+  for (int i = 0; i < D - 1; ++i)
+    if (i < T) issue_next();
+
+  i32x8 qa[MT];
+  float qpop[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const uint32_t w = reinterpret_cast<const uint32_t*>(a.q + m * 16 + r)[g];
+    const float4 pc = *reinterpret_cast<const float4*>(a.qpop + m * 16 + g * 4);
+    qa[m][0] = (int)(0xCCCCCCCCu - ((w & 0x11111111u) << 3));
+    qa[m][1] = (int)(0xAAAAAAAAu - (((w >> 1) & 0x11111111u) << 3));
+    qa[m][2] = (int)(0x99999999u - (((w >> 2) & 0x11111111u) << 3));
+    qa[m][3] = (int)(0x99999999u - (((w >> 3) & 0x11111111u) << 3));
+#pragma unroll
+    for (int i = 4; i < 8; ++i) qa[m][i] = 0;
+    qpop[m][0] = pc.x; qpop[m][1] = pc.y; qpop[m][2] = pc.z; qpop[m][3] = pc.w;
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      asm volatile("" : "+v"(qa[m][i]));
+      asm volatile("" : "+v"(qpop[m][i]));
+    }
+  }
+
+  f32x4b mx[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) mx[m] = f32x4b{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+
+  auto expand = [&](uint32_t w) {
+    i32x8 b;
+    b[0] = (int)(w & 0x11111111u);
+    b[1] = (int)(w & 0x22222222u);
+    b[2] = (int)(w & 0x44444444u);
+    b[3] = (int)((w >> 1) & 0x44444444u);
+    b[4] = 0; b[5] = 0; b[6] = 0; b[7] = 0;
+    return b;
+  };
+  auto mma = [&](const i32x8& qam, const i32x8& b) {
+    f32x4b acc = {0.f, 0.f, 0.f, 0.f};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(qam, b, acc, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  };
+
+  int cs = 0, cslot = 0;
+  int64_t cj = 0;
+  for (int64_t t = 0; t < T; ++t) {
+    if (t + D - 1 < T) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // WAR: last reads of the slot being refilled
+      issue_next();
+      bin_wait_vmcnt<D - 1>();
+    } else {
+      const int64_t left = T - 1 - t;
+      if (left >= 2 && D > 2) bin_wait_vmcnt<2>();
+      else if (left == 1) bin_wait_vmcnt<1>();
+      else bin_wait_vmcnt<0>();
+    }
+    const char* slot = ring + cslot * kBinSlotBytes + rd_off;
+    uint32_t w[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) w[tt] = *reinterpret_cast<const uint32_t*>(slot + tt * 256);
+#pragma unroll
+    for (int tp = 0; tp < 4; tp += 2) {
+      const i32x8 b0 = expand(w[tp]), b1 = expand(w[tp + 1]);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const f32x4b c0 = mma(qa[m], b0), c1 = mma(qa[m], b1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mx[m][i] = fmaxf(fmaxf(mx[m][i], c0[i]), c1[i]);
+      }
+    }
+    if (++cslot == D) cslot = 0;
+    if (++cs == S) {  // page complete: finish under the next page's loads
+      float ham = 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = bin_group16_max(mx[m][i]);
+          if (qpop[m][i] >= 0.f) ham += qpop[m][i] - v;
+          mx[m][i] = -INFINITY;
+        }
+      ham += __shfl_xor(ham, 16);
+      ham += __shfl_xor(ham, 32);
+      if (lane == 0) {
+        const int64_t page = w0 + cj * W;
+        const float part = (float)a.n_q - ham * (1.0f / 128.0f);
+        a.scores[page] = args.accumulate ? a.scores[page] + part : part;
+      }
+      cs = 0;
+      ++cj;
+    }
+  }
+}
+
 // popc(q row) as float for rows < n_q, -1 for the padding rows up to `padded`; also zero-fills the padding bit rows
 __global__ void binary_qprep_kernel(uint4* qbits, int n_q, int padded, float* qpop) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -536,6 +679,20 @@ template <int MT>
 static void launch_binary_mfma(const BArgs& k, int accumulate, int variant, hipStream_t s) {
   BMArgs m{k, accumulate};
   const dim3 grid((unsigned)((k.n + 3) / 4)), block(256);
+  if (variant == 5) {
+    // persistent stream form: only for fixed-size, unfiltered corpora whose pages are whole 64-row slots
+    if (!k.n_rows && !k.doc_ord && k.stride % kBinSlotRows == 0) {
+      static int ncu = 0;
+      if (ncu == 0) {
+        int dev = 0, v = 0;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+      }
+      const int64_t blocks = std::min<int64_t>((k.n + 3) / 4, (int64_t)ncu * 8);
+      hipLaunchKernelGGL((maxsim_binary_stream_kernel<MT, 4>), dim3((unsigned)blocks), block, 0, s, m);
+      return;
+    }
+    variant = 4;
+  }
   switch (variant) {
     case 1: hipLaunchKernelGGL((maxsim_binary_mfma_kernel<MT, 6>), grid, block, 0, s, m); break;
     case 3: hipLaunchKernelGGL((maxsim_binary_mfma2_kernel<MT, 16>), grid, block, 0, s, m); break;
@@ -552,7 +709,7 @@ int launch_maxsim_binary(const BinaryArgs& a, int variant, hipStream_t s) {
   if (variant < 0) variant = 4;  // measured (200k pages x 1024): 408 M pages/s (4-slot ring) > 390 (8) > 295 (16) > 345 (v1) > 48 (popcount)
   if (variant == 0 || a.n_q <= 0) {
     hipLaunchKernelGGL(maxsim_binary_kernel, dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, s, k);
-  } else if (variant >= 1 && variant <= 4) {
+  } else if (variant >= 1 && variant <= 5) {
     if (!a.qpop) { set_error("binary MFMA scan needs the qpop workspace"); return MV_ERR_INVALID; }
     const int padded = ((a.n_q + 15) / 16) * 16;
     hipLaunchKernelGGL(binary_qprep_kernel, dim3((unsigned)((padded + 63) / 64)), dim3(64), 0, s,

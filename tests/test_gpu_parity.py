@@ -296,7 +296,7 @@ def test_hamming_batch_matches_reference_golden(mv, golden_dir):
         hamming_batch(b"ab", [b"abc"])
 
 
-BINARY_VARIANTS = [0, 1, 2, 3, 4]  # 0 = popcount on the VALU, 1..4 = FP4 MFMA forms (4 = default); identical integers required
+BINARY_VARIANTS = [0, 1, 2, 3, 4, 5]  # 0 = popcount on the VALU, 1..5 = FP4 MFMA forms (5 = persistent stream); identical integers required
 
 
 def _set_binary_variant(ix, variant):

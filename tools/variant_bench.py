@@ -79,6 +79,7 @@ def main():
                 ("binary_v2_fp4mfma_lean_d8", "binary", a.patches * 16, (_lib.MV_OPT_BINARY_VARIANT, 2)),
                 ("binary_v3_fp4mfma_lean_d16", "binary", a.patches * 16, (_lib.MV_OPT_BINARY_VARIANT, 3)),
                 ("binary_v4_fp4mfma_lean_d4", "binary", a.patches * 16, (_lib.MV_OPT_BINARY_VARIANT, 4)),
+                ("binary_v5_fp4mfma_stream", "binary", a.patches * 16, (_lib.MV_OPT_BINARY_VARIANT, 5)),
                 ("fde_v0_regs", "fde", 10240 * 2, (_lib.MV_OPT_FDE_SCAN_VARIANT, 0)),
                 ("fde_v1_lds", "fde", 10240 * 2, (_lib.MV_OPT_FDE_SCAN_VARIANT, 1)),
                 ("fde_v2_coop", "fde", 10240 * 2, (_lib.MV_OPT_FDE_SCAN_VARIANT, 2)),
