@@ -217,7 +217,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int MT, int WPP, int D, bool NT = false>
+template <int MT, int WPP, int D, bool NT = false, bool CONTIG = false>
 __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
   // one __shared__ object only (a second one makes hipcc drain vmcnt before every ds_read)
   __shared__ __attribute__((aligned(16))) char lds[4 * D * kTileBytes + 1024];
@@ -240,8 +240,12 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
 #pragma unroll
   for (int m = 0; m < MT; ++m) mx[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 
-  const int t0 = (WPP == 1) ? 0 : wave;
-  const int ntw = (ntiles - t0 + WPP - 1) / WPP;
+  // tile ownership: interleaved (wave w takes tiles w, w+4, ...: the workgroup reads 16 KiB bursts) or, CONTIG,
+  // a contiguous quarter of the page per wave
+  const int tq = (ntiles + WPP - 1) / WPP;
+  const int t0 = (WPP == 1) ? 0 : (CONTIG ? wave * tq : wave);
+  const int tstep = CONTIG ? 1 : WPP;
+  const int ntw = CONTIG ? max(0, min(tq, ntiles - t0)) : (ntiles - t0 + WPP - 1) / WPP;
   const char* pbase = a.slab + (size_t)page * (size_t)a.stride * kRowBytes;
   char* ring = lds + wave * (D * kTileBytes);
 
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
   // the LDS address) walks the four 1 KiB pieces, so src_off[i] carries -i*1024 to compensate.
   // s_nop 4 covers SALU-write -> VMEM-read of the base SGPRs and the M0 write -> LDS-DMA hazard.
   auto issue = [&](int it) {
-    const char* tp = pbase + (size_t)(t0 + it * WPP) * kTileBytes;
+    const char* tp = pbase + (size_t)(t0 + it * tstep) * kTileBytes;
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
     const uint64_t tpu = ((uint64_t)hi << 32) | lo;
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
     bf16x8 b[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(slot + rd_off[j]);
-    const int t = t0 + it * WPP;
+    const int t = t0 + it * tstep;
     const bool partial = (t + 1) * kTileRows > nr;
     tile_mfma<MT>(qa, b, mx, partial, t * kTileRows + r < nr);
   }
@@ -367,6 +371,7 @@ int launch_mt(const KArgs& k0, int variant, hipStream_t s) {
       case 9: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 2, true>), dim3((unsigned)n), block, 0, s, k); break;
       case 10: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 6, true>), dim3((unsigned)n), block, 0, s, k); break;
       case 11: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 1, 8, true>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
+      case 12: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true, true>), dim3((unsigned)n), block, 0, s, k); break;
       default: set_error("unknown maxsim variant %d", variant); return MV_ERR_INVALID;
     }
   }
@@ -396,6 +401,7 @@ const char* maxsim_variant_name(int v) {
     case 9: return "ldsdma_wpp4_d2_nt";
     case 10: return "ldsdma_wpp4_d6_nt";
     case 11: return "ldsdma_wpp1_d8_nt";
+    case 12: return "ldsdma_wpp4_d4_nt_contig";
     default: return "?";
   }
 }

@@ -58,7 +58,7 @@ def test_synth_generator_bit_identical_to_oracle(mv):
 
 
 # ------------------------------------------------------------------ float MaxSim
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 def test_float_maxsim_all_variants_small(mv, variant):
     from morphik_core_amd import _lib
 
@@ -90,7 +90,7 @@ def test_float_maxsim_1024_patches_query_lengths(mv, nq):
     ix.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7, 9, 12])
 def test_float_maxsim_ragged_pages(mv, variant):
     """Ragged pages through mv_index_add: rows beyond n_rows never count (pad_to = 0)."""
     from morphik_core_amd import _lib
