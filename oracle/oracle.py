@@ -190,6 +190,22 @@ def maxsim_binary_np(doc_bits, q_bits) -> np.ndarray:
     return (1.0 - hd.min(-1).astype(np.float64) / max(nbits, 1)).sum(-1)
 
 
+def maxsim_binary_popcount_np(doc_bits, q_bits, chunk: int = 64) -> np.ndarray:
+    """Faster CPU formulation of the same SQL max_sim for timing: 64-bit popcounts (np.bitwise_count) in page chunks.
+    doc_bits [N, P, 16] uint8, q_bits [Q, 16] uint8 -> float64 [N].  Equal to maxsim_binary_np bit for bit."""
+    d = _c(doc_bits, np.uint8)
+    q = _c(q_bits, np.uint8)
+    assert d.shape[-1] == 16 and q.shape[-1] == 16
+    d64 = d.view(np.uint64)  # [N, P, 2]
+    q64 = q.view(np.uint64)  # [Q, 2]
+    out = np.empty(d.shape[0], np.float64)
+    for s0 in range(0, d.shape[0], chunk):
+        x = d64[s0 : s0 + chunk, None, :, :] ^ q64[None, :, None, :]  # n, Q, P, 2
+        hd = np.bitwise_count(x).sum(-1, dtype=np.uint16)              # n, Q, P
+        out[s0 : s0 + chunk] = (1.0 - hd.min(-1).astype(np.float64) / 128.0).sum(-1)
+    return out
+
+
 # --------------------------------------------------------------------------- float MaxSim
 def maxsim_f32(q, page, pad_to: int = 0) -> float:
     q = _c(q, np.float32)
