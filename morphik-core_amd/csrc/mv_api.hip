@@ -7,6 +7,7 @@
 // so there is no room for growth-by-copy.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -20,6 +21,7 @@
 namespace mv {
 
 static thread_local std::string g_err;
+static int g_stateless_fde_variant = 1;  // mv_fde_encode (no index): 1 = f32-MFMA kernel; MV_FDE_SCALAR=1 in the environment selects the scalar kernel
 
 void set_error(const char* fmt, ...) {
   char buf[1024];
@@ -112,6 +114,7 @@ struct mv_index {
   int binary_variant = -1;
   int fde_scan_variant = -1;
   int batch_variant = 0;
+  int fde_encode_variant = 1;  // 1 = f32-MFMA kernel, 0 = scalar kernel
   int64_t fde_coarse_n = 0;
   int fde_cosine = 1;
   int pad_semantics = -1;  // -1: mode default (reference batch rule for FDE_THEN_FLOAT / candidates, none for full scan)
@@ -340,6 +343,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
     const int64_t off[2] = {0, n_q};
     MV_HIP(hipMemcpyAsync(ix->d_qoff, off, sizeof(off), hipMemcpyHostToDevice, ix->stream));
     FdeEncodeArgs e{};
+    e.variant = ix->fde_encode_variant;
     e.x_f32 = ix->d_qf32; e.row_offsets = ix->d_qoff; e.n_pages = 1; e.is_query = 1; e.out_f32 = ix->d_qfde;
     rc = launch_fde_encode(ix->fde_t, e, ix->stream);
     if (rc) return rc;
@@ -480,6 +484,7 @@ int add_pages_common(mv_index* ix, const void* d_src, int dtype, const int32_t* 
     }
     if (!rc && (ix->cfg.flags & MV_WITH_FDE)) {
       FdeEncodeArgs e{};
+      e.variant = ix->fde_encode_variant;
       int32_t* d_nr = nullptr;
       if (dtype == MV_F32) {
         e.x_f32 = (const float*)d_src; e.row_offsets = d_off;
@@ -653,6 +658,7 @@ int mv_index_set_option(mv_index* ix, int option, int64_t value) {
     case MV_OPT_BINARY_VARIANT: ix->binary_variant = (int)value; return MV_OK;
     case MV_OPT_FDE_SCAN_VARIANT: ix->fde_scan_variant = (int)value; return MV_OK;
     case MV_OPT_BATCH_VARIANT: ix->batch_variant = (int)value; return MV_OK;
+    case MV_OPT_FDE_ENCODE_VARIANT: ix->fde_encode_variant = (int)value; return MV_OK;
     default: set_error("unknown option %d", option); return MV_ERR_INVALID;
   }
 }
@@ -810,6 +816,7 @@ static int derive_slabs_from_bf16(mv_index* ix, const uint16_t* src, int64_t fir
     while (done < n && !rc) {  // grid.x limit: chunk launches
       const int64_t c = std::min<int64_t>(n - done, 1 << 20);
       FdeEncodeArgs e{};
+      e.variant = ix->fde_encode_variant;
       e.x_bf16 = src + (size_t)done * stride * kDim; e.n_rows = d_nr + done; e.stride = stride; e.n_pages = c; e.is_query = 0;
       e.out_bf16 = ix->fde + (size_t)(first + done) * ix->fde_t.out_dim;
       e.out_inv_norm = ix->fde_inv_norm + first + done;
@@ -1207,6 +1214,10 @@ int64_t mv_fde_output_dim(const mv_fde_config* c) {
 }
 
 int mv_fde_encode(int device, const mv_fde_config* cfg, const float* x, int32_t n_rows, int32_t is_query, float* out) {
+  {
+    const char* ev = getenv("MV_FDE_SCALAR");
+    g_stateless_fde_variant = (ev && ev[0] == '1') ? 0 : 1;
+  }
   if (!cfg || !x || !out || n_rows < 0) { set_error("mv_fde_encode: bad argument"); return MV_ERR_INVALID; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device available"); return MV_ERR_HIP; }
@@ -1223,6 +1234,7 @@ int mv_fde_encode(int device, const mv_fde_config* cfg, const float* x, int32_t 
               hipMemcpy(doff, off, 16, hipMemcpyHostToDevice) != hipSuccess)) { set_error("H2D failed"); rc = MV_ERR_HIP; }
   if (!rc) {
     FdeEncodeArgs e{};
+    e.variant = g_stateless_fde_variant;
     e.x_f32 = dx; e.row_offsets = doff; e.n_pages = 1; e.is_query = is_query; e.out_f32 = dout;
     rc = launch_fde_encode(t, e, nullptr);
   }

@@ -125,6 +125,7 @@ struct FdeEncodeArgs {
   float* out_f32;
   uint16_t* out_bf16;
   float* out_inv_norm;
+  int32_t variant;           // 0 = scalar kernel (LDS atomics), != 0 = f32-MFMA kernel (callers set 1; zero-initialised structs get 0)
 };
 int launch_fde_encode(const FdeTables& t, const FdeEncodeArgs& a, hipStream_t s);
 struct FdeScanArgs {

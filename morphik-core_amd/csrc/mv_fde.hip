@@ -189,6 +189,174 @@ __global__ __launch_bounds__(256) void fde_encode_kernel(EncArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------ encode on the f32 matrix cores
+// The same arithmetic as fde_encode_kernel, bit for bit where the oracle is bit-exact:
+//   * v_mfma_f32_16x16x4_f32 IS a k-ordered fp32 fmaf chain (one rounding per product-add, C chained across the
+//     K steps), so the SimHash sketches  fmaf(x_k, G[k][h], acc)  over k ascending from 0.0f  are reproduced exactly
+//     -> identical sign bits -> identical partitions;
+//   * the AMS projection is the same chain against a dense {0, +1, -1} column:  fma(x, 0, acc) = acc  and
+//     fma(x, +-1, acc) = round(acc +- x)  -- the oracle's ascending sparse sum, exactly.
+// What changes is the cost: the scalar kernel reads x from LDS once per FMA and funnels 64 lanes into 32 bucket
+// addresses with LDS atomics (11 us/page); here a wave keeps a 16-row x 128-dim tile in 32 VGPRs as the MFMA A operand
+// and streams 27 column tiles (7 SimHash + 20 AMS) past it; bucket sums are 4-way conflicts at worst.
+// LDS: G^T [128][112] fp32 (56 KiB) + packed AMS codes (2.5 KiB) + acc (40 KiB) + cnt + per-wave x tile / signs.
+struct EncMArgs {
+  EncArgs e;
+  const int32_t* H;   // [R][128] bucket of each input dim
+  const float* S;     // [R][128] sign of each input dim
+  int64_t n_pages;
+};
+
+constexpr int kXStride = 130;  // floats per staged row: conflict-free A-fragment reads
+
+__global__ __launch_bounds__(256) void fde_encode_mfma_kernel(EncMArgs m) {
+  const EncArgs& a = m.e;
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NP = 1 << a.NS;
+  const int NH = a.R * a.NS;              // hash functions
+  const int NHP = ((NH + 15) / 16) * 16;  // padded to column tiles
+  const int NT = NHP / 16;
+  float* Gs = reinterpret_cast<float*>(smem);                       // [128][NHP]
+  float* acc = Gs + kDim * NHP;                                     // [out_dim]
+  int32_t* cnt = reinterpret_cast<int32_t*>(acc + a.out_dim);       // [R*NP]
+  float* red = reinterpret_cast<float*>(cnt + a.R * NP);            // [4]
+  uint8_t* codeT = reinterpret_cast<uint8_t*>(red + 4);             // [R][4][32]: code of dim 4s+k at [rep][k][s]
+  float* xs_all = reinterpret_cast<float*>(codeT + ((a.R * 128 + 15) / 16) * 16);  // [4 waves][16][kXStride]
+  uint8_t* sg_all = reinterpret_cast<uint8_t*>(xs_all + 4 * 16 * kXStride);         // [4 waves][16][NHP] sign bytes
+  uint8_t* pt_all = sg_all + 4 * 16 * NHP;                                          // [4 waves][16][R] partitions
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, k = lane >> 4;
+  float* xs = xs_all + wave * 16 * kXStride;
+  uint8_t* sg = sg_all + wave * 16 * NHP;
+  uint8_t* pt = pt_all + wave * 16 * a.R;
+
+  // tables -> LDS (once per block; blocks are persistent over pages)
+  for (int i = threadIdx.x; i < kDim * NHP; i += 256) {
+    const int dim = i / NHP, h = i - dim * NHP;
+    float v = 0.f;
+    if (h < NH) { const int r = h / a.NS, jj = h - r * a.NS; v = a.G[((size_t)r * kDim + dim) * a.NS + jj]; }
+    Gs[i] = v;
+  }
+  for (int i = threadIdx.x; i < a.R * kDim; i += 256) {
+    const int r = i >> 7, dim = i & 127;
+    const uint8_t code = (uint8_t)(m.H[i] & 15) | (m.S[i] < 0.f ? 0x80u : 0u);
+    codeT[r * 128 + (dim & 3) * 32 + (dim >> 2)] = code;
+  }
+
+  for (int64_t page = blockIdx.x; page < m.n_pages; page += gridDim.x) {
+    int64_t r0 = 0;
+    int32_t nr;
+    if (a.x_f32) {
+      r0 = a.row_offsets[page];
+      nr = (int32_t)(a.row_offsets[page + 1] - r0);
+    } else {
+      nr = a.n_rows ? a.n_rows[page] : a.stride;
+      r0 = page * (int64_t)a.stride;
+    }
+    __syncthreads();  // tables staged / previous page's finish done with acc
+    for (int i = threadIdx.x; i < (int)a.out_dim; i += 256) acc[i] = 0.0f;
+    for (int i = threadIdx.x; i < a.R * NP; i += 256) cnt[i] = 0;
+    __syncthreads();
+
+    const int ntiles = (nr + 15) >> 4;
+    for (int t = wave; t < ntiles; t += 4) {
+      const int row0 = t * 16;
+      // ---- stage 16 rows x 128 dims as fp32 (rows >= nr are zero)
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int idx = it * 64 + lane, row = idx >> 5, c4 = (idx & 31) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + row < nr) {
+          const int64_t e = (r0 + row0 + row) * kDim + c4;
+          if (a.x_f32) {
+            v = *reinterpret_cast<const float4*>(a.x_f32 + e);
+          } else {
+            const uint2 hh = *reinterpret_cast<const uint2*>(a.x_bf16 + e);
+            v.x = bf16_to_f32((uint16_t)(hh.x & 0xffff)); v.y = bf16_to_f32((uint16_t)(hh.x >> 16));
+            v.z = bf16_to_f32((uint16_t)(hh.y & 0xffff)); v.w = bf16_to_f32((uint16_t)(hh.y >> 16));
+          }
+        }
+        float* d = xs + row * kXStride + c4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private LDS: in-order, just make the stores land
+      // ---- A fragments: x[row = j][dim = 4s + k]
+      float af[32];
+#pragma unroll
+      for (int s = 0; s < 32; ++s) af[s] = xs[j * kXStride + 4 * s + k];
+      // ---- SimHash sketches, one 16-hash column tile at a time; only the signs are kept
+      for (int n = 0; n < NT; ++n) {
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 32; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], Gs[(4 * s + k) * NHP + 16 * n + j], c, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sg[(4 * k + i) * NHP + 16 * n + j] = c[i] > 0.0f ? 1 : 0;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // ---- partition ids (Gray code of the NS sign bits) for the 16 x R (row, repetition) pairs
+      for (int pi = lane; pi < 16 * a.R; pi += 64) {
+        const int row = pi & 15, rep = pi >> 4;
+        uint32_t part = 0;
+        for (int jj = 0; jj < a.NS; ++jj) part = (part << 1) + ((uint32_t)sg[row * NHP + rep * a.NS + jj] ^ (part & 1u));
+        pt[row * a.R + rep] = (uint8_t)part;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // ---- AMS projection per repetition (dense {0,+1,-1} column against the same A fragments) + bucket sums
+      for (int rep = 0; rep < a.R; ++rep) {
+        const uint4 c0 = *reinterpret_cast<const uint4*>(codeT + rep * 128 + k * 32);
+        const uint4 c1 = *reinterpret_cast<const uint4*>(codeT + rep * 128 + k * 32 + 16);
+        const uint32_t cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+          const uint32_t code = (cw[s >> 2] >> (8 * (s & 3))) & 0xffu;
+          const float b = ((int)(code & 15u) == j) ? ((code & 0x80u) ? -1.0f : 1.0f) : 0.0f;
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], b, c, 0, 0, 0);
+        }
+        if (j < a.PD) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = 4 * k + i;
+            if (row0 + row < nr) {
+              const int part = pt[row * a.R + rep];
+              atomicAdd(&acc[((size_t)rep * NP + part) * a.PD + j], c[i] * a.scale);
+              if (j == 0) atomicAdd(&cnt[rep * NP + part], 1);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- finish (as fde_encode_kernel): AVERAGE for documents, write fp32 / bf16, inverse norm of the bf16 image
+    float nn = 0.0f;
+    for (int i = threadIdx.x; i < (int)a.out_dim; i += 256) {
+      float v = acc[i];
+      if (!a.is_query) {
+        const int n = cnt[i / a.PD];
+        if (n > 1) v = v / (float)n;
+      }
+      if (a.out_f32) a.out_f32[page * a.out_dim + i] = v;
+      const uint16_t hb = f32_to_bf16_rne(v);
+      if (a.out_bf16) a.out_bf16[page * a.out_dim + i] = hb;
+      const float vb = bf16_to_f32(hb);
+      nn += vb * vb;
+    }
+    if (a.out_inv_norm) {
+#pragma unroll
+      for (int sft = 1; sft < 64; sft <<= 1) nn += __shfl_xor(nn, sft);
+      if (lane == 0) red[wave] = nn;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const float tt = (red[0] + red[1]) + (red[2] + red[3]);
+        a.out_inv_norm[page] = tt > 0.0f ? 1.0f / sqrtf(tt) : 0.0f;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ coarse scan
 struct ScanArgs {
   const uint16_t* fde;
@@ -510,6 +678,25 @@ int launch_fde_encode(const FdeTables& t, const FdeEncodeArgs& a, hipStream_t s)
   k.scale = 1.0f / sqrtf((float)PD);
   k.out_dim = t.out_dim;
   k.out_f32 = a.out_f32; k.out_bf16 = a.out_bf16; k.out_inv_norm = a.out_inv_norm;
+  if (a.variant != 0 && PD <= 16 && R * NS <= 128) {
+    // f32-MFMA form (default): persistent blocks, one per CU
+    const int NHP = ((R * NS + 15) / 16) * 16;
+    const size_t ldsm = (size_t)kDim * NHP * 4 + (size_t)t.out_dim * 4 + (size_t)R * (1 << NS) * 4 + 16 + (size_t)((R * 128 + 15) / 16) * 16 +
+                        (size_t)4 * 16 * kXStride * 4 + (size_t)4 * 16 * NHP + (size_t)4 * 16 * R + 64;
+    if (ldsm <= 160 * 1024) {
+      static int ncu = 0;
+      if (ncu == 0) {
+        int dev = 0, v = 0;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+      }
+      EncMArgs mm{k, t.H, t.S, a.n_pages};
+      MV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fde_encode_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
+      const int64_t grid = std::min<int64_t>(a.n_pages, ncu);
+      hipLaunchKernelGGL(fde_encode_mfma_kernel, dim3((unsigned)grid), dim3(256), ldsm, s, mm);
+      MV_HIP(hipGetLastError());
+      return MV_OK;
+    }
+  }
   const size_t lds = (size_t)kDim * kRowsPerPass * 4 + (size_t)t.out_dim * 4 + (size_t)R * (1 << NS) * 4 + 16;
   if (lds > 160 * 1024) {
     set_error("FDE config needs %zu B of LDS (> 160 KiB)", lds);

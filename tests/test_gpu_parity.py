@@ -384,15 +384,41 @@ def test_fde_encode_matches_oracle(mv):
     cfg = FdeConfig()
     ocfg = orc.FdeConfig.reference_default()
     assert cfg.output_dim == 10240
-    for n in (1, 32, 63, 64, 65, 200):
-        x = orc.bf16_to_f32(orc.synth_rows(9, n, 0, n))
-        x[0, :5] *= 3.7  # not unit norm, not bf16-exact
+    for scalar in ("0", "1"):  # f32-MFMA kernel (default) and the scalar kernel: the same fmaf chains
+        os.environ["MV_FDE_SCALAR"] = scalar
+        for n in (1, 15, 16, 17, 32, 63, 64, 65, 200, 1030):
+            x = orc.bf16_to_f32(orc.synth_rows(9, n, 0, n))
+            x[0, :5] *= 3.7  # not unit norm, not bf16-exact
+            for is_q in (True, False):
+                got = fde_encode(x, cfg, is_query=is_q)
+                want = orc.fde_encode(ocfg, x, is_q)
+                # partitions agree bit for bit (same fmaf chain) -> the support of the vectors is identical
+                assert np.array_equal(got != 0, want != 0), (scalar, n, is_q)
+                np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+    os.environ.pop("MV_FDE_SCALAR", None)
+    # other FDE shapes through the MFMA kernel (fewer repetitions / projections / narrower buckets)
+    for (R, NS, PD) in ((3, 4, 8), (20, 6, 16), (7, 1, 16)):
+        c2 = FdeConfig(num_repetitions=R, num_simhash_projections=NS, projection_dimension=PD, seed=5)
+        o2 = orc.FdeConfig(128, R, NS, PD, 5)
+        x = orc.bf16_to_f32(orc.synth_rows(11, 0, 0, 77))
         for is_q in (True, False):
-            got = fde_encode(x, cfg, is_query=is_q)
-            want = orc.fde_encode(ocfg, x, is_q)
-            # partitions agree bit for bit (same fmaf chain) -> the support of the vectors is identical
+            got, want = fde_encode(x, c2, is_query=is_q), orc.fde_encode(o2, x, is_q)
             assert np.array_equal(got != 0, want != 0)
             np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+def test_fde_slab_same_scores_from_both_encode_kernels(mv):
+    from morphik_core_amd import _lib
+
+    q = orc.synth_rows(4321, 0, 0, 32)
+    outs = []
+    for variant in (0, 1):
+        ix = _idx(mv, capacity_pages=300, stride_rows=208, with_fde=True)
+        ix.set_option(_lib.MV_OPT_FDE_ENCODE_VARIANT, variant)
+        ix.fill_synthetic(1234, 0, 300, n_rows=200)
+        outs.append(ix.score_all(q, mode="fde"))
+        ix.close()
+    np.testing.assert_allclose(outs[0], outs[1], rtol=2e-3, atol=2e-4)  # bf16 slab, bucket sums in different orders
 
 
 def test_fde_coarse_scan_and_pipeline(mv):
