@@ -72,6 +72,7 @@ MV_WITH_FLOAT, MV_WITH_BINARY, MV_WITH_FDE, MV_WITH_FP8 = 1, 2, 4, 8
 MV_OPT_MAXSIM_VARIANT, MV_OPT_FDE_COARSE_N, MV_OPT_FDE_COSINE, MV_OPT_PAD_SEMANTICS, MV_OPT_BINARY_VARIANT, MV_OPT_FDE_SCAN_VARIANT = 1, 2, 3, 4, 5, 6
 MV_OPT_BATCH_VARIANT = 7
 MV_OPT_FDE_ENCODE_VARIANT = 8
+MV_OPT_FILTER_COMPACT_PCT = 9
 MV_CAL_READ_NT, MV_CAL_MFMA_BF16 = 1, 2
 
 # every symbol include/mvmaxsim.h declares (tests check the .so exports all of them)

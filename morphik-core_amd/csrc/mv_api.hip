@@ -98,6 +98,10 @@ struct mv_index {
   float* d_q8fac = nullptr;    // 2^-s per query row
   uint16_t* d_bq = nullptr;    // [512][128] bf16 query block of the batched scan
   float* d_bscores = nullptr;  // [32][capacity] per-query score vectors of the batched scan (lazily allocated)
+  int32_t* d_fcand = nullptr;  // [capacity] pages a selective doc filter lets through (lazily allocated)
+  int32_t* d_fcounts = nullptr;
+  int32_t max_doc_ord = -1;    // largest document ordinal seen (filter selectivity estimate)
+  int filter_compact_pct = 25; // compact when the filter allows less than this share of the documents (0 = never)
   float* d_qfde = nullptr;
   int64_t* d_qoff = nullptr;   // [2] row offsets for the query "page"
   uint32_t* d_allow = nullptr;
@@ -290,7 +294,7 @@ int fp8_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_wor
 
 // Core of every query entry point: leaves per-item scores on the device.
 int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const uint32_t* allow_bits, int64_t n_words,
-             int64_t want_coarse, ScanResult* out, mv_query_stats* st) {
+             int64_t want_coarse, ScanResult* out, mv_query_stats* st, bool want_compact = false) {
   if (!q || n_q <= 0) { set_error("query must have at least one row"); return MV_ERR_INVALID; }
   if (q_dtype != MV_F32 && q_dtype != MV_BF16) { set_error("bad query dtype %d", q_dtype); return MV_ERR_INVALID; }
   const bool want_fde = mode == MV_MODE_FDE_THEN_FLOAT || mode == MV_MODE_FDE_ONLY;
@@ -312,21 +316,42 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
   if (rc) return rc;
   const bool need_meta = ix->tombstones || d_allow != nullptr;
   const int64_t n = ix->size;
-  int64_t pages = 0;
-  const int64_t rows = st ? count_allowed_rows(ix, allow_bits, n_words, &pages) : 0;  // accounting only
+  int64_t pages = 0, rows = 0;  // accounting only (filled below, once it is known whether the filter was compacted)
 
   MV_HIP(hipEventRecord(ix->ev[0], ix->stream));
   out->launches = 0;
+  // Selective doc filter on a top-k scan: compact the allowed pages (in page order) and scan only those.
+  const int32_t* d_scan_cand = nullptr;
+  int64_t n_scan = n;
+  if (want_compact && d_allow && (mode == MV_MODE_FLOAT || mode == MV_MODE_FLOAT_FP8) && ix->filter_compact_pct > 0 && ix->max_doc_ord >= 0) {
+    int64_t allowed_docs = 0;
+    for (int64_t w = 0; w < n_words; ++w) allowed_docs += __builtin_popcount(allow_bits[w]);
+    if (allowed_docs * 100 < (int64_t)ix->filter_compact_pct * ((int64_t)ix->max_doc_ord + 1)) {
+      if (!ix->d_fcand) {
+        MV_HIP(hipMalloc(&ix->d_fcand, (size_t)ix->cfg.capacity_pages * 4));
+        MV_HIP(hipMalloc(&ix->d_fcounts, filter_ws_bytes(ix->cfg.capacity_pages)));
+      }
+      rc = launch_filter_compact(ix->d_doc_ord, d_allow, n_words * 32, n, ix->d_fcounts, ix->d_fcand, &n_scan, ix->stream);
+      if (rc) return rc;
+      d_scan_cand = ix->d_fcand;
+      out->launches += 3;
+    }
+  }
+  if (st) {
+    if (d_scan_cand && !ix->ragged) { pages = n_scan; rows = n_scan * (int64_t)ix->cfg.stride_rows; }  // the device already counted
+    else rows = count_allowed_rows(ix, allow_bits, n_words, &pages);
+  }
   if (mode == MV_MODE_FLOAT) {
-    rc = float_scan(ix, n_q, d_allow, n_words, nullptr, n, 0 /* full scan: no padding rows exist */, ix->d_scores,
-                    &out->launches);
+    rc = d_scan_cand ? float_scan(ix, n_q, nullptr, 0, d_scan_cand, n_scan, 0, ix->d_scores, &out->launches)
+                     : float_scan(ix, n_q, d_allow, n_words, nullptr, n, 0 /* full scan: no padding rows exist */, ix->d_scores, &out->launches);
     if (rc) return rc;
-    out->d_scores = ix->d_scores; out->n = n; out->d_ids_map = nullptr;
+    out->d_scores = ix->d_scores; out->n = n_scan; out->d_ids_map = d_scan_cand;
     out->pages = pages; out->bytes = rows * (int64_t)kRowBytes;
   } else if (mode == MV_MODE_FLOAT_FP8) {
-    rc = fp8_scan(ix, n_q, d_allow, n_words, nullptr, n, 0, ix->d_scores, &out->launches);
+    rc = d_scan_cand ? fp8_scan(ix, n_q, nullptr, 0, d_scan_cand, n_scan, 0, ix->d_scores, &out->launches)
+                     : fp8_scan(ix, n_q, d_allow, n_words, nullptr, n, 0, ix->d_scores, &out->launches);
     if (rc) return rc;
-    out->d_scores = ix->d_scores; out->n = n; out->d_ids_map = nullptr;
+    out->d_scores = ix->d_scores; out->n = n_scan; out->d_ids_map = d_scan_cand;
     out->pages = pages; out->bytes = rows * (int64_t)kDim;
   } else if (mode == MV_MODE_BINARY) {
     BinaryArgs b{};
@@ -519,6 +544,7 @@ int add_pages_common(mv_index* ix, const void* d_src, int dtype, const int32_t* 
   for (int64_t i = 0; i < n_pages; ++i) {
     ix->h_n_rows[first + i] = n_rows[i];
     ix->h_doc_ord[first + i] = doc_ordinals ? doc_ordinals[i] : 0;
+    ix->max_doc_ord = std::max(ix->max_doc_ord, ix->h_doc_ord[first + i]);
     if (n_rows[i] != ix->cfg.stride_rows) ix->ragged = true;
     if (doc_ordinals && doc_ordinals[i] < 0) ix->tombstones = true;
   }
@@ -566,7 +592,7 @@ void mv_index_destroy(mv_index* ix) {
   if (!ix) return;
   DeviceGuard g(ix->cfg.device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-  void* ptrs[] = {ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
+  void* ptrs[] = {ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
                   ix->d_topk_ws, ix->d_q, ix->d_qf32, ix->d_qbits, ix->d_qpop, ix->d_qfde, ix->d_qoff, ix->d_allow, ix->d_out_s,
                   ix->d_out_id, ix->d_cand, ix->d_cand_scores};
   for (void* p : ptrs)
@@ -659,6 +685,7 @@ int mv_index_set_option(mv_index* ix, int option, int64_t value) {
     case MV_OPT_FDE_SCAN_VARIANT: ix->fde_scan_variant = (int)value; return MV_OK;
     case MV_OPT_BATCH_VARIANT: ix->batch_variant = (int)value; return MV_OK;
     case MV_OPT_FDE_ENCODE_VARIANT: ix->fde_encode_variant = (int)value; return MV_OK;
+    case MV_OPT_FILTER_COMPACT_PCT: ix->filter_compact_pct = (int)value; return MV_OK;
     default: set_error("unknown option %d", option); return MV_ERR_INVALID;
   }
 }
@@ -735,6 +762,7 @@ int mv_index_add_bits(mv_index* ix, const uint8_t* bits, const int32_t* n_rows, 
   for (int64_t i = 0; i < n_pages; ++i) {
     ix->h_n_rows[first + i] = n_rows[i];
     ix->h_doc_ord[first + i] = doc_ordinals ? doc_ordinals[i] : 0;
+    ix->max_doc_ord = std::max(ix->max_doc_ord, ix->h_doc_ord[first + i]);
     if (n_rows[i] != stride) ix->ragged = true;
     if (doc_ordinals && doc_ordinals[i] < 0) ix->tombstones = true;
   }
@@ -839,6 +867,7 @@ int mv_index_fill_synthetic(mv_index* ix, uint64_t seed, uint64_t first_unit, in
   for (int64_t i = 0; i < n_pages; ++i) {
     ix->h_n_rows[first + i] = n_rows;
     ix->h_doc_ord[first + i] = (int32_t)((first_unit + (uint64_t)i) / (uint64_t)pages_per_doc);
+    ix->max_doc_ord = std::max(ix->max_doc_ord, ix->h_doc_ord[first + i]);
   }
   if (n_rows != stride) ix->ragged = true;
   MV_HIP(hipMemcpyAsync(ix->d_n_rows + first, ix->h_n_rows.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice, ix->stream));
@@ -945,7 +974,7 @@ static int query_common(mv_index* ix, const void* q, int q_dtype, int32_t n_q, i
     return MV_OK;
   }
   ScanResult r;
-  int rc = run_scan(ix, q, q_dtype, n_q, mode, allow_bits, n_words, coarse_n_for(ix, k), &r, st);
+  int rc = run_scan(ix, q, q_dtype, n_q, mode, allow_bits, n_words, coarse_n_for(ix, k), &r, st, /*want_compact=*/true);
   if (rc) return rc;
   const int64_t id_base = ix->cfg.id_base;
   if (r.n == 0) {
@@ -1410,6 +1439,7 @@ int mv_index_load(const char* path, int32_t device, mv_index** out) {
     for (int64_t p = 0; p < h.size; ++p) {
       if (ix->h_n_rows[p] != h.cfg.stride_rows) ix->ragged = true;
       if (ix->h_doc_ord[p] < 0) ix->tombstones = true;
+      ix->max_doc_ord = std::max(ix->max_doc_ord, ix->h_doc_ord[p]);
     }
     if (h.size && (hipMemcpy(ix->d_n_rows, ix->h_n_rows.data(), (size_t)h.size * 4, hipMemcpyHostToDevice) != hipSuccess ||
                    hipMemcpy(ix->d_doc_ord, ix->h_doc_ord.data(), (size_t)h.size * 4, hipMemcpyHostToDevice) != hipSuccess)) { set_error("H2D of metadata failed"); rc = MV_ERR_HIP; }

@@ -167,6 +167,11 @@ struct Fp8ScanArgs {
 };
 int launch_maxsim_fp8(const Fp8ScanArgs& a, hipStream_t s);
 
+// ---------------------------------------------------------------- doc_ids filter compaction (mv_filter.hip)
+size_t filter_ws_bytes(int64_t capacity);
+int launch_filter_compact(const int32_t* d_doc_ord, const uint32_t* d_allow, int64_t n_allow_bits, int64_t n, int32_t* d_counts,
+                          int32_t* d_cand, int64_t* out_n, hipStream_t s);
+
 // ---------------------------------------------------------------- misc device helpers
 int launch_f32_to_bf16(const float* d_in, uint16_t* d_out, int64_t n, hipStream_t s);
 int launch_read_bw(const void* d_buf, int64_t bytes, float* d_sink, hipStream_t s);

@@ -156,6 +156,40 @@ def test_doc_filter_and_tombstones(mv):
     ix.close()
 
 
+def test_selective_doc_filter_compaction_equals_in_scan_masking(mv):
+    """A filter that allows < 25 % of the documents takes the compaction path (ordered candidate list + scan of the
+    candidates only); the result must be identical to masking inside the full scan, ties included."""
+    from morphik_core_amd import _lib
+    from morphik_core_amd.index import allow_bitmap
+
+    n = 9000
+    ix = _idx(mv, capacity_pages=n, stride_rows=64, with_fp8=True)
+    base = [orc.synth_rows(5, i, 0, 50) for i in range(30)]
+    ix.add([base[i % 30] for i in range(n)], [i // 4 for i in range(n)])  # duplicates -> ties; 4 pages per doc; ragged (50 of 64 rows)
+    ix.remove_doc(3)
+    ix.remove_page(4001)
+    q = orc.synth_rows(4321, 3, 0, 20)
+    n_docs = n // 4
+    rng = np.random.default_rng(1)
+    for frac in (0.2, 0.02, 0.0005):
+        docs = sorted(set(rng.choice(n_docs, size=max(1, int(n_docs * frac)), replace=False).tolist()) | {3, 1000})
+        allow = allow_bitmap(docs, n_docs)
+        for mode in ("float", "float_fp8"):
+            res = []
+            for pct in (0, 25):
+                ix.set_option(_lib.MV_OPT_FILTER_COMPACT_PCT, pct)
+                res.append(ix.query(q, 40, mode=mode, allow=allow))
+            assert res[0][1].tolist() == res[1][1].tolist() and res[0][0].tolist() == res[1][0].tolist()
+            sc = ix.score_all(q, mode=mode, allow=allow)
+            ws, wi = orc.topk(sc, 40)
+            assert res[1][1].tolist() == wi.tolist()
+            assert all((p // 4) in docs and (p // 4) != 3 and p != 4001 for p in res[1][1].tolist())
+    # a filter that allows nothing live
+    s, i = ix.query(q, 5, allow=allow_bitmap([3], n_docs))
+    assert len(i) == 0
+    ix.close()
+
+
 def test_topk_ties_k_edge_cases_and_large_k(mv):
     ix = _idx(mv, capacity_pages=6000, stride_rows=16)
     base = [orc.synth_rows(5, i, 0, 16) for i in range(40)]
