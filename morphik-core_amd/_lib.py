@@ -88,6 +88,25 @@ _lock = threading.Lock()
 _lib = None
 
 
+def _preload_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7) and its
+    libraries ask for it by FILE name, while libmvmaxsim.so asks for the SONAME: if /opt/rocm's copy were loaded first,
+    a later `import torch` would bring in a SECOND runtime and fail with "No HIP GPUs are available" (measured).
+    Loading torch's copy first makes both resolve to the same, already-loaded runtime, in either import order.
+    Without torch in the environment this is a no-op and the system ROCm runtime is used."""
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001 -- best effort: the system runtime still works for torch-free processes
+        pass
+
+
 def lib() -> C.CDLL:
     """Load libmvmaxsim.so (built in-tree by csrc/Makefile). Raises if it is missing."""
     global _lib
@@ -97,6 +116,7 @@ def lib() -> C.CDLL:
         if not os.path.exists(_LIB):
             raise MvError(-2, f"{_LIB} not found: build it with morphik_core_amd.build_library() "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        _preload_torch_hip_runtime()
         L = C.CDLL(_LIB)
         vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
         L.mv_last_error.restype = C.c_char_p

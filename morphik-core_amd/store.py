@@ -352,6 +352,51 @@ class MI355XMultiVectorStore(BaseVectorStore):
             logger.error(f"Error deleting chunks for document {document_id}: {e}")
             return False
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def save(self, directory: str) -> None:
+        """Persist the HBM index (mv_index_save: raw slabs + metadata) and the store's bookkeeping (payload rows,
+        document ordinals) so a restarted process resumes without re-embedding -- the role Postgres / S3 play for the
+        reference stores (checkpoint/resume)."""
+        import os
+
+        os.makedirs(directory, exist_ok=True)
+        with self._lock:
+            ix = self._require_index()
+            ix.save(os.path.join(directory, "index.mv"))
+            book = {
+                "version": 1, "mode": self.mode, "capacity_pages": self.capacity_pages, "stride_rows": self.stride_rows,
+                "id_base": self.id_base, "fde_coarse_n": self.fde_coarse_n,
+                "rows": [[p, r[0], r[1], r[2], r[3], r[4]] for p, r in self._rows.items()],
+                "doc_ord": self._doc_ord, "doc_app": {str(k): v for k, v in self._doc_app.items()},
+            }
+            tmp = os.path.join(directory, "store.json.tmp")
+            with open(tmp, "w") as f:
+                json.dump(book, f)
+            os.replace(tmp, os.path.join(directory, "store.json"))
+
+    @classmethod
+    def load(cls, directory: str, device: int = 0, storage: Any = None, **kw: Any) -> "MI355XMultiVectorStore":
+        import os
+
+        from .index import MvIndex
+
+        with open(os.path.join(directory, "store.json")) as f:
+            book = json.load(f)
+        self = cls(capacity_pages=book["capacity_pages"], stride_rows=book["stride_rows"], device=device, mode=book["mode"], storage=storage,
+                   id_base=book["id_base"], fde_coarse_n=book.get("fde_coarse_n", 0), **kw)
+        self._index = MvIndex.load(os.path.join(directory, "index.mv"), device=device)
+        if self.fde_coarse_n:
+            from ._lib import MV_OPT_FDE_COARSE_N
+
+            self._index.set_option(MV_OPT_FDE_COARSE_N, self.fde_coarse_n)
+        for p, doc, chunk_no, content, meta_json, app in book["rows"]:
+            self._rows[int(p)] = (doc, int(chunk_no), content, meta_json, app)
+            self._page_of[(doc, int(chunk_no))] = int(p)
+            self._doc_pages.setdefault(doc, []).append(int(p))
+        self._doc_ord = {k: int(v) for k, v in book["doc_ord"].items()}
+        self._doc_app = {int(k): v for k, v in book["doc_app"].items()}
+        return self
+
     # ------------------------------------------------------------------ introspection
     def __len__(self) -> int:
         return len(self._rows)

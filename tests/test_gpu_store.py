@@ -1,5 +1,6 @@
 """The reference's store scenarios on the REAL MI355X index (through libmvmaxsim.so)."""
 import asyncio
+import os
 
 import numpy as np
 import pytest
@@ -150,3 +151,51 @@ def test_request_coalescing_on_the_real_index():
     for w, g in zip(want, got):
         assert [(c.document_id, c.chunk_number) for c in g] == [(c.document_id, c.chunk_number) for c in w]
         np.testing.assert_allclose([c.score for c in g], [c.score for c in w], rtol=1e-5)
+
+
+def test_store_checkpoint_and_resume(tmp_path):
+    """save() -> a fresh process-like load(): same answers, same payloads, deletes and filters still work."""
+    from morphik_core_amd.store import MI355XFastMultiVectorStore
+    from tests import store_scenarios as sc2
+
+    rng = np.random.default_rng(4)
+    chunks = sc2.make_chunks(rng, n_docs=4, chunks_per_doc=3)
+    s = _store("fde_then_float")
+    sc2.run(s.store_embeddings(chunks, app_id="app-x"))
+    sc2.run(s.delete_chunks_by_document_id(chunks[3].document_id))
+    before = [sc2.run(s.query_similar(c.embedding, k=4, app_id="app-x")) for c in chunks[:3] + chunks[6:8]]
+    s.save(str(tmp_path / "ckpt"))
+    s.close()
+    r = MI355XFastMultiVectorStore.load(str(tmp_path / "ckpt"))
+    assert len(r) == len(chunks) - 3
+    after = [sc2.run(r.query_similar(c.embedding, k=4, app_id="app-x")) for c in chunks[:3] + chunks[6:8]]
+    for b, a in zip(before, after):
+        assert [(c.document_id, c.chunk_number, c.content, c.metadata) for c in a] == [(c.document_id, c.chunk_number, c.content, c.metadata) for c in b]
+        assert [c.score for c in a] == [c.score for c in b]
+    got = sc2.run(r.get_chunks_by_id([(chunks[0].document_id, chunks[0].chunk_number)]))
+    assert got[0].content == chunks[0].content
+    # the resumed store keeps ingesting and filtering
+    more = [c.model_copy(update={"document_id": "late-doc"}) for c in sc2.make_chunks(rng, n_docs=1, chunks_per_doc=2)]
+    ok, ids, _m = sc2.run(r.store_embeddings(more, app_id="app-x"))
+    assert ok and len(ids) == 2
+    res = sc2.run(r.query_similar(more[0].embedding, k=3, doc_ids=["late-doc"], app_id="app-x"))
+    assert {c.document_id for c in res} == {"late-doc"}
+    r.close()
+
+
+def test_library_first_then_torch_share_one_hip_runtime():
+    """Regression: using libmvmaxsim.so BEFORE torch initialises CUDA must not leave torch without GPUs (two HIP
+    runtimes in one process).  Fresh interpreter, library first."""
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, sys; sys.path.insert(0, %r);"
+        "from morphik_core_amd.index import MvIndex;"
+        "ix = MvIndex(capacity_pages=8, stride_rows=16); ix.add([np.ones((4,128), np.float32)]);"
+        "s, i = ix.query(np.ones((2,128), np.float32), 1);"
+        "import torch; t = torch.ones(4, device='cuda') * 2;"
+        "assert t.sum().item() == 8.0 and i.tolist() == [0]; print('ok')"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
