@@ -64,7 +64,7 @@ __global__ void ids64_to_32_kernel(const int64_t* in, int32_t* out, int n) {
 
 using namespace mv;
 
-constexpr int kMaxQRowsPerPass = 64;  // 4 MFMA row tiles held in VGPRs
+constexpr int kMaxQRowsPerPass = 128;  // 8 MFMA row tiles held in VGPRs
 constexpr int kMaxCand = 65536;
 
 struct mv_index {

@@ -37,7 +37,7 @@ namespace {
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kMaxQTiles = 4;
+constexpr int kMaxQTiles = 8;  // 128 query rows per pass (A fragments: 16 VGPRs per tile)
 
 struct KArgs {
   const char* slab;
@@ -112,7 +112,7 @@ __device__ __forceinline__ float finish_wave(const f32x4 (&mx)[MT], bool clamp) 
   return total;
 }
 
-// Cross-wave finish for four waves that split one page's tiles. red: 4 x 64 floats of LDS.
+// Cross-wave finish for four waves that split one page's tiles. red: 4 x 128 floats of LDS.
 template <int MT>
 __device__ __forceinline__ void finish_block(const f32x4 (&mx)[MT], bool clamp, float* red, int wave, int lane,
                                              float* out) {
@@ -122,15 +122,20 @@ __device__ __forceinline__ void finish_block(const f32x4 (&mx)[MT], bool clamp, 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float v = group16_max(mx[m][i]);
-      if (r == 0) red[wave * 64 + m * 16 + g * 4 + i] = v;
+      if (r == 0) red[wave * 128 + m * 16 + g * 4 + i] = v;
     }
   __syncthreads();
   if (wave == 0) {
     float v = 0.f;
-    if (lane < MT * 16) {
-      v = fmaxf(fmaxf(red[lane], red[64 + lane]), fmaxf(red[128 + lane], red[192 + lane]));
-      if (clamp) v = fmaxf(v, 0.f);
-      if (v == -INFINITY) v = 0.f;
+#pragma unroll
+    for (int h = 0; h < (MT * 16 + 63) / 64; ++h) {  // query rows lane, lane + 64
+      const int row = lane + 64 * h;
+      if (row < MT * 16) {
+        float x = fmaxf(fmaxf(red[row], red[128 + row]), fmaxf(red[256 + row], red[384 + row]));
+        if (clamp) x = fmaxf(x, 0.f);
+        if (x == -INFINITY) x = 0.f;
+        v += x;
+      }
     }
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s);
@@ -143,7 +148,7 @@ __device__ __forceinline__ void finish_block(const f32x4 (&mx)[MT], bool clamp, 
 template <int MT, int WPP, bool NT>
 __global__ __launch_bounds__(256) void maxsim_direct_kernel(KArgs a) {
   constexpr int PF = 3;  // register ring depth (tiles in flight per wave = PF-1 .. PF)
-  __shared__ float red[256];
+  __shared__ float red[512];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -220,7 +225,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int MT, int WPP, int D, bool NT = false, bool CONTIG = false>
 __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
   // one __shared__ object only (a second one makes hipcc drain vmcnt before every ds_read)
-  __shared__ __attribute__((aligned(16))) char lds[4 * D * kTileBytes + 1024];
+  __shared__ __attribute__((aligned(16))) char lds[4 * D * kTileBytes + 2048];
   float* red = reinterpret_cast<float*>(lds + 4 * D * kTileBytes);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -422,7 +427,11 @@ int launch_maxsim_bf16(const MaxsimArgs& a, int variant, hipStream_t s) {
     case 1: return launch_mt<1>(k, variant, s);
     case 2: return launch_mt<2>(k, variant, s);
     case 3: return launch_mt<3>(k, variant, s);
-    default: return launch_mt<4>(k, variant, s);
+    case 4: return launch_mt<4>(k, variant, s);
+    case 5: return launch_mt<5>(k, variant, s);
+    case 6: return launch_mt<6>(k, variant, s);
+    case 7: return launch_mt<7>(k, variant, s);
+    default: return launch_mt<8>(k, variant, s);
   }
 }
 

@@ -78,7 +78,7 @@ def test_float_maxsim_all_variants_small(mv, variant):
     ix.close()
 
 
-@pytest.mark.parametrize("nq", [1, 16, 17, 32, 64, 65, 100])
+@pytest.mark.parametrize("nq", [1, 16, 17, 32, 64, 65, 100, 112, 128, 129, 200, 300])
 def test_float_maxsim_1024_patches_query_lengths(mv, nq):
     ix = _idx(mv, capacity_pages=64, stride_rows=1024)
     ix.fill_synthetic(1234, 100, 40)
@@ -87,6 +87,12 @@ def test_float_maxsim_1024_patches_query_lengths(mv, nq):
     want = orc.maxsim_float_np(orc.bf16_to_f32(q), orc.bf16_to_f32(pages))
     got = ix.score_all(q)
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6)
+    if nq in (100, 128, 200):  # long queries (5..8 row tiles per pass, several passes) on every kernel family
+        from morphik_core_amd import _lib
+
+        for variant in (0, 1, 2, 7):
+            ix.set_option(_lib.MV_OPT_MAXSIM_VARIANT, variant)
+            np.testing.assert_allclose(ix.score_all(q), want, rtol=1e-4, atol=1e-6)
     ix.close()
 
 

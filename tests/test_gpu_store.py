@@ -183,19 +183,25 @@ def test_store_checkpoint_and_resume(tmp_path):
     r.close()
 
 
-def test_library_first_then_torch_share_one_hip_runtime():
+def test_library_and_torch_share_one_hip_runtime():
     """Regression: using libmvmaxsim.so BEFORE torch initialises CUDA must not leave torch without GPUs (two HIP
-    runtimes in one process).  Fresh interpreter, library first."""
-    import subprocess
-    import sys
+    runtimes in one process).  The binding preloads torch's bundled libamdhip64: exactly one copy may be mapped, and
+    torch must still see the GPU after the library has been used (this file runs after the parity tests, which use
+    the library first)."""
+    import importlib.util
 
-    code = (
-        "import numpy as np, sys; sys.path.insert(0, %r);"
-        "from morphik_core_amd.index import MvIndex;"
-        "ix = MvIndex(capacity_pages=8, stride_rows=16); ix.add([np.ones((4,128), np.float32)]);"
-        "s, i = ix.query(np.ones((2,128), np.float32), 1);"
-        "import torch; t = torch.ones(4, device='cuda') * 2;"
-        "assert t.sum().item() == 8.0 and i.tolist() == [0]; print('ok')"
-    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+    from morphik_core_amd.index import MvIndex
+
+    ix = MvIndex(capacity_pages=8, stride_rows=16)
+    ix.add([np.ones((4, 128), np.float32)])
+    s, i = ix.query(np.ones((2, 128), np.float32), 1)
+    assert i.tolist() == [0]
+    ix.close()
+    with open("/proc/self/maps") as f:
+        hips = sorted({ln.split()[-1] for ln in f if "libamdhip64" in ln})
+    assert len(hips) == 1, hips
+    if importlib.util.find_spec("torch") is not None:
+        import torch
+
+        assert os.path.dirname(hips[0]) == os.path.join(os.path.dirname(torch.__file__), "lib")
+        assert (torch.ones(4, device="cuda") * 2).sum().item() == 8.0
