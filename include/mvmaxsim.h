@@ -138,6 +138,11 @@ MV_API int mv_index_add_bits(mv_index* ix, const uint8_t* bits, const int32_t* n
 MV_API int mv_index_remove_doc(mv_index* ix, int32_t doc_ordinal, int64_t* out_n);
 MV_API int mv_index_remove_page(mv_index* ix, int64_t page);
 
+/* Reclaim the slots of tombstoned pages: live pages move down IN ORDER to a dense prefix of every slab (in place,
+ * through a 256 MiB staging buffer).  out_old_to_new (nullable) has mv_index_size() entries: new local page id or -1.
+ * Page ids change: the caller remaps whatever it keyed by page id.  *out_new_size = pages after compaction. */
+MV_API int mv_index_compact(mv_index* ix, int64_t* out_old_to_new, int64_t* out_new_size);
+
 /* Read back bf16 rows of pages [page0, page0+n) (stride_rows x dim each) to a host buffer. */
 MV_API int mv_index_read_pages(mv_index* ix, int64_t page0, int64_t n_pages, void* out_bf16);
 /* Overwrite rows [row0,row0+n) of one page with host bf16 data (test/bench: planted neighbours).

@@ -79,7 +79,7 @@ MV_CAL_READ_NT, MV_CAL_MFMA_BF16 = 1, 2
 EXPORTS = [
     "mv_last_error", "mv_version", "mv_device_count", "mv_index_create", "mv_index_destroy", "mv_index_set_option",
     "mv_index_size", "mv_index_capacity", "mv_index_add", "mv_index_add_device", "mv_index_add_bits", "mv_index_remove_doc",
-    "mv_index_remove_page", "mv_index_read_pages", "mv_index_write_rows", "mv_index_replace_page", "mv_index_read_fp8", "mv_index_fill_synthetic", "mv_synth_rows",
+    "mv_index_remove_page", "mv_index_compact", "mv_index_read_pages", "mv_index_write_rows", "mv_index_replace_page", "mv_index_read_fp8", "mv_index_fill_synthetic", "mv_synth_rows",
     "mv_query_topk", "mv_query_topk_device", "mv_query_topk_batch", "mv_score_all", "mv_score_candidates", "mv_sign_pack", "mv_hamming_batch",
     "mv_fde_output_dim", "mv_fde_encode", "mv_calibrate_read_bw", "mv_calibrate", "mv_index_save", "mv_index_load",
 ]
@@ -135,6 +135,7 @@ def lib() -> C.CDLL:
         L.mv_index_add_bits.argtypes = [vp, vp, vp, i64, vp, C.POINTER(i64)]
         L.mv_index_remove_doc.argtypes = [vp, i32, C.POINTER(i64)]
         L.mv_index_remove_page.argtypes = [vp, i64]
+        L.mv_index_compact.argtypes = [vp, vp, C.POINTER(i64)]
         L.mv_index_read_pages.argtypes = [vp, i64, i64, vp]
         L.mv_index_write_rows.argtypes = [vp, i64, i32, i32, vp]
         L.mv_index_replace_page.argtypes = [vp, i64, vp, i32]

@@ -921,6 +921,94 @@ int mv_index_replace_page(mv_index* ix, int64_t page, const void* bf16_rows, int
   return rc;
 }
 
+// ---------------------------------------------------------------------------------- compaction
+__global__ __launch_bounds__(256) void gather_pages_kernel(const char* base, size_t page_bytes, const int64_t* src_pages, int64_t n,
+                                                           char* dst) {
+  // grid.x = pages of the batch, grid.y = 16-byte lanes of a page in units of 256 threads
+  const int64_t p = blockIdx.x;
+  const size_t off = ((size_t)blockIdx.y * 256 + threadIdx.x) * 16;
+  if (p >= n || off >= page_bytes) return;
+  *reinterpret_cast<uint4*>(dst + (size_t)p * page_bytes + off) =
+      *reinterpret_cast<const uint4*>(base + (size_t)src_pages[p] * page_bytes + off);
+}
+
+// Reclaim the slots of tombstoned pages: live pages move down, in order, to a dense prefix of every slab.
+// old_to_new[old page] = new page or -1 (removed); the caller remaps its ids (store.py does).  In place: batches of
+// live pages are gathered into a staging buffer and written back as one contiguous block -- sources are always at or
+// above their destination and batches ascend, so a write never lands on a page that is still to be read.
+int mv_index_compact(mv_index* ix, int64_t* out_old_to_new, int64_t* out_new_size) {
+  if (!ix) { set_error("null index"); return MV_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->cfg.device);
+  const int64_t n = ix->size;
+  std::vector<int64_t> live;
+  live.reserve((size_t)n);
+  for (int64_t p = 0; p < n; ++p) {
+    const bool alive = ix->h_doc_ord[p] >= 0;
+    if (out_old_to_new) out_old_to_new[p] = alive ? (int64_t)live.size() : -1;
+    if (alive) live.push_back(p);
+  }
+  const int64_t m = (int64_t)live.size();
+  if (out_new_size) *out_new_size = m;
+  if (m == n) return MV_OK;  // nothing to reclaim
+  int64_t first_moved = 0;
+  while (first_moved < m && live[first_moved] == first_moved) ++first_moved;
+  struct Slab { char* base; size_t page_bytes; };
+  std::vector<Slab> slabs;
+  const size_t stride = (size_t)ix->cfg.stride_rows;
+  if (ix->cfg.flags & MV_WITH_FLOAT) slabs.push_back({(char*)ix->slab, stride * kRowBytes});
+  if (ix->cfg.flags & MV_WITH_FP8) { slabs.push_back({(char*)ix->slab8, stride * kDim}); slabs.push_back({(char*)ix->inv_scale8, 16}); }
+  if (ix->cfg.flags & MV_WITH_BINARY) slabs.push_back({(char*)ix->bits, stride * kSignBytes});
+  if (ix->cfg.flags & MV_WITH_FDE) { slabs.push_back({(char*)ix->fde, (size_t)ix->fde_t.out_dim * 2}); slabs.push_back({(char*)ix->fde_inv_norm, 16}); }
+  int rc = MV_OK;
+  int64_t* d_idx = nullptr;
+  char* stage = nullptr;
+  const size_t stage_bytes = (size_t)256 << 20;
+  if (hipMalloc(&d_idx, (size_t)std::max<int64_t>(m - first_moved, 1) * 8) != hipSuccess || hipMalloc(&stage, stage_bytes) != hipSuccess) {
+    set_error("compact: out of device memory for the staging buffer");
+    rc = MV_ERR_NOMEM;
+  }
+  if (!rc && hipMemcpy(d_idx, live.data() + first_moved, (size_t)(m - first_moved) * 8, hipMemcpyHostToDevice) != hipSuccess) { set_error("compact: H2D failed"); rc = MV_ERR_HIP; }
+  for (const Slab& sl : slabs) {
+    if (rc) break;
+    if (sl.page_bytes == 16) {
+      // per-page scalars (fp32): 4-byte records -- move on the host side of a small round trip
+      std::vector<float> h((size_t)n);
+      if (hipMemcpy(h.data(), sl.base, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_error("compact: D2H failed"); rc = MV_ERR_HIP; break; }
+      for (int64_t j = first_moved; j < m; ++j) h[(size_t)j] = h[(size_t)live[j]];
+      if (hipMemcpy(sl.base, h.data(), (size_t)m * 4, hipMemcpyHostToDevice) != hipSuccess) { set_error("compact: H2D failed"); rc = MV_ERR_HIP; }
+      continue;
+    }
+    const int64_t batch = std::max<int64_t>(1, (int64_t)(stage_bytes / sl.page_bytes));
+    for (int64_t j0 = first_moved; j0 < m && !rc; j0 += batch) {
+      const int64_t c = std::min(batch, m - j0);
+      const unsigned gy = (unsigned)((sl.page_bytes / 16 + 255) / 256);
+      hipLaunchKernelGGL(gather_pages_kernel, dim3((unsigned)c, gy), dim3(256), 0, ix->stream, (const char*)sl.base, sl.page_bytes,
+                         (const int64_t*)(d_idx + (j0 - first_moved)), c, stage);
+      if (hipMemcpyAsync(sl.base + (size_t)j0 * sl.page_bytes, stage, (size_t)c * sl.page_bytes, hipMemcpyDeviceToDevice, ix->stream) != hipSuccess ||
+          hipStreamSynchronize(ix->stream) != hipSuccess) { set_error("compact: device copy failed"); rc = MV_ERR_HIP; }
+    }
+  }
+  if (d_idx) (void)hipFree(d_idx);
+  if (stage) (void)hipFree(stage);
+  if (rc) return rc;
+  for (int64_t j = first_moved; j < m; ++j) {
+    ix->h_n_rows[(size_t)j] = ix->h_n_rows[(size_t)live[j]];
+    ix->h_doc_ord[(size_t)j] = ix->h_doc_ord[(size_t)live[j]];
+  }
+  for (int64_t j = m; j < n; ++j) { ix->h_n_rows[(size_t)j] = 0; ix->h_doc_ord[(size_t)j] = -1; }
+  ix->size = m;
+  ix->tombstones = false;
+  ix->ragged = false;
+  for (int64_t j = 0; j < m; ++j)
+    if (ix->h_n_rows[(size_t)j] != ix->cfg.stride_rows) { ix->ragged = true; break; }
+  if (n > 0) {
+    MV_HIP(hipMemcpy(ix->d_n_rows, ix->h_n_rows.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    MV_HIP(hipMemcpy(ix->d_doc_ord, ix->h_doc_ord.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  }
+  return MV_OK;
+}
+
 // Read back the e4m3 codes (stride_rows x 128 bytes per page) and 2^-e scales of pages [page0, page0+n).
 int mv_index_read_fp8(mv_index* ix, int64_t page0, int64_t n_pages, void* out_codes, float* out_inv_scale) {
   if (!ix || !out_codes || !out_inv_scale || page0 < 0 || n_pages < 0 || page0 + n_pages > ix->size) { set_error("read_fp8: range"); return MV_ERR_INVALID; }

@@ -230,6 +230,15 @@ class MvIndex:
     def remove_page(self, page: int) -> None:
         check(lib().mv_index_remove_page(self._h, page))
 
+    def compact(self) -> np.ndarray:
+        """Reclaim tombstoned slots (live pages move down in order). -> old_to_new int64 [old size], -1 = removed.
+        Page ids change: remap whatever was keyed by them (MI355XMultiVectorStore.compact does)."""
+        old = len(self)
+        o2n = np.empty(max(old, 1), np.int64)
+        new_size = C.c_int64()
+        check(lib().mv_index_compact(self._h, o2n.ctypes.data, C.byref(new_size)))
+        return o2n[:old]
+
     # -- query
     def query(self, q: Any, k: int, mode: str = "float", allow: Optional[np.ndarray] = None, want_stats: bool = False):
         """-> (scores[n] float32, ids[n] int64 global page ids[, QueryStats]); n <= k."""

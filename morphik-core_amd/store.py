@@ -352,6 +352,20 @@ class MI355XMultiVectorStore(BaseVectorStore):
             logger.error(f"Error deleting chunks for document {document_id}: {e}")
             return False
 
+    # ------------------------------------------------------------------ maintenance
+    def compact(self) -> int:
+        """Reclaim the slab slots of deleted / replaced pages (mv_index_compact) and remap the bookkeeping.
+        Returns the number of slots reclaimed.  Page ids are internal to the store, so callers see no change."""
+        with self._lock:
+            ix = self._require_index()
+            before = len(ix)
+            o2n = ix.compact()
+            remap = {self.id_base + int(o): self.id_base + int(n) for o, n in enumerate(o2n.tolist()) if n >= 0}
+            self._rows = {remap[p]: r for p, r in self._rows.items() if p in remap}
+            self._page_of = {key: remap[p] for key, p in self._page_of.items() if p in remap}
+            self._doc_pages = {d: [remap[p] for p in ps if p in remap] for d, ps in self._doc_pages.items()}
+            return before - len(ix)
+
     # ------------------------------------------------------------------ checkpoint / resume
     def save(self, directory: str) -> None:
         """Persist the HBM index (mv_index_save: raw slabs + metadata) and the store's bookkeeping (payload rows,

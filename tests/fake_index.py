@@ -66,6 +66,16 @@ class OracleIndex:
         sc, ids = orc.topk(s, k)
         return sc, ids + self.id_base
 
+    def compact(self):
+        o2n, pages, ords = [], [], []
+        for p, o, a in zip(self.pages, self.ords, self.alive):
+            o2n.append(len(pages) if a else -1)
+            if a:
+                pages.append(p)
+                ords.append(o)
+        self.pages, self.ords, self.alive = pages, ords, [True] * len(pages)
+        return np.array(o2n, np.int64)
+
     def query_batch(self, queries, k, mode=None, allow=None, want_stats=False, allows=None, n_docs=0):
         out = []
         for j, q in enumerate(queries):

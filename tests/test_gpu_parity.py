@@ -646,6 +646,35 @@ def test_concurrent_threads_on_one_index_get_their_own_answers(mv):
     ix.close()
 
 
+def test_compaction_moves_every_slab_in_order(mv):
+    n = 700
+    ix = _idx(mv, capacity_pages=n, stride_rows=48, with_binary=True, with_fde=True, with_fp8=True)
+    ix.fill_synthetic(1234, 0, n, n_rows=40, pages_per_doc=3)
+    rng = np.random.default_rng(3)
+    dead_docs = sorted(rng.choice(n // 3, size=60, replace=False).tolist())
+    for d in dead_docs:
+        ix.remove_doc(d)
+    ix.remove_page(0)
+    ix.remove_page(n - 1)
+    q = orc.synth_rows(4321, 5, 0, 32)
+    before = {m: ix.score_all(q, mode=m) for m in ("float", "binary", "float_fp8", "fde")}
+    pages_before = ix.read_pages(0, n)
+    o2n = ix.compact()
+    live = np.nonzero(o2n >= 0)[0]
+    assert len(ix) == live.size and np.array_equal(o2n[live], np.arange(live.size))
+    assert np.all(np.isinf(before["float"][o2n < 0])) and not np.any(np.isinf(before["float"][live]))
+    assert np.array_equal(ix.read_pages(0, live.size), pages_before[live])
+    for m, sc in before.items():
+        got = ix.score_all(q, mode=m)
+        assert got.tolist() == sc[live].tolist(), m  # same bytes in a dense prefix -> bit-identical scores
+    s, i = ix.query(q, 10)
+    ws, wi = orc.topk(before["float"], 10)
+    assert o2n[wi].tolist() == i.tolist() and s.tolist() == ws.tolist()
+    first = ix.add([orc.bf16_to_f32(orc.synth_rows(9, 1, 0, 40))], [5])  # reclaimed capacity is usable
+    assert first == live.size and ix.compact().size == live.size + 1  # nothing left to reclaim
+    ix.close()
+
+
 # ------------------------------------------------------------------ persistence
 def test_save_load_roundtrip(mv, tmp_path):
     from morphik_core_amd.index import MvIndex

@@ -83,3 +83,26 @@ def test_concurrent_requests_are_coalesced_into_one_batched_scan():
         assert [c.score for c in g] == [c.score for c in w] and len(g) <= k
         if d:
             assert {c.document_id for c in g} <= set(d)
+
+
+def test_compaction_reclaims_slots_and_keeps_answers():
+    rng = np.random.default_rng(7)
+    chunks = sc.make_chunks(rng, n_docs=5, chunks_per_doc=3)
+    s = _store(mode="float")
+    sc.run(s.store_embeddings(chunks))
+    sc.run(s.delete_chunks_by_document_id("doc1"))
+    sc.run(s.store_embeddings([chunks[0]]))  # upsert of an existing (doc, chunk): the old slot is tombstoned
+    keep = [c for c in chunks if c.document_id != "doc1"]
+    before = [sc.run(s.query_similar(c.embedding, k=5)) for c in keep]
+    assert s.compact() == 4 and s.compact() == 0
+    assert len(s._require_index()) == len(keep)
+    after = [sc.run(s.query_similar(c.embedding, k=5)) for c in keep]
+    for b, a in zip(before, after):
+        assert [(c.document_id, c.chunk_number, c.content) for c in a] == [(c.document_id, c.chunk_number, c.content) for c in b]
+        assert [c.score for c in a] == [c.score for c in b]
+    got = sc.run(s.get_chunks_by_id([("doc4", 2), ("doc1", 0)]))
+    assert [(c.document_id, c.chunk_number) for c in got] == [("doc4", 2)]
+    # the reclaimed capacity is usable again and filters still resolve
+    more = [c.model_copy(update={"document_id": "new"}) for c in sc.make_chunks(rng, n_docs=1, chunks_per_doc=2)]
+    sc.run(s.store_embeddings(more))
+    assert {c.document_id for c in sc.run(s.query_similar(more[0].embedding, k=2, doc_ids=["new"]))} == {"new"}
