@@ -111,6 +111,12 @@ struct mv_index {
   int32_t* d_cand = nullptr;   // [kMaxCand]
   float* d_cand_scores = nullptr;
   int q_rows_cap = 0;
+  // pinned host staging of the query (fp32 + padded bf16) and of the k results: async copies, no sync on the way in
+  float* h_qf32 = nullptr;
+  uint16_t* h_qbf16 = nullptr;
+  float* h_out_s = nullptr;
+  int64_t* h_out_id = nullptr;
+  hipEvent_t ev_stage = nullptr;  // recorded behind the H2D copies of the staging buffers
   hipEvent_t ev[6] = {};
   std::mutex mu;
   // options
@@ -143,10 +149,14 @@ int ensure_query_cap(mv_index* ix, int n_rows) {
   const int padded = ((n_rows + 15) / 16) * 16;
   if (padded <= ix->q_rows_cap) return MV_OK;
   const int cap = std::max(padded, 256);
+  if (ix->stream) (void)hipStreamSynchronize(ix->stream);  // nothing may still read the buffers being replaced
   if (ix->d_q) (void)hipFree(ix->d_q);
   if (ix->d_qf32) (void)hipFree(ix->d_qf32);
   if (ix->d_qbits) (void)hipFree(ix->d_qbits);
   if (ix->d_qpop) (void)hipFree(ix->d_qpop);
+  if (ix->h_qf32) (void)hipHostFree(ix->h_qf32);
+  if (ix->h_qbf16) (void)hipHostFree(ix->h_qbf16);
+  ix->h_qf32 = nullptr; ix->h_qbf16 = nullptr;
   if (ix->d_q8hi) (void)hipFree(ix->d_q8hi);
   if (ix->d_q8lo) (void)hipFree(ix->d_q8lo);
   if (ix->d_q8fac) (void)hipFree(ix->d_q8fac);
@@ -159,6 +169,8 @@ int ensure_query_cap(mv_index* ix, int n_rows) {
   MV_HIP(hipMalloc(&ix->d_q8hi, (size_t)cap * kDim));
   MV_HIP(hipMalloc(&ix->d_q8lo, (size_t)cap * kDim));
   MV_HIP(hipMalloc(&ix->d_q8fac, (size_t)cap * 4));
+  MV_HIP(hipHostMalloc((void**)&ix->h_qf32, (size_t)cap * kDim * 4, hipHostMallocDefault));
+  MV_HIP(hipHostMalloc((void**)&ix->h_qbf16, (size_t)cap * kDim * 2, hipHostMallocDefault));
   ix->q_rows_cap = cap;
   return MV_OK;
 }
@@ -169,22 +181,28 @@ int upload_query(mv_index* ix, const void* q, int q_dtype, int n_q, bool want_bf
   int rc = ensure_query_cap(ix, n_q);
   if (rc) return rc;
   const int padded = ((n_q + 15) / 16) * 16;
-  std::vector<float> f((size_t)n_q * kDim);
-  if (q_dtype == MV_F32) {
-    memcpy(f.data(), q, f.size() * 4);
-  } else {
-    const uint16_t* h = (const uint16_t*)q;
-    for (size_t i = 0; i < f.size(); ++i) f[i] = host_bf16_to_f32(h[i]);
+  // the pinned staging buffers are free once the previous query's H2D copies have run
+  if (ix->ev_stage) MV_HIP(hipEventSynchronize(ix->ev_stage));
+  const size_t ne = (size_t)n_q * kDim;
+  float* f = ix->h_qf32;
+  const bool need_f32 = want_f32 || want_bits || want_fp8 || (want_bf16 && q_dtype == MV_F32);
+  if (need_f32) {
+    if (q_dtype == MV_F32) {
+      memcpy(f, q, ne * 4);
+    } else {
+      const uint16_t* h = (const uint16_t*)q;
+      for (size_t i = 0; i < ne; ++i) f[i] = host_bf16_to_f32(h[i]);
+    }
   }
   if (want_bf16) {
-    std::vector<uint16_t> b((size_t)padded * kDim, 0);
-    if (q_dtype == MV_BF16) memcpy(b.data(), q, (size_t)n_q * kDim * 2);
-    else for (size_t i = 0; i < f.size(); ++i) b[i] = host_f32_to_bf16(f[i]);
-    MV_HIP(hipMemcpyAsync(ix->d_q, b.data(), b.size() * 2, hipMemcpyHostToDevice, ix->stream));
-    MV_HIP(hipStreamSynchronize(ix->stream));  // b goes out of scope
+    uint16_t* b = ix->h_qbf16;
+    if (q_dtype == MV_BF16) memcpy(b, q, ne * 2);
+    else for (size_t i = 0; i < ne; ++i) b[i] = host_f32_to_bf16(f[i]);
+    memset(b + ne, 0, ((size_t)padded * kDim - ne) * 2);
+    MV_HIP(hipMemcpyAsync(ix->d_q, b, (size_t)padded * kDim * 2, hipMemcpyHostToDevice, ix->stream));
   }
   if (want_f32 || want_bits || want_fp8) {
-    MV_HIP(hipMemcpyAsync(ix->d_qf32, f.data(), f.size() * 4, hipMemcpyHostToDevice, ix->stream));
+    MV_HIP(hipMemcpyAsync(ix->d_qf32, f, ne * 4, hipMemcpyHostToDevice, ix->stream));
     if (want_bits) {
       rc = launch_sign_pack_f32(ix->d_qf32, n_q, kDim, ix->d_qbits, ix->stream);
       if (rc) return rc;
@@ -193,8 +211,8 @@ int upload_query(mv_index* ix, const void* q, int q_dtype, int n_q, bool want_bf
       rc = launch_fp8_query_prep(ix->d_qf32, n_q, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->stream);
       if (rc) return rc;
     }
-    MV_HIP(hipStreamSynchronize(ix->stream));
   }
+  MV_HIP(hipEventRecord(ix->ev_stage, ix->stream));
   return MV_OK;
 }
 
@@ -600,6 +618,9 @@ void mv_index_destroy(mv_index* ix) {
   fde_tables_destroy(&ix->fde_t);
   for (auto& e : ix->ev)
     if (e) (void)hipEventDestroy(e);
+  if (ix->ev_stage) (void)hipEventDestroy(ix->ev_stage);
+  for (void* hp : {(void*)ix->h_qf32, (void*)ix->h_qbf16, (void*)ix->h_out_s, (void*)ix->h_out_id})
+    if (hp) (void)hipHostFree(hp);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
   delete ix;
 }
@@ -633,6 +654,9 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); rc = MV_ERR_HIP; }
   for (auto& e : ix->ev)
     if (!rc && hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); rc = MV_ERR_HIP; }
+  if (!rc && hipEventCreateWithFlags(&ix->ev_stage, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); rc = MV_ERR_HIP; }
+  if (!rc && (hipHostMalloc((void**)&ix->h_out_s, (size_t)kTopkMaxDeviceK * 4, hipHostMallocDefault) != hipSuccess ||
+              hipHostMalloc((void**)&ix->h_out_id, (size_t)kTopkMaxDeviceK * 8, hipHostMallocDefault) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = MV_ERR_NOMEM; }
   if (cfg->flags & MV_WITH_FLOAT) alloc((void**)&ix->slab, rows * kRowBytes + 32768, "bf16 page slab");  // +32 KiB: the batched scans DMA whole 16 / 32 KiB chunks
   if (cfg->flags & MV_WITH_FP8) {
     alloc((void**)&ix->slab8, rows * kDim + 4096, "fp8 page slab");  // +4 KiB: the scan DMAs whole 4 KiB pieces
@@ -1088,15 +1112,15 @@ static int query_common(mv_index* ix, const void* q, int q_dtype, int32_t n_q, i
       }
       return st ? finish_stats(ix, st, true) : MV_OK;
     }
-    std::vector<float> s((size_t)k);
-    std::vector<int64_t> id((size_t)k);
-    MV_HIP(hipMemcpyAsync(s.data(), ds, (size_t)k * 4, hipMemcpyDeviceToHost, ix->stream));
-    MV_HIP(hipMemcpyAsync(id.data(), di, (size_t)k * 8, hipMemcpyDeviceToHost, ix->stream));
+    float* s = ix->h_out_s;
+    int64_t* id = ix->h_out_id;
+    MV_HIP(hipMemcpyAsync(s, ds, (size_t)k * 4, hipMemcpyDeviceToHost, ix->stream));
+    MV_HIP(hipMemcpyAsync(id, di, (size_t)k * 8, hipMemcpyDeviceToHost, ix->stream));
     MV_HIP(hipStreamSynchronize(ix->stream));
     int32_t n = 0;
     while (n < k && id[n] >= 0) ++n;
-    memcpy(h_scores, s.data(), (size_t)n * 4);
-    memcpy(h_ids, id.data(), (size_t)n * 8);
+    memcpy(h_scores, s, (size_t)n * 4);
+    memcpy(h_ids, id, (size_t)n * 8);
     if (out_n) *out_n = n;
     return finish_stats(ix, st, true);
   }
