@@ -52,6 +52,24 @@ def allgather_topk(local_scores, local_ids, k: int, group=None):
     return merge_topk(gs.view(world, kk), gi.view(world, kk), k)
 
 
+def allgather_topk_batch(local_scores, local_ids, k: int, group=None):
+    """Batched form: local_* are [B, kk] (row b = this shard's top-kk of query b, padded with -inf / -1).  ONE
+    all-gather of B*kk pairs per rank; returns a list of (scores, ids) per query."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    B, kk = local_scores.shape
+    if world == 1:
+        return [merge_topk(local_scores[b][None], local_ids[b][None], k) for b in range(B)]
+    gs = torch.empty(world * B * kk, dtype=local_scores.dtype, device=local_scores.device)
+    gi = torch.empty(world * B * kk, dtype=local_ids.dtype, device=local_ids.device)
+    dist.all_gather_into_tensor(gs, local_scores.contiguous().view(-1), group=group)
+    dist.all_gather_into_tensor(gi, local_ids.contiguous().view(-1), group=group)
+    gs, gi = gs.view(world, B, kk), gi.view(world, B, kk)
+    return [merge_topk(gs[:, b], gi[:, b], k) for b in range(B)]
+
+
 class ShardedSearcher:
     """Wraps a per-rank search function.  `local_topk(q, k)` must return two tensors of exactly k entries
     (padded with -inf / -1) on the collective's device; on the GPU it is MvIndex.query_device writing
@@ -64,6 +82,12 @@ class ShardedSearcher:
     def query(self, q, k: int):
         s, i = self.local_topk(q, k)
         return allgather_topk(s, i, k, self.group)
+
+    def query_batch(self, queries, k: int, local_topk_batch: Callable):
+        """Several queries in one slab pass per shard (mv_query_topk_batch) and one all-gather for all of them.
+        `local_topk_batch(queries, k)` -> two [B, k] tensors padded with (-inf, -1)."""
+        s, i = local_topk_batch(queries, k)
+        return allgather_topk_batch(s, i, k, self.group)
 
 
 def make_gpu_local_topk(index, device=None, mode: str = "float", collect_stats: Optional[list] = None):
@@ -83,3 +107,22 @@ def make_gpu_local_topk(index, device=None, mode: str = "float", collect_stats: 
         return s, i
 
     return local_topk
+
+
+def make_gpu_local_topk_batch(index, device=None, mode: str = "float"):
+    """Adapter: MvIndex.query_batch -> padded [B, k] tensors on the collective's device."""
+    import numpy as np
+    import torch
+
+    dev = torch.device("cuda", index.device) if device is None else device
+
+    def local_topk_batch(queries, k):
+        res = index.query_batch(queries, k, mode=mode)
+        s = np.full((len(res), k), -np.inf, np.float32)
+        i = np.full((len(res), k), -1, np.int64)
+        for b, (rs, ri) in enumerate(res):
+            s[b, : len(rs)] = rs
+            i[b, : len(ri)] = ri
+        return torch.from_numpy(s).to(dev), torch.from_numpy(i).to(dev)
+
+    return local_topk_batch

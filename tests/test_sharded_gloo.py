@@ -51,6 +51,17 @@ def _worker(rank, world, port, n_total, k, out_q):
     searcher = sharded.ShardedSearcher(local_topk)
     q = orc.synth_rows(4321, 0, 0, 6)
     s, i = searcher.query(q, k)
+
+    def local_topk_batch(qs, kk):  # the batched form: [B, kk] per shard, one all-gather for all queries
+        rows = [local_topk(qq, kk) for qq in qs]
+        return torch.stack([r[0] for r in rows]), torch.stack([r[1] for r in rows])
+
+    qs = [orc.synth_rows(4321, j, 0, 6) for j in range(3)]
+    batch = searcher.query_batch(qs, k, local_topk_batch)
+    assert batch[0][1].tolist() == i.tolist() and batch[0][0].tolist() == s.tolist()
+    for qq, (bs, bi) in zip(qs, batch):
+        ss, si = searcher.query(qq, k)
+        assert bi.tolist() == si.tolist() and bs.tolist() == ss.tolist()
     out_q.put((rank, s.numpy().tolist(), i.numpy().tolist()))
     dist.barrier()
     dist.destroy_process_group()
