@@ -106,3 +106,43 @@ def test_compaction_reclaims_slots_and_keeps_answers():
     more = [c.model_copy(update={"document_id": "new"}) for c in sc.make_chunks(rng, n_docs=1, chunks_per_doc=2)]
     sc.run(s.store_embeddings(more))
     assert {c.document_id for c in sc.run(s.query_similar(more[0].embedding, k=2, doc_ids=["new"]))} == {"new"}
+
+
+def test_import_of_a_reference_npy_tree_into_the_store(tmp_path):
+    """multivector/{document_id}/{chunk_number}.npy trees written by FastMultiVectorStore import page by page."""
+    from morphik_core_amd import formats
+
+    rng = np.random.default_rng(5)
+    truth = {}
+    for d in ("alpha", "beta"):
+        for c in (0, 1, 3):
+            e = rng.standard_normal((rng.integers(3, 20), 128)).astype(np.float32)
+            e /= np.linalg.norm(e, axis=1, keepdims=True)
+            p = tmp_path / "multivector" / d
+            p.mkdir(parents=True, exist_ok=True)
+            (p / f"{c}.npy").write_bytes(formats.save_npy_page(e))
+            truth[(d, c)] = e
+    s = _store(mode="float")
+    assert formats.import_npy_tree_into_store(s, str(tmp_path), batch=4) == 6
+    for (d, c), e in truth.items():
+        hit = sc.run(s.query_similar(e, k=1))[0]
+        assert (hit.document_id, hit.chunk_number) == (d, c)  # self-retrieval through the imported pages
+    assert {c.document_id for c in sc.run(s.query_similar(truth[("beta", 1)], k=6, doc_ids=["beta"]))} == {"beta"}
+
+
+def test_coalesced_requests_all_see_a_scan_failure():
+    import asyncio
+
+    s = _store(mode="float", batch_window_ms=5.0, max_batch=4)
+    sc.run(s.store_embeddings(sc.make_chunks(np.random.default_rng(0), n_docs=1, chunks_per_doc=2)))
+
+    def boom(*a, **k):
+        raise RuntimeError("scan failed")
+
+    s._index.query_batch = boom  # type: ignore[attr-defined]
+
+    async def fire():
+        return await asyncio.gather(*(s.query_similar(np.ones((3, 128), np.float32), k=1) for _ in range(3)), return_exceptions=True)
+
+    res = sc.run(fire())
+    assert len(res) == 3 and all(isinstance(r, RuntimeError) for r in res)  # query errors propagate to every waiter
