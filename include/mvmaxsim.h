@@ -193,6 +193,12 @@ MV_API int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_
 MV_API int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, int32_t k,
                                int mode, const uint32_t* allow_bits, int64_t n_allow_words, int32_t allow_per_query,
                                float* out_scores, int64_t* out_ids, int32_t* out_n, mv_query_stats* stats);
+/* Merge of the per-shard top-k lists after the RCCL all-gather (row-sharded corpus).  d_scores / d_ids: DEVICE buffers
+ * [world][kk], each row sorted (score desc, id asc), padded with (-inf, -1), rank r owning ids below rank r+1's;
+ * world*kk <= 2048.  Writes k entries (padded the same way) on `stream` (enqueue only).  Same tie rule as one index. */
+MV_API int mv_merge_topk(int device, const float* d_scores, const int64_t* d_ids, int32_t world, int32_t kk, int32_t k,
+                         float* d_out_scores, int64_t* d_out_ids, void* stream);
+
 /* Score every page (no selection): out_scores[size] floats on the host; masked pages get -inf.
  * For MV_MODE_FDE_* this returns the coarse scores. */
 MV_API int mv_score_all(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int mode,

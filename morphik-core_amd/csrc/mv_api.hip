@@ -1413,6 +1413,13 @@ int mv_calibrate_read_bw(int device, int64_t bytes, int32_t iters, double* out_g
   return rc;
 }
 
+int mv_merge_topk(int device, const float* d_scores, const int64_t* d_ids, int32_t world, int32_t kk, int32_t k, float* d_out_scores,
+                  int64_t* d_out_ids, void* stream) {
+  if (!d_scores || !d_ids || !d_out_scores || !d_out_ids) { set_error("mv_merge_topk: null argument"); return MV_ERR_INVALID; }
+  DeviceGuard g(device);
+  return launch_merge_topk(d_scores, d_ids, world, kk, k, d_out_scores, d_out_ids, (hipStream_t)stream);
+}
+
 int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out) {
   if (!out || iters < 1) { set_error("calibrate: bad argument"); return MV_ERR_INVALID; }
   DeviceGuard g(device);

@@ -71,6 +71,9 @@ constexpr int kTopkMaxDeviceK = 1024;
 int launch_topk(const float* d_scores, int64_t n, int32_t k, const int32_t* d_ids_map, int64_t id_base, void* ws,
                 float* d_out_scores, int64_t* d_out_ids, hipStream_t s);
 
+int launch_merge_topk(const float* d_scores, const int64_t* d_ids, int32_t world, int32_t kk, int32_t k, float* d_out_scores,
+                      int64_t* d_out_ids, hipStream_t s);
+
 // ---------------------------------------------------------------- synthetic generator (mv_synth.hip)
 int launch_synth_rows(uint16_t* d_out, uint64_t seed, uint64_t first_unit, int64_t n_units, int32_t n_rows,
                       int32_t stride_rows, hipStream_t s);

@@ -21,35 +21,41 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def merge_topk(scores, ids, k: int):
+def merge_topk(scores, ids, k: int, compact: bool = True):
     """scores/ids: [R, kk] tensors of per-shard results, each row sorted (score desc, id asc) and padded
     with (-inf, -1); shards in rank order own ascending id ranges.  Returns the global top-k in the same
     order.  A stable descending sort keeps (rank, position) order among equal scores, which IS
-    ascending id order, so ties resolve exactly as on a single index."""
+    ascending id order, so ties resolve exactly as on a single index.
+    compact=False returns exactly k entries still padded with (-inf, -1): no boolean indexing, hence no
+    device->host synchronisation on the query path (the padded tail is dropped by whoever reads the result)."""
     import torch
 
     s = scores.reshape(-1)
     i = ids.reshape(-1)
     order = torch.sort(s, descending=True, stable=True).indices[:k]
     ms, mi = s[order], i[order]
+    if not compact:
+        return ms, mi
     keep = mi >= 0
     return ms[keep], mi[keep]
 
 
-def allgather_topk(local_scores, local_ids, k: int, group=None):
-    """local_*: [kk] tensors on this rank (cuda for nccl/RCCL, cpu for gloo). Every rank returns the merged top-k."""
+def allgather_topk(local_scores, local_ids, k: int, group=None, compact: bool = True):
+    """local_*: [kk] tensors on this rank (cuda for nccl/RCCL, cpu for gloo). Every rank returns the merged top-k.
+    The (score, id) pairs travel as ONE float64 buffer (fp32 scores and ids < 2^53 are exact in it): one collective
+    of 16*kk bytes per rank instead of two."""
     import torch
     import torch.distributed as dist
 
-    world = dist.get_world_size(group)
-    if world == 1:
-        return merge_topk(local_scores[None], local_ids[None], k)
+    if not dist.is_initialized():  # single process, no communicator: nothing to gather
+        return merge_topk(local_scores[None], local_ids[None], k, compact)
+    world = dist.get_world_size(group)  # a 1-rank communicator still runs the collective (RCCL smoke test)
     kk = local_scores.numel()
-    gs = torch.empty(world * kk, dtype=local_scores.dtype, device=local_scores.device)  # rank-major concatenation
-    gi = torch.empty(world * kk, dtype=local_ids.dtype, device=local_ids.device)
-    dist.all_gather_into_tensor(gs, local_scores.contiguous().view(-1), group=group)
-    dist.all_gather_into_tensor(gi, local_ids.contiguous().view(-1), group=group)
-    return merge_topk(gs.view(world, kk), gi.view(world, kk), k)
+    mine = torch.cat([local_scores.reshape(-1).to(torch.float64), local_ids.reshape(-1).to(torch.float64)])
+    allb = torch.empty(world * 2 * kk, dtype=torch.float64, device=mine.device)
+    dist.all_gather_into_tensor(allb, mine, group=group)
+    allb = allb.view(world, 2, kk)
+    return merge_topk(allb[:, 0].to(local_scores.dtype), allb[:, 1].to(local_ids.dtype), k, compact)
 
 
 def allgather_topk_batch(local_scores, local_ids, k: int, group=None):
@@ -58,10 +64,10 @@ def allgather_topk_batch(local_scores, local_ids, k: int, group=None):
     import torch
     import torch.distributed as dist
 
-    world = dist.get_world_size(group)
     B, kk = local_scores.shape
-    if world == 1:
+    if not dist.is_initialized():
         return [merge_topk(local_scores[b][None], local_ids[b][None], k) for b in range(B)]
+    world = dist.get_world_size(group)
     gs = torch.empty(world * B * kk, dtype=local_scores.dtype, device=local_scores.device)
     gi = torch.empty(world * B * kk, dtype=local_ids.dtype, device=local_ids.device)
     dist.all_gather_into_tensor(gs, local_scores.contiguous().view(-1), group=group)
@@ -79,9 +85,9 @@ class ShardedSearcher:
         self.local_topk = local_topk
         self.group = group
 
-    def query(self, q, k: int):
+    def query(self, q, k: int, compact: bool = True):
         s, i = self.local_topk(q, k)
-        return allgather_topk(s, i, k, self.group)
+        return allgather_topk(s, i, k, self.group, compact)
 
     def query_batch(self, queries, k: int, local_topk_batch: Callable):
         """Several queries in one slab pass per shard (mv_query_topk_batch) and one all-gather for all of them.
@@ -126,3 +132,57 @@ def make_gpu_local_topk_batch(index, device=None, mode: str = "float"):
         return torch.from_numpy(s).to(dev), torch.from_numpy(i).to(dev)
 
     return local_topk_batch
+
+
+class GpuShardedSearcher:
+    """The RCCL path with the fewest host-side steps per query: MvIndex.query_device leaves the local top-k in
+    preallocated cuda buffers, two all_gather_into_tensor calls (scores fp32, ids int64) fill preallocated gather
+    buffers, and ONE library launch (mv_merge_topk, on torch's current stream, behind the collectives) produces the
+    merged top-k -- no framework sort / index / cast ops, no host synchronisation.  Results are padded with
+    (-inf, -1) and become valid in stream order (read them after a synchronize or from the same stream)."""
+
+    def __init__(self, index, device=None, mode: str = "float", group=None, collect_stats=None):
+        import torch
+        import torch.distributed as dist
+
+        self.index, self.mode, self.group, self.stats = index, mode, group, collect_stats
+        self.dev = torch.device("cuda", index.device) if device is None else device
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._bufs = {}
+        self._flip = 0
+
+    def _buffers(self, k):
+        import torch
+
+        # two buffer sets used alternately: the collectives of query i may still be reading set A while the
+        # library writes the local top-k of query i+1 (they run on different streams)
+        self._flip ^= 1
+        key = (k, self._flip)
+        if key not in self._bufs:
+            d, w = self.dev, self.world
+            self._bufs[key] = (torch.empty(k, dtype=torch.float32, device=d), torch.empty(k, dtype=torch.int64, device=d),
+                             torch.empty(w * k, dtype=torch.float32, device=d), torch.empty(w * k, dtype=torch.int64, device=d),
+                             torch.empty(k, dtype=torch.float32, device=d), torch.empty(k, dtype=torch.int64, device=d))
+        return self._bufs[key]
+
+    def query(self, q, k: int):
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+
+        from ._lib import check, lib
+
+        ls, li, gs, gi, os_, oi = self._buffers(k)
+        st = self.index.query_device(q, k, ls.data_ptr(), li.data_ptr(), mode=self.mode, want_stats=self.stats is not None)
+        if self.stats is not None:
+            self.stats.append(st)
+        if dist.is_initialized():
+            dist.all_gather_into_tensor(gs, ls, group=self.group)
+            dist.all_gather_into_tensor(gi, li, group=self.group)
+        else:
+            gs, gi = ls, li
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        check(lib().mv_merge_topk(self.index.device, C.c_void_p(gs.data_ptr()), C.c_void_p(gi.data_ptr()), self.world, k, k,
+                                  C.c_void_p(os_.data_ptr()), C.c_void_p(oi.data_ptr()), C.c_void_p(stream)))
+        return os_, oi

@@ -205,3 +205,40 @@ def test_library_and_torch_share_one_hip_runtime():
 
         assert os.path.dirname(hips[0]) == os.path.join(os.path.dirname(torch.__file__), "lib")
         assert (torch.ones(4, device="cuda") * 2).sum().item() == 8.0
+
+
+def test_library_merge_of_gathered_topk_equals_reference_merge():
+    """mv_merge_topk (the post-all-gather merge used on the RCCL path) against sharded.merge_topk, ties included."""
+    import ctypes as C
+
+    import torch
+
+    from morphik_core_amd import sharded
+    from morphik_core_amd._lib import check, lib
+
+    rng = np.random.default_rng(8)
+    for world, kk, k in ((1, 10, 10), (8, 10, 10), (4, 7, 12), (8, 128, 100), (3, 5, 3)):
+        rows_s, rows_i = [], []
+        for r in range(world):
+            n_valid = int(rng.integers(0, kk + 1))
+            sc_ = np.sort(rng.integers(0, 6, n_valid).astype(np.float32) * 0.5)[::-1]  # few distinct values -> ties
+            ids = np.sort(rng.choice(1000, n_valid, replace=False)) + r * 1000
+            # within equal scores ids must ascend (how a shard reports): sort by (-score, id)
+            order = np.lexsort((ids, -sc_))
+            s_row = np.full(kk, -np.inf, np.float32)
+            i_row = np.full(kk, -1, np.int64)
+            s_row[:n_valid], i_row[:n_valid] = sc_[order], ids[order]
+            rows_s.append(s_row)
+            rows_i.append(i_row)
+        gs = torch.tensor(np.stack(rows_s), device="cuda")
+        gi = torch.tensor(np.stack(rows_i), device="cuda")
+        out_s = torch.empty(k, dtype=torch.float32, device="cuda")
+        out_i = torch.empty(k, dtype=torch.int64, device="cuda")
+        check(lib().mv_merge_topk(0, C.c_void_p(gs.data_ptr()), C.c_void_p(gi.data_ptr()), world, kk, k, C.c_void_p(out_s.data_ptr()),
+                                  C.c_void_p(out_i.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        ws, wi = sharded.merge_topk(gs.cpu(), gi.cpu(), k)
+        torch.cuda.synchronize()
+        got_i = out_i.cpu().numpy()
+        n = int((got_i >= 0).sum())
+        assert n == len(wi) and got_i[:n].tolist() == wi.tolist() and out_s.cpu().numpy()[:n].tolist() == ws.tolist()
+        assert np.all(got_i[n:] == -1)
