@@ -305,6 +305,8 @@ def main():
             return s.cpu(), i.cpu()
     searcher = sharded.ShardedSearcher(local_topk)
     fast_searcher = sharded.GpuShardedSearcher(ix, dev, MODE, collect_stats=stats) if (dist_on and args.backend == "nccl") else None
+    # config 4 across ranks: GLOBAL coarse top-1000, owners rerank (the same candidate set as one big index)
+    two_stage = sharded.make_gpu_two_stage(ix, cdev) if (dist_on and args.workload == "fde_fp8") else None
 
     def step(i):
         q = queries[i % N_QUERIES]
@@ -312,6 +314,8 @@ def main():
             s, ids, st = ix.query(q, K, mode=MODE, want_stats=True)
             stats.append(st)
             return s, ids
+        if two_stage is not None:
+            return two_stage.query(q, K, coarse_n=1000)
         if fast_searcher is not None:  # RCCL: 2 collectives + one library merge launch, nothing else on the host
             return fast_searcher.query(q, K)
         s, ids = searcher.query(q, K, compact=False)  # padded (-inf, -1) tail: no host sync inside the timed loop

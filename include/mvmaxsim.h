@@ -208,6 +208,11 @@ MV_API int mv_score_all(mv_index* ix, const void* q, int q_dtype, int32_t n_q_ro
 MV_API int mv_score_candidates(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const int32_t* cand,
                                int32_t n_cand, int32_t pad_to, float* out_scores, mv_query_stats* stats);
 
+/* Row counts of the named pages (local page ids) from the index's host-side metadata; no device work.  A sharded
+ * FDE_THEN_FLOAT query needs them to apply the reference's pad-to-longest rule (pad_sequence at
+ * fast_multivector_store.py:553-555) over a candidate list whose pages live on several ranks. */
+MV_API int mv_index_page_rows(mv_index* ix, const int32_t* pages, int64_t n_pages, int32_t* out_rows);
+
 /* Stateless helpers (host in, host out, computed on `device`).
  * mv_sign_pack replaces fast_ops.binary_quantize_packed (core/utils/fast_ops.py:191-227 ->
  * morphik_rust binary_quantize_batch_packed, src/binary_ops.rs:148-222): bit = v > 0, MSB first. */

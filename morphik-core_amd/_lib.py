@@ -80,7 +80,7 @@ EXPORTS = [
     "mv_last_error", "mv_version", "mv_device_count", "mv_index_create", "mv_index_destroy", "mv_index_set_option",
     "mv_index_size", "mv_index_capacity", "mv_index_add", "mv_index_add_device", "mv_index_add_bits", "mv_index_remove_doc",
     "mv_index_remove_page", "mv_index_compact", "mv_index_read_pages", "mv_index_write_rows", "mv_index_replace_page", "mv_index_read_fp8", "mv_index_fill_synthetic", "mv_synth_rows",
-    "mv_query_topk", "mv_query_topk_device", "mv_query_topk_batch", "mv_merge_topk", "mv_score_all", "mv_score_candidates", "mv_sign_pack", "mv_hamming_batch",
+    "mv_query_topk", "mv_query_topk_device", "mv_query_topk_batch", "mv_merge_topk", "mv_score_all", "mv_score_candidates", "mv_index_page_rows", "mv_sign_pack", "mv_hamming_batch",
     "mv_fde_output_dim", "mv_fde_encode", "mv_calibrate_read_bw", "mv_calibrate", "mv_index_save", "mv_index_load",
 ]
 
@@ -148,6 +148,7 @@ def lib() -> C.CDLL:
         L.mv_merge_topk.argtypes = [C.c_int, vp, vp, i32, i32, i32, vp, vp, vp]
         L.mv_score_all.argtypes = [vp, vp, C.c_int, i32, C.c_int, vp, i64, vp, C.POINTER(QueryStatsC)]
         L.mv_score_candidates.argtypes = [vp, vp, C.c_int, i32, vp, i32, i32, vp, C.POINTER(QueryStatsC)]
+        L.mv_index_page_rows.argtypes = [vp, vp, i64, vp]
         L.mv_sign_pack.argtypes = [C.c_int, vp, i64, i32, vp]
         L.mv_hamming_batch.argtypes = [C.c_int, vp, vp, i64, i32, vp]
         L.mv_fde_output_dim.argtypes = [C.POINTER(FdeConfigC)]

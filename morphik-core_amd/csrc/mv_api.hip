@@ -1306,6 +1306,16 @@ int mv_score_candidates(mv_index* ix, const void* q, int q_dtype, int32_t n_q_ro
   return finish_stats(ix, stats, false);
 }
 
+int mv_index_page_rows(mv_index* ix, const int32_t* pages, int64_t n_pages, int32_t* out_rows) {
+  if (!ix || n_pages < 0 || (n_pages > 0 && (!pages || !out_rows))) { set_error("page_rows: bad argument"); return MV_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(ix->mu);
+  for (int64_t i = 0; i < n_pages; ++i) {
+    if (pages[i] < 0 || pages[i] >= ix->size) { set_error("page %d out of range", pages[i]); return MV_ERR_INVALID; }
+    out_rows[i] = ix->h_n_rows[pages[i]];
+  }
+  return MV_OK;
+}
+
 int mv_sign_pack(int device, const float* x, int64_t n_rows, int32_t d, uint8_t* out) {
   if (!x || !out || n_rows < 0 || d < 1) { set_error("mv_sign_pack: bad argument"); return MV_ERR_INVALID; }
   if (n_rows == 0) return MV_OK;

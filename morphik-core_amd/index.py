@@ -336,6 +336,13 @@ class MvIndex:
         check(lib().mv_score_candidates(self._h, qa.ctypes.data, code, qa.shape[0], c.ctypes.data, c.size, int(pad_to), out.ctypes.data, None))
         return out[: c.size]
 
+    def page_rows(self, pages: Sequence[int]) -> np.ndarray:
+        """Row counts of local pages (host metadata; no device work)."""
+        c = np.ascontiguousarray(pages, dtype=np.int32)
+        out = np.empty(max(c.size, 1), np.int32)
+        check(lib().mv_index_page_rows(self._h, c.ctypes.data, c.size, out.ctypes.data))
+        return out[: c.size]
+
     # -- persistence
     def save(self, path: str) -> None:
         check(lib().mv_index_save(self._h, path.encode()))

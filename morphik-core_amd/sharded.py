@@ -186,3 +186,96 @@ class GpuShardedSearcher:
         check(lib().mv_merge_topk(self.index.device, C.c_void_p(gs.data_ptr()), C.c_void_p(gi.data_ptr()), self.world, k, k,
                                   C.c_void_p(os_.data_ptr()), C.c_void_p(oi.data_ptr()), C.c_void_p(stream)))
         return os_, oi
+
+
+class TwoStageShardedSearcher:
+    """FDE_THEN_FLOAT on a row-sharded corpus: the reference pipeline (FDE coarse search ->
+    top-n candidates -> exact MaxSim rerank -> top-k, fast_multivector_store.py:521-556) with the SAME candidate set
+    as one big index, whatever the rank count:
+
+      1. every rank: FDE coarse scan of its shard -> local top-n (score, global id)
+      2. all-gather of n pairs per rank (16 B each) -> global coarse top-n, identical on every rank
+      3. every rank keeps the candidates IT OWNS; all-reduce(MAX) of their row counts gives the pad-to-longest
+         length of the reference's rerank batch (pad_sequence, :553-555)
+      4. every rank: exact MaxSim of its own candidates (no embedding crosses xGMI) -> local top-k
+      5. all-gather of k pairs per rank -> merged top-k
+
+    Three small collectives, all latency-bound.  The callables keep the class testable on CPU (gloo + oracle):
+      local_coarse(q, n, allow) -> (scores[n], ids[n]) tensors on the collective's device, padded (-inf, -1), GLOBAL ids
+      local_rows(global_ids)    -> int array of row counts of owned pages
+      local_rerank(q, global_ids, pad_to) -> float32 array of exact MaxSim scores of owned pages
+    `id_range` = [lo, hi) of global ids this rank owns."""
+
+    def __init__(self, local_coarse: Callable, local_rows: Callable, local_rerank: Callable, id_range: Tuple[int, int],
+                 group=None, pad_semantics: bool = True):
+        self.local_coarse, self.local_rows, self.local_rerank = local_coarse, local_rows, local_rerank
+        self.lo, self.hi = int(id_range[0]), int(id_range[1])
+        self.group, self.pad = group, pad_semantics
+
+    # The three local phases are public so that R logical shards on ONE device can be driven without a process group
+    # (tests; SURVEY 8e "R logical shards on one device"); query() chains them with the collectives in between.
+    def coarse(self, q, k: int, coarse_n: Optional[int] = None, allow=None):
+        n = int(coarse_n) if coarse_n else min(10 * k, 75)  # reference: top_k = min(10 * k, 75) (:529)
+        cs, ci = self.local_coarse(q, n, allow)
+        return n, cs, ci
+
+    def owned(self, global_ids):
+        """-> (candidates this rank owns, their longest row count)"""
+        import numpy as np
+
+        gid = global_ids.detach().cpu().numpy().astype(np.int64)
+        mine = gid[(gid >= self.lo) & (gid < self.hi)]
+        return mine, (int(self.local_rows(mine).max()) if (self.pad and mine.size) else 0)
+
+    def rerank(self, q, mine, longest: int, k: int):
+        """-> local top-k (scores[k], ids[k]) padded with (-inf, -1), ordered (score desc, id asc)"""
+        import numpy as np
+        import torch
+
+        ls = torch.full((k,), float("-inf"), dtype=torch.float32)
+        li = torch.full((k,), -1, dtype=torch.int64)
+        if mine.size:
+            sc = np.asarray(self.local_rerank(q, mine, longest if self.pad else 0), np.float32)
+            order = np.lexsort((mine, -sc.astype(np.float64)))[:k]
+            ls[: order.size] = torch.from_numpy(sc[order])
+            li[: order.size] = torch.from_numpy(mine[order])
+        return ls, li
+
+    def query(self, q, k: int, coarse_n: Optional[int] = None, allow=None):
+        import torch
+        import torch.distributed as dist
+
+        n, cs, ci = self.coarse(q, k, coarse_n, allow)
+        _, gi = allgather_topk(cs, ci, n, self.group, compact=False)
+        mine, longest = self.owned(gi)
+        if self.pad and dist.is_initialized():
+            t = torch.tensor([longest], dtype=torch.int64, device=cs.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            longest = int(t.item())
+        ls, li = self.rerank(q, mine, longest, k)
+        return allgather_topk(ls.to(cs.device), li.to(cs.device), k, self.group)
+
+
+def make_gpu_two_stage(index, device=None, group=None) -> TwoStageShardedSearcher:
+    """TwoStageShardedSearcher over one MvIndex shard (FDE slab + bf16 or fp8 slab): coarse = MV_MODE_FDE_ONLY top-n,
+    rerank = mv_score_candidates on the pages this rank owns."""
+    import numpy as np
+    import torch
+
+    dev = torch.device("cuda", index.device) if device is None else device
+    base = int(index.id_base)
+
+    def coarse(q, n, allow):
+        s, i = index.query(q, n, mode="fde", allow=allow)
+        ps = np.full(n, -np.inf, np.float32)
+        pi = np.full(n, -1, np.int64)
+        ps[: len(s)], pi[: len(i)] = s, i
+        return torch.from_numpy(ps).to(dev), torch.from_numpy(pi).to(dev)
+
+    def rows(gids):
+        return index.page_rows(np.asarray(gids, np.int64) - base)
+
+    def rerank(q, gids, pad_to):
+        return index.score_candidates(q, np.asarray(gids, np.int64) - base, pad_to=pad_to)
+
+    return TwoStageShardedSearcher(coarse, rows, rerank, (base, base + len(index)), group)

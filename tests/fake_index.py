@@ -6,9 +6,10 @@ from oracle import oracle as orc
 
 
 class OracleIndex:
-    def __init__(self, capacity_pages, stride_rows, device=0, id_base=0, mode="float", **_):
+    def __init__(self, capacity_pages, stride_rows, device=0, id_base=0, mode="float", fde=None, **_):
         self.capacity, self.stride_rows, self.id_base, self.mode = capacity_pages, stride_rows, id_base, mode
         self.pages, self.ords, self.alive = [], [], []
+        self.fde = fde  # oracle FdeConfig; enables mode "fde" / "fde_then_float"
 
     def __len__(self):
         return len(self.pages)
@@ -50,6 +51,12 @@ class OracleIndex:
         qf = orc.bf16_to_f32(q) if q.dtype == np.uint16 else np.asarray(q, np.float32)
         out = np.full(len(self.pages), -np.inf, np.float32)
         m = self._mask(allow)
+        if mode == "fde":
+            fq = orc.fde_encode(self.fde, orc.bf16_to_f32(orc.f32_to_bf16(qf)), True)
+            slab = np.stack([orc.fde_encode(self.fde, orc.bf16_to_f32(orc.f32_to_bf16(p)), False) for p in self.pages])
+            s = orc.fde_coarse_scores(fq, orc.f32_to_bf16(slab), use_cosine=True)
+            out[m] = s[m]
+            return out
         for i, p in enumerate(self.pages):
             if not m[i]:
                 continue
@@ -61,10 +68,29 @@ class OracleIndex:
                 out[i] = orc.maxsim_f32(qb, pb)
         return out
 
-    def query(self, q, k, mode=None, allow=None, want_stats=False):
+    def query(self, q, k, mode=None, allow=None, want_stats=False, coarse_n=None):
+        if (mode or self.mode) == "fde_then_float":
+            # reference pipeline (fast_multivector_store.py:521-556): coarse top-n -> pad-to-longest rerank -> top-k
+            n = coarse_n or min(10 * k, 75)
+            cs, ci = orc.topk(self.score_all(q, "fde", allow), n)
+            ci = ci[np.isfinite(cs)]
+            if ci.size == 0:
+                return np.zeros(0, np.float32), np.zeros(0, np.int64)
+            sc = self.score_candidates(q, ci, pad_to=int(self.page_rows(ci).max()))
+            order = np.lexsort((ci, -sc.astype(np.float64)))[:k]
+            return sc[order], ci[order] + self.id_base
         s = self.score_all(q, mode, allow)
         sc, ids = orc.topk(s, k)
         return sc, ids + self.id_base
+
+    def page_rows(self, pages):
+        return np.array([len(self.pages[int(i)]) for i in pages], np.int32)
+
+    def score_candidates(self, q, cand, pad_to=0):
+        q = np.asarray(q)
+        qf = orc.bf16_to_f32(q) if q.dtype == np.uint16 else np.asarray(q, np.float32)
+        qb = orc.bf16_to_f32(orc.f32_to_bf16(qf))
+        return np.array([orc.maxsim_f32(qb, orc.bf16_to_f32(orc.f32_to_bf16(self.pages[int(i)])), pad_to) for i in cand], np.float32)
 
     def compact(self):
         o2n, pages, ords = [], [], []

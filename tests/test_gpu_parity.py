@@ -285,6 +285,47 @@ def test_logical_shards_equal_single_index(mv):
     one.close()
 
 
+@pytest.mark.parametrize("with_float", [True, False])  # rerank from the bf16 slab / from the fp8 slab
+def test_two_stage_fde_logical_shards_equal_single_index(mv, with_float):
+    """Config 4 sharded: global coarse top-n, each shard reranks only the candidates it owns with the
+    GLOBAL pad-to-longest length, merge -> exactly the single index's FDE_THEN_FLOAT answer for R = 1, 2, 4."""
+    import torch
+
+    from morphik_core_amd import _lib, sharded
+
+    N, stride, k, coarse_n = 240, 48, 6, 40
+    pages = [orc.synth_rows(11, i, 0, 5 + (i * 7) % 40) for i in range(N)]  # ragged: 5..44 rows
+    ords = [i % 9 for i in range(N)]
+    kw = dict(stride_rows=stride, with_fde=True, with_float=with_float, with_fp8=not with_float)
+    one = _idx(mv, capacity_pages=N, **kw)
+    one.add(pages, doc_ordinals=ords)
+    one.set_option(_lib.MV_OPT_FDE_COARSE_N, coarse_n)
+    qs = [orc.synth_rows(4321, j, 0, 20) for j in range(3)]
+    allow = np.array([0b101101011], np.uint32)
+    for R in (1, 2, 4):
+        per = N // R
+        shards, searchers = [], []
+        for r in range(R):
+            sh = _idx(mv, capacity_pages=per, id_base=r * per, **kw)
+            sh.add(pages[r * per : (r + 1) * per], doc_ordinals=ords[r * per : (r + 1) * per])
+            shards.append(sh)
+            searchers.append(sharded.make_gpu_two_stage(sh))
+        for q in qs:
+            for al in (None, allow):
+                ws, wi = one.query(q, k, mode="fde_then_float", allow=al)
+                co = [se.coarse(q, k, coarse_n, al) for se in searchers]
+                _, gi = sharded.merge_topk(torch.stack([c[1] for c in co]), torch.stack([c[2] for c in co]), coarse_n, compact=False)
+                own = [se.owned(gi) for se in searchers]
+                longest = max(o[1] for o in own)
+                loc = [se.rerank(q, o[0], longest, k) for se, o in zip(searchers, own)]
+                ms, mi = sharded.merge_topk(torch.stack([l[0] for l in loc]), torch.stack([l[1] for l in loc]), k)
+                assert mi.tolist() == wi.tolist()
+                assert ms.tolist() == ws.tolist()
+        for sh in shards:
+            sh.close()
+    one.close()
+
+
 def test_planted_neighbours_recall_and_sampled_parity_midsize(mv):
     """20k pages x 1024 patches (5.2 GB): recall@10 == 1.0 on planted neighbours; sampled oracle parity."""
     from morphik_core_amd import synth

@@ -106,3 +106,80 @@ def test_merge_topk_tie_rule():
     assert mi.tolist() == [4, 10, 12, 1] and ms.tolist() == [3.0, 3.0, 3.0, 2.0]
     ms, mi = sharded.merge_topk(s, i, 10)
     assert mi.tolist() == [4, 10, 12, 1, 11]
+
+
+# --------------------------------------------------------------------------- config 4: FDE coarse -> exact rerank, sharded
+def _ragged_corpus(n):
+    from oracle import oracle as orc
+
+    return [orc.synth_rows(7, i, 0, 3 + (i * 5) % 9) for i in range(n)]  # 3..11 rows: the pad-to-longest rule matters
+
+
+def _fde_cfg():
+    from oracle import oracle as orc
+
+    return orc.FdeConfig(128, 4, 3, 8, 1)
+
+
+def _two_stage(ix, lo):
+    def coarse(q, n, allow):
+        s, i = ix.query(q, n, mode="fde", allow=allow)
+        ok = np.isfinite(s)
+        ps = np.full(n, -np.inf, np.float32)
+        pi = np.full(n, -1, np.int64)
+        ps[: ok.sum()], pi[: ok.sum()] = s[ok], i[ok]
+        return torch.from_numpy(ps), torch.from_numpy(pi)
+
+    return sharded.TwoStageShardedSearcher(coarse, lambda g: ix.page_rows(np.asarray(g) - lo),
+                                           lambda q, g, pad: ix.score_candidates(q, np.asarray(g) - lo, pad_to=pad),
+                                           (lo, lo + len(ix)))
+
+
+def _worker_two_stage(rank, world, port, n_total, k, coarse_n, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    from tests.fake_index import OracleIndex
+
+    lo, hi = sharded.shard_range(n_total, rank, world)
+    ix = OracleIndex(capacity_pages=max(hi - lo, 1), stride_rows=16, id_base=lo, fde=_fde_cfg())
+    ix.add(_ragged_corpus(n_total)[lo:hi], doc_ordinals=[(lo + j) % 5 for j in range(hi - lo)])
+    searcher = _two_stage(ix, lo)
+    res = []
+    for j, allow in enumerate([None, np.array([0b01101], np.uint32)]):
+        s, i = searcher.query(orc.synth_rows(4321, j, 0, 6), k, coarse_n=coarse_n, allow=allow)
+        res.append((s.numpy().tolist(), i.numpy().tolist()))
+    out_q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total,k,coarse_n", [(2, 37, 5, 12), (3, 40, 4, 9), (2, 2, 5, 12)])
+def test_two_stage_fde_pipeline_is_rank_count_invariant(world, n_total, k, coarse_n):
+    """The sharded FDE_THEN_FLOAT (global coarse top-n, owners rerank with the global pad length) returns exactly what
+    ONE index returns: same candidate set, same pad-to-longest clamp, same top-k."""
+    from oracle import oracle as orc
+    from tests.fake_index import OracleIndex
+
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_two_stage, args=(r, world, port, n_total, k, coarse_n, out_q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out_q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    one = OracleIndex(capacity_pages=n_total, stride_rows=16, fde=_fde_cfg())
+    one.add(_ragged_corpus(n_total), doc_ordinals=[j % 5 for j in range(n_total)])
+    for j, allow in enumerate([None, np.array([0b01101], np.uint32)]):
+        ws, wi = one.query(orc.synth_rows(4321, j, 0, 6), k, mode="fde_then_float", allow=allow, coarse_n=coarse_n)
+        for _rank, res in results:
+            assert res[j][1] == wi.tolist() and res[j][0] == ws.tolist()
+    # the same class without a process group == the single index as well
+    solo = _two_stage(one, 0)
+    s, i = solo.query(orc.synth_rows(4321, 0, 0, 6), k, coarse_n=coarse_n)
+    ws, wi = one.query(orc.synth_rows(4321, 0, 0, 6), k, mode="fde_then_float", coarse_n=coarse_n)
+    assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist()
