@@ -341,7 +341,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
   // Selective doc filter on a top-k scan: compact the allowed pages (in page order) and scan only those.
   const int32_t* d_scan_cand = nullptr;
   int64_t n_scan = n;
-  if (want_compact && d_allow && (mode == MV_MODE_FLOAT || mode == MV_MODE_FLOAT_FP8) && ix->filter_compact_pct > 0 && ix->max_doc_ord >= 0) {
+  if (want_compact && d_allow && (mode == MV_MODE_FLOAT || mode == MV_MODE_FLOAT_FP8 || mode == MV_MODE_BINARY) && ix->filter_compact_pct > 0 && ix->max_doc_ord >= 0) {
     int64_t allowed_docs = 0;
     for (int64_t w = 0; w < n_words; ++w) allowed_docs += __builtin_popcount(allow_bits[w]);
     if (allowed_docs * 100 < (int64_t)ix->filter_compact_pct * ((int64_t)ix->max_doc_ord + 1)) {
@@ -373,13 +373,17 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
     out->pages = pages; out->bytes = rows * (int64_t)kDim;
   } else if (mode == MV_MODE_BINARY) {
     BinaryArgs b{};
-    b.bits = ix->bits; b.n_rows = ix->ragged ? ix->d_n_rows : nullptr; b.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
-    b.allow = d_allow; b.n_allow_bits = n_words * 32; b.qbits = ix->d_qbits; b.qpop_rw = ix->d_qpop; b.qpop = ix->d_qpop; b.scores = ix->d_scores; b.n = n;
+    b.bits = ix->bits; b.n_rows = ix->ragged ? ix->d_n_rows : nullptr;
+    // compacted filter: the list holds only live, allowed pages -- no per-page mask test left to do
+    b.doc_ord = (need_meta && !d_scan_cand) ? ix->d_doc_ord : nullptr;
+    b.allow = d_scan_cand ? nullptr : d_allow; b.n_allow_bits = n_words * 32;
+    b.qbits = ix->d_qbits; b.qpop_rw = ix->d_qpop; b.qpop = ix->d_qpop; b.scores = ix->d_scores;
+    b.n = n_scan; b.cand = d_scan_cand;
     b.stride = ix->cfg.stride_rows; b.n_q = n_q;
     rc = launch_maxsim_binary(b, ix->binary_variant, ix->stream);
     if (rc) return rc;
-    out->launches = 1;
-    out->d_scores = ix->d_scores; out->n = n; out->d_ids_map = nullptr;
+    out->launches += 1;
+    out->d_scores = ix->d_scores; out->n = n_scan; out->d_ids_map = d_scan_cand;
     out->pages = pages; out->bytes = rows * (int64_t)kSignBytes;
   } else {
     // FDE: encode the query (SUM), scan the FDE slab

@@ -71,6 +71,7 @@ struct BArgs {
   int32_t stride;
   int32_t n_q;
   const float* qpop;  // [n_q padded to 16] popc of each query row as float, -1 for padding rows (MFMA variant)
+  const int32_t* cand;  // optional candidate list: item i scores page cand[i] into scores[i] (variants 0 and 2..4)
 };
 
 __device__ __forceinline__ bool masked(const BArgs& a, int64_t page) {
@@ -94,15 +95,16 @@ __device__ __forceinline__ int wave_min(int v) {
 __global__ __launch_bounds__(256) void maxsim_binary_kernel(BArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t page = (int64_t)blockIdx.x * 4 + wave;
-  if (page >= a.n) return;
+  const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+  if (item >= a.n) return;
+  const int64_t page = a.cand ? (int64_t)a.cand[item] : item;
   if (masked(a, page)) {
-    if (lane == 0) a.scores[page] = -INFINITY;
+    if (lane == 0) a.scores[item] = -INFINITY;
     return;
   }
   const int nr = a.n_rows ? a.n_rows[page] : a.stride;
   if (nr <= 0 || a.n_q <= 0) {
-    if (lane == 0) a.scores[page] = 0.0f;  // COALESCE(SUM over nothing, 0.0)
+    if (lane == 0) a.scores[item] = 0.0f;  // COALESCE(SUM over nothing, 0.0)
     return;
   }
   const uint4* pg = a.bits + (size_t)page * (size_t)a.stride;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void maxsim_binary_kernel(BArgs a) {
     for (int i = 0; i < kQChunk; ++i)
       if (i < nq) total += wave_min(mn[i]);
   }
-  if (lane == 0) a.scores[page] = (float)a.n_q - (float)total * (1.0f / 128.0f);
+  if (lane == 0) a.scores[item] = (float)a.n_q - (float)total * (1.0f / 128.0f);
 }
 
 // ------------------------------------------------------------------------------ binary MaxSim on the matrix cores
@@ -371,15 +373,16 @@ __global__ __launch_bounds__(256) void maxsim_binary_mfma2_kernel(BMArgs args) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
-  const int64_t page = (int64_t)blockIdx.x * 4 + wave;
-  if (page >= a.n) return;
+  const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+  if (item >= a.n) return;
+  const int64_t page = a.cand ? (int64_t)a.cand[item] : item;
   if (masked(a, page)) {
-    if (lane == 0) a.scores[page] = -INFINITY;
+    if (lane == 0) a.scores[item] = -INFINITY;
     return;
   }
   const int nr = a.n_rows ? a.n_rows[page] : a.stride;
   if (nr <= 0 || a.n_q <= 0) {
-    if (lane == 0 && !args.accumulate) a.scores[page] = 0.0f;
+    if (lane == 0 && !args.accumulate) a.scores[item] = 0.0f;
     return;
   }
   const int ntiles = (nr + 15) >> 4;
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(256) void maxsim_binary_mfma2_kernel(BMArgs args) {
   ham += __shfl_xor(ham, 32);
   if (lane == 0) {
     const float part = (float)a.n_q - ham * (1.0f / 128.0f);
-    a.scores[page] = args.accumulate ? a.scores[page] + part : part;
+    a.scores[item] = args.accumulate ? a.scores[item] + part : part;
   }
 }
 
@@ -704,7 +707,8 @@ static void launch_binary_mfma(const BArgs& k, int accumulate, int variant, hipS
 int launch_maxsim_binary(const BinaryArgs& a, int variant, hipStream_t s) {
   if (a.n <= 0) return MV_OK;
   BArgs k{reinterpret_cast<const uint4*>(a.bits), a.n_rows, a.doc_ord, a.allow, a.n_allow_bits,
-          reinterpret_cast<const uint4*>(a.qbits), a.scores, a.n, a.stride, a.n_q, a.qpop};
+          reinterpret_cast<const uint4*>(a.qbits), a.scores, a.n, a.stride, a.n_q, a.qpop, a.cand};
+  if (a.cand && (variant == 1 || variant == 5)) variant = 4;  // the candidate-list form exists for variants 0 and 2..4
   if (a.n > ((int64_t)1 << 25)) { set_error("binary scan: more than 2^25 pages per launch is not supported"); return MV_ERR_INVALID; }
   if (variant < 0) variant = 4;  // measured (200k pages x 1024): 408 M pages/s (4-slot ring) > 390 (8) > 295 (16) > 345 (v1) > 48 (popcount)
   if (variant == 0 || a.n_q <= 0) {

@@ -95,6 +95,7 @@ struct BinaryArgs {
   int64_t n;
   int32_t stride;
   int32_t n_q;
+  const int32_t* cand;     // optional candidate list (item i = page cand[i], scores[i]); n = number of candidates
 };
 // variant: 0 = popcount (VALU), 1 = FP4 MFMA (16 VALU ops/tile), 2 = FP4 MFMA with in-place bit operands (9 VALU
 // ops/tile, 8-slot ring), 3 / 4 = variant 2 with a 16- / 4-slot ring (4 = default, -1), 5 = persistent waves with one DMA

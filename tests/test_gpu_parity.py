@@ -169,7 +169,7 @@ def test_selective_doc_filter_compaction_equals_in_scan_masking(mv):
     from morphik_core_amd.index import allow_bitmap
 
     n = 9000
-    ix = _idx(mv, capacity_pages=n, stride_rows=64, with_fp8=True)
+    ix = _idx(mv, capacity_pages=n, stride_rows=64, with_fp8=True, with_binary=True)
     base = [orc.synth_rows(5, i, 0, 50) for i in range(30)]
     ix.add([base[i % 30] for i in range(n)], [i // 4 for i in range(n)])  # duplicates -> ties; 4 pages per doc; ragged (50 of 64 rows)
     ix.remove_doc(3)
@@ -180,7 +180,9 @@ def test_selective_doc_filter_compaction_equals_in_scan_masking(mv):
     for frac in (0.2, 0.02, 0.0005):
         docs = sorted(set(rng.choice(n_docs, size=max(1, int(n_docs * frac)), replace=False).tolist()) | {3, 1000})
         allow = allow_bitmap(docs, n_docs)
-        for mode in ("float", "float_fp8"):
+        for mode, bvar in (("float", -1), ("float_fp8", -1), ("binary", 0), ("binary", 1), ("binary", 2), ("binary", 4), ("binary", 5)):
+            if mode == "binary":  # the candidate-list form exists in variants 0 and 2..4; 1 and 5 are routed to 4
+                ix.set_option(_lib.MV_OPT_BINARY_VARIANT, bvar)
             res = []
             for pct in (0, 25):
                 ix.set_option(_lib.MV_OPT_FILTER_COMPACT_PCT, pct)
