@@ -73,6 +73,7 @@ MV_OPT_MAXSIM_VARIANT, MV_OPT_FDE_COARSE_N, MV_OPT_FDE_COSINE, MV_OPT_PAD_SEMANT
 MV_OPT_BATCH_VARIANT = 7
 MV_OPT_FDE_ENCODE_VARIANT = 8
 MV_OPT_FILTER_COMPACT_PCT = 9
+MV_OPT_LONG_QUERY_VARIANT = 10
 MV_CAL_READ_NT, MV_CAL_MFMA_BF16 = 1, 2
 
 # every symbol include/mvmaxsim.h declares (tests check the .so exports all of them)

@@ -78,7 +78,7 @@ def test_float_maxsim_all_variants_small(mv, variant):
     ix.close()
 
 
-@pytest.mark.parametrize("nq", [1, 16, 17, 32, 64, 65, 100, 112, 128, 129, 200, 300])
+@pytest.mark.parametrize("nq", [1, 16, 17, 32, 64, 65, 100, 112, 128, 129, 200, 300, 384, 400, 512, 530, 900])
 def test_float_maxsim_1024_patches_query_lengths(mv, nq):
     ix = _idx(mv, capacity_pages=64, stride_rows=1024)
     ix.fill_synthetic(1234, 100, 40)
@@ -87,12 +87,43 @@ def test_float_maxsim_1024_patches_query_lengths(mv, nq):
     want = orc.maxsim_float_np(orc.bf16_to_f32(q), orc.bf16_to_f32(pages))
     got = ix.score_all(q)
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6)
-    if nq in (100, 128, 200):  # long queries (5..8 row tiles per pass, several passes) on every kernel family
+    if nq in (100, 128, 200):  # long queries (5..8 row tiles per pass, several passes) on every page-split kernel family
         from morphik_core_amd import _lib
 
+        ix.set_option(_lib.MV_OPT_LONG_QUERY_VARIANT, 0)  # default 1 = the row-split workgroup checked above
         for variant in (0, 1, 2, 7):
             ix.set_option(_lib.MV_OPT_MAXSIM_VARIANT, variant)
             np.testing.assert_allclose(ix.score_all(q), want, rtol=1e-4, atol=1e-6)
+    ix.close()
+
+
+@pytest.mark.parametrize("nq", [70, 130, 390, 600])
+def test_long_query_row_split_route_ragged_filter_tombstones(mv, nq):
+    """Queries > 64 rows take the row-split (batched) workgroup as ONE query: ragged pages, doc filter, tombstones and
+    top-k must agree with the oracle and with the page-split kernel route."""
+    from morphik_core_amd import _lib
+    from morphik_core_amd.index import allow_bitmap
+
+    lens = [(i * 37) % 200 + 1 for i in range(90)] + [0, 208, 16]
+    pages = [orc.synth_rows(78, i, 0, n) if n else np.zeros((0, 128), np.uint16) for i, n in enumerate(lens)]
+    ix = _idx(mv, capacity_pages=128, stride_rows=208)
+    ix.add(pages, doc_ordinals=[i // 3 for i in range(len(pages))])
+    ix.remove_page(7)
+    q = orc.synth_rows(4321, 50 + nq, 0, nq)
+    allow = allow_bitmap([d for d in range(31) if d % 4 != 1], 31)
+    want = np.array([orc.maxsim_bf16(q, p) for p in pages], np.float32)
+    ok = np.array([(i // 3) % 4 != 1 and i != 7 for i in range(len(pages))])
+    res = {}
+    for route in (1, 0):
+        ix.set_option(_lib.MV_OPT_LONG_QUERY_VARIANT, route)
+        got = ix.score_all(q, allow=allow)
+        assert np.all(np.isneginf(got[~ok]))
+        np.testing.assert_allclose(got[ok], want[ok], rtol=1e-4, atol=1e-6)
+        res[route] = ix.query(q, 12, allow=allow)
+        ws, wi = orc.topk(got, 12)
+        assert res[route][1].tolist() == wi.tolist()
+    assert set(res[0][1].tolist()) == set(res[1][1].tolist())
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-5)
     ix.close()
 
 
