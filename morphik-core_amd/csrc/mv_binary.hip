@@ -171,6 +171,13 @@ __device__ __forceinline__ float bin_group16_max(float v) {
   v = fmaxf(v, dpp_mov<0x121>(v));  // row_ror:1
   return v;
 }
+__device__ __forceinline__ float bin_group16_sum(float v) {
+  v += dpp_mov<0x128>(v);  // row_ror:8
+  v += dpp_mov<0x124>(v);  // row_ror:4
+  v += dpp_mov<0x122>(v);  // row_ror:2
+  v += dpp_mov<0x121>(v);  // row_ror:1
+  return v;
+}
 
 struct BMArgs {
   BArgs b;
@@ -357,19 +364,23 @@ int launch_sign_pack_bf16_rows(const uint16_t* d_rows, int64_t n_rows, uint8_t* 
   return MV_OK;
 }
 
-// Variant 2: the same MFMA with 9 instead of 16 VALU ops per tile (the 1-wave-per-page scan is VALU-issue bound:
-// a wave64 VALU op occupies its SIMD for 4 cycles).  Lane (r, g) takes dword g of row r (ds_read_b32) and feeds
-// its 32 bits as the lane's 32 FP4 K-slots WITHOUT moving three of every four bits:
-//     B_0 = w & 0x11111111  -> nibble 0x1 = 0.5      A slot magnitude 2.0   (product 1)
-//     B_1 = w & 0x22222222  -> nibble 0x2 = 1.0      A slot magnitude 1.0
-//     B_2 = w & 0x44444444  -> nibble 0x4 = 2.0      A slot magnitude 0.5
-//     B_3 = (w >> 1) & 0x44444444  (bit 3 of a nibble is the FP4 sign: it has to move)   A magnitude 0.5
-// so D[q][d] = sum_k (2 q_k - 1) d_k = 2 popc(q & d) - popc(d)  and  hamming = popc(q) - D.
-// The running max takes two tiles per v_max3_f32.
+// Variant 2: the same MFMA with 8 instead of 16 VALU ops per tile (4 operand masks + 4 v_max3).  Lane (r, g) takes dword g
+// of patch row r (ds_read_b32) and feeds its 32 bits as the lane's 32 FP4 K-slots WITHOUT moving any of them:
+//     P_0 = w & 0x11111111  -> nibble 0x1 = 0.5      query slot +-2.0   (product +-1)
+//     P_1 = w & 0x22222222  -> nibble 0x2 = 1.0      query slot +-1.0
+//     P_2 = w & 0x44444444  -> nibble 0x4 = 2.0      query slot +-0.5
+//     P_3 = (w & 0x88888888) | 0x11111111  -> -+0.5 (bit 3 of a nibble is the FP4 SIGN)   query slot -+1.0, plus a
+//           query-only constant folded into qpop[] (see expand() below)
+// so D[d][q] = sum_k (2 q_k - 1) d_k (+ const_q) = 2 popc(q & d) - popc(d)  and  hamming = popc(q) - D.
+// The patch rows are the MFMA's A operand: a lane's four results are four patches of ONE query column, so the running
+// maximum is one register per query tile (two v_max3 per MFMA) and a page ends with two cross-group maxima.
+// Measured (1 M pages, DMA-only run of the same kernel = 6.9 TB/s): 6.7 TB/s; 2 / 4 KiB slots, 2..8 consecutive pages
+// per wave and block-interleaved slots were all tried and are no faster.
 template <int MT, int D>
 __global__ __launch_bounds__(256) void maxsim_binary_mfma2_kernel(BMArgs args) {
   const BArgs& a = args.b;
-  __shared__ __attribute__((aligned(16))) char lds[4 * D * kBinSlotBytes];
+  constexpr int SL = 1, SLB = kBinSlotBytes, SLR = kBinSlotRows;  // a slot = one DMA instruction (1 KiB); 2 / 4 KiB slots measured no better
+  __shared__ __attribute__((aligned(16))) char lds[4 * D * SLB];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
@@ -386,121 +397,136 @@ __global__ __launch_bounds__(256) void maxsim_binary_mfma2_kernel(BMArgs args) {
     return;
   }
   const int ntiles = (nr + 15) >> 4;
-  const int nslots = (nr + kBinSlotRows - 1) / kBinSlotRows;
+  const int nslots = (nr + SLR - 1) / SLR;
   const char* pbase = reinterpret_cast<const char*>(a.bits) + (size_t)page * (size_t)a.stride * kSignBytes;
-  char* ring = lds + wave * (D * kBinSlotBytes);
+  char* ring = lds + wave * (D * SLB);
   const int src_off = lane * 16;
   const int rd_off = r * kSignBytes + g * 4;
 
   auto issue = [&](int it) {
-    const char* tp = pbase + (size_t)it * kBinSlotBytes;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
-    const uint64_t tpu = ((uint64_t)hi << 32) | lo;
-    const uint32_t slot = __builtin_amdgcn_readfirstlane(
-        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + (it % D) * kBinSlotBytes));
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 4\n\t"
-        "global_load_lds_dwordx4 %1, %3 nt\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(src_off), "s"(slot), "s"(tpu)
-        : "memory");
+#pragma unroll
+    for (int j = 0; j < SL; ++j) {
+      const char* tp = pbase + (size_t)it * SLB + j * kBinSlotBytes;
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
+      const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
+      const uint64_t tpu = ((uint64_t)hi << 32) | lo;
+      const uint32_t slot = __builtin_amdgcn_readfirstlane(
+          (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + (it % D) * SLB + j * kBinSlotBytes));
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %2\n\t"
+          "s_nop 4\n\t"
+          "global_load_lds_dwordx4 %1, %3 nt\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src_off), "s"(slot), "s"(tpu)
+          : "memory");
+    }
   };
 
 #pragma unroll
   for (int i = 0; i < D - 1; ++i)
     if (i < nslots) issue(i);
 
-  i32x8 qa[MT];
-  float qpop[MT][4];
+  // Operand roles: A = 16 patch rows (masked in place, see above), B = 16 query rows.  D[patch][query]: lane (c, g)
+  // holds patches g*4 + i (i = 0..3) of query column c, so a lane's four results all fold into ONE running maximum
+  // per query tile, and the page finish is two cross-group maxima instead of a 16-lane reduction per register.
+  i32x8 qb[MT];
+  float qpop[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const uint32_t w = reinterpret_cast<const uint32_t*>(a.q + m * 16 + r)[g];
-    const float4 pc = *reinterpret_cast<const float4*>(a.qpop + m * 16 + g * 4);
-    qa[m][0] = (int)(0xCCCCCCCCu - ((w & 0x11111111u) << 3));         // +-2.0
-    qa[m][1] = (int)(0xAAAAAAAAu - (((w >> 1) & 0x11111111u) << 3));  // +-1.0
-    qa[m][2] = (int)(0x99999999u - (((w >> 2) & 0x11111111u) << 3));  // +-0.5
-    qa[m][3] = (int)(0x99999999u - (((w >> 3) & 0x11111111u) << 3));  // +-0.5
+    qb[m][0] = (int)(0xCCCCCCCCu - ((w & 0x11111111u) << 3));         // +-2.0
+    qb[m][1] = (int)(0xAAAAAAAAu - (((w >> 1) & 0x11111111u) << 3));  // +-1.0
+    qb[m][2] = (int)(0x99999999u - (((w >> 2) & 0x11111111u) << 3));  // +-0.5
+    qb[m][3] = (int)(0x22222222u + (((w >> 3) & 0x11111111u) << 3));  // -+1.0 (the sign-slot class, see expand())
 #pragma unroll
-    for (int i = 4; i < 8; ++i) qa[m][i] = 0;
-    qpop[m][0] = pc.x; qpop[m][1] = pc.y; qpop[m][2] = pc.z; qpop[m][3] = pc.w;
+    for (int i = 4; i < 8; ++i) qb[m][i] = 0;
+    qpop[m] = a.qpop[m * 16 + r];
   }
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      asm volatile("" : "+v"(qa[m][i]));
-      asm volatile("" : "+v"(qpop[m][i]));
-    }
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(qb[m][i]));
+    asm volatile("" : "+v"(qpop[m]));
   }
 
-  f32x4b mx[MT];
+  float mx[MT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) mx[m] = f32x4b{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  for (int m = 0; m < MT; ++m) mx[m] = -INFINITY;
 
+  uint32_t ones = 0x11111111u;
+  asm volatile("" : "+v"(ones));
+  // Bits 0..2 of every nibble stay where they are (one AND each).  Bit 3 is the FP4 sign: instead of moving it, the
+  // slot is given a constant magnitude -- (w & 0x8...) | 0x1... = -+0.5 -- and multiplied by -+1.0 on the query side:
+  // (1 - 2q)(1 - 2d)/2 = (2q - 1) d + (1 - 2q)/2; the query-only term sums to 16 - popc(q & 0x88888888...) per row and is
+  // folded into qpop[] by binary_qprep_kernel (signslot = 1).  One v_and_or_b32 instead of shift + and.
   auto expand = [&](uint32_t w) {
     i32x8 b;
     b[0] = (int)(w & 0x11111111u);
     b[1] = (int)(w & 0x22222222u);
     b[2] = (int)(w & 0x44444444u);
-    b[3] = (int)((w >> 1) & 0x44444444u);
+    // v_and_or_b32 is VOP3: no literals on gfx9 and one SGPR at most, so the second mask lives in a VGPR
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(b[3]) : "v"(w), "s"(0x88888888u), "v"(ones));
     b[4] = 0; b[5] = 0; b[6] = 0; b[7] = 0;
     return b;
   };
-  auto mma = [&](const i32x8& qam, const i32x8& b) {
+  auto mma = [&](const i32x8& pa, const i32x8& qbm) {
     f32x4b acc = {0.f, 0.f, 0.f, 0.f};
-    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(qam, b, acc, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(pa, qbm, acc, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
   };
 
-  // Main loop: full 64-row slots only (no column masks, no divergent register assignment); a ragged tail slot is
-  // handled after the loop, when every DMA has landed.
-  const int nfull = nr / kBinSlotRows;
+  // Main loop: full slots only (no row masks, no divergent register assignment); a ragged tail slot is handled after
+  // the loop, when every DMA has landed.
+  const int nfull = nr / SLR;
   for (int it = 0; it < nfull; ++it) {
     if (it + D - 1 < nslots) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // WAR: last reads of the slot being refilled
       issue(it + D - 1);
-      bin_wait_vmcnt<D - 1>();
+      bin_wait_vmcnt<SL * (D - 1)>();
     } else {
       const int left = nslots - 1 - it;  // slots still allowed in flight (conservative ladder)
-      if (left >= 4 && D > 4) bin_wait_vmcnt<4>();
-      else if (left >= 2) bin_wait_vmcnt<2>();
-      else if (left == 1) bin_wait_vmcnt<1>();
+      if (left >= 4 && D > 4) bin_wait_vmcnt<SL * 4>();
+      else if (left >= 2) bin_wait_vmcnt<SL * 2>();
+      else if (left == 1) bin_wait_vmcnt<SL>();
       else bin_wait_vmcnt<0>();
     }
-    const char* slot = ring + (it % D) * kBinSlotBytes + rd_off;
-    uint32_t w[4];
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) w[tt] = *reinterpret_cast<const uint32_t*>(slot + tt * 256);
+    for (int sub = 0; sub < SL; ++sub) {
+      const char* slot = ring + (it % D) * SLB + sub * kBinSlotBytes + rd_off;
+      uint32_t w[4];
 #pragma unroll
-    for (int tp = 0; tp < 4; tp += 2) {
-      const i32x8 b0 = expand(w[tp]), b1 = expand(w[tp + 1]);
+      for (int tt = 0; tt < 4; ++tt) w[tt] = *reinterpret_cast<const uint32_t*>(slot + tt * 256);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const f32x4b c0 = mma(qa[m], b0), c1 = mma(qa[m], b1);
+      for (int tp = 0; tp < 4; tp += 2) {
+        const i32x8 b0 = expand(w[tp]), b1 = expand(w[tp + 1]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) mx[m][i] = fmaxf(fmaxf(mx[m][i], c0[i]), c1[i]);
+        for (int m = 0; m < MT; ++m) {
+          const f32x4b c0 = mma(b0, qb[m]), c1 = mma(b1, qb[m]);
+          const float t0 = fmaxf(fmaxf(c0[0], c0[1]), c0[2]);
+          const float t1 = fmaxf(fmaxf(c0[3], c1[0]), c1[1]);
+          const float t2 = fmaxf(fmaxf(c1[2], c1[3]), mx[m]);
+          mx[m] = fmaxf(fmaxf(t0, t1), t2);
+        }
       }
     }
   }
-  if (nfull < nslots) {  // ragged tail: 1..4 tiles of the last slot, the final tile possibly partial
+  if (nfull < nslots) {  // ragged tail: the tiles of the last slot, the final tile possibly partial
     bin_wait_vmcnt<0>();
-    const char* slot = ring + (nfull % D) * kBinSlotBytes + rd_off;
+    const char* slot = ring + (nfull % D) * SLB + rd_off;
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      const int t = nfull * 4 + tt;
+    for (int tt = 0; tt < 4 * SL; ++tt) {
+      const int t = nfull * 4 * SL + tt;
       if (t < ntiles) {  // wave-uniform
         const i32x8 b = expand(*reinterpret_cast<const uint32_t*>(slot + tt * 256));
-        const bool col_valid = t * 16 + r < nr;
+        const int row0 = t * 16 + g * 4;  // this lane's four patch rows
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          f32x4b c = mma(qa[m], b);
-          if (!col_valid) c = f32x4b{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+          const f32x4b c = mma(b, qb[m]);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) mx[m][i] = fmaxf(mx[m][i], c[i]);
+          for (int i = 0; i < 4; ++i)
+            if (row0 + i < nr) mx[m] = fmaxf(mx[m], c[i]);
         }
       }
     }
@@ -508,14 +534,13 @@ __global__ __launch_bounds__(256) void maxsim_binary_mfma2_kernel(BMArgs args) {
 
   float ham = 0.f;
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float v = bin_group16_max(mx[m][i]);
-      if (qpop[m][i] >= 0.f) ham += qpop[m][i] - v;
-    }
-  ham += __shfl_xor(ham, 16);
-  ham += __shfl_xor(ham, 32);
+  for (int m = 0; m < MT; ++m) {
+    float v = mx[m];
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    if (qpop[m] >= 0.f) ham += qpop[m] - v;
+  }
+  ham = bin_group16_sum(ham);  // over the 16 query columns of the row (exact: small integers)
   if (lane == 0) {
     const float part = (float)a.n_q - ham * (1.0f / 128.0f);
     a.scores[item] = args.accumulate ? a.scores[item] + part : part;
@@ -666,12 +691,15 @@ __global__ __launch_bounds__(256) void maxsim_binary_stream_kernel(BMArgs args) 
 }
 
 // popc(q row) as float for rows < n_q, -1 for the padding rows up to `padded`; also zero-fills the padding bit rows
-__global__ void binary_qprep_kernel(uint4* qbits, int n_q, int padded, float* qpop) {
+__global__ void binary_qprep_kernel(uint4* qbits, int n_q, int padded, float* qpop, int signslot) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= padded) return;
   if (i < n_q) {
     const uint4 v = qbits[i];
-    qpop[i] = (float)(__popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w));
+    int pc = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    // variants 2..4: the sign-slot class contributes a query-only constant (see maxsim_binary_mfma2_kernel::expand)
+    if (signslot) pc += 16 - (__popc(v.x & 0x88888888u) + __popc(v.y & 0x88888888u) + __popc(v.z & 0x88888888u) + __popc(v.w & 0x88888888u));
+    qpop[i] = (float)pc;
   } else {
     qbits[i] = make_uint4(0u, 0u, 0u, 0u);
     qpop[i] = -1.0f;
@@ -708,8 +736,11 @@ int launch_maxsim_binary(const BinaryArgs& a, int variant, hipStream_t s) {
   if (a.n <= 0) return MV_OK;
   BArgs k{reinterpret_cast<const uint4*>(a.bits), a.n_rows, a.doc_ord, a.allow, a.n_allow_bits,
           reinterpret_cast<const uint4*>(a.qbits), a.scores, a.n, a.stride, a.n_q, a.qpop, a.cand};
-  if (a.cand && (variant == 1 || variant == 5)) variant = 4;  // the candidate-list form exists for variants 0 and 2..4
+  if (a.cand && (variant == 1 || variant >= 5)) variant = 4;  // the candidate-list form exists for variants 0 and 2..4
   if (a.n > ((int64_t)1 << 25)) { set_error("binary scan: more than 2^25 pages per launch is not supported"); return MV_ERR_INVALID; }
+  // the stream form needs fixed-size, unfiltered pages of whole 64-row slots; resolve the fallback HERE so that the
+  // query prep below matches the kernel that runs
+  if (variant == 5 && (a.n_rows || a.doc_ord || a.stride % kBinSlotRows != 0)) variant = 4;
   if (variant < 0) variant = 4;  // measured (200k pages x 1024): 408 M pages/s (4-slot ring) > 390 (8) > 295 (16) > 345 (v1) > 48 (popcount)
   if (variant == 0 || a.n_q <= 0) {
     hipLaunchKernelGGL(maxsim_binary_kernel, dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, s, k);
@@ -717,7 +748,8 @@ int launch_maxsim_binary(const BinaryArgs& a, int variant, hipStream_t s) {
     if (!a.qpop) { set_error("binary MFMA scan needs the qpop workspace"); return MV_ERR_INVALID; }
     const int padded = ((a.n_q + 15) / 16) * 16;
     hipLaunchKernelGGL(binary_qprep_kernel, dim3((unsigned)((padded + 63) / 64)), dim3(64), 0, s,
-                       reinterpret_cast<uint4*>(const_cast<uint8_t*>(a.qbits)), a.n_q, padded, a.qpop_rw);
+                       reinterpret_cast<uint4*>(const_cast<uint8_t*>(a.qbits)), a.n_q, padded, a.qpop_rw,
+                       variant >= 2 && variant <= 4 ? 1 : 0);
     // query rows in passes of <= 64 (4 MFMA row tiles); later passes accumulate into scores[]
     for (int q0 = 0, pass = 0; q0 < a.n_q; q0 += 64, ++pass) {
       BArgs kp = k;

@@ -97,7 +97,7 @@ struct BinaryArgs {
   int32_t n_q;
   const int32_t* cand;     // optional candidate list (item i = page cand[i], scores[i]); n = number of candidates
 };
-// variant: 0 = popcount (VALU), 1 = FP4 MFMA (16 VALU ops/tile), 2 = FP4 MFMA with in-place bit operands (9 VALU
+// variant: 0 = popcount (VALU), 1 = FP4 MFMA (16 VALU ops/tile), 2 = FP4 MFMA with in-place bit operands (8 VALU
 // ops/tile, 8-slot ring), 3 / 4 = variant 2 with a 16- / 4-slot ring (4 = default, -1), 5 = persistent waves with one DMA
 // stream across pages (fixed-size unfiltered corpora; measured 6.1 vs 6.7 TB/s for 4)
 int launch_maxsim_binary(const BinaryArgs& a, int variant, hipStream_t s);
