@@ -26,6 +26,7 @@ from __future__ import annotations
 import asyncio
 import base64
 import io
+import os
 import logging
 import time
 import zlib
@@ -97,7 +98,8 @@ class MI355XColpaliEmbeddingModel(BaseEmbeddingModel):
         model_name_or_path: Optional[str] = None,
         preset: str = "colpali-v1.2",
         device: Optional[str] = None,
-        batch_size: int = 8,  # the reference uses 8 in cloud mode, 1 self-hosted (:61)
+        batch_size: int = 32,  # the reference uses 8 in cloud mode, 1 self-hosted (:61); measured here (model only):
+                               # 8 -> 109 pages/s, 16 -> 126, 32 -> 140, 64 -> 145 (profiles/r1/embed_batch_probe.json)
         seed: int = 0,
         model: Any = None,
     ):
@@ -109,6 +111,7 @@ class MI355XColpaliEmbeddingModel(BaseEmbeddingModel):
         self.device = torch.device(device)
         self.dtype = torch.bfloat16
         self.batch_size = int(batch_size)
+        self._decode_pool = None
         self.processor = None
         self._timing: Dict[str, Any] = {}
         t0 = time.perf_counter()
@@ -124,6 +127,7 @@ class MI355XColpaliEmbeddingModel(BaseEmbeddingModel):
         else:
             self.model = self._build_random(preset, seed)
             self.random_init = True
+        self._patch_embedding_as_gemm()
         cfg = self.model.config.vlm_config
         self.image_size = int(cfg.vision_config.image_size)
         self.n_image_tokens = (self.image_size // int(cfg.vision_config.patch_size)) ** 2
@@ -155,6 +159,34 @@ class MI355XColpaliEmbeddingModel(BaseEmbeddingModel):
         finally:
             torch.set_default_dtype(prev)
         return model.to(self.device).eval()
+
+    def _patch_embedding_as_gemm(self) -> int:
+        """SigLIP's patch embedding is a Conv2d with kernel == stride (non-overlapping patches): the same arithmetic as
+        an unfold + ONE hipBLASLt GEMM [B*1024, 588] x [588, 1152].  Going through MIOpen instead costs a solver search at
+        first use (8 trial runs of `naive_conv_ab_nonpacked_fwd_nhwc`, 80 ms each at batch 32 -- 40 % of the GPU time of a
+        short run) for no steady-state gain.  The module
+        and its parameters stay in place (checkpoints load unchanged), only its forward is replaced.
+        -> number of modules rewired."""
+        import types
+
+        import torch.nn as nn
+        import torch.nn.functional as F
+
+        def gemm_forward(conv, x):
+            B, C, H, W = x.shape
+            p = conv.kernel_size[0]
+            gh, gw = H // p, W // p
+            cols = x.reshape(B, C, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * p * p)
+            y = F.linear(cols, conv.weight.reshape(conv.out_channels, -1), conv.bias)
+            return y.transpose(1, 2).reshape(B, conv.out_channels, gh, gw)
+
+        n = 0
+        for m in self.model.modules():
+            if (isinstance(m, nn.Conv2d) and m.kernel_size == m.stride and m.padding in ((0, 0), "valid") and m.dilation == (1, 1)
+                    and m.groups == 1 and m.kernel_size[0] == m.kernel_size[1]):
+                m.forward = types.MethodType(gemm_forward, m)
+                n += 1
+        return n
 
     # ------------------------------------------------------------------ preprocessing
     def _pixel_values(self, images: Sequence[Any]):
@@ -253,8 +285,25 @@ class MI355XColpaliEmbeddingModel(BaseEmbeddingModel):
         if not chunks:
             return torch.zeros((0, 128), dtype=self.dtype, device=self.device), []
         images, image_pos, texts, text_pos = [], [], [], []
-        for i, c in enumerate(chunks):
+
+        def decode(c):  # PNG/JPEG decode + RGB + resize on a pool thread (PIL releases the GIL in all three)
             img = _decode_image(c) if (c.metadata or {}).get("is_image") else None
+            if img is None or self.processor is not None:
+                return img  # a real processor does its own resizing / normalisation
+            return np.asarray(img.resize((self.image_size, self.image_size)))
+
+        t_dec = time.perf_counter()
+        if len(chunks) > 1:
+            if self._decode_pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+
+                self._decode_pool = ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1), thread_name_prefix="mv-decode")
+            decoded = list(self._decode_pool.map(decode, chunks))
+        else:
+            decoded = [decode(chunks[0])]
+        self._acc("image_process", time.perf_counter() - t_dec)
+        for i, c in enumerate(chunks):
+            img = decoded[i]
             if img is not None:
                 images.append(img)
                 image_pos.append(i)
@@ -264,8 +313,9 @@ class MI355XColpaliEmbeddingModel(BaseEmbeddingModel):
         per_chunk: List[Any] = [None] * len(chunks)
         for b0 in range(0, len(images), self.batch_size):
             emb, mask = self._embed_images_device(images[b0 : b0 + self.batch_size])
+            full = bool(mask.all())  # fixed-size pages: every row is valid, no per-chunk gather (and no per-chunk sync)
             for j in range(emb.shape[0]):
-                per_chunk[image_pos[b0 + j]] = emb[j][mask[j].bool()]
+                per_chunk[image_pos[b0 + j]] = emb[j] if full else emb[j][mask[j].bool()]
         for b0 in range(0, len(texts), self.batch_size):
             emb, mask = self._embed_texts_device(texts[b0 : b0 + self.batch_size])  # text documents use the query template (:310)
             for j in range(emb.shape[0]):

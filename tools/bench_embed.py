@@ -30,7 +30,8 @@ def synth_page(rng, size=448):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pages", type=int, default=1000)
-    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--feed", type=int, default=16, help="chunks per embed_for_ingestion call (the worker's COLPALI_STORE_BATCH_SIZE)")
     ap.add_argument("--preset", default="colpali-v1.2")
     ap.add_argument("--queries", type=int, default=8)
     ap.add_argument("--out", default="")
@@ -63,7 +64,7 @@ def main():
     model_s = 0.0
     done = 0
     while done < a.pages:
-        n = min(16, a.pages - done)  # the worker's COLPALI_STORE_BATCH_SIZE (ingestion_worker.py:1035)
+        n = min(a.feed, a.pages - done)  # default 16 = the worker's COLPALI_STORE_BATCH_SIZE (ingestion_worker.py:1035)
         t = time.perf_counter()
         chunks = [chunk(done + j) for j in range(n)]
         prep_s += time.perf_counter() - t
@@ -102,7 +103,7 @@ def main():
         "embed_tflops_est": round(flops_page * a.pages / model_s / 1e12, 1),
         "store_device_path_pages_per_s": round(a.pages / store_s, 1), "png_synthesis_s": round(prep_s, 2),
         "query_embed_ms_med": round(float(np.median(q_embed_ms)), 2), "query_maxsim_top10_ms_med": round(float(np.median(q_search_ms)), 3),
-        "dtype": "bf16", "data": "synthetic page images; random-init weights (no checkpoint in this environment)",
+        "model_batch": a.batch, "chunks_per_call": a.feed, "dtype": "bf16", "data": "synthetic page images; random-init weights (no checkpoint in this environment)",
         "top1_examples": top[:3],
     }
     js = json.dumps(res)
