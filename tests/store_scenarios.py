@@ -122,3 +122,73 @@ async def scenario_input_tolerance(store):
 
 ALL = [scenario_store_query_roundtrip, scenario_doc_filter, scenario_empty_and_missing, scenario_get_delete_upsert,
        scenario_input_tolerance]
+
+
+async def scenario_random_ops_against_model(store, seed=0, n_ops=60, mode="float", capacity=64):
+    """Model-based check of the store's bookkeeping: a random sequence of store (incl. upserts), delete, compact and
+    filtered queries; after every query the answer must be the brute-force top-k of the LIVE chunks (a plain dict is the
+    model), scored by the oracle.  Catches id remapping / tombstone / ordinal-reuse mistakes that fixed scenarios miss."""
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(seed)
+    model = {}  # (doc, chunk) -> embedding fp32 (bf16-rounded like the slab)
+    docs = [f"d{j}" for j in range(7)]
+    used_slots = 0
+
+    def bf16r(x):
+        return orc.bf16_to_f32(orc.f32_to_bf16(x))
+
+    for step in range(n_ops):
+        op = rng.choice(["store", "store", "delete", "compact", "query", "query"])
+        if op == "store":
+            n = int(rng.integers(1, 5))
+            if used_slots + n > capacity:
+                used_slots -= store.compact()
+                if used_slots + n > capacity:
+                    continue
+            chunks, seen = [], set()
+            for _ in range(n):
+                key = (str(rng.choice(docs)), int(rng.integers(0, 4)))
+                if key in seen:
+                    continue
+                seen.add(key)
+                e = rand_emb(rng, int(rng.integers(1, 25)))
+                chunks.append(DocumentChunk(document_id=key[0], chunk_number=key[1], content=f"{key[0]}/{key[1]}@{step}", embedding=e,
+                                            metadata={"step": step}))
+            ok, ids, _m = await store.store_embeddings(chunks)
+            assert ok and len(ids) == len(chunks)
+            used_slots += len(chunks)
+            for c in chunks:
+                model[(c.document_id, c.chunk_number)] = (bf16r(c.embedding), c.content)
+        elif op == "delete":
+            d = str(rng.choice(docs))
+            assert await store.delete_chunks_by_document_id(d) is True
+            for key in [k for k in model if k[0] == d]:
+                del model[key]
+        elif op == "compact":
+            used_slots -= store.compact()
+            assert used_slots == len(model) == len(store)
+        else:
+            q = rand_emb(rng, int(rng.integers(1, 9)))
+            filt = None
+            if rng.random() < 0.5:
+                filt = [str(d) for d in rng.choice(docs + ["nope"], size=int(rng.integers(1, 4)), replace=False)]
+            k = int(rng.integers(1, 8))
+            res = await store.query_similar(q, k=k, doc_ids=filt)
+            live = [(key, v) for key, v in model.items() if filt is None or key[0] in filt]
+            qb = bf16r(q)
+            if mode == "binary":
+                want = sorted(((float(orc.maxsim_binary(orc.sign_pack(v[0]), orc.sign_pack(q))), key) for key, v in live), key=lambda t: -t[0])
+            else:
+                want = sorted(((float(orc.maxsim_f32(qb, v[0])), key) for key, v in live), key=lambda t: -t[0])
+            assert len(res) == min(k, len(live))
+            got_scores = [r.score for r in res]
+            assert all(got_scores[i] >= got_scores[i + 1] for i in range(len(res) - 1))
+            np.testing.assert_allclose(got_scores, [w[0] for w in want[: len(res)]], rtol=1e-4, atol=1e-5)
+            cutoff = want[len(res) - 1][0] if res else 0.0
+            for r in res:  # every hit is a live chunk with its CURRENT payload; ties at the cut may pick either chunk
+                assert (r.document_id, r.chunk_number) in model and r.content == model[(r.document_id, r.chunk_number)][1]
+                assert filt is None or r.document_id in filt
+                assert r.score >= cutoff - 1e-4 * abs(cutoff) - 1e-5
+            got = await store.get_chunks_by_id([(key[0], key[1]) for key in list(model)[:3]] + [("nope", 0)])
+            assert {(g.document_id, g.chunk_number) for g in got} == set(list(model)[:3])

@@ -242,3 +242,14 @@ def test_library_merge_of_gathered_topk_equals_reference_merge():
         n = int((got_i >= 0).sum())
         assert n == len(wi) and got_i[:n].tolist() == wi.tolist() and out_s.cpu().numpy()[:n].tolist() == ws.tolist()
         assert np.all(got_i[n:] == -1)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("mode", ["float", "binary"])
+def test_random_op_sequences_match_a_brute_force_model_on_gpu(seed, mode):
+    """Store bookkeeping + real tombstones / compaction / upserts in the HBM index vs a dict model scored by the oracle."""
+    s = _store(mode)
+    try:
+        sc.run(sc.scenario_random_ops_against_model(s, seed=seed, n_ops=80, mode=mode, capacity=64))
+    finally:
+        s.close()

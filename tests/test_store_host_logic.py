@@ -146,3 +146,9 @@ def test_coalesced_requests_all_see_a_scan_failure():
 
     res = sc.run(fire())
     assert len(res) == 3 and all(isinstance(r, RuntimeError) for r in res)  # query errors propagate to every waiter
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("mode", ["float", "binary"])
+def test_random_op_sequences_match_a_brute_force_model(seed, mode):
+    sc.run(sc.scenario_random_ops_against_model(_store(mode=mode), seed=seed, n_ops=50, mode=mode, capacity=64))

@@ -17,3 +17,12 @@ import json
 d=json.load(open('gpurun_out/bench_2rank.json'))
 print('2-rank gloo functional:', d['n_gpus'], d['value'], 'recall', d['recall_at_10'], d['config']['parallelism'])
 PY
+# 1-rank RCCL communicator: the nccl-backend code path (GpuShardedSearcher: collectives + mv_merge_topk; two-stage FDE pipeline)
+MV_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29519 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python bench.py --pages 200000 --steps 10 --warmup 2 --no-aux 2>$OUT/bench_rccl1.err | grep '^{' > $OUT/bench_rccl1.json
+MV_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29521 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python bench.py --workload fde_fp8 --pages 200000 --steps 10 --warmup 2 --no-aux 2>$OUT/bench_rccl1_fde.err | grep '^{' > $OUT/bench_rccl1_fde.json
+python - <<'PY'
+import json
+for f in ('bench_rccl1', 'bench_rccl1_fde'):
+    d=json.load(open(f'gpurun_out/{f}.json'))
+    print(f, 'RCCL 1-rank:', d['value'], 'ms/step', d['ms_per_step'], 'kernel', d['roofline']['kernel_ms_avg'], 'recall', d['recall_at_10'])
+PY
