@@ -359,6 +359,53 @@ def test_two_stage_fde_logical_shards_equal_single_index(mv, with_float):
     one.close()
 
 
+def test_full_size_one_million_pages_properties(mv):
+    """BASELINE configs[2] at FULL size (1 M pages x 1024 patches x 128-d bf16 = 262 GB): the oracle cannot score it in
+    test time, so parity is carried by size-independent properties over ALL pages plus sampled oracle scores:
+    planted recall@10 = 1.0, sorted + idempotent top-k, top-k == selection over the full score vector, additivity of
+    MaxSim over query rows (score(q1 ++ q2) = score(q1) + score(q2) on every page), 64 sampled pages vs the oracle."""
+    import torch
+
+    from morphik_core_amd import synth
+
+    free_b, _total = torch.cuda.mem_get_info(0)
+    N, stride = 1_000_000, 1024
+    if free_b < N * stride * 256 + (8 << 30):
+        pytest.skip(f"needs {N * stride * 256 / 2**30:.0f} GiB of free HBM, have {free_b / 2**30:.0f}")
+    ix = _idx(mv, capacity_pages=N, stride_rows=stride)
+    try:
+        ix.fill_synthetic(synth.SEED_CORPUS, 0, N)
+        queries = [orc.synth_rows(synth.SEED_QUERIES, qi, 0, 32) for qi in range(2)]
+        spec = synth.planted_spec(queries, N, stride)
+        assert synth.plant_neighbours(ix, spec) == 20
+        all_scores = []
+        for qi, q in enumerate(queries):
+            s, i = ix.query(q, 10)
+            planted = [p for (qq, _r, p, _row0, _rows) in spec if qq == qi]
+            assert i.tolist() == planted  # rank order of the planted neighbours, recall@10 = 1.0
+            assert all(s[j] > s[j + 1] for j in range(9))
+            s2, i2 = ix.query(q, 10)
+            assert i2.tolist() == i.tolist() and s2.tolist() == s.tolist()  # idempotent, bit for bit
+            sc = ix.score_all(q)
+            assert sc.shape == (N,) and np.isfinite(sc).all()
+            ws, wi = orc.topk(sc, 10)
+            assert wi.tolist() == i.tolist() and ws.tolist() == s.tolist()  # device selection == selection over every score
+            ws, wi = orc.topk(sc, 1000)
+            s3, i3 = ix.query(q, 1000)  # radix-threshold selection path at full size
+            assert i3.tolist() == wi.tolist() and s3.tolist() == ws.tolist()
+            all_scores.append(sc)
+        both = ix.score_all(np.concatenate(queries))  # 64 query rows in one pass
+        np.testing.assert_allclose(both, all_scores[0] + all_scores[1], rtol=2e-6, atol=1e-5)
+        rng = np.random.default_rng(3)
+        sample = np.sort(rng.choice(N, 64, replace=False))
+        qf = orc.bf16_to_f32(queries[0])
+        for p in sample.tolist() + [N - 1, 0]:
+            want = orc.maxsim_float_np(qf, orc.bf16_to_f32(ix.read_pages(p, 1)))[0]
+            assert abs(all_scores[0][p] - want) <= 1e-4 * abs(want)
+    finally:
+        ix.close()
+
+
 def test_planted_neighbours_recall_and_sampled_parity_midsize(mv):
     """20k pages x 1024 patches (5.2 GB): recall@10 == 1.0 on planted neighbours; sampled oracle parity."""
     from morphik_core_amd import synth
