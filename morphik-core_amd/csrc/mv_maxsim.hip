@@ -388,9 +388,10 @@ int launch_mt(const KArgs& k0, int variant, hipStream_t s) {
 
 // Measured on MI355X (profiles/r1/variants_r1*.json, 100-200k pages x 1024 patches, Q=32): non-temporal LDS-DMA ring
 // with four waves per page 7.34 TB/s > the same with one wave per page 7.08 > default-policy LDS-DMA 6.53 / 6.37 >
-// direct loads 6.2-6.4 TB/s > non-temporal direct 5.9-6.0 TB/s.  Short pages (< 16 tiles) cannot feed four waves,
-// so they take the wave-per-page form.
-int maxsim_default_variant(int stride_rows) { return stride_rows >= 256 ? 6 : 7; }
+// direct loads 6.2-6.4 TB/s > non-temporal direct 5.9-6.0 TB/s.  Short pages cannot feed four waves: at 256 rows (64 KiB)
+// the four-wave form drops to 5.84 TB/s against 6.92 for one wave per page, at 512 rows it leads 7.26 to 6.88
+// (profiles/r1/float_scan_vs_page_size.json), so pages below 512 rows take the wave-per-page form.
+int maxsim_default_variant(int stride_rows) { return stride_rows >= 512 ? 6 : 7; }
 
 const char* maxsim_variant_name(int v) {
   switch (v) {
