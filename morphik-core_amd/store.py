@@ -70,6 +70,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         fde_coarse_n: int = 0,
         batch_window_ms: float = 0.0,
         max_batch: int = 16,
+        min_score: Optional[float] = None,
         **_ignored: Any,
     ):
         self.capacity_pages = int(capacity_pages)
@@ -86,6 +87,10 @@ class MI355XMultiVectorStore(BaseVectorStore):
         # scored in ONE slab pass by the batched MFMA kernel, each keeping its own doc_ids filter and k
         self.batch_window_s = float(batch_window_ms) / 1e3
         self.max_batch = int(max_batch)
+        # The API accepts min_score (core/models/request.py:138) and threads it through retrieve_chunks
+        # (document_service.py:184) but the reference never applies it to multivector hits; None keeps that behaviour,
+        # a number drops hits scoring below it
+        self.min_score = None if min_score is None else float(min_score)
         self._pending: List[Tuple[np.ndarray, int, Any, Any]] = []
         self._flush_handle = None
         self.coalesced_batches: List[int] = []  # sizes of the batches actually issued (introspection / tests)
@@ -310,6 +315,8 @@ class MI355XMultiVectorStore(BaseVectorStore):
         out: List[DocumentChunk] = []
         with self._lock:
             for s, p in zip(scores.tolist(), pages.tolist()):
+                if self.min_score is not None and s < self.min_score:
+                    break  # hits are sorted by score desc
                 row = self._rows.get(int(p))
                 if row is None:
                     continue  # deleted between scan and lookup

@@ -152,3 +152,17 @@ def test_coalesced_requests_all_see_a_scan_failure():
 @pytest.mark.parametrize("mode", ["float", "binary"])
 def test_random_op_sequences_match_a_brute_force_model(seed, mode):
     sc.run(sc.scenario_random_ops_against_model(_store(mode=mode), seed=seed, n_ops=50, mode=mode, capacity=64))
+
+
+def test_optional_min_score_cut():
+    """The reference accepts min_score but never applies it to multivector hits (default None = same); a number cuts."""
+    rng = np.random.default_rng(5)
+    chunks = sc.make_chunks(rng, n_docs=2, chunks_per_doc=3)
+    plain, cut = _store(mode="float"), _store(mode="float", min_score=0.0)
+    for st in (plain, cut):
+        sc.run(st.store_embeddings(chunks))
+    res = sc.run(plain.query_similar(chunks[0].embedding, k=6))
+    assert len(res) == 6
+    cut.min_score = (res[1].score + res[2].score) / 2
+    got = sc.run(cut.query_similar(chunks[0].embedding, k=6))
+    assert [(r.document_id, r.chunk_number) for r in got] == [(r.document_id, r.chunk_number) for r in res[:2]]
