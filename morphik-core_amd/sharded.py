@@ -195,12 +195,12 @@ class TwoStageShardedSearcher:
 
       1. every rank: FDE coarse scan of its shard -> local top-n (score, global id)
       2. all-gather of n pairs per rank (16 B each) -> global coarse top-n, identical on every rank
-      3. every rank keeps the candidates IT OWNS; all-reduce(MAX) of their row counts gives the pad-to-longest
-         length of the reference's rerank batch (pad_sequence, :553-555)
+      3. every rank keeps the candidates IT OWNS; the candidates' row counts travel in the same all-gather, so every
+         rank knows the pad-to-longest length of the reference's rerank batch (pad_sequence, :553-555)
       4. every rank: exact MaxSim of its own candidates (no embedding crosses xGMI) -> local top-k
       5. all-gather of k pairs per rank -> merged top-k
 
-    Three small collectives, all latency-bound.  The callables keep the class testable on CPU (gloo + oracle):
+    Two small collectives, both latency-bound.  The callables keep the class testable on CPU (gloo + oracle):
       local_coarse(q, n, allow) -> (scores[n], ids[n]) tensors on the collective's device, padded (-inf, -1), GLOBAL ids
       local_rows(global_ids)    -> int array of row counts of owned pages
       local_rerank(q, global_ids, pad_to) -> float32 array of exact MaxSim scores of owned pages
@@ -242,16 +242,32 @@ class TwoStageShardedSearcher:
         return ls, li
 
     def query(self, q, k: int, coarse_n: Optional[int] = None, allow=None):
+        import numpy as np
         import torch
         import torch.distributed as dist
 
         n, cs, ci = self.coarse(q, k, coarse_n, allow)
-        _, gi = allgather_topk(cs, ci, n, self.group, compact=False)
-        mine, longest = self.owned(gi)
-        if self.pad and dist.is_initialized():
-            t = torch.tensor([longest], dtype=torch.int64, device=cs.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            longest = int(t.item())
+        # the row counts of this rank's coarse candidates ride in the same all-gather as their (score, id) pairs, so the
+        # pad-to-longest length of the GLOBAL candidate list needs no collective of its own
+        ids_h = ci.detach().cpu().numpy().astype(np.int64)
+        rows_h = np.zeros(n, np.float64)
+        if self.pad and (ids_h >= 0).any():
+            rows_h[ids_h >= 0] = self.local_rows(ids_h[ids_h >= 0])
+        mine3 = torch.cat([cs.reshape(-1).to(torch.float64), ci.reshape(-1).to(torch.float64),
+                           torch.from_numpy(rows_h).to(cs.device)])
+        if dist.is_initialized():
+            world = dist.get_world_size(self.group)
+            allb = torch.empty(world * 3 * n, dtype=torch.float64, device=mine3.device)
+            dist.all_gather_into_tensor(allb, mine3, group=self.group)
+            allb = allb.view(world, 3, n)
+        else:
+            allb = mine3.view(1, 3, n)
+        gs, gi, gr = allb[:, 0].reshape(-1), allb[:, 1].reshape(-1), allb[:, 2].reshape(-1)
+        order = torch.sort(gs, descending=True, stable=True).indices[:n]  # (score desc, id asc): ranks own ascending ids
+        sel = torch.stack([gi[order], gr[order]]).cpu().numpy()  # ONE device->host copy: global top-n ids + row counts
+        gid, grows = sel[0].astype(np.int64), sel[1]
+        longest = int(grows[gid >= 0].max()) if (self.pad and (gid >= 0).any()) else 0
+        mine = gid[(gid >= self.lo) & (gid < self.hi)]
         ls, li = self.rerank(q, mine, longest, k)
         return allgather_topk(ls.to(cs.device), li.to(cs.device), k, self.group)
 
