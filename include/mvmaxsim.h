@@ -202,14 +202,25 @@ MV_API int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t
 MV_API int mv_merge_topk(int device, const float* d_scores, const int64_t* d_ids, int32_t world, int32_t kk, int32_t k,
                          float* d_out_scores, int64_t* d_out_ids, void* stream);
 
-/* Score every page (no selection): out_scores[size] floats on the host; masked pages get -inf.
+/* Score every page (no selection) into a host buffer of out_cap floats; masked pages get -inf.  *out_n = entries
+ * written = min(published pages, out_cap) -- the corpus may grow between the caller's mv_index_size() and this call.
  * For MV_MODE_FDE_* this returns the coarse scores. */
 MV_API int mv_score_all(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int mode,
-                        const uint32_t* allow_bits, int64_t n_allow_words, float* out_scores, mv_query_stats* stats);
-/* Exact float MaxSim of an explicit candidate list (local page ids). pad_to as in MV_OPT_PAD_SEMANTICS=1
- * (0 = none).  Replaces processor.score_multi_vector(...) at fast_multivector_store.py:553-555. */
+                        const uint32_t* allow_bits, int64_t n_allow_words, float* out_scores, int64_t out_cap,
+                        int64_t* out_n, mv_query_stats* stats);
+/* Exact float MaxSim of an explicit candidate list (local page ids), in list order.  Replaces
+ * processor.score_multi_vector(...) at fast_multivector_store.py:553-555 (colpali_engine: passages are scored in
+ * batches of 128, each batch zero-padded to ITS longest page by pad_sequence, so a page shorter than its batch's
+ * longest sees zero rows and every query token's maximum is clamped at 0).
+ *   pad_to = -1  the reference rule: pad length of candidate i = longest page among candidates [128*(i/128), +128)
+ *   pad_to =  0  no padding: the maximum runs over a page's own rows only
+ *   pad_to >  0  one explicit pad length for the whole list */
 MV_API int mv_score_candidates(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const int32_t* cand,
                                int32_t n_cand, int32_t pad_to, float* out_scores, mv_query_stats* stats);
+/* Same with an explicit pad length PER candidate (pads[i] rows): a row-sharded rerank scores only the candidates a
+ * shard owns, but each one's pad length is that of its batch in the GLOBAL candidate list. */
+MV_API int mv_score_candidates_pads(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const int32_t* cand,
+                                    int32_t n_cand, const int32_t* pads, float* out_scores, mv_query_stats* stats);
 
 /* Row counts of the named pages (local page ids) from the index's host-side metadata; no device work.  A sharded
  * FDE_THEN_FLOAT query needs them to apply the reference's pad-to-longest rule (pad_sequence at
@@ -236,11 +247,62 @@ MV_API int mv_calibrate_read_bw(int device, int64_t bytes, int32_t iters, double
 /* Measured peaks for the roofline denominators, taken in the same process as the measurement:
  *   MV_CAL_READ_NT    streams `bytes` of device memory `iters` times in contiguous 16 KiB pieces with non-temporal
  *                     loads (the scan kernels' access pattern, no arithmetic)            -> *out in GB/s
- *   MV_CAL_MFMA_BF16  register-only v_mfma_f32_16x16x32_bf16 chains on every CU        -> *out in TFLOP/s */
-enum { MV_CAL_READ_NT = 1, MV_CAL_MFMA_BF16 = 2 };
+ *   MV_CAL_MFMA_BF16  register-only v_mfma_f32_16x16x32_bf16 chains on every CU        -> *out in TFLOP/s
+ *   MV_CAL_READ_LDSDMA the float scan's own transport with the arithmetic removed: non-temporal global_load_lds_dwordx4
+ *                     into the 4-slot wave-private ring, four waves per 256 KiB piece     -> *out in GB/s */
+enum { MV_CAL_READ_NT = 1, MV_CAL_MFMA_BF16 = 2, MV_CAL_READ_LDSDMA = 3 };
 MV_API int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out);
 
-/* Persistence ("checkpoint" of the HBM index): raw slabs + metadata in one file. */
+/* ---------------------------------------------------------------------------------------------------------------
+ * Row-sharded corpus: the two-stage pipeline (FastMultiVectorStore.query_similar, fast_multivector_store.py:521-556)
+ * over R shards with the SAME candidate set, pad lengths and answer as one big index.  Stage entry points for callers
+ * that own the collective themselves (one process per GPU over torch.distributed / RCCL: morphik_core_amd/sharded.py);
+ * mv_comm below drives them for a single-process multi-GPU store.
+ * --------------------------------------------------------------------------------------------------------------- */
+/* One coarse candidate: 16 bytes, all-gathered as raw bytes.  Padding entries are (-inf, 0, -1). */
+typedef struct {
+  float score;   /* FDE coarse score */
+  int32_t rows;  /* the page's row count (pad-to-longest needs it on every shard) */
+  int64_t id;    /* GLOBAL page id */
+} mv_cand_rec;
+
+/* Stage 1 on one shard: FDE coarse scan + local top-n_coarse -> d_out_recs (DEVICE, n_coarse records sorted by
+ * (score desc, id asc)).  n_coarse <= 1024.  stream as in mv_query_topk_device (NULL = return when finished). */
+MV_API int mv_two_stage_coarse_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int32_t n_coarse,
+                                      const uint32_t* allow_bits, int64_t n_allow_words, mv_cand_rec* d_out_recs,
+                                      void* stream);
+/* Stage 2 on one shard: d_all_recs = [world][n_coarse] records (the all-gather of stage 1 in shard order, shards
+ * owning ascending id ranges).  Derives the GLOBAL coarse top-n_coarse (identical on every shard), keeps the
+ * candidates this shard owns, reranks them exactly (bf16 slab, else fp8) with the pad length of each candidate's batch
+ * of 128 in the GLOBAL list, and leaves the local top-k in d_out_scores / d_out_ids (DEVICE, padded (-inf, -1)).
+ * No host synchronisation between the steps; world * n_coarse <= 16384. */
+MV_API int mv_two_stage_rerank_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows,
+                                      const mv_cand_rec* d_all_recs, int32_t world, int32_t n_coarse, int32_t k,
+                                      float* d_out_scores, int64_t* d_out_ids, void* stream);
+
+/* Single-process communicator over R shards (SURVEY.md 8b "mv_comm_init(n_ranks, device_ids)"): the reference builds
+ * ONE store object in ONE process (core/services_init.py:141-165) -- a store that owns 8 GPUs needs the top-k exchange
+ * behind the C ABI.  Shard i lives on device_ids[i] (several shards may share a device: logical shards) and owns the
+ * global ids [id_base_i, id_base_i + size_i), ascending with i.
+ *   MV_COMM_RCCL  ncclCommInitAll + one grouped ncclAllGather of the k (score,id) pairs per query (distinct devices only)
+ *   MV_COMM_P2P   hipMemcpyPeerAsync of every shard's k pairs into shard 0's device, merged there (mv_merge_topk)
+ *   MV_COMM_HOST  per-shard results copied to the host and merged there (the correctness reference)
+ *   MV_COMM_AUTO  RCCL when the devices are distinct and librccl loads, else P2P */
+typedef struct mv_comm mv_comm;
+enum { MV_COMM_AUTO = 0, MV_COMM_RCCL = 1, MV_COMM_P2P = 2, MV_COMM_HOST = 3 };
+MV_API int mv_comm_create(int32_t n_shards, const int32_t* device_ids, int32_t transport, mv_comm** out);
+MV_API void mv_comm_destroy(mv_comm* c);
+MV_API int mv_comm_attach(mv_comm* c, int32_t shard, mv_index* ix);
+MV_API int mv_comm_transport(const mv_comm* c); /* the transport in use (MV_COMM_RCCL / P2P / HOST) */
+/* Query every shard (scans run concurrently, one stream per shard), exchange, merge: same results, order and tie
+ * rule as ONE index holding all pages.  MV_MODE_FDE_THEN_FLOAT runs the two-stage pipeline above.
+ * stats (nullable): n_shards entries, per-shard device timings of this query. */
+MV_API int mv_comm_query_topk(mv_comm* c, const void* q, int q_dtype, int32_t n_q_rows, int32_t k, int mode,
+                              const uint32_t* allow_bits, int64_t n_allow_words, float* out_scores, int64_t* out_ids,
+                              int32_t* out_n, mv_query_stats* stats);
+
+/* Persistence ("checkpoint" of the HBM index): raw slabs + metadata in one file (written to <path>.tmp, fsync'ed and
+ * renamed: a crash mid-save keeps the previous checkpoint). */
 MV_API int mv_index_save(mv_index* ix, const char* path);
 MV_API int mv_index_load(const char* path, int32_t device, mv_index** out);
 

@@ -74,14 +74,24 @@ MV_OPT_BATCH_VARIANT = 7
 MV_OPT_FDE_ENCODE_VARIANT = 8
 MV_OPT_FILTER_COMPACT_PCT = 9
 MV_OPT_LONG_QUERY_VARIANT = 10
-MV_CAL_READ_NT, MV_CAL_MFMA_BF16 = 1, 2
+MV_CAL_READ_NT, MV_CAL_MFMA_BF16, MV_CAL_READ_LDSDMA = 1, 2, 3
+MV_COMM_AUTO, MV_COMM_RCCL, MV_COMM_P2P, MV_COMM_HOST = 0, 1, 2, 3
+
+
+class CandRecC(C.Structure):
+    """mv_cand_rec: one coarse candidate of the sharded two-stage pipeline (16 bytes)."""
+
+    _fields_ = [("score", C.c_float), ("rows", C.c_int32), ("id", C.c_int64)]
+
 
 # every symbol include/mvmaxsim.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "mv_last_error", "mv_version", "mv_device_count", "mv_index_create", "mv_index_destroy", "mv_index_set_option",
     "mv_index_size", "mv_index_capacity", "mv_index_add", "mv_index_add_device", "mv_index_add_bits", "mv_index_remove_doc",
     "mv_index_remove_page", "mv_index_compact", "mv_index_read_pages", "mv_index_write_rows", "mv_index_replace_page", "mv_index_read_fp8", "mv_index_fill_synthetic", "mv_synth_rows",
-    "mv_query_topk", "mv_query_topk_device", "mv_query_topk_batch", "mv_merge_topk", "mv_score_all", "mv_score_candidates", "mv_index_page_rows", "mv_sign_pack", "mv_hamming_batch",
+    "mv_query_topk", "mv_query_topk_device", "mv_query_topk_batch", "mv_merge_topk", "mv_score_all", "mv_score_candidates", "mv_score_candidates_pads", "mv_index_page_rows",
+    "mv_two_stage_coarse_device", "mv_two_stage_rerank_device", "mv_comm_create", "mv_comm_destroy", "mv_comm_attach", "mv_comm_transport",
+    "mv_comm_query_topk", "mv_sign_pack", "mv_hamming_batch",
     "mv_fde_output_dim", "mv_fde_encode", "mv_calibrate_read_bw", "mv_calibrate", "mv_index_save", "mv_index_load",
 ]
 
@@ -147,8 +157,17 @@ def lib() -> C.CDLL:
         L.mv_query_topk_device.argtypes = [vp, vp, C.c_int, i32, i32, C.c_int, vp, i64, vp, vp, vp, C.POINTER(QueryStatsC)]
         L.mv_query_topk_batch.argtypes = [vp, vp, C.c_int, i32, i32, i32, C.c_int, vp, i64, i32, vp, vp, vp, C.POINTER(QueryStatsC)]
         L.mv_merge_topk.argtypes = [C.c_int, vp, vp, i32, i32, i32, vp, vp, vp]
-        L.mv_score_all.argtypes = [vp, vp, C.c_int, i32, C.c_int, vp, i64, vp, C.POINTER(QueryStatsC)]
+        L.mv_score_all.argtypes = [vp, vp, C.c_int, i32, C.c_int, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(QueryStatsC)]
         L.mv_score_candidates.argtypes = [vp, vp, C.c_int, i32, vp, i32, i32, vp, C.POINTER(QueryStatsC)]
+        L.mv_score_candidates_pads.argtypes = [vp, vp, C.c_int, i32, vp, i32, vp, vp, C.POINTER(QueryStatsC)]
+        L.mv_two_stage_coarse_device.argtypes = [vp, vp, C.c_int, i32, i32, vp, i64, vp, vp]
+        L.mv_two_stage_rerank_device.argtypes = [vp, vp, C.c_int, i32, vp, i32, i32, i32, vp, vp, vp]
+        L.mv_comm_create.argtypes = [i32, vp, i32, C.POINTER(vp)]
+        L.mv_comm_destroy.argtypes = [vp]
+        L.mv_comm_destroy.restype = None
+        L.mv_comm_attach.argtypes = [vp, i32, vp]
+        L.mv_comm_transport.argtypes = [vp]
+        L.mv_comm_query_topk.argtypes = [vp, vp, C.c_int, i32, i32, C.c_int, vp, i64, vp, vp, C.POINTER(i32), vp]
         L.mv_index_page_rows.argtypes = [vp, vp, i64, vp]
         L.mv_sign_pack.argtypes = [C.c_int, vp, i64, i32, vp]
         L.mv_hamming_batch.argtypes = [C.c_int, vp, vp, i64, i32, vp]

@@ -16,7 +16,10 @@
 #include <new>
 #include <vector>
 
-#include "mv_common.h"
+#include "mv_index_priv.h"
+
+#include <fcntl.h>
+#include <unistd.h>
 
 namespace mv {
 
@@ -64,87 +67,7 @@ __global__ void ids64_to_32_kernel(const int64_t* in, int32_t* out, int n) {
 
 using namespace mv;
 
-constexpr int kMaxQRowsPerPass = 128;  // 8 MFMA row tiles held in VGPRs
-constexpr int kMaxCand = 65536;
-
-struct mv_index {
-  mv_config cfg{};
-  hipStream_t stream = nullptr;
-  // slabs
-  uint16_t* slab = nullptr;
-  uint8_t* bits = nullptr;
-  uint16_t* fde = nullptr;
-  float* fde_inv_norm = nullptr;
-  uint8_t* slab8 = nullptr;      // e4m3 page slab [capacity][stride][128]
-  float* inv_scale8 = nullptr;   // [capacity] 2^-e per page
-  int32_t* d_n_rows = nullptr;
-  int32_t* d_doc_ord = nullptr;
-  std::vector<int32_t> h_n_rows, h_doc_ord;
-  int64_t size = 0;
-  bool ragged = false;      // some page has n_rows != stride
-  bool tombstones = false;  // some page is deleted
-  FdeTables fde_t;
-  // per-query workspace
-  float* d_scores = nullptr;   // [capacity]
-  float* d_scores2 = nullptr;  // [capacity] (second accumulator for > 64 query rows)
-  void* d_topk_ws = nullptr;
-  size_t topk_ws_bytes = 0;
-  uint16_t* d_q = nullptr;     // bf16 query, padded
-  float* d_qf32 = nullptr;     // fp32 query rows (FDE encode input)
-  uint8_t* d_qbits = nullptr;
-  float* d_qpop = nullptr;     // popc per query row (binary MFMA scan)
-  uint8_t* d_q8hi = nullptr;   // e4m3 query rows, two-term split (fp8 scan)
-  uint8_t* d_q8lo = nullptr;
-  float* d_q8fac = nullptr;    // 2^-s per query row
-  uint16_t* d_bq = nullptr;    // [512][128] bf16 query block of the batched scan
-  float* d_bscores = nullptr;  // [32][capacity] per-query score vectors of the batched scan (lazily allocated)
-  int32_t* d_fcand = nullptr;  // [capacity] pages a selective doc filter lets through (lazily allocated)
-  int32_t* d_fcounts = nullptr;
-  int32_t max_doc_ord = -1;    // largest document ordinal seen (filter selectivity estimate)
-  int filter_compact_pct = 25; // compact when the filter allows less than this share of the documents (0 = never)
-  float* d_qfde = nullptr;
-  int64_t* d_qoff = nullptr;   // [2] row offsets for the query "page"
-  uint32_t* d_allow = nullptr;
-  int64_t allow_cap_words = 0;
-  float* d_out_s = nullptr;    // [kTopkMaxDeviceK]
-  int64_t* d_out_id = nullptr;
-  int32_t* d_cand = nullptr;   // [kMaxCand]
-  float* d_cand_scores = nullptr;
-  int q_rows_cap = 0;
-  // pinned host staging of the query (fp32 + padded bf16) and of the k results: async copies, no sync on the way in
-  float* h_qf32 = nullptr;
-  uint16_t* h_qbf16 = nullptr;
-  float* h_out_s = nullptr;
-  int64_t* h_out_id = nullptr;
-  hipEvent_t ev_stage = nullptr;  // recorded behind the H2D copies of the staging buffers
-  hipEvent_t ev[6] = {};
-  std::mutex mu;
-  // options
-  int maxsim_variant = -1;
-  int binary_variant = -1;
-  int fde_scan_variant = -1;
-  int batch_variant = -1;      // -1 = auto: pipelined kernel up to 384 query rows, 512-row kernel above
-  int long_query_variant = 1;  // 1 = single queries > 64 rows use the row-split (batched) workgroup; 0 = page-split passes
-  int fde_encode_variant = 1;  // 1 = f32-MFMA kernel, 0 = scalar kernel
-  int64_t fde_coarse_n = 0;
-  int fde_cosine = 1;
-  int pad_semantics = -1;  // -1: mode default (reference batch rule for FDE_THEN_FLOAT / candidates, none for full scan)
-};
-
-namespace {
-
-struct DeviceGuard {
-  int prev = -1;
-  explicit DeviceGuard(int dev) {
-    (void)hipGetDevice(&prev);
-    if (prev != dev) (void)hipSetDevice(dev);
-  }
-  ~DeviceGuard() {
-    int cur = -1;
-    (void)hipGetDevice(&cur);
-    if (prev >= 0 && cur != prev) (void)hipSetDevice(prev);
-  }
-};
+namespace mv {
 
 int ensure_query_cap(mv_index* ix, int n_rows) {
   const int padded = ((n_rows + 15) / 16) * 16;
@@ -178,7 +101,7 @@ int ensure_query_cap(mv_index* ix, int n_rows) {
 
 // Upload the query in every representation the mode needs.  Returns padded row count.
 int upload_query(mv_index* ix, const void* q, int q_dtype, int n_q, bool want_bf16, bool want_f32, bool want_bits,
-                 bool want_fp8 = false) {
+                 bool want_fp8) {
   int rc = ensure_query_cap(ix, n_q);
   if (rc) return rc;
   const int padded = ((n_q + 15) / 16) * 16;
@@ -233,24 +156,15 @@ int upload_allow(mv_index* ix, const uint32_t* allow_bits, int64_t n_words, cons
   return MV_OK;
 }
 
-struct ScanResult {
-  const float* d_scores = nullptr;  // per work item
-  int64_t n = 0;
-  const int32_t* d_ids_map = nullptr;  // work item -> local page (candidate list) or null
-  int launches = 0;
-  int64_t pages = 0;
-  int64_t bytes = 0;
-};
-
-int64_t count_allowed_rows(const mv_index* ix, const uint32_t* allow_bits, int64_t n_words, int64_t* pages_out) {
+int64_t count_allowed_rows(const mv_index* ix, int64_t n, const uint32_t* allow_bits, int64_t n_words, int64_t* pages_out) {
   // algorithmic accounting on the host metadata (exact): pages that are read and their valid rows
   int64_t rows = 0, pages = 0;
   const bool filt = allow_bits != nullptr;
-  if (!filt && !ix->tombstones && !ix->ragged) {
-    *pages_out = ix->size;
-    return ix->size * (int64_t)ix->cfg.stride_rows;
+  if (!filt && !ix->tombstones.load() && !ix->ragged.load()) {
+    *pages_out = n;
+    return n * (int64_t)ix->cfg.stride_rows;
   }
-  for (int64_t p = 0; p < ix->size; ++p) {
+  for (int64_t p = 0; p < n; ++p) {
     const int32_t o = ix->h_doc_ord[p];
     if (o < 0) continue;
     if (filt && ((int64_t)o >= n_words * 32 || !((allow_bits[o >> 5] >> (o & 31)) & 1u))) continue;
@@ -261,16 +175,52 @@ int64_t count_allowed_rows(const mv_index* ix, const uint32_t* allow_bits, int64
   return rows;
 }
 
+// Candidate list of a rerank, built on the device: ids (int64 from the selection kernels, or int32 from the caller)
+// -> int32 local pages (-1 kept as padding) + the pad_to of every candidate = the longest page of ITS batch of 128 in
+// list order (score_multi_vector pads each passage batch on its own: pad_sequence at fast_multivector_store.py:553-555
+// -> colpali_engine score_multi_vector, batch_size = 128).  One block per batch.
+__global__ __launch_bounds__(kRerankBatch) void cand_prepare_kernel(const int64_t* ids64, const int32_t* ids32, int n,
+                                                                    const int32_t* n_rows, int32_t stride, int pad_sem,
+                                                                    int32_t* cand, int32_t* pads) {
+  __shared__ int32_t wmax[kRerankBatch / 64];
+  const int i = blockIdx.x * kRerankBatch + threadIdx.x;
+  int32_t c = -1, rows = 0;
+  if (i < n) {
+    c = ids64 ? (ids64[i] < 0 ? -1 : (int32_t)ids64[i]) : ids32[i];
+    if (c >= 0) rows = n_rows ? n_rows[c] : stride;
+  }
+  int32_t m = rows;
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) m = max(m, __shfl_xor(m, s));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = max(wmax[0], wmax[1]);
+  if (i < n) {
+    cand[i] = c;
+    pads[i] = pad_sem ? m : 0;
+  }
+}
+
+int launch_cand_prepare(mv_index* ix, const int64_t* d_ids64, const int32_t* d_ids32, int n, int pad_sem) {
+  if (n <= 0) return MV_OK;
+  hipLaunchKernelGGL(cand_prepare_kernel, dim3((unsigned)((n + kRerankBatch - 1) / kRerankBatch)), dim3(kRerankBatch), 0, ix->stream,
+                     d_ids64, d_ids32, n, (const int32_t*)ix->d_n_rows, ix->cfg.stride_rows, pad_sem, ix->d_cand, ix->d_cand_pads);
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
 int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_words, const int32_t* d_cand, int64_t n_items,
-               int32_t pad_to, float* d_out, int* launches) {
-  const bool need_meta = ix->tombstones || d_allow != nullptr;
+               int32_t pad_to, const int32_t* d_pad_items, float* d_out, int* launches, bool no_mask = false) {
+  if (n_items <= 0) return MV_OK;  // nothing to launch (a grid of 0 blocks is an invalid configuration)
+  const bool need_meta = !no_mask && (ix->tombstones.load() || d_allow != nullptr);
+  const bool ragged = ix->ragged.load();
   const int padded = ((n_q + 15) / 16) * 16;
   int done = 0, pass = 0;
   // A long query (> 64 rows) over the whole slab goes through the row-split workgroup of the batched scan (4 waves
   // share the page tiles in LDS, each holds a quarter of the query rows) as ONE query of up to 512 rows: the
   // page-split kernel below keeps all query rows in every wave and falls off the HBM roof past 64 rows
   // (400 k pages: 128 rows 19.2 -> 16.0 ms, 256 rows 38.3 -> 22.7 ms).
-  if (!d_cand && pad_to == 0 && padded > 64 && ix->long_query_variant == 1) {
+  if (!d_cand && pad_to == 0 && !d_pad_items && padded > 64 && ix->long_query_variant == 1) {
     if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)512 * kRowBytes));
     while (done < padded) {
       const int left = padded - done;
@@ -278,7 +228,7 @@ int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_w
       MV_HIP(hipMemsetAsync(ix->d_bq, 0, (size_t)512 * kRowBytes, ix->stream));
       MV_HIP(hipMemcpyAsync(ix->d_bq, ix->d_q + (size_t)done * kDim, (size_t)rows * kRowBytes, hipMemcpyDeviceToDevice, ix->stream));
       BatchArgs b{};
-      b.slab = ix->slab; b.n_rows = ix->ragged ? ix->d_n_rows : nullptr; b.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
+      b.slab = ix->slab; b.n_rows = ragged ? ix->d_n_rows : nullptr; b.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
       b.allow = d_allow; b.n_allow_bits = n_allow_words * 32; b.allow_stride_bits = 0;
       b.q = ix->d_bq; b.scores = pass == 0 ? d_out : ix->d_scores2; b.n = n_items; b.score_stride = n_items;
       b.stride = ix->cfg.stride_rows; b.n_queries = 1; b.rows_per_query = rows; b.variant = rows <= 384 ? 2 : 0;
@@ -291,13 +241,14 @@ int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_w
       done += rows;
       ++pass;
     }
+    MV_HIP(hipGetLastError());
     return MV_OK;
   }
   while (done < padded) {
     const int rows = std::min(padded - done, kMaxQRowsPerPass);
     MaxsimArgs a{};
     a.slab = ix->slab;
-    a.n_rows = ix->ragged ? ix->d_n_rows : nullptr;
+    a.n_rows = ragged ? ix->d_n_rows : nullptr;
     a.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
     a.allow = d_allow;
     a.n_allow_bits = n_allow_words * 32;
@@ -308,37 +259,68 @@ int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_w
     a.stride = ix->cfg.stride_rows;
     a.q_tiles = rows / 16;
     a.pad_to = pad_to;
+    a.pad_items = d_pad_items;
     int rc = launch_maxsim_bf16(a, ix->maxsim_variant, ix->stream);
     if (rc) return rc;
     ++*launches;
     if (pass > 0) {
+      // -inf (masked item / padding entry) + anything stays -inf
       hipLaunchKernelGGL(add_scores_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, ix->stream, d_out,
                          (const float*)ix->d_scores2, n_items);
     }
     done += rows;
     ++pass;
   }
+  MV_HIP(hipGetLastError());
   return MV_OK;
 }
 
 // Exact float MaxSim over the e4m3 slab (all query rows in passes of 64 inside the launcher).
 int fp8_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_words, const int32_t* d_cand, int64_t n_items,
-             int32_t pad_to, float* d_out, int* launches) {
-  const bool need_meta = ix->tombstones || d_allow != nullptr;
+             int32_t pad_to, const int32_t* d_pad_items, float* d_out, int* launches, bool no_mask = false) {
+  if (n_items <= 0) return MV_OK;
+  const bool need_meta = !no_mask && (ix->tombstones.load() || d_allow != nullptr);
   Fp8ScanArgs a{};
   a.slab = ix->slab8; a.inv_scale = ix->inv_scale8;
-  a.n_rows = ix->ragged ? ix->d_n_rows : nullptr;
+  a.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr;
   a.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
   a.allow = d_allow; a.n_allow_bits = n_allow_words * 32; a.cand = d_cand;
   a.qhi = ix->d_q8hi; a.qlo = ix->d_q8lo; a.qfac = ix->d_q8fac; a.n_q = n_q;
-  a.scores = d_out; a.n = n_items; a.stride = ix->cfg.stride_rows; a.pad_to = pad_to;
+  a.scores = d_out; a.n = n_items; a.stride = ix->cfg.stride_rows; a.pad_to = pad_to; a.pad_items = d_pad_items;
   int rc = launch_maxsim_fp8(a, ix->stream);
   if (rc) return rc;
   *launches += (((n_q + 15) / 16) * 16 + 63) / 64;
   return MV_OK;
 }
 
-// Core of every query entry point: leaves per-item scores on the device.
+// FDE coarse stage: encode the query already uploaded to d_qf32 (SUM aggregation) and scan the FDE slab -> d_scores[n].
+int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_words, int64_t n, int* launches) {
+  const bool need_meta = ix->tombstones.load() || d_allow != nullptr;
+  const int64_t off[2] = {0, n_q};
+  MV_HIP(hipMemcpyAsync(ix->d_qoff, off, sizeof(off), hipMemcpyHostToDevice, ix->stream));
+  FdeEncodeArgs e{};
+  e.variant = ix->fde_encode_variant;
+  e.x_f32 = ix->d_qf32; e.row_offsets = ix->d_qoff; e.n_pages = 1; e.is_query = 1; e.out_f32 = ix->d_qfde;
+  int rc = launch_fde_encode(ix->fde_t, e, ix->stream);
+  if (rc) return rc;
+  FdeScanArgs s{};
+  s.fde = ix->fde; s.inv_norm = ix->fde_cosine ? ix->fde_inv_norm : nullptr; s.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
+  s.allow = d_allow; s.n_allow_bits = n_words * 32; s.q = ix->d_qfde; s.scores = ix->d_scores; s.n = n;
+  s.out_dim = ix->fde_t.out_dim;
+  rc = launch_fde_scan(s, ix->fde_scan_variant, ix->stream);
+  if (rc) return rc;
+  *launches += 2;
+  return MV_OK;
+}
+
+// Exact rerank of the candidate list in d_cand / d_cand_pads (built by launch_cand_prepare or the owned-select kernel).
+// The candidates were named explicitly or chosen from live, allowed pages: no mask is applied.
+int rerank_scan(mv_index* ix, int n_q, bool use_fp8, int64_t n_items, float* d_out, int* launches) {
+  return use_fp8 ? fp8_scan(ix, n_q, nullptr, 0, ix->d_cand, n_items, 0, ix->d_cand_pads, d_out, launches, /*no_mask=*/true)
+                 : float_scan(ix, n_q, nullptr, 0, ix->d_cand, n_items, 0, ix->d_cand_pads, d_out, launches, /*no_mask=*/true);
+}
+
+// Core of every query entry point: leaves per-item scores on the device.  Caller holds q_mu.
 int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const uint32_t* allow_bits, int64_t n_words,
              int64_t want_coarse, ScanResult* out, mv_query_stats* st, bool want_compact = false) {
   if (!q || n_q <= 0) { set_error("query must have at least one row"); return MV_ERR_INVALID; }
@@ -355,13 +337,15 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
   if (want_bin && !(ix->cfg.flags & MV_WITH_BINARY)) { set_error("index has no sign-bit slab (MV_WITH_BINARY)"); return MV_ERR_STATE; }
   if (want_fde && !(ix->cfg.flags & MV_WITH_FDE)) { set_error("index has no FDE slab (MV_WITH_FDE)"); return MV_ERR_STATE; }
 
+  // snapshot of the published corpus: pages appended while this query runs are not seen
+  const int64_t n = ix->size.load(std::memory_order_acquire);
+  const bool ragged = ix->ragged.load();
   int rc = upload_query(ix, q, q_dtype, n_q, want_float, want_fde, want_bin, want_fp8);
   if (rc) return rc;
   const uint32_t* d_allow = nullptr;
   rc = upload_allow(ix, allow_bits, n_words, &d_allow);
   if (rc) return rc;
-  const bool need_meta = ix->tombstones || d_allow != nullptr;
-  const int64_t n = ix->size;
+  const bool need_meta = ix->tombstones.load() || d_allow != nullptr;
   int64_t pages = 0, rows = 0;  // accounting only (filled below, once it is known whether the filter was compacted)
 
   MV_HIP(hipEventRecord(ix->ev[0], ix->stream));
@@ -369,10 +353,11 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
   // Selective doc filter on a top-k scan: compact the allowed pages (in page order) and scan only those.
   const int32_t* d_scan_cand = nullptr;
   int64_t n_scan = n;
-  if (want_compact && d_allow && (mode == MV_MODE_FLOAT || mode == MV_MODE_FLOAT_FP8 || mode == MV_MODE_BINARY) && ix->filter_compact_pct > 0 && ix->max_doc_ord >= 0) {
+  const int32_t max_ord = ix->max_doc_ord.load();
+  if (want_compact && d_allow && (mode == MV_MODE_FLOAT || mode == MV_MODE_FLOAT_FP8 || mode == MV_MODE_BINARY) && ix->filter_compact_pct > 0 && max_ord >= 0) {
     int64_t allowed_docs = 0;
     for (int64_t w = 0; w < n_words; ++w) allowed_docs += __builtin_popcount(allow_bits[w]);
-    if (allowed_docs * 100 < (int64_t)ix->filter_compact_pct * ((int64_t)ix->max_doc_ord + 1)) {
+    if (allowed_docs * 100 < (int64_t)ix->filter_compact_pct * ((int64_t)max_ord + 1)) {
       if (!ix->d_fcand) {
         MV_HIP(hipMalloc(&ix->d_fcand, (size_t)ix->cfg.capacity_pages * 4));
         MV_HIP(hipMalloc(&ix->d_fcounts, filter_ws_bytes(ix->cfg.capacity_pages)));
@@ -384,85 +369,62 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
     }
   }
   if (st) {
-    if (d_scan_cand && !ix->ragged) { pages = n_scan; rows = n_scan * (int64_t)ix->cfg.stride_rows; }  // the device already counted
-    else rows = count_allowed_rows(ix, allow_bits, n_words, &pages);
+    if (d_scan_cand && !ragged) { pages = n_scan; rows = n_scan * (int64_t)ix->cfg.stride_rows; }  // the device already counted
+    else rows = count_allowed_rows(ix, n, allow_bits, n_words, &pages);
   }
   if (mode == MV_MODE_FLOAT) {
-    rc = d_scan_cand ? float_scan(ix, n_q, nullptr, 0, d_scan_cand, n_scan, 0, ix->d_scores, &out->launches)
-                     : float_scan(ix, n_q, d_allow, n_words, nullptr, n, 0 /* full scan: no padding rows exist */, ix->d_scores, &out->launches);
+    rc = d_scan_cand ? float_scan(ix, n_q, nullptr, 0, d_scan_cand, n_scan, 0, nullptr, ix->d_scores, &out->launches, true)
+                     : float_scan(ix, n_q, d_allow, n_words, nullptr, n, 0 /* full scan: no padding rows exist */, nullptr, ix->d_scores, &out->launches);
     if (rc) return rc;
     out->d_scores = ix->d_scores; out->n = n_scan; out->d_ids_map = d_scan_cand;
     out->pages = pages; out->bytes = rows * (int64_t)kRowBytes;
   } else if (mode == MV_MODE_FLOAT_FP8) {
-    rc = d_scan_cand ? fp8_scan(ix, n_q, nullptr, 0, d_scan_cand, n_scan, 0, ix->d_scores, &out->launches)
-                     : fp8_scan(ix, n_q, d_allow, n_words, nullptr, n, 0, ix->d_scores, &out->launches);
+    rc = d_scan_cand ? fp8_scan(ix, n_q, nullptr, 0, d_scan_cand, n_scan, 0, nullptr, ix->d_scores, &out->launches, true)
+                     : fp8_scan(ix, n_q, d_allow, n_words, nullptr, n, 0, nullptr, ix->d_scores, &out->launches);
     if (rc) return rc;
     out->d_scores = ix->d_scores; out->n = n_scan; out->d_ids_map = d_scan_cand;
     out->pages = pages; out->bytes = rows * (int64_t)kDim;
   } else if (mode == MV_MODE_BINARY) {
     BinaryArgs b{};
-    b.bits = ix->bits; b.n_rows = ix->ragged ? ix->d_n_rows : nullptr;
+    b.bits = ix->bits; b.n_rows = ragged ? ix->d_n_rows : nullptr;
     // compacted filter: the list holds only live, allowed pages -- no per-page mask test left to do
     b.doc_ord = (need_meta && !d_scan_cand) ? ix->d_doc_ord : nullptr;
     b.allow = d_scan_cand ? nullptr : d_allow; b.n_allow_bits = n_words * 32;
     b.qbits = ix->d_qbits; b.qpop_rw = ix->d_qpop; b.qpop = ix->d_qpop; b.scores = ix->d_scores;
     b.n = n_scan; b.cand = d_scan_cand;
     b.stride = ix->cfg.stride_rows; b.n_q = n_q;
-    rc = launch_maxsim_binary(b, ix->binary_variant, ix->stream);
-    if (rc) return rc;
+    if (n_scan > 0) {
+      rc = launch_maxsim_binary(b, ix->binary_variant, ix->stream);
+      if (rc) return rc;
+    }
     out->launches += 1;
     out->d_scores = ix->d_scores; out->n = n_scan; out->d_ids_map = d_scan_cand;
     out->pages = pages; out->bytes = rows * (int64_t)kSignBytes;
   } else {
     // FDE: encode the query (SUM), scan the FDE slab
-    const int64_t off[2] = {0, n_q};
-    MV_HIP(hipMemcpyAsync(ix->d_qoff, off, sizeof(off), hipMemcpyHostToDevice, ix->stream));
-    FdeEncodeArgs e{};
-    e.variant = ix->fde_encode_variant;
-    e.x_f32 = ix->d_qf32; e.row_offsets = ix->d_qoff; e.n_pages = 1; e.is_query = 1; e.out_f32 = ix->d_qfde;
-    rc = launch_fde_encode(ix->fde_t, e, ix->stream);
+    rc = fde_coarse_scan(ix, n_q, d_allow, n_words, n, &out->launches);
     if (rc) return rc;
-    FdeScanArgs s{};
-    s.fde = ix->fde; s.inv_norm = ix->fde_cosine ? ix->fde_inv_norm : nullptr; s.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
-    s.allow = d_allow; s.n_allow_bits = n_words * 32; s.q = ix->d_qfde; s.scores = ix->d_scores; s.n = n;
-    s.out_dim = ix->fde_t.out_dim;
-    rc = launch_fde_scan(s, ix->fde_scan_variant, ix->stream);
-    if (rc) return rc;
-    out->launches = 2;
     out->pages = pages; out->bytes = pages * ix->fde_t.out_dim * 2;
     if (mode == MV_MODE_FDE_ONLY) {
       out->d_scores = ix->d_scores; out->n = n; out->d_ids_map = nullptr;
     } else {
-      // coarse top-n -> candidate list -> exact rerank
+      // coarse top-n -> candidate list -> exact rerank, all in stream order: the selection kernels leave the n local
+      // page ids on the device, cand_prepare turns them into the rerank list + per-batch pad lengths, the rerank
+      // kernel skips the (-1) padding entries.  No host round trip between the stages.
       int64_t nc = std::min<int64_t>(std::min<int64_t>(want_coarse, n), kTopkMaxDeviceK);
       if (nc < 1) nc = 1;
       rc = launch_topk(ix->d_scores, n, (int32_t)nc, nullptr, 0, ix->d_topk_ws, ix->d_out_s, ix->d_out_id, ix->stream);
       if (rc) return rc;
-      std::vector<int64_t> cand64((size_t)nc);
-      MV_HIP(hipMemcpyAsync(cand64.data(), ix->d_out_id, (size_t)nc * 8, hipMemcpyDeviceToHost, ix->stream));
-      MV_HIP(hipStreamSynchronize(ix->stream));
-      std::vector<int32_t> cand;
-      int32_t longest = 0;
-      int64_t cand_rows = 0;
-      for (int64_t i = 0; i < nc; ++i)
-        if (cand64[i] >= 0) {
-          cand.push_back((int32_t)cand64[i]);
-          longest = std::max(longest, ix->h_n_rows[cand64[i]]);
-          cand_rows += ix->h_n_rows[cand64[i]];
-        }
-      out->n = (int64_t)cand.size();
+      // reference rule: pad_sequence over each rerank batch (<= 128 pages): shorter pages see zero rows
+      const int pad_sem = ix->pad_semantics < 0 ? 1 : ix->pad_semantics;
+      rc = launch_cand_prepare(ix, ix->d_out_id, nullptr, (int)nc, pad_sem);
+      if (rc) return rc;
+      rc = rerank_scan(ix, n_q, rerank_fp8, nc, ix->d_cand_scores, &out->launches);
+      if (rc) return rc;
+      out->launches += 1;
+      out->n = nc;
       out->d_ids_map = ix->d_cand;
       out->d_scores = ix->d_cand_scores;
-      if (!cand.empty()) {
-        MV_HIP(hipMemcpyAsync(ix->d_cand, cand.data(), cand.size() * 4, hipMemcpyHostToDevice, ix->stream));
-        // reference rule: pad_sequence over the rerank batch (<=128 pages): shorter pages see zero rows
-        const int pad_sem = ix->pad_semantics < 0 ? 1 : ix->pad_semantics;
-        rc = rerank_fp8 ? fp8_scan(ix, n_q, nullptr, 0, ix->d_cand, out->n, pad_sem ? longest : 0, ix->d_cand_scores, &out->launches)
-                        : float_scan(ix, n_q, nullptr, 0, ix->d_cand, out->n, pad_sem ? longest : 0, ix->d_cand_scores, &out->launches);
-        if (rc) return rc;
-        MV_HIP(hipStreamSynchronize(ix->stream));  // cand goes out of scope
-      }
-      out->bytes += cand_rows * (int64_t)(rerank_fp8 ? kDim : kRowBytes);
     }
   }
   MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
@@ -471,6 +433,8 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
     st->score_launches = out->launches;
     st->pages_scored = out->pages;
     st->bytes_scanned = out->bytes;
+    // FDE_THEN_FLOAT: the candidates' rows are added by finish_stats (read back behind the timed span)
+    if (mode == MV_MODE_FDE_THEN_FLOAT) st->reserved = (int32_t)out->n | (rerank_fp8 ? (1 << 30) : 0);
   }
   return MV_OK;
 }
@@ -478,6 +442,17 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
 int finish_stats(mv_index* ix, mv_query_stats* st, bool had_topk) {
   if (!st) return MV_OK;
   MV_HIP(hipEventSynchronize(ix->ev[had_topk ? 2 : 1]));
+  if (st->reserved) {  // accounting of the rerank stage: rows of the candidates actually read
+    const int nc = st->reserved & 0xffff;
+    const bool f8 = (st->reserved >> 30) & 1;
+    st->reserved = 0;
+    MV_HIP(hipMemcpyAsync(ix->h_cand, ix->d_cand, (size_t)nc * 4, hipMemcpyDeviceToHost, ix->stream));
+    MV_HIP(hipStreamSynchronize(ix->stream));
+    int64_t cand_rows = 0;
+    for (int i = 0; i < nc; ++i)
+      if (ix->h_cand[i] >= 0) cand_rows += ix->h_n_rows[ix->h_cand[i]];
+    st->bytes_scanned += cand_rows * (int64_t)(f8 ? kDim : kRowBytes);
+  }
   MV_HIP(hipEventElapsedTime(&st->score_kernel_ms, ix->ev[0], ix->ev[1]));
   if (had_topk) {
     MV_HIP(hipEventElapsedTime(&st->topk_ms, ix->ev[1], ix->ev[2]));
@@ -511,105 +486,115 @@ void host_topk(const std::vector<float>& s, const std::vector<int32_t>* ids_map,
   for (size_t i = 0; i < kk; ++i) { (*os)[i] = v[i].first; (*oi)[i] = id_base + v[i].second; }
 }
 
-int add_pages_common(mv_index* ix, const void* d_src, int dtype, const int32_t* n_rows, int64_t n_pages,
-                     const int32_t* doc_ordinals, int64_t total_rows, int64_t* out_first) {
-  // d_src: device rows [total_rows][128] of dtype; scatter into the slab and derive the other slabs.
-  const int64_t first = ix->size;
-  std::vector<int64_t> off((size_t)n_pages + 1);
-  off[0] = 0;
-  for (int64_t i = 0; i < n_pages; ++i) off[i + 1] = off[i] + n_rows[i];
-  int64_t* d_off = nullptr;
-  MV_HIP(hipMalloc(&d_off, off.size() * 8));
-  int rc = MV_OK;
-  do {
-    if (hipMemcpyAsync(d_off, off.data(), off.size() * 8, hipMemcpyHostToDevice, ix->stream) != hipSuccess) { rc = MV_ERR_HIP; set_error("H2D of row offsets failed"); break; }
-    const int32_t stride = ix->cfg.stride_rows;
-    uint16_t* slab_dst = nullptr;
-    uint16_t* tmp_slab = nullptr;
-    if (ix->cfg.flags & MV_WITH_FLOAT) {
-      slab_dst = ix->slab + (size_t)first * stride * kDim;
-    } else {
-      // no float slab kept: still need fixed-stride bf16 rows as the source of the sign bits
-      if (hipMalloc(&tmp_slab, (size_t)n_pages * stride * kRowBytes) != hipSuccess) { rc = MV_ERR_NOMEM; set_error("out of device memory staging %lld pages", (long long)n_pages); break; }
-      slab_dst = tmp_slab;
-    }
-    rc = launch_scatter_rows(d_src, dtype, d_off, n_pages, stride, slab_dst, ix->stream);
-    if (!rc && (ix->cfg.flags & MV_WITH_BINARY)) {
-      // sign bits come from the bf16 image: bf16 RNE preserves sign and zero-ness of every fp32 value
-      // that is not an fp32 subnormal rounding to zero; fp32 inputs are packed from the fp32 rows below.
-      uint8_t* bdst = ix->bits + (size_t)first * stride * kSignBytes;
-      if (dtype == MV_BF16) {
-        rc = launch_sign_pack_bf16_rows(slab_dst, n_pages * (int64_t)stride, bdst, ix->stream);
-      } else {
-        // exact fp32 rule (v > 0.0f): pack the ragged fp32 rows, then scatter 16-byte rows
-        uint8_t* tmp_bits = nullptr;
-        if (hipMalloc(&tmp_bits, (size_t)std::max<int64_t>(total_rows, 1) * kSignBytes) != hipSuccess) { rc = MV_ERR_NOMEM; set_error("out of device memory"); }
-        if (!rc) rc = launch_sign_pack_f32((const float*)d_src, total_rows, kDim, tmp_bits, ix->stream);
-        if (!rc) {
-          (void)hipMemsetAsync(bdst, 0, (size_t)n_pages * stride * kSignBytes, ix->stream);
-          for (int64_t i = 0; i < n_pages && !rc; ++i)
-            if (n_rows[i] > 0 && hipMemcpyAsync(bdst + (size_t)i * stride * kSignBytes, tmp_bits + (size_t)off[i] * kSignBytes,
-                                                (size_t)n_rows[i] * kSignBytes, hipMemcpyDeviceToDevice, ix->stream) != hipSuccess) {
-              rc = MV_ERR_HIP; set_error("D2D of sign rows failed");
-            }
-        }
-        (void)hipStreamSynchronize(ix->stream);
-        if (tmp_bits) (void)hipFree(tmp_bits);
-      }
-    }
-    if (!rc && (ix->cfg.flags & MV_WITH_FDE)) {
-      FdeEncodeArgs e{};
-      e.variant = ix->fde_encode_variant;
-      int32_t* d_nr = nullptr;
-      if (dtype == MV_F32) {
-        e.x_f32 = (const float*)d_src; e.row_offsets = d_off;
-      } else {
-        if (hipMalloc(&d_nr, (size_t)n_pages * 4) != hipSuccess) { rc = MV_ERR_NOMEM; set_error("out of device memory"); }
-        if (!rc) (void)hipMemcpyAsync(d_nr, n_rows, (size_t)n_pages * 4, hipMemcpyHostToDevice, ix->stream);
-        e.x_bf16 = slab_dst; e.n_rows = d_nr; e.stride = stride;
-      }
-      e.n_pages = n_pages; e.is_query = 0;
-      e.out_bf16 = ix->fde + (size_t)first * ix->fde_t.out_dim;
-      e.out_inv_norm = ix->fde_inv_norm + first;
-      if (!rc) rc = launch_fde_encode(ix->fde_t, e, ix->stream);
-      (void)hipStreamSynchronize(ix->stream);
-      if (d_nr) (void)hipFree(d_nr);
-    }
-    if (!rc && (ix->cfg.flags & MV_WITH_FP8)) {
-      int32_t* d_nr8 = nullptr;
-      if (hipMalloc(&d_nr8, (size_t)n_pages * 4) != hipSuccess) { rc = MV_ERR_NOMEM; set_error("out of device memory"); }
-      if (!rc) (void)hipMemcpyAsync(d_nr8, n_rows, (size_t)n_pages * 4, hipMemcpyHostToDevice, ix->stream);
-      if (!rc) rc = launch_quantize_pages_fp8(slab_dst, d_nr8, stride, n_pages, ix->slab8 + (size_t)first * stride * kDim,
-                                              ix->inv_scale8 + first, ix->stream);
-      (void)hipStreamSynchronize(ix->stream);
-      if (d_nr8) (void)hipFree(d_nr8);
-    }
-    (void)hipStreamSynchronize(ix->stream);
-    if (tmp_slab) (void)hipFree(tmp_slab);
-  } while (0);
-  (void)hipStreamSynchronize(ix->stream);
-  (void)hipFree(d_off);
-  if (rc) return rc;
-  // metadata
-  for (int64_t i = 0; i < n_pages; ++i) {
-    ix->h_n_rows[first + i] = n_rows[i];
-    ix->h_doc_ord[first + i] = doc_ordinals ? doc_ordinals[i] : 0;
-    ix->max_doc_ord = std::max(ix->max_doc_ord, ix->h_doc_ord[first + i]);
-    if (n_rows[i] != ix->cfg.stride_rows) ix->ragged = true;
-    if (doc_ordinals && doc_ordinals[i] < 0) ix->tombstones = true;
-  }
-  MV_HIP(hipMemcpy(ix->d_n_rows + first, ix->h_n_rows.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice));
-  MV_HIP(hipMemcpy(ix->d_doc_ord + first, ix->h_doc_ord.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice));
-  ix->size += n_pages;
-  if (out_first) *out_first = first;
+// Writer-side scratch (w_mu held): grown on demand and kept -- hipFree synchronises the whole device, which would stall
+// the scans an ingest is supposed to run beside, so it only happens when a buffer has to grow.
+int w_reserve(void** p, size_t* cap, size_t need) {
+  if (need <= *cap) return MV_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr; *cap = 0;
+  const size_t want = std::max<size_t>(need, 4096);
+  hipError_t e = hipMalloc(p, want);
+  if (e != hipSuccess) { *p = nullptr; set_error("out of device memory for %zu bytes of ingest staging", want); return MV_ERR_NOMEM; }
+  *cap = want;
   return MV_OK;
 }
 
+// Fill slab slots [first, first + n_pages) from device rows d_src ([total_rows][128] of dtype) on the writer stream.
+// The slots are beyond the published size: no query can see them until the caller publishes.  Caller holds w_mu.
+int add_pages_common(mv_index* ix, const void* d_src, int dtype, const int32_t* n_rows, int64_t n_pages,
+                     const int32_t* doc_ordinals, int64_t total_rows, int64_t first) {
+  hipStream_t ws = ix->w_stream;
+  const int32_t stride = ix->cfg.stride_rows;
+  std::vector<int64_t> off((size_t)n_pages + 1);
+  off[0] = 0;
+  for (int64_t i = 0; i < n_pages; ++i) off[i + 1] = off[i] + n_rows[i];
+  // host + device metadata of the new slots first: the derive kernels read the device row counts
+  for (int64_t i = 0; i < n_pages; ++i) {
+    ix->h_n_rows[first + i] = n_rows[i];
+    ix->h_doc_ord[first + i] = doc_ordinals ? doc_ordinals[i] : 0;
+  }
+  MV_HIP(hipMemcpyAsync(ix->d_n_rows + first, ix->h_n_rows.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice, ws));
+  MV_HIP(hipMemcpyAsync(ix->d_doc_ord + first, ix->h_doc_ord.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice, ws));
+  const bool f32_bits = (ix->cfg.flags & MV_WITH_BINARY) && dtype == MV_F32;
+  const size_t off_bytes = ((off.size() * 8 + 255) / 256) * 256;
+  int rc = w_reserve(&ix->w_aux, &ix->w_aux_bytes, off_bytes + (f32_bits ? (size_t)std::max<int64_t>(total_rows, 1) * kSignBytes : 0));
+  if (rc) return rc;
+  int64_t* d_off = (int64_t*)ix->w_aux;
+  uint8_t* tmp_bits = (uint8_t*)ix->w_aux + off_bytes;
+  MV_HIP(hipMemcpyAsync(d_off, off.data(), off.size() * 8, hipMemcpyHostToDevice, ws));
+  uint16_t* slab_dst = nullptr;
+  if (ix->cfg.flags & MV_WITH_FLOAT) {
+    slab_dst = ix->slab + (size_t)first * stride * kDim;
+  } else {
+    // no float slab kept: still need fixed-stride bf16 rows as the source of the other slabs
+    rc = w_reserve(&ix->w_tmp, &ix->w_tmp_bytes, (size_t)n_pages * stride * kRowBytes);
+    if (rc) return rc;
+    slab_dst = (uint16_t*)ix->w_tmp;
+  }
+  rc = launch_scatter_rows(d_src, dtype, d_off, n_pages, stride, slab_dst, ws);
+  if (!rc && (ix->cfg.flags & MV_WITH_BINARY)) {
+    // sign bits come from the bf16 image: bf16 RNE preserves sign and zero-ness of every fp32 value
+    // that is not an fp32 subnormal rounding to zero; fp32 inputs are packed from the fp32 rows below.
+    uint8_t* bdst = ix->bits + (size_t)first * stride * kSignBytes;
+    if (dtype == MV_BF16) {
+      rc = launch_sign_pack_bf16_rows(slab_dst, n_pages * (int64_t)stride, bdst, ws);
+    } else {
+      // exact fp32 rule (v > 0.0f): pack the ragged fp32 rows, then scatter 16-byte rows
+      rc = launch_sign_pack_f32((const float*)d_src, total_rows, kDim, tmp_bits, ws);
+      if (!rc) {
+        (void)hipMemsetAsync(bdst, 0, (size_t)n_pages * stride * kSignBytes, ws);
+        for (int64_t i = 0; i < n_pages && !rc; ++i)
+          if (n_rows[i] > 0 && hipMemcpyAsync(bdst + (size_t)i * stride * kSignBytes, tmp_bits + (size_t)off[i] * kSignBytes,
+                                              (size_t)n_rows[i] * kSignBytes, hipMemcpyDeviceToDevice, ws) != hipSuccess) {
+            rc = MV_ERR_HIP; set_error("D2D of sign rows failed");
+          }
+      }
+    }
+  }
+  if (!rc && (ix->cfg.flags & MV_WITH_FDE)) {
+    FdeEncodeArgs e{};
+    e.variant = ix->fde_encode_variant;
+    if (dtype == MV_F32) {
+      e.x_f32 = (const float*)d_src; e.row_offsets = d_off;
+    } else {
+      e.x_bf16 = slab_dst; e.n_rows = ix->d_n_rows + first; e.stride = stride;
+    }
+    e.n_pages = n_pages; e.is_query = 0;
+    e.out_bf16 = ix->fde + (size_t)first * ix->fde_t.out_dim;
+    e.out_inv_norm = ix->fde_inv_norm + first;
+    rc = launch_fde_encode(ix->fde_t, e, ws);
+  }
+  if (!rc && (ix->cfg.flags & MV_WITH_FP8))
+    rc = launch_quantize_pages_fp8(slab_dst, ix->d_n_rows + first, stride, n_pages, ix->slab8 + (size_t)first * stride * kDim,
+                                   ix->inv_scale8 + first, ws);
+  hipError_t e = hipStreamSynchronize(ws);  // the staging buffers are reused by the next chunk; the caller publishes after this
+  if (rc) return rc;
+  if (e != hipSuccess) return hip_fail(e, "ingest", __FILE__, __LINE__);
+  return MV_OK;
+}
+
+// Make pages [first, first + n) visible to queries: flags first, then the size (release).  Caller holds w_mu.
+void publish_pages(mv_index* ix, int64_t first, int64_t n) {
+  int32_t mo = ix->max_doc_ord.load();
+  bool rag = false, tomb = false;
+  for (int64_t i = first; i < first + n; ++i) {
+    mo = std::max(mo, ix->h_doc_ord[i]);
+    rag = rag || ix->h_n_rows[i] != ix->cfg.stride_rows;
+    tomb = tomb || ix->h_doc_ord[i] < 0;
+  }
+  ix->max_doc_ord.store(mo);
+  if (rag) ix->ragged.store(true);
+  if (tomb) ix->tombstones.store(true);
+  ix->size.store(first + n, std::memory_order_release);
+}
+
+// Caller holds w_mu (the capacity check must see the size no other writer can move).
 int validate_add(mv_index* ix, const void* emb, int dtype, const int32_t* n_rows, int64_t n_pages, int64_t* total_rows) {
   if (!ix || (!emb && n_pages > 0) || (!n_rows && n_pages > 0) || n_pages < 0) { set_error("mv_index_add: null argument"); return MV_ERR_INVALID; }
   if (dtype != MV_F32 && dtype != MV_BF16) { set_error("mv_index_add: bad dtype %d", dtype); return MV_ERR_INVALID; }
-  if (ix->size + n_pages > ix->cfg.capacity_pages) {
-    set_error("slab full: %lld + %lld > capacity %lld", (long long)ix->size, (long long)n_pages, (long long)ix->cfg.capacity_pages);
+  const int64_t size = ix->size.load();
+  if (size + n_pages > ix->cfg.capacity_pages) {
+    set_error("slab full: %lld + %lld > capacity %lld", (long long)size, (long long)n_pages, (long long)ix->cfg.capacity_pages);
     return MV_ERR_CAPACITY;
   }
   int64_t t = 0;
@@ -624,7 +609,13 @@ int validate_add(mv_index* ix, const void* emb, int dtype, const int32_t* n_rows
   return MV_OK;
 }
 
-}  // namespace
+// Operations that move or rewrite PUBLISHED pages exclude writers and queries (lock order: w_mu, then q_mu).
+struct ExclusiveLock {
+  std::lock_guard<std::mutex> w, q;
+  explicit ExclusiveLock(mv_index* ix) : w(ix->w_mu), q(ix->q_mu) {}
+};
+
+}  // namespace mv
 
 // =================================================================================== C ABI
 extern "C" {
@@ -642,7 +633,8 @@ void mv_index_destroy(mv_index* ix) {
   if (!ix) return;
   DeviceGuard g(ix->cfg.device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-  void* ptrs[] = {ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
+  if (ix->w_stream) (void)hipStreamSynchronize(ix->w_stream);
+  void* ptrs[] = {ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
                   ix->d_topk_ws, ix->d_q, ix->d_qf32, ix->d_qbits, ix->d_qpop, ix->d_qfde, ix->d_qoff, ix->d_allow, ix->d_out_s,
                   ix->d_out_id, ix->d_cand, ix->d_cand_scores};
   for (void* p : ptrs)
@@ -651,9 +643,10 @@ void mv_index_destroy(mv_index* ix) {
   for (auto& e : ix->ev)
     if (e) (void)hipEventDestroy(e);
   if (ix->ev_stage) (void)hipEventDestroy(ix->ev_stage);
-  for (void* hp : {(void*)ix->h_qf32, (void*)ix->h_qbf16, (void*)ix->h_out_s, (void*)ix->h_out_id})
+  for (void* hp : {(void*)ix->h_qf32, (void*)ix->h_qbf16, (void*)ix->h_out_s, (void*)ix->h_out_id, (void*)ix->h_cand})
     if (hp) (void)hipHostFree(hp);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
+  if (ix->w_stream) (void)hipStreamDestroy(ix->w_stream);
   delete ix;
 }
 
@@ -683,12 +676,14 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
       *p = nullptr;
     }
   };
-  if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); rc = MV_ERR_HIP; }
+  if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ix->w_stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); rc = MV_ERR_HIP; }
   for (auto& e : ix->ev)
     if (!rc && hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); rc = MV_ERR_HIP; }
   if (!rc && hipEventCreateWithFlags(&ix->ev_stage, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); rc = MV_ERR_HIP; }
   if (!rc && (hipHostMalloc((void**)&ix->h_out_s, (size_t)kTopkMaxDeviceK * 4, hipHostMallocDefault) != hipSuccess ||
-              hipHostMalloc((void**)&ix->h_out_id, (size_t)kTopkMaxDeviceK * 8, hipHostMallocDefault) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = MV_ERR_NOMEM; }
+              hipHostMalloc((void**)&ix->h_out_id, (size_t)kTopkMaxDeviceK * 8, hipHostMallocDefault) != hipSuccess ||
+              hipHostMalloc((void**)&ix->h_cand, (size_t)kTopkMaxDeviceK * 4, hipHostMallocDefault) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = MV_ERR_NOMEM; }
   if (cfg->flags & MV_WITH_FLOAT) alloc((void**)&ix->slab, rows * kRowBytes + 32768, "bf16 page slab");  // +32 KiB: the batched scans DMA whole 16 / 32 KiB chunks
   if (cfg->flags & MV_WITH_FP8) {
     alloc((void**)&ix->slab8, rows * kDim + 4096, "fp8 page slab");  // +4 KiB: the scan DMAs whole 4 KiB pieces
@@ -705,12 +700,15 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   alloc((void**)&ix->d_doc_ord, (size_t)cap * 4, "doc ordinals");
   alloc((void**)&ix->d_scores, (size_t)cap * 4, "scores");
   alloc((void**)&ix->d_scores2, (size_t)cap * 4, "scores2");
-  ix->topk_ws_bytes = topk_ws_bytes(cap, kTopkMaxDeviceK);
+  ix->topk_ws_bytes = topk_ws_bytes(std::max<int64_t>(cap, 16384), kTopkMaxDeviceK);  // >= the gathered list of a two-stage rerank
   alloc(&ix->d_topk_ws, ix->topk_ws_bytes, "top-k workspace");
   alloc((void**)&ix->d_out_s, (size_t)kTopkMaxDeviceK * 4, "top-k scores");
   alloc((void**)&ix->d_out_id, (size_t)kTopkMaxDeviceK * 8, "top-k ids");
   alloc((void**)&ix->d_cand, (size_t)kMaxCand * 4, "candidates");
   alloc((void**)&ix->d_cand_scores, (size_t)kMaxCand * 4, "candidate scores");
+  alloc((void**)&ix->d_cand_pads, (size_t)kMaxCand * 4, "candidate pad lengths");
+  alloc((void**)&ix->d_recs, (size_t)kTopkMaxDeviceK * sizeof(mv_cand_rec), "coarse candidate records");
+  alloc((void**)&ix->d_sel_pos, (size_t)kTopkMaxDeviceK * 8, "coarse selection");
   alloc((void**)&ix->d_qoff, 16, "query offsets");
   if (!rc) {
     ix->h_n_rows.assign((size_t)cap, 0);
@@ -729,7 +727,7 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
 
 int mv_index_set_option(mv_index* ix, int option, int64_t value) {
   if (!ix) { set_error("null index"); return MV_ERR_INVALID; }
-  std::lock_guard<std::mutex> lk(ix->mu);
+  std::lock_guard<std::mutex> lk(ix->q_mu);
   switch (option) {
     case MV_OPT_MAXSIM_VARIANT: ix->maxsim_variant = (int)value; return MV_OK;
     case MV_OPT_FDE_COARSE_N:
@@ -747,47 +745,57 @@ int mv_index_set_option(mv_index* ix, int option, int64_t value) {
   }
 }
 
-int64_t mv_index_size(const mv_index* ix) { return ix ? ix->size : 0; }
+int64_t mv_index_size(const mv_index* ix) { return ix ? ix->size.load(std::memory_order_acquire) : 0; }
 int64_t mv_index_capacity(const mv_index* ix) { return ix ? ix->cfg.capacity_pages : 0; }
 
 int mv_index_add_device(mv_index* ix, const void* d_emb, int dtype, const int32_t* n_rows, int64_t n_pages,
                         const int32_t* doc_ordinals, int64_t* out_first_page) {
+  if (!ix) { set_error("null index"); return MV_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(ix->w_mu);  // writers only: queries keep running on the published prefix
   int64_t total = 0;
   int rc = validate_add(ix, d_emb, dtype, n_rows, n_pages, &total);
   if (rc) return rc;
-  if (n_pages == 0) { if (out_first_page) *out_first_page = ix->size; return MV_OK; }
-  std::lock_guard<std::mutex> lk(ix->mu);
+  const int64_t first = ix->size.load();
+  if (out_first_page) *out_first_page = first;
+  if (n_pages == 0) return MV_OK;
   DeviceGuard g(ix->cfg.device);
-  return add_pages_common(ix, d_emb, dtype, n_rows, n_pages, doc_ordinals, total, out_first_page);
+  rc = add_pages_common(ix, d_emb, dtype, n_rows, n_pages, doc_ordinals, total, first);
+  if (rc) return rc;  // nothing was published: the half-written slots stay invisible and are overwritten by the next add
+  publish_pages(ix, first, n_pages);
+  return MV_OK;
 }
 
 int mv_index_add(mv_index* ix, const void* emb, int dtype, const int32_t* n_rows, int64_t n_pages,
                  const int32_t* doc_ordinals, int64_t* out_first_page) {
+  if (!ix) { set_error("null index"); return MV_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(ix->w_mu);
   int64_t total = 0;
   int rc = validate_add(ix, emb, dtype, n_rows, n_pages, &total);
   if (rc) return rc;
-  if (n_pages == 0) { if (out_first_page) *out_first_page = ix->size; return MV_OK; }
-  std::lock_guard<std::mutex> lk(ix->mu);
+  const int64_t first = ix->size.load();
+  if (out_first_page) *out_first_page = first;
+  if (n_pages == 0) return MV_OK;
   DeviceGuard g(ix->cfg.device);
-  // stage in chunks so the staging buffer stays <= ~1 GiB
+  // stage in chunks so the staging buffer stays <= ~1 GiB; the whole call is published at once (all or nothing)
   const size_t esz = dtype == MV_F32 ? 4 : 2;
-  const int64_t first = ix->size;
   int64_t p = 0;
   int64_t row_base = 0;
   while (p < n_pages) {
     int64_t q = p, rows = 0;
     while (q < n_pages && (q == p || (size_t)(rows + n_rows[q]) * kDim * esz <= ((size_t)1 << 30))) rows += n_rows[q++];
-    void* d_stage = nullptr;
-    MV_HIP(hipMalloc(&d_stage, std::max<size_t>((size_t)rows * kDim * esz, 16)));
-    hipError_t e = hipMemcpy(d_stage, (const char*)emb + (size_t)row_base * kDim * esz, (size_t)rows * kDim * esz, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(d_stage); return hip_fail(e, "H2D of embeddings", __FILE__, __LINE__); }
-    rc = add_pages_common(ix, d_stage, dtype, n_rows + p, q - p, doc_ordinals ? doc_ordinals + p : nullptr, rows, nullptr);
-    (void)hipFree(d_stage);
+    const size_t bytes = (size_t)rows * kDim * esz;
+    rc = w_reserve(&ix->w_stage, &ix->w_stage_bytes, std::max<size_t>(bytes, 16));
+    if (rc) return rc;
+    if (bytes) {
+      hipError_t e = hipMemcpyAsync(ix->w_stage, (const char*)emb + (size_t)row_base * kDim * esz, bytes, hipMemcpyHostToDevice, ix->w_stream);
+      if (e != hipSuccess) return hip_fail(e, "H2D of embeddings", __FILE__, __LINE__);
+    }
+    rc = add_pages_common(ix, ix->w_stage, dtype, n_rows + p, q - p, doc_ordinals ? doc_ordinals + p : nullptr, rows, first + p);
     if (rc) return rc;
     row_base += rows;
     p = q;
   }
-  if (out_first_page) *out_first_page = first;
+  publish_pages(ix, first, n_pages);
   return MV_OK;
 }
 
@@ -798,13 +806,13 @@ int mv_index_add_bits(mv_index* ix, const uint8_t* bits, const int32_t* n_rows, 
                       int64_t* out_first_page) {
   if (!ix || (!bits && n_pages > 0) || (!n_rows && n_pages > 0) || n_pages < 0) { set_error("mv_index_add_bits: null argument"); return MV_ERR_INVALID; }
   if (ix->cfg.flags != MV_WITH_BINARY) { set_error("mv_index_add_bits needs an index with MV_WITH_BINARY only (floats are not recoverable from sign bits)"); return MV_ERR_STATE; }
-  if (ix->size + n_pages > ix->cfg.capacity_pages) { set_error("slab full"); return MV_ERR_CAPACITY; }
+  std::lock_guard<std::mutex> lk(ix->w_mu);
+  if (ix->size.load() + n_pages > ix->cfg.capacity_pages) { set_error("slab full"); return MV_ERR_CAPACITY; }
   const int32_t stride = ix->cfg.stride_rows;
   for (int64_t i = 0; i < n_pages; ++i)
     if (n_rows[i] < 0 || n_rows[i] > stride) { set_error("page %lld has %d rows; stride_rows is %d", (long long)i, n_rows[i], stride); return MV_ERR_INVALID; }
-  std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->cfg.device);
-  const int64_t first = ix->size;
+  const int64_t first = ix->size.load();
   std::vector<uint8_t> img((size_t)std::min<int64_t>(n_pages, 4096) * stride * kSignBytes);
   int64_t src_row = 0;
   for (int64_t p0 = 0; p0 < n_pages; p0 += 4096) {  // fixed-stride image of up to 4096 pages per copy
@@ -819,35 +827,35 @@ int mv_index_add_bits(mv_index* ix, const uint8_t* bits, const int32_t* n_rows, 
   for (int64_t i = 0; i < n_pages; ++i) {
     ix->h_n_rows[first + i] = n_rows[i];
     ix->h_doc_ord[first + i] = doc_ordinals ? doc_ordinals[i] : 0;
-    ix->max_doc_ord = std::max(ix->max_doc_ord, ix->h_doc_ord[first + i]);
-    if (n_rows[i] != stride) ix->ragged = true;
-    if (doc_ordinals && doc_ordinals[i] < 0) ix->tombstones = true;
   }
   if (n_pages) {
     MV_HIP(hipMemcpy(ix->d_n_rows + first, ix->h_n_rows.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice));
     MV_HIP(hipMemcpy(ix->d_doc_ord + first, ix->h_doc_ord.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice));
+    publish_pages(ix, first, n_pages);
   }
-  ix->size += n_pages;
   if (out_first_page) *out_first_page = first;
   return MV_OK;
 }
 
 int mv_index_remove_page(mv_index* ix, int64_t page) {
-  if (!ix || page < 0 || page >= ix->size) { set_error("page out of range"); return MV_ERR_INVALID; }
-  std::lock_guard<std::mutex> lk(ix->mu);
+  if (!ix) { set_error("null index"); return MV_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(ix->w_mu);
+  if (page < 0 || page >= ix->size.load()) { set_error("page out of range"); return MV_ERR_INVALID; }
   DeviceGuard g(ix->cfg.device);
   ix->h_doc_ord[page] = -1;
-  ix->tombstones = true;
-  MV_HIP(hipMemcpy(ix->d_doc_ord + page, &ix->h_doc_ord[page], 4, hipMemcpyHostToDevice));
+  ix->tombstones.store(true);  // before the device write: a scan that sees the tombstone also reads doc_ord
+  MV_HIP(hipMemcpyAsync(ix->d_doc_ord + page, &ix->h_doc_ord[page], 4, hipMemcpyHostToDevice, ix->w_stream));
+  MV_HIP(hipStreamSynchronize(ix->w_stream));
   return MV_OK;
 }
 
 int mv_index_remove_doc(mv_index* ix, int32_t doc_ordinal, int64_t* out_n) {
   if (!ix || doc_ordinal < 0) { set_error("bad doc ordinal"); return MV_ERR_INVALID; }
-  std::lock_guard<std::mutex> lk(ix->mu);
+  std::lock_guard<std::mutex> lk(ix->w_mu);
   DeviceGuard g(ix->cfg.device);
   int64_t n = 0, lo = -1, hi = -1;
-  for (int64_t p = 0; p < ix->size; ++p)
+  const int64_t size = ix->size.load();
+  for (int64_t p = 0; p < size; ++p)
     if (ix->h_doc_ord[p] == doc_ordinal) {
       ix->h_doc_ord[p] = -1;
       if (lo < 0) lo = p;
@@ -855,17 +863,18 @@ int mv_index_remove_doc(mv_index* ix, int32_t doc_ordinal, int64_t* out_n) {
       ++n;
     }
   if (n) {
-    ix->tombstones = true;
-    MV_HIP(hipMemcpy(ix->d_doc_ord + lo, ix->h_doc_ord.data() + lo, (size_t)(hi - lo + 1) * 4, hipMemcpyHostToDevice));
+    ix->tombstones.store(true);
+    MV_HIP(hipMemcpyAsync(ix->d_doc_ord + lo, ix->h_doc_ord.data() + lo, (size_t)(hi - lo + 1) * 4, hipMemcpyHostToDevice, ix->w_stream));
+    MV_HIP(hipStreamSynchronize(ix->w_stream));
   }
   if (out_n) *out_n = n;
   return MV_OK;
 }
 
 int mv_index_read_pages(mv_index* ix, int64_t page0, int64_t n_pages, void* out_bf16) {
-  if (!ix || !out_bf16 || page0 < 0 || n_pages < 0 || page0 + n_pages > ix->size) { set_error("read_pages: range"); return MV_ERR_INVALID; }
+  if (!ix || !out_bf16 || page0 < 0 || n_pages < 0 || page0 + n_pages > ix->size.load()) { set_error("read_pages: range"); return MV_ERR_INVALID; }
   if (!(ix->cfg.flags & MV_WITH_FLOAT)) { set_error("index has no float slab"); return MV_ERR_STATE; }
-  std::lock_guard<std::mutex> lk(ix->mu);
+  std::lock_guard<std::mutex> lk(ix->q_mu);
   DeviceGuard g(ix->cfg.device);
   const size_t pb = (size_t)ix->cfg.stride_rows * kRowBytes;
   MV_HIP(hipMemcpy(out_bf16, (const char*)ix->slab + (size_t)page0 * pb, (size_t)n_pages * pb, hipMemcpyDeviceToHost));
@@ -873,9 +882,9 @@ int mv_index_read_pages(mv_index* ix, int64_t page0, int64_t n_pages, void* out_
 }
 
 int mv_index_write_rows(mv_index* ix, int64_t page, int32_t row0, int32_t n, const void* bf16_rows) {
-  if (!ix || !bf16_rows || page < 0 || page >= ix->size || row0 < 0 || n < 0 || row0 + n > ix->cfg.stride_rows) { set_error("write_rows: range"); return MV_ERR_INVALID; }
+  if (!ix || !bf16_rows || page < 0 || page >= ix->size.load() || row0 < 0 || n < 0 || row0 + n > ix->cfg.stride_rows) { set_error("write_rows: range"); return MV_ERR_INVALID; }
   if (!(ix->cfg.flags & MV_WITH_FLOAT)) { set_error("index has no float slab"); return MV_ERR_STATE; }
-  std::lock_guard<std::mutex> lk(ix->mu);
+  ExclusiveLock lk(ix);
   DeviceGuard g(ix->cfg.device);
   char* dst = (char*)ix->slab + ((size_t)page * ix->cfg.stride_rows + row0) * kRowBytes;
   MV_HIP(hipMemcpy(dst, bf16_rows, (size_t)n * kRowBytes, hipMemcpyHostToDevice));
@@ -884,16 +893,16 @@ int mv_index_write_rows(mv_index* ix, int64_t page, int32_t row0, int32_t n, con
 
 // Derive every enabled non-float slab of pages [first, first+n) from their fixed-stride bf16 image `src`
 // (the float slab itself, or a staging buffer).  d_nr = device row counts of those pages.
-static int derive_slabs_from_bf16(mv_index* ix, const uint16_t* src, int64_t first, int64_t n, const int32_t* d_nr) {
+static int derive_slabs_from_bf16(mv_index* ix, const uint16_t* src, int64_t first, int64_t n, const int32_t* d_nr, hipStream_t st) {
   const int32_t stride = ix->cfg.stride_rows;
   int rc = MV_OK;
   if (ix->cfg.flags & MV_WITH_BINARY) {
-    rc = launch_sign_pack_bf16_rows(src, n * (int64_t)stride, ix->bits + (size_t)first * stride * kSignBytes, ix->stream);
+    rc = launch_sign_pack_bf16_rows(src, n * (int64_t)stride, ix->bits + (size_t)first * stride * kSignBytes, st);
     if (rc) return rc;
   }
   if (ix->cfg.flags & MV_WITH_FP8) {
     rc = launch_quantize_pages_fp8(src, d_nr, stride, n, ix->slab8 + (size_t)first * stride * kDim, ix->inv_scale8 + first,
-                                   ix->stream);
+                                   st);
     if (rc) return rc;
   }
   if (ix->cfg.flags & MV_WITH_FDE) {
@@ -905,7 +914,7 @@ static int derive_slabs_from_bf16(mv_index* ix, const uint16_t* src, int64_t fir
       e.x_bf16 = src + (size_t)done * stride * kDim; e.n_rows = d_nr + done; e.stride = stride; e.n_pages = c; e.is_query = 0;
       e.out_bf16 = ix->fde + (size_t)(first + done) * ix->fde_t.out_dim;
       e.out_inv_norm = ix->fde_inv_norm + first + done;
-      rc = launch_fde_encode(ix->fde_t, e, ix->stream);
+      rc = launch_fde_encode(ix->fde_t, e, st);
       done += c;
     }
   }
@@ -915,46 +924,44 @@ static int derive_slabs_from_bf16(mv_index* ix, const uint16_t* src, int64_t fir
 int mv_index_fill_synthetic(mv_index* ix, uint64_t seed, uint64_t first_unit, int64_t n_pages, int32_t n_rows,
                             int32_t pages_per_doc) {
   if (!ix || n_pages < 0 || n_rows < 0 || n_rows > ix->cfg.stride_rows) { set_error("fill_synthetic: bad argument"); return MV_ERR_INVALID; }
-  if (ix->size + n_pages > ix->cfg.capacity_pages) { set_error("slab full"); return MV_ERR_CAPACITY; }
   if (pages_per_doc < 1) pages_per_doc = 1;
-  std::lock_guard<std::mutex> lk(ix->mu);
+  std::lock_guard<std::mutex> lk(ix->w_mu);
+  if (ix->size.load() + n_pages > ix->cfg.capacity_pages) { set_error("slab full"); return MV_ERR_CAPACITY; }
+  if (n_pages == 0) return MV_OK;
   DeviceGuard g(ix->cfg.device);
-  const int64_t first = ix->size;
+  hipStream_t ws = ix->w_stream;
+  const int64_t first = ix->size.load();
   const int32_t stride = ix->cfg.stride_rows;
   for (int64_t i = 0; i < n_pages; ++i) {
     ix->h_n_rows[first + i] = n_rows;
     ix->h_doc_ord[first + i] = (int32_t)((first_unit + (uint64_t)i) / (uint64_t)pages_per_doc);
-    ix->max_doc_ord = std::max(ix->max_doc_ord, ix->h_doc_ord[first + i]);
   }
-  if (n_rows != stride) ix->ragged = true;
-  MV_HIP(hipMemcpyAsync(ix->d_n_rows + first, ix->h_n_rows.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice, ix->stream));
-  MV_HIP(hipMemcpyAsync(ix->d_doc_ord + first, ix->h_doc_ord.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice, ix->stream));
+  MV_HIP(hipMemcpyAsync(ix->d_n_rows + first, ix->h_n_rows.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice, ws));
+  MV_HIP(hipMemcpyAsync(ix->d_doc_ord + first, ix->h_doc_ord.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice, ws));
   const bool has_float = (ix->cfg.flags & MV_WITH_FLOAT) != 0;
   // without a float slab the bf16 image is staged chunk by chunk (<= 512 MiB) and only its derivatives are kept
   const int64_t chunk = has_float ? n_pages : std::max<int64_t>(1, ((int64_t)512 << 20) / ((int64_t)stride * kRowBytes));
-  uint16_t* stage = nullptr;
-  if (!has_float && n_pages > 0) MV_HIP(hipMalloc(&stage, (size_t)std::min(chunk, n_pages) * stride * kRowBytes));
   int rc = MV_OK;
+  if (!has_float) rc = w_reserve(&ix->w_tmp, &ix->w_tmp_bytes, (size_t)std::min(chunk, n_pages) * stride * kRowBytes);
   for (int64_t done = 0; done < n_pages && !rc; done += chunk) {
     const int64_t c = std::min(chunk, n_pages - done);
-    uint16_t* dst = has_float ? ix->slab + (size_t)(first + done) * stride * kDim : stage;
-    rc = launch_synth_rows(dst, seed, first_unit + (uint64_t)done, c, n_rows, stride, ix->stream);
-    if (!rc) rc = derive_slabs_from_bf16(ix, dst, first + done, c, ix->d_n_rows + first + done);
-    if (!has_float && hipStreamSynchronize(ix->stream) != hipSuccess && !rc) { set_error("fill_synthetic: stream error"); rc = MV_ERR_HIP; }
+    uint16_t* dst = has_float ? ix->slab + (size_t)(first + done) * stride * kDim : (uint16_t*)ix->w_tmp;
+    rc = launch_synth_rows(dst, seed, first_unit + (uint64_t)done, c, n_rows, stride, ws);
+    if (!rc) rc = derive_slabs_from_bf16(ix, dst, first + done, c, ix->d_n_rows + first + done, ws);
+    if (!has_float && hipStreamSynchronize(ws) != hipSuccess && !rc) { set_error("fill_synthetic: stream error"); rc = MV_ERR_HIP; }
   }
-  hipError_t e = hipStreamSynchronize(ix->stream);
-  if (stage) (void)hipFree(stage);
+  hipError_t e = hipStreamSynchronize(ws);
   if (rc) return rc;
   if (e != hipSuccess) return hip_fail(e, "fill_synthetic", __FILE__, __LINE__);
-  ix->size += n_pages;
+  publish_pages(ix, first, n_pages);
   return MV_OK;
 }
 
 // Overwrite one whole page from host bf16 rows and refresh every slab (bench/test: planted neighbours on any
 // combination of slabs; also the update path of a re-embedded page).
 int mv_index_replace_page(mv_index* ix, int64_t page, const void* bf16_rows, int32_t n_rows) {
-  if (!ix || !bf16_rows || page < 0 || page >= ix->size || n_rows < 0 || n_rows > ix->cfg.stride_rows) { set_error("replace_page: bad argument"); return MV_ERR_INVALID; }
-  std::lock_guard<std::mutex> lk(ix->mu);
+  if (!ix || !bf16_rows || page < 0 || page >= ix->size.load() || n_rows < 0 || n_rows > ix->cfg.stride_rows) { set_error("replace_page: bad argument"); return MV_ERR_INVALID; }
+  ExclusiveLock lk(ix);
   DeviceGuard g(ix->cfg.device);
   const int32_t stride = ix->cfg.stride_rows;
   const bool has_float = (ix->cfg.flags & MV_WITH_FLOAT) != 0;
@@ -968,11 +975,11 @@ int mv_index_replace_page(mv_index* ix, int64_t page, const void* bf16_rows, int
   if (e != hipSuccess) rc = hip_fail(e, "replace_page upload", __FILE__, __LINE__);
   if (!rc) {
     ix->h_n_rows[page] = n_rows;
-    if (n_rows != stride) ix->ragged = true;
+    if (n_rows != stride) ix->ragged.store(true);
     e = hipMemcpyAsync(ix->d_n_rows + page, &ix->h_n_rows[page], 4, hipMemcpyHostToDevice, ix->stream);
     if (e != hipSuccess) rc = hip_fail(e, "replace_page metadata", __FILE__, __LINE__);
   }
-  if (!rc) rc = derive_slabs_from_bf16(ix, dst, page, 1, ix->d_n_rows + page);
+  if (!rc) rc = derive_slabs_from_bf16(ix, dst, page, 1, ix->d_n_rows + page, ix->stream);
   (void)hipStreamSynchronize(ix->stream);
   if (stage) (void)hipFree(stage);
   return rc;
@@ -995,9 +1002,9 @@ __global__ __launch_bounds__(256) void gather_pages_kernel(const char* base, siz
 // above their destination and batches ascend, so a write never lands on a page that is still to be read.
 int mv_index_compact(mv_index* ix, int64_t* out_old_to_new, int64_t* out_new_size) {
   if (!ix) { set_error("null index"); return MV_ERR_INVALID; }
-  std::lock_guard<std::mutex> lk(ix->mu);
+  ExclusiveLock lk(ix);
   DeviceGuard g(ix->cfg.device);
-  const int64_t n = ix->size;
+  const int64_t n = ix->size.load();
   std::vector<int64_t> live;
   live.reserve((size_t)n);
   for (int64_t p = 0; p < n; ++p) {
@@ -1054,11 +1061,11 @@ int mv_index_compact(mv_index* ix, int64_t* out_old_to_new, int64_t* out_new_siz
     ix->h_doc_ord[(size_t)j] = ix->h_doc_ord[(size_t)live[j]];
   }
   for (int64_t j = m; j < n; ++j) { ix->h_n_rows[(size_t)j] = 0; ix->h_doc_ord[(size_t)j] = -1; }
-  ix->size = m;
-  ix->tombstones = false;
-  ix->ragged = false;
-  for (int64_t j = 0; j < m; ++j)
-    if (ix->h_n_rows[(size_t)j] != ix->cfg.stride_rows) { ix->ragged = true; break; }
+  ix->size.store(m, std::memory_order_release);
+  ix->tombstones.store(false);
+  bool rag = false;
+  for (int64_t j = 0; j < m && !rag; ++j) rag = ix->h_n_rows[(size_t)j] != ix->cfg.stride_rows;
+  ix->ragged.store(rag);
   if (n > 0) {
     MV_HIP(hipMemcpy(ix->d_n_rows, ix->h_n_rows.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     MV_HIP(hipMemcpy(ix->d_doc_ord, ix->h_doc_ord.data(), (size_t)n * 4, hipMemcpyHostToDevice));
@@ -1068,9 +1075,9 @@ int mv_index_compact(mv_index* ix, int64_t* out_old_to_new, int64_t* out_new_siz
 
 // Read back the e4m3 codes (stride_rows x 128 bytes per page) and 2^-e scales of pages [page0, page0+n).
 int mv_index_read_fp8(mv_index* ix, int64_t page0, int64_t n_pages, void* out_codes, float* out_inv_scale) {
-  if (!ix || !out_codes || !out_inv_scale || page0 < 0 || n_pages < 0 || page0 + n_pages > ix->size) { set_error("read_fp8: range"); return MV_ERR_INVALID; }
+  if (!ix || !out_codes || !out_inv_scale || page0 < 0 || n_pages < 0 || page0 + n_pages > ix->size.load()) { set_error("read_fp8: range"); return MV_ERR_INVALID; }
   if (!(ix->cfg.flags & MV_WITH_FP8)) { set_error("index has no fp8 slab"); return MV_ERR_STATE; }
-  std::lock_guard<std::mutex> lk(ix->mu);
+  std::lock_guard<std::mutex> lk(ix->q_mu);
   DeviceGuard g(ix->cfg.device);
   const size_t pb = (size_t)ix->cfg.stride_rows * kDim;
   MV_HIP(hipMemcpy(out_codes, ix->slab8 + (size_t)page0 * pb, (size_t)n_pages * pb, hipMemcpyDeviceToHost));
@@ -1092,12 +1099,14 @@ int mv_synth_rows(int device, uint64_t seed, uint64_t unit, int32_t n_rows, void
   return rc;
 }
 
-static int query_common(mv_index* ix, const void* q, int q_dtype, int32_t n_q, int32_t k, int mode,
-                        const uint32_t* allow_bits, int64_t n_words, float* h_scores, int64_t* h_ids, int32_t* out_n,
-                        float* d_scores_out, int64_t* d_ids_out, void* user_stream, mv_query_stats* st) {
+// Shared body of the top-k entry points (also used by mv_comm.hip).  defer_stats: fill the accounting fields of `st` but
+// leave the event timings to a later mv::finish_stats(ix, st, true) -- the call then only enqueues.
+int mv_internal_query_common(mv_index* ix, const void* q, int q_dtype, int32_t n_q, int32_t k, int mode,
+                             const uint32_t* allow_bits, int64_t n_words, float* h_scores, int64_t* h_ids, int32_t* out_n,
+                             float* d_scores_out, int64_t* d_ids_out, void* user_stream, mv_query_stats* st, int defer_stats) {
   if (!ix) { set_error("null index"); return MV_ERR_INVALID; }
   if (k < 0) { set_error("k must be >= 0"); return MV_ERR_INVALID; }
-  std::lock_guard<std::mutex> lk(ix->mu);
+  std::lock_guard<std::mutex> lk(ix->q_mu);
   DeviceGuard g(ix->cfg.device);
   if (out_n) *out_n = 0;
   const bool to_device = d_scores_out != nullptr;
@@ -1106,7 +1115,7 @@ static int query_common(mv_index* ix, const void* q, int q_dtype, int32_t n_q, i
     MV_HIP(hipEventRecord(ix->ev[3], (hipStream_t)user_stream));
     MV_HIP(hipStreamWaitEvent(ix->stream, ix->ev[3], 0));
   }
-  if (k == 0 || ix->size == 0) {
+  if (k == 0 || ix->size.load(std::memory_order_acquire) == 0) {
     if (to_device) {
       std::vector<float> s((size_t)std::max(k, 1), -INFINITY);
       std::vector<int64_t> id((size_t)std::max(k, 1), -1);
@@ -1143,7 +1152,7 @@ static int query_common(mv_index* ix, const void* q, int q_dtype, int32_t n_q, i
       } else {
         MV_HIP(hipStreamSynchronize(ix->stream));
       }
-      return st ? finish_stats(ix, st, true) : MV_OK;
+      return (st && !defer_stats) ? finish_stats(ix, st, true) : MV_OK;
     }
     float* s = ix->h_out_s;
     int64_t* id = ix->h_out_id;
@@ -1179,16 +1188,16 @@ int mv_query_topk(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, in
                   const uint32_t* allow_bits, int64_t n_allow_words, float* out_scores, int64_t* out_ids, int32_t* out_n,
                   mv_query_stats* stats) {
   if (k > 0 && (!out_scores || !out_ids)) { set_error("null output buffer"); return MV_ERR_INVALID; }
-  return query_common(ix, q, q_dtype, n_q_rows, k, mode, allow_bits, n_allow_words, out_scores, out_ids, out_n, nullptr,
-                      nullptr, nullptr, stats);
+  return mv_internal_query_common(ix, q, q_dtype, n_q_rows, k, mode, allow_bits, n_allow_words, out_scores, out_ids, out_n, nullptr,
+                                  nullptr, nullptr, stats, 0);
 }
 
 int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int32_t k, int mode,
                          const uint32_t* allow_bits, int64_t n_allow_words, float* d_out_scores, int64_t* d_out_ids,
                          void* stream, mv_query_stats* stats) {
   if (k < 1 || !d_out_scores || !d_out_ids) { set_error("mv_query_topk_device: k >= 1 and device buffers required"); return MV_ERR_INVALID; }
-  return query_common(ix, q, q_dtype, n_q_rows, k, mode, allow_bits, n_allow_words, nullptr, nullptr, nullptr, d_out_scores,
-                      d_out_ids, stream, stats);
+  return mv_internal_query_common(ix, q, q_dtype, n_q_rows, k, mode, allow_bits, n_allow_words, nullptr, nullptr, nullptr, d_out_scores,
+                                  d_out_ids, stream, stats, 0);
 }
 
 int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, int32_t k, int mode,
@@ -1204,9 +1213,9 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
     for (int32_t b = 0; b < n_queries; ++b) {
       mv_query_stats st{};
       const uint32_t* ab = (allow_bits && allow_per_query) ? allow_bits + (size_t)b * n_allow_words : allow_bits;
-      int rc = query_common(ix, (const char*)q + (size_t)b * n_q_rows * kDim * esz, q_dtype, n_q_rows, k, mode, ab, n_allow_words,
-                            out_scores ? out_scores + (size_t)b * k : nullptr, out_ids ? out_ids + (size_t)b * k : nullptr, out_n + b, nullptr,
-                            nullptr, nullptr, stats ? &st : nullptr);
+      int rc = mv_internal_query_common(ix, (const char*)q + (size_t)b * n_q_rows * kDim * esz, q_dtype, n_q_rows, k, mode, ab, n_allow_words,
+                                        out_scores ? out_scores + (size_t)b * k : nullptr, out_ids ? out_ids + (size_t)b * k : nullptr, out_n + b, nullptr,
+                                        nullptr, nullptr, stats ? &st : nullptr, 0);
       if (rc) return rc;
       total.score_kernel_ms += st.score_kernel_ms; total.topk_ms += st.topk_ms; total.total_device_ms += st.total_device_ms;
       total.score_launches += st.score_launches; total.pages_scored += st.pages_scored; total.bytes_scanned += st.bytes_scanned;
@@ -1215,10 +1224,11 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
     return MV_OK;
   }
   if (!(ix->cfg.flags & MV_WITH_FLOAT)) { set_error("index has no float slab (MV_WITH_FLOAT)"); return MV_ERR_STATE; }
-  std::lock_guard<std::mutex> lk(ix->mu);
+  std::lock_guard<std::mutex> lk(ix->q_mu);
   DeviceGuard g(ix->cfg.device);
   for (int32_t b = 0; b < n_queries; ++b) out_n[b] = 0;
-  if (ix->size == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return MV_OK; }
+  const int64_t n = ix->size.load(std::memory_order_acquire);  // snapshot of the published corpus
+  if (n == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return MV_OK; }
   const int group_rows = ix->batch_variant == 2 ? 384 : 512;  // variant 2: 6 row tiles per wave (pipelined kernel)
   if (rpq > group_rows) { set_error("query of %d rows exceeds the %d-row group of batch variant %d", rpq, group_rows, ix->batch_variant); return MV_ERR_INVALID; }
   const int group = std::min(group_rows / rpq, 32);
@@ -1232,11 +1242,11 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
   // per-query bitmaps: all n_queries x n_allow_words words are uploaded once; a group reads its slice
   int rc = upload_allow(ix, allow_bits, per_query ? n_allow_words * (int64_t)n_queries : n_allow_words, &d_allow);
   if (rc) return rc;
-  const bool need_meta = ix->tombstones || d_allow != nullptr;
-  const int64_t n = ix->size;
+  const bool need_meta = ix->tombstones.load() || d_allow != nullptr;
+  const bool ragged = ix->ragged.load();
   int64_t pages = 0;
   // accounting: with per-query filters every live page is read (a page is skipped only when no query may see it)
-  const int64_t rows = stats ? count_allowed_rows(ix, per_query ? nullptr : allow_bits, n_allow_words, &pages) : 0;
+  const int64_t rows = stats ? count_allowed_rows(ix, n, per_query ? nullptr : allow_bits, n_allow_words, &pages) : 0;
   std::vector<uint16_t> hq((size_t)512 * kDim);
   std::vector<float> hs((size_t)k);
   std::vector<int64_t> hi((size_t)k);
@@ -1252,7 +1262,7 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
     MV_HIP(hipMemcpyAsync(ix->d_bq, hq.data(), hq.size() * 2, hipMemcpyHostToDevice, ix->stream));
     MV_HIP(hipEventRecord(ix->ev[0], ix->stream));
     BatchArgs a{};
-    a.slab = ix->slab; a.n_rows = ix->ragged ? ix->d_n_rows : nullptr; a.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
+    a.slab = ix->slab; a.n_rows = ragged ? ix->d_n_rows : nullptr; a.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
     a.allow = per_query ? d_allow + (size_t)b0 * n_allow_words : d_allow; a.n_allow_bits = n_allow_words * 32;
     a.allow_stride_bits = per_query ? n_allow_words * 32 : 0; a.q = ix->d_bq; a.scores = ix->d_bscores; a.n = n;
     a.score_stride = ix->cfg.capacity_pages; a.stride = ix->cfg.stride_rows; a.n_queries = nb; a.rows_per_query = rpq;
@@ -1288,45 +1298,62 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
 }
 
 int mv_score_all(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int mode, const uint32_t* allow_bits,
-                 int64_t n_allow_words, float* out_scores, mv_query_stats* stats) {
-  if (!ix || !out_scores) { set_error("null argument"); return MV_ERR_INVALID; }
+                 int64_t n_allow_words, float* out_scores, int64_t out_cap, int64_t* out_n, mv_query_stats* stats) {
+  if (!ix || !out_scores || out_cap < 0) { set_error("null argument"); return MV_ERR_INVALID; }
   if (mode == MV_MODE_FDE_THEN_FLOAT) mode = MV_MODE_FDE_ONLY;
-  std::lock_guard<std::mutex> lk(ix->mu);
+  std::lock_guard<std::mutex> lk(ix->q_mu);
   DeviceGuard g(ix->cfg.device);
-  if (ix->size == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return MV_OK; }
+  if (out_n) *out_n = 0;
+  if (ix->size.load(std::memory_order_acquire) == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return MV_OK; }
   ScanResult r;
   int rc = run_scan(ix, q, q_dtype, n_q_rows, mode, allow_bits, n_allow_words, 0, &r, stats);
   if (rc) return rc;
-  MV_HIP(hipMemcpyAsync(out_scores, r.d_scores, (size_t)r.n * 4, hipMemcpyDeviceToHost, ix->stream));
+  // the corpus may have grown since the caller sized its buffer: never write past out_cap
+  const int64_t m = std::min<int64_t>(r.n, out_cap);
+  MV_HIP(hipMemcpyAsync(out_scores, r.d_scores, (size_t)m * 4, hipMemcpyDeviceToHost, ix->stream));
   MV_HIP(hipStreamSynchronize(ix->stream));
+  if (out_n) *out_n = m;
   return finish_stats(ix, stats, false);
 }
 
-int mv_score_candidates(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const int32_t* cand, int32_t n_cand,
-                        int32_t pad_to, float* out_scores, mv_query_stats* stats) {
-  if (!ix || !q || !cand || !out_scores || n_cand < 0 || n_cand > kMaxCand || n_q_rows < 1) { set_error("score_candidates: bad argument"); return MV_ERR_INVALID; }
+// Shared body of mv_score_candidates / mv_score_candidates_pads.  pads: per-candidate pad_to (host) or null;
+// pad_to >= 0: one pad length for the whole list, -1: the reference rule (longest page of each batch of 128).
+static int score_candidates_common(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const int32_t* cand, int32_t n_cand,
+                                   int32_t pad_to, const int32_t* pads, float* out_scores, mv_query_stats* stats) {
+  if (!ix || !q || !cand || !out_scores || n_cand < 0 || n_cand > kMaxCand || n_q_rows < 1 || pad_to < -1) { set_error("score_candidates: bad argument"); return MV_ERR_INVALID; }
   const bool use_fp8 = !(ix->cfg.flags & MV_WITH_FLOAT);
   if (use_fp8 && !(ix->cfg.flags & MV_WITH_FP8)) { set_error("index has neither a float nor an fp8 slab"); return MV_ERR_STATE; }
-  std::lock_guard<std::mutex> lk(ix->mu);
+  std::lock_guard<std::mutex> lk(ix->q_mu);
   DeviceGuard g(ix->cfg.device);
   if (stats) memset(stats, 0, sizeof(*stats));
   if (n_cand == 0) return MV_OK;
+  const int64_t size = ix->size.load(std::memory_order_acquire);
   int64_t rows = 0;
   for (int i = 0; i < n_cand; ++i) {
-    if (cand[i] < 0 || cand[i] >= ix->size) { set_error("candidate %d out of range", cand[i]); return MV_ERR_INVALID; }
+    if (cand[i] < 0 || cand[i] >= size) { set_error("candidate %d out of range", cand[i]); return MV_ERR_INVALID; }
     rows += ix->h_n_rows[cand[i]];
   }
   int rc = upload_query(ix, q, q_dtype, n_q_rows, !use_fp8, false, false, use_fp8);
   if (rc) return rc;
-  MV_HIP(hipMemcpyAsync(ix->d_cand, cand, (size_t)n_cand * 4, hipMemcpyHostToDevice, ix->stream));
+  // tombstones are NOT applied here: the caller named the pages explicitly
   MV_HIP(hipEventRecord(ix->ev[0], ix->stream));
   int launches = 0;
-  // tombstones are NOT applied here: the caller named the pages explicitly
-  const bool keep = ix->tombstones;
-  ix->tombstones = false;
-  rc = use_fp8 ? fp8_scan(ix, n_q_rows, nullptr, 0, ix->d_cand, n_cand, pad_to, ix->d_cand_scores, &launches)
-               : float_scan(ix, n_q_rows, nullptr, 0, ix->d_cand, n_cand, pad_to, ix->d_cand_scores, &launches);
-  ix->tombstones = keep;
+  if (pads) {
+    MV_HIP(hipMemcpyAsync(ix->d_cand, cand, (size_t)n_cand * 4, hipMemcpyHostToDevice, ix->stream));
+    MV_HIP(hipMemcpyAsync(ix->d_cand_pads, pads, (size_t)n_cand * 4, hipMemcpyHostToDevice, ix->stream));
+  } else if (pad_to < 0) {
+    // the ids are staged in d_cand_scores (same size; the scan overwrites it afterwards, in stream order);
+    // cand_prepare copies them to d_cand and derives each batch-of-128's pad length on the device
+    MV_HIP(hipMemcpyAsync(ix->d_cand_scores, cand, (size_t)n_cand * 4, hipMemcpyHostToDevice, ix->stream));
+    rc = launch_cand_prepare(ix, nullptr, (const int32_t*)ix->d_cand_scores, n_cand, 1);
+    if (rc) return rc;
+    ++launches;
+  } else {
+    MV_HIP(hipMemcpyAsync(ix->d_cand, cand, (size_t)n_cand * 4, hipMemcpyHostToDevice, ix->stream));
+  }
+  const bool per_item = pads || pad_to < 0;
+  rc = use_fp8 ? fp8_scan(ix, n_q_rows, nullptr, 0, ix->d_cand, n_cand, per_item ? 0 : pad_to, per_item ? ix->d_cand_pads : nullptr, ix->d_cand_scores, &launches, true)
+               : float_scan(ix, n_q_rows, nullptr, 0, ix->d_cand, n_cand, per_item ? 0 : pad_to, per_item ? ix->d_cand_pads : nullptr, ix->d_cand_scores, &launches, true);
   if (rc) return rc;
   MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
   MV_HIP(hipMemcpyAsync(out_scores, ix->d_cand_scores, (size_t)n_cand * 4, hipMemcpyDeviceToHost, ix->stream));
@@ -1339,11 +1366,22 @@ int mv_score_candidates(mv_index* ix, const void* q, int q_dtype, int32_t n_q_ro
   return finish_stats(ix, stats, false);
 }
 
+int mv_score_candidates(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const int32_t* cand, int32_t n_cand,
+                        int32_t pad_to, float* out_scores, mv_query_stats* stats) {
+  return score_candidates_common(ix, q, q_dtype, n_q_rows, cand, n_cand, pad_to, nullptr, out_scores, stats);
+}
+
+int mv_score_candidates_pads(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const int32_t* cand, int32_t n_cand,
+                             const int32_t* pads, float* out_scores, mv_query_stats* stats) {
+  if (!pads) { set_error("score_candidates_pads: null pads"); return MV_ERR_INVALID; }
+  return score_candidates_common(ix, q, q_dtype, n_q_rows, cand, n_cand, 0, pads, out_scores, stats);
+}
+
 int mv_index_page_rows(mv_index* ix, const int32_t* pages, int64_t n_pages, int32_t* out_rows) {
   if (!ix || n_pages < 0 || (n_pages > 0 && (!pages || !out_rows))) { set_error("page_rows: bad argument"); return MV_ERR_INVALID; }
-  std::lock_guard<std::mutex> lk(ix->mu);
+  const int64_t size = ix->size.load(std::memory_order_acquire);  // published pages are immutable: no lock needed
   for (int64_t i = 0; i < n_pages; ++i) {
-    if (pages[i] < 0 || pages[i] >= ix->size) { set_error("page %d out of range", pages[i]); return MV_ERR_INVALID; }
+    if (pages[i] < 0 || pages[i] >= size) { set_error("page %d out of range", pages[i]); return MV_ERR_INVALID; }
     out_rows[i] = ix->h_n_rows[pages[i]];
   }
   return MV_OK;
@@ -1520,20 +1558,24 @@ struct SaveHeader {
 
 int mv_index_save(mv_index* ix, const char* path) {
   if (!ix || !path) { set_error("save: null argument"); return MV_ERR_INVALID; }
-  std::lock_guard<std::mutex> lk(ix->mu);
+  ExclusiveLock lk(ix);  // a consistent image: no ingest, no compaction while the slabs are dumped
   DeviceGuard g(ix->cfg.device);
-  FILE* f = fopen(path, "wb");
-  if (!f) { set_error("cannot open %s for writing", path); return MV_ERR_IO; }
+  // crash safety: write <path>.tmp, fsync, then rename over the previous checkpoint -- a crash mid-save leaves the old
+  // file intact
+  const std::string tmp = std::string(path) + ".tmp";
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) { set_error("cannot open %s for writing", tmp.c_str()); return MV_ERR_IO; }
+  const int64_t size = ix->size.load();
   SaveHeader h{};
   memcpy(h.magic, "MVIDX002", 8);
   h.cfg = ix->cfg;
-  h.size = ix->size;
+  h.size = size;
   h.fde_out_dim = ix->fde_t.out_dim;
   int rc = MV_OK;
-  auto wr = [&](const void* p, size_t n) { if (!rc && n && fwrite(p, 1, n, f) != n) { set_error("short write to %s", path); rc = MV_ERR_IO; } };
+  auto wr = [&](const void* p, size_t n) { if (!rc && n && fwrite(p, 1, n, f) != n) { set_error("short write to %s", tmp.c_str()); rc = MV_ERR_IO; } };
   wr(&h, sizeof(h));
-  wr(ix->h_n_rows.data(), (size_t)ix->size * 4);
-  wr(ix->h_doc_ord.data(), (size_t)ix->size * 4);
+  wr(ix->h_n_rows.data(), (size_t)size * 4);
+  wr(ix->h_doc_ord.data(), (size_t)size * 4);
   std::vector<char> buf((size_t)64 << 20);
   auto dump = [&](const void* d, size_t bytes) {
     size_t off = 0;
@@ -1544,18 +1586,21 @@ int mv_index_save(mv_index* ix, const char* path) {
       off += n;
     }
   };
-  const size_t rows = (size_t)ix->size * ix->cfg.stride_rows;
+  const size_t rows = (size_t)size * ix->cfg.stride_rows;
   if (ix->cfg.flags & MV_WITH_FLOAT) dump(ix->slab, rows * kRowBytes);
   if (ix->cfg.flags & MV_WITH_BINARY) dump(ix->bits, rows * kSignBytes);
   if (ix->cfg.flags & MV_WITH_FDE) {
-    dump(ix->fde, (size_t)ix->size * ix->fde_t.out_dim * 2);
-    dump(ix->fde_inv_norm, (size_t)ix->size * 4);
+    dump(ix->fde, (size_t)size * ix->fde_t.out_dim * 2);
+    dump(ix->fde_inv_norm, (size_t)size * 4);
   }
   if (ix->cfg.flags & MV_WITH_FP8) {
     dump(ix->slab8, rows * kDim);
-    dump(ix->inv_scale8, (size_t)ix->size * 4);
+    dump(ix->inv_scale8, (size_t)size * 4);
   }
-  if (fclose(f) != 0 && !rc) { set_error("close failed for %s", path); rc = MV_ERR_IO; }
+  if (!rc && (fflush(f) != 0 || fsync(fileno(f)) != 0)) { set_error("flush failed for %s", tmp.c_str()); rc = MV_ERR_IO; }
+  if (fclose(f) != 0 && !rc) { set_error("close failed for %s", tmp.c_str()); rc = MV_ERR_IO; }
+  if (!rc && rename(tmp.c_str(), path) != 0) { set_error("cannot rename %s to %s", tmp.c_str(), path); rc = MV_ERR_IO; }
+  if (rc) (void)remove(tmp.c_str());
   return rc;
 }
 
@@ -1566,14 +1611,19 @@ int mv_index_load(const char* path, int32_t device, mv_index** out) {
   if (!f) { set_error("cannot open %s", path); return MV_ERR_IO; }
   SaveHeader h{};
   if (fread(&h, 1, sizeof(h), f) != sizeof(h) || memcmp(h.magic, "MVIDX002", 8) != 0) { fclose(f); set_error("%s is not an mv index file", path); return MV_ERR_IO; }
+  // the header is untrusted input: everything read below is sized by it
+  if (h.size < 0 || h.size > h.cfg.capacity_pages) { fclose(f); set_error("%s: size %lld outside 0..capacity %lld", path, (long long)h.size, (long long)h.cfg.capacity_pages); return MV_ERR_IO; }
+  if ((h.cfg.flags & MV_WITH_FDE) && h.fde_out_dim != mv_fde_output_dim(&h.cfg.fde)) { fclose(f); set_error("%s: FDE width %lld does not match its FDE config", path, (long long)h.fde_out_dim); return MV_ERR_IO; }
   h.cfg.device = device;
   mv_index* ix = nullptr;
-  int rc = mv_index_create(&h.cfg, &ix);
+  int rc = mv_index_create(&h.cfg, &ix);  // validates dim / stride / capacity / flags
   if (rc) { fclose(f); return rc; }
   DeviceGuard g(device);
   auto rd = [&](void* p, size_t n) { if (!rc && n && fread(p, 1, n, f) != n) { set_error("short read from %s", path); rc = MV_ERR_IO; } };
   rd(ix->h_n_rows.data(), (size_t)h.size * 4);
   rd(ix->h_doc_ord.data(), (size_t)h.size * 4);
+  for (int64_t p = 0; p < h.size && !rc; ++p)
+    if (ix->h_n_rows[p] < 0 || ix->h_n_rows[p] > h.cfg.stride_rows) { set_error("%s: page %lld has %d rows (stride %d)", path, (long long)p, ix->h_n_rows[p], h.cfg.stride_rows); rc = MV_ERR_IO; }
   std::vector<char> buf((size_t)64 << 20);
   auto fill = [&](void* d, size_t bytes) {
     size_t off = 0;
@@ -1596,15 +1646,10 @@ int mv_index_load(const char* path, int32_t device, mv_index** out) {
     fill(ix->inv_scale8, (size_t)h.size * 4);
   }
   fclose(f);
-  if (!rc) {
-    ix->size = h.size;
-    for (int64_t p = 0; p < h.size; ++p) {
-      if (ix->h_n_rows[p] != h.cfg.stride_rows) ix->ragged = true;
-      if (ix->h_doc_ord[p] < 0) ix->tombstones = true;
-      ix->max_doc_ord = std::max(ix->max_doc_ord, ix->h_doc_ord[p]);
-    }
-    if (h.size && (hipMemcpy(ix->d_n_rows, ix->h_n_rows.data(), (size_t)h.size * 4, hipMemcpyHostToDevice) != hipSuccess ||
-                   hipMemcpy(ix->d_doc_ord, ix->h_doc_ord.data(), (size_t)h.size * 4, hipMemcpyHostToDevice) != hipSuccess)) { set_error("H2D of metadata failed"); rc = MV_ERR_HIP; }
+  if (!rc && h.size) {
+    if (hipMemcpy(ix->d_n_rows, ix->h_n_rows.data(), (size_t)h.size * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ix->d_doc_ord, ix->h_doc_ord.data(), (size_t)h.size * 4, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D of metadata failed"); rc = MV_ERR_HIP; }
+    if (!rc) publish_pages(ix, 0, h.size);
   }
   if (rc) { std::string keep = g_err; mv_index_destroy(ix); g_err = keep; return rc; }
   *out = ix;

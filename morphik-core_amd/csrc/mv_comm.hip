@@ -1,0 +1,558 @@
+// mv_comm.hip -- row-sharded corpus behind the C ABI.
+//
+//  (1) mv_two_stage_coarse_device / mv_two_stage_rerank_device: the stages of FastMultiVectorStore.query_similar
+//      (core/vector_store/fast_multivector_store.py:521-556: FDE coarse search -> candidates -> exact rerank -> top-k)
+//      on ONE shard of a row-sharded corpus, with every intermediate left on the device, so a caller that owns the
+//      collective (one process per GPU over RCCL: morphik_core_amd/sharded.py) strings them together without a host
+//      round trip.
+//  (2) mv_comm: R shards driven from ONE process -- the shape the reference wires its store in
+//      (core/services_init.py:141-165 builds one store object; SURVEY.md 8b proposed mv_comm_init(n_ranks, device_ids)).
+//      Scans of all shards are enqueued back to back on per-shard streams and run concurrently on their GPUs; the only
+//      exchange is k (score, id) pairs per shard (plus n_coarse 16-byte candidate records for the two-stage mode), moved
+//      by one grouped RCCL all-gather over xGMI, by peer copies, or through the host (the correctness reference).
+//
+// RCCL is bound at run time (dlopen of librccl.so.1, the copy torch ships resolves to the same soname): processes that
+// never create a multi-device communicator do not load it.
+#include <dlfcn.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+#include <new>
+#include <string>
+#include <vector>
+
+#include <rccl/rccl.h>  // types and prototypes only; the symbols are resolved with dlsym
+
+#include "mv_index_priv.h"
+
+using namespace mv;
+
+namespace {
+
+// ---------------------------------------------------------------- two-stage device kernels
+__global__ __launch_bounds__(256) void recs_build_kernel(const float* s, const int64_t* gid, int n, const int32_t* n_rows,
+                                                         int32_t stride, int64_t id_base, mv_cand_rec* out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  mv_cand_rec r;
+  const int64_t g = gid[i];
+  if (g < 0) {
+    r.score = -INFINITY; r.rows = 0; r.id = -1;
+  } else {
+    r.score = s[i];
+    r.rows = n_rows ? n_rows[g - id_base] : stride;
+    r.id = g;
+  }
+  out[i] = r;
+}
+
+__global__ __launch_bounds__(256) void recs_fill_pad_kernel(mv_cand_rec* out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = mv_cand_rec{-INFINITY, 0, -1};
+}
+
+__global__ __launch_bounds__(256) void recs_scores_kernel(const mv_cand_rec* recs, int n, float* out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = recs[i].id < 0 ? -INFINITY : recs[i].score;
+}
+
+// Global coarse top-n (positions into the gathered records, in coarse rank order) -> this shard's rerank list: local page
+// of the candidates it owns, -1 for the others (the rerank kernel skips them), and for every entry the pad length of
+// its batch of 128 in the GLOBAL list (longest page of the batch, owned or not).  One block per batch.
+__global__ __launch_bounds__(kRerankBatch) void owned_select_kernel(const mv_cand_rec* recs, const int64_t* pos, int n, int64_t lo,
+                                                                    int64_t hi, int pad_sem, int32_t* cand, int32_t* pads) {
+  __shared__ int32_t wmax[kRerankBatch / 64];
+  const int j = blockIdx.x * kRerankBatch + threadIdx.x;
+  int32_t c = -1, rows = 0;
+  if (j < n) {
+    const int64_t p = pos[j];
+    if (p >= 0) {
+      const mv_cand_rec r = recs[p];
+      rows = r.rows;
+      if (r.id >= lo && r.id < hi) c = (int32_t)(r.id - lo);
+    }
+  }
+  int32_t m = rows;
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) m = max(m, __shfl_xor(m, s));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = max(wmax[0], wmax[1]);
+  if (j < n) {
+    cand[j] = c;
+    pads[j] = pad_sem ? m : 0;
+  }
+}
+
+__global__ void fill_topk_pad_kernel(float* s, int64_t* id, int k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < k) { s[i] = -INFINITY; id[i] = -1; }
+}
+
+int order_behind(mv_index* ix, void* user_stream) {
+  if (!user_stream) return MV_OK;
+  MV_HIP(hipEventRecord(ix->ev[3], (hipStream_t)user_stream));
+  MV_HIP(hipStreamWaitEvent(ix->stream, ix->ev[3], 0));
+  return MV_OK;
+}
+int hand_back(mv_index* ix, void* user_stream) {
+  if (user_stream) {
+    MV_HIP(hipEventRecord(ix->ev[4], ix->stream));
+    MV_HIP(hipStreamWaitEvent((hipStream_t)user_stream, ix->ev[4], 0));
+  } else {
+    MV_HIP(hipStreamSynchronize(ix->stream));
+  }
+  return MV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mv_two_stage_coarse_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int32_t n_coarse,
+                               const uint32_t* allow_bits, int64_t n_allow_words, mv_cand_rec* d_out_recs, void* stream) {
+  if (!ix || !q || !d_out_recs || n_q_rows < 1 || n_coarse < 1 || n_coarse > kTopkMaxDeviceK) { set_error("two_stage_coarse: bad argument"); return MV_ERR_INVALID; }
+  if (q_dtype != MV_F32 && q_dtype != MV_BF16) { set_error("bad query dtype %d", q_dtype); return MV_ERR_INVALID; }
+  if (!(ix->cfg.flags & MV_WITH_FDE)) { set_error("index has no FDE slab (MV_WITH_FDE)"); return MV_ERR_STATE; }
+  std::lock_guard<std::mutex> lk(ix->q_mu);
+  DeviceGuard g(ix->cfg.device);
+  int rc = order_behind(ix, stream);
+  if (rc) return rc;
+  const int64_t n = ix->size.load(std::memory_order_acquire);
+  const unsigned gb = (unsigned)((n_coarse + 255) / 256);
+  if (n == 0) {
+    hipLaunchKernelGGL(recs_fill_pad_kernel, dim3(gb), dim3(256), 0, ix->stream, d_out_recs, (int)n_coarse);
+    MV_HIP(hipGetLastError());
+    return hand_back(ix, stream);
+  }
+  rc = upload_query(ix, q, q_dtype, n_q_rows, false, true, false, false);
+  if (rc) return rc;
+  const uint32_t* d_allow = nullptr;
+  rc = upload_allow(ix, allow_bits, n_allow_words, &d_allow);
+  if (rc) return rc;
+  int launches = 0;
+  rc = fde_coarse_scan(ix, n_q_rows, d_allow, n_allow_words, n, &launches);
+  if (rc) return rc;
+  rc = launch_topk(ix->d_scores, n, n_coarse, nullptr, ix->cfg.id_base, ix->d_topk_ws, ix->d_out_s, ix->d_out_id, ix->stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(recs_build_kernel, dim3(gb), dim3(256), 0, ix->stream, (const float*)ix->d_out_s, (const int64_t*)ix->d_out_id,
+                     (int)n_coarse, ix->ragged.load() ? (const int32_t*)ix->d_n_rows : (const int32_t*)nullptr, ix->cfg.stride_rows,
+                     ix->cfg.id_base, d_out_recs);
+  MV_HIP(hipGetLastError());
+  return hand_back(ix, stream);
+}
+
+int mv_two_stage_rerank_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const mv_cand_rec* d_all_recs,
+                               int32_t world, int32_t n_coarse, int32_t k, float* d_out_scores, int64_t* d_out_ids, void* stream) {
+  if (!ix || !q || !d_all_recs || !d_out_scores || !d_out_ids || n_q_rows < 1 || world < 1 || n_coarse < 1 || n_coarse > kTopkMaxDeviceK ||
+      k < 1 || k > kTopkMaxDeviceK || (int64_t)world * n_coarse > 16384) { set_error("two_stage_rerank: bad argument"); return MV_ERR_INVALID; }
+  if (q_dtype != MV_F32 && q_dtype != MV_BF16) { set_error("bad query dtype %d", q_dtype); return MV_ERR_INVALID; }
+  const bool use_fp8 = !(ix->cfg.flags & MV_WITH_FLOAT);
+  if (use_fp8 && !(ix->cfg.flags & MV_WITH_FP8)) { set_error("index has neither a float nor an fp8 slab"); return MV_ERR_STATE; }
+  std::lock_guard<std::mutex> lk(ix->q_mu);
+  DeviceGuard g(ix->cfg.device);
+  int rc = order_behind(ix, stream);
+  if (rc) return rc;
+  const int64_t n = ix->size.load(std::memory_order_acquire);
+  const int total = world * n_coarse;
+  if (total > ix->gscores_cap) {
+    if (ix->d_gscores) (void)hipFree(ix->d_gscores);
+    ix->d_gscores = nullptr; ix->gscores_cap = 0;
+    MV_HIP(hipMalloc(&ix->d_gscores, (size_t)16384 * 4));
+    ix->gscores_cap = 16384;
+  }
+  rc = upload_query(ix, q, q_dtype, n_q_rows, !use_fp8, false, false, use_fp8);
+  if (rc) return rc;
+  // global coarse top-n: the gathered lists are in shard order and each is sorted (score desc, id asc), shards own
+  // ascending ids, so "ties by position" is "ties by ascending id" -- the single-index rule
+  hipLaunchKernelGGL(recs_scores_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ix->stream, d_all_recs, total, ix->d_gscores);
+  rc = launch_topk(ix->d_gscores, total, n_coarse, nullptr, 0, ix->d_topk_ws, ix->d_out_s, ix->d_sel_pos, ix->stream);
+  if (rc) return rc;
+  const int pad_sem = ix->pad_semantics < 0 ? 1 : ix->pad_semantics;
+  hipLaunchKernelGGL(owned_select_kernel, dim3((unsigned)((n_coarse + kRerankBatch - 1) / kRerankBatch)), dim3(kRerankBatch), 0, ix->stream,
+                     d_all_recs, (const int64_t*)ix->d_sel_pos, (int)n_coarse, ix->cfg.id_base, ix->cfg.id_base + n, pad_sem, ix->d_cand,
+                     ix->d_cand_pads);
+  MV_HIP(hipGetLastError());
+  int launches = 0;
+  rc = rerank_scan(ix, n_q_rows, use_fp8, n_coarse, ix->d_cand_scores, &launches);
+  if (rc) return rc;
+  // local top-k of the owned candidates; equal scores resolve by coarse rank (the work index), as on one index
+  rc = launch_topk(ix->d_cand_scores, n_coarse, k, ix->d_cand, ix->cfg.id_base, ix->d_topk_ws, d_out_scores, d_out_ids, ix->stream);
+  if (rc) return rc;
+  return hand_back(ix, stream);
+}
+
+}  // extern "C"
+
+// =================================================================================== communicator
+namespace {
+
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool load() {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (handle) break;
+    }
+    if (!handle) return false;
+    CommInitAll = (decltype(CommInitAll))dlsym(handle, "ncclCommInitAll");
+    CommDestroy = (decltype(CommDestroy))dlsym(handle, "ncclCommDestroy");
+    AllGather = (decltype(AllGather))dlsym(handle, "ncclAllGather");
+    GroupStart = (decltype(GroupStart))dlsym(handle, "ncclGroupStart");
+    GroupEnd = (decltype(GroupEnd))dlsym(handle, "ncclGroupEnd");
+    GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
+    return CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd && GetErrorString;
+  }
+};
+
+struct Shard {
+  int dev = 0;
+  mv_index* ix = nullptr;
+  hipStream_t cs = nullptr;     // comm stream on the shard's device
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_done = nullptr;
+  float* d_ls = nullptr;        // [1024] local top-k scores
+  int64_t* d_li = nullptr;      // [1024]
+  float* d_gs = nullptr;        // [R][1024] gathered scores (shard 0 always; every shard under RCCL)
+  int64_t* d_gi = nullptr;
+  mv_cand_rec* d_recs = nullptr;  // [1024] local coarse candidates
+  mv_cand_rec* d_all = nullptr;   // [R][1024] gathered coarse candidates
+  ncclComm_t nccl = nullptr;
+};
+
+}  // namespace
+
+struct mv_comm {
+  int n = 0;
+  int transport = MV_COMM_HOST;
+  std::vector<Shard> sh;
+  RcclApi rccl;
+  float* d_os = nullptr;   // merged result on shard 0's device
+  int64_t* d_oi = nullptr;
+  float* h_s = nullptr;    // pinned host: [R][1024] + merged
+  int64_t* h_i = nullptr;
+  mv_cand_rec* h_recs = nullptr;  // pinned host: [R][1024] (HOST transport of the two-stage mode)
+  std::mutex mu;
+};
+
+namespace {
+
+constexpr int kK = kTopkMaxDeviceK;
+
+#define MV_NCCL(c, expr)                                                                  \
+  do {                                                                                    \
+    ncclResult_t _r = (expr);                                                             \
+    if (_r != ncclSuccess) { set_error("RCCL error %d (%s) in %s", (int)_r, (c)->rccl.GetErrorString(_r), #expr); return MV_ERR_HIP; } \
+  } while (0)
+
+int copy_between(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return MV_OK;
+  if (dst_dev == src_dev) MV_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+  else MV_HIP(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, s));
+  return MV_OK;
+}
+
+// Host merge of R sorted lists (score desc; ties: shard asc, position asc == id asc): the correctness reference.
+void host_merge(const float* s, const int64_t* id, int R, int kk, int k, float* os, int64_t* oi, int* out_n) {
+  std::vector<int> head((size_t)R, 0);
+  int m = 0;
+  while (m < k) {
+    int best = -1;
+    for (int r = 0; r < R; ++r) {
+      if (head[r] >= kk) continue;
+      const int64_t gid = id[(size_t)r * kk + head[r]];
+      if (gid < 0) { head[r] = kk; continue; }
+      if (best < 0 || s[(size_t)r * kk + head[r]] > s[(size_t)best * kk + head[best]]) best = r;
+    }
+    if (best < 0) break;
+    os[m] = s[(size_t)best * kk + head[best]];
+    oi[m] = id[(size_t)best * kk + head[best]];
+    ++head[best];
+    ++m;
+  }
+  *out_n = m;
+}
+
+// All-gather of `bytes` per shard from src(i) into dst(j)[i * bytes] for the shards that need the result.
+// all = every shard receives everything (two-stage candidates); else only shard 0 must (the final top-k).
+int exchange(mv_comm* c, size_t bytes, bool all, void* (*src)(Shard&), void* (*dst)(Shard&)) {
+  const int R = c->n;
+  if (c->transport == MV_COMM_RCCL) {
+    MV_NCCL(c, c->rccl.GroupStart());
+    for (int i = 0; i < R; ++i) {
+      Shard& s = c->sh[i];
+      ncclResult_t r = c->rccl.AllGather(src(s), dst(s), bytes, ncclChar, s.nccl, s.cs);
+      if (r != ncclSuccess) { (void)c->rccl.GroupEnd(); set_error("RCCL error %d (%s) in ncclAllGather", (int)r, c->rccl.GetErrorString(r)); return MV_ERR_HIP; }
+    }
+    MV_NCCL(c, c->rccl.GroupEnd());
+    return MV_OK;
+  }
+  // P2P: every shard pushes its piece into shard 0's buffer on its own stream; shard 0 waits for all of them
+  Shard& z = c->sh[0];
+  for (int i = 0; i < R; ++i) {
+    Shard& s = c->sh[i];
+    DeviceGuard g(s.dev);
+    int rc = copy_between((char*)dst(z) + (size_t)i * bytes, z.dev, src(s), s.dev, bytes, s.cs);
+    if (rc) return rc;
+    if (i) MV_HIP(hipEventRecord(s.ev_done, s.cs));
+  }
+  {
+    DeviceGuard g(z.dev);
+    for (int i = 1; i < R; ++i) MV_HIP(hipStreamWaitEvent(z.cs, c->sh[i].ev_done, 0));
+    if (all && R > 1) MV_HIP(hipEventRecord(z.ev_done, z.cs));
+  }
+  if (all) {  // ... and shard 0 hands the assembled block to the others
+    for (int j = 1; j < R; ++j) {
+      Shard& s = c->sh[j];
+      DeviceGuard g(s.dev);
+      MV_HIP(hipStreamWaitEvent(s.cs, z.ev_done, 0));
+      int rc = copy_between(dst(s), s.dev, dst(z), z.dev, bytes * (size_t)R, s.cs);
+      if (rc) return rc;
+    }
+  }
+  return MV_OK;
+}
+
+void* src_ls(Shard& s) { return s.d_ls; }
+void* src_li(Shard& s) { return s.d_li; }
+void* dst_gs(Shard& s) { return s.d_gs; }
+void* dst_gi(Shard& s) { return s.d_gi; }
+void* src_recs(Shard& s) { return s.d_recs; }
+void* dst_all(Shard& s) { return s.d_all; }
+
+int sync_all(mv_comm* c) {
+  for (int i = 0; i < c->n; ++i) {
+    DeviceGuard g(c->sh[i].dev);
+    MV_HIP(hipStreamSynchronize(c->sh[i].cs));
+  }
+  return MV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void mv_comm_destroy(mv_comm* c) {
+  if (!c) return;
+  for (Shard& s : c->sh) {
+    DeviceGuard g(s.dev);
+    if (s.cs) (void)hipStreamSynchronize(s.cs);
+    if (s.nccl && c->rccl.CommDestroy) (void)c->rccl.CommDestroy(s.nccl);
+    for (void* p : {(void*)s.d_ls, (void*)s.d_li, (void*)s.d_gs, (void*)s.d_gi, (void*)s.d_recs, (void*)s.d_all})
+      if (p) (void)hipFree(p);
+    for (hipEvent_t e : {s.ev_t0, s.ev_t1, s.ev_done})
+      if (e) (void)hipEventDestroy(e);
+    if (s.cs) (void)hipStreamDestroy(s.cs);
+  }
+  if (!c->sh.empty()) {
+    DeviceGuard g(c->sh[0].dev);
+    if (c->d_os) (void)hipFree(c->d_os);
+    if (c->d_oi) (void)hipFree(c->d_oi);
+  }
+  for (void* p : {(void*)c->h_s, (void*)c->h_i, (void*)c->h_recs})
+    if (p) (void)hipHostFree(p);
+  // the RCCL handle stays loaded for the life of the process (its worker threads outlive communicators)
+  delete c;
+}
+
+int mv_comm_create(int32_t n_shards, const int32_t* device_ids, int32_t transport, mv_comm** out) {
+  if (!out || !device_ids || n_shards < 1 || n_shards > 64) { set_error("mv_comm_create: bad argument"); return MV_ERR_INVALID; }
+  *out = nullptr;
+  if (transport < MV_COMM_AUTO || transport > MV_COMM_HOST) { set_error("mv_comm_create: unknown transport %d", transport); return MV_ERR_INVALID; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device available (libmvmaxsim requires an MI355X / gfx950 GPU)"); return MV_ERR_HIP; }
+  bool distinct = true;
+  for (int i = 0; i < n_shards; ++i) {
+    if (device_ids[i] < 0 || device_ids[i] >= ndev) { set_error("device %d out of range (have %d)", device_ids[i], ndev); return MV_ERR_INVALID; }
+    for (int j = 0; j < i; ++j) distinct = distinct && device_ids[j] != device_ids[i];
+  }
+  if (transport == MV_COMM_RCCL && !distinct) { set_error("MV_COMM_RCCL needs one distinct device per shard (logical shards on one device: use MV_COMM_P2P)"); return MV_ERR_INVALID; }
+  mv_comm* c = new (std::nothrow) mv_comm();
+  if (!c) { set_error("host allocation failed"); return MV_ERR_NOMEM; }
+  c->n = n_shards;
+  c->sh.resize((size_t)n_shards);
+  int rc = MV_OK;
+  auto fail = [&](int code) { std::string keep = mv_last_error(); mv_comm_destroy(c); set_error("%s", keep.c_str()); return code; };
+  for (int i = 0; i < n_shards && !rc; ++i) {
+    Shard& s = c->sh[i];
+    s.dev = device_ids[i];
+    DeviceGuard g(s.dev);
+    const size_t R = (size_t)n_shards;
+    if (hipStreamCreateWithFlags(&s.cs, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&s.ev_t0) != hipSuccess ||
+        hipEventCreate(&s.ev_t1) != hipSuccess || hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) != hipSuccess) { set_error("mv_comm_create: stream / event creation failed"); rc = MV_ERR_HIP; break; }
+    if (hipMalloc(&s.d_ls, kK * 4) != hipSuccess || hipMalloc(&s.d_li, kK * 8) != hipSuccess || hipMalloc(&s.d_gs, R * kK * 4) != hipSuccess ||
+        hipMalloc(&s.d_gi, R * kK * 8) != hipSuccess || hipMalloc(&s.d_recs, kK * sizeof(mv_cand_rec)) != hipSuccess ||
+        hipMalloc(&s.d_all, R * kK * sizeof(mv_cand_rec)) != hipSuccess) { set_error("mv_comm_create: out of device memory"); rc = MV_ERR_NOMEM; break; }
+  }
+  if (!rc) {
+    DeviceGuard g(c->sh[0].dev);
+    const size_t R = (size_t)n_shards;
+    if (hipMalloc(&c->d_os, kK * 4) != hipSuccess || hipMalloc(&c->d_oi, kK * 8) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_s, (R + 1) * kK * 4, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_i, (R + 1) * kK * 8, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_recs, R * kK * sizeof(mv_cand_rec), hipHostMallocDefault) != hipSuccess) { set_error("mv_comm_create: out of memory"); rc = MV_ERR_NOMEM; }
+  }
+  if (rc) return fail(rc);
+  c->transport = transport;
+  if (transport == MV_COMM_AUTO) c->transport = (distinct && n_shards > 1) ? MV_COMM_RCCL : MV_COMM_P2P;
+  if (c->transport == MV_COMM_RCCL) {
+    bool ok = c->rccl.load();
+    if (ok) {
+      std::vector<ncclComm_t> comms((size_t)n_shards, nullptr);
+      std::vector<int> devs(device_ids, device_ids + n_shards);
+      ncclResult_t r = c->rccl.CommInitAll(comms.data(), n_shards, devs.data());
+      if (r == ncclSuccess) {
+        for (int i = 0; i < n_shards; ++i) c->sh[i].nccl = comms[i];
+      } else {
+        set_error("ncclCommInitAll failed: %s", c->rccl.GetErrorString(r));
+        ok = false;
+      }
+    } else {
+      set_error("librccl.so.1 could not be loaded: %s", dlerror() ? dlerror() : "symbol missing");
+    }
+    if (!ok) {
+      if (transport == MV_COMM_RCCL) return fail(MV_ERR_HIP);  // asked for explicitly
+      c->transport = MV_COMM_P2P;
+    }
+  }
+  *out = c;
+  return MV_OK;
+}
+
+int mv_comm_attach(mv_comm* c, int32_t shard, mv_index* ix) {
+  if (!c || !ix || shard < 0 || shard >= c->n) { set_error("mv_comm_attach: bad argument"); return MV_ERR_INVALID; }
+  if (ix->cfg.device != c->sh[shard].dev) { set_error("mv_comm_attach: shard %d lives on device %d, the index on device %d", shard, c->sh[shard].dev, ix->cfg.device); return MV_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->sh[shard].ix = ix;
+  return MV_OK;
+}
+
+int mv_comm_transport(const mv_comm* c) { return c ? c->transport : MV_ERR_INVALID; }
+
+int mv_comm_query_topk(mv_comm* c, const void* q, int q_dtype, int32_t n_q_rows, int32_t k, int mode, const uint32_t* allow_bits,
+                       int64_t n_allow_words, float* out_scores, int64_t* out_ids, int32_t* out_n, mv_query_stats* stats) {
+  if (!c || !q || !out_n || k < 0 || (k > 0 && (!out_scores || !out_ids))) { set_error("mv_comm_query_topk: bad argument"); return MV_ERR_INVALID; }
+  if (k > kK) { set_error("mv_comm_query_topk supports k <= %d", kK); return MV_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(c->mu);
+  *out_n = 0;
+  const int R = c->n;
+  for (int i = 0; i < R; ++i)
+    if (!c->sh[i].ix) { set_error("mv_comm_query_topk: shard %d has no index attached", i); return MV_ERR_STATE; }
+  if (stats) memset(stats, 0, sizeof(mv_query_stats) * (size_t)R);
+  if (k == 0) return MV_OK;
+  const bool two_stage = mode == MV_MODE_FDE_THEN_FLOAT;
+  int rc = MV_OK;
+  // ---- enqueue the local work of every shard; nothing below waits for a GPU until the final copy
+  for (int i = 0; i < R; ++i) {
+    Shard& s = c->sh[i];
+    DeviceGuard g(s.dev);
+    MV_HIP(hipEventRecord(s.ev_t0, s.cs));
+  }
+  int n_coarse = 0;
+  if (two_stage) {
+    n_coarse = (int)std::min<int64_t>(coarse_n_for(c->sh[0].ix, k), kK);
+    if ((int64_t)R * n_coarse > 16384) { set_error("two-stage query: %d shards x %d candidates exceed 16384", R, n_coarse); return MV_ERR_INVALID; }
+    for (int i = 0; i < R; ++i) {
+      Shard& s = c->sh[i];
+      rc = mv_two_stage_coarse_device(s.ix, q, q_dtype, n_q_rows, n_coarse, allow_bits, n_allow_words, s.d_recs, s.cs);
+      if (rc) return rc;
+    }
+    const size_t rb = (size_t)n_coarse * sizeof(mv_cand_rec);
+    if (c->transport == MV_COMM_HOST) {
+      for (int i = 0; i < R; ++i) {
+        Shard& s = c->sh[i];
+        DeviceGuard g(s.dev);
+        MV_HIP(hipMemcpyAsync(c->h_recs + (size_t)i * n_coarse, s.d_recs, rb, hipMemcpyDeviceToHost, s.cs));
+      }
+      rc = sync_all(c);
+      if (rc) return rc;
+      for (int i = 0; i < R; ++i) {
+        Shard& s = c->sh[i];
+        DeviceGuard g(s.dev);
+        MV_HIP(hipMemcpyAsync(s.d_all, c->h_recs, rb * (size_t)R, hipMemcpyHostToDevice, s.cs));
+      }
+    } else {
+      rc = exchange(c, rb, true, src_recs, dst_all);
+      if (rc) return rc;
+    }
+    for (int i = 0; i < R; ++i) {
+      Shard& s = c->sh[i];
+      rc = mv_two_stage_rerank_device(s.ix, q, q_dtype, n_q_rows, s.d_all, R, n_coarse, k, s.d_ls, s.d_li, s.cs);
+      if (rc) return rc;
+    }
+  } else {
+    for (int i = 0; i < R; ++i) {
+      Shard& s = c->sh[i];
+      rc = mv_internal_query_common(s.ix, q, q_dtype, n_q_rows, k, mode, allow_bits, n_allow_words, nullptr, nullptr, nullptr, s.d_ls, s.d_li,
+                                    s.cs, stats ? &stats[i] : nullptr, 1);
+      if (rc) return rc;
+    }
+  }
+  for (int i = 0; i < R; ++i) {
+    Shard& s = c->sh[i];
+    DeviceGuard g(s.dev);
+    MV_HIP(hipEventRecord(s.ev_t1, s.cs));
+  }
+  // ---- exchange of the k (score, id) pairs and merge
+  float* hs = c->h_s + (size_t)R * kK;
+  int64_t* hi = c->h_i + (size_t)R * kK;
+  int n_out = 0;
+  if (c->transport == MV_COMM_HOST) {
+    for (int i = 0; i < R; ++i) {
+      Shard& s = c->sh[i];
+      DeviceGuard g(s.dev);
+      MV_HIP(hipMemcpyAsync(c->h_s + (size_t)i * k, s.d_ls, (size_t)k * 4, hipMemcpyDeviceToHost, s.cs));
+      MV_HIP(hipMemcpyAsync(c->h_i + (size_t)i * k, s.d_li, (size_t)k * 8, hipMemcpyDeviceToHost, s.cs));
+    }
+    rc = sync_all(c);
+    if (rc) return rc;
+    host_merge(c->h_s, c->h_i, R, k, k, hs, hi, &n_out);
+  } else {
+    rc = exchange(c, (size_t)k * 4, false, src_ls, dst_gs);
+    if (!rc) rc = exchange(c, (size_t)k * 8, false, src_li, dst_gi);
+    if (rc) return rc;
+    Shard& z = c->sh[0];
+    DeviceGuard g(z.dev);
+    if ((int64_t)R * k <= 2048) {
+      rc = launch_merge_topk(z.d_gs, z.d_gi, R, k, k, c->d_os, c->d_oi, z.cs);
+      if (rc) return rc;
+      MV_HIP(hipMemcpyAsync(hs, c->d_os, (size_t)k * 4, hipMemcpyDeviceToHost, z.cs));
+      MV_HIP(hipMemcpyAsync(hi, c->d_oi, (size_t)k * 8, hipMemcpyDeviceToHost, z.cs));
+      rc = sync_all(c);
+      if (rc) return rc;
+      while (n_out < k && hi[n_out] >= 0) ++n_out;
+    } else {  // beyond the merge kernel's 2048 keys: gather on the device, merge on the host
+      MV_HIP(hipMemcpyAsync(c->h_s, z.d_gs, (size_t)R * k * 4, hipMemcpyDeviceToHost, z.cs));
+      MV_HIP(hipMemcpyAsync(c->h_i, z.d_gi, (size_t)R * k * 8, hipMemcpyDeviceToHost, z.cs));
+      rc = sync_all(c);
+      if (rc) return rc;
+      host_merge(c->h_s, c->h_i, R, k, k, hs, hi, &n_out);
+    }
+  }
+  memcpy(out_scores, hs, (size_t)n_out * 4);
+  memcpy(out_ids, hi, (size_t)n_out * 8);
+  *out_n = n_out;
+  if (stats) {
+    for (int i = 0; i < R; ++i) {
+      Shard& s = c->sh[i];
+      DeviceGuard g(s.dev);
+      float whole = 0.f;
+      if (!two_stage) {
+        std::lock_guard<std::mutex> ql(s.ix->q_mu);
+        rc = finish_stats(s.ix, &stats[i], true);
+        if (rc) return rc;
+      }
+      MV_HIP(hipEventElapsedTime(&whole, s.ev_t0, s.ev_t1));
+      stats[i].total_device_ms = whole;  // the shard's whole local span on its comm stream
+    }
+  }
+  return MV_OK;
+}
+
+}  // extern "C"

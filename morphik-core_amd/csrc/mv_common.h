@@ -38,6 +38,7 @@ struct MaxsimArgs {
   int32_t stride;           // rows per page slot
   int32_t q_tiles;          // q_rows_padded / 16 (1..4)
   int32_t pad_to;           // zero-padding clamp: pages with n_rows < pad_to clamp each token max at 0
+  const int32_t* pad_items; // per-item pad_to (device; the reference pads every rerank batch of 128 on its own); null -> pad_to
 };
 // variant: -1 default; see DESIGN.md "Kernel variants".
 int launch_maxsim_bf16(const MaxsimArgs& a, int variant, hipStream_t s);
@@ -168,6 +169,7 @@ struct Fp8ScanArgs {
   int64_t n;
   int32_t stride;
   int32_t pad_to;
+  const int32_t* pad_items;  // per-item pad_to (device); null -> pad_to
 };
 int launch_maxsim_fp8(const Fp8ScanArgs& a, hipStream_t s);
 

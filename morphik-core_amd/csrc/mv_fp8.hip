@@ -194,6 +194,7 @@ struct F8Args {
   int32_t pad_to;
   int64_t page0;
   int32_t accumulate;
+  const int32_t* pad_items;  // per-item pad_to; null -> pad_to
 };
 
 __device__ __forceinline__ bool f8_masked(const F8Args& a, int64_t page) {
@@ -232,14 +233,14 @@ __global__ __launch_bounds__(256) void maxsim_fp8_kernel(F8Args a) {
   const int64_t item = blockIdx.x;
   if (item >= a.n) return;
   const int64_t page = a.cand ? (int64_t)a.cand[item] : a.page0 + item;
-  if (f8_masked(a, page)) {
+  if (page < 0 || f8_masked(a, page)) {  // page < 0: padding entry of a device-built candidate list
     if (threadIdx.x == 0) a.scores[item] = -INFINITY;
     return;
   }
   const int nr = a.n_rows ? a.n_rows[page] : a.stride;
   const int ntiles = (nr + 15) >> 4;
   const int nslots = (nr + kF8SlotRows - 1) / kF8SlotRows;
-  const bool clamp = a.pad_to > nr;
+  const bool clamp = (a.pad_items ? a.pad_items[item] : a.pad_to) > nr;
   const int nsw = (nslots - wave + 3) / 4;  // slots owned by this wave (may be <= 0)
   const char* pbase = reinterpret_cast<const char*>(a.slab) + (size_t)page * (size_t)a.stride * kF8RowBytes;
   char* ring = lds + wave * (D * kF8SlotBytes);
@@ -387,6 +388,7 @@ int launch_f8_mt(const F8Args& k0, hipStream_t s) {
     k.scores = k0.scores + off;
     if (k0.cand) k.cand = k0.cand + off;
     else k.page0 = k0.page0 + off;
+    if (k0.pad_items) k.pad_items = k0.pad_items + off;
     hipLaunchKernelGGL((maxsim_fp8_kernel<MT, 4>), dim3((unsigned)k.n), dim3(256), 0, s, k);
   }
   MV_HIP(hipGetLastError());
@@ -421,7 +423,7 @@ int launch_maxsim_fp8(const Fp8ScanArgs& a, hipStream_t s) {
   for (int q0 = 0, pass = 0; q0 < padded; q0 += 64, ++pass) {
     const int mt = std::min(4, (padded - q0) / 16);
     F8Args k{a.slab, a.inv_scale, a.n_rows, a.doc_ord, a.allow, a.n_allow_bits, a.cand,
-             a.qhi + (size_t)q0 * kDim, a.qlo + (size_t)q0 * kDim, a.qfac + q0, a.scores, a.n, a.stride, a.pad_to, 0, pass > 0};
+             a.qhi + (size_t)q0 * kDim, a.qlo + (size_t)q0 * kDim, a.qfac + q0, a.scores, a.n, a.stride, a.pad_to, 0, pass > 0, a.pad_items};
     int rc;
     switch (mt) {
       case 1: rc = launch_f8_mt<1>(k, s); break;

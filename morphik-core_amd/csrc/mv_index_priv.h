@@ -1,0 +1,141 @@
+// mv_index_priv.h -- the mv_index object shared by mv_api.hip (single-index C ABI) and mv_comm.hip
+// (multi-shard communicator).  Not part of the public ABI.
+//
+// Concurrency model ("append-only slab + atomic published length"):
+//   * `size` is the PUBLISHED page count.  A query snapshots it once (acquire) and never looks past it.
+//   * Writers (mv_index_add*, fill_synthetic, remove_*) serialise on `w_mu`, work on `w_stream` with their own
+//     staging buffers, fill slab slots [size, size+n) that no query can see yet, and publish the new size
+//     (release) only after the device work has completed.  They never take `q_mu`: an ingest does not block queries.
+//   * Queries serialise on `q_mu` (there is ONE per-query workspace and one GPU to saturate).
+//   * Operations that move or rewrite PUBLISHED pages (compact, replace_page, write_rows, save) take both, in the
+//     order w_mu -> q_mu.
+//   * Tombstoning (remove_*) rewrites 4-byte doc ordinals of published pages in place; a scan in flight sees the
+//     old or the new value of each, i.e. it is ordered before or after the removal page by page.
+#pragma once
+#include <atomic>
+#include <mutex>
+#include <vector>
+
+#include "mv_common.h"
+
+constexpr int kMaxQRowsPerPass = 128;  // 8 MFMA row tiles held in VGPRs
+constexpr int kMaxCand = 65536;
+constexpr int kRerankBatch = 128;      // score_multi_vector scores passages in batches of 128, each padded on its own
+
+struct mv_index {
+  mv_config cfg{};
+  hipStream_t stream = nullptr;    // query stream
+  hipStream_t w_stream = nullptr;  // writer stream (ingest runs beside the scans)
+  // slabs
+  uint16_t* slab = nullptr;
+  uint8_t* bits = nullptr;
+  uint16_t* fde = nullptr;
+  float* fde_inv_norm = nullptr;
+  uint8_t* slab8 = nullptr;      // e4m3 page slab [capacity][stride][128]
+  float* inv_scale8 = nullptr;   // [capacity] 2^-e per page
+  int32_t* d_n_rows = nullptr;
+  int32_t* d_doc_ord = nullptr;
+  std::vector<int32_t> h_n_rows, h_doc_ord;  // sized to capacity at create: never reallocated
+  std::atomic<int64_t> size{0};              // published pages
+  std::atomic<bool> ragged{false};           // some page has n_rows != stride
+  std::atomic<bool> tombstones{false};       // some page is deleted
+  std::atomic<int32_t> max_doc_ord{-1};      // largest document ordinal seen (filter selectivity estimate)
+  mv::FdeTables fde_t;
+  // per-query workspace (q_mu)
+  float* d_scores = nullptr;   // [capacity]
+  float* d_scores2 = nullptr;  // [capacity] (second accumulator for > 64 query rows)
+  void* d_topk_ws = nullptr;
+  size_t topk_ws_bytes = 0;
+  uint16_t* d_q = nullptr;     // bf16 query, padded
+  float* d_qf32 = nullptr;     // fp32 query rows (FDE encode input)
+  uint8_t* d_qbits = nullptr;
+  float* d_qpop = nullptr;     // popc per query row (binary MFMA scan)
+  uint8_t* d_q8hi = nullptr;   // e4m3 query rows, two-term split (fp8 scan)
+  uint8_t* d_q8lo = nullptr;
+  float* d_q8fac = nullptr;    // 2^-s per query row
+  uint16_t* d_bq = nullptr;    // [512][128] bf16 query block of the batched scan
+  float* d_bscores = nullptr;  // [32][capacity] per-query score vectors of the batched scan (lazily allocated)
+  int32_t* d_fcand = nullptr;  // [capacity] pages a selective doc filter lets through (lazily allocated)
+  int32_t* d_fcounts = nullptr;
+  int filter_compact_pct = 25; // compact when the filter allows less than this share of the documents (0 = never)
+  float* d_qfde = nullptr;
+  int64_t* d_qoff = nullptr;   // [2] row offsets for the query "page"
+  uint32_t* d_allow = nullptr;
+  int64_t allow_cap_words = 0;
+  float* d_out_s = nullptr;    // [kTopkMaxDeviceK]
+  int64_t* d_out_id = nullptr;
+  int32_t* d_cand = nullptr;   // [kMaxCand] candidate pages of a rerank (-1 = padding entry)
+  int32_t* d_cand_pads = nullptr;  // [kMaxCand] pad_to of each candidate (its batch-of-128's longest page)
+  float* d_cand_scores = nullptr;
+  mv_cand_rec* d_recs = nullptr;   // [kTopkMaxDeviceK] coarse candidates of the sharded two-stage pipeline
+  int64_t* d_sel_pos = nullptr;    // [kTopkMaxDeviceK] positions of the global coarse top-n inside the gathered records
+  float* d_gscores = nullptr;      // gathered coarse scores (two-stage rerank), grown on demand
+  int64_t gscores_cap = 0;
+  int q_rows_cap = 0;
+  // pinned host staging of the query (fp32 + padded bf16) and of the k results: async copies, no sync on the way in
+  float* h_qf32 = nullptr;
+  uint16_t* h_qbf16 = nullptr;
+  float* h_out_s = nullptr;
+  int64_t* h_out_id = nullptr;
+  int32_t* h_cand = nullptr;       // [kTopkMaxDeviceK] pinned: candidate ids read back for the accounting only
+  hipEvent_t ev_stage = nullptr;  // recorded behind the H2D copies of the staging buffers
+  hipEvent_t ev[6] = {};
+  std::mutex q_mu;  // queries + the per-query workspace
+  std::mutex w_mu;  // writers
+  // writer-side staging (w_mu): grown on demand, never freed while a scan may run (hipFree synchronises the device)
+  void* w_stage = nullptr;
+  size_t w_stage_bytes = 0;
+  void* w_aux = nullptr;       // row offsets / sign rows of the batch being added
+  size_t w_aux_bytes = 0;
+  void* w_tmp = nullptr;       // fixed-stride bf16 image of the batch when the index keeps no float slab
+  size_t w_tmp_bytes = 0;
+  // options
+  int maxsim_variant = -1;
+  int binary_variant = -1;
+  int fde_scan_variant = -1;
+  int batch_variant = -1;      // -1 = auto: pipelined kernel up to 384 query rows, 512-row kernel above
+  int long_query_variant = 1;  // 1 = single queries > 64 rows use the row-split (batched) workgroup; 0 = page-split passes
+  int fde_encode_variant = 1;  // 1 = f32-MFMA kernel, 0 = scalar kernel
+  int64_t fde_coarse_n = 0;
+  int fde_cosine = 1;
+  int pad_semantics = -1;  // -1: mode default (reference batch rule for FDE_THEN_FLOAT / candidates, none for full scan)
+};
+
+namespace mv {
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    (void)hipGetDevice(&prev);
+    if (prev != dev) (void)hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (prev >= 0 && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+// Scan result left on the device (mv_api.hip).
+struct ScanResult {
+  const float* d_scores = nullptr;  // per work item
+  int64_t n = 0;
+  const int32_t* d_ids_map = nullptr;  // work item -> local page (candidate list) or null
+  int launches = 0;
+  int64_t pages = 0;
+  int64_t bytes = 0;
+};
+
+// Internal entry points of mv_api.hip used by mv_comm.hip.  Callers hold ix->q_mu and have the index's device current.
+int upload_query(mv_index* ix, const void* q, int q_dtype, int n_q, bool want_bf16, bool want_f32, bool want_bits, bool want_fp8);
+int upload_allow(mv_index* ix, const uint32_t* allow_bits, int64_t n_words, const uint32_t** d_allow);
+int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_words, int64_t n, int* launches);
+int rerank_scan(mv_index* ix, int n_q, bool use_fp8, int64_t n_items, float* d_out, int* launches);
+int64_t coarse_n_for(const mv_index* ix, int k);
+int finish_stats(mv_index* ix, mv_query_stats* st, bool had_topk);
+
+}  // namespace mv
+
+extern "C" int mv_internal_query_common(mv_index* ix, const void* q, int q_dtype, int32_t n_q, int32_t k, int mode,
+                                        const uint32_t* allow_bits, int64_t n_words, float* h_scores, int64_t* h_ids, int32_t* out_n,
+                                        float* d_scores_out, int64_t* d_ids_out, void* user_stream, mv_query_stats* st, int defer_stats);

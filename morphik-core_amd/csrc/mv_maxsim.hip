@@ -52,6 +52,7 @@ struct KArgs {
   int32_t stride;
   int32_t pad_to;
   int64_t page0;  // first page of this launch when there is no candidate list
+  const int32_t* pad_items;  // per-item pad_to (rerank batches of 128 pad independently); null -> pad_to
 };
 
 __device__ __forceinline__ bool page_masked(const KArgs& a, int64_t page) {
@@ -155,13 +156,13 @@ __global__ __launch_bounds__(256) void maxsim_direct_kernel(KArgs a) {
   const int64_t item = (WPP == 1) ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
   if (item >= a.n) return;
   const int64_t page = a.cand ? (int64_t)a.cand[item] : a.page0 + item;
-  if (page_masked(a, page)) {
+  if (page < 0 || page_masked(a, page)) {  // page < 0: padding entry of a device-built candidate list
     if (lane == 0 && (WPP == 1 || wave == 0)) a.scores[item] = -INFINITY;
     return;
   }
   const int nr = a.n_rows ? a.n_rows[page] : a.stride;
   const int ntiles = (nr + kTileRows - 1) / kTileRows;
-  const bool clamp = a.pad_to > nr;
+  const bool clamp = (a.pad_items ? a.pad_items[item] : a.pad_to) > nr;
 
   bf16x8 qa[MT][4];
   load_query<MT>(a.q, r, g, qa);
@@ -233,13 +234,13 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
   const int64_t item = (WPP == 1) ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
   if (item >= a.n) return;
   const int64_t page = a.cand ? (int64_t)a.cand[item] : a.page0 + item;
-  if (page_masked(a, page)) {
+  if (page < 0 || page_masked(a, page)) {  // page < 0: padding entry of a device-built candidate list
     if (lane == 0 && (WPP == 1 || wave == 0)) a.scores[item] = -INFINITY;
     return;
   }
   const int nr = a.n_rows ? a.n_rows[page] : a.stride;
   const int ntiles = (nr + kTileRows - 1) / kTileRows;
-  const bool clamp = a.pad_to > nr;
+  const bool clamp = (a.pad_items ? a.pad_items[item] : a.pad_to) > nr;
 
   f32x4 mx[MT];
 #pragma unroll
@@ -362,6 +363,7 @@ int launch_mt(const KArgs& k0, int variant, hipStream_t s) {
     k.scores = k0.scores + off;
     if (k0.cand) k.cand = k0.cand + off;
     else k.page0 = k0.page0 + off;
+    if (k0.pad_items) k.pad_items = k0.pad_items + off;
     const int64_t n = k.n;
     switch (variant) {
       case 0: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 1, false>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
@@ -423,7 +425,7 @@ int launch_maxsim_bf16(const MaxsimArgs& a, int variant, hipStream_t s) {
     return MV_ERR_INVALID;
   }
   KArgs k{reinterpret_cast<const char*>(a.slab), a.n_rows, a.doc_ord, a.allow, a.n_allow_bits, a.cand, a.q, a.scores,
-          a.n, a.stride, a.pad_to, 0};
+          a.n, a.stride, a.pad_to, 0, a.pad_items};
   switch (a.q_tiles) {
     case 1: return launch_mt<1>(k, variant, s);
     case 2: return launch_mt<2>(k, variant, s);

@@ -16,7 +16,7 @@ namespace {
 
 constexpr int kChunk = 2048;
 constexpr int kThreads = 256;
-constexpr size_t kRadixTailBytes = 4096 * 8 + 2048 * 4 + 64;  // survivors + histogram + state (radix path, k > 32)
+constexpr size_t kRadixTailBytes = 4096 * 8 + 2048 * 4 + 64;  // [survivors][histogram][RadixState]  // survivors + histogram + state (radix path, k > 32)
 
 __device__ __forceinline__ uint32_t ordered_u32(float f) {
   uint32_t u = __float_as_uint(f);
@@ -192,9 +192,15 @@ struct RadixState {
   uint32_t prefix_mask;
   uint32_t k_remaining;
   uint32_t count;  // compaction counter
+  uint32_t done;   // 1 = the radix path produced the result; 0 = more than kRadixCap survivors -> serial fallback runs
 };
 constexpr int kRadixBins = 2048;
 constexpr int kRadixCap = 4096;
+
+__global__ __launch_bounds__(256) void radix_init_kernel(RadixState* st, uint32_t* hist, uint32_t k) {
+  for (int i = threadIdx.x; i < kRadixBins; i += 256) hist[i] = 0;
+  if (threadIdx.x == 0) *st = RadixState{0u, 0u, k, 0u, 0u};
+}
 
 __global__ __launch_bounds__(256) void radix_hist_kernel(const float* scores, int64_t n, int shift, int nbits, const RadixState* st,
                                                          uint32_t* hist) {
@@ -214,22 +220,45 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const float* scores, in
     if (h[i]) atomicAdd(&hist[i], h[i]);
 }
 
-// one wave: walk the bins from the top until the cumulative count reaches k_remaining; fix those bits of the threshold
-__global__ void radix_pick_kernel(uint32_t* hist, int nbits, int shift, RadixState* st) {
-  if (threadIdx.x == 0) {
-    const int nb = 1 << nbits;
-    uint32_t kr = st->k_remaining, cum = 0;
-    int b = nb - 1;
-    for (; b > 0; --b) {
-      if (cum + hist[b] >= kr) break;
-      cum += hist[b];
-    }
-    st->k_remaining = kr - cum;  // still needed inside bin b (bin 0 absorbs a k beyond the number of valid scores)
-    st->prefix_val |= (uint32_t)b << shift;
-    st->prefix_mask |= ((1u << nbits) - 1u) << shift;
+// One block of 256 threads, 8 bins each: the bin b >= 1 (highest first) where the count of keys in higher bins is still
+// below k_remaining but reaches it with bin b; none -> bin 0 (absorbs a k beyond the number of valid scores).  Fixes
+// those bits of the threshold, then clears the histogram for the next pass.
+__global__ __launch_bounds__(256) void radix_pick_kernel(uint32_t* hist, int nbits, int shift, RadixState* st) {
+  __shared__ uint32_t part[256];
+  __shared__ uint32_t found_bin, found_above;
+  const int t = threadIdx.x;
+  uint32_t loc[8], sum = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { loc[j] = hist[t * 8 + j]; sum += loc[j]; }  // bins beyond 1 << nbits are zero
+  part[t] = sum;
+  if (t == 0) { found_bin = 0u; found_above = 0xffffffffu; }
+  __syncthreads();
+  // inclusive suffix sum over threads (Hillis-Steele), then exclusive = inclusive - own
+  uint32_t v = sum;
+  for (int d = 1; d < 256; d <<= 1) {
+    const uint32_t o = (t + d < 256) ? part[t + d] : 0u;
+    __syncthreads();
+    v += o;
+    part[t] = v;
+    __syncthreads();
+  }
+  const uint32_t kr = st->k_remaining;
+  uint32_t above = v - sum;  // keys in bins owned by higher threads
+#pragma unroll
+  for (int j = 7; j >= 0; --j) {
+    const int b = t * 8 + j;
+    if (b >= 1 && above < kr && above + loc[j] >= kr) { found_bin = (uint32_t)b; found_above = above; }
+    above += loc[j];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < kRadixBins; i += blockDim.x) hist[i] = 0;
+  if (t == 0) {
+    // not found: bin 0, with every key of bins >= 1 above it (part[0] = total, loc[0] = bin 0 of thread 0)
+    const uint32_t cum = found_above != 0xffffffffu ? found_above : part[0] - loc[0];
+    st->k_remaining = kr - cum;
+    st->prefix_val |= found_bin << shift;
+    st->prefix_mask |= ((1u << nbits) - 1u) << shift;
+  }
+  for (int i = t; i < kRadixBins; i += 256) hist[i] = 0;
 }
 
 __global__ __launch_bounds__(256) void radix_compact_kernel(const float* scores, int64_t n, RadixState* st, uint64_t* out) {
@@ -244,6 +273,74 @@ __global__ __launch_bounds__(256) void radix_compact_kernel(const float* scores,
       }
     }
   }
+}
+
+__device__ __forceinline__ void topk_write_out(const uint64_t* sk, const TopkOut& o) {
+  for (int i = threadIdx.x; i < o.k; i += kThreads) {
+    const uint64_t key = sk[i];
+    if (key == 0) {
+      o.out_s[i] = -INFINITY;
+      o.out_id[i] = -1;
+    } else {
+      const uint32_t idx = ~(uint32_t)(key & 0xffffffffu);
+      o.out_s[i] = unordered_f32((uint32_t)(key >> 32));
+      o.out_id[i] = o.id_base + (o.ids_map ? (int64_t)o.ids_map[idx] : (int64_t)idx);
+    }
+  }
+}
+
+// Last step of the radix path: ONE block sorts the survivors (their number is read from the device state, so the host
+// never waits for it) and writes the k results.  More than kRadixCap survivors: leaves done = 0 for the fallback.
+__global__ __launch_bounds__(kThreads) void radix_final_kernel(const uint64_t* surv, RadixState* st, int kk, TopkOut o) {
+  __shared__ uint64_t sk[kChunk];
+  __shared__ uint64_t best[kChunk];
+  const uint32_t cnt = st->count;
+  if (cnt > (uint32_t)kRadixCap) return;  // done stays 0
+  const int sub = cnt > (uint32_t)kChunk ? 2 : 1;
+  for (int sc = 0; sc < sub; ++sc) {
+    for (int i = threadIdx.x; i < kChunk; i += kThreads) {
+      const uint32_t gi = (uint32_t)sc * kChunk + i;
+      sk[i] = gi < cnt ? surv[gi] : 0;
+    }
+    __syncthreads();
+    bitonic_sort_desc(sk);
+    if (sub > 1) {
+      for (int i = threadIdx.x; i < kk; i += kThreads) best[sc * kk + i] = sk[i];
+      __syncthreads();
+    }
+  }
+  if (sub > 1) {
+    for (int i = threadIdx.x; i < kChunk; i += kThreads) sk[i] = i < 2 * kk ? best[i] : 0;
+    __syncthreads();
+    bitonic_sort_desc(sk);
+  }
+  topk_write_out(sk, o);
+  if (threadIdx.x == 0) st->done = 1u;
+}
+
+// Fallback of the radix path (masses of equal scores at the threshold): one block streams the whole score vector,
+// keeping the best kk (<= 1024) keys in the lower half of a 2048-key LDS array and sorting 1024 new keys against them
+// per step.  Slow (one block), deterministic, and launched unconditionally BEHIND radix_final_kernel so that the
+// selection never needs a host decision: it returns at once when done == 1.
+__global__ __launch_bounds__(kThreads) void topk_serial_fallback_kernel(const float* scores, int64_t n, const RadixState* st, TopkOut o) {
+  __shared__ uint64_t sk[kChunk];
+  if (st->done) return;
+  constexpr int kHalf = kChunk / 2;
+  for (int i = threadIdx.x; i < kHalf; i += kThreads) sk[i] = 0;
+  for (int64_t base = 0; base < n; base += kHalf) {
+    for (int i = threadIdx.x; i < kHalf; i += kThreads) {
+      const int64_t gi = base + i;
+      uint64_t key = 0;
+      if (gi < n) {
+        const float s = scores[gi] + 0.0f;
+        if (s == s && s != -INFINITY) key = ((uint64_t)ordered_u32(s) << 32) | (uint32_t)(~(uint32_t)gi);
+      }
+      sk[kHalf + i] = key;
+    }
+    __syncthreads();
+    bitonic_sort_desc(sk);  // best 1024 of (previous best, new 1024) end up in the lower half
+  }
+  topk_write_out(sk, o);
 }
 
 inline int64_t nblocks(int64_t n) { return (n + kChunk - 1) / kChunk; }
@@ -325,14 +422,13 @@ int launch_topk(const float* d_scores, int64_t n, int32_t k, const int32_t* d_id
   const uint64_t* in = nullptr;
   uint64_t* outk = bufA;
   if (k > 32 && cur_n > 2 * kChunk) {
-    // radix threshold + compaction; workspace tail: [survivors 4096 x u64][hist 2048 x u32][state]
+    // radix threshold + compaction; workspace tail: [survivors 4096 x u64][hist 2048 x u32][state].  Entirely in stream
+    // order: the survivor count never comes back to the host.
     char* tail = reinterpret_cast<char*>(ws) + topk_ws_bytes(n, k) - kRadixTailBytes;
     uint64_t* surv = reinterpret_cast<uint64_t*>(tail);
     uint32_t* hist = reinterpret_cast<uint32_t*>(tail + kRadixCap * 8);
     RadixState* st = reinterpret_cast<RadixState*>(tail + kRadixCap * 8 + kRadixBins * 4);
-    const RadixState init{0u, 0u, (uint32_t)k, 0u};
-    MV_HIP(hipMemsetAsync(hist, 0, kRadixBins * 4, s));
-    MV_HIP(hipMemcpyAsync(st, &init, sizeof(init), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(radix_init_kernel, dim3(1), dim3(256), 0, s, st, hist, (uint32_t)k);
     const int grid = (int)std::min<int64_t>((cur_n + 255) / 256, 256 * 8);
     const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
     for (int p = 0; p < 3; ++p) {
@@ -340,17 +436,10 @@ int launch_topk(const float* d_scores, int64_t n, int32_t k, const int32_t* d_id
       hipLaunchKernelGGL(radix_pick_kernel, dim3(1), dim3(256), 0, s, hist, bits[p], shifts[p], st);
     }
     hipLaunchKernelGGL(radix_compact_kernel, dim3((unsigned)grid), dim3(256), 0, s, sc, cur_n, st, surv);
-    RadixState fin{};
-    MV_HIP(hipMemcpyAsync(&fin, st, sizeof(fin), hipMemcpyDeviceToHost, s));
-    MV_HIP(hipStreamSynchronize(s));
-    if (fin.count <= (uint32_t)kRadixCap) {
-      const int sub = (int)std::max<uint32_t>(1u, (fin.count + kChunk - 1) / kChunk);
-      hipLaunchKernelGGL(topk_level_kernel, dim3(1), dim3(kThreads), 0, s, (const float*)nullptr, (const uint64_t*)surv, (int64_t)fin.count,
-                         (int)k, outk, sub, 1, out);
-      MV_HIP(hipGetLastError());
-      return MV_OK;
-    }
-    // too many ties at the threshold: fall through to the sort cascade
+    hipLaunchKernelGGL(radix_final_kernel, dim3(1), dim3(kThreads), 0, s, (const uint64_t*)surv, st, (int)k, out);
+    hipLaunchKernelGGL(topk_serial_fallback_kernel, dim3(1), dim3(kThreads), 0, s, sc, cur_n, (const RadixState*)st, out);
+    MV_HIP(hipGetLastError());
+    return MV_OK;
   }
   while (true) {
     const int sub = pick_sub(cur_n);

@@ -317,24 +317,47 @@ class MvIndex:
 
     def score_all(self, q: Any, mode: str = "float", allow: Optional[np.ndarray] = None, want_stats: bool = False):
         qa, code = as_rows(q)
-        out = np.empty(max(len(self), 1), np.float32)
+        out = np.empty(max(len(self), 1), np.float32)  # the library never writes past this, even if the corpus grows meanwhile
+        n = C.c_int64()
         st = QueryStatsC()
         ab = None if allow is None else np.ascontiguousarray(allow, dtype=np.uint32)
         check(
             lib().mv_score_all(
                 self._h, qa.ctypes.data, code, qa.shape[0], MODES[mode], None if ab is None else ab.ctypes.data,
-                0 if ab is None else ab.size, out.ctypes.data, C.byref(st) if want_stats else None,
+                0 if ab is None else ab.size, out.ctypes.data, out.size, C.byref(n), C.byref(st) if want_stats else None,
             )
         )
-        out = out[: len(self)]
+        out = out[: n.value]
         return (out, QueryStats.from_c(st)) if want_stats else out
 
-    def score_candidates(self, q: Any, cand: Sequence[int], pad_to: int = 0) -> np.ndarray:
+    def score_candidates(self, q: Any, cand: Sequence[int], pad_to: int = 0, pads: Optional[Sequence[int]] = None) -> np.ndarray:
+        """Exact float MaxSim of the named local pages, in list order.  pad_to = -1: the reference rule (every batch of
+        128 candidates is zero-padded to its own longest page); 0: none; > 0: one length for all.  `pads` = an explicit
+        pad length per candidate (row-sharded rerank: the batch is the GLOBAL list's)."""
         qa, code = as_rows(q)
         c = np.ascontiguousarray(cand, dtype=np.int32)
         out = np.empty(max(c.size, 1), np.float32)
-        check(lib().mv_score_candidates(self._h, qa.ctypes.data, code, qa.shape[0], c.ctypes.data, c.size, int(pad_to), out.ctypes.data, None))
+        if pads is not None:
+            pd = np.ascontiguousarray(pads, dtype=np.int32)
+            if pd.size != c.size:
+                raise ValueError("pads must have one entry per candidate")
+            check(lib().mv_score_candidates_pads(self._h, qa.ctypes.data, code, qa.shape[0], c.ctypes.data, c.size, pd.ctypes.data, out.ctypes.data, None))
+        else:
+            check(lib().mv_score_candidates(self._h, qa.ctypes.data, code, qa.shape[0], c.ctypes.data, c.size, int(pad_to), out.ctypes.data, None))
         return out[: c.size]
+
+    # -- sharded two-stage pipeline (device-resident stages; see include/mvmaxsim.h)
+    def two_stage_coarse_device(self, q: Any, n_coarse: int, d_recs_ptr: int, allow: Optional[np.ndarray] = None, stream: int = 0) -> None:
+        qa, code = as_rows(q)
+        ab = None if allow is None else np.ascontiguousarray(allow, dtype=np.uint32)
+        check(lib().mv_two_stage_coarse_device(self._h, qa.ctypes.data, code, qa.shape[0], int(n_coarse), None if ab is None else ab.ctypes.data,
+                                               0 if ab is None else ab.size, C.c_void_p(d_recs_ptr), C.c_void_p(stream) if stream else None))
+
+    def two_stage_rerank_device(self, q: Any, d_all_recs_ptr: int, world: int, n_coarse: int, k: int, d_scores_ptr: int, d_ids_ptr: int,
+                                stream: int = 0) -> None:
+        qa, code = as_rows(q)
+        check(lib().mv_two_stage_rerank_device(self._h, qa.ctypes.data, code, qa.shape[0], C.c_void_p(d_all_recs_ptr), int(world), int(n_coarse), int(k),
+                                               C.c_void_p(d_scores_ptr), C.c_void_p(d_ids_ptr), C.c_void_p(stream) if stream else None))
 
     def page_rows(self, pages: Sequence[int]) -> np.ndarray:
         """Row counts of local pages (host metadata; no device work)."""
@@ -411,7 +434,55 @@ def calibrate_read_bw(bytes_: int = 8 << 30, iters: int = 5, device: int = 0) ->
 
 
 def calibrate(what: str, bytes_: int = 8 << 30, iters: int = 5, device: int = 0) -> float:
-    """Measured peaks (same process as the measurement): "read_nt" -> GB/s, "mfma_bf16" -> TFLOP/s."""
+    """Measured peaks (same process as the measurement): "read_nt" / "read_ldsdma" -> GB/s, "mfma_bf16" -> TFLOP/s."""
     g = C.c_double()
-    check(lib().mv_calibrate(device, {"read_nt": _lib.MV_CAL_READ_NT, "mfma_bf16": _lib.MV_CAL_MFMA_BF16}[what], bytes_, iters, C.byref(g)))
+    code = {"read_nt": _lib.MV_CAL_READ_NT, "mfma_bf16": _lib.MV_CAL_MFMA_BF16, "read_ldsdma": _lib.MV_CAL_READ_LDSDMA}[what]
+    check(lib().mv_calibrate(device, code, bytes_, iters, C.byref(g)))
     return float(g.value)
+
+
+class ShardComm:
+    """mv_comm: R MvIndex shards driven from ONE process (one GPU each, or logical shards on one GPU).  Shard i must own
+    the global ids [id_base_i, id_base_i + len_i), ascending with i.  query() returns what ONE index holding every page
+    would return (same order, same tie rule)."""
+
+    TRANSPORTS = {"auto": _lib.MV_COMM_AUTO, "rccl": _lib.MV_COMM_RCCL, "p2p": _lib.MV_COMM_P2P, "host": _lib.MV_COMM_HOST}
+
+    def __init__(self, shards: Sequence["MvIndex"], transport: str = "auto"):
+        self.shards = list(shards)
+        devs = np.ascontiguousarray([s.device for s in self.shards], dtype=np.int32)
+        h = C.c_void_p()
+        check(lib().mv_comm_create(len(self.shards), devs.ctypes.data, self.TRANSPORTS[transport], C.byref(h)))
+        self._h = h
+        for i, s in enumerate(self.shards):
+            check(lib().mv_comm_attach(self._h, i, s._h))
+
+    @property
+    def transport(self) -> str:
+        code = lib().mv_comm_transport(self._h)
+        return {v: k for k, v in self.TRANSPORTS.items()}[code]
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().mv_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def query(self, q: Any, k: int, mode: str = "float", allow: Optional[np.ndarray] = None, want_stats: bool = False):
+        qa, code = as_rows(q)
+        k = int(k)
+        scores = np.empty(max(k, 1), np.float32)
+        ids = np.empty(max(k, 1), np.int64)
+        n = C.c_int32()
+        ab = None if allow is None else np.ascontiguousarray(allow, dtype=np.uint32)
+        st = (QueryStatsC * len(self.shards))()
+        check(lib().mv_comm_query_topk(self._h, qa.ctypes.data, code, qa.shape[0], k, MODES[mode], None if ab is None else ab.ctypes.data,
+                                       0 if ab is None else ab.size, scores.ctypes.data, ids.ctypes.data, C.byref(n),
+                                       C.cast(st, C.c_void_p) if want_stats else None))
+        res = (scores[: n.value].copy(), ids[: n.value].copy())
+        return res + ([QueryStats.from_c(x) for x in st],) if want_stats else res

@@ -196,15 +196,19 @@ class TwoStageShardedSearcher:
       1. every rank: FDE coarse scan of its shard -> local top-n (score, global id)
       2. all-gather of n pairs per rank (16 B each) -> global coarse top-n, identical on every rank
       3. every rank keeps the candidates IT OWNS; the candidates' row counts travel in the same all-gather, so every
-         rank knows the pad-to-longest length of the reference's rerank batch (pad_sequence, :553-555)
+         rank knows the pad length of each candidate: the longest page of ITS batch of 128 in the GLOBAL list
+         (score_multi_vector scores passages in batches of 128, each padded on its own by pad_sequence, :553-555)
       4. every rank: exact MaxSim of its own candidates (no embedding crosses xGMI) -> local top-k
       5. all-gather of k pairs per rank -> merged top-k
 
-    Two small collectives, both latency-bound.  The callables keep the class testable on CPU (gloo + oracle):
+    Two small collectives, both latency-bound.  This class is the host-driven form whose callables keep it testable on
+    CPU (gloo + oracle); GpuTwoStageSearcher below is the device-resident form of the same steps.
       local_coarse(q, n, allow) -> (scores[n], ids[n]) tensors on the collective's device, padded (-inf, -1), GLOBAL ids
       local_rows(global_ids)    -> int array of row counts of owned pages
-      local_rerank(q, global_ids, pad_to) -> float32 array of exact MaxSim scores of owned pages
+      local_rerank(q, global_ids, pads) -> float32 array of exact MaxSim scores of owned pages (pads[i] = pad length)
     `id_range` = [lo, hi) of global ids this rank owns."""
+
+    BATCH = 128  # score_multi_vector's passage batch size
 
     def __init__(self, local_coarse: Callable, local_rows: Callable, local_rerank: Callable, id_range: Tuple[int, int],
                  group=None, pad_semantics: bool = True):
@@ -212,31 +216,38 @@ class TwoStageShardedSearcher:
         self.lo, self.hi = int(id_range[0]), int(id_range[1])
         self.group, self.pad = group, pad_semantics
 
-    # The three local phases are public so that R logical shards on ONE device can be driven without a process group
+    # The local phases are public so that R logical shards on ONE device can be driven without a process group
     # (tests; SURVEY 8e "R logical shards on one device"); query() chains them with the collectives in between.
     def coarse(self, q, k: int, coarse_n: Optional[int] = None, allow=None):
         n = int(coarse_n) if coarse_n else min(10 * k, 75)  # reference: top_k = min(10 * k, 75) (:529)
         cs, ci = self.local_coarse(q, n, allow)
         return n, cs, ci
 
-    def owned(self, global_ids):
-        """-> (candidates this rank owns, their longest row count)"""
+    def batch_pads(self, global_ids, global_rows):
+        """Pad length of every entry of the GLOBAL candidate list (coarse rank order): longest page of its batch of 128."""
         import numpy as np
 
-        gid = global_ids.detach().cpu().numpy().astype(np.int64)
-        mine = gid[(gid >= self.lo) & (gid < self.hi)]
-        return mine, (int(self.local_rows(mine).max()) if (self.pad and mine.size) else 0)
+        gid = np.asarray(global_ids, np.int64)
+        rows = np.where(gid >= 0, np.asarray(global_rows, np.int64), 0)
+        pads = np.zeros(gid.size, np.int32)
+        if self.pad:
+            for j in range(0, gid.size, self.BATCH):
+                pads[j : j + self.BATCH] = rows[j : j + self.BATCH].max() if rows[j : j + self.BATCH].size else 0
+        return pads
 
-    def rerank(self, q, mine, longest: int, k: int):
-        """-> local top-k (scores[k], ids[k]) padded with (-inf, -1), ordered (score desc, id asc)"""
+    def rerank(self, q, gid, pads, k: int):
+        """gid / pads: the GLOBAL candidate list and its pad lengths.  -> local top-k (scores[k], ids[k]) of the candidates
+        this rank owns, padded with (-inf, -1), ordered (score desc, coarse rank asc) like a single index."""
         import numpy as np
         import torch
 
         ls = torch.full((k,), float("-inf"), dtype=torch.float32)
         li = torch.full((k,), -1, dtype=torch.int64)
-        if mine.size:
-            sc = np.asarray(self.local_rerank(q, mine, longest if self.pad else 0), np.float32)
-            order = np.lexsort((mine, -sc.astype(np.float64)))[:k]
+        own = np.nonzero((gid >= self.lo) & (gid < self.hi))[0]
+        if own.size:
+            mine = gid[own]
+            sc = np.asarray(self.local_rerank(q, mine, pads[own]), np.float32)
+            order = np.lexsort((own, -sc.astype(np.float64)))[:k]
             ls[: order.size] = torch.from_numpy(sc[order])
             li[: order.size] = torch.from_numpy(mine[order])
         return ls, li
@@ -248,7 +259,7 @@ class TwoStageShardedSearcher:
 
         n, cs, ci = self.coarse(q, k, coarse_n, allow)
         # the row counts of this rank's coarse candidates ride in the same all-gather as their (score, id) pairs, so the
-        # pad-to-longest length of the GLOBAL candidate list needs no collective of its own
+        # pad lengths of the GLOBAL candidate list need no collective of their own
         ids_h = ci.detach().cpu().numpy().astype(np.int64)
         rows_h = np.zeros(n, np.float64)
         if self.pad and (ids_h >= 0).any():
@@ -266,15 +277,13 @@ class TwoStageShardedSearcher:
         order = torch.sort(gs, descending=True, stable=True).indices[:n]  # (score desc, id asc): ranks own ascending ids
         sel = torch.stack([gi[order], gr[order]]).cpu().numpy()  # ONE device->host copy: global top-n ids + row counts
         gid, grows = sel[0].astype(np.int64), sel[1]
-        longest = int(grows[gid >= 0].max()) if (self.pad and (gid >= 0).any()) else 0
-        mine = gid[(gid >= self.lo) & (gid < self.hi)]
-        ls, li = self.rerank(q, mine, longest, k)
+        ls, li = self.rerank(q, gid, self.batch_pads(gid, grows), k)
         return allgather_topk(ls.to(cs.device), li.to(cs.device), k, self.group)
 
 
 def make_gpu_two_stage(index, device=None, group=None) -> TwoStageShardedSearcher:
-    """TwoStageShardedSearcher over one MvIndex shard (FDE slab + bf16 or fp8 slab): coarse = MV_MODE_FDE_ONLY top-n,
-    rerank = mv_score_candidates on the pages this rank owns."""
+    """Host-driven TwoStageShardedSearcher over one MvIndex shard (FDE slab + bf16 or fp8 slab): coarse = MV_MODE_FDE_ONLY
+    top-n, rerank = mv_score_candidates_pads on the pages this rank owns.  The cross-check of GpuTwoStageSearcher."""
     import numpy as np
     import torch
 
@@ -291,7 +300,67 @@ def make_gpu_two_stage(index, device=None, group=None) -> TwoStageShardedSearche
     def rows(gids):
         return index.page_rows(np.asarray(gids, np.int64) - base)
 
-    def rerank(q, gids, pad_to):
-        return index.score_candidates(q, np.asarray(gids, np.int64) - base, pad_to=pad_to)
+    def rerank(q, gids, pads):
+        return index.score_candidates(q, np.asarray(gids, np.int64) - base, pads=pads)
 
     return TwoStageShardedSearcher(coarse, rows, rerank, (base, base + len(index)), group)
+
+
+class GpuTwoStageSearcher:
+    """Device-resident form of TwoStageShardedSearcher for one process per GPU over RCCL: the library leaves the coarse
+    candidates (16-byte records: score, rows, global id) in a cuda buffer (mv_two_stage_coarse_device), ONE
+    all_gather_into_tensor moves n records per rank, the library derives the global top-n, its owned candidates, their
+    per-batch pad lengths, reranks and selects the local top-k (mv_two_stage_rerank_device), a second all-gather moves the
+    k pairs and mv_merge_topk finishes.  Everything is ordered on torch's current stream: no host synchronisation and
+    no host copy of any intermediate on the query path."""
+
+    REC = 16  # sizeof(mv_cand_rec)
+
+    def __init__(self, index, device=None, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.index, self.group = index, group
+        self.dev = torch.device("cuda", index.device) if device is None else device
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._bufs = {}
+        self._flip = 0
+
+    def _buffers(self, n, k):
+        import torch
+
+        self._flip ^= 1  # two sets: collectives of query i may still read set A while query i+1 fills set B
+        key = (n, k, self._flip)
+        if key not in self._bufs:
+            d, w = self.dev, self.world
+            self._bufs[key] = (torch.empty(n * self.REC, dtype=torch.uint8, device=d), torch.empty(w * n * self.REC, dtype=torch.uint8, device=d),
+                               torch.empty(k, dtype=torch.float32, device=d), torch.empty(k, dtype=torch.int64, device=d),
+                               torch.empty(w * k, dtype=torch.float32, device=d), torch.empty(w * k, dtype=torch.int64, device=d),
+                               torch.empty(k, dtype=torch.float32, device=d), torch.empty(k, dtype=torch.int64, device=d))
+        return self._bufs[key]
+
+    def query(self, q, k: int, coarse_n: Optional[int] = None, allow=None):
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+
+        from ._lib import check, lib
+
+        n = int(coarse_n) if coarse_n else min(10 * k, 75)
+        recs, allrecs, ls, li, gs, gi, os_, oi = self._buffers(n, k)
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        self.index.two_stage_coarse_device(q, n, recs.data_ptr(), allow=allow, stream=stream)
+        if dist.is_initialized():
+            dist.all_gather_into_tensor(allrecs, recs, group=self.group)
+        else:
+            allrecs = recs
+        self.index.two_stage_rerank_device(q, allrecs.data_ptr(), self.world, n, k, ls.data_ptr(), li.data_ptr(), stream=stream)
+        if dist.is_initialized():
+            dist.all_gather_into_tensor(gs, ls, group=self.group)
+            dist.all_gather_into_tensor(gi, li, group=self.group)
+        else:
+            gs, gi = ls, li
+        check(lib().mv_merge_topk(self.index.device, C.c_void_p(gs.data_ptr()), C.c_void_p(gi.data_ptr()), self.world, k, k,
+                                  C.c_void_p(os_.data_ptr()), C.c_void_p(oi.data_ptr()), C.c_void_p(stream)))
+        return os_, oi

@@ -76,8 +76,8 @@ class OracleIndex:
             ci = ci[np.isfinite(cs)]
             if ci.size == 0:
                 return np.zeros(0, np.float32), np.zeros(0, np.int64)
-            sc = self.score_candidates(q, ci, pad_to=int(self.page_rows(ci).max()))
-            order = np.lexsort((ci, -sc.astype(np.float64)))[:k]
+            sc = self.score_candidates(q, ci, pad_to=-1)  # every batch of 128 candidates pads to its own longest page
+            order = np.lexsort((np.arange(ci.size), -sc.astype(np.float64)))[:k]  # ties keep coarse rank order
             return sc[order], ci[order] + self.id_base
         s = self.score_all(q, mode, allow)
         sc, ids = orc.topk(s, k)
@@ -86,11 +86,20 @@ class OracleIndex:
     def page_rows(self, pages):
         return np.array([len(self.pages[int(i)]) for i in pages], np.int32)
 
-    def score_candidates(self, q, cand, pad_to=0):
+    def score_candidates(self, q, cand, pad_to=0, pads=None):
+        """pad_to = -1: the reference rule (score_multi_vector scores passages in batches of 128, each zero-padded to its
+        own longest page); pads = explicit pad length per candidate."""
         q = np.asarray(q)
         qf = orc.bf16_to_f32(q) if q.dtype == np.uint16 else np.asarray(q, np.float32)
         qb = orc.bf16_to_f32(orc.f32_to_bf16(qf))
-        return np.array([orc.maxsim_f32(qb, orc.bf16_to_f32(orc.f32_to_bf16(self.pages[int(i)])), pad_to) for i in cand], np.float32)
+        cand = [int(i) for i in cand]
+        if pads is None:
+            if pad_to < 0:
+                rows = [len(self.pages[i]) for i in cand]
+                pads = [max(rows[j - j % 128 : j - j % 128 + 128]) for j in range(len(cand))]
+            else:
+                pads = [pad_to] * len(cand)
+        return np.array([orc.maxsim_f32(qb, orc.bf16_to_f32(orc.f32_to_bf16(self.pages[i])), int(pd)) for i, pd in zip(cand, pads)], np.float32)
 
     def compact(self):
         o2n, pages, ords = [], [], []

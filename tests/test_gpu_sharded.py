@@ -1,0 +1,259 @@
+"""GPU tests of the row-sharded forms through the C ABI: the per-batch-of-128 rerank pad rule, the
+device-resident two-stage (FDE coarse -> exact rerank) stages, and mv_comm -- R shards driven from one process -- against
+ONE index holding every page (same candidates, same pad lengths, same order, ties included) and against the oracle.
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc  # noqa: E402  (checker only)
+
+RTOL = 1e-3
+
+
+def _idx(**kw):
+    from morphik_core_amd.index import MvIndex
+
+    return MvIndex(**kw)
+
+
+def _ragged_pages(n, lo=5, span=40, seed=11):
+    return [orc.synth_rows(seed, i, 0, lo + (i * 7) % span) for i in range(n)]
+
+
+def _batch_pads(rows, batch=128):
+    rows = np.asarray(rows)
+    pads = np.empty_like(rows)
+    for j in range(0, len(rows), batch):
+        pads[j : j + batch] = rows[j : j + batch].max()
+    return pads
+
+
+# ------------------------------------------------------------------ the reference's rerank pad rule (> 128 candidates)
+@pytest.mark.parametrize("with_float", [True, False])
+def test_score_candidates_pads_every_batch_of_128_on_its_own(with_float):
+    """score_multi_vector scores passages in batches of 128, each zero-padded to ITS longest page
+    (fast_multivector_store.py:553-555 -> colpali_engine; golden case 5 of oracle/gen_golden.py crosses a batch
+    boundary).  300 ragged candidates: pad_to = -1 must equal the oracle with the per-batch pad length."""
+    n, stride = 400, 48
+    pages = _ragged_pages(n)
+    ix = _idx(capacity_pages=n, stride_rows=stride, with_float=with_float, with_fp8=not with_float)
+    ix.add(pages)
+    rng = np.random.default_rng(3)
+    cand = rng.permutation(n)[:300]
+    # make the batches differ: batch 0 holds the longest page, batch 2 only short ones
+    rows = np.array([pages[c].shape[0] for c in cand])
+    order = np.argsort(-rows, kind="stable")
+    cand = np.concatenate([cand[order[:128]], cand[order[172:]], cand[order[128:172]]])
+    rows = np.array([pages[c].shape[0] for c in cand])
+    pads = _batch_pads(rows)
+    assert len(set(pads.tolist())) >= 2
+    q = orc.synth_rows(4321, 5, 0, 20)
+    qf = orc.bf16_to_f32(q)
+    got = ix.score_candidates(q, cand, pad_to=-1)
+    if with_float:
+        want = np.array([orc.maxsim_f32(qf, orc.bf16_to_f32(pages[c]), int(p)) for c, p in zip(cand, pads)], np.float32)
+    else:
+        codes, inv = ix.read_fp8(0, n)
+        want = np.array([orc.maxsim_fp8(qf, codes[c], int(r), float(inv[c]), int(p)) for c, r, p in zip(cand, rows, pads)], np.float32)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-6)
+    # the clamp is visible: some page scores differ from the unpadded rule
+    plain = ix.score_candidates(q, cand, pad_to=0)
+    assert (np.abs(plain - got) > 1e-4).any()
+    # explicit per-candidate pads == the rule; one global pad length == the old single-batch behaviour
+    np.testing.assert_array_equal(ix.score_candidates(q, cand, pads=pads), got)
+    one_len = ix.score_candidates(q, cand, pad_to=int(rows.max()))
+    np.testing.assert_array_equal(one_len[:128], got[:128])
+    ix.close()
+
+
+def test_fde_then_float_with_more_than_128_candidates_follows_the_batch_rule():
+    """FDE_THEN_FLOAT at coarse_n = 300 on ragged pages: candidates in coarse rank order, per-batch pad lengths, exact
+    rerank -- equals the oracle pipeline built from the library's own coarse scores."""
+    from morphik_core_amd import _lib
+
+    n, stride, k, coarse_n = 500, 48, 10, 300
+    pages = _ragged_pages(n, seed=12)
+    ix = _idx(capacity_pages=n, stride_rows=stride, with_fde=True)
+    ix.add(pages, doc_ordinals=[i % 7 for i in range(n)])
+    ix.set_option(_lib.MV_OPT_FDE_COARSE_N, coarse_n)
+    for j, allow in enumerate([None, np.array([0b1011011], np.uint32)]):
+        q = orc.synth_rows(4321, 10 + j, 0, 24)
+        qf = orc.bf16_to_f32(q)
+        coarse = ix.score_all(q, mode="fde", allow=allow)
+        cs, ci = orc.topk(coarse, coarse_n)
+        ci = ci[np.isfinite(cs)]
+        rows = np.array([pages[c].shape[0] for c in ci])
+        pads = _batch_pads(rows)
+        exact = np.array([orc.maxsim_f32(qf, orc.bf16_to_f32(pages[c]), int(p)) for c, p in zip(ci, pads)], np.float32)
+        order = np.lexsort((np.arange(ci.size), -exact.astype(np.float64)))[:k]
+        s, i, st = ix.query(q, k, mode="fde_then_float", allow=allow, want_stats=True)
+        assert i.tolist() == ci[order].tolist()
+        np.testing.assert_allclose(s, exact[order], rtol=RTOL)
+        assert st.bytes_scanned == (np.isfinite(coarse).sum()) * 10240 * 2 + int(rows.sum()) * 256
+    ix.close()
+
+
+# ------------------------------------------------------------------ two-stage pipeline, R logical shards on one GPU
+@pytest.mark.parametrize("with_float", [True, False])  # rerank from the bf16 slab / from the fp8 slab
+def test_two_stage_fde_logical_shards_equal_single_index(with_float):
+    """Config 4 sharded: global coarse top-n, each shard reranks only the candidates it owns with the pad
+    length of their batch in the GLOBAL list, merge -> exactly the single index's FDE_THEN_FLOAT answer for R = 1, 2, 4;
+    host-driven stages (mv_score_candidates_pads) and device-resident stages (mv_two_stage_*_device) both."""
+    import torch
+
+    from morphik_core_amd import _lib, sharded
+
+    N, stride, k, coarse_n = 480, 48, 6, 200  # 200 candidates: two rerank batches
+    pages = _ragged_pages(N)
+    ords = [i % 9 for i in range(N)]
+    kw = dict(stride_rows=stride, with_fde=True, with_float=with_float, with_fp8=not with_float)
+    one = _idx(capacity_pages=N, **kw)
+    one.add(pages, doc_ordinals=ords)
+    one.set_option(_lib.MV_OPT_FDE_COARSE_N, coarse_n)
+    qs = [orc.synth_rows(4321, j, 0, 20) for j in range(3)]
+    allow = np.array([0b101101011], np.uint32)
+    dev = torch.device("cuda", 0)
+    for R in (1, 2, 4):
+        per = N // R
+        shards, searchers = [], []
+        for r in range(R):
+            sh = _idx(capacity_pages=per, id_base=r * per, **kw)
+            sh.add(pages[r * per : (r + 1) * per], doc_ordinals=ords[r * per : (r + 1) * per])
+            shards.append(sh)
+            searchers.append(sharded.make_gpu_two_stage(sh))
+        for q in qs:
+            for al in (None, allow):
+                ws, wi = one.query(q, k, mode="fde_then_float", allow=al)
+                # --- host-driven stages
+                co = [se.coarse(q, k, coarse_n, al) for se in searchers]
+                gs = torch.stack([c[1] for c in co]).reshape(-1)
+                gi = torch.stack([c[2] for c in co]).reshape(-1)
+                order = torch.sort(gs, descending=True, stable=True).indices[:coarse_n]
+                gid = gi[order].cpu().numpy().astype(np.int64)
+                grows = np.array([pages[g].shape[0] if g >= 0 else 0 for g in gid])
+                pads = searchers[0].batch_pads(gid, grows)
+                loc = [se.rerank(q, gid, pads, k) for se in searchers]
+                ms, mi = sharded.merge_topk(torch.stack([l[0] for l in loc]), torch.stack([l[1] for l in loc]), k)
+                assert mi.tolist() == wi.tolist()
+                assert ms.tolist() == ws.tolist()
+                # --- device-resident stages: records -> "all-gather" (concatenation in shard order) -> rerank -> merge
+                recs = [torch.empty(coarse_n * 16, dtype=torch.uint8, device=dev) for _ in range(R)]
+                for sh, rb in zip(shards, recs):
+                    sh.two_stage_coarse_device(q, coarse_n, rb.data_ptr(), allow=al)
+                allrecs = torch.cat(recs)
+                ls = torch.empty((R, k), dtype=torch.float32, device=dev)
+                li = torch.empty((R, k), dtype=torch.int64, device=dev)
+                for r, sh in enumerate(shards):
+                    sh.two_stage_rerank_device(q, allrecs.data_ptr(), R, coarse_n, k, ls[r].data_ptr(), li[r].data_ptr())
+                ds, di = sharded.merge_topk(ls.cpu(), li.cpu(), k)
+                assert di.tolist() == wi.tolist()
+                assert ds.tolist() == ws.tolist()
+        for sh in shards:
+            sh.close()
+    one.close()
+
+
+def test_gpu_two_stage_searcher_single_rank_equals_index():
+    """GpuTwoStageSearcher without a process group (world 1): the stream-ordered device pipeline == mv_query_topk."""
+    import torch
+
+    from morphik_core_amd import _lib, sharded
+
+    N, stride, k, coarse_n = 300, 32, 5, 150
+    pages = _ragged_pages(N, lo=3, span=29, seed=13)
+    ix = _idx(capacity_pages=N, stride_rows=stride, with_fde=True, with_float=False, with_fp8=True)
+    ix.add(pages)
+    ix.set_option(_lib.MV_OPT_FDE_COARSE_N, coarse_n)
+    se = sharded.GpuTwoStageSearcher(ix)
+    for j in range(3):
+        q = orc.synth_rows(4321, 20 + j, 0, 16)
+        ws, wi = ix.query(q, k, mode="fde_then_float")
+        s, i = se.query(q, k, coarse_n=coarse_n)
+        torch.cuda.synchronize()
+        assert i.cpu().tolist() == wi.tolist() and s.cpu().tolist() == ws.tolist()
+    ix.close()
+
+
+# ------------------------------------------------------------------ mv_comm: R shards, one process
+@pytest.mark.parametrize("transport", ["p2p", "host"])
+@pytest.mark.parametrize("R", [1, 2, 4])
+def test_shard_comm_equals_single_index_all_modes(R, transport):
+    """mv_comm_query_topk over R logical shards on one GPU == ONE index holding every page: float / fp8 / sign-bit
+    scans and the two-stage FDE pipeline, with a doc filter and tombstones, duplicates for exact ties."""
+    from morphik_core_amd import _lib
+    from morphik_core_amd.index import ShardComm
+
+    N, stride, k = 360, 32, 12
+    base = _ragged_pages(60, lo=4, span=27, seed=21)
+    pages = [base[i % 60] if i % 4 == 0 else orc.synth_rows(22, i, 0, 4 + (i * 5) % 28) for i in range(N)]  # duplicates -> ties across shards
+    ords = [i % 11 for i in range(N)]
+    kw = dict(stride_rows=stride, with_float=True, with_binary=True, with_fde=True, with_fp8=True)
+    one = _idx(capacity_pages=N, **kw)
+    one.add(pages, doc_ordinals=ords)
+    per = N // R
+    shards = []
+    for r in range(R):
+        sh = _idx(capacity_pages=per, id_base=r * per, **kw)
+        sh.add(pages[r * per : (r + 1) * per], doc_ordinals=ords[r * per : (r + 1) * per])
+        shards.append(sh)
+    for ix in [one] + shards:
+        ix.set_option(_lib.MV_OPT_FDE_COARSE_N, 150)
+    one.remove_page(17)
+    shards[17 // per].remove_page(17 % per)
+    comm = ShardComm(shards, transport=transport)
+    assert comm.transport == transport
+    allow = np.array([0b10110111011], np.uint32)
+    for j in range(2):
+        q = orc.synth_rows(4321, 30 + j, 0, 18)
+        for mode in ("float", "float_fp8", "binary", "fde_then_float"):
+            for al in (None, allow):
+                ws, wi = one.query(q, k, mode=mode, allow=al)
+                s, i, st = comm.query(q, k, mode=mode, allow=al, want_stats=True)
+                assert i.tolist() == wi.tolist(), (mode, R, transport)
+                assert s.tolist() == ws.tolist()
+                assert len(st) == R and all(x.total_device_ms > 0 for x in st)
+    # k beyond the merge kernel's 2048 keys (R * k > 2048) and beyond the corpus
+    s, i = comm.query(q, 700, mode="float")
+    ws, wi = one.query(q, 700, mode="float")
+    assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist()
+    comm.close()
+    for sh in shards:
+        sh.close()
+    one.close()
+
+
+def test_shard_comm_rccl_on_one_device_is_refused_loudly():
+    from morphik_core_amd import MvError
+    from morphik_core_amd.index import ShardComm
+
+    a = _idx(capacity_pages=8, stride_rows=16)
+    b = _idx(capacity_pages=8, stride_rows=16, id_base=8)
+    with pytest.raises(MvError):
+        ShardComm([a, b], transport="rccl")  # two ranks of one communicator cannot share a device
+    c = ShardComm([a, b])  # auto falls back to peer copies
+    assert c.transport == "p2p"
+    c.close()
+    a.close()
+    b.close()
+
+
+def test_shard_comm_rccl_single_rank_communicator():
+    """ncclCommInitAll with one device: the RCCL code path (dlopen, communicator, grouped all-gather) on a 1-GPU box."""
+    from morphik_core_amd.index import ShardComm
+
+    N = 200
+    ix = _idx(capacity_pages=N, stride_rows=32, with_fde=True)
+    ix.fill_synthetic(1234, 0, N)
+    comm = ShardComm([ix], transport="rccl")
+    assert comm.transport == "rccl"
+    q = orc.synth_rows(4321, 1, 0, 16)
+    for mode in ("float", "fde_then_float"):
+        ws, wi = ix.query(q, 10, mode=mode)
+        s, i = comm.query(q, 10, mode=mode)
+        assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist()
+    comm.close()
+    ix.close()

@@ -131,7 +131,7 @@ def _two_stage(ix, lo):
         return torch.from_numpy(ps), torch.from_numpy(pi)
 
     return sharded.TwoStageShardedSearcher(coarse, lambda g: ix.page_rows(np.asarray(g) - lo),
-                                           lambda q, g, pad: ix.score_candidates(q, np.asarray(g) - lo, pad_to=pad),
+                                           lambda q, g, pads: ix.score_candidates(q, np.asarray(g) - lo, pads=pads),
                                            (lo, lo + len(ix)))
 
 
@@ -155,10 +155,11 @@ def _worker_two_stage(rank, world, port, n_total, k, coarse_n, out_q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_total,k,coarse_n", [(2, 37, 5, 12), (3, 40, 4, 9), (2, 2, 5, 12)])
+@pytest.mark.parametrize("world,n_total,k,coarse_n", [(2, 37, 5, 12), (3, 40, 4, 9), (2, 2, 5, 12), (2, 330, 6, 300)])
 def test_two_stage_fde_pipeline_is_rank_count_invariant(world, n_total, k, coarse_n):
-    """The sharded FDE_THEN_FLOAT (global coarse top-n, owners rerank with the global pad length) returns exactly what
-    ONE index returns: same candidate set, same pad-to-longest clamp, same top-k."""
+    """The sharded FDE_THEN_FLOAT (global coarse top-n, owners rerank with the pad length of each candidate's batch of
+    128 in the GLOBAL list) returns exactly what ONE index returns: same candidate set, same pad-to-longest clamp per
+    batch, same top-k.  The 330-page / 300-candidate case spans three rerank batches."""
     from oracle import oracle as orc
     from tests.fake_index import OracleIndex
 
