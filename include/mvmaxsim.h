@@ -82,6 +82,12 @@ typedef struct {
   int32_t reserved;
   int64_t pages_scored;   /* pages whose embeddings were read (masked pages excluded) */
   int64_t bytes_scanned;  /* algorithmic bytes: pages_scored * rows * row_bytes */
+  /* Stage split of the FDE modes -- the device-side counterparts of the reference's per-stage log lines
+   * (fast_multivector_store.py:521-605: encode_query / ns.query / load_multivectors + rerank_scoring); 0 elsewhere. */
+  float encode_ms;        /* fde.generate_query_encoding */
+  float coarse_ms;        /* FDE slab scan (the ANN stage) */
+  float select_ms;        /* coarse top-n selection + candidate list */
+  float rerank_ms;        /* exact MaxSim of the candidates */
 } mv_query_stats;
 
 typedef struct mv_index mv_index;

@@ -63,6 +63,10 @@ class QueryStatsC(C.Structure):
         ("reserved", C.c_int32),
         ("pages_scored", C.c_int64),
         ("bytes_scanned", C.c_int64),
+        ("encode_ms", C.c_float),
+        ("coarse_ms", C.c_float),
+        ("select_ms", C.c_float),
+        ("rerank_ms", C.c_float),
     ]
 
 

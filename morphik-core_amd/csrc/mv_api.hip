@@ -294,7 +294,7 @@ int fp8_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_wor
 }
 
 // FDE coarse stage: encode the query already uploaded to d_qf32 (SUM aggregation) and scan the FDE slab -> d_scores[n].
-int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_words, int64_t n, int* launches) {
+int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_words, int64_t n, int* launches, bool stage_events) {
   const bool need_meta = ix->tombstones.load() || d_allow != nullptr;
   const int64_t off[2] = {0, n_q};
   MV_HIP(hipMemcpyAsync(ix->d_qoff, off, sizeof(off), hipMemcpyHostToDevice, ix->stream));
@@ -303,12 +303,14 @@ int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_wo
   e.x_f32 = ix->d_qf32; e.row_offsets = ix->d_qoff; e.n_pages = 1; e.is_query = 1; e.out_f32 = ix->d_qfde;
   int rc = launch_fde_encode(ix->fde_t, e, ix->stream);
   if (rc) return rc;
+  if (stage_events) MV_HIP(hipEventRecord(ix->ev_st[0], ix->stream));
   FdeScanArgs s{};
   s.fde = ix->fde; s.inv_norm = ix->fde_cosine ? ix->fde_inv_norm : nullptr; s.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
   s.allow = d_allow; s.n_allow_bits = n_words * 32; s.q = ix->d_qfde; s.scores = ix->d_scores; s.n = n;
   s.out_dim = ix->fde_t.out_dim;
   rc = launch_fde_scan(s, ix->fde_scan_variant, ix->stream);
   if (rc) return rc;
+  if (stage_events) MV_HIP(hipEventRecord(ix->ev_st[1], ix->stream));
   *launches += 2;
   return MV_OK;
 }
@@ -402,7 +404,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
     out->pages = pages; out->bytes = rows * (int64_t)kSignBytes;
   } else {
     // FDE: encode the query (SUM), scan the FDE slab
-    rc = fde_coarse_scan(ix, n_q, d_allow, n_words, n, &out->launches);
+    rc = fde_coarse_scan(ix, n_q, d_allow, n_words, n, &out->launches, st != nullptr);
     if (rc) return rc;
     out->pages = pages; out->bytes = pages * ix->fde_t.out_dim * 2;
     if (mode == MV_MODE_FDE_ONLY) {
@@ -419,6 +421,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
       const int pad_sem = ix->pad_semantics < 0 ? 1 : ix->pad_semantics;
       rc = launch_cand_prepare(ix, ix->d_out_id, nullptr, (int)nc, pad_sem);
       if (rc) return rc;
+      if (st) MV_HIP(hipEventRecord(ix->ev_st[2], ix->stream));
       rc = rerank_scan(ix, n_q, rerank_fp8, nc, ix->d_cand_scores, &out->launches);
       if (rc) return rc;
       out->launches += 1;
@@ -435,6 +438,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
     st->bytes_scanned = out->bytes;
     // FDE_THEN_FLOAT: the candidates' rows are added by finish_stats (read back behind the timed span)
     if (mode == MV_MODE_FDE_THEN_FLOAT) st->reserved = (int32_t)out->n | (rerank_fp8 ? (1 << 30) : 0);
+    else if (mode == MV_MODE_FDE_ONLY) st->reserved = 1 << 29;  // stage split without a rerank
   }
   return MV_OK;
 }
@@ -442,7 +446,14 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
 int finish_stats(mv_index* ix, mv_query_stats* st, bool had_topk) {
   if (!st) return MV_OK;
   MV_HIP(hipEventSynchronize(ix->ev[had_topk ? 2 : 1]));
+  if (st->reserved) {  // stage split of the FDE modes (events recorded by run_scan)
+    MV_HIP(hipEventElapsedTime(&st->encode_ms, ix->ev[0], ix->ev_st[0]));
+    MV_HIP(hipEventElapsedTime(&st->coarse_ms, ix->ev_st[0], ix->ev_st[1]));
+    if (st->reserved & (1 << 29)) { st->reserved = 0; }
+  }
   if (st->reserved) {  // accounting of the rerank stage: rows of the candidates actually read
+    MV_HIP(hipEventElapsedTime(&st->select_ms, ix->ev_st[1], ix->ev_st[2]));
+    MV_HIP(hipEventElapsedTime(&st->rerank_ms, ix->ev_st[2], ix->ev[1]));
     const int nc = st->reserved & 0xffff;
     const bool f8 = (st->reserved >> 30) & 1;
     st->reserved = 0;
@@ -642,6 +653,8 @@ void mv_index_destroy(mv_index* ix) {
   fde_tables_destroy(&ix->fde_t);
   for (auto& e : ix->ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto& e : ix->ev_st)
+    if (e) (void)hipEventDestroy(e);
   if (ix->ev_stage) (void)hipEventDestroy(ix->ev_stage);
   for (void* hp : {(void*)ix->h_qf32, (void*)ix->h_qbf16, (void*)ix->h_out_s, (void*)ix->h_out_id, (void*)ix->h_cand})
     if (hp) (void)hipHostFree(hp);
@@ -679,6 +692,8 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ix->w_stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); rc = MV_ERR_HIP; }
   for (auto& e : ix->ev)
+    if (!rc && hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); rc = MV_ERR_HIP; }
+  for (auto& e : ix->ev_st)
     if (!rc && hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); rc = MV_ERR_HIP; }
   if (!rc && hipEventCreateWithFlags(&ix->ev_stage, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); rc = MV_ERR_HIP; }
   if (!rc && (hipHostMalloc((void**)&ix->h_out_s, (size_t)kTopkMaxDeviceK * 4, hipHostMallocDefault) != hipSuccess ||

@@ -80,6 +80,7 @@ struct mv_index {
   int32_t* h_cand = nullptr;       // [kTopkMaxDeviceK] pinned: candidate ids read back for the accounting only
   hipEvent_t ev_stage = nullptr;  // recorded behind the H2D copies of the staging buffers
   hipEvent_t ev[6] = {};
+  hipEvent_t ev_st[3] = {};       // FDE stage boundaries: after the query encode, after the coarse scan, after the selection
   std::mutex q_mu;  // queries + the per-query workspace
   std::mutex w_mu;  // writers
   // writer-side staging (w_mu): grown on demand, never freed while a scan may run (hipFree synchronises the device)
@@ -129,7 +130,7 @@ struct ScanResult {
 // Internal entry points of mv_api.hip used by mv_comm.hip.  Callers hold ix->q_mu and have the index's device current.
 int upload_query(mv_index* ix, const void* q, int q_dtype, int n_q, bool want_bf16, bool want_f32, bool want_bits, bool want_fp8);
 int upload_allow(mv_index* ix, const uint32_t* allow_bits, int64_t n_words, const uint32_t** d_allow);
-int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_words, int64_t n, int* launches);
+int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_words, int64_t n, int* launches, bool stage_events = false);
 int rerank_scan(mv_index* ix, int n_q, bool use_fp8, int64_t n_items, float* d_out, int* launches);
 int64_t coarse_n_for(const mv_index* ix, int k);
 int finish_stats(mv_index* ix, mv_query_stats* st, bool had_topk);

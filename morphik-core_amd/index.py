@@ -62,10 +62,15 @@ class QueryStats:
     score_launches: int = 0
     pages_scored: int = 0
     bytes_scanned: int = 0
+    encode_ms: float = 0.0   # FDE modes: query encode / coarse scan / candidate selection / exact rerank
+    coarse_ms: float = 0.0
+    select_ms: float = 0.0
+    rerank_ms: float = 0.0
 
     @classmethod
     def from_c(cls, s: QueryStatsC) -> "QueryStats":
-        return cls(s.score_kernel_ms, s.topk_ms, s.total_device_ms, s.score_launches, s.pages_scored, s.bytes_scanned)
+        return cls(s.score_kernel_ms, s.topk_ms, s.total_device_ms, s.score_launches, s.pages_scored, s.bytes_scanned,
+                   s.encode_ms, s.coarse_ms, s.select_ms, s.rerank_ms)
 
 
 def _to_host(x: Any) -> np.ndarray:

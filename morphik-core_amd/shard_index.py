@@ -1,0 +1,159 @@
+"""ShardedIndex -- R MvIndex shards + one mv_comm behind the interface the stores use for ONE index.
+
+The reference builds one store object in one process (core/services_init.py:141-165); a node with 8 MI355X therefore
+needs the shard fan-out and the top-k exchange BELOW the store, not in a launcher.  Shard r owns the fixed global id
+range [r * capacity_per_shard, (r + 1) * capacity_per_shard) -- ascending with r, which is what makes the merged order
+(score desc, id asc) the single-index order -- on device `devices[r]` (several shards may name the same device: logical
+shards, used by the tests on a 1-GPU box).  Queries go through libmvmaxsim's communicator (RCCL all-gather of k pairs
+over xGMI, peer copies, or the host reference path); this file only routes writes and remaps ids.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+class ShardedIndex:
+    def __init__(self, capacity_pages: int, stride_rows: int, devices: Sequence[int], with_float: bool = True, with_binary: bool = False,
+                 with_fde: bool = False, with_fp8: bool = False, fde=None, transport: str = "auto", id_base: int = 0,
+                 index_cls=None, comm_cls=None):
+        from .index import MvIndex, ShardComm
+
+        index_cls = index_cls or MvIndex
+        comm_cls = comm_cls or ShardComm
+        self.devices = [int(d) for d in devices]
+        self.n_shards = len(self.devices)
+        if self.n_shards < 1:
+            raise ValueError("ShardedIndex needs at least one device")
+        self.per = -(-int(capacity_pages) // self.n_shards)  # ceil: slots per shard
+        self.stride_rows = int(stride_rows)
+        self.id_base = int(id_base)
+        self.device = self.devices[0]
+        self.shards = [
+            index_cls(capacity_pages=self.per, stride_rows=stride_rows, device=d, with_float=with_float, with_binary=with_binary,
+                      with_fde=with_fde, with_fp8=with_fp8, fde=fde, id_base=self.id_base + r * self.per)
+            for r, d in enumerate(self.devices)
+        ]
+        self.comm = comm_cls(self.shards, transport=transport)
+
+    # -- lifecycle
+    def close(self) -> None:
+        if getattr(self, "comm", None) is not None:
+            self.comm.close()
+            self.comm = None
+        for s in getattr(self, "shards", []):
+            s.close()
+        self.shards = []
+
+    def __len__(self) -> int:
+        return sum(len(s) for s in self.shards)
+
+    @property
+    def capacity(self) -> int:
+        return self.per * self.n_shards
+
+    @property
+    def transport(self) -> str:
+        return self.comm.transport
+
+    def set_option(self, option: int, value: int) -> None:
+        for s in self.shards:
+            s.set_option(option, value)
+
+    def _route(self, page: int) -> Tuple[int, int]:
+        r, local = divmod(int(page) - self.id_base, self.per)
+        if r < 0 or r >= self.n_shards:
+            raise ValueError(f"page {page} is outside every shard")
+        return r, local
+
+    def _pick(self, n_pages: int, device: Optional[int] = None) -> int:
+        """Least-full shard with room for the batch (on `device` when the rows already sit there)."""
+        best, best_free = -1, -1
+        for r, s in enumerate(self.shards):
+            if device is not None and self.devices[r] != device:
+                continue
+            free = self.per - len(s)
+            if free >= n_pages and free > best_free:
+                best, best_free = r, free
+        return best
+
+    # -- build: a batch lands on ONE shard so that its pages get consecutive global ids
+    def add(self, pages: Sequence[Any], doc_ordinals: Optional[Sequence[int]] = None) -> int:
+        if len(pages) == 0:
+            return self.id_base
+        r = self._pick(len(pages))
+        if r < 0:
+            from ._lib import MvError
+
+            raise MvError(-4, f"slab full: no shard has {len(pages)} free slots (capacity {self.per} per shard)")
+        return self.shards[r].add(pages, doc_ordinals) + self.shards[r].id_base
+
+    def add_device(self, d_ptr: int, dtype_code: int, n_rows: Sequence[int], doc_ordinals: Optional[Sequence[int]] = None,
+                   device: Optional[int] = None) -> int:
+        r = self._pick(len(n_rows), device if device is not None else self.devices[0])
+        if r < 0:
+            from ._lib import MvError
+
+            raise MvError(-4, f"slab full: no shard on device {device} has {len(n_rows)} free slots")
+        return self.shards[r].add_device(d_ptr, dtype_code, n_rows, doc_ordinals) + self.shards[r].id_base
+
+    def remove_page(self, page: int) -> None:
+        r, local = self._route(page)
+        self.shards[r].remove_page(local)
+
+    def remove_doc(self, doc_ordinal: int) -> int:
+        return sum(s.remove_doc(doc_ordinal) for s in self.shards)
+
+    def page_rows(self, pages: Sequence[int]) -> np.ndarray:
+        out = np.empty(len(pages), np.int32)
+        for j, p in enumerate(pages):
+            r, local = self._route(p)
+            out[j] = self.shards[r].page_rows([local])[0]
+        return out
+
+    def compact(self) -> Dict[int, int]:
+        """Every shard compacts on its own (ids stay inside the shard's range).  -> {old global id: new global id}."""
+        remap: Dict[int, int] = {}
+        for s in self.shards:
+            o2n = s.compact()
+            base = s.id_base
+            for o, n in enumerate(o2n.tolist()):
+                if n >= 0:
+                    remap[base + o] = base + int(n)
+        return remap
+
+    # -- query
+    def query(self, q: Any, k: int, mode: str = "float", allow: Optional[np.ndarray] = None, want_stats: bool = False):
+        return self.comm.query(q, k, mode=mode, allow=allow, want_stats=want_stats)
+
+    def query_batch(self, queries: Sequence[Any], k: int, mode: str = "float", allow: Optional[np.ndarray] = None, want_stats: bool = False,
+                    allows: Optional[Sequence[Optional[np.ndarray]]] = None, n_docs: int = 0):
+        """Coalesced requests on a sharded store: one communicator query each (the shards already run concurrently)."""
+        out = []
+        for j, q in enumerate(queries):
+            a = allow if allows is None else allows[j]
+            out.append(self.comm.query(q, k, mode=mode, allow=None if a is None else np.asarray(a, np.uint32)))
+        return out
+
+    # -- persistence: one file per shard next to `path`
+    def save(self, path: str) -> None:
+        for r, s in enumerate(self.shards):
+            s.save(f"{path}.shard{r}")
+
+    @classmethod
+    def load(cls, path: str, devices: Sequence[int], transport: str = "auto", index_cls=None, comm_cls=None) -> "ShardedIndex":
+        from .index import MvIndex, ShardComm
+
+        index_cls = index_cls or MvIndex
+        comm_cls = comm_cls or ShardComm
+        self = cls.__new__(cls)
+        self.devices = [int(d) for d in devices]
+        self.n_shards = len(self.devices)
+        self.shards = [index_cls.load(f"{path}.shard{r}", device=d) for r, d in enumerate(self.devices)]
+        self.per = self.shards[0].capacity
+        self.stride_rows = self.shards[0].stride_rows
+        self.id_base = self.shards[0].id_base
+        self.device = self.devices[0]
+        self.comm = comm_cls(self.shards, transport=transport)
+        return self

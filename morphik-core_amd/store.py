@@ -1,9 +1,13 @@
 """BaseVectorStore plugins backed by the MI355X index -- the drop-in boundary of SURVEY.md 8(b).
 
-  MI355XMultiVectorStore      drop-in for core/vector_store/multi_vector_store.py:MultiVectorStore
-                              (scores = SQL max_sim on sign bits; mode "binary")
-  MI355XFastMultiVectorStore  drop-in for core/vector_store/fast_multivector_store.py:FastMultiVectorStore
-                              (FDE coarse top min(10k,75) -> exact float MaxSim rerank; mode "fde_then_float")
+  MI355XMultiVectorStore            drop-in for core/vector_store/multi_vector_store.py:MultiVectorStore
+                                    (scores = SQL max_sim on sign bits; mode "binary")
+  MI355XFastMultiVectorStore        drop-in for core/vector_store/fast_multivector_store.py:FastMultiVectorStore
+                                    (FDE coarse top min(10k,75) -> exact float MaxSim rerank; mode "fde_then_float";
+                                    per-app namespaces)
+  MI355XSharded{,Fast}MultiVectorStore   the same stores over R shards (one per GPU, or logical shards on one GPU)
+                                    behind ONE object: one payload table, writes routed to the least-full shard, queries
+                                    through libmvmaxsim's communicator (mv_comm: RCCL all-gather of k pairs over xGMI)
   either can run mode "float": exact float MaxSim over the WHOLE corpus (no coarse stage) -- what the
   HBM-resident slab makes affordable (1 M pages in ~40 ms on one GPU).
 
@@ -13,7 +17,8 @@ Signatures, return shapes and error conventions follow the reference:
   get_chunks_by_id -> score 0.0                                                  multi_vector_store.py:824-919
   delete_chunks_by_document_id -> bool, False on error                           multi_vector_store.py:921-951
   initialize() -> bool, never raises                                             multi_vector_store.py:186-327
-Scoring is done by libmvmaxsim.so only; this file is bookkeeping (ids, payloads, filters).
+Chunk content goes to the caller's `.storage` (payloads.py) exactly as the reference stores it externally; only the
+storage key stays in host memory.  Scoring is done by libmvmaxsim.so only; this file is bookkeeping (ids, keys, filters).
 """
 from __future__ import annotations
 
@@ -22,11 +27,12 @@ import json
 import logging
 import threading
 import time
-from typing import Any, Callable, Dict, List, Optional, Tuple
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
 from .models import BaseVectorStore, DocumentChunk, build_store_metrics
+from .payloads import DEFAULT_APP_ID, PayloadStore, is_storage_key, parse_metadata, storage_backend_name
 
 logger = logging.getLogger(__name__)
 
@@ -46,9 +52,9 @@ def _embedding_rows(e: Any) -> np.ndarray:
     return a
 
 
-def _device_tensor(e: Any, device_index: int):
-    """The embedding itself when it is a torch tensor resident on the index's GPU ([n,128], bf16 or fp32), else None."""
-    if hasattr(e, "is_cuda") and getattr(e, "is_cuda") and e.device.index == device_index and e.dim() == 2 and e.shape[1] == 128:
+def _device_tensor(e: Any, devices: Sequence[int]):
+    """The embedding itself when it is a torch tensor resident on one of the index's GPUs ([n,128], bf16 or fp32), else None."""
+    if hasattr(e, "is_cuda") and getattr(e, "is_cuda") and e.device.index in devices and e.dim() == 2 and e.shape[1] == 128:
         if str(e.dtype) in ("torch.bfloat16", "torch.float32"):
             return e
     return None
@@ -57,6 +63,7 @@ def _device_tensor(e: Any, device_index: int):
 class MI355XMultiVectorStore(BaseVectorStore):
     backend_name = "mi355x"
     default_mode = "binary"
+    _filter_by_app = False  # MultiVectorStore.query_similar ignores app_id (multi_vector_store.py:721-763)
 
     def __init__(
         self,
@@ -71,6 +78,8 @@ class MI355XMultiVectorStore(BaseVectorStore):
         batch_window_ms: float = 0.0,
         max_batch: int = 16,
         min_score: Optional[float] = None,
+        enable_external_storage: bool = True,
+        app_id_resolver: Optional[Callable[[str], Optional[str]]] = None,
         **_ignored: Any,
     ):
         self.capacity_pages = int(capacity_pages)
@@ -80,6 +89,12 @@ class MI355XMultiVectorStore(BaseVectorStore):
         if self.mode not in ("binary", "float", "fde_then_float", "float_fp8"):
             raise ValueError(f"unknown mode {self.mode}")
         self.storage = storage  # callers reach for .storage (document_service.py:1570-1575)
+        # multi_vector_store.py:120-160: content is stored externally when a storage object is configured
+        self.enable_external_storage = bool(enable_external_storage)
+        self._payloads = PayloadStore(storage) if storage is not None else None
+        # store_embeddings resolves a missing app_id from the document (multi_vector_store.py:644-648 /
+        # fast_multivector_store.py:440-444 -> SELECT app_id FROM documents); the callback plays that lookup's role
+        self._app_id_resolver = app_id_resolver
         self.id_base = int(id_base)
         self.fde_coarse_n = int(fde_coarse_n)
         self._index_factory = index_factory
@@ -96,32 +111,42 @@ class MI355XMultiVectorStore(BaseVectorStore):
         self.coalesced_batches: List[int] = []  # sizes of the batches actually issued (introspection / tests)
         self._index = None
         self._lock = threading.RLock()
-        # payload table: page -> (document_id, chunk_number, content, metadata_json, app_id)
+        # bookkeeping: page -> (document_id, chunk_number, content OR storage key, metadata_json, app_id)
         self._rows: Dict[int, Tuple[str, int, str, str, Optional[str]]] = {}
         self._page_of: Dict[Tuple[str, int], int] = {}
         self._doc_ord: Dict[str, int] = {}
+        self._next_ord = 0
         self._doc_app: Dict[int, Optional[str]] = {}
         self._doc_pages: Dict[str, List[int]] = {}
+        # bumped by compact() (page ids are renumbered): a query whose scan ran against the old numbering is re-run
+        self._generation = 0
         self._last_store_metrics: Dict[str, Any] = {}
         self.last_query_timing: Dict[str, float] = {}
 
     # ------------------------------------------------------------------ lifecycle
+    def _devices(self) -> List[int]:
+        return [self.device]
+
+    def _slab_flags(self) -> Dict[str, bool]:
+        return dict(with_float=self.mode in ("float", "fde_then_float"), with_binary=self.mode == "binary",
+                    with_fde=self.mode == "fde_then_float", with_fp8=self.mode == "float_fp8")
+
     def _make_index(self):
         if self._index_factory is not None:
             return self._index_factory(capacity_pages=self.capacity_pages, stride_rows=self.stride_rows, device=self.device,
                                        id_base=self.id_base, mode=self.mode)
         from .index import MvIndex  # HIP-only: raises MvError when libmvmaxsim.so or the GPU is missing
 
-        ix = MvIndex(
-            capacity_pages=self.capacity_pages, stride_rows=self.stride_rows, device=self.device, id_base=self.id_base,
-            with_float=self.mode in ("float", "fde_then_float"), with_binary=self.mode == "binary",
-            with_fde=self.mode == "fde_then_float", with_fp8=self.mode == "float_fp8",
-        )
+        ix = MvIndex(capacity_pages=self.capacity_pages, stride_rows=self.stride_rows, device=self.device, id_base=self.id_base,
+                     **self._slab_flags())
+        self._apply_options(ix)
+        return ix
+
+    def _apply_options(self, ix) -> None:
         if self.fde_coarse_n:
             from ._lib import MV_OPT_FDE_COARSE_N
 
             ix.set_option(MV_OPT_FDE_COARSE_N, self.fde_coarse_n)
-        return ix
 
     def initialize(self) -> bool:
         """Allocate the HBM slabs. Returns False on failure, never raises (multi_vector_store.py:325-327)."""
@@ -152,25 +177,34 @@ class MI355XMultiVectorStore(BaseVectorStore):
         return self._index
 
     # ------------------------------------------------------------------ store
-    def _store_sync(self, valid: List[DocumentChunk], embs: List[np.ndarray], app_id: Optional[str]) -> List[str]:
+    def _resolve_app(self, app_id: Optional[str], chunks: List[DocumentChunk]) -> Optional[str]:
+        """app_id given -> it; else, for a single-document batch, the document's app (callback) as the reference looks it
+        up in the documents table; stores with per-app namespaces fall back to "default"."""
+        if app_id is not None:
+            return app_id
+        if self._app_id_resolver is not None and chunks and all(c.document_id == chunks[0].document_id for c in chunks):
+            try:
+                got = self._app_id_resolver(chunks[0].document_id)
+                if got:
+                    return got
+            except Exception as e:  # noqa: BLE001
+                logger.warning(f"Failed to get app_id for document {chunks[0].document_id}: {e}")
+        return DEFAULT_APP_ID if self._filter_by_app else None
+
+    def _store_sync(self, valid: List[DocumentChunk], embs: List[Any], contents: List[str], app_id: Optional[str]) -> List[str]:
         ix = self._require_index()
         with self._lock:
             ords = []
             for c in valid:
                 o = self._doc_ord.get(c.document_id)
                 if o is None:
-                    o = len(self._doc_ord)
+                    o = self._next_ord
+                    self._next_ord += 1
                     self._doc_ord[c.document_id] = o
                     self._doc_app[o] = app_id
                 ords.append(o)
-            # upsert: an existing (document_id, chunk_number) is replaced (FastMultiVectorStore upserts by id)
-            for c in valid:
-                old = self._page_of.pop((c.document_id, c.chunk_number), None)
-                if old is not None:
-                    ix.remove_page(old - self.id_base)
-                    self._rows.pop(old, None)
-                    if old in self._doc_pages.get(c.document_id, []):
-                        self._doc_pages[c.document_id].remove(old)
+            # ADD FIRST: if the slab is full or the device call fails nothing was published (mv_index_add is all or
+            # nothing) and the previous versions of these chunks are still live
             if embs and all(not isinstance(e, np.ndarray) for e in embs):
                 # ingest-side fusion (SURVEY.md 8f rank 1): encoder output already on this GPU -> one D2D pass fills
                 # every slab (mv_index_add_device); no D2H -> fp32 -> H2D round trip
@@ -181,19 +215,33 @@ class MI355XMultiVectorStore(BaseVectorStore):
                 code = MV_BF16 if all(e.dtype == torch.bfloat16 for e in embs) else MV_F32
                 flat = torch.cat([e if code == MV_BF16 else e.to(torch.float32) for e in embs], 0).contiguous()
                 torch.cuda.current_stream(flat.device).synchronize()  # the library orders on its own stream
-                first = ix.add_device(flat.data_ptr(), code, [int(e.shape[0]) for e in embs], ords) + self.id_base
+                kw = {"device": flat.device.index} if len(self._devices()) > 1 or flat.device.index != self.device else {}
+                first = ix.add_device(flat.data_ptr(), code, [int(e.shape[0]) for e in embs], ords, **kw)
             else:
-                first = ix.add([e if isinstance(e, np.ndarray) else _embedding_rows(e) for e in embs], ords) + self.id_base
+                first = ix.add([e if isinstance(e, np.ndarray) else _embedding_rows(e) for e in embs], ords)
+            first += 0 if self._global_ids else self.id_base
+            # upsert: the previous page of an existing (document_id, chunk_number) is retired only now
+            # (FastMultiVectorStore upserts by id)
+            for c in valid:
+                old = self._page_of.pop((c.document_id, int(c.chunk_number)), None)
+                if old is not None:
+                    ix.remove_page(old if self._global_ids else old - self.id_base)
+                    self._rows.pop(old, None)
+                    if old in self._doc_pages.get(c.document_id, []):
+                        self._doc_pages[c.document_id].remove(old)
             ids = []
             for i, c in enumerate(valid):
                 page = first + i
-                self._rows[page] = (c.document_id, int(c.chunk_number), c.content, json.dumps(c.metadata or {}), app_id)
+                self._rows[page] = (c.document_id, int(c.chunk_number), contents[i], json.dumps(c.metadata or {}), app_id)
                 self._page_of[(c.document_id, int(c.chunk_number))] = page
                 self._doc_pages.setdefault(c.document_id, []).append(page)
                 ids.append(f"{c.document_id}-{c.chunk_number}")
             return ids
 
+    _global_ids = False  # a ShardedIndex hands out global page ids itself
+
     async def store_embeddings(self, chunks: List[DocumentChunk], app_id: Optional[str] = None) -> Tuple[bool, List[str], Dict[str, Any]]:
+        payload_backend = storage_backend_name(self.storage) if self._use_external() else "memory"
         valid: List[DocumentChunk] = []
         for chunk in chunks:
             if not hasattr(chunk, "embedding") or chunk.embedding is None:
@@ -202,53 +250,91 @@ class MI355XMultiVectorStore(BaseVectorStore):
             valid.append(chunk)
         if not valid:
             self._last_store_metrics = build_store_metrics(
-                chunk_payload_backend="memory", multivector_backend=self.backend_name, vector_store_backend=self.backend_name
+                chunk_payload_backend=payload_backend, multivector_backend=self.backend_name, vector_store_backend=self.backend_name
             )
             return True, [], self._last_store_metrics
+        resolved_app = self._resolve_app(app_id, valid)
         use_dev = self._index_factory is None
-        embs = [(_device_tensor(c.embedding, self.device) if use_dev else None) for c in valid]
+        devs = self._devices()
+        embs = [(_device_tensor(c.embedding, devs) if use_dev else None) for c in valid]
+        if len({e.device.index for e in embs if e is not None}) > 1:
+            embs = [None] * len(valid)  # rows spread over several GPUs: take the host path
         embs = [e if e is not None else _embedding_rows(c.embedding) for c, e in zip(valid, embs)]
+        if any(isinstance(e, np.ndarray) for e in embs) and not all(isinstance(e, np.ndarray) for e in embs):
+            embs = [e if isinstance(e, np.ndarray) else _embedding_rows(e) for e in embs]
         for c, e in zip(valid, embs):
             if e.shape[0] > self.stride_rows:
                 raise ValueError(
                     f"chunk {c.document_id}-{c.chunk_number} has {e.shape[0]} vectors; this store was created with "
                     f"stride_rows={self.stride_rows}"
                 )
+        # chunk content -> external storage, keys stay here (multi_vector_store.py:650-676)
+        contents = [c.content for c in valid]
+        payload_s, payload_objects, payload_bytes = 0.0, 0, 0
+        if self._use_external():
+            t0 = time.perf_counter()
+            res = await asyncio.gather(*[self._payloads.put(c.content, c.document_id, int(c.chunk_number), c.metadata or {}, resolved_app)
+                                         for c in valid])
+            payload_s = time.perf_counter() - t0
+            for i, (key, nbytes) in enumerate(res):
+                if key:
+                    contents[i] = key
+                    payload_objects += 1
+                    payload_bytes += nbytes
+                else:
+                    logger.warning(f"Failed to store chunk {valid[i].document_id}-{valid[i].chunk_number} externally, keeping it inline")
         t0 = time.perf_counter()
-        ids = await asyncio.to_thread(self._store_sync, valid, embs, app_id)
+        ids = await asyncio.to_thread(self._store_sync, valid, embs, contents, resolved_app)
         dt = time.perf_counter() - t0
         self._last_store_metrics = build_store_metrics(
-            chunk_payload_backend="memory", multivector_backend=self.backend_name, vector_store_backend=self.backend_name,
+            chunk_payload_backend=payload_backend, multivector_backend=self.backend_name, vector_store_backend=self.backend_name,
+            chunk_payload_upload_s=payload_s, chunk_payload_objects=payload_objects, chunk_payload_bytes=payload_bytes,
             multivector_upload_s=dt, multivector_objects=len(ids), multivector_bytes=int(sum(e.shape[0] for e in embs)) * 256,
             vector_store_write_s=dt, vector_store_rows=len(ids),
         )
         return True, ids, self._last_store_metrics
 
+    def _use_external(self) -> bool:
+        return self.enable_external_storage and self._payloads is not None
+
     # ------------------------------------------------------------------ query
     def _allow_for(self, doc_ids: Optional[List[str]], app_id: Optional[str]):
-        """doc_ids falsy => no filter (multi_vector_store.py:754). Returns (bitmap or None, empty?)."""
+        """doc_ids falsy => no doc filter (multi_vector_store.py:754).  Stores with per-app namespaces ALWAYS restrict to
+        the resolved app: FastMultiVectorStore queries self.ns(app_id), so app_id=None reads the default namespace only
+        (fast_multivector_store.py:526).  Returns (bitmap or None, empty?)."""
         from .index import allow_bitmap
 
         ords = None
         if doc_ids:
             ords = [self._doc_ord[d] for d in doc_ids if d in self._doc_ord]
-        if app_id is not None and self._filter_by_app:
-            base = range(len(self._doc_ord)) if ords is None else ords
-            ords = [o for o in base if self._doc_app.get(o) == app_id]
+        if self._filter_by_app:
+            want = app_id if app_id is not None else DEFAULT_APP_ID
+            base = list(self._doc_ord.values()) if ords is None else ords
+            ords = [o for o in base if self._doc_app.get(o) == want]
         if ords is None:
             return None, False
         if not ords:
             return None, True
-        return allow_bitmap(ords, len(self._doc_ord)), False
-
-    _filter_by_app = False  # MultiVectorStore.query_similar ignores app_id (multi_vector_store.py:721-763)
+        return allow_bitmap(ords, self._next_ord), False
 
     def _query_sync(self, q: np.ndarray, k: int, allow) -> Tuple[np.ndarray, np.ndarray]:
         ix = self._require_index()
         t0 = time.perf_counter()
-        s, i = ix.query(q, k, mode=self.mode, allow=allow)
-        self.last_query_timing = {"vector_search_s": time.perf_counter() - t0}
-        return s, i
+        want_stats = self.mode == "fde_then_float" and logger.isEnabledFor(logging.INFO) and self._index_factory is None
+        res = ix.query(q, k, mode=self.mode, allow=allow, want_stats=want_stats)
+        dt = time.perf_counter() - t0
+        self.last_query_timing = {"vector_search_s": dt}
+        if want_stats and len(res) == 3 and not isinstance(res[2], list):
+            st = res[2]
+            # the reference's stage lines (fast_multivector_store.py:523-577), device-side: there is no network hop and no
+            # multivector download -- the candidates never leave HBM
+            logger.info(f"query_similar timing - encode_query: {st.encode_ms:.2f} ms")
+            logger.info(f"query_similar timing - ns.query: {st.coarse_ms + st.select_ms:.2f} ms")
+            logger.info("query_similar timing - load_multivectors: 0.00 ms")
+            logger.info(f"query_similar timing - rerank_scoring: {st.rerank_ms + st.topk_ms:.2f} ms")
+            self.last_query_timing.update(encode_query_ms=st.encode_ms, ns_query_ms=st.coarse_ms + st.select_ms,
+                                          rerank_scoring_ms=st.rerank_ms + st.topk_ms, device_ms=st.total_device_ms)
+        return res[0], res[1]
 
     # -- request coalescing
     def _batch_sync(self, items: List[Tuple[np.ndarray, int, Any, Any]]):
@@ -256,7 +342,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         kmax = max(k for _q, k, _a, _f in items)
         allows = [a for _q, _k, a, _f in items]
         with self._lock:
-            n_docs = len(self._doc_ord)
+            n_docs = self._next_ord
         t0 = time.perf_counter()
         res = ix.query_batch([q for q, _k, _a, _f in items], kmax, mode="float", allows=allows if any(a is not None for a in allows) else None,
                              n_docs=n_docs)
@@ -295,6 +381,26 @@ class MI355XMultiVectorStore(BaseVectorStore):
             self._flush_handle = loop.call_later(self.batch_window_s, self._flush)
         return await fut
 
+    async def _resolve_contents(self, rows: List[Tuple[str, int, str, str, Optional[str]]], skip_image_content: bool) -> Tuple[List[str], List[dict]]:
+        """content column -> content: storage keys are downloaded, except image payloads the caller asked to skip (their
+        key is returned as the content: multi_vector_store.py:778-790, fast_multivector_store.py:583-586)."""
+        metas = [parse_metadata(r[3]) for r in rows]
+        tasks = []
+        for r, m in zip(rows, metas):
+            content = r[2]
+            if self._use_external() and is_storage_key(content) and not (skip_image_content and m.get("is_image")):
+                tasks.append(self._payloads.get(content, m))
+            else:
+                tasks.append(asyncio.sleep(0, result=content))
+        resolved = await asyncio.gather(*tasks, return_exceptions=True)
+        out = []
+        for r, c in zip(rows, resolved):
+            if isinstance(c, Exception):
+                logger.error("Failed to retrieve content from storage for chunk %s-%s: %s", r[0], r[1], c)
+                c = r[2]
+            out.append(c)
+        return out, metas
+
     async def query_similar(
         self,
         query_embedding: Any,
@@ -303,45 +409,60 @@ class MI355XMultiVectorStore(BaseVectorStore):
         app_id: Optional[str] = None,
         skip_image_content: bool = False,
     ) -> List[DocumentChunk]:
+        t_start = time.perf_counter()
         q = _embedding_rows(query_embedding)
-        with self._lock:
-            allow, empty = self._allow_for(doc_ids, app_id)
-        if empty or k <= 0:
+        if k <= 0:
             return []
-        if self.batch_window_s > 0 and self.mode == "float":
-            scores, pages = await self._coalesced_query(q, int(k), allow)
+        for _attempt in range(8):
+            with self._lock:
+                allow, empty = self._allow_for(doc_ids, app_id)
+                gen = self._generation
+            if empty:
+                return []
+            if self.batch_window_s > 0 and self.mode == "float":
+                scores, pages = await self._coalesced_query(q, int(k), allow)
+            else:
+                scores, pages = await asyncio.to_thread(self._query_sync, q, int(k), allow)  # exceptions propagate (:819-822)
+            hits: List[Tuple[float, Tuple[str, int, str, str, Optional[str]]]] = []
+            with self._lock:
+                if self._generation != gen:
+                    continue  # compact() renumbered the pages while the scan ran: these ids are stale, scan again
+                for s, p in zip(scores.tolist(), pages.tolist()):
+                    if self.min_score is not None and s < self.min_score:
+                        break  # hits are sorted by score desc
+                    row = self._rows.get(int(p))
+                    if row is not None:  # None: deleted between scan and lookup
+                        hits.append((float(s), row))
+            break
         else:
-            scores, pages = await asyncio.to_thread(self._query_sync, q, int(k), allow)  # exceptions propagate (:819-822)
-        out: List[DocumentChunk] = []
-        with self._lock:
-            for s, p in zip(scores.tolist(), pages.tolist()):
-                if self.min_score is not None and s < self.min_score:
-                    break  # hits are sorted by score desc
-                row = self._rows.get(int(p))
-                if row is None:
-                    continue  # deleted between scan and lookup
-                doc_id, chunk_no, content, meta_json, _app = row
-                out.append(DocumentChunk(document_id=doc_id, chunk_number=chunk_no, content=content, embedding=[],
-                                         metadata=json.loads(meta_json) if meta_json else {}, score=float(s)))
+            raise RuntimeError("query_similar: the index was compacted during every attempt")
+        t_scan = time.perf_counter()
+        contents, metas = await self._resolve_contents([r for _s, r in hits], skip_image_content)
+        out = [DocumentChunk(document_id=r[0], chunk_number=r[1], content=c, embedding=[], metadata=m, score=s)
+               for (s, r), c, m in zip(hits, contents, metas)]
+        if self.mode == "fde_then_float" and logger.isEnabledFor(logging.INFO):
+            t_end = time.perf_counter()
+            logger.info(f"query_similar timing - load_contents: {(t_end - t_scan)*1000:.2f} ms")
+            logger.info(f"query_similar total time: {(t_end - t_start)*1000:.2f} ms")
         return out
 
     async def get_chunks_by_id(self, chunk_identifiers: List[Tuple[str, int]], app_id: Optional[str] = None,
                                skip_image_content: bool = False) -> List[DocumentChunk]:
         if not chunk_identifiers:
             return []
-        out = []
+        rows = []
         with self._lock:
             for doc_id, chunk_no in dict.fromkeys((d, int(c)) for d, c in chunk_identifiers):
                 page = self._page_of.get((doc_id, chunk_no))
-                if page is None:
-                    continue
-                _d, _c, content, meta_json, _app = self._rows[page]
-                out.append(DocumentChunk(document_id=doc_id, chunk_number=chunk_no, content=content, embedding=[],
-                                         metadata=json.loads(meta_json) if meta_json else {}, score=0.0))
-        return out
+                if page is not None:
+                    rows.append(self._rows[page])
+        contents, metas = await self._resolve_contents(rows, skip_image_content)
+        return [DocumentChunk(document_id=r[0], chunk_number=r[1], content=c, embedding=[], metadata=m, score=0.0)
+                for r, c, m in zip(rows, contents, metas)]
 
     async def delete_chunks_by_document_id(self, document_id: str, app_id: Optional[str] = None) -> bool:
         try:
+            keys: List[str] = []
             with self._lock:
                 o = self._doc_ord.get(document_id)
                 if o is None:
@@ -352,8 +473,12 @@ class MI355XMultiVectorStore(BaseVectorStore):
                     row = self._rows.pop(page, None)
                     if row is not None:
                         self._page_of.pop((row[0], row[1]), None)
-                # the ordinal stays reserved (its pages are tombstoned in the slab)
+                        if self._use_external() and is_storage_key(row[2]):
+                            keys.append(row[2])
+                # the ordinal stays reserved until compact() (its pages are tombstoned in the slab under that ordinal)
             logger.info(f"Deleted all chunks for document {document_id} from {self.backend_name} store")
+            if keys:
+                await self._payloads.delete(keys, document_id)
             return True
         except Exception as e:  # noqa: BLE001
             logger.error(f"Error deleting chunks for document {document_id}: {e}")
@@ -362,60 +487,90 @@ class MI355XMultiVectorStore(BaseVectorStore):
     # ------------------------------------------------------------------ maintenance
     def compact(self) -> int:
         """Reclaim the slab slots of deleted / replaced pages (mv_index_compact) and remap the bookkeeping.
-        Returns the number of slots reclaimed.  Page ids are internal to the store, so callers see no change."""
+        Returns the number of slots reclaimed.  Page ids are internal to the store, so callers see no change; a query whose
+        scan overlapped the renumbering notices the generation change and scans again."""
         with self._lock:
             ix = self._require_index()
             before = len(ix)
             o2n = ix.compact()
-            remap = {self.id_base + int(o): self.id_base + int(n) for o, n in enumerate(o2n.tolist()) if n >= 0}
+            if isinstance(o2n, dict):
+                remap = o2n
+            else:
+                remap = {self.id_base + int(o): self.id_base + int(n) for o, n in enumerate(o2n.tolist()) if n >= 0}
             self._rows = {remap[p]: r for p, r in self._rows.items() if p in remap}
             self._page_of = {key: remap[p] for key, p in self._page_of.items() if p in remap}
             self._doc_pages = {d: [remap[p] for p in ps if p in remap] for d, ps in self._doc_pages.items()}
+            # documents without a live page no longer appear in the slab: forget their ordinals (a re-ingest gets a new one)
+            for d in [d for d in self._doc_ord if not self._doc_pages.get(d)]:
+                self._doc_app.pop(self._doc_ord.pop(d), None)
+                self._doc_pages.pop(d, None)
+            self._generation += 1
             return before - len(ix)
 
     # ------------------------------------------------------------------ checkpoint / resume
+    def _book(self) -> Dict[str, Any]:
+        return {
+            "version": 2, "mode": self.mode, "capacity_pages": self.capacity_pages, "stride_rows": self.stride_rows,
+            "id_base": self.id_base, "fde_coarse_n": self.fde_coarse_n, "next_ord": self._next_ord,
+            "rows": [[p, r[0], r[1], r[2], r[3], r[4]] for p, r in self._rows.items()],
+            "doc_ord": self._doc_ord, "doc_app": {str(k): v for k, v in self._doc_app.items()},
+        }
+
     def save(self, directory: str) -> None:
-        """Persist the HBM index (mv_index_save: raw slabs + metadata) and the store's bookkeeping (payload rows,
-        document ordinals) so a restarted process resumes without re-embedding -- the role Postgres / S3 play for the
-        reference stores (checkpoint/resume)."""
+        """Persist the HBM index (mv_index_save: raw slabs + metadata, written to a temp file and renamed) and the store's
+        bookkeeping (keys, document ordinals) so a restarted process resumes without re-embedding -- the role Postgres /
+        S3 play for the reference stores (checkpoint/resume).  store.json is written LAST and carries
+        the checkpoint id also stamped beside the index file: load() refuses a mixed pair."""
         import os
+        import uuid
 
         os.makedirs(directory, exist_ok=True)
         with self._lock:
             ix = self._require_index()
+            ckpt = uuid.uuid4().hex
             ix.save(os.path.join(directory, "index.mv"))
-            book = {
-                "version": 1, "mode": self.mode, "capacity_pages": self.capacity_pages, "stride_rows": self.stride_rows,
-                "id_base": self.id_base, "fde_coarse_n": self.fde_coarse_n,
-                "rows": [[p, r[0], r[1], r[2], r[3], r[4]] for p, r in self._rows.items()],
-                "doc_ord": self._doc_ord, "doc_app": {str(k): v for k, v in self._doc_app.items()},
-            }
+            with open(os.path.join(directory, "index.id.tmp"), "w") as f:
+                f.write(ckpt)
+                f.flush()
+                os.fsync(f.fileno())
+            os.replace(os.path.join(directory, "index.id.tmp"), os.path.join(directory, "index.id"))
+            book = self._book()
+            book["checkpoint"] = ckpt
             tmp = os.path.join(directory, "store.json.tmp")
             with open(tmp, "w") as f:
                 json.dump(book, f)
+                f.flush()
+                os.fsync(f.fileno())
             os.replace(tmp, os.path.join(directory, "store.json"))
+
+    @classmethod
+    def _load_index(cls, self, directory: str, book: Dict[str, Any], device: int):
+        import os
+
+        from .index import MvIndex
+
+        return MvIndex.load(os.path.join(directory, "index.mv"), device=device)
 
     @classmethod
     def load(cls, directory: str, device: int = 0, storage: Any = None, **kw: Any) -> "MI355XMultiVectorStore":
         import os
 
-        from .index import MvIndex
-
         with open(os.path.join(directory, "store.json")) as f:
             book = json.load(f)
+        idp = os.path.join(directory, "index.id")
+        if book.get("checkpoint") and os.path.exists(idp) and open(idp).read().strip() != book["checkpoint"]:
+            raise RuntimeError(f"{directory}: index.mv and store.json belong to different checkpoints (crash during save?)")
         self = cls(capacity_pages=book["capacity_pages"], stride_rows=book["stride_rows"], device=device, mode=book["mode"], storage=storage,
                    id_base=book["id_base"], fde_coarse_n=book.get("fde_coarse_n", 0), **kw)
-        self._index = MvIndex.load(os.path.join(directory, "index.mv"), device=device)
-        if self.fde_coarse_n:
-            from ._lib import MV_OPT_FDE_COARSE_N
-
-            self._index.set_option(MV_OPT_FDE_COARSE_N, self.fde_coarse_n)
+        self._index = cls._load_index(self, directory, book, device)
+        self._apply_options(self._index)
         for p, doc, chunk_no, content, meta_json, app in book["rows"]:
             self._rows[int(p)] = (doc, int(chunk_no), content, meta_json, app)
             self._page_of[(doc, int(chunk_no))] = int(p)
             self._doc_pages.setdefault(doc, []).append(int(p))
         self._doc_ord = {k: int(v) for k, v in book["doc_ord"].items()}
         self._doc_app = {int(k): v for k, v in book["doc_app"].items()}
+        self._next_ord = int(book.get("next_ord", max(self._doc_ord.values(), default=-1) + 1))
         return self
 
     # ------------------------------------------------------------------ introspection
@@ -425,18 +580,90 @@ class MI355XMultiVectorStore(BaseVectorStore):
 
 class MI355XFastMultiVectorStore(MI355XMultiVectorStore):
     """Drop-in for FastMultiVectorStore: FDE coarse stage + exact float rerank, per-app namespaces
-    (fast_multivector_store.py:504-607; `self.ns(app_id)` :526)."""
+    (fast_multivector_store.py:504-607; `self.ns(app_id)` :526).  A query only ever sees the pages of ONE app:
+    the given app_id, else "default"."""
 
     default_mode = "fde_then_float"
     _filter_by_app = True
 
+    def __init__(self, capacity_pages: int = 250_000, **kw: Any):
+        # sizing rule: fde_then_float keeps the bf16 slab (stride_rows * 256 B / page) AND the FDE slab (20 480 B / page):
+        # 250 k pages of 1040 rows = 66.6 + 5.1 GB.  1 M such pages (266 + 20 GB) do not fit one MI355X; use
+        # MI355XShardedFastMultiVectorStore over several GPUs, or mode="float_fp8" slabs, for corpora of that size.
+        super().__init__(capacity_pages=capacity_pages, **kw)
+
+
+class _ShardedMixin:
+    """R shards behind one store object (SURVEY.md 8e / VERDICT r1 item 4).  `devices` names the GPU of every shard
+    (default: every visible GPU once); repeating a device gives logical shards."""
+
+    _global_ids = True
+
+    def _init_sharding(self, devices: Optional[Sequence[int]], transport: str) -> None:
+        if devices is None:
+            from . import _lib
+
+            devices = list(range(max(int(_lib.lib().mv_device_count()), 1)))
+        self.devices = [int(d) for d in devices]
+        self.transport = transport
+        self.device = self.devices[0]
+
+    def _devices(self) -> List[int]:
+        return list(self.devices)
+
+    def _make_index(self):
+        from .shard_index import ShardedIndex
+
+        kw = {}
+        if self._index_factory is not None:  # CPU tests: oracle-backed shards + host merge
+            kw = dict(index_cls=self._index_factory, comm_cls=self._comm_factory)
+        ix = ShardedIndex(capacity_pages=self.capacity_pages, stride_rows=self.stride_rows, devices=self.devices, transport=self.transport,
+                          id_base=self.id_base, **self._slab_flags(), **kw)
+        self._apply_options(ix)
+        return ix
+
+    @classmethod
+    def _load_index(cls, self, directory: str, book: Dict[str, Any], device: int):
+        import os
+
+        from .shard_index import ShardedIndex
+
+        return ShardedIndex.load(os.path.join(directory, "index.mv"), devices=self.devices, transport=self.transport)
+
+    def _book(self) -> Dict[str, Any]:
+        b = super()._book()
+        b["n_shards"] = len(self.devices)
+        return b
+
+
+class MI355XShardedMultiVectorStore(_ShardedMixin, MI355XMultiVectorStore):
+    def __init__(self, devices: Optional[Sequence[int]] = None, transport: str = "auto", comm_factory: Any = None, **kw: Any):
+        super().__init__(**kw)
+        self._comm_factory = comm_factory
+        self._init_sharding(devices, transport)
+
+
+class MI355XShardedFastMultiVectorStore(_ShardedMixin, MI355XFastMultiVectorStore):
+    def __init__(self, devices: Optional[Sequence[int]] = None, transport: str = "auto", comm_factory: Any = None,
+                 capacity_pages: int = 1_000_000, **kw: Any):
+        super().__init__(capacity_pages=capacity_pages, **kw)
+        self._comm_factory = comm_factory
+        self._init_sharding(devices, transport)
+
 
 def create_store(provider: str, **kw: Any) -> MI355XMultiVectorStore:
-    """Factory for core/services_init.py: [multivector_store] provider = "mi355x" | "mi355x_fast" | "mi355x_float"."""
+    """Factory for core/services_init.py: [multivector_store] provider =
+    "mi355x" | "mi355x_fast" | "mi355x_float" | "mi355x_sharded" | "mi355x_sharded_fast" | "mi355x_sharded_float"."""
     if provider == "mi355x":
         return MI355XMultiVectorStore(**kw)
     if provider == "mi355x_fast":
         return MI355XFastMultiVectorStore(**kw)
     if provider == "mi355x_float":
         return MI355XMultiVectorStore(mode="float", **kw)
+    if provider == "mi355x_sharded":
+        return MI355XShardedMultiVectorStore(**kw)
+    if provider == "mi355x_sharded_fast":
+        return MI355XShardedFastMultiVectorStore(**kw)
+    if provider == "mi355x_sharded_float":
+        return MI355XShardedMultiVectorStore(mode="float", **kw)
     raise ValueError(f"unknown MI355X multivector provider {provider!r}")

@@ -6,8 +6,11 @@ from oracle import oracle as orc
 
 
 class OracleIndex:
-    def __init__(self, capacity_pages, stride_rows, device=0, id_base=0, mode="float", fde=None, **_):
+    def __init__(self, capacity_pages, stride_rows, device=0, id_base=0, mode="float", fde=None, with_binary=False, **_):
         self.capacity, self.stride_rows, self.id_base, self.mode = capacity_pages, stride_rows, id_base, mode
+        self.device = device
+        if with_binary and mode == "float":
+            self.mode = "binary"  # built by ShardedIndex from slab flags
         self.pages, self.ords, self.alive = [], [], []
         self.fde = fde  # oracle FdeConfig; enables mode "fde" / "fde_then_float"
 
@@ -40,7 +43,7 @@ class OracleIndex:
     def _mask(self, allow):
         m = np.array(self.alive, bool)
         if allow is not None:
-            o = np.array(self.ords)
+            o = np.array(self.ords, dtype=np.int64)
             ok = (o < allow.size * 32) & (((allow[np.minimum(o >> 5, allow.size - 1)] >> (o & 31).astype(np.uint32)) & 1) == 1)
             m &= ok
         return m
@@ -120,3 +123,27 @@ class OracleIndex:
 
     def close(self):
         pass
+
+
+class OracleComm:
+    """Stand-in for index.ShardComm over OracleIndex shards: per-shard top-k merged on the host with the library's rule
+    (score desc; ties: shard asc, position asc == ascending global id).  Single-stage modes only."""
+
+    def __init__(self, shards, transport="auto"):
+        self.shards, self.transport = list(shards), "host"
+
+    def close(self):
+        pass
+
+    def query(self, q, k, mode="float", allow=None, want_stats=False):
+        s_all, i_all = [], []
+        for sh in self.shards:
+            s, i = sh.query(q, k, mode=mode, allow=allow)
+            ok = np.isfinite(s)
+            s_all.append(s[ok])
+            i_all.append(i[ok])
+        s = np.concatenate(s_all) if s_all else np.zeros(0, np.float32)
+        i = np.concatenate(i_all) if i_all else np.zeros(0, np.int64)
+        order = np.lexsort((i, -s.astype(np.float64)))[:k]
+        res = (s[order].astype(np.float32), i[order].astype(np.int64))
+        return res + ([None] * len(self.shards),) if want_stats else res

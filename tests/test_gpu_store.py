@@ -253,3 +253,106 @@ def test_random_op_sequences_match_a_brute_force_model_on_gpu(seed, mode):
         sc.run(sc.scenario_random_ops_against_model(s, seed=seed, n_ops=80, mode=mode, capacity=64))
     finally:
         s.close()
+
+
+# ------------------------------------------------------------------ one store object over R shards (mv_comm)
+def _sharded(R, mode, transport="auto", **kw):
+    from morphik_core_amd.store import MI355XShardedFastMultiVectorStore, MI355XShardedMultiVectorStore
+
+    cls = MI355XShardedFastMultiVectorStore if mode == "fde_then_float" else MI355XShardedMultiVectorStore
+    s = cls(devices=[0] * R, transport=transport, capacity_pages=64, stride_rows=32, mode=mode, **kw)
+    assert s.initialize() is True
+    return s
+
+
+@pytest.mark.parametrize("R", [1, 2, 4])
+@pytest.mark.parametrize("scenario", sc.ALL, ids=lambda f: f.__name__)
+@pytest.mark.parametrize("mode", ["binary", "float", "fde_then_float"])
+def test_sharded_store_reference_scenarios_on_gpu(scenario, mode, R):
+    """the reference's store scenarios on ONE store object that owns R logical shards of one GPU
+    (mv_comm with peer copies: RCCL cannot put two ranks on one device)."""
+    s = _sharded(R, mode)
+    try:
+        assert s._index.transport == "p2p"
+        sc.run(scenario(s))
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("R", [2, 4])
+@pytest.mark.parametrize("mode", ["float", "binary"])
+def test_sharded_store_random_ops_match_the_model_on_gpu(R, mode):
+    s = _sharded(R, mode, transport="host" if R == 2 else "p2p")
+    try:
+        sc.run(sc.scenario_random_ops_against_model(s, seed=10 + R, n_ops=60, mode=mode, capacity=40))
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("mode", ["float", "binary", "fde_then_float", "float_fp8"])
+def test_sharded_store_answers_equal_the_single_store(mode, tmp_path):
+    """Same ingest sequence into a single store and into 1 / 2 / 4-shard stores: identical hits, order and scores (ties
+    included: duplicated pages land on different shards), before and after a checkpoint round trip."""
+    from morphik_core_amd.store import MI355XShardedFastMultiVectorStore, MI355XShardedMultiVectorStore
+
+    rng = np.random.default_rng(31)
+    chunks = sc.make_chunks(rng, n_docs=8, chunks_per_doc=3, rows=30)
+    for j in (4, 9, 14, 19):  # exact duplicates of page 0 scattered over the documents -> equal scores across shards
+        chunks[j] = chunks[j].model_copy(update={"embedding": chunks[0].embedding})
+    kw = dict(fde_coarse_n=20) if mode == "fde_then_float" else {}
+    one = _store(mode) if mode != "fde_then_float" else None
+    if one is None:
+        from morphik_core_amd.store import MI355XFastMultiVectorStore
+
+        one = MI355XFastMultiVectorStore(capacity_pages=64, stride_rows=32, mode=mode, **kw)
+        assert one.initialize()
+    stores = {R: _sharded(R, mode, **kw) for R in (1, 2, 4)}
+    for st in [one] + list(stores.values()):
+        for d in range(8):
+            sc.run(st.store_embeddings(chunks[d * 3 : d * 3 + 3]))
+        sc.run(st.delete_chunks_by_document_id("doc5"))
+    queries = [chunks[0].embedding, chunks[7].embedding, sc.rand_emb(rng, 11)]
+
+    def answers(st):
+        out = []
+        for q in queries:
+            for filt in (None, ["doc0", "doc1", "doc3", "doc6"]):
+                r = sc.run(st.query_similar(q, k=9, doc_ids=filt))
+                out.append([(c.document_id, c.chunk_number, c.content, c.score) for c in r])
+        return out
+
+    want = answers(one)
+    assert any(len({s for *_x, s in a}) < len(a) for a in want)  # ties are really present
+    for R, st in stores.items():
+        assert answers(st) == want, (mode, R)
+    # checkpoint / resume of the sharded store: one index file per shard + one bookkeeping file
+    d = str(tmp_path / "ckpt")
+    stores[4].save(d)
+    stores[4].close()
+    cls = MI355XShardedFastMultiVectorStore if mode == "fde_then_float" else MI355XShardedMultiVectorStore
+    back = cls.load(d, devices=[0] * 4)
+    assert answers(back) == want
+    back.close()
+    for st in (one, stores[1], stores[2]):
+        st.close()
+
+
+def test_fast_store_emits_the_reference_stage_timing_lines(caplog):
+    """fast_multivector_store.py:523-605 logs encode_query / ns.query / load_multivectors / rerank_scoring / load_contents /
+    total per query; the MI355X store emits the same lines from the library's device-side stage split."""
+    import logging
+
+    s = _store("fde_then_float")
+    rng = np.random.default_rng(2)
+    chunks = sc.make_chunks(rng)
+    sc.run(s.store_embeddings(chunks))
+    with caplog.at_level(logging.INFO, logger="morphik_core_amd.store"):
+        res = sc.run(s.query_similar(chunks[3].embedding, k=3))
+    assert res[0].content == chunks[3].content
+    text = caplog.text
+    for stage in ("encode_query", "ns.query", "load_multivectors", "rerank_scoring", "load_contents"):
+        assert f"query_similar timing - {stage}:" in text
+    assert "query_similar total time:" in text
+    t = s.last_query_timing
+    assert t["encode_query_ms"] > 0 and t["ns_query_ms"] > 0 and t["rerank_scoring_ms"] > 0 and t["device_ms"] >= t["ns_query_ms"]
+    s.close()

@@ -44,7 +44,20 @@ def test_fast_store_filters_by_app_namespace():
     sc.run(s.store_embeddings(b, app_id="app-b"))
     res = sc.run(s.query_similar(a[0].embedding, k=10, app_id="app-b"))
     assert {r.document_id for r in res} == {"other"}
-    assert len(sc.run(s.query_similar(a[0].embedding, k=10))) == 4
+    # FastMultiVectorStore always queries ONE namespace, self.ns(app_id) (fast_multivector_store.py:526): without an app_id
+    # that is the default namespace -- never every tenant's pages
+    assert sc.run(s.query_similar(a[0].embedding, k=10)) == []
+    c = [x.model_copy(update={"document_id": "mine"}) for x in sc.make_chunks(rng, n_docs=1, chunks_per_doc=2)]
+    sc.run(s.store_embeddings(c))  # no app_id on the way in -> the default namespace too
+    assert {r.document_id for r in sc.run(s.query_similar(c[0].embedding, k=10))} == {"mine"}
+    assert {r.document_id for r in sc.run(s.query_similar(c[0].embedding, k=10, app_id="default"))} == {"mine"}
+    # a doc_ids filter cannot reach into another app's namespace
+    assert sc.run(s.query_similar(a[0].embedding, k=10, doc_ids=["other"], app_id="app-a")) == []
+    # store_embeddings without app_id resolves the document's app through the callback (the reference's documents-table lookup)
+    s2 = _store(MI355XFastMultiVectorStore, mode="float", app_id_resolver=lambda doc: {"doc0": "app-z"}.get(doc))
+    sc.run(s2.store_embeddings(a))
+    assert len(sc.run(s2.query_similar(a[0].embedding, k=10, app_id="app-z"))) == 2
+    assert sc.run(s2.query_similar(a[0].embedding, k=10)) == []
 
 
 def test_too_many_vectors_is_an_error_and_factory():
@@ -166,3 +179,145 @@ def test_optional_min_score_cut():
     cut.min_score = (res[1].score + res[2].score) / 2
     got = sc.run(cut.query_similar(chunks[0].embedding, k=6))
     assert [(r.document_id, r.chunk_number) for r in got] == [(r.document_id, r.chunk_number) for r in res[:2]]
+
+
+# --------------------------------------------------------------------------- payloads through .storage
+class MemStorage:
+    """BaseStorage stand-in (core/storage/base_storage.py): the three coroutines the stores use."""
+
+    def __init__(self):
+        self.objects, self.uploads, self.downloads, self.fail_upload = {}, 0, 0, False
+
+    async def upload_from_base64(self, content, key, content_type=None, bucket=""):
+        import base64
+
+        if self.fail_upload:
+            raise RuntimeError("storage down")
+        self.objects[(bucket, key)] = (base64.b64decode(content), content_type)
+        self.uploads += 1
+        return bucket, key
+
+    async def download_file(self, bucket, key):
+        self.downloads += 1
+        return self.objects[(bucket, key)][0]
+
+    async def delete_file(self, bucket, key):
+        return self.objects.pop((bucket, key), None) is not None
+
+
+def _png_data_uri(n=200):
+    import base64
+
+    return "data:image/png;base64," + base64.b64encode(b"\x89PNG\r\n\x1a\n" + bytes(range(256)) * (n // 256 + 1)).decode()
+
+
+def test_payloads_live_in_storage_and_skip_image_content_returns_the_key():
+    """multi_vector_store.py:650-699 (upload, keep the key), :778-817 / :866-919 (download on hit unless the caller skips image
+    payloads), :921-946 (delete the objects with the document)."""
+    from morphik_core_amd.models import DocumentChunk
+    from morphik_core_amd.payloads import MULTIVECTOR_CHUNKS_BUCKET
+
+    st = MemStorage()
+    s = _store(mode="float", storage=st)
+    rng = np.random.default_rng(9)
+    img = _png_data_uri()
+    chunks = [DocumentChunk(document_id="d", chunk_number=0, content=img, embedding=sc.rand_emb(rng, 9), metadata={"is_image": True}),
+              DocumentChunk(document_id="d", chunk_number=1, content="plain text of page 2", embedding=sc.rand_emb(rng, 9), metadata={"is_image": False})]
+    ok, ids, m = sc.run(s.store_embeddings(chunks, app_id="app1"))
+    assert ok and m["chunk_payload_objects"] == 2 and m["chunk_payload_bytes"] > 200 and m["chunk_payload_backend"] == "memstorage"
+    assert set(st.objects) == {(MULTIVECTOR_CHUNKS_BUCKET, "app1/d/0.png"), (MULTIVECTOR_CHUNKS_BUCKET, "app1/d/1.txt")}
+    assert st.objects[(MULTIVECTOR_CHUNKS_BUCKET, "app1/d/1.txt")] == (b"plain text of page 2", "text/plain")
+    assert all(len(r[2]) < 64 for r in s._rows.values())  # only keys in RAM
+    hit = sc.run(s.query_similar(chunks[0].embedding, k=2))
+    assert [h.chunk_number for h in hit] == [0, 1] and hit[0].content == img and hit[1].content == "plain text of page 2"
+    n_dl = st.downloads
+    skipped = sc.run(s.query_similar(chunks[0].embedding, k=2, skip_image_content=True))
+    assert skipped[0].content == "app1/d/0.png" and skipped[1].content == "plain text of page 2" and st.downloads == n_dl + 1
+    got = sc.run(s.get_chunks_by_id([("d", 0)], skip_image_content=True))
+    assert got[0].content == "app1/d/0.png"
+    assert sc.run(s.get_chunks_by_id([("d", 0)]))[0].content == img
+    assert sc.run(s.delete_chunks_by_document_id("d")) is True and st.objects == {}
+    # a failing upload keeps the content inline (the reference's database-column fallback) and the store keeps working
+    st.fail_upload = True
+    ok, ids, m = sc.run(s.store_embeddings([chunks[1]], app_id="app1"))
+    assert ok and m["chunk_payload_objects"] == 0
+    assert sc.run(s.query_similar(chunks[1].embedding, k=1))[0].content == "plain text of page 2"
+
+
+# --------------------------------------------------------------------------- ADVICE r1: compaction vs queries, upsert order
+def test_query_that_overlaps_a_compaction_is_rerun_against_the_new_numbering():
+    rng = np.random.default_rng(11)
+    chunks = sc.make_chunks(rng, n_docs=4, chunks_per_doc=3)
+    s = _store(mode="float")
+    sc.run(s.store_embeddings(chunks))
+    sc.run(s.delete_chunks_by_document_id("doc0"))  # pages 0..2 tombstoned: compaction will renumber everything else
+    want = sc.run(s.query_similar(chunks[7].embedding, k=3))
+    real = s._index.query
+    calls = []
+
+    def racing_query(q, k, **kw):
+        out = real(q, k, **kw)
+        if not calls:  # a compaction lands between this query's scan and its id lookup
+            calls.append(1)
+            assert s.compact() == 3
+        else:
+            calls.append(2)
+        return out
+
+    s._index.query = racing_query
+    got = sc.run(s.query_similar(chunks[7].embedding, k=3))
+    assert calls == [1, 2]  # the stale scan was thrown away and repeated
+    assert [(c.document_id, c.chunk_number, c.content, c.score) for c in got] == [(c.document_id, c.chunk_number, c.content, c.score) for c in want]
+
+
+def test_failed_upsert_keeps_the_previous_version_and_ordinals_are_reclaimed():
+    rng = np.random.default_rng(12)
+    s = MI355XMultiVectorStore(capacity_pages=4, stride_rows=32, mode="float", index_factory=OracleIndex)
+    chunks = sc.make_chunks(rng, n_docs=1, chunks_per_doc=4)
+    sc.run(s.store_embeddings(chunks))
+    with pytest.raises(Exception):  # slab full: the add fails BEFORE anything is tombstoned
+        sc.run(s.store_embeddings([chunks[1].model_copy(update={"content": "v2"})]))
+    assert sc.run(s.query_similar(chunks[1].embedding, k=1))[0].content == chunks[1].content
+    assert len(s) == 4
+    sc.run(s.delete_chunks_by_document_id("doc0"))
+    assert s.compact() == 4 and s._doc_ord == {} and s._doc_app == {}  # no page left: the ordinal is forgotten
+    sc.run(s.store_embeddings(chunks[:2]))
+    assert len(sc.run(s.query_similar(chunks[0].embedding, k=5, doc_ids=["doc0"]))) == 2
+
+
+# --------------------------------------------------------------------------- sharded store (host logic; GPU: test_gpu_store.py)
+def _sharded(R, **kw):
+    from morphik_core_amd.store import MI355XShardedMultiVectorStore
+    from tests.fake_index import OracleComm
+
+    s = MI355XShardedMultiVectorStore(devices=[0] * R, capacity_pages=64, stride_rows=32, index_factory=OracleIndex, comm_factory=OracleComm, **kw)
+    assert s.initialize() is True
+    return s
+
+
+@pytest.mark.parametrize("R", [1, 2, 4])
+@pytest.mark.parametrize("scenario", sc.ALL, ids=lambda f: f.__name__)
+def test_sharded_store_passes_the_reference_scenarios(scenario, R):
+    sc.run(scenario(_sharded(R, mode="float")))
+
+
+@pytest.mark.parametrize("R", [2, 4])
+@pytest.mark.parametrize("mode", ["float", "binary"])
+def test_sharded_store_random_ops_match_the_model(R, mode):
+    sc.run(sc.scenario_random_ops_against_model(_sharded(R, mode=mode), seed=R, n_ops=50, mode=mode, capacity=40))
+
+
+def test_sharded_store_equals_single_store_and_spreads_the_pages():
+    rng = np.random.default_rng(21)
+    chunks = sc.make_chunks(rng, n_docs=6, chunks_per_doc=3)
+    one, four = _store(mode="float"), _sharded(4, mode="float")
+    for st in (one, four):
+        for d in range(6):  # one store_embeddings call per document, like the ingestion worker
+            sc.run(st.store_embeddings(chunks[d * 3 : d * 3 + 3]))
+    assert [len(sh) for sh in four._index.shards] == [6, 6, 3, 3]  # least-full routing
+    for c in chunks[::4]:
+        for filt in (None, ["doc1", "doc4"]):
+            a = sc.run(one.query_similar(c.embedding, k=7, doc_ids=filt))
+            b = sc.run(four.query_similar(c.embedding, k=7, doc_ids=filt))
+            assert [(x.document_id, x.chunk_number, x.content) for x in a] == [(x.document_id, x.chunk_number, x.content) for x in b]
+            assert [x.score for x in a] == [x.score for x in b]
