@@ -16,12 +16,22 @@ rank merges them.  Inputs are resident in HBM when the timed region starts.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no launcher in the environment starts the N ranks itself (it re-executes
+this file under torch.distributed.run on 127.0.0.1 and relays rank 0's JSON line).
+
+Other workloads (`--workload`): fp8 (configs[4] shape), binary (MultiVectorStore's sign-bit max_sim), fde_fp8
+(configs[3] shard shape: FDE coarse top-1000 -> exact fp8 rerank), embed (configs[1]: ColPali-v1.2 architecture embeds
+1 k synthetic pages -> device ingest -> MaxSim top-10).
+
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
 import argparse
 import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +42,7 @@ sys.path.insert(0, ROOT)
 
 PAGE_ROW_BYTES = 256  # 128 x bf16
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 (same guide)
 N_QUERIES = 16
 N_PLANTED = 10
 K = 10
@@ -41,12 +52,25 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(sample_pages_u16, q_u16, budget_s=20.0):
-    """Reference CPU path timed on this box's host cores, on a bounded sample of the same workload.
-    Two formulations of the reference's float MaxSim (fast_multivector_store.py:553-555 ->
-    score_multi_vector): (i) torch einsum over page batches of 128 (the reference's own expression),
-    (ii) numpy sgemm -> max -> sum.  fp32 on upcast bf16 data (the reference upcasts at load,
-    fast_multivector_store.py:736,774).  The faster one is the baseline of record."""
+def timed_runs(fn, min_runs=5, budget_s=12.0, max_runs=7):
+    """Warm-up call, then >= min_runs timed calls (more while the budget lasts).  -> list of seconds."""
+    fn()
+    times = []
+    t_end = time.time() + budget_s
+    while len(times) < min_runs or (time.time() < t_end and len(times) < max_runs):
+        t0 = time.perf_counter()
+        fn()
+        times.append(time.perf_counter() - t0)
+    return times
+
+
+def cpu_baseline(sample_pages_u16, q_u16):
+    """Reference CPU path timed on this box's host cores, on a bounded sample of the same workload (BASELINE.md section
+    3: >= 20 000 pages, >= 5 repeats, median).  Two formulations of the reference's float MaxSim
+    (fast_multivector_store.py:553-555 -> score_multi_vector): (i) numpy sgemm -> max -> sum over all cores,
+    (ii) torch einsum over page batches of 128 (the reference's own expression; ~20x slower, smaller sample).
+    fp32 on upcast bf16 data (the reference upcasts at load, fast_multivector_store.py:736,774).  The faster one is the
+    baseline of record."""
     from oracle import oracle as orc  # CPU checker / baseline only
 
     import torch
@@ -56,32 +80,28 @@ def cpu_baseline(sample_pages_u16, q_u16, budget_s=20.0):
     q = orc.bf16_to_f32(q_u16)
     pages = orc.bf16_to_f32(sample_pages_u16)  # upcast outside the timed region, like the reference's load step
     n = pages.shape[0]
-    n_torch = min(n, 2048)  # the einsum formulation is ~20x slower: smaller sample, same per-page work
+    n_torch = min(n, 2048)
     res, used = {}, {}
-    for name, fn, m in (("numpy_sgemm", lambda: orc.maxsim_float_np(q, pages), n),
-                        ("torch_einsum", lambda: orc.maxsim_float_torch(q, pages[:n_torch]), n_torch)):
-        fn()  # warm-up
-        times = []
-        t_end = time.time() + budget_s / 2
-        while len(times) < 5 and (time.time() < t_end or not times):
-            t0 = time.perf_counter()
-            fn()
-            times.append(time.perf_counter() - t0)
+    for name, fn, m, budget in (("numpy_sgemm", lambda: orc.maxsim_float_np(q, pages), n, 14.0),
+                                ("torch_einsum", lambda: orc.maxsim_float_torch(q, pages[:n_torch]), n_torch, 8.0)):
+        times = timed_runs(fn, min_runs=5, budget_s=budget)
         res[name] = m / float(np.median(times))
         used[name] = (m, len(times))
     best = max(res, key=res.get)
+    page_bytes_f32 = pages.shape[1] * 128 * 4
     return {
         "value": round(res[best], 1),
         "unit": "pages/s",
         "cores": cores,
         "kind": "port",
+        "achieved_GBps_fp32_pages": round(res[best] * page_bytes_f32 / 1e9, 2),
         "sample": f"{pages.shape[1]} patches x 128-d fp32 (upcast bf16), Q={q.shape[0]}; numpy_sgemm={res['numpy_sgemm']:.0f} pages/s on {used['numpy_sgemm'][0]} pages "
                   f"(median of {used['numpy_sgemm'][1]}), torch_einsum={res['torch_einsum']:.0f} pages/s on {used['torch_einsum'][0]} pages "
                   f"(median of {used['torch_einsum'][1]}); best={best}",
     }
 
 
-def cpu_baseline_binary(bits_sample, q_bits, budget_s=20.0):
+def cpu_baseline_binary(bits_sample, q_bits):
     """CPU restatement of SQL max_sim (core/vector_store/multi_vector_store.py:285-313) on the host cores, bounded
     sample: (i) 64-bit popcounts in numpy (one thread), (ii) the +-1 identity as an all-core sgemm -> max -> sum
     (0.5 Q + sum_q max_d (s_q . s_d) / 256).  Postgres itself is not available on the box."""
@@ -102,66 +122,128 @@ def cpu_baseline_binary(bits_sample, q_bits, budget_s=20.0):
     ref = orc.maxsim_binary_popcount_np(bits_sample[:64], q_bits)
     assert np.array_equal(ref, orc.maxsim_binary_np(bits_sample[:64], q_bits)) and np.allclose(ref, pm1()[:64])
     for name, fn in (("numpy_popcount_1thread", lambda: orc.maxsim_binary_popcount_np(bits_sample, q_bits)), ("pm1_sgemm_allcores", pm1)):
-        fn()
-        times = []
-        t_end = time.time() + budget_s / 2
-        while len(times) < 5 and (time.time() < t_end or not times):
-            t0 = time.perf_counter()
-            fn()
-            times.append(time.perf_counter() - t0)
+        times = timed_runs(fn, min_runs=5, budget_s=8.0)
         res[name] = n / float(np.median(times))
     best = max(res, key=res.get)
     return {"value": round(res[best], 1), "unit": "pages/s", "cores": 1 if best.endswith("1thread") else (os.cpu_count() or 1), "kind": "port",
-            "sample": f"{n} pages x {bits_sample.shape[1]} patches x BIT(128), Q={q_bits.shape[0]}, median of <=5 runs; "
+            "sample": f"{n} pages x {bits_sample.shape[1]} patches x BIT(128), Q={q_bits.shape[0]}, median of >=5 runs; "
                       + "; ".join(f"{k}={v:.0f}" for k, v in res.items()) + f" pages/s; best={best}"}
 
 
+def lib_sha256():
+    import morphik_core_amd as mca
+
+    h = hashlib.sha256()
+    with open(mca.library_path(), "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def pmc_traffic(n_local, patches):
+    """HBM traffic of the scan kernel from rocprofv3 PMC counters (FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch
+    correction calibrated on a known byte count in the same pass), collected by tools/pmc_traffic.sh and committed under
+    profiles/.  Only a record taken on THIS library build counts: the file names the kernel symbol and the sha256 of the
+    libmvmaxsim.so it profiled; anything else -> null (a kernel change must not inherit an old measurement)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "**", "pmc_traffic*.json"), recursive=True), key=os.path.getmtime)
+    sha = lib_sha256()
+    for f in reversed(files):
+        try:
+            rec = json.load(open(f))
+            if rec.get("lib_sha256") == sha and "maxsim_ldsdma_kernel" in rec.get("kernel", ""):
+                return int(round(float(rec["hbm_bytes_per_page"]) * n_local * patches / 1024.0)), os.path.relpath(f, ROOT), rec.get("kernel")
+        except Exception:  # noqa: BLE001
+            continue
+    return None, None, None
+
+
+def recall_block(ix, qs, truths, K, coarse_ns=(75, 1000)):
+    """recall@10 against the exact bf16 top-10 for every lossy path of an all-slab index, + FDE coarse recall."""
+    from morphik_core_amd import _lib as L
+    from morphik_core_amd import synth
+
+    out = {}
+    for mode in ("float_fp8", "binary"):
+        out[mode] = float(np.mean([synth.recall_at_k(ix.query(q, K, mode=mode)[1].tolist(), t) for q, t in zip(qs, truths)]))
+    for cn in coarse_ns:
+        ix.set_option(L.MV_OPT_FDE_COARSE_N, cn)
+        out[f"fde_top{cn}_then_float"] = float(np.mean([synth.recall_at_k(ix.query(q, K, mode="fde_then_float")[1].tolist(), t) for q, t in zip(qs, truths)]))
+    out["fde_coarse_recall_at_1000"] = float(np.mean([synth.recall_at_k(ix.query(q, 1000, mode="fde")[1].tolist(), t) for q, t in zip(qs, truths)]))
+    return out
+
+
 def aux_paths(args, device, mfma_peak=None):
-    """Quick, separately sized measurements of the other hot-path kernels (same HIP-event method, a smaller
-    corpus): sign-bit MaxSim (SQL max_sim semantics), fp8 slab, FDE coarse scan, FDE -> fp8 rerank, and the
-    batched-query MFMA form.  Reported next to the headline number, never mixed into `value`.  None of them launches
-    the headline scan kernel, so the rocprofv3 kernel stats of this command stay those of the timed workload."""
+    """Quick, separately sized measurements of the other hot-path kernels (same HIP-event method, a smaller corpus with
+    EVERY slab): sign-bit MaxSim (SQL max_sim semantics), fp8 slab, FDE coarse scan, FDE -> rerank, the batched-query MFMA
+    form, and recall@10 of the lossy paths against the exact bf16 top-10 on hard negatives and on a corpus with no
+    planted structure at all.  Reported next to the headline number, never mixed into `value`.  None of them launches the
+    headline scan kernel inside a timed region of the main workload."""
     from morphik_core_amd import _lib as L
     from morphik_core_amd import synth
     from morphik_core_amd.index import MvIndex, synth_rows
 
     n = args.aux_pages
     stride = ((args.patches + 15) // 16) * 16
-    qs = [synth_rows(synth.SEED_QUERIES, qi, args.qtokens, device=device) for qi in range(N_QUERIES)]
-    spec = synth.planted_spec(qs, n, args.patches, n_ranks=N_PLANTED)
+    NH, NR = 8, 4  # hard-negative queries, unplanted queries
+    qs = [synth_rows(synth.SEED_QUERIES, qi, args.qtokens, device=device) for qi in range(N_QUERIES + NH + NR)]
+    spec = synth.planted_spec(qs[:N_QUERIES], n, args.patches, n_ranks=N_PLANTED)
     planted = {qi: [p for (qq, _r, p, _a, _b) in spec if qq == qi] for qi in range(N_QUERIES)}
-    res = {"pages": n, "note": "kernel-only HIP-event times, median of 5; recall@10 against the planted exact (bf16) top-10"}
-    # --- index A: sign bits + e4m3 + FDE (no bf16 slab)
-    ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=False, with_binary=True, with_fde=True, with_fp8=True)
+    taken = {p for (_q, _r, p, _a, _b) in spec}
+    hq = qs[N_QUERIES : N_QUERIES + NH]
+    hspec = [t for t in synth.hard_spec(hq, n, args.patches) if t[2] not in taken]
+    res = {"pages": n, "note": "kernel-only HIP-event times, median of 5, on one index holding bf16 + e4m3 + sign-bit + FDE slabs"}
+    ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=True, with_binary=True, with_fde=True, with_fp8=True)
     ix.fill_synthetic(synth.SEED_CORPUS, 0, n, n_rows=args.patches)
     synth.plant_neighbours_any(ix, spec, synth.SEED_CORPUS, args.patches)
+    synth.plant_neighbours_any(ix, hspec, synth.SEED_CORPUS, args.patches)
     per_page = {"binary": args.patches * 16, "float_fp8": args.patches * 128, "fde": 10240 * 2}
     for mode in ("binary", "float_fp8", "fde"):
-        ms = []
+        ms, coarse = [], []
         for r in range(6):
             _s, _i, st = ix.query(qs[r % N_QUERIES], K, mode=mode, want_stats=True)
             if r:
                 ms.append(st.score_kernel_ms)
-        m = float(np.median(ms))
+                coarse.append(st.coarse_ms)
+        m = float(np.median(coarse)) if mode == "fde" else float(np.median(ms))  # FDE: the slab scan alone (the query encode is its own stage)
         ent = {"kernel_ms": round(m, 4), "pages_per_s": round(n / m * 1e3, 1), "GBps": round(n * per_page[mode] / m / 1e6, 1),
                "frac_hbm_8TBps": round(n * per_page[mode] / m / 1e6 / HBM_PEAK_GBPS, 4), "bytes_per_page": per_page[mode]}
-        if mode == "float_fp8":
-            ent["recall_at_10"] = float(np.mean([synth.recall_at_k(ix.query(qs[qi], K, mode=mode)[1].tolist(), planted[qi]) for qi in range(N_QUERIES)]))
+        if mode == "fde":
+            ent["span_with_query_encode_ms"] = round(float(np.median(ms)), 4)
         res[mode] = ent
-    # FDE coarse top-1000 -> exact rerank on the fp8 slab (configs[3] pipeline): recall of the planted top-10
+    # FDE coarse top-1000 -> exact rerank (configs[3] pipeline), all in stream order on the device
     ix.set_option(L.MV_OPT_FDE_COARSE_N, 1000)
-    rec, ms = [], []
+    ms, stg = [], []
     for qi in range(N_QUERIES):
         _s, ids, st = ix.query(qs[qi], K, mode="fde_then_float", want_stats=True)
         ms.append(st.total_device_ms)
-        rec.append(synth.recall_at_k(ids.tolist(), planted[qi]))
-    res["fde_top1000_then_fp8"] = {"device_ms": round(float(np.median(ms)), 4), "pages_per_s": round(n / float(np.median(ms)) * 1e3, 1),
-                                   "recall_at_10": float(np.mean(rec))}
-    ix.close()
-    # --- index B: bf16 slab for the batched form (B x 32 tokens per slab pass)
-    ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device)
-    ix.fill_synthetic(synth.SEED_CORPUS, 0, n, n_rows=args.patches)
-    synth.plant_neighbours(ix, spec)
+        stg.append((st.encode_ms, st.coarse_ms, st.select_ms, st.rerank_ms, st.topk_ms))
+    stg = np.median(np.array(stg), axis=0)
+    res["fde_top1000_then_float"] = {"device_ms": round(float(np.median(ms)), 4), "pages_per_s": round(n / float(np.median(ms)) * 1e3, 1),
+                                     "stage_ms": {k: round(float(v), 4) for k, v in zip(("encode_query", "coarse_scan", "select_top1000", "rerank_1000", "topk"), stg)},
+                                     "overhead_over_coarse_scan_ms": round(float(np.median(ms)) - float(stg[1]), 4)}
+    # ---- recall@10 of the lossy paths vs the exact bf16 top-10
+    easy = recall_block(ix, qs[:N_QUERIES], [planted[qi] for qi in range(N_QUERIES)], K)
+    truths, hardness = [], []
+    for j, q in enumerate(hq):
+        pages = synth.hard_pages_of(hspec, j)
+        exact = ix.score_candidates(q, pages, pad_to=0)  # exact bf16 MaxSim (parity-checked kernel) of the hard set
+        top, info = synth.exact_truth_from_scores(pages, exact, K)
+        truths.append(top)
+        hardness.append(info)
+        full = ix.query(q, K, mode="float")[1].tolist()
+        assert full == top, "the hard set must hold the exact top-10"
+    hard = recall_block(ix, hq, truths, K)
+    rq = qs[N_QUERIES + NH :]
+    rtruth = [ix.query(q, K, mode="float")[1].tolist() for q in rq]
+    rnd = recall_block(ix, rq, rtruth, K)
+    res["recall_at_10_vs_exact_bf16"] = {
+        "planted_3x_margin": easy,
+        "hard_negatives": dict(hard, queries=NH, pages_per_query=synth.N_HARD,
+                               median_rel_gap_rank10_rank11=float(np.median([h["gap_10_11"] for h in hardness])),
+                               min_distractors_within_2pct_of_rank10=int(min(h["within_2pct"] for h in hardness))),
+        "unplanted_random_corpus": dict(rnd, queries=NR, note="no planted structure: the top-10 of 200 k random pages are separated by ~1e-3 relative"),
+    }
+    # ---- batched form (B x 32 tokens per slab pass)
     res["batched_float"] = {}
     for B in (4, 16):
         ms = []
@@ -172,12 +254,38 @@ def aux_paths(args, device, mfma_peak=None):
         m = float(np.median(ms))
         tf = 2.0 * B * args.qtokens * args.patches * 128 * n / m / 1e9
         res["batched_float"][f"B{B}"] = {"kernel_ms": round(m, 4), "query_pages_per_s": round(B * n / m * 1e3, 1), "TFLOPs": round(tf, 1),
-                                         "frac_mfma_bf16_2500TF": round(tf / 2500.0, 4),
+                                         "frac_mfma_bf16_2500TF": round(tf / MFMA_BF16_PEAK_TF, 4),
                                          "frac_of_measured_mfma_peak": None if not mfma_peak else round(tf / mfma_peak, 4),
                                          "GBps": round(n * args.patches * 256 / m / 1e6, 1),
                                          "recall_at_10": float(np.mean([synth.recall_at_k(out[qi][1].tolist(), planted[qi]) for qi in range(B)]))}
     ix.close()
     return res
+
+
+def embed_workload(args, pages, quick=False):
+    """BASELINE configs[1]: ColPali-v1.2 architecture embeds synthetic pages -> device ingest -> MaxSim top-10."""
+    from tools.bench_embed import run as run_embed
+
+    return run_embed(pages=pages, batch=32, feed=16, preset="colpali-v1.2", queries=4 if quick else 8)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks here (one per GPU, rendezvous on
+    127.0.0.1) by re-executing this file under torch.distributed.run, and relay rank 0's JSON line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"bench.py: launching {args.gpus} ranks: {' '.join(cmd[1:8])} ...")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    return p.returncode if (p.returncode or lines) else 1
 
 
 def main():
@@ -189,18 +297,23 @@ def main():
     ap.add_argument("--patches", type=int, default=1024)
     ap.add_argument("--qtokens", type=int, default=32)
     ap.add_argument("--variant", type=int, default=-1, help="float kernel variant (-1 = library default)")
-    ap.add_argument("--cpu-sample-pages", type=int, default=16384)
+    ap.add_argument("--cpu-sample-pages", type=int, default=20480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
-    ap.add_argument("--workload", choices=["float", "fp8", "binary", "fde_fp8"], default="float",
+    ap.add_argument("--workload", choices=["float", "fp8", "binary", "fde_fp8", "embed"], default="float",
                     help="float = BASELINE configs[2] (the headline, default); fp8 = e4m3 slab (configs[4]); binary = sign-bit "
-                         "max_sim (MultiVectorStore); fde_fp8 = FDE coarse top-1000 -> exact fp8 rerank (configs[3] shard shape)")
+                         "max_sim (MultiVectorStore); fde_fp8 = FDE coarse top-1000 -> exact fp8 rerank (configs[3] shard shape); "
+                         "embed = configs[1] (ColPali-v1.2 architecture, 1 k pages -> top-10)")
     ap.add_argument("--no-aux", action="store_true", help="skip the secondary kernels' quick measurements (aux_paths)")
     ap.add_argument("--aux-pages", type=int, default=200_000)
+    ap.add_argument("--aux-embed-pages", type=int, default=96, help="pages of the full-size encoder run inside aux_paths (0 = skip)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend for N>1 (nccl == RCCL; gloo + MV_BENCH_SINGLE_DEVICE=1 lets N ranks share one GPU to "
                          "exercise the multi-rank path on a 1-GPU box -- a functional check, not a measurement)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
 
     import torch
     import torch.distributed as dist
@@ -208,10 +321,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the product path is HIP-only (no CPU fallback)")
     single_device = os.environ.get("MV_BENCH_SINGLE_DEVICE") == "1"
@@ -219,6 +329,25 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    if args.workload == "embed":
+        if world != 1:
+            sys.exit("bench.py --workload embed: the encoder scales as independent replicas; run it with --gpus 1")
+        pages = args.pages if args.pages != 1_000_000 else 1000
+        r = embed_workload(args, pages)
+        print(json.dumps({
+            "metric": "pages embedded + ingested per second (ColPali-v1.2 architecture, bf16) -> MaxSim top-10", "value": r["embed_pages_per_s"],
+            "unit": "pages/s", "n_gpus": 1, "steps": pages, "warmup": 32, "ms_per_step": round(1e3 / r["embed_pages_per_s"], 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic page images; random-init weights of the ColPali-v1.2 architecture (no checkpoint in this environment)",
+            "config": {"workload": r["workload"], "pages_total": pages, "rows_per_page": r["rows_per_page"], "params": r["params"], "k": 10,
+                       "parallelism": "replicas only"},
+            "roofline": {"bound": "mfma", "kernel": "hipBLASLt GEMMs of the PyTorch-ROCm forward (plumbing, not a hand-written kernel)",
+                         "achieved": r["embed_tflops_est"], "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": round(r["embed_tflops_est"] / MFMA_BF16_PEAK_TF, 4), "traffic": None},
+            "cpu_baseline": None, "detail": r}), flush=True)
+        return
+
     # MV_BENCH_FORCE_DIST=1 runs the collective path even with one rank (RCCL smoke test on a 1-GPU box)
     dist_on = world > 1 or os.environ.get("MV_BENCH_FORCE_DIST") == "1"
     if dist_on:
@@ -232,9 +361,8 @@ def main():
             dist.init_process_group(backend="gloo")
     cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collective payloads live
 
-    import morphik_core_amd as mca
     from morphik_core_amd import _lib, sharded, synth
-    from morphik_core_amd.index import MvIndex, synth_rows
+    from morphik_core_amd.index import MvIndex, calibrate, synth_rows
 
     stride = ((args.patches + 15) // 16) * 16
     WL = {
@@ -267,16 +395,13 @@ def main():
     n_local = hi - lo
     log(f"[rank {rank}] HBM free {free_b/2**30:.1f} GiB of {total_b/2**30:.1f}; corpus {n_total} pages, shard [{lo},{hi}) = {n_local*page_bytes/1e9:.1f} GB")
 
-    measured_peak = measured_mfma = None
+    measured_peak = measured_nt = measured_mfma = None
     if rank == 0 and world == 1:
-        from morphik_core_amd.index import calibrate_read_bw
-
-        from morphik_core_amd.index import calibrate
-
-        grid_stride_peak = calibrate_read_bw(4 << 30, 10, device=local_rank)  # grid-stride 16 B/lane read (the PMC calibration kernel)
-        measured_peak = calibrate("read_nt", 8 << 30, 10, device=local_rank)   # contiguous 16 KiB pieces, nt loads, no arithmetic
+        # measured denominators, same process: the scan's own transport without arithmetic, plain nt loads, register-only MFMA
+        measured_peak = calibrate("read_ldsdma", 8 << 30, 10, device=local_rank)
+        measured_nt = calibrate("read_nt", 8 << 30, 10, device=local_rank)
         measured_mfma = calibrate("mfma_bf16", 0, 5, device=local_rank)
-        log(f"[rank 0] calibration: nt streaming read {measured_peak:.0f} GB/s (grid-stride read {grid_stride_peak:.0f}); bf16 MFMA {measured_mfma:.0f} TFLOP/s")
+        log(f"[rank 0] calibration: nt LDS-DMA ring without arithmetic {measured_peak:.0f} GB/s (plain nt loads {measured_nt:.0f}); bf16 MFMA {measured_mfma:.0f} TFLOP/s")
 
     t0 = time.time()
     ix = MvIndex(capacity_pages=n_local, stride_rows=stride, device=local_rank, id_base=lo, **WL["flags"])
@@ -305,8 +430,11 @@ def main():
             return s.cpu(), i.cpu()
     searcher = sharded.ShardedSearcher(local_topk)
     fast_searcher = sharded.GpuShardedSearcher(ix, dev, MODE, collect_stats=stats) if (dist_on and args.backend == "nccl") else None
-    # config 4 across ranks: GLOBAL coarse top-1000, owners rerank (the same candidate set as one big index)
-    two_stage = sharded.make_gpu_two_stage(ix, cdev) if (dist_on and args.workload == "fde_fp8") else None
+    # config 4 across ranks: GLOBAL coarse top-1000, owners rerank (the same candidate set as one big index); over RCCL the
+    # device-resident stages (no host copy of any intermediate), over gloo the host-driven cross-check
+    two_stage = None
+    if dist_on and args.workload == "fde_fp8":
+        two_stage = sharded.GpuTwoStageSearcher(ix, dev) if args.backend == "nccl" else sharded.make_gpu_two_stage(ix, cdev)
 
     def step(i):
         q = queries[i % N_QUERIES]
@@ -348,18 +476,22 @@ def main():
         bytes_per_launch = n_local * 20480 + min(1000, n_local) * args.patches * 128
     else:
         bytes_per_launch = n_local * args.patches * WL["row_bytes"]  # algorithmic: every valid patch row read once
-    if dist_on:  # report the slowest rank's kernel
-        t = torch.tensor([float(kms.mean()) if kms.size else 0.0], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        k_ms = float(t.item())
-    else:
-        k_ms = float(kms.mean()) if kms.size else 0.0
+    my_kms = float(kms.mean()) if kms.size else 0.0
+    per_rank_kms = [my_kms]
+    if dist_on:  # report the slowest rank's kernel, and every rank's
+        t = torch.tensor([my_kms], dtype=torch.float64, device=cdev)
+        allk = torch.empty(world, dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(allk, t)
+        per_rank_kms = [float(x) for x in allk.cpu().tolist()]
+    k_ms = max(per_rank_kms)
     achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
 
     # ---- parity inside the bench (outside the timed region): recall@10 and sampled oracle scores
     recall = []
     for qi in range(N_QUERIES):
         s, ids = step(qi) if dist_on else ix.query(queries[qi], K, mode=MODE)
+        if dist_on:
+            torch.cuda.synchronize()
         ids = ids.tolist() if hasattr(ids, "tolist") else list(ids)
         ids = [p for p in ids if p >= 0]
         planted = [p for (qq, r, p, _, _) in spec if qq == qi]
@@ -368,19 +500,7 @@ def main():
 
     out = None
     if rank == 0:
-        # HBM traffic of the scan kernel from rocprofv3 PMC counters (FETCH_SIZE / WRITE_SIZE, separate
-        # passes, gfx950 x2 fetch correction calibrated on a known byte count) -- collected by a separate
-        # profiled run and committed under profiles/; scaled per page to this launch.  null if absent.
-        traffic = None
-        traffic_src = None
-        pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "**", "pmc_traffic*.json"), recursive=True))
-        if pmc:
-            try:
-                per_page = float(json.load(open(pmc[-1]))["hbm_bytes_per_page"])
-                traffic = int(round(per_page * n_local * args.patches / 1024.0))
-                traffic_src = os.path.relpath(pmc[-1], ROOT)
-            except Exception:
-                traffic = None
+        traffic, traffic_src, traffic_kernel = pmc_traffic(n_local, args.patches) if args.workload == "float" else (None, None, None)
         roofline = {
             "bound": "hbm",
             "kernel": {"float": "maxsim_ldsdma_kernel (bf16 page scan, variant %s)" % (args.variant if args.variant >= 0 else "default: nt LDS-DMA"),
@@ -391,12 +511,17 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "measured_read_peak": None if measured_peak is None else round(measured_peak, 1),
+            "measured_read_peak_kind": "the scan's own nt LDS-DMA ring with the arithmetic removed (MV_CAL_READ_LDSDMA)",
             "frac_of_measured_peak": None if not measured_peak else round(achieved / measured_peak, 4),
+            "measured_plain_nt_read": None if measured_nt is None else round(measured_nt, 1),
             "measured_mfma_bf16_tflops": None if not measured_mfma else round(measured_mfma, 1),
-            "traffic": traffic if args.workload == "float" else None,
+            "traffic": traffic,
             "traffic_source": traffic_src,
+            "traffic_kernel": traffic_kernel,
+            "lib_sha256": lib_sha256()[:16],
             "bytes_per_launch": bytes_per_launch,
             "kernel_ms_avg": round(k_ms, 4),
+            "kernel_ms_per_rank": [round(x, 4) for x in per_rank_kms],
             "launches_timed": int(kms.size),
             "mfma_tflops_achieved": round(2.0 * args.qtokens * args.patches * 128 * n_local / (k_ms * 1e-3) / 1e12, 2) if k_ms > 0 else 0.0,
         }
@@ -471,6 +596,8 @@ def main():
                 "k": K,
                 "requested_pages": args.pages,
                 "parallelism": "row-shard x%d + all-gather top-k" % world,
+                "collective_backend": (args.backend if dist_on else None),
+                "rccl_ranks": (dist.get_world_size() if (dist_on and args.backend == "nccl") else 0),
             },
             "recall_at_10": recall10,
             "max_rel_score_err_vs_oracle": max_rel,
@@ -478,14 +605,20 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        if cpu:
-            out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
     ix.close()
     if out is not None and world == 1 and not args.no_aux:
         try:
             out["aux_paths"] = aux_paths(args, local_rank, measured_mfma)
         except Exception as e:  # the headline number must survive a failure of the side measurements
             out["aux_paths"] = {"error": repr(e)}
+        if args.aux_embed_pages > 0:
+            try:  # configs[1] at full model size, short: encoder -> device ingest -> top-10
+                r = embed_workload(args, args.aux_embed_pages, quick=True)
+                out["aux_paths"]["embed_colpali_v1_2"] = {k: r[k] for k in ("workload", "params", "rows_per_page", "embed_pages_per_s", "embed_model_only_pages_per_s",
+                                                                             "embed_tflops_est", "store_device_path_pages_per_s", "query_embed_ms_med",
+                                                                             "query_maxsim_top10_ms_med", "model_batch", "dtype", "data")}
+            except Exception as e:  # noqa: BLE001
+                out["aux_paths"]["embed_colpali_v1_2"] = {"error": repr(e)}
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

@@ -1521,9 +1521,9 @@ int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out
   DeviceGuard g(device);
   float* sink = nullptr;
   MV_HIP(hipMalloc(&sink, 4));
-  hipEvent_t a, b;
-  (void)hipEventCreate(&a);
-  (void)hipEventCreate(&b);
+  hipEvent_t a_ev, b_ev;
+  (void)hipEventCreate(&a_ev);
+  (void)hipEventCreate(&b_ev);
   int rc = MV_OK;
   float ms = 0;
   if (what == MV_CAL_READ_NT) {
@@ -1533,32 +1533,54 @@ int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out
     if (!rc) {
       (void)hipMemset(buf, 1, (size_t)bytes);
       rc = launch_read_bw_nt(buf, bytes, sink, nullptr);
-      (void)hipEventRecord(a, nullptr);
+      (void)hipEventRecord(a_ev, nullptr);
       for (int i = 0; i < iters && !rc; ++i) rc = launch_read_bw_nt(buf, bytes, sink, nullptr);
-      (void)hipEventRecord(b, nullptr);
-      (void)hipEventSynchronize(b);
-      (void)hipEventElapsedTime(&ms, a, b);
+      (void)hipEventRecord(b_ev, nullptr);
+      (void)hipEventSynchronize(b_ev);
+      (void)hipEventElapsedTime(&ms, a_ev, b_ev);
       *out = ms > 0 ? (double)(bytes / 16384 * 16384) * iters / (ms * 1e-3) / 1e9 : 0.0;  // GB/s
     }
     if (buf) (void)hipFree(buf);
+  } else if (what == MV_CAL_READ_LDSDMA) {
+    // the float scan's own transport (nt LDS-DMA ring, 4 waves per 256 KiB page) with the arithmetic removed
+    const int64_t page_bytes = 1024 * kRowBytes;
+    const int64_t n = bytes / page_bytes;
+    if (n < 64) { set_error("calibrate: need >= 16 MiB"); rc = MV_ERR_INVALID; }
+    void* buf = nullptr;
+    float* sc = nullptr;
+    if (!rc && (hipMalloc(&buf, (size_t)n * page_bytes + 32768) != hipSuccess || hipMalloc(&sc, (size_t)n * 4) != hipSuccess)) { set_error("calibrate: out of memory"); rc = MV_ERR_NOMEM; }
+    if (!rc) {
+      (void)hipMemset(buf, 1, (size_t)n * page_bytes);
+      MaxsimArgs a{};
+      a.slab = (const uint16_t*)buf; a.q = (const uint16_t*)buf; a.scores = sc; a.n = n; a.stride = 1024; a.q_tiles = 2;
+      rc = launch_maxsim_bf16(a, 13, nullptr);
+      (void)hipEventRecord(a_ev, nullptr);
+      for (int i = 0; i < iters && !rc; ++i) rc = launch_maxsim_bf16(a, 13, nullptr);
+      (void)hipEventRecord(b_ev, nullptr);
+      (void)hipEventSynchronize(b_ev);
+      (void)hipEventElapsedTime(&ms, a_ev, b_ev);
+      *out = ms > 0 ? (double)(n * page_bytes) * iters / (ms * 1e-3) / 1e9 : 0.0;  // GB/s
+    }
+    if (buf) (void)hipFree(buf);
+    if (sc) (void)hipFree(sc);
   } else if (what == MV_CAL_MFMA_BF16) {
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
     const int blocks = ncu * 2, loop = 4096;  // 8 waves / CU
     rc = launch_mfma_peak(blocks, 64, sink, nullptr);
-    (void)hipEventRecord(a, nullptr);
+    (void)hipEventRecord(a_ev, nullptr);
     for (int i = 0; i < iters && !rc; ++i) rc = launch_mfma_peak(blocks, loop, sink, nullptr);
-    (void)hipEventRecord(b, nullptr);
-    (void)hipEventSynchronize(b);
-    (void)hipEventElapsedTime(&ms, a, b);
+    (void)hipEventRecord(b_ev, nullptr);
+    (void)hipEventSynchronize(b_ev);
+    (void)hipEventElapsedTime(&ms, a_ev, b_ev);
     const double flops = (double)blocks * 4 * loop * 8 * (2.0 * 16 * 16 * 32) * iters;
     *out = ms > 0 ? flops / (ms * 1e-3) / 1e12 : 0.0;  // TFLOP/s
   } else {
     set_error("calibrate: unknown measurement %d", what);
     rc = MV_ERR_INVALID;
   }
-  (void)hipEventDestroy(a);
-  (void)hipEventDestroy(b);
+  (void)hipEventDestroy(a_ev);
+  (void)hipEventDestroy(b_ev);
   (void)hipFree(sink);
   return rc;
 }

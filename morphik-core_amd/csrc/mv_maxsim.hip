@@ -223,7 +223,9 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int MT, int WPP, int D, bool NT = false, bool CONTIG = false>
+// STREAM_ONLY: the same ring, the same waits, no fragment reads and no MFMA -- the transport ceiling of this kernel
+// (MV_CAL_READ_LDSDMA: the roofline's measured denominator).
+template <int MT, int WPP, int D, bool NT = false, bool CONTIG = false, bool STREAM_ONLY = false>
 __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
   // one __shared__ object only (a second one makes hipcc drain vmcnt before every ds_read)
   __shared__ __attribute__((aligned(16))) char lds[4 * D * kTileBytes + 2048];
@@ -317,11 +319,13 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
   // hipcc waits for them once, before the loop.  Left to itself it defers the wait to the first MFMA
   // inside the loop, where its counted vmcnt(7..0) ladder drains our DMA ring on every iteration.
   bf16x8 qa[MT][4];
-  load_query<MT>(a.q, r, g, qa);
+  if (!STREAM_ONLY) {
+    load_query<MT>(a.q, r, g, qa);
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(qa[m][j]));
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(qa[m][j]));
+  }
 
   for (int it = 0; it < ntw; ++it) {
     if (it + D - 1 < ntw) {
@@ -334,6 +338,7 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
       else if (left == 1) wait_vmcnt<4>();
       else wait_vmcnt<0>();
     }
+    if (STREAM_ONLY) continue;
     const char* slot = ring + (it % D) * kTileBytes;
     bf16x8 b[4];
 #pragma unroll
@@ -341,6 +346,10 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
     const int t = t0 + it * tstep;
     const bool partial = (t + 1) * kTileRows > nr;
     tile_mfma<MT>(qa, b, mx, partial, t * kTileRows + r < nr);
+  }
+  if (STREAM_ONLY) {
+    if (threadIdx.x == 0) a.scores[item] = 0.f;
+    return;
   }
 
   if (WPP == 1) {
@@ -379,6 +388,7 @@ int launch_mt(const KArgs& k0, int variant, hipStream_t s) {
       case 10: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 6, true>), dim3((unsigned)n), block, 0, s, k); break;
       case 11: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 1, 8, true>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
       case 12: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true, true>), dim3((unsigned)n), block, 0, s, k); break;
+      case 13: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true, false, true>), dim3((unsigned)n), block, 0, s, k); break;
       default: set_error("unknown maxsim variant %d", variant); return MV_ERR_INVALID;
     }
   }
@@ -410,6 +420,7 @@ const char* maxsim_variant_name(int v) {
     case 10: return "ldsdma_wpp4_d6_nt";
     case 11: return "ldsdma_wpp1_d8_nt";
     case 12: return "ldsdma_wpp4_d4_nt_contig";
+    case 13: return "ldsdma_wpp4_d4_nt_stream_only";
     default: return "?";
   }
 }

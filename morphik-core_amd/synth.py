@@ -98,3 +98,60 @@ def recall_at_k(got_ids: Sequence[int], want_ids: Sequence[int]) -> float:
     if not want:
         return 1.0
     return len(want & set(int(i) for i in got_ids)) / float(len(want))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Hard negatives (BASELINE configs[3] / [4] ask for recall "vs bf16 reference": planted neighbours with a 3x score
+# margin cannot fail).  Every query gets N_HARD pages whose exact bf16 MaxSim scores are tightly clustered:
+# page j of the set carries rows normalize(q_row + sigma_j * noise) with sigma_j = SIGMA0 * (1 + REL_STEP * j)
+# -- the expected scores fall by ~0.03 % per rank while each page's own noise moves its score by a few tenths of a
+# percent, so rank 10 and rank 11 are typically < 0.5 % apart and 50+ distractors sit within ~2 % of rank 10.  The
+# truth is NOT assumed from the construction: it is the exact bf16 top-10 computed by the float MaxSim scan (or the CPU
+# oracle) over the hard set, whose pages score far above the random background.
+# ---------------------------------------------------------------------------------------------------------------------
+N_HARD = 64
+SIGMA0 = 0.5
+REL_STEP = 3e-4 / 0.4  # d(score)/score per rank ~ 3e-4 at sigma 0.5 (d ln cos / d ln sigma ~ -0.2)
+SEED_HARD = 7
+
+
+def hard_rows(q_bf16: np.ndarray, j: int, rng: np.random.Generator) -> np.ndarray:
+    q = bf16_to_f32(q_bf16)
+    sigma = SIGMA0 * (1.0 + REL_STEP * j)
+    noise = rng.standard_normal(q.shape).astype(np.float32) / np.sqrt(q.shape[1])
+    v = q + sigma * noise
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    return f32_to_bf16(v)
+
+
+def hard_spec(queries_bf16: Sequence[np.ndarray], n_pages_total: int, stride_rows: int, n_hard: int = N_HARD,
+              seed: int = SEED_HARD) -> List[Tuple[int, int, int, int, np.ndarray]]:
+    """[(query_idx, j, GLOBAL page id, first_row, rows_bf16)] -- same shape as planted_spec, n_hard pages per query; a pure
+    function of its arguments (every rank of a sharded run and the CPU checker derive the same overrides)."""
+    rng0 = np.random.default_rng(seed)
+    plan = rng0.choice(n_pages_total, size=len(queries_bf16) * n_hard, replace=False).reshape(len(queries_bf16), n_hard)
+    out = []
+    for qi, q in enumerate(queries_bf16):
+        for j in range(n_hard):
+            rng = np.random.default_rng([seed, qi, j])
+            row0 = int(rng.integers(0, max(stride_rows - q.shape[0], 0) + 1))
+            rows = hard_rows(q, j, rng)[: stride_rows - row0]
+            out.append((qi, j, int(plan[qi, j]), row0, rows))
+    return out
+
+
+def hard_pages_of(spec, qi: int) -> List[int]:
+    return [p for (qq, _j, p, _a, _b) in spec if qq == qi]
+
+
+def exact_truth_from_scores(pages: Sequence[int], scores: np.ndarray, k: int = 10) -> Tuple[List[int], Dict[str, float]]:
+    """Exact top-k of the hard set from its exact scores (score desc, id asc) + how hard it is:
+    gap_10_11 = relative score gap between rank k and rank k+1; within_2pct = pages beyond rank k within 2 % of rank k."""
+    pages = np.asarray(pages, np.int64)
+    s = np.asarray(scores, np.float64)
+    order = np.lexsort((pages, -s))
+    top = pages[order[:k]].tolist()
+    sk = s[order[k - 1]]
+    info = {"gap_10_11": float((sk - s[order[k]]) / abs(sk)) if len(order) > k else float("nan"),
+            "within_2pct": int(np.sum(s[order[k:]] >= sk * 0.98))}
+    return top, info

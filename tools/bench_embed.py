@@ -27,15 +27,9 @@ def synth_page(rng, size=448):
     return img
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--pages", type=int, default=1000)
-    ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--feed", type=int, default=16, help="chunks per embed_for_ingestion call (the worker's COLPALI_STORE_BATCH_SIZE)")
-    ap.add_argument("--preset", default="colpali-v1.2")
-    ap.add_argument("--queries", type=int, default=8)
-    ap.add_argument("--out", default="")
-    a = ap.parse_args()
+def run(pages=1000, batch=32, feed=16, preset="colpali-v1.2", queries=8):
+    """-> result dict (also used by bench.py --workload embed and by its aux_paths)."""
+    a = argparse.Namespace(pages=pages, batch=batch, feed=feed, preset=preset, queries=queries)
     import torch
     from PIL import Image
 
@@ -106,6 +100,22 @@ def main():
         "model_batch": a.batch, "chunks_per_call": a.feed, "dtype": "bf16", "data": "synthetic page images; random-init weights (no checkpoint in this environment)",
         "top1_examples": top[:3],
     }
+    store.close()
+    del emb
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pages", type=int, default=1000)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--feed", type=int, default=16, help="chunks per embed_for_ingestion call (the worker's COLPALI_STORE_BATCH_SIZE)")
+    ap.add_argument("--preset", default="colpali-v1.2")
+    ap.add_argument("--queries", type=int, default=8)
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    res = run(a.pages, a.batch, a.feed, a.preset, a.queries)
     js = json.dumps(res)
     if a.out:
         os.makedirs(os.path.dirname(a.out), exist_ok=True)

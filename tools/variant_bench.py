@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--qtokens", default="32")
     ap.add_argument("--aux", action="store_true", help="also time binary and FDE scans (smaller corpus)")
     ap.add_argument("--out", default="")
+    ap.add_argument("--no-batch", action="store_true", help="skip the batched-query sweep")
     a = ap.parse_args()
     from morphik_core_amd import _lib
     from morphik_core_amd.index import MvIndex, calibrate_read_bw, synth_rows
@@ -52,7 +53,7 @@ def main():
             print(f"q={qt} variant {v}: {np.median(k):.3f} ms  {nbytes/np.median(k)/1e6:.0f} GB/s (best {nbytes/k.min()/1e6:.0f})  topk {np.median([t[1] for t in times[v]]):.3f} ms", flush=True)
     # batched queries: one slab pass for B queries of 32 tokens (HBM-bound -> MFMA-bound as B grows)
     res["batch"] = {}
-    for bv, B in [(0, 1), (0, 2), (0, 4), (0, 8), (0, 16), (1, 16), (2, 4), (2, 6), (2, 8), (2, 10), (2, 12), (0, 10), (0, 12)]:
+    for bv, B in ([] if a.no_batch else [(0, 1), (0, 2), (0, 4), (0, 8), (0, 16), (1, 16), (2, 4), (2, 6), (2, 8), (2, 10), (2, 12), (0, 10), (0, 12)]):
         ix.set_option(_lib.MV_OPT_BATCH_VARIANT, bv)
         qs = [synth_rows(4321, j, 32) for j in range(B)]
         ts = []
