@@ -102,8 +102,10 @@ typedef enum {
   MV_OPT_BINARY_VARIANT = 5, /* sign-bit scan: 0 = popcount on the VALU, 1 = FP4 MFMA, 2/3/4 = FP4 MFMA with in-place bit operands and an
                                 8/16/4-slot ring (4 = default), 5 = persistent-stream form; all produce the same integers */
   MV_OPT_FDE_SCAN_VARIANT = 6, /* FDE coarse scan: 0 = wave per page (default), 1 = query in LDS, 2 = workgroup per page */
-  MV_OPT_BATCH_VARIANT = 7,   /* batched float scan: 0 = 16x16x32 MFMA / 4 waves, 1 = 32x32x16 MFMA / 8 waves, 2 = pipelined 16x16x32 (<= 384 rows);
-                                 -1 = auto (default): 2 up to 384 query rows in the group, 0 above */
+  MV_OPT_BATCH_VARIANT = 7,   /* batched float scan: -1 / 0 = auto (default): page-split form (wave-private rings, no barrier) up to 128
+                                 query rows in the group, row-split workgroup above; both with transposed MFMA roles (one running
+                                 max per query tile, v_max3).  3 = row-split form always, 1 = 32x32x16 MFMA / 8 waves,
+                                 2 = the round-1 two-stage pipeline (<= 384 rows); 1 and 2 are kept as cross-checks */
   MV_OPT_FDE_ENCODE_VARIANT = 8, /* FDE encode: 1 = f32-MFMA kernel (default), 0 = scalar kernel; same partitions bit for bit */
   MV_OPT_FILTER_COMPACT_PCT = 9, /* doc filter allowing < this % of the documents: compact the allowed pages first and scan
                                     only those (default 25; 0 = always mask inside the scan) */

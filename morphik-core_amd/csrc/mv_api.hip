@@ -231,7 +231,7 @@ int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_w
       b.slab = ix->slab; b.n_rows = ragged ? ix->d_n_rows : nullptr; b.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
       b.allow = d_allow; b.n_allow_bits = n_allow_words * 32; b.allow_stride_bits = 0;
       b.q = ix->d_bq; b.scores = pass == 0 ? d_out : ix->d_scores2; b.n = n_items; b.score_stride = n_items;
-      b.stride = ix->cfg.stride_rows; b.n_queries = 1; b.rows_per_query = rows; b.variant = rows <= 384 ? 2 : 0;
+      b.stride = ix->cfg.stride_rows; b.n_queries = 1; b.rows_per_query = rows; b.variant = ix->batch_variant >= 0 ? ix->batch_variant : 0;
       int rc = launch_maxsim_batch(b, ix->stream);
       if (rc) return rc;
       ++*launches;
@@ -1281,7 +1281,7 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
     a.allow = per_query ? d_allow + (size_t)b0 * n_allow_words : d_allow; a.n_allow_bits = n_allow_words * 32;
     a.allow_stride_bits = per_query ? n_allow_words * 32 : 0; a.q = ix->d_bq; a.scores = ix->d_bscores; a.n = n;
     a.score_stride = ix->cfg.capacity_pages; a.stride = ix->cfg.stride_rows; a.n_queries = nb; a.rows_per_query = rpq;
-    a.variant = ix->batch_variant >= 0 ? ix->batch_variant : (nb * rpq <= 384 ? 2 : 0);
+    a.variant = ix->batch_variant >= 0 ? ix->batch_variant : 0;  // auto: page-split form up to 128 rows, transposed row-split form above
     rc = launch_maxsim_batch(a, ix->stream);
     if (rc) return rc;
     MV_HIP(hipEventRecord(ix->ev[1], ix->stream));

@@ -584,7 +584,7 @@ def test_fde_coarse_scan_and_pipeline(mv):
 
 
 # ------------------------------------------------------------------ batched queries (one slab pass, MFMA-bound form)
-@pytest.mark.parametrize("bvariant", [0, 1, 2])  # 16x16x32 / 4 waves, 32x32x16 / 8 waves, pipelined 16x16x32 (384-row groups)
+@pytest.mark.parametrize("bvariant", [0, 1, 2, 3])  # auto (page-split <= 128 rows, row-split above), 32x32x16 / 8 waves, round-1 pipeline, row-split always
 @pytest.mark.parametrize("stride,nrows", [(1024, 1024), (1024, 1000), (208, 200), (64, 50), (16, 7)])
 def test_batched_queries_equal_single_queries_and_oracle(mv, stride, nrows, bvariant):
     from morphik_core_amd import _lib
@@ -631,6 +631,36 @@ def test_batched_queries_equal_single_queries_and_oracle(mv, stride, nrows, bvar
     for q, (s, i) in zip(qs, got):
         ws, wi = ix.query(q, 4, mode="binary")
         assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist()
+    ix.close()
+
+
+@pytest.mark.parametrize("stride", [64, 80, 208, 1024, 1040])
+def test_batched_queries_on_a_uniform_corpus(mv, stride):
+    """Uniform corpus (every page full, nothing masked; more pages than persistent workgroups), batches of 5..16 queries:
+    strides whose tile count is not a multiple of the 4-tile chunk (80 -> 5 tiles, 1040 -> 65) end a page in a partial
+    chunk.  Auto routing (page-split form <= 128 rows, row-split above) and the row-split form on its own (variant 3) must
+    equal the single-query scan and the oracle."""
+    from morphik_core_amd import _lib
+
+    n = 1500 if stride <= 208 else 700  # more pages than persistent workgroups (512): several pages per workgroup
+    ix = _idx(mv, capacity_pages=n, stride_rows=stride)
+    ix.fill_synthetic(1234, 0, n)
+    pages = orc.bf16_to_f32(ix.read_pages(0, n))
+    for lens in ([32] * 5, [32] * 16, [48] * 10, [20, 32, 1, 17, 64, 33]):
+        qs = [orc.synth_rows(4321, 70 + j, 0, L) for j, L in enumerate(lens)]
+        res = {}
+        for bv in (0, 3):
+            ix.set_option(_lib.MV_OPT_BATCH_VARIANT, bv)
+            res[bv] = ix.query_batch(qs, 9)
+        for j, q in enumerate(qs):
+            ws, wi = ix.query(q, 9)
+            for bv in (0, 3):
+                s, i = res[bv][j]
+                assert i.tolist() == wi.tolist(), (stride, lens, bv, j)
+                np.testing.assert_allclose(s, ws, rtol=1e-5)
+        want = orc.maxsim_float_np(orc.bf16_to_f32(qs[0]), pages)
+        ws, wi = orc.topk(want, 9)
+        _assert_topk_matches(res[0][0][0], res[0][0][1], ws, wi)
     ix.close()
 
 

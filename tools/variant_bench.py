@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--aux", action="store_true", help="also time binary and FDE scans (smaller corpus)")
     ap.add_argument("--out", default="")
     ap.add_argument("--no-batch", action="store_true", help="skip the batched-query sweep")
+    ap.add_argument("--batch-only", action="store_true", help="only the batched-query sweep (SQ counter passes)")
     a = ap.parse_args()
     from morphik_core_amd import _lib
     from morphik_core_amd.index import MvIndex, calibrate_read_bw, synth_rows
@@ -30,7 +31,7 @@ def main():
     ix.fill_synthetic(1234, 0, a.pages)
     nbytes = a.pages * a.patches * 256
     variants = [int(v) for v in a.variants.split(",")]
-    for qt in [int(x) for x in a.qtokens.split(",")]:
+    for qt in ([] if a.batch_only else [int(x) for x in a.qtokens.split(",")]):
         q = synth_rows(4321, 0, qt)
         times = {v: [] for v in variants}
         ref = None
@@ -53,7 +54,8 @@ def main():
             print(f"q={qt} variant {v}: {np.median(k):.3f} ms  {nbytes/np.median(k)/1e6:.0f} GB/s (best {nbytes/k.min()/1e6:.0f})  topk {np.median([t[1] for t in times[v]]):.3f} ms", flush=True)
     # batched queries: one slab pass for B queries of 32 tokens (HBM-bound -> MFMA-bound as B grows)
     res["batch"] = {}
-    for bv, B in ([] if a.no_batch else [(0, 1), (0, 2), (0, 4), (0, 8), (0, 16), (1, 16), (2, 4), (2, 6), (2, 8), (2, 10), (2, 12), (0, 10), (0, 12)]):
+    # 0 = auto (page-split form <= 128 rows, transposed row-split form above), 3 = row-split always, 2 = round-1 pipeline, 1 = 32x32x16
+    for bv, B in ([] if a.no_batch else [(0, 1), (0, 2), (0, 4), (3, 4), (2, 4), (0, 8), (2, 8), (0, 12), (0, 16), (1, 16)]):
         ix.set_option(_lib.MV_OPT_BATCH_VARIANT, bv)
         qs = [synth_rows(4321, j, 32) for j in range(B)]
         ts = []
