@@ -191,17 +191,18 @@ def aux_paths(args, device, mfma_peak=None):
     taken = {p for (_q, _r, p, _a, _b) in spec}
     hq = qs[N_QUERIES : N_QUERIES + NH]
     hspec = [t for t in synth.hard_spec(hq, n, args.patches) if t[2] not in taken]
-    res = {"pages": n, "note": "kernel-only HIP-event times, median of 5, on one index holding bf16 + e4m3 + sign-bit + FDE slabs"}
+    res = {"pages": n, "note": "kernel-only HIP-event times, median of 15 after 10 warm-up launches, on one index holding bf16 + e4m3 + sign-bit + FDE slabs"}
     ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=True, with_binary=True, with_fde=True, with_fp8=True)
     ix.fill_synthetic(synth.SEED_CORPUS, 0, n, n_rows=args.patches)
     synth.plant_neighbours_any(ix, spec, synth.SEED_CORPUS, args.patches)
     synth.plant_neighbours_any(ix, hspec, synth.SEED_CORPUS, args.patches)
     per_page = {"binary": args.patches * 16, "float_fp8": args.patches * 128, "fde": 10240 * 2}
+    WARM, TIMED = 10, 15  # the clocks need tens of milliseconds of load to settle: short kernels get a real warm-up
     for mode in ("binary", "float_fp8", "fde"):
         ms, coarse = [], []
-        for r in range(6):
+        for r in range(WARM + TIMED):
             _s, _i, st = ix.query(qs[r % N_QUERIES], K, mode=mode, want_stats=True)
-            if r:
+            if r >= WARM:
                 ms.append(st.score_kernel_ms)
                 coarse.append(st.coarse_ms)
         m = float(np.median(coarse)) if mode == "fde" else float(np.median(ms))  # FDE: the slab scan alone (the query encode is its own stage)
@@ -213,10 +214,11 @@ def aux_paths(args, device, mfma_peak=None):
     # FDE coarse top-1000 -> exact rerank (configs[3] pipeline), all in stream order on the device
     ix.set_option(L.MV_OPT_FDE_COARSE_N, 1000)
     ms, stg = [], []
-    for qi in range(N_QUERIES):
-        _s, ids, st = ix.query(qs[qi], K, mode="fde_then_float", want_stats=True)
-        ms.append(st.total_device_ms)
-        stg.append((st.encode_ms, st.coarse_ms, st.select_ms, st.rerank_ms, st.topk_ms))
+    for r in range(WARM + N_QUERIES):
+        _s, ids, st = ix.query(qs[r % N_QUERIES], K, mode="fde_then_float", want_stats=True)
+        if r >= WARM:
+            ms.append(st.total_device_ms)
+            stg.append((st.encode_ms, st.coarse_ms, st.select_ms, st.rerank_ms, st.topk_ms))
     stg = np.median(np.array(stg), axis=0)
     res["fde_top1000_then_float"] = {"device_ms": round(float(np.median(ms)), 4), "pages_per_s": round(n / float(np.median(ms)) * 1e3, 1),
                                      "stage_ms": {k: round(float(v), 4) for k, v in zip(("encode_query", "coarse_scan", "select_top1000", "rerank_1000", "topk"), stg)},
@@ -247,9 +249,9 @@ def aux_paths(args, device, mfma_peak=None):
     res["batched_float"] = {}
     for B in (4, 16):
         ms = []
-        for r in range(4):
+        for r in range(7):
             out, st = ix.query_batch(qs[:B], K, want_stats=True)
-            if r:
+            if r >= 2:
                 ms.append(st.score_kernel_ms)
         m = float(np.median(ms))
         tf = 2.0 * B * args.qtokens * args.patches * 128 * n / m / 1e9

@@ -109,6 +109,8 @@ typedef enum {
   MV_OPT_FDE_ENCODE_VARIANT = 8, /* FDE encode: 1 = f32-MFMA kernel (default), 0 = scalar kernel; same partitions bit for bit */
   MV_OPT_FILTER_COMPACT_PCT = 9, /* doc filter allowing < this % of the documents: compact the allowed pages first and scan
                                     only those (default 25; 0 = always mask inside the scan) */
+  MV_OPT_FDE_QUERY_ENCODE_VARIANT = 11, /* FDE encode of the query (one page, latency matters): 2 = latency kernel, one block per
+                                    repetition (default), 1 = the bulk f32-MFMA kernel, 0 = scalar kernel; same partitions bit for bit */
   MV_OPT_LONG_QUERY_VARIANT = 10 /* single query of > 64 rows over the whole slab: 1 = row-split workgroup of the batched scan
                                     (default), 0 = page-split kernel in passes of 128 rows */
 } mv_option;

@@ -296,11 +296,10 @@ int fp8_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_wor
 // FDE coarse stage: encode the query already uploaded to d_qf32 (SUM aggregation) and scan the FDE slab -> d_scores[n].
 int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_words, int64_t n, int* launches, bool stage_events) {
   const bool need_meta = ix->tombstones.load() || d_allow != nullptr;
-  const int64_t off[2] = {0, n_q};
-  MV_HIP(hipMemcpyAsync(ix->d_qoff, off, sizeof(off), hipMemcpyHostToDevice, ix->stream));
   FdeEncodeArgs e{};
-  e.variant = ix->fde_encode_variant;
-  e.x_f32 = ix->d_qf32; e.row_offsets = ix->d_qoff; e.n_pages = 1; e.is_query = 1; e.out_f32 = ix->d_qfde;
+  e.variant = ix->fde_query_encode_variant;
+  // one page of n_q rows: the row count travels as a kernel argument (no 16-byte H2D copy in front of every query)
+  e.x_f32 = ix->d_qf32; e.row_offsets = nullptr; e.stride = n_q; e.n_pages = 1; e.is_query = 1; e.out_f32 = ix->d_qfde;
   int rc = launch_fde_encode(ix->fde_t, e, ix->stream);
   if (rc) return rc;
   if (stage_events) MV_HIP(hipEventRecord(ix->ev_st[0], ix->stream));
@@ -717,6 +716,7 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   alloc((void**)&ix->d_scores2, (size_t)cap * 4, "scores2");
   ix->topk_ws_bytes = topk_ws_bytes(std::max<int64_t>(cap, 16384), kTopkMaxDeviceK);  // >= the gathered list of a two-stage rerank
   alloc(&ix->d_topk_ws, ix->topk_ws_bytes, "top-k workspace");
+  if (!rc && hipMemset(ix->d_topk_ws, 0, ix->topk_ws_bytes) != hipSuccess) { set_error("hipMemset of the top-k workspace failed"); rc = MV_ERR_HIP; }  // the radix selection keeps its histograms zeroed between calls
   alloc((void**)&ix->d_out_s, (size_t)kTopkMaxDeviceK * 4, "top-k scores");
   alloc((void**)&ix->d_out_id, (size_t)kTopkMaxDeviceK * 8, "top-k ids");
   alloc((void**)&ix->d_cand, (size_t)kMaxCand * 4, "candidates");
@@ -756,6 +756,7 @@ int mv_index_set_option(mv_index* ix, int option, int64_t value) {
     case MV_OPT_LONG_QUERY_VARIANT: ix->long_query_variant = (int)value; return MV_OK;
     case MV_OPT_FDE_ENCODE_VARIANT: ix->fde_encode_variant = (int)value; return MV_OK;
     case MV_OPT_FILTER_COMPACT_PCT: ix->filter_compact_pct = (int)value; return MV_OK;
+    case MV_OPT_FDE_QUERY_ENCODE_VARIANT: ix->fde_query_encode_variant = (int)value; return MV_OK;
     default: set_error("unknown option %d", option); return MV_ERR_INVALID;
   }
 }

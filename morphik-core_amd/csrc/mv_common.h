@@ -122,7 +122,7 @@ void fde_tables_destroy(FdeTables* t);
 struct FdeEncodeArgs {
   const float* x_f32;        // ragged fp32 rows (row_offsets gives the start row of each page) or null
   const uint16_t* x_bf16;    // fixed-stride bf16 slab pages or null
-  const int64_t* row_offsets;// [n_pages+1] for x_f32 (nullable when n_pages==1 -> 0,n_rows0)
+  const int64_t* row_offsets;// [n_pages+1] for x_f32; null with n_pages == 1: the one page has `stride` rows
   const int32_t* n_rows;     // per page rows (for x_bf16; nullable -> stride)
   int32_t stride;
   int64_t n_pages;

@@ -86,8 +86,12 @@ __global__ __launch_bounds__(256) void fde_encode_kernel(EncArgs a) {
   int64_t r0 = 0;
   int32_t nr;
   if (a.x_f32) {
-    r0 = a.row_offsets[page];
-    nr = (int32_t)(a.row_offsets[page + 1] - r0);
+    if (a.row_offsets) {
+      r0 = a.row_offsets[page];
+      nr = (int32_t)(a.row_offsets[page + 1] - r0);
+    } else {  // ONE page of `stride` rows (the query): no offset array to upload
+      nr = a.stride;
+    }
   } else {
     nr = a.n_rows ? a.n_rows[page] : a.stride;
     r0 = page * (int64_t)a.stride;
@@ -250,8 +254,12 @@ __global__ __launch_bounds__(256) void fde_encode_mfma_kernel(EncMArgs m) {
     int64_t r0 = 0;
     int32_t nr;
     if (a.x_f32) {
-      r0 = a.row_offsets[page];
-      nr = (int32_t)(a.row_offsets[page + 1] - r0);
+      if (a.row_offsets) {
+        r0 = a.row_offsets[page];
+        nr = (int32_t)(a.row_offsets[page + 1] - r0);
+      } else {  // ONE page of `stride` rows (the query)
+        nr = a.stride;
+      }
     } else {
       nr = a.n_rows ? a.n_rows[page] : a.stride;
       r0 = page * (int64_t)a.stride;
@@ -354,6 +362,92 @@ __global__ __launch_bounds__(256) void fde_encode_mfma_kernel(EncMArgs m) {
         a.out_inv_norm[page] = tt > 0.0f ? 1.0f / sqrtf(tt) : 0.0f;
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------ the QUERY: latency form
+// One query page per request sits in front of every FDE search, so what matters is its latency, not throughput: the
+// bulk kernel above is one persistent block that stages all 20 repetitions' tables (56 KiB) and walks 27 dependent
+// 32-MFMA chains per row tile (~65 us for a 32-token query, measured).  Here every repetition gets its own block: it
+// stages only its own 128 x NS SimHash columns and 128 AMS codes, and a wave runs TWO chains per 16-row tile (SimHash,
+// AMS).  Same v_mfma_f32_16x16x4_f32 fmaf chains -> the same sign bits, partitions and products as the other kernels.
+// SUM aggregation only (queries are never averaged, have no norm).
+__global__ __launch_bounds__(256) void fde_encode_query_kernel(EncMArgs m) {
+  const EncArgs& a = m.e;
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  __shared__ float Gs[kDim * 16];                 // [128][16]: this repetition's NS hash columns, zero padded
+  __shared__ __attribute__((aligned(16))) uint8_t codeT[128];  // code of dim 4s+k at [k][s]
+  __shared__ float acc[(1 << kMaxNS) * kMaxPD];   // [NP][PD]
+  __shared__ float xs_all[4 * 16 * kXStride];
+  __shared__ uint8_t sg_all[4 * 16 * 16];
+  const int NP = 1 << a.NS;
+  const int rep = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, k = lane >> 4;
+  float* xs = xs_all + wave * 16 * kXStride;
+  uint8_t* sg = sg_all + wave * 256;
+  const int nr = a.stride;  // ONE page of `stride` fp32 rows at x_f32
+
+  for (int i = threadIdx.x; i < kDim * 16; i += 256) {
+    const int dim = i >> 4, h = i & 15;
+    Gs[i] = h < a.NS ? a.G[((size_t)rep * kDim + dim) * a.NS + h] : 0.f;
+  }
+  if (threadIdx.x < kDim) {
+    const int dim = threadIdx.x;
+    codeT[(dim & 3) * 32 + (dim >> 2)] = (uint8_t)(m.H[rep * kDim + dim] & 15) | (m.S[rep * kDim + dim] < 0.f ? 0x80u : 0u);
+  }
+  for (int i = threadIdx.x; i < NP * a.PD; i += 256) acc[i] = 0.0f;
+  __syncthreads();
+
+  const int ntiles = (nr + 15) >> 4;
+  for (int t = wave; t < ntiles; t += 4) {
+    const int row0 = t * 16;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {  // stage 16 rows x 128 dims (rows >= nr are zero)
+      const int idx = it * 64 + lane, row = idx >> 5, c4 = (idx & 31) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + row < nr) v = *reinterpret_cast<const float4*>(a.x_f32 + (size_t)(row0 + row) * kDim + c4);
+      float* d = xs + row * kXStride + c4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float af[32];  // A fragments: x[row = j][dim = 4s + k]
+#pragma unroll
+    for (int s = 0; s < 32; ++s) af[s] = xs[j * kXStride + 4 * s + k];
+    // two independent chains, interleaved: SimHash sketches (hash column j) and the AMS projection (bucket j)
+    const uint4 c0 = *reinterpret_cast<const uint4*>(codeT + k * 32);
+    const uint4 c1 = *reinterpret_cast<const uint4*>(codeT + k * 32 + 16);
+    const uint32_t cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      cs = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], Gs[(4 * s + k) * 16 + j], cs, 0, 0, 0);
+      const uint32_t code = (cw[s >> 2] >> (8 * (s & 3))) & 0xffu;
+      const float b = ((int)(code & 15u) == j) ? ((code & 0x80u) ? -1.0f : 1.0f) : 0.0f;
+      cp = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], b, cp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sg[(4 * k + i) * 16 + j] = cs[i] > 0.0f ? 1 : 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (j < a.PD) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = 4 * k + i;
+        if (row0 + row < nr) {
+          uint32_t part = 0;
+          for (int jj = 0; jj < a.NS; ++jj) part = (part << 1) + ((uint32_t)sg[row * 16 + jj] ^ (part & 1u));  // AppendToGrayCode
+          atomicAdd(&acc[(size_t)part * a.PD + j], cp[i] * a.scale);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int rep_elems = NP * a.PD;
+  for (int i = threadIdx.x; i < rep_elems; i += 256) {
+    const float v = acc[i];
+    if (a.out_f32) a.out_f32[(size_t)rep * rep_elems + i] = v;
+    if (a.out_bf16) a.out_bf16[(size_t)rep * rep_elems + i] = f32_to_bf16_rne(v);
   }
 }
 
@@ -678,6 +772,12 @@ int launch_fde_encode(const FdeTables& t, const FdeEncodeArgs& a, hipStream_t s)
   k.scale = 1.0f / sqrtf((float)PD);
   k.out_dim = t.out_dim;
   k.out_f32 = a.out_f32; k.out_bf16 = a.out_bf16; k.out_inv_norm = a.out_inv_norm;
+  if (a.variant == 2 && a.n_pages == 1 && a.is_query && a.x_f32 && !a.row_offsets && !a.out_inv_norm && PD <= 16 && NS <= kMaxNS) {
+    EncMArgs mm{k, t.H, t.S, 1};
+    hipLaunchKernelGGL(fde_encode_query_kernel, dim3((unsigned)R), dim3(256), 0, s, mm);  // one block per repetition
+    MV_HIP(hipGetLastError());
+    return MV_OK;
+  }
   if (a.variant != 0 && PD <= 16 && R * NS <= 128) {
     // f32-MFMA form (default): persistent blocks, one per CU
     const int NHP = ((R * NS + 15) / 16) * 16;

@@ -97,6 +97,7 @@ struct mv_index {
   int batch_variant = -1;      // -1 = auto: pipelined kernel up to 384 query rows, 512-row kernel above
   int long_query_variant = 1;  // 1 = single queries > 64 rows use the row-split (batched) workgroup; 0 = page-split passes
   int fde_encode_variant = 1;  // 1 = f32-MFMA kernel, 0 = scalar kernel
+  int fde_query_encode_variant = 2;  // the ONE query page: 2 = latency kernel (one block per repetition, default), 1 = bulk f32-MFMA kernel, 0 = scalar kernel
   int64_t fde_coarse_n = 0;
   int fde_cosine = 1;
   int pad_semantics = -1;  // -1: mode default (reference batch rule for FDE_THEN_FLOAT / candidates, none for full scan)

@@ -16,7 +16,6 @@ namespace {
 
 constexpr int kChunk = 2048;
 constexpr int kThreads = 256;
-constexpr size_t kRadixTailBytes = 4096 * 8 + 2048 * 4 + 64;  // [survivors][histogram][RadixState]  // survivors + histogram + state (radix path, k > 32)
 
 __device__ __forceinline__ uint32_t ordered_u32(float f) {
   uint32_t u = __float_as_uint(f);
@@ -182,68 +181,48 @@ __global__ __launch_bounds__(kThreads) void topk_extract_kernel(const float* sco
 }
 
 // Large k (> 32) over many scores: radix threshold instead of a 2048/k-per-level sort cascade (k = 1000 over 1.25 M FDE
-// scores took ~10 dependent bitonic levels, ~0.5 ms).  Three histogram passes over the order-preserving 32-bit keys
-// (11 + 11 + 10 bits, the bin choice stays on the device) give the exact k-th key T; one compaction pass collects
-// every key >= T (all ties included) as 64-bit (key, ~index) words; a single block sorts those <= 4096 survivors, so
-// order and the lowest-index tie rule are exactly those of the cascade.  More than 4096 survivors (masses of equal
-// scores) fall back to the cascade.
-struct RadixState {
-  uint32_t prefix_val;
-  uint32_t prefix_mask;
-  uint32_t k_remaining;
-  uint32_t count;  // compaction counter
-  uint32_t done;   // 1 = the radix path produced the result; 0 = more than kRadixCap survivors -> serial fallback runs
-};
+// scores took ~10 dependent bitonic levels, ~0.5 ms).  Two histogram passes over the order-preserving 32-bit keys
+// (11 + 11 bits) fix the top 22 bits T of the k-th key; a compaction pass collects every key >= T (the top k plus the
+// rest of the threshold bin, all ties included) as 64-bit (key, ~index) words; ONE block merge-sorts the survivors, so
+// order and the lowest-index tie rule are exactly those of the cascade.  Nothing is decided on the host and no kernel
+// takes a device-wide fence (on a multi-XCD part a fence per block costs more than a launch -- measured): the bin
+// choice of a pass is recomputed by every block of the NEXT kernel from the finished histogram (2048 bins, ~2 us), so
+// the chain is memset + 4 launches.  More than kRadixCap survivors (masses of equal scores): the final block streams
+// the whole score vector instead (slow, deterministic, rare).
 constexpr int kRadixBins = 2048;
-constexpr int kRadixCap = 4096;
+constexpr int kRadixCap = 16384;
+// workspace head (fixed place, zeroed once when the workspace is allocated):
+//   [survivors kRadixCap x u64][histA 2048 x u32][histB 2048 x u32][RadixCtl]
+// No memset in the chain: the histograms are cleared for the NEXT selection by the rank kernel of this one (they are
+// dead by then), the survivor counter by the first histogram kernel of the next one (it is dead until the compaction).
+struct RadixCtl {
+  uint32_t count;
+  uint32_t pad[15];
+};
+constexpr size_t kRadixTailBytes = (size_t)kRadixCap * 8 + 2 * kRadixBins * 4 + sizeof(RadixCtl);
 
-__global__ __launch_bounds__(256) void radix_init_kernel(RadixState* st, uint32_t* hist, uint32_t k) {
-  for (int i = threadIdx.x; i < kRadixBins; i += 256) hist[i] = 0;
-  if (threadIdx.x == 0) *st = RadixState{0u, 0u, k, 0u, 0u};
-}
-
-__global__ __launch_bounds__(256) void radix_hist_kernel(const float* scores, int64_t n, int shift, int nbits, const RadixState* st,
-                                                         uint32_t* hist) {
-  __shared__ uint32_t h[kRadixBins];
-  for (int i = threadIdx.x; i < kRadixBins; i += 256) h[i] = 0;
-  __syncthreads();
-  const uint32_t pm = st->prefix_mask, pv = st->prefix_val, bm = (1u << nbits) - 1u;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float s = scores[i] + 0.0f;
-    if (s == s && s != -INFINITY) {
-      const uint32_t key = ordered_u32(s);
-      if ((key & pm) == pv) atomicAdd(&h[(key >> shift) & bm], 1u);
-    }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < kRadixBins; i += 256)
-    if (h[i]) atomicAdd(&hist[i], h[i]);
-}
-
-// One block of 256 threads, 8 bins each: the bin b >= 1 (highest first) where the count of keys in higher bins is still
-// below k_remaining but reaches it with bin b; none -> bin 0 (absorbs a k beyond the number of valid scores).  Fixes
-// those bits of the threshold, then clears the histogram for the next pass.
-__global__ __launch_bounds__(256) void radix_pick_kernel(uint32_t* hist, int nbits, int shift, RadixState* st) {
-  __shared__ uint32_t part[256];
+// Every thread of a 256-thread block gets (bin, keys_above): the bin b >= 1 (highest first) where the number of keys in
+// higher bins is still below kr but reaches it with bin b; none -> bin 0 with every key of bins >= 1 above it (absorbs a
+// k beyond the number of valid scores).  Suffix sums: shuffles inside a wave, four wave totals through LDS.
+__device__ __forceinline__ void radix_pick(const uint32_t* hist, uint32_t kr, uint32_t* out_bin, uint32_t* out_above) {
+  __shared__ uint32_t wtot[4];
   __shared__ uint32_t found_bin, found_above;
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   uint32_t loc[8], sum = 0;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { loc[j] = hist[t * 8 + j]; sum += loc[j]; }  // bins beyond 1 << nbits are zero
-  part[t] = sum;
+  for (int j = 0; j < 8; ++j) { loc[j] = hist[t * 8 + j]; sum += loc[j]; }
+  uint32_t v = sum;  // inclusive suffix sum over the lanes of this wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_down(v, d);
+    if (lane + d < 64) v += o;
+  }
+  __syncthreads();  // wtot / found_* may still be read from a previous call
+  if (lane == 0) wtot[wave] = v;
   if (t == 0) { found_bin = 0u; found_above = 0xffffffffu; }
   __syncthreads();
-  // inclusive suffix sum over threads (Hillis-Steele), then exclusive = inclusive - own
-  uint32_t v = sum;
-  for (int d = 1; d < 256; d <<= 1) {
-    const uint32_t o = (t + d < 256) ? part[t + d] : 0u;
-    __syncthreads();
-    v += o;
-    part[t] = v;
-    __syncthreads();
-  }
-  const uint32_t kr = st->k_remaining;
   uint32_t above = v - sum;  // keys in bins owned by higher threads
+  for (int w = wave + 1; w < 4; ++w) above += wtot[w];
 #pragma unroll
   for (int j = 7; j >= 0; --j) {
     const int b = t * 8 + j;
@@ -251,25 +230,52 @@ __global__ __launch_bounds__(256) void radix_pick_kernel(uint32_t* hist, int nbi
     above += loc[j];
   }
   __syncthreads();
-  if (t == 0) {
-    // not found: bin 0, with every key of bins >= 1 above it (part[0] = total, loc[0] = bin 0 of thread 0)
-    const uint32_t cum = found_above != 0xffffffffu ? found_above : part[0] - loc[0];
-    st->k_remaining = kr - cum;
-    st->prefix_val |= found_bin << shift;
-    st->prefix_mask |= ((1u << nbits) - 1u) << shift;
-  }
-  for (int i = t; i < kRadixBins; i += 256) hist[i] = 0;
+  *out_bin = found_bin;
+  *out_above = found_above != 0xffffffffu ? found_above : (wtot[0] + wtot[1] + wtot[2] + wtot[3]) - hist[0];
 }
 
-__global__ __launch_bounds__(256) void radix_compact_kernel(const float* scores, int64_t n, RadixState* st, uint64_t* out) {
-  const uint32_t T = st->prefix_val;
+constexpr int kShift0 = 21, kShift1 = 10;  // key bits [31:21] then [20:10]
+
+__global__ __launch_bounds__(256) void radix_hist_kernel(const float* scores, int64_t n, int pass, uint32_t k, const uint32_t* hist_prev,
+                                                         uint32_t* hist, RadixCtl* ctl) {
+  __shared__ uint32_t h[kRadixBins];
+  if (pass == 0 && blockIdx.x == 0 && threadIdx.x == 0) ctl->count = 0;  // dead until the compaction kernel
+  for (int i = threadIdx.x; i < kRadixBins; i += 256) h[i] = 0;
+  uint32_t pm = 0, pv = 0;
+  if (pass == 1) {
+    uint32_t bin0, above0;
+    radix_pick(hist_prev, k, &bin0, &above0);
+    pm = 0x7ffu << kShift0;
+    pv = bin0 << kShift0;
+  }
+  __syncthreads();
+  const int shift = pass == 0 ? kShift0 : kShift1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float s = scores[i] + 0.0f;
+    if (s == s && s != -INFINITY) {
+      const uint32_t key = ordered_u32(s);
+      if ((key & pm) == pv) atomicAdd(&h[(key >> shift) & 0x7ffu], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kRadixBins; i += 256)
+    if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+__global__ __launch_bounds__(256) void radix_compact_kernel(const float* scores, int64_t n, uint32_t k, const uint32_t* histA, const uint32_t* histB,
+                                                            RadixCtl* ctl, uint64_t* out) {
+  uint32_t* count = &ctl->count;
+  uint32_t bin0, above0, bin1, above1;
+  radix_pick(histA, k, &bin0, &above0);
+  radix_pick(histB, k - above0, &bin1, &above1);
+  const uint32_t T = (bin0 << kShift0) | (bin1 << kShift1);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float s = scores[i] + 0.0f;
     if (s == s && s != -INFINITY) {
       const uint32_t key = ordered_u32(s);
       if (key >= T) {
-        const uint32_t pos = atomicAdd(&st->count, 1u);
-        if (pos < kRadixCap) out[pos] = ((uint64_t)key << 32) | (uint32_t)(~(uint32_t)i);
+        const uint32_t pos = atomicAdd(count, 1u);
+        if (pos < (uint32_t)kRadixCap) out[pos] = ((uint64_t)key << 32) | (uint32_t)(~(uint32_t)i);
       }
     }
   }
@@ -289,42 +295,42 @@ __device__ __forceinline__ void topk_write_out(const uint64_t* sk, const TopkOut
   }
 }
 
-// Last step of the radix path: ONE block sorts the survivors (their number is read from the device state, so the host
-// never waits for it) and writes the k results.  More than kRadixCap survivors: leaves done = 0 for the fallback.
-__global__ __launch_bounds__(kThreads) void radix_final_kernel(const uint64_t* surv, RadixState* st, int kk, TopkOut o) {
+// Last step: every survivor's RANK (number of larger keys; keys are unique) computed by brute force against the survivor
+// list staged 2048 keys at a time in LDS -- ~1600 survivors x 1600 compares spread over several blocks is a few
+// microseconds, against ~40 for a single-block bitonic merge -- and the owner of rank < k writes result slot `rank`.
+// More survivors than the list holds (masses of equal scores): block 0 streams the whole score vector instead, keeping the
+// best kk (<= 1024) keys in the lower half of a 2048-key LDS array and sorting 1024 new keys against them per step (slow,
+// deterministic, rare); the other blocks leave.
+__global__ __launch_bounds__(kThreads) void radix_rank_kernel(const float* scores, int64_t n, const uint64_t* surv, RadixCtl* ctl, uint32_t* hists,
+                                                              TopkOut o) {
   __shared__ uint64_t sk[kChunk];
-  __shared__ uint64_t best[kChunk];
-  const uint32_t cnt = st->count;
-  if (cnt > (uint32_t)kRadixCap) return;  // done stays 0
-  const int sub = cnt > (uint32_t)kChunk ? 2 : 1;
-  for (int sc = 0; sc < sub; ++sc) {
-    for (int i = threadIdx.x; i < kChunk; i += kThreads) {
-      const uint32_t gi = (uint32_t)sc * kChunk + i;
-      sk[i] = gi < cnt ? surv[gi] : 0;
+  const uint32_t cnt = ctl->count;
+  if (blockIdx.x == gridDim.x - 1)  // housekeeping for the next selection (a block past the survivor list in practice)
+    for (int i = threadIdx.x; i < 2 * kRadixBins; i += kThreads) hists[i] = 0;
+  if (cnt <= (uint32_t)kRadixCap) {
+    const uint32_t me = blockIdx.x * kThreads + threadIdx.x;
+    const uint64_t mine = me < cnt ? surv[me] : 0;
+    uint32_t rank = 0;
+    if ((uint32_t)blockIdx.x * kThreads < cnt) {  // block-uniform: blocks past the list only pad
+      for (uint32_t base = 0; base < cnt; base += kChunk) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < kChunk; i += kThreads) sk[i] = base + i < cnt ? surv[base + i] : 0;
+        __syncthreads();
+        const int m = (int)min((uint32_t)kChunk, cnt - base);
+#pragma unroll 8
+        for (int i = 0; i < m; ++i) rank += sk[i] > mine ? 1u : 0u;  // broadcast reads
+      }
+      if (me < cnt && rank < (uint32_t)o.k) {
+        const uint32_t idx = ~(uint32_t)(mine & 0xffffffffu);
+        o.out_s[rank] = unordered_f32((uint32_t)(mine >> 32));
+        o.out_id[rank] = o.id_base + (o.ids_map ? (int64_t)o.ids_map[idx] : (int64_t)idx);
+      }
     }
-    __syncthreads();
-    bitonic_sort_desc(sk);
-    if (sub > 1) {
-      for (int i = threadIdx.x; i < kk; i += kThreads) best[sc * kk + i] = sk[i];
-      __syncthreads();
-    }
+    if (blockIdx.x == 0)  // fewer valid scores than k: pad the tail
+      for (int i = (int)cnt + threadIdx.x; i < o.k; i += kThreads) { o.out_s[i] = -INFINITY; o.out_id[i] = -1; }
+    return;
   }
-  if (sub > 1) {
-    for (int i = threadIdx.x; i < kChunk; i += kThreads) sk[i] = i < 2 * kk ? best[i] : 0;
-    __syncthreads();
-    bitonic_sort_desc(sk);
-  }
-  topk_write_out(sk, o);
-  if (threadIdx.x == 0) st->done = 1u;
-}
-
-// Fallback of the radix path (masses of equal scores at the threshold): one block streams the whole score vector,
-// keeping the best kk (<= 1024) keys in the lower half of a 2048-key LDS array and sorting 1024 new keys against them
-// per step.  Slow (one block), deterministic, and launched unconditionally BEHIND radix_final_kernel so that the
-// selection never needs a host decision: it returns at once when done == 1.
-__global__ __launch_bounds__(kThreads) void topk_serial_fallback_kernel(const float* scores, int64_t n, const RadixState* st, TopkOut o) {
-  __shared__ uint64_t sk[kChunk];
-  if (st->done) return;
+  if (blockIdx.x != 0) return;
   constexpr int kHalf = kChunk / 2;
   for (int i = threadIdx.x; i < kHalf; i += kThreads) sk[i] = 0;
   for (int64_t base = 0; base < n; base += kHalf) {
@@ -406,7 +412,7 @@ int launch_topk(const float* d_scores, int64_t n, int32_t k, const int32_t* d_id
     set_error("launch_topk: n too large");
     return MV_ERR_INVALID;
   }
-  uint64_t* bufA = reinterpret_cast<uint64_t*>(ws);
+  uint64_t* bufA = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(ws) + kRadixTailBytes);  // behind the radix head
   const int64_t l1 = nblocks(n > 0 ? n : 1) * (int64_t)k;
   uint64_t* bufB = bufA + (l1 + kChunk);
   const TopkOut out{d_ids_map, id_base, d_out_scores, d_out_ids, k};
@@ -422,22 +428,17 @@ int launch_topk(const float* d_scores, int64_t n, int32_t k, const int32_t* d_id
   const uint64_t* in = nullptr;
   uint64_t* outk = bufA;
   if (k > 32 && cur_n > 2 * kChunk) {
-    // radix threshold + compaction; workspace tail: [survivors 4096 x u64][hist 2048 x u32][state].  Entirely in stream
-    // order: the survivor count never comes back to the host.
-    char* tail = reinterpret_cast<char*>(ws) + topk_ws_bytes(n, k) - kRadixTailBytes;
-    uint64_t* surv = reinterpret_cast<uint64_t*>(tail);
-    uint32_t* hist = reinterpret_cast<uint32_t*>(tail + kRadixCap * 8);
-    RadixState* st = reinterpret_cast<RadixState*>(tail + kRadixCap * 8 + kRadixBins * 4);
-    hipLaunchKernelGGL(radix_init_kernel, dim3(1), dim3(256), 0, s, st, hist, (uint32_t)k);
+    char* head = reinterpret_cast<char*>(ws);
+    uint64_t* surv = reinterpret_cast<uint64_t*>(head);
+    uint32_t* histA = reinterpret_cast<uint32_t*>(head + (size_t)kRadixCap * 8);
+    uint32_t* histB = histA + kRadixBins;
+    RadixCtl* ctl = reinterpret_cast<RadixCtl*>(histB + kRadixBins);
     const int grid = (int)std::min<int64_t>((cur_n + 255) / 256, 256 * 8);
-    const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
-    for (int p = 0; p < 3; ++p) {
-      hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)grid), dim3(256), 0, s, sc, cur_n, shifts[p], bits[p], (const RadixState*)st, hist);
-      hipLaunchKernelGGL(radix_pick_kernel, dim3(1), dim3(256), 0, s, hist, bits[p], shifts[p], st);
-    }
-    hipLaunchKernelGGL(radix_compact_kernel, dim3((unsigned)grid), dim3(256), 0, s, sc, cur_n, st, surv);
-    hipLaunchKernelGGL(radix_final_kernel, dim3(1), dim3(kThreads), 0, s, (const uint64_t*)surv, st, (int)k, out);
-    hipLaunchKernelGGL(topk_serial_fallback_kernel, dim3(1), dim3(kThreads), 0, s, sc, cur_n, (const RadixState*)st, out);
+    hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)grid), dim3(256), 0, s, sc, cur_n, 0, (uint32_t)k, (const uint32_t*)nullptr, histA, ctl);
+    hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)grid), dim3(256), 0, s, sc, cur_n, 1, (uint32_t)k, (const uint32_t*)histA, histB, ctl);
+    hipLaunchKernelGGL(radix_compact_kernel, dim3((unsigned)grid), dim3(256), 0, s, sc, cur_n, (uint32_t)k, (const uint32_t*)histA,
+                       (const uint32_t*)histB, ctl, surv);
+    hipLaunchKernelGGL(radix_rank_kernel, dim3((unsigned)(kRadixCap / kThreads)), dim3(kThreads), 0, s, sc, cur_n, (const uint64_t*)surv, ctl, histA, out);
     MV_HIP(hipGetLastError());
     return MV_OK;
   }
