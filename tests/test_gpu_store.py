@@ -291,15 +291,15 @@ def test_sharded_store_random_ops_match_the_model_on_gpu(R, mode):
 
 @pytest.mark.parametrize("mode", ["float", "binary", "fde_then_float", "float_fp8"])
 def test_sharded_store_answers_equal_the_single_store(mode, tmp_path):
-    """Same ingest sequence into a single store and into 1 / 2 / 4-shard stores: identical hits, order and scores (ties
-    included: duplicated pages land on different shards), before and after a checkpoint round trip."""
+    """Same ingest sequence into a single store and into 1 / 2 / 4-shard stores: identical hits and scores (duplicated pages
+    land on different shards: every member of a tie must come back), before and after a checkpoint round trip."""
     from morphik_core_amd.store import MI355XShardedFastMultiVectorStore, MI355XShardedMultiVectorStore
 
     rng = np.random.default_rng(31)
     chunks = sc.make_chunks(rng, n_docs=8, chunks_per_doc=3, rows=30)
     for j in (4, 9, 14, 19):  # exact duplicates of page 0 scattered over the documents -> equal scores across shards
         chunks[j] = chunks[j].model_copy(update={"embedding": chunks[0].embedding})
-    kw = dict(fde_coarse_n=20) if mode == "fde_then_float" else {}
+    kw = dict(fde_coarse_n=64) if mode == "fde_then_float" else {}  # every live page is a candidate: no tie can straddle the coarse cut
     one = _store(mode) if mode != "fde_then_float" else None
     if one is None:
         from morphik_core_amd.store import MI355XFastMultiVectorStore
@@ -318,11 +318,17 @@ def test_sharded_store_answers_equal_the_single_store(mode, tmp_path):
         for q in queries:
             for filt in (None, ["doc0", "doc1", "doc3", "doc6"]):
                 r = sc.run(st.query_similar(q, k=9, doc_ids=filt))
-                out.append([(c.document_id, c.chunk_number, c.content, c.score) for c in r])
+                assert all(r[i].score >= r[i + 1].score for i in range(len(r) - 1))
+                # equal scores are ordered by internal page id, which depends on how the pages were routed to shards (the
+                # reference leaves tie order unspecified): compare with ties in a canonical order.  Exact tie ORDER against one
+                # index with the same id assignment is asserted in test_gpu_sharded.py.
+                rows = sorted(((c.document_id, c.chunk_number, c.content, c.score) for c in r), key=lambda t: (-t[3], t[0], t[1]))
+                cut = rows[-1][3] if rows else None  # a tie that straddles the k-th place may keep different members
+                out.append(([t for t in rows if t[3] != cut], [t[3] for t in rows]))
         return out
 
     want = answers(one)
-    assert any(len({s for *_x, s in a}) < len(a) for a in want)  # ties are really present
+    assert any(len(set(scores)) < len(scores) for _rows, scores in want)  # ties are really present
     for R, st in stores.items():
         assert answers(st) == want, (mode, R)
     # checkpoint / resume of the sharded store: one index file per shard + one bookkeeping file
