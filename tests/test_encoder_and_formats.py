@@ -135,3 +135,161 @@ def test_embed_server_speaks_the_reference_protocol(tiny_embedder):
     assert client.post("/embeddings", json={"input_type": "text", "inputs": ["x"]}).status_code == 401
     assert client.post("/embeddings", json={"input_type": "text", "inputs": ["x"] * 300}, headers=hdr).status_code == 413  # client bisects
     assert client.post("/embeddings", json={"input_type": "audio", "inputs": ["x"]}, headers=hdr).status_code == 422
+
+
+# --------------------------------------------------------------------------- checkpoint + processor branch, ColQwen2 family
+def test_colpali_adapter_loads_a_checkpoint_directory_with_its_processor(tmp_path):
+    """The `model_name_or_path` branch (from_pretrained + ColPaliProcessor: colpali_embedding_model.py:47-59): a tiny
+    random-init checkpoint and an offline-built processor saved to disk, loaded back and driven end to end."""
+    import asyncio
+
+    from morphik_core_amd.embedding import MI355XColpaliEmbeddingModel
+    from morphik_core_amd.models import Chunk
+    from tests import offline_assets as oa
+
+    d = oa.colpali_checkpoint(str(tmp_path / "ckpt"))
+    m = MI355XColpaliEmbeddingModel(model_name_or_path=d, device="cpu", batch_size=2)
+    assert m.processor is not None and m.random_init is False
+    rng = np.random.default_rng(0)
+    chunks = [Chunk(content="", metadata={"is_image": True, "_image_bytes": oa.png_bytes(oa.page_image(rng, 60, 80))}) for _ in range(3)]
+    chunks.append(Chunk(content="total revenue by quarter", metadata={}))
+    embs = asyncio.run(m.embed_for_ingestion(chunks))
+    n_img = (56 // 14) ** 2
+    assert [e.shape[0] for e in embs[:3]] == [n_img + 4] * 3  # 16 image tokens + the processor's prompt tokens
+    assert all(e.dtype == np.float32 and e.shape[1] == 128 for e in embs)
+    for e in embs:
+        np.testing.assert_allclose(np.linalg.norm(e, axis=1), 1.0, atol=2e-2)  # L2-normalised by the model head
+    again = asyncio.run(m.embed_for_ingestion(chunks[:1]))
+    np.testing.assert_allclose(again[0], embs[0], atol=2e-2)  # deterministic, batch-independent
+    q = asyncio.run(m.embed_for_query("what is shown in this image"))
+    assert q.ndim == 2 and q.shape[1] == 128 and q.dtype == np.float32
+    t = m.latest_ingest_timing()
+    assert t["image_count"] == 1 and t["model"] > 0
+
+
+def test_colqwen2_adapter_ragged_pages_through_the_store():
+    """The reference's encoder family (ColQwen2.5: colpali_embedding_model.py:47-52) has DYNAMIC patch counts.  Tiny
+    random-init ColQwen2ForRetrieval + offline processor: pages of different resolutions give different row counts, the
+    store takes them as ragged pages, every page retrieves itself."""
+    import asyncio
+
+    import torch
+
+    from morphik_core_amd.colqwen_embedding import MI355XColQwen2EmbeddingModel, build_random_colqwen2
+    from morphik_core_amd.models import Chunk, DocumentChunk
+    from morphik_core_amd.store import MI355XMultiVectorStore
+    from tests import offline_assets as oa
+    from tests.fake_index import OracleIndex
+
+    proc, ids = oa.colqwen2_processor()
+    emb = MI355XColQwen2EmbeddingModel(model=build_random_colqwen2("tiny", ids, "cpu", torch.bfloat16), processor=proc, device="cpu", batch_size=2)
+    rng = np.random.default_rng(1)
+    sizes = [(60, 60), (56, 112), (112, 84), (30, 200), (84, 84)]
+    chunks = [Chunk(content="", metadata={"is_image": True, "_image_bytes": oa.png_bytes(oa.page_image(rng, h, w))}) for h, w in sizes]
+    chunks.append(Chunk(content="hello world", metadata={}))
+    embs = asyncio.run(emb.embed_for_ingestion(chunks))
+    n_rows = [e.shape[0] for e in embs]
+    assert len(set(n_rows[:5])) >= 3, n_rows  # the row count follows the page's resolution
+    for e in embs:
+        assert e.dtype == np.float32 and e.shape[1] == 128
+        np.testing.assert_allclose(np.linalg.norm(e, axis=1), 1.0, atol=2e-2)
+    rows, nr = asyncio.run(emb.embed_for_ingestion_device(chunks))
+    assert nr == n_rows and rows.shape == (sum(n_rows), 128) and rows.dtype == torch.bfloat16
+    store = MI355XMultiVectorStore(capacity_pages=16, stride_rows=32, mode="float", index_factory=OracleIndex)
+    assert store.initialize()
+    dcs = [DocumentChunk(document_id=f"d{i // 3}", chunk_number=i % 3, content=f"page {i}", embedding=e, metadata={"rows": e.shape[0]}) for i, e in enumerate(embs)]
+    ok, ids_, m = asyncio.run(store.store_embeddings(dcs))
+    assert ok and len(ids_) == 6 and m["multivector_bytes"] == sum(n_rows) * 256
+    for i, e in enumerate(embs):
+        hit = asyncio.run(store.query_similar(e, k=2))[0]
+        assert hit.content == f"page {i}" and hit.metadata == {"rows": n_rows[i]}
+    q = asyncio.run(emb.embed_for_query("total revenue by quarter"))
+    assert q.shape[1] == 128 and len(asyncio.run(store.query_similar(q, k=3))) == 3
+
+
+def _serve(app):
+    """uvicorn on a free localhost port in a background thread -> (base url, stop())."""
+    import socket
+    import threading
+    import time
+
+    import uvicorn
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    server = uvicorn.Server(uvicorn.Config(app, host="127.0.0.1", port=port, log_level="warning"))
+    th = threading.Thread(target=server.run, daemon=True)
+    th.start()
+    for _ in range(200):
+        if server.started:
+            break
+        time.sleep(0.05)
+    assert server.started
+
+    def stop():
+        server.should_exit = True
+        th.join(timeout=10)
+
+    return f"http://127.0.0.1:{port}", stop
+
+
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference checkout exists in the build container only")
+def test_the_references_own_api_client_drives_the_embed_server(tiny_embedder):
+    """ColpaliApiEmbeddingModel (core/embedding/colpali_api_embedding_model.py) -- the reference's
+    client class itself, imported from the reference checkout -- talks to the MI355X embed server over real HTTP:
+    _call_api_endpoint (:273-310), embed_for_query (:312-319) and embed_for_ingestion with its batching (:109-271)."""
+    import asyncio
+    import sys
+    import types
+
+    from morphik_core_amd.embed_server import create_app
+    from morphik_core_amd.models import Chunk
+
+    url, stop = _serve(create_app(tiny_embedder, api_key="secret"))
+    saved = {k: sys.modules.get(k) for k in ("core", "core.config", "core.embedding", "core.models")}
+    try:
+        # the client's package __init__ imports colpali_engine (absent here): register bare package modules that point at the
+        # reference directories, and a settings stub carrying the two fields the client reads (:41-48)
+        core = types.ModuleType("core")
+        core.__path__ = [os.path.join(REF, "core")]
+        emb_pkg = types.ModuleType("core.embedding")
+        emb_pkg.__path__ = [os.path.join(REF, "core", "embedding")]
+        models_pkg = types.ModuleType("core.models")
+        models_pkg.__path__ = [os.path.join(REF, "core", "models")]
+        cfg = types.ModuleType("core.config")
+        cfg.get_settings = lambda: types.SimpleNamespace(MORPHIK_EMBEDDING_API_KEY="secret", MORPHIK_EMBEDDING_API_DOMAIN=[url])
+        sys.modules.update({"core": core, "core.config": cfg, "core.embedding": emb_pkg, "core.models": models_pkg})
+        from core.embedding.colpali_api_embedding_model import ColpaliApiEmbeddingModel  # the reference's class
+
+        client = ColpaliApiEmbeddingModel()
+        assert client.endpoints == [url + "/embeddings"]
+        q = asyncio.run(client.embed_for_query("hello world"))
+        want = asyncio.run(tiny_embedder.embed_for_query("hello world"))
+        assert isinstance(q, np.ndarray) and q.dtype == np.float32 and q.shape == want.shape
+        np.testing.assert_allclose(q, want, atol=2e-2)
+        got = asyncio.run(client._call_api_endpoint(url + "/embeddings", [base64.b64encode(_png(3)).decode(), base64.b64encode(_png(4)).decode()], "image"))
+        assert len(got) == 2 and all(g.shape == (tiny_embedder.n_image_tokens + 6, 128) and g.dtype == np.float32 for g in got)
+        from core.models.chunk import Chunk as RefChunk  # the reference's own record type
+
+        chunks = [RefChunk(content="data:image/png;base64," + base64.b64encode(_png(i)).decode(), metadata={"is_image": True}) for i in range(3)]
+        chunks.insert(1, RefChunk(content="second query here", metadata={}))
+        embs = asyncio.run(client.embed_for_ingestion(chunks))
+        ours = asyncio.run(tiny_embedder.embed_for_ingestion([Chunk(content=c.content, metadata=dict(c.metadata)) for c in chunks]))
+        assert len(embs) == 4
+        for a, b in zip(embs, ours):  # order restored across the client's image / text partition
+            assert np.asarray(a).shape == b.shape
+            np.testing.assert_allclose(np.asarray(a, np.float32), b, atol=2e-2)
+    finally:
+        stop()
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        for k in [k for k in sys.modules if k.startswith("core.")]:
+            sys.modules.pop(k, None)

@@ -411,3 +411,80 @@ def test_full_size_colpali_v1_2_encoder_feeds_the_store():
     hits = asyncio.run(store.query_similar(q, k=10))
     assert len(hits) == 10 and all(hits[i].score >= hits[i + 1].score for i in range(9))
     store.close()
+
+
+def test_colqwen2_ragged_pages_stay_on_the_gpu_into_the_slab():
+    """ColQwen2 family (the reference's encoder, dynamic patch counts) on the GPU: ragged bf16 pages go from the model's
+    output straight into the slab (mv_index_add_device); the same pages through the float32-ndarray contract score the same."""
+    import torch
+
+    from morphik_core_amd.colqwen_embedding import MI355XColQwen2EmbeddingModel, build_random_colqwen2
+    from morphik_core_amd.models import Chunk, DocumentChunk
+    from morphik_core_amd.store import MI355XMultiVectorStore
+    from tests import offline_assets as oa
+
+    proc, ids = oa.colqwen2_processor(min_tokens=4, max_tokens=64)
+    emb = MI355XColQwen2EmbeddingModel(model=build_random_colqwen2("tiny", ids, "cuda:0", torch.bfloat16), processor=proc, device="cuda:0", batch_size=4)
+    rng = np.random.default_rng(4)
+    sizes = [(60, 60), (56, 112), (112, 84), (30, 200), (84, 84), (224, 224), (140, 196), (100, 300), (28, 28)]
+    chunks = [Chunk(content="", metadata={"is_image": True, "_image_bytes": oa.png_bytes(oa.page_image(rng, h, w))}) for h, w in sizes]
+    rows, n_rows = asyncio.run(emb.embed_for_ingestion_device(chunks))
+    assert rows.is_cuda and rows.dtype == torch.bfloat16 and sum(n_rows) == rows.shape[0] and len(set(n_rows)) >= 4, n_rows
+    host = asyncio.run(emb.embed_for_ingestion(chunks))
+    stride = ((max(n_rows) + 15) // 16) * 16
+    dev_store = MI355XMultiVectorStore(capacity_pages=16, stride_rows=stride, mode="float")
+    host_store = MI355XMultiVectorStore(capacity_pages=16, stride_rows=stride, mode="float")
+    assert dev_store.initialize() and host_store.initialize()
+    o, dcs, hcs = 0, [], []
+    for i, n in enumerate(n_rows):
+        dcs.append(DocumentChunk(document_id=f"d{i // 3}", content=f"p{i}", embedding=rows[o : o + n], chunk_number=i % 3, metadata={}))
+        hcs.append(DocumentChunk(document_id=f"d{i // 3}", content=f"p{i}", embedding=host[i], chunk_number=i % 3, metadata={}))
+        o += n
+    asyncio.run(dev_store.store_embeddings(dcs))
+    asyncio.run(host_store.store_embeddings(hcs))
+    assert dev_store._index.page_rows(list(range(len(n_rows)))).tolist() == n_rows  # ragged pages in fixed-stride slots
+    for i in (0, 3, 5, 8):
+        got = asyncio.run(dev_store.query_similar(host[i], k=3))
+        want = asyncio.run(host_store.query_similar(host[i], k=3))
+        assert got[0].content == f"p{i}" and [c.content for c in got] == [c.content for c in want]
+        np.testing.assert_allclose([c.score for c in got], [c.score for c in want], rtol=1e-3)
+    dev_store.close()
+    host_store.close()
+
+
+def test_embed_server_on_the_gpu_over_http():
+    """SURVEY 8f row 3 on the MI355X: the /embeddings server around a GPU-resident encoder, driven over real HTTP with the
+    reference client's own request / decode steps (colpali_api_embedding_model.py:286-310; the client class itself drives it
+    in the CPU suite, where the reference checkout exists)."""
+    import base64
+    import io
+
+    import httpx
+
+    from morphik_core_amd import formats
+    from morphik_core_amd.embed_server import create_app
+    from morphik_core_amd.embedding import MI355XColpaliEmbeddingModel
+    from tests import offline_assets as oa
+    from tests.test_encoder_and_formats import _serve
+
+    emb = MI355XColpaliEmbeddingModel(preset="tiny", device="cuda:0", batch_size=4)
+    url, stop = _serve(create_app(emb, api_key="k"))
+    try:
+        rng = np.random.default_rng(0)
+        imgs = [base64.b64encode(oa.png_bytes(oa.page_image(rng, 56, 56))).decode() for _ in range(5)]
+        hdr = {"Authorization": "Bearer k"}
+        r = httpx.post(url + "/embeddings", json={"input_type": "image", "inputs": imgs}, headers=hdr, timeout=60)
+        assert r.status_code == 200
+        z = np.load(io.BytesIO(r.content))  # the client's decode steps
+        assert int(z["count"]) == 5 and str(z["input_type"]) == "image"
+        got = [z[f"emb_{i}"].astype(np.float32, copy=False) for i in range(5)]
+        assert all(g.shape == (emb.n_image_tokens + 6, 128) for g in got)
+        np.testing.assert_allclose(np.linalg.norm(got[0], axis=1), 1.0, atol=2e-2)
+        r = httpx.post(url + "/embeddings", json={"input_type": "text", "inputs": ["hello world"]}, headers=hdr, timeout=60)
+        embs, it = formats.decode_embeddings_npz(r.content)
+        want = asyncio.run(emb.embed_for_query("hello world"))
+        assert it == "text" and embs[0].shape == want.shape
+        np.testing.assert_allclose(embs[0], want, atol=2e-2)
+        assert httpx.post(url + "/embeddings", json={"input_type": "text", "inputs": ["x"]}, timeout=60).status_code == 401
+    finally:
+        stop()
