@@ -653,7 +653,7 @@ class MI355XShardedFastMultiVectorStore(_ShardedMixin, MI355XFastMultiVectorStor
 
 def create_store(provider: str, **kw: Any) -> MI355XMultiVectorStore:
     """Factory for core/services_init.py: [multivector_store] provider =
-    "mi355x" | "mi355x_fast" | "mi355x_float" | "mi355x_sharded" | "mi355x_sharded_fast" | "mi355x_sharded_float"."""
+    "mi355x" | "mi355x_fast" | "mi355x_float" | "mi355x_sharded" | "mi355x_sharded_fast" | "mi355x_sharded_float" | "mi355x_remote"."""
     if provider == "mi355x":
         return MI355XMultiVectorStore(**kw)
     if provider == "mi355x_fast":
@@ -666,4 +666,8 @@ def create_store(provider: str, **kw: Any) -> MI355XMultiVectorStore:
         return MI355XShardedFastMultiVectorStore(**kw)
     if provider == "mi355x_sharded_float":
         return MI355XShardedMultiVectorStore(mode="float", **kw)
+    if provider == "mi355x_remote":  # every process but the one that owns the HBM slab (store_server.py)
+        from .store_server import MI355XRemoteMultiVectorStore
+
+        return MI355XRemoteMultiVectorStore(**kw)
     raise ValueError(f"unknown MI355X multivector provider {provider!r}")

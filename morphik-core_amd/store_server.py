@@ -1,0 +1,213 @@
+"""One HBM slab, many processes: the store-owner server and its BaseVectorStore client.
+
+The reference constructs its multivector store in EVERY process that needs one -- the API server
+(core/services_init.py:141-165) and each ingestion worker (core/workers/ingestion_worker.py:102-142) -- which is fine
+when the store is a Postgres / TurboPuffer client, and impossible when the store IS 262 GB of HBM: a second process
+cannot allocate a second slab, and pages ingested by the worker must be visible to the API process's queries.  So one
+process owns the MI355X store (this server, one per node) and every other process uses `MI355XRemoteMultiVectorStore`,
+a BaseVectorStore whose four coroutines forward over HTTP on localhost:
+
+    POST /store_embeddings   npz {meta: json [{document_id, chunk_number, content, metadata}], app_id, emb_0..emb_{n-1}}
+    POST /query_similar      npz {meta: json {k, doc_ids, app_id, skip_image_content}, q}          -> json chunks
+    POST /get_chunks_by_id   json {chunk_identifiers, app_id, skip_image_content}                  -> json chunks
+    POST /delete_chunks_by_document_id   json {document_id, app_id}                                -> json {ok}
+    GET  /health
+
+Embeddings travel as float32 (or bf16 bit patterns as uint16) arrays inside one .npz body -- the wire format the
+reference already uses for multi-vectors (colpali_api_embedding_model.py:293-310).  Scoring still happens only in
+libmvmaxsim.so inside the owner.
+
+    python -m morphik_core_amd.store_server --provider mi355x_fast --capacity-pages 250000 --port 8766
+"""
+# (no `from __future__ import annotations` here: FastAPI resolves the handler annotations at decoration time)
+
+import argparse
+import io
+import json
+import logging
+import os
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .models import BaseVectorStore, DocumentChunk
+
+logger = logging.getLogger(__name__)
+
+
+def _chunks_json(chunks: List[DocumentChunk]) -> List[Dict[str, Any]]:
+    return [{"document_id": c.document_id, "chunk_number": int(c.chunk_number), "content": c.content, "metadata": c.metadata or {}, "score": float(c.score)}
+            for c in chunks]
+
+
+def _pack(meta: Any, arrays: Dict[str, np.ndarray]) -> bytes:
+    buf = io.BytesIO()
+    np.savez(buf, meta=np.array(json.dumps(meta)), **arrays)
+    return buf.getvalue()
+
+
+def _unpack(body: bytes) -> Tuple[Any, Any]:
+    z = np.load(io.BytesIO(body), allow_pickle=False)
+    return json.loads(str(z["meta"])), z
+
+
+def create_app(store: Any, api_key: Optional[str] = None):
+    """FastAPI app around any BaseVectorStore (normally an MI355X store that owns the GPU)."""
+    from fastapi import FastAPI, Header, HTTPException, Request
+
+    app = FastAPI(title="mi355x-multivector-store")
+
+    def auth(authorization: Optional[str]) -> None:
+        if api_key and authorization != f"Bearer {api_key}":
+            raise HTTPException(status_code=401, detail="invalid api key")
+
+    @app.get("/health")
+    async def health():
+        return {"status": "ok", "pages": len(store) if hasattr(store, "__len__") else None}
+
+    @app.post("/store_embeddings")
+    async def store_embeddings(request: Request, authorization: Optional[str] = Header(default=None)):  # noqa: B008
+        auth(authorization)
+        meta, z = _unpack(await request.body())
+        chunks = []
+        for i, m in enumerate(meta["chunks"]):
+            emb = z[f"emb_{i}"] if f"emb_{i}" in z.files else None
+            chunks.append(DocumentChunk(document_id=m["document_id"], chunk_number=int(m["chunk_number"]), content=m["content"], embedding=emb,
+                                        metadata=m.get("metadata") or {}))
+        try:
+            ok, ids, metrics = await store.store_embeddings(chunks, app_id=meta.get("app_id"))
+        except Exception as e:  # noqa: BLE001 -- the client re-raises it, as a local store would have raised
+            raise HTTPException(status_code=500, detail=f"{type(e).__name__}: {e}")
+        return {"ok": bool(ok), "ids": ids, "metrics": metrics}
+
+    @app.post("/query_similar")
+    async def query_similar(request: Request, authorization: Optional[str] = Header(default=None)):  # noqa: B008
+        auth(authorization)
+        meta, z = _unpack(await request.body())
+        try:
+            res = await store.query_similar(z["q"], int(meta["k"]), doc_ids=meta.get("doc_ids"), app_id=meta.get("app_id"),
+                                            skip_image_content=bool(meta.get("skip_image_content", False)))
+        except Exception as e:  # noqa: BLE001
+            raise HTTPException(status_code=500, detail=f"{type(e).__name__}: {e}")
+        return {"chunks": _chunks_json(res)}
+
+    @app.post("/get_chunks_by_id")
+    async def get_chunks_by_id(req: Dict[str, Any], authorization: Optional[str] = Header(default=None)):  # noqa: B008
+        auth(authorization)
+        res = await store.get_chunks_by_id([(d, int(c)) for d, c in req.get("chunk_identifiers", [])], app_id=req.get("app_id"),
+                                           skip_image_content=bool(req.get("skip_image_content", False)))
+        return {"chunks": _chunks_json(res)}
+
+    @app.post("/delete_chunks_by_document_id")
+    async def delete_chunks(req: Dict[str, Any], authorization: Optional[str] = Header(default=None)):  # noqa: B008
+        auth(authorization)
+        return {"ok": bool(await store.delete_chunks_by_document_id(req["document_id"], app_id=req.get("app_id")))}
+
+    return app
+
+
+class MI355XRemoteMultiVectorStore(BaseVectorStore):
+    """BaseVectorStore whose work is done by the store-owner process (see module docstring).  Same signatures, return shapes
+    and error conventions as the local stores: initialize() -> bool and never raises; query errors propagate."""
+
+    backend_name = "mi355x-remote"
+
+    def __init__(self, url: str = "http://127.0.0.1:8766", api_key: Optional[str] = None, timeout_s: float = 600.0, storage: Any = None,
+                 **_ignored: Any):
+        self.url = url.rstrip("/")
+        self.storage = storage
+        self._headers = {"Authorization": f"Bearer {api_key}"} if api_key else {}
+        self._timeout = timeout_s
+        self._last_store_metrics: Dict[str, Any] = {}
+
+    async def _post(self, path: str, *, content: Optional[bytes] = None, json_body: Optional[Dict[str, Any]] = None) -> Dict[str, Any]:
+        import httpx
+
+        async with httpx.AsyncClient(timeout=self._timeout) as client:
+            if content is not None:
+                r = await client.post(self.url + path, content=content, headers={**self._headers, "Content-Type": "application/octet-stream"})
+            else:
+                r = await client.post(self.url + path, json=json_body, headers=self._headers)
+        if r.status_code != 200:
+            raise RuntimeError(f"store server {path} -> {r.status_code}: {r.text[:300]}")
+        return r.json()
+
+    def initialize(self) -> bool:
+        try:
+            import httpx
+
+            r = httpx.get(self.url + "/health", headers=self._headers, timeout=10.0)
+            return r.status_code == 200
+        except Exception as e:  # noqa: BLE001
+            logger.error("Error initializing %s: %s", type(self).__name__, e)
+            return False
+
+    @staticmethod
+    def _rows(e: Any) -> np.ndarray:
+        from .store import _embedding_rows
+
+        return _embedding_rows(e)
+
+    async def store_embeddings(self, chunks: List[DocumentChunk], app_id: Optional[str] = None) -> Tuple[bool, List[str], Dict[str, Any]]:
+        meta = {"app_id": app_id, "chunks": []}
+        arrays: Dict[str, np.ndarray] = {}
+        for i, c in enumerate(chunks):
+            meta["chunks"].append({"document_id": c.document_id, "chunk_number": int(c.chunk_number), "content": c.content, "metadata": c.metadata or {}})
+            if getattr(c, "embedding", None) is not None:
+                arrays[f"emb_{i}"] = self._rows(c.embedding)
+        out = await self._post("/store_embeddings", content=_pack(meta, arrays))
+        self._last_store_metrics = out.get("metrics", {})
+        return bool(out["ok"]), list(out["ids"]), self._last_store_metrics
+
+    @staticmethod
+    def _to_chunks(rows: List[Dict[str, Any]]) -> List[DocumentChunk]:
+        return [DocumentChunk(document_id=r["document_id"], chunk_number=int(r["chunk_number"]), content=r["content"], embedding=[],
+                              metadata=r.get("metadata") or {}, score=float(r.get("score", 0.0))) for r in rows]
+
+    async def query_similar(self, query_embedding: Any, k: int, doc_ids: Optional[List[str]] = None, app_id: Optional[str] = None,
+                            skip_image_content: bool = False) -> List[DocumentChunk]:
+        meta = {"k": int(k), "doc_ids": doc_ids, "app_id": app_id, "skip_image_content": bool(skip_image_content)}
+        out = await self._post("/query_similar", content=_pack(meta, {"q": self._rows(query_embedding)}))
+        return self._to_chunks(out["chunks"])
+
+    async def get_chunks_by_id(self, chunk_identifiers: List[Tuple[str, int]], app_id: Optional[str] = None,
+                               skip_image_content: bool = False) -> List[DocumentChunk]:
+        if not chunk_identifiers:
+            return []
+        out = await self._post("/get_chunks_by_id", json_body={"chunk_identifiers": [[d, int(c)] for d, c in chunk_identifiers], "app_id": app_id,
+                                                               "skip_image_content": bool(skip_image_content)})
+        return self._to_chunks(out["chunks"])
+
+    async def delete_chunks_by_document_id(self, document_id: str, app_id: Optional[str] = None) -> bool:
+        try:
+            return bool((await self._post("/delete_chunks_by_document_id", json_body={"document_id": document_id, "app_id": app_id}))["ok"])
+        except Exception as e:  # noqa: BLE001 -- delete returns False on error (multi_vector_store.py:944-946)
+            logger.error(f"Error deleting chunks for document {document_id}: {e}")
+            return False
+
+
+def main(argv: Optional[List[str]] = None) -> None:
+    ap = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+    ap.add_argument("--host", default="127.0.0.1")
+    ap.add_argument("--port", type=int, default=8766)
+    ap.add_argument("--provider", default="mi355x_fast", help="create_store provider (mi355x | mi355x_fast | mi355x_float | mi355x_sharded ...)")
+    ap.add_argument("--capacity-pages", type=int, default=250_000)
+    ap.add_argument("--stride-rows", type=int, default=1040)
+    ap.add_argument("--devices", default="", help="comma separated GPU ordinals for the sharded providers (default: all)")
+    ap.add_argument("--load", default="", help="checkpoint directory to resume from")
+    a = ap.parse_args(argv)
+    import uvicorn
+
+    from .store import create_store
+
+    kw: Dict[str, Any] = dict(capacity_pages=a.capacity_pages, stride_rows=a.stride_rows)
+    if a.devices:
+        kw["devices"] = [int(x) for x in a.devices.split(",")]
+    store = create_store(a.provider, **kw)
+    if not store.initialize():
+        raise SystemExit("store_server: the MI355X store could not be initialised (no GPU / slab does not fit)")
+    uvicorn.run(create_app(store, os.environ.get("MORPHIK_STORE_API_KEY")), host=a.host, port=a.port, log_level="info")
+
+
+if __name__ == "__main__":
+    main()

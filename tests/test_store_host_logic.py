@@ -321,3 +321,49 @@ def test_sharded_store_equals_single_store_and_spreads_the_pages():
             b = sc.run(four.query_similar(c.embedding, k=7, doc_ids=filt))
             assert [(x.document_id, x.chunk_number, x.content) for x in a] == [(x.document_id, x.chunk_number, x.content) for x in b]
             assert [x.score for x in a] == [x.score for x in b]
+
+
+# --------------------------------------------------------------------------- one slab, many processes: owner server + remote store
+def test_remote_store_passes_the_reference_scenarios_through_the_owner_server():
+    """the ingestion worker builds its own store object (ingestion_worker.py:102-142); with the store being
+    HBM, every process but one uses MI355XRemoteMultiVectorStore, which forwards the four coroutines to the owner over HTTP.
+    The reference's store scenarios must pass through that hop unchanged."""
+    from morphik_core_amd.store_server import MI355XRemoteMultiVectorStore, create_app
+    from tests.test_encoder_and_formats import _serve
+
+    for scenario in sc.ALL:
+        owner = _store(mode="float")
+        url, stop = _serve(create_app(owner, api_key="s3"))
+        try:
+            remote = MI355XRemoteMultiVectorStore(url, api_key="s3")
+            assert remote.initialize() is True
+            sc.run(scenario(remote))
+        finally:
+            stop()
+    assert MI355XRemoteMultiVectorStore("http://127.0.0.1:9", api_key="x").initialize() is False  # nobody there: False, no raise
+
+
+def test_remote_store_two_clients_see_each_others_pages_and_errors_propagate():
+    from morphik_core_amd.store_server import MI355XRemoteMultiVectorStore, create_app
+    from tests.test_encoder_and_formats import _serve
+
+    owner = MI355XFastMultiVectorStore(capacity_pages=8, stride_rows=32, mode="float", index_factory=OracleIndex)
+    assert owner.initialize()
+    url, stop = _serve(create_app(owner))
+    try:
+        worker, api = MI355XRemoteMultiVectorStore(url), MI355XRemoteMultiVectorStore(url)
+        rng = np.random.default_rng(3)
+        chunks = sc.make_chunks(rng, n_docs=2, chunks_per_doc=3)
+        ok, ids, metrics = sc.run(worker.store_embeddings(chunks, app_id="tenant"))  # the ingestion worker's process
+        assert ok and len(ids) == 6 and metrics["vector_store_rows"] == 6
+        hit = sc.run(api.query_similar(chunks[4].embedding, k=2, app_id="tenant"))  # the API server's process
+        assert (hit[0].document_id, hit[0].chunk_number, hit[0].content, hit[0].metadata) == ("doc1", 1, chunks[4].content, chunks[4].metadata)
+        assert sc.run(api.query_similar(chunks[4].embedding, k=2, app_id="other")) == []
+        with pytest.raises(RuntimeError, match="slab full"):  # the owner's exception text reaches the caller
+            sc.run(worker.store_embeddings(sc.make_chunks(rng, n_docs=1, chunks_per_doc=4), app_id="tenant"))
+        with pytest.raises(RuntimeError, match="401"):
+            stop()
+            url2, stop = _serve(create_app(owner, api_key="k"))
+            sc.run(MI355XRemoteMultiVectorStore(url2, api_key="wrong").query_similar(chunks[0].embedding, k=1))
+    finally:
+        stop()
