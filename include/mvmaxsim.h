@@ -100,7 +100,8 @@ typedef enum {
   MV_OPT_PAD_SEMANTICS = 4,  /* 0 = max over a page's own rows only; 1 = reference rerank batch rule
                                 (pad_to = longest candidate of the batch of 128 => clamp at 0) */
   MV_OPT_BINARY_VARIANT = 5, /* sign-bit scan: 0 = popcount on the VALU, 1 = FP4 MFMA, 2/3/4 = FP4 MFMA with in-place bit operands and an
-                                8/16/4-slot ring (4 = default), 5 = persistent-stream form; all produce the same integers */
+                                8/16/4-slot ring (4 = default), 5 = persistent-stream form, 6 = four-page burst form (uniform corpora,
+                                stride % 256 == 0); all produce the same integers */
   MV_OPT_FDE_SCAN_VARIANT = 6, /* FDE coarse scan: 0 = wave per page (default), 1 = query in LDS, 2 = workgroup per page */
   MV_OPT_BATCH_VARIANT = 7,   /* batched float scan: -1 / 0 = auto (default): page-split form (wave-private rings, no barrier) up to 128
                                  query rows in the group, row-split workgroup above; both with transposed MFMA roles (one running

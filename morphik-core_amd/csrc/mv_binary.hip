@@ -84,6 +84,7 @@ __device__ __forceinline__ bool masked(const BArgs& a, int64_t page) {
 }
 
 constexpr int kQChunk = 32;  // query rows whose running minima live in registers
+constexpr int kBinaryDefaultUniform = 4;  // default variant on uniform, unmasked corpora too (the burst form, 6, measured slower)
 
 __device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
@@ -547,6 +548,158 @@ __global__ __launch_bounds__(256) void maxsim_binary_mfma2_kernel(BMArgs args) {
   }
 }
 
+// Variant 6 (round 2): the BURST form.  Every wave-per-page stream measured so far caps at ~6.9 TB/s, while the float scan's
+// four-waves-per-page interleave (one workgroup reads contiguous 16 KiB bursts) reaches 7.3: here a workgroup takes FOUR
+// consecutive pages -- 64 KiB contiguous -- and its waves interleave the 1 KiB slots of that range (wave w: slots w,
+// w + 4, ...), so each round of the workgroup is one contiguous 4 KiB read and the whole workgroup is ONE sequential
+// 64 KiB stream instead of four parallel 16 KiB streams.  A wave sees a quarter of every page's rows: four running
+// maxima per query tile (one per page; the page loop is unrolled so they stay in fixed registers), merged across the
+// waves through LDS at the end; wave p finishes page p.  Same ring, same arithmetic, same integers as variant 4.
+// Needs a uniform, unmasked corpus whose pages are whole multiples of 256 rows (every wave gets the same number of slots
+// of every page); anything else runs variant 4.
+// MEASURED (round 2, 1 M pages x 1024 rows, interleaved rounds on one box): 6.29-6.31 TB/s against 6.56-6.61 for variant 4
+// (200 k pages: 6.62-6.65 vs 6.68-6.72) -- the sequential burst does not pay for the extra barrier, the LDS merge and
+// the page loop here, where a page is only four slots per wave.  Kept as a parity-checked option, not the default.
+template <int MT, int D>
+__global__ __launch_bounds__(256) void maxsim_binary_burst_kernel(BMArgs args) {
+  const BArgs& a = args.b;
+  constexpr int SLB = kBinSlotBytes;
+  __shared__ __attribute__((aligned(16))) char lds[4 * D * SLB + 4 * 4 * MT * 16 * 4];
+  float* red = reinterpret_cast<float*>(lds + 4 * D * SLB);  // [wave][page][MT * 16 tokens]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t page0 = (int64_t)blockIdx.x * 4;
+  if (page0 >= a.n) return;
+  const int npg = (int)min((int64_t)4, a.n - page0);  // pages of this workgroup
+  const int spw = a.stride / (4 * kBinSlotRows);       // slots of ONE page owned by one wave
+  const int total = npg * spw;                         // this wave's slots
+  const char* base = reinterpret_cast<const char*>(a.bits) + (size_t)page0 * (size_t)a.stride * kSignBytes + (size_t)wave * SLB;
+  char* ring = lds + wave * (D * SLB);
+  const int src_off = lane * 16;
+  const int rd_off = r * kSignBytes + g * 4;
+
+  auto issue = [&](int it) {  // wave-local slot `it` = slot 4 * it + wave of the 64 KiB range
+    const char* tp = base + (size_t)it * (4 * SLB);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
+    const uint64_t tpu = ((uint64_t)hi << 32) | lo;
+    const uint32_t slot = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + (it % D) * SLB));
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %3 nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src_off), "s"(slot), "s"(tpu)
+        : "memory");
+  };
+
+#pragma unroll
+  for (int i = 0; i < D - 1; ++i)
+    if (i < total) issue(i);
+
+  i32x8 qb[MT];
+  float qpop[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const uint32_t w = reinterpret_cast<const uint32_t*>(a.q + m * 16 + r)[g];
+    qb[m][0] = (int)(0xCCCCCCCCu - ((w & 0x11111111u) << 3));         // +-2.0
+    qb[m][1] = (int)(0xAAAAAAAAu - (((w >> 1) & 0x11111111u) << 3));  // +-1.0
+    qb[m][2] = (int)(0x99999999u - (((w >> 2) & 0x11111111u) << 3));  // +-0.5
+    qb[m][3] = (int)(0x22222222u + (((w >> 3) & 0x11111111u) << 3));  // -+1.0 (the sign-slot class)
+#pragma unroll
+    for (int i = 4; i < 8; ++i) qb[m][i] = 0;
+    qpop[m] = a.qpop[m * 16 + r];
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(qb[m][i]));
+    asm volatile("" : "+v"(qpop[m]));
+  }
+
+  uint32_t ones = 0x11111111u;
+  asm volatile("" : "+v"(ones));
+  auto expand = [&](uint32_t w) {
+    i32x8 b;
+    b[0] = (int)(w & 0x11111111u);
+    b[1] = (int)(w & 0x22222222u);
+    b[2] = (int)(w & 0x44444444u);
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(b[3]) : "v"(w), "s"(0x88888888u), "v"(ones));
+    b[4] = 0; b[5] = 0; b[6] = 0; b[7] = 0;
+    return b;
+  };
+  auto mma = [&](const i32x8& pa, const i32x8& qbm) {
+    f32x4b acc = {0.f, 0.f, 0.f, 0.f};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(pa, qbm, acc, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  };
+
+  int it = 0;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    if (p < npg) {  // block-uniform
+      float mx[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) mx[m] = -INFINITY;
+      for (int i = 0; i < spw; ++i, ++it) {
+        if (it + D - 1 < total) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // WAR: last reads of the slot being refilled
+          issue(it + D - 1);
+          bin_wait_vmcnt<D - 1>();
+        } else {
+          const int left = total - 1 - it;
+          if (left >= 2) bin_wait_vmcnt<2>();
+          else if (left == 1) bin_wait_vmcnt<1>();
+          else bin_wait_vmcnt<0>();
+        }
+        const char* slot = ring + (it % D) * SLB + rd_off;
+        uint32_t w[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) w[tt] = *reinterpret_cast<const uint32_t*>(slot + tt * 256);
+#pragma unroll
+        for (int tp = 0; tp < 4; tp += 2) {
+          const i32x8 b0 = expand(w[tp]), b1 = expand(w[tp + 1]);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const f32x4b c0 = mma(b0, qb[m]), c1 = mma(b1, qb[m]);
+            const float t0 = fmaxf(fmaxf(c0[0], c0[1]), c0[2]);
+            const float t1 = fmaxf(fmaxf(c0[3], c1[0]), c1[1]);
+            const float t2 = fmaxf(fmaxf(c1[2], c1[3]), mx[m]);
+            mx[m] = fmaxf(fmaxf(t0, t1), t2);
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        float v = mx[m];
+        v = fmaxf(v, __shfl_xor(v, 16));
+        v = fmaxf(v, __shfl_xor(v, 32));
+        if (g == 0) red[((wave * 4 + p) * MT + m) * 16 + r] = v;
+      }
+    }
+  }
+  __syncthreads();
+  if (wave < npg) {  // wave p finishes page p
+    float ham = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float v = fmaxf(fmaxf(red[((0 * 4 + wave) * MT + m) * 16 + r], red[((1 * 4 + wave) * MT + m) * 16 + r]),
+                            fmaxf(red[((2 * 4 + wave) * MT + m) * 16 + r], red[((3 * 4 + wave) * MT + m) * 16 + r]));
+      if (qpop[m] >= 0.f) ham += qpop[m] - v;
+    }
+    ham = bin_group16_sum(ham);  // over the 16 query columns of the row (exact: small integers)
+    if (lane == 0) {
+      const int64_t item = page0 + wave;
+      const float part = (float)a.n_q - ham * (1.0f / 128.0f);
+      a.scores[item] = args.accumulate ? a.scores[item] + part : part;
+    }
+  }
+}
+
 // Variant 5: persistent waves with ONE continuous DMA stream across pages (fixed-size, unfiltered corpora only: every
 // page has S = stride/64 full slots, no metadata reads on the issue path).  Wave w takes pages w, w+W, w+2W, ...; the
 // ring keeps D-1 slots in flight across page boundaries, so the per-page prologue bubble, the query-operand reload and
@@ -724,6 +877,10 @@ static void launch_binary_mfma(const BArgs& k, int accumulate, int variant, hipS
     }
     variant = 4;
   }
+  if (variant == 6) {  // burst form (resolved by launch_maxsim_binary: uniform, unmasked, stride % 256 == 0)
+    hipLaunchKernelGGL((maxsim_binary_burst_kernel<MT, 4>), grid, block, 0, s, m);
+    return;
+  }
   switch (variant) {
     case 1: hipLaunchKernelGGL((maxsim_binary_mfma_kernel<MT, 6>), grid, block, 0, s, m); break;
     case 3: hipLaunchKernelGGL((maxsim_binary_mfma2_kernel<MT, 16>), grid, block, 0, s, m); break;
@@ -741,15 +898,17 @@ int launch_maxsim_binary(const BinaryArgs& a, int variant, hipStream_t s) {
   // the stream form needs fixed-size, unfiltered pages of whole 64-row slots; resolve the fallback HERE so that the
   // query prep below matches the kernel that runs
   if (variant == 5 && (a.n_rows || a.doc_ord || a.stride % kBinSlotRows != 0)) variant = 4;
-  if (variant < 0) variant = 4;  // measured (200k pages x 1024): 408 M pages/s (4-slot ring) > 390 (8) > 295 (16) > 345 (v1) > 48 (popcount)
+  const bool burst_ok = !a.n_rows && !a.doc_ord && !a.cand && a.stride % (4 * kBinSlotRows) == 0;
+  if (variant < 0) variant = burst_ok ? kBinaryDefaultUniform : 4;  // 4: 408 M pages/s (4-slot ring) > 390 (8) > 295 (16) > 345 (v1) > 48 (popcount)
+  if (variant == 6 && !burst_ok) variant = 4;
   if (variant == 0 || a.n_q <= 0) {
     hipLaunchKernelGGL(maxsim_binary_kernel, dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, s, k);
-  } else if (variant >= 1 && variant <= 5) {
+  } else if (variant >= 1 && variant <= 6) {
     if (!a.qpop) { set_error("binary MFMA scan needs the qpop workspace"); return MV_ERR_INVALID; }
     const int padded = ((a.n_q + 15) / 16) * 16;
     hipLaunchKernelGGL(binary_qprep_kernel, dim3((unsigned)((padded + 63) / 64)), dim3(64), 0, s,
                        reinterpret_cast<uint4*>(const_cast<uint8_t*>(a.qbits)), a.n_q, padded, a.qpop_rw,
-                       variant >= 2 && variant <= 4 ? 1 : 0);
+                       (variant >= 2 && variant <= 4) || variant == 6 ? 1 : 0);
     // query rows in passes of <= 64 (4 MFMA row tiles); later passes accumulate into scores[]
     for (int q0 = 0, pass = 0; q0 < a.n_q; q0 += 64, ++pass) {
       BArgs kp = k;

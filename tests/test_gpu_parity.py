@@ -423,7 +423,7 @@ def test_hamming_batch_matches_reference_golden(mv, golden_dir):
         hamming_batch(b"ab", [b"abc"])
 
 
-BINARY_VARIANTS = [0, 1, 2, 3, 4, 5]  # 0 = popcount on the VALU, 1..5 = FP4 MFMA forms (5 = persistent stream); identical integers required
+BINARY_VARIANTS = [0, 1, 2, 3, 4, 5, 6]  # 0 = popcount on the VALU, 1..6 = FP4 MFMA forms (5 = persistent stream, 6 = four-page burst); identical integers required
 
 
 def _set_binary_variant(ix, variant):
@@ -480,6 +480,18 @@ def test_binary_maxsim_synthetic_slab_1024(mv, variant):
         got = ix.score_all(q, mode="binary")
         assert got.astype(np.float64).tolist() == want.tolist()
     ix.close()
+    # uniform corpora of whole 256-row pages whose page count is NOT a multiple of the burst form's four pages per workgroup,
+    # queries of 1..64 rows (1..4 query tiles, the 64-row pass boundary) and beyond (two passes)
+    for stride, n in ((256, 1001), (512, 403), (1024, 1030)):
+        ix = _idx(mv, capacity_pages=n, stride_rows=stride, with_binary=True)
+        ix.fill_synthetic(77, 0, n)
+        for nq in (1, 17, 48, 64, 70):
+            q = orc.synth_rows(4321, 30 + nq, 0, nq)
+            _set_binary_variant(ix, 0)
+            want = ix.score_all(q, mode="binary")  # the popcount kernel, itself checked against the oracle above
+            _set_binary_variant(ix, variant)
+            assert np.array_equal(ix.score_all(q, mode="binary"), want), (stride, n, nq)
+        ix.close()
 
 
 def test_binary_variants_agree_with_filter_and_tombstones_midsize(mv):
