@@ -614,9 +614,12 @@ def main():
     if out is not None and world == 1:
         # measured denominators, same process, GPU still warm from the timed run (the 262 GB slab had to go first): the scan's
         # own transport with the arithmetic removed, plain nt loads, register-only MFMA chains
-        calibrate("read_ldsdma", 16 << 30, 5, device=local_rank)
-        measured_peak = max(calibrate("read_ldsdma", 16 << 30, 20, device=local_rank) for _ in range(2))
-        measured_nt = calibrate("read_nt", 16 << 30, 10, device=local_rank)
+        # (a launch must be as long as the scan's own: a 2 ms launch over 16 GiB loses ~2.5 % to ramp-up and tail)
+        free_now, _tot = torch.cuda.mem_get_info(dev)
+        cal_bytes = int(min(max(free_now - (12 << 30), 8 << 30), 160 << 30))
+        calibrate("read_ldsdma", cal_bytes, 2, device=local_rank)
+        measured_peak = calibrate("read_ldsdma", cal_bytes, 8, device=local_rank)
+        measured_nt = calibrate("read_nt", min(cal_bytes, 64 << 30), 5, device=local_rank)
         measured_mfma = calibrate("mfma_bf16", 0, 5, device=local_rank)
         log(f"[rank 0] calibration: nt LDS-DMA ring without arithmetic {measured_peak:.0f} GB/s (plain nt loads {measured_nt:.0f}); bf16 MFMA {measured_mfma:.0f} TFLOP/s")
         rf = out["roofline"]
