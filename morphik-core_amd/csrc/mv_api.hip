@@ -294,7 +294,8 @@ int fp8_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_wor
 }
 
 // FDE coarse stage: encode the query already uploaded to d_qf32 (SUM aggregation) and scan the FDE slab -> d_scores[n].
-int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_words, int64_t n, int* launches, bool stage_events) {
+int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_words, int64_t n, int* launches, bool stage_events, int32_t k_next,
+                    bool* hist0_done) {
   const bool need_meta = ix->tombstones.load() || d_allow != nullptr;
   FdeEncodeArgs e{};
   e.variant = ix->fde_query_encode_variant;
@@ -307,6 +308,9 @@ int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_wo
   s.fde = ix->fde; s.inv_norm = ix->fde_cosine ? ix->fde_inv_norm : nullptr; s.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
   s.allow = d_allow; s.n_allow_bits = n_words * 32; s.q = ix->d_qfde; s.scores = ix->d_scores; s.n = n;
   s.out_dim = ix->fde_t.out_dim;
+  const bool prebin = k_next > 0 && hist0_done && topk_uses_radix(n, k_next) && fde_scan_prebins(ix->fde_scan_variant, s.out_dim);
+  s.hist0 = prebin ? topk_radix_hist0(ix->d_topk_ws) : nullptr;  // zero between selections (cleared by the previous one's last kernel)
+  if (hist0_done) *hist0_done = prebin;
   rc = launch_fde_scan(s, ix->fde_scan_variant, ix->stream);
   if (rc) return rc;
   if (stage_events) MV_HIP(hipEventRecord(ix->ev_st[1], ix->stream));
@@ -403,7 +407,10 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
     out->pages = pages; out->bytes = rows * (int64_t)kSignBytes;
   } else {
     // FDE: encode the query (SUM), scan the FDE slab
-    rc = fde_coarse_scan(ix, n_q, d_allow, n_words, n, &out->launches, st != nullptr);
+    int64_t nc = std::min<int64_t>(std::min<int64_t>(want_coarse, n), kTopkMaxDeviceK);
+    if (nc < 1) nc = 1;
+    bool hist0_done = false;
+    rc = fde_coarse_scan(ix, n_q, d_allow, n_words, n, &out->launches, st != nullptr, mode == MV_MODE_FDE_THEN_FLOAT ? (int32_t)nc : 0, &hist0_done);
     if (rc) return rc;
     out->pages = pages; out->bytes = pages * ix->fde_t.out_dim * 2;
     if (mode == MV_MODE_FDE_ONLY) {
@@ -412,9 +419,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
       // coarse top-n -> candidate list -> exact rerank, all in stream order: the selection kernels leave the n local
       // page ids on the device, cand_prepare turns them into the rerank list + per-batch pad lengths, the rerank
       // kernel skips the (-1) padding entries.  No host round trip between the stages.
-      int64_t nc = std::min<int64_t>(std::min<int64_t>(want_coarse, n), kTopkMaxDeviceK);
-      if (nc < 1) nc = 1;
-      rc = launch_topk(ix->d_scores, n, (int32_t)nc, nullptr, 0, ix->d_topk_ws, ix->d_out_s, ix->d_out_id, ix->stream);
+      rc = launch_topk(ix->d_scores, n, (int32_t)nc, nullptr, 0, ix->d_topk_ws, ix->d_out_s, ix->d_out_id, ix->stream, hist0_done);
       if (rc) return rc;
       // reference rule: pad_sequence over each rerank batch (<= 128 pages): shorter pages see zero rows
       const int pad_sem = ix->pad_semantics < 0 ? 1 : ix->pad_semantics;

@@ -132,9 +132,10 @@ int mv_two_stage_coarse_device(mv_index* ix, const void* q, int q_dtype, int32_t
   rc = upload_allow(ix, allow_bits, n_allow_words, &d_allow);
   if (rc) return rc;
   int launches = 0;
-  rc = fde_coarse_scan(ix, n_q_rows, d_allow, n_allow_words, n, &launches);
+  bool hist0_done = false;
+  rc = fde_coarse_scan(ix, n_q_rows, d_allow, n_allow_words, n, &launches, false, n_coarse, &hist0_done);
   if (rc) return rc;
-  rc = launch_topk(ix->d_scores, n, n_coarse, nullptr, ix->cfg.id_base, ix->d_topk_ws, ix->d_out_s, ix->d_out_id, ix->stream);
+  rc = launch_topk(ix->d_scores, n, n_coarse, nullptr, ix->cfg.id_base, ix->d_topk_ws, ix->d_out_s, ix->d_out_id, ix->stream, hist0_done);
   if (rc) return rc;
   hipLaunchKernelGGL(recs_build_kernel, dim3(gb), dim3(256), 0, ix->stream, (const float*)ix->d_out_s, (const int64_t*)ix->d_out_id,
                      (int)n_coarse, ix->ragged.load() ? (const int32_t*)ix->d_n_rows : (const int32_t*)nullptr, ix->cfg.stride_rows,

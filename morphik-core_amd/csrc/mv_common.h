@@ -69,8 +69,17 @@ int launch_maxsim_batch(const BatchArgs& a, hipStream_t s);
 size_t topk_ws_bytes(int64_t n, int32_t k);
 constexpr int kTopkMaxDeviceK = 1024;
 // d_ids_map: optional int32 map from work index to local page id (candidate lists); id_base added on output.
+// hist0_done: the first radix histogram (key bits [31:21]) of THESE scores was already accumulated into
+// topk_radix_hist0(ws) by the kernel that produced them (the FDE scan does, when topk_uses_radix(n, k)).
 int launch_topk(const float* d_scores, int64_t n, int32_t k, const int32_t* d_ids_map, int64_t id_base, void* ws,
-                float* d_out_scores, int64_t* d_out_ids, hipStream_t s);
+                float* d_out_scores, int64_t* d_out_ids, hipStream_t s, bool hist0_done = false);
+bool topk_uses_radix(int64_t n, int32_t k);   // the selection of k of n takes the radix-threshold path
+uint32_t* topk_radix_hist0(void* ws);          // its first histogram (2048 bins, zero between selections)
+// order-preserving key of a score (larger score -> larger key); shared by the selection and the kernels that pre-bin
+__device__ __forceinline__ uint32_t topk_ordered_u32(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
 
 int launch_merge_topk(const float* d_scores, const int64_t* d_ids, int32_t world, int32_t kk, int32_t k, float* d_out_scores,
                       int64_t* d_out_ids, hipStream_t s);
@@ -143,9 +152,12 @@ struct FdeScanArgs {
   float* scores;            // [n]
   int64_t n;
   int64_t out_dim;
+  uint32_t* hist0;          // nullable: 2048-bin histogram of the scores' key bits [31:21], accumulated by the scan itself
+                            // (saves the selection's first pass); default variant at out_dim 10240 / 5120 only
 };
 // variant: 0 = query in registers, one wave per page, nt loads (default, -1), 1 = query in LDS, 2 = workgroup-cooperative
 int launch_fde_scan(const FdeScanArgs& a, int variant, hipStream_t s);
+bool fde_scan_prebins(int variant, int64_t out_dim);  // the form launch_fde_scan would run fills FdeScanArgs::hist0
 
 // ---------------------------------------------------------------- fp8 path (mv_fp8.hip)
 // quantise fixed-stride bf16 pages -> e4m3 codes + one power-of-two scale per page (inv_scale = 2^-e)

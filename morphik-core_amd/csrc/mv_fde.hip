@@ -462,12 +462,18 @@ struct ScanArgs {
   float* scores;
   int64_t n;
   int32_t out_dim;
+  uint32_t* hist0;  // nullable: the selection's first radix histogram, accumulated here (see FdeScanArgs)
 };
 
 // Persistent waves: each lane keeps its slice of the query FDE in registers (ITERS x 8 floats) and
 // streams pages; one page = ITERS coalesced 1 KiB wave loads.  out_dim = ITERS * 512.
 template <int ITERS>
 __global__ __launch_bounds__(256) void fde_scan_kernel(ScanArgs a) {
+  __shared__ uint32_t h0[2048];  // per-block share of the selection's first histogram (persistent blocks: zeroed / flushed once)
+  if (a.hist0) {
+    for (int i = threadIdx.x; i < 2048; i += 256) h0[i] = 0;
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -504,7 +510,19 @@ __global__ __launch_bounds__(256) void fde_scan_kernel(ScanArgs a) {
     }
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) acc += __shfl_xor(acc, s);
-    if (lane == 0) a.scores[p] = a.inv_norm ? acc * a.inv_norm[p] : acc;
+    if (lane == 0) {
+      const float sc = a.inv_norm ? acc * a.inv_norm[p] : acc;
+      a.scores[p] = sc;
+      if (a.hist0) {
+        const float s0 = sc + 0.0f;
+        if (s0 == s0 && s0 != -INFINITY) atomicAdd(&h0[topk_ordered_u32(s0) >> 21], 1u);
+      }
+    }
+  }
+  if (a.hist0) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += 256)
+      if (h0[i]) atomicAdd(&a.hist0[i], h0[i]);
   }
 }
 
@@ -821,9 +839,11 @@ static int launch_fde_scan_lds(const ScanArgs& k, hipStream_t s) {
   return MV_OK;
 }
 
+bool fde_scan_prebins(int variant, int64_t out_dim) { return variant <= 0 && (out_dim == 10240 || out_dim == 5120); }
+
 int launch_fde_scan(const FdeScanArgs& a, int variant, hipStream_t s) {
   if (a.n <= 0) return MV_OK;
-  ScanArgs k{a.fde, a.inv_norm, a.doc_ord, a.allow, a.n_allow_bits, a.q, a.scores, a.n, (int32_t)a.out_dim};
+  ScanArgs k{a.fde, a.inv_norm, a.doc_ord, a.allow, a.n_allow_bits, a.q, a.scores, a.n, (int32_t)a.out_dim, nullptr};
   const int grid = 256 * 2;  // 2 blocks/CU x 4 waves, persistent
   if (variant < 0) variant = 0;  // measured: 6.87 TB/s (wave per page, nt loads) vs 6.1 for the LDS / cooperative forms
   if (variant == 2 && a.out_dim % 2048 == 0 && a.out_dim / 2048 <= 5 && a.out_dim >= 2048) {
@@ -842,8 +862,10 @@ int launch_fde_scan(const FdeScanArgs& a, int variant, hipStream_t s) {
     int rc = launch_fde_scan_lds<10>(k, s);
     if (rc) return rc;
   } else if (a.out_dim == 10240) {
+    k.hist0 = a.hist0;
     hipLaunchKernelGGL((fde_scan_kernel<20>), dim3(grid), dim3(256), 0, s, k);
   } else if (a.out_dim == 5120) {
+    k.hist0 = a.hist0;
     hipLaunchKernelGGL((fde_scan_kernel<10>), dim3(grid), dim3(256), 0, s, k);
   } else {
     if (a.n > ((int64_t)1 << 25)) { set_error("generic FDE scan: more than 2^25 pages per launch is not supported"); return MV_ERR_INVALID; }

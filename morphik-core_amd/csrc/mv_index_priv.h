@@ -131,7 +131,10 @@ struct ScanResult {
 // Internal entry points of mv_api.hip used by mv_comm.hip.  Callers hold ix->q_mu and have the index's device current.
 int upload_query(mv_index* ix, const void* q, int q_dtype, int n_q, bool want_bf16, bool want_f32, bool want_bits, bool want_fp8);
 int upload_allow(mv_index* ix, const uint32_t* allow_bits, int64_t n_words, const uint32_t** d_allow);
-int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_words, int64_t n, int* launches, bool stage_events = false);
+// k_next > 0: a top-k_next selection of these scores follows; when it takes the radix path the scan pre-bins its first
+// histogram and *hist0_done tells the caller to pass that on to launch_topk.
+int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_words, int64_t n, int* launches, bool stage_events = false,
+                    int32_t k_next = 0, bool* hist0_done = nullptr);
 int rerank_scan(mv_index* ix, int n_q, bool use_fp8, int64_t n_items, float* d_out, int* launches);
 int64_t coarse_n_for(const mv_index* ix, int k);
 int finish_stats(mv_index* ix, mv_query_stats* st, bool had_topk);

@@ -17,10 +17,7 @@ namespace {
 constexpr int kChunk = 2048;
 constexpr int kThreads = 256;
 
-__device__ __forceinline__ uint32_t ordered_u32(float f) {
-  uint32_t u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
+__device__ __forceinline__ uint32_t ordered_u32(float f) { return topk_ordered_u32(f); }
 __device__ __forceinline__ float unordered_f32(uint32_t o) {
   uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
   return __uint_as_float(u);
@@ -239,7 +236,7 @@ constexpr int kShift0 = 21, kShift1 = 10;  // key bits [31:21] then [20:10]
 __global__ __launch_bounds__(256) void radix_hist_kernel(const float* scores, int64_t n, int pass, uint32_t k, const uint32_t* hist_prev,
                                                          uint32_t* hist, RadixCtl* ctl) {
   __shared__ uint32_t h[kRadixBins];
-  if (pass == 0 && blockIdx.x == 0 && threadIdx.x == 0) ctl->count = 0;  // dead until the compaction kernel
+  if (blockIdx.x == 0 && threadIdx.x == 0) ctl->count = 0;  // dead until the compaction kernel (both passes: pass 0 may have run inside the scan)
   for (int i = threadIdx.x; i < kRadixBins; i += 256) h[i] = 0;
   uint32_t pm = 0, pv = 0;
   if (pass == 1) {
@@ -303,7 +300,7 @@ __device__ __forceinline__ void topk_write_out(const uint64_t* sk, const TopkOut
 // deterministic, rare); the other blocks leave.
 __global__ __launch_bounds__(kThreads) void radix_rank_kernel(const float* scores, int64_t n, const uint64_t* surv, RadixCtl* ctl, uint32_t* hists,
                                                               TopkOut o) {
-  __shared__ uint64_t sk[kChunk];
+  __shared__ __attribute__((aligned(16))) uint64_t sk[kChunk];
   const uint32_t cnt = ctl->count;
   if (blockIdx.x == gridDim.x - 1)  // housekeeping for the next selection (a block past the survivor list in practice)
     for (int i = threadIdx.x; i < 2 * kRadixBins; i += kThreads) hists[i] = 0;
@@ -316,9 +313,14 @@ __global__ __launch_bounds__(kThreads) void radix_rank_kernel(const float* score
         __syncthreads();
         for (int i = threadIdx.x; i < kChunk; i += kThreads) sk[i] = base + i < cnt ? surv[base + i] : 0;
         __syncthreads();
-        const int m = (int)min((uint32_t)kChunk, cnt - base);
+        // broadcast reads, two keys per ds_read_b128 (the slots past the list hold 0, which is never larger than a key)
+        const int m2 = ((int)min((uint32_t)kChunk, cnt - base) + 1) >> 1;
+        const ulonglong2* sk2 = reinterpret_cast<const ulonglong2*>(sk);
 #pragma unroll 8
-        for (int i = 0; i < m; ++i) rank += sk[i] > mine ? 1u : 0u;  // broadcast reads
+        for (int i = 0; i < m2; ++i) {
+          const ulonglong2 o2 = sk2[i];
+          rank += (o2.x > mine ? 1u : 0u) + (o2.y > mine ? 1u : 0u);
+        }
       }
       if (me < cnt && rank < (uint32_t)o.k) {
         const uint32_t idx = ~(uint32_t)(mine & 0xffffffffu);
@@ -402,8 +404,11 @@ int launch_merge_topk(const float* d_scores, const int64_t* d_ids, int32_t world
   return MV_OK;
 }
 
+bool topk_uses_radix(int64_t n, int32_t k) { return k > 32 && n > 2 * kChunk; }
+uint32_t* topk_radix_hist0(void* ws) { return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ws) + (size_t)kRadixCap * 8); }
+
 int launch_topk(const float* d_scores, int64_t n, int32_t k, const int32_t* d_ids_map, int64_t id_base, void* ws,
-                float* d_out_scores, int64_t* d_out_ids, hipStream_t s) {
+                float* d_out_scores, int64_t* d_out_ids, hipStream_t s, bool hist0_done) {
   if (k < 1 || k > kTopkMaxDeviceK) {
     set_error("launch_topk: k=%d outside 1..%d", k, kTopkMaxDeviceK);
     return MV_ERR_INVALID;
@@ -427,14 +432,15 @@ int launch_topk(const float* d_scores, int64_t n, int32_t k, const int32_t* d_id
   const float* sc = d_scores;
   const uint64_t* in = nullptr;
   uint64_t* outk = bufA;
-  if (k > 32 && cur_n > 2 * kChunk) {
+  if (topk_uses_radix(cur_n, k)) {
     char* head = reinterpret_cast<char*>(ws);
     uint64_t* surv = reinterpret_cast<uint64_t*>(head);
     uint32_t* histA = reinterpret_cast<uint32_t*>(head + (size_t)kRadixCap * 8);
     uint32_t* histB = histA + kRadixBins;
     RadixCtl* ctl = reinterpret_cast<RadixCtl*>(histB + kRadixBins);
     const int grid = (int)std::min<int64_t>((cur_n + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)grid), dim3(256), 0, s, sc, cur_n, 0, (uint32_t)k, (const uint32_t*)nullptr, histA, ctl);
+    if (!hist0_done)
+      hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)grid), dim3(256), 0, s, sc, cur_n, 0, (uint32_t)k, (const uint32_t*)nullptr, histA, ctl);
     hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)grid), dim3(256), 0, s, sc, cur_n, 1, (uint32_t)k, (const uint32_t*)histA, histB, ctl);
     hipLaunchKernelGGL(radix_compact_kernel, dim3((unsigned)grid), dim3(256), 0, s, sc, cur_n, (uint32_t)k, (const uint32_t*)histA,
                        (const uint32_t*)histB, ctl, surv);
