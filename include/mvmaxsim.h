@@ -94,7 +94,7 @@ typedef struct mv_index mv_index;
 
 /* Tunables for mv_index_set_option. */
 typedef enum {
-  MV_OPT_MAXSIM_VARIANT = 1, /* float kernel variant id; -1 = default */
+  MV_OPT_MAXSIM_VARIANT = 1, /* float kernel variant id (14 = persistent-stream form); -1 = default */
   MV_OPT_FDE_COARSE_N = 2,   /* candidates kept by the FDE stage (reference: min(10*k, 75)) ; 0 = reference rule */
   MV_OPT_FDE_COSINE = 3,     /* 1 = rank coarse stage by cosine (TurboPuffer cosine_distance, reference), 0 = dot */
   MV_OPT_PAD_SEMANTICS = 4,  /* 0 = max over a page's own rows only; 1 = reference rerank batch rule

@@ -58,7 +58,7 @@ def test_synth_generator_bit_identical_to_oracle(mv):
 
 
 # ------------------------------------------------------------------ float MaxSim
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14])
 def test_float_maxsim_all_variants_small(mv, variant):
     from morphik_core_amd import _lib
 
@@ -75,6 +75,30 @@ def test_float_maxsim_all_variants_small(mv, variant):
         gs, gi = ix.query(q, 10)
         ws, wi = orc.topk(want, 10)
         _assert_topk_matches(gs, gi, ws, wi)
+    ix.close()
+
+
+@pytest.mark.parametrize("stride,n", [(64, 1700), (80, 1300), (1024, 1100)])
+def test_float_maxsim_persistent_stream_variant(mv, stride, n):
+    """Variant 14: persistent workgroups, one DMA stream per wave across page boundaries (more pages than workgroups;
+    80-row pages give the waves unequal tile counts).  Same scores and top-k as the default kernel and the oracle."""
+    from morphik_core_amd import _lib
+
+    ix = _idx(mv, capacity_pages=n, stride_rows=stride)
+    ix.fill_synthetic(1234, 0, n)
+    pages = ix.read_pages(0, n)
+    for nq in (32, 5, 64):
+        q = orc.synth_rows(4321, 400 + nq, 0, nq)
+        ix.set_option(_lib.MV_OPT_MAXSIM_VARIANT, -1)
+        base = ix.score_all(q)
+        ix.set_option(_lib.MV_OPT_MAXSIM_VARIANT, 14)
+        got = ix.score_all(q)
+        np.testing.assert_allclose(got, base, rtol=1e-5, atol=1e-6)  # (the default below 512-row pages is the wave-per-page form: another summation order)
+        want = orc.maxsim_bf16_slab(q, pages[:200])
+        np.testing.assert_allclose(got[:200], want, rtol=RTOL, atol=1e-6)
+        gs, gi = ix.query(q, 10)
+        ws, wi = orc.topk(got, 10)
+        assert gi.tolist() == wi.tolist()
     ix.close()
 
 
