@@ -1008,3 +1008,70 @@ def test_recall_of_lossy_paths_on_hard_negatives_and_unplanted_corpus(mv):
     print(f"unplanted corpus: fp8 {r8u:.3f} fde coarse@1000 {rcu:.3f}")
     assert r8u >= 0.6
     ix.close()
+
+
+# ------------------------------------------------------------------ advisor findings of round 1 (checkpoint validation, empty filters)
+def test_checkpoint_is_replaced_atomically_and_a_corrupt_header_is_refused(mv, tmp_path):
+    """mv_index_save writes <path>.tmp, fsyncs and renames (a crash mid-save keeps the previous checkpoint);
+    mv_index_load treats the header as untrusted input: size beyond capacity, negative size, FDE width that does not match
+    the config, row counts beyond the stride are refused loudly instead of overrunning the slabs."""
+    import struct
+
+    from morphik_core_amd import MvError
+    from morphik_core_amd._lib import ConfigC
+    from morphik_core_amd.index import MvIndex
+    import ctypes as C
+
+    ix = _idx(mv, capacity_pages=32, stride_rows=32, with_fde=True)
+    ix.fill_synthetic(1234, 0, 20)
+    path = str(tmp_path / "ix.mv")
+    ix.save(path)
+    first = open(path, "rb").read()
+    ix.fill_synthetic(1234, 20, 5)
+    ix.save(path)  # replaces the file in one rename; no temp file is left behind
+    assert not os.path.exists(path + ".tmp") and len(open(path, "rb").read()) > len(first)
+    q = orc.synth_rows(4321, 0, 0, 16)
+    want = ix.query(q, 5)
+    ix.close()
+    back = MvIndex.load(path)
+    got = back.query(q, 5)
+    assert len(back) == 25 and got[1].tolist() == want[1].tolist() and got[0].tolist() == want[0].tolist()
+    back.close()
+    good = bytearray(open(path, "rb").read())
+    off_size = 8 + C.sizeof(ConfigC)
+
+    def corrupt(mutate, name):
+        b = bytearray(good)
+        mutate(b)
+        p = str(tmp_path / name)
+        open(p, "wb").write(b)
+        with pytest.raises(MvError):
+            MvIndex.load(p)
+
+    corrupt(lambda b: b.__setitem__(slice(off_size, off_size + 8), struct.pack("<q", 33)), "size_over_capacity.mv")
+    corrupt(lambda b: b.__setitem__(slice(off_size, off_size + 8), struct.pack("<q", -1)), "negative_size.mv")
+    corrupt(lambda b: b.__setitem__(slice(off_size + 8, off_size + 16), struct.pack("<q", 12345)), "fde_width.mv")
+    corrupt(lambda b: b.__setitem__(slice(off_size + 16, off_size + 20), struct.pack("<i", 33)), "row_count_over_stride.mv")
+    corrupt(lambda b: b.__setitem__(slice(0, 8), b"NOTANIDX"), "magic.mv")
+    with pytest.raises(MvError):
+        MvIndex.load(str(tmp_path / "missing.mv"))
+
+
+def test_filter_that_names_only_deleted_documents_and_long_queries(mv):
+    """A compacted doc filter with ZERO live pages (the filter names only tombstoned documents) under a query of more than
+    128 rows (several scan passes + the score accumulation launch): no launch with an empty grid, an empty answer."""
+    from morphik_core_amd.index import allow_bitmap
+
+    ix = _idx(mv, capacity_pages=400, stride_rows=32, with_fp8=True, with_binary=True)
+    ix.fill_synthetic(1234, 0, 400, pages_per_doc=2)
+    for d in (7, 8):
+        ix.remove_doc(d)
+    allow = allow_bitmap([7, 8], 200)
+    for nq in (20, 150, 300):
+        q = orc.synth_rows(4321, 900 + nq, 0, nq)
+        for mode in ("float", "float_fp8", "binary"):
+            s, i = ix.query(q, 10, mode=mode, allow=allow)
+            assert len(i) == 0, (mode, nq)
+        s, i = ix.query(q, 10, allow=allow_bitmap([7, 9], 200))
+        assert sorted(i.tolist()) == [18, 19]
+    ix.close()
