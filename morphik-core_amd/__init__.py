@@ -6,6 +6,7 @@ Only what the hot path needs:
   index.py       MvIndex: one GPU's shard of the page corpus; ShardComm: mv_comm over R shards in one process
   shard_index.py ShardedIndex: R shards + communicator behind the one-index interface the stores use
   store.py       MI355X{,Fast,Sharded,ShardedFast}MultiVectorStore: BaseVectorStore plugins (+ request coalescing)
+  scoring.py     score_multi_vector(qs, ps): the reference's rerank call on loose multi-vectors
   payloads.py    chunk content in the caller's blob storage (keys in RAM, skip_image_content)
   store_server.py  one HBM slab, many processes: owner server + MI355XRemoteMultiVectorStore
   embedding.py   MI355XColpaliEmbeddingModel: BaseEmbeddingModel plugin (PyTorch-ROCm encoder, device-resident ingest)

@@ -1075,3 +1075,23 @@ def test_filter_that_names_only_deleted_documents_and_long_queries(mv):
         s, i = ix.query(q, 10, allow=allow_bitmap([7, 9], 200))
         assert sorted(i.tolist()) == [18, 19]
     ix.close()
+
+
+def test_score_multi_vector_function_equals_the_reference_outputs(mv, golden_dir):
+    """morphik_core_amd.scoring.score_multi_vector(qs, ps) -- the call FastMultiVectorStore makes (:553-555) -- against the
+    committed outputs of the reference formula (tests/golden/maxsim_float.npz, transformers' score_retrieval), including
+    the 133-passage case that crosses the batch-of-128 boundary, and its argument errors."""
+    from morphik_core_amd.scoring import score_multi_vector
+
+    g = np.load(os.path.join(golden_dir, "maxsim_float.npz"))
+    for ci in range(int(g["n_cases"])):
+        q, slab, n_rows, want = (g[f"{k}{ci}"] for k in ("q", "slab", "n_rows", "scores"))
+        ps = [slab[i, : n_rows[i]] for i in range(slab.shape[0])]
+        got = score_multi_vector([q, q[: max(1, q.shape[0] // 2)]], ps)
+        assert got.shape == (2, len(ps)) and got.dtype == np.float32
+        exact = np.array_equal(orc.bf16_to_f32(orc.f32_to_bf16(slab)), slab)
+        np.testing.assert_allclose(got[0], want, rtol=RTOL if exact else 5e-3, atol=1e-5 if exact else 2e-2)
+    with pytest.raises(ValueError):
+        score_multi_vector([], [np.ones((2, 128), np.float32)])
+    with pytest.raises(ValueError):
+        score_multi_vector([np.ones((2, 128), np.float32)], [])
