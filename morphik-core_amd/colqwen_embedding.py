@@ -39,6 +39,21 @@ PRESETS: Dict[str, Dict[str, Any]] = {
         text=dict(vocab_size=64, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
                   max_position_embeddings=2048),
     ),
+    # the reference's model: tsystems/colqwen2.5-3b-multilingual-v1.0 = Qwen2.5-VL-3B backbone (windowed-attention ViT) + 128-d head
+    "colqwen2.5-3b": dict(
+        backbone="qwen2_5_vl",
+        vision=dict(depth=32, hidden_size=1280, out_hidden_size=2048, intermediate_size=3420, num_heads=16, patch_size=14, spatial_merge_size=2,
+                    temporal_patch_size=2, window_size=112, fullatt_block_indexes=[7, 15, 23, 31]),
+        text=dict(vocab_size=151936, hidden_size=2048, intermediate_size=11008, num_hidden_layers=36, num_attention_heads=16, num_key_value_heads=2,
+                  max_position_embeddings=128000),
+    ),
+    "tiny-2.5": dict(
+        backbone="qwen2_5_vl",
+        vision=dict(depth=2, hidden_size=32, out_hidden_size=64, intermediate_size=64, num_heads=4, patch_size=14, spatial_merge_size=2,
+                    temporal_patch_size=2, window_size=56, fullatt_block_indexes=[1]),
+        text=dict(vocab_size=64, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                  max_position_embeddings=2048),
+    ),
 }
 
 
@@ -46,9 +61,14 @@ def build_random_colqwen2(preset: str, tokenizer_ids: Dict[str, int], device, dt
     """Random-init ColQwen2ForRetrieval of a preset architecture; the special-token ids come from the processor's tokenizer."""
     import torch
     from transformers import ColQwen2Config, ColQwen2ForRetrieval
-    from transformers.models.qwen2_vl.configuration_qwen2_vl import Qwen2VLConfig, Qwen2VLTextConfig, Qwen2VLVisionConfig
 
     p = PRESETS[preset]
+    if p.get("backbone") == "qwen2_5_vl":  # ColQwen2.5: the same retrieval head over the Qwen2.5-VL backbone
+        from transformers.models.qwen2_5_vl.configuration_qwen2_5_vl import Qwen2_5_VLConfig as Qwen2VLConfig
+        from transformers.models.qwen2_5_vl.configuration_qwen2_5_vl import Qwen2_5_VLTextConfig as Qwen2VLTextConfig
+        from transformers.models.qwen2_5_vl.configuration_qwen2_5_vl import Qwen2_5_VLVisionConfig as Qwen2VLVisionConfig
+    else:
+        from transformers.models.qwen2_vl.configuration_qwen2_vl import Qwen2VLConfig, Qwen2VLTextConfig, Qwen2VLVisionConfig
     txt = dict(p["text"])
     txt["vocab_size"] = max(txt["vocab_size"], max(tokenizer_ids.values()) + 1)
     head_dim = txt["hidden_size"] // txt["num_attention_heads"]

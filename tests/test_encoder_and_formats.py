@@ -167,7 +167,8 @@ def test_colpali_adapter_loads_a_checkpoint_directory_with_its_processor(tmp_pat
     assert t["image_count"] == 1 and t["model"] > 0
 
 
-def test_colqwen2_adapter_ragged_pages_through_the_store():
+@pytest.mark.parametrize("preset", ["tiny", "tiny-2.5"])  # Qwen2-VL backbone / Qwen2.5-VL backbone (the reference's ColQwen2.5)
+def test_colqwen2_adapter_ragged_pages_through_the_store(preset):
     """The reference's encoder family (ColQwen2.5: colpali_embedding_model.py:47-52) has DYNAMIC patch counts.  Tiny
     random-init ColQwen2ForRetrieval + offline processor: pages of different resolutions give different row counts, the
     store takes them as ragged pages, every page retrieves itself."""
@@ -182,7 +183,7 @@ def test_colqwen2_adapter_ragged_pages_through_the_store():
     from tests.fake_index import OracleIndex
 
     proc, ids = oa.colqwen2_processor()
-    emb = MI355XColQwen2EmbeddingModel(model=build_random_colqwen2("tiny", ids, "cpu", torch.bfloat16), processor=proc, device="cpu", batch_size=2)
+    emb = MI355XColQwen2EmbeddingModel(model=build_random_colqwen2(preset, ids, "cpu", torch.bfloat16), processor=proc, device="cpu", batch_size=2)
     rng = np.random.default_rng(1)
     sizes = [(60, 60), (56, 112), (112, 84), (30, 200), (84, 84)]
     chunks = [Chunk(content="", metadata={"is_image": True, "_image_bytes": oa.png_bytes(oa.page_image(rng, h, w))}) for h, w in sizes]

@@ -488,3 +488,42 @@ def test_embed_server_on_the_gpu_over_http():
         assert httpx.post(url + "/embeddings", json={"input_type": "text", "inputs": ["x"]}, timeout=60).status_code == 401
     finally:
         stop()
+
+
+def test_full_size_colqwen2_5_3b_architecture_embeds_ragged_pages_on_the_gpu():
+    """The reference's own model family at full size: ColQwen2.5-3B architecture (Qwen2.5-VL-3B backbone, 3.75 B parameters,
+    random init -- no checkpoint in this environment) embeds pages of different resolutions on the GPU; the ragged bf16
+    rows go straight into the slab and every page retrieves itself."""
+    import torch
+
+    from morphik_core_amd.colqwen_embedding import MI355XColQwen2EmbeddingModel, build_random_colqwen2
+    from morphik_core_amd.models import Chunk, DocumentChunk
+    from morphik_core_amd.store import MI355XMultiVectorStore
+    from tests import offline_assets as oa
+
+    proc, ids = oa.colqwen2_processor(min_tokens=64, max_tokens=768)
+    model = build_random_colqwen2("colqwen2.5-3b", ids, "cuda:0", torch.bfloat16)
+    assert sum(p.numel() for p in model.parameters()) > 3.0e9
+    emb = MI355XColQwen2EmbeddingModel(model=model, processor=proc, device="cuda:0", batch_size=4)
+    rng = np.random.default_rng(8)
+    sizes = [(448, 448), (560, 420), (336, 672), (784, 588), (448, 448), (280, 280), (700, 500), (644, 476)]
+    chunks = [Chunk(content="", metadata={"is_image": True, "_image_bytes": oa.png_bytes(oa.page_image(rng, h, w))}) for h, w in sizes]
+    rows, n_rows = asyncio.run(emb.embed_for_ingestion_device(chunks))
+    assert rows.is_cuda and rows.dtype == torch.bfloat16 and len(set(n_rows)) >= 4 and max(n_rows) <= 800, n_rows
+    norms = rows.float().norm(dim=1)
+    assert torch.allclose(norms, torch.ones_like(norms), atol=2e-2)
+    stride = ((max(n_rows) + 15) // 16) * 16
+    store = MI355XMultiVectorStore(capacity_pages=8, stride_rows=stride, mode="float")
+    assert store.initialize()
+    o, dcs = 0, []
+    for i, n in enumerate(n_rows):
+        dcs.append(DocumentChunk(document_id="doc", content=f"page {i}", embedding=rows[o : o + n], chunk_number=i, metadata={}))
+        o += n
+    ok, ids_, _m = asyncio.run(store.store_embeddings(dcs))
+    assert ok and len(ids_) == 8
+    o = 0
+    for i, n in enumerate(n_rows):
+        hit = asyncio.run(store.query_similar(rows[o : o + n], k=2))
+        assert hit[0].content == f"page {i}" and hit[0].score == pytest.approx(float(n), rel=2e-2)
+        o += n
+    store.close()
