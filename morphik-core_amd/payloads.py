@@ -96,13 +96,17 @@ class PayloadStore:
     def __init__(self, storage: Any, bucket: str = MULTIVECTOR_CHUNKS_BUCKET, max_concurrency: int = 16):
         self.storage = storage
         self.bucket = bucket
-        self._sem: Optional[asyncio.Semaphore] = None
+        self._sems: Dict[int, asyncio.Semaphore] = {}  # one per event loop (a semaphore is bound to the loop it first waits in)
         self._max = int(max_concurrency)
 
     def _semaphore(self) -> asyncio.Semaphore:
-        if self._sem is None:
-            self._sem = asyncio.Semaphore(self._max)
-        return self._sem
+        loop = asyncio.get_running_loop()
+        sem = self._sems.get(id(loop))
+        if sem is None:
+            if len(self._sems) > 8:  # loops come and go (asyncio.run per call in scripts and tests)
+                self._sems.clear()
+            sem = self._sems[id(loop)] = asyncio.Semaphore(self._max)
+        return sem
 
     async def put(self, content: str, document_id: str, chunk_number: int, metadata: Dict[str, Any],
                   app_id: Optional[str]) -> Tuple[Optional[str], int]:

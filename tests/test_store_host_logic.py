@@ -237,6 +237,11 @@ def test_payloads_live_in_storage_and_skip_image_content_returns_the_key():
     assert got[0].content == "app1/d/0.png"
     assert sc.run(s.get_chunks_by_id([("d", 0)]))[0].content == img
     assert sc.run(s.delete_chunks_by_document_id("d")) is True and st.objects == {}
+    # more uploads than the concurrency limit, from a SECOND event loop (asyncio.run per call): the limiter is per loop
+    many = [DocumentChunk(document_id="bulk", chunk_number=i, content=f"text {i}", embedding=sc.rand_emb(rng, 4), metadata={}) for i in range(40)]
+    ok, ids, m = sc.run(s.store_embeddings(many, app_id="app1"))
+    assert ok and m["chunk_payload_objects"] == 40 and len(st.objects) == 40
+    assert sc.run(s.delete_chunks_by_document_id("bulk")) is True and st.objects == {}
     # a failing upload keeps the content inline (the reference's database-column fallback) and the store keeps working
     st.fail_upload = True
     ok, ids, m = sc.run(s.store_embeddings([chunks[1]], app_id="app1"))
