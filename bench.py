@@ -232,6 +232,32 @@ def aux_paths(args, device, mfma_peak=None):
     res["fde_top1000_then_float"] = {"device_ms": round(float(np.median(ms)), 4), "pages_per_s": round(n / float(np.median(ms)) * 1e3, 1),
                                      "stage_ms": {k: round(float(v), 4) for k, v in zip(("encode_query", "coarse_scan", "select_top1000", "rerank_1000", "topk"), stg)},
                                      "overhead_over_coarse_scan_ms": round(float(np.median(ms)) - float(stg[1]), 4)}
+    # ---- the same pipeline for a BATCH of requests (mv_query_topk_batch): one FDE-slab pass per 32 queries
+    bq = [qs[i % N_QUERIES] for i in range(32)]
+    res["fde_batched_32_queries"] = {}
+    for cn, key in ((1000, "coarse1000_then_float"), (75, "coarse75_then_float_reference_rule")):
+        ix.set_option(L.MV_OPT_FDE_COARSE_N, cn)
+        one = []
+        for r in range(12):
+            _s, _i, st = ix.query(qs[r % N_QUERIES], K, mode="fde_then_float", want_stats=True)
+            if r >= 4:
+                one.append(st.total_device_ms)
+        dev, stg_b, out_b = [], [], None
+        for r in range(9):
+            out_b, st = ix.query_batch(bq, K, mode="fde_then_float", want_stats=True)
+            if r >= 3:
+                dev.append(st.total_device_ms)
+                stg_b.append((st.encode_ms, st.coarse_ms, st.select_ms, st.rerank_ms, st.topk_ms))
+        d, sb = float(np.median(dev)), np.median(np.array(stg_b), axis=0)
+        res["fde_batched_32_queries"][key] = {
+            "device_ms_per_batch": round(d, 4), "device_us_per_query": round(d * 1e3 / 32, 2), "queries_per_s": round(32 / d * 1e3, 1),
+            "single_query_device_us": round(float(np.median(one)) * 1e3, 2), "throughput_vs_query_by_query": round(float(np.median(one)) * 32 / d, 2),
+            "stage_ms": {k: round(float(v), 4) for k, v in zip(("encode_32_queries", "coarse_gemm_one_slab_pass", "select", "rerank", "topk"), sb)},
+            "coarse_pass_GBps": round(n * per_page["fde"] / float(sb[1]) / 1e6, 1),
+            "recall_at_10": float(np.mean([synth.recall_at_k(out_b[i][1].tolist(), planted[i % N_QUERIES]) for i in range(32)])),
+            "same_ids_as_single_query": float(np.mean([out_b[i][1].tolist() == ix.query(bq[i], K, mode="fde_then_float")[1].tolist() for i in range(0, 32, 4)])),
+        }
+    ix.set_option(L.MV_OPT_FDE_COARSE_N, 1000)
     # ---- recall@10 of the lossy paths vs the exact bf16 top-10
     easy = recall_block(ix, qs[:N_QUERIES], [planted[qi] for qi in range(N_QUERIES)], K)
     truths, hardness = [], []

@@ -112,8 +112,12 @@ typedef enum {
                                     only those (default 25; 0 = always mask inside the scan) */
   MV_OPT_FDE_QUERY_ENCODE_VARIANT = 11, /* FDE encode of the query (one page, latency matters): 2 = latency kernel, one block per
                                     repetition (default), 1 = the bulk f32-MFMA kernel, 0 = scalar kernel; same partitions bit for bit */
-  MV_OPT_LONG_QUERY_VARIANT = 10 /* single query of > 64 rows over the whole slab: 1 = row-split workgroup of the batched scan
+  MV_OPT_LONG_QUERY_VARIANT = 10, /* single query of > 64 rows over the whole slab: 1 = row-split workgroup of the batched scan
                                     (default), 0 = page-split kernel in passes of 128 rows */
+  MV_OPT_FDE_BATCH_VARIANT = 12  /* mv_query_topk_batch in the FDE modes: 0 = batched pipeline (default): up to 32 queries per pass
+                                    over the FDE slab (bf16 MFMA, query FDE as bf16 hi + lo), batched selection, every query's
+                                    candidates reranked in one launch, one read-back; 1 = query by query; 2 = as 0 with the query
+                                    FDE rounded to bf16 (one MFMA per fragment: -13 % pass time, coarse scores within ~2e-3) */
 } mv_option;
 
 MV_API const char* mv_last_error(void);
@@ -202,8 +206,11 @@ MV_API int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_
  *   allow_bits n_allow_words words shared by all queries (allow_per_query = 0) or n_queries bitmaps of n_allow_words
  *              words back to back (allow_per_query = 1: every request keeps its own doc_ids / auth filter)
  *   out_*      n_queries x k entries (row b = results of query b), out_n[b] = results of query b
- * MV_MODE_FLOAT runs the batched MFMA kernel (up to 512 query rows per slab pass: B x Q flop/byte); the other
- * modes are served query by query.  stats sum over the passes. */
+ * MV_MODE_FLOAT runs the batched MFMA kernel (up to 512 query rows per slab pass: B x Q flop/byte).
+ * MV_MODE_FDE_THEN_FLOAT / MV_MODE_FDE_ONLY run the batched FDE pipeline: one pass over the FDE slab per 32 queries
+ * (the coarse stage as a bf16-MFMA GEMM, query FDEs as bf16 hi + lo: coarse scores within ~1e-5 of the single-query
+ * scan), one batched selection, the exact rerank of every query's candidates, one read-back.  The remaining modes are
+ * served query by query.  stats sum over the passes. */
 MV_API int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, int32_t k,
                                int mode, const uint32_t* allow_bits, int64_t n_allow_words, int32_t allow_per_query,
                                float* out_scores, int64_t* out_ids, int32_t* out_n, mv_query_stats* stats);

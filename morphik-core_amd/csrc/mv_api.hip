@@ -181,8 +181,13 @@ int64_t count_allowed_rows(const mv_index* ix, int64_t n, const uint32_t* allow_
 // -> colpali_engine score_multi_vector, batch_size = 128).  One block per batch.
 __global__ __launch_bounds__(kRerankBatch) void cand_prepare_kernel(const int64_t* ids64, const int32_t* ids32, int n,
                                                                     const int32_t* n_rows, int32_t stride, int pad_sem,
-                                                                    int32_t* cand, int32_t* pads) {
+                                                                    int32_t* cand, int32_t* pads, int64_t list_stride) {
   __shared__ int32_t wmax[kRerankBatch / 64];
+  // blockIdx.y: list of a batch of queries (every list starts its own batches of 128), list_stride entries apart
+  if (ids64) ids64 += (int64_t)blockIdx.y * list_stride;
+  if (ids32) ids32 += (int64_t)blockIdx.y * list_stride;
+  cand += (int64_t)blockIdx.y * list_stride;
+  pads += (int64_t)blockIdx.y * list_stride;
   const int i = blockIdx.x * kRerankBatch + threadIdx.x;
   int32_t c = -1, rows = 0;
   if (i < n) {
@@ -204,14 +209,16 @@ __global__ __launch_bounds__(kRerankBatch) void cand_prepare_kernel(const int64_
 int launch_cand_prepare(mv_index* ix, const int64_t* d_ids64, const int32_t* d_ids32, int n, int pad_sem) {
   if (n <= 0) return MV_OK;
   hipLaunchKernelGGL(cand_prepare_kernel, dim3((unsigned)((n + kRerankBatch - 1) / kRerankBatch)), dim3(kRerankBatch), 0, ix->stream,
-                     d_ids64, d_ids32, n, (const int32_t*)ix->d_n_rows, ix->cfg.stride_rows, pad_sem, ix->d_cand, ix->d_cand_pads);
+                     d_ids64, d_ids32, n, (const int32_t*)ix->d_n_rows, ix->cfg.stride_rows, pad_sem, ix->d_cand, ix->d_cand_pads, (int64_t)0);
   MV_HIP(hipGetLastError());
   return MV_OK;
 }
 
 int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_words, const int32_t* d_cand, int64_t n_items,
-               int32_t pad_to, const int32_t* d_pad_items, float* d_out, int* launches, bool no_mask = false) {
+               int32_t pad_to, const int32_t* d_pad_items, float* d_out, int* launches, bool no_mask = false,
+               const uint16_t* d_q_base = nullptr) {
   if (n_items <= 0) return MV_OK;  // nothing to launch (a grid of 0 blocks is an invalid configuration)
+  const uint16_t* qbase = d_q_base ? d_q_base : ix->d_q;  // padded bf16 query rows (a batch keeps its queries in d_bq)
   const bool need_meta = !no_mask && (ix->tombstones.load() || d_allow != nullptr);
   const bool ragged = ix->ragged.load();
   const int padded = ((n_q + 15) / 16) * 16;
@@ -221,12 +228,12 @@ int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_w
   // page-split kernel below keeps all query rows in every wave and falls off the HBM roof past 64 rows
   // (400 k pages: 128 rows 19.2 -> 16.0 ms, 256 rows 38.3 -> 22.7 ms).
   if (!d_cand && pad_to == 0 && !d_pad_items && padded > 64 && ix->long_query_variant == 1) {
-    if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)512 * kRowBytes));
+    if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)kBatchQRows * kRowBytes));
     while (done < padded) {
       const int left = padded - done;
       const int rows = left <= 512 ? left : 384;
       MV_HIP(hipMemsetAsync(ix->d_bq, 0, (size_t)512 * kRowBytes, ix->stream));
-      MV_HIP(hipMemcpyAsync(ix->d_bq, ix->d_q + (size_t)done * kDim, (size_t)rows * kRowBytes, hipMemcpyDeviceToDevice, ix->stream));
+      MV_HIP(hipMemcpyAsync(ix->d_bq, qbase + (size_t)done * kDim, (size_t)rows * kRowBytes, hipMemcpyDeviceToDevice, ix->stream));
       BatchArgs b{};
       b.slab = ix->slab; b.n_rows = ragged ? ix->d_n_rows : nullptr; b.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
       b.allow = d_allow; b.n_allow_bits = n_allow_words * 32; b.allow_stride_bits = 0;
@@ -253,7 +260,7 @@ int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_w
     a.allow = d_allow;
     a.n_allow_bits = n_allow_words * 32;
     a.cand = d_cand;
-    a.q = ix->d_q + (size_t)done * kDim;
+    a.q = qbase + (size_t)done * kDim;
     a.scores = pass == 0 ? d_out : ix->d_scores2;
     a.n = n_items;
     a.stride = ix->cfg.stride_rows;
@@ -651,7 +658,8 @@ void mv_index_destroy(mv_index* ix) {
   if (ix->w_stream) (void)hipStreamSynchronize(ix->w_stream);
   void* ptrs[] = {ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
                   ix->d_topk_ws, ix->d_q, ix->d_qf32, ix->d_qbits, ix->d_qpop, ix->d_qfde, ix->d_qoff, ix->d_allow, ix->d_out_s,
-                  ix->d_out_id, ix->d_cand, ix->d_cand_scores};
+                  ix->d_out_id, ix->d_cand, ix->d_cand_scores, ix->d_bqf32, ix->d_bqfde, ix->d_bqimage, ix->d_btopk_ws, ix->d_bsel_s,
+                  ix->d_bsel_id, ix->d_bcand, ix->d_bcand_pads, ix->d_bcand_scores, ix->d_bout_s, ix->d_bout_id};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   fde_tables_destroy(&ix->fde_t);
@@ -660,7 +668,8 @@ void mv_index_destroy(mv_index* ix) {
   for (auto& e : ix->ev_st)
     if (e) (void)hipEventDestroy(e);
   if (ix->ev_stage) (void)hipEventDestroy(ix->ev_stage);
-  for (void* hp : {(void*)ix->h_qf32, (void*)ix->h_qbf16, (void*)ix->h_out_s, (void*)ix->h_out_id, (void*)ix->h_cand})
+  for (void* hp : {(void*)ix->h_qf32, (void*)ix->h_qbf16, (void*)ix->h_out_s, (void*)ix->h_out_id, (void*)ix->h_cand, (void*)ix->h_bout_s,
+                   (void*)ix->h_bout_id, (void*)ix->h_bcand})
     if (hp) (void)hipHostFree(hp);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
   if (ix->w_stream) (void)hipStreamDestroy(ix->w_stream);
@@ -762,6 +771,7 @@ int mv_index_set_option(mv_index* ix, int option, int64_t value) {
     case MV_OPT_FDE_ENCODE_VARIANT: ix->fde_encode_variant = (int)value; return MV_OK;
     case MV_OPT_FILTER_COMPACT_PCT: ix->filter_compact_pct = (int)value; return MV_OK;
     case MV_OPT_FDE_QUERY_ENCODE_VARIANT: ix->fde_query_encode_variant = (int)value; return MV_OK;
+    case MV_OPT_FDE_BATCH_VARIANT: ix->fde_batch_variant = (int)value; return MV_OK;
     default: set_error("unknown option %d", option); return MV_ERR_INVALID;
   }
 }
@@ -1221,6 +1231,188 @@ int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_r
                                   d_out_ids, stream, stats, 0);
 }
 
+// Workspace of the batched FDE pipeline (q_mu held).
+static int ensure_fde_batch_ws(mv_index* ix) {
+  if (ix->h_bcand) return MV_OK;
+  const int64_t out_dim = ix->fde_t.out_dim;
+  const size_t lists = (size_t)kFdeBatchMaxQueries * kTopkMaxDeviceK;
+  if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)kBatchQRows * kRowBytes));
+  if (!ix->d_bscores) {
+    hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->cfg.capacity_pages * 4);
+    if (e != hipSuccess) { ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->cfg.capacity_pages * 4); return MV_ERR_NOMEM; }
+  }
+  if (!ix->d_bqf32) MV_HIP(hipMalloc(&ix->d_bqf32, (size_t)kBatchQRows * kDim * 4));
+  if (!ix->d_bqfde) MV_HIP(hipMalloc(&ix->d_bqfde, (size_t)kFdeBatchMaxQueries * out_dim * 4));
+  if (!ix->d_bqimage) MV_HIP(hipMalloc(&ix->d_bqimage, mv::fde_scan_batch_image_bytes(out_dim)));
+  if (!ix->d_btopk_ws) {
+    hipError_t e = hipMalloc(&ix->d_btopk_ws, (size_t)kFdeBatchMaxQueries * ix->topk_ws_bytes);
+    if (e != hipSuccess) { ix->d_btopk_ws = nullptr; set_error("hipMalloc of the batched selection workspace (%zu B) failed", (size_t)kFdeBatchMaxQueries * ix->topk_ws_bytes); return MV_ERR_NOMEM; }
+    MV_HIP(hipMemset(ix->d_btopk_ws, 0, (size_t)kFdeBatchMaxQueries * ix->topk_ws_bytes));  // the radix histograms are kept zero between selections
+  }
+  if (!ix->d_bsel_s) MV_HIP(hipMalloc(&ix->d_bsel_s, lists * 4));
+  if (!ix->d_bsel_id) MV_HIP(hipMalloc(&ix->d_bsel_id, lists * 8));
+  if (!ix->d_bcand) MV_HIP(hipMalloc(&ix->d_bcand, lists * 4));
+  if (!ix->d_bcand_pads) MV_HIP(hipMalloc(&ix->d_bcand_pads, lists * 4));
+  if (!ix->d_bcand_scores) MV_HIP(hipMalloc(&ix->d_bcand_scores, lists * 4));
+  if (!ix->d_bout_s) MV_HIP(hipMalloc(&ix->d_bout_s, lists * 4));
+  if (!ix->d_bout_id) MV_HIP(hipMalloc(&ix->d_bout_id, lists * 8));
+  if (!ix->h_bout_s) MV_HIP(hipHostMalloc((void**)&ix->h_bout_s, lists * 4, hipHostMallocDefault));
+  if (!ix->h_bout_id) MV_HIP(hipHostMalloc((void**)&ix->h_bout_id, lists * 8, hipHostMallocDefault));
+  MV_HIP(hipHostMalloc((void**)&ix->h_bcand, lists * 4, hipHostMallocDefault));  // last: marks the workspace complete
+  return MV_OK;
+}
+
+// mv_query_topk_batch in the FDE modes: per group of <= 32 queries (<= 1024 query rows)
+//   encode (one launch, a block per repetition and query) -> ONE pass over the FDE slab for all of them (bf16 MFMA)
+//   -> one batched selection of the coarse top-n -> rerank lists + per-batch pad lengths -> exact MaxSim of every
+//   query's candidates against ITS query -> one batched final selection -> one read-back.
+// The per-query stages are the kernels of the single-query pipeline (same query FDE, same candidate rule, same rerank
+// arithmetic); only the coarse dot products differ, by the bf16 hi+lo split of the query FDE (~1e-5 relative).
+static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, int32_t k, int mode,
+                           const uint32_t* allow_bits, int64_t n_allow_words, int32_t allow_per_query, float* out_scores,
+                           int64_t* out_ids, int32_t* out_n, mv_query_stats* stats) {
+  std::lock_guard<std::mutex> lk(ix->q_mu);
+  DeviceGuard g(ix->cfg.device);
+  for (int32_t b = 0; b < n_queries; ++b) out_n[b] = 0;
+  mv_query_stats total{};
+  const int64_t n = ix->size.load(std::memory_order_acquire);  // snapshot of the published corpus
+  if (n == 0) { if (stats) *stats = total; return MV_OK; }
+  int rc = ensure_fde_batch_ws(ix);
+  if (rc) return rc;
+  const size_t esz = q_dtype == MV_F32 ? 4 : 2;
+  const int rpq = ((n_q_rows + 15) / 16) * 16;
+  const int group = std::min(kBatchQRows / rpq, kFdeBatchMaxQueries);
+  const bool rerank = mode == MV_MODE_FDE_THEN_FLOAT;
+  const bool per_query = allow_bits && allow_per_query;
+  const uint32_t* d_allow = nullptr;
+  rc = upload_allow(ix, allow_bits, per_query ? n_allow_words * (int64_t)n_queries : n_allow_words, &d_allow);
+  if (rc) return rc;
+  const bool need_meta = ix->tombstones.load() || d_allow != nullptr;
+  const int64_t out_dim = ix->fde_t.out_dim;
+  const int64_t cap = ix->cfg.capacity_pages;
+  int64_t nc = std::min<int64_t>(std::min<int64_t>(coarse_n_for(ix, k), n), kTopkMaxDeviceK);
+  if (nc < 1) nc = 1;
+  const int64_t L = nc;  // the per-query lists lie back to back: [query][nc]
+  // every query's candidates in ONE rerank launch (work item -> its query): the default kernels, queries of <= 128 rows
+  const int rr_variant = ix->maxsim_variant < 0 ? maxsim_default_variant(ix->cfg.stride_rows) : ix->maxsim_variant;
+  const bool rerank_one_launch = rpq <= kMaxQRowsPerPass && (rr_variant == 6 || rr_variant == 7);
+  const int pad_sem = ix->pad_semantics < 0 ? 1 : ix->pad_semantics;
+  int64_t pages = 0;
+  if (stats) (void)count_allowed_rows(ix, n, per_query ? nullptr : allow_bits, n_allow_words, &pages);
+  std::vector<float> hf((size_t)group * n_q_rows * kDim);
+  std::vector<uint16_t> hb((size_t)kBatchQRows * kDim);
+  for (int32_t b0 = 0; b0 < n_queries; b0 += group) {
+    const int nb = std::min(group, n_queries - b0);
+    std::fill(hb.begin(), hb.end(), (uint16_t)0);
+    for (int b = 0; b < nb; ++b) {
+      const char* src = (const char*)q + (size_t)(b0 + b) * n_q_rows * kDim * esz;
+      float* df = hf.data() + (size_t)b * n_q_rows * kDim;
+      uint16_t* db = hb.data() + (size_t)b * rpq * kDim;
+      const size_t ne = (size_t)n_q_rows * kDim;
+      if (q_dtype == MV_F32) {
+        memcpy(df, src, ne * 4);
+        for (size_t i = 0; i < ne; ++i) db[i] = host_f32_to_bf16(df[i]);
+      } else {
+        memcpy(db, src, ne * 2);
+        for (size_t i = 0; i < ne; ++i) df[i] = host_bf16_to_f32(db[i]);
+      }
+    }
+    MV_HIP(hipMemcpyAsync(ix->d_bqf32, hf.data(), (size_t)nb * n_q_rows * kDim * 4, hipMemcpyHostToDevice, ix->stream));
+    if (rerank) MV_HIP(hipMemcpyAsync(ix->d_bq, hb.data(), hb.size() * 2, hipMemcpyHostToDevice, ix->stream));
+    MV_HIP(hipEventRecord(ix->ev[0], ix->stream));
+    int launches = 0;
+    FdeEncodeArgs e{};
+    e.variant = 2;  // the latency kernel of the single-query path, one grid row per query
+    e.x_f32 = ix->d_bqf32; e.row_offsets = nullptr; e.stride = n_q_rows; e.n_pages = nb; e.is_query = 1; e.out_f32 = ix->d_bqfde;
+    rc = launch_fde_encode(ix->fde_t, e, ix->stream);
+    if (rc) return rc;
+    MV_HIP(hipEventRecord(ix->ev_st[0], ix->stream));
+    FdeScanBatchArgs sa{};
+    sa.fde = ix->fde; sa.inv_norm = ix->fde_cosine ? ix->fde_inv_norm : nullptr; sa.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
+    sa.allow = per_query ? d_allow + (size_t)b0 * n_allow_words : d_allow; sa.n_allow_bits = n_allow_words * 32;
+    sa.allow_stride_bits = per_query ? n_allow_words * 32 : 0;
+    sa.q = ix->d_bqfde; sa.image = ix->d_bqimage; sa.scores = ix->d_bscores; sa.score_stride = cap; sa.n = n; sa.out_dim = out_dim; sa.n_queries = nb;
+    sa.hi_only = ix->fde_batch_variant == 2;
+    rc = launch_fde_scan_batch(sa, ix->stream);
+    if (rc) return rc;
+    launches += 3;
+    MV_HIP(hipEventRecord(ix->ev_st[1], ix->stream));
+    if (rerank) {
+      rc = launch_topk_batch(ix->d_bscores, cap, n, (int32_t)nc, nullptr, 0, 0, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bsel_s, ix->d_bsel_id, L, nb, ix->stream);
+      if (rc) return rc;
+      hipLaunchKernelGGL(cand_prepare_kernel, dim3((unsigned)((nc + kRerankBatch - 1) / kRerankBatch), (unsigned)nb), dim3(kRerankBatch), 0, ix->stream,
+                         (const int64_t*)ix->d_bsel_id, (const int32_t*)nullptr, (int)nc, (const int32_t*)ix->d_n_rows, ix->cfg.stride_rows, pad_sem,
+                         ix->d_bcand, ix->d_bcand_pads, L);
+      MV_HIP(hipGetLastError());
+      MV_HIP(hipEventRecord(ix->ev_st[2], ix->stream));
+      if (rerank_one_launch) {
+        MaxsimArgs ma{};
+        ma.slab = ix->slab; ma.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr; ma.cand = ix->d_bcand; ma.q = ix->d_bq;
+        ma.scores = ix->d_bcand_scores; ma.n = (int64_t)nb * nc; ma.stride = ix->cfg.stride_rows; ma.q_tiles = rpq / 16; ma.pad_to = 0;
+        ma.pad_items = ix->d_bcand_pads; ma.items_per_query = (int32_t)nc; ma.q_item_stride = rpq * kDim;
+        rc = launch_maxsim_bf16(ma, rr_variant, ix->stream);
+        if (rc) return rc;
+        ++launches;
+      } else {
+        for (int b = 0; b < nb; ++b) {  // one launch per query (long queries, non-default kernel variants)
+          rc = float_scan(ix, n_q_rows, nullptr, 0, ix->d_bcand + (size_t)b * L, nc, 0, ix->d_bcand_pads + (size_t)b * L,
+                          ix->d_bcand_scores + (size_t)b * L, &launches, /*no_mask=*/true, ix->d_bq + (size_t)b * rpq * kDim);
+          if (rc) return rc;
+        }
+      }
+      MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
+      rc = launch_topk_batch(ix->d_bcand_scores, L, nc, k, ix->d_bcand, L, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bout_s, ix->d_bout_id, k,
+                             nb, ix->stream);
+      if (rc) return rc;
+    } else {
+      MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
+      rc = launch_topk_batch(ix->d_bscores, cap, n, k, nullptr, 0, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bout_s, ix->d_bout_id, k, nb,
+                             ix->stream);
+      if (rc) return rc;
+    }
+    MV_HIP(hipEventRecord(ix->ev[2], ix->stream));
+    MV_HIP(hipMemcpyAsync(ix->h_bout_s, ix->d_bout_s, (size_t)nb * k * 4, hipMemcpyDeviceToHost, ix->stream));
+    MV_HIP(hipMemcpyAsync(ix->h_bout_id, ix->d_bout_id, (size_t)nb * k * 8, hipMemcpyDeviceToHost, ix->stream));
+    if (stats && rerank) MV_HIP(hipMemcpyAsync(ix->h_bcand, ix->d_bcand, (size_t)nb * L * 4, hipMemcpyDeviceToHost, ix->stream));
+    MV_HIP(hipStreamSynchronize(ix->stream));
+    for (int b = 0; b < nb; ++b) {
+      const float* hs = ix->h_bout_s + (size_t)b * k;
+      const int64_t* hi = ix->h_bout_id + (size_t)b * k;
+      int32_t m = 0;
+      while (m < k && hi[m] >= 0) ++m;
+      memcpy(out_scores + (size_t)(b0 + b) * k, hs, (size_t)m * 4);
+      memcpy(out_ids + (size_t)(b0 + b) * k, hi, (size_t)m * 8);
+      out_n[b0 + b] = m;
+    }
+    if (stats) {
+      float enc = 0, coarse = 0, sel = 0, rr = 0, fin = 0, span = 0;
+      MV_HIP(hipEventElapsedTime(&enc, ix->ev[0], ix->ev_st[0]));
+      MV_HIP(hipEventElapsedTime(&coarse, ix->ev_st[0], ix->ev_st[1]));
+      if (rerank) {
+        MV_HIP(hipEventElapsedTime(&sel, ix->ev_st[1], ix->ev_st[2]));
+        MV_HIP(hipEventElapsedTime(&rr, ix->ev_st[2], ix->ev[1]));
+      }
+      MV_HIP(hipEventElapsedTime(&fin, ix->ev[1], ix->ev[2]));
+      MV_HIP(hipEventElapsedTime(&span, ix->ev[0], ix->ev[2]));
+      total.encode_ms += enc; total.coarse_ms += coarse; total.select_ms += sel; total.rerank_ms += rr;
+      total.score_kernel_ms += span - fin; total.topk_ms += fin; total.total_device_ms += span;
+      total.score_launches += launches; total.pages_scored += pages * nb;
+      total.bytes_scanned += pages * out_dim * 2;  // ONE pass over the FDE slab for the whole group
+      if (rerank) {
+        int64_t cand_rows = 0;
+        for (int b = 0; b < nb; ++b)
+          for (int64_t i = 0; i < nc; ++i) {
+            const int32_t c = ix->h_bcand[(size_t)b * L + i];
+            if (c >= 0) cand_rows += ix->h_n_rows[c];
+          }
+        total.bytes_scanned += cand_rows * (int64_t)kRowBytes;
+      }
+    }
+  }
+  if (stats) *stats = total;
+  return MV_OK;
+}
+
 int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, int32_t k, int mode,
                         const uint32_t* allow_bits, int64_t n_allow_words, int32_t allow_per_query, float* out_scores,
                         int64_t* out_ids, int32_t* out_n, mv_query_stats* stats) {
@@ -1229,6 +1421,11 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
   const size_t esz = q_dtype == MV_F32 ? 4 : 2;
   const int rpq = ((n_q_rows + 15) / 16) * 16;
   mv_query_stats total{};
+  // FDE modes: the batched pipeline (the rerank needs the bf16 slab; fp8-only indexes go query by query)
+  if ((mode == MV_MODE_FDE_THEN_FLOAT || mode == MV_MODE_FDE_ONLY) && n_queries > 1 && k >= 1 && k <= kTopkMaxDeviceK && rpq <= 512 &&
+      ix->fde_batch_variant != 1 && (ix->cfg.flags & MV_WITH_FDE) && (mode == MV_MODE_FDE_ONLY || (ix->cfg.flags & MV_WITH_FLOAT)) &&
+      mv::fde_scan_batch_supported(ix->fde_t.out_dim) && ix->fde_t.cfg.projection_dimension <= 16)
+    return fde_batch_query(ix, q, q_dtype, n_queries, n_q_rows, k, mode, allow_bits, n_allow_words, allow_per_query, out_scores, out_ids, out_n, stats);
   // anything but the exact float scan (and queries longer than one 512-row group) runs query by query
   if (mode != MV_MODE_FLOAT || rpq > 512 || k > kTopkMaxDeviceK || k == 0) {
     for (int32_t b = 0; b < n_queries; ++b) {
@@ -1253,7 +1450,7 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
   const int group_rows = ix->batch_variant == 2 ? 384 : 512;  // variant 2: 6 row tiles per wave (pipelined kernel)
   if (rpq > group_rows) { set_error("query of %d rows exceeds the %d-row group of batch variant %d", rpq, group_rows, ix->batch_variant); return MV_ERR_INVALID; }
   const int group = std::min(group_rows / rpq, 32);
-  if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)512 * kRowBytes));
+  if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)kBatchQRows * kRowBytes));
   if (!ix->d_bscores) {
     hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->cfg.capacity_pages * 4);
     if (e != hipSuccess) { ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->cfg.capacity_pages * 4); return MV_ERR_NOMEM; }

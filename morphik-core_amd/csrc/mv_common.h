@@ -39,6 +39,8 @@ struct MaxsimArgs {
   int32_t q_tiles;          // q_rows_padded / 16 (1..4)
   int32_t pad_to;           // zero-padding clamp: pages with n_rows < pad_to clamp each token max at 0
   const int32_t* pad_items; // per-item pad_to (device; the reference pads every rerank batch of 128 on its own); null -> pad_to
+  int32_t items_per_query;  // > 0: the candidate lists of a batch of queries in one launch -- item i is scored against the
+  int32_t q_item_stride;    //      query at q + (i / items_per_query) * q_item_stride (bf16 elements); default variants only
 };
 // variant: -1 default; see DESIGN.md "Kernel variants".
 int launch_maxsim_bf16(const MaxsimArgs& a, int variant, hipStream_t s);
@@ -73,6 +75,12 @@ constexpr int kTopkMaxDeviceK = 1024;
 // topk_radix_hist0(ws) by the kernel that produced them (the FDE scan does, when topk_uses_radix(n, k)).
 int launch_topk(const float* d_scores, int64_t n, int32_t k, const int32_t* d_ids_map, int64_t id_base, void* ws,
                 float* d_out_scores, int64_t* d_out_ids, hipStream_t s, bool hist0_done = false);
+// nb selections in one chain of launches (grid.y = selection): query b reads d_scores + b*score_stride, maps through
+// d_ids_map + b*map_stride (when given), uses the workspace at ws + b*ws_stride BYTES (each topk_ws_bytes(n, k), zeroed
+// once) and writes row b of the [nb][out_stride] results.
+int launch_topk_batch(const float* d_scores, int64_t score_stride, int64_t n, int32_t k, const int32_t* d_ids_map, int64_t map_stride,
+                      int64_t id_base, void* ws, size_t ws_stride, float* d_out_scores, int64_t* d_out_ids, int64_t out_stride, int nb,
+                      hipStream_t s, bool hist0_done = false);
 bool topk_uses_radix(int64_t n, int32_t k);   // the selection of k of n takes the radix-threshold path
 uint32_t* topk_radix_hist0(void* ws);          // its first histogram (2048 bins, zero between selections)
 // order-preserving key of a score (larger score -> larger key); shared by the selection and the kernels that pre-bin
@@ -158,6 +166,28 @@ struct FdeScanArgs {
 // variant: 0 = query in registers, one wave per page, nt loads (default, -1), 1 = query in LDS, 2 = workgroup-cooperative
 int launch_fde_scan(const FdeScanArgs& a, int variant, hipStream_t s);
 bool fde_scan_prebins(int variant, int64_t out_dim);  // the form launch_fde_scan would run fills FdeScanArgs::hist0
+constexpr int kFdeBatchMaxQueries = 32;
+// Up to 32 queries per pass over the FDE slab (bf16 MFMA, fp32 queries as bf16 hi + lo): scores[q][page] at
+// scores + q*score_stride.  `image` is a scratch buffer of fde_scan_batch_image_bytes(out_dim).
+struct FdeScanBatchArgs {
+  const uint16_t* fde;
+  const float* inv_norm;      // nullable -> dot
+  const int32_t* doc_ord;     // nullable -> no masks
+  const uint32_t* allow;      // nullable
+  int64_t n_allow_bits;
+  int64_t allow_stride_bits;  // 0: one bitmap for every query
+  const float* q;             // [n_queries][out_dim] fp32 query FDEs
+  uint16_t* image;
+  float* scores;
+  int64_t score_stride;
+  int64_t n;
+  int64_t out_dim;
+  int32_t n_queries;
+  int32_t hi_only;            // 1: bf16 query FDE (one MFMA per fragment, half the query traffic; coarse scores within ~2e-3)
+};
+bool fde_scan_batch_supported(int64_t out_dim);
+size_t fde_scan_batch_image_bytes(int64_t out_dim);
+int launch_fde_scan_batch(const FdeScanBatchArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- fp8 path (mv_fp8.hip)
 // quantise fixed-stride bf16 pages -> e4m3 codes + one power-of-two scale per page (inv_scale = 2^-e)

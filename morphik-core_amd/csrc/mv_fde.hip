@@ -387,7 +387,9 @@ __global__ __launch_bounds__(256) void fde_encode_query_kernel(EncMArgs m) {
   const int j = lane & 15, k = lane >> 4;
   float* xs = xs_all + wave * 16 * kXStride;
   uint8_t* sg = sg_all + wave * 256;
-  const int nr = a.stride;  // ONE page of `stride` fp32 rows at x_f32
+  const int nr = a.stride;  // ONE page of `stride` fp32 rows at x_f32 (blockIdx.y: query of a batch, packed [y][stride][128])
+  const float* x_f32 = a.x_f32 + (size_t)blockIdx.y * (size_t)nr * kDim;
+  const size_t out_base = (size_t)blockIdx.y * (size_t)a.out_dim;
 
   for (int i = threadIdx.x; i < kDim * 16; i += 256) {
     const int dim = i >> 4, h = i & 15;
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(256) void fde_encode_query_kernel(EncMArgs m) {
     for (int it = 0; it < 8; ++it) {  // stage 16 rows x 128 dims (rows >= nr are zero)
       const int idx = it * 64 + lane, row = idx >> 5, c4 = (idx & 31) * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row0 + row < nr) v = *reinterpret_cast<const float4*>(a.x_f32 + (size_t)(row0 + row) * kDim + c4);
+      if (row0 + row < nr) v = *reinterpret_cast<const float4*>(x_f32 + (size_t)(row0 + row) * kDim + c4);
       float* d = xs + row * kXStride + c4;
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
@@ -446,8 +448,8 @@ __global__ __launch_bounds__(256) void fde_encode_query_kernel(EncMArgs m) {
   const int rep_elems = NP * a.PD;
   for (int i = threadIdx.x; i < rep_elems; i += 256) {
     const float v = acc[i];
-    if (a.out_f32) a.out_f32[(size_t)rep * rep_elems + i] = v;
-    if (a.out_bf16) a.out_bf16[(size_t)rep * rep_elems + i] = f32_to_bf16_rne(v);
+    if (a.out_f32) a.out_f32[out_base + (size_t)rep * rep_elems + i] = v;
+    if (a.out_bf16) a.out_bf16[out_base + (size_t)rep * rep_elems + i] = f32_to_bf16_rne(v);
   }
 }
 
@@ -689,6 +691,288 @@ __global__ __launch_bounds__(256) void fde_scan_generic_kernel(ScanArgs a) {
   if (lane == 0) a.scores[p] = a.inv_norm ? acc * a.inv_norm[p] : acc;
 }
 
+// ------------------------------------------------------------------------------ batched coarse scan
+// Up to 32 queries per pass over the FDE slab: the scan above reads 2 * out_dim bytes per page for ONE dot product, so
+// under load the coarse stage is a GEMM  S[pages x 16] = F[pages x out_dim] . Qf^T  that is still HBM-bound (16 queries:
+// ~16 flop/byte against a ~300 flop/byte ridge) -- sixteen searches for the slab traffic of one.
+//
+// Workgroup = 4 waves, page tile = 64 pages, ring slot = 64 pages x 256 dims (512 B per page, 32 KiB), 4 slots.
+//   * transport: every wave DMAs a quarter of each slot (global_load_lds_dwordx4 nt, 2 pages x 512 B per instruction),
+//     counted s_waitcnt, one barrier per slot -- three slots (96 KiB per CU) are in flight while one is consumed;
+//   * arithmetic: v_mfma_f32_16x16x32_bf16, A = 16 pages x 32 dims from LDS (XOR-swizzled 16-byte chunks, conflict-free
+//     ds_read_b128), B = 32 dims x 16 queries.  Wave w owns dims [64w, 64w+64) of every slot for all four page tiles
+//     (K-split): its query fragments are 4 coalesced 1 KiB loads per slot from a fragment-ordered image in L2, issued
+//     three slots ahead into a static 4-set register ring, and counted with the DMAs (all VMEM of the loop is inline
+//     asm: the compiler's own vmcnt bookkeeping would drain the ring);
+//   * the fp32 query FDE enters as bf16 hi + bf16 lo (two MFMAs per fragment): 16 mantissa bits, so the coarse scores
+//     agree with the fp32-query scan above to ~1e-5 relative; the slab is bf16 either way;
+//   * tile end: the four waves' partial sums meet in LDS and are added in a fixed order (deterministic), 64 x 16
+//     scores leave as 256-byte rows.  Masks / cosine normalisation are applied by fde_batch_finish_kernel (a global
+//     load in this loop would make the compiler wait for the whole ring).
+struct ScanBatchArgs {
+  const char* fde;     // [n][out_dim] bf16
+  const char* qfrag;   // fragment-ordered hi/lo image of the queries (fde_batch_qprep_kernel)
+  float* scores;       // [n_queries][score_stride]
+  int64_t score_stride;
+  int64_t n;
+  int32_t out_dim;
+  int32_t n_queries;
+  int32_t n_tiles;     // ceil(n / 64)
+};
+
+constexpr int kFbPages = 64;
+constexpr int kFbSlotBytes = kFbPages * 512;
+constexpr int kFbSlots = 4;
+constexpr int kFbRedStride = 68;  // floats per (wave, query) row of the tile-end reduction: 64 pages + 4 (16-byte skew)
+
+// [nb][out_dim] fp32 -> image[kc][wave][e][query tile][hi|lo][lane] of 16-byte B fragments: lane (query qt*16 + (l&15),
+// group l>>4) holds dims kc*256 + (2*wave + e)*32 + 8*(l>>4) .. +8 of its query; queries >= nb are zero.
+__global__ __launch_bounds__(256) void fde_batch_qprep_kernel(const float* q, int nb, int out_dim, int nqt, uint16_t* image) {
+  const int t = blockIdx.x * 256 + threadIdx.x;  // (kc, wave, e, qt, lane)
+  const int lane = t & 63;
+  int r = t >> 6;
+  const int qt = r % nqt; r /= nqt;
+  const int e = r & 1, w = (r >> 1) & 3, kc = r >> 3;
+  if (kc * 256 >= out_dim) return;
+  const int ql = qt * 16 + (lane & 15), g = lane >> 4;
+  const int d0 = kc * 256 + (2 * w + e) * 32 + g * 8;
+  uint16_t hi[8], lo[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float x = ql < nb ? q[(size_t)ql * out_dim + d0 + i] : 0.0f;
+    hi[i] = f32_to_bf16_rne(x);
+    lo[i] = f32_to_bf16_rne(x - bf16_to_f32(hi[i]));
+  }
+  uint16_t* dst = image + ((size_t)(((kc * 4 + w) * 2 + e) * nqt + qt) * 2) * 512 + lane * 8;  // 512 bf16 = 1 KiB per fragment
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { dst[i] = hi[i]; dst[512 + i] = lo[i]; }
+}
+
+// NQT query tiles of 16 (16 or 32 queries per pass).
+template <int NQT, bool LO = true>
+__global__ __launch_bounds__(256) void fde_scan_batch_kernel(ScanBatchArgs a) {
+  using bf16x8 = __attribute__((ext_vector_type(8))) short;
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  constexpr int NF = 4 * NQT;       // query fragments per slot and wave: (e, qt, hi|lo)
+  constexpr int OPS = 8 + (LO ? NF : NF / 2);  // VMEM operations per slot and wave
+  // one __shared__ object only (a second one makes hipcc drain vmcnt before every ds_read)
+  __shared__ __attribute__((aligned(16))) char lds[kFbSlots * kFbSlotBytes + 4 * 16 * kFbRedStride * 4];
+  float* red = reinterpret_cast<float*>(lds + kFbSlots * kFbSlotBytes);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = lane & 15, g = lane >> 4;
+  const int G = gridDim.x, b = blockIdx.x;
+  const int KC = a.out_dim >> 8;
+  const int n_my = (a.n_tiles - b + G - 1) / G;  // tiles b, b + G, ...  (grid <= n_tiles)
+  const int total = n_my * KC;                   // ring slots of this workgroup; KC % 4 == 0
+  const uint32_t row_bytes = (uint32_t)a.out_dim * 2u;
+
+  // DMA source offsets: instruction i of this wave fills LDS bytes [(wave*8 + i) KiB, +1 KiB) of the slot = pages
+  // pl, pl+1 (pl = wave*16 + 2i); lane -> page pl + (lane>>5), chunk position lane&31, which receives the page's
+  // logical chunk (lane&31) ^ (page & 15).  The scalar base is 4 KiB below the tile so the offsets (which also carry
+  // -1 KiB per instruction of a group of four, see issue()) stay positive.
+  uint32_t src_off[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t pl = (uint32_t)(wave * 16 + 2 * i + (lane >> 5));
+    src_off[i] = pl * row_bytes + ((((uint32_t)lane & 31u) ^ (pl & 15u)) << 4) + 4096u - (uint32_t)(i & 3) * 1024u;
+  }
+  const uint32_t q_off = (uint32_t)lane * 16u;
+
+  bf16x8 qf[4][NF];  // [ring set][(e*NQT + qt)*2 + (0 = hi, 1 = lo)]
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) qf[u][j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+
+  int i_tile = b, i_kc = 0;  // issue-side position (advanced by issue_q: a slot's DMAs come first, its fragments second)
+  auto issue_dma = [&](int slot_idx) {
+    const int64_t page0 = (int64_t)i_tile * kFbPages;
+    const char* tp = a.fde + (size_t)page0 * row_bytes + (size_t)i_kc * 512 - 4096;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
+    const uint64_t tpu = ((uint64_t)hi << 32) | lo;
+    const uint32_t slot = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + slot_idx * kFbSlotBytes + wave * 8192));
+    uint32_t so[8];
+    if (page0 + kFbPages > a.n) {  // last tile: rows past the corpus re-read its last page (their sums are never written)
+      const uint32_t last = (uint32_t)(a.n - 1 - page0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t pl = (uint32_t)(wave * 16 + 2 * i + (lane >> 5));
+        so[i] = min(pl, last) * row_bytes + ((((uint32_t)lane & 31u) ^ (pl & 15u)) << 4) + 4096u - (uint32_t)(i & 3) * 1024u;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) so[i] = src_off[i];
+    }
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %9\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %11 nt\n\t"
+        "global_load_lds_dwordx4 %2, %11 offset:1024 nt\n\t"
+        "global_load_lds_dwordx4 %3, %11 offset:2048 nt\n\t"
+        "global_load_lds_dwordx4 %4, %11 offset:3072 nt\n\t"
+        "s_mov_b32 m0, %10\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %5, %11 nt\n\t"
+        "global_load_lds_dwordx4 %6, %11 offset:1024 nt\n\t"
+        "global_load_lds_dwordx4 %7, %11 offset:2048 nt\n\t"
+        "global_load_lds_dwordx4 %8, %11 offset:3072 nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(so[0]), "v"(so[1]), "v"(so[2]), "v"(so[3]), "v"(so[4]), "v"(so[5]), "v"(so[6]), "v"(so[7]), "s"(slot),
+          "s"(slot + 4096u), "s"(tpu)
+        : "memory");
+  };
+  auto issue_q = [&](bf16x8 (&qs)[NF]) {  // this wave's query fragments of the slot: NF KiB contiguous in the image, four per statement
+#pragma unroll
+    for (int h = 0; h < NQT; ++h) {
+      const char* qp = a.qfrag + (size_t)(i_kc * 4 + wave) * (NF * 1024) + h * 4096;
+      const uint32_t qlo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)qp);
+      const uint32_t qhi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)qp >> 32));
+      const uint64_t qpu = ((uint64_t)qhi << 32) | qlo;
+      if (LO)
+        asm volatile(
+            "s_nop 4\n\t"
+            "global_load_dwordx4 %0, %4, %5\n\t"
+            "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+            "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
+            "global_load_dwordx4 %3, %4, %5 offset:3072"
+            : "+v"(qs[4 * h + 0]), "+v"(qs[4 * h + 1]), "+v"(qs[4 * h + 2]), "+v"(qs[4 * h + 3])
+            : "v"(q_off), "s"(qpu)
+            : "memory");
+      else  // bf16 query FDE (hi term only)
+        asm volatile(
+            "s_nop 4\n\t"
+            "global_load_dwordx4 %0, %2, %3\n\t"
+            "global_load_dwordx4 %1, %2, %3 offset:2048"
+            : "+v"(qs[4 * h + 0]), "+v"(qs[4 * h + 2])
+            : "v"(q_off), "s"(qpu)
+            : "memory");
+    }
+    if (++i_kc == KC) { i_kc = 0; i_tile += G; }
+  };
+
+  // fragment read offsets inside a slot: page tile t, k-step kk = 2*wave + e -> page t*16 + p, logical chunk kk*4 + g
+  uint32_t rd_off[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) rd_off[e] = (uint32_t)p * 512u + (((uint32_t)((2 * wave + e) * 4 + g) ^ (uint32_t)p) << 4);
+
+  f32x4 acc[4][NQT];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) acc[t][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Four slots in flight.  Per slot: counted wait + barrier (the slot has landed for all waves) -> every wave pulls
+  // its fragments into registers -> barrier (the slot is drained) -> its refill is issued AT ONCE, before the MFMAs:
+  // a ring position idles for one LDS read, not for a slot's arithmetic plus the wait for the next slot's data.
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (u < total) {
+      issue_dma(u);
+      issue_q(qf[u]);
+    }
+  }
+
+  int c_tile = b, c_kc = 0;  // consume-side position
+  for (int s0 = 0; s0 < total; s0 += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = s0 + u;
+      // OPS VMEM operations per slot and wave (8 DMAs + the fragment loads), completed in issue order
+      if (s + 3 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * OPS) : "memory");
+      else if (s + 2 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
+      else if (s + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // slot s landed for all waves
+#pragma unroll
+      for (int j = 0; j < NF; ++j) asm volatile("" : "+v"(qf[u][j]));  // uses stay behind the wait
+      const char* slot = lds + u * kFbSlotBytes;
+      bf16x8 af[2][4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[e][t] = *reinterpret_cast<const bf16x8*>(slot + t * (16 * 512) + rd_off[e]);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // slot s is in registers everywhere: refill it
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(af[e][t]));  // the fragment reads stay in front of the barrier
+      if (s + 4 < total) issue_dma(u);
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int qt = 0; qt < NQT; ++qt) {
+            acc[t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[e][t], qf[u][(e * NQT + qt) * 2 + 0], acc[t][qt], 0, 0, 0);
+            if (LO) acc[t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[e][t], qf[u][(e * NQT + qt) * 2 + 1], acc[t][qt], 0, 0, 0);
+          }
+      if (s + 4 < total) {
+        // the register set is free after its last MFMA was issued; at most 63 VMEM operations may be outstanding
+        if (4 * OPS > 63) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(63 - (OPS - 8)) : "memory");
+        issue_q(qf[u]);
+      }
+      if (++c_kc == KC) {  // tile done: acc[t][qt][i] = partial dot of page t*16 + 4g + i with query qt*16 + p over this wave's dims
+        const int pg = threadIdx.x & 63;
+        const int64_t page = (int64_t)c_tile * kFbPages + pg;
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) {
+          if (qt > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone has read the previous query tile's sums
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            *reinterpret_cast<f32x4*>(red + (wave * 16 + p) * kFbRedStride + t * 16 + g * 4) = acc[t][qt];
+            acc[t][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          if (page < a.n) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int ql = (threadIdx.x >> 6) + 4 * j;
+              if (qt * 16 + ql < a.n_queries) {
+                const float v = (red[(0 * 16 + ql) * kFbRedStride + pg] + red[(1 * 16 + ql) * kFbRedStride + pg]) +
+                                (red[(2 * 16 + ql) * kFbRedStride + pg] + red[(3 * 16 + ql) * kFbRedStride + pg]);
+                a.scores[(size_t)(qt * 16 + ql) * a.score_stride + page] = v;
+              }
+            }
+          }
+        }
+        // red[] is rewritten KC slots (>= 4 barriers) later
+        c_kc = 0;
+        c_tile += G;
+      }
+    }
+  }
+}
+
+// Masks and the cosine rule of the batched scan, in place: scores[q][page] *= inv_norm[page]; -inf for tombstones and for
+// pages outside query q's doc filter (allow_stride_bits = 0: one bitmap for all queries).
+__global__ __launch_bounds__(256) void fde_batch_finish_kernel(float* scores, int64_t score_stride, int64_t n, int nq, const float* inv_norm,
+                                                               const int32_t* doc_ord, const uint32_t* allow, int64_t n_allow_bits,
+                                                               int64_t allow_stride_bits) {
+  const int64_t page = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (page >= n) return;
+  const float inv = inv_norm ? inv_norm[page] : 1.0f;
+  const int32_t o = doc_ord ? doc_ord[page] : 0;
+  for (int q = 0; q < nq; ++q) {
+    bool m = false;
+    if (doc_ord) {
+      m = o < 0;
+      if (!m && allow) {
+        const uint32_t* ab = allow + (size_t)q * (size_t)(allow_stride_bits >> 5);
+        m = (int64_t)o >= n_allow_bits || ((ab[o >> 5] >> (o & 31)) & 1u) == 0u;
+      }
+    }
+    float* sp = scores + (size_t)q * score_stride + page;
+    if (m) *sp = -INFINITY;
+    else if (inv_norm) *sp = *sp * inv;
+  }
+}
+
 struct FdeDeviceExtra {  // bucket-sorted projection tables
   int32_t* order = nullptr;
   float* sgn = nullptr;
@@ -790,9 +1074,10 @@ int launch_fde_encode(const FdeTables& t, const FdeEncodeArgs& a, hipStream_t s)
   k.scale = 1.0f / sqrtf((float)PD);
   k.out_dim = t.out_dim;
   k.out_f32 = a.out_f32; k.out_bf16 = a.out_bf16; k.out_inv_norm = a.out_inv_norm;
-  if (a.variant == 2 && a.n_pages == 1 && a.is_query && a.x_f32 && !a.row_offsets && !a.out_inv_norm && PD <= 16 && NS <= kMaxNS) {
-    EncMArgs mm{k, t.H, t.S, 1};
-    hipLaunchKernelGGL(fde_encode_query_kernel, dim3((unsigned)R), dim3(256), 0, s, mm);  // one block per repetition
+  if (a.variant == 2 && a.n_pages <= 64 && a.is_query && a.x_f32 && !a.row_offsets && !a.out_inv_norm && PD <= 16 && NS <= kMaxNS) {
+    // one block per repetition; n_pages > 1: a batch of queries of `stride` rows each, packed back to back (grid.y)
+    EncMArgs mm{k, t.H, t.S, a.n_pages};
+    hipLaunchKernelGGL(fde_encode_query_kernel, dim3((unsigned)R, (unsigned)a.n_pages), dim3(256), 0, s, mm);
     MV_HIP(hipGetLastError());
     return MV_OK;
   }
@@ -871,6 +1156,37 @@ int launch_fde_scan(const FdeScanArgs& a, int variant, hipStream_t s) {
     if (a.n > ((int64_t)1 << 25)) { set_error("generic FDE scan: more than 2^25 pages per launch is not supported"); return MV_ERR_INVALID; }
     hipLaunchKernelGGL(fde_scan_generic_kernel, dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, s, k);
   }
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
+bool fde_scan_batch_supported(int64_t out_dim) { return out_dim >= 1024 && out_dim <= 65536 && out_dim % 1024 == 0; }
+size_t fde_scan_batch_image_bytes(int64_t out_dim) { return (size_t)(out_dim / 256) * 16384 * 2; }  // two query tiles
+
+int launch_fde_scan_batch(const FdeScanBatchArgs& a, hipStream_t s) {
+  if (a.n <= 0 || a.n_queries <= 0) return MV_OK;
+  if (a.n_queries > kFdeBatchMaxQueries || !fde_scan_batch_supported(a.out_dim)) { set_error("batched FDE scan: %d queries / out_dim %lld not supported", a.n_queries, (long long)a.out_dim); return MV_ERR_INVALID; }
+  if (a.n > ((int64_t)1 << 36)) { set_error("batched FDE scan: too many pages"); return MV_ERR_INVALID; }
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0, v = 0;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  const int KC = (int)(a.out_dim / 256);
+  const int nqt = a.n_queries > 16 ? 2 : 1;
+  hipLaunchKernelGGL(fde_batch_qprep_kernel, dim3((unsigned)(KC * 2 * nqt)), dim3(256), 0, s, a.q, a.n_queries, (int)a.out_dim, nqt, a.image);
+  const int64_t n_tiles = (a.n + kFbPages - 1) / kFbPages;
+  ScanBatchArgs k{reinterpret_cast<const char*>(a.fde), reinterpret_cast<const char*>(a.image), a.scores, a.score_stride, a.n,
+                  (int32_t)a.out_dim, a.n_queries, (int32_t)n_tiles};
+  const dim3 grid((unsigned)std::min<int64_t>(n_tiles, ncu));
+  if (a.hi_only) {
+    if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch_kernel<1, false>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((fde_scan_batch_kernel<2, false>), grid, dim3(256), 0, s, k);
+  } else if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch_kernel<1>), grid, dim3(256), 0, s, k);
+  else hipLaunchKernelGGL((fde_scan_batch_kernel<2>), grid, dim3(256), 0, s, k);
+  if (a.inv_norm || a.doc_ord)
+    hipLaunchKernelGGL(fde_batch_finish_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a.scores, a.score_stride, a.n, a.n_queries,
+                       a.inv_norm, a.doc_ord, a.allow, a.n_allow_bits, a.allow_stride_bits);
   MV_HIP(hipGetLastError());
   return MV_OK;
 }

@@ -20,6 +20,7 @@
 
 constexpr int kMaxQRowsPerPass = 128;  // 8 MFMA row tiles held in VGPRs
 constexpr int kMaxCand = 65536;
+constexpr int kBatchQRows = 1024;       // bf16 query block of the batched paths (float batch: groups of 512 rows; FDE batch: 32 x 32)
 constexpr int kRerankBatch = 128;      // score_multi_vector scores passages in batches of 128, each padded on its own
 
 struct mv_index {
@@ -53,8 +54,23 @@ struct mv_index {
   uint8_t* d_q8hi = nullptr;   // e4m3 query rows, two-term split (fp8 scan)
   uint8_t* d_q8lo = nullptr;
   float* d_q8fac = nullptr;    // 2^-s per query row
-  uint16_t* d_bq = nullptr;    // [512][128] bf16 query block of the batched scan
+  uint16_t* d_bq = nullptr;    // [kBatchQRows][128] bf16 query block of the batched scans
   float* d_bscores = nullptr;  // [32][capacity] per-query score vectors of the batched scan (lazily allocated)
+  // batched FDE pipeline (mv_query_topk_batch in the FDE modes; lazily allocated, up to 32 queries per slab pass)
+  float* d_bqf32 = nullptr;        // [kBatchQRows][128] fp32 query rows of the group, packed [query][n_q_rows][128]
+  float* d_bqfde = nullptr;        // [32][out_dim] fp32 query FDEs
+  uint16_t* d_bqimage = nullptr;   // fragment-ordered bf16 hi/lo image of the query FDEs
+  void* d_btopk_ws = nullptr;      // 32 selection workspaces of topk_ws_bytes each
+  float* d_bsel_s = nullptr;       // [32][n_coarse] coarse top-n per query
+  int64_t* d_bsel_id = nullptr;
+  int32_t* d_bcand = nullptr;      // [32][n_coarse] rerank lists + per-batch pad lengths
+  int32_t* d_bcand_pads = nullptr;
+  float* d_bcand_scores = nullptr;
+  float* d_bout_s = nullptr;       // [32][k] results
+  int64_t* d_bout_id = nullptr;
+  float* h_bout_s = nullptr;       // pinned
+  int64_t* h_bout_id = nullptr;
+  int32_t* h_bcand = nullptr;      // pinned: candidate lists read back for the accounting
   int32_t* d_fcand = nullptr;  // [capacity] pages a selective doc filter lets through (lazily allocated)
   int32_t* d_fcounts = nullptr;
   int filter_compact_pct = 25; // compact when the filter allows less than this share of the documents (0 = never)
@@ -97,6 +113,8 @@ struct mv_index {
   int batch_variant = -1;      // -1 = auto: pipelined kernel up to 384 query rows, 512-row kernel above
   int long_query_variant = 1;  // 1 = single queries > 64 rows use the row-split (batched) workgroup; 0 = page-split passes
   int fde_encode_variant = 1;  // 1 = f32-MFMA kernel, 0 = scalar kernel
+  int fde_batch_variant = 0;   // mv_query_topk_batch in the FDE modes: 0 = batched pipeline (one slab pass per 32 queries), 1 = query by query,
+                               // 2 = batched with the query FDE rounded to bf16 (no lo term)
   int fde_query_encode_variant = 2;  // the ONE query page: 2 = latency kernel (one block per repetition, default), 1 = bulk f32-MFMA kernel, 0 = scalar kernel
   int64_t fde_coarse_n = 0;
   int fde_cosine = 1;

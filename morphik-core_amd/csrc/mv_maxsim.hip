@@ -53,6 +53,8 @@ struct KArgs {
   int32_t pad_to;
   int64_t page0;  // first page of this launch when there is no candidate list
   const int32_t* pad_items;  // per-item pad_to (rerank batches of 128 pad independently); null -> pad_to
+  int32_t items_per_q;       // QITEM kernels: work item i scores against the query at q + (i / items_per_q) * q_item_stride
+  int32_t q_item_stride;     // (bf16 elements) -- the candidate lists of a batch of queries in ONE launch
 };
 
 __device__ __forceinline__ bool page_masked(const KArgs& a, int64_t page) {
@@ -225,7 +227,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // STREAM_ONLY: the same ring, the same waits, no fragment reads and no MFMA -- the transport ceiling of this kernel
 // (MV_CAL_READ_LDSDMA: the roofline's measured denominator).
-template <int MT, int WPP, int D, bool NT = false, bool CONTIG = false, bool STREAM_ONLY = false>
+template <int MT, int WPP, int D, bool NT = false, bool CONTIG = false, bool STREAM_ONLY = false, bool QITEM = false>
 __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
   // one __shared__ object only (a second one makes hipcc drain vmcnt before every ds_read)
   __shared__ __attribute__((aligned(16))) char lds[4 * D * kTileBytes + 2048];
@@ -320,7 +322,9 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
   // inside the loop, where its counted vmcnt(7..0) ladder drains our DMA ring on every iteration.
   bf16x8 qa[MT][4];
   if (!STREAM_ONLY) {
-    load_query<MT>(a.q, r, g, qa);
+    const uint16_t* qp = a.q;
+    if (QITEM) qp += (size_t)(item / a.items_per_q) * (size_t)a.q_item_stride;  // this item's query (batched rerank)
+    load_query<MT>(qp, r, g, qa);
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -480,6 +484,12 @@ int launch_mt(const KArgs& k0, int variant, hipStream_t s) {
     else k.page0 = k0.page0 + off;
     if (k0.pad_items) k.pad_items = k0.pad_items + off;
     const int64_t n = k.n;
+    if (k.items_per_q > 0) {  // per-item queries: the two default forms only, one launch
+      if (k0.n > kChunk || (variant != 6 && variant != 7)) { set_error("per-item queries: variant %d / %lld items not supported", variant, (long long)k0.n); return MV_ERR_INVALID; }
+      if (variant == 6) hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true, false, false, true>), dim3((unsigned)n), block, 0, s, k);
+      else hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 1, 4, true, false, false, true>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k);
+      continue;
+    }
     switch (variant) {
       case 0: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 1, false>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
       case 1: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 4, false>), dim3((unsigned)n), block, 0, s, k); break;
@@ -555,7 +565,8 @@ int launch_maxsim_bf16(const MaxsimArgs& a, int variant, hipStream_t s) {
     return MV_ERR_INVALID;
   }
   KArgs k{reinterpret_cast<const char*>(a.slab), a.n_rows, a.doc_ord, a.allow, a.n_allow_bits, a.cand, a.q, a.scores,
-          a.n, a.stride, a.pad_to, 0, a.pad_items};
+          a.n, a.stride, a.pad_to, 0, a.pad_items, a.items_per_query, a.q_item_stride};
+  if (a.items_per_query < 0 || (a.items_per_query > 0 && !a.cand)) { set_error("items_per_query needs a candidate list"); return MV_ERR_INVALID; }
   switch (a.q_tiles) {
     case 1: return launch_mt<1>(k, variant, s);
     case 2: return launch_mt<2>(k, variant, s);

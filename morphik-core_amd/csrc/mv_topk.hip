@@ -47,6 +47,24 @@ struct TopkOut {  // only read by the final (single-block) level: decode fused i
   int32_t k;
 };
 
+// Batched selection: blockIdx.y = query.  Every query has its own score vector, ids map, result row and workspace at a
+// fixed stride from query 0's (all strides zero / unused for a single selection, grid.y = 1).
+struct TopkBatch {
+  int64_t score_stride;  // floats
+  int64_t map_stride;    // int32 entries
+  int64_t out_stride;    // result entries
+  int64_t ws_stride;     // BYTES
+};
+template <typename T>
+__device__ __forceinline__ T* tb_ws(T* p, const TopkBatch& tb) {
+  return p ? reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + (uintptr_t)((int64_t)blockIdx.y * tb.ws_stride)) : p;
+}
+__device__ __forceinline__ void tb_out(TopkOut& o, const TopkBatch& tb) {
+  if (o.ids_map) o.ids_map += (int64_t)blockIdx.y * tb.map_stride;
+  o.out_s += (int64_t)blockIdx.y * tb.out_stride;
+  o.out_id += (int64_t)blockIdx.y * tb.out_stride;
+}
+
 // One level of the selection.  A block owns `sub` consecutive chunks of 2048 keys: each is bitonic-sorted in LDS and
 // its best kk survive into a second LDS array, which is sorted once more when sub > 1 (sub * kk <= 2048).  Fewer,
 // fatter blocks mean fewer LEVELS -- the selection is launch-latency bound (~20 us per dependent launch), not
@@ -54,9 +72,13 @@ struct TopkOut {  // only read by the final (single-block) level: decode fused i
 // 1 M pages, k = 10: 2 launches (was 4).
 // keys_in == nullptr: build keys from scores[base .. base+n).  Invalid (-inf / NaN / out of range) -> 0.
 __global__ __launch_bounds__(kThreads) void topk_level_kernel(const float* scores, const uint64_t* keys_in, int64_t n,
-                                                              int kk, uint64_t* keys_out, int sub, int final, TopkOut o) {
+                                                              int kk, uint64_t* keys_out, int sub, int final, TopkOut o, TopkBatch tb) {
   __shared__ uint64_t sk[kChunk];
   __shared__ uint64_t best[kChunk];
+  if (scores) scores += (int64_t)blockIdx.y * tb.score_stride;
+  keys_in = tb_ws(keys_in, tb);
+  keys_out = tb_ws(keys_out, tb);
+  tb_out(o, tb);
   int nbest = 0;
   for (int sc = 0; sc < sub; ++sc) {
     const int64_t base = ((int64_t)blockIdx.x * sub + sc) * kChunk;
@@ -118,9 +140,13 @@ __device__ __forceinline__ uint64_t umax64(uint64_t a, uint64_t b) { return a > 
 
 template <int SUB>
 __global__ __launch_bounds__(kThreads) void topk_extract_kernel(const float* scores, const uint64_t* keys_in, int64_t n, int kk,
-                                                                uint64_t* keys_out, int final, TopkOut o) {
+                                                                uint64_t* keys_out, int final, TopkOut o, TopkBatch tb) {
   __shared__ uint64_t rowmax[2][16];
   __shared__ uint64_t winners[32];
+  if (scores) scores += (int64_t)blockIdx.y * tb.score_stride;
+  keys_in = tb_ws(keys_in, tb);
+  keys_out = tb_ws(keys_out, tb);
+  tb_out(o, tb);
   constexpr int NK = 8 * SUB;
   uint64_t key[NK];
   const int64_t base = (int64_t)blockIdx.x * SUB * kChunk;
@@ -234,8 +260,12 @@ __device__ __forceinline__ void radix_pick(const uint32_t* hist, uint32_t kr, ui
 constexpr int kShift0 = 21, kShift1 = 10;  // key bits [31:21] then [20:10]
 
 __global__ __launch_bounds__(256) void radix_hist_kernel(const float* scores, int64_t n, int pass, uint32_t k, const uint32_t* hist_prev,
-                                                         uint32_t* hist, RadixCtl* ctl) {
+                                                         uint32_t* hist, RadixCtl* ctl, TopkBatch tb) {
   __shared__ uint32_t h[kRadixBins];
+  scores += (int64_t)blockIdx.y * tb.score_stride;
+  hist_prev = tb_ws(hist_prev, tb);
+  hist = tb_ws(hist, tb);
+  ctl = tb_ws(ctl, tb);
   if (blockIdx.x == 0 && threadIdx.x == 0) ctl->count = 0;  // dead until the compaction kernel (both passes: pass 0 may have run inside the scan)
   for (int i = threadIdx.x; i < kRadixBins; i += 256) h[i] = 0;
   uint32_t pm = 0, pv = 0;
@@ -260,7 +290,12 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const float* scores, in
 }
 
 __global__ __launch_bounds__(256) void radix_compact_kernel(const float* scores, int64_t n, uint32_t k, const uint32_t* histA, const uint32_t* histB,
-                                                            RadixCtl* ctl, uint64_t* out) {
+                                                            RadixCtl* ctl, uint64_t* out, TopkBatch tb) {
+  scores += (int64_t)blockIdx.y * tb.score_stride;
+  histA = tb_ws(histA, tb);
+  histB = tb_ws(histB, tb);
+  ctl = tb_ws(ctl, tb);
+  out = tb_ws(out, tb);
   uint32_t* count = &ctl->count;
   uint32_t bin0, above0, bin1, above1;
   radix_pick(histA, k, &bin0, &above0);
@@ -299,8 +334,13 @@ __device__ __forceinline__ void topk_write_out(const uint64_t* sk, const TopkOut
 // best kk (<= 1024) keys in the lower half of a 2048-key LDS array and sorting 1024 new keys against them per step (slow,
 // deterministic, rare); the other blocks leave.
 __global__ __launch_bounds__(kThreads) void radix_rank_kernel(const float* scores, int64_t n, const uint64_t* surv, RadixCtl* ctl, uint32_t* hists,
-                                                              TopkOut o) {
+                                                              TopkOut o, TopkBatch tb) {
   __shared__ __attribute__((aligned(16))) uint64_t sk[kChunk];
+  scores += (int64_t)blockIdx.y * tb.score_stride;
+  surv = tb_ws(surv, tb);
+  ctl = tb_ws(ctl, tb);
+  hists = tb_ws(hists, tb);
+  tb_out(o, tb);
   const uint32_t cnt = ctl->count;
   if (blockIdx.x == gridDim.x - 1)  // housekeeping for the next selection (a block past the survivor list in practice)
     for (int i = threadIdx.x; i < 2 * kRadixBins; i += kThreads) hists[i] = 0;
@@ -407,8 +447,9 @@ int launch_merge_topk(const float* d_scores, const int64_t* d_ids, int32_t world
 bool topk_uses_radix(int64_t n, int32_t k) { return k > 32 && n > 2 * kChunk; }
 uint32_t* topk_radix_hist0(void* ws) { return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ws) + (size_t)kRadixCap * 8); }
 
-int launch_topk(const float* d_scores, int64_t n, int32_t k, const int32_t* d_ids_map, int64_t id_base, void* ws,
-                float* d_out_scores, int64_t* d_out_ids, hipStream_t s, bool hist0_done) {
+int launch_topk_batch(const float* d_scores, int64_t score_stride, int64_t n, int32_t k, const int32_t* d_ids_map, int64_t map_stride,
+                      int64_t id_base, void* ws, size_t ws_stride, float* d_out_scores, int64_t* d_out_ids, int64_t out_stride, int nb,
+                      hipStream_t s, bool hist0_done) {
   if (k < 1 || k > kTopkMaxDeviceK) {
     set_error("launch_topk: k=%d outside 1..%d", k, kTopkMaxDeviceK);
     return MV_ERR_INVALID;
@@ -417,6 +458,9 @@ int launch_topk(const float* d_scores, int64_t n, int32_t k, const int32_t* d_id
     set_error("launch_topk: n too large");
     return MV_ERR_INVALID;
   }
+  if (nb < 1 || nb > 65535) { set_error("launch_topk: batch of %d selections", nb); return MV_ERR_INVALID; }
+  const TopkBatch tb{score_stride, map_stride, out_stride, (int64_t)ws_stride};
+  const unsigned gy = (unsigned)nb;
   uint64_t* bufA = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(ws) + kRadixTailBytes);  // behind the radix head
   const int64_t l1 = nblocks(n > 0 ? n : 1) * (int64_t)k;
   uint64_t* bufB = bufA + (l1 + kChunk);
@@ -438,13 +482,13 @@ int launch_topk(const float* d_scores, int64_t n, int32_t k, const int32_t* d_id
     uint32_t* histA = reinterpret_cast<uint32_t*>(head + (size_t)kRadixCap * 8);
     uint32_t* histB = histA + kRadixBins;
     RadixCtl* ctl = reinterpret_cast<RadixCtl*>(histB + kRadixBins);
-    const int grid = (int)std::min<int64_t>((cur_n + 255) / 256, 256 * 8);
+    const int grid = (int)std::min<int64_t>((cur_n + 255) / 256, nb > 1 ? 256 * 2 : 256 * 8);
     if (!hist0_done)
-      hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)grid), dim3(256), 0, s, sc, cur_n, 0, (uint32_t)k, (const uint32_t*)nullptr, histA, ctl);
-    hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)grid), dim3(256), 0, s, sc, cur_n, 1, (uint32_t)k, (const uint32_t*)histA, histB, ctl);
-    hipLaunchKernelGGL(radix_compact_kernel, dim3((unsigned)grid), dim3(256), 0, s, sc, cur_n, (uint32_t)k, (const uint32_t*)histA,
-                       (const uint32_t*)histB, ctl, surv);
-    hipLaunchKernelGGL(radix_rank_kernel, dim3((unsigned)(kRadixCap / kThreads)), dim3(kThreads), 0, s, sc, cur_n, (const uint64_t*)surv, ctl, histA, out);
+      hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)grid, gy), dim3(256), 0, s, sc, cur_n, 0, (uint32_t)k, (const uint32_t*)nullptr, histA, ctl, tb);
+    hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)grid, gy), dim3(256), 0, s, sc, cur_n, 1, (uint32_t)k, (const uint32_t*)histA, histB, ctl, tb);
+    hipLaunchKernelGGL(radix_compact_kernel, dim3((unsigned)grid, gy), dim3(256), 0, s, sc, cur_n, (uint32_t)k, (const uint32_t*)histA,
+                       (const uint32_t*)histB, ctl, surv, tb);
+    hipLaunchKernelGGL(radix_rank_kernel, dim3((unsigned)(kRadixCap / kThreads), gy), dim3(kThreads), 0, s, sc, cur_n, (const uint64_t*)surv, ctl, histA, out, tb);
     MV_HIP(hipGetLastError());
     return MV_OK;
   }
@@ -453,15 +497,16 @@ int launch_topk(const float* d_scores, int64_t n, int32_t k, const int32_t* d_id
     const int64_t per_block = (int64_t)kChunk * sub;
     const int64_t blocks = std::max<int64_t>(1, (cur_n + per_block - 1) / per_block);
     const int final = blocks == 1;
+    const dim3 gr((unsigned)blocks, gy);
     if (k <= 32) {
       switch (sub) {
-        case 1: hipLaunchKernelGGL((topk_extract_kernel<1>), dim3((unsigned)blocks), dim3(kThreads), 0, s, sc, in, cur_n, (int)k, outk, final, out); break;
-        case 2: hipLaunchKernelGGL((topk_extract_kernel<2>), dim3((unsigned)blocks), dim3(kThreads), 0, s, sc, in, cur_n, (int)k, outk, final, out); break;
-        case 3: case 4: hipLaunchKernelGGL((topk_extract_kernel<4>), dim3((unsigned)blocks), dim3(kThreads), 0, s, sc, in, cur_n, (int)k, outk, final, out); break;
-        default: hipLaunchKernelGGL((topk_extract_kernel<8>), dim3((unsigned)blocks), dim3(kThreads), 0, s, sc, in, cur_n, (int)k, outk, final, out); break;
+        case 1: hipLaunchKernelGGL((topk_extract_kernel<1>), gr, dim3(kThreads), 0, s, sc, in, cur_n, (int)k, outk, final, out, tb); break;
+        case 2: hipLaunchKernelGGL((topk_extract_kernel<2>), gr, dim3(kThreads), 0, s, sc, in, cur_n, (int)k, outk, final, out, tb); break;
+        case 3: case 4: hipLaunchKernelGGL((topk_extract_kernel<4>), gr, dim3(kThreads), 0, s, sc, in, cur_n, (int)k, outk, final, out, tb); break;
+        default: hipLaunchKernelGGL((topk_extract_kernel<8>), gr, dim3(kThreads), 0, s, sc, in, cur_n, (int)k, outk, final, out, tb); break;
       }
     } else {
-      hipLaunchKernelGGL(topk_level_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, s, sc, in, cur_n, (int)k, outk, sub, final, out);
+      hipLaunchKernelGGL(topk_level_kernel, gr, dim3(kThreads), 0, s, sc, in, cur_n, (int)k, outk, sub, final, out, tb);
     }
     if (final) break;
     cur_n = blocks * k;
@@ -471,6 +516,11 @@ int launch_topk(const float* d_scores, int64_t n, int32_t k, const int32_t* d_id
   }
   MV_HIP(hipGetLastError());
   return MV_OK;
+}
+
+int launch_topk(const float* d_scores, int64_t n, int32_t k, const int32_t* d_ids_map, int64_t id_base, void* ws,
+                float* d_out_scores, int64_t* d_out_ids, hipStream_t s, bool hist0_done) {
+  return launch_topk_batch(d_scores, 0, n, k, d_ids_map, 0, id_base, ws, 0, d_out_scores, d_out_ids, 0, 1, s, hist0_done);
 }
 
 }  // namespace mv

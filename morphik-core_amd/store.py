@@ -98,8 +98,9 @@ class MI355XMultiVectorStore(BaseVectorStore):
         self.id_base = int(id_base)
         self.fde_coarse_n = int(fde_coarse_n)
         self._index_factory = index_factory
-        # request coalescing (mode "float" only): concurrent query_similar calls arriving within batch_window_ms are
-        # scored in ONE slab pass by the batched MFMA kernel, each keeping its own doc_ids filter and k
+        # request coalescing (modes "float" and "fde_then_float"): concurrent query_similar calls arriving within
+        # batch_window_ms are scored in ONE slab pass (batched MFMA MaxSim scan / batched FDE pipeline: up to 32 requests per
+        # pass over the FDE slab, every request's candidates reranked exactly), each keeping its own doc_ids filter and k
         self.batch_window_s = float(batch_window_ms) / 1e3
         self.max_batch = int(max_batch)
         # The API accepts min_score (core/models/request.py:138) and threads it through retrieve_chunks
@@ -339,15 +340,28 @@ class MI355XMultiVectorStore(BaseVectorStore):
     # -- request coalescing
     def _batch_sync(self, items: List[Tuple[np.ndarray, int, Any, Any]]):
         ix = self._require_index()
-        kmax = max(k for _q, k, _a, _f in items)
-        allows = [a for _q, _k, a, _f in items]
         with self._lock:
             n_docs = self._next_ord
         t0 = time.perf_counter()
-        res = ix.query_batch([q for q, _k, _a, _f in items], kmax, mode="float", allows=allows if any(a is not None for a in allows) else None,
-                             n_docs=n_docs)
+        if self.mode == "float":
+            groups = [list(range(len(items)))]  # exact scan: the top-k of a larger k is a prefix, one pass serves every k
+        else:
+            # the FDE stage keeps min(10*k, 75) candidates (fast_multivector_store.py:529): requests share a pass only with
+            # requests of the same k, so each sees exactly the candidates a lone call would have reranked
+            by_k: Dict[int, List[int]] = {}
+            for j, (_q, k, _a, _f) in enumerate(items):
+                by_k.setdefault(int(k), []).append(j)
+            groups = list(by_k.values())
+        out: List[Any] = [None] * len(items)
+        for g in groups:
+            kmax = max(items[j][1] for j in g)
+            allows = [items[j][2] for j in g]
+            res = ix.query_batch([items[j][0] for j in g], kmax, mode=self.mode, allows=allows if any(a is not None for a in allows) else None,
+                                 n_docs=n_docs)
+            for j, (s, i) in zip(g, res):
+                out[j] = (s[: items[j][1]], i[: items[j][1]])
         self.last_query_timing = {"vector_search_s": time.perf_counter() - t0, "batched_queries": len(items)}
-        return [(s[:k], i[:k]) for (s, i), (_q, k, _a, _f) in zip(res, items)]
+        return out
 
     def _flush(self) -> None:
         items, self._pending = self._pending, []
@@ -419,7 +433,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
                 gen = self._generation
             if empty:
                 return []
-            if self.batch_window_s > 0 and self.mode == "float":
+            if self.batch_window_s > 0 and self.mode in ("float", "fde_then_float"):
                 scores, pages = await self._coalesced_query(q, int(k), allow)
             else:
                 scores, pages = await asyncio.to_thread(self._query_sync, q, int(k), allow)  # exceptions propagate (:819-822)

@@ -646,6 +646,109 @@ def test_query_fde_encode_kernels_agree(mv, nq):
 
 
 # ------------------------------------------------------------------ batched queries (one slab pass, MFMA-bound form)
+@pytest.mark.parametrize("n,stride", [(40, 16), (64, 16), (700, 32), (5000, 16)])
+def test_fde_batched_coarse_scan_matches_the_single_query_scan(mv, n, stride):
+    """mv_query_topk_batch in FDE mode: ONE pass over the FDE slab per 32 queries (bf16 MFMA, query FDE as bf16 hi + lo;
+    37 queries = a pass with two query tiles + a pass with one).
+    Coarse scores must agree with the single-query scan (fp32 query) to ~1e-5, through tombstones, a shared filter and
+    per-query filters, for corpus sizes around the 64-page tile (partial last tile, fewer tiles than CUs) and with the
+    radix selection (k > 32, n > 4096)."""
+    from morphik_core_amd import _lib
+    from morphik_core_amd.index import allow_bitmap
+
+    ix = _idx(mv, capacity_pages=n + 7, stride_rows=stride, with_fde=True, with_float=False)
+    ix.fill_synthetic(1234, 0, n, pages_per_doc=3)
+    ix.remove_doc(2)
+    n_docs = (n + 2) // 3
+    nq = 37
+    queries = [orc.synth_rows(4321, b, 0, 20 + (b * 5) % 13) for b in range(nq)]  # ragged lengths, padded to 32 rows
+    shared = allow_bitmap([d for d in range(n_docs) if d % 4 != 1])
+    per_q = [None if b % 3 == 0 else allow_bitmap([d for d in range(n_docs) if (d + b) % 3 != 0]) for b in range(nq)]
+    for cosine in (1, 0):
+        ix.set_option(_lib.MV_OPT_FDE_COSINE, cosine)
+        for k in (10, 64):
+            kk = min(k, n)
+            for kind in ("none", "shared", "per_query"):
+                if kind == "none":
+                    got = ix.query_batch(queries, kk, mode="fde")
+                elif kind == "shared":
+                    got = ix.query_batch(queries, kk, mode="fde", allow=shared)
+                else:
+                    got = ix.query_batch(queries, kk, mode="fde", allows=per_q, n_docs=n_docs)
+                for b, (s, i) in enumerate(got):
+                    al = None if kind == "none" else shared if kind == "shared" else per_q[b]
+                    ws, wi = ix.query(queries[b], kk, mode="fde", allow=al)
+                    assert len(i) == len(wi)
+                    np.testing.assert_allclose(s, ws, rtol=1e-4, atol=1e-6)
+                    assert len(set(i.tolist()) & set(wi.tolist())) >= len(wi) - 2  # near-ties may swap at the cut
+                    full = ix.score_all(queries[b], mode="fde", allow=al)
+                    np.testing.assert_allclose(s, full[i], rtol=1e-4, atol=1e-6)  # every returned id carries ITS score
+    # MV_OPT_FDE_BATCH_VARIANT = 2: the query FDE rounded to bf16 (no lo term) -- the slab's own precision
+    ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, 2)
+    kk = min(10, n)
+    for (s, i), q in zip(ix.query_batch(queries, kk, mode="fde"), queries):
+        full = ix.score_all(q, mode="fde")
+        np.testing.assert_allclose(s, full[i], rtol=5e-3, atol=2e-3 * np.abs(full[np.isfinite(full)]).max())
+        ws, _ = ix.query(q, kk, mode="fde")
+        np.testing.assert_allclose(s, ws, rtol=5e-3, atol=2e-3 * np.abs(ws).max())
+    # the query-by-query form of the same entry point (MV_OPT_FDE_BATCH_VARIANT = 1) is the single-query path itself
+    ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, 1)
+    for (s, i), q in zip(ix.query_batch(queries[:3], min(10, n), mode="fde"), queries[:3]):
+        ws, wi = ix.query(q, min(10, n), mode="fde")
+        assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist()
+    ix.close()
+
+
+def test_fde_batched_pipeline_equals_query_by_query(mv):
+    """FDE coarse -> exact rerank for a batch: same query FDE, same candidate rule (min(10k, 75) or MV_OPT_FDE_COARSE_N),
+    same per-batch-of-128 pad rule and the same rerank kernel as the single-query pipeline -> the planted neighbours
+    come back with bit-identical exact scores; ragged pages, a tombstone, per-query filters; stage accounting."""
+    from morphik_core_amd import _lib, synth
+    from morphik_core_amd.index import allow_bitmap
+
+    N, stride, nb = 1500, 64, 35  # 35 queries = a group of 32 + a group of 3
+    rng = np.random.default_rng(5)
+    queries = [orc.synth_rows(4321, b, 0, 32 if b % 2 else 24) for b in range(nb)]
+    base = orc.synth_pages(1234, 0, N, stride)
+    spec = synth.planted_spec(queries, N, stride, n_ranks=5)
+    for (_, _, p, row0, rows) in spec:
+        base[p, row0 : row0 + rows.shape[0]] = rows
+    planted_pages = {p for (_, _, p, _, _) in spec}
+    lens = [stride if (p in planted_pages or p % 3 == 0) else int(rng.integers(40, stride + 1)) for p in range(N)]
+    pages = [base[p, : lens[p]] for p in range(N)]
+    ix = _idx(mv, capacity_pages=N, stride_rows=stride, with_fde=True)
+    ix.add(pages, doc_ordinals=[p // 2 for p in range(N)])
+    victim = next(p for p in range(N) if p not in planted_pages and (p ^ 1) not in planted_pages)
+    ix.remove_doc(victim // 2)
+    planted = {b: [p for (qi, _, p, _, _) in spec if qi == b] for b in range(nb)}
+    for coarse_n, k in ((0, 5), (300, 5), (300, 10)):
+        ix.set_option(_lib.MV_OPT_FDE_COARSE_N, coarse_n)
+        got, st = ix.query_batch(queries, k, mode="fde_then_float", want_stats=True)
+        for b, (s, i) in enumerate(got):
+            ws, wi = ix.query(queries[b], k, mode="fde_then_float")
+            assert i[:5].tolist() == planted[b] == wi[:5].tolist()
+            assert s[:5].tolist() == ws[:5].tolist()  # same candidates' exact scores, same kernel: bit-identical
+            common = set(i.tolist()) & set(wi.tolist())
+            assert len(common) >= k - 1  # a candidate at the coarse cut may differ (bf16 hi+lo query FDE)
+            ds, dw = dict(zip(i.tolist(), s.tolist())), dict(zip(wi.tolist(), ws.tolist()))
+            assert all(ds[c] == dw[c] for c in common)
+        nc = coarse_n if coarse_n else min(10 * k, 75)
+        groups = 2  # 32 + 3 queries
+        assert st.coarse_ms > 0 and st.rerank_ms > 0 and st.encode_ms > 0 and st.select_ms > 0
+        live = N - 2
+        assert st.pages_scored == live * nb
+        cand_rows = st.bytes_scanned - groups * live * ix.fde_config.output_dim * 2
+        assert cand_rows % 256 == 0 and 40 * nc * nb <= cand_rows // 256 <= stride * nc * nb
+    # per-query doc filters: query b may not see its own best planted page's document
+    allows = [allow_bitmap([d for d in range(N // 2) if d != planted[b][0] // 2]) for b in range(nb)]
+    got = ix.query_batch(queries, 5, mode="fde_then_float", allows=allows, n_docs=N // 2)
+    for b, (s, i) in enumerate(got):
+        ws, wi = ix.query(queries[b], 5, mode="fde_then_float", allow=allows[b])
+        assert planted[b][0] not in i.tolist()
+        assert i[:4].tolist() == wi[:4].tolist() and s[:4].tolist() == ws[:4].tolist()
+    ix.close()
+
+
 @pytest.mark.parametrize("bvariant", [0, 1, 2, 3])  # auto (page-split <= 128 rows, row-split above), 32x32x16 / 8 waves, round-1 pipeline, row-split always
 @pytest.mark.parametrize("stride,nrows", [(1024, 1024), (1024, 1000), (208, 200), (64, 50), (16, 7)])
 def test_batched_queries_equal_single_queries_and_oracle(mv, stride, nrows, bvariant):

@@ -153,6 +153,33 @@ def test_request_coalescing_on_the_real_index():
         np.testing.assert_allclose([c.score for c in g], [c.score for c in w], rtol=1e-5)
 
 
+def test_request_coalescing_on_the_fast_store_rides_the_batched_fde_pipeline():
+    """Concurrent query_similar calls on the FDE ("fast") store: one pass over the FDE slab for the coalesced requests
+    (mv_query_topk_batch), each with its own k (requests share a pass only with requests of the same k: the candidate
+    rule min(10k, 75) depends on it) and doc_ids filter -> exactly what the lone calls return."""
+    from tests import store_scenarios as sc2
+
+    rng = np.random.default_rng(3)
+    chunks = sc2.make_chunks(rng, n_docs=6, chunks_per_doc=4)
+    plain, fused = _store("fde_then_float"), _store("fde_then_float")
+    fused.batch_window_s, fused.max_batch = 0.05, 16
+    sc2.run(plain.store_embeddings(chunks))
+    sc2.run(fused.store_embeddings(chunks))
+    reqs = [(chunks[i % len(chunks)].embedding, 2 + i % 3, None if i % 4 else [chunks[i % len(chunks)].document_id, chunks[1].document_id])
+            for i in range(21)]
+
+    async def fire(store):
+        return await asyncio.gather(*(store.query_similar(q, k=k, doc_ids=d) for q, k, d in reqs))
+
+    want, got = sc2.run(fire(plain)), sc2.run(fire(fused))
+    assert fused.coalesced_batches == [16, 5]
+    for w, g, (_q, k, d) in zip(want, got, reqs):
+        assert [(c.document_id, c.chunk_number) for c in g] == [(c.document_id, c.chunk_number) for c in w]
+        assert [c.score for c in g] == [c.score for c in w] and len(g) <= k
+        if d:
+            assert {c.document_id for c in g} <= set(d)
+
+
 def test_store_checkpoint_and_resume(tmp_path):
     """save() -> a fresh process-like load(): same answers, same payloads, deletes and filters still work."""
     from morphik_core_amd.store import MI355XFastMultiVectorStore

@@ -98,6 +98,34 @@ def test_concurrent_requests_are_coalesced_into_one_batched_scan():
             assert {c.document_id for c in g} <= set(d)
 
 
+def test_concurrent_requests_on_the_fast_store_are_coalesced_by_k():
+    """mode fde_then_float: coalesced requests share a batched call only with requests of the same k (the candidate rule
+    min(10k, 75) depends on k), so every request gets exactly what a lone call returns."""
+    import asyncio
+
+    rng = np.random.default_rng(3)
+    chunks = sc.make_chunks(rng, n_docs=4, chunks_per_doc=3)
+    from oracle import oracle as orc
+
+    def fde_index(**kw):
+        return OracleIndex(fde=orc.FdeConfig.reference_default(), **kw)
+
+    plain = MI355XMultiVectorStore(capacity_pages=64, stride_rows=32, index_factory=fde_index, mode="fde_then_float")
+    fused = MI355XMultiVectorStore(capacity_pages=64, stride_rows=32, index_factory=fde_index, mode="fde_then_float", batch_window_ms=20.0, max_batch=8)
+    assert plain.initialize() and fused.initialize()
+    sc.run(plain.store_embeddings(chunks))
+    sc.run(fused.store_embeddings(chunks))
+    reqs = [(chunks[i].embedding, 1 + i % 3, None if i % 3 else [chunks[i].document_id, chunks[0].document_id]) for i in range(10)]
+
+    async def fire(store):
+        return await asyncio.gather(*(store.query_similar(q, k=k, doc_ids=d) for q, k, d in reqs))
+
+    want, got = sc.run(fire(plain)), sc.run(fire(fused))
+    assert fused.coalesced_batches == [8, 2]
+    for w, g, (_q, k, _d) in zip(want, got, reqs):
+        assert [(c.document_id, c.chunk_number, c.score) for c in g] == [(c.document_id, c.chunk_number, c.score) for c in w] and len(g) <= k
+
+
 def test_compaction_reclaims_slots_and_keeps_answers():
     rng = np.random.default_rng(7)
     chunks = sc.make_chunks(rng, n_docs=5, chunks_per_doc=3)
