@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
+    from morphik_core_amd import _lib as L
     from morphik_core_amd.index import MvIndex, synth_rows
 
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
@@ -17,7 +18,9 @@ def main():
     ix.fill_synthetic(1234, 0, n)
     out_dim = ix.fde_config.output_dim
     qs = [synth_rows(4321, j, 32) for j in range(32)]
-    out = {"pages": n, "hi_only": bool(os.environ.get("MV_FDE_BATCH_HI_ONLY"))}
+    hi_only = len(sys.argv) > 2 and sys.argv[2] == "hi_only"  # MV_OPT_FDE_BATCH_VARIANT = 2: query FDE rounded to bf16
+    ix.set_option(L.MV_OPT_FDE_BATCH_VARIANT, 2 if hi_only else 0)
+    out = {"pages": n, "hi_only": hi_only}
     for B in (16, 32):
         for _ in range(5):
             ix.query_batch(qs[:B], 10, mode="fde")

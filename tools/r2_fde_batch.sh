@@ -7,6 +7,6 @@ tail -6 $OUT/pytest_fde_batch.log
 timeout 600 python tools/fde_batch_probe.py ${1:-200000} > $OUT/fde_batch_probe.json 2> $OUT/fde_batch_probe.err || tail -5 $OUT/fde_batch_probe.err
 cat $OUT/fde_batch_probe.json
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_fde_batch -o fb -- python $OLDPWD/tools/fde_batch_probe.py ${1:-200000} > /dev/null 2> $OUT/prof_fde_batch.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_fde_batch -- python $OLDPWD/tools/fde_batch_probe.py ${1:-200000} > /dev/null 2> $OUT/prof_fde_batch.err
 cd $OLDPWD
-f=$(ls $OUT/prof_fde_batch/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && head -14 "$f" | cut -c1-230
+f=$(find /tmp/prof_fde_batch -name "*kernel_stats.csv" | head -1); if [ -n "$f" ]; then cp "$f" $OUT/rocprofv3_kernel_stats_fde_batch_probe.csv; head -14 "$f" | cut -c1-200; fi
