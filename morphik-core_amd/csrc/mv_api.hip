@@ -659,7 +659,7 @@ void mv_index_destroy(mv_index* ix) {
   void* ptrs[] = {ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
                   ix->d_topk_ws, ix->d_q, ix->d_qf32, ix->d_qbits, ix->d_qpop, ix->d_qfde, ix->d_qoff, ix->d_allow, ix->d_out_s,
                   ix->d_out_id, ix->d_cand, ix->d_cand_scores, ix->d_bqf32, ix->d_bqfde, ix->d_bqimage, ix->d_btopk_ws, ix->d_bsel_s,
-                  ix->d_bsel_id, ix->d_bcand, ix->d_bcand_pads, ix->d_bcand_scores, ix->d_bout_s, ix->d_bout_id};
+                  ix->d_bsel_id, ix->d_bcand, ix->d_bcand_pads, ix->d_bcand_scores, ix->d_bout_s, ix->d_bout_id, ix->d_bq8hi, ix->d_bq8lo, ix->d_bq8fac};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   fde_tables_destroy(&ix->fde_t);
@@ -1244,6 +1244,11 @@ static int ensure_fde_batch_ws(mv_index* ix) {
   if (!ix->d_bqf32) MV_HIP(hipMalloc(&ix->d_bqf32, (size_t)kBatchQRows * kDim * 4));
   if (!ix->d_bqfde) MV_HIP(hipMalloc(&ix->d_bqfde, (size_t)kFdeBatchMaxQueries * out_dim * 4));
   if (!ix->d_bqimage) MV_HIP(hipMalloc(&ix->d_bqimage, mv::fde_scan_batch_image_bytes(out_dim)));
+  if (ix->cfg.flags & MV_WITH_FP8) {
+    if (!ix->d_bq8hi) MV_HIP(hipMalloc(&ix->d_bq8hi, (size_t)kBatchQRows * kDim));
+    if (!ix->d_bq8lo) MV_HIP(hipMalloc(&ix->d_bq8lo, (size_t)kBatchQRows * kDim));
+    if (!ix->d_bq8fac) MV_HIP(hipMalloc(&ix->d_bq8fac, (size_t)kBatchQRows * 4));
+  }
   if (!ix->d_btopk_ws) {
     hipError_t e = hipMalloc(&ix->d_btopk_ws, (size_t)kFdeBatchMaxQueries * ix->topk_ws_bytes);
     if (e != hipSuccess) { ix->d_btopk_ws = nullptr; set_error("hipMalloc of the batched selection workspace (%zu B) failed", (size_t)kFdeBatchMaxQueries * ix->topk_ws_bytes); return MV_ERR_NOMEM; }
@@ -1283,6 +1288,8 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
   const int rpq = ((n_q_rows + 15) / 16) * 16;
   const int group = std::min(kBatchQRows / rpq, kFdeBatchMaxQueries);
   const bool rerank = mode == MV_MODE_FDE_THEN_FLOAT;
+  // the rerank uses the bf16 slab when the index has one, else the fp8 slab (the rule of the single-query pipeline)
+  const bool rerank_fp8 = rerank && !(ix->cfg.flags & MV_WITH_FLOAT) && (ix->cfg.flags & MV_WITH_FP8);
   const bool per_query = allow_bits && allow_per_query;
   const uint32_t* d_allow = nullptr;
   rc = upload_allow(ix, allow_bits, per_query ? n_allow_words * (int64_t)n_queries : n_allow_words, &d_allow);
@@ -1295,18 +1302,19 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
   const int64_t L = nc;  // the per-query lists lie back to back: [query][nc]
   // every query's candidates in ONE rerank launch (work item -> its query): the default kernels, queries of <= 128 rows
   const int rr_variant = ix->maxsim_variant < 0 ? maxsim_default_variant(ix->cfg.stride_rows) : ix->maxsim_variant;
-  const bool rerank_one_launch = rpq <= kMaxQRowsPerPass && (rr_variant == 6 || rr_variant == 7);
+  const bool rerank_one_launch = rerank_fp8 || (rpq <= kMaxQRowsPerPass && (rr_variant == 6 || rr_variant == 7));
   const int pad_sem = ix->pad_semantics < 0 ? 1 : ix->pad_semantics;
   int64_t pages = 0;
   if (stats) (void)count_allowed_rows(ix, n, per_query ? nullptr : allow_bits, n_allow_words, &pages);
-  std::vector<float> hf((size_t)group * n_q_rows * kDim);
+  std::vector<float> hf((size_t)group * rpq * kDim);
   std::vector<uint16_t> hb((size_t)kBatchQRows * kDim);
   for (int32_t b0 = 0; b0 < n_queries; b0 += group) {
     const int nb = std::min(group, n_queries - b0);
     std::fill(hb.begin(), hb.end(), (uint16_t)0);
-    for (int b = 0; b < nb; ++b) {
+    std::fill(hf.begin(), hf.end(), 0.0f);
+    for (int b = 0; b < nb; ++b) {  // every query padded to rpq rows with zero rows (a zero row adds exactly 0 to the FDE and to MaxSim)
       const char* src = (const char*)q + (size_t)(b0 + b) * n_q_rows * kDim * esz;
-      float* df = hf.data() + (size_t)b * n_q_rows * kDim;
+      float* df = hf.data() + (size_t)b * rpq * kDim;
       uint16_t* db = hb.data() + (size_t)b * rpq * kDim;
       const size_t ne = (size_t)n_q_rows * kDim;
       if (q_dtype == MV_F32) {
@@ -1317,13 +1325,17 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
         for (size_t i = 0; i < ne; ++i) df[i] = host_bf16_to_f32(db[i]);
       }
     }
-    MV_HIP(hipMemcpyAsync(ix->d_bqf32, hf.data(), (size_t)nb * n_q_rows * kDim * 4, hipMemcpyHostToDevice, ix->stream));
-    if (rerank) MV_HIP(hipMemcpyAsync(ix->d_bq, hb.data(), hb.size() * 2, hipMemcpyHostToDevice, ix->stream));
+    MV_HIP(hipMemcpyAsync(ix->d_bqf32, hf.data(), (size_t)nb * rpq * kDim * 4, hipMemcpyHostToDevice, ix->stream));
+    if (rerank && !rerank_fp8) MV_HIP(hipMemcpyAsync(ix->d_bq, hb.data(), hb.size() * 2, hipMemcpyHostToDevice, ix->stream));
+    if (rerank_fp8) {
+      rc = launch_fp8_query_prep(ix->d_bqf32, nb * rpq, ix->d_bq8hi, ix->d_bq8lo, ix->d_bq8fac, ix->stream);
+      if (rc) return rc;
+    }
     MV_HIP(hipEventRecord(ix->ev[0], ix->stream));
     int launches = 0;
     FdeEncodeArgs e{};
     e.variant = 2;  // the latency kernel of the single-query path, one grid row per query
-    e.x_f32 = ix->d_bqf32; e.row_offsets = nullptr; e.stride = n_q_rows; e.n_pages = nb; e.is_query = 1; e.out_f32 = ix->d_bqfde;
+    e.x_f32 = ix->d_bqf32; e.row_offsets = nullptr; e.stride = rpq; e.n_pages = nb; e.is_query = 1; e.out_f32 = ix->d_bqfde;
     rc = launch_fde_encode(ix->fde_t, e, ix->stream);
     if (rc) return rc;
     MV_HIP(hipEventRecord(ix->ev_st[0], ix->stream));
@@ -1345,7 +1357,15 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
                          ix->d_bcand, ix->d_bcand_pads, L);
       MV_HIP(hipGetLastError());
       MV_HIP(hipEventRecord(ix->ev_st[2], ix->stream));
-      if (rerank_one_launch) {
+      if (rerank_fp8) {
+        Fp8ScanArgs fa{};
+        fa.slab = ix->slab8; fa.inv_scale = ix->inv_scale8; fa.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr; fa.cand = ix->d_bcand;
+        fa.qhi = ix->d_bq8hi; fa.qlo = ix->d_bq8lo; fa.qfac = ix->d_bq8fac; fa.n_q = rpq; fa.scores = ix->d_bcand_scores; fa.n = (int64_t)nb * nc;
+        fa.stride = ix->cfg.stride_rows; fa.pad_to = 0; fa.pad_items = ix->d_bcand_pads; fa.items_per_query = (int32_t)nc;
+        rc = launch_maxsim_fp8(fa, ix->stream);
+        if (rc) return rc;
+        ++launches;
+      } else if (rerank_one_launch) {
         MaxsimArgs ma{};
         ma.slab = ix->slab; ma.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr; ma.cand = ix->d_bcand; ma.q = ix->d_bq;
         ma.scores = ix->d_bcand_scores; ma.n = (int64_t)nb * nc; ma.stride = ix->cfg.stride_rows; ma.q_tiles = rpq / 16; ma.pad_to = 0;
@@ -1405,7 +1425,7 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
             const int32_t c = ix->h_bcand[(size_t)b * L + i];
             if (c >= 0) cand_rows += ix->h_n_rows[c];
           }
-        total.bytes_scanned += cand_rows * (int64_t)kRowBytes;
+        total.bytes_scanned += cand_rows * (int64_t)(rerank_fp8 ? kDim : kRowBytes);
       }
     }
   }
@@ -1421,9 +1441,10 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
   const size_t esz = q_dtype == MV_F32 ? 4 : 2;
   const int rpq = ((n_q_rows + 15) / 16) * 16;
   mv_query_stats total{};
-  // FDE modes: the batched pipeline (the rerank needs the bf16 slab; fp8-only indexes go query by query)
+  // FDE modes: the batched pipeline (rerank on the bf16 slab, or on the fp8 slab of an index without one: queries of <= 64 rows)
   if ((mode == MV_MODE_FDE_THEN_FLOAT || mode == MV_MODE_FDE_ONLY) && n_queries > 1 && k >= 1 && k <= kTopkMaxDeviceK && rpq <= 512 &&
-      ix->fde_batch_variant != 1 && (ix->cfg.flags & MV_WITH_FDE) && (mode == MV_MODE_FDE_ONLY || (ix->cfg.flags & MV_WITH_FLOAT)) &&
+      ix->fde_batch_variant != 1 && (ix->cfg.flags & MV_WITH_FDE) &&
+      (mode == MV_MODE_FDE_ONLY || (ix->cfg.flags & MV_WITH_FLOAT) || ((ix->cfg.flags & MV_WITH_FP8) && rpq <= 64)) &&
       mv::fde_scan_batch_supported(ix->fde_t.out_dim) && ix->fde_t.cfg.projection_dimension <= 16)
     return fde_batch_query(ix, q, q_dtype, n_queries, n_q_rows, k, mode, allow_bits, n_allow_words, allow_per_query, out_scores, out_ids, out_n, stats);
   // anything but the exact float scan (and queries longer than one 512-row group) runs query by query

@@ -212,6 +212,8 @@ struct Fp8ScanArgs {
   int32_t stride;
   int32_t pad_to;
   const int32_t* pad_items;  // per-item pad_to (device); null -> pad_to
+  int32_t items_per_query;   // > 0: rerank lists of a batch of queries in one launch -- item i uses the query whose rows start
+                             // (i / items_per_query) * padded(n_q) rows into qhi / qlo / qfac; needs cand, n_q <= 64
 };
 int launch_maxsim_fp8(const Fp8ScanArgs& a, hipStream_t s);
 

@@ -195,6 +195,8 @@ struct F8Args {
   int64_t page0;
   int32_t accumulate;
   const int32_t* pad_items;  // per-item pad_to; null -> pad_to
+  int32_t items_per_q;       // QITEM kernels: work item i scores against query i / items_per_q, whose rows start
+  int32_t q_item_rows;       // (i / items_per_q) * q_item_rows rows into qhi / qlo / qfac (the rerank lists of a batch of queries)
 };
 
 __device__ __forceinline__ bool f8_masked(const F8Args& a, int64_t page) {
@@ -223,7 +225,7 @@ __device__ __forceinline__ void f8_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int MT, int D>
+template <int MT, int D, bool QITEM = false>
 __global__ __launch_bounds__(256) void maxsim_fp8_kernel(F8Args a) {
   __shared__ __attribute__((aligned(16))) char lds[4 * D * kF8SlotBytes + 1024];
   float* red = reinterpret_cast<float*>(lds + 4 * D * kF8SlotBytes);
@@ -285,16 +287,25 @@ __global__ __launch_bounds__(256) void maxsim_fp8_kernel(F8Args a) {
     if (i < nsw) issue(i);
 
   // query operands (loop invariant), loaded after the prologue DMAs and pinned (see mv_maxsim.hip)
+  const uint8_t* qhi = a.qhi;
+  const uint8_t* qlo = a.qlo;
+  const float* qfac = a.qfac;
+  if (QITEM) {  // this item's query (batched rerank)
+    const size_t qrow = (size_t)(item / a.items_per_q) * (size_t)a.q_item_rows;
+    qhi += qrow * kF8RowBytes;
+    qlo += qrow * kF8RowBytes;
+    qfac += qrow;
+  }
   i32x8 ah[MT], al[MT];
   float fac[MT][4];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const size_t ro = (size_t)(m * 16 + r) * kF8RowBytes;
-    const i32x4 h0 = *reinterpret_cast<const i32x4*>(a.qhi + ro + g * 16);
-    const i32x4 h1 = *reinterpret_cast<const i32x4*>(a.qhi + ro + 64 + g * 16);
-    const i32x4 l0 = *reinterpret_cast<const i32x4*>(a.qlo + ro + g * 16);
-    const i32x4 l1 = *reinterpret_cast<const i32x4*>(a.qlo + ro + 64 + g * 16);
-    const float4 f = *reinterpret_cast<const float4*>(a.qfac + m * 16 + g * 4);
+    const i32x4 h0 = *reinterpret_cast<const i32x4*>(qhi + ro + g * 16);
+    const i32x4 h1 = *reinterpret_cast<const i32x4*>(qhi + ro + 64 + g * 16);
+    const i32x4 l0 = *reinterpret_cast<const i32x4*>(qlo + ro + g * 16);
+    const i32x4 l1 = *reinterpret_cast<const i32x4*>(qlo + ro + 64 + g * 16);
+    const float4 f = *reinterpret_cast<const float4*>(qfac + m * 16 + g * 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       ah[m][i] = h0[i]; ah[m][4 + i] = h1[i];
@@ -368,7 +379,7 @@ __global__ __launch_bounds__(256) void maxsim_fp8_kernel(F8Args a) {
       v = fmaxf(fmaxf(red[lane], red[64 + lane]), fmaxf(red[128 + lane], red[192 + lane]));
       if (clamp) v = fmaxf(v, 0.f);
       if (v == -INFINITY) v = 0.f;
-      v *= a.qfac[lane];
+      v *= qfac[lane];
     }
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s);
@@ -389,7 +400,12 @@ int launch_f8_mt(const F8Args& k0, hipStream_t s) {
     if (k0.cand) k.cand = k0.cand + off;
     else k.page0 = k0.page0 + off;
     if (k0.pad_items) k.pad_items = k0.pad_items + off;
-    hipLaunchKernelGGL((maxsim_fp8_kernel<MT, 4>), dim3((unsigned)k.n), dim3(256), 0, s, k);
+    if (k.items_per_q > 0) {
+      if (k0.n > kChunk) { set_error("per-item queries: %lld items in one launch not supported", (long long)k0.n); return MV_ERR_INVALID; }
+      hipLaunchKernelGGL((maxsim_fp8_kernel<MT, 4, true>), dim3((unsigned)k.n), dim3(256), 0, s, k);
+    } else {
+      hipLaunchKernelGGL((maxsim_fp8_kernel<MT, 4>), dim3((unsigned)k.n), dim3(256), 0, s, k);
+    }
   }
   MV_HIP(hipGetLastError());
   return MV_OK;
@@ -420,10 +436,11 @@ int launch_fp8_query_prep(const float* d_q_f32, int n_q, uint8_t* d_hi, uint8_t*
 int launch_maxsim_fp8(const Fp8ScanArgs& a, hipStream_t s) {
   if (a.n <= 0) return MV_OK;
   const int padded = ((a.n_q + 15) / 16) * 16;
+  if (a.items_per_query > 0 && (padded > 64 || !a.cand)) { set_error("per-item queries need a candidate list and <= 64 query rows"); return MV_ERR_INVALID; }
   for (int q0 = 0, pass = 0; q0 < padded; q0 += 64, ++pass) {
     const int mt = std::min(4, (padded - q0) / 16);
     F8Args k{a.slab, a.inv_scale, a.n_rows, a.doc_ord, a.allow, a.n_allow_bits, a.cand,
-             a.qhi + (size_t)q0 * kDim, a.qlo + (size_t)q0 * kDim, a.qfac + q0, a.scores, a.n, a.stride, a.pad_to, 0, pass > 0, a.pad_items};
+             a.qhi + (size_t)q0 * kDim, a.qlo + (size_t)q0 * kDim, a.qfac + q0, a.scores, a.n, a.stride, a.pad_to, 0, pass > 0, a.pad_items, a.items_per_query, padded};
     int rc;
     switch (mt) {
       case 1: rc = launch_f8_mt<1>(k, s); break;

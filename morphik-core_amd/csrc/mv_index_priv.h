@@ -57,9 +57,12 @@ struct mv_index {
   uint16_t* d_bq = nullptr;    // [kBatchQRows][128] bf16 query block of the batched scans
   float* d_bscores = nullptr;  // [32][capacity] per-query score vectors of the batched scan (lazily allocated)
   // batched FDE pipeline (mv_query_topk_batch in the FDE modes; lazily allocated, up to 32 queries per slab pass)
-  float* d_bqf32 = nullptr;        // [kBatchQRows][128] fp32 query rows of the group, packed [query][n_q_rows][128]
+  float* d_bqf32 = nullptr;        // [kBatchQRows][128] fp32 query rows of the group, [query][rows padded to 16][128], zero rows behind each query
   float* d_bqfde = nullptr;        // [32][out_dim] fp32 query FDEs
   uint16_t* d_bqimage = nullptr;   // fragment-ordered bf16 hi/lo image of the query FDEs
+  uint8_t* d_bq8hi = nullptr;      // [kBatchQRows][128] e4m3 two-term split of the group's query rows (fp8 rerank)
+  uint8_t* d_bq8lo = nullptr;
+  float* d_bq8fac = nullptr;       // [kBatchQRows]
   void* d_btopk_ws = nullptr;      // 32 selection workspaces of topk_ws_bytes each
   float* d_bsel_s = nullptr;       // [32][n_coarse] coarse top-n per query
   int64_t* d_bsel_id = nullptr;

@@ -699,10 +699,12 @@ def test_fde_batched_coarse_scan_matches_the_single_query_scan(mv, n, stride):
     ix.close()
 
 
-def test_fde_batched_pipeline_equals_query_by_query(mv):
+@pytest.mark.parametrize("slab", ["bf16", "fp8"])
+def test_fde_batched_pipeline_equals_query_by_query(mv, slab):
     """FDE coarse -> exact rerank for a batch: same query FDE, same candidate rule (min(10k, 75) or MV_OPT_FDE_COARSE_N),
     same per-batch-of-128 pad rule and the same rerank kernel as the single-query pipeline -> the planted neighbours
-    come back with bit-identical exact scores; ragged pages, a tombstone, per-query filters; stage accounting."""
+    come back with bit-identical exact scores; ragged pages, a tombstone, per-query filters; stage accounting.
+    slab = fp8: an index without the bf16 slab reranks on its e4m3 slab (BASELINE configs[3] shape)."""
     from morphik_core_amd import _lib, synth
     from morphik_core_amd.index import allow_bitmap
 
@@ -716,7 +718,8 @@ def test_fde_batched_pipeline_equals_query_by_query(mv):
     planted_pages = {p for (_, _, p, _, _) in spec}
     lens = [stride if (p in planted_pages or p % 3 == 0) else int(rng.integers(40, stride + 1)) for p in range(N)]
     pages = [base[p, : lens[p]] for p in range(N)]
-    ix = _idx(mv, capacity_pages=N, stride_rows=stride, with_fde=True)
+    ix = _idx(mv, capacity_pages=N, stride_rows=stride, with_fde=True, with_float=slab == "bf16", with_fp8=slab == "fp8")
+    row_bytes = 256 if slab == "bf16" else 128
     ix.add(pages, doc_ordinals=[p // 2 for p in range(N)])
     victim = next(p for p in range(N) if p not in planted_pages and (p ^ 1) not in planted_pages)
     ix.remove_doc(victim // 2)
@@ -738,7 +741,7 @@ def test_fde_batched_pipeline_equals_query_by_query(mv):
         live = N - 2
         assert st.pages_scored == live * nb
         cand_rows = st.bytes_scanned - groups * live * ix.fde_config.output_dim * 2
-        assert cand_rows % 256 == 0 and 40 * nc * nb <= cand_rows // 256 <= stride * nc * nb
+        assert cand_rows % row_bytes == 0 and 40 * nc * nb <= cand_rows // row_bytes <= stride * nc * nb
     # per-query doc filters: query b may not see its own best planted page's document
     allows = [allow_bitmap([d for d in range(N // 2) if d != planted[b][0] // 2]) for b in range(nb)]
     got = ix.query_batch(queries, 5, mode="fde_then_float", allows=allows, n_docs=N // 2)
