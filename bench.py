@@ -636,6 +636,23 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+    if out is not None and world == 1 and args.workload == "fde_fp8" and not args.no_aux:
+        # the same shard serving 32 concurrent requests: mv_query_topk_batch, one FDE-slab pass for all of them
+        bq = [queries[i % N_QUERIES] for i in range(32)]
+        dev_ms, stages, res_b = [], [], None
+        for r in range(8):
+            res_b, st = ix.query_batch(bq, K, mode=MODE, want_stats=True)
+            if r >= 3:
+                dev_ms.append(st.total_device_ms)
+                stages.append((st.encode_ms, st.coarse_ms, st.select_ms, st.rerank_ms, st.topk_ms))
+        d, sb = float(np.median(dev_ms)), np.median(np.array(stages), axis=0)
+        rb = [synth.recall_at_k([p for p in res_b[i][1].tolist() if p >= 0], [p for (qq, _r, p, _a, _b) in spec if qq == i % N_QUERIES]) for i in range(32)]
+        out["batched_32_requests"] = {
+            "device_ms_per_batch": round(d, 4), "device_us_per_request": round(d * 1e3 / 32, 2), "requests_per_s": round(32 / d * 1e3, 1),
+            "pages_searched_per_s": round(32 * n_local / d * 1e3, 1), "throughput_vs_one_request_per_step": round(32 * ms_per_step / d, 2),
+            "stage_ms": {k: round(float(v), 4) for k, v in zip(("encode_32_queries", "coarse_gemm_one_slab_pass", "select", "rerank_fp8", "topk"), sb)},
+            "coarse_pass_GBps": round(n_local * 20480 / float(sb[1]) / 1e6, 1), "recall_at_10": float(np.mean(rb)),
+        }
     ix.close()
     if out is not None and world == 1:
         # measured denominators, same process, GPU still warm from the timed run (the 262 GB slab had to go first): the scan's

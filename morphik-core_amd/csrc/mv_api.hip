@@ -1231,9 +1231,27 @@ int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_r
                                   d_out_ids, stream, stats, 0);
 }
 
+// Selection workspace of the batched entry point: one top-k workspace, result row and pinned read-back row per query of a
+// group (q_mu held).
+static int ensure_batch_select_ws(mv_index* ix) {
+  const size_t lists = (size_t)kFdeBatchMaxQueries * kTopkMaxDeviceK;
+  if (!ix->d_btopk_ws) {
+    hipError_t e = hipMalloc(&ix->d_btopk_ws, (size_t)kFdeBatchMaxQueries * ix->topk_ws_bytes);
+    if (e != hipSuccess) { ix->d_btopk_ws = nullptr; set_error("hipMalloc of the batched selection workspace (%zu B) failed", (size_t)kFdeBatchMaxQueries * ix->topk_ws_bytes); return MV_ERR_NOMEM; }
+    MV_HIP(hipMemset(ix->d_btopk_ws, 0, (size_t)kFdeBatchMaxQueries * ix->topk_ws_bytes));  // the radix histograms are kept zero between selections
+  }
+  if (!ix->d_bout_s) MV_HIP(hipMalloc(&ix->d_bout_s, lists * 4));
+  if (!ix->d_bout_id) MV_HIP(hipMalloc(&ix->d_bout_id, lists * 8));
+  if (!ix->h_bout_s) MV_HIP(hipHostMalloc((void**)&ix->h_bout_s, lists * 4, hipHostMallocDefault));
+  if (!ix->h_bout_id) MV_HIP(hipHostMalloc((void**)&ix->h_bout_id, lists * 8, hipHostMallocDefault));
+  return MV_OK;
+}
+
 // Workspace of the batched FDE pipeline (q_mu held).
 static int ensure_fde_batch_ws(mv_index* ix) {
   if (ix->h_bcand) return MV_OK;
+  int rc0 = ensure_batch_select_ws(ix);
+  if (rc0) return rc0;
   const int64_t out_dim = ix->fde_t.out_dim;
   const size_t lists = (size_t)kFdeBatchMaxQueries * kTopkMaxDeviceK;
   if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)kBatchQRows * kRowBytes));
@@ -1249,20 +1267,11 @@ static int ensure_fde_batch_ws(mv_index* ix) {
     if (!ix->d_bq8lo) MV_HIP(hipMalloc(&ix->d_bq8lo, (size_t)kBatchQRows * kDim));
     if (!ix->d_bq8fac) MV_HIP(hipMalloc(&ix->d_bq8fac, (size_t)kBatchQRows * 4));
   }
-  if (!ix->d_btopk_ws) {
-    hipError_t e = hipMalloc(&ix->d_btopk_ws, (size_t)kFdeBatchMaxQueries * ix->topk_ws_bytes);
-    if (e != hipSuccess) { ix->d_btopk_ws = nullptr; set_error("hipMalloc of the batched selection workspace (%zu B) failed", (size_t)kFdeBatchMaxQueries * ix->topk_ws_bytes); return MV_ERR_NOMEM; }
-    MV_HIP(hipMemset(ix->d_btopk_ws, 0, (size_t)kFdeBatchMaxQueries * ix->topk_ws_bytes));  // the radix histograms are kept zero between selections
-  }
   if (!ix->d_bsel_s) MV_HIP(hipMalloc(&ix->d_bsel_s, lists * 4));
   if (!ix->d_bsel_id) MV_HIP(hipMalloc(&ix->d_bsel_id, lists * 8));
   if (!ix->d_bcand) MV_HIP(hipMalloc(&ix->d_bcand, lists * 4));
   if (!ix->d_bcand_pads) MV_HIP(hipMalloc(&ix->d_bcand_pads, lists * 4));
   if (!ix->d_bcand_scores) MV_HIP(hipMalloc(&ix->d_bcand_scores, lists * 4));
-  if (!ix->d_bout_s) MV_HIP(hipMalloc(&ix->d_bout_s, lists * 4));
-  if (!ix->d_bout_id) MV_HIP(hipMalloc(&ix->d_bout_id, lists * 8));
-  if (!ix->h_bout_s) MV_HIP(hipHostMalloc((void**)&ix->h_bout_s, lists * 4, hipHostMallocDefault));
-  if (!ix->h_bout_id) MV_HIP(hipHostMalloc((void**)&ix->h_bout_id, lists * 8, hipHostMallocDefault));
   MV_HIP(hipHostMalloc((void**)&ix->h_bcand, lists * 4, hipHostMallocDefault));  // last: marks the workspace complete
   return MV_OK;
 }
@@ -1487,8 +1496,8 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
   // accounting: with per-query filters every live page is read (a page is skipped only when no query may see it)
   const int64_t rows = stats ? count_allowed_rows(ix, n, per_query ? nullptr : allow_bits, n_allow_words, &pages) : 0;
   std::vector<uint16_t> hq((size_t)512 * kDim);
-  std::vector<float> hs((size_t)k);
-  std::vector<int64_t> hi((size_t)k);
+  rc = ensure_batch_select_ws(ix);
+  if (rc) return rc;
   for (int32_t b0 = 0; b0 < n_queries; b0 += group) {
     const int nb = std::min(group, n_queries - b0);
     std::fill(hq.begin(), hq.end(), (uint16_t)0);
@@ -1509,20 +1518,23 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
     rc = launch_maxsim_batch(a, ix->stream);
     if (rc) return rc;
     MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
+    // the group's selections in one chain of launches (grid.y = query), one read-back, one synchronisation
+    rc = launch_topk_batch(ix->d_bscores, ix->cfg.capacity_pages, n, k, nullptr, 0, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bout_s,
+                           ix->d_bout_id, k, nb, ix->stream);
+    if (rc) return rc;
+    MV_HIP(hipEventRecord(ix->ev[2], ix->stream));
+    MV_HIP(hipMemcpyAsync(ix->h_bout_s, ix->d_bout_s, (size_t)nb * k * 4, hipMemcpyDeviceToHost, ix->stream));
+    MV_HIP(hipMemcpyAsync(ix->h_bout_id, ix->d_bout_id, (size_t)nb * k * 8, hipMemcpyDeviceToHost, ix->stream));
+    MV_HIP(hipStreamSynchronize(ix->stream));
     for (int b = 0; b < nb; ++b) {
-      rc = launch_topk(ix->d_bscores + (size_t)b * ix->cfg.capacity_pages, n, k, nullptr, ix->cfg.id_base, ix->d_topk_ws, ix->d_out_s,
-                       ix->d_out_id, ix->stream);
-      if (rc) return rc;
-      MV_HIP(hipMemcpyAsync(hs.data(), ix->d_out_s, (size_t)k * 4, hipMemcpyDeviceToHost, ix->stream));
-      MV_HIP(hipMemcpyAsync(hi.data(), ix->d_out_id, (size_t)k * 8, hipMemcpyDeviceToHost, ix->stream));
-      MV_HIP(hipStreamSynchronize(ix->stream));
+      const float* hs = ix->h_bout_s + (size_t)b * k;
+      const int64_t* hi = ix->h_bout_id + (size_t)b * k;
       int32_t m = 0;
       while (m < k && hi[m] >= 0) ++m;
-      memcpy(out_scores + (size_t)(b0 + b) * k, hs.data(), (size_t)m * 4);
-      memcpy(out_ids + (size_t)(b0 + b) * k, hi.data(), (size_t)m * 8);
+      memcpy(out_scores + (size_t)(b0 + b) * k, hs, (size_t)m * 4);
+      memcpy(out_ids + (size_t)(b0 + b) * k, hi, (size_t)m * 8);
       out_n[b0 + b] = m;
     }
-    MV_HIP(hipEventRecord(ix->ev[2], ix->stream));
     if (stats) {
       MV_HIP(hipEventSynchronize(ix->ev[2]));
       float ms_scan = 0, ms_sel = 0;
