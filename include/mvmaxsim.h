@@ -117,7 +117,9 @@ typedef enum {
   MV_OPT_FDE_BATCH_VARIANT = 12  /* mv_query_topk_batch in the FDE modes: 0 = batched pipeline (default): up to 32 queries per pass
                                     over the FDE slab (bf16 MFMA, query FDE as bf16 hi + lo), batched selection, every query's
                                     candidates reranked in one launch, one read-back; 1 = query by query; 2 = as 0 with the query
-                                    FDE rounded to bf16 (one MFMA per fragment: -13 % pass time, coarse scores within ~2e-3) */
+                                    FDE rounded to bf16 (one MFMA per fragment: -13 % pass time, coarse scores within ~2e-3);
+                                    3 = as 0 with one page tile per query fragment (the first form of the coarse kernel; the
+                                    default walks a workgroup's tiles in pairs: same scores, half the fragment traffic) */
 } mv_option;
 
 MV_API const char* mv_last_error(void);

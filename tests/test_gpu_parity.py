@@ -683,6 +683,15 @@ def test_fde_batched_coarse_scan_matches_the_single_query_scan(mv, n, stride):
                     assert len(set(i.tolist()) & set(wi.tolist())) >= len(wi) - 2  # near-ties may swap at the cut
                     full = ix.score_all(queries[b], mode="fde", allow=al)
                     np.testing.assert_allclose(s, full[i], rtol=1e-4, atol=1e-6)  # every returned id carries ITS score
+    # MV_OPT_FDE_BATCH_VARIANT = 3: one page tile per query fragment (the default walks a workgroup's tiles in pairs): same
+    # tile -> workgroup map, same order of the K chunks and of the partial sums -> the same scores bit for bit
+    kk = min(64, n)
+    ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, 0)
+    paired = ix.query_batch(queries, kk, mode="fde", allows=per_q, n_docs=n_docs)
+    ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, 3)
+    single_tile = ix.query_batch(queries, kk, mode="fde", allows=per_q, n_docs=n_docs)
+    for (s0, i0), (s3, i3) in zip(paired, single_tile):
+        assert i0.tolist() == i3.tolist() and s0.tolist() == s3.tolist()
     # MV_OPT_FDE_BATCH_VARIANT = 2: the query FDE rounded to bf16 (no lo term) -- the slab's own precision
     ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, 2)
     kk = min(10, n)

@@ -18,9 +18,9 @@ def main():
     ix.fill_synthetic(1234, 0, n)
     out_dim = ix.fde_config.output_dim
     qs = [synth_rows(4321, j, 32) for j in range(32)]
-    hi_only = len(sys.argv) > 2 and sys.argv[2] == "hi_only"  # MV_OPT_FDE_BATCH_VARIANT = 2: query FDE rounded to bf16
-    ix.set_option(L.MV_OPT_FDE_BATCH_VARIANT, 2 if hi_only else 0)
-    out = {"pages": n, "hi_only": hi_only}
+    form = sys.argv[2] if len(sys.argv) > 2 else "default"  # MV_OPT_FDE_BATCH_VARIANT: hi_only = 2 (query FDE rounded to bf16), single_tile = 3
+    ix.set_option(L.MV_OPT_FDE_BATCH_VARIANT, {"default": 0, "hi_only": 2, "single_tile": 3}[form])
+    out = {"pages": n, "form": form}
     for B in (16, 32):
         for _ in range(5):
             ix.query_batch(qs[:B], 10, mode="fde")
