@@ -266,6 +266,9 @@ class MvIndex:
     def query_batch(self, queries: Sequence[Any], k: int, mode: str = "float", allow: Optional[np.ndarray] = None,
                     want_stats: bool = False, allows: Optional[Sequence[Optional[np.ndarray]]] = None, n_docs: int = 0):
         """Top-k of several queries in one slab pass.  -> list of (scores, ids) per query [, QueryStats].
+        mode "float": the batched MFMA MaxSim scan (<= 512 query rows per pass); "fde_then_float" / "fde": the batched FDE
+        pipeline (one pass over the FDE slab per 32 queries, every query's candidates reranked exactly, same results as
+        query()); other modes are served query by query inside the library.
         Queries may have different lengths: they are zero-padded to the longest (a zero row contributes 0).
         `allow` = one doc bitmap for all queries; `allows` = one bitmap (or None = everything) PER query
         (pass n_docs = number of document ordinals in use so an unfiltered query's all-ones bitmap covers them)."""
