@@ -194,19 +194,33 @@ def main(argv: Optional[List[str]] = None) -> None:
     ap.add_argument("--capacity-pages", type=int, default=250_000)
     ap.add_argument("--stride-rows", type=int, default=1040)
     ap.add_argument("--devices", default="", help="comma separated GPU ordinals for the sharded providers (default: all)")
-    ap.add_argument("--load", default="", help="checkpoint directory to resume from")
+    ap.add_argument("--load", default="", help="checkpoint directory (store.save) to resume from; capacity / stride / mode come from the checkpoint")
+    ap.add_argument("--batch-window-ms", type=float, default=0.0,
+                    help="coalesce concurrent query_similar requests arriving within this window into one batched slab pass "
+                         "(0 = off; 0.3-1.0 for many concurrent clients: a lone request pays the window)")
+    ap.add_argument("--max-batch", type=int, default=32, help="largest coalesced batch")
     a = ap.parse_args(argv)
     import uvicorn
 
+    store = build_store(a)
+    uvicorn.run(create_app(store, os.environ.get("MORPHIK_STORE_API_KEY")), host=a.host, port=a.port, log_level="info")
+
+
+def build_store(a: Any) -> Any:
+    """The store the server owns: a fresh one of the requested provider, or the same class resumed from a checkpoint."""
     from .store import create_store
 
-    kw: Dict[str, Any] = dict(capacity_pages=a.capacity_pages, stride_rows=a.stride_rows)
+    opts: Dict[str, Any] = dict(batch_window_ms=a.batch_window_ms, max_batch=a.max_batch)
     if a.devices:
-        kw["devices"] = [int(x) for x in a.devices.split(",")]
-    store = create_store(a.provider, **kw)
-    if not store.initialize():
+        opts["devices"] = [int(x) for x in a.devices.split(",")]
+    proto = create_store(a.provider, capacity_pages=a.capacity_pages, stride_rows=a.stride_rows, **opts)  # allocates nothing yet
+    if a.load:
+        if not hasattr(proto, "devices"):
+            opts.pop("devices", None)  # only the sharded stores take a device list
+        return type(proto).load(a.load, **opts)  # raises loudly when the checkpoint does not fit / is inconsistent
+    if not proto.initialize():
         raise SystemExit("store_server: the MI355X store could not be initialised (no GPU / slab does not fit)")
-    uvicorn.run(create_app(store, os.environ.get("MORPHIK_STORE_API_KEY")), host=a.host, port=a.port, log_level="info")
+    return proto
 
 
 if __name__ == "__main__":

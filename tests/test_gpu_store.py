@@ -153,6 +153,28 @@ def test_request_coalescing_on_the_real_index():
         np.testing.assert_allclose([c.score for c in g], [c.score for c in w], rtol=1e-5)
 
 
+def test_owner_server_resumes_from_a_checkpoint_with_request_coalescing(tmp_path):
+    """store_server --load <dir> --batch-window-ms: the process that owns the slab comes back from store.save() with the same
+    answers, and its coalescer is on."""
+    import argparse
+
+    from morphik_core_amd import store_server
+    from tests import store_scenarios as sc2
+
+    rng = np.random.default_rng(6)
+    chunks = sc2.make_chunks(rng, n_docs=4, chunks_per_doc=3)
+    s = _store("fde_then_float")
+    sc2.run(s.store_embeddings(chunks, app_id="app-x"))
+    want = sc2.run(s.query_similar(chunks[5].embedding, k=3, app_id="app-x"))
+    s.save(str(tmp_path))
+    a = argparse.Namespace(provider="mi355x_fast", capacity_pages=1, stride_rows=16, devices="", load=str(tmp_path), batch_window_ms=20.0, max_batch=8)
+    r = store_server.build_store(a)
+    assert r.batch_window_s == 0.02 and r.max_batch == 8 and r.capacity_pages == s.capacity_pages
+    got = sc2.run(r.query_similar(chunks[5].embedding, k=3, app_id="app-x"))
+    assert [(c.document_id, c.chunk_number, c.score) for c in got] == [(c.document_id, c.chunk_number, c.score) for c in want]
+    assert r.coalesced_batches == [1]
+
+
 def test_request_coalescing_on_the_fast_store_rides_the_batched_fde_pipeline():
     """Concurrent query_similar calls on the FDE ("fast") store: one pass over the FDE slab for the coalesced requests
     (mv_query_topk_batch), each with its own k (requests share a pass only with requests of the same k: the candidate
