@@ -22,6 +22,8 @@ libmvmaxsim.so inside the owner.
 # (no `from __future__ import annotations` here: FastAPI resolves the handler annotations at decoration time)
 
 import argparse
+import asyncio
+import hmac
 import io
 import json
 import logging
@@ -58,7 +60,7 @@ def create_app(store: Any, api_key: Optional[str] = None):
     app = FastAPI(title="mi355x-multivector-store")
 
     def auth(authorization: Optional[str]) -> None:
-        if api_key and authorization != f"Bearer {api_key}":
+        if api_key and not hmac.compare_digest((authorization or "").encode(), f"Bearer {api_key}".encode()):
             raise HTTPException(status_code=401, detail="invalid api key")
 
     @app.get("/health")
@@ -119,15 +121,33 @@ class MI355XRemoteMultiVectorStore(BaseVectorStore):
         self._headers = {"Authorization": f"Bearer {api_key}"} if api_key else {}
         self._timeout = timeout_s
         self._last_store_metrics: Dict[str, Any] = {}
+        self._clients: Dict[int, Any] = {}  # one keep-alive client per event loop (a request costs no connection set-up)
 
-    async def _post(self, path: str, *, content: Optional[bytes] = None, json_body: Optional[Dict[str, Any]] = None) -> Dict[str, Any]:
+    def _client(self):
         import httpx
 
-        async with httpx.AsyncClient(timeout=self._timeout) as client:
-            if content is not None:
-                r = await client.post(self.url + path, content=content, headers={**self._headers, "Content-Type": "application/octet-stream"})
-            else:
-                r = await client.post(self.url + path, json=json_body, headers=self._headers)
+        loop = asyncio.get_running_loop()
+        c = self._clients.get(id(loop))
+        if c is None or c.is_closed:
+            if len(self._clients) > 8:  # loops come and go (asyncio.run per call in scripts and tests)
+                self._clients.clear()
+            c = self._clients[id(loop)] = httpx.AsyncClient(timeout=self._timeout, limits=httpx.Limits(max_keepalive_connections=64, max_connections=256))
+        return c
+
+    async def aclose(self) -> None:
+        for c in list(self._clients.values()):
+            try:
+                await c.aclose()
+            except Exception:  # noqa: BLE001 -- a client of a finished loop
+                pass
+        self._clients.clear()
+
+    async def _post(self, path: str, *, content: Optional[bytes] = None, json_body: Optional[Dict[str, Any]] = None) -> Dict[str, Any]:
+        client = self._client()
+        if content is not None:
+            r = await client.post(self.url + path, content=content, headers={**self._headers, "Content-Type": "application/octet-stream"})
+        else:
+            r = await client.post(self.url + path, json=json_body, headers=self._headers)
         if r.status_code != 200:
             raise RuntimeError(f"store server {path} -> {r.status_code}: {r.text[:300]}")
         return r.json()
