@@ -761,6 +761,31 @@ def test_fde_batched_pipeline_equals_query_by_query(mv, slab):
     ix.close()
 
 
+def test_fde_batched_pipeline_fallback_branches(mv):
+    """The branches of the batched FDE pipeline that do NOT take the one-launch rerank: queries longer than 128 rows (one
+    rerank launch per query, in passes), a non-default float kernel variant, and an fp8-only index with queries longer than
+    64 rows (served query by query) -- all must equal the single-query pipeline."""
+    from morphik_core_amd import _lib
+
+    N, stride = 900, 48
+    for kind, nq_rows in (("bf16_long", 130), ("bf16_variant3", 20), ("fp8_long", 70)):
+        ix = _idx(mv, capacity_pages=N, stride_rows=stride, with_fde=True, with_float=kind != "fp8_long", with_fp8=kind == "fp8_long")
+        ix.fill_synthetic(1234, 0, N, pages_per_doc=2)
+        ix.remove_doc(3)
+        if kind == "bf16_variant3":
+            ix.set_option(_lib.MV_OPT_MAXSIM_VARIANT, 3)
+        ix.set_option(_lib.MV_OPT_FDE_COARSE_N, 200)
+        queries = [orc.synth_rows(4321, b, 0, nq_rows - (b % 3)) for b in range(9)]
+        got = ix.query_batch(queries, 6, mode="fde_then_float")
+        for (s, i), q in zip(got, queries):
+            ws, wi = ix.query(q, 6, mode="fde_then_float")
+            common = set(i.tolist()) & set(wi.tolist())
+            assert len(common) >= 5, kind
+            ds, dw = dict(zip(i.tolist(), s.tolist())), dict(zip(wi.tolist(), ws.tolist()))
+            assert all(ds[c] == dw[c] for c in common), kind
+        ix.close()
+
+
 @pytest.mark.parametrize("bvariant", [0, 1, 2, 3])  # auto (page-split <= 128 rows, row-split above), 32x32x16 / 8 waves, round-1 pipeline, row-split always
 @pytest.mark.parametrize("stride,nrows", [(1024, 1024), (1024, 1000), (208, 200), (64, 50), (16, 7)])
 def test_batched_queries_equal_single_queries_and_oracle(mv, stride, nrows, bvariant):
