@@ -204,7 +204,8 @@ MV_API int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_
 /* Top-k of a BATCH of queries in one pass over the slab (score_multi_vector takes a list of queries:
  * fast_multivector_store.py:553-555 passes [query_embedding]; a serving process batches concurrent requests).
  *   q          host buffer, n_queries x n_q_rows x dim (every query padded to n_q_rows with zero rows -- a zero
- *              query row contributes exactly 0, the reference's own padding rule)
+ *              query row contributes exactly 0, the reference's own padding rule; NOT in MV_MODE_BINARY, where SQL
+ *              max_sim scores a row of zero bits like any other: there every query must have exactly n_q_rows rows)
  *   allow_bits n_allow_words words shared by all queries (allow_per_query = 0) or n_queries bitmaps of n_allow_words
  *              words back to back (allow_per_query = 1: every request keeps its own doc_ids / auth filter)
  *   out_*      n_queries x k entries (row b = results of query b), out_n[b] = results of query b

@@ -274,6 +274,14 @@ class MvIndex:
         (pass n_docs = number of document ordinals in use so an unfiltered query's all-ones bitmap covers them)."""
         rows = [as_rows(q) for q in queries]
         nmax = max(a.shape[0] for a, _ in rows)
+        if mode == "binary" and any(a.shape[0] != nmax for a, _ in rows):
+            # SQL max_sim scores a row of zero bits like any other row, so zero padding would change the answer: queries of
+            # different lengths go one by one (the library serves this mode query by query anyway)
+            out = []
+            for j, q in enumerate(queries):
+                a = allow if allows is None else allows[j]
+                out.append(self.query(q, k, mode=mode, allow=None if a is None else np.ascontiguousarray(a, dtype=np.uint32)))
+            return (out, QueryStats.from_c(QueryStatsC())) if want_stats else out
         code = MV_BF16 if all(c == MV_BF16 for _, c in rows) else MV_F32
         blk = np.zeros((len(rows), nmax, 128), np.uint16 if code == MV_BF16 else np.float32)
         for i, (a, c) in enumerate(rows):

@@ -39,6 +39,9 @@ class ShardedIndex:
 
     # -- lifecycle
     def close(self) -> None:
+        if getattr(self, "_pool", None) is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
         if getattr(self, "comm", None) is not None:
             self.comm.close()
             self.comm = None
@@ -127,13 +130,37 @@ class ShardedIndex:
     def query(self, q: Any, k: int, mode: str = "float", allow: Optional[np.ndarray] = None, want_stats: bool = False):
         return self.comm.query(q, k, mode=mode, allow=allow, want_stats=want_stats)
 
+    _SINGLE_STAGE = ("float", "float_fp8", "binary", "fde")  # one scan + top-k: the merge of per-shard top-k lists is exact
+
     def query_batch(self, queries: Sequence[Any], k: int, mode: str = "float", allow: Optional[np.ndarray] = None, want_stats: bool = False,
                     allows: Optional[Sequence[Optional[np.ndarray]]] = None, n_docs: int = 0):
-        """Coalesced requests on a sharded store: one communicator query each (the shards already run concurrently)."""
+        """Coalesced requests on a sharded store.
+        Single-stage modes: every shard runs the WHOLE batch through its own mv_query_topk_batch (one slab pass per shard for
+        all requests; the shards run side by side, one host thread each -- the library releases the GIL), and the per-shard
+        top-k lists of a request are merged with the communicator's rule (score desc, ties by ascending global id), which
+        is the single-index order.  The two-stage FDE pipeline keeps its GLOBAL candidate rule (the coarse top-n is taken over
+        all shards before the rerank), so its requests go through the communicator one by one."""
+        if mode not in self._SINGLE_STAGE or len(queries) < 2:
+            out = []
+            for j, q in enumerate(queries):
+                a = allow if allows is None else allows[j]
+                out.append(self.comm.query(q, k, mode=mode, allow=None if a is None else np.asarray(a, np.uint32)))
+            return out
+        if getattr(self, "_pool", None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            self._pool = ThreadPoolExecutor(max_workers=self.n_shards, thread_name_prefix="mv-shard")
+
+        def run(shard):
+            return shard.query_batch(queries, k, mode=mode, allow=allow, allows=allows, n_docs=n_docs)
+
+        per_shard = list(self._pool.map(run, self.shards))
         out = []
-        for j, q in enumerate(queries):
-            a = allow if allows is None else allows[j]
-            out.append(self.comm.query(q, k, mode=mode, allow=None if a is None else np.asarray(a, np.uint32)))
+        for j in range(len(queries)):
+            sc = np.concatenate([np.asarray(per_shard[r][j][0], np.float32) for r in range(self.n_shards)])
+            ids = np.concatenate([np.asarray(per_shard[r][j][1], np.int64) for r in range(self.n_shards)])
+            order = np.lexsort((ids, -sc.astype(np.float64)))[: int(k)]
+            out.append((sc[order], ids[order]))
         return out
 
     # -- persistence: one file per shard next to `path`

@@ -226,6 +226,42 @@ def test_shard_comm_equals_single_index_all_modes(R, transport):
     one.close()
 
 
+def test_sharded_index_batch_runs_every_shard_batched_and_merges_exactly():
+    """ShardedIndex.query_batch in the single-stage modes: each shard serves the whole batch through mv_query_topk_batch (a
+    host thread per shard), merged per request with the communicator's rule == the communicator's answers."""
+    from morphik_core_amd.index import allow_bitmap
+    from morphik_core_amd.shard_index import ShardedIndex
+
+    stride = 32
+    ix = ShardedIndex(capacity_pages=390, stride_rows=stride, devices=[0, 0, 0], with_float=True, with_binary=True, with_fde=True, with_fp8=True,
+                      transport="host")
+    base = _ragged_pages(40, lo=4, span=27, seed=5)
+    for b in range(12):  # twelve batches spread over the shards; every fourth page repeats -> exact ties across shards
+        pages = [base[(b * 7 + i) % 40] if i % 4 == 0 else orc.synth_rows(23, b * 30 + i, 0, 4 + (i * 5) % 28) for i in range(30)]
+        ix.add(pages, doc_ordinals=[(b * 30 + i) % 13 for i in range(30)])
+    ix.remove_page(ix.shards[1].id_base + 3)
+    queries = [orc.synth_rows(4321, 60 + j, 0, 12 + j) for j in range(6)]
+    allows = [None, allow_bitmap([0, 2, 4, 5]), None, allow_bitmap([1, 3, 12]), allow_bitmap([7]), None]
+    for mode in ("float", "float_fp8", "binary", "fde"):
+        got = ix.query_batch(queries, 9, mode=mode, allows=allows, n_docs=13)
+        for (s, i), q, a in zip(got, queries, allows):
+            ws, wi = ix.query(q, 9, mode=mode, allow=a)
+            if mode == "fde":  # the batched coarse scan carries the query FDE as bf16 hi + lo: scores to ~1e-5
+                np.testing.assert_allclose(s, ws, rtol=1e-4, atol=1e-6)
+                assert len(set(i.tolist()) & set(wi.tolist())) >= 7
+            elif mode == "float":  # the batched MFMA scan sums in another order than the single-query kernel (~1e-7)
+                np.testing.assert_allclose(s, ws, rtol=1e-5)
+                assert i.tolist() == wi.tolist() or len(set(i.tolist()) & set(wi.tolist())) >= 8
+            else:  # served by the single-query kernels inside the library: identical
+                assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist(), mode
+    # the two-stage pipeline keeps its global candidate rule: through the communicator, request by request
+    got = ix.query_batch(queries[:3], 5, mode="fde_then_float")
+    for (s, i), q in zip(got, queries[:3]):
+        ws, wi = ix.query(q, 5, mode="fde_then_float")
+        assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist()
+    ix.close()
+
+
 def test_shard_comm_rccl_on_one_device_is_refused_loudly():
     from morphik_core_amd import MvError
     from morphik_core_amd.index import ShardComm

@@ -340,6 +340,28 @@ def test_sharded_store_random_ops_match_the_model(R, mode):
     sc.run(sc.scenario_random_ops_against_model(_sharded(R, mode=mode), seed=R, n_ops=50, mode=mode, capacity=40))
 
 
+def test_sharded_index_batch_merges_per_shard_topk_like_the_communicator():
+    """ShardedIndex.query_batch (single-stage modes): every shard serves the whole batch, the per-shard lists are merged with
+    the communicator's rule -> exactly the communicator's (= single index) answers, ties and per-request filters included."""
+    from morphik_core_amd.index import allow_bitmap
+    from morphik_core_amd.shard_index import ShardedIndex
+    from tests.fake_index import OracleComm
+
+    rng = np.random.default_rng(11)
+    ix = ShardedIndex(capacity_pages=48, stride_rows=16, devices=[0, 0, 0], index_cls=OracleIndex, comm_cls=OracleComm)
+    base = [sc.rand_emb(rng, 6) for _ in range(8)]
+    for b in range(6):  # six batches of five pages; duplicates give exact ties across shards
+        ix.add([base[(b + i) % 8] for i in range(5)], doc_ordinals=[(b * 5 + i) % 7 for i in range(5)])
+    queries = [sc.rand_emb(rng, 4) for _ in range(5)]
+    allows = [None, allow_bitmap([0, 2, 4]), allow_bitmap([1, 3]), None, allow_bitmap([6])]
+    for mode in ("float", "binary"):
+        got = ix.query_batch(queries, 7, mode=mode, allows=allows, n_docs=7)
+        for (s, i), q, a in zip(got, queries, allows):
+            ws, wi = ix.query(q, 7, mode=mode, allow=a)
+            assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist(), mode
+    ix.close()
+
+
 def test_sharded_store_equals_single_store_and_spreads_the_pages():
     rng = np.random.default_rng(21)
     chunks = sc.make_chunks(rng, n_docs=6, chunks_per_doc=3)
