@@ -251,3 +251,28 @@ def test_fp8_quantised_scores_track_fp32_scores():
     hi, lo, fac = orc.fp8_query_prep(q)
     rec = (orc.e4m3_decode(hi) + orc.e4m3_decode(lo) / 16.0) * fac[:, None]
     assert np.max(np.abs(rec - q) / np.abs(q).max(axis=1, keepdims=True)) < 2.0**-7
+
+
+def test_bf16_hi_lo_split_of_the_query_fde_bounds_the_batched_coarse_scores():
+    """The batched FDE coarse scan (csrc/mv_fde.hip, fde_scan_batch2_kernel) feeds the fp32 query FDE to the bf16 MFMA as
+    hi = bf16(x), lo = bf16(x - hi).  hi + lo keeps 16 mantissa bits (|x - hi - lo| <= 2^-17 |x|), so its coarse scores sit
+    within ~1e-5 of the fp32-query scan's on the same bf16 slab -- the bound the GPU tests assert at 1e-4."""
+    rng = np.random.default_rng(0)
+    cfg = orc.FdeConfig.reference_default()
+    q = rng.standard_normal((32, 128)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    fq = orc.fde_encode(cfg, q, True).astype(np.float32)
+    hi = orc.bf16_to_f32(orc.f32_to_bf16(fq))
+    lo = orc.bf16_to_f32(orc.f32_to_bf16(fq - hi))
+    nz = fq != 0
+    assert np.all(np.abs(fq - hi - lo)[nz] <= np.abs(fq[nz]) * 2.0 ** -16)
+    pages = rng.standard_normal((64, 40, 128)).astype(np.float32)
+    pages /= np.linalg.norm(pages, axis=2, keepdims=True)
+    slab = orc.bf16_to_f32(orc.f32_to_bf16(np.stack([orc.fde_encode(cfg, p, False) for p in pages])))
+    exact = slab.astype(np.float64) @ fq.astype(np.float64)
+    split = slab.astype(np.float64) @ (hi.astype(np.float64) + lo.astype(np.float64))
+    hi_only = slab.astype(np.float64) @ hi.astype(np.float64)
+    scale = np.abs(exact).max()
+    assert np.abs(split - exact).max() <= 2e-5 * scale          # MV_OPT_FDE_BATCH_VARIANT = 0 (default)
+    assert np.abs(hi_only - exact).max() <= 5e-3 * scale        # = 2: the query at the slab's own precision
+    assert np.abs(hi_only - exact).max() > np.abs(split - exact).max()
