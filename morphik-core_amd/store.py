@@ -101,8 +101,13 @@ class MI355XMultiVectorStore(BaseVectorStore):
         # request coalescing (modes "float" and "fde_then_float"): concurrent query_similar calls arriving within
         # batch_window_ms are scored in ONE slab pass (batched MFMA MaxSim scan / batched FDE pipeline: up to 32 requests per
         # pass over the FDE slab, every request's candidates reranked exactly), each keeping its own doc_ids filter and k
+        # batch_window_ms > 0: a timer window (a lone request pays it); batch_window_ms < 0: ADAPTIVE (group commit) -- a
+        # request that finds the index idle is dispatched at once, requests arriving while a scan is in flight ride the next
+        # pass together: no added latency when idle, natural batches under load
         self.batch_window_s = float(batch_window_ms) / 1e3
         self.max_batch = int(max_batch)
+        self._inflight = 0
+        self._flush_scheduled = False
         # The API accepts min_score (core/models/request.py:138) and threads it through retrieve_chunks
         # (document_service.py:184) but the reference never applies it to multivector hits; None keeps that behaviour,
         # a number drops hits scoring below it
@@ -364,13 +369,15 @@ class MI355XMultiVectorStore(BaseVectorStore):
         return out
 
     def _flush(self) -> None:
-        items, self._pending = self._pending, []
+        self._flush_scheduled = False
+        items, self._pending = self._pending[: self.max_batch], self._pending[self.max_batch :]
         if self._flush_handle is not None:
             self._flush_handle.cancel()
             self._flush_handle = None
         if not items:
             return
         self.coalesced_batches.append(len(items))
+        self._inflight += 1
 
         async def run():
             try:
@@ -382,6 +389,10 @@ class MI355XMultiVectorStore(BaseVectorStore):
                 for _q, _k, _a, fut in items:
                     if not fut.done():
                         fut.set_exception(e)
+            finally:
+                self._inflight -= 1
+                if self._pending and self._inflight == 0 and self.batch_window_s < 0:
+                    self._flush()  # adaptive: everything that arrived during this pass rides the next one
 
         asyncio.ensure_future(run())
 
@@ -389,7 +400,11 @@ class MI355XMultiVectorStore(BaseVectorStore):
         loop = asyncio.get_running_loop()
         fut = loop.create_future()
         self._pending.append((q, k, allow, fut))
-        if len(self._pending) >= self.max_batch:
+        if self.batch_window_s < 0:  # adaptive: dispatch when idle (after the requests that are ready in this same loop tick)
+            if self._inflight == 0 and not self._flush_scheduled:
+                self._flush_scheduled = True
+                loop.call_soon(self._flush)
+        elif len(self._pending) >= self.max_batch:
             self._flush()
         elif self._flush_handle is None:
             self._flush_handle = loop.call_later(self.batch_window_s, self._flush)
@@ -433,7 +448,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
                 gen = self._generation
             if empty:
                 return []
-            if self.batch_window_s > 0 and self.mode in ("float", "fde_then_float"):
+            if self.batch_window_s != 0 and self.mode in ("float", "fde_then_float"):
                 scores, pages = await self._coalesced_query(q, int(k), allow)
             else:
                 scores, pages = await asyncio.to_thread(self._query_sync, q, int(k), allow)  # exceptions propagate (:819-822)

@@ -215,9 +215,10 @@ def main(argv: Optional[List[str]] = None) -> None:
     ap.add_argument("--stride-rows", type=int, default=1040)
     ap.add_argument("--devices", default="", help="comma separated GPU ordinals for the sharded providers (default: all)")
     ap.add_argument("--load", default="", help="checkpoint directory (store.save) to resume from; capacity / stride / mode come from the checkpoint")
-    ap.add_argument("--batch-window-ms", type=float, default=0.0,
-                    help="coalesce concurrent query_similar requests arriving within this window into one batched slab pass "
-                         "(0 = off; 0.3-1.0 for many concurrent clients: a lone request pays the window)")
+    ap.add_argument("--batch-window-ms", type=float, default=-1.0,
+                    help="request coalescing: < 0 (default) = adaptive -- a request that finds the GPU idle is dispatched at once, "
+                         "requests arriving while a scan is in flight share the next slab pass; > 0 = timer window in ms (a lone "
+                         "request pays it); 0 = off, one scan per request")
     ap.add_argument("--max-batch", type=int, default=32, help="largest coalesced batch")
     a = ap.parse_args(argv)
     import uvicorn

@@ -98,6 +98,47 @@ def test_concurrent_requests_are_coalesced_into_one_batched_scan():
             assert {c.document_id for c in g} <= set(d)
 
 
+def test_adaptive_coalescing_dispatches_a_lone_request_at_once_and_batches_what_arrives_meanwhile():
+    """batch_window_ms < 0 (group commit): no timer -- a request that finds the index idle goes out immediately (with the
+    requests that became ready in the same loop tick); requests arriving while a pass is in flight ride the next pass."""
+    import asyncio
+    import time
+
+    rng = np.random.default_rng(4)
+    chunks = sc.make_chunks(rng, n_docs=4, chunks_per_doc=3)
+    plain = _store(mode="float")
+    fused = _store(mode="float", batch_window_ms=-1, max_batch=8)
+    sc.run(plain.store_embeddings(chunks))
+    sc.run(fused.store_embeddings(chunks))
+    t0 = time.perf_counter()
+    lone = sc.run(fused.query_similar(chunks[0].embedding, k=2))
+    assert fused.coalesced_batches == [1] and time.perf_counter() - t0 < 5.0
+    assert [(c.document_id, c.chunk_number) for c in lone] == [(c.document_id, c.chunk_number) for c in sc.run(plain.query_similar(chunks[0].embedding, k=2))]
+    reqs = [(chunks[i].embedding, 1 + i % 4, None if i % 3 else [chunks[i].document_id, chunks[0].document_id]) for i in range(11)]
+
+    async def fire(store):
+        return await asyncio.gather(*(store.query_similar(q, k=k, doc_ids=d) for q, k, d in reqs))
+
+    fused.coalesced_batches.clear()
+    want, got = sc.run(fire(plain)), sc.run(fire(fused))
+    assert fused.coalesced_batches == [8, 3]  # one tick: 8 go out at once, the rest ride the pass that follows
+    for w, g in zip(want, got):
+        assert [(c.document_id, c.chunk_number, c.score) for c in g] == [(c.document_id, c.chunk_number, c.score) for c in w]
+
+    async def staggered():  # a second wave arrives while the first pass is in flight
+        first = [asyncio.ensure_future(fused.query_similar(q, k=k, doc_ids=d)) for q, k, d in reqs[:3]]
+        await asyncio.sleep(0)  # the first wave is dispatched
+        await asyncio.sleep(0)
+        second = [asyncio.ensure_future(fused.query_similar(q, k=k, doc_ids=d)) for q, k, d in reqs[3:9]]
+        return await asyncio.gather(*first, *second)
+
+    fused.coalesced_batches.clear()
+    got2 = sc.run(staggered())
+    assert sum(fused.coalesced_batches) == 9 and fused.coalesced_batches[0] == 3 and len(fused.coalesced_batches) <= 3
+    for w, g in zip(want[:9], got2):
+        assert [(c.document_id, c.chunk_number, c.score) for c in g] == [(c.document_id, c.chunk_number, c.score) for c in w]
+
+
 def test_concurrent_requests_on_the_fast_store_are_coalesced_by_k():
     """mode fde_then_float: coalesced requests share a batched call only with requests of the same k (the candidate rule
     min(10k, 75) depends on k), so every request gets exactly what a lone call returns."""
