@@ -13,7 +13,7 @@ function exists for callers that hold loose multi-vectors -- and so that the par
 """
 from __future__ import annotations
 
-from typing import Any, List, Optional, Sequence
+from typing import Any, Optional, Sequence
 
 import numpy as np
 

@@ -9,7 +9,7 @@ over xGMI, peer copies, or the host reference path); this file only routes write
 """
 from __future__ import annotations
 
-from typing import Any, Dict, List, Optional, Sequence, Tuple
+from typing import Any, Dict, Optional, Sequence, Tuple
 
 import numpy as np
 
