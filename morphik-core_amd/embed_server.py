@@ -8,13 +8,14 @@ HTTP 413 makes the client bisect its batch (:243-268).  Pointing `colpali_mode =
 on N MI355X with zero changes inside morphik-core: the reference's own round-robin fan-out and failover
 (:160-207) is the data parallelism ("replicas only").
 
-    python -m morphik_core_amd.embed_server --port 8765 [--model /path/to/colpali] [--device cuda:0]
+    python -m morphik_core_amd.embed_server --port 8765 [--family colpali|colqwen2] [--model /path/to/checkpoint] [--device cuda:0]
 """
 from __future__ import annotations
 
 import argparse
 import asyncio
 import base64
+import hmac
 import logging
 import os
 from typing import Any, List, Optional
@@ -50,7 +51,7 @@ def create_app(embedder: Any, api_key: Optional[str] = None):
 
     @app.post("/embeddings")
     async def embeddings(req: EmbedRequest, authorization: Optional[str] = Header(default=None)):  # noqa: B008
-        if api_key and authorization != f"Bearer {api_key}":
+        if api_key and not hmac.compare_digest((authorization or "").encode(), f"Bearer {api_key}".encode()):
             raise HTTPException(status_code=401, detail="invalid api key")
         if req.input_type not in ("image", "text"):
             raise HTTPException(status_code=422, detail="input_type must be 'image' or 'text'")
@@ -78,16 +79,26 @@ def main(argv: Optional[List[str]] = None) -> None:
     ap = argparse.ArgumentParser(description=__doc__.splitlines()[0])
     ap.add_argument("--host", default="0.0.0.0")
     ap.add_argument("--port", type=int, default=8765)
-    ap.add_argument("--model", default=None, help="ColPali checkpoint directory (default: random-init colpali-v1.2 architecture)")
+    ap.add_argument("--family", choices=["colpali", "colqwen2"], default="colpali",
+                    help="encoder family: colpali (ColPali-v1.2 / PaliGemma) or colqwen2 (ColQwen2 / ColQwen2.5, the reference's "
+                         "colpali_embedding_model.py:47-52 family: dynamic patch counts -> ragged pages; needs --model)")
+    ap.add_argument("--model", default=None, help="checkpoint directory (colpali default: random-init colpali-v1.2 architecture)")
     ap.add_argument("--preset", default="colpali-v1.2")
     ap.add_argument("--device", default=None)
     ap.add_argument("--batch-size", type=int, default=8)
     a = ap.parse_args(argv)
     import uvicorn
 
-    from .embedding import MI355XColpaliEmbeddingModel
+    if a.family == "colqwen2":
+        if not a.model:
+            raise SystemExit("embed_server: --family colqwen2 needs --model <checkpoint directory> (its processor ships with the checkpoint)")
+        from .colqwen_embedding import MI355XColQwen2EmbeddingModel
 
-    emb = MI355XColpaliEmbeddingModel(model_name_or_path=a.model, preset=a.preset, device=a.device, batch_size=a.batch_size)
+        emb: Any = MI355XColQwen2EmbeddingModel(model_name_or_path=a.model, device=a.device, batch_size=a.batch_size)
+    else:
+        from .embedding import MI355XColpaliEmbeddingModel
+
+        emb = MI355XColpaliEmbeddingModel(model_name_or_path=a.model, preset=a.preset, device=a.device, batch_size=a.batch_size)
     uvicorn.run(create_app(emb, os.environ.get("MORPHIK_EMBEDDING_API_KEY")), host=a.host, port=a.port, log_level="info")
 
 
