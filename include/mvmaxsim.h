@@ -106,7 +106,10 @@ typedef enum {
   MV_OPT_BATCH_VARIANT = 7,   /* batched float scan: -1 / 0 = auto (default): page-split form (wave-private rings, no barrier) up to 128
                                  query rows in the group, row-split workgroup above; both with transposed MFMA roles (one running
                                  max per query tile, v_max3).  3 = row-split form always, 1 = 32x32x16 MFMA / 8 waves,
-                                 2 = the round-1 two-stage pipeline (<= 384 rows); 1 and 2 are kept as cross-checks */
+                                 2 = the round-1 two-stage pipeline (<= 384 rows); 1 and 2 are kept as cross-checks.
+                                 5 / 6 = 32x32x16 MFMA with the transposed roles (round 3): 5 = four row groups of <= 128 query
+                                 rows, 6 = two row groups of <= 256 rows at ONE wave per SIMD (query fragments in AGPRs), the two
+                                 tiles of a ring chunk split over the other two waves */
   MV_OPT_FDE_ENCODE_VARIANT = 8, /* FDE encode: 1 = f32-MFMA kernel (default), 0 = scalar kernel; same partitions bit for bit */
   MV_OPT_FILTER_COMPACT_PCT = 9, /* doc filter allowing < this % of the documents: compact the allowed pages first and scan
                                     only those (default 25; 0 = always mask inside the scan) */
@@ -268,10 +271,12 @@ MV_API int mv_calibrate_read_bw(int device, int64_t bytes, int32_t iters, double
 /* Measured peaks for the roofline denominators, taken in the same process as the measurement:
  *   MV_CAL_READ_NT    streams `bytes` of device memory `iters` times in contiguous 16 KiB pieces with non-temporal
  *                     loads (the scan kernels' access pattern, no arithmetic)            -> *out in GB/s
- *   MV_CAL_MFMA_BF16  register-only v_mfma_f32_16x16x32_bf16 chains on every CU        -> *out in TFLOP/s
+ *   MV_CAL_MFMA_BF16  register-only v_mfma_f32_16x16x32_bf16 chains on every CU (pseudo-random operands of
+ *                     embedding magnitude, ~4 ms per launch: the sustained clock, not a burst) -> *out in TFLOP/s
+ *   MV_CAL_MFMA_BF16_32X32  the same with v_mfma_f32_32x32x16_bf16 (half the operand-register reads per flop) -> TFLOP/s
  *   MV_CAL_READ_LDSDMA the float scan's own transport with the arithmetic removed: non-temporal global_load_lds_dwordx4
  *                     into the 4-slot wave-private ring, four waves per 256 KiB piece     -> *out in GB/s */
-enum { MV_CAL_READ_NT = 1, MV_CAL_MFMA_BF16 = 2, MV_CAL_READ_LDSDMA = 3 };
+enum { MV_CAL_READ_NT = 1, MV_CAL_MFMA_BF16 = 2, MV_CAL_READ_LDSDMA = 3, MV_CAL_MFMA_BF16_32X32 = 4 };
 MV_API int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out);
 
 /* ---------------------------------------------------------------------------------------------------------------

@@ -1800,17 +1800,19 @@ int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out
     }
     if (buf) (void)hipFree(buf);
     if (sc) (void)hipFree(sc);
-  } else if (what == MV_CAL_MFMA_BF16) {
+  } else if (what == MV_CAL_MFMA_BF16 || what == MV_CAL_MFMA_BF16_32X32) {
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
-    const int blocks = ncu * 2, loop = 4096;  // 8 waves / CU
-    rc = launch_mfma_peak(blocks, 64, sink, nullptr);
+    const int shape = what == MV_CAL_MFMA_BF16_32X32 ? 1 : 0;
+    const int blocks = ncu * 2, loop = 1 << 16;  // 8 waves / CU; ~4 ms per launch: the clock settles at its sustained value
+    rc = launch_mfma_peak(blocks, loop, shape, sink, nullptr);  // warm-up of the same length
     (void)hipEventRecord(a_ev, nullptr);
-    for (int i = 0; i < iters && !rc; ++i) rc = launch_mfma_peak(blocks, loop, sink, nullptr);
+    for (int i = 0; i < iters && !rc; ++i) rc = launch_mfma_peak(blocks, loop, shape, sink, nullptr);
     (void)hipEventRecord(b_ev, nullptr);
     (void)hipEventSynchronize(b_ev);
     (void)hipEventElapsedTime(&ms, a_ev, b_ev);
-    const double flops = (double)blocks * 4 * loop * 8 * (2.0 * 16 * 16 * 32) * iters;
+    // per wave and iteration: 8 x (16x16x32) or 4 x (32x32x16) MFMAs = 131 072 flop either way
+    const double flops = (double)blocks * 4 * loop * (shape ? 4 * (2.0 * 32 * 32 * 16) : 8 * (2.0 * 16 * 16 * 32)) * iters;
     *out = ms > 0 ? flops / (ms * 1e-3) / 1e12 : 0.0;  // TFLOP/s
   } else {
     set_error("calibrate: unknown measurement %d", what);

@@ -19,6 +19,7 @@
 // Workgroups are persistent (grid = 2 per CU): the query fragments are loaded once, pages are taken round-robin.
 // Per page the row maxima go through LDS and thread b sums the rows of query b: scores[b][page].
 #include <algorithm>
+#include <type_traits>
 
 #include "mv_common.h"
 
@@ -735,6 +736,245 @@ __global__ __launch_bounds__(512, 2) void maxsim_batch32_kernel(BKArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Round 3: 32x32x16 MFMA with the TRANSPOSED roles of maxsim_batch_kernel.  A = 32 patches x 16 dims (from LDS),
+// B = 16 dims x 32 query tokens (registers, resident for the whole launch), D[row = patch][col = token]: lane l holds
+// token l & 31 and 16 of the tile's 32 patches (rows (i & 3) + 8 (i >> 2) + 4 (l >> 5) of accumulator register i), so
+// the running maximum over patches is ONE register per 32-token tile, fed by 8 v_max3_f32 per 8 MFMAs (one VALU op per
+// 32-cycle MFMA), and a page ends with ONE cross-half exchange per token tile.  Against the 16x16x32 form every byte
+// read from LDS feeds twice the flops and the matrix pipe reads half the operand registers per flop (the shape the
+// guide's micro-benchmark puts ~15 % above 16x16x32).  The round-1 32x32x16 kernel above (variant 1) has the
+// untransposed roles: 16 running maxima per tile and a 32-lane reduction per accumulator register.
+//
+// Work split: RS waves split the query rows (NT tiles of 32 tokens per wave), the other PS = 4 / RS-way split is over
+// the two 32-patch tiles of a 16 KiB ring chunk.  RS = 4: 128 rows per wave, two workgroups per CU (<= 256 VGPRs);
+// RS = 2: 256 rows per wave at ONE wave per SIMD (512-VGPR budget), every staged tile is read by two waves instead of
+// four.  The ring is the row-split kernel's (each wave DMAs one 16-row sub-tile of every chunk, XOR-swizzled image),
+// but the barrier runs ONE chunk ahead: the barrier at the top of iteration c publishes chunk c + 1, and a tile's
+// fragments are re-filled IN PLACE for the next tile while the last pair of token tiles still multiplies (register
+// b[kk] is dead once its last MFMA has issued) -- no LDS latency between tiles and no second fragment set.
+template <int NT, int RS, int S>
+__global__ __launch_bounds__(256, (RS == 4 && NT <= 3) ? 2 : 1) void maxsim_batch32t_kernel(BKArgs a) {
+  constexpr int PS = 4 / RS;
+  constexpr int LAG = PS == 1 ? 1 : 0;  // PS = 1: a wave still reads tile 1 of chunk c during iteration c, so the slot freed at its top is chunk c-1's
+  constexpr int ROWS = RS * NT * 32;
+  constexpr bool PEND = RS == 2;  // one wave per SIMD: the last group's folds ride behind the next tile's first MFMAs
+  constexpr int kTile32 = 2 * kTileBytes;  // 8 KiB = 32 patch rows
+  __shared__ __attribute__((aligned(16))) char lds[S * kChunkBytes + PS * ROWS * 4 + (ROWS / 16) * 4];
+  float* red = reinterpret_cast<float*>(lds + S * kChunkBytes);  // [PS][ROWS] token maxima of the current page
+  float* part = red + PS * ROWS;                                 // [ROWS / 16] sums of 16 rows
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n32 = lane & 31, h = lane >> 5;
+  const int rg = wave % RS, pg = wave / RS;
+
+  // query fragments (B operand): token row (rg * NT + m) * 32 + n32, dims kk * 16 + 8 h .. + 7
+  bf16x8 qb[NT][8];
+#pragma unroll
+  for (int m = 0; m < NT; ++m)
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+      qb[m][kk] = *reinterpret_cast<const bf16x8*>(a.q + ((size_t)((rg * NT + m) * 32 + n32)) * kDim + kk * 16 + h * 8);
+#pragma unroll
+  for (int m = 0; m < NT; ++m)
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      if (RS == 2) asm volatile("" : "+a"(qb[m][kk]));  // one wave per SIMD: the query fragments live in the AGPR half of the 512-entry file (MFMA reads them there)
+      else asm volatile("" : "+v"(qb[m][kk]));
+    }
+
+  int src_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int w = i * 4 + (lane >> 4);
+    src_off[i] = w * kRowBytes + (((lane & 15) ^ w) << 4) - i * 1024;
+  }
+  // A fragment of MFMA kk inside a 32-patch tile: patch n32 = 16-row sub-tile n32 >> 4, row n32 & 15, 16-byte chunk 2 kk + h
+  int rd_off[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) rd_off[kk] = (n32 >> 4) * kTileBytes + (n32 & 15) * kRowBytes + (((kk * 2 + h) ^ (n32 & 15)) << 4);
+
+  for (int64_t item = blockIdx.x; item < a.n; item += gridDim.x) {
+    const int64_t page = a.page0 + item;
+    if (bk_masked(a, page)) {  // block-uniform
+      if ((int)threadIdx.x < a.n_queries) a.scores[(size_t)threadIdx.x * a.score_stride + item] = -INFINITY;
+      continue;
+    }
+    const int nr = a.n_rows ? a.n_rows[page] : a.stride;
+    if (nr <= 0) {
+      if ((int)threadIdx.x < a.n_queries) a.scores[(size_t)threadIdx.x * a.score_stride + item] = 0.0f;
+      continue;
+    }
+    const int ntiles = (nr + 31) / 32;
+    const int nchunks = (nr + 63) / 64;
+    const char* pbase = a.slab + (size_t)page * (size_t)a.stride * kRowBytes;
+
+    auto issue = [&](int c) {  // wave w moves 16-row sub-tile w of chunk c
+      const char* tp = pbase + (size_t)(c * kChunkTiles + wave) * kTileBytes;
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
+      const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
+      const uint64_t tpu = ((uint64_t)hi << 32) | lo;
+      const uint32_t slot = __builtin_amdgcn_readfirstlane(
+          (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + (c % S) * kChunkBytes + wave * kTileBytes));
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %5\n\t"
+          "s_nop 4\n\t"
+          "global_load_lds_dwordx4 %1, %6 nt\n\t"
+          "global_load_lds_dwordx4 %2, %6 offset:1024 nt\n\t"
+          "global_load_lds_dwordx4 %3, %6 offset:2048 nt\n\t"
+          "global_load_lds_dwordx4 %4, %6 offset:3072 nt\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src_off[0]), "v"(src_off[1]), "v"(src_off[2]), "v"(src_off[3]), "s"(slot), "s"(tpu)
+          : "memory");
+    };
+    auto wait_chunks = [&](int ahead) {  // at most `ahead` whole chunks (4 DMA instructions each) of this wave may stay in flight
+      if (ahead >= 5) bk_wait_vmcnt<20>();
+      else if (ahead == 4) bk_wait_vmcnt<16>();
+      else if (ahead == 3) bk_wait_vmcnt<12>();
+      else if (ahead == 2) bk_wait_vmcnt<8>();
+      else if (ahead == 1) bk_wait_vmcnt<4>();
+      else bk_wait_vmcnt<0>();
+    };
+
+#pragma unroll
+    for (int c = 0; c < S - LAG; ++c)
+      if (c < nchunks) issue(c);
+
+    float mx[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) mx[m] = -INFINITY;
+
+    wait_chunks(min(S - 1 - LAG, nchunks - 1));
+    bk_barrier();  // chunk 0 visible
+    // Fragment addresses of tile t (tile base `tb` in LDS).  The last tile of a ragged page holds patches past n_rows:
+    // instead of masking 16 accumulator registers per token tile, the lanes of such patches read patch 0 of the tile
+    // (always valid) -- a duplicated patch cannot change a maximum -- so the tile body has ONE form and no masks.
+    int ra[8];
+    auto frag_addr = [&](int t, const char* tb) {
+      const int base = (int)(uintptr_t)(__attribute__((address_space(3))) const char*)tb;
+      if ((t + 1) * 32 > nr) {  // wave-uniform
+        const bool ok = t * 32 + n32 < nr;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) ra[kk] = base + (ok ? rd_off[kk] : (kk * 2 + h) << 4);
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) ra[kk] = base + rd_off[kk];
+      }
+    };
+    auto lds_frag = [&](int addr) {
+      typedef __attribute__((address_space(3))) const bf16x8 lds_frag_t;
+      return *(lds_frag_t*)(uintptr_t)(uint32_t)addr;  // a 32-bit LDS address -> ds_read_b128
+    };
+    bf16x8 b[8];
+    frag_addr(pg, lds + pg * kTile32);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) b[kk] = lds_frag(ra[kk]);
+
+    // One 32-patch tile against this wave's NT token tiles, in groups of two token tiles (two independent MFMA chains
+    // of 8).  Software pipeline: the v_max3 folds of a group's accumulators ride behind the NEXT group's MFMAs (one VALU
+    // op per MFMA; the last group's accumulators stay pending across the tile boundary and are folded behind the first
+    // group of the wave's next tile), and b[] is re-filled from ra[] (the wave's next tile) behind the last group's
+    // MFMAs.  The body is branch-free: one scheduling region.
+    constexpr int NG = (NT + 1) / 2;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][i] = -INFINITY;  // "tile -1": max-neutral
+    auto fold = [&](int m) {
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) mx[m] = fmaxf(fmaxf(mx[m], acc[m][i]), acc[m][i + 1]);  // v_max3_f32
+    };
+    auto tile = [&]() {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int m0 = 2 * g, m1 = 2 * g + 1 < NT ? 2 * g + 1 : 2 * g;
+        const bool two = 2 * g + 1 < NT;
+        const int pgp = (g + NG - 1) % NG;  // the group whose accumulators are folded behind this group's MFMAs
+        const int p0 = 2 * pgp, p1 = 2 * pgp + 1 < NT ? 2 * pgp + 1 : 2 * pgp;
+        const bool ptwo = 2 * pgp + 1 < NT;
+        f32x16 n0, n1;
+        f32x16 z;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) z[i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[kk], qb[m0][kk], kk == 0 ? z : n0, 0, 0, 0);
+          if (two) n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[kk], qb[m1][kk], kk == 0 ? z : n1, 0, 0, 0);
+          if (g == NG - 1) b[kk] = lds_frag(ra[kk]);
+        }
+        if (PEND || g > 0) {  // previous group: of this tile (g > 0) or of the wave's previous tile (g == 0)
+          fold(p0);
+          if (ptwo) fold(p1);
+        }
+        acc[m0] = n0;
+        if (two) acc[m1] = n1;
+        if (!PEND && g == NG - 1) {  // two waves per SIMD: the partner's MFMAs cover this fold; no accumulators live across tiles
+          fold(m0);
+          if (two) fold(m1);
+        }
+        // issue order: one VALU op behind every MFMA, the fragment re-fills spread over the last group
+#pragma unroll
+        for (int i = 0; i < (two ? 16 : 8); ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (PEND || g > 0) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          if (g == NG - 1 && (i % (two ? 2 : 1)) == (two ? 1 : 0)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // b[kk] is free after its second MFMA
+        }
+      }
+    };
+
+    for (int c = 0; c < nchunks; ++c) {
+      if (c + 1 < nchunks) {  // block-uniform: publish chunk c + 1, release the slot of chunk c - LAG
+        wait_chunks(min(c + S - 1 - LAG, nchunks - 1) - (c + 1));
+        bk_barrier();
+        if (c + S - LAG < nchunks) issue(c + S - LAG);
+      }
+      const char* cur = lds + (c % S) * kChunkBytes;
+      const char* nx = lds + ((c + 1) % S) * kChunkBytes;
+      if (PS == 1) {
+        const int t0 = 2 * c;
+        if (t0 + 1 < ntiles) frag_addr(t0 + 1, cur + kTile32);  // else: ra[] keeps pointing at a landed tile (the re-fill is unused)
+        tile();
+        if (t0 + 1 < ntiles) {
+          if (t0 + 2 < ntiles) frag_addr(t0 + 2, nx);
+          tile();
+        }
+      } else {
+        const int t = 2 * c + pg;
+        if (t < ntiles) {  // wave-uniform (no barrier inside)
+          if (t + 2 < ntiles) frag_addr(t + 2, nx + pg * kTile32);
+          tile();
+        }
+      }
+    }
+    if (PEND) {  // drain: the last group's accumulators of the wave's last tile
+      constexpr int l0 = 2 * (NG - 1);
+      fold(l0);
+      if (l0 + 1 < NT) fold(l0 + 1);
+    }
+
+    // token maxima: lanes l and l ^ 32 hold the two halves of the tile's patches
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      float v = mx[m];
+      v = fmaxf(v, __shfl_xor(v, 32));
+      if (h == 0) red[pg * ROWS + (rg * NT + m) * 32 + n32] = v;
+    }
+    __syncthreads();
+    const int rows_total = a.n_queries * a.rows_per_query;  // <= ROWS
+    if (PS == 2) {
+      for (int t = threadIdx.x; t < rows_total; t += 256) red[t] = fmaxf(red[t], red[ROWS + t]);
+      __syncthreads();
+    }
+    bk_write_scores(a, red, part, rows_total, page, item);
+    // the next page's first bk_barrier() orders these reads of red[] / part[] before their rewrite; its prologue DMAs
+    // only start after the __syncthreads() above, i.e. after every wave's last fragment read
+  }
+}
+
 template <int MTW>
 int launch_batch_mtw(const BKArgs& k, int grid, hipStream_t s) {
   // (Round 2 measured two further forms of this kernel on uniform corpora -- one DMA stream across page boundaries,
@@ -767,6 +1007,31 @@ int launch_maxsim_batch(const BatchArgs& a, hipStream_t s) {
     const int grid32 = (int)std::min<int64_t>(a.n, (int64_t)ncu);
     if (rows <= 256) hipLaunchKernelGGL((maxsim_batch32_kernel<1, 4>), dim3((unsigned)grid32), dim3(512), 0, s, k);
     else hipLaunchKernelGGL((maxsim_batch32_kernel<2, 4>), dim3((unsigned)grid32), dim3(512), 0, s, k);
+    MV_HIP(hipGetLastError());
+    return MV_OK;
+  }
+  if ((a.variant == 5 || a.variant == 6) && rows > 0) {  // transposed 32x32x16 forms (round 3)
+    if (a.variant == 5) {  // four row groups, two workgroups per CU
+      const int grid5 = (int)std::min<int64_t>(a.n, (int64_t)ncu * (rows > 384 ? 1 : 2));  // 4 token tiles per wave need > 256 registers: one workgroup per CU
+      switch ((rows + 127) / 128) {
+        case 1: hipLaunchKernelGGL((maxsim_batch32t_kernel<1, 4, 4>), dim3((unsigned)grid5), dim3(256), 0, s, k); break;
+        case 2: hipLaunchKernelGGL((maxsim_batch32t_kernel<2, 4, 4>), dim3((unsigned)grid5), dim3(256), 0, s, k); break;
+        case 3: hipLaunchKernelGGL((maxsim_batch32t_kernel<3, 4, 4>), dim3((unsigned)grid5), dim3(256), 0, s, k); break;
+        default: hipLaunchKernelGGL((maxsim_batch32t_kernel<4, 4, 4>), dim3((unsigned)grid5), dim3(256), 0, s, k); break;
+      }
+    } else {  // two row groups x two tile groups, one wave per SIMD
+      const int grid6 = (int)std::min<int64_t>(a.n, (int64_t)ncu);
+      switch ((rows + 63) / 64) {
+        case 1: hipLaunchKernelGGL((maxsim_batch32t_kernel<1, 2, 6>), dim3((unsigned)grid6), dim3(256), 0, s, k); break;
+        case 2: hipLaunchKernelGGL((maxsim_batch32t_kernel<2, 2, 6>), dim3((unsigned)grid6), dim3(256), 0, s, k); break;
+        case 3: hipLaunchKernelGGL((maxsim_batch32t_kernel<3, 2, 6>), dim3((unsigned)grid6), dim3(256), 0, s, k); break;
+        case 4: hipLaunchKernelGGL((maxsim_batch32t_kernel<4, 2, 6>), dim3((unsigned)grid6), dim3(256), 0, s, k); break;
+        case 5: hipLaunchKernelGGL((maxsim_batch32t_kernel<5, 2, 6>), dim3((unsigned)grid6), dim3(256), 0, s, k); break;
+        case 6: hipLaunchKernelGGL((maxsim_batch32t_kernel<6, 2, 6>), dim3((unsigned)grid6), dim3(256), 0, s, k); break;
+        case 7: hipLaunchKernelGGL((maxsim_batch32t_kernel<7, 2, 6>), dim3((unsigned)grid6), dim3(256), 0, s, k); break;
+        default: hipLaunchKernelGGL((maxsim_batch32t_kernel<8, 2, 6>), dim3((unsigned)grid6), dim3(256), 0, s, k); break;
+      }
+    }
     MV_HIP(hipGetLastError());
     return MV_OK;
   }

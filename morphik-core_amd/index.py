@@ -450,9 +450,10 @@ def calibrate_read_bw(bytes_: int = 8 << 30, iters: int = 5, device: int = 0) ->
 
 
 def calibrate(what: str, bytes_: int = 8 << 30, iters: int = 5, device: int = 0) -> float:
-    """Measured peaks (same process as the measurement): "read_nt" / "read_ldsdma" -> GB/s, "mfma_bf16" -> TFLOP/s."""
+    """Measured peaks (same process as the measurement): "read_nt" / "read_ldsdma" -> GB/s, "mfma_bf16" (16x16x32 chains) / "mfma_bf16_32x32" (32x32x16 chains) -> TFLOP/s."""
     g = C.c_double()
-    code = {"read_nt": _lib.MV_CAL_READ_NT, "mfma_bf16": _lib.MV_CAL_MFMA_BF16, "read_ldsdma": _lib.MV_CAL_READ_LDSDMA}[what]
+    code = {"read_nt": _lib.MV_CAL_READ_NT, "mfma_bf16": _lib.MV_CAL_MFMA_BF16, "read_ldsdma": _lib.MV_CAL_READ_LDSDMA,
+            "mfma_bf16_32x32": _lib.MV_CAL_MFMA_BF16_32X32}[what]
     check(lib().mv_calibrate(device, code, bytes_, iters, C.byref(g)))
     return float(g.value)
 

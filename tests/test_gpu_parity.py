@@ -786,7 +786,7 @@ def test_fde_batched_pipeline_fallback_branches(mv):
         ix.close()
 
 
-@pytest.mark.parametrize("bvariant", [0, 1, 2, 3])  # auto (page-split <= 128 rows, row-split above), 32x32x16 / 8 waves, round-1 pipeline, row-split always
+@pytest.mark.parametrize("bvariant", [0, 1, 2, 3, 5, 6])  # auto, 32x32x16 / 8 waves, round-1 pipeline, row-split always, transposed 32x32x16 (4 row groups / 2 row groups at one wave per SIMD)
 @pytest.mark.parametrize("stride,nrows", [(1024, 1024), (1024, 1000), (208, 200), (64, 50), (16, 7)])
 def test_batched_queries_equal_single_queries_and_oracle(mv, stride, nrows, bvariant):
     from morphik_core_amd import _lib
@@ -851,12 +851,12 @@ def test_batched_queries_on_a_uniform_corpus(mv, stride):
     for lens in ([32] * 5, [32] * 16, [48] * 10, [20, 32, 1, 17, 64, 33]):
         qs = [orc.synth_rows(4321, 70 + j, 0, L) for j, L in enumerate(lens)]
         res = {}
-        for bv in (0, 3):
+        for bv in (0, 3, 5, 6):
             ix.set_option(_lib.MV_OPT_BATCH_VARIANT, bv)
             res[bv] = ix.query_batch(qs, 9)
         for j, q in enumerate(qs):
             ws, wi = ix.query(q, 9)
-            for bv in (0, 3):
+            for bv in (0, 3, 5, 6):
                 s, i = res[bv][j]
                 assert i.tolist() == wi.tolist(), (stride, lens, bv, j)
                 np.testing.assert_allclose(s, ws, rtol=1e-5)

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--no-batch", action="store_true", help="skip the batched-query sweep")
     ap.add_argument("--batch-only", action="store_true", help="only the batched-query sweep (SQ counter passes)")
+    ap.add_argument("--batch-variants", default="", help="variant:B pairs, e.g. 0:16,6:16 (default: the full sweep)")
     a = ap.parse_args()
     from morphik_core_amd import _lib
     from morphik_core_amd.index import MvIndex, calibrate_read_bw, synth_rows
@@ -55,7 +56,14 @@ def main():
     # batched queries: one slab pass for B queries of 32 tokens (HBM-bound -> MFMA-bound as B grows)
     res["batch"] = {}
     # 0 = auto (page-split form <= 128 rows, transposed row-split form above), 3 = row-split always, 2 = round-1 pipeline, 1 = 32x32x16
-    for bv, B in ([] if a.no_batch else [(0, 1), (0, 2), (0, 4), (3, 4), (2, 4), (0, 8), (2, 8), (0, 12), (0, 16), (1, 16)]):
+    from morphik_core_amd.index import calibrate
+    if not a.no_batch:
+        res["mfma_calibration_TF"] = {"16x16x32": calibrate("mfma_bf16", 0, 5), "32x32x16": calibrate("mfma_bf16_32x32", 0, 5)}
+        print("mfma calibration", res["mfma_calibration_TF"], flush=True)
+    combos = [(0, 1), (0, 2), (0, 4), (5, 4), (6, 4), (3, 4), (0, 8), (5, 8), (6, 8), (0, 12), (6, 12), (0, 16), (5, 16), (6, 16), (1, 16)]
+    if a.batch_variants:
+        combos = [(int(v), int(b)) for v, b in (x.split(":") for x in a.batch_variants.split(","))]
+    for bv, B in ([] if a.no_batch else combos):
         ix.set_option(_lib.MV_OPT_BATCH_VARIANT, bv)
         qs = [synth_rows(4321, j, 32) for j in range(B)]
         ts = []
