@@ -40,7 +40,12 @@ typedef enum {
   MV_MODE_BINARY = 1,         /* sign-bit MaxSim == SQL max_sim(bit[],bit[]) */
   MV_MODE_FDE_THEN_FLOAT = 2, /* FDE coarse top-n_coarse -> exact float rerank (FastMultiVectorStore) */
   MV_MODE_FDE_ONLY = 3,       /* coarse FDE scores only (the TurboPuffer ANN stage) */
-  MV_MODE_FLOAT_FP8 = 4       /* exact float MaxSim over the e4m3 slab (BASELINE configs[4]; 128 B / patch row) */
+  MV_MODE_FLOAT_FP8 = 4,      /* exact float MaxSim over the e4m3 slab (BASELINE configs[4]; 128 B / patch row) */
+  MV_MODE_FP8_THEN_FLOAT = 5  /* e4m3 scan of every page -> top-n (MV_OPT_RERANK_N, default 128) -> exact bf16 re-score of the n
+                                 candidates from the index's exact tier (the bf16 slab in HBM, or the pinned-host tier of
+                                 MV_WITH_HOST_EXACT read by the rerank kernel itself over PCIe: n x 256 KiB, no staging copy
+                                 and no host round trip) -> top-k.  The fp8 scan's 0.3-1 % score noise reorders near-ties;
+                                 the exact tier restores the bf16 order among the candidates. */
 } mv_mode;
 
 /* Index feature flags (mv_config.flags). */
@@ -48,7 +53,11 @@ enum {
   MV_WITH_FLOAT = 1,  /* bf16 page slab (262 144 B / 1024-patch page) */
   MV_WITH_BINARY = 2, /* sign-bit slab   ( 16 384 B / page)            */
   MV_WITH_FDE = 4,    /* bf16 FDE slab   ( 20 480 B / page)            */
-  MV_WITH_FP8 = 8     /* e4m3 page slab  (131 072 B / page) + one power-of-two scale per page */
+  MV_WITH_FP8 = 8,    /* e4m3 page slab  (131 072 B / page) + one power-of-two scale per page */
+  MV_WITH_HOST_EXACT = 16 /* exact bf16 rows kept in PINNED HOST memory (262 144 B / page of host RAM, none of HBM), mapped
+                             into the device's address space: the exact tier of MV_MODE_FP8_THEN_FLOAT for a shard whose
+                             bf16 slab does not fit HBM beside its fp8 slab ("host-resident exact vectors
+                             with a gather of the candidates") */
 };
 
 /* fixed_dimensional_encoding.FixedDimensionalEncodingConfig as constructed at
@@ -117,6 +126,7 @@ typedef enum {
                                     repetition (default), 1 = the bulk f32-MFMA kernel, 0 = scalar kernel; same partitions bit for bit */
   MV_OPT_LONG_QUERY_VARIANT = 10, /* single query of > 64 rows over the whole slab: 1 = row-split workgroup of the batched scan
                                     (default), 0 = page-split kernel in passes of 128 rows */
+  MV_OPT_RERANK_N = 13,          /* MV_MODE_FP8_THEN_FLOAT: candidates re-scored exactly (1..1024, default 128) */
   MV_OPT_FDE_BATCH_VARIANT = 12  /* mv_query_topk_batch in the FDE modes: 0 = batched pipeline (default): up to 32 queries per pass
                                     over the FDE slab (bf16 MFMA, query FDE as bf16 hi + lo), batched selection, every query's
                                     candidates reranked in one launch, one read-back; 1 = query by query; 2 = as 0 with the query
@@ -166,7 +176,8 @@ MV_API int mv_index_remove_page(mv_index* ix, int64_t page);
  * Page ids change: the caller remaps whatever it keyed by page id.  *out_new_size = pages after compaction. */
 MV_API int mv_index_compact(mv_index* ix, int64_t* out_old_to_new, int64_t* out_new_size);
 
-/* Read back bf16 rows of pages [page0, page0+n) (stride_rows x dim each) to a host buffer. */
+/* Read back bf16 rows of pages [page0, page0+n) (stride_rows x dim each) to a host buffer (from the bf16 slab, or from the
+ * pinned-host exact tier of an index without one). */
 MV_API int mv_index_read_pages(mv_index* ix, int64_t page0, int64_t n_pages, void* out_bf16);
 /* Overwrite rows [row0,row0+n) of one page with host bf16 data (test/bench: planted neighbours).
  * Only the float slab is touched. */

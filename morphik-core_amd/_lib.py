@@ -71,8 +71,8 @@ class QueryStatsC(C.Structure):
 
 
 MV_F32, MV_BF16 = 0, 1
-MV_MODE_FLOAT, MV_MODE_BINARY, MV_MODE_FDE_THEN_FLOAT, MV_MODE_FDE_ONLY, MV_MODE_FLOAT_FP8 = 0, 1, 2, 3, 4
-MV_WITH_FLOAT, MV_WITH_BINARY, MV_WITH_FDE, MV_WITH_FP8 = 1, 2, 4, 8
+MV_MODE_FLOAT, MV_MODE_BINARY, MV_MODE_FDE_THEN_FLOAT, MV_MODE_FDE_ONLY, MV_MODE_FLOAT_FP8, MV_MODE_FP8_THEN_FLOAT = 0, 1, 2, 3, 4, 5
+MV_WITH_FLOAT, MV_WITH_BINARY, MV_WITH_FDE, MV_WITH_FP8, MV_WITH_HOST_EXACT = 1, 2, 4, 8, 16
 MV_OPT_MAXSIM_VARIANT, MV_OPT_FDE_COARSE_N, MV_OPT_FDE_COSINE, MV_OPT_PAD_SEMANTICS, MV_OPT_BINARY_VARIANT, MV_OPT_FDE_SCAN_VARIANT = 1, 2, 3, 4, 5, 6
 MV_OPT_BATCH_VARIANT = 7
 MV_OPT_FDE_ENCODE_VARIANT = 8
@@ -80,6 +80,7 @@ MV_OPT_FILTER_COMPACT_PCT = 9
 MV_OPT_LONG_QUERY_VARIANT = 10
 MV_OPT_FDE_QUERY_ENCODE_VARIANT = 11
 MV_OPT_FDE_BATCH_VARIANT = 12
+MV_OPT_RERANK_N = 13
 MV_CAL_READ_NT, MV_CAL_MFMA_BF16, MV_CAL_READ_LDSDMA, MV_CAL_MFMA_BF16_32X32 = 1, 2, 3, 4
 MV_COMM_AUTO, MV_COMM_RCCL, MV_COMM_P2P, MV_COMM_HOST = 0, 1, 2, 3
 

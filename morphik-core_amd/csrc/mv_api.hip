@@ -216,7 +216,7 @@ int launch_cand_prepare(mv_index* ix, const int64_t* d_ids64, const int32_t* d_i
 
 int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_words, const int32_t* d_cand, int64_t n_items,
                int32_t pad_to, const int32_t* d_pad_items, float* d_out, int* launches, bool no_mask = false,
-               const uint16_t* d_q_base = nullptr) {
+               const uint16_t* d_q_base = nullptr, const uint16_t* slab_override = nullptr) {
   if (n_items <= 0) return MV_OK;  // nothing to launch (a grid of 0 blocks is an invalid configuration)
   const uint16_t* qbase = d_q_base ? d_q_base : ix->d_q;  // padded bf16 query rows (a batch keeps its queries in d_bq)
   const bool need_meta = !no_mask && (ix->tombstones.load() || d_allow != nullptr);
@@ -254,7 +254,7 @@ int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_w
   while (done < padded) {
     const int rows = std::min(padded - done, kMaxQRowsPerPass);
     MaxsimArgs a{};
-    a.slab = ix->slab;
+    a.slab = slab_override ? slab_override : ix->slab;  // the exact tier of FP8_THEN_FLOAT may be pinned host memory mapped into the device
     a.n_rows = ragged ? ix->d_n_rows : nullptr;
     a.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
     a.allow = d_allow;
@@ -341,10 +341,12 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
   const bool want_bin = mode == MV_MODE_BINARY;
   // the rerank stage of FDE_THEN_FLOAT uses the bf16 slab when the index has one, else the fp8 slab
   const bool rerank_fp8 = mode == MV_MODE_FDE_THEN_FLOAT && !(ix->cfg.flags & MV_WITH_FLOAT) && (ix->cfg.flags & MV_WITH_FP8);
-  const bool want_fp8 = mode == MV_MODE_FLOAT_FP8 || rerank_fp8;
-  const bool want_float = mode == MV_MODE_FLOAT || (mode == MV_MODE_FDE_THEN_FLOAT && !rerank_fp8);
+  const bool two_tier = mode == MV_MODE_FP8_THEN_FLOAT;
+  const bool want_fp8 = mode == MV_MODE_FLOAT_FP8 || rerank_fp8 || two_tier;
+  const bool want_float = mode == MV_MODE_FLOAT || (mode == MV_MODE_FDE_THEN_FLOAT && !rerank_fp8) || two_tier;
   if (!want_float && !want_fde && !want_bin && !want_fp8) { set_error("unknown mode %d", mode); return MV_ERR_INVALID; }
-  if (want_float && !(ix->cfg.flags & MV_WITH_FLOAT)) { set_error("index has no float slab (MV_WITH_FLOAT)"); return MV_ERR_STATE; }
+  if (two_tier && !(ix->cfg.flags & (MV_WITH_FLOAT | MV_WITH_HOST_EXACT))) { set_error("MV_MODE_FP8_THEN_FLOAT needs an exact tier (MV_WITH_FLOAT or MV_WITH_HOST_EXACT)"); return MV_ERR_STATE; }
+  if (want_float && !two_tier && !(ix->cfg.flags & MV_WITH_FLOAT)) { set_error("index has no float slab (MV_WITH_FLOAT)"); return MV_ERR_STATE; }
   if (want_fp8 && !(ix->cfg.flags & MV_WITH_FP8)) { set_error("index has no fp8 slab (MV_WITH_FP8)"); return MV_ERR_STATE; }
   if (want_bin && !(ix->cfg.flags & MV_WITH_BINARY)) { set_error("index has no sign-bit slab (MV_WITH_BINARY)"); return MV_ERR_STATE; }
   if (want_fde && !(ix->cfg.flags & MV_WITH_FDE)) { set_error("index has no FDE slab (MV_WITH_FDE)"); return MV_ERR_STATE; }
@@ -366,7 +368,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
   const int32_t* d_scan_cand = nullptr;
   int64_t n_scan = n;
   const int32_t max_ord = ix->max_doc_ord.load();
-  if (want_compact && d_allow && (mode == MV_MODE_FLOAT || mode == MV_MODE_FLOAT_FP8 || mode == MV_MODE_BINARY) && ix->filter_compact_pct > 0 && max_ord >= 0) {
+  if (want_compact && d_allow && (mode == MV_MODE_FLOAT || mode == MV_MODE_FLOAT_FP8 || mode == MV_MODE_BINARY || two_tier) && ix->filter_compact_pct > 0 && max_ord >= 0) {
     int64_t allowed_docs = 0;
     for (int64_t w = 0; w < n_words; ++w) allowed_docs += __builtin_popcount(allow_bits[w]);
     if (allowed_docs * 100 < (int64_t)ix->filter_compact_pct * ((int64_t)max_ord + 1)) {
@@ -396,6 +398,33 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
     if (rc) return rc;
     out->d_scores = ix->d_scores; out->n = n_scan; out->d_ids_map = d_scan_cand;
     out->pages = pages; out->bytes = rows * (int64_t)kDim;
+  } else if (two_tier) {
+    // e4m3 scan of every (allowed) page -> top-n -> exact bf16 re-score of the n candidates from the exact tier -> the
+    // caller's top-k.  One stream-ordered chain: the candidate ids never leave the device, and with a pinned-host exact
+    // tier the rerank kernel's own LDS-DMA reads fetch the n pages over PCIe (n x 256 KiB; no staging copy).
+    if (st) MV_HIP(hipEventRecord(ix->ev_st[0], ix->stream));
+    rc = d_scan_cand ? fp8_scan(ix, n_q, nullptr, 0, d_scan_cand, n_scan, 0, nullptr, ix->d_scores, &out->launches, true)
+                     : fp8_scan(ix, n_q, d_allow, n_words, nullptr, n, 0, nullptr, ix->d_scores, &out->launches);
+    if (rc) return rc;
+    if (st) MV_HIP(hipEventRecord(ix->ev_st[1], ix->stream));
+    out->pages = pages; out->bytes = rows * (int64_t)kDim;
+    const int64_t nc = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want_coarse, n_scan), kTopkMaxDeviceK));  // want_coarse = max(MV_OPT_RERANK_N, k)
+    if (n_scan > 0) {
+      // local page ids (id_base 0) of the fp8 top-n, through the compacted filter list when there is one
+      rc = launch_topk(ix->d_scores, n_scan, (int32_t)nc, d_scan_cand, 0, ix->d_topk_ws, ix->d_out_s, ix->d_out_id, ix->stream);
+      if (rc) return rc;
+      rc = launch_cand_prepare(ix, ix->d_out_id, nullptr, (int)nc, /*pad_sem=*/0);  // a full-corpus scan has no padding rows
+      if (rc) return rc;
+      if (st) MV_HIP(hipEventRecord(ix->ev_st[2], ix->stream));
+      const uint16_t* exact = (ix->cfg.flags & MV_WITH_FLOAT) ? ix->slab : ix->d_exact;
+      rc = float_scan(ix, n_q, nullptr, 0, ix->d_cand, nc, 0, ix->d_cand_pads, ix->d_cand_scores, &out->launches, /*no_mask=*/true, nullptr, exact);
+      if (rc) return rc;
+      out->launches += 2;
+      out->n = nc; out->d_ids_map = ix->d_cand; out->d_scores = ix->d_cand_scores;
+    } else {
+      out->n = 0; out->d_ids_map = nullptr; out->d_scores = ix->d_scores;
+      if (st) MV_HIP(hipEventRecord(ix->ev_st[2], ix->stream));
+    }
   } else if (mode == MV_MODE_BINARY) {
     BinaryArgs b{};
     b.bits = ix->bits; b.n_rows = ragged ? ix->d_n_rows : nullptr;
@@ -448,7 +477,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
     st->pages_scored = out->pages;
     st->bytes_scanned = out->bytes;
     // FDE_THEN_FLOAT: the candidates' rows are added by finish_stats (read back behind the timed span)
-    if (mode == MV_MODE_FDE_THEN_FLOAT) st->reserved = (int32_t)out->n | (rerank_fp8 ? (1 << 30) : 0);
+    if (mode == MV_MODE_FDE_THEN_FLOAT || (two_tier && out->n > 0)) st->reserved = (int32_t)out->n | (rerank_fp8 ? (1 << 30) : 0);
     else if (mode == MV_MODE_FDE_ONLY) st->reserved = 1 << 29;  // stage split without a rerank
   }
   return MV_OK;
@@ -554,6 +583,10 @@ int add_pages_common(mv_index* ix, const void* d_src, int dtype, const int32_t* 
     slab_dst = (uint16_t*)ix->w_tmp;
   }
   rc = launch_scatter_rows(d_src, dtype, d_off, n_pages, stride, slab_dst, ws);
+  if (!rc && ix->h_exact) {  // exact tier in pinned host memory: the fixed-stride bf16 image, slot for slot
+    hipError_t he = hipMemcpyAsync(ix->h_exact + (size_t)first * stride * kDim, slab_dst, (size_t)n_pages * stride * kRowBytes, hipMemcpyDeviceToHost, ws);
+    if (he != hipSuccess) rc = hip_fail(he, "D2H of the exact tier", __FILE__, __LINE__);
+  }
   if (!rc && (ix->cfg.flags & MV_WITH_BINARY)) {
     // sign bits come from the bf16 image: bf16 RNE preserves sign and zero-ness of every fp32 value
     // that is not an fp32 subnormal rounding to zero; fp32 inputs are packed from the fp32 rows below.
@@ -669,7 +702,7 @@ void mv_index_destroy(mv_index* ix) {
     if (e) (void)hipEventDestroy(e);
   if (ix->ev_stage) (void)hipEventDestroy(ix->ev_stage);
   for (void* hp : {(void*)ix->h_qf32, (void*)ix->h_qbf16, (void*)ix->h_out_s, (void*)ix->h_out_id, (void*)ix->h_cand, (void*)ix->h_bout_s,
-                   (void*)ix->h_bout_id, (void*)ix->h_bcand})
+                   (void*)ix->h_bout_id, (void*)ix->h_bcand, (void*)ix->h_exact})
     if (hp) (void)hipHostFree(hp);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
   if (ix->w_stream) (void)hipStreamDestroy(ix->w_stream);
@@ -683,6 +716,7 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   if (cfg->stride_rows < 16 || cfg->stride_rows % 16) { set_error("stride_rows must be a positive multiple of 16 (got %d)", cfg->stride_rows); return MV_ERR_INVALID; }
   if (cfg->capacity_pages < 1 || cfg->capacity_pages > 0x7fffffffLL) { set_error("capacity_pages out of range"); return MV_ERR_INVALID; }
   if (!(cfg->flags & (MV_WITH_FLOAT | MV_WITH_BINARY | MV_WITH_FDE | MV_WITH_FP8))) { set_error("flags select no slab"); return MV_ERR_INVALID; }
+  if ((cfg->flags & MV_WITH_HOST_EXACT) && (cfg->flags & MV_WITH_FLOAT)) { set_error("MV_WITH_HOST_EXACT is the exact tier of an index WITHOUT a bf16 slab in HBM: drop one of the two flags"); return MV_ERR_INVALID; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device available (libmvmaxsim requires an MI355X / gfx950 GPU)"); return MV_ERR_HIP; }
   if (cfg->device < 0 || cfg->device >= ndev) { set_error("device %d out of range (have %d)", cfg->device, ndev); return MV_ERR_INVALID; }
@@ -713,6 +747,12 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
               hipHostMalloc((void**)&ix->h_out_id, (size_t)kTopkMaxDeviceK * 8, hipHostMallocDefault) != hipSuccess ||
               hipHostMalloc((void**)&ix->h_cand, (size_t)kTopkMaxDeviceK * 4, hipHostMallocDefault) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = MV_ERR_NOMEM; }
   if (cfg->flags & MV_WITH_FLOAT) alloc((void**)&ix->slab, rows * kRowBytes + 32768, "bf16 page slab");  // +32 KiB: the batched scans DMA whole 16 / 32 KiB chunks
+  if (!rc && (cfg->flags & MV_WITH_HOST_EXACT)) {
+    // pinned + mapped: the rerank kernel reads the candidates' rows straight out of host RAM (+32 KiB: whole DMA chunks)
+    hipError_t e = hipHostMalloc((void**)&ix->h_exact, rows * kRowBytes + 32768, hipHostMallocMapped | hipHostMallocPortable);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&ix->d_exact, ix->h_exact, 0);
+    if (e != hipSuccess) { set_error("pinned host allocation of %zu bytes for the exact tier failed: %s", rows * kRowBytes, hipGetErrorString(e)); rc = MV_ERR_NOMEM; }
+  }
   if (cfg->flags & MV_WITH_FP8) {
     alloc((void**)&ix->slab8, rows * kDim + 4096, "fp8 page slab");  // +4 KiB: the scan DMAs whole 4 KiB pieces
     alloc((void**)&ix->inv_scale8, (size_t)cap * 4, "fp8 page scales");
@@ -772,6 +812,9 @@ int mv_index_set_option(mv_index* ix, int option, int64_t value) {
     case MV_OPT_FILTER_COMPACT_PCT: ix->filter_compact_pct = (int)value; return MV_OK;
     case MV_OPT_FDE_QUERY_ENCODE_VARIANT: ix->fde_query_encode_variant = (int)value; return MV_OK;
     case MV_OPT_FDE_BATCH_VARIANT: ix->fde_batch_variant = (int)value; return MV_OK;
+    case MV_OPT_RERANK_N:
+      if (value < 1 || value > kTopkMaxDeviceK) { set_error("RERANK_N must be 1..%d", kTopkMaxDeviceK); return MV_ERR_INVALID; }
+      ix->rerank_n = value; return MV_OK;
     default: set_error("unknown option %d", option); return MV_ERR_INVALID;
   }
 }
@@ -904,19 +947,22 @@ int mv_index_remove_doc(mv_index* ix, int32_t doc_ordinal, int64_t* out_n) {
 
 int mv_index_read_pages(mv_index* ix, int64_t page0, int64_t n_pages, void* out_bf16) {
   if (!ix || !out_bf16 || page0 < 0 || n_pages < 0 || page0 + n_pages > ix->size.load()) { set_error("read_pages: range"); return MV_ERR_INVALID; }
-  if (!(ix->cfg.flags & MV_WITH_FLOAT)) { set_error("index has no float slab"); return MV_ERR_STATE; }
+  if (!(ix->cfg.flags & (MV_WITH_FLOAT | MV_WITH_HOST_EXACT))) { set_error("index has no float slab"); return MV_ERR_STATE; }
   std::lock_guard<std::mutex> lk(ix->q_mu);
   DeviceGuard g(ix->cfg.device);
   const size_t pb = (size_t)ix->cfg.stride_rows * kRowBytes;
+  if (!(ix->cfg.flags & MV_WITH_FLOAT)) { memcpy(out_bf16, (const char*)ix->h_exact + (size_t)page0 * pb, (size_t)n_pages * pb); return MV_OK; }  // exact tier
   MV_HIP(hipMemcpy(out_bf16, (const char*)ix->slab + (size_t)page0 * pb, (size_t)n_pages * pb, hipMemcpyDeviceToHost));
   return MV_OK;
 }
 
 int mv_index_write_rows(mv_index* ix, int64_t page, int32_t row0, int32_t n, const void* bf16_rows) {
   if (!ix || !bf16_rows || page < 0 || page >= ix->size.load() || row0 < 0 || n < 0 || row0 + n > ix->cfg.stride_rows) { set_error("write_rows: range"); return MV_ERR_INVALID; }
-  if (!(ix->cfg.flags & MV_WITH_FLOAT)) { set_error("index has no float slab"); return MV_ERR_STATE; }
+  if (!(ix->cfg.flags & (MV_WITH_FLOAT | MV_WITH_HOST_EXACT))) { set_error("index has no float slab"); return MV_ERR_STATE; }
   ExclusiveLock lk(ix);
   DeviceGuard g(ix->cfg.device);
+  if (ix->h_exact) memcpy((char*)ix->h_exact + ((size_t)page * ix->cfg.stride_rows + row0) * kRowBytes, bf16_rows, (size_t)n * kRowBytes);
+  if (!(ix->cfg.flags & MV_WITH_FLOAT)) return MV_OK;
   char* dst = (char*)ix->slab + ((size_t)page * ix->cfg.stride_rows + row0) * kRowBytes;
   MV_HIP(hipMemcpy(dst, bf16_rows, (size_t)n * kRowBytes, hipMemcpyHostToDevice));
   return MV_OK;
@@ -978,6 +1024,9 @@ int mv_index_fill_synthetic(mv_index* ix, uint64_t seed, uint64_t first_unit, in
     const int64_t c = std::min(chunk, n_pages - done);
     uint16_t* dst = has_float ? ix->slab + (size_t)(first + done) * stride * kDim : (uint16_t*)ix->w_tmp;
     rc = launch_synth_rows(dst, seed, first_unit + (uint64_t)done, c, n_rows, stride, ws);
+    if (!rc && ix->h_exact && hipMemcpyAsync(ix->h_exact + (size_t)(first + done) * stride * kDim, dst, (size_t)c * stride * kRowBytes, hipMemcpyDeviceToHost, ws) != hipSuccess) {
+      set_error("fill_synthetic: D2H of the exact tier failed"); rc = MV_ERR_HIP;
+    }
     if (!rc) rc = derive_slabs_from_bf16(ix, dst, first + done, c, ix->d_n_rows + first + done, ws);
     if (!has_float && hipStreamSynchronize(ws) != hipSuccess && !rc) { set_error("fill_synthetic: stream error"); rc = MV_ERR_HIP; }
   }
@@ -1009,6 +1058,10 @@ int mv_index_replace_page(mv_index* ix, int64_t page, const void* bf16_rows, int
     if (n_rows != stride) ix->ragged.store(true);
     e = hipMemcpyAsync(ix->d_n_rows + page, &ix->h_n_rows[page], 4, hipMemcpyHostToDevice, ix->stream);
     if (e != hipSuccess) rc = hip_fail(e, "replace_page metadata", __FILE__, __LINE__);
+  }
+  if (!rc && ix->h_exact) {
+    memset(ix->h_exact + (size_t)page * stride * kDim, 0, (size_t)stride * kRowBytes);
+    if (n_rows > 0) memcpy(ix->h_exact + (size_t)page * stride * kDim, bf16_rows, (size_t)n_rows * kRowBytes);
   }
   if (!rc) rc = derive_slabs_from_bf16(ix, dst, page, 1, ix->d_n_rows + page, ix->stream);
   (void)hipStreamSynchronize(ix->stream);
@@ -1087,6 +1140,10 @@ int mv_index_compact(mv_index* ix, int64_t* out_old_to_new, int64_t* out_new_siz
   if (d_idx) (void)hipFree(d_idx);
   if (stage) (void)hipFree(stage);
   if (rc) return rc;
+  if (ix->h_exact) {  // the exact tier moves with the pages (ascending: a destination is never a page still to be read)
+    const size_t pb = stride * kRowBytes;
+    for (int64_t j = first_moved; j < m; ++j) memmove((char*)ix->h_exact + (size_t)j * pb, (const char*)ix->h_exact + (size_t)live[j] * pb, pb);
+  }
   for (int64_t j = first_moved; j < m; ++j) {
     ix->h_n_rows[(size_t)j] = ix->h_n_rows[(size_t)live[j]];
     ix->h_doc_ord[(size_t)j] = ix->h_doc_ord[(size_t)live[j]];
@@ -1159,7 +1216,8 @@ int mv_internal_query_common(mv_index* ix, const void* q, int q_dtype, int32_t n
     return MV_OK;
   }
   ScanResult r;
-  int rc = run_scan(ix, q, q_dtype, n_q, mode, allow_bits, n_words, coarse_n_for(ix, k), &r, st, /*want_compact=*/true);
+  const int64_t want_n = mode == MV_MODE_FP8_THEN_FLOAT ? std::max<int64_t>(ix->rerank_n, k) : coarse_n_for(ix, k);
+  int rc = run_scan(ix, q, q_dtype, n_q, mode, allow_bits, n_words, want_n, &r, st, /*want_compact=*/true);
   if (rc) return rc;
   const int64_t id_base = ix->cfg.id_base;
   if (r.n == 0) {
@@ -1553,6 +1611,7 @@ int mv_score_all(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int
                  int64_t n_allow_words, float* out_scores, int64_t out_cap, int64_t* out_n, mv_query_stats* stats) {
   if (!ix || !out_scores || out_cap < 0) { set_error("null argument"); return MV_ERR_INVALID; }
   if (mode == MV_MODE_FDE_THEN_FLOAT) mode = MV_MODE_FDE_ONLY;
+  if (mode == MV_MODE_FP8_THEN_FLOAT) mode = MV_MODE_FLOAT_FP8;  // the first-stage scores
   std::lock_guard<std::mutex> lk(ix->q_mu);
   DeviceGuard g(ix->cfg.device);
   if (out_n) *out_n = 0;
@@ -1873,6 +1932,7 @@ int mv_index_save(mv_index* ix, const char* path) {
     dump(ix->slab8, rows * kDim);
     dump(ix->inv_scale8, (size_t)size * 4);
   }
+  if (ix->h_exact) wr(ix->h_exact, rows * kRowBytes);  // the pinned-host exact tier, last
   if (!rc && (fflush(f) != 0 || fsync(fileno(f)) != 0)) { set_error("flush failed for %s", tmp.c_str()); rc = MV_ERR_IO; }
   if (fclose(f) != 0 && !rc) { set_error("close failed for %s", tmp.c_str()); rc = MV_ERR_IO; }
   if (!rc && rename(tmp.c_str(), path) != 0) { set_error("cannot rename %s to %s", tmp.c_str(), path); rc = MV_ERR_IO; }
@@ -1921,6 +1981,7 @@ int mv_index_load(const char* path, int32_t device, mv_index** out) {
     fill(ix->slab8, rows * kDim);
     fill(ix->inv_scale8, (size_t)h.size * 4);
   }
+  if (ix->h_exact) rd(ix->h_exact, rows * kRowBytes);
   fclose(f);
   if (!rc && h.size) {
     if (hipMemcpy(ix->d_n_rows, ix->h_n_rows.data(), (size_t)h.size * 4, hipMemcpyHostToDevice) != hipSuccess ||

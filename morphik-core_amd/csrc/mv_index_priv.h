@@ -32,6 +32,8 @@ struct mv_index {
   uint8_t* bits = nullptr;
   uint16_t* fde = nullptr;
   float* fde_inv_norm = nullptr;
+  uint16_t* h_exact = nullptr;   // MV_WITH_HOST_EXACT: pinned host bf16 rows [capacity][stride][128] (+32 KiB), the exact tier
+  uint16_t* d_exact = nullptr;   // the same memory through the device's address space (hipHostGetDevicePointer)
   uint8_t* slab8 = nullptr;      // e4m3 page slab [capacity][stride][128]
   float* inv_scale8 = nullptr;   // [capacity] 2^-e per page
   int32_t* d_n_rows = nullptr;
@@ -120,6 +122,7 @@ struct mv_index {
                                // 2 = batched with the query FDE rounded to bf16 (no lo term)
   int fde_query_encode_variant = 2;  // the ONE query page: 2 = latency kernel (one block per repetition, default), 1 = bulk f32-MFMA kernel, 0 = scalar kernel
   int64_t fde_coarse_n = 0;
+  int64_t rerank_n = 128;  // MV_MODE_FP8_THEN_FLOAT: candidates re-scored on the exact tier
   int fde_cosine = 1;
   int pad_semantics = -1;  // -1: mode default (reference batch rule for FDE_THEN_FLOAT / candidates, none for full scan)
 };

@@ -20,10 +20,12 @@ from ._lib import (
     MV_MODE_FDE_THEN_FLOAT,
     MV_MODE_FLOAT,
     MV_MODE_FLOAT_FP8,
+    MV_MODE_FP8_THEN_FLOAT,
     MV_WITH_BINARY,
     MV_WITH_FDE,
     MV_WITH_FLOAT,
     MV_WITH_FP8,
+    MV_WITH_HOST_EXACT,
     ConfigC,
     FdeConfigC,
     QueryStatsC,
@@ -32,7 +34,7 @@ from ._lib import (
 )
 
 MODES = {"float": MV_MODE_FLOAT, "binary": MV_MODE_BINARY, "fde_then_float": MV_MODE_FDE_THEN_FLOAT, "fde": MV_MODE_FDE_ONLY,
-         "float_fp8": MV_MODE_FLOAT_FP8}
+         "float_fp8": MV_MODE_FLOAT_FP8, "fp8_then_float": MV_MODE_FP8_THEN_FLOAT}
 
 
 @dataclass
@@ -129,10 +131,13 @@ class MvIndex:
         fde: Optional[FdeConfig] = None,
         id_base: int = 0,
         with_fp8: bool = False,
+        with_host_exact: bool = False,
     ):
+        """with_host_exact: keep the exact bf16 rows in PINNED HOST memory (no HBM) as the exact tier of mode
+        "fp8_then_float" -- for shards whose bf16 slab does not fit beside the fp8 slab (not together with with_float)."""
         self.fde_config = fde or FdeConfig()
         flags = ((MV_WITH_FLOAT if with_float else 0) | (MV_WITH_BINARY if with_binary else 0) | (MV_WITH_FDE if with_fde else 0)
-                 | (MV_WITH_FP8 if with_fp8 else 0))
+                 | (MV_WITH_FP8 if with_fp8 else 0) | (MV_WITH_HOST_EXACT if with_host_exact else 0))
         cfg = ConfigC(128, int(stride_rows), int(capacity_pages), int(device), flags, int(id_base), self.fde_config.to_c())
         h = C.c_void_p()
         check(lib().mv_index_create(C.byref(cfg), C.byref(h)))

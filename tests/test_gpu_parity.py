@@ -1097,6 +1097,87 @@ def test_errors_are_loud(mv):
     ix.close()
 
 
+# ------------------------------------------------------------------ fp8 scan -> exact bf16 re-score from the exact tier
+@pytest.mark.parametrize("tier", ["host", "hbm"])
+def test_fp8_then_float_rescoring_from_the_exact_tier(mv, tier, tmp_path):
+    """MV_MODE_FP8_THEN_FLOAT: e4m3 scan -> top-n -> exact bf16 MaxSim of the n candidates read from the exact tier (pinned
+    host memory mapped into the device, or the bf16 slab) -> top-k.  Checked against the oracle composed the same way on
+    the device's own codes and rows: candidate set = fp8 top-n, final scores = the exact bf16 scores (1e-3 as north_star
+    states; measured ~1e-7), final order = exact order.  Ragged pages, a doc filter, a tombstone, an upsert, compaction
+    and a checkpoint round trip all keep the two tiers in step."""
+    from morphik_core_amd import _lib, synth
+    from morphik_core_amd.index import MvIndex, allow_bitmap
+
+    N, stride, nrows, NR = 1200, 64, 60, 48
+    ix = _idx(mv, capacity_pages=N + 8, stride_rows=stride, with_float=tier == "hbm", with_fp8=True, with_host_exact=tier == "host")
+    ix.fill_synthetic(1234, 0, N - 40, n_rows=nrows, pages_per_doc=4)
+    rag = [orc.synth_rows(77, j, 0, 10 + j) for j in range(40)]  # ragged pages through the host add path
+    ix.add(rag, doc_ordinals=[1000 + j for j in range(40)])
+    ix.set_option(_lib.MV_OPT_RERANK_N, NR)
+    q_bf = orc.synth_rows(4321, 0, 0, 32)
+    q = orc.bf16_to_f32(q_bf)
+    spec = synth.hard_spec([q_bf], N - 40, nrows, n_hard=24)
+    synth.plant_neighbours_any(ix, spec, 1234, nrows)  # replace_page refreshes both tiers
+    lens = [nrows] * (N - 40) + [10 + j for j in range(40)]
+
+    def oracle_two_tier(k, allowed=None):
+        pages = ix.read_pages(0, len(ix))  # exact tier rows (host tier when there is no bf16 slab)
+        codes, inv = ix.read_fp8(0, len(ix))
+        c8 = orc.maxsim_fp8_np(q, codes, inv, n_rows=lens[: len(ix)])
+        if allowed is not None:
+            c8 = np.where(allowed, c8, -np.inf)
+        cs, ci = orc.topk(c8, NR)
+        ex = np.array([orc.maxsim_bf16(q_bf, pages[c][: lens[c]]) for c in ci], np.float32)
+        order = np.lexsort((ci, -ex.astype(np.float64)))[:k]
+        return ex[order], ci[order], set(ci.tolist()), c8
+
+    ws, wi, cand, c8 = oracle_two_tier(10)
+    s, i, st = ix.query(q_bf, 10, mode="fp8_then_float", want_stats=True)
+    _assert_topk_matches(s, i, ws, wi)
+    assert st.rerank_ms > 0 and st.coarse_ms > 0
+    # the hard set's exact top-10 comes back in exact order although the fp8 scan alone reorders it
+    hard_pages = synth.hard_pages_of(spec, 0)
+    pages_all = ix.read_pages(0, len(ix))
+    exact = np.array([orc.maxsim_bf16(q_bf, pages_all[p][:nrows]) for p in hard_pages], np.float32)
+    top, _info = synth.exact_truth_from_scores(hard_pages, exact)
+    assert i.tolist() == top
+    np.testing.assert_allclose(ix.score_all(q_bf, mode="fp8_then_float"), c8, rtol=RTOL, atol=1e-6)  # first-stage scores
+    # doc filter (selective -> compacted candidate list) + tombstone
+    ix.remove_doc(top[0] // 4)
+    allowed_docs = [d for d in range((N - 40) // 4 + 1) if d % 3 != 1] + [1000 + j for j in range(0, 40, 2)]
+    al = allow_bitmap(allowed_docs)
+    docs = np.array([p // 4 for p in range(N - 40)] + [1000 + j for j in range(40)])
+    mask = np.isin(docs, allowed_docs) & (docs != top[0] // 4)
+    ws2, wi2, _c, _ = oracle_two_tier(7, mask)
+    s2, i2 = ix.query(q_bf, 7, mode="fp8_then_float", allow=al)
+    _assert_topk_matches(s2, i2, ws2, wi2)
+    few = allow_bitmap([top[3] // 4, top[5] // 4, 1003])
+    s3, i3 = ix.query(q_bf, 50, mode="fp8_then_float", allow=few)
+    assert set(i3.tolist()) == {p for p in range(N) if docs[p] in (top[3] // 4, top[5] // 4, 1003) and docs[p] != top[0] // 4}
+    # compaction moves both tiers; a checkpoint carries the exact tier
+    o2n = ix.compact()
+    lens = [lens[p] for p in range(N) if o2n[p] >= 0]
+    ws4, wi4, _c, _ = oracle_two_tier(10)
+    s4, i4 = ix.query(q_bf, 10, mode="fp8_then_float")
+    _assert_topk_matches(s4, i4, ws4, wi4)
+    path = str(tmp_path / "two_tier.mv")
+    ix.save(path)
+    ix2 = MvIndex.load(path)
+    s5, i5 = ix2.query(q_bf, 10, mode="fp8_then_float")
+    assert i5.tolist() == i4.tolist() and np.array_equal(s5, s4)
+    assert np.array_equal(ix2.read_pages(0, len(ix2)), ix.read_pages(0, len(ix)))
+    ix2.close()
+    ix.close()
+    if tier == "host":  # the mode refuses an index without an exact tier, loudly
+        from morphik_core_amd import MvError
+
+        ix3 = _idx(mv, capacity_pages=8, stride_rows=16, with_float=False, with_fp8=True)
+        ix3.fill_synthetic(1, 0, 8)
+        with pytest.raises(MvError):
+            ix3.query(q_bf, 3, mode="fp8_then_float")
+        ix3.close()
+
+
 # ------------------------------------------------------------------ recall of the lossy paths on hard negatives (configs[3], [4])
 def test_recall_of_lossy_paths_on_hard_negatives_and_unplanted_corpus(mv):
     """VERDICT r1 item 1.  64 pages per query whose exact bf16 scores sit within ~2 % of each other (rank 10 and rank 11
