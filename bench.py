@@ -157,146 +157,238 @@ def pmc_traffic(n_local, patches):
     return None, None, None
 
 
-def recall_block(ix, qs, truths, K, coarse_ns=(75, 1000)):
-    """recall@10 against the exact bf16 top-10 for every lossy path of an all-slab index, + FDE coarse recall."""
-    from morphik_core_amd import _lib as L
+N_HARD_Q = 64      # hard-negative queries (64 near-tied pages each)
+N_TOPIC_Q = 64     # clustered-corpus queries (one per topic, graded relevance)
+N_RANDOM_Q = 16    # queries against the unstructured background only
+
+
+def recall_sets(args, n_pages, device, planted_queries, planted_spec_):
+    """The query / page sets every lossy path is scored on (>= 64 queries per structured corpus):
+    planted (3x margin), hard negatives (64 near-tied pages per query), clustered topics (graded relevance), and queries
+    with no structure at all.  Pages of the sets are disjoint; everything is a pure function of (seeds, n_pages, patches)."""
+    from morphik_core_amd import synth
+    from morphik_core_amd.index import synth_rows
+
+    taken = {p for (_q, _r, p, _a, _b) in planted_spec_}
+    hq = [synth_rows(synth.SEED_QUERIES, 1000 + j, args.qtokens, device=device) for j in range(N_HARD_Q)]
+    hspec = [t for t in synth.hard_spec(hq, n_pages, args.patches) if t[2] not in taken]
+    taken |= {t[2] for t in hspec}
+    cq, cspec = synth.clustered_spec(N_TOPIC_Q, n_pages, args.patches, q_tokens=args.qtokens, exclude=taken)
+    rq = [synth_rows(synth.SEED_QUERIES, 2000 + j, args.qtokens, device=device) for j in range(N_RANDOM_Q)]
+    return {"planted": {"queries": list(planted_queries), "spec": list(planted_spec_)},
+            "hard_negatives": {"queries": hq, "spec": hspec},
+            "clustered_topics": {"queries": cq, "spec": cspec},
+            "unstructured": {"queries": rq, "spec": []}}
+
+
+def exact_truth(ix, queries, k=K):
+    """Exact bf16 top-k of every query over the whole index (the parity-checked float scan, 16 queries per slab pass)
+    + the relative margin between rank k and rank k+1."""
+    tops, gaps = [], []
+    for g0 in range(0, len(queries), 16):
+        for s, i in ix.query_batch(queries[g0 : g0 + 16], k + 1):
+            tops.append(i[:k].tolist())
+            gaps.append(float((s[k - 1] - s[k]) / abs(s[k - 1])) if len(s) > k else float("nan"))
+    return tops, gaps
+
+
+def timed_mode(ix, qs, mode, n_timed=9, warm_s=0.25, k=K):
+    """HIP-event times of one query mode after a time-based warm-up -> (median QueryStats fields as dict)."""
+    t_end = time.perf_counter() + warm_s
+    i = 0
+    while time.perf_counter() < t_end:
+        ix.query(qs[i % len(qs)], k, mode=mode)
+        i += 1
+    rows = []
+    for r in range(n_timed):
+        _s, _i, st = ix.query(qs[r % len(qs)], k, mode=mode, want_stats=True)
+        rows.append((st.score_kernel_ms, st.total_device_ms, st.encode_ms, st.coarse_ms, st.select_ms, st.rerank_ms, st.topk_ms))
+    m = np.median(np.array(rows), axis=0)
+    return dict(zip(("score_kernel_ms", "total_device_ms", "encode_ms", "coarse_ms", "select_ms", "rerank_ms", "topk_ms"), (float(x) for x in m)))
+
+
+def scan_entry(n, bytes_per_page, ms):
+    return {"kernel_ms": round(ms, 4), "pages_per_s": round(n / ms * 1e3, 1), "GBps": round(n * bytes_per_page / ms / 1e6, 1),
+            "frac_hbm_8TBps": round(n * bytes_per_page / ms / 1e6 / HBM_PEAK_GBPS, 4), "bytes_per_page": bytes_per_page}
+
+
+def recall_of(ix, sets, truths, gaps, modes, allow_unstructured=None):
+    """recall@10 vs the exact bf16 top-10 for every (set, mode); `modes` = [(name, callable(q, allow) -> ids)].
+    + recall as a function of the rank-10 / rank-11 margin over the hard-negative and clustered queries together."""
     from morphik_core_amd import synth
 
     out = {}
-    for mode in ("float_fp8", "binary"):
-        out[mode] = float(np.mean([synth.recall_at_k(ix.query(q, K, mode=mode)[1].tolist(), t) for q, t in zip(qs, truths)]))
-    for cn in coarse_ns:
-        ix.set_option(L.MV_OPT_FDE_COARSE_N, cn)
-        out[f"fde_top{cn}_then_float"] = float(np.mean([synth.recall_at_k(ix.query(q, K, mode="fde_then_float")[1].tolist(), t) for q, t in zip(qs, truths)]))
-    out["fde_coarse_recall_at_1000"] = float(np.mean([synth.recall_at_k(ix.query(q, 1000, mode="fde")[1].tolist(), t) for q, t in zip(qs, truths)]))
+    per_query = {name: ([], []) for name, _f in modes}
+    for sname, st_ in sets.items():
+        ent = {"queries": len(st_["queries"]), "median_rel_gap_rank10_rank11": float(np.median(gaps[sname]))}
+        al = allow_unstructured if sname == "unstructured" else None
+        for name, f in modes:
+            hits = [synth.recall_at_k(f(q, al), t) for q, t in zip(st_["queries"], truths[sname])]
+            ent[name] = round(float(np.mean(hits)), 4)
+            if sname in ("hard_negatives", "clustered_topics"):
+                per_query[name][0].extend(gaps[sname])
+                per_query[name][1].extend(hits)
+        out[sname] = ent
+    out["by_margin_hard_and_clustered"] = {name: synth.margin_bins(g, h) for name, (g, h) in per_query.items()}
     return out
 
 
-def aux_paths(args, device, mfma_peak=None):
-    """Quick, separately sized measurements of the other hot-path kernels (same HIP-event method, a smaller corpus with
-    EVERY slab): sign-bit MaxSim (SQL max_sim semantics), fp8 slab, FDE coarse scan, FDE -> rerank, the batched-query MFMA
-    form, and recall@10 of the lossy paths against the exact bf16 top-10 on hard negatives and on a corpus with no
-    planted structure at all.  Reported next to the headline number, never mixed into `value`.  None of them launches the
-    headline scan kernel inside a timed region of the main workload."""
+def full_shard(args, device, sets, truths, gaps, n_truth_pages):
+    """BASELINE configs[3] / [4] at their per-GPU shard shape: ONE index of args.full_shard_pages pages (10 M / 8 GPUs =
+    1.25 M) holding the e4m3, FDE and sign-bit slabs (no bf16 slab: 328 GB would not fit), built by the same generator as
+    the bf16 corpus the truth was computed on (its first n_truth_pages pages ARE that corpus; the rest is unstructured
+    background, which the queries without structure are kept away from by a doc filter so their truth stays exact)."""
+    from morphik_core_amd import _lib as L
+    from morphik_core_amd import synth
+    from morphik_core_amd.index import MvIndex
+
+    import torch
+
+    stride = ((args.patches + 15) // 16) * 16
+    per_page = stride * 128 + stride * 16 + 20480 + 16 + 32 * 4  # slabs + metadata + the batched score vectors
+    free_b, _tot = torch.cuda.mem_get_info(device)
+    n = int(min(args.full_shard_pages, (free_b - (8 << 30)) // per_page))
+    res = {"pages": n, "slabs": "e4m3 + FDE(10240 bf16) + sign bits, no bf16 slab", "resident_GB": round(n * per_page / 1e9, 1),
+           "note": "kernel-only HIP-event times (median of 9 after 0.25 s of warm-up queries); recall@10 against the exact bf16 top-10 of the same "
+                   "corpus computed by the float scan before the bf16 slab was freed"}
+    t0 = time.time()
+    ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=False, with_binary=True, with_fde=True, with_fp8=True)
+    ix.fill_synthetic(synth.SEED_CORPUS, 0, n, n_rows=args.patches)
+    res["fill_s"] = round(time.time() - t0, 1)
+    t0 = time.time()
+    planted_pages = 0
+    for st_ in sets.values():
+        planted_pages += synth.plant_neighbours_any(ix, st_["spec"], synth.SEED_CORPUS, args.patches, 0, n)
+    res["planted_pages"] = planted_pages
+    res["plant_s"] = round(time.time() - t0, 1)
+    log(f"[full shard] {n} pages generated in {res['fill_s']} s, {planted_pages} structured pages written in {res['plant_s']} s")
+    qs = sets["planted"]["queries"]
+    # ---- the three full-corpus scans
+    for key, mode, bpp in (("fp8_scan", "float_fp8", args.patches * 128), ("sign_bit_scan", "binary", args.patches * 16)):
+        t = timed_mode(ix, qs, mode)
+        res[key] = scan_entry(n, bpp, t["score_kernel_ms"])
+    t = timed_mode(ix, qs, "fde")
+    res["fde_coarse_scan"] = dict(scan_entry(n, 20480, t["coarse_ms"]), query_encode_ms=round(t["encode_ms"], 4))
+    # ---- FDE -> top-n -> exact rerank on the e4m3 slab (configs[3] pipeline), one request and 32 per slab pass
+    res["fde_then_fp8_rerank"] = {}
+    bq = [qs[i % len(qs)] for i in range(32)]
+    for cn in (75, 1000):
+        ix.set_option(L.MV_OPT_FDE_COARSE_N, cn)
+        t = timed_mode(ix, qs, "fde_then_float", n_timed=12)
+        dev, stg, out_b = [], [], None
+        for r in range(8):
+            out_b, st = ix.query_batch(bq, K, mode="fde_then_float", want_stats=True)
+            if r >= 3:
+                dev.append(st.total_device_ms)
+                stg.append((st.encode_ms, st.coarse_ms, st.select_ms, st.rerank_ms, st.topk_ms))
+        d, sb = float(np.median(dev)), np.median(np.array(stg), axis=0)
+        same = float(np.mean([out_b[i][1].tolist() == ix.query(bq[i], K, mode="fde_then_float")[1].tolist() for i in range(0, 32, 4)]))
+        res["fde_then_fp8_rerank"][f"coarse{cn}"] = {
+            "one_request": {"device_ms": round(t["total_device_ms"], 4), "pages_searched_per_s": round(n / t["total_device_ms"] * 1e3, 1),
+                            "stage_ms": {k: round(t[k], 4) for k in ("encode_ms", "coarse_ms", "select_ms", "rerank_ms", "topk_ms")},
+                            "coarse_scan_GBps": round(n * 20480 / t["coarse_ms"] / 1e6, 1),
+                            "coarse_scan_frac_hbm_8TBps": round(n * 20480 / t["coarse_ms"] / 1e6 / HBM_PEAK_GBPS, 4)},
+            "batch_of_32": {"device_ms_per_batch": round(d, 4), "device_us_per_request": round(d * 1e3 / 32, 2), "requests_per_s": round(32 / d * 1e3, 1),
+                            "throughput_vs_one_request_per_pass": round(t["total_device_ms"] * 32 / d, 2),
+                            "stage_ms": {k: round(float(v), 4) for k, v in zip(("encode_32_queries", "coarse_gemm_one_slab_pass", "select", "rerank", "topk"), sb)},
+                            "coarse_pass_GBps": round(n * 20480 / float(sb[1]) / 1e6, 1),
+                            "coarse_pass_frac_hbm_8TBps": round(n * 20480 / float(sb[1]) / 1e6 / HBM_PEAK_GBPS, 4),
+                            "same_ids_as_single_query": same}}
+    # ---- recall of every lossy path vs the exact bf16 truth, >= 64 queries per structured corpus
+    background_off = None
+    if n > n_truth_pages:  # doc ordinal == page (pages_per_doc 1): allow exactly the pages the truth was computed on
+        background_off = np.zeros((n + 31) // 32, np.uint32)
+        background_off[: n_truth_pages // 32] = 0xFFFFFFFF
+        if n_truth_pages % 32:
+            background_off[n_truth_pages // 32] = (1 << (n_truth_pages % 32)) - 1
+
+    def ids_of(mode, k=K, cn=None):
+        def f(q, al):
+            if cn is not None:
+                ix.set_option(L.MV_OPT_FDE_COARSE_N, cn)
+            return ix.query(q, k, mode=mode, allow=al)[1].tolist()
+        return f
+
+    modes = [("fp8_scan", ids_of("float_fp8")), ("sign_bit_scan", ids_of("binary")),
+             ("fde_top75_then_fp8", ids_of("fde_then_float", cn=75)), ("fde_top1000_then_fp8", ids_of("fde_then_float", cn=1000)),
+             ("fde_coarse_recall_at_75", ids_of("fde", k=75)), ("fde_coarse_recall_at_1000", ids_of("fde", k=1000))]
+    t0 = time.time()
+    res["recall_at_10_vs_exact_bf16"] = recall_of(ix, sets, truths, gaps, modes, background_off)
+    res["recall_s"] = round(time.time() - t0, 1)
+    ix.set_option(L.MV_OPT_FDE_COARSE_N, 1000)
+    ix.close()
+    return res
+
+
+def two_tier(args, device):
+    """fp8 scan -> top-n -> exact bf16 re-score from the exact tier (MV_MODE_FP8_THEN_FLOAT), on one index holding the e4m3
+    slab, the bf16 slab (the truth, and the HBM form of the exact tier) and the PINNED-HOST exact tier the rerank kernel
+    reads over PCIe (what a shard without room for a bf16 slab uses): recall of the fp8 scan alone next to the two-tier
+    result, and what the second tier adds to the device time."""
     from morphik_core_amd import _lib as L
     from morphik_core_amd import synth
     from morphik_core_amd.index import MvIndex, synth_rows
 
     n = args.aux_pages
     stride = ((args.patches + 15) // 16) * 16
-    NH, NR = 8, 4  # hard-negative queries, unplanted queries
-    qs = [synth_rows(synth.SEED_QUERIES, qi, args.qtokens, device=device) for qi in range(N_QUERIES + NH + NR)]
-    spec = synth.planted_spec(qs[:N_QUERIES], n, args.patches, n_ranks=N_PLANTED)
-    planted = {qi: [p for (qq, _r, p, _a, _b) in spec if qq == qi] for qi in range(N_QUERIES)}
-    taken = {p for (_q, _r, p, _a, _b) in spec}
-    hq = qs[N_QUERIES : N_QUERIES + NH]
-    hspec = [t for t in synth.hard_spec(hq, n, args.patches) if t[2] not in taken]
-    res = {"pages": n, "note": "kernel-only HIP-event times, median of 15 after 0.25 s of warm-up queries, on one index holding bf16 + e4m3 + sign-bit + FDE slabs"}
-    ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=True, with_binary=True, with_fde=True, with_fp8=True)
+    res = {"pages": n, "host_tier_GB": round(n * stride * 256 / 1e9, 1)}
+    t0 = time.time()
+    ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=True, with_fp8=True, with_host_exact=True)
+    res["create_with_pinned_host_tier_s"] = round(time.time() - t0, 1)
+    t0 = time.time()
     ix.fill_synthetic(synth.SEED_CORPUS, 0, n, n_rows=args.patches)
-    synth.plant_neighbours_any(ix, spec, synth.SEED_CORPUS, args.patches)
-    synth.plant_neighbours_any(ix, hspec, synth.SEED_CORPUS, args.patches)
-    per_page = {"binary": args.patches * 16, "float_fp8": args.patches * 128, "fde": 10240 * 2}
-    WARM, TIMED = 10, 15
+    res["fill_s"] = round(time.time() - t0, 1)
+    pq = [synth_rows(synth.SEED_QUERIES, qi, args.qtokens, device=device) for qi in range(N_QUERIES)]
+    sets = recall_sets(args, n, device, pq, synth.planted_spec(pq, n, args.patches, n_ranks=N_PLANTED))
+    t0 = time.time()
+    for st_ in sets.values():
+        synth.plant_neighbours_any(ix, st_["spec"], synth.SEED_CORPUS, args.patches, 0, n)
+    res["plant_s"] = round(time.time() - t0, 1)
+    truths, gaps = {}, {}
+    for sname, st_ in sets.items():
+        truths[sname], gaps[sname] = exact_truth(ix, st_["queries"])
+    qs = sets["hard_negatives"]["queries"]
+    base = timed_mode(ix, qs, "float_fp8")
+    res["fp8_scan_alone_device_ms"] = round(base["total_device_ms"], 4)
 
-    def warm(mode, seconds=0.25):  # the clocks need ~100 ms of load to settle after an idle spell: warm up by TIME, not by count
-        t_end = time.perf_counter() + seconds
-        i = 0
-        while time.perf_counter() < t_end:
-            ix.query(qs[i % N_QUERIES], K, mode=mode)
-            i += 1
+    def ids_of(mode):
+        return lambda q, al: ix.query(q, K, mode=mode, allow=al)[1].tolist()
 
-    for mode in ("binary", "float_fp8", "fde"):
-        ms, coarse = [], []
-        warm(mode)
-        for r in range(TIMED):
-            _s, _i, st = ix.query(qs[r % N_QUERIES], K, mode=mode, want_stats=True)
-            ms.append(st.score_kernel_ms)
-            coarse.append(st.coarse_ms)
-        m = float(np.median(coarse)) if mode == "fde" else float(np.median(ms))  # FDE: the slab scan alone (the query encode is its own stage)
-        ent = {"kernel_ms": round(m, 4), "pages_per_s": round(n / m * 1e3, 1), "GBps": round(n * per_page[mode] / m / 1e6, 1),
-               "frac_hbm_8TBps": round(n * per_page[mode] / m / 1e6 / HBM_PEAK_GBPS, 4), "bytes_per_page": per_page[mode]}
-        if mode == "fde":
-            ent["span_with_query_encode_ms"] = round(float(np.median(ms)), 4)
-        res[mode] = ent
-    # FDE coarse top-1000 -> exact rerank (configs[3] pipeline), all in stream order on the device
-    ix.set_option(L.MV_OPT_FDE_COARSE_N, 1000)
-    ms, stg = [], []
-    warm("fde_then_float")
-    for r in range(WARM + N_QUERIES):
-        _s, ids, st = ix.query(qs[r % N_QUERIES], K, mode="fde_then_float", want_stats=True)
-        if r >= WARM:
-            ms.append(st.total_device_ms)
-            stg.append((st.encode_ms, st.coarse_ms, st.select_ms, st.rerank_ms, st.topk_ms))
-    stg = np.median(np.array(stg), axis=0)
-    res["fde_top1000_then_float"] = {"device_ms": round(float(np.median(ms)), 4), "pages_per_s": round(n / float(np.median(ms)) * 1e3, 1),
-                                     "stage_ms": {k: round(float(v), 4) for k, v in zip(("encode_query", "coarse_scan", "select_top1000", "rerank_1000", "topk"), stg)},
-                                     "overhead_over_coarse_scan_ms": round(float(np.median(ms)) - float(stg[1]), 4)}
-    # ---- the same pipeline for a BATCH of requests (mv_query_topk_batch): one FDE-slab pass per 32 queries
-    bq = [qs[i % N_QUERIES] for i in range(32)]
-    res["fde_batched_32_queries"] = {}
-    for cn, key in ((1000, "coarse1000_then_float"), (75, "coarse75_then_float_reference_rule")):
-        ix.set_option(L.MV_OPT_FDE_COARSE_N, cn)
-        one = []
-        for r in range(12):
-            _s, _i, st = ix.query(qs[r % N_QUERIES], K, mode="fde_then_float", want_stats=True)
-            if r >= 4:
-                one.append(st.total_device_ms)
-        dev, stg_b, out_b = [], [], None
-        for r in range(9):
-            out_b, st = ix.query_batch(bq, K, mode="fde_then_float", want_stats=True)
-            if r >= 3:
-                dev.append(st.total_device_ms)
-                stg_b.append((st.encode_ms, st.coarse_ms, st.select_ms, st.rerank_ms, st.topk_ms))
-        d, sb = float(np.median(dev)), np.median(np.array(stg_b), axis=0)
-        res["fde_batched_32_queries"][key] = {
-            "device_ms_per_batch": round(d, 4), "device_us_per_query": round(d * 1e3 / 32, 2), "queries_per_s": round(32 / d * 1e3, 1),
-            "single_query_device_us": round(float(np.median(one)) * 1e3, 2), "throughput_vs_query_by_query": round(float(np.median(one)) * 32 / d, 2),
-            "stage_ms": {k: round(float(v), 4) for k, v in zip(("encode_32_queries", "coarse_gemm_one_slab_pass", "select", "rerank", "topk"), sb)},
-            "coarse_pass_GBps": round(n * per_page["fde"] / float(sb[1]) / 1e6, 1),
-            "recall_at_10": float(np.mean([synth.recall_at_k(out_b[i][1].tolist(), planted[i % N_QUERIES]) for i in range(32)])),
-            "same_ids_as_single_query": float(np.mean([out_b[i][1].tolist() == ix.query(bq[i], K, mode="fde_then_float")[1].tolist() for i in range(0, 32, 4)])),
-        }
-    ix.set_option(L.MV_OPT_FDE_COARSE_N, 1000)
-    # ---- recall@10 of the lossy paths vs the exact bf16 top-10
-    easy = recall_block(ix, qs[:N_QUERIES], [planted[qi] for qi in range(N_QUERIES)], K)
-    truths, hardness = [], []
-    for j, q in enumerate(hq):
-        pages = synth.hard_pages_of(hspec, j)
-        exact = ix.score_candidates(q, pages, pad_to=0)  # exact bf16 MaxSim (parity-checked kernel) of the hard set
-        top, info = synth.exact_truth_from_scores(pages, exact, K)
-        truths.append(top)
-        hardness.append(info)
-        full = ix.query(q, K, mode="float")[1].tolist()
-        assert full == top, "the hard set must hold the exact top-10"
-    hard = recall_block(ix, hq, truths, K)
-    rq = qs[N_QUERIES + NH :]
-    rtruth = [ix.query(q, K, mode="float")[1].tolist() for q in rq]
-    rnd = recall_block(ix, rq, rtruth, K)
-    res["recall_at_10_vs_exact_bf16"] = {
-        "planted_3x_margin": easy,
-        "hard_negatives": dict(hard, queries=NH, pages_per_query=synth.N_HARD,
-                               median_rel_gap_rank10_rank11=float(np.median([h["gap_10_11"] for h in hardness])),
-                               min_distractors_within_2pct_of_rank10=int(min(h["within_2pct"] for h in hardness))),
-        "unplanted_random_corpus": dict(rnd, queries=NR, note="no planted structure: the top-10 of 200 k random pages are separated by ~1e-3 relative"),
-    }
-    # ---- batched form (B x 32 tokens per slab pass)
-    res["batched_float"] = {}
+    res["by_rerank_n"] = {}
+    for nn in (64, 128, 256):
+        ix.set_option(L.MV_OPT_RERANK_N, nn)
+        ent = {}
+        for tier, code in (("hbm_bf16_slab", 0), ("pinned_host_over_pcie", 1)):
+            ix.set_option(L.MV_OPT_EXACT_TIER, code)
+            t = timed_mode(ix, qs, "fp8_then_float")
+            ent[tier] = {"device_ms": round(t["total_device_ms"], 4), "added_ms_over_fp8_scan": round(t["total_device_ms"] - base["total_device_ms"], 4),
+                         "rerank_ms": round(t["rerank_ms"], 4), "select_ms": round(t["select_ms"], 4),
+                         "rerank_GBps": round(nn * args.patches * 256 / max(t["rerank_ms"], 1e-6) / 1e6, 1)}
+        res["by_rerank_n"][f"n{nn}"] = ent
+    ix.set_option(L.MV_OPT_RERANK_N, 128)
+    ix.set_option(L.MV_OPT_EXACT_TIER, 1)  # recall through the host tier (same rows: same answers as the HBM tier)
+    res["recall_at_10_vs_exact_bf16"] = recall_of(ix, sets, truths, gaps, [("fp8_scan", ids_of("float_fp8")), ("fp8_then_float_n128", ids_of("fp8_then_float"))])
+    ix.close()
+    return res
+
+
+def batched_float_block(ix, queries, n, args, mfma_cal):
+    """Batched MFMA scan (B x 32 tokens per slab pass) on the headline bf16 index."""
+    from morphik_core_amd import synth
+
+    out = {}
     for B in (4, 16):
         ms = []
-        for r in range(7):
-            out, st = ix.query_batch(qs[:B], K, want_stats=True)
+        for r in range(6):
+            res_b, st = ix.query_batch(queries[:B], K, want_stats=True)
             if r >= 2:
                 ms.append(st.score_kernel_ms)
         m = float(np.median(ms))
         tf = 2.0 * B * args.qtokens * args.patches * 128 * n / m / 1e9
-        res["batched_float"][f"B{B}"] = {"kernel_ms": round(m, 4), "query_pages_per_s": round(B * n / m * 1e3, 1), "TFLOPs": round(tf, 1),
-                                         "frac_mfma_bf16_2500TF": round(tf / MFMA_BF16_PEAK_TF, 4),
-                                         "frac_of_measured_mfma_peak": None if not mfma_peak else round(tf / mfma_peak, 4),
-                                         "GBps": round(n * args.patches * 256 / m / 1e6, 1),
-                                         "recall_at_10": float(np.mean([synth.recall_at_k(out[qi][1].tolist(), planted[qi]) for qi in range(B)]))}
-    ix.close()
-    return res
+        out[f"B{B}"] = {"pages": n, "kernel_ms": round(m, 4), "query_pages_per_s": round(B * n / m * 1e3, 1), "TFLOPs": round(tf, 1),
+                        "frac_mfma_bf16_2500TF": round(tf / MFMA_BF16_PEAK_TF, 4), "GBps": round(n * args.patches * 256 / m / 1e6, 1),
+                        "frac_hbm_8TBps": round(n * args.patches * 256 / m / 1e6 / HBM_PEAK_GBPS, 4)}
+    return out
 
 
 def embed_workload(args, pages, quick=False):
@@ -342,7 +434,9 @@ def main():
                          "max_sim (MultiVectorStore); fde_fp8 = FDE coarse top-1000 -> exact fp8 rerank (configs[3] shard shape); "
                          "embed = configs[1] (ColPali-v1.2 architecture, 1 k pages -> top-10)")
     ap.add_argument("--no-aux", action="store_true", help="skip the secondary kernels' quick measurements (aux_paths)")
-    ap.add_argument("--aux-pages", type=int, default=200_000)
+    ap.add_argument("--aux-pages", type=int, default=200_000, help="pages of the two-tier (fp8 -> exact bf16 from the pinned-host tier) index in aux_paths (0 = skip)")
+    ap.add_argument("--full-shard-pages", type=int, default=1_250_000,
+                    help="pages of the e4m3 + FDE + sign-bit index in aux_paths.full_shard (BASELINE configs[3]/[4] per-GPU shard of 10 M pages / 8 GPUs; 0 = skip)")
     ap.add_argument("--aux-embed-pages", type=int, default=96, help="pages of the full-size encoder run inside aux_paths (0 = skip)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend for N>1 (nccl == RCCL; gloo + MV_BENCH_SINGLE_DEVICE=1 lets N ranks share one GPU to "
@@ -447,6 +541,17 @@ def main():
         synth.plant_neighbours(ix, spec, lo, hi)
     else:
         synth.plant_neighbours_any(ix, spec, synth.SEED_CORPUS, args.patches, lo, hi)
+    # the query / page sets the lossy paths are scored on (aux_paths): written into the bf16 corpus now, so the exact bf16
+    # truth can be taken from THIS slab before it is freed for the configs[3] / [4] shard
+    want_full = world == 1 and args.workload == "float" and not args.no_aux and args.full_shard_pages > 0
+    rsets = None
+    if want_full:
+        t1 = time.time()
+        rsets = recall_sets(args, n_total, local_rank, queries, spec)
+        for name, st_ in rsets.items():
+            if name != "planted":
+                synth.plant_neighbours(ix, st_["spec"], lo, hi)
+        log(f"[rank {rank}] recall sets: {sum(len(v['spec']) for v in rsets.values())} structured pages written in {time.time()-t1:.1f}s")
     MODE = WL["mode"]
     torch.cuda.synchronize()
     log(f"[rank {rank}] corpus generated + planted in {time.time()-t0:.1f}s")
@@ -500,9 +605,19 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total * args.steps / elapsed
+    local_only_ms = None
+    if dist_on:  # the same steps WITHOUT the exchange (scan + local top-k only): what the collective + merge add per step
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            gpu_topk(queries[i % N_QUERIES], K)
+        fence()
+        t = torch.tensor([(time.perf_counter() - t0) / args.steps * 1e3], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        local_only_ms = float(t.item())
 
     # ---- roofline of the dominant kernel (the page scan), from HIP events recorded in the timed region
-    kms = np.array([s.score_kernel_ms for s in stats if s is not None and s.score_kernel_ms > 0])
+    kms = np.array([s.score_kernel_ms for s in stats[: args.steps] if s is not None and s.score_kernel_ms > 0])  # the timed steps' launches
     if args.workload == "fde_fp8":  # coarse scan of every FDE vector + exact rerank of 1000 candidates
         bytes_per_launch = n_local * 20480 + min(1000, n_local) * args.patches * 128
     else:
@@ -558,11 +673,11 @@ def main():
         }
         cpu = None
         max_rel = None
-        if world == 1 and not args.no_cpu_baseline and args.workload == "float":
+        if not args.no_cpu_baseline and args.workload == "float":  # rank 0 of any world size: its own shard is the sample
             from oracle import oracle as orc  # checker / baseline only
 
             ns = min(args.cpu_sample_pages, n_local)
-            sample = ix.read_pages(0, ns)[:, : args.patches]
+            sample = ix.read_pages(0, ns)[:, : args.patches]  # the device's own bytes (planted rows included)
             q0 = queries[0]
             cpu = cpu_baseline(sample, q0)
             want = orc.maxsim_float_np(orc.bf16_to_f32(q0), orc.bf16_to_f32(sample))
@@ -571,7 +686,9 @@ def main():
             # the device generator must equal the oracle's across the WHOLE slab (catches partial fills),
             # and the scan must agree with the oracle on those far-apart pages too
             planted_pages = {p for (_, _, p, _, _) in spec}
-            probe = [p for p in np.unique(np.linspace(0, n_local - 1, 24).astype(np.int64)).tolist() if p not in planted_pages]
+            if rsets:
+                planted_pages |= {t[2] for st_ in rsets.values() for t in st_["spec"]}
+            probe = [p for p in np.unique(np.linspace(0, n_local - 1, 24).astype(np.int64)).tolist() if (lo + p) not in planted_pages]
             gen_ok = True
             for p in probe:
                 dev_page = ix.read_pages(p, 1)[0, : args.patches]
@@ -581,7 +698,7 @@ def main():
                 max_rel = max(max_rel, float(abs(full[p] - w) / max(abs(w), 1e-6)))
             if not gen_ok:
                 sys.exit("bench.py: device-generated corpus differs from the oracle generator")
-        if world == 1 and not args.no_cpu_baseline and args.workload == "binary":
+        if not args.no_cpu_baseline and args.workload == "binary":
             from oracle import oracle as orc  # checker / baseline only
 
             ns = min(args.cpu_sample_pages, n_local, 2048)
@@ -629,6 +746,9 @@ def main():
                 "parallelism": "row-shard x%d + all-gather top-k" % world,
                 "collective_backend": (args.backend if dist_on else None),
                 "rccl_ranks": (dist.get_world_size() if (dist_on and args.backend == "nccl") else 0),
+                "kernel_ms_per_rank": [round(x, 4) for x in per_rank_kms],
+                "local_scan_and_topk_ms_per_step": None if local_only_ms is None else round(local_only_ms, 4),
+                "collective_and_merge_ms_per_step": None if local_only_ms is None else round(ms_per_step - local_only_ms, 4),
             },
             "recall_at_10": recall10,
             "max_rel_score_err_vs_oracle": max_rel,
@@ -653,6 +773,27 @@ def main():
             "stage_ms": {k: round(float(v), 4) for k, v in zip(("encode_32_queries", "coarse_gemm_one_slab_pass", "select", "rerank_fp8", "topk"), sb)},
             "coarse_pass_GBps": round(n_local * 20480 / float(sb[1]) / 1e6, 1), "recall_at_10": float(np.mean(rb)),
         }
+    aux = {}
+    truths = gaps = None
+    if out is not None and want_full:
+        try:  # exact bf16 truth of every recall set + the batched MFMA scan, on the headline slab before it is freed
+            t1 = time.time()
+            truths, gaps = {}, {}
+            for name, st_ in rsets.items():
+                truths[name], gaps[name] = exact_truth(ix, st_["queries"])
+            for j, top in enumerate(truths["hard_negatives"]):  # the near-tied set must hold the exact top-10
+                assert set(top) <= set(synth.hard_pages_of(rsets["hard_negatives"]["spec"], j)), "hard set does not hold the exact top-10"
+            assert all(t == [p for (qq, _r, p, _a, _b) in spec if qq == qi] for qi, t in enumerate(truths["planted"])), "planted truth"
+            aux["truth"] = {"source": "exact bf16 float scan over the %d-page corpus (batched form, 16 queries per slab pass), top-11" % n_total,
+                            "seconds": round(time.time() - t1, 1),
+                            "median_rel_gap_rank10_rank11": {k_: float(np.median(v)) for k_, v in gaps.items()}}
+            aux["batched_float"] = batched_float_block(ix, queries, n_local, args, None)
+            for B in (4, 16):
+                res_b = ix.query_batch(queries[:B], K)
+                aux["batched_float"][f"B{B}"]["recall_at_10"] = float(np.mean([synth.recall_at_k(res_b[qi][1].tolist(), truths["planted"][qi]) for qi in range(B)]))
+        except Exception as e:  # noqa: BLE001 -- the headline number must survive a failure of the side measurements
+            aux["truth_error"] = repr(e)
+            truths = None
     ix.close()
     if out is not None and world == 1:
         # measured denominators, same process, GPU still warm from the timed run (the 262 GB slab had to go first): the scan's
@@ -664,17 +805,32 @@ def main():
         measured_peak = calibrate("read_ldsdma", cal_bytes, 8, device=local_rank)
         measured_nt = calibrate("read_nt", min(cal_bytes, 64 << 30), 5, device=local_rank)
         measured_mfma = calibrate("mfma_bf16", 0, 5, device=local_rank)
-        log(f"[rank 0] calibration: nt LDS-DMA ring without arithmetic {measured_peak:.0f} GB/s (plain nt loads {measured_nt:.0f}); bf16 MFMA {measured_mfma:.0f} TFLOP/s")
+        measured_mfma32 = calibrate("mfma_bf16_32x32", 0, 5, device=local_rank)
+        log(f"[rank 0] calibration: nt LDS-DMA ring without arithmetic {measured_peak:.0f} GB/s (plain nt loads {measured_nt:.0f}); bf16 MFMA 16x16x32 {measured_mfma:.0f} / 32x32x16 {measured_mfma32:.0f} TFLOP/s")
         rf = out["roofline"]
         rf["measured_read_peak"] = round(measured_peak, 1)
         rf["frac_of_measured_peak"] = round(rf["achieved"] / measured_peak, 4)
         rf["measured_plain_nt_read"] = round(measured_nt, 1)
         rf["measured_mfma_bf16_tflops"] = round(measured_mfma, 1)
+        rf["measured_mfma_bf16_32x32x16_tflops"] = round(measured_mfma32, 1)
+        rf["measured_mfma_note"] = ("register-only MFMA chains, pseudo-random operands of embedding magnitude, ~4 ms launches (sustained clock): "
+                                    "a proxy for what the matrix pipe sustains on this box, not a strict ceiling")
+        rf["measured_read_peak_note"] = "a proxy (the scan's own transport without arithmetic), not a strict ceiling: boxes read 0.99-1.02 of it"
+        for ent in aux.get("batched_float", {}).values():
+            ent["frac_of_measured_mfma_16x16x32"] = round(ent["TFLOPs"] / measured_mfma, 4)
+            ent["frac_of_measured_mfma_32x32x16"] = round(ent["TFLOPs"] / measured_mfma32, 4)
     if out is not None and world == 1 and not args.no_aux:
-        try:
-            out["aux_paths"] = aux_paths(args, local_rank, measured_mfma)
-        except Exception as e:  # the headline number must survive a failure of the side measurements
-            out["aux_paths"] = {"error": repr(e)}
+        out["aux_paths"] = aux
+        if truths is not None:
+            try:  # BASELINE configs[3] / [4] at their per-GPU shard shape
+                aux["full_shard"] = full_shard(args, local_rank, rsets, truths, gaps, n_total)
+            except Exception as e:  # noqa: BLE001
+                aux["full_shard"] = {"error": repr(e)}
+        if args.aux_pages > 0:
+            try:  # fp8 scan -> exact bf16 re-score from the exact tier (HBM / pinned host)
+                aux["fp8_then_float"] = two_tier(args, local_rank)
+            except Exception as e:  # noqa: BLE001
+                aux["fp8_then_float"] = {"error": repr(e)}
         if args.aux_embed_pages > 0:
             try:  # configs[1] at full model size, short: encoder -> device ingest -> top-10
                 r = embed_workload(args, args.aux_embed_pages, quick=True)

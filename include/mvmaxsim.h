@@ -57,7 +57,8 @@ enum {
   MV_WITH_HOST_EXACT = 16 /* exact bf16 rows kept in PINNED HOST memory (262 144 B / page of host RAM, none of HBM), mapped
                              into the device's address space: the exact tier of MV_MODE_FP8_THEN_FLOAT for a shard whose
                              bf16 slab does not fit HBM beside its fp8 slab ("host-resident exact vectors
-                             with a gather of the candidates") */
+                             with a gather of the candidates").  May be combined with MV_WITH_FLOAT (both tiers
+                             hold the same rows; MV_OPT_EXACT_TIER picks the one the rerank reads) */
 };
 
 /* fixed_dimensional_encoding.FixedDimensionalEncodingConfig as constructed at
@@ -127,6 +128,8 @@ typedef enum {
   MV_OPT_LONG_QUERY_VARIANT = 10, /* single query of > 64 rows over the whole slab: 1 = row-split workgroup of the batched scan
                                     (default), 0 = page-split kernel in passes of 128 rows */
   MV_OPT_RERANK_N = 13,          /* MV_MODE_FP8_THEN_FLOAT: candidates re-scored exactly (1..1024, default 128) */
+  MV_OPT_EXACT_TIER = 14,        /* MV_MODE_FP8_THEN_FLOAT on an index holding BOTH exact tiers: 0 = the bf16 slab in HBM (default),
+                                    1 = the pinned-host tier (what an index without a bf16 slab always uses) */
   MV_OPT_FDE_BATCH_VARIANT = 12  /* mv_query_topk_batch in the FDE modes: 0 = batched pipeline (default): up to 32 queries per pass
                                     over the FDE slab (bf16 MFMA, query FDE as bf16 hi + lo), batched selection, every query's
                                     candidates reranked in one launch, one read-back; 1 = query by query; 2 = as 0 with the query

@@ -81,6 +81,7 @@ MV_OPT_LONG_QUERY_VARIANT = 10
 MV_OPT_FDE_QUERY_ENCODE_VARIANT = 11
 MV_OPT_FDE_BATCH_VARIANT = 12
 MV_OPT_RERANK_N = 13
+MV_OPT_EXACT_TIER = 14
 MV_CAL_READ_NT, MV_CAL_MFMA_BF16, MV_CAL_READ_LDSDMA, MV_CAL_MFMA_BF16_32X32 = 1, 2, 3, 4
 MV_COMM_AUTO, MV_COMM_RCCL, MV_COMM_P2P, MV_COMM_HOST = 0, 1, 2, 3
 

@@ -416,7 +416,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
       rc = launch_cand_prepare(ix, ix->d_out_id, nullptr, (int)nc, /*pad_sem=*/0);  // a full-corpus scan has no padding rows
       if (rc) return rc;
       if (st) MV_HIP(hipEventRecord(ix->ev_st[2], ix->stream));
-      const uint16_t* exact = (ix->cfg.flags & MV_WITH_FLOAT) ? ix->slab : ix->d_exact;
+      const uint16_t* exact = ((ix->cfg.flags & MV_WITH_FLOAT) && !(ix->exact_tier == 1 && ix->d_exact)) ? ix->slab : ix->d_exact;
       rc = float_scan(ix, n_q, nullptr, 0, ix->d_cand, nc, 0, ix->d_cand_pads, ix->d_cand_scores, &out->launches, /*no_mask=*/true, nullptr, exact);
       if (rc) return rc;
       out->launches += 2;
@@ -716,7 +716,6 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   if (cfg->stride_rows < 16 || cfg->stride_rows % 16) { set_error("stride_rows must be a positive multiple of 16 (got %d)", cfg->stride_rows); return MV_ERR_INVALID; }
   if (cfg->capacity_pages < 1 || cfg->capacity_pages > 0x7fffffffLL) { set_error("capacity_pages out of range"); return MV_ERR_INVALID; }
   if (!(cfg->flags & (MV_WITH_FLOAT | MV_WITH_BINARY | MV_WITH_FDE | MV_WITH_FP8))) { set_error("flags select no slab"); return MV_ERR_INVALID; }
-  if ((cfg->flags & MV_WITH_HOST_EXACT) && (cfg->flags & MV_WITH_FLOAT)) { set_error("MV_WITH_HOST_EXACT is the exact tier of an index WITHOUT a bf16 slab in HBM: drop one of the two flags"); return MV_ERR_INVALID; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device available (libmvmaxsim requires an MI355X / gfx950 GPU)"); return MV_ERR_HIP; }
   if (cfg->device < 0 || cfg->device >= ndev) { set_error("device %d out of range (have %d)", cfg->device, ndev); return MV_ERR_INVALID; }
@@ -812,6 +811,7 @@ int mv_index_set_option(mv_index* ix, int option, int64_t value) {
     case MV_OPT_FILTER_COMPACT_PCT: ix->filter_compact_pct = (int)value; return MV_OK;
     case MV_OPT_FDE_QUERY_ENCODE_VARIANT: ix->fde_query_encode_variant = (int)value; return MV_OK;
     case MV_OPT_FDE_BATCH_VARIANT: ix->fde_batch_variant = (int)value; return MV_OK;
+    case MV_OPT_EXACT_TIER: ix->exact_tier = (int)value; return MV_OK;
     case MV_OPT_RERANK_N:
       if (value < 1 || value > kTopkMaxDeviceK) { set_error("RERANK_N must be 1..%d", kTopkMaxDeviceK); return MV_ERR_INVALID; }
       ix->rerank_n = value; return MV_OK;

@@ -123,6 +123,7 @@ struct mv_index {
   int fde_query_encode_variant = 2;  // the ONE query page: 2 = latency kernel (one block per repetition, default), 1 = bulk f32-MFMA kernel, 0 = scalar kernel
   int64_t fde_coarse_n = 0;
   int64_t rerank_n = 128;  // MV_MODE_FP8_THEN_FLOAT: candidates re-scored on the exact tier
+  int exact_tier = 0;      // 0 = the bf16 slab in HBM when the index has one, else the pinned-host tier; 1 = the host tier when present
   int fde_cosine = 1;
   int pad_semantics = -1;  // -1: mode default (reference batch rule for FDE_THEN_FLOAT / candidates, none for full scan)
 };

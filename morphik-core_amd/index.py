@@ -134,7 +134,7 @@ class MvIndex:
         with_host_exact: bool = False,
     ):
         """with_host_exact: keep the exact bf16 rows in PINNED HOST memory (no HBM) as the exact tier of mode
-        "fp8_then_float" -- for shards whose bf16 slab does not fit beside the fp8 slab (not together with with_float)."""
+        "fp8_then_float" -- for shards whose bf16 slab does not fit beside the fp8 slab."""
         self.fde_config = fde or FdeConfig()
         flags = ((MV_WITH_FLOAT if with_float else 0) | (MV_WITH_BINARY if with_binary else 0) | (MV_WITH_FDE if with_fde else 0)
                  | (MV_WITH_FP8 if with_fp8 else 0) | (MV_WITH_HOST_EXACT if with_host_exact else 0))

@@ -155,3 +155,61 @@ def exact_truth_from_scores(pages: Sequence[int], scores: np.ndarray, k: int = 1
     info = {"gap_10_11": float((sk - s[order[k]]) / abs(sk)) if len(order) > k else float("nan"),
             "within_2pct": int(np.sum(s[order[k:]] >= sk * 0.98))}
     return top, info
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Clustered corpus mode (graded relevance).  Planted neighbours have a 3x margin and hard negatives are one tight
+# cluster per query; real corpora sit in between: many pages share a TOPIC with the query and differ in how much of it
+# they cover and how closely.  Topic t owns a vocabulary of V unit vectors.  A page of topic t overwrites R of its rows
+# with normalize(vocab[i] + sigma_p * noise), i drawn from a page-specific SUBSET of the vocabulary (coverage c_p of the
+# V words) -- sigma_p and c_p vary from page to page, so the exact MaxSim scores of a topic's pages against a query of
+# that topic (32 rows normalize(vocab[i] + SIGMA_Q * noise)) spread continuously from "near duplicate" down to the random
+# background.  Truth is never assumed: it is the exact bf16 scan's top-10 over the whole corpus, and the rank-10 / rank-11
+# margin of every query is reported so recall can be read as a function of it.
+# ---------------------------------------------------------------------------------------------------------------------
+SEED_CLUSTER = 11
+TOPIC_VOCAB = 64
+TOPIC_PAGES = 48
+TOPIC_ROWS = 256
+SIGMA_Q = 0.3
+
+
+def _unit(x: np.ndarray) -> np.ndarray:
+    return x / np.linalg.norm(x, axis=-1, keepdims=True)
+
+
+def clustered_spec(n_topics: int, n_pages_total: int, stride_rows: int, q_tokens: int = 32, pages_per_topic: int = TOPIC_PAGES,
+                   seed: int = SEED_CLUSTER, exclude: Sequence[int] = ()):
+    """-> (queries [n_topics] of bf16 [q_tokens,128], spec [(topic, j, GLOBAL page id, first_row, rows_bf16)]).
+    A pure function of its arguments; pages are chosen outside `exclude`."""
+    rng0 = np.random.default_rng(seed)
+    excl = np.fromiter((int(p) for p in exclude), dtype=np.int64)
+    pool = rng0.choice(n_pages_total, size=n_topics * pages_per_topic + len(excl), replace=False)
+    pool = pool[~np.isin(pool, excl)][: n_topics * pages_per_topic].reshape(n_topics, pages_per_topic)
+    R = min(TOPIC_ROWS, stride_rows)
+    queries, spec = [], []
+    for t in range(n_topics):
+        rng = np.random.default_rng([seed, t])
+        vocab = _unit(rng.standard_normal((TOPIC_VOCAB, 128)).astype(np.float32))
+        qi = rng.integers(0, TOPIC_VOCAB, size=q_tokens)
+        qn = rng.standard_normal((q_tokens, 128)).astype(np.float32) / np.sqrt(128.0)
+        queries.append(f32_to_bf16(_unit(vocab[qi] + SIGMA_Q * qn)))
+        for j in range(pages_per_topic):
+            sigma = float(rng.uniform(0.2, 1.2))       # how closely the page's rows follow the vocabulary
+            cover = float(rng.uniform(0.25, 1.0))      # share of the vocabulary the page uses at all
+            words = rng.permutation(TOPIC_VOCAB)[: max(int(round(cover * TOPIC_VOCAB)), 1)]
+            wi = words[rng.integers(0, len(words), size=R)]
+            noise = rng.standard_normal((R, 128)).astype(np.float32) / np.sqrt(128.0)
+            rows = f32_to_bf16(_unit(vocab[wi] + sigma * noise))
+            row0 = int(rng.integers(0, max(stride_rows - R, 0) + 1))
+            spec.append((t, j, int(pool[t, j]), row0, rows))
+    return queries, spec
+
+
+def margin_bins(gaps: Sequence[float], hits: Sequence[float], edges=(1e-3, 1e-2)) -> Dict[str, Dict[str, float]]:
+    """Mean recall of the queries whose rank-10 / rank-11 relative margin falls below edges[0], between the edges, above."""
+    g = np.asarray(gaps, np.float64)
+    h = np.asarray(hits, np.float64)
+    names = [f"margin<{edges[0]:g}", f"{edges[0]:g}<=margin<{edges[1]:g}", f"margin>={edges[1]:g}"]
+    masks = [g < edges[0], (g >= edges[0]) & (g < edges[1]), g >= edges[1]]
+    return {n: {"queries": int(m.sum()), "recall_at_10": (float(h[m].mean()) if m.any() else None)} for n, m in zip(names, masks)}

@@ -1098,7 +1098,7 @@ def test_errors_are_loud(mv):
 
 
 # ------------------------------------------------------------------ fp8 scan -> exact bf16 re-score from the exact tier
-@pytest.mark.parametrize("tier", ["host", "hbm"])
+@pytest.mark.parametrize("tier", ["host", "hbm", "both"])
 def test_fp8_then_float_rescoring_from_the_exact_tier(mv, tier, tmp_path):
     """MV_MODE_FP8_THEN_FLOAT: e4m3 scan -> top-n -> exact bf16 MaxSim of the n candidates read from the exact tier (pinned
     host memory mapped into the device, or the bf16 slab) -> top-k.  Checked against the oracle composed the same way on
@@ -1109,7 +1109,9 @@ def test_fp8_then_float_rescoring_from_the_exact_tier(mv, tier, tmp_path):
     from morphik_core_amd.index import MvIndex, allow_bitmap
 
     N, stride, nrows, NR = 1200, 64, 60, 48
-    ix = _idx(mv, capacity_pages=N + 8, stride_rows=stride, with_float=tier == "hbm", with_fp8=True, with_host_exact=tier == "host")
+    ix = _idx(mv, capacity_pages=N + 8, stride_rows=stride, with_float=tier != "host", with_fp8=True, with_host_exact=tier != "hbm")
+    if tier == "both":  # an index holding both exact tiers: the rerank is told to read the pinned-host one
+        ix.set_option(_lib.MV_OPT_EXACT_TIER, 1)
     ix.fill_synthetic(1234, 0, N - 40, n_rows=nrows, pages_per_doc=4)
     rag = [orc.synth_rows(77, j, 0, 10 + j) for j in range(40)]  # ragged pages through the host add path
     ix.add(rag, doc_ordinals=[1000 + j for j in range(40)])

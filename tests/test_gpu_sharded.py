@@ -293,3 +293,31 @@ def test_shard_comm_rccl_single_rank_communicator():
         assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist()
     comm.close()
     ix.close()
+
+
+# ------------------------------------------------------------------ the N > 1 bench line is as complete as the N = 1 line
+def test_bench_two_ranks_line_carries_roofline_cpu_baseline_and_oracle_parity():
+    """`python bench.py --gpus 2` (self-spawned ranks sharing the one GPU, gloo): the JSON line of a multi-rank run must
+    carry everything the 1-GPU line does -- roofline, cpu_baseline, the sampled oracle parity, recall -- plus per-rank
+    kernel times and what the exchange adds per step."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MV_BENCH_SINGLE_DEVICE="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--pages", "40000", "--steps", "6", "--warmup", "2",
+           "--cpu-sample-pages", "512", "--no-aux"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=root)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and lines, p.stderr[-2000:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["recall_at_10"] == 1.0 and d["config"]["pages_total"] == 40000
+    rf, cpu = d["roofline"], d["cpu_baseline"]
+    assert rf["bound"] == "hbm" and rf["achieved"] > 0 and 0 < rf["frac"] < 1.2 and len(rf["kernel_ms_per_rank"]) == 2
+    assert cpu is not None and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["kind"] == "port"
+    assert d["max_rel_score_err_vs_oracle"] is not None and d["max_rel_score_err_vs_oracle"] < 1e-3 and d["generator_matches_oracle"] is True
+    cfg = d["config"]
+    assert len(cfg["kernel_ms_per_rank"]) == 2 and cfg["collective_and_merge_ms_per_step"] is not None and cfg["local_scan_and_topk_ms_per_step"] > 0
+    assert cfg["collective_backend"] == "gloo" and cfg["parallelism"].startswith("row-shard x2")
