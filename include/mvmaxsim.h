@@ -138,6 +138,12 @@ typedef enum {
                                     default walks a workgroup's tiles in pairs: same scores, half the fragment traffic) */
 } mv_option;
 
+/* Bumped whenever a signature, a struct layout or an enum value of this header changes incompatibly.  A binding compares
+ * mv_abi_version() of the library it loaded with the MV_ABI_VERSION it was written against and refuses a mismatch (a stale
+ * libmvmaxsim.so driven with newer argument lists would corrupt memory silently). */
+#define MV_ABI_VERSION 3
+MV_API int mv_abi_version(void);
+
 MV_API const char* mv_last_error(void);
 MV_API const char* mv_version(void);
 MV_API int mv_device_count(void);

@@ -93,8 +93,10 @@ class CandRecC(C.Structure):
 
 
 # every symbol include/mvmaxsim.h declares (tests check the .so exports all of them)
+MV_ABI_VERSION = 3  # include/mvmaxsim.h: the header revision this binding's argument lists were written against
+
 EXPORTS = [
-    "mv_last_error", "mv_version", "mv_device_count", "mv_index_create", "mv_index_destroy", "mv_index_set_option",
+    "mv_abi_version", "mv_last_error", "mv_version", "mv_device_count", "mv_index_create", "mv_index_destroy", "mv_index_set_option",
     "mv_index_size", "mv_index_capacity", "mv_index_add", "mv_index_add_device", "mv_index_add_bits", "mv_index_remove_doc",
     "mv_index_remove_page", "mv_index_compact", "mv_index_read_pages", "mv_index_write_rows", "mv_index_replace_page", "mv_index_read_fp8", "mv_index_fill_synthetic", "mv_synth_rows",
     "mv_query_topk", "mv_query_topk_device", "mv_query_topk_batch", "mv_merge_topk", "mv_score_all", "mv_score_candidates", "mv_score_candidates_pads", "mv_index_page_rows",
@@ -137,6 +139,12 @@ def lib() -> C.CDLL:
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
         _preload_torch_hip_runtime()
         L = C.CDLL(_LIB)
+        have = L.mv_abi_version() if hasattr(L, "mv_abi_version") else 0
+        if have != MV_ABI_VERSION:
+            # a library left over from another revision of the header: its entry points would be driven with the wrong
+            # argument lists -- refuse it instead of corrupting memory (rebuild: morphik_core_amd.build_library(force=True))
+            raise MvError(-5, f"{_LIB} implements ABI revision {have}, this binding needs {MV_ABI_VERSION}: rebuild it "
+                              "(morphik_core_amd.build_library(force=True))")
         vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
         L.mv_last_error.restype = C.c_char_p
         L.mv_version.restype = C.c_char_p

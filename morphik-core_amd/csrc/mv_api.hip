@@ -676,7 +676,8 @@ struct ExclusiveLock {
 extern "C" {
 
 const char* mv_last_error(void) { return g_err.c_str(); }
-const char* mv_version(void) { return "mvmaxsim 0.1 (gfx950)"; }
+const char* mv_version(void) { return "mvmaxsim 0.3 (gfx950)"; }
+int mv_abi_version(void) { return MV_ABI_VERSION; }
 
 int mv_device_count(void) {
   int n = 0;

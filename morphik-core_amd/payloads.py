@@ -166,11 +166,23 @@ class PayloadStore:
                 logger.warning("Failed to delete external storage key %s for document %s: %s", k, document_id, r)
 
 
+_META_CACHE: Dict[str, Dict[str, Any]] = {}
+
+
 def parse_metadata(meta_json: Optional[str]) -> Dict[str, Any]:
-    if not meta_json:
+    """chunk_metadata column -> dict.  Every hit of every query passes through here: the decoded form of a JSON string is
+    kept (bounded), and each caller gets its own top-level dict."""
+    if not meta_json or meta_json == "{}":
         return {}
-    try:
-        m = json.loads(meta_json)
-        return m if isinstance(m, dict) else {}
-    except Exception:  # noqa: BLE001
-        return {}
+    m = _META_CACHE.get(meta_json)
+    if m is None:
+        try:
+            m = json.loads(meta_json)
+            if not isinstance(m, dict):
+                m = {}
+        except Exception:  # noqa: BLE001
+            m = {}
+        if len(_META_CACHE) >= 65536:
+            _META_CACHE.clear()
+        _META_CACHE[meta_json] = m
+    return dict(m)

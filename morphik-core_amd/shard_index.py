@@ -177,10 +177,20 @@ class ShardedIndex:
         self = cls.__new__(cls)
         self.devices = [int(d) for d in devices]
         self.n_shards = len(self.devices)
+        import os
+
+        if os.path.exists(f"{path}.shard{self.n_shards}"):
+            raise ValueError(f"{path}: more shard files than the {self.n_shards} devices given -- refusing to drop shards")
         self.shards = [index_cls.load(f"{path}.shard{r}", device=d) for r, d in enumerate(self.devices)]
         self.per = self.shards[0].capacity
         self.stride_rows = self.shards[0].stride_rows
         self.id_base = self.shards[0].id_base
+        for r, sh in enumerate(self.shards):  # the files must be the consecutive id ranges of ONE checkpoint
+            if sh.id_base != self.id_base + r * self.per or sh.capacity != self.per:
+                for x in self.shards:
+                    x.close()
+                raise ValueError(f"{path}.shard{r}: id_base {sh.id_base} / capacity {sh.capacity} do not continue shard 0 "
+                                 f"(id_base {self.id_base}, {self.per} slots per shard)")
         self.device = self.devices[0]
         self.comm = comm_cls(self.shards, transport=transport)
         return self

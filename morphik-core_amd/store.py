@@ -126,6 +126,9 @@ class MI355XMultiVectorStore(BaseVectorStore):
         self._doc_pages: Dict[str, List[int]] = {}
         # bumped by compact() (page ids are renumbered): a query whose scan ran against the old numbering is re-run
         self._generation = 0
+        # bumped whenever the document-ordinal / app tables change: cached doc_ids / app bitmaps are valid for one stamp
+        self._ord_stamp = 0
+        self._allow_cache: Dict[Any, Tuple[int, Any, bool]] = {}
         self._last_store_metrics: Dict[str, Any] = {}
         self.last_query_timing: Dict[str, float] = {}
 
@@ -208,6 +211,11 @@ class MI355XMultiVectorStore(BaseVectorStore):
                     self._next_ord += 1
                     self._doc_ord[c.document_id] = o
                     self._doc_app[o] = app_id
+                    self._ord_stamp += 1
+                elif self._filter_by_app and self._doc_app.get(o) != app_id:
+                    # re-ingested under another app: the document moves to that namespace (its chunks are upserted below)
+                    self._doc_app[o] = app_id
+                    self._ord_stamp += 1
                 ords.append(o)
             # ADD FIRST: if the slab is full or the device call fails nothing was published (mv_index_add is all or
             # nothing) and the previous versions of these chunks are still live
@@ -310,18 +318,33 @@ class MI355XMultiVectorStore(BaseVectorStore):
         (fast_multivector_store.py:526).  Returns (bitmap or None, empty?)."""
         from .index import allow_bitmap
 
+        # The bitmap of a (doc_ids, app) pair only changes when documents are added / compacted away (_ord_stamp): requests
+        # repeat the same authorised document set, so it is built once per stamp, not once per request (deleted documents
+        # keep their ordinal until compact(); their pages are tombstoned in the slab itself).
+        want = (app_id if app_id is not None else DEFAULT_APP_ID) if self._filter_by_app else None
+        key = (tuple(doc_ids) if doc_ids else None, want)
+        hit = self._allow_cache.get(key)
+        if hit is not None and hit[0] == self._ord_stamp:
+            return hit[1], hit[2]
         ords = None
         if doc_ids:
             ords = [self._doc_ord[d] for d in doc_ids if d in self._doc_ord]
         if self._filter_by_app:
-            want = app_id if app_id is not None else DEFAULT_APP_ID
-            base = list(self._doc_ord.values()) if ords is None else ords
-            ords = [o for o in base if self._doc_app.get(o) == want]
+            if ords is None and all(a == want for a in self._doc_app.values()):
+                ords = None  # every document belongs to this app: the namespace filter is the identity
+            else:
+                base = list(self._doc_ord.values()) if ords is None else ords
+                ords = [o for o in base if self._doc_app.get(o) == want]
         if ords is None:
-            return None, False
-        if not ords:
-            return None, True
-        return allow_bitmap(ords, self._next_ord), False
+            res = (None, False)
+        elif not ords:
+            res = (None, True)
+        else:
+            res = (allow_bitmap(ords, self._next_ord), False)
+        if len(self._allow_cache) >= 512:
+            self._allow_cache.clear()
+        self._allow_cache[key] = (self._ord_stamp, res[0], res[1])
+        return res
 
     def _query_sync(self, q: np.ndarray, k: int, allow) -> Tuple[np.ndarray, np.ndarray]:
         ix = self._require_index()
@@ -414,20 +437,17 @@ class MI355XMultiVectorStore(BaseVectorStore):
         """content column -> content: storage keys are downloaded, except image payloads the caller asked to skip (their
         key is returned as the content: multi_vector_store.py:778-790, fast_multivector_store.py:583-586)."""
         metas = [parse_metadata(r[3]) for r in rows]
-        tasks = []
-        for r, m in zip(rows, metas):
-            content = r[2]
-            if self._use_external() and is_storage_key(content) and not (skip_image_content and m.get("is_image")):
-                tasks.append(self._payloads.get(content, m))
-            else:
-                tasks.append(asyncio.sleep(0, result=content))
-        resolved = await asyncio.gather(*tasks, return_exceptions=True)
-        out = []
-        for r, c in zip(rows, resolved):
-            if isinstance(c, Exception):
-                logger.error("Failed to retrieve content from storage for chunk %s-%s: %s", r[0], r[1], c)
-                c = r[2]
-            out.append(c)
+        out = [r[2] for r in rows]
+        if not self._use_external():
+            return out, metas  # nothing to fetch: no task, no await (the common case of an in-memory payload table)
+        fetch = [j for j, (r, m) in enumerate(zip(rows, metas)) if is_storage_key(r[2]) and not (skip_image_content and m.get("is_image"))]
+        if fetch:
+            resolved = await asyncio.gather(*[self._payloads.get(rows[j][2], metas[j]) for j in fetch], return_exceptions=True)
+            for j, c in zip(fetch, resolved):
+                if isinstance(c, Exception):
+                    logger.error("Failed to retrieve content from storage for chunk %s-%s: %s", rows[j][0], rows[j][1], c)
+                else:
+                    out[j] = c
         return out, metas
 
     async def query_similar(
@@ -480,10 +500,12 @@ class MI355XMultiVectorStore(BaseVectorStore):
         if not chunk_identifiers:
             return []
         rows = []
+        want = (app_id if app_id is not None else DEFAULT_APP_ID) if self._filter_by_app else None
         with self._lock:
             for doc_id, chunk_no in dict.fromkeys((d, int(c)) for d, c in chunk_identifiers):
                 page = self._page_of.get((doc_id, chunk_no))
-                if page is not None:
+                # per-app namespaces: a chunk is visible through ITS app only (fast_multivector_store.py:615 reads self.ns(app_id))
+                if page is not None and (want is None or self._doc_app.get(self._doc_ord.get(doc_id, -1)) == want):
                     rows.append(self._rows[page])
         contents, metas = await self._resolve_contents(rows, skip_image_content)
         return [DocumentChunk(document_id=r[0], chunk_number=r[1], content=c, embedding=[], metadata=m, score=0.0)
@@ -496,6 +518,8 @@ class MI355XMultiVectorStore(BaseVectorStore):
                 o = self._doc_ord.get(document_id)
                 if o is None:
                     return True  # DELETE of nothing succeeds
+                if self._filter_by_app and self._doc_app.get(o) != (app_id if app_id is not None else DEFAULT_APP_ID):
+                    return True  # another app's document: nothing of THIS namespace to delete (fast_multivector_store.py:643)
                 ix = self._require_index()
                 ix.remove_doc(o)
                 for page in self._doc_pages.pop(document_id, []):
@@ -534,6 +558,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
                 self._doc_app.pop(self._doc_ord.pop(d), None)
                 self._doc_pages.pop(d, None)
             self._generation += 1
+            self._ord_stamp += 1
             return before - len(ix)
 
     # ------------------------------------------------------------------ checkpoint / resume
@@ -548,21 +573,31 @@ class MI355XMultiVectorStore(BaseVectorStore):
     def save(self, directory: str) -> None:
         """Persist the HBM index (mv_index_save: raw slabs + metadata, written to a temp file and renamed) and the store's
         bookkeeping (keys, document ordinals) so a restarted process resumes without re-embedding -- the role Postgres /
-        S3 play for the reference stores (checkpoint/resume).  store.json is written LAST and carries
-        the checkpoint id also stamped beside the index file: load() refuses a mixed pair."""
+        S3 play for the reference stores (checkpoint/resume).
+        Order (each step atomic, a crash between any two leaves a directory load() REFUSES or the previous checkpoint):
+          1. index.id <- "writing:<new id>"      the old pair is invalidated BEFORE any index file is touched
+          2. index.mv (every shard file)         temp file + fsync + rename each
+          3. index.id <- "<new id>"
+          4. store.json carrying "<new id>"      last
+        load() accepts a directory only when index.id and store.json name the same id."""
         import os
         import uuid
 
         os.makedirs(directory, exist_ok=True)
-        with self._lock:
-            ix = self._require_index()
-            ckpt = uuid.uuid4().hex
-            ix.save(os.path.join(directory, "index.mv"))
+
+        def stamp(text: str) -> None:
             with open(os.path.join(directory, "index.id.tmp"), "w") as f:
-                f.write(ckpt)
+                f.write(text)
                 f.flush()
                 os.fsync(f.fileno())
             os.replace(os.path.join(directory, "index.id.tmp"), os.path.join(directory, "index.id"))
+
+        with self._lock:
+            ix = self._require_index()
+            ckpt = uuid.uuid4().hex
+            stamp("writing:" + ckpt)
+            ix.save(os.path.join(directory, "index.mv"))
+            stamp(ckpt)
             book = self._book()
             book["checkpoint"] = ckpt
             tmp = os.path.join(directory, "store.json.tmp")
@@ -587,7 +622,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         with open(os.path.join(directory, "store.json")) as f:
             book = json.load(f)
         idp = os.path.join(directory, "index.id")
-        if book.get("checkpoint") and os.path.exists(idp) and open(idp).read().strip() != book["checkpoint"]:
+        if book.get("checkpoint") and (not os.path.exists(idp) or open(idp).read().strip() != book["checkpoint"]):
             raise RuntimeError(f"{directory}: index.mv and store.json belong to different checkpoints (crash during save?)")
         self = cls(capacity_pages=book["capacity_pages"], stride_rows=book["stride_rows"], device=device, mode=book["mode"], storage=storage,
                    id_base=book["id_base"], fde_coarse_n=book.get("fde_coarse_n", 0), **kw)
@@ -601,6 +636,32 @@ class MI355XMultiVectorStore(BaseVectorStore):
         self._doc_app = {int(k): v for k, v in book["doc_app"].items()}
         self._next_ord = int(book.get("next_ord", max(self._doc_ord.values(), default=-1) + 1))
         return self
+
+    # ------------------------------------------------------------------ bench / test helper
+    def adopt_synthetic_corpus(self, seed: int, n_pages: int, n_rows: Optional[int] = None, pages_per_doc: int = 1,
+                               app_id: Optional[str] = None) -> None:
+        """Fill an EMPTY store with n_pages pages of the device generator (mv_index_fill_synthetic: no embeddings cross
+        PCIe) and create the matching bookkeeping: document "synth-<d>" owns pages [d * pages_per_doc, ...), chunk j of
+        it is its j-th page.  Serving benchmarks (tools/serve_bench.py) and tests build 10^5..10^6-page stores this way."""
+        ix = self._require_index()
+        with self._lock:
+            if self._rows or self._next_ord or len(ix):
+                raise RuntimeError("adopt_synthetic_corpus needs an empty store")
+            ix.fill_synthetic(seed, 0, int(n_pages), n_rows=n_rows, pages_per_doc=int(pages_per_doc))
+            app = app_id if app_id is not None else (DEFAULT_APP_ID if self._filter_by_app else None)
+            for p in range(int(n_pages)):
+                d, j = divmod(p, int(pages_per_doc))
+                doc = f"synth-{d}"
+                page = p + (0 if self._global_ids else self.id_base)
+                self._rows[page] = (doc, j, f"page {p}", "{}", app)
+                self._page_of[(doc, j)] = page
+                if j == 0:
+                    self._doc_ord[doc] = d
+                    self._doc_app[d] = app
+                    self._doc_pages[doc] = []
+                self._doc_pages[doc].append(page)
+            self._next_ord = (int(n_pages) + int(pages_per_doc) - 1) // int(pages_per_doc)
+            self._ord_stamp += 1
 
     # ------------------------------------------------------------------ introspection
     def __len__(self) -> int:
@@ -657,6 +718,11 @@ class _ShardedMixin:
 
         from .shard_index import ShardedIndex
 
+        n_saved = int(book.get("n_shards", len(self.devices)))
+        if n_saved != len(self.devices):
+            # every shard file holds pages the bookkeeping refers to: opening fewer would silently lose them from queries
+            raise RuntimeError(f"{directory} holds {n_saved} shards but this store was given {len(self.devices)} devices "
+                               f"({self.devices}); pass devices= with {n_saved} entries (a device may repeat: logical shards)")
         return ShardedIndex.load(os.path.join(directory, "index.mv"), devices=self.devices, transport=self.transport)
 
     def _book(self) -> Dict[str, Any]:
