@@ -251,8 +251,26 @@ def full_shard(args, device, sets, truths, gaps, n_truth_pages):
     res = {"pages": n, "slabs": "e4m3 + FDE(10240 bf16) + sign bits, no bf16 slab", "resident_GB": round(n * per_page / 1e9, 1),
            "note": "kernel-only HIP-event times (median of 9 after 0.25 s of warm-up queries); recall@10 against the exact bf16 top-10 of the same "
                    "corpus computed by the float scan before the bf16 slab was freed"}
+    # the exact tier of the shard lives in pinned host RAM (n x 256 KiB: 328 GB at 1.25 M pages) when the box has room for it
+    host_tier = False
+    try:
+        avail = [int(ln.split()[1]) * 1024 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable:")][0]
+        host_tier = args.full_shard_host_tier and avail > 2.5 * n * stride * 256
+    except Exception:  # noqa: BLE001
+        host_tier = False
     t0 = time.time()
-    ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=False, with_binary=True, with_fde=True, with_fp8=True)
+    ix = None
+    if host_tier:
+        try:
+            ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=False, with_binary=True, with_fde=True, with_fp8=True, with_host_exact=True)
+        except Exception as e:  # noqa: BLE001 -- no pinned memory for it: the shard runs without its exact tier
+            res["host_tier_error"] = repr(e)
+            host_tier = False
+    if ix is None:
+        ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=False, with_binary=True, with_fde=True, with_fp8=True)
+    res["create_s"] = round(time.time() - t0, 1)
+    res["pinned_host_exact_tier_GB"] = round(n * stride * 256 / 1e9, 1) if host_tier else 0
+    t0 = time.time()
     ix.fill_synthetic(synth.SEED_CORPUS, 0, n, n_rows=args.patches)
     res["fill_s"] = round(time.time() - t0, 1)
     t0 = time.time()
@@ -309,9 +327,19 @@ def full_shard(args, device, sets, truths, gaps, n_truth_pages):
             return ix.query(q, k, mode=mode, allow=al)[1].tolist()
         return f
 
+    if host_tier:  # configs[4] with its exact tier: e4m3 scan -> top-128 -> exact bf16 re-score out of host RAM over PCIe
+        base = timed_mode(ix, qs, "float_fp8")
+        t = timed_mode(ix, qs, "fp8_then_float")
+        res["fp8_then_float_from_pinned_host_tier"] = {
+            "rerank_n": 128, "device_ms": round(t["total_device_ms"], 4), "fp8_scan_alone_device_ms": round(base["total_device_ms"], 4),
+            "added_ms_over_fp8_scan": round(t["total_device_ms"] - base["total_device_ms"], 4), "rerank_ms": round(t["rerank_ms"], 4),
+            "rerank_GBps_over_pcie": round(128 * args.patches * 256 / max(t["rerank_ms"], 1e-6) / 1e6, 1),
+            "pages_searched_per_s": round(n / t["total_device_ms"] * 1e3, 1)}
     modes = [("fp8_scan", ids_of("float_fp8")), ("sign_bit_scan", ids_of("binary")),
              ("fde_top75_then_fp8", ids_of("fde_then_float", cn=75)), ("fde_top1000_then_fp8", ids_of("fde_then_float", cn=1000)),
              ("fde_coarse_recall_at_75", ids_of("fde", k=75)), ("fde_coarse_recall_at_1000", ids_of("fde", k=1000))]
+    if host_tier:
+        modes.insert(1, ("fp8_then_float_n128", ids_of("fp8_then_float")))
     t0 = time.time()
     res["recall_at_10_vs_exact_bf16"] = recall_of(ix, sets, truths, gaps, modes, background_off)
     res["recall_s"] = round(time.time() - t0, 1)
@@ -370,6 +398,18 @@ def two_tier(args, device):
     res["recall_at_10_vs_exact_bf16"] = recall_of(ix, sets, truths, gaps, [("fp8_scan", ids_of("float_fp8")), ("fp8_then_float_n128", ids_of("fp8_then_float"))])
     ix.close()
     return res
+
+
+def serving_block(args):
+    """QPS / latency of `await store.query_similar(...)` (the plugin boundary, where the reference logs its per-query totals:
+    fast_multivector_store.py:513-605) under 1 / 8 / 32 / 128 concurrent asyncio clients, coalescer off / adaptive, next
+    to the device time of the same requests -- tools/serve_bench.py on an MI355XFastMultiVectorStore of args.aux_pages pages."""
+    import types
+
+    from tools import serve_bench
+
+    a = types.SimpleNamespace(mode="fde_then_float", pages=args.aux_pages, patches=args.patches, clients="1,8,32,128", seconds=0.8, k=K, null_index=False)
+    return serve_bench.measure(a)
 
 
 def batched_float_block(ix, queries, n, args, mfma_cal):
@@ -435,6 +475,8 @@ def main():
                          "embed = configs[1] (ColPali-v1.2 architecture, 1 k pages -> top-10)")
     ap.add_argument("--no-aux", action="store_true", help="skip the secondary kernels' quick measurements (aux_paths)")
     ap.add_argument("--aux-pages", type=int, default=200_000, help="pages of the two-tier (fp8 -> exact bf16 from the pinned-host tier) index in aux_paths (0 = skip)")
+    ap.add_argument("--no-full-shard-host-tier", dest="full_shard_host_tier", action="store_false",
+                    help="do not keep the full shard's exact bf16 rows in pinned host RAM (n x 256 KiB; skips fp8_then_float at the shard shape)")
     ap.add_argument("--full-shard-pages", type=int, default=1_250_000,
                     help="pages of the e4m3 + FDE + sign-bit index in aux_paths.full_shard (BASELINE configs[3]/[4] per-GPU shard of 10 M pages / 8 GPUs; 0 = skip)")
     ap.add_argument("--aux-embed-pages", type=int, default=96, help="pages of the full-size encoder run inside aux_paths (0 = skip)")
@@ -831,6 +873,11 @@ def main():
                 aux["fp8_then_float"] = two_tier(args, local_rank)
             except Exception as e:  # noqa: BLE001
                 aux["fp8_then_float"] = {"error": repr(e)}
+        if args.aux_pages > 0:
+            try:  # the same path measured where the reference measures it: at the store's coroutine
+                aux["serving"] = serving_block(args)
+            except Exception as e:  # noqa: BLE001
+                aux["serving"] = {"error": repr(e)}
         if args.aux_embed_pages > 0:
             try:  # configs[1] at full model size, short: encoder -> device ingest -> top-10
                 r = embed_workload(args, args.aux_embed_pages, quick=True)

@@ -347,6 +347,16 @@ MV_API int mv_comm_query_topk(mv_comm* c, const void* q, int q_dtype, int32_t n_
                               const uint32_t* allow_bits, int64_t n_allow_words, float* out_scores, int64_t* out_ids,
                               int32_t* out_n, mv_query_stats* stats);
 
+/* A batch of requests against the sharded corpus (the store's request coalescer on a sharded store; every request
+ * awaits the same store object: core/services/document_service.py:411-417).  Arguments as mv_query_topk_batch.
+ * MV_MODE_FDE_THEN_FLOAT: per group of <= 32 requests ONE pass over every shard's FDE slab, ONE exchange of all the
+ * requests' candidate records, every request's share of its GLOBAL candidate list reranked in one launch per shard --
+ * the same candidate sets, pad lengths and answers as mv_query_topk_batch on one index.  Other modes run request by
+ * request through mv_comm_query_topk.  stats (nullable): n_shards entries, device spans summed over the groups. */
+MV_API int mv_comm_query_topk_batch(mv_comm* c, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, int32_t k,
+                                    int mode, const uint32_t* allow_bits, int64_t n_allow_words, int32_t allow_per_query,
+                                    float* out_scores, int64_t* out_ids, int32_t* out_n, mv_query_stats* stats);
+
 /* Persistence ("checkpoint" of the HBM index): raw slabs + metadata in one file (written to <path>.tmp, fsync'ed and
  * renamed: a crash mid-save keeps the previous checkpoint). */
 MV_API int mv_index_save(mv_index* ix, const char* path);

@@ -10,7 +10,8 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libmvmaxsim.so")
+# MVMAXSIM_LIB: load another build of the same library (the sanitizer builds of csrc/Makefile: libmvmaxsim_tsan.so / _asan.so)
+_LIB = os.environ.get("MVMAXSIM_LIB") or os.path.join(_HERE, "libmvmaxsim.so")
 _CSRC = os.path.join(_HERE, "csrc")
 
 
@@ -101,7 +102,7 @@ EXPORTS = [
     "mv_index_remove_page", "mv_index_compact", "mv_index_read_pages", "mv_index_write_rows", "mv_index_replace_page", "mv_index_read_fp8", "mv_index_fill_synthetic", "mv_synth_rows",
     "mv_query_topk", "mv_query_topk_device", "mv_query_topk_batch", "mv_merge_topk", "mv_score_all", "mv_score_candidates", "mv_score_candidates_pads", "mv_index_page_rows",
     "mv_two_stage_coarse_device", "mv_two_stage_rerank_device", "mv_comm_create", "mv_comm_destroy", "mv_comm_attach", "mv_comm_transport",
-    "mv_comm_query_topk", "mv_sign_pack", "mv_hamming_batch",
+    "mv_comm_query_topk", "mv_comm_query_topk_batch", "mv_sign_pack", "mv_hamming_batch",
     "mv_fde_output_dim", "mv_fde_encode", "mv_calibrate_read_bw", "mv_calibrate", "mv_index_save", "mv_index_load",
 ]
 
@@ -184,6 +185,7 @@ def lib() -> C.CDLL:
         L.mv_comm_attach.argtypes = [vp, i32, vp]
         L.mv_comm_transport.argtypes = [vp]
         L.mv_comm_query_topk.argtypes = [vp, vp, C.c_int, i32, i32, C.c_int, vp, i64, vp, vp, C.POINTER(i32), vp]
+        L.mv_comm_query_topk_batch.argtypes = [vp, vp, C.c_int, i32, i32, i32, C.c_int, vp, i64, i32, vp, vp, vp, vp]
         L.mv_index_page_rows.argtypes = [vp, vp, i64, vp]
         L.mv_sign_pack.argtypes = [C.c_int, vp, i64, i32, vp]
         L.mv_hamming_batch.argtypes = [C.c_int, vp, vp, i64, i32, vp]

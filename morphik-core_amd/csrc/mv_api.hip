@@ -40,14 +40,14 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   return e == hipErrorOutOfMemory ? MV_ERR_NOMEM : MV_ERR_HIP;
 }
 
-static uint16_t host_f32_to_bf16(float f) {
+uint16_t host_f32_to_bf16(float f) {
   uint32_t u;
   memcpy(&u, &f, 4);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
-static float host_bf16_to_f32(uint16_t h) {
+float host_bf16_to_f32(uint16_t h) {
   uint32_t u = (uint32_t)h << 16;
   float f;
   memcpy(&f, &u, 4);
@@ -1292,7 +1292,7 @@ int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_r
 
 // Selection workspace of the batched entry point: one top-k workspace, result row and pinned read-back row per query of a
 // group (q_mu held).
-static int ensure_batch_select_ws(mv_index* ix) {
+int mv_internal_ensure_batch_select_ws(mv_index* ix) {
   const size_t lists = (size_t)kFdeBatchMaxQueries * kTopkMaxDeviceK;
   if (!ix->d_btopk_ws) {
     hipError_t e = hipMalloc(&ix->d_btopk_ws, (size_t)kFdeBatchMaxQueries * ix->topk_ws_bytes);
@@ -1307,9 +1307,9 @@ static int ensure_batch_select_ws(mv_index* ix) {
 }
 
 // Workspace of the batched FDE pipeline (q_mu held).
-static int ensure_fde_batch_ws(mv_index* ix) {
+int mv_internal_ensure_fde_batch_ws(mv_index* ix) {
   if (ix->h_bcand) return MV_OK;
-  int rc0 = ensure_batch_select_ws(ix);
+  int rc0 = mv_internal_ensure_batch_select_ws(ix);
   if (rc0) return rc0;
   const int64_t out_dim = ix->fde_t.out_dim;
   const size_t lists = (size_t)kFdeBatchMaxQueries * kTopkMaxDeviceK;
@@ -1335,6 +1335,73 @@ static int ensure_fde_batch_ws(mv_index* ix) {
   return MV_OK;
 }
 
+// Upload a group of nb queries (host buffer, every query n_q_rows rows) into the batch workspace, each padded to rpq rows
+// with zero rows (a zero row adds exactly 0 to the FDE and to MaxSim): fp32 rows for the FDE encode (d_bqf32), bf16 rows
+// for the bf16 rerank (d_bq), the two-term e4m3 split for the fp8 rerank (d_bq8*).  q_mu held; workspace allocated.
+int mv_internal_batch_upload_queries(mv_index* ix, const void* q, int q_dtype, int nb, int n_q_rows, bool want_f32, bool want_bf16, bool want_fp8) {
+  const size_t esz = q_dtype == MV_F32 ? 4 : 2;
+  const int rpq = ((n_q_rows + 15) / 16) * 16;
+  std::vector<float> hf((size_t)nb * rpq * kDim, 0.0f);
+  std::vector<uint16_t> hb(want_bf16 ? (size_t)kBatchQRows * kDim : 0, (uint16_t)0);
+  for (int b = 0; b < nb; ++b) {
+    const char* src = (const char*)q + (size_t)b * n_q_rows * kDim * esz;
+    float* df = hf.data() + (size_t)b * rpq * kDim;
+    const size_t ne = (size_t)n_q_rows * kDim;
+    if (q_dtype == MV_F32) {
+      memcpy(df, src, ne * 4);
+      if (want_bf16) { uint16_t* db = hb.data() + (size_t)b * rpq * kDim; for (size_t i = 0; i < ne; ++i) db[i] = host_f32_to_bf16(df[i]); }
+    } else {
+      const uint16_t* sb = (const uint16_t*)src;
+      if (want_bf16) memcpy(hb.data() + (size_t)b * rpq * kDim, sb, ne * 2);
+      for (size_t i = 0; i < ne; ++i) df[i] = host_bf16_to_f32(sb[i]);
+    }
+  }
+  if (want_f32 || want_fp8) MV_HIP(hipMemcpyAsync(ix->d_bqf32, hf.data(), (size_t)nb * rpq * kDim * 4, hipMemcpyHostToDevice, ix->stream));
+  if (want_bf16) MV_HIP(hipMemcpyAsync(ix->d_bq, hb.data(), hb.size() * 2, hipMemcpyHostToDevice, ix->stream));
+  if (want_fp8) {
+    int rc = launch_fp8_query_prep(ix->d_bqf32, nb * rpq, ix->d_bq8hi, ix->d_bq8lo, ix->d_bq8fac, ix->stream);
+    if (rc) return rc;
+  }
+  MV_HIP(hipStreamSynchronize(ix->stream));  // the pageable staging vectors die with this call
+  return MV_OK;
+}
+
+// Exact rerank of the group's candidate lists d_bcand / d_bcand_pads ([nb][nc], list b against query b of the uploaded
+// group) into d_bcand_scores: ONE launch for all lists where the kernels allow it (fp8 slab; bf16 slab with the default
+// kernels and queries of <= 128 rows), else one launch per query.  q_mu held.
+int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t nc, int* launches) {
+  const int rpq = ((n_q_rows + 15) / 16) * 16;
+  const int64_t L = nc;
+  const bool rerank_fp8 = !(ix->cfg.flags & MV_WITH_FLOAT) && (ix->cfg.flags & MV_WITH_FP8);
+  const int rr_variant = ix->maxsim_variant < 0 ? maxsim_default_variant(ix->cfg.stride_rows) : ix->maxsim_variant;
+  const bool rerank_one_launch = rerank_fp8 || (rpq <= kMaxQRowsPerPass && (rr_variant == 6 || rr_variant == 7));
+  int rc = MV_OK;
+  if (rerank_fp8) {
+    Fp8ScanArgs fa{};
+    fa.slab = ix->slab8; fa.inv_scale = ix->inv_scale8; fa.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr; fa.cand = ix->d_bcand;
+    fa.qhi = ix->d_bq8hi; fa.qlo = ix->d_bq8lo; fa.qfac = ix->d_bq8fac; fa.n_q = rpq; fa.scores = ix->d_bcand_scores; fa.n = (int64_t)nb * nc;
+    fa.stride = ix->cfg.stride_rows; fa.pad_to = 0; fa.pad_items = ix->d_bcand_pads; fa.items_per_query = (int32_t)nc;
+    rc = launch_maxsim_fp8(fa, ix->stream);
+    if (rc) return rc;
+    ++*launches;
+  } else if (rerank_one_launch) {
+    MaxsimArgs ma{};
+    ma.slab = ix->slab; ma.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr; ma.cand = ix->d_bcand; ma.q = ix->d_bq;
+    ma.scores = ix->d_bcand_scores; ma.n = (int64_t)nb * nc; ma.stride = ix->cfg.stride_rows; ma.q_tiles = rpq / 16; ma.pad_to = 0;
+    ma.pad_items = ix->d_bcand_pads; ma.items_per_query = (int32_t)nc; ma.q_item_stride = rpq * kDim;
+    rc = launch_maxsim_bf16(ma, rr_variant, ix->stream);
+    if (rc) return rc;
+    ++*launches;
+  } else {
+    for (int b = 0; b < nb; ++b) {  // one launch per query (long queries, non-default kernel variants)
+      rc = float_scan(ix, n_q_rows, nullptr, 0, ix->d_bcand + (size_t)b * L, nc, 0, ix->d_bcand_pads + (size_t)b * L,
+                      ix->d_bcand_scores + (size_t)b * L, launches, /*no_mask=*/true, ix->d_bq + (size_t)b * rpq * kDim);
+      if (rc) return rc;
+    }
+  }
+  return MV_OK;
+}
+
 // mv_query_topk_batch in the FDE modes: per group of <= 32 queries (<= 1024 query rows)
 //   encode (one launch, a block per repetition and query) -> ONE pass over the FDE slab for all of them (bf16 MFMA)
 //   -> one batched selection of the coarse top-n -> rerank lists + per-batch pad lengths -> exact MaxSim of every
@@ -1350,7 +1417,7 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
   mv_query_stats total{};
   const int64_t n = ix->size.load(std::memory_order_acquire);  // snapshot of the published corpus
   if (n == 0) { if (stats) *stats = total; return MV_OK; }
-  int rc = ensure_fde_batch_ws(ix);
+  int rc = mv_internal_ensure_fde_batch_ws(ix);
   if (rc) return rc;
   const size_t esz = q_dtype == MV_F32 ? 4 : 2;
   const int rpq = ((n_q_rows + 15) / 16) * 16;
@@ -1368,37 +1435,14 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
   int64_t nc = std::min<int64_t>(std::min<int64_t>(coarse_n_for(ix, k), n), kTopkMaxDeviceK);
   if (nc < 1) nc = 1;
   const int64_t L = nc;  // the per-query lists lie back to back: [query][nc]
-  // every query's candidates in ONE rerank launch (work item -> its query): the default kernels, queries of <= 128 rows
-  const int rr_variant = ix->maxsim_variant < 0 ? maxsim_default_variant(ix->cfg.stride_rows) : ix->maxsim_variant;
-  const bool rerank_one_launch = rerank_fp8 || (rpq <= kMaxQRowsPerPass && (rr_variant == 6 || rr_variant == 7));
   const int pad_sem = ix->pad_semantics < 0 ? 1 : ix->pad_semantics;
   int64_t pages = 0;
   if (stats) (void)count_allowed_rows(ix, n, per_query ? nullptr : allow_bits, n_allow_words, &pages);
-  std::vector<float> hf((size_t)group * rpq * kDim);
-  std::vector<uint16_t> hb((size_t)kBatchQRows * kDim);
   for (int32_t b0 = 0; b0 < n_queries; b0 += group) {
     const int nb = std::min(group, n_queries - b0);
-    std::fill(hb.begin(), hb.end(), (uint16_t)0);
-    std::fill(hf.begin(), hf.end(), 0.0f);
-    for (int b = 0; b < nb; ++b) {  // every query padded to rpq rows with zero rows (a zero row adds exactly 0 to the FDE and to MaxSim)
-      const char* src = (const char*)q + (size_t)(b0 + b) * n_q_rows * kDim * esz;
-      float* df = hf.data() + (size_t)b * rpq * kDim;
-      uint16_t* db = hb.data() + (size_t)b * rpq * kDim;
-      const size_t ne = (size_t)n_q_rows * kDim;
-      if (q_dtype == MV_F32) {
-        memcpy(df, src, ne * 4);
-        for (size_t i = 0; i < ne; ++i) db[i] = host_f32_to_bf16(df[i]);
-      } else {
-        memcpy(db, src, ne * 2);
-        for (size_t i = 0; i < ne; ++i) df[i] = host_bf16_to_f32(db[i]);
-      }
-    }
-    MV_HIP(hipMemcpyAsync(ix->d_bqf32, hf.data(), (size_t)nb * rpq * kDim * 4, hipMemcpyHostToDevice, ix->stream));
-    if (rerank && !rerank_fp8) MV_HIP(hipMemcpyAsync(ix->d_bq, hb.data(), hb.size() * 2, hipMemcpyHostToDevice, ix->stream));
-    if (rerank_fp8) {
-      rc = launch_fp8_query_prep(ix->d_bqf32, nb * rpq, ix->d_bq8hi, ix->d_bq8lo, ix->d_bq8fac, ix->stream);
-      if (rc) return rc;
-    }
+    rc = mv_internal_batch_upload_queries(ix, (const char*)q + (size_t)b0 * n_q_rows * kDim * esz, q_dtype, nb, n_q_rows, /*want_f32=*/true,
+                                          /*want_bf16=*/rerank && !rerank_fp8, /*want_fp8=*/rerank_fp8);
+    if (rc) return rc;
     MV_HIP(hipEventRecord(ix->ev[0], ix->stream));
     int launches = 0;
     FdeEncodeArgs e{};
@@ -1426,29 +1470,8 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
                          ix->d_bcand, ix->d_bcand_pads, L);
       MV_HIP(hipGetLastError());
       MV_HIP(hipEventRecord(ix->ev_st[2], ix->stream));
-      if (rerank_fp8) {
-        Fp8ScanArgs fa{};
-        fa.slab = ix->slab8; fa.inv_scale = ix->inv_scale8; fa.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr; fa.cand = ix->d_bcand;
-        fa.qhi = ix->d_bq8hi; fa.qlo = ix->d_bq8lo; fa.qfac = ix->d_bq8fac; fa.n_q = rpq; fa.scores = ix->d_bcand_scores; fa.n = (int64_t)nb * nc;
-        fa.stride = ix->cfg.stride_rows; fa.pad_to = 0; fa.pad_items = ix->d_bcand_pads; fa.items_per_query = (int32_t)nc;
-        rc = launch_maxsim_fp8(fa, ix->stream);
-        if (rc) return rc;
-        ++launches;
-      } else if (rerank_one_launch) {
-        MaxsimArgs ma{};
-        ma.slab = ix->slab; ma.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr; ma.cand = ix->d_bcand; ma.q = ix->d_bq;
-        ma.scores = ix->d_bcand_scores; ma.n = (int64_t)nb * nc; ma.stride = ix->cfg.stride_rows; ma.q_tiles = rpq / 16; ma.pad_to = 0;
-        ma.pad_items = ix->d_bcand_pads; ma.items_per_query = (int32_t)nc; ma.q_item_stride = rpq * kDim;
-        rc = launch_maxsim_bf16(ma, rr_variant, ix->stream);
-        if (rc) return rc;
-        ++launches;
-      } else {
-        for (int b = 0; b < nb; ++b) {  // one launch per query (long queries, non-default kernel variants)
-          rc = float_scan(ix, n_q_rows, nullptr, 0, ix->d_bcand + (size_t)b * L, nc, 0, ix->d_bcand_pads + (size_t)b * L,
-                          ix->d_bcand_scores + (size_t)b * L, &launches, /*no_mask=*/true, ix->d_bq + (size_t)b * rpq * kDim);
-          if (rc) return rc;
-        }
-      }
+      rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, nc, &launches);
+      if (rc) return rc;
       MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
       rc = launch_topk_batch(ix->d_bcand_scores, L, nc, k, ix->d_bcand, L, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bout_s, ix->d_bout_id, k,
                              nb, ix->stream);
@@ -1556,7 +1579,7 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
   // accounting: with per-query filters every live page is read (a page is skipped only when no query may see it)
   const int64_t rows = stats ? count_allowed_rows(ix, n, per_query ? nullptr : allow_bits, n_allow_words, &pages) : 0;
   std::vector<uint16_t> hq((size_t)512 * kDim);
-  rc = ensure_batch_select_ws(ix);
+  rc = mv_internal_ensure_batch_select_ws(ix);
   if (rc) return rc;
   for (int32_t b0 = 0; b0 < n_queries; b0 += group) {
     const int nb = std::min(group, n_queries - b0);

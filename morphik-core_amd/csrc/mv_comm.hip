@@ -90,6 +90,63 @@ __global__ void fill_topk_pad_kernel(float* s, int64_t* id, int k) {
   if (i < k) { s[i] = -INFINITY; id[i] = -1; }
 }
 
+// ---- the same stages for a GROUP of requests (mv_comm_query_topk_batch): grid.y = request
+// coarse top-n of request b (scores / GLOBAL ids at b * list_stride) -> records out[b][n]
+__global__ __launch_bounds__(256) void recs_build_batch_kernel(const float* s, const int64_t* gid, int n, int64_t list_stride, const int32_t* n_rows,
+                                                               int32_t stride, int64_t id_base, mv_cand_rec* out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (i >= n) return;
+  mv_cand_rec r;
+  const int64_t g = gid[(int64_t)b * list_stride + i];
+  if (g < 0) {
+    r.score = -INFINITY; r.rows = 0; r.id = -1;
+  } else {
+    r.score = s[(int64_t)b * list_stride + i];
+    r.rows = n_rows ? n_rows[g - id_base] : stride;
+    r.id = g;
+  }
+  out[(int64_t)b * n + i] = r;
+}
+
+// gathered records [world][nb][n] -> per-request score rows out[b][r * n + i] (shard order: ties by position = by ascending id)
+__global__ __launch_bounds__(256) void recs_scores_batch_kernel(const mv_cand_rec* recs, int world, int nb, int n, float* out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;  // r * n + i
+  const int b = blockIdx.y;
+  if (j >= world * n) return;
+  const int r = j / n, i = j - r * n;
+  const mv_cand_rec x = recs[((int64_t)r * nb + b) * n + i];
+  out[(int64_t)b * world * n + j] = x.id < 0 ? -INFINITY : x.score;
+}
+
+// request b: positions of its GLOBAL coarse top-n (pos[b][j] = r * n + i) -> this shard's rerank list + per-batch pad lengths
+__global__ __launch_bounds__(kRerankBatch) void owned_select_batch_kernel(const mv_cand_rec* recs, const int64_t* pos, int n, int nb, int64_t lo,
+                                                                          int64_t hi, int pad_sem, int32_t* cand, int32_t* pads) {
+  __shared__ int32_t wmax[kRerankBatch / 64];
+  const int j = blockIdx.x * kRerankBatch + threadIdx.x;
+  const int b = blockIdx.y;
+  int32_t c = -1, rows = 0;
+  if (j < n) {
+    const int64_t p = pos[(int64_t)b * n + j];
+    if (p >= 0) {
+      const int r = (int)(p / n), i = (int)(p - (int64_t)r * n);
+      const mv_cand_rec x = recs[((int64_t)r * nb + b) * n + i];
+      rows = x.rows;
+      if (x.id >= lo && x.id < hi) c = (int32_t)(x.id - lo);
+    }
+  }
+  int32_t m = rows;
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) m = max(m, __shfl_xor(m, s));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = max(wmax[0], wmax[1]);
+  if (j < n) {
+    cand[(int64_t)b * n + j] = c;
+    pads[(int64_t)b * n + j] = pad_sem ? m : 0;
+  }
+}
+
 int order_behind(mv_index* ix, void* user_stream) {
   if (!user_stream) return MV_OK;
   MV_HIP(hipEventRecord(ix->ev[3], (hipStream_t)user_stream));
@@ -184,6 +241,100 @@ int mv_two_stage_rerank_device(mv_index* ix, const void* q, int q_dtype, int32_t
   return hand_back(ix, stream);
 }
 
+// The two stages for a group of nb requests (<= 32, nb * padded rows <= 1024): ONE pass over the shard's FDE slab for all
+// of them (the batched coarse GEMM of mv_query_topk_batch), then every request's share of ITS global candidate list
+// reranked in one launch.  d_out_recs: [nb][n_coarse]; d_all_recs: [world][nb][n_coarse]; d_out_*: [nb][k].
+int mv_internal_two_stage_batch_coarse(mv_index* ix, const void* q, int q_dtype, int32_t nb, int32_t n_q_rows, int32_t n_coarse,
+                                       const uint32_t* allow_bits, int64_t n_allow_words, int32_t allow_per_query, mv_cand_rec* d_out_recs,
+                                       void* stream) {
+  std::lock_guard<std::mutex> lk(ix->q_mu);
+  DeviceGuard g(ix->cfg.device);
+  int rc = order_behind(ix, stream);
+  if (rc) return rc;
+  const int64_t n = ix->size.load(std::memory_order_acquire);
+  if (n == 0) {
+    hipLaunchKernelGGL(recs_fill_pad_kernel, dim3((unsigned)((nb * n_coarse + 255) / 256)), dim3(256), 0, ix->stream, d_out_recs, (int)(nb * n_coarse));
+    MV_HIP(hipGetLastError());
+    return hand_back(ix, stream);
+  }
+  rc = mv_internal_ensure_fde_batch_ws(ix);
+  if (rc) return rc;
+  rc = mv_internal_batch_upload_queries(ix, q, q_dtype, nb, n_q_rows, true, false, false);
+  if (rc) return rc;
+  const int rpq = ((n_q_rows + 15) / 16) * 16;
+  const bool per_query = allow_bits && allow_per_query;
+  const uint32_t* d_allow = nullptr;
+  rc = upload_allow(ix, allow_bits, per_query ? n_allow_words * (int64_t)nb : n_allow_words, &d_allow);
+  if (rc) return rc;
+  const bool need_meta = ix->tombstones.load() || d_allow != nullptr;
+  FdeEncodeArgs e{};
+  e.variant = 2;
+  e.x_f32 = ix->d_bqf32; e.row_offsets = nullptr; e.stride = rpq; e.n_pages = nb; e.is_query = 1; e.out_f32 = ix->d_bqfde;
+  rc = launch_fde_encode(ix->fde_t, e, ix->stream);
+  if (rc) return rc;
+  const int64_t cap = ix->cfg.capacity_pages;
+  FdeScanBatchArgs sa{};
+  sa.fde = ix->fde; sa.inv_norm = ix->fde_cosine ? ix->fde_inv_norm : nullptr; sa.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
+  sa.allow = d_allow; sa.n_allow_bits = n_allow_words * 32; sa.allow_stride_bits = per_query ? n_allow_words * 32 : 0;
+  sa.q = ix->d_bqfde; sa.image = ix->d_bqimage; sa.scores = ix->d_bscores; sa.score_stride = cap; sa.n = n; sa.out_dim = ix->fde_t.out_dim; sa.n_queries = nb;
+  sa.hi_only = ix->fde_batch_variant == 2;
+  sa.single_tile = ix->fde_batch_variant == 3;
+  rc = launch_fde_scan_batch(sa, ix->stream);
+  if (rc) return rc;
+  // local coarse top-n of every request, GLOBAL ids, padded with (-inf, -1) when the shard holds fewer pages
+  rc = launch_topk_batch(ix->d_bscores, cap, n, n_coarse, nullptr, 0, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bsel_s, ix->d_bsel_id,
+                         n_coarse, nb, ix->stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(recs_build_batch_kernel, dim3((unsigned)((n_coarse + 255) / 256), (unsigned)nb), dim3(256), 0, ix->stream, (const float*)ix->d_bsel_s,
+                     (const int64_t*)ix->d_bsel_id, (int)n_coarse, (int64_t)n_coarse, ix->ragged.load() ? (const int32_t*)ix->d_n_rows : (const int32_t*)nullptr,
+                     ix->cfg.stride_rows, ix->cfg.id_base, d_out_recs);
+  MV_HIP(hipGetLastError());
+  return hand_back(ix, stream);
+}
+
+int mv_internal_two_stage_batch_rerank(mv_index* ix, const void* q, int q_dtype, int32_t nb, int32_t n_q_rows, const mv_cand_rec* d_all_recs,
+                                       int32_t world, int32_t n_coarse, int32_t k, float* d_out_scores, int64_t* d_out_ids, void* stream) {
+  const bool use_fp8 = !(ix->cfg.flags & MV_WITH_FLOAT);
+  if (use_fp8 && !(ix->cfg.flags & MV_WITH_FP8)) { set_error("index has neither a float nor an fp8 slab"); return MV_ERR_STATE; }
+  std::lock_guard<std::mutex> lk(ix->q_mu);
+  DeviceGuard g(ix->cfg.device);
+  int rc = order_behind(ix, stream);
+  if (rc) return rc;
+  rc = mv_internal_ensure_fde_batch_ws(ix);
+  if (rc) return rc;
+  const int64_t n = ix->size.load(std::memory_order_acquire);
+  const int total = world * n_coarse;
+  if ((int64_t)nb * total > ix->gscores_cap) {  // [nb][world * n_coarse] gathered coarse scores
+    if (ix->d_gscores) (void)hipFree(ix->d_gscores);
+    ix->d_gscores = nullptr; ix->gscores_cap = 0;
+    MV_HIP(hipMalloc(&ix->d_gscores, (size_t)kFdeBatchMaxQueries * 16384 * 4));
+    ix->gscores_cap = (int64_t)kFdeBatchMaxQueries * 16384;
+  }
+  // the group's queries again (another caller may have used the workspace between the stages)
+  rc = mv_internal_batch_upload_queries(ix, q, q_dtype, nb, n_q_rows, false, !use_fp8, use_fp8);
+  if (rc) return rc;
+  hipLaunchKernelGGL(recs_scores_batch_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)nb), dim3(256), 0, ix->stream, d_all_recs, (int)world, (int)nb,
+                     (int)n_coarse, ix->d_gscores);
+  MV_HIP(hipGetLastError());
+  // GLOBAL coarse top-n of every request: positions into its gathered row (ids map = none, id_base 0)
+  rc = launch_topk_batch(ix->d_gscores, total, total, n_coarse, nullptr, 0, 0, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bsel_s, ix->d_bsel_id, n_coarse, nb,
+                         ix->stream);
+  if (rc) return rc;
+  const int pad_sem = ix->pad_semantics < 0 ? 1 : ix->pad_semantics;
+  hipLaunchKernelGGL(owned_select_batch_kernel, dim3((unsigned)((n_coarse + kRerankBatch - 1) / kRerankBatch), (unsigned)nb), dim3(kRerankBatch), 0, ix->stream,
+                     d_all_recs, (const int64_t*)ix->d_bsel_id, (int)n_coarse, (int)nb, ix->cfg.id_base, ix->cfg.id_base + n, pad_sem, ix->d_bcand,
+                     ix->d_bcand_pads);
+  MV_HIP(hipGetLastError());
+  int launches = 0;
+  rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, n_coarse, &launches);
+  if (rc) return rc;
+  // local top-k of the owned candidates of every request; equal scores resolve by coarse rank, as on one index
+  rc = launch_topk_batch(ix->d_bcand_scores, n_coarse, n_coarse, k, ix->d_bcand, n_coarse, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, d_out_scores,
+                         d_out_ids, k, nb, ix->stream);
+  if (rc) return rc;
+  return hand_back(ix, stream);
+}
+
 }  // extern "C"
 
 // =================================================================================== communicator
@@ -224,6 +375,11 @@ struct Shard {
   int64_t* d_gi = nullptr;
   mv_cand_rec* d_recs = nullptr;  // [1024] local coarse candidates
   mv_cand_rec* d_all = nullptr;   // [R][1024] gathered coarse candidates
+  // batched two-stage queries (allocated on first use): <= 32 requests per group
+  mv_cand_rec* d_brecs = nullptr;  // [32][1024]
+  mv_cand_rec* d_ball = nullptr;   // [R][32][1024]
+  float* d_bls = nullptr;          // [32][1024] local top-k of every request
+  int64_t* d_bli = nullptr;
   ncclComm_t nccl = nullptr;
 };
 
@@ -239,6 +395,9 @@ struct mv_comm {
   float* h_s = nullptr;    // pinned host: [R][1024] + merged
   int64_t* h_i = nullptr;
   mv_cand_rec* h_recs = nullptr;  // pinned host: [R][1024] (HOST transport of the two-stage mode)
+  float* h_bs = nullptr;          // pinned host: [R][32][1024] local top-k lists of a request group (batched queries)
+  int64_t* h_bi = nullptr;
+  mv_cand_rec* h_brecs = nullptr; // pinned host: [R][32][1024] (HOST transport)
   std::mutex mu;
 };
 
@@ -326,6 +485,8 @@ void* dst_gs(Shard& s) { return s.d_gs; }
 void* dst_gi(Shard& s) { return s.d_gi; }
 void* src_recs(Shard& s) { return s.d_recs; }
 void* dst_all(Shard& s) { return s.d_all; }
+void* src_brecs(Shard& s) { return s.d_brecs; }
+void* dst_ball(Shard& s) { return s.d_ball; }
 
 int sync_all(mv_comm* c) {
   for (int i = 0; i < c->n; ++i) {
@@ -345,7 +506,8 @@ void mv_comm_destroy(mv_comm* c) {
     DeviceGuard g(s.dev);
     if (s.cs) (void)hipStreamSynchronize(s.cs);
     if (s.nccl && c->rccl.CommDestroy) (void)c->rccl.CommDestroy(s.nccl);
-    for (void* p : {(void*)s.d_ls, (void*)s.d_li, (void*)s.d_gs, (void*)s.d_gi, (void*)s.d_recs, (void*)s.d_all})
+    for (void* p : {(void*)s.d_ls, (void*)s.d_li, (void*)s.d_gs, (void*)s.d_gi, (void*)s.d_recs, (void*)s.d_all, (void*)s.d_brecs, (void*)s.d_ball,
+                    (void*)s.d_bls, (void*)s.d_bli})
       if (p) (void)hipFree(p);
     for (hipEvent_t e : {s.ev_t0, s.ev_t1, s.ev_done})
       if (e) (void)hipEventDestroy(e);
@@ -356,7 +518,7 @@ void mv_comm_destroy(mv_comm* c) {
     if (c->d_os) (void)hipFree(c->d_os);
     if (c->d_oi) (void)hipFree(c->d_oi);
   }
-  for (void* p : {(void*)c->h_s, (void*)c->h_i, (void*)c->h_recs})
+  for (void* p : {(void*)c->h_s, (void*)c->h_i, (void*)c->h_recs, (void*)c->h_bs, (void*)c->h_bi, (void*)c->h_brecs})
     if (p) (void)hipHostFree(p);
   // the RCCL handle stays loaded for the life of the process (its worker threads outlive communicators)
   delete c;
@@ -551,6 +713,137 @@ int mv_comm_query_topk(mv_comm* c, const void* q, int q_dtype, int32_t n_q_rows,
       }
       MV_HIP(hipEventElapsedTime(&whole, s.ev_t0, s.ev_t1));
       stats[i].total_device_ms = whole;  // the shard's whole local span on its comm stream
+    }
+  }
+  return MV_OK;
+}
+
+
+// A batch of requests against the sharded corpus.  MV_MODE_FDE_THEN_FLOAT: per group of <= 32 requests every shard makes ONE
+// pass over its FDE slab for all of them (the batched coarse GEMM), ONE exchange carries every request's n_coarse
+// candidate records, every shard derives each request's GLOBAL top-n, reranks its share of all lists in one launch and
+// leaves the local top-k lists, which meet on the host (they are on their way there anyway).  Same candidate sets, pad
+// lengths and answers as mv_query_topk_batch on ONE index holding every page.  Other modes: request by request.
+int mv_comm_query_topk_batch(mv_comm* c, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, int32_t k, int mode,
+                             const uint32_t* allow_bits, int64_t n_allow_words, int32_t allow_per_query, float* out_scores, int64_t* out_ids,
+                             int32_t* out_n, mv_query_stats* stats) {
+  if (!c || !q || !out_n || n_queries < 1 || n_q_rows < 1 || k < 0 || (k > 0 && (!out_scores || !out_ids))) { set_error("mv_comm_query_topk_batch: bad argument"); return MV_ERR_INVALID; }
+  if (q_dtype != MV_F32 && q_dtype != MV_BF16) { set_error("bad query dtype %d", q_dtype); return MV_ERR_INVALID; }
+  if (k > kK) { set_error("mv_comm_query_topk_batch supports k <= %d", kK); return MV_ERR_INVALID; }
+  const size_t esz = q_dtype == MV_F32 ? 4 : 2;
+  const int rpq = ((n_q_rows + 15) / 16) * 16;
+  const int R = c->n;
+  bool batched = mode == MV_MODE_FDE_THEN_FLOAT && n_queries > 1 && k >= 1 && rpq <= 512;
+  int n_coarse = 0;
+  if (batched) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    for (int i = 0; i < R && batched; ++i) {
+      mv_index* ix = c->sh[i].ix;
+      if (!ix) { set_error("mv_comm_query_topk_batch: shard %d has no index attached", i); return MV_ERR_STATE; }
+      const bool fp8_rr = !(ix->cfg.flags & MV_WITH_FLOAT);
+      batched = (ix->cfg.flags & MV_WITH_FDE) && ix->fde_batch_variant != 1 && fde_scan_batch_supported(ix->fde_t.out_dim) &&
+                ix->fde_t.cfg.projection_dimension <= 16 && (!fp8_rr || ((ix->cfg.flags & MV_WITH_FP8) && rpq <= 64));
+    }
+    n_coarse = (int)std::min<int64_t>(coarse_n_for(c->sh[0].ix, k), kK);
+    if ((int64_t)R * n_coarse > 16384) batched = false;
+  }
+  if (!batched) {  // request by request through the single-query communicator (each call takes c->mu itself)
+    for (int32_t b = 0; b < n_queries; ++b) {
+      const uint32_t* ab = (allow_bits && allow_per_query) ? allow_bits + (size_t)b * n_allow_words : allow_bits;
+      int rc = mv_comm_query_topk(c, (const char*)q + (size_t)b * n_q_rows * kDim * esz, q_dtype, n_q_rows, k, mode, ab, n_allow_words,
+                                  out_scores ? out_scores + (size_t)b * k : nullptr, out_ids ? out_ids + (size_t)b * k : nullptr, out_n + b, nullptr);
+      if (rc) return rc;
+    }
+    if (stats) memset(stats, 0, sizeof(mv_query_stats) * (size_t)R);
+    return MV_OK;
+  }
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (stats) memset(stats, 0, sizeof(mv_query_stats) * (size_t)R);
+  constexpr int kG = kFdeBatchMaxQueries;
+  // batch buffers, once
+  for (int i = 0; i < R; ++i) {
+    Shard& s = c->sh[i];
+    if (s.d_brecs) continue;
+    DeviceGuard g(s.dev);
+    if (hipMalloc(&s.d_brecs, (size_t)kG * kK * sizeof(mv_cand_rec)) != hipSuccess || hipMalloc(&s.d_ball, (size_t)R * kG * kK * sizeof(mv_cand_rec)) != hipSuccess ||
+        hipMalloc(&s.d_bls, (size_t)kG * kK * 4) != hipSuccess || hipMalloc(&s.d_bli, (size_t)kG * kK * 8) != hipSuccess) { set_error("mv_comm_query_topk_batch: out of device memory"); return MV_ERR_NOMEM; }
+  }
+  if (!c->h_bs) {
+    if (hipHostMalloc((void**)&c->h_bs, (size_t)R * kG * kK * 4, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_bi, (size_t)R * kG * kK * 8, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_brecs, (size_t)R * kG * kK * sizeof(mv_cand_rec), hipHostMallocDefault) != hipSuccess) { set_error("mv_comm_query_topk_batch: out of pinned memory"); return MV_ERR_NOMEM; }
+  }
+  const int group = std::min(kBatchQRows / rpq, kG);
+  const bool per_query = allow_bits && allow_per_query;
+  int rc = MV_OK;
+  std::vector<float> ms((size_t)R * k), os((size_t)k);
+  std::vector<int64_t> mi((size_t)R * k), oi((size_t)k);
+  for (int32_t b0 = 0; b0 < n_queries; b0 += group) {
+    const int nb = std::min(group, n_queries - b0);
+    const char* qg = (const char*)q + (size_t)b0 * n_q_rows * kDim * esz;
+    const uint32_t* ag = per_query ? allow_bits + (size_t)b0 * n_allow_words : allow_bits;
+    for (int i = 0; i < R; ++i) {
+      Shard& s = c->sh[i];
+      DeviceGuard g(s.dev);
+      MV_HIP(hipEventRecord(s.ev_t0, s.cs));
+    }
+    for (int i = 0; i < R; ++i) {
+      Shard& s = c->sh[i];
+      rc = mv_internal_two_stage_batch_coarse(s.ix, qg, q_dtype, nb, n_q_rows, n_coarse, ag, n_allow_words, per_query ? 1 : 0, s.d_brecs, s.cs);
+      if (rc) return rc;
+    }
+    const size_t rb = (size_t)nb * n_coarse * sizeof(mv_cand_rec);
+    if (c->transport == MV_COMM_HOST) {
+      for (int i = 0; i < R; ++i) {
+        Shard& s = c->sh[i];
+        DeviceGuard g(s.dev);
+        MV_HIP(hipMemcpyAsync((char*)c->h_brecs + (size_t)i * rb, s.d_brecs, rb, hipMemcpyDeviceToHost, s.cs));
+      }
+      rc = sync_all(c);
+      if (rc) return rc;
+      for (int i = 0; i < R; ++i) {
+        Shard& s = c->sh[i];
+        DeviceGuard g(s.dev);
+        MV_HIP(hipMemcpyAsync(s.d_ball, c->h_brecs, rb * (size_t)R, hipMemcpyHostToDevice, s.cs));
+      }
+    } else {
+      rc = exchange(c, rb, true, src_brecs, dst_ball);
+      if (rc) return rc;
+    }
+    for (int i = 0; i < R; ++i) {
+      Shard& s = c->sh[i];
+      rc = mv_internal_two_stage_batch_rerank(s.ix, qg, q_dtype, nb, n_q_rows, s.d_ball, R, n_coarse, k, s.d_bls, s.d_bli, s.cs);
+      if (rc) return rc;
+    }
+    for (int i = 0; i < R; ++i) {
+      Shard& s = c->sh[i];
+      DeviceGuard g(s.dev);
+      MV_HIP(hipEventRecord(s.ev_t1, s.cs));
+      MV_HIP(hipMemcpyAsync(c->h_bs + (size_t)i * nb * k, s.d_bls, (size_t)nb * k * 4, hipMemcpyDeviceToHost, s.cs));
+      MV_HIP(hipMemcpyAsync(c->h_bi + (size_t)i * nb * k, s.d_bli, (size_t)nb * k * 8, hipMemcpyDeviceToHost, s.cs));
+    }
+    rc = sync_all(c);
+    if (rc) return rc;
+    for (int b = 0; b < nb; ++b) {  // merge of the R local lists of request b (score desc; ties: shard asc = id asc)
+      for (int i = 0; i < R; ++i) {
+        memcpy(ms.data() + (size_t)i * k, c->h_bs + ((size_t)i * nb + b) * k, (size_t)k * 4);
+        memcpy(mi.data() + (size_t)i * k, c->h_bi + ((size_t)i * nb + b) * k, (size_t)k * 8);
+      }
+      int m = 0;
+      host_merge(ms.data(), mi.data(), R, k, k, os.data(), oi.data(), &m);
+      memcpy(out_scores + (size_t)(b0 + b) * k, os.data(), (size_t)m * 4);
+      memcpy(out_ids + (size_t)(b0 + b) * k, oi.data(), (size_t)m * 8);
+      out_n[b0 + b] = m;
+    }
+    if (stats) {
+      for (int i = 0; i < R; ++i) {
+        Shard& s = c->sh[i];
+        DeviceGuard g(s.dev);
+        float whole = 0.f;
+        MV_HIP(hipEventElapsedTime(&whole, s.ev_t0, s.ev_t1));
+        stats[i].total_device_ms += whole;  // the shard's whole local span of the group on its comm stream
+        stats[i].score_launches += 1;
+      }
     }
   }
   return MV_OK;

@@ -119,6 +119,36 @@ def allow_bitmap(allowed_ordinals: Optional[Iterable[int]], n_docs_hint: int = 0
     return bits
 
 
+def _stack_queries(queries: Sequence[Any], rows=None):
+    """Queries of possibly different lengths -> one [n, longest, 128] block (zero rows behind the shorter ones: a zero row
+    contributes exactly 0), its dtype code and the padded length."""
+    rows = rows if rows is not None else [as_rows(q) for q in queries]
+    nmax = max(a.shape[0] for a, _ in rows)
+    code = MV_BF16 if all(c == MV_BF16 for _, c in rows) else MV_F32
+    blk = np.zeros((len(rows), nmax, 128), np.uint16 if code == MV_BF16 else np.float32)
+    for i, (a, c) in enumerate(rows):
+        blk[i, : a.shape[0]] = a if c == code else (a.astype(np.uint32) << 16).view(np.float32)
+    return blk, code, nmax
+
+
+def _allow_block(n_queries: int, allow, allows, n_docs: int):
+    """-> (bitmap block or None, words per bitmap, per_query flag): one doc bitmap for all queries, or one per query
+    (None = everything: an all-ones bitmap covering n_docs ordinals)."""
+    if allows is not None and any(a is not None for a in allows):
+        if len(allows) != n_queries:
+            raise ValueError("allows must have one entry per query")
+        n_words = max(max(int(np.size(a)) for a in allows if a is not None), (int(n_docs) + 31) // 32, 1)
+        ab = np.zeros((n_queries, n_words), np.uint32)
+        for i, a in enumerate(allows):
+            if a is None:
+                ab[i] = 0xFFFFFFFF  # no filter for this query
+            else:
+                ab[i, : np.size(a)] = np.asarray(a, dtype=np.uint32)
+        return ab, n_words, 1
+    ab = None if allow is None else np.ascontiguousarray(allow, dtype=np.uint32)
+    return ab, (0 if ab is None else ab.size), 0
+
+
 class MvIndex:
     def __init__(
         self,
@@ -287,31 +317,13 @@ class MvIndex:
                 a = allow if allows is None else allows[j]
                 out.append(self.query(q, k, mode=mode, allow=None if a is None else np.ascontiguousarray(a, dtype=np.uint32)))
             return (out, QueryStats.from_c(QueryStatsC())) if want_stats else out
-        code = MV_BF16 if all(c == MV_BF16 for _, c in rows) else MV_F32
-        blk = np.zeros((len(rows), nmax, 128), np.uint16 if code == MV_BF16 else np.float32)
-        for i, (a, c) in enumerate(rows):
-            blk[i, : a.shape[0]] = a if c == code else (a.astype(np.uint32) << 16).view(np.float32)
+        blk, code, nmax = _stack_queries(queries, rows)
         k = int(k)
         scores = np.empty((len(rows), max(k, 1)), np.float32)
         ids = np.empty((len(rows), max(k, 1)), np.int64)
         n = np.zeros(len(rows), np.int32)
         st = QueryStatsC()
-        per_query = 0
-        n_words = 0
-        if allows is not None and any(a is not None for a in allows):
-            if len(allows) != len(rows):
-                raise ValueError("allows must have one entry per query")
-            n_words = max(max(int(np.size(a)) for a in allows if a is not None), (int(n_docs) + 31) // 32, 1)
-            ab = np.zeros((len(rows), n_words), np.uint32)
-            for i, a in enumerate(allows):
-                if a is None:
-                    ab[i] = 0xFFFFFFFF  # no filter for this query
-                else:
-                    ab[i, : np.size(a)] = np.asarray(a, dtype=np.uint32)
-            per_query = 1
-        else:
-            ab = None if allow is None else np.ascontiguousarray(allow, dtype=np.uint32)
-            n_words = 0 if ab is None else ab.size
+        ab, n_words, per_query = _allow_block(len(rows), allow, allows, n_docs)
         check(
             lib().mv_query_topk_batch(
                 self._h, blk.ctypes.data, code, len(rows), nmax, k, MODES[mode], None if ab is None else ab.ctypes.data,
@@ -508,3 +520,22 @@ class ShardComm:
                                        C.cast(st, C.c_void_p) if want_stats else None))
         res = (scores[: n.value].copy(), ids[: n.value].copy())
         return res + ([QueryStats.from_c(x) for x in st],) if want_stats else res
+
+    def query_batch(self, queries: Sequence[Any], k: int, mode: str = "fde_then_float", allow: Optional[np.ndarray] = None,
+                    want_stats: bool = False, allows: Optional[Sequence[Optional[np.ndarray]]] = None, n_docs: int = 0):
+        """mv_comm_query_topk_batch: a batch of requests against the sharded corpus (arguments as MvIndex.query_batch).
+        "fde_then_float": one FDE-slab pass per shard and 32 requests, one exchange of all their candidate records, every
+        request's share of its GLOBAL candidate list reranked in one launch per shard.  -> [(scores, ids)] per request
+        [, per-shard QueryStats]."""
+        blk, code, nmax = _stack_queries(queries)
+        k = int(k)
+        nq = blk.shape[0]
+        scores = np.empty((nq, max(k, 1)), np.float32)
+        ids = np.empty((nq, max(k, 1)), np.int64)
+        n = np.zeros(nq, np.int32)
+        ab, n_words, per_query = _allow_block(nq, allow, allows, n_docs)
+        st = (QueryStatsC * len(self.shards))()
+        check(lib().mv_comm_query_topk_batch(self._h, blk.ctypes.data, code, nq, nmax, k, MODES[mode], None if ab is None else ab.ctypes.data, n_words,
+                                             per_query, scores.ctypes.data, ids.ctypes.data, n.ctypes.data, C.cast(st, C.c_void_p) if want_stats else None))
+        res = [(scores[i, : n[i]].copy(), ids[i, : n[i]].copy()) for i in range(nq)]
+        return (res, [QueryStats.from_c(x) for x in st]) if want_stats else res

@@ -139,7 +139,10 @@ class ShardedIndex:
         all requests; the shards run side by side, one host thread each -- the library releases the GIL), and the per-shard
         top-k lists of a request are merged with the communicator's rule (score desc, ties by ascending global id), which
         is the single-index order.  The two-stage FDE pipeline keeps its GLOBAL candidate rule (the coarse top-n is taken over
-        all shards before the rerank), so its requests go through the communicator one by one."""
+        all shards before the rerank): its requests go through the communicator's batched form (mv_comm_query_topk_batch:
+        one FDE-slab pass per shard and 32 requests, one exchange of all their candidate records)."""
+        if mode == "fde_then_float" and len(queries) >= 2 and hasattr(self.comm, "query_batch"):
+            return self.comm.query_batch(queries, k, mode=mode, allow=allow, allows=allows, n_docs=n_docs, want_stats=want_stats)
         if mode not in self._SINGLE_STAGE or len(queries) < 2:
             out = []
             for j, q in enumerate(queries):

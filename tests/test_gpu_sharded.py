@@ -321,3 +321,90 @@ def test_bench_two_ranks_line_carries_roofline_cpu_baseline_and_oracle_parity():
     cfg = d["config"]
     assert len(cfg["kernel_ms_per_rank"]) == 2 and cfg["collective_and_merge_ms_per_step"] is not None and cfg["local_scan_and_topk_ms_per_step"] > 0
     assert cfg["collective_backend"] == "gloo" and cfg["parallelism"].startswith("row-shard x2")
+
+
+# ------------------------------------------------------------------ batched two-stage communicator
+@pytest.mark.parametrize("with_float", [True, False])  # rerank from the bf16 slab / from the fp8 slab
+def test_comm_batched_two_stage_equals_single_index_batched_pipeline(with_float):
+    """mv_comm_query_topk_batch, MV_MODE_FDE_THEN_FLOAT: R = 1, 2, 4 logical shards (peer-copy and host transports) serve a
+    batch of requests with ONE FDE-slab pass per shard and ONE exchange of all the candidate records, and return exactly
+    what mv_query_topk_batch returns on one index holding every page -- ids AND scores, ties included -- for shared and
+    per-request doc filters, ragged pages, 200 candidates (two rerank batches) and more requests than one group of 32."""
+    from morphik_core_amd import _lib
+    from morphik_core_amd.index import ShardComm
+
+    N, stride, k, coarse_n = 480, 48, 6, 200
+    pages = _ragged_pages(N)
+    pages[7] = pages[5].copy()  # duplicated pages: exact score ties across shard boundaries resolve by id
+    pages[N - 3] = pages[5].copy()
+    ords = [i % 9 for i in range(N)]
+    kw = dict(stride_rows=stride, with_fde=True, with_float=with_float, with_fp8=not with_float)
+    one = _idx(capacity_pages=N, **kw)
+    one.add(pages, doc_ordinals=ords)
+    one.set_option(_lib.MV_OPT_FDE_COARSE_N, coarse_n)
+    one.remove_page(11)
+    qs = [orc.synth_rows(4321, j, 0, 12 + (j * 5) % 21) for j in range(37)]  # ragged query lengths, 37 > one group of 32
+    qs[3] = orc.bf16_to_f32(pages[5][:16])  # a query that ties the duplicated pages
+    shared = np.array([0b101101011], np.uint32)
+    per_req = [None if j % 3 == 0 else np.array([(0b111111111 >> (j % 4)) & 0x1FF], np.uint32) for j in range(len(qs))]
+    want_plain = one.query_batch(qs, k, mode="fde_then_float")
+    want_shared = one.query_batch(qs, k, mode="fde_then_float", allow=shared)
+    want_per = one.query_batch(qs, k, mode="fde_then_float", allows=per_req, n_docs=9)
+    for (s, i), q in zip(want_plain[:5], qs[:5]):  # the batched pipeline itself equals the single-query pipeline
+        ws, wi = one.query(q, k, mode="fde_then_float")
+        assert i.tolist() == wi.tolist()
+    for R in (1, 2, 4):
+        per = N // R
+        shards = []
+        for r in range(R):
+            sh = _idx(capacity_pages=per, id_base=r * per, **kw)
+            sh.add(pages[r * per : (r + 1) * per], doc_ordinals=ords[r * per : (r + 1) * per])
+            sh.set_option(_lib.MV_OPT_FDE_COARSE_N, coarse_n)
+            shards.append(sh)
+        shards[11 // per].remove_page(11 % per)
+        for transport in ("p2p", "host"):
+            comm = ShardComm(shards, transport=transport)
+            for want, kwq in ((want_plain, {}), (want_shared, dict(allow=shared)), (want_per, dict(allows=per_req, n_docs=9))):
+                got, st = comm.query_batch(qs, k, mode="fde_then_float", want_stats=True, **kwq)
+                assert len(got) == len(qs) and len(st) == R and all(x.total_device_ms > 0 for x in st)
+                for j, ((s, i), (ws, wi)) in enumerate(zip(got, want)):
+                    assert i.tolist() == wi.tolist(), (R, transport, j)
+                    assert s.tolist() == ws.tolist(), (R, transport, j)
+            # other modes go request by request through the same entry point
+            got = comm.query_batch(qs[:3], k, mode="float" if with_float else "float_fp8")
+            for (s, i), q in zip(got, qs[:3]):
+                ws, wi = one.query(q, k, mode="float" if with_float else "float_fp8")
+                assert i.tolist() == wi.tolist()
+            comm.close()
+        for sh in shards:
+            sh.close()
+    one.close()
+
+
+def test_sharded_store_coalesced_fde_requests_ride_the_batched_communicator():
+    """ShardedIndex.query_batch routes fde_then_float batches through mv_comm_query_topk_batch; at R = 1 the per-request
+    device time stays close to the single index's batched pipeline (reported; bound loosely against box noise)."""
+    from morphik_core_amd import _lib
+    from morphik_core_amd.shard_index import ShardedIndex
+
+    N, stride = 20000, 64
+    one = _idx(capacity_pages=N, stride_rows=stride, with_fde=True)
+    one.fill_synthetic(1234, 0, N)
+    sh = ShardedIndex(capacity_pages=N, stride_rows=stride, devices=[0], with_fde=True, transport="p2p")
+    sh.shards[0].fill_synthetic(1234, 0, N)
+    qs = [orc.synth_rows(4321, j, 0, 32) for j in range(32)]
+    want = one.query_batch(qs, 10, mode="fde_then_float")
+    got = sh.query_batch(qs, 10, mode="fde_then_float")
+    for (s, i), (ws, wi) in zip(got, want):
+        assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist()
+    t1, t2 = [], []
+    for _ in range(6):
+        _r, st = one.query_batch(qs, 10, mode="fde_then_float", want_stats=True)
+        t1.append(st.total_device_ms)
+        _r, st2 = sh.query_batch(qs, 10, mode="fde_then_float", want_stats=True)
+        t2.append(st2[0].total_device_ms)
+    a, b = float(np.median(t1)), float(np.median(t2))
+    print(f"batched two-stage at R = 1: single index {a*1e3/32:.1f} us / request, communicator {b*1e3/32:.1f} us / request")
+    assert b < 1.5 * a + 0.2
+    sh.close()
+    one.close()

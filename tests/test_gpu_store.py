@@ -576,3 +576,123 @@ def test_full_size_colqwen2_5_3b_architecture_embeds_ragged_pages_on_the_gpu():
         assert hit[0].content == f"page {i}" and hit[0].score == pytest.approx(float(n), rel=2e-2)
         o += n
     store.close()
+
+
+# ------------------------------------------------------------------ numeric reference for the encoder forward
+def _cpu_fp32_twin(model):
+    """The same architecture and the same (bf16-valued) weights on the CPU in fp32: the reference formulation is
+    model(**processor(x)) -> float32 (colpali_embedding_model.py:251-262, :275-305); fp32 on the host is its gold form."""
+    import copy
+
+    import torch
+
+    twin = type(model)(copy.deepcopy(model.config)).to(torch.float32).eval()
+    twin.load_state_dict({k: v.detach().to("cpu", torch.float32) for k, v in model.state_dict().items()})
+    return twin
+
+
+def _rowwise_cosine(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return (a * b).sum(-1) / np.maximum(np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1), 1e-30)
+
+
+@pytest.mark.parametrize("preset", ["tiny", "one-layer-full-width"])
+def test_colpali_forward_on_the_gpu_matches_an_fp32_cpu_forward_of_the_same_weights(preset):
+    """bf16 forward on the MI355X (SDPA / hipBLASLt, the patch embedding run as one GEMM) against an fp32 CPU forward of the
+    SAME weights and inputs: every output row within cosine 0.999 of the reference row, MaxSim scores within 1 %.  A wrong
+    attention backend, a broken mask or a transposed patch grid on ROCm fails this; the contract tests above cannot."""
+    import torch
+
+    from morphik_core_amd import embedding as E
+
+    if preset == "one-layer-full-width":  # ColPali-v1.2's real widths (SigLIP 1152 / Gemma 2048, 448 px -> 1024 patches), one layer each
+        p = {k: (dict(v) if isinstance(v, dict) else v) for k, v in E.PRESETS["colpali-v1.2"].items()}
+        p["vision"]["num_hidden_layers"] = 1
+        p["text"]["num_hidden_layers"] = 1
+        p["text"]["vocab_size"] = 4096
+        p["image_token_index"] = 4000
+        E.PRESETS["one-layer-full-width"] = p
+    emb = E.MI355XColpaliEmbeddingModel(preset=preset, device="cuda:0", batch_size=2, seed=3)
+    twin = _cpu_fp32_twin(emb.model)
+    rng = np.random.default_rng(5)
+    S = emb.image_size
+    imgs = [rng.integers(0, 255, (S, S, 3), dtype=np.uint8) for _ in range(2)]
+    pv = emb._pixel_values(imgs)
+    B = pv.shape[0]
+    prompt = torch.tensor(emb.tokenizer("Describe the image .")[: E.IMAGE_PROMPT_TOKENS - 2] + [1, 1], device=emb.device)[: E.IMAGE_PROMPT_TOKENS]
+    ids = torch.cat([torch.full((B, emb.n_image_tokens), emb.image_token_index, device=emb.device), prompt.expand(B, -1)], 1)
+    mask = torch.ones_like(ids)
+    got = emb._forward(ids, mask, pv).float().cpu().numpy()
+    with torch.inference_mode():
+        want = twin(input_ids=ids.cpu(), attention_mask=mask.cpu(), pixel_values=pv.float().cpu()).embeddings.numpy()
+    assert got.shape == want.shape == (B, emb.n_image_tokens + E.IMAGE_PROMPT_TOKENS, 128)
+    cos = _rowwise_cosine(got, want)
+    print(f"colpali {preset}: rows {got.shape}, cosine min {cos.min():.5f} mean {cos.mean():.6f}; attn {getattr(emb.model.config, '_attn_implementation', '?')}")
+    assert cos.min() >= 0.999
+    # queries through the text path, then MaxSim of every query against every page, both ways
+    qg, qm = emb._embed_texts_device(["total revenue by quarter", "hello world"])
+    toks = [[1] + emb.tokenizer(t) + [0] * E.N_QUERY_AUGMENTATION_TOKENS for t in ["total revenue by quarter", "hello world"]]
+    L = max(len(t) for t in toks)
+    qi = torch.zeros((2, L), dtype=torch.long)
+    qa = torch.zeros((2, L), dtype=torch.long)
+    for i, t in enumerate(toks):
+        qi[i, : len(t)] = torch.tensor(t)
+        qa[i, : len(t)] = 1
+    with torch.inference_mode():
+        qw = twin(input_ids=qi, attention_mask=qa).embeddings.numpy()
+    qg = qg.float().cpu().numpy()
+    cq = _rowwise_cosine(qg[qa.numpy() > 0], qw[qa.numpy() > 0])
+    assert cq.min() >= 0.999, cq.min()
+    for b in range(2):
+        n = int(qa[b].sum())
+        for pg in range(B):
+            sg = float((qg[b, :n] @ got[pg].T).max(1).sum())
+            sw = float((qw[b, :n] @ want[pg].T).max(1).sum())
+            assert abs(sg - sw) <= 0.01 * abs(sw), (b, pg, sg, sw)
+
+
+@pytest.mark.parametrize("preset", ["tiny-2.5", "one-layer-2.5"])
+def test_colqwen2_5_forward_on_the_gpu_matches_an_fp32_cpu_forward_of_the_same_weights(preset):
+    """The reference's own family (ColQwen2.5: windowed-attention ViT, M-RoPE, ragged patch grids): bf16 on the MI355X vs
+    fp32 on the CPU, same weights, same processor output -> row-wise cosine >= 0.999 on every valid row, MaxSim within 1 %."""
+    import torch
+
+    from morphik_core_amd import colqwen_embedding as CQ
+    from tests import offline_assets as oa
+
+    if preset == "one-layer-2.5":  # ColQwen2.5-3B's real widths (ViT 1280 -> 2048, decoder 2048 / 11008), one block each
+        p = {k: (dict(v) if isinstance(v, dict) else v) for k, v in CQ.PRESETS["colqwen2.5-3b"].items()}
+        p["vision"]["depth"] = 1
+        p["vision"]["fullatt_block_indexes"] = [0]
+        p["text"]["num_hidden_layers"] = 1
+        p["text"]["vocab_size"] = 256
+        CQ.PRESETS["one-layer-2.5"] = p
+    proc, ids = oa.colqwen2_processor(min_tokens=4, max_tokens=64)
+    model = CQ.build_random_colqwen2(preset, ids, "cuda:0", torch.bfloat16, seed=2)
+    twin = _cpu_fp32_twin(model)
+    rng = np.random.default_rng(9)
+    imgs = [oa.page_image(rng, h, w) for h, w in ((84, 84), (56, 196), (168, 112))]
+    batch = proc(images=imgs, return_tensors="pt")
+    dev = {k: (v.to("cuda:0") if hasattr(v, "to") else v) for k, v in batch.items()}
+    dev["pixel_values"] = dev["pixel_values"].to(torch.bfloat16)
+    cpu = {k: v for k, v in batch.items()}
+    cpu["pixel_values"] = dev["pixel_values"].float().cpu()  # the same bf16-valued pixels
+    with torch.inference_mode():
+        got = model(**dev).embeddings.float().cpu().numpy()
+        want = twin(**cpu).embeddings.numpy()
+    m = batch["attention_mask"].numpy() > 0
+    cos = _rowwise_cosine(got[m], want[m])
+    print(f"colqwen2.5 {preset}: rows {got.shape}, valid {int(m.sum())}, cosine min {cos.min():.5f} mean {cos.mean():.6f}")
+    assert cos.min() >= 0.999
+    qb = proc(text=["total revenue by quarter", "what is shown in this image"], return_tensors="pt", padding=True)
+    with torch.inference_mode():
+        qg = model(**{k: v.to("cuda:0") for k, v in qb.items()}).embeddings.float().cpu().numpy()
+        qw = twin(**qb).embeddings.numpy()
+    qm = qb["attention_mask"].numpy() > 0
+    assert _rowwise_cosine(qg[qm], qw[qm]).min() >= 0.999
+    for b in range(2):
+        for pg in range(len(imgs)):
+            sg = float((qg[b][qm[b]] @ got[pg][m[pg]].T).max(1).sum())
+            sw = float((qw[b][qm[b]] @ want[pg][m[pg]].T).max(1).sum())
+            assert abs(sg - sw) <= 0.01 * abs(sw), (b, pg, sg, sw)

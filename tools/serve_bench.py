@@ -67,6 +67,7 @@ def build_store(a):
     else:
         st = MI355XMultiVectorStore(mode=a.mode, **kw)
     assert st.initialize()
+    st.collect_device_time = True
     st.adopt_synthetic_corpus(synth.SEED_CORPUS, a.pages, n_rows=a.patches, pages_per_doc=4)
     return st
 
@@ -96,17 +97,8 @@ async def run_clients(st, queries, n_clients, seconds, k, doc_ids):
             "device_ms_per_request_p50": (round(float(np.percentile(dev, 50)), 4) if dev else None)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", default="fde_then_float", choices=["fde_then_float", "float", "float_fp8", "binary"])
-    ap.add_argument("--pages", type=int, default=200_000)
-    ap.add_argument("--patches", type=int, default=1024)
-    ap.add_argument("--clients", default="1,8,32,128")
-    ap.add_argument("--seconds", type=float, default=2.0)
-    ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--null-index", action="store_true")
-    ap.add_argument("--out", default="")
-    a = ap.parse_args()
+def measure(a):
+    """a: namespace with mode, pages, patches, clients ("1,8,.."), seconds, k, null_index.  -> result dict."""
     from morphik_core_amd import synth
 
     st = build_store(a)
@@ -141,7 +133,7 @@ def main():
         if label == "coalescer_adaptive" and a.mode not in ("float", "fde_then_float"):
             continue
         st.batch_window_s = window / 1e3
-        for nc in [int(x) for x in a.clients.split(",")]:
+        for nc in [int(x) for x in str(a.clients).split(",")]:
             st.coalesced_batches.clear()
             r = asyncio.run(run_clients(st, queries, nc, a.seconds, a.k, None))
             r["coalescer"] = label
@@ -150,6 +142,28 @@ def main():
             res["runs"].append(r)
             print(json.dumps(r), file=sys.stderr, flush=True)
     st.close()
+    one = [r for r in res["runs"] if r["clients"] == 1 and r["coalescer"] == "coalescer_off"]
+    if one and "direct_single" in res:
+        res["lone_request_overhead_over_device_ms"] = round(one[0]["p50_ms"] - res["direct_single"]["device_ms_p50"], 4)
+    if "direct_batch" in res:
+        best = max(r["requests_per_s"] for r in res["runs"])
+        res["best_store_requests_per_s"] = best
+        res["best_store_vs_direct_batch"] = round(best / res["direct_batch"]["requests_per_s"], 4)
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="fde_then_float", choices=["fde_then_float", "float", "float_fp8", "binary"])
+    ap.add_argument("--pages", type=int, default=200_000)
+    ap.add_argument("--patches", type=int, default=1024)
+    ap.add_argument("--clients", default="1,8,32,128")
+    ap.add_argument("--seconds", type=float, default=2.0)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--null-index", action="store_true")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    res = measure(a)
     js = json.dumps(res)
     if a.out:
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
