@@ -400,6 +400,39 @@ def two_tier(args, device):
     return res
 
 
+def fde_encode_block(args, device):
+    """Roofline entry of the FDE DOCUMENT encode (fde.generate_document_encoding, fast_multivector_store.py:447-449 ->
+    fde_encode_mfma_kernel): corpus build of the same pages with and without the FDE slab; the difference is the encode,
+    which reads every page's bf16 rows once (262 144 B) and writes 20 480 B.  Its arithmetic runs on the f32 matrix path
+    (v_mfma_f32_16x16x4_f32, exact fmaf chains): 128 x (20 x 5 SimHash + 20 x 16 AMS) MACs per row as issued ("dense"),
+    of which the AMS part is 128 signed adds per row and repetition in exact arithmetic ("useful")."""
+    from morphik_core_amd import synth
+    from morphik_core_amd.index import MvIndex
+
+    n = min(args.aux_pages, 100_000)
+    stride = ((args.patches + 15) // 16) * 16
+    t = {}
+    for key, fde in (("gen", False), ("gen_encode", True)):
+        ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=True, with_fde=fde)
+        ix.fill_synthetic(synth.SEED_CORPUS, 0, min(n, 2000), n_rows=args.patches)  # warm-up (tables, clocks)
+        ix.close()
+        ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=True, with_fde=fde)
+        t0 = time.perf_counter()
+        ix.fill_synthetic(synth.SEED_CORPUS, 0, n, n_rows=args.patches)
+        t[key] = time.perf_counter() - t0
+        ix.close()
+    enc = max(t["gen_encode"] - t["gen"], 1e-9)
+    us = enc / n * 1e6
+    dense = 2.0 * args.patches * 128 * (112 + 20 * 16)  # 7 SimHash column tiles (112) + 20 AMS tiles (16 each)
+    useful = 2.0 * args.patches * 128 * (20 * 5) + args.patches * 128 * 20  # SimHash MACs + one signed add per (dim, repetition)
+    return {"pages": n, "us_per_page": round(us, 3), "pages_per_s": round(n / enc, 1), "page_input_GBps": round(args.patches * 256 / us / 1e3, 1),
+            "frac_hbm_8TBps": round(args.patches * 256 / us / 1e3 / HBM_PEAK_GBPS, 4),
+            "f32_mfma_TFLOPs_as_issued": round(dense / us / 1e6, 1), "frac_f32_mfma_155TF": round(dense / us / 1e6 / 155.0, 4),
+            "useful_TFLOPs": round(useful / us / 1e6, 1),
+            "bound": "f32 MFMA (dense AMS columns; the exact signed-add form would cut the issued flops 3.9x -- DESIGN.md 3.9)",
+            "corpus_generation_us_per_page": round(t["gen"] / n * 1e6, 3)}
+
+
 def serving_block(args):
     """QPS / latency of `await store.query_similar(...)` (the plugin boundary, where the reference logs its per-query totals:
     fast_multivector_store.py:513-605) under 1 / 8 / 32 / 128 concurrent asyncio clients, coalescer off / adaptive, next
@@ -475,8 +508,9 @@ def main():
                          "embed = configs[1] (ColPali-v1.2 architecture, 1 k pages -> top-10)")
     ap.add_argument("--no-aux", action="store_true", help="skip the secondary kernels' quick measurements (aux_paths)")
     ap.add_argument("--aux-pages", type=int, default=200_000, help="pages of the two-tier (fp8 -> exact bf16 from the pinned-host tier) index in aux_paths (0 = skip)")
-    ap.add_argument("--no-full-shard-host-tier", dest="full_shard_host_tier", action="store_false",
-                    help="do not keep the full shard's exact bf16 rows in pinned host RAM (n x 256 KiB; skips fp8_then_float at the shard shape)")
+    ap.add_argument("--full-shard-host-tier", action="store_true",
+                    help="also keep the full shard's exact bf16 rows in PINNED host RAM (n x 256 KiB = 328 GB at 1.25 M pages) and measure "
+                         "fp8_then_float at the shard shape; off by default (the default run pins 52 GB for the 200 k-page two-tier index only)")
     ap.add_argument("--full-shard-pages", type=int, default=1_250_000,
                     help="pages of the e4m3 + FDE + sign-bit index in aux_paths.full_shard (BASELINE configs[3]/[4] per-GPU shard of 10 M pages / 8 GPUs; 0 = skip)")
     ap.add_argument("--aux-embed-pages", type=int, default=96, help="pages of the full-size encoder run inside aux_paths (0 = skip)")
@@ -873,6 +907,11 @@ def main():
                 aux["fp8_then_float"] = two_tier(args, local_rank)
             except Exception as e:  # noqa: BLE001
                 aux["fp8_then_float"] = {"error": repr(e)}
+        if args.aux_pages > 0:
+            try:  # roofline entry of the FDE document encode
+                aux["fde_document_encode"] = fde_encode_block(args, local_rank)
+            except Exception as e:  # noqa: BLE001
+                aux["fde_document_encode"] = {"error": repr(e)}
         if args.aux_pages > 0:
             try:  # the same path measured where the reference measures it: at the store's coroutine
                 aux["serving"] = serving_block(args)

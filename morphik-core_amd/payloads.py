@@ -186,3 +186,56 @@ def parse_metadata(meta_json: Optional[str]) -> Dict[str, Any]:
             _META_CACHE.clear()
         _META_CACHE[meta_json] = m
     return dict(m)
+
+
+class LocalDirStorage:
+    """The three coroutines of core/storage/base_storage.py the stores use, over a directory -- what the store-owner server
+    (store_server.py --payload-dir) keeps chunk payloads in when no S3 / LocalStorage object of the host application is
+    wired in: base64 page images of hundreds of kilobytes each belong on disk, not in the owner's RAM or in store.json."""
+
+    def __init__(self, root: str):
+        import os
+
+        self.root = os.path.abspath(root)
+        os.makedirs(self.root, exist_ok=True)
+
+    def _path(self, bucket: str, key: str) -> str:
+        import os
+
+        p = os.path.abspath(os.path.join(self.root, bucket or "", key))
+        if not p.startswith(self.root + os.sep):
+            raise ValueError(f"storage key escapes the payload directory: {key!r}")
+        return p
+
+    async def upload_from_base64(self, content: str, key: str, content_type: Optional[str] = None, bucket: str = "") -> Tuple[str, str]:
+        import os
+
+        path = self._path(bucket, key)
+
+        def write():
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            tmp = path + ".tmp"
+            with open(tmp, "wb") as f:
+                f.write(base64.b64decode(content))
+            os.replace(tmp, path)
+
+        await asyncio.to_thread(write)
+        return bucket, key
+
+    async def download_file(self, bucket: str, key: str) -> bytes:
+        path = self._path(bucket, key)
+
+        def read():
+            with open(path, "rb") as f:
+                return f.read()
+
+        return await asyncio.to_thread(read)
+
+    async def delete_file(self, bucket: str, key: str) -> bool:
+        import os
+
+        try:
+            os.remove(self._path(bucket, key))
+            return True
+        except FileNotFoundError:
+            return False

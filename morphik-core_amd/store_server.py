@@ -11,7 +11,14 @@ a BaseVectorStore whose four coroutines forward over HTTP on localhost:
     POST /query_similar      npz {meta: json {k, doc_ids, app_id, skip_image_content}, q}          -> json chunks
     POST /get_chunks_by_id   json {chunk_identifiers, app_id, skip_image_content}                  -> json chunks
     POST /delete_chunks_by_document_id   json {document_id, app_id}                                -> json {ok}
+    POST /save               checkpoint now (store.save into --save-dir)                            -> json {ok, pages, seconds}
     GET  /health
+
+The owner holds the ONLY copy of the corpus: with --save-dir it checkpoints on POST /save, every --save-every-s seconds when
+pages changed, and on shutdown; --load resumes from such a directory.  Chunk payloads (page images) go to the owner's
+`.storage` (--payload-dir: a directory; or the host application's storage object passed to build_store / create_app's
+store) -- or, when the REMOTE client was constructed with a `storage` of its own, the client uploads them there and only
+the storage keys cross the wire.
 
 Embeddings travel as float32 (or bf16 bit patterns as uint16) arrays inside one .npz body -- the wire format the
 reference already uses for multi-vectors (colpali_api_embedding_model.py:293-310).  Scoring still happens only in
@@ -53,11 +60,63 @@ def _unpack(body: bytes) -> Tuple[Any, Any]:
     return json.loads(str(z["meta"])), z
 
 
-def create_app(store: Any, api_key: Optional[str] = None):
+class _Checkpointer:
+    """Serialised store.save() calls into one directory + the dirty flag the periodic / shutdown saves look at."""
+
+    def __init__(self, store: Any, save_dir: Optional[str]):
+        self.store, self.save_dir = store, save_dir
+        self.dirty = False
+        self._lock = asyncio.Lock()
+        self.last: Dict[str, Any] = {}
+
+    async def save(self) -> Dict[str, Any]:
+        import time
+
+        if not self.save_dir:
+            raise RuntimeError("the server was started without --save-dir")
+        async with self._lock:
+            t0 = time.perf_counter()
+            self.dirty = False  # writes landing during the save set it again
+            await asyncio.to_thread(self.store.save, self.save_dir)
+            self.last = {"ok": True, "pages": len(self.store) if hasattr(self.store, "__len__") else None, "seconds": round(time.perf_counter() - t0, 3),
+                         "directory": self.save_dir}
+            return self.last
+
+
+def create_app(store: Any, api_key: Optional[str] = None, save_dir: Optional[str] = None, save_every_s: float = 0.0):
     """FastAPI app around any BaseVectorStore (normally an MI355X store that owns the GPU)."""
+    from contextlib import asynccontextmanager
+
     from fastapi import FastAPI, Header, HTTPException, Request
 
-    app = FastAPI(title="mi355x-multivector-store")
+    ckpt = _Checkpointer(store, save_dir)
+
+    @asynccontextmanager
+    async def lifespan(_app):
+        task = None
+        if save_dir and save_every_s > 0:
+            async def periodic():
+                while True:
+                    await asyncio.sleep(save_every_s)
+                    if ckpt.dirty:
+                        try:
+                            await ckpt.save()
+                        except Exception as e:  # noqa: BLE001 -- keep serving; the next tick tries again
+                            logger.error("periodic checkpoint failed: %s", e)
+            task = asyncio.ensure_future(periodic())
+        try:
+            yield
+        finally:
+            if task is not None:
+                task.cancel()
+            if save_dir and ckpt.dirty:  # everything ingested over HTTP since the last checkpoint
+                try:
+                    await ckpt.save()
+                except Exception as e:  # noqa: BLE001
+                    logger.error("checkpoint on shutdown failed: %s", e)
+
+    app = FastAPI(title="mi355x-multivector-store", lifespan=lifespan)
+    app.state.checkpointer = ckpt
 
     def auth(authorization: Optional[str]) -> None:
         if api_key and not hmac.compare_digest((authorization or "").encode(), f"Bearer {api_key}".encode()):
@@ -80,7 +139,16 @@ def create_app(store: Any, api_key: Optional[str] = None):
             ok, ids, metrics = await store.store_embeddings(chunks, app_id=meta.get("app_id"))
         except Exception as e:  # noqa: BLE001 -- the client re-raises it, as a local store would have raised
             raise HTTPException(status_code=500, detail=f"{type(e).__name__}: {e}")
+        ckpt.dirty = True
         return {"ok": bool(ok), "ids": ids, "metrics": metrics}
+
+    @app.post("/save")
+    async def save(authorization: Optional[str] = Header(default=None)):  # noqa: B008
+        auth(authorization)
+        try:
+            return await ckpt.save()
+        except Exception as e:  # noqa: BLE001
+            raise HTTPException(status_code=500, detail=f"{type(e).__name__}: {e}")
 
     @app.post("/query_similar")
     async def query_similar(request: Request, authorization: Optional[str] = Header(default=None)):  # noqa: B008
@@ -103,7 +171,9 @@ def create_app(store: Any, api_key: Optional[str] = None):
     @app.post("/delete_chunks_by_document_id")
     async def delete_chunks(req: Dict[str, Any], authorization: Optional[str] = Header(default=None)):  # noqa: B008
         auth(authorization)
-        return {"ok": bool(await store.delete_chunks_by_document_id(req["document_id"], app_id=req.get("app_id")))}
+        ok = bool(await store.delete_chunks_by_document_id(req["document_id"], app_id=req.get("app_id")))
+        ckpt.dirty = ckpt.dirty or ok
+        return {"ok": ok}
 
     return app
 
@@ -117,7 +187,13 @@ class MI355XRemoteMultiVectorStore(BaseVectorStore):
     def __init__(self, url: str = "http://127.0.0.1:8766", api_key: Optional[str] = None, timeout_s: float = 600.0, storage: Any = None,
                  **_ignored: Any):
         self.url = url.rstrip("/")
+        # A client constructed with the application's storage object uploads chunk payloads THERE (as the local stores do:
+        # multi_vector_store.py:650-676) and sends the owner only the storage keys; hits come back as keys and are
+        # resolved through the same object.  Without one the payloads travel to the owner, which keeps them in ITS storage.
         self.storage = storage
+        from .payloads import PayloadStore
+
+        self._payloads = PayloadStore(storage) if storage is not None else None
         self._headers = {"Authorization": f"Bearer {api_key}"} if api_key else {}
         self._timeout = timeout_s
         self._last_store_metrics: Dict[str, Any] = {}
@@ -171,24 +247,36 @@ class MI355XRemoteMultiVectorStore(BaseVectorStore):
     async def store_embeddings(self, chunks: List[DocumentChunk], app_id: Optional[str] = None) -> Tuple[bool, List[str], Dict[str, Any]]:
         meta = {"app_id": app_id, "chunks": []}
         arrays: Dict[str, np.ndarray] = {}
+        contents = [c.content for c in chunks]
+        if self._payloads is not None:  # payloads stay on this side of the wire: upload, send the keys
+            res = await asyncio.gather(*[self._payloads.put(c.content, c.document_id, int(c.chunk_number), c.metadata or {}, app_id)
+                                         if getattr(c, "embedding", None) is not None else asyncio.sleep(0, result=(None, 0)) for c in chunks])
+            contents = [key if key else c.content for (key, _n), c in zip(res, chunks)]
         for i, c in enumerate(chunks):
-            meta["chunks"].append({"document_id": c.document_id, "chunk_number": int(c.chunk_number), "content": c.content, "metadata": c.metadata or {}})
+            meta["chunks"].append({"document_id": c.document_id, "chunk_number": int(c.chunk_number), "content": contents[i], "metadata": c.metadata or {}})
             if getattr(c, "embedding", None) is not None:
                 arrays[f"emb_{i}"] = self._rows(c.embedding)
         out = await self._post("/store_embeddings", content=_pack(meta, arrays))
         self._last_store_metrics = out.get("metrics", {})
         return bool(out["ok"]), list(out["ids"]), self._last_store_metrics
 
-    @staticmethod
-    def _to_chunks(rows: List[Dict[str, Any]]) -> List[DocumentChunk]:
-        return [DocumentChunk(document_id=r["document_id"], chunk_number=int(r["chunk_number"]), content=r["content"], embedding=[],
-                              metadata=r.get("metadata") or {}, score=float(r.get("score", 0.0))) for r in rows]
+    async def _to_chunks(self, rows: List[Dict[str, Any]], skip_image_content: bool = False) -> List[DocumentChunk]:
+        from .payloads import is_storage_key
+
+        contents = [r["content"] for r in rows]
+        if self._payloads is not None:  # keys this client uploaded: resolve them here (images stay keys when the caller skips them)
+            fetch = [j for j, r in enumerate(rows) if is_storage_key(r["content"]) and not (skip_image_content and (r.get("metadata") or {}).get("is_image"))]
+            got = await asyncio.gather(*[self._payloads.get(rows[j]["content"], rows[j].get("metadata") or {}) for j in fetch])
+            for j, c in zip(fetch, got):
+                contents[j] = c
+        return [DocumentChunk(document_id=r["document_id"], chunk_number=int(r["chunk_number"]), content=c, embedding=[],
+                              metadata=r.get("metadata") or {}, score=float(r.get("score", 0.0))) for r, c in zip(rows, contents)]
 
     async def query_similar(self, query_embedding: Any, k: int, doc_ids: Optional[List[str]] = None, app_id: Optional[str] = None,
                             skip_image_content: bool = False) -> List[DocumentChunk]:
         meta = {"k": int(k), "doc_ids": doc_ids, "app_id": app_id, "skip_image_content": bool(skip_image_content)}
         out = await self._post("/query_similar", content=_pack(meta, {"q": self._rows(query_embedding)}))
-        return self._to_chunks(out["chunks"])
+        return await self._to_chunks(out["chunks"], skip_image_content)
 
     async def get_chunks_by_id(self, chunk_identifiers: List[Tuple[str, int]], app_id: Optional[str] = None,
                                skip_image_content: bool = False) -> List[DocumentChunk]:
@@ -196,7 +284,7 @@ class MI355XRemoteMultiVectorStore(BaseVectorStore):
             return []
         out = await self._post("/get_chunks_by_id", json_body={"chunk_identifiers": [[d, int(c)] for d, c in chunk_identifiers], "app_id": app_id,
                                                                "skip_image_content": bool(skip_image_content)})
-        return self._to_chunks(out["chunks"])
+        return await self._to_chunks(out["chunks"], skip_image_content)
 
     async def delete_chunks_by_document_id(self, document_id: str, app_id: Optional[str] = None) -> bool:
         try:
@@ -220,11 +308,15 @@ def main(argv: Optional[List[str]] = None) -> None:
                          "requests arriving while a scan is in flight share the next slab pass; > 0 = timer window in ms (a lone "
                          "request pays it); 0 = off, one scan per request")
     ap.add_argument("--max-batch", type=int, default=32, help="largest coalesced batch")
+    ap.add_argument("--save-dir", default="", help="checkpoint directory: POST /save, --save-every-s and shutdown write store.save() here (resume with --load)")
+    ap.add_argument("--save-every-s", type=float, default=0.0, help="checkpoint every N seconds when pages were added or deleted since the last one (0 = only /save and shutdown)")
+    ap.add_argument("--payload-dir", default="", help="directory for chunk payloads (page images): the owner's `.storage`; without it payloads stay inline in the owner's memory")
     a = ap.parse_args(argv)
     import uvicorn
 
     store = build_store(a)
-    uvicorn.run(create_app(store, os.environ.get("MORPHIK_STORE_API_KEY")), host=a.host, port=a.port, log_level="info")
+    uvicorn.run(create_app(store, os.environ.get("MORPHIK_STORE_API_KEY"), save_dir=a.save_dir or None, save_every_s=a.save_every_s), host=a.host,
+                port=a.port, log_level="info")
 
 
 def build_store(a: Any) -> Any:
@@ -232,6 +324,10 @@ def build_store(a: Any) -> Any:
     from .store import create_store
 
     opts: Dict[str, Any] = dict(batch_window_ms=a.batch_window_ms, max_batch=a.max_batch)
+    if getattr(a, "payload_dir", ""):
+        from .payloads import LocalDirStorage
+
+        opts["storage"] = LocalDirStorage(a.payload_dir)
     if a.devices:
         opts["devices"] = [int(x) for x in a.devices.split(",")]
     proto = create_store(a.provider, capacity_pages=a.capacity_pages, stride_rows=a.stride_rows, **opts)  # allocates nothing yet

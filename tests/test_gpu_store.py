@@ -175,6 +175,55 @@ def test_owner_server_resumes_from_a_checkpoint_with_request_coalescing(tmp_path
     assert r.coalesced_batches == [1]
 
 
+def test_owner_server_checkpoints_what_it_ingested_over_http_and_keeps_payloads_on_disk(tmp_path):
+    """the owner holds the ONLY copy of the corpus.  With --save-dir / --payload-dir it checkpoints on the
+    authenticated POST /save and again on shutdown when pages arrived since, chunk payloads (page images) live in the
+    payload directory -- store.json carries storage keys, not base64 -- and `--load` brings everything back."""
+    import argparse
+    import json
+    import os
+
+    import httpx
+
+    from morphik_core_amd import store_server
+    from morphik_core_amd.store_server import MI355XRemoteMultiVectorStore, create_app
+    from tests import store_scenarios as sc2
+    from tests.test_encoder_and_formats import _serve
+
+    save_dir, pay_dir = str(tmp_path / "ckpt"), str(tmp_path / "payloads")
+    a = argparse.Namespace(provider="mi355x_fast", capacity_pages=64, stride_rows=32, devices="", load="", batch_window_ms=-1.0, max_batch=8,
+                           payload_dir=pay_dir)
+    owner = store_server.build_store(a)
+    url, stop = _serve(create_app(owner, api_key="k", save_dir=save_dir, save_every_s=0.0))
+    rng = np.random.default_rng(8)
+    chunks = sc2.make_chunks(rng, n_docs=3, chunks_per_doc=3)
+    img = "data:image/png;base64," + __import__("base64").b64encode(b"\x89PNG\r\n\x1a\n" + bytes(range(200)) * 50).decode()
+    chunks[4].content, chunks[4].metadata = img, {"is_image": True}
+    try:
+        remote = MI355XRemoteMultiVectorStore(url, api_key="k")
+        ok, ids, _m = sc2.run(remote.store_embeddings(chunks[:6], app_id="t"))
+        assert ok and len(ids) == 6
+        assert httpx.post(url + "/save", timeout=60).status_code == 401  # the checkpoint endpoint is authenticated
+        r = httpx.post(url + "/save", headers={"Authorization": "Bearer k"}, timeout=120)
+        assert r.status_code == 200 and r.json()["ok"] and r.json()["pages"] == 6
+        book = json.load(open(os.path.join(save_dir, "store.json")))
+        assert len(book["rows"]) == 6 and all(len(row[3]) < 200 for row in book["rows"])  # keys, not payloads
+        assert any(f.endswith(".png") for _d, _s, fs in os.walk(pay_dir) for f in fs)
+        sc2.run(remote.store_embeddings(chunks[6:], app_id="t"))  # after the checkpoint: only the shutdown save can keep these
+    finally:
+        stop()  # lifespan shutdown -> checkpoint because pages arrived since /save
+    owner.close()
+    a2 = argparse.Namespace(provider="mi355x_fast", capacity_pages=1, stride_rows=16, devices="", load=save_dir, batch_window_ms=0.0, max_batch=8,
+                            payload_dir=pay_dir)
+    back = store_server.build_store(a2)
+    assert len(back) == 9
+    hit = sc2.run(back.query_similar(chunks[4].embedding, k=1, app_id="t"))
+    assert (hit[0].document_id, hit[0].chunk_number) == (chunks[4].document_id, chunks[4].chunk_number) and hit[0].content == img
+    hit = sc2.run(back.query_similar(chunks[7].embedding, k=1, app_id="t"))
+    assert hit[0].content == chunks[7].content
+    back.close()
+
+
 def test_request_coalescing_on_the_fast_store_rides_the_batched_fde_pipeline():
     """Concurrent query_similar calls on the FDE ("fast") store: one pass over the FDE slab for the coalesced requests
     (mv_query_topk_batch), each with its own k (requests share a pass only with requests of the same k: the candidate

@@ -463,3 +463,35 @@ def test_remote_store_two_clients_see_each_others_pages_and_errors_propagate():
             sc.run(MI355XRemoteMultiVectorStore(url2, api_key="wrong").query_similar(chunks[0].embedding, k=1))
     finally:
         stop()
+
+
+def test_remote_client_with_its_own_storage_keeps_payloads_off_the_wire():
+    """MI355XRemoteMultiVectorStore(storage=...) uploads chunk payloads through ITS storage object (as the local
+    stores do, multi_vector_store.py:650-676); the owner only ever sees storage keys, hits are resolved on the client, and
+    image payloads stay keys when the caller asks for skip_image_content."""
+    import base64
+
+    from morphik_core_amd.store_server import MI355XRemoteMultiVectorStore, create_app
+    from tests.test_encoder_and_formats import _serve
+
+    owner = MI355XFastMultiVectorStore(capacity_pages=16, stride_rows=32, mode="float", index_factory=OracleIndex)
+    assert owner.initialize()
+    url, stop = _serve(create_app(owner))
+    try:
+        st = MemStorage()
+        remote = MI355XRemoteMultiVectorStore(url, storage=st)
+        rng = np.random.default_rng(12)
+        chunks = sc.make_chunks(rng, n_docs=2, chunks_per_doc=2)
+        img = "data:image/png;base64," + base64.b64encode(b"\x89PNG\r\n\x1a\n" + b"x" * 5000).decode()
+        chunks[1].content, chunks[1].metadata = img, {"is_image": True}
+        ok, ids, _m = sc.run(remote.store_embeddings(chunks, app_id="t"))
+        assert ok and len(ids) == 4 and st.uploads == 4
+        assert all(len(r[2]) < 100 and "/" in r[2] for r in owner._rows.values())  # the owner holds keys only
+        hit = sc.run(remote.query_similar(chunks[1].embedding, k=1, app_id="t"))
+        assert hit[0].content == img  # resolved through the client's storage
+        hit = sc.run(remote.query_similar(chunks[1].embedding, k=1, app_id="t", skip_image_content=True))
+        assert hit[0].content.endswith(".png") and "/" in hit[0].content  # the key itself
+        got = sc.run(remote.get_chunks_by_id([(chunks[2].document_id, chunks[2].chunk_number)], app_id="t"))
+        assert got[0].content == chunks[2].content
+    finally:
+        stop()
