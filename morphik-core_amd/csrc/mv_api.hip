@@ -165,7 +165,10 @@ int64_t count_allowed_rows(const mv_index* ix, int64_t n, const uint32_t* allow_
     return n * (int64_t)ix->cfg.stride_rows;
   }
   for (int64_t p = 0; p < n; ++p) {
-    const int32_t o = ix->h_doc_ord[p];
+    // a writer may tombstone a PUBLISHED page (remove_*, under w_mu) while this accounting loop runs under q_mu: the
+    // page counts as read or not -- either is a valid ordering -- but the access itself must not be a data race
+    // (ThreadSanitizer, tools/sanitize/): relaxed atomics on both sides
+    const int32_t o = __atomic_load_n(&ix->h_doc_ord[p], __ATOMIC_RELAXED);
     if (o < 0) continue;
     if (filt && ((int64_t)o >= n_words * 32 || !((allow_bits[o >> 5] >> (o & 31)) & 1u))) continue;
     ++pages;
@@ -917,7 +920,7 @@ int mv_index_remove_page(mv_index* ix, int64_t page) {
   std::lock_guard<std::mutex> lk(ix->w_mu);
   if (page < 0 || page >= ix->size.load()) { set_error("page out of range"); return MV_ERR_INVALID; }
   DeviceGuard g(ix->cfg.device);
-  ix->h_doc_ord[page] = -1;
+  __atomic_store_n(&ix->h_doc_ord[page], -1, __ATOMIC_RELAXED);  // queries read it under q_mu only (count_allowed_rows)
   ix->tombstones.store(true);  // before the device write: a scan that sees the tombstone also reads doc_ord
   MV_HIP(hipMemcpyAsync(ix->d_doc_ord + page, &ix->h_doc_ord[page], 4, hipMemcpyHostToDevice, ix->w_stream));
   MV_HIP(hipStreamSynchronize(ix->w_stream));
@@ -932,7 +935,7 @@ int mv_index_remove_doc(mv_index* ix, int32_t doc_ordinal, int64_t* out_n) {
   const int64_t size = ix->size.load();
   for (int64_t p = 0; p < size; ++p)
     if (ix->h_doc_ord[p] == doc_ordinal) {
-      ix->h_doc_ord[p] = -1;
+      __atomic_store_n(&ix->h_doc_ord[p], -1, __ATOMIC_RELAXED);
       if (lo < 0) lo = p;
       hi = p;
       ++n;
