@@ -37,12 +37,24 @@ from .payloads import DEFAULT_APP_ID, PayloadStore, is_storage_key, parse_metada
 logger = logging.getLogger(__name__)
 
 
+_HELPERS = None
+
+
+def _index_helpers():
+    """(index._to_host, index.allow_bitmap), imported once: an `import` statement inside a per-request function costs a
+    microsecond of import-system lookups every call (index.py pulls in ctypes bindings; keep its import lazy for CPU-only hosts)."""
+    global _HELPERS
+    if _HELPERS is None:
+        from .index import _to_host, allow_bitmap
+
+        _HELPERS = (_to_host, allow_bitmap)
+    return _HELPERS
+
+
 def _embedding_rows(e: Any) -> np.ndarray:
     """ndarray / torch.Tensor (any device) / list -> C-contiguous [n,128] fp32 or uint16(bf16)
     (multi_vector_store.py:334-337 and fast_multivector_store.py:515-518 accept the same inputs)."""
-    from .index import _to_host
-
-    a = _to_host(e)
+    a = e if isinstance(e, np.ndarray) else _index_helpers()[0](e)
     if a.dtype != np.uint16:
         a = np.ascontiguousarray(a, dtype=np.float32)
     if a.ndim == 1:
@@ -317,8 +329,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         """doc_ids falsy => no doc filter (multi_vector_store.py:754).  Stores with per-app namespaces ALWAYS restrict to
         the resolved app: FastMultiVectorStore queries self.ns(app_id), so app_id=None reads the default namespace only
         (fast_multivector_store.py:526).  Returns (bitmap or None, empty?)."""
-        from .index import allow_bitmap
-
+        allow_bitmap = _index_helpers()[1]
         # The bitmap of a (doc_ids, app) pair only changes when documents are added / compacted away (_ord_stamp): requests
         # repeat the same authorised document set, so it is built once per stamp, not once per request (deleted documents
         # keep their ordinal until compact(); their pages are tombstoned in the slab itself).

@@ -484,6 +484,7 @@ def test_remote_client_with_its_own_storage_keeps_payloads_off_the_wire():
         chunks = sc.make_chunks(rng, n_docs=2, chunks_per_doc=2)
         img = "data:image/png;base64," + base64.b64encode(b"\x89PNG\r\n\x1a\n" + b"x" * 5000).decode()
         chunks[1].content, chunks[1].metadata = img, {"is_image": True}
+        chunks[2].metadata = {"is_image": False}
         ok, ids, _m = sc.run(remote.store_embeddings(chunks, app_id="t"))
         assert ok and len(ids) == 4 and st.uploads == 4
         assert all(len(r[2]) < 100 and "/" in r[2] for r in owner._rows.values())  # the owner holds keys only
