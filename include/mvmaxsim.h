@@ -119,7 +119,10 @@ typedef enum {
                                  2 = the round-1 two-stage pipeline (<= 384 rows); 1 and 2 are kept as cross-checks.
                                  5 / 6 = 32x32x16 MFMA with the transposed roles (round 3): 5 = four row groups of <= 128 query
                                  rows, 6 = two row groups of <= 256 rows at ONE wave per SIMD (query fragments in AGPRs), the two
-                                 tiles of a ring chunk split over the other two waves */
+                                 tiles of a ring chunk split over the other two waves.
+                                 MV_MODE_FLOAT_FP8 batches (the batched block-scaled MFMA scan of the e4m3 slab): 7 = ONE e4m3
+                                 term per query row instead of the hi + lo split (half the matrix work; the coarse pass of a
+                                 two-tier search), 8 = query by query */
   MV_OPT_FDE_ENCODE_VARIANT = 8, /* FDE encode: 1 = f32-MFMA kernel (default), 0 = scalar kernel; same partitions bit for bit */
   MV_OPT_FILTER_COMPACT_PCT = 9, /* doc filter allowing < this % of the documents: compact the allowed pages first and scan
                                     only those (default 25; 0 = always mask inside the scan) */
@@ -233,6 +236,7 @@ MV_API int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_
  *              words back to back (allow_per_query = 1: every request keeps its own doc_ids / auth filter)
  *   out_*      n_queries x k entries (row b = results of query b), out_n[b] = results of query b
  * MV_MODE_FLOAT runs the batched MFMA kernel (up to 512 query rows per slab pass: B x Q flop/byte).
+ * MV_MODE_FLOAT_FP8 runs its e4m3 form (block-scaled MFMA, K = 128 per instruction): half the page bytes per pass.
  * MV_MODE_FDE_THEN_FLOAT / MV_MODE_FDE_ONLY run the batched FDE pipeline: one pass over the FDE slab per 32 queries
  * (the coarse stage as a bf16-MFMA GEMM, query FDEs as bf16 hi + lo: coarse scores within ~1e-5 of the single-query
  * scan), one batched selection, the exact rerank of every query's candidates, one read-back.  The remaining modes are

@@ -1528,6 +1528,82 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
   return MV_OK;
 }
 
+// mv_query_topk_batch, MV_MODE_FLOAT_FP8: groups of <= 512 query rows, ONE pass over the e4m3 slab per group
+// (maxsim_batch_fp8_kernel), the group's selections in one chain of launches, one read-back.
+static int fp8_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, int32_t k, const uint32_t* allow_bits,
+                           int64_t n_allow_words, int32_t allow_per_query, float* out_scores, int64_t* out_ids, int32_t* out_n, mv_query_stats* stats) {
+  std::lock_guard<std::mutex> lk(ix->q_mu);
+  DeviceGuard g(ix->cfg.device);
+  for (int32_t b = 0; b < n_queries; ++b) out_n[b] = 0;
+  mv_query_stats total{};
+  const int64_t n = ix->size.load(std::memory_order_acquire);
+  if (n == 0) { if (stats) *stats = total; return MV_OK; }
+  const size_t esz = q_dtype == MV_F32 ? 4 : 2;
+  const int rpq = ((n_q_rows + 15) / 16) * 16;
+  const int group = std::min(512 / rpq, 32);
+  int rc = mv_internal_ensure_batch_select_ws(ix);
+  if (rc) return rc;
+  if (!ix->d_bscores) {
+    hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->cfg.capacity_pages * 4);
+    if (e != hipSuccess) { ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->cfg.capacity_pages * 4); return MV_ERR_NOMEM; }
+  }
+  if (!ix->d_bqf32) MV_HIP(hipMalloc(&ix->d_bqf32, (size_t)kBatchQRows * kDim * 4));
+  if (!ix->d_bq8hi) MV_HIP(hipMalloc(&ix->d_bq8hi, (size_t)kBatchQRows * kDim));
+  if (!ix->d_bq8lo) MV_HIP(hipMalloc(&ix->d_bq8lo, (size_t)kBatchQRows * kDim));
+  if (!ix->d_bq8fac) MV_HIP(hipMalloc(&ix->d_bq8fac, (size_t)kBatchQRows * 4));
+  const bool per_query = allow_bits && allow_per_query;
+  const uint32_t* d_allow = nullptr;
+  rc = upload_allow(ix, allow_bits, per_query ? n_allow_words * (int64_t)n_queries : n_allow_words, &d_allow);
+  if (rc) return rc;
+  const bool need_meta = ix->tombstones.load() || d_allow != nullptr;
+  int64_t pages = 0;
+  const int64_t rows = stats ? count_allowed_rows(ix, n, per_query ? nullptr : allow_bits, n_allow_words, &pages) : 0;
+  for (int32_t b0 = 0; b0 < n_queries; b0 += group) {
+    const int nb = std::min(group, n_queries - b0);
+    // zero rows behind the last query of the group: the kernel's row tiles run to the next multiple of 64 rows
+    MV_HIP(hipMemsetAsync(ix->d_bqf32, 0, (size_t)512 * kDim * 4, ix->stream));
+    rc = mv_internal_batch_upload_queries(ix, (const char*)q + (size_t)b0 * n_q_rows * kDim * esz, q_dtype, nb, n_q_rows, true, false, false);
+    if (rc) return rc;
+    rc = launch_fp8_query_prep(ix->d_bqf32, 512, ix->d_bq8hi, ix->d_bq8lo, ix->d_bq8fac, ix->stream);
+    if (rc) return rc;
+    MV_HIP(hipEventRecord(ix->ev[0], ix->stream));
+    Fp8BatchArgs a{};
+    a.slab = ix->slab8; a.inv_scale = ix->inv_scale8; a.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr; a.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
+    a.allow = per_query ? d_allow + (size_t)b0 * n_allow_words : d_allow; a.n_allow_bits = n_allow_words * 32;
+    a.allow_stride_bits = per_query ? n_allow_words * 32 : 0;
+    a.qhi = ix->d_bq8hi; a.qlo = ix->d_bq8lo; a.qfac = ix->d_bq8fac; a.scores = ix->d_bscores; a.n = n; a.score_stride = ix->cfg.capacity_pages;
+    a.stride = ix->cfg.stride_rows; a.n_queries = nb; a.rows_per_query = rpq; a.single_term = ix->batch_variant == 7 ? 1 : 0;
+    rc = launch_maxsim_batch_fp8(a, ix->stream);
+    if (rc) return rc;
+    MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
+    rc = launch_topk_batch(ix->d_bscores, ix->cfg.capacity_pages, n, k, nullptr, 0, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bout_s,
+                           ix->d_bout_id, k, nb, ix->stream);
+    if (rc) return rc;
+    MV_HIP(hipEventRecord(ix->ev[2], ix->stream));
+    MV_HIP(hipMemcpyAsync(ix->h_bout_s, ix->d_bout_s, (size_t)nb * k * 4, hipMemcpyDeviceToHost, ix->stream));
+    MV_HIP(hipMemcpyAsync(ix->h_bout_id, ix->d_bout_id, (size_t)nb * k * 8, hipMemcpyDeviceToHost, ix->stream));
+    MV_HIP(hipStreamSynchronize(ix->stream));
+    for (int b = 0; b < nb; ++b) {
+      const float* hs = ix->h_bout_s + (size_t)b * k;
+      const int64_t* hi = ix->h_bout_id + (size_t)b * k;
+      int32_t m = 0;
+      while (m < k && hi[m] >= 0) ++m;
+      memcpy(out_scores + (size_t)(b0 + b) * k, hs, (size_t)m * 4);
+      memcpy(out_ids + (size_t)(b0 + b) * k, hi, (size_t)m * 8);
+      out_n[b0 + b] = m;
+    }
+    if (stats) {
+      float ms_scan = 0, ms_sel = 0;
+      MV_HIP(hipEventElapsedTime(&ms_scan, ix->ev[0], ix->ev[1]));
+      MV_HIP(hipEventElapsedTime(&ms_sel, ix->ev[1], ix->ev[2]));
+      total.score_kernel_ms += ms_scan; total.topk_ms += ms_sel; total.total_device_ms += ms_scan + ms_sel;
+      total.score_launches += 1; total.pages_scored += pages * nb; total.bytes_scanned += rows * (int64_t)kDim;
+    }
+  }
+  if (stats) *stats = total;
+  return MV_OK;
+}
+
 int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, int32_t k, int mode,
                         const uint32_t* allow_bits, int64_t n_allow_words, int32_t allow_per_query, float* out_scores,
                         int64_t* out_ids, int32_t* out_n, mv_query_stats* stats) {
@@ -1542,6 +1618,9 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
       (mode == MV_MODE_FDE_ONLY || (ix->cfg.flags & MV_WITH_FLOAT) || ((ix->cfg.flags & MV_WITH_FP8) && rpq <= 64)) &&
       mv::fde_scan_batch_supported(ix->fde_t.out_dim) && ix->fde_t.cfg.projection_dimension <= 16)
     return fde_batch_query(ix, q, q_dtype, n_queries, n_q_rows, k, mode, allow_bits, n_allow_words, allow_per_query, out_scores, out_ids, out_n, stats);
+  // e4m3 slab: the batched block-scaled MFMA scan (<= 512 query rows per slab pass); MV_OPT_BATCH_VARIANT 8 = query by query
+  if (mode == MV_MODE_FLOAT_FP8 && n_queries > 1 && rpq <= 512 && k >= 1 && k <= kTopkMaxDeviceK && (ix->cfg.flags & MV_WITH_FP8) && ix->batch_variant != 8)
+    return fp8_batch_query(ix, q, q_dtype, n_queries, n_q_rows, k, allow_bits, n_allow_words, allow_per_query, out_scores, out_ids, out_n, stats);
   // anything but the exact float scan (and queries longer than one 512-row group) runs query by query
   if (mode != MV_MODE_FLOAT || rpq > 512 || k > kTopkMaxDeviceK || k == 0) {
     for (int32_t b = 0; b < n_queries; ++b) {

@@ -217,6 +217,29 @@ struct Fp8ScanArgs {
                              // (i / items_per_query) * padded(n_q) rows into qhi / qlo / qfac; needs cand, n_q <= 64
 };
 int launch_maxsim_fp8(const Fp8ScanArgs& a, hipStream_t s);
+// A batch of queries (n_queries * rows_per_query <= 512 rows, each query padded to rows_per_query with zero rows) against
+// every page of the e4m3 slab in one pass: scores[q][page] at scores + q * score_stride.  qhi / qlo / qfac hold the
+// group's rows back to back (launch_fp8_query_prep over all of them), zero rows up to 512.
+struct Fp8BatchArgs {
+  const uint8_t* slab;
+  const float* inv_scale;
+  const int32_t* n_rows;
+  const int32_t* doc_ord;
+  const uint32_t* allow;
+  int64_t n_allow_bits;
+  int64_t allow_stride_bits;
+  const uint8_t* qhi;
+  const uint8_t* qlo;
+  const float* qfac;
+  float* scores;
+  int64_t n;
+  int64_t score_stride;
+  int32_t stride;
+  int32_t n_queries;
+  int32_t rows_per_query;
+  int32_t single_term;  // 1: hi term only (query rounded to e4m3: half the matrix work; coarse pass of a two-tier search)
+};
+int launch_maxsim_batch_fp8(const Fp8BatchArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- doc_ids filter compaction (mv_filter.hip)
 size_t filter_ws_bytes(int64_t capacity);

@@ -411,6 +411,235 @@ int launch_f8_mt(const F8Args& k0, hipStream_t s) {
   return MV_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// A BATCH of queries against the e4m3 slab in one pass (round 3): the row-split workgroup of mv_batch.hip on the
+// block-scaled matrix path.  The M = B x Q query rows are split over the four waves (MTW 16-row tiles per wave, their
+// two-term e4m3 fragments resident in VGPRs), page tiles of 16 patches x 128 B are staged ONCE per workgroup in a ring of
+// 16 KiB chunks (128 patch rows; wave w DMAs rows [32w, 32w+32) of every chunk with the swizzled image of the single-query
+// scan) and read by all four waves.  MFMA roles transposed as in maxsim_batch_kernel: A = page tile, B = query tile,
+// D[patch 4(l>>4)+i][token l&15] -- one running maximum per query tile, fed by v_max3_f32.  K = 128 is ONE
+// v_mfma_scale_f32_16x16x128_f8f6f4 per (page tile, query tile) and term: with LO the query keeps its hi + lo*2^-4 split
+// (the scores of the single-query scan); without it (MV_OPT_BATCH_VARIANT 7) one term only -- half the matrix work, the
+// query rounded to e4m3 like the pages: the coarse pass of a two-tier search.
+// Half the page bytes of the bf16 batch and, per term, half its matrix cycles: the HBM-bound small batches gain ~2x.
+struct F8BatchArgs {
+  const uint8_t* slab;
+  const float* inv_scale;
+  const int32_t* n_rows;
+  const int32_t* doc_ord;
+  const uint32_t* allow;
+  int64_t n_allow_bits;
+  int64_t allow_stride_bits;  // 0: one bitmap for all queries
+  const uint8_t* qhi;         // [4 * MTW * 16][128] e4m3, zero rows behind the last query
+  const uint8_t* qlo;
+  const float* qfac;          // [4 * MTW * 16]
+  float* scores;              // [n_queries][score_stride]
+  int64_t n;
+  int64_t score_stride;
+  int32_t stride;
+  int32_t n_queries;
+  int32_t rows_per_query;     // multiple of 16
+};
+
+constexpr int kF8ChunkRows = 128;
+constexpr int kF8ChunkBytes = kF8ChunkRows * kF8RowBytes;  // 16 KiB
+constexpr int kF8TileBytes = 16 * kF8RowBytes;             // 2 KiB
+
+template <int CTRL>
+__device__ __forceinline__ float f8b_dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+template <int MTW, int S, bool LO>
+__global__ __launch_bounds__(256, 2) void maxsim_batch_fp8_kernel(F8BatchArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[S * kF8ChunkBytes + 64 * MTW * 4 + 4 * MTW * 4];
+  float* red = reinterpret_cast<float*>(lds + S * kF8ChunkBytes);  // [64 * MTW] factor-scaled token maxima of the current page
+  float* part = red + 64 * MTW;                                    // [4 * MTW] sums of 16 rows
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+
+  i32x8 qh[MTW], ql[LO ? MTW : 1];
+  float fq[MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    const size_t row = (size_t)(wave * MTW + m) * 16 + r;
+    const i32x4 h0 = *reinterpret_cast<const i32x4*>(a.qhi + row * kF8RowBytes + g * 16);
+    const i32x4 h1 = *reinterpret_cast<const i32x4*>(a.qhi + row * kF8RowBytes + 64 + g * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { qh[m][i] = h0[i]; qh[m][4 + i] = h1[i]; }
+    if (LO) {
+      const i32x4 l0 = *reinterpret_cast<const i32x4*>(a.qlo + row * kF8RowBytes + g * 16);
+      const i32x4 l1 = *reinterpret_cast<const i32x4*>(a.qlo + row * kF8RowBytes + 64 + g * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { ql[m][i] = l0[i]; ql[m][4 + i] = l1[i]; }
+    }
+    fq[m] = a.qfac[row];
+  }
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      asm volatile("" : "+v"(qh[m][i]));
+      if (LO) asm volatile("" : "+v"(ql[m][i]));
+    }
+    asm volatile("" : "+v"(fq[m]));
+  }
+
+  int src_off[4];  // DMA instruction i covers rows 8i..8i+7 of the wave's 32-row piece (as maxsim_fp8_kernel)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int w = i * 8 + (lane >> 3);
+    src_off[i] = w * kF8RowBytes + ((((lane & 7) ^ (w & 7))) << 4) - i * 1024;
+  }
+  int rd_off[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) rd_off[h] = r * kF8RowBytes + (((g + 4 * h) ^ (r & 7)) << 4);
+
+  for (int64_t item = blockIdx.x; item < a.n; item += gridDim.x) {
+    const int64_t page = item;
+    bool masked = false;
+    if (a.doc_ord) {
+      const int32_t o = a.doc_ord[page];
+      masked = o < 0;
+      if (!masked && a.allow && !a.allow_stride_bits) masked = (int64_t)o >= a.n_allow_bits || ((a.allow[o >> 5] >> (o & 31)) & 1u) == 0u;
+    }
+    if (masked) {  // block-uniform
+      if ((int)threadIdx.x < a.n_queries) a.scores[(size_t)threadIdx.x * a.score_stride + item] = -INFINITY;
+      continue;
+    }
+    const int nr = a.n_rows ? a.n_rows[page] : a.stride;
+    if (nr <= 0) {
+      if ((int)threadIdx.x < a.n_queries) a.scores[(size_t)threadIdx.x * a.score_stride + item] = 0.0f;
+      continue;
+    }
+    const int ntiles = (nr + 15) >> 4;
+    const int nchunks = (nr + kF8ChunkRows - 1) / kF8ChunkRows;
+    const char* pbase = reinterpret_cast<const char*>(a.slab) + (size_t)page * (size_t)a.stride * kF8RowBytes;
+
+    auto issue = [&](int c) {  // wave w moves rows [32w, 32w+32) of chunk c (always issued: the slab is padded)
+      const char* tp = pbase + (size_t)(c * 4 + wave) * 4096;
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
+      const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
+      const uint64_t tpu = ((uint64_t)hi << 32) | lo;
+      const uint32_t slot = __builtin_amdgcn_readfirstlane(
+          (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + (c % S) * kF8ChunkBytes + wave * 4096));
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %5\n\t"
+          "s_nop 4\n\t"
+          "global_load_lds_dwordx4 %1, %6 nt\n\t"
+          "global_load_lds_dwordx4 %2, %6 offset:1024 nt\n\t"
+          "global_load_lds_dwordx4 %3, %6 offset:2048 nt\n\t"
+          "global_load_lds_dwordx4 %4, %6 offset:3072 nt\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src_off[0]), "v"(src_off[1]), "v"(src_off[2]), "v"(src_off[3]), "s"(slot), "s"(tpu)
+          : "memory");
+    };
+    auto frags = [&](i32x8& b, const char* tile) {
+      const i32x4 b0 = *reinterpret_cast<const i32x4*>(tile + rd_off[0]);
+      const i32x4 b1 = *reinterpret_cast<const i32x4*>(tile + rd_off[1]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { b[i] = b0[i]; b[4 + i] = b1[i]; }
+    };
+
+#pragma unroll
+    for (int c = 0; c < S - 1; ++c)
+      if (c < nchunks) issue(c);
+
+    float mx[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) mx[m] = -INFINITY;
+
+    for (int c = 0; c < nchunks; ++c) {
+      const int ahead = min(S - 2, nchunks - 1 - c);
+      if (ahead >= 2) f8_wait_vmcnt<8>();
+      else if (ahead == 1) f8_wait_vmcnt<4>();
+      else f8_wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // chunk c visible to all four waves; everyone is done reading chunk c-1
+      if (c + S - 1 < nchunks) issue(c + S - 1);
+      const char* chunk = lds + (c % S) * kF8ChunkBytes;
+      i32x8 b[2];
+      frags(b[0], chunk);
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+        const int t = c * 8 + tt;
+        if (t < ntiles) {  // block-uniform
+          if (tt + 1 < 8) frags(b[(tt + 1) & 1], chunk + (tt + 1) * kF8TileBytes);  // next tile's fragments behind this tile's MFMAs
+          f32x4 acc[MTW];
+#pragma unroll
+          for (int m = 0; m < MTW; ++m)
+            acc[m] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b[tt & 1], qh[m], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          if (LO) {
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+              acc[m] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b[tt & 1], ql[m], acc[m], 0, 0, 0, 0x7f7f7f7f, 0, 0x7b7b7b7b /* 2^-4 */);
+          }
+          if ((t + 1) * 16 > nr) {  // partial last tile: mask the patches (rows of D) past n_rows
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const bool row_valid = t * 16 + g * 4 + i < nr;
+#pragma unroll
+              for (int m = 0; m < MTW; ++m)
+                if (!row_valid) acc[m][i] = -INFINITY;
+            }
+          }
+#pragma unroll
+          for (int m = 0; m < MTW; ++m) {
+            mx[m] = fmaxf(fmaxf(mx[m], acc[m][0]), acc[m][1]);  // v_max3_f32
+            mx[m] = fmaxf(fmaxf(mx[m], acc[m][2]), acc[m][3]);
+          }
+        }
+      }
+    }
+
+    // token maxima (the four lane groups hold disjoint patches of the same token), scaled by the token's 2^-s
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+      float v = mx[m];
+      v = fmaxf(v, __shfl_xor(v, 16));
+      v = fmaxf(v, __shfl_xor(v, 32));
+      if (g == 0) red[(wave * MTW + m) * 16 + r] = (v == -INFINITY ? 0.f : v) * fq[m];
+    }
+    __syncthreads();
+    const int rows_total = a.n_queries * a.rows_per_query;
+    for (int t = threadIdx.x; t < rows_total; t += 256) {  // whole 16-row groups (rows_total and 256 are multiples of 16)
+      float x = red[t];
+      x = f8b_dpp_add<0x128>(x);
+      x = f8b_dpp_add<0x124>(x);
+      x = f8b_dpp_add<0x122>(x);
+      x = f8b_dpp_add<0x121>(x);
+      if ((t & 15) == 0) part[t >> 4] = x;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < a.n_queries) {
+      const int g16 = a.rows_per_query >> 4;
+      const float* pp = part + (size_t)threadIdx.x * g16;
+      float sum = 0.f;
+      for (int i = 0; i < g16; ++i) sum += pp[i];
+      sum *= a.inv_scale[page];
+      if (a.allow && a.allow_stride_bits) {  // this query's own doc_ids filter
+        const int32_t o = a.doc_ord[page];
+        const uint32_t* ab = a.allow + (size_t)threadIdx.x * (size_t)(a.allow_stride_bits >> 5);
+        if ((int64_t)o >= a.n_allow_bits || ((ab[o >> 5] >> (o & 31)) & 1u) == 0u) sum = -INFINITY;
+      }
+      a.scores[(size_t)threadIdx.x * a.score_stride + item] = sum;
+    }
+    // the next page's first barrier orders these reads of red[] / part[] before their rewrite
+  }
+}
+
+template <int MTW>
+int launch_f8_batch_mtw(const F8BatchArgs& k, int grid, bool lo, hipStream_t s) {
+  if (lo) hipLaunchKernelGGL((maxsim_batch_fp8_kernel<MTW, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, k);
+  else hipLaunchKernelGGL((maxsim_batch_fp8_kernel<MTW, 4, false>), dim3((unsigned)grid), dim3(256), 0, s, k);
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
 }  // namespace
 
 int launch_quantize_pages_fp8(const uint16_t* d_src_pages, const int32_t* d_n_rows, int32_t stride, int64_t n_pages,
@@ -451,6 +680,33 @@ int launch_maxsim_fp8(const Fp8ScanArgs& a, hipStream_t s) {
     if (rc) return rc;
   }
   return MV_OK;
+}
+
+int launch_maxsim_batch_fp8(const Fp8BatchArgs& a, hipStream_t s) {
+  if (a.n <= 0 || a.n_queries <= 0) return MV_OK;
+  if (a.rows_per_query < 16 || a.rows_per_query % 16) { set_error("fp8 batch scan: rows_per_query must be a positive multiple of 16"); return MV_ERR_INVALID; }
+  const int rows = a.n_queries * a.rows_per_query;
+  if (rows > 512 || a.n_queries > 256) { set_error("fp8 batch scan: %d query rows exceed the 512-row group", rows); return MV_ERR_INVALID; }
+  F8BatchArgs k{a.slab, a.inv_scale, a.n_rows, a.doc_ord, a.allow, a.n_allow_bits, a.allow_stride_bits, a.qhi, a.qlo, a.qfac, a.scores, a.n,
+                a.score_stride, a.stride, a.n_queries, a.rows_per_query};
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+    else ncu = 256;
+  }
+  const int grid = (int)std::min<int64_t>(a.n, (int64_t)ncu * 2);
+  const bool lo = a.single_term == 0;
+  switch ((rows + 63) / 64) {  // query tiles per wave
+    case 1: return launch_f8_batch_mtw<1>(k, grid, lo, s);
+    case 2: return launch_f8_batch_mtw<2>(k, grid, lo, s);
+    case 3: return launch_f8_batch_mtw<3>(k, grid, lo, s);
+    case 4: return launch_f8_batch_mtw<4>(k, grid, lo, s);
+    case 5: return launch_f8_batch_mtw<5>(k, grid, lo, s);
+    case 6: return launch_f8_batch_mtw<6>(k, grid, lo, s);
+    case 7: return launch_f8_batch_mtw<7>(k, grid, lo, s);
+    default: return launch_f8_batch_mtw<8>(k, grid, lo, s);
+  }
 }
 
 }  // namespace mv

@@ -1097,6 +1097,55 @@ def test_errors_are_loud(mv):
     ix.close()
 
 
+@pytest.mark.parametrize("stride,nrows", [(1024, 1024), (1024, 1000), (208, 200), (64, 50), (16, 7)])
+def test_batched_fp8_scan_equals_single_query_scan_and_oracle(mv, stride, nrows):
+    """mv_query_topk_batch, MV_MODE_FLOAT_FP8: one pass over the e4m3 slab for a group of queries (maxsim_batch_fp8_kernel,
+    block-scaled MFMA with the page tile as the A operand) returns the single-query fp8 scan's answers, which are the
+    oracle's on the device's own codes; per-request doc filters, tombstones, ragged pages, ragged query lengths.  Variant 7
+    (one e4m3 term per query row) stays within e4m3 rounding of the two-term scores; variant 8 is the query-by-query form."""
+    from morphik_core_amd import _lib
+    from morphik_core_amd.index import allow_bitmap
+
+    n = 700 if stride < 1024 else 300
+    ix = _idx(mv, capacity_pages=n, stride_rows=stride, with_float=False, with_fp8=True)
+    ix.fill_synthetic(1234, 0, n, n_rows=nrows, pages_per_doc=3)
+    ix.remove_doc(5)
+    allow = allow_bitmap([d for d in range(n // 3 + 1) if d % 4 != 2])
+    codes, inv = ix.read_fp8(0, n)
+    for lens in ([32], [32, 32, 32], [32] * 16, [32] * 20, [20, 32, 1, 17], [64] * 8, [16] * 32, [48] * 10):
+        qs = [orc.synth_rows(4321, 10 + j, 0, L) for j, L in enumerate(lens)]
+        for al in (None, allow):
+            got = ix.query_batch(qs, 7, mode="float_fp8", allow=al)
+            assert len(got) == len(qs)
+            for q, (s, i) in zip(qs, got):
+                ws, wi = ix.query(q, 7, mode="float_fp8", allow=al)
+                assert i.tolist() == wi.tolist()
+                np.testing.assert_allclose(s, ws, rtol=1e-5)
+        got = ix.query_batch(qs, 5, mode="float_fp8")
+        for q, (s, i) in zip(qs[:3], got[:3]):
+            want = orc.maxsim_fp8_np(orc.bf16_to_f32(q), codes, inv, n_rows=[nrows] * n)
+            want[15:18] = -np.inf  # doc 5 was tombstoned (pages 15..17)
+            ws, wi = orc.topk(want, 5)
+            _assert_topk_matches(s, i, ws, wi)
+    qs = [orc.synth_rows(4321, 40 + j, 0, 32) for j in range(6)]
+    n_docs = n // 3 + 1
+    allows = [None, allow_bitmap([1, 2, 3]), allow, allow_bitmap(range(0, n_docs, 2)), None, allow_bitmap([n_docs - 1])]
+    got = ix.query_batch(qs, 6, mode="float_fp8", allows=allows, n_docs=n_docs)
+    for q, al, (s, i) in zip(qs, allows, got):
+        ws, wi = ix.query(q, 6, mode="float_fp8", allow=al)
+        assert i.tolist() == wi.tolist()
+        np.testing.assert_allclose(s, ws, rtol=1e-5)
+    two = ix.query_batch(qs, 6, mode="float_fp8")
+    ix.set_option(_lib.MV_OPT_BATCH_VARIANT, 8)
+    for (s, i), (ws, wi) in zip(ix.query_batch(qs, 6, mode="float_fp8"), two):
+        assert i.tolist() == wi.tolist()
+    ix.set_option(_lib.MV_OPT_BATCH_VARIANT, 7)  # single e4m3 term on the query side
+    one = ix.query_batch(qs, 6, mode="float_fp8")
+    for (s, i), (ws, wi) in zip(one, two):
+        np.testing.assert_allclose(np.sort(s)[::-1], np.sort(ws)[::-1], rtol=3e-2)
+    ix.close()
+
+
 # ------------------------------------------------------------------ fp8 scan -> exact bf16 re-score from the exact tier
 @pytest.mark.parametrize("tier", ["host", "hbm", "both"])
 def test_fp8_then_float_rescoring_from_the_exact_tier(mv, tier, tmp_path):

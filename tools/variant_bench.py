@@ -76,6 +76,25 @@ def main():
         res["batch"][f"v{bv}_B{B}"] = {"kernel_ms_med": ms, "GBps": nbytes / ms / 1e6, "TFLOPs": flops / ms / 1e9, "query_pages_per_s": B * a.pages / ms * 1e3}
         print(f"batch v{bv} B={B}: {ms:.3f} ms  {nbytes/ms/1e6:.0f} GB/s  {flops/ms/1e9:.0f} TFLOP/s  {B*a.pages/ms*1e3/1e6:.1f} M query-pages/s", flush=True)
     ix.close()
+    if not a.no_batch and not a.batch_variants:
+        # the e4m3 form of the batched scan: half the page bytes; two-term (parity) and single-term (coarse pass) queries
+        ix = MvIndex(capacity_pages=a.pages, stride_rows=a.patches, with_float=False, with_fp8=True)
+        ix.fill_synthetic(1234, 0, a.pages)
+        res["batch_fp8"] = {}
+        for bv, B in [(0, 1), (0, 2), (0, 4), (7, 4), (0, 8), (7, 8), (0, 16), (7, 16)]:
+            ix.set_option(_lib.MV_OPT_BATCH_VARIANT, bv)
+            qs = [synth_rows(4321, j, 32) for j in range(B)]
+            ts = []
+            for r in range(a.rounds + 1):
+                out, st = ix.query_batch(qs, 10, mode="float_fp8", want_stats=True)
+                if r:
+                    ts.append(st.score_kernel_ms)
+            ms = float(np.median(ts))
+            flops = 2.0 * B * 32 * a.patches * 128 * a.pages
+            res["batch_fp8"][f"v{bv}_B{B}"] = {"kernel_ms_med": ms, "GBps": a.pages * a.patches * 128 / ms / 1e6, "useful_TFLOPs": flops / ms / 1e9,
+                                               "issued_TFLOPs": flops * (1 if bv == 7 else 2) / ms / 1e9, "query_pages_per_s": B * a.pages / ms * 1e3}
+            print(f"batch fp8 v{bv} B={B}: {ms:.3f} ms  {a.pages*a.patches*128/ms/1e6:.0f} GB/s  {flops/ms/1e9:.0f} useful TFLOP/s  {B*a.pages/ms*1e3/1e6:.1f} M query-pages/s", flush=True)
+        ix.close()
     if a.aux:
         n = min(a.pages, 200_000)
         ix = MvIndex(capacity_pages=n, stride_rows=a.patches, with_float=True, with_binary=True, with_fde=True, with_fp8=True)
