@@ -138,7 +138,8 @@ typedef enum {
                                     candidates reranked in one launch, one read-back; 1 = query by query; 2 = as 0 with the query
                                     FDE rounded to bf16 (one MFMA per fragment: -13 % pass time, coarse scores within ~2e-3);
                                     3 = as 0 with one page tile per query fragment (the first form of the coarse kernel; the
-                                    default walks a workgroup's tiles in pairs: same scores, half the fragment traffic) */
+                                    default walks a workgroup's tiles in pairs: same scores, half the fragment traffic);
+                                    4 = 32-page tiles, two workgroups per CU, four tiles per fragment set (same scores) */
 } mv_option;
 
 /* Bumped whenever a signature, a struct layout or an enum value of this header changes incompatibly.  A binding compares

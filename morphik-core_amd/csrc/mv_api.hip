@@ -1461,6 +1461,7 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
     sa.q = ix->d_bqfde; sa.image = ix->d_bqimage; sa.scores = ix->d_bscores; sa.score_stride = cap; sa.n = n; sa.out_dim = out_dim; sa.n_queries = nb;
     sa.hi_only = ix->fde_batch_variant == 2;
     sa.single_tile = ix->fde_batch_variant == 3;
+    sa.half_tiles = ix->fde_batch_variant == 4;
     rc = launch_fde_scan_batch(sa, ix->stream);
     if (rc) return rc;
     launches += 3;

@@ -279,6 +279,7 @@ int mv_internal_two_stage_batch_coarse(mv_index* ix, const void* q, int q_dtype,
   sa.q = ix->d_bqfde; sa.image = ix->d_bqimage; sa.scores = ix->d_bscores; sa.score_stride = cap; sa.n = n; sa.out_dim = ix->fde_t.out_dim; sa.n_queries = nb;
   sa.hi_only = ix->fde_batch_variant == 2;
   sa.single_tile = ix->fde_batch_variant == 3;
+  sa.half_tiles = ix->fde_batch_variant == 4;
   rc = launch_fde_scan_batch(sa, ix->stream);
   if (rc) return rc;
   // local coarse top-n of every request, GLOBAL ids, padded with (-inf, -1) when the shard holds fewer pages

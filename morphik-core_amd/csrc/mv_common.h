@@ -185,6 +185,7 @@ struct FdeScanBatchArgs {
   int32_t n_queries;
   int32_t hi_only;            // 1: bf16 query FDE (one MFMA per fragment, half the query traffic; coarse scores within ~2e-3)
   int32_t single_tile;        // 1: one page tile per query fragment (the first form; default: tiles in pairs)
+  int32_t half_tiles;         // 1: 32-page tiles, two workgroups per CU, four tiles per query fragment set (round 3)
 };
 bool fde_scan_batch_supported(int64_t out_dim);
 size_t fde_scan_batch_image_bytes(int64_t out_dim);

@@ -1187,6 +1187,256 @@ __global__ __launch_bounds__(256) void fde_scan_batch2_kernel(ScanBatchArgs a) {
   fb_phase<NQT, LO, 1>(a, lds, red, lane, wave, (n_my / 2) * 2, n_my & 1, src_off, rd_off);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Round 3: the same phase with the page-tile height and the depth of the fragment register ring as parameters.
+// PT = 16-page sub-tiles per page tile (4 = the 64-page tile above; 2 = 32 pages: a 16 KiB ring slot, so TWO workgroups fit a
+// CU's LDS and a late slot stalls half a CU instead of all of it); NSETS = fragment register sets (a K chunk's fragments
+// serve T slots, so T = 4 needs only the current and the next set: 64 instead of 128 VGPRs -- what lets two workgroups'
+// waves share a SIMD's register file).  Arithmetic, K order and the order of the four waves' partial sums are those of
+// fb_phase: identical scores.
+// n_groups groups of T tiles: tiles i0 + grp*T + j of this workgroup's list b, b + G, b + 2G, ...
+template <int NQT, bool LO, int T, int PT, int NSETS>
+__device__ __forceinline__ void fb_phase_g(const ScanBatchArgs& a, char* lds, float* red, const int lane, const int wave, const int i0,
+                                         const int n_groups, const uint32_t (&src_off)[2 * PT], const uint32_t (&rd_off)[2]) {
+  using bf16x8 = __attribute__((ext_vector_type(8))) short;
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  constexpr int NF = 4 * NQT;              // query fragments per K chunk and wave: (e, qt, hi|lo)
+  constexpr int QOPS = LO ? NF : NF / 2;   // fragment loads per K chunk and wave
+  constexpr int PAGES = 16 * PT;           // pages per tile
+  constexpr int SLOTB = PAGES * 512;       // ring slot: PAGES pages x 256 dims
+  constexpr int NDMA = 2 * PT;             // DMA instructions per slot and wave (2 pages x 512 B each)
+  constexpr int REDS = PAGES + 4;          // floats per (wave, query) row of the tile-end reduction
+  static_assert(PT == 2 || PT == 4, "page tile of 32 or 64 pages");
+  static_assert(NSETS >= 2 && (4 % NSETS == 0) && (NSETS >= 4 / T + (T == 4 ? 1 : 0) || T == 1), "fragment ring too shallow for T");
+  const int p = lane & 15, g = lane >> 4;
+  const int G = gridDim.x, b = blockIdx.x;
+  const int KC = a.out_dim >> 8;
+  const int total = n_groups * KC * T;     // ring slots of this phase; a multiple of 4 * T
+  if (total == 0) return;
+  const uint32_t row_bytes = (uint32_t)a.out_dim * 2u;
+  const uint32_t q_off = (uint32_t)lane * 16u;
+
+  bf16x8 qf[NSETS][NF];  // [K chunk % NSETS][(e*NQT + qt)*2 + (0 = hi, 1 = lo)]
+#pragma unroll
+  for (int u = 0; u < NSETS; ++u)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) qf[u][j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  f32x4 acc[T][PT][NQT];
+#pragma unroll
+  for (int j = 0; j < T; ++j)
+#pragma unroll
+    for (int t = 0; t < PT; ++t)
+#pragma unroll
+      for (int qt = 0; qt < NQT; ++qt) acc[j][t][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int i_grp = 0, i_kc = 0, i_j = 0;  // issue-side position: (group, K chunk, tile of the group)
+  auto issue_dma = [&](int slot_idx) {
+    const int64_t tile = (int64_t)b + (int64_t)(i0 + i_grp * T + i_j) * G;
+    const int64_t page0 = tile * PAGES;
+    const char* tp = a.fde + (size_t)page0 * row_bytes + (size_t)i_kc * 512 - 4096;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
+    const uint64_t tpu = ((uint64_t)hi << 32) | lo;
+    const uint32_t slot = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + slot_idx * SLOTB + wave * (4 * PT * 512)));
+    uint32_t so[NDMA];
+    if (page0 + PAGES > a.n) {  // last tile: rows past the corpus re-read its last page (their sums are never written)
+      const uint32_t last = (uint32_t)(a.n - 1 - page0);
+#pragma unroll
+      for (int i = 0; i < NDMA; ++i) {
+        const uint32_t pl = (uint32_t)(wave * (4 * PT) + 2 * i + (lane >> 5));
+        so[i] = min(pl, last) * row_bytes + ((((uint32_t)lane & 31u) ^ (pl & 15u)) << 4) + 4096u - (uint32_t)(i & 3) * 1024u;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NDMA; ++i) so[i] = src_off[i];
+    }
+    uint32_t keep;
+    if constexpr (PT == 4) {
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %9\n\t"
+          "s_nop 4\n\t"
+          "global_load_lds_dwordx4 %1, %11 nt\n\t"
+          "global_load_lds_dwordx4 %2, %11 offset:1024 nt\n\t"
+          "global_load_lds_dwordx4 %3, %11 offset:2048 nt\n\t"
+          "global_load_lds_dwordx4 %4, %11 offset:3072 nt\n\t"
+          "s_mov_b32 m0, %10\n\t"
+          "s_nop 4\n\t"
+          "global_load_lds_dwordx4 %5, %11 nt\n\t"
+          "global_load_lds_dwordx4 %6, %11 offset:1024 nt\n\t"
+          "global_load_lds_dwordx4 %7, %11 offset:2048 nt\n\t"
+          "global_load_lds_dwordx4 %8, %11 offset:3072 nt\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(so[0]), "v"(so[1]), "v"(so[2]), "v"(so[3]), "v"(so[NDMA > 4 ? 4 : 0]), "v"(so[NDMA > 4 ? 5 : 0]), "v"(so[NDMA > 4 ? 6 : 0]),
+            "v"(so[NDMA > 4 ? 7 : 0]), "s"(slot), "s"(slot + 4096u), "s"(tpu)
+          : "memory");
+    } else {
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %5\n\t"
+          "s_nop 4\n\t"
+          "global_load_lds_dwordx4 %1, %6 nt\n\t"
+          "global_load_lds_dwordx4 %2, %6 offset:1024 nt\n\t"
+          "global_load_lds_dwordx4 %3, %6 offset:2048 nt\n\t"
+          "global_load_lds_dwordx4 %4, %6 offset:3072 nt\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(so[0]), "v"(so[1]), "v"(so[2]), "v"(so[3]), "s"(slot), "s"(tpu)
+          : "memory");
+    }
+  };
+  auto issue_q = [&](bf16x8 (&qs)[NF]) {  // the fragments of K chunk i_kc
+#pragma unroll
+    for (int h = 0; h < NQT; ++h) {
+      const char* qp = a.qfrag + (size_t)(i_kc * 4 + wave) * (NF * 1024) + h * 4096;
+      const uint32_t qlo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)qp);
+      const uint32_t qhi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)qp >> 32));
+      const uint64_t qpu = ((uint64_t)qhi << 32) | qlo;
+      if (LO)
+        asm volatile(
+            "s_nop 4\n\t"
+            "global_load_dwordx4 %0, %4, %5\n\t"
+            "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+            "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
+            "global_load_dwordx4 %3, %4, %5 offset:3072"
+            : "+v"(qs[4 * h + 0]), "+v"(qs[4 * h + 1]), "+v"(qs[4 * h + 2]), "+v"(qs[4 * h + 3])
+            : "v"(q_off), "s"(qpu)
+            : "memory");
+      else
+        asm volatile(
+            "s_nop 4\n\t"
+            "global_load_dwordx4 %0, %2, %3\n\t"
+            "global_load_dwordx4 %1, %2, %3 offset:2048"
+            : "+v"(qs[4 * h + 0]), "+v"(qs[4 * h + 2])
+            : "v"(q_off), "s"(qpu)
+            : "memory");
+    }
+  };
+  auto advance = [&]() {
+    if (++i_j == T) {
+      i_j = 0;
+      if (++i_kc == KC) { i_kc = 0; ++i_grp; }
+    }
+  };
+
+  // prologue: slots 0..3 (slot x = K chunk x / T, tile x % T); a chunk's fragments ride with its first slot
+  fb_static_for<4>([&](auto UC) {
+    constexpr int u = decltype(UC)::value;
+    issue_dma(u);
+    if constexpr (u % T == 0) issue_q(qf[(u / T) % NSETS]);
+    advance();
+  });
+
+  int c_grp = 0, c_kc = 0;  // consume-side position
+  for (int s0 = 0; s0 < total; s0 += 4 * T) {
+    fb_static_for<4 * T>([&](auto UC) {
+      constexpr int u = decltype(UC)::value;
+      constexpr int j = u % T;            // tile of the group
+      constexpr int kcs = (u / T) % NSETS;  // K chunk -> fragment register set
+      const int s = s0 + u;
+      // VMEM operations of the slots x behind this one (8 DMAs + the fragment loads of a chunk's first slot), in issue order
+      constexpr int o1 = NDMA + (((u + 1) % T == 0) ? QOPS : 0), o2 = NDMA + (((u + 2) % T == 0) ? QOPS : 0), o3 = NDMA + (((u + 3) % T == 0) ? QOPS : 0);
+      if (s + 3 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(o1 + o2 + o3) : "memory");
+      else if (s + 2 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(o1 + o2) : "memory");
+      else if (s + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(o1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // slot s landed for all waves
+#pragma unroll
+      for (int x = 0; x < NF; ++x) asm volatile("" : "+v"(qf[kcs][x]));  // uses stay behind the wait
+      const char* slot = lds + (u & 3) * SLOTB;
+      bf16x8 af[2][PT];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int t = 0; t < PT; ++t) af[e][t] = *reinterpret_cast<const bf16x8*>(slot + t * (16 * 512) + rd_off[e]);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // slot s is in registers everywhere: refill it
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int t = 0; t < PT; ++t) asm volatile("" : "+v"(af[e][t]));  // the fragment reads stay in front of the barrier
+      if (s + 4 < total) issue_dma(u & 3);
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+#pragma unroll
+          for (int qt = 0; qt < NQT; ++qt) {
+            acc[j][t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[e][t], qf[kcs][(e * NQT + qt) * 2 + 0], acc[j][t][qt], 0, 0, 0);
+            if (LO) acc[j][t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[e][t], qf[kcs][(e * NQT + qt) * 2 + 1], acc[j][t][qt], 0, 0, 0);
+          }
+      if (s + 4 < total) {
+        if constexpr (j == 0) {  // slot s + 4 opens K chunk (u + 4) / T: its fragments go into that chunk's register set
+          // (T = 1: the set the MFMAs above just read; at most 63 VMEM operations may be outstanding)
+          constexpr int peak = 4 * NDMA + (4 / T) * QOPS;
+          if constexpr (peak > 63) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(63 - QOPS) : "memory");
+          issue_q(qf[((u + 4) / T) % NSETS]);
+        }
+        advance();
+      }
+      if (c_kc == KC - 1) {  // tile j of the group is done: acc[j][t][qt][i] = partial dot of page t*16 + 4g + i with query qt*16 + p
+        const int pg = threadIdx.x & (PAGES - 1);
+        const int64_t tile = (int64_t)b + (int64_t)(i0 + c_grp * T + j) * G;
+        const int64_t page = tile * PAGES + pg;
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) {
+          if (qt > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone has read the previous query tile's sums
+#pragma unroll
+          for (int t = 0; t < PT; ++t) {
+            *reinterpret_cast<f32x4*>(red + (wave * 16 + p) * REDS + t * 16 + g * 4) = acc[j][t][qt];
+            acc[j][t][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          if (page < a.n) {
+#pragma unroll
+            for (int x = 0; x < PAGES / 16; ++x) {
+              const int ql = (int)(threadIdx.x / PAGES) + (256 / PAGES) * x;
+              if (qt * 16 + ql < a.n_queries) {
+                const float v = (red[(0 * 16 + ql) * REDS + pg] + red[(1 * 16 + ql) * REDS + pg]) +
+                                (red[(2 * 16 + ql) * REDS + pg] + red[(3 * 16 + ql) * REDS + pg]);
+                a.scores[(size_t)(qt * 16 + ql) * a.score_stride + page] = v;
+              }
+            }
+          }
+        }
+        // red[] is rewritten by the next tile end: at least one slot barrier later
+      }
+      if constexpr (j == T - 1) {
+        if (++c_kc == KC) { c_kc = 0; ++c_grp; }
+      }
+    });
+  }
+}
+
+
+// Two workgroups per CU, 32-page tiles, fragment ring of two sets at four tiles per K chunk (MV_OPT_FDE_BATCH_VARIANT = 4).
+template <int NQT, bool LO>
+__global__ __launch_bounds__(256, 2) void fde_scan_batch3_kernel(ScanBatchArgs a) {
+  constexpr int PT = 2;
+  __shared__ __attribute__((aligned(16))) char lds[4 * (16 * PT * 512) + 4 * 16 * (16 * PT + 4) * 4];
+  float* red = reinterpret_cast<float*>(lds + 4 * (16 * PT * 512));
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = lane & 15, g = lane >> 4;
+  const int G = gridDim.x, b = blockIdx.x;
+  const int n_my = (a.n_tiles - b + G - 1) / G;  // tiles b, b + G, ...  (grid <= n_tiles; a.n_tiles counts 32-page tiles here)
+  const uint32_t row_bytes = (uint32_t)a.out_dim * 2u;
+  uint32_t src_off[2 * PT];
+#pragma unroll
+  for (int i = 0; i < 2 * PT; ++i) {
+    const uint32_t pl = (uint32_t)(wave * (4 * PT) + 2 * i + (lane >> 5));
+    src_off[i] = pl * row_bytes + ((((uint32_t)lane & 31u) ^ (pl & 15u)) << 4) + 4096u - (uint32_t)(i & 3) * 1024u;
+  }
+  uint32_t rd_off[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) rd_off[e] = (uint32_t)p * 512u + (((uint32_t)((2 * wave + e) * 4 + g) ^ (uint32_t)p) << 4);
+  const int n4 = n_my / 4, n2 = (n_my - 4 * n4) / 2, n1 = n_my - 4 * n4 - 2 * n2;
+  fb_phase_g<NQT, LO, 4, PT, 2>(a, lds, red, lane, wave, 0, n4, src_off, rd_off);
+  fb_phase_g<NQT, LO, 2, PT, 4>(a, lds, red, lane, wave, 4 * n4, n2, src_off, rd_off);
+  fb_phase_g<NQT, LO, 1, PT, 4>(a, lds, red, lane, wave, 4 * n4 + 2 * n2, n1, src_off, rd_off);
+}
+
 // Masks and the cosine rule of the batched scan, in place: scores[q][page] *= inv_norm[page]; -inf for tombstones and for
 // pages outside query q's doc filter (allow_stride_bits = 0: one bitmap for all queries).
 __global__ __launch_bounds__(256) void fde_batch_finish_kernel(float* scores, int64_t score_stride, int64_t n, int nq, const float* inv_norm,
@@ -1417,7 +1667,16 @@ int launch_fde_scan_batch(const FdeScanBatchArgs& a, hipStream_t s) {
   ScanBatchArgs k{reinterpret_cast<const char*>(a.fde), reinterpret_cast<const char*>(a.image), a.scores, a.score_stride, a.n,
                   (int32_t)a.out_dim, a.n_queries, (int32_t)n_tiles};
   const dim3 grid((unsigned)std::min<int64_t>(n_tiles, ncu));
-  if (a.single_tile) {  // one page tile per query fragment (MV_OPT_FDE_BATCH_VARIANT = 3: the cross-check of the paired form)
+  if (a.half_tiles) {  // 32-page tiles, two workgroups per CU (MV_OPT_FDE_BATCH_VARIANT = 4)
+    const int64_t n32 = (a.n + 31) / 32;
+    k.n_tiles = (int32_t)n32;
+    const dim3 grid2((unsigned)std::min<int64_t>(n32, (int64_t)ncu * 2));
+    if (a.hi_only) {
+      if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch3_kernel<1, false>), grid2, dim3(256), 0, s, k);
+      else hipLaunchKernelGGL((fde_scan_batch3_kernel<2, false>), grid2, dim3(256), 0, s, k);
+    } else if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch3_kernel<1, true>), grid2, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((fde_scan_batch3_kernel<2, true>), grid2, dim3(256), 0, s, k);
+  } else if (a.single_tile) {  // one page tile per query fragment (MV_OPT_FDE_BATCH_VARIANT = 3: the cross-check of the paired form)
     if (a.hi_only) {
       if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch_kernel<1, false>), grid, dim3(256), 0, s, k);
       else hipLaunchKernelGGL((fde_scan_batch_kernel<2, false>), grid, dim3(256), 0, s, k);

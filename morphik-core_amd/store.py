@@ -9,7 +9,9 @@
                                     behind ONE object: one payload table, writes routed to the least-full shard, queries
                                     through libmvmaxsim's communicator (mv_comm: RCCL all-gather of k pairs over xGMI)
   either can run mode "float": exact float MaxSim over the WHOLE corpus (no coarse stage) -- what the
-  HBM-resident slab makes affordable (1 M pages in ~40 ms on one GPU).
+  HBM-resident slab makes affordable (1 M pages in ~40 ms on one GPU) -- "float_fp8" (the same scan over an e4m3 slab, half
+  the bytes) or "fp8_then_float" (e4m3 scan -> top-128 -> exact bf16 re-score from a pinned-host exact tier: the exact scan's
+  answers at the fp8 slab's HBM footprint).
 
 Signatures, return shapes and error conventions follow the reference:
   store_embeddings -> (True, ["{document_id}-{chunk_number}", ...], metrics)   multi_vector_store.py:623-719
@@ -98,7 +100,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         self.stride_rows = int(stride_rows)
         self.device = int(device)
         self.mode = mode or self.default_mode
-        if self.mode not in ("binary", "float", "fde_then_float", "float_fp8"):
+        if self.mode not in ("binary", "float", "fde_then_float", "float_fp8", "fp8_then_float"):
             raise ValueError(f"unknown mode {self.mode}")
         self.storage = storage  # callers reach for .storage (document_service.py:1570-1575)
         # multi_vector_store.py:120-160: content is stored externally when a storage object is configured
@@ -150,8 +152,12 @@ class MI355XMultiVectorStore(BaseVectorStore):
         return [self.device]
 
     def _slab_flags(self) -> Dict[str, bool]:
+        # "fp8_then_float": e4m3 slab in HBM (131 KB / page) + the exact bf16 rows in PINNED HOST memory (262 KB / page of host
+        # RAM): every page scanned in fp8, the top candidates re-scored exactly out of host RAM by the rerank kernel itself --
+        # exact-scan answers for corpora whose bf16 slab does not fit the GPU (BASELINE configs[4] with recall 1.0)
         return dict(with_float=self.mode in ("float", "fde_then_float"), with_binary=self.mode == "binary",
-                    with_fde=self.mode == "fde_then_float", with_fp8=self.mode == "float_fp8")
+                    with_fde=self.mode == "fde_then_float", with_fp8=self.mode in ("float_fp8", "fp8_then_float"),
+                    **({"with_host_exact": True} if self.mode == "fp8_then_float" else {}))
 
     def _make_index(self):
         if self._index_factory is not None:
@@ -767,13 +773,15 @@ class MI355XShardedFastMultiVectorStore(_ShardedMixin, MI355XFastMultiVectorStor
 
 def create_store(provider: str, **kw: Any) -> MI355XMultiVectorStore:
     """Factory for core/services_init.py: [multivector_store] provider =
-    "mi355x" | "mi355x_fast" | "mi355x_float" | "mi355x_sharded" | "mi355x_sharded_fast" | "mi355x_sharded_float" | "mi355x_remote"."""
+    "mi355x" | "mi355x_fast" | "mi355x_float" | "mi355x_fp8_exact" | "mi355x_sharded" | "mi355x_sharded_fast" | "mi355x_sharded_float" | "mi355x_remote"."""
     if provider == "mi355x":
         return MI355XMultiVectorStore(**kw)
     if provider == "mi355x_fast":
         return MI355XFastMultiVectorStore(**kw)
     if provider == "mi355x_float":
         return MI355XMultiVectorStore(mode="float", **kw)
+    if provider == "mi355x_fp8_exact":  # e4m3 slab in HBM + exact bf16 tier in pinned host RAM
+        return MI355XMultiVectorStore(mode="fp8_then_float", **kw)
     if provider == "mi355x_sharded":
         return MI355XShardedMultiVectorStore(**kw)
     if provider == "mi355x_sharded_fast":

@@ -692,6 +692,12 @@ def test_fde_batched_coarse_scan_matches_the_single_query_scan(mv, n, stride):
     single_tile = ix.query_batch(queries, kk, mode="fde", allows=per_q, n_docs=n_docs)
     for (s0, i0), (s3, i3) in zip(paired, single_tile):
         assert i0.tolist() == i3.tolist() and s0.tolist() == s3.tolist()
+    # MV_OPT_FDE_BATCH_VARIANT = 4: 32-page tiles, two workgroups per CU, four tiles per fragment set -- the same K order and
+    # the same order of the four waves' partial sums per page -> the same scores bit for bit
+    ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, 4)
+    half_tiles = ix.query_batch(queries, kk, mode="fde", allows=per_q, n_docs=n_docs)
+    for (s0, i0), (s4, i4) in zip(paired, half_tiles):
+        assert i0.tolist() == i4.tolist() and s0.tolist() == s4.tolist()
     # MV_OPT_FDE_BATCH_VARIANT = 2: the query FDE rounded to bf16 (no lo term) -- the slab's own precision
     ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, 2)
     kk = min(10, n)

@@ -745,3 +745,37 @@ def test_colqwen2_5_forward_on_the_gpu_matches_an_fp32_cpu_forward_of_the_same_w
             sg = float((qg[b][qm[b]] @ got[pg][m[pg]].T).max(1).sum())
             sw = float((qw[b][qm[b]] @ want[pg][m[pg]].T).max(1).sum())
             assert abs(sg - sw) <= 0.01 * abs(sw), (b, pg, sg, sw)
+
+
+def test_store_mode_fp8_then_float_returns_the_exact_stores_answers():
+    """provider "mi355x_fp8_exact": e4m3 slab in HBM + exact bf16 rows in pinned host RAM.  On the reference's store
+    scenarios and on a corpus of near-duplicates it answers like the exact float store (same chunks, same order, scores
+    within 1e-3), although every page is scanned in fp8 only."""
+    from morphik_core_amd.store import create_store
+    from tests import store_scenarios as sc2
+
+    for scenario in sc2.ALL:
+        st = create_store("mi355x_fp8_exact", capacity_pages=64, stride_rows=32)
+        assert st.initialize() is True
+        sc2.run(scenario(st))
+        st.close()
+    rng = np.random.default_rng(21)
+    base = rng.standard_normal((24, 128)).astype(np.float32)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    chunks = []
+    from morphik_core_amd.models import DocumentChunk
+
+    for j in range(40):  # near-duplicates: exact scores a few 1e-4 apart, below the fp8 scan's noise
+        e = base + (2e-3 * (1 + j)) * rng.standard_normal(base.shape).astype(np.float32)
+        chunks.append(DocumentChunk(document_id=f"d{j // 4}", chunk_number=j % 4, content=f"c{j}", embedding=e / np.linalg.norm(e, axis=1, keepdims=True), metadata={}))
+    exact = create_store("mi355x_float", capacity_pages=64, stride_rows=32)
+    two = create_store("mi355x_fp8_exact", capacity_pages=64, stride_rows=32)
+    assert exact.initialize() and two.initialize()
+    sc2.run(exact.store_embeddings(chunks))
+    sc2.run(two.store_embeddings(chunks))
+    want = sc2.run(exact.query_similar(base, k=10))
+    got = sc2.run(two.query_similar(base, k=10))
+    assert [c.content for c in got] == [c.content for c in want]
+    np.testing.assert_allclose([c.score for c in got], [c.score for c in want], rtol=1e-3)
+    exact.close()
+    two.close()
