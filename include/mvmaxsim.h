@@ -238,6 +238,7 @@ MV_API int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_
  *   out_*      n_queries x k entries (row b = results of query b), out_n[b] = results of query b
  * MV_MODE_FLOAT runs the batched MFMA kernel (up to 512 query rows per slab pass: B x Q flop/byte).
  * MV_MODE_FLOAT_FP8 runs its e4m3 form (block-scaled MFMA, K = 128 per instruction): half the page bytes per pass.
+ * MV_MODE_FP8_THEN_FLOAT runs that pass, then re-scores every request's fp8 top-n exactly from the exact tier in ONE launch.
  * MV_MODE_FDE_THEN_FLOAT / MV_MODE_FDE_ONLY run the batched FDE pipeline: one pass over the FDE slab per 32 queries
  * (the coarse stage as a bf16-MFMA GEMM, query FDEs as bf16 hi + lo: coarse scores within ~1e-5 of the single-query
  * scan), one batched selection, the exact rerank of every query's candidates, one read-back.  The remaining modes are

@@ -1372,10 +1372,11 @@ int mv_internal_batch_upload_queries(mv_index* ix, const void* q, int q_dtype, i
 // Exact rerank of the group's candidate lists d_bcand / d_bcand_pads ([nb][nc], list b against query b of the uploaded
 // group) into d_bcand_scores: ONE launch for all lists where the kernels allow it (fp8 slab; bf16 slab with the default
 // kernels and queries of <= 128 rows), else one launch per query.  q_mu held.
-int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t nc, int* launches) {
+int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t nc, int* launches, const uint16_t* exact_tier) {
+  // exact_tier != null: rerank on THAT bf16 image (the HBM slab or the pinned-host exact tier of MV_MODE_FP8_THEN_FLOAT)
   const int rpq = ((n_q_rows + 15) / 16) * 16;
   const int64_t L = nc;
-  const bool rerank_fp8 = !(ix->cfg.flags & MV_WITH_FLOAT) && (ix->cfg.flags & MV_WITH_FP8);
+  const bool rerank_fp8 = !exact_tier && !(ix->cfg.flags & MV_WITH_FLOAT) && (ix->cfg.flags & MV_WITH_FP8);
   const int rr_variant = ix->maxsim_variant < 0 ? maxsim_default_variant(ix->cfg.stride_rows) : ix->maxsim_variant;
   const bool rerank_one_launch = rerank_fp8 || (rpq <= kMaxQRowsPerPass && (rr_variant == 6 || rr_variant == 7));
   int rc = MV_OK;
@@ -1389,7 +1390,7 @@ int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t n
     ++*launches;
   } else if (rerank_one_launch) {
     MaxsimArgs ma{};
-    ma.slab = ix->slab; ma.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr; ma.cand = ix->d_bcand; ma.q = ix->d_bq;
+    ma.slab = exact_tier ? exact_tier : ix->slab; ma.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr; ma.cand = ix->d_bcand; ma.q = ix->d_bq;
     ma.scores = ix->d_bcand_scores; ma.n = (int64_t)nb * nc; ma.stride = ix->cfg.stride_rows; ma.q_tiles = rpq / 16; ma.pad_to = 0;
     ma.pad_items = ix->d_bcand_pads; ma.items_per_query = (int32_t)nc; ma.q_item_stride = rpq * kDim;
     rc = launch_maxsim_bf16(ma, rr_variant, ix->stream);
@@ -1398,7 +1399,7 @@ int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t n
   } else {
     for (int b = 0; b < nb; ++b) {  // one launch per query (long queries, non-default kernel variants)
       rc = float_scan(ix, n_q_rows, nullptr, 0, ix->d_bcand + (size_t)b * L, nc, 0, ix->d_bcand_pads + (size_t)b * L,
-                      ix->d_bcand_scores + (size_t)b * L, launches, /*no_mask=*/true, ix->d_bq + (size_t)b * rpq * kDim);
+                      ix->d_bcand_scores + (size_t)b * L, launches, /*no_mask=*/true, ix->d_bq + (size_t)b * rpq * kDim, exact_tier);
       if (rc) return rc;
     }
   }
@@ -1474,7 +1475,7 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
                          ix->d_bcand, ix->d_bcand_pads, L);
       MV_HIP(hipGetLastError());
       MV_HIP(hipEventRecord(ix->ev_st[2], ix->stream));
-      rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, nc, &launches);
+      rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, nc, &launches, nullptr);
       if (rc) return rc;
       MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
       rc = launch_topk_batch(ix->d_bcand_scores, L, nc, k, ix->d_bcand, L, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bout_s, ix->d_bout_id, k,
@@ -1531,8 +1532,11 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
 
 // mv_query_topk_batch, MV_MODE_FLOAT_FP8: groups of <= 512 query rows, ONE pass over the e4m3 slab per group
 // (maxsim_batch_fp8_kernel), the group's selections in one chain of launches, one read-back.
-static int fp8_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, int32_t k, const uint32_t* allow_bits,
-                           int64_t n_allow_words, int32_t allow_per_query, float* out_scores, int64_t* out_ids, int32_t* out_n, mv_query_stats* stats) {
+// two_tier (MV_MODE_FP8_THEN_FLOAT): every request's fp8 top-n (MV_OPT_RERANK_N) is re-scored exactly from the exact tier, all
+// lists in ONE rerank launch, before the final selection -- the exact scan's answers for a batch at the fp8 slab's cost.
+static int fp8_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, int32_t k, bool two_tier,
+                           const uint32_t* allow_bits, int64_t n_allow_words, int32_t allow_per_query, float* out_scores, int64_t* out_ids,
+                           int32_t* out_n, mv_query_stats* stats) {
   std::lock_guard<std::mutex> lk(ix->q_mu);
   DeviceGuard g(ix->cfg.device);
   for (int32_t b = 0; b < n_queries; ++b) out_n[b] = 0;
@@ -1552,6 +1556,19 @@ static int fp8_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
   if (!ix->d_bq8hi) MV_HIP(hipMalloc(&ix->d_bq8hi, (size_t)kBatchQRows * kDim));
   if (!ix->d_bq8lo) MV_HIP(hipMalloc(&ix->d_bq8lo, (size_t)kBatchQRows * kDim));
   if (!ix->d_bq8fac) MV_HIP(hipMalloc(&ix->d_bq8fac, (size_t)kBatchQRows * 4));
+  const uint16_t* exact = nullptr;
+  int64_t nc = 0;
+  if (two_tier) {
+    exact = ((ix->cfg.flags & MV_WITH_FLOAT) && !(ix->exact_tier == 1 && ix->d_exact)) ? ix->slab : ix->d_exact;
+    nc = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(std::max<int64_t>(ix->rerank_n, k), n), kTopkMaxDeviceK));
+    const size_t lists = (size_t)kFdeBatchMaxQueries * kTopkMaxDeviceK;
+    if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)kBatchQRows * kRowBytes));
+    if (!ix->d_bsel_s) MV_HIP(hipMalloc(&ix->d_bsel_s, lists * 4));
+    if (!ix->d_bsel_id) MV_HIP(hipMalloc(&ix->d_bsel_id, lists * 8));
+    if (!ix->d_bcand) MV_HIP(hipMalloc(&ix->d_bcand, lists * 4));
+    if (!ix->d_bcand_pads) MV_HIP(hipMalloc(&ix->d_bcand_pads, lists * 4));
+    if (!ix->d_bcand_scores) MV_HIP(hipMalloc(&ix->d_bcand_scores, lists * 4));
+  }
   const bool per_query = allow_bits && allow_per_query;
   const uint32_t* d_allow = nullptr;
   rc = upload_allow(ix, allow_bits, per_query ? n_allow_words * (int64_t)n_queries : n_allow_words, &d_allow);
@@ -1563,7 +1580,7 @@ static int fp8_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
     const int nb = std::min(group, n_queries - b0);
     // zero rows behind the last query of the group: the kernel's row tiles run to the next multiple of 64 rows
     MV_HIP(hipMemsetAsync(ix->d_bqf32, 0, (size_t)512 * kDim * 4, ix->stream));
-    rc = mv_internal_batch_upload_queries(ix, (const char*)q + (size_t)b0 * n_q_rows * kDim * esz, q_dtype, nb, n_q_rows, true, false, false);
+    rc = mv_internal_batch_upload_queries(ix, (const char*)q + (size_t)b0 * n_q_rows * kDim * esz, q_dtype, nb, n_q_rows, true, two_tier, false);
     if (rc) return rc;
     rc = launch_fp8_query_prep(ix->d_bqf32, 512, ix->d_bq8hi, ix->d_bq8lo, ix->d_bq8fac, ix->stream);
     if (rc) return rc;
@@ -1576,10 +1593,28 @@ static int fp8_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
     a.stride = ix->cfg.stride_rows; a.n_queries = nb; a.rows_per_query = rpq; a.single_term = ix->batch_variant == 7 ? 1 : 0;
     rc = launch_maxsim_batch_fp8(a, ix->stream);
     if (rc) return rc;
-    MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
-    rc = launch_topk_batch(ix->d_bscores, ix->cfg.capacity_pages, n, k, nullptr, 0, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bout_s,
-                           ix->d_bout_id, k, nb, ix->stream);
-    if (rc) return rc;
+    if (two_tier) {
+      // fp8 top-n of every request (local page ids) -> rerank lists -> exact bf16 scores from the exact tier, one launch
+      rc = launch_topk_batch(ix->d_bscores, ix->cfg.capacity_pages, n, (int32_t)nc, nullptr, 0, 0, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bsel_s,
+                             ix->d_bsel_id, nc, nb, ix->stream);
+      if (rc) return rc;
+      hipLaunchKernelGGL(cand_prepare_kernel, dim3((unsigned)((nc + kRerankBatch - 1) / kRerankBatch), (unsigned)nb), dim3(kRerankBatch), 0, ix->stream,
+                         (const int64_t*)ix->d_bsel_id, (const int32_t*)nullptr, (int)nc, (const int32_t*)ix->d_n_rows, ix->cfg.stride_rows, /*pad_sem=*/0,
+                         ix->d_bcand, ix->d_bcand_pads, nc);
+      MV_HIP(hipGetLastError());
+      int launches = 0;
+      rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, nc, &launches, exact);
+      if (rc) return rc;
+      MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
+      rc = launch_topk_batch(ix->d_bcand_scores, nc, nc, k, ix->d_bcand, nc, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bout_s, ix->d_bout_id,
+                             k, nb, ix->stream);
+      if (rc) return rc;
+    } else {
+      MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
+      rc = launch_topk_batch(ix->d_bscores, ix->cfg.capacity_pages, n, k, nullptr, 0, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bout_s,
+                             ix->d_bout_id, k, nb, ix->stream);
+      if (rc) return rc;
+    }
     MV_HIP(hipEventRecord(ix->ev[2], ix->stream));
     MV_HIP(hipMemcpyAsync(ix->h_bout_s, ix->d_bout_s, (size_t)nb * k * 4, hipMemcpyDeviceToHost, ix->stream));
     MV_HIP(hipMemcpyAsync(ix->h_bout_id, ix->d_bout_id, (size_t)nb * k * 8, hipMemcpyDeviceToHost, ix->stream));
@@ -1620,8 +1655,10 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
       mv::fde_scan_batch_supported(ix->fde_t.out_dim) && ix->fde_t.cfg.projection_dimension <= 16)
     return fde_batch_query(ix, q, q_dtype, n_queries, n_q_rows, k, mode, allow_bits, n_allow_words, allow_per_query, out_scores, out_ids, out_n, stats);
   // e4m3 slab: the batched block-scaled MFMA scan (<= 512 query rows per slab pass); MV_OPT_BATCH_VARIANT 8 = query by query
-  if (mode == MV_MODE_FLOAT_FP8 && n_queries > 1 && rpq <= 512 && k >= 1 && k <= kTopkMaxDeviceK && (ix->cfg.flags & MV_WITH_FP8) && ix->batch_variant != 8)
-    return fp8_batch_query(ix, q, q_dtype, n_queries, n_q_rows, k, allow_bits, n_allow_words, allow_per_query, out_scores, out_ids, out_n, stats);
+  if ((mode == MV_MODE_FLOAT_FP8 || (mode == MV_MODE_FP8_THEN_FLOAT && rpq <= kMaxQRowsPerPass && (ix->cfg.flags & (MV_WITH_FLOAT | MV_WITH_HOST_EXACT)))) &&
+      n_queries > 1 && rpq <= 512 && k >= 1 && k <= kTopkMaxDeviceK && (ix->cfg.flags & MV_WITH_FP8) && ix->batch_variant != 8)
+    return fp8_batch_query(ix, q, q_dtype, n_queries, n_q_rows, k, mode == MV_MODE_FP8_THEN_FLOAT, allow_bits, n_allow_words, allow_per_query, out_scores,
+                           out_ids, out_n, stats);
   // anything but the exact float scan (and queries longer than one 512-row group) runs query by query
   if (mode != MV_MODE_FLOAT || rpq > 512 || k > kTopkMaxDeviceK || k == 0) {
     for (int32_t b = 0; b < n_queries; ++b) {

@@ -327,7 +327,7 @@ int mv_internal_two_stage_batch_rerank(mv_index* ix, const void* q, int q_dtype,
                      ix->d_bcand_pads);
   MV_HIP(hipGetLastError());
   int launches = 0;
-  rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, n_coarse, &launches);
+  rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, n_coarse, &launches, nullptr);
   if (rc) return rc;
   // local top-k of the owned candidates of every request; equal scores resolve by coarse rank, as on one index
   rc = launch_topk_batch(ix->d_bcand_scores, n_coarse, n_coarse, k, ix->d_bcand, n_coarse, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, d_out_scores,

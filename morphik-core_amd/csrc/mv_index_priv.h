@@ -174,7 +174,7 @@ float host_bf16_to_f32(uint16_t h);
 extern "C" int mv_internal_ensure_batch_select_ws(mv_index* ix);
 extern "C" int mv_internal_ensure_fde_batch_ws(mv_index* ix);
 extern "C" int mv_internal_batch_upload_queries(mv_index* ix, const void* q, int q_dtype, int nb, int n_q_rows, bool want_f32, bool want_bf16, bool want_fp8);
-extern "C" int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t nc, int* launches);
+extern "C" int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t nc, int* launches, const uint16_t* exact_tier);
 
 extern "C" int mv_internal_query_common(mv_index* ix, const void* q, int q_dtype, int32_t n_q, int32_t k, int mode,
                                         const uint32_t* allow_bits, int64_t n_words, float* h_scores, int64_t* h_ids, int32_t* out_n,

@@ -112,7 +112,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         self.id_base = int(id_base)
         self.fde_coarse_n = int(fde_coarse_n)
         self._index_factory = index_factory
-        # request coalescing (modes "float" and "fde_then_float"): concurrent query_similar calls arriving within
+        # request coalescing (modes "float", "float_fp8", "fp8_then_float" and "fde_then_float"): concurrent query_similar calls arriving within
         # batch_window_ms are scored in ONE slab pass (batched MFMA MaxSim scan / batched FDE pipeline: up to 32 requests per
         # pass over the FDE slab, every request's candidates reranked exactly), each keeping its own doc_ids filter and k
         # batch_window_ms > 0: a timer window (a lone request pays it); batch_window_ms < 0: ADAPTIVE (group commit) -- a
@@ -392,8 +392,8 @@ class MI355XMultiVectorStore(BaseVectorStore):
         with self._lock:
             n_docs = self._next_ord
         t0 = time.perf_counter()
-        if self.mode == "float":
-            groups = [list(range(len(items)))]  # exact scan: the top-k of a larger k is a prefix, one pass serves every k
+        if self.mode in ("float", "float_fp8"):
+            groups = [list(range(len(items)))]  # full scan: the top-k of a larger k is a prefix, one pass serves every k
         else:
             # the FDE stage keeps min(10*k, 75) candidates (fast_multivector_store.py:529): requests share a pass only with
             # requests of the same k, so each sees exactly the candidates a lone call would have reranked
@@ -493,7 +493,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
                 gen = self._generation
             if empty:
                 return []
-            if self.batch_window_s != 0 and self.mode in ("float", "fde_then_float"):
+            if self.batch_window_s != 0 and self.mode in ("float", "fde_then_float", "float_fp8", "fp8_then_float"):
                 scores, pages = await self._coalesced_query(q, int(k), allow)
             else:
                 scores, pages = await asyncio.to_thread(self._query_sync, q, int(k), allow)  # exceptions propagate (:819-822)

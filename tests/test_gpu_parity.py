@@ -1199,6 +1199,20 @@ def test_fp8_then_float_rescoring_from_the_exact_tier(mv, tier, tmp_path):
     top, _info = synth.exact_truth_from_scores(hard_pages, exact)
     assert i.tolist() == top
     np.testing.assert_allclose(ix.score_all(q_bf, mode="fp8_then_float"), c8, rtol=RTOL, atol=1e-6)  # first-stage scores
+    # a BATCH of requests: one pass of the batched fp8 scan, every request's top-n re-scored exactly in one launch -- the lone
+    # calls' answers; with one e4m3 term per query row in the first stage (variant 7) the exact tier still restores them
+    bqs = [q_bf] + [orc.synth_rows(4321, 50 + j, 0, 20 + j) for j in range(5)]
+    lone = [ix.query(x, 10, mode="fp8_then_float") for x in bqs]
+    for variant in (0, 7):
+        ix.set_option(_lib.MV_OPT_BATCH_VARIANT, variant)
+        for (bs, bi), (ls, li) in zip(ix.query_batch(bqs, 10, mode="fp8_then_float"), lone):
+            if variant == 0:
+                assert bi.tolist() == li.tolist()
+                np.testing.assert_allclose(bs, ls, rtol=1e-5)
+            else:
+                assert bi.tolist()[:5] == li.tolist()[:5]  # the clear neighbours; the tail may differ where the fp8 cut differs
+        assert ix.query_batch(bqs, 10, mode="fp8_then_float")[0][1].tolist() == top
+    ix.set_option(_lib.MV_OPT_BATCH_VARIANT, -1)
     # doc filter (selective -> compacted candidate list) + tombstone
     ix.remove_doc(top[0] // 4)
     allowed_docs = [d for d in range((N - 40) // 4 + 1) if d % 3 != 1] + [1000 + j for j in range(0, 40, 2)]
