@@ -287,6 +287,23 @@ def full_shard(args, device, sets, truths, gaps, n_truth_pages):
         res[key] = scan_entry(n, bpp, t["score_kernel_ms"])
     t = timed_mode(ix, qs, "fde")
     res["fde_coarse_scan"] = dict(scan_entry(n, 20480, t["coarse_ms"]), query_encode_ms=round(t["encode_ms"], 4))
+    # ---- B requests per pass over the e4m3 slab (maxsim_batch_fp8_kernel): two-term queries (the scan's scores) and the
+    # single-term coarse form (MV_OPT_BATCH_VARIANT 7: half the matrix work)
+    res["batched_fp8_scan"] = {}
+    for bv, B, name in ((0, 4, "B4_two_term"), (0, 16, "B16_two_term"), (7, 16, "B16_single_term")):
+        ix.set_option(L.MV_OPT_BATCH_VARIANT, bv)
+        ms = []
+        for r in range(5):
+            _res_b, st = ix.query_batch(qs[:B], K, mode="float_fp8", want_stats=True)
+            if r >= 2:
+                ms.append(st.score_kernel_ms)
+        m = float(np.median(ms))
+        useful = 2.0 * B * args.qtokens * args.patches * 128 * n / m / 1e9
+        res["batched_fp8_scan"][name] = {"kernel_ms": round(m, 4), "query_pages_per_s": round(B * n / m * 1e3, 1), "useful_TFLOPs": round(useful, 1),
+                                         "issued_fp8_TFLOPs": round(useful * (1 if bv == 7 else 2), 1),
+                                         "frac_fp8_mfma_5000TF_issued": round(useful * (1 if bv == 7 else 2) / 5000.0, 4),
+                                         "GBps": round(n * args.patches * 128 / m / 1e6, 1), "frac_hbm_8TBps": round(n * args.patches * 128 / m / 1e6 / HBM_PEAK_GBPS, 4)}
+    ix.set_option(L.MV_OPT_BATCH_VARIANT, -1)
     # ---- FDE -> top-n -> exact rerank on the e4m3 slab (configs[3] pipeline), one request and 32 per slab pass
     res["fde_then_fp8_rerank"] = {}
     bq = [qs[i % len(qs)] for i in range(32)]
@@ -394,6 +411,25 @@ def two_tier(args, device):
                          "rerank_GBps": round(nn * args.patches * 256 / max(t["rerank_ms"], 1e-6) / 1e6, 1)}
         res["by_rerank_n"][f"n{nn}"] = ent
     ix.set_option(L.MV_OPT_RERANK_N, 128)
+    # the same for a BATCH of 16 requests per pass of the batched fp8 scan, every list re-scored exactly in one launch
+    from morphik_core_amd import synth as _synth
+
+    res["batch_of_16"] = {}
+    hq16, ht16 = qs[:16], truths["hard_negatives"][:16]
+    for bv, name in ((0, "two_term_first_stage"), (7, "single_term_first_stage")):
+        ix.set_option(L.MV_OPT_BATCH_VARIANT, bv)
+        for tier, code in (("hbm_bf16_slab", 0), ("pinned_host_over_pcie", 1)):
+            ix.set_option(L.MV_OPT_EXACT_TIER, code)
+            dev, out_b = [], None
+            for r in range(5):
+                out_b, st = ix.query_batch(hq16, K, mode="fp8_then_float", want_stats=True)
+                if r >= 2:
+                    dev.append(st.total_device_ms)
+            d = float(np.median(dev))
+            res["batch_of_16"][f"{name}_{tier}"] = {
+                "device_ms_per_batch": round(d, 4), "device_us_per_request": round(d * 1e3 / 16, 1), "query_pages_per_s": round(16 * n / d * 1e3, 1),
+                "recall_at_10_hard_negatives": round(float(np.mean([_synth.recall_at_k(out_b[j][1].tolist(), ht16[j]) for j in range(16)])), 4)}
+    ix.set_option(L.MV_OPT_BATCH_VARIANT, -1)
     ix.set_option(L.MV_OPT_EXACT_TIER, 1)  # recall through the host tier (same rows: same answers as the HBM tier)
     res["recall_at_10_vs_exact_bf16"] = recall_of(ix, sets, truths, gaps, [("fp8_scan", ids_of("float_fp8")), ("fp8_then_float_n128", ids_of("fp8_then_float"))])
     ix.close()
