@@ -260,7 +260,9 @@ def test_store_checkpoint_and_resume(tmp_path):
     chunks = sc2.make_chunks(rng, n_docs=4, chunks_per_doc=3)
     s = _store("fde_then_float")
     sc2.run(s.store_embeddings(chunks, app_id="app-x"))
-    sc2.run(s.delete_chunks_by_document_id(chunks[3].document_id))
+    sc2.run(s.delete_chunks_by_document_id(chunks[3].document_id))  # another namespace ("default"): deletes nothing (fast_multivector_store.py:643)
+    assert len(s) == len(chunks)
+    sc2.run(s.delete_chunks_by_document_id(chunks[3].document_id, app_id="app-x"))
     before = [sc2.run(s.query_similar(c.embedding, k=4, app_id="app-x")) for c in chunks[:3] + chunks[6:8]]
     s.save(str(tmp_path / "ckpt"))
     s.close()
@@ -270,7 +272,8 @@ def test_store_checkpoint_and_resume(tmp_path):
     for b, a in zip(before, after):
         assert [(c.document_id, c.chunk_number, c.content, c.metadata) for c in a] == [(c.document_id, c.chunk_number, c.content, c.metadata) for c in b]
         assert [c.score for c in a] == [c.score for c in b]
-    got = sc2.run(r.get_chunks_by_id([(chunks[0].document_id, chunks[0].chunk_number)]))
+    assert sc2.run(r.get_chunks_by_id([(chunks[0].document_id, chunks[0].chunk_number)])) == []  # not visible through another namespace
+    got = sc2.run(r.get_chunks_by_id([(chunks[0].document_id, chunks[0].chunk_number)], app_id="app-x"))
     assert got[0].content == chunks[0].content
     # the resumed store keeps ingesting and filtering
     more = [c.model_copy(update={"document_id": "late-doc"}) for c in sc2.make_chunks(rng, n_docs=1, chunks_per_doc=2)]

@@ -26,9 +26,24 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 class NullIndex:
     """Answers instantly with fixed pages: isolates the store's own per-request cost (no scoring happens here)."""
 
+    delay_s = 0.0          # simulated device time of one call (sleeps with the GIL released, serialised like mv_index's query mutex)
+    delay_per_query_s = 0.0
+
     def __init__(self, **kw):
+        import threading
+
         self.n = 0
         self.device = 0
+        self._mutex = threading.Lock()
+
+    def _device(self, nq):
+        d = self.delay_s + self.delay_per_query_s * nq
+        if d > 0:
+            with self._mutex:
+                t_end = time.perf_counter() + d
+                time.sleep(max(d - 1e-4, 0))
+                while time.perf_counter() < t_end:
+                    pass
 
     def __len__(self):
         return self.n
@@ -42,13 +57,17 @@ class NullIndex:
     def query(self, q, k, mode="float", allow=None, want_stats=False):
         from morphik_core_amd.index import QueryStats
 
+        if not getattr(self, "_in_batch", False):
+            self._device(1)
         s = np.linspace(1.0, 0.5, k, dtype=np.float32)
         i = np.arange(k, dtype=np.int64)
         return (s, i, QueryStats()) if want_stats else (s, i)
 
     def query_batch(self, queries, k, mode="float", allow=None, want_stats=False, allows=None, n_docs=0):
-        r = [self.query(q, k) for q in queries]
-        return r
+        self._device(len(queries))
+        s = np.linspace(1.0, 0.5, k, dtype=np.float32)
+        i = np.arange(k, dtype=np.int64)
+        return [(s, i) for _q in queries]
 
     def close(self):
         pass
@@ -161,8 +180,12 @@ def main():
     ap.add_argument("--seconds", type=float, default=2.0)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--null-index", action="store_true")
+    ap.add_argument("--null-delay-ms", type=float, default=0.0, help="--null-index: simulated device time per call (fixed part)")
+    ap.add_argument("--null-delay-per-query-us", type=float, default=0.0, help="--null-index: simulated device time per query of a call")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
+    NullIndex.delay_s = a.null_delay_ms / 1e3
+    NullIndex.delay_per_query_s = a.null_delay_per_query_us / 1e6
     res = measure(a)
     js = json.dumps(res)
     if a.out:
