@@ -91,6 +91,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         fde_coarse_n: int = 0,
         batch_window_ms: float = 0.0,
         max_batch: int = 16,
+        pipeline_depth: int = 2,
         min_score: Optional[float] = None,
         enable_external_storage: bool = True,
         app_id_resolver: Optional[Callable[[str], Optional[str]]] = None,
@@ -120,6 +121,10 @@ class MI355XMultiVectorStore(BaseVectorStore):
         # pass together: no added latency when idle, natural batches under load
         self.batch_window_s = float(batch_window_ms) / 1e3
         self.max_batch = int(max_batch)
+        # adaptive mode: a SECOND batch may be dispatched while one is on the device, but only a full one (max_batch requests
+        # waiting): the library serialises the two passes, and the event loop builds the hits of pass N while pass N+1 runs
+        # (ctypes releases the GIL) -- without it the GPU idles for the ~0.7 ms of Python that 32 finished requests cost
+        self.pipeline_depth = max(1, int(pipeline_depth))
         self._inflight = 0
         self._flush_scheduled = False
         # The API accepts min_score (core/models/request.py:138) and threads it through retrieve_chunks
@@ -439,17 +444,23 @@ class MI355XMultiVectorStore(BaseVectorStore):
                         fut.set_exception(e)
             finally:
                 self._inflight -= 1
-                if self._pending and self._inflight == 0 and self.batch_window_s < 0:
+                if self._pending and self.batch_window_s < 0 and self._may_dispatch():
                     self._flush()  # adaptive: everything that arrived during this pass rides the next one
 
         asyncio.ensure_future(run())
+        if self.batch_window_s < 0 and self._pending and self._may_dispatch():
+            self._flush()  # a full batch is still waiting and the pipeline has room
+
+    def _may_dispatch(self) -> bool:
+        """Adaptive mode: an idle index takes whatever waits; behind a pass in flight only a full batch goes out."""
+        return self._inflight == 0 or (self._inflight < self.pipeline_depth and len(self._pending) >= self.max_batch)
 
     async def _coalesced_query(self, q: np.ndarray, k: int, allow) -> Tuple[np.ndarray, np.ndarray]:
         loop = asyncio.get_running_loop()
         fut = loop.create_future()
         self._pending.append((q, k, allow, fut))
         if self.batch_window_s < 0:  # adaptive: dispatch when idle (after the requests that are ready in this same loop tick)
-            if self._inflight == 0 and not self._flush_scheduled:
+            if not self._flush_scheduled and self._may_dispatch():
                 self._flush_scheduled = True
                 loop.call_soon(self._flush)
         elif len(self._pending) >= self.max_batch:
@@ -498,22 +509,27 @@ class MI355XMultiVectorStore(BaseVectorStore):
             else:
                 scores, pages = await asyncio.to_thread(self._query_sync, q, int(k), allow)  # exceptions propagate (:819-822)
             hits: List[Tuple[float, Tuple[str, int, str, str, Optional[str]]]] = []
+            min_score, rows_get = self.min_score, self._rows.get
             with self._lock:
                 if self._generation != gen:
                     continue  # compact() renumbered the pages while the scan ran: these ids are stale, scan again
-                for s, p in zip(scores.tolist(), pages.tolist()):
-                    if self.min_score is not None and s < self.min_score:
+                for s, p in zip(scores.tolist(), pages.tolist()):  # tolist(): python float / int already
+                    if min_score is not None and s < min_score:
                         break  # hits are sorted by score desc
-                    row = self._rows.get(int(p))
+                    row = rows_get(p)
                     if row is not None:  # None: deleted between scan and lookup
-                        hits.append((float(s), row))
+                        hits.append((s, row))
             break
         else:
             raise RuntimeError("query_similar: the index was compacted during every attempt")
         t_scan = time.perf_counter()
-        contents, metas = await self._resolve_contents([r for _s, r in hits], skip_image_content)
-        out = [DocumentChunk(document_id=r[0], chunk_number=r[1], content=c, embedding=[], metadata=m, score=s)
-               for (s, r), c, m in zip(hits, contents, metas)]
+        if self.enable_external_storage and self._payloads is not None:
+            contents, metas = await self._resolve_contents([r for _s, r in hits], skip_image_content)
+            out = [DocumentChunk(document_id=r[0], chunk_number=r[1], content=c, embedding=[], metadata=m, score=s)
+                   for (s, r), c, m in zip(hits, contents, metas)]
+        else:  # in-memory payload table: nothing to fetch, no coroutine, one pass over the hits
+            out = [DocumentChunk(document_id=r[0], chunk_number=r[1], content=r[2], embedding=[], metadata=parse_metadata(r[3]), score=s)
+                   for s, r in hits]
         if self.mode == "fde_then_float" and logger.isEnabledFor(logging.INFO):
             t_end = time.perf_counter()
             logger.info(f"query_similar timing - load_contents: {(t_end - t_scan)*1000:.2f} ms")

@@ -139,6 +139,53 @@ def test_adaptive_coalescing_dispatches_a_lone_request_at_once_and_batches_what_
         assert [(c.document_id, c.chunk_number, c.score) for c in g] == [(c.document_id, c.chunk_number, c.score) for c in w]
 
 
+def test_adaptive_coalescing_keeps_a_second_full_batch_in_flight():
+    """pipeline_depth = 2 (default): behind a pass in flight, a FULL batch is dispatched at once (the library serialises the two
+    passes; the event loop builds the first pass's hits while the second runs); a partial batch still waits for an idle index.
+    pipeline_depth = 1 is the strict one-pass-at-a-time form.  Answers are those of a lone call either way."""
+    import asyncio
+    import threading
+    import time
+
+    rng = np.random.default_rng(6)
+    chunks = sc.make_chunks(rng, n_docs=4, chunks_per_doc=3)
+
+    class SlowIndex(OracleIndex):
+        live = 0
+        peak = 0
+        mu = threading.Lock()
+
+        def query_batch(self, *a, **kw):
+            with SlowIndex.mu:
+                SlowIndex.live += 1
+                SlowIndex.peak = max(SlowIndex.peak, SlowIndex.live)
+            time.sleep(0.05)
+            try:
+                return super().query_batch(*a, **kw)
+            finally:
+                with SlowIndex.mu:
+                    SlowIndex.live -= 1
+
+    plain = _store(mode="float")
+    sc.run(plain.store_embeddings(chunks))
+    reqs = [(chunks[i % 12].embedding, 1 + i % 4) for i in range(20)]
+    want = [sc.run(plain.query_similar(q, k=k)) for q, k in reqs]
+    for depth, peak, sizes in ((2, 2, [8, 8, 4]), (1, 1, [8, 8, 4])):
+        fused = MI355XMultiVectorStore(capacity_pages=64, stride_rows=32, index_factory=SlowIndex, mode="float", batch_window_ms=-1, max_batch=8,
+                                       pipeline_depth=depth)
+        assert fused.initialize()
+        sc.run(fused.store_embeddings(chunks))
+        SlowIndex.peak = 0
+
+        async def fire():
+            return await asyncio.gather(*(fused.query_similar(q, k=k) for q, k in reqs))
+
+        got = sc.run(fire())
+        assert fused.coalesced_batches == sizes and SlowIndex.peak == peak
+        for w, g in zip(want, got):
+            assert [(c.document_id, c.chunk_number, c.score) for c in g] == [(c.document_id, c.chunk_number, c.score) for c in w]
+
+
 def test_concurrent_requests_on_the_fast_store_are_coalesced_by_k():
     """mode fde_then_float: coalesced requests share a batched call only with requests of the same k (the candidate rule
     min(10k, 75) depends on k), so every request gets exactly what a lone call returns."""
