@@ -139,7 +139,9 @@ typedef enum {
                                     FDE rounded to bf16 (one MFMA per fragment: -13 % pass time, coarse scores within ~2e-3);
                                     3 = as 0 with one page tile per query fragment (the first form of the coarse kernel; the
                                     default walks a workgroup's tiles in pairs: same scores, half the fragment traffic);
-                                    4 = 32-page tiles, two workgroups per CU, four tiles per fragment set (same scores) */
+                                    4 = 32-page tiles, two workgroups per CU, four tiles per fragment set (same scores);
+                                    5 = as 0 with the round-2 selection: the scan's finish pass does not pre-bin the scores, the
+                                    selection runs all three of its passes (same results; 3 does the same) */
 } mv_option;
 
 /* Bumped whenever a signature, a struct layout or an enum value of this header changes incompatibly.  A binding compares

@@ -1463,12 +1463,21 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
     sa.hi_only = ix->fde_batch_variant == 2;
     sa.single_tile = ix->fde_batch_variant == 3;
     sa.half_tiles = ix->fde_batch_variant == 4;
+    // the finish pass of the coarse scan bins every request's scores for the selection's first radix pass (variant 3, the
+    // cross-check form, keeps the separate three-pass selection)
+    const int32_t k_sel = rerank ? (int32_t)nc : k;
+    if (ix->fde_batch_variant != 3 && ix->fde_batch_variant != 5 && topk_uses_radix(n, k_sel)) {
+      sa.hist0 = topk_radix_hist0(ix->d_btopk_ws);
+      sa.hist0_stride_bytes = (int64_t)ix->topk_ws_bytes;
+    }
+    const bool prebinned = fde_scan_batch_prebins(sa);
     rc = launch_fde_scan_batch(sa, ix->stream);
     if (rc) return rc;
     launches += 3;
     MV_HIP(hipEventRecord(ix->ev_st[1], ix->stream));
     if (rerank) {
-      rc = launch_topk_batch(ix->d_bscores, cap, n, (int32_t)nc, nullptr, 0, 0, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bsel_s, ix->d_bsel_id, L, nb, ix->stream);
+      rc = launch_topk_batch(ix->d_bscores, cap, n, (int32_t)nc, nullptr, 0, 0, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bsel_s, ix->d_bsel_id, L, nb, ix->stream,
+                             prebinned);
       if (rc) return rc;
       hipLaunchKernelGGL(cand_prepare_kernel, dim3((unsigned)((nc + kRerankBatch - 1) / kRerankBatch), (unsigned)nb), dim3(kRerankBatch), 0, ix->stream,
                          (const int64_t*)ix->d_bsel_id, (const int32_t*)nullptr, (int)nc, (const int32_t*)ix->d_n_rows, ix->cfg.stride_rows, pad_sem,
@@ -1484,7 +1493,7 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
     } else {
       MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
       rc = launch_topk_batch(ix->d_bscores, cap, n, k, nullptr, 0, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bout_s, ix->d_bout_id, k, nb,
-                             ix->stream);
+                             ix->stream, prebinned);
       if (rc) return rc;
     }
     MV_HIP(hipEventRecord(ix->ev[2], ix->stream));

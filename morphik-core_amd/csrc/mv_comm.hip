@@ -280,11 +280,16 @@ int mv_internal_two_stage_batch_coarse(mv_index* ix, const void* q, int q_dtype,
   sa.hi_only = ix->fde_batch_variant == 2;
   sa.single_tile = ix->fde_batch_variant == 3;
   sa.half_tiles = ix->fde_batch_variant == 4;
+  if (ix->fde_batch_variant != 3 && ix->fde_batch_variant != 5 && topk_uses_radix(n, n_coarse)) {  // the finish pass bins the scores for the selection (mv_api.hip)
+    sa.hist0 = topk_radix_hist0(ix->d_btopk_ws);
+    sa.hist0_stride_bytes = (int64_t)ix->topk_ws_bytes;
+  }
+  const bool prebinned = fde_scan_batch_prebins(sa);
   rc = launch_fde_scan_batch(sa, ix->stream);
   if (rc) return rc;
   // local coarse top-n of every request, GLOBAL ids, padded with (-inf, -1) when the shard holds fewer pages
   rc = launch_topk_batch(ix->d_bscores, cap, n, n_coarse, nullptr, 0, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bsel_s, ix->d_bsel_id,
-                         n_coarse, nb, ix->stream);
+                         n_coarse, nb, ix->stream, prebinned);
   if (rc) return rc;
   hipLaunchKernelGGL(recs_build_batch_kernel, dim3((unsigned)((n_coarse + 255) / 256), (unsigned)nb), dim3(256), 0, ix->stream, (const float*)ix->d_bsel_s,
                      (const int64_t*)ix->d_bsel_id, (int)n_coarse, (int64_t)n_coarse, ix->ragged.load() ? (const int32_t*)ix->d_n_rows : (const int32_t*)nullptr,

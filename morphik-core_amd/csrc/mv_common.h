@@ -89,6 +89,27 @@ __device__ __forceinline__ uint32_t topk_ordered_u32(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// LDS histogram increment for one key per lane.  Scores of one scan crowd into a handful of bins of the FIRST pass (the top
+// 11 key bits are sign + exponent + 2 mantissa bits: cosine-like FDE scores share them), and 64 lanes incrementing the
+// same LDS word serialise (measured: the two histogram passes were 0.14 of the 0.26 ms a 32-request selection took).  So the
+// wave first aggregates: up to two rounds of "the first active lane's bin -> ballot of the lanes holding it -> ONE add of
+// the population count", then whatever is left (the spread-out tail, and every key of the second pass, whose bins are
+// mantissa bits) goes through plain atomics.  Every lane of the wave must make the call (the ballots need all of them).
+__device__ __forceinline__ void topk_hist_add_wave(uint32_t* h, uint32_t bin, bool valid) {
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    const uint64_t active = __ballot(valid);
+    if (!active) return;
+    const int leader = __ffsll((unsigned long long)active) - 1;
+    const uint32_t lb = (uint32_t)__shfl((int)bin, leader);
+    const bool mine = valid && bin == lb;
+    const uint64_t same = __ballot(mine);
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&h[lb], (uint32_t)__popcll((unsigned long long)same));
+    valid = valid && !mine;
+  }
+  if (valid) atomicAdd(&h[bin], 1u);
+}
+
 int launch_merge_topk(const float* d_scores, const int64_t* d_ids, int32_t world, int32_t kk, int32_t k, float* d_out_scores,
                       int64_t* d_out_ids, hipStream_t s);
 
@@ -186,7 +207,13 @@ struct FdeScanBatchArgs {
   int32_t hi_only;            // 1: bf16 query FDE (one MFMA per fragment, half the query traffic; coarse scores within ~2e-3)
   int32_t single_tile;        // 1: one page tile per query fragment (the first form; default: tiles in pairs)
   int32_t half_tiles;         // 1: 32-page tiles, two workgroups per CU, four tiles per query fragment set (round 3)
+  // nullable: query b's first selection histogram (topk_radix_hist0 of ITS workspace) at hist0 + b * hist0_stride_bytes, zero on
+  // entry; accumulated by the finish pass (which touches every score anyway) so the selection starts at its second pass.
+  // Only honoured when a finish pass runs (inv_norm or doc_ord given): fde_scan_batch_prebins().
+  uint32_t* hist0;
+  int64_t hist0_stride_bytes;
 };
+inline bool fde_scan_batch_prebins(const FdeScanBatchArgs& a) { return a.hist0 != nullptr && (a.inv_norm != nullptr || a.doc_ord != nullptr); }
 bool fde_scan_batch_supported(int64_t out_dim);
 size_t fde_scan_batch_image_bytes(int64_t out_dim);
 int launch_fde_scan_batch(const FdeScanBatchArgs& a, hipStream_t s);

@@ -1461,6 +1461,74 @@ __global__ __launch_bounds__(256) void fde_batch_finish_kernel(float* scores, in
   }
 }
 
+// The same pass, also accumulating the FIRST histogram of every query's selection (order-preserving key bits [31:21], the bins
+// radix_hist_kernel's pass 0 would count): the finish touches every score anyway, so the 32-request selection loses one of its
+// three passes over the 4 * n * nq-byte score matrix.  Block = a page range x kFinQ queries (one 2048-bin LDS histogram each,
+// wave-aggregated increments); page metadata is read once per page and block.
+constexpr int kFinQ = 4;
+__global__ __launch_bounds__(256) void fde_batch_finish_hist_kernel(float* scores, int64_t score_stride, int64_t n, int nq, const float* inv_norm,
+                                                                    const int32_t* doc_ord, const uint32_t* allow, int64_t n_allow_bits,
+                                                                    int64_t allow_stride_bits, uint32_t* hist0, int64_t hist0_stride_words) {
+  __shared__ uint32_t h[kFinQ][2048];
+  const int q0 = blockIdx.y * kFinQ;
+  const int nql = min(kFinQ, nq - q0);
+  for (int i = threadIdx.x; i < kFinQ * 2048; i += 256) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const int64_t step = (int64_t)gridDim.x * 256;
+  const int64_t n_round = ((n + step - 1) / step) * step;  // whole waves walk the loop together (the ballots need every lane)
+  for (int64_t page = (int64_t)blockIdx.x * 256 + threadIdx.x; page < n_round; page += step) {
+    const bool in = page < n;
+    float inv = 1.0f;
+    int32_t o = 0;
+    if (in) {
+      if (inv_norm) inv = inv_norm[page];
+      if (doc_ord) o = doc_ord[page];
+    }
+    float v[kFinQ];
+#pragma unroll
+    for (int ql = 0; ql < kFinQ; ++ql)
+      v[ql] = (in && ql < nql) ? __builtin_nontemporal_load(scores + (size_t)(q0 + ql) * score_stride + page) : -INFINITY;
+#pragma unroll
+    for (int ql = 0; ql < kFinQ; ++ql) {
+      if (ql < nql) {  // block-uniform
+        bool valid = false;
+        uint32_t bin = 0;
+        if (in) {
+          bool m = false;
+          if (doc_ord) {
+            m = o < 0;
+            if (!m && allow) {
+              const uint32_t* ab = allow + (size_t)(q0 + ql) * (size_t)(allow_stride_bits >> 5);
+              m = (int64_t)o >= n_allow_bits || ((ab[o >> 5] >> (o & 31)) & 1u) == 0u;
+            }
+          }
+          float* sp = scores + (size_t)(q0 + ql) * score_stride + page;
+          float s = v[ql];
+          if (m) {
+            s = -INFINITY;
+            *sp = s;
+          } else if (inv_norm) {
+            s = s * inv;
+            *sp = s;
+          }
+          const float s0 = s + 0.0f;
+          if (s0 == s0 && s0 != -INFINITY) {
+            valid = true;
+            bin = topk_ordered_u32(s0) >> 21;
+          }
+        }
+        topk_hist_add_wave(h[ql], bin, valid);
+      }
+    }
+  }
+  __syncthreads();
+  for (int ql = 0; ql < nql; ++ql) {
+    uint32_t* dst = hist0 + (size_t)(q0 + ql) * (size_t)hist0_stride_words;
+    for (int i = threadIdx.x; i < 2048; i += 256)
+      if (h[ql][i]) atomicAdd(&dst[i], h[ql][i]);
+  }
+}
+
 struct FdeDeviceExtra {  // bucket-sorted projection tables
   int32_t* order = nullptr;
   float* sgn = nullptr;
@@ -1687,7 +1755,12 @@ int launch_fde_scan_batch(const FdeScanBatchArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL((fde_scan_batch2_kernel<2, false>), grid, dim3(256), 0, s, k);
   } else if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch2_kernel<1, true>), grid, dim3(256), 0, s, k);
   else hipLaunchKernelGGL((fde_scan_batch2_kernel<2, true>), grid, dim3(256), 0, s, k);
-  if (a.inv_norm || a.doc_ord)
+  if (fde_scan_batch_prebins(a)) {
+    const int gx = (int)std::min<int64_t>((a.n + 255) / 256, 128);
+    hipLaunchKernelGGL(fde_batch_finish_hist_kernel, dim3((unsigned)gx, (unsigned)((a.n_queries + kFinQ - 1) / kFinQ)), dim3(256), 0, s, a.scores,
+                       a.score_stride, a.n, a.n_queries, a.inv_norm, a.doc_ord, a.allow, a.n_allow_bits, a.allow_stride_bits, a.hist0,
+                       a.hist0_stride_bytes / 4);
+  } else if (a.inv_norm || a.doc_ord)
     hipLaunchKernelGGL(fde_batch_finish_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a.scores, a.score_stride, a.n, a.n_queries,
                        a.inv_norm, a.doc_ord, a.allow, a.n_allow_bits, a.allow_stride_bits);
   MV_HIP(hipGetLastError());

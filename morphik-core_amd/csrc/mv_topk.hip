@@ -259,26 +259,7 @@ __device__ __forceinline__ void radix_pick(const uint32_t* hist, uint32_t kr, ui
 
 constexpr int kShift0 = 21, kShift1 = 10;  // key bits [31:21] then [20:10]
 
-// LDS histogram increment for one key per lane.  Scores of one scan crowd into a handful of bins of the FIRST pass (the top
-// 11 key bits are sign + exponent + 2 mantissa bits: cosine-like FDE scores share them), and 64 lanes incrementing the
-// same LDS word serialise (measured: the two histogram passes were 0.14 of the 0.26 ms a 32-request selection took).  So the
-// wave first aggregates: up to two rounds of "the first active lane's bin -> ballot of the lanes holding it -> ONE add of
-// the population count", then whatever is left (the spread-out tail, and every key of the second pass, whose bins are
-// mantissa bits) goes through plain atomics.
-__device__ __forceinline__ void hist_add_wave(uint32_t* h, uint32_t bin, bool valid) {
-#pragma unroll
-  for (int round = 0; round < 2; ++round) {
-    const uint64_t active = __ballot(valid);
-    if (!active) return;
-    const int leader = __ffsll((unsigned long long)active) - 1;
-    const uint32_t lb = (uint32_t)__shfl((int)bin, leader);
-    const bool mine = valid && bin == lb;
-    const uint64_t same = __ballot(mine);
-    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&h[lb], (uint32_t)__popcll((unsigned long long)same));
-    valid = valid && !mine;
-  }
-  if (valid) atomicAdd(&h[bin], 1u);
-}
+__device__ __forceinline__ void hist_add_wave(uint32_t* h, uint32_t bin, bool valid) { topk_hist_add_wave(h, bin, valid); }
 
 __global__ __launch_bounds__(256) void radix_hist_kernel(const float* scores, int64_t n, int pass, uint32_t k, const uint32_t* hist_prev,
                                                          uint32_t* hist, RadixCtl* ctl, TopkBatch tb) {

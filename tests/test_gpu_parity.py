@@ -814,6 +814,17 @@ def test_fde_batched_coarse_scan_matches_the_single_query_scan(mv, n, stride):
     single_tile = ix.query_batch(queries, kk, mode="fde", allows=per_q, n_docs=n_docs)
     for (s0, i0), (s3, i3) in zip(paired, single_tile):
         assert i0.tolist() == i3.tolist() and s0.tolist() == s3.tolist()
+    # MV_OPT_FDE_BATCH_VARIANT = 5: the default scan with the round-2 selection -- the finish pass does not pre-bin the scores for the
+    # radix selection's first pass (the default does when k > 32 and n > 4096; 3 does not either): the same answers
+    ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, 5)
+    for kind_allows in (per_q, None):
+        ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, 5)
+        three_pass = ix.query_batch(queries, kk, mode="fde", allows=kind_allows, n_docs=n_docs)
+        ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, 0)
+        for rep in range(2):  # twice: the pre-binned histograms must be left clean for the next selection
+            fused = ix.query_batch(queries, kk, mode="fde", allows=kind_allows, n_docs=n_docs)
+            for (s0, i0), (s5, i5) in zip(fused, three_pass):
+                assert i0.tolist() == i5.tolist() and s0.tolist() == s5.tolist()
     # MV_OPT_FDE_BATCH_VARIANT = 4: 32-page tiles, two workgroups per CU, four tiles per fragment set -- the same K order and
     # the same order of the four waves' partial sums per page -> the same scores bit for bit
     ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, 4)
