@@ -224,6 +224,8 @@ __global__ __launch_bounds__(256, 2) void maxsim_batch_kernel(BKArgs a) {
               const f32x4 cin = j == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[m];
               acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[tt & 1][j], qa[m][j], cin, 0, 0, 0);
             }
+          // one row tile per wave: pin the MFMA -> VALU wait states (see maxsim_batch_fp8_kernel; hipcc leaves the branch-target path short)
+          if constexpr (MTW == 1) asm volatile("s_nop 7\n\ts_nop 4" : "+v"(acc[0]));
           if ((t + 1) * kTileRows > nr) {  // partial last tile: mask the patches (rows of D) past n_rows
 #pragma unroll
             for (int i = 0; i < 4; ++i) {

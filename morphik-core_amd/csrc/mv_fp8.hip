@@ -578,6 +578,11 @@ __global__ __launch_bounds__(256, 2) void maxsim_batch_fp8_kernel(F8BatchArgs a)
             for (int m = 0; m < MTW; ++m)
               acc[m] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b[tt & 1], ql[m], acc[m], 0, 0, 0, 0x7f7f7f7f, 0, 0x7b7b7b7b /* 2^-4 */);
           }
+          // One row tile per wave: nothing but a uniform branch (full tiles skip the mask block) separates the MFMA from the maxima
+          // that read its result, and hipcc's hazard pass leaves that branch-target path short of the wait states an 8-pass MFMA
+          // result needs before a VALU read (ISA of this instantiation: s_cbranch straight onto v_max3_f32) -- two queries over
+          // 1.25 M pages came back as garbage.  Pinned here; with two or more tiles the other tiles' MFMAs cover the distance.
+          if constexpr (MTW == 1) asm volatile("s_nop 7\n\ts_nop 4" : "+v"(acc[0]));
           if ((t + 1) * 16 > nr) {  // partial last tile: mask the patches (rows of D) past n_rows
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
