@@ -140,8 +140,10 @@ typedef enum {
                                     3 = as 0 with one page tile per query fragment (the first form of the coarse kernel; the
                                     default walks a workgroup's tiles in pairs: same scores, half the fragment traffic);
                                     4 = 32-page tiles, two workgroups per CU, four tiles per fragment set (same scores);
-                                    5 = as 0 with the round-2 selection: the scan's finish pass does not pre-bin the scores, the
-                                    selection runs all three of its passes (same results; 3 does the same) */
+                                    5 = as 0 with the round-2 structure: the cosine rule / tombstones as a finish pass of their
+                                    own (the default applies them where the scan kernel writes a tile's scores) and all three
+                                    passes of the selection (variants 3 / 4 let their finish pass pre-bin the scores for the
+                                    selection's first pass); the same results bit for bit */
 } mv_option;
 
 /* Bumped whenever a signature, a struct layout or an enum value of this header changes incompatibly.  A binding compares

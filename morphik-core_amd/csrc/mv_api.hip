@@ -1463,10 +1463,12 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
     sa.hi_only = ix->fde_batch_variant == 2;
     sa.single_tile = ix->fde_batch_variant == 3;
     sa.half_tiles = ix->fde_batch_variant == 4;
-    // the finish pass of the coarse scan bins every request's scores for the selection's first radix pass (variant 3, the
-    // cross-check form, keeps the separate three-pass selection)
+    sa.separate_finish = ix->fde_batch_variant == 5;
+    // Default: the scan kernel applies the cosine rule / tombstones itself (no finish pass) and the selection runs its three
+    // vectorised passes.  Where a finish pass runs anyway (variants 3 / 4, or a dot-product index with masks) it also bins every
+    // request's scores for the selection's first radix pass; variant 5 is the round-2 pipeline (separate finish, three passes).
     const int32_t k_sel = rerank ? (int32_t)nc : k;
-    if (ix->fde_batch_variant != 3 && ix->fde_batch_variant != 5 && topk_uses_radix(n, k_sel)) {
+    if (ix->fde_batch_variant != 5 && topk_uses_radix(n, k_sel)) {
       sa.hist0 = topk_radix_hist0(ix->d_btopk_ws);
       sa.hist0_stride_bytes = (int64_t)ix->topk_ws_bytes;
     }

@@ -212,8 +212,15 @@ struct FdeScanBatchArgs {
   // Only honoured when a finish pass runs (inv_norm or doc_ord given): fde_scan_batch_prebins().
   uint32_t* hist0;
   int64_t hist0_stride_bytes;
+  int32_t separate_finish;    // 1: keep the finish a pass of its own even where the scan kernel could apply it (MV_OPT_FDE_BATCH_VARIANT 5)
 };
-inline bool fde_scan_batch_prebins(const FdeScanBatchArgs& a) { return a.hist0 != nullptr && (a.inv_norm != nullptr || a.doc_ord != nullptr); }
+// the default (paired-tile) kernel applies the cosine rule and the tombstones where it writes a tile's scores: no finish pass
+inline bool fde_scan_batch_fuses_finish(const FdeScanBatchArgs& a) {
+  return a.inv_norm != nullptr && !a.single_tile && !a.half_tiles && !a.separate_finish;
+}
+inline bool fde_scan_batch_prebins(const FdeScanBatchArgs& a) {
+  return a.hist0 != nullptr && (a.inv_norm != nullptr || a.doc_ord != nullptr) && !fde_scan_batch_fuses_finish(a);
+}
 bool fde_scan_batch_supported(int64_t out_dim);
 size_t fde_scan_batch_image_bytes(int64_t out_dim);
 int launch_fde_scan_batch(const FdeScanBatchArgs& a, hipStream_t s);

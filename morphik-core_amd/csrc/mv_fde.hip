@@ -721,6 +721,8 @@ struct ScanBatchArgs {
   int32_t out_dim;
   int32_t n_queries;
   int32_t n_tiles;     // ceil(n / 64)
+  const float* inv_norm;    // FIN kernels: the cosine rule and the tombstones are applied where the scores are written
+  const int32_t* doc_ord;   // nullable (no tombstones)
 };
 
 constexpr int kFbPages = 64;
@@ -970,13 +972,24 @@ __device__ __forceinline__ void fb_static_for(F&& f) {
 }
 
 // n_groups groups of T tiles: tiles i0 + grp*T + j of this workgroup's list b, b + G, b + 2G, ...
-template <int NQT, bool LO, int T>
+// FIN: the finish of the pass (scores *= 1/|d|, -inf for tombstoned pages) happens where a tile's scores are written, instead of in
+// a second pass over the [queries][pages] matrix (fde_batch_finish_kernel: 54 us of a 4.0 ms pass at 1.25 M pages x 32 queries).
+// A tile's 64 norms and 64 document ordinals travel like its pages: two global_load_lds_dword per wave into a 512-byte LDS
+// record, issued with the tile's slots of every FOURTH K chunk (kc & 3 == 0 is a compile-time property of the unrolled slot, so the
+// counted vmcnt waits stay constants; the re-loads bring the same 512 bytes, +0.4 % requests), landed -- in issue order -- before that
+// slot's own wait returns, read with ds_read at the tile's end.  Every wave issues them (same data, same place: the per-wave
+// counts stay uniform).  Records are double-buffered by group parity: the next group's first slots are issued before this group's
+// epilogue runs.  The arithmetic is the finish kernel's (one fp32 multiply of the same sum): identical scores.
+template <int NQT, bool LO, int T, bool FIN = false>
 __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, float* red, const int lane, const int wave, const int i0,
                                          const int n_groups, const uint32_t (&src_off)[8], const uint32_t (&rd_off)[2]) {
   using bf16x8 = __attribute__((ext_vector_type(8))) short;
   using f32x4 = __attribute__((ext_vector_type(4))) float;
   constexpr int NF = 4 * NQT;              // query fragments per K chunk and wave: (e, qt, hi|lo)
   constexpr int QOPS = LO ? NF : NF / 2;   // fragment loads per K chunk and wave
+  constexpr int MOPS = FIN ? 2 : 0;        // metadata loads per slot of a K chunk with kc & 3 == 0
+  char* meta = reinterpret_cast<char*>(red) + 4 * 16 * kFbRedStride * 4;  // FIN: [group parity][tile of the group][64 x 1/|d| | 64 x doc ordinal]
+  if constexpr (FIN) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the previous phase's last epilogue has read its records
   const int p = lane & 15, g = lane >> 4;
   const int G = gridDim.x, b = blockIdx.x;
   const int KC = a.out_dim >> 8;
@@ -1068,6 +1081,34 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
             : "memory");
     }
   };
+  auto issue_meta = [&]() {  // the slot being issued belongs to tile (i_grp, i_j): its norms and ordinals -> meta[i_grp & 1][i_j]
+    const int64_t tile = (int64_t)b + (int64_t)(i0 + i_grp * T + i_j) * G;
+    const int64_t page0 = tile * kFbPages;
+    const float* ip = a.inv_norm + page0;
+    const int32_t* op = (a.doc_ord ? a.doc_ord : reinterpret_cast<const int32_t*>(a.inv_norm)) + page0;
+    const uint32_t ilo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ip);
+    const uint32_t ihi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)ip >> 32));
+    const uint32_t olo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)op);
+    const uint32_t ohi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)op >> 32));
+    const uint64_t ipu = ((uint64_t)ihi << 32) | ilo, opu = ((uint64_t)ohi << 32) | olo;
+    const uint32_t rec = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(meta + ((i_grp & 1) * T + i_j) * 512));
+    uint32_t vo = (uint32_t)lane * 4u;
+    if (page0 + kFbPages > a.n) vo = min((uint32_t)lane, (uint32_t)(a.n - 1 - page0)) * 4u;  // last tile: lanes past the corpus re-read its last page
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dword %1, %4\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dword %1, %5\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(vo), "s"(rec), "s"(rec + 256u), "s"(ipu), "s"(opu)
+        : "memory");
+  };
   auto advance = [&]() {
     if (++i_j == T) {
       i_j = 0;
@@ -1079,6 +1120,7 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
   fb_static_for<4>([&](auto UC) {
     constexpr int u = decltype(UC)::value;
     issue_dma(u);
+    if constexpr (FIN && ((u / T) & 3) == 0) issue_meta();
     if constexpr (u % T == 0) issue_q(qf[(u / T) & 3]);
     advance();
   });
@@ -1090,8 +1132,11 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
       constexpr int j = u % T;            // tile of the group
       constexpr int kcs = (u / T) & 3;    // K chunk & 3 -> fragment register set
       const int s = s0 + u;
-      // VMEM operations of the slots x behind this one (8 DMAs + the fragment loads of a chunk's first slot), in issue order
-      constexpr int o1 = 8 + (((u + 1) % T == 0) ? QOPS : 0), o2 = 8 + (((u + 2) % T == 0) ? QOPS : 0), o3 = 8 + (((u + 3) % T == 0) ? QOPS : 0);
+      // VMEM operations of the slots x behind this one (8 DMAs + the fragment loads of a chunk's first slot + the metadata loads of
+      // the slots of every fourth chunk), in issue order
+      constexpr int o1 = 8 + (((u + 1) % T == 0) ? QOPS : 0) + (((((u + 1) % (4 * T)) / T) & 3) == 0 ? MOPS : 0);
+      constexpr int o2 = 8 + (((u + 2) % T == 0) ? QOPS : 0) + (((((u + 2) % (4 * T)) / T) & 3) == 0 ? MOPS : 0);
+      constexpr int o3 = 8 + (((u + 3) % T == 0) ? QOPS : 0) + (((((u + 3) % (4 * T)) / T) & 3) == 0 ? MOPS : 0);
       if (s + 3 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(o1 + o2 + o3) : "memory");
       else if (s + 2 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(o1 + o2) : "memory");
       else if (s + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(o1) : "memory");
@@ -1110,7 +1155,10 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
       for (int e = 0; e < 2; ++e)
 #pragma unroll
         for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(af[e][t]));  // the fragment reads stay in front of the barrier
-      if (s + 4 < total) issue_dma(u & 3);
+      if (s + 4 < total) {
+        issue_dma(u & 3);
+        if constexpr (FIN && ((((u + 4) % (4 * T)) / T) & 3) == 0) issue_meta();
+      }
 #pragma unroll
       for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -1123,7 +1171,7 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
       if (s + 4 < total) {
         if constexpr (j == 0) {  // slot s + 4 opens K chunk (u + 4) / T: its fragments go into that chunk's register set
           // (T = 1: the set the MFMAs above just read; at most 63 VMEM operations may be outstanding)
-          constexpr int peak = 4 * 8 + ((T == 1) ? 4 : (T == 2 ? 2 : 1)) * QOPS;
+          constexpr int peak = 4 * 8 + ((T == 1) ? 4 : (T == 2 ? 2 : 1)) * QOPS + MOPS * T;
           if constexpr (peak > 63) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(63 - QOPS) : "memory");
           issue_q(qf[((u + 4) / T) & 3]);
         }
@@ -1133,6 +1181,13 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
         const int pg = threadIdx.x & 63;
         const int64_t tile = (int64_t)b + (int64_t)(i0 + c_grp * T + j) * G;
         const int64_t page = tile * kFbPages + pg;
+        float inv = 1.0f;
+        bool dead = false;
+        if constexpr (FIN) {  // the record of this tile landed KC slots ago
+          const char* rec = meta + ((c_grp & 1) * T + j) * 512;
+          inv = reinterpret_cast<const float*>(rec)[pg];
+          if (a.doc_ord) dead = reinterpret_cast<const int32_t*>(rec + 256)[pg] < 0;
+        }
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt) {
           if (qt > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone has read the previous query tile's sums
@@ -1147,8 +1202,9 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
             for (int x = 0; x < 4; ++x) {
               const int ql = (threadIdx.x >> 6) + 4 * x;
               if (qt * 16 + ql < a.n_queries) {
-                const float v = (red[(0 * 16 + ql) * kFbRedStride + pg] + red[(1 * 16 + ql) * kFbRedStride + pg]) +
-                                (red[(2 * 16 + ql) * kFbRedStride + pg] + red[(3 * 16 + ql) * kFbRedStride + pg]);
+                float v = (red[(0 * 16 + ql) * kFbRedStride + pg] + red[(1 * 16 + ql) * kFbRedStride + pg]) +
+                          (red[(2 * 16 + ql) * kFbRedStride + pg] + red[(3 * 16 + ql) * kFbRedStride + pg]);
+                if constexpr (FIN) v = dead ? -INFINITY : v * inv;
                 a.scores[(size_t)(qt * 16 + ql) * a.score_stride + page] = v;
               }
             }
@@ -1163,10 +1219,10 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
   }
 }
 
-template <int NQT, bool LO>
+template <int NQT, bool LO, bool FIN = false>
 __global__ __launch_bounds__(256) void fde_scan_batch2_kernel(ScanBatchArgs a) {
   // one __shared__ object only (a second one makes hipcc drain vmcnt before every ds_read)
-  __shared__ __attribute__((aligned(16))) char lds[kFbSlots * kFbSlotBytes + 4 * 16 * kFbRedStride * 4];
+  __shared__ __attribute__((aligned(16))) char lds[kFbSlots * kFbSlotBytes + 4 * 16 * kFbRedStride * 4 + (FIN ? 2 * 2 * 512 : 0)];
   float* red = reinterpret_cast<float*>(lds + kFbSlots * kFbSlotBytes);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1183,8 +1239,8 @@ __global__ __launch_bounds__(256) void fde_scan_batch2_kernel(ScanBatchArgs a) {
   uint32_t rd_off[2];
 #pragma unroll
   for (int e = 0; e < 2; ++e) rd_off[e] = (uint32_t)p * 512u + (((uint32_t)((2 * wave + e) * 4 + g) ^ (uint32_t)p) << 4);
-  fb_phase<NQT, LO, 2>(a, lds, red, lane, wave, 0, n_my / 2, src_off, rd_off);
-  fb_phase<NQT, LO, 1>(a, lds, red, lane, wave, (n_my / 2) * 2, n_my & 1, src_off, rd_off);
+  fb_phase<NQT, LO, 2, FIN>(a, lds, red, lane, wave, 0, n_my / 2, src_off, rd_off);
+  fb_phase<NQT, LO, 1, FIN>(a, lds, red, lane, wave, (n_my / 2) * 2, n_my & 1, src_off, rd_off);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1733,7 +1789,8 @@ int launch_fde_scan_batch(const FdeScanBatchArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(fde_batch_qprep_kernel, dim3((unsigned)(KC * 2 * nqt)), dim3(256), 0, s, a.q, a.n_queries, (int)a.out_dim, nqt, a.image);
   const int64_t n_tiles = (a.n + kFbPages - 1) / kFbPages;
   ScanBatchArgs k{reinterpret_cast<const char*>(a.fde), reinterpret_cast<const char*>(a.image), a.scores, a.score_stride, a.n,
-                  (int32_t)a.out_dim, a.n_queries, (int32_t)n_tiles};
+                  (int32_t)a.out_dim, a.n_queries, (int32_t)n_tiles, a.inv_norm, a.doc_ord};
+  const bool fin = fde_scan_batch_fuses_finish(a);  // the paired-tile kernel applies the cosine rule and the tombstones itself
   const dim3 grid((unsigned)std::min<int64_t>(n_tiles, ncu));
   if (a.half_tiles) {  // 32-page tiles, two workgroups per CU (MV_OPT_FDE_BATCH_VARIANT = 4)
     const int64_t n32 = (a.n + 31) / 32;
@@ -1750,6 +1807,18 @@ int launch_fde_scan_batch(const FdeScanBatchArgs& a, hipStream_t s) {
       else hipLaunchKernelGGL((fde_scan_batch_kernel<2, false>), grid, dim3(256), 0, s, k);
     } else if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch_kernel<1>), grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((fde_scan_batch_kernel<2>), grid, dim3(256), 0, s, k);
+  } else if (fin) {
+    if (a.hi_only) {
+      if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch2_kernel<1, false, true>), grid, dim3(256), 0, s, k);
+      else hipLaunchKernelGGL((fde_scan_batch2_kernel<2, false, true>), grid, dim3(256), 0, s, k);
+    } else if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch2_kernel<1, true, true>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((fde_scan_batch2_kernel<2, true, true>), grid, dim3(256), 0, s, k);
+    // per-request doc filters are a dependent lookup (ordinal -> bitmap word): they stay a pass of their own, masks only
+    if (a.allow && a.doc_ord)
+      hipLaunchKernelGGL(fde_batch_finish_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a.scores, a.score_stride, a.n, a.n_queries,
+                         (const float*)nullptr, a.doc_ord, a.allow, a.n_allow_bits, a.allow_stride_bits);
+    MV_HIP(hipGetLastError());
+    return MV_OK;
   } else if (a.hi_only) {
     if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch2_kernel<1, false>), grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((fde_scan_batch2_kernel<2, false>), grid, dim3(256), 0, s, k);

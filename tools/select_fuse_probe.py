@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Batched FDE pipeline at the full-shard shape: the finish pass that pre-bins the scores for the selection (default) against
-the round-2 three-pass selection (MV_OPT_FDE_BATCH_VARIANT = 5).  Stage medians from the library's own events; one JSON object.
+"""Batched FDE pipeline at the full-shard shape: the default (the scan kernel applies the cosine rule / tombstones where it writes a
+tile's scores; vectorised selection passes) against the round-2 structure (MV_OPT_FDE_BATCH_VARIANT = 5: a finish pass of its own).
+Stage medians from the library's own events; one JSON object.
 
   python tools/select_fuse_probe.py [pages=1250000] [patches=1024]"""
 import json
@@ -27,7 +28,7 @@ def main():
         ix.set_option(L.MV_OPT_FDE_COARSE_N, coarse_n)
         row = {}
         ref = None
-        for variant, name in ((5, "three_pass_selection"), (0, "prebinned_by_the_finish_pass"), (5, "three_pass_selection_again"), (0, "prebinned_again")):
+        for variant, name in ((5, "separate_finish_pass"), (0, "finish_in_the_scan_kernel"), (5, "separate_finish_pass_again"), (0, "finish_in_the_scan_kernel_again")):
             ix.set_option(L.MV_OPT_FDE_BATCH_VARIANT, variant)
             for _ in range(3):
                 ix.query_batch(qs, 10, mode="fde_then_float")
@@ -44,7 +45,7 @@ def main():
             if ref is None:
                 ref = r
             else:
-                row[name]["identical_to_three_pass"] = all(a[1].tolist() == b[1].tolist() and a[0].tolist() == b[0].tolist() for a, b in zip(ref, r))
+                row[name]["identical_to_first"] = all(a[1].tolist() == b[1].tolist() and a[0].tolist() == b[0].tolist() for a, b in zip(ref, r))
         out[f"coarse{coarse_n}"] = row
     ix.set_option(L.MV_OPT_FDE_BATCH_VARIANT, 0)
     ix.close()
