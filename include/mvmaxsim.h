@@ -149,7 +149,7 @@ typedef enum {
 /* Bumped whenever a signature, a struct layout or an enum value of this header changes incompatibly.  A binding compares
  * mv_abi_version() of the library it loaded with the MV_ABI_VERSION it was written against and refuses a mismatch (a stale
  * libmvmaxsim.so driven with newer argument lists would corrupt memory silently). */
-#define MV_ABI_VERSION 3
+#define MV_ABI_VERSION 4
 MV_API int mv_abi_version(void);
 
 MV_API const char* mv_last_error(void);
@@ -293,6 +293,20 @@ MV_API int mv_hamming_batch(int device, const uint8_t* query, const uint8_t* can
 MV_API int64_t mv_fde_output_dim(const mv_fde_config* cfg);
 MV_API int mv_fde_encode(int device, const mv_fde_config* cfg, const float* x, int32_t n_rows, int32_t is_query,
                          float* out);
+
+/* Encoder adapters (A1 / A2, morphik_core_amd/encoder_ops.py): the two elementwise chains of the PaliGemma / Qwen2-VL blocks that the
+ * framework runs as strings of kernels over fp32 copies, each as ONE pass over bf16 operands.  DEVICE pointers, the caller's
+ * stream (0 = the null stream).  The reference formulation is model(**processor(x)) under bf16 autocast
+ * (core/embedding/colpali_embedding_model.py:251-262, 275-305); the arithmetic here is the transformers modules', in their order.
+ *   mv_enc_rmsnorm_bf16   rows x dim bf16 (contiguous).  style 0 (GemmaRMSNorm): bf16((x * rsqrt(mean x^2 + eps)) * (weight_offset + w));
+ *                         style 1 (Llama / Qwen2 RMSNorm): bf16(w * bf16(x * rsqrt(mean x^2 + eps))).  weight: dim values, MV_F32 or MV_BF16.
+ *   mv_enc_gated_act_bf16 out[r][c] = bf16( bf16(act(gate[r][c])) * up[r][c] ), out contiguous rows x cols; gate / up rows start every
+ *                         *_row_stride elements (the two halves of one fused gate|up GEMM output).  act: 0 = gelu (tanh form),
+ *                         1 = silu, 2 = gelu (erf form).  cols, strides: multiples of 8; pointers 16-byte aligned. */
+MV_API int mv_enc_rmsnorm_bf16(int device, const void* d_x, const void* d_weight, int weight_dtype, void* d_out, int64_t rows, int32_t dim,
+                               float eps, float weight_offset, int style, void* stream);
+MV_API int mv_enc_gated_act_bf16(int device, const void* d_gate, int64_t gate_row_stride, const void* d_up, int64_t up_row_stride, void* d_out,
+                                 int64_t rows, int64_t cols, int act, void* stream);
 
 /* Calibration: stream-read `bytes` of device memory `iters` times, returns average GB/s (measured peak
  * for the roofline denominator next to the 8 TB/s datasheet figure). */

@@ -94,7 +94,7 @@ class CandRecC(C.Structure):
 
 
 # every symbol include/mvmaxsim.h declares (tests check the .so exports all of them)
-MV_ABI_VERSION = 3  # include/mvmaxsim.h: the header revision this binding's argument lists were written against
+MV_ABI_VERSION = 4  # include/mvmaxsim.h: the header revision this binding's argument lists were written against
 
 EXPORTS = [
     "mv_abi_version", "mv_last_error", "mv_version", "mv_device_count", "mv_index_create", "mv_index_destroy", "mv_index_set_option",
@@ -104,6 +104,7 @@ EXPORTS = [
     "mv_two_stage_coarse_device", "mv_two_stage_rerank_device", "mv_comm_create", "mv_comm_destroy", "mv_comm_attach", "mv_comm_transport",
     "mv_comm_query_topk", "mv_comm_query_topk_batch", "mv_sign_pack", "mv_hamming_batch",
     "mv_fde_output_dim", "mv_fde_encode", "mv_calibrate_read_bw", "mv_calibrate", "mv_index_save", "mv_index_load",
+    "mv_enc_rmsnorm_bf16", "mv_enc_gated_act_bf16",
 ]
 
 _lock = threading.Lock()
@@ -194,6 +195,8 @@ def lib() -> C.CDLL:
         L.mv_fde_encode.argtypes = [C.c_int, C.POINTER(FdeConfigC), vp, i32, i32, vp]
         L.mv_calibrate_read_bw.argtypes = [C.c_int, i64, i32, C.POINTER(C.c_double)]
         L.mv_calibrate.argtypes = [C.c_int, C.c_int, i64, i32, C.POINTER(C.c_double)]
+        L.mv_enc_rmsnorm_bf16.argtypes = [C.c_int, vp, vp, C.c_int, vp, i64, i32, C.c_float, C.c_float, C.c_int, vp]
+        L.mv_enc_gated_act_bf16.argtypes = [C.c_int, vp, i64, vp, i64, vp, i64, i64, C.c_int, vp]
         L.mv_index_save.argtypes = [vp, C.c_char_p]
         L.mv_index_load.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
         _lib = L

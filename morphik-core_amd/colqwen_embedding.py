@@ -91,7 +91,7 @@ def build_random_colqwen2(preset: str, tokenizer_ids: Dict[str, int], device, dt
 
 class MI355XColQwen2EmbeddingModel(BaseEmbeddingModel):
     def __init__(self, model_name_or_path: Optional[str] = None, model: Any = None, processor: Any = None, device: Optional[str] = None,
-                 batch_size: int = 8):
+                 batch_size: int = 8, fused_ops: Optional[bool] = None):
         import torch
 
         self.torch = torch
@@ -111,6 +111,13 @@ class MI355XColQwen2EmbeddingModel(BaseEmbeddingModel):
             self.processor = ColQwen2Processor.from_pretrained(model_name_or_path)
         else:
             raise ValueError("MI355XColQwen2EmbeddingModel needs a checkpoint directory or a (model, processor) pair")
+        # RMSNorm and the gated-MLP activation as one HIP pass each (encoder_ops.py; MV_ENCODER_FUSED_OPS=0 keeps the framework's kernels)
+        self.fused_ops = {"rmsnorm": 0, "gated_mlp": 0}
+        if self.device.type == "cuda" and fused_ops is not False:
+            from . import encoder_ops
+
+            if fused_ops or encoder_ops.enabled_by_env():
+                self.fused_ops = encoder_ops.patch_encoder(self.model)
 
     # ------------------------------------------------------------------ forward
     def _forward(self, batch) -> Tuple[Any, Any]:

@@ -102,6 +102,7 @@ class MI355XColpaliEmbeddingModel(BaseEmbeddingModel):
                                # 8 -> 109 pages/s, 16 -> 126, 32 -> 140, 64 -> 145 (profiles/r1/embed_batch_probe.json)
         seed: int = 0,
         model: Any = None,
+        fused_ops: Optional[bool] = None,  # None: on for a GPU unless MV_ENCODER_FUSED_OPS=0; False: the framework's own kernels
     ):
         import torch
 
@@ -128,6 +129,13 @@ class MI355XColpaliEmbeddingModel(BaseEmbeddingModel):
             self.model = self._build_random(preset, seed)
             self.random_init = True
         self._patch_embedding_as_gemm()
+        # RMSNorm and the gated-MLP activation as one HIP pass each (encoder_ops.py; MV_ENCODER_FUSED_OPS=0 keeps the framework's kernels)
+        self.fused_ops = {"rmsnorm": 0, "gated_mlp": 0}
+        if self.device.type == "cuda" and fused_ops is not False:
+            from . import encoder_ops
+
+            if fused_ops or encoder_ops.enabled_by_env():
+                self.fused_ops = encoder_ops.patch_encoder(self.model)
         cfg = self.model.config.vlm_config
         self.image_size = int(cfg.vision_config.image_size)
         self.n_image_tokens = (self.image_size // int(cfg.vision_config.patch_size)) ** 2

@@ -1,0 +1,126 @@
+"""Fused elementwise chains for the encoder adapters (A1 / A2): RMSNorm and the gated-MLP activation of the PaliGemma
+(ColPali) and Qwen2-VL / Qwen2.5-VL (ColQwen2) blocks as ONE HIP pass each (csrc/mv_encops.hip) instead of the strings of
+framework kernels the transformers modules run -- about a fifth of the forward's device time on an MI355X
+(profiles/r1/rocprofv3_kernel_stats_embed_b32.csv: GEMM 55 %, attention 17 %, elementwise strings ~20 %).
+
+The reference formulation is `model(**processor(x))` under bf16 autocast
+(core/embedding/colpali_embedding_model.py:251-262, 275-305); `patch_encoder(model)` keeps it: every patched module computes
+what its transformers `forward` computes, in the same order and with the same roundings (the only difference is the summation
+order of the mean inside the norm), and falls back to that `forward` for anything the kernels do not take (not bf16, not on a
+GPU, not contiguous, autograd enabled).  Gate and up projections are also run as one GEMM (their weights become two views of
+one [2I, H] matrix; checkpoints load and save as before).
+
+There is no CPU path here and none is needed: without a GPU the modules simply keep their own forward.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import types
+from typing import Any, Dict
+
+from . import _lib
+
+_ACT = {"gelu_pytorch_tanh": 0, "gelu_tanh": 0, "silu": 1, "swish": 1, "gelu": 2}
+
+
+def _act_code(act_fn: Any, config: Any) -> int:
+    name = getattr(config, "hidden_act", None) or getattr(config, "hidden_activation", None)
+    if isinstance(name, str) and name in _ACT:
+        return _ACT[name]
+    cls = type(act_fn).__name__.lower()
+    if "tanh" in cls:
+        return 0
+    if "silu" in cls or "swish" in cls:
+        return 1
+    if cls in ("geluactivation", "gelu"):
+        return 2
+    return -1
+
+
+def _usable(torch, x) -> bool:
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and not torch.is_grad_enabled() and x.numel() > 0
+            and x.data_ptr() % 16 == 0)
+
+
+def _stream(torch, x) -> int:
+    return torch.cuda.current_stream(x.device).cuda_stream
+
+
+def patch_encoder(model: Any) -> Dict[str, int]:
+    """Patch every RMSNorm / gated MLP of `model` in place.  -> {"rmsnorm": n, "gated_mlp": m} (modules patched)."""
+    import torch
+
+    lib = _lib.lib()
+    counts = {"rmsnorm": 0, "gated_mlp": 0}
+    for mod in model.modules():
+        cls = type(mod).__name__
+        if cls.endswith("RMSNorm") and hasattr(mod, "weight") and not hasattr(mod, "_mv_orig_forward"):
+            eps = float(getattr(mod, "eps", getattr(mod, "variance_epsilon", 1e-6)))
+            gemma = cls.startswith("Gemma")  # (1 + w) in fp32, one rounding; everything else: Llama style (round, then * w)
+            dim = int(mod.weight.shape[0])
+            if dim % 8:
+                continue
+            mod._mv_orig_forward = mod.forward
+
+            def norm_forward(self, x, _eps=eps, _gemma=gemma, _dim=dim):
+                w = self.weight
+                if not (_usable(torch, x) and x.shape[-1] == _dim and w.is_cuda and w.is_contiguous() and w.dtype in (torch.float32, torch.bfloat16)):
+                    return self._mv_orig_forward(x)
+                out = torch.empty_like(x)
+                _lib.check(lib.mv_enc_rmsnorm_bf16(x.device.index or 0, C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()),
+                                                   0 if w.dtype == torch.float32 else 1, C.c_void_p(out.data_ptr()), x.numel() // _dim, _dim,
+                                                   _eps, 1.0 if _gemma else 0.0, 0 if _gemma else 1, C.c_void_p(_stream(torch, x))))
+                return out
+
+            mod.forward = types.MethodType(norm_forward, mod)
+            counts["rmsnorm"] += 1
+        elif all(hasattr(mod, a) for a in ("gate_proj", "up_proj", "down_proj", "act_fn")) and not hasattr(mod, "_mv_orig_forward"):
+            g, u = mod.gate_proj, mod.up_proj
+            if not (isinstance(g, torch.nn.Linear) and isinstance(u, torch.nn.Linear) and g.weight.shape == u.weight.shape):
+                continue
+            act = _act_code(mod.act_fn, getattr(mod, "config", None))
+            inter, hidden = int(g.weight.shape[0]), int(g.weight.shape[1])
+            if act < 0 or inter % 8 or (g.bias is None) != (u.bias is None):
+                continue
+            # one [2I, H] weight, gate_proj / up_proj become its two halves (views: no second copy, state_dict unchanged)
+            with torch.no_grad():
+                fused_w = torch.cat([g.weight.data, u.weight.data], 0).contiguous()
+                g.weight.data = fused_w[:inter]
+                u.weight.data = fused_w[inter:]
+                fused_b = None
+                if g.bias is not None:
+                    fused_b = torch.cat([g.bias.data, u.bias.data], 0).contiguous()
+                    g.bias.data = fused_b[:inter]
+                    u.bias.data = fused_b[inter:]
+            mod._mv_fused_w, mod._mv_fused_b = fused_w, fused_b
+            mod._mv_orig_forward = mod.forward
+
+            def mlp_forward(self, x, _act=act, _inter=inter, _hidden=hidden):
+                fw = self._mv_fused_w
+                if not (_usable(torch, x) and x.shape[-1] == _hidden and fw.is_cuda and fw.dtype == torch.bfloat16
+                        and self.gate_proj.weight.data_ptr() == fw.data_ptr()):  # .to() / load_state_dict re-materialised the halves
+                    return self._mv_orig_forward(x)
+                gu = torch.nn.functional.linear(x, fw, self._mv_fused_b)  # [..., 2I]: gate | up
+                rows = gu.numel() // (2 * _inter)
+                h = torch.empty(x.shape[:-1] + (_inter,), dtype=x.dtype, device=x.device)
+                base = gu.data_ptr()
+                _lib.check(lib.mv_enc_gated_act_bf16(x.device.index or 0, C.c_void_p(base), 2 * _inter, C.c_void_p(base + 2 * _inter), 2 * _inter,
+                                                     C.c_void_p(h.data_ptr()), rows, _inter, _act, C.c_void_p(_stream(torch, x))))
+                return self.down_proj(h)
+
+            mod.forward = types.MethodType(mlp_forward, mod)
+            counts["gated_mlp"] += 1
+    return counts
+
+
+def unpatch_encoder(model: Any) -> None:
+    """Give every patched module its transformers forward back (the fused gate|up weight views stay: they are the same numbers)."""
+    for mod in model.modules():
+        if hasattr(mod, "_mv_orig_forward"):
+            mod.forward = mod._mv_orig_forward
+            del mod._mv_orig_forward
+
+
+def enabled_by_env() -> bool:
+    return os.environ.get("MV_ENCODER_FUSED_OPS", "1") not in ("0", "false", "no")

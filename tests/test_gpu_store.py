@@ -750,6 +750,120 @@ def test_colqwen2_5_forward_on_the_gpu_matches_an_fp32_cpu_forward_of_the_same_w
             assert abs(sg - sw) <= 0.01 * abs(sw), (b, pg, sg, sw)
 
 
+def test_fused_encoder_ops_match_the_transformers_modules():
+    """encoder_ops.patch_encoder: RMSNorm (Gemma style: (1 + w) in fp32; Llama / Qwen2 style: round, then * w) and the gated-MLP
+    activation (tanh-gelu, silu) as one HIP pass each against the transformers modules they replace, same weights, same bf16 input:
+    the same arithmetic in the same order, so the results agree to a bf16 rounding step on a vanishing fraction of the elements (the
+    mean's summation order; the framework's build may contract multiply-adds).  Widths: Gemma-2B (2048 / 16384), Qwen2.5-VL's ViT
+    (1280: the any-width kernel), a width that is no multiple of 8 (left to the framework).  Inputs the kernels do not take
+    (fp32, a strided view) fall back to the module's own forward."""
+    import torch
+    from transformers.models.gemma import modeling_gemma as mg
+    from transformers.models.gemma.configuration_gemma import GemmaConfig
+    from transformers.models.qwen2 import modeling_qwen2 as mq
+    from transformers.models.qwen2.configuration_qwen2 import Qwen2Config
+
+    from morphik_core_amd import encoder_ops
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+
+    def ulps(a, b):  # distance in bf16 steps of the larger magnitude
+        a32, b32 = a.float(), b.float()
+        step = torch.maximum(a32.abs(), b32.abs()).clamp_min(1e-30) * 2.0**-7
+        return ((a32 - b32).abs() / step)
+
+    def check(mod, x, kind):
+        with torch.inference_mode():
+            want = mod(x)
+            n = encoder_ops.patch_encoder(mod)
+            assert n[kind] == 1, n
+            got = mod(x)
+            again = mod(x)
+        assert got.dtype == want.dtype and got.shape == want.shape
+        assert torch.equal(got, again)  # deterministic
+        if kind == "rmsnorm":
+            d = ulps(got, want)
+            frac = float((d > 0).float().mean())
+            print(f"{type(mod).__name__} {tuple(x.shape)}: {100 * frac:.4f} % of the elements differ, at most {float(d.max()):.2f} bf16 steps")
+            assert float(d.max()) <= 2.0 and frac <= 0.02
+        else:  # behind down_proj (a 16 384-term sum; the fused gate|up GEMM also sums in another order): against the output's scale
+            rms = float(want.float().pow(2).mean().sqrt())
+            err = float((got.float() - want.float()).abs().max())
+            cos = float(torch.nn.functional.cosine_similarity(got.float().flatten(), want.float().flatten(), dim=0))
+            print(f"{type(mod).__name__} {tuple(x.shape)}: max |diff| {err:.3e} at output rms {rms:.3e}, cosine {cos:.7f}")
+            assert err <= 0.03 * rms and cos >= 0.99995
+        return mod
+
+    def check_gate_kernel(act, torch_act, rows, cols):
+        # the kernel alone against the framework's two kernels on the same gate / up tensors (the halves of one wider matrix)
+        import ctypes as C
+
+        from morphik_core_amd import _lib
+
+        gu = (torch.randn(rows, 2 * cols, device=dev) * 2.5).to(torch.bfloat16)
+        gate, up = gu[:, :cols], gu[:, cols:]
+        want = torch_act(gate) * up
+        out = torch.empty(rows, cols, dtype=torch.bfloat16, device=dev)
+        _lib.check(_lib.lib().mv_enc_gated_act_bf16(0, C.c_void_p(gate.data_ptr()), 2 * cols, C.c_void_p(up.data_ptr()), 2 * cols,
+                                                    C.c_void_p(out.data_ptr()), rows, cols, act, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        d = ulps(out, want)
+        frac = float((d > 0).float().mean())
+        print(f"gated act {act} [{rows} x {cols}]: {100 * frac:.4f} % of the elements differ, at most {float(d.max()):.2f} bf16 steps")
+        assert float(d.max()) <= 2.0 and frac <= 0.02
+
+    check_gate_kernel(0, lambda t: torch.nn.functional.gelu(t, approximate="tanh"), 517, 16384)
+    check_gate_kernel(1, torch.nn.functional.silu, 333, 11008)
+    check_gate_kernel(2, torch.nn.functional.gelu, 64, 4304 - 4304 % 8)
+
+    # RMSNorm, Gemma style, fp32 and bf16 weights, rows not a multiple of the 4 rows of a block
+    for wdt in (torch.float32, torch.bfloat16):
+        m = mg.GemmaRMSNorm(2048, eps=1e-6).to(dev)
+        m.weight.data = (0.3 * torch.randn(2048, device=dev)).to(wdt)
+        m = check(m, torch.randn(3, 1030, 2048, device=dev).to(torch.bfloat16) * 3.0, "rmsnorm")
+    with torch.inference_mode():  # fallbacks: fp32 input, a strided view
+        xf = torch.randn(2, 5, 2048, device=dev)
+        assert m(xf).dtype == torch.float32
+        xs = torch.randn(4, 7, 4096, device=dev).to(torch.bfloat16)[..., ::2]
+        assert torch.equal(m(xs), m._mv_orig_forward(xs))
+    # RMSNorm, Llama / Qwen2 style: 1280 wide (the any-width kernel), 3584 (7 vectors per lane)
+    for dim in (1280, 3584, 2048):
+        m = mq.Qwen2RMSNorm(dim, eps=1e-6).to(dev).to(torch.bfloat16)
+        m.weight.data = (1.0 + 0.3 * torch.randn(dim, device=dev)).to(torch.bfloat16)
+        check(m, torch.randn(2, 333, dim, device=dev).to(torch.bfloat16) * 2.0, "rmsnorm")
+    odd = mq.Qwen2RMSNorm(1148, eps=1e-6).to(dev).to(torch.bfloat16)
+    assert encoder_ops.patch_encoder(odd)["rmsnorm"] == 0  # not a multiple of 8: left alone
+    # gated MLP: Gemma-2B widths with tanh-gelu; Qwen2 widths with silu
+    gm = mg.GemmaMLP(GemmaConfig(hidden_size=2048, intermediate_size=16384, hidden_act="gelu_pytorch_tanh")).to(dev).to(torch.bfloat16)
+    w_before = {k: v.clone() for k, v in gm.state_dict().items()}
+    gm = check(gm, torch.randn(2, 1030, 2048, device=dev).to(torch.bfloat16), "gated_mlp")
+    assert all(torch.equal(v, w_before[k]) for k, v in gm.state_dict().items())  # the fused gate|up matrix holds the same numbers
+    qm = mq.Qwen2MLP(Qwen2Config(hidden_size=2048, intermediate_size=11008, hidden_act="silu")).to(dev).to(torch.bfloat16)
+    check(qm, torch.randn(3, 77, 2048, device=dev).to(torch.bfloat16), "gated_mlp")
+    # a whole model: the ColQwen2.5 tiny architecture with and without the fused ops -> the same embeddings
+    from morphik_core_amd import colqwen_embedding as CQ
+    from tests import offline_assets as oa
+
+    proc, ids = oa.colqwen2_processor(min_tokens=4, max_tokens=64)
+    model = CQ.build_random_colqwen2("tiny-2.5", ids, "cuda:0", torch.bfloat16, seed=2)
+    rng = np.random.default_rng(9)
+    batch = proc(images=[oa.page_image(rng, 84, 84), oa.page_image(rng, 56, 196)], return_tensors="pt")
+    devb = {k: (v.to("cuda:0") if hasattr(v, "to") else v) for k, v in batch.items()}
+    devb["pixel_values"] = devb["pixel_values"].to(torch.bfloat16)
+    with torch.inference_mode():
+        want = model(**devb).embeddings.float().cpu().numpy()
+        n = encoder_ops.patch_encoder(model)
+        got = model(**devb).embeddings.float().cpu().numpy()
+        encoder_ops.unpatch_encoder(model)
+        back = model(**devb).embeddings.float().cpu().numpy()
+    assert n["rmsnorm"] > 0 and n["gated_mlp"] > 0
+    msk = batch["attention_mask"].numpy() > 0
+    cos = _rowwise_cosine(got[msk], want[msk])
+    print(f"colqwen2.5 tiny, fused {n}: cosine vs the framework forward min {cos.min():.6f}")
+    assert cos.min() >= 0.9995 and np.array_equal(back, want)
+
+
 def test_store_mode_fp8_then_float_returns_the_exact_stores_answers():
     """provider "mi355x_fp8_exact": e4m3 slab in HBM + exact bf16 rows in pinned host RAM.  On the reference's store
     scenarios and on a corpus of near-duplicates it answers like the exact float store (same chunks, same order, scores
