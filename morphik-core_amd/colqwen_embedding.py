@@ -112,7 +112,7 @@ class MI355XColQwen2EmbeddingModel(BaseEmbeddingModel):
         else:
             raise ValueError("MI355XColQwen2EmbeddingModel needs a checkpoint directory or a (model, processor) pair")
         # RMSNorm and the gated-MLP activation as one HIP pass each (encoder_ops.py; MV_ENCODER_FUSED_OPS=0 keeps the framework's kernels)
-        self.fused_ops = {"rmsnorm": 0, "gated_mlp": 0}
+        self.fused_ops = {"rmsnorm": 0, "gated_mlp": 0, "gelu_epilogue": 0}
         if self.device.type == "cuda" and fused_ops is not False:
             from . import encoder_ops
 

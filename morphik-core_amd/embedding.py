@@ -130,7 +130,7 @@ class MI355XColpaliEmbeddingModel(BaseEmbeddingModel):
             self.random_init = True
         self._patch_embedding_as_gemm()
         # RMSNorm and the gated-MLP activation as one HIP pass each (encoder_ops.py; MV_ENCODER_FUSED_OPS=0 keeps the framework's kernels)
-        self.fused_ops = {"rmsnorm": 0, "gated_mlp": 0}
+        self.fused_ops = {"rmsnorm": 0, "gated_mlp": 0, "gelu_epilogue": 0}
         if self.device.type == "cuda" and fused_ops is not False:
             from . import encoder_ops
 

@@ -48,11 +48,11 @@ def _stream(torch, x) -> int:
 
 
 def patch_encoder(model: Any) -> Dict[str, int]:
-    """Patch every RMSNorm / gated MLP of `model` in place.  -> {"rmsnorm": n, "gated_mlp": m} (modules patched)."""
+    """Patch every RMSNorm / gated MLP / tanh-gelu ViT MLP of `model` in place.  -> modules patched per kind."""
     import torch
 
     lib = _lib.lib()
-    counts = {"rmsnorm": 0, "gated_mlp": 0}
+    counts = {"rmsnorm": 0, "gated_mlp": 0, "gelu_epilogue": 0}
     for mod in model.modules():
         cls = type(mod).__name__
         if cls.endswith("RMSNorm") and hasattr(mod, "weight") and not hasattr(mod, "_mv_orig_forward"):
@@ -111,6 +111,25 @@ def patch_encoder(model: Any) -> Dict[str, int]:
 
             mod.forward = types.MethodType(mlp_forward, mod)
             counts["gated_mlp"] += 1
+        elif all(hasattr(mod, a) for a in ("fc1", "fc2", "activation_fn")) and not hasattr(mod, "_mv_orig_forward"):
+            # SigLIP's MLP: fc1 -> tanh-gelu -> fc2.  The activation rides fc1's GEMM as its epilogue (hipBLASLt through
+            # torch._addmm_activation: bias + tanh-gelu on the fp32 accumulator, one rounding) instead of a pass of its own
+            f1, f2 = mod.fc1, mod.fc2
+            if not (isinstance(f1, torch.nn.Linear) and isinstance(f2, torch.nn.Linear) and f1.bias is not None):
+                continue
+            if _act_code(mod.activation_fn, getattr(mod, "config", None)) != 0 or not hasattr(torch, "_addmm_activation"):
+                continue
+            mod._mv_orig_forward = mod.forward
+
+            def vit_mlp_forward(self, x):
+                w = self.fc1.weight
+                if not (_usable(torch, x) and w.is_cuda and w.dtype == torch.bfloat16):
+                    return self._mv_orig_forward(x)
+                h = torch._addmm_activation(self.fc1.bias, x.reshape(-1, x.shape[-1]), w.t(), use_gelu=True)
+                return self.fc2(h).view(x.shape[:-1] + (self.fc2.out_features,))
+
+            mod.forward = types.MethodType(vit_mlp_forward, mod)
+            counts["gelu_epilogue"] += 1
     return counts
 
 
