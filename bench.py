@@ -549,7 +549,7 @@ def main():
                          "fp8_then_float at the shard shape; off by default (the default run pins 52 GB for the 200 k-page two-tier index only)")
     ap.add_argument("--full-shard-pages", type=int, default=1_250_000,
                     help="pages of the e4m3 + FDE + sign-bit index in aux_paths.full_shard (BASELINE configs[3]/[4] per-GPU shard of 10 M pages / 8 GPUs; 0 = skip)")
-    ap.add_argument("--aux-embed-pages", type=int, default=96, help="pages of the full-size encoder run inside aux_paths (0 = skip)")
+    ap.add_argument("--aux-embed-pages", type=int, default=1000, help="pages of the full-size encoder run inside aux_paths (configs[1] names 1 k pages; 0 = skip)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend for N>1 (nccl == RCCL; gloo + MV_BENCH_SINGLE_DEVICE=1 lets N ranks share one GPU to "
                          "exercise the multi-rank path on a 1-GPU box -- a functional check, not a measurement)")
@@ -958,7 +958,7 @@ def main():
                 r = embed_workload(args, args.aux_embed_pages, quick=True)
                 out["aux_paths"]["embed_colpali_v1_2"] = {k: r[k] for k in ("workload", "params", "rows_per_page", "embed_pages_per_s", "embed_model_only_pages_per_s",
                                                                              "embed_tflops_est", "store_device_path_pages_per_s", "query_embed_ms_med",
-                                                                             "query_maxsim_top10_ms_med", "model_batch", "dtype", "data")}
+                                                                             "query_maxsim_top10_ms_med", "model_batch", "chunks_per_call", "fused_encoder_ops", "dtype", "data")}
             except Exception as e:  # noqa: BLE001
                 out["aux_paths"]["embed_colpali_v1_2"] = {"error": repr(e)}
     if dist_on:
