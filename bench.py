@@ -437,35 +437,44 @@ def two_tier(args, device):
 
 
 def fde_encode_block(args, device):
-    """Roofline entry of the FDE DOCUMENT encode (fde.generate_document_encoding, fast_multivector_store.py:447-449 ->
-    fde_encode_mfma_kernel): corpus build of the same pages with and without the FDE slab; the difference is the encode,
-    which reads every page's bf16 rows once (262 144 B) and writes 20 480 B.  Its arithmetic runs on the f32 matrix path
-    (v_mfma_f32_16x16x4_f32, exact fmaf chains): 128 x (20 x 5 SimHash + 20 x 16 AMS) MACs per row as issued ("dense"),
-    of which the AMS part is 128 signed adds per row and repetition in exact arithmetic ("useful")."""
-    from morphik_core_amd import synth
+    """Roofline entry of the FDE DOCUMENT encode (fde.generate_document_encoding, fast_multivector_store.py:447-449): corpus build of
+    the same pages with and without the FDE slab; the difference is the encode, which reads every page's bf16 rows once (262 144 B)
+    and writes 20 480 B.  Default kernel (fde_encode_doc_kernel): the SimHash sketches are k-ordered fp32 fmaf chains on the f32 matrix
+    path (v_mfma_f32_16x16x4_f32: 128 x 112 MACs per row as issued, 7 column tiles), the AMS projection -- a {0, +1, -1} matrix against
+    rows that are already bf16: exact products -- rides the bf16 matrix path (v_mfma_f32_16x16x32_bf16: 128 x 20 x 16 MACs per row as
+    issued).  The round-2 kernel (MV_OPT_FDE_ENCODE_VARIANT 1: both parts on the f32 path, operands from LDS) is timed beside it."""
+    from morphik_core_amd import _lib, synth
     from morphik_core_amd.index import MvIndex
 
     n = min(args.aux_pages, 100_000)
     stride = ((args.patches + 15) // 16) * 16
     t = {}
-    for key, fde in (("gen", False), ("gen_encode", True)):
-        ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=True, with_fde=fde)
-        ix.fill_synthetic(synth.SEED_CORPUS, 0, min(n, 2000), n_rows=args.patches)  # warm-up (tables, clocks)
-        ix.close()
-        ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=True, with_fde=fde)
-        t0 = time.perf_counter()
-        ix.fill_synthetic(synth.SEED_CORPUS, 0, n, n_rows=args.patches)
-        t[key] = time.perf_counter() - t0
-        ix.close()
-    enc = max(t["gen_encode"] - t["gen"], 1e-9)
-    us = enc / n * 1e6
-    dense = 2.0 * args.patches * 128 * (112 + 20 * 16)  # 7 SimHash column tiles (112) + 20 AMS tiles (16 each)
+    for key, fde, variant in (("gen", False, None), ("bf16_pipe", True, 3), ("f32_pipe", True, 1)):
+        for warm in (True, False):
+            ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=True, with_fde=fde)
+            if variant is not None:
+                ix.set_option(_lib.MV_OPT_FDE_ENCODE_VARIANT, variant)
+            t0 = time.perf_counter()
+            ix.fill_synthetic(synth.SEED_CORPUS, 0, min(n, 2000) if warm else n, n_rows=args.patches)  # warm-up: tables, clocks
+            if not warm:
+                t[key] = time.perf_counter() - t0
+            ix.close()
+    enc = max(t["bf16_pipe"] - t["gen"], 1e-9)
+    enc_f32 = max(t["f32_pipe"] - t["gen"], 1e-9)
+    us, us_f32 = enc / n * 1e6, enc_f32 / n * 1e6
+    simhash = 2.0 * args.patches * 128 * 112    # f32 MFMA flops per page as issued (7 column tiles of 16 hashes)
+    ams = 2.0 * args.patches * 128 * (20 * 16)  # AMS flops per page as issued (one 16-column tile per repetition)
     useful = 2.0 * args.patches * 128 * (20 * 5) + args.patches * 128 * 20  # SimHash MACs + one signed add per (dim, repetition)
     return {"pages": n, "us_per_page": round(us, 3), "pages_per_s": round(n / enc, 1), "page_input_GBps": round(args.patches * 256 / us / 1e3, 1),
             "frac_hbm_8TBps": round(args.patches * 256 / us / 1e3 / HBM_PEAK_GBPS, 4),
-            "f32_mfma_TFLOPs_as_issued": round(dense / us / 1e6, 1), "frac_f32_mfma_155TF": round(dense / us / 1e6 / 155.0, 4),
+            "f32_mfma_TFLOPs_as_issued": round(simhash / us / 1e6, 1), "frac_f32_mfma_155TF": round(simhash / us / 1e6 / 155.0, 4),
+            "bf16_mfma_TFLOPs_as_issued": round(ams / us / 1e6, 1),
+            "matrix_pipe_time_frac_est": round((simhash / 155e12 + ams / 2500e12) / (us * 1e-6), 4),
             "useful_TFLOPs": round(useful / us / 1e6, 1),
-            "bound": "f32 MFMA (dense AMS columns; the exact signed-add form would cut the issued flops 3.9x -- DESIGN.md 3.9)",
+            "bound": "per-tile LDS work (bucket-sum atomics, partition ids), not the matrix pipes: by instruction count they are ~11 % busy (SimHash fmaf chains on the f32 pipe = 83 % of those cycles; the AMS projection on the bf16 pipe at 1/16 of its f32 cost) -- DESIGN.md 3.9",
+            "round2_kernel_f32_pipe_only": {"us_per_page": round(us_f32, 3), "pages_per_s": round(n / enc_f32, 1),
+                                            "f32_mfma_TFLOPs_as_issued": round((simhash + ams) / us_f32 / 1e6, 1),
+                                            "frac_f32_mfma_155TF": round((simhash + ams) / us_f32 / 1e6 / 155.0, 4)},
             "corpus_generation_us_per_page": round(t["gen"] / n * 1e6, 3)}
 
 

@@ -123,7 +123,10 @@ typedef enum {
                                  MV_MODE_FLOAT_FP8 batches (the batched block-scaled MFMA scan of the e4m3 slab): 7 = ONE e4m3
                                  term per query row instead of the hi + lo split (half the matrix work; the coarse pass of a
                                  two-tier search), 8 = query by query */
-  MV_OPT_FDE_ENCODE_VARIANT = 8, /* FDE encode: 1 = f32-MFMA kernel (default), 0 = scalar kernel; same partitions bit for bit */
+  MV_OPT_FDE_ENCODE_VARIANT = 8, /* FDE encode of corpus pages: 3 = (default) pages that are already bf16 -- the slab -- take the AMS projection
+                                    through the bf16 matrix pipe (exact products, sums to fp32 rounding) with the SimHash columns in
+                                    registers; other inputs / FDE shapes run as 1; 1 = f32-MFMA kernel, 0 = scalar kernel.  The same
+                                    partitions bit for bit in all three */
   MV_OPT_FILTER_COMPACT_PCT = 9, /* doc filter allowing < this % of the documents: compact the allowed pages first and scan
                                     only those (default 25; 0 = always mask inside the scan) */
   MV_OPT_FDE_QUERY_ENCODE_VARIANT = 11, /* FDE encode of the query (one page, latency matters): 2 = latency kernel, one block per

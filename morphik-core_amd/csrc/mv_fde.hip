@@ -368,6 +368,178 @@ __global__ __launch_bounds__(256) void fde_encode_mfma_kernel(EncMArgs m) {
   }
 }
 
+// ------------------------------------------------------------------------------ documents from the bf16 slab: AMS on the bf16 matrix pipe
+// The corpus build encodes pages that are ALREADY bf16 (the slab), and the AMS projection is a {0, +1, -1} matrix: every product
+// x * (+-1) is exact in bf16 x bf16 -> fp32, so the projection can ride v_mfma_f32_16x16x32_bf16 -- K = 128 in FOUR 16-cycle MFMAs per
+// repetition instead of thirty-two 32-cycle v_mfma_f32_16x16x4_f32 (16 x fewer matrix cycles for the part that was 74 % of them).  Only the
+// summation order inside a 32-wide K block differs from the oracle's ascending chain: the projections agree to fp32 rounding (~1e-7),
+// far inside the bf16 rounding of the slab they are stored in.  The SimHash sketches stay the k-ordered fp32 fmaf chains of the other
+// kernels (v_mfma_f32_16x16x4_f32) -> identical sign bits -> identical partitions, bit for bit; what changes there is the feeding: the
+// Gaussian columns of all NT column tiles live in VGPRs (NT x 32 registers per lane, loop invariant; one wave per SIMD has 512) instead
+// of one ds_read + s_waitcnt in front of every MFMA, and the NT chains are interleaved so no MFMA waits for its predecessor.
+// The next tile's rows are requested before the current tile's arithmetic (one wave per SIMD: nobody else hides the latency).
+// LDS: AMS operand table [R][4 K steps][64 lanes][8 bf16] (80 KiB at R = 20) + acc (40 KiB) + cnt + per-wave x tile / signs / partitions.
+constexpr int kXStrideB = 132;  // bf16 elements per staged row of the document kernel (264 B)
+
+template <int NT>
+__global__ __launch_bounds__(256) void fde_encode_doc_kernel(EncMArgs m) {
+  const EncArgs& a = m.e;
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  using bf16x8 = __attribute__((ext_vector_type(8))) short;
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NP = 1 << a.NS;
+  const int NH = a.R * a.NS;
+  constexpr int NHP = NT * 16;
+  uint16_t* Bt = reinterpret_cast<uint16_t*>(smem);                                  // [R][4][64][8] bf16 AMS operand fragments
+  float* acc = reinterpret_cast<float*>(smem + (size_t)a.R * 4096);                  // [out_dim]
+  int32_t* cnt = reinterpret_cast<int32_t*>(acc + a.out_dim);                        // [R*NP]
+  float* red = reinterpret_cast<float*>(cnt + a.R * NP);                             // [4]
+  uint16_t* xs_all = reinterpret_cast<uint16_t*>(red + 4);                           // [4 waves][16][kXStrideB] the tile's rows, bf16 as they come
+  uint8_t* sg_all = reinterpret_cast<uint8_t*>(xs_all + 4 * 16 * kXStrideB);         // [4 waves][16][NHP] sign bytes
+  uint8_t* pt_all = sg_all + 4 * 16 * NHP;                                           // [4 waves][16][R] partitions
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, k = lane >> 4;
+  uint16_t* xs = xs_all + wave * 16 * kXStrideB;
+  uint8_t* sg = sg_all + wave * 16 * NHP;
+  uint8_t* pt = pt_all + wave * 16 * a.R;
+
+  // ---- once per block: the AMS operand fragments (lane (c = l & 15, g = l >> 4) of K step kk holds column c of dims kk*32 + 8g .. +8)
+  for (int i = threadIdx.x; i < a.R * 4 * 64; i += 256) {
+    const int l = i & 63, kk = (i >> 6) & 3, r = i >> 8;
+    const int c = l & 15, g = l >> 4;
+    uint16_t* dst = Bt + (size_t)i * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int dim = kk * 32 + g * 8 + e;
+      const bool hit = (m.H[r * kDim + dim] & 15) == c && c < a.PD;
+      dst[e] = hit ? (m.S[r * kDim + dim] < 0.f ? (uint16_t)0xbf80u : (uint16_t)0x3f80u) : (uint16_t)0;  // -1.0 / +1.0 / 0 in bf16
+    }
+  }
+  // ---- once per wave: the SimHash columns, in registers: greg[n][s] = G[dim 4s + k][hash 16n + j]
+  float greg[NT][32];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int h = 16 * n + j;
+    const int r = h / a.NS, jj = h - r * a.NS;
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2) greg[n][s2] = h < NH ? a.G[((size_t)r * kDim + (4 * s2 + k)) * a.NS + jj] : 0.f;
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2) asm volatile("" : "+v"(greg[n][s2]));  // loop invariant: keep them where they are
+
+  for (int64_t page = blockIdx.x; page < m.n_pages; page += gridDim.x) {
+    const int32_t nr = a.n_rows ? a.n_rows[page] : a.stride;
+    const uint16_t* pg = a.x_bf16 + (size_t)page * (size_t)a.stride * kDim;
+    __syncthreads();  // tables staged / previous page's finish done with acc
+    for (int i = threadIdx.x; i < (int)a.out_dim; i += 256) acc[i] = 0.0f;
+    for (int i = threadIdx.x; i < a.R * NP; i += 256) cnt[i] = 0;
+    __syncthreads();
+
+    const int ntiles = (nr + 15) >> 4;
+    // rows of a tile as the two kernels need them: 8 x (4 bf16) per lane for the fp32 staging, 4 x (8 bf16) A fragments for the bf16 MFMA
+    uint2 nx[8];
+    u32x4 nab[4];
+    auto request = [&](int t) {
+      const int row0 = t * 16;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int idx = it * 64 + lane, row = idx >> 5, c4 = (idx & 31) * 4;
+        nx[it] = row0 + row < nr ? *reinterpret_cast<const uint2*>(pg + (size_t)(row0 + row) * kDim + c4) : make_uint2(0u, 0u);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        nab[kk] = row0 + j < nr ? *reinterpret_cast<const u32x4*>(pg + (size_t)(row0 + j) * kDim + kk * 32 + k * 8) : u32x4{0u, 0u, 0u, 0u};
+    };
+    if (wave < ntiles) request(wave);
+    for (int t = wave; t < ntiles; t += 4) {
+      const int row0 = t * 16;
+      // ---- this tile's rows (requested one tile ago) -> fp32 staging + bf16 A fragments; then ask for the next tile's
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int idx = it * 64 + lane, row = idx >> 5, c4 = (idx & 31) * 4;
+        *reinterpret_cast<uint2*>(xs + row * kXStrideB + c4) = nx[it];  // 264-byte rows: 8-byte aligned, conflict-free column reads
+      }
+      bf16x8 abf[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) abf[kk] = __builtin_bit_cast(bf16x8, nab[kk]);
+      if (t + 4 < ntiles) request(t + 4);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private LDS: in-order, just make the stores land
+      float af[32];  // A fragments of the fp32 chain: x[row = j][dim = 4s + k]
+#pragma unroll
+      for (int s2 = 0; s2 < 32; ++s2) af[s2] = bf16_to_f32(xs[j * kXStrideB + 4 * s2 + k]);
+      // ---- SimHash sketches: NT independent k-ordered chains, interleaved; only the signs are kept
+      f32x4 c[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) c[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s2 = 0; s2 < 32; ++s2)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) c[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s2], greg[n][s2], c[n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sg[(4 * k + i) * NHP + 16 * n + j] = c[n][i] > 0.0f ? 1 : 0;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // ---- partition ids (Gray code of the NS sign bits) for the 16 x R (row, repetition) pairs
+      for (int pi = lane; pi < 16 * a.R; pi += 64) {
+        const int row = pi & 15, rep = pi >> 4;
+        uint32_t part = 0;
+        for (int jj = 0; jj < a.NS; ++jj) part = (part << 1) + ((uint32_t)sg[row * NHP + rep * a.NS + jj] ^ (part & 1u));
+        pt[row * a.R + rep] = (uint8_t)part;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // ---- AMS projection per repetition on the bf16 pipe + bucket sums
+      for (int rep = 0; rep < a.R; ++rep) {
+        const bf16x8* bt = reinterpret_cast<const bf16x8*>(Bt + (size_t)rep * 2048) + lane;
+        f32x4 pj = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) pj = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abf[kk], bt[kk * 64], pj, 0, 0, 0);
+        if (j < a.PD) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = 4 * k + i;
+            if (row0 + row < nr) {
+              const int part = pt[row * a.R + rep];
+              atomicAdd(&acc[((size_t)rep * NP + part) * a.PD + j], pj[i] * a.scale);
+              if (j == 0) atomicAdd(&cnt[rep * NP + part], 1);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- finish (as fde_encode_kernel): AVERAGE for documents, write fp32 / bf16, inverse norm of the bf16 image
+    float nn = 0.0f;
+    for (int i = threadIdx.x; i < (int)a.out_dim; i += 256) {
+      float v = acc[i];
+      if (!a.is_query) {
+        const int n = cnt[i / a.PD];
+        if (n > 1) v = v / (float)n;
+      }
+      if (a.out_f32) a.out_f32[page * a.out_dim + i] = v;
+      const uint16_t hb = f32_to_bf16_rne(v);
+      if (a.out_bf16) a.out_bf16[page * a.out_dim + i] = hb;
+      const float vb = bf16_to_f32(hb);
+      nn += vb * vb;
+    }
+    if (a.out_inv_norm) {
+#pragma unroll
+      for (int sft = 1; sft < 64; sft <<= 1) nn += __shfl_xor(nn, sft);
+      if (lane == 0) red[wave] = nn;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const float tt = (red[0] + red[1]) + (red[2] + red[3]);
+        a.out_inv_norm[page] = tt > 0.0f ? 1.0f / sqrtf(tt) : 0.0f;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ the QUERY: latency form
 // One query page per request sits in front of every FDE search, so what matters is its latency, not throughput: the
 // bulk kernel above is one persistent block that stages all 20 repetitions' tables (56 KiB) and walks 27 dependent
@@ -1693,8 +1865,25 @@ int launch_fde_encode(const FdeTables& t, const FdeEncodeArgs& a, hipStream_t s)
     MV_HIP(hipGetLastError());
     return MV_OK;
   }
+  if (a.variant == 3 && a.x_bf16 && !a.is_query && PD <= 16 && R * NS > 96 && R * NS <= 112) {
+    // documents from the bf16 slab (default for the corpus build): AMS on the bf16 pipe, SimHash columns in registers (NT = 7 column tiles)
+    const size_t ldsd = (size_t)R * 4096 + (size_t)t.out_dim * 4 + (size_t)R * (1 << NS) * 4 + 16 + (size_t)4 * 16 * kXStrideB * 2 + (size_t)4 * 16 * 112 +
+                        (size_t)4 * 16 * R + 64;
+    if (ldsd <= 160 * 1024) {
+      static int ncu2 = 0;
+      if (ncu2 == 0) {
+        int dev = 0, v = 0;
+        ncu2 = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+      }
+      EncMArgs mm{k, t.H, t.S, a.n_pages};
+      MV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fde_encode_doc_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));
+      hipLaunchKernelGGL((fde_encode_doc_kernel<7>), dim3((unsigned)std::min<int64_t>(a.n_pages, ncu2)), dim3(256), ldsd, s, mm);
+      MV_HIP(hipGetLastError());
+      return MV_OK;
+    }
+  }
   if (a.variant != 0 && PD <= 16 && R * NS <= 128) {
-    // f32-MFMA form (default): persistent blocks, one per CU
+    // f32-MFMA form: persistent blocks, one per CU
     const int NHP = ((R * NS + 15) / 16) * 16;
     const size_t ldsm = (size_t)kDim * NHP * 4 + (size_t)t.out_dim * 4 + (size_t)R * (1 << NS) * 4 + 16 + (size_t)((R * 128 + 15) / 16) * 16 +
                         (size_t)4 * 16 * kXStride * 4 + (size_t)4 * 16 * NHP + (size_t)4 * 16 * R + 64;

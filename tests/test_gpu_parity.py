@@ -697,13 +697,33 @@ def test_fde_slab_same_scores_from_both_encode_kernels(mv):
 
     q = orc.synth_rows(4321, 0, 0, 32)
     outs = []
-    for variant in (0, 1):
+    for variant in (0, 1, 3):  # scalar kernel, f32-MFMA kernel, bf16-slab kernel (AMS on the bf16 matrix pipe: the default)
         ix = _idx(mv, capacity_pages=300, stride_rows=208, with_fde=True)
         ix.set_option(_lib.MV_OPT_FDE_ENCODE_VARIANT, variant)
         ix.fill_synthetic(1234, 0, 300, n_rows=200)
         outs.append(ix.score_all(q, mode="fde"))
         ix.close()
     np.testing.assert_allclose(outs[0], outs[1], rtol=2e-3, atol=2e-4)  # bf16 slab, bucket sums in different orders
+    np.testing.assert_allclose(outs[2], outs[1], rtol=2e-3, atol=2e-4)
+    # the bf16-slab kernel on ragged pages (1 .. stride rows, an empty page) added from the host as bf16 and as fp32 (fp32 rows take the
+    # f32-MFMA kernel: the slab kernel only sees pages that are already bf16), against the oracle's FDE of the same bf16 rows
+    rng = np.random.default_rng(12)
+    stride = 64
+    lens = [1, 15, 16, 17, 33, 64, 0, 48] + [int(x) for x in rng.integers(1, stride + 1, 40)]
+    pages = [orc.synth_rows(77, p, 0, stride)[:n] for p, n in enumerate(lens)]
+    ocfg = orc.FdeConfig.reference_default()
+    fq = orc.fde_encode(ocfg, orc.bf16_to_f32(q), True)
+    want = np.array([orc.fde_coarse_scores(fq, orc.f32_to_bf16(orc.fde_encode(ocfg, orc.bf16_to_f32(pg), False))[None], use_cosine=True)[0]
+                     if len(pg) else 0.0 for pg in pages], np.float32)
+    for as_f32 in (False, True):
+        for variant in (3, 1):
+            ix = _idx(mv, capacity_pages=len(pages), stride_rows=stride, with_fde=True)
+            ix.set_option(_lib.MV_OPT_FDE_ENCODE_VARIANT, variant)
+            ix.add([orc.bf16_to_f32(pg) if as_f32 else pg for pg in pages])
+            got = ix.score_all(q, mode="fde")
+            live = np.array([n > 0 for n in lens])
+            np.testing.assert_allclose(got[live], want[live], rtol=2e-3, atol=2e-4)
+            ix.close()
 
 
 def test_fde_coarse_scan_and_pipeline(mv):
