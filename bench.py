@@ -471,7 +471,7 @@ def fde_encode_block(args, device):
             "bf16_mfma_TFLOPs_as_issued": round(ams / us / 1e6, 1),
             "matrix_pipe_time_frac_est": round((simhash / 155e12 + ams / 2500e12) / (us * 1e-6), 4),
             "useful_TFLOPs": round(useful / us / 1e6, 1),
-            "bound": "per-tile LDS work (bucket-sum atomics, partition ids), not the matrix pipes: by instruction count they are ~11 % busy (SimHash fmaf chains on the f32 pipe = 83 % of those cycles; the AMS projection on the bf16 pipe at 1/16 of its f32 cost) -- DESIGN.md 3.9",
+            "bound": "LDS latency behind the bucket-sum atomics (SQ counters, profiles/r3/pmc_fde_encode_kernels_r3d.json: matrix pipes 11 % busy, waves in s_waitcnt half their cycles); SimHash fmaf chains on the f32 pipe, AMS projection on the bf16 pipe at 1/16 of its f32 cost -- DESIGN.md 3.9",
             "round2_kernel_f32_pipe_only": {"us_per_page": round(us_f32, 3), "pages_per_s": round(n / enc_f32, 1),
                                             "f32_mfma_TFLOPs_as_issued": round((simhash + ams) / us_f32 / 1e6, 1),
                                             "frac_f32_mfma_155TF": round((simhash + ams) / us_f32 / 1e6 / 155.0, 4)},

@@ -485,26 +485,47 @@ __global__ __launch_bounds__(256) void fde_encode_doc_kernel(EncMArgs m) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) sg[(4 * k + i) * NHP + 16 * n + j] = c[n][i] > 0.0f ? 1 : 0;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      // ---- partition ids (Gray code of the NS sign bits) for the 16 x R (row, repetition) pairs
+      // ---- partition ids (Gray code of the NS sign bits) for the 16 x R (row, repetition) pairs, stored [repetition][row]: a lane's
+      //      four rows of one repetition are ONE dword
       for (int pi = lane; pi < 16 * a.R; pi += 64) {
         const int row = pi & 15, rep = pi >> 4;
         uint32_t part = 0;
         for (int jj = 0; jj < a.NS; ++jj) part = (part << 1) + ((uint32_t)sg[row * NHP + rep * a.NS + jj] ^ (part & 1u));
-        pt[row * a.R + rep] = (uint8_t)part;
+        pt[rep * 16 + row] = (uint8_t)part;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      // ---- AMS projection per repetition on the bf16 pipe + bucket sums
+      // ---- AMS projection per repetition on the bf16 pipe + bucket sums.  One wave per SIMD: nothing hides an LDS round trip, so
+      //      the loop is software-pipelined -- the NEXT repetition's four operand fragments and its partition dword are requested
+      //      before this repetition's MFMAs and atomics (LDS returns in order: the atomics queue behind the reads and nobody waits
+      //      for them).  Measured before: 8 exposed round trips per repetition, waves waiting 78 % of their cycles.
+      const bf16x8* bt0 = reinterpret_cast<const bf16x8*>(Bt) + lane;
+      const uint32_t* ptw = reinterpret_cast<const uint32_t*>(pt) + k;  // rows 4k .. 4k+3 of repetition r at dword r*4 + k
+      bf16x8 nb[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) nb[kk] = bt0[kk * 64];
+      uint32_t npw = ptw[0];
+      bool rv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rv[i] = row0 + 4 * k + i < nr;
       for (int rep = 0; rep < a.R; ++rep) {
-        const bf16x8* bt = reinterpret_cast<const bf16x8*>(Bt + (size_t)rep * 2048) + lane;
+        bf16x8 cb[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) cb[kk] = nb[kk];
+        const uint32_t pw = npw;
+        if (rep + 1 < a.R) {
+          const bf16x8* btn = bt0 + (size_t)(rep + 1) * 256;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) nb[kk] = btn[kk * 64];
+          npw = ptw[(rep + 1) * 4];
+        }
         f32x4 pj = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) pj = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abf[kk], bt[kk * 64], pj, 0, 0, 0);
+        for (int kk = 0; kk < 4; ++kk) pj = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abf[kk], cb[kk], pj, 0, 0, 0);
         if (j < a.PD) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const int row = 4 * k + i;
-            if (row0 + row < nr) {
-              const int part = pt[row * a.R + rep];
+            if (rv[i]) {
+              const int part = (int)((pw >> (8 * i)) & 0xffu);
               atomicAdd(&acc[((size_t)rep * NP + part) * a.PD + j], pj[i] * a.scale);
               if (j == 0) atomicAdd(&cnt[rep * NP + part], 1);
             }
