@@ -73,6 +73,41 @@ def test_patch_embedding_gemm_equals_the_convolution(tiny_embedder):
         k.endswith("patch_embedding.weight") for k in tiny_embedder.model.state_dict())
 
 
+def test_fused_encoder_ops_leave_a_model_without_a_gpu_exactly_as_it_was():
+    """encoder_ops.patch_encoder on a CPU model: every RMSNorm / gated MLP / tanh-gelu ViT MLP is found and wrapped, the gate|up weights become
+    two views of one matrix holding the same numbers (state_dict unchanged), and -- no GPU tensor in sight -- every wrapped module falls
+    back to its transformers forward: bit-identical outputs.  The kernels themselves are held to the modules on the GPU
+    (tests/test_gpu_store.py::test_fused_encoder_ops_match_the_transformers_modules)."""
+    import torch
+
+    from morphik_core_amd import encoder_ops
+    from morphik_core_amd.embedding import MI355XColpaliEmbeddingModel
+
+    emb = MI355XColpaliEmbeddingModel(preset="tiny", device="cpu", batch_size=2, seed=4)
+    assert emb.fused_ops == {"rmsnorm": 0, "gated_mlp": 0, "gelu_epilogue": 0}  # never patched on its own without a GPU
+    model = emb.model
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    ids = torch.tensor([[1, 5, 9, 3, 2]])
+    with torch.inference_mode():
+        want = model(input_ids=ids, attention_mask=torch.ones_like(ids)).embeddings.clone()
+    n = encoder_ops.patch_encoder(model)
+    cfg = model.config.vlm_config
+    assert n["rmsnorm"] == 2 * cfg.text_config.num_hidden_layers + 1 and n["gated_mlp"] == cfg.text_config.num_hidden_layers
+    assert n["gelu_epilogue"] == cfg.vision_config.num_hidden_layers
+    assert encoder_ops.patch_encoder(model) == {"rmsnorm": 0, "gated_mlp": 0, "gelu_epilogue": 0}  # idempotent
+    after = model.state_dict()
+    assert set(after) == set(before) and all(torch.equal(after[k], before[k]) for k in before)
+    mlp = next(m for m in model.modules() if hasattr(m, "_mv_fused_w"))
+    assert mlp.gate_proj.weight.data_ptr() == mlp._mv_fused_w.data_ptr()  # the halves ARE the fused matrix
+    with torch.inference_mode():
+        got = model(input_ids=ids, attention_mask=torch.ones_like(ids)).embeddings
+    assert torch.equal(got, want)
+    encoder_ops.unpatch_encoder(model)
+    assert not any(hasattr(m, "_mv_orig_forward") for m in model.modules())
+    with torch.inference_mode():
+        assert torch.equal(model(input_ids=ids, attention_mask=torch.ones_like(ids)).embeddings, want)
+
+
 def test_npy_pages_roundtrip_and_tree_walk(tmp_path):
     rng = np.random.default_rng(0)
     pages = {("docA", 0): rng.standard_normal((5, 128)), ("docA", 2): rng.standard_normal((1, 128)), ("docB", 10): rng.standard_normal((7, 128))}

@@ -18,11 +18,13 @@ LIMIT = 20
 
 
 def regs(tok):
-    m = re.match(r"v\[(\d+):(\d+)\]", tok)
+    """v / a register (range) -> set of ids (AGPRs offset by 1000: MFMA results may live in either file)."""
+    m = re.match(r"([va])\[(\d+):(\d+)\]", tok)
     if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
-    m = re.match(r"v(\d+)$", tok)
-    return {int(m.group(1))} if m else set()
+        base = 1000 if m.group(1) == "a" else 0
+        return set(range(base + int(m.group(2)), base + int(m.group(3)) + 1))
+    m = re.match(r"([va])(\d+)$", tok)
+    return {(1000 if m.group(1) == "a" else 0) + int(m.group(2))} if m else set()
 
 
 def parse(path):
@@ -67,7 +69,7 @@ def scan(ins):
                 if op.startswith("v_mfma") or op in ("s_waitcnt", "s_barrier", "s_endpgm", "s_setpc_b64"):
                     break
                 if op.startswith("v_"):
-                    toks = re.findall(r"v\[\d+:\d+\]|v\d+", x)
+                    toks = re.findall(r"\b[va]\[\d+:\d+\]|\b[va]\d+\b", x)
                     if toks and set().union(*[regs(t) for t in toks]) & dst:
                         found.append((ws, l, x))
                         break
