@@ -967,7 +967,7 @@ def main():
                 r = embed_workload(args, args.aux_embed_pages, quick=True)
                 out["aux_paths"]["embed_colpali_v1_2"] = {k: r[k] for k in ("workload", "params", "rows_per_page", "embed_pages_per_s", "embed_model_only_pages_per_s",
                                                                              "embed_tflops_est", "store_device_path_pages_per_s", "query_embed_ms_med",
-                                                                             "query_maxsim_top10_ms_med", "model_batch", "chunks_per_call", "fused_encoder_ops", "dtype", "data")}
+                                                                             "query_maxsim_top10_ms_med", "model_batch", "chunks_per_call", "fused_encoder_ops", "tuned_gemm_selections", "dtype", "data")}
             except Exception as e:  # noqa: BLE001
                 out["aux_paths"]["embed_colpali_v1_2"] = {"error": repr(e)}
     if dist_on:

@@ -131,11 +131,14 @@ class MI355XColpaliEmbeddingModel(BaseEmbeddingModel):
         self._patch_embedding_as_gemm()
         # RMSNorm and the gated-MLP activation as one HIP pass each (encoder_ops.py; MV_ENCODER_FUSED_OPS=0 keeps the framework's kernels)
         self.fused_ops = {"rmsnorm": 0, "gated_mlp": 0, "gelu_epilogue": 0}
+        self.tuned_gemms = False
         if self.device.type == "cuda" and fused_ops is not False:
             from . import encoder_ops
 
             if fused_ops or encoder_ops.enabled_by_env():
                 self.fused_ops = encoder_ops.patch_encoder(self.model)
+            # GEMM solutions tuned for this architecture's shapes on an MI355X (ignored by PyTorch on any other stack)
+            self.tuned_gemms = encoder_ops.load_tuned_gemms()
         cfg = self.model.config.vlm_config
         self.image_size = int(cfg.vision_config.image_size)
         self.n_image_tokens = (self.image_size // int(cfg.vision_config.patch_size)) ** 2
@@ -234,7 +237,13 @@ class MI355XColpaliEmbeddingModel(BaseEmbeddingModel):
             ids = torch.cat([torch.full((B, self.n_image_tokens), self.image_token_index, device=self.device), prompt.expand(B, -1)], 1)
             mask = torch.ones_like(ids)
         t1 = time.perf_counter()
-        emb = self._forward(ids, mask, pv)
+        if self.tuned_gemms:
+            from .encoder_ops import tuned_gemms
+
+            with tuned_gemms(True):  # the page batches' GEMM shapes are the ones the selections were tuned for
+                emb = self._forward(ids, mask, pv)
+        else:
+            emb = self._forward(ids, mask, pv)
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         t2 = time.perf_counter()

@@ -143,3 +143,52 @@ def unpatch_encoder(model: Any) -> None:
 
 def enabled_by_env() -> bool:
     return os.environ.get("MV_ENCODER_FUSED_OPS", "1") not in ("0", "false", "no")
+
+
+_TUNED_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned")
+
+
+def load_tuned_gemms(name: str = "tunableop_colpali_v1_2_gfx950.csv") -> bool:
+    """hipBLASLt / rocBLAS solution selection for the encoder's GEMM shapes, tuned on an MI355X with PyTorch's TunableOp
+    (tools/tune_encoder_gemms.py; + 9 % pages/s at the reference worker's 16 pages per forward) and shipped as a CSV: TunableOp is
+    switched on WITHOUT tuning and reads the file.  PyTorch itself validates the file's ROCm / hipBLASLt / rocBLAS versions and GPU
+    architecture against the running stack and ignores it on a mismatch; shapes that are not in it take the library default.
+    MV_ENCODER_TUNED_GEMMS=0 leaves TunableOp alone.  -> True when the selections were loaded."""
+    if os.environ.get("MV_ENCODER_TUNED_GEMMS", "1") in ("0", "false", "no"):
+        return False
+    path = os.path.join(_TUNED_DIR, name)
+    if not os.path.exists(path):
+        return False
+    try:
+        import torch.cuda.tunable as tun
+
+        if tun.is_enabled() and tun.tuning_is_enabled():  # somebody is tuning in this process (tuning is on by default once TunableOp is): leave it
+            return False
+        tun.enable(True)
+        tun.tuning_enable(False)
+        ok = bool(tun.read_file(path))
+        tun.enable(False)  # switched on only around the page forwards (tuned_gemms() below): with TunableOp on, shapes that are NOT in
+        return ok          # the file -- every query length -- take a slower default path (query embedding 15 -> 27 ms, measured)
+    except Exception:  # noqa: BLE001 -- an optimisation only: the library defaults are always correct
+        return False
+
+
+class tuned_gemms:
+    """`with tuned_gemms(active):` -- TunableOp (loaded selections, no tuning) for the duration of a page-batch forward."""
+
+    def __init__(self, active: bool):
+        self.active = bool(active)
+
+    def __enter__(self):
+        if self.active:
+            import torch.cuda.tunable as tun
+
+            tun.enable(True)
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            import torch.cuda.tunable as tun
+
+            tun.enable(False)
+        return False

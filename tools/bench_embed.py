@@ -97,7 +97,7 @@ def run(pages=1000, batch=32, feed=16, preset="colpali-v1.2", queries=8):
         "embed_tflops_est": round(flops_page * a.pages / model_s / 1e12, 1),
         "store_device_path_pages_per_s": round(a.pages / store_s, 1), "png_synthesis_s": round(prep_s, 2),
         "query_embed_ms_med": round(float(np.median(q_embed_ms)), 2), "query_maxsim_top10_ms_med": round(float(np.median(q_search_ms)), 3),
-        "model_batch": a.batch, "chunks_per_call": a.feed, "fused_encoder_ops": getattr(emb, "fused_ops", None), "dtype": "bf16", "data": "synthetic page images; random-init weights (no checkpoint in this environment)",
+        "model_batch": a.batch, "chunks_per_call": a.feed, "fused_encoder_ops": getattr(emb, "fused_ops", None), "tuned_gemm_selections": getattr(emb, "tuned_gemms", None), "dtype": "bf16", "data": "synthetic page images; random-init weights (no checkpoint in this environment)",
         "top1_examples": top[:3],
     }
     store.close()
