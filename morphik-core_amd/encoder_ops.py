@@ -98,8 +98,11 @@ def patch_encoder(model: Any) -> Dict[str, int]:
 
             def mlp_forward(self, x, _act=act, _inter=inter, _hidden=hidden):
                 fw = self._mv_fused_w
-                if not (_usable(torch, x) and x.shape[-1] == _hidden and fw.is_cuda and fw.dtype == torch.bfloat16
-                        and self.gate_proj.weight.data_ptr() == fw.data_ptr()):  # .to() / load_state_dict re-materialised the halves
+                if fw is not None and self.gate_proj.weight.data_ptr() != fw.data_ptr():
+                    # .to() / .half() re-materialised the halves: the fused copy is stale -- release it (a 3.6 GB copy per model at
+                    # Gemma-2B size) and leave this module to its own forward from now on
+                    fw = self._mv_fused_w = self._mv_fused_b = None
+                if fw is None or not (_usable(torch, x) and x.shape[-1] == _hidden and fw.is_cuda and fw.dtype == torch.bfloat16):
                     return self._mv_orig_forward(x)
                 gu = torch.nn.functional.linear(x, fw, self._mv_fused_b)  # [..., 2I]: gate | up
                 rows = gu.numel() // (2 * _inter)

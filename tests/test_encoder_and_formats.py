@@ -102,6 +102,11 @@ def test_fused_encoder_ops_leave_a_model_without_a_gpu_exactly_as_it_was():
     with torch.inference_mode():
         got = model(input_ids=ids, attention_mask=torch.ones_like(ids)).embeddings
     assert torch.equal(got, want)
+    model.float()  # re-materialises every parameter: the fused gate|up copy is stale now and must be let go, not used
+    with torch.inference_mode():
+        model(input_ids=ids, attention_mask=torch.ones_like(ids))
+    assert mlp._mv_fused_w is None and mlp.gate_proj.weight.dtype == torch.float32
+    model.to(torch.bfloat16)  # bf16 -> fp32 -> bf16 is exact: the same weights again
     encoder_ops.unpatch_encoder(model)
     assert not any(hasattr(m, "_mv_orig_forward") for m in model.modules())
     with torch.inference_mode():
