@@ -102,11 +102,14 @@ def test_fused_encoder_ops_leave_a_model_without_a_gpu_exactly_as_it_was():
     with torch.inference_mode():
         got = model(input_ids=ids, attention_mask=torch.ones_like(ids)).embeddings
     assert torch.equal(got, want)
-    model.float()  # re-materialises every parameter: the fused gate|up copy is stale now and must be let go, not used
+    import copy
+
+    twin = copy.deepcopy(model).float()  # re-materialises every parameter: the fused gate|up copy is stale there and must be let go, not used
+    tmlp = next(m for m in twin.modules() if hasattr(m, "_mv_fused_w"))
     with torch.inference_mode():
-        model(input_ids=ids, attention_mask=torch.ones_like(ids))
-    assert mlp._mv_fused_w is None and mlp.gate_proj.weight.dtype == torch.float32
-    model.to(torch.bfloat16)  # bf16 -> fp32 -> bf16 is exact: the same weights again
+        twin(input_ids=ids, attention_mask=torch.ones_like(ids))
+    assert tmlp._mv_fused_w is None and tmlp.gate_proj.weight.dtype == torch.float32
+    assert mlp._mv_fused_w is not None  # the original keeps its own
     encoder_ops.unpatch_encoder(model)
     assert not any(hasattr(m, "_mv_orig_forward") for m in model.modules())
     with torch.inference_mode():
