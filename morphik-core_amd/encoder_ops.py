@@ -176,22 +176,35 @@ def load_tuned_gemms(name: str = "tunableop_colpali_v1_2_gfx950.csv") -> bool:
         return False
 
 
+_tuned_lock = __import__("threading").Lock()
+_tuned_users = 0
+
+
 class tuned_gemms:
-    """`with tuned_gemms(active):` -- TunableOp (loaded selections, no tuning) for the duration of a page-batch forward."""
+    """`with tuned_gemms(active):` -- TunableOp (loaded selections, no tuning) for the duration of a page-batch forward.  The switch is
+    process-wide, so concurrent forwards are counted: it goes off when the last of them leaves."""
 
     def __init__(self, active: bool):
         self.active = bool(active)
 
     def __enter__(self):
+        global _tuned_users
         if self.active:
             import torch.cuda.tunable as tun
 
-            tun.enable(True)
+            with _tuned_lock:
+                _tuned_users += 1
+                if _tuned_users == 1:
+                    tun.enable(True)
         return self
 
     def __exit__(self, *exc):
+        global _tuned_users
         if self.active:
             import torch.cuda.tunable as tun
 
-            tun.enable(False)
+            with _tuned_lock:
+                _tuned_users -= 1
+                if _tuned_users == 0:
+                    tun.enable(False)
         return False
