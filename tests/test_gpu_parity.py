@@ -959,7 +959,10 @@ def test_batched_queries_equal_single_queries_and_oracle(mv, stride, nrows, bvar
     allow = allow_bitmap([d for d in range(n // 3 + 1) if d % 4 != 2])
     pages = orc.bf16_to_f32(ix.read_pages(0, n)[:, :nrows])
     # [32, 32] / [16] * 4: <= 64 rows in all -- the single-row-tile instantiations of the row-split forms
-    for lens in ([32], [32, 32], [16] * 4, [32, 32, 32], [32] * 16, [32] * 20, [20, 32, 1, 17], [64] * 8, [16] * 32, [48] * 11, [100, 30]):
+    # [8, 8] / [16] * 3 / 5 / 7: 2, 3, 5, 7 row tiles in the page-split form; [32] * 6 / 10 / 12 / 14: 3, 5, 6, 7 row tiles per wave in the
+    # row-split forms -- every instantiation a launcher can pick is run at least once
+    for lens in ([32], [8, 8], [16] * 3, [32, 32], [16] * 4, [16] * 5, [32, 32, 32], [16] * 7, [32] * 6, [32] * 10, [32] * 12, [32] * 14, [32] * 16,
+                 [32] * 20, [20, 32, 1, 17], [64] * 8, [16] * 32, [48] * 11, [100, 30]):
         qs = [orc.synth_rows(4321, 10 + j, 0, L) for j, L in enumerate(lens)]
         for al in (None, allow):
             got = ix.query_batch(qs, 7, allow=al)
@@ -1274,7 +1277,9 @@ def test_batched_fp8_scan_equals_single_query_scan_and_oracle(mv, stride, nrows)
     codes, inv = ix.read_fp8(0, n)
     # [32, 32] / [16] * 4 / [20, 9]: <= 64 query rows in all = ONE row tile per wave (its own instantiation of the kernel; two
     # requests over a full shard is how the store's coalescer meets it)
-    for lens in ([32], [32, 32], [16] * 4, [20, 9], [32, 32, 32], [32] * 16, [32] * 20, [20, 32, 1, 17], [64] * 8, [16] * 32, [48] * 10):
+    # [32] * 6 / 8 / 10 / 12 / 14: 3 .. 7 row tiles per wave -- every instantiation of the kernel the launcher can pick is run
+    for lens in ([32], [32, 32], [16] * 4, [20, 9], [32, 32, 32], [32] * 6, [32] * 8, [32] * 10, [32] * 12, [32] * 14, [32] * 16, [32] * 20,
+                 [20, 32, 1, 17], [64] * 8, [16] * 32, [48] * 10):
         qs = [orc.synth_rows(4321, 10 + j, 0, L) for j, L in enumerate(lens)]
         for al in (None, allow):
             got = ix.query_batch(qs, 7, mode="float_fp8", allow=al)
