@@ -726,6 +726,42 @@ def test_fde_slab_same_scores_from_both_encode_kernels(mv):
             ix.close()
 
 
+@pytest.mark.parametrize("R,NS,PD", [(10, 5, 16), (8, 5, 16), (7, 4, 16), (20, 4, 8), (3, 6, 16)])
+def test_fde_index_with_other_fde_shapes(mv, R, NS, PD):
+    """Indexes built with FDE shapes other than the reference's 20 x 32 x 16: 5 120 dims (the second unrolled single-query scan), 4 096
+    (batched GEMM scan with 16 K chunks), 1 792 / 2 560 / 3 072 dims (the any-width scan; the batched entry point then runs query by query
+    unless the width is a multiple of 1 024).  The document-encode kernel of the corpus build falls back where its 7-column-tile form does
+    not apply.  Coarse scores against the oracle's FDE of the same rows; the batched pipeline against the single-query one."""
+    from morphik_core_amd import _lib
+    from morphik_core_amd.index import FdeConfig
+
+    cfg = FdeConfig(num_repetitions=R, num_simhash_projections=NS, projection_dimension=PD, seed=9)
+    ocfg = orc.FdeConfig(128, R, NS, PD, 9)
+    N, stride = 333, 64
+    ix = _idx(mv, capacity_pages=N, stride_rows=stride, with_fde=True, fde=cfg)
+    assert ix.fde_config.output_dim == R * (1 << NS) * PD
+    ix.fill_synthetic(1234, 0, N, n_rows=50, pages_per_doc=3)
+    ix.remove_doc(4)
+    pages = ix.read_pages(0, N)[:, :50]
+    queries = [orc.synth_rows(4321, 60 + b, 0, 20 + b) for b in range(5)]
+    fds = np.stack([orc.f32_to_bf16(orc.fde_encode(ocfg, orc.bf16_to_f32(pg), False)) for pg in pages])
+    for q in queries[:2]:
+        fq = orc.fde_encode(ocfg, orc.bf16_to_f32(q), True)
+        want = orc.fde_coarse_scores(fq, fds, use_cosine=True)
+        got = ix.score_all(q, mode="fde")
+        live = np.isfinite(got)
+        assert (~live).sum() == 3  # the tombstoned document's pages
+        np.testing.assert_allclose(got[live], want[live], rtol=2e-3, atol=2e-4 * max(1.0, float(np.abs(want).max())))
+    for mode, k in (("fde", 40), ("fde_then_float", 5)):
+        batch = ix.query_batch(queries, k, mode=mode)
+        for q, (s, i) in zip(queries, batch):
+            ws, wi = ix.query(q, k, mode=mode)
+            assert len(i) == len(wi)
+            np.testing.assert_allclose(s, ws, rtol=1e-4, atol=1e-6)
+            assert len(set(i.tolist()) & set(wi.tolist())) >= len(wi) - 2  # near-ties may swap at the cut
+    ix.close()
+
+
 def test_fde_coarse_scan_and_pipeline(mv):
     from morphik_core_amd import _lib, synth
 
