@@ -828,7 +828,7 @@ def test_fused_encoder_ops_match_the_transformers_modules():
         xs = torch.randn(4, 7, 4096, device=dev).to(torch.bfloat16)[..., ::2]
         assert torch.equal(m(xs), m._mv_orig_forward(xs))
     # RMSNorm, Llama / Qwen2 style: 1280 wide (the any-width kernel), 3584 (7 vectors per lane)
-    for dim in (1280, 3584, 2048):
+    for dim in (1280, 3584, 2048, 512, 1024, 1536, 2560, 3072, 4096, 4608):  # every width instantiation of the one-wave-per-row kernel + the any-width one
         m = mq.Qwen2RMSNorm(dim, eps=1e-6).to(dev).to(torch.bfloat16)
         m.weight.data = (1.0 + 0.3 * torch.randn(dim, device=dev)).to(torch.bfloat16)
         check(m, torch.randn(2, 333, dim, device=dev).to(torch.bfloat16) * 2.0, "rmsnorm")
