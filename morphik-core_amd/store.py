@@ -33,7 +33,7 @@ from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .models import BaseVectorStore, DocumentChunk, build_store_metrics
+from .models import BaseVectorStore, DocumentChunk, build_store_metrics, hit_chunk_builder
 from .payloads import DEFAULT_APP_ID, PayloadStore, is_storage_key, parse_metadata, storage_backend_name
 
 logger = logging.getLogger(__name__)
@@ -151,6 +151,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         self._allow_cache: Dict[Any, Tuple[int, Any, bool]] = {}
         self._last_store_metrics: Dict[str, Any] = {}
         self.last_query_timing: Dict[str, float] = {}
+        self._hit_chunk = hit_chunk_builder()
 
     # ------------------------------------------------------------------ lifecycle
     def _devices(self) -> List[int]:
@@ -523,13 +524,12 @@ class MI355XMultiVectorStore(BaseVectorStore):
         else:
             raise RuntimeError("query_similar: the index was compacted during every attempt")
         t_scan = time.perf_counter()
+        hit = self._hit_chunk  # models.hit_chunk_builder(): the stored values were validated at ingest
         if self.enable_external_storage and self._payloads is not None:
             contents, metas = await self._resolve_contents([r for _s, r in hits], skip_image_content)
-            out = [DocumentChunk(document_id=r[0], chunk_number=r[1], content=c, embedding=[], metadata=m, score=s)
-                   for (s, r), c, m in zip(hits, contents, metas)]
+            out = [hit(r[0], r[1], c, m, s) for (s, r), c, m in zip(hits, contents, metas)]
         else:  # in-memory payload table: nothing to fetch, no coroutine, one pass over the hits
-            out = [DocumentChunk(document_id=r[0], chunk_number=r[1], content=r[2], embedding=[], metadata=parse_metadata(r[3]), score=s)
-                   for s, r in hits]
+            out = [hit(r[0], r[1], r[2], parse_metadata(r[3]), s) for s, r in hits]
         if self.mode == "fde_then_float" and logger.isEnabledFor(logging.INFO):
             t_end = time.perf_counter()
             logger.info(f"query_similar timing - load_contents: {(t_end - t_scan)*1000:.2f} ms")
