@@ -903,8 +903,8 @@ __global__ __launch_bounds__(256) void fde_scan_generic_kernel(ScanArgs a) {
 //   * the fp32 query FDE enters as bf16 hi + bf16 lo (two MFMAs per fragment): 16 mantissa bits, so the coarse scores
 //     agree with the fp32-query scan above to ~1e-5 relative; the slab is bf16 either way;
 //   * tile end: the four waves' partial sums meet in LDS and are added in a fixed order (deterministic), 64 x 16
-//     scores leave as 256-byte rows.  Masks / cosine normalisation are applied by fde_batch_finish_kernel (a global
-//     load in this loop would make the compiler wait for the whole ring).
+//     scores leave as 256-byte rows.  Cosine rule / tombstones: in the tile epilogue of the FIN instantiations (metadata through
+//     the DMA ring: a plain global load in this loop would make the compiler drain it), else by fde_batch_finish_kernel.
 struct ScanBatchArgs {
   const char* fde;     // [n][out_dim] bf16
   const char* qfrag;   // fragment-ordered hi/lo image of the queries (fde_batch_qprep_kernel)
