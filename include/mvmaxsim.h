@@ -38,7 +38,11 @@ typedef enum { MV_F32 = 0, MV_BF16 = 1 } mv_dtype;
 typedef enum {
   MV_MODE_FLOAT = 0,          /* exact float MaxSim over every page (score_multi_vector semantics) */
   MV_MODE_BINARY = 1,         /* sign-bit MaxSim == SQL max_sim(bit[],bit[]) */
-  MV_MODE_FDE_THEN_FLOAT = 2, /* FDE coarse top-n_coarse -> exact float rerank (FastMultiVectorStore) */
+  MV_MODE_FDE_THEN_FLOAT = 2, /* FDE coarse top-n_coarse -> exact float rerank (FastMultiVectorStore).  The rerank reads the index's
+                                 exact tier: the bf16 slab, else the pinned-host tier of MV_WITH_HOST_EXACT (a list longer than
+                                 MV_OPT_RERANK_N is first re-scored on the e4m3 slab, when there is one, and only its
+                                 max(MV_OPT_RERANK_N, k) best entries are read over PCIe).  An index with neither exact tier
+                                 reranks on its e4m3 slab: NOT the reference's exact rerank (scores 0.3-1 % off) */
   MV_MODE_FDE_ONLY = 3,       /* coarse FDE scores only (the TurboPuffer ANN stage) */
   MV_MODE_FLOAT_FP8 = 4,      /* exact float MaxSim over the e4m3 slab (BASELINE configs[4]; 128 B / patch row) */
   MV_MODE_FP8_THEN_FLOAT = 5  /* e4m3 scan of every page -> top-n (MV_OPT_RERANK_N, default 128) -> exact bf16 re-score of the n
@@ -133,9 +137,13 @@ typedef enum {
                                     repetition (default), 1 = the bulk f32-MFMA kernel, 0 = scalar kernel; same partitions bit for bit */
   MV_OPT_LONG_QUERY_VARIANT = 10, /* single query of > 64 rows over the whole slab: 1 = row-split workgroup of the batched scan
                                     (default), 0 = page-split kernel in passes of 128 rows */
-  MV_OPT_RERANK_N = 13,          /* MV_MODE_FP8_THEN_FLOAT: candidates re-scored exactly (1..1024, default 128) */
-  MV_OPT_EXACT_TIER = 14,        /* MV_MODE_FP8_THEN_FLOAT on an index holding BOTH exact tiers: 0 = the bf16 slab in HBM (default),
-                                    1 = the pinned-host tier (what an index without a bf16 slab always uses) */
+  MV_OPT_RERANK_N = 13,          /* candidates read from the exact tier (1..1024, default 128): the list of MV_MODE_FP8_THEN_FLOAT; in
+                                    MV_MODE_FDE_THEN_FLOAT over a pinned-host exact tier the cut of the e4m3 pruning stage (coarse lists
+                                    up to this length -- the reference's min(10 k, 75) -- go to the exact tier whole) */
+  MV_OPT_EXACT_TIER = 14,        /* reranks on an index holding BOTH exact tiers: 0 = the bf16 slab in HBM (default),
+                                    1 = the pinned-host tier (what an index without a bf16 slab always uses), 2 = the e4m3 slab
+                                    (MV_MODE_FDE_THEN_FLOAT / mv_score_candidates only: the scores an index WITHOUT an exact tier
+                                    returns; the host-driven cross-check of the pruning stage uses it) */
   MV_OPT_FDE_BATCH_VARIANT = 12  /* mv_query_topk_batch in the FDE modes: 0 = batched pipeline (default): up to 32 queries per pass
                                     over the FDE slab (bf16 MFMA, query FDE as bf16 hi + lo), batched selection, every query's
                                     candidates reranked in one launch, one read-back; 1 = query by query; 2 = as 0 with the query
@@ -152,7 +160,7 @@ typedef enum {
 /* Bumped whenever a signature, a struct layout or an enum value of this header changes incompatibly.  A binding compares
  * mv_abi_version() of the library it loaded with the MV_ABI_VERSION it was written against and refuses a mismatch (a stale
  * libmvmaxsim.so driven with newer argument lists would corrupt memory silently). */
-#define MV_ABI_VERSION 4
+#define MV_ABI_VERSION 5
 MV_API int mv_abi_version(void);
 
 MV_API const char* mv_last_error(void);
@@ -265,7 +273,8 @@ MV_API int mv_merge_topk(int device, const float* d_scores, const int64_t* d_ids
 MV_API int mv_score_all(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int mode,
                         const uint32_t* allow_bits, int64_t n_allow_words, float* out_scores, int64_t out_cap,
                         int64_t* out_n, mv_query_stats* stats);
-/* Exact float MaxSim of an explicit candidate list (local page ids), in list order.  Replaces
+/* Exact float MaxSim of an explicit candidate list (local page ids), in list order, on the index's exact tier (the bf16 slab,
+ * else the pinned-host tier; an index with neither scores on its e4m3 slab).  Replaces
  * processor.score_multi_vector(...) at fast_multivector_store.py:553-555 (colpali_engine: passages are scored in
  * batches of 128, each batch zero-padded to ITS longest page by pad_sequence, so a page shorter than its batch's
  * longest sees zero rows and every query token's maximum is clamped at 0).
@@ -339,19 +348,34 @@ typedef struct {
   int64_t id;    /* GLOBAL page id */
 } mv_cand_rec;
 
-/* Stage 1 on one shard: FDE coarse scan + local top-n_coarse -> d_out_recs (DEVICE, n_coarse records sorted by
- * (score desc, id asc)).  n_coarse <= 1024.  stream as in mv_query_topk_device (NULL = return when finished). */
-MV_API int mv_two_stage_coarse_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int32_t n_coarse,
+/* Stage 1 on one shard: coarse scan + local top-n_coarse -> d_out_recs (DEVICE, n_coarse records sorted by (score desc, id asc)).
+ *   mode = MV_MODE_FDE_THEN_FLOAT  FDE coarse scan (the reference pipeline)
+ *   mode = MV_MODE_FP8_THEN_FLOAT  e4m3 scan of every page (configs[4]); n_coarse = max(MV_OPT_RERANK_N, k)
+ * n_coarse <= 1024.  stream as in mv_query_topk_device (NULL = return when finished). */
+MV_API int mv_two_stage_coarse_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int32_t n_coarse, int mode,
                                       const uint32_t* allow_bits, int64_t n_allow_words, mv_cand_rec* d_out_recs,
                                       void* stream);
-/* Stage 2 on one shard: d_all_recs = [world][n_coarse] records (the all-gather of stage 1 in shard order, shards
+/* The rerank rule of a list of n_list candidates on THIS index (one rule for every entry point, so a request takes the same path
+ * whatever carries it): *out_tier = 0 bf16 slab in HBM, 1 pinned-host exact tier, 2 e4m3 slab (no exact copy);
+ * *out_n_mid > 0: an e4m3 pruning stage runs first and keeps that many entries (MV_MODE_FDE_THEN_FLOAT over a host tier with
+ * n_list > max(MV_OPT_RERANK_N, k)); batched = the one-launch rerank of a request group (its e4m3 form takes <= 64 rows). */
+MV_API int mv_index_rerank_plan(mv_index* ix, int mode, int32_t n_list, int32_t k, int32_t n_q_rows, int32_t batched,
+                                int32_t* out_n_mid, int32_t* out_tier);
+/* Pruning stage on one shard (only when mv_index_rerank_plan names one): d_all_recs as below; leaves in d_out_mid (DEVICE,
+ * n_coarse floats) the e4m3 MaxSim of the entries of the GLOBAL coarse list this shard owns, -inf elsewhere.  The caller
+ * all-gathers the n_coarse floats of every shard ([world][n_coarse]) and hands them to the rerank stage. */
+MV_API int mv_two_stage_mid_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int mode,
+                                   const mv_cand_rec* d_all_recs, int32_t world, int32_t n_coarse, float* d_out_mid, void* stream);
+/* Last stage on one shard: d_all_recs = [world][n_coarse] records (the all-gather of stage 1 in shard order, shards
  * owning ascending id ranges).  Derives the GLOBAL coarse top-n_coarse (identical on every shard), keeps the
- * candidates this shard owns, reranks them exactly (bf16 slab, else fp8) with the pad length of each candidate's batch
- * of 128 in the GLOBAL list, and leaves the local top-k in d_out_scores / d_out_ids (DEVICE, padded (-inf, -1)).
+ * candidates this shard owns (d_all_mid != NULL: only those among the n_mid best of the gathered pruning scores, ties by list
+ * position), reranks them on the exact tier (bf16 slab, else pinned-host tier, else e4m3 slab) with the pad length of each
+ * candidate's batch of 128 in the GLOBAL list (MV_MODE_FDE_THEN_FLOAT; none for MV_MODE_FP8_THEN_FLOAT), and leaves the local
+ * top-k in d_out_scores / d_out_ids (DEVICE, padded (-inf, -1)).
  * No host synchronisation between the steps; world * n_coarse <= 16384. */
-MV_API int mv_two_stage_rerank_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows,
-                                      const mv_cand_rec* d_all_recs, int32_t world, int32_t n_coarse, int32_t k,
-                                      float* d_out_scores, int64_t* d_out_ids, void* stream);
+MV_API int mv_two_stage_rerank_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int mode,
+                                      const mv_cand_rec* d_all_recs, int32_t world, int32_t n_coarse, const float* d_all_mid,
+                                      int32_t n_mid, int32_t k, float* d_out_scores, int64_t* d_out_ids, void* stream);
 
 /* Single-process communicator over R shards (SURVEY.md 8b "mv_comm_init(n_ranks, device_ids)"): the reference builds
  * ONE store object in ONE process (core/services_init.py:141-165) -- a store that owns 8 GPUs needs the top-k exchange
@@ -368,7 +392,8 @@ MV_API void mv_comm_destroy(mv_comm* c);
 MV_API int mv_comm_attach(mv_comm* c, int32_t shard, mv_index* ix);
 MV_API int mv_comm_transport(const mv_comm* c); /* the transport in use (MV_COMM_RCCL / P2P / HOST) */
 /* Query every shard (scans run concurrently, one stream per shard), exchange, merge: same results, order and tie
- * rule as ONE index holding all pages.  MV_MODE_FDE_THEN_FLOAT runs the two-stage pipeline above.
+ * rule as ONE index holding all pages.  MV_MODE_FDE_THEN_FLOAT and MV_MODE_FP8_THEN_FLOAT run the staged pipeline above (the
+ * candidate list is the GLOBAL one; every shard must keep the same slabs and rerank options).
  * stats (nullable): n_shards entries, per-shard device timings of this query. */
 MV_API int mv_comm_query_topk(mv_comm* c, const void* q, int q_dtype, int32_t n_q_rows, int32_t k, int mode,
                               const uint32_t* allow_bits, int64_t n_allow_words, float* out_scores, int64_t* out_ids,
@@ -376,10 +401,11 @@ MV_API int mv_comm_query_topk(mv_comm* c, const void* q, int q_dtype, int32_t n_
 
 /* A batch of requests against the sharded corpus (the store's request coalescer on a sharded store; every request
  * awaits the same store object: core/services/document_service.py:411-417).  Arguments as mv_query_topk_batch.
- * MV_MODE_FDE_THEN_FLOAT: per group of <= 32 requests ONE pass over every shard's FDE slab, ONE exchange of all the
- * requests' candidate records, every request's share of its GLOBAL candidate list reranked in one launch per shard --
- * the same candidate sets, pad lengths and answers as mv_query_topk_batch on one index.  Other modes run request by
- * request through mv_comm_query_topk.  stats (nullable): n_shards entries, device spans summed over the groups. */
+ * MV_MODE_FDE_THEN_FLOAT / MV_MODE_FP8_THEN_FLOAT: per group of requests (<= 32; <= 1024 / 512 query rows) ONE pass over every
+ * shard's FDE / e4m3 slab, ONE exchange of all the requests' candidate records (+ one of their pruning scores when the rerank
+ * plan has that stage), every request's share of its GLOBAL candidate list reranked in one launch per shard -- the same
+ * candidate sets, pad lengths and answers as mv_query_topk_batch on one index.  Other modes run request by request through
+ * mv_comm_query_topk.  stats (nullable): n_shards entries, device spans summed over the groups. */
 MV_API int mv_comm_query_topk_batch(mv_comm* c, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, int32_t k,
                                     int mode, const uint32_t* allow_bits, int64_t n_allow_words, int32_t allow_per_query,
                                     float* out_scores, int64_t* out_ids, int32_t* out_n, mv_query_stats* stats);

@@ -94,14 +94,14 @@ class CandRecC(C.Structure):
 
 
 # every symbol include/mvmaxsim.h declares (tests check the .so exports all of them)
-MV_ABI_VERSION = 4  # include/mvmaxsim.h: the header revision this binding's argument lists were written against
+MV_ABI_VERSION = 5  # include/mvmaxsim.h: the header revision this binding's argument lists were written against
 
 EXPORTS = [
     "mv_abi_version", "mv_last_error", "mv_version", "mv_device_count", "mv_index_create", "mv_index_destroy", "mv_index_set_option",
     "mv_index_size", "mv_index_capacity", "mv_index_add", "mv_index_add_device", "mv_index_add_bits", "mv_index_remove_doc",
     "mv_index_remove_page", "mv_index_compact", "mv_index_read_pages", "mv_index_write_rows", "mv_index_replace_page", "mv_index_read_fp8", "mv_index_fill_synthetic", "mv_synth_rows",
     "mv_query_topk", "mv_query_topk_device", "mv_query_topk_batch", "mv_merge_topk", "mv_score_all", "mv_score_candidates", "mv_score_candidates_pads", "mv_index_page_rows",
-    "mv_two_stage_coarse_device", "mv_two_stage_rerank_device", "mv_comm_create", "mv_comm_destroy", "mv_comm_attach", "mv_comm_transport",
+    "mv_two_stage_coarse_device", "mv_two_stage_mid_device", "mv_two_stage_rerank_device", "mv_index_rerank_plan", "mv_comm_create", "mv_comm_destroy", "mv_comm_attach", "mv_comm_transport",
     "mv_comm_query_topk", "mv_comm_query_topk_batch", "mv_sign_pack", "mv_hamming_batch",
     "mv_fde_output_dim", "mv_fde_encode", "mv_calibrate_read_bw", "mv_calibrate", "mv_index_save", "mv_index_load",
     "mv_enc_rmsnorm_bf16", "mv_enc_gated_act_bf16",
@@ -178,8 +178,10 @@ def lib() -> C.CDLL:
         L.mv_score_all.argtypes = [vp, vp, C.c_int, i32, C.c_int, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(QueryStatsC)]
         L.mv_score_candidates.argtypes = [vp, vp, C.c_int, i32, vp, i32, i32, vp, C.POINTER(QueryStatsC)]
         L.mv_score_candidates_pads.argtypes = [vp, vp, C.c_int, i32, vp, i32, vp, vp, C.POINTER(QueryStatsC)]
-        L.mv_two_stage_coarse_device.argtypes = [vp, vp, C.c_int, i32, i32, vp, i64, vp, vp]
-        L.mv_two_stage_rerank_device.argtypes = [vp, vp, C.c_int, i32, vp, i32, i32, i32, vp, vp, vp]
+        L.mv_two_stage_coarse_device.argtypes = [vp, vp, C.c_int, i32, i32, C.c_int, vp, i64, vp, vp]
+        L.mv_two_stage_mid_device.argtypes = [vp, vp, C.c_int, i32, C.c_int, vp, i32, i32, vp, vp]
+        L.mv_two_stage_rerank_device.argtypes = [vp, vp, C.c_int, i32, C.c_int, vp, i32, i32, vp, i32, i32, vp, vp, vp]
+        L.mv_index_rerank_plan.argtypes = [vp, C.c_int, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
         L.mv_comm_create.argtypes = [i32, vp, i32, C.POINTER(vp)]
         L.mv_comm_destroy.argtypes = [vp]
         L.mv_comm_destroy.restype = None

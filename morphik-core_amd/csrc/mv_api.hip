@@ -287,7 +287,7 @@ int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_w
 
 // Exact float MaxSim over the e4m3 slab (all query rows in passes of 64 inside the launcher).
 int fp8_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_words, const int32_t* d_cand, int64_t n_items,
-             int32_t pad_to, const int32_t* d_pad_items, float* d_out, int* launches, bool no_mask = false) {
+             int32_t pad_to, const int32_t* d_pad_items, float* d_out, int* launches, bool no_mask) {
   if (n_items <= 0) return MV_OK;
   const bool need_meta = !no_mask && (ix->tombstones.load() || d_allow != nullptr);
   Fp8ScanArgs a{};
@@ -330,32 +330,82 @@ int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_wo
 
 // Exact rerank of the candidate list in d_cand / d_cand_pads (built by launch_cand_prepare or the owned-select kernel).
 // The candidates were named explicitly or chosen from live, allowed pages: no mask is applied.
-int rerank_scan(mv_index* ix, int n_q, bool use_fp8, int64_t n_items, float* d_out, int* launches) {
+int rerank_scan(mv_index* ix, int n_q, bool use_fp8, int64_t n_items, float* d_out, int* launches, const uint16_t* exact) {
   return use_fp8 ? fp8_scan(ix, n_q, nullptr, 0, ix->d_cand, n_items, 0, ix->d_cand_pads, d_out, launches, /*no_mask=*/true)
-                 : float_scan(ix, n_q, nullptr, 0, ix->d_cand, n_items, 0, ix->d_cand_pads, d_out, launches, /*no_mask=*/true);
+                 : float_scan(ix, n_q, nullptr, 0, ix->d_cand, n_items, 0, ix->d_cand_pads, d_out, launches, /*no_mask=*/true, nullptr, exact);
+}
+
+// The tier a rerank reads and whether an e4m3 stage prunes the list first (mv_index_priv.h).  One rule for every entry point
+// (single / batched / sharded), so the same request takes the same path whatever carries it.
+RerankPlan rerank_plan(const mv_index* ix, int mode, int64_t n_list, int32_t k, int rpq, bool batched) {
+  RerankPlan p;
+  const int fl = ix->cfg.flags;
+  const bool force_fp8 = ix->exact_tier == 2 && (fl & MV_WITH_FP8) && mode != MV_MODE_FP8_THEN_FLOAT;  // MV_OPT_EXACT_TIER 2: score on the e4m3 slab although an exact tier exists
+  const bool host = !force_fp8 && ix->d_exact != nullptr && (!(fl & MV_WITH_FLOAT) || ix->exact_tier == 1);
+  p.host_tier = host;
+  p.exact = force_fp8 ? nullptr : (host ? ix->d_exact : ((fl & MV_WITH_FLOAT) ? ix->slab : nullptr));
+  p.final_fp8 = p.exact == nullptr;
+  const int64_t n_mid = std::max<int64_t>(ix->rerank_n, k);
+  // the e4m3 scan of MV_MODE_FP8_THEN_FLOAT already was the pruning stage; the one-launch e4m3 rerank of a batch takes <= 64 rows
+  p.mid = mode == MV_MODE_FDE_THEN_FLOAT && host && (fl & MV_WITH_FP8) && n_list > n_mid && (!batched || rpq <= 64);
+  p.n_mid = p.mid ? (int32_t)n_mid : 0;
+  return p;
+}
+
+// One block per list (lists are <= kTopkMaxDeviceK = 1024 entries): flag the selected positions in LDS, clear the rest.
+__global__ __launch_bounds__(1024) void keep_selected_kernel(const int64_t* pos, int64_t pos_stride, int n_sel, int32_t* cand,
+                                                             int64_t cand_stride, int n) {
+  __shared__ uint8_t keep[kTopkMaxDeviceK];
+  pos += (int64_t)blockIdx.x * pos_stride;
+  cand += (int64_t)blockIdx.x * cand_stride;
+  const int t = threadIdx.x;
+  keep[t] = 0;
+  __syncthreads();
+  if (t < n_sel) {
+    const int64_t p = pos[t];
+    if (p >= 0 && p < n) keep[p] = 1;
+  }
+  __syncthreads();
+  if (t < n && !keep[t]) cand[t] = -1;
+}
+
+int launch_keep_selected(const int64_t* d_pos, int64_t pos_stride, int n_sel, int32_t* d_cand, int64_t cand_stride, int n, int nb, hipStream_t s) {
+  if (n < 1 || nb < 1) return MV_OK;
+  if (n > kTopkMaxDeviceK || n_sel > kTopkMaxDeviceK) { set_error("keep_selected: lists of %d / %d entries exceed %d", n, n_sel, kTopkMaxDeviceK); return MV_ERR_INVALID; }
+  hipLaunchKernelGGL(keep_selected_kernel, dim3((unsigned)nb), dim3(1024), 0, s, d_pos, pos_stride, n_sel, d_cand, cand_stride, n);
+  MV_HIP(hipGetLastError());
+  return MV_OK;
 }
 
 // Core of every query entry point: leaves per-item scores on the device.  Caller holds q_mu.
 int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const uint32_t* allow_bits, int64_t n_words,
-             int64_t want_coarse, ScanResult* out, mv_query_stats* st, bool want_compact = false) {
+             int64_t want_coarse, ScanResult* out, mv_query_stats* st, bool want_compact = false, int32_t k_final = 0) {
   if (!q || n_q <= 0) { set_error("query must have at least one row"); return MV_ERR_INVALID; }
   if (q_dtype != MV_F32 && q_dtype != MV_BF16) { set_error("bad query dtype %d", q_dtype); return MV_ERR_INVALID; }
   const bool want_fde = mode == MV_MODE_FDE_THEN_FLOAT || mode == MV_MODE_FDE_ONLY;
   const bool want_bin = mode == MV_MODE_BINARY;
-  // the rerank stage of FDE_THEN_FLOAT uses the bf16 slab when the index has one, else the fp8 slab
-  const bool rerank_fp8 = mode == MV_MODE_FDE_THEN_FLOAT && !(ix->cfg.flags & MV_WITH_FLOAT) && (ix->cfg.flags & MV_WITH_FP8);
   const bool two_tier = mode == MV_MODE_FP8_THEN_FLOAT;
-  const bool want_fp8 = mode == MV_MODE_FLOAT_FP8 || rerank_fp8 || two_tier;
+  // The rerank stage of FDE_THEN_FLOAT reads the index's exact tier (the bf16 slab, or the pinned-host tier: through an e4m3
+  // pruning stage when the list is longer than MV_OPT_RERANK_N); an index with neither reranks on the e4m3 slab -- the best
+  // copy it holds, NOT the reference's exact fp32 rerank (fast_multivector_store.py:553-556).
+  const int64_t n_pub = ix->size.load(std::memory_order_acquire);
+  const int64_t nc_fde = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want_coarse, n_pub), kTopkMaxDeviceK));
+  const RerankPlan plan = mode == MV_MODE_FDE_THEN_FLOAT ? rerank_plan(ix, mode, nc_fde, k_final, ((n_q + 15) / 16) * 16, false) : RerankPlan{};
+  const bool rerank_fp8 = mode == MV_MODE_FDE_THEN_FLOAT && plan.final_fp8;
+  const bool want_fp8 = mode == MV_MODE_FLOAT_FP8 || rerank_fp8 || plan.mid || two_tier;
   const bool want_float = mode == MV_MODE_FLOAT || (mode == MV_MODE_FDE_THEN_FLOAT && !rerank_fp8) || two_tier;
   if (!want_float && !want_fde && !want_bin && !want_fp8) { set_error("unknown mode %d", mode); return MV_ERR_INVALID; }
   if (two_tier && !(ix->cfg.flags & (MV_WITH_FLOAT | MV_WITH_HOST_EXACT))) { set_error("MV_MODE_FP8_THEN_FLOAT needs an exact tier (MV_WITH_FLOAT or MV_WITH_HOST_EXACT)"); return MV_ERR_STATE; }
-  if (want_float && !two_tier && !(ix->cfg.flags & MV_WITH_FLOAT)) { set_error("index has no float slab (MV_WITH_FLOAT)"); return MV_ERR_STATE; }
-  if (want_fp8 && !(ix->cfg.flags & MV_WITH_FP8)) { set_error("index has no fp8 slab (MV_WITH_FP8)"); return MV_ERR_STATE; }
+  if (mode == MV_MODE_FLOAT && !(ix->cfg.flags & MV_WITH_FLOAT)) { set_error("index has no float slab (MV_WITH_FLOAT)"); return MV_ERR_STATE; }
+  if (want_fp8 && !(ix->cfg.flags & MV_WITH_FP8)) {
+    set_error(rerank_fp8 ? "MV_MODE_FDE_THEN_FLOAT needs a copy of the pages to rerank on (MV_WITH_FLOAT, MV_WITH_HOST_EXACT or MV_WITH_FP8)" : "index has no fp8 slab (MV_WITH_FP8)");
+    return MV_ERR_STATE;
+  }
   if (want_bin && !(ix->cfg.flags & MV_WITH_BINARY)) { set_error("index has no sign-bit slab (MV_WITH_BINARY)"); return MV_ERR_STATE; }
   if (want_fde && !(ix->cfg.flags & MV_WITH_FDE)) { set_error("index has no FDE slab (MV_WITH_FDE)"); return MV_ERR_STATE; }
 
   // snapshot of the published corpus: pages appended while this query runs are not seen
-  const int64_t n = ix->size.load(std::memory_order_acquire);
+  const int64_t n = n_pub;
   const bool ragged = ix->ragged.load();
   int rc = upload_query(ix, q, q_dtype, n_q, want_float, want_fde, want_bin, want_fp8);
   if (rc) return rc;
@@ -419,7 +469,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
       rc = launch_cand_prepare(ix, ix->d_out_id, nullptr, (int)nc, /*pad_sem=*/0);  // a full-corpus scan has no padding rows
       if (rc) return rc;
       if (st) MV_HIP(hipEventRecord(ix->ev_st[2], ix->stream));
-      const uint16_t* exact = ((ix->cfg.flags & MV_WITH_FLOAT) && !(ix->exact_tier == 1 && ix->d_exact)) ? ix->slab : ix->d_exact;
+      const uint16_t* exact = rerank_plan(ix, mode, nc, k_final, ((n_q + 15) / 16) * 16, false).exact;
       rc = float_scan(ix, n_q, nullptr, 0, ix->d_cand, nc, 0, ix->d_cand_pads, ix->d_cand_scores, &out->launches, /*no_mask=*/true, nullptr, exact);
       if (rc) return rc;
       out->launches += 2;
@@ -446,8 +496,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
     out->pages = pages; out->bytes = rows * (int64_t)kSignBytes;
   } else {
     // FDE: encode the query (SUM), scan the FDE slab
-    int64_t nc = std::min<int64_t>(std::min<int64_t>(want_coarse, n), kTopkMaxDeviceK);
-    if (nc < 1) nc = 1;
+    const int64_t nc = nc_fde;
     bool hist0_done = false;
     rc = fde_coarse_scan(ix, n_q, d_allow, n_words, n, &out->launches, st != nullptr, mode == MV_MODE_FDE_THEN_FLOAT ? (int32_t)nc : 0, &hist0_done);
     if (rc) return rc;
@@ -465,7 +514,20 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
       rc = launch_cand_prepare(ix, ix->d_out_id, nullptr, (int)nc, pad_sem);
       if (rc) return rc;
       if (st) MV_HIP(hipEventRecord(ix->ev_st[2], ix->stream));
-      rc = rerank_scan(ix, n_q, rerank_fp8, nc, ix->d_cand_scores, &out->launches);
+      if (plan.mid) {
+        // pinned-host exact tier behind a long list: e4m3 scores of all nc candidates (HBM) -> the n_mid best positions ->
+        // every other entry of the list becomes -1; the list keeps its order, so the pad lengths (the reference's batches of
+        // 128 over the WHOLE coarse list) and the tie rule (coarse rank) are those of the direct rerank
+        if (st) MV_HIP(hipMemcpyAsync(ix->h_cand + kTopkMaxDeviceK, ix->d_cand, (size_t)nc * 4, hipMemcpyDeviceToHost, ix->stream));
+        rc = rerank_scan(ix, n_q, /*use_fp8=*/true, nc, ix->d_cand_scores, &out->launches);
+        if (rc) return rc;
+        rc = launch_topk(ix->d_cand_scores, nc, plan.n_mid, nullptr, 0, ix->d_topk_ws, ix->d_out_s, ix->d_sel_pos, ix->stream);
+        if (rc) return rc;
+        rc = launch_keep_selected(ix->d_sel_pos, 0, plan.n_mid, ix->d_cand, 0, (int)nc, 1, ix->stream);
+        if (rc) return rc;
+        out->launches += 2;
+      }
+      rc = rerank_scan(ix, n_q, rerank_fp8, nc, ix->d_cand_scores, &out->launches, plan.exact);
       if (rc) return rc;
       out->launches += 1;
       out->n = nc;
@@ -480,7 +542,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
     st->pages_scored = out->pages;
     st->bytes_scanned = out->bytes;
     // FDE_THEN_FLOAT: the candidates' rows are added by finish_stats (read back behind the timed span)
-    if (mode == MV_MODE_FDE_THEN_FLOAT || (two_tier && out->n > 0)) st->reserved = (int32_t)out->n | (rerank_fp8 ? (1 << 30) : 0);
+    if (mode == MV_MODE_FDE_THEN_FLOAT || (two_tier && out->n > 0)) st->reserved = (int32_t)out->n | (rerank_fp8 ? (1 << 30) : 0) | (plan.mid ? (1 << 28) : 0);
     else if (mode == MV_MODE_FDE_ONLY) st->reserved = 1 << 29;  // stage split without a rerank
   }
   return MV_OK;
@@ -499,13 +561,16 @@ int finish_stats(mv_index* ix, mv_query_stats* st, bool had_topk) {
     MV_HIP(hipEventElapsedTime(&st->rerank_ms, ix->ev_st[2], ix->ev[1]));
     const int nc = st->reserved & 0xffff;
     const bool f8 = (st->reserved >> 30) & 1;
+    const bool mid = (st->reserved >> 28) & 1;  // the list before its e4m3 pruning stage was copied to h_cand[1024..) in stream order
     st->reserved = 0;
     MV_HIP(hipMemcpyAsync(ix->h_cand, ix->d_cand, (size_t)nc * 4, hipMemcpyDeviceToHost, ix->stream));
     MV_HIP(hipStreamSynchronize(ix->stream));
-    int64_t cand_rows = 0;
-    for (int i = 0; i < nc; ++i)
+    int64_t cand_rows = 0, mid_rows = 0;
+    for (int i = 0; i < nc; ++i) {
       if (ix->h_cand[i] >= 0) cand_rows += ix->h_n_rows[ix->h_cand[i]];
-    st->bytes_scanned += cand_rows * (int64_t)(f8 ? kDim : kRowBytes);
+      if (mid && ix->h_cand[kTopkMaxDeviceK + i] >= 0) mid_rows += ix->h_n_rows[ix->h_cand[kTopkMaxDeviceK + i]];
+    }
+    st->bytes_scanned += cand_rows * (int64_t)(f8 ? kDim : kRowBytes) + mid_rows * (int64_t)kDim;
   }
   MV_HIP(hipEventElapsedTime(&st->score_kernel_ms, ix->ev[0], ix->ev[1]));
   if (had_topk) {
@@ -748,7 +813,7 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   if (!rc && hipEventCreateWithFlags(&ix->ev_stage, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); rc = MV_ERR_HIP; }
   if (!rc && (hipHostMalloc((void**)&ix->h_out_s, (size_t)kTopkMaxDeviceK * 4, hipHostMallocDefault) != hipSuccess ||
               hipHostMalloc((void**)&ix->h_out_id, (size_t)kTopkMaxDeviceK * 8, hipHostMallocDefault) != hipSuccess ||
-              hipHostMalloc((void**)&ix->h_cand, (size_t)kTopkMaxDeviceK * 4, hipHostMallocDefault) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = MV_ERR_NOMEM; }
+              hipHostMalloc((void**)&ix->h_cand, (size_t)2 * kTopkMaxDeviceK * 4, hipHostMallocDefault) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = MV_ERR_NOMEM; }
   if (cfg->flags & MV_WITH_FLOAT) alloc((void**)&ix->slab, rows * kRowBytes + 32768, "bf16 page slab");  // +32 KiB: the batched scans DMA whole 16 / 32 KiB chunks
   if (!rc && (cfg->flags & MV_WITH_HOST_EXACT)) {
     // pinned + mapped: the rerank kernel reads the candidates' rows straight out of host RAM (+32 KiB: whole DMA chunks)
@@ -815,7 +880,9 @@ int mv_index_set_option(mv_index* ix, int option, int64_t value) {
     case MV_OPT_FILTER_COMPACT_PCT: ix->filter_compact_pct = (int)value; return MV_OK;
     case MV_OPT_FDE_QUERY_ENCODE_VARIANT: ix->fde_query_encode_variant = (int)value; return MV_OK;
     case MV_OPT_FDE_BATCH_VARIANT: ix->fde_batch_variant = (int)value; return MV_OK;
-    case MV_OPT_EXACT_TIER: ix->exact_tier = (int)value; return MV_OK;
+    case MV_OPT_EXACT_TIER:
+      if (value < 0 || value > 2) { set_error("EXACT_TIER must be 0 (HBM slab), 1 (pinned-host tier) or 2 (e4m3 slab)"); return MV_ERR_INVALID; }
+      ix->exact_tier = (int)value; return MV_OK;
     case MV_OPT_RERANK_N:
       if (value < 1 || value > kTopkMaxDeviceK) { set_error("RERANK_N must be 1..%d", kTopkMaxDeviceK); return MV_ERR_INVALID; }
       ix->rerank_n = value; return MV_OK;
@@ -1221,7 +1288,7 @@ int mv_internal_query_common(mv_index* ix, const void* q, int q_dtype, int32_t n
   }
   ScanResult r;
   const int64_t want_n = mode == MV_MODE_FP8_THEN_FLOAT ? std::max<int64_t>(ix->rerank_n, k) : coarse_n_for(ix, k);
-  int rc = run_scan(ix, q, q_dtype, n_q, mode, allow_bits, n_words, want_n, &r, st, /*want_compact=*/true);
+  int rc = run_scan(ix, q, q_dtype, n_q, mode, allow_bits, n_words, want_n, &r, st, /*want_compact=*/true, k);
   if (rc) return rc;
   const int64_t id_base = ix->cfg.id_base;
   if (r.n == 0) {
@@ -1338,6 +1405,28 @@ int mv_internal_ensure_fde_batch_ws(mv_index* ix) {
   return MV_OK;
 }
 
+// Workspace of the batched e4m3 scan and its two-tier rerank (q_mu held).
+int mv_internal_ensure_fp8_batch_ws(mv_index* ix) {
+  int rc = mv_internal_ensure_batch_select_ws(ix);
+  if (rc) return rc;
+  if (!ix->d_bscores) {
+    hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->cfg.capacity_pages * 4);
+    if (e != hipSuccess) { ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->cfg.capacity_pages * 4); return MV_ERR_NOMEM; }
+  }
+  const size_t lists = (size_t)kFdeBatchMaxQueries * kTopkMaxDeviceK;
+  if (!ix->d_bqf32) MV_HIP(hipMalloc(&ix->d_bqf32, (size_t)kBatchQRows * kDim * 4));
+  if (!ix->d_bq8hi) MV_HIP(hipMalloc(&ix->d_bq8hi, (size_t)kBatchQRows * kDim));
+  if (!ix->d_bq8lo) MV_HIP(hipMalloc(&ix->d_bq8lo, (size_t)kBatchQRows * kDim));
+  if (!ix->d_bq8fac) MV_HIP(hipMalloc(&ix->d_bq8fac, (size_t)kBatchQRows * 4));
+  if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)kBatchQRows * kRowBytes));
+  if (!ix->d_bsel_s) MV_HIP(hipMalloc(&ix->d_bsel_s, lists * 4));
+  if (!ix->d_bsel_id) MV_HIP(hipMalloc(&ix->d_bsel_id, lists * 8));
+  if (!ix->d_bcand) MV_HIP(hipMalloc(&ix->d_bcand, lists * 4));
+  if (!ix->d_bcand_pads) MV_HIP(hipMalloc(&ix->d_bcand_pads, lists * 4));
+  if (!ix->d_bcand_scores) MV_HIP(hipMalloc(&ix->d_bcand_scores, lists * 4));
+  return MV_OK;
+}
+
 // Upload a group of nb queries (host buffer, every query n_q_rows rows) into the batch workspace, each padded to rpq rows
 // with zero rows (a zero row adds exactly 0 to the FDE and to MaxSim): fp32 rows for the FDE encode (d_bqf32), bf16 rows
 // for the bf16 rerank (d_bq), the two-term e4m3 split for the fp8 rerank (d_bq8*).  q_mu held; workspace allocated.
@@ -1372,26 +1461,28 @@ int mv_internal_batch_upload_queries(mv_index* ix, const void* q, int q_dtype, i
 // Exact rerank of the group's candidate lists d_bcand / d_bcand_pads ([nb][nc], list b against query b of the uploaded
 // group) into d_bcand_scores: ONE launch for all lists where the kernels allow it (fp8 slab; bf16 slab with the default
 // kernels and queries of <= 128 rows), else one launch per query.  q_mu held.
-int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t nc, int* launches, const uint16_t* exact_tier) {
-  // exact_tier != null: rerank on THAT bf16 image (the HBM slab or the pinned-host exact tier of MV_MODE_FP8_THEN_FLOAT)
+int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t nc, int* launches, const uint16_t* exact, float* d_out) {
+  // exact != null: rerank on THAT bf16 image (the HBM slab or the pinned-host exact tier); null: on the e4m3 slab
   const int rpq = ((n_q_rows + 15) / 16) * 16;
   const int64_t L = nc;
-  const bool rerank_fp8 = !exact_tier && !(ix->cfg.flags & MV_WITH_FLOAT) && (ix->cfg.flags & MV_WITH_FP8);
+  const bool rerank_fp8 = exact == nullptr;
+  float* dst = d_out ? d_out : ix->d_bcand_scores;
   const int rr_variant = ix->maxsim_variant < 0 ? maxsim_default_variant(ix->cfg.stride_rows) : ix->maxsim_variant;
   const bool rerank_one_launch = rerank_fp8 || (rpq <= kMaxQRowsPerPass && (rr_variant == 6 || rr_variant == 7));
   int rc = MV_OK;
   if (rerank_fp8) {
+    if (!(ix->cfg.flags & MV_WITH_FP8) || rpq > 64) { set_error("batched e4m3 rerank needs an fp8 slab and queries of <= 64 rows"); return MV_ERR_STATE; }
     Fp8ScanArgs fa{};
     fa.slab = ix->slab8; fa.inv_scale = ix->inv_scale8; fa.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr; fa.cand = ix->d_bcand;
-    fa.qhi = ix->d_bq8hi; fa.qlo = ix->d_bq8lo; fa.qfac = ix->d_bq8fac; fa.n_q = rpq; fa.scores = ix->d_bcand_scores; fa.n = (int64_t)nb * nc;
+    fa.qhi = ix->d_bq8hi; fa.qlo = ix->d_bq8lo; fa.qfac = ix->d_bq8fac; fa.n_q = rpq; fa.scores = dst; fa.n = (int64_t)nb * nc;
     fa.stride = ix->cfg.stride_rows; fa.pad_to = 0; fa.pad_items = ix->d_bcand_pads; fa.items_per_query = (int32_t)nc;
     rc = launch_maxsim_fp8(fa, ix->stream);
     if (rc) return rc;
     ++*launches;
   } else if (rerank_one_launch) {
     MaxsimArgs ma{};
-    ma.slab = exact_tier ? exact_tier : ix->slab; ma.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr; ma.cand = ix->d_bcand; ma.q = ix->d_bq;
-    ma.scores = ix->d_bcand_scores; ma.n = (int64_t)nb * nc; ma.stride = ix->cfg.stride_rows; ma.q_tiles = rpq / 16; ma.pad_to = 0;
+    ma.slab = exact; ma.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr; ma.cand = ix->d_bcand; ma.q = ix->d_bq;
+    ma.scores = dst; ma.n = (int64_t)nb * nc; ma.stride = ix->cfg.stride_rows; ma.q_tiles = rpq / 16; ma.pad_to = 0;
     ma.pad_items = ix->d_bcand_pads; ma.items_per_query = (int32_t)nc; ma.q_item_stride = rpq * kDim;
     rc = launch_maxsim_bf16(ma, rr_variant, ix->stream);
     if (rc) return rc;
@@ -1399,7 +1490,7 @@ int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t n
   } else {
     for (int b = 0; b < nb; ++b) {  // one launch per query (long queries, non-default kernel variants)
       rc = float_scan(ix, n_q_rows, nullptr, 0, ix->d_bcand + (size_t)b * L, nc, 0, ix->d_bcand_pads + (size_t)b * L,
-                      ix->d_bcand_scores + (size_t)b * L, launches, /*no_mask=*/true, ix->d_bq + (size_t)b * rpq * kDim, exact_tier);
+                      dst + (size_t)b * L, launches, /*no_mask=*/true, ix->d_bq + (size_t)b * rpq * kDim, exact);
       if (rc) return rc;
     }
   }
@@ -1427,8 +1518,6 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
   const int rpq = ((n_q_rows + 15) / 16) * 16;
   const int group = std::min(kBatchQRows / rpq, kFdeBatchMaxQueries);
   const bool rerank = mode == MV_MODE_FDE_THEN_FLOAT;
-  // the rerank uses the bf16 slab when the index has one, else the fp8 slab (the rule of the single-query pipeline)
-  const bool rerank_fp8 = rerank && !(ix->cfg.flags & MV_WITH_FLOAT) && (ix->cfg.flags & MV_WITH_FP8);
   const bool per_query = allow_bits && allow_per_query;
   const uint32_t* d_allow = nullptr;
   rc = upload_allow(ix, allow_bits, per_query ? n_allow_words * (int64_t)n_queries : n_allow_words, &d_allow);
@@ -1439,13 +1528,16 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
   int64_t nc = std::min<int64_t>(std::min<int64_t>(coarse_n_for(ix, k), n), kTopkMaxDeviceK);
   if (nc < 1) nc = 1;
   const int64_t L = nc;  // the per-query lists lie back to back: [query][nc]
+  // the rerank tier and the e4m3 pruning stage: the rule of the single-query pipeline (rerank_plan)
+  const RerankPlan plan = rerank ? rerank_plan(ix, mode, nc, k, rpq, true) : RerankPlan{};
+  const bool rerank_fp8 = rerank && plan.final_fp8;
   const int pad_sem = ix->pad_semantics < 0 ? 1 : ix->pad_semantics;
   int64_t pages = 0;
   if (stats) (void)count_allowed_rows(ix, n, per_query ? nullptr : allow_bits, n_allow_words, &pages);
   for (int32_t b0 = 0; b0 < n_queries; b0 += group) {
     const int nb = std::min(group, n_queries - b0);
     rc = mv_internal_batch_upload_queries(ix, (const char*)q + (size_t)b0 * n_q_rows * kDim * esz, q_dtype, nb, n_q_rows, /*want_f32=*/true,
-                                          /*want_bf16=*/rerank && !rerank_fp8, /*want_fp8=*/rerank_fp8);
+                                          /*want_bf16=*/rerank && !rerank_fp8, /*want_fp8=*/rerank_fp8 || plan.mid);
     if (rc) return rc;
     MV_HIP(hipEventRecord(ix->ev[0], ix->stream));
     int launches = 0;
@@ -1486,7 +1578,16 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
                          ix->d_bcand, ix->d_bcand_pads, L);
       MV_HIP(hipGetLastError());
       MV_HIP(hipEventRecord(ix->ev_st[2], ix->stream));
-      rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, nc, &launches, nullptr);
+      if (stats) MV_HIP(hipMemcpyAsync(ix->h_bcand, ix->d_bcand, (size_t)nb * L * 4, hipMemcpyDeviceToHost, ix->stream));  // the lists as selected (accounting)
+      if (plan.mid) {  // e4m3 scores of every list -> each list's n_mid best positions -> the rest of the list becomes -1
+        rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, nc, &launches, nullptr, nullptr);
+        if (rc) return rc;
+        rc = launch_topk_batch(ix->d_bcand_scores, L, nc, plan.n_mid, nullptr, 0, 0, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bsel_s, ix->d_bsel_id, L, nb, ix->stream);
+        if (rc) return rc;
+        rc = launch_keep_selected(ix->d_bsel_id, L, plan.n_mid, ix->d_bcand, L, (int)nc, nb, ix->stream);
+        if (rc) return rc;
+      }
+      rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, nc, &launches, plan.exact, nullptr);
       if (rc) return rc;
       MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
       rc = launch_topk_batch(ix->d_bcand_scores, L, nc, k, ix->d_bcand, L, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bout_s, ix->d_bout_id, k,
@@ -1501,7 +1602,6 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
     MV_HIP(hipEventRecord(ix->ev[2], ix->stream));
     MV_HIP(hipMemcpyAsync(ix->h_bout_s, ix->d_bout_s, (size_t)nb * k * 4, hipMemcpyDeviceToHost, ix->stream));
     MV_HIP(hipMemcpyAsync(ix->h_bout_id, ix->d_bout_id, (size_t)nb * k * 8, hipMemcpyDeviceToHost, ix->stream));
-    if (stats && rerank) MV_HIP(hipMemcpyAsync(ix->h_bcand, ix->d_bcand, (size_t)nb * L * 4, hipMemcpyDeviceToHost, ix->stream));
     MV_HIP(hipStreamSynchronize(ix->stream));
     for (int b = 0; b < nb; ++b) {
       const float* hs = ix->h_bout_s + (size_t)b * k;
@@ -1533,7 +1633,9 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
             const int32_t c = ix->h_bcand[(size_t)b * L + i];
             if (c >= 0) cand_rows += ix->h_n_rows[c];
           }
-        total.bytes_scanned += cand_rows * (int64_t)(rerank_fp8 ? kDim : kRowBytes);
+        // with the pruning stage: all candidates on the e4m3 slab, then n_mid of them (at most stride rows each) on the exact tier
+        total.bytes_scanned += plan.mid ? cand_rows * (int64_t)kDim + (int64_t)nb * std::min<int64_t>(plan.n_mid, nc) * ix->cfg.stride_rows * kRowBytes
+                                        : cand_rows * (int64_t)(rerank_fp8 ? kDim : kRowBytes);
       }
     }
   }
@@ -1557,28 +1659,13 @@ static int fp8_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
   const size_t esz = q_dtype == MV_F32 ? 4 : 2;
   const int rpq = ((n_q_rows + 15) / 16) * 16;
   const int group = std::min(512 / rpq, 32);
-  int rc = mv_internal_ensure_batch_select_ws(ix);
+  int rc = mv_internal_ensure_fp8_batch_ws(ix);
   if (rc) return rc;
-  if (!ix->d_bscores) {
-    hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->cfg.capacity_pages * 4);
-    if (e != hipSuccess) { ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->cfg.capacity_pages * 4); return MV_ERR_NOMEM; }
-  }
-  if (!ix->d_bqf32) MV_HIP(hipMalloc(&ix->d_bqf32, (size_t)kBatchQRows * kDim * 4));
-  if (!ix->d_bq8hi) MV_HIP(hipMalloc(&ix->d_bq8hi, (size_t)kBatchQRows * kDim));
-  if (!ix->d_bq8lo) MV_HIP(hipMalloc(&ix->d_bq8lo, (size_t)kBatchQRows * kDim));
-  if (!ix->d_bq8fac) MV_HIP(hipMalloc(&ix->d_bq8fac, (size_t)kBatchQRows * 4));
   const uint16_t* exact = nullptr;
   int64_t nc = 0;
   if (two_tier) {
-    exact = ((ix->cfg.flags & MV_WITH_FLOAT) && !(ix->exact_tier == 1 && ix->d_exact)) ? ix->slab : ix->d_exact;
+    exact = rerank_plan(ix, MV_MODE_FP8_THEN_FLOAT, 0, k, rpq, true).exact;
     nc = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(std::max<int64_t>(ix->rerank_n, k), n), kTopkMaxDeviceK));
-    const size_t lists = (size_t)kFdeBatchMaxQueries * kTopkMaxDeviceK;
-    if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)kBatchQRows * kRowBytes));
-    if (!ix->d_bsel_s) MV_HIP(hipMalloc(&ix->d_bsel_s, lists * 4));
-    if (!ix->d_bsel_id) MV_HIP(hipMalloc(&ix->d_bsel_id, lists * 8));
-    if (!ix->d_bcand) MV_HIP(hipMalloc(&ix->d_bcand, lists * 4));
-    if (!ix->d_bcand_pads) MV_HIP(hipMalloc(&ix->d_bcand_pads, lists * 4));
-    if (!ix->d_bcand_scores) MV_HIP(hipMalloc(&ix->d_bcand_scores, lists * 4));
   }
   const bool per_query = allow_bits && allow_per_query;
   const uint32_t* d_allow = nullptr;
@@ -1614,7 +1701,7 @@ static int fp8_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
                          ix->d_bcand, ix->d_bcand_pads, nc);
       MV_HIP(hipGetLastError());
       int launches = 0;
-      rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, nc, &launches, exact);
+      rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, nc, &launches, exact, nullptr);
       if (rc) return rc;
       MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
       rc = launch_topk_batch(ix->d_bcand_scores, nc, nc, k, ix->d_bcand, nc, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bout_s, ix->d_bout_id,
@@ -1662,7 +1749,7 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
   // FDE modes: the batched pipeline (rerank on the bf16 slab, or on the fp8 slab of an index without one: queries of <= 64 rows)
   if ((mode == MV_MODE_FDE_THEN_FLOAT || mode == MV_MODE_FDE_ONLY) && n_queries > 1 && k >= 1 && k <= kTopkMaxDeviceK && rpq <= 512 &&
       ix->fde_batch_variant != 1 && (ix->cfg.flags & MV_WITH_FDE) &&
-      (mode == MV_MODE_FDE_ONLY || (ix->cfg.flags & MV_WITH_FLOAT) || ((ix->cfg.flags & MV_WITH_FP8) && rpq <= 64)) &&
+      (mode == MV_MODE_FDE_ONLY || (ix->cfg.flags & (MV_WITH_FLOAT | MV_WITH_HOST_EXACT)) || ((ix->cfg.flags & MV_WITH_FP8) && rpq <= 64)) &&
       mv::fde_scan_batch_supported(ix->fde_t.out_dim) && ix->fde_t.cfg.projection_dimension <= 16)
     return fde_batch_query(ix, q, q_dtype, n_queries, n_q_rows, k, mode, allow_bits, n_allow_words, allow_per_query, out_scores, out_ids, out_n, stats);
   // e4m3 slab: the batched block-scaled MFMA scan (<= 512 query rows per slab pass); MV_OPT_BATCH_VARIANT 8 = query by query
@@ -1787,9 +1874,11 @@ int mv_score_all(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int
 static int score_candidates_common(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const int32_t* cand, int32_t n_cand,
                                    int32_t pad_to, const int32_t* pads, float* out_scores, mv_query_stats* stats) {
   if (!ix || !q || !cand || !out_scores || n_cand < 0 || n_cand > kMaxCand || n_q_rows < 1 || pad_to < -1) { set_error("score_candidates: bad argument"); return MV_ERR_INVALID; }
-  const bool use_fp8 = !(ix->cfg.flags & MV_WITH_FLOAT);
-  if (use_fp8 && !(ix->cfg.flags & MV_WITH_FP8)) { set_error("index has neither a float nor an fp8 slab"); return MV_ERR_STATE; }
   std::lock_guard<std::mutex> lk(ix->q_mu);
+  // the named pages are scored on the exact tier (bf16 slab, else the pinned-host tier), else on the e4m3 slab
+  const RerankPlan plan = rerank_plan(ix, MV_MODE_FLOAT, n_cand, 0, ((n_q_rows + 15) / 16) * 16, false);
+  const bool use_fp8 = plan.final_fp8;
+  if (use_fp8 && !(ix->cfg.flags & MV_WITH_FP8)) { set_error("index has neither a float slab, an exact host tier nor an fp8 slab"); return MV_ERR_STATE; }
   DeviceGuard g(ix->cfg.device);
   if (stats) memset(stats, 0, sizeof(*stats));
   if (n_cand == 0) return MV_OK;
@@ -1819,7 +1908,8 @@ static int score_candidates_common(mv_index* ix, const void* q, int q_dtype, int
   }
   const bool per_item = pads || pad_to < 0;
   rc = use_fp8 ? fp8_scan(ix, n_q_rows, nullptr, 0, ix->d_cand, n_cand, per_item ? 0 : pad_to, per_item ? ix->d_cand_pads : nullptr, ix->d_cand_scores, &launches, true)
-               : float_scan(ix, n_q_rows, nullptr, 0, ix->d_cand, n_cand, per_item ? 0 : pad_to, per_item ? ix->d_cand_pads : nullptr, ix->d_cand_scores, &launches, true);
+               : float_scan(ix, n_q_rows, nullptr, 0, ix->d_cand, n_cand, per_item ? 0 : pad_to, per_item ? ix->d_cand_pads : nullptr, ix->d_cand_scores, &launches, true,
+                            nullptr, plan.exact);
   if (rc) return rc;
   MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
   MV_HIP(hipMemcpyAsync(out_scores, ix->d_cand_scores, (size_t)n_cand * 4, hipMemcpyDeviceToHost, ix->stream));

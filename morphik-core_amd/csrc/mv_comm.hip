@@ -167,11 +167,57 @@ int hand_back(mv_index* ix, void* user_stream) {
 
 extern "C" {
 
-int mv_two_stage_coarse_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int32_t n_coarse,
+// ---- shared pieces of the stages (q_mu held, device current)
+static bool two_stage_mode_ok(int mode) { return mode == MV_MODE_FDE_THEN_FLOAT || mode == MV_MODE_FP8_THEN_FLOAT; }
+// pad rule of the rerank: the reference's batches of 128 for the FDE pipeline (pad_sequence, fast_multivector_store.py:553-555);
+// the candidates of an e4m3 scan are scored like a full scan (a page's own rows only)
+static int two_stage_pad_sem(const mv_index* ix, int mode) { return mode == MV_MODE_FDE_THEN_FLOAT ? (ix->pad_semantics < 0 ? 1 : ix->pad_semantics) : 0; }
+
+static int ensure_gscores(mv_index* ix, int64_t need) {
+  if (need <= ix->gscores_cap) return MV_OK;
+  if (ix->d_gscores) (void)hipFree(ix->d_gscores);
+  ix->d_gscores = nullptr; ix->gscores_cap = 0;
+  const int64_t cap = need <= 16384 ? 16384 : (int64_t)kFdeBatchMaxQueries * 16384;
+  MV_HIP(hipMalloc(&ix->d_gscores, (size_t)cap * 4));
+  ix->gscores_cap = cap;
+  return MV_OK;
+}
+
+// gathered records -> GLOBAL top-n_coarse (positions, identical on every shard) -> this shard's rerank list d_cand / d_cand_pads
+static int global_owned_list(mv_index* ix, int mode, const mv_cand_rec* d_all_recs, int world, int n_coarse) {
+  const int64_t n = ix->size.load(std::memory_order_acquire);
+  const int total = world * n_coarse;
+  int rc = ensure_gscores(ix, total);
+  if (rc) return rc;
+  // the gathered lists are in shard order and each is sorted (score desc, id asc), shards own ascending ids, so
+  // "ties by position" is "ties by ascending id" -- the single-index rule
+  hipLaunchKernelGGL(recs_scores_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ix->stream, d_all_recs, total, ix->d_gscores);
+  rc = launch_topk(ix->d_gscores, total, n_coarse, nullptr, 0, ix->d_topk_ws, ix->d_out_s, ix->d_sel_pos, ix->stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(owned_select_kernel, dim3((unsigned)((n_coarse + kRerankBatch - 1) / kRerankBatch)), dim3(kRerankBatch), 0, ix->stream,
+                     d_all_recs, (const int64_t*)ix->d_sel_pos, (int)n_coarse, ix->cfg.id_base, ix->cfg.id_base + n, two_stage_pad_sem(ix, mode), ix->d_cand,
+                     ix->d_cand_pads);
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
+// out[j] = max over the shards of all_mid[r][j]: every list position is owned by exactly one shard, the others hold -inf
+__global__ __launch_bounds__(256) void mid_combine_kernel(const float* all_mid, int world, int64_t n, float* out) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  float m = -INFINITY;
+  for (int r = 0; r < world; ++r) m = fmaxf(m, all_mid[(int64_t)r * n + j]);
+  out[j] = m;
+}
+
+int mv_two_stage_coarse_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int32_t n_coarse, int mode,
                                const uint32_t* allow_bits, int64_t n_allow_words, mv_cand_rec* d_out_recs, void* stream) {
   if (!ix || !q || !d_out_recs || n_q_rows < 1 || n_coarse < 1 || n_coarse > kTopkMaxDeviceK) { set_error("two_stage_coarse: bad argument"); return MV_ERR_INVALID; }
   if (q_dtype != MV_F32 && q_dtype != MV_BF16) { set_error("bad query dtype %d", q_dtype); return MV_ERR_INVALID; }
-  if (!(ix->cfg.flags & MV_WITH_FDE)) { set_error("index has no FDE slab (MV_WITH_FDE)"); return MV_ERR_STATE; }
+  if (!two_stage_mode_ok(mode)) { set_error("two_stage_coarse: mode %d is not a two-stage mode (MV_MODE_FDE_THEN_FLOAT / MV_MODE_FP8_THEN_FLOAT)", mode); return MV_ERR_INVALID; }
+  const bool fde = mode == MV_MODE_FDE_THEN_FLOAT;
+  if (fde && !(ix->cfg.flags & MV_WITH_FDE)) { set_error("index has no FDE slab (MV_WITH_FDE)"); return MV_ERR_STATE; }
+  if (!fde && !(ix->cfg.flags & MV_WITH_FP8)) { set_error("index has no fp8 slab (MV_WITH_FP8)"); return MV_ERR_STATE; }
   std::lock_guard<std::mutex> lk(ix->q_mu);
   DeviceGuard g(ix->cfg.device);
   int rc = order_behind(ix, stream);
@@ -183,14 +229,15 @@ int mv_two_stage_coarse_device(mv_index* ix, const void* q, int q_dtype, int32_t
     MV_HIP(hipGetLastError());
     return hand_back(ix, stream);
   }
-  rc = upload_query(ix, q, q_dtype, n_q_rows, false, true, false, false);
+  rc = upload_query(ix, q, q_dtype, n_q_rows, false, fde, false, !fde);
   if (rc) return rc;
   const uint32_t* d_allow = nullptr;
   rc = upload_allow(ix, allow_bits, n_allow_words, &d_allow);
   if (rc) return rc;
   int launches = 0;
   bool hist0_done = false;
-  rc = fde_coarse_scan(ix, n_q_rows, d_allow, n_allow_words, n, &launches, false, n_coarse, &hist0_done);
+  if (fde) rc = fde_coarse_scan(ix, n_q_rows, d_allow, n_allow_words, n, &launches, false, n_coarse, &hist0_done);
+  else rc = fp8_scan(ix, n_q_rows, d_allow, n_allow_words, nullptr, n, 0, nullptr, ix->d_scores, &launches);
   if (rc) return rc;
   rc = launch_topk(ix->d_scores, n, n_coarse, nullptr, ix->cfg.id_base, ix->d_topk_ws, ix->d_out_s, ix->d_out_id, ix->stream, hist0_done);
   if (rc) return rc;
@@ -201,39 +248,68 @@ int mv_two_stage_coarse_device(mv_index* ix, const void* q, int q_dtype, int32_t
   return hand_back(ix, stream);
 }
 
-int mv_two_stage_rerank_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const mv_cand_rec* d_all_recs,
-                               int32_t world, int32_t n_coarse, int32_t k, float* d_out_scores, int64_t* d_out_ids, void* stream) {
-  if (!ix || !q || !d_all_recs || !d_out_scores || !d_out_ids || n_q_rows < 1 || world < 1 || n_coarse < 1 || n_coarse > kTopkMaxDeviceK ||
-      k < 1 || k > kTopkMaxDeviceK || (int64_t)world * n_coarse > 16384) { set_error("two_stage_rerank: bad argument"); return MV_ERR_INVALID; }
+int mv_index_rerank_plan(mv_index* ix, int mode, int32_t n_list, int32_t k, int32_t n_q_rows, int32_t batched, int32_t* out_n_mid, int32_t* out_tier) {
+  if (!ix || n_list < 0 || k < 0 || n_q_rows < 1) { set_error("rerank_plan: bad argument"); return MV_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(ix->q_mu);
+  const RerankPlan p = rerank_plan(ix, mode, n_list, k, ((n_q_rows + 15) / 16) * 16, batched != 0);
+  if (out_n_mid) *out_n_mid = p.mid ? p.n_mid : 0;
+  if (out_tier) *out_tier = p.final_fp8 ? 2 : (p.host_tier ? 1 : 0);
+  return MV_OK;
+}
+
+int mv_two_stage_mid_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int mode, const mv_cand_rec* d_all_recs,
+                            int32_t world, int32_t n_coarse, float* d_out_mid, void* stream) {
+  if (!ix || !q || !d_all_recs || !d_out_mid || n_q_rows < 1 || world < 1 || n_coarse < 1 || n_coarse > kTopkMaxDeviceK ||
+      (int64_t)world * n_coarse > 16384) { set_error("two_stage_mid: bad argument"); return MV_ERR_INVALID; }
   if (q_dtype != MV_F32 && q_dtype != MV_BF16) { set_error("bad query dtype %d", q_dtype); return MV_ERR_INVALID; }
-  const bool use_fp8 = !(ix->cfg.flags & MV_WITH_FLOAT);
-  if (use_fp8 && !(ix->cfg.flags & MV_WITH_FP8)) { set_error("index has neither a float nor an fp8 slab"); return MV_ERR_STATE; }
+  if (mode != MV_MODE_FDE_THEN_FLOAT) { set_error("two_stage_mid: only MV_MODE_FDE_THEN_FLOAT has a pruning stage"); return MV_ERR_INVALID; }
+  if (!(ix->cfg.flags & MV_WITH_FP8)) { set_error("index has no fp8 slab (MV_WITH_FP8)"); return MV_ERR_STATE; }
   std::lock_guard<std::mutex> lk(ix->q_mu);
   DeviceGuard g(ix->cfg.device);
   int rc = order_behind(ix, stream);
   if (rc) return rc;
-  const int64_t n = ix->size.load(std::memory_order_acquire);
-  const int total = world * n_coarse;
-  if (total > ix->gscores_cap) {
-    if (ix->d_gscores) (void)hipFree(ix->d_gscores);
-    ix->d_gscores = nullptr; ix->gscores_cap = 0;
-    MV_HIP(hipMalloc(&ix->d_gscores, (size_t)16384 * 4));
-    ix->gscores_cap = 16384;
-  }
+  rc = upload_query(ix, q, q_dtype, n_q_rows, false, false, false, true);
+  if (rc) return rc;
+  rc = global_owned_list(ix, mode, d_all_recs, world, n_coarse);
+  if (rc) return rc;
+  int launches = 0;
+  rc = rerank_scan(ix, n_q_rows, /*use_fp8=*/true, n_coarse, d_out_mid, &launches);  // -inf at the positions other shards own
+  if (rc) return rc;
+  return hand_back(ix, stream);
+}
+
+int mv_two_stage_rerank_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int mode, const mv_cand_rec* d_all_recs,
+                               int32_t world, int32_t n_coarse, const float* d_all_mid, int32_t n_mid, int32_t k, float* d_out_scores,
+                               int64_t* d_out_ids, void* stream) {
+  if (!ix || !q || !d_all_recs || !d_out_scores || !d_out_ids || n_q_rows < 1 || world < 1 || n_coarse < 1 || n_coarse > kTopkMaxDeviceK ||
+      k < 1 || k > kTopkMaxDeviceK || (int64_t)world * n_coarse > 16384 || (d_all_mid && (n_mid < 1 || n_mid > kTopkMaxDeviceK))) { set_error("two_stage_rerank: bad argument"); return MV_ERR_INVALID; }
+  if (q_dtype != MV_F32 && q_dtype != MV_BF16) { set_error("bad query dtype %d", q_dtype); return MV_ERR_INVALID; }
+  if (!two_stage_mode_ok(mode)) { set_error("two_stage_rerank: mode %d is not a two-stage mode", mode); return MV_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(ix->q_mu);
+  const RerankPlan plan = rerank_plan(ix, mode, n_coarse, k, ((n_q_rows + 15) / 16) * 16, false);
+  const bool use_fp8 = plan.final_fp8;
+  if (use_fp8 && mode == MV_MODE_FP8_THEN_FLOAT) { set_error("MV_MODE_FP8_THEN_FLOAT needs an exact tier (MV_WITH_FLOAT or MV_WITH_HOST_EXACT)"); return MV_ERR_STATE; }
+  if (use_fp8 && !(ix->cfg.flags & MV_WITH_FP8)) { set_error("index has neither an exact tier nor an fp8 slab"); return MV_ERR_STATE; }
+  DeviceGuard g(ix->cfg.device);
+  int rc = order_behind(ix, stream);
+  if (rc) return rc;
   rc = upload_query(ix, q, q_dtype, n_q_rows, !use_fp8, false, false, use_fp8);
   if (rc) return rc;
-  // global coarse top-n: the gathered lists are in shard order and each is sorted (score desc, id asc), shards own
-  // ascending ids, so "ties by position" is "ties by ascending id" -- the single-index rule
-  hipLaunchKernelGGL(recs_scores_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ix->stream, d_all_recs, total, ix->d_gscores);
-  rc = launch_topk(ix->d_gscores, total, n_coarse, nullptr, 0, ix->d_topk_ws, ix->d_out_s, ix->d_sel_pos, ix->stream);
+  rc = global_owned_list(ix, mode, d_all_recs, world, n_coarse);
   if (rc) return rc;
-  const int pad_sem = ix->pad_semantics < 0 ? 1 : ix->pad_semantics;
-  hipLaunchKernelGGL(owned_select_kernel, dim3((unsigned)((n_coarse + kRerankBatch - 1) / kRerankBatch)), dim3(kRerankBatch), 0, ix->stream,
-                     d_all_recs, (const int64_t*)ix->d_sel_pos, (int)n_coarse, ix->cfg.id_base, ix->cfg.id_base + n, pad_sem, ix->d_cand,
-                     ix->d_cand_pads);
-  MV_HIP(hipGetLastError());
+  if (d_all_mid) {
+    // the e4m3 scores of the GLOBAL list, one owner per position -> its n_mid best positions (ties by list position, as on one
+    // index) -> the owned entries outside them leave this shard's rerank list
+    rc = ensure_gscores(ix, n_coarse);
+    if (rc) return rc;
+    hipLaunchKernelGGL(mid_combine_kernel, dim3((unsigned)((n_coarse + 255) / 256)), dim3(256), 0, ix->stream, d_all_mid, (int)world, (int64_t)n_coarse, ix->d_gscores);
+    rc = launch_topk(ix->d_gscores, n_coarse, std::min(n_mid, n_coarse), nullptr, 0, ix->d_topk_ws, ix->d_out_s, ix->d_sel_pos, ix->stream);
+    if (rc) return rc;
+    rc = launch_keep_selected(ix->d_sel_pos, 0, std::min(n_mid, n_coarse), ix->d_cand, 0, n_coarse, 1, ix->stream);
+    if (rc) return rc;
+  }
   int launches = 0;
-  rc = rerank_scan(ix, n_q_rows, use_fp8, n_coarse, ix->d_cand_scores, &launches);
+  rc = rerank_scan(ix, n_q_rows, use_fp8, n_coarse, ix->d_cand_scores, &launches, plan.exact);
   if (rc) return rc;
   // local top-k of the owned candidates; equal scores resolve by coarse rank (the work index), as on one index
   rc = launch_topk(ix->d_cand_scores, n_coarse, k, ix->d_cand, ix->cfg.id_base, ix->d_topk_ws, d_out_scores, d_out_ids, ix->stream);
@@ -241,10 +317,10 @@ int mv_two_stage_rerank_device(mv_index* ix, const void* q, int q_dtype, int32_t
   return hand_back(ix, stream);
 }
 
-// The two stages for a group of nb requests (<= 32, nb * padded rows <= 1024): ONE pass over the shard's FDE slab for all
-// of them (the batched coarse GEMM of mv_query_topk_batch), then every request's share of ITS global candidate list
-// reranked in one launch.  d_out_recs: [nb][n_coarse]; d_all_recs: [world][nb][n_coarse]; d_out_*: [nb][k].
-int mv_internal_two_stage_batch_coarse(mv_index* ix, const void* q, int q_dtype, int32_t nb, int32_t n_q_rows, int32_t n_coarse,
+// The stages for a group of nb requests (<= 32; FDE: nb * padded rows <= 1024, e4m3 scan: <= 512): ONE pass over the shard's
+// FDE (or e4m3) slab for all of them (the batched kernels of mv_query_topk_batch), then every request's share of ITS global
+// candidate list reranked in one launch.  d_out_recs: [nb][n_coarse]; d_all_recs: [world][nb][n_coarse]; d_out_*: [nb][k].
+int mv_internal_two_stage_batch_coarse(mv_index* ix, const void* q, int q_dtype, int32_t nb, int32_t n_q_rows, int32_t n_coarse, int mode,
                                        const uint32_t* allow_bits, int64_t n_allow_words, int32_t allow_per_query, mv_cand_rec* d_out_recs,
                                        void* stream) {
   std::lock_guard<std::mutex> lk(ix->q_mu);
@@ -257,37 +333,52 @@ int mv_internal_two_stage_batch_coarse(mv_index* ix, const void* q, int q_dtype,
     MV_HIP(hipGetLastError());
     return hand_back(ix, stream);
   }
-  rc = mv_internal_ensure_fde_batch_ws(ix);
-  if (rc) return rc;
-  rc = mv_internal_batch_upload_queries(ix, q, q_dtype, nb, n_q_rows, true, false, false);
+  const bool fde = mode == MV_MODE_FDE_THEN_FLOAT;
+  rc = fde ? mv_internal_ensure_fde_batch_ws(ix) : mv_internal_ensure_fp8_batch_ws(ix);
   if (rc) return rc;
   const int rpq = ((n_q_rows + 15) / 16) * 16;
+  if (!fde) MV_HIP(hipMemsetAsync(ix->d_bqf32, 0, (size_t)512 * kDim * 4, ix->stream));  // zero rows behind the group: the kernel's row tiles run to a multiple of 64
+  rc = mv_internal_batch_upload_queries(ix, q, q_dtype, nb, n_q_rows, true, false, false);
+  if (rc) return rc;
   const bool per_query = allow_bits && allow_per_query;
   const uint32_t* d_allow = nullptr;
   rc = upload_allow(ix, allow_bits, per_query ? n_allow_words * (int64_t)nb : n_allow_words, &d_allow);
   if (rc) return rc;
   const bool need_meta = ix->tombstones.load() || d_allow != nullptr;
-  FdeEncodeArgs e{};
-  e.variant = 2;
-  e.x_f32 = ix->d_bqf32; e.row_offsets = nullptr; e.stride = rpq; e.n_pages = nb; e.is_query = 1; e.out_f32 = ix->d_bqfde;
-  rc = launch_fde_encode(ix->fde_t, e, ix->stream);
-  if (rc) return rc;
   const int64_t cap = ix->cfg.capacity_pages;
-  FdeScanBatchArgs sa{};
-  sa.fde = ix->fde; sa.inv_norm = ix->fde_cosine ? ix->fde_inv_norm : nullptr; sa.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
-  sa.allow = d_allow; sa.n_allow_bits = n_allow_words * 32; sa.allow_stride_bits = per_query ? n_allow_words * 32 : 0;
-  sa.q = ix->d_bqfde; sa.image = ix->d_bqimage; sa.scores = ix->d_bscores; sa.score_stride = cap; sa.n = n; sa.out_dim = ix->fde_t.out_dim; sa.n_queries = nb;
-  sa.hi_only = ix->fde_batch_variant == 2;
-  sa.single_tile = ix->fde_batch_variant == 3;
-  sa.half_tiles = ix->fde_batch_variant == 4;
-  sa.separate_finish = ix->fde_batch_variant == 5;
-  if (ix->fde_batch_variant != 5 && topk_uses_radix(n, n_coarse)) {  // the finish pass bins the scores for the selection (mv_api.hip)
-    sa.hist0 = topk_radix_hist0(ix->d_btopk_ws);
-    sa.hist0_stride_bytes = (int64_t)ix->topk_ws_bytes;
+  bool prebinned = false;
+  if (fde) {
+    FdeEncodeArgs e{};
+    e.variant = 2;
+    e.x_f32 = ix->d_bqf32; e.row_offsets = nullptr; e.stride = rpq; e.n_pages = nb; e.is_query = 1; e.out_f32 = ix->d_bqfde;
+    rc = launch_fde_encode(ix->fde_t, e, ix->stream);
+    if (rc) return rc;
+    FdeScanBatchArgs sa{};
+    sa.fde = ix->fde; sa.inv_norm = ix->fde_cosine ? ix->fde_inv_norm : nullptr; sa.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
+    sa.allow = d_allow; sa.n_allow_bits = n_allow_words * 32; sa.allow_stride_bits = per_query ? n_allow_words * 32 : 0;
+    sa.q = ix->d_bqfde; sa.image = ix->d_bqimage; sa.scores = ix->d_bscores; sa.score_stride = cap; sa.n = n; sa.out_dim = ix->fde_t.out_dim; sa.n_queries = nb;
+    sa.hi_only = ix->fde_batch_variant == 2;
+    sa.single_tile = ix->fde_batch_variant == 3;
+    sa.half_tiles = ix->fde_batch_variant == 4;
+    sa.separate_finish = ix->fde_batch_variant == 5;
+    if (ix->fde_batch_variant != 5 && topk_uses_radix(n, n_coarse)) {  // the finish pass bins the scores for the selection (mv_api.hip)
+      sa.hist0 = topk_radix_hist0(ix->d_btopk_ws);
+      sa.hist0_stride_bytes = (int64_t)ix->topk_ws_bytes;
+    }
+    prebinned = fde_scan_batch_prebins(sa);
+    rc = launch_fde_scan_batch(sa, ix->stream);
+    if (rc) return rc;
+  } else {
+    rc = launch_fp8_query_prep(ix->d_bqf32, 512, ix->d_bq8hi, ix->d_bq8lo, ix->d_bq8fac, ix->stream);
+    if (rc) return rc;
+    Fp8BatchArgs a{};
+    a.slab = ix->slab8; a.inv_scale = ix->inv_scale8; a.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr; a.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
+    a.allow = d_allow; a.n_allow_bits = n_allow_words * 32; a.allow_stride_bits = per_query ? n_allow_words * 32 : 0;
+    a.qhi = ix->d_bq8hi; a.qlo = ix->d_bq8lo; a.qfac = ix->d_bq8fac; a.scores = ix->d_bscores; a.n = n; a.score_stride = cap;
+    a.stride = ix->cfg.stride_rows; a.n_queries = nb; a.rows_per_query = rpq; a.single_term = ix->batch_variant == 7 ? 1 : 0;
+    rc = launch_maxsim_batch_fp8(a, ix->stream);
+    if (rc) return rc;
   }
-  const bool prebinned = fde_scan_batch_prebins(sa);
-  rc = launch_fde_scan_batch(sa, ix->stream);
-  if (rc) return rc;
   // local coarse top-n of every request, GLOBAL ids, padded with (-inf, -1) when the shard holds fewer pages
   rc = launch_topk_batch(ix->d_bscores, cap, n, n_coarse, nullptr, 0, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bsel_s, ix->d_bsel_id,
                          n_coarse, nb, ix->stream, prebinned);
@@ -299,26 +390,11 @@ int mv_internal_two_stage_batch_coarse(mv_index* ix, const void* q, int q_dtype,
   return hand_back(ix, stream);
 }
 
-int mv_internal_two_stage_batch_rerank(mv_index* ix, const void* q, int q_dtype, int32_t nb, int32_t n_q_rows, const mv_cand_rec* d_all_recs,
-                                       int32_t world, int32_t n_coarse, int32_t k, float* d_out_scores, int64_t* d_out_ids, void* stream) {
-  const bool use_fp8 = !(ix->cfg.flags & MV_WITH_FLOAT);
-  if (use_fp8 && !(ix->cfg.flags & MV_WITH_FP8)) { set_error("index has neither a float nor an fp8 slab"); return MV_ERR_STATE; }
-  std::lock_guard<std::mutex> lk(ix->q_mu);
-  DeviceGuard g(ix->cfg.device);
-  int rc = order_behind(ix, stream);
-  if (rc) return rc;
-  rc = mv_internal_ensure_fde_batch_ws(ix);
-  if (rc) return rc;
+// gathered records of the group -> every request's GLOBAL top-n -> this shard's lists d_bcand / d_bcand_pads ([nb][n_coarse])
+static int global_owned_lists_batch(mv_index* ix, int mode, int nb, const mv_cand_rec* d_all_recs, int world, int n_coarse) {
   const int64_t n = ix->size.load(std::memory_order_acquire);
   const int total = world * n_coarse;
-  if ((int64_t)nb * total > ix->gscores_cap) {  // [nb][world * n_coarse] gathered coarse scores
-    if (ix->d_gscores) (void)hipFree(ix->d_gscores);
-    ix->d_gscores = nullptr; ix->gscores_cap = 0;
-    MV_HIP(hipMalloc(&ix->d_gscores, (size_t)kFdeBatchMaxQueries * 16384 * 4));
-    ix->gscores_cap = (int64_t)kFdeBatchMaxQueries * 16384;
-  }
-  // the group's queries again (another caller may have used the workspace between the stages)
-  rc = mv_internal_batch_upload_queries(ix, q, q_dtype, nb, n_q_rows, false, !use_fp8, use_fp8);
+  int rc = ensure_gscores(ix, (int64_t)nb * total);  // [nb][world * n_coarse] gathered coarse scores
   if (rc) return rc;
   hipLaunchKernelGGL(recs_scores_batch_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)nb), dim3(256), 0, ix->stream, d_all_recs, (int)world, (int)nb,
                      (int)n_coarse, ix->d_gscores);
@@ -327,13 +403,64 @@ int mv_internal_two_stage_batch_rerank(mv_index* ix, const void* q, int q_dtype,
   rc = launch_topk_batch(ix->d_gscores, total, total, n_coarse, nullptr, 0, 0, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bsel_s, ix->d_bsel_id, n_coarse, nb,
                          ix->stream);
   if (rc) return rc;
-  const int pad_sem = ix->pad_semantics < 0 ? 1 : ix->pad_semantics;
   hipLaunchKernelGGL(owned_select_batch_kernel, dim3((unsigned)((n_coarse + kRerankBatch - 1) / kRerankBatch), (unsigned)nb), dim3(kRerankBatch), 0, ix->stream,
-                     d_all_recs, (const int64_t*)ix->d_bsel_id, (int)n_coarse, (int)nb, ix->cfg.id_base, ix->cfg.id_base + n, pad_sem, ix->d_bcand,
+                     d_all_recs, (const int64_t*)ix->d_bsel_id, (int)n_coarse, (int)nb, ix->cfg.id_base, ix->cfg.id_base + n, two_stage_pad_sem(ix, mode), ix->d_bcand,
                      ix->d_bcand_pads);
   MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
+// the pruning stage of a group: e4m3 scores of every request's owned candidates -> d_out_mid [nb][n_coarse] (-inf elsewhere)
+int mv_internal_two_stage_batch_mid(mv_index* ix, const void* q, int q_dtype, int32_t nb, int32_t n_q_rows, int mode, const mv_cand_rec* d_all_recs,
+                                    int32_t world, int32_t n_coarse, float* d_out_mid, void* stream) {
+  std::lock_guard<std::mutex> lk(ix->q_mu);
+  DeviceGuard g(ix->cfg.device);
+  int rc = order_behind(ix, stream);
+  if (rc) return rc;
+  rc = mv_internal_ensure_fde_batch_ws(ix);
+  if (rc) return rc;
+  rc = mv_internal_batch_upload_queries(ix, q, q_dtype, nb, n_q_rows, false, false, true);
+  if (rc) return rc;
+  rc = global_owned_lists_batch(ix, mode, nb, d_all_recs, world, n_coarse);
+  if (rc) return rc;
   int launches = 0;
-  rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, n_coarse, &launches, nullptr);
+  rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, n_coarse, &launches, nullptr, d_out_mid);
+  if (rc) return rc;
+  return hand_back(ix, stream);
+}
+
+int mv_internal_two_stage_batch_rerank(mv_index* ix, const void* q, int q_dtype, int32_t nb, int32_t n_q_rows, int mode, const mv_cand_rec* d_all_recs,
+                                       int32_t world, int32_t n_coarse, const float* d_all_mid, int32_t n_mid, int32_t k, float* d_out_scores,
+                                       int64_t* d_out_ids, void* stream) {
+  std::lock_guard<std::mutex> lk(ix->q_mu);
+  const int rpq = ((n_q_rows + 15) / 16) * 16;
+  const RerankPlan plan = rerank_plan(ix, mode, n_coarse, k, rpq, true);
+  const bool use_fp8 = plan.final_fp8;
+  if (use_fp8 && mode == MV_MODE_FP8_THEN_FLOAT) { set_error("MV_MODE_FP8_THEN_FLOAT needs an exact tier (MV_WITH_FLOAT or MV_WITH_HOST_EXACT)"); return MV_ERR_STATE; }
+  if (use_fp8 && !(ix->cfg.flags & MV_WITH_FP8)) { set_error("index has neither an exact tier nor an fp8 slab"); return MV_ERR_STATE; }
+  DeviceGuard g(ix->cfg.device);
+  int rc = order_behind(ix, stream);
+  if (rc) return rc;
+  rc = mode == MV_MODE_FDE_THEN_FLOAT ? mv_internal_ensure_fde_batch_ws(ix) : mv_internal_ensure_fp8_batch_ws(ix);
+  if (rc) return rc;
+  // the group's queries again (another caller may have used the workspace between the stages)
+  rc = mv_internal_batch_upload_queries(ix, q, q_dtype, nb, n_q_rows, false, !use_fp8, use_fp8);
+  if (rc) return rc;
+  rc = global_owned_lists_batch(ix, mode, nb, d_all_recs, world, n_coarse);
+  if (rc) return rc;
+  if (d_all_mid) {  // [world][nb][n_coarse] e4m3 scores -> every request's n_mid best list positions -> the rest of its list becomes -1
+    const int64_t tot = (int64_t)nb * n_coarse;
+    rc = ensure_gscores(ix, tot);
+    if (rc) return rc;
+    hipLaunchKernelGGL(mid_combine_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ix->stream, d_all_mid, (int)world, tot, ix->d_gscores);
+    const int nm = std::min(n_mid, n_coarse);
+    rc = launch_topk_batch(ix->d_gscores, n_coarse, n_coarse, nm, nullptr, 0, 0, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bsel_s, ix->d_bsel_id, n_coarse, nb, ix->stream);
+    if (rc) return rc;
+    rc = launch_keep_selected(ix->d_bsel_id, n_coarse, nm, ix->d_bcand, n_coarse, n_coarse, nb, ix->stream);
+    if (rc) return rc;
+  }
+  int launches = 0;
+  rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, n_coarse, &launches, plan.exact, nullptr);
   if (rc) return rc;
   // local top-k of the owned candidates of every request; equal scores resolve by coarse rank, as on one index
   rc = launch_topk_batch(ix->d_bcand_scores, n_coarse, n_coarse, k, ix->d_bcand, n_coarse, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, d_out_scores,
@@ -382,11 +509,15 @@ struct Shard {
   int64_t* d_gi = nullptr;
   mv_cand_rec* d_recs = nullptr;  // [1024] local coarse candidates
   mv_cand_rec* d_all = nullptr;   // [R][1024] gathered coarse candidates
+  float* d_mid = nullptr;         // [1024] e4m3 scores of the owned entries of the global list (pruning stage), -inf elsewhere
+  float* d_mid_all = nullptr;     // [R][1024]
   // batched two-stage queries (allocated on first use): <= 32 requests per group
   mv_cand_rec* d_brecs = nullptr;  // [32][1024]
   mv_cand_rec* d_ball = nullptr;   // [R][32][1024]
   float* d_bls = nullptr;          // [32][1024] local top-k of every request
   int64_t* d_bli = nullptr;
+  float* d_bmid = nullptr;         // [32][1024] pruning-stage scores of a request group
+  float* d_bmid_all = nullptr;     // [R][32][1024]
   ncclComm_t nccl = nullptr;
 };
 
@@ -405,6 +536,7 @@ struct mv_comm {
   float* h_bs = nullptr;          // pinned host: [R][32][1024] local top-k lists of a request group (batched queries)
   int64_t* h_bi = nullptr;
   mv_cand_rec* h_brecs = nullptr; // pinned host: [R][32][1024] (HOST transport)
+  float* h_mid = nullptr;         // pinned host: [R][32][1024] pruning-stage scores (HOST transport)
   std::mutex mu;
 };
 
@@ -494,11 +626,52 @@ void* src_recs(Shard& s) { return s.d_recs; }
 void* dst_all(Shard& s) { return s.d_all; }
 void* src_brecs(Shard& s) { return s.d_brecs; }
 void* dst_ball(Shard& s) { return s.d_ball; }
+void* src_mid(Shard& s) { return s.d_mid; }
+void* dst_mid_all(Shard& s) { return s.d_mid_all; }
+void* src_bmid(Shard& s) { return s.d_bmid; }
+void* dst_bmid_all(Shard& s) { return s.d_bmid_all; }
+
+// every shard's `bytes` through the host: D2H into h[i], wait, H2D of the assembled block to every shard (the reference transport)
+int exchange_host(mv_comm* c, size_t bytes, void* h, void* (*src)(Shard&), void* (*dst)(Shard&));
 
 int sync_all(mv_comm* c) {
   for (int i = 0; i < c->n; ++i) {
     DeviceGuard g(c->sh[i].dev);
     MV_HIP(hipStreamSynchronize(c->sh[i].cs));
+  }
+  return MV_OK;
+}
+
+int exchange_host(mv_comm* c, size_t bytes, void* h, void* (*src)(Shard&), void* (*dst)(Shard&)) {
+  const int R = c->n;
+  for (int i = 0; i < R; ++i) {
+    Shard& s = c->sh[i];
+    DeviceGuard g(s.dev);
+    MV_HIP(hipMemcpyAsync((char*)h + (size_t)i * bytes, src(s), bytes, hipMemcpyDeviceToHost, s.cs));
+  }
+  int rc = sync_all(c);
+  if (rc) return rc;
+  for (int i = 0; i < R; ++i) {
+    Shard& s = c->sh[i];
+    DeviceGuard g(s.dev);
+    MV_HIP(hipMemcpyAsync(dst(s), h, bytes * (size_t)R, hipMemcpyHostToDevice, s.cs));
+  }
+  return MV_OK;
+}
+
+// The rerank plan of a two-stage query must be the same on every shard (same slabs, same options): the pruning stage needs every
+// shard's scores of the global list.
+int comm_plan(mv_comm* c, int mode, int n_coarse, int k, int n_q_rows, bool batched, RerankPlan* out) {
+  const int rpq = ((n_q_rows + 15) / 16) * 16;
+  for (int i = 0; i < c->n; ++i) {
+    mv_index* ix = c->sh[i].ix;
+    std::lock_guard<std::mutex> ql(ix->q_mu);
+    const RerankPlan p = rerank_plan(ix, mode, n_coarse, k, rpq, batched);
+    if (i == 0) *out = p;
+    else if (p.mid != out->mid || p.n_mid != out->n_mid || p.final_fp8 != out->final_fp8 || p.host_tier != out->host_tier) {
+      set_error("two-stage query: shard %d keeps different slabs / rerank options than shard 0 (exact tier, fp8 slab, MV_OPT_RERANK_N, MV_OPT_EXACT_TIER must agree)", i);
+      return MV_ERR_STATE;
+    }
   }
   return MV_OK;
 }
@@ -514,7 +687,7 @@ void mv_comm_destroy(mv_comm* c) {
     if (s.cs) (void)hipStreamSynchronize(s.cs);
     if (s.nccl && c->rccl.CommDestroy) (void)c->rccl.CommDestroy(s.nccl);
     for (void* p : {(void*)s.d_ls, (void*)s.d_li, (void*)s.d_gs, (void*)s.d_gi, (void*)s.d_recs, (void*)s.d_all, (void*)s.d_brecs, (void*)s.d_ball,
-                    (void*)s.d_bls, (void*)s.d_bli})
+                    (void*)s.d_bls, (void*)s.d_bli, (void*)s.d_mid, (void*)s.d_mid_all, (void*)s.d_bmid, (void*)s.d_bmid_all})
       if (p) (void)hipFree(p);
     for (hipEvent_t e : {s.ev_t0, s.ev_t1, s.ev_done})
       if (e) (void)hipEventDestroy(e);
@@ -525,7 +698,7 @@ void mv_comm_destroy(mv_comm* c) {
     if (c->d_os) (void)hipFree(c->d_os);
     if (c->d_oi) (void)hipFree(c->d_oi);
   }
-  for (void* p : {(void*)c->h_s, (void*)c->h_i, (void*)c->h_recs, (void*)c->h_bs, (void*)c->h_bi, (void*)c->h_brecs})
+  for (void* p : {(void*)c->h_s, (void*)c->h_i, (void*)c->h_recs, (void*)c->h_bs, (void*)c->h_bi, (void*)c->h_brecs, (void*)c->h_mid})
     if (p) (void)hipHostFree(p);
   // the RCCL handle stays loaded for the life of the process (its worker threads outlive communicators)
   delete c;
@@ -558,7 +731,8 @@ int mv_comm_create(int32_t n_shards, const int32_t* device_ids, int32_t transpor
         hipEventCreate(&s.ev_t1) != hipSuccess || hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) != hipSuccess) { set_error("mv_comm_create: stream / event creation failed"); rc = MV_ERR_HIP; break; }
     if (hipMalloc(&s.d_ls, kK * 4) != hipSuccess || hipMalloc(&s.d_li, kK * 8) != hipSuccess || hipMalloc(&s.d_gs, R * kK * 4) != hipSuccess ||
         hipMalloc(&s.d_gi, R * kK * 8) != hipSuccess || hipMalloc(&s.d_recs, kK * sizeof(mv_cand_rec)) != hipSuccess ||
-        hipMalloc(&s.d_all, R * kK * sizeof(mv_cand_rec)) != hipSuccess) { set_error("mv_comm_create: out of device memory"); rc = MV_ERR_NOMEM; break; }
+        hipMalloc(&s.d_all, R * kK * sizeof(mv_cand_rec)) != hipSuccess || hipMalloc(&s.d_mid, kK * 4) != hipSuccess ||
+        hipMalloc(&s.d_mid_all, R * kK * 4) != hipSuccess) { set_error("mv_comm_create: out of device memory"); rc = MV_ERR_NOMEM; break; }
   }
   if (!rc) {
     DeviceGuard g(c->sh[0].dev);
@@ -566,7 +740,8 @@ int mv_comm_create(int32_t n_shards, const int32_t* device_ids, int32_t transpor
     if (hipMalloc(&c->d_os, kK * 4) != hipSuccess || hipMalloc(&c->d_oi, kK * 8) != hipSuccess ||
         hipHostMalloc((void**)&c->h_s, (R + 1) * kK * 4, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&c->h_i, (R + 1) * kK * 8, hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_recs, R * kK * sizeof(mv_cand_rec), hipHostMallocDefault) != hipSuccess) { set_error("mv_comm_create: out of memory"); rc = MV_ERR_NOMEM; }
+        hipHostMalloc((void**)&c->h_recs, R * kK * sizeof(mv_cand_rec), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_mid, R * (size_t)kFdeBatchMaxQueries * kK * 4, hipHostMallocDefault) != hipSuccess) { set_error("mv_comm_create: out of memory"); rc = MV_ERR_NOMEM; }
   }
   if (rc) return fail(rc);
   c->transport = transport;
@@ -616,7 +791,7 @@ int mv_comm_query_topk(mv_comm* c, const void* q, int q_dtype, int32_t n_q_rows,
     if (!c->sh[i].ix) { set_error("mv_comm_query_topk: shard %d has no index attached", i); return MV_ERR_STATE; }
   if (stats) memset(stats, 0, sizeof(mv_query_stats) * (size_t)R);
   if (k == 0) return MV_OK;
-  const bool two_stage = mode == MV_MODE_FDE_THEN_FLOAT;
+  const bool two_stage = mode == MV_MODE_FDE_THEN_FLOAT || mode == MV_MODE_FP8_THEN_FLOAT;
   int rc = MV_OK;
   // ---- enqueue the local work of every shard; nothing below waits for a GPU until the final copy
   for (int i = 0; i < R; ++i) {
@@ -626,34 +801,37 @@ int mv_comm_query_topk(mv_comm* c, const void* q, int q_dtype, int32_t n_q_rows,
   }
   int n_coarse = 0;
   if (two_stage) {
-    n_coarse = (int)std::min<int64_t>(coarse_n_for(c->sh[0].ix, k), kK);
+    // the candidate rule of ONE index: FDE coarse top-n (reference: min(10 k, 75)) or the e4m3 scan's top-max(MV_OPT_RERANK_N, k),
+    // taken over ALL shards before anything is reranked
+    n_coarse = mode == MV_MODE_FDE_THEN_FLOAT ? (int)std::min<int64_t>(coarse_n_for(c->sh[0].ix, k), kK)
+                                              : (int)std::min<int64_t>(std::max<int64_t>(c->sh[0].ix->rerank_n, k), kK);
     if ((int64_t)R * n_coarse > 16384) { set_error("two-stage query: %d shards x %d candidates exceed 16384", R, n_coarse); return MV_ERR_INVALID; }
+    RerankPlan plan;
+    rc = comm_plan(c, mode, n_coarse, k, n_q_rows, false, &plan);
+    if (rc) return rc;
     for (int i = 0; i < R; ++i) {
       Shard& s = c->sh[i];
-      rc = mv_two_stage_coarse_device(s.ix, q, q_dtype, n_q_rows, n_coarse, allow_bits, n_allow_words, s.d_recs, s.cs);
+      rc = mv_two_stage_coarse_device(s.ix, q, q_dtype, n_q_rows, n_coarse, mode, allow_bits, n_allow_words, s.d_recs, s.cs);
       if (rc) return rc;
     }
     const size_t rb = (size_t)n_coarse * sizeof(mv_cand_rec);
-    if (c->transport == MV_COMM_HOST) {
+    if (c->transport == MV_COMM_HOST) rc = exchange_host(c, rb, c->h_recs, src_recs, dst_all);
+    else rc = exchange(c, rb, true, src_recs, dst_all);
+    if (rc) return rc;
+    if (plan.mid) {  // pruning stage: every shard scores its share of the global list on its e4m3 slab; n floats per shard are exchanged
       for (int i = 0; i < R; ++i) {
         Shard& s = c->sh[i];
-        DeviceGuard g(s.dev);
-        MV_HIP(hipMemcpyAsync(c->h_recs + (size_t)i * n_coarse, s.d_recs, rb, hipMemcpyDeviceToHost, s.cs));
+        rc = mv_two_stage_mid_device(s.ix, q, q_dtype, n_q_rows, mode, s.d_all, R, n_coarse, s.d_mid, s.cs);
+        if (rc) return rc;
       }
-      rc = sync_all(c);
-      if (rc) return rc;
-      for (int i = 0; i < R; ++i) {
-        Shard& s = c->sh[i];
-        DeviceGuard g(s.dev);
-        MV_HIP(hipMemcpyAsync(s.d_all, c->h_recs, rb * (size_t)R, hipMemcpyHostToDevice, s.cs));
-      }
-    } else {
-      rc = exchange(c, rb, true, src_recs, dst_all);
+      const size_t mb = (size_t)n_coarse * 4;
+      if (c->transport == MV_COMM_HOST) rc = exchange_host(c, mb, c->h_mid, src_mid, dst_mid_all);
+      else rc = exchange(c, mb, true, src_mid, dst_mid_all);
       if (rc) return rc;
     }
     for (int i = 0; i < R; ++i) {
       Shard& s = c->sh[i];
-      rc = mv_two_stage_rerank_device(s.ix, q, q_dtype, n_q_rows, s.d_all, R, n_coarse, k, s.d_ls, s.d_li, s.cs);
+      rc = mv_two_stage_rerank_device(s.ix, q, q_dtype, n_q_rows, mode, s.d_all, R, n_coarse, plan.mid ? s.d_mid_all : nullptr, plan.n_mid, k, s.d_ls, s.d_li, s.cs);
       if (rc) return rc;
     }
   } else {
@@ -740,19 +918,28 @@ int mv_comm_query_topk_batch(mv_comm* c, const void* q, int q_dtype, int32_t n_q
   const size_t esz = q_dtype == MV_F32 ? 4 : 2;
   const int rpq = ((n_q_rows + 15) / 16) * 16;
   const int R = c->n;
-  bool batched = mode == MV_MODE_FDE_THEN_FLOAT && n_queries > 1 && k >= 1 && rpq <= 512;
+  const bool fde_mode = mode == MV_MODE_FDE_THEN_FLOAT;
+  bool batched = (fde_mode || mode == MV_MODE_FP8_THEN_FLOAT) && n_queries > 1 && k >= 1 && rpq <= (fde_mode ? 512 : kMaxQRowsPerPass);
   int n_coarse = 0;
+  RerankPlan plan;
   if (batched) {
     std::lock_guard<std::mutex> lk(c->mu);
     for (int i = 0; i < R && batched; ++i) {
       mv_index* ix = c->sh[i].ix;
       if (!ix) { set_error("mv_comm_query_topk_batch: shard %d has no index attached", i); return MV_ERR_STATE; }
-      const bool fp8_rr = !(ix->cfg.flags & MV_WITH_FLOAT);
-      batched = (ix->cfg.flags & MV_WITH_FDE) && ix->fde_batch_variant != 1 && fde_scan_batch_supported(ix->fde_t.out_dim) &&
-                ix->fde_t.cfg.projection_dimension <= 16 && (!fp8_rr || ((ix->cfg.flags & MV_WITH_FP8) && rpq <= 64));
+      const bool fp8_rr = !(ix->cfg.flags & (MV_WITH_FLOAT | MV_WITH_HOST_EXACT));
+      if (fde_mode)
+        batched = (ix->cfg.flags & MV_WITH_FDE) && ix->fde_batch_variant != 1 && fde_scan_batch_supported(ix->fde_t.out_dim) &&
+                  ix->fde_t.cfg.projection_dimension <= 16 && (!fp8_rr || ((ix->cfg.flags & MV_WITH_FP8) && rpq <= 64));
+      else
+        batched = (ix->cfg.flags & MV_WITH_FP8) && !fp8_rr && ix->batch_variant != 8;
     }
-    n_coarse = (int)std::min<int64_t>(coarse_n_for(c->sh[0].ix, k), kK);
+    n_coarse = fde_mode ? (int)std::min<int64_t>(coarse_n_for(c->sh[0].ix, k), kK) : (int)std::min<int64_t>(std::max<int64_t>(c->sh[0].ix->rerank_n, k), kK);
     if ((int64_t)R * n_coarse > 16384) batched = false;
+    if (batched) {
+      int prc = comm_plan(c, mode, n_coarse, k, n_q_rows, true, &plan);
+      if (prc) return prc;
+    }
   }
   if (!batched) {  // request by request through the single-query communicator (each call takes c->mu itself)
     for (int32_t b = 0; b < n_queries; ++b) {
@@ -773,14 +960,15 @@ int mv_comm_query_topk_batch(mv_comm* c, const void* q, int q_dtype, int32_t n_q
     if (s.d_brecs) continue;
     DeviceGuard g(s.dev);
     if (hipMalloc(&s.d_brecs, (size_t)kG * kK * sizeof(mv_cand_rec)) != hipSuccess || hipMalloc(&s.d_ball, (size_t)R * kG * kK * sizeof(mv_cand_rec)) != hipSuccess ||
-        hipMalloc(&s.d_bls, (size_t)kG * kK * 4) != hipSuccess || hipMalloc(&s.d_bli, (size_t)kG * kK * 8) != hipSuccess) { set_error("mv_comm_query_topk_batch: out of device memory"); return MV_ERR_NOMEM; }
+        hipMalloc(&s.d_bls, (size_t)kG * kK * 4) != hipSuccess || hipMalloc(&s.d_bli, (size_t)kG * kK * 8) != hipSuccess ||
+        hipMalloc(&s.d_bmid, (size_t)kG * kK * 4) != hipSuccess || hipMalloc(&s.d_bmid_all, (size_t)R * kG * kK * 4) != hipSuccess) { set_error("mv_comm_query_topk_batch: out of device memory"); return MV_ERR_NOMEM; }
   }
   if (!c->h_bs) {
     if (hipHostMalloc((void**)&c->h_bs, (size_t)R * kG * kK * 4, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&c->h_bi, (size_t)R * kG * kK * 8, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&c->h_brecs, (size_t)R * kG * kK * sizeof(mv_cand_rec), hipHostMallocDefault) != hipSuccess) { set_error("mv_comm_query_topk_batch: out of pinned memory"); return MV_ERR_NOMEM; }
   }
-  const int group = std::min(kBatchQRows / rpq, kG);
+  const int group = std::min((fde_mode ? kBatchQRows : 512) / rpq, kG);  // query rows per pass of the batched FDE / e4m3 scan
   const bool per_query = allow_bits && allow_per_query;
   int rc = MV_OK;
   std::vector<float> ms((size_t)R * k), os((size_t)k);
@@ -796,30 +984,28 @@ int mv_comm_query_topk_batch(mv_comm* c, const void* q, int q_dtype, int32_t n_q
     }
     for (int i = 0; i < R; ++i) {
       Shard& s = c->sh[i];
-      rc = mv_internal_two_stage_batch_coarse(s.ix, qg, q_dtype, nb, n_q_rows, n_coarse, ag, n_allow_words, per_query ? 1 : 0, s.d_brecs, s.cs);
+      rc = mv_internal_two_stage_batch_coarse(s.ix, qg, q_dtype, nb, n_q_rows, n_coarse, mode, ag, n_allow_words, per_query ? 1 : 0, s.d_brecs, s.cs);
       if (rc) return rc;
     }
     const size_t rb = (size_t)nb * n_coarse * sizeof(mv_cand_rec);
-    if (c->transport == MV_COMM_HOST) {
+    if (c->transport == MV_COMM_HOST) rc = exchange_host(c, rb, c->h_brecs, src_brecs, dst_ball);
+    else rc = exchange(c, rb, true, src_brecs, dst_ball);
+    if (rc) return rc;
+    if (plan.mid) {
       for (int i = 0; i < R; ++i) {
         Shard& s = c->sh[i];
-        DeviceGuard g(s.dev);
-        MV_HIP(hipMemcpyAsync((char*)c->h_brecs + (size_t)i * rb, s.d_brecs, rb, hipMemcpyDeviceToHost, s.cs));
+        rc = mv_internal_two_stage_batch_mid(s.ix, qg, q_dtype, nb, n_q_rows, mode, s.d_ball, R, n_coarse, s.d_bmid, s.cs);
+        if (rc) return rc;
       }
-      rc = sync_all(c);
-      if (rc) return rc;
-      for (int i = 0; i < R; ++i) {
-        Shard& s = c->sh[i];
-        DeviceGuard g(s.dev);
-        MV_HIP(hipMemcpyAsync(s.d_ball, c->h_brecs, rb * (size_t)R, hipMemcpyHostToDevice, s.cs));
-      }
-    } else {
-      rc = exchange(c, rb, true, src_brecs, dst_ball);
+      const size_t mb = (size_t)nb * n_coarse * 4;
+      if (c->transport == MV_COMM_HOST) rc = exchange_host(c, mb, c->h_mid, src_bmid, dst_bmid_all);
+      else rc = exchange(c, mb, true, src_bmid, dst_bmid_all);
       if (rc) return rc;
     }
     for (int i = 0; i < R; ++i) {
       Shard& s = c->sh[i];
-      rc = mv_internal_two_stage_batch_rerank(s.ix, qg, q_dtype, nb, n_q_rows, s.d_ball, R, n_coarse, k, s.d_bls, s.d_bli, s.cs);
+      rc = mv_internal_two_stage_batch_rerank(s.ix, qg, q_dtype, nb, n_q_rows, mode, s.d_ball, R, n_coarse, plan.mid ? s.d_bmid_all : nullptr, plan.n_mid, k, s.d_bls,
+                                              s.d_bli, s.cs);
       if (rc) return rc;
     }
     for (int i = 0; i < R; ++i) {

@@ -160,8 +160,30 @@ int upload_allow(mv_index* ix, const uint32_t* allow_bits, int64_t n_words, cons
 // histogram and *hist0_done tells the caller to pass that on to launch_topk.
 int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_words, int64_t n, int* launches, bool stage_events = false,
                     int32_t k_next = 0, bool* hist0_done = nullptr);
-int rerank_scan(mv_index* ix, int n_q, bool use_fp8, int64_t n_items, float* d_out, int* launches);
+int rerank_scan(mv_index* ix, int n_q, bool use_fp8, int64_t n_items, float* d_out, int* launches, const uint16_t* exact = nullptr);
+// e4m3 scan of pages 0..n_items-1 (or of the candidate list d_cand) with the query uploaded by upload_query(want_fp8)
+int fp8_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_words, const int32_t* d_cand, int64_t n_items,
+             int32_t pad_to, const int32_t* d_pad_items, float* d_out, int* launches, bool no_mask = false);
 int64_t coarse_n_for(const mv_index* ix, int k);
+
+// Which copy of the candidates' rows the rerank of a cascade reads (FastMultiVectorStore reranks with exact fp32 MaxSim on fp32
+// pages: fast_multivector_store.py:553-556, upcast at load :736,774), and whether an e4m3 stage prunes the list first.
+//   exact      bf16 rows of the exact tier: the HBM slab, or the pinned-host tier mapped into the device (MV_WITH_HOST_EXACT);
+//              null = the index keeps no exact copy: the e4m3 slab is the best it has (final_fp8)
+//   mid        the exact tier is host memory and the list is longer than MV_OPT_RERANK_N: the candidates are first re-scored on
+//              the e4m3 slab (HBM) and only the n_mid best of them (ties by list position) are read over PCIe
+struct RerankPlan {
+  const uint16_t* exact = nullptr;
+  bool host_tier = false;
+  bool final_fp8 = false;
+  bool mid = false;
+  int32_t n_mid = 0;
+};
+// n_list: candidates entering the rerank; rpq: padded query rows; batched: the batched one-launch rerank (e4m3 form: <= 64 rows)
+RerankPlan rerank_plan(const mv_index* ix, int mode, int64_t n_list, int32_t k, int rpq, bool batched);
+// Keep only the entries of each candidate list whose POSITION is named in pos ([nb][n_sel], padded with -1): the others become
+// -1 (skipped by the rerank kernels).  The list keeps its order, so pad lengths and the tie rule (by list position) are untouched.
+int launch_keep_selected(const int64_t* d_pos, int64_t pos_stride, int n_sel, int32_t* d_cand, int64_t cand_stride, int n, int nb, hipStream_t s);
 int finish_stats(mv_index* ix, mv_query_stats* st, bool had_topk);
 
 }  // namespace mv
@@ -173,8 +195,10 @@ float host_bf16_to_f32(uint16_t h);
 // Batch workspace and stages of mv_api.hip shared with the batched two-stage communicator (mv_comm.hip).  Callers hold q_mu.
 extern "C" int mv_internal_ensure_batch_select_ws(mv_index* ix);
 extern "C" int mv_internal_ensure_fde_batch_ws(mv_index* ix);
+extern "C" int mv_internal_ensure_fp8_batch_ws(mv_index* ix);
 extern "C" int mv_internal_batch_upload_queries(mv_index* ix, const void* q, int q_dtype, int nb, int n_q_rows, bool want_f32, bool want_bf16, bool want_fp8);
-extern "C" int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t nc, int* launches, const uint16_t* exact_tier);
+// exact != null: bf16 rerank on that image (HBM slab or pinned-host tier); null: e4m3 rerank.  d_out null -> d_bcand_scores.
+extern "C" int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t nc, int* launches, const uint16_t* exact, float* d_out);
 
 extern "C" int mv_internal_query_common(mv_index* ix, const void* q, int q_dtype, int32_t n_q, int32_t k, int mode,
                                         const uint32_t* allow_bits, int64_t n_words, float* h_scores, int64_t* h_ids, int32_t* out_n,

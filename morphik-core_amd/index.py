@@ -198,6 +198,11 @@ class MvIndex:
 
     def set_option(self, option: int, value: int) -> None:
         check(lib().mv_index_set_option(self._h, option, int(value)))
+        self.__dict__.setdefault("_opts", {})[int(option)] = int(value)  # what was last set through this object
+
+    def get_option(self, option: int, default: int = 0) -> int:
+        """The value last set through set_option() on this object (the library has no getter), else `default`."""
+        return self.__dict__.get("_opts", {}).get(int(option), default)
 
     # -- build
     def add(self, pages: Sequence[Any], doc_ordinals: Optional[Sequence[int]] = None) -> int:
@@ -380,16 +385,34 @@ class MvIndex:
         return out[: c.size]
 
     # -- sharded two-stage pipeline (device-resident stages; see include/mvmaxsim.h)
-    def two_stage_coarse_device(self, q: Any, n_coarse: int, d_recs_ptr: int, allow: Optional[np.ndarray] = None, stream: int = 0) -> None:
+    def two_stage_coarse_device(self, q: Any, n_coarse: int, d_recs_ptr: int, allow: Optional[np.ndarray] = None, stream: int = 0,
+                                mode: str = "fde_then_float") -> None:
+        """Stage 1 of a staged query on this shard: coarse scan ("fde_then_float": the FDE slab; "fp8_then_float": the e4m3
+        slab) + local top-n_coarse -> n_coarse 16-byte records in a device buffer."""
         qa, code = as_rows(q)
         ab = None if allow is None else np.ascontiguousarray(allow, dtype=np.uint32)
-        check(lib().mv_two_stage_coarse_device(self._h, qa.ctypes.data, code, qa.shape[0], int(n_coarse), None if ab is None else ab.ctypes.data,
+        check(lib().mv_two_stage_coarse_device(self._h, qa.ctypes.data, code, qa.shape[0], int(n_coarse), MODES[mode], None if ab is None else ab.ctypes.data,
                                                0 if ab is None else ab.size, C.c_void_p(d_recs_ptr), C.c_void_p(stream) if stream else None))
 
-    def two_stage_rerank_device(self, q: Any, d_all_recs_ptr: int, world: int, n_coarse: int, k: int, d_scores_ptr: int, d_ids_ptr: int,
-                                stream: int = 0) -> None:
+    def rerank_plan(self, n_list: int, k: int, n_q_rows: int, mode: str = "fde_then_float", batched: bool = False) -> Tuple[int, str]:
+        """-> (n_mid, tier): tier = "hbm" | "host" | "fp8" (what the rerank of a list of n_list candidates reads on this index);
+        n_mid > 0: an e4m3 pruning stage keeps that many entries first (pinned-host tier behind a long FDE candidate list)."""
+        n_mid, tier = C.c_int32(), C.c_int32()
+        check(lib().mv_index_rerank_plan(self._h, MODES[mode], int(n_list), int(k), int(n_q_rows), 1 if batched else 0, C.byref(n_mid), C.byref(tier)))
+        return int(n_mid.value), ("hbm", "host", "fp8")[tier.value]
+
+    def two_stage_mid_device(self, q: Any, d_all_recs_ptr: int, world: int, n_coarse: int, d_mid_ptr: int, stream: int = 0,
+                             mode: str = "fde_then_float") -> None:
+        """Pruning stage: e4m3 scores of the entries of the GLOBAL coarse list this shard owns -> n_coarse floats (device)."""
         qa, code = as_rows(q)
-        check(lib().mv_two_stage_rerank_device(self._h, qa.ctypes.data, code, qa.shape[0], C.c_void_p(d_all_recs_ptr), int(world), int(n_coarse), int(k),
+        check(lib().mv_two_stage_mid_device(self._h, qa.ctypes.data, code, qa.shape[0], MODES[mode], C.c_void_p(d_all_recs_ptr), int(world), int(n_coarse),
+                                            C.c_void_p(d_mid_ptr), C.c_void_p(stream) if stream else None))
+
+    def two_stage_rerank_device(self, q: Any, d_all_recs_ptr: int, world: int, n_coarse: int, k: int, d_scores_ptr: int, d_ids_ptr: int,
+                                stream: int = 0, mode: str = "fde_then_float", d_all_mid_ptr: int = 0, n_mid: int = 0) -> None:
+        qa, code = as_rows(q)
+        check(lib().mv_two_stage_rerank_device(self._h, qa.ctypes.data, code, qa.shape[0], MODES[mode], C.c_void_p(d_all_recs_ptr), int(world), int(n_coarse),
+                                               C.c_void_p(d_all_mid_ptr) if d_all_mid_ptr else None, int(n_mid), int(k),
                                                C.c_void_p(d_scores_ptr), C.c_void_p(d_ids_ptr), C.c_void_p(stream) if stream else None))
 
     def page_rows(self, pages: Sequence[int]) -> np.ndarray:

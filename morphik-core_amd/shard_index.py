@@ -17,7 +17,7 @@ import numpy as np
 class ShardedIndex:
     def __init__(self, capacity_pages: int, stride_rows: int, devices: Sequence[int], with_float: bool = True, with_binary: bool = False,
                  with_fde: bool = False, with_fp8: bool = False, fde=None, transport: str = "auto", id_base: int = 0,
-                 index_cls=None, comm_cls=None):
+                 index_cls=None, comm_cls=None, with_host_exact: bool = False):
         from .index import MvIndex, ShardComm
 
         index_cls = index_cls or MvIndex
@@ -30,9 +30,10 @@ class ShardedIndex:
         self.stride_rows = int(stride_rows)
         self.id_base = int(id_base)
         self.device = self.devices[0]
+        extra = {"with_host_exact": True} if with_host_exact else {}  # every shard pins the exact rows of ITS pages (per / n of the corpus)
         self.shards = [
             index_cls(capacity_pages=self.per, stride_rows=stride_rows, device=d, with_float=with_float, with_binary=with_binary,
-                      with_fde=with_fde, with_fp8=with_fp8, fde=fde, id_base=self.id_base + r * self.per)
+                      with_fde=with_fde, with_fp8=with_fp8, fde=fde, id_base=self.id_base + r * self.per, **extra)
             for r, d in enumerate(self.devices)
         ]
         self.comm = comm_cls(self.shards, transport=transport)
@@ -139,9 +140,10 @@ class ShardedIndex:
         all requests; the shards run side by side, one host thread each -- the library releases the GIL), and the per-shard
         top-k lists of a request are merged with the communicator's rule (score desc, ties by ascending global id), which
         is the single-index order.  The two-stage FDE pipeline keeps its GLOBAL candidate rule (the coarse top-n is taken over
-        all shards before the rerank): its requests go through the communicator's batched form (mv_comm_query_topk_batch:
-        one FDE-slab pass per shard and 32 requests, one exchange of all their candidate records)."""
-        if mode == "fde_then_float" and len(queries) >= 2 and hasattr(self.comm, "query_batch"):
+        all shards before the rerank), and so does "fp8_then_float" (the e4m3 scan's GLOBAL top-n is re-scored exactly): their
+        requests go through the communicator's batched form (mv_comm_query_topk_batch: one FDE / e4m3 slab pass per shard and
+        group of requests, one exchange of all their candidate records)."""
+        if mode in ("fde_then_float", "fp8_then_float") and len(queries) >= 2 and hasattr(self.comm, "query_batch"):
             return self.comm.query_batch(queries, k, mode=mode, allow=allow, allows=allows, n_docs=n_docs, want_stats=want_stats)
         if mode not in self._SINGLE_STAGE or len(queries) < 2:
             out = []

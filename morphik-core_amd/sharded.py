@@ -189,32 +189,36 @@ class GpuShardedSearcher:
 
 
 class TwoStageShardedSearcher:
-    """FDE_THEN_FLOAT on a row-sharded corpus: the reference pipeline (FDE coarse search ->
-    top-n candidates -> exact MaxSim rerank -> top-k, fast_multivector_store.py:521-556) with the SAME candidate set
-    as one big index, whatever the rank count:
+    """The staged pipelines on a row-sharded corpus with the SAME candidate set as one big
+    index, whatever the rank count.  "fde_then_float" is the reference pipeline (FDE coarse search -> top-n candidates ->
+    exact MaxSim rerank -> top-k, fast_multivector_store.py:521-556); "fp8_then_float" takes the e4m3 scan's top-n instead:
 
-      1. every rank: FDE coarse scan of its shard -> local top-n (score, global id)
+      1. every rank: coarse scan of its shard -> local top-n (score, global id)
       2. all-gather of n pairs per rank (16 B each) -> global coarse top-n, identical on every rank
       3. every rank keeps the candidates IT OWNS; the candidates' row counts travel in the same all-gather, so every
          rank knows the pad length of each candidate: the longest page of ITS batch of 128 in the GLOBAL list
          (score_multi_vector scores passages in batches of 128, each padded on its own by pad_sequence, :553-555)
+      3b. (only with a pinned-host exact tier behind a list longer than MV_OPT_RERANK_N) pruning stage: every rank scores its
+         owned candidates on its e4m3 slab, the n scores per rank are all-gathered, the n_mid best list positions stay
       4. every rank: exact MaxSim of its own candidates (no embedding crosses xGMI) -> local top-k
       5. all-gather of k pairs per rank -> merged top-k
 
-    Two small collectives, both latency-bound.  This class is the host-driven form whose callables keep it testable on
+    Small collectives, all latency-bound.  This class is the host-driven form whose callables keep it testable on
     CPU (gloo + oracle); GpuTwoStageSearcher below is the device-resident form of the same steps.
       local_coarse(q, n, allow) -> (scores[n], ids[n]) tensors on the collective's device, padded (-inf, -1), GLOBAL ids
       local_rows(global_ids)    -> int array of row counts of owned pages
       local_rerank(q, global_ids, pads) -> float32 array of exact MaxSim scores of owned pages (pads[i] = pad length)
+      local_prune(q, global_ids, pads)  -> float32 array of e4m3 MaxSim scores of owned pages (optional; with n_mid)
     `id_range` = [lo, hi) of global ids this rank owns."""
 
     BATCH = 128  # score_multi_vector's passage batch size
 
     def __init__(self, local_coarse: Callable, local_rows: Callable, local_rerank: Callable, id_range: Tuple[int, int],
-                 group=None, pad_semantics: bool = True):
+                 group=None, pad_semantics: bool = True, local_prune: Optional[Callable] = None, n_mid: int = 0):
         self.local_coarse, self.local_rows, self.local_rerank = local_coarse, local_rows, local_rerank
         self.lo, self.hi = int(id_range[0]), int(id_range[1])
         self.group, self.pad = group, pad_semantics
+        self.local_prune, self.n_mid = local_prune, int(n_mid)
 
     # The local phases are public so that R logical shards on ONE device can be driven without a process group
     # (tests; SURVEY 8e "R logical shards on one device"); query() chains them with the collectives in between.
@@ -234,6 +238,28 @@ class TwoStageShardedSearcher:
             for j in range(0, gid.size, self.BATCH):
                 pads[j : j + self.BATCH] = rows[j : j + self.BATCH].max() if rows[j : j + self.BATCH].size else 0
         return pads
+
+    def prune_scores(self, q, gid, pads):
+        """This rank's e4m3 scores of the GLOBAL list: -inf at the positions other ranks own (float32 [n])."""
+        import numpy as np
+
+        out = np.full(gid.size, -np.inf, np.float32)
+        own = np.nonzero((gid >= self.lo) & (gid < self.hi))[0]
+        if own.size:
+            out[own] = np.asarray(self.local_prune(q, gid[own], pads[own]), np.float32)
+        return out
+
+    @staticmethod
+    def prune_keep(all_mid, n_mid: int):
+        """all_mid: [world, n] pruning scores (one owner per position) -> boolean mask of the n_mid best list positions
+        (score desc, ties by list position -- the rule of the library's selection)."""
+        import numpy as np
+
+        comb = np.max(np.asarray(all_mid, np.float32), axis=0)
+        order = np.lexsort((np.arange(comb.size), -comb.astype(np.float64)))[: int(n_mid)]
+        keep = np.zeros(comb.size, bool)
+        keep[order[np.isfinite(comb[order])]] = True
+        return keep
 
     def rerank(self, q, gid, pads, k: int):
         """gid / pads: the GLOBAL candidate list and its pad lengths.  -> local top-k (scores[k], ids[k]) of the candidates
@@ -277,21 +303,35 @@ class TwoStageShardedSearcher:
         order = torch.sort(gs, descending=True, stable=True).indices[:n]  # (score desc, id asc): ranks own ascending ids
         sel = torch.stack([gi[order], gr[order]]).cpu().numpy()  # ONE device->host copy: global top-n ids + row counts
         gid, grows = sel[0].astype(np.int64), sel[1]
-        ls, li = self.rerank(q, gid, self.batch_pads(gid, grows), k)
+        pads = self.batch_pads(gid, grows)
+        if self.local_prune is not None and 0 < self.n_mid < n:  # pruning stage: n e4m3 scores per rank, one small all-gather
+            mid = torch.from_numpy(self.prune_scores(q, gid, pads)).to(cs.device)
+            if dist.is_initialized():
+                allm = torch.empty(dist.get_world_size(self.group) * n, dtype=torch.float32, device=mid.device)
+                dist.all_gather_into_tensor(allm, mid, group=self.group)
+                allm = allm.view(-1, n)
+            else:
+                allm = mid.view(1, n)
+            gid = np.where(self.prune_keep(allm.cpu().numpy(), self.n_mid), gid, -1)  # the list keeps its order and pad lengths
+        ls, li = self.rerank(q, gid, pads, k)
         return allgather_topk(ls.to(cs.device), li.to(cs.device), k, self.group)
 
 
-def make_gpu_two_stage(index, device=None, group=None) -> TwoStageShardedSearcher:
-    """Host-driven TwoStageShardedSearcher over one MvIndex shard (FDE slab + bf16 or fp8 slab): coarse = MV_MODE_FDE_ONLY
-    top-n, rerank = mv_score_candidates_pads on the pages this rank owns.  The cross-check of GpuTwoStageSearcher."""
+def make_gpu_two_stage(index, device=None, group=None, mode: str = "fde_then_float", k: int = 10, coarse_n: int = 0, n_q_rows: int = 32) -> TwoStageShardedSearcher:
+    """Host-driven TwoStageShardedSearcher over one MvIndex shard: coarse = MV_MODE_FDE_ONLY (or, for "fp8_then_float", the
+    e4m3 scan's) top-n, rerank = mv_score_candidates_pads on the pages this rank owns (exact tier: bf16 slab, else the
+    pinned-host tier, else the e4m3 slab), pruning stage per the index's own plan.  The cross-check of GpuTwoStageSearcher."""
     import numpy as np
     import torch
 
+    from . import _lib
+
     dev = torch.device("cuda", index.device) if device is None else device
     base = int(index.id_base)
+    fde = mode == "fde_then_float"
 
     def coarse(q, n, allow):
-        s, i = index.query(q, n, mode="fde", allow=allow)
+        s, i = index.query(q, n, mode="fde" if fde else "float_fp8", allow=allow)
         ps = np.full(n, -np.inf, np.float32)
         pi = np.full(n, -1, np.int64)
         ps[: len(s)], pi[: len(i)] = s, i
@@ -303,24 +343,36 @@ def make_gpu_two_stage(index, device=None, group=None) -> TwoStageShardedSearche
     def rerank(q, gids, pads):
         return index.score_candidates(q, np.asarray(gids, np.int64) - base, pads=pads)
 
-    return TwoStageShardedSearcher(coarse, rows, rerank, (base, base + len(index)), group)
+    def prune(q, gids, pads):  # the e4m3 scores of the named pages (MV_OPT_EXACT_TIER 2), then back to the index's own tier
+        prev = index.get_option(_lib.MV_OPT_EXACT_TIER, 0)
+        index.set_option(_lib.MV_OPT_EXACT_TIER, 2)
+        try:
+            return index.score_candidates(q, np.asarray(gids, np.int64) - base, pads=pads)
+        finally:
+            index.set_option(_lib.MV_OPT_EXACT_TIER, prev)
+
+    n = int(coarse_n) if coarse_n else min(10 * k, 75)
+    n_mid, _tier = index.rerank_plan(n, k, n_q_rows, mode=mode)
+    return TwoStageShardedSearcher(coarse, rows, rerank, (base, base + len(index)), group, pad_semantics=fde,
+                                   local_prune=prune if n_mid else None, n_mid=n_mid)
 
 
 class GpuTwoStageSearcher:
     """Device-resident form of TwoStageShardedSearcher for one process per GPU over RCCL: the library leaves the coarse
     candidates (16-byte records: score, rows, global id) in a cuda buffer (mv_two_stage_coarse_device), ONE
-    all_gather_into_tensor moves n records per rank, the library derives the global top-n, its owned candidates, their
-    per-batch pad lengths, reranks and selects the local top-k (mv_two_stage_rerank_device), a second all-gather moves the
-    k pairs and mv_merge_topk finishes.  Everything is ordered on torch's current stream: no host synchronisation and
-    no host copy of any intermediate on the query path."""
+    all_gather_into_tensor moves n records per rank, (pruning stage, when the index's rerank plan has one:
+    mv_two_stage_mid_device + an all-gather of n floats per rank,) the library derives the global top-n, its owned
+    candidates, their per-batch pad lengths, reranks on the exact tier and selects the local top-k
+    (mv_two_stage_rerank_device), a last all-gather moves the k pairs and mv_merge_topk finishes.  Everything is ordered on
+    torch's current stream: no host synchronisation and no host copy of any intermediate on the query path."""
 
     REC = 16  # sizeof(mv_cand_rec)
 
-    def __init__(self, index, device=None, group=None):
+    def __init__(self, index, device=None, group=None, mode: str = "fde_then_float"):
         import torch
         import torch.distributed as dist
 
-        self.index, self.group = index, group
+        self.index, self.group, self.mode = index, group, mode
         self.dev = torch.device("cuda", index.device) if device is None else device
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._bufs = {}
@@ -336,26 +388,37 @@ class GpuTwoStageSearcher:
             self._bufs[key] = (torch.empty(n * self.REC, dtype=torch.uint8, device=d), torch.empty(w * n * self.REC, dtype=torch.uint8, device=d),
                                torch.empty(k, dtype=torch.float32, device=d), torch.empty(k, dtype=torch.int64, device=d),
                                torch.empty(w * k, dtype=torch.float32, device=d), torch.empty(w * k, dtype=torch.int64, device=d),
-                               torch.empty(k, dtype=torch.float32, device=d), torch.empty(k, dtype=torch.int64, device=d))
+                               torch.empty(k, dtype=torch.float32, device=d), torch.empty(k, dtype=torch.int64, device=d),
+                               torch.empty(n, dtype=torch.float32, device=d), torch.empty(w * n, dtype=torch.float32, device=d))
         return self._bufs[key]
 
     def query(self, q, k: int, coarse_n: Optional[int] = None, allow=None):
         import ctypes as C
 
+        import numpy as np
         import torch
         import torch.distributed as dist
 
         from ._lib import check, lib
 
         n = int(coarse_n) if coarse_n else min(10 * k, 75)
-        recs, allrecs, ls, li, gs, gi, os_, oi = self._buffers(n, k)
+        recs, allrecs, ls, li, gs, gi, os_, oi, mid, allmid = self._buffers(n, k)
         stream = torch.cuda.current_stream(self.dev).cuda_stream
-        self.index.two_stage_coarse_device(q, n, recs.data_ptr(), allow=allow, stream=stream)
+        n_q = int(np.shape(q)[0]) if np.ndim(q) == 2 else 1
+        n_mid, _tier = self.index.rerank_plan(n, k, n_q, mode=self.mode)  # host-side rule, identical on every rank
+        self.index.two_stage_coarse_device(q, n, recs.data_ptr(), allow=allow, stream=stream, mode=self.mode)
         if dist.is_initialized():
             dist.all_gather_into_tensor(allrecs, recs, group=self.group)
         else:
             allrecs = recs
-        self.index.two_stage_rerank_device(q, allrecs.data_ptr(), self.world, n, k, ls.data_ptr(), li.data_ptr(), stream=stream)
+        if n_mid:
+            self.index.two_stage_mid_device(q, allrecs.data_ptr(), self.world, n, mid.data_ptr(), stream=stream, mode=self.mode)
+            if dist.is_initialized():
+                dist.all_gather_into_tensor(allmid, mid, group=self.group)
+            else:
+                allmid = mid
+        self.index.two_stage_rerank_device(q, allrecs.data_ptr(), self.world, n, k, ls.data_ptr(), li.data_ptr(), stream=stream, mode=self.mode,
+                                           d_all_mid_ptr=allmid.data_ptr() if n_mid else 0, n_mid=n_mid)
         if dist.is_initialized():
             dist.all_gather_into_tensor(gs, ls, group=self.group)
             dist.all_gather_into_tensor(gi, li, group=self.group)

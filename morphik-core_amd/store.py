@@ -95,6 +95,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         min_score: Optional[float] = None,
         enable_external_storage: bool = True,
         app_id_resolver: Optional[Callable[[str], Optional[str]]] = None,
+        exact_tier: str = "hbm",
         **_ignored: Any,
     ):
         self.capacity_pages = int(capacity_pages)
@@ -103,6 +104,13 @@ class MI355XMultiVectorStore(BaseVectorStore):
         self.mode = mode or self.default_mode
         if self.mode not in ("binary", "float", "fde_then_float", "float_fp8", "fp8_then_float"):
             raise ValueError(f"unknown mode {self.mode}")
+        # where the exact bf16 rows of mode "fde_then_float" live: "hbm" = the bf16 slab (262 KB / page of HBM), "host" = PINNED
+        # HOST memory (262 KB / page of host RAM) with an e4m3 slab in HBM beside the FDE slab -- BASELINE configs[3]'s shard
+        # shape (1.25 M pages / GPU: a bf16 slab would need 328 GB of HBM): the coarse candidates are reranked exactly out of
+        # host RAM (lists longer than MV_OPT_RERANK_N through an e4m3 pruning stage first).  "fp8_then_float" always uses "host".
+        if exact_tier not in ("hbm", "host"):
+            raise ValueError(f"unknown exact_tier {exact_tier!r} (\"hbm\" or \"host\")")
+        self.exact_tier = exact_tier
         self.storage = storage  # callers reach for .storage (document_service.py:1570-1575)
         # multi_vector_store.py:120-160: content is stored externally when a storage object is configured
         self.enable_external_storage = bool(enable_external_storage)
@@ -137,6 +145,9 @@ class MI355XMultiVectorStore(BaseVectorStore):
         self.coalesced_batches: List[int] = []  # sizes of the batches actually issued (introspection / tests)
         self._index = None
         self._lock = threading.RLock()
+        # writers (store / delete / compact) and save() exclude each other here; queries never take it (save() holds the store
+        # lock only for the bookkeeping snapshot, so the event loop keeps serving while the slabs are dumped)
+        self._write_gate = threading.RLock()
         # bookkeeping: page -> (document_id, chunk_number, content OR storage key, metadata_json, app_id)
         self._rows: Dict[int, Tuple[str, int, str, str, Optional[str]]] = {}
         self._page_of: Dict[Tuple[str, int], int] = {}
@@ -161,9 +172,10 @@ class MI355XMultiVectorStore(BaseVectorStore):
         # "fp8_then_float": e4m3 slab in HBM (131 KB / page) + the exact bf16 rows in PINNED HOST memory (262 KB / page of host
         # RAM): every page scanned in fp8, the top candidates re-scored exactly out of host RAM by the rerank kernel itself --
         # exact-scan answers for corpora whose bf16 slab does not fit the GPU (BASELINE configs[4] with recall 1.0)
-        return dict(with_float=self.mode in ("float", "fde_then_float"), with_binary=self.mode == "binary",
-                    with_fde=self.mode == "fde_then_float", with_fp8=self.mode in ("float_fp8", "fp8_then_float"),
-                    **({"with_host_exact": True} if self.mode == "fp8_then_float" else {}))
+        host = self.mode == "fp8_then_float" or (self.mode == "fde_then_float" and self.exact_tier == "host")
+        return dict(with_float=self.mode == "float" or (self.mode == "fde_then_float" and not host), with_binary=self.mode == "binary",
+                    with_fde=self.mode == "fde_then_float", with_fp8=self.mode in ("float_fp8", "fp8_then_float") or (self.mode == "fde_then_float" and host),
+                    **({"with_host_exact": True} if host else {}))
 
     def _make_index(self):
         if self._index_factory is not None:
@@ -225,57 +237,74 @@ class MI355XMultiVectorStore(BaseVectorStore):
                 logger.warning(f"Failed to get app_id for document {chunks[0].document_id}: {e}")
         return DEFAULT_APP_ID if self._filter_by_app else None
 
+    def _nk(self, document_id: str, app_id: Optional[str]) -> str:
+        """Bookkeeping key of a document.  Stores with per-app namespaces key by (app, document_id): the same document_id under
+        two apps is two documents with two ordinals -- FastMultiVectorStore writes to self.ns(app_id) and never touches another
+        namespace (fast_multivector_store.py:440-502) -- so a re-ingest under app B can neither expose nor delete app A's chunks."""
+        if not self._filter_by_app:
+            return document_id
+        return f"{app_id if app_id is not None else DEFAULT_APP_ID}\x1f{document_id}"
+
     def _store_sync(self, valid: List[DocumentChunk], embs: List[Any], contents: List[str], app_id: Optional[str]) -> List[str]:
         ix = self._require_index()
-        with self._lock:
-            ords = []
+        with self._write_gate, self._lock:
+            ords, fresh = [], []
             for c in valid:
-                o = self._doc_ord.get(c.document_id)
+                key = self._nk(c.document_id, app_id)
+                o = self._doc_ord.get(key)
                 if o is None:
                     o = self._next_ord
                     self._next_ord += 1
-                    self._doc_ord[c.document_id] = o
+                    self._doc_ord[key] = o
                     self._doc_app[o] = app_id
-                    self._ord_stamp += 1
-                elif self._filter_by_app and self._doc_app.get(o) != app_id:
-                    # re-ingested under another app: the document moves to that namespace (its chunks are upserted below)
-                    self._doc_app[o] = app_id
-                    self._ord_stamp += 1
+                    fresh.append(key)
                 ords.append(o)
-            # ADD FIRST: if the slab is full or the device call fails nothing was published (mv_index_add is all or
-            # nothing) and the previous versions of these chunks are still live
-            if embs and all(not isinstance(e, np.ndarray) for e in embs):
-                # ingest-side fusion: encoder output already on this GPU -> one D2D pass fills
-                # every slab (mv_index_add_device); no D2H -> fp32 -> H2D round trip
-                import torch
-
-                from ._lib import MV_BF16, MV_F32
-
-                code = MV_BF16 if all(e.dtype == torch.bfloat16 for e in embs) else MV_F32
-                flat = torch.cat([e if code == MV_BF16 else e.to(torch.float32) for e in embs], 0).contiguous()
-                torch.cuda.current_stream(flat.device).synchronize()  # the library orders on its own stream
-                kw = {"device": flat.device.index} if len(self._devices()) > 1 or flat.device.index != self.device else {}
-                first = ix.add_device(flat.data_ptr(), code, [int(e.shape[0]) for e in embs], ords, **kw)
-            else:
-                first = ix.add([e if isinstance(e, np.ndarray) else _embedding_rows(e) for e in embs], ords)
+            try:
+                first = self._add_pages(ix, embs, ords)
+            except Exception:
+                # ADD FIRST: the slab was full or the device call failed -- nothing was published (mv_index_add is all or
+                # nothing), the previous versions of these chunks are still live, and the ordinals handed out above are taken back
+                for key in fresh:
+                    self._doc_app.pop(self._doc_ord.pop(key), None)
+                raise
+            if fresh:
+                self._ord_stamp += 1
             first += 0 if self._global_ids else self.id_base
-            # upsert: the previous page of an existing (document_id, chunk_number) is retired only now
+            # upsert: the previous page of an existing (document, chunk_number) is retired only now
             # (FastMultiVectorStore upserts by id)
             for c in valid:
-                old = self._page_of.pop((c.document_id, int(c.chunk_number)), None)
+                key = self._nk(c.document_id, app_id)
+                old = self._page_of.pop((key, int(c.chunk_number)), None)
                 if old is not None:
                     ix.remove_page(old if self._global_ids else old - self.id_base)
                     self._rows.pop(old, None)
-                    if old in self._doc_pages.get(c.document_id, []):
-                        self._doc_pages[c.document_id].remove(old)
+                    if old in self._doc_pages.get(key, []):
+                        self._doc_pages[key].remove(old)
             ids = []
             for i, c in enumerate(valid):
                 page = first + i
+                key = self._nk(c.document_id, app_id)
                 self._rows[page] = (c.document_id, int(c.chunk_number), contents[i], json.dumps(c.metadata or {}), app_id)
-                self._page_of[(c.document_id, int(c.chunk_number))] = page
-                self._doc_pages.setdefault(c.document_id, []).append(page)
+                self._page_of[(key, int(c.chunk_number))] = page
+                self._doc_pages.setdefault(key, []).append(page)
                 ids.append(f"{c.document_id}-{c.chunk_number}")
             return ids
+
+    def _add_pages(self, ix, embs: List[Any], ords: List[int]) -> int:
+        """Append the pages to the slab (all or nothing) -> first page id the index assigned."""
+        if embs and all(not isinstance(e, np.ndarray) for e in embs):
+            # ingest-side fusion (SURVEY.md 8f rank 1): encoder output already on this GPU -> one D2D pass fills
+            # every slab (mv_index_add_device); no D2H -> fp32 -> H2D round trip
+            import torch
+
+            from ._lib import MV_BF16, MV_F32
+
+            code = MV_BF16 if all(e.dtype == torch.bfloat16 for e in embs) else MV_F32
+            flat = torch.cat([e if code == MV_BF16 else e.to(torch.float32) for e in embs], 0).contiguous()
+            torch.cuda.current_stream(flat.device).synchronize()  # the library orders on its own stream
+            kw = {"device": flat.device.index} if len(self._devices()) > 1 or flat.device.index != self.device else {}
+            return ix.add_device(flat.data_ptr(), code, [int(e.shape[0]) for e in embs], ords, **kw)
+        return ix.add([e if isinstance(e, np.ndarray) else _embedding_rows(e) for e in embs], ords)
 
     _global_ids = False  # a ShardedIndex hands out global page ids itself
 
@@ -352,7 +381,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
             return hit[1], hit[2]
         ords = None
         if doc_ids:
-            ords = [self._doc_ord[d] for d in doc_ids if d in self._doc_ord]
+            ords = [self._doc_ord[kd] for kd in (self._nk(d, want) for d in doc_ids) if kd in self._doc_ord]
         if self._filter_by_app:
             if ords is None and all(a == want for a in self._doc_app.values()):
                 ords = None  # every document belongs to this app: the namespace filter is the identity
@@ -544,32 +573,38 @@ class MI355XMultiVectorStore(BaseVectorStore):
         want = (app_id if app_id is not None else DEFAULT_APP_ID) if self._filter_by_app else None
         with self._lock:
             for doc_id, chunk_no in dict.fromkeys((d, int(c)) for d, c in chunk_identifiers):
-                page = self._page_of.get((doc_id, chunk_no))
                 # per-app namespaces: a chunk is visible through ITS app only (fast_multivector_store.py:615 reads self.ns(app_id))
-                if page is not None and (want is None or self._doc_app.get(self._doc_ord.get(doc_id, -1)) == want):
+                page = self._page_of.get((self._nk(doc_id, want), chunk_no))
+                if page is not None:
                     rows.append(self._rows[page])
         contents, metas = await self._resolve_contents(rows, skip_image_content)
         return [DocumentChunk(document_id=r[0], chunk_number=r[1], content=c, embedding=[], metadata=m, score=0.0)
                 for r, c, m in zip(rows, contents, metas)]
 
+    def _delete_sync(self, document_id: str, app_id: Optional[str]) -> List[str]:
+        """Tombstone one app's copy of a document -> the storage keys of its payloads.  Runs in a worker thread: it waits behind
+        a checkpoint in progress (_write_gate) without holding up the event loop."""
+        keys: List[str] = []
+        with self._write_gate, self._lock:
+            # per-app namespaces: only THIS app's copy of the document (fast_multivector_store.py:643 deletes from self.ns(app_id))
+            key = self._nk(document_id, app_id)
+            o = self._doc_ord.get(key)
+            if o is None:
+                return keys  # DELETE of nothing succeeds
+            ix = self._require_index()
+            ix.remove_doc(o)
+            for page in self._doc_pages.pop(key, []):
+                row = self._rows.pop(page, None)
+                if row is not None:
+                    self._page_of.pop((key, row[1]), None)
+                    if self._use_external() and is_storage_key(row[2]):
+                        keys.append(row[2])
+            # the ordinal stays reserved until compact() (its pages are tombstoned in the slab under that ordinal)
+        return keys
+
     async def delete_chunks_by_document_id(self, document_id: str, app_id: Optional[str] = None) -> bool:
         try:
-            keys: List[str] = []
-            with self._lock:
-                o = self._doc_ord.get(document_id)
-                if o is None:
-                    return True  # DELETE of nothing succeeds
-                if self._filter_by_app and self._doc_app.get(o) != (app_id if app_id is not None else DEFAULT_APP_ID):
-                    return True  # another app's document: nothing of THIS namespace to delete (fast_multivector_store.py:643)
-                ix = self._require_index()
-                ix.remove_doc(o)
-                for page in self._doc_pages.pop(document_id, []):
-                    row = self._rows.pop(page, None)
-                    if row is not None:
-                        self._page_of.pop((row[0], row[1]), None)
-                        if self._use_external() and is_storage_key(row[2]):
-                            keys.append(row[2])
-                # the ordinal stays reserved until compact() (its pages are tombstoned in the slab under that ordinal)
+            keys = await asyncio.to_thread(self._delete_sync, document_id, app_id)
             logger.info(f"Deleted all chunks for document {document_id} from {self.backend_name} store")
             if keys:
                 await self._payloads.delete(keys, document_id)
@@ -583,7 +618,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         """Reclaim the slab slots of deleted / replaced pages (mv_index_compact) and remap the bookkeeping.
         Returns the number of slots reclaimed.  Page ids are internal to the store, so callers see no change; a query whose
         scan overlapped the renumbering notices the generation change and scans again."""
-        with self._lock:
+        with self._write_gate, self._lock:
             ix = self._require_index()
             before = len(ix)
             o2n = ix.compact()
@@ -605,53 +640,86 @@ class MI355XMultiVectorStore(BaseVectorStore):
     # ------------------------------------------------------------------ checkpoint / resume
     def _book(self) -> Dict[str, Any]:
         return {
-            "version": 2, "mode": self.mode, "capacity_pages": self.capacity_pages, "stride_rows": self.stride_rows,
-            "id_base": self.id_base, "fde_coarse_n": self.fde_coarse_n, "next_ord": self._next_ord,
+            "version": 3, "mode": self.mode, "capacity_pages": self.capacity_pages, "stride_rows": self.stride_rows,
+            "id_base": self.id_base, "fde_coarse_n": self.fde_coarse_n, "exact_tier": self.exact_tier, "next_ord": self._next_ord,
             "rows": [[p, r[0], r[1], r[2], r[3], r[4]] for p, r in self._rows.items()],
             "doc_ord": self._doc_ord, "doc_app": {str(k): v for k, v in self._doc_app.items()},
         }
 
-    def save(self, directory: str) -> None:
-        """Persist the HBM index (mv_index_save: raw slabs + metadata, written to a temp file and renamed) and the store's
-        bookkeeping (keys, document ordinals) so a restarted process resumes without re-embedding -- the role Postgres /
-        S3 play for the reference stores (checkpoint/resume).
-        Order (each step atomic, a crash between any two leaves a directory load() REFUSES or the previous checkpoint):
-          1. index.id <- "writing:<new id>"      the old pair is invalidated BEFORE any index file is touched
-          2. index.mv (every shard file)         temp file + fsync + rename each
-          3. index.id <- "<new id>"
-          4. store.json carrying "<new id>"      last
-        load() accepts a directory only when index.id and store.json name the same id."""
+    @staticmethod
+    def checkpoint_path(directory: str) -> str:
+        """Directory of the CURRENT checkpoint generation under `directory` (`directory` itself for the flat layout of checkpoints
+        written before generations existed)."""
         import os
+
+        cur = os.path.join(directory, "CURRENT")
+        if os.path.exists(cur):
+            with open(cur) as f:
+                return os.path.join(directory, f.read().strip())
+        return directory
+
+    def save(self, directory: str) -> None:
+        """Persist the HBM index (mv_index_save: raw slabs + metadata) and the store's bookkeeping (keys, document ordinals) so
+        a restarted process resumes without re-embedding -- the role Postgres / S3 play for the reference stores (SURVEY.md
+        section 5, checkpoint/resume).
+        Every checkpoint is a fresh GENERATION: <directory>/gen-<id>/{index.mv*, store.json} is written and fsync'ed in full while
+        <directory>/CURRENT still names the previous generation; CURRENT is then replaced by one atomic rename and the older
+        generations are removed.  A crash, OOM or kill at ANY point leaves CURRENT naming a complete checkpoint (the previous one
+        until the rename, the new one after): the owner process holds the only copy of the corpus, an interrupted periodic save
+        must not cost it.
+        Locking: writers (store / delete / compact) are held off for the duration (_write_gate); the store lock is held only while
+        the bookkeeping is snapshotted, NOT across the slab dump -- the async query paths take that lock on the event loop and
+        would freeze it (and /health) for the seconds a dump takes.  Queries keep being served from the event loop; those that
+        reach the library wait in their worker threads while mv_index_save holds the index (ExclusiveLock)."""
+        import os
+        import shutil
         import uuid
 
         os.makedirs(directory, exist_ok=True)
-
-        def stamp(text: str) -> None:
-            with open(os.path.join(directory, "index.id.tmp"), "w") as f:
-                f.write(text)
-                f.flush()
-                os.fsync(f.fileno())
-            os.replace(os.path.join(directory, "index.id.tmp"), os.path.join(directory, "index.id"))
-
-        with self._lock:
-            ix = self._require_index()
-            ckpt = uuid.uuid4().hex
-            stamp("writing:" + ckpt)
-            ix.save(os.path.join(directory, "index.mv"))
-            stamp(ckpt)
-            book = self._book()
-            book["checkpoint"] = ckpt
-            tmp = os.path.join(directory, "store.json.tmp")
-            with open(tmp, "w") as f:
-                json.dump(book, f)
-                f.flush()
-                os.fsync(f.fileno())
-            os.replace(tmp, os.path.join(directory, "store.json"))
+        with self._write_gate:
+            with self._lock:
+                ix = self._require_index()
+                book = self._book()
+            gen = "gen-" + uuid.uuid4().hex
+            gdir = os.path.join(directory, gen)
+            os.makedirs(gdir)
+            book["checkpoint"] = gen
+            try:
+                ix.save(os.path.join(gdir, "index.mv"))  # every shard file: temp file + fsync + rename each
+                with open(os.path.join(gdir, "store.json"), "w") as f:
+                    json.dump(book, f)
+                    f.flush()
+                    os.fsync(f.fileno())
+                dfd = os.open(gdir, os.O_RDONLY)
+                try:
+                    os.fsync(dfd)
+                finally:
+                    os.close(dfd)
+                tmp = os.path.join(directory, "CURRENT.tmp")
+                with open(tmp, "w") as f:
+                    f.write(gen)
+                    f.flush()
+                    os.fsync(f.fileno())
+                os.replace(tmp, os.path.join(directory, "CURRENT"))  # the switch: one atomic rename
+            except BaseException:
+                shutil.rmtree(gdir, ignore_errors=True)  # an incomplete generation is never named by CURRENT
+                raise
+            for name in os.listdir(directory):  # older generations, and the flat files of the pre-generation layout
+                pth = os.path.join(directory, name)
+                if name.startswith("gen-") and name != gen:
+                    shutil.rmtree(pth, ignore_errors=True)
+                elif name in ("store.json", "index.id") or name.startswith("index.mv"):
+                    try:
+                        os.remove(pth)
+                    except OSError:
+                        pass
 
     @classmethod
     def _load_index(cls, self, directory: str, book: Dict[str, Any], device: int):
         import os
 
+        if self._index_factory is not None and hasattr(self._index_factory, "load"):  # CPU tests: the injected index class
+            return self._index_factory.load(os.path.join(directory, "index.mv"), device=device)
         from .index import MvIndex
 
         return MvIndex.load(os.path.join(directory, "index.mv"), device=device)
@@ -660,21 +728,27 @@ class MI355XMultiVectorStore(BaseVectorStore):
     def load(cls, directory: str, device: int = 0, storage: Any = None, **kw: Any) -> "MI355XMultiVectorStore":
         import os
 
+        directory = cls.checkpoint_path(directory)  # the generation CURRENT names (or the flat pre-generation layout)
         with open(os.path.join(directory, "store.json")) as f:
             book = json.load(f)
         idp = os.path.join(directory, "index.id")
-        if book.get("checkpoint") and (not os.path.exists(idp) or open(idp).read().strip() != book["checkpoint"]):
+        if str(book.get("checkpoint", "")).startswith("gen-"):
+            if os.path.basename(os.path.normpath(directory)) != book["checkpoint"]:
+                raise RuntimeError(f"{directory}: store.json belongs to generation {book['checkpoint']} (directory moved or mixed up?)")
+        elif book.get("checkpoint") and (not os.path.exists(idp) or open(idp).read().strip() != book["checkpoint"]):
             raise RuntimeError(f"{directory}: index.mv and store.json belong to different checkpoints (crash during save?)")
         self = cls(capacity_pages=book["capacity_pages"], stride_rows=book["stride_rows"], device=device, mode=book["mode"], storage=storage,
-                   id_base=book["id_base"], fde_coarse_n=book.get("fde_coarse_n", 0), **kw)
+                   id_base=book["id_base"], fde_coarse_n=book.get("fde_coarse_n", 0), exact_tier=book.get("exact_tier", "hbm"), **kw)
         self._index = cls._load_index(self, directory, book, device)
         self._apply_options(self._index)
         for p, doc, chunk_no, content, meta_json, app in book["rows"]:
             self._rows[int(p)] = (doc, int(chunk_no), content, meta_json, app)
-            self._page_of[(doc, int(chunk_no))] = int(p)
-            self._doc_pages.setdefault(doc, []).append(int(p))
-        self._doc_ord = {k: int(v) for k, v in book["doc_ord"].items()}
+            self._page_of[(self._nk(doc, app), int(chunk_no))] = int(p)
+            self._doc_pages.setdefault(self._nk(doc, app), []).append(int(p))
         self._doc_app = {int(k): v for k, v in book["doc_app"].items()}
+        self._doc_ord = {k: int(v) for k, v in book["doc_ord"].items()}
+        if int(book.get("version", 2)) < 3 and self._filter_by_app:  # checkpoints before the per-app keys: one ordinal per document_id
+            self._doc_ord = {self._nk(d, self._doc_app.get(o)): o for d, o in self._doc_ord.items()}
         self._next_ord = int(book.get("next_ord", max(self._doc_ord.values(), default=-1) + 1))
         return self
 
@@ -693,14 +767,15 @@ class MI355XMultiVectorStore(BaseVectorStore):
             for p in range(int(n_pages)):
                 d, j = divmod(p, int(pages_per_doc))
                 doc = f"synth-{d}"
+                key = self._nk(doc, app)
                 page = p + (0 if self._global_ids else self.id_base)
                 self._rows[page] = (doc, j, f"page {p}", "{}", app)
-                self._page_of[(doc, j)] = page
+                self._page_of[(key, j)] = page
                 if j == 0:
-                    self._doc_ord[doc] = d
+                    self._doc_ord[key] = d
                     self._doc_app[d] = app
-                    self._doc_pages[doc] = []
-                self._doc_pages[doc].append(page)
+                    self._doc_pages[key] = []
+                self._doc_pages[key].append(page)
             self._next_ord = (int(n_pages) + int(pages_per_doc) - 1) // int(pages_per_doc)
             self._ord_stamp += 1
 
@@ -789,11 +864,14 @@ class MI355XShardedFastMultiVectorStore(_ShardedMixin, MI355XFastMultiVectorStor
 
 def create_store(provider: str, **kw: Any) -> MI355XMultiVectorStore:
     """Factory for core/services_init.py: [multivector_store] provider =
-    "mi355x" | "mi355x_fast" | "mi355x_float" | "mi355x_fp8_exact" | "mi355x_sharded" | "mi355x_sharded_fast" | "mi355x_sharded_float" | "mi355x_remote"."""
+    "mi355x" | "mi355x_fast" | "mi355x_fast_host_exact" | "mi355x_float" | "mi355x_fp8_exact" | "mi355x_sharded" | "mi355x_sharded_fast" |
+    "mi355x_sharded_fast_host_exact" | "mi355x_sharded_float" | "mi355x_sharded_fp8_exact" | "mi355x_remote"."""
     if provider == "mi355x":
         return MI355XMultiVectorStore(**kw)
     if provider == "mi355x_fast":
         return MI355XFastMultiVectorStore(**kw)
+    if provider == "mi355x_fast_host_exact":  # FDE + e4m3 slabs in HBM, exact bf16 rows in pinned host RAM (configs[3] shard shape)
+        return MI355XFastMultiVectorStore(exact_tier="host", **kw)
     if provider == "mi355x_float":
         return MI355XMultiVectorStore(mode="float", **kw)
     if provider == "mi355x_fp8_exact":  # e4m3 slab in HBM + exact bf16 tier in pinned host RAM
@@ -802,8 +880,12 @@ def create_store(provider: str, **kw: Any) -> MI355XMultiVectorStore:
         return MI355XShardedMultiVectorStore(**kw)
     if provider == "mi355x_sharded_fast":
         return MI355XShardedFastMultiVectorStore(**kw)
+    if provider == "mi355x_sharded_fast_host_exact":  # configs[3]: 10 M pages over 8 GPUs, every shard with its pinned-host exact tier
+        return MI355XShardedFastMultiVectorStore(exact_tier="host", **kw)
     if provider == "mi355x_sharded_float":
         return MI355XShardedMultiVectorStore(mode="float", **kw)
+    if provider == "mi355x_sharded_fp8_exact":  # configs[4]: e4m3 scan of every shard -> GLOBAL top-n -> exact re-score from the owners' host tiers
+        return MI355XShardedMultiVectorStore(mode="fp8_then_float", **kw)
     if provider == "mi355x_remote":  # every process but the one that owns the HBM slab (store_server.py)
         from .store_server import MI355XRemoteMultiVectorStore
 

@@ -121,6 +121,26 @@ class OracleIndex:
             out.append(self.query(q, k, mode, None if a is None else np.asarray(a, np.uint32)))
         return out
 
+    def save(self, path):
+        import pickle
+
+        with open(path + ".tmp", "wb") as f:
+            pickle.dump({"capacity": self.capacity, "stride_rows": self.stride_rows, "id_base": self.id_base, "mode": self.mode,
+                         "pages": self.pages, "ords": self.ords, "alive": self.alive}, f)
+        import os
+
+        os.replace(path + ".tmp", path)
+
+    @classmethod
+    def load(cls, path, device=0):
+        import pickle
+
+        with open(path, "rb") as f:
+            d = pickle.load(f)
+        self = cls(d["capacity"], d["stride_rows"], device=device, id_base=d["id_base"], mode=d["mode"])
+        self.pages, self.ords, self.alive = d["pages"], d["ords"], d["alive"]
+        return self
+
     def close(self):
         pass
 

@@ -1,0 +1,310 @@
+"""GPU tests of the exact rerank at the shard shape of BASELINE configs[3] / [4]: an index WITHOUT a bf16
+slab (FDE + e4m3 slabs in HBM) keeps its exact bf16 rows in pinned host memory, and MV_MODE_FDE_THEN_FLOAT /
+MV_MODE_FP8_THEN_FLOAT rerank on THAT tier -- the reference reranks with exact fp32 MaxSim on fp32 pages
+(core/vector_store/fast_multivector_store.py:553-556, upcast at load :736,774), not on a quantised copy.
+
+Checked: against the float oracle (orc.maxsim_f32 on the bf16 rows, NOT the fp8 oracle) within north_star's 1e-3, against an
+index that holds the bf16 slab in HBM (bit-identical scores: same kernel, same rows), single / batched / R logical shards
+through mv_comm (peer-copy and host transports) / the device-resident stages of the one-process-per-GPU flow.
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc  # noqa: E402  (checker only)
+
+RTOL = 1e-3  # north_star tolerance for float MaxSim
+
+
+def _idx(**kw):
+    from morphik_core_amd.index import MvIndex
+
+    return MvIndex(**kw)
+
+
+def _batch_pads(rows, batch=128):
+    rows = np.asarray(rows)
+    pads = np.empty_like(rows)
+    for j in range(0, len(rows), batch):
+        pads[j : j + batch] = rows[j : j + batch].max()
+    return pads
+
+
+def _corpus(n, stride, seed=31):
+    """Ragged pages; every seventh page nearly repeats page 3 (a cluster of near-ties the e4m3 noise reorders)."""
+    pages = [orc.synth_rows(seed, i, 0, 6 + (i * 7) % (stride - 6)) for i in range(n)]
+    base = orc.bf16_to_f32(orc.synth_rows(seed, 3, 0, stride))
+    rng = np.random.default_rng(seed)
+    for i in range(10, n, 7):
+        x = base[: pages[i].shape[0]] + 0.002 * rng.standard_normal((pages[i].shape[0], 128)).astype(np.float32)
+        pages[i] = orc.f32_to_bf16(x / np.linalg.norm(x, axis=1, keepdims=True))
+    return pages
+
+
+def _oracle_cascade(ix, q, pages, k, coarse_n, n_mid, allow=None):
+    """The reference pipeline composed on the host from the library's own coarse scores: coarse top-n (coarse rank order) -> per
+    batch-of-128 pad lengths -> [e4m3 pruning to n_mid list positions, the device's own e4m3 scores] -> EXACT float MaxSim
+    (oracle, fp32 on the bf16 rows) -> top-k by (score desc, list position asc)."""
+    from morphik_core_amd import _lib
+
+    qf = orc.bf16_to_f32(q)
+    coarse = ix.score_all(q, mode="fde", allow=allow)
+    cs, ci = orc.topk(coarse, coarse_n)
+    ci = ci[np.isfinite(cs)]
+    rows = np.array([pages[c].shape[0] for c in ci])
+    pads = _batch_pads(rows)
+    keep = np.ones(ci.size, bool)
+    if n_mid and ci.size > n_mid:
+        prev = ix.get_option(_lib.MV_OPT_EXACT_TIER, 0)
+        ix.set_option(_lib.MV_OPT_EXACT_TIER, 2)  # the e4m3 scores of the named pages (checked against the fp8 oracle elsewhere)
+        f8 = ix.score_candidates(q, ci, pads=pads)
+        ix.set_option(_lib.MV_OPT_EXACT_TIER, prev)
+        sel = np.lexsort((np.arange(ci.size), -f8.astype(np.float64)))[:n_mid]
+        keep[:] = False
+        keep[sel] = True
+    exact = np.array([orc.maxsim_f32(qf, orc.bf16_to_f32(pages[c]), int(p)) if kp else -np.inf for c, p, kp in zip(ci, pads, keep)], np.float32)
+    order = np.lexsort((np.arange(ci.size), -exact.astype(np.float64)))[:k]
+    order = order[np.isfinite(exact[order])]
+    return exact[order], ci[order]
+
+
+@pytest.mark.parametrize("coarse_n,rerank_n", [(75, 128), (300, 64), (300, 1024)])
+def test_fde_then_float_reranks_exactly_from_the_pinned_host_tier(coarse_n, rerank_n):
+    """configs[3] at its shard shape: no bf16 slab; coarse top-n -> (n > MV_OPT_RERANK_N: e4m3 pruning) -> exact bf16 MaxSim read
+    from pinned host memory -> top-k.  Scores within 1e-3 of the FLOAT oracle, identical to an index with the bf16 slab in HBM."""
+    from morphik_core_amd import MvError, _lib
+    from morphik_core_amd.index import allow_bitmap
+
+    N, stride, k = 900, 48, 10
+    pages = _corpus(N, stride)
+    ords = [i % 13 for i in range(N)]
+    host = _idx(capacity_pages=N, stride_rows=stride, with_float=False, with_fde=True, with_fp8=True, with_host_exact=True)
+    hbm = _idx(capacity_pages=N, stride_rows=stride, with_float=True, with_fde=True)
+    f8 = _idx(capacity_pages=N, stride_rows=stride, with_float=False, with_fde=True, with_fp8=True)  # no exact tier at all
+    for ix in (host, hbm, f8):
+        ix.add(pages, doc_ordinals=ords)
+        ix.set_option(_lib.MV_OPT_FDE_COARSE_N, coarse_n)
+        ix.set_option(_lib.MV_OPT_RERANK_N, rerank_n)
+    n_mid, tier = host.rerank_plan(coarse_n, k, 20)
+    assert tier == "host" and n_mid == (max(rerank_n, k) if coarse_n > max(rerank_n, k) else 0)
+    assert hbm.rerank_plan(coarse_n, k, 20) == (0, "hbm") and f8.rerank_plan(coarse_n, k, 20) == (0, "fp8")
+    host.remove_page(24)
+    hbm.remove_page(24)
+    f8.remove_page(24)
+    near = orc.synth_rows(31, 3, 0, 20)  # a query inside the near-tie cluster: the e4m3 rerank reorders it, the exact one must not
+    qs = [near] + [orc.synth_rows(4321, j, 0, 14 + 3 * j) for j in range(4)]
+    differs = 0
+    for j, q in enumerate(qs):
+        for al in (None, allow_bitmap([0, 1, 2, 3, 5, 7, 8, 11, 12])):
+            ws, wi = _oracle_cascade(host, q, pages, k, coarse_n, n_mid, allow=al)
+            s, i, st = host.query(q, k, mode="fde_then_float", allow=al, want_stats=True)
+            assert i.tolist() == wi.tolist(), (j, i.tolist(), wi.tolist())
+            np.testing.assert_allclose(s, ws, rtol=RTOL, atol=1e-6)
+            assert st.rerank_ms > 0 and st.coarse_ms > 0
+            hs, hi = hbm.query(q, k, mode="fde_then_float", allow=al)  # the bf16 slab in HBM: same rows, same kernel, no pruning stage
+            if n_mid == 0 or j > 0:  # (inside the near-tie cluster a cut at 64 of ~130 near-identical e4m3 scores is arbitrary)
+                assert hi.tolist() == i.tolist() and hs.tolist() == s.tolist()
+            fs, fi = f8.query(q, k, mode="fde_then_float", allow=al)  # the e4m3 rerank: close, not exact
+            np.testing.assert_allclose(fs, s, rtol=3e-2)
+            differs += int(fi.tolist() != i.tolist() or np.max(np.abs(fs - s) / np.abs(s)) > RTOL)
+    assert differs > 0  # the corpus does separate the two reranks
+    # a batch of requests: the batched pipeline (one FDE pass, every list pruned / reranked in one launch) == the lone calls
+    for (bs, bi), q in zip(host.query_batch(qs, k, mode="fde_then_float"), qs):
+        s, i = host.query(q, k, mode="fde_then_float")
+        assert bi.tolist() == i.tolist()
+        np.testing.assert_allclose(bs, s, rtol=1e-5)
+    # mv_score_candidates names pages explicitly: exact tier too
+    cand = np.arange(0, 200, 3)
+    got = host.score_candidates(qs[1], cand, pad_to=-1)
+    assert got.tolist() == hbm.score_candidates(qs[1], cand, pad_to=-1).tolist()
+    # an index with an FDE slab only has nothing to rerank on: loud
+    bare = _idx(capacity_pages=8, stride_rows=stride, with_float=False, with_fde=True)
+    bare.add(pages[:8])
+    with pytest.raises(MvError):
+        bare.query(qs[0], 3, mode="fde_then_float")
+    for ix in (host, hbm, f8, bare):
+        ix.close()
+
+
+@pytest.mark.parametrize("transport", ["p2p", "host"])
+@pytest.mark.parametrize("mode,coarse_n,rerank_n", [("fde_then_float", 75, 128), ("fde_then_float", 300, 64), ("fp8_then_float", 0, 96)])
+def test_sharded_exact_tier_equals_single_index(transport, mode, coarse_n, rerank_n):
+    """configs[3] / [4] on a sharded corpus: R = 1, 2, 4 logical shards, every shard with ITS pinned-host exact tier, through
+    mv_comm (single requests and batches) == ONE index holding every page -- ids and scores, near-ties and duplicates
+    included: the candidate list (FDE top-n / e4m3 top-n) and the pruning cut are GLOBAL, whatever the shard count."""
+    from morphik_core_amd import _lib
+    from morphik_core_amd.index import ShardComm, allow_bitmap
+
+    N, stride, k = 720, 48, 8
+    pages = _corpus(N, stride, seed=32)
+    pages[N - 5] = pages[17].copy()  # exact duplicates across shard boundaries: ties resolve by id, as on one index
+    pages[400] = pages[17].copy()
+    ords = [i % 11 for i in range(N)]
+    kw = dict(stride_rows=stride, with_float=False, with_fde=True, with_fp8=True, with_host_exact=True)
+
+    def opts(ix):
+        if coarse_n:
+            ix.set_option(_lib.MV_OPT_FDE_COARSE_N, coarse_n)
+        ix.set_option(_lib.MV_OPT_RERANK_N, rerank_n)
+
+    one = _idx(capacity_pages=N, **kw)
+    one.add(pages, doc_ordinals=ords)
+    opts(one)
+    one.remove_page(33)
+    qs = [orc.synth_rows(32, 3, 0, 20), orc.bf16_to_f32(pages[17][:12])] + [orc.synth_rows(4321, 40 + j, 0, 10 + (j * 5) % 23) for j in range(34)]  # 36 > one group of 32
+    al = allow_bitmap([0, 1, 3, 4, 6, 7, 9, 10])
+    per_req = [None if j % 3 == 0 else allow_bitmap([(j + d) % 11 for d in range(6)]) for j in range(len(qs))]
+    want = [one.query(q, k, mode=mode) for q in qs[:6]]
+    want_al = [one.query(q, k, mode=mode, allow=al) for q in qs[:6]]
+    want_b = one.query_batch(qs, k, mode=mode)
+    want_bp = one.query_batch(qs, k, mode=mode, allows=per_req, n_docs=11)
+    for (bs, bi), (s, i) in zip(want_b[:6], want):  # the batched pipeline agrees with the lone calls on one index
+        assert bi.tolist() == i.tolist()
+    for R in (1, 2, 4):
+        per = N // R
+        shards = []
+        for r in range(R):
+            sh = _idx(capacity_pages=per, id_base=r * per, **kw)
+            sh.add(pages[r * per : (r + 1) * per], doc_ordinals=ords[r * per : (r + 1) * per])
+            opts(sh)
+            shards.append(sh)
+        shards[33 // per].remove_page(33 % per)
+        comm = ShardComm(shards, transport=transport)
+        for q, (ws, wi), (was, wai) in zip(qs[:6], want, want_al):
+            s, i, st = comm.query(q, k, mode=mode, want_stats=True)
+            assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist(), (R, transport)
+            assert len(st) == R and all(x.total_device_ms > 0 for x in st)
+            s, i = comm.query(q, k, mode=mode, allow=al)
+            assert i.tolist() == wai.tolist() and s.tolist() == was.tolist(), (R, transport)
+        for wantb, kwq in ((want_b, {}), (want_bp, dict(allows=per_req, n_docs=11))):
+            got = comm.query_batch(qs, k, mode=mode, **kwq)
+            for j, ((s, i), (ws, wi)) in enumerate(zip(got, wantb)):
+                assert i.tolist() == wi.tolist(), (R, transport, j)
+                assert s.tolist() == ws.tolist(), (R, transport, j)
+        comm.close()
+        for sh in shards:
+            sh.close()
+    one.close()
+
+
+@pytest.mark.parametrize("mode,coarse_n,rerank_n", [("fde_then_float", 300, 64), ("fp8_then_float", 96, 96)])
+def test_device_resident_and_host_driven_stages_with_the_host_tier(mode, coarse_n, rerank_n):
+    """The stages of the one-process-per-GPU flow (mv_two_stage_coarse / mid / rerank_device; sharded.GpuTwoStageSearcher and
+    the host-driven TwoStageShardedSearcher) over R logical shards with pinned-host exact tiers == the single index."""
+    import torch
+
+    from morphik_core_amd import _lib, sharded
+
+    N, stride, k = 480, 48, 6
+    pages = _corpus(N, stride, seed=33)
+    kw = dict(stride_rows=stride, with_float=False, with_fde=True, with_fp8=True, with_host_exact=True)
+
+    def opts(ix):
+        ix.set_option(_lib.MV_OPT_FDE_COARSE_N, coarse_n)
+        ix.set_option(_lib.MV_OPT_RERANK_N, rerank_n)
+
+    one = _idx(capacity_pages=N, **kw)
+    one.add(pages)
+    opts(one)
+    qs = [orc.synth_rows(33, 3, 0, 20)] + [orc.synth_rows(4321, 70 + j, 0, 20) for j in range(2)]
+    dev = torch.device("cuda", 0)
+    n_mid, tier = one.rerank_plan(coarse_n, k, 20, mode=mode)
+    assert tier == "host" and (n_mid == 64 if mode == "fde_then_float" else n_mid == 0)
+    for R in (1, 2, 4):
+        per = N // R
+        shards, searchers = [], []
+        for r in range(R):
+            sh = _idx(capacity_pages=per, id_base=r * per, **kw)
+            sh.add(pages[r * per : (r + 1) * per])
+            opts(sh)
+            shards.append(sh)
+            searchers.append(sharded.make_gpu_two_stage(sh, mode=mode, k=k, coarse_n=coarse_n, n_q_rows=20))
+        for q in qs:
+            ws, wi = one.query(q, k, mode=mode)
+            # --- host-driven stages (the gloo-testable form), the collectives replaced by concatenation in shard order
+            co = [se.coarse(q, k, coarse_n, None) for se in searchers]
+            gs = torch.stack([c[1] for c in co]).reshape(-1)
+            gi = torch.stack([c[2] for c in co]).reshape(-1)
+            order = torch.sort(gs, descending=True, stable=True).indices[:coarse_n]
+            gid = gi[order].cpu().numpy().astype(np.int64)
+            grows = np.array([pages[g].shape[0] if g >= 0 else 0 for g in gid])
+            pads = searchers[0].batch_pads(gid, grows)
+            if n_mid:
+                allm = np.stack([se.prune_scores(q, gid, pads) for se in searchers])
+                gid = np.where(sharded.TwoStageShardedSearcher.prune_keep(allm, n_mid), gid, -1)
+            loc = [se.rerank(q, gid, pads, k) for se in searchers]
+            ms, mi = sharded.merge_topk(torch.stack([l[0] for l in loc]), torch.stack([l[1] for l in loc]), k)
+            assert mi.tolist() == wi.tolist() and ms.tolist() == ws.tolist(), (R, "host-driven")
+            # --- device-resident stages
+            recs = [torch.empty(coarse_n * 16, dtype=torch.uint8, device=dev) for _ in range(R)]
+            for sh, rb in zip(shards, recs):
+                sh.two_stage_coarse_device(q, coarse_n, rb.data_ptr(), mode=mode)
+            allrecs = torch.cat(recs)
+            allmid = None
+            if n_mid:
+                mids = [torch.empty(coarse_n, dtype=torch.float32, device=dev) for _ in range(R)]
+                for sh, mb in zip(shards, mids):
+                    sh.two_stage_mid_device(q, allrecs.data_ptr(), R, coarse_n, mb.data_ptr(), mode=mode)
+                allmid = torch.cat(mids)
+                owners = (torch.isfinite(allmid.view(R, coarse_n)).sum(0)).cpu().numpy()
+                assert (owners <= 1).all() and owners.sum() > n_mid  # one owner per list position
+            ls = torch.empty((R, k), dtype=torch.float32, device=dev)
+            li = torch.empty((R, k), dtype=torch.int64, device=dev)
+            for r, sh in enumerate(shards):
+                sh.two_stage_rerank_device(q, allrecs.data_ptr(), R, coarse_n, k, ls[r].data_ptr(), li[r].data_ptr(), mode=mode,
+                                           d_all_mid_ptr=allmid.data_ptr() if n_mid else 0, n_mid=n_mid)
+            ds, di = sharded.merge_topk(ls.cpu(), li.cpu(), k)
+            assert di.tolist() == wi.tolist() and ds.tolist() == ws.tolist(), (R, "device-resident")
+        if R == 1:  # GpuTwoStageSearcher without a process group: the stream-ordered pipeline, pruning stage included
+            se = sharded.GpuTwoStageSearcher(shards[0], mode=mode)
+            for q in qs:
+                ws, wi = one.query(q, k, mode=mode)
+                s, i = se.query(q, k, coarse_n=coarse_n)
+                torch.cuda.synchronize()
+                assert i.cpu().tolist() == wi.tolist() and s.cpu().tolist() == ws.tolist()
+        for sh in shards:
+            sh.close()
+    one.close()
+
+
+def test_sharded_stores_with_host_exact_tiers_behind_the_plugin_surface():
+    """create_store("mi355x_sharded_fast_host_exact") / ("mi355x_sharded_fp8_exact"): the BaseVectorStore surface over R logical
+    shards whose exact rows live in pinned host memory; query_similar returns the exact scores (float oracle, 1e-3)."""
+    import asyncio
+
+    from morphik_core_amd.models import DocumentChunk
+    from morphik_core_amd.store import create_store
+
+    stride = 48
+    pages = _corpus(120, stride, seed=34)
+    chunks = [DocumentChunk(document_id=f"d{i // 4}", content=f"p{i}", embedding=orc.bf16_to_f32(p), chunk_number=i % 4, metadata={}) for i, p in enumerate(pages)]
+    q = orc.bf16_to_f32(orc.synth_rows(34, 3, 0, 20))
+    exact = np.array([orc.maxsim_f32(q, orc.bf16_to_f32(p), 0) for p in pages], np.float32)
+    for provider in ("mi355x_sharded_fast_host_exact", "mi355x_sharded_fp8_exact", "mi355x_fast_host_exact"):
+        kw = dict(devices=[0, 0, 0], transport="p2p") if "sharded" in provider else {}
+        st = create_store(provider, capacity_pages=300, stride_rows=stride, **kw)
+        assert st.initialize()
+
+        async def run():
+            ok, ids, _m = await st.store_embeddings(chunks[:60], app_id=None)
+            assert ok and len(ids) == 60
+            ok, ids, _m = await st.store_embeddings(chunks[60:], app_id=None)
+            assert ok
+            return await st.query_similar(q, k=5)
+
+        hits = asyncio.run(run())
+        assert len(hits) == 5
+        got = {(h.document_id, h.chunk_number): h.score for h in hits}
+        for (doc, cn), sc in got.items():
+            p = int(doc[1:]) * 4 + cn
+            if "fast" in provider:  # FDE pipeline: the reference pads every rerank batch to its longest page (clamp at 0)
+                assert sc >= exact[p] - 1e-3 * abs(exact[p])
+            else:
+                assert abs(sc - exact[p]) <= RTOL * abs(exact[p])
+        if "fast" not in provider:  # exhaustive e4m3 scan + exact re-score: the exact top-5
+            top = np.lexsort((np.arange(len(pages)), -exact.astype(np.float64)))[:5]
+            assert [int(h.document_id[1:]) * 4 + h.chunk_number for h in hits] == top.tolist()
+        st.close()

@@ -186,6 +186,7 @@ def test_owner_server_checkpoints_what_it_ingested_over_http_and_keeps_payloads_
     import httpx
 
     from morphik_core_amd import store_server
+    from morphik_core_amd.store import MI355XMultiVectorStore
     from morphik_core_amd.store_server import MI355XRemoteMultiVectorStore, create_app
     from tests import store_scenarios as sc2
     from tests.test_encoder_and_formats import _serve
@@ -206,7 +207,7 @@ def test_owner_server_checkpoints_what_it_ingested_over_http_and_keeps_payloads_
         assert httpx.post(url + "/save", timeout=60).status_code == 401  # the checkpoint endpoint is authenticated
         r = httpx.post(url + "/save", headers={"Authorization": "Bearer k"}, timeout=120)
         assert r.status_code == 200 and r.json()["ok"] and r.json()["pages"] == 6
-        book = json.load(open(os.path.join(save_dir, "store.json")))
+        book = json.load(open(os.path.join(MI355XMultiVectorStore.checkpoint_path(save_dir), "store.json")))
         assert len(book["rows"]) == 6 and all(len(row[3]) < 200 for row in book["rows"])  # keys, not payloads
         assert any(f.endswith(".png") for _d, _s, fs in os.walk(pay_dir) for f in fs)
         sc2.run(remote.store_embeddings(chunks[6:], app_id="t"))  # after the checkpoint: only the shutdown save can keep these

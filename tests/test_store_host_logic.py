@@ -60,6 +60,34 @@ def test_fast_store_filters_by_app_namespace():
     assert sc.run(s2.query_similar(a[0].embedding, k=10)) == []
 
 
+def test_same_document_id_under_two_apps_is_two_documents():
+    """FastMultiVectorStore writes to self.ns(app_id) and leaves every other namespace alone (fast_multivector_store.py:440-502,
+    :643): a re-ingest of a document_id under app B must not expose, move or delete app A's chunks."""
+    s = _store(MI355XFastMultiVectorStore, mode="float")
+    rng = np.random.default_rng(5)
+    a = sc.make_chunks(rng, n_docs=1, chunks_per_doc=3)  # doc0, chunks 0..2, app-a
+    sc.run(s.store_embeddings(a, app_id="app-a"))
+    b0 = a[0].model_copy(update={"content": "b-version"})
+    sc.run(s.store_embeddings([b0], app_id="app-b"))  # the same document_id, ONE chunk, another tenant
+    seen_a = sc.run(s.query_similar(a[1].embedding, k=10, app_id="app-a"))
+    assert sorted((c.chunk_number, c.content) for c in seen_a) == sorted((c.chunk_number, c.content) for c in a)  # A keeps all three, its own versions
+    seen_b = sc.run(s.query_similar(a[1].embedding, k=10, app_id="app-b"))
+    assert [(c.chunk_number, c.content) for c in seen_b] == [(0, "b-version")]  # B sees its one chunk, none of A's
+    assert [c.content for c in sc.run(s.get_chunks_by_id([("doc0", 0), ("doc0", 2)], app_id="app-b"))] == ["b-version"]
+    assert len(sc.run(s.get_chunks_by_id([("doc0", 0), ("doc0", 2)], app_id="app-a"))) == 2
+    assert sc.run(s.query_similar(a[1].embedding, k=10, doc_ids=["doc0"], app_id="app-b"))[0].content == "b-version"
+    assert sc.run(s.delete_chunks_by_document_id("doc0", app_id="app-b")) is True  # B deletes ITS copy only
+    assert len(sc.run(s.query_similar(a[1].embedding, k=10, app_id="app-a"))) == 3
+    assert sc.run(s.query_similar(a[1].embedding, k=10, app_id="app-b")) == []
+    # a failed add hands its fresh ordinals back and leaves the other namespace untouched
+    full = MI355XFastMultiVectorStore(capacity_pages=3, stride_rows=32, mode="float", index_factory=OracleIndex)
+    sc.run(full.store_embeddings(a, app_id="app-a"))
+    ords = dict(full._doc_ord)
+    with pytest.raises(Exception):
+        sc.run(full.store_embeddings([b0], app_id="app-b"))  # slab full
+    assert full._doc_ord == ords and len(sc.run(full.query_similar(a[1].embedding, k=10, app_id="app-a"))) == 3
+
+
 def test_too_many_vectors_is_an_error_and_factory():
     s = _store(mode="float")
     from morphik_core_amd.models import DocumentChunk
@@ -436,6 +464,78 @@ def test_failed_upsert_keeps_the_previous_version_and_ordinals_are_reclaimed():
     assert s.compact() == 4 and s._doc_ord == {} and s._doc_app == {}  # no page left: the ordinal is forgotten
     sc.run(s.store_embeddings(chunks[:2]))
     assert len(sc.run(s.query_similar(chunks[0].embedding, k=5, doc_ids=["doc0"]))) == 2
+
+
+def test_checkpoint_generations_survive_an_interrupted_save_and_do_not_hold_the_store_lock(tmp_path, monkeypatch):
+    """a crash / kill during a (periodic) save must leave the PREVIOUS checkpoint loadable -- the owner process holds
+    the only copy of the corpus -- and the slab dump must not run under the store lock the event loop's query paths take."""
+    import os
+    import threading
+    import time
+
+    rng = np.random.default_rng(3)
+    s = MI355XFastMultiVectorStore(capacity_pages=32, stride_rows=32, mode="float", index_factory=OracleIndex)
+    chunks = sc.make_chunks(rng, n_docs=3, chunks_per_doc=2)
+    sc.run(s.store_embeddings(chunks[:4], app_id="t"))
+    d = str(tmp_path / "ckpt")
+    s.save(d)
+    gen1 = open(os.path.join(d, "CURRENT")).read()
+    assert sorted(os.listdir(d)) == sorted(["CURRENT", gen1]) and MI355XFastMultiVectorStore.checkpoint_path(d) == os.path.join(d, gen1)
+    sc.run(s.store_embeddings(chunks[4:], app_id="t"))
+    # (1) the index dump dies half way (kill -9, OOM, disk full): CURRENT still names generation 1, which still loads
+    real_save = OracleIndex.save
+
+    def dying_save(self, path):
+        with open(path + ".tmp", "wb") as f:
+            f.write(b"half a slab")
+        raise OSError("killed mid-dump")
+
+    monkeypatch.setattr(OracleIndex, "save", dying_save)
+    with pytest.raises(OSError):
+        s.save(d)
+    assert open(os.path.join(d, "CURRENT")).read() == gen1 and sorted(os.listdir(d)) == sorted(["CURRENT", gen1])
+    back = MI355XFastMultiVectorStore.load(d, index_factory=OracleIndex)
+    assert len(back) == 4 and sc.run(back.query_similar(chunks[1].embedding, k=1, app_id="t"))[0].content == chunks[1].content
+    monkeypatch.setattr(OracleIndex, "save", real_save)
+    # (2) everything written, the process dies before CURRENT is switched: still generation 1
+    real_replace = os.replace
+
+    def no_switch(a, b):
+        if os.path.basename(b) == "CURRENT":
+            raise OSError("killed before the switch")
+        return real_replace(a, b)
+
+    monkeypatch.setattr(os, "replace", no_switch)
+    with pytest.raises(OSError):
+        s.save(d)
+    monkeypatch.setattr(os, "replace", real_replace)
+    assert open(os.path.join(d, "CURRENT")).read() == gen1
+    assert len(MI355XFastMultiVectorStore.load(d, index_factory=OracleIndex)) == 4
+    # (3) a save that completes replaces the generation; the store lock is free while the slabs are being written
+    free_during_dump = []
+
+    def slow_save(self, path):
+        time.sleep(0.3)
+        return real_save(self, path)
+
+    monkeypatch.setattr(OracleIndex, "save", slow_save)
+    t = threading.Thread(target=s.save, args=(d,))
+    t.start()
+    time.sleep(0.1)
+    got = s._lock.acquire(timeout=0.05)  # what query_similar / get_chunks_by_id take on the event loop
+    free_during_dump.append(got)
+    if got:
+        s._lock.release()
+    res = sc.run(s.query_similar(chunks[5].embedding, k=1, app_id="t"))  # served while the dump is in flight
+    assert t.is_alive() and res[0].content == chunks[5].content
+    t.join()
+    assert free_during_dump == [True]
+    gen2 = open(os.path.join(d, "CURRENT")).read()
+    assert gen2 != gen1 and sorted(os.listdir(d)) == sorted(["CURRENT", gen2])
+    back = MI355XFastMultiVectorStore.load(d, index_factory=OracleIndex)
+    assert len(back) == 6 and sc.run(back.query_similar(chunks[5].embedding, k=1, app_id="t"))[0].content == chunks[5].content
+    # a store_embeddings that arrives during a save waits for it (writers are gated) and lands in the NEXT checkpoint
+    monkeypatch.setattr(OracleIndex, "save", real_save)
 
 
 # --------------------------------------------------------------------------- sharded store (host logic; GPU: test_gpu_store.py)
