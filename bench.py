@@ -65,39 +65,98 @@ def timed_runs(fn, min_runs=5, budget_s=12.0, max_runs=7):
 
 
 def cpu_baseline(sample_pages_u16, q_u16):
-    """Reference CPU path timed on this box's host cores, on a bounded sample of the same workload (BASELINE.md section
-    3: >= 20 000 pages, >= 5 repeats, median).  Two formulations of the reference's float MaxSim
-    (fast_multivector_store.py:553-555 -> score_multi_vector): (i) numpy sgemm -> max -> sum over all cores,
-    (ii) torch einsum over page batches of 128 (the reference's own expression; ~20x slower, smaller sample).
-    fp32 on upcast bf16 data (the reference upcasts at load, fast_multivector_store.py:736,774).  The faster one is the
-    baseline of record."""
+    """Reference CPU path timed on this box's host cores, on a bounded sample of the same workload (BASELINE.md section 3:
+    >= 20 000 pages, >= 5 repeats, median).  The reference's float MaxSim (fast_multivector_store.py:553-555 ->
+    score_multi_vector) in its two CPU formulations, each at the thread count that serves it best on THIS box -- a 32-column
+    skinny GEMM does not scale to 256 BLAS threads, so "all cores" is not automatically the fastest the host does:
+      (i)   numpy sgemm -> max -> sum, BLAS threads swept over {8, 32, 64, 128, all}
+      (ii)  the same arithmetic chunk-parallel: a pool of T workers over page chunks, ONE BLAS thread each, T swept
+      (iii) torch einsum over page batches of 128 (the reference's own expression), torch threads swept
+    fp32 on upcast bf16 data (the reference upcasts at load, fast_multivector_store.py:736,774).  The sweep runs on a 4096-page
+    slice; the winner of every family is then timed on the whole sample (median of >= 5).  The fastest is the baseline of record."""
+    from concurrent.futures import ThreadPoolExecutor
+
     from oracle import oracle as orc  # CPU checker / baseline only
 
     import torch
+    from threadpoolctl import threadpool_limits
 
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     q = orc.bf16_to_f32(q_u16)
     pages = orc.bf16_to_f32(sample_pages_u16)  # upcast outside the timed region, like the reference's load step
     n = pages.shape[0]
-    n_torch = min(n, 2048)
+    sweep_n = min(n, 4096)
+    counts = sorted({t for t in (8, 32, 64, 128, cores) if t <= cores})
+
+    def numpy_blas(t, m):
+        def run():
+            with threadpool_limits(limits=t, user_api="blas"):
+                return orc.maxsim_float_np(q, pages[:m])
+        return run
+
+    def numpy_chunks(t, m):
+        step = max(16, min(128, -(-m // (4 * t))))
+        spans = [(s0, min(s0 + step, m)) for s0 in range(0, m, step)]
+        pool = ThreadPoolExecutor(max_workers=t)
+
+        def run():
+            with threadpool_limits(limits=1, user_api="blas"):
+                return np.concatenate(list(pool.map(lambda ab: orc.maxsim_float_np(q, pages[ab[0] : ab[1]], chunk=64), spans)))
+        return run, pool
+
+    def torch_einsum(t, m):
+        def run():
+            torch.set_num_threads(t)
+            return orc.maxsim_float_torch(q, pages[:m])
+        return run
+
+    def rate(fn, m, min_runs, budget):
+        times = timed_runs(fn, min_runs=min_runs, budget_s=budget, max_runs=max(min_runs, 7))
+        return m / float(np.median(times)), len(times)
+
+    want = orc.maxsim_float_np(q, pages[:256])
+    sweep = {"numpy_sgemm_blas_threads": {}, "numpy_chunk_parallel_workers": {}, "torch_einsum_threads": {}}
+    for t in counts:
+        sweep["numpy_sgemm_blas_threads"][t] = rate(numpy_blas(t, sweep_n), sweep_n, 2, 1.5)[0]
+        fn, pool = numpy_chunks(t, sweep_n)
+        assert np.allclose(fn()[:256], want, rtol=1e-6)
+        sweep["numpy_chunk_parallel_workers"][t] = rate(fn, sweep_n, 2, 1.5)[0]
+        pool.shutdown()
+        sweep["torch_einsum_threads"][t] = rate(torch_einsum(t, min(sweep_n, 1024)), min(sweep_n, 1024), 2, 1.0)[0]
+    best_t = {fam: max(v, key=v.get) for fam, v in sweep.items()}
     res, used = {}, {}
-    for name, fn, m, budget in (("numpy_sgemm", lambda: orc.maxsim_float_np(q, pages), n, 14.0),
-                                ("torch_einsum", lambda: orc.maxsim_float_torch(q, pages[:n_torch]), n_torch, 8.0)):
-        times = timed_runs(fn, min_runs=5, budget_s=budget)
-        res[name] = m / float(np.median(times))
-        used[name] = (m, len(times))
+    res["numpy_sgemm"], used["numpy_sgemm"] = rate(numpy_blas(best_t["numpy_sgemm_blas_threads"], n), n, 5, 8.0)
+    fn, pool = numpy_chunks(best_t["numpy_chunk_parallel_workers"], n)
+    res["numpy_chunk_parallel"], used["numpy_chunk_parallel"] = rate(fn, n, 5, 8.0)
+    pool.shutdown()
+    n_torch = min(n, 4096)
+    res["torch_einsum"], used["torch_einsum"] = rate(torch_einsum(best_t["torch_einsum_threads"], n_torch), n_torch, 5, 6.0)
+    torch.set_num_threads(cores)
     best = max(res, key=res.get)
+    threads = {"numpy_sgemm": best_t["numpy_sgemm_blas_threads"], "numpy_chunk_parallel": best_t["numpy_chunk_parallel_workers"],
+               "torch_einsum": best_t["torch_einsum_threads"]}
     page_bytes_f32 = pages.shape[1] * 128 * 4
+    numa = None
+    try:
+        numa = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+    except OSError:
+        pass
     return {
         "value": round(res[best], 1),
         "unit": "pages/s",
-        "cores": cores,
+        "cores": int(threads[best]),
+        "cores_available": cores,
         "kind": "port",
+        "formulation": best,
         "achieved_GBps_fp32_pages": round(res[best] * page_bytes_f32 / 1e9, 2),
-        "sample": f"{pages.shape[1]} patches x 128-d fp32 (upcast bf16), Q={q.shape[0]}; numpy_sgemm={res['numpy_sgemm']:.0f} pages/s on {used['numpy_sgemm'][0]} pages "
-                  f"(median of {used['numpy_sgemm'][1]}), torch_einsum={res['torch_einsum']:.0f} pages/s on {used['torch_einsum'][0]} pages "
-                  f"(median of {used['torch_einsum'][1]}); best={best}",
+        "pages_per_s_by_formulation": {k_: round(v, 1) for k_, v in res.items()},
+        "threads_by_formulation": threads,
+        "thread_sweep_pages_per_s_on_4096_pages": {fam: {str(t): round(v, 1) for t, v in d.items()} for fam, d in sweep.items()},
+        "numa_nodes": numa,
+        "numa_note": "the sample is first-touched by one thread (one node); workers on the other socket read it across the link -- as a single-process "
+                     "reference deployment would",
+        "sample": f"{n} pages x {pages.shape[1]} patches x 128-d fp32 (upcast bf16), Q={q.shape[0]}; thread counts swept on {sweep_n} pages, every family's best "
+                  f"timed on the whole sample (median of {min(used.values())}+ runs; torch_einsum on {n_torch} pages); best = {best} with {threads[best]} threads",
     }
 
 
@@ -162,31 +221,47 @@ N_TOPIC_Q = 64     # clustered-corpus queries (one per topic, graded relevance)
 N_RANDOM_Q = 16    # queries against the unstructured background only
 
 
-def recall_sets(args, n_pages, device, planted_queries, planted_spec_):
-    """The query / page sets every lossy path is scored on (>= 64 queries per structured corpus):
-    planted (3x margin), hard negatives (64 near-tied pages per query), clustered topics (graded relevance), and queries
-    with no structure at all.  Pages of the sets are disjoint; everything is a pure function of (seeds, n_pages, patches)."""
+def recall_sets(args, n_pages, device, headline_spec):
+    """The query / page sets every lossy path is scored on (>= 64 queries per structured corpus), all written into the FIRST
+    n_pages pages of the corpus (the pages the shard-shaped indexes of aux_paths hold too): planted (3x margin), hard negatives
+    (64 near-tied pages per query), clustered topics (graded relevance), and queries with no structure at all.  Pages of the
+    sets are disjoint from each other and from the headline's planted pages; everything is a pure function of
+    (seeds, n_pages, patches)."""
     from morphik_core_amd import synth
     from morphik_core_amd.index import synth_rows
 
-    taken = {p for (_q, _r, p, _a, _b) in planted_spec_}
+    taken = {p for (_q, _r, p, _a, _b) in headline_spec}
+    pq = [synth_rows(synth.SEED_QUERIES, 3000 + j, args.qtokens, device=device) for j in range(N_QUERIES)]
+    pspec = [t for t in synth.planted_spec(pq, n_pages, args.patches, n_ranks=N_PLANTED, seed=synth.SEED_PLANTED + 1) if t[2] not in taken]
+    taken |= {t[2] for t in pspec}
     hq = [synth_rows(synth.SEED_QUERIES, 1000 + j, args.qtokens, device=device) for j in range(N_HARD_Q)]
     hspec = [t for t in synth.hard_spec(hq, n_pages, args.patches) if t[2] not in taken]
     taken |= {t[2] for t in hspec}
     cq, cspec = synth.clustered_spec(N_TOPIC_Q, n_pages, args.patches, q_tokens=args.qtokens, exclude=taken)
     rq = [synth_rows(synth.SEED_QUERIES, 2000 + j, args.qtokens, device=device) for j in range(N_RANDOM_Q)]
-    return {"planted": {"queries": list(planted_queries), "spec": list(planted_spec_)},
+    return {"planted": {"queries": pq, "spec": pspec},
             "hard_negatives": {"queries": hq, "spec": hspec},
             "clustered_topics": {"queries": cq, "spec": cspec},
             "unstructured": {"queries": rq, "spec": []}}
 
 
-def exact_truth(ix, queries, k=K):
-    """Exact bf16 top-k of every query over the whole index (the parity-checked float scan, 16 queries per slab pass)
-    + the relative margin between rank k and rank k+1."""
+def first_pages_bitmap(n_allowed, n_total):
+    """Doc bitmap allowing pages [0, n_allowed) of a corpus whose doc ordinal == page (pages_per_doc 1); None = everything."""
+    if n_allowed >= n_total:
+        return None
+    bm = np.zeros((n_total + 31) // 32, np.uint32)
+    bm[: n_allowed // 32] = 0xFFFFFFFF
+    if n_allowed % 32:
+        bm[n_allowed // 32] = (1 << (n_allowed % 32)) - 1
+    return bm
+
+
+def exact_truth(ix, queries, k=K, allow=None):
+    """Exact bf16 top-k of every query over the (allowed pages of the) index (the parity-checked float scan, 16 queries per slab
+    pass) + the relative margin between rank k and rank k+1."""
     tops, gaps = [], []
     for g0 in range(0, len(queries), 16):
-        for s, i in ix.query_batch(queries[g0 : g0 + 16], k + 1):
+        for s, i in ix.query_batch(queries[g0 : g0 + 16], k + 1, allow=allow):
             tops.append(i[:k].tolist())
             gaps.append(float((s[k - 1] - s[k]) / abs(s[k - 1])) if len(s) > k else float("nan"))
     return tops, gaps
@@ -233,11 +308,41 @@ def recall_of(ix, sets, truths, gaps, modes, allow_unstructured=None):
     return out
 
 
-def full_shard(args, device, sets, truths, gaps, n_truth_pages):
-    """BASELINE configs[3] / [4] at their per-GPU shard shape: ONE index of args.full_shard_pages pages (10 M / 8 GPUs =
-    1.25 M) holding the e4m3, FDE and sign-bit slabs (no bf16 slab: 328 GB would not fit), built by the same generator as
-    the bf16 corpus the truth was computed on (its first n_truth_pages pages ARE that corpus; the rest is unstructured
-    background, which the queries without structure are kept away from by a doc filter so their truth stays exact)."""
+def container_memory_GB():
+    """Memory charged to this container right now and its limit (cgroup v2 / v1), GB -- next to the pinned tier it carries."""
+    out = {}
+    for key, paths in (("current", ("/sys/fs/cgroup/memory.current", "/sys/fs/cgroup/memory/memory.usage_in_bytes")),
+                       ("limit", ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"))):
+        for pth in paths:
+            try:
+                v = open(pth).read().strip()
+                out[key] = round(int(v) / 1e9, 1) if v.isdigit() else v
+                break
+            except OSError:
+                continue
+    return out
+
+
+def exact_shard_pages(args, stride):
+    """Pages of the shard-shaped index that carries its exact tier in pinned host RAM (aux_paths.exact_shard).  configs[3] / [4]
+    name 1.25 M pages per GPU = 328 GB of pinned rows; the process may pin only what its memory cgroup allows
+    (mv_host_pin_budget_bytes(): limit - usage - headroom; the MI355X pool's containers run with memory.max = 300 GiB on a
+    3 TiB host, and pinning past it gets the container killed, not an error).  args.exact_shard_pin_frac of that budget is used."""
+    from morphik_core_amd import _lib
+
+    if args.exact_shard_pages <= 0:
+        return 0, 0
+    budget = int(_lib.lib().mv_host_pin_budget_bytes())
+    fit = int(args.exact_shard_pin_frac * budget // (stride * 256))
+    return max(min(args.exact_shard_pages, fit), 0), budget
+
+
+def full_shard(args, device, qs):
+    """BASELINE configs[3] / [4] at their per-GPU shard SIZE: ONE index of args.full_shard_pages pages (10 M / 8 GPUs = 1.25 M)
+    holding the e4m3, FDE and sign-bit slabs (no bf16 slab: 328 GB would not fit) -- the rates of the three full-corpus scans, of
+    the batched e4m3 scan and of the batched FDE pipeline, which scale with the page count.  (The exact tier of such a shard is
+    328 GB of pinned host RAM, more than this container may pin: the exact pipelines and every recall figure are measured on
+    aux_paths.exact_shard, the largest shard whose exact tier does fit.)"""
     from morphik_core_amd import _lib as L
     from morphik_core_amd import synth
     from morphik_core_amd.index import MvIndex
@@ -248,39 +353,17 @@ def full_shard(args, device, sets, truths, gaps, n_truth_pages):
     per_page = stride * 128 + stride * 16 + 20480 + 16 + 32 * 4  # slabs + metadata + the batched score vectors
     free_b, _tot = torch.cuda.mem_get_info(device)
     n = int(min(args.full_shard_pages, (free_b - (8 << 30)) // per_page))
-    res = {"pages": n, "slabs": "e4m3 + FDE(10240 bf16) + sign bits, no bf16 slab", "resident_GB": round(n * per_page / 1e9, 1),
-           "note": "kernel-only HIP-event times (median of 9 after 0.25 s of warm-up queries); recall@10 against the exact bf16 top-10 of the same "
-                   "corpus computed by the float scan before the bf16 slab was freed"}
-    # the exact tier of the shard lives in pinned host RAM (n x 256 KiB: 328 GB at 1.25 M pages) when the box has room for it
-    host_tier = False
-    try:
-        avail = [int(ln.split()[1]) * 1024 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable:")][0]
-        host_tier = args.full_shard_host_tier and avail > 2.5 * n * stride * 256
-    except Exception:  # noqa: BLE001
-        host_tier = False
+    res = {"pages": n, "slabs": "e4m3 + FDE(10240 bf16) + sign bits, no bf16 slab, no exact tier", "resident_GB": round(n * per_page / 1e9, 1),
+           "exact_tier_needed_GB": round(n * stride * 256 / 1e9, 1),
+           "note": "kernel-only HIP-event times (median of 9 after 0.25 s of warm-up queries); unstructured corpus (timing only: recall and the exact "
+                   "pipelines are on aux_paths.exact_shard)"}
     t0 = time.time()
-    ix = None
-    if host_tier:
-        try:
-            ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=False, with_binary=True, with_fde=True, with_fp8=True, with_host_exact=True)
-        except Exception as e:  # noqa: BLE001 -- no pinned memory for it: the shard runs without its exact tier
-            res["host_tier_error"] = repr(e)
-            host_tier = False
-    if ix is None:
-        ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=False, with_binary=True, with_fde=True, with_fp8=True)
+    ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=False, with_binary=True, with_fde=True, with_fp8=True)
     res["create_s"] = round(time.time() - t0, 1)
-    res["pinned_host_exact_tier_GB"] = round(n * stride * 256 / 1e9, 1) if host_tier else 0
     t0 = time.time()
     ix.fill_synthetic(synth.SEED_CORPUS, 0, n, n_rows=args.patches)
     res["fill_s"] = round(time.time() - t0, 1)
-    t0 = time.time()
-    planted_pages = 0
-    for st_ in sets.values():
-        planted_pages += synth.plant_neighbours_any(ix, st_["spec"], synth.SEED_CORPUS, args.patches, 0, n)
-    res["planted_pages"] = planted_pages
-    res["plant_s"] = round(time.time() - t0, 1)
-    log(f"[full shard] {n} pages generated in {res['fill_s']} s, {planted_pages} structured pages written in {res['plant_s']} s")
-    qs = sets["planted"]["queries"]
+    log(f"[full shard] {n} pages generated in {res['fill_s']} s")
     # ---- the three full-corpus scans
     for key, mode, bpp in (("fp8_scan", "float_fp8", args.patches * 128), ("sign_bit_scan", "binary", args.patches * 16)):
         t = timed_mode(ix, qs, mode)
@@ -304,10 +387,20 @@ def full_shard(args, device, sets, truths, gaps, n_truth_pages):
                                          "frac_fp8_mfma_5000TF_issued": round(useful * (1 if bv == 7 else 2) / 5000.0, 4),
                                          "GBps": round(n * args.patches * 128 / m / 1e6, 1), "frac_hbm_8TBps": round(n * args.patches * 128 / m / 1e6 / HBM_PEAK_GBPS, 4)}
     ix.set_option(L.MV_OPT_BATCH_VARIANT, -1)
-    # ---- FDE -> top-n -> exact rerank on the e4m3 slab (configs[3] pipeline), one request and 32 per slab pass
-    res["fde_then_fp8_rerank"] = {}
+    # ---- FDE -> top-n -> rerank on the e4m3 slab (what an index WITHOUT an exact tier does), one request and 32 per slab pass
+    res["fde_then_fp8_rerank"] = {cn_key: ent for cn_key, ent in fde_pipeline_timings(ix, qs, n, (75, 1000)).items()}
+    ix.close()
+    return res
+
+
+def fde_pipeline_timings(ix, qs, n, coarse_ns):
+    """Device times of MV_MODE_FDE_THEN_FLOAT on `ix` for every coarse list length: one request (stage split) and 32 requests per
+    pass over the FDE slab (mv_query_topk_batch)."""
+    from morphik_core_amd import _lib as L
+
+    out = {}
     bq = [qs[i % len(qs)] for i in range(32)]
-    for cn in (75, 1000):
+    for cn in coarse_ns:
         ix.set_option(L.MV_OPT_FDE_COARSE_N, cn)
         t = timed_mode(ix, qs, "fde_then_float", n_timed=12)
         dev, stg, out_b = [], [], None
@@ -318,7 +411,7 @@ def full_shard(args, device, sets, truths, gaps, n_truth_pages):
                 stg.append((st.encode_ms, st.coarse_ms, st.select_ms, st.rerank_ms, st.topk_ms))
         d, sb = float(np.median(dev)), np.median(np.array(stg), axis=0)
         same = float(np.mean([out_b[i][1].tolist() == ix.query(bq[i], K, mode="fde_then_float")[1].tolist() for i in range(0, 32, 4)]))
-        res["fde_then_fp8_rerank"][f"coarse{cn}"] = {
+        out[f"coarse{cn}"] = {
             "one_request": {"device_ms": round(t["total_device_ms"], 4), "pages_searched_per_s": round(n / t["total_device_ms"] * 1e3, 1),
                             "stage_ms": {k: round(t[k], 4) for k in ("encode_ms", "coarse_ms", "select_ms", "rerank_ms", "topk_ms")},
                             "coarse_scan_GBps": round(n * 20480 / t["coarse_ms"] / 1e6, 1),
@@ -329,13 +422,89 @@ def full_shard(args, device, sets, truths, gaps, n_truth_pages):
                             "coarse_pass_GBps": round(n * 20480 / float(sb[1]) / 1e6, 1),
                             "coarse_pass_frac_hbm_8TBps": round(n * 20480 / float(sb[1]) / 1e6 / HBM_PEAK_GBPS, 4),
                             "same_ids_as_single_query": same}}
-    # ---- recall of every lossy path vs the exact bf16 truth, >= 64 queries per structured corpus
-    background_off = None
-    if n > n_truth_pages:  # doc ordinal == page (pages_per_doc 1): allow exactly the pages the truth was computed on
-        background_off = np.zeros((n + 31) // 32, np.uint32)
-        background_off[: n_truth_pages // 32] = 0xFFFFFFFF
-        if n_truth_pages % 32:
-            background_off[n_truth_pages // 32] = (1 << (n_truth_pages % 32)) - 1
+    return out
+
+
+def exact_shard(args, device, n, budget, sets, truths, gaps):
+    """BASELINE configs[3] / [4] at their per-GPU shard SHAPE with the EXACT rerank the reference does (fp32 MaxSim on fp32 pages,
+    fast_multivector_store.py:553-556): e4m3 + FDE + sign-bit slabs in HBM (no bf16 slab), the exact bf16 rows of every page in
+    PINNED HOST memory (n x 256 KiB).  n = as many of the 1.25 M pages as this process may pin (exact_shard_pages()).  Its
+    pages are the first n of the headline corpus -- the pages the recall sets were written into and the exact bf16 truth was
+    taken on (with a doc filter over those pages) before the bf16 slab was freed.
+    Measured: the FDE pipeline with its exact rerank (coarse top-75: straight out of host RAM; coarse top-1000: e4m3 pruning to
+    128, then host RAM) and fp8_then_float -- device ms for one request and for a batch, the PCIe rate of the exact stage, recall@10
+    of every lossy and every exact path against the bf16 truth on the four corpora, and the largest relative error of the
+    returned scores against the FLOAT oracle on the rows the tier holds."""
+    from oracle import oracle as orc  # checker only (outside every timed region)
+
+    from morphik_core_amd import _lib as L
+    from morphik_core_amd import synth
+    from morphik_core_amd.index import MvIndex
+
+    stride = ((args.patches + 15) // 16) * 16
+    res = {"pages": n, "pages_of_a_full_shard": args.exact_shard_pages, "slabs": "e4m3 + FDE(10240 bf16) + sign bits in HBM; exact bf16 rows in pinned host RAM",
+           "pinned_host_exact_tier_GB": round(n * stride * 256 / 1e9, 1), "pin_budget_GB": round(budget / 1e9, 1),
+           "pin_budget_note": "mv_host_pin_budget_bytes(): memory cgroup limit - usage - headroom (the pool's containers: memory.max 300 GiB on a 3 TiB host; "
+                              "a 1.25 M-page shard's 328 GB tier cannot be pinned here -- two boxes were lost finding that out); %.2f of it is used" % args.exact_shard_pin_frac,
+           "note": "kernel-only HIP-event times (median after 0.25 s of warm-up queries); recall@10 against the exact bf16 top-10 of the same pages computed by the "
+                   "float scan (doc filter over the first n pages) before the bf16 slab was freed"}
+    t0 = time.time()
+    ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=False, with_binary=True, with_fde=True, with_fp8=True, with_host_exact=True)
+    res["create_and_pin_s"] = round(time.time() - t0, 1)
+    t0 = time.time()
+    ix.fill_synthetic(synth.SEED_CORPUS, 0, n, n_rows=args.patches)
+    res["fill_s"] = round(time.time() - t0, 1)
+    res["container_memory_GB_with_the_tier_resident"] = container_memory_GB()
+    t0 = time.time()
+    planted_pages = 0
+    for st_ in sets.values():
+        planted_pages += synth.plant_neighbours_any(ix, st_["spec"], synth.SEED_CORPUS, args.patches, 0, n)
+    planted_pages += synth.plant_neighbours_any(ix, sets["_headline_spec"], synth.SEED_CORPUS, args.patches, 0, n) if "_headline_spec" in sets else 0
+    res["planted_pages"] = planted_pages
+    res["plant_s"] = round(time.time() - t0, 1)
+    log(f"[exact shard] {n} pages ({res['pinned_host_exact_tier_GB']} GB pinned in {res['create_and_pin_s']} s) generated in {res['fill_s']} s, "
+        f"{planted_pages} structured pages written in {res['plant_s']} s")
+    rsets = {k_: v for k_, v in sets.items() if not k_.startswith("_")}
+    qs = rsets["planted"]["queries"]
+    # ---- configs[3]: FDE coarse -> exact rerank out of the pinned-host tier
+    base_fde = timed_mode(ix, qs, "fde")
+    res["fde_then_exact_rerank"] = fde_pipeline_timings(ix, qs, n, (75, 1000))
+    for cn in (75, 1000):
+        ent = res["fde_then_exact_rerank"][f"coarse{cn}"]
+        n_mid, tier = ix.rerank_plan(cn, K, args.qtokens)
+        read = (n_mid or cn) * args.patches * 256
+        ent["rerank_plan"] = {"tier": tier, "e4m3_pruning_to": n_mid, "exact_pages_read_over_pcie": (n_mid or cn)}
+        one = ent["one_request"]
+        one["added_ms_over_coarse_scan_and_encode"] = round(one["device_ms"] - base_fde["total_device_ms"], 4)
+        one["exact_stage_GBps_over_pcie_upper_bound"] = round(read / max(one["stage_ms"]["rerank_ms"], 1e-6) / 1e6, 1)
+    # ---- configs[4]: e4m3 scan of every page -> top-128 -> exact re-score out of the pinned-host tier
+    base = timed_mode(ix, qs, "float_fp8")
+    t = timed_mode(ix, qs, "fp8_then_float")
+    res["fp8_then_float_n128"] = {
+        "rerank_n": 128, "device_ms": round(t["total_device_ms"], 4), "fp8_scan_alone_device_ms": round(base["total_device_ms"], 4),
+        "added_ms_over_fp8_scan": round(t["total_device_ms"] - base["total_device_ms"], 4), "rerank_ms": round(t["rerank_ms"], 4),
+        "rerank_GBps_over_pcie": round(128 * args.patches * 256 / max(t["rerank_ms"], 1e-6) / 1e6, 1),
+        "pages_searched_per_s": round(n / t["total_device_ms"] * 1e3, 1)}
+    dev = []
+    for r in range(5):
+        _o, st = ix.query_batch(qs[:16], K, mode="fp8_then_float", want_stats=True)
+        if r >= 2:
+            dev.append(st.total_device_ms)
+    d = float(np.median(dev))
+    res["fp8_then_float_n128"]["batch_of_16"] = {"device_ms_per_batch": round(d, 4), "device_us_per_request": round(d * 1e3 / 16, 1),
+                                                  "query_pages_per_s": round(16 * n / d * 1e3, 1)}
+    # ---- returned scores vs the FLOAT oracle on the tier's own rows (the bar: 1e-3 relative; the fp8 rerank misses it by 3-10x)
+    worst = {}
+    for name, mode, cn in (("fde_top75_then_exact", "fde_then_float", 75), ("fde_top1000_then_exact", "fde_then_float", 1000), ("fp8_then_float_n128", "fp8_then_float", None)):
+        if cn:
+            ix.set_option(L.MV_OPT_FDE_COARSE_N, cn)
+        w = 0.0
+        for q in qs[:4]:
+            s, i = ix.query(q, K, mode=mode)
+            want = np.array([orc.maxsim_bf16(q, ix.read_pages(int(p), 1)[0, : args.patches]) for p in i], np.float32)
+            w = max(w, float(np.max(np.abs(s - want) / np.maximum(np.abs(want), 1e-6))))
+        worst[name] = w
+    res["max_rel_score_err_vs_float_oracle"] = worst
 
     def ids_of(mode, k=K, cn=None):
         def f(q, al):
@@ -344,21 +513,17 @@ def full_shard(args, device, sets, truths, gaps, n_truth_pages):
             return ix.query(q, k, mode=mode, allow=al)[1].tolist()
         return f
 
-    if host_tier:  # configs[4] with its exact tier: e4m3 scan -> top-128 -> exact bf16 re-score out of host RAM over PCIe
-        base = timed_mode(ix, qs, "float_fp8")
-        t = timed_mode(ix, qs, "fp8_then_float")
-        res["fp8_then_float_from_pinned_host_tier"] = {
-            "rerank_n": 128, "device_ms": round(t["total_device_ms"], 4), "fp8_scan_alone_device_ms": round(base["total_device_ms"], 4),
-            "added_ms_over_fp8_scan": round(t["total_device_ms"] - base["total_device_ms"], 4), "rerank_ms": round(t["rerank_ms"], 4),
-            "rerank_GBps_over_pcie": round(128 * args.patches * 256 / max(t["rerank_ms"], 1e-6) / 1e6, 1),
-            "pages_searched_per_s": round(n / t["total_device_ms"] * 1e3, 1)}
-    modes = [("fp8_scan", ids_of("float_fp8")), ("sign_bit_scan", ids_of("binary")),
-             ("fde_top75_then_fp8", ids_of("fde_then_float", cn=75)), ("fde_top1000_then_fp8", ids_of("fde_then_float", cn=1000)),
+    modes = [("fp8_scan", ids_of("float_fp8")), ("fp8_then_float_n128", ids_of("fp8_then_float")), ("sign_bit_scan", ids_of("binary")),
+             ("fde_top75_then_exact", ids_of("fde_then_float", cn=75)), ("fde_top1000_then_exact", ids_of("fde_then_float", cn=1000)),
              ("fde_coarse_recall_at_75", ids_of("fde", k=75)), ("fde_coarse_recall_at_1000", ids_of("fde", k=1000))]
-    if host_tier:
-        modes.insert(1, ("fp8_then_float_n128", ids_of("fp8_then_float")))
     t0 = time.time()
-    res["recall_at_10_vs_exact_bf16"] = recall_of(ix, sets, truths, gaps, modes, background_off)
+    res["recall_at_10_vs_exact_bf16"] = recall_of(ix, rsets, truths, gaps, modes, None)
+    # the e4m3 rerank an index WITHOUT an exact tier falls back to (MV_OPT_EXACT_TIER 2), on the same candidates: what the exact tier buys
+    ix.set_option(L.MV_OPT_EXACT_TIER, 2)
+    res["recall_at_10_vs_exact_bf16_with_the_e4m3_rerank_instead"] = recall_of(
+        ix, {k_: rsets[k_] for k_ in ("hard_negatives", "clustered_topics")}, truths, gaps,
+        [("fde_top75_then_fp8", ids_of("fde_then_float", cn=75)), ("fde_top1000_then_fp8", ids_of("fde_then_float", cn=1000))], None)
+    ix.set_option(L.MV_OPT_EXACT_TIER, 0)
     res["recall_s"] = round(time.time() - t0, 1)
     ix.set_option(L.MV_OPT_FDE_COARSE_N, 1000)
     ix.close()
@@ -383,8 +548,7 @@ def two_tier(args, device):
     t0 = time.time()
     ix.fill_synthetic(synth.SEED_CORPUS, 0, n, n_rows=args.patches)
     res["fill_s"] = round(time.time() - t0, 1)
-    pq = [synth_rows(synth.SEED_QUERIES, qi, args.qtokens, device=device) for qi in range(N_QUERIES)]
-    sets = recall_sets(args, n, device, pq, synth.planted_spec(pq, n, args.patches, n_ranks=N_PLANTED))
+    sets = recall_sets(args, n, device, [])
     t0 = time.time()
     for st_ in sets.values():
         synth.plant_neighbours_any(ix, st_["spec"], synth.SEED_CORPUS, args.patches, 0, n)
@@ -553,9 +717,11 @@ def main():
                          "embed = configs[1] (ColPali-v1.2 architecture, 1 k pages -> top-10)")
     ap.add_argument("--no-aux", action="store_true", help="skip the secondary kernels' quick measurements (aux_paths)")
     ap.add_argument("--aux-pages", type=int, default=200_000, help="pages of the two-tier (fp8 -> exact bf16 from the pinned-host tier) index in aux_paths (0 = skip)")
-    ap.add_argument("--full-shard-host-tier", action="store_true",
-                    help="also keep the full shard's exact bf16 rows in PINNED host RAM (n x 256 KiB = 328 GB at 1.25 M pages) and measure "
-                         "fp8_then_float at the shard shape; off by default (the default run pins 52 GB for the 200 k-page two-tier index only)")
+    ap.add_argument("--exact-shard-pages", type=int, default=1_250_000,
+                    help="pages of the shard-shaped index WITH its exact tier in pinned host RAM (aux_paths.exact_shard; n x 256 KiB = 328 GB at 1.25 M "
+                         "pages), cut to what the process may pin (see --exact-shard-pin-frac); 0 = skip")
+    ap.add_argument("--exact-shard-pin-frac", type=float, default=0.7,
+                    help="share of mv_host_pin_budget_bytes() (memory cgroup limit - usage - headroom) the exact shard's pinned tier may take")
     ap.add_argument("--full-shard-pages", type=int, default=1_250_000,
                     help="pages of the e4m3 + FDE + sign-bit index in aux_paths.full_shard (BASELINE configs[3]/[4] per-GPU shard of 10 M pages / 8 GPUs; 0 = skip)")
     ap.add_argument("--aux-embed-pages", type=int, default=1000, help="pages of the full-size encoder run inside aux_paths (configs[1] names 1 k pages; 0 = skip)")
@@ -630,7 +796,9 @@ def main():
     free_b, total_b = torch.cuda.mem_get_info(dev)
     reserve = 6 << 30
     if single_device:
-        free_b = free_b // world  # the ranks share one GPU
+        # the ranks share one GPU: an equal share of its TOTAL memory (what is free right now depends on which ranks allocated first)
+        free_b = total_b // world
+        reserve = 2 << 30
     fit = max(int((free_b - reserve) // (page_bytes + 64)), 1)
     if args.scaling == "strong":
         n_total = args.pages
@@ -664,14 +832,20 @@ def main():
         synth.plant_neighbours_any(ix, spec, synth.SEED_CORPUS, args.patches, lo, hi)
     # the query / page sets the lossy paths are scored on (aux_paths): written into the bf16 corpus now, so the exact bf16
     # truth can be taken from THIS slab before it is freed for the configs[3] / [4] shard
-    want_full = world == 1 and args.workload == "float" and not args.no_aux and args.full_shard_pages > 0
+    want_full = world == 1 and args.workload == "float" and not args.no_aux and (args.full_shard_pages > 0 or args.exact_shard_pages > 0)
     rsets = None
+    n_exact = exact_budget = 0
+    n_truth = n_total
     if want_full:
         t1 = time.time()
-        rsets = recall_sets(args, n_total, local_rank, queries, spec)
+        n_exact, exact_budget = exact_shard_pages(args, stride)
+        if n_exact < 50_000:
+            n_exact = 0  # nothing worth measuring fits: the recall sets then span the whole corpus, as the lossy paths of full_shard need them
+        else:
+            n_truth = min(n_total, n_exact)  # every structured page lies inside the pages the exact shard will hold
+        rsets = recall_sets(args, n_truth, local_rank, spec)
         for name, st_ in rsets.items():
-            if name != "planted":
-                synth.plant_neighbours(ix, st_["spec"], lo, hi)
+            synth.plant_neighbours(ix, st_["spec"], lo, hi)
         log(f"[rank {rank}] recall sets: {sum(len(v['spec']) for v in rsets.values())} structured pages written in {time.time()-t1:.1f}s")
     MODE = WL["mode"]
     torch.cuda.synchronize()
@@ -848,7 +1022,9 @@ def main():
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": args.scaling,
-            "vs_baseline": None,
+            "vs_baseline": (round(value / cpu["value"], 1) if (cpu and cpu.get("value")) else None),
+            "vs_baseline_note": ("value / cpu_baseline.value: BASELINE.md publishes no number for this metric (section 1); the denominator is the reference's "
+                                 "CPU formulation at its best thread count on this box's own host cores, measured in this run" if cpu else None),
             "dtype": WL["dtype"],
             "data": "synthetic (on-device counter-based generator, L2-normalised bf16 rows, planted neighbours)",
             "config": {
@@ -900,12 +1076,15 @@ def main():
         try:  # exact bf16 truth of every recall set + the batched MFMA scan, on the headline slab before it is freed
             t1 = time.time()
             truths, gaps = {}, {}
+            truth_allow = first_pages_bitmap(n_truth, n_total)  # the pages the exact shard holds (doc ordinal == page)
             for name, st_ in rsets.items():
-                truths[name], gaps[name] = exact_truth(ix, st_["queries"])
+                truths[name], gaps[name] = exact_truth(ix, st_["queries"], allow=truth_allow)
             for j, top in enumerate(truths["hard_negatives"]):  # the near-tied set must hold the exact top-10
                 assert set(top) <= set(synth.hard_pages_of(rsets["hard_negatives"]["spec"], j)), "hard set does not hold the exact top-10"
-            assert all(t == [p for (qq, _r, p, _a, _b) in spec if qq == qi] for qi, t in enumerate(truths["planted"])), "planted truth"
-            aux["truth"] = {"source": "exact bf16 float scan over the %d-page corpus (batched form, 16 queries per slab pass), top-11" % n_total,
+            for qi, t in enumerate(truths["planted"]):
+                pl = [p for (qq, _r, p, _a, _b) in rsets["planted"]["spec"] if qq == qi]
+                assert t[: len(pl)] == pl, "planted truth"
+            aux["truth"] = {"source": "exact bf16 float scan over the first %d pages of the %d-page corpus (doc filter; batched form, 16 queries per slab pass), top-11" % (n_truth, n_total),
                             "seconds": round(time.time() - t1, 1),
                             "median_rel_gap_rank10_rank11": {k_: float(np.median(v)) for k_, v in gaps.items()}}
             aux["batched_float"] = batched_float_block(ix, queries, n_local, args, None)
@@ -942,11 +1121,16 @@ def main():
             ent["frac_of_measured_mfma_32x32x16"] = round(ent["TFLOPs"] / measured_mfma32, 4)
     if out is not None and world == 1 and not args.no_aux:
         out["aux_paths"] = aux
-        if truths is not None:
-            try:  # BASELINE configs[3] / [4] at their per-GPU shard shape
-                aux["full_shard"] = full_shard(args, local_rank, rsets, truths, gaps, n_total)
+        if rsets is not None and args.full_shard_pages > 0:
+            try:  # BASELINE configs[3] / [4] at their per-GPU shard SIZE: the scan rates
+                aux["full_shard"] = full_shard(args, local_rank, rsets["planted"]["queries"])
             except Exception as e:  # noqa: BLE001
                 aux["full_shard"] = {"error": repr(e)}
+        if truths is not None and n_exact > 0:
+            try:  # ... and at their shard SHAPE with the exact tier in pinned host RAM: the exact pipelines and every recall figure
+                aux["exact_shard"] = exact_shard(args, local_rank, n_truth, exact_budget, dict(rsets, _headline_spec=spec), truths, gaps)
+            except Exception as e:  # noqa: BLE001
+                aux["exact_shard"] = {"error": repr(e)}
         if args.aux_pages > 0:
             try:  # fp8 scan -> exact bf16 re-score from the exact tier (HBM / pinned host)
                 aux["fp8_then_float"] = two_tier(args, local_rank)

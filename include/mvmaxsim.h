@@ -166,6 +166,11 @@ MV_API int mv_abi_version(void);
 MV_API const char* mv_last_error(void);
 MV_API const char* mv_version(void);
 MV_API int mv_device_count(void);
+/* Bytes of host memory this process can still pin (MV_WITH_HOST_EXACT: 262 144 B per 1024-row page) without running into its memory
+ * cgroup limit or the machine's available memory, minus a headroom of max(4 GiB, 5 %); INT64_MAX = unlimited.  mv_index_create
+ * refuses an exact tier beyond it with MV_ERR_NOMEM -- a container over its cgroup limit is killed during the allocation, not told.
+ * MV_HOST_EXACT_MAX_BYTES in the environment lowers it.  No GPU needed. */
+MV_API int64_t mv_host_pin_budget_bytes(void);
 
 /* Lifecycle.  Replaces MultiVectorStore.initialize() (core/vector_store/multi_vector_store.py:186-327:
  * table + max_sim function creation) and FastMultiVectorStore.__init__ (fast_multivector_store.py:296-338). */

@@ -740,12 +740,85 @@ struct ExclusiveLock {
 
 }  // namespace mv
 
+// ---------------------------------------------------------------------------------- host memory the process may still pin
+// The exact tier of MV_WITH_HOST_EXACT is pinned host memory (262 144 B per 1024-row page: 328 GB for a 1.25 M-page shard).
+// Pinned pages are charged to the process's memory cgroup; a container whose memory.max is below the request is KILLED by the
+// kernel half way through hipHostMalloc (measured on the MI355X pool: memory.max = 300 GiB on a 3 TiB host -- the box is lost,
+// no error is returned).  So the library reads the limits itself and refuses up front.
+namespace mv {
+
+static int64_t read_i64_file(const char* path) {  // -1: missing / "max" / unparsable
+  FILE* f = fopen(path, "r");
+  if (!f) return -1;
+  char buf[64] = {0};
+  const size_t n = fread(buf, 1, sizeof(buf) - 1, f);
+  fclose(f);
+  if (n == 0 || buf[0] < '0' || buf[0] > '9') return -1;
+  return (int64_t)strtoll(buf, nullptr, 10);
+}
+
+// Bytes of host memory this process can still pin without running into its cgroup limit or the machine's free memory, minus a
+// headroom of max(4 GiB, 5 % of the limit); INT64_MAX when nothing limits it.  MV_HOST_EXACT_MAX_BYTES in the environment caps it.
+int64_t host_pin_budget_bytes() {
+  int64_t budget = INT64_MAX;
+  // cgroup v2: the namespace root and every level down to the process's own group; v1: the memory controller's files
+  std::string rel, rel_v1;
+  if (FILE* f = fopen("/proc/self/cgroup", "r")) {
+    char line[1024];
+    while (fgets(line, sizeof(line), f)) {
+      std::string ln = line;
+      while (!ln.empty() && (ln.back() == '\n' || ln.back() == '/')) ln.pop_back();
+      if (ln.compare(0, 3, "0::") == 0) rel = ln.substr(3);
+      const size_t m = ln.find(":memory:");
+      if (m != std::string::npos) rel_v1 = ln.substr(m + 8);
+    }
+    fclose(f);
+  }
+  std::vector<std::string> dirs{"/sys/fs/cgroup"};
+  for (size_t pos = 0; pos < rel.size();) {
+    const size_t nxt = rel.find('/', pos + 1);
+    dirs.push_back("/sys/fs/cgroup" + rel.substr(0, nxt == std::string::npos ? rel.size() : nxt));
+    if (nxt == std::string::npos) break;
+    pos = nxt;
+  }
+  for (const std::string& d : dirs) {
+    const int64_t lim = read_i64_file((d + "/memory.max").c_str());
+    if (lim < 0) continue;
+    const int64_t cur = std::max<int64_t>(0, read_i64_file((d + "/memory.current").c_str()));
+    budget = std::min(budget, lim - cur - std::max<int64_t>((int64_t)4 << 30, lim / 20));
+  }
+  for (const std::string& d : {std::string("/sys/fs/cgroup/memory"), "/sys/fs/cgroup/memory" + rel_v1}) {
+    const int64_t lim = read_i64_file((d + "/memory.limit_in_bytes").c_str());
+    if (lim > 0 && lim < ((int64_t)1 << 60)) {  // v1 reports "no limit" as a huge number
+      const int64_t cur = std::max<int64_t>(0, read_i64_file((d + "/memory.usage_in_bytes").c_str()));
+      budget = std::min(budget, lim - cur - std::max<int64_t>((int64_t)4 << 30, lim / 20));
+    }
+  }
+  if (FILE* f = fopen("/proc/meminfo", "r")) {
+    char line[256];
+    while (fgets(line, sizeof(line), f)) {
+      long long kb = 0;
+      if (sscanf(line, "MemAvailable: %lld kB", &kb) == 1) budget = std::min(budget, (int64_t)kb * 1024 - ((int64_t)4 << 30));
+    }
+    fclose(f);
+  }
+  if (const char* e = getenv("MV_HOST_EXACT_MAX_BYTES")) {
+    const int64_t cap = (int64_t)strtoll(e, nullptr, 10);
+    if (cap >= 0) budget = std::min(budget, cap);
+  }
+  return std::max<int64_t>(budget, 0);
+}
+
+}  // namespace mv
+
 // =================================================================================== C ABI
 extern "C" {
 
 const char* mv_last_error(void) { return g_err.c_str(); }
 const char* mv_version(void) { return "mvmaxsim 0.3 (gfx950)"; }
 int mv_abi_version(void) { return MV_ABI_VERSION; }
+
+int64_t mv_host_pin_budget_bytes(void) { return host_pin_budget_bytes(); }
 
 int mv_device_count(void) {
   int n = 0;
@@ -815,6 +888,16 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
               hipHostMalloc((void**)&ix->h_out_id, (size_t)kTopkMaxDeviceK * 8, hipHostMallocDefault) != hipSuccess ||
               hipHostMalloc((void**)&ix->h_cand, (size_t)2 * kTopkMaxDeviceK * 4, hipHostMallocDefault) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = MV_ERR_NOMEM; }
   if (cfg->flags & MV_WITH_FLOAT) alloc((void**)&ix->slab, rows * kRowBytes + 32768, "bf16 page slab");  // +32 KiB: the batched scans DMA whole 16 / 32 KiB chunks
+  if (!rc && (cfg->flags & MV_WITH_HOST_EXACT)) {
+    const int64_t budget = host_pin_budget_bytes();
+    if ((int64_t)(rows * kRowBytes + 32768) > budget) {
+      // refuse BEFORE pinning: a container past its memory cgroup limit is killed, not told
+      set_error("the pinned-host exact tier needs %zu bytes (%lld pages x %d rows x 256 B) but this process may pin only %lld more "
+                "(memory cgroup limit / MemAvailable minus headroom; mv_host_pin_budget_bytes()): use fewer pages per shard or raise the container's memory limit",
+                rows * kRowBytes, (long long)cap, cfg->stride_rows, (long long)budget);
+      rc = MV_ERR_NOMEM;
+    }
+  }
   if (!rc && (cfg->flags & MV_WITH_HOST_EXACT)) {
     // pinned + mapped: the rerank kernel reads the candidates' rows straight out of host RAM (+32 KiB: whole DMA chunks)
     hipError_t e = hipHostMalloc((void**)&ix->h_exact, rows * kRowBytes + 32768, hipHostMallocMapped | hipHostMallocPortable);

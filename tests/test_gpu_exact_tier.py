@@ -308,3 +308,66 @@ def test_sharded_stores_with_host_exact_tiers_behind_the_plugin_surface():
             top = np.lexsort((np.arange(len(pages)), -exact.astype(np.float64)))[:5]
             assert [int(h.document_id[1:]) * 4 + h.chunk_number for h in hits] == top.tolist()
         st.close()
+
+
+def test_host_exact_tier_beyond_the_memory_budget_is_refused_before_pinning(monkeypatch):
+    """A container over its memory cgroup limit is KILLED in the middle of hipHostMalloc (measured on the MI355X pool: memory.max
+    300 GiB on a 3 TiB host; the 328 GB tier of a 1.25 M-page shard took the box down twice): mv_index_create reads the limits
+    and refuses up front, loudly."""
+    from morphik_core_amd import MvError, _lib
+
+    assert _lib.lib().mv_host_pin_budget_bytes() > 0
+    monkeypatch.setenv("MV_HOST_EXACT_MAX_BYTES", str(64 << 20))
+    assert _lib.lib().mv_host_pin_budget_bytes() <= 64 << 20
+    with pytest.raises(MvError) as e:
+        _idx(capacity_pages=1000, stride_rows=1024, with_float=False, with_fp8=True, with_host_exact=True)  # 262 MB > 64 MiB
+    assert "may pin only" in str(e.value)
+    ix = _idx(capacity_pages=100, stride_rows=1024, with_float=False, with_fp8=True, with_host_exact=True)  # 26 MB: fine
+    ix.close()
+
+
+def test_exact_pipelines_at_shard_scale_return_float_oracle_scores():
+    """configs[3] / [4] at (as much as this box allows of) their per-GPU shard shape: FDE + e4m3 slabs in HBM, the exact bf16 rows
+    of EVERY page in pinned host memory.  A 1.25 M-page shard needs 328 GB pinned; the page count is cut to HALF of what the
+    process may still pin (mv_host_pin_budget_bytes: the container's memory cgroup limit, 300 GiB on the MI355X pool) and to the
+    free HBM.  The oracle cannot scan a corpus of this size, so the test checks size-independent properties: the planted top-10
+    comes back in rank order from every exact pipeline, single and batched, with scores within 1e-3 of orc.maxsim_bf16 (the
+    FLOAT oracle) on the rows read back from the tier -- which is also where the kernels read them."""
+    import torch
+
+    from morphik_core_amd import _lib, synth
+    from morphik_core_amd.index import synth_rows
+
+    patches, qt, k = 1024, 32, 10
+    budget = int(_lib.lib().mv_host_pin_budget_bytes())
+    free_b, _tot = torch.cuda.mem_get_info(0)
+    n = int(min(1_250_000, 0.5 * budget // (patches * 256), (free_b - (16 << 30)) // (patches * 128 + 20480 + 64 + 33 * 4)))
+    assert n >= 20_000, f"only {n} pages fit (pin budget {budget / 1e9:.0f} GB, free HBM {free_b / 1e9:.0f} GB)"
+    ix = _idx(capacity_pages=n, stride_rows=patches, with_float=False, with_fde=True, with_fp8=True, with_host_exact=True)
+    ix.fill_synthetic(synth.SEED_CORPUS, 0, n, n_rows=patches)
+    qs = [synth_rows(synth.SEED_QUERIES, qi, qt) for qi in range(6)]
+    spec = synth.planted_spec(qs, n, patches, n_ranks=k)
+    synth.plant_neighbours_any(ix, spec, synth.SEED_CORPUS, patches, 0, n)
+    planted = [[p for (qq, _r, p, _a, _b) in spec if qq == qi] for qi in range(len(qs))]
+    print(f"shard-scale exact tier: {n} pages, {n * patches * 256 / 1e9:.0f} GB pinned (budget {budget / 1e9:.0f} GB)")
+
+    def check(s, i, qi):
+        assert i.tolist() == planted[qi], (qi, i.tolist(), planted[qi])
+        want = np.array([orc.maxsim_bf16(qs[qi], ix.read_pages(p, 1)[0]) for p in planted[qi]], np.float32)
+        np.testing.assert_allclose(s, want, rtol=RTOL)
+
+    for coarse_n in (75, 1000):  # 75: the reference's min(10 k, 75), straight to the exact tier; 1000: through the e4m3 pruning stage
+        ix.set_option(_lib.MV_OPT_FDE_COARSE_N, coarse_n)
+        assert ix.rerank_plan(coarse_n, k, qt) == ((128 if coarse_n > 128 else 0), "host")
+        for qi, q in enumerate(qs):
+            s, i, st = ix.query(q, k, mode="fde_then_float", want_stats=True)
+            check(s, i, qi)
+            assert st.rerank_ms > 0
+        for qi, (s, i) in enumerate(ix.query_batch(qs, k, mode="fde_then_float")):
+            check(s, i, qi)
+    for qi, q in enumerate(qs):
+        s, i = ix.query(q, k, mode="fp8_then_float")
+        check(s, i, qi)
+    for qi, (s, i) in enumerate(ix.query_batch(qs, k, mode="fp8_then_float")):
+        check(s, i, qi)
+    ix.close()

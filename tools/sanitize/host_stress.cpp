@@ -1,8 +1,15 @@
 // host_stress.cpp -- concurrency stress of libmvmaxsim's HOST side through its C ABI, built with -fsanitize=thread /
 // address and run against the host-only HIP stub (tools/sanitize/hip_stub.c): reader threads over every query mode and
-// entry point, a writer thread (add / remove / replace / compact / save), and a two-shard communicator under load.
-// Kernel launches are no-ops in the stub, so answers are meaningless; what is checked is that every call succeeds and that
-// the sanitizer sees no data race / lock-order inversion / heap error in the library's own code.
+// entry point, a writer thread (add / remove / replace / compact / save), a two-shard communicator under load, and (round 4)
+// EIGHT shards on eight stub devices behind one communicator in all three transports -- RCCL (tools/sanitize/rccl_stub.c: grouped
+// all-gathers with rank / device / size checks), peer copies, host -- through the single, batched, staged (FDE -> pruning -> exact
+// rerank from the pinned-host tier; e4m3 scan -> exact re-score) pipelines, with a writer feeding one shard.
+// Kernel launches are no-ops in the stub, so answers are meaningless; what is checked is that every call succeeds, that the
+// stub sees every launch / copy / event on the device it belongs to (it aborts otherwise), and that the sanitizer sees no data
+// race / lock-order inversion / heap error in the library's own code.
+//   host_stress <iterations>     the stress;   host_stress violation   a deliberate cross-device memset: the stub must abort
+#include <dlfcn.h>
+
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -35,7 +42,23 @@ static mv_index* make_index(int device, int64_t cap, int64_t id_base, int flags)
   return ix;
 }
 
+extern "C" {  // the HIP stub's own entry points (the stress drives them directly only for the self-test and the counters)
+int hipSetDevice(int);
+int hipMalloc(void**, size_t);
+int hipMemset(void*, int, size_t);
+void hipstub_counters(long* copies, long* launches, long* events);
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && !strcmp(argv[1], "violation")) {  // the affinity checker must catch a cross-device access (run.sh expects the abort)
+    void* p = nullptr;
+    hipSetDevice(2);
+    hipMalloc(&p, 64);
+    hipSetDevice(5);
+    hipMemset(p, 0, 16);
+    printf("NOT CAUGHT: a memset of device 2's memory from device 5 went through\n");
+    return 0;
+  }
   const int iters = argc > 1 ? atoi(argv[1]) : 200;
   const int all = MV_WITH_FLOAT | MV_WITH_BINARY | MV_WITH_FDE | MV_WITH_FP8 | MV_WITH_HOST_EXACT;
   mv_index* ix = make_index(0, 4096, 0, all);
@@ -119,7 +142,73 @@ int main(int argc, char** argv) {
   }
   mv_index_destroy(sh[0]);
   mv_index_destroy(sh[1]);
+
+  // ---- EIGHT shards on eight "devices": the node shape of BASELINE configs[2]-[4], every transport, every staged pipeline
+  std::atomic<long> n_comm8{0};
+  for (int shape = 0; shape < 2; ++shape) {
+    // shape 0: configs[3] / [4] shard shape -- FDE + e4m3 slabs, exact rows in the pinned-host tier (pruning stage: coarse 300 > 64)
+    // shape 1: bf16 + sign-bit + FDE slabs (single-stage float / binary scans, FDE pipeline reranking in "HBM")
+    const int eflags = shape == 0 ? (MV_WITH_FDE | MV_WITH_FP8 | MV_WITH_HOST_EXACT) : (MV_WITH_FLOAT | MV_WITH_BINARY | MV_WITH_FDE);
+    mv_index* s8[8];
+    int32_t devs8[8];
+    for (int r = 0; r < 8; ++r) {
+      devs8[r] = r;
+      s8[r] = make_index(r, 512, (int64_t)r * 512, eflags);
+      CHECK(mv_index_fill_synthetic(s8[r], 1, (uint64_t)r * 512, 128, 32, 4));
+      CHECK(mv_index_set_option(s8[r], MV_OPT_FDE_COARSE_N, 300));
+      CHECK(mv_index_set_option(s8[r], MV_OPT_RERANK_N, 64));
+    }
+    for (int transport : {MV_COMM_RCCL, MV_COMM_P2P, MV_COMM_HOST}) {
+      mv_comm* c = nullptr;
+      CHECK(mv_comm_create(8, devs8, transport, &c));
+      if (mv_comm_transport(c) != transport) { fprintf(stderr, "FAIL transport %d came up as %d: %s\n", transport, mv_comm_transport(c), mv_last_error()); std::abort(); }
+      for (int r = 0; r < 8; ++r) CHECK(mv_comm_attach(c, r, s8[r]));
+      auto cq8 = [&](int tid) {
+        const int modes0[] = {MV_MODE_FDE_THEN_FLOAT, MV_MODE_FP8_THEN_FLOAT, MV_MODE_FLOAT_FP8, MV_MODE_FDE_ONLY};
+        const int modes1[] = {MV_MODE_FLOAT, MV_MODE_BINARY, MV_MODE_FDE_THEN_FLOAT, MV_MODE_FDE_ONLY};
+        const int* modes = shape == 0 ? modes0 : modes1;
+        std::vector<float> q = rows(16, 500 + tid), qb = rows(36 * 16, 600 + tid);
+        std::vector<uint32_t> allow(8, 0xdeadbeefu), per(36 * 8, 0x77777777u);
+        std::vector<float> s(36 * 10);
+        std::vector<int64_t> id(36 * 10);
+        int32_t n = 0, nb[36];
+        mv_query_stats st[8];
+        for (int it = 0; it < iters / 4; ++it) {
+          const int mode = modes[(it + tid) % 4];
+          CHECK(mv_comm_query_topk(c, q.data(), MV_F32, 16, 10, mode, (it & 1) ? allow.data() : nullptr, (it & 1) ? 8 : 0, s.data(), id.data(), &n, (it & 2) ? st : nullptr));
+          if (it % 3 == 0) {  // batches: 5 requests, and 36 (more than one group of 32); shared and per-request filters
+            const int nq = (it % 6 == 0) ? 36 : 5;
+            const int bmode = shape == 0 ? ((it % 2) ? MV_MODE_FP8_THEN_FLOAT : MV_MODE_FDE_THEN_FLOAT) : ((it % 2) ? MV_MODE_FLOAT : MV_MODE_FDE_THEN_FLOAT);
+            CHECK(mv_comm_query_topk_batch(c, qb.data(), MV_F32, nq, 16, 10, bmode, (it % 4 == 0) ? per.data() : nullptr, (it % 4 == 0) ? 8 : 0, (it % 4 == 0) ? 1 : 0,
+                                           s.data(), id.data(), nb, st));
+          }
+          n_comm8.fetch_add(1);
+        }
+      };
+      auto cw8 = [&]() {
+        std::vector<float> emb = rows(4 * 20, 11);
+        int32_t nr[4] = {20, 20, 20, 20}, ords[4] = {70, 70, 71, 71};
+        for (int it = 0; it < iters / 8; ++it) {
+          if (mv_index_size(s8[5]) + 4 <= mv_index_capacity(s8[5])) CHECK(mv_index_add(s8[5], emb.data(), MV_F32, nr, 4, ords, nullptr));
+          if (it % 5 == 3) { int64_t gone = 0; CHECK(mv_index_remove_doc(s8[2], it % 32, &gone)); }
+        }
+      };
+      th.emplace_back(cq8, 0);
+      th.emplace_back(cq8, 1);
+      th.emplace_back(cw8);
+      for (auto& t : th) t.join();
+      th.clear();
+      mv_comm_destroy(c);
+    }
+    for (int r = 0; r < 8; ++r) mv_index_destroy(s8[r]);
+  }
   mv_index_destroy(ix);
-  printf("host_stress ok: %ld queries, %ld write rounds, %d iterations per thread\n", n_queries.load(), n_writes.load(), iters);
+  long copies = 0, launches = 0, events = 0, gathers = -1;
+  hipstub_counters(&copies, &launches, &events);
+  if (void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD))
+    if (auto f = (long (*)())dlsym(h, "rcclstub_gathers")) gathers = f();
+  printf("host_stress ok: %ld queries, %ld write rounds, %ld queries through the 8-shard communicators, %d iterations per thread; "
+         "stub checked %ld copies, %ld kernel launches, %ld event records for device affinity, %ld grouped RCCL all-gathers\n",
+         n_queries.load(), n_writes.load(), n_comm8.load(), iters, copies, launches, events, gathers);
   return 0;
 }
