@@ -457,9 +457,8 @@ def exact_shard(args, device, n, budget, sets, truths, gaps):
     res["container_memory_GB_with_the_tier_resident"] = container_memory_GB()
     t0 = time.time()
     planted_pages = 0
-    for st_ in sets.values():
-        planted_pages += synth.plant_neighbours_any(ix, st_["spec"], synth.SEED_CORPUS, args.patches, 0, n)
-    planted_pages += synth.plant_neighbours_any(ix, sets["_headline_spec"], synth.SEED_CORPUS, args.patches, 0, n) if "_headline_spec" in sets else 0
+    for name, st_ in sets.items():  # "_headline_spec": the headline's own planted pages that fall inside these n pages
+        planted_pages += synth.plant_neighbours_any(ix, st_ if name.startswith("_") else st_["spec"], synth.SEED_CORPUS, args.patches, 0, n)
     res["planted_pages"] = planted_pages
     res["plant_s"] = round(time.time() - t0, 1)
     log(f"[exact shard] {n} pages ({res['pinned_host_exact_tier_GB']} GB pinned in {res['create_and_pin_s']} s) generated in {res['fill_s']} s, "

@@ -180,6 +180,16 @@ MV_API int mv_index_set_option(mv_index* ix, int option, int64_t value);
 MV_API int64_t mv_index_size(const mv_index* ix);     /* pages appended so far (including tombstoned) */
 MV_API int64_t mv_index_capacity(const mv_index* ix);
 
+/* NON-FINITE VALUES.  A NaN / +-Inf embedding has no defined MaxSim (the reference's torch einsum -> max -> topk propagates NaN
+ * and ranks it FIRST), and the scan kernels are compiled without NaN handling.  So they never enter a float-derived slab:
+ *   - mv_index_add / _add_device / _replace_page / _write_rows return MV_ERR_INVALID (nothing is published) when a row holds a NaN,
+ *     an Inf, or an fp32 value that rounds to Inf in bf16 -- one flag set by the ingest pass that touches every row anyway;
+ *   - queries (mv_query_topk*, mv_score_*, mv_two_stage_*, mv_comm_query_*) with such a row return MV_ERR_INVALID;
+ *   - the ONE exception is the sign-bit path, whose quantiser defines every input (bit = v > 0: NaN, +0 and -0 give 0, +Inf 1,
+ *     -Inf 0 -- core/utils/fast_ops.py:191-227, morphik_rust/src/binary_ops.rs:81-136): an index with MV_WITH_BINARY only accepts
+ *     such pages, MV_MODE_BINARY accepts such queries, mv_sign_pack packs them by that rule.
+ * -0.0 is an ordinary value everywhere (it scores like +0.0). */
+
 /* Append pages.  `emb` is a HOST buffer of sum(n_rows) rows x dim, pages back to back (ragged),
  * dtype MV_F32 or MV_BF16.  doc_ordinals[i] >= 0 is the caller's dense document number used by
  * the doc_ids filter.  The call fills every enabled slab (bf16 rows, sign bits, FDE) on the GPU.

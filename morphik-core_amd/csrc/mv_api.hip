@@ -54,6 +54,25 @@ float host_bf16_to_f32(uint16_t h) {
   return f;
 }
 
+bool host_rows_finite(const void* x, int dtype, size_t n_elems) {
+  if (dtype == MV_BF16) {
+    const uint16_t* h = (const uint16_t*)x;
+    for (size_t i = 0; i < n_elems; ++i)
+      if ((h[i] & 0x7f80u) == 0x7f80u) return false;
+    return true;
+  }
+  const float* f = (const float*)x;
+  for (size_t i = 0; i < n_elems; ++i)
+    if ((host_f32_to_bf16(f[i]) & 0x7f80u) == 0x7f80u) return false;  // NaN, +-Inf, or beyond the bf16 range (an Inf once rounded)
+  return true;
+}
+
+int check_query_finite(const void* q, int q_dtype, size_t n_elems, int mode) {
+  if (mode == MV_MODE_BINARY || host_rows_finite(q, q_dtype, n_elems)) return MV_OK;
+  set_error("the query holds a NaN / Inf value: MaxSim is undefined for it (only MV_MODE_BINARY defines non-finite inputs: bit = v > 0)");
+  return MV_ERR_INVALID;
+}
+
 __global__ void add_scores_kernel(float* dst, const float* src, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] += src[i];
@@ -382,6 +401,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
              int64_t want_coarse, ScanResult* out, mv_query_stats* st, bool want_compact = false, int32_t k_final = 0) {
   if (!q || n_q <= 0) { set_error("query must have at least one row"); return MV_ERR_INVALID; }
   if (q_dtype != MV_F32 && q_dtype != MV_BF16) { set_error("bad query dtype %d", q_dtype); return MV_ERR_INVALID; }
+  if (int frc = check_query_finite(q, q_dtype, (size_t)n_q * kDim, mode)) return frc;
   const bool want_fde = mode == MV_MODE_FDE_THEN_FLOAT || mode == MV_MODE_FDE_ONLY;
   const bool want_bin = mode == MV_MODE_BINARY;
   const bool two_tier = mode == MV_MODE_FP8_THEN_FLOAT;
@@ -650,7 +670,11 @@ int add_pages_common(mv_index* ix, const void* d_src, int dtype, const int32_t* 
     if (rc) return rc;
     slab_dst = (uint16_t*)ix->w_tmp;
   }
-  rc = launch_scatter_rows(d_src, dtype, d_off, n_pages, stride, slab_dst, ws);
+  // NaN / Inf rows: an index with any float-derived slab refuses them (their MaxSim is undefined: torch's einsum -> max -> topk
+  // would rank a NaN page first); a sign-bit-only index takes them -- its quantiser defines every input (binary_ops.rs:81-136)
+  const bool check_finite = (ix->cfg.flags & ~MV_WITH_BINARY) != 0;
+  if (check_finite) MV_HIP(hipMemsetAsync(ix->d_w_flag, 0, 4, ws));
+  rc = launch_scatter_rows(d_src, dtype, d_off, n_pages, stride, slab_dst, ws, check_finite ? ix->d_w_flag : nullptr);
   if (!rc && ix->h_exact) {  // exact tier in pinned host memory: the fixed-stride bf16 image, slot for slot
     hipError_t he = hipMemcpyAsync(ix->h_exact + (size_t)first * stride * kDim, slab_dst, (size_t)n_pages * stride * kRowBytes, hipMemcpyDeviceToHost, ws);
     if (he != hipSuccess) rc = hip_fail(he, "D2H of the exact tier", __FILE__, __LINE__);
@@ -693,6 +717,14 @@ int add_pages_common(mv_index* ix, const void* d_src, int dtype, const int32_t* 
   hipError_t e = hipStreamSynchronize(ws);  // the staging buffers are reused by the next chunk; the caller publishes after this
   if (rc) return rc;
   if (e != hipSuccess) return hip_fail(e, "ingest", __FILE__, __LINE__);
+  if (check_finite) {
+    int32_t bad = 0;
+    MV_HIP(hipMemcpy(&bad, ix->d_w_flag, 4, hipMemcpyDeviceToHost));
+    if (bad) {  // nothing was published: the slots stay invisible and are overwritten by the next add
+      set_error("mv_index_add: an embedding row holds a NaN / Inf (or an fp32 value beyond the bf16 range): MaxSim is undefined for it; nothing was added");
+      return MV_ERR_INVALID;
+    }
+  }
   return MV_OK;
 }
 
@@ -831,7 +863,7 @@ void mv_index_destroy(mv_index* ix) {
   DeviceGuard g(ix->cfg.device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
   if (ix->w_stream) (void)hipStreamSynchronize(ix->w_stream);
-  void* ptrs[] = {ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
+  void* ptrs[] = {ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
                   ix->d_topk_ws, ix->d_q, ix->d_qf32, ix->d_qbits, ix->d_qpop, ix->d_qfde, ix->d_qoff, ix->d_allow, ix->d_out_s,
                   ix->d_out_id, ix->d_cand, ix->d_cand_scores, ix->d_bqf32, ix->d_bqfde, ix->d_bqimage, ix->d_btopk_ws, ix->d_bsel_s,
                   ix->d_bsel_id, ix->d_bcand, ix->d_bcand_pads, ix->d_bcand_scores, ix->d_bout_s, ix->d_bout_id, ix->d_bq8hi, ix->d_bq8lo, ix->d_bq8fac};
@@ -930,6 +962,7 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   alloc((void**)&ix->d_recs, (size_t)kTopkMaxDeviceK * sizeof(mv_cand_rec), "coarse candidate records");
   alloc((void**)&ix->d_sel_pos, (size_t)kTopkMaxDeviceK * 8, "coarse selection");
   alloc((void**)&ix->d_qoff, 16, "query offsets");
+  alloc((void**)&ix->d_w_flag, 4, "ingest flag");
   if (!rc) {
     ix->h_n_rows.assign((size_t)cap, 0);
     ix->h_doc_ord.assign((size_t)cap, -1);
@@ -1113,6 +1146,7 @@ int mv_index_read_pages(mv_index* ix, int64_t page0, int64_t n_pages, void* out_
 int mv_index_write_rows(mv_index* ix, int64_t page, int32_t row0, int32_t n, const void* bf16_rows) {
   if (!ix || !bf16_rows || page < 0 || page >= ix->size.load() || row0 < 0 || n < 0 || row0 + n > ix->cfg.stride_rows) { set_error("write_rows: range"); return MV_ERR_INVALID; }
   if (!(ix->cfg.flags & (MV_WITH_FLOAT | MV_WITH_HOST_EXACT))) { set_error("index has no float slab"); return MV_ERR_STATE; }
+  if (!host_rows_finite(bf16_rows, MV_BF16, (size_t)n * kDim)) { set_error("write_rows: a row holds a NaN / Inf"); return MV_ERR_INVALID; }
   ExclusiveLock lk(ix);
   DeviceGuard g(ix->cfg.device);
   if (ix->h_exact) memcpy((char*)ix->h_exact + ((size_t)page * ix->cfg.stride_rows + row0) * kRowBytes, bf16_rows, (size_t)n * kRowBytes);
@@ -1195,6 +1229,7 @@ int mv_index_fill_synthetic(mv_index* ix, uint64_t seed, uint64_t first_unit, in
 // combination of slabs; also the update path of a re-embedded page).
 int mv_index_replace_page(mv_index* ix, int64_t page, const void* bf16_rows, int32_t n_rows) {
   if (!ix || !bf16_rows || page < 0 || page >= ix->size.load() || n_rows < 0 || n_rows > ix->cfg.stride_rows) { set_error("replace_page: bad argument"); return MV_ERR_INVALID; }
+  if ((ix->cfg.flags & ~MV_WITH_BINARY) && !host_rows_finite(bf16_rows, MV_BF16, (size_t)n_rows * kDim)) { set_error("replace_page: a row holds a NaN / Inf"); return MV_ERR_INVALID; }
   ExclusiveLock lk(ix);
   DeviceGuard g(ix->cfg.device);
   const int32_t stride = ix->cfg.stride_rows;
@@ -1826,6 +1861,7 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
                         int64_t* out_ids, int32_t* out_n, mv_query_stats* stats) {
   if (!ix || !q || n_queries < 1 || n_q_rows < 1 || k < 0 || !out_n || (k > 0 && (!out_scores || !out_ids))) { set_error("mv_query_topk_batch: bad argument"); return MV_ERR_INVALID; }
   if (q_dtype != MV_F32 && q_dtype != MV_BF16) { set_error("bad query dtype %d", q_dtype); return MV_ERR_INVALID; }
+  if (int frc = check_query_finite(q, q_dtype, (size_t)n_queries * n_q_rows * kDim, mode)) return frc;
   const size_t esz = q_dtype == MV_F32 ? 4 : 2;
   const int rpq = ((n_q_rows + 15) / 16) * 16;
   mv_query_stats total{};
@@ -1957,6 +1993,8 @@ int mv_score_all(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int
 static int score_candidates_common(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const int32_t* cand, int32_t n_cand,
                                    int32_t pad_to, const int32_t* pads, float* out_scores, mv_query_stats* stats) {
   if (!ix || !q || !cand || !out_scores || n_cand < 0 || n_cand > kMaxCand || n_q_rows < 1 || pad_to < -1) { set_error("score_candidates: bad argument"); return MV_ERR_INVALID; }
+  if (q_dtype != MV_F32 && q_dtype != MV_BF16) { set_error("bad query dtype %d", q_dtype); return MV_ERR_INVALID; }
+  if (int frc = check_query_finite(q, q_dtype, (size_t)n_q_rows * kDim, MV_MODE_FLOAT)) return frc;
   std::lock_guard<std::mutex> lk(ix->q_mu);
   // the named pages are scored on the exact tier (bf16 slab, else the pinned-host tier), else on the e4m3 slab
   const RerankPlan plan = rerank_plan(ix, MV_MODE_FLOAT, n_cand, 0, ((n_q_rows + 15) / 16) * 16, false);

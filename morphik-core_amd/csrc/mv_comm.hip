@@ -215,6 +215,7 @@ int mv_two_stage_coarse_device(mv_index* ix, const void* q, int q_dtype, int32_t
   if (!ix || !q || !d_out_recs || n_q_rows < 1 || n_coarse < 1 || n_coarse > kTopkMaxDeviceK) { set_error("two_stage_coarse: bad argument"); return MV_ERR_INVALID; }
   if (q_dtype != MV_F32 && q_dtype != MV_BF16) { set_error("bad query dtype %d", q_dtype); return MV_ERR_INVALID; }
   if (!two_stage_mode_ok(mode)) { set_error("two_stage_coarse: mode %d is not a two-stage mode (MV_MODE_FDE_THEN_FLOAT / MV_MODE_FP8_THEN_FLOAT)", mode); return MV_ERR_INVALID; }
+  if (int frc = check_query_finite(q, q_dtype, (size_t)n_q_rows * kDim, mode)) return frc;
   const bool fde = mode == MV_MODE_FDE_THEN_FLOAT;
   if (fde && !(ix->cfg.flags & MV_WITH_FDE)) { set_error("index has no FDE slab (MV_WITH_FDE)"); return MV_ERR_STATE; }
   if (!fde && !(ix->cfg.flags & MV_WITH_FP8)) { set_error("index has no fp8 slab (MV_WITH_FP8)"); return MV_ERR_STATE; }
@@ -784,6 +785,8 @@ int mv_comm_query_topk(mv_comm* c, const void* q, int q_dtype, int32_t n_q_rows,
                        int64_t n_allow_words, float* out_scores, int64_t* out_ids, int32_t* out_n, mv_query_stats* stats) {
   if (!c || !q || !out_n || k < 0 || (k > 0 && (!out_scores || !out_ids))) { set_error("mv_comm_query_topk: bad argument"); return MV_ERR_INVALID; }
   if (k > kK) { set_error("mv_comm_query_topk supports k <= %d", kK); return MV_ERR_INVALID; }
+  if (q_dtype != MV_F32 && q_dtype != MV_BF16) { set_error("bad query dtype %d", q_dtype); return MV_ERR_INVALID; }
+  if (int frc = check_query_finite(q, q_dtype, (size_t)n_q_rows * kDim, mode)) return frc;
   std::lock_guard<std::mutex> lk(c->mu);
   *out_n = 0;
   const int R = c->n;
@@ -915,6 +918,7 @@ int mv_comm_query_topk_batch(mv_comm* c, const void* q, int q_dtype, int32_t n_q
   if (!c || !q || !out_n || n_queries < 1 || n_q_rows < 1 || k < 0 || (k > 0 && (!out_scores || !out_ids))) { set_error("mv_comm_query_topk_batch: bad argument"); return MV_ERR_INVALID; }
   if (q_dtype != MV_F32 && q_dtype != MV_BF16) { set_error("bad query dtype %d", q_dtype); return MV_ERR_INVALID; }
   if (k > kK) { set_error("mv_comm_query_topk_batch supports k <= %d", kK); return MV_ERR_INVALID; }
+  if (int frc = check_query_finite(q, q_dtype, (size_t)n_queries * n_q_rows * kDim, mode)) return frc;
   const size_t esz = q_dtype == MV_F32 ? 4 : 2;
   const int rpq = ((n_q_rows + 15) / 16) * 16;
   const int R = c->n;

@@ -286,8 +286,9 @@ int launch_f32_to_bf16(const float* d_in, uint16_t* d_out, int64_t n, hipStream_
 int launch_read_bw(const void* d_buf, int64_t bytes, float* d_sink, hipStream_t s);
 int launch_read_bw_nt(const void* d_buf, int64_t bytes, float* d_sink, hipStream_t s);  // contiguous 16 KiB pieces, nt loads
 int launch_mfma_peak(int blocks, int iters, int shape, float* d_sink, hipStream_t s);   // per iteration per wave: shape 0 = 8 x 16x16x32, 1 = 4 x 32x32x16 bf16 MFMA
-// scatter ragged bf16/f32 rows into the fixed-stride slab (zero-filling the tail of each page slot)
+// scatter ragged bf16/f32 rows into the fixed-stride slab (zero-filling the tail of each page slot);
+// d_nonfinite (nullable): set to 1 when a row holds a NaN / Inf (in its bf16 image)
 int launch_scatter_rows(const void* d_src, int dtype, const int64_t* d_row_offsets, int64_t n_pages, int32_t stride,
-                        uint16_t* d_slab_pages, hipStream_t s);
+                        uint16_t* d_slab_pages, hipStream_t s, int32_t* d_nonfinite = nullptr);
 
 }  // namespace mv

@@ -166,6 +166,11 @@ int mv_enc_rmsnorm_bf16(int device, const void* d_x, const void* d_weight, int w
     set_error("mv_enc_rmsnorm_bf16: bad argument (dim must be a positive multiple of 8)");
     return MV_ERR_INVALID;
   }
+  // the row kernels move 16-byte vectors (x, out: 8 bf16; weight: 4 fp32 / 8 bf16): a misaligned pointer is a memory fault on the device, not an error
+  if ((reinterpret_cast<uintptr_t>(d_x) & 15) || (reinterpret_cast<uintptr_t>(d_out) & 15) || (reinterpret_cast<uintptr_t>(d_weight) & 15)) {
+    set_error("mv_enc_rmsnorm_bf16: x, weight and out must be 16-byte aligned");
+    return MV_ERR_INVALID;
+  }
   if (rows == 0) return MV_OK;
   DeviceGuard g(device);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -111,6 +111,7 @@ struct mv_index {
   size_t w_aux_bytes = 0;
   void* w_tmp = nullptr;       // fixed-stride bf16 image of the batch when the index keeps no float slab
   size_t w_tmp_bytes = 0;
+  int32_t* d_w_flag = nullptr; // set by the ingest's scatter pass when a row holds a NaN / Inf
   // options
   int maxsim_variant = -1;
   int binary_variant = -1;
@@ -191,6 +192,11 @@ int finish_stats(mv_index* ix, mv_query_stats* st, bool had_topk);
 namespace mv {
 uint16_t host_f32_to_bf16(float f);
 float host_bf16_to_f32(uint16_t h);
+// every element finite (no NaN / Inf; for fp32 input also: inside the bf16 range, i.e. finite once rounded to bf16)
+bool host_rows_finite(const void* x, int dtype, size_t n_elems);
+// a query with a NaN / Inf row has no defined MaxSim (torch's einsum -> max -> topk would rank NaN first): refused, except in
+// MV_MODE_BINARY, whose quantiser defines every input (bit = v > 0: NaN and +-0 give 0, binary_ops.rs:81-136)
+int check_query_finite(const void* q, int q_dtype, size_t n_elems, int mode);
 }
 // Batch workspace and stages of mv_api.hip shared with the batched two-stage communicator (mv_comm.hip).  Callers hold q_mu.
 extern "C" int mv_internal_ensure_batch_select_ws(mv_index* ix);

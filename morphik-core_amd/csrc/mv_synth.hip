@@ -89,7 +89,7 @@ __global__ void f32_to_bf16_kernel(const float* in, uint16_t* out, int64_t n) {
 
 // One block per page: copy/convert rows [off[p], off[p+1]) into slab page p, zero the tail.
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const void* src, int dtype, const int64_t* off, int32_t stride,
-                                                           uint16_t* slab) {
+                                                           uint16_t* slab, int32_t* nonfinite) {
   const int64_t p = blockIdx.x;
   const int64_t r0 = off[p];
   const int32_t nr = (int32_t)(off[p + 1] - r0);
@@ -109,6 +109,12 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const void* src, int 
       }
     }
     *reinterpret_cast<uint2*>(dst + (int64_t)row * kDim + c4 * 4) = v;
+    // NaN / +-Inf (exponent all ones) in the bf16 image the slabs are derived from -- an fp32 value beyond the bf16 range counts:
+    // it IS an Inf in the slab.  The ingest reports it (mv_index_add*: MV_ERR_INVALID, nothing published).
+    if (nonfinite) {
+      const uint32_t a = v.x & 0x7f807f80u, b = v.y & 0x7f807f80u;
+      if ((a & 0xffffu) == 0x7f80u || (a >> 16) == 0x7f80u || (b & 0xffffu) == 0x7f80u || (b >> 16) == 0x7f80u) atomicOr(nonfinite, 1);
+    }
   }
 }
 
@@ -259,10 +265,10 @@ int launch_f32_to_bf16(const float* d_in, uint16_t* d_out, int64_t n, hipStream_
 }
 
 int launch_scatter_rows(const void* d_src, int dtype, const int64_t* d_row_offsets, int64_t n_pages, int32_t stride,
-                        uint16_t* d_slab_pages, hipStream_t s) {
+                        uint16_t* d_slab_pages, hipStream_t s, int32_t* d_nonfinite) {
   if (n_pages <= 0) return MV_OK;
   hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)n_pages), dim3(256), 0, s, d_src, dtype, d_row_offsets, stride,
-                     d_slab_pages);
+                     d_slab_pages, d_nonfinite);
   MV_HIP(hipGetLastError());
   return MV_OK;
 }

@@ -65,9 +65,12 @@ def patch_encoder(model: Any) -> Dict[str, int]:
 
             def norm_forward(self, x, _eps=eps, _gemma=gemma, _dim=dim):
                 w = self.weight
-                if not (_usable(torch, x) and x.shape[-1] == _dim and w.is_cuda and w.is_contiguous() and w.dtype in (torch.float32, torch.bfloat16)):
+                if not (_usable(torch, x) and x.shape[-1] == _dim and w.is_cuda and w.is_contiguous() and w.dtype in (torch.float32, torch.bfloat16)
+                        and w.data_ptr() % 16 == 0 and w.device == x.device):
                     return self._mv_orig_forward(x)
                 out = torch.empty_like(x)
+                if out.data_ptr() % 16:
+                    return self._mv_orig_forward(x)
                 _lib.check(lib.mv_enc_rmsnorm_bf16(x.device.index or 0, C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()),
                                                    0 if w.dtype == torch.float32 else 1, C.c_void_p(out.data_ptr()), x.numel() // _dim, _dim,
                                                    _eps, 1.0 if _gemma else 0.0, 0 if _gemma else 1, C.c_void_p(_stream(torch, x))))
@@ -165,19 +168,26 @@ def load_tuned_gemms(name: str = "tunableop_colpali_v1_2_gfx950.csv") -> bool:
     try:
         import torch.cuda.tunable as tun
 
-        if tun.is_enabled() and tun.tuning_is_enabled():  # somebody is tuning in this process (tuning is on by default once TunableOp is): leave it
+        if tun.is_enabled():
+            # the HOST application runs TunableOp itself (its own results file, tuning on or off): its table is not ours to merge entries
+            # into, and its switch is not ours to flip -- the encoder takes whatever selections that setup gives it
             return False
+        tuning_was = tun.tuning_is_enabled()
         tun.enable(True)
         tun.tuning_enable(False)
-        ok = bool(tun.read_file(path))
-        tun.enable(False)  # switched on only around the page forwards (tuned_gemms() below): with TunableOp on, shapes that are NOT in
-        return ok          # the file -- every query length -- take a slower default path (query embedding 15 -> 27 ms, measured)
+        try:
+            ok = bool(tun.read_file(path))
+        finally:
+            tun.enable(False)  # back to the state found (off): switched on only around the page forwards (tuned_gemms() below) -- with TunableOp
+            tun.tuning_enable(tuning_was)  # on, shapes that are NOT in the file (every query length) take a slower default path (15 -> 27 ms, measured)
+        return ok
     except Exception:  # noqa: BLE001 -- an optimisation only: the library defaults are always correct
         return False
 
 
 _tuned_lock = __import__("threading").Lock()
 _tuned_users = 0
+_tuned_prev = (False, True)
 
 
 class tuned_gemms:
@@ -195,7 +205,10 @@ class tuned_gemms:
             with _tuned_lock:
                 _tuned_users += 1
                 if _tuned_users == 1:
+                    global _tuned_prev
+                    _tuned_prev = (bool(tun.is_enabled()), bool(tun.tuning_is_enabled()))  # restored when the last forward leaves
                     tun.enable(True)
+                    tun.tuning_enable(False)
         return self
 
     def __exit__(self, *exc):
@@ -206,5 +219,6 @@ class tuned_gemms:
             with _tuned_lock:
                 _tuned_users -= 1
                 if _tuned_users == 0:
-                    tun.enable(False)
+                    tun.enable(_tuned_prev[0])
+                    tun.tuning_enable(_tuned_prev[1])
         return False

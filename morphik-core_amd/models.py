@@ -83,7 +83,7 @@ def hit_chunk_builder():
 
 
 try:
-    from core.vector_store.base_vector_store import BaseVectorStore  # type: ignore  # noqa: F401"""
+    from core.vector_store.base_vector_store import BaseVectorStore  # type: ignore  # noqa: F401
 except Exception:  # noqa: BLE001
     from abc import ABC
 

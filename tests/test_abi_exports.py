@@ -53,3 +53,48 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert "libmvoracle" not in src and "mv_oracle.c\"" not in src, f
+
+
+def _integration_md_binding():
+    """The ctypes stub INTEGRATION.md section 2 tells a morphik-core maintainer to add, extracted from the document and executed
+    as it stands (only the library NAME is replaced by the built file's path).  -> its namespace."""
+    import os
+    import re
+
+    import morphik_core_amd as m
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = [b for b in re.findall(r"```python\n(.*?)```", text, re.S) if "mv_abi_version" in b]
+    assert len(blocks) == 1, "INTEGRATION.md must hold exactly one binding stub"
+    code = blocks[0]
+    assert 'C.CDLL("libmvmaxsim.so")' in code
+    ns = {}
+    exec(compile(code.replace('"libmvmaxsim.so"', repr(m.library_path())), "INTEGRATION.md#binding", "exec"), ns)
+    return ns, code
+
+
+def test_integration_md_binding_loads_and_fails_loudly_without_a_gpu():
+    """the documented binding asserted ABI 3 against a header at 4 -- nothing executed the document.  Now the
+    stub is run: it must load the built library, pass ITS OWN abi assertion against the shipped header, and (on a box without a
+    GPU) `create` must raise instead of falling back to anything."""
+    import re
+
+    import pytest
+    import torch
+
+    from morphik_core_amd import _lib
+
+    ns, code = _integration_md_binding()  # the import itself runs `assert L.mv_abi_version() == N`
+    lit = [int(x) for x in re.findall(r"mv_abi_version\(\) == (\d+)", code)]
+    assert lit == [_lib.MV_ABI_VERSION], f"INTEGRATION.md asserts ABI {lit}, the header / binding are at {_lib.MV_ABI_VERSION}"
+    # no other stale literal anywhere in the documents
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for doc in ("INTEGRATION.md", "DESIGN.md", "README.md"):
+        for x in re.findall(r"abi_version\(\) == (\d+)", open(os.path.join(root, doc)).read()):
+            assert int(x) == _lib.MV_ABI_VERSION, (doc, x)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no HIP device|MI355X"):
+            ns["create"](16)

@@ -6,7 +6,7 @@ echo skip-tests
 
 ( while true; do cat /sys/fs/cgroup/memory.current 2>/dev/null; sleep 2; done ) > gpurun_out/r4_memcurrent.log 2>&1 &
 MON=$!
-timeout 1200 python bench.py --steps 20 --warmup 5 --exact-shard-pin-frac ${PIN_FRAC:-0.5} > gpurun_out/r4_bench_a.json 2> gpurun_out/r4_bench_a.err
+timeout 1200 python bench.py --steps 20 --warmup 5 --exact-shard-pin-frac ${PIN_FRAC:-0.7} > gpurun_out/r4_bench_a.json 2> gpurun_out/r4_bench_a.err
 kill $MON
 tail -c 600 gpurun_out/r4_bench_a.err
 sort -n gpurun_out/r4_memcurrent.log | tail -1
