@@ -341,8 +341,11 @@ class MI355XMultiVectorStore(BaseVectorStore):
         payload_s, payload_objects, payload_bytes = 0.0, 0, 0
         if self._use_external():
             t0 = time.perf_counter()
-            res = await asyncio.gather(*[self._payloads.put(c.content, c.document_id, int(c.chunk_number), c.metadata or {}, resolved_app)
-                                         for c in valid])
+            async def keep(c):  # content that already IS a storage key (a remote client uploaded the payload to ITS storage) stays a key
+                return c.content, 0
+
+            res = await asyncio.gather(*[keep(c) if is_storage_key(c.content) else
+                                         self._payloads.put(c.content, c.document_id, int(c.chunk_number), c.metadata or {}, resolved_app) for c in valid])
             payload_s = time.perf_counter() - t0
             for i, (key, nbytes) in enumerate(res):
                 if key:
@@ -581,9 +584,10 @@ class MI355XMultiVectorStore(BaseVectorStore):
         return [DocumentChunk(document_id=r[0], chunk_number=r[1], content=c, embedding=[], metadata=m, score=0.0)
                 for r, c, m in zip(rows, contents, metas)]
 
-    def _delete_sync(self, document_id: str, app_id: Optional[str]) -> List[str]:
-        """Tombstone one app's copy of a document -> the storage keys of its payloads.  Runs in a worker thread: it waits behind
-        a checkpoint in progress (_write_gate) without holding up the event loop."""
+    def _delete_sync(self, document_id: str, app_id: Optional[str], all_keys: Optional[List[str]] = None) -> List[str]:
+        """Tombstone one app's copy of a document -> the storage keys of its payloads THIS store uploaded (all_keys, when given,
+        collects every storage key among the deleted rows, whoever uploaded it).  Runs in a worker thread: it waits behind a
+        checkpoint in progress (_write_gate) without holding up the event loop."""
         keys: List[str] = []
         with self._write_gate, self._lock:
             # per-app namespaces: only THIS app's copy of the document (fast_multivector_store.py:643 deletes from self.ns(app_id))
@@ -597,10 +601,27 @@ class MI355XMultiVectorStore(BaseVectorStore):
                 row = self._rows.pop(page, None)
                 if row is not None:
                     self._page_of.pop((key, row[1]), None)
-                    if self._use_external() and is_storage_key(row[2]):
-                        keys.append(row[2])
+                    if is_storage_key(row[2]):
+                        if all_keys is not None:
+                            all_keys.append(row[2])
+                        if self._use_external():
+                            keys.append(row[2])
             # the ordinal stays reserved until compact() (its pages are tombstoned in the slab under that ordinal)
         return keys
+
+    async def delete_chunks_returning_keys(self, document_id: str, app_id: Optional[str] = None) -> Tuple[bool, List[str]]:
+        """delete_chunks_by_document_id that also reports the storage keys of the deleted chunks' payloads which this store could
+        NOT delete itself (it has no storage object: a remote client uploaded them to its own) -- the owner server hands them back
+        to that client, which removes the objects as the reference does on delete (multi_vector_store.py:921-951)."""
+        all_keys: List[str] = []
+        try:
+            keys = await asyncio.to_thread(self._delete_sync, document_id, app_id, all_keys)
+            if keys:
+                await self._payloads.delete(keys, document_id)
+            return True, [k_ for k_ in all_keys if k_ not in set(keys)]
+        except Exception as e:  # noqa: BLE001
+            logger.error(f"Error deleting chunks for document {document_id}: {e}")
+            return False, []
 
     async def delete_chunks_by_document_id(self, document_id: str, app_id: Optional[str] = None) -> bool:
         try:

@@ -171,9 +171,12 @@ def create_app(store: Any, api_key: Optional[str] = None, save_dir: Optional[str
     @app.post("/delete_chunks_by_document_id")
     async def delete_chunks(req: Dict[str, Any], authorization: Optional[str] = Header(default=None)):  # noqa: B008
         auth(authorization)
-        ok = bool(await store.delete_chunks_by_document_id(req["document_id"], app_id=req.get("app_id")))
+        if hasattr(store, "delete_chunks_returning_keys"):  # keys of payloads a client uploaded to ITS storage go back to it
+            ok, left = await store.delete_chunks_returning_keys(req["document_id"], app_id=req.get("app_id"))
+        else:
+            ok, left = bool(await store.delete_chunks_by_document_id(req["document_id"], app_id=req.get("app_id"))), []
         ckpt.dirty = ckpt.dirty or ok
-        return {"ok": ok}
+        return {"ok": bool(ok), "content_keys": left}
 
     return app
 
@@ -256,7 +259,17 @@ class MI355XRemoteMultiVectorStore(BaseVectorStore):
             meta["chunks"].append({"document_id": c.document_id, "chunk_number": int(c.chunk_number), "content": contents[i], "metadata": c.metadata or {}})
             if getattr(c, "embedding", None) is not None:
                 arrays[f"emb_{i}"] = self._rows(c.embedding)
-        out = await self._post("/store_embeddings", content=_pack(meta, arrays))
+        try:
+            out = await self._post("/store_embeddings", content=_pack(meta, arrays))
+        except Exception:
+            if self._payloads is not None:  # the owner refused the chunks: the payloads uploaded for them must not stay behind
+                orphans = [k for k, c in zip(contents, chunks) if k is not c.content]
+                if orphans:
+                    try:
+                        await self._payloads.delete(orphans, chunks[0].document_id if chunks else "")
+                    except Exception as e:  # noqa: BLE001
+                        logger.error(f"could not remove {len(orphans)} payloads uploaded for a failed store_embeddings: {e}")
+            raise
         self._last_store_metrics = out.get("metrics", {})
         return bool(out["ok"]), list(out["ids"]), self._last_store_metrics
 
@@ -288,7 +301,11 @@ class MI355XRemoteMultiVectorStore(BaseVectorStore):
 
     async def delete_chunks_by_document_id(self, document_id: str, app_id: Optional[str] = None) -> bool:
         try:
-            return bool((await self._post("/delete_chunks_by_document_id", json_body={"document_id": document_id, "app_id": app_id}))["ok"])
+            out = await self._post("/delete_chunks_by_document_id", json_body={"document_id": document_id, "app_id": app_id})
+            keys = list(out.get("content_keys") or [])
+            if keys and self._payloads is not None:  # the payloads THIS side uploaded: the reference deletes storage objects on delete
+                await self._payloads.delete(keys, document_id)
+            return bool(out["ok"])
         except Exception as e:  # noqa: BLE001 -- delete returns False on error (multi_vector_store.py:944-946)
             logger.error(f"Error deleting chunks for document {document_id}: {e}")
             return False

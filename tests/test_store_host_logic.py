@@ -673,5 +673,31 @@ def test_remote_client_with_its_own_storage_keeps_payloads_off_the_wire():
         assert hit[0].content.endswith(".png") and "/" in hit[0].content  # the key itself
         got = sc.run(remote.get_chunks_by_id([(chunks[2].document_id, chunks[2].chunk_number)], app_id="t"))
         assert got[0].content == chunks[2].content
+        # deleting a document removes ITS payload objects from the client's storage too (the owner has no storage
+        # object and hands the keys back: multi_vector_store.py:921-951 deletes storage objects on delete) ...
+        assert len(st.objects) == 4
+        assert sc.run(remote.delete_chunks_by_document_id(chunks[0].document_id, app_id="t")) is True
+        assert len(st.objects) == 2 and sc.run(remote.query_similar(chunks[0].embedding, k=4, app_id="t"))[0].document_id == chunks[2].document_id
+        # ... a store_embeddings the owner refuses leaves no orphaned uploads behind ...
+        too_long = sc.make_chunks(rng, n_docs=1, chunks_per_doc=1)
+        too_long[0].embedding = np.ones((40, 128), np.float32)  # stride_rows is 32
+        with pytest.raises(RuntimeError):
+            sc.run(remote.store_embeddings(too_long, app_id="t"))
+        assert len(st.objects) == 2
     finally:
         stop()
+    # ... and an owner that HAS a payload store keeps a client's key as the key (no second upload of the key string as "content")
+    owner2 = MI355XFastMultiVectorStore(capacity_pages=16, stride_rows=32, mode="float", index_factory=OracleIndex, storage=MemStorage())
+    assert owner2.initialize()
+    url2, stop2 = _serve(create_app(owner2))
+    try:
+        st2 = MemStorage()
+        remote2 = MI355XRemoteMultiVectorStore(url2, storage=st2)
+        ch = sc.make_chunks(np.random.default_rng(13), n_docs=1, chunks_per_doc=2)
+        ch[0].content, ch[0].metadata = _png_data_uri(), {"is_image": True}
+        sc.run(remote2.store_embeddings(ch, app_id="t"))
+        assert owner2.storage.uploads == 0 and st2.uploads == 2
+        hit = sc.run(remote2.query_similar(ch[0].embedding, k=1, app_id="t"))
+        assert hit[0].content == ch[0].content
+    finally:
+        stop2()
