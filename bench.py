@@ -601,18 +601,21 @@ def two_tier(args, device):
 
 def fde_encode_block(args, device):
     """Roofline entry of the FDE DOCUMENT encode (fde.generate_document_encoding, fast_multivector_store.py:447-449): corpus build of
-    the same pages with and without the FDE slab; the difference is the encode, which reads every page's bf16 rows once (262 144 B)
-    and writes 20 480 B.  Default kernel (fde_encode_doc_kernel): the SimHash sketches are k-ordered fp32 fmaf chains on the f32 matrix
-    path (v_mfma_f32_16x16x4_f32: 128 x 112 MACs per row as issued, 7 column tiles), the AMS projection -- a {0, +1, -1} matrix against
-    rows that are already bf16: exact products -- rides the bf16 matrix path (v_mfma_f32_16x16x32_bf16: 128 x 20 x 16 MACs per row as
-    issued).  The round-2 kernel (MV_OPT_FDE_ENCODE_VARIANT 1: both parts on the f32 path, operands from LDS) is timed beside it."""
+    the same pages with and without the FDE slab; the difference is the encode, which reads every page's bf16 rows (262 144 B; twice in
+    the two-pass form) and writes 20 480 B.  Default since round 4 (MV_OPT_FDE_ENCODE_VARIANT 4): pass 1 fde_hash_kernel -- the SimHash
+    sketches as k-ordered fp32 fmaf chains on the f32 matrix path (v_mfma_f32_16x16x4_f32: 128 x 112 MACs per row as issued, 7 column
+    tiles) -> one partition byte per (row, repetition); pass 2 fde_project_kernel -- the AMS projection ({0, +1, -1} matrix against rows
+    that are already bf16: exact products) on the bf16 matrix path (v_mfma_f32_16x16x32_bf16) and the bucket sums as a ONE-HOT matrix
+    product on the f32 path (16 rows x 32 partitions x 16 columns per repetition and tile).  The round-3 one-pass kernel (variant 3:
+    bucket sums through LDS float atomics) and the round-2 kernel (variant 1: everything on the f32 path, operands from LDS) are timed
+    beside it."""
     from morphik_core_amd import _lib, synth
     from morphik_core_amd.index import MvIndex
 
     n = min(args.aux_pages, 100_000)
     stride = ((args.patches + 15) // 16) * 16
     t = {}
-    for key, fde, variant in (("gen", False, None), ("bf16_pipe", True, 3), ("f32_pipe", True, 1)):
+    for key, fde, variant in (("gen", False, None), ("two_pass", True, 4), ("one_pass_r3", True, 3), ("f32_pipe", True, 1)):
         for warm in (True, False):
             ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=True, with_fde=fde)
             if variant is not None:
@@ -622,19 +625,25 @@ def fde_encode_block(args, device):
             if not warm:
                 t[key] = time.perf_counter() - t0
             ix.close()
-    enc = max(t["bf16_pipe"] - t["gen"], 1e-9)
+    enc = max(t["two_pass"] - t["gen"], 1e-9)
+    enc_r3 = max(t["one_pass_r3"] - t["gen"], 1e-9)
     enc_f32 = max(t["f32_pipe"] - t["gen"], 1e-9)
-    us, us_f32 = enc / n * 1e6, enc_f32 / n * 1e6
+    us, us_r3, us_f32 = enc / n * 1e6, enc_r3 / n * 1e6, enc_f32 / n * 1e6
     simhash = 2.0 * args.patches * 128 * 112    # f32 MFMA flops per page as issued (7 column tiles of 16 hashes)
     ams = 2.0 * args.patches * 128 * (20 * 16)  # AMS flops per page as issued (one 16-column tile per repetition)
+    onehot = 2.0 * args.patches * 32 * 16 * 20  # one-hot bucket sums as issued: rows x 32 partitions x 16 columns per repetition
     useful = 2.0 * args.patches * 128 * (20 * 5) + args.patches * 128 * 20  # SimHash MACs + one signed add per (dim, repetition)
-    return {"pages": n, "us_per_page": round(us, 3), "pages_per_s": round(n / enc, 1), "page_input_GBps": round(args.patches * 256 / us / 1e3, 1),
-            "frac_hbm_8TBps": round(args.patches * 256 / us / 1e3 / HBM_PEAK_GBPS, 4),
-            "f32_mfma_TFLOPs_as_issued": round(simhash / us / 1e6, 1), "frac_f32_mfma_155TF": round(simhash / us / 1e6 / 155.0, 4),
+    f32_issued = simhash + onehot
+    return {"pages": n, "us_per_page": round(us, 3), "pages_per_s": round(n / enc, 1), "page_input_GBps": round(2 * args.patches * 256 / us / 1e3, 1),
+            "frac_hbm_8TBps": round(2 * args.patches * 256 / us / 1e3 / HBM_PEAK_GBPS, 4),
+            "f32_mfma_TFLOPs_as_issued": round(f32_issued / us / 1e6, 1), "frac_f32_mfma_155TF": round(f32_issued / us / 1e6 / 155.0, 4),
             "bf16_mfma_TFLOPs_as_issued": round(ams / us / 1e6, 1),
-            "matrix_pipe_time_frac_est": round((simhash / 155e12 + ams / 2500e12) / (us * 1e-6), 4),
+            "matrix_pipe_time_frac_est": round((f32_issued / 155e12 + ams / 2500e12) / (us * 1e-6), 4),
             "useful_TFLOPs": round(useful / us / 1e6, 1),
-            "bound": "LDS latency behind the bucket-sum atomics (SQ counters, profiles/r3/pmc_fde_encode_kernels_r3d.json: matrix pipes 11 % busy, waves in s_waitcnt half their cycles); SimHash fmaf chains on the f32 pipe, AMS projection on the bf16 pipe at 1/16 of its f32 cost -- DESIGN.md 3.9",
+            "bound": "the f32 matrix pipe: SQ counters (profiles/r4/pmc_fde_encode_kernels_r4.json) show it 51 % busy in the hash pass and 47 % in the "
+                     "projection pass, waves waiting on LDS 0.4 % / 0.0 % of their cycles (the round-3 kernel: matrix pipes 11 % busy, 17 % of the "
+                     "wave cycles behind LDS atomics) -- DESIGN.md 3.9",
+            "round3_one_pass_kernel_lds_atomics": {"us_per_page": round(us_r3, 3), "pages_per_s": round(n / enc_r3, 1)},
             "round2_kernel_f32_pipe_only": {"us_per_page": round(us_f32, 3), "pages_per_s": round(n / enc_f32, 1),
                                             "f32_mfma_TFLOPs_as_issued": round((simhash + ams) / us_f32 / 1e6, 1),
                                             "frac_f32_mfma_155TF": round((simhash + ams) / us_f32 / 1e6 / 155.0, 4)},

@@ -125,12 +125,15 @@ typedef enum {
                                  rows, 6 = two row groups of <= 256 rows at ONE wave per SIMD (query fragments in AGPRs), the two
                                  tiles of a ring chunk split over the other two waves.
                                  MV_MODE_FLOAT_FP8 batches (the batched block-scaled MFMA scan of the e4m3 slab): 7 = ONE e4m3
-                                 term per query row instead of the hi + lo split (half the matrix work; the coarse pass of a
-                                 two-tier search), 8 = query by query */
-  MV_OPT_FDE_ENCODE_VARIANT = 8, /* FDE encode of corpus pages: 3 = (default) pages that are already bf16 -- the slab -- take the AMS projection
-                                    through the bf16 matrix pipe (exact products, sums to fp32 rounding) with the SimHash columns in
-                                    registers; other inputs / FDE shapes run as 1; 1 = f32-MFMA kernel, 0 = scalar kernel.  The same
-                                    partitions bit for bit in all three */
+                                 term per query row instead of the hi + lo split (half the matrix work), 8 = query by query.
+                                 MV_MODE_FP8_THEN_FLOAT batches use ONE term by default (the first stage only nominates candidates,
+                                 the exact tier restores their order); 0 = the two-term scores of the single-query scan */
+  MV_OPT_FDE_ENCODE_VARIANT = 8, /* FDE encode of corpus pages: 4 = (default) pages that are already bf16 -- the slab -- in two passes: SimHash
+                                    partitions (fp32 fmaf chains, columns in registers) to a scratch byte per (row, repetition), then the
+                                    AMS projection on the bf16 matrix pipe with the bucket sums as a one-hot f32 matrix product (no LDS
+                                    atomics: a fixed summation order); 3 = the round-3 one-pass form (bucket sums through LDS float
+                                    atomics); other inputs / FDE shapes run as 1; 1 = f32-MFMA kernel, 0 = scalar kernel.  The same
+                                    partitions bit for bit in all of them */
   MV_OPT_FILTER_COMPACT_PCT = 9, /* doc filter allowing < this % of the documents: compact the allowed pages first and scan
                                     only those (default 25; 0 = always mask inside the scan) */
   MV_OPT_FDE_QUERY_ENCODE_VARIANT = 11, /* FDE encode of the query (one page, latency matters): 2 = latency kernel, one block per

@@ -150,6 +150,10 @@ struct FdeTables {           // device copies of the projection tables of one mv
   int32_t* H = nullptr;      // [rep][dim]
   float* S = nullptr;        // [rep][dim]
   int64_t out_dim = 0;
+  // partition ids between the two passes of the document encode (stride * R bytes per page of a chunk); grown on demand by the
+  // writer that encodes (writers are serialised), freed with the tables
+  mutable uint8_t* scratch = nullptr;
+  mutable size_t scratch_bytes = 0;
 };
 void fde_host_tables(const mv_fde_config& c, float* G, int32_t* H, float* S);
 int fde_tables_create(const mv_fde_config& c, FdeTables* t);
@@ -168,7 +172,8 @@ struct FdeEncodeArgs {
   float* out_f32;
   uint16_t* out_bf16;
   float* out_inv_norm;
-  int32_t variant;           // 0 = scalar kernel (LDS atomics), != 0 = f32-MFMA kernel (callers set 1; zero-initialised structs get 0)
+  int32_t variant;           // 0 = scalar kernel (LDS atomics), 1 = f32-MFMA kernel, 2 = query latency kernel, 3 = one-pass document kernel (bf16 AMS,
+                             // LDS-atomic bucket sums), 4 = two-pass document form (hash pass + projection pass with one-hot MFMA bucket sums)
 };
 int launch_fde_encode(const FdeTables& t, const FdeEncodeArgs& a, hipStream_t s);
 struct FdeScanArgs {

@@ -561,6 +561,251 @@ __global__ __launch_bounds__(256) void fde_encode_doc_kernel(EncMArgs m) {
   }
 }
 
+// ------------------------------------------------------------------------------ documents, round 4: two passes, no LDS atomics
+// The one-pass kernel above spends its time behind LDS: 100 float atomics per 16-row tile (the bucket sums), the sign / partition
+// bytes bounced through LDS, and ONE wave per SIMD (224 VGPRs of SimHash columns + 128 KiB of LDS tables) to hide none of it
+// (profiles/r3/pmc_fde_encode_kernels_r3d.json: matrix pipes 11 % busy, waves in s_waitcnt half their cycles; 1.94 us per page).
+// Split by what each half needs:
+//   pass 1, fde_hash_kernel      the SimHash sketches (the k-ordered fp32 fmaf chains on v_mfma_f32_16x16x4_f32, Gaussian columns in
+//                                VGPRs: bit-identical partitions) -> ONE byte per (row, repetition) in a scratch buffer (20 B per row);
+//                                no tables in LDS, no accumulators, no barrier: a wave owns its tiles outright
+//   pass 2, fde_project_kernel   a wave owns REPETITIONS (5 of 20), not rows: it walks every tile of the page, projects it with its
+//                                repetitions' AMS columns (bf16 MFMA, operands loop-invariant in VGPRs) and adds the 16 projected rows
+//                                to their buckets with a ONE-HOT matrix product on the f32 pipe:
+//                                    acc[col][part] += sum_row PJ[row][col] * [part(row) == part]      (v_mfma_f32_16x16x4_f32, K = rows)
+//                                The C layout of the projection (lane (col, k) holds rows 4k .. 4k+3) IS the A layout of that product
+//                                when K step s is taken to mean rows {4k + s}: no lane crossing, and the one-hot B operand of the
+//                                same step needs the partition bytes of rows 4k .. 4k+3 -- one dword of the scratch buffer.
+//                                Bucket sums live in 40 VGPRs for the whole page (no LDS, no atomics, a fixed summation order:
+//                                deterministic, where the atomics were not); row counts ride along as integer adds of the same
+//                                compares.  ~190 VGPRs, 16 bytes of LDS: two workgroups per CU.
+// Cost per 16-row tile: pass 1 224 f32 MFMAs on one wave; pass 2 (20 bf16 + 40 f32 MFMAs) on each of four waves.  The page is read
+// twice from HBM / L2 (once per pass; the four waves of pass 2 share their loads through the L1).
+template <int NT>
+__global__ __launch_bounds__(256) void fde_hash_kernel(EncMArgs m, uint8_t* parts, int tiles_per_page) {
+  const EncArgs& a = m.e;
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  constexpr int NHP = NT * 16;
+  __shared__ __attribute__((aligned(16))) char smem[4 * 16 * kXStrideB * 2 + 4 * 16 * NHP + 4 * 16 * 32];
+  uint16_t* xs_all = reinterpret_cast<uint16_t*>(smem);                       // [4 waves][16][kXStrideB] the tile's rows, bf16 as they come
+  uint8_t* sg_all = reinterpret_cast<uint8_t*>(xs_all + 4 * 16 * kXStrideB);  // [4 waves][16][NHP] sign bytes
+  uint8_t* pt_all = sg_all + 4 * 16 * NHP;                                    // [4 waves][R <= 32][16] partitions
+  const int NH = a.R * a.NS;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, k = lane >> 4;
+  uint16_t* xs = xs_all + wave * 16 * kXStrideB;
+  uint8_t* sg = sg_all + wave * 16 * NHP;
+  uint8_t* pt = pt_all + wave * 16 * 32;
+
+  // once per wave: the SimHash columns, in registers: greg[n][s] = G[dim 4s + k][hash 16n + j]
+  float greg[NT][32];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int h = 16 * n + j;
+    const int r = h / a.NS, jj = h - r * a.NS;
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2) greg[n][s2] = h < NH ? a.G[((size_t)r * kDim + (4 * s2 + k)) * a.NS + jj] : 0.f;
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2) asm volatile("" : "+v"(greg[n][s2]));  // loop invariant: keep them where they are
+
+  for (int64_t page = blockIdx.x; page < m.n_pages; page += gridDim.x) {
+    const int32_t nr = a.n_rows ? a.n_rows[page] : a.stride;
+    const uint16_t* pg = a.x_bf16 + (size_t)page * (size_t)a.stride * kDim;
+    uint8_t* pp = parts + (size_t)page * (size_t)tiles_per_page * (size_t)a.R * 16;
+    const int ntiles = (nr + 15) >> 4;
+    uint2 nx[8];
+    auto request = [&](int t) {
+      const int row0 = t * 16;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int idx = it * 64 + lane, row = idx >> 5, c4 = (idx & 31) * 4;
+        nx[it] = row0 + row < nr ? *reinterpret_cast<const uint2*>(pg + (size_t)(row0 + row) * kDim + c4) : make_uint2(0u, 0u);
+      }
+    };
+    if (wave < ntiles) request(wave);
+    for (int t = wave; t < ntiles; t += 4) {
+      const int row0 = t * 16;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int idx = it * 64 + lane, row = idx >> 5, c4 = (idx & 31) * 4;
+        *reinterpret_cast<uint2*>(xs + row * kXStrideB + c4) = nx[it];  // 264-byte rows: 8-byte aligned, conflict-free column reads
+      }
+      if (t + 4 < ntiles) request(t + 4);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private LDS: in-order, just make the stores land
+      float af[32];  // A fragments of the fp32 chain: x[row = j][dim = 4s + k]
+#pragma unroll
+      for (int s2 = 0; s2 < 32; ++s2) af[s2] = bf16_to_f32(xs[j * kXStrideB + 4 * s2 + k]);
+      f32x4 c[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) c[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s2 = 0; s2 < 32; ++s2)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) c[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s2], greg[n][s2], c[n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sg[(4 * k + i) * NHP + 16 * n + j] = c[n][i] > 0.0f ? 1 : 0;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // partition ids (Gray code of the NS sign bits), stored [repetition][row]; rows past the page's end get 0xFF (no bucket)
+      for (int pi = lane; pi < 16 * a.R; pi += 64) {
+        const int row = pi & 15, rep = pi >> 4;
+        uint32_t part = 0;
+        for (int jj = 0; jj < a.NS; ++jj) part = (part << 1) + ((uint32_t)sg[row * NHP + rep * a.NS + jj] ^ (part & 1u));
+        pt[rep * 16 + row] = row0 + row < nr ? (uint8_t)part : (uint8_t)0xFF;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      uint32_t* dst = reinterpret_cast<uint32_t*>(pp + (size_t)t * a.R * 16);
+      for (int d = lane; d < a.R * 4; d += 64) dst[d] = reinterpret_cast<const uint32_t*>(pt)[d];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // pt is rewritten by this wave's next tile
+    }
+  }
+}
+
+template <int RPW>  // repetitions per wave: R <= 4 * RPW
+__global__ __launch_bounds__(256, 2) void fde_project_kernel(EncMArgs m, const uint8_t* parts, int tiles_per_page) {
+  const EncArgs& a = m.e;
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  using bf16x8 = __attribute__((ext_vector_type(8))) short;
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+  __shared__ float red[2][4];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, k = lane >> 4;
+  const int NP = 1 << a.NS;
+  const int rep0 = wave * RPW;
+
+  // once per wave: the AMS operand fragments of its repetitions (lane (c = j, g = k) of K step kk holds column c of dims kk*32 + 8g .. +8)
+  bf16x8 cb[RPW][4];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int rep = rep0 + r, dim = kk * 32 + k * 8 + e;
+        short x = 0;
+        if (rep < a.R && j < a.PD && (m.H[rep * kDim + dim] & 15) == j) x = m.S[rep * kDim + dim] < 0.f ? (short)0xbf80 : (short)0x3f80;  // -1.0 / +1.0 in bf16
+        v[e] = x;
+      }
+      cb[r][kk] = v;
+    }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) asm volatile("" : "+v"(cb[r][kk]));  // loop invariant
+
+  int parity = 0;
+  for (int64_t page = blockIdx.x; page < m.n_pages; page += gridDim.x, parity ^= 1) {
+    const int32_t nr = a.n_rows ? a.n_rows[page] : a.stride;
+    const uint16_t* pg = a.x_bf16 + (size_t)page * (size_t)a.stride * kDim;
+    const uint8_t* pp = parts + (size_t)page * (size_t)tiles_per_page * (size_t)a.R * 16;
+    const int ntiles = (nr + 15) >> 4;
+    f32x4 acc[RPW][2];
+    int32_t cnt[RPW][2];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) { acc[r][mt] = f32x4{0.f, 0.f, 0.f, 0.f}; cnt[r][mt] = 0; }
+    u32x4 nab[4];
+    uint32_t npw[RPW];
+    auto request = [&](int t) {
+      const int row = t * 16 + j;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        nab[kk] = row < nr ? *reinterpret_cast<const u32x4*>(pg + (size_t)row * kDim + kk * 32 + k * 8) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int r = 0; r < RPW; ++r)  // partitions of rows 4k .. 4k+3 of the tile under repetition rep0 + r (0xFF: not a row)
+        npw[r] = rep0 + r < a.R ? *reinterpret_cast<const uint32_t*>(pp + ((size_t)t * a.R + rep0 + r) * 16 + 4 * k) : 0xffffffffu;
+    };
+    if (ntiles > 0) request(0);
+    for (int t = 0; t < ntiles; ++t) {
+      bf16x8 abf[4];
+      uint32_t pw[RPW];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) abf[kk] = __builtin_bit_cast(bf16x8, nab[kk]);
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) pw[r] = npw[r];
+      if (t + 1 < ntiles) request(t + 1);
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        f32x4 pj = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) pj = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abf[kk], cb[r][kk], pj, 0, 0, 0);
+        float as[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) as[s2] = pj[s2] * a.scale;  // lane (col j, k): row 4k + s2
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const uint32_t tgt = (uint32_t)(j + 16 * mt);
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) {
+            const bool hit = ((pw[r] >> (8 * s2)) & 0xffu) == tgt;  // lane (partition tgt, k): does row 4k + s2 fall into it?
+            acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[s2], hit ? 1.0f : 0.0f, acc[r][mt], 0, 0, 0);
+            cnt[r][mt] += hit ? 1 : 0;
+          }
+        }
+      }
+    }
+    // ---- finish: acc[r][mt][i] = bucket sum of (col 4k + i, partition j + 16 mt) under repetition rep0 + r; AVERAGE for documents
+    float nn = 0.0f;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int rep = rep0 + r;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        int32_t n = cnt[r][mt];
+        n += __shfl_xor(n, 16);
+        n += __shfl_xor(n, 32);  // rows of the page in partition j + 16 mt (the four k groups each counted their rows)
+        const int part = j + 16 * mt;
+        if (rep < a.R && part < NP) {
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[i] = acc[r][mt][i];
+            if (!a.is_query && n > 1) v[i] = v[i] / (float)n;
+          }
+          const int64_t base = (int64_t)page * a.out_dim + ((int64_t)rep * NP + part) * a.PD + 4 * k;
+          uint16_t hb[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            hb[i] = f32_to_bf16_rne(v[i]);
+            if (4 * k + i < a.PD) {
+              const float vb = bf16_to_f32(hb[i]);
+              nn += vb * vb;
+              if (a.out_f32) a.out_f32[base + i] = v[i];
+            }
+          }
+          if (a.out_bf16) {
+            if (a.PD == 16) {
+              *reinterpret_cast<uint2*>(a.out_bf16 + base) = make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
+            } else {
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if (4 * k + i < a.PD) a.out_bf16[base + i] = hb[i];
+            }
+          }
+        }
+      }
+    }
+    if (a.out_inv_norm) {
+#pragma unroll
+      for (int sft = 1; sft < 64; sft <<= 1) nn += __shfl_xor(nn, sft);
+      if (lane == 0) red[parity][wave] = nn;
+      __syncthreads();  // one barrier per page: the sums of page p + 1 go to the other half of red
+      if (threadIdx.x == 0) {
+        const float tt = (red[parity][0] + red[parity][1]) + (red[parity][2] + red[parity][3]);
+        a.out_inv_norm[page] = tt > 0.0f ? 1.0f / sqrtf(tt) : 0.0f;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ the QUERY: latency form
 // One query page per request sits in front of every FDE search, so what matters is its latency, not throughput: the
 // bulk kernel above is one persistent block that stages all 20 repetitions' tables (56 KiB) and walks 27 dependent
@@ -1857,6 +2102,9 @@ int fde_tables_create(const mv_fde_config& c, FdeTables* t) {
 }
 
 void fde_tables_destroy(FdeTables* t) {
+  if (t->scratch) (void)hipFree(t->scratch);
+  t->scratch = nullptr;
+  t->scratch_bytes = 0;
   if (t->G) (void)hipFree(t->G);
   t->G = nullptr;
   t->H = nullptr;
@@ -1886,7 +2134,40 @@ int launch_fde_encode(const FdeTables& t, const FdeEncodeArgs& a, hipStream_t s)
     MV_HIP(hipGetLastError());
     return MV_OK;
   }
-  if (a.variant == 3 && a.x_bf16 && !a.is_query && PD <= 16 && R * NS > 96 && R * NS <= 112) {
+  if (a.variant == 4 && a.x_bf16 && !a.is_query && PD <= 16 && NS <= 5 && R <= 20 && R * NS > 96 && R * NS <= 112 && a.stride % 16 == 0 && (a.out_bf16 || a.out_f32)) {
+    // documents from the bf16 slab, two passes (default for the corpus build): hash pass -> partition bytes in scratch -> projection pass with
+    // one-hot MFMA bucket sums.  Chunks of <= 8192 pages share one scratch buffer (stride * R bytes per page); stream order keeps them apart.
+    static int ncu4 = 0;
+    if (ncu4 == 0) {
+      int dev = 0, v = 0;
+      ncu4 = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    const int tiles_per_page = a.stride / 16;
+    const size_t per_page = (size_t)a.stride * R;
+    const int64_t chunk = std::min<int64_t>(a.n_pages, 8192);
+    if (t.scratch_bytes < (size_t)chunk * per_page) {
+      if (t.scratch) (void)hipFree(t.scratch);
+      t.scratch = nullptr; t.scratch_bytes = 0;
+      hipError_t e = hipMalloc(&t.scratch, (size_t)chunk * per_page);
+      if (e != hipSuccess) { t.scratch = nullptr; set_error("out of device memory for %zu bytes of FDE partition scratch", (size_t)chunk * per_page); return MV_ERR_NOMEM; }
+      t.scratch_bytes = (size_t)chunk * per_page;
+    }
+    for (int64_t p0 = 0; p0 < a.n_pages; p0 += chunk) {
+      const int64_t c = std::min<int64_t>(chunk, a.n_pages - p0);
+      EncArgs kc = k;
+      kc.x_bf16 = a.x_bf16 + (size_t)p0 * a.stride * kDim;
+      kc.n_rows = a.n_rows ? a.n_rows + p0 : nullptr;
+      kc.out_f32 = a.out_f32 ? a.out_f32 + (size_t)p0 * t.out_dim : nullptr;
+      kc.out_bf16 = a.out_bf16 ? a.out_bf16 + (size_t)p0 * t.out_dim : nullptr;
+      kc.out_inv_norm = a.out_inv_norm ? a.out_inv_norm + p0 : nullptr;
+      EncMArgs mm{kc, t.H, t.S, c};
+      hipLaunchKernelGGL((fde_hash_kernel<7>), dim3((unsigned)std::min<int64_t>(c, ncu4)), dim3(256), 0, s, mm, t.scratch, tiles_per_page);
+      hipLaunchKernelGGL((fde_project_kernel<5>), dim3((unsigned)std::min<int64_t>(c, 2 * (int64_t)ncu4)), dim3(256), 0, s, mm, (const uint8_t*)t.scratch, tiles_per_page);
+    }
+    MV_HIP(hipGetLastError());
+    return MV_OK;
+  }
+  if ((a.variant == 3 || a.variant == 4) && a.x_bf16 && !a.is_query && PD <= 16 && R * NS > 96 && R * NS <= 112) {
     // documents from the bf16 slab (default for the corpus build): AMS on the bf16 pipe, SimHash columns in registers (NT = 7 column tiles)
     const size_t ldsd = (size_t)R * 4096 + (size_t)t.out_dim * 4 + (size_t)R * (1 << NS) * 4 + 16 + (size_t)4 * 16 * kXStrideB * 2 + (size_t)4 * 16 * 112 +
                         (size_t)4 * 16 * R + 64;

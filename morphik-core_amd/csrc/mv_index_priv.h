@@ -118,7 +118,8 @@ struct mv_index {
   int fde_scan_variant = -1;
   int batch_variant = -1;      // -1 = auto: pipelined kernel up to 384 query rows, 512-row kernel above
   int long_query_variant = 1;  // 1 = single queries > 64 rows use the row-split (batched) workgroup; 0 = page-split passes
-  int fde_encode_variant = 3;  // 3 = documents from the bf16 slab: AMS on the bf16 matrix pipe (falls back to 1 for other inputs / shapes), 1 = f32-MFMA kernel, 0 = scalar kernel
+  int fde_encode_variant = 4;  // 4 = documents from the bf16 slab in two passes (hash -> partitions; projection + one-hot MFMA bucket sums), 3 = the one-pass
+                               // form (bf16 AMS, LDS-atomic bucket sums); both fall back to 1 for other inputs / shapes; 1 = f32-MFMA kernel, 0 = scalar kernel
   int fde_batch_variant = 0;   // mv_query_topk_batch in the FDE modes: 0 = batched pipeline (one slab pass per 32 queries), 1 = query by query,
                                // 2 = batched with the query FDE rounded to bf16 (no lo term)
   int fde_query_encode_variant = 2;  // the ONE query page: 2 = latency kernel (one block per repetition, default), 1 = bulk f32-MFMA kernel, 0 = scalar kernel

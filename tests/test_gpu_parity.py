@@ -697,7 +697,7 @@ def test_fde_slab_same_scores_from_both_encode_kernels(mv):
 
     q = orc.synth_rows(4321, 0, 0, 32)
     outs = []
-    for variant in (0, 1, 3):  # scalar kernel, f32-MFMA kernel, bf16-slab kernel (AMS on the bf16 matrix pipe: the default)
+    for variant in (0, 1, 3, 4):  # scalar kernel, f32-MFMA kernel, one-pass bf16-slab kernel (r3), two-pass form (hash + one-hot MFMA bucket sums: the default)
         ix = _idx(mv, capacity_pages=300, stride_rows=208, with_fde=True)
         ix.set_option(_lib.MV_OPT_FDE_ENCODE_VARIANT, variant)
         ix.fill_synthetic(1234, 0, 300, n_rows=200)
@@ -705,6 +705,8 @@ def test_fde_slab_same_scores_from_both_encode_kernels(mv):
         ix.close()
     np.testing.assert_allclose(outs[0], outs[1], rtol=2e-3, atol=2e-4)  # bf16 slab, bucket sums in different orders
     np.testing.assert_allclose(outs[2], outs[1], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(outs[3], outs[1], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(outs[3], outs[2], rtol=3e-4, atol=3e-5)  # the two bf16-slab forms differ only in the order of the bucket sums
     # the bf16-slab kernel on ragged pages (1 .. stride rows, an empty page) added from the host as bf16 and as fp32 (fp32 rows take the
     # f32-MFMA kernel: the slab kernel only sees pages that are already bf16), against the oracle's FDE of the same bf16 rows
     rng = np.random.default_rng(12)
@@ -716,7 +718,7 @@ def test_fde_slab_same_scores_from_both_encode_kernels(mv):
     want = np.array([orc.fde_coarse_scores(fq, orc.f32_to_bf16(orc.fde_encode(ocfg, orc.bf16_to_f32(pg), False))[None], use_cosine=True)[0]
                      if len(pg) else 0.0 for pg in pages], np.float32)
     for as_f32 in (False, True):
-        for variant in (3, 1):
+        for variant in (4, 3, 1):
             ix = _idx(mv, capacity_pages=len(pages), stride_rows=stride, with_fde=True)
             ix.set_option(_lib.MV_OPT_FDE_ENCODE_VARIANT, variant)
             ix.add([orc.bf16_to_f32(pg) if as_f32 else pg for pg in pages])

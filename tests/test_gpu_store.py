@@ -897,3 +897,44 @@ def test_store_mode_fp8_then_float_returns_the_exact_stores_answers():
     np.testing.assert_allclose([c.score for c in got], [c.score for c in want], rtol=1e-3)
     exact.close()
     two.close()
+
+
+def test_encoder_start_ups_with_fused_ops_and_tuned_gemms_stay_clean_in_fresh_processes():
+    """a standing stress test for the encoder's fused HIP passes.  Round 3 saw ONE `Memory access fault by GPU`
+    three seconds into a full-size model start-up with the fused ops on and never reproduced it; a product path with one
+    unexplained fault gets a test, not a paragraph.  Twelve FRESH processes -- {1, 4, 16 pages} x fused ops on / off x tuned GEMM
+    selections on / off -- each build the full 2.9 B-parameter ColPali-v1.2 architecture, embed their pages in one forward, embed a
+    query and embed the pages again; four run at a time on the one GPU (start-ups overlap, as an API process and ingestion workers
+    do).  Every one must exit 0 with finite, L2-normalised rows that a second forward reproduces; the pages' rows must not depend on the switches beyond
+    bf16 rounding (checked through the norms and the row counts; the numerics of each fused pass have their own tests)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    combos = [(pages, fused, tuned) for pages in (1, 4, 16) for fused in ("1", "0") for tuned in ("1", "0")]
+
+    def run(combo):
+        pages, fused, tuned = combo
+        env = dict(os.environ, MV_ENCODER_FUSED_OPS=fused, MV_ENCODER_TUNED_GEMMS=tuned)
+        p = subprocess.run([sys.executable, os.path.join(root, "tools", "encoder_startup_probe.py"), str(pages)], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=600, cwd=root)
+        return combo, p.returncode, p.stdout, p.stderr
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        results = list(pool.map(run, combos))
+    log = []
+    for (pages, fused, tuned), rc, out, err in results:
+        assert rc == 0, (pages, fused, tuned, rc, err[-1500:])
+        assert "Memory access fault" not in err and "HSA_STATUS_ERROR" not in err, err[-1500:]
+        d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+        assert d["rows"] == [1030] * pages and d["finite"] and d["query_finite"] and d["repeat_max_diff"] <= 1e-2 and d["norm_err"] < 2e-2, d
+        assert (sum(d["fused_ops"].values()) > 0) == (fused == "1"), d
+        assert d["tuned_gemms"] == (tuned == "1") or tuned == "1", d  # the CSV is ignored by PyTorch on another ROCm / hipBLASLt build
+        log.append(dict(d, fused=fused, tuned=tuned))
+    out_dir = os.path.join(root, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "encoder_startup_stress.json"), "w") as f:
+        json.dump(log, f, indent=1)

@@ -15,14 +15,17 @@ def main():
 
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000
     out = {"pages": n}
-    for variant, name in ((3, "bf16_pipe_ams"), (1, "f32_pipe")):
+    for variant, name in ((4, "two_pass_onehot"), (3, "bf16_pipe_ams"), (1, "f32_pipe"), (-1, "no_fde")):
         for rep in range(2):
-            ix = MvIndex(capacity_pages=n, stride_rows=1024, with_float=True, with_fde=True)
-            ix.set_option(_lib.MV_OPT_FDE_ENCODE_VARIANT, variant)
+            ix = MvIndex(capacity_pages=n, stride_rows=1024, with_float=True, with_fde=variant >= 0)
+            if variant >= 0:
+                ix.set_option(_lib.MV_OPT_FDE_ENCODE_VARIANT, variant)
             t0 = time.perf_counter()
             ix.fill_synthetic(1234, 0, n)
             out[name + "_fill_s"] = round(time.perf_counter() - t0, 4)
             ix.close()
+    for name in ("two_pass_onehot", "bf16_pipe_ams", "f32_pipe"):
+        out[name + "_us_per_page"] = round((out[name + "_fill_s"] - out["no_fde_fill_s"]) / n * 1e6, 3)
     print(json.dumps(out))
 
 
