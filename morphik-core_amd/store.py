@@ -96,6 +96,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         enable_external_storage: bool = True,
         app_id_resolver: Optional[Callable[[str], Optional[str]]] = None,
         exact_tier: str = "hbm",
+        rerank_n: int = 0,
         **_ignored: Any,
     ):
         self.capacity_pages = int(capacity_pages)
@@ -111,6 +112,9 @@ class MI355XMultiVectorStore(BaseVectorStore):
         if exact_tier not in ("hbm", "host"):
             raise ValueError(f"unknown exact_tier {exact_tier!r} (\"hbm\" or \"host\")")
         self.exact_tier = exact_tier
+        # pages read from the exact tier per request (MV_OPT_RERANK_N; 0 = the library's 128): the candidate list of "fp8_then_float",
+        # the cut of the e4m3 pruning stage of "fde_then_float" over a host tier -- n x 256 KiB over PCIe per request
+        self.rerank_n = int(rerank_n)
         self.storage = storage  # callers reach for .storage (document_service.py:1570-1575)
         # multi_vector_store.py:120-160: content is stored externally when a storage object is configured
         self.enable_external_storage = bool(enable_external_storage)
@@ -193,6 +197,10 @@ class MI355XMultiVectorStore(BaseVectorStore):
             from ._lib import MV_OPT_FDE_COARSE_N
 
             ix.set_option(MV_OPT_FDE_COARSE_N, self.fde_coarse_n)
+        if self.rerank_n:
+            from ._lib import MV_OPT_RERANK_N
+
+            ix.set_option(MV_OPT_RERANK_N, self.rerank_n)
 
     def initialize(self) -> bool:
         """Allocate the HBM slabs. Returns False on failure, never raises (multi_vector_store.py:325-327)."""
@@ -662,7 +670,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
     def _book(self) -> Dict[str, Any]:
         return {
             "version": 3, "mode": self.mode, "capacity_pages": self.capacity_pages, "stride_rows": self.stride_rows,
-            "id_base": self.id_base, "fde_coarse_n": self.fde_coarse_n, "exact_tier": self.exact_tier, "next_ord": self._next_ord,
+            "id_base": self.id_base, "fde_coarse_n": self.fde_coarse_n, "exact_tier": self.exact_tier, "rerank_n": self.rerank_n, "next_ord": self._next_ord,
             "rows": [[p, r[0], r[1], r[2], r[3], r[4]] for p, r in self._rows.items()],
             "doc_ord": self._doc_ord, "doc_app": {str(k): v for k, v in self._doc_app.items()},
         }
@@ -759,7 +767,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         elif book.get("checkpoint") and (not os.path.exists(idp) or open(idp).read().strip() != book["checkpoint"]):
             raise RuntimeError(f"{directory}: index.mv and store.json belong to different checkpoints (crash during save?)")
         self = cls(capacity_pages=book["capacity_pages"], stride_rows=book["stride_rows"], device=device, mode=book["mode"], storage=storage,
-                   id_base=book["id_base"], fde_coarse_n=book.get("fde_coarse_n", 0), exact_tier=book.get("exact_tier", "hbm"), **kw)
+                   id_base=book["id_base"], fde_coarse_n=book.get("fde_coarse_n", 0), exact_tier=book.get("exact_tier", "hbm"), rerank_n=book.get("rerank_n", 0), **kw)
         self._index = cls._load_index(self, directory, book, device)
         self._apply_options(self._index)
         for p, doc, chunk_no, content, meta_json, app in book["rows"]:
