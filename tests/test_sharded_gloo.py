@@ -184,3 +184,88 @@ def test_two_stage_fde_pipeline_is_rank_count_invariant(world, n_total, k, coars
     s, i = solo.query(orc.synth_rows(4321, 0, 0, 6), k, coarse_n=coarse_n)
     ws, wi = one.query(orc.synth_rows(4321, 0, 0, 6), k, mode="fde_then_float", coarse_n=coarse_n)
     assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist()
+
+
+# --------------------------------------------------------------------------- the pruning stage (exact tier in host RAM behind a long coarse list)
+def _fp8_scores(ix, q, local_pages, pads):
+    """e4m3 MaxSim (oracle quantiser + oracle scan) of the named local pages of an OracleIndex: the pruning stage's scores."""
+    from oracle import oracle as orc
+
+    q = np.asarray(q)
+    qf = orc.bf16_to_f32(q) if q.dtype == np.uint16 else np.asarray(q, np.float32)
+    out = []
+    for p, pad in zip(local_pages, pads):
+        rows = orc.f32_to_bf16(ix.pages[int(p)])
+        codes, inv = orc.quantize_page_fp8(rows, 16)
+        out.append(orc.maxsim_fp8(qf, codes, rows.shape[0], float(inv), int(pad)))
+    return np.array(out, np.float32)
+
+
+def _two_stage_pruned(ix, lo, n_mid):
+    base = _two_stage(ix, lo)
+    return sharded.TwoStageShardedSearcher(base.local_coarse, base.local_rows, base.local_rerank, (lo, lo + len(ix)),
+                                           local_prune=lambda q, g, pads: _fp8_scores(ix, q, np.asarray(g) - lo, pads), n_mid=n_mid)
+
+
+def _worker_pruned(rank, world, port, n_total, k, coarse_n, n_mid, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    from tests.fake_index import OracleIndex
+
+    lo, hi = sharded.shard_range(n_total, rank, world)
+    ix = OracleIndex(capacity_pages=max(hi - lo, 1), stride_rows=16, id_base=lo, fde=_fde_cfg())
+    ix.add(_ragged_corpus(n_total)[lo:hi])
+    searcher = _two_stage_pruned(ix, lo, n_mid)
+    res = []
+    for j in range(3):
+        s, i = searcher.query(orc.synth_rows(4321, j, 0, 6), k, coarse_n=coarse_n)
+        res.append((s.numpy().tolist(), i.numpy().tolist()))
+    out_q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total,k,coarse_n,n_mid", [(2, 90, 5, 60, 16), (3, 200, 6, 150, 40)])
+def test_two_stage_with_the_pruning_stage_is_rank_count_invariant(world, n_total, k, coarse_n, n_mid):
+    """configs[3] on shards whose exact tier is host memory: between the coarse exchange and the exact rerank every rank scores
+    the entries of the GLOBAL list it owns on its e4m3 slab, the scores are all-gathered, the n_mid best list POSITIONS stay
+    (ties by position).  Over gloo, world 2 and 3, the answer is the one a single index composes: coarse top-n -> batch pad
+    lengths over the WHOLE list -> pruning -> exact rerank -> top-k (the device form is in test_gpu_exact_tier.py)."""
+    from oracle import oracle as orc
+    from tests.fake_index import OracleIndex
+
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pruned, args=(r, world, port, n_total, k, coarse_n, n_mid, out_q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out_q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    one = OracleIndex(capacity_pages=n_total, stride_rows=16, fde=_fde_cfg())
+    one.add(_ragged_corpus(n_total))
+    differs = 0
+    for j in range(3):
+        q = orc.synth_rows(4321, j, 0, 6)
+        cs, ci = orc.topk(one.score_all(q, "fde"), coarse_n)
+        ci = ci[np.isfinite(cs)]
+        rows = one.page_rows(ci)
+        pads = np.concatenate([np.full(len(rows[b : b + 128]), rows[b : b + 128].max()) for b in range(0, len(rows), 128)])
+        f8 = _fp8_scores(one, q, ci, pads)
+        keep = np.lexsort((np.arange(ci.size), -f8.astype(np.float64)))[:n_mid]
+        exact = np.full(ci.size, -np.inf, np.float32)
+        exact[keep] = one.score_candidates(q, ci[keep], pads=pads[keep])
+        order = np.lexsort((np.arange(ci.size), -exact.astype(np.float64)))[:k]
+        ws, wi = exact[order], ci[order]
+        for _rank, res in results:
+            assert res[j][1] == wi.tolist() and res[j][0] == ws.tolist()
+        us, ui = one.query(q, k, mode="fde_then_float", coarse_n=coarse_n)
+        differs += int(ui.tolist() != wi.tolist())
+    # without a process group the class composes the same answer
+    solo = _two_stage_pruned(one, 0, n_mid)
+    s, i = solo.query(orc.synth_rows(4321, 0, 0, 6), k, coarse_n=coarse_n)
+    assert i.tolist() == results[0][1][0][1] and s.tolist() == results[0][1][0][0]
