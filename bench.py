@@ -323,18 +323,36 @@ def container_memory_GB():
     return out
 
 
-def exact_shard_pages(args, stride):
-    """Pages of the shard-shaped index that carries its exact tier in pinned host RAM (aux_paths.exact_shard).  configs[3] / [4]
-    name 1.25 M pages per GPU = 328 GB of pinned rows; the process may pin only what its memory cgroup allows
+def exact_shard_pages(args, stride, device):
+    """Pages of the shard-shaped index that carries its exact tier outside the slabs (aux_paths.exact_shard).  configs[3] / [4]
+    name 1.25 M pages per GPU = 328 GB of exact rows; the process may pin only what its memory cgroup allows
     (mv_host_pin_budget_bytes(): limit - usage - headroom; the MI355X pool's containers run with memory.max = 300 GiB on a
-    3 TiB host, and pinning past it gets the container killed, not an error).  args.exact_shard_pin_frac of that budget is used."""
+    3 TiB host, and pinning past it gets the container killed, not an error).
+    --exact-shard-split 1 (default): MV_WITH_EXACT_SPLIT -- the exact rows of the leading pages fill the HBM the e4m3 + FDE +
+    sign-bit slabs leave free, the rest is pinned; the page count is cut (if at all) so that the pinned part stays under
+    args.exact_shard_split_pin_frac of the budget.  0: the whole tier pinned, args.exact_shard_pin_frac of the budget.
+    -> (pages, pin budget, split)"""
+    import torch
+
     from morphik_core_amd import _lib
 
     if args.exact_shard_pages <= 0:
-        return 0, 0
+        return 0, 0, False
     budget = int(_lib.lib().mv_host_pin_budget_bytes())
-    fit = int(args.exact_shard_pin_frac * budget // (stride * 256))
-    return max(min(args.exact_shard_pages, fit), 0), budget
+    page_b = stride * 256
+    if not args.exact_shard_split:
+        fit = int(args.exact_shard_pin_frac * budget // page_b)
+        return max(min(args.exact_shard_pages, fit), 0), budget, False
+    _free, total_b = torch.cuda.mem_get_info(device)
+    hbm = total_b - (3 << 30)  # what is free once the headline's bf16 slab is gone (context, torch's own blocks)
+    slab_b = stride * 128 + stride * 16 + 20480 + 64 + 33 * 4  # e4m3 + sign bits + FDE + metadata + the batched score vectors
+    n = int(min(args.exact_shard_pages, (hbm - (14 << 30)) // slab_b))
+    while n > 0:
+        in_hbm = max(0, (hbm - n * slab_b - (13 << 30)) // page_b)  # the library keeps 12 GiB back (MV_EXACT_HBM_RESERVE_BYTES)
+        if (n - min(n, in_hbm)) * page_b <= args.exact_shard_split_pin_frac * budget:
+            break
+        n -= 10_000
+    return max(n, 0), budget, True
 
 
 def full_shard(args, device, qs):
@@ -425,12 +443,14 @@ def fde_pipeline_timings(ix, qs, n, coarse_ns):
     return out
 
 
-def exact_shard(args, device, n, budget, sets, truths, gaps):
+def exact_shard(args, device, n, n_truth, budget, split, sets, truths, gaps):
     """BASELINE configs[3] / [4] at their per-GPU shard SHAPE with the EXACT rerank the reference does (fp32 MaxSim on fp32 pages,
     fast_multivector_store.py:553-556): e4m3 + FDE + sign-bit slabs in HBM (no bf16 slab), the exact bf16 rows of every page in
-    PINNED HOST memory (n x 256 KiB).  n = as many of the 1.25 M pages as this process may pin (exact_shard_pages()).  Its
-    pages are the first n of the headline corpus -- the pages the recall sets were written into and the exact bf16 truth was
-    taken on (with a doc filter over those pages) before the bf16 slab was freed.
+    PINNED HOST memory (n x 256 KiB) -- split: of the leading pages in the HBM the slabs leave free (MV_WITH_EXACT_SPLIT), which
+    is what lets the FULL 1.25 M-page shard run in a 300 GiB container (exact_shard_pages()).  Its first n_truth pages are
+    those of the headline corpus -- the pages the recall sets were written into and the exact bf16 truth was taken on (with
+    a doc filter over those pages) before the bf16 slab was freed; the recall queries carry the same doc filter when the
+    shard is larger than that corpus.
     Measured: the FDE pipeline with its exact rerank (coarse top-75: straight out of host RAM; coarse top-1000: e4m3 pruning to
     128, then host RAM) and fp8_then_float -- device ms for one request and for a batch, the PCIe rate of the exact stage, recall@10
     of every lossy and every exact path against the bf16 truth on the four corpora, and the largest relative error of the
@@ -442,15 +462,24 @@ def exact_shard(args, device, n, budget, sets, truths, gaps):
     from morphik_core_amd.index import MvIndex
 
     stride = ((args.patches + 15) // 16) * 16
-    res = {"pages": n, "pages_of_a_full_shard": args.exact_shard_pages, "slabs": "e4m3 + FDE(10240 bf16) + sign bits in HBM; exact bf16 rows in pinned host RAM",
-           "pinned_host_exact_tier_GB": round(n * stride * 256 / 1e9, 1), "pin_budget_GB": round(budget / 1e9, 1),
+    res = {"pages": n, "pages_of_a_full_shard": args.exact_shard_pages,
+           "slabs": "e4m3 + FDE(10240 bf16) + sign bits in HBM; exact bf16 rows " + ("split: leading pages in the free HBM, the rest in pinned host RAM" if split else "in pinned host RAM"),
+           "exact_tier_GB": round(n * stride * 256 / 1e9, 1), "pin_budget_GB": round(budget / 1e9, 1),
            "pin_budget_note": "mv_host_pin_budget_bytes(): memory cgroup limit - usage - headroom (the pool's containers: memory.max 300 GiB on a 3 TiB host; "
-                              "a 1.25 M-page shard's 328 GB tier cannot be pinned here -- two boxes were lost finding that out); %.2f of it is used" % args.exact_shard_pin_frac,
+                              "a 1.25 M-page shard's 328 GB tier cannot be pinned whole here -- two boxes were lost finding that out)",
            "note": "kernel-only HIP-event times (median after 0.25 s of warm-up queries); recall@10 against the exact bf16 top-10 of the same pages computed by the "
                    "float scan (doc filter over the first n pages) before the bf16 slab was freed"}
     t0 = time.time()
-    ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=False, with_binary=True, with_fde=True, with_fp8=True, with_host_exact=True)
+    ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=False, with_binary=True, with_fde=True, with_fp8=True, with_host_exact=True,
+                 with_exact_split=split)
     res["create_and_pin_s"] = round(time.time() - t0, 1)
+    in_hbm = ix.exact_hbm_pages
+    res["exact_tier_pages_in_hbm"] = in_hbm
+    res["exact_tier_in_hbm_GB"] = round(in_hbm * stride * 256 / 1e9, 1)
+    res["pinned_host_exact_tier_GB"] = round((n - in_hbm) * stride * 256 / 1e9, 1)
+    res["pinned_share_of_budget"] = round((n - in_hbm) * stride * 256 / max(budget, 1), 3)
+    allow_truth = first_pages_bitmap(n_truth, n)  # None when the shard is no larger than the corpus the truth was taken on
+    res["recall_doc_filter"] = None if allow_truth is None else f"first {n_truth} pages (the corpus of the exact bf16 truth)"
     t0 = time.time()
     ix.fill_synthetic(synth.SEED_CORPUS, 0, n, n_rows=args.patches)
     res["fill_s"] = round(time.time() - t0, 1)
@@ -471,8 +500,9 @@ def exact_shard(args, device, n, budget, sets, truths, gaps):
     for cn in (75, 1000):
         ent = res["fde_then_exact_rerank"][f"coarse{cn}"]
         n_mid, tier = ix.rerank_plan(cn, K, args.qtokens)
-        read = (n_mid or cn) * args.patches * 256
-        ent["rerank_plan"] = {"tier": tier, "e4m3_pruning_to": n_mid, "exact_pages_read_over_pcie": (n_mid or cn)}
+        host_share = (n - in_hbm) / n  # candidates are spread over the shard: this share of the exact reads crosses PCIe
+        read = (n_mid or cn) * args.patches * 256 * host_share
+        ent["rerank_plan"] = {"tier": tier, "e4m3_pruning_to": n_mid, "exact_pages_read": (n_mid or cn), "expected_share_over_pcie": round(host_share, 3)}
         one = ent["one_request"]
         one["added_ms_over_coarse_scan_and_encode"] = round(one["device_ms"] - base_fde["total_device_ms"], 4)
         one["exact_stage_GBps_over_pcie_upper_bound"] = round(read / max(one["stage_ms"]["rerank_ms"], 1e-6) / 1e6, 1)
@@ -482,7 +512,7 @@ def exact_shard(args, device, n, budget, sets, truths, gaps):
     res["fp8_then_float_n128"] = {
         "rerank_n": 128, "device_ms": round(t["total_device_ms"], 4), "fp8_scan_alone_device_ms": round(base["total_device_ms"], 4),
         "added_ms_over_fp8_scan": round(t["total_device_ms"] - base["total_device_ms"], 4), "rerank_ms": round(t["rerank_ms"], 4),
-        "rerank_GBps_over_pcie": round(128 * args.patches * 256 / max(t["rerank_ms"], 1e-6) / 1e6, 1),
+        "rerank_GBps_over_pcie": round(128 * args.patches * 256 * (n - in_hbm) / n / max(t["rerank_ms"], 1e-6) / 1e6, 1),
         "pages_searched_per_s": round(n / t["total_device_ms"] * 1e3, 1)}
     dev = []
     for r in range(5):
@@ -516,12 +546,12 @@ def exact_shard(args, device, n, budget, sets, truths, gaps):
              ("fde_top75_then_exact", ids_of("fde_then_float", cn=75)), ("fde_top1000_then_exact", ids_of("fde_then_float", cn=1000)),
              ("fde_coarse_recall_at_75", ids_of("fde", k=75)), ("fde_coarse_recall_at_1000", ids_of("fde", k=1000))]
     t0 = time.time()
-    res["recall_at_10_vs_exact_bf16"] = recall_of(ix, rsets, truths, gaps, modes, None)
+    res["recall_at_10_vs_exact_bf16"] = recall_of(ix, rsets, truths, gaps, modes, allow_truth)
     # the e4m3 rerank an index WITHOUT an exact tier falls back to (MV_OPT_EXACT_TIER 2), on the same candidates: what the exact tier buys
     ix.set_option(L.MV_OPT_EXACT_TIER, 2)
     res["recall_at_10_vs_exact_bf16_with_the_e4m3_rerank_instead"] = recall_of(
         ix, {k_: rsets[k_] for k_ in ("hard_negatives", "clustered_topics")}, truths, gaps,
-        [("fde_top75_then_fp8", ids_of("fde_then_float", cn=75)), ("fde_top1000_then_fp8", ids_of("fde_then_float", cn=1000))], None)
+        [("fde_top75_then_fp8", ids_of("fde_then_float", cn=75)), ("fde_top1000_then_fp8", ids_of("fde_then_float", cn=1000))], allow_truth)
     ix.set_option(L.MV_OPT_EXACT_TIER, 0)
     res["recall_s"] = round(time.time() - t0, 1)
     ix.set_option(L.MV_OPT_FDE_COARSE_N, 1000)
@@ -729,7 +759,11 @@ def main():
                     help="pages of the shard-shaped index WITH its exact tier in pinned host RAM (aux_paths.exact_shard; n x 256 KiB = 328 GB at 1.25 M "
                          "pages), cut to what the process may pin (see --exact-shard-pin-frac); 0 = skip")
     ap.add_argument("--exact-shard-pin-frac", type=float, default=0.7,
-                    help="share of mv_host_pin_budget_bytes() (memory cgroup limit - usage - headroom) the exact shard's pinned tier may take")
+                    help="share of mv_host_pin_budget_bytes() (memory cgroup limit - usage - headroom) the exact shard's pinned tier may take (--exact-shard-split 0)")
+    ap.add_argument("--exact-shard-split", type=int, default=1,
+                    help="1: MV_WITH_EXACT_SPLIT -- the exact rows of the leading pages in the HBM the slabs leave free, the rest pinned (the full 1.25 M pages fit); 0: all pinned")
+    ap.add_argument("--exact-shard-split-pin-frac", type=float, default=0.84,
+                    help="share of the pin budget the PINNED part of a split exact tier may take (the page count is cut to keep it)")
     ap.add_argument("--full-shard-pages", type=int, default=1_250_000,
                     help="pages of the e4m3 + FDE + sign-bit index in aux_paths.full_shard (BASELINE configs[3]/[4] per-GPU shard of 10 M pages / 8 GPUs; 0 = skip)")
     ap.add_argument("--aux-embed-pages", type=int, default=1000, help="pages of the full-size encoder run inside aux_paths (configs[1] names 1 k pages; 0 = skip)")
@@ -846,7 +880,7 @@ def main():
     n_truth = n_total
     if want_full:
         t1 = time.time()
-        n_exact, exact_budget = exact_shard_pages(args, stride)
+        n_exact, exact_budget, exact_split = exact_shard_pages(args, stride, local_rank)
         if n_exact < 50_000:
             n_exact = 0  # nothing worth measuring fits: the recall sets then span the whole corpus, as the lossy paths of full_shard need them
         else:
@@ -1137,7 +1171,7 @@ def main():
                 aux["full_shard"] = {"error": repr(e)}
         if truths is not None and n_exact > 0:
             try:  # ... and at their shard SHAPE with the exact tier in pinned host RAM: the exact pipelines and every recall figure
-                aux["exact_shard"] = exact_shard(args, local_rank, n_truth, exact_budget, dict(rsets, _headline_spec=spec), truths, gaps)
+                aux["exact_shard"] = exact_shard(args, local_rank, n_exact, n_truth, exact_budget, exact_split, dict(rsets, _headline_spec=spec), truths, gaps)
             except Exception as e:  # noqa: BLE001
                 aux["exact_shard"] = {"error": repr(e)}
         if args.aux_pages > 0:

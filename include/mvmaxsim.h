@@ -58,11 +58,18 @@ enum {
   MV_WITH_BINARY = 2, /* sign-bit slab   ( 16 384 B / page)            */
   MV_WITH_FDE = 4,    /* bf16 FDE slab   ( 20 480 B / page)            */
   MV_WITH_FP8 = 8,    /* e4m3 page slab  (131 072 B / page) + one power-of-two scale per page */
-  MV_WITH_HOST_EXACT = 16 /* exact bf16 rows kept in PINNED HOST memory (262 144 B / page of host RAM, none of HBM), mapped
+  MV_WITH_HOST_EXACT = 16, /* exact bf16 rows kept in PINNED HOST memory (262 144 B / page of host RAM, none of HBM), mapped
                              into the device's address space: the exact tier of MV_MODE_FP8_THEN_FLOAT for a shard whose
                              bf16 slab does not fit HBM beside its fp8 slab ("host-resident exact vectors
                              with a gather of the candidates").  May be combined with MV_WITH_FLOAT (both tiers
                              hold the same rows; MV_OPT_EXACT_TIER picks the one the rerank reads) */
+  MV_WITH_EXACT_SPLIT = 32 /* with MV_WITH_HOST_EXACT (and no MV_WITH_FLOAT): split the exact tier -- the exact rows of the FIRST
+                             pages go to whatever HBM is free once the other slabs are allocated (minus
+                             MV_EXACT_HBM_RESERVE_BYTES, default 12 GiB, for the lazily allocated workspaces and the caller's
+                             own device memory), the rest to pinned host memory.  A 1.25 M-page shard (328 GB of exact rows
+                             beside 190 GB of FDE + e4m3 slabs) keeps ~105 GB of them in HBM and pins ~223 GB: it fits a
+                             288 GiB GPU in a container that may pin 300 GiB, and a third of the rerank reads never cross
+                             PCIe.  Same answers as an unsplit tier (mv_index_exact_hbm_pages: the pages the HBM part got) */
 };
 
 /* fixed_dimensional_encoding.FixedDimensionalEncodingConfig as constructed at
@@ -182,6 +189,7 @@ MV_API void mv_index_destroy(mv_index* ix);
 MV_API int mv_index_set_option(mv_index* ix, int option, int64_t value);
 MV_API int64_t mv_index_size(const mv_index* ix);     /* pages appended so far (including tombstoned) */
 MV_API int64_t mv_index_capacity(const mv_index* ix);
+MV_API int64_t mv_index_exact_hbm_pages(const mv_index* ix); /* pages of a split exact tier (MV_WITH_EXACT_SPLIT) whose rows live in HBM; 0 otherwise */
 
 /* NON-FINITE VALUES.  A NaN / +-Inf embedding has no defined MaxSim (the reference's torch einsum -> max -> topk propagates NaN
  * and ranks it FIRST), and the scan kernels are compiled without NaN handling.  So they never enter a float-derived slab:

@@ -73,7 +73,7 @@ class QueryStatsC(C.Structure):
 
 MV_F32, MV_BF16 = 0, 1
 MV_MODE_FLOAT, MV_MODE_BINARY, MV_MODE_FDE_THEN_FLOAT, MV_MODE_FDE_ONLY, MV_MODE_FLOAT_FP8, MV_MODE_FP8_THEN_FLOAT = 0, 1, 2, 3, 4, 5
-MV_WITH_FLOAT, MV_WITH_BINARY, MV_WITH_FDE, MV_WITH_FP8, MV_WITH_HOST_EXACT = 1, 2, 4, 8, 16
+MV_WITH_FLOAT, MV_WITH_BINARY, MV_WITH_FDE, MV_WITH_FP8, MV_WITH_HOST_EXACT, MV_WITH_EXACT_SPLIT = 1, 2, 4, 8, 16, 32
 MV_OPT_MAXSIM_VARIANT, MV_OPT_FDE_COARSE_N, MV_OPT_FDE_COSINE, MV_OPT_PAD_SEMANTICS, MV_OPT_BINARY_VARIANT, MV_OPT_FDE_SCAN_VARIANT = 1, 2, 3, 4, 5, 6
 MV_OPT_BATCH_VARIANT = 7
 MV_OPT_FDE_ENCODE_VARIANT = 8
@@ -97,7 +97,7 @@ class CandRecC(C.Structure):
 MV_ABI_VERSION = 5  # include/mvmaxsim.h: the header revision this binding's argument lists were written against
 
 EXPORTS = [
-    "mv_abi_version", "mv_last_error", "mv_version", "mv_device_count", "mv_host_pin_budget_bytes", "mv_index_create", "mv_index_destroy", "mv_index_set_option",
+    "mv_abi_version", "mv_last_error", "mv_version", "mv_device_count", "mv_host_pin_budget_bytes", "mv_index_exact_hbm_pages", "mv_index_create", "mv_index_destroy", "mv_index_set_option",
     "mv_index_size", "mv_index_capacity", "mv_index_add", "mv_index_add_device", "mv_index_add_bits", "mv_index_remove_doc",
     "mv_index_remove_page", "mv_index_compact", "mv_index_read_pages", "mv_index_write_rows", "mv_index_replace_page", "mv_index_read_fp8", "mv_index_fill_synthetic", "mv_synth_rows",
     "mv_query_topk", "mv_query_topk_device", "mv_query_topk_batch", "mv_merge_topk", "mv_score_all", "mv_score_candidates", "mv_score_candidates_pads", "mv_index_page_rows",
@@ -152,6 +152,8 @@ def lib() -> C.CDLL:
         L.mv_version.restype = C.c_char_p
         L.mv_device_count.restype = C.c_int
         L.mv_host_pin_budget_bytes.restype = C.c_int64
+        L.mv_index_exact_hbm_pages.restype = C.c_int64
+        L.mv_index_exact_hbm_pages.argtypes = [C.c_void_p]
         L.mv_index_create.argtypes = [C.POINTER(ConfigC), C.POINTER(vp)]
         L.mv_index_destroy.argtypes = [vp]
         L.mv_index_destroy.restype = None

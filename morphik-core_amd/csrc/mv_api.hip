@@ -349,9 +349,107 @@ int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_wo
 
 // Exact rerank of the candidate list in d_cand / d_cand_pads (built by launch_cand_prepare or the owned-select kernel).
 // The candidates were named explicitly or chosen from live, allowed pages: no mask is applied.
-int rerank_scan(mv_index* ix, int n_q, bool use_fp8, int64_t n_items, float* d_out, int* launches, const uint16_t* exact) {
-  return use_fp8 ? fp8_scan(ix, n_q, nullptr, 0, ix->d_cand, n_items, 0, ix->d_cand_pads, d_out, launches, /*no_mask=*/true)
-                 : float_scan(ix, n_q, nullptr, 0, ix->d_cand, n_items, 0, ix->d_cand_pads, d_out, launches, /*no_mask=*/true, nullptr, exact);
+int rerank_scan(mv_index* ix, int n_q, int tier, int64_t n_items, float* d_out, int* launches) {
+  if (tier == kTierFp8) return fp8_scan(ix, n_q, nullptr, 0, ix->d_cand, n_items, 0, ix->d_cand_pads, d_out, launches, /*no_mask=*/true);
+  return exact_scan(ix, n_q, tier, ix->d_cand, n_items, 0, ix->d_cand_pads, d_out, launches);
+}
+
+// ---- the exact host tier, possibly split: pages [0, x_split) in HBM (slab_x), pages [x_split, capacity) in pinned host memory
+__global__ __launch_bounds__(256) void split_cand_kernel(const int32_t* cand, int64_t n, int32_t split, int32_t* lo, int32_t* hi) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int32_t c = cand[i];
+  lo[i] = (c >= 0 && c < split) ? c : -1;
+  hi[i] = c >= split ? c : -1;
+}
+__global__ __launch_bounds__(256) void max_scores_kernel(float* dst, const float* src, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = fmaxf(dst[i], src[i]);  // every entry was scored by exactly one part; the other wrote -inf
+}
+static inline size_t page_elems(const mv_index* ix) { return (size_t)ix->cfg.stride_rows * kDim; }
+// base pointer that makes `base + page * stride * 128` the rows of page >= x_split in the host part
+static inline const uint16_t* xt_host_vbase(const mv_index* ix) { return ix->d_exact - (size_t)ix->x_split * page_elems(ix); }
+
+int ensure_split_ws(mv_index* ix) {
+  if (!ix->d_xcand) MV_HIP(hipMalloc(&ix->d_xcand, (size_t)2 * kMaxCand * 4));
+  if (!ix->d_xscores) MV_HIP(hipMalloc(&ix->d_xscores, (size_t)kMaxCand * 4));
+  return MV_OK;
+}
+
+int exact_scan(mv_index* ix, int n_q, int tier, const int32_t* d_cand, int64_t n_items, int32_t pad_to, const int32_t* d_pad_items, float* d_out,
+               int* launches, const uint16_t* d_q_base) {
+  if (n_items <= 0) return MV_OK;
+  if (tier == kTierSlab) return float_scan(ix, n_q, nullptr, 0, d_cand, n_items, pad_to, d_pad_items, d_out, launches, /*no_mask=*/true, d_q_base, ix->slab);
+  const int64_t cap = ix->cfg.capacity_pages;
+  if (ix->x_split <= 0) return float_scan(ix, n_q, nullptr, 0, d_cand, n_items, pad_to, d_pad_items, d_out, launches, true, d_q_base, ix->d_exact);
+  if (ix->x_split >= cap) return float_scan(ix, n_q, nullptr, 0, d_cand, n_items, pad_to, d_pad_items, d_out, launches, true, d_q_base, ix->slab_x);
+  // split tier: the candidates of each part against that part's base, two launches, merged (an entry is -1 in exactly one of the two lists)
+  if (n_items > kMaxCand) { set_error("exact_scan: %lld candidates exceed %d", (long long)n_items, kMaxCand); return MV_ERR_INVALID; }
+  int rc = ensure_split_ws(ix);
+  if (rc) return rc;
+  int32_t* lo = ix->d_xcand;
+  int32_t* hi = ix->d_xcand + kMaxCand;
+  const unsigned gb = (unsigned)((n_items + 255) / 256);
+  hipLaunchKernelGGL(split_cand_kernel, dim3(gb), dim3(256), 0, ix->stream, d_cand, n_items, (int32_t)ix->x_split, lo, hi);
+  rc = float_scan(ix, n_q, nullptr, 0, lo, n_items, pad_to, d_pad_items, d_out, launches, true, d_q_base, ix->slab_x);
+  if (rc) return rc;
+  rc = float_scan(ix, n_q, nullptr, 0, hi, n_items, pad_to, d_pad_items, ix->d_xscores, launches, true, d_q_base, xt_host_vbase(ix));
+  if (rc) return rc;
+  hipLaunchKernelGGL(max_scores_kernel, dim3(gb), dim3(256), 0, ix->stream, d_out, (const float*)ix->d_xscores, n_items);
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
+// Store the fixed-stride bf16 image of pages [first, first + n) (device memory `d_src`) into the exact host tier on `st`.
+int xt_store_from_device(mv_index* ix, const uint16_t* d_src, int64_t first, int64_t n, hipStream_t st) {
+  if (!ix->h_exact && !ix->slab_x) return MV_OK;
+  const size_t pe = page_elems(ix);
+  const int64_t n_hbm = std::max<int64_t>(0, std::min<int64_t>(first + n, ix->x_split) - first);  // leading pages of the range that fall into the HBM part
+  if (n_hbm > 0) MV_HIP(hipMemcpyAsync(ix->slab_x + (size_t)first * pe, d_src, (size_t)n_hbm * pe * 2, hipMemcpyDeviceToDevice, st));
+  if (n > n_hbm) MV_HIP(hipMemcpyAsync(ix->h_exact + (size_t)(first + n_hbm - ix->x_split) * pe, d_src + (size_t)n_hbm * pe, (size_t)(n - n_hbm) * pe * 2, hipMemcpyDeviceToHost, st));
+  return MV_OK;
+}
+// Overwrite rows [row0, row0 + n_rows) of one page from HOST bf16 rows (zero_rest: the page's other rows become zero).
+int xt_store_rows_from_host(mv_index* ix, int64_t page, int32_t row0, int32_t n_rows, const void* bf16_rows, bool zero_rest) {
+  if (!ix->h_exact && !ix->slab_x) return MV_OK;
+  const size_t pe = page_elems(ix);
+  if (page < ix->x_split) {
+    uint16_t* dst = ix->slab_x + (size_t)page * pe;
+    if (zero_rest) MV_HIP(hipMemsetAsync(dst, 0, pe * 2, ix->stream));
+    if (n_rows > 0) MV_HIP(hipMemcpyAsync(dst + (size_t)row0 * kDim, bf16_rows, (size_t)n_rows * kRowBytes, hipMemcpyHostToDevice, ix->stream));
+    MV_HIP(hipStreamSynchronize(ix->stream));  // the caller's buffer may be pageable
+  } else {
+    uint16_t* dst = ix->h_exact + (size_t)(page - ix->x_split) * pe;
+    if (zero_rest) memset(dst, 0, pe * 2);
+    if (n_rows > 0) memcpy(dst + (size_t)row0 * kDim, bf16_rows, (size_t)n_rows * kRowBytes);
+  }
+  return MV_OK;
+}
+// Copy whole pages [page0, page0 + n) of the tier to a HOST buffer.
+int xt_read_pages(mv_index* ix, int64_t page0, int64_t n, void* out) {
+  const size_t pe = page_elems(ix);
+  const int64_t n_hbm = std::max<int64_t>(0, std::min<int64_t>(page0 + n, ix->x_split) - page0);
+  if (n_hbm > 0) MV_HIP(hipMemcpy(out, ix->slab_x + (size_t)page0 * pe, (size_t)n_hbm * pe * 2, hipMemcpyDeviceToHost));
+  if (n > n_hbm) memcpy((char*)out + (size_t)n_hbm * pe * 2, ix->h_exact + (size_t)(page0 + n_hbm - ix->x_split) * pe, (size_t)(n - n_hbm) * pe * 2);
+  return MV_OK;
+}
+// Compaction of the tier: page live[j] moves to slot j for j in [first_moved, m) (live ascending, live[j] >= j: a destination is
+// never a page still to be read).  Device destinations are stream-ordered copies (from the HBM part or up from the pinned part),
+// then the host part moves with memmove.
+int xt_compact(mv_index* ix, const std::vector<int64_t>& live, int64_t first_moved, int64_t m) {
+  if (!ix->h_exact && !ix->slab_x) return MV_OK;
+  const size_t pe = page_elems(ix), pb = pe * 2;
+  const int64_t sp = ix->x_split;
+  for (int64_t j = first_moved; j < std::min(m, sp); ++j) {
+    const int64_t src = live[(size_t)j];
+    if (src == j) continue;
+    if (src < sp) MV_HIP(hipMemcpyAsync(ix->slab_x + (size_t)j * pe, ix->slab_x + (size_t)src * pe, pb, hipMemcpyDeviceToDevice, ix->stream));
+    else MV_HIP(hipMemcpyAsync(ix->slab_x + (size_t)j * pe, ix->h_exact + (size_t)(src - sp) * pe, pb, hipMemcpyHostToDevice, ix->stream));
+  }
+  MV_HIP(hipStreamSynchronize(ix->stream));  // before the host part below overwrites pages the copies above read
+  for (int64_t j = std::max(first_moved, sp); j < m; ++j)
+    if (live[(size_t)j] != j) memmove(ix->h_exact + (size_t)(j - sp) * pe, ix->h_exact + (size_t)(live[(size_t)j] - sp) * pe, pb);
+  return MV_OK;
 }
 
 // The tier a rerank reads and whether an e4m3 stage prunes the list first (mv_index_priv.h).  One rule for every entry point
@@ -360,10 +458,10 @@ RerankPlan rerank_plan(const mv_index* ix, int mode, int64_t n_list, int32_t k, 
   RerankPlan p;
   const int fl = ix->cfg.flags;
   const bool force_fp8 = ix->exact_tier == 2 && (fl & MV_WITH_FP8) && mode != MV_MODE_FP8_THEN_FLOAT;  // MV_OPT_EXACT_TIER 2: score on the e4m3 slab although an exact tier exists
-  const bool host = !force_fp8 && ix->d_exact != nullptr && (!(fl & MV_WITH_FLOAT) || ix->exact_tier == 1);
+  const bool host = !force_fp8 && (fl & MV_WITH_HOST_EXACT) && (!(fl & MV_WITH_FLOAT) || ix->exact_tier == 1);
   p.host_tier = host;
-  p.exact = force_fp8 ? nullptr : (host ? ix->d_exact : ((fl & MV_WITH_FLOAT) ? ix->slab : nullptr));
-  p.final_fp8 = p.exact == nullptr;
+  p.final_fp8 = force_fp8 || (!host && !(fl & MV_WITH_FLOAT));
+  p.tier = p.final_fp8 ? kTierFp8 : (host ? kTierHost : kTierSlab);
   const int64_t n_mid = std::max<int64_t>(ix->rerank_n, k);
   // the e4m3 scan of MV_MODE_FP8_THEN_FLOAT already was the pruning stage; the one-launch e4m3 rerank of a batch takes <= 64 rows
   p.mid = mode == MV_MODE_FDE_THEN_FLOAT && host && (fl & MV_WITH_FP8) && n_list > n_mid && (!batched || rpq <= 64);
@@ -489,8 +587,8 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
       rc = launch_cand_prepare(ix, ix->d_out_id, nullptr, (int)nc, /*pad_sem=*/0);  // a full-corpus scan has no padding rows
       if (rc) return rc;
       if (st) MV_HIP(hipEventRecord(ix->ev_st[2], ix->stream));
-      const uint16_t* exact = rerank_plan(ix, mode, nc, k_final, ((n_q + 15) / 16) * 16, false).exact;
-      rc = float_scan(ix, n_q, nullptr, 0, ix->d_cand, nc, 0, ix->d_cand_pads, ix->d_cand_scores, &out->launches, /*no_mask=*/true, nullptr, exact);
+      rc = exact_scan(ix, n_q, rerank_plan(ix, mode, nc, k_final, ((n_q + 15) / 16) * 16, false).tier, ix->d_cand, nc, 0, ix->d_cand_pads, ix->d_cand_scores,
+                      &out->launches);
       if (rc) return rc;
       out->launches += 2;
       out->n = nc; out->d_ids_map = ix->d_cand; out->d_scores = ix->d_cand_scores;
@@ -539,7 +637,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
         // every other entry of the list becomes -1; the list keeps its order, so the pad lengths (the reference's batches of
         // 128 over the WHOLE coarse list) and the tie rule (coarse rank) are those of the direct rerank
         if (st) MV_HIP(hipMemcpyAsync(ix->h_cand + kTopkMaxDeviceK, ix->d_cand, (size_t)nc * 4, hipMemcpyDeviceToHost, ix->stream));
-        rc = rerank_scan(ix, n_q, /*use_fp8=*/true, nc, ix->d_cand_scores, &out->launches);
+        rc = rerank_scan(ix, n_q, kTierFp8, nc, ix->d_cand_scores, &out->launches);
         if (rc) return rc;
         rc = launch_topk(ix->d_cand_scores, nc, plan.n_mid, nullptr, 0, ix->d_topk_ws, ix->d_out_s, ix->d_sel_pos, ix->stream);
         if (rc) return rc;
@@ -547,7 +645,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
         if (rc) return rc;
         out->launches += 2;
       }
-      rc = rerank_scan(ix, n_q, rerank_fp8, nc, ix->d_cand_scores, &out->launches, plan.exact);
+      rc = rerank_scan(ix, n_q, plan.tier, nc, ix->d_cand_scores, &out->launches);
       if (rc) return rc;
       out->launches += 1;
       out->n = nc;
@@ -675,10 +773,7 @@ int add_pages_common(mv_index* ix, const void* d_src, int dtype, const int32_t* 
   const bool check_finite = (ix->cfg.flags & ~MV_WITH_BINARY) != 0;
   if (check_finite) MV_HIP(hipMemsetAsync(ix->d_w_flag, 0, 4, ws));
   rc = launch_scatter_rows(d_src, dtype, d_off, n_pages, stride, slab_dst, ws, check_finite ? ix->d_w_flag : nullptr);
-  if (!rc && ix->h_exact) {  // exact tier in pinned host memory: the fixed-stride bf16 image, slot for slot
-    hipError_t he = hipMemcpyAsync(ix->h_exact + (size_t)first * stride * kDim, slab_dst, (size_t)n_pages * stride * kRowBytes, hipMemcpyDeviceToHost, ws);
-    if (he != hipSuccess) rc = hip_fail(he, "D2H of the exact tier", __FILE__, __LINE__);
-  }
+  if (!rc) rc = xt_store_from_device(ix, slab_dst, first, n_pages, ws);  // exact host tier (pinned host memory, or split with HBM): the fixed-stride bf16 image, slot for slot
   if (!rc && (ix->cfg.flags & MV_WITH_BINARY)) {
     // sign bits come from the bf16 image: bf16 RNE preserves sign and zero-ness of every fp32 value
     // that is not an fp32 subnormal rounding to zero; fp32 inputs are packed from the fp32 rows below.
@@ -863,7 +958,7 @@ void mv_index_destroy(mv_index* ix) {
   DeviceGuard g(ix->cfg.device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
   if (ix->w_stream) (void)hipStreamSynchronize(ix->w_stream);
-  void* ptrs[] = {ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
+  void* ptrs[] = {ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
                   ix->d_topk_ws, ix->d_q, ix->d_qf32, ix->d_qbits, ix->d_qpop, ix->d_qfde, ix->d_qoff, ix->d_allow, ix->d_out_s,
                   ix->d_out_id, ix->d_cand, ix->d_cand_scores, ix->d_bqf32, ix->d_bqfde, ix->d_bqimage, ix->d_btopk_ws, ix->d_bsel_s,
                   ix->d_bsel_id, ix->d_bcand, ix->d_bcand_pads, ix->d_bcand_scores, ix->d_bout_s, ix->d_bout_id, ix->d_bq8hi, ix->d_bq8lo, ix->d_bq8fac};
@@ -876,7 +971,7 @@ void mv_index_destroy(mv_index* ix) {
     if (e) (void)hipEventDestroy(e);
   if (ix->ev_stage) (void)hipEventDestroy(ix->ev_stage);
   for (void* hp : {(void*)ix->h_qf32, (void*)ix->h_qbf16, (void*)ix->h_out_s, (void*)ix->h_out_id, (void*)ix->h_cand, (void*)ix->h_bout_s,
-                   (void*)ix->h_bout_id, (void*)ix->h_bcand, (void*)ix->h_exact})
+                   (void*)ix->h_bout_id, (void*)ix->h_bcand, (void*)ix->h_exact})  // (slab_x, the HBM part of a split exact tier, went with ptrs[])
     if (hp) (void)hipHostFree(hp);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
   if (ix->w_stream) (void)hipStreamDestroy(ix->w_stream);
@@ -890,6 +985,9 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   if (cfg->stride_rows < 16 || cfg->stride_rows % 16) { set_error("stride_rows must be a positive multiple of 16 (got %d)", cfg->stride_rows); return MV_ERR_INVALID; }
   if (cfg->capacity_pages < 1 || cfg->capacity_pages > 0x7fffffffLL) { set_error("capacity_pages out of range"); return MV_ERR_INVALID; }
   if (!(cfg->flags & (MV_WITH_FLOAT | MV_WITH_BINARY | MV_WITH_FDE | MV_WITH_FP8))) { set_error("flags select no slab"); return MV_ERR_INVALID; }
+  if ((cfg->flags & MV_WITH_EXACT_SPLIT) && (!(cfg->flags & MV_WITH_HOST_EXACT) || (cfg->flags & MV_WITH_FLOAT))) {
+    set_error("MV_WITH_EXACT_SPLIT splits the host exact tier: it needs MV_WITH_HOST_EXACT and no MV_WITH_FLOAT"); return MV_ERR_INVALID;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device available (libmvmaxsim requires an MI355X / gfx950 GPU)"); return MV_ERR_HIP; }
   if (cfg->device < 0 || cfg->device >= ndev) { set_error("device %d out of range (have %d)", cfg->device, ndev); return MV_ERR_INVALID; }
@@ -920,22 +1018,6 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
               hipHostMalloc((void**)&ix->h_out_id, (size_t)kTopkMaxDeviceK * 8, hipHostMallocDefault) != hipSuccess ||
               hipHostMalloc((void**)&ix->h_cand, (size_t)2 * kTopkMaxDeviceK * 4, hipHostMallocDefault) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = MV_ERR_NOMEM; }
   if (cfg->flags & MV_WITH_FLOAT) alloc((void**)&ix->slab, rows * kRowBytes + 32768, "bf16 page slab");  // +32 KiB: the batched scans DMA whole 16 / 32 KiB chunks
-  if (!rc && (cfg->flags & MV_WITH_HOST_EXACT)) {
-    const int64_t budget = host_pin_budget_bytes();
-    if ((int64_t)(rows * kRowBytes + 32768) > budget) {
-      // refuse BEFORE pinning: a container past its memory cgroup limit is killed, not told
-      set_error("the pinned-host exact tier needs %zu bytes (%lld pages x %d rows x 256 B) but this process may pin only %lld more "
-                "(memory cgroup limit / MemAvailable minus headroom; mv_host_pin_budget_bytes()): use fewer pages per shard or raise the container's memory limit",
-                rows * kRowBytes, (long long)cap, cfg->stride_rows, (long long)budget);
-      rc = MV_ERR_NOMEM;
-    }
-  }
-  if (!rc && (cfg->flags & MV_WITH_HOST_EXACT)) {
-    // pinned + mapped: the rerank kernel reads the candidates' rows straight out of host RAM (+32 KiB: whole DMA chunks)
-    hipError_t e = hipHostMalloc((void**)&ix->h_exact, rows * kRowBytes + 32768, hipHostMallocMapped | hipHostMallocPortable);
-    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&ix->d_exact, ix->h_exact, 0);
-    if (e != hipSuccess) { set_error("pinned host allocation of %zu bytes for the exact tier failed: %s", rows * kRowBytes, hipGetErrorString(e)); rc = MV_ERR_NOMEM; }
-  }
   if (cfg->flags & MV_WITH_FP8) {
     alloc((void**)&ix->slab8, rows * kDim + 4096, "fp8 page slab");  // +4 KiB: the scan DMAs whole 4 KiB pieces
     alloc((void**)&ix->inv_scale8, (size_t)cap * 4, "fp8 page scales");
@@ -968,6 +1050,39 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
     ix->h_doc_ord.assign((size_t)cap, -1);
     rc = ensure_query_cap(ix, 64);
   }
+  if (!rc && (cfg->flags & MV_WITH_HOST_EXACT)) {
+    // The exact host tier, allocated LAST.  MV_WITH_EXACT_SPLIT: as many leading pages as the HBM left over by the other slabs
+    // holds (minus MV_EXACT_HBM_RESERVE_BYTES, default 12 GiB, for the lazily sized batch workspaces and the caller's own
+    // device memory) keep their exact rows on the device; only the rest is pinned.
+    const size_t page_b = (size_t)cfg->stride_rows * kRowBytes;
+    if (cfg->flags & MV_WITH_EXACT_SPLIT) {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { set_error("hipMemGetInfo failed"); rc = MV_ERR_HIP; }
+      int64_t reserve = (int64_t)12 << 30;
+      if (const char* e = getenv("MV_EXACT_HBM_RESERVE_BYTES")) reserve = std::max<int64_t>(0, (int64_t)strtoll(e, nullptr, 10));
+      int64_t split = ((int64_t)free_b - reserve - 32768) / (int64_t)page_b;
+      if (const char* e = getenv("MV_EXACT_HBM_MAX_PAGES")) split = std::min<int64_t>(split, (int64_t)strtoll(e, nullptr, 10));  // (tests: force a split on a small index)
+      ix->x_split = std::max<int64_t>(0, std::min<int64_t>(cap, split));
+      if (ix->x_split > 0) alloc((void**)&ix->slab_x, (size_t)ix->x_split * page_b + 32768, "HBM part of the exact tier");  // +32 KiB: whole DMA chunks
+    }
+    const size_t host_b = (size_t)(cap - ix->x_split) * page_b;
+    if (!rc && host_b) {
+      const int64_t budget = host_pin_budget_bytes();
+      if ((int64_t)(host_b + 32768) > budget) {
+        // refuse BEFORE pinning: a container past its memory cgroup limit is killed, not told
+        set_error("the pinned-host exact tier needs %zu bytes (%lld pages x %d rows x 256 B%s) but this process may pin only %lld more "
+                  "(memory cgroup limit / MemAvailable minus headroom; mv_host_pin_budget_bytes()): use fewer pages per shard, MV_WITH_EXACT_SPLIT, or raise the container's memory limit",
+                  host_b, (long long)(cap - ix->x_split), cfg->stride_rows, ix->x_split ? "; the rest is in HBM" : "", (long long)budget);
+        rc = MV_ERR_NOMEM;
+      }
+    }
+    if (!rc && host_b) {
+      // pinned + mapped: the rerank kernel reads the candidates' rows straight out of host RAM (+32 KiB: whole DMA chunks)
+      hipError_t e = hipHostMalloc((void**)&ix->h_exact, host_b + 32768, hipHostMallocMapped | hipHostMallocPortable);
+      if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&ix->d_exact, ix->h_exact, 0);
+      if (e != hipSuccess) { set_error("pinned host allocation of %zu bytes for the exact tier failed: %s", host_b, hipGetErrorString(e)); rc = MV_ERR_NOMEM; }
+    }
+  }
   if (rc) {
     std::string keep = g_err;
     mv_index_destroy(ix);
@@ -977,6 +1092,8 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   *out = ix;
   return MV_OK;
 }
+
+int64_t mv_index_exact_hbm_pages(const mv_index* ix) { return ix ? ix->x_split : 0; }
 
 int mv_index_set_option(mv_index* ix, int option, int64_t value) {
   if (!ix) { set_error("null index"); return MV_ERR_INVALID; }
@@ -1138,7 +1255,7 @@ int mv_index_read_pages(mv_index* ix, int64_t page0, int64_t n_pages, void* out_
   std::lock_guard<std::mutex> lk(ix->q_mu);
   DeviceGuard g(ix->cfg.device);
   const size_t pb = (size_t)ix->cfg.stride_rows * kRowBytes;
-  if (!(ix->cfg.flags & MV_WITH_FLOAT)) { memcpy(out_bf16, (const char*)ix->h_exact + (size_t)page0 * pb, (size_t)n_pages * pb); return MV_OK; }  // exact tier
+  if (!(ix->cfg.flags & MV_WITH_FLOAT)) return xt_read_pages(ix, page0, n_pages, out_bf16);  // exact host tier
   MV_HIP(hipMemcpy(out_bf16, (const char*)ix->slab + (size_t)page0 * pb, (size_t)n_pages * pb, hipMemcpyDeviceToHost));
   return MV_OK;
 }
@@ -1149,7 +1266,7 @@ int mv_index_write_rows(mv_index* ix, int64_t page, int32_t row0, int32_t n, con
   if (!host_rows_finite(bf16_rows, MV_BF16, (size_t)n * kDim)) { set_error("write_rows: a row holds a NaN / Inf"); return MV_ERR_INVALID; }
   ExclusiveLock lk(ix);
   DeviceGuard g(ix->cfg.device);
-  if (ix->h_exact) memcpy((char*)ix->h_exact + ((size_t)page * ix->cfg.stride_rows + row0) * kRowBytes, bf16_rows, (size_t)n * kRowBytes);
+  if (int rc = xt_store_rows_from_host(ix, page, row0, n, bf16_rows, /*zero_rest=*/false)) return rc;
   if (!(ix->cfg.flags & MV_WITH_FLOAT)) return MV_OK;
   char* dst = (char*)ix->slab + ((size_t)page * ix->cfg.stride_rows + row0) * kRowBytes;
   MV_HIP(hipMemcpy(dst, bf16_rows, (size_t)n * kRowBytes, hipMemcpyHostToDevice));
@@ -1212,9 +1329,7 @@ int mv_index_fill_synthetic(mv_index* ix, uint64_t seed, uint64_t first_unit, in
     const int64_t c = std::min(chunk, n_pages - done);
     uint16_t* dst = has_float ? ix->slab + (size_t)(first + done) * stride * kDim : (uint16_t*)ix->w_tmp;
     rc = launch_synth_rows(dst, seed, first_unit + (uint64_t)done, c, n_rows, stride, ws);
-    if (!rc && ix->h_exact && hipMemcpyAsync(ix->h_exact + (size_t)(first + done) * stride * kDim, dst, (size_t)c * stride * kRowBytes, hipMemcpyDeviceToHost, ws) != hipSuccess) {
-      set_error("fill_synthetic: D2H of the exact tier failed"); rc = MV_ERR_HIP;
-    }
+    if (!rc) rc = xt_store_from_device(ix, dst, first + done, c, ws);
     if (!rc) rc = derive_slabs_from_bf16(ix, dst, first + done, c, ix->d_n_rows + first + done, ws);
     if (!has_float && hipStreamSynchronize(ws) != hipSuccess && !rc) { set_error("fill_synthetic: stream error"); rc = MV_ERR_HIP; }
   }
@@ -1248,10 +1363,7 @@ int mv_index_replace_page(mv_index* ix, int64_t page, const void* bf16_rows, int
     e = hipMemcpyAsync(ix->d_n_rows + page, &ix->h_n_rows[page], 4, hipMemcpyHostToDevice, ix->stream);
     if (e != hipSuccess) rc = hip_fail(e, "replace_page metadata", __FILE__, __LINE__);
   }
-  if (!rc && ix->h_exact) {
-    memset(ix->h_exact + (size_t)page * stride * kDim, 0, (size_t)stride * kRowBytes);
-    if (n_rows > 0) memcpy(ix->h_exact + (size_t)page * stride * kDim, bf16_rows, (size_t)n_rows * kRowBytes);
-  }
+  if (!rc) rc = xt_store_rows_from_host(ix, page, 0, n_rows, bf16_rows, /*zero_rest=*/true);
   if (!rc) rc = derive_slabs_from_bf16(ix, dst, page, 1, ix->d_n_rows + page, ix->stream);
   (void)hipStreamSynchronize(ix->stream);
   if (stage) (void)hipFree(stage);
@@ -1329,10 +1441,7 @@ int mv_index_compact(mv_index* ix, int64_t* out_old_to_new, int64_t* out_new_siz
   if (d_idx) (void)hipFree(d_idx);
   if (stage) (void)hipFree(stage);
   if (rc) return rc;
-  if (ix->h_exact) {  // the exact tier moves with the pages (ascending: a destination is never a page still to be read)
-    const size_t pb = stride * kRowBytes;
-    for (int64_t j = first_moved; j < m; ++j) memmove((char*)ix->h_exact + (size_t)j * pb, (const char*)ix->h_exact + (size_t)live[j] * pb, pb);
-  }
+  if ((rc = xt_compact(ix, live, first_moved, m)) != MV_OK) return rc;  // the exact host tier moves with the pages
   for (int64_t j = first_moved; j < m; ++j) {
     ix->h_n_rows[(size_t)j] = ix->h_n_rows[(size_t)live[j]];
     ix->h_doc_ord[(size_t)j] = ix->h_doc_ord[(size_t)live[j]];
@@ -1579,11 +1688,14 @@ int mv_internal_batch_upload_queries(mv_index* ix, const void* q, int q_dtype, i
 // Exact rerank of the group's candidate lists d_bcand / d_bcand_pads ([nb][nc], list b against query b of the uploaded
 // group) into d_bcand_scores: ONE launch for all lists where the kernels allow it (fp8 slab; bf16 slab with the default
 // kernels and queries of <= 128 rows), else one launch per query.  q_mu held.
-int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t nc, int* launches, const uint16_t* exact, float* d_out) {
-  // exact != null: rerank on THAT bf16 image (the HBM slab or the pinned-host exact tier); null: on the e4m3 slab
+int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t nc, int* launches, int tier, float* d_out) {
+  // tier: the bf16 slab in HBM, the exact host tier (pinned host memory, possibly split with HBM), or the e4m3 slab
   const int rpq = ((n_q_rows + 15) / 16) * 16;
   const int64_t L = nc;
-  const bool rerank_fp8 = exact == nullptr;
+  const bool rerank_fp8 = tier == kTierFp8;
+  const int64_t cap = ix->cfg.capacity_pages;
+  const bool split = tier == kTierHost && ix->x_split > 0 && ix->x_split < cap;
+  const uint16_t* exact = tier == kTierSlab ? ix->slab : (ix->x_split >= cap ? ix->slab_x : ix->d_exact);
   float* dst = d_out ? d_out : ix->d_bcand_scores;
   const int rr_variant = ix->maxsim_variant < 0 ? maxsim_default_variant(ix->cfg.stride_rows) : ix->maxsim_variant;
   const bool rerank_one_launch = rerank_fp8 || (rpq <= kMaxQRowsPerPass && (rr_variant == 6 || rr_variant == 7));
@@ -1598,17 +1710,34 @@ int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t n
     if (rc) return rc;
     ++*launches;
   } else if (rerank_one_launch) {
+    const int64_t n = (int64_t)nb * nc;
     MaxsimArgs ma{};
     ma.slab = exact; ma.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr; ma.cand = ix->d_bcand; ma.q = ix->d_bq;
-    ma.scores = dst; ma.n = (int64_t)nb * nc; ma.stride = ix->cfg.stride_rows; ma.q_tiles = rpq / 16; ma.pad_to = 0;
+    ma.scores = dst; ma.n = n; ma.stride = ix->cfg.stride_rows; ma.q_tiles = rpq / 16; ma.pad_to = 0;
     ma.pad_items = ix->d_bcand_pads; ma.items_per_query = (int32_t)nc; ma.q_item_stride = rpq * kDim;
-    rc = launch_maxsim_bf16(ma, rr_variant, ix->stream);
-    if (rc) return rc;
-    ++*launches;
+    if (!split) {
+      rc = launch_maxsim_bf16(ma, rr_variant, ix->stream);
+      if (rc) return rc;
+      ++*launches;
+    } else {  // the lists of all queries split by tier part: one launch per part, merged
+      if (n > kMaxCand) { set_error("batched rerank: %lld list entries exceed %d", (long long)n, kMaxCand); return MV_ERR_INVALID; }
+      if ((rc = ensure_split_ws(ix)) != MV_OK) return rc;
+      int32_t* lo = ix->d_xcand;
+      int32_t* hi = ix->d_xcand + kMaxCand;
+      const unsigned gb = (unsigned)((n + 255) / 256);
+      hipLaunchKernelGGL(split_cand_kernel, dim3(gb), dim3(256), 0, ix->stream, (const int32_t*)ix->d_bcand, n, (int32_t)ix->x_split, lo, hi);
+      ma.slab = ix->slab_x; ma.cand = lo;
+      if ((rc = launch_maxsim_bf16(ma, rr_variant, ix->stream)) != MV_OK) return rc;
+      ma.slab = xt_host_vbase(ix); ma.cand = hi; ma.scores = ix->d_xscores;
+      if ((rc = launch_maxsim_bf16(ma, rr_variant, ix->stream)) != MV_OK) return rc;
+      hipLaunchKernelGGL(max_scores_kernel, dim3(gb), dim3(256), 0, ix->stream, dst, (const float*)ix->d_xscores, n);
+      MV_HIP(hipGetLastError());
+      *launches += 2;
+    }
   } else {
     for (int b = 0; b < nb; ++b) {  // one launch per query (long queries, non-default kernel variants)
-      rc = float_scan(ix, n_q_rows, nullptr, 0, ix->d_bcand + (size_t)b * L, nc, 0, ix->d_bcand_pads + (size_t)b * L,
-                      dst + (size_t)b * L, launches, /*no_mask=*/true, ix->d_bq + (size_t)b * rpq * kDim, exact);
+      rc = exact_scan(ix, n_q_rows, tier, ix->d_bcand + (size_t)b * L, nc, 0, ix->d_bcand_pads + (size_t)b * L, dst + (size_t)b * L, launches,
+                      ix->d_bq + (size_t)b * rpq * kDim);
       if (rc) return rc;
     }
   }
@@ -1698,14 +1827,14 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
       MV_HIP(hipEventRecord(ix->ev_st[2], ix->stream));
       if (stats) MV_HIP(hipMemcpyAsync(ix->h_bcand, ix->d_bcand, (size_t)nb * L * 4, hipMemcpyDeviceToHost, ix->stream));  // the lists as selected (accounting)
       if (plan.mid) {  // e4m3 scores of every list -> each list's n_mid best positions -> the rest of the list becomes -1
-        rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, nc, &launches, nullptr, nullptr);
+        rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, nc, &launches, kTierFp8, nullptr);
         if (rc) return rc;
         rc = launch_topk_batch(ix->d_bcand_scores, L, nc, plan.n_mid, nullptr, 0, 0, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bsel_s, ix->d_bsel_id, L, nb, ix->stream);
         if (rc) return rc;
         rc = launch_keep_selected(ix->d_bsel_id, L, plan.n_mid, ix->d_bcand, L, (int)nc, nb, ix->stream);
         if (rc) return rc;
       }
-      rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, nc, &launches, plan.exact, nullptr);
+      rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, nc, &launches, plan.tier, nullptr);
       if (rc) return rc;
       MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
       rc = launch_topk_batch(ix->d_bcand_scores, L, nc, k, ix->d_bcand, L, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bout_s, ix->d_bout_id, k,
@@ -1779,10 +1908,10 @@ static int fp8_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
   const int group = std::min(512 / rpq, 32);
   int rc = mv_internal_ensure_fp8_batch_ws(ix);
   if (rc) return rc;
-  const uint16_t* exact = nullptr;
+  int exact_tier = kTierSlab;
   int64_t nc = 0;
   if (two_tier) {
-    exact = rerank_plan(ix, MV_MODE_FP8_THEN_FLOAT, 0, k, rpq, true).exact;
+    exact_tier = rerank_plan(ix, MV_MODE_FP8_THEN_FLOAT, 0, k, rpq, true).tier;
     nc = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(std::max<int64_t>(ix->rerank_n, k), n), kTopkMaxDeviceK));
   }
   const bool per_query = allow_bits && allow_per_query;
@@ -1823,7 +1952,7 @@ static int fp8_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
                          ix->d_bcand, ix->d_bcand_pads, nc);
       MV_HIP(hipGetLastError());
       int launches = 0;
-      rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, nc, &launches, exact, nullptr);
+      rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, nc, &launches, exact_tier, nullptr);
       if (rc) return rc;
       MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
       rc = launch_topk_batch(ix->d_bcand_scores, nc, nc, k, ix->d_bcand, nc, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bout_s, ix->d_bout_id,
@@ -2033,8 +2162,7 @@ static int score_candidates_common(mv_index* ix, const void* q, int q_dtype, int
   }
   const bool per_item = pads || pad_to < 0;
   rc = use_fp8 ? fp8_scan(ix, n_q_rows, nullptr, 0, ix->d_cand, n_cand, per_item ? 0 : pad_to, per_item ? ix->d_cand_pads : nullptr, ix->d_cand_scores, &launches, true)
-               : float_scan(ix, n_q_rows, nullptr, 0, ix->d_cand, n_cand, per_item ? 0 : pad_to, per_item ? ix->d_cand_pads : nullptr, ix->d_cand_scores, &launches, true,
-                            nullptr, plan.exact);
+               : exact_scan(ix, n_q_rows, plan.tier, ix->d_cand, n_cand, per_item ? 0 : pad_to, per_item ? ix->d_cand_pads : nullptr, ix->d_cand_scores, &launches);
   if (rc) return rc;
   MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
   MV_HIP(hipMemcpyAsync(out_scores, ix->d_cand_scores, (size_t)n_cand * 4, hipMemcpyDeviceToHost, ix->stream));
@@ -2302,7 +2430,12 @@ int mv_index_save(mv_index* ix, const char* path) {
     dump(ix->slab8, rows * kDim);
     dump(ix->inv_scale8, (size_t)size * 4);
   }
-  if (ix->h_exact) wr(ix->h_exact, rows * kRowBytes);  // the pinned-host exact tier, last
+  if (ix->cfg.flags & MV_WITH_HOST_EXACT) {  // the exact host tier, last: ONE logical stream of pages whatever the split (a load may split elsewhere)
+    const size_t pb = (size_t)ix->cfg.stride_rows * kRowBytes;
+    const int64_t n_hbm = std::min<int64_t>(size, ix->x_split);
+    if (n_hbm > 0) dump(ix->slab_x, (size_t)n_hbm * pb);
+    if (size > n_hbm) wr(ix->h_exact, (size_t)(size - n_hbm) * pb);
+  }
   if (!rc && (fflush(f) != 0 || fsync(fileno(f)) != 0)) { set_error("flush failed for %s", tmp.c_str()); rc = MV_ERR_IO; }
   if (fclose(f) != 0 && !rc) { set_error("close failed for %s", tmp.c_str()); rc = MV_ERR_IO; }
   if (!rc && rename(tmp.c_str(), path) != 0) { set_error("cannot rename %s to %s", tmp.c_str(), path); rc = MV_ERR_IO; }
@@ -2351,7 +2484,12 @@ int mv_index_load(const char* path, int32_t device, mv_index** out) {
     fill(ix->slab8, rows * kDim);
     fill(ix->inv_scale8, (size_t)h.size * 4);
   }
-  if (ix->h_exact) rd(ix->h_exact, rows * kRowBytes);
+  if (h.cfg.flags & MV_WITH_HOST_EXACT) {  // this process's split, not the saver's
+    const size_t pb = (size_t)h.cfg.stride_rows * kRowBytes;
+    const int64_t n_hbm = std::min<int64_t>(h.size, ix->x_split);
+    if (n_hbm > 0) fill(ix->slab_x, (size_t)n_hbm * pb);
+    if (h.size > n_hbm) rd(ix->h_exact, (size_t)(h.size - n_hbm) * pb);
+  }
   fclose(f);
   if (!rc && h.size) {
     if (hipMemcpy(ix->d_n_rows, ix->h_n_rows.data(), (size_t)h.size * 4, hipMemcpyHostToDevice) != hipSuccess ||

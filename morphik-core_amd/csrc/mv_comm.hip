@@ -274,7 +274,7 @@ int mv_two_stage_mid_device(mv_index* ix, const void* q, int q_dtype, int32_t n_
   rc = global_owned_list(ix, mode, d_all_recs, world, n_coarse);
   if (rc) return rc;
   int launches = 0;
-  rc = rerank_scan(ix, n_q_rows, /*use_fp8=*/true, n_coarse, d_out_mid, &launches);  // -inf at the positions other shards own
+  rc = rerank_scan(ix, n_q_rows, kTierFp8, n_coarse, d_out_mid, &launches);  // -inf at the positions other shards own
   if (rc) return rc;
   return hand_back(ix, stream);
 }
@@ -310,7 +310,7 @@ int mv_two_stage_rerank_device(mv_index* ix, const void* q, int q_dtype, int32_t
     if (rc) return rc;
   }
   int launches = 0;
-  rc = rerank_scan(ix, n_q_rows, use_fp8, n_coarse, ix->d_cand_scores, &launches, plan.exact);
+  rc = rerank_scan(ix, n_q_rows, plan.tier, n_coarse, ix->d_cand_scores, &launches);
   if (rc) return rc;
   // local top-k of the owned candidates; equal scores resolve by coarse rank (the work index), as on one index
   rc = launch_topk(ix->d_cand_scores, n_coarse, k, ix->d_cand, ix->cfg.id_base, ix->d_topk_ws, d_out_scores, d_out_ids, ix->stream);
@@ -426,7 +426,7 @@ int mv_internal_two_stage_batch_mid(mv_index* ix, const void* q, int q_dtype, in
   rc = global_owned_lists_batch(ix, mode, nb, d_all_recs, world, n_coarse);
   if (rc) return rc;
   int launches = 0;
-  rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, n_coarse, &launches, nullptr, d_out_mid);
+  rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, n_coarse, &launches, kTierFp8, d_out_mid);
   if (rc) return rc;
   return hand_back(ix, stream);
 }
@@ -462,7 +462,7 @@ int mv_internal_two_stage_batch_rerank(mv_index* ix, const void* q, int q_dtype,
     if (rc) return rc;
   }
   int launches = 0;
-  rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, n_coarse, &launches, plan.exact, nullptr);
+  rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, n_coarse, &launches, plan.tier, nullptr);
   if (rc) return rc;
   // local top-k of the owned candidates of every request; equal scores resolve by coarse rank, as on one index
   rc = launch_topk_batch(ix->d_bcand_scores, n_coarse, n_coarse, k, ix->d_bcand, n_coarse, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, d_out_scores,

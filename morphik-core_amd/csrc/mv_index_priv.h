@@ -32,8 +32,12 @@ struct mv_index {
   uint8_t* bits = nullptr;
   uint16_t* fde = nullptr;
   float* fde_inv_norm = nullptr;
-  uint16_t* h_exact = nullptr;   // MV_WITH_HOST_EXACT: pinned host bf16 rows [capacity][stride][128] (+32 KiB), the exact tier
+  uint16_t* h_exact = nullptr;   // MV_WITH_HOST_EXACT: pinned host bf16 rows of pages [x_split, capacity) ([..][stride][128] + 32 KiB), the exact tier
   uint16_t* d_exact = nullptr;   // the same memory through the device's address space (hipHostGetDevicePointer)
+  uint16_t* slab_x = nullptr;    // MV_WITH_EXACT_SPLIT: the exact rows of pages [0, x_split) in HBM (what was free after the other slabs)
+  int64_t x_split = 0;           // pages of the exact tier that live in HBM (0: the whole tier is host memory)
+  int32_t* d_xcand = nullptr;    // [2][kMaxCand] a rerank list split by tier part (lazily allocated)
+  float* d_xscores = nullptr;    // [kMaxCand] scores of the second part
   uint8_t* slab8 = nullptr;      // e4m3 page slab [capacity][stride][128]
   float* inv_scale8 = nullptr;   // [capacity] 2^-e per page
   int32_t* d_n_rows = nullptr;
@@ -162,7 +166,12 @@ int upload_allow(mv_index* ix, const uint32_t* allow_bits, int64_t n_words, cons
 // histogram and *hist0_done tells the caller to pass that on to launch_topk.
 int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_words, int64_t n, int* launches, bool stage_events = false,
                     int32_t k_next = 0, bool* hist0_done = nullptr);
-int rerank_scan(mv_index* ix, int n_q, bool use_fp8, int64_t n_items, float* d_out, int* launches, const uint16_t* exact = nullptr);
+// exact rerank of the list in d_cand / d_cand_pads on `tier`
+int rerank_scan(mv_index* ix, int n_q, int tier, int64_t n_items, float* d_out, int* launches);
+// exact bf16 MaxSim of a candidate list on the bf16 slab (kTierSlab) or on the exact host tier (kTierHost): a tier split between HBM and
+// host memory is scored in two launches (each part's candidates against its own base) and merged
+int exact_scan(mv_index* ix, int n_q, int tier, const int32_t* d_cand, int64_t n_items, int32_t pad_to, const int32_t* d_pad_items, float* d_out,
+               int* launches, const uint16_t* d_q_base = nullptr);
 // e4m3 scan of pages 0..n_items-1 (or of the candidate list d_cand) with the query uploaded by upload_query(want_fp8)
 int fp8_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_words, const int32_t* d_cand, int64_t n_items,
              int32_t pad_to, const int32_t* d_pad_items, float* d_out, int* launches, bool no_mask = false);
@@ -170,12 +179,13 @@ int64_t coarse_n_for(const mv_index* ix, int k);
 
 // Which copy of the candidates' rows the rerank of a cascade reads (FastMultiVectorStore reranks with exact fp32 MaxSim on fp32
 // pages: fast_multivector_store.py:553-556, upcast at load :736,774), and whether an e4m3 stage prunes the list first.
-//   exact      bf16 rows of the exact tier: the HBM slab, or the pinned-host tier mapped into the device (MV_WITH_HOST_EXACT);
-//              null = the index keeps no exact copy: the e4m3 slab is the best it has (final_fp8)
+//   tier       the bf16 slab in HBM, or the exact host tier (MV_WITH_HOST_EXACT: pinned host memory mapped into the device; with
+//              MV_WITH_EXACT_SPLIT its leading pages sit in HBM), or -- the index keeps no exact copy -- the e4m3 slab (final_fp8)
 //   mid        the exact tier is host memory and the list is longer than MV_OPT_RERANK_N: the candidates are first re-scored on
 //              the e4m3 slab (HBM) and only the n_mid best of them (ties by list position) are read over PCIe
+enum { kTierSlab = 0, kTierHost = 1, kTierFp8 = 2 };  // what a rerank reads: the bf16 slab, the exact host tier (maybe split with HBM), the e4m3 slab
 struct RerankPlan {
-  const uint16_t* exact = nullptr;
+  int tier = kTierSlab;
   bool host_tier = false;
   bool final_fp8 = false;
   bool mid = false;
@@ -204,8 +214,8 @@ extern "C" int mv_internal_ensure_batch_select_ws(mv_index* ix);
 extern "C" int mv_internal_ensure_fde_batch_ws(mv_index* ix);
 extern "C" int mv_internal_ensure_fp8_batch_ws(mv_index* ix);
 extern "C" int mv_internal_batch_upload_queries(mv_index* ix, const void* q, int q_dtype, int nb, int n_q_rows, bool want_f32, bool want_bf16, bool want_fp8);
-// exact != null: bf16 rerank on that image (HBM slab or pinned-host tier); null: e4m3 rerank.  d_out null -> d_bcand_scores.
-extern "C" int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t nc, int* launches, const uint16_t* exact, float* d_out);
+// tier: kTierSlab / kTierHost (bf16 rerank on the slab / the exact host tier) or kTierFp8 (e4m3 rerank).  d_out null -> d_bcand_scores.
+extern "C" int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t nc, int* launches, int tier, float* d_out);
 
 extern "C" int mv_internal_query_common(mv_index* ix, const void* q, int q_dtype, int32_t n_q, int32_t k, int mode,
                                         const uint32_t* allow_bits, int64_t n_words, float* h_scores, int64_t* h_ids, int32_t* out_n,

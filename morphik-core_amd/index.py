@@ -26,6 +26,7 @@ from ._lib import (
     MV_WITH_FLOAT,
     MV_WITH_FP8,
     MV_WITH_HOST_EXACT,
+    MV_WITH_EXACT_SPLIT,
     ConfigC,
     FdeConfigC,
     QueryStatsC,
@@ -162,12 +163,15 @@ class MvIndex:
         id_base: int = 0,
         with_fp8: bool = False,
         with_host_exact: bool = False,
+        with_exact_split: bool = False,
     ):
         """with_host_exact: keep the exact bf16 rows in PINNED HOST memory (no HBM) as the exact tier of mode
-        "fp8_then_float" -- for shards whose bf16 slab does not fit beside the fp8 slab."""
+        "fp8_then_float" -- for shards whose bf16 slab does not fit beside the fp8 slab.
+        with_exact_split (with with_host_exact, without with_float): the exact rows of the first pages fill the HBM the other
+        slabs leave free, only the rest is pinned (exact_hbm_pages tells the split)."""
         self.fde_config = fde or FdeConfig()
         flags = ((MV_WITH_FLOAT if with_float else 0) | (MV_WITH_BINARY if with_binary else 0) | (MV_WITH_FDE if with_fde else 0)
-                 | (MV_WITH_FP8 if with_fp8 else 0) | (MV_WITH_HOST_EXACT if with_host_exact else 0))
+                 | (MV_WITH_FP8 if with_fp8 else 0) | (MV_WITH_HOST_EXACT if with_host_exact else 0) | (MV_WITH_EXACT_SPLIT if with_exact_split else 0))
         cfg = ConfigC(128, int(stride_rows), int(capacity_pages), int(device), flags, int(id_base), self.fde_config.to_c())
         h = C.c_void_p()
         check(lib().mv_index_create(C.byref(cfg), C.byref(h)))
@@ -176,6 +180,11 @@ class MvIndex:
         self.device = int(device)
         self.id_base = int(id_base)
         self.flags = flags
+
+    @property
+    def exact_hbm_pages(self) -> int:
+        """Pages of a split exact tier (with_exact_split) whose exact rows live in HBM; 0 without a split."""
+        return int(lib().mv_index_exact_hbm_pages(self._h))
 
     # -- lifecycle
     def close(self) -> None:

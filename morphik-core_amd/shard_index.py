@@ -17,7 +17,7 @@ import numpy as np
 class ShardedIndex:
     def __init__(self, capacity_pages: int, stride_rows: int, devices: Sequence[int], with_float: bool = True, with_binary: bool = False,
                  with_fde: bool = False, with_fp8: bool = False, fde=None, transport: str = "auto", id_base: int = 0,
-                 index_cls=None, comm_cls=None, with_host_exact: bool = False):
+                 index_cls=None, comm_cls=None, with_host_exact: bool = False, with_exact_split: bool = False):
         from .index import MvIndex, ShardComm
 
         index_cls = index_cls or MvIndex
@@ -31,6 +31,8 @@ class ShardedIndex:
         self.id_base = int(id_base)
         self.device = self.devices[0]
         extra = {"with_host_exact": True} if with_host_exact else {}  # every shard pins the exact rows of ITS pages (per / n of the corpus)
+        if with_exact_split:
+            extra["with_exact_split"] = True  # ... after filling the HBM its other slabs leave free
         self.shards = [
             index_cls(capacity_pages=self.per, stride_rows=stride_rows, device=d, with_float=with_float, with_binary=with_binary,
                       with_fde=with_fde, with_fp8=with_fp8, fde=fde, id_base=self.id_base + r * self.per, **extra)

@@ -109,8 +109,8 @@ class MI355XMultiVectorStore(BaseVectorStore):
         # HOST memory (262 KB / page of host RAM) with an e4m3 slab in HBM beside the FDE slab -- BASELINE configs[3]'s shard
         # shape (1.25 M pages / GPU: a bf16 slab would need 328 GB of HBM): the coarse candidates are reranked exactly out of
         # host RAM (lists longer than MV_OPT_RERANK_N through an e4m3 pruning stage first).  "fp8_then_float" always uses "host".
-        if exact_tier not in ("hbm", "host"):
-            raise ValueError(f"unknown exact_tier {exact_tier!r} (\"hbm\" or \"host\")")
+        if exact_tier not in ("hbm", "host", "split"):
+            raise ValueError(f"unknown exact_tier {exact_tier!r} (\"hbm\", \"host\" or \"split\")")
         self.exact_tier = exact_tier
         # pages read from the exact tier per request (MV_OPT_RERANK_N; 0 = the library's 128): the candidate list of "fp8_then_float",
         # the cut of the e4m3 pruning stage of "fde_then_float" over a host tier -- n x 256 KiB over PCIe per request
@@ -176,10 +176,11 @@ class MI355XMultiVectorStore(BaseVectorStore):
         # "fp8_then_float": e4m3 slab in HBM (131 KB / page) + the exact bf16 rows in PINNED HOST memory (262 KB / page of host
         # RAM): every page scanned in fp8, the top candidates re-scored exactly out of host RAM by the rerank kernel itself --
         # exact-scan answers for corpora whose bf16 slab does not fit the GPU (BASELINE configs[4] with recall 1.0)
-        host = self.mode == "fp8_then_float" or (self.mode == "fde_then_float" and self.exact_tier == "host")
+        # exact_tier "split": the host tier, with the exact rows of the leading pages in whatever HBM the other slabs leave free
+        host = self.mode == "fp8_then_float" or (self.mode == "fde_then_float" and self.exact_tier in ("host", "split"))
         return dict(with_float=self.mode == "float" or (self.mode == "fde_then_float" and not host), with_binary=self.mode == "binary",
                     with_fde=self.mode == "fde_then_float", with_fp8=self.mode in ("float_fp8", "fp8_then_float") or (self.mode == "fde_then_float" and host),
-                    **({"with_host_exact": True} if host else {}))
+                    **({"with_host_exact": True} if host else {}), **({"with_exact_split": True} if host and self.exact_tier == "split" else {}))
 
     def _make_index(self):
         if self._index_factory is not None:
@@ -893,14 +894,17 @@ class MI355XShardedFastMultiVectorStore(_ShardedMixin, MI355XFastMultiVectorStor
 
 def create_store(provider: str, **kw: Any) -> MI355XMultiVectorStore:
     """Factory for core/services_init.py: [multivector_store] provider =
-    "mi355x" | "mi355x_fast" | "mi355x_fast_host_exact" | "mi355x_float" | "mi355x_fp8_exact" | "mi355x_sharded" | "mi355x_sharded_fast" |
-    "mi355x_sharded_fast_host_exact" | "mi355x_sharded_float" | "mi355x_sharded_fp8_exact" | "mi355x_remote"."""
+    "mi355x" | "mi355x_fast" | "mi355x_fast_host_exact" | "mi355x_fast_split_exact" | "mi355x_float" | "mi355x_fp8_exact" | "mi355x_sharded" |
+    "mi355x_sharded_fast" | "mi355x_sharded_fast_host_exact" | "mi355x_sharded_fast_split_exact" | "mi355x_sharded_float" |
+    "mi355x_sharded_fp8_exact" | "mi355x_remote"."""
     if provider == "mi355x":
         return MI355XMultiVectorStore(**kw)
     if provider == "mi355x_fast":
         return MI355XFastMultiVectorStore(**kw)
     if provider == "mi355x_fast_host_exact":  # FDE + e4m3 slabs in HBM, exact bf16 rows in pinned host RAM (configs[3] shard shape)
         return MI355XFastMultiVectorStore(exact_tier="host", **kw)
+    if provider == "mi355x_fast_split_exact":  # the same, with the exact rows of the leading pages in the HBM the slabs leave free (1.25 M pages / GPU)
+        return MI355XFastMultiVectorStore(exact_tier="split", **kw)
     if provider == "mi355x_float":
         return MI355XMultiVectorStore(mode="float", **kw)
     if provider == "mi355x_fp8_exact":  # e4m3 slab in HBM + exact bf16 tier in pinned host RAM
@@ -911,6 +915,8 @@ def create_store(provider: str, **kw: Any) -> MI355XMultiVectorStore:
         return MI355XShardedFastMultiVectorStore(**kw)
     if provider == "mi355x_sharded_fast_host_exact":  # configs[3]: 10 M pages over 8 GPUs, every shard with its pinned-host exact tier
         return MI355XShardedFastMultiVectorStore(exact_tier="host", **kw)
+    if provider == "mi355x_sharded_fast_split_exact":  # configs[3] at full size: every shard splits its exact tier between its free HBM and pinned host memory
+        return MI355XShardedFastMultiVectorStore(exact_tier="split", **kw)
     if provider == "mi355x_sharded_float":
         return MI355XShardedMultiVectorStore(mode="float", **kw)
     if provider == "mi355x_sharded_fp8_exact":  # configs[4]: e4m3 scan of every shard -> GLOBAL top-n -> exact re-score from the owners' host tiers

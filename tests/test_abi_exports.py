@@ -98,3 +98,19 @@ def test_integration_md_binding_loads_and_fails_loudly_without_a_gpu():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no HIP device|MI355X"):
             ns["create"](16)
+
+
+def test_host_pin_budget_is_readable_without_a_gpu_and_honours_the_environment_cap(monkeypatch):
+    """mv_host_pin_budget_bytes(): what mv_index_create checks a pinned-host exact tier against BEFORE pinning (a container past its memory
+    cgroup limit is killed, not told).  No GPU needed: it reads the cgroup files and /proc/meminfo."""
+    from morphik_core_amd import _lib
+
+    L = _lib.lib()
+    b = int(L.mv_host_pin_budget_bytes())
+    assert b > 0
+    avail = [int(ln.split()[1]) * 1024 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable:")][0]
+    assert b <= avail  # never more than the machine has free; less when a cgroup limit is tighter
+    monkeypatch.setenv("MV_HOST_EXACT_MAX_BYTES", "123456789")
+    assert int(L.mv_host_pin_budget_bytes()) == min(123456789, b) or int(L.mv_host_pin_budget_bytes()) <= 123456789
+    monkeypatch.setenv("MV_HOST_EXACT_MAX_BYTES", "0")
+    assert int(L.mv_host_pin_budget_bytes()) == 0

@@ -329,9 +329,11 @@ def test_host_exact_tier_beyond_the_memory_budget_is_refused_before_pinning(monk
     ix.close()
 
 
-def test_exact_pipelines_at_shard_scale_return_float_oracle_scores():
+@pytest.mark.parametrize("split", [False, True])
+def test_exact_pipelines_at_shard_scale_return_float_oracle_scores(split):
     """configs[3] / [4] at (as much as this box allows of) their per-GPU shard shape: FDE + e4m3 slabs in HBM, the exact bf16 rows
-    of EVERY page in pinned host memory.  A 1.25 M-page shard needs 328 GB pinned; the page count is cut to HALF of what the
+    of EVERY page in pinned host memory -- or (split) in the free HBM first and pinned host memory for the rest, which is what
+    lets the FULL 1.25 M-page shard run inside the pool's 300 GiB containers.  A 1.25 M-page shard needs 328 GB pinned; the page count is cut to HALF of what the
     process may still pin (mv_host_pin_budget_bytes: the container's memory cgroup limit, 300 GiB on the MI355X pool) and to the
     free HBM.  The oracle cannot scan a corpus of this size, so the test checks size-independent properties: the planted top-10
     comes back in rank order from every exact pipeline, single and batched, with scores within 1e-3 of orc.maxsim_bf16 (the
@@ -344,15 +346,26 @@ def test_exact_pipelines_at_shard_scale_return_float_oracle_scores():
     patches, qt, k = 1024, 32, 10
     budget = int(_lib.lib().mv_host_pin_budget_bytes())
     free_b, _tot = torch.cuda.mem_get_info(0)
-    n = int(min(1_250_000, 0.5 * budget // (patches * 256), (free_b - (16 << 30)) // (patches * 128 + 20480 + 64 + 33 * 4)))
+    page_b, slab_b = patches * 256, patches * 128 + 20480 + 64 + 33 * 4
+    if not split:
+        n = int(min(1_250_000, 0.5 * budget // page_b, (free_b - (16 << 30)) // slab_b))
+    else:
+        # BASELINE configs[3]'s FULL shard: 1.25 M pages.  The FDE + e4m3 slabs take 190 GB of HBM, the exact rows of the leading
+        # pages fill what is left (minus the library's 12 GiB reserve), the rest is pinned -- at most 0.78 of the pin budget here
+        n = int(min(1_250_000, (free_b - (16 << 30)) // slab_b))
+        while n > 20_000 and (n - max(0, (free_b - n * slab_b - (13 << 30)) // page_b)) * page_b > 0.78 * budget:
+            n -= 10_000
     assert n >= 20_000, f"only {n} pages fit (pin budget {budget / 1e9:.0f} GB, free HBM {free_b / 1e9:.0f} GB)"
-    ix = _idx(capacity_pages=n, stride_rows=patches, with_float=False, with_fde=True, with_fp8=True, with_host_exact=True)
+    ix = _idx(capacity_pages=n, stride_rows=patches, with_float=False, with_fde=True, with_fp8=True, with_host_exact=True, with_exact_split=split)
+    if split:
+        assert 0 < ix.exact_hbm_pages < n and (n - ix.exact_hbm_pages) * page_b <= 0.8 * budget, (n, ix.exact_hbm_pages)
     ix.fill_synthetic(synth.SEED_CORPUS, 0, n, n_rows=patches)
     qs = [synth_rows(synth.SEED_QUERIES, qi, qt) for qi in range(6)]
     spec = synth.planted_spec(qs, n, patches, n_ranks=k)
     synth.plant_neighbours_any(ix, spec, synth.SEED_CORPUS, patches, 0, n)
     planted = [[p for (qq, _r, p, _a, _b) in spec if qq == qi] for qi in range(len(qs))]
-    print(f"shard-scale exact tier: {n} pages, {n * patches * 256 / 1e9:.0f} GB pinned (budget {budget / 1e9:.0f} GB)")
+    print(f"shard-scale exact tier: {n} pages, {ix.exact_hbm_pages * page_b / 1e9:.0f} GB of exact rows in HBM, {(n - ix.exact_hbm_pages) * page_b / 1e9:.0f} GB pinned "
+          f"(budget {budget / 1e9:.0f} GB)")
 
     def check(s, i, qi):
         assert i.tolist() == planted[qi], (qi, i.tolist(), planted[qi])
@@ -374,3 +387,193 @@ def test_exact_pipelines_at_shard_scale_return_float_oracle_scores():
     for qi, (s, i) in enumerate(ix.query_batch(qs, k, mode="fp8_then_float")):
         check(s, i, qi)
     ix.close()
+
+
+# ------------------------------------------------------------------ the SPLIT exact tier (MV_WITH_EXACT_SPLIT)
+class _SplitAt:
+    """MV_EXACT_HBM_MAX_PAGES for the creation of a small index: forces the split where a real shard's free HBM would put it."""
+
+    def __init__(self, pages):
+        self.pages = pages
+
+    def __enter__(self):
+        import os
+
+        self.prev = os.environ.get("MV_EXACT_HBM_MAX_PAGES")
+        os.environ["MV_EXACT_HBM_MAX_PAGES"] = str(self.pages)
+
+    def __exit__(self, *a):
+        import os
+
+        if self.prev is None:
+            os.environ.pop("MV_EXACT_HBM_MAX_PAGES", None)
+        else:
+            os.environ["MV_EXACT_HBM_MAX_PAGES"] = self.prev
+
+
+@pytest.mark.parametrize("split_at", [0, 137, 10_000])
+def test_split_exact_tier_answers_like_the_unsplit_tier(split_at):
+    """The exact tier split between HBM (pages [0, split)) and pinned host memory (the rest): every rerank entry point returns the
+    SAME scores and ids, bit for bit, as the unsplit host tier -- single queries (with and without the e4m3 pruning stage, with an
+    allow-list), batches (one-launch rerank and the per-query form of long queries), named candidates, the staged device entry
+    points.  split 0 = all host, 10 000 > capacity = all HBM."""
+    import torch
+
+    from morphik_core_amd import MvError, _lib
+    from morphik_core_amd.index import allow_bitmap
+
+    N, stride, k = 420, 48, 7
+    pages = _corpus(N, stride, seed=35)
+    kw = dict(capacity_pages=N + 4, stride_rows=stride, with_float=False, with_fde=True, with_fp8=True, with_host_exact=True)
+    host = _idx(**kw)
+    with _SplitAt(split_at):
+        split = _idx(with_exact_split=True, **kw)
+    assert split.exact_hbm_pages == min(split_at, N + 4) and host.exact_hbm_pages == 0
+    with pytest.raises(MvError, match="MV_WITH_EXACT_SPLIT"):
+        _idx(capacity_pages=8, stride_rows=stride, with_float=True, with_fp8=True, with_host_exact=True, with_exact_split=True)
+    for ix in (host, split):
+        ix.add(pages[:200])
+        ix.add(pages[200:])  # a second ingest that starts on the HBM side or the host side, depending on the split
+    qs = [orc.synth_rows(35, 3, 0, 20)] + [orc.synth_rows(977, j, 0, 20) for j in range(4)]
+    long_q = orc.synth_rows(978, 0, 0, 80)  # > 64 rows: the batched rerank runs per query
+    allow = allow_bitmap(np.arange(0, N, 3), N)
+    for coarse_n, rerank_n in ((75, 128), (300, 64)):
+        for ix in (host, split):
+            ix.set_option(_lib.MV_OPT_FDE_COARSE_N, coarse_n)
+            ix.set_option(_lib.MV_OPT_RERANK_N, rerank_n)
+        assert split.rerank_plan(coarse_n, k, 20) == host.rerank_plan(coarse_n, k, 20)
+        for q in qs + [long_q]:
+            for mode in ("fde_then_float", "fp8_then_float"):
+                for al in (None, allow):
+                    ws, wi = host.query(q, k, mode=mode, allow=al)
+                    s, i = split.query(q, k, mode=mode, allow=al)
+                    assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist(), (coarse_n, mode, al is not None)
+        for mode in ("fde_then_float", "fp8_then_float"):
+            for batch in (qs, [long_q, long_q[:80]]):
+                want = host.query_batch(batch, k, mode=mode)
+                got = split.query_batch(batch, k, mode=mode)
+                for (ws, wi), (s, i) in zip(want, got):
+                    assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist(), (coarse_n, mode, "batch")
+    cand = np.array([0, 136, 137, 138, 419, 3, 200, 199, 10, 17], np.int32)
+    for q in qs[:2]:
+        a, b = host.score_candidates(q, cand), split.score_candidates(q, cand)
+        assert a.tolist() == b.tolist()
+        want = np.array([orc.maxsim_bf16(q, pages[c]) for c in cand], np.float32)
+        np.testing.assert_allclose(b, want, rtol=RTOL)
+    # the staged entry points of the one-process-per-GPU flow
+    dev = torch.device("cuda", 0)
+    coarse_n = 300
+    for mode in ("fde_then_float", "fp8_then_float"):
+        n_mid, tier = split.rerank_plan(coarse_n, k, 20, mode=mode)
+        assert tier == "host"
+        outs = []
+        for ix in (host, split):
+            recs = torch.empty(coarse_n * 16, dtype=torch.uint8, device=dev)
+            ix.two_stage_coarse_device(qs[0], coarse_n, recs.data_ptr(), mode=mode)
+            mid = None
+            if n_mid:
+                mid = torch.empty(coarse_n, dtype=torch.float32, device=dev)
+                ix.two_stage_mid_device(qs[0], recs.data_ptr(), 1, coarse_n, mid.data_ptr(), mode=mode)
+            ls = torch.empty(k, dtype=torch.float32, device=dev)
+            li = torch.empty(k, dtype=torch.int64, device=dev)
+            ix.two_stage_rerank_device(qs[0], recs.data_ptr(), 1, coarse_n, k, ls.data_ptr(), li.data_ptr(), mode=mode,
+                                       d_all_mid_ptr=mid.data_ptr() if n_mid else 0, n_mid=n_mid)
+            torch.cuda.synchronize()
+            outs.append((ls.cpu().tolist(), li.cpu().tolist()))
+        assert outs[0] == outs[1], mode
+    host.close()
+    split.close()
+
+
+def test_split_exact_tier_writers_compaction_and_checkpoints(tmp_path):
+    """replace_page / write_rows / read_pages on both sides of the split, compaction that moves pages ACROSS it, and a checkpoint
+    that is reloaded with a different split: the tier's rows stay those of an unsplit index put through the same calls."""
+    from morphik_core_amd import _lib
+    from morphik_core_amd.index import MvIndex
+
+    N, stride, k = 300, 32, 5
+    pages = _corpus(N, stride, seed=36)
+    kw = dict(capacity_pages=N, stride_rows=stride, with_float=False, with_fde=True, with_fp8=True, with_host_exact=True)
+    host = _idx(**kw)
+    with _SplitAt(101):
+        split = _idx(with_exact_split=True, **kw)
+    qs = [orc.synth_rows(36, 3, 0, 16), orc.synth_rows(979, 1, 0, 16)]
+
+    def same(a, b, tag):
+        assert len(a) == len(b), tag
+        np.testing.assert_array_equal(a.read_pages(0, len(a)), b.read_pages(0, len(b)), err_msg=tag)
+        for q in qs:
+            for mode in ("fde_then_float", "fp8_then_float"):
+                ws, wi = a.query(q, k, mode=mode)
+                s, i = b.query(q, k, mode=mode)
+                assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist(), (tag, mode)
+
+    for ix in (host, split):
+        ix.add(pages, doc_ordinals=np.arange(N, dtype=np.int32) // 3)
+        ix.set_option(_lib.MV_OPT_FDE_COARSE_N, 60)
+    same(host, split, "ingest")
+    new_rows = orc.synth_rows(555, 0, 0, 24)
+    for ix in (host, split):
+        for page in (0, 100, 101, 299):
+            ix.replace_page(page, new_rows[: 10 + page % 7])
+        ix.write_rows(100, 2, new_rows[:4])
+        ix.write_rows(101, 0, new_rows[4:9])
+    same(host, split, "replace / write")
+    np.testing.assert_array_equal(split.read_pages(95, 12), host.read_pages(95, 12))
+    for ix in (host, split):
+        for d in (2, 20, 33, 34, 70):  # pages 6-8, 60-62, 99-104 (straddling the split), 210-212
+            ix.remove_doc(d)
+        ix.compact()
+    assert len(split) == N - 15
+    same(host, split, "compact")
+    path = str(tmp_path / "split.idx")
+    split.save(path)
+    with _SplitAt(40):
+        re = MvIndex.load(path, device=0)
+    assert re.exact_hbm_pages == 40
+    re.set_option(_lib.MV_OPT_FDE_COARSE_N, 60)  # options are the caller's, not the checkpoint's
+    same(host, re, "reload with another split")
+    re.close()
+    re = MvIndex.load(path, device=0)  # no cap: everything the free HBM holds -- the whole (small) tier
+    assert re.exact_hbm_pages == N
+    re.set_option(_lib.MV_OPT_FDE_COARSE_N, 60)
+    same(host, re, "reload all in HBM")
+    re.close()
+    host.close()
+    split.close()
+
+
+def test_split_exact_tier_behind_the_store():
+    """create_store("mi355x_fast_split_exact" / "mi355x_sharded_fast_split_exact"): the plugin surface over split tiers returns the
+    hits of the unsplit host-tier providers, score for score."""
+    import asyncio
+
+    from morphik_core_amd.models import DocumentChunk
+    from morphik_core_amd.store import create_store
+
+    stride = 48
+    pages = _corpus(120, stride, seed=37)
+    chunks = [DocumentChunk(document_id=f"d{i // 4}", content=f"p{i}", embedding=orc.bf16_to_f32(p), chunk_number=i % 4, metadata={}) for i, p in enumerate(pages)]
+    q = orc.bf16_to_f32(orc.synth_rows(37, 3, 0, 20))
+    res = {}
+    for provider in ("mi355x_fast_host_exact", "mi355x_fast_split_exact", "mi355x_sharded_fast_host_exact", "mi355x_sharded_fast_split_exact"):
+        kw = dict(devices=[0, 0, 0], transport="p2p") if "sharded" in provider else {}
+        with _SplitAt(23):  # of 300 (one index) or 100 (each of three shards) slots
+            st = create_store(provider, capacity_pages=300, stride_rows=stride, **kw)
+            assert st.initialize()
+
+        async def run():
+            ok, ids, _m = await st.store_embeddings(chunks[:50], app_id=None)
+            assert ok and len(ids) == 50
+            ok, ids, _m = await st.store_embeddings(chunks[50:], app_id=None)
+            assert ok
+            return await st.query_similar(q, k=6)
+
+        hits = asyncio.run(run())
+        res[provider] = [(h.document_id, h.chunk_number, h.score) for h in hits]
+        if "split" in provider:
+            shards = st._index.shards if "sharded" in provider else [st._index]
+            assert [sh.exact_hbm_pages for sh in shards] == [23] * len(shards)
+        st.close()
+    assert res["mi355x_fast_split_exact"] == res["mi355x_fast_host_exact"] and len(res["mi355x_fast_host_exact"]) == 6
+    assert res["mi355x_sharded_fast_split_exact"] == res["mi355x_sharded_fast_host_exact"]

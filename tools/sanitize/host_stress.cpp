@@ -145,10 +145,13 @@ int main(int argc, char** argv) {
 
   // ---- EIGHT shards on eight "devices": the node shape of BASELINE configs[2]-[4], every transport, every staged pipeline
   std::atomic<long> n_comm8{0};
-  for (int shape = 0; shape < 2; ++shape) {
+  for (int shape = 0; shape < 3; ++shape) {
     // shape 0: configs[3] / [4] shard shape -- FDE + e4m3 slabs, exact rows in the pinned-host tier (pruning stage: coarse 300 > 64)
     // shape 1: bf16 + sign-bit + FDE slabs (single-stage float / binary scans, FDE pipeline reranking in "HBM")
-    const int eflags = shape == 0 ? (MV_WITH_FDE | MV_WITH_FP8 | MV_WITH_HOST_EXACT) : (MV_WITH_FLOAT | MV_WITH_BINARY | MV_WITH_FDE);
+    // shape 2: shape 0 with the exact tier SPLIT: pages [0, 70) of every shard in "HBM", the other filled pages pinned
+    const int eflags = shape == 1 ? (MV_WITH_FLOAT | MV_WITH_BINARY | MV_WITH_FDE)
+                                  : (MV_WITH_FDE | MV_WITH_FP8 | MV_WITH_HOST_EXACT | (shape == 2 ? MV_WITH_EXACT_SPLIT : 0));
+    if (shape == 2) setenv("MV_EXACT_HBM_MAX_PAGES", "70", 1);
     mv_index* s8[8];
     int32_t devs8[8];
     for (int r = 0; r < 8; ++r) {
@@ -158,6 +161,28 @@ int main(int argc, char** argv) {
       CHECK(mv_index_set_option(s8[r], MV_OPT_FDE_COARSE_N, 300));
       CHECK(mv_index_set_option(s8[r], MV_OPT_RERANK_N, 64));
     }
+    if (shape == 2) {  // the writers of a split tier: pages on both sides of the split, compaction across it, a checkpoint re-split on load
+      if (mv_index_exact_hbm_pages(s8[7]) != 70) { fprintf(stderr, "FAIL split: %lld HBM pages, expected 70\n", (long long)mv_index_exact_hbm_pages(s8[7])); std::abort(); }
+      std::vector<uint16_t> pg(32 * 128, 0x3c00), back(40 * 32 * 128);
+      for (int64_t page : {3, 69, 70, 127}) {
+        CHECK(mv_index_replace_page(s8[7], page, pg.data(), 20));
+        CHECK(mv_index_write_rows(s8[7], page, 4, 8, pg.data()));
+      }
+      CHECK(mv_index_read_pages(s8[7], 50, 40, back.data()));
+      for (int64_t page : {5, 40, 68, 71, 90}) CHECK(mv_index_remove_page(s8[7], page));
+      int64_t new_size = 0;
+      CHECK(mv_index_compact(s8[7], nullptr, &new_size));
+      if (new_size != 123) { fprintf(stderr, "FAIL compact of the split tier: %lld pages left\n", (long long)new_size); std::abort(); }
+      CHECK(mv_index_save(s8[7], "/tmp/mv_split_stress.idx"));
+      setenv("MV_EXACT_HBM_MAX_PAGES", "33", 1);
+      mv_index* re = nullptr;
+      CHECK(mv_index_load("/tmp/mv_split_stress.idx", 3, &re));
+      if (mv_index_exact_hbm_pages(re) != 33 || mv_index_size(re) != 123) { fprintf(stderr, "FAIL reload of the split tier\n"); std::abort(); }
+      CHECK(mv_index_read_pages(re, 20, 40, back.data()));
+      mv_index_destroy(re);
+      remove("/tmp/mv_split_stress.idx");
+      unsetenv("MV_EXACT_HBM_MAX_PAGES");
+    }
     for (int transport : {MV_COMM_RCCL, MV_COMM_P2P, MV_COMM_HOST}) {
       mv_comm* c = nullptr;
       CHECK(mv_comm_create(8, devs8, transport, &c));
@@ -166,7 +191,7 @@ int main(int argc, char** argv) {
       auto cq8 = [&](int tid) {
         const int modes0[] = {MV_MODE_FDE_THEN_FLOAT, MV_MODE_FP8_THEN_FLOAT, MV_MODE_FLOAT_FP8, MV_MODE_FDE_ONLY};
         const int modes1[] = {MV_MODE_FLOAT, MV_MODE_BINARY, MV_MODE_FDE_THEN_FLOAT, MV_MODE_FDE_ONLY};
-        const int* modes = shape == 0 ? modes0 : modes1;
+        const int* modes = shape != 1 ? modes0 : modes1;
         std::vector<float> q = rows(16, 500 + tid), qb = rows(36 * 16, 600 + tid);
         std::vector<uint32_t> allow(8, 0xdeadbeefu), per(36 * 8, 0x77777777u);
         std::vector<float> s(36 * 10);
@@ -178,7 +203,7 @@ int main(int argc, char** argv) {
           CHECK(mv_comm_query_topk(c, q.data(), MV_F32, 16, 10, mode, (it & 1) ? allow.data() : nullptr, (it & 1) ? 8 : 0, s.data(), id.data(), &n, (it & 2) ? st : nullptr));
           if (it % 3 == 0) {  // batches: 5 requests, and 36 (more than one group of 32); shared and per-request filters
             const int nq = (it % 6 == 0) ? 36 : 5;
-            const int bmode = shape == 0 ? ((it % 2) ? MV_MODE_FP8_THEN_FLOAT : MV_MODE_FDE_THEN_FLOAT) : ((it % 2) ? MV_MODE_FLOAT : MV_MODE_FDE_THEN_FLOAT);
+            const int bmode = shape != 1 ? ((it % 2) ? MV_MODE_FP8_THEN_FLOAT : MV_MODE_FDE_THEN_FLOAT) : ((it % 2) ? MV_MODE_FLOAT : MV_MODE_FDE_THEN_FLOAT);
             CHECK(mv_comm_query_topk_batch(c, qb.data(), MV_F32, nq, 16, 10, bmode, (it % 4 == 0) ? per.data() : nullptr, (it % 4 == 0) ? 8 : 0, (it % 4 == 0) ? 1 : 0,
                                            s.data(), id.data(), nb, st));
           }
