@@ -164,7 +164,11 @@ typedef enum {
                                     5 = as 0 with the round-2 structure: the cosine rule / tombstones as a finish pass of their
                                     own (the default applies them where the scan kernel writes a tile's scores) and all three
                                     passes of the selection (variants 3 / 4 let their finish pass pre-bin the scores for the
-                                    selection's first pass); the same results bit for bit */
+                                    selection's first pass); the same results bit for bit;
+                                    6 / 7 / 8 = round-4 experiments kept as cross-checks (same scores, none faster: DESIGN 3.14):
+                                    6 = as 0 with a private DMA ring per wave (every wave fetches the 128-byte quarter of the 64 rows it
+                                    consumes: no workgroup barrier per ring slot); 7 = 32-page tiles, one workgroup per CU, a ring of
+                                    NINE slots (128 KiB in flight a CU instead of 96); 8 = the same with four slots (48 KiB) */
 } mv_option;
 
 /* Bumped whenever a signature, a struct layout or an enum value of this header changes incompatibly.  A binding compares
@@ -358,7 +362,13 @@ MV_API int mv_calibrate_read_bw(int device, int64_t bytes, int32_t iters, double
  *   MV_CAL_MFMA_BF16_32X32  the same with v_mfma_f32_32x32x16_bf16 (half the operand-register reads per flop) -> TFLOP/s
  *   MV_CAL_READ_LDSDMA the float scan's own transport with the arithmetic removed: non-temporal global_load_lds_dwordx4
  *                     into the 4-slot wave-private ring, four waves per 256 KiB piece     -> *out in GB/s */
-enum { MV_CAL_READ_NT = 1, MV_CAL_MFMA_BF16 = 2, MV_CAL_READ_LDSDMA = 3, MV_CAL_MFMA_BF16_32X32 = 4 };
+enum { MV_CAL_READ_NT = 1, MV_CAL_MFMA_BF16 = 2, MV_CAL_READ_LDSDMA = 3, MV_CAL_MFMA_BF16_32X32 = 4,
+       /* the batched FDE coarse pass's access pattern without LDS, barriers or arithmetic: a [rows][20 480 B] matrix read tile by tile,
+        * 512 / 1024 / 2048 / 4096 contiguous bytes per row and step (32 KiB per workgroup and step, three steps in flight), or whole rows */
+       MV_CAL_READ_STRIDED_512 = 5, MV_CAL_READ_STRIDED_1K = 6, MV_CAL_READ_STRIDED_2K = 7, MV_CAL_READ_STRIDED_4K = 8, MV_CAL_READ_ROWS_20K = 9,
+       /* ... and through the pass's own transport (non-temporal global_load_lds_dwordx4 into an LDS ring, nothing read back): 512 B /
+        * 1 KiB / 2 KiB per row and step, and 128 B per row with 8 rows per instruction (the private-ring form) */
+       MV_CAL_DMA_STRIDED_128 = 10, MV_CAL_DMA_STRIDED_512 = 11, MV_CAL_DMA_STRIDED_1K = 12, MV_CAL_DMA_STRIDED_2K = 13 };
 MV_API int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out);
 
 /* ---------------------------------------------------------------------------------------------------------------

@@ -1802,6 +1802,8 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
     sa.hi_only = ix->fde_batch_variant == 2;
     sa.single_tile = ix->fde_batch_variant == 3;
     sa.half_tiles = ix->fde_batch_variant == 4;
+    sa.private_rings = ix->fde_batch_variant == 6;
+    sa.ring_slots = ix->fde_batch_variant == 7 ? 9 : (ix->fde_batch_variant == 8 ? 4 : 0);
     sa.separate_finish = ix->fde_batch_variant == 5;
     // Default: the scan kernel applies the cosine rule / tombstones itself (no finish pass) and the selection runs its three
     // vectorised passes.  Where a finish pass runs anyway (variants 3 / 4, or a dot-product index with masks) it also bins every
@@ -2357,6 +2359,25 @@ int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out
     }
     if (buf) (void)hipFree(buf);
     if (sc) (void)hipFree(sc);
+  } else if ((what >= MV_CAL_READ_STRIDED_512 && what <= MV_CAL_READ_ROWS_20K) || (what >= MV_CAL_DMA_STRIDED_128 && what <= MV_CAL_DMA_STRIDED_2K)) {
+    // the batched FDE pass's access pattern (tiles of rows, `piece` contiguous bytes per row and step) without LDS, barriers or arithmetic
+    const int piece = what == MV_CAL_READ_STRIDED_512 ? 512 : what == MV_CAL_READ_STRIDED_1K ? 1024 : what == MV_CAL_READ_STRIDED_2K ? 2048 : what == MV_CAL_READ_STRIDED_4K ? 4096 :
+                      what == MV_CAL_DMA_STRIDED_128 ? -128 : what == MV_CAL_DMA_STRIDED_512 ? -512 : what == MV_CAL_DMA_STRIDED_1K ? -1024 : what == MV_CAL_DMA_STRIDED_2K ? -2048 : 20480;
+    const int64_t n_rows = bytes / 20480 / 64 * 64;
+    if (n_rows < 64 * 256) { set_error("calibrate: need >= 336 MB"); rc = MV_ERR_INVALID; }
+    void* buf = nullptr;
+    if (!rc && hipMalloc(&buf, (size_t)n_rows * 20480) != hipSuccess) { set_error("calibrate: out of memory"); rc = MV_ERR_NOMEM; }
+    if (!rc) {
+      (void)hipMemset(buf, 1, (size_t)n_rows * 20480);
+      rc = launch_read_bw_strided(buf, n_rows, piece, sink, nullptr);
+      (void)hipEventRecord(a_ev, nullptr);
+      for (int i = 0; i < iters && !rc; ++i) rc = launch_read_bw_strided(buf, n_rows, piece, sink, nullptr);
+      (void)hipEventRecord(b_ev, nullptr);
+      (void)hipEventSynchronize(b_ev);
+      (void)hipEventElapsedTime(&ms, a_ev, b_ev);
+      *out = ms > 0 ? (double)n_rows * 20480 * (piece > 8192 ? 1.2 : 1.0) * iters / (ms * 1e-3) / 1e9 : 0.0;  // GB/s (whole rows: 3 x 8 KiB read per 20 KiB row)
+    }
+    if (buf) (void)hipFree(buf);
   } else if (what == MV_CAL_MFMA_BF16 || what == MV_CAL_MFMA_BF16_32X32) {
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);

@@ -217,11 +217,13 @@ struct FdeScanBatchArgs {
   // Only honoured when a finish pass runs (inv_norm or doc_ord given): fde_scan_batch_prebins().
   uint32_t* hist0;
   int64_t hist0_stride_bytes;
+  int32_t ring_slots;         // > 0: 32-page tiles, one workgroup per CU, a DMA ring of that many slots (4 / 9; MV_OPT_FDE_BATCH_VARIANT 8 / 7)
+  int32_t private_rings;      // 1: every wave DMAs the quarter of the slot it consumes into a ring of its own -- no slot barriers (MV_OPT_FDE_BATCH_VARIANT 6)
   int32_t separate_finish;    // 1: keep the finish a pass of its own even where the scan kernel could apply it (MV_OPT_FDE_BATCH_VARIANT 5)
 };
 // the default (paired-tile) kernel applies the cosine rule and the tombstones where it writes a tile's scores: no finish pass
 inline bool fde_scan_batch_fuses_finish(const FdeScanBatchArgs& a) {
-  return a.inv_norm != nullptr && !a.single_tile && !a.half_tiles && !a.separate_finish;
+  return a.inv_norm != nullptr && !a.single_tile && !a.half_tiles && !a.ring_slots && !a.separate_finish;
 }
 inline bool fde_scan_batch_prebins(const FdeScanBatchArgs& a) {
   return a.hist0 != nullptr && (a.inv_norm != nullptr || a.doc_ord != nullptr) && !fde_scan_batch_fuses_finish(a);
@@ -290,6 +292,7 @@ int launch_filter_compact(const int32_t* d_doc_ord, const uint32_t* d_allow, int
 int launch_f32_to_bf16(const float* d_in, uint16_t* d_out, int64_t n, hipStream_t s);
 int launch_read_bw(const void* d_buf, int64_t bytes, float* d_sink, hipStream_t s);
 int launch_read_bw_nt(const void* d_buf, int64_t bytes, float* d_sink, hipStream_t s);  // contiguous 16 KiB pieces, nt loads
+int launch_read_bw_strided(const void* d_buf, int64_t n_rows, int piece, float* d_sink, hipStream_t s);  // [rows][20 480 B], `piece` bytes per row and step
 int launch_mfma_peak(int blocks, int iters, int shape, float* d_sink, hipStream_t s);   // per iteration per wave: shape 0 = 8 x 16x16x32, 1 = 4 x 32x32x16 bf16 MFMA
 // scatter ragged bf16/f32 rows into the fixed-stride slab (zero-filling the tail of each page slot);
 // d_nonfinite (nullable): set to 1 when a row holds a NaN / Inf (in its bf16 image)

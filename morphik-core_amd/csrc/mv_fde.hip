@@ -1418,7 +1418,11 @@ __device__ __forceinline__ void fb_static_for(F&& f) {
 // slot's own wait returns, read with ds_read at the tile's end.  Every wave issues them (same data, same place: the per-wave
 // counts stay uniform).  Records are double-buffered by group parity: the next group's first slots are issued before this group's
 // epilogue runs.  The arithmetic is the finish kernel's (one fp32 multiply of the same sum): identical scores.
-template <int NQT, bool LO, int T, bool FIN = false>
+// PRIV (MV_OPT_FDE_BATCH_VARIANT = 6): every wave DMAs exactly the bytes IT consumes -- its 64-dim quarter (128 B) of all 64 pages of the
+// slot instead of the full 512 B of 16 pages -- into a ring of its own, so a slot needs no workgroup barrier at all: "landed" is the
+// wave's own vmcnt, "consumed" its own lgkmcnt.  The waves meet only at a tile's end (the cross-wave sum).  Same fragments, same K
+// order, same order of the four partial sums: identical scores.
+template <int NQT, bool LO, int T, bool FIN = false, bool PRIV = false>
 __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, float* red, const int lane, const int wave, const int i0,
                                          const int n_groups, const uint32_t (&src_off)[8], const uint32_t (&rd_off)[2]) {
   using bf16x8 = __attribute__((ext_vector_type(8))) short;
@@ -1464,8 +1468,13 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
       const uint32_t last = (uint32_t)(a.n - 1 - page0);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const uint32_t pl = (uint32_t)(wave * 16 + 2 * i + (lane >> 5));
-        so[i] = min(pl, last) * row_bytes + ((((uint32_t)lane & 31u) ^ (pl & 15u)) << 4) + 4096u - (uint32_t)(i & 3) * 1024u;
+        if constexpr (PRIV) {
+          const uint32_t pl = (uint32_t)(8 * i + (lane >> 3));
+          so[i] = min(pl, last) * row_bytes + (uint32_t)wave * 128u + ((((uint32_t)lane & 7u) ^ ((pl >> 1) & 7u)) << 4) + 4096u - (uint32_t)(i & 3) * 1024u;
+        } else {
+          const uint32_t pl = (uint32_t)(wave * 16 + 2 * i + (lane >> 5));
+          so[i] = min(pl, last) * row_bytes + ((((uint32_t)lane & 31u) ^ (pl & 15u)) << 4) + 4096u - (uint32_t)(i & 3) * 1024u;
+        }
       }
     } else {
 #pragma unroll
@@ -1579,7 +1588,7 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
       else if (s + 2 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(o1 + o2) : "memory");
       else if (s + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(o1) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // slot s landed for all waves
+      if constexpr (!PRIV) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // slot s landed for all waves
 #pragma unroll
       for (int x = 0; x < NF; ++x) asm volatile("" : "+v"(qf[kcs][x]));  // uses stay behind the wait
       const char* slot = lds + (u & 3) * kFbSlotBytes;
@@ -1587,8 +1596,9 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
 #pragma unroll
       for (int e = 0; e < 2; ++e)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) af[e][t] = *reinterpret_cast<const bf16x8*>(slot + t * (16 * 512) + rd_off[e]);
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // slot s is in registers everywhere: refill it
+        for (int t = 0; t < 4; ++t) af[e][t] = *reinterpret_cast<const bf16x8*>(slot + t * (PRIV ? 16 * 128 : 16 * 512) + rd_off[e]);
+      if constexpr (PRIV) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's part of slot s is in its registers: refill it
+      else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // slot s is in registers everywhere: refill it
 #pragma unroll
       for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -1628,7 +1638,7 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
         }
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt) {
-          if (qt > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone has read the previous query tile's sums
+          if (PRIV || qt > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone has read the previous query tile's sums
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             *reinterpret_cast<f32x4*>(red + (wave * 16 + p) * kFbRedStride + t * 16 + g * 4) = acc[j][t][qt];
@@ -1657,7 +1667,7 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
   }
 }
 
-template <int NQT, bool LO, bool FIN = false>
+template <int NQT, bool LO, bool FIN = false, bool PRIV = false>
 __global__ __launch_bounds__(256) void fde_scan_batch2_kernel(ScanBatchArgs a) {
   // one __shared__ object only (a second one makes hipcc drain vmcnt before every ds_read)
   __shared__ __attribute__((aligned(16))) char lds[kFbSlots * kFbSlotBytes + 4 * 16 * kFbRedStride * 4 + (FIN ? 2 * 2 * 512 : 0)];
@@ -1669,16 +1679,29 @@ __global__ __launch_bounds__(256) void fde_scan_batch2_kernel(ScanBatchArgs a) {
   const int n_my = (a.n_tiles - b + G - 1) / G;  // tiles b, b + G, ...  (grid <= n_tiles)
   const uint32_t row_bytes = (uint32_t)a.out_dim * 2u;
   uint32_t src_off[8];  // see fde_scan_batch_kernel
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const uint32_t pl = (uint32_t)(wave * 16 + 2 * i + (lane >> 5));
-    src_off[i] = pl * row_bytes + ((((uint32_t)lane & 31u) ^ (pl & 15u)) << 4) + 4096u - (uint32_t)(i & 3) * 1024u;
-  }
   uint32_t rd_off[2];
+  if constexpr (PRIV) {
+    // DMA i of a slot: lane l fetches 16 B of page 8i + (l >> 3) -- piece (l & 7) ^ swizzle(page) of this wave's 128-byte quarter of the
+    // row -- and the LDS write is lane-linear: page P sits at P * 128 of the wave's 8 KiB, its piece c at ((c ^ ((P >> 1) & 7)) << 4).
+    // A ds_read_b128 serves 8 lanes a clock: pages p, p + 1 share a 256-byte bank row, the swizzle spreads the four pairs' pieces.
 #pragma unroll
-  for (int e = 0; e < 2; ++e) rd_off[e] = (uint32_t)p * 512u + (((uint32_t)((2 * wave + e) * 4 + g) ^ (uint32_t)p) << 4);
-  fb_phase<NQT, LO, 2, FIN>(a, lds, red, lane, wave, 0, n_my / 2, src_off, rd_off);
-  fb_phase<NQT, LO, 1, FIN>(a, lds, red, lane, wave, (n_my / 2) * 2, n_my & 1, src_off, rd_off);
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t pl = (uint32_t)(8 * i + (lane >> 3));
+      src_off[i] = pl * row_bytes + (uint32_t)wave * 128u + ((((uint32_t)lane & 7u) ^ ((pl >> 1) & 7u)) << 4) + 4096u - (uint32_t)(i & 3) * 1024u;
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) rd_off[e] = (uint32_t)wave * 8192u + (uint32_t)p * 128u + (((uint32_t)(e * 4 + g) ^ (((uint32_t)p >> 1) & 7u)) << 4);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t pl = (uint32_t)(wave * 16 + 2 * i + (lane >> 5));
+      src_off[i] = pl * row_bytes + ((((uint32_t)lane & 31u) ^ (pl & 15u)) << 4) + 4096u - (uint32_t)(i & 3) * 1024u;
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) rd_off[e] = (uint32_t)p * 512u + (((uint32_t)((2 * wave + e) * 4 + g) ^ (uint32_t)p) << 4);
+  }
+  fb_phase<NQT, LO, 2, FIN, PRIV>(a, lds, red, lane, wave, 0, n_my / 2, src_off, rd_off);
+  fb_phase<NQT, LO, 1, FIN, PRIV>(a, lds, red, lane, wave, (n_my / 2) * 2, n_my & 1, src_off, rd_off);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1903,6 +1926,238 @@ __device__ __forceinline__ void fb_phase_g(const ScanBatchArgs& a, char* lds, fl
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Round 4: the phase with the DEPTH of the DMA ring as a parameter.  The pass is latency-bound (SQ counters: MFMA 15 % busy, half the
+// wave cycles waiting; removing the slot barriers altogether -- private rings, variant 6 -- changed nothing), i.e. its rate is the
+// bytes a CU keeps in flight over the loaded HBM latency: 3 x 32 KiB with the 4-slot ring of 64-page slots.  Here: 32-page slots
+// (16 KiB), ONE workgroup per CU, R slots -- R = 9 keeps 8 x 16 = 128 KiB in flight out of a 144 KiB ring.  The ring position is a
+// run-time scalar (R need not divide the unroll period); what stays compile-time is the slot's place in its K chunk, which fixes the
+// counted vmcnt waits: the operations of the R - 1 slots behind the one waited for, in issue order.  A K chunk's fragments are
+// loaded R slots ahead with its first slot, so (R + T - 1) / T + 1 register sets are live: NSETS = 4 at T = 4, R = 9.
+// Arithmetic, K order and the order of the four waves' partial sums are those of fb_phase: identical scores.
+template <int NQT, bool LO, int T, int PT, int NSETS, int R>
+__device__ __forceinline__ void fb_phase_r(const ScanBatchArgs& a, char* lds, float* red, const int lane, const int wave, const int i0,
+                                         const int n_groups, const uint32_t (&src_off)[2 * PT], const uint32_t (&rd_off)[2]) {
+  using bf16x8 = __attribute__((ext_vector_type(8))) short;
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  constexpr int NF = 4 * NQT;              // query fragments per K chunk and wave: (e, qt, hi|lo)
+  constexpr int QOPS = LO ? NF : NF / 2;   // fragment loads per K chunk and wave
+  constexpr int PAGES = 16 * PT;           // pages per tile
+  constexpr int SLOTB = PAGES * 512;       // ring slot: PAGES pages x 256 dims
+  constexpr int NDMA = 2 * PT;             // DMA instructions per slot and wave (2 pages x 512 B each)
+  constexpr int REDS = PAGES + 4;          // floats per (wave, query) row of the tile-end reduction
+  constexpr int U = T * NSETS;             // unroll period: the slot's tile of the group and its chunk's register set are compile-time
+  static_assert(PT == 2, "32-page tiles");
+  static_assert((R + T - 1) / T + 1 <= NSETS, "fragment ring too shallow for this DMA ring");
+  static_assert(R * NDMA + ((R + T - 1) / T) * QOPS <= 63, "more VMEM operations in flight than vmcnt counts");
+  const int p = lane & 15, g = lane >> 4;
+  const int G = gridDim.x, b = blockIdx.x;
+  const int KC = a.out_dim >> 8;
+  const int total = n_groups * KC * T;     // ring slots of this phase; a multiple of U (KC % 4 == 0)
+  if (total == 0) return;
+  const uint32_t row_bytes = (uint32_t)a.out_dim * 2u;
+  const uint32_t q_off = (uint32_t)lane * 16u;
+
+  bf16x8 qf[NSETS][NF];  // [K chunk % NSETS][(e*NQT + qt)*2 + (0 = hi, 1 = lo)]
+#pragma unroll
+  for (int u = 0; u < NSETS; ++u)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) qf[u][j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  f32x4 acc[T][PT][NQT];
+#pragma unroll
+  for (int j = 0; j < T; ++j)
+#pragma unroll
+    for (int t = 0; t < PT; ++t)
+#pragma unroll
+      for (int qt = 0; qt < NQT; ++qt) acc[j][t][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int i_grp = 0, i_kc = 0, i_j = 0;  // issue-side position: (group, K chunk, tile of the group)
+  int i_pos = 0, c_pos = 0;          // ring position of the slot issued next / consumed next
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  auto issue_dma = [&]() {
+    const int64_t tile = (int64_t)b + (int64_t)(i0 + i_grp * T + i_j) * G;
+    const int64_t page0 = tile * PAGES;
+    const char* tp = a.fde + (size_t)page0 * row_bytes + (size_t)i_kc * 512 - 4096;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
+    const uint64_t tpu = ((uint64_t)hi << 32) | lo;
+    const uint32_t slot = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)i_pos * (uint32_t)SLOTB + (uint32_t)wave * (uint32_t)(4 * PT * 512));
+    uint32_t so[NDMA];
+    if (page0 + PAGES > a.n) {  // last tile: rows past the corpus re-read its last page (their sums are never written)
+      const uint32_t last = (uint32_t)(a.n - 1 - page0);
+#pragma unroll
+      for (int i = 0; i < NDMA; ++i) {
+        const uint32_t pl = (uint32_t)(wave * (4 * PT) + 2 * i + (lane >> 5));
+        so[i] = min(pl, last) * row_bytes + ((((uint32_t)lane & 31u) ^ (pl & 15u)) << 4) + 4096u - (uint32_t)(i & 3) * 1024u;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NDMA; ++i) so[i] = src_off[i];
+    }
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %6 nt\n\t"
+        "global_load_lds_dwordx4 %2, %6 offset:1024 nt\n\t"
+        "global_load_lds_dwordx4 %3, %6 offset:2048 nt\n\t"
+        "global_load_lds_dwordx4 %4, %6 offset:3072 nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(so[0]), "v"(so[1]), "v"(so[2]), "v"(so[3]), "s"(slot), "s"(tpu)
+        : "memory");
+    if (++i_pos == R) i_pos = 0;
+  };
+  auto issue_q = [&](bf16x8 (&qs)[NF]) {  // the fragments of K chunk i_kc
+#pragma unroll
+    for (int h = 0; h < NQT; ++h) {
+      const char* qp = a.qfrag + (size_t)(i_kc * 4 + wave) * (NF * 1024) + h * 4096;
+      const uint32_t qlo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)qp);
+      const uint32_t qhi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)qp >> 32));
+      const uint64_t qpu = ((uint64_t)qhi << 32) | qlo;
+      if (LO)
+        asm volatile(
+            "s_nop 4\n\t"
+            "global_load_dwordx4 %0, %4, %5\n\t"
+            "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+            "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
+            "global_load_dwordx4 %3, %4, %5 offset:3072"
+            : "+v"(qs[4 * h + 0]), "+v"(qs[4 * h + 1]), "+v"(qs[4 * h + 2]), "+v"(qs[4 * h + 3])
+            : "v"(q_off), "s"(qpu)
+            : "memory");
+      else
+        asm volatile(
+            "s_nop 4\n\t"
+            "global_load_dwordx4 %0, %2, %3\n\t"
+            "global_load_dwordx4 %1, %2, %3 offset:2048"
+            : "+v"(qs[4 * h + 0]), "+v"(qs[4 * h + 2])
+            : "v"(q_off), "s"(qpu)
+            : "memory");
+    }
+  };
+  auto advance = [&]() {
+    if (++i_j == T) {
+      i_j = 0;
+      if (++i_kc == KC) { i_kc = 0; ++i_grp; }
+    }
+  };
+
+  // prologue: slots 0 .. R-1 (slot x = K chunk x / T, tile x % T); a chunk's fragments ride with its first slot  (total >= U >= R is
+  // not guaranteed for tiny phases: total is a multiple of U = 16 and R <= 12)
+  static_assert(R <= U, "the prologue assumes one unroll period covers the ring");
+  fb_static_for<R>([&](auto UC) {
+    constexpr int u = decltype(UC)::value;
+    issue_dma();
+    if constexpr (u % T == 0) issue_q(qf[(u / T) % NSETS]);
+    advance();
+  });
+
+  int c_grp = 0, c_kc = 0;  // consume-side position
+  for (int s0 = 0; s0 < total; s0 += U) {
+    fb_static_for<U>([&](auto UC) {
+      constexpr int u = decltype(UC)::value;
+      constexpr int j = u % T;              // tile of the group
+      constexpr int kcs = (u / T) % NSETS;  // K chunk -> fragment register set
+      const int s = s0 + u;
+      // VMEM operations of the R - 1 slots behind this one (NDMA DMAs + the fragment loads of a chunk's first slot), in issue order
+      constexpr int behind = [] {
+        int n = 0;
+        for (int x = 1; x < R; ++x) n += NDMA + (((u + x) % T == 0) ? QOPS : 0);
+        return n;
+      }();
+      if (s + R - 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(behind) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the phase's tail: everything left was issued >= one ring ago
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // slot s landed for all waves
+#pragma unroll
+      for (int x = 0; x < NF; ++x) asm volatile("" : "+v"(qf[kcs][x]));  // uses stay behind the wait
+      const char* slot = lds + c_pos * SLOTB;
+      bf16x8 af[2][PT];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int t = 0; t < PT; ++t) af[e][t] = *reinterpret_cast<const bf16x8*>(slot + t * (16 * 512) + rd_off[e]);
+      if (++c_pos == R) c_pos = 0;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // slot s is in registers everywhere: refill it
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int t = 0; t < PT; ++t) asm volatile("" : "+v"(af[e][t]));  // the fragment reads stay in front of the barrier
+      if (s + R < total) issue_dma();  // into the slot just read (i_pos trails c_pos by one ring)
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+#pragma unroll
+          for (int qt = 0; qt < NQT; ++qt) {
+            acc[j][t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[e][t], qf[kcs][(e * NQT + qt) * 2 + 0], acc[j][t][qt], 0, 0, 0);
+            if (LO) acc[j][t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[e][t], qf[kcs][(e * NQT + qt) * 2 + 1], acc[j][t][qt], 0, 0, 0);
+          }
+      if (s + R < total) {
+        if constexpr ((u + R) % T == 0) issue_q(qf[((u + R) / T) % NSETS]);  // slot s + R opens a K chunk: its fragments go into that chunk's set
+        advance();
+      }
+      if (c_kc == KC - 1) {  // tile j of the group is done: acc[j][t][qt][i] = partial dot of page t*16 + 4g + i with query qt*16 + p
+        const int pg = threadIdx.x & (PAGES - 1);
+        const int64_t tile = (int64_t)b + (int64_t)(i0 + c_grp * T + j) * G;
+        const int64_t page = tile * PAGES + pg;
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) {
+          if (qt > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone has read the previous query tile's sums
+#pragma unroll
+          for (int t = 0; t < PT; ++t) {
+            *reinterpret_cast<f32x4*>(red + (wave * 16 + p) * REDS + t * 16 + g * 4) = acc[j][t][qt];
+            acc[j][t][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          if (page < a.n) {
+#pragma unroll
+            for (int x = 0; x < PAGES / 16; ++x) {
+              const int ql = (int)(threadIdx.x / PAGES) + (256 / PAGES) * x;
+              if (qt * 16 + ql < a.n_queries) {
+                const float v = (red[(0 * 16 + ql) * REDS + pg] + red[(1 * 16 + ql) * REDS + pg]) +
+                                (red[(2 * 16 + ql) * REDS + pg] + red[(3 * 16 + ql) * REDS + pg]);
+                a.scores[(size_t)(qt * 16 + ql) * a.score_stride + page] = v;
+              }
+            }
+          }
+        }
+        // red[] is rewritten by the next tile end: at least one slot barrier later
+      }
+      if constexpr (j == T - 1) {
+        if (++c_kc == KC) { c_kc = 0; ++c_grp; }
+      }
+    });
+  }
+}
+
+// One workgroup per CU, 32-page tiles, a DMA ring of R slots (MV_OPT_FDE_BATCH_VARIANT = 7: R = 9; 8: R = 4, the control).
+template <int NQT, bool LO, int R>
+__global__ __launch_bounds__(256) void fde_scan_batch5_kernel(ScanBatchArgs a) {
+  constexpr int PT = 2;
+  __shared__ __attribute__((aligned(16))) char lds[R * (16 * PT * 512) + 4 * 16 * (16 * PT + 4) * 4];
+  float* red = reinterpret_cast<float*>(lds + R * (16 * PT * 512));
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = lane & 15, g = lane >> 4;
+  const int G = gridDim.x, b = blockIdx.x;
+  const int n_my = (a.n_tiles - b + G - 1) / G;  // tiles b, b + G, ...  (grid <= n_tiles; a.n_tiles counts 32-page tiles here)
+  const uint32_t row_bytes = (uint32_t)a.out_dim * 2u;
+  uint32_t src_off[2 * PT];
+#pragma unroll
+  for (int i = 0; i < 2 * PT; ++i) {
+    const uint32_t pl = (uint32_t)(wave * (4 * PT) + 2 * i + (lane >> 5));
+    src_off[i] = pl * row_bytes + ((((uint32_t)lane & 31u) ^ (pl & 15u)) << 4) + 4096u - (uint32_t)(i & 3) * 1024u;
+  }
+  uint32_t rd_off[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) rd_off[e] = (uint32_t)p * 512u + (((uint32_t)((2 * wave + e) * 4 + g) ^ (uint32_t)p) << 4);
+  const int n4 = n_my / 4, n2 = (n_my - 4 * n4) / 2, n1 = n_my - 4 * n4 - 2 * n2;
+  fb_phase_r<NQT, LO, 4, PT, 4, R>(a, lds, red, lane, wave, 0, n4, src_off, rd_off);
+  fb_phase_g<NQT, LO, 2, PT, 4>(a, lds, red, lane, wave, 4 * n4, n2, src_off, rd_off);  // the odd tiles out: the 4-slot ring
+  fb_phase_g<NQT, LO, 1, PT, 4>(a, lds, red, lane, wave, 4 * n4 + 2 * n2, n1, src_off, rd_off);
+}
 
 // Two workgroups per CU, 32-page tiles, fragment ring of two sets at four tiles per K chunk (MV_OPT_FDE_BATCH_VARIANT = 4).
 template <int NQT, bool LO>
@@ -2283,7 +2538,21 @@ int launch_fde_scan_batch(const FdeScanBatchArgs& a, hipStream_t s) {
                   (int32_t)a.out_dim, a.n_queries, (int32_t)n_tiles, a.inv_norm, a.doc_ord};
   const bool fin = fde_scan_batch_fuses_finish(a);  // the paired-tile kernel applies the cosine rule and the tombstones itself
   const dim3 grid((unsigned)std::min<int64_t>(n_tiles, ncu));
-  if (a.half_tiles) {  // 32-page tiles, two workgroups per CU (MV_OPT_FDE_BATCH_VARIANT = 4)
+  if (a.ring_slots) {  // 32-page tiles, one workgroup per CU, a deep DMA ring (MV_OPT_FDE_BATCH_VARIANT = 7 / 8)
+    const int64_t n32 = (a.n + 31) / 32;
+    k.n_tiles = (int32_t)n32;
+    const dim3 grid1((unsigned)std::min<int64_t>(n32, (int64_t)ncu));
+    auto go = [&](auto RC) {
+      constexpr int R = decltype(RC)::value;
+      if (a.hi_only) {
+        if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch5_kernel<1, false, R>), grid1, dim3(256), 0, s, k);
+        else hipLaunchKernelGGL((fde_scan_batch5_kernel<2, false, R>), grid1, dim3(256), 0, s, k);
+      } else if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch5_kernel<1, true, R>), grid1, dim3(256), 0, s, k);
+      else hipLaunchKernelGGL((fde_scan_batch5_kernel<2, true, R>), grid1, dim3(256), 0, s, k);
+    };
+    if (a.ring_slots >= 9) go(std::integral_constant<int, 9>{});
+    else go(std::integral_constant<int, 4>{});
+  } else if (a.half_tiles) {  // 32-page tiles, two workgroups per CU (MV_OPT_FDE_BATCH_VARIANT = 4)
     const int64_t n32 = (a.n + 31) / 32;
     k.n_tiles = (int32_t)n32;
     const dim3 grid2((unsigned)std::min<int64_t>(n32, (int64_t)ncu * 2));
@@ -2299,7 +2568,13 @@ int launch_fde_scan_batch(const FdeScanBatchArgs& a, hipStream_t s) {
     } else if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch_kernel<1>), grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((fde_scan_batch_kernel<2>), grid, dim3(256), 0, s, k);
   } else if (fin) {
-    if (a.hi_only) {
+    if (a.private_rings) {
+      if (a.hi_only) {
+        if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch2_kernel<1, false, true, true>), grid, dim3(256), 0, s, k);
+        else hipLaunchKernelGGL((fde_scan_batch2_kernel<2, false, true, true>), grid, dim3(256), 0, s, k);
+      } else if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch2_kernel<1, true, true, true>), grid, dim3(256), 0, s, k);
+      else hipLaunchKernelGGL((fde_scan_batch2_kernel<2, true, true, true>), grid, dim3(256), 0, s, k);
+    } else if (a.hi_only) {
       if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch2_kernel<1, false, true>), grid, dim3(256), 0, s, k);
       else hipLaunchKernelGGL((fde_scan_batch2_kernel<2, false, true>), grid, dim3(256), 0, s, k);
     } else if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch2_kernel<1, true, true>), grid, dim3(256), 0, s, k);
@@ -2310,6 +2585,12 @@ int launch_fde_scan_batch(const FdeScanBatchArgs& a, hipStream_t s) {
                          (const float*)nullptr, a.doc_ord, a.allow, a.n_allow_bits, a.allow_stride_bits);
     MV_HIP(hipGetLastError());
     return MV_OK;
+  } else if (a.private_rings) {
+    if (a.hi_only) {
+      if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch2_kernel<1, false, false, true>), grid, dim3(256), 0, s, k);
+      else hipLaunchKernelGGL((fde_scan_batch2_kernel<2, false, false, true>), grid, dim3(256), 0, s, k);
+    } else if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch2_kernel<1, true, false, true>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((fde_scan_batch2_kernel<2, true, false, true>), grid, dim3(256), 0, s, k);
   } else if (a.hi_only) {
     if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch2_kernel<1, false>), grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((fde_scan_batch2_kernel<2, false>), grid, dim3(256), 0, s, k);

@@ -826,6 +826,32 @@ def test_query_fde_encode_kernels_agree(mv, nq):
 
 
 # ------------------------------------------------------------------ batched queries (one slab pass, MFMA-bound form)
+def test_fde_batched_coarse_scan_forms_agree_on_a_corpus_of_many_tiles_per_workgroup(mv):
+    """The forms of the batched coarse pass (MV_OPT_FDE_BATCH_VARIANT 0 / 3 / 4 / 5 and the round-4 experiments 6 / 7 / 8) on a
+    corpus large enough that every workgroup walks several tiles -- the deep-ring form's main phase takes groups of four 32-page
+    tiles, which the small corpora of the test below never reach: 41 013 pages = 1 282 tiles of 32 (five per workgroup on 256 CUs,
+    a partial last tile), tombstones, 32 + 5 requests: the same scores and ids bit for bit."""
+    from morphik_core_amd import _lib
+
+    n = 41_013
+    ix = _idx(mv, capacity_pages=n, stride_rows=16, with_fde=True, with_float=False)
+    ix.fill_synthetic(1234, 0, n, pages_per_doc=3)
+    ix.remove_doc(7)
+    queries = [orc.synth_rows(4321, b, 0, 24) for b in range(37)]
+    for cosine in (1, 0):
+        ix.set_option(_lib.MV_OPT_FDE_COSINE, cosine)
+        ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, 0)
+        want = ix.query_batch(queries, 50, mode="fde")
+        ws, wi = ix.query(queries[0], 50, mode="fde")
+        np.testing.assert_allclose(want[0][0], ws, rtol=1e-4, atol=1e-6)
+        for form in (3, 4, 5, 6, 7, 8):
+            ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, form)
+            got = ix.query_batch(queries, 50, mode="fde")
+            for (s0, i0), (sx, ix_) in zip(want, got):
+                assert i0.tolist() == ix_.tolist() and s0.tolist() == sx.tolist(), (cosine, form)
+    ix.close()
+
+
 @pytest.mark.parametrize("n,stride", [(40, 16), (64, 16), (700, 32), (5000, 16)])
 def test_fde_batched_coarse_scan_matches_the_single_query_scan(mv, n, stride):
     """mv_query_topk_batch in FDE mode: ONE pass over the FDE slab per 32 queries (bf16 MFMA, query FDE as bf16 hi + lo;
@@ -889,6 +915,18 @@ def test_fde_batched_coarse_scan_matches_the_single_query_scan(mv, n, stride):
     half_tiles = ix.query_batch(queries, kk, mode="fde", allows=per_q, n_docs=n_docs)
     for (s0, i0), (s4, i4) in zip(paired, half_tiles):
         assert i0.tolist() == i4.tolist() and s0.tolist() == s4.tolist()
+    # MV_OPT_FDE_BATCH_VARIANT = 6 / 7 / 8 (round-4 experiments, kept as cross-checks): a private DMA ring per wave without slot
+    # barriers; 32-page tiles with a ring of nine / four slots -- the same K order and the same order of the partial sums: bit for bit
+    for form in (6, 7, 8):
+        ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, form)
+        for kind_allows, want in ((per_q, paired), (None, None)):
+            got = ix.query_batch(queries, kk, mode="fde", allows=kind_allows, n_docs=n_docs)
+            if want is None:
+                ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, 0)
+                want = ix.query_batch(queries, kk, mode="fde", allows=kind_allows, n_docs=n_docs)
+                ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, form)
+            for (s0, i0), (sx, ix_) in zip(want, got):
+                assert i0.tolist() == ix_.tolist() and s0.tolist() == sx.tolist(), form
     # MV_OPT_FDE_BATCH_VARIANT = 2: the query FDE rounded to bf16 (no lo term) -- the slab's own precision
     ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, 2)
     kk = min(10, n)

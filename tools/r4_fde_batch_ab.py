@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the batched FDE coarse pass forms in ONE process (interleaved rounds, stats.coarse_ms): default (0) against the look-ahead form (6).
+"""A/B of the batched FDE coarse pass forms (MV_OPT_FDE_BATCH_VARIANT) in ONE process (interleaved rounds, stats.coarse_ms), identical answers asserted.
    python tools/r4_fde_batch_ab.py [pages=1250000] [forms=0,6]"""
 import json
 import os
@@ -28,7 +28,8 @@ for r in range(9):
             got = [(s.tolist(), i.tolist()) for s, i in res]
             if key not in ref:
                 ref[key] = got
-            assert got == ref[key], f"form {f} B{B} differs from form {forms[0]}"
+            if f != 2:  # form 2 drops the low halves of the query split: other scores by design
+                assert got == ref[key], f"form {f} B{B} differs from form {forms[0]}"
             if r >= 2:
                 times[(f, B)].append(st.coarse_ms)
 out = {"pages": n}
