@@ -100,6 +100,27 @@ def test_too_many_vectors_is_an_error_and_factory():
         create_store("postgres")
 
 
+def test_exact_tier_choices_map_to_the_slab_flags_of_the_index():
+    """exact_tier "hbm" / "host" / "split" (and the providers that name them) -> the slabs and exact-tier flags MvIndex is created with:
+    the bf16 slab in HBM; FDE + e4m3 slabs with the exact rows pinned; the same with the leading pages' exact rows in the free HBM."""
+    want = {"hbm": dict(with_float=True, with_fp8=False), "host": dict(with_float=False, with_fp8=True, with_host_exact=True),
+            "split": dict(with_float=False, with_fp8=True, with_host_exact=True, with_exact_split=True)}
+    for tier, provider in (("hbm", "mi355x_fast"), ("host", "mi355x_fast_host_exact"), ("split", "mi355x_fast_split_exact"),
+                           ("host", "mi355x_sharded_fast_host_exact"), ("split", "mi355x_sharded_fast_split_exact")):
+        kw = dict(devices=[0, 0]) if "sharded" in provider else {}
+        st = create_store(provider, capacity_pages=8, **kw)
+        assert st.exact_tier == tier and st.mode == "fde_then_float"
+        fl = st._slab_flags()
+        assert fl["with_fde"] and not fl["with_binary"]
+        for k, v in want[tier].items():
+            assert fl.get(k, False) == v, (provider, k)
+        assert ("with_exact_split" in fl) == (tier == "split") and ("with_host_exact" in fl) == (tier != "hbm")
+    fl = create_store("mi355x_fp8_exact", capacity_pages=8)._slab_flags()  # configs[4]: e4m3 scan + exact re-score, no FDE
+    assert fl["with_fp8"] and fl["with_host_exact"] and not fl["with_fde"] and not fl["with_float"]
+    with pytest.raises(ValueError, match="exact_tier"):
+        MI355XFastMultiVectorStore(capacity_pages=8, exact_tier="nvme")
+
+
 def test_fast_hit_chunks_are_indistinguishable_from_validated_ones(monkeypatch):
     """models.hit_chunk_builder: search hits are built without re-validating values that were validated at ingest (1.5 -> 0.8 us per chunk,
     a third of the store's per-request Python).  The objects must be DocumentChunks in every observable way, must not share their metadata
