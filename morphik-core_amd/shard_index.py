@@ -33,6 +33,12 @@ class ShardedIndex:
         extra = {"with_host_exact": True} if with_host_exact else {}  # every shard pins the exact rows of ITS pages (per / n of the corpus)
         if with_exact_split:
             extra["with_exact_split"] = True  # ... after filling the HBM its other slabs leave free
+            import os
+
+            if len(set(self.devices)) < self.n_shards and "MV_EXACT_HBM_MAX_PAGES" not in os.environ:
+                # the split is "whatever this device has free": the first shard created on a device would leave none for the slabs of the next
+                raise ValueError("exact_tier=\"split\" takes the device's free HBM per shard: give every shard its own device "
+                                 "(or bound the HBM part with MV_EXACT_HBM_MAX_PAGES)")
         self.shards = [
             index_cls(capacity_pages=self.per, stride_rows=stride_rows, device=d, with_float=with_float, with_binary=with_binary,
                       with_fde=with_fde, with_fp8=with_fp8, fde=fde, id_base=self.id_base + r * self.per, **extra)

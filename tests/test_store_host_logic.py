@@ -107,7 +107,7 @@ def test_exact_tier_choices_map_to_the_slab_flags_of_the_index():
             "split": dict(with_float=False, with_fp8=True, with_host_exact=True, with_exact_split=True)}
     for tier, provider in (("hbm", "mi355x_fast"), ("host", "mi355x_fast_host_exact"), ("split", "mi355x_fast_split_exact"),
                            ("host", "mi355x_sharded_fast_host_exact"), ("split", "mi355x_sharded_fast_split_exact")):
-        kw = dict(devices=[0, 0]) if "sharded" in provider else {}
+        kw = dict(devices=[0, 1]) if "sharded" in provider else {}
         st = create_store(provider, capacity_pages=8, **kw)
         assert st.exact_tier == tier and st.mode == "fde_then_float"
         fl = st._slab_flags()
@@ -119,6 +119,13 @@ def test_exact_tier_choices_map_to_the_slab_flags_of_the_index():
     assert fl["with_fp8"] and fl["with_host_exact"] and not fl["with_fde"] and not fl["with_float"]
     with pytest.raises(ValueError, match="exact_tier"):
         MI355XFastMultiVectorStore(capacity_pages=8, exact_tier="nvme")
+    # a split takes "what the device has free": two shards of one store on ONE device are refused (unless the HBM part is bounded)
+    from morphik_core_amd.shard_index import ShardedIndex
+    from tests.fake_index import OracleComm
+
+    with pytest.raises(ValueError, match="its own device"):
+        ShardedIndex(capacity_pages=8, stride_rows=32, devices=[0, 0], with_float=False, with_fde=True, with_fp8=True, with_host_exact=True,
+                     with_exact_split=True, index_cls=OracleIndex, comm_cls=OracleComm)
 
 
 def test_fast_hit_chunks_are_indistinguishable_from_validated_ones(monkeypatch):
