@@ -556,6 +556,62 @@ def exact_shard(args, device, n, n_truth, budget, split, sets, truths, gaps):
     res["recall_s"] = round(time.time() - t0, 1)
     ix.set_option(L.MV_OPT_FDE_COARSE_N, 1000)
     ix.close()
+    if split and args.exact_shard_lean:
+        try:
+            res["lean_fde_plus_split_exact_tier"] = exact_shard_lean(args, device, n, n_truth, budget, sets, truths, gaps)
+        except Exception as e:  # noqa: BLE001
+            res["lean_fde_plus_split_exact_tier"] = {"error": repr(e)}
+    return res
+
+
+def exact_shard_lean(args, device, n, n_truth, budget, sets, truths, gaps):
+    """configs[3]'s shard WITHOUT the e4m3 slab (store option prune_slab=False, provider mi355x_fast_split_exact_lean): the FDE slab
+    and the exact rows only.  In the FDE pipeline the e4m3 slab only serves the pruning stage behind lists longer than
+    MV_OPT_RERANK_N, which the reference's own candidate rule (min(10 k, 75)) never reaches -- and its 164 GB hold the exact rows of
+    another 625 k pages: ~80 % of a 1.25 M-page shard's exact tier then sits in HBM, and a batch's rerank stops being a PCIe mover."""
+    from oracle import oracle as orc  # checker only (outside every timed region)
+
+    from morphik_core_amd import _lib as L
+    from morphik_core_amd import synth
+    from morphik_core_amd.index import MvIndex
+
+    stride = ((args.patches + 15) // 16) * 16
+    t0 = time.time()
+    ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=False, with_fde=True, with_host_exact=True, with_exact_split=True)
+    in_hbm = ix.exact_hbm_pages
+    res = {"pages": n, "slabs": "FDE(10240 bf16) in HBM; exact bf16 rows split between the rest of the HBM and pinned host RAM; no e4m3 / sign-bit slab",
+           "exact_tier_pages_in_hbm": in_hbm, "exact_tier_in_hbm_GB": round(in_hbm * stride * 256 / 1e9, 1),
+           "pinned_host_exact_tier_GB": round((n - in_hbm) * stride * 256 / 1e9, 1), "share_of_exact_reads_over_pcie": round((n - in_hbm) / n, 3),
+           "create_and_pin_s": round(time.time() - t0, 1)}
+    t0 = time.time()
+    ix.fill_synthetic(synth.SEED_CORPUS, 0, n, n_rows=args.patches)
+    for name, st_ in sets.items():
+        synth.plant_neighbours_any(ix, st_ if name.startswith("_") else st_["spec"], synth.SEED_CORPUS, args.patches, 0, n)
+    res["fill_and_plant_s"] = round(time.time() - t0, 1)
+    rsets = {k_: v for k_, v in sets.items() if not k_.startswith("_")}
+    qs = rsets["planted"]["queries"]
+    res["fde_then_exact_rerank"] = fde_pipeline_timings(ix, qs, n, (75, 1000))
+    for cn in (75, 1000):
+        n_mid, tier = ix.rerank_plan(cn, K, args.qtokens)
+        res["fde_then_exact_rerank"][f"coarse{cn}"]["rerank_plan"] = {"tier": tier, "e4m3_pruning_to": n_mid, "exact_pages_read": (n_mid or cn)}
+    ix.set_option(L.MV_OPT_FDE_COARSE_N, 75)
+    w = 0.0
+    for q in qs[:4]:
+        s, i = ix.query(q, K, mode="fde_then_float")
+        want = np.array([orc.maxsim_bf16(q, ix.read_pages(int(p), 1)[0, : args.patches]) for p in i], np.float32)
+        w = max(w, float(np.max(np.abs(s - want) / np.maximum(np.abs(want), 1e-6))))
+    res["max_rel_score_err_vs_float_oracle"] = w
+
+    def ids_of(cn):
+        def f(q, al):
+            ix.set_option(L.MV_OPT_FDE_COARSE_N, cn)
+            return ix.query(q, K, mode="fde_then_float", allow=al)[1].tolist()
+        return f
+
+    keep = {k_: rsets[k_] for k_ in ("planted", "hard_negatives", "clustered_topics")}
+    rec = recall_of(ix, keep, truths, gaps, [("fde_top75_then_exact", ids_of(75)), ("fde_top1000_then_exact", ids_of(1000))], first_pages_bitmap(n_truth, n))
+    res["recall_at_10_vs_exact_bf16"] = {k_: {m: v[m] for m in ("fde_top75_then_exact", "fde_top1000_then_exact")} for k_, v in rec.items() if k_ in keep}
+    ix.close()
     return res
 
 
@@ -762,6 +818,8 @@ def main():
                     help="share of mv_host_pin_budget_bytes() (memory cgroup limit - usage - headroom) the exact shard's pinned tier may take (--exact-shard-split 0)")
     ap.add_argument("--exact-shard-split", type=int, default=1,
                     help="1: MV_WITH_EXACT_SPLIT -- the exact rows of the leading pages in the HBM the slabs leave free, the rest pinned (the full 1.25 M pages fit); 0: all pinned")
+    ap.add_argument("--exact-shard-lean", type=int, default=1,
+                    help="1: after the exact shard, the same shard WITHOUT the e4m3 / sign-bit slabs (FDE slab + split exact tier only: most exact rows in HBM)")
     ap.add_argument("--exact-shard-split-pin-frac", type=float, default=0.84,
                     help="share of the pin budget the PINNED part of a split exact tier may take (the page count is cut to keep it)")
     ap.add_argument("--full-shard-pages", type=int, default=1_250_000,

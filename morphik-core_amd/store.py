@@ -97,6 +97,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         app_id_resolver: Optional[Callable[[str], Optional[str]]] = None,
         exact_tier: str = "hbm",
         rerank_n: int = 0,
+        prune_slab: bool = True,
         **_ignored: Any,
     ):
         self.capacity_pages = int(capacity_pages)
@@ -115,6 +116,11 @@ class MI355XMultiVectorStore(BaseVectorStore):
         # pages read from the exact tier per request (MV_OPT_RERANK_N; 0 = the library's 128): the candidate list of "fp8_then_float",
         # the cut of the e4m3 pruning stage of "fde_then_float" over a host tier -- n x 256 KiB over PCIe per request
         self.rerank_n = int(rerank_n)
+        # "fde_then_float" over a host / split exact tier: keep the e4m3 slab (131 KB / page of HBM) whose only job there is the pruning
+        # stage behind coarse lists longer than rerank_n.  False: no e4m3 slab -- every candidate goes to the exact tier (the reference's
+        # pipeline with its own min(10 k, 75) rule never prunes anyway), and a split tier gets that HBM for exact rows instead: a
+        # 1.25 M-page shard keeps ~1 M pages' exact rows on the device and pins the rest
+        self.prune_slab = bool(prune_slab)
         self.storage = storage  # callers reach for .storage (document_service.py:1570-1575)
         # multi_vector_store.py:120-160: content is stored externally when a storage object is configured
         self.enable_external_storage = bool(enable_external_storage)
@@ -179,7 +185,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         # exact_tier "split": the host tier, with the exact rows of the leading pages in whatever HBM the other slabs leave free
         host = self.mode == "fp8_then_float" or (self.mode == "fde_then_float" and self.exact_tier in ("host", "split"))
         return dict(with_float=self.mode == "float" or (self.mode == "fde_then_float" and not host), with_binary=self.mode == "binary",
-                    with_fde=self.mode == "fde_then_float", with_fp8=self.mode in ("float_fp8", "fp8_then_float") or (self.mode == "fde_then_float" and host),
+                    with_fde=self.mode == "fde_then_float", with_fp8=self.mode in ("float_fp8", "fp8_then_float") or (self.mode == "fde_then_float" and host and self.prune_slab),
                     **({"with_host_exact": True} if host else {}), **({"with_exact_split": True} if host and self.exact_tier == "split" else {}))
 
     def _make_index(self):
@@ -671,7 +677,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
     def _book(self) -> Dict[str, Any]:
         return {
             "version": 3, "mode": self.mode, "capacity_pages": self.capacity_pages, "stride_rows": self.stride_rows,
-            "id_base": self.id_base, "fde_coarse_n": self.fde_coarse_n, "exact_tier": self.exact_tier, "rerank_n": self.rerank_n, "next_ord": self._next_ord,
+            "id_base": self.id_base, "fde_coarse_n": self.fde_coarse_n, "exact_tier": self.exact_tier, "rerank_n": self.rerank_n, "prune_slab": self.prune_slab, "next_ord": self._next_ord,
             "rows": [[p, r[0], r[1], r[2], r[3], r[4]] for p, r in self._rows.items()],
             "doc_ord": self._doc_ord, "doc_app": {str(k): v for k, v in self._doc_app.items()},
         }
@@ -768,7 +774,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         elif book.get("checkpoint") and (not os.path.exists(idp) or open(idp).read().strip() != book["checkpoint"]):
             raise RuntimeError(f"{directory}: index.mv and store.json belong to different checkpoints (crash during save?)")
         self = cls(capacity_pages=book["capacity_pages"], stride_rows=book["stride_rows"], device=device, mode=book["mode"], storage=storage,
-                   id_base=book["id_base"], fde_coarse_n=book.get("fde_coarse_n", 0), exact_tier=book.get("exact_tier", "hbm"), rerank_n=book.get("rerank_n", 0), **kw)
+                   id_base=book["id_base"], fde_coarse_n=book.get("fde_coarse_n", 0), exact_tier=book.get("exact_tier", "hbm"), rerank_n=book.get("rerank_n", 0), prune_slab=book.get("prune_slab", True), **kw)
         self._index = cls._load_index(self, directory, book, device)
         self._apply_options(self._index)
         for p, doc, chunk_no, content, meta_json, app in book["rows"]:
@@ -894,8 +900,8 @@ class MI355XShardedFastMultiVectorStore(_ShardedMixin, MI355XFastMultiVectorStor
 
 def create_store(provider: str, **kw: Any) -> MI355XMultiVectorStore:
     """Factory for core/services_init.py: [multivector_store] provider =
-    "mi355x" | "mi355x_fast" | "mi355x_fast_host_exact" | "mi355x_fast_split_exact" | "mi355x_float" | "mi355x_fp8_exact" | "mi355x_sharded" |
-    "mi355x_sharded_fast" | "mi355x_sharded_fast_host_exact" | "mi355x_sharded_fast_split_exact" | "mi355x_sharded_float" |
+    "mi355x" | "mi355x_fast" | "mi355x_fast_host_exact" | "mi355x_fast_split_exact" | "mi355x_fast_split_exact_lean" | "mi355x_float" | "mi355x_fp8_exact" | "mi355x_sharded" |
+    "mi355x_sharded_fast" | "mi355x_sharded_fast_host_exact" | "mi355x_sharded_fast_split_exact" | "mi355x_sharded_fast_split_exact_lean" | "mi355x_sharded_float" |
     "mi355x_sharded_fp8_exact" | "mi355x_remote"."""
     if provider == "mi355x":
         return MI355XMultiVectorStore(**kw)
@@ -905,6 +911,8 @@ def create_store(provider: str, **kw: Any) -> MI355XMultiVectorStore:
         return MI355XFastMultiVectorStore(exact_tier="host", **kw)
     if provider == "mi355x_fast_split_exact":  # the same, with the exact rows of the leading pages in the HBM the slabs leave free (1.25 M pages / GPU)
         return MI355XFastMultiVectorStore(exact_tier="split", **kw)
+    if provider == "mi355x_fast_split_exact_lean":  # ... without the e4m3 pruning slab: FDE slab + exact rows only, ~80 % of them in HBM at 1.25 M pages / GPU
+        return MI355XFastMultiVectorStore(exact_tier="split", prune_slab=False, **kw)
     if provider == "mi355x_float":
         return MI355XMultiVectorStore(mode="float", **kw)
     if provider == "mi355x_fp8_exact":  # e4m3 slab in HBM + exact bf16 tier in pinned host RAM
@@ -917,6 +925,8 @@ def create_store(provider: str, **kw: Any) -> MI355XMultiVectorStore:
         return MI355XShardedFastMultiVectorStore(exact_tier="host", **kw)
     if provider == "mi355x_sharded_fast_split_exact":  # configs[3] at full size: every shard splits its exact tier between its free HBM and pinned host memory
         return MI355XShardedFastMultiVectorStore(exact_tier="split", **kw)
+    if provider == "mi355x_sharded_fast_split_exact_lean":  # ... and no e4m3 pruning slab: most of every shard's exact rows stay in its HBM
+        return MI355XShardedFastMultiVectorStore(exact_tier="split", prune_slab=False, **kw)
     if provider == "mi355x_sharded_float":
         return MI355XShardedMultiVectorStore(mode="float", **kw)
     if provider == "mi355x_sharded_fp8_exact":  # configs[4]: e4m3 scan of every shard -> GLOBAL top-n -> exact re-score from the owners' host tiers

@@ -577,3 +577,48 @@ def test_split_exact_tier_behind_the_store():
         st.close()
     assert res["mi355x_fast_split_exact"] == res["mi355x_fast_host_exact"] and len(res["mi355x_fast_host_exact"]) == 6
     assert res["mi355x_sharded_fast_split_exact"] == res["mi355x_sharded_fast_host_exact"]
+
+
+def test_lean_shard_fde_slab_plus_split_exact_tier_without_the_e4m3_slab():
+    """An FDE shard WITHOUT the e4m3 slab (store option prune_slab=False): there is no pruning stage -- every coarse candidate goes to the
+    (split) exact tier, whatever the list length -- and the answers are those of an index that keeps the slab but never prunes
+    (MV_OPT_RERANK_N at its maximum).  The modes that need the e4m3 slab are refused."""
+    from morphik_core_amd import MvError, _lib
+
+    N, stride, k = 420, 48, 7
+    pages = _corpus(N, stride, seed=38)
+    full = _idx(capacity_pages=N, stride_rows=stride, with_float=False, with_fde=True, with_fp8=True, with_host_exact=True)
+    with _SplitAt(150):
+        lean = _idx(capacity_pages=N, stride_rows=stride, with_float=False, with_fde=True, with_host_exact=True, with_exact_split=True)
+    assert lean.exact_hbm_pages == 150
+    for ix in (full, lean):
+        ix.add(pages)
+    full.set_option(_lib.MV_OPT_RERANK_N, 1024)
+    qs = [orc.synth_rows(38, 3, 0, 20)] + [orc.synth_rows(981, j, 0, 20) for j in range(3)]
+    for coarse_n in (75, 300):
+        for ix in (full, lean):
+            ix.set_option(_lib.MV_OPT_FDE_COARSE_N, coarse_n)
+        assert lean.rerank_plan(coarse_n, k, 20) == (0, "host")
+        for q in qs:
+            ws, wi = full.query(q, k, mode="fde_then_float")
+            s, i = lean.query(q, k, mode="fde_then_float")
+            assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist(), coarse_n
+            want = np.array([orc.maxsim_bf16(q, pages[p], int(_cascade_pad(lean, q, pages, coarse_n, p))) for p in i], np.float32)
+            np.testing.assert_allclose(s, want, rtol=RTOL)
+        for (ws, wi), (s, i) in zip(full.query_batch(qs, k, mode="fde_then_float"), lean.query_batch(qs, k, mode="fde_then_float")):
+            assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist(), (coarse_n, "batch")
+    for mode in ("fp8_then_float", "float_fp8"):
+        with pytest.raises(MvError):
+            lean.query(qs[0], k, mode=mode)
+    full.close()
+    lean.close()
+
+
+def _cascade_pad(ix, q, pages, coarse_n, page):
+    """Pad length the reference's rerank gives `page`: the longest page of its batch of 128 in the coarse list (coarse rank order)."""
+    coarse = ix.score_all(q, mode="fde")
+    cs, ci = orc.topk(coarse, coarse_n)
+    ci = ci[np.isfinite(cs)]
+    rows = np.array([pages[c].shape[0] for c in ci])
+    pads = _batch_pads(rows)
+    return pads[list(ci).index(page)]

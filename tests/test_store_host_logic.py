@@ -115,6 +115,9 @@ def test_exact_tier_choices_map_to_the_slab_flags_of_the_index():
         for k, v in want[tier].items():
             assert fl.get(k, False) == v, (provider, k)
         assert ("with_exact_split" in fl) == (tier == "split") and ("with_host_exact" in fl) == (tier != "hbm")
+    for provider, kw in (("mi355x_fast_split_exact_lean", {}), ("mi355x_sharded_fast_split_exact_lean", dict(devices=[0, 1]))):
+        fl = create_store(provider, capacity_pages=8, **kw)._slab_flags()  # no e4m3 pruning slab: FDE slab + the split exact tier only
+        assert fl["with_fde"] and fl["with_host_exact"] and fl["with_exact_split"] and not fl["with_fp8"] and not fl["with_float"]
     fl = create_store("mi355x_fp8_exact", capacity_pages=8)._slab_flags()  # configs[4]: e4m3 scan + exact re-score, no FDE
     assert fl["with_fp8"] and fl["with_host_exact"] and not fl["with_fde"] and not fl["with_float"]
     with pytest.raises(ValueError, match="exact_tier"):
