@@ -900,9 +900,9 @@ class MI355XShardedFastMultiVectorStore(_ShardedMixin, MI355XFastMultiVectorStor
 
 def create_store(provider: str, **kw: Any) -> MI355XMultiVectorStore:
     """Factory for core/services_init.py: [multivector_store] provider =
-    "mi355x" | "mi355x_fast" | "mi355x_fast_host_exact" | "mi355x_fast_split_exact" | "mi355x_fast_split_exact_lean" | "mi355x_float" | "mi355x_fp8_exact" | "mi355x_sharded" |
+    "mi355x" | "mi355x_fast" | "mi355x_fast_host_exact" | "mi355x_fast_split_exact" | "mi355x_fast_split_exact_lean" | "mi355x_float" | "mi355x_fp8_exact" | "mi355x_fp8_split_exact" | "mi355x_sharded" |
     "mi355x_sharded_fast" | "mi355x_sharded_fast_host_exact" | "mi355x_sharded_fast_split_exact" | "mi355x_sharded_fast_split_exact_lean" | "mi355x_sharded_float" |
-    "mi355x_sharded_fp8_exact" | "mi355x_remote"."""
+    "mi355x_sharded_fp8_exact" | "mi355x_sharded_fp8_split_exact" | "mi355x_remote"."""
     if provider == "mi355x":
         return MI355XMultiVectorStore(**kw)
     if provider == "mi355x_fast":
@@ -917,6 +917,8 @@ def create_store(provider: str, **kw: Any) -> MI355XMultiVectorStore:
         return MI355XMultiVectorStore(mode="float", **kw)
     if provider == "mi355x_fp8_exact":  # e4m3 slab in HBM + exact bf16 tier in pinned host RAM
         return MI355XMultiVectorStore(mode="fp8_then_float", **kw)
+    if provider == "mi355x_fp8_split_exact":  # ... with the exact rows of the leading pages in the HBM the e4m3 slab leaves free
+        return MI355XMultiVectorStore(mode="fp8_then_float", exact_tier="split", **kw)
     if provider == "mi355x_sharded":
         return MI355XShardedMultiVectorStore(**kw)
     if provider == "mi355x_sharded_fast":
@@ -931,6 +933,8 @@ def create_store(provider: str, **kw: Any) -> MI355XMultiVectorStore:
         return MI355XShardedMultiVectorStore(mode="float", **kw)
     if provider == "mi355x_sharded_fp8_exact":  # configs[4]: e4m3 scan of every shard -> GLOBAL top-n -> exact re-score from the owners' host tiers
         return MI355XShardedMultiVectorStore(mode="fp8_then_float", **kw)
+    if provider == "mi355x_sharded_fp8_split_exact":  # ... every shard with a split exact tier
+        return MI355XShardedMultiVectorStore(mode="fp8_then_float", exact_tier="split", **kw)
     if provider == "mi355x_remote":  # every process but the one that owns the HBM slab (store_server.py)
         from .store_server import MI355XRemoteMultiVectorStore
 

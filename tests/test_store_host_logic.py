@@ -120,6 +120,9 @@ def test_exact_tier_choices_map_to_the_slab_flags_of_the_index():
         assert fl["with_fde"] and fl["with_host_exact"] and fl["with_exact_split"] and not fl["with_fp8"] and not fl["with_float"]
     fl = create_store("mi355x_fp8_exact", capacity_pages=8)._slab_flags()  # configs[4]: e4m3 scan + exact re-score, no FDE
     assert fl["with_fp8"] and fl["with_host_exact"] and not fl["with_fde"] and not fl["with_float"]
+    for provider, kw in (("mi355x_fp8_split_exact", {}), ("mi355x_sharded_fp8_split_exact", dict(devices=[0, 1]))):
+        fl = create_store(provider, capacity_pages=8, **kw)._slab_flags()
+        assert fl["with_fp8"] and fl["with_host_exact"] and fl["with_exact_split"] and not fl["with_fde"] and not fl["with_float"]
     with pytest.raises(ValueError, match="exact_tier"):
         MI355XFastMultiVectorStore(capacity_pages=8, exact_tier="nvme")
     # a split takes "what the device has free": two shards of one store on ONE device are refused (unless the HBM part is bounded)
