@@ -291,6 +291,24 @@ MV_API int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_
 MV_API int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, int32_t k,
                                int mode, const uint32_t* allow_bits, int64_t n_allow_words, int32_t allow_per_query,
                                float* out_scores, int64_t* out_ids, int32_t* out_n, mv_query_stats* stats);
+/* Bring-your-own FDE.  The reference computes its FDE vectors with a C++ extension that is not part of its source tree
+ * (`fde.generate_document_encoding` / `generate_query_encoding`: fast_multivector_store.py:447-449, :521); this library restates the
+ * published algorithm, which matches that extension only as far as the publication pins it.  Where the extension is
+ * installed -- or document FDEs already exist in a TurboPuffer namespace -- a deployment can keep ITS vectors and use the GPU for the
+ * scan and the rerank:
+ *   mv_index_import_fde      document FDE vectors (host fp32 [n_pages][mv_fde_output_dim(cfg)]) REPLACE the encodings the library made
+ *                            of pages [page0, page0 + n_pages) at ingest (bf16-rounded into the slab, 1/|d| of the rounded vector
+ *                            beside it: the encode kernels' own convention).  mv_index_replace_page re-encodes that page: import again.
+ *   mv_query_topk_fde,       mv_query_topk / _batch (MV_MODE_FDE_THEN_FLOAT or MV_MODE_FDE_ONLY) with the caller's query FDE vector(s)
+ *   mv_query_topk_batch_fde  (host fp32 [n_queries][out_dim]) in place of the encoding of the query rows on the device; the rerank
+ *                            still scores the query ROWS (q).  NaN / Inf in either kind of vector: MV_ERR_INVALID. */
+MV_API int mv_index_import_fde(mv_index* ix, int64_t page0, int64_t n_pages, const float* fde);
+MV_API int mv_query_topk_fde(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const float* q_fde, int32_t k, int mode,
+                             const uint32_t* allow_bits, int64_t n_allow_words, float* out_scores, int64_t* out_ids, int32_t* out_n,
+                             mv_query_stats* stats);
+MV_API int mv_query_topk_batch_fde(mv_index* ix, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, const float* q_fde,
+                                   int32_t k, int mode, const uint32_t* allow_bits, int64_t n_allow_words, int32_t allow_per_query,
+                                   float* out_scores, int64_t* out_ids, int32_t* out_n, mv_query_stats* stats);
 /* Merge of the per-shard top-k lists after the RCCL all-gather (row-sharded corpus).  d_scores / d_ids: DEVICE buffers
  * [world][kk], each row sorted (score desc, id asc), padded with (-inf, -1), rank r owning ids below rank r+1's;
  * world*kk <= 2048.  Writes k entries (padded the same way) on `stream` (enqueue only).  Same tie rule as one index. */
@@ -448,6 +466,16 @@ MV_API int mv_comm_query_topk_batch(mv_comm* c, const void* q, int q_dtype, int3
 
 /* Persistence ("checkpoint" of the HBM index): raw slabs + metadata in one file (written to <path>.tmp, fsync'ed and
  * renamed: a crash mid-save keeps the previous checkpoint). */
+/* ... and with the caller's own query FDE vectors (mv_query_topk_fde above): every shard's coarse stage uses them */
+MV_API int mv_comm_query_topk_fde(mv_comm* c, const void* q, int q_dtype, int32_t n_q_rows, const float* q_fde, int32_t k, int mode,
+                                  const uint32_t* allow_bits, int64_t n_allow_words, float* out_scores, int64_t* out_ids, int32_t* out_n,
+                                  mv_query_stats* stats);
+MV_API int mv_comm_query_topk_batch_fde(mv_comm* c, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, const float* q_fde,
+                                        int32_t k, int mode, const uint32_t* allow_bits, int64_t n_allow_words, int32_t allow_per_query,
+                                        float* out_scores, int64_t* out_ids, int32_t* out_n, mv_query_stats* stats);
+MV_API int mv_two_stage_coarse_device_fde(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const float* q_fde, int32_t n_coarse,
+                                          int mode, const uint32_t* allow_bits, int64_t n_allow_words, mv_cand_rec* d_out_recs, void* stream);
+
 MV_API int mv_index_save(mv_index* ix, const char* path);
 MV_API int mv_index_load(const char* path, int32_t device, mv_index** out);
 

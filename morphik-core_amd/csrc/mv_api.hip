@@ -330,7 +330,11 @@ int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_wo
   e.variant = ix->fde_query_encode_variant;
   // one page of n_q rows: the row count travels as a kernel argument (no 16-byte H2D copy in front of every query)
   e.x_f32 = ix->d_qf32; e.row_offsets = nullptr; e.stride = n_q; e.n_pages = 1; e.is_query = 1; e.out_f32 = ix->d_qfde;
-  int rc = launch_fde_encode(ix->fde_t, e, ix->stream);
+  int rc = MV_OK;
+  if (const float* ov = query_fde_override(ix->fde_t.out_dim))  // mv_query_topk_fde: the caller's own encoding of this query
+    MV_HIP(hipMemcpyAsync(ix->d_qfde, ov, (size_t)ix->fde_t.out_dim * 4, hipMemcpyHostToDevice, ix->stream));
+  else
+    rc = launch_fde_encode(ix->fde_t, e, ix->stream);
   if (rc) return rc;
   if (stage_events) MV_HIP(hipEventRecord(ix->ev_st[0], ix->stream));
   FdeScanArgs s{};
@@ -873,6 +877,14 @@ struct ExclusiveLock {
 // kernel half way through hipHostMalloc (measured on the MI355X pool: memory.max = 300 GiB on a 3 TiB host -- the box is lost,
 // no error is returned).  So the library reads the limits itself and refuses up front.
 namespace mv {
+
+thread_local QueryFdeOverride g_qfde;
+
+int check_fde_finite(const float* v, size_t n, const char* what) {
+  for (size_t i = 0; i < n; ++i)
+    if (!std::isfinite(v[i])) { set_error("%s: element %zu of the FDE vectors is NaN / Inf", what, i); return MV_ERR_INVALID; }
+  return MV_OK;
+}
 
 static int64_t read_i64_file(const char* path) {  // -1: missing / "max" / unparsable
   FILE* f = fopen(path, "r");
@@ -1587,6 +1599,48 @@ int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_r
                                   d_out_ids, stream, stats, 0);
 }
 
+// ---- the caller's own FDE vectors (the reference computes them with its `fde` extension: fast_multivector_store.py:447-449, :521)
+static int check_fde_call(const mv_index* ix, int mode, const float* q_fde, int64_t n_queries, const char* what) {
+  if (!ix || !q_fde) { set_error("%s: null argument", what); return MV_ERR_INVALID; }
+  if (mode != MV_MODE_FDE_THEN_FLOAT && mode != MV_MODE_FDE_ONLY) { set_error("%s: mode %d has no FDE stage (MV_MODE_FDE_THEN_FLOAT / MV_MODE_FDE_ONLY)", what, mode); return MV_ERR_INVALID; }
+  if (!(ix->cfg.flags & MV_WITH_FDE)) { set_error("index has no FDE slab (MV_WITH_FDE)"); return MV_ERR_STATE; }
+  return check_fde_finite(q_fde, (size_t)n_queries * (size_t)ix->fde_t.out_dim, what);
+}
+
+int mv_query_topk_fde(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const float* q_fde, int32_t k, int mode,
+                      const uint32_t* allow_bits, int64_t n_allow_words, float* out_scores, int64_t* out_ids, int32_t* out_n, mv_query_stats* stats) {
+  if (int rc = check_fde_call(ix, mode, q_fde, 1, "mv_query_topk_fde")) return rc;
+  QueryFdeScope sc(q_fde);
+  return mv_query_topk(ix, q, q_dtype, n_q_rows, k, mode, allow_bits, n_allow_words, out_scores, out_ids, out_n, stats);
+}
+
+int mv_query_topk_batch_fde(mv_index* ix, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, const float* q_fde, int32_t k, int mode,
+                            const uint32_t* allow_bits, int64_t n_allow_words, int32_t allow_per_query, float* out_scores, int64_t* out_ids,
+                            int32_t* out_n, mv_query_stats* stats) {
+  if (n_queries < 1) { set_error("mv_query_topk_batch_fde: bad argument"); return MV_ERR_INVALID; }
+  if (int rc = check_fde_call(ix, mode, q_fde, n_queries, "mv_query_topk_batch_fde")) return rc;
+  QueryFdeScope sc(q_fde);
+  return mv_query_topk_batch(ix, q, q_dtype, n_queries, n_q_rows, k, mode, allow_bits, n_allow_words, allow_per_query, out_scores, out_ids, out_n, stats);
+}
+
+int mv_index_import_fde(mv_index* ix, int64_t page0, int64_t n_pages, const float* fde) {
+  if (!ix || !fde || page0 < 0 || n_pages < 0 || page0 + n_pages > ix->size.load()) { set_error("import_fde: range"); return MV_ERR_INVALID; }
+  if (!(ix->cfg.flags & MV_WITH_FDE)) { set_error("index has no FDE slab (MV_WITH_FDE)"); return MV_ERR_STATE; }
+  const int64_t out_dim = ix->fde_t.out_dim;
+  if (int rc = check_fde_finite(fde, (size_t)n_pages * (size_t)out_dim, "import_fde")) return rc;
+  ExclusiveLock lk(ix);  // queries read the FDE slab without the writer lock
+  DeviceGuard g(ix->cfg.device);
+  const int64_t chunk = std::max<int64_t>(1, ((int64_t)64 << 20) / (out_dim * 4));  // 64 MiB of fp32 vectors per staging round
+  int rc = w_reserve(&ix->w_tmp, &ix->w_tmp_bytes, (size_t)std::min(chunk, std::max<int64_t>(n_pages, 1)) * out_dim * 4);
+  for (int64_t done = 0; done < n_pages && !rc; done += chunk) {
+    const int64_t c = std::min(chunk, n_pages - done);
+    MV_HIP(hipMemcpyAsync(ix->w_tmp, fde + (size_t)done * out_dim, (size_t)c * out_dim * 4, hipMemcpyHostToDevice, ix->w_stream));
+    rc = launch_fde_import((const float*)ix->w_tmp, c, out_dim, ix->fde + (size_t)(page0 + done) * out_dim, ix->fde_inv_norm + page0 + done, ix->w_stream);
+    MV_HIP(hipStreamSynchronize(ix->w_stream));  // the staging buffer is reused; the caller's buffer may be pageable
+  }
+  return rc;
+}
+
 // Selection workspace of the batched entry point: one top-k workspace, result row and pinned read-back row per query of a
 // group (q_mu held).
 int mv_internal_ensure_batch_select_ws(mv_index* ix) {
@@ -1791,7 +1845,10 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
     FdeEncodeArgs e{};
     e.variant = 2;  // the latency kernel of the single-query path, one grid row per query
     e.x_f32 = ix->d_bqf32; e.row_offsets = nullptr; e.stride = rpq; e.n_pages = nb; e.is_query = 1; e.out_f32 = ix->d_bqfde;
-    rc = launch_fde_encode(ix->fde_t, e, ix->stream);
+    if (const float* ov = query_fde_override(out_dim, b0))  // mv_query_topk_batch_fde: the caller's own encodings of this group's queries
+      MV_HIP(hipMemcpyAsync(ix->d_bqfde, ov, (size_t)nb * out_dim * 4, hipMemcpyHostToDevice, ix->stream));
+    else
+      rc = launch_fde_encode(ix->fde_t, e, ix->stream);
     if (rc) return rc;
     MV_HIP(hipEventRecord(ix->ev_st[0], ix->stream));
     FdeScanBatchArgs sa{};
@@ -2016,6 +2073,7 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
     for (int32_t b = 0; b < n_queries; ++b) {
       mv_query_stats st{};
       const uint32_t* ab = (allow_bits && allow_per_query) ? allow_bits + (size_t)b * n_allow_words : allow_bits;
+      QueryFdeCursor cur(g_qfde.cur + b);
       int rc = mv_internal_query_common(ix, (const char*)q + (size_t)b * n_q_rows * kDim * esz, q_dtype, n_q_rows, k, mode, ab, n_allow_words,
                                         out_scores ? out_scores + (size_t)b * k : nullptr, out_ids ? out_ids + (size_t)b * k : nullptr, out_n + b, nullptr,
                                         nullptr, nullptr, stats ? &st : nullptr, 0);

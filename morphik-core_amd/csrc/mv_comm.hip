@@ -352,7 +352,10 @@ int mv_internal_two_stage_batch_coarse(mv_index* ix, const void* q, int q_dtype,
     FdeEncodeArgs e{};
     e.variant = 2;
     e.x_f32 = ix->d_bqf32; e.row_offsets = nullptr; e.stride = rpq; e.n_pages = nb; e.is_query = 1; e.out_f32 = ix->d_bqfde;
-    rc = launch_fde_encode(ix->fde_t, e, ix->stream);
+    if (const float* ov = query_fde_override(ix->fde_t.out_dim))  // mv_comm_query_topk_batch_fde: the caller's encodings of this group's queries
+      MV_HIP(hipMemcpyAsync(ix->d_bqfde, ov, (size_t)nb * ix->fde_t.out_dim * 4, hipMemcpyHostToDevice, ix->stream));
+    else
+      rc = launch_fde_encode(ix->fde_t, e, ix->stream);
     if (rc) return rc;
     FdeScanBatchArgs sa{};
     sa.fde = ix->fde; sa.inv_norm = ix->fde_cosine ? ix->fde_inv_norm : nullptr; sa.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
@@ -951,6 +954,7 @@ int mv_comm_query_topk_batch(mv_comm* c, const void* q, int q_dtype, int32_t n_q
   if (!batched) {  // request by request through the single-query communicator (each call takes c->mu itself)
     for (int32_t b = 0; b < n_queries; ++b) {
       const uint32_t* ab = (allow_bits && allow_per_query) ? allow_bits + (size_t)b * n_allow_words : allow_bits;
+      QueryFdeCursor cur(g_qfde.cur + b);
       int rc = mv_comm_query_topk(c, (const char*)q + (size_t)b * n_q_rows * kDim * esz, q_dtype, n_q_rows, k, mode, ab, n_allow_words,
                                   out_scores ? out_scores + (size_t)b * k : nullptr, out_ids ? out_ids + (size_t)b * k : nullptr, out_n + b, nullptr);
       if (rc) return rc;
@@ -984,6 +988,7 @@ int mv_comm_query_topk_batch(mv_comm* c, const void* q, int q_dtype, int32_t n_q
     const int nb = std::min(group, n_queries - b0);
     const char* qg = (const char*)q + (size_t)b0 * n_q_rows * kDim * esz;
     const uint32_t* ag = per_query ? allow_bits + (size_t)b0 * n_allow_words : allow_bits;
+    QueryFdeCursor fde_cur(g_qfde.cur + b0);  // a caller's own query FDEs: this group's start
     for (int i = 0; i < R; ++i) {
       Shard& s = c->sh[i];
       DeviceGuard g(s.dev);
@@ -1047,6 +1052,41 @@ int mv_comm_query_topk_batch(mv_comm* c, const void* q, int q_dtype, int32_t n_q
     }
   }
   return MV_OK;
+}
+
+// ---- the same entry points with the caller's own query FDE vectors (mv_query_topk_fde, mv_api.hip): every shard's coarse stage takes
+// the query's FDE from the caller instead of encoding the query rows on its device
+static int comm_fde_check(mv_comm* c, int mode, const float* q_fde, int64_t n_queries, const char* what) {
+  if (!c || !q_fde || n_queries < 1) { set_error("%s: bad argument", what); return MV_ERR_INVALID; }
+  if (mode != MV_MODE_FDE_THEN_FLOAT && mode != MV_MODE_FDE_ONLY) { set_error("%s: mode %d has no FDE stage", what, mode); return MV_ERR_INVALID; }
+  const mv_index* ix0 = c->n > 0 ? c->sh[0].ix : nullptr;
+  if (!ix0 || !(ix0->cfg.flags & MV_WITH_FDE)) { set_error("%s: shard 0 has no index with an FDE slab attached", what); return MV_ERR_STATE; }
+  return check_fde_finite(q_fde, (size_t)n_queries * (size_t)ix0->fde_t.out_dim, what);
+}
+
+int mv_comm_query_topk_fde(mv_comm* c, const void* q, int q_dtype, int32_t n_q_rows, const float* q_fde, int32_t k, int mode, const uint32_t* allow_bits,
+                           int64_t n_allow_words, float* out_scores, int64_t* out_ids, int32_t* out_n, mv_query_stats* stats) {
+  if (int rc = comm_fde_check(c, mode, q_fde, 1, "mv_comm_query_topk_fde")) return rc;
+  QueryFdeScope sc(q_fde);
+  return mv_comm_query_topk(c, q, q_dtype, n_q_rows, k, mode, allow_bits, n_allow_words, out_scores, out_ids, out_n, stats);
+}
+
+int mv_comm_query_topk_batch_fde(mv_comm* c, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, const float* q_fde, int32_t k, int mode,
+                                 const uint32_t* allow_bits, int64_t n_allow_words, int32_t allow_per_query, float* out_scores, int64_t* out_ids,
+                                 int32_t* out_n, mv_query_stats* stats) {
+  if (int rc = comm_fde_check(c, mode, q_fde, n_queries, "mv_comm_query_topk_batch_fde")) return rc;
+  QueryFdeScope sc(q_fde);
+  return mv_comm_query_topk_batch(c, q, q_dtype, n_queries, n_q_rows, k, mode, allow_bits, n_allow_words, allow_per_query, out_scores, out_ids, out_n, stats);
+}
+
+int mv_two_stage_coarse_device_fde(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const float* q_fde, int32_t n_coarse, int mode,
+                                   const uint32_t* allow_bits, int64_t n_allow_words, mv_cand_rec* d_out_recs, void* stream) {
+  if (!ix || !q_fde) { set_error("two_stage_coarse_fde: null argument"); return MV_ERR_INVALID; }
+  if (mode != MV_MODE_FDE_THEN_FLOAT) { set_error("two_stage_coarse_fde: MV_MODE_FDE_THEN_FLOAT only"); return MV_ERR_INVALID; }
+  if (!(ix->cfg.flags & MV_WITH_FDE)) { set_error("index has no FDE slab (MV_WITH_FDE)"); return MV_ERR_STATE; }
+  if (int rc = check_fde_finite(q_fde, (size_t)ix->fde_t.out_dim, "two_stage_coarse_fde")) return rc;
+  QueryFdeScope sc(q_fde);
+  return mv_two_stage_coarse_device(ix, q, q_dtype, n_q_rows, n_coarse, mode, allow_bits, n_allow_words, d_out_recs, stream);
 }
 
 }  // extern "C"

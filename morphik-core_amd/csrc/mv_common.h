@@ -176,6 +176,8 @@ struct FdeEncodeArgs {
                              // LDS-atomic bucket sums), 4 = two-pass document form (hash pass + projection pass with one-hot MFMA bucket sums)
 };
 int launch_fde_encode(const FdeTables& t, const FdeEncodeArgs& a, hipStream_t s);
+// caller-supplied document FDE vectors (fp32 [n][out_dim], device memory) -> the slab's bf16 rows + 1 / |d| of the ROUNDED rows (the encode kernels' rule)
+int launch_fde_import(const float* d_src, int64_t n, int64_t out_dim, uint16_t* out_bf16, float* out_inv_norm, hipStream_t s);
 struct FdeScanArgs {
   const uint16_t* fde;      // [pages][out_dim] bf16
   const float* inv_norm;    // [pages] (nullable -> dot)

@@ -2186,6 +2186,30 @@ __global__ __launch_bounds__(256, 2) void fde_scan_batch3_kernel(ScanBatchArgs a
   fb_phase_g<NQT, LO, 1, PT, 4>(a, lds, red, lane, wave, 4 * n4 + 2 * n2, n1, src_off, rd_off);
 }
 
+// Caller-supplied document FDE vectors (mv_index_import_fde): one block per page rounds the fp32 vector to the slab's bf16 (RNE, as the
+// encode kernels do) and stores 1 / |d| of the ROUNDED vector -- the same convention, so cosine scores mean the same thing for both sources.
+__global__ __launch_bounds__(256) void fde_import_kernel(const float* src, int64_t out_dim, uint16_t* out, float* inv_norm) {
+  __shared__ float red[4];
+  const int64_t page = blockIdx.x;
+  const float* x = src + page * out_dim;
+  uint16_t* o = out + page * out_dim;
+  float nn = 0.f;
+  for (int64_t i = threadIdx.x; i < out_dim; i += 256) {
+    const uint16_t h = f32_to_bf16_rne(x[i]);
+    o[i] = h;
+    const float vb = bf16_to_f32(h);
+    nn += vb * vb;
+  }
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) nn += __shfl_xor(nn, sft);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nn;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = (red[0] + red[1]) + (red[2] + red[3]);
+    inv_norm[page] = t > 0.0f ? 1.0f / sqrtf(t) : 0.0f;
+  }
+}
+
 // Masks and the cosine rule of the batched scan, in place: scores[q][page] *= inv_norm[page]; -inf for tombstones and for
 // pages outside query q's doc filter (allow_stride_bits = 0: one bitmap for all queries).
 __global__ __launch_bounds__(256) void fde_batch_finish_kernel(float* scores, int64_t score_stride, int64_t n, int nq, const float* inv_norm,
@@ -2514,6 +2538,13 @@ int launch_fde_scan(const FdeScanArgs& a, int variant, hipStream_t s) {
     if (a.n > ((int64_t)1 << 25)) { set_error("generic FDE scan: more than 2^25 pages per launch is not supported"); return MV_ERR_INVALID; }
     hipLaunchKernelGGL(fde_scan_generic_kernel, dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, s, k);
   }
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
+int launch_fde_import(const float* d_src, int64_t n, int64_t out_dim, uint16_t* out_bf16, float* out_inv_norm, hipStream_t s) {
+  if (n <= 0) return MV_OK;
+  hipLaunchKernelGGL(fde_import_kernel, dim3((unsigned)n), dim3(256), 0, s, d_src, out_dim, out_bf16, out_inv_norm);
   MV_HIP(hipGetLastError());
   return MV_OK;
 }

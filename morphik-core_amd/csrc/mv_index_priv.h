@@ -183,6 +183,27 @@ int64_t coarse_n_for(const mv_index* ix, int k);
 //              MV_WITH_EXACT_SPLIT its leading pages sit in HBM), or -- the index keeps no exact copy -- the e4m3 slab (final_fp8)
 //   mid        the exact tier is host memory and the list is longer than MV_OPT_RERANK_N: the candidates are first re-scored on
 //              the e4m3 slab (HBM) and only the n_mid best of them (ties by list position) are read over PCIe
+// The caller's own query FDE vectors (mv_query_topk_fde and friends): for the duration of ONE API call on the calling thread the coarse stages
+// take the query's FDE from here -- fp32 [queries][out_dim], host memory -- instead of encoding the query rows on the device.  cur = index of
+// the call's query the stage at hand starts with (request-by-request loops and the groups of a batch move it).
+struct QueryFdeOverride {
+  const float* base = nullptr;
+  int64_t cur = 0;
+};
+extern thread_local QueryFdeOverride g_qfde;
+inline const float* query_fde_override(int64_t out_dim, int64_t j = 0) { return g_qfde.base ? g_qfde.base + (g_qfde.cur + j) * out_dim : nullptr; }
+struct QueryFdeScope {  // sets the override for a call, restores what was there
+  QueryFdeOverride prev;
+  explicit QueryFdeScope(const float* base) : prev(g_qfde) { g_qfde = QueryFdeOverride{base, 0}; }
+  ~QueryFdeScope() { g_qfde = prev; }
+};
+struct QueryFdeCursor {  // moves the cursor inside a call (a batch's group / request loop)
+  int64_t prev;
+  explicit QueryFdeCursor(int64_t cur) : prev(g_qfde.cur) { g_qfde.cur = cur; }
+  ~QueryFdeCursor() { g_qfde.cur = prev; }
+};
+int check_fde_finite(const float* v, size_t n, const char* what);
+
 enum { kTierSlab = 0, kTierHost = 1, kTierFp8 = 2 };  // what a rerank reads: the bf16 slab, the exact host tier (maybe split with HBM), the e4m3 slab
 struct RerankPlan {
   int tier = kTierSlab;

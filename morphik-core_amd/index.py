@@ -120,6 +120,13 @@ def allow_bitmap(allowed_ordinals: Optional[Iterable[int]], n_docs_hint: int = 0
     return bits
 
 
+def _fde_block(q_fde: Any, n_queries: int) -> np.ndarray:
+    """Caller-supplied query FDE vector(s) -> contiguous float32 [n_queries][out_dim] (the library checks the width against its config)."""
+    a = np.ascontiguousarray(np.asarray(q_fde, dtype=np.float32))
+    a = a.reshape(n_queries, -1)
+    return a
+
+
 def _stack_queries(queries: Sequence[Any], rows=None):
     """Queries of possibly different lengths -> one [n, longest, 128] block (zero rows behind the shorter ones: a zero row
     contributes exactly 0), its dtype code and the padded length."""
@@ -264,6 +271,14 @@ class MvIndex:
         r = np.ascontiguousarray(rows_bf16, dtype=np.uint16).reshape(-1, 128)
         check(lib().mv_index_replace_page(self._h, page, r.ctypes.data, r.shape[0]))
 
+    def import_fde(self, page0: int, fde: Any) -> None:
+        """Replace the FDE vectors the library encoded for pages [page0, page0 + len(fde)) with the caller's own document encodings
+        (float32 [n][fde_config.output_dim]; e.g. `fde.generate_document_encoding` of the reference, or vectors exported from a
+        TurboPuffer namespace).  Query such an index with q_fde= vectors from the SAME encoder."""
+        a = np.ascontiguousarray(np.asarray(fde, dtype=np.float32))
+        a = a.reshape(-1, self.fde_config.output_dim)
+        check(lib().mv_index_import_fde(self._h, int(page0), a.shape[0], a.ctypes.data))
+
     def read_fp8(self, page0: int, n_pages: int) -> Tuple[np.ndarray, np.ndarray]:
         """-> (e4m3 codes [n, stride_rows, 128] uint8, per-page inverse scales [n] float32)."""
         codes = np.empty((n_pages, self.stride_rows, 128), np.uint8)
@@ -294,8 +309,10 @@ class MvIndex:
         return o2n[:old]
 
     # -- query
-    def query(self, q: Any, k: int, mode: str = "float", allow: Optional[np.ndarray] = None, want_stats: bool = False):
-        """-> (scores[n] float32, ids[n] int64 global page ids[, QueryStats]); n <= k."""
+    def query(self, q: Any, k: int, mode: str = "float", allow: Optional[np.ndarray] = None, want_stats: bool = False, q_fde: Any = None):
+        """-> (scores[n] float32, ids[n] int64 global page ids[, QueryStats]); n <= k.
+        q_fde (FDE modes): the caller's own FDE of this query (float32 [fde_config.output_dim], e.g. from the reference's `fde` extension)
+        instead of the encoding of the query rows on the device; the rerank still scores the rows."""
         qa, code = as_rows(q)
         k = int(k)
         scores = np.empty(max(k, 1), np.float32)
@@ -303,18 +320,26 @@ class MvIndex:
         n = C.c_int32()
         st = QueryStatsC()
         ab = None if allow is None else np.ascontiguousarray(allow, dtype=np.uint32)
-        check(
+        if q_fde is not None:
+            qf = _fde_block(q_fde, 1)
+            if qf.shape[1] != self.fde_config.output_dim:
+                raise ValueError(f"query FDE of {qf.shape[1]} dims, the index's FDE config gives {self.fde_config.output_dim}")
+            check(lib().mv_query_topk_fde(self._h, qa.ctypes.data, code, qa.shape[0], qf.ctypes.data, k, MODES[mode], None if ab is None else ab.ctypes.data,
+                                          0 if ab is None else ab.size, scores.ctypes.data, ids.ctypes.data, C.byref(n), C.byref(st) if want_stats else None))
+        else:
+          check(
             lib().mv_query_topk(
                 self._h, qa.ctypes.data, code, qa.shape[0], k, MODES[mode], None if ab is None else ab.ctypes.data,
                 0 if ab is None else ab.size, scores.ctypes.data, ids.ctypes.data, C.byref(n), C.byref(st) if want_stats else None,
             )
-        )
+          )
         res = (scores[: n.value].copy(), ids[: n.value].copy())
         return res + (QueryStats.from_c(st),) if want_stats else res
 
     def query_batch(self, queries: Sequence[Any], k: int, mode: str = "float", allow: Optional[np.ndarray] = None,
-                    want_stats: bool = False, allows: Optional[Sequence[Optional[np.ndarray]]] = None, n_docs: int = 0):
+                    want_stats: bool = False, allows: Optional[Sequence[Optional[np.ndarray]]] = None, n_docs: int = 0, q_fdes: Any = None):
         """Top-k of several queries in one slab pass.  -> list of (scores, ids) per query [, QueryStats].
+        q_fdes (FDE modes): the caller's own FDE vector of every query (float32 [len(queries)][output_dim]), see query().
         mode "float": the batched MFMA MaxSim scan (<= 512 query rows per pass); "fde_then_float" / "fde": the batched FDE
         pipeline (one pass over the FDE slab per 32 queries, every query's candidates reranked exactly, same results as
         query()); other modes are served query by query inside the library.
@@ -338,12 +363,20 @@ class MvIndex:
         n = np.zeros(len(rows), np.int32)
         st = QueryStatsC()
         ab, n_words, per_query = _allow_block(len(rows), allow, allows, n_docs)
-        check(
+        if q_fdes is not None:
+            qf = _fde_block(q_fdes, len(rows))
+            if qf.shape[1] != self.fde_config.output_dim:
+                raise ValueError(f"query FDEs of {qf.shape[1]} dims, the index's FDE config gives {self.fde_config.output_dim}")
+            check(lib().mv_query_topk_batch_fde(self._h, blk.ctypes.data, code, len(rows), nmax, qf.ctypes.data, k, MODES[mode],
+                                                None if ab is None else ab.ctypes.data, n_words, per_query, scores.ctypes.data, ids.ctypes.data,
+                                                n.ctypes.data, C.byref(st) if want_stats else None))
+        else:
+          check(
             lib().mv_query_topk_batch(
                 self._h, blk.ctypes.data, code, len(rows), nmax, k, MODES[mode], None if ab is None else ab.ctypes.data,
                 n_words, per_query, scores.ctypes.data, ids.ctypes.data, n.ctypes.data, C.byref(st) if want_stats else None,
             )
-        )
+          )
         res = [(scores[i, : n[i]].copy(), ids[i, : n[i]].copy()) for i in range(len(rows))]
         return (res, QueryStats.from_c(st)) if want_stats else res
 
@@ -539,7 +572,7 @@ class ShardComm:
         except Exception:
             pass
 
-    def query(self, q: Any, k: int, mode: str = "float", allow: Optional[np.ndarray] = None, want_stats: bool = False):
+    def query(self, q: Any, k: int, mode: str = "float", allow: Optional[np.ndarray] = None, want_stats: bool = False, q_fde: Any = None):
         qa, code = as_rows(q)
         k = int(k)
         scores = np.empty(max(k, 1), np.float32)
@@ -547,14 +580,20 @@ class ShardComm:
         n = C.c_int32()
         ab = None if allow is None else np.ascontiguousarray(allow, dtype=np.uint32)
         st = (QueryStatsC * len(self.shards))()
-        check(lib().mv_comm_query_topk(self._h, qa.ctypes.data, code, qa.shape[0], k, MODES[mode], None if ab is None else ab.ctypes.data,
-                                       0 if ab is None else ab.size, scores.ctypes.data, ids.ctypes.data, C.byref(n),
-                                       C.cast(st, C.c_void_p) if want_stats else None))
+        if q_fde is not None:  # the caller's own FDE of the query: every shard's coarse stage uses it (MvIndex.query)
+            qf = _fde_block(q_fde, 1)
+            check(lib().mv_comm_query_topk_fde(self._h, qa.ctypes.data, code, qa.shape[0], qf.ctypes.data, k, MODES[mode], None if ab is None else ab.ctypes.data,
+                                               0 if ab is None else ab.size, scores.ctypes.data, ids.ctypes.data, C.byref(n),
+                                               C.cast(st, C.c_void_p) if want_stats else None))
+        else:
+            check(lib().mv_comm_query_topk(self._h, qa.ctypes.data, code, qa.shape[0], k, MODES[mode], None if ab is None else ab.ctypes.data,
+                                           0 if ab is None else ab.size, scores.ctypes.data, ids.ctypes.data, C.byref(n),
+                                           C.cast(st, C.c_void_p) if want_stats else None))
         res = (scores[: n.value].copy(), ids[: n.value].copy())
         return res + ([QueryStats.from_c(x) for x in st],) if want_stats else res
 
     def query_batch(self, queries: Sequence[Any], k: int, mode: str = "fde_then_float", allow: Optional[np.ndarray] = None,
-                    want_stats: bool = False, allows: Optional[Sequence[Optional[np.ndarray]]] = None, n_docs: int = 0):
+                    want_stats: bool = False, allows: Optional[Sequence[Optional[np.ndarray]]] = None, n_docs: int = 0, q_fdes: Any = None):
         """mv_comm_query_topk_batch: a batch of requests against the sharded corpus (arguments as MvIndex.query_batch).
         "fde_then_float": one FDE-slab pass per shard and 32 requests, one exchange of all their candidate records, every
         request's share of its GLOBAL candidate list reranked in one launch per shard.  -> [(scores, ids)] per request
@@ -567,7 +606,13 @@ class ShardComm:
         n = np.zeros(nq, np.int32)
         ab, n_words, per_query = _allow_block(nq, allow, allows, n_docs)
         st = (QueryStatsC * len(self.shards))()
-        check(lib().mv_comm_query_topk_batch(self._h, blk.ctypes.data, code, nq, nmax, k, MODES[mode], None if ab is None else ab.ctypes.data, n_words,
-                                             per_query, scores.ctypes.data, ids.ctypes.data, n.ctypes.data, C.cast(st, C.c_void_p) if want_stats else None))
+        if q_fdes is not None:
+            qf = _fde_block(q_fdes, nq)
+            check(lib().mv_comm_query_topk_batch_fde(self._h, blk.ctypes.data, code, nq, nmax, qf.ctypes.data, k, MODES[mode], None if ab is None else ab.ctypes.data,
+                                                     n_words, per_query, scores.ctypes.data, ids.ctypes.data, n.ctypes.data,
+                                                     C.cast(st, C.c_void_p) if want_stats else None))
+        else:
+            check(lib().mv_comm_query_topk_batch(self._h, blk.ctypes.data, code, nq, nmax, k, MODES[mode], None if ab is None else ab.ctypes.data, n_words,
+                                                 per_query, scores.ctypes.data, ids.ctypes.data, n.ctypes.data, C.cast(st, C.c_void_p) if want_stats else None))
         res = [(scores[i, : n[i]].copy(), ids[i, : n[i]].copy()) for i in range(nq)]
         return (res, [QueryStats.from_c(x) for x in st]) if want_stats else res

@@ -110,6 +110,11 @@ class ShardedIndex:
             raise MvError(-4, f"slab full: no shard on device {device} has {len(n_rows)} free slots")
         return self.shards[r].add_device(d_ptr, dtype_code, n_rows, doc_ordinals) + self.shards[r].id_base
 
+    def import_fde(self, page0: int, fde: Any) -> None:
+        """Caller-supplied document FDE vectors for pages [page0, page0 + n) (global ids of ONE add() call: they lie in one shard)."""
+        r, local = self._route(page0)
+        self.shards[r].import_fde(local, fde)
+
     def remove_page(self, page: int) -> None:
         r, local = self._route(page)
         self.shards[r].remove_page(local)
@@ -136,13 +141,15 @@ class ShardedIndex:
         return remap
 
     # -- query
-    def query(self, q: Any, k: int, mode: str = "float", allow: Optional[np.ndarray] = None, want_stats: bool = False):
+    def query(self, q: Any, k: int, mode: str = "float", allow: Optional[np.ndarray] = None, want_stats: bool = False, q_fde: Any = None):
+        if q_fde is not None:
+            return self.comm.query(q, k, mode=mode, allow=allow, want_stats=want_stats, q_fde=q_fde)
         return self.comm.query(q, k, mode=mode, allow=allow, want_stats=want_stats)
 
     _SINGLE_STAGE = ("float", "float_fp8", "binary", "fde")  # one scan + top-k: the merge of per-shard top-k lists is exact
 
     def query_batch(self, queries: Sequence[Any], k: int, mode: str = "float", allow: Optional[np.ndarray] = None, want_stats: bool = False,
-                    allows: Optional[Sequence[Optional[np.ndarray]]] = None, n_docs: int = 0):
+                    allows: Optional[Sequence[Optional[np.ndarray]]] = None, n_docs: int = 0, q_fdes: Any = None):
         """Coalesced requests on a sharded store.
         Single-stage modes: every shard runs the WHOLE batch through its own mv_query_topk_batch (one slab pass per shard for
         all requests; the shards run side by side, one host thread each -- the library releases the GIL), and the per-shard
@@ -151,13 +158,15 @@ class ShardedIndex:
         all shards before the rerank), and so does "fp8_then_float" (the e4m3 scan's GLOBAL top-n is re-scored exactly): their
         requests go through the communicator's batched form (mv_comm_query_topk_batch: one FDE / e4m3 slab pass per shard and
         group of requests, one exchange of all their candidate records)."""
+        fkw = {} if q_fdes is None else {"q_fdes": q_fdes}  # the callers' own query FDEs (MvIndex.query_batch)
         if mode in ("fde_then_float", "fp8_then_float") and len(queries) >= 2 and hasattr(self.comm, "query_batch"):
-            return self.comm.query_batch(queries, k, mode=mode, allow=allow, allows=allows, n_docs=n_docs, want_stats=want_stats)
+            return self.comm.query_batch(queries, k, mode=mode, allow=allow, allows=allows, n_docs=n_docs, want_stats=want_stats, **fkw)
         if mode not in self._SINGLE_STAGE or len(queries) < 2:
             out = []
             for j, q in enumerate(queries):
                 a = allow if allows is None else allows[j]
-                out.append(self.comm.query(q, k, mode=mode, allow=None if a is None else np.asarray(a, np.uint32)))
+                qk = {} if q_fdes is None else {"q_fde": np.asarray(q_fdes, np.float32).reshape(len(queries), -1)[j]}
+                out.append(self.comm.query(q, k, mode=mode, allow=None if a is None else np.asarray(a, np.uint32), **qk))
             return out
         if getattr(self, "_pool", None) is None:
             from concurrent.futures import ThreadPoolExecutor
@@ -165,7 +174,7 @@ class ShardedIndex:
             self._pool = ThreadPoolExecutor(max_workers=self.n_shards, thread_name_prefix="mv-shard")
 
         def run(shard):
-            return shard.query_batch(queries, k, mode=mode, allow=allow, allows=allows, n_docs=n_docs)
+            return shard.query_batch(queries, k, mode=mode, allow=allow, allows=allows, n_docs=n_docs, **fkw)
 
         per_shard = list(self._pool.map(run, self.shards))
         out = []

@@ -98,6 +98,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         exact_tier: str = "hbm",
         rerank_n: int = 0,
         prune_slab: bool = True,
+        fde_module: Any = None,
         **_ignored: Any,
     ):
         self.capacity_pages = int(capacity_pages)
@@ -121,6 +122,18 @@ class MI355XMultiVectorStore(BaseVectorStore):
         # pipeline with its own min(10 k, 75) rule never prunes anyway), and a split tier gets that HBM for exact rows instead: a
         # 1.25 M-page shard keeps ~1 M pages' exact rows on the device and pins the rest
         self.prune_slab = bool(prune_slab)
+        # Bring-your-own FDE ("fde_then_float"): an object with the API of the reference's `fde` extension -- FixedDimensionalEncodingConfig,
+        # generate_document_encoding(emb, cfg), generate_query_encoding(q, cfg) (fast_multivector_store.py:325-331, :447-449, :521).  The
+        # store then calls IT, on the host as the reference does, for every chunk and every query, imports the document vectors into the
+        # FDE slab and hands the query vectors to the scan: candidate generation runs on the deployment's own encodings (the published
+        # algorithm this library restates matches that extension only as far as the publication pins it), the GPU does scan and rerank.
+        self.fde_module = fde_module
+        self._fde_ext_cfg = None
+        if fde_module is not None:
+            if self.mode != "fde_then_float":
+                raise ValueError("fde_module only applies to mode \"fde_then_float\"")
+            self._fde_ext_cfg = fde_module.FixedDimensionalEncodingConfig(dimension=128, num_repetitions=20, num_simhash_projections=5,
+                                                                          projection_dimension=16, projection_type="AMS_SKETCH")
         self.storage = storage  # callers reach for .storage (document_service.py:1570-1575)
         # multi_vector_store.py:120-160: content is stored externally when a storage object is configured
         self.enable_external_storage = bool(enable_external_storage)
@@ -305,8 +318,36 @@ class MI355XMultiVectorStore(BaseVectorStore):
                 ids.append(f"{c.document_id}-{c.chunk_number}")
             return ids
 
+    def _external_doc_fdes(self, embs: List[Any]) -> Optional[np.ndarray]:
+        """The deployment's own document encodings of these pages (fde_module), or None.  Computed BEFORE anything is appended: an
+        encoder failure or a malformed vector aborts the call with nothing stored."""
+        if self.fde_module is None:
+            return None
+        out = []
+        for e in embs:
+            rows = e if isinstance(e, np.ndarray) else _embedding_rows(e) if not hasattr(e, "detach") else e.detach().to("cpu").float().numpy()
+            v = np.asarray(self.fde_module.generate_document_encoding(np.asarray(rows, np.float32), self._fde_ext_cfg), np.float32).reshape(-1)
+            out.append(v)
+        docs = np.stack(out) if out else np.zeros((0, 0), np.float32)
+        if out and not np.isfinite(docs).all():
+            raise ValueError("fde_module.generate_document_encoding returned NaN / Inf")
+        return docs
+
+    def _query_fde_kw(self, q: Any) -> Dict[str, Any]:
+        if self.fde_module is None:
+            return {}
+        rows = q if isinstance(q, np.ndarray) else _embedding_rows(q)
+        return {"q_fde": np.asarray(self.fde_module.generate_query_encoding(np.asarray(rows, np.float32), self._fde_ext_cfg), np.float32).reshape(-1)}
+
     def _add_pages(self, ix, embs: List[Any], ords: List[int]) -> int:
         """Append the pages to the slab (all or nothing) -> first page id the index assigned."""
+        docs = self._external_doc_fdes(embs)
+        first = self._add_pages_raw(ix, embs, ords)
+        if docs is not None and len(docs):
+            ix.import_fde(first, docs)  # the library's own encodings of these pages are replaced before the pages get their bookkeeping
+        return first
+
+    def _add_pages_raw(self, ix, embs: List[Any], ords: List[int]) -> int:
         if embs and all(not isinstance(e, np.ndarray) for e in embs):
             # ingest-side fusion (SURVEY.md 8f rank 1): encoder output already on this GPU -> one D2D pass fills
             # every slab (mv_index_add_device); no D2H -> fp32 -> H2D round trip
@@ -421,7 +462,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         ix = self._require_index()
         t0 = time.perf_counter()
         want_stats = self._index_factory is None and (self.collect_device_time or (self.mode == "fde_then_float" and logger.isEnabledFor(logging.INFO)))
-        res = ix.query(q, k, mode=self.mode, allow=allow, want_stats=want_stats)
+        res = ix.query(q, k, mode=self.mode, allow=allow, want_stats=want_stats, **self._query_fde_kw(q))
         dt = time.perf_counter() - t0
         self.last_query_timing = {"vector_search_s": dt}
         if want_stats and len(res) == 3 and not isinstance(res[2], list):
@@ -459,8 +500,9 @@ class MI355XMultiVectorStore(BaseVectorStore):
         for g in groups:
             kmax = max(items[j][1] for j in g)
             allows = [items[j][2] for j in g]
+            fkw = {} if self.fde_module is None else {"q_fdes": np.stack([self._query_fde_kw(items[j][0])["q_fde"] for j in g])}
             res = ix.query_batch([items[j][0] for j in g], kmax, mode=self.mode, allows=allows if any(a is not None for a in allows) else None,
-                                 n_docs=n_docs, want_stats=self._index_factory is None)
+                                 n_docs=n_docs, want_stats=self._index_factory is None, **fkw)
             if isinstance(res, tuple):  # (results, QueryStats)
                 res, st = res
                 device_ms += float(getattr(st, "total_device_ms", 0.0))
@@ -677,7 +719,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
     def _book(self) -> Dict[str, Any]:
         return {
             "version": 3, "mode": self.mode, "capacity_pages": self.capacity_pages, "stride_rows": self.stride_rows,
-            "id_base": self.id_base, "fde_coarse_n": self.fde_coarse_n, "exact_tier": self.exact_tier, "rerank_n": self.rerank_n, "prune_slab": self.prune_slab, "next_ord": self._next_ord,
+            "id_base": self.id_base, "fde_coarse_n": self.fde_coarse_n, "exact_tier": self.exact_tier, "rerank_n": self.rerank_n, "prune_slab": self.prune_slab, "fde_external": self.fde_module is not None, "next_ord": self._next_ord,
             "rows": [[p, r[0], r[1], r[2], r[3], r[4]] for p, r in self._rows.items()],
             "doc_ord": self._doc_ord, "doc_app": {str(k): v for k, v in self._doc_app.items()},
         }
@@ -773,6 +815,10 @@ class MI355XMultiVectorStore(BaseVectorStore):
                 raise RuntimeError(f"{directory}: store.json belongs to generation {book['checkpoint']} (directory moved or mixed up?)")
         elif book.get("checkpoint") and (not os.path.exists(idp) or open(idp).read().strip() != book["checkpoint"]):
             raise RuntimeError(f"{directory}: index.mv and store.json belong to different checkpoints (crash during save?)")
+        if bool(book.get("fde_external")) != (kw.get("fde_module") is not None):
+            # the FDE slab holds one encoder's document vectors: queries must come from the same one
+            raise RuntimeError(f"{directory}: this checkpoint " + ("holds document FDE vectors of an external encoder: pass fde_module= to load()"
+                                                                     if book.get("fde_external") else "was encoded by the library itself: load it without fde_module"))
         self = cls(capacity_pages=book["capacity_pages"], stride_rows=book["stride_rows"], device=device, mode=book["mode"], storage=storage,
                    id_base=book["id_base"], fde_coarse_n=book.get("fde_coarse_n", 0), exact_tier=book.get("exact_tier", "hbm"), rerank_n=book.get("rerank_n", 0), prune_slab=book.get("prune_slab", True), **kw)
         self._index = cls._load_index(self, directory, book, device)

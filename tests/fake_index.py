@@ -13,6 +13,7 @@ class OracleIndex:
             self.mode = "binary"  # built by ShardedIndex from slab flags
         self.pages, self.ords, self.alive = [], [], []
         self.fde = fde  # oracle FdeConfig; enables mode "fde" / "fde_then_float"
+        self.ext_fde = {}  # page -> caller-supplied document FDE (import_fde): replaces the oracle's own encoding of that page
 
     def __len__(self):
         return len(self.pages)
@@ -28,6 +29,11 @@ class OracleIndex:
             self.ords.append(0 if doc_ordinals is None else int(doc_ordinals[i]))
             self.alive.append(True)
         return first
+
+    def import_fde(self, page0, fde):
+        fde = np.asarray(fde, np.float32)
+        for i, v in enumerate(fde.reshape(len(fde), -1)):
+            self.ext_fde[int(page0) + i] = v
 
     def remove_page(self, page):
         self.alive[page] = False
@@ -48,15 +54,16 @@ class OracleIndex:
             m &= ok
         return m
 
-    def score_all(self, q, mode=None, allow=None):
+    def score_all(self, q, mode=None, allow=None, q_fde=None):
         mode = mode or self.mode
         q = np.asarray(q)
         qf = orc.bf16_to_f32(q) if q.dtype == np.uint16 else np.asarray(q, np.float32)
         out = np.full(len(self.pages), -np.inf, np.float32)
         m = self._mask(allow)
         if mode == "fde":
-            fq = orc.fde_encode(self.fde, orc.bf16_to_f32(orc.f32_to_bf16(qf)), True)
-            slab = np.stack([orc.fde_encode(self.fde, orc.bf16_to_f32(orc.f32_to_bf16(p)), False) for p in self.pages])
+            fq = np.asarray(q_fde, np.float32).reshape(-1) if q_fde is not None else orc.fde_encode(self.fde, orc.bf16_to_f32(orc.f32_to_bf16(qf)), True)
+            slab = np.stack([self.ext_fde[i] if i in self.ext_fde else orc.fde_encode(self.fde, orc.bf16_to_f32(orc.f32_to_bf16(p)), False)
+                             for i, p in enumerate(self.pages)])
             s = orc.fde_coarse_scores(fq, orc.f32_to_bf16(slab), use_cosine=True)
             out[m] = s[m]
             return out
@@ -71,18 +78,18 @@ class OracleIndex:
                 out[i] = orc.maxsim_f32(qb, pb)
         return out
 
-    def query(self, q, k, mode=None, allow=None, want_stats=False, coarse_n=None):
+    def query(self, q, k, mode=None, allow=None, want_stats=False, coarse_n=None, q_fde=None):
         if (mode or self.mode) == "fde_then_float":
             # reference pipeline (fast_multivector_store.py:521-556): coarse top-n -> pad-to-longest rerank -> top-k
             n = coarse_n or min(10 * k, 75)
-            cs, ci = orc.topk(self.score_all(q, "fde", allow), n)
+            cs, ci = orc.topk(self.score_all(q, "fde", allow, q_fde=q_fde), n)
             ci = ci[np.isfinite(cs)]
             if ci.size == 0:
                 return np.zeros(0, np.float32), np.zeros(0, np.int64)
             sc = self.score_candidates(q, ci, pad_to=-1)  # every batch of 128 candidates pads to its own longest page
             order = np.lexsort((np.arange(ci.size), -sc.astype(np.float64)))[:k]  # ties keep coarse rank order
             return sc[order], ci[order] + self.id_base
-        s = self.score_all(q, mode, allow)
+        s = self.score_all(q, mode, allow, q_fde=q_fde)
         sc, ids = orc.topk(s, k)
         return sc, ids + self.id_base
 
@@ -111,14 +118,15 @@ class OracleIndex:
             if a:
                 pages.append(p)
                 ords.append(o)
+        self.ext_fde = {o2n[i]: v for i, v in self.ext_fde.items() if o2n[i] >= 0}
         self.pages, self.ords, self.alive = pages, ords, [True] * len(pages)
         return np.array(o2n, np.int64)
 
-    def query_batch(self, queries, k, mode=None, allow=None, want_stats=False, allows=None, n_docs=0):
+    def query_batch(self, queries, k, mode=None, allow=None, want_stats=False, allows=None, n_docs=0, q_fdes=None):
         out = []
         for j, q in enumerate(queries):
             a = allow if allows is None else allows[j]
-            out.append(self.query(q, k, mode, None if a is None else np.asarray(a, np.uint32)))
+            out.append(self.query(q, k, mode, None if a is None else np.asarray(a, np.uint32), q_fde=None if q_fdes is None else np.asarray(q_fdes)[j]))
         return out
 
     def save(self, path):
@@ -126,7 +134,7 @@ class OracleIndex:
 
         with open(path + ".tmp", "wb") as f:
             pickle.dump({"capacity": self.capacity, "stride_rows": self.stride_rows, "id_base": self.id_base, "mode": self.mode,
-                         "pages": self.pages, "ords": self.ords, "alive": self.alive}, f)
+                         "pages": self.pages, "ords": self.ords, "alive": self.alive, "ext_fde": self.ext_fde, "fde": self.fde}, f)
         import os
 
         os.replace(path + ".tmp", path)
@@ -139,6 +147,7 @@ class OracleIndex:
             d = pickle.load(f)
         self = cls(d["capacity"], d["stride_rows"], device=device, id_base=d["id_base"], mode=d["mode"])
         self.pages, self.ords, self.alive = d["pages"], d["ords"], d["alive"]
+        self.ext_fde, self.fde = d.get("ext_fde", {}), d.get("fde")
         return self
 
     def close(self):
@@ -155,10 +164,10 @@ class OracleComm:
     def close(self):
         pass
 
-    def query(self, q, k, mode="float", allow=None, want_stats=False):
+    def query(self, q, k, mode="float", allow=None, want_stats=False, q_fde=None):
         s_all, i_all = [], []
         for sh in self.shards:
-            s, i = sh.query(q, k, mode=mode, allow=allow)
+            s, i = sh.query(q, k, mode=mode, allow=allow, q_fde=q_fde)
             ok = np.isfinite(s)
             s_all.append(s[ok])
             i_all.append(i[ok])

@@ -622,3 +622,97 @@ def _cascade_pad(ix, q, pages, coarse_n, page):
     rows = np.array([pages[c].shape[0] for c in ci])
     pads = _batch_pads(rows)
     return pads[list(ci).index(page)]
+
+
+# ------------------------------------------------------------------ bring-your-own FDE (mv_index_import_fde, mv_query_topk_fde)
+def test_caller_supplied_fde_vectors_drive_the_coarse_stage():
+    """Document FDE vectors imported into the slab and query FDE vectors handed to the scan -- the path a deployment takes that keeps the
+    reference's own `fde` extension (or vectors exported from a TurboPuffer namespace) for the encodings:
+    (a) arbitrary vectors: the coarse scores (mode "fde", k = all) are cosine(q_fde, bf16(d_fde)) computed on the host, 1e-4;
+    (b) the pipeline reranks exactly the candidates those scores nominate (float oracle on the rows), single, batched, 2 shards;
+    (c) the library's OWN encodings fed back through the same doors reproduce the internal path (coarse scores 1e-3, same answers);
+    (d) NaN / Inf and a wrong width are refused, so are modes without an FDE stage."""
+    from morphik_core_amd import MvError, _lib
+    from morphik_core_amd.index import ShardComm, fde_encode
+
+    N, stride, k = 300, 32, 6
+    pages = _corpus(N, stride, seed=39)
+    kw = dict(stride_rows=stride, with_float=True, with_fde=True)
+    ix = _idx(capacity_pages=N, **kw)
+    ix.add(pages)
+    D = ix.fde_config.output_dim
+    rng = np.random.default_rng(39)
+    docs = rng.standard_normal((N, D)).astype(np.float32)
+    qs = [orc.synth_rows(39, 3, 0, 20)] + [orc.synth_rows(983, j, 0, 20) for j in range(4)]
+    qf = rng.standard_normal((len(qs), D)).astype(np.float32)
+    docs[7] = 3.0 * qf[0] + 0.1 * docs[7]  # a planted coarse neighbour of query 0
+    ix.import_fde(0, docs[:120])
+    ix.import_fde(120, docs[120:])
+    db = orc.bf16_to_f32(orc.f32_to_bf16(docs))
+    want_all = (db @ qf.T) / np.linalg.norm(db, axis=1, keepdims=True)  # [page][query]: the scan's cosine rule (1/|d| of the rounded vector)
+    ix.set_option(_lib.MV_OPT_FDE_COARSE_N, 40)
+    for j, q in enumerate(qs):
+        s, i = ix.query(q, N, mode="fde", q_fde=qf[j])
+        assert sorted(i.tolist()) == list(range(N))
+        np.testing.assert_allclose(s, want_all[i, j], rtol=2e-4, atol=2e-5)
+        # (b) the candidates of the pipeline are the coarse top-40 of THOSE scores; the rerank is the float oracle on the rows
+        cand = np.lexsort((np.arange(N), -want_all[:, j].astype(np.float64)))[:40]
+        rows = np.array([pages[c].shape[0] for c in cand])
+        pads = _batch_pads(rows)
+        exact = np.array([orc.maxsim_bf16(q, pages[c], int(p)) for c, p in zip(cand, pads)], np.float32)
+        order = np.lexsort((np.arange(40), -exact.astype(np.float64)))[:k]
+        s, i = ix.query(q, k, mode="fde_then_float", q_fde=qf[j])
+        assert set(i.tolist()) <= set(cand.tolist())
+        np.testing.assert_allclose(s, exact[order], rtol=RTOL)
+        assert i.tolist() == cand[order].tolist() or len(set(i.tolist()) ^ set(cand[order].tolist())) <= 2  # near-ties of the coarse cut
+    assert ix.query(qs[0], 1, mode="fde", q_fde=qf[0])[1].tolist() == [7]
+    single = [ix.query(q, k, mode="fde_then_float", q_fde=qf[j]) for j, q in enumerate(qs)]
+    for (ws, wi), (s, i) in zip(single, ix.query_batch(qs, k, mode="fde_then_float", q_fdes=qf)):
+        assert i.tolist() == wi.tolist()
+        np.testing.assert_allclose(s, ws, rtol=1e-6)
+    # two shards behind the communicator: the same answers (global candidate rule), single and batched
+    shards = []
+    for r in range(2):
+        sh = _idx(capacity_pages=N // 2, id_base=r * (N // 2), **kw)
+        sh.add(pages[r * (N // 2) : (r + 1) * (N // 2)])
+        sh.import_fde(0, docs[r * (N // 2) : (r + 1) * (N // 2)])
+        sh.set_option(_lib.MV_OPT_FDE_COARSE_N, 40)
+        shards.append(sh)
+    comm = ShardComm(shards, transport="p2p")
+    for j, q in enumerate(qs):
+        s, i = comm.query(q, k, mode="fde_then_float", q_fde=qf[j])
+        assert i.tolist() == single[j][1].tolist() and s.tolist() == single[j][0].tolist()
+    for (ws, wi), (s, i) in zip(single, comm.query_batch(qs, k, mode="fde_then_float", q_fdes=qf)):
+        assert i.tolist() == wi.tolist()
+        np.testing.assert_allclose(s, ws, rtol=1e-6)
+    comm.close()
+    for sh in shards:
+        sh.close()
+    # (c) the library's own encodings through the same doors == the internal path
+    own = _idx(capacity_pages=N, **kw)
+    own.add(pages)
+    own.set_option(_lib.MV_OPT_FDE_COARSE_N, 40)
+    mine = np.stack([fde_encode(orc.bf16_to_f32(p), ix.fde_config, is_query=False) for p in pages])
+    ix.import_fde(0, mine)
+    for q in qs:
+        ws, wi = own.query(q, k, mode="fde_then_float")
+        s, i = ix.query(q, k, mode="fde_then_float", q_fde=fde_encode(orc.bf16_to_f32(q), ix.fde_config, is_query=True))
+        # (the ingest kernels and mv_fde_encode may round an FDE element differently in the last bit: a near-tie at the coarse cut may swap)
+        common = set(i.tolist()) & set(wi.tolist())
+        assert len(common) >= k - 1
+        assert {int(a): float(b) for a, b in zip(i, s) if int(a) in common} == {int(a): float(b) for a, b in zip(wi, ws) if int(a) in common}
+        ca, cb = own.query(q, N, mode="fde"), ix.query(q, N, mode="fde", q_fde=fde_encode(orc.bf16_to_f32(q), ix.fde_config, is_query=True))
+        np.testing.assert_allclose(cb[0][np.argsort(cb[1])], ca[0][np.argsort(ca[1])], rtol=1e-3, atol=1e-5)
+    # (d) refusals
+    bad = qf[0].copy()
+    bad[5] = np.nan
+    with pytest.raises(MvError, match="NaN"):
+        ix.query(qs[0], k, mode="fde_then_float", q_fde=bad)
+    with pytest.raises(MvError, match="NaN"):
+        ix.import_fde(3, bad[None, :])
+    with pytest.raises(ValueError, match="dims"):
+        ix.query(qs[0], k, mode="fde_then_float", q_fde=qf[0][:100])
+    with pytest.raises(MvError, match="no FDE stage"):
+        ix.query(qs[0], k, mode="float", q_fde=qf[0])
+    own.close()
+    ix.close()

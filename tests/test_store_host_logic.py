@@ -308,6 +308,101 @@ def test_concurrent_requests_on_the_fast_store_are_coalesced_by_k():
         assert [(c.document_id, c.chunk_number, c.score) for c in g] == [(c.document_id, c.chunk_number, c.score) for c in w] and len(g) <= k
 
 
+class _KeyedFde:
+    """The API of the reference's `fde` extension (fast_multivector_store.py:325-331, :447-449, :521) with a transparent encoder behind
+    it: a page / query whose first element is x encodes to the unit vector e_j, j = round(10 x) -- so the coarse score of a page is 1
+    when its key equals the query's and 0 otherwise, whatever the rows say."""
+
+    class FixedDimensionalEncodingConfig:
+        def __init__(self, **kw):
+            self.kw = kw
+
+    def __init__(self):
+        self.docs = self.queries = 0
+
+    @staticmethod
+    def _enc(rows):
+        v = np.zeros(10240, np.float32)
+        v[int(round(10 * float(np.asarray(rows, np.float32)[0, 0]))) % 10240] = 1.0
+        return v
+
+    def generate_document_encoding(self, emb, cfg):
+        assert cfg.kw == dict(dimension=128, num_repetitions=20, num_simhash_projections=5, projection_dimension=16, projection_type="AMS_SKETCH")
+        self.docs += 1
+        return self._enc(emb)
+
+    def generate_query_encoding(self, q, cfg):
+        self.queries += 1
+        return self._enc(q)
+
+
+def test_bring_your_own_fde_module_drives_the_candidate_stage(tmp_path):
+    """fde_module=: the store calls the deployment's own FDE encoder (the reference's extension where it is installed) for every chunk and
+    every query, imports the document vectors into the FDE slab and hands the query vectors to the scan.  With the keyed stand-in above
+    the candidate list of a k = 1 request (min(10 k, 75) = 10 pages) is exactly the pages of the query's key -- the exact best page, under
+    another key, must NOT come back, although the store without the module finds it."""
+    from morphik_core_amd.models import DocumentChunk
+    from oracle import oracle as orc
+
+    class fde_index(OracleIndex):  # an index class (the store's checkpoint path calls index_factory.load)
+        def __init__(self, *a, **kw):
+            kw["fde"] = orc.FdeConfig.reference_default()
+            super().__init__(*a, **kw)
+
+    rng = np.random.default_rng(5)
+    q = rng.standard_normal((6, 128)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[0, 0] = 0.3  # key 3
+    chunks = []
+    for i in range(40):
+        e = rng.standard_normal((8, 128)).astype(np.float32)
+        e /= np.linalg.norm(e, axis=1, keepdims=True)
+        e[0, 0] = 0.3 if i % 4 == 0 else 0.7  # ten pages of key 3, thirty of key 7
+        if i == 17:  # the exact best page of the query -- under the OTHER key
+            e[1:7] = q
+        if i == 8:   # the best page among the query's own key
+            e[1:4] = q[:3]
+        chunks.append(DocumentChunk(document_id=f"d{i}", content=f"c{i}", embedding=e, chunk_number=0, metadata={}))
+    mod = _KeyedFde()
+    own = MI355XMultiVectorStore(capacity_pages=64, stride_rows=32, index_factory=fde_index, mode="fde_then_float")
+    byo = MI355XMultiVectorStore(capacity_pages=64, stride_rows=32, index_factory=fde_index, mode="fde_then_float", fde_module=mod)
+    assert own.initialize() and byo.initialize()
+    for st in (own, byo):
+        ok, ids, _m = sc.run(st.store_embeddings(chunks))
+        assert ok and len(ids) == 40
+    assert mod.docs == 40
+    exact_best = sc.run(own.query_similar(q, k=3))[0]  # 30 candidates of 40: the exact best is among them
+    assert exact_best.document_id == "d17"
+    hit = sc.run(byo.query_similar(q, k=1))
+    assert [h.document_id for h in hit] == ["d8"] and mod.queries == 1  # ten candidates: the pages of key 3, reranked exactly
+    # coalesced requests carry their own query encodings
+    fused = MI355XMultiVectorStore(capacity_pages=64, stride_rows=32, index_factory=fde_index, mode="fde_then_float", fde_module=mod, batch_window_ms=20.0, max_batch=8)
+    assert fused.initialize()
+    sc.run(fused.store_embeddings(chunks))
+    q7 = q.copy()
+    q7[0, 0] = 0.7
+
+    async def both():
+        import asyncio
+
+        return await asyncio.gather(fused.query_similar(q, k=1), fused.query_similar(q7, k=1))
+
+    a, b = sc.run(both())
+    assert [h.document_id for h in a] == ["d8"] and b[0].document_id != "d8"
+    assert fused.last_query_timing.get("batched_queries") == 2
+    # a checkpoint remembers whose vectors its FDE slab holds
+    byo.save(str(tmp_path / "ck"))
+    with pytest.raises(RuntimeError, match="fde_module"):
+        MI355XMultiVectorStore.load(str(tmp_path / "ck"), index_factory=fde_index)
+    back = MI355XMultiVectorStore.load(str(tmp_path / "ck"), index_factory=fde_index, fde_module=mod)
+    assert [h.document_id for h in sc.run(back.query_similar(q, k=1))] == ["d8"]
+    own.save(str(tmp_path / "ck2"))
+    with pytest.raises(RuntimeError, match="without fde_module"):
+        MI355XMultiVectorStore.load(str(tmp_path / "ck2"), index_factory=fde_index, fde_module=mod)
+    with pytest.raises(ValueError, match="fde_then_float"):
+        MI355XMultiVectorStore(capacity_pages=8, mode="float", fde_module=mod)
+
+
 def test_compaction_reclaims_slots_and_keeps_answers():
     rng = np.random.default_rng(7)
     chunks = sc.make_chunks(rng, n_docs=5, chunks_per_doc=3)

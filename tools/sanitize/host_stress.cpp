@@ -72,6 +72,7 @@ int main(int argc, char** argv) {
     std::vector<uint32_t> allow(64, 0x55555555u * (tid % 2 ? 1u : 3u));
     float s[64 * 5]; int64_t id[64 * 5]; int32_t n = 0, nb[5];
     std::vector<float> all_scores(4096);
+    std::vector<float> qfde = rows((5 * 10240 + 127) / 128, 900 + tid);  // five query FDE vectors of 10 240 floats
     for (int it = 0; it < iters && !stop.load(); ++it) {
       const int mode = modes[(it + tid) % 6];
       mv_query_stats st{};
@@ -79,12 +80,17 @@ int main(int argc, char** argv) {
       if (it % 5 == 0) CHECK(mv_query_topk_batch(ix, qb.data(), MV_F32, 5, 20, 7, (it % 10) ? MV_MODE_FLOAT : MV_MODE_FDE_THEN_FLOAT, nullptr, 0, 0, s, id, nb, &st));
       if (it % 7 == 0) { int64_t got = 0; CHECK(mv_score_all(ix, q.data(), MV_F32, 20, MV_MODE_FLOAT, nullptr, 0, all_scores.data(), 4096, &got, nullptr)); }
       if (it % 11 == 0) { int32_t cand[8] = {0, 3, 5, 9, 100, 101, 200, 7}; CHECK(mv_score_candidates(ix, q.data(), MV_F32, 20, cand, 8, -1, s, nullptr)); }
+      if (it % 6 == 3) {  // the caller's own query FDE vectors (thread-local override inside the library): single and batched
+        CHECK(mv_query_topk_fde(ix, q.data(), MV_F32, 20, qfde.data(), 10, (it & 1) ? MV_MODE_FDE_THEN_FLOAT : MV_MODE_FDE_ONLY, nullptr, 0, s, id, &n, nullptr));
+        CHECK(mv_query_topk_batch_fde(ix, qb.data(), MV_F32, 5, 20, qfde.data(), 7, MV_MODE_FDE_THEN_FLOAT, nullptr, 0, 0, s, id, nb, nullptr));
+      }
       (void)mv_index_size(ix);
       n_queries.fetch_add(1);
     }
   };
   auto writer = [&]() {
     std::vector<float> emb = rows(8 * 24, 7);
+    std::vector<float> dfde = rows((3 * 10240 + 127) / 128, 8);
     int32_t nr[8]; int32_t ords[8];
     for (int i = 0; i < 8; ++i) nr[i] = 24;
     for (int it = 0; it < iters / 2; ++it) {
@@ -94,6 +100,7 @@ int main(int argc, char** argv) {
       if (it % 3 == 1) { int64_t gone = 0; CHECK(mv_index_remove_doc(ix, 1000 + it - 1, &gone)); }
       if (it % 9 == 4) { std::vector<uint16_t> pg(24 * 128, 0x3c00); CHECK(mv_index_replace_page(ix, 5, pg.data(), 24)); }
       if (it % 25 == 12) { int64_t m = 0; CHECK(mv_index_compact(ix, nullptr, &m)); }
+      if (it % 6 == 2) CHECK(mv_index_import_fde(ix, 2, 3, dfde.data()));  // caller-supplied document FDE vectors under the readers
       if (it % 40 == 20) CHECK(mv_index_save(ix, "/tmp/mv_host_stress.idx"));
       n_writes.fetch_add(1);
     }
@@ -120,11 +127,16 @@ int main(int argc, char** argv) {
     CHECK(mv_comm_attach(c, 1, sh[1]));
     auto cq = [&](int tid) {
       std::vector<float> q = rows(16, 300 + tid), qb = rows(4 * 16, 400 + tid);
+      std::vector<float> cqfde = rows((4 * 10240 + 127) / 128, 950 + tid);
       float s[40]; int64_t id[40]; int32_t n = 0, nb[4];
       mv_query_stats st[2];
       for (int it = 0; it < iters / 2; ++it) {
         CHECK(mv_comm_query_topk(c, q.data(), MV_F32, 16, 10, (it & 1) ? MV_MODE_FLOAT : MV_MODE_FDE_THEN_FLOAT, nullptr, 0, s, id, &n, (it & 2) ? st : nullptr));
         if (it % 4 == 0) CHECK(mv_comm_query_topk_batch(c, qb.data(), MV_F32, 4, 16, 10, MV_MODE_FDE_THEN_FLOAT, nullptr, 0, 0, s, id, nb, st));
+        if (it % 5 == 1) {
+          CHECK(mv_comm_query_topk_fde(c, q.data(), MV_F32, 16, cqfde.data(), 10, MV_MODE_FDE_THEN_FLOAT, nullptr, 0, s, id, &n, nullptr));
+          CHECK(mv_comm_query_topk_batch_fde(c, qb.data(), MV_F32, 4, 16, cqfde.data(), 10, MV_MODE_FDE_THEN_FLOAT, nullptr, 0, 0, s, id, nb, nullptr));
+        }
       }
     };
     auto cw = [&]() {
