@@ -865,6 +865,88 @@ def test_fused_encoder_ops_match_the_transformers_modules():
     assert cos.min() >= 0.9995 and np.array_equal(back, want)
 
 
+def test_store_with_an_fde_module_on_the_real_index_single_and_sharded(tmp_path):
+    """fde_module= on the HIP-backed stores (one index; three logical shards through mv_comm): the module here wraps the library's own
+    encoder (mv_fde_encode), so the store that calls it per chunk / per query must answer like the store that encodes inside the index --
+    and a keyed module (candidates by key, not by content) must change the answers, single and coalesced."""
+    from morphik_core_amd.index import FdeConfig, fde_encode
+    from morphik_core_amd.models import DocumentChunk
+    from morphik_core_amd.store import MI355XFastMultiVectorStore, MI355XShardedFastMultiVectorStore
+    from oracle import oracle as orc
+
+    class LibFde:
+        class FixedDimensionalEncodingConfig:
+            def __init__(self, **kw):
+                self.kw = kw
+
+        @staticmethod
+        def generate_document_encoding(emb, cfg):
+            return fde_encode(emb, FdeConfig(), is_query=False)
+
+        @staticmethod
+        def generate_query_encoding(q, cfg):
+            return fde_encode(q, FdeConfig(), is_query=True)
+
+    class KeyedFde(LibFde):
+        @staticmethod
+        def _enc(rows):
+            v = np.zeros(10240, np.float32)
+            v[int(round(10 * float(rows[0, 0]))) % 10240] = 1.0
+            return v
+
+        generate_document_encoding = staticmethod(lambda emb, cfg: KeyedFde._enc(emb))
+        generate_query_encoding = staticmethod(lambda q, cfg: KeyedFde._enc(q))
+
+    rng = np.random.default_rng(11)
+
+    def unit_rows(n):
+        x = rng.standard_normal((n, 128)).astype(np.float32)
+        return orc.bf16_to_f32(orc.f32_to_bf16(x / np.linalg.norm(x, axis=1, keepdims=True)))  # bf16-exact: what the slab keeps is what the module sees
+
+    q = unit_rows(6)
+    q[0, 0] = 0.296875  # bf16-exact, key 3
+    chunks = []
+    for i in range(120):
+        e = unit_rows(12)
+        e[0, 0] = 0.296875 if i % 12 == 0 else 0.703125  # ten pages of key 3
+        if i == 17:
+            e[1:7] = q      # the exact best page, under the other key
+        if i == 24:
+            e[1:4] = q[:3]  # the best page of key 3
+        chunks.append(DocumentChunk(document_id=f"d{i // 2}", content=f"c{i}", embedding=e, chunk_number=i % 2, metadata={}))
+    for cls, kw in ((MI355XFastMultiVectorStore, {}), (MI355XShardedFastMultiVectorStore, dict(devices=[0, 0, 0], transport="p2p"))):
+        own = cls(capacity_pages=300, stride_rows=32, **kw)
+        lib_ = cls(capacity_pages=300, stride_rows=32, fde_module=LibFde, **kw)
+        keyed = cls(capacity_pages=300, stride_rows=32, fde_module=KeyedFde, batch_window_ms=20.0, max_batch=8, **kw)
+        for st in (own, lib_, keyed):
+            assert st.initialize()
+            ok, ids, _m = sc.run(st.store_embeddings(chunks[:70]))
+            assert ok and len(ids) == 70
+            assert sc.run(st.store_embeddings(chunks[70:]))[0]
+        for k in (1, 5):
+            a = sc.run(own.query_similar(q, k=k))
+            b = sc.run(lib_.query_similar(q, k=k))
+            assert a[0].document_id == "d8" and a[0].chunk_number == 1  # page 17
+            common = {(h.document_id, h.chunk_number) for h in a} & {(h.document_id, h.chunk_number) for h in b}
+            assert len(common) >= k - 1 and b[0].document_id == "d8"
+        hit = sc.run(keyed.query_similar(q, k=1))
+        assert (hit[0].document_id, hit[0].chunk_number) == ("d12", 0)  # page 24: the best of the ten pages the keyed vectors nominate
+
+        async def two():
+            return await asyncio.gather(keyed.query_similar(q, k=1), keyed.query_similar(q, k=1))
+
+        h1, h2 = sc.run(two())
+        assert h1[0].document_id == h2[0].document_id == "d12"
+        d = str(tmp_path / cls.__name__)
+        keyed.save(d)
+        back = cls.load(d, fde_module=KeyedFde, **kw)
+        assert sc.run(back.query_similar(q, k=1))[0].document_id == "d12"
+        with pytest.raises(RuntimeError, match="fde_module"):
+            cls.load(d, **kw)
+        for st in (own, lib_, keyed, back):
+            st.close()
+
+
 def test_store_mode_fp8_then_float_returns_the_exact_stores_answers():
     """provider "mi355x_fp8_exact": e4m3 slab in HBM + exact bf16 rows in pinned host RAM.  On the reference's store
     scenarios and on a corpus of near-duplicates it answers like the exact float store (same chunks, same order, scores
