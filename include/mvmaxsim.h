@@ -303,6 +303,9 @@ MV_API int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t
  *   mv_query_topk_batch_fde  (host fp32 [n_queries][out_dim]) in place of the encoding of the query rows on the device; the rerank
  *                            still scores the query ROWS (q).  NaN / Inf in either kind of vector: MV_ERR_INVALID. */
 MV_API int mv_index_import_fde(mv_index* ix, int64_t page0, int64_t n_pages, const float* fde);
+/* the FDE slab's rows of pages [page0, page0 + n_pages) as fp32 (the bf16 values the scan reads; host buffer of n_pages x out_dim floats):
+ * the library's own document encodings, or what was imported -- for export to another store and for tests */
+MV_API int mv_index_read_fde(mv_index* ix, int64_t page0, int64_t n_pages, float* out);
 MV_API int mv_query_topk_fde(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const float* q_fde, int32_t k, int mode,
                              const uint32_t* allow_bits, int64_t n_allow_words, float* out_scores, int64_t* out_ids, int32_t* out_n,
                              mv_query_stats* stats);

@@ -103,7 +103,7 @@ EXPORTS = [
     "mv_query_topk", "mv_query_topk_device", "mv_query_topk_batch", "mv_merge_topk", "mv_score_all", "mv_score_candidates", "mv_score_candidates_pads", "mv_index_page_rows",
     "mv_two_stage_coarse_device", "mv_two_stage_mid_device", "mv_two_stage_rerank_device", "mv_index_rerank_plan", "mv_comm_create", "mv_comm_destroy", "mv_comm_attach", "mv_comm_transport",
     "mv_comm_query_topk", "mv_comm_query_topk_batch", "mv_sign_pack", "mv_hamming_batch",
-    "mv_index_import_fde", "mv_query_topk_fde", "mv_query_topk_batch_fde", "mv_comm_query_topk_fde", "mv_comm_query_topk_batch_fde", "mv_two_stage_coarse_device_fde",
+    "mv_index_import_fde", "mv_index_read_fde", "mv_query_topk_fde", "mv_query_topk_batch_fde", "mv_comm_query_topk_fde", "mv_comm_query_topk_batch_fde", "mv_two_stage_coarse_device_fde",
     "mv_fde_output_dim", "mv_fde_encode", "mv_calibrate_read_bw", "mv_calibrate", "mv_index_save", "mv_index_load",
     "mv_enc_rmsnorm_bf16", "mv_enc_gated_act_bf16",
 ]
@@ -179,6 +179,7 @@ def lib() -> C.CDLL:
         L.mv_query_topk_device.argtypes = [vp, vp, C.c_int, i32, i32, C.c_int, vp, i64, vp, vp, vp, C.POINTER(QueryStatsC)]
         L.mv_query_topk_batch.argtypes = [vp, vp, C.c_int, i32, i32, i32, C.c_int, vp, i64, i32, vp, vp, vp, C.POINTER(QueryStatsC)]
         L.mv_index_import_fde.argtypes = [vp, i64, i64, vp]
+        L.mv_index_read_fde.argtypes = [vp, i64, i64, vp]
         L.mv_query_topk_fde.argtypes = [vp, vp, C.c_int, i32, vp, i32, C.c_int, vp, i64, vp, vp, C.POINTER(i32), C.POINTER(QueryStatsC)]
         L.mv_query_topk_batch_fde.argtypes = [vp, vp, C.c_int, i32, i32, vp, i32, C.c_int, vp, i64, i32, vp, vp, vp, C.POINTER(QueryStatsC)]
         L.mv_comm_query_topk_fde.argtypes = [vp, vp, C.c_int, i32, vp, i32, C.c_int, vp, i64, vp, vp, C.POINTER(i32), vp]

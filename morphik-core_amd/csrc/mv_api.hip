@@ -1641,6 +1641,21 @@ int mv_index_import_fde(mv_index* ix, int64_t page0, int64_t n_pages, const floa
   return rc;
 }
 
+int mv_index_read_fde(mv_index* ix, int64_t page0, int64_t n_pages, float* out) {
+  if (!ix || !out || page0 < 0 || n_pages < 0 || page0 + n_pages > ix->size.load()) { set_error("read_fde: range"); return MV_ERR_INVALID; }
+  if (!(ix->cfg.flags & MV_WITH_FDE)) { set_error("index has no FDE slab (MV_WITH_FDE)"); return MV_ERR_STATE; }
+  std::lock_guard<std::mutex> lk(ix->q_mu);
+  DeviceGuard g(ix->cfg.device);
+  const size_t n = (size_t)n_pages * (size_t)ix->fde_t.out_dim;
+  std::vector<uint16_t> h(n);
+  MV_HIP(hipMemcpy(h.data(), ix->fde + (size_t)page0 * ix->fde_t.out_dim, n * 2, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) {
+    const uint32_t u = (uint32_t)h[i] << 16;
+    memcpy(&out[i], &u, 4);
+  }
+  return MV_OK;
+}
+
 // Selection workspace of the batched entry point: one top-k workspace, result row and pinned read-back row per query of a
 // group (q_mu held).
 int mv_internal_ensure_batch_select_ws(mv_index* ix) {

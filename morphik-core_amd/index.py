@@ -279,6 +279,12 @@ class MvIndex:
         a = a.reshape(-1, self.fde_config.output_dim)
         check(lib().mv_index_import_fde(self._h, int(page0), a.shape[0], a.ctypes.data))
 
+    def read_fde(self, page0: int, n_pages: int) -> np.ndarray:
+        """-> float32 [n_pages][output_dim]: the document FDE vectors the scan reads (bf16 values), own or imported."""
+        out = np.empty((int(n_pages), self.fde_config.output_dim), np.float32)
+        check(lib().mv_index_read_fde(self._h, int(page0), int(n_pages), out.ctypes.data))
+        return out
+
     def read_fp8(self, page0: int, n_pages: int) -> Tuple[np.ndarray, np.ndarray]:
         """-> (e4m3 codes [n, stride_rows, 128] uint8, per-page inverse scales [n] float32)."""
         codes = np.empty((n_pages, self.stride_rows, 128), np.uint8)

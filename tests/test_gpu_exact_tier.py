@@ -649,6 +649,7 @@ def test_caller_supplied_fde_vectors_drive_the_coarse_stage():
     ix.import_fde(0, docs[:120])
     ix.import_fde(120, docs[120:])
     db = orc.bf16_to_f32(orc.f32_to_bf16(docs))
+    np.testing.assert_array_equal(ix.read_fde(100, 40), db[100:140])  # the slab holds the rounded vectors, read back through mv_index_read_fde
     want_all = (db @ qf.T) / np.linalg.norm(db, axis=1, keepdims=True)  # [page][query]: the scan's cosine rule (1/|d| of the rounded vector)
     ix.set_option(_lib.MV_OPT_FDE_COARSE_N, 40)
     for j, q in enumerate(qs):
