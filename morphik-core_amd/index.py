@@ -434,11 +434,17 @@ class MvIndex:
 
     # -- sharded two-stage pipeline (device-resident stages; see include/mvmaxsim.h)
     def two_stage_coarse_device(self, q: Any, n_coarse: int, d_recs_ptr: int, allow: Optional[np.ndarray] = None, stream: int = 0,
-                                mode: str = "fde_then_float") -> None:
+                                mode: str = "fde_then_float", q_fde: Any = None) -> None:
         """Stage 1 of a staged query on this shard: coarse scan ("fde_then_float": the FDE slab; "fp8_then_float": the e4m3
-        slab) + local top-n_coarse -> n_coarse 16-byte records in a device buffer."""
+        slab) + local top-n_coarse -> n_coarse 16-byte records in a device buffer.  q_fde: the caller's own FDE of the query (query())."""
         qa, code = as_rows(q)
         ab = None if allow is None else np.ascontiguousarray(allow, dtype=np.uint32)
+        if q_fde is not None:
+            qf = _fde_block(q_fde, 1)
+            check(lib().mv_two_stage_coarse_device_fde(self._h, qa.ctypes.data, code, qa.shape[0], qf.ctypes.data, int(n_coarse), MODES[mode],
+                                                       None if ab is None else ab.ctypes.data, 0 if ab is None else ab.size, C.c_void_p(d_recs_ptr),
+                                                       C.c_void_p(stream) if stream else None))
+            return
         check(lib().mv_two_stage_coarse_device(self._h, qa.ctypes.data, code, qa.shape[0], int(n_coarse), MODES[mode], None if ab is None else ab.ctypes.data,
                                                0 if ab is None else ab.size, C.c_void_p(d_recs_ptr), C.c_void_p(stream) if stream else None))
 

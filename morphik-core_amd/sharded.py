@@ -392,7 +392,8 @@ class GpuTwoStageSearcher:
                                torch.empty(n, dtype=torch.float32, device=d), torch.empty(w * n, dtype=torch.float32, device=d))
         return self._bufs[key]
 
-    def query(self, q, k: int, coarse_n: Optional[int] = None, allow=None):
+    def query(self, q, k: int, coarse_n: Optional[int] = None, allow=None, q_fde=None):
+        """q_fde: the caller's own FDE vector of the query (every rank passes the same one), MvIndex.query."""
         import ctypes as C
 
         import numpy as np
@@ -406,7 +407,7 @@ class GpuTwoStageSearcher:
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         n_q = int(np.shape(q)[0]) if np.ndim(q) == 2 else 1
         n_mid, _tier = self.index.rerank_plan(n, k, n_q, mode=self.mode)  # host-side rule, identical on every rank
-        self.index.two_stage_coarse_device(q, n, recs.data_ptr(), allow=allow, stream=stream, mode=self.mode)
+        self.index.two_stage_coarse_device(q, n, recs.data_ptr(), allow=allow, stream=stream, mode=self.mode, **({} if q_fde is None else {"q_fde": q_fde}))
         if dist.is_initialized():
             dist.all_gather_into_tensor(allrecs, recs, group=self.group)
         else:

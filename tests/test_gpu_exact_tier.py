@@ -687,6 +687,15 @@ def test_caller_supplied_fde_vectors_drive_the_coarse_stage():
         assert i.tolist() == wi.tolist()
         np.testing.assert_allclose(s, ws, rtol=1e-6)
     comm.close()
+    # the stream-ordered staged pipeline of the one-process-per-GPU flow (no process group: one rank) with the caller's query FDE
+    from morphik_core_amd import sharded
+    import torch
+
+    se = sharded.GpuTwoStageSearcher(ix, mode="fde_then_float")
+    for j, q in enumerate(qs[:2]):
+        s, i = se.query(q, k, coarse_n=40, q_fde=qf[j])
+        torch.cuda.synchronize()
+        assert i.cpu().tolist() == single[j][1].tolist() and s.cpu().tolist() == single[j][0].tolist()
     for sh in shards:
         sh.close()
     # (c) the library's own encodings through the same doors == the internal path
