@@ -333,12 +333,8 @@ class MvIndex:
             check(lib().mv_query_topk_fde(self._h, qa.ctypes.data, code, qa.shape[0], qf.ctypes.data, k, MODES[mode], None if ab is None else ab.ctypes.data,
                                           0 if ab is None else ab.size, scores.ctypes.data, ids.ctypes.data, C.byref(n), C.byref(st) if want_stats else None))
         else:
-          check(
-            lib().mv_query_topk(
-                self._h, qa.ctypes.data, code, qa.shape[0], k, MODES[mode], None if ab is None else ab.ctypes.data,
-                0 if ab is None else ab.size, scores.ctypes.data, ids.ctypes.data, C.byref(n), C.byref(st) if want_stats else None,
-            )
-          )
+            check(lib().mv_query_topk(self._h, qa.ctypes.data, code, qa.shape[0], k, MODES[mode], None if ab is None else ab.ctypes.data,
+                                      0 if ab is None else ab.size, scores.ctypes.data, ids.ctypes.data, C.byref(n), C.byref(st) if want_stats else None))
         res = (scores[: n.value].copy(), ids[: n.value].copy())
         return res + (QueryStats.from_c(st),) if want_stats else res
 
@@ -377,12 +373,8 @@ class MvIndex:
                                                 None if ab is None else ab.ctypes.data, n_words, per_query, scores.ctypes.data, ids.ctypes.data,
                                                 n.ctypes.data, C.byref(st) if want_stats else None))
         else:
-          check(
-            lib().mv_query_topk_batch(
-                self._h, blk.ctypes.data, code, len(rows), nmax, k, MODES[mode], None if ab is None else ab.ctypes.data,
-                n_words, per_query, scores.ctypes.data, ids.ctypes.data, n.ctypes.data, C.byref(st) if want_stats else None,
-            )
-          )
+            check(lib().mv_query_topk_batch(self._h, blk.ctypes.data, code, len(rows), nmax, k, MODES[mode], None if ab is None else ab.ctypes.data,
+                                            n_words, per_query, scores.ctypes.data, ids.ctypes.data, n.ctypes.data, C.byref(st) if want_stats else None))
         res = [(scores[i, : n[i]].copy(), ids[i, : n[i]].copy()) for i in range(len(rows))]
         return (res, QueryStats.from_c(st)) if want_stats else res
 
