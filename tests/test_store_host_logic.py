@@ -711,6 +711,43 @@ def test_sharded_index_batch_merges_per_shard_topk_like_the_communicator():
     ix.close()
 
 
+def test_sharded_index_routes_imported_fde_vectors_and_query_fdes_to_the_shards():
+    """ShardedIndex.import_fde (global page ids of one add() -> the owning shard) and q_fde / q_fdes through query and query_batch:
+    with caller-supplied vectors on every page the coarse ("fde") scores are dot products the test computes itself."""
+    from morphik_core_amd.shard_index import ShardedIndex
+    from oracle import oracle as orc
+    from tests.fake_index import OracleComm
+
+    class fde_index(OracleIndex):
+        def __init__(self, *a, **kw):
+            kw["fde"] = orc.FdeConfig.reference_default()
+            super().__init__(*a, **kw)
+
+    rng = np.random.default_rng(13)
+    ix = ShardedIndex(capacity_pages=30, stride_rows=16, devices=[0, 0, 0], index_cls=fde_index, comm_cls=OracleComm, with_float=True, with_fde=True)
+    D = 10240
+    docs = {}
+    for b in range(5):
+        first = ix.add([sc.rand_emb(rng, 5) for _ in range(4)], doc_ordinals=[b] * 4)
+        vec = rng.standard_normal((4, D)).astype(np.float32)
+        ix.import_fde(first, vec)
+        for i in range(4):
+            docs[first + i] = vec[i]
+    queries = [sc.rand_emb(rng, 4) for _ in range(3)]
+    qf = rng.standard_normal((3, D)).astype(np.float32)
+    ids = sorted(docs)
+    db = orc.bf16_to_f32(orc.f32_to_bf16(np.stack([docs[i] for i in ids])))
+    want = (db @ qf.T) / np.linalg.norm(db, axis=1, keepdims=True)
+    for j, q in enumerate(queries):
+        s, i = ix.query(q, 20, mode="fde", q_fde=qf[j])
+        assert sorted(i.tolist()) == ids
+        np.testing.assert_allclose(s, want[[ids.index(int(x)) for x in i], j], rtol=2e-3, atol=1e-4)
+    for j, (s, i) in enumerate(ix.query_batch(queries, 5, mode="fde", q_fdes=qf)):
+        ws, wi = ix.query(queries[j], 5, mode="fde", q_fde=qf[j])
+        assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist()
+    ix.close()
+
+
 def test_sharded_store_equals_single_store_and_spreads_the_pages():
     rng = np.random.default_rng(21)
     chunks = sc.make_chunks(rng, n_docs=6, chunks_per_doc=3)
