@@ -328,6 +328,8 @@ def main(argv: Optional[List[str]] = None) -> None:
     ap.add_argument("--save-dir", default="", help="checkpoint directory: POST /save, --save-every-s and shutdown write store.save() here (resume with --load)")
     ap.add_argument("--save-every-s", type=float, default=0.0, help="checkpoint every N seconds when pages were added or deleted since the last one (0 = only /save and shutdown)")
     ap.add_argument("--payload-dir", default="", help="directory for chunk payloads (page images): the owner's `.storage`; without it payloads stay inline in the owner's memory")
+    ap.add_argument("--fde-module", default="", help="importable module with the API of the reference's `fde` extension (FixedDimensionalEncodingConfig, "
+                                                      "generate_document_encoding, generate_query_encoding): the fast providers use ITS vectors for the candidate stage")
     a = ap.parse_args(argv)
     import uvicorn
 
@@ -347,6 +349,10 @@ def build_store(a: Any) -> Any:
         opts["storage"] = LocalDirStorage(a.payload_dir)
     if a.devices:
         opts["devices"] = [int(x) for x in a.devices.split(",")]
+    if getattr(a, "fde_module", ""):
+        import importlib
+
+        opts["fde_module"] = importlib.import_module(a.fde_module)  # raises loudly when the deployment's encoder is not installed
     proto = create_store(a.provider, capacity_pages=a.capacity_pages, stride_rows=a.stride_rows, **opts)  # allocates nothing yet
     if a.load:
         if not hasattr(proto, "devices"):

@@ -403,6 +403,34 @@ def test_bring_your_own_fde_module_drives_the_candidate_stage(tmp_path):
         MI355XMultiVectorStore(capacity_pages=8, mode="float", fde_module=mod)
 
 
+def test_owner_server_takes_the_deployments_fde_module_by_name(monkeypatch):
+    """store_server --fde-module <importable name>: the owner process imports the deployment's encoder and builds the store over it;
+    a module that is not installed fails loudly."""
+    import argparse
+
+    from morphik_core_amd import store as store_mod
+    from morphik_core_amd import store_server
+
+    seen = {}
+    real = store_mod.create_store
+
+    def spy(provider, **kw):
+        seen.update(kw)
+        kw["index_factory"] = OracleIndex  # no GPU here: the oracle-backed index stands in
+        return real(provider, **kw)
+
+    monkeypatch.setattr(store_mod, "create_store", spy)
+    a = argparse.Namespace(provider="mi355x_fast", capacity_pages=16, stride_rows=32, devices="", load="", batch_window_ms=-1.0, max_batch=8,
+                           payload_dir="", fde_module="tests.fake_fde_module")
+    st = store_server.build_store(a)
+    import tests.fake_fde_module as fm
+
+    assert seen["fde_module"] is fm and st.fde_module is fm and st._fde_ext_cfg.kw["num_repetitions"] == 20
+    a.fde_module = "no_such_fde_module_anywhere"
+    with pytest.raises(ModuleNotFoundError):
+        store_server.build_store(a)
+
+
 def test_compaction_reclaims_slots_and_keeps_answers():
     rng = np.random.default_rng(7)
     chunks = sc.make_chunks(rng, n_docs=5, chunks_per_doc=3)
