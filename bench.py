@@ -199,6 +199,20 @@ def lib_sha256():
     return h.hexdigest()
 
 
+def src_sha256():
+    """sha256 over the library's SOURCES (csrc/*.hip, csrc/*.h, csrc/Makefile, include/mvmaxsim.h; names + bytes, sorted).  The built file
+    embeds its build directory (__FILE__ in the error messages), so the same sources built in another checkout hash differently: a PMC
+    record is also accepted for the sources it was taken on."""
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "morphik-core_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "morphik-core_amd", "csrc", "*.h"))
+                   + [os.path.join(ROOT, "morphik-core_amd", "csrc", "Makefile"), os.path.join(ROOT, "include", "mvmaxsim.h")])
+    for f in files:
+        h.update(os.path.relpath(f, ROOT).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def pmc_traffic(n_local, patches):
     """HBM traffic of the scan kernel from rocprofv3 PMC counters (FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch
     correction calibrated on a known byte count in the same pass), collected by tools/pmc_traffic.sh and committed under
@@ -206,10 +220,15 @@ def pmc_traffic(n_local, patches):
     libmvmaxsim.so it profiled; anything else -> null (a kernel change must not inherit an old measurement)."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "**", "pmc_traffic*.json"), recursive=True), key=os.path.getmtime)
     sha = lib_sha256()
+    try:
+        ssha = src_sha256()
+    except OSError:
+        ssha = None
     for f in reversed(files):
         try:
             rec = json.load(open(f))
-            if rec.get("lib_sha256") == sha and "maxsim_ldsdma_kernel" in rec.get("kernel", ""):
+            same_build = rec.get("lib_sha256") == sha or (ssha is not None and rec.get("src_sha256") == ssha)  # this very file, or these very sources
+            if same_build and "maxsim_ldsdma_kernel" in rec.get("kernel", ""):
                 return int(round(float(rec["hbm_bytes_per_page"]) * n_local * patches / 1024.0)), os.path.relpath(f, ROOT), rec.get("kernel")
         except Exception:  # noqa: BLE001
             continue
@@ -1060,6 +1079,7 @@ def main():
             "traffic_source": traffic_src,
             "traffic_kernel": traffic_kernel,
             "lib_sha256": lib_sha256()[:16],
+            "src_sha256": src_sha256()[:16],  # the traffic record is accepted for this built file or for these sources (another checkout embeds another path)
             "bytes_per_launch": bytes_per_launch,
             "kernel_ms_avg": round(k_ms, 4),
             "kernel_ms_per_rank": [round(x, 4) for x in per_rank_kms],

@@ -28,9 +28,13 @@ def main(fetch_json, write_json, pages, out):
     wr = write_kib * 1024.0
     alg = pages * 1024 * 256
     h = hashlib.sha256(open(os.path.join(ROOT, "morphik-core_amd", "libmvmaxsim.so"), "rb").read()).hexdigest()
+    sys.path.insert(0, ROOT)
+    import bench  # the sources' hash, by bench.py's own rule (the built file embeds its build directory)
+
+    src = bench.src_sha256()
     rec = {
         "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on tools/variant_bench.py --pages {pages} --variants 6 --rounds 3, MI355X",
-        "kernel": kern, "lib_sha256": h, "pages_per_launch": pages, "algorithmic_bytes_per_launch": alg,
+        "kernel": kern, "lib_sha256": h, "src_sha256": src, "pages_per_launch": pages, "algorithmic_bytes_per_launch": alg,
         "FETCH_SIZE_KiB_avg": fetch_kib, "WRITE_SIZE_KiB_avg": write_kib,
         "calibration": {"kernel": cal[0], "known_bytes": known, "FETCH_SIZE_KiB_avg": f[cal[0]]["FETCH_SIZE"]["avg"], "reported_over_known": ratio},
         "gfx950_fetch_correction": corr,
