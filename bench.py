@@ -23,7 +23,10 @@ Other workloads (`--workload`): fp8 (configs[4] shape), binary (MultiVectorStore
 (configs[3] shard shape: FDE coarse top-1000 -> exact fp8 rerank), embed (configs[1]: ColPali-v1.2 architecture embeds
 1 k synthetic pages -> device ingest -> MaxSim top-10).
 
-Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+Rank 0's LAST stdout line is the result record (contract in the task statement) with `roofline` and `cpu_baseline`, kept under
+3 KB (HEADLINE_MAX_BYTES).  Everything else -- the cut fields of those two objects and `aux_paths` (the secondary kernels and
+pipelines, measured by a child process after the headline is complete) -- is one EARLIER stdout line without a `metric` key,
+also written to gpurun_out/bench_aux.json.  stderr carries plain-text progress only.
 """
 import argparse
 import glob
@@ -814,8 +817,8 @@ def spawn_ranks(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    if lines:
-        print(lines[-1], flush=True)
+    for ln in lines:  # rank 0's detail record, then its headline (last)
+        print(ln, flush=True)
     return p.returncode if (p.returncode or lines) else 1
 
 
@@ -854,6 +857,8 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend for N>1 (nccl == RCCL; gloo + MV_BENCH_SINGLE_DEVICE=1 lets N ranks share one GPU to "
                          "exercise the multi-rank path on a 1-GPU box -- a functional check, not a measurement)")
+    ap.add_argument("--aux-timeout", type=int, default=900, help="limit (s) of the child process that measures aux_paths")
+    ap.add_argument("--aux-child", default=None, help=argparse.SUPPRESS)  # internal: state file of the aux child (run_aux_child)
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -873,6 +878,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    if args.aux_child:
+        aux_child(args, local_rank)
+        return
 
     if args.workload == "embed":
         if world != 1:
@@ -1149,9 +1158,8 @@ def main():
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": args.scaling,
-            "vs_baseline": (round(value / cpu["value"], 1) if (cpu and cpu.get("value")) else None),
-            "vs_baseline_note": ("value / cpu_baseline.value: BASELINE.md publishes no number for this metric (section 1); the denominator is the reference's "
-                                 "CPU formulation at its best thread count on this box's own host cores, measured in this run" if cpu else None),
+            "vs_baseline": None,  # the reference publishes no number for this metric
+            "speedup_vs_cpu_baseline": (round(value / cpu["value"], 1) if (cpu and cpu.get("value")) else None),
             "dtype": WL["dtype"],
             "data": "synthetic (on-device counter-based generator, L2-normalised bf16 rows, planted neighbours)",
             "config": {
@@ -1170,7 +1178,6 @@ def main():
                 "parallelism": "row-shard x%d + all-gather top-k" % world,
                 "collective_backend": (args.backend if dist_on else None),
                 "rccl_ranks": (dist.get_world_size() if (dist_on and args.backend == "nccl") else 0),
-                "kernel_ms_per_rank": [round(x, 4) for x in per_rank_kms],
                 "local_scan_and_topk_ms_per_step": None if local_only_ms is None else round(local_only_ms, 4),
                 "collective_and_merge_ms_per_step": None if local_only_ms is None else round(ms_per_step - local_only_ms, 4),
             },
@@ -1180,6 +1187,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+    aux = {}
     if out is not None and world == 1 and args.workload == "fde_fp8" and not args.no_aux:
         # the same shard serving 32 concurrent requests: mv_query_topk_batch, one FDE-slab pass for all of them
         bq = [queries[i % N_QUERIES] for i in range(32)]
@@ -1191,13 +1199,12 @@ def main():
                 stages.append((st.encode_ms, st.coarse_ms, st.select_ms, st.rerank_ms, st.topk_ms))
         d, sb = float(np.median(dev_ms)), np.median(np.array(stages), axis=0)
         rb = [synth.recall_at_k([p for p in res_b[i][1].tolist() if p >= 0], [p for (qq, _r, p, _a, _b) in spec if qq == i % N_QUERIES]) for i in range(32)]
-        out["batched_32_requests"] = {
+        aux["batched_32_requests"] = {
             "device_ms_per_batch": round(d, 4), "device_us_per_request": round(d * 1e3 / 32, 2), "requests_per_s": round(32 / d * 1e3, 1),
             "pages_searched_per_s": round(32 * n_local / d * 1e3, 1), "throughput_vs_one_request_per_step": round(32 * ms_per_step / d, 2),
             "stage_ms": {k: round(float(v), 4) for k, v in zip(("encode_32_queries", "coarse_gemm_one_slab_pass", "select", "rerank_fp8", "topk"), sb)},
             "coarse_pass_GBps": round(n_local * 20480 / float(sb[1]) / 1e6, 1), "recall_at_10": float(np.mean(rb)),
         }
-    aux = {}
     truths = gaps = None
     if out is not None and want_full:
         try:  # exact bf16 truth of every recall set + the batched MFMA scan, on the headline slab before it is freed
@@ -1247,47 +1254,157 @@ def main():
         for ent in aux.get("batched_float", {}).values():
             ent["frac_of_measured_mfma_16x16x32"] = round(ent["TFLOPs"] / measured_mfma, 4)
             ent["frac_of_measured_mfma_32x32x16"] = round(ent["TFLOPs"] / measured_mfma32, 4)
-    if out is not None and world == 1 and not args.no_aux:
-        out["aux_paths"] = aux
-        if rsets is not None and args.full_shard_pages > 0:
-            try:  # BASELINE configs[3] / [4] at their per-GPU shard SIZE: the scan rates
-                aux["full_shard"] = full_shard(args, local_rank, rsets["planted"]["queries"])
-            except Exception as e:  # noqa: BLE001
-                aux["full_shard"] = {"error": repr(e)}
-        if truths is not None and n_exact > 0:
-            try:  # ... and at their shard SHAPE with the exact tier in pinned host RAM: the exact pipelines and every recall figure
-                aux["exact_shard"] = exact_shard(args, local_rank, n_exact, n_truth, exact_budget, exact_split, dict(rsets, _headline_spec=spec), truths, gaps)
-            except Exception as e:  # noqa: BLE001
-                aux["exact_shard"] = {"error": repr(e)}
-        if args.aux_pages > 0:
-            try:  # fp8 scan -> exact bf16 re-score from the exact tier (HBM / pinned host)
-                aux["fp8_then_float"] = two_tier(args, local_rank)
-            except Exception as e:  # noqa: BLE001
-                aux["fp8_then_float"] = {"error": repr(e)}
-        if args.aux_pages > 0:
-            try:  # roofline entry of the FDE document encode
-                aux["fde_document_encode"] = fde_encode_block(args, local_rank)
-            except Exception as e:  # noqa: BLE001
-                aux["fde_document_encode"] = {"error": repr(e)}
-        if args.aux_pages > 0:
-            try:  # the same path measured where the reference measures it: at the store's coroutine
-                aux["serving"] = serving_block(args)
-            except Exception as e:  # noqa: BLE001
-                aux["serving"] = {"error": repr(e)}
-        if args.aux_embed_pages > 0:
-            try:  # configs[1] at full model size, short: encoder -> device ingest -> top-10
-                r = embed_workload(args, args.aux_embed_pages, quick=True)
-                out["aux_paths"]["embed_colpali_v1_2"] = {k: r[k] for k in ("workload", "params", "rows_per_page", "embed_pages_per_s", "embed_model_only_pages_per_s",
-                                                                             "embed_tflops_est", "store_device_path_pages_per_s", "query_embed_ms_med",
-                                                                             "query_maxsim_top10_ms_med", "model_batch", "chunks_per_call", "fused_encoder_ops", "tuned_gemm_selections", "dtype", "data")}
-            except Exception as e:  # noqa: BLE001
-                out["aux_paths"]["embed_colpali_v1_2"] = {"error": repr(e)}
+    if out is not None:
+        # the record of the timed region is complete: keep it on disk before any side measurement runs
+        write_record("bench_headline.json", split_headline(out)[0])
+    if out is not None and world == 1 and not args.no_aux and args.workload == "float":
+        # the secondary paths (configs[1] / [3] / [4] shapes, serving, encoder) run in a CHILD process with every slab of this one
+        # freed: a crash, an out-of-memory kill or a hang there costs the aux record, never the headline line printed below
+        state = {"n_total": n_total, "n_truth": n_truth, "n_exact": n_exact, "exact_budget": exact_budget,
+                 "exact_split": bool(exact_split) if want_full and n_exact else False, "truths": truths, "gaps": gaps, "have_sets": rsets is not None}
+        del rsets, queries
+        torch.cuda.empty_cache()
+        aux.update(run_aux_child(args, state))
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
-        print(json.dumps(out), flush=True)
+        emit(out, aux)
 
+
+HEADLINE_ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "bytes_per_launch", "kernel_ms_avg",
+                          "kernel_ms_per_rank", "launches_timed", "measured_read_peak", "frac_of_measured_peak")
+HEADLINE_CPU_KEYS = ("value", "unit", "cores", "cores_available", "kind", "formulation", "sample")
+HEADLINE_MAX_BYTES = 3000
+
+
+def split_headline(out):
+    """-> (headline, detail): the compact result record (every contract key, `roofline` and `cpu_baseline` cut to the fields a
+    reader needs to recompute them) and what was cut.  The headline must stay under HEADLINE_MAX_BYTES serialised: round 4's
+    one-line record grew to 23-28 KB and fell out of the driver's capture window."""
+    head = {k: v for k, v in out.items() if k not in ("roofline", "cpu_baseline")}
+    detail = {}
+    for key, keep in (("roofline", HEADLINE_ROOFLINE_KEYS), ("cpu_baseline", HEADLINE_CPU_KEYS)):
+        full = out.get(key)
+        if isinstance(full, dict):
+            head[key] = {k: full[k] for k in keep if k in full}
+            rest = {k: v for k, v in full.items() if k not in keep}
+            if rest:
+                detail[key] = rest
+        else:
+            head[key] = full
+    if len(json.dumps(head)) >= HEADLINE_MAX_BYTES and isinstance(head.get("cpu_baseline"), dict):  # the free-text fields go first
+        detail.setdefault("cpu_baseline", {})["sample"] = head["cpu_baseline"].pop("sample", None)
+    return head, detail
+
+
+def out_dir():
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def write_record(name, doc):
+    """Best effort: gpurun_out/ is scratch that travels back from the GPU box; a read-only tree must not cost the result line."""
+    try:
+        with open(os.path.join(out_dir(), name), "w") as f:
+            json.dump(doc, f, indent=1)
+        return os.path.join("gpurun_out", name)
+    except OSError:
+        return None
+
+
+def emit(out, aux):
+    """stdout of rank 0: (1) the detail record -- `bench_detail` + `aux_paths`, no `metric` key, any length -- then (2) the
+    headline as the LAST line, < HEADLINE_MAX_BYTES.  Nothing JSON-shaped goes to stderr."""
+    head, detail = split_headline(out)
+    doc = {"bench_detail": detail, "aux_paths": aux}
+    head["aux_file"] = write_record("bench_aux.json", doc)
+    if detail or aux:
+        print(json.dumps(doc), flush=True)
+    line = json.dumps(head)
+    if len(line) >= HEADLINE_MAX_BYTES:
+        sys.exit(f"bench.py: the headline record is {len(line)} bytes (limit {HEADLINE_MAX_BYTES})")
+    print(line, flush=True)
+
+
+def run_aux_child(args, state):
+    """Re-execute this file with --aux-child <state file>: the child rebuilds the (deterministic) query / page sets, takes the
+    exact truths from the state file and measures the secondary paths; its one stdout line is the aux dict."""
+    path = os.path.join(out_dir(), "bench_aux_state.json")
+    with open(path, "w") as f:
+        json.dump(state, f)
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--aux-child", path]
+    t0 = time.time()
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, timeout=args.aux_timeout)
+    except subprocess.TimeoutExpired:
+        return {"aux_child_error": f"timed out after {args.aux_timeout} s"}
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if not lines:
+        return {"aux_child_error": f"no record (exit code {p.returncode})"}
+    try:
+        res = json.loads(lines[-1])
+    except ValueError as e:
+        return {"aux_child_error": repr(e)}
+    res["aux_child_seconds"] = round(time.time() - t0, 1)
+    if p.returncode:
+        res["aux_child_exit_code"] = p.returncode
+    return res
+
+
+def aux_child(args, local_rank):
+    """The secondary paths of the default run (BASELINE configs[1] / [3] / [4] shapes, the plugin boundary under load), one
+    try-block each; prints ONE JSON line (the aux dict)."""
+    import torch
+
+    from morphik_core_amd import synth
+    from morphik_core_amd.index import synth_rows
+
+    st = json.load(open(args.aux_child))
+    stride = ((args.patches + 15) // 16) * 16
+    n_total, n_truth, n_exact = st["n_total"], st["n_truth"], st["n_exact"]
+    truths, gaps = st["truths"], st["gaps"]
+    aux = {}
+    rsets = spec = None
+    if st["have_sets"]:
+        queries = [synth_rows(synth.SEED_QUERIES, qi, args.qtokens, device=local_rank) for qi in range(N_QUERIES)]
+        spec = synth.planted_spec(queries, n_total, args.patches, n_ranks=N_PLANTED)
+        rsets = recall_sets(args, n_truth, local_rank, spec)
+        del queries
+    if rsets is not None and args.full_shard_pages > 0:
+        try:  # BASELINE configs[3] / [4] at their per-GPU shard SIZE: the scan rates
+            aux["full_shard"] = full_shard(args, local_rank, rsets["planted"]["queries"])
+        except Exception as e:  # noqa: BLE001
+            aux["full_shard"] = {"error": repr(e)}
+    if truths is not None and n_exact > 0:
+        try:  # ... and at their shard SHAPE with the exact tier in pinned host RAM: the exact pipelines and every recall figure
+            aux["exact_shard"] = exact_shard(args, local_rank, n_exact, n_truth, st["exact_budget"], st["exact_split"], dict(rsets, _headline_spec=spec), truths, gaps)
+        except Exception as e:  # noqa: BLE001
+            aux["exact_shard"] = {"error": repr(e)}
+    if args.aux_pages > 0:
+        try:  # fp8 scan -> exact bf16 re-score from the exact tier (HBM / pinned host)
+            aux["fp8_then_float"] = two_tier(args, local_rank)
+        except Exception as e:  # noqa: BLE001
+            aux["fp8_then_float"] = {"error": repr(e)}
+        try:  # roofline entry of the FDE document encode
+            aux["fde_document_encode"] = fde_encode_block(args, local_rank)
+        except Exception as e:  # noqa: BLE001
+            aux["fde_document_encode"] = {"error": repr(e)}
+        try:  # the same path measured where the reference measures it: at the store's coroutine
+            aux["serving"] = serving_block(args)
+        except Exception as e:  # noqa: BLE001
+            aux["serving"] = {"error": repr(e)}
+    if args.aux_embed_pages > 0:
+        try:  # configs[1] at full model size, short: encoder -> device ingest -> top-10
+            r = embed_workload(args, args.aux_embed_pages, quick=True)
+            aux["embed_colpali_v1_2"] = {k: r[k] for k in ("workload", "params", "rows_per_page", "embed_pages_per_s", "embed_model_only_pages_per_s",
+                                                           "embed_tflops_est", "store_device_path_pages_per_s", "query_embed_ms_med",
+                                                           "query_maxsim_top10_ms_med", "model_batch", "chunks_per_call", "fused_encoder_ops", "tuned_gemm_selections", "dtype", "data")}
+        except Exception as e:  # noqa: BLE001
+            aux["embed_colpali_v1_2"] = {"error": repr(e)}
+    torch.cuda.synchronize()
+    print(json.dumps(aux), flush=True)
 
 if __name__ == "__main__":
     main()

@@ -1,0 +1,102 @@
+"""bench.py's result line: the LAST stdout line, compact (< 3 KB), complete.
+
+Round 4's record grew to 23-28 KB (aux_paths inside the one line) and the driver parsed no result line at all.  The CPU test
+cuts a recorded round-4 line with the bench's own split_headline(); the GPU test runs the default-aux path (child process and
+all) at a reduced size and checks what the driver's parser will see."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                 "roofline", "cpu_baseline")
+
+
+def _bench_module():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _check_headline(line):
+    assert len(line) < 3000, len(line)
+    d = json.loads(line)
+    for k in CONTRACT_KEYS:
+        assert k in d, k
+    rf, cpu = d["roofline"], d["cpu_baseline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cpu, k
+    assert "workload" in d["config"] and "model" not in d["config"] and "aux_paths" not in d
+    return d
+
+
+def test_recorded_round4_line_cut_to_a_compact_headline():
+    b = _bench_module()
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r4", "bench_1gpu_1M_pages_r4f.json")))
+    assert len(json.dumps(rec)) > 20000  # what the driver could not parse
+    aux = rec.pop("aux_paths")
+    head, detail = b.split_headline(rec)
+    d = _check_headline(json.dumps(head))
+    assert d["value"] == rec["value"] and d["roofline"]["frac"] == rec["roofline"]["frac"] and d["cpu_baseline"]["value"] == rec["cpu_baseline"]["value"]
+    # nothing is lost: what the headline drops is in the detail record
+    assert set(detail["roofline"]) | set(head["roofline"]) == set(rec["roofline"])
+    assert set(detail["cpu_baseline"]) | set(head["cpu_baseline"]) == set(rec["cpu_baseline"])
+    assert aux  # (goes to the earlier stdout line / gpurun_out/bench_aux.json)
+
+
+def test_emit_prints_detail_first_and_headline_last(capsys, tmp_path, monkeypatch):
+    b = _bench_module()
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r4", "bench_1gpu_1M_pages_r4f.json")))
+    aux = rec.pop("aux_paths")
+    b.emit(rec, aux)
+    cap = capsys.readouterr()
+    lines = cap.out.splitlines()
+    assert len(lines) == 2 and not any(ln.startswith("{") for ln in cap.err.splitlines())
+    first = json.loads(lines[0])
+    assert "metric" not in first and first["aux_paths"] == aux and "roofline" in first["bench_detail"]
+    d = _check_headline(lines[1])
+    assert d["aux_file"] == os.path.join("gpurun_out", "bench_aux.json")
+    assert json.load(open(tmp_path / "gpurun_out" / "bench_aux.json"))["aux_paths"] == aux
+
+
+def test_serving_progress_lines_are_not_json():
+    src = open(os.path.join(ROOT, "tools", "serve_bench.py")).read()
+    assert "print(json.dumps(r), file=sys.stderr" not in src
+
+
+@pytest.mark.gpu
+def test_default_aux_run_last_line_is_the_compact_headline():
+    """The driver's command shape (`python bench.py --steps K --warmup W`, aux ON) at a reduced corpus: the last stdout line is
+    the headline, short, with roofline.frac and cpu_baseline.value; the timed region fits the wall clock of the run; the aux
+    record is an earlier line and a file."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--pages", "50000", "--cpu-sample-pages", "1024",
+           "--full-shard-pages", "60000", "--exact-shard-pages", "60000", "--aux-pages", "20000", "--aux-embed-pages", "0"]
+    t0 = time.time()
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200, cwd=ROOT)
+    wall = time.time() - t0
+    assert p.returncode == 0, p.stderr[-3000:]
+    out_lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert not any(ln.startswith("{") for ln in p.stderr.splitlines()), "JSON-shaped line on stderr"
+    d = _check_headline(out_lines[-1])
+    assert len(out_lines[-1]) < 4096
+    assert d["steps"] == 8 and d["warmup"] == 2 and d["n_gpus"] == 1 and d["recall_at_10"] == 1.0
+    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0 and d["vs_baseline"] is None
+    assert d["ms_per_step"] * d["steps"] / 1e3 <= wall
+    assert abs(d["value"] - d["config"]["pages_total"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    earlier = [json.loads(ln) for ln in out_lines[:-1] if ln.startswith("{")]
+    assert len(earlier) == 1 and "metric" not in earlier[0]
+    aux = earlier[0]["aux_paths"]
+    assert "aux_child_error" not in aux, aux
+    for key in ("truth", "batched_float", "full_shard", "exact_shard", "fp8_then_float", "fde_document_encode", "serving"):
+        assert key in aux and "error" not in aux[key], (key, aux.get(key))
+    assert json.load(open(os.path.join(ROOT, "gpurun_out", "bench_aux.json")))["aux_paths"].keys() == aux.keys()

@@ -159,7 +159,9 @@ def measure(a):
             if st.coalesced_batches:
                 r["mean_batch"] = round(float(np.mean(st.coalesced_batches)), 2)
             res["runs"].append(r)
-            print(json.dumps(r), file=sys.stderr, flush=True)
+            # plain text on stderr: a JSON-shaped progress line is what the driver mistook for the bench record in round 4
+            print("[serving] %s clients=%d: %.0f req/s, p50 %.3f ms, p99 %.3f ms%s" % (label, nc, r["requests_per_s"], r["p50_ms"], r["p99_ms"],
+                  (", mean batch %.1f" % r["mean_batch"]) if "mean_batch" in r else ""), file=sys.stderr, flush=True)
     st.close()
     one = [r for r in res["runs"] if r["clients"] == 1 and r["coalescer"] == "coalescer_off"]
     if one and "direct_single" in res:
