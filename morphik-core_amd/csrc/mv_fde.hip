@@ -969,6 +969,188 @@ __global__ __launch_bounds__(256) void fde_scan_kernel(ScanArgs a) {
   }
 }
 
+// ---- round 5 (default): the float scan's transport under the same arithmetic.
+// The wave-per-page kernel above reads with plain nt loads into VGPRs and stops at the plain-nt ceiling of the box
+// (6.6-6.85 TB/s); the float page scan's nt LDS-DMA ring streams 7.2-7.3 TB/s on the same HBM.  This kernel keeps the
+// register kernel's arithmetic -- lane l owns elements [512 it + 8 l, +8) of every page, one accumulator, the same FMA
+// order, the same xor butterfly: scores are BIT-IDENTICAL -- and replaces only the transport:
+//   * `global_load_lds_dwordx4 ... nt` copies 1 KiB chunks (64 lanes x 16 B, linear) into a wave-private ring of D tiles of
+//     CPT chunks; lane l reads back exactly the 16 B it requested (ds_read_b128, conflict-free), so the LDS is a FIFO that
+//     holds D-1 tiles (12 KiB at CPT 4, D 4) in flight per wave at no VGPR cost; counted `s_waitcnt vmcnt`, no barrier.
+//   * NOTHING but the DMAs touches vector memory inside the stream: a workgroup walks the corpus in chunks of 4 x ppw pages
+//     (wave w takes pages w, w+4, ... of the chunk; ppw <= 64) and at each chunk start -- the ring is empty there anyway --
+//     lane i evaluates the doc filter and loads 1/norm of the wave's i-th page; the live pages are a 64-bit ballot walked
+//     with s_ff1; lane i keeps page i's score and the chunk ends with one store (+ one LDS histogram add) per lane.
+//     A per-page load of inv_norm / doc_ord would make hipcc drain vmcnt(0) -- the whole ring -- once per page.
+//   * persistent workgroups (2 per CU), the query FDE in 8 x ITERS VGPRs per lane loaded once.
+template <int N>
+__device__ __forceinline__ void fde_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int CPT, int D>
+__device__ __forceinline__ void fde_wait_left(int left) {  // all tiles issued; `left` (< D - 1) tiles are younger than the one needed
+  if (D > 6 && left >= 5) fde_wait_vmcnt<5 * CPT>();
+  else if (D > 5 && left == 4) fde_wait_vmcnt<4 * CPT>();
+  else if (D > 4 && left == 3) fde_wait_vmcnt<3 * CPT>();
+  else if (D > 3 && left == 2) fde_wait_vmcnt<2 * CPT>();
+  else if (D > 2 && left == 1) fde_wait_vmcnt<1 * CPT>();
+  else fde_wait_vmcnt<0>();
+}
+
+template <int ITERS, int CPT, int D>  // out_dim = 512 ITERS; tile = CPT chunks of 1 KiB; ITERS % CPT == 0; CPT * (D-1) <= 63
+__global__ __launch_bounds__(256) void fde_scan_ldsdma_kernel(ScanArgs a, int ppw) {
+  constexpr int TPP = ITERS / CPT;  // tiles per page
+  constexpr int TILEB = CPT * 1024;
+  static_assert(ITERS % CPT == 0 && CPT * (D - 1) <= 63 && (CPT == 2 || CPT == 4) && D >= 2 && D <= 8, "ring shape");
+  // one __shared__ object only (a second one makes hipcc drain vmcnt before every ds_read)
+  __shared__ __attribute__((aligned(16))) char lds[4 * D * TILEB + 8192];
+  uint32_t* h0 = reinterpret_cast<uint32_t*>(lds + 4 * D * TILEB);  // per-block share of the selection's first histogram
+  if (a.hist0) {
+    for (int i = threadIdx.x; i < 2048; i += 256) h0[i] = 0;
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* ring = lds + wave * (D * TILEB);
+  const int voff = lane * 16;
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+  float q[ITERS][8];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const float4 lo = *reinterpret_cast<const float4*>(a.q + it * 512 + lane * 8);
+    const float4 hi = *reinterpret_cast<const float4*>(a.q + it * 512 + lane * 8 + 4);
+    q[it][0] = lo.x; q[it][1] = lo.y; q[it][2] = lo.z; q[it][3] = lo.w;
+    q[it][4] = hi.x; q[it][5] = hi.y; q[it][6] = hi.z; q[it][7] = hi.w;
+  }
+  // waited for HERE, once: left alone hipcc sinks the wait to the first FMA inside the stream, where its counted vmcnt
+  // would drain the DMA ring on every iteration
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(q[it][k]));
+
+  const int64_t chunk_pages = 4 * (int64_t)ppw;
+  const int64_t nchunks = (a.n + chunk_pages - 1) / chunk_pages;
+  const size_t page_bytes = (size_t)a.out_dim * 2;
+  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    // ---- chunk prologue (ring empty): lane i <-> this wave's i-th page
+    const int64_t base = c * chunk_pages + wave;
+    const int64_t myp = base + 4 * (int64_t)lane;
+    const bool valid = lane < ppw && myp < a.n;
+    bool masked = false;
+    float my_inv = 1.0f;
+    if (valid) {
+      if (a.doc_ord) {
+        const int32_t o = a.doc_ord[myp];
+        masked = o < 0 || (a.allow && ((int64_t)o >= a.n_allow_bits || ((a.allow[o >> 5] >> (o & 31)) & 1u) == 0u));
+      }
+      if (a.inv_norm && !masked) my_inv = a.inv_norm[myp];
+    }
+    asm volatile("" : "+v"(my_inv));  // loaded and waited for before the stream starts
+    float my_score = -INFINITY;
+    const uint64_t live = __ballot(valid && !masked);
+    uint64_t iss = live, cons = live;
+    int to_issue = __builtin_popcountll(live) * TPP;  // tiles not yet requested
+    int to_read = to_issue;                             // tiles not yet consumed
+    int iss_t = 0, iss_slot = 0, cons_slot = 0;
+
+    auto issue_next = [&]() {
+      const int i = __builtin_ctzll(iss);
+      const char* tp = reinterpret_cast<const char*>(a.fde) + (size_t)(base + 4 * (int64_t)i) * page_bytes + (size_t)iss_t * TILEB;
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
+      const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
+      const uint64_t tpu = ((uint64_t)hi << 32) | lo;
+      const uint32_t slot = __builtin_amdgcn_readfirstlane(
+          (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + iss_slot * TILEB));
+      uint32_t keep;
+      // M0 = wave-uniform LDS slot; the instruction offset walks BOTH addresses; s_nop 4: SALU-write -> VMEM-read of the
+      // base SGPRs and M0-write -> LDS-DMA (as in mv_maxsim.hip)
+      if (CPT == 4) {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 4\n\t"
+            "global_load_lds_dwordx4 %1, %3 nt\n\t"
+            "global_load_lds_dwordx4 %1, %3 offset:1024 nt\n\t"
+            "global_load_lds_dwordx4 %1, %3 offset:2048 nt\n\t"
+            "global_load_lds_dwordx4 %1, %3 offset:3072 nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(slot), "s"(tpu)
+            : "memory");
+      } else {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 4\n\t"
+            "global_load_lds_dwordx4 %1, %3 nt\n\t"
+            "global_load_lds_dwordx4 %1, %3 offset:1024 nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(slot), "s"(tpu)
+            : "memory");
+      }
+      iss_slot = (iss_slot + 1 == D) ? 0 : iss_slot + 1;
+      if (++iss_t == TPP) {
+        iss_t = 0;
+        iss &= iss - 1;
+      }
+      --to_issue;
+    };
+
+#pragma unroll
+    for (int k = 0; k < D - 1; ++k)
+      if (to_issue > 0) issue_next();
+
+    while (cons) {
+      const int i = __builtin_ctzll(cons);
+      cons &= cons - 1;
+      float acc = 0.0f;
+#pragma unroll
+      for (int t = 0; t < TPP; ++t) {
+        if (to_issue > 0) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // WAR: the last reads of the slot being refilled
+          issue_next();
+          fde_wait_vmcnt<CPT * (D - 1)>();
+        } else {
+          fde_wait_left<CPT, D>(to_read - 1);
+        }
+        --to_read;
+        const char* slot = ring + cons_slot * TILEB + voff;
+        cons_slot = (cons_slot + 1 == D) ? 0 : cons_slot + 1;
+#pragma unroll
+        for (int ch = 0; ch < CPT; ++ch) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(slot + ch * 1024);
+          const uint32_t w[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            acc = __builtin_fmaf(__uint_as_float(w[k] << 16), q[t * CPT + ch][2 * k], acc);
+            acc = __builtin_fmaf(__uint_as_float(w[k] & 0xffff0000u), q[t * CPT + ch][2 * k + 1], acc);
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 1; s < 64; s <<= 1) acc += __shfl_xor(acc, s);
+      if (lane == i) my_score = a.inv_norm ? acc * my_inv : acc;
+    }
+
+    // ---- chunk epilogue: one store and one histogram add per lane
+    if (valid) {
+      a.scores[myp] = my_score;
+      if (a.hist0) {
+        const float s0 = my_score + 0.0f;
+        if (s0 == s0 && s0 != -INFINITY) atomicAdd(&h0[topk_ordered_u32(s0) >> 21], 1u);
+      }
+    }
+  }
+  if (a.hist0) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += 256)
+      if (h0[i]) atomicAdd(&a.hist0[i], h0[i]);
+  }
+}
+
 // v2 coarse scan: the query FDE lives in LDS (40 KiB at 10 240 dims), not in 160 VGPRs per lane, so a wave
 // needs only the registers of one page's loads (ITERS x 16 B per lane, all issued before the first use) and
 // 16 waves fit a CU: 16 x 20 KiB = 320 KiB of HBM reads in flight per CU.  A 512-thread block stages the
@@ -2506,13 +2688,47 @@ static int launch_fde_scan_lds(const ScanArgs& k, hipStream_t s) {
   return MV_OK;
 }
 
-bool fde_scan_prebins(int variant, int64_t out_dim) { return variant <= 0 && (out_dim == 10240 || out_dim == 5120); }
+bool fde_scan_prebins(int variant, int64_t out_dim) { return (variant <= 0 || variant == 3) && (out_dim == 10240 || out_dim == 5120); }
+
+// Chunk shape of the LDS-DMA scan: `grid` persistent workgroups walk ceil(n / (4 ppw)) chunks; ppw (<= 64 pages per wave per
+// chunk) is chosen so that the chunk count is as close below a multiple of the grid as the page count allows (a 4 883-chunk
+// corpus over 512 workgroups would leave 46 % of them idle for the last tenth of the launch).
+static void fde_ldsdma_shape(int64_t n, int* grid, int* ppw) {
+  static int env_ppw = -1, env_bpc = -1;
+  if (env_ppw < 0) {  // tuning hooks (tools/fde_scan_probe.py); unset in production
+    const char* e = getenv("MV_FDE_SCAN_PPW");
+    env_ppw = e ? atoi(e) : 0;
+    e = getenv("MV_FDE_SCAN_BLOCKS_PER_CU");
+    env_bpc = e ? atoi(e) : 0;
+  }
+  const int g = 256 * (env_bpc > 0 ? env_bpc : 2);
+  int64_t w = (n + 3) / 4;  // pages per wave position if one chunk held everything
+  if (env_ppw > 0) {
+    *ppw = env_ppw > 64 ? 64 : env_ppw;
+  } else {
+    const int64_t rounds = (w + (int64_t)g * 64 - 1) / ((int64_t)g * 64);  // chunks per workgroup at ppw = 64
+    int64_t p = (w + rounds * g - 1) / (rounds * g);
+    *ppw = (int)(p < 1 ? 1 : (p > 64 ? 64 : p));
+  }
+  const int64_t nchunks = (n + 4 * (int64_t)*ppw - 1) / (4 * (int64_t)*ppw);
+  *grid = (int)(nchunks < g ? nchunks : g);
+}
 
 int launch_fde_scan(const FdeScanArgs& a, int variant, hipStream_t s) {
   if (a.n <= 0) return MV_OK;
   ScanArgs k{a.fde, a.inv_norm, a.doc_ord, a.allow, a.n_allow_bits, a.q, a.scores, a.n, (int32_t)a.out_dim, nullptr};
   const int grid = 256 * 2;  // 2 blocks/CU x 4 waves, persistent
-  if (variant < 0) variant = 0;  // measured: 6.87 TB/s (wave per page, nt loads) vs 6.1 for the LDS / cooperative forms
+  if (variant < 0) variant = 3;  // round 5: nt LDS-DMA ring (0 = the same arithmetic on plain nt loads: 6.8 TB/s)
+  if (variant == 3 && (a.out_dim == 10240 || a.out_dim == 5120)) {
+    int g, ppw;
+    fde_ldsdma_shape(a.n, &g, &ppw);
+    k.hist0 = a.hist0;
+    if (a.out_dim == 10240) hipLaunchKernelGGL((fde_scan_ldsdma_kernel<20, 4, 4>), dim3(g), dim3(256), 0, s, k, ppw);
+    else hipLaunchKernelGGL((fde_scan_ldsdma_kernel<10, 2, 8>), dim3(g), dim3(256), 0, s, k, ppw);
+    MV_HIP(hipGetLastError());
+    return MV_OK;
+  }
+  if (variant == 3) variant = 0;
   if (variant == 2 && a.out_dim % 2048 == 0 && a.out_dim / 2048 <= 5 && a.out_dim >= 2048) {
     const int wg = 256 * 4;  // 4 workgroups per CU, persistent
     switch ((int)(a.out_dim / 2048)) {

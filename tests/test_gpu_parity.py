@@ -799,6 +799,53 @@ def test_fde_coarse_scan_and_pipeline(mv):
     ix.close()
 
 
+@pytest.mark.parametrize("n", [1, 3, 255, 2049, 70_001, 300_017])
+def test_fde_scan_ldsdma_ring_bit_identical_to_the_register_scan(mv, n):
+    """The default coarse scan (round 5: nt LDS-DMA ring, chunks of 4 x ppw pages per persistent workgroup, filter and
+    1/norm evaluated per chunk) keeps the arithmetic of the wave-per-page register scan (variant 0): every score is
+    BIT-identical -- unfiltered, with tombstoned pages, with a doc filter, cosine on and off -- for page counts that give one
+    partial chunk, ppw = 1, a partial last chunk, and several chunks per workgroup; the top-k (whose first radix
+    histogram the scan accumulates) is identical too, and a sample agrees with the oracle's coarse scores."""
+    from morphik_core_amd import _lib
+    from morphik_core_amd.index import allow_bitmap
+
+    stride = 16
+    ix = _idx(mv, capacity_pages=n, stride_rows=stride, with_fde=True, with_float=False, with_fp8=True)
+    ix.fill_synthetic(1234, 0, n, n_rows=stride, pages_per_doc=3)
+    rng = np.random.default_rng(n)
+    for p in rng.choice(n, size=min(n // 3, 500), replace=False).tolist():
+        ix.remove_page(int(p))
+    n_docs = (n + 2) // 3
+    allow = allow_bitmap([d for d in range(n_docs) if d % 5 != 1], n_docs)
+    q = orc.synth_rows(4321, 7, 0, 32)
+    got = {}
+    for v in (0, 3):
+        ix.set_option(_lib.MV_OPT_FDE_SCAN_VARIANT, v)
+        for cosine in (1, 0):
+            ix.set_option(_lib.MV_OPT_FDE_COSINE, cosine)
+            got[v, cosine, "all"] = ix.score_all(q, mode="fde")
+            got[v, cosine, "flt"] = ix.score_all(q, mode="fde", allow=allow)
+        ix.set_option(_lib.MV_OPT_FDE_COSINE, 1)
+        got[v, "top"] = ix.query(q, min(200, n), mode="fde", allow=allow)
+        got[v, "top_all"] = ix.query(q, min(1000, n), mode="fde")
+    for cosine in (1, 0):
+        for key in ("all", "flt"):
+            a, b = got[0, cosine, key], got[3, cosine, key]
+            assert a.shape == (n,) and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (cosine, key)
+    assert np.isneginf(got[3, 1, "flt"]).sum() >= np.isneginf(got[3, 1, "all"]).sum()
+    for key in ("top", "top_all"):
+        assert np.array_equal(got[0, key][1], got[3, key][1]) and np.array_equal(got[0, key][0], got[3, key][0])
+    # ... and the scores are the oracle's (sample of live pages; the slab's own FDE rows)
+    live = np.flatnonzero(np.isfinite(got[3, 1, "all"]))[:: max(1, n // 40)][:40]
+    if live.size:
+        ocfg = orc.FdeConfig.reference_default()
+        fq = orc.fde_encode(ocfg, orc.bf16_to_f32(q), True)
+        rows = np.concatenate([ix.read_fde(int(p), 1) for p in live])
+        want = orc.fde_coarse_scores(fq, orc.f32_to_bf16(rows), use_cosine=True)
+        np.testing.assert_allclose(got[3, 1, "all"][live], want, rtol=2e-3, atol=2e-4)
+    ix.close()
+
+
 @pytest.mark.parametrize("nq", [1, 15, 16, 32, 40, 70, 129])
 def test_query_fde_encode_kernels_agree(mv, nq):
     """The query's FDE has three kernels (latency form: one block per repetition -- the default; bulk f32-MFMA; scalar).
