@@ -120,11 +120,15 @@ def allow_bitmap(allowed_ordinals: Optional[Iterable[int]], n_docs_hint: int = 0
     return bits
 
 
-def _fde_block(q_fde: Any, n_queries: int) -> np.ndarray:
-    """Caller-supplied query FDE vector(s) -> contiguous float32 [n_queries][out_dim] (the library checks the width against its config)."""
+def _fde_block(q_fde: Any, n_queries: int, out_dim: int) -> np.ndarray:
+    """Caller-supplied query FDE vector(s) -> contiguous float32 [n_queries][out_dim].  The *_fde entry points of the C ABI take a
+    bare pointer and read out_dim floats per query: a vector of another width (an fde_module configured differently from the index)
+    must stop HERE, not become a host over-read."""
     a = np.ascontiguousarray(np.asarray(q_fde, dtype=np.float32))
-    a = a.reshape(n_queries, -1)
-    return a
+    if a.size != int(n_queries) * int(out_dim):
+        raise ValueError(f"query FDE block holds {a.size} floats; this index expects {n_queries} x {out_dim} "
+                         "(is the fde_module configured like the index's FDE?)")
+    return a.reshape(int(n_queries), int(out_dim))
 
 
 def _stack_queries(queries: Sequence[Any], rows=None):
@@ -271,12 +275,18 @@ class MvIndex:
         r = np.ascontiguousarray(rows_bf16, dtype=np.uint16).reshape(-1, 128)
         check(lib().mv_index_replace_page(self._h, page, r.ctypes.data, r.shape[0]))
 
-    def import_fde(self, page0: int, fde: Any) -> None:
+    def import_fde(self, page0: int, fde: Any, n_pages: Optional[int] = None) -> None:
         """Replace the FDE vectors the library encoded for pages [page0, page0 + len(fde)) with the caller's own document encodings
         (float32 [n][fde_config.output_dim]; e.g. `fde.generate_document_encoding` of the reference, or vectors exported from a
         TurboPuffer namespace).  Query such an index with q_fde= vectors from the SAME encoder."""
         a = np.ascontiguousarray(np.asarray(fde, dtype=np.float32))
-        a = a.reshape(-1, self.fde_config.output_dim)
+        od = self.fde_config.output_dim
+        if a.ndim == 2 and a.shape[1] != od or a.ndim == 1 and a.size != od or a.ndim > 2 or a.size % od:
+            # never regroup vectors of another width into "some number of pages"
+            raise ValueError(f"document FDE block of shape {a.shape}; this index expects [n_pages][{od}]")
+        a = a.reshape(-1, od)
+        if n_pages is not None and a.shape[0] != int(n_pages):
+            raise ValueError(f"{a.shape[0]} document FDE vectors for {int(n_pages)} pages")
         check(lib().mv_index_import_fde(self._h, int(page0), a.shape[0], a.ctypes.data))
 
     def read_fde(self, page0: int, n_pages: int) -> np.ndarray:
@@ -327,9 +337,7 @@ class MvIndex:
         st = QueryStatsC()
         ab = None if allow is None else np.ascontiguousarray(allow, dtype=np.uint32)
         if q_fde is not None:
-            qf = _fde_block(q_fde, 1)
-            if qf.shape[1] != self.fde_config.output_dim:
-                raise ValueError(f"query FDE of {qf.shape[1]} dims, the index's FDE config gives {self.fde_config.output_dim}")
+            qf = _fde_block(q_fde, 1, self.fde_config.output_dim)
             check(lib().mv_query_topk_fde(self._h, qa.ctypes.data, code, qa.shape[0], qf.ctypes.data, k, MODES[mode], None if ab is None else ab.ctypes.data,
                                           0 if ab is None else ab.size, scores.ctypes.data, ids.ctypes.data, C.byref(n), C.byref(st) if want_stats else None))
         else:
@@ -366,9 +374,7 @@ class MvIndex:
         st = QueryStatsC()
         ab, n_words, per_query = _allow_block(len(rows), allow, allows, n_docs)
         if q_fdes is not None:
-            qf = _fde_block(q_fdes, len(rows))
-            if qf.shape[1] != self.fde_config.output_dim:
-                raise ValueError(f"query FDEs of {qf.shape[1]} dims, the index's FDE config gives {self.fde_config.output_dim}")
+            qf = _fde_block(q_fdes, len(rows), self.fde_config.output_dim)
             check(lib().mv_query_topk_batch_fde(self._h, blk.ctypes.data, code, len(rows), nmax, qf.ctypes.data, k, MODES[mode],
                                                 None if ab is None else ab.ctypes.data, n_words, per_query, scores.ctypes.data, ids.ctypes.data,
                                                 n.ctypes.data, C.byref(st) if want_stats else None))
@@ -432,7 +438,7 @@ class MvIndex:
         qa, code = as_rows(q)
         ab = None if allow is None else np.ascontiguousarray(allow, dtype=np.uint32)
         if q_fde is not None:
-            qf = _fde_block(q_fde, 1)
+            qf = _fde_block(q_fde, 1, self.fde_config.output_dim)
             check(lib().mv_two_stage_coarse_device_fde(self._h, qa.ctypes.data, code, qa.shape[0], qf.ctypes.data, int(n_coarse), MODES[mode],
                                                        None if ab is None else ab.ctypes.data, 0 if ab is None else ab.size, C.c_void_p(d_recs_ptr),
                                                        C.c_void_p(stream) if stream else None))
@@ -585,7 +591,7 @@ class ShardComm:
         ab = None if allow is None else np.ascontiguousarray(allow, dtype=np.uint32)
         st = (QueryStatsC * len(self.shards))()
         if q_fde is not None:  # the caller's own FDE of the query: every shard's coarse stage uses it (MvIndex.query)
-            qf = _fde_block(q_fde, 1)
+            qf = _fde_block(q_fde, 1, self.shards[0].fde_config.output_dim)
             check(lib().mv_comm_query_topk_fde(self._h, qa.ctypes.data, code, qa.shape[0], qf.ctypes.data, k, MODES[mode], None if ab is None else ab.ctypes.data,
                                                0 if ab is None else ab.size, scores.ctypes.data, ids.ctypes.data, C.byref(n),
                                                C.cast(st, C.c_void_p) if want_stats else None))
@@ -611,7 +617,7 @@ class ShardComm:
         ab, n_words, per_query = _allow_block(nq, allow, allows, n_docs)
         st = (QueryStatsC * len(self.shards))()
         if q_fdes is not None:
-            qf = _fde_block(q_fdes, nq)
+            qf = _fde_block(q_fdes, nq, self.shards[0].fde_config.output_dim)
             check(lib().mv_comm_query_topk_batch_fde(self._h, blk.ctypes.data, code, nq, nmax, qf.ctypes.data, k, MODES[mode], None if ab is None else ab.ctypes.data,
                                                      n_words, per_query, scores.ctypes.data, ids.ctypes.data, n.ctypes.data,
                                                      C.cast(st, C.c_void_p) if want_stats else None))

@@ -14,6 +14,20 @@ from typing import Any, Dict, Optional, Sequence, Tuple
 import numpy as np
 
 
+def _checkpoint_has_exact_split(shard_path: str) -> bool:
+    """MV_WITH_EXACT_SPLIT in the flags of a shard file's header (8-byte magic + mv_index_config)."""
+    import ctypes as C
+
+    from ._lib import MV_WITH_EXACT_SPLIT, ConfigC
+
+    try:
+        with open(shard_path, "rb") as f:
+            hdr = f.read(8 + C.sizeof(ConfigC))
+        return bool(ConfigC.from_buffer_copy(hdr[8:]).flags & MV_WITH_EXACT_SPLIT)
+    except (OSError, ValueError):
+        return False
+
+
 class ShardedIndex:
     def __init__(self, capacity_pages: int, stride_rows: int, devices: Sequence[int], with_float: bool = True, with_binary: bool = False,
                  with_fde: bool = False, with_fp8: bool = False, fde=None, transport: str = "auto", id_base: int = 0,
@@ -203,6 +217,11 @@ class ShardedIndex:
 
         if os.path.exists(f"{path}.shard{self.n_shards}"):
             raise ValueError(f"{path}: more shard files than the {self.n_shards} devices given -- refusing to drop shards")
+        if len(set(self.devices)) < self.n_shards and "MV_EXACT_HBM_MAX_PAGES" not in os.environ and _checkpoint_has_exact_split(f"{path}.shard0"):
+            # the same rule as the constructor: mv_index_load sizes the HBM part of a split exact tier by what the device has free at
+            # that moment -- the first shard loaded on a shared device would leave nothing for the slabs of the next
+            raise ValueError("this checkpoint holds a split exact tier (exact_tier=\"split\"): give every shard its own device "
+                             "(or bound the HBM part with MV_EXACT_HBM_MAX_PAGES)")
         self.shards = [index_cls.load(f"{path}.shard{r}", device=d) for r, d in enumerate(self.devices)]
         self.per = self.shards[0].capacity
         self.stride_rows = self.shards[0].stride_rows

@@ -38,6 +38,26 @@ from .payloads import DEFAULT_APP_ID, PayloadStore, is_storage_key, parse_metada
 
 logger = logging.getLogger(__name__)
 
+# what a row's content column holds -- recorded at ingest, never guessed from the text (rows of checkpoints written before
+# round 5 have no such field: row_origin() falls back to what those builds did)
+ROW_INLINE, ROW_OWN_KEY, ROW_CLIENT_KEY = 0, 1, 2
+
+
+def row_origin(row: Sequence[Any]) -> int:
+    if len(row) > 5:
+        return int(row[5])
+    return ROW_OWN_KEY if is_storage_key(row[2]) else ROW_INLINE
+
+
+def _fsync_dir(path: str) -> None:
+    import os
+
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        os.fsync(fd)
+    finally:
+        os.close(fd)
+
 
 _HELPERS = None
 
@@ -273,8 +293,10 @@ class MI355XMultiVectorStore(BaseVectorStore):
             return document_id
         return f"{app_id if app_id is not None else DEFAULT_APP_ID}\x1f{document_id}"
 
-    def _store_sync(self, valid: List[DocumentChunk], embs: List[Any], contents: List[str], app_id: Optional[str]) -> List[str]:
+    def _store_sync(self, valid: List[DocumentChunk], embs: List[Any], contents: List[str], app_id: Optional[str],
+                    origins: Optional[List[int]] = None) -> List[str]:
         ix = self._require_index()
+        origins = origins if origins is not None else [ROW_INLINE] * len(valid)
         with self._write_gate, self._lock:
             ords, fresh = [], []
             for c in valid:
@@ -312,7 +334,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
             for i, c in enumerate(valid):
                 page = first + i
                 key = self._nk(c.document_id, app_id)
-                self._rows[page] = (c.document_id, int(c.chunk_number), contents[i], json.dumps(c.metadata or {}), app_id)
+                self._rows[page] = (c.document_id, int(c.chunk_number), contents[i], json.dumps(c.metadata or {}), app_id, origins[i])
                 self._page_of[(key, int(c.chunk_number))] = page
                 self._doc_pages.setdefault(key, []).append(page)
                 ids.append(f"{c.document_id}-{c.chunk_number}")
@@ -328,23 +350,49 @@ class MI355XMultiVectorStore(BaseVectorStore):
             rows = e if isinstance(e, np.ndarray) else _embedding_rows(e) if not hasattr(e, "detach") else e.detach().to("cpu").float().numpy()
             v = np.asarray(self.fde_module.generate_document_encoding(np.asarray(rows, np.float32), self._fde_ext_cfg), np.float32).reshape(-1)
             out.append(v)
+        want = self._fde_out_dim()
+        for v in out:
+            if want and v.size != want:  # before anything is appended: vectors of another width are never regrouped into pages
+                raise ValueError(f"fde_module.generate_document_encoding returned {v.size} floats; the index's FDE holds {want} per page")
         docs = np.stack(out) if out else np.zeros((0, 0), np.float32)
         if out and not np.isfinite(docs).all():
             raise ValueError("fde_module.generate_document_encoding returned NaN / Inf")
         return docs
 
+    def _fde_out_dim(self) -> int:
+        """Width of one FDE vector of the index (0 if it cannot be told, e.g. a test double without an FDE config)."""
+        ix = self._index
+        cfg = getattr(ix, "fde_config", None) if ix is not None else None
+        if cfg is None and ix is not None and getattr(ix, "shards", None):
+            cfg = getattr(ix.shards[0], "fde_config", None)
+        return int(cfg.output_dim) if cfg is not None else 0
+
     def _query_fde_kw(self, q: Any) -> Dict[str, Any]:
         if self.fde_module is None:
             return {}
         rows = q if isinstance(q, np.ndarray) else _embedding_rows(q)
-        return {"q_fde": np.asarray(self.fde_module.generate_query_encoding(np.asarray(rows, np.float32), self._fde_ext_cfg), np.float32).reshape(-1)}
+        v = np.asarray(self.fde_module.generate_query_encoding(np.asarray(rows, np.float32), self._fde_ext_cfg), np.float32).reshape(-1)
+        want = self._fde_out_dim()
+        if want and v.size != want:  # the *_fde entry points of the C ABI read `want` floats from a bare pointer
+            raise ValueError(f"fde_module.generate_query_encoding returned {v.size} floats; the index's FDE holds {want}")
+        return {"q_fde": v}
 
     def _add_pages(self, ix, embs: List[Any], ords: List[int]) -> int:
         """Append the pages to the slab (all or nothing) -> first page id the index assigned."""
         docs = self._external_doc_fdes(embs)
         first = self._add_pages_raw(ix, embs, ords)
         if docs is not None and len(docs):
-            ix.import_fde(first, docs)  # the library's own encodings of these pages are replaced before the pages get their bookkeeping
+            try:
+                ix.import_fde(first, docs)  # the library's own encodings of these pages are replaced before the pages get their bookkeeping
+            except Exception:
+                # the pages are live in the slab but will never get bookkeeping (_store_sync takes the ordinals back): retire them,
+                # or they would hold slab slots and top-k positions for rows nobody can return
+                for page in range(first, first + len(embs)):
+                    try:
+                        ix.remove_page(page)
+                    except Exception:  # noqa: BLE001
+                        logger.error(f"could not retire page {page} after a failed import_fde")
+                raise
         return first
 
     def _add_pages_raw(self, ix, embs: List[Any], ords: List[int]) -> int:
@@ -364,14 +412,23 @@ class MI355XMultiVectorStore(BaseVectorStore):
 
     _global_ids = False  # a ShardedIndex hands out global page ids itself
 
-    async def store_embeddings(self, chunks: List[DocumentChunk], app_id: Optional[str] = None) -> Tuple[bool, List[str], Dict[str, Any]]:
+    async def store_embeddings(self, chunks: List[DocumentChunk], app_id: Optional[str] = None,
+                               content_is_key: Optional[Sequence[bool]] = None) -> Tuple[bool, List[str], Dict[str, Any]]:
+        """content_is_key (owner-server path only, store_server.py): per chunk, True = `content` is the key of a payload the
+        remote CLIENT uploaded to ITS storage.  Nothing is ever inferred from what the content looks like: without the flag the
+        content is content and is uploaded (when this store has a storage) exactly as the reference does
+        (multi_vector_store.py:650-676) -- a chunk whose text merely resembles another tenant's key is just text."""
         payload_backend = storage_backend_name(self.storage) if self._use_external() else "memory"
         valid: List[DocumentChunk] = []
-        for chunk in chunks:
+        key_flags: List[bool] = []
+        if content_is_key is not None and len(content_is_key) != len(chunks):
+            raise ValueError("content_is_key must have one entry per chunk")
+        for j, chunk in enumerate(chunks):
             if not hasattr(chunk, "embedding") or chunk.embedding is None:
                 logger.error(f"Missing embeddings for chunk {chunk.document_id}-{chunk.chunk_number}")
                 continue
             valid.append(chunk)
+            key_flags.append(bool(content_is_key[j]) if content_is_key is not None else False)
         if not valid:
             self._last_store_metrics = build_store_metrics(
                 chunk_payload_backend=payload_backend, multivector_backend=self.backend_name, vector_store_backend=self.backend_name
@@ -394,24 +451,33 @@ class MI355XMultiVectorStore(BaseVectorStore):
                 )
         # chunk content -> external storage, keys stay here (multi_vector_store.py:650-676)
         contents = [c.content for c in valid]
+        origins = [ROW_CLIENT_KEY if f else ROW_INLINE for f in key_flags]
         payload_s, payload_objects, payload_bytes = 0.0, 0, 0
         if self._use_external():
             t0 = time.perf_counter()
-            async def keep(c):  # content that already IS a storage key (a remote client uploaded the payload to ITS storage) stays a key
-                return c.content, 0
-
-            res = await asyncio.gather(*[keep(c) if is_storage_key(c.content) else
-                                         self._payloads.put(c.content, c.document_id, int(c.chunk_number), c.metadata or {}, resolved_app) for c in valid])
+            mine = [i for i, f in enumerate(key_flags) if not f]  # a client's keys stay keys; everything else is uploaded
+            res = await asyncio.gather(*[self._payloads.put(valid[i].content, valid[i].document_id, int(valid[i].chunk_number), valid[i].metadata or {}, resolved_app)
+                                         for i in mine])
             payload_s = time.perf_counter() - t0
-            for i, (key, nbytes) in enumerate(res):
+            for i, (key, nbytes) in zip(mine, res):
                 if key:
                     contents[i] = key
+                    origins[i] = ROW_OWN_KEY
                     payload_objects += 1
                     payload_bytes += nbytes
                 else:
                     logger.warning(f"Failed to store chunk {valid[i].document_id}-{valid[i].chunk_number} externally, keeping it inline")
         t0 = time.perf_counter()
-        ids = await asyncio.to_thread(self._store_sync, valid, embs, contents, resolved_app)
+        try:
+            ids = await asyncio.to_thread(self._store_sync, valid, embs, contents, resolved_app, origins)
+        except Exception:
+            own = [contents[i] for i, o in enumerate(origins) if o == ROW_OWN_KEY]
+            if own:  # the slab refused the pages: the payloads uploaded for them must not stay behind
+                try:
+                    await self._payloads.delete(own, valid[0].document_id)
+                except Exception as e:  # noqa: BLE001
+                    logger.error(f"could not remove {len(own)} payloads uploaded for a failed store_embeddings: {e}")
+            raise
         dt = time.perf_counter() - t0
         self._last_store_metrics = build_store_metrics(
             chunk_payload_backend=payload_backend, multivector_backend=self.backend_name, vector_store_backend=self.backend_name,
@@ -566,7 +632,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         out = [r[2] for r in rows]
         if not self._use_external():
             return out, metas  # nothing to fetch: no task, no await (the common case of an in-memory payload table)
-        fetch = [j for j, (r, m) in enumerate(zip(rows, metas)) if is_storage_key(r[2]) and not (skip_image_content and m.get("is_image"))]
+        fetch = [j for j, (r, m) in enumerate(zip(rows, metas)) if row_origin(r) == ROW_OWN_KEY and not (skip_image_content and m.get("is_image"))]
         if fetch:
             resolved = await asyncio.gather(*[self._payloads.get(rows[j][2], metas[j]) for j in fetch], return_exceptions=True)
             for j, c in zip(fetch, resolved):
@@ -641,9 +707,21 @@ class MI355XMultiVectorStore(BaseVectorStore):
         return [DocumentChunk(document_id=r[0], chunk_number=r[1], content=c, embedding=[], metadata=m, score=0.0)
                 for r, c, m in zip(rows, contents, metas)]
 
+    def content_key_flags(self, chunk_identifiers: Sequence[Tuple[str, int]], app_id: Optional[str] = None) -> List[bool]:
+        """Per (document_id, chunk_number): True = the chunk's content column holds a key a remote CLIENT uploaded (the owner
+        server marks such chunks so that the client dereferences those and nothing else)."""
+        want = (app_id if app_id is not None else DEFAULT_APP_ID) if self._filter_by_app else None
+        out = []
+        with self._lock:
+            for doc_id, chunk_no in chunk_identifiers:
+                page = self._page_of.get((self._nk(doc_id, want), int(chunk_no)))
+                row = self._rows.get(page) if page is not None else None
+                out.append(row is not None and row_origin(row) == ROW_CLIENT_KEY)
+        return out
+
     def _delete_sync(self, document_id: str, app_id: Optional[str], all_keys: Optional[List[str]] = None) -> List[str]:
         """Tombstone one app's copy of a document -> the storage keys of its payloads THIS store uploaded (all_keys, when given,
-        collects every storage key among the deleted rows, whoever uploaded it).  Runs in a worker thread: it waits behind a
+        collects the keys a remote client uploaded to its own storage and flagged as such at ingest: they go back to it).  Runs in a worker thread: it waits behind a
         checkpoint in progress (_write_gate) without holding up the event loop."""
         keys: List[str] = []
         with self._write_gate, self._lock:
@@ -658,11 +736,11 @@ class MI355XMultiVectorStore(BaseVectorStore):
                 row = self._rows.pop(page, None)
                 if row is not None:
                     self._page_of.pop((key, row[1]), None)
-                    if is_storage_key(row[2]):
-                        if all_keys is not None:
-                            all_keys.append(row[2])
-                        if self._use_external():
-                            keys.append(row[2])
+                    o_ = row_origin(row)
+                    if o_ == ROW_CLIENT_KEY and all_keys is not None:
+                        all_keys.append(row[2])  # a client's payload: only that client may delete it
+                    elif o_ == ROW_OWN_KEY and self._use_external():
+                        keys.append(row[2])
             # the ordinal stays reserved until compact() (its pages are tombstoned in the slab under that ordinal)
         return keys
 
@@ -675,7 +753,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
             keys = await asyncio.to_thread(self._delete_sync, document_id, app_id, all_keys)
             if keys:
                 await self._payloads.delete(keys, document_id)
-            return True, [k_ for k_ in all_keys if k_ not in set(keys)]
+            return True, all_keys
         except Exception as e:  # noqa: BLE001
             logger.error(f"Error deleting chunks for document {document_id}: {e}")
             return False, []
@@ -720,7 +798,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         return {
             "version": 3, "mode": self.mode, "capacity_pages": self.capacity_pages, "stride_rows": self.stride_rows,
             "id_base": self.id_base, "fde_coarse_n": self.fde_coarse_n, "exact_tier": self.exact_tier, "rerank_n": self.rerank_n, "prune_slab": self.prune_slab, "fde_external": self.fde_module is not None, "next_ord": self._next_ord,
-            "rows": [[p, r[0], r[1], r[2], r[3], r[4]] for p, r in self._rows.items()],
+            "rows": [[p, r[0], r[1], r[2], r[3], r[4], row_origin(r)] for p, r in self._rows.items()],
             "doc_ord": self._doc_ord, "doc_app": {str(k): v for k, v in self._doc_app.items()},
         }
 
@@ -742,8 +820,9 @@ class MI355XMultiVectorStore(BaseVectorStore):
         section 5, checkpoint/resume).
         Every checkpoint is a fresh GENERATION: <directory>/gen-<id>/{index.mv*, store.json} is written and fsync'ed in full while
         <directory>/CURRENT still names the previous generation; CURRENT is then replaced by one atomic rename and the older
-        generations are removed.  A crash, OOM or kill at ANY point leaves CURRENT naming a complete checkpoint (the previous one
-        until the rename, the new one after): the owner process holds the only copy of the corpus, an interrupted periodic save
+        generations are removed; the parent directory
+        is fsync'ed after the generation directory is created and again after the rename, before any removal.  A crash, OOM, kill or
+        power loss at ANY point leaves CURRENT naming a complete checkpoint (the previous one until the rename, the new one after): the owner process holds the only copy of the corpus, an interrupted periodic save
         must not cost it.
         Locking: writers (store / delete / compact) are held off for the duration (_write_gate); the store lock is held only while
         the bookkeeping is snapshotted, NOT across the slab dump -- the async query paths take that lock on the event loop and
@@ -761,28 +840,27 @@ class MI355XMultiVectorStore(BaseVectorStore):
             gen = "gen-" + uuid.uuid4().hex
             gdir = os.path.join(directory, gen)
             os.makedirs(gdir)
+            _fsync_dir(directory)  # the new generation's directory ENTRY
             book["checkpoint"] = gen
+            cur = os.path.join(directory, "CURRENT")
             try:
                 ix.save(os.path.join(gdir, "index.mv"))  # every shard file: temp file + fsync + rename each
                 with open(os.path.join(gdir, "store.json"), "w") as f:
                     json.dump(book, f)
                     f.flush()
                     os.fsync(f.fileno())
-                dfd = os.open(gdir, os.O_RDONLY)
-                try:
-                    os.fsync(dfd)
-                finally:
-                    os.close(dfd)
+                _fsync_dir(gdir)
                 tmp = os.path.join(directory, "CURRENT.tmp")
                 with open(tmp, "w") as f:
                     f.write(gen)
                     f.flush()
                     os.fsync(f.fileno())
-                os.replace(tmp, os.path.join(directory, "CURRENT"))  # the switch: one atomic rename
+                os.replace(tmp, cur)  # the switch: one atomic rename ...
+                _fsync_dir(directory)  # ... made durable BEFORE anything older is removed (a power loss must not keep the deletions and lose the rename)
             except BaseException:
                 shutil.rmtree(gdir, ignore_errors=True)  # an incomplete generation is never named by CURRENT
                 raise
-            for name in os.listdir(directory):  # older generations, and the flat files of the pre-generation layout
+            for name in os.listdir(directory):  # older generations (the rename that retired them is durable), and the flat files of the pre-generation layout
                 pth = os.path.join(directory, name)
                 if name.startswith("gen-") and name != gen:
                     shutil.rmtree(pth, ignore_errors=True)
@@ -823,8 +901,9 @@ class MI355XMultiVectorStore(BaseVectorStore):
                    id_base=book["id_base"], fde_coarse_n=book.get("fde_coarse_n", 0), exact_tier=book.get("exact_tier", "hbm"), rerank_n=book.get("rerank_n", 0), prune_slab=book.get("prune_slab", True), **kw)
         self._index = cls._load_index(self, directory, book, device)
         self._apply_options(self._index)
-        for p, doc, chunk_no, content, meta_json, app in book["rows"]:
-            self._rows[int(p)] = (doc, int(chunk_no), content, meta_json, app)
+        for p, doc, chunk_no, content, meta_json, app, *rest in book["rows"]:
+            # rows written before round 5 carry no origin: they keep what those builds did (a key-shaped content is this store's key)
+            self._rows[int(p)] = (doc, int(chunk_no), content, meta_json, app, int(rest[0])) if rest else (doc, int(chunk_no), content, meta_json, app)
             self._page_of[(self._nk(doc, app), int(chunk_no))] = int(p)
             self._doc_pages.setdefault(self._nk(doc, app), []).append(int(p))
         self._doc_app = {int(k): v for k, v in book["doc_app"].items()}

@@ -44,7 +44,10 @@ from .models import BaseVectorStore, DocumentChunk
 logger = logging.getLogger(__name__)
 
 
-def _chunks_json(chunks: List[DocumentChunk]) -> List[Dict[str, Any]]:
+def _chunks_json(chunks: List[DocumentChunk], key_flags: Optional[List[bool]] = None) -> List[Dict[str, Any]]:
+    if key_flags is not None:
+        return [{"document_id": c.document_id, "chunk_number": int(c.chunk_number), "content": c.content, "metadata": c.metadata or {}, "score": float(c.score),
+                 "content_is_key": bool(f)} for c, f in zip(chunks, key_flags)]
     return [{"document_id": c.document_id, "chunk_number": int(c.chunk_number), "content": c.content, "metadata": c.metadata or {}, "score": float(c.score)}
             for c in chunks]
 
@@ -122,6 +125,11 @@ def create_app(store: Any, api_key: Optional[str] = None, save_dir: Optional[str
         if api_key and not hmac.compare_digest((authorization or "").encode(), f"Bearer {api_key}".encode()):
             raise HTTPException(status_code=401, detail="invalid api key")
 
+    def _key_flags(chunks: List[DocumentChunk], app_id: Optional[str]) -> Optional[List[bool]]:
+        if not hasattr(store, "content_key_flags"):
+            return None
+        return store.content_key_flags([(c.document_id, int(c.chunk_number)) for c in chunks], app_id)
+
     @app.get("/health")
     async def health():
         return {"status": "ok", "pages": len(store) if hasattr(store, "__len__") else None}
@@ -130,13 +138,15 @@ def create_app(store: Any, api_key: Optional[str] = None, save_dir: Optional[str
     async def store_embeddings(request: Request, authorization: Optional[str] = Header(default=None)):  # noqa: B008
         auth(authorization)
         meta, z = _unpack(await request.body())
-        chunks = []
+        chunks, flags = [], []
         for i, m in enumerate(meta["chunks"]):
             emb = z[f"emb_{i}"] if f"emb_{i}" in z.files else None
             chunks.append(DocumentChunk(document_id=m["document_id"], chunk_number=int(m["chunk_number"]), content=m["content"], embedding=emb,
                                         metadata=m.get("metadata") or {}))
+            flags.append(bool(m.get("content_is_key", False)))  # the client says so explicitly; nothing is inferred from the text
         try:
-            ok, ids, metrics = await store.store_embeddings(chunks, app_id=meta.get("app_id"))
+            kw = {"content_is_key": flags} if any(flags) else {}
+            ok, ids, metrics = await store.store_embeddings(chunks, app_id=meta.get("app_id"), **kw)
         except Exception as e:  # noqa: BLE001 -- the client re-raises it, as a local store would have raised
             raise HTTPException(status_code=500, detail=f"{type(e).__name__}: {e}")
         ckpt.dirty = True
@@ -159,14 +169,14 @@ def create_app(store: Any, api_key: Optional[str] = None, save_dir: Optional[str
                                             skip_image_content=bool(meta.get("skip_image_content", False)))
         except Exception as e:  # noqa: BLE001
             raise HTTPException(status_code=500, detail=f"{type(e).__name__}: {e}")
-        return {"chunks": _chunks_json(res)}
+        return {"chunks": _chunks_json(res, _key_flags(res, meta.get("app_id")))}
 
     @app.post("/get_chunks_by_id")
     async def get_chunks_by_id(req: Dict[str, Any], authorization: Optional[str] = Header(default=None)):  # noqa: B008
         auth(authorization)
         res = await store.get_chunks_by_id([(d, int(c)) for d, c in req.get("chunk_identifiers", [])], app_id=req.get("app_id"),
                                            skip_image_content=bool(req.get("skip_image_content", False)))
-        return {"chunks": _chunks_json(res)}
+        return {"chunks": _chunks_json(res, _key_flags(res, req.get("app_id")))}
 
     @app.post("/delete_chunks_by_document_id")
     async def delete_chunks(req: Dict[str, Any], authorization: Optional[str] = Header(default=None)):  # noqa: B008
@@ -256,7 +266,8 @@ class MI355XRemoteMultiVectorStore(BaseVectorStore):
                                          if getattr(c, "embedding", None) is not None else asyncio.sleep(0, result=(None, 0)) for c in chunks])
             contents = [key if key else c.content for (key, _n), c in zip(res, chunks)]
         for i, c in enumerate(chunks):
-            meta["chunks"].append({"document_id": c.document_id, "chunk_number": int(c.chunk_number), "content": contents[i], "metadata": c.metadata or {}})
+            meta["chunks"].append({"document_id": c.document_id, "chunk_number": int(c.chunk_number), "content": contents[i], "metadata": c.metadata or {},
+                                   "content_is_key": contents[i] is not c.content})  # True only for a key THIS client just uploaded
             if getattr(c, "embedding", None) is not None:
                 arrays[f"emb_{i}"] = self._rows(c.embedding)
         try:
@@ -274,11 +285,9 @@ class MI355XRemoteMultiVectorStore(BaseVectorStore):
         return bool(out["ok"]), list(out["ids"]), self._last_store_metrics
 
     async def _to_chunks(self, rows: List[Dict[str, Any]], skip_image_content: bool = False) -> List[DocumentChunk]:
-        from .payloads import is_storage_key
-
         contents = [r["content"] for r in rows]
-        if self._payloads is not None:  # keys this client uploaded: resolve them here (images stay keys when the caller skips them)
-            fetch = [j for j, r in enumerate(rows) if is_storage_key(r["content"]) and not (skip_image_content and (r.get("metadata") or {}).get("is_image"))]
+        if self._payloads is not None:  # keys this client uploaded (the owner flags them): resolve them here (images stay keys when the caller skips them)
+            fetch = [j for j, r in enumerate(rows) if r.get("content_is_key") and not (skip_image_content and (r.get("metadata") or {}).get("is_image"))]
             got = await asyncio.gather(*[self._payloads.get(rows[j]["content"], rows[j].get("metadata") or {}) for j in fetch])
             for j, c in zip(fetch, got):
                 contents[j] = c

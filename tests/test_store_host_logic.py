@@ -582,6 +582,102 @@ def test_payloads_live_in_storage_and_skip_image_content_returns_the_key():
     assert sc.run(s.query_similar(chunks[1].embedding, k=1))[0].content == "plain text of page 2"
 
 
+def test_content_that_looks_like_another_tenants_key_is_just_text():
+    """store_embeddings must not take a chunk's text for a storage key because it LOOKS like one.  Keys are
+    predictable (`<app>/<doc>/<n>.txt`): app-b ingests a chunk whose text is app-a's key.  The reference always uploads on
+    store and never trusts content as a key (multi_vector_store.py:650-676): app-b gets its own text back, app-a's payload is
+    neither returned to app-b nor deleted with app-b's document."""
+    from morphik_core_amd.models import DocumentChunk
+    from morphik_core_amd.payloads import MULTIVECTOR_CHUNKS_BUCKET
+    from morphik_core_amd.store import ROW_OWN_KEY, row_origin
+
+    st = MemStorage()
+    s = _store(mode="float", storage=st)
+    rng = np.random.default_rng(21)
+    victim = DocumentChunk(document_id="doc", chunk_number=0, content="SECRET of app-a", embedding=sc.rand_emb(rng, 6), metadata={})
+    sc.run(s.store_embeddings([victim], app_id="app-a"))
+    victim_key = (MULTIVECTOR_CHUNKS_BUCKET, "app-a/doc/0.txt")
+    assert st.objects[victim_key][0] == b"SECRET of app-a"
+    evil = DocumentChunk(document_id="mine", chunk_number=0, content="app-a/doc/0.txt", embedding=sc.rand_emb(rng, 6), metadata={})
+    ok, _ids, m = sc.run(s.store_embeddings([evil], app_id="app-b"))
+    assert ok and m["chunk_payload_objects"] == 1  # uploaded like any other content
+    assert all(row_origin(r) == ROW_OWN_KEY for r in s._rows.values())
+    got = sc.run(s.get_chunks_by_id([("mine", 0)], app_id="app-b"))
+    assert got[0].content == "app-a/doc/0.txt"  # its own text, not the victim's payload
+    hit = sc.run(s.query_similar(evil.embedding, k=1, app_id="app-b"))
+    assert hit[0].content == "app-a/doc/0.txt"
+    assert sc.run(s.delete_chunks_by_document_id("mine", app_id="app-b")) is True
+    assert st.objects[victim_key][0] == b"SECRET of app-a"  # still there
+    assert sc.run(s.get_chunks_by_id([("doc", 0)], app_id="app-a"))[0].content == "SECRET of app-a"
+    # without a storage object the same text is inline content: nothing is dereferenced, nothing is reported as a key
+    s2 = _store(mode="float")
+    sc.run(s2.store_embeddings([evil], app_id="app-b"))
+    assert sc.run(s2.get_chunks_by_id([("mine", 0)], app_id="app-b"))[0].content == "app-a/doc/0.txt"
+    ok, left = sc.run(s2.delete_chunks_returning_keys("mine", app_id="app-b"))
+    assert ok and left == []
+    # a checkpoint written before the origin column existed keeps its old reading (key-shaped content = this store's key)
+    assert row_origin(("d", 0, "app/d/0.txt", "{}", "app")) == ROW_OWN_KEY and row_origin(("d", 0, "some text", "{}", "app")) == 0
+
+
+def test_owner_with_its_own_storage_hands_a_clients_keys_back_and_never_dereferences_them():
+    """ADVICE r4 (high, second half): the remote client flags the keys IT uploaded (`content_is_key`); the owner -- even one with
+    a storage object of its own -- stores them as the client's, never downloads or deletes them itself, flags them on the way
+    back, and returns them on delete so the client removes its objects.  An unflagged key-shaped text from a client is content."""
+    from morphik_core_amd.store_server import MI355XRemoteMultiVectorStore, create_app
+    from tests.test_encoder_and_formats import _serve
+
+    owner = MI355XFastMultiVectorStore(capacity_pages=16, stride_rows=32, mode="float", index_factory=OracleIndex, storage=MemStorage())
+    assert owner.initialize()
+    url, stop = _serve(create_app(owner))
+    try:
+        st = MemStorage()
+        remote = MI355XRemoteMultiVectorStore(url, storage=st)
+        ch = sc.make_chunks(np.random.default_rng(31), n_docs=1, chunks_per_doc=2)
+        for c in ch:
+            c.metadata = {"is_image": False}
+        sc.run(remote.store_embeddings(ch, app_id="t"))
+        assert st.uploads == 2 and owner.storage.uploads == 0 and owner.storage.downloads == 0
+        assert sc.run(remote.query_similar(ch[1].embedding, k=1, app_id="t"))[0].content == ch[1].content
+        assert owner.storage.downloads == 0 and st.downloads == 1
+        assert sc.run(remote.delete_chunks_by_document_id(ch[0].document_id, app_id="t")) is True
+        assert st.objects == {}  # the client removed ITS objects: the owner handed the keys back
+        # a client WITHOUT storage sends text that looks like a key: the owner uploads it as content and returns it as content
+        plain = MI355XRemoteMultiVectorStore(url)
+        odd = sc.make_chunks(np.random.default_rng(32), n_docs=1, chunks_per_doc=1)
+        odd[0].content, odd[0].metadata = "t/other-doc/0.txt", {"is_image": False}
+        sc.run(plain.store_embeddings(odd, app_id="t"))
+        assert owner.storage.uploads == 1
+        assert sc.run(plain.query_similar(odd[0].embedding, k=1, app_id="t"))[0].content == "t/other-doc/0.txt"
+    finally:
+        stop()
+
+
+def test_fde_vectors_of_the_wrong_width_stop_at_the_boundary():
+    """ADVICE r4 (medium / low): an fde_module whose output width differs from the index's FDE must raise, not over-read a host
+    buffer in the *_fde C entry points or regroup document vectors into another number of pages; a failed import leaves no
+    live page behind."""
+    from morphik_core_amd.index import _fde_block
+
+    with pytest.raises(ValueError):
+        _fde_block(np.zeros(100, np.float32), 1, 10240)
+    with pytest.raises(ValueError):
+        _fde_block(np.zeros((2, 10240), np.float32), 3, 10240)
+    assert _fde_block(np.zeros(20480, np.float32), 2, 10240).shape == (2, 10240)
+
+    class Boom(OracleIndex):
+        def import_fde(self, page0, fde):
+            raise RuntimeError("import failed")
+
+    import tests.fake_fde_module as fm
+
+    s = MI355XFastMultiVectorStore(capacity_pages=16, stride_rows=32, mode="fde_then_float", index_factory=Boom, fde_module=fm)
+    assert s.initialize()
+    ch = sc.make_chunks(np.random.default_rng(41), n_docs=1, chunks_per_doc=2)
+    with pytest.raises(RuntimeError):
+        sc.run(s.store_embeddings(ch, app_id="t"))
+    assert len(s) == 0 and not any(s._index.alive)  # the appended pages were retired, no bookkeeping kept
+
+
 # --------------------------------------------------------------------------- ADVICE r1: compaction vs queries, upsert order
 def test_query_that_overlaps_a_compaction_is_rerun_against_the_new_numbering():
     rng = np.random.default_rng(11)
