@@ -988,14 +988,10 @@ def main():
 
     stats = []
     gpu_topk = sharded.make_gpu_local_topk(ix, dev, MODE, collect_stats=stats)
-    if args.backend == "nccl":
-        local_topk = gpu_topk
-    else:
-        def local_topk(q, k):  # gloo: the k (score, id) pairs go through host memory
-            s, i = gpu_topk(q, k)
-            return s.cpu(), i.cpu()
-    searcher = sharded.ShardedSearcher(local_topk)
+    # one rank's step: RCCL -- scan enqueued behind torch's stream, ONE all-gather of a 16-byte-aligned {ids, scores} block, one
+    # library merge launch, no host wait in between; gloo (ranks sharing one GPU) -- the same step through host memory
     fast_searcher = sharded.GpuShardedSearcher(ix, dev, MODE, collect_stats=stats) if (dist_on and args.backend == "nccl") else None
+    host_searcher = sharded.HostShardedSearcher(ix, MODE, collect_stats=stats) if (dist_on and args.backend == "gloo") else None
     # config 4 across ranks: GLOBAL coarse top-1000, owners rerank (the same candidate set as one big index); over RCCL the
     # device-resident stages (no host copy of any intermediate), over gloo the host-driven cross-check
     two_stage = None
@@ -1010,10 +1006,9 @@ def main():
             return s, ids
         if two_stage is not None:
             return two_stage.query(q, K, coarse_n=1000)
-        if fast_searcher is not None:  # RCCL: 2 collectives + one library merge launch, nothing else on the host
+        if fast_searcher is not None:
             return fast_searcher.query(q, K)
-        s, ids = searcher.query(q, K, compact=False)  # padded (-inf, -1) tail: no host sync inside the timed loop
-        return s, ids
+        return host_searcher.query(q, K)
 
     def fence():
         if dist_on:
@@ -1040,7 +1035,10 @@ def main():
         fence()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            gpu_topk(queries[i % N_QUERIES], K)
+            if host_searcher is not None:
+                ix.query(queries[i % N_QUERIES], K, mode=MODE)  # the gloo step's local part: results through the pinned host buffers
+            else:
+                gpu_topk(queries[i % N_QUERIES], K)
         fence()
         t = torch.tensor([(time.perf_counter() - t0) / args.steps * 1e3], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -123,7 +123,8 @@ typedef enum {
   MV_OPT_BINARY_VARIANT = 5, /* sign-bit scan: 0 = popcount on the VALU, 1 = FP4 MFMA, 2/3/4 = FP4 MFMA with in-place bit operands and an
                                 8/16/4-slot ring (4 = default), 5 = persistent-stream form, 6 = four-page burst form (uniform corpora,
                                 stride % 256 == 0); all produce the same integers */
-  MV_OPT_FDE_SCAN_VARIANT = 6, /* FDE coarse scan: 0 = wave per page (default), 1 = query in LDS, 2 = workgroup per page */
+  MV_OPT_FDE_SCAN_VARIANT = 6, /* FDE coarse scan: 3 = nt LDS-DMA ring, chunks claimed dynamically (default), 4 = the same with a static chunk
+                                * order, 0 = wave per page on plain nt loads (the same arithmetic: bit-identical scores) */
   MV_OPT_BATCH_VARIANT = 7,   /* batched float scan: -1 / 0 = auto (default): page-split form (wave-private rings, no barrier) up to 128
                                  query rows in the group, row-split workgroup above; both with transposed MFMA roles (one running
                                  max per query tile, v_max3).  3 = row-split form always, 1 = 32x32x16 MFMA / 8 waves,
@@ -174,7 +175,7 @@ typedef enum {
 /* Bumped whenever a signature, a struct layout or an enum value of this header changes incompatibly.  A binding compares
  * mv_abi_version() of the library it loaded with the MV_ABI_VERSION it was written against and refuses a mismatch (a stale
  * libmvmaxsim.so driven with newer argument lists would corrupt memory silently). */
-#define MV_ABI_VERSION 5
+#define MV_ABI_VERSION 6
 MV_API int mv_abi_version(void);
 
 MV_API const char* mv_last_error(void);
@@ -273,6 +274,14 @@ MV_API int mv_query_topk(mv_index* ix, const void* q, int q_dtype, int32_t n_q_r
 MV_API int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int32_t k, int mode,
                                 const uint32_t* allow_bits, int64_t n_allow_words, float* d_out_scores,
                                 int64_t* d_out_ids, void* stream, mv_query_stats* stats);
+/* The enqueue-only form WITH timings (one rank's step of a row-sharded search: the scan, then the all-gather and the merge
+ * behind it on `stream`, nothing of which should wait for the host): as mv_query_topk_device with a non-NULL stream, but
+ * `stats` (non-NULL) receives only the accounting fields now; the HIP-event timings of THIS query are filled in by
+ * mv_query_stats_finish(ix, stats) -- which waits for the scan's events -- called any time before the next query on `ix`. */
+MV_API int mv_query_topk_device_async(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int32_t k, int mode,
+                                      const uint32_t* allow_bits, int64_t n_allow_words, float* d_out_scores,
+                                      int64_t* d_out_ids, void* stream, mv_query_stats* stats);
+MV_API int mv_query_stats_finish(mv_index* ix, mv_query_stats* stats);
 /* Top-k of a BATCH of queries in one pass over the slab (score_multi_vector takes a list of queries:
  * fast_multivector_store.py:553-555 passes [query_embedding]; a serving process batches concurrent requests).
  *   q          host buffer, n_queries x n_q_rows x dim (every query padded to n_q_rows with zero rows -- a zero
@@ -317,6 +326,12 @@ MV_API int mv_query_topk_batch_fde(mv_index* ix, const void* q, int q_dtype, int
  * world*kk <= 2048.  Writes k entries (padded the same way) on `stream` (enqueue only).  Same tie rule as one index. */
 MV_API int mv_merge_topk(int device, const float* d_scores, const int64_t* d_ids, int32_t world, int32_t kk, int32_t k,
                          float* d_out_scores, int64_t* d_out_ids, void* stream);
+/* The same merge over the result of ONE all-gather: every rank contributes one block of mv_topk_block_bytes(kk) bytes --
+ * {int64 ids[kk], float scores[kk]}, padded to a multiple of 16 -- (mv_query_topk_device writes its two outputs straight into the
+ * two halves of the local block), d_blocks = the world gathered blocks in rank order. */
+MV_API int64_t mv_topk_block_bytes(int32_t kk);
+MV_API int mv_merge_topk_blocks(int device, const void* d_blocks, int32_t world, int32_t kk, int32_t k, float* d_out_scores,
+                                int64_t* d_out_ids, void* stream);
 
 /* Score every page (no selection) into a host buffer of out_cap floats; masked pages get -inf.  *out_n = entries
  * written = min(published pages, out_cap) -- the corpus may grow between the caller's mv_index_size() and this call.
@@ -389,7 +404,12 @@ enum { MV_CAL_READ_NT = 1, MV_CAL_MFMA_BF16 = 2, MV_CAL_READ_LDSDMA = 3, MV_CAL_
        MV_CAL_READ_STRIDED_512 = 5, MV_CAL_READ_STRIDED_1K = 6, MV_CAL_READ_STRIDED_2K = 7, MV_CAL_READ_STRIDED_4K = 8, MV_CAL_READ_ROWS_20K = 9,
        /* ... and through the pass's own transport (non-temporal global_load_lds_dwordx4 into an LDS ring, nothing read back): 512 B /
         * 1 KiB / 2 KiB per row and step, and 128 B per row with 8 rows per instruction (the private-ring form) */
-       MV_CAL_DMA_STRIDED_128 = 10, MV_CAL_DMA_STRIDED_512 = 11, MV_CAL_DMA_STRIDED_1K = 12, MV_CAL_DMA_STRIDED_2K = 13 };
+       MV_CAL_DMA_STRIDED_128 = 10, MV_CAL_DMA_STRIDED_512 = 11, MV_CAL_DMA_STRIDED_1K = 12, MV_CAL_DMA_STRIDED_2K = 13,
+       /* the single-query FDE coarse scan itself over bytes / 20 480 synthetic pages, `iters` launches back to back -> GB/s
+        * (what the kernel sustains without the host gaps between requests): the register form / the nt LDS-DMA ring */
+       MV_CAL_FDE_SCAN_REGS = 14, MV_CAL_FDE_SCAN_LDSDMA = 15, MV_CAL_FDE_SCAN_LDSDMA_STATIC = 16 /* ... with a static chunk order */,
+       MV_CAL_FDE_SCAN_STREAM = 17 /* the LDS-DMA form's transport alone (no read-back, no arithmetic) */,
+       MV_CAL_READ_LDSDMA_20K = 18 /* MV_CAL_READ_LDSDMA over 20 KiB pages: one fresh workgroup per FDE-row-sized page */ };
 MV_API int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out);
 
 /* ---------------------------------------------------------------------------------------------------------------

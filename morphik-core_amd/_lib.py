@@ -94,13 +94,13 @@ class CandRecC(C.Structure):
 
 
 # every symbol include/mvmaxsim.h declares (tests check the .so exports all of them)
-MV_ABI_VERSION = 5  # include/mvmaxsim.h: the header revision this binding's argument lists were written against
+MV_ABI_VERSION = 6  # include/mvmaxsim.h: the header revision this binding's argument lists were written against
 
 EXPORTS = [
     "mv_abi_version", "mv_last_error", "mv_version", "mv_device_count", "mv_host_pin_budget_bytes", "mv_index_exact_hbm_pages", "mv_index_create", "mv_index_destroy", "mv_index_set_option",
     "mv_index_size", "mv_index_capacity", "mv_index_add", "mv_index_add_device", "mv_index_add_bits", "mv_index_remove_doc",
     "mv_index_remove_page", "mv_index_compact", "mv_index_read_pages", "mv_index_write_rows", "mv_index_replace_page", "mv_index_read_fp8", "mv_index_fill_synthetic", "mv_synth_rows",
-    "mv_query_topk", "mv_query_topk_device", "mv_query_topk_batch", "mv_merge_topk", "mv_score_all", "mv_score_candidates", "mv_score_candidates_pads", "mv_index_page_rows",
+    "mv_query_topk", "mv_query_topk_device", "mv_query_topk_device_async", "mv_query_stats_finish", "mv_query_topk_batch", "mv_merge_topk", "mv_topk_block_bytes", "mv_merge_topk_blocks", "mv_score_all", "mv_score_candidates", "mv_score_candidates_pads", "mv_index_page_rows",
     "mv_two_stage_coarse_device", "mv_two_stage_mid_device", "mv_two_stage_rerank_device", "mv_index_rerank_plan", "mv_comm_create", "mv_comm_destroy", "mv_comm_attach", "mv_comm_transport",
     "mv_comm_query_topk", "mv_comm_query_topk_batch", "mv_sign_pack", "mv_hamming_batch",
     "mv_index_import_fde", "mv_index_read_fde", "mv_query_topk_fde", "mv_query_topk_batch_fde", "mv_comm_query_topk_fde", "mv_comm_query_topk_batch_fde", "mv_two_stage_coarse_device_fde",
@@ -177,6 +177,11 @@ def lib() -> C.CDLL:
         L.mv_synth_rows.argtypes = [C.c_int, u64, u64, i32, vp]
         L.mv_query_topk.argtypes = [vp, vp, C.c_int, i32, i32, C.c_int, vp, i64, vp, vp, C.POINTER(i32), C.POINTER(QueryStatsC)]
         L.mv_query_topk_device.argtypes = [vp, vp, C.c_int, i32, i32, C.c_int, vp, i64, vp, vp, vp, C.POINTER(QueryStatsC)]
+        L.mv_query_topk_device_async.argtypes = [vp, vp, C.c_int, i32, i32, C.c_int, vp, i64, vp, vp, vp, C.POINTER(QueryStatsC)]
+        L.mv_query_stats_finish.argtypes = [vp, C.POINTER(QueryStatsC)]
+        L.mv_topk_block_bytes.argtypes = [i32]
+        L.mv_topk_block_bytes.restype = C.c_int64
+        L.mv_merge_topk_blocks.argtypes = [C.c_int, vp, i32, i32, i32, vp, vp, vp]
         L.mv_query_topk_batch.argtypes = [vp, vp, C.c_int, i32, i32, i32, C.c_int, vp, i64, i32, vp, vp, vp, C.POINTER(QueryStatsC)]
         L.mv_index_import_fde.argtypes = [vp, i64, i64, vp]
         L.mv_index_read_fde.argtypes = [vp, i64, i64, vp]

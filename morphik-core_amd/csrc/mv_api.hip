@@ -343,6 +343,7 @@ int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_wo
   s.out_dim = ix->fde_t.out_dim;
   const bool prebin = k_next > 0 && hist0_done && topk_uses_radix(n, k_next) && fde_scan_prebins(ix->fde_scan_variant, s.out_dim);
   s.hist0 = prebin ? topk_radix_hist0(ix->d_topk_ws) : nullptr;  // zero between selections (cleared by the previous one's last kernel)
+  s.work = ix->d_fde_work;  // every coarse scan of this index runs on ix->stream: one scan holds the counter at a time
   if (hist0_done) *hist0_done = prebin;
   rc = launch_fde_scan(s, ix->fde_scan_variant, ix->stream);
   if (rc) return rc;
@@ -970,7 +971,7 @@ void mv_index_destroy(mv_index* ix) {
   DeviceGuard g(ix->cfg.device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
   if (ix->w_stream) (void)hipStreamSynchronize(ix->w_stream);
-  void* ptrs[] = {ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
+  void* ptrs[] = {ix->d_fde_work, ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
                   ix->d_topk_ws, ix->d_q, ix->d_qf32, ix->d_qbits, ix->d_qpop, ix->d_qfde, ix->d_qoff, ix->d_allow, ix->d_out_s,
                   ix->d_out_id, ix->d_cand, ix->d_cand_scores, ix->d_bqf32, ix->d_bqfde, ix->d_bqimage, ix->d_btopk_ws, ix->d_bsel_s,
                   ix->d_bsel_id, ix->d_bcand, ix->d_bcand_pads, ix->d_bcand_scores, ix->d_bout_s, ix->d_bout_id, ix->d_bq8hi, ix->d_bq8lo, ix->d_bq8fac};
@@ -1040,6 +1041,8 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
     alloc((void**)&ix->fde, (size_t)cap * ix->fde_t.out_dim * 2, "FDE slab");
     alloc((void**)&ix->fde_inv_norm, (size_t)cap * 4, "FDE norms");
     alloc((void**)&ix->d_qfde, (size_t)std::max<int64_t>(ix->fde_t.out_dim, 1) * 4, "query FDE");
+    alloc((void**)&ix->d_fde_work, 64, "FDE scan work counter");
+    if (!rc && hipMemset(ix->d_fde_work, 0, 64) != hipSuccess) { set_error("hipMemset of the FDE scan work counter failed"); rc = MV_ERR_HIP; }
   }
   alloc((void**)&ix->d_n_rows, (size_t)cap * 4, "row counts");
   alloc((void**)&ix->d_doc_ord, (size_t)cap * 4, "doc ordinals");
@@ -1597,6 +1600,21 @@ int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_r
   if (k < 1 || !d_out_scores || !d_out_ids) { set_error("mv_query_topk_device: k >= 1 and device buffers required"); return MV_ERR_INVALID; }
   return mv_internal_query_common(ix, q, q_dtype, n_q_rows, k, mode, allow_bits, n_allow_words, nullptr, nullptr, nullptr, d_out_scores,
                                   d_out_ids, stream, stats, 0);
+}
+
+int mv_query_topk_device_async(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int32_t k, int mode,
+                               const uint32_t* allow_bits, int64_t n_allow_words, float* d_out_scores, int64_t* d_out_ids,
+                               void* stream, mv_query_stats* stats) {
+  if (k < 1 || !d_out_scores || !d_out_ids || !stream || !stats) { set_error("mv_query_topk_device_async: k >= 1, device buffers, a stream and a stats record required"); return MV_ERR_INVALID; }
+  return mv_internal_query_common(ix, q, q_dtype, n_q_rows, k, mode, allow_bits, n_allow_words, nullptr, nullptr, nullptr, d_out_scores,
+                                  d_out_ids, stream, stats, /*defer_stats=*/1);
+}
+
+int mv_query_stats_finish(mv_index* ix, mv_query_stats* stats) {
+  if (!ix || !stats) { set_error("mv_query_stats_finish: null argument"); return MV_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(ix->q_mu);
+  DeviceGuard g(ix->cfg.device);
+  return finish_stats(ix, stats, true);
 }
 
 // ---- the caller's own FDE vectors (the reference computes them with its `fde` extension: fast_multivector_store.py:447-449, :521)
@@ -2385,6 +2403,17 @@ int mv_merge_topk(int device, const float* d_scores, const int64_t* d_ids, int32
   return launch_merge_topk(d_scores, d_ids, world, kk, k, d_out_scores, d_out_ids, (hipStream_t)stream);
 }
 
+int64_t mv_topk_block_bytes(int32_t kk) { return kk < 1 ? 0 : (((int64_t)kk * 12 + 15) / 16) * 16; }
+
+int mv_merge_topk_blocks(int device, const void* d_blocks, int32_t world, int32_t kk, int32_t k, float* d_out_scores, int64_t* d_out_ids, void* stream) {
+  if (!d_blocks || !d_out_scores || !d_out_ids) { set_error("mv_merge_topk_blocks: null argument"); return MV_ERR_INVALID; }
+  DeviceGuard g(device);
+  const int64_t bb = mv_topk_block_bytes(kk);  // multiple of 16: both strides are whole elements
+  const char* b = static_cast<const char*>(d_blocks);
+  return launch_merge_topk(reinterpret_cast<const float*>(b + (size_t)kk * 8), reinterpret_cast<const int64_t*>(b), world, kk, k, d_out_scores, d_out_ids,
+                           (hipStream_t)stream, bb / 4, bb / 8);
+}
+
 int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out) {
   if (!out || iters < 1) { set_error("calibrate: bad argument"); return MV_ERR_INVALID; }
   DeviceGuard g(device);
@@ -2410,9 +2439,10 @@ int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out
       *out = ms > 0 ? (double)(bytes / 16384 * 16384) * iters / (ms * 1e-3) / 1e9 : 0.0;  // GB/s
     }
     if (buf) (void)hipFree(buf);
-  } else if (what == MV_CAL_READ_LDSDMA) {
+  } else if (what == MV_CAL_READ_LDSDMA || what == MV_CAL_READ_LDSDMA_20K) {
     // the float scan's own transport (nt LDS-DMA ring, 4 waves per 256 KiB page) with the arithmetic removed
-    const int64_t page_bytes = 1024 * kRowBytes;
+    // (_20K: the same kernel over 20 KiB pages -- one FRESH workgroup per FDE-row-sized page, 5 tiles over 4 waves)
+    const int64_t page_bytes = (what == MV_CAL_READ_LDSDMA_20K ? 80 : 1024) * kRowBytes;
     const int64_t n = bytes / page_bytes;
     if (n < 64) { set_error("calibrate: need >= 16 MiB"); rc = MV_ERR_INVALID; }
     void* buf = nullptr;
@@ -2421,7 +2451,7 @@ int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out
     if (!rc) {
       (void)hipMemset(buf, 1, (size_t)n * page_bytes);
       MaxsimArgs a{};
-      a.slab = (const uint16_t*)buf; a.q = (const uint16_t*)buf; a.scores = sc; a.n = n; a.stride = 1024; a.q_tiles = 2;
+      a.slab = (const uint16_t*)buf; a.q = (const uint16_t*)buf; a.scores = sc; a.n = n; a.stride = (int32_t)(page_bytes / kRowBytes); a.q_tiles = 2;
       rc = launch_maxsim_bf16(a, 13, nullptr);
       (void)hipEventRecord(a_ev, nullptr);
       for (int i = 0; i < iters && !rc; ++i) rc = launch_maxsim_bf16(a, 13, nullptr);
@@ -2451,6 +2481,35 @@ int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out
       *out = ms > 0 ? (double)n_rows * 20480 * (piece > 8192 ? 1.2 : 1.0) * iters / (ms * 1e-3) / 1e9 : 0.0;  // GB/s (whole rows: 3 x 8 KiB read per 20 KiB row)
     }
     if (buf) (void)hipFree(buf);
+  } else if (what == MV_CAL_FDE_SCAN_REGS || what == MV_CAL_FDE_SCAN_LDSDMA || what == MV_CAL_FDE_SCAN_LDSDMA_STATIC || what == MV_CAL_FDE_SCAN_STREAM) {
+    // the single-query FDE coarse scan itself (10 240-d rows, cosine on, no filter), `iters` launches back to back: what the
+    // kernel sustains without the host gaps between requests (variant 0: plain nt loads; variant 3: nt LDS-DMA ring)
+    const int64_t od = 10240, n = bytes / (od * 2);
+    if (n < 1024) { set_error("calibrate: need >= 21 MB"); rc = MV_ERR_INVALID; }
+    void* buf = nullptr;
+    float *sc = nullptr, *qv = nullptr, *inv = nullptr;
+    if (!rc && (hipMalloc(&buf, (size_t)n * od * 2) != hipSuccess || hipMalloc(&sc, (size_t)n * 4) != hipSuccess || hipMalloc(&inv, (size_t)n * 4) != hipSuccess ||
+                hipMalloc(&qv, (size_t)od * 4) != hipSuccess)) { set_error("calibrate: out of memory"); rc = MV_ERR_NOMEM; }
+    if (!rc) {
+      (void)hipMemset(buf, 1, (size_t)n * od * 2);
+      (void)hipMemset(inv, 0, (size_t)n * 4);
+      (void)hipMemset(qv, 0, (size_t)od * 4);
+      FdeScanArgs a{};
+      a.fde = (const uint16_t*)buf; a.inv_norm = inv; a.q = qv; a.scores = sc; a.n = n; a.out_dim = od;
+      a.work = (uint32_t*)inv;  // zeros; inv[0..1] are re-armed by every launch (page 0 / 1 score 0 either way: q = 0)
+      const int v = what == MV_CAL_FDE_SCAN_REGS ? 0 : what == MV_CAL_FDE_SCAN_LDSDMA_STATIC ? 4 : what == MV_CAL_FDE_SCAN_STREAM ? 5 : 3;
+      rc = launch_fde_scan(a, v, nullptr);
+      (void)hipEventRecord(a_ev, nullptr);
+      for (int i = 0; i < iters && !rc; ++i) rc = launch_fde_scan(a, v, nullptr);
+      (void)hipEventRecord(b_ev, nullptr);
+      (void)hipEventSynchronize(b_ev);
+      (void)hipEventElapsedTime(&ms, a_ev, b_ev);
+      *out = ms > 0 ? (double)(n * od * 2) * iters / (ms * 1e-3) / 1e9 : 0.0;  // GB/s
+    }
+    if (buf) (void)hipFree(buf);
+    if (sc) (void)hipFree(sc);
+    if (qv) (void)hipFree(qv);
+    if (inv) (void)hipFree(inv);
   } else if (what == MV_CAL_MFMA_BF16 || what == MV_CAL_MFMA_BF16_32X32) {
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);

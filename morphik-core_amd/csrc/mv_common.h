@@ -110,8 +110,9 @@ __device__ __forceinline__ void topk_hist_add_wave(uint32_t* h, uint32_t bin, bo
   if (valid) atomicAdd(&h[bin], 1u);
 }
 
+// s_stride / i_stride: distance between two ranks' lists in floats / int64s (0 = kk: two dense [world][kk] arrays)
 int launch_merge_topk(const float* d_scores, const int64_t* d_ids, int32_t world, int32_t kk, int32_t k, float* d_out_scores,
-                      int64_t* d_out_ids, hipStream_t s);
+                      int64_t* d_out_ids, hipStream_t s, int64_t s_stride = 0, int64_t i_stride = 0);
 
 // ---------------------------------------------------------------- synthetic generator (mv_synth.hip)
 int launch_synth_rows(uint16_t* d_out, uint64_t seed, uint64_t first_unit, int64_t n_units, int32_t n_rows,
@@ -190,6 +191,8 @@ struct FdeScanArgs {
   int64_t out_dim;
   uint32_t* hist0;          // nullable: 2048-bin histogram of the scores' key bits [31:21], accumulated by the scan itself
                             // (saves the selection's first pass); default variant at out_dim 10240 / 5120 only
+  uint32_t* work;           // nullable: 2 device words, zero between launches -- the LDS-DMA form claims its chunks from them
+                            // (dynamic load balance); null: static chunk order
 };
 // variant: 0 = query in registers, one wave per page, nt loads (default, -1), 1 = query in LDS, 2 = workgroup-cooperative
 int launch_fde_scan(const FdeScanArgs& a, int variant, hipStream_t s);

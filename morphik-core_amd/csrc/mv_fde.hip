@@ -906,6 +906,7 @@ struct ScanArgs {
   int64_t n;
   int32_t out_dim;
   uint32_t* hist0;  // nullable: the selection's first radix histogram, accumulated here (see FdeScanArgs)
+  uint32_t* work;   // nullable: {next chunk, waves done}, both 0 between launches (LDS-DMA form: dynamic chunk claiming)
 };
 
 // Persistent waves: each lane keeps its slice of the query FDE in registers (ITERS x 8 floats) and
@@ -977,12 +978,16 @@ __global__ __launch_bounds__(256) void fde_scan_kernel(ScanArgs a) {
 //   * `global_load_lds_dwordx4 ... nt` copies 1 KiB chunks (64 lanes x 16 B, linear) into a wave-private ring of D tiles of
 //     CPT chunks; lane l reads back exactly the 16 B it requested (ds_read_b128, conflict-free), so the LDS is a FIFO that
 //     holds D-1 tiles (12 KiB at CPT 4, D 4) in flight per wave at no VGPR cost; counted `s_waitcnt vmcnt`, no barrier.
-//   * NOTHING but the DMAs touches vector memory inside the stream: a workgroup walks the corpus in chunks of 4 x ppw pages
-//     (wave w takes pages w, w+4, ... of the chunk; ppw <= 64) and at each chunk start -- the ring is empty there anyway --
-//     lane i evaluates the doc filter and loads 1/norm of the wave's i-th page; the live pages are a 64-bit ballot walked
-//     with s_ff1; lane i keeps page i's score and the chunk ends with one store (+ one LDS histogram add) per lane.
-//     A per-page load of inv_norm / doc_ord would make hipcc drain vmcnt(0) -- the whole ring -- once per page.
-//   * persistent workgroups (2 per CU), the query FDE in 8 x ITERS VGPRs per lane loaded once.
+//   * NOTHING but the DMAs touches vector memory inside the stream: a wave walks the corpus in chunks of ppw (<= 64)
+//     consecutive pages and at each chunk start -- the ring is empty there anyway -- lane i evaluates the doc filter and
+//     loads 1/norm of the chunk's i-th page; the live pages are a 64-bit ballot walked with s_ff1; lane i keeps page i's
+//     score and the chunk ends with one store (+ one LDS histogram add) per lane.  A per-page load of inv_norm / doc_ord
+//     would make hipcc drain vmcnt(0) -- the whole ring -- once per page.
+//   * persistent workgroups (2 per CU), the query FDE in 8 x ITERS VGPRs per lane loaded once; chunks are CLAIMED from a
+//     device counter (one atomic per chunk per wave).  Measured (profiles/r5): with a static partition of the pages this
+//     kernel -- like the register kernel, like the float scan's persistent variant 14 -- stops at 6.7-6.8 TB/s while the
+//     float scan's transport, whose workgroups are handed out by the dispatcher, streams 7.3 TB/s over the same 25.6 GB:
+//     the CUs do not all stream at the same rate, and a static split runs at the pace of the slowest.
 template <int N>
 __device__ __forceinline__ void fde_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -997,7 +1002,9 @@ __device__ __forceinline__ void fde_wait_left(int left) {  // all tiles issued; 
   else fde_wait_vmcnt<0>();
 }
 
-template <int ITERS, int CPT, int D>  // out_dim = 512 ITERS; tile = CPT chunks of 1 KiB; ITERS % CPT == 0; CPT * (D-1) <= 63
+// STREAM_ONLY: the same ring, claims and waits without the read-back and the arithmetic (MV_CAL_FDE_SCAN_STREAM: what this
+// kernel's transport alone sustains).
+template <int ITERS, int CPT, int D, bool STREAM_ONLY = false>  // out_dim = 512 ITERS; tile = CPT chunks of 1 KiB; ITERS % CPT == 0; CPT * (D-1) <= 63
 __global__ __launch_bounds__(256) void fde_scan_ldsdma_kernel(ScanArgs a, int ppw) {
   constexpr int TPP = ITERS / CPT;  // tiles per page
   constexpr int TILEB = CPT * 1024;
@@ -1030,13 +1037,20 @@ __global__ __launch_bounds__(256) void fde_scan_ldsdma_kernel(ScanArgs a, int pp
 #pragma unroll
     for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(q[it][k]));
 
-  const int64_t chunk_pages = 4 * (int64_t)ppw;
-  const int64_t nchunks = (a.n + chunk_pages - 1) / chunk_pages;
+  const int64_t nchunks = (a.n + ppw - 1) / ppw;  // a chunk = ppw consecutive pages, streamed by ONE wave
   const size_t page_bytes = (size_t)a.out_dim * 2;
-  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-    // ---- chunk prologue (ring empty): lane i <-> this wave's i-th page
-    const int64_t base = c * chunk_pages + wave;
-    const int64_t myp = base + 4 * (int64_t)lane;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  int64_t c = (int64_t)blockIdx.x * 4 + wave;  // static order (no work counter): chunks g, g + nwaves, ...
+  for (;; c += nwaves) {
+    if (a.work) {  // dynamic: the next unclaimed chunk (a CU that streams faster takes more of them -- see the header comment)
+      uint32_t t = 0;
+      if (lane == 0) t = atomicAdd(a.work, 1u);
+      c = (int64_t)__builtin_amdgcn_readfirstlane(t);
+    }
+    if (c >= nchunks) break;
+    // ---- chunk prologue (ring empty): lane i <-> the chunk's i-th page
+    const int64_t base = c * (int64_t)ppw;
+    const int64_t myp = base + (int64_t)lane;
     const bool valid = lane < ppw && myp < a.n;
     bool masked = false;
     float my_inv = 1.0f;
@@ -1057,7 +1071,7 @@ __global__ __launch_bounds__(256) void fde_scan_ldsdma_kernel(ScanArgs a, int pp
 
     auto issue_next = [&]() {
       const int i = __builtin_ctzll(iss);
-      const char* tp = reinterpret_cast<const char*>(a.fde) + (size_t)(base + 4 * (int64_t)i) * page_bytes + (size_t)iss_t * TILEB;
+      const char* tp = reinterpret_cast<const char*>(a.fde) + (size_t)(base + (int64_t)i) * page_bytes + (size_t)iss_t * TILEB;
       const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
       const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
       const uint64_t tpu = ((uint64_t)hi << 32) | lo;
@@ -1119,6 +1133,7 @@ __global__ __launch_bounds__(256) void fde_scan_ldsdma_kernel(ScanArgs a, int pp
         --to_read;
         const char* slot = ring + cons_slot * TILEB + voff;
         cons_slot = (cons_slot + 1 == D) ? 0 : cons_slot + 1;
+        if (STREAM_ONLY) continue;
 #pragma unroll
         for (int ch = 0; ch < CPT; ++ch) {
           const u32x4 v = *reinterpret_cast<const u32x4*>(slot + ch * 1024);
@@ -1142,6 +1157,14 @@ __global__ __launch_bounds__(256) void fde_scan_ldsdma_kernel(ScanArgs a, int pp
         const float s0 = my_score + 0.0f;
         if (s0 == s0 && s0 != -INFINITY) atomicAdd(&h0[topk_ordered_u32(s0) >> 21], 1u);
       }
+    }
+  }
+  if (a.work && lane == 0) {  // the last wave to leave re-arms the counters for the next launch on this stream
+    const uint32_t done = atomicAdd(a.work + 1, 1u);
+    if (done == (uint32_t)nwaves - 1u) {
+      __threadfence();
+      a.work[0] = 0u;
+      a.work[1] = 0u;
     }
   }
   if (a.hist0) {
@@ -2688,12 +2711,13 @@ static int launch_fde_scan_lds(const ScanArgs& k, hipStream_t s) {
   return MV_OK;
 }
 
-bool fde_scan_prebins(int variant, int64_t out_dim) { return (variant <= 0 || variant == 3) && (out_dim == 10240 || out_dim == 5120); }
+bool fde_scan_prebins(int variant, int64_t out_dim) { return (variant <= 0 || variant == 3 || variant == 4) && (out_dim == 10240 || out_dim == 5120); }
 
-// Chunk shape of the LDS-DMA scan: `grid` persistent workgroups walk ceil(n / (4 ppw)) chunks; ppw (<= 64 pages per wave per
-// chunk) is chosen so that the chunk count is as close below a multiple of the grid as the page count allows (a 4 883-chunk
-// corpus over 512 workgroups would leave 46 % of them idle for the last tenth of the launch).
-static void fde_ldsdma_shape(int64_t n, int* grid, int* ppw) {
+// Shape of the LDS-DMA scan: `grid` persistent workgroups (4 waves each); a chunk is ppw (<= 64) consecutive pages for one wave.
+// Dynamic claiming (work counter given): 16 pages per chunk -- 320 KiB, ~90 us of one wave's stream; the ring drains once per
+// chunk and the launch ends within one chunk time of the last claim.  Static order: ppw chosen so that every wave gets the
+// same number of (nearly full) chunks.
+static void fde_ldsdma_shape(int64_t n, bool dynamic, int* grid, int* ppw) {
   static int env_ppw = -1, env_bpc = -1;
   if (env_ppw < 0) {  // tuning hooks (tools/fde_scan_probe.py); unset in production
     const char* e = getenv("MV_FDE_SCAN_PPW");
@@ -2702,16 +2726,19 @@ static void fde_ldsdma_shape(int64_t n, int* grid, int* ppw) {
     env_bpc = e ? atoi(e) : 0;
   }
   const int g = 256 * (env_bpc > 0 ? env_bpc : 2);
-  int64_t w = (n + 3) / 4;  // pages per wave position if one chunk held everything
+  const int64_t waves = (int64_t)g * 4;
   if (env_ppw > 0) {
     *ppw = env_ppw > 64 ? 64 : env_ppw;
+  } else if (dynamic) {
+    *ppw = 16;
   } else {
-    const int64_t rounds = (w + (int64_t)g * 64 - 1) / ((int64_t)g * 64);  // chunks per workgroup at ppw = 64
-    int64_t p = (w + rounds * g - 1) / (rounds * g);
+    const int64_t rounds = (n + waves * 64 - 1) / (waves * 64);  // chunks per wave at ppw = 64
+    const int64_t p = (n + rounds * waves - 1) / (rounds * waves);
     *ppw = (int)(p < 1 ? 1 : (p > 64 ? 64 : p));
   }
-  const int64_t nchunks = (n + 4 * (int64_t)*ppw - 1) / (4 * (int64_t)*ppw);
-  *grid = (int)(nchunks < g ? nchunks : g);
+  const int64_t nchunks = (n + *ppw - 1) / *ppw;
+  const int64_t blocks = (nchunks + 3) / 4;
+  *grid = (int)(blocks < g ? blocks : g);
 }
 
 int launch_fde_scan(const FdeScanArgs& a, int variant, hipStream_t s) {
@@ -2719,16 +2746,25 @@ int launch_fde_scan(const FdeScanArgs& a, int variant, hipStream_t s) {
   ScanArgs k{a.fde, a.inv_norm, a.doc_ord, a.allow, a.n_allow_bits, a.q, a.scores, a.n, (int32_t)a.out_dim, nullptr};
   const int grid = 256 * 2;  // 2 blocks/CU x 4 waves, persistent
   if (variant < 0) variant = 3;  // round 5: nt LDS-DMA ring (0 = the same arithmetic on plain nt loads: 6.8 TB/s)
-  if (variant == 3 && (a.out_dim == 10240 || a.out_dim == 5120)) {
+  if (variant == 5 && a.out_dim == 10240) {  // calibration: the LDS-DMA form's transport alone
     int g, ppw;
-    fde_ldsdma_shape(a.n, &g, &ppw);
+    k.work = a.work;
+    fde_ldsdma_shape(a.n, k.work != nullptr, &g, &ppw);
+    hipLaunchKernelGGL((fde_scan_ldsdma_kernel<20, 4, 4, true>), dim3(g), dim3(256), 0, s, k, ppw);
+    MV_HIP(hipGetLastError());
+    return MV_OK;
+  }
+  if ((variant == 3 || variant == 4) && (a.out_dim == 10240 || a.out_dim == 5120)) {
+    int g, ppw;
+    k.work = variant == 3 ? a.work : nullptr;
+    fde_ldsdma_shape(a.n, k.work != nullptr, &g, &ppw);
     k.hist0 = a.hist0;
     if (a.out_dim == 10240) hipLaunchKernelGGL((fde_scan_ldsdma_kernel<20, 4, 4>), dim3(g), dim3(256), 0, s, k, ppw);
     else hipLaunchKernelGGL((fde_scan_ldsdma_kernel<10, 2, 8>), dim3(g), dim3(256), 0, s, k, ppw);
     MV_HIP(hipGetLastError());
     return MV_OK;
   }
-  if (variant == 3) variant = 0;
+  if (variant == 3 || variant == 4) variant = 0;
   if (variant == 2 && a.out_dim % 2048 == 0 && a.out_dim / 2048 <= 5 && a.out_dim >= 2048) {
     const int wg = 256 * 4;  // 4 workgroups per CU, persistent
     switch ((int)(a.out_dim / 2048)) {

@@ -455,14 +455,19 @@ size_t topk_ws_bytes(int64_t n, int32_t k) {
 // [world][kk], each row sorted (score desc, id asc) and padded with (-inf, -1), rank r owning ids below rank r+1's.
 // One block: 64-bit keys (ordered score, ~position) -> bitonic sort -> first k.  Equal scores keep (rank, position)
 // order, which is ascending id order: the same tie rule as a single index.  One launch instead of ~8 framework ops.
-__global__ __launch_bounds__(kThreads) void merge_topk_kernel(const float* scores, const int64_t* ids, int n, int k, float* out_s,
-                                                              int64_t* out_id) {
+// Rank r's list: scores at scores + r * s_stride (floats), ids at ids + r * i_stride (int64s), kk entries each -- two separate
+// [world][kk] arrays (s_stride = i_stride = kk) or the per-rank BLOCKS of one all-gather ({ids[kk], scores[kk]} per rank).
+__global__ __launch_bounds__(kThreads) void merge_topk_kernel(const float* scores, const int64_t* ids, int n, int kk, int64_t s_stride, int64_t i_stride,
+                                                              int k, float* out_s, int64_t* out_id) {
   __shared__ uint64_t sk[kChunk];
   for (int i = threadIdx.x; i < kChunk; i += kThreads) {
     uint64_t key = 0;
-    if (i < n && ids[i] >= 0) {
-      const float s = scores[i] + 0.0f;
-      if (s == s && s != -INFINITY) key = ((uint64_t)ordered_u32(s) << 32) | (uint32_t)(~(uint32_t)i);
+    if (i < n) {
+      const int r = i / kk, j = i - r * kk;
+      if (ids[r * i_stride + j] >= 0) {
+        const float s = scores[r * s_stride + j] + 0.0f;
+        if (s == s && s != -INFINITY) key = ((uint64_t)ordered_u32(s) << 32) | (uint32_t)(~(uint32_t)i);
+      }
     }
     sk[i] = key;
   }
@@ -474,20 +479,23 @@ __global__ __launch_bounds__(kThreads) void merge_topk_kernel(const float* score
       out_s[i] = -INFINITY;
       out_id[i] = -1;
     } else {
+      const int pos = (int)(~(uint32_t)(key & 0xffffffffu));
+      const int r = pos / kk, j = pos - r * kk;
       out_s[i] = unordered_f32((uint32_t)(key >> 32));
-      out_id[i] = ids[~(uint32_t)(key & 0xffffffffu)];
+      out_id[i] = ids[r * i_stride + j];
     }
   }
 }
 
 int launch_merge_topk(const float* d_scores, const int64_t* d_ids, int32_t world, int32_t kk, int32_t k, float* d_out_scores,
-                      int64_t* d_out_ids, hipStream_t s) {
+                      int64_t* d_out_ids, hipStream_t s, int64_t s_stride, int64_t i_stride) {
   const int64_t n = (int64_t)world * kk;
   if (world < 1 || kk < 1 || k < 1 || n > kChunk || k > kChunk) {
     set_error("merge_topk: world*kk = %lld and k = %d must be within 1..%d", (long long)n, k, kChunk);
     return MV_ERR_INVALID;
   }
-  hipLaunchKernelGGL(merge_topk_kernel, dim3(1), dim3(kThreads), 0, s, d_scores, d_ids, (int)n, (int)k, d_out_scores, d_out_ids);
+  hipLaunchKernelGGL(merge_topk_kernel, dim3(1), dim3(kThreads), 0, s, d_scores, d_ids, (int)n, (int)kk, s_stride > 0 ? s_stride : (int64_t)kk,
+                     i_stride > 0 ? i_stride : (int64_t)kk, (int)k, d_out_scores, d_out_ids);
   MV_HIP(hipGetLastError());
   return MV_OK;
 }

@@ -399,6 +399,22 @@ class MvIndex:
         )
         return QueryStats.from_c(st) if want_stats else None
 
+    def query_device_async(self, q: Any, k: int, d_scores_ptr: int, d_ids_ptr: int, stream: int, mode: str = "float",
+                           allow: Optional[np.ndarray] = None) -> "QueryStatsC":
+        """mv_query_topk_device_async: enqueue only (the caller's `stream` is ordered behind the result); -> the pending stats
+        record to hand to finish_stats() before the next query on this index."""
+        qa, code = as_rows(q)
+        ab = None if allow is None else np.ascontiguousarray(allow, dtype=np.uint32)
+        st = QueryStatsC()
+        check(lib().mv_query_topk_device_async(self._h, qa.ctypes.data, code, qa.shape[0], int(k), MODES[mode], None if ab is None else ab.ctypes.data,
+                                               0 if ab is None else ab.size, C.c_void_p(d_scores_ptr), C.c_void_p(d_ids_ptr), C.c_void_p(stream), C.byref(st)))
+        return st
+
+    def finish_stats(self, pending: "QueryStatsC") -> QueryStats:
+        """Fill the HIP-event timings of the query `pending` came from (waits for that query's kernels, nothing else)."""
+        check(lib().mv_query_stats_finish(self._h, C.byref(pending)))
+        return QueryStats.from_c(pending)
+
     def score_all(self, q: Any, mode: str = "float", allow: Optional[np.ndarray] = None, want_stats: bool = False):
         qa, code = as_rows(q)
         out = np.empty(max(len(self), 1), np.float32)  # the library never writes past this, even if the corpus grows meanwhile
@@ -545,7 +561,7 @@ def calibrate(what: str, bytes_: int = 8 << 30, iters: int = 5, device: int = 0)
     """Measured peaks (same process as the measurement): "read_nt" / "read_ldsdma" -> GB/s, "mfma_bf16" (16x16x32 chains) / "mfma_bf16_32x32" (32x32x16 chains) -> TFLOP/s."""
     g = C.c_double()
     code = {"read_nt": _lib.MV_CAL_READ_NT, "mfma_bf16": _lib.MV_CAL_MFMA_BF16, "read_ldsdma": _lib.MV_CAL_READ_LDSDMA,
-            "mfma_bf16_32x32": _lib.MV_CAL_MFMA_BF16_32X32}[what]
+            "mfma_bf16_32x32": _lib.MV_CAL_MFMA_BF16_32X32, "fde_scan_regs": 14, "fde_scan_ldsdma": 15, "fde_scan_ldsdma_static": 16, "fde_scan_stream": 17, "read_ldsdma_20k": 18}[what]
     check(lib().mv_calibrate(device, code, bytes_, iters, C.byref(g)))
     return float(g.value)
 

@@ -135,34 +135,41 @@ def make_gpu_local_topk_batch(index, device=None, mode: str = "float"):
 
 
 class GpuShardedSearcher:
-    """The RCCL path with the fewest host-side steps per query: MvIndex.query_device leaves the local top-k in
-    preallocated cuda buffers, two all_gather_into_tensor calls (scores fp32, ids int64) fill preallocated gather
-    buffers, and ONE library launch (mv_merge_topk, on torch's current stream, behind the collectives) produces the
-    merged top-k -- no framework sort / index / cast ops, no host synchronisation.  Results are padded with
-    (-inf, -1) and become valid in stream order (read them after a synchronize or from the same stream)."""
+    """The RCCL path with the fewest steps per query, none of which waits for the host:
+      1. MvIndex.query_device_async -- scan + local top-k enqueued on the index's stream, torch's current stream ordered behind
+         the result; the k ids and k scores land in the two halves of ONE preallocated block ({int64 ids[k], float scores[k]})
+      2. ONE all_gather_into_tensor of that block (uint8, mv_topk_block_bytes(k) = 128 B per rank at k = 10)
+      3. ONE library launch (mv_merge_topk_blocks, torch's current stream, behind the collective) -> merged top-k.
+    The HIP-event timings of the scan are collected AFTER step 3 was enqueued (finish_stats): the host waits for the scan there,
+    with the collective and the merge already queued behind it.  Results are padded with (-inf, -1) and become valid in stream
+    order (read them after a synchronize or from the same stream)."""
 
     def __init__(self, index, device=None, mode: str = "float", group=None, collect_stats=None):
         import torch
         import torch.distributed as dist
 
+        from ._lib import lib
+
         self.index, self.mode, self.group, self.stats = index, mode, group, collect_stats
         self.dev = torch.device("cuda", index.device) if device is None else device
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._lib = lib()
         self._bufs = {}
         self._flip = 0
 
     def _buffers(self, k):
         import torch
 
-        # two buffer sets used alternately: the collectives of query i may still be reading set A while the
+        # two buffer sets used alternately: the collective of query i may still be reading set A while the
         # library writes the local top-k of query i+1 (they run on different streams)
         self._flip ^= 1
         key = (k, self._flip)
         if key not in self._bufs:
             d, w = self.dev, self.world
-            self._bufs[key] = (torch.empty(k, dtype=torch.float32, device=d), torch.empty(k, dtype=torch.int64, device=d),
-                             torch.empty(w * k, dtype=torch.float32, device=d), torch.empty(w * k, dtype=torch.int64, device=d),
-                             torch.empty(k, dtype=torch.float32, device=d), torch.empty(k, dtype=torch.int64, device=d))
+            bb = int(self._lib.mv_topk_block_bytes(k))
+            mine = torch.zeros(bb, dtype=torch.uint8, device=d)
+            self._bufs[key] = (mine, mine.data_ptr() + 8 * k, mine.data_ptr(), torch.empty(w * bb, dtype=torch.uint8, device=d),
+                               torch.empty(k, dtype=torch.float32, device=d), torch.empty(k, dtype=torch.int64, device=d))
         return self._bufs[key]
 
     def query(self, q, k: int):
@@ -171,21 +178,61 @@ class GpuShardedSearcher:
         import torch
         import torch.distributed as dist
 
-        from ._lib import check, lib
+        from ._lib import check
 
-        ls, li, gs, gi, os_, oi = self._buffers(k)
-        st = self.index.query_device(q, k, ls.data_ptr(), li.data_ptr(), mode=self.mode, want_stats=self.stats is not None)
-        if self.stats is not None:
-            self.stats.append(st)
-        if dist.is_initialized():
-            dist.all_gather_into_tensor(gs, ls, group=self.group)
-            dist.all_gather_into_tensor(gi, li, group=self.group)
-        else:
-            gs, gi = ls, li
+        mine, p_scores, p_ids, gathered, os_, oi = self._buffers(k)
         stream = torch.cuda.current_stream(self.dev).cuda_stream
-        check(lib().mv_merge_topk(self.index.device, C.c_void_p(gs.data_ptr()), C.c_void_p(gi.data_ptr()), self.world, k, k,
-                                  C.c_void_p(os_.data_ptr()), C.c_void_p(oi.data_ptr()), C.c_void_p(stream)))
+        pending = self.index.query_device_async(q, k, p_scores, p_ids, stream, mode=self.mode)
+        if dist.is_initialized():
+            dist.all_gather_into_tensor(gathered, mine, group=self.group)
+        else:
+            gathered = mine
+        check(self._lib.mv_merge_topk_blocks(self.index.device, C.c_void_p(gathered.data_ptr()), self.world, k, k,
+                                             C.c_void_p(os_.data_ptr()), C.c_void_p(oi.data_ptr()), C.c_void_p(stream)))
+        if self.stats is not None:
+            self.stats.append(self.index.finish_stats(pending))
         return os_, oi
+
+
+class HostShardedSearcher:
+    """The same step when the collective runs on HOST memory (gloo: the CPU tests, and N ranks sharing one GPU): the local top-k
+    comes back through the index's pinned result buffers (MvIndex.query: one stream synchronisation), the k (score, id) pairs
+    travel as ONE 16-byte-per-pair float64 buffer (fp32 scores and ids < 2^53 are exact in it) in ONE all-gather into a
+    preallocated tensor, and the merge is a numpy lexsort with the single index's tie rule (score desc, then rank / position =
+    ascending id).  -> (scores, ids) numpy arrays of exactly k entries padded with (-inf, -1)."""
+
+    def __init__(self, index, mode: str = "float", group=None, collect_stats=None):
+        import torch.distributed as dist
+
+        self.index, self.mode, self.group, self.stats = index, mode, group, collect_stats
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._bufs = {}
+
+    def query(self, q, k: int):
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+
+        if k not in self._bufs:
+            self._bufs[k] = (torch.empty(2 * k, dtype=torch.float64), torch.empty(self.world * 2 * k, dtype=torch.float64))
+        mine, allb = self._bufs[k]
+        res = self.index.query(q, k, mode=self.mode, want_stats=self.stats is not None)
+        if self.stats is not None:
+            self.stats.append(res[2])
+        s, i = res[0], res[1]
+        m = mine.numpy()
+        m[:k] = -np.inf
+        m[k:] = -1
+        m[: len(s)] = s
+        m[k : k + len(i)] = i
+        if dist.is_initialized():
+            dist.all_gather_into_tensor(allb, mine, group=self.group)
+            g = allb.numpy().reshape(self.world, 2, k)
+        else:
+            g = m.reshape(1, 2, k)
+        gs, gi = g[:, 0].reshape(-1), g[:, 1].reshape(-1)
+        order = np.lexsort((np.arange(gs.size), -gs))[:k]  # stable: equal scores keep (rank, position) order
+        return gs[order].astype(np.float32), gi[order].astype(np.int64)
 
 
 class TwoStageShardedSearcher:

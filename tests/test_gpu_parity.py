@@ -801,8 +801,8 @@ def test_fde_coarse_scan_and_pipeline(mv):
 
 @pytest.mark.parametrize("n", [1, 3, 255, 2049, 70_001, 300_017])
 def test_fde_scan_ldsdma_ring_bit_identical_to_the_register_scan(mv, n):
-    """The default coarse scan (round 5: nt LDS-DMA ring, chunks of 4 x ppw pages per persistent workgroup, filter and
-    1/norm evaluated per chunk) keeps the arithmetic of the wave-per-page register scan (variant 0): every score is
+    """The default coarse scan (round 5: nt LDS-DMA ring, chunks of ppw pages claimed from a device counter (variant 3) or in a
+    static order (variant 4) by persistent waves, filter and 1/norm evaluated per chunk) keeps the arithmetic of the wave-per-page register scan (variant 0): every score is
     BIT-identical -- unfiltered, with tombstoned pages, with a doc filter, cosine on and off -- for page counts that give one
     partial chunk, ppw = 1, a partial last chunk, and several chunks per workgroup; the top-k (whose first radix
     histogram the scan accumulates) is identical too, and a sample agrees with the oracle's coarse scores."""
@@ -819,7 +819,7 @@ def test_fde_scan_ldsdma_ring_bit_identical_to_the_register_scan(mv, n):
     allow = allow_bitmap([d for d in range(n_docs) if d % 5 != 1], n_docs)
     q = orc.synth_rows(4321, 7, 0, 32)
     got = {}
-    for v in (0, 3):
+    for v in (0, 3, 4, 3):  # (3 twice: the scan re-arms its own work counter)
         ix.set_option(_lib.MV_OPT_FDE_SCAN_VARIANT, v)
         for cosine in (1, 0):
             ix.set_option(_lib.MV_OPT_FDE_COSINE, cosine)
@@ -828,13 +828,14 @@ def test_fde_scan_ldsdma_ring_bit_identical_to_the_register_scan(mv, n):
         ix.set_option(_lib.MV_OPT_FDE_COSINE, 1)
         got[v, "top"] = ix.query(q, min(200, n), mode="fde", allow=allow)
         got[v, "top_all"] = ix.query(q, min(1000, n), mode="fde")
-    for cosine in (1, 0):
-        for key in ("all", "flt"):
-            a, b = got[0, cosine, key], got[3, cosine, key]
-            assert a.shape == (n,) and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (cosine, key)
+    for v in (3, 4):
+        for cosine in (1, 0):
+            for key in ("all", "flt"):
+                a, b = got[0, cosine, key], got[v, cosine, key]
+                assert a.shape == (n,) and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (v, cosine, key)
+        for key in ("top", "top_all"):
+            assert np.array_equal(got[0, key][1], got[v, key][1]) and np.array_equal(got[0, key][0], got[v, key][0])
     assert np.isneginf(got[3, 1, "flt"]).sum() >= np.isneginf(got[3, 1, "all"]).sum()
-    for key in ("top", "top_all"):
-        assert np.array_equal(got[0, key][1], got[3, key][1]) and np.array_equal(got[0, key][0], got[3, key][0])
     # ... and the scores are the oracle's (sample of live pages; the slab's own FDE rows)
     live = np.flatnonzero(np.isfinite(got[3, 1, "all"]))[:: max(1, n // 40)][:40]
     if live.size:

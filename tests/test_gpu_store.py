@@ -344,6 +344,45 @@ def test_library_merge_of_gathered_topk_equals_reference_merge():
         n = int((got_i >= 0).sum())
         assert n == len(wi) and got_i[:n].tolist() == wi.tolist() and out_s.cpu().numpy()[:n].tolist() == ws.tolist()
         assert np.all(got_i[n:] == -1)
+        # the one-all-gather layout (round 5): per rank ONE block {int64 ids[kk], float scores[kk]} of mv_topk_block_bytes(kk) bytes
+        bb = int(lib().mv_topk_block_bytes(kk))
+        assert bb % 16 == 0 and bb >= 12 * kk
+        blocks = np.zeros((world, bb), np.uint8)
+        for r in range(world):
+            blocks[r, : 8 * kk] = rows_i[r].view(np.uint8)
+            blocks[r, 8 * kk : 12 * kk] = rows_s[r].view(np.uint8)
+        gb = torch.tensor(blocks, device="cuda")
+        out_s2 = torch.empty(k, dtype=torch.float32, device="cuda")
+        out_i2 = torch.empty(k, dtype=torch.int64, device="cuda")
+        check(lib().mv_merge_topk_blocks(0, C.c_void_p(gb.data_ptr()), world, kk, k, C.c_void_p(out_s2.data_ptr()), C.c_void_p(out_i2.data_ptr()),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        assert torch.equal(out_i2, out_i) and torch.equal(out_s2, out_s)
+
+
+def test_gpu_sharded_searcher_step_enqueues_without_a_host_wait_and_reports_the_scan_time():
+    """GpuShardedSearcher (the per-rank step of the RCCL path) with no process group: mv_query_topk_device_async writes ids and
+    scores into the two halves of one block behind torch's current stream, mv_merge_topk_blocks merges it, the deferred stats carry
+    the scan's HIP-event time -- same top-k as MvIndex.query, query after query (alternating buffer sets)."""
+    import torch
+
+    from morphik_core_amd import sharded
+    from morphik_core_amd.index import MvIndex, synth_rows
+
+    ix = MvIndex(capacity_pages=3000, stride_rows=64, id_base=7000)
+    ix.fill_synthetic(1234, 0, 3000)
+    stats = []
+    gs = sharded.GpuShardedSearcher(ix, torch.device("cuda", 0), "float", collect_stats=stats)
+    side = torch.cuda.Stream()
+    for j in range(5):
+        q = synth_rows(4321, j, 32)
+        with torch.cuda.stream(side):  # any current stream, not only the default one
+            s, i = gs.query(q, 10)
+        side.synchronize()
+        ws, wi = ix.query(q, 10)
+        assert i.cpu().numpy().tolist() == wi.tolist() and s.cpu().numpy().tolist() == ws.tolist()
+    assert len(stats) == 5 and all(st.score_kernel_ms > 0 and st.total_device_ms >= st.score_kernel_ms for st in stats)
+    ix.close()
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])

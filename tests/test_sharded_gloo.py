@@ -62,6 +62,16 @@ def _worker(rank, world, port, n_total, k, out_q):
     for qq, (bs, bi) in zip(qs, batch):
         ss, si = searcher.query(qq, k)
         assert bi.tolist() == si.tolist() and bs.tolist() == ss.tolist()
+    # the host-memory step bench.py runs under gloo (ONE packed all-gather into a preallocated buffer, numpy merge): the same answer,
+    # padded to exactly k entries with (-inf, -1)
+    host = sharded.HostShardedSearcher(ix, mode="float")
+    for qq in [q] + qs:
+        hs, hi_ = host.query(qq, k)
+        ss, si = searcher.query(qq, k)
+        assert hs.shape == (k,) and hi_.shape == (k,)
+        keep = hi_ >= 0
+        assert hi_[keep].tolist() == si.tolist() and hs[keep].tolist() == ss.tolist()
+        assert np.isneginf(hs[~keep]).all() and (hi_[~keep] == -1).all()
     out_q.put((rank, s.numpy().tolist(), i.numpy().tolist()))
     dist.barrier()
     dist.destroy_process_group()
