@@ -1043,6 +1043,19 @@ def main():
         t = torch.tensor([(time.perf_counter() - t0) / args.steps * 1e3], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         local_only_ms = float(t.item())
+    exchange_ms = None
+    if dist_on and two_stage is None:  # ... and the exchange BY ITSELF: the all-gather of the k pairs + the merge, no scan in front of it
+        ex = fast_searcher if fast_searcher is not None else host_searcher
+        for i in range(3):
+            ex.exchange_only(K)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            ex.exchange_only(K)
+        fence()
+        t = torch.tensor([(time.perf_counter() - t0) / args.steps * 1e3], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exchange_ms = float(t.item())
 
     # ---- roofline of the dominant kernel (the page scan), from HIP events recorded in the timed region
     kms = np.array([s.score_kernel_ms for s in stats[: args.steps] if s is not None and s.score_kernel_ms > 0])  # the timed steps' launches
@@ -1177,7 +1190,10 @@ def main():
                 "collective_backend": (args.backend if dist_on else None),
                 "rccl_ranks": (dist.get_world_size() if (dist_on and args.backend == "nccl") else 0),
                 "local_scan_and_topk_ms_per_step": None if local_only_ms is None else round(local_only_ms, 4),
-                "collective_and_merge_ms_per_step": None if local_only_ms is None else round(ms_per_step - local_only_ms, 4),
+                # the exchange timed by itself (all-gather of k pairs per rank + merge, K back-to-back rounds); the difference of the two
+                # loops beside it also carries the ranks' waiting for each other (large when they share one GPU)
+                "collective_and_merge_ms_per_step": None if exchange_ms is None else round(exchange_ms, 4),
+                "step_minus_local_ms_per_step": None if local_only_ms is None else round(ms_per_step - local_only_ms, 4),
             },
             "recall_at_10": recall10,
             "max_rel_score_err_vs_oracle": max_rel,

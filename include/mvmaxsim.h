@@ -277,7 +277,8 @@ MV_API int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_
 /* The enqueue-only form WITH timings (one rank's step of a row-sharded search: the scan, then the all-gather and the merge
  * behind it on `stream`, nothing of which should wait for the host): as mv_query_topk_device with a non-NULL stream, but
  * `stats` (non-NULL) receives only the accounting fields now; the HIP-event timings of THIS query are filled in by
- * mv_query_stats_finish(ix, stats) -- which waits for the scan's events -- called any time before the next query on `ix`. */
+ * mv_query_stats_finish(ix, stats) -- which waits for the scan's events -- called any time before the next query on `ix`.
+ * stream = NULL names the legacy default stream here (the call still only enqueues). */
 MV_API int mv_query_topk_device_async(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int32_t k, int mode,
                                       const uint32_t* allow_bits, int64_t n_allow_words, float* d_out_scores,
                                       int64_t* d_out_ids, void* stream, mv_query_stats* stats);
@@ -409,7 +410,9 @@ enum { MV_CAL_READ_NT = 1, MV_CAL_MFMA_BF16 = 2, MV_CAL_READ_LDSDMA = 3, MV_CAL_
         * (what the kernel sustains without the host gaps between requests): the register form / the nt LDS-DMA ring */
        MV_CAL_FDE_SCAN_REGS = 14, MV_CAL_FDE_SCAN_LDSDMA = 15, MV_CAL_FDE_SCAN_LDSDMA_STATIC = 16 /* ... with a static chunk order */,
        MV_CAL_FDE_SCAN_STREAM = 17 /* the LDS-DMA form's transport alone (no read-back, no arithmetic) */,
-       MV_CAL_READ_LDSDMA_20K = 18 /* MV_CAL_READ_LDSDMA over 20 KiB pages: one fresh workgroup per FDE-row-sized page */ };
+       MV_CAL_READ_LDSDMA_20K = 18 /* MV_CAL_READ_LDSDMA over 20 KiB pages: one fresh workgroup per FDE-row-sized page */,
+       MV_CAL_FDE_SCAN_ROWS = 20 /* the FDE coarse scan, one fresh workgroup per row (MV_OPT_FDE_SCAN_VARIANT 5), back to back */,
+       MV_CAL_STREAM_PROBE = 19 /* the ring transport with the SHAPE of the work taken from MV_PROBE_CT / _OWN / _SCHED / _BPC (csrc/mv_synth.hip) */ };
 MV_API int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out);
 
 /* ---------------------------------------------------------------------------------------------------------------

@@ -1512,7 +1512,9 @@ int mv_internal_query_common(mv_index* ix, const void* q, int q_dtype, int32_t n
   if (out_n) *out_n = 0;
   const bool to_device = d_scores_out != nullptr;
   if (to_device && k > kTopkMaxDeviceK) { set_error("device-output top-k supports k <= %d", kTopkMaxDeviceK); return MV_ERR_INVALID; }
-  if (user_stream) {  // order our stream behind the caller's
+  const bool ordered = user_stream != nullptr;  // kNullStreamTag: ordered against the null stream itself
+  if (user_stream == kNullStreamTag) user_stream = nullptr;
+  if (ordered) {  // order our stream behind the caller's
     MV_HIP(hipEventRecord(ix->ev[3], (hipStream_t)user_stream));
     MV_HIP(hipStreamWaitEvent(ix->stream, ix->ev[3], 0));
   }
@@ -1549,7 +1551,7 @@ int mv_internal_query_common(mv_index* ix, const void* q, int q_dtype, int32_t n
     if (rc) return rc;
     MV_HIP(hipEventRecord(ix->ev[2], ix->stream));
     if (to_device) {
-      if (user_stream) {  // caller's stream waits for our result
+      if (ordered) {  // caller's stream waits for our result
         MV_HIP(hipStreamWaitEvent((hipStream_t)user_stream, ix->ev[2], 0));
       } else {
         MV_HIP(hipStreamSynchronize(ix->stream));
@@ -1605,7 +1607,8 @@ int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_t n_q_r
 int mv_query_topk_device_async(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int32_t k, int mode,
                                const uint32_t* allow_bits, int64_t n_allow_words, float* d_out_scores, int64_t* d_out_ids,
                                void* stream, mv_query_stats* stats) {
-  if (k < 1 || !d_out_scores || !d_out_ids || !stream || !stats) { set_error("mv_query_topk_device_async: k >= 1, device buffers, a stream and a stats record required"); return MV_ERR_INVALID; }
+  if (k < 1 || !d_out_scores || !d_out_ids || !stats) { set_error("mv_query_topk_device_async: k >= 1, device buffers and a stats record required"); return MV_ERR_INVALID; }
+  if (!stream) stream = kNullStreamTag;  // 0 names the default stream here (torch's default stream is the null stream): order against it, do not block
   return mv_internal_query_common(ix, q, q_dtype, n_q_rows, k, mode, allow_bits, n_allow_words, nullptr, nullptr, nullptr, d_out_scores,
                                   d_out_ids, stream, stats, /*defer_stats=*/1);
 }
@@ -2481,7 +2484,35 @@ int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out
       *out = ms > 0 ? (double)n_rows * 20480 * (piece > 8192 ? 1.2 : 1.0) * iters / (ms * 1e-3) / 1e9 : 0.0;  // GB/s (whole rows: 3 x 8 KiB read per 20 KiB row)
     }
     if (buf) (void)hipFree(buf);
-  } else if (what == MV_CAL_FDE_SCAN_REGS || what == MV_CAL_FDE_SCAN_LDSDMA || what == MV_CAL_FDE_SCAN_LDSDMA_STATIC || what == MV_CAL_FDE_SCAN_STREAM) {
+  } else if (what == MV_CAL_STREAM_PROBE) {
+    // shape of the work from the environment (read per call: tools/stream_structure_probe.py sweeps it inside one process)
+    auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+    const int ct = env_int("MV_PROBE_CT", 64), own = env_int("MV_PROBE_OWN", 0), sched = env_int("MV_PROBE_SCHED", 0), bpc = env_int("MV_PROBE_BPC", 2);
+    const int qload = env_int("MV_PROBE_QLOAD", 0);
+    void* buf = nullptr;
+    uint32_t* work = nullptr;
+    float *qv = nullptr, *uo = nullptr;
+    const int64_t unit_bytes = (int64_t)ct * (own == 3 ? 20480 : 4096);
+    if (qload && (hipMalloc((void**)&qv, 40960) != hipSuccess || hipMalloc((void**)&uo, (size_t)(bytes / unit_bytes + 1) * 4) != hipSuccess)) { set_error("calibrate: out of memory"); rc = MV_ERR_NOMEM; }
+    if (qv) (void)hipMemset(qv, 0, 40960);
+    if (bytes < (1 << 24)) { set_error("calibrate: need >= 16 MiB"); rc = MV_ERR_INVALID; }
+    if (!rc && (hipMalloc(&buf, (size_t)bytes) != hipSuccess || hipMalloc((void**)&work, 64) != hipSuccess)) { set_error("calibrate: out of memory"); rc = MV_ERR_NOMEM; }
+    if (!rc) {
+      (void)hipMemset(buf, 1, (size_t)bytes);
+      (void)hipMemset(work, 0, 64);
+      rc = launch_stream_probe(buf, bytes, ct, own, sched, bpc, work, sink, nullptr, qv, uo);
+      (void)hipEventRecord(a_ev, nullptr);
+      for (int i = 0; i < iters && !rc; ++i) rc = launch_stream_probe(buf, bytes, ct, own, sched, bpc, work, sink, nullptr, qv, uo);
+      (void)hipEventRecord(b_ev, nullptr);
+      (void)hipEventSynchronize(b_ev);
+      (void)hipEventElapsedTime(&ms, a_ev, b_ev);
+      *out = ms > 0 ? (double)(bytes / unit_bytes * unit_bytes) * iters / (ms * 1e-3) / 1e9 : 0.0;  // GB/s
+    }
+    if (buf) (void)hipFree(buf);
+    if (work) (void)hipFree(work);
+    if (qv) (void)hipFree(qv);
+    if (uo) (void)hipFree(uo);
+  } else if (what == MV_CAL_FDE_SCAN_REGS || what == MV_CAL_FDE_SCAN_LDSDMA || what == MV_CAL_FDE_SCAN_LDSDMA_STATIC || what == MV_CAL_FDE_SCAN_STREAM || what == MV_CAL_FDE_SCAN_ROWS) {
     // the single-query FDE coarse scan itself (10 240-d rows, cosine on, no filter), `iters` launches back to back: what the
     // kernel sustains without the host gaps between requests (variant 0: plain nt loads; variant 3: nt LDS-DMA ring)
     const int64_t od = 10240, n = bytes / (od * 2);
@@ -2497,7 +2528,7 @@ int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out
       FdeScanArgs a{};
       a.fde = (const uint16_t*)buf; a.inv_norm = inv; a.q = qv; a.scores = sc; a.n = n; a.out_dim = od;
       a.work = (uint32_t*)inv;  // zeros; inv[0..1] are re-armed by every launch (page 0 / 1 score 0 either way: q = 0)
-      const int v = what == MV_CAL_FDE_SCAN_REGS ? 0 : what == MV_CAL_FDE_SCAN_LDSDMA_STATIC ? 4 : what == MV_CAL_FDE_SCAN_STREAM ? 5 : 3;
+      const int v = what == MV_CAL_FDE_SCAN_REGS ? 0 : what == MV_CAL_FDE_SCAN_LDSDMA_STATIC ? 4 : what == MV_CAL_FDE_SCAN_STREAM ? 9 : what == MV_CAL_FDE_SCAN_ROWS ? 5 : 3;
       rc = launch_fde_scan(a, v, nullptr);
       (void)hipEventRecord(a_ev, nullptr);
       for (int i = 0; i < iters && !rc; ++i) rc = launch_fde_scan(a, v, nullptr);

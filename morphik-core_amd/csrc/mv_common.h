@@ -297,6 +297,8 @@ int launch_filter_compact(const int32_t* d_doc_ord, const uint32_t* d_allow, int
 int launch_f32_to_bf16(const float* d_in, uint16_t* d_out, int64_t n, hipStream_t s);
 int launch_read_bw(const void* d_buf, int64_t bytes, float* d_sink, hipStream_t s);
 int launch_read_bw_nt(const void* d_buf, int64_t bytes, float* d_sink, hipStream_t s);  // contiguous 16 KiB pieces, nt loads
+int launch_stream_probe(const void* d_buf, int64_t bytes, int ct, int own, int sched, int blocks_per_cu, uint32_t* d_work, float* d_sink, hipStream_t s,
+                        const float* d_q = nullptr, float* d_unit_out = nullptr);  // see mv_synth.hip
 int launch_read_bw_strided(const void* d_buf, int64_t n_rows, int piece, float* d_sink, hipStream_t s);  // [rows][20 480 B], `piece` bytes per row and step
 int launch_mfma_peak(int blocks, int iters, int shape, float* d_sink, hipStream_t s);   // per iteration per wave: shape 0 = 8 x 16x16x32, 1 = 4 x 32x32x16 bf16 MFMA
 // scatter ragged bf16/f32 rows into the fixed-stride slab (zero-filling the tail of each page slot);

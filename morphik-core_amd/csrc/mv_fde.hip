@@ -911,8 +911,12 @@ struct ScanArgs {
 
 // Persistent waves: each lane keeps its slice of the query FDE in registers (ITERS x 8 floats) and
 // streams pages; one page = ITERS coalesced 1 KiB wave loads.  out_dim = ITERS * 512.
-template <int ITERS>
+// The cross-check of the default form (fde_scan_rows_kernel): the SAME arithmetic order -- the row in WPR parts of ITERS / WPR
+// chunks, one accumulator and one xor butterfly per part, parts summed pairwise -- on plain nt loads by one wave per page.
+template <int ITERS, int WPR>
 __global__ __launch_bounds__(256) void fde_scan_kernel(ScanArgs a) {
+  constexpr int CPW = ITERS / WPR;
+  static_assert(ITERS % WPR == 0 && (WPR == 2 || WPR == 4), "part shape");
   __shared__ uint32_t h0[2048];  // per-block share of the selection's first histogram (persistent blocks: zeroed / flushed once)
   if (a.hist0) {
     for (int i = threadIdx.x; i < 2048; i += 256) h0[i] = 0;
@@ -941,21 +945,28 @@ __global__ __launch_bounds__(256) void fde_scan_kernel(ScanArgs a) {
     }
     using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
     const u32x4* row = reinterpret_cast<const u32x4*>(a.fde + p * (int64_t)a.out_dim) + lane;
-    float acc = 0.0f;
+    float part[WPR];
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-      const u32x4 v = __builtin_nontemporal_load(row + it * 64);
-      const uint32_t w[4] = {v[0], v[1], v[2], v[3]};
+    for (int w = 0; w < WPR; ++w) {
+      float acc = 0.0f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        acc = __builtin_fmaf(__uint_as_float(w[k] << 16), q[it][2 * k], acc);
-        acc = __builtin_fmaf(__uint_as_float(w[k] & 0xffff0000u), q[it][2 * k + 1], acc);
+      for (int c = 0; c < CPW; ++c) {
+        const int it = w * CPW + c;
+        const u32x4 v = __builtin_nontemporal_load(row + it * 64);
+        const uint32_t x[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          acc = __builtin_fmaf(__uint_as_float(x[k] << 16), q[it][2 * k], acc);
+          acc = __builtin_fmaf(__uint_as_float(x[k] & 0xffff0000u), q[it][2 * k + 1], acc);
+        }
       }
-    }
 #pragma unroll
-    for (int s = 1; s < 64; s <<= 1) acc += __shfl_xor(acc, s);
+      for (int s = 1; s < 64; s <<= 1) acc += __shfl_xor(acc, s);
+      part[w] = acc;
+    }
+    const float total = WPR == 4 ? (part[0] + part[1]) + (part[2] + part[3]) : part[0] + part[1];
     if (lane == 0) {
-      const float sc = a.inv_norm ? acc * a.inv_norm[p] : acc;
+      const float sc = a.inv_norm ? total * a.inv_norm[p] : total;
       a.scores[p] = sc;
       if (a.hist0) {
         const float s0 = sc + 0.0f;
@@ -1171,6 +1182,114 @@ __global__ __launch_bounds__(256) void fde_scan_ldsdma_kernel(ScanArgs a, int pp
     __syncthreads();
     for (int i = threadIdx.x; i < 2048; i += 256)
       if (h0[i]) atomicAdd(&a.hist0[i], h0[i]);
+  }
+}
+
+// ---- round 5, second form: ONE FRESH WORKGROUP PER ROW.
+// The transport probe (csrc/mv_synth.hip: stream_probe_kernel; profiles/r5/stream_structure_*.json) says what shape of work the nt
+// LDS-DMA streams fastest over a 25.6 GB FDE slab: fresh workgroups of ONE 20 KiB row each, handed out by the dispatcher in row
+// order -- 7.18 TB/s, the float scan's rate -- against 6.75-6.95 for every persistent form (claimed or static, wave- or
+// workgroup-owned chunks) and for fresh workgroups over larger units.  So: the row is split over the workgroup's waves (WPR waves
+// per row, CPW chunks of 1 KiB each; 4 x 5 at 10 240 dims), every wave needs only ITS slice of the query FDE (8 CPW floats per
+// lane: 40 VGPRs, read from L2 -- the price of fresh workgroups, 2 bytes of L2 traffic per byte of HBM), and up to eight such
+// workgroups share a CU (5 KiB of LDS and <= 64 VGPRs each).  Per row: DMA issue -> query slice -> filter / norm -> one wait ->
+// CPW x (ds_read_b128, 8 FMA) -> xor butterfly -> partial to LDS -> barrier -> ((p0 + p1) + (p2 + p3)) / |d|.
+// Arithmetic order == fde_scan_kernel's (lane l: elements [512 c + 8 l, +8) of chunks c of ONE part, sequentially; butterfly per
+// part; parts summed pairwise): scores are bit-identical across the two.
+template <int CPW, int WPR>  // out_dim = 512 CPW WPR; CPW <= 5, WPR in {2, 4}; rows per workgroup = 4 / WPR
+__global__ __launch_bounds__(256) void fde_scan_rows_kernel(ScanArgs a) {
+  static_assert(CPW >= 1 && CPW <= 5 && (WPR == 2 || WPR == 4), "row shape");
+  constexpr int RPB = 4 / WPR;
+  // one __shared__ object only (see fde_scan_ldsdma_kernel)
+  __shared__ __attribute__((aligned(16))) char lds[4 * CPW * 1024 + 64];
+  float* part_sum = reinterpret_cast<float*>(lds + 4 * CPW * 1024);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int part = wave % WPR;
+  const int64_t row = (int64_t)blockIdx.x * RPB + wave / WPR;
+  const bool in_range = row < a.n;
+  bool masked = !in_range;
+  if (in_range && a.doc_ord) {
+    const int32_t o = a.doc_ord[row];
+    masked = o < 0 || (a.allow && ((int64_t)o >= a.n_allow_bits || ((a.allow[o >> 5] >> (o & 31)) & 1u) == 0u));
+  }
+  char* slot = lds + wave * (CPW * 1024);
+  const int voff = lane * 16;
+  if (!masked) {
+    const char* tp = reinterpret_cast<const char*>(a.fde) + (size_t)row * (size_t)a.out_dim * 2 + (size_t)part * (CPW * 1024);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
+    const uint64_t tpu = ((uint64_t)hi << 32) | lo;
+    const uint32_t m0a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)slot);
+    uint32_t keep;
+    // the instruction offset (12 bits here) walks BOTH addresses; the fifth chunk takes a second M0 and a +4 KiB lane offset
+    if (CPW == 5) {
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %2\n\t"
+          "s_nop 4\n\t"
+          "global_load_lds_dwordx4 %1, %4 nt\n\t"
+          "global_load_lds_dwordx4 %1, %4 offset:1024 nt\n\t"
+          "global_load_lds_dwordx4 %1, %4 offset:2048 nt\n\t"
+          "global_load_lds_dwordx4 %1, %4 offset:3072 nt\n\t"
+          "s_mov_b32 m0, %3\n\t"
+          "s_nop 4\n\t"
+          "global_load_lds_dwordx4 %5, %4 nt\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(voff), "s"(m0a), "s"(m0a + 4096u), "s"(tpu), "v"(voff + 4096)
+          : "memory");
+    } else {
+#pragma unroll
+      for (int c = 0; c < CPW; ++c) {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 4\n\t"
+            "global_load_lds_dwordx4 %1, %3 nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff + c * 1024), "s"(m0a + (uint32_t)(c * 1024)), "s"(tpu)
+            : "memory");
+      }
+    }
+  }
+  // this wave's slice of the query FDE (issued behind the DMAs: they are older in the vmcnt order, so the compiler's own counted
+  // waits for these loads cover them too)
+  float q[CPW][8];
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    const float* qp = a.q + (size_t)(part * CPW + c) * 512 + lane * 8;
+    const float4 lo4 = *reinterpret_cast<const float4*>(qp);
+    const float4 hi4 = *reinterpret_cast<const float4*>(qp + 4);
+    q[c][0] = lo4.x; q[c][1] = lo4.y; q[c][2] = lo4.z; q[c][3] = lo4.w;
+    q[c][4] = hi4.x; q[c][5] = hi4.y; q[c][6] = hi4.z; q[c][7] = hi4.w;
+  }
+  float inv = 1.0f;
+  if (!masked && a.inv_norm && part == 0) inv = a.inv_norm[row];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMAs, query slice, norm: everything this row needs has landed
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+  float acc = 0.0f;
+  if (!masked) {
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(slot + c * 1024 + voff);
+      const uint32_t w[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc = __builtin_fmaf(__uint_as_float(w[k] << 16), q[c][2 * k], acc);
+        acc = __builtin_fmaf(__uint_as_float(w[k] & 0xffff0000u), q[c][2 * k + 1], acc);
+      }
+    }
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) acc += __shfl_xor(acc, s);
+  }
+  if (lane == 0) part_sum[wave] = acc;
+  __syncthreads();
+  if (part == 0 && lane == 0 && in_range) {
+    const float* p = part_sum + wave;
+    const float t = WPR == 4 ? (p[0] + p[1]) + (p[2] + p[3]) : p[0] + p[1];
+    a.scores[row] = masked ? -INFINITY : (a.inv_norm ? t * inv : t);
   }
 }
 
@@ -2746,7 +2865,23 @@ int launch_fde_scan(const FdeScanArgs& a, int variant, hipStream_t s) {
   ScanArgs k{a.fde, a.inv_norm, a.doc_ord, a.allow, a.n_allow_bits, a.q, a.scores, a.n, (int32_t)a.out_dim, nullptr};
   const int grid = 256 * 2;  // 2 blocks/CU x 4 waves, persistent
   if (variant < 0) variant = 3;  // round 5: nt LDS-DMA ring (0 = the same arithmetic on plain nt loads: 6.8 TB/s)
-  if (variant == 5 && a.out_dim == 10240) {  // calibration: the LDS-DMA form's transport alone
+  if (variant == 5 && (a.out_dim == 10240 || a.out_dim == 5120)) {  // one fresh workgroup per row
+    constexpr int64_t kRowsPerLaunch = (int64_t)1 << 23;  // a launch's work-item count must stay below 2^32
+    for (int64_t off = 0; off < a.n; off += kRowsPerLaunch) {
+      ScanArgs c = k;
+      c.n = std::min(kRowsPerLaunch, a.n - off);
+      c.fde = k.fde + (size_t)off * (size_t)a.out_dim;
+      c.scores = k.scores + off;
+      if (k.inv_norm) c.inv_norm = k.inv_norm + off;
+      if (k.doc_ord) c.doc_ord = k.doc_ord + off;
+      if (a.out_dim == 10240) hipLaunchKernelGGL((fde_scan_rows_kernel<5, 4>), dim3((unsigned)c.n), dim3(256), 0, s, c);
+      else hipLaunchKernelGGL((fde_scan_rows_kernel<5, 2>), dim3((unsigned)((c.n + 1) / 2)), dim3(256), 0, s, c);
+    }
+    MV_HIP(hipGetLastError());
+    return MV_OK;
+  }
+  if (variant == 5) variant = 0;
+  if (variant == 9 && a.out_dim == 10240) {  // calibration: the LDS-DMA form's transport alone
     int g, ppw;
     k.work = a.work;
     fde_ldsdma_shape(a.n, k.work != nullptr, &g, &ppw);
@@ -2782,10 +2917,10 @@ int launch_fde_scan(const FdeScanArgs& a, int variant, hipStream_t s) {
     if (rc) return rc;
   } else if (a.out_dim == 10240) {
     k.hist0 = a.hist0;
-    hipLaunchKernelGGL((fde_scan_kernel<20>), dim3(grid), dim3(256), 0, s, k);
+    hipLaunchKernelGGL((fde_scan_kernel<20, 4>), dim3(grid), dim3(256), 0, s, k);
   } else if (a.out_dim == 5120) {
     k.hist0 = a.hist0;
-    hipLaunchKernelGGL((fde_scan_kernel<10>), dim3(grid), dim3(256), 0, s, k);
+    hipLaunchKernelGGL((fde_scan_kernel<10, 2>), dim3(grid), dim3(256), 0, s, k);
   } else {
     if (a.n > ((int64_t)1 << 25)) { set_error("generic FDE scan: more than 2^25 pages per launch is not supported"); return MV_ERR_INVALID; }
     hipLaunchKernelGGL(fde_scan_generic_kernel, dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, s, k);

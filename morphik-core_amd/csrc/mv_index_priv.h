@@ -219,6 +219,8 @@ RerankPlan rerank_plan(const mv_index* ix, int mode, int64_t n_list, int32_t k, 
 // -1 (skipped by the rerank kernels).  The list keeps its order, so pad lengths and the tie rule (by list position) are untouched.
 int launch_keep_selected(const int64_t* d_pos, int64_t pos_stride, int n_sel, int32_t* d_cand, int64_t cand_stride, int n, int nb, hipStream_t s);
 int finish_stats(mv_index* ix, mv_query_stats* st, bool had_topk);
+// user_stream value of mv_internal_query_common meaning "the NULL (default) stream, ordered against -- not `no stream, block`"
+static void* const kNullStreamTag = reinterpret_cast<void*>(~(uintptr_t)0);
 
 }  // namespace mv
 

@@ -323,6 +323,160 @@ __global__ __launch_bounds__(256) void read_bw_dma_kernel(const char* buf, int64
   if (reinterpret_cast<const uint32_t*>(lds)[threadIdx.x] == 0x9e3779b9u) *sink = 1.0f;
 }
 
+// Transport-STRUCTURE probe (round 5, MV_CAL_STREAM_PROBE): 4-wave workgroups stream work units of `ct` 4 KiB tiles through
+// wave-private nt LDS-DMA rings (4 slots, nothing read back) -- the float scan's and the FDE scan's transport with the shape of the
+// work as the only variable:
+//   own   0: a unit belongs to a WORKGROUP, tiles interleaved over its waves (w, w+4, ...: 16 KiB bursts)   [float scan]
+//         1: a unit belongs to a workgroup, every wave a contiguous quarter
+//         2: a unit belongs to ONE WAVE (four independent streams per workgroup)                            [FDE scan, round 5]
+//   sched 0: one fresh workgroup per unit (own 2: per four units), handed out by the dispatcher
+//         1: persistent workgroups, static order      2: persistent, units claimed from a device counter
+// The ring drains at the end of every unit (as the scans' do at a page / chunk end).
+//   own   3: a unit = `ct` ROWS of 20 KiB; wave w streams the w-th 5 KiB quarter of every row (5 DMAs of 1 KiB per row and wave, ring of
+//            3 rows): the workgroup reads whole rows                                                            [FDE scan, block per row]
+//   qload 1: every workgroup first loads 40 KiB from `qbuf` into registers (10 KiB per wave), as a scan that keeps a slice of the
+//            query FDE per wave would, and stores one float per unit
+__global__ __launch_bounds__(256) void stream_probe_kernel(const char* base, int64_t n_units, int ct, int own, int sched, uint32_t* work, float* sink,
+                                                           const float* qbuf, float* unit_out) {
+  constexpr int D = 4;
+  __shared__ __attribute__((aligned(16))) char lds[4 * D * 4096 + 64];
+  uint32_t* bcast = reinterpret_cast<uint32_t*>(lds + 4 * D * 4096);
+  float qsum = 0.f;
+  if (qbuf) {
+    const float4* qp = reinterpret_cast<const float4*>(qbuf) + (threadIdx.x >> 6) * 640 + (threadIdx.x & 63);
+    float4 v[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) v[i] = qp[i * 64];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) qsum += v[i].x + v[i].w;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* ring = lds + wave * (D * 4096);
+  const int voff = lane * 16;
+  const int64_t stride_units = own == 2 ? (int64_t)gridDim.x * 4 : (int64_t)gridDim.x;
+  int64_t u = own == 2 ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
+  for (int round = 0;; ++round, u += stride_units) {
+    if (sched == 2) {
+      if (own == 2) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(work, 1u);
+        u = (int64_t)__builtin_amdgcn_readfirstlane(t);
+      } else {
+        __syncthreads();  // the previous round's readers of bcast are done
+        if (threadIdx.x == 0) *bcast = atomicAdd(work, 1u);
+        __syncthreads();
+        u = (int64_t)*bcast;
+      }
+    } else if (sched == 0 && round > 0) {
+      break;
+    }
+    if (u >= n_units) break;
+    if (own == 3) {  // rows of 20 KiB, quarters of 5 KiB: slot r % 3 of this wave's 15 KiB ring
+      const char* rb = base + (size_t)u * (size_t)ct * 20480 + wave * 5120;
+      auto issue_row = [&](int r) {
+        const char* tp = rb + (size_t)r * 20480;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
+        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
+        const uint64_t tpu = ((uint64_t)hi << 32) | lo;
+        const uint32_t slot = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + (r % 3) * 5120));
+        uint32_t keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 4\n\t"
+            "global_load_lds_dwordx4 %1, %4 nt\n\t"
+            "global_load_lds_dwordx4 %1, %4 offset:1024 nt\n\t"
+            "global_load_lds_dwordx4 %1, %4 offset:2048 nt\n\t"
+            "global_load_lds_dwordx4 %1, %4 offset:3072 nt\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 4\n\t"
+            "global_load_lds_dwordx4 %5, %4 nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(slot), "s"(slot + 4096u), "s"(tpu), "v"(voff + 4096)
+            : "memory");
+      };
+      for (int r = 0; r < 2; ++r)
+        if (r < ct) issue_row(r);
+      for (int r = 0; r < ct; ++r) {
+        if (r + 2 < ct) {
+          issue_row(r + 2);
+          asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        } else if (r + 1 < ct) {
+          asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      if (unit_out && threadIdx.x == 0) unit_out[u] = qsum;
+      continue;
+    }
+    const char* ub = base + (size_t)u * (size_t)ct * 4096;
+    int t0 = 0, tstep = 1, ntw = ct;
+    if (own == 0) { t0 = wave; tstep = 4; ntw = (ct - wave + 3) / 4; }
+    else if (own == 1) { const int tq = (ct + 3) / 4; t0 = wave * tq; ntw = max(0, min(tq, ct - t0)); }
+    auto issue = [&](int it) {
+      const char* tp = ub + (size_t)(t0 + it * tstep) * 4096;
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
+      const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
+      const uint64_t tpu = ((uint64_t)hi << 32) | lo;
+      const uint32_t slot = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + (it % D) * 4096));
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %2\n\t"
+          "s_nop 4\n\t"
+          "global_load_lds_dwordx4 %1, %3 nt\n\t"
+          "global_load_lds_dwordx4 %1, %3 offset:1024 nt\n\t"
+          "global_load_lds_dwordx4 %1, %3 offset:2048 nt\n\t"
+          "global_load_lds_dwordx4 %1, %3 offset:3072 nt\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(voff), "s"(slot), "s"(tpu)
+          : "memory");
+    };
+    for (int i = 0; i < D - 1; ++i)
+      if (i < ntw) issue(i);
+    for (int it = 0; it < ntw; ++it) {
+      if (it + D - 1 < ntw) {
+        issue(it + D - 1);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      } else {
+        const int left = ntw - 1 - it;
+        if (left >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (left == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+    if (unit_out && lane == 0 && (own == 2 || wave == 0)) unit_out[u] = qsum;
+  }
+  if (sched == 2 && lane == 0 && (own == 2 || wave == 0)) {  // the last claimer re-arms the counters
+    const uint32_t total = own == 2 ? gridDim.x * 4 : gridDim.x;
+    const uint32_t done = atomicAdd(work + 1, 1u);
+    if (done == total - 1u) {
+      __threadfence();
+      work[0] = 0u;
+      work[1] = 0u;
+    }
+  }
+  __syncthreads();
+  if (reinterpret_cast<const uint32_t*>(lds)[threadIdx.x] == 0x9e3779b9u) *sink = 1.0f;
+}
+
+int launch_stream_probe(const void* d_buf, int64_t bytes, int ct, int own, int sched, int blocks_per_cu, uint32_t* d_work, float* d_sink, hipStream_t s,
+                        const float* d_q, float* d_unit_out) {
+  if (ct < 1 || own < 0 || own > 3 || sched < 0 || sched > 2) { set_error("stream probe: bad shape"); return MV_ERR_INVALID; }
+  const int64_t n_units = bytes / ((int64_t)ct * (own == 3 ? 20480 : 4096));
+  if (n_units < 1) { set_error("stream probe: buffer smaller than one unit"); return MV_ERR_INVALID; }
+  const int64_t blocks_needed = own == 2 ? (n_units + 3) / 4 : n_units;
+  const int64_t persistent = 256LL * (blocks_per_cu > 0 ? blocks_per_cu : 2);
+  const int64_t grid = sched == 0 ? blocks_needed : std::min(blocks_needed, persistent);
+  hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)grid), dim3(256), 0, s, reinterpret_cast<const char*>(d_buf), n_units, ct, own, sched, d_work, d_sink, d_q, d_unit_out);
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
 int launch_read_bw_strided(const void* d_buf, int64_t n_rows, int piece, float* d_sink, hipStream_t s) {
   const char* b = reinterpret_cast<const char*>(d_buf);
   switch (piece) {

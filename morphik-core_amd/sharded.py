@@ -193,6 +193,24 @@ class GpuShardedSearcher:
             self.stats.append(self.index.finish_stats(pending))
         return os_, oi
 
+    def exchange_only(self, k: int):
+        """Steps 2 and 3 alone on the block of the last query(k): what the exchange adds to a step, measured by itself."""
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+
+        from ._lib import check
+
+        mine, _ps, _pi, gathered, os_, oi = self._bufs[(k, self._flip)]
+        if dist.is_initialized():
+            dist.all_gather_into_tensor(gathered, mine, group=self.group)
+        else:
+            gathered = mine
+        check(self._lib.mv_merge_topk_blocks(self.index.device, C.c_void_p(gathered.data_ptr()), self.world, k, k, C.c_void_p(os_.data_ptr()),
+                                             C.c_void_p(oi.data_ptr()), C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
+        return os_, oi
+
 
 class HostShardedSearcher:
     """The same step when the collective runs on HOST memory (gloo: the CPU tests, and N ranks sharing one GPU): the local top-k
@@ -225,6 +243,15 @@ class HostShardedSearcher:
         m[k:] = -1
         m[: len(s)] = s
         m[k : k + len(i)] = i
+        return self.exchange_only(k)
+
+    def exchange_only(self, k: int):
+        """The all-gather of the packed buffer (as the last query(k) left it) and the merge -- by themselves."""
+        import numpy as np
+        import torch.distributed as dist
+
+        mine, allb = self._bufs[k]
+        m = mine.numpy()
         if dist.is_initialized():
             dist.all_gather_into_tensor(allb, mine, group=self.group)
             g = allb.numpy().reshape(self.world, 2, k)

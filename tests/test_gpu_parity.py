@@ -819,7 +819,7 @@ def test_fde_scan_ldsdma_ring_bit_identical_to_the_register_scan(mv, n):
     allow = allow_bitmap([d for d in range(n_docs) if d % 5 != 1], n_docs)
     q = orc.synth_rows(4321, 7, 0, 32)
     got = {}
-    for v in (0, 3, 4, 3):  # (3 twice: the scan re-arms its own work counter)
+    for v in (0, 3, 4, 5, 3):  # (3 twice: the scan re-arms its own work counter)
         ix.set_option(_lib.MV_OPT_FDE_SCAN_VARIANT, v)
         for cosine in (1, 0):
             ix.set_option(_lib.MV_OPT_FDE_COSINE, cosine)
@@ -828,7 +828,7 @@ def test_fde_scan_ldsdma_ring_bit_identical_to_the_register_scan(mv, n):
         ix.set_option(_lib.MV_OPT_FDE_COSINE, 1)
         got[v, "top"] = ix.query(q, min(200, n), mode="fde", allow=allow)
         got[v, "top_all"] = ix.query(q, min(1000, n), mode="fde")
-    for v in (3, 4):
+    for v in (3, 4, 5):
         for cosine in (1, 0):
             for key in ("all", "flt"):
                 a, b = got[0, cosine, key], got[v, cosine, key]
@@ -844,6 +844,45 @@ def test_fde_scan_ldsdma_ring_bit_identical_to_the_register_scan(mv, n):
         rows = np.concatenate([ix.read_fde(int(p), 1) for p in live])
         want = orc.fde_coarse_scores(fq, orc.f32_to_bf16(rows), use_cosine=True)
         np.testing.assert_allclose(got[3, 1, "all"][live], want, rtol=2e-3, atol=2e-4)
+    ix.close()
+
+
+def test_gpu_fde_encoder_against_the_pinned_reference_fixture_or_its_stand_in(mv, tmp_path, monkeypatch):
+    """mv_fde_encode measured against tests/golden/fde.npz -- the reference extension's own document / query
+    encodings (oracle/gen_golden_fde.py) -- when that fixture exists; here, where the extension does not import, the SAME check runs
+    on a fixture the recipe writes from the oracle-backed stand-in, so the code path is exercised on the device either way.  And the
+    fixture's vectors drive the bring-your-own-FDE entry points (mv_index_import_fde / mv_query_topk_fde): planted page first."""
+    import importlib.util
+
+    from morphik_core_amd.index import fde_encode
+    from tests.test_oracle_golden import GOLDEN, ROOT, fde_pin_report
+
+    path = os.path.join(GOLDEN, "fde.npz")
+    pinned = os.path.exists(path)
+    if not pinned:
+        spec = importlib.util.spec_from_file_location("gen_golden_fde", os.path.join(ROOT, "oracle", "gen_golden_fde.py"))
+        g = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(g)
+        import tests.fake_fde_module as fm
+
+        monkeypatch.setattr(g, "find_extension", lambda: fm)
+        path = str(tmp_path / "fde.npz")
+        monkeypatch.setattr(g, "OUT", path)
+        assert g.main() == 0
+    rep = fde_pin_report(path, lambda p: fde_encode(p, is_query=False), lambda q: fde_encode(q, is_query=True))
+    print("FDE pin report (mv_fde_encode vs %s):" % ("reference extension" if pinned else "oracle stand-in"), rep)
+    if not pinned:  # against the oracle the device encoder is the parity-tested one: same partitions, fp32 summation order aside
+        assert rep["median_cosine_doc_vectors"] > 0.99999 and rep["max_abs_diff_doc"] < 1e-3
+    z = np.load(path)
+    pages, queries = z["pages"], z["queries"]
+    ix = _idx(mv, capacity_pages=pages.shape[0], stride_rows=pages.shape[1], with_fde=True)
+    ix.add([orc.f32_to_bf16(p) for p in pages])
+    ix.import_fde(0, z["doc_fde"], n_pages=pages.shape[0])
+    for j, q in enumerate(queries):
+        s, i = ix.query(orc.f32_to_bf16(q), 3, mode="fde_then_float", q_fde=z["q_fde"][j])
+        assert i[0] == 3 * j + 1
+    with pytest.raises(ValueError):
+        ix.import_fde(0, z["doc_fde"][:, :-1])  # another width is refused, not regrouped
     ix.close()
 
 

@@ -376,12 +376,19 @@ def test_gpu_sharded_searcher_step_enqueues_without_a_host_wait_and_reports_the_
     side = torch.cuda.Stream()
     for j in range(5):
         q = synth_rows(4321, j, 32)
-        with torch.cuda.stream(side):  # any current stream, not only the default one
+        with torch.cuda.stream(side):  # any current stream ...
             s, i = gs.query(q, 10)
         side.synchronize()
         ws, wi = ix.query(q, 10)
         assert i.cpu().numpy().tolist() == wi.tolist() and s.cpu().numpy().tolist() == ws.tolist()
-    assert len(stats) == 5 and all(st.score_kernel_ms > 0 and st.total_device_ms >= st.score_kernel_ms for st in stats)
+    for j in range(5, 8):  # ... and the default one (handle 0: the null stream is ordered against, the call still only enqueues)
+        q = synth_rows(4321, j, 32)
+        s, i = gs.query(q, 10)
+        gs.exchange_only(10)
+        torch.cuda.synchronize()
+        ws, wi = ix.query(q, 10)
+        assert i.cpu().numpy().tolist() == wi.tolist() and s.cpu().numpy().tolist() == ws.tolist()
+    assert len(stats) == 8 and all(st.score_kernel_ms > 0 and st.total_device_ms >= st.score_kernel_ms for st in stats)
     ix.close()
 
 

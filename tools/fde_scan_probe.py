@@ -23,15 +23,15 @@ def main():
     out_dim = ix.fde_config.output_dim
     qs = [synth_rows(4321, j, 32) for j in range(8)]
     out = {"pages": n, "label": sys.argv[2] if len(sys.argv) > 2 else "", "ppw": os.environ.get("MV_FDE_SCAN_PPW"), "blocks_per_cu": os.environ.get("MV_FDE_SCAN_BLOCKS_PER_CU")}
-    ts = {0: [], 3: [], 4: []}
+    ts = {0: [], 3: [], 4: [], 5: []}
     for rnd in range(4):
-        for v in (0, 3, 4):
+        for v in (0, 3, 4, 5):
             ix.set_option(L.MV_OPT_FDE_SCAN_VARIANT, v)
             for r in range(12):
                 _s, _i, st = ix.query(qs[r % 8], 10, mode="fde", want_stats=True)
                 if r >= 4:
                     ts[v].append(st.coarse_ms)
-    for v in (0, 3, 4):
+    for v in (0, 3, 4, 5):
         ms = float(np.median(ts[v]))
         out[f"variant_{v}"] = {"coarse_ms": round(ms, 4), "min_ms": round(float(np.min(ts[v])), 4), "GBps": round(n * out_dim * 2 / ms / 1e6, 1),
                                "frac_hbm_8TBps": round(n * out_dim * 2 / ms / 1e6 / 8000.0, 4)}

@@ -12,7 +12,7 @@ from morphik_core_amd.index import calibrate  # noqa: E402
 
 gb = float(sys.argv[1]) if len(sys.argv) > 1 else 25.6
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-whats = ("read_ldsdma", "read_ldsdma_20k", "fde_scan_stream", "fde_scan_ldsdma", "fde_scan_ldsdma_static", "fde_scan_regs", "read_nt")
+whats = ("read_ldsdma", "fde_scan_rows", "fde_scan_stream", "fde_scan_ldsdma", "fde_scan_ldsdma_static", "fde_scan_regs", "read_nt")
 b = int(gb * 1e9)
 got = {w: [] for w in whats}
 for w in whats:
