@@ -730,7 +730,7 @@ def fde_encode_block(args, device):
     n = min(args.aux_pages, 100_000)
     stride = ((args.patches + 15) // 16) * 16
     t = {}
-    for key, fde, variant in (("gen", False, None), ("two_pass", True, 4), ("one_pass_r3", True, 3), ("f32_pipe", True, 1)):
+    for key, fde, variant in (("gen", False, None), ("two_pass", True, 4), ("f32_pipe", True, 1)):
         for warm in (True, False):
             ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=True, with_fde=fde)
             if variant is not None:
@@ -741,9 +741,8 @@ def fde_encode_block(args, device):
                 t[key] = time.perf_counter() - t0
             ix.close()
     enc = max(t["two_pass"] - t["gen"], 1e-9)
-    enc_r3 = max(t["one_pass_r3"] - t["gen"], 1e-9)
     enc_f32 = max(t["f32_pipe"] - t["gen"], 1e-9)
-    us, us_r3, us_f32 = enc / n * 1e6, enc_r3 / n * 1e6, enc_f32 / n * 1e6
+    us, us_f32 = enc / n * 1e6, enc_f32 / n * 1e6
     simhash = 2.0 * args.patches * 128 * 112    # f32 MFMA flops per page as issued (7 column tiles of 16 hashes)
     ams = 2.0 * args.patches * 128 * (20 * 16)  # AMS flops per page as issued (one 16-column tile per repetition)
     onehot = 2.0 * args.patches * 32 * 16 * 20  # one-hot bucket sums as issued: rows x 32 partitions x 16 columns per repetition
@@ -758,7 +757,6 @@ def fde_encode_block(args, device):
             "bound": "the f32 matrix pipe: SQ counters (profiles/r4/pmc_fde_encode_kernels_r4.json) show it 51 % busy in the hash pass and 47 % in the "
                      "projection pass, waves waiting on LDS 0.4 % / 0.0 % of their cycles (the round-3 kernel: matrix pipes 11 % busy, 17 % of the "
                      "wave cycles behind LDS atomics) -- DESIGN.md 3.9",
-            "round3_one_pass_kernel_lds_atomics": {"us_per_page": round(us_r3, 3), "pages_per_s": round(n / enc_r3, 1)},
             "round2_kernel_f32_pipe_only": {"us_per_page": round(us_f32, 3), "pages_per_s": round(n / enc_f32, 1),
                                             "f32_mfma_TFLOPs_as_issued": round((simhash + ams) / us_f32 / 1e6, 1),
                                             "frac_f32_mfma_155TF": round((simhash + ams) / us_f32 / 1e6 / 155.0, 4)},

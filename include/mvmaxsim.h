@@ -120,18 +120,15 @@ typedef enum {
   MV_OPT_FDE_COSINE = 3,     /* 1 = rank coarse stage by cosine (TurboPuffer cosine_distance, reference), 0 = dot */
   MV_OPT_PAD_SEMANTICS = 4,  /* 0 = max over a page's own rows only; 1 = reference rerank batch rule
                                 (pad_to = longest candidate of the batch of 128 => clamp at 0) */
-  MV_OPT_BINARY_VARIANT = 5, /* sign-bit scan: 0 = popcount on the VALU, 1 = FP4 MFMA, 2/3/4 = FP4 MFMA with in-place bit operands and an
-                                8/16/4-slot ring (4 = default), 5 = persistent-stream form, 6 = four-page burst form (uniform corpora,
-                                stride % 256 == 0); all produce the same integers */
-  MV_OPT_FDE_SCAN_VARIANT = 6, /* FDE coarse scan: 3 = nt LDS-DMA ring, chunks claimed dynamically (default), 4 = the same with a static chunk
-                                * order, 0 = wave per page on plain nt loads (the same arithmetic: bit-identical scores) */
+  MV_OPT_BINARY_VARIANT = 5, /* sign-bit scan: 0 = popcount on the VALU (the independent cross-check), 4 = FP4 MFMA with in-place bit
+                                operands and a 4-slot ring (default); the same integers.  (1-3, 5, 6 lost by measurement and were
+                                removed in round 5: MV_ERR_INVALID.) */
+  MV_OPT_FDE_SCAN_VARIANT = 6, /* FDE coarse scan: 5 = row quarters through the nt LDS-DMA ring, one fresh workgroup per 16 rows (default),
+                                * 0 = one wave per row on plain nt loads (the same arithmetic order: bit-identical scores) */
   MV_OPT_BATCH_VARIANT = 7,   /* batched float scan: -1 / 0 = auto (default): page-split form (wave-private rings, no barrier) up to 128
                                  query rows in the group, row-split workgroup above; both with transposed MFMA roles (one running
-                                 max per query tile, v_max3).  3 = row-split form always, 1 = 32x32x16 MFMA / 8 waves,
-                                 2 = the round-1 two-stage pipeline (<= 384 rows); 1 and 2 are kept as cross-checks.
-                                 5 / 6 = 32x32x16 MFMA with the transposed roles (round 3): 5 = four row groups of <= 128 query
-                                 rows, 6 = two row groups of <= 256 rows at ONE wave per SIMD (query fragments in AGPRs), the two
-                                 tiles of a ring chunk split over the other two waves.
+                                 max per query tile, v_max3).  3 = row-split form always, 4 = page-split form (<= 128 rows): each is
+                                 the other's cross-check.  (1, 2, 5, 6 lost by measurement and were removed in round 5.)
                                  MV_MODE_FLOAT_FP8 batches (the batched block-scaled MFMA scan of the e4m3 slab): 7 = ONE e4m3
                                  term per query row instead of the hi + lo split (half the matrix work), 8 = query by query.
                                  MV_MODE_FP8_THEN_FLOAT batches use ONE term by default (the first stage only nominates candidates,
@@ -139,9 +136,9 @@ typedef enum {
   MV_OPT_FDE_ENCODE_VARIANT = 8, /* FDE encode of corpus pages: 4 = (default) pages that are already bf16 -- the slab -- in two passes: SimHash
                                     partitions (fp32 fmaf chains, columns in registers) to a scratch byte per (row, repetition), then the
                                     AMS projection on the bf16 matrix pipe with the bucket sums as a one-hot f32 matrix product (no LDS
-                                    atomics: a fixed summation order); 3 = the round-3 one-pass form (bucket sums through LDS float
-                                    atomics); other inputs / FDE shapes run as 1; 1 = f32-MFMA kernel, 0 = scalar kernel.  The same
-                                    partitions bit for bit in all of them */
+                                    atomics: a fixed summation order); other inputs / FDE shapes run as 1; 1 = f32-MFMA kernel, 0 = scalar
+                                    kernel (the cross-check).  The same partitions bit for bit in all of them.  (3, round 3's one-pass
+                                    form with LDS-atomic bucket sums, was removed in round 5 and runs as 1.) */
   MV_OPT_FILTER_COMPACT_PCT = 9, /* doc filter allowing < this % of the documents: compact the allowed pages first and scan
                                     only those (default 25; 0 = always mask inside the scan) */
   MV_OPT_FDE_QUERY_ENCODE_VARIANT = 11, /* FDE encode of the query (one page, latency matters): 2 = latency kernel, one block per
@@ -161,15 +158,12 @@ typedef enum {
                                     FDE rounded to bf16 (one MFMA per fragment: -13 % pass time, coarse scores within ~2e-3);
                                     3 = as 0 with one page tile per query fragment (the first form of the coarse kernel; the
                                     default walks a workgroup's tiles in pairs: same scores, half the fragment traffic);
-                                    4 = 32-page tiles, two workgroups per CU, four tiles per fragment set (same scores);
                                     5 = as 0 with the round-2 structure: the cosine rule / tombstones as a finish pass of their
                                     own (the default applies them where the scan kernel writes a tile's scores) and all three
-                                    passes of the selection (variants 3 / 4 let their finish pass pre-bin the scores for the
-                                    selection's first pass); the same results bit for bit;
-                                    6 / 7 / 8 = round-4 experiments kept as cross-checks (same scores, none faster: DESIGN 3.14):
-                                    6 = as 0 with a private DMA ring per wave (every wave fetches the 128-byte quarter of the 64 rows it
-                                    consumes: no workgroup barrier per ring slot); 7 = 32-page tiles, one workgroup per CU, a ring of
-                                    NINE slots (128 KiB in flight a CU instead of 96); 8 = the same with four slots (48 KiB) */
+                                    passes of the selection (variant 3 lets its finish pass pre-bin the scores for the
+                                    selection's first pass); the same results bit for bit.
+                                    (4, 6, 7, 8 -- 32-page tiles, private rings, deeper / shallower rings -- lost by measurement and
+                                    were removed in round 5: MV_ERR_INVALID.) */
 } mv_option;
 
 /* Bumped whenever a signature, a struct layout or an enum value of this header changes incompatibly.  A binding compares
@@ -406,13 +400,12 @@ enum { MV_CAL_READ_NT = 1, MV_CAL_MFMA_BF16 = 2, MV_CAL_READ_LDSDMA = 3, MV_CAL_
        /* ... and through the pass's own transport (non-temporal global_load_lds_dwordx4 into an LDS ring, nothing read back): 512 B /
         * 1 KiB / 2 KiB per row and step, and 128 B per row with 8 rows per instruction (the private-ring form) */
        MV_CAL_DMA_STRIDED_128 = 10, MV_CAL_DMA_STRIDED_512 = 11, MV_CAL_DMA_STRIDED_1K = 12, MV_CAL_DMA_STRIDED_2K = 13,
-       /* the single-query FDE coarse scan itself over bytes / 20 480 synthetic pages, `iters` launches back to back -> GB/s
-        * (what the kernel sustains without the host gaps between requests): the register form / the nt LDS-DMA ring */
-       MV_CAL_FDE_SCAN_REGS = 14, MV_CAL_FDE_SCAN_LDSDMA = 15, MV_CAL_FDE_SCAN_LDSDMA_STATIC = 16 /* ... with a static chunk order */,
-       MV_CAL_FDE_SCAN_STREAM = 17 /* the LDS-DMA form's transport alone (no read-back, no arithmetic) */,
-       MV_CAL_READ_LDSDMA_20K = 18 /* MV_CAL_READ_LDSDMA over 20 KiB pages: one fresh workgroup per FDE-row-sized page */,
-       MV_CAL_FDE_SCAN_ROWS = 20 /* the FDE coarse scan, one fresh workgroup per row (MV_OPT_FDE_SCAN_VARIANT 5), back to back */,
-       MV_CAL_STREAM_PROBE = 19 /* the ring transport with the SHAPE of the work taken from MV_PROBE_CT / _OWN / _SCHED / _BPC (csrc/mv_synth.hip) */ };
+       /* the single-query FDE coarse scan itself over bytes / 20 480 synthetic rows, `iters` launches back to back -> GB/s
+        * (what the kernel sustains without the host gaps between requests): the register form / the default row-quarter form */
+       MV_CAL_FDE_SCAN_REGS = 14, MV_CAL_FDE_SCAN_ROWQ = 15,
+       /* the ring transport with the SHAPE of the work taken from MV_PROBE_CT / _OWN / _SCHED / _BPC / _QLOAD (csrc/mv_synth.hip:
+        * stream_probe_kernel) -- the experiment behind the row-quarter form */
+       MV_CAL_STREAM_PROBE = 19 };
 MV_API int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out);
 
 /* ---------------------------------------------------------------------------------------------------------------

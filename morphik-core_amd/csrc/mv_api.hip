@@ -343,7 +343,6 @@ int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_wo
   s.out_dim = ix->fde_t.out_dim;
   const bool prebin = k_next > 0 && hist0_done && topk_uses_radix(n, k_next) && fde_scan_prebins(ix->fde_scan_variant, s.out_dim);
   s.hist0 = prebin ? topk_radix_hist0(ix->d_topk_ws) : nullptr;  // zero between selections (cleared by the previous one's last kernel)
-  s.work = ix->d_fde_work;  // every coarse scan of this index runs on ix->stream: one scan holds the counter at a time
   if (hist0_done) *hist0_done = prebin;
   rc = launch_fde_scan(s, ix->fde_scan_variant, ix->stream);
   if (rc) return rc;
@@ -971,7 +970,7 @@ void mv_index_destroy(mv_index* ix) {
   DeviceGuard g(ix->cfg.device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
   if (ix->w_stream) (void)hipStreamSynchronize(ix->w_stream);
-  void* ptrs[] = {ix->d_fde_work, ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
+  void* ptrs[] = {ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
                   ix->d_topk_ws, ix->d_q, ix->d_qf32, ix->d_qbits, ix->d_qpop, ix->d_qfde, ix->d_qoff, ix->d_allow, ix->d_out_s,
                   ix->d_out_id, ix->d_cand, ix->d_cand_scores, ix->d_bqf32, ix->d_bqfde, ix->d_bqimage, ix->d_btopk_ws, ix->d_bsel_s,
                   ix->d_bsel_id, ix->d_bcand, ix->d_bcand_pads, ix->d_bcand_scores, ix->d_bout_s, ix->d_bout_id, ix->d_bq8hi, ix->d_bq8lo, ix->d_bq8fac};
@@ -1041,8 +1040,6 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
     alloc((void**)&ix->fde, (size_t)cap * ix->fde_t.out_dim * 2, "FDE slab");
     alloc((void**)&ix->fde_inv_norm, (size_t)cap * 4, "FDE norms");
     alloc((void**)&ix->d_qfde, (size_t)std::max<int64_t>(ix->fde_t.out_dim, 1) * 4, "query FDE");
-    alloc((void**)&ix->d_fde_work, 64, "FDE scan work counter");
-    if (!rc && hipMemset(ix->d_fde_work, 0, 64) != hipSuccess) { set_error("hipMemset of the FDE scan work counter failed"); rc = MV_ERR_HIP; }
   }
   alloc((void**)&ix->d_n_rows, (size_t)cap * 4, "row counts");
   alloc((void**)&ix->d_doc_ord, (size_t)cap * 4, "doc ordinals");
@@ -1127,7 +1124,9 @@ int mv_index_set_option(mv_index* ix, int option, int64_t value) {
     case MV_OPT_FDE_ENCODE_VARIANT: ix->fde_encode_variant = (int)value; return MV_OK;
     case MV_OPT_FILTER_COMPACT_PCT: ix->filter_compact_pct = (int)value; return MV_OK;
     case MV_OPT_FDE_QUERY_ENCODE_VARIANT: ix->fde_query_encode_variant = (int)value; return MV_OK;
-    case MV_OPT_FDE_BATCH_VARIANT: ix->fde_batch_variant = (int)value; return MV_OK;
+    case MV_OPT_FDE_BATCH_VARIANT:
+      if (value == 4 || value > 5) { set_error("FDE batch variant %lld was removed in round 5 (0 default, 1 query by query, 2 bf16 query, 3 single tile, 5 separate finish)", (long long)value); return MV_ERR_INVALID; }
+      ix->fde_batch_variant = (int)value; return MV_OK;
     case MV_OPT_EXACT_TIER:
       if (value < 0 || value > 2) { set_error("EXACT_TIER must be 0 (HBM slab), 1 (pinned-host tier) or 2 (e4m3 slab)"); return MV_ERR_INVALID; }
       ix->exact_tier = (int)value; return MV_OK;
@@ -1894,9 +1893,6 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
     sa.q = ix->d_bqfde; sa.image = ix->d_bqimage; sa.scores = ix->d_bscores; sa.score_stride = cap; sa.n = n; sa.out_dim = out_dim; sa.n_queries = nb;
     sa.hi_only = ix->fde_batch_variant == 2;
     sa.single_tile = ix->fde_batch_variant == 3;
-    sa.half_tiles = ix->fde_batch_variant == 4;
-    sa.private_rings = ix->fde_batch_variant == 6;
-    sa.ring_slots = ix->fde_batch_variant == 7 ? 9 : (ix->fde_batch_variant == 8 ? 4 : 0);
     sa.separate_finish = ix->fde_batch_variant == 5;
     // Default: the scan kernel applies the cosine rule / tombstones itself (no finish pass) and the selection runs its three
     // vectorised passes.  Where a finish pass runs anyway (variants 3 / 4, or a dot-product index with masks) it also bins every
@@ -2126,8 +2122,8 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
   for (int32_t b = 0; b < n_queries; ++b) out_n[b] = 0;
   const int64_t n = ix->size.load(std::memory_order_acquire);  // snapshot of the published corpus
   if (n == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return MV_OK; }
-  const int group_rows = ix->batch_variant == 2 ? 384 : 512;  // variant 2: 6 row tiles per wave (pipelined kernel)
-  if (rpq > group_rows) { set_error("query of %d rows exceeds the %d-row group of batch variant %d", rpq, group_rows, ix->batch_variant); return MV_ERR_INVALID; }
+  const int group_rows = 512;
+  if (rpq > group_rows) { set_error("query of %d rows exceeds the %d-row group of the batched scan", rpq, group_rows); return MV_ERR_INVALID; }
   const int group = std::min(group_rows / rpq, 32);
   if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)kBatchQRows * kRowBytes));
   if (!ix->d_bscores) {
@@ -2442,10 +2438,9 @@ int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out
       *out = ms > 0 ? (double)(bytes / 16384 * 16384) * iters / (ms * 1e-3) / 1e9 : 0.0;  // GB/s
     }
     if (buf) (void)hipFree(buf);
-  } else if (what == MV_CAL_READ_LDSDMA || what == MV_CAL_READ_LDSDMA_20K) {
+  } else if (what == MV_CAL_READ_LDSDMA) {
     // the float scan's own transport (nt LDS-DMA ring, 4 waves per 256 KiB page) with the arithmetic removed
-    // (_20K: the same kernel over 20 KiB pages -- one FRESH workgroup per FDE-row-sized page, 5 tiles over 4 waves)
-    const int64_t page_bytes = (what == MV_CAL_READ_LDSDMA_20K ? 80 : 1024) * kRowBytes;
+    const int64_t page_bytes = 1024 * kRowBytes;
     const int64_t n = bytes / page_bytes;
     if (n < 64) { set_error("calibrate: need >= 16 MiB"); rc = MV_ERR_INVALID; }
     void* buf = nullptr;
@@ -2512,9 +2507,9 @@ int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out
     if (work) (void)hipFree(work);
     if (qv) (void)hipFree(qv);
     if (uo) (void)hipFree(uo);
-  } else if (what == MV_CAL_FDE_SCAN_REGS || what == MV_CAL_FDE_SCAN_LDSDMA || what == MV_CAL_FDE_SCAN_LDSDMA_STATIC || what == MV_CAL_FDE_SCAN_STREAM || what == MV_CAL_FDE_SCAN_ROWS) {
+  } else if (what == MV_CAL_FDE_SCAN_REGS || what == MV_CAL_FDE_SCAN_ROWQ) {
     // the single-query FDE coarse scan itself (10 240-d rows, cosine on, no filter), `iters` launches back to back: what the
-    // kernel sustains without the host gaps between requests (variant 0: plain nt loads; variant 3: nt LDS-DMA ring)
+    // kernel sustains without the host gaps between requests (variant 0: plain nt loads; variant 5: row quarters on the nt LDS-DMA ring)
     const int64_t od = 10240, n = bytes / (od * 2);
     if (n < 1024) { set_error("calibrate: need >= 21 MB"); rc = MV_ERR_INVALID; }
     void* buf = nullptr;
@@ -2527,8 +2522,7 @@ int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out
       (void)hipMemset(qv, 0, (size_t)od * 4);
       FdeScanArgs a{};
       a.fde = (const uint16_t*)buf; a.inv_norm = inv; a.q = qv; a.scores = sc; a.n = n; a.out_dim = od;
-      a.work = (uint32_t*)inv;  // zeros; inv[0..1] are re-armed by every launch (page 0 / 1 score 0 either way: q = 0)
-      const int v = what == MV_CAL_FDE_SCAN_REGS ? 0 : what == MV_CAL_FDE_SCAN_LDSDMA_STATIC ? 4 : what == MV_CAL_FDE_SCAN_STREAM ? 9 : what == MV_CAL_FDE_SCAN_ROWS ? 5 : 3;
+      const int v = what == MV_CAL_FDE_SCAN_REGS ? 0 : 5;
       rc = launch_fde_scan(a, v, nullptr);
       (void)hipEventRecord(a_ev, nullptr);
       for (int i = 0; i < iters && !rc; ++i) rc = launch_fde_scan(a, v, nullptr);

@@ -84,7 +84,6 @@ __device__ __forceinline__ bool masked(const BArgs& a, int64_t page) {
 }
 
 constexpr int kQChunk = 32;  // query rows whose running minima live in registers
-constexpr int kBinaryDefaultUniform = 4;  // default variant on uniform, unmasked corpora too (the burst form, 6, measured slower)
 
 __device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
@@ -184,147 +183,6 @@ struct BMArgs {
   BArgs b;
   int32_t accumulate;  // add to scores[] (second and later query passes)
 };
-
-template <int MT, int D>
-__global__ __launch_bounds__(256) void maxsim_binary_mfma_kernel(BMArgs args) {
-  const BArgs& a = args.b;
-  __shared__ __attribute__((aligned(16))) char lds[4 * D * kBinSlotBytes];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r = lane & 15, g = lane >> 4;
-  const int64_t page = (int64_t)blockIdx.x * 4 + wave;
-  if (page >= a.n) return;
-  if (masked(a, page)) {
-    if (lane == 0) a.scores[page] = -INFINITY;
-    return;
-  }
-  const int nr = a.n_rows ? a.n_rows[page] : a.stride;
-  if (nr <= 0 || a.n_q <= 0) {
-    if (lane == 0 && !args.accumulate) a.scores[page] = 0.0f;  // COALESCE(SUM over nothing, 0.0)
-    return;
-  }
-  const int ntiles = (nr + 15) >> 4;
-  const int nslots = (nr + kBinSlotRows - 1) / kBinSlotRows;
-  const char* pbase = reinterpret_cast<const char*>(a.bits) + (size_t)page * (size_t)a.stride * kSignBytes;
-  char* ring = lds + wave * (D * kBinSlotBytes);
-  const int src_off = lane * 16;
-
-  auto issue = [&](int it) {
-    const char* tp = pbase + (size_t)it * kBinSlotBytes;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
-    const uint64_t tpu = ((uint64_t)hi << 32) | lo;
-    const uint32_t slot = __builtin_amdgcn_readfirstlane(
-        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + (it % D) * kBinSlotBytes));
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 4\n\t"
-        "global_load_lds_dwordx4 %1, %3 nt\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(src_off), "s"(slot), "s"(tpu)
-        : "memory");
-  };
-
-#pragma unroll
-  for (int i = 0; i < D - 1; ++i)
-    if (i < nslots) issue(i);
-
-  // query operand (loop invariant) and popc(q) of the rows this lane finishes; loaded after the prologue
-  // DMAs and pinned so the compiler's own vmcnt waits are all in front of the loop.
-  i32x8 qa[MT];
-  float qpop[MT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const uint4 qv = a.q[m * 16 + r];  // qbits is zero padded to a multiple of 16 rows
-    const float4 pc = *reinterpret_cast<const float4*>(a.qpop + m * 16 + g * 4);  // popc(q row), -1 = padding row
-    const uint32_t w[4] = {qv.x, qv.y, qv.z, qv.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) qa[m][i] = (int)(0xAAAAAAAAu - (((w[i] >> g) & 0x11111111u) << 3));
-#pragma unroll
-    for (int i = 4; i < 8; ++i) qa[m][i] = 0;
-    qpop[m][0] = pc.x; qpop[m][1] = pc.y; qpop[m][2] = pc.z; qpop[m][3] = pc.w;
-  }
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      asm volatile("" : "+v"(qa[m][i]));
-      asm volatile("" : "+v"(qpop[m][i]));
-    }
-  }
-
-  f32x4b mx[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) mx[m] = f32x4b{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-
-  for (int it = 0; it < nslots; ++it) {
-    if (it + D - 1 < nslots) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // WAR: last reads of the slot being refilled
-      issue(it + D - 1);
-      bin_wait_vmcnt<D - 1>();
-    } else {
-      const int left = nslots - 1 - it;  // slots still allowed in flight
-      if (left >= 4) bin_wait_vmcnt<4>();
-      else if (left == 3) bin_wait_vmcnt<3>();
-      else if (left == 2) bin_wait_vmcnt<2>();
-      else if (left == 1) bin_wait_vmcnt<1>();
-      else bin_wait_vmcnt<0>();
-    }
-    const char* slot = ring + (it % D) * kBinSlotBytes;
-    auto tile = [&](const uint4& wv, bool col_valid) {
-      i32x8 b;
-      b[0] = (int)((wv.x >> g) & 0x11111111u);
-      b[1] = (int)((wv.y >> g) & 0x11111111u);
-      b[2] = (int)((wv.z >> g) & 0x11111111u);
-      b[3] = (int)((wv.w >> g) & 0x11111111u);
-      b[4] = 0; b[5] = 0; b[6] = 0; b[7] = 0;
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        f32x4b acc = {0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(qa[m], b, acc, 4 /* A fp4 */, 4 /* B fp4 */, 0, 0x7f7f7f7f, 0,
-                                                               0x7f7f7f7f);
-        if (!col_valid) acc = f32x4b{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mx[m][i] = fmaxf(mx[m][i], acc[i]);
-      }
-    };
-    if ((it + 1) * kBinSlotRows <= nr) {  // whole slot valid (wave-uniform): 4 reads in flight, no column masks
-      uint4 wv[4];
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) wv[tt] = *reinterpret_cast<const uint4*>(slot + (tt * 16 + r) * kSignBytes);
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) tile(wv[tt], true);
-    } else {
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        const int t = it * 4 + tt;
-        if (t < ntiles) {  // wave-uniform
-          const uint4 wv = *reinterpret_cast<const uint4*>(slot + (tt * 16 + r) * kSignBytes);
-          tile(wv, t * 16 + r < nr);
-        }
-      }
-    }
-  }
-
-  // min_d hamming of query row (16m + 4g + i) = popc(q) - 2 max_d D; integers <= 128, exact in fp32
-  float ham = 0.f;
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float v = bin_group16_max(mx[m][i]);
-      if (qpop[m][i] >= 0.f) ham += qpop[m][i] - 2.0f * v;
-    }
-  ham += __shfl_xor(ham, 16);
-  ham += __shfl_xor(ham, 32);
-  if (lane == 0) {
-    const float part = (float)a.n_q - ham * (1.0f / 128.0f);
-    a.scores[page] = args.accumulate ? a.scores[page] + part : part;
-  }
-}
 
 __global__ void hamming_batch_kernel(const uint8_t* q, const uint8_t* c, int64_t n, int32_t nb, int32_t* out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -548,300 +406,11 @@ __global__ __launch_bounds__(256) void maxsim_binary_mfma2_kernel(BMArgs args) {
   }
 }
 
-// Variant 6 (round 2): the BURST form.  Every wave-per-page stream measured so far caps at ~6.9 TB/s, while the float scan's
-// four-waves-per-page interleave (one workgroup reads contiguous 16 KiB bursts) reaches 7.3: here a workgroup takes FOUR
-// consecutive pages -- 64 KiB contiguous -- and its waves interleave the 1 KiB slots of that range (wave w: slots w,
-// w + 4, ...), so each round of the workgroup is one contiguous 4 KiB read and the whole workgroup is ONE sequential
-// 64 KiB stream instead of four parallel 16 KiB streams.  A wave sees a quarter of every page's rows: four running
-// maxima per query tile (one per page; the page loop is unrolled so they stay in fixed registers), merged across the
-// waves through LDS at the end; wave p finishes page p.  Same ring, same arithmetic, same integers as variant 4.
-// Needs a uniform, unmasked corpus whose pages are whole multiples of 256 rows (every wave gets the same number of slots
-// of every page); anything else runs variant 4.
-// MEASURED (round 2, 1 M pages x 1024 rows, interleaved rounds on one box): 6.29-6.31 TB/s against 6.56-6.61 for variant 4
-// (200 k pages: 6.62-6.65 vs 6.68-6.72) -- the sequential burst does not pay for the extra barrier, the LDS merge and
-// the page loop here, where a page is only four slots per wave.  Kept as a parity-checked option, not the default.
-template <int MT, int D>
-__global__ __launch_bounds__(256) void maxsim_binary_burst_kernel(BMArgs args) {
-  const BArgs& a = args.b;
-  constexpr int SLB = kBinSlotBytes;
-  __shared__ __attribute__((aligned(16))) char lds[4 * D * SLB + 4 * 4 * MT * 16 * 4];
-  float* red = reinterpret_cast<float*>(lds + 4 * D * SLB);  // [wave][page][MT * 16 tokens]
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r = lane & 15, g = lane >> 4;
-  const int64_t page0 = (int64_t)blockIdx.x * 4;
-  if (page0 >= a.n) return;
-  const int npg = (int)min((int64_t)4, a.n - page0);  // pages of this workgroup
-  const int spw = a.stride / (4 * kBinSlotRows);       // slots of ONE page owned by one wave
-  const int total = npg * spw;                         // this wave's slots
-  const char* base = reinterpret_cast<const char*>(a.bits) + (size_t)page0 * (size_t)a.stride * kSignBytes + (size_t)wave * SLB;
-  char* ring = lds + wave * (D * SLB);
-  const int src_off = lane * 16;
-  const int rd_off = r * kSignBytes + g * 4;
-
-  auto issue = [&](int it) {  // wave-local slot `it` = slot 4 * it + wave of the 64 KiB range
-    const char* tp = base + (size_t)it * (4 * SLB);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
-    const uint64_t tpu = ((uint64_t)hi << 32) | lo;
-    const uint32_t slot = __builtin_amdgcn_readfirstlane(
-        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + (it % D) * SLB));
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 4\n\t"
-        "global_load_lds_dwordx4 %1, %3 nt\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(src_off), "s"(slot), "s"(tpu)
-        : "memory");
-  };
-
-#pragma unroll
-  for (int i = 0; i < D - 1; ++i)
-    if (i < total) issue(i);
-
-  i32x8 qb[MT];
-  float qpop[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const uint32_t w = reinterpret_cast<const uint32_t*>(a.q + m * 16 + r)[g];
-    qb[m][0] = (int)(0xCCCCCCCCu - ((w & 0x11111111u) << 3));         // +-2.0
-    qb[m][1] = (int)(0xAAAAAAAAu - (((w >> 1) & 0x11111111u) << 3));  // +-1.0
-    qb[m][2] = (int)(0x99999999u - (((w >> 2) & 0x11111111u) << 3));  // +-0.5
-    qb[m][3] = (int)(0x22222222u + (((w >> 3) & 0x11111111u) << 3));  // -+1.0 (the sign-slot class)
-#pragma unroll
-    for (int i = 4; i < 8; ++i) qb[m][i] = 0;
-    qpop[m] = a.qpop[m * 16 + r];
-  }
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(qb[m][i]));
-    asm volatile("" : "+v"(qpop[m]));
-  }
-
-  uint32_t ones = 0x11111111u;
-  asm volatile("" : "+v"(ones));
-  auto expand = [&](uint32_t w) {
-    i32x8 b;
-    b[0] = (int)(w & 0x11111111u);
-    b[1] = (int)(w & 0x22222222u);
-    b[2] = (int)(w & 0x44444444u);
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(b[3]) : "v"(w), "s"(0x88888888u), "v"(ones));
-    b[4] = 0; b[5] = 0; b[6] = 0; b[7] = 0;
-    return b;
-  };
-  auto mma = [&](const i32x8& pa, const i32x8& qbm) {
-    f32x4b acc = {0.f, 0.f, 0.f, 0.f};
-    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(pa, qbm, acc, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-  };
-
-  int it = 0;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    if (p < npg) {  // block-uniform
-      float mx[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) mx[m] = -INFINITY;
-      for (int i = 0; i < spw; ++i, ++it) {
-        if (it + D - 1 < total) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // WAR: last reads of the slot being refilled
-          issue(it + D - 1);
-          bin_wait_vmcnt<D - 1>();
-        } else {
-          const int left = total - 1 - it;
-          if (left >= 2) bin_wait_vmcnt<2>();
-          else if (left == 1) bin_wait_vmcnt<1>();
-          else bin_wait_vmcnt<0>();
-        }
-        const char* slot = ring + (it % D) * SLB + rd_off;
-        uint32_t w[4];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) w[tt] = *reinterpret_cast<const uint32_t*>(slot + tt * 256);
-#pragma unroll
-        for (int tp = 0; tp < 4; tp += 2) {
-          const i32x8 b0 = expand(w[tp]), b1 = expand(w[tp + 1]);
-#pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            const f32x4b c0 = mma(b0, qb[m]), c1 = mma(b1, qb[m]);
-            const float t0 = fmaxf(fmaxf(c0[0], c0[1]), c0[2]);
-            const float t1 = fmaxf(fmaxf(c0[3], c1[0]), c1[1]);
-            const float t2 = fmaxf(fmaxf(c1[2], c1[3]), mx[m]);
-            mx[m] = fmaxf(fmaxf(t0, t1), t2);
-          }
-        }
-      }
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        float v = mx[m];
-        v = fmaxf(v, __shfl_xor(v, 16));
-        v = fmaxf(v, __shfl_xor(v, 32));
-        if (g == 0) red[((wave * 4 + p) * MT + m) * 16 + r] = v;
-      }
-    }
-  }
-  __syncthreads();
-  if (wave < npg) {  // wave p finishes page p
-    float ham = 0.f;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const float v = fmaxf(fmaxf(red[((0 * 4 + wave) * MT + m) * 16 + r], red[((1 * 4 + wave) * MT + m) * 16 + r]),
-                            fmaxf(red[((2 * 4 + wave) * MT + m) * 16 + r], red[((3 * 4 + wave) * MT + m) * 16 + r]));
-      if (qpop[m] >= 0.f) ham += qpop[m] - v;
-    }
-    ham = bin_group16_sum(ham);  // over the 16 query columns of the row (exact: small integers)
-    if (lane == 0) {
-      const int64_t item = page0 + wave;
-      const float part = (float)a.n_q - ham * (1.0f / 128.0f);
-      a.scores[item] = args.accumulate ? a.scores[item] + part : part;
-    }
-  }
-}
-
-// Variant 5: persistent waves with ONE continuous DMA stream across pages (fixed-size, unfiltered corpora only: every
-// page has S = stride/64 full slots, no metadata reads on the issue path).  Wave w takes pages w, w+W, w+2W, ...; the
-// ring keeps D-1 slots in flight across page boundaries, so the per-page prologue bubble, the query-operand reload and
-// the block launch of variant 4 disappear; a page's finish (DPP max + score store) runs under the next page's loads.
-template <int MT, int D>
-__global__ __launch_bounds__(256) void maxsim_binary_stream_kernel(BMArgs args) {
-  const BArgs& a = args.b;
-  __shared__ __attribute__((aligned(16))) char lds[4 * D * kBinSlotBytes];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r = lane & 15, g = lane >> 4;
-  const int64_t W = (int64_t)gridDim.x * 4;
-  const int64_t w0 = (int64_t)blockIdx.x * 4 + wave;
-  if (w0 >= a.n) return;
-  const int S = a.stride / kBinSlotRows;            // slots per page (stride % 64 == 0)
-  const int64_t npages = (a.n - w0 + W - 1) / W;    // pages of this wave
-  const int64_t T = npages * S;                     // slots of this wave
-  char* ring = lds + wave * (D * kBinSlotBytes);
-  const int src_off = lane * 16;
-  const int rd_off = r * kSignBytes + g * 4;
-  const char* bits = reinterpret_cast<const char*>(a.bits);
-  const size_t page_bytes = (size_t)a.stride * kSignBytes;
-
-  // issue cursor (page ordinal j, slot s) advances one slot per call
-  int64_t ij = 0;
-  int is = 0;
-  int islot = 0;
-  auto issue_next = [&]() {
-    const char* tp = bits + (size_t)(w0 + ij * W) * page_bytes + (size_t)is * kBinSlotBytes;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
-    const uint64_t tpu = ((uint64_t)hi << 32) | lo;
-    const uint32_t slot = __builtin_amdgcn_readfirstlane(
-        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + islot * kBinSlotBytes));
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 4\n\t"
-        "global_load_lds_dwordx4 %1, %3 nt\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(src_off), "s"(slot), "s"(tpu)
-        : "memory");
-    if (++is == S) { is = 0; ++ij; }
-    if (++islot == D) islot = 0;
-  };
-
-  for (int i = 0; i < D - 1; ++i)
-    if (i < T) issue_next();
-
-  i32x8 qa[MT];
-  float qpop[MT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const uint32_t w = reinterpret_cast<const uint32_t*>(a.q + m * 16 + r)[g];
-    const float4 pc = *reinterpret_cast<const float4*>(a.qpop + m * 16 + g * 4);
-    qa[m][0] = (int)(0xCCCCCCCCu - ((w & 0x11111111u) << 3));
-    qa[m][1] = (int)(0xAAAAAAAAu - (((w >> 1) & 0x11111111u) << 3));
-    qa[m][2] = (int)(0x99999999u - (((w >> 2) & 0x11111111u) << 3));
-    qa[m][3] = (int)(0x99999999u - (((w >> 3) & 0x11111111u) << 3));
-#pragma unroll
-    for (int i = 4; i < 8; ++i) qa[m][i] = 0;
-    qpop[m][0] = pc.x; qpop[m][1] = pc.y; qpop[m][2] = pc.z; qpop[m][3] = pc.w;
-  }
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      asm volatile("" : "+v"(qa[m][i]));
-      asm volatile("" : "+v"(qpop[m][i]));
-    }
-  }
-
-  f32x4b mx[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) mx[m] = f32x4b{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-
-  auto expand = [&](uint32_t w) {
-    i32x8 b;
-    b[0] = (int)(w & 0x11111111u);
-    b[1] = (int)(w & 0x22222222u);
-    b[2] = (int)(w & 0x44444444u);
-    b[3] = (int)((w >> 1) & 0x44444444u);
-    b[4] = 0; b[5] = 0; b[6] = 0; b[7] = 0;
-    return b;
-  };
-  auto mma = [&](const i32x8& qam, const i32x8& b) {
-    f32x4b acc = {0.f, 0.f, 0.f, 0.f};
-    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(qam, b, acc, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-  };
-
-  int cs = 0, cslot = 0;
-  int64_t cj = 0;
-  for (int64_t t = 0; t < T; ++t) {
-    if (t + D - 1 < T) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // WAR: last reads of the slot being refilled
-      issue_next();
-      bin_wait_vmcnt<D - 1>();
-    } else {
-      const int64_t left = T - 1 - t;
-      if (left >= 2 && D > 2) bin_wait_vmcnt<2>();
-      else if (left == 1) bin_wait_vmcnt<1>();
-      else bin_wait_vmcnt<0>();
-    }
-    const char* slot = ring + cslot * kBinSlotBytes + rd_off;
-    uint32_t w[4];
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) w[tt] = *reinterpret_cast<const uint32_t*>(slot + tt * 256);
-#pragma unroll
-    for (int tp = 0; tp < 4; tp += 2) {
-      const i32x8 b0 = expand(w[tp]), b1 = expand(w[tp + 1]);
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const f32x4b c0 = mma(qa[m], b0), c1 = mma(qa[m], b1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mx[m][i] = fmaxf(fmaxf(mx[m][i], c0[i]), c1[i]);
-      }
-    }
-    if (++cslot == D) cslot = 0;
-    if (++cs == S) {  // page complete: finish under the next page's loads
-      float ham = 0.f;
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float v = bin_group16_max(mx[m][i]);
-          if (qpop[m][i] >= 0.f) ham += qpop[m][i] - v;
-          mx[m][i] = -INFINITY;
-        }
-      ham += __shfl_xor(ham, 16);
-      ham += __shfl_xor(ham, 32);
-      if (lane == 0) {
-        const int64_t page = w0 + cj * W;
-        const float part = (float)a.n_q - ham * (1.0f / 128.0f);
-        a.scores[page] = args.accumulate ? a.scores[page] + part : part;
-      }
-      cs = 0;
-      ++cj;
-    }
-  }
-}
+// Round-2 forms that lost by measurement and were removed in round 5 (records: profiles/r2, DESIGN.md "Sign-bit scan"):
+//   variant 1  the first MFMA form (16 VALU ops per tile)                         345 M pages/s against 408 for variant 4
+//   variant 5  persistent waves, one continuous DMA stream across pages           slower than fresh workgroups (as for the float scan)
+//   variant 6  four-page burst per workgroup (64 KiB contiguous)                  6.29-6.31 TB/s against 6.56-6.61 for variant 4
+//   variants 2 / 3  the ring of variant 4 with 8 / 16 slots                       390 / 295 M pages/s
 
 // popc(q row) as float for rows < n_q, -1 for the padding rows up to `padded`; also zero-fills the padding bit rows
 __global__ void binary_qprep_kernel(uint4* qbits, int n_q, int padded, float* qpop, int signslot) {
@@ -860,55 +429,26 @@ __global__ void binary_qprep_kernel(uint4* qbits, int n_q, int padded, float* qp
 }
 
 template <int MT>
-static void launch_binary_mfma(const BArgs& k, int accumulate, int variant, hipStream_t s) {
+static void launch_binary_mfma(const BArgs& k, int accumulate, hipStream_t s) {
   BMArgs m{k, accumulate};
-  const dim3 grid((unsigned)((k.n + 3) / 4)), block(256);
-  if (variant == 5) {
-    // persistent stream form: only for fixed-size, unfiltered corpora whose pages are whole 64-row slots
-    if (!k.n_rows && !k.doc_ord && k.stride % kBinSlotRows == 0) {
-      static int ncu = 0;
-      if (ncu == 0) {
-        int dev = 0, v = 0;
-        ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-      }
-      const int64_t blocks = std::min<int64_t>((k.n + 3) / 4, (int64_t)ncu * 8);
-      hipLaunchKernelGGL((maxsim_binary_stream_kernel<MT, 4>), dim3((unsigned)blocks), block, 0, s, m);
-      return;
-    }
-    variant = 4;
-  }
-  if (variant == 6) {  // burst form (resolved by launch_maxsim_binary: uniform, unmasked, stride % 256 == 0)
-    hipLaunchKernelGGL((maxsim_binary_burst_kernel<MT, 4>), grid, block, 0, s, m);
-    return;
-  }
-  switch (variant) {
-    case 1: hipLaunchKernelGGL((maxsim_binary_mfma_kernel<MT, 6>), grid, block, 0, s, m); break;
-    case 3: hipLaunchKernelGGL((maxsim_binary_mfma2_kernel<MT, 16>), grid, block, 0, s, m); break;
-    case 4: hipLaunchKernelGGL((maxsim_binary_mfma2_kernel<MT, 4>), grid, block, 0, s, m); break;
-    default: hipLaunchKernelGGL((maxsim_binary_mfma2_kernel<MT, 8>), grid, block, 0, s, m); break;
-  }
+  hipLaunchKernelGGL((maxsim_binary_mfma2_kernel<MT, 4>), dim3((unsigned)((k.n + 3) / 4)), dim3(256), 0, s, m);
 }
 
+// variant: 0 = popcount on the VALU (the independent cross-check), 4 (default, -1) = FP4 MFMA, 4-slot ring -- 408 M pages/s at
+// 1 M pages against 48 for the popcount form
 int launch_maxsim_binary(const BinaryArgs& a, int variant, hipStream_t s) {
   if (a.n <= 0) return MV_OK;
   BArgs k{reinterpret_cast<const uint4*>(a.bits), a.n_rows, a.doc_ord, a.allow, a.n_allow_bits,
           reinterpret_cast<const uint4*>(a.qbits), a.scores, a.n, a.stride, a.n_q, a.qpop, a.cand};
-  if (a.cand && (variant == 1 || variant >= 5)) variant = 4;  // the candidate-list form exists for variants 0 and 2..4
   if (a.n > ((int64_t)1 << 25)) { set_error("binary scan: more than 2^25 pages per launch is not supported"); return MV_ERR_INVALID; }
-  // the stream form needs fixed-size, unfiltered pages of whole 64-row slots; resolve the fallback HERE so that the
-  // query prep below matches the kernel that runs
-  if (variant == 5 && (a.n_rows || a.doc_ord || a.stride % kBinSlotRows != 0)) variant = 4;
-  const bool burst_ok = !a.n_rows && !a.doc_ord && !a.cand && a.stride % (4 * kBinSlotRows) == 0;
-  if (variant < 0) variant = burst_ok ? kBinaryDefaultUniform : 4;  // 4: 408 M pages/s (4-slot ring) > 390 (8) > 295 (16) > 345 (v1) > 48 (popcount)
-  if (variant == 6 && !burst_ok) variant = 4;
+  if (variant < 0) variant = 4;
   if (variant == 0 || a.n_q <= 0) {
     hipLaunchKernelGGL(maxsim_binary_kernel, dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, s, k);
-  } else if (variant >= 1 && variant <= 6) {
+  } else if (variant == 4) {
     if (!a.qpop) { set_error("binary MFMA scan needs the qpop workspace"); return MV_ERR_INVALID; }
     const int padded = ((a.n_q + 15) / 16) * 16;
     hipLaunchKernelGGL(binary_qprep_kernel, dim3((unsigned)((padded + 63) / 64)), dim3(64), 0, s,
-                       reinterpret_cast<uint4*>(const_cast<uint8_t*>(a.qbits)), a.n_q, padded, a.qpop_rw,
-                       (variant >= 2 && variant <= 4) || variant == 6 ? 1 : 0);
+                       reinterpret_cast<uint4*>(const_cast<uint8_t*>(a.qbits)), a.n_q, padded, a.qpop_rw, 1);
     // query rows in passes of <= 64 (4 MFMA row tiles); later passes accumulate into scores[]
     for (int q0 = 0, pass = 0; q0 < a.n_q; q0 += 64, ++pass) {
       BArgs kp = k;
@@ -917,14 +457,14 @@ int launch_maxsim_binary(const BinaryArgs& a, int variant, hipStream_t s) {
       kp.n_q = std::min(64, a.n_q - q0);
       const int mt = (kp.n_q + 15) / 16;
       switch (mt) {
-        case 1: launch_binary_mfma<1>(kp, pass > 0, variant, s); break;
-        case 2: launch_binary_mfma<2>(kp, pass > 0, variant, s); break;
-        case 3: launch_binary_mfma<3>(kp, pass > 0, variant, s); break;
-        default: launch_binary_mfma<4>(kp, pass > 0, variant, s); break;
+        case 1: launch_binary_mfma<1>(kp, pass > 0, s); break;
+        case 2: launch_binary_mfma<2>(kp, pass > 0, s); break;
+        case 3: launch_binary_mfma<3>(kp, pass > 0, s); break;
+        default: launch_binary_mfma<4>(kp, pass > 0, s); break;
       }
     }
   } else {
-    set_error("unknown binary variant %d", variant);
+    set_error("unknown binary variant %d (0 = popcount, 4 = FP4 MFMA)", variant);
     return MV_ERR_INVALID;
   }
   MV_HIP(hipGetLastError());

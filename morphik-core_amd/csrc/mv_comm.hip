@@ -363,9 +363,6 @@ int mv_internal_two_stage_batch_coarse(mv_index* ix, const void* q, int q_dtype,
     sa.q = ix->d_bqfde; sa.image = ix->d_bqimage; sa.scores = ix->d_bscores; sa.score_stride = cap; sa.n = n; sa.out_dim = ix->fde_t.out_dim; sa.n_queries = nb;
     sa.hi_only = ix->fde_batch_variant == 2;
     sa.single_tile = ix->fde_batch_variant == 3;
-    sa.half_tiles = ix->fde_batch_variant == 4;
-    sa.private_rings = ix->fde_batch_variant == 6;
-    sa.ring_slots = ix->fde_batch_variant == 7 ? 9 : (ix->fde_batch_variant == 8 ? 4 : 0);
     sa.separate_finish = ix->fde_batch_variant == 5;
     if (ix->fde_batch_variant != 5 && topk_uses_radix(n, n_coarse)) {  // the finish pass bins the scores for the selection (mv_api.hip)
       sa.hist0 = topk_radix_hist0(ix->d_btopk_ws);

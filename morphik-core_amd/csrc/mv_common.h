@@ -191,10 +191,8 @@ struct FdeScanArgs {
   int64_t out_dim;
   uint32_t* hist0;          // nullable: 2048-bin histogram of the scores' key bits [31:21], accumulated by the scan itself
                             // (saves the selection's first pass); default variant at out_dim 10240 / 5120 only
-  uint32_t* work;           // nullable: 2 device words, zero between launches -- the LDS-DMA form claims its chunks from them
-                            // (dynamic load balance); null: static chunk order
 };
-// variant: 0 = query in registers, one wave per page, nt loads (default, -1), 1 = query in LDS, 2 = workgroup-cooperative
+// variant: -1 / 5 = row quarters through the nt LDS-DMA ring (default), 0 = query in registers, one wave per row, nt loads (cross-check)
 int launch_fde_scan(const FdeScanArgs& a, int variant, hipStream_t s);
 bool fde_scan_prebins(int variant, int64_t out_dim);  // the form launch_fde_scan would run fills FdeScanArgs::hist0
 constexpr int kFdeBatchMaxQueries = 32;
@@ -216,19 +214,16 @@ struct FdeScanBatchArgs {
   int32_t n_queries;
   int32_t hi_only;            // 1: bf16 query FDE (one MFMA per fragment, half the query traffic; coarse scores within ~2e-3)
   int32_t single_tile;        // 1: one page tile per query fragment (the first form; default: tiles in pairs)
-  int32_t half_tiles;         // 1: 32-page tiles, two workgroups per CU, four tiles per query fragment set (round 3)
   // nullable: query b's first selection histogram (topk_radix_hist0 of ITS workspace) at hist0 + b * hist0_stride_bytes, zero on
   // entry; accumulated by the finish pass (which touches every score anyway) so the selection starts at its second pass.
   // Only honoured when a finish pass runs (inv_norm or doc_ord given): fde_scan_batch_prebins().
   uint32_t* hist0;
   int64_t hist0_stride_bytes;
-  int32_t ring_slots;         // > 0: 32-page tiles, one workgroup per CU, a DMA ring of that many slots (4 / 9; MV_OPT_FDE_BATCH_VARIANT 8 / 7)
-  int32_t private_rings;      // 1: every wave DMAs the quarter of the slot it consumes into a ring of its own -- no slot barriers (MV_OPT_FDE_BATCH_VARIANT 6)
   int32_t separate_finish;    // 1: keep the finish a pass of its own even where the scan kernel could apply it (MV_OPT_FDE_BATCH_VARIANT 5)
 };
 // the default (paired-tile) kernel applies the cosine rule and the tombstones where it writes a tile's scores: no finish pass
 inline bool fde_scan_batch_fuses_finish(const FdeScanBatchArgs& a) {
-  return a.inv_norm != nullptr && !a.single_tile && !a.half_tiles && !a.ring_slots && !a.separate_finish;
+  return a.inv_norm != nullptr && !a.single_tile && !a.separate_finish;
 }
 inline bool fde_scan_batch_prebins(const FdeScanBatchArgs& a) {
   return a.hist0 != nullptr && (a.inv_norm != nullptr || a.doc_ord != nullptr) && !fde_scan_batch_fuses_finish(a);

@@ -53,7 +53,6 @@ struct mv_index {
   float* d_scores2 = nullptr;  // [capacity] (second accumulator for > 64 query rows)
   void* d_topk_ws = nullptr;
   size_t topk_ws_bytes = 0;
-  uint32_t* d_fde_work = nullptr;  // {next chunk, waves done} of the FDE coarse scan's chunk claiming; zero between launches
   uint16_t* d_q = nullptr;     // bf16 query, padded
   float* d_qf32 = nullptr;     // fp32 query rows (FDE encode input)
   uint8_t* d_qbits = nullptr;

@@ -19,14 +19,11 @@
 // so the max over patches is an elementwise max over tiles t followed by ONE 16-lane butterfly.
 //
 // Variants (MV_OPT_MAXSIM_VARIANT; measured table in DESIGN.md):
-//   0  direct-to-VGPR loads, one wave per page, 3-tile register ring
-//   1  direct-to-VGPR loads, four waves per page (tiles interleaved), LDS cross-wave max
-//   2  LDS-DMA (global_load_lds_dwordx4) into a wave-private 4-slot ring, XOR-swizzled rows,
-//      ds_read_b128 fragments, one wave per page
-//   3  as 2 with four waves per page
-//   4/5  as 0/1 with non-temporal loads
-//   6/7  as 3/2 with non-temporal LDS-DMA
-//   8..11 ring-depth probes of 6/7 (D = 3, 2, 6 with four waves per page; D = 8 with one)
+//   6  (default, pages of >= 512 rows) non-temporal LDS-DMA (global_load_lds_dwordx4 nt) into a wave-private 4-slot ring,
+//      XOR-swizzled rows, ds_read_b128 fragments, FOUR waves per page (tiles interleaved)
+//   7  (default below 512 rows) the same ring, one wave per page
+//   0  direct global -> VGPR fragment loads, one wave per page, 3-tile register ring: the independent cross-check
+//   13 the default's transport with the arithmetic removed (calibration)
 #include <algorithm>
 
 #include "mv_common.h"
@@ -365,110 +362,13 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------
-// Variant 14 (round 2 experiment): PERSISTENT workgroups with ONE continuous DMA stream per wave across pages.  A
-// workgroup of the default kernel lives for one 256 KiB page (~18 us): its ring starts empty and drains empty, and only
-// two workgroups share a CU, so for ~10 % of a workgroup's life the CU has less in flight than the ring allows.  Here a
-// workgroup takes pages blockIdx.x, + gridDim.x, ...; wave w's tile sequence runs on through the page boundary, so the
-// next page's tiles are already in flight while the current page is reduced (finish_block works on a double-buffered
-// red[] under the loads).  Uniform, unmasked corpora only (anything else: the default kernel).
-// MEASURED (400 k pages x 1024 rows, interleaved rounds): 6.86 TB/s against 7.33 for the default -- fresh workgroups handed
-// out by the dispatcher beat the persistent stream here (as they did for the sign-bit scan's variant 5).  Parity-green
-// option, not the default.
-template <int MT, int D>
-__global__ __launch_bounds__(256) void maxsim_ldsdma_stream_kernel(KArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[4 * D * kTileBytes + 2 * 2048];
-  float* red_all = reinterpret_cast<float*>(lds + 4 * D * kTileBytes);  // [2][512]
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r = lane & 15, g = lane >> 4;
-  const int ntiles = a.stride / kTileRows;  // uniform pages
-  const int tpw = (ntiles - wave + 3) / 4;  // tiles of ONE page owned by this wave
-  const int64_t my_pages = a.n > (int64_t)blockIdx.x ? (a.n - 1 - blockIdx.x) / gridDim.x + 1 : 0;
-  const int64_t total = my_pages * tpw;
-  const size_t page_bytes = (size_t)a.stride * kRowBytes;
-  char* ring = lds + wave * (D * kTileBytes);
-
-  int src_off[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int w = i * 4 + (lane >> 4);
-    src_off[i] = w * kRowBytes + (((lane & 15) ^ w) << 4) - i * 1024;
-  }
-  int rd_off[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) rd_off[j] = r * kRowBytes + (((j * 4 + g) ^ r) << 4);
-
-  // issue cursor: page / tile-in-page of the next tile of this wave's stream
-  const char* iss_page = a.slab + (size_t)(a.page0 + blockIdx.x) * page_bytes;
-  int iss_t = 0, iss_slot = 0;
-  auto issue_next = [&]() {
-    const char* tp = iss_page + (size_t)(wave + iss_t * 4) * kTileBytes;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
-    const uint64_t tpu = ((uint64_t)hi << 32) | lo;
-    const uint32_t slot = __builtin_amdgcn_readfirstlane(
-        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + iss_slot * kTileBytes));
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %5\n\t"
-        "s_nop 4\n\t"
-        "global_load_lds_dwordx4 %1, %6 nt\n\t"
-        "global_load_lds_dwordx4 %2, %6 offset:1024 nt\n\t"
-        "global_load_lds_dwordx4 %3, %6 offset:2048 nt\n\t"
-        "global_load_lds_dwordx4 %4, %6 offset:3072 nt\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(src_off[0]), "v"(src_off[1]), "v"(src_off[2]), "v"(src_off[3]), "s"(slot), "s"(tpu)
-        : "memory");
-    iss_slot = iss_slot + 1 == D ? 0 : iss_slot + 1;
-    if (++iss_t == tpw) { iss_t = 0; iss_page += (size_t)gridDim.x * page_bytes; }
-  };
-
-#pragma unroll
-  for (int i = 0; i < D - 1; ++i)
-    if (i < total) issue_next();
-
-  bf16x8 qa[MT][4];
-  load_query<MT>(a.q, r, g, qa);
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(qa[m][j]));
-
-  f32x4 mx[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) mx[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-
-  int t = 0, slot = 0, parity = 0;
-  int64_t item = blockIdx.x;
-  for (int64_t G = 0; G < total; ++G) {
-    if (G + D - 1 < total) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // WAR: last reads of the slot being refilled
-      issue_next();
-      wait_vmcnt<4 * (D - 1)>();
-    } else {
-      const int64_t left = total - 1 - G;
-      if (left >= 2) wait_vmcnt<8>();
-      else if (left == 1) wait_vmcnt<4>();
-      else wait_vmcnt<0>();
-    }
-    const char* sp = ring + slot * kTileBytes;
-    bf16x8 b[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sp + rd_off[j]);
-    tile_mfma<MT>(qa, b, mx, false, true);
-    slot = slot + 1 == D ? 0 : slot + 1;
-    if (++t == tpw) {  // page done for this wave: cross-wave reduce under the next page's loads
-      t = 0;
-      finish_block<MT>(mx, false, red_all + parity * 512, wave, lane, &a.scores[item]);
-      parity ^= 1;
-      item += gridDim.x;
-#pragma unroll
-      for (int m = 0; m < MT; ++m) mx[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    }
-  }
-}
+// Removed in round 5 (they lost by measurement; records in profiles/r1, profiles/r2 and DESIGN.md "Kernel variants"):
+//   1 / 4 / 5   direct-to-VGPR loads with four waves per page / non-temporal          6.2-6.4 / 5.9-6.0 TB/s
+//   2 / 3       the LDS-DMA ring with default-policy (temporal) loads                    6.37 / 6.53 TB/s
+//   8..12       ring-depth and tile-ownership probes of the default (D = 2, 3, 6, 8; contiguous quarters): within 1 % or slower
+//   14          persistent workgroups with one continuous DMA stream across pages        6.86 TB/s against 7.33
+// What stays: 6 (default from 512 rows per page), 7 (default below), 0 (direct loads, one wave per page: the independent
+// cross-check of the ring), 13 (the default's transport without arithmetic: MV_CAL_READ_LDSDMA).
 
 template <int MT>
 int launch_mt(const KArgs& k0, int variant, hipStream_t s) {
@@ -492,31 +392,9 @@ int launch_mt(const KArgs& k0, int variant, hipStream_t s) {
     }
     switch (variant) {
       case 0: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 1, false>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
-      case 1: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 4, false>), dim3((unsigned)n), block, 0, s, k); break;
-      case 2: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 1, 4>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
-      case 3: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4>), dim3((unsigned)n), block, 0, s, k); break;
-      case 4: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 1, true>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
-      case 5: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 4, true>), dim3((unsigned)n), block, 0, s, k); break;
       case 6: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true>), dim3((unsigned)n), block, 0, s, k); break;
       case 7: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 1, 4, true>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
-      case 8: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 3, true>), dim3((unsigned)n), block, 0, s, k); break;
-      case 9: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 2, true>), dim3((unsigned)n), block, 0, s, k); break;
-      case 10: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 6, true>), dim3((unsigned)n), block, 0, s, k); break;
-      case 11: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 1, 8, true>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
-      case 12: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true, true>), dim3((unsigned)n), block, 0, s, k); break;
       case 13: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true, false, true>), dim3((unsigned)n), block, 0, s, k); break;
-      case 14:  // persistent stream form: uniform unmasked corpora with >= 4 tiles per page, else the default kernel
-        if (!k.n_rows && !k.doc_ord && !k.cand && !k.pad_items && k.pad_to == 0 && k.stride >= 64) {
-          static int ncu = 0;
-          if (ncu == 0) {
-            int dev = 0, v = 0;
-            ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-          }
-          hipLaunchKernelGGL((maxsim_ldsdma_stream_kernel<MT, 4>), dim3((unsigned)std::min<int64_t>(n, (int64_t)ncu * 2)), block, 0, s, k);
-        } else {
-          hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true>), dim3((unsigned)n), block, 0, s, k);
-        }
-        break;
       default: set_error("unknown maxsim variant %d", variant); return MV_ERR_INVALID;
     }
   }
@@ -536,20 +414,9 @@ int maxsim_default_variant(int stride_rows) { return stride_rows >= 512 ? 6 : 7;
 const char* maxsim_variant_name(int v) {
   switch (v) {
     case 0: return "direct_wpp1";
-    case 1: return "direct_wpp4";
-    case 2: return "ldsdma_wpp1_d4";
-    case 3: return "ldsdma_wpp4_d4";
-    case 4: return "direct_wpp1_nt";
-    case 5: return "direct_wpp4_nt";
     case 6: return "ldsdma_wpp4_d4_nt";
     case 7: return "ldsdma_wpp1_d4_nt";
-    case 8: return "ldsdma_wpp4_d3_nt";
-    case 9: return "ldsdma_wpp4_d2_nt";
-    case 10: return "ldsdma_wpp4_d6_nt";
-    case 11: return "ldsdma_wpp1_d8_nt";
-    case 12: return "ldsdma_wpp4_d4_nt_contig";
     case 13: return "ldsdma_wpp4_d4_nt_stream_only";
-    case 14: return "ldsdma_wpp4_d4_nt_persistent_stream";
     default: return "?";
   }
 }

@@ -561,7 +561,7 @@ def calibrate(what: str, bytes_: int = 8 << 30, iters: int = 5, device: int = 0)
     """Measured peaks (same process as the measurement): "read_nt" / "read_ldsdma" -> GB/s, "mfma_bf16" (16x16x32 chains) / "mfma_bf16_32x32" (32x32x16 chains) -> TFLOP/s."""
     g = C.c_double()
     code = {"read_nt": _lib.MV_CAL_READ_NT, "mfma_bf16": _lib.MV_CAL_MFMA_BF16, "read_ldsdma": _lib.MV_CAL_READ_LDSDMA,
-            "mfma_bf16_32x32": _lib.MV_CAL_MFMA_BF16_32X32, "fde_scan_regs": 14, "fde_scan_ldsdma": 15, "fde_scan_ldsdma_static": 16, "fde_scan_stream": 17, "read_ldsdma_20k": 18, "stream_probe": 19, "fde_scan_rows": 20}[what]
+            "mfma_bf16_32x32": _lib.MV_CAL_MFMA_BF16_32X32, "fde_scan_regs": 14, "fde_scan_rowq": 15, "stream_probe": 19}[what]
     check(lib().mv_calibrate(device, code, bytes_, iters, C.byref(g)))
     return float(g.value)
 

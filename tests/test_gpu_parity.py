@@ -58,7 +58,7 @@ def test_synth_generator_bit_identical_to_oracle(mv):
 
 
 # ------------------------------------------------------------------ float MaxSim
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14])
+@pytest.mark.parametrize("variant", [0, 6, 7])  # direct loads (cross-check), the two defaults (four waves / one wave per page on the nt LDS-DMA ring)
 def test_float_maxsim_all_variants_small(mv, variant):
     from morphik_core_amd import _lib
 
@@ -78,30 +78,6 @@ def test_float_maxsim_all_variants_small(mv, variant):
     ix.close()
 
 
-@pytest.mark.parametrize("stride,n", [(64, 1700), (80, 1300), (1024, 1100)])
-def test_float_maxsim_persistent_stream_variant(mv, stride, n):
-    """Variant 14: persistent workgroups, one DMA stream per wave across page boundaries (more pages than workgroups;
-    80-row pages give the waves unequal tile counts).  Same scores and top-k as the default kernel and the oracle."""
-    from morphik_core_amd import _lib
-
-    ix = _idx(mv, capacity_pages=n, stride_rows=stride)
-    ix.fill_synthetic(1234, 0, n)
-    pages = ix.read_pages(0, n)
-    for nq in (32, 5, 64):
-        q = orc.synth_rows(4321, 400 + nq, 0, nq)
-        ix.set_option(_lib.MV_OPT_MAXSIM_VARIANT, -1)
-        base = ix.score_all(q)
-        ix.set_option(_lib.MV_OPT_MAXSIM_VARIANT, 14)
-        got = ix.score_all(q)
-        np.testing.assert_allclose(got, base, rtol=1e-5, atol=1e-6)  # (the default below 512-row pages is the wave-per-page form: another summation order)
-        want = orc.maxsim_bf16_slab(q, pages[:200])
-        np.testing.assert_allclose(got[:200], want, rtol=RTOL, atol=1e-6)
-        gs, gi = ix.query(q, 10)
-        ws, wi = orc.topk(got, 10)
-        assert gi.tolist() == wi.tolist()
-    ix.close()
-
-
 @pytest.mark.parametrize("nq", [1, 16, 17, 32, 64, 65, 100, 112, 128, 129, 200, 300, 384, 400, 512, 530, 900])
 def test_float_maxsim_1024_patches_query_lengths(mv, nq):
     ix = _idx(mv, capacity_pages=64, stride_rows=1024)
@@ -115,7 +91,7 @@ def test_float_maxsim_1024_patches_query_lengths(mv, nq):
         from morphik_core_amd import _lib
 
         ix.set_option(_lib.MV_OPT_LONG_QUERY_VARIANT, 0)  # default 1 = the row-split workgroup checked above
-        for variant in (0, 1, 2, 7):
+        for variant in (0, 6, 7):
             ix.set_option(_lib.MV_OPT_MAXSIM_VARIANT, variant)
             np.testing.assert_allclose(ix.score_all(q), want, rtol=1e-4, atol=1e-6)
     ix.close()
@@ -151,7 +127,7 @@ def test_long_query_row_split_route_ragged_filter_tombstones(mv, nq):
     ix.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7, 9, 12])
+@pytest.mark.parametrize("variant", [0, 6, 7])
 def test_float_maxsim_ragged_pages(mv, variant):
     """Ragged pages through mv_index_add: rows beyond n_rows never count (pad_to = 0)."""
     from morphik_core_amd import _lib
@@ -242,8 +218,8 @@ def test_selective_doc_filter_compaction_equals_in_scan_masking(mv):
     for frac in (0.2, 0.02, 0.0005):
         docs = sorted(set(rng.choice(n_docs, size=max(1, int(n_docs * frac)), replace=False).tolist()) | {3, 1000})
         allow = allow_bitmap(docs, n_docs)
-        for mode, bvar in (("float", -1), ("float_fp8", -1), ("binary", 0), ("binary", 1), ("binary", 2), ("binary", 4), ("binary", 5)):
-            if mode == "binary":  # the candidate-list form exists in variants 0 and 2..4; 1 and 5 are routed to 4
+        for mode, bvar in (("float", -1), ("float_fp8", -1), ("binary", 0), ("binary", 4)):
+            if mode == "binary":  # the popcount cross-check and the FP4 MFMA default
                 ix.set_option(_lib.MV_OPT_BINARY_VARIANT, bvar)
             res = []
             for pct in (0, 25):
@@ -569,7 +545,7 @@ def test_hamming_batch_matches_reference_golden(mv, golden_dir):
         hamming_batch(b"ab", [b"abc"])
 
 
-BINARY_VARIANTS = [0, 1, 2, 3, 4, 5, 6]  # 0 = popcount on the VALU, 1..6 = FP4 MFMA forms (5 = persistent stream, 6 = four-page burst); identical integers required
+BINARY_VARIANTS = [0, 4]  # 0 = popcount on the VALU (the independent cross-check), 4 = FP4 MFMA (default); identical integers required
 
 
 def _set_binary_variant(ix, variant):
@@ -697,7 +673,7 @@ def test_fde_slab_same_scores_from_both_encode_kernels(mv):
 
     q = orc.synth_rows(4321, 0, 0, 32)
     outs = []
-    for variant in (0, 1, 3, 4):  # scalar kernel, f32-MFMA kernel, one-pass bf16-slab kernel (r3), two-pass form (hash + one-hot MFMA bucket sums: the default)
+    for variant in (0, 1, 4):  # scalar kernel, f32-MFMA kernel, two-pass bf16-slab form (hash + one-hot MFMA bucket sums: the default)
         ix = _idx(mv, capacity_pages=300, stride_rows=208, with_fde=True)
         ix.set_option(_lib.MV_OPT_FDE_ENCODE_VARIANT, variant)
         ix.fill_synthetic(1234, 0, 300, n_rows=200)
@@ -705,8 +681,7 @@ def test_fde_slab_same_scores_from_both_encode_kernels(mv):
         ix.close()
     np.testing.assert_allclose(outs[0], outs[1], rtol=2e-3, atol=2e-4)  # bf16 slab, bucket sums in different orders
     np.testing.assert_allclose(outs[2], outs[1], rtol=2e-3, atol=2e-4)
-    np.testing.assert_allclose(outs[3], outs[1], rtol=2e-3, atol=2e-4)
-    np.testing.assert_allclose(outs[3], outs[2], rtol=3e-4, atol=3e-5)  # the two bf16-slab forms differ only in the order of the bucket sums
+    np.testing.assert_allclose(outs[2], outs[0], rtol=2e-3, atol=2e-4)
     # the bf16-slab kernel on ragged pages (1 .. stride rows, an empty page) added from the host as bf16 and as fp32 (fp32 rows take the
     # f32-MFMA kernel: the slab kernel only sees pages that are already bf16), against the oracle's FDE of the same bf16 rows
     rng = np.random.default_rng(12)
@@ -718,7 +693,7 @@ def test_fde_slab_same_scores_from_both_encode_kernels(mv):
     want = np.array([orc.fde_coarse_scores(fq, orc.f32_to_bf16(orc.fde_encode(ocfg, orc.bf16_to_f32(pg), False))[None], use_cosine=True)[0]
                      if len(pg) else 0.0 for pg in pages], np.float32)
     for as_f32 in (False, True):
-        for variant in (4, 3, 1):
+        for variant in (4, 1, 0):  # two-pass MFMA form (default), the f32-pipe form, the scalar kernel
             ix = _idx(mv, capacity_pages=len(pages), stride_rows=stride, with_fde=True)
             ix.set_option(_lib.MV_OPT_FDE_ENCODE_VARIANT, variant)
             ix.add([orc.bf16_to_f32(pg) if as_f32 else pg for pg in pages])
@@ -799,13 +774,15 @@ def test_fde_coarse_scan_and_pipeline(mv):
     ix.close()
 
 
-@pytest.mark.parametrize("n", [1, 3, 255, 2049, 70_001, 300_017])
-def test_fde_scan_ldsdma_ring_bit_identical_to_the_register_scan(mv, n):
-    """The default coarse scan (round 5: nt LDS-DMA ring, chunks of ppw pages claimed from a device counter (variant 3) or in a
-    static order (variant 4) by persistent waves, filter and 1/norm evaluated per chunk) keeps the arithmetic of the wave-per-page register scan (variant 0): every score is
-    BIT-identical -- unfiltered, with tombstoned pages, with a doc filter, cosine on and off -- for page counts that give one
-    partial chunk, ppw = 1, a partial last chunk, and several chunks per workgroup; the top-k (whose first radix
-    histogram the scan accumulates) is identical too, and a sample agrees with the oracle's coarse scores."""
+@pytest.mark.parametrize("n", [1, 3, 17, 255, 2049, 70_001, 300_017])
+def test_fde_scan_row_quarters_bit_identical_to_the_register_scan(mv, n):
+    """The default coarse scan (round 5: row quarters through the nt LDS-DMA ring -- a fresh workgroup per 16 rows, wave w
+    streams the w-th quarter of every row and keeps its slice of the query FDE, one barrier joins the four partial sums; filter
+    and 1/norm evaluated per workgroup) and the register scan (variant 0: one wave per row on plain nt loads) share ONE
+    arithmetic order: every score is BIT-identical -- unfiltered, with tombstoned pages, with a doc filter, cosine on and off --
+    for page counts that give a single partial unit, whole units and a partial last unit; the top-k is identical too (variant 0
+    accumulates the selection's first radix histogram itself, the default leaves it to the selection), and a sample agrees with
+    the oracle's coarse scores."""
     from morphik_core_amd import _lib
     from morphik_core_amd.index import allow_bitmap
 
@@ -819,7 +796,7 @@ def test_fde_scan_ldsdma_ring_bit_identical_to_the_register_scan(mv, n):
     allow = allow_bitmap([d for d in range(n_docs) if d % 5 != 1], n_docs)
     q = orc.synth_rows(4321, 7, 0, 32)
     got = {}
-    for v in (0, 3, 4, 5, 3):  # (3 twice: the scan re-arms its own work counter)
+    for v in (0, 5, -1):
         ix.set_option(_lib.MV_OPT_FDE_SCAN_VARIANT, v)
         for cosine in (1, 0):
             ix.set_option(_lib.MV_OPT_FDE_COSINE, cosine)
@@ -828,22 +805,26 @@ def test_fde_scan_ldsdma_ring_bit_identical_to_the_register_scan(mv, n):
         ix.set_option(_lib.MV_OPT_FDE_COSINE, 1)
         got[v, "top"] = ix.query(q, min(200, n), mode="fde", allow=allow)
         got[v, "top_all"] = ix.query(q, min(1000, n), mode="fde")
-    for v in (3, 4, 5):
+    for v in (5, -1):
         for cosine in (1, 0):
             for key in ("all", "flt"):
                 a, b = got[0, cosine, key], got[v, cosine, key]
                 assert a.shape == (n,) and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (v, cosine, key)
         for key in ("top", "top_all"):
             assert np.array_equal(got[0, key][1], got[v, key][1]) and np.array_equal(got[0, key][0], got[v, key][0])
-    assert np.isneginf(got[3, 1, "flt"]).sum() >= np.isneginf(got[3, 1, "all"]).sum()
+    assert np.isneginf(got[5, 1, "flt"]).sum() >= np.isneginf(got[5, 1, "all"]).sum()
+    with pytest.raises(Exception):  # the forms that lost are gone, not silently rerouted
+        ix.set_option(_lib.MV_OPT_FDE_SCAN_VARIANT, 3)
+        ix.score_all(q, mode="fde")
+    ix.set_option(_lib.MV_OPT_FDE_SCAN_VARIANT, -1)
     # ... and the scores are the oracle's (sample of live pages; the slab's own FDE rows)
-    live = np.flatnonzero(np.isfinite(got[3, 1, "all"]))[:: max(1, n // 40)][:40]
+    live = np.flatnonzero(np.isfinite(got[5, 1, "all"]))[:: max(1, n // 40)][:40]
     if live.size:
         ocfg = orc.FdeConfig.reference_default()
         fq = orc.fde_encode(ocfg, orc.bf16_to_f32(q), True)
         rows = np.concatenate([ix.read_fde(int(p), 1) for p in live])
         want = orc.fde_coarse_scores(fq, orc.f32_to_bf16(rows), use_cosine=True)
-        np.testing.assert_allclose(got[3, 1, "all"][live], want, rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(got[5, 1, "all"][live], want, rtol=2e-3, atol=2e-4)
     ix.close()
 
 
@@ -914,7 +895,7 @@ def test_query_fde_encode_kernels_agree(mv, nq):
 
 # ------------------------------------------------------------------ batched queries (one slab pass, MFMA-bound form)
 def test_fde_batched_coarse_scan_forms_agree_on_a_corpus_of_many_tiles_per_workgroup(mv):
-    """The forms of the batched coarse pass (MV_OPT_FDE_BATCH_VARIANT 0 / 3 / 4 / 5 and the round-4 experiments 6 / 7 / 8) on a
+    """The forms of the batched coarse pass (MV_OPT_FDE_BATCH_VARIANT 0 / 3 / 5) on a
     corpus large enough that every workgroup walks several tiles -- the deep-ring form's main phase takes groups of four 32-page
     tiles, which the small corpora of the test below never reach: 41 013 pages = 1 282 tiles of 32 (five per workgroup on 256 CUs,
     a partial last tile), tombstones, 32 + 5 requests: the same scores and ids bit for bit."""
@@ -931,7 +912,7 @@ def test_fde_batched_coarse_scan_forms_agree_on_a_corpus_of_many_tiles_per_workg
         want = ix.query_batch(queries, 50, mode="fde")
         ws, wi = ix.query(queries[0], 50, mode="fde")
         np.testing.assert_allclose(want[0][0], ws, rtol=1e-4, atol=1e-6)
-        for form in (3, 4, 5, 6, 7, 8):
+        for form in (3, 5):
             ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, form)
             got = ix.query_batch(queries, 50, mode="fde")
             for (s0, i0), (sx, ix_) in zip(want, got):
@@ -996,24 +977,12 @@ def test_fde_batched_coarse_scan_matches_the_single_query_scan(mv, n, stride):
             fused = ix.query_batch(queries, kk, mode="fde", allows=kind_allows, n_docs=n_docs)
             for (s0, i0), (s5, i5) in zip(fused, three_pass):
                 assert i0.tolist() == i5.tolist() and s0.tolist() == s5.tolist()
-    # MV_OPT_FDE_BATCH_VARIANT = 4: 32-page tiles, two workgroups per CU, four tiles per fragment set -- the same K order and
-    # the same order of the four waves' partial sums per page -> the same scores bit for bit
-    ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, 4)
-    half_tiles = ix.query_batch(queries, kk, mode="fde", allows=per_q, n_docs=n_docs)
-    for (s0, i0), (s4, i4) in zip(paired, half_tiles):
-        assert i0.tolist() == i4.tolist() and s0.tolist() == s4.tolist()
-    # MV_OPT_FDE_BATCH_VARIANT = 6 / 7 / 8 (round-4 experiments, kept as cross-checks): a private DMA ring per wave without slot
-    # barriers; 32-page tiles with a ring of nine / four slots -- the same K order and the same order of the partial sums: bit for bit
-    for form in (6, 7, 8):
-        ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, form)
-        for kind_allows, want in ((per_q, paired), (None, None)):
-            got = ix.query_batch(queries, kk, mode="fde", allows=kind_allows, n_docs=n_docs)
-            if want is None:
-                ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, 0)
-                want = ix.query_batch(queries, kk, mode="fde", allows=kind_allows, n_docs=n_docs)
-                ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, form)
-            for (s0, i0), (sx, ix_) in zip(want, got):
-                assert i0.tolist() == ix_.tolist() and s0.tolist() == sx.tolist(), form
+    # the forms that lost by measurement (4, 6, 7, 8) are gone, not rerouted
+    from morphik_core_amd._lib import MvError
+
+    for form in (4, 6, 7, 8):
+        with pytest.raises(MvError):
+            ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, form)
     # MV_OPT_FDE_BATCH_VARIANT = 2: the query FDE rounded to bf16 (no lo term) -- the slab's own precision
     ix.set_option(_lib.MV_OPT_FDE_BATCH_VARIANT, 2)
     kk = min(10, n)
@@ -1090,12 +1059,12 @@ def test_fde_batched_pipeline_fallback_branches(mv):
     from morphik_core_amd import _lib
 
     N, stride = 900, 48
-    for kind, nq_rows in (("bf16_long", 130), ("bf16_variant3", 20), ("fp8_long", 70)):
+    for kind, nq_rows in (("bf16_long", 130), ("bf16_variant0", 20), ("fp8_long", 70)):
         ix = _idx(mv, capacity_pages=N, stride_rows=stride, with_fde=True, with_float=kind != "fp8_long", with_fp8=kind == "fp8_long")
         ix.fill_synthetic(1234, 0, N, pages_per_doc=2)
         ix.remove_doc(3)
-        if kind == "bf16_variant3":
-            ix.set_option(_lib.MV_OPT_MAXSIM_VARIANT, 3)
+        if kind == "bf16_variant0":
+            ix.set_option(_lib.MV_OPT_MAXSIM_VARIANT, 0)
         ix.set_option(_lib.MV_OPT_FDE_COARSE_N, 200)
         queries = [orc.synth_rows(4321, b, 0, nq_rows - (b % 3)) for b in range(9)]
         got = ix.query_batch(queries, 6, mode="fde_then_float")
@@ -1108,7 +1077,7 @@ def test_fde_batched_pipeline_fallback_branches(mv):
         ix.close()
 
 
-@pytest.mark.parametrize("bvariant", [0, 1, 2, 3, 5, 6])  # auto, 32x32x16 / 8 waves, round-1 pipeline, row-split always, transposed 32x32x16 (4 row groups / 2 row groups at one wave per SIMD)
+@pytest.mark.parametrize("bvariant", [0, 3])  # auto (page-split form up to 128 query rows, row-split above), row-split always
 @pytest.mark.parametrize("stride,nrows", [(1024, 1024), (1024, 1000), (208, 200), (64, 50), (16, 7)])
 def test_batched_queries_equal_single_queries_and_oracle(mv, stride, nrows, bvariant):
     from morphik_core_amd import _lib
@@ -1177,12 +1146,12 @@ def test_batched_queries_on_a_uniform_corpus(mv, stride):
     for lens in ([32] * 5, [32] * 16, [48] * 10, [20, 32, 1, 17, 64, 33]):
         qs = [orc.synth_rows(4321, 70 + j, 0, L) for j, L in enumerate(lens)]
         res = {}
-        for bv in (0, 3, 5, 6):
+        for bv in (0, 3):
             ix.set_option(_lib.MV_OPT_BATCH_VARIANT, bv)
             res[bv] = ix.query_batch(qs, 9)
         for j, q in enumerate(qs):
             ws, wi = ix.query(q, 9)
-            for bv in (0, 3, 5, 6):
+            for bv in (0, 3):
                 s, i = res[bv][j]
                 assert i.tolist() == wi.tolist(), (stride, lens, bv, j)
                 np.testing.assert_allclose(s, ws, rtol=1e-5)

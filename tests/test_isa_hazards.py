@@ -17,7 +17,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 BASE = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "-fno-fast-math",
         "-I" + os.path.join(ROOT, "include"), "-S", "--offload-device-only"]
 SCAN = ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-honor-nans"]  # csrc/Makefile: SCAN_FLAGS
-FILES = {"mv_fp8": SCAN, "mv_batch": SCAN, "mv_binary": SCAN, "mv_maxsim": SCAN, "mv_fde": []}
+FILES = {"mv_fp8": SCAN, "mv_batch": SCAN, "mv_binary": SCAN, "mv_maxsim": SCAN, "mv_fde": [], "mv_fde_batch": []}
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Coarse-stage time (stats.coarse_ms, HIP events) of the single-query FDE scan: variant 0 (wave per page, plain nt loads into
-VGPRs) against variant 3 (the same arithmetic behind the nt LDS-DMA ring), interleaved rounds on one index.
+VGPRs) against variant 5 (the same arithmetic, row quarters through the nt LDS-DMA ring), interleaved rounds on one index.
 
   python tools/fde_scan_probe.py [pages] [label]
-Chunk shape hooks of variant 3 (read once per process): MV_FDE_SCAN_PPW, MV_FDE_SCAN_BLOCKS_PER_CU."""
+Rows per workgroup of variant 5 (read once per process): MV_FDE_SCAN_RU."""
 import json
 import os
 import sys
@@ -22,16 +22,16 @@ def main():
     ix.fill_synthetic(1234, 0, n)
     out_dim = ix.fde_config.output_dim
     qs = [synth_rows(4321, j, 32) for j in range(8)]
-    out = {"pages": n, "label": sys.argv[2] if len(sys.argv) > 2 else "", "ppw": os.environ.get("MV_FDE_SCAN_PPW"), "blocks_per_cu": os.environ.get("MV_FDE_SCAN_BLOCKS_PER_CU")}
-    ts = {0: [], 3: [], 4: [], 5: []}
+    out = {"pages": n, "label": sys.argv[2] if len(sys.argv) > 2 else "", "rows_per_workgroup": os.environ.get("MV_FDE_SCAN_RU")}
+    ts = {0: [], 5: []}
     for rnd in range(4):
-        for v in (0, 3, 4, 5):
+        for v in (0, 5):
             ix.set_option(L.MV_OPT_FDE_SCAN_VARIANT, v)
             for r in range(12):
                 _s, _i, st = ix.query(qs[r % 8], 10, mode="fde", want_stats=True)
                 if r >= 4:
                     ts[v].append(st.coarse_ms)
-    for v in (0, 3, 4, 5):
+    for v in (0, 5):
         ms = float(np.median(ts[v]))
         out[f"variant_{v}"] = {"coarse_ms": round(ms, 4), "min_ms": round(float(np.min(ts[v])), 4), "GBps": round(n * out_dim * 2 / ms / 1e6, 1),
                                "frac_hbm_8TBps": round(n * out_dim * 2 / ms / 1e6 / 8000.0, 4)}

@@ -12,7 +12,7 @@ from morphik_core_amd.index import calibrate  # noqa: E402
 
 gb = float(sys.argv[1]) if len(sys.argv) > 1 else 25.6
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-whats = ("read_ldsdma", "fde_scan_rows", "fde_scan_stream", "fde_scan_ldsdma", "fde_scan_ldsdma_static", "fde_scan_regs", "read_nt")
+whats = ("read_ldsdma", "fde_scan_rowq", "fde_scan_regs", "read_nt")
 b = int(gb * 1e9)
 got = {w: [] for w in whats}
 for w in whats:
@@ -20,7 +20,7 @@ for w in whats:
 for r in range(rounds):
     for w in whats:
         got[w].append(calibrate(w, b, 8))
-out = {"GB": gb, "rounds": rounds, "ppw": os.environ.get("MV_FDE_SCAN_PPW"), "blocks_per_cu": os.environ.get("MV_FDE_SCAN_BLOCKS_PER_CU")}
+out = {"GB": gb, "rounds": rounds, "rows_per_workgroup": os.environ.get("MV_FDE_SCAN_RU")}
 for w in whats:
     out[w] = {"median": round(float(np.median(got[w])), 1), "min": round(float(np.min(got[w])), 1), "max": round(float(np.max(got[w])), 1)}
 print(json.dumps(out))
