@@ -771,7 +771,7 @@ def serving_block(args):
 
     from tools import serve_bench
 
-    a = types.SimpleNamespace(mode="fde_then_float", pages=args.aux_pages, patches=args.patches, clients="1,8,32,128", seconds=0.8, k=K, null_index=False)
+    a = types.SimpleNamespace(mode="fde_then_float", pages=args.aux_pages, patches=args.patches, clients="1,8,32,128", seconds=args.aux_serve_seconds, k=K, null_index=False)
     return serve_bench.measure(a)
 
 
@@ -855,6 +855,7 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend for N>1 (nccl == RCCL; gloo + MV_BENCH_SINGLE_DEVICE=1 lets N ranks share one GPU to "
                          "exercise the multi-rank path on a 1-GPU box -- a functional check, not a measurement)")
+    ap.add_argument("--aux-serve-seconds", type=float, default=0.8, help="seconds per (clients, coalescer) cell of aux_paths.serving")
     ap.add_argument("--aux-timeout", type=int, default=900, help="limit (s) of the child process that measures aux_paths")
     ap.add_argument("--aux-child", default=None, help=argparse.SUPPRESS)  # internal: state file of the aux child (run_aux_child)
     args = ap.parse_args()

@@ -155,7 +155,8 @@ int upload_query(mv_index* ix, const void* q, int q_dtype, int n_q, bool want_bf
       if (rc) return rc;
     }
   }
-  MV_HIP(hipEventRecord(ix->ev_stage, ix->stream));
+  // (a call that drains the stream before it returns needs no marker for the staging buffers: one event record less in the chain)
+  if (!ix->sync_call) MV_HIP(hipEventRecord(ix->ev_stage, ix->stream));
   return MV_OK;
 }
 
@@ -537,7 +538,10 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
   const bool need_meta = ix->tombstones.load() || d_allow != nullptr;
   int64_t pages = 0, rows = 0;  // accounting only (filled below, once it is known whether the filter was compacted)
 
-  MV_HIP(hipEventRecord(ix->ev[0], ix->stream));
+  // Stage events only when somebody will read them: every hipEventRecord between two dependent kernels costs ~5.8 us of device
+  // time on this stack (rocprofv3 kernel trace of one request, profiles/r5: gaps of 0.0 us between kernels with no event between
+  // them, 5.7-6.1 us with one), five of them on a 75-candidate FDE request.
+  if (st) MV_HIP(hipEventRecord(ix->ev[0], ix->stream));
   out->launches = 0;
   // Selective doc filter on a top-k scan: compact the allowed pages (in page order) and scan only those.
   const int32_t* d_scan_cand = nullptr;
@@ -657,7 +661,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
       out->d_scores = ix->d_cand_scores;
     }
   }
-  MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
+  if (st) MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
   if (st) {
     memset(st, 0, sizeof(*st));
     st->score_launches = out->launches;
@@ -1029,6 +1033,14 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   if (!rc && (hipHostMalloc((void**)&ix->h_out_s, (size_t)kTopkMaxDeviceK * 4, hipHostMallocDefault) != hipSuccess ||
               hipHostMalloc((void**)&ix->h_out_id, (size_t)kTopkMaxDeviceK * 8, hipHostMallocDefault) != hipSuccess ||
               hipHostMalloc((void**)&ix->h_cand, (size_t)2 * kTopkMaxDeviceK * 4, hipHostMallocDefault) != hipSuccess)) { set_error("hipHostMalloc failed"); rc = MV_ERR_NOMEM; }
+  if (!rc) {  // the device's view of the pinned result buffers (MV_DIRECT_HOST_RESULTS=0 keeps the D2H copies)
+    const char* e = getenv("MV_DIRECT_HOST_RESULTS");
+    void *ds = nullptr, *di = nullptr;
+    if (!(e && e[0] == '0') && hipHostGetDevicePointer(&ds, ix->h_out_s, 0) == hipSuccess && hipHostGetDevicePointer(&di, ix->h_out_id, 0) == hipSuccess) {
+      ix->hd_out_s = (float*)ds;
+      ix->hd_out_id = (int64_t*)di;
+    }
+  }
   if (cfg->flags & MV_WITH_FLOAT) alloc((void**)&ix->slab, rows * kRowBytes + 32768, "bf16 page slab");  // +32 KiB: the batched scans DMA whole 16 / 32 KiB chunks
   if (cfg->flags & MV_WITH_FP8) {
     alloc((void**)&ix->slab8, rows * kDim + 4096, "fp8 page slab");  // +4 KiB: the scan DMAs whole 4 KiB pieces
@@ -1531,10 +1543,13 @@ int mv_internal_query_common(mv_index* ix, const void* q, int q_dtype, int32_t n
   }
   ScanResult r;
   const int64_t want_n = mode == MV_MODE_FP8_THEN_FLOAT ? std::max<int64_t>(ix->rerank_n, k) : coarse_n_for(ix, k);
+  ix->sync_call = !ordered;  // every unordered path below ends in a hipStreamSynchronize (q_mu is held)
   int rc = run_scan(ix, q, q_dtype, n_q, mode, allow_bits, n_words, want_n, &r, st, /*want_compact=*/true, k);
+  ix->sync_call = false;
   if (rc) return rc;
   const int64_t id_base = ix->cfg.id_base;
   if (r.n == 0) {
+    if (!ordered) MV_HIP(hipStreamSynchronize(ix->stream));  // the query's H2D copies: the staging buffers are free when we return
     if (to_device) {
       std::vector<float> s((size_t)k, -INFINITY);
       std::vector<int64_t> id((size_t)k, -1);
@@ -1544,11 +1559,14 @@ int mv_internal_query_common(mv_index* ix, const void* q, int q_dtype, int32_t n
     return finish_stats(ix, st, false);
   }
   if (k <= kTopkMaxDeviceK) {
-    float* ds = to_device ? d_scores_out : ix->d_out_s;
-    int64_t* di = to_device ? d_ids_out : ix->d_out_id;
+    // host results: the selection's last kernel writes its k pairs straight into the pinned result buffers (device-visible host memory;
+    // visible to the host once the stream has drained) -- two D2H blit kernels and an event gap less at the end of every request
+    const bool direct = !to_device && ix->hd_out_s != nullptr && ix->hd_out_id != nullptr;
+    float* ds = to_device ? d_scores_out : (direct ? ix->hd_out_s : ix->d_out_s);
+    int64_t* di = to_device ? d_ids_out : (direct ? ix->hd_out_id : ix->d_out_id);
     rc = launch_topk(r.d_scores, r.n, k, r.d_ids_map, id_base, ix->d_topk_ws, ds, di, ix->stream);
     if (rc) return rc;
-    MV_HIP(hipEventRecord(ix->ev[2], ix->stream));
+    if (st || (to_device && ordered)) MV_HIP(hipEventRecord(ix->ev[2], ix->stream));  // timings / the caller's stream waits on it
     if (to_device) {
       if (ordered) {  // caller's stream waits for our result
         MV_HIP(hipStreamWaitEvent((hipStream_t)user_stream, ix->ev[2], 0));
@@ -1559,8 +1577,10 @@ int mv_internal_query_common(mv_index* ix, const void* q, int q_dtype, int32_t n
     }
     float* s = ix->h_out_s;
     int64_t* id = ix->h_out_id;
-    MV_HIP(hipMemcpyAsync(s, ds, (size_t)k * 4, hipMemcpyDeviceToHost, ix->stream));
-    MV_HIP(hipMemcpyAsync(id, di, (size_t)k * 8, hipMemcpyDeviceToHost, ix->stream));
+    if (!direct) {
+      MV_HIP(hipMemcpyAsync(s, ds, (size_t)k * 4, hipMemcpyDeviceToHost, ix->stream));
+      MV_HIP(hipMemcpyAsync(id, di, (size_t)k * 8, hipMemcpyDeviceToHost, ix->stream));
+    }
     MV_HIP(hipStreamSynchronize(ix->stream));
     int32_t n = 0;
     while (n < k && id[n] >= 0) ++n;

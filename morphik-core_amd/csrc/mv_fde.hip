@@ -1188,8 +1188,10 @@ int launch_fde_encode(const FdeTables& t, const FdeEncodeArgs& a, hipStream_t s)
   return MV_OK;
 }
 
-// Only the register form accumulates the selection's first histogram itself (persistent workgroups: one LDS histogram each);
-// behind the default form the radix selection takes its own first pass over the n scores (4 bytes per page against 20 480).
+// Only the register form accumulates the selection's first histogram itself (persistent workgroups: one LDS histogram each, flushed
+// once).  The row-quarter form's workgroups live for 16 rows: binning from them means global atomics on the dozen bins FDE scores share
+// -- measured (round 5, one atomic per distinct bin per workgroup): the 1.25 M-row scan went from 3.69 to 4.50 ms.  Behind the default
+// form the radix selection takes its own first pass over the n scores (4 bytes per page against 20 480).
 bool fde_scan_prebins(int variant, int64_t out_dim) { return variant == 0 && (out_dim == 10240 || out_dim == 5120); }
 
 // variant: -1 / 5 = row quarters on the nt LDS-DMA ring, one fresh workgroup per 16 rows (default at 10 240 / 5 120 dims);

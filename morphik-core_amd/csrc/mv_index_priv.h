@@ -53,6 +53,7 @@ struct mv_index {
   float* d_scores2 = nullptr;  // [capacity] (second accumulator for > 64 query rows)
   void* d_topk_ws = nullptr;
   size_t topk_ws_bytes = 0;
+  bool sync_call = false;      // the running query drains the stream before it returns (no staging-buffer event needed)
   uint16_t* d_q = nullptr;     // bf16 query, padded
   float* d_qf32 = nullptr;     // fp32 query rows (FDE encode input)
   uint8_t* d_qbits = nullptr;
@@ -102,6 +103,8 @@ struct mv_index {
   uint16_t* h_qbf16 = nullptr;
   float* h_out_s = nullptr;
   int64_t* h_out_id = nullptr;
+  float* hd_out_s = nullptr;    // the same pinned buffers as the DEVICE addresses them (the selection writes host results in place)
+  int64_t* hd_out_id = nullptr;
   int32_t* h_cand = nullptr;       // [kTopkMaxDeviceK] pinned: candidate ids read back for the accounting only
   hipEvent_t ev_stage = nullptr;  // recorded behind the H2D copies of the staging buffers
   hipEvent_t ev[6] = {};

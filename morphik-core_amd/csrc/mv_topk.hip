@@ -451,6 +451,52 @@ size_t topk_ws_bytes(int64_t n, int32_t k) {
   return (size_t)(2 * (l1 + kChunk)) * sizeof(uint64_t) + kRadixTailBytes;
 }
 
+// The last step of every reranked request: k of a list of <= 256 scores (the reference's min(10 k, 75) candidates, torch.topk at
+// fast_multivector_store.py:556).  ONE wave: four keys per lane in registers, k rounds of lane maximum -> xor butterfly -> the owner
+// retires its key; no LDS, no barrier.  The block-wide extraction kernel spent ~10 us on a 75-entry list (rocprofv3 trace of one
+// request, profiles/r5), this one is at the floor of a launch.  Same keys, same tie rule (score desc, list position asc).
+__global__ __launch_bounds__(64) void topk_small_kernel(const float* scores, int n, int kk, TopkOut o, TopkBatch tb) {
+  if (scores) scores += (int64_t)blockIdx.y * tb.score_stride;
+  tb_out(o, tb);
+  const int lane = threadIdx.x;
+  uint64_t key[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int gi = lane + 64 * j;
+    uint64_t k64 = 0;
+    if (gi < n) {
+      const float s = scores[gi] + 0.0f;
+      if (s == s && s != -INFINITY) k64 = ((uint64_t)ordered_u32(s) << 32) | (uint32_t)(~(uint32_t)gi);
+    }
+    key[j] = k64;
+  }
+  uint64_t mine = 0;  // lane r keeps the r-th winner
+  for (int r = 0; r < kk; ++r) {
+    uint64_t m = umax64(umax64(key[0], key[1]), umax64(key[2], key[3]));
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+      const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)m, sft);
+      const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(m >> 32), sft);
+      m = umax64(m, ((uint64_t)hi << 32) | lo);
+    }
+    if (lane == r) mine = m;
+    if (m == 0) break;  // the list is exhausted (wave-uniform): the remaining lanes keep 0 = padding
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (key[j] == m) key[j] = 0;  // keys are unique (they carry their position)
+  }
+  if (lane < o.k) {
+    if (mine == 0) {
+      o.out_s[lane] = -INFINITY;
+      o.out_id[lane] = -1;
+    } else {
+      const uint32_t idx = ~(uint32_t)(mine & 0xffffffffu);
+      o.out_s[lane] = unordered_f32((uint32_t)(mine >> 32));
+      o.out_id[lane] = o.id_base + (o.ids_map ? (int64_t)o.ids_map[idx] : (int64_t)idx);
+    }
+  }
+}
+
 // Merge of per-shard top-k lists after the all-gather (row-sharded corpus, morphik_core_amd/sharded.py): scores/ids are
 // [world][kk], each row sorted (score desc, id asc) and padded with (-inf, -1), rank r owning ids below rank r+1's.
 // One block: 64-bit keys (ordered score, ~position) -> bitonic sort -> first k.  Equal scores keep (rank, position)
@@ -532,6 +578,11 @@ int launch_topk_batch(const float* d_scores, int64_t score_stride, int64_t n, in
   const float* sc = d_scores;
   const uint64_t* in = nullptr;
   uint64_t* outk = bufA;
+  if (cur_n <= 256 && k <= 64 && d_scores) {  // a rerank list: one wave finishes it
+    hipLaunchKernelGGL(topk_small_kernel, dim3(1, gy), dim3(64), 0, s, sc, (int)cur_n, (int)std::min<int64_t>(k, 64), out, tb);
+    MV_HIP(hipGetLastError());
+    return MV_OK;
+  }
   if (topk_uses_radix(cur_n, k)) {
     char* head = reinterpret_cast<char*>(ws);
     uint64_t* surv = reinterpret_cast<uint64_t*>(head);

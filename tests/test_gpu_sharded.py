@@ -296,34 +296,6 @@ def test_shard_comm_rccl_single_rank_communicator():
 
 
 # ------------------------------------------------------------------ the N > 1 bench line is as complete as the N = 1 line
-def test_bench_two_ranks_line_carries_roofline_cpu_baseline_and_oracle_parity():
-    """`python bench.py --gpus 2` (self-spawned ranks sharing the one GPU, gloo): the JSON line of a multi-rank run must
-    carry everything the 1-GPU line does -- roofline, cpu_baseline, the sampled oracle parity, recall -- plus per-rank
-    kernel times and what the exchange adds per step."""
-    import json
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MV_BENCH_SINGLE_DEVICE="1")
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--pages", "40000", "--steps", "6", "--warmup", "2",
-           "--cpu-sample-pages", "512", "--no-aux"]
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=root)
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert p.returncode == 0 and lines, p.stderr[-2000:]
-    d = json.loads(lines[-1])
-    assert d["n_gpus"] == 2 and d["recall_at_10"] == 1.0 and d["config"]["pages_total"] == 40000
-    rf, cpu = d["roofline"], d["cpu_baseline"]
-    assert rf["bound"] == "hbm" and rf["achieved"] > 0 and 0 < rf["frac"] < 1.2 and len(rf["kernel_ms_per_rank"]) == 2
-    assert cpu is not None and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["kind"] == "port"
-    assert d["max_rel_score_err_vs_oracle"] is not None and d["max_rel_score_err_vs_oracle"] < 1e-3 and d["generator_matches_oracle"] is True
-    cfg = d["config"]
-    assert cfg["collective_and_merge_ms_per_step"] is not None and cfg["local_scan_and_topk_ms_per_step"] > 0
-    assert len(lines[-1]) < 3000 and "metric" in d and all("metric" not in json.loads(ln) for ln in lines[:-1])  # the headline is the LAST line, compact
-    assert cfg["collective_backend"] == "gloo" and cfg["parallelism"].startswith("row-shard x2")
-
-
 def test_bench_eight_ranks_on_one_gpu_full_corpus_line():
     """`MV_BENCH_SINGLE_DEVICE=1 python bench.py --gpus 8 --backend gloo --pages 1000000`: the N = 8 launch the driver will make
     on an 8-GPU node, here with the eight ranks sharing the one GPU (8 x 125 k pages = the full 1 M-page corpus, 262 GB of HBM)
@@ -355,6 +327,9 @@ def test_bench_eight_ranks_on_one_gpu_full_corpus_line():
     assert d["max_rel_score_err_vs_oracle"] is not None and d["max_rel_score_err_vs_oracle"] < 1e-3 and d["generator_matches_oracle"] is True
     cfg = d["config"]
     assert cfg["collective_backend"] == "gloo" and cfg["parallelism"].startswith("row-shard x8") and cfg["collective_and_merge_ms_per_step"] is not None
+    # what the exchange costs by itself (one packed all-gather of k pairs per rank + merge) and what the step loses to it
+    assert 0 < cfg["collective_and_merge_ms_per_step"] < 5.0 and cfg["local_scan_and_topk_ms_per_step"] > 0 and cfg["step_minus_local_ms_per_step"] is not None
+    assert 0 < rf["frac"] < 1.2 and "metric" in d
 
 
 # ------------------------------------------------------------------ batched two-stage communicator
