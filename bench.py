@@ -67,6 +67,9 @@ def timed_runs(fn, min_runs=5, budget_s=12.0, max_runs=7):
     return times
 
 
+CPU_SWEEP_SCALE = 1.0  # --cpu-baseline-quick shortens every timing budget of cpu_baseline (tests of the LINE, not of the host)
+
+
 def cpu_baseline(sample_pages_u16, q_u16):
     """Reference CPU path timed on this box's host cores, on a bounded sample of the same workload (BASELINE.md section 3:
     >= 20 000 pages, >= 5 repeats, median).  The reference's float MaxSim (fast_multivector_store.py:553-555 ->
@@ -114,6 +117,8 @@ def cpu_baseline(sample_pages_u16, q_u16):
         return run
 
     def rate(fn, m, min_runs, budget):
+        if CPU_SWEEP_SCALE < 1.0:
+            min_runs, budget = min(min_runs, 2), budget * CPU_SWEEP_SCALE
         times = timed_runs(fn, min_runs=min_runs, budget_s=budget, max_runs=max(min_runs, 7))
         return m / float(np.median(times)), len(times)
 
@@ -158,7 +163,7 @@ def cpu_baseline(sample_pages_u16, q_u16):
         "numa_nodes": numa,
         "numa_note": "the sample is first-touched by one thread (one node); workers on the other socket read it across the link -- as a single-process "
                      "reference deployment would",
-        "sample": f"{n} pages x {pages.shape[1]} patches x 128-d fp32 (upcast bf16), Q={q.shape[0]}; thread counts swept on {sweep_n} pages, every family's best "
+        "sample": ("QUICK (a tenth of the timing budgets: not a record) " if CPU_SWEEP_SCALE < 1.0 else "") + f"{n} pages x {pages.shape[1]} patches x 128-d fp32 (upcast bf16), Q={q.shape[0]}; thread counts swept on {sweep_n} pages, every family's best "
                   f"timed on the whole sample (median of {min(used.values())}+ runs; torch_einsum on {n_torch} pages); best = {best} with {threads[best]} threads",
     }
 
@@ -831,6 +836,7 @@ def main():
     ap.add_argument("--variant", type=int, default=-1, help="float kernel variant (-1 = library default)")
     ap.add_argument("--cpu-sample-pages", type=int, default=20480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-quick", action="store_true", help="a tenth of every CPU timing budget (tests of the result line; not for a record)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--workload", choices=["float", "fp8", "binary", "fde_fp8", "embed"], default="float",
                     help="float = BASELINE configs[2] (the headline, default); fp8 = e4m3 slab (configs[4]); binary = sign-bit "
@@ -859,6 +865,9 @@ def main():
     ap.add_argument("--aux-timeout", type=int, default=900, help="limit (s) of the child process that measures aux_paths")
     ap.add_argument("--aux-child", default=None, help=argparse.SUPPRESS)  # internal: state file of the aux child (run_aux_child)
     args = ap.parse_args()
+    if args.cpu_baseline_quick:
+        global CPU_SWEEP_SCALE
+        CPU_SWEEP_SCALE = 0.1
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))

@@ -79,7 +79,7 @@ def test_default_aux_run_last_line_is_the_compact_headline():
     """The driver's command shape (`python bench.py --steps K --warmup W`, aux ON) at a reduced corpus: the last stdout line is
     the headline, short, with roofline.frac and cpu_baseline.value; the timed region fits the wall clock of the run; the aux
     record is an earlier line and a file."""
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--pages", "50000", "--cpu-sample-pages", "512",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--pages", "50000", "--cpu-sample-pages", "512", "--cpu-baseline-quick",
            "--full-shard-pages", "50000", "--exact-shard-pages", "50000", "--aux-pages", "8000", "--aux-embed-pages", "0", "--aux-serve-seconds", "0.15"]
     t0 = time.time()
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200, cwd=ROOT)

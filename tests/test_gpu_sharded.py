@@ -310,7 +310,7 @@ def test_bench_eight_ranks_on_one_gpu_full_corpus_line():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MV_BENCH_SINGLE_DEVICE="1")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--pages", "1000000", "--steps", "6", "--warmup", "2",
-           "--cpu-sample-pages", "2048", "--no-aux"]
+           "--cpu-sample-pages", "2048", "--cpu-baseline-quick", "--no-aux"]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500, cwd=root)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert p.returncode == 0 and lines, p.stderr[-3000:]

@@ -1,12 +1,13 @@
 #!/bin/bash
 # Host-side sanitizer runs WITHOUT a GPU: libmvmaxsim_{tsan,asan}.so (csrc/Makefile) + the host-only HIP stub + host_stress.cpp.
-#   bash tools/sanitize/run.sh [iterations]      -> profiles/r4/sanitize_{tsan,asan}_host_8dev.log
+#   bash tools/sanitize/run.sh [iterations]      -> profiles/r5/sanitize_{tsan,asan}_host_8dev.log (PROFILE_DIR)
 set -u
 R=$(cd "$(dirname "$0")/../.." && pwd)
 ITERS=${1:-200}
 CLANG=/opt/rocm/lib/llvm/bin/clang
 CLANGXX=/opt/rocm/lib/llvm/bin/clang++
-B=$R/tools/sanitize/build; mkdir -p $B $R/profiles/r4
+P=${PROFILE_DIR:-$R/profiles/r5}
+B=$R/tools/sanitize/build; mkdir -p $B $P
 make -C $R/morphik-core_amd/csrc -s -j8 tsan asan || exit 1
 for SAN in thread address; do
   S=$([ $SAN = thread ] && echo tsan || echo asan)
@@ -19,7 +20,7 @@ for SAN in thread address; do
   $CLANGXX -O1 -g -std=c++17 -fsanitize=$SAN -shared-libsan -I$R/include -o $B/$S/host_stress $R/tools/sanitize/host_stress.cpp \
       $R/morphik-core_amd/libmvmaxsim_$S.so -L$B/$S -l:libamdhip64.so.7 -lpthread -ldl -Wl,-rpath,$R/morphik-core_amd || exit 1
   RT=$(dirname $($CLANG -print-file-name=libclang_rt.$S-x86_64.so))
-  LOG=$R/profiles/r4/sanitize_${S}_host_8dev.log
+  LOG=$P/sanitize_${S}_host_8dev.log
   if [ $S = tsan ]; then OPT="TSAN_OPTIONS=halt_on_error=0:second_deadlock_stack=1:history_size=4"; else OPT="ASAN_OPTIONS=detect_leaks=1:halt_on_error=0"; fi
   ( cd /tmp && env $OPT LD_LIBRARY_PATH=$B/$S:$RT timeout 1200 $B/$S/host_stress $ITERS ) > $LOG 2>&1
   echo "$S: exit $? ; reports: $(grep -c 'WARNING: ThreadSanitizer\|ERROR: AddressSanitizer\|ERROR: LeakSanitizer\|AFFINITY VIOLATION\|RCCL STUB VIOLATION' $LOG)"; tail -2 $LOG
