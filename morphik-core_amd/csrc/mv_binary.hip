@@ -411,6 +411,11 @@ __global__ __launch_bounds__(256) void maxsim_binary_mfma2_kernel(BMArgs args) {
 //   variant 5  persistent waves, one continuous DMA stream across pages           slower than fresh workgroups (as for the float scan)
 //   variant 6  four-page burst per workgroup (64 KiB contiguous)                  6.29-6.31 TB/s against 6.56-6.61 for variant 4
 //   variants 2 / 3  the ring of variant 4 with 8 / 16 slots                       390 / 295 M pages/s
+// Round 5 built one more and removed it: the same arithmetic over PAGE QUARTERS (sixteen pages per fresh workgroup, wave w streaming the w-th
+// 4 KiB of every page, one barrier per workgroup joining the quarters) -- the shape the ring transport streams 8 % faster than this kernel's
+// (7.05 against 6.51 TB/s with no consumer, profiles/r5/stream_structure_probe_sweep3_*).  Bit-identical scores, 5.3-5.5 TB/s against 6.8
+// (profiles/r5/sign_bit_page_quarter_form_experiment_r5m.jsonl): this scan is bound by issue slots (VALU 69 %, MFMA 41 % busy), and the ring
+// and partial-sum LDS of the quarter form leave a CU 8 waves where this kernel has 32.
 
 // popc(q row) as float for rows < n_q, -1 for the padding rows up to `padded`; also zero-fills the padding bit rows
 __global__ void binary_qprep_kernel(uint4* qbits, int n_q, int padded, float* qpop, int signslot) {

@@ -616,25 +616,30 @@ def test_binary_maxsim_synthetic_slab_1024(mv, variant):
         ix.close()
 
 
-def test_binary_variants_agree_with_filter_and_tombstones_midsize(mv):
-    """Both sign-bit kernels over 20 k ragged pages with a doc filter and tombstones: identical vectors."""
-    n = 20_000
+@pytest.mark.parametrize("n_rows", [1000, 1024])  # ragged / uniform pages
+def test_binary_variants_agree_with_filter_and_tombstones_midsize(mv, n_rows):
+    """The sign-bit kernels over 20 k pages with a doc filter and tombstones: identical vectors (20 003 pages: a partial last workgroup;
+    a run of 140 tombstoned pages; queries of one and of several row tiles, one and two passes)."""
+    n = 20_003
     ix = _idx(mv, capacity_pages=n, stride_rows=1024, with_binary=True)
-    ix.fill_synthetic(1234, 0, n, n_rows=1000, pages_per_doc=7)
+    ix.fill_synthetic(1234, 0, n, n_rows=n_rows, pages_per_doc=7)
+    for d in range(40, 60):  # 140 consecutive pages gone: whole workgroups have nothing to stream
+        ix.remove_doc(d)
     for d in (3, 11, 500):
         ix.remove_doc(d)
     from morphik_core_amd.index import allow_bitmap
 
     allow = allow_bitmap([d for d in range(0, n // 7 + 1) if d % 3 != 1])
-    q = orc.synth_rows(4321, 1, 0, 32)
-    outs = []
-    for v in BINARY_VARIANTS:
-        _set_binary_variant(ix, v)
-        outs.append((ix.score_all(q, mode="binary", allow=allow), ix.query(q, 10, mode="binary", allow=allow)))
-    for o in outs[1:]:
-        assert np.array_equal(outs[0][0], o[0])
-        assert outs[0][1][1].tolist() == o[1][1].tolist() and outs[0][1][0].tolist() == o[1][0].tolist()
-    assert np.isinf(outs[0][0]).sum() > n // 4  # the filter really masked pages
+    for nq in (32, 9, 40, 100):
+        q = orc.synth_rows(4321, nq, 0, nq)
+        outs = []
+        for v in BINARY_VARIANTS + [-1]:
+            _set_binary_variant(ix, v)
+            outs.append((ix.score_all(q, mode="binary", allow=allow), ix.query(q, 10, mode="binary", allow=allow), ix.score_all(q, mode="binary")))
+        for o in outs[1:]:
+            assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][2], o[2])
+            assert outs[0][1][1].tolist() == o[1][1].tolist() and outs[0][1][0].tolist() == o[1][0].tolist()
+        assert np.isinf(outs[0][0]).sum() > n // 4  # the filter really masked pages
     ix.close()
 
 

@@ -30,6 +30,17 @@ SHAPES2 = [  # second sweep (round 5, call 6): rows of 20 KiB, row quarters, the
     ("row quarters, persistent claimed, 16 rows", 3, 2, 16, 2, 0),
     ("row quarters, persistent static, 64 rows", 3, 1, 64, 2, 0),
 ]
+SHAPES3 = [  # third sweep: shapes within reach of a 16 KiB sign-bit page (4 tiles of 4 KiB)
+    ("float-scan shape: wg/interleaved, fresh, 256 KiB", 0, 0, 64, 2, 0),
+    ("sign-bit scan today: four wave-owned 16 KiB pages per fresh workgroup", 2, 0, 4, 2, 0),
+    ("one 16 KiB page per fresh workgroup, one 4 KiB tile per wave", 0, 0, 4, 2, 0),
+    ("four pages (64 KiB) per fresh workgroup, tiles interleaved", 0, 0, 16, 2, 0),
+    ("four pages per fresh workgroup, contiguous quarters (= one page per wave, one unit)", 1, 0, 16, 2, 0),
+    ("sixteen pages (256 KiB) per fresh workgroup, tiles interleaved", 0, 0, 64, 2, 0),
+    ("wave-owned 64 KiB (four pages per wave), fresh", 2, 0, 16, 2, 0),
+    ("wave-owned 16 KiB, persistent claimed", 2, 2, 4, 2, 0),
+    ("e4m3 page: 128 KiB per fresh workgroup, tiles interleaved", 0, 0, 32, 2, 0),
+]
 SHAPES = [  # (label, own, sched, ct, blocks_per_cu)
     ("float-scan shape: wg/interleaved, fresh, 256 KiB", 0, 0, 64, 2),
     ("wg/interleaved, fresh, 20 KiB (one FDE row)", 0, 0, 5, 2),
@@ -48,6 +59,8 @@ SHAPES = [  # (label, own, sched, ct, blocks_per_cu)
 ]
 if os.environ.get("MV_PROBE_SWEEP") == "2":
     SHAPES = SHAPES2
+if os.environ.get("MV_PROBE_SWEEP") == "3":
+    SHAPES = SHAPES3
 SHAPES = [t if len(t) == 6 else t + (0,) for t in SHAPES]
 got = {s[0]: [] for s in SHAPES}
 ref = []
