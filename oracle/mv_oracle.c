@@ -39,7 +39,8 @@
  *                         the reference itself has no test of this boundary.
  *   binary MaxSim       : pinned against the reference test's known answers
  *                         (core/tests/unit/test_multivector.py:214-256 -> 1.0 / 0.0).
- *   FDE                 : PARITY UNPINNED (no source, no tests upstream).
+ *   FDE                 : PARITY UNPINNED (no source, no tests upstream).  oracle/gen_golden_fde.py writes tests/golden/fde.npz from the
+ *                         reference's own extension wherever it imports; the tests load it when present (skip otherwise).
  */
 #include <math.h>
 #include <stdint.h>
