@@ -202,6 +202,8 @@ class GpuShardedSearcher:
 
         from ._lib import check
 
+        if (k, self._flip) not in self._bufs:
+            raise RuntimeError("exchange_only(k) repeats the exchange of the last query(q, k): run one first")
         mine, _ps, _pi, gathered, os_, oi = self._bufs[(k, self._flip)]
         if dist.is_initialized():
             dist.all_gather_into_tensor(gathered, mine, group=self.group)
@@ -250,6 +252,8 @@ class HostShardedSearcher:
         import numpy as np
         import torch.distributed as dist
 
+        if k not in self._bufs:
+            raise RuntimeError("exchange_only(k) repeats the exchange of the last query(q, k): run one first")
         mine, allb = self._bufs[k]
         m = mine.numpy()
         if dist.is_initialized():
