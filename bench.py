@@ -1353,15 +1353,27 @@ def emit(out, aux):
 def run_aux_child(args, state):
     """Re-execute this file with --aux-child <state file>: the child rebuilds the (deterministic) query / page sets, takes the
     exact truths from the state file and measures the secondary paths; its one stdout line is the aux dict."""
-    path = os.path.join(out_dir(), "bench_aux_state.json")
-    with open(path, "w") as f:
-        json.dump(state, f)
+    import tempfile
+
+    try:  # nothing on this path may cost the headline: an unwritable tree falls back to the temp directory, any other failure is recorded
+        try:
+            path = os.path.join(out_dir(), "bench_aux_state.json")
+            with open(path, "w") as f:
+                json.dump(state, f)
+        except OSError:
+            fd, path = tempfile.mkstemp(prefix="bench_aux_state_", suffix=".json")
+            with os.fdopen(fd, "w") as f:
+                json.dump(state, f)
+    except Exception as e:  # noqa: BLE001
+        return {"aux_child_error": f"could not write the state file: {e!r}"}
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--aux-child", path]
     t0 = time.time()
     try:
         p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, timeout=args.aux_timeout)
     except subprocess.TimeoutExpired:
         return {"aux_child_error": f"timed out after {args.aux_timeout} s"}
+    except OSError as e:
+        return {"aux_child_error": f"could not start the child: {e!r}"}
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     if not lines:
         return {"aux_child_error": f"no record (exit code {p.returncode})"}
