@@ -271,7 +271,11 @@ MV_API int mv_query_topk_device(mv_index* ix, const void* q, int q_dtype, int32_
 /* The enqueue-only form WITH timings (one rank's step of a row-sharded search: the scan, then the all-gather and the merge
  * behind it on `stream`, nothing of which should wait for the host): as mv_query_topk_device with a non-NULL stream, but
  * `stats` (non-NULL) receives only the accounting fields now; the HIP-event timings of THIS query are filled in by
- * mv_query_stats_finish(ix, stats) -- which waits for the scan's events -- called any time before the next query on `ix`.
+ * mv_query_stats_finish(ix, stats) -- which waits for the scan's events.  ONE such record may stay outstanding across the NEXT
+ * mv_query_topk_device_async on `ix` (the library keeps two sets of timing events): a caller that collects query i's timings right
+ * after enqueueing query i+1 never lets the GPU wait for the host.  (Records of the FDE modes carry stage accounting that reads the
+ * candidate list: finish those before the next query, MV_ERR_STATE otherwise; and a query WITH timings through any other entry point
+ * in between records into the outstanding record's events.)
  * stream = NULL names the legacy default stream here (the call still only enqueues). */
 MV_API int mv_query_topk_device_async(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, int32_t k, int mode,
                                       const uint32_t* allow_bits, int64_t n_allow_words, float* d_out_scores,

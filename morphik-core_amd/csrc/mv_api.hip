@@ -676,6 +676,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
 
 int finish_stats(mv_index* ix, mv_query_stats* st, bool had_topk) {
   if (!st) return MV_OK;
+  st->reserved &= ~(kStatsDeferredTag | kStatsParityBit);  // a deferred record's routing bits are not stage flags
   MV_HIP(hipEventSynchronize(ix->ev[had_topk ? 2 : 1]));
   if (st->reserved) {  // stage split of the FDE modes (events recorded by run_scan)
     MV_HIP(hipEventElapsedTime(&st->encode_ms, ix->ev[0], ix->ev_st[0]));
@@ -985,6 +986,10 @@ void mv_index_destroy(mv_index* ix) {
     if (e) (void)hipEventDestroy(e);
   for (auto& e : ix->ev_st)
     if (e) (void)hipEventDestroy(e);
+  for (auto& e : ix->ev_alt)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : ix->ev_st_alt)
+    if (e) (void)hipEventDestroy(e);
   if (ix->ev_stage) (void)hipEventDestroy(ix->ev_stage);
   for (void* hp : {(void*)ix->h_qf32, (void*)ix->h_qbf16, (void*)ix->h_out_s, (void*)ix->h_out_id, (void*)ix->h_cand, (void*)ix->h_bout_s,
                    (void*)ix->h_bout_id, (void*)ix->h_bcand, (void*)ix->h_exact})  // (slab_x, the HBM part of a split exact tier, went with ptrs[])
@@ -1028,6 +1033,10 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   for (auto& e : ix->ev)
     if (!rc && hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); rc = MV_ERR_HIP; }
   for (auto& e : ix->ev_st)
+    if (!rc && hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); rc = MV_ERR_HIP; }
+  for (auto& e : ix->ev_alt)
+    if (!rc && hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); rc = MV_ERR_HIP; }
+  for (auto& e : ix->ev_st_alt)
     if (!rc && hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); rc = MV_ERR_HIP; }
   if (!rc && hipEventCreateWithFlags(&ix->ev_stage, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); rc = MV_ERR_HIP; }
   if (!rc && (hipHostMalloc((void**)&ix->h_out_s, (size_t)kTopkMaxDeviceK * 4, hipHostMallocDefault) != hipSuccess ||
@@ -1513,6 +1522,11 @@ int mv_synth_rows(int device, uint64_t seed, uint64_t unit, int32_t n_rows, void
 
 // Shared body of the top-k entry points (also used by mv_comm.hip).  defer_stats: fill the accounting fields of `st` but
 // leave the event timings to a later mv::finish_stats(ix, st, true) -- the call then only enqueues.
+static void swap_timing_event_sets(mv_index* ix) {
+  for (int i = 0; i < 3; ++i) { std::swap(ix->ev[i], ix->ev_alt[i]); std::swap(ix->ev_st[i], ix->ev_st_alt[i]); }
+  ix->ev_parity ^= 1;
+}
+
 int mv_internal_query_common(mv_index* ix, const void* q, int q_dtype, int32_t n_q, int32_t k, int mode,
                              const uint32_t* allow_bits, int64_t n_words, float* h_scores, int64_t* h_ids, int32_t* out_n,
                              float* d_scores_out, int64_t* d_ids_out, void* user_stream, mv_query_stats* st, int defer_stats) {
@@ -1525,6 +1539,7 @@ int mv_internal_query_common(mv_index* ix, const void* q, int q_dtype, int32_t n
   if (to_device && k > kTopkMaxDeviceK) { set_error("device-output top-k supports k <= %d", kTopkMaxDeviceK); return MV_ERR_INVALID; }
   const bool ordered = user_stream != nullptr;  // kNullStreamTag: ordered against the null stream itself
   if (user_stream == kNullStreamTag) user_stream = nullptr;
+  if (st && defer_stats) swap_timing_event_sets(ix);  // the previous deferred query's events stay readable (mv_query_stats_finish)
   if (ordered) {  // order our stream behind the caller's
     MV_HIP(hipEventRecord(ix->ev[3], (hipStream_t)user_stream));
     MV_HIP(hipStreamWaitEvent(ix->stream, ix->ev[3], 0));
@@ -1573,6 +1588,7 @@ int mv_internal_query_common(mv_index* ix, const void* q, int q_dtype, int32_t n
       } else {
         MV_HIP(hipStreamSynchronize(ix->stream));
       }
+      if (st && defer_stats) st->reserved |= kStatsDeferredTag | (ix->ev_parity ? kStatsParityBit : 0);
       return (st && !defer_stats) ? finish_stats(ix, st, true) : MV_OK;
     }
     float* s = ix->h_out_s;
@@ -1636,7 +1652,17 @@ int mv_query_stats_finish(mv_index* ix, mv_query_stats* stats) {
   if (!ix || !stats) { set_error("mv_query_stats_finish: null argument"); return MV_ERR_INVALID; }
   std::lock_guard<std::mutex> lk(ix->q_mu);
   DeviceGuard g(ix->cfg.device);
-  return finish_stats(ix, stats, true);
+  const bool tagged = (stats->reserved & kStatsDeferredTag) != 0;
+  const int parity = (stats->reserved & kStatsParityBit) ? 1 : 0;
+  stats->reserved &= ~(kStatsDeferredTag | kStatsParityBit);
+  if (!tagged || parity == ix->ev_parity) return finish_stats(ix, stats, true);  // the most recent query: the current event set
+  // ONE query behind: its events are in the other set.  The stage accounting of the FDE modes reads the candidate list, which the newer
+  // query has overwritten by now: such a record must be finished before the next query is enqueued
+  if (stats->reserved) { set_error("mv_query_stats_finish: the stage accounting of an FDE-mode query must be collected before the next query on this index"); return MV_ERR_STATE; }
+  swap_timing_event_sets(ix);
+  const int rc = finish_stats(ix, stats, true);
+  swap_timing_event_sets(ix);
+  return rc;
 }
 
 // ---- the caller's own FDE vectors (the reference computes them with its `fde` extension: fast_multivector_store.py:447-449, :521)

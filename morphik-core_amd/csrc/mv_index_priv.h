@@ -109,6 +109,11 @@ struct mv_index {
   hipEvent_t ev_stage = nullptr;  // recorded behind the H2D copies of the staging buffers
   hipEvent_t ev[6] = {};
   hipEvent_t ev_st[3] = {};       // FDE stage boundaries: after the query encode, after the coarse scan, after the selection
+  // second set of the timing events: an enqueue-only query with deferred timings (mv_query_topk_device_async) swaps the sets before
+  // it records, so the PREVIOUS deferred query's events survive until mv_query_stats_finish reads them -- one query may be outstanding
+  hipEvent_t ev_alt[3] = {};
+  hipEvent_t ev_st_alt[3] = {};
+  int ev_parity = 0;
   std::mutex q_mu;  // queries + the per-query workspace
   std::mutex w_mu;  // writers
   // writer-side staging (w_mu): grown on demand, never freed while a scan may run (hipFree synchronises the device)
@@ -221,6 +226,9 @@ RerankPlan rerank_plan(const mv_index* ix, int mode, int64_t n_list, int32_t k, 
 // -1 (skipped by the rerank kernels).  The list keeps its order, so pad lengths and the tie rule (by list position) are untouched.
 int launch_keep_selected(const int64_t* d_pos, int64_t pos_stride, int n_sel, int32_t* d_cand, int64_t cand_stride, int n, int nb, hipStream_t s);
 int finish_stats(mv_index* ix, mv_query_stats* st, bool had_topk);
+// bits of mv_query_stats::reserved that travel with a DEFERRED record (mv_query_topk_device_async -> mv_query_stats_finish): which of the two
+// timing-event sets its query recorded into; the low bits are finish_stats' own stage flags
+constexpr int32_t kStatsDeferredTag = 1 << 25, kStatsParityBit = 1 << 26;
 // user_stream value of mv_internal_query_common meaning "the NULL (default) stream, ordered against -- not `no stream, block`"
 static void* const kNullStreamTag = reinterpret_cast<void*>(~(uintptr_t)0);
 

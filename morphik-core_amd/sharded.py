@@ -140,9 +140,9 @@ class GpuShardedSearcher:
          the result; the k ids and k scores land in the two halves of ONE preallocated block ({int64 ids[k], float scores[k]})
       2. ONE all_gather_into_tensor of that block (uint8, mv_topk_block_bytes(k) = 128 B per rank at k = 10)
       3. ONE library launch (mv_merge_topk_blocks, torch's current stream, behind the collective) -> merged top-k.
-    The HIP-event timings of the scan are collected AFTER step 3 was enqueued (finish_stats): the host waits for the scan there,
-    with the collective and the merge already queued behind it.  Results are padded with (-inf, -1) and become valid in stream
-    order (read them after a synchronize or from the same stream)."""
+    The HIP-event timings of a scan are collected ONE QUERY LATER (the library keeps two sets of timing events): query i's record
+    is finished right after query i + 1 was enqueued, so the host never holds the GPU up -- call flush() for the last one.  Results are
+    padded with (-inf, -1) and become valid in stream order (read them after a synchronize or from the same stream)."""
 
     def __init__(self, index, device=None, mode: str = "float", group=None, collect_stats=None):
         import torch
@@ -156,6 +156,14 @@ class GpuShardedSearcher:
         self._lib = lib()
         self._bufs = {}
         self._flip = 0
+        self._pending = None  # the stats record of the last enqueued query (finished one query later, or by flush())
+        self._trail = mode not in ("fde_then_float", "fde")  # (FDE-mode records carry stage accounting: finished before the next query)
+
+    def flush(self) -> None:
+        """Collect the timings of the last enqueued query (waits for its scan)."""
+        if self._pending is not None and self.stats is not None:
+            self.stats.append(self.index.finish_stats(self._pending))
+        self._pending = None
 
     def _buffers(self, k):
         import torch
@@ -190,7 +198,12 @@ class GpuShardedSearcher:
         check(self._lib.mv_merge_topk_blocks(self.index.device, C.c_void_p(gathered.data_ptr()), self.world, k, k,
                                              C.c_void_p(os_.data_ptr()), C.c_void_p(oi.data_ptr()), C.c_void_p(stream)))
         if self.stats is not None:
-            self.stats.append(self.index.finish_stats(pending))
+            if not self._trail:
+                self.stats.append(self.index.finish_stats(pending))
+            else:
+                prev, self._pending = self._pending, pending
+                if prev is not None:  # the query BEFORE this one: its scan ran while this one was being enqueued
+                    self.stats.append(self.index.finish_stats(prev))
         return os_, oi
 
     def exchange_only(self, k: int):

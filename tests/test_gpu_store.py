@@ -388,7 +388,30 @@ def test_gpu_sharded_searcher_step_enqueues_without_a_host_wait_and_reports_the_
         torch.cuda.synchronize()
         ws, wi = ix.query(q, 10)
         assert i.cpu().numpy().tolist() == wi.tolist() and s.cpu().numpy().tolist() == ws.tolist()
+    assert len(stats) == 7  # the timings trail the queries by one (two event sets in the library) ...
+    gs.flush()
     assert len(stats) == 8 and all(st.score_kernel_ms > 0 and st.total_device_ms >= st.score_kernel_ms for st in stats)
+    # an FDE-mode record carries stage accounting that reads the candidate list: it cannot trail (MV_ERR_STATE), the searcher finishes it at once
+    from morphik_core_amd._lib import MvError
+
+    fx = MvIndex(capacity_pages=600, stride_rows=64, with_fde=True)
+    fx.fill_synthetic(1234, 0, 600)
+    fstats = []
+    fs = sharded.GpuShardedSearcher(fx, torch.device("cuda", 0), "fde_then_float", collect_stats=fstats)
+    for j in range(3):
+        s, i = fs.query(synth_rows(4321, j, 32), 5)
+        torch.cuda.synchronize()
+        ws, wi = fx.query(synth_rows(4321, j, 32), 5, mode="fde_then_float")
+        assert i.cpu().numpy().tolist() == wi.tolist()
+    assert len(fstats) == 3 and all(st.coarse_ms > 0 for st in fstats)
+    buf_s, buf_i = torch.empty(5, device="cuda"), torch.empty(5, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    p1 = fx.query_device_async(synth_rows(4321, 0, 32), 5, buf_s.data_ptr(), buf_i.data_ptr(), stream, mode="fde_then_float")
+    p2 = fx.query_device_async(synth_rows(4321, 1, 32), 5, buf_s.data_ptr(), buf_i.data_ptr(), stream, mode="fde_then_float")
+    with pytest.raises(MvError):
+        fx.finish_stats(p1)
+    assert fx.finish_stats(p2).coarse_ms > 0
+    fx.close()
     ix.close()
 
 
