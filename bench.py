@@ -55,6 +55,18 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def flush_c_stdio():
+    """RCCL prints its version banner through C stdio: into a pipe that is block-buffered, so the lines surface when the process exits --
+    BEHIND the result line (seen in round 5: `Librccl path : ...` was the last stdout line of a 1-rank RCCL run).  Flushing the C streams
+    right after the communicator is up, and again before the record is printed, keeps the headline the last line."""
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+
+
 def timed_runs(fn, min_runs=5, budget_s=12.0, max_runs=7):
     """Warm-up call, then >= min_runs timed calls (more while the budget lasts).  -> list of seconds."""
     fn()
@@ -954,6 +966,7 @@ def main():
         t = torch.tensor([n_total], dtype=torch.int64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         n_total = int(t.item())
+        flush_c_stdio()  # every rank: the collective library's start-up banner leaves its buffer NOW
     lo, hi = sharded.shard_range(n_total, rank, world)
     n_local = hi - lo
     log(f"[rank {rank}] HBM free {free_b/2**30:.1f} GiB of {total_b/2**30:.1f}; corpus {n_total} pages, shard [{lo},{hi}) = {n_local*page_bytes/1e9:.1f} GB")
@@ -1294,6 +1307,9 @@ def main():
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+        flush_c_stdio()
+        if out is not None and world > 1:
+            time.sleep(1.5)  # the other ranks are tearing down too: whatever their runtimes still print reaches the shared stdout before the record
     if out is not None:
         emit(out, aux)
 
@@ -1346,6 +1362,7 @@ def emit(out, aux):
     head, detail = split_headline(out)
     doc = {"bench_detail": detail, "aux_paths": aux}
     head["aux_file"] = write_record("bench_aux.json", doc)
+    flush_c_stdio()
     if detail or aux:
         print(json.dumps(doc), flush=True)
     line = json.dumps(head)

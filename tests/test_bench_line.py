@@ -100,3 +100,29 @@ def test_default_aux_run_last_line_is_the_compact_headline():
     for key in ("truth", "batched_float", "full_shard", "exact_shard", "fp8_then_float", "fde_document_encode", "serving"):
         assert key in aux and "error" not in aux[key], (key, aux.get(key))
     assert json.load(open(os.path.join(ROOT, "gpurun_out", "bench_aux.json")))["aux_paths"].keys() == aux.keys()
+
+
+@pytest.mark.gpu
+def test_rccl_rank_under_the_drivers_launcher_keeps_the_headline_last():
+    """The driver's N > 1 command shape (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`) with the one rank this box has and a real RCCL communicator (MV_BENCH_FORCE_DIST=1).  RCCL
+    prints a version banner through C stdio, which a pipe block-buffers until the process exits: in round 5 `Librccl path : ...` was the
+    last stdout line of such a run.  bench.py flushes the C streams once the communicator is up and again before it prints: the LAST
+    non-empty stdout line must be the headline, with the exchange timed by itself."""
+    import socket
+
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    env = dict(os.environ, MV_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3", "--pages", "60000", "--cpu-sample-pages", "512",
+           "--cpu-baseline-quick", "--no-aux"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out_lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    d = _check_headline(out_lines[-1])
+    cfg = d["config"]
+    assert cfg["collective_backend"] == "nccl" and cfg["rccl_ranks"] == 1 and d["recall_at_10"] == 1.0
+    assert 0 < cfg["collective_and_merge_ms_per_step"] < 1.0 and d["roofline"]["launches_timed"] == 10

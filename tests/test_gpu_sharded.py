@@ -314,6 +314,7 @@ def test_bench_eight_ranks_on_one_gpu_full_corpus_line():
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500, cwd=root)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert p.returncode == 0 and lines, p.stderr[-3000:]
+    assert [ln for ln in p.stdout.splitlines() if ln.strip()][-1] == lines[-1]  # the record is the LAST stdout line, whatever the runtimes print
     d = json.loads(lines[-1])
     out_dir = os.path.join(root, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
