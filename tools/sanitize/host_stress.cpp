@@ -73,6 +73,15 @@ int main(int argc, char** argv) {
     float s[64 * 5]; int64_t id[64 * 5]; int32_t n = 0, nb[5];
     std::vector<float> all_scores(4096);
     std::vector<float> qfde = rows((5 * 10240 + 127) / 128, 900 + tid);  // five query FDE vectors of 10 240 floats
+    // round 5: the enqueue-only device query with deferred timings (the N > 1 step of sharded.py): ids and scores into ONE block, the block
+    // merge, the timings collected one query later.  Six threads share the index, so a record may be older than "one behind" when it is
+    // finished -- its timings are then another query's (documented), which a host-side check does not care about.
+    void* blk = nullptr;
+    float* d_os = nullptr; int64_t* d_oi = nullptr;
+    hipSetDevice(0);
+    if (hipMalloc(&blk, (size_t)mv_topk_block_bytes(10)) || hipMalloc((void**)&d_os, 40) || hipMalloc((void**)&d_oi, 80)) std::abort();
+    mv_query_stats pend{};
+    bool have_pend = false;
     for (int it = 0; it < iters && !stop.load(); ++it) {
       const int mode = modes[(it + tid) % 6];
       mv_query_stats st{};
@@ -84,9 +93,19 @@ int main(int argc, char** argv) {
         CHECK(mv_query_topk_fde(ix, q.data(), MV_F32, 20, qfde.data(), 10, (it & 1) ? MV_MODE_FDE_THEN_FLOAT : MV_MODE_FDE_ONLY, nullptr, 0, s, id, &n, nullptr));
         CHECK(mv_query_topk_batch_fde(ix, qb.data(), MV_F32, 5, 20, qfde.data(), 7, MV_MODE_FDE_THEN_FLOAT, nullptr, 0, 0, s, id, nb, nullptr));
       }
+      if (it % 4 == 1) {
+        mv_query_stats now{};
+        CHECK(mv_query_topk_device_async(ix, q.data(), MV_F32, 20, 10, (it & 8) ? MV_MODE_FLOAT : MV_MODE_FLOAT_FP8, nullptr, 0, (float*)((char*)blk + 80), (int64_t*)blk,
+                                         nullptr /* the null stream: ordered against, not blocked on */, &now));
+        CHECK(mv_merge_topk_blocks(0, blk, 1, 10, 10, d_os, d_oi, nullptr));
+        if (have_pend) CHECK(mv_query_stats_finish(ix, &pend));
+        pend = now;
+        have_pend = true;
+      }
       (void)mv_index_size(ix);
       n_queries.fetch_add(1);
     }
+    if (have_pend) CHECK(mv_query_stats_finish(ix, &pend));
   };
   auto writer = [&]() {
     std::vector<float> emb = rows(8 * 24, 7);
