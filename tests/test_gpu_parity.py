@@ -1397,7 +1397,7 @@ def test_errors_are_loud(mv):
     ix.close()
 
 
-XX
+@pytest.mark.parametrize("stride,nrows", [(1024, 1000), (208, 208), (64, 50), (16, 7)])  # ragged 1024-row pages, UNIFORM 208-row pages (no row masks), short ragged pages
 def test_batched_fp8_scan_equals_single_query_scan_and_oracle(mv, stride, nrows):
     """mv_query_topk_batch, MV_MODE_FLOAT_FP8: one pass over the e4m3 slab for a group of queries (maxsim_batch_fp8_kernel,
     block-scaled MFMA with the page tile as the A operand) returns the single-query fp8 scan's answers, which are the
