@@ -1116,7 +1116,7 @@ def main():
         roofline = {
             "bound": "hbm",
             "kernel": {"float": "maxsim_ldsdma_kernel (bf16 page scan, variant %s)" % (args.variant if args.variant >= 0 else "default: nt LDS-DMA"),
-                       "fp8": "maxsim_fp8_kernel (e4m3 page scan, MX-scaled MFMA)", "binary": "maxsim_binary_mfma2_kernel (sign-bit scan, FP4 MFMA)",
+                       "fp8": "maxsim_fp8_pair_kernel (e4m3 page scan, two pages per workgroup, MX-scaled MFMA)", "binary": "maxsim_binary_mfma2_kernel (sign-bit scan, FP4 MFMA)",
                        "fde_fp8": "fde_scan_kernel + top-1000 + maxsim_fp8_kernel rerank (whole device span)"}[args.workload],
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBPS,

@@ -26,7 +26,11 @@
 // the loop.  LDS image: 16-byte chunk c of row w at chunk position c ^ (w & 7) of that row (swizzle applied to the
 // per-lane global source address); the ds_read_b128 fragment reads (chunk g+4h of rows r) then hit 16 distinct
 // 16-byte columns per 16-lane group.
+// The full scan (no candidate list) runs maxsim_fp8_pair_kernel: the same stream over TWO consecutive pages per fresh
+// workgroup, 256 KiB of contiguous slab -- measured +2.3 / +2.8 % over one page per workgroup in alternating processes
+// (profiles/r5/fp8_scan_page_pairs_ab_r5.jsonl); candidate lists and per-item queries keep maxsim_fp8_kernel.
 #include <algorithm>
+#include <cstdlib>
 
 #include "mv_common.h"
 
@@ -390,6 +394,180 @@ __global__ __launch_bounds__(256) void maxsim_fp8_kernel(F8Args a) {
   }
 }
 
+// Two CONSECUTIVE pages per workgroup (round 5, the full scan only: no candidate list, no per-item queries): wave w
+// streams its slots of page 2b and then, without draining the ring, its slots of page 2b+1 -- 256 KiB of contiguous
+// slab per fresh workgroup, the unit the float scan reads (128 KiB units deliver ~1.3 % less than 256 KiB
+// ones), and one query-fragment load per two pages.  Per page the arithmetic is maxsim_fp8_kernel's: the running maxima
+// are handed to LDS at the page boundary, waves 0 / 1 finish pages 0 / 1 after the single barrier.
+template <int MT, int D>
+__global__ __launch_bounds__(256) void maxsim_fp8_pair_kernel(F8Args a) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * D * kF8SlotBytes + 2048];
+  float* red = reinterpret_cast<float*>(lds + 4 * D * kF8SlotBytes);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t item0 = (int64_t)blockIdx.x * 2;
+  if (item0 >= a.n) return;
+  int nr[2], nsw[2];
+  bool live[2];
+  const char* pbase[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int64_t page = a.page0 + item0 + p;
+    live[p] = item0 + p < a.n && !f8_masked(a, page);
+    nr[p] = live[p] ? (a.n_rows ? a.n_rows[page] : a.stride) : 0;
+    const int nslots = (nr[p] + kF8SlotRows - 1) / kF8SlotRows;
+    nsw[p] = max(0, (nslots - wave + 3) / 4);
+    pbase[p] = reinterpret_cast<const char*>(a.slab) + (size_t)page * (size_t)a.stride * kF8RowBytes;
+  }
+  const int total = nsw[0] + nsw[1];
+  char* ring = lds + wave * (D * kF8SlotBytes);
+
+  int src_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int w = i * 8 + (lane >> 3);
+    src_off[i] = w * kF8RowBytes + ((((lane & 7) ^ (w & 7))) << 4) - i * 1024;
+  }
+  int rd_off[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) rd_off[h] = r * kF8RowBytes + (((g + 4 * h) ^ (r & 7)) << 4);
+
+  auto issue = [&](int j) {  // j: position in this wave's stream over both pages
+    const char* tp = j < nsw[0] ? pbase[0] + (size_t)(wave + j * 4) * kF8SlotBytes
+                                : pbase[1] + (size_t)(wave + (j - nsw[0]) * 4) * kF8SlotBytes;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
+    const uint64_t tpu = ((uint64_t)hi << 32) | lo;
+    const uint32_t slot = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + (j % D) * kF8SlotBytes));
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %6 nt\n\t"
+        "global_load_lds_dwordx4 %2, %6 offset:1024 nt\n\t"
+        "global_load_lds_dwordx4 %3, %6 offset:2048 nt\n\t"
+        "global_load_lds_dwordx4 %4, %6 offset:3072 nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src_off[0]), "v"(src_off[1]), "v"(src_off[2]), "v"(src_off[3]), "s"(slot), "s"(tpu)
+        : "memory");
+  };
+
+#pragma unroll
+  for (int i = 0; i < D - 1; ++i)
+    if (i < total) issue(i);
+
+  i32x8 ah[MT], al[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const size_t ro = (size_t)(m * 16 + r) * kF8RowBytes;
+    const i32x4 h0 = *reinterpret_cast<const i32x4*>(a.qhi + ro + g * 16);
+    const i32x4 h1 = *reinterpret_cast<const i32x4*>(a.qhi + ro + 64 + g * 16);
+    const i32x4 l0 = *reinterpret_cast<const i32x4*>(a.qlo + ro + g * 16);
+    const i32x4 l1 = *reinterpret_cast<const i32x4*>(a.qlo + ro + 64 + g * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[m][i] = h0[i]; ah[m][4 + i] = h1[i];
+      al[m][i] = l0[i]; al[m][4 + i] = l1[i];
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      asm volatile("" : "+v"(ah[m][i]));
+      asm volatile("" : "+v"(al[m][i]));
+    }
+
+  int j = 0;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    f32x4 mx[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) mx[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    const int ntiles = (nr[p] + 15) >> 4;
+    for (int it = 0; it < nsw[p]; ++it, ++j) {
+      if (j + D - 1 < total) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // WAR: last reads of the slot being refilled
+        issue(j + D - 1);
+        f8_wait_vmcnt<4 * (D - 1)>();
+      } else {
+        const int left = total - 1 - j;
+        if (left >= 2) f8_wait_vmcnt<8>();
+        else if (left == 1) f8_wait_vmcnt<4>();
+        else f8_wait_vmcnt<0>();
+      }
+      const char* slot = ring + (j % D) * kF8SlotBytes;
+      const int t0 = (wave + it * 4) * 2;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = t0 + tt;
+        if (t < ntiles) {  // wave-uniform
+          const i32x4 b0 = *reinterpret_cast<const i32x4*>(slot + tt * 2048 + rd_off[0]);
+          const i32x4 b1 = *reinterpret_cast<const i32x4*>(slot + tt * 2048 + rd_off[1]);
+          i32x8 b;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { b[i] = b0[i]; b[4 + i] = b1[i]; }
+          const bool col_valid = t * 16 + r < nr[p];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ah[m], b, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(al[m], b, acc, 0, 0, 0, 0x7b7b7b7b /* 2^-4 */, 0, 0x7f7f7f7f);
+            if (!col_valid) acc = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mx[m][i] = fmaxf(mx[m][i], acc[i]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = f8_group16_max(mx[m][i]);
+        if (r == 0) red[p * 256 + wave * 64 + m * 16 + g * 4 + i] = v;
+      }
+  }
+  __syncthreads();
+  if (wave < 2 && item0 + wave < a.n) {
+    const int p = wave;
+    const int64_t item = item0 + p;
+    const float* rp = red + p * 256;
+    const int nr_p = p ? nr[1] : nr[0];
+    const bool live_p = p ? live[1] : live[0];
+    float v = 0.f;
+    if (lane < MT * 16) {
+      v = fmaxf(fmaxf(rp[lane], rp[64 + lane]), fmaxf(rp[128 + lane], rp[192 + lane]));
+      if ((a.pad_items ? a.pad_items[item] : a.pad_to) > nr_p) v = fmaxf(v, 0.f);
+      if (v == -INFINITY) v = 0.f;
+      v *= a.qfac[lane];
+    }
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s);
+    if (lane == 0) {
+      if (!live_p) {
+        a.scores[item] = -INFINITY;
+      } else {
+        const float part = v * a.inv_scale[a.page0 + item];
+        a.scores[item] = a.accumulate ? a.scores[item] + part : part;
+      }
+    }
+  }
+}
+
+// MV_FP8_SCAN_PAIRS=0: one page per workgroup for the full scan too (the measurement switch of the pair kernel).
+bool f8_scan_pairs() {
+  static const bool on = [] {
+    const char* e = getenv("MV_FP8_SCAN_PAIRS");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 template <int MT>
 int launch_f8_mt(const F8Args& k0, hipStream_t s) {
   constexpr int64_t kChunk = (int64_t)1 << 22;  // work-item count per launch stays below 2^32
@@ -403,6 +581,8 @@ int launch_f8_mt(const F8Args& k0, hipStream_t s) {
     if (k.items_per_q > 0) {
       if (k0.n > kChunk) { set_error("per-item queries: %lld items in one launch not supported", (long long)k0.n); return MV_ERR_INVALID; }
       hipLaunchKernelGGL((maxsim_fp8_kernel<MT, 4, true>), dim3((unsigned)k.n), dim3(256), 0, s, k);
+    } else if (!k.cand && f8_scan_pairs()) {
+      hipLaunchKernelGGL((maxsim_fp8_pair_kernel<MT, 4>), dim3((unsigned)((k.n + 1) / 2)), dim3(256), 0, s, k);
     } else {
       hipLaunchKernelGGL((maxsim_fp8_kernel<MT, 4>), dim3((unsigned)k.n), dim3(256), 0, s, k);
     }

@@ -1201,6 +1201,42 @@ def test_fp8_maxsim_matches_oracle_on_same_codes(mv, stride, nrows):
     ix.close()
 
 
+def test_fp8_full_scan_page_pairs_equal_the_per_page_kernel_on_ragged_masked_odd_corpora(mv):
+    """The full e4m3 scan streams two consecutive pages per workgroup (maxsim_fp8_pair_kernel); the candidate path scores
+    one page per workgroup (maxsim_fp8_kernel).  Same arithmetic per page: bit-identical scores, whatever the two
+    pages of a pair look like -- ragged lengths (incl. empty and one-row pages next to full ones), tombstones, filtered
+    documents, an odd page count (the last workgroup has one page), more query rows than one pass holds."""
+    from morphik_core_amd.index import allow_bitmap
+
+    stride = 256
+    rng = np.random.default_rng(77)
+    lens = [256, 1, 0, 256, 33, 200, 97, 256, 256, 5, 128, 129, 31, 32, 64, 250, 3, 256, 160, 161, 0, 0, 255, 17, 224]
+    assert len(lens) % 2 == 1
+    ix = _idx(mv, capacity_pages=len(lens) + 4, stride_rows=stride, with_float=False, with_fp8=True)
+    ix.add([rng.standard_normal((n, 128)).astype(np.float32) * (0.5 + p % 3) for p, n in enumerate(lens)], doc_ordinals=list(range(len(lens))))
+    codes, inv = ix.read_fp8(0, len(lens))
+    every = list(range(len(lens)))
+    for nq in (1, 32, 64, 80):
+        q = rng.standard_normal((nq, 128)).astype(np.float32)
+        want = orc.maxsim_fp8_np(q, codes, inv, n_rows=lens)
+        got = ix.score_all(q, mode="float_fp8")
+        per_page = ix.score_candidates(q, every)
+        assert got.tobytes() == per_page.tobytes(), nq
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-6)
+    # masked pages inside pairs: a tombstone in the first half of one pair, a filtered document in the second half of another
+    ix.remove_doc(7)
+    allow = allow_bitmap([d for d in range(len(lens)) if d != 10])
+    q = rng.standard_normal((32, 128)).astype(np.float32)
+    got = ix.score_all(q, mode="float_fp8", allow=allow)
+    ref = ix.score_candidates(q, every)
+    for pg in every:
+        if pg in (7, 10):
+            assert got[pg] == -np.inf, pg
+        else:
+            assert got[pg].tobytes() == ref[pg].tobytes(), pg
+    ix.close()
+
+
 def test_fp8_only_index_ragged_filter_candidates_and_pipeline(mv):
     from morphik_core_amd import _lib, synth
     from morphik_core_amd.index import allow_bitmap

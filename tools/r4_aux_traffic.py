@@ -12,7 +12,7 @@ def main(fetch_json, write_json, pages, out):
     w = json.load(open(write_json))["counters"]
     cal = [k for k in f if "read_bw_kernel" in k]
     corr = (4 << 30) / (f[cal[0]]["FETCH_SIZE"]["avg"] * 1024.0)
-    want = {"maxsim_fp8_kernel": ("e4m3 scan", 1024 * 128), "maxsim_binary_mfma2_kernel": ("sign-bit scan", 1024 * 16),
+    want = {"maxsim_fp8_pair_kernel": ("e4m3 scan", 1024 * 128), "maxsim_fp8_kernel": ("e4m3 scan, one page per workgroup (candidate lists)", 1024 * 128), "maxsim_binary_mfma2_kernel": ("sign-bit scan", 1024 * 16),
             "fde_scan_rowq_kernel": ("FDE coarse scan (row quarters, default since round 5)", 20480), "fde_scan_kernel": ("FDE coarse scan (register form)", 20480), "fde_scan_batch2_kernel": ("batched FDE coarse pass, 32 requests", 20480)}
     rec = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on tools/r4_aux_traffic_probe.py, MI355X", "pages": pages,
            "gfx950_fetch_correction": corr, "kernels": {}}
