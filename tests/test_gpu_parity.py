@@ -1213,7 +1213,9 @@ def test_fp8_full_scan_page_pairs_equal_the_per_page_kernel_on_ragged_masked_odd
     lens = [256, 1, 0, 256, 33, 200, 97, 256, 256, 5, 128, 129, 31, 32, 64, 250, 3, 256, 160, 161, 0, 0, 255, 17, 224]
     assert len(lens) % 2 == 1
     ix = _idx(mv, capacity_pages=len(lens) + 4, stride_rows=stride, with_float=False, with_fp8=True)
-    ix.add([rng.standard_normal((n, 128)).astype(np.float32) * (0.5 + p % 3) for p, n in enumerate(lens)], doc_ordinals=list(range(len(lens))))
+    rows = [rng.standard_normal((n, 128)).astype(np.float32) * (0.5 + p % 3) for p, n in enumerate(lens)]
+    ix.add(rows, doc_ordinals=list(range(len(lens))))
+    longest_row = max(float(np.linalg.norm(r, axis=1).max()) for r in rows if len(r))
     codes, inv = ix.read_fp8(0, len(lens))
     every = list(range(len(lens)))
     for nq in (1, 32, 64, 80):
@@ -1222,7 +1224,9 @@ def test_fp8_full_scan_page_pairs_equal_the_per_page_kernel_on_ragged_masked_odd
         got = ix.score_all(q, mode="float_fp8")
         per_page = ix.score_candidates(q, every)
         assert got.tobytes() == per_page.tobytes(), nq
-        np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-6)
+        # against the fp64 oracle on the same codes: fp32 accumulation errs relative to the OPERANDS (sum_q |q| |p|), which a
+        # one-row page of random signs does not cancel (its score is ~ 0 beside terms of ~ 200 per token)
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=2e-6 * float(np.linalg.norm(q, axis=1).sum()) * longest_row)
     # masked pages inside pairs: a tombstone in the first half of one pair, a filtered document in the second half of another
     ix.remove_doc(7)
     allow = allow_bitmap([d for d in range(len(lens)) if d != 10])
