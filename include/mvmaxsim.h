@@ -63,13 +63,23 @@ enum {
                              bf16 slab does not fit HBM beside its fp8 slab ("host-resident exact vectors
                              with a gather of the candidates").  May be combined with MV_WITH_FLOAT (both tiers
                              hold the same rows; MV_OPT_EXACT_TIER picks the one the rerank reads) */
-  MV_WITH_EXACT_SPLIT = 32 /* with MV_WITH_HOST_EXACT (and no MV_WITH_FLOAT): split the exact tier -- the exact rows of the FIRST
+  MV_WITH_EXACT_SPLIT = 32, /* with MV_WITH_HOST_EXACT (and no MV_WITH_FLOAT): split the exact tier -- the exact rows of the FIRST
                              pages go to whatever HBM is free once the other slabs are allocated (minus
                              MV_EXACT_HBM_RESERVE_BYTES, default 12 GiB, for the lazily allocated workspaces and the caller's
                              own device memory), the rest to pinned host memory.  A 1.25 M-page shard (328 GB of exact rows
                              beside 190 GB of FDE + e4m3 slabs) keeps ~105 GB of them in HBM and pins ~223 GB: it fits a
                              288 GiB GPU in a container that may pin 300 GiB, and a third of the rerank reads never cross
                              PCIe.  Same answers as an unsplit tier (mv_index_exact_hbm_pages: the pages the HBM part got) */
+  MV_WITH_FLOAT_LO = 64    /* with MV_WITH_FLOAT: a second bf16 slab holding lo = bf16(x - bf16(x)) of every element (+262 144 B / page).
+                             The reference keeps its pages as fp32 `.npy` and scores them in fp32 (fast_multivector_store.py:676-681
+                             save, :736 / :774 load, :553-555 score); hi + lo is the same 4 bytes per element, reproduces x to
+                             2^-18 |x|, and both halves are bf16 MFMA operands: every candidate scorer (mv_score_candidates*, the
+                             rerank stages of MV_MODE_FDE_THEN_FLOAT / MV_MODE_FP8_THEN_FLOAT) and -- MV_OPT_FLOAT_LO_SCAN -- the full
+                             scan accumulate qhi.phi + qlo.phi + qhi.plo in fp32 before the max: the reference's fp32 score to
+                             ~1e-6 relative on fp32 inputs.  Pages added as MV_BF16 have lo = 0 and score bit-identically to an
+                             index without the flag.  (Independently of the flag, an MV_F32 QUERY is always split into hi + lo
+                             and both halves are scored -- free where the scan is HBM-bound; a bf16-representable query takes
+                             the one-term kernels, bit for bit as before.) */
 };
 
 /* fixed_dimensional_encoding.FixedDimensionalEncodingConfig as constructed at
@@ -152,6 +162,12 @@ typedef enum {
                                     1 = the pinned-host tier (what an index without a bf16 slab always uses), 2 = the e4m3 slab
                                     (MV_MODE_FDE_THEN_FLOAT / mv_score_candidates only: the scores an index WITHOUT an exact tier
                                     returns; the host-driven cross-check of the pruning stage uses it) */
+  MV_OPT_FLOAT_LO_SCAN = 15,     /* MV_MODE_FLOAT over every page of an index with MV_WITH_FLOAT_LO: 1 = read hi and lo (default: the
+                                    fp32-faithful score of every page, twice the bytes per page), 0 = the hi slab only (scores of the
+                                    bf16-rounded pages, the speed of an index without the flag), 2 = hi-only scan -> top
+                                    max(MV_OPT_RERANK_N, k) -> split-bf16 re-score of those -> top-k (fp32-faithful scores at the
+                                    hi-only scan's speed; a page whose hi-only score misses the candidate cut by rounding alone --
+                                    ~1e-4 relative -- would be lost: same caveat as MV_MODE_FP8_THEN_FLOAT, three orders smaller) */
   MV_OPT_FDE_BATCH_VARIANT = 12  /* mv_query_topk_batch in the FDE modes: 0 = batched pipeline (default): up to 32 queries per pass
                                     over the FDE slab (bf16 MFMA, query FDE as bf16 hi + lo), batched selection, every query's
                                     candidates reranked in one launch, one read-back; 1 = query by query; 2 = as 0 with the query
@@ -169,7 +185,7 @@ typedef enum {
 /* Bumped whenever a signature, a struct layout or an enum value of this header changes incompatibly.  A binding compares
  * mv_abi_version() of the library it loaded with the MV_ABI_VERSION it was written against and refuses a mismatch (a stale
  * libmvmaxsim.so driven with newer argument lists would corrupt memory silently). */
-#define MV_ABI_VERSION 6
+#define MV_ABI_VERSION 7
 MV_API int mv_abi_version(void);
 
 MV_API const char* mv_last_error(void);
@@ -232,6 +248,10 @@ MV_API int mv_index_compact(mv_index* ix, int64_t* out_old_to_new, int64_t* out_
 /* Read back bf16 rows of pages [page0, page0+n) (stride_rows x dim each) to a host buffer (from the bf16 slab, or from the
  * pinned-host exact tier of an index without one). */
 MV_API int mv_index_read_pages(mv_index* ix, int64_t page0, int64_t n_pages, void* out_bf16);
+/* The same pages as fp32 (stride_rows x dim floats each): hi + lo of an index with MV_WITH_FLOAT_LO -- the values the split-bf16
+ * scorers see, equal to the fp32 input to 2^-18 relative (the reference's `.npy` payload, fast_multivector_store.py:676-681) --
+ * else the bf16 rows widened. */
+MV_API int mv_index_read_pages_f32(mv_index* ix, int64_t page0, int64_t n_pages, float* out_f32);
 /* Overwrite rows [row0,row0+n) of one page with host bf16 data (test/bench: planted neighbours).
  * Only the float slab is touched. */
 MV_API int mv_index_write_rows(mv_index* ix, int64_t page, int32_t row0, int32_t n, const void* bf16_rows);

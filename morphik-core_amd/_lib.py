@@ -74,6 +74,7 @@ class QueryStatsC(C.Structure):
 MV_F32, MV_BF16 = 0, 1
 MV_MODE_FLOAT, MV_MODE_BINARY, MV_MODE_FDE_THEN_FLOAT, MV_MODE_FDE_ONLY, MV_MODE_FLOAT_FP8, MV_MODE_FP8_THEN_FLOAT = 0, 1, 2, 3, 4, 5
 MV_WITH_FLOAT, MV_WITH_BINARY, MV_WITH_FDE, MV_WITH_FP8, MV_WITH_HOST_EXACT, MV_WITH_EXACT_SPLIT = 1, 2, 4, 8, 16, 32
+MV_WITH_FLOAT_LO = 64
 MV_OPT_MAXSIM_VARIANT, MV_OPT_FDE_COARSE_N, MV_OPT_FDE_COSINE, MV_OPT_PAD_SEMANTICS, MV_OPT_BINARY_VARIANT, MV_OPT_FDE_SCAN_VARIANT = 1, 2, 3, 4, 5, 6
 MV_OPT_BATCH_VARIANT = 7
 MV_OPT_FDE_ENCODE_VARIANT = 8
@@ -83,6 +84,7 @@ MV_OPT_FDE_QUERY_ENCODE_VARIANT = 11
 MV_OPT_FDE_BATCH_VARIANT = 12
 MV_OPT_RERANK_N = 13
 MV_OPT_EXACT_TIER = 14
+MV_OPT_FLOAT_LO_SCAN = 15
 MV_CAL_READ_NT, MV_CAL_MFMA_BF16, MV_CAL_READ_LDSDMA, MV_CAL_MFMA_BF16_32X32 = 1, 2, 3, 4
 MV_COMM_AUTO, MV_COMM_RCCL, MV_COMM_P2P, MV_COMM_HOST = 0, 1, 2, 3
 
@@ -94,12 +96,12 @@ class CandRecC(C.Structure):
 
 
 # every symbol include/mvmaxsim.h declares (tests check the .so exports all of them)
-MV_ABI_VERSION = 6  # include/mvmaxsim.h: the header revision this binding's argument lists were written against
+MV_ABI_VERSION = 7  # include/mvmaxsim.h: the header revision this binding's argument lists were written against
 
 EXPORTS = [
     "mv_abi_version", "mv_last_error", "mv_version", "mv_device_count", "mv_host_pin_budget_bytes", "mv_index_exact_hbm_pages", "mv_index_create", "mv_index_destroy", "mv_index_set_option",
     "mv_index_size", "mv_index_capacity", "mv_index_add", "mv_index_add_device", "mv_index_add_bits", "mv_index_remove_doc",
-    "mv_index_remove_page", "mv_index_compact", "mv_index_read_pages", "mv_index_write_rows", "mv_index_replace_page", "mv_index_read_fp8", "mv_index_fill_synthetic", "mv_synth_rows",
+    "mv_index_remove_page", "mv_index_compact", "mv_index_read_pages", "mv_index_read_pages_f32", "mv_index_write_rows", "mv_index_replace_page", "mv_index_read_fp8", "mv_index_fill_synthetic", "mv_synth_rows",
     "mv_query_topk", "mv_query_topk_device", "mv_query_topk_device_async", "mv_query_stats_finish", "mv_query_topk_batch", "mv_merge_topk", "mv_topk_block_bytes", "mv_merge_topk_blocks", "mv_score_all", "mv_score_candidates", "mv_score_candidates_pads", "mv_index_page_rows",
     "mv_two_stage_coarse_device", "mv_two_stage_mid_device", "mv_two_stage_rerank_device", "mv_index_rerank_plan", "mv_comm_create", "mv_comm_destroy", "mv_comm_attach", "mv_comm_transport",
     "mv_comm_query_topk", "mv_comm_query_topk_batch", "mv_sign_pack", "mv_hamming_batch",
@@ -170,6 +172,7 @@ def lib() -> C.CDLL:
         L.mv_index_remove_page.argtypes = [vp, i64]
         L.mv_index_compact.argtypes = [vp, vp, C.POINTER(i64)]
         L.mv_index_read_pages.argtypes = [vp, i64, i64, vp]
+        L.mv_index_read_pages_f32.argtypes = [vp, i64, i64, vp]
         L.mv_index_write_rows.argtypes = [vp, i64, i32, i32, vp]
         L.mv_index_replace_page.argtypes = [vp, i64, vp, i32]
         L.mv_index_read_fp8.argtypes = [vp, i64, i64, vp, vp]

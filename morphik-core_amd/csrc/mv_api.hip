@@ -94,6 +94,9 @@ int ensure_query_cap(mv_index* ix, int n_rows) {
   const int cap = std::max(padded, 256);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);  // nothing may still read the buffers being replaced
   if (ix->d_q) (void)hipFree(ix->d_q);
+  if (ix->d_qlo) (void)hipFree(ix->d_qlo);
+  if (ix->h_qlo) (void)hipHostFree(ix->h_qlo);
+  ix->d_qlo = nullptr; ix->h_qlo = nullptr; ix->q_lo_valid = false;
   if (ix->d_qf32) (void)hipFree(ix->d_qf32);
   if (ix->d_qbits) (void)hipFree(ix->d_qbits);
   if (ix->d_qpop) (void)hipFree(ix->d_qpop);
@@ -106,6 +109,8 @@ int ensure_query_cap(mv_index* ix, int n_rows) {
   ix->d_q = nullptr; ix->d_qf32 = nullptr; ix->d_qbits = nullptr; ix->d_qpop = nullptr;
   ix->d_q8hi = nullptr; ix->d_q8lo = nullptr; ix->d_q8fac = nullptr;
   MV_HIP(hipMalloc(&ix->d_q, (size_t)cap * kDim * 2));
+  MV_HIP(hipMalloc(&ix->d_qlo, (size_t)cap * kDim * 2));
+  MV_HIP(hipHostMalloc((void**)&ix->h_qlo, (size_t)cap * kDim * 2, hipHostMallocDefault));
   MV_HIP(hipMalloc(&ix->d_qf32, (size_t)cap * kDim * 4));
   MV_HIP(hipMalloc(&ix->d_qbits, (size_t)cap * kSignBytes));
   MV_HIP(hipMalloc(&ix->d_qpop, (size_t)cap * 4));
@@ -138,11 +143,28 @@ int upload_query(mv_index* ix, const void* q, int q_dtype, int n_q, bool want_bf
     }
   }
   if (want_bf16) {
+    // An fp32 query is split q = hi + lo (hi = bf16(q), lo = bf16(q - hi): the subtraction is exact in fp32, |q - hi - lo| <= 2^-18 |q|)
+    // and BOTH halves are scored (mv_maxsim.hip tile_mfma_lo): the query side of the reference's fp32 product
+    // (fast_multivector_store.py:553-555) costs a second MFMA chain in an HBM-bound scan, not a rounding.  A query that IS bf16
+    // (MV_BF16, or fp32 values with lo == 0) takes the one-term kernels unchanged.
     uint16_t* b = ix->h_qbf16;
+    uint16_t* bl = ix->h_qlo;
+    bool any_lo = false;
     if (q_dtype == MV_BF16) memcpy(b, q, ne * 2);
-    else for (size_t i = 0; i < ne; ++i) b[i] = host_f32_to_bf16(f[i]);
+    else for (size_t i = 0; i < ne; ++i) {
+      b[i] = host_f32_to_bf16(f[i]);
+      bl[i] = host_f32_to_bf16(f[i] - host_bf16_to_f32(b[i]));
+      any_lo = any_lo || (bl[i] & 0x7fffu) != 0;
+    }
     memset(b + ne, 0, ((size_t)padded * kDim - ne) * 2);
     MV_HIP(hipMemcpyAsync(ix->d_q, b, (size_t)padded * kDim * 2, hipMemcpyHostToDevice, ix->stream));
+    ix->q_has_lo = any_lo;
+    ix->q_lo_valid = any_lo || ix->slab_lo != nullptr;  // the three-term kernels of a lo slab always take a lo query (zeros for a bf16 one)
+    if (ix->q_lo_valid) {
+      if (any_lo) memset(bl + ne, 0, ((size_t)padded * kDim - ne) * 2);
+      else memset(bl, 0, (size_t)padded * kDim * 2);
+      MV_HIP(hipMemcpyAsync(ix->d_qlo, bl, (size_t)padded * kDim * 2, hipMemcpyHostToDevice, ix->stream));
+    }
   }
   if (want_f32 || want_bits || want_fp8) {
     MV_HIP(hipMemcpyAsync(ix->d_qf32, f, ne * 4, hipMemcpyHostToDevice, ix->stream));
@@ -239,9 +261,16 @@ int launch_cand_prepare(mv_index* ix, const int64_t* d_ids64, const int32_t* d_i
 
 int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_words, const int32_t* d_cand, int64_t n_items,
                int32_t pad_to, const int32_t* d_pad_items, float* d_out, int* launches, bool no_mask = false,
-               const uint16_t* d_q_base = nullptr, const uint16_t* slab_override = nullptr) {
+               const uint16_t* d_q_base = nullptr, const uint16_t* slab_override = nullptr, const uint16_t* d_qlo_base = nullptr,
+               const uint16_t* slab_lo = nullptr) {
   if (n_items <= 0) return MV_OK;  // nothing to launch (a grid of 0 blocks is an invalid configuration)
   const uint16_t* qbase = d_q_base ? d_q_base : ix->d_q;  // padded bf16 query rows (a batch keeps its queries in d_bq)
+  // split-bf16 operands: the query's lo rows (single query: d_qlo when upload_query filled it; a batch block: the caller's d_qlo_base)
+  // and -- slab_lo -- the pages' lo slab (only ever beside the bf16 slab in HBM: the host exact tier keeps hi rows only)
+  const uint16_t* qlo_base = d_q_base ? d_qlo_base : (ix->q_lo_valid ? ix->d_qlo : nullptr);
+  if (slab_lo && !qlo_base) { set_error("float_scan: the lo slab needs the query's lo rows"); return MV_ERR_STATE; }
+  const bool lo_q = qlo_base != nullptr && (slab_lo != nullptr || d_q_base != nullptr || ix->q_has_lo);
+  if (!lo_q) qlo_base = nullptr;
   const bool need_meta = !no_mask && (ix->tombstones.load() || d_allow != nullptr);
   const bool ragged = ix->ragged.load();
   const int padded = ((n_q + 15) / 16) * 16;
@@ -250,7 +279,7 @@ int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_w
   // share the page tiles in LDS, each holds a quarter of the query rows) as ONE query of up to 512 rows: the
   // page-split kernel below keeps all query rows in every wave and falls off the HBM roof past 64 rows
   // (400 k pages: 128 rows 19.2 -> 16.0 ms, 256 rows 38.3 -> 22.7 ms).
-  if (!d_cand && pad_to == 0 && !d_pad_items && padded > 64 && ix->long_query_variant == 1) {
+  if (!d_cand && pad_to == 0 && !d_pad_items && padded > 64 && ix->long_query_variant == 1 && !lo_q) {  // (split-bf16 operands: the page-split passes below)
     if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)kBatchQRows * kRowBytes));
     while (done < padded) {
       const int left = padded - done;
@@ -275,8 +304,10 @@ int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_w
     return MV_OK;
   }
   while (done < padded) {
-    const int rows = std::min(padded - done, kMaxQRowsPerPass);
+    const int rows = std::min(padded - done, lo_q ? kMaxQRowsPerPass / 2 : kMaxQRowsPerPass);  // the lo fragments take the registers of 64 rows
     MaxsimArgs a{};
+    a.qlo = lo_q ? qlo_base + (size_t)done * kDim : nullptr;
+    a.slab_lo = slab_lo;
     a.slab = slab_override ? slab_override : ix->slab;  // the exact tier of FP8_THEN_FLOAT may be pinned host memory mapped into the device
     a.n_rows = ragged ? ix->d_n_rows : nullptr;
     a.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
@@ -382,12 +413,13 @@ int ensure_split_ws(mv_index* ix) {
 }
 
 int exact_scan(mv_index* ix, int n_q, int tier, const int32_t* d_cand, int64_t n_items, int32_t pad_to, const int32_t* d_pad_items, float* d_out,
-               int* launches, const uint16_t* d_q_base) {
+               int* launches, const uint16_t* d_q_base, const uint16_t* d_qlo_base) {
   if (n_items <= 0) return MV_OK;
-  if (tier == kTierSlab) return float_scan(ix, n_q, nullptr, 0, d_cand, n_items, pad_to, d_pad_items, d_out, launches, /*no_mask=*/true, d_q_base, ix->slab);
+  // the bf16 slab in HBM: with its lo half when the index keeps one (MV_WITH_FLOAT_LO) -- the fp32-faithful rerank
+  if (tier == kTierSlab) return float_scan(ix, n_q, nullptr, 0, d_cand, n_items, pad_to, d_pad_items, d_out, launches, /*no_mask=*/true, d_q_base, ix->slab, d_qlo_base, ix->slab_lo);
   const int64_t cap = ix->cfg.capacity_pages;
-  if (ix->x_split <= 0) return float_scan(ix, n_q, nullptr, 0, d_cand, n_items, pad_to, d_pad_items, d_out, launches, true, d_q_base, ix->d_exact);
-  if (ix->x_split >= cap) return float_scan(ix, n_q, nullptr, 0, d_cand, n_items, pad_to, d_pad_items, d_out, launches, true, d_q_base, ix->slab_x);
+  if (ix->x_split <= 0) return float_scan(ix, n_q, nullptr, 0, d_cand, n_items, pad_to, d_pad_items, d_out, launches, true, d_q_base, ix->d_exact, d_qlo_base);
+  if (ix->x_split >= cap) return float_scan(ix, n_q, nullptr, 0, d_cand, n_items, pad_to, d_pad_items, d_out, launches, true, d_q_base, ix->slab_x, d_qlo_base);
   // split tier: the candidates of each part against that part's base, two launches, merged (an entry is -1 in exactly one of the two lists)
   if (n_items > kMaxCand) { set_error("exact_scan: %lld candidates exceed %d", (long long)n_items, kMaxCand); return MV_ERR_INVALID; }
   int rc = ensure_split_ws(ix);
@@ -396,9 +428,9 @@ int exact_scan(mv_index* ix, int n_q, int tier, const int32_t* d_cand, int64_t n
   int32_t* hi = ix->d_xcand + kMaxCand;
   const unsigned gb = (unsigned)((n_items + 255) / 256);
   hipLaunchKernelGGL(split_cand_kernel, dim3(gb), dim3(256), 0, ix->stream, d_cand, n_items, (int32_t)ix->x_split, lo, hi);
-  rc = float_scan(ix, n_q, nullptr, 0, lo, n_items, pad_to, d_pad_items, d_out, launches, true, d_q_base, ix->slab_x);
+  rc = float_scan(ix, n_q, nullptr, 0, lo, n_items, pad_to, d_pad_items, d_out, launches, true, d_q_base, ix->slab_x, d_qlo_base);
   if (rc) return rc;
-  rc = float_scan(ix, n_q, nullptr, 0, hi, n_items, pad_to, d_pad_items, ix->d_xscores, launches, true, d_q_base, xt_host_vbase(ix));
+  rc = float_scan(ix, n_q, nullptr, 0, hi, n_items, pad_to, d_pad_items, ix->d_xscores, launches, true, d_q_base, xt_host_vbase(ix), d_qlo_base);
   if (rc) return rc;
   hipLaunchKernelGGL(max_scores_kernel, dim3(gb), dim3(256), 0, ix->stream, d_out, (const float*)ix->d_xscores, n_items);
   MV_HIP(hipGetLastError());
@@ -537,6 +569,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
   if (rc) return rc;
   const bool need_meta = ix->tombstones.load() || d_allow != nullptr;
   int64_t pages = 0, rows = 0;  // accounting only (filled below, once it is known whether the filter was compacted)
+  bool rr_lo = false, lo_cascade = false;  // a rerank stage read the candidates' lo rows too / MV_OPT_FLOAT_LO_SCAN 2 ran its rerank
 
   // Stage events only when somebody will read them: every hipEventRecord between two dependent kernels costs ~5.8 us of device
   // time on this stack (rocprofv3 kernel trace of one request, profiles/r5: gaps of 0.0 us between kernels with no event between
@@ -566,11 +599,32 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
     else rows = count_allowed_rows(ix, n, allow_bits, n_words, &pages);
   }
   if (mode == MV_MODE_FLOAT) {
-    rc = d_scan_cand ? float_scan(ix, n_q, nullptr, 0, d_scan_cand, n_scan, 0, nullptr, ix->d_scores, &out->launches, true)
-                     : float_scan(ix, n_q, d_allow, n_words, nullptr, n, 0 /* full scan: no padding rows exist */, nullptr, ix->d_scores, &out->launches);
+    // an index with a lo slab (MV_WITH_FLOAT_LO): MV_OPT_FLOAT_LO_SCAN 1 reads both halves of every page (fp32-faithful scores),
+    // 0 the hi half only, 2 (with a selection to follow: k_final > 0) the hi half and re-scores the best max(MV_OPT_RERANK_N, k)
+    const bool cascade = ix->slab_lo && ix->float_lo_scan == 2 && k_final > 0;
+    const uint16_t* scan_lo = (ix->slab_lo && (ix->float_lo_scan == 1 || (ix->float_lo_scan == 2 && !cascade))) ? ix->slab_lo : nullptr;
+    if (cascade && st) MV_HIP(hipEventRecord(ix->ev_st[0], ix->stream));
+    rc = d_scan_cand ? float_scan(ix, n_q, nullptr, 0, d_scan_cand, n_scan, 0, nullptr, ix->d_scores, &out->launches, true, nullptr, nullptr, nullptr, scan_lo)
+                     : float_scan(ix, n_q, d_allow, n_words, nullptr, n, 0 /* full scan: no padding rows exist */, nullptr, ix->d_scores, &out->launches, false, nullptr, nullptr, nullptr, scan_lo);
     if (rc) return rc;
     out->d_scores = ix->d_scores; out->n = n_scan; out->d_ids_map = d_scan_cand;
-    out->pages = pages; out->bytes = rows * (int64_t)kRowBytes;
+    out->pages = pages; out->bytes = rows * (int64_t)kRowBytes * (scan_lo ? 2 : 1);
+    if (cascade) {
+      if (st) MV_HIP(hipEventRecord(ix->ev_st[1], ix->stream));
+      const int64_t nc = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(std::max<int64_t>(ix->rerank_n, k_final), n_scan), kTopkMaxDeviceK));
+      if (n_scan > 0) {
+        rc = launch_topk(ix->d_scores, n_scan, (int32_t)nc, d_scan_cand, 0, ix->d_topk_ws, ix->d_out_s, ix->d_out_id, ix->stream);
+        if (rc) return rc;
+        rc = launch_cand_prepare(ix, ix->d_out_id, nullptr, (int)nc, /*pad_sem=*/0);
+        if (rc) return rc;
+        if (st) MV_HIP(hipEventRecord(ix->ev_st[2], ix->stream));
+        rc = exact_scan(ix, n_q, kTierSlab, ix->d_cand, nc, 0, ix->d_cand_pads, ix->d_cand_scores, &out->launches);
+        if (rc) return rc;
+        rr_lo = lo_cascade = true;
+        out->launches += 2;
+        out->n = nc; out->d_ids_map = ix->d_cand; out->d_scores = ix->d_cand_scores;
+      } else if (st) MV_HIP(hipEventRecord(ix->ev_st[2], ix->stream));
+    }
   } else if (mode == MV_MODE_FLOAT_FP8) {
     rc = d_scan_cand ? fp8_scan(ix, n_q, nullptr, 0, d_scan_cand, n_scan, 0, nullptr, ix->d_scores, &out->launches, true)
                      : fp8_scan(ix, n_q, d_allow, n_words, nullptr, n, 0, nullptr, ix->d_scores, &out->launches);
@@ -595,9 +649,10 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
       rc = launch_cand_prepare(ix, ix->d_out_id, nullptr, (int)nc, /*pad_sem=*/0);  // a full-corpus scan has no padding rows
       if (rc) return rc;
       if (st) MV_HIP(hipEventRecord(ix->ev_st[2], ix->stream));
-      rc = exact_scan(ix, n_q, rerank_plan(ix, mode, nc, k_final, ((n_q + 15) / 16) * 16, false).tier, ix->d_cand, nc, 0, ix->d_cand_pads, ix->d_cand_scores,
-                      &out->launches);
+      const int rr_tier = rerank_plan(ix, mode, nc, k_final, ((n_q + 15) / 16) * 16, false).tier;
+      rc = exact_scan(ix, n_q, rr_tier, ix->d_cand, nc, 0, ix->d_cand_pads, ix->d_cand_scores, &out->launches);
       if (rc) return rc;
+      rr_lo = rr_tier == kTierSlab && ix->slab_lo != nullptr;
       out->launches += 2;
       out->n = nc; out->d_ids_map = ix->d_cand; out->d_scores = ix->d_cand_scores;
     } else {
@@ -655,6 +710,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
       }
       rc = rerank_scan(ix, n_q, plan.tier, nc, ix->d_cand_scores, &out->launches);
       if (rc) return rc;
+      rr_lo = plan.tier == kTierSlab && ix->slab_lo != nullptr;
       out->launches += 1;
       out->n = nc;
       out->d_ids_map = ix->d_cand;
@@ -668,7 +724,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
     st->pages_scored = out->pages;
     st->bytes_scanned = out->bytes;
     // FDE_THEN_FLOAT: the candidates' rows are added by finish_stats (read back behind the timed span)
-    if (mode == MV_MODE_FDE_THEN_FLOAT || (two_tier && out->n > 0)) st->reserved = (int32_t)out->n | (rerank_fp8 ? (1 << 30) : 0) | (plan.mid ? (1 << 28) : 0);
+    if (mode == MV_MODE_FDE_THEN_FLOAT || ((two_tier || lo_cascade) && out->n > 0)) st->reserved = (int32_t)out->n | (rerank_fp8 ? (1 << 30) : 0) | (plan.mid ? (1 << 28) : 0) | (rr_lo ? (1 << 27) : 0);
     else if (mode == MV_MODE_FDE_ONLY) st->reserved = 1 << 29;  // stage split without a rerank
   }
   return MV_OK;
@@ -689,6 +745,7 @@ int finish_stats(mv_index* ix, mv_query_stats* st, bool had_topk) {
     const int nc = st->reserved & 0xffff;
     const bool f8 = (st->reserved >> 30) & 1;
     const bool mid = (st->reserved >> 28) & 1;  // the list before its e4m3 pruning stage was copied to h_cand[1024..) in stream order
+    const bool rr_lo = (st->reserved >> 27) & 1;  // the rerank read the candidates' lo rows too (MV_WITH_FLOAT_LO)
     st->reserved = 0;
     MV_HIP(hipMemcpyAsync(ix->h_cand, ix->d_cand, (size_t)nc * 4, hipMemcpyDeviceToHost, ix->stream));
     MV_HIP(hipStreamSynchronize(ix->stream));
@@ -697,7 +754,7 @@ int finish_stats(mv_index* ix, mv_query_stats* st, bool had_topk) {
       if (ix->h_cand[i] >= 0) cand_rows += ix->h_n_rows[ix->h_cand[i]];
       if (mid && ix->h_cand[kTopkMaxDeviceK + i] >= 0) mid_rows += ix->h_n_rows[ix->h_cand[kTopkMaxDeviceK + i]];
     }
-    st->bytes_scanned += cand_rows * (int64_t)(f8 ? kDim : kRowBytes) + mid_rows * (int64_t)kDim;
+    st->bytes_scanned += cand_rows * (int64_t)(f8 ? kDim : (rr_lo ? 2 * kRowBytes : kRowBytes)) + mid_rows * (int64_t)kDim;
   }
   MV_HIP(hipEventElapsedTime(&st->score_kernel_ms, ix->ev[0], ix->ev[1]));
   if (had_topk) {
@@ -781,7 +838,8 @@ int add_pages_common(mv_index* ix, const void* d_src, int dtype, const int32_t* 
   // would rank a NaN page first); a sign-bit-only index takes them -- its quantiser defines every input (binary_ops.rs:81-136)
   const bool check_finite = (ix->cfg.flags & ~MV_WITH_BINARY) != 0;
   if (check_finite) MV_HIP(hipMemsetAsync(ix->d_w_flag, 0, 4, ws));
-  rc = launch_scatter_rows(d_src, dtype, d_off, n_pages, stride, slab_dst, ws, check_finite ? ix->d_w_flag : nullptr);
+  rc = launch_scatter_rows(d_src, dtype, d_off, n_pages, stride, slab_dst, ws, check_finite ? ix->d_w_flag : nullptr,
+                           ix->slab_lo ? ix->slab_lo + (size_t)first * stride * kDim : nullptr);  // lo = bf16(x - bf16(x)) of fp32 rows, zeros for bf16 rows
   if (!rc) rc = xt_store_from_device(ix, slab_dst, first, n_pages, ws);  // exact host tier (pinned host memory, or split with HBM): the fixed-stride bf16 image, slot for slot
   if (!rc && (ix->cfg.flags & MV_WITH_BINARY)) {
     // sign bits come from the bf16 image: bf16 RNE preserves sign and zero-ness of every fp32 value
@@ -975,7 +1033,7 @@ void mv_index_destroy(mv_index* ix) {
   DeviceGuard g(ix->cfg.device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
   if (ix->w_stream) (void)hipStreamSynchronize(ix->w_stream);
-  void* ptrs[] = {ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
+  void* ptrs[] = {ix->slab_lo, ix->d_qlo, ix->d_bqlo, ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
                   ix->d_topk_ws, ix->d_q, ix->d_qf32, ix->d_qbits, ix->d_qpop, ix->d_qfde, ix->d_qoff, ix->d_allow, ix->d_out_s,
                   ix->d_out_id, ix->d_cand, ix->d_cand_scores, ix->d_bqf32, ix->d_bqfde, ix->d_bqimage, ix->d_btopk_ws, ix->d_bsel_s,
                   ix->d_bsel_id, ix->d_bcand, ix->d_bcand_pads, ix->d_bcand_scores, ix->d_bout_s, ix->d_bout_id, ix->d_bq8hi, ix->d_bq8lo, ix->d_bq8fac};
@@ -991,7 +1049,7 @@ void mv_index_destroy(mv_index* ix) {
   for (auto& e : ix->ev_st_alt)
     if (e) (void)hipEventDestroy(e);
   if (ix->ev_stage) (void)hipEventDestroy(ix->ev_stage);
-  for (void* hp : {(void*)ix->h_qf32, (void*)ix->h_qbf16, (void*)ix->h_out_s, (void*)ix->h_out_id, (void*)ix->h_cand, (void*)ix->h_bout_s,
+  for (void* hp : {(void*)ix->h_qlo, (void*)ix->h_qf32, (void*)ix->h_qbf16, (void*)ix->h_out_s, (void*)ix->h_out_id, (void*)ix->h_cand, (void*)ix->h_bout_s,
                    (void*)ix->h_bout_id, (void*)ix->h_bcand, (void*)ix->h_exact})  // (slab_x, the HBM part of a split exact tier, went with ptrs[])
     if (hp) (void)hipHostFree(hp);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -1006,6 +1064,7 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   if (cfg->stride_rows < 16 || cfg->stride_rows % 16) { set_error("stride_rows must be a positive multiple of 16 (got %d)", cfg->stride_rows); return MV_ERR_INVALID; }
   if (cfg->capacity_pages < 1 || cfg->capacity_pages > 0x7fffffffLL) { set_error("capacity_pages out of range"); return MV_ERR_INVALID; }
   if (!(cfg->flags & (MV_WITH_FLOAT | MV_WITH_BINARY | MV_WITH_FDE | MV_WITH_FP8))) { set_error("flags select no slab"); return MV_ERR_INVALID; }
+  if ((cfg->flags & MV_WITH_FLOAT_LO) && !(cfg->flags & MV_WITH_FLOAT)) { set_error("MV_WITH_FLOAT_LO is the lo half of the bf16 slab: it needs MV_WITH_FLOAT"); return MV_ERR_INVALID; }
   if ((cfg->flags & MV_WITH_EXACT_SPLIT) && (!(cfg->flags & MV_WITH_HOST_EXACT) || (cfg->flags & MV_WITH_FLOAT))) {
     set_error("MV_WITH_EXACT_SPLIT splits the host exact tier: it needs MV_WITH_HOST_EXACT and no MV_WITH_FLOAT"); return MV_ERR_INVALID;
   }
@@ -1051,6 +1110,7 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
     }
   }
   if (cfg->flags & MV_WITH_FLOAT) alloc((void**)&ix->slab, rows * kRowBytes + 32768, "bf16 page slab");  // +32 KiB: the batched scans DMA whole 16 / 32 KiB chunks
+  if (cfg->flags & MV_WITH_FLOAT_LO) alloc((void**)&ix->slab_lo, rows * kRowBytes + 32768, "lo half of the bf16 page slab");
   if (cfg->flags & MV_WITH_FP8) {
     alloc((void**)&ix->slab8, rows * kDim + 4096, "fp8 page slab");  // +4 KiB: the scan DMAs whole 4 KiB pieces
     alloc((void**)&ix->inv_scale8, (size_t)cap * 4, "fp8 page scales");
@@ -1151,6 +1211,9 @@ int mv_index_set_option(mv_index* ix, int option, int64_t value) {
     case MV_OPT_EXACT_TIER:
       if (value < 0 || value > 2) { set_error("EXACT_TIER must be 0 (HBM slab), 1 (pinned-host tier) or 2 (e4m3 slab)"); return MV_ERR_INVALID; }
       ix->exact_tier = (int)value; return MV_OK;
+    case MV_OPT_FLOAT_LO_SCAN:
+      if (value < 0 || value > 2) { set_error("FLOAT_LO_SCAN must be 0 (hi slab only), 1 (hi + lo) or 2 (hi-only scan, split-bf16 re-score of the best)"); return MV_ERR_INVALID; }
+      ix->float_lo_scan = (int)value; return MV_OK;
     case MV_OPT_RERANK_N:
       if (value < 1 || value > kTopkMaxDeviceK) { set_error("RERANK_N must be 1..%d", kTopkMaxDeviceK); return MV_ERR_INVALID; }
       ix->rerank_n = value; return MV_OK;
@@ -1295,6 +1358,28 @@ int mv_index_read_pages(mv_index* ix, int64_t page0, int64_t n_pages, void* out_
   return MV_OK;
 }
 
+int mv_index_read_pages_f32(mv_index* ix, int64_t page0, int64_t n_pages, float* out_f32) {
+  if (!ix || !out_f32 || page0 < 0 || n_pages < 0 || page0 + n_pages > ix->size.load()) { set_error("read_pages_f32: range"); return MV_ERR_INVALID; }
+  if (!(ix->cfg.flags & (MV_WITH_FLOAT | MV_WITH_HOST_EXACT))) { set_error("index has no float slab"); return MV_ERR_STATE; }
+  const size_t pe = (size_t)ix->cfg.stride_rows * kDim;
+  const int64_t chunk = std::max<int64_t>(1, (int64_t)(((size_t)32 << 20) / (pe * 2)));
+  std::vector<uint16_t> hi((size_t)std::min<int64_t>(chunk, std::max<int64_t>(n_pages, 1)) * pe), lo;
+  for (int64_t done = 0; done < n_pages; done += chunk) {
+    const int64_t c = std::min(chunk, n_pages - done);
+    if (int rc = mv_index_read_pages(ix, page0 + done, c, hi.data())) return rc;
+    float* o = out_f32 + (size_t)done * pe;
+    for (size_t i = 0; i < (size_t)c * pe; ++i) o[i] = host_bf16_to_f32(hi[i]);
+    if (ix->slab_lo) {
+      lo.resize((size_t)c * pe);
+      std::lock_guard<std::mutex> lk(ix->q_mu);
+      DeviceGuard g(ix->cfg.device);
+      MV_HIP(hipMemcpy(lo.data(), ix->slab_lo + (size_t)(page0 + done) * pe, (size_t)c * pe * 2, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < (size_t)c * pe; ++i) o[i] += host_bf16_to_f32(lo[i]);  // exact: both halves came from ONE fp32 value
+    }
+  }
+  return MV_OK;
+}
+
 int mv_index_write_rows(mv_index* ix, int64_t page, int32_t row0, int32_t n, const void* bf16_rows) {
   if (!ix || !bf16_rows || page < 0 || page >= ix->size.load() || row0 < 0 || n < 0 || row0 + n > ix->cfg.stride_rows) { set_error("write_rows: range"); return MV_ERR_INVALID; }
   if (!(ix->cfg.flags & (MV_WITH_FLOAT | MV_WITH_HOST_EXACT))) { set_error("index has no float slab"); return MV_ERR_STATE; }
@@ -1305,6 +1390,7 @@ int mv_index_write_rows(mv_index* ix, int64_t page, int32_t row0, int32_t n, con
   if (!(ix->cfg.flags & MV_WITH_FLOAT)) return MV_OK;
   char* dst = (char*)ix->slab + ((size_t)page * ix->cfg.stride_rows + row0) * kRowBytes;
   MV_HIP(hipMemcpy(dst, bf16_rows, (size_t)n * kRowBytes, hipMemcpyHostToDevice));
+  if (ix->slab_lo && n > 0) MV_HIP(hipMemset((char*)ix->slab_lo + ((size_t)page * ix->cfg.stride_rows + row0) * kRowBytes, 0, (size_t)n * kRowBytes));  // bf16 rows: lo = 0
   return MV_OK;
 }
 
@@ -1364,6 +1450,9 @@ int mv_index_fill_synthetic(mv_index* ix, uint64_t seed, uint64_t first_unit, in
     const int64_t c = std::min(chunk, n_pages - done);
     uint16_t* dst = has_float ? ix->slab + (size_t)(first + done) * stride * kDim : (uint16_t*)ix->w_tmp;
     rc = launch_synth_rows(dst, seed, first_unit + (uint64_t)done, c, n_rows, stride, ws);
+    if (!rc && ix->slab_lo && hipMemsetAsync(ix->slab_lo + (size_t)(first + done) * stride * kDim, 0, (size_t)c * stride * kRowBytes, ws) != hipSuccess) {
+      set_error("fill_synthetic: clearing the lo slab failed"); rc = MV_ERR_HIP;  // the generator's rows ARE bf16: lo = 0
+    }
     if (!rc) rc = xt_store_from_device(ix, dst, first + done, c, ws);
     if (!rc) rc = derive_slabs_from_bf16(ix, dst, first + done, c, ix->d_n_rows + first + done, ws);
     if (!has_float && hipStreamSynchronize(ws) != hipSuccess && !rc) { set_error("fill_synthetic: stream error"); rc = MV_ERR_HIP; }
@@ -1389,6 +1478,7 @@ int mv_index_replace_page(mv_index* ix, int64_t page, const void* bf16_rows, int
   if (!has_float) { MV_HIP(hipMalloc(&stage, (size_t)stride * kRowBytes)); dst = stage; }
   int rc = MV_OK;
   hipError_t e = hipMemsetAsync(dst, 0, (size_t)stride * kRowBytes, ix->stream);
+  if (e == hipSuccess && ix->slab_lo) e = hipMemsetAsync(ix->slab_lo + (size_t)page * stride * kDim, 0, (size_t)stride * kRowBytes, ix->stream);  // bf16 rows: lo = 0
   if (e == hipSuccess && n_rows > 0) e = hipMemcpyAsync(dst, bf16_rows, (size_t)n_rows * kRowBytes, hipMemcpyHostToDevice, ix->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);  // the host buffer may be pageable
   if (e != hipSuccess) rc = hip_fail(e, "replace_page upload", __FILE__, __LINE__);
@@ -1441,6 +1531,7 @@ int mv_index_compact(mv_index* ix, int64_t* out_old_to_new, int64_t* out_new_siz
   std::vector<Slab> slabs;
   const size_t stride = (size_t)ix->cfg.stride_rows;
   if (ix->cfg.flags & MV_WITH_FLOAT) slabs.push_back({(char*)ix->slab, stride * kRowBytes});
+  if (ix->slab_lo) slabs.push_back({(char*)ix->slab_lo, stride * kRowBytes});
   if (ix->cfg.flags & MV_WITH_FP8) { slabs.push_back({(char*)ix->slab8, stride * kDim}); slabs.push_back({(char*)ix->inv_scale8, 16}); }
   if (ix->cfg.flags & MV_WITH_BINARY) slabs.push_back({(char*)ix->bits, stride * kSignBytes});
   if (ix->cfg.flags & MV_WITH_FDE) { slabs.push_back({(char*)ix->fde, (size_t)ix->fde_t.out_dim * 2}); slabs.push_back({(char*)ix->fde_inv_norm, 16}); }
@@ -1554,6 +1645,10 @@ int mv_internal_query_common(mv_index* ix, const void* q, int q_dtype, int32_t n
       }
     }
     if (st) memset(st, 0, sizeof(*st));
+    if (st && defer_stats) {  // nothing was enqueued: no events to read later -- the record is complete (all zeros) as it stands
+      swap_timing_event_sets(ix);
+      st->reserved = kStatsDoneTag;
+    }
     return MV_OK;
   }
   ScanResult r;
@@ -1571,7 +1666,9 @@ int mv_internal_query_common(mv_index* ix, const void* q, int q_dtype, int32_t n
       MV_HIP(hipMemcpy(d_scores_out, s.data(), (size_t)k * 4, hipMemcpyHostToDevice));
       MV_HIP(hipMemcpy(d_ids_out, id.data(), (size_t)k * 8, hipMemcpyHostToDevice));
     }
-    return finish_stats(ix, st, false);
+    rc = finish_stats(ix, st, false);
+    if (st && defer_stats) st->reserved = kStatsDoneTag;  // finished here (no selection ran): mv_query_stats_finish has nothing left to read
+    return rc;
   }
   if (k <= kTopkMaxDeviceK) {
     // host results: the selection's last kernel writes its k pairs straight into the pinned result buffers (device-visible host memory;
@@ -1652,6 +1749,7 @@ int mv_query_stats_finish(mv_index* ix, mv_query_stats* stats) {
   if (!ix || !stats) { set_error("mv_query_stats_finish: null argument"); return MV_ERR_INVALID; }
   std::lock_guard<std::mutex> lk(ix->q_mu);
   DeviceGuard g(ix->cfg.device);
+  if (stats->reserved & kStatsDoneTag) { stats->reserved = 0; return MV_OK; }  // a deferred query that had nothing to enqueue (empty shard, no allowed page)
   const bool tagged = (stats->reserved & kStatsDeferredTag) != 0;
   const int parity = (stats->reserved & kStatsParityBit) ? 1 : 0;
   stats->reserved &= ~(kStatsDeferredTag | kStatsParityBit);
@@ -1797,13 +1895,23 @@ int mv_internal_batch_upload_queries(mv_index* ix, const void* q, int q_dtype, i
   const int rpq = ((n_q_rows + 15) / 16) * 16;
   std::vector<float> hf((size_t)nb * rpq * kDim, 0.0f);
   std::vector<uint16_t> hb(want_bf16 ? (size_t)kBatchQRows * kDim : 0, (uint16_t)0);
+  std::vector<uint16_t> hbl(want_bf16 ? (size_t)kBatchQRows * kDim : 0, (uint16_t)0);  // lo halves of fp32 queries (upload_query)
+  bool any_lo = false;
   for (int b = 0; b < nb; ++b) {
     const char* src = (const char*)q + (size_t)b * n_q_rows * kDim * esz;
     float* df = hf.data() + (size_t)b * rpq * kDim;
     const size_t ne = (size_t)n_q_rows * kDim;
     if (q_dtype == MV_F32) {
       memcpy(df, src, ne * 4);
-      if (want_bf16) { uint16_t* db = hb.data() + (size_t)b * rpq * kDim; for (size_t i = 0; i < ne; ++i) db[i] = host_f32_to_bf16(df[i]); }
+      if (want_bf16) {
+        uint16_t* db = hb.data() + (size_t)b * rpq * kDim;
+        uint16_t* dl = hbl.data() + (size_t)b * rpq * kDim;
+        for (size_t i = 0; i < ne; ++i) {
+          db[i] = host_f32_to_bf16(df[i]);
+          dl[i] = host_f32_to_bf16(df[i] - host_bf16_to_f32(db[i]));
+          any_lo = any_lo || (dl[i] & 0x7fffu) != 0;
+        }
+      }
     } else {
       const uint16_t* sb = (const uint16_t*)src;
       if (want_bf16) memcpy(hb.data() + (size_t)b * rpq * kDim, sb, ne * 2);
@@ -1811,7 +1919,15 @@ int mv_internal_batch_upload_queries(mv_index* ix, const void* q, int q_dtype, i
     }
   }
   if (want_f32 || want_fp8) MV_HIP(hipMemcpyAsync(ix->d_bqf32, hf.data(), (size_t)nb * rpq * kDim * 4, hipMemcpyHostToDevice, ix->stream));
-  if (want_bf16) MV_HIP(hipMemcpyAsync(ix->d_bq, hb.data(), hb.size() * 2, hipMemcpyHostToDevice, ix->stream));
+  if (want_bf16) {
+    MV_HIP(hipMemcpyAsync(ix->d_bq, hb.data(), hb.size() * 2, hipMemcpyHostToDevice, ix->stream));
+    ix->bq_has_lo = any_lo;
+    ix->bq_lo_valid = any_lo || ix->slab_lo != nullptr;
+    if (ix->bq_lo_valid) {
+      if (!ix->d_bqlo) MV_HIP(hipMalloc(&ix->d_bqlo, (size_t)kBatchQRows * kRowBytes));
+      MV_HIP(hipMemcpyAsync(ix->d_bqlo, hbl.data(), hbl.size() * 2, hipMemcpyHostToDevice, ix->stream));
+    }
+  }
   if (want_fp8) {
     int rc = launch_fp8_query_prep(ix->d_bqf32, nb * rpq, ix->d_bq8hi, ix->d_bq8lo, ix->d_bq8fac, ix->stream);
     if (rc) return rc;
@@ -1833,7 +1949,11 @@ int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t n
   const uint16_t* exact = tier == kTierSlab ? ix->slab : (ix->x_split >= cap ? ix->slab_x : ix->d_exact);
   float* dst = d_out ? d_out : ix->d_bcand_scores;
   const int rr_variant = ix->maxsim_variant < 0 ? maxsim_default_variant(ix->cfg.stride_rows) : ix->maxsim_variant;
-  const bool rerank_one_launch = rerank_fp8 || (rpq <= kMaxQRowsPerPass && (rr_variant == 6 || rr_variant == 7));
+  // split-bf16 operands: the pages' lo slab beside the bf16 slab in HBM, and / or fp32 queries whose lo halves sit in d_bqlo
+  const uint16_t* slab_lo = tier == kTierSlab ? ix->slab_lo : nullptr;
+  const uint16_t* qlo = (ix->bq_lo_valid && (slab_lo || ix->bq_has_lo)) ? ix->d_bqlo : nullptr;
+  if (slab_lo && !qlo) { set_error("batched rerank: the lo slab needs the group's lo query rows (mv_internal_batch_upload_queries with want_bf16)"); return MV_ERR_STATE; }
+  const bool rerank_one_launch = rerank_fp8 || (rpq <= (qlo ? kMaxQRowsPerPass / 2 : kMaxQRowsPerPass) && (rr_variant == 6 || rr_variant == 7));
   int rc = MV_OK;
   if (rerank_fp8) {
     if (!(ix->cfg.flags & MV_WITH_FP8) || rpq > 64) { set_error("batched e4m3 rerank needs an fp8 slab and queries of <= 64 rows"); return MV_ERR_STATE; }
@@ -1850,6 +1970,7 @@ int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t n
     ma.slab = exact; ma.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr; ma.cand = ix->d_bcand; ma.q = ix->d_bq;
     ma.scores = dst; ma.n = n; ma.stride = ix->cfg.stride_rows; ma.q_tiles = rpq / 16; ma.pad_to = 0;
     ma.pad_items = ix->d_bcand_pads; ma.items_per_query = (int32_t)nc; ma.q_item_stride = rpq * kDim;
+    ma.qlo = qlo; ma.slab_lo = slab_lo;
     if (!split) {
       rc = launch_maxsim_bf16(ma, rr_variant, ix->stream);
       if (rc) return rc;
@@ -1872,7 +1993,7 @@ int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t n
   } else {
     for (int b = 0; b < nb; ++b) {  // one launch per query (long queries, non-default kernel variants)
       rc = exact_scan(ix, n_q_rows, tier, ix->d_bcand + (size_t)b * L, nc, 0, ix->d_bcand_pads + (size_t)b * L, dst + (size_t)b * L, launches,
-                      ix->d_bq + (size_t)b * rpq * kDim);
+                      ix->d_bq + (size_t)b * rpq * kDim, qlo ? qlo + (size_t)b * rpq * kDim : nullptr);
       if (rc) return rc;
     }
   }
@@ -2146,8 +2267,17 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
       n_queries > 1 && rpq <= 512 && k >= 1 && k <= kTopkMaxDeviceK && (ix->cfg.flags & MV_WITH_FP8) && ix->batch_variant != 8)
     return fp8_batch_query(ix, q, q_dtype, n_queries, n_q_rows, k, mode == MV_MODE_FP8_THEN_FLOAT, allow_bits, n_allow_words, allow_per_query, out_scores,
                            out_ids, out_n, stats);
+  // Split-bf16 operands (fp32 queries that are not bf16-representable; an index with a lo slab scanned with it): the batched MFMA
+  // kernel multiplies ONE bf16 term per operand -- such batches are served query by query by the single-query kernels, which carry
+  // the lo halves (the batch stays one call; bf16 queries on a plain index keep the one-pass form).
+  bool batch_lo = mode == MV_MODE_FLOAT && ix->slab_lo && ix->float_lo_scan != 0;
+  if (mode == MV_MODE_FLOAT && !batch_lo && q_dtype == MV_F32) {
+    const float* qf = (const float*)q;
+    const size_t ne = (size_t)n_queries * n_q_rows * kDim;
+    for (size_t i = 0; i < ne && !batch_lo; ++i) batch_lo = host_bf16_to_f32(host_f32_to_bf16(qf[i])) != qf[i];
+  }
   // anything but the exact float scan (and queries longer than one 512-row group) runs query by query
-  if (mode != MV_MODE_FLOAT || rpq > 512 || k > kTopkMaxDeviceK || k == 0) {
+  if (mode != MV_MODE_FLOAT || rpq > 512 || k > kTopkMaxDeviceK || k == 0 || batch_lo) {
     for (int32_t b = 0; b < n_queries; ++b) {
       mv_query_stats st{};
       const uint32_t* ab = (allow_bits && allow_per_query) ? allow_bits + (size_t)b * n_allow_words : allow_bits;
@@ -2645,6 +2775,7 @@ int mv_index_save(mv_index* ix, const char* path) {
   };
   const size_t rows = (size_t)size * ix->cfg.stride_rows;
   if (ix->cfg.flags & MV_WITH_FLOAT) dump(ix->slab, rows * kRowBytes);
+  if (ix->cfg.flags & MV_WITH_FLOAT_LO) dump(ix->slab_lo, rows * kRowBytes);
   if (ix->cfg.flags & MV_WITH_BINARY) dump(ix->bits, rows * kSignBytes);
   if (ix->cfg.flags & MV_WITH_FDE) {
     dump(ix->fde, (size_t)size * ix->fde_t.out_dim * 2);
@@ -2699,6 +2830,7 @@ int mv_index_load(const char* path, int32_t device, mv_index** out) {
   };
   const size_t rows = (size_t)h.size * h.cfg.stride_rows;
   if (h.cfg.flags & MV_WITH_FLOAT) fill(ix->slab, rows * kRowBytes);
+  if (h.cfg.flags & MV_WITH_FLOAT_LO) fill(ix->slab_lo, rows * kRowBytes);
   if (h.cfg.flags & MV_WITH_BINARY) fill(ix->bits, rows * kSignBytes);
   if (h.cfg.flags & MV_WITH_FDE) {
     fill(ix->fde, (size_t)h.size * ix->fde_t.out_dim * 2);

@@ -41,6 +41,11 @@ struct MaxsimArgs {
   const int32_t* pad_items; // per-item pad_to (device; the reference pads every rerank batch of 128 on its own); null -> pad_to
   int32_t items_per_query;  // > 0: the candidate lists of a batch of queries in one launch -- item i is scored against the
   int32_t q_item_stride;    //      query at q + (i / items_per_query) * q_item_stride (bf16 elements); default variants only
+  // split-bf16 operands (fp32-faithful scores on the bf16 matrix pipe; the reference scores fp32 pages with fp32 queries,
+  // fast_multivector_store.py:553-555, :736, :774): x = hi + lo, hi = bf16(x), lo = bf16(x - hi), |x - hi - lo| <= 2^-18 |x|
+  const uint16_t* qlo;      // nullable: the lo half of the query rows (layout of q, q_item_stride applies): S = qhi.p + qlo.p
+  const uint16_t* slab_lo;  // nullable: the lo half of the page rows (layout of slab; needs qlo -- zeros for a bf16 query):
+                            //           S = qhi.phi + qlo.phi + qhi.plo (the dropped qlo.plo term is <= 2^-18 of the product)
 };
 // variant: -1 default; see DESIGN.md "Kernel variants".
 int launch_maxsim_bf16(const MaxsimArgs& a, int variant, hipStream_t s);
@@ -297,8 +302,9 @@ int launch_stream_probe(const void* d_buf, int64_t bytes, int ct, int own, int s
 int launch_read_bw_strided(const void* d_buf, int64_t n_rows, int piece, float* d_sink, hipStream_t s);  // [rows][20 480 B], `piece` bytes per row and step
 int launch_mfma_peak(int blocks, int iters, int shape, float* d_sink, hipStream_t s);   // per iteration per wave: shape 0 = 8 x 16x16x32, 1 = 4 x 32x32x16 bf16 MFMA
 // scatter ragged bf16/f32 rows into the fixed-stride slab (zero-filling the tail of each page slot);
-// d_nonfinite (nullable): set to 1 when a row holds a NaN / Inf (in its bf16 image)
+// d_nonfinite (nullable): set to 1 when a row holds a NaN / Inf (in its bf16 image);
+// d_slab_lo_pages (nullable): the same slots of the lo slab receive bf16(x - bf16(x)) of fp32 input (zeros for bf16 input)
 int launch_scatter_rows(const void* d_src, int dtype, const int64_t* d_row_offsets, int64_t n_pages, int32_t stride,
-                        uint16_t* d_slab_pages, hipStream_t s, int32_t* d_nonfinite = nullptr);
+                        uint16_t* d_slab_pages, hipStream_t s, int32_t* d_nonfinite = nullptr, uint16_t* d_slab_lo_pages = nullptr);
 
 }  // namespace mv

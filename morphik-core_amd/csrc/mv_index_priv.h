@@ -29,6 +29,8 @@ struct mv_index {
   hipStream_t w_stream = nullptr;  // writer stream (ingest runs beside the scans)
   // slabs
   uint16_t* slab = nullptr;
+  uint16_t* slab_lo = nullptr;   // MV_WITH_FLOAT_LO: bf16(x - bf16(x)) of every slab element (zeros for pages ingested as bf16) -- with `slab` the
+                                 // split-bf16 image of the reference's fp32 pages (fast_multivector_store.py:676-681): the same 4 bytes per element
   uint8_t* bits = nullptr;
   uint16_t* fde = nullptr;
   float* fde_inv_norm = nullptr;
@@ -55,6 +57,12 @@ struct mv_index {
   size_t topk_ws_bytes = 0;
   bool sync_call = false;      // the running query drains the stream before it returns (no staging-buffer event needed)
   uint16_t* d_q = nullptr;     // bf16 query, padded
+  uint16_t* d_qlo = nullptr;   // lo half of an fp32 query (bf16(q - bf16(q))), padded like d_q; valid when q_lo_valid
+  bool q_has_lo = false;       // the uploaded query is not bf16-representable (some lo element is non-zero)
+  bool q_lo_valid = false;     // d_qlo holds the uploaded query's lo rows (zeros for a bf16 query): q_has_lo, or the index keeps a lo slab
+  uint16_t* d_bqlo = nullptr;  // the same for the batch block d_bq (lazily allocated)
+  bool bq_has_lo = false, bq_lo_valid = false;
+  uint16_t* h_qlo = nullptr;   // pinned staging of d_qlo
   float* d_qf32 = nullptr;     // fp32 query rows (FDE encode input)
   uint8_t* d_qbits = nullptr;
   float* d_qpop = nullptr;     // popc per query row (binary MFMA scan)
@@ -140,6 +148,8 @@ struct mv_index {
   int exact_tier = 0;      // 0 = the bf16 slab in HBM when the index has one, else the pinned-host tier; 1 = the host tier when present
   int fde_cosine = 1;
   int pad_semantics = -1;  // -1: mode default (reference batch rule for FDE_THEN_FLOAT / candidates, none for full scan)
+  int float_lo_scan = 1;   // MV_MODE_FLOAT full scans on an index with a lo slab: 1 = read both halves (fp32-faithful scores, 2 x the bytes),
+                           // 0 = the hi half only (the bf16-rounded pages), 2 = hi-only scan -> top max(MV_OPT_RERANK_N, k) -> split-bf16 re-score
 };
 
 namespace mv {
@@ -178,8 +188,9 @@ int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_wo
 int rerank_scan(mv_index* ix, int n_q, int tier, int64_t n_items, float* d_out, int* launches);
 // exact bf16 MaxSim of a candidate list on the bf16 slab (kTierSlab) or on the exact host tier (kTierHost): a tier split between HBM and
 // host memory is scored in two launches (each part's candidates against its own base) and merged
+// d_q_base / d_qlo_base: the query rows of a batch block (d_bq / d_bqlo + offset) instead of the single-query buffers
 int exact_scan(mv_index* ix, int n_q, int tier, const int32_t* d_cand, int64_t n_items, int32_t pad_to, const int32_t* d_pad_items, float* d_out,
-               int* launches, const uint16_t* d_q_base = nullptr);
+               int* launches, const uint16_t* d_q_base = nullptr, const uint16_t* d_qlo_base = nullptr);
 // e4m3 scan of pages 0..n_items-1 (or of the candidate list d_cand) with the query uploaded by upload_query(want_fp8)
 int fp8_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_words, const int32_t* d_cand, int64_t n_items,
              int32_t pad_to, const int32_t* d_pad_items, float* d_out, int* launches, bool no_mask = false);
@@ -229,6 +240,8 @@ int finish_stats(mv_index* ix, mv_query_stats* st, bool had_topk);
 // bits of mv_query_stats::reserved that travel with a DEFERRED record (mv_query_topk_device_async -> mv_query_stats_finish): which of the two
 // timing-event sets its query recorded into; the low bits are finish_stats' own stage flags
 constexpr int32_t kStatsDeferredTag = 1 << 25, kStatsParityBit = 1 << 26;
+// ... and the record of a deferred query that was complete when the call returned (nothing enqueued): mv_query_stats_finish just clears it
+constexpr int32_t kStatsDoneTag = 1 << 24;
 // user_stream value of mv_internal_query_common meaning "the NULL (default) stream, ordered against -- not `no stream, block`"
 static void* const kNullStreamTag = reinterpret_cast<void*>(~(uintptr_t)0);
 

@@ -35,6 +35,7 @@ using bf16x8 = __attribute__((ext_vector_type(8))) short;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kMaxQTiles = 8;  // 128 query rows per pass (A fragments: 16 VGPRs per tile)
+constexpr int kMaxQTilesLo = 4;  // 64 rows per pass when the query's lo half rides along (32 VGPRs per tile)
 
 struct KArgs {
   const char* slab;
@@ -52,6 +53,8 @@ struct KArgs {
   const int32_t* pad_items;  // per-item pad_to (rerank batches of 128 pad independently); null -> pad_to
   int32_t items_per_q;       // QITEM kernels: work item i scores against the query at q + (i / items_per_q) * q_item_stride
   int32_t q_item_stride;     // (bf16 elements) -- the candidate lists of a batch of queries in ONE launch
+  const uint16_t* qlo;       // LO >= 1: lo half of the query rows (bf16(q - bf16(q)); layout of q)
+  const char* slab_lo;       // LO == 2: lo half of the page rows (layout of slab)
 };
 
 __device__ __forceinline__ bool page_masked(const KArgs& a, int64_t page) {
@@ -88,6 +91,31 @@ __device__ __forceinline__ void tile_mfma(const bf16x8 (&a)[MT][4], const bf16x8
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][j], b[j], acc, 0, 0, 0);
+    if (mask_cols && !col_valid) acc = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mx[m][i] = fmaxf(mx[m][i], acc[i]);
+  }
+}
+
+// Split-bf16 form: the operands are hi + lo pairs of bf16 values (x = hi + lo to 2^-18 |x|), the products accumulate in the
+// SAME fp32 accumulator before the max -- the maximum runs over the fp32-faithful sums, as the reference's fp32 einsum -> max does.
+//   LO == 1  query hi + lo against bf16 pages:        S = qh.p + ql.p
+//   LO == 2  ... against page hi + lo (the lo slab):  S = qh.ph + ql.ph + qh.pl   (ql.pl <= 2^-18 of the product: dropped)
+// The hi.hi chain comes first, so operands that ARE bf16 (lo = 0) give the bits of tile_mfma (x + 0 = x).
+template <int MT, int LO>
+__device__ __forceinline__ void tile_mfma_lo(const bf16x8 (&a)[MT][4], const bf16x8 (&al)[MT][4], const bf16x8 (&b)[4], const bf16x8 (&bl)[4],
+                                             f32x4 (&mx)[MT], bool mask_cols, bool col_valid) {
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][j], b[j], acc, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m][j], b[j], acc, 0, 0, 0);
+    if (LO == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][j], bl[j], acc, 0, 0, 0);
+    }
     if (mask_cols && !col_valid) acc = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
     for (int i = 0; i < 4; ++i) mx[m][i] = fmaxf(mx[m][i], acc[i]);
@@ -145,7 +173,7 @@ __device__ __forceinline__ void finish_block(const f32x4 (&mx)[MT], bool clamp, 
 
 // --------------------------------------------------------------------------------------------
 // Variants 0/1/4/5: direct global -> VGPR fragment loads (64 contiguous bytes per row per instruction).
-template <int MT, int WPP, bool NT>
+template <int MT, int WPP, bool NT, int LO = 0>
 __global__ __launch_bounds__(256) void maxsim_direct_kernel(KArgs a) {
   constexpr int PF = 3;  // register ring depth (tiles in flight per wave = PF-1 .. PF)
   __shared__ float red[512];
@@ -165,37 +193,48 @@ __global__ __launch_bounds__(256) void maxsim_direct_kernel(KArgs a) {
 
   bf16x8 qa[MT][4];
   load_query<MT>(a.q, r, g, qa);
+  bf16x8 qal[LO ? MT : 1][4];
+  if constexpr (LO > 0) load_query<MT>(a.qlo, r, g, qal);
 
   f32x4 mx[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) mx[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 
-  const char* base = a.slab + (size_t)page * (size_t)a.stride * kRowBytes + r * kRowBytes + g * 16;
+  const size_t poff = (size_t)page * (size_t)a.stride * kRowBytes + r * kRowBytes + g * 16;
+  const char* base = a.slab + poff;
+  const char* base_lo = LO == 2 ? a.slab_lo + poff : nullptr;
   const int t0 = (WPP == 1) ? 0 : wave;
   const int ntw = (ntiles - t0 + WPP - 1) / WPP;  // tiles owned by this wave (may be <= 0)
 
   bf16x8 buf[PF][4];
-  auto load_tile = [&](bf16x8(&b)[4], int it) {
-    const char* tp = base + (size_t)(t0 + it * WPP) * kTileBytes;
+  bf16x8 bufl[LO == 2 ? PF : 1][4];
+  auto load_from = [&](const char* bs, bf16x8(&b)[4], int it) {
+    const char* tp = bs + (size_t)(t0 + it * WPP) * kTileBytes;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bf16x8* p = reinterpret_cast<const bf16x8*>(tp + j * 64);
       b[j] = NT ? __builtin_nontemporal_load(p) : *p;
     }
   };
+  auto load_tile = [&](int slot, int it) {
+    load_from(base, buf[slot], it);
+    if constexpr (LO == 2) load_from(base_lo, bufl[slot], it);
+  };
 #pragma unroll
   for (int i = 0; i < PF - 1; ++i)
-    if (i < ntw) load_tile(buf[i], i);
+    if (i < ntw) load_tile(i, i);
 
   for (int it0 = 0; it0 < ntw; it0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int it = it0 + u;
       if (it < ntw) {
-        if (it + PF - 1 < ntw) load_tile(buf[(u + PF - 1) % PF], it + PF - 1);
+        if (it + PF - 1 < ntw) load_tile((u + PF - 1) % PF, it + PF - 1);
         const int t = t0 + it * WPP;
         const bool partial = (t + 1) * kTileRows > nr;
-        tile_mfma<MT>(qa, buf[u], mx, partial, t * kTileRows + r < nr);
+        if constexpr (LO == 0) tile_mfma<MT>(qa, buf[u], mx, partial, t * kTileRows + r < nr);
+        else if constexpr (LO == 1) tile_mfma_lo<MT, 1>(qa, qal, buf[u], buf[u], mx, partial, t * kTileRows + r < nr);
+        else tile_mfma_lo<MT, 2>(qa, qal, buf[u], bufl[u], mx, partial, t * kTileRows + r < nr);
       }
     }
   }
@@ -224,11 +263,17 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // STREAM_ONLY: the same ring, the same waits, no fragment reads and no MFMA -- the transport ceiling of this kernel
 // (MV_CAL_READ_LDSDMA: the roofline's measured denominator).
-template <int MT, int WPP, int D, bool NT = false, bool CONTIG = false, bool STREAM_ONLY = false, bool QITEM = false>
+//
+// LO (split-bf16 operands, tile_mfma_lo): 1 = the query's lo half rides along in registers; 2 = also the pages' lo slab --
+// a ring item is then the PAIR (hi tile, lo tile) of one 16-row tile, 8 KiB, the ring D pairs deep (128 KiB of LDS per
+// workgroup at D = 4: one workgroup per CU with the bytes in flight of two hi-only ones).
+template <int MT, int WPP, int D, bool NT = false, bool CONTIG = false, bool STREAM_ONLY = false, bool QITEM = false, int LO = 0>
 __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
+  constexpr int TPI = LO == 2 ? 2 : 1;               // tiles per ring item
+  constexpr int kItemBytes = TPI * kTileBytes;
   // one __shared__ object only (a second one makes hipcc drain vmcnt before every ds_read)
-  __shared__ __attribute__((aligned(16))) char lds[4 * D * kTileBytes + 2048];
-  float* red = reinterpret_cast<float*>(lds + 4 * D * kTileBytes);
+  __shared__ __attribute__((aligned(16))) char lds[4 * D * kItemBytes + 2048];
+  float* red = reinterpret_cast<float*>(lds + 4 * D * kItemBytes);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
@@ -254,7 +299,8 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
   const int tstep = CONTIG ? 1 : WPP;
   const int ntw = CONTIG ? max(0, min(tq, ntiles - t0)) : (ntiles - t0 + WPP - 1) / WPP;
   const char* pbase = a.slab + (size_t)page * (size_t)a.stride * kRowBytes;
-  char* ring = lds + wave * (D * kTileBytes);
+  const char* plbase = LO == 2 ? a.slab_lo + (size_t)page * (size_t)a.stride * kRowBytes : nullptr;
+  char* ring = lds + wave * (D * kItemBytes);
 
   // DMA source offsets: instruction i covers rows 4i..4i+3; lane -> row 4i+(lane>>4), position lane&15.
   int src_off[4];
@@ -273,13 +319,11 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
   // tile: M0 = wave-uniform LDS slot address; the instruction offset (applied to BOTH the global and
   // the LDS address) walks the four 1 KiB pieces, so src_off[i] carries -i*1024 to compensate.
   // s_nop 4 covers SALU-write -> VMEM-read of the base SGPRs and the M0 write -> LDS-DMA hazard.
-  auto issue = [&](int it) {
-    const char* tp = pbase + (size_t)(t0 + it * tstep) * kTileBytes;
+  auto issue_tile = [&](const char* tp, char* slot_ptr) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
     const uint64_t tpu = ((uint64_t)hi << 32) | lo;
-    const uint32_t slot = __builtin_amdgcn_readfirstlane(
-        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + (it % D) * kTileBytes));
+    const uint32_t slot = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)slot_ptr);
     uint32_t keep;
     if (NT) {  // non-temporal: the page stream is read once; do not let it displace the query / metadata in L2
       asm volatile(
@@ -309,6 +353,12 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
           : "memory");
     }
   };
+  auto issue = [&](int it) {
+    const size_t toff = (size_t)(t0 + it * tstep) * kTileBytes;
+    char* sp = ring + (it % D) * kItemBytes;
+    issue_tile(pbase + toff, sp);
+    if constexpr (LO == 2) issue_tile(plbase + toff, sp + kTileBytes);
+  };
 
 #pragma unroll
   for (int i = 0; i < D - 1; ++i)
@@ -327,26 +377,45 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(qa[m][j]));
   }
+  bf16x8 qal[LO ? MT : 1][4];
+  if constexpr (LO > 0 && !STREAM_ONLY) {
+    const uint16_t* qlp = a.qlo;
+    if (QITEM) qlp += (size_t)(item / a.items_per_q) * (size_t)a.q_item_stride;
+    load_query<MT>(qlp, r, g, qal);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(qal[m][j]));
+  }
 
   for (int it = 0; it < ntw; ++it) {
     if (it + D - 1 < ntw) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // WAR: last reads of the slot being refilled
       issue(it + D - 1);
-      wait_vmcnt<4 * (D - 1)>();
+      wait_vmcnt<4 * TPI * (D - 1)>();
     } else {
-      const int left = ntw - 1 - it;  // tiles still allowed in flight
-      if (left >= 2) wait_vmcnt<8>();
-      else if (left == 1) wait_vmcnt<4>();
+      const int left = ntw - 1 - it;  // items still allowed in flight
+      if (left >= 2) wait_vmcnt<8 * TPI>();
+      else if (left == 1) wait_vmcnt<4 * TPI>();
       else wait_vmcnt<0>();
     }
     if (STREAM_ONLY) continue;
-    const char* slot = ring + (it % D) * kTileBytes;
+    const char* slot = ring + (it % D) * kItemBytes;
     bf16x8 b[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(slot + rd_off[j]);
     const int t = t0 + it * tstep;
     const bool partial = (t + 1) * kTileRows > nr;
-    tile_mfma<MT>(qa, b, mx, partial, t * kTileRows + r < nr);
+    if constexpr (LO == 0) {
+      tile_mfma<MT>(qa, b, mx, partial, t * kTileRows + r < nr);
+    } else if constexpr (LO == 1) {
+      tile_mfma_lo<MT, 1>(qa, qal, b, b, mx, partial, t * kTileRows + r < nr);
+    } else {
+      bf16x8 bl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const bf16x8*>(slot + kTileBytes + rd_off[j]);
+      tile_mfma_lo<MT, 2>(qa, qal, b, bl, mx, partial, t * kTileRows + r < nr);
+    }
   }
   if (STREAM_ONLY) {
     if (threadIdx.x == 0) a.scores[item] = 0.f;
@@ -370,7 +439,7 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
 // What stays: 6 (default from 512 rows per page), 7 (default below), 0 (direct loads, one wave per page: the independent
 // cross-check of the ring), 13 (the default's transport without arithmetic: MV_CAL_READ_LDSDMA).
 
-template <int MT>
+template <int MT, int LO>
 int launch_mt(const KArgs& k0, int variant, hipStream_t s) {
   if (k0.n <= 0) return MV_OK;
   dim3 block(256);
@@ -386,20 +455,32 @@ int launch_mt(const KArgs& k0, int variant, hipStream_t s) {
     const int64_t n = k.n;
     if (k.items_per_q > 0) {  // per-item queries: the two default forms only, one launch
       if (k0.n > kChunk || (variant != 6 && variant != 7)) { set_error("per-item queries: variant %d / %lld items not supported", variant, (long long)k0.n); return MV_ERR_INVALID; }
-      if (variant == 6) hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true, false, false, true>), dim3((unsigned)n), block, 0, s, k);
-      else hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 1, 4, true, false, false, true>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k);
+      if (variant == 6) hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true, false, false, true, LO>), dim3((unsigned)n), block, 0, s, k);
+      else hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 1, 4, true, false, false, true, LO>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k);
       continue;
     }
     switch (variant) {
-      case 0: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 1, false>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
-      case 6: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true>), dim3((unsigned)n), block, 0, s, k); break;
-      case 7: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 1, 4, true>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
-      case 13: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true, false, true>), dim3((unsigned)n), block, 0, s, k); break;
-      default: set_error("unknown maxsim variant %d", variant); return MV_ERR_INVALID;
+      case 0: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 1, false, LO>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
+      case 6: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true, false, false, false, LO>), dim3((unsigned)n), block, 0, s, k); break;
+      case 7: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 1, 4, true, false, false, false, LO>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
+      case 13:
+        if constexpr (LO == 0) { hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true, false, true>), dim3((unsigned)n), block, 0, s, k); break; }
+        [[fallthrough]];
+      default: set_error("unknown maxsim variant %d%s", variant, LO ? " (split-bf16 operands: 0, 6, 7)" : ""); return MV_ERR_INVALID;
     }
   }
   MV_HIP(hipGetLastError());
   return MV_OK;
+}
+
+template <int LO>
+int launch_lo(const KArgs& k, int q_tiles, int variant, hipStream_t s) {
+  switch (q_tiles) {
+    case 1: return launch_mt<1, LO>(k, variant, s);
+    case 2: return launch_mt<2, LO>(k, variant, s);
+    case 3: return launch_mt<3, LO>(k, variant, s);
+    default: return launch_mt<4, LO>(k, variant, s);
+  }
 }
 
 }  // namespace
@@ -432,17 +513,22 @@ int launch_maxsim_bf16(const MaxsimArgs& a, int variant, hipStream_t s) {
     return MV_ERR_INVALID;
   }
   KArgs k{reinterpret_cast<const char*>(a.slab), a.n_rows, a.doc_ord, a.allow, a.n_allow_bits, a.cand, a.q, a.scores,
-          a.n, a.stride, a.pad_to, 0, a.pad_items, a.items_per_query, a.q_item_stride};
+          a.n, a.stride, a.pad_to, 0, a.pad_items, a.items_per_query, a.q_item_stride, a.qlo, reinterpret_cast<const char*>(a.slab_lo)};
   if (a.items_per_query < 0 || (a.items_per_query > 0 && !a.cand)) { set_error("items_per_query needs a candidate list"); return MV_ERR_INVALID; }
+  if (a.slab_lo || a.qlo) {  // split-bf16 operands: the lo fragments double the query registers -- 64 query rows per pass
+    if (!a.qlo) { set_error("the lo slab needs the query's lo half (zeros for a bf16 query)"); return MV_ERR_INVALID; }
+    if (a.q_tiles > kMaxQTilesLo) { set_error("q_tiles=%d out of range (1..%d with split-bf16 operands)", a.q_tiles, kMaxQTilesLo); return MV_ERR_INVALID; }
+    return a.slab_lo ? launch_lo<2>(k, a.q_tiles, variant, s) : launch_lo<1>(k, a.q_tiles, variant, s);
+  }
   switch (a.q_tiles) {
-    case 1: return launch_mt<1>(k, variant, s);
-    case 2: return launch_mt<2>(k, variant, s);
-    case 3: return launch_mt<3>(k, variant, s);
-    case 4: return launch_mt<4>(k, variant, s);
-    case 5: return launch_mt<5>(k, variant, s);
-    case 6: return launch_mt<6>(k, variant, s);
-    case 7: return launch_mt<7>(k, variant, s);
-    default: return launch_mt<8>(k, variant, s);
+    case 1: return launch_mt<1, 0>(k, variant, s);
+    case 2: return launch_mt<2, 0>(k, variant, s);
+    case 3: return launch_mt<3, 0>(k, variant, s);
+    case 4: return launch_mt<4, 0>(k, variant, s);
+    case 5: return launch_mt<5, 0>(k, variant, s);
+    case 6: return launch_mt<6, 0>(k, variant, s);
+    case 7: return launch_mt<7, 0>(k, variant, s);
+    default: return launch_mt<8, 0>(k, variant, s);
   }
 }
 

@@ -89,32 +89,44 @@ __global__ void f32_to_bf16_kernel(const float* in, uint16_t* out, int64_t n) {
 
 // One block per page: copy/convert rows [off[p], off[p+1]) into slab page p, zero the tail.
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const void* src, int dtype, const int64_t* off, int32_t stride,
-                                                           uint16_t* slab, int32_t* nonfinite) {
+                                                           uint16_t* slab, int32_t* nonfinite, uint16_t* slab_lo) {
   const int64_t p = blockIdx.x;
   const int64_t r0 = off[p];
   const int32_t nr = (int32_t)(off[p + 1] - r0);
   uint16_t* dst = slab + p * (int64_t)stride * kDim;
+  uint16_t* dst_lo = slab_lo ? slab_lo + p * (int64_t)stride * kDim : nullptr;
   const int total = stride * (kDim / 4);  // 4 elements per thread-step
   for (int i = threadIdx.x; i < total; i += blockDim.x) {
     const int row = i / (kDim / 4), c4 = i % (kDim / 4);
     uint2 v = make_uint2(0u, 0u);
+    uint2 l = make_uint2(0u, 0u);  // lo half of the split: bf16(x - bf16(x)); the subtraction is exact in fp32
     if (row < nr) {
       const int64_t e = (r0 + row) * kDim + c4 * 4;
       if (dtype == MV_BF16) {
         v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(src) + e);
       } else {
         const float4 f = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + e);
-        v.x = (uint32_t)f32_to_bf16_rne(f.x) | ((uint32_t)f32_to_bf16_rne(f.y) << 16);
-        v.y = (uint32_t)f32_to_bf16_rne(f.z) | ((uint32_t)f32_to_bf16_rne(f.w) << 16);
+        const uint32_t h0 = f32_to_bf16_rne(f.x), h1 = f32_to_bf16_rne(f.y), h2 = f32_to_bf16_rne(f.z), h3 = f32_to_bf16_rne(f.w);
+        v.x = h0 | (h1 << 16);
+        v.y = h2 | (h3 << 16);
+        if (dst_lo) {
+          const uint32_t l0 = f32_to_bf16_rne(f.x - __uint_as_float(h0 << 16)), l1 = f32_to_bf16_rne(f.y - __uint_as_float(h1 << 16));
+          const uint32_t l2 = f32_to_bf16_rne(f.z - __uint_as_float(h2 << 16)), l3 = f32_to_bf16_rne(f.w - __uint_as_float(h3 << 16));
+          l.x = l0 | (l1 << 16);
+          l.y = l2 | (l3 << 16);
+        }
       }
     }
     *reinterpret_cast<uint2*>(dst + (int64_t)row * kDim + c4 * 4) = v;
     // NaN / +-Inf (exponent all ones) in the bf16 image the slabs are derived from -- an fp32 value beyond the bf16 range counts:
     // it IS an Inf in the slab.  The ingest reports it (mv_index_add*: MV_ERR_INVALID, nothing published).
+    bool bad = false;
     if (nonfinite) {
       const uint32_t a = v.x & 0x7f807f80u, b = v.y & 0x7f807f80u;
-      if ((a & 0xffffu) == 0x7f80u || (a >> 16) == 0x7f80u || (b & 0xffffu) == 0x7f80u || (b >> 16) == 0x7f80u) atomicOr(nonfinite, 1);
+      bad = (a & 0xffffu) == 0x7f80u || (a >> 16) == 0x7f80u || (b & 0xffffu) == 0x7f80u || (b >> 16) == 0x7f80u;
+      if (bad) atomicOr(nonfinite, 1);
     }
+    if (dst_lo) *reinterpret_cast<uint2*>(dst_lo + (int64_t)row * kDim + c4 * 4) = bad ? make_uint2(0u, 0u) : l;  // (x - Inf would be a NaN)
   }
 }
 
@@ -540,10 +552,10 @@ int launch_f32_to_bf16(const float* d_in, uint16_t* d_out, int64_t n, hipStream_
 }
 
 int launch_scatter_rows(const void* d_src, int dtype, const int64_t* d_row_offsets, int64_t n_pages, int32_t stride,
-                        uint16_t* d_slab_pages, hipStream_t s, int32_t* d_nonfinite) {
+                        uint16_t* d_slab_pages, hipStream_t s, int32_t* d_nonfinite, uint16_t* d_slab_lo_pages) {
   if (n_pages <= 0) return MV_OK;
   hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)n_pages), dim3(256), 0, s, d_src, dtype, d_row_offsets, stride,
-                     d_slab_pages, d_nonfinite);
+                     d_slab_pages, d_nonfinite, d_slab_lo_pages);
   MV_HIP(hipGetLastError());
   return MV_OK;
 }

@@ -27,6 +27,7 @@ from ._lib import (
     MV_WITH_FP8,
     MV_WITH_HOST_EXACT,
     MV_WITH_EXACT_SPLIT,
+    MV_WITH_FLOAT_LO,
     ConfigC,
     FdeConfigC,
     QueryStatsC,
@@ -175,14 +176,19 @@ class MvIndex:
         with_fp8: bool = False,
         with_host_exact: bool = False,
         with_exact_split: bool = False,
+        with_float_lo: bool = False,
     ):
         """with_host_exact: keep the exact bf16 rows in PINNED HOST memory (no HBM) as the exact tier of mode
         "fp8_then_float" -- for shards whose bf16 slab does not fit beside the fp8 slab.
         with_exact_split (with with_host_exact, without with_float): the exact rows of the first pages fill the HBM the other
-        slabs leave free, only the rest is pinned (exact_hbm_pages tells the split)."""
+        slabs leave free, only the rest is pinned (exact_hbm_pages tells the split).
+        with_float_lo (with with_float): a second bf16 slab holding lo = bf16(x - bf16(x)) -- pages added as float32 keep 16
+        significant bits (x = hi + lo to 2^-18), the candidate scorers and the float scan multiply both halves on the bf16 MFMA
+        and return the reference's fp32 scores (fast_multivector_store.py:553-555 on its fp32 `.npy` pages) to ~1e-6."""
         self.fde_config = fde or FdeConfig()
         flags = ((MV_WITH_FLOAT if with_float else 0) | (MV_WITH_BINARY if with_binary else 0) | (MV_WITH_FDE if with_fde else 0)
-                 | (MV_WITH_FP8 if with_fp8 else 0) | (MV_WITH_HOST_EXACT if with_host_exact else 0) | (MV_WITH_EXACT_SPLIT if with_exact_split else 0))
+                 | (MV_WITH_FP8 if with_fp8 else 0) | (MV_WITH_HOST_EXACT if with_host_exact else 0) | (MV_WITH_EXACT_SPLIT if with_exact_split else 0)
+                 | (MV_WITH_FLOAT_LO if with_float_lo else 0))
         cfg = ConfigC(128, int(stride_rows), int(capacity_pages), int(device), flags, int(id_base), self.fde_config.to_c())
         h = C.c_void_p()
         check(lib().mv_index_create(C.byref(cfg), C.byref(h)))
@@ -305,6 +311,12 @@ class MvIndex:
     def read_pages(self, page0: int, n_pages: int) -> np.ndarray:
         out = np.empty((n_pages, self.stride_rows, 128), np.uint16)
         check(lib().mv_index_read_pages(self._h, page0, n_pages, out.ctypes.data))
+        return out
+
+    def read_pages_f32(self, page0: int, n_pages: int) -> np.ndarray:
+        """-> float32 [n_pages, stride_rows, 128]: hi + lo of an index with with_float_lo (the fp32 input to 2^-18), else the bf16 rows widened."""
+        out = np.empty((n_pages, self.stride_rows, 128), np.float32)
+        check(lib().mv_index_read_pages_f32(self._h, page0, n_pages, out.ctypes.data))
         return out
 
     def remove_doc(self, doc_ordinal: int) -> int:

@@ -157,7 +157,15 @@ class GpuShardedSearcher:
         self._bufs = {}
         self._flip = 0
         self._pending = None  # the stats record of the last enqueued query (finished one query later, or by flush())
-        self._trail = mode not in ("fde_then_float", "fde")  # (FDE-mode records carry stage accounting: finished before the next query)
+
+    # bits of mv_query_stats.reserved that only ROUTE a deferred record (csrc/mv_index_priv.h: done / deferred / parity); anything else
+    # is stage accounting (the FDE modes, fp8_then_float, the MV_OPT_FLOAT_LO_SCAN 2 cascade), which reads the candidate list the NEXT
+    # query overwrites: such a record must be finished before the next query is enqueued (mv_query_stats_finish: MV_ERR_STATE otherwise)
+    _ROUTING_BITS = (1 << 24) | (1 << 25) | (1 << 26)
+
+    @classmethod
+    def _may_trail(cls, pending) -> bool:
+        return (int(pending.reserved) & ~cls._ROUTING_BITS) == 0
 
     def flush(self) -> None:
         """Collect the timings of the last enqueued query (waits for its scan)."""
@@ -198,12 +206,13 @@ class GpuShardedSearcher:
         check(self._lib.mv_merge_topk_blocks(self.index.device, C.c_void_p(gathered.data_ptr()), self.world, k, k,
                                              C.c_void_p(os_.data_ptr()), C.c_void_p(oi.data_ptr()), C.c_void_p(stream)))
         if self.stats is not None:
-            if not self._trail:
+            prev, self._pending = self._pending, None
+            if prev is not None:  # the query BEFORE this one: its scan ran while this one was being enqueued
+                self.stats.append(self.index.finish_stats(prev))
+            if self._may_trail(pending):
+                self._pending = pending
+            else:  # the record says so itself (not the mode's name): stage accounting -> collect now
                 self.stats.append(self.index.finish_stats(pending))
-            else:
-                prev, self._pending = self._pending, pending
-                if prev is not None:  # the query BEFORE this one: its scan ran while this one was being enqueued
-                    self.stats.append(self.index.finish_stats(prev))
         return os_, oi
 
     def exchange_only(self, k: int):

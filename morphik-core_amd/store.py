@@ -38,15 +38,17 @@ from .payloads import DEFAULT_APP_ID, PayloadStore, is_storage_key, parse_metada
 
 logger = logging.getLogger(__name__)
 
-# what a row's content column holds -- recorded at ingest, never guessed from the text (rows of checkpoints written before
-# round 5 have no such field: row_origin() falls back to what those builds did)
-ROW_INLINE, ROW_OWN_KEY, ROW_CLIENT_KEY = 0, 1, 2
+# what a row's content column holds -- recorded at ingest, never guessed from the text.  Rows of checkpoints written before
+# round 5 carry no such field; those builds treated every key-SHAPED content as a key: this store's own when it has a storage
+# object, else one a remote client uploaded (the owner server flagged it by is_storage_key and handed it back on delete).
+# ROW_LEGACY_KEY keeps exactly that for such rows, in-process and behind the owner server alike.
+ROW_INLINE, ROW_OWN_KEY, ROW_CLIENT_KEY, ROW_LEGACY_KEY = 0, 1, 2, 3
 
 
 def row_origin(row: Sequence[Any]) -> int:
     if len(row) > 5:
         return int(row[5])
-    return ROW_OWN_KEY if is_storage_key(row[2]) else ROW_INLINE
+    return ROW_LEGACY_KEY if is_storage_key(row[2]) else ROW_INLINE
 
 
 def _fsync_dir(path: str) -> None:
@@ -119,6 +121,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         rerank_n: int = 0,
         prune_slab: bool = True,
         fde_module: Any = None,
+        fp32_pages: bool = False,
         **_ignored: Any,
     ):
         self.capacity_pages = int(capacity_pages)
@@ -142,6 +145,11 @@ class MI355XMultiVectorStore(BaseVectorStore):
         # pipeline with its own min(10 k, 75) rule never prunes anyway), and a split tier gets that HBM for exact rows instead: a
         # 1.25 M-page shard keeps ~1 M pages' exact rows on the device and pins the rest
         self.prune_slab = bool(prune_slab)
+        # FastMultiVectorStore keeps every page as an fp32 `.npy` and reranks in fp32 (fast_multivector_store.py:676-681, :736, :774, :553-555).
+        # True: the bf16 slab gets its lo half (MV_WITH_FLOAT_LO: x = hi + lo to 2^-18, the same 4 bytes per element) and the rerank /
+        # the float scan return that fp32 score to ~1e-6 -- for encoders whose output is not bf16 to begin with.  (A bf16 encoder under
+        # autocast -- the reference's own, colpali_embedding_model.py:251-262 -- emits bf16 values: False loses nothing there.)
+        self.fp32_pages = bool(fp32_pages)
         # Bring-your-own FDE ("fde_then_float"): an object with the API of the reference's `fde` extension -- FixedDimensionalEncodingConfig,
         # generate_document_encoding(emb, cfg), generate_query_encoding(q, cfg) (fast_multivector_store.py:325-331, :447-449, :521).  The
         # store then calls IT, on the host as the reference does, for every chunk and every query, imports the document vectors into the
@@ -217,7 +225,8 @@ class MI355XMultiVectorStore(BaseVectorStore):
         # exact-scan answers for corpora whose bf16 slab does not fit the GPU (BASELINE configs[4] with recall 1.0)
         # exact_tier "split": the host tier, with the exact rows of the leading pages in whatever HBM the other slabs leave free
         host = self.mode == "fp8_then_float" or (self.mode == "fde_then_float" and self.exact_tier in ("host", "split"))
-        return dict(with_float=self.mode == "float" or (self.mode == "fde_then_float" and not host), with_binary=self.mode == "binary",
+        with_float = self.mode == "float" or (self.mode == "fde_then_float" and not host)
+        return dict(with_float=with_float, with_binary=self.mode == "binary", **({"with_float_lo": True} if with_float and self.fp32_pages else {}),
                     with_fde=self.mode == "fde_then_float", with_fp8=self.mode in ("float_fp8", "fp8_then_float") or (self.mode == "fde_then_float" and host and self.prune_slab),
                     **({"with_host_exact": True} if host else {}), **({"with_exact_split": True} if host and self.exact_tier == "split" else {}))
 
@@ -632,7 +641,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         out = [r[2] for r in rows]
         if not self._use_external():
             return out, metas  # nothing to fetch: no task, no await (the common case of an in-memory payload table)
-        fetch = [j for j, (r, m) in enumerate(zip(rows, metas)) if row_origin(r) == ROW_OWN_KEY and not (skip_image_content and m.get("is_image"))]
+        fetch = [j for j, (r, m) in enumerate(zip(rows, metas)) if row_origin(r) in (ROW_OWN_KEY, ROW_LEGACY_KEY) and not (skip_image_content and m.get("is_image"))]
         if fetch:
             resolved = await asyncio.gather(*[self._payloads.get(rows[j][2], metas[j]) for j in fetch], return_exceptions=True)
             for j, c in zip(fetch, resolved):
@@ -716,7 +725,8 @@ class MI355XMultiVectorStore(BaseVectorStore):
             for doc_id, chunk_no in chunk_identifiers:
                 page = self._page_of.get((self._nk(doc_id, want), int(chunk_no)))
                 row = self._rows.get(page) if page is not None else None
-                out.append(row is not None and row_origin(row) == ROW_CLIENT_KEY)
+                o = row_origin(row) if row is not None else ROW_INLINE
+                out.append(o == ROW_CLIENT_KEY or (o == ROW_LEGACY_KEY and not self._use_external()))
         return out
 
     def _delete_sync(self, document_id: str, app_id: Optional[str], all_keys: Optional[List[str]] = None) -> List[str]:
@@ -737,6 +747,8 @@ class MI355XMultiVectorStore(BaseVectorStore):
                 if row is not None:
                     self._page_of.pop((key, row[1]), None)
                     o_ = row_origin(row)
+                    if o_ == ROW_LEGACY_KEY:  # pre-round-5 row: this store's key when it has storage, else a client's
+                        o_ = ROW_OWN_KEY if self._use_external() else ROW_CLIENT_KEY
                     if o_ == ROW_CLIENT_KEY and all_keys is not None:
                         all_keys.append(row[2])  # a client's payload: only that client may delete it
                     elif o_ == ROW_OWN_KEY and self._use_external():
@@ -797,7 +809,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
     def _book(self) -> Dict[str, Any]:
         return {
             "version": 3, "mode": self.mode, "capacity_pages": self.capacity_pages, "stride_rows": self.stride_rows,
-            "id_base": self.id_base, "fde_coarse_n": self.fde_coarse_n, "exact_tier": self.exact_tier, "rerank_n": self.rerank_n, "prune_slab": self.prune_slab, "fde_external": self.fde_module is not None, "next_ord": self._next_ord,
+            "id_base": self.id_base, "fde_coarse_n": self.fde_coarse_n, "exact_tier": self.exact_tier, "rerank_n": self.rerank_n, "prune_slab": self.prune_slab, "fp32_pages": self.fp32_pages, "fde_external": self.fde_module is not None, "next_ord": self._next_ord,
             "rows": [[p, r[0], r[1], r[2], r[3], r[4], row_origin(r)] for p, r in self._rows.items()],
             "doc_ord": self._doc_ord, "doc_app": {str(k): v for k, v in self._doc_app.items()},
         }
@@ -898,7 +910,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
             raise RuntimeError(f"{directory}: this checkpoint " + ("holds document FDE vectors of an external encoder: pass fde_module= to load()"
                                                                      if book.get("fde_external") else "was encoded by the library itself: load it without fde_module"))
         self = cls(capacity_pages=book["capacity_pages"], stride_rows=book["stride_rows"], device=device, mode=book["mode"], storage=storage,
-                   id_base=book["id_base"], fde_coarse_n=book.get("fde_coarse_n", 0), exact_tier=book.get("exact_tier", "hbm"), rerank_n=book.get("rerank_n", 0), prune_slab=book.get("prune_slab", True), **kw)
+                   id_base=book["id_base"], fde_coarse_n=book.get("fde_coarse_n", 0), exact_tier=book.get("exact_tier", "hbm"), rerank_n=book.get("rerank_n", 0), prune_slab=book.get("prune_slab", True), **{"fp32_pages": book.get("fp32_pages", False), **kw})
         self._index = cls._load_index(self, directory, book, device)
         self._apply_options(self._index)
         for p, doc, chunk_no, content, meta_json, app, *rest in book["rows"]:

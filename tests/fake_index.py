@@ -6,9 +6,10 @@ from oracle import oracle as orc
 
 
 class OracleIndex:
-    def __init__(self, capacity_pages, stride_rows, device=0, id_base=0, mode="float", fde=None, with_binary=False, **_):
+    def __init__(self, capacity_pages, stride_rows, device=0, id_base=0, mode="float", fde=None, with_binary=False, with_float_lo=False, **_):
         self.capacity, self.stride_rows, self.id_base, self.mode = capacity_pages, stride_rows, id_base, mode
         self.device = device
+        self.float_lo = bool(with_float_lo)  # MV_WITH_FLOAT_LO: fp32 pages keep their low bits (hi + lo); else the slab holds bf16(x)
         if with_binary and mode == "float":
             self.mode = "binary"  # built by ShardedIndex from slab flags
         self.pages, self.ords, self.alive = [], [], []
@@ -73,9 +74,8 @@ class OracleIndex:
             if mode == "binary":
                 out[i] = orc.maxsim_binary(orc.sign_pack(p) if len(p) else np.zeros((0, 16), np.uint8), orc.sign_pack(qf))
             else:
-                pb = orc.bf16_to_f32(orc.f32_to_bf16(p))
-                qb = orc.bf16_to_f32(orc.f32_to_bf16(qf))
-                out[i] = orc.maxsim_f32(qb, pb)
+                # the library's rule: an fp32 query is scored exactly (hi + lo halves); pages are bf16 unless the index keeps the lo slab
+                out[i] = orc.maxsim_f32(qf, self._slab_page(p))
         return out
 
     def query(self, q, k, mode=None, allow=None, want_stats=False, coarse_n=None, q_fde=None):
@@ -101,7 +101,6 @@ class OracleIndex:
         own longest page); pads = explicit pad length per candidate."""
         q = np.asarray(q)
         qf = orc.bf16_to_f32(q) if q.dtype == np.uint16 else np.asarray(q, np.float32)
-        qb = orc.bf16_to_f32(orc.f32_to_bf16(qf))
         cand = [int(i) for i in cand]
         if pads is None:
             if pad_to < 0:
@@ -109,7 +108,10 @@ class OracleIndex:
                 pads = [max(rows[j - j % 128 : j - j % 128 + 128]) for j in range(len(cand))]
             else:
                 pads = [pad_to] * len(cand)
-        return np.array([orc.maxsim_f32(qb, orc.bf16_to_f32(orc.f32_to_bf16(self.pages[i])), int(pd)) for i, pd in zip(cand, pads)], np.float32)
+        return np.array([orc.maxsim_f32(qf, self._slab_page(self.pages[i]), int(pd)) for i, pd in zip(cand, pads)], np.float32)
+
+    def _slab_page(self, p):
+        return p if self.float_lo else orc.bf16_to_f32(orc.f32_to_bf16(p))
 
     def compact(self):
         o2n, pages, ords = [], [], []

@@ -176,7 +176,7 @@ async def scenario_random_ops_against_model(store, seed=0, n_ops=60, mode="float
             k = int(rng.integers(1, 8))
             res = await store.query_similar(q, k=k, doc_ids=filt)
             live = [(key, v) for key, v in model.items() if filt is None or key[0] in filt]
-            qb = bf16r(q)
+            qb = np.asarray(q, np.float32)  # an fp32 query is scored exactly (split hi + lo); only the slab's pages are bf16
             if mode == "binary":
                 want = sorted(((float(orc.maxsim_binary(orc.sign_pack(v[0]), orc.sign_pack(q))), key) for key, v in live), key=lambda t: -t[0])
             else:

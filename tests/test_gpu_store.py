@@ -415,6 +415,38 @@ def test_gpu_sharded_searcher_step_enqueues_without_a_host_wait_and_reports_the_
     ix.close()
 
 
+@pytest.mark.parametrize("mode", ["fp8_then_float", "fde", "float_fp8", "binary"])
+def test_gpu_sharded_searcher_collects_stats_in_every_mode_and_on_an_empty_shard(mode):
+    """whether a deferred stats record may trail by one query is read off the RECORD (stage-accounting bits), not off the
+    mode's name -- fp8_then_float sets them too and used to fail with MV_ERR_STATE on the second query.  And a rank whose shard is
+    empty (k results of nothing: the early return of mv_query_topk_device_async) hands back a record that finishes cleanly."""
+    import torch
+
+    from morphik_core_amd import sharded
+    from morphik_core_amd.index import MvIndex, synth_rows
+
+    kw = dict(with_fp8=mode in ("fp8_then_float", "float_fp8"), with_fde=mode == "fde", with_binary=mode == "binary",
+              with_float=mode in ("fp8_then_float",))
+    ix = MvIndex(capacity_pages=800, stride_rows=64, **kw)
+    stats = []
+    gs = sharded.GpuShardedSearcher(ix, torch.device("cuda", 0), mode, collect_stats=stats)
+    s, i = gs.query(synth_rows(4321, 0, 32), 5)  # empty shard
+    torch.cuda.synchronize()
+    assert (i.cpu().numpy() == -1).all()
+    gs.flush()
+    assert len(stats) == 1 and stats[0].score_kernel_ms == 0 and stats[0].pages_scored == 0
+    ix.fill_synthetic(1234, 0, 800)
+    for j in range(4):
+        q = synth_rows(4321, j, 32)
+        s, i = gs.query(q, 5)
+        torch.cuda.synchronize()
+        ws, wi = ix.query(q, 5, mode=mode)
+        assert i.cpu().numpy().tolist() == wi.tolist() and s.cpu().numpy().tolist() == ws.tolist()
+    gs.flush()
+    assert len(stats) == 5 and all(st.score_kernel_ms > 0 and st.pages_scored == 800 for st in stats[1:])
+    ix.close()
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 @pytest.mark.parametrize("mode", ["float", "binary"])
 def test_random_op_sequences_match_a_brute_force_model_on_gpu(seed, mode):

@@ -615,8 +615,11 @@ def test_content_that_looks_like_another_tenants_key_is_just_text():
     assert sc.run(s2.get_chunks_by_id([("mine", 0)], app_id="app-b"))[0].content == "app-a/doc/0.txt"
     ok, left = sc.run(s2.delete_chunks_returning_keys("mine", app_id="app-b"))
     assert ok and left == []
-    # a checkpoint written before the origin column existed keeps its old reading (key-shaped content = this store's key)
-    assert row_origin(("d", 0, "app/d/0.txt", "{}", "app")) == ROW_OWN_KEY and row_origin(("d", 0, "some text", "{}", "app")) == 0
+    # a checkpoint written before the origin column existed keeps its old reading (key-shaped content = a key: this store's when it
+    # has storage, a remote client's otherwise -- test_checkpoint_without_the_origin_column_keeps_key_shaped_rows_as_keys)
+    from morphik_core_amd.store import ROW_LEGACY_KEY
+
+    assert row_origin(("d", 0, "app/d/0.txt", "{}", "app")) == ROW_LEGACY_KEY and row_origin(("d", 0, "some text", "{}", "app")) == 0
 
 
 def test_owner_with_its_own_storage_hands_a_clients_keys_back_and_never_dereferences_them():
@@ -991,3 +994,51 @@ def test_remote_client_with_its_own_storage_keeps_payloads_off_the_wire():
         assert hit[0].content == ch[0].content
     finally:
         stop2()
+
+
+def test_checkpoint_without_the_origin_column_keeps_key_shaped_rows_as_keys(tmp_path):
+    """rows of checkpoints written before round 5 carry no origin.  Those builds treated key-shaped content as a key --
+    this store's own when it has storage, a remote client's otherwise (flagged on the wire, handed back on delete).  After loading
+    such a checkpoint the same must hold: an owner WITHOUT storage flags the rows as client keys and returns them on delete; an owner
+    WITH storage dereferences and deletes them itself."""
+    import json
+    import os
+
+    from morphik_core_amd.store import ROW_LEGACY_KEY, row_origin
+
+    rng = np.random.default_rng(21)
+    chunks = sc.make_chunks(rng, n_docs=2, chunks_per_doc=2)
+    st = MemStorage()
+    s = MI355XFastMultiVectorStore(capacity_pages=16, stride_rows=32, mode="float", index_factory=OracleIndex, storage=st)
+    assert s.initialize()
+    sc.run(s.store_embeddings(chunks, app_id="t"))
+    assert st.uploads == 4
+    d = str(tmp_path / "old")
+    s.save(d)
+    gdir = MI355XFastMultiVectorStore.checkpoint_path(d)
+    with open(os.path.join(gdir, "store.json")) as f:
+        book = json.load(f)
+    book["rows"] = [r[:6] for r in book["rows"]]  # the pre-round-5 layout: [page, doc, chunk, content, meta, app]
+    assert all(len(r) == 6 for r in book["rows"])
+    with open(os.path.join(gdir, "store.json"), "w") as f:
+        json.dump(book, f)
+    # (a) owner WITHOUT a storage object (the remote client holds the payloads): rows are flagged as keys, keys come back on delete
+    bare = MI355XFastMultiVectorStore.load(d, index_factory=OracleIndex)
+    assert all(row_origin(r) == ROW_LEGACY_KEY for r in bare._rows.values())
+    ids = [(c.document_id, c.chunk_number) for c in chunks]
+    assert bare.content_key_flags(ids, app_id="t") == [True] * 4
+    ok, keys = sc.run(bare.delete_chunks_returning_keys(chunks[0].document_id, app_id="t"))
+    assert ok and len(keys) == 2 and all(k in {kk for _b, kk in st.objects} for k in keys)
+    # (b) owner WITH the storage object: contents are dereferenced, delete removes the objects, nothing is flagged for a client
+    own = MI355XFastMultiVectorStore.load(d, index_factory=OracleIndex, storage=st)
+    assert own.content_key_flags(ids, app_id="t") == [False] * 4
+    hit = sc.run(own.query_similar(chunks[1].embedding, k=1, app_id="t"))
+    want = sc.run(s.query_similar(chunks[1].embedding, k=1, app_id="t"))  # the store that wrote the checkpoint (rows WITH origins)
+    assert hit[0].content == want[0].content and hit[0].content != own._rows[own._page_of[(own._nk(chunks[1].document_id, "t"), chunks[1].chunk_number)]][2]
+    n_before = len(st.objects)
+    assert sc.run(own.delete_chunks_by_document_id(chunks[2].document_id, app_id="t")) is True
+    assert len(st.objects) == n_before - 2
+    # a fresh save writes the origin column (legacy rows keep their marker)
+    own.save(str(tmp_path / "new"))
+    with open(os.path.join(MI355XFastMultiVectorStore.checkpoint_path(str(tmp_path / "new")), "store.json")) as f:
+        assert all(len(r) == 7 and r[6] == ROW_LEGACY_KEY for r in json.load(f)["rows"])
