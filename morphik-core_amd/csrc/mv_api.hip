@@ -1192,14 +1192,20 @@ int mv_index_set_option(mv_index* ix, int option, int64_t value) {
   if (!ix) { set_error("null index"); return MV_ERR_INVALID; }
   std::lock_guard<std::mutex> lk(ix->q_mu);
   switch (option) {
-    case MV_OPT_MAXSIM_VARIANT: ix->maxsim_variant = (int)value; return MV_OK;
+    case MV_OPT_MAXSIM_VARIANT:
+      if (value != -1 && value != 0 && value != 6 && value != 7 && value != 13) { set_error("float kernel variant %lld does not exist (-1 default, 0 direct loads, 6 / 7 the ring with four / one wave per page, 13 transport only; 1-5, 8-12, 14 were removed in round 5)", (long long)value); return MV_ERR_INVALID; }
+      ix->maxsim_variant = (int)value; return MV_OK;
     case MV_OPT_FDE_COARSE_N:
       if (value < 0 || value > kTopkMaxDeviceK) { set_error("FDE_COARSE_N must be 0..%d", kTopkMaxDeviceK); return MV_ERR_INVALID; }
       ix->fde_coarse_n = value; return MV_OK;
     case MV_OPT_FDE_COSINE: ix->fde_cosine = value ? 1 : 0; return MV_OK;
     case MV_OPT_PAD_SEMANTICS: ix->pad_semantics = (int)value; return MV_OK;
-    case MV_OPT_BINARY_VARIANT: ix->binary_variant = (int)value; return MV_OK;
-    case MV_OPT_FDE_SCAN_VARIANT: ix->fde_scan_variant = (int)value; return MV_OK;
+    case MV_OPT_BINARY_VARIANT:
+      if (value != -1 && value != 0 && value != 4) { set_error("sign-bit scan variant %lld does not exist (-1 / 4 FP4 MFMA, 0 popcount; 1-3, 5, 6 were removed in round 5)", (long long)value); return MV_ERR_INVALID; }
+      ix->binary_variant = (int)value; return MV_OK;
+    case MV_OPT_FDE_SCAN_VARIANT:
+      if (value != -1 && value != 0 && value != 5) { set_error("FDE scan variant %lld does not exist (-1 / 5 row quarters on the ring, 0 register form; 1-4 were removed in round 5)", (long long)value); return MV_ERR_INVALID; }
+      ix->fde_scan_variant = (int)value; return MV_OK;
     case MV_OPT_BATCH_VARIANT: ix->batch_variant = (int)value; return MV_OK;
     case MV_OPT_LONG_QUERY_VARIANT: ix->long_query_variant = (int)value; return MV_OK;
     case MV_OPT_FDE_ENCODE_VARIANT: ix->fde_encode_variant = (int)value; return MV_OK;

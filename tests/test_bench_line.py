@@ -67,6 +67,34 @@ def test_emit_prints_detail_first_and_headline_last(capsys, tmp_path, monkeypatc
     d = _check_headline(lines[1])
     assert d["aux_file"] == os.path.join("gpurun_out", "bench_aux.json")
     assert json.load(open(tmp_path / "gpurun_out" / "bench_aux.json"))["aux_paths"] == aux
+    # the secondary kernels' figures ride in the headline: every value is the aux record's own
+    summ = d["aux_summary"]
+    assert summ and len(json.dumps(summ)) <= 900
+    if "full_shard" in aux and "fp8_scan" in aux["full_shard"]:
+        assert summ["fp8_scan_frac"] == aux["full_shard"]["fp8_scan"]["frac_hbm_8TBps"]
+
+
+def test_emit_always_prints_a_headline_even_when_fields_must_be_cut(capsys, tmp_path, monkeypatch):
+    """emit() used to sys.exit when the line reached the limit -- after the whole measurement, leaving NO record.  Now
+    free-text and optional fields move to the detail record step by step; the contract keys and the roofline / cpu_baseline
+    numbers always print."""
+    b = _bench_module()
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r4", "bench_1gpu_1M_pages_r4f.json")))
+    aux = rec.pop("aux_paths")
+    rec["data"] = "synthetic " + "x" * 1500
+    rec["config"]["workload"] = "BASELINE configs[2] " + "y" * 1500
+    rec["cpu_baseline"]["sample"] = "z" * 1500
+    b.emit(rec, aux)
+    lines = capsys.readouterr().out.splitlines()
+    assert len(lines) == 2 and len(lines[1]) < 3000
+    d = json.loads(lines[1])
+    for k in CONTRACT_KEYS:
+        assert k in d, k
+    assert d["value"] == rec["value"] and d["roofline"]["frac"] == rec["roofline"]["frac"] and d["cpu_baseline"]["value"] == rec["cpu_baseline"]["value"]
+    assert d["config"]["workload"].startswith("BASELINE configs[2]") and d["data"].startswith("synthetic")
+    detail = json.loads(lines[0])["bench_detail"]
+    assert detail["cpu_baseline"]["sample"] == "z" * 1500 and detail["config"]["workload"].endswith("y" * 100)
 
 
 def test_serving_progress_lines_are_not_json():
@@ -94,11 +122,20 @@ def test_default_aux_run_last_line_is_the_compact_headline():
     assert d["ms_per_step"] * d["steps"] / 1e3 <= wall
     assert abs(d["value"] - d["config"]["pages_total"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
     earlier = [json.loads(ln) for ln in out_lines[:-1] if ln.startswith("{")]
-    assert len(earlier) == 1 and "metric" not in earlier[0]
-    aux = earlier[0]["aux_paths"]
+    # (1) the crash-fallback headline printed BEFORE the aux child started (same timed-region fields, no aux_summary), (2) the detail record
+    assert len(earlier) == 2 and earlier[0]["value"] == d["value"] and "aux_summary" not in earlier[0] and "metric" not in earlier[1]
+    _check_headline(json.dumps(earlier[0]))
+    aux = earlier[1]["aux_paths"]
     assert "aux_child_error" not in aux, aux
-    for key in ("truth", "batched_float", "full_shard", "exact_shard", "fp8_then_float", "fde_document_encode", "serving"):
+    for key in ("truth", "batched_float", "full_shard", "exact_shard", "fp8_then_float", "fde_document_encode", "serving", "fp32_split_bf16"):
         assert key in aux and "error" not in aux[key], (key, aux.get(key))
+    # the secondary kernels' figures travel in the driver-parsed line itself
+    summ = d["aux_summary"]
+    for key in ("fp8_scan_frac", "sign_bit_frac", "fde_scan_frac", "fde_batch32_frac", "batched_bf16_B16_PF", "fde_request_ms", "fp8_recall_hard",
+                "fp8_then_float_recall", "fp32_split_max_rel_err", "fp32_hi_lo_scan_frac"):
+        assert key in summ, (key, summ)
+    assert len(json.dumps(summ)) <= 900 and summ["fp32_split_max_rel_err"] < 1e-4
+    assert summ["fp8_scan_frac"] == aux["full_shard"]["fp8_scan"]["frac_hbm_8TBps"]
     assert json.load(open(os.path.join(ROOT, "gpurun_out", "bench_aux.json")))["aux_paths"].keys() == aux.keys()
 
 

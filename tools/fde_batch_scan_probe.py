@@ -18,8 +18,8 @@ def main():
     ix.fill_synthetic(1234, 0, n)
     out_dim = ix.fde_config.output_dim
     qs = [synth_rows(4321, j, 32) for j in range(32)]
-    form = sys.argv[2] if len(sys.argv) > 2 else "default"  # MV_OPT_FDE_BATCH_VARIANT: hi_only = 2 (query FDE rounded to bf16), single_tile = 3, half_tiles = 4 (32-page tiles, two workgroups per CU)
-    ix.set_option(L.MV_OPT_FDE_BATCH_VARIANT, {"default": 0, "hi_only": 2, "single_tile": 3, "half_tiles": 4}[form])
+    form = sys.argv[2] if len(sys.argv) > 2 else "default"  # MV_OPT_FDE_BATCH_VARIANT: hi_only = 2 (query FDE rounded to bf16), single_tile = 3, separate_finish = 5 (4, 6-8 were removed in round 5)
+    ix.set_option(L.MV_OPT_FDE_BATCH_VARIANT, {"default": 0, "hi_only": 2, "single_tile": 3, "separate_finish": 5}[form])
     out = {"pages": n, "form": form}
     for B in (16, 32):
         for _ in range(5):
