@@ -70,7 +70,7 @@ enum {
                              beside 190 GB of FDE + e4m3 slabs) keeps ~105 GB of them in HBM and pins ~223 GB: it fits a
                              288 GiB GPU in a container that may pin 300 GiB, and a third of the rerank reads never cross
                              PCIe.  Same answers as an unsplit tier (mv_index_exact_hbm_pages: the pages the HBM part got) */
-  MV_WITH_FLOAT_LO = 64    /* with MV_WITH_FLOAT: a second bf16 slab holding lo = bf16(x - bf16(x)) of every element (+262 144 B / page).
+  MV_WITH_FLOAT_LO = 64,   /* with MV_WITH_FLOAT: a second bf16 slab holding lo = bf16(x - bf16(x)) of every element (+262 144 B / page).
                              The reference keeps its pages as fp32 `.npy` and scores them in fp32 (fast_multivector_store.py:676-681
                              save, :736 / :774 load, :553-555 score); hi + lo is the same 4 bytes per element, reproduces x to
                              2^-18 |x|, and both halves are bf16 MFMA operands: every candidate scorer (mv_score_candidates*, the
@@ -80,6 +80,14 @@ enum {
                              index without the flag.  (Independently of the flag, an MV_F32 QUERY is always split into hi + lo
                              and both halves are scored -- free where the scan is HBM-bound; a bf16-representable query takes
                              the one-term kernels, bit for bit as before.) */
+  MV_LAYOUT_PACKED = 128   /* PACKED page layout for ragged corpora (the reference's real encoder, ColQwen2.5, emits a different token
+                             count per page: core/embedding/colpali_embedding_model.py:47-52): pages lie back to back in whole 16-row
+                             tiles instead of one stride_rows slot each.  A table of row offsets (int64 per page, on the device) replaces
+                             `page * stride_rows` in every kernel; the row-indexed slabs (bf16, its lo half, e4m3, sign bits) share it.
+                             mv_config.capacity_rows sizes those slabs (rows, a multiple of 16; 0 = capacity_pages * stride_rows);
+                             stride_rows remains the longest page the index accepts.  Appends publish as before; a page may be replaced
+                             in place only by one that fits its tiles; mv_index_compact closes the holes of removed pages.  Same scores,
+                             bit for bit, as the fixed-stride layout.  Not combinable with MV_WITH_HOST_EXACT. */
 };
 
 /* fixed_dimensional_encoding.FixedDimensionalEncodingConfig as constructed at
@@ -101,6 +109,7 @@ typedef struct {
   int32_t flags;          /* MV_WITH_* */
   int64_t id_base;        /* global page id of local page 0 (row-sharded corpora: rank r passes r*N/R) */
   mv_fde_config fde;      /* used when flags & MV_WITH_FDE */
+  int64_t capacity_rows;  /* MV_LAYOUT_PACKED: rows the row-indexed slabs hold in all (multiple of 16); 0 = capacity_pages * stride_rows */
 } mv_config;
 
 /* Per-call timing and accounting, filled when a non-NULL pointer is passed. Times are HIP-event
@@ -204,6 +213,9 @@ MV_API void mv_index_destroy(mv_index* ix);
 MV_API int mv_index_set_option(mv_index* ix, int option, int64_t value);
 MV_API int64_t mv_index_size(const mv_index* ix);     /* pages appended so far (including tombstoned) */
 MV_API int64_t mv_index_capacity(const mv_index* ix);
+MV_API int64_t mv_index_rows_used(const mv_index* ix);     /* slab rows taken by the pages appended so far (packed layout: whole 16-row tiles per page;
+                                                              fixed layout: pages * stride_rows) */
+MV_API int64_t mv_index_capacity_rows(const mv_index* ix); /* rows the row-indexed slabs hold */
 MV_API int64_t mv_index_exact_hbm_pages(const mv_index* ix); /* pages of a split exact tier (MV_WITH_EXACT_SPLIT) whose rows live in HBM; 0 otherwise */
 
 /* NON-FINITE VALUES.  A NaN / +-Inf embedding has no defined MaxSim (the reference's torch einsum -> max -> topk propagates NaN
@@ -266,6 +278,11 @@ MV_API int mv_index_read_fp8(mv_index* ix, int64_t page0, int64_t n_pages, void*
  * Without MV_WITH_FLOAT the bf16 image is staged in chunks and only its derivatives (bits / FDE / fp8) are kept. */
 MV_API int mv_index_fill_synthetic(mv_index* ix, uint64_t seed, uint64_t first_unit, int64_t n_pages, int32_t n_rows,
                                    int32_t pages_per_doc);
+/* The same generator with a DIFFERENT row count per page -- the shape of a ColQwen2.5 corpus (dynamic token counts): page i (unit
+ * u = first_unit + i) gets its first n(u) rows, n(u) = min_rows + splitmix64(seed ^ 0x9E3779B97F4A7C15 * (u + 1)) % (max_rows - min_rows + 1)
+ * (oracle/oracle.py: synth_ragged_rows restates it).  Both layouts; max_rows <= stride_rows. */
+MV_API int mv_index_fill_synthetic_ragged(mv_index* ix, uint64_t seed, uint64_t first_unit, int64_t n_pages, int32_t min_rows, int32_t max_rows,
+                                          int32_t pages_per_doc);
 /* Host helper: the same generator for queries (n_rows x 128 bf16 to a host buffer, computed on the GPU). */
 MV_API int mv_synth_rows(int device, uint64_t seed, uint64_t unit, int32_t n_rows, void* out_bf16);
 

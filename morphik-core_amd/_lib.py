@@ -52,6 +52,7 @@ class ConfigC(C.Structure):
         ("flags", C.c_int32),
         ("id_base", C.c_int64),
         ("fde", FdeConfigC),
+        ("capacity_rows", C.c_int64),  # MV_LAYOUT_PACKED: rows of the row-indexed slabs (0 = capacity_pages * stride_rows)
     ]
 
 
@@ -75,6 +76,7 @@ MV_F32, MV_BF16 = 0, 1
 MV_MODE_FLOAT, MV_MODE_BINARY, MV_MODE_FDE_THEN_FLOAT, MV_MODE_FDE_ONLY, MV_MODE_FLOAT_FP8, MV_MODE_FP8_THEN_FLOAT = 0, 1, 2, 3, 4, 5
 MV_WITH_FLOAT, MV_WITH_BINARY, MV_WITH_FDE, MV_WITH_FP8, MV_WITH_HOST_EXACT, MV_WITH_EXACT_SPLIT = 1, 2, 4, 8, 16, 32
 MV_WITH_FLOAT_LO = 64
+MV_LAYOUT_PACKED = 128
 MV_OPT_MAXSIM_VARIANT, MV_OPT_FDE_COARSE_N, MV_OPT_FDE_COSINE, MV_OPT_PAD_SEMANTICS, MV_OPT_BINARY_VARIANT, MV_OPT_FDE_SCAN_VARIANT = 1, 2, 3, 4, 5, 6
 MV_OPT_BATCH_VARIANT = 7
 MV_OPT_FDE_ENCODE_VARIANT = 8
@@ -100,8 +102,8 @@ MV_ABI_VERSION = 7  # include/mvmaxsim.h: the header revision this binding's arg
 
 EXPORTS = [
     "mv_abi_version", "mv_last_error", "mv_version", "mv_device_count", "mv_host_pin_budget_bytes", "mv_index_exact_hbm_pages", "mv_index_create", "mv_index_destroy", "mv_index_set_option",
-    "mv_index_size", "mv_index_capacity", "mv_index_add", "mv_index_add_device", "mv_index_add_bits", "mv_index_remove_doc",
-    "mv_index_remove_page", "mv_index_compact", "mv_index_read_pages", "mv_index_read_pages_f32", "mv_index_write_rows", "mv_index_replace_page", "mv_index_read_fp8", "mv_index_fill_synthetic", "mv_synth_rows",
+    "mv_index_size", "mv_index_capacity", "mv_index_rows_used", "mv_index_capacity_rows", "mv_index_add", "mv_index_add_device", "mv_index_add_bits", "mv_index_remove_doc",
+    "mv_index_remove_page", "mv_index_compact", "mv_index_read_pages", "mv_index_read_pages_f32", "mv_index_write_rows", "mv_index_replace_page", "mv_index_read_fp8", "mv_index_fill_synthetic", "mv_index_fill_synthetic_ragged", "mv_synth_rows",
     "mv_query_topk", "mv_query_topk_device", "mv_query_topk_device_async", "mv_query_stats_finish", "mv_query_topk_batch", "mv_merge_topk", "mv_topk_block_bytes", "mv_merge_topk_blocks", "mv_score_all", "mv_score_candidates", "mv_score_candidates_pads", "mv_index_page_rows",
     "mv_two_stage_coarse_device", "mv_two_stage_mid_device", "mv_two_stage_rerank_device", "mv_index_rerank_plan", "mv_comm_create", "mv_comm_destroy", "mv_comm_attach", "mv_comm_transport",
     "mv_comm_query_topk", "mv_comm_query_topk_batch", "mv_sign_pack", "mv_hamming_batch",
@@ -165,6 +167,11 @@ def lib() -> C.CDLL:
         L.mv_index_size.restype = i64
         L.mv_index_capacity.argtypes = [vp]
         L.mv_index_capacity.restype = i64
+        L.mv_index_rows_used.argtypes = [vp]
+        L.mv_index_rows_used.restype = i64
+        L.mv_index_capacity_rows.argtypes = [vp]
+        L.mv_index_capacity_rows.restype = i64
+        L.mv_index_fill_synthetic_ragged.argtypes = [vp, u64, u64, i64, i32, i32, i32]
         L.mv_index_add.argtypes = [vp, vp, C.c_int, vp, i64, vp, C.POINTER(i64)]
         L.mv_index_add_device.argtypes = [vp, vp, C.c_int, vp, i64, vp, C.POINTER(i64)]
         L.mv_index_add_bits.argtypes = [vp, vp, vp, i64, vp, C.POINTER(i64)]

@@ -291,6 +291,7 @@ int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_w
       b.allow = d_allow; b.n_allow_bits = n_allow_words * 32; b.allow_stride_bits = 0;
       b.q = ix->d_bq; b.scores = pass == 0 ? d_out : ix->d_scores2; b.n = n_items; b.score_stride = n_items;
       b.stride = ix->cfg.stride_rows; b.n_queries = 1; b.rows_per_query = rows; b.variant = ix->batch_variant >= 0 ? ix->batch_variant : 0;
+      b.row_off = ix->d_row_off;
       int rc = launch_maxsim_batch(b, ix->stream);
       if (rc) return rc;
       ++*launches;
@@ -308,6 +309,7 @@ int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_w
     MaxsimArgs a{};
     a.qlo = lo_q ? qlo_base + (size_t)done * kDim : nullptr;
     a.slab_lo = slab_lo;
+    a.row_off = ix->d_row_off;  // packed layout (never together with a host exact tier: slab_override then is the slab itself)
     a.slab = slab_override ? slab_override : ix->slab;  // the exact tier of FP8_THEN_FLOAT may be pinned host memory mapped into the device
     a.n_rows = ragged ? ix->d_n_rows : nullptr;
     a.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
@@ -348,6 +350,7 @@ int fp8_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_wor
   a.allow = d_allow; a.n_allow_bits = n_allow_words * 32; a.cand = d_cand;
   a.qhi = ix->d_q8hi; a.qlo = ix->d_q8lo; a.qfac = ix->d_q8fac; a.n_q = n_q;
   a.scores = d_out; a.n = n_items; a.stride = ix->cfg.stride_rows; a.pad_to = pad_to; a.pad_items = d_pad_items;
+  a.row_off = ix->d_row_off;
   int rc = launch_maxsim_fp8(a, ix->stream);
   if (rc) return rc;
   *launches += (((n_q + 15) / 16) * 16 + 63) / 64;
@@ -667,7 +670,7 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
     b.allow = d_scan_cand ? nullptr : d_allow; b.n_allow_bits = n_words * 32;
     b.qbits = ix->d_qbits; b.qpop_rw = ix->d_qpop; b.qpop = ix->d_qpop; b.scores = ix->d_scores;
     b.n = n_scan; b.cand = d_scan_cand;
-    b.stride = ix->cfg.stride_rows; b.n_q = n_q;
+    b.stride = ix->cfg.stride_rows; b.n_q = n_q; b.row_off = ix->d_row_off;
     if (n_scan > 0) {
       rc = launch_maxsim_binary(b, ix->binary_variant, ix->stream);
       if (rc) return rc;
@@ -808,6 +811,7 @@ int add_pages_common(mv_index* ix, const void* d_src, int dtype, const int32_t* 
                      const int32_t* doc_ordinals, int64_t total_rows, int64_t first) {
   hipStream_t ws = ix->w_stream;
   const int32_t stride = ix->cfg.stride_rows;
+  const bool packed = ix->packed;
   std::vector<int64_t> off((size_t)n_pages + 1);
   off[0] = 0;
   for (int64_t i = 0; i < n_pages; ++i) off[i + 1] = off[i] + n_rows[i];
@@ -815,9 +819,15 @@ int add_pages_common(mv_index* ix, const void* d_src, int dtype, const int32_t* 
   for (int64_t i = 0; i < n_pages; ++i) {
     ix->h_n_rows[first + i] = n_rows[i];
     ix->h_doc_ord[first + i] = doc_ordinals ? doc_ordinals[i] : 0;
+    if (packed) ix->h_row_off[(size_t)(first + i + 1)] = ix->h_row_off[(size_t)(first + i)] + ((int64_t)n_rows[i] + 15) / 16 * 16;  // whole 16-row tiles
   }
   MV_HIP(hipMemcpyAsync(ix->d_n_rows + first, ix->h_n_rows.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice, ws));
   MV_HIP(hipMemcpyAsync(ix->d_doc_ord + first, ix->h_doc_ord.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice, ws));
+  if (packed) MV_HIP(hipMemcpyAsync(ix->d_row_off + first, ix->h_row_off.data() + first, (size_t)(n_pages + 1) * 8, hipMemcpyHostToDevice, ws));
+  // the batch's rows in the row-indexed slabs: [row0, row0 + slot_rows) -- one stride slot per page, or (packed) whole tiles back to back
+  const int64_t row0 = page_row0(ix, first);
+  const int64_t slot_rows = rows_in_use(ix, first + n_pages) - row0;
+  const int64_t* d_ro = packed ? ix->d_row_off + first : nullptr;
   const bool f32_bits = (ix->cfg.flags & MV_WITH_BINARY) && dtype == MV_F32;
   const size_t off_bytes = ((off.size() * 8 + 255) / 256) * 256;
   int rc = w_reserve(&ix->w_aux, &ix->w_aux_bytes, off_bytes + (f32_bits ? (size_t)std::max<int64_t>(total_rows, 1) * kSignBytes : 0));
@@ -825,35 +835,39 @@ int add_pages_common(mv_index* ix, const void* d_src, int dtype, const int32_t* 
   int64_t* d_off = (int64_t*)ix->w_aux;
   uint8_t* tmp_bits = (uint8_t*)ix->w_aux + off_bytes;
   MV_HIP(hipMemcpyAsync(d_off, off.data(), off.size() * 8, hipMemcpyHostToDevice, ws));
-  uint16_t* slab_dst = nullptr;
+  // `img`: where the kernels below find the batch's fixed-stride / packed bf16 image.  Fixed layout: the address of page `first`'s
+  // slot (pages are indexed locally).  Packed layout: the base the row offsets count from -- the slab itself, or, for an index that
+  // keeps no float slab, the staging buffer shifted back by row0 rows (the offsets are absolute; only rows >= row0 are touched).
+  uint16_t* rows_ptr = nullptr;  // the batch's first row
   if (ix->cfg.flags & MV_WITH_FLOAT) {
-    slab_dst = ix->slab + (size_t)first * stride * kDim;
+    rows_ptr = ix->slab + (size_t)row0 * kDim;
   } else {
-    // no float slab kept: still need fixed-stride bf16 rows as the source of the other slabs
-    rc = w_reserve(&ix->w_tmp, &ix->w_tmp_bytes, (size_t)n_pages * stride * kRowBytes);
+    // no float slab kept: still need the bf16 rows as the source of the other slabs
+    rc = w_reserve(&ix->w_tmp, &ix->w_tmp_bytes, (size_t)std::max<int64_t>(slot_rows, 1) * kRowBytes);
     if (rc) return rc;
-    slab_dst = (uint16_t*)ix->w_tmp;
+    rows_ptr = (uint16_t*)ix->w_tmp;
   }
+  uint16_t* img = packed ? reinterpret_cast<uint16_t*>(reinterpret_cast<uintptr_t>(rows_ptr) - (uintptr_t)row0 * kRowBytes) : rows_ptr;
+  uint16_t* lo_img = ix->slab_lo ? (packed ? ix->slab_lo : ix->slab_lo + (size_t)row0 * kDim) : nullptr;  // lo = bf16(x - bf16(x)) of fp32 rows, zeros for bf16 rows
   // NaN / Inf rows: an index with any float-derived slab refuses them (their MaxSim is undefined: torch's einsum -> max -> topk
   // would rank a NaN page first); a sign-bit-only index takes them -- its quantiser defines every input (binary_ops.rs:81-136)
-  const bool check_finite = (ix->cfg.flags & ~MV_WITH_BINARY) != 0;
+  const bool check_finite = (ix->cfg.flags & ~(MV_WITH_BINARY | MV_LAYOUT_PACKED)) != 0;
   if (check_finite) MV_HIP(hipMemsetAsync(ix->d_w_flag, 0, 4, ws));
-  rc = launch_scatter_rows(d_src, dtype, d_off, n_pages, stride, slab_dst, ws, check_finite ? ix->d_w_flag : nullptr,
-                           ix->slab_lo ? ix->slab_lo + (size_t)first * stride * kDim : nullptr);  // lo = bf16(x - bf16(x)) of fp32 rows, zeros for bf16 rows
-  if (!rc) rc = xt_store_from_device(ix, slab_dst, first, n_pages, ws);  // exact host tier (pinned host memory, or split with HBM): the fixed-stride bf16 image, slot for slot
+  rc = launch_scatter_rows(d_src, dtype, d_off, n_pages, stride, img, ws, check_finite ? ix->d_w_flag : nullptr, lo_img, d_ro);
+  if (!rc) rc = xt_store_from_device(ix, rows_ptr, first, n_pages, ws);  // exact host tier (pinned host memory, or split with HBM; fixed layout only): the bf16 image, slot for slot
   if (!rc && (ix->cfg.flags & MV_WITH_BINARY)) {
     // sign bits come from the bf16 image: bf16 RNE preserves sign and zero-ness of every fp32 value
     // that is not an fp32 subnormal rounding to zero; fp32 inputs are packed from the fp32 rows below.
-    uint8_t* bdst = ix->bits + (size_t)first * stride * kSignBytes;
+    uint8_t* bdst = ix->bits + (size_t)row0 * kSignBytes;
     if (dtype == MV_BF16) {
-      rc = launch_sign_pack_bf16_rows(slab_dst, n_pages * (int64_t)stride, bdst, ws);
+      rc = launch_sign_pack_bf16_rows(rows_ptr, slot_rows, bdst, ws);
     } else {
       // exact fp32 rule (v > 0.0f): pack the ragged fp32 rows, then scatter 16-byte rows
       rc = launch_sign_pack_f32((const float*)d_src, total_rows, kDim, tmp_bits, ws);
       if (!rc) {
-        (void)hipMemsetAsync(bdst, 0, (size_t)n_pages * stride * kSignBytes, ws);
+        (void)hipMemsetAsync(bdst, 0, (size_t)slot_rows * kSignBytes, ws);
         for (int64_t i = 0; i < n_pages && !rc; ++i)
-          if (n_rows[i] > 0 && hipMemcpyAsync(bdst + (size_t)i * stride * kSignBytes, tmp_bits + (size_t)off[i] * kSignBytes,
+          if (n_rows[i] > 0 && hipMemcpyAsync(bdst + (size_t)(page_row0(ix, first + i) - row0) * kSignBytes, tmp_bits + (size_t)off[i] * kSignBytes,
                                               (size_t)n_rows[i] * kSignBytes, hipMemcpyDeviceToDevice, ws) != hipSuccess) {
             rc = MV_ERR_HIP; set_error("D2D of sign rows failed");
           }
@@ -866,7 +880,7 @@ int add_pages_common(mv_index* ix, const void* d_src, int dtype, const int32_t* 
     if (dtype == MV_F32) {
       e.x_f32 = (const float*)d_src; e.row_offsets = d_off;
     } else {
-      e.x_bf16 = slab_dst; e.n_rows = ix->d_n_rows + first; e.stride = stride;
+      e.x_bf16 = img; e.x_row_off = d_ro; e.n_rows = ix->d_n_rows + first; e.stride = stride;
     }
     e.n_pages = n_pages; e.is_query = 0;
     e.out_bf16 = ix->fde + (size_t)first * ix->fde_t.out_dim;
@@ -874,8 +888,8 @@ int add_pages_common(mv_index* ix, const void* d_src, int dtype, const int32_t* 
     rc = launch_fde_encode(ix->fde_t, e, ws);
   }
   if (!rc && (ix->cfg.flags & MV_WITH_FP8))
-    rc = launch_quantize_pages_fp8(slab_dst, ix->d_n_rows + first, stride, n_pages, ix->slab8 + (size_t)first * stride * kDim,
-                                   ix->inv_scale8 + first, ws);
+    rc = launch_quantize_pages_fp8(img, ix->d_n_rows + first, stride, n_pages, packed ? ix->slab8 : ix->slab8 + (size_t)row0 * kDim,
+                                   ix->inv_scale8 + first, ws, d_ro);
   hipError_t e = hipStreamSynchronize(ws);  // the staging buffers are reused by the next chunk; the caller publishes after this
   if (rc) return rc;
   if (e != hipSuccess) return hip_fail(e, "ingest", __FILE__, __LINE__);
@@ -914,13 +928,18 @@ int validate_add(mv_index* ix, const void* emb, int dtype, const int32_t* n_rows
     set_error("slab full: %lld + %lld > capacity %lld", (long long)size, (long long)n_pages, (long long)ix->cfg.capacity_pages);
     return MV_ERR_CAPACITY;
   }
-  int64_t t = 0;
+  int64_t t = 0, slots = 0;
   for (int64_t i = 0; i < n_pages; ++i) {
     if (n_rows[i] < 0 || n_rows[i] > ix->cfg.stride_rows) {
       set_error("page %lld has %d rows; stride_rows is %d", (long long)i, n_rows[i], ix->cfg.stride_rows);
       return MV_ERR_INVALID;
     }
     t += n_rows[i];
+    slots += ((int64_t)n_rows[i] + 15) / 16 * 16;
+  }
+  if (ix->packed && rows_in_use(ix, size) + slots > ix->cap_rows) {
+    set_error("slab full: %lld rows in use + %lld > capacity_rows %lld", (long long)rows_in_use(ix, size), (long long)slots, (long long)ix->cap_rows);
+    return MV_ERR_CAPACITY;
   }
   *total_rows = t;
   return MV_OK;
@@ -1033,7 +1052,7 @@ void mv_index_destroy(mv_index* ix) {
   DeviceGuard g(ix->cfg.device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
   if (ix->w_stream) (void)hipStreamSynchronize(ix->w_stream);
-  void* ptrs[] = {ix->slab_lo, ix->d_qlo, ix->d_bqlo, ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
+  void* ptrs[] = {ix->d_row_off, ix->slab_lo, ix->d_qlo, ix->d_bqlo, ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
                   ix->d_topk_ws, ix->d_q, ix->d_qf32, ix->d_qbits, ix->d_qpop, ix->d_qfde, ix->d_qoff, ix->d_allow, ix->d_out_s,
                   ix->d_out_id, ix->d_cand, ix->d_cand_scores, ix->d_bqf32, ix->d_bqfde, ix->d_bqimage, ix->d_btopk_ws, ix->d_bsel_s,
                   ix->d_bsel_id, ix->d_bcand, ix->d_bcand_pads, ix->d_bcand_scores, ix->d_bout_s, ix->d_bout_id, ix->d_bq8hi, ix->d_bq8lo, ix->d_bq8fac};
@@ -1064,6 +1083,12 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   if (cfg->stride_rows < 16 || cfg->stride_rows % 16) { set_error("stride_rows must be a positive multiple of 16 (got %d)", cfg->stride_rows); return MV_ERR_INVALID; }
   if (cfg->capacity_pages < 1 || cfg->capacity_pages > 0x7fffffffLL) { set_error("capacity_pages out of range"); return MV_ERR_INVALID; }
   if (!(cfg->flags & (MV_WITH_FLOAT | MV_WITH_BINARY | MV_WITH_FDE | MV_WITH_FP8))) { set_error("flags select no slab"); return MV_ERR_INVALID; }
+  if (cfg->flags & MV_LAYOUT_PACKED) {
+    if (cfg->flags & MV_WITH_HOST_EXACT) { set_error("MV_LAYOUT_PACKED cannot be combined with MV_WITH_HOST_EXACT (the host exact tier keeps fixed-stride pages)"); return MV_ERR_INVALID; }
+    if (cfg->capacity_rows < 0 || cfg->capacity_rows % 16 || (cfg->capacity_rows > 0 && cfg->capacity_rows < cfg->stride_rows)) {
+      set_error("capacity_rows must be 0 or a multiple of 16 >= stride_rows (got %lld)", (long long)cfg->capacity_rows); return MV_ERR_INVALID;
+    }
+  }
   if ((cfg->flags & MV_WITH_FLOAT_LO) && !(cfg->flags & MV_WITH_FLOAT)) { set_error("MV_WITH_FLOAT_LO is the lo half of the bf16 slab: it needs MV_WITH_FLOAT"); return MV_ERR_INVALID; }
   if ((cfg->flags & MV_WITH_EXACT_SPLIT) && (!(cfg->flags & MV_WITH_HOST_EXACT) || (cfg->flags & MV_WITH_FLOAT))) {
     set_error("MV_WITH_EXACT_SPLIT splits the host exact tier: it needs MV_WITH_HOST_EXACT and no MV_WITH_FLOAT"); return MV_ERR_INVALID;
@@ -1076,7 +1101,10 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   if (!ix) { set_error("host allocation failed"); return MV_ERR_NOMEM; }
   ix->cfg = *cfg;
   const int64_t cap = cfg->capacity_pages;
-  const size_t rows = (size_t)cap * cfg->stride_rows;
+  ix->packed = (cfg->flags & MV_LAYOUT_PACKED) != 0;
+  ix->cap_rows = (ix->packed && cfg->capacity_rows > 0) ? cfg->capacity_rows : cap * (int64_t)cfg->stride_rows;
+  ix->cfg.capacity_rows = ix->cap_rows;
+  const size_t rows = (size_t)ix->cap_rows;  // rows of every row-indexed slab
   int rc = MV_OK;
   auto alloc = [&](void** p, size_t bytes, const char* what) {
     if (rc) return;
@@ -1122,6 +1150,11 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
     alloc((void**)&ix->fde_inv_norm, (size_t)cap * 4, "FDE norms");
     alloc((void**)&ix->d_qfde, (size_t)std::max<int64_t>(ix->fde_t.out_dim, 1) * 4, "query FDE");
   }
+  if (ix->packed) {
+    alloc((void**)&ix->d_row_off, (size_t)(cap + 1) * 8, "page row offsets");
+    if (!rc && hipMemset(ix->d_row_off, 0, (size_t)(cap + 1) * 8) != hipSuccess) { set_error("hipMemset of the row offsets failed"); rc = MV_ERR_HIP; }
+    ix->ragged.store(true);  // the kernels always take the per-page row counts: a slot is whole tiles, not stride_rows
+  }
   alloc((void**)&ix->d_n_rows, (size_t)cap * 4, "row counts");
   alloc((void**)&ix->d_doc_ord, (size_t)cap * 4, "doc ordinals");
   alloc((void**)&ix->d_scores, (size_t)cap * 4, "scores");
@@ -1141,6 +1174,7 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   if (!rc) {
     ix->h_n_rows.assign((size_t)cap, 0);
     ix->h_doc_ord.assign((size_t)cap, -1);
+    if (ix->packed) ix->h_row_off.assign((size_t)cap + 1, 0);
     rc = ensure_query_cap(ix, 64);
   }
   if (!rc && (cfg->flags & MV_WITH_HOST_EXACT)) {
@@ -1229,6 +1263,12 @@ int mv_index_set_option(mv_index* ix, int option, int64_t value) {
 
 int64_t mv_index_size(const mv_index* ix) { return ix ? ix->size.load(std::memory_order_acquire) : 0; }
 int64_t mv_index_capacity(const mv_index* ix) { return ix ? ix->cfg.capacity_pages : 0; }
+int64_t mv_index_capacity_rows(const mv_index* ix) { return ix ? ix->cap_rows : 0; }
+int64_t mv_index_rows_used(const mv_index* ix) {
+  if (!ix) return 0;
+  std::lock_guard<std::mutex> lk(const_cast<mv_index*>(ix)->w_mu);  // row_off[size] belongs to the writers
+  return rows_in_use(ix, ix->size.load());
+}
 
 int mv_index_add_device(mv_index* ix, const void* d_emb, int dtype, const int32_t* n_rows, int64_t n_pages,
                         const int32_t* doc_ordinals, int64_t* out_first_page) {
@@ -1281,13 +1321,17 @@ int mv_index_add(mv_index* ix, const void* emb, int dtype, const int32_t* n_rows
   return MV_OK;
 }
 
+static inline int64_t page_slot_rows_of(const mv_index* ix, int64_t /*page*/, int32_t n_rows) {
+  return ix->packed ? ((int64_t)n_rows + 15) / 16 * 16 : ix->cfg.stride_rows;
+}
+
 // Append pages given only their packed sign rows (16 B per row, MSB first): the import path for an existing
 // MultiVectorStore table (BIT(128)[] column, core/vector_store/multi_vector_store.py:248) -- floats cannot be
 // recovered from it, so the index must carry the sign-bit slab only.
 int mv_index_add_bits(mv_index* ix, const uint8_t* bits, const int32_t* n_rows, int64_t n_pages, const int32_t* doc_ordinals,
                       int64_t* out_first_page) {
   if (!ix || (!bits && n_pages > 0) || (!n_rows && n_pages > 0) || n_pages < 0) { set_error("mv_index_add_bits: null argument"); return MV_ERR_INVALID; }
-  if (ix->cfg.flags != MV_WITH_BINARY) { set_error("mv_index_add_bits needs an index with MV_WITH_BINARY only (floats are not recoverable from sign bits)"); return MV_ERR_STATE; }
+  if ((ix->cfg.flags & ~MV_LAYOUT_PACKED) != MV_WITH_BINARY) { set_error("mv_index_add_bits needs an index with MV_WITH_BINARY only (floats are not recoverable from sign bits)"); return MV_ERR_STATE; }
   std::lock_guard<std::mutex> lk(ix->w_mu);
   if (ix->size.load() + n_pages > ix->cfg.capacity_pages) { set_error("slab full"); return MV_ERR_CAPACITY; }
   const int32_t stride = ix->cfg.stride_rows;
@@ -1295,16 +1339,24 @@ int mv_index_add_bits(mv_index* ix, const uint8_t* bits, const int32_t* n_rows, 
     if (n_rows[i] < 0 || n_rows[i] > stride) { set_error("page %lld has %d rows; stride_rows is %d", (long long)i, n_rows[i], stride); return MV_ERR_INVALID; }
   DeviceGuard g(ix->cfg.device);
   const int64_t first = ix->size.load();
-  std::vector<uint8_t> img((size_t)std::min<int64_t>(n_pages, 4096) * stride * kSignBytes);
+  if (ix->packed) {
+    int64_t slots = 0;
+    for (int64_t i = 0; i < n_pages; ++i) slots += ((int64_t)n_rows[i] + 15) / 16 * 16;
+    if (rows_in_use(ix, first) + slots > ix->cap_rows) { set_error("slab full (capacity_rows)"); return MV_ERR_CAPACITY; }
+    for (int64_t i = 0; i < n_pages; ++i) ix->h_row_off[(size_t)(first + i + 1)] = ix->h_row_off[(size_t)(first + i)] + ((int64_t)n_rows[i] + 15) / 16 * 16;
+    MV_HIP(hipMemcpy(ix->d_row_off + first, ix->h_row_off.data() + first, (size_t)(n_pages + 1) * 8, hipMemcpyHostToDevice));
+  }
+  std::vector<uint8_t> img;
   int64_t src_row = 0;
-  for (int64_t p0 = 0; p0 < n_pages; p0 += 4096) {  // fixed-stride image of up to 4096 pages per copy
+  for (int64_t p0 = 0; p0 < n_pages; p0 += 4096) {  // the slot image (stride slots / whole tiles back to back) of up to 4096 pages per copy
     const int64_t c = std::min<int64_t>(4096, n_pages - p0);
-    std::fill(img.begin(), img.begin() + (size_t)c * stride * kSignBytes, (uint8_t)0);
+    const int64_t r0 = page_row0(ix, first + p0), rows = page_row0(ix, first + p0 + c - 1) + page_slot_rows_of(ix, first + p0 + c - 1, n_rows[p0 + c - 1]) - r0;
+    img.assign((size_t)rows * kSignBytes, (uint8_t)0);
     for (int64_t i = 0; i < c; ++i) {
-      memcpy(img.data() + (size_t)i * stride * kSignBytes, bits + (size_t)src_row * kSignBytes, (size_t)n_rows[p0 + i] * kSignBytes);
+      memcpy(img.data() + (size_t)(page_row0(ix, first + p0 + i) - r0) * kSignBytes, bits + (size_t)src_row * kSignBytes, (size_t)n_rows[p0 + i] * kSignBytes);
       src_row += n_rows[p0 + i];
     }
-    MV_HIP(hipMemcpy(ix->bits + (size_t)(first + p0) * stride * kSignBytes, img.data(), (size_t)c * stride * kSignBytes, hipMemcpyHostToDevice));
+    MV_HIP(hipMemcpy(ix->bits + (size_t)r0 * kSignBytes, img.data(), (size_t)rows * kSignBytes, hipMemcpyHostToDevice));
   }
   for (int64_t i = 0; i < n_pages; ++i) {
     ix->h_n_rows[first + i] = n_rows[i];
@@ -1353,6 +1405,20 @@ int mv_index_remove_doc(mv_index* ix, int32_t doc_ordinal, int64_t* out_n) {
   return MV_OK;
 }
 
+// Packed layout -> the fixed-stride image the readers hand out ([n][stride_rows] rows of row_bytes, zero rows behind a page's slot):
+// one D2H copy of the pages' contiguous rows, then a host scatter.  q_mu held.
+static int read_packed_pages(mv_index* ix, const void* slab, size_t row_bytes, int64_t page0, int64_t n_pages, void* out) {
+  if (n_pages <= 0) return MV_OK;
+  const int64_t r0 = page_row0(ix, page0), r1 = page_row0(ix, page0 + n_pages - 1) + page_slot_rows(ix, page0 + n_pages - 1);
+  std::vector<char> tmp((size_t)(r1 - r0) * row_bytes);
+  MV_HIP(hipMemcpy(tmp.data(), (const char*)slab + (size_t)r0 * row_bytes, tmp.size(), hipMemcpyDeviceToHost));
+  const size_t pb = (size_t)ix->cfg.stride_rows * row_bytes;
+  memset(out, 0, (size_t)n_pages * pb);
+  for (int64_t i = 0; i < n_pages; ++i)
+    memcpy((char*)out + (size_t)i * pb, tmp.data() + (size_t)(page_row0(ix, page0 + i) - r0) * row_bytes, (size_t)page_slot_rows(ix, page0 + i) * row_bytes);
+  return MV_OK;
+}
+
 int mv_index_read_pages(mv_index* ix, int64_t page0, int64_t n_pages, void* out_bf16) {
   if (!ix || !out_bf16 || page0 < 0 || n_pages < 0 || page0 + n_pages > ix->size.load()) { set_error("read_pages: range"); return MV_ERR_INVALID; }
   if (!(ix->cfg.flags & (MV_WITH_FLOAT | MV_WITH_HOST_EXACT))) { set_error("index has no float slab"); return MV_ERR_STATE; }
@@ -1360,6 +1426,7 @@ int mv_index_read_pages(mv_index* ix, int64_t page0, int64_t n_pages, void* out_
   DeviceGuard g(ix->cfg.device);
   const size_t pb = (size_t)ix->cfg.stride_rows * kRowBytes;
   if (!(ix->cfg.flags & MV_WITH_FLOAT)) return xt_read_pages(ix, page0, n_pages, out_bf16);  // exact host tier
+  if (ix->packed) return read_packed_pages(ix, ix->slab, kRowBytes, page0, n_pages, out_bf16);
   MV_HIP(hipMemcpy(out_bf16, (const char*)ix->slab + (size_t)page0 * pb, (size_t)n_pages * pb, hipMemcpyDeviceToHost));
   return MV_OK;
 }
@@ -1379,7 +1446,8 @@ int mv_index_read_pages_f32(mv_index* ix, int64_t page0, int64_t n_pages, float*
       lo.resize((size_t)c * pe);
       std::lock_guard<std::mutex> lk(ix->q_mu);
       DeviceGuard g(ix->cfg.device);
-      MV_HIP(hipMemcpy(lo.data(), ix->slab_lo + (size_t)(page0 + done) * pe, (size_t)c * pe * 2, hipMemcpyDeviceToHost));
+      if (ix->packed) { if (int rc = read_packed_pages(ix, ix->slab_lo, kRowBytes, page0 + done, c, lo.data())) return rc; }
+      else MV_HIP(hipMemcpy(lo.data(), ix->slab_lo + (size_t)(page0 + done) * pe, (size_t)c * pe * 2, hipMemcpyDeviceToHost));
       for (size_t i = 0; i < (size_t)c * pe; ++i) o[i] += host_bf16_to_f32(lo[i]);  // exact: both halves came from ONE fp32 value
     }
   }
@@ -1388,30 +1456,35 @@ int mv_index_read_pages_f32(mv_index* ix, int64_t page0, int64_t n_pages, float*
 
 int mv_index_write_rows(mv_index* ix, int64_t page, int32_t row0, int32_t n, const void* bf16_rows) {
   if (!ix || !bf16_rows || page < 0 || page >= ix->size.load() || row0 < 0 || n < 0 || row0 + n > ix->cfg.stride_rows) { set_error("write_rows: range"); return MV_ERR_INVALID; }
+  if (ix->packed && row0 + n > page_slot_rows(ix, page)) { set_error("write_rows: rows %d..%d lie outside the page's %d-row slot (packed layout)", row0, row0 + n, page_slot_rows(ix, page)); return MV_ERR_INVALID; }
   if (!(ix->cfg.flags & (MV_WITH_FLOAT | MV_WITH_HOST_EXACT))) { set_error("index has no float slab"); return MV_ERR_STATE; }
   if (!host_rows_finite(bf16_rows, MV_BF16, (size_t)n * kDim)) { set_error("write_rows: a row holds a NaN / Inf"); return MV_ERR_INVALID; }
   ExclusiveLock lk(ix);
   DeviceGuard g(ix->cfg.device);
   if (int rc = xt_store_rows_from_host(ix, page, row0, n, bf16_rows, /*zero_rest=*/false)) return rc;
   if (!(ix->cfg.flags & MV_WITH_FLOAT)) return MV_OK;
-  char* dst = (char*)ix->slab + ((size_t)page * ix->cfg.stride_rows + row0) * kRowBytes;
+  char* dst = (char*)ix->slab + ((size_t)page_row0(ix, page) + row0) * kRowBytes;
   MV_HIP(hipMemcpy(dst, bf16_rows, (size_t)n * kRowBytes, hipMemcpyHostToDevice));
-  if (ix->slab_lo && n > 0) MV_HIP(hipMemset((char*)ix->slab_lo + ((size_t)page * ix->cfg.stride_rows + row0) * kRowBytes, 0, (size_t)n * kRowBytes));  // bf16 rows: lo = 0
+  if (ix->slab_lo && n > 0) MV_HIP(hipMemset((char*)ix->slab_lo + ((size_t)page_row0(ix, page) + row0) * kRowBytes, 0, (size_t)n * kRowBytes));  // bf16 rows: lo = 0
   return MV_OK;
 }
 
-// Derive every enabled non-float slab of pages [first, first+n) from their fixed-stride bf16 image `src`
-// (the float slab itself, or a staging buffer).  d_nr = device row counts of those pages.
-static int derive_slabs_from_bf16(mv_index* ix, const uint16_t* src, int64_t first, int64_t n, const int32_t* d_nr, hipStream_t st) {
+// Derive every enabled non-float slab of pages [first, first+n) from their bf16 image: `rows_ptr` = the first row of page `first`
+// in an image laid out like the slabs (stride slots, or -- packed -- whole tiles back to back): the float slab itself, or a
+// staging buffer.  d_nr = device row counts of those pages; their row offsets (packed) are already on the device.
+static int derive_slabs_from_bf16(mv_index* ix, const uint16_t* rows_ptr, int64_t first, int64_t n, const int32_t* d_nr, hipStream_t st) {
   const int32_t stride = ix->cfg.stride_rows;
+  const int64_t row0 = page_row0(ix, first), slot_rows = rows_in_use(ix, first + n) - row0;
+  // packed: the kernels index absolute rows -- hand them the base those offsets count from (see add_pages_common)
+  const uint16_t* img = ix->packed ? reinterpret_cast<const uint16_t*>(reinterpret_cast<uintptr_t>(rows_ptr) - (uintptr_t)row0 * kRowBytes) : rows_ptr;
+  const int64_t* d_ro = ix->packed ? ix->d_row_off + first : nullptr;
   int rc = MV_OK;
   if (ix->cfg.flags & MV_WITH_BINARY) {
-    rc = launch_sign_pack_bf16_rows(src, n * (int64_t)stride, ix->bits + (size_t)first * stride * kSignBytes, st);
+    rc = launch_sign_pack_bf16_rows(rows_ptr, slot_rows, ix->bits + (size_t)row0 * kSignBytes, st);
     if (rc) return rc;
   }
   if (ix->cfg.flags & MV_WITH_FP8) {
-    rc = launch_quantize_pages_fp8(src, d_nr, stride, n, ix->slab8 + (size_t)first * stride * kDim, ix->inv_scale8 + first,
-                                   st);
+    rc = launch_quantize_pages_fp8(img, d_nr, stride, n, ix->packed ? ix->slab8 : ix->slab8 + (size_t)row0 * kDim, ix->inv_scale8 + first, st, d_ro);
     if (rc) return rc;
   }
   if (ix->cfg.flags & MV_WITH_FDE) {
@@ -1420,7 +1493,8 @@ static int derive_slabs_from_bf16(mv_index* ix, const uint16_t* src, int64_t fir
       const int64_t c = std::min<int64_t>(n - done, 1 << 20);
       FdeEncodeArgs e{};
       e.variant = ix->fde_encode_variant;
-      e.x_bf16 = src + (size_t)done * stride * kDim; e.n_rows = d_nr + done; e.stride = stride; e.n_pages = c; e.is_query = 0;
+      e.x_bf16 = ix->packed ? img : img + (size_t)done * stride * kDim; e.x_row_off = d_ro ? d_ro + done : nullptr;
+      e.n_rows = d_nr + done; e.stride = stride; e.n_pages = c; e.is_query = 0;
       e.out_bf16 = ix->fde + (size_t)(first + done) * ix->fde_t.out_dim;
       e.out_inv_norm = ix->fde_inv_norm + first + done;
       rc = launch_fde_encode(ix->fde_t, e, st);
@@ -1430,9 +1504,18 @@ static int derive_slabs_from_bf16(mv_index* ix, const uint16_t* src, int64_t fir
   return rc;
 }
 
-int mv_index_fill_synthetic(mv_index* ix, uint64_t seed, uint64_t first_unit, int64_t n_pages, int32_t n_rows,
-                            int32_t pages_per_doc) {
-  if (!ix || n_pages < 0 || n_rows < 0 || n_rows > ix->cfg.stride_rows) { set_error("fill_synthetic: bad argument"); return MV_ERR_INVALID; }
+// n(u): the row count of unit u in a ragged synthetic corpus (mv_index_fill_synthetic_ragged; oracle/oracle.py restates it)
+static inline int32_t synth_ragged_rows(uint64_t seed, uint64_t unit, int32_t min_rows, int32_t max_rows) {
+  uint64_t z = seed ^ (0x9E3779B97F4A7C15ull * (unit + 1));
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return min_rows + (int32_t)(z % (uint64_t)(max_rows - min_rows + 1));
+}
+
+// Shared body of the synthetic fills: page i (unit first_unit + i) gets rows_of(i) rows.  Caller checked the arguments.
+static int fill_synthetic_common(mv_index* ix, uint64_t seed, uint64_t first_unit, int64_t n_pages, int32_t uniform_rows, int32_t min_rows, int32_t max_rows,
+                                 int32_t pages_per_doc) {
   if (pages_per_doc < 1) pages_per_doc = 1;
   std::lock_guard<std::mutex> lk(ix->w_mu);
   if (ix->size.load() + n_pages > ix->cfg.capacity_pages) { set_error("slab full"); return MV_ERR_CAPACITY; }
@@ -1441,26 +1524,43 @@ int mv_index_fill_synthetic(mv_index* ix, uint64_t seed, uint64_t first_unit, in
   hipStream_t ws = ix->w_stream;
   const int64_t first = ix->size.load();
   const int32_t stride = ix->cfg.stride_rows;
+  const bool ragged_fill = uniform_rows < 0;
+  int64_t slots = 0;
   for (int64_t i = 0; i < n_pages; ++i) {
-    ix->h_n_rows[first + i] = n_rows;
+    const int32_t nr = ragged_fill ? synth_ragged_rows(seed, first_unit + (uint64_t)i, min_rows, max_rows) : uniform_rows;
+    ix->h_n_rows[first + i] = nr;
     ix->h_doc_ord[first + i] = (int32_t)((first_unit + (uint64_t)i) / (uint64_t)pages_per_doc);
+    slots += ((int64_t)nr + 15) / 16 * 16;
+  }
+  if (ix->packed) {
+    if (rows_in_use(ix, first) + slots > ix->cap_rows) { set_error("slab full: %lld rows in use + %lld > capacity_rows %lld", (long long)rows_in_use(ix, first), (long long)slots, (long long)ix->cap_rows); return MV_ERR_CAPACITY; }
+    for (int64_t i = 0; i < n_pages; ++i) ix->h_row_off[(size_t)(first + i + 1)] = ix->h_row_off[(size_t)(first + i)] + ((int64_t)ix->h_n_rows[first + i] + 15) / 16 * 16;
+    MV_HIP(hipMemcpyAsync(ix->d_row_off + first, ix->h_row_off.data() + first, (size_t)(n_pages + 1) * 8, hipMemcpyHostToDevice, ws));
   }
   MV_HIP(hipMemcpyAsync(ix->d_n_rows + first, ix->h_n_rows.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice, ws));
   MV_HIP(hipMemcpyAsync(ix->d_doc_ord + first, ix->h_doc_ord.data() + first, (size_t)n_pages * 4, hipMemcpyHostToDevice, ws));
   const bool has_float = (ix->cfg.flags & MV_WITH_FLOAT) != 0;
   // without a float slab the bf16 image is staged chunk by chunk (<= 512 MiB) and only its derivatives are kept
-  const int64_t chunk = has_float ? n_pages : std::max<int64_t>(1, ((int64_t)512 << 20) / ((int64_t)stride * kRowBytes));
+  const int64_t max_slot = ix->packed ? ((int64_t)(ragged_fill ? max_rows : uniform_rows) + 15) / 16 * 16 : stride;
+  const int64_t chunk = has_float ? n_pages : std::max<int64_t>(1, ((int64_t)512 << 20) / (std::max<int64_t>(max_slot, 16) * kRowBytes));
   int rc = MV_OK;
-  if (!has_float) rc = w_reserve(&ix->w_tmp, &ix->w_tmp_bytes, (size_t)std::min(chunk, n_pages) * stride * kRowBytes);
+  if (!has_float) rc = w_reserve(&ix->w_tmp, &ix->w_tmp_bytes, (size_t)std::min(chunk, n_pages) * std::max<int64_t>(max_slot, 16) * kRowBytes);
   for (int64_t done = 0; done < n_pages && !rc; done += chunk) {
     const int64_t c = std::min(chunk, n_pages - done);
-    uint16_t* dst = has_float ? ix->slab + (size_t)(first + done) * stride * kDim : (uint16_t*)ix->w_tmp;
-    rc = launch_synth_rows(dst, seed, first_unit + (uint64_t)done, c, n_rows, stride, ws);
-    if (!rc && ix->slab_lo && hipMemsetAsync(ix->slab_lo + (size_t)(first + done) * stride * kDim, 0, (size_t)c * stride * kRowBytes, ws) != hipSuccess) {
+    const int64_t row0 = page_row0(ix, first + done), slot_rows = rows_in_use(ix, first + done + c) - row0;
+    uint16_t* rows_ptr = has_float ? ix->slab + (size_t)row0 * kDim : (uint16_t*)ix->w_tmp;
+    if (!ragged_fill) {
+      // uniform pages: a packed slot is ceil16(n_rows) rows -- a fixed-stride region of that stride
+      rc = launch_synth_rows(rows_ptr, seed, first_unit + (uint64_t)done, c, uniform_rows, ix->packed ? (int32_t)max_slot : stride, ws);
+    } else {
+      uint16_t* img = ix->packed ? reinterpret_cast<uint16_t*>(reinterpret_cast<uintptr_t>(rows_ptr) - (uintptr_t)row0 * kRowBytes) : rows_ptr;
+      rc = launch_synth_rows_ragged(img, seed, first_unit + (uint64_t)done, c, ix->d_n_rows + first + done, ix->packed ? ix->d_row_off + first + done : nullptr, stride, ws);
+    }
+    if (!rc && ix->slab_lo && hipMemsetAsync(ix->slab_lo + (size_t)row0 * kDim, 0, (size_t)slot_rows * kRowBytes, ws) != hipSuccess) {
       set_error("fill_synthetic: clearing the lo slab failed"); rc = MV_ERR_HIP;  // the generator's rows ARE bf16: lo = 0
     }
-    if (!rc) rc = xt_store_from_device(ix, dst, first + done, c, ws);
-    if (!rc) rc = derive_slabs_from_bf16(ix, dst, first + done, c, ix->d_n_rows + first + done, ws);
+    if (!rc) rc = xt_store_from_device(ix, rows_ptr, first + done, c, ws);
+    if (!rc) rc = derive_slabs_from_bf16(ix, rows_ptr, first + done, c, ix->d_n_rows + first + done, ws);
     if (!has_float && hipStreamSynchronize(ws) != hipSuccess && !rc) { set_error("fill_synthetic: stream error"); rc = MV_ERR_HIP; }
   }
   hipError_t e = hipStreamSynchronize(ws);
@@ -1470,27 +1570,44 @@ int mv_index_fill_synthetic(mv_index* ix, uint64_t seed, uint64_t first_unit, in
   return MV_OK;
 }
 
+int mv_index_fill_synthetic(mv_index* ix, uint64_t seed, uint64_t first_unit, int64_t n_pages, int32_t n_rows,
+                            int32_t pages_per_doc) {
+  if (!ix || n_pages < 0 || n_rows < 0 || n_rows > ix->cfg.stride_rows) { set_error("fill_synthetic: bad argument"); return MV_ERR_INVALID; }
+  return fill_synthetic_common(ix, seed, first_unit, n_pages, n_rows, 0, 0, pages_per_doc);
+}
+
+int mv_index_fill_synthetic_ragged(mv_index* ix, uint64_t seed, uint64_t first_unit, int64_t n_pages, int32_t min_rows, int32_t max_rows,
+                                   int32_t pages_per_doc) {
+  if (!ix || n_pages < 0 || min_rows < 0 || max_rows < min_rows || max_rows > ix->cfg.stride_rows) { set_error("fill_synthetic_ragged: bad argument (0 <= min_rows <= max_rows <= stride_rows)"); return MV_ERR_INVALID; }
+  return fill_synthetic_common(ix, seed, first_unit, n_pages, -1, min_rows, max_rows, pages_per_doc);
+}
+
 // Overwrite one whole page from host bf16 rows and refresh every slab (bench/test: planted neighbours on any
 // combination of slabs; also the update path of a re-embedded page).
 int mv_index_replace_page(mv_index* ix, int64_t page, const void* bf16_rows, int32_t n_rows) {
   if (!ix || !bf16_rows || page < 0 || page >= ix->size.load() || n_rows < 0 || n_rows > ix->cfg.stride_rows) { set_error("replace_page: bad argument"); return MV_ERR_INVALID; }
-  if ((ix->cfg.flags & ~MV_WITH_BINARY) && !host_rows_finite(bf16_rows, MV_BF16, (size_t)n_rows * kDim)) { set_error("replace_page: a row holds a NaN / Inf"); return MV_ERR_INVALID; }
+  if ((ix->cfg.flags & ~(MV_WITH_BINARY | MV_LAYOUT_PACKED)) && !host_rows_finite(bf16_rows, MV_BF16, (size_t)n_rows * kDim)) { set_error("replace_page: a row holds a NaN / Inf"); return MV_ERR_INVALID; }
   ExclusiveLock lk(ix);
   DeviceGuard g(ix->cfg.device);
   const int32_t stride = ix->cfg.stride_rows;
+  // packed layout: a page owns the tiles it was appended with -- a longer replacement does not fit (remove the page and append the new one)
+  const int32_t slot = page_slot_rows(ix, page);
+  if (n_rows > slot) { set_error("replace_page: %d rows do not fit the page's %d-row slot (packed layout: remove the page and append its replacement)", n_rows, slot); return MV_ERR_CAPACITY; }
+  const int64_t row0 = page_row0(ix, page);
   const bool has_float = (ix->cfg.flags & MV_WITH_FLOAT) != 0;
-  uint16_t* dst = has_float ? ix->slab + (size_t)page * stride * kDim : nullptr;
+  uint16_t* dst = has_float ? ix->slab + (size_t)row0 * kDim : nullptr;
   uint16_t* stage = nullptr;
-  if (!has_float) { MV_HIP(hipMalloc(&stage, (size_t)stride * kRowBytes)); dst = stage; }
+  if (!has_float) { MV_HIP(hipMalloc(&stage, (size_t)slot * kRowBytes)); dst = stage; }
   int rc = MV_OK;
-  hipError_t e = hipMemsetAsync(dst, 0, (size_t)stride * kRowBytes, ix->stream);
-  if (e == hipSuccess && ix->slab_lo) e = hipMemsetAsync(ix->slab_lo + (size_t)page * stride * kDim, 0, (size_t)stride * kRowBytes, ix->stream);  // bf16 rows: lo = 0
+  hipError_t e = hipMemsetAsync(dst, 0, (size_t)slot * kRowBytes, ix->stream);
+  if (e == hipSuccess && ix->slab_lo) e = hipMemsetAsync(ix->slab_lo + (size_t)row0 * kDim, 0, (size_t)slot * kRowBytes, ix->stream);  // bf16 rows: lo = 0
   if (e == hipSuccess && n_rows > 0) e = hipMemcpyAsync(dst, bf16_rows, (size_t)n_rows * kRowBytes, hipMemcpyHostToDevice, ix->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);  // the host buffer may be pageable
   if (e != hipSuccess) rc = hip_fail(e, "replace_page upload", __FILE__, __LINE__);
   if (!rc) {
     ix->h_n_rows[page] = n_rows;
     if (n_rows != stride) ix->ragged.store(true);
+    (void)stride;
     e = hipMemcpyAsync(ix->d_n_rows + page, &ix->h_n_rows[page], 4, hipMemcpyHostToDevice, ix->stream);
     if (e != hipSuccess) rc = hip_fail(e, "replace_page metadata", __FILE__, __LINE__);
   }
@@ -1510,6 +1627,15 @@ __global__ __launch_bounds__(256) void gather_pages_kernel(const char* base, siz
   if (p >= n || off >= page_bytes) return;
   *reinterpret_cast<uint4*>(dst + (size_t)p * page_bytes + off) =
       *reinterpret_cast<const uint4*>(base + (size_t)src_pages[p] * page_bytes + off);
+}
+
+// Packed layout: page p of the batch = rows [src_row0[p], +rows[p]) of a row-indexed slab -> stage + dst_rel[p] * row_bytes.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const char* base, size_t row_bytes, const int64_t* src_row0, const int64_t* dst_rel,
+                                                          const int64_t* rows, int64_t n, char* dst) {
+  const int64_t p = blockIdx.x;
+  const size_t off = ((size_t)blockIdx.y * 256 + threadIdx.x) * 16;
+  if (p >= n || off >= (size_t)rows[p] * row_bytes) return;
+  *reinterpret_cast<uint4*>(dst + (size_t)dst_rel[p] * row_bytes + off) = *reinterpret_cast<const uint4*>(base + (size_t)src_row0[p] * row_bytes + off);
 }
 
 // Reclaim the slots of tombstoned pages: live pages move down, in order, to a dense prefix of every slab.
@@ -1533,15 +1659,34 @@ int mv_index_compact(mv_index* ix, int64_t* out_old_to_new, int64_t* out_new_siz
   if (m == n) return MV_OK;  // nothing to reclaim
   int64_t first_moved = 0;
   while (first_moved < m && live[first_moved] == first_moved) ++first_moved;
-  struct Slab { char* base; size_t page_bytes; };
+  struct Slab { char* base; size_t page_bytes; size_t row_bytes; };  // row_bytes > 0: a row-indexed slab (packed layout: ragged slots)
   std::vector<Slab> slabs;
   const size_t stride = (size_t)ix->cfg.stride_rows;
-  if (ix->cfg.flags & MV_WITH_FLOAT) slabs.push_back({(char*)ix->slab, stride * kRowBytes});
-  if (ix->slab_lo) slabs.push_back({(char*)ix->slab_lo, stride * kRowBytes});
-  if (ix->cfg.flags & MV_WITH_FP8) { slabs.push_back({(char*)ix->slab8, stride * kDim}); slabs.push_back({(char*)ix->inv_scale8, 16}); }
-  if (ix->cfg.flags & MV_WITH_BINARY) slabs.push_back({(char*)ix->bits, stride * kSignBytes});
-  if (ix->cfg.flags & MV_WITH_FDE) { slabs.push_back({(char*)ix->fde, (size_t)ix->fde_t.out_dim * 2}); slabs.push_back({(char*)ix->fde_inv_norm, 16}); }
+  if (ix->cfg.flags & MV_WITH_FLOAT) slabs.push_back({(char*)ix->slab, stride * kRowBytes, (size_t)kRowBytes});
+  if (ix->slab_lo) slabs.push_back({(char*)ix->slab_lo, stride * kRowBytes, (size_t)kRowBytes});
+  if (ix->cfg.flags & MV_WITH_FP8) { slabs.push_back({(char*)ix->slab8, stride * kDim, (size_t)kDim}); slabs.push_back({(char*)ix->inv_scale8, 16, 0}); }
+  if (ix->cfg.flags & MV_WITH_BINARY) slabs.push_back({(char*)ix->bits, stride * kSignBytes, (size_t)kSignBytes});
+  if (ix->cfg.flags & MV_WITH_FDE) { slabs.push_back({(char*)ix->fde, (size_t)ix->fde_t.out_dim * 2, 0}); slabs.push_back({(char*)ix->fde_inv_norm, 16, 0}); }
   int rc = MV_OK;
+  // packed layout: the new row offsets (live pages keep their slots, back to back) and, per moved page, (old first row, new first row, rows)
+  std::vector<int64_t> new_off;
+  int64_t* d_rowmeta = nullptr;  // [3][moved]: src_row0 | dst_row0 | rows
+  const int64_t moved = m - first_moved;
+  if (ix->packed) {
+    new_off.assign((size_t)m + 1, 0);
+    for (int64_t j = 0; j < m; ++j) new_off[(size_t)j + 1] = new_off[(size_t)j] + page_slot_rows(ix, live[(size_t)j]);
+    if (moved > 0) {
+      std::vector<int64_t> meta((size_t)3 * moved);
+      for (int64_t j = first_moved; j < m; ++j) {
+        meta[(size_t)(j - first_moved)] = ix->h_row_off[(size_t)live[(size_t)j]];
+        meta[(size_t)(moved + j - first_moved)] = new_off[(size_t)j];
+        meta[(size_t)(2 * moved + j - first_moved)] = page_slot_rows(ix, live[(size_t)j]);
+      }
+      if (hipMalloc(&d_rowmeta, meta.size() * 8) != hipSuccess || hipMemcpy(d_rowmeta, meta.data(), meta.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("compact: out of device memory for the row tables"); rc = MV_ERR_NOMEM;
+      }
+    }
+  }
   int64_t* d_idx = nullptr;
   char* stage = nullptr;
   const size_t stage_bytes = (size_t)256 << 20;
@@ -1560,6 +1705,26 @@ int mv_index_compact(mv_index* ix, int64_t* out_old_to_new, int64_t* out_new_siz
       if (hipMemcpy(sl.base, h.data(), (size_t)m * 4, hipMemcpyHostToDevice) != hipSuccess) { set_error("compact: H2D failed"); rc = MV_ERR_HIP; }
       continue;
     }
+    if (ix->packed && sl.row_bytes) {
+      // ragged slots: batches of consecutive live pages whose slots fill the staging buffer; gathered, then written back as ONE block at
+      // the batch's new first row (destinations never lie above their sources and batches ascend: nothing still to be read is overwritten)
+      for (int64_t j0 = first_moved; j0 < m && !rc;) {
+        int64_t j1 = j0;
+        const int64_t rbase = new_off[(size_t)j0];
+        while (j1 < m && (size_t)(new_off[(size_t)j1 + 1] - rbase) * sl.row_bytes <= stage_bytes) ++j1;
+        if (j1 == j0) { set_error("compact: a page slot exceeds the staging buffer"); rc = MV_ERR_INVALID; break; }
+        const int64_t c = j1 - j0;
+        const unsigned gy = (unsigned)((stride * sl.row_bytes / 16 + 255) / 256);
+        // dst_rel = new first row relative to the batch: computed on the fly from the dst_row0 table by offsetting the stage pointer
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)c, gy), dim3(256), 0, ix->stream, (const char*)sl.base, sl.row_bytes,
+                           (const int64_t*)(d_rowmeta + (j0 - first_moved)), (const int64_t*)(d_rowmeta + moved + (j0 - first_moved)),
+                           (const int64_t*)(d_rowmeta + 2 * moved + (j0 - first_moved)), c, stage - (size_t)rbase * sl.row_bytes);
+        if (hipMemcpyAsync(sl.base + (size_t)rbase * sl.row_bytes, stage, (size_t)(new_off[(size_t)j1] - rbase) * sl.row_bytes, hipMemcpyDeviceToDevice, ix->stream) != hipSuccess ||
+            hipStreamSynchronize(ix->stream) != hipSuccess) { set_error("compact: device copy failed"); rc = MV_ERR_HIP; }
+        j0 = j1;
+      }
+      continue;
+    }
     const int64_t batch = std::max<int64_t>(1, (int64_t)(stage_bytes / sl.page_bytes));
     for (int64_t j0 = first_moved; j0 < m && !rc; j0 += batch) {
       const int64_t c = std::min(batch, m - j0);
@@ -1572,7 +1737,13 @@ int mv_index_compact(mv_index* ix, int64_t* out_old_to_new, int64_t* out_new_siz
   }
   if (d_idx) (void)hipFree(d_idx);
   if (stage) (void)hipFree(stage);
+  if (d_rowmeta) (void)hipFree(d_rowmeta);
   if (rc) return rc;
+  if (ix->packed) {
+    for (int64_t j = 0; j <= m; ++j) ix->h_row_off[(size_t)j] = new_off[(size_t)j];
+    for (int64_t j = m + 1; j <= n; ++j) ix->h_row_off[(size_t)j] = new_off[(size_t)m];
+    MV_HIP(hipMemcpy(ix->d_row_off, ix->h_row_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+  }
   if ((rc = xt_compact(ix, live, first_moved, m)) != MV_OK) return rc;  // the exact host tier moves with the pages
   for (int64_t j = first_moved; j < m; ++j) {
     ix->h_n_rows[(size_t)j] = ix->h_n_rows[(size_t)live[j]];
@@ -1583,7 +1754,7 @@ int mv_index_compact(mv_index* ix, int64_t* out_old_to_new, int64_t* out_new_siz
   ix->tombstones.store(false);
   bool rag = false;
   for (int64_t j = 0; j < m && !rag; ++j) rag = ix->h_n_rows[(size_t)j] != ix->cfg.stride_rows;
-  ix->ragged.store(rag);
+  ix->ragged.store(rag || ix->packed);
   if (n > 0) {
     MV_HIP(hipMemcpy(ix->d_n_rows, ix->h_n_rows.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     MV_HIP(hipMemcpy(ix->d_doc_ord, ix->h_doc_ord.data(), (size_t)n * 4, hipMemcpyHostToDevice));
@@ -1598,7 +1769,8 @@ int mv_index_read_fp8(mv_index* ix, int64_t page0, int64_t n_pages, void* out_co
   std::lock_guard<std::mutex> lk(ix->q_mu);
   DeviceGuard g(ix->cfg.device);
   const size_t pb = (size_t)ix->cfg.stride_rows * kDim;
-  MV_HIP(hipMemcpy(out_codes, ix->slab8 + (size_t)page0 * pb, (size_t)n_pages * pb, hipMemcpyDeviceToHost));
+  if (ix->packed) { if (int rc = read_packed_pages(ix, ix->slab8, kDim, page0, n_pages, out_codes)) return rc; }
+  else MV_HIP(hipMemcpy(out_codes, ix->slab8 + (size_t)page0 * pb, (size_t)n_pages * pb, hipMemcpyDeviceToHost));
   MV_HIP(hipMemcpy(out_inv_scale, ix->inv_scale8 + page0, (size_t)n_pages * 4, hipMemcpyDeviceToHost));
   return MV_OK;
 }
@@ -1966,7 +2138,7 @@ int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t n
     Fp8ScanArgs fa{};
     fa.slab = ix->slab8; fa.inv_scale = ix->inv_scale8; fa.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr; fa.cand = ix->d_bcand;
     fa.qhi = ix->d_bq8hi; fa.qlo = ix->d_bq8lo; fa.qfac = ix->d_bq8fac; fa.n_q = rpq; fa.scores = dst; fa.n = (int64_t)nb * nc;
-    fa.stride = ix->cfg.stride_rows; fa.pad_to = 0; fa.pad_items = ix->d_bcand_pads; fa.items_per_query = (int32_t)nc;
+    fa.stride = ix->cfg.stride_rows; fa.pad_to = 0; fa.pad_items = ix->d_bcand_pads; fa.items_per_query = (int32_t)nc; fa.row_off = ix->d_row_off;
     rc = launch_maxsim_fp8(fa, ix->stream);
     if (rc) return rc;
     ++*launches;
@@ -1976,7 +2148,7 @@ int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t n
     ma.slab = exact; ma.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr; ma.cand = ix->d_bcand; ma.q = ix->d_bq;
     ma.scores = dst; ma.n = n; ma.stride = ix->cfg.stride_rows; ma.q_tiles = rpq / 16; ma.pad_to = 0;
     ma.pad_items = ix->d_bcand_pads; ma.items_per_query = (int32_t)nc; ma.q_item_stride = rpq * kDim;
-    ma.qlo = qlo; ma.slab_lo = slab_lo;
+    ma.qlo = qlo; ma.slab_lo = slab_lo; ma.row_off = ix->d_row_off;
     if (!split) {
       rc = launch_maxsim_bf16(ma, rr_variant, ix->stream);
       if (rc) return rc;
@@ -2199,7 +2371,7 @@ static int fp8_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
     a.allow = per_query ? d_allow + (size_t)b0 * n_allow_words : d_allow; a.n_allow_bits = n_allow_words * 32;
     a.allow_stride_bits = per_query ? n_allow_words * 32 : 0;
     a.qhi = ix->d_bq8hi; a.qlo = ix->d_bq8lo; a.qfac = ix->d_bq8fac; a.scores = ix->d_bscores; a.n = n; a.score_stride = ix->cfg.capacity_pages;
-    a.stride = ix->cfg.stride_rows; a.n_queries = nb; a.rows_per_query = rpq;
+    a.stride = ix->cfg.stride_rows; a.n_queries = nb; a.rows_per_query = rpq; a.row_off = ix->d_row_off;
     // two-tier search: the first stage only NOMINATES candidates and the exact tier restores their order, so by default it runs with ONE
     // e4m3 term per query row (half the matrix work: 9.9 vs 16.3 ms per 16 requests at 200 k pages; recall@10 1.0 on every corpus of
     // bench.py either way); MV_OPT_BATCH_VARIANT 0 asks for the two-term scores (the single-query scan's), 7 for one term in either mode
@@ -2340,7 +2512,7 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
     a.slab = ix->slab; a.n_rows = ragged ? ix->d_n_rows : nullptr; a.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
     a.allow = per_query ? d_allow + (size_t)b0 * n_allow_words : d_allow; a.n_allow_bits = n_allow_words * 32;
     a.allow_stride_bits = per_query ? n_allow_words * 32 : 0; a.q = ix->d_bq; a.scores = ix->d_bscores; a.n = n;
-    a.score_stride = ix->cfg.capacity_pages; a.stride = ix->cfg.stride_rows; a.n_queries = nb; a.rows_per_query = rpq;
+    a.score_stride = ix->cfg.capacity_pages; a.stride = ix->cfg.stride_rows; a.n_queries = nb; a.rows_per_query = rpq; a.row_off = ix->d_row_off;
     a.variant = ix->batch_variant >= 0 ? ix->batch_variant : 0;  // auto: page-split form up to 128 rows, transposed row-split form above
     rc = launch_maxsim_batch(a, ix->stream);
     if (rc) return rc;
@@ -2742,9 +2914,19 @@ int mv_calibrate(int device, int what, int64_t bytes, int32_t iters, double* out
 }
 
 // ---------------------------------------------------------------------------------- persistence
-struct SaveHeader {
+struct SaveHeader {  // "MVIDX003"
   char magic[8];
   mv_config cfg;
+  int64_t size;
+  int64_t fde_out_dim;
+};
+struct SaveHeaderV2 {  // "MVIDX002": checkpoints written before mv_config grew capacity_rows (fixed layout only)
+  char magic[8];
+  int32_t dim, stride_rows;
+  int64_t capacity_pages;
+  int32_t device, flags;
+  int64_t id_base;
+  mv_fde_config fde;
   int64_t size;
   int64_t fde_out_dim;
 };
@@ -2760,7 +2942,7 @@ int mv_index_save(mv_index* ix, const char* path) {
   if (!f) { set_error("cannot open %s for writing", tmp.c_str()); return MV_ERR_IO; }
   const int64_t size = ix->size.load();
   SaveHeader h{};
-  memcpy(h.magic, "MVIDX002", 8);
+  memcpy(h.magic, "MVIDX003", 8);
   h.cfg = ix->cfg;
   h.size = size;
   h.fde_out_dim = ix->fde_t.out_dim;
@@ -2769,6 +2951,7 @@ int mv_index_save(mv_index* ix, const char* path) {
   wr(&h, sizeof(h));
   wr(ix->h_n_rows.data(), (size_t)size * 4);
   wr(ix->h_doc_ord.data(), (size_t)size * 4);
+  if (ix->packed) wr(ix->h_row_off.data(), (size_t)(size + 1) * 8);  // packed layout: the page -> first-row table
   std::vector<char> buf((size_t)64 << 20);
   auto dump = [&](const void* d, size_t bytes) {
     size_t off = 0;
@@ -2779,7 +2962,7 @@ int mv_index_save(mv_index* ix, const char* path) {
       off += n;
     }
   };
-  const size_t rows = (size_t)size * ix->cfg.stride_rows;
+  const size_t rows = (size_t)rows_in_use(ix, size);
   if (ix->cfg.flags & MV_WITH_FLOAT) dump(ix->slab, rows * kRowBytes);
   if (ix->cfg.flags & MV_WITH_FLOAT_LO) dump(ix->slab_lo, rows * kRowBytes);
   if (ix->cfg.flags & MV_WITH_BINARY) dump(ix->bits, rows * kSignBytes);
@@ -2810,7 +2993,17 @@ int mv_index_load(const char* path, int32_t device, mv_index** out) {
   FILE* f = fopen(path, "rb");
   if (!f) { set_error("cannot open %s", path); return MV_ERR_IO; }
   SaveHeader h{};
-  if (fread(&h, 1, sizeof(h), f) != sizeof(h) || memcmp(h.magic, "MVIDX002", 8) != 0) { fclose(f); set_error("%s is not an mv index file", path); return MV_ERR_IO; }
+  char magic[8] = {0};
+  if (fread(magic, 1, 8, f) != 8) { fclose(f); set_error("%s is not an mv index file", path); return MV_ERR_IO; }
+  if (memcmp(magic, "MVIDX003", 8) == 0) {
+    memcpy(h.magic, magic, 8);
+    if (fread((char*)&h + 8, 1, sizeof(h) - 8, f) != sizeof(h) - 8) { fclose(f); set_error("%s: truncated header", path); return MV_ERR_IO; }
+  } else if (memcmp(magic, "MVIDX002", 8) == 0) {  // the previous header: the same fields without capacity_rows
+    SaveHeaderV2 o{};
+    if (fread((char*)&o + 8, 1, sizeof(o) - 8, f) != sizeof(o) - 8) { fclose(f); set_error("%s: truncated header", path); return MV_ERR_IO; }
+    h.cfg.dim = o.dim; h.cfg.stride_rows = o.stride_rows; h.cfg.capacity_pages = o.capacity_pages; h.cfg.device = o.device; h.cfg.flags = o.flags & ~MV_LAYOUT_PACKED;
+    h.cfg.id_base = o.id_base; h.cfg.fde = o.fde; h.cfg.capacity_rows = 0; h.size = o.size; h.fde_out_dim = o.fde_out_dim;
+  } else { fclose(f); set_error("%s is not an mv index file", path); return MV_ERR_IO; }
   // the header is untrusted input: everything read below is sized by it
   if (h.size < 0 || h.size > h.cfg.capacity_pages) { fclose(f); set_error("%s: size %lld outside 0..capacity %lld", path, (long long)h.size, (long long)h.cfg.capacity_pages); return MV_ERR_IO; }
   if ((h.cfg.flags & MV_WITH_FDE) && h.fde_out_dim != mv_fde_output_dim(&h.cfg.fde)) { fclose(f); set_error("%s: FDE width %lld does not match its FDE config", path, (long long)h.fde_out_dim); return MV_ERR_IO; }
@@ -2824,6 +3017,16 @@ int mv_index_load(const char* path, int32_t device, mv_index** out) {
   rd(ix->h_doc_ord.data(), (size_t)h.size * 4);
   for (int64_t p = 0; p < h.size && !rc; ++p)
     if (ix->h_n_rows[p] < 0 || ix->h_n_rows[p] > h.cfg.stride_rows) { set_error("%s: page %lld has %d rows (stride %d)", path, (long long)p, ix->h_n_rows[p], h.cfg.stride_rows); rc = MV_ERR_IO; }
+  if (ix->packed) {  // the row table is untrusted too: ascending whole tiles, every page inside its slot, all inside the slabs
+    rd(ix->h_row_off.data(), (size_t)(h.size + 1) * 8);
+    if (!rc && ix->h_row_off[0] != 0) { set_error("%s: row table does not start at 0", path); rc = MV_ERR_IO; }
+    for (int64_t p = 0; p < h.size && !rc; ++p) {
+      const int64_t slot = ix->h_row_off[(size_t)p + 1] - ix->h_row_off[(size_t)p];
+      if (slot < 0 || slot % 16 || slot > h.cfg.stride_rows || ix->h_n_rows[p] > slot || ix->h_row_off[(size_t)p + 1] > ix->cap_rows) { set_error("%s: bad row table at page %lld", path, (long long)p); rc = MV_ERR_IO; }
+    }
+    for (int64_t p = h.size + 1; p <= h.cfg.capacity_pages && !rc; ++p) ix->h_row_off[(size_t)p] = ix->h_row_off[(size_t)h.size];
+    if (!rc && hipMemcpy(ix->d_row_off, ix->h_row_off.data(), (size_t)(h.cfg.capacity_pages + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D of the row table failed"); rc = MV_ERR_HIP; }
+  }
   std::vector<char> buf((size_t)64 << 20);
   auto fill = [&](void* d, size_t bytes) {
     size_t off = 0;
@@ -2834,7 +3037,7 @@ int mv_index_load(const char* path, int32_t device, mv_index** out) {
       off += n;
     }
   };
-  const size_t rows = (size_t)h.size * h.cfg.stride_rows;
+  const size_t rows = rc ? 0 : (size_t)rows_in_use(ix, h.size);
   if (h.cfg.flags & MV_WITH_FLOAT) fill(ix->slab, rows * kRowBytes);
   if (h.cfg.flags & MV_WITH_FLOAT_LO) fill(ix->slab_lo, rows * kRowBytes);
   if (h.cfg.flags & MV_WITH_BINARY) fill(ix->bits, rows * kSignBytes);

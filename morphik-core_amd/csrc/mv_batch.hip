@@ -47,6 +47,7 @@ struct BKArgs {
   int32_t n_queries;
   int32_t rows_per_query;  // multiple of 16
   int64_t allow_stride_bits;  // 0: one bitmap shared by all queries; > 0: query b filters with allow + b * stride/32
+  const int64_t* row_off;     // packed layout: first slab row of every page; null: page * stride
 };
 
 __device__ __forceinline__ bool bk_masked(const BKArgs& a, int64_t page) {
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_batch_kernel(BKArgs a) {
     }
     const int ntiles = (nr + kTileRows - 1) / kTileRows;
     const int nchunks = (ntiles + kChunkTiles - 1) / kChunkTiles;
-    const char* pbase = a.slab + (size_t)page * (size_t)a.stride * kRowBytes;
+    const char* pbase = a.slab + (a.row_off ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride) * kRowBytes;
 
     // wave w moves tile w of chunk c (always issued: the slab is padded, rows past n_rows are never consumed)
     auto issue = [&](int c) {
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_batch_ps_kernel(BKArgs a) {
   }
   const int ntiles = (nr + kTileRows - 1) / kTileRows;
   const int ntw = (ntiles - wave + 3) / 4;  // tiles wave, wave + 4, ... (may be <= 0)
-  const char* pbase = a.slab + (size_t)page * (size_t)a.stride * kRowBytes;
+  const char* pbase = a.slab + (a.row_off ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride) * kRowBytes;
   char* ring = lds + wave * (D * kTileBytes);
 
   int src_off[4];
@@ -424,7 +425,7 @@ int launch_maxsim_batch(const BatchArgs& a, hipStream_t s) {
   const int rows = a.n_queries * a.rows_per_query;
   if (rows > 512 || a.n_queries > 256) { set_error("batch scan: %d query rows exceed the 512-row group", rows); return MV_ERR_INVALID; }
   BKArgs k{reinterpret_cast<const char*>(a.slab), a.n_rows, a.doc_ord, a.allow, a.n_allow_bits, a.q, a.scores, a.n,
-           a.score_stride, 0, a.stride, a.n_queries, a.rows_per_query, a.allow_stride_bits};
+           a.score_stride, 0, a.stride, a.n_queries, a.rows_per_query, a.allow_stride_bits, a.row_off};
   static int ncu = 0;  // CUs of the (single-architecture) node's GPUs, queried once
   if (ncu == 0) {
     int dev = 0, v = 0;

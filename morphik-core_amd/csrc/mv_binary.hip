@@ -72,6 +72,7 @@ struct BArgs {
   int32_t n_q;
   const float* qpop;  // [n_q padded to 16] popc of each query row as float, -1 for padding rows (MFMA variant)
   const int32_t* cand;  // optional candidate list: item i scores page cand[i] into scores[i] (variants 0 and 2..4)
+  const int64_t* row_off;  // packed layout: first slab row of every page; null: page * stride
 };
 
 __device__ __forceinline__ bool masked(const BArgs& a, int64_t page) {
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void maxsim_binary_kernel(BArgs a) {
     if (lane == 0) a.scores[item] = 0.0f;  // COALESCE(SUM over nothing, 0.0)
     return;
   }
-  const uint4* pg = a.bits + (size_t)page * (size_t)a.stride;
+  const uint4* pg = a.bits + (a.row_off ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride);
   int total = 0;
   for (int q0 = 0; q0 < a.n_q; q0 += kQChunk) {
     const int nq = min(kQChunk, a.n_q - q0);
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void maxsim_binary_mfma2_kernel(BMArgs args) {
   }
   const int ntiles = (nr + 15) >> 4;
   const int nslots = (nr + SLR - 1) / SLR;
-  const char* pbase = reinterpret_cast<const char*>(a.bits) + (size_t)page * (size_t)a.stride * kSignBytes;
+  const char* pbase = reinterpret_cast<const char*>(a.bits) + (a.row_off ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride) * kSignBytes;
   char* ring = lds + wave * (D * SLB);
   const int src_off = lane * 16;
   const int rd_off = r * kSignBytes + g * 4;
@@ -444,7 +445,7 @@ static void launch_binary_mfma(const BArgs& k, int accumulate, hipStream_t s) {
 int launch_maxsim_binary(const BinaryArgs& a, int variant, hipStream_t s) {
   if (a.n <= 0) return MV_OK;
   BArgs k{reinterpret_cast<const uint4*>(a.bits), a.n_rows, a.doc_ord, a.allow, a.n_allow_bits,
-          reinterpret_cast<const uint4*>(a.qbits), a.scores, a.n, a.stride, a.n_q, a.qpop, a.cand};
+          reinterpret_cast<const uint4*>(a.qbits), a.scores, a.n, a.stride, a.n_q, a.qpop, a.cand, a.row_off};
   if (a.n > ((int64_t)1 << 25)) { set_error("binary scan: more than 2^25 pages per launch is not supported"); return MV_ERR_INVALID; }
   if (variant < 0) variant = 4;
   if (variant == 0 || a.n_q <= 0) {

@@ -378,7 +378,7 @@ int mv_internal_two_stage_batch_coarse(mv_index* ix, const void* q, int q_dtype,
     a.slab = ix->slab8; a.inv_scale = ix->inv_scale8; a.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr; a.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
     a.allow = d_allow; a.n_allow_bits = n_allow_words * 32; a.allow_stride_bits = per_query ? n_allow_words * 32 : 0;
     a.qhi = ix->d_bq8hi; a.qlo = ix->d_bq8lo; a.qfac = ix->d_bq8fac; a.scores = ix->d_bscores; a.n = n; a.score_stride = cap;
-    a.stride = ix->cfg.stride_rows; a.n_queries = nb; a.rows_per_query = rpq;
+    a.stride = ix->cfg.stride_rows; a.n_queries = nb; a.rows_per_query = rpq; a.row_off = ix->d_row_off;
     a.single_term = ix->batch_variant == 0 ? 0 : 1;  // the first stage of a two-tier search: one e4m3 term per query row unless asked otherwise (fp8_batch_query)
     rc = launch_maxsim_batch_fp8(a, ix->stream);
     if (rc) return rc;

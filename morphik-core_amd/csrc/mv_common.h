@@ -46,6 +46,7 @@ struct MaxsimArgs {
   const uint16_t* qlo;      // nullable: the lo half of the query rows (layout of q, q_item_stride applies): S = qhi.p + qlo.p
   const uint16_t* slab_lo;  // nullable: the lo half of the page rows (layout of slab; needs qlo -- zeros for a bf16 query):
                             //           S = qhi.phi + qlo.phi + qhi.plo (the dropped qlo.plo term is <= 2^-18 of the product)
+  const int64_t* row_off;   // nullable: MV_LAYOUT_PACKED -- first slab row of every page (a multiple of 16); null: page * stride
 };
 // variant: -1 default; see DESIGN.md "Kernel variants".
 int launch_maxsim_bf16(const MaxsimArgs& a, int variant, hipStream_t s);
@@ -68,6 +69,7 @@ struct BatchArgs {
   int32_t rows_per_query;   // multiple of 16; n_queries * rows_per_query <= 512
   int64_t allow_stride_bits;  // 0 = `allow` is shared; else query b uses allow + b * allow_stride_bits / 32 (n_allow_bits each)
   int32_t variant;          // 0 = 16x16x32 MFMA, 4 waves / workgroup; 1 = 32x32x16 MFMA, 8 waves / workgroup (> 128 rows)
+  const int64_t* row_off;   // nullable: packed layout (MaxsimArgs::row_off)
 };
 int launch_maxsim_batch(const BatchArgs& a, hipStream_t s);
 
@@ -122,6 +124,10 @@ int launch_merge_topk(const float* d_scores, const int64_t* d_ids, int32_t world
 // ---------------------------------------------------------------- synthetic generator (mv_synth.hip)
 int launch_synth_rows(uint16_t* d_out, uint64_t seed, uint64_t first_unit, int64_t n_units, int32_t n_rows,
                       int32_t stride_rows, hipStream_t s);
+// ragged form: unit i gets its first d_n_rows[i] rows at d_base + (d_row_off ? d_row_off[i] : i * stride_rows) * 128, zero rows up to
+// the end of its allotment (d_row_off[i + 1], or the stride slot)
+int launch_synth_rows_ragged(uint16_t* d_base, uint64_t seed, uint64_t first_unit, int64_t n_units, const int32_t* d_n_rows,
+                             const int64_t* d_row_off, int32_t stride_rows, hipStream_t s);
 
 // ---------------------------------------------------------------- binary path (mv_binary.hip)
 int launch_sign_pack_f32(const float* d_x, int64_t n_rows, int32_t d, uint8_t* d_out, hipStream_t s);
@@ -141,6 +147,7 @@ struct BinaryArgs {
   int32_t stride;
   int32_t n_q;
   const int32_t* cand;     // optional candidate list (item i = page cand[i], scores[i]); n = number of candidates
+  const int64_t* row_off;  // nullable: packed layout (MaxsimArgs::row_off; the sign slab shares the row numbering)
 };
 // variant: 0 = popcount (VALU), 1 = FP4 MFMA (16 VALU ops/tile), 2 = FP4 MFMA with in-place bit operands (8 VALU
 // ops/tile, 8-slot ring), 3 / 4 = variant 2 with a 16- / 4-slot ring (4 = default, -1), 5 = persistent waves with one DMA
@@ -180,6 +187,8 @@ struct FdeEncodeArgs {
   float* out_inv_norm;
   int32_t variant;           // 0 = scalar kernel (LDS atomics), 1 = f32-MFMA kernel, 2 = query latency kernel, 3 = one-pass document kernel (bf16 AMS,
                              // LDS-atomic bucket sums), 4 = two-pass document form (hash pass + projection pass with one-hot MFMA bucket sums)
+  const int64_t* x_row_off;  // nullable, with x_bf16: packed layout -- page i's rows start at x_bf16 + x_row_off[i] * 128 (x_bf16 then is
+                             // the slab BASE the offsets count from, x_row_off already points at the first page of the call)
 };
 int launch_fde_encode(const FdeTables& t, const FdeEncodeArgs& a, hipStream_t s);
 // caller-supplied document FDE vectors (fp32 [n][out_dim], device memory) -> the slab's bf16 rows + 1 / |d| of the ROUNDED rows (the encode kernels' rule)
@@ -239,8 +248,10 @@ int launch_fde_scan_batch(const FdeScanBatchArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- fp8 path (mv_fp8.hip)
 // quantise fixed-stride bf16 pages -> e4m3 codes + one power-of-two scale per page (inv_scale = 2^-e)
+// d_row_off (nullable, packed layout): page i's rows start d_row_off[i] rows into BOTH d_src_pages and d_dst (the two slabs share the
+// row numbering; the pointers then are the bases the offsets count from)
 int launch_quantize_pages_fp8(const uint16_t* d_src_pages, const int32_t* d_n_rows, int32_t stride, int64_t n_pages,
-                              uint8_t* d_dst, float* d_inv_scale, hipStream_t s);
+                              uint8_t* d_dst, float* d_inv_scale, hipStream_t s, const int64_t* d_row_off = nullptr);
 // fp32 query rows -> two-term e4m3 split (hi, lo*16) + 2^-s per row; buffers padded to a multiple of 16 rows
 int launch_fp8_query_prep(const float* d_q_f32, int n_q, uint8_t* d_hi, uint8_t* d_lo, float* d_fac, hipStream_t s);
 struct Fp8ScanArgs {
@@ -262,6 +273,7 @@ struct Fp8ScanArgs {
   const int32_t* pad_items;  // per-item pad_to (device); null -> pad_to
   int32_t items_per_query;   // > 0: rerank lists of a batch of queries in one launch -- item i uses the query whose rows start
                              // (i / items_per_query) * padded(n_q) rows into qhi / qlo / qfac; needs cand, n_q <= 64
+  const int64_t* row_off;    // nullable: packed layout (MaxsimArgs::row_off)
 };
 int launch_maxsim_fp8(const Fp8ScanArgs& a, hipStream_t s);
 // A batch of queries (n_queries * rows_per_query <= 512 rows, each query padded to rows_per_query with zero rows) against
@@ -285,6 +297,7 @@ struct Fp8BatchArgs {
   int32_t n_queries;
   int32_t rows_per_query;
   int32_t single_term;  // 1: hi term only (query rounded to e4m3: half the matrix work; coarse pass of a two-tier search)
+  const int64_t* row_off;  // nullable: packed layout
 };
 int launch_maxsim_batch_fp8(const Fp8BatchArgs& a, hipStream_t s);
 
@@ -303,8 +316,10 @@ int launch_read_bw_strided(const void* d_buf, int64_t n_rows, int piece, float* 
 int launch_mfma_peak(int blocks, int iters, int shape, float* d_sink, hipStream_t s);   // per iteration per wave: shape 0 = 8 x 16x16x32, 1 = 4 x 32x32x16 bf16 MFMA
 // scatter ragged bf16/f32 rows into the fixed-stride slab (zero-filling the tail of each page slot);
 // d_nonfinite (nullable): set to 1 when a row holds a NaN / Inf (in its bf16 image);
-// d_slab_lo_pages (nullable): the same slots of the lo slab receive bf16(x - bf16(x)) of fp32 input (zeros for bf16 input)
+// d_slab_lo_pages (nullable): the same slots of the lo slab receive bf16(x - bf16(x)) of fp32 input (zeros for bf16 input);
+// d_dst_row_off (nullable, packed layout): page i goes to rows [d_dst_row_off[i], d_dst_row_off[i + 1]) of d_slab_pages / d_slab_lo_pages
 int launch_scatter_rows(const void* d_src, int dtype, const int64_t* d_row_offsets, int64_t n_pages, int32_t stride,
-                        uint16_t* d_slab_pages, hipStream_t s, int32_t* d_nonfinite = nullptr, uint16_t* d_slab_lo_pages = nullptr);
+                        uint16_t* d_slab_pages, hipStream_t s, int32_t* d_nonfinite = nullptr, uint16_t* d_slab_lo_pages = nullptr,
+                        const int64_t* d_dst_row_off = nullptr);
 
 }  // namespace mv

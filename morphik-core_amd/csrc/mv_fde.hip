@@ -71,6 +71,7 @@ struct EncArgs {
   float* out_f32;
   uint16_t* out_bf16;
   float* out_inv_norm;
+  const int64_t* x_row_off;  // packed layout (with x_bf16): page i's rows start x_row_off[i] rows into x_bf16; null: i * stride
 };
 
 // One block per page; 4 waves split the repetitions; 64 rows staged per pass, transposed in LDS.
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void fde_encode_kernel(EncArgs a) {
     }
   } else {
     nr = a.n_rows ? a.n_rows[page] : a.stride;
-    r0 = page * (int64_t)a.stride;
+    r0 = a.x_row_off ? a.x_row_off[page] : page * (int64_t)a.stride;
   }
 
   for (int i = threadIdx.x; i < (int)a.out_dim; i += 256) acc[i] = 0.0f;
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void fde_encode_mfma_kernel(EncMArgs m) {
       }
     } else {
       nr = a.n_rows ? a.n_rows[page] : a.stride;
-      r0 = page * (int64_t)a.stride;
+      r0 = a.x_row_off ? a.x_row_off[page] : page * (int64_t)a.stride;
     }
     __syncthreads();  // tables staged / previous page's finish done with acc
     for (int i = threadIdx.x; i < (int)a.out_dim; i += 256) acc[i] = 0.0f;
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(256) void fde_hash_kernel(EncMArgs m, uint8_t* part
 
   for (int64_t page = blockIdx.x; page < m.n_pages; page += gridDim.x) {
     const int32_t nr = a.n_rows ? a.n_rows[page] : a.stride;
-    const uint16_t* pg = a.x_bf16 + (size_t)page * (size_t)a.stride * kDim;
+    const uint16_t* pg = a.x_bf16 + (a.x_row_off ? (size_t)a.x_row_off[page] : (size_t)page * (size_t)a.stride) * kDim;
     uint8_t* pp = parts + (size_t)page * (size_t)tiles_per_page * (size_t)a.R * 16;
     const int ntiles = (nr + 15) >> 4;
     uint2 nx[8];
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void fde_project_kernel(EncMArgs m, const u
   int parity = 0;
   for (int64_t page = blockIdx.x; page < m.n_pages; page += gridDim.x, parity ^= 1) {
     const int32_t nr = a.n_rows ? a.n_rows[page] : a.stride;
-    const uint16_t* pg = a.x_bf16 + (size_t)page * (size_t)a.stride * kDim;
+    const uint16_t* pg = a.x_bf16 + (a.x_row_off ? (size_t)a.x_row_off[page] : (size_t)page * (size_t)a.stride) * kDim;
     const uint8_t* pp = parts + (size_t)page * (size_t)tiles_per_page * (size_t)a.R * 16;
     const int ntiles = (nr + 15) >> 4;
     f32x4 acc[RPW][2];
@@ -1106,6 +1107,7 @@ int launch_fde_encode(const FdeTables& t, const FdeEncodeArgs& a, hipStream_t s)
   EncArgs k{};
   k.x_f32 = a.x_f32; k.x_bf16 = a.x_bf16; k.row_offsets = a.row_offsets; k.n_rows = a.n_rows;
   k.stride = a.stride; k.is_query = a.is_query;
+  k.x_row_off = a.x_bf16 ? a.x_row_off : nullptr;
   k.G = t.G;
   const char* after_S = reinterpret_cast<const char*>(t.S) + (size_t)R * D * 4;
   k.order = reinterpret_cast<const int32_t*>(after_S);
@@ -1143,7 +1145,8 @@ int launch_fde_encode(const FdeTables& t, const FdeEncodeArgs& a, hipStream_t s)
     for (int64_t p0 = 0; p0 < a.n_pages; p0 += chunk) {
       const int64_t c = std::min<int64_t>(chunk, a.n_pages - p0);
       EncArgs kc = k;
-      kc.x_bf16 = a.x_bf16 + (size_t)p0 * a.stride * kDim;
+      kc.x_bf16 = a.x_row_off ? a.x_bf16 : a.x_bf16 + (size_t)p0 * a.stride * kDim;  // packed: the offsets are absolute rows of the slab
+      kc.x_row_off = a.x_row_off ? a.x_row_off + p0 : nullptr;
       kc.n_rows = a.n_rows ? a.n_rows + p0 : nullptr;
       kc.out_f32 = a.out_f32 ? a.out_f32 + (size_t)p0 * t.out_dim : nullptr;
       kc.out_bf16 = a.out_bf16 ? a.out_bf16 + (size_t)p0 * t.out_dim : nullptr;

@@ -100,13 +100,16 @@ __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((uint32_t
 
 // ---------------------------------------------------------------- page quantisation (ingest side)
 // One block per page.  src = fixed-stride bf16 slab pages; rows >= n_rows become zero codes.
+// row_off (packed layout): the page's rows start row_off[page] rows into both slabs and its slot ends at row_off[page + 1].
 __global__ __launch_bounds__(256) void quantize_pages_kernel(const uint16_t* src, const int32_t* n_rows, int32_t stride,
-                                                             uint8_t* dst, float* inv_scale) {
+                                                             uint8_t* dst, float* inv_scale, const int64_t* row_off) {
   __shared__ uint32_t red[4];
   const int64_t page = blockIdx.x;
   const int nr = n_rows ? n_rows[page] : stride;
-  const uint16_t* sp = src + (size_t)page * stride * kDim;
-  uint8_t* dp = dst + (size_t)page * stride * kDim;
+  const size_t row0 = row_off ? (size_t)row_off[page] : (size_t)page * stride;
+  const int slot_rows = row_off ? (int)(row_off[page + 1] - row_off[page]) : stride;
+  const uint16_t* sp = src + row0 * kDim;
+  uint8_t* dp = dst + row0 * kDim;
   const int n8 = nr * (kDim / 8);  // 16-byte chunks of valid data
   uint32_t amax = 0;
   for (int i = threadIdx.x; i < n8; i += 256) {
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) void quantize_pages_kernel(const uint16_t* src
   const int e = pow2_scale_exp(amax << 16);
   const float sc = pow2f(e);
   if (threadIdx.x == 0) inv_scale[page] = pow2f(-e);
-  const int tot8 = stride * (kDim / 8);
+  const int tot8 = slot_rows * (kDim / 8);
   for (int i = threadIdx.x; i < tot8; i += 256) {
     uint2 out = make_uint2(0u, 0u);
     if (i < n8) {
@@ -201,7 +204,12 @@ struct F8Args {
   const int32_t* pad_items;  // per-item pad_to; null -> pad_to
   int32_t items_per_q;       // QITEM kernels: work item i scores against query i / items_per_q, whose rows start
   int32_t q_item_rows;       // (i / items_per_q) * q_item_rows rows into qhi / qlo / qfac (the rerank lists of a batch of queries)
+  const int64_t* row_off;    // packed layout: first slab row of every page; null: page * stride
 };
+
+__device__ __forceinline__ const char* f8_page_base(const F8Args& a, int64_t page) {
+  return reinterpret_cast<const char*>(a.slab) + (a.row_off ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride) * kF8RowBytes;
+}
 
 __device__ __forceinline__ bool f8_masked(const F8Args& a, int64_t page) {
   if (!a.doc_ord) return false;
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(256) void maxsim_fp8_kernel(F8Args a) {
   const int nslots = (nr + kF8SlotRows - 1) / kF8SlotRows;
   const bool clamp = (a.pad_items ? a.pad_items[item] : a.pad_to) > nr;
   const int nsw = (nslots - wave + 3) / 4;  // slots owned by this wave (may be <= 0)
-  const char* pbase = reinterpret_cast<const char*>(a.slab) + (size_t)page * (size_t)a.stride * kF8RowBytes;
+  const char* pbase = f8_page_base(a, page);
   char* ring = lds + wave * (D * kF8SlotBytes);
 
   // DMA source offsets: instruction i covers rows 8i..8i+7 of the slot; lane -> LDS row 8i + (lane>>3), chunk
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(256) void maxsim_fp8_pair_kernel(F8Args a) {
     nr[p] = live[p] ? (a.n_rows ? a.n_rows[page] : a.stride) : 0;
     const int nslots = (nr[p] + kF8SlotRows - 1) / kF8SlotRows;
     nsw[p] = max(0, (nslots - wave + 3) / 4);
-    pbase[p] = reinterpret_cast<const char*>(a.slab) + (size_t)page * (size_t)a.stride * kF8RowBytes;
+    pbase[p] = (item0 + p < a.n) ? f8_page_base(a, page) : reinterpret_cast<const char*>(a.slab);  // (no table entry behind the last page)
   }
   const int total = nsw[0] + nsw[1];
   char* ring = lds + wave * (D * kF8SlotBytes);
@@ -620,6 +628,7 @@ struct F8BatchArgs {
   int32_t stride;
   int32_t n_queries;
   int32_t rows_per_query;     // multiple of 16
+  const int64_t* row_off;     // packed layout
 };
 
 constexpr int kF8ChunkRows = 128;
@@ -696,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_batch_fp8_kernel(F8BatchArgs a)
     }
     const int ntiles = (nr + 15) >> 4;
     const int nchunks = (nr + kF8ChunkRows - 1) / kF8ChunkRows;
-    const char* pbase = reinterpret_cast<const char*>(a.slab) + (size_t)page * (size_t)a.stride * kF8RowBytes;
+    const char* pbase = reinterpret_cast<const char*>(a.slab) + (a.row_off ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride) * kF8RowBytes;
 
     auto issue = [&](int c) {  // wave w moves rows [32w, 32w+32) of chunk c (always issued: the slab is padded)
       const char* tp = pbase + (size_t)(c * 4 + wave) * 4096;
@@ -828,12 +837,16 @@ int launch_f8_batch_mtw(const F8BatchArgs& k, int grid, bool lo, hipStream_t s) 
 }  // namespace
 
 int launch_quantize_pages_fp8(const uint16_t* d_src_pages, const int32_t* d_n_rows, int32_t stride, int64_t n_pages,
-                              uint8_t* d_dst, float* d_inv_scale, hipStream_t s) {
+                              uint8_t* d_dst, float* d_inv_scale, hipStream_t s, const int64_t* d_row_off) {
   int64_t done = 0;
   while (done < n_pages) {
     const int64_t c = std::min<int64_t>(n_pages - done, (int64_t)1 << 22);
-    hipLaunchKernelGGL(quantize_pages_kernel, dim3((unsigned)c), dim3(256), 0, s, d_src_pages + (size_t)done * stride * kDim,
-                       d_n_rows ? d_n_rows + done : nullptr, stride, d_dst + (size_t)done * stride * kDim, d_inv_scale + done);
+    if (d_row_off)  // packed: the offsets are absolute rows of both slabs
+      hipLaunchKernelGGL(quantize_pages_kernel, dim3((unsigned)c), dim3(256), 0, s, d_src_pages, d_n_rows ? d_n_rows + done : nullptr, stride, d_dst,
+                         d_inv_scale + done, d_row_off + done);
+    else
+      hipLaunchKernelGGL(quantize_pages_kernel, dim3((unsigned)c), dim3(256), 0, s, d_src_pages + (size_t)done * stride * kDim,
+                         d_n_rows ? d_n_rows + done : nullptr, stride, d_dst + (size_t)done * stride * kDim, d_inv_scale + done, (const int64_t*)nullptr);
     done += c;
   }
   MV_HIP(hipGetLastError());
@@ -854,7 +867,7 @@ int launch_maxsim_fp8(const Fp8ScanArgs& a, hipStream_t s) {
   for (int q0 = 0, pass = 0; q0 < padded; q0 += 64, ++pass) {
     const int mt = std::min(4, (padded - q0) / 16);
     F8Args k{a.slab, a.inv_scale, a.n_rows, a.doc_ord, a.allow, a.n_allow_bits, a.cand,
-             a.qhi + (size_t)q0 * kDim, a.qlo + (size_t)q0 * kDim, a.qfac + q0, a.scores, a.n, a.stride, a.pad_to, 0, pass > 0, a.pad_items, a.items_per_query, padded};
+             a.qhi + (size_t)q0 * kDim, a.qlo + (size_t)q0 * kDim, a.qfac + q0, a.scores, a.n, a.stride, a.pad_to, 0, pass > 0, a.pad_items, a.items_per_query, padded, a.row_off};
     int rc;
     switch (mt) {
       case 1: rc = launch_f8_mt<1>(k, s); break;
@@ -873,7 +886,7 @@ int launch_maxsim_batch_fp8(const Fp8BatchArgs& a, hipStream_t s) {
   const int rows = a.n_queries * a.rows_per_query;
   if (rows > 512 || a.n_queries > 256) { set_error("fp8 batch scan: %d query rows exceed the 512-row group", rows); return MV_ERR_INVALID; }
   F8BatchArgs k{a.slab, a.inv_scale, a.n_rows, a.doc_ord, a.allow, a.n_allow_bits, a.allow_stride_bits, a.qhi, a.qlo, a.qfac, a.scores, a.n,
-                a.score_stride, a.stride, a.n_queries, a.rows_per_query};
+                a.score_stride, a.stride, a.n_queries, a.rows_per_query, a.row_off};
   static int ncu = 0;
   if (ncu == 0) {
     int dev = 0, v = 0;

@@ -45,6 +45,13 @@ struct mv_index {
   int32_t* d_n_rows = nullptr;
   int32_t* d_doc_ord = nullptr;
   std::vector<int32_t> h_n_rows, h_doc_ord;  // sized to capacity at create: never reallocated
+  // MV_LAYOUT_PACKED: pages lie back to back in whole 16-row tiles.  row_off[p] = first slab row of page p (a multiple of 16),
+  // row_off[p + 1] - row_off[p] = the rows its slot holds, row_off[size] = rows in use.  The row-indexed slabs (slab, slab_lo,
+  // slab8, bits) share the numbering.  Entries of published pages are immutable (compaction rewrites them under both locks).
+  bool packed = false;
+  int64_t cap_rows = 0;          // rows the row-indexed slabs hold (capacity_pages * stride_rows in the fixed layout)
+  int64_t* d_row_off = nullptr;  // [capacity + 1] (packed only; nullptr in the fixed layout: kernels then use page * stride)
+  std::vector<int64_t> h_row_off;
   std::atomic<int64_t> size{0};              // published pages
   std::atomic<bool> ragged{false};           // some page has n_rows != stride
   std::atomic<bool> tombstones{false};       // some page is deleted
@@ -153,6 +160,13 @@ struct mv_index {
 };
 
 namespace mv {
+
+// first slab row of a page / rows its slot holds, in either layout (host metadata)
+inline int64_t page_row0(const mv_index* ix, int64_t p) { return ix->packed ? ix->h_row_off[(size_t)p] : p * (int64_t)ix->cfg.stride_rows; }
+inline int32_t page_slot_rows(const mv_index* ix, int64_t p) {
+  return ix->packed ? (int32_t)(ix->h_row_off[(size_t)p + 1] - ix->h_row_off[(size_t)p]) : ix->cfg.stride_rows;
+}
+inline int64_t rows_in_use(const mv_index* ix, int64_t size) { return ix->packed ? ix->h_row_off[(size_t)size] : size * (int64_t)ix->cfg.stride_rows; }
 
 struct DeviceGuard {
   int prev = -1;

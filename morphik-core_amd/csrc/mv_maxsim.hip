@@ -55,7 +55,13 @@ struct KArgs {
   int32_t q_item_stride;     // (bf16 elements) -- the candidate lists of a batch of queries in ONE launch
   const uint16_t* qlo;       // LO >= 1: lo half of the query rows (bf16(q - bf16(q)); layout of q)
   const char* slab_lo;       // LO == 2: lo half of the page rows (layout of slab)
+  const int64_t* row_off;    // packed layout: first slab row of every page; null: page * stride
 };
+
+// byte offset of a page's first row in a slab of 256-byte rows
+__device__ __forceinline__ size_t page_byte_off(const KArgs& a, int64_t page) {
+  return (a.row_off ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride) * kRowBytes;
+}
 
 __device__ __forceinline__ bool page_masked(const KArgs& a, int64_t page) {
   if (!a.doc_ord) return false;
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(256) void maxsim_direct_kernel(KArgs a) {
 #pragma unroll
   for (int m = 0; m < MT; ++m) mx[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 
-  const size_t poff = (size_t)page * (size_t)a.stride * kRowBytes + r * kRowBytes + g * 16;
+  const size_t poff = page_byte_off(a, page) + r * kRowBytes + g * 16;
   const char* base = a.slab + poff;
   const char* base_lo = LO == 2 ? a.slab_lo + poff : nullptr;
   const int t0 = (WPP == 1) ? 0 : wave;
@@ -298,8 +304,9 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
   const int t0 = (WPP == 1) ? 0 : (CONTIG ? wave * tq : wave);
   const int tstep = CONTIG ? 1 : WPP;
   const int ntw = CONTIG ? max(0, min(tq, ntiles - t0)) : (ntiles - t0 + WPP - 1) / WPP;
-  const char* pbase = a.slab + (size_t)page * (size_t)a.stride * kRowBytes;
-  const char* plbase = LO == 2 ? a.slab_lo + (size_t)page * (size_t)a.stride * kRowBytes : nullptr;
+  const size_t pboff = page_byte_off(a, page);
+  const char* pbase = a.slab + pboff;
+  const char* plbase = LO == 2 ? a.slab_lo + pboff : nullptr;
   char* ring = lds + wave * (D * kItemBytes);
 
   // DMA source offsets: instruction i covers rows 4i..4i+3; lane -> row 4i+(lane>>4), position lane&15.
@@ -513,7 +520,7 @@ int launch_maxsim_bf16(const MaxsimArgs& a, int variant, hipStream_t s) {
     return MV_ERR_INVALID;
   }
   KArgs k{reinterpret_cast<const char*>(a.slab), a.n_rows, a.doc_ord, a.allow, a.n_allow_bits, a.cand, a.q, a.scores,
-          a.n, a.stride, a.pad_to, 0, a.pad_items, a.items_per_query, a.q_item_stride, a.qlo, reinterpret_cast<const char*>(a.slab_lo)};
+          a.n, a.stride, a.pad_to, 0, a.pad_items, a.items_per_query, a.q_item_stride, a.qlo, reinterpret_cast<const char*>(a.slab_lo), a.row_off};
   if (a.items_per_query < 0 || (a.items_per_query > 0 && !a.cand)) { set_error("items_per_query needs a candidate list"); return MV_ERR_INVALID; }
   if (a.slab_lo || a.qlo) {  // split-bf16 operands: the lo fragments double the query registers -- 64 query rows per pass
     if (!a.qlo) { set_error("the lo slab needs the query's lo half (zeros for a bf16 query)"); return MV_ERR_INVALID; }

@@ -34,6 +34,9 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
   return (uint16_t)(u >> 16);
 }
 
+// Four dims (chunk) of row `row` of unit `unit`: 32 lanes of a half-wave make one row (the norm is a half-wave reduction).
+__device__ __forceinline__ uint2 synth_row_chunk(uint64_t seed, uint64_t unit, int32_t row, int chunk);
+
 // One wave = two rows (32 lanes x 4 dims each).  dim fixed at 128.
 __global__ __launch_bounds__(256) void synth_rows_kernel(uint16_t* out, uint64_t seed, uint64_t first_unit,
                                                          int64_t n_units, int32_t n_rows, int32_t stride_rows) {
@@ -46,8 +49,29 @@ __global__ __launch_bounds__(256) void synth_rows_kernel(uint16_t* out, uint64_t
   const int32_t row = (int32_t)(grow - ui * stride_rows);
   const int chunk = lane & 31;
   uint2 packed = make_uint2(0u, 0u);
-  if (row < n_rows) {  // wave-uniform per half; rows >= n_rows are zero filled
-    const uint64_t unit = first_unit + (uint64_t)ui;
+  if (row < n_rows) packed = synth_row_chunk(seed, first_unit + (uint64_t)ui, row, chunk);  // wave-uniform per half; rows >= n_rows are zero filled
+  *reinterpret_cast<uint2*>(out + grow * kDim + chunk * 4) = packed;
+}
+
+// Ragged form: one block per unit; unit i gets its first n_rows[i] rows at base + row0(i) * 128 and zero rows up to the end of its
+// allotment (row_off[i + 1], or the stride slot).
+__global__ __launch_bounds__(256) void synth_rows_ragged_kernel(uint16_t* base, uint64_t seed, uint64_t first_unit, const int32_t* n_rows,
+                                                                const int64_t* row_off, int32_t stride_rows) {
+  const int64_t ui = blockIdx.x;
+  const int64_t r0 = row_off ? row_off[ui] : ui * (int64_t)stride_rows;
+  const int32_t slot = row_off ? (int32_t)(row_off[ui + 1] - r0) : stride_rows;
+  const int32_t nr = n_rows[ui];
+  const int half = threadIdx.x >> 5, chunk = threadIdx.x & 31;  // 8 rows per step
+  for (int32_t row = half; row < slot; row += 8) {
+    uint2 packed = make_uint2(0u, 0u);
+    if (row < nr) packed = synth_row_chunk(seed, first_unit + (uint64_t)ui, row, chunk);
+    *reinterpret_cast<uint2*>(base + (r0 + row) * kDim + chunk * 4) = packed;
+  }
+}
+
+__device__ __forceinline__ uint2 synth_row_chunk(uint64_t seed, uint64_t unit, int32_t row, int chunk) {
+  uint2 packed;
+  {
     uint32_t w[4];
     philox4x32_10((uint32_t)unit, (uint32_t)(unit >> 32), (uint32_t)row, (uint32_t)chunk, (uint32_t)seed,
                   (uint32_t)(seed >> 32), w);
@@ -71,7 +95,7 @@ __global__ __launch_bounds__(256) void synth_rows_kernel(uint16_t* out, uint64_t
     packed.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
     packed.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
   }
-  *reinterpret_cast<uint2*>(out + grow * kDim + chunk * 4) = packed;
+  return packed;
 }
 
 __global__ void f32_to_bf16_kernel(const float* in, uint16_t* out, int64_t n) {
@@ -88,14 +112,17 @@ __global__ void f32_to_bf16_kernel(const float* in, uint16_t* out, int64_t n) {
 }
 
 // One block per page: copy/convert rows [off[p], off[p+1]) into slab page p, zero the tail.
+// dst_row_off (packed layout): page p occupies rows [dst_row_off[p], dst_row_off[p + 1]) of the slab instead of the p-th stride slot.
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const void* src, int dtype, const int64_t* off, int32_t stride,
-                                                           uint16_t* slab, int32_t* nonfinite, uint16_t* slab_lo) {
+                                                           uint16_t* slab, int32_t* nonfinite, uint16_t* slab_lo, const int64_t* dst_row_off) {
   const int64_t p = blockIdx.x;
   const int64_t r0 = off[p];
   const int32_t nr = (int32_t)(off[p + 1] - r0);
-  uint16_t* dst = slab + p * (int64_t)stride * kDim;
-  uint16_t* dst_lo = slab_lo ? slab_lo + p * (int64_t)stride * kDim : nullptr;
-  const int total = stride * (kDim / 4);  // 4 elements per thread-step
+  const int64_t d0 = dst_row_off ? dst_row_off[p] : p * (int64_t)stride;
+  const int32_t slot_rows = dst_row_off ? (int32_t)(dst_row_off[p + 1] - d0) : stride;
+  uint16_t* dst = slab + d0 * kDim;
+  uint16_t* dst_lo = slab_lo ? slab_lo + d0 * kDim : nullptr;
+  const int total = slot_rows * (kDim / 4);  // 4 elements per thread-step
   for (int i = threadIdx.x; i < total; i += blockDim.x) {
     const int row = i / (kDim / 4), c4 = i % (kDim / 4);
     uint2 v = make_uint2(0u, 0u);
@@ -540,6 +567,18 @@ int launch_synth_rows(uint16_t* d_out, uint64_t seed, uint64_t first_unit, int64
   return MV_OK;
 }
 
+int launch_synth_rows_ragged(uint16_t* d_base, uint64_t seed, uint64_t first_unit, int64_t n_units, const int32_t* d_n_rows,
+                             const int64_t* d_row_off, int32_t stride_rows, hipStream_t s) {
+  // one block per unit; grid.x chunks of 2^22 units (the table pointers move with the chunk; d_base does so only in the fixed layout)
+  for (int64_t done = 0; done < n_units; done += (int64_t)1 << 22) {
+    const int64_t c = std::min<int64_t>(n_units - done, (int64_t)1 << 22);
+    hipLaunchKernelGGL(synth_rows_ragged_kernel, dim3((unsigned)c), dim3(256), 0, s, d_row_off ? d_base : d_base + done * (int64_t)stride_rows * kDim, seed,
+                       first_unit + (uint64_t)done, d_n_rows + done, d_row_off ? d_row_off + done : nullptr, stride_rows);
+  }
+  MV_HIP(hipGetLastError());
+  return MV_OK;
+}
+
 int launch_f32_to_bf16(const float* d_in, uint16_t* d_out, int64_t n, hipStream_t s) {
   if (n <= 0) return MV_OK;
   const int64_t per = (int64_t)1 << 32;  // elements per launch (2^30 threads x 4)
@@ -552,10 +591,10 @@ int launch_f32_to_bf16(const float* d_in, uint16_t* d_out, int64_t n, hipStream_
 }
 
 int launch_scatter_rows(const void* d_src, int dtype, const int64_t* d_row_offsets, int64_t n_pages, int32_t stride,
-                        uint16_t* d_slab_pages, hipStream_t s, int32_t* d_nonfinite, uint16_t* d_slab_lo_pages) {
+                        uint16_t* d_slab_pages, hipStream_t s, int32_t* d_nonfinite, uint16_t* d_slab_lo_pages, const int64_t* d_dst_row_off) {
   if (n_pages <= 0) return MV_OK;
   hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)n_pages), dim3(256), 0, s, d_src, dtype, d_row_offsets, stride,
-                     d_slab_pages, d_nonfinite, d_slab_lo_pages);
+                     d_slab_pages, d_nonfinite, d_slab_lo_pages, d_dst_row_off);
   MV_HIP(hipGetLastError());
   return MV_OK;
 }

@@ -28,6 +28,7 @@ from ._lib import (
     MV_WITH_HOST_EXACT,
     MV_WITH_EXACT_SPLIT,
     MV_WITH_FLOAT_LO,
+    MV_LAYOUT_PACKED,
     ConfigC,
     FdeConfigC,
     QueryStatsC,
@@ -177,6 +178,8 @@ class MvIndex:
         with_host_exact: bool = False,
         with_exact_split: bool = False,
         with_float_lo: bool = False,
+        packed: bool = False,
+        capacity_rows: int = 0,
     ):
         """with_host_exact: keep the exact bf16 rows in PINNED HOST memory (no HBM) as the exact tier of mode
         "fp8_then_float" -- for shards whose bf16 slab does not fit beside the fp8 slab.
@@ -184,12 +187,16 @@ class MvIndex:
         slabs leave free, only the rest is pinned (exact_hbm_pages tells the split).
         with_float_lo (with with_float): a second bf16 slab holding lo = bf16(x - bf16(x)) -- pages added as float32 keep 16
         significant bits (x = hi + lo to 2^-18), the candidate scorers and the float scan multiply both halves on the bf16 MFMA
-        and return the reference's fp32 scores (fast_multivector_store.py:553-555 on its fp32 `.npy` pages) to ~1e-6."""
+        and return the reference's fp32 scores (fast_multivector_store.py:553-555 on its fp32 `.npy` pages) to ~1e-6.
+        packed (MV_LAYOUT_PACKED): ragged pages lie back to back in whole 16-row tiles instead of one stride_rows slot each -- a
+        ColQwen2.5-like corpus (dynamic token counts, colpali_embedding_model.py:47-52) then takes the HBM of its valid rows, not of
+        its longest page; capacity_rows = rows the row-indexed slabs hold in all (0 = capacity_pages * stride_rows); stride_rows stays
+        the longest page accepted.  Same scores as the fixed layout, bit for bit."""
         self.fde_config = fde or FdeConfig()
         flags = ((MV_WITH_FLOAT if with_float else 0) | (MV_WITH_BINARY if with_binary else 0) | (MV_WITH_FDE if with_fde else 0)
                  | (MV_WITH_FP8 if with_fp8 else 0) | (MV_WITH_HOST_EXACT if with_host_exact else 0) | (MV_WITH_EXACT_SPLIT if with_exact_split else 0)
-                 | (MV_WITH_FLOAT_LO if with_float_lo else 0))
-        cfg = ConfigC(128, int(stride_rows), int(capacity_pages), int(device), flags, int(id_base), self.fde_config.to_c())
+                 | (MV_WITH_FLOAT_LO if with_float_lo else 0) | (MV_LAYOUT_PACKED if packed else 0))
+        cfg = ConfigC(128, int(stride_rows), int(capacity_pages), int(device), flags, int(id_base), self.fde_config.to_c(), int(capacity_rows) if packed else 0)
         h = C.c_void_p()
         check(lib().mv_index_create(C.byref(cfg), C.byref(h)))
         self._h = h
@@ -221,6 +228,16 @@ class MvIndex:
     @property
     def capacity(self) -> int:
         return int(lib().mv_index_capacity(self._h))
+
+    @property
+    def capacity_rows(self) -> int:
+        """Rows the row-indexed slabs hold (packed layout: the capacity_rows it was created with; fixed: capacity * stride_rows)."""
+        return int(lib().mv_index_capacity_rows(self._h))
+
+    @property
+    def rows_used(self) -> int:
+        """Slab rows taken by the pages appended so far (packed: whole 16-row tiles per page; fixed: pages * stride_rows)."""
+        return int(lib().mv_index_rows_used(self._h))
 
     def set_option(self, option: int, value: int) -> None:
         check(lib().mv_index_set_option(self._h, option, int(value)))
@@ -271,6 +288,11 @@ class MvIndex:
 
     def fill_synthetic(self, seed: int, first_unit: int, n_pages: int, n_rows: Optional[int] = None, pages_per_doc: int = 1) -> None:
         check(lib().mv_index_fill_synthetic(self._h, seed, first_unit, n_pages, self.stride_rows if n_rows is None else n_rows, pages_per_doc))
+
+    def fill_synthetic_ragged(self, seed: int, first_unit: int, n_pages: int, min_rows: int, max_rows: int, pages_per_doc: int = 1) -> None:
+        """Pages of the device generator with a different row count each (synth_ragged_rows(seed, unit, min_rows, max_rows)): the shape of
+        a ColQwen2.5 corpus.  Both layouts."""
+        check(lib().mv_index_fill_synthetic_ragged(self._h, seed, first_unit, n_pages, int(min_rows), int(max_rows), pages_per_doc))
 
     def write_rows(self, page: int, row0: int, rows_bf16: np.ndarray) -> None:
         r = np.ascontiguousarray(rows_bf16, dtype=np.uint16)
@@ -555,6 +577,17 @@ def fde_encode(x: Any, cfg: Optional[FdeConfig] = None, is_query: bool = False, 
     cc = cfg.to_c()
     check(lib().mv_fde_encode(device, C.byref(cc), a.ctypes.data, a.shape[0], 1 if is_query else 0, out.ctypes.data))
     return out
+
+
+def synth_ragged_rows(seed: int, unit: int, min_rows: int, max_rows: int) -> int:
+    """Row count of unit `unit` in a ragged synthetic corpus (mv_index_fill_synthetic_ragged): min_rows + splitmix64(seed ^ golden * (unit + 1))
+    % (max_rows - min_rows + 1).  Pure host arithmetic (the library computes the same on the host and uploads the counts)."""
+    m = (1 << 64) - 1
+    z = (int(seed) ^ (0x9E3779B97F4A7C15 * (int(unit) + 1))) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    z ^= z >> 31
+    return int(min_rows) + int(z % (int(max_rows) - int(min_rows) + 1))
 
 
 def synth_rows(seed: int, unit: int, n_rows: int, device: int = 0) -> np.ndarray:
