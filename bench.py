@@ -860,13 +860,59 @@ def aux_summary(out, aux):
         "fp32_split_max_rel_err": g("fp32_split_bf16", "max_rel_score_err_vs_fp32_reference"),
         "fp32_hi_lo_scan_frac": g("fp32_split_bf16", "scan_hi_plus_lo", "frac_hbm_8TBps"),
         "ragged_packed_valid_frac": g("ragged_corpus", "packed", "frac_hbm_8TBps_valid_bytes"),
-        "q_sweep_frac": g("query_length_sweep", "frac_hbm_8TBps"),
+        "ragged_fixed_valid_frac": g("ragged_corpus", "fixed_stride", "frac_hbm_8TBps_valid_bytes"),
+        "ragged_capacity_gain": g("ragged_corpus", "capacity_gain_packed_over_fixed"),
+        "q16_q64_frac": [g("query_length_sweep", "Q16", "frac_hbm_8TBps"), g("query_length_sweep", "Q64", "frac_hbm_8TBps")] if g("query_length_sweep", "Q16") else None,
         "aux_s": g("aux_child_seconds"),
     }
     rec = {k: v for k, v in rec.items() if v is not None}
     if "aux_child_error" in aux:
         rec["error"] = str(aux["aux_child_error"])[:80]
     return rec
+
+
+def ragged_block(args, device):
+    """A ColQwen2.5-like corpus (the reference's real encoder emits a different token count per page: colpali_embedding_model.py:47-52):
+    n_rows(page) uniform in 550..1024, on BOTH layouts -- fixed stride_rows slots and MV_LAYOUT_PACKED (whole 16-row tiles back to back).
+    The scan reads only a page's valid tiles either way, so the rate is quoted on VALID bytes; what the packed layout buys is HBM:
+    pages resident per GB."""
+    from morphik_core_amd import synth
+    from morphik_core_amd.index import MvIndex, synth_ragged_rows
+
+    import torch
+
+    stride = ((args.patches + 15) // 16) * 16
+    lo_rows, hi_rows = min(550, args.patches), args.patches
+    free_b, _tot = torch.cuda.mem_get_info(device)
+    n = int(min(args.ragged_pages, (free_b - (8 << 30)) // (stride * 256 + 64)))
+    rows = np.array([synth_ragged_rows(synth.SEED_CORPUS, u, lo_rows, hi_rows) for u in range(n)], np.int64)
+    valid_bytes = int(rows.sum()) * 256
+    slot_rows = int(((rows + 15) // 16 * 16).sum())
+    qs = [synth_rows_dev(synth.SEED_QUERIES, 2000 + j, args.qtokens, device) for j in range(4)]
+    res = {"pages": n, "rows_per_page": f"uniform {lo_rows}..{hi_rows} (mean {rows.mean():.1f})", "valid_GB": round(valid_bytes / 1e9, 2)}
+    ref = None
+    for name, kw in (("fixed_stride", {}), ("packed", {"packed": True, "capacity_rows": slot_rows})):
+        ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, **kw)
+        ix.fill_synthetic_ragged(synth.SEED_CORPUS, 0, n, lo_rows, hi_rows)
+        t = timed_mode(ix, qs, "float")
+        top = [ix.query(q, K) for q in qs]
+        if ref is None:
+            ref = top
+        ms = t["score_kernel_ms"]
+        slab_bytes = ix.capacity_rows * 256
+        res[name] = {"kernel_ms": round(ms, 4), "pages_per_s": round(n / ms * 1e3, 1), "valid_GBps": round(valid_bytes / ms / 1e6, 1),
+                     "frac_hbm_8TBps_valid_bytes": round(valid_bytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "slab_GB": round(slab_bytes / 1e9, 2),
+                     "pages_per_262GB_slab": int(262.144e9 / (slab_bytes / n)),
+                     "same_top10_as_fixed_stride": all(a[1].tolist() == b[1].tolist() and a[0].tolist() == b[0].tolist() for a, b in zip(top, ref))}
+        ix.close()
+    res["capacity_gain_packed_over_fixed"] = round(res["packed"]["pages_per_262GB_slab"] / res["fixed_stride"]["pages_per_262GB_slab"], 3)
+    return res
+
+
+def synth_rows_dev(seed, unit, n_rows, device):
+    from morphik_core_amd.index import synth_rows
+
+    return synth_rows(seed, unit, n_rows, device=device)
 
 
 def serving_block(args):
@@ -958,6 +1004,7 @@ def main():
                     help="share of the pin budget the PINNED part of a split exact tier may take (the page count is cut to keep it)")
     ap.add_argument("--full-shard-pages", type=int, default=1_250_000,
                     help="pages of the e4m3 + FDE + sign-bit index in aux_paths.full_shard (BASELINE configs[3]/[4] per-GPU shard of 10 M pages / 8 GPUs; 0 = skip)")
+    ap.add_argument("--ragged-pages", type=int, default=300_000, help="pages of the ColQwen-like ragged corpus (550..1024 rows per page) scanned on the fixed-stride and the packed layout (aux_paths.ragged_corpus; 0 = skip)")
     ap.add_argument("--aux-embed-pages", type=int, default=1000, help="pages of the full-size encoder run inside aux_paths (configs[1] names 1 k pages; 0 = skip)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend for N>1 (nccl == RCCL; gloo + MV_BENCH_SINGLE_DEVICE=1 lets N ranks share one GPU to "
@@ -1350,6 +1397,13 @@ def main():
                             "seconds": round(time.time() - t1, 1),
                             "median_rel_gap_rank10_rank11": {k_: float(np.median(v)) for k_, v in gaps.items()}}
             aux["batched_float"] = batched_float_block(ix, queries, n_local, args, None)
+            # the reference's queries run ~15-40 rows -- the default kernel at Q = 16 / 32 / 64 on the headline slab
+            sweep = {}
+            for qt in (16, 32, 64):
+                qs_q = [synth_rows(synth.SEED_QUERIES, 1000 + qt + j, qt, device=local_rank) for j in range(4)]
+                t = timed_mode(ix, qs_q, "float", n_timed=7, warm_s=0.15)
+                sweep[f"Q{qt}"] = scan_entry(n_local, args.patches * PAGE_ROW_BYTES, t["score_kernel_ms"])
+            aux["query_length_sweep"] = sweep
             for B in (4, 16):
                 res_b = ix.query_batch(queries[:B], K)
                 aux["batched_float"][f"B{B}"]["recall_at_10"] = float(np.mean([synth.recall_at_k(res_b[qi][1].tolist(), [p for (qq, _r, p, _a, _b) in spec if qq == qi])
@@ -1572,6 +1626,11 @@ def aux_child(args, local_rank):
             aux["serving"] = serving_block(args)
         except Exception as e:  # noqa: BLE001
             aux["serving"] = {"error": repr(e)}
+    if args.ragged_pages > 0:
+        try:  # a ColQwen-like ragged corpus on the fixed-stride and the packed layout
+            aux["ragged_corpus"] = ragged_block(args, local_rank)
+        except Exception as e:  # noqa: BLE001
+            aux["ragged_corpus"] = {"error": repr(e)}
     if args.aux_pages > 0:
         try:  # the fp32-faithful tier: split-bf16 pages + query against a numpy fp32 restatement, and what its scans cost
             aux["fp32_split_bf16"] = fp32_split_block(args, local_rank)

@@ -1101,6 +1101,8 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   if (!ix) { set_error("host allocation failed"); return MV_ERR_NOMEM; }
   ix->cfg = *cfg;
   const int64_t cap = cfg->capacity_pages;
+  ix->bscore_stride = cap;
+  if (const char* e = getenv("MV_BSCORE_STRIDE_PAD")) ix->bscore_stride = cap + std::max<int64_t>(0, (int64_t)strtoll(e, nullptr, 10));  // placement experiments
   ix->packed = (cfg->flags & MV_LAYOUT_PACKED) != 0;
   ix->cap_rows = (ix->packed && cfg->capacity_rows > 0) ? cfg->capacity_rows : cap * (int64_t)cfg->stride_rows;
   ix->cfg.capacity_rows = ix->cap_rows;
@@ -2023,8 +2025,8 @@ int mv_internal_ensure_fde_batch_ws(mv_index* ix) {
   const size_t lists = (size_t)kFdeBatchMaxQueries * kTopkMaxDeviceK;
   if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)kBatchQRows * kRowBytes));
   if (!ix->d_bscores) {
-    hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->cfg.capacity_pages * 4);
-    if (e != hipSuccess) { ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->cfg.capacity_pages * 4); return MV_ERR_NOMEM; }
+    hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->bscore_stride * 4);
+    if (e != hipSuccess) { ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->bscore_stride * 4); return MV_ERR_NOMEM; }
   }
   if (!ix->d_bqf32) MV_HIP(hipMalloc(&ix->d_bqf32, (size_t)kBatchQRows * kDim * 4));
   if (!ix->d_bqfde) MV_HIP(hipMalloc(&ix->d_bqfde, (size_t)kFdeBatchMaxQueries * out_dim * 4));
@@ -2048,8 +2050,8 @@ int mv_internal_ensure_fp8_batch_ws(mv_index* ix) {
   int rc = mv_internal_ensure_batch_select_ws(ix);
   if (rc) return rc;
   if (!ix->d_bscores) {
-    hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->cfg.capacity_pages * 4);
-    if (e != hipSuccess) { ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->cfg.capacity_pages * 4); return MV_ERR_NOMEM; }
+    hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->bscore_stride * 4);
+    if (e != hipSuccess) { ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->bscore_stride * 4); return MV_ERR_NOMEM; }
   }
   const size_t lists = (size_t)kFdeBatchMaxQueries * kTopkMaxDeviceK;
   if (!ix->d_bqf32) MV_HIP(hipMalloc(&ix->d_bqf32, (size_t)kBatchQRows * kDim * 4));
@@ -2205,7 +2207,7 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
   if (rc) return rc;
   const bool need_meta = ix->tombstones.load() || d_allow != nullptr;
   const int64_t out_dim = ix->fde_t.out_dim;
-  const int64_t cap = ix->cfg.capacity_pages;
+  const int64_t cap = ix->bscore_stride;  // elements between two requests' score vectors (the capacity + MV_BSCORE_STRIDE_PAD)
   int64_t nc = std::min<int64_t>(std::min<int64_t>(coarse_n_for(ix, k), n), kTopkMaxDeviceK);
   if (nc < 1) nc = 1;
   const int64_t L = nc;  // the per-query lists lie back to back: [query][nc]
@@ -2370,7 +2372,7 @@ static int fp8_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
     a.slab = ix->slab8; a.inv_scale = ix->inv_scale8; a.n_rows = ix->ragged.load() ? ix->d_n_rows : nullptr; a.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
     a.allow = per_query ? d_allow + (size_t)b0 * n_allow_words : d_allow; a.n_allow_bits = n_allow_words * 32;
     a.allow_stride_bits = per_query ? n_allow_words * 32 : 0;
-    a.qhi = ix->d_bq8hi; a.qlo = ix->d_bq8lo; a.qfac = ix->d_bq8fac; a.scores = ix->d_bscores; a.n = n; a.score_stride = ix->cfg.capacity_pages;
+    a.qhi = ix->d_bq8hi; a.qlo = ix->d_bq8lo; a.qfac = ix->d_bq8fac; a.scores = ix->d_bscores; a.n = n; a.score_stride = ix->bscore_stride;
     a.stride = ix->cfg.stride_rows; a.n_queries = nb; a.rows_per_query = rpq; a.row_off = ix->d_row_off;
     // two-tier search: the first stage only NOMINATES candidates and the exact tier restores their order, so by default it runs with ONE
     // e4m3 term per query row (half the matrix work: 9.9 vs 16.3 ms per 16 requests at 200 k pages; recall@10 1.0 on every corpus of
@@ -2380,7 +2382,7 @@ static int fp8_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
     if (rc) return rc;
     if (two_tier) {
       // fp8 top-n of every request (local page ids) -> rerank lists -> exact bf16 scores from the exact tier, one launch
-      rc = launch_topk_batch(ix->d_bscores, ix->cfg.capacity_pages, n, (int32_t)nc, nullptr, 0, 0, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bsel_s,
+      rc = launch_topk_batch(ix->d_bscores, ix->bscore_stride, n, (int32_t)nc, nullptr, 0, 0, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bsel_s,
                              ix->d_bsel_id, nc, nb, ix->stream);
       if (rc) return rc;
       hipLaunchKernelGGL(cand_prepare_kernel, dim3((unsigned)((nc + kRerankBatch - 1) / kRerankBatch), (unsigned)nb), dim3(kRerankBatch), 0, ix->stream,
@@ -2396,7 +2398,7 @@ static int fp8_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
       if (rc) return rc;
     } else {
       MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
-      rc = launch_topk_batch(ix->d_bscores, ix->cfg.capacity_pages, n, k, nullptr, 0, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bout_s,
+      rc = launch_topk_batch(ix->d_bscores, ix->bscore_stride, n, k, nullptr, 0, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bout_s,
                              ix->d_bout_id, k, nb, ix->stream);
       if (rc) return rc;
     }
@@ -2481,8 +2483,8 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
   const int group = std::min(group_rows / rpq, 32);
   if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)kBatchQRows * kRowBytes));
   if (!ix->d_bscores) {
-    hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->cfg.capacity_pages * 4);
-    if (e != hipSuccess) { ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->cfg.capacity_pages * 4); return MV_ERR_NOMEM; }
+    hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->bscore_stride * 4);
+    if (e != hipSuccess) { ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->bscore_stride * 4); return MV_ERR_NOMEM; }
   }
   const bool per_query = allow_bits && allow_per_query;
   const uint32_t* d_allow = nullptr;
@@ -2512,13 +2514,13 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
     a.slab = ix->slab; a.n_rows = ragged ? ix->d_n_rows : nullptr; a.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
     a.allow = per_query ? d_allow + (size_t)b0 * n_allow_words : d_allow; a.n_allow_bits = n_allow_words * 32;
     a.allow_stride_bits = per_query ? n_allow_words * 32 : 0; a.q = ix->d_bq; a.scores = ix->d_bscores; a.n = n;
-    a.score_stride = ix->cfg.capacity_pages; a.stride = ix->cfg.stride_rows; a.n_queries = nb; a.rows_per_query = rpq; a.row_off = ix->d_row_off;
+    a.score_stride = ix->bscore_stride; a.stride = ix->cfg.stride_rows; a.n_queries = nb; a.rows_per_query = rpq; a.row_off = ix->d_row_off;
     a.variant = ix->batch_variant >= 0 ? ix->batch_variant : 0;  // auto: page-split form up to 128 rows, transposed row-split form above
     rc = launch_maxsim_batch(a, ix->stream);
     if (rc) return rc;
     MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
     // the group's selections in one chain of launches (grid.y = query), one read-back, one synchronisation
-    rc = launch_topk_batch(ix->d_bscores, ix->cfg.capacity_pages, n, k, nullptr, 0, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bout_s,
+    rc = launch_topk_batch(ix->d_bscores, ix->bscore_stride, n, k, nullptr, 0, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bout_s,
                            ix->d_bout_id, k, nb, ix->stream);
     if (rc) return rc;
     MV_HIP(hipEventRecord(ix->ev[2], ix->stream));

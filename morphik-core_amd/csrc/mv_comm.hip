@@ -346,7 +346,7 @@ int mv_internal_two_stage_batch_coarse(mv_index* ix, const void* q, int q_dtype,
   rc = upload_allow(ix, allow_bits, per_query ? n_allow_words * (int64_t)nb : n_allow_words, &d_allow);
   if (rc) return rc;
   const bool need_meta = ix->tombstones.load() || d_allow != nullptr;
-  const int64_t cap = ix->cfg.capacity_pages;
+  const int64_t cap = ix->bscore_stride;  // elements between two requests' score vectors
   bool prebinned = false;
   if (fde) {
     FdeEncodeArgs e{};

@@ -77,7 +77,8 @@ struct mv_index {
   uint8_t* d_q8lo = nullptr;
   float* d_q8fac = nullptr;    // 2^-s per query row
   uint16_t* d_bq = nullptr;    // [kBatchQRows][128] bf16 query block of the batched scans
-  float* d_bscores = nullptr;  // [32][capacity] per-query score vectors of the batched scan (lazily allocated)
+  float* d_bscores = nullptr;  // [32][bscore_stride] per-query score vectors of the batched scan (lazily allocated)
+  int64_t bscore_stride = 0;   // elements between two requests' score vectors: capacity_pages (+ MV_BSCORE_STRIDE_PAD from the environment)
   // batched FDE pipeline (mv_query_topk_batch in the FDE modes; lazily allocated, up to 32 queries per slab pass)
   float* d_bqf32 = nullptr;        // [kBatchQRows][128] fp32 query rows of the group, [query][rows padded to 16][128], zero rows behind each query
   float* d_bqfde = nullptr;        // [32][out_dim] fp32 query FDEs

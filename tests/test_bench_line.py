@@ -108,7 +108,7 @@ def test_default_aux_run_last_line_is_the_compact_headline():
     the headline, short, with roofline.frac and cpu_baseline.value; the timed region fits the wall clock of the run; the aux
     record is an earlier line and a file."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--pages", "50000", "--cpu-sample-pages", "512", "--cpu-baseline-quick",
-           "--full-shard-pages", "50000", "--exact-shard-pages", "50000", "--aux-pages", "8000", "--aux-embed-pages", "0", "--aux-serve-seconds", "0.15"]
+           "--full-shard-pages", "50000", "--exact-shard-pages", "50000", "--aux-pages", "8000", "--aux-embed-pages", "0", "--aux-serve-seconds", "0.15", "--ragged-pages", "6000"]
     t0 = time.time()
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200, cwd=ROOT)
     wall = time.time() - t0
@@ -127,7 +127,7 @@ def test_default_aux_run_last_line_is_the_compact_headline():
     _check_headline(json.dumps(earlier[0]))
     aux = earlier[1]["aux_paths"]
     assert "aux_child_error" not in aux, aux
-    for key in ("truth", "batched_float", "full_shard", "exact_shard", "fp8_then_float", "fde_document_encode", "serving", "fp32_split_bf16"):
+    for key in ("truth", "batched_float", "query_length_sweep", "full_shard", "exact_shard", "fp8_then_float", "fde_document_encode", "serving", "fp32_split_bf16", "ragged_corpus"):
         assert key in aux and "error" not in aux[key], (key, aux.get(key))
     # the secondary kernels' figures travel in the driver-parsed line itself
     summ = d["aux_summary"]
@@ -135,6 +135,9 @@ def test_default_aux_run_last_line_is_the_compact_headline():
                 "fp8_then_float_recall", "fp32_split_max_rel_err", "fp32_hi_lo_scan_frac"):
         assert key in summ, (key, summ)
     assert len(json.dumps(summ)) <= 900 and summ["fp32_split_max_rel_err"] < 1e-4
+    rg = aux["ragged_corpus"]
+    assert rg["packed"]["same_top10_as_fixed_stride"] and rg["capacity_gain_packed_over_fixed"] > 1.2 and summ["ragged_packed_valid_frac"] == rg["packed"]["frac_hbm_8TBps_valid_bytes"]
+    assert set(aux["query_length_sweep"]) == {"Q16", "Q32", "Q64"}
     assert summ["fp8_scan_frac"] == aux["full_shard"]["fp8_scan"]["frac_hbm_8TBps"]
     assert json.load(open(os.path.join(ROOT, "gpurun_out", "bench_aux.json")))["aux_paths"].keys() == aux.keys()
 

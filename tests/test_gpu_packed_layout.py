@@ -52,7 +52,9 @@ def test_packed_float_scan_and_candidates_equal_the_fixed_layout_bit_for_bit(var
         a, b = fx.score_all(q), pk.score_all(q)
         _same(a, b)
         want = np.array([orc.maxsim_bf16(q, p) for p in pages], np.float32)
-        np.testing.assert_allclose(b, want, rtol=1e-4, atol=1e-6)
+        alive = np.array([not (nq != 21 and i == 7) for i in range(len(pages))])  # page 7 is removed at the end of the first round
+        np.testing.assert_allclose(b[alive], want[alive], rtol=1e-4, atol=1e-6)
+        assert np.all(np.isneginf(b[~alive]))
         cand = [1, 4, 11, 12, 15, 16, 23, 0]
         _same(fx.score_candidates(q, cand, 208), pk.score_candidates(q, cand, 208))
         _same(fx.score_candidates(q, np.arange(len(pages)), pad_to=-1), pk.score_candidates(q, np.arange(len(pages)), pad_to=-1))
