@@ -1121,3 +1121,46 @@ def test_encoder_start_ups_with_fused_ops_and_tuned_gemms_stay_clean_in_fresh_pr
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, "encoder_startup_stress.json"), "w") as f:
         json.dump(log, f, indent=1)
+
+
+@pytest.mark.parametrize("cls_name,mode", [("MI355XFastMultiVectorStore", "fde_then_float"), ("MI355XMultiVectorStore", "float")])
+def test_store_with_fp32_pages_returns_the_references_fp32_scores(cls_name, mode):
+    """FastMultiVectorStore reranks fp32 pages (`.npy`, fast_multivector_store.py:676-681 / :736) with an fp32 query (:553-555).  With
+    fp32_pages=True the drop-in keeps hi + lo (MV_WITH_FLOAT_LO) and `score` is that fp32 score to ~1e-6 -- through the plugin call
+    `await store.query_similar(...)`, single and on two shards; without the flag the pages are bf16 (3e-4 on this data)."""
+    import morphik_core_amd.store as st
+    from oracle import oracle as orc  # checker only
+
+    rng = np.random.default_rng(17)
+    chunks = sc.make_chunks(rng, n_docs=4, chunks_per_doc=3, rows=30)
+    for c in chunks:  # unit rows that are NOT bf16-representable
+        e = rng.standard_normal((30, 128)).astype(np.float32)
+        c.embedding = e / np.linalg.norm(e, axis=-1, keepdims=True)
+    q = rng.standard_normal((20, 128)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    want = {(c.document_id, c.chunk_number): orc.maxsim_f32(q, c.embedding) for c in chunks}
+    errs = {}
+    for flag in (True, False):
+        s = getattr(st, cls_name)(capacity_pages=32, stride_rows=32, mode=mode, fp32_pages=flag)
+        assert s.initialize() is True
+        try:
+            sc.run(s.store_embeddings(chunks, app_id="t"))
+            hits = sc.run(s.query_similar(q, k=12, app_id="t"))
+            assert len(hits) == 12
+            errs[flag] = max(abs(h.score - want[(h.document_id, h.chunk_number)]) / abs(want[(h.document_id, h.chunk_number)]) for h in hits)
+            if flag:
+                order = sorted(want, key=lambda k_: -want[k_])
+                assert [(h.document_id, h.chunk_number) for h in hits] == order
+        finally:
+            s.close()
+    assert errs[True] < 2e-5 and errs[True] < errs[False] / 10, errs
+    # two shards behind one store object
+    sh_cls = st.MI355XShardedFastMultiVectorStore if mode == "fde_then_float" else st.MI355XShardedMultiVectorStore
+    s2 = sh_cls(devices=[0, 0], capacity_pages=32, stride_rows=32, mode=mode, fp32_pages=True)
+    assert s2.initialize() is True
+    try:
+        sc.run(s2.store_embeddings(chunks, app_id="t"))
+        hits = sc.run(s2.query_similar(q, k=12, app_id="t"))
+        assert max(abs(h.score - want[(h.document_id, h.chunk_number)]) / abs(want[(h.document_id, h.chunk_number)]) for h in hits) < 2e-5
+    finally:
+        s2.close()

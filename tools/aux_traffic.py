@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM bytes per page of the e4m3 / sign-bit / FDE scans and of the batched FDE pass from the two PMC summaries of
-tools/r4_aux_traffic_probe.py (FETCH_SIZE x the correction measured on the known 4 GiB read of the same pass, + WRITE_SIZE).
-   python tools/r4_aux_traffic.py fetch.json write.json pages out.json"""
+tools/aux_traffic_probe.py (FETCH_SIZE x the correction measured on the known 4 GiB read of the same pass, + WRITE_SIZE).
+   python tools/aux_traffic.py fetch.json write.json pages out.json"""
 import json
 import sys
 
@@ -14,7 +14,7 @@ def main(fetch_json, write_json, pages, out):
     corr = (4 << 30) / (f[cal[0]]["FETCH_SIZE"]["avg"] * 1024.0)
     want = {"maxsim_fp8_pair_kernel": ("e4m3 scan", 1024 * 128), "maxsim_fp8_kernel": ("e4m3 scan, one page per workgroup (candidate lists)", 1024 * 128), "maxsim_binary_mfma2_kernel": ("sign-bit scan", 1024 * 16),
             "fde_scan_rowq_kernel": ("FDE coarse scan (row quarters, default since round 5)", 20480), "fde_scan_kernel": ("FDE coarse scan (register form)", 20480), "fde_scan_batch2_kernel": ("batched FDE coarse pass, 32 requests", 20480)}
-    rec = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on tools/r4_aux_traffic_probe.py, MI355X", "pages": pages,
+    rec = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on tools/aux_traffic_probe.py, MI355X", "pages": pages,
            "gfx950_fetch_correction": corr, "kernels": {}}
     for key, (name, alg) in want.items():
         ks = [k for k in f if key in k]

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Workload for the PMC traffic passes over the OTHER scans (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per run): a known-size read
 for the gfx950 FETCH_SIZE correction, then the e4m3 scan, the sign-bit scan, the FDE coarse scan and the batched FDE coarse pass (32 requests)
-over one index, three launches each.  tools/r4_aux_traffic.py turns the two summaries into bytes per page against the algorithmic figure.
-   python tools/r4_aux_traffic_probe.py [pages=400000]"""
+over one index, three launches each.  tools/aux_traffic.py turns the two summaries into bytes per page against the algorithmic figure.
+   python tools/aux_traffic_probe.py [pages=400000]"""
 import ctypes as C
 import os
 import sys

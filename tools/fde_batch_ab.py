@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of the batched FDE coarse pass forms (MV_OPT_FDE_BATCH_VARIANT) in ONE process (interleaved rounds, stats.coarse_ms), identical answers asserted.
-   python tools/r4_fde_batch_ab.py [pages=1250000] [forms=0,6]"""
+   python tools/fde_batch_ab.py [pages=1250000] [forms=0,6]"""
 import json
 import os
 import sys

@@ -7,6 +7,7 @@
 #   bench            the driver's command (python bench.py --steps 20 --warmup 5)    -> bench_1gpu_1M_pages_{stdout,stderr}.txt, bench_headline.json, bench_detail_and_aux.json
 #   bench_rocprof    the same (no aux, no CPU leg) under rocprofv3 --kernel-trace --stats -> rocprofv3_kernel_stats_bench_1M.csv, bench_under_rocprofv3.json
 #   pmc_traffic      FETCH_SIZE / WRITE_SIZE passes (separate runs) of the headline kernel -> pmc_traffic_<round>.json (hash-tied to the library; also copied to profiles/<round>/)
+#   pmc_traffic_aux [pages]  the same two passes over the secondary scans (e4m3, sign-bit, FDE)   -> pmc_traffic_aux_scans_<round>.json
 #   batch_sq [pages] SQ counters (two counter-only passes) of the batched bf16 scan at B = 16 -> pmc_sq_batched_bf16_B16.json, batch_scan_probe.jsonl
 #   fde_batch_sq [pages]  SQ / TCC counters of the batched FDE coarse pass, one process per placement -> pmc_fde_batch_modes.json (tools/fde_batch_mode_probe.py)
 #   binary_sq [pages] SQ counters of the sign-bit scan                                -> pmc_sq_sign_bit_scan.json
@@ -54,6 +55,12 @@ case $what in
       pmc_pass traffic_$C $C python $R/tools/variant_bench.py --pages 50000 --variants 6 --rounds 3 --no-batch
     done
     python $R/tools/pmc_traffic.py $OUT/pmc_traffic_FETCH_SIZE.raw.json $OUT/pmc_traffic_WRITE_SIZE.raw.json 50000 $OUT/pmc_traffic_$ROUND.json && mkdir -p $R/profiles/$ROUND && cp $OUT/pmc_traffic_$ROUND.json $R/profiles/$ROUND/pmc_traffic_$ROUND.json ;;
+  pmc_traffic_aux)
+    pages=${1:-400000}
+    for C in FETCH_SIZE WRITE_SIZE; do
+      pmc_pass aux_traffic_$C $C python $R/tools/aux_traffic_probe.py $pages
+    done
+    python $R/tools/aux_traffic.py $OUT/pmc_aux_traffic_FETCH_SIZE.raw.json $OUT/pmc_aux_traffic_WRITE_SIZE.raw.json $pages $OUT/pmc_traffic_aux_scans_$ROUND.json | head -30 ;;
   batch_sq)
     pages=${1:-200000}
     (cd $R && python tools/batch_scan_probe.py $pages ${2:-0:16,0:4} 5 > $OUT/batch_scan_probe.jsonl 2> $OUT/batch_scan_probe.err; cat $OUT/batch_scan_probe.jsonl)

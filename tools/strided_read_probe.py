@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What the batched FDE coarse pass's ACCESS PATTERN alone sustains (mv_calibrate, no LDS / barriers / MFMA): a [rows][20 480 B] matrix
 read tile by tile with 512 B (the pass's K chunk) / 1 / 2 / 4 KiB per row and step, whole rows, and the contiguous nt stream.
-   python tools/r4_strided_read_probe.py [GiB=24]"""
+   python tools/strided_read_probe.py [GiB=24]"""
 import ctypes as C
 import json
 import os
