@@ -601,12 +601,58 @@ def exact_shard(args, device, n, n_truth, budget, split, sets, truths, gaps):
     ix.set_option(L.MV_OPT_EXACT_TIER, 0)
     res["recall_s"] = round(time.time() - t0, 1)
     ix.set_option(L.MV_OPT_FDE_COARSE_N, 1000)
+    if split and in_hbm < n:
+        try:  # placement of the split tier: the pages the reranks read most move into its HBM part (mv_index_exact_tier_rebalance)
+            res["hot_pages_in_hbm"] = hot_pages_block(ix, rsets["clustered_topics"]["queries"], allow_truth)
+        except Exception as e:  # noqa: BLE001
+            res["hot_pages_in_hbm"] = {"error": repr(e)}
     ix.close()
     if split and args.exact_shard_lean:
         try:
             res["lean_fde_plus_split_exact_tier"] = exact_shard_lean(args, device, n, n_truth, budget, sets, truths, gaps)
         except Exception as e:  # noqa: BLE001
             res["lean_fde_plus_split_exact_tier"] = {"error": repr(e)}
+    return res
+
+
+def hot_pages_block(ix, cq, allow):
+    """The split exact tier keeps the LEADING pages in HBM; mv_index_exact_tier_rebalance keeps the HOT ones there (read counts per page
+    from every rerank).  Clustered-topics queries (overlapping candidate sets: the case a serving corpus presents) at coarse top-1000
+    (e4m3 pruning to 128 exact reads per request), 32 requests per pass: device time of a batch and the share of the exact reads that
+    crossed PCIe, before and after ONE rebalance trained on the first 32 queries; the other 32 queries of the same topics were never
+    seen by the counters.  Answers must not change."""
+    train, test = cq[:32], cq[32:64]
+
+    def batch(qs32):
+        dev, out = [], None
+        for r in range(6):
+            out, st = ix.query_batch(qs32, K, mode="fde_then_float", want_stats=True, allow=allow)
+            if r >= 2:
+                dev.append(st.total_device_ms)
+        return float(np.median(dev)), [o[1].tolist() for o in out], [o[0].tolist() for o in out]
+
+    def share(qs32):
+        h0 = ix.exact_tier_hits()
+        ix.query_batch(qs32, K, mode="fde_then_float", allow=allow)
+        h1 = ix.exact_tier_hits()
+        hb, ho = h1[0] - h0[0], h1[1] - h0[1]
+        return round(ho / max(hb + ho, 1), 4)
+
+    ix.rebalance_exact_tier(max_moves=1)  # (clears the counters the earlier measurements left; one swap at most)
+    res = {"queries": "clustered_topics: 32 train + 32 unseen of the same topics; coarse top-1000 -> e4m3 pruning -> 128 exact reads per request, 32 requests per pass"}
+    res["share_of_exact_reads_over_pcie_before"] = {"train": share(train), "unseen": share(test)}
+    ix.rebalance_exact_tier(max_moves=1)
+    b_ms, b_ids, b_sc = batch(train)
+    t0 = time.time()
+    moved = ix.rebalance_exact_tier()
+    res["pages_moved_into_hbm"] = moved
+    res["rebalance_s"] = round(time.time() - t0, 2)
+    a_ms, a_ids, a_sc = batch(train)
+    u_ms, _ui, _us = batch(test)
+    ix.rebalance_exact_tier(max_moves=1)
+    res["share_of_exact_reads_over_pcie_after"] = {"train": share(train), "unseen": share(test)}
+    res["batch_of_32_device_ms"] = {"train_before": round(b_ms, 4), "train_after": round(a_ms, 4), "unseen_after": round(u_ms, 4)}
+    res["same_ids_and_scores_as_before"] = a_ids == b_ids and a_sc == b_sc
     return res
 
 
@@ -854,6 +900,8 @@ def aux_summary(out, aux):
         "batched_bf16_B16_frac_2500TF": g("batched_float", "B16", "frac_mfma_bf16_2500TF"),
         "fde_request_ms": g("exact_shard", "fde_then_exact_rerank", "coarse75", "one_request", "device_ms"),
         "fde_batch32_exact_ms": g("exact_shard", "fde_then_exact_rerank", "coarse1000", "batch_of_32", "device_ms_per_batch"),
+        "hot_pages_batch32_ms": [g("exact_shard", "hot_pages_in_hbm", "batch_of_32_device_ms", "train_before"), g("exact_shard", "hot_pages_in_hbm", "batch_of_32_device_ms", "train_after"),
+                                 g("exact_shard", "hot_pages_in_hbm", "batch_of_32_device_ms", "unseen_after")] if g("exact_shard", "hot_pages_in_hbm", "batch_of_32_device_ms") else None,
         "fp8_recall_hard": g("exact_shard", "recall_at_10_vs_exact_bf16", "hard_negatives", "fp8_scan"),
         "fp8_then_float_recall": g("exact_shard", "recall_at_10_vs_exact_bf16", "hard_negatives", "fp8_then_float_n128"),
         "fde75_recall_hard": g("exact_shard", "recall_at_10_vs_exact_bf16", "hard_negatives", "fde_top75_then_exact"),

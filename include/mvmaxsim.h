@@ -217,6 +217,14 @@ MV_API int64_t mv_index_rows_used(const mv_index* ix);     /* slab rows taken by
                                                               fixed layout: pages * stride_rows) */
 MV_API int64_t mv_index_capacity_rows(const mv_index* ix); /* rows the row-indexed slabs hold */
 MV_API int64_t mv_index_exact_hbm_pages(const mv_index* ix); /* pages of a split exact tier (MV_WITH_EXACT_SPLIT) whose rows live in HBM; 0 otherwise */
+/* PLACEMENT of a split exact tier.  Every rerank counts, per page, the reads of its exact rows; mv_index_exact_tier_rebalance swaps the
+ * most-read pages that live in pinned host memory with the least-read pages that live in HBM (while a swap raises the HBM part's
+ * read count; at most max_moves swaps, 0 = no limit), then clears the counters.  Page ids, answers and scores are unchanged -- only
+ * where a page's exact rows are read from: the PCIe share of a rerank falls to the share of COLD candidates.  Exclusive with queries
+ * and writers for its duration (2 x 256 KiB over PCIe per swap).  A store calls it after compaction or from a maintenance task.
+ * mv_index_exact_tier_hits: reads since the last rebalance that were served from HBM / from host memory.  No-ops without a split. */
+MV_API int mv_index_exact_tier_rebalance(mv_index* ix, int64_t max_moves, int64_t* out_moved);
+MV_API int mv_index_exact_tier_hits(mv_index* ix, int64_t* out_hbm_reads, int64_t* out_host_reads);
 
 /* NON-FINITE VALUES.  A NaN / +-Inf embedding has no defined MaxSim (the reference's torch einsum -> max -> topk propagates NaN
  * and ranks it FIRST), and the scan kernels are compiled without NaN handling.  So they never enter a float-derived slab:

@@ -262,7 +262,7 @@ int launch_cand_prepare(mv_index* ix, const int64_t* d_ids64, const int32_t* d_i
 int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_words, const int32_t* d_cand, int64_t n_items,
                int32_t pad_to, const int32_t* d_pad_items, float* d_out, int* launches, bool no_mask = false,
                const uint16_t* d_q_base = nullptr, const uint16_t* slab_override = nullptr, const uint16_t* d_qlo_base = nullptr,
-               const uint16_t* slab_lo = nullptr) {
+               const uint16_t* slab_lo = nullptr, const int64_t* row_off_override = nullptr) {
   if (n_items <= 0) return MV_OK;  // nothing to launch (a grid of 0 blocks is an invalid configuration)
   const uint16_t* qbase = d_q_base ? d_q_base : ix->d_q;  // padded bf16 query rows (a batch keeps its queries in d_bq)
   // split-bf16 operands: the query's lo rows (single query: d_qlo when upload_query filled it; a batch block: the caller's d_qlo_base)
@@ -309,7 +309,7 @@ int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_w
     MaxsimArgs a{};
     a.qlo = lo_q ? qlo_base + (size_t)done * kDim : nullptr;
     a.slab_lo = slab_lo;
-    a.row_off = ix->d_row_off;  // packed layout (never together with a host exact tier: slab_override then is the slab itself)
+    a.row_off = row_off_override ? row_off_override : ix->d_row_off;  // packed layout, or the placement table of a rebalanced split exact tier (never both)
     a.slab = slab_override ? slab_override : ix->slab;  // the exact tier of FP8_THEN_FLOAT may be pinned host memory mapped into the device
     a.n_rows = ragged ? ix->d_n_rows : nullptr;
     a.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
@@ -394,12 +394,17 @@ int rerank_scan(mv_index* ix, int n_q, int tier, int64_t n_items, float* d_out, 
 }
 
 // ---- the exact host tier, possibly split: pages [0, x_split) in HBM (slab_x), pages [x_split, capacity) in pinned host memory
-__global__ __launch_bounds__(256) void split_cand_kernel(const int32_t* cand, int64_t n, int32_t split, int32_t* lo, int32_t* hi) {
+// loc (nullable): page -> slot of the tier after a rebalance (identity otherwise); a slot below `split` is HBM.  hits (nullable): one
+// count per page whose exact rows this rerank reads -- what mv_index_exact_tier_rebalance ranks pages by.
+__global__ __launch_bounds__(256) void split_cand_kernel(const int32_t* cand, int64_t n, int32_t split, int32_t* lo, int32_t* hi, const int32_t* loc,
+                                                         uint32_t* hits) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int32_t c = cand[i];
-  lo[i] = (c >= 0 && c < split) ? c : -1;
-  hi[i] = c >= split ? c : -1;
+  const int32_t s = c < 0 ? -1 : (loc ? loc[c] : c);
+  lo[i] = (c >= 0 && s < split) ? c : -1;
+  hi[i] = (c >= 0 && s >= split) ? c : -1;
+  if (hits && c >= 0) atomicAdd(&hits[c], 1u);
 }
 __global__ __launch_bounds__(256) void max_scores_kernel(float* dst, const float* src, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -430,17 +435,21 @@ int exact_scan(mv_index* ix, int n_q, int tier, const int32_t* d_cand, int64_t n
   int32_t* lo = ix->d_xcand;
   int32_t* hi = ix->d_xcand + kMaxCand;
   const unsigned gb = (unsigned)((n_items + 255) / 256);
-  hipLaunchKernelGGL(split_cand_kernel, dim3(gb), dim3(256), 0, ix->stream, d_cand, n_items, (int32_t)ix->x_split, lo, hi);
-  rc = float_scan(ix, n_q, nullptr, 0, lo, n_items, pad_to, d_pad_items, d_out, launches, true, d_q_base, ix->slab_x, d_qlo_base);
+  hipLaunchKernelGGL(split_cand_kernel, dim3(gb), dim3(256), 0, ix->stream, d_cand, n_items, (int32_t)ix->x_split, lo, hi, (const int32_t*)ix->d_xloc, ix->d_xhits);
+  // one row-offset table serves both parts: slot * stride rows from slab_x, or from the host part's virtual base (slot x_split = its row 0)
+  rc = float_scan(ix, n_q, nullptr, 0, lo, n_items, pad_to, d_pad_items, d_out, launches, true, d_q_base, ix->slab_x, d_qlo_base, nullptr, ix->d_xoff);
   if (rc) return rc;
-  rc = float_scan(ix, n_q, nullptr, 0, hi, n_items, pad_to, d_pad_items, ix->d_xscores, launches, true, d_q_base, xt_host_vbase(ix), d_qlo_base);
+  rc = float_scan(ix, n_q, nullptr, 0, hi, n_items, pad_to, d_pad_items, ix->d_xscores, launches, true, d_q_base, xt_host_vbase(ix), d_qlo_base, nullptr, ix->d_xoff);
   if (rc) return rc;
   hipLaunchKernelGGL(max_scores_kernel, dim3(gb), dim3(256), 0, ix->stream, d_out, (const float*)ix->d_xscores, n_items);
   MV_HIP(hipGetLastError());
   return MV_OK;
 }
 
+static inline int64_t xt_slot(const mv_index* ix, int64_t page) { return ix->x_loc.empty() ? page : ix->x_loc[(size_t)page]; }
+
 // Store the fixed-stride bf16 image of pages [first, first + n) (device memory `d_src`) into the exact host tier on `st`.
+// (New pages: slot == page -- only published pages are ever re-placed, so the slots behind the published prefix are free.)
 int xt_store_from_device(mv_index* ix, const uint16_t* d_src, int64_t first, int64_t n, hipStream_t st) {
   if (!ix->h_exact && !ix->slab_x) return MV_OK;
   const size_t pe = page_elems(ix);
@@ -453,6 +462,7 @@ int xt_store_from_device(mv_index* ix, const uint16_t* d_src, int64_t first, int
 int xt_store_rows_from_host(mv_index* ix, int64_t page, int32_t row0, int32_t n_rows, const void* bf16_rows, bool zero_rest) {
   if (!ix->h_exact && !ix->slab_x) return MV_OK;
   const size_t pe = page_elems(ix);
+  page = xt_slot(ix, page);  // where the page's rows live (a rebalanced split tier)
   if (page < ix->x_split) {
     uint16_t* dst = ix->slab_x + (size_t)page * pe;
     if (zero_rest) MV_HIP(hipMemsetAsync(dst, 0, pe * 2, ix->stream));
@@ -468,6 +478,15 @@ int xt_store_rows_from_host(mv_index* ix, int64_t page, int32_t row0, int32_t n_
 // Copy whole pages [page0, page0 + n) of the tier to a HOST buffer.
 int xt_read_pages(mv_index* ix, int64_t page0, int64_t n, void* out) {
   const size_t pe = page_elems(ix);
+  if (!ix->x_loc.empty()) {  // rebalanced: page by page through the placement table
+    for (int64_t i = 0; i < n; ++i) {
+      const int64_t s = ix->x_loc[(size_t)(page0 + i)];
+      char* o = (char*)out + (size_t)i * pe * 2;
+      if (s < ix->x_split) MV_HIP(hipMemcpy(o, ix->slab_x + (size_t)s * pe, pe * 2, hipMemcpyDeviceToHost));
+      else memcpy(o, ix->h_exact + (size_t)(s - ix->x_split) * pe, pe * 2);
+    }
+    return MV_OK;
+  }
   const int64_t n_hbm = std::max<int64_t>(0, std::min<int64_t>(page0 + n, ix->x_split) - page0);
   if (n_hbm > 0) MV_HIP(hipMemcpy(out, ix->slab_x + (size_t)page0 * pe, (size_t)n_hbm * pe * 2, hipMemcpyDeviceToHost));
   if (n > n_hbm) memcpy((char*)out + (size_t)n_hbm * pe * 2, ix->h_exact + (size_t)(page0 + n_hbm - ix->x_split) * pe, (size_t)(n - n_hbm) * pe * 2);
@@ -476,8 +495,10 @@ int xt_read_pages(mv_index* ix, int64_t page0, int64_t n, void* out) {
 // Compaction of the tier: page live[j] moves to slot j for j in [first_moved, m) (live ascending, live[j] >= j: a destination is
 // never a page still to be read).  Device destinations are stream-ordered copies (from the HBM part or up from the pinned part),
 // then the host part moves with memmove.
+static int xt_restore_identity(mv_index* ix);
 int xt_compact(mv_index* ix, const std::vector<int64_t>& live, int64_t first_moved, int64_t m) {
   if (!ix->h_exact && !ix->slab_x) return MV_OK;
+  if (int rc = xt_restore_identity(ix)) return rc;  // a rebalanced tier goes back to slot == page first (the next rebalance re-places the hot pages)
   const size_t pe = page_elems(ix), pb = pe * 2;
   const int64_t sp = ix->x_split;
   for (int64_t j = first_moved; j < std::min(m, sp); ++j) {
@@ -489,6 +510,89 @@ int xt_compact(mv_index* ix, const std::vector<int64_t>& live, int64_t first_mov
   MV_HIP(hipStreamSynchronize(ix->stream));  // before the host part below overwrites pages the copies above read
   for (int64_t j = std::max(first_moved, sp); j < m; ++j)
     if (live[(size_t)j] != j) memmove(ix->h_exact + (size_t)(j - sp) * pe, ix->h_exact + (size_t)(live[(size_t)j] - sp) * pe, pb);
+  return MV_OK;
+}
+
+// ---- placement of a split exact tier: hot pages in the HBM part
+static inline uint16_t* xt_slot_ptr(mv_index* ix, int64_t slot) {
+  const size_t pe = page_elems(ix);
+  return slot < ix->x_split ? ix->slab_x + (size_t)slot * pe : ix->h_exact + (size_t)(slot - ix->x_split) * pe;
+}
+static inline hipMemcpyKind xt_kind(const mv_index* ix, int64_t dst_slot, int64_t src_slot) {
+  const bool dd = dst_slot < ix->x_split, sd = src_slot < ix->x_split;
+  return dd ? (sd ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) : (sd ? hipMemcpyDeviceToHost : hipMemcpyHostToHost);
+}
+static int xt_ensure_tables(mv_index* ix) {
+  if (!ix->x_loc.empty()) return MV_OK;
+  const int64_t cap = ix->cfg.capacity_pages;
+  ix->x_loc.resize((size_t)cap);
+  ix->x_page_at.resize((size_t)cap);
+  for (int64_t p = 0; p < cap; ++p) ix->x_loc[(size_t)p] = ix->x_page_at[(size_t)p] = (int32_t)p;
+  if (!ix->d_xloc) MV_HIP(hipMalloc(&ix->d_xloc, (size_t)cap * 4));
+  if (!ix->d_xoff) MV_HIP(hipMalloc(&ix->d_xoff, (size_t)cap * 8));
+  return MV_OK;
+}
+static int xt_upload_tables(mv_index* ix) {
+  const int64_t cap = ix->cfg.capacity_pages;
+  std::vector<int64_t> off((size_t)cap);
+  for (int64_t p = 0; p < cap; ++p) off[(size_t)p] = (int64_t)ix->x_loc[(size_t)p] * ix->cfg.stride_rows;
+  MV_HIP(hipMemcpy(ix->d_xloc, ix->x_loc.data(), (size_t)cap * 4, hipMemcpyHostToDevice));
+  MV_HIP(hipMemcpy(ix->d_xoff, off.data(), (size_t)cap * 8, hipMemcpyHostToDevice));
+  return MV_OK;
+}
+// Exchange the contents of slot pairs (any mix of HBM and pinned-host slots) through a ring of device staging pages, stream-ordered;
+// the tables follow.  Exclusive access (both locks) is the caller's.
+static int xt_swap_slots(mv_index* ix, const std::vector<std::pair<int64_t, int64_t>>& pairs) {
+  if (pairs.empty()) return MV_OK;
+  const size_t pb = page_elems(ix) * 2;
+  const int ring = (int)std::min<size_t>(pairs.size(), 64);
+  char* stg = nullptr;
+  if (hipMalloc(&stg, (size_t)ring * pb) != hipSuccess) { set_error("exact tier placement: out of device memory for %zu bytes of staging", (size_t)ring * pb); return MV_ERR_NOMEM; }
+  int rc = MV_OK;
+  for (size_t i = 0; i < pairs.size() && !rc; ++i) {
+    const int64_t a = pairs[i].first, b = pairs[i].second;
+    char* t = stg + (i % ring) * pb;
+    if (i && i % ring == 0 && hipStreamSynchronize(ix->stream) != hipSuccess) { set_error("exact tier placement: stream error"); rc = MV_ERR_HIP; break; }
+    if (a >= ix->x_split && b >= ix->x_split) {
+      // both in pinned host memory (only when a composed placement is undone): a host swap, ordered behind the stream's copies
+      if (hipStreamSynchronize(ix->stream) != hipSuccess) { set_error("exact tier placement: stream error"); rc = MV_ERR_HIP; break; }
+      std::vector<char> tmp(pb);
+      memcpy(tmp.data(), xt_slot_ptr(ix, a), pb);
+      memcpy(xt_slot_ptr(ix, a), xt_slot_ptr(ix, b), pb);
+      memcpy(xt_slot_ptr(ix, b), tmp.data(), pb);
+    } else {
+      hipError_t e = hipMemcpyAsync(t, xt_slot_ptr(ix, a), pb, a < ix->x_split ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ix->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(xt_slot_ptr(ix, a), xt_slot_ptr(ix, b), pb, xt_kind(ix, a, b), ix->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(xt_slot_ptr(ix, b), t, pb, b < ix->x_split ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ix->stream);
+      if (e != hipSuccess) { rc = hip_fail(e, "exact tier placement copy", __FILE__, __LINE__); break; }
+    }
+    const int32_t pa = ix->x_page_at[(size_t)a], pbg = ix->x_page_at[(size_t)b];
+    ix->x_page_at[(size_t)a] = pbg; ix->x_page_at[(size_t)b] = pa;
+    ix->x_loc[(size_t)pbg] = (int32_t)a; ix->x_loc[(size_t)pa] = (int32_t)b;
+  }
+  if (hipStreamSynchronize(ix->stream) != hipSuccess && !rc) { set_error("exact tier placement: stream error"); rc = MV_ERR_HIP; }
+  (void)hipFree(stg);
+  if (!rc) rc = xt_upload_tables(ix);
+  return rc;
+}
+// Back to slot == page (compaction and the bulk checkpoint paths assume it): every swap puts at least one page home.
+static int xt_restore_identity(mv_index* ix) {
+  if (ix->x_loc.empty()) return MV_OK;
+  const int64_t n = ix->size.load();
+  std::vector<int32_t> at(ix->x_page_at.begin(), ix->x_page_at.begin() + n);  // simulate, collect the swaps, apply them in one go
+  std::vector<std::pair<int64_t, int64_t>> pairs;
+  for (int64_t s0 = 0; s0 < n; ++s0)
+    while (at[(size_t)s0] != s0) {
+      const int64_t p = at[(size_t)s0];  // the page in slot s0 belongs into slot p
+      pairs.emplace_back(s0, p);
+      std::swap(at[(size_t)s0], at[(size_t)p]);
+    }
+  int rc = xt_swap_slots(ix, pairs);
+  if (rc) return rc;
+  // identity again: drop the tables (the kernels fall back to page * stride)
+  ix->x_loc.clear(); ix->x_page_at.clear();
+  if (ix->d_xloc) { (void)hipFree(ix->d_xloc); ix->d_xloc = nullptr; }
+  if (ix->d_xoff) { (void)hipFree(ix->d_xoff); ix->d_xoff = nullptr; }
   return MV_OK;
 }
 
@@ -1052,7 +1156,7 @@ void mv_index_destroy(mv_index* ix) {
   DeviceGuard g(ix->cfg.device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
   if (ix->w_stream) (void)hipStreamSynchronize(ix->w_stream);
-  void* ptrs[] = {ix->d_row_off, ix->slab_lo, ix->d_qlo, ix->d_bqlo, ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
+  void* ptrs[] = {ix->d_xloc, ix->d_xoff, ix->d_xhits, ix->d_row_off, ix->slab_lo, ix->d_qlo, ix->d_bqlo, ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
                   ix->d_topk_ws, ix->d_q, ix->d_qf32, ix->d_qbits, ix->d_qpop, ix->d_qfde, ix->d_qoff, ix->d_allow, ix->d_out_s,
                   ix->d_out_id, ix->d_cand, ix->d_cand_scores, ix->d_bqf32, ix->d_bqfde, ix->d_bqimage, ix->d_btopk_ws, ix->d_bsel_s,
                   ix->d_bsel_id, ix->d_bcand, ix->d_bcand_pads, ix->d_bcand_scores, ix->d_bout_s, ix->d_bout_id, ix->d_bq8hi, ix->d_bq8lo, ix->d_bq8fac};
@@ -1193,6 +1297,10 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
       if (const char* e = getenv("MV_EXACT_HBM_MAX_PAGES")) split = std::min<int64_t>(split, (int64_t)strtoll(e, nullptr, 10));  // (tests: force a split on a small index)
       ix->x_split = std::max<int64_t>(0, std::min<int64_t>(cap, split));
       if (ix->x_split > 0) alloc((void**)&ix->slab_x, (size_t)ix->x_split * page_b + 32768, "HBM part of the exact tier");  // +32 KiB: whole DMA chunks
+      if (ix->x_split > 0 && ix->x_split < cap) {  // a real split: count the exact reads per page (mv_index_exact_tier_rebalance ranks by them)
+        alloc((void**)&ix->d_xhits, (size_t)cap * 4, "exact-tier hit counters");
+        if (!rc && hipMemset(ix->d_xhits, 0, (size_t)cap * 4) != hipSuccess) { set_error("hipMemset of the hit counters failed"); rc = MV_ERR_HIP; }
+      }
     }
     const size_t host_b = (size_t)(cap - ix->x_split) * page_b;
     if (!rc && host_b) {
@@ -1223,6 +1331,63 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
 }
 
 int64_t mv_index_exact_hbm_pages(const mv_index* ix) { return ix ? ix->x_split : 0; }
+
+int mv_index_exact_tier_hits(mv_index* ix, int64_t* out_hbm_reads, int64_t* out_host_reads) {
+  if (!ix) { set_error("null index"); return MV_ERR_INVALID; }
+  if (out_hbm_reads) *out_hbm_reads = 0;
+  if (out_host_reads) *out_host_reads = 0;
+  if (!ix->d_xhits) return MV_OK;  // not a split tier
+  ExclusiveLock lk(ix);
+  DeviceGuard g(ix->cfg.device);
+  const int64_t n = ix->size.load();
+  std::vector<uint32_t> h((size_t)std::max<int64_t>(n, 1));
+  MV_HIP(hipStreamSynchronize(ix->stream));
+  MV_HIP(hipMemcpy(h.data(), ix->d_xhits, (size_t)n * 4, hipMemcpyDeviceToHost));
+  int64_t hb = 0, ho = 0;
+  for (int64_t p = 0; p < n; ++p) (xt_slot(ix, p) < ix->x_split ? hb : ho) += h[(size_t)p];
+  if (out_hbm_reads) *out_hbm_reads = hb;
+  if (out_host_reads) *out_host_reads = ho;
+  return MV_OK;
+}
+
+int mv_index_exact_tier_rebalance(mv_index* ix, int64_t max_moves, int64_t* out_moved) {
+  if (!ix) { set_error("null index"); return MV_ERR_INVALID; }
+  if (out_moved) *out_moved = 0;
+  if (!ix->d_xhits) return MV_OK;  // no split: nothing to place
+  ExclusiveLock lk(ix);
+  DeviceGuard g(ix->cfg.device);
+  const int64_t n = ix->size.load();
+  if (n <= ix->x_split) return MV_OK;  // every published page already sits in HBM
+  std::vector<uint32_t> h((size_t)n);
+  MV_HIP(hipStreamSynchronize(ix->stream));
+  MV_HIP(hipMemcpy(h.data(), ix->d_xhits, (size_t)n * 4, hipMemcpyDeviceToHost));
+  // hot pages now in pinned host memory (most read first) against cold pages now in HBM (least read first): swap while it pays
+  std::vector<int32_t> hot, cold;
+  for (int64_t p = 0; p < n; ++p) {
+    if (ix->h_doc_ord[(size_t)p] < 0) { if (xt_slot(ix, p) < ix->x_split) cold.push_back((int32_t)p); continue; }  // a tombstoned page in HBM is the best victim
+    if (xt_slot(ix, p) < ix->x_split) cold.push_back((int32_t)p);
+    else if (h[(size_t)p] > 0) hot.push_back((int32_t)p);
+  }
+  auto heat = [&](int32_t p) { return ix->h_doc_ord[(size_t)p] < 0 ? 0u : h[(size_t)p]; };
+  std::sort(hot.begin(), hot.end(), [&](int32_t a, int32_t b) { return heat(a) > heat(b) || (heat(a) == heat(b) && a < b); });
+  std::sort(cold.begin(), cold.end(), [&](int32_t a, int32_t b) { return heat(a) < heat(b) || (heat(a) == heat(b) && a > b); });
+  size_t k = std::min(hot.size(), cold.size());
+  if (max_moves > 0) k = std::min<size_t>(k, (size_t)max_moves);
+  size_t m = 0;
+  while (m < k && heat(hot[m]) > heat(cold[m])) ++m;
+  if (m > 0) {
+    int rc = xt_ensure_tables(ix);
+    if (rc) return rc;
+    std::vector<std::pair<int64_t, int64_t>> pairs;
+    pairs.reserve(m);
+    for (size_t i = 0; i < m; ++i) pairs.emplace_back(ix->x_loc[(size_t)cold[i]], ix->x_loc[(size_t)hot[i]]);  // (HBM slot, host slot)
+    rc = xt_swap_slots(ix, pairs);
+    if (rc) return rc;
+  }
+  MV_HIP(hipMemset(ix->d_xhits, 0, (size_t)ix->cfg.capacity_pages * 4));  // the next window starts empty
+  if (out_moved) *out_moved = (int64_t)m;
+  return MV_OK;
+}
 
 int mv_index_set_option(mv_index* ix, int option, int64_t value) {
   if (!ix) { set_error("null index"); return MV_ERR_INVALID; }
@@ -1747,6 +1912,7 @@ int mv_index_compact(mv_index* ix, int64_t* out_old_to_new, int64_t* out_new_siz
     MV_HIP(hipMemcpy(ix->d_row_off, ix->h_row_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
   }
   if ((rc = xt_compact(ix, live, first_moved, m)) != MV_OK) return rc;  // the exact host tier moves with the pages
+  if (ix->d_xhits) MV_HIP(hipMemset(ix->d_xhits, 0, (size_t)ix->cfg.capacity_pages * 4));  // page ids changed: the read counts start over
   for (int64_t j = first_moved; j < m; ++j) {
     ix->h_n_rows[(size_t)j] = ix->h_n_rows[(size_t)live[j]];
     ix->h_doc_ord[(size_t)j] = ix->h_doc_ord[(size_t)live[j]];
@@ -2161,7 +2327,8 @@ int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t n
       int32_t* lo = ix->d_xcand;
       int32_t* hi = ix->d_xcand + kMaxCand;
       const unsigned gb = (unsigned)((n + 255) / 256);
-      hipLaunchKernelGGL(split_cand_kernel, dim3(gb), dim3(256), 0, ix->stream, (const int32_t*)ix->d_bcand, n, (int32_t)ix->x_split, lo, hi);
+      hipLaunchKernelGGL(split_cand_kernel, dim3(gb), dim3(256), 0, ix->stream, (const int32_t*)ix->d_bcand, n, (int32_t)ix->x_split, lo, hi, (const int32_t*)ix->d_xloc, ix->d_xhits);
+      if (ix->d_xoff) ma.row_off = ix->d_xoff;  // a rebalanced tier: page -> slot * stride rows (serves both parts, see exact_scan)
       ma.slab = ix->slab_x; ma.cand = lo;
       if ((rc = launch_maxsim_bf16(ma, rr_variant, ix->stream)) != MV_OK) return rc;
       ma.slab = xt_host_vbase(ix); ma.cand = hi; ma.scores = ix->d_xscores;
@@ -2979,8 +3146,16 @@ int mv_index_save(mv_index* ix, const char* path) {
   if (ix->cfg.flags & MV_WITH_HOST_EXACT) {  // the exact host tier, last: ONE logical stream of pages whatever the split (a load may split elsewhere)
     const size_t pb = (size_t)ix->cfg.stride_rows * kRowBytes;
     const int64_t n_hbm = std::min<int64_t>(size, ix->x_split);
-    if (n_hbm > 0) dump(ix->slab_x, (size_t)n_hbm * pb);
-    if (size > n_hbm) wr(ix->h_exact, (size_t)(size - n_hbm) * pb);
+    if (!ix->x_loc.empty()) {  // a rebalanced split tier: page by page through the placement table (the file keeps page order)
+      for (int64_t p2 = 0; p2 < size && !rc; ++p2) {
+        const int64_t sl = ix->x_loc[(size_t)p2];
+        if (sl < ix->x_split) dump(ix->slab_x + (size_t)sl * (pb / 2), pb);
+        else wr(ix->h_exact + (size_t)(sl - ix->x_split) * (pb / 2), pb);
+      }
+    } else {
+      if (n_hbm > 0) dump(ix->slab_x, (size_t)n_hbm * pb);
+      if (size > n_hbm) wr(ix->h_exact, (size_t)(size - n_hbm) * pb);
+    }
   }
   if (!rc && (fflush(f) != 0 || fsync(fileno(f)) != 0)) { set_error("flush failed for %s", tmp.c_str()); rc = MV_ERR_IO; }
   if (fclose(f) != 0 && !rc) { set_error("close failed for %s", tmp.c_str()); rc = MV_ERR_IO; }

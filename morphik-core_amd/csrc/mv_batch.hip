@@ -119,7 +119,7 @@ __device__ __forceinline__ void bk_write_scores(const BKArgs& a, const float* re
 // 4 MFMAs instead of 4 (the fragment registers are the same either way: lane l holds row l&15, k-slice 8(l>>4)).  The 24
 // registers this frees at 8 query tiles per wave pay for a second set of page fragments: tile t+1 is read from LDS while
 // tile t multiplies.
-template <int MTW, int S>
+template <int MTW, int S, bool PK = false>  // PK: packed layout (row-offset table); a template parameter so the fixed layout's code is untouched
 __global__ __launch_bounds__(256, 2) void maxsim_batch_kernel(BKArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[S * kChunkBytes + 64 * MTW * 4 + 4 * MTW * 4];
   float* red = reinterpret_cast<float*>(lds + S * kChunkBytes);  // [64 * MTW] row maxima of the current page
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_batch_kernel(BKArgs a) {
     }
     const int ntiles = (nr + kTileRows - 1) / kTileRows;
     const int nchunks = (ntiles + kChunkTiles - 1) / kChunkTiles;
-    const char* pbase = a.slab + (a.row_off ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride) * kRowBytes;
+    const char* pbase = a.slab + (PK ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride) * kRowBytes;
 
     // wave w moves tile w of chunk c (always issued: the slab is padded, rows past n_rows are never consumed)
     auto issue = [&](int c) {
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_batch_kernel(BKArgs a) {
 // the single-query scan's transport is kept as it is -- four waves per page, every wave DMAs its own interleaved 4 KiB
 // tiles into a wave-private 4-slot ring, no barrier in the loop (mv_maxsim.hip) -- and every wave holds ALL query
 // rows (MT <= 8 tiles).  MFMA roles transposed as above: one running maximum per query tile, v_max3_f32.
-template <int MT, int D>
+template <int MT, int D, bool PK = false>
 __global__ __launch_bounds__(256, 2) void maxsim_batch_ps_kernel(BKArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[4 * D * kTileBytes + 4 * 128 * 4 + 8 * 4];
   float* red = reinterpret_cast<float*>(lds + 4 * D * kTileBytes);  // [4 waves][128 rows]; row maxima land in red[0..128)
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_batch_ps_kernel(BKArgs a) {
   }
   const int ntiles = (nr + kTileRows - 1) / kTileRows;
   const int ntw = (ntiles - wave + 3) / 4;  // tiles wave, wave + 4, ... (may be <= 0)
-  const char* pbase = a.slab + (a.row_off ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride) * kRowBytes;
+  const char* pbase = a.slab + (PK ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride) * kRowBytes;
   char* ring = lds + wave * (D * kTileBytes);
 
   int src_off[4];
@@ -410,7 +410,8 @@ int launch_batch_mtw(const BKArgs& k, int grid, hipStream_t s) {
   // and that stream WITHOUT the per-chunk barrier as a timing probe: both ran in exactly the time of this kernel
   // (profiles/r2/batched_variants_200k_barrier_probe.json: 18.85 / 19.17 / 19.03 ms at B = 16), i.e. neither page-start
   // bubbles nor barrier skew limit it; see DESIGN.md 3.5 for what does.)
-  hipLaunchKernelGGL((maxsim_batch_kernel<MTW, 4>), dim3((unsigned)grid), dim3(256), 0, s, k);
+  if (k.row_off) hipLaunchKernelGGL((maxsim_batch_kernel<MTW, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, k);
+  else hipLaunchKernelGGL((maxsim_batch_kernel<MTW, 4>), dim3((unsigned)grid), dim3(256), 0, s, k);
   MV_HIP(hipGetLastError());
   return MV_OK;
 }
@@ -448,14 +449,14 @@ int launch_maxsim_batch(const BatchArgs& a, hipStream_t s) {
       kk.scores = a.scores + off;
       const dim3 gr((unsigned)kk.n), bl(256);
       switch (mt) {
-        case 1: hipLaunchKernelGGL((maxsim_batch_ps_kernel<1, 4>), gr, bl, 0, s, kk); break;
-        case 2: hipLaunchKernelGGL((maxsim_batch_ps_kernel<2, 4>), gr, bl, 0, s, kk); break;
-        case 3: hipLaunchKernelGGL((maxsim_batch_ps_kernel<3, 4>), gr, bl, 0, s, kk); break;
-        case 4: hipLaunchKernelGGL((maxsim_batch_ps_kernel<4, 4>), gr, bl, 0, s, kk); break;
-        case 5: hipLaunchKernelGGL((maxsim_batch_ps_kernel<5, 4>), gr, bl, 0, s, kk); break;
-        case 6: hipLaunchKernelGGL((maxsim_batch_ps_kernel<6, 4>), gr, bl, 0, s, kk); break;
-        case 7: hipLaunchKernelGGL((maxsim_batch_ps_kernel<7, 4>), gr, bl, 0, s, kk); break;
-        default: hipLaunchKernelGGL((maxsim_batch_ps_kernel<8, 4>), gr, bl, 0, s, kk); break;
+        case 1: if (kk.row_off) hipLaunchKernelGGL((maxsim_batch_ps_kernel<1, 4, true>), gr, bl, 0, s, kk); else hipLaunchKernelGGL((maxsim_batch_ps_kernel<1, 4>), gr, bl, 0, s, kk); break;
+        case 2: if (kk.row_off) hipLaunchKernelGGL((maxsim_batch_ps_kernel<2, 4, true>), gr, bl, 0, s, kk); else hipLaunchKernelGGL((maxsim_batch_ps_kernel<2, 4>), gr, bl, 0, s, kk); break;
+        case 3: if (kk.row_off) hipLaunchKernelGGL((maxsim_batch_ps_kernel<3, 4, true>), gr, bl, 0, s, kk); else hipLaunchKernelGGL((maxsim_batch_ps_kernel<3, 4>), gr, bl, 0, s, kk); break;
+        case 4: if (kk.row_off) hipLaunchKernelGGL((maxsim_batch_ps_kernel<4, 4, true>), gr, bl, 0, s, kk); else hipLaunchKernelGGL((maxsim_batch_ps_kernel<4, 4>), gr, bl, 0, s, kk); break;
+        case 5: if (kk.row_off) hipLaunchKernelGGL((maxsim_batch_ps_kernel<5, 4, true>), gr, bl, 0, s, kk); else hipLaunchKernelGGL((maxsim_batch_ps_kernel<5, 4>), gr, bl, 0, s, kk); break;
+        case 6: if (kk.row_off) hipLaunchKernelGGL((maxsim_batch_ps_kernel<6, 4, true>), gr, bl, 0, s, kk); else hipLaunchKernelGGL((maxsim_batch_ps_kernel<6, 4>), gr, bl, 0, s, kk); break;
+        case 7: if (kk.row_off) hipLaunchKernelGGL((maxsim_batch_ps_kernel<7, 4, true>), gr, bl, 0, s, kk); else hipLaunchKernelGGL((maxsim_batch_ps_kernel<7, 4>), gr, bl, 0, s, kk); break;
+        default: if (kk.row_off) hipLaunchKernelGGL((maxsim_batch_ps_kernel<8, 4, true>), gr, bl, 0, s, kk); else hipLaunchKernelGGL((maxsim_batch_ps_kernel<8, 4>), gr, bl, 0, s, kk); break;
       }
     }
     MV_HIP(hipGetLastError());

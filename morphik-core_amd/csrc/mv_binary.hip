@@ -93,6 +93,7 @@ __device__ __forceinline__ int wave_min(int v) {
 }
 
 // One wave per page, 4 pages per block.  Lane l owns patches l, l+64, ...
+template <bool PK>  // PK: packed layout (row-offset table) -- a template parameter so the fixed layout's code is untouched
 __global__ __launch_bounds__(256) void maxsim_binary_kernel(BArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void maxsim_binary_kernel(BArgs a) {
     if (lane == 0) a.scores[item] = 0.0f;  // COALESCE(SUM over nothing, 0.0)
     return;
   }
-  const uint4* pg = a.bits + (a.row_off ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride);
+  const uint4* pg = a.bits + (PK ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride);
   int total = 0;
   for (int q0 = 0; q0 < a.n_q; q0 += kQChunk) {
     const int nq = min(kQChunk, a.n_q - q0);
@@ -236,7 +237,7 @@ int launch_sign_pack_bf16_rows(const uint16_t* d_rows, int64_t n_rows, uint8_t* 
 // maximum is one register per query tile (two v_max3 per MFMA) and a page ends with two cross-group maxima.
 // Measured (1 M pages, DMA-only run of the same kernel = 6.9 TB/s): 6.7 TB/s; 2 / 4 KiB slots, 2..8 consecutive pages
 // per wave and block-interleaved slots were all tried and are no faster.
-template <int MT, int D>
+template <int MT, int D, bool PK = false>
 __global__ __launch_bounds__(256) void maxsim_binary_mfma2_kernel(BMArgs args) {
   const BArgs& a = args.b;
   constexpr int SL = 1, SLB = kBinSlotBytes, SLR = kBinSlotRows;  // a slot = one DMA instruction (1 KiB); 2 / 4 KiB slots measured no better
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void maxsim_binary_mfma2_kernel(BMArgs args) {
   }
   const int ntiles = (nr + 15) >> 4;
   const int nslots = (nr + SLR - 1) / SLR;
-  const char* pbase = reinterpret_cast<const char*>(a.bits) + (a.row_off ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride) * kSignBytes;
+  const char* pbase = reinterpret_cast<const char*>(a.bits) + (PK ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride) * kSignBytes;
   char* ring = lds + wave * (D * SLB);
   const int src_off = lane * 16;
   const int rd_off = r * kSignBytes + g * 4;
@@ -437,7 +438,8 @@ __global__ void binary_qprep_kernel(uint4* qbits, int n_q, int padded, float* qp
 template <int MT>
 static void launch_binary_mfma(const BArgs& k, int accumulate, hipStream_t s) {
   BMArgs m{k, accumulate};
-  hipLaunchKernelGGL((maxsim_binary_mfma2_kernel<MT, 4>), dim3((unsigned)((k.n + 3) / 4)), dim3(256), 0, s, m);
+  if (k.row_off) hipLaunchKernelGGL((maxsim_binary_mfma2_kernel<MT, 4, true>), dim3((unsigned)((k.n + 3) / 4)), dim3(256), 0, s, m);
+  else hipLaunchKernelGGL((maxsim_binary_mfma2_kernel<MT, 4, false>), dim3((unsigned)((k.n + 3) / 4)), dim3(256), 0, s, m);
 }
 
 // variant: 0 = popcount on the VALU (the independent cross-check), 4 (default, -1) = FP4 MFMA, 4-slot ring -- 408 M pages/s at
@@ -449,7 +451,8 @@ int launch_maxsim_binary(const BinaryArgs& a, int variant, hipStream_t s) {
   if (a.n > ((int64_t)1 << 25)) { set_error("binary scan: more than 2^25 pages per launch is not supported"); return MV_ERR_INVALID; }
   if (variant < 0) variant = 4;
   if (variant == 0 || a.n_q <= 0) {
-    hipLaunchKernelGGL(maxsim_binary_kernel, dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, s, k);
+    if (k.row_off) hipLaunchKernelGGL(maxsim_binary_kernel<true>, dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, s, k);
+    else hipLaunchKernelGGL(maxsim_binary_kernel<false>, dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, s, k);
   } else if (variant == 4) {
     if (!a.qpop) { set_error("binary MFMA scan needs the qpop workspace"); return MV_ERR_INVALID; }
     const int padded = ((a.n_q + 15) / 16) * 16;

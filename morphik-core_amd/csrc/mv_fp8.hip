@@ -207,8 +207,9 @@ struct F8Args {
   const int64_t* row_off;    // packed layout: first slab row of every page; null: page * stride
 };
 
+template <bool PK>  // PK: packed layout -- a template parameter so the fixed layout's kernels are untouched
 __device__ __forceinline__ const char* f8_page_base(const F8Args& a, int64_t page) {
-  return reinterpret_cast<const char*>(a.slab) + (a.row_off ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride) * kF8RowBytes;
+  return reinterpret_cast<const char*>(a.slab) + (PK ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride) * kF8RowBytes;
 }
 
 __device__ __forceinline__ bool f8_masked(const F8Args& a, int64_t page) {
@@ -237,7 +238,7 @@ __device__ __forceinline__ void f8_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int MT, int D, bool QITEM = false>
+template <int MT, int D, bool QITEM = false, bool PK = false>
 __global__ __launch_bounds__(256) void maxsim_fp8_kernel(F8Args a) {
   __shared__ __attribute__((aligned(16))) char lds[4 * D * kF8SlotBytes + 1024];
   float* red = reinterpret_cast<float*>(lds + 4 * D * kF8SlotBytes);
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void maxsim_fp8_kernel(F8Args a) {
   const int nslots = (nr + kF8SlotRows - 1) / kF8SlotRows;
   const bool clamp = (a.pad_items ? a.pad_items[item] : a.pad_to) > nr;
   const int nsw = (nslots - wave + 3) / 4;  // slots owned by this wave (may be <= 0)
-  const char* pbase = f8_page_base(a, page);
+  const char* pbase = f8_page_base<PK>(a, page);
   char* ring = lds + wave * (D * kF8SlotBytes);
 
   // DMA source offsets: instruction i covers rows 8i..8i+7 of the slot; lane -> LDS row 8i + (lane>>3), chunk
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(256) void maxsim_fp8_kernel(F8Args a) {
 // slab per fresh workgroup, the unit the float scan reads (128 KiB units deliver ~1.3 % less than 256 KiB
 // ones), and one query-fragment load per two pages.  Per page the arithmetic is maxsim_fp8_kernel's: the running maxima
 // are handed to LDS at the page boundary, waves 0 / 1 finish pages 0 / 1 after the single barrier.
-template <int MT, int D>
+template <int MT, int D, bool PK = false>
 __global__ __launch_bounds__(256) void maxsim_fp8_pair_kernel(F8Args a) {
   __shared__ __attribute__((aligned(16))) char lds[4 * D * kF8SlotBytes + 2048];
   float* red = reinterpret_cast<float*>(lds + 4 * D * kF8SlotBytes);
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(256) void maxsim_fp8_pair_kernel(F8Args a) {
     nr[p] = live[p] ? (a.n_rows ? a.n_rows[page] : a.stride) : 0;
     const int nslots = (nr[p] + kF8SlotRows - 1) / kF8SlotRows;
     nsw[p] = max(0, (nslots - wave + 3) / 4);
-    pbase[p] = (item0 + p < a.n) ? f8_page_base(a, page) : reinterpret_cast<const char*>(a.slab);  // (no table entry behind the last page)
+    pbase[p] = (!PK || item0 + p < a.n) ? f8_page_base<PK>(a, page) : reinterpret_cast<const char*>(a.slab);  // (packed: no table entry to read behind the last page)
   }
   const int total = nsw[0] + nsw[1];
   char* ring = lds + wave * (D * kF8SlotBytes);
@@ -588,11 +589,14 @@ int launch_f8_mt(const F8Args& k0, hipStream_t s) {
     if (k0.pad_items) k.pad_items = k0.pad_items + off;
     if (k.items_per_q > 0) {
       if (k0.n > kChunk) { set_error("per-item queries: %lld items in one launch not supported", (long long)k0.n); return MV_ERR_INVALID; }
-      hipLaunchKernelGGL((maxsim_fp8_kernel<MT, 4, true>), dim3((unsigned)k.n), dim3(256), 0, s, k);
+      if (k.row_off) hipLaunchKernelGGL((maxsim_fp8_kernel<MT, 4, true, true>), dim3((unsigned)k.n), dim3(256), 0, s, k);
+      else hipLaunchKernelGGL((maxsim_fp8_kernel<MT, 4, true>), dim3((unsigned)k.n), dim3(256), 0, s, k);
     } else if (!k.cand && f8_scan_pairs()) {
-      hipLaunchKernelGGL((maxsim_fp8_pair_kernel<MT, 4>), dim3((unsigned)((k.n + 1) / 2)), dim3(256), 0, s, k);
+      if (k.row_off) hipLaunchKernelGGL((maxsim_fp8_pair_kernel<MT, 4, true>), dim3((unsigned)((k.n + 1) / 2)), dim3(256), 0, s, k);
+      else hipLaunchKernelGGL((maxsim_fp8_pair_kernel<MT, 4>), dim3((unsigned)((k.n + 1) / 2)), dim3(256), 0, s, k);
     } else {
-      hipLaunchKernelGGL((maxsim_fp8_kernel<MT, 4>), dim3((unsigned)k.n), dim3(256), 0, s, k);
+      if (k.row_off) hipLaunchKernelGGL((maxsim_fp8_kernel<MT, 4, false, true>), dim3((unsigned)k.n), dim3(256), 0, s, k);
+      else hipLaunchKernelGGL((maxsim_fp8_kernel<MT, 4>), dim3((unsigned)k.n), dim3(256), 0, s, k);
     }
   }
   MV_HIP(hipGetLastError());
@@ -640,7 +644,7 @@ __device__ __forceinline__ float f8b_dpp_add(float v) {
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
-template <int MTW, int S, bool LO>
+template <int MTW, int S, bool LO, bool PK = false>
 __global__ __launch_bounds__(256, 2) void maxsim_batch_fp8_kernel(F8BatchArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[S * kF8ChunkBytes + 64 * MTW * 4 + 4 * MTW * 4];
   float* red = reinterpret_cast<float*>(lds + S * kF8ChunkBytes);  // [64 * MTW] factor-scaled token maxima of the current page
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_batch_fp8_kernel(F8BatchArgs a)
     }
     const int ntiles = (nr + 15) >> 4;
     const int nchunks = (nr + kF8ChunkRows - 1) / kF8ChunkRows;
-    const char* pbase = reinterpret_cast<const char*>(a.slab) + (a.row_off ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride) * kF8RowBytes;
+    const char* pbase = reinterpret_cast<const char*>(a.slab) + (PK ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride) * kF8RowBytes;
 
     auto issue = [&](int c) {  // wave w moves rows [32w, 32w+32) of chunk c (always issued: the slab is padded)
       const char* tp = pbase + (size_t)(c * 4 + wave) * 4096;
@@ -828,7 +832,10 @@ __global__ __launch_bounds__(256, 2) void maxsim_batch_fp8_kernel(F8BatchArgs a)
 
 template <int MTW>
 int launch_f8_batch_mtw(const F8BatchArgs& k, int grid, bool lo, hipStream_t s) {
-  if (lo) hipLaunchKernelGGL((maxsim_batch_fp8_kernel<MTW, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, k);
+  if (k.row_off) {
+    if (lo) hipLaunchKernelGGL((maxsim_batch_fp8_kernel<MTW, 4, true, true>), dim3((unsigned)grid), dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((maxsim_batch_fp8_kernel<MTW, 4, false, true>), dim3((unsigned)grid), dim3(256), 0, s, k);
+  } else if (lo) hipLaunchKernelGGL((maxsim_batch_fp8_kernel<MTW, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, k);
   else hipLaunchKernelGGL((maxsim_batch_fp8_kernel<MTW, 4, false>), dim3((unsigned)grid), dim3(256), 0, s, k);
   MV_HIP(hipGetLastError());
   return MV_OK;

@@ -38,6 +38,15 @@ struct mv_index {
   uint16_t* d_exact = nullptr;   // the same memory through the device's address space (hipHostGetDevicePointer)
   uint16_t* slab_x = nullptr;    // MV_WITH_EXACT_SPLIT: the exact rows of pages [0, x_split) in HBM (what was free after the other slabs)
   int64_t x_split = 0;           // pages of the exact tier that live in HBM (0: the whole tier is host memory)
+  // PLACEMENT of a split tier (mv_index_exact_tier_rebalance): slot s of the tier is HBM for s < x_split, pinned host memory above.
+  // Page p's exact rows live in slot x_loc[p] -- the identity until the first rebalance swaps HOT host-resident pages (counted in
+  // d_xhits by every rerank's list split) with cold HBM-resident ones.  Only published pages are ever swapped, so slot p of a page
+  // appended later is always free.  d_xoff[p] = x_loc[p] * stride_rows: the row-offset table the rerank kernels take in place of
+  // page * stride_rows (the packed layout's mechanism, mv_maxsim.hip KArgs::row_off).
+  std::vector<int32_t> x_loc, x_page_at;  // [capacity] page -> slot, slot -> page (empty until the first rebalance: identity)
+  int32_t* d_xloc = nullptr;              // device copy of x_loc (split_cand_kernel); null = identity
+  int64_t* d_xoff = nullptr;              // [capacity] rows; null = identity
+  uint32_t* d_xhits = nullptr;            // [capacity] times a page's exact rows were read by a rerank since the last rebalance (split tiers only)
   int32_t* d_xcand = nullptr;    // [2][kMaxCand] a rerank list split by tier part (lazily allocated)
   float* d_xscores = nullptr;    // [kMaxCand] scores of the second part
   uint8_t* slab8 = nullptr;      // e4m3 page slab [capacity][stride][128]

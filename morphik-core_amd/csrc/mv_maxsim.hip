@@ -58,9 +58,12 @@ struct KArgs {
   const int64_t* row_off;    // packed layout: first slab row of every page; null: page * stride
 };
 
-// byte offset of a page's first row in a slab of 256-byte rows
+// byte offset of a page's first row in a slab of 256-byte rows.  PK (packed layout) is a template parameter, not a test of a.row_off:
+// the fixed layout's kernels are instruction for instruction those of round 5 (the extra kernarg load + branch sat in front of the first
+// DMA of every fresh workgroup), and the packed kernels issue the table load beside the n_rows load instead of behind a branch.
+template <bool PK>
 __device__ __forceinline__ size_t page_byte_off(const KArgs& a, int64_t page) {
-  return (a.row_off ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride) * kRowBytes;
+  return (PK ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride) * kRowBytes;
 }
 
 __device__ __forceinline__ bool page_masked(const KArgs& a, int64_t page) {
@@ -179,7 +182,7 @@ __device__ __forceinline__ void finish_block(const f32x4 (&mx)[MT], bool clamp, 
 
 // --------------------------------------------------------------------------------------------
 // Variants 0/1/4/5: direct global -> VGPR fragment loads (64 contiguous bytes per row per instruction).
-template <int MT, int WPP, bool NT, int LO = 0>
+template <int MT, int WPP, bool NT, int LO = 0, bool PK = false>
 __global__ __launch_bounds__(256) void maxsim_direct_kernel(KArgs a) {
   constexpr int PF = 3;  // register ring depth (tiles in flight per wave = PF-1 .. PF)
   __shared__ float red[512];
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256) void maxsim_direct_kernel(KArgs a) {
 #pragma unroll
   for (int m = 0; m < MT; ++m) mx[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 
-  const size_t poff = page_byte_off(a, page) + r * kRowBytes + g * 16;
+  const size_t poff = page_byte_off<PK>(a, page) + r * kRowBytes + g * 16;
   const char* base = a.slab + poff;
   const char* base_lo = LO == 2 ? a.slab_lo + poff : nullptr;
   const int t0 = (WPP == 1) ? 0 : wave;
@@ -273,7 +276,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // LO (split-bf16 operands, tile_mfma_lo): 1 = the query's lo half rides along in registers; 2 = also the pages' lo slab --
 // a ring item is then the PAIR (hi tile, lo tile) of one 16-row tile, 8 KiB, the ring D pairs deep (128 KiB of LDS per
 // workgroup at D = 4: one workgroup per CU with the bytes in flight of two hi-only ones).
-template <int MT, int WPP, int D, bool NT = false, bool CONTIG = false, bool STREAM_ONLY = false, bool QITEM = false, int LO = 0>
+template <int MT, int WPP, int D, bool NT = false, bool CONTIG = false, bool STREAM_ONLY = false, bool QITEM = false, int LO = 0, bool PK = false>
 __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
   constexpr int TPI = LO == 2 ? 2 : 1;               // tiles per ring item
   constexpr int kItemBytes = TPI * kTileBytes;
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
   const int t0 = (WPP == 1) ? 0 : (CONTIG ? wave * tq : wave);
   const int tstep = CONTIG ? 1 : WPP;
   const int ntw = CONTIG ? max(0, min(tq, ntiles - t0)) : (ntiles - t0 + WPP - 1) / WPP;
-  const size_t pboff = page_byte_off(a, page);
+  const size_t pboff = page_byte_off<PK>(a, page);
   const char* pbase = a.slab + pboff;
   const char* plbase = LO == 2 ? a.slab_lo + pboff : nullptr;
   char* ring = lds + wave * (D * kItemBytes);
@@ -446,8 +449,8 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
 // What stays: 6 (default from 512 rows per page), 7 (default below), 0 (direct loads, one wave per page: the independent
 // cross-check of the ring), 13 (the default's transport without arithmetic: MV_CAL_READ_LDSDMA).
 
-template <int MT, int LO>
-int launch_mt(const KArgs& k0, int variant, hipStream_t s) {
+template <int MT, int LO, bool PK>
+int launch_mt_pk(const KArgs& k0, int variant, hipStream_t s) {
   if (k0.n <= 0) return MV_OK;
   dim3 block(256);
   // a launch's work-item count must stay below 2^32: at most 2^22 pages per launch (x256 or x64 threads)
@@ -462,22 +465,27 @@ int launch_mt(const KArgs& k0, int variant, hipStream_t s) {
     const int64_t n = k.n;
     if (k.items_per_q > 0) {  // per-item queries: the two default forms only, one launch
       if (k0.n > kChunk || (variant != 6 && variant != 7)) { set_error("per-item queries: variant %d / %lld items not supported", variant, (long long)k0.n); return MV_ERR_INVALID; }
-      if (variant == 6) hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true, false, false, true, LO>), dim3((unsigned)n), block, 0, s, k);
-      else hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 1, 4, true, false, false, true, LO>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k);
+      if (variant == 6) hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true, false, false, true, LO, PK>), dim3((unsigned)n), block, 0, s, k);
+      else hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 1, 4, true, false, false, true, LO, PK>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k);
       continue;
     }
     switch (variant) {
-      case 0: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 1, false, LO>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
-      case 6: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true, false, false, false, LO>), dim3((unsigned)n), block, 0, s, k); break;
-      case 7: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 1, 4, true, false, false, false, LO>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
+      case 0: hipLaunchKernelGGL((maxsim_direct_kernel<MT, 1, false, LO, PK>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
+      case 6: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true, false, false, false, LO, PK>), dim3((unsigned)n), block, 0, s, k); break;
+      case 7: hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 1, 4, true, false, false, false, LO, PK>), dim3((unsigned)((n + 3) / 4)), block, 0, s, k); break;
       case 13:
-        if constexpr (LO == 0) { hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true, false, true>), dim3((unsigned)n), block, 0, s, k); break; }
+        if constexpr (LO == 0 && !PK) { hipLaunchKernelGGL((maxsim_ldsdma_kernel<MT, 4, 4, true, false, true>), dim3((unsigned)n), block, 0, s, k); break; }
         [[fallthrough]];
       default: set_error("unknown maxsim variant %d%s", variant, LO ? " (split-bf16 operands: 0, 6, 7)" : ""); return MV_ERR_INVALID;
     }
   }
   MV_HIP(hipGetLastError());
   return MV_OK;
+}
+
+template <int MT, int LO>
+int launch_mt(const KArgs& k, int variant, hipStream_t s) {
+  return k.row_off ? launch_mt_pk<MT, LO, true>(k, variant, s) : launch_mt_pk<MT, LO, false>(k, variant, s);
 }
 
 template <int LO>

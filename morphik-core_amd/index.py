@@ -210,6 +210,19 @@ class MvIndex:
         """Pages of a split exact tier (with_exact_split) whose exact rows live in HBM; 0 without a split."""
         return int(lib().mv_index_exact_hbm_pages(self._h))
 
+    def rebalance_exact_tier(self, max_moves: int = 0) -> int:
+        """Split exact tier: swap the most-read host-resident pages with the least-read HBM-resident ones (reads counted by every
+        rerank since the last call). -> pages moved into HBM.  Answers are unchanged; the PCIe share of the reranks falls."""
+        moved = C.c_int64()
+        check(lib().mv_index_exact_tier_rebalance(self._h, int(max_moves), C.byref(moved)))
+        return int(moved.value)
+
+    def exact_tier_hits(self) -> Tuple[int, int]:
+        """-> (reads served from the HBM part, reads served from pinned host memory) since the last rebalance."""
+        a, b = C.c_int64(), C.c_int64()
+        check(lib().mv_index_exact_tier_hits(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     # -- lifecycle
     def close(self) -> None:
         if getattr(self, "_h", None):

@@ -156,6 +156,10 @@ class ShardedIndex:
                     remap[base + o] = base + int(n)
         return remap
 
+    def rebalance_exact_tier(self, max_moves: int = 0) -> int:
+        """Every shard re-places the hot pages of ITS split exact tier (MvIndex.rebalance_exact_tier).  -> pages moved in all."""
+        return sum(int(s.rebalance_exact_tier(max_moves)) for s in self.shards if hasattr(s, "rebalance_exact_tier"))
+
     # -- query
     def query(self, q: Any, k: int, mode: str = "float", allow: Optional[np.ndarray] = None, want_stats: bool = False, q_fde: Any = None):
         if q_fde is not None:

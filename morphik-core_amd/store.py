@@ -805,6 +805,15 @@ class MI355XMultiVectorStore(BaseVectorStore):
             self._ord_stamp += 1
             return before - len(ix)
 
+    def rebalance_exact_tier(self, max_moves: int = 0) -> int:
+        """exact_tier="split" only: move the pages the reranks read most into the HBM part of the exact tier (the library counts the
+        reads per page; mv_index_exact_tier_rebalance).  -> pages moved.  Answers do not change; the PCIe share of the reranks does.
+        Writers and queries wait for its duration: call it from a maintenance task (or after compact())."""
+        with self._write_gate, self._lock:
+            ix = self._require_index()
+            f = getattr(ix, "rebalance_exact_tier", None)
+            return int(f(max_moves)) if f is not None else 0
+
     # ------------------------------------------------------------------ checkpoint / resume
     def _book(self) -> Dict[str, Any]:
         return {

@@ -543,6 +543,92 @@ def test_split_exact_tier_writers_compaction_and_checkpoints(tmp_path):
     split.close()
 
 
+def test_split_exact_tier_rebalance_moves_hot_pages_into_hbm_and_changes_no_answer(tmp_path):
+    """the HBM part of a split exact tier should hold the HOT pages, not the leading ones.  Every rerank counts the
+    exact reads per page; mv_index_exact_tier_rebalance swaps the most-read host-resident pages with the least-read HBM-resident ones.
+    Checked: the reads of a repeated workload move from host memory to HBM; ids and scores stay those of the unsplit host tier bit for
+    bit -- single, batched, named candidates, staged, after a second rebalance (composed placements), through writers, a checkpoint
+    (the file keeps page order: reloaded with any split) and a compaction (which restores slot == page first)."""
+    from morphik_core_amd import _lib
+    from morphik_core_amd.index import MvIndex
+
+    N, stride, k = 400, 32, 6
+    pages = _corpus(N, stride, seed=37)
+    kw = dict(capacity_pages=N + 8, stride_rows=stride, with_float=False, with_fde=True, with_fp8=True, with_host_exact=True)
+    host = _idx(**kw)
+    with _SplitAt(60):
+        split = _idx(with_exact_split=True, **kw)
+    for ix in (host, split):
+        ix.add(pages, doc_ordinals=np.arange(N, dtype=np.int32) // 2)
+        ix.set_option(_lib.MV_OPT_FDE_COARSE_N, 40)
+    # a workload whose candidates sit almost entirely behind the split (pages >= 60): "topic" queries built from late pages
+    hot_q = [pages[300 + 7 * j][:16] for j in range(8)]
+    other_q = [orc.synth_rows(980, j, 0, 16) for j in range(4)]
+
+    def same(tag, qs=None):
+        for q in (qs or hot_q[:3] + other_q[:2]):
+            for mode in ("fde_then_float", "fp8_then_float"):
+                ws, wi = host.query(q, k, mode=mode)
+                s, i = split.query(q, k, mode=mode)
+                assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist(), (tag, mode)
+        want = host.query_batch(hot_q[:5], k, mode="fde_then_float")
+        got = split.query_batch(hot_q[:5], k, mode="fde_then_float")
+        for (ws, wi), (s, i) in zip(want, got):
+            assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist(), (tag, "batch")
+
+    assert host.rebalance_exact_tier() == 0 and host.exact_tier_hits() == (0, 0)  # no split: a no-op
+    assert split.rebalance_exact_tier() == 0  # nothing read yet
+    for q in hot_q:
+        split.query(q, k, mode="fde_then_float")
+    hb0, ho0 = split.exact_tier_hits()
+    assert hb0 + ho0 == 8 * 40 and ho0 > hb0  # 40 candidates per request went to the exact tier, most of them behind the split
+    moved = split.rebalance_exact_tier()
+    assert 0 < moved <= 60 and split.exact_tier_hits() == (0, 0)  # counters cleared
+    same("after the first rebalance")
+    for q in hot_q:
+        split.query(q, k, mode="fde_then_float")
+    hb1, ho1 = split.exact_tier_hits()
+    assert hb1 + ho1 == 8 * 40 and hb1 > hb0 and ho1 < ho0  # the same workload now reads (mostly) HBM
+    # a different workload, a second rebalance: placements compose
+    for q in other_q * 3:
+        split.query(q, k, mode="fp8_then_float")
+    assert split.rebalance_exact_tier(max_moves=10) <= 10
+    same("after the second rebalance")
+    cand = np.array([0, 59, 60, 61, 300, 307, 399, 3], np.int32)
+    assert split.score_candidates(hot_q[0], cand).tolist() == host.score_candidates(hot_q[0], cand).tolist()
+    np.testing.assert_array_equal(split.read_pages(0, N), host.read_pages(0, N))
+    # writers address pages, not slots
+    new_rows = orc.synth_rows(556, 0, 0, 20)
+    for ix in (host, split):
+        ix.replace_page(300, new_rows[:14])
+        ix.replace_page(5, new_rows[:9])
+        ix.write_rows(307, 1, new_rows[:3])
+        ix.add([new_rows[:11]], doc_ordinals=[999])
+    same("writers on a rebalanced tier")
+    np.testing.assert_array_equal(split.read_pages(295, 20), host.read_pages(295, 20))
+    # checkpoint: page order in the file, any split on reload
+    path = str(tmp_path / "rebalanced.idx")
+    split.save(path)
+    with _SplitAt(25):
+        re = MvIndex.load(path, device=0)
+    re.set_option(_lib.MV_OPT_FDE_COARSE_N, 40)
+    np.testing.assert_array_equal(re.read_pages(0, len(re)), host.read_pages(0, len(host)))
+    ws, wi = host.query(hot_q[1], k, mode="fde_then_float")
+    s, i = re.query(hot_q[1], k, mode="fde_then_float")
+    assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist()
+    re.close()
+    # compaction on a rebalanced tier
+    for ix in (host, split):
+        for d in (1, 20, 150, 155):
+            ix.remove_doc(d)
+        ix.compact()
+    assert len(split) == len(host) == N + 1 - 8
+    np.testing.assert_array_equal(split.read_pages(0, len(split)), host.read_pages(0, len(host)))
+    same("after compaction", qs=other_q[:2])
+    host.close()
+    split.close()
+
+
 def test_split_exact_tier_behind_the_store():
     """create_store("mi355x_fast_split_exact" / "mi355x_sharded_fast_split_exact"): the plugin surface over split tiers returns the
     hits of the unsplit host-tier providers, score for score."""

@@ -8,7 +8,7 @@ processes ~4 % faster, same code, same virtual layout).  This driver looks for t
   2. counters: fresh processes of the shipped layout under `rocprofv3 --pmc` (one counter set per process: address translation / the L2's
      external-agent queues), each process reporting its own times -> the counters of a fast and of a slow process side by side.
 
-  python tools/fde_batch_mode_probe.py [pages=1250000] [procs_per_setting=6] [pmc_procs_per_set=4]
+  python tools/fde_batch_mode_probe.py [pages=1250000] [procs_per_setting=6] [pmc_procs_per_set=4] [pads=0,64,1056,32800 | none] [sets=all | name,name]
 One JSON document on stdout."""
 import csv
 import glob
@@ -25,6 +25,8 @@ PMC_SETS = {  # <= 4 counters of one block per pass (the TCC / TCP blocks expose
     "l2_read_side": "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_TAG_STALL_sum",
     "l2_write_side": "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_LEVEL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum",
     "l2_hit_miss": "TCC_HIT_sum TCC_MISS_sum TCC_BUSY_sum TCC_REQ_sum",
+    # GRBM_GUI_ACTIVE / 8 XCDs / (kernel time) = the shader clock the launch ran at; the SQ counters are in its cycles
+    "clock_and_issue": "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA",
 }
 
 
@@ -55,13 +57,17 @@ def main():
     pages = int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000
     procs = int(sys.argv[2]) if len(sys.argv) > 2 else 6
     pmc_procs = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    pads = [] if (len(sys.argv) > 4 and sys.argv[4] == "none") else [int(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "0,64,1056,32800").split(",")]
+    sets = None if len(sys.argv) <= 5 or sys.argv[5] == "all" else sys.argv[5].split(",")
     out = {"pages": pages, "what": "batched FDE coarse pass (32 / 16 requests per read of the FDE slab), stats.coarse_ms medians of fresh processes",
            "placement": {}, "counters": {}}
-    for pad in (0, 64, 1056, 32800):
+    for pad in pads:
         runs = [run_probe(pages, {"MV_BSCORE_STRIDE_PAD": str(pad)}) for _ in range(procs)]
         out["placement"][f"score_stride_pad_{pad}_elements"] = runs
         print(f"pad {pad}: " + " ".join(f"{r.get('B16_ms')}/{r.get('B32_ms')}" for r in runs), file=sys.stderr, flush=True)
     for name, cset in PMC_SETS.items():
+        if sets is not None and name not in sets:
+            continue
         recs = []
         for i in range(pmc_procs):
             d = f"/tmp/fde_mode_pmc_{name}_{i}"
