@@ -252,14 +252,16 @@ __global__ __launch_bounds__(256) void maxsim_binary_mfma2_kernel(BMArgs args) {
     if (lane == 0) a.scores[item] = -INFINITY;
     return;
   }
-  const int nr = a.n_rows ? a.n_rows[page] : a.stride;
+  int64_t pk_row0 = 0;  // packed layout: loaded beside the row count (one s_waitcnt for both)
+  if constexpr (PK) pk_row0 = a.row_off[page];
+  const int nr = PK ? a.n_rows[page] : (a.n_rows ? a.n_rows[page] : a.stride);
   if (nr <= 0 || a.n_q <= 0) {
     if (lane == 0 && !args.accumulate) a.scores[item] = 0.0f;
     return;
   }
   const int ntiles = (nr + 15) >> 4;
   const int nslots = (nr + SLR - 1) / SLR;
-  const char* pbase = reinterpret_cast<const char*>(a.bits) + (PK ? (size_t)a.row_off[page] : (size_t)page * (size_t)a.stride) * kSignBytes;
+  const char* pbase = reinterpret_cast<const char*>(a.bits) + (PK ? (size_t)pk_row0 : (size_t)page * (size_t)a.stride) * kSignBytes;
   char* ring = lds + wave * (D * SLB);
   const int src_off = lane * 16;
   const int rd_off = r * kSignBytes + g * 4;

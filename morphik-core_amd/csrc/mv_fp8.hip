@@ -252,12 +252,14 @@ __global__ __launch_bounds__(256) void maxsim_fp8_kernel(F8Args a) {
     if (threadIdx.x == 0) a.scores[item] = -INFINITY;
     return;
   }
-  const int nr = a.n_rows ? a.n_rows[page] : a.stride;
+  int64_t pk_row0 = 0;  // packed layout: loaded beside the row count (one s_waitcnt for both)
+  if constexpr (PK) pk_row0 = a.row_off[page];
+  const int nr = PK ? a.n_rows[page] : (a.n_rows ? a.n_rows[page] : a.stride);
   const int ntiles = (nr + 15) >> 4;
   const int nslots = (nr + kF8SlotRows - 1) / kF8SlotRows;
   const bool clamp = (a.pad_items ? a.pad_items[item] : a.pad_to) > nr;
   const int nsw = (nslots - wave + 3) / 4;  // slots owned by this wave (may be <= 0)
-  const char* pbase = f8_page_base<PK>(a, page);
+  const char* pbase = PK ? reinterpret_cast<const char*>(a.slab) + (size_t)pk_row0 * kF8RowBytes : f8_page_base<false>(a, page);
   char* ring = lds + wave * (D * kF8SlotBytes);
 
   // DMA source offsets: instruction i covers rows 8i..8i+7 of the slot; lane -> LDS row 8i + (lane>>3), chunk

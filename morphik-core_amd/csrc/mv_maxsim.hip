@@ -196,7 +196,10 @@ __global__ __launch_bounds__(256) void maxsim_direct_kernel(KArgs a) {
     if (lane == 0 && (WPP == 1 || wave == 0)) a.scores[item] = -INFINITY;
     return;
   }
-  const int nr = a.n_rows ? a.n_rows[page] : a.stride;
+  // packed layout: the table entry is loaded BESIDE the row count (both scalar loads before the one s_waitcnt; a packed index always carries n_rows)
+  int64_t pk_row0 = 0;
+  if constexpr (PK) pk_row0 = a.row_off[page];
+  const int nr = PK ? a.n_rows[page] : (a.n_rows ? a.n_rows[page] : a.stride);
   const int ntiles = (nr + kTileRows - 1) / kTileRows;
   const bool clamp = (a.pad_items ? a.pad_items[item] : a.pad_to) > nr;
 
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256) void maxsim_direct_kernel(KArgs a) {
 #pragma unroll
   for (int m = 0; m < MT; ++m) mx[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 
-  const size_t poff = page_byte_off<PK>(a, page) + r * kRowBytes + g * 16;
+  const size_t poff = (PK ? (size_t)pk_row0 * kRowBytes : page_byte_off<false>(a, page)) + r * kRowBytes + g * 16;
   const char* base = a.slab + poff;
   const char* base_lo = LO == 2 ? a.slab_lo + poff : nullptr;
   const int t0 = (WPP == 1) ? 0 : wave;
@@ -293,7 +296,10 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
     if (lane == 0 && (WPP == 1 || wave == 0)) a.scores[item] = -INFINITY;
     return;
   }
-  const int nr = a.n_rows ? a.n_rows[page] : a.stride;
+  // packed layout: the table entry is loaded BESIDE the row count (both scalar loads before the one s_waitcnt; a packed index always carries n_rows)
+  int64_t pk_row0 = 0;
+  if constexpr (PK) pk_row0 = a.row_off[page];
+  const int nr = PK ? a.n_rows[page] : (a.n_rows ? a.n_rows[page] : a.stride);
   const int ntiles = (nr + kTileRows - 1) / kTileRows;
   const bool clamp = (a.pad_items ? a.pad_items[item] : a.pad_to) > nr;
 
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(256) void maxsim_ldsdma_kernel(KArgs a) {
   const int t0 = (WPP == 1) ? 0 : (CONTIG ? wave * tq : wave);
   const int tstep = CONTIG ? 1 : WPP;
   const int ntw = CONTIG ? max(0, min(tq, ntiles - t0)) : (ntiles - t0 + WPP - 1) / WPP;
-  const size_t pboff = page_byte_off<PK>(a, page);
+  const size_t pboff = PK ? (size_t)pk_row0 * kRowBytes : page_byte_off<false>(a, page);
   const char* pbase = a.slab + pboff;
   const char* plbase = LO == 2 ? a.slab_lo + pboff : nullptr;
   char* ring = lds + wave * (D * kItemBytes);

@@ -122,6 +122,8 @@ class MI355XMultiVectorStore(BaseVectorStore):
         prune_slab: bool = True,
         fde_module: Any = None,
         fp32_pages: bool = False,
+        packed_layout: bool = False,
+        capacity_rows: int = 0,
         **_ignored: Any,
     ):
         self.capacity_pages = int(capacity_pages)
@@ -150,6 +152,11 @@ class MI355XMultiVectorStore(BaseVectorStore):
         # the float scan return that fp32 score to ~1e-6 -- for encoders whose output is not bf16 to begin with.  (A bf16 encoder under
         # autocast -- the reference's own, colpali_embedding_model.py:251-262 -- emits bf16 values: False loses nothing there.)
         self.fp32_pages = bool(fp32_pages)
+        # MV_LAYOUT_PACKED: pages of different lengths (ColQwen2.5's dynamic token counts, colpali_embedding_model.py:47-52) lie back to back
+        # in whole 16-row tiles instead of one stride_rows slot each; capacity_rows sizes the row-indexed slabs (0 = capacity_pages *
+        # stride_rows: no saving, only the layout).  Not with the host / split exact tiers.
+        self.packed_layout = bool(packed_layout)
+        self.capacity_rows = int(capacity_rows)
         # Bring-your-own FDE ("fde_then_float"): an object with the API of the reference's `fde` extension -- FixedDimensionalEncodingConfig,
         # generate_document_encoding(emb, cfg), generate_query_encoding(q, cfg) (fast_multivector_store.py:325-331, :447-449, :521).  The
         # store then calls IT, on the host as the reference does, for every chunk and every query, imports the document vectors into the
@@ -226,7 +233,10 @@ class MI355XMultiVectorStore(BaseVectorStore):
         # exact_tier "split": the host tier, with the exact rows of the leading pages in whatever HBM the other slabs leave free
         host = self.mode == "fp8_then_float" or (self.mode == "fde_then_float" and self.exact_tier in ("host", "split"))
         with_float = self.mode == "float" or (self.mode == "fde_then_float" and not host)
+        if self.packed_layout and host:
+            raise ValueError("packed_layout cannot be combined with a host / split exact tier")
         return dict(with_float=with_float, with_binary=self.mode == "binary", **({"with_float_lo": True} if with_float and self.fp32_pages else {}),
+                    **({"packed": True, "capacity_rows": self.capacity_rows} if self.packed_layout else {}),
                     with_fde=self.mode == "fde_then_float", with_fp8=self.mode in ("float_fp8", "fp8_then_float") or (self.mode == "fde_then_float" and host and self.prune_slab),
                     **({"with_host_exact": True} if host else {}), **({"with_exact_split": True} if host and self.exact_tier == "split" else {}))
 
@@ -818,7 +828,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
     def _book(self) -> Dict[str, Any]:
         return {
             "version": 3, "mode": self.mode, "capacity_pages": self.capacity_pages, "stride_rows": self.stride_rows,
-            "id_base": self.id_base, "fde_coarse_n": self.fde_coarse_n, "exact_tier": self.exact_tier, "rerank_n": self.rerank_n, "prune_slab": self.prune_slab, "fp32_pages": self.fp32_pages, "fde_external": self.fde_module is not None, "next_ord": self._next_ord,
+            "id_base": self.id_base, "fde_coarse_n": self.fde_coarse_n, "exact_tier": self.exact_tier, "rerank_n": self.rerank_n, "prune_slab": self.prune_slab, "fp32_pages": self.fp32_pages, "packed_layout": self.packed_layout, "capacity_rows": self.capacity_rows, "fde_external": self.fde_module is not None, "next_ord": self._next_ord,
             "rows": [[p, r[0], r[1], r[2], r[3], r[4], row_origin(r)] for p, r in self._rows.items()],
             "doc_ord": self._doc_ord, "doc_app": {str(k): v for k, v in self._doc_app.items()},
         }
@@ -919,7 +929,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
             raise RuntimeError(f"{directory}: this checkpoint " + ("holds document FDE vectors of an external encoder: pass fde_module= to load()"
                                                                      if book.get("fde_external") else "was encoded by the library itself: load it without fde_module"))
         self = cls(capacity_pages=book["capacity_pages"], stride_rows=book["stride_rows"], device=device, mode=book["mode"], storage=storage,
-                   id_base=book["id_base"], fde_coarse_n=book.get("fde_coarse_n", 0), exact_tier=book.get("exact_tier", "hbm"), rerank_n=book.get("rerank_n", 0), prune_slab=book.get("prune_slab", True), **{"fp32_pages": book.get("fp32_pages", False), **kw})
+                   id_base=book["id_base"], fde_coarse_n=book.get("fde_coarse_n", 0), exact_tier=book.get("exact_tier", "hbm"), rerank_n=book.get("rerank_n", 0), prune_slab=book.get("prune_slab", True), **{"fp32_pages": book.get("fp32_pages", False), "packed_layout": book.get("packed_layout", False), "capacity_rows": book.get("capacity_rows", 0), **kw})
         self._index = cls._load_index(self, directory, book, device)
         self._apply_options(self._index)
         for p, doc, chunk_no, content, meta_json, app, *rest in book["rows"]:

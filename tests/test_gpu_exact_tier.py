@@ -576,18 +576,21 @@ def test_split_exact_tier_rebalance_moves_hot_pages_into_hbm_and_changes_no_answ
         for (ws, wi), (s, i) in zip(want, got):
             assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist(), (tag, "batch")
 
+    def workload_reads():  # (reads served from HBM, from host memory) of one pass of the hot workload
+        a = split.exact_tier_hits()
+        for q in hot_q:
+            split.query(q, k, mode="fde_then_float")
+        b = split.exact_tier_hits()
+        return b[0] - a[0], b[1] - a[1]
+
     assert host.rebalance_exact_tier() == 0 and host.exact_tier_hits() == (0, 0)  # no split: a no-op
     assert split.rebalance_exact_tier() == 0  # nothing read yet
-    for q in hot_q:
-        split.query(q, k, mode="fde_then_float")
-    hb0, ho0 = split.exact_tier_hits()
+    hb0, ho0 = workload_reads()
     assert hb0 + ho0 == 8 * 40 and ho0 > hb0  # 40 candidates per request went to the exact tier, most of them behind the split
     moved = split.rebalance_exact_tier()
     assert 0 < moved <= 60 and split.exact_tier_hits() == (0, 0)  # counters cleared
     same("after the first rebalance")
-    for q in hot_q:
-        split.query(q, k, mode="fde_then_float")
-    hb1, ho1 = split.exact_tier_hits()
+    hb1, ho1 = workload_reads()
     assert hb1 + ho1 == 8 * 40 and hb1 > hb0 and ho1 < ho0  # the same workload now reads (mostly) HBM
     # a different workload, a second rebalance: placements compose
     for q in other_q * 3:

@@ -271,3 +271,51 @@ def test_packed_flag_is_refused_with_the_host_exact_tier():
         MvIndex(capacity_pages=4, stride_rows=16, with_float=False, with_fp8=True, with_host_exact=True, packed=True)
     with pytest.raises(MvError):
         MvIndex(capacity_pages=4, stride_rows=16, packed=True, capacity_rows=24)  # not a multiple of 16
+
+
+@pytest.mark.parametrize("mode", ["float", "fde_then_float", "binary"])
+def test_store_with_the_packed_layout_answers_like_the_fixed_one(mode, tmp_path):
+    """Behind the plugin surface: `MI355X*MultiVectorStore(packed_layout=True, capacity_rows=...)` -- ragged chunk embeddings, the same hits and
+    scores as the fixed-stride store, a row budget instead of a slot budget, checkpoint round trip."""
+    import morphik_core_amd.store as st
+    from tests import store_scenarios as sc
+
+    cls = st.MI355XFastMultiVectorStore if mode == "fde_then_float" else st.MI355XMultiVectorStore
+    rng = np.random.default_rng(23)
+    chunks = sc.make_chunks(rng, n_docs=5, chunks_per_doc=4, rows=24)
+    for j, c in enumerate(chunks):  # 3 .. 60 rows
+        c.embedding = sc.rand_emb(rng, 3 + (j * 7) % 58)
+    need = sum((np.asarray(c.embedding).shape[0] + 15) // 16 * 16 for c in chunks)
+    fixed = cls(capacity_pages=32, stride_rows=64, mode=mode)
+    packed = cls(capacity_pages=32, stride_rows=64, mode=mode, packed_layout=True, capacity_rows=need + 64)
+    assert fixed.initialize() and packed.initialize()
+    try:
+        for s in (fixed, packed):
+            ok, ids, _m = sc.run(s.store_embeddings(chunks, app_id="t"))
+            assert ok and len(ids) == len(chunks)
+        assert packed._index.rows_used == need and packed._index.capacity_rows == need + 64 < 32 * 64
+        for c in chunks[::3]:
+            a = sc.run(fixed.query_similar(c.embedding, k=6, app_id="t"))
+            b = sc.run(packed.query_similar(c.embedding, k=6, app_id="t"))
+            assert [(h.document_id, h.chunk_number, h.score) for h in a] == [(h.document_id, h.chunk_number, h.score) for h in b]
+        # the row budget is what fills up: one more 64-row chunk fits, the next does not
+        from morphik_core_amd.models import DocumentChunk
+
+        extra = DocumentChunk(document_id="x", chunk_number=0, content="x", embedding=sc.rand_emb(rng, 64), metadata={})
+        assert sc.run(packed.store_embeddings([extra], app_id="t"))[0] is True
+        extra2 = DocumentChunk(document_id="x", chunk_number=1, content="y", embedding=sc.rand_emb(rng, 40), metadata={})
+        with pytest.raises(Exception):
+            sc.run(packed.store_embeddings([extra2], app_id="t"))
+        d = str(tmp_path / "ck")
+        packed.save(d)
+        back = cls.load(d)
+        try:
+            assert back.packed_layout and back._index.rows_used == need + 64
+            b = sc.run(back.query_similar(chunks[3].embedding, k=4, app_id="t"))
+            a = sc.run(packed.query_similar(chunks[3].embedding, k=4, app_id="t"))
+            assert [(h.document_id, h.chunk_number, h.score) for h in a] == [(h.document_id, h.chunk_number, h.score) for h in b]
+        finally:
+            back.close()
+    finally:
+        fixed.close()
+        packed.close()
