@@ -42,6 +42,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# A GPU fault in a side measurement must cost that measurement, not the run: the ROCm runtime otherwise writes a GPU core dump (the size of
+# the resident HBM) into the working directory -- round 6 lost a whole bench record to "No space left on device" that way.
+os.environ.setdefault("HSA_DISABLE_COREDUMP_ON_EXCEPTION", "1")
 
 PAGE_ROW_BYTES = 256  # 128 x bf16
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -1565,7 +1568,10 @@ def emit(out, aux):
     head["aux_file"] = write_record("bench_aux.json", doc)
     flush_c_stdio()
     if detail or aux:
-        print(json.dumps(doc), flush=True)
+        try:
+            print(json.dumps(doc), flush=True)
+        except OSError as e:  # a full disk behind a redirected stdout: the (short) headline below may still fit
+            log(f"bench.py: could not print the detail record: {e!r}")
     print(json.dumps(head), flush=True)
 
 
@@ -1613,8 +1619,14 @@ def run_aux_child(args, state):
         return {"aux_child_error": f"could not write the state file: {e!r}"}
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--aux-child", path]
     t0 = time.time()
+    def no_core():  # (and no host core file either)
+        import resource
+
+        resource.setrlimit(resource.RLIMIT_CORE, (0, 0))
+
     try:
-        p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, timeout=args.aux_timeout)
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, timeout=args.aux_timeout, preexec_fn=no_core,
+                           env=dict(os.environ, HSA_DISABLE_COREDUMP_ON_EXCEPTION="1"))
     except subprocess.TimeoutExpired:
         return {"aux_child_error": f"timed out after {args.aux_timeout} s"}
     except OSError as e:

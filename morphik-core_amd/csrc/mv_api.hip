@@ -311,7 +311,7 @@ int float_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_w
     a.slab_lo = slab_lo;
     a.row_off = row_off_override ? row_off_override : ix->d_row_off;  // packed layout, or the placement table of a rebalanced split exact tier (never both)
     a.slab = slab_override ? slab_override : ix->slab;  // the exact tier of FP8_THEN_FLOAT may be pinned host memory mapped into the device
-    a.n_rows = ragged ? ix->d_n_rows : nullptr;
+    a.n_rows = (ragged || a.row_off) ? ix->d_n_rows : nullptr;  // the table-driven kernels read the row count unconditionally (it always exists: stride_rows for a full page)
     a.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
     a.allow = d_allow;
     a.n_allow_bits = n_allow_words * 32;
@@ -2328,7 +2328,7 @@ int mv_internal_batch_rerank_lists(mv_index* ix, int nb, int n_q_rows, int64_t n
       int32_t* hi = ix->d_xcand + kMaxCand;
       const unsigned gb = (unsigned)((n + 255) / 256);
       hipLaunchKernelGGL(split_cand_kernel, dim3(gb), dim3(256), 0, ix->stream, (const int32_t*)ix->d_bcand, n, (int32_t)ix->x_split, lo, hi, (const int32_t*)ix->d_xloc, ix->d_xhits);
-      if (ix->d_xoff) ma.row_off = ix->d_xoff;  // a rebalanced tier: page -> slot * stride rows (serves both parts, see exact_scan)
+      if (ix->d_xoff) { ma.row_off = ix->d_xoff; ma.n_rows = ix->d_n_rows; }  // a rebalanced tier: page -> slot * stride rows (serves both parts, see exact_scan); the table-driven kernels read n_rows unconditionally
       ma.slab = ix->slab_x; ma.cand = lo;
       if ((rc = launch_maxsim_bf16(ma, rr_variant, ix->stream)) != MV_OK) return rc;
       ma.slab = xt_host_vbase(ix); ma.cand = hi; ma.scores = ix->d_xscores;

@@ -422,6 +422,7 @@ int batch_rows_capacity() { return 512; }
 
 int launch_maxsim_batch(const BatchArgs& a, hipStream_t s) {
   if (a.n <= 0 || a.n_queries <= 0) return MV_OK;
+  if (a.row_off && !a.n_rows) { set_error("batch scan: a row-offset table needs the per-page row counts"); return MV_ERR_INVALID; }
   if (a.rows_per_query < 16 || a.rows_per_query % 16) { set_error("batch scan: rows_per_query must be a positive multiple of 16"); return MV_ERR_INVALID; }
   const int rows = a.n_queries * a.rows_per_query;
   if (rows > 512 || a.n_queries > 256) { set_error("batch scan: %d query rows exceed the 512-row group", rows); return MV_ERR_INVALID; }

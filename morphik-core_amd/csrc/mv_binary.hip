@@ -448,6 +448,7 @@ static void launch_binary_mfma(const BArgs& k, int accumulate, hipStream_t s) {
 // 1 M pages against 48 for the popcount form
 int launch_maxsim_binary(const BinaryArgs& a, int variant, hipStream_t s) {
   if (a.n <= 0) return MV_OK;
+  if (a.row_off && !a.n_rows) { set_error("sign-bit scan: a row-offset table needs the per-page row counts"); return MV_ERR_INVALID; }
   BArgs k{reinterpret_cast<const uint4*>(a.bits), a.n_rows, a.doc_ord, a.allow, a.n_allow_bits,
           reinterpret_cast<const uint4*>(a.qbits), a.scores, a.n, a.stride, a.n_q, a.qpop, a.cand, a.row_off};
   if (a.n > ((int64_t)1 << 25)) { set_error("binary scan: more than 2^25 pages per launch is not supported"); return MV_ERR_INVALID; }

@@ -871,6 +871,7 @@ int launch_fp8_query_prep(const float* d_q_f32, int n_q, uint8_t* d_hi, uint8_t*
 
 int launch_maxsim_fp8(const Fp8ScanArgs& a, hipStream_t s) {
   if (a.n <= 0) return MV_OK;
+  if (a.row_off && !a.n_rows) { set_error("fp8 scan: a row-offset table needs the per-page row counts"); return MV_ERR_INVALID; }
   const int padded = ((a.n_q + 15) / 16) * 16;
   if (a.items_per_query > 0 && (padded > 64 || !a.cand)) { set_error("per-item queries need a candidate list and <= 64 query rows"); return MV_ERR_INVALID; }
   for (int q0 = 0, pass = 0; q0 < padded; q0 += 64, ++pass) {
@@ -891,6 +892,7 @@ int launch_maxsim_fp8(const Fp8ScanArgs& a, hipStream_t s) {
 
 int launch_maxsim_batch_fp8(const Fp8BatchArgs& a, hipStream_t s) {
   if (a.n <= 0 || a.n_queries <= 0) return MV_OK;
+  if (a.row_off && !a.n_rows) { set_error("fp8 batch scan: a row-offset table needs the per-page row counts"); return MV_ERR_INVALID; }
   if (a.rows_per_query < 16 || a.rows_per_query % 16) { set_error("fp8 batch scan: rows_per_query must be a positive multiple of 16"); return MV_ERR_INVALID; }
   const int rows = a.n_queries * a.rows_per_query;
   if (rows > 512 || a.n_queries > 256) { set_error("fp8 batch scan: %d query rows exceed the 512-row group", rows); return MV_ERR_INVALID; }

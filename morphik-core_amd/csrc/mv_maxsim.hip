@@ -536,6 +536,7 @@ int launch_maxsim_bf16(const MaxsimArgs& a, int variant, hipStream_t s) {
   KArgs k{reinterpret_cast<const char*>(a.slab), a.n_rows, a.doc_ord, a.allow, a.n_allow_bits, a.cand, a.q, a.scores,
           a.n, a.stride, a.pad_to, 0, a.pad_items, a.items_per_query, a.q_item_stride, a.qlo, reinterpret_cast<const char*>(a.slab_lo), a.row_off};
   if (a.items_per_query < 0 || (a.items_per_query > 0 && !a.cand)) { set_error("items_per_query needs a candidate list"); return MV_ERR_INVALID; }
+  if (a.row_off && !a.n_rows) { set_error("a row-offset table (packed layout / re-placed exact tier) needs the per-page row counts"); return MV_ERR_INVALID; }
   if (a.slab_lo || a.qlo) {  // split-bf16 operands: the lo fragments double the query registers -- 64 query rows per pass
     if (!a.qlo) { set_error("the lo slab needs the query's lo half (zeros for a bf16 query)"); return MV_ERR_INVALID; }
     if (a.q_tiles > kMaxQTilesLo) { set_error("q_tiles=%d out of range (1..%d with split-bf16 operands)", a.q_tiles, kMaxQTilesLo); return MV_ERR_INVALID; }

@@ -632,6 +632,35 @@ def test_split_exact_tier_rebalance_moves_hot_pages_into_hbm_and_changes_no_answ
     split.close()
 
 
+def test_split_exact_tier_rebalance_on_uniform_pages():
+    """Regression (round 6, found by bench.py): the kernels that take a page -> row table read the row count unconditionally; on an index whose
+    pages all fill stride_rows (not "ragged": the scans get no n_rows array) the re-placed tier must still hand it over.  Uniform synthetic pages,
+    single and batched reranks before and after a rebalance, against the unsplit host tier."""
+    from morphik_core_amd import _lib
+
+    N, stride, k = 300, 64, 5
+    kw = dict(capacity_pages=N, stride_rows=stride, with_float=False, with_fde=True, with_fp8=True, with_host_exact=True)
+    host = _idx(**kw)
+    with _SplitAt(40):
+        split = _idx(with_exact_split=True, **kw)
+    for ix in (host, split):
+        ix.fill_synthetic(1234, 0, N)  # every page has exactly stride_rows rows
+        ix.set_option(_lib.MV_OPT_FDE_COARSE_N, 30)
+    qs = [orc.synth_rows(4321, j, 0, 16) for j in range(6)]
+    for rnd in range(2):
+        for q in qs:
+            for mode in ("fde_then_float", "fp8_then_float"):
+                ws, wi = host.query(q, k, mode=mode)
+                s, i = split.query(q, k, mode=mode)
+                assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist(), (rnd, mode)
+        for (ws, wi), (s, i) in zip(host.query_batch(qs, k, mode="fde_then_float"), split.query_batch(qs, k, mode="fde_then_float")):
+            assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist(), (rnd, "batch")
+        if rnd == 0:
+            assert split.rebalance_exact_tier() > 0
+    host.close()
+    split.close()
+
+
 def test_split_exact_tier_behind_the_store():
     """create_store("mi355x_fast_split_exact" / "mi355x_sharded_fast_split_exact"): the plugin surface over split tiers returns the
     hits of the unsplit host-tier providers, score for score."""
