@@ -502,6 +502,11 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
         }
         advance();
       }
+      // A tile ends with its last K chunk, and KC is a multiple of 4 (fde_scan_batch_supported: out_dim % 1024 == 0) while every pass of
+      // this unrolled body starts at a chunk index that is one too: the last chunk always sits in fragment set 3.  Saying so at compile
+      // time keeps the finish out of the other 3 T slots -- round 6: the body was 38 / 55 KB of code (16 / 32 requests) in front of a
+      // 64 KB instruction cache shared by two CUs, and the pass ran in a fast or a slow mode depending on the process.
+      if constexpr (kcs == 3)
       if (c_kc == KC - 1) {  // tile j of the group is done: acc[j][t][qt][i] = partial dot of page t*16 + 4g + i with query qt*16 + p
         const int pg = threadIdx.x & 63;
         const int64_t tile = (int64_t)b + (int64_t)(i0 + c_grp * T + j) * G;

@@ -27,6 +27,9 @@ PMC_SETS = {  # <= 4 counters of one block per pass (the TCC / TCP blocks expose
     "l2_hit_miss": "TCC_HIT_sum TCC_MISS_sum TCC_BUSY_sum TCC_REQ_sum",
     # GRBM_GUI_ACTIVE / 8 XCDs / (kernel time) = the shader clock the launch ran at; the SQ counters are in its cycles
     "clock_and_issue": "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA",
+    # instruction fetch: the code object lands at another address in every process -- do the hot loop's lines miss the instruction cache more
+    # often in a slow process?  (GRBM_GUI_ACTIVE rides along: the launch's cycle count is what tells fast from slow)
+    "instruction_cache": "GRBM_GUI_ACTIVE SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_IFETCH_LEVEL SQC_TC_INST_REQ",
 }
 
 

@@ -64,6 +64,19 @@ def main():
         rep.append(measure(ix, qs, rounds=7)["B32_ms"])
     res["last_build_B32_ms_repeated"] = rep
     ix.close()
+    # the pass's TRANSPORT alone -- mv_calibrate allocates a fresh 24 GiB buffer per call and reads it in the pass's pattern (64 rows x 512 B
+    # per step at a 20 480 B stride, nt LDS-DMA, nothing consumed): is the placement effect there without the kernel?  Control: whole rows.
+    import ctypes as C
+
+    from morphik_core_amd._lib import check, lib
+
+    tr = {"dma_strided_512B_GBps": [], "plain_strided_512B_GBps": [], "whole_rows_20K_GBps": []}
+    for _ in range(8):
+        for key, code in (("dma_strided_512B_GBps", 11), ("plain_strided_512B_GBps", 5), ("whole_rows_20K_GBps", 9)):
+            g = C.c_double()
+            check(lib().mv_calibrate(0, code, 24 << 30, 6, C.byref(g)))
+            tr[key].append(round(float(g.value), 1))
+    res["transport_alone_fresh_24GiB_buffer_per_call"] = tr
     print(json.dumps(res, indent=1))
 
 
