@@ -225,6 +225,14 @@ MV_API int64_t mv_index_exact_hbm_pages(const mv_index* ix); /* pages of a split
  * mv_index_exact_tier_hits: reads since the last rebalance that were served from HBM / from host memory.  No-ops without a split. */
 MV_API int mv_index_exact_tier_rebalance(mv_index* ix, int64_t max_moves, int64_t* out_moved);
 MV_API int mv_index_exact_tier_hits(mv_index* ix, int64_t* out_hbm_reads, int64_t* out_host_reads);
+/* PLACEMENT of the FDE slab.  The batched coarse pass (mv_query_topk_batch in the FDE modes) reads the slab in 512-byte pieces at a 2*out_dim-byte
+ * stride, and its time depends on WHICH physical memory hipMalloc gave the slab: up to 10 % between allocations of one process, constant for the
+ * life of an allocation.  mv_index_fde_placement_trial takes up to `trials` further allocations of the slab's size, one after the
+ * other, copies the slab into each, times the pass on it (5 launches) and keeps the faster of the two; the loser is freed.  Peak device memory:
+ * three slabs; a candidate that cannot be allocated ends the trial quietly.  Contents, ids, answers and scores are unchanged.  Exclusive with
+ * queries and writers for its duration (about 25 ms per trial and 10 GB of slab).  out_before_ms / out_after_ms: the pass's time (32 requests)
+ * on the slab it found / the slab it leaves; out_moves: how often a candidate won.  Any pointer may be NULL.  MV_ERR_INVALID without an FDE slab. */
+MV_API int mv_index_fde_placement_trial(mv_index* ix, int32_t trials, double* out_before_ms, double* out_after_ms, int32_t* out_moves);
 
 /* NON-FINITE VALUES.  A NaN / +-Inf embedding has no defined MaxSim (the reference's torch einsum -> max -> topk propagates NaN
  * and ranks it FIRST), and the scan kernels are compiled without NaN handling.  So they never enter a float-derived slab:

@@ -1156,12 +1156,13 @@ void mv_index_destroy(mv_index* ix) {
   DeviceGuard g(ix->cfg.device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
   if (ix->w_stream) (void)hipStreamSynchronize(ix->w_stream);
-  void* ptrs[] = {ix->d_xloc, ix->d_xoff, ix->d_xhits, ix->d_row_off, ix->slab_lo, ix->d_qlo, ix->d_bqlo, ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
+  void* ptrs[] = {ix->d_xloc, ix->d_xoff, ix->d_xhits, ix->d_row_off, ix->slab_lo, ix->d_qlo, ix->d_bqlo, ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores_raw, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
                   ix->d_topk_ws, ix->d_q, ix->d_qf32, ix->d_qbits, ix->d_qpop, ix->d_qfde, ix->d_qoff, ix->d_allow, ix->d_out_s,
-                  ix->d_out_id, ix->d_cand, ix->d_cand_scores, ix->d_bqf32, ix->d_bqfde, ix->d_bqimage, ix->d_btopk_ws, ix->d_bsel_s,
+                  ix->d_out_id, ix->d_cand, ix->d_cand_scores, ix->d_bqf32, ix->d_bqfde, ix->d_bqimage_raw, ix->d_btopk_ws, ix->d_bsel_s,
                   ix->d_bsel_id, ix->d_bcand, ix->d_bcand_pads, ix->d_bcand_scores, ix->d_bout_s, ix->d_bout_id, ix->d_bq8hi, ix->d_bq8lo, ix->d_bq8fac};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (void* p : ix->parked) (void)hipFree(p);
   fde_tables_destroy(&ix->fde_t);
   for (auto& e : ix->ev)
     if (e) (void)hipEventDestroy(e);
@@ -1389,6 +1390,82 @@ int mv_index_exact_tier_rebalance(mv_index* ix, int64_t max_moves, int64_t* out_
   return MV_OK;
 }
 
+// One batched coarse pass (32 requests, a fixed pseudo-random query encoding) over `slab`, median of `reps` timed launches behind `warm` untimed ones.
+static int time_fde_batch_pass(mv_index* ix, const uint16_t* slab, int64_t n, int warm, int reps, double* out_ms) {
+  FdeScanBatchArgs sa{};
+  sa.fde = slab; sa.inv_norm = ix->fde_cosine ? ix->fde_inv_norm : nullptr; sa.doc_ord = nullptr;
+  sa.q = ix->d_bqfde; sa.image = ix->d_bqimage; sa.scores = ix->d_bscores; sa.score_stride = ix->bscore_stride; sa.n = n; sa.out_dim = ix->fde_t.out_dim;
+  sa.n_queries = kFdeBatchMaxQueries;
+  std::vector<float> ms;
+  for (int r = 0; r < reps + warm; ++r) {
+    MV_HIP(hipEventRecord(ix->ev_st[0], ix->stream));
+    int rc = launch_fde_scan_batch(sa, ix->stream);
+    if (rc) return rc;
+    MV_HIP(hipEventRecord(ix->ev_st[1], ix->stream));
+    MV_HIP(hipEventSynchronize(ix->ev_st[1]));
+    float t = 0.f;
+    MV_HIP(hipEventElapsedTime(&t, ix->ev_st[0], ix->ev_st[1]));
+    if (r >= warm) ms.push_back(t);
+  }
+  std::sort(ms.begin(), ms.end());
+  *out_ms = ms[ms.size() / 2];
+  return MV_OK;
+}
+
+int mv_index_fde_placement_trial(mv_index* ix, int32_t trials, double* out_before_ms, double* out_after_ms, int32_t* out_moves) {
+  if (!ix) { set_error("null index"); return MV_ERR_INVALID; }
+  if (out_before_ms) *out_before_ms = 0.0;
+  if (out_after_ms) *out_after_ms = 0.0;
+  if (out_moves) *out_moves = 0;
+  if (!(ix->cfg.flags & MV_WITH_FDE)) { set_error("mv_index_fde_placement_trial: the index has no FDE slab"); return MV_ERR_INVALID; }
+  if (trials < 0 || trials > 16) { set_error("mv_index_fde_placement_trial: trials must be 0..16"); return MV_ERR_INVALID; }
+  if (!fde_scan_batch_supported(ix->fde_t.out_dim)) return MV_OK;  // no batched pass over this encoding width: nothing to place
+  ExclusiveLock lk(ix);
+  DeviceGuard g(ix->cfg.device);
+  int rc = mv_internal_ensure_fde_batch_ws(ix);
+  if (rc) return rc;
+  const int64_t cap = ix->cfg.capacity_pages, out_dim = ix->fde_t.out_dim;
+  const int64_t n = ix->size.load() > 0 ? ix->size.load() : cap;  // an empty index is timed over its whole slab (the pass's time does not depend on what it reads)
+  const size_t bytes = (size_t)cap * out_dim * 2;
+  {  // the requests of the timing passes: fixed pseudo-random encodings (the next real batch overwrites them)
+    std::vector<float> q((size_t)kFdeBatchMaxQueries * out_dim);
+    uint64_t z = 0x9E3779B97F4A7C15ull;
+    for (auto& v : q) { z ^= z << 13; z ^= z >> 7; z ^= z << 17; v = (float)((int64_t)(z >> 40) - (1 << 23)) * (1.0f / (1 << 23)); }
+    MV_HIP(hipStreamSynchronize(ix->stream));
+    MV_HIP(hipMemcpy(ix->d_bqfde, q.data(), q.size() * 4, hipMemcpyHostToDevice));
+  }
+  double best = 0.0;
+  rc = time_fde_batch_pass(ix, ix->fde, n, 4, 5, &best);
+  if (rc) return rc;
+  if (out_before_ms) *out_before_ms = best;
+  void* held = nullptr;  // the loser of the last comparison stays allocated while the next candidate is taken, so that the candidate is OTHER memory
+  int moves = 0;
+  for (int t = 0; t < trials; ++t) {
+    void* cand = nullptr;
+    if (hipMalloc(&cand, bytes) != hipSuccess) { (void)hipGetLastError(); break; }  // no room for another candidate: keep what we have
+    if (held) { (void)hipFree(held); held = nullptr; }
+    hipError_t e = hipMemcpyAsync(cand, ix->fde, bytes, hipMemcpyDeviceToDevice, ix->stream);
+    // incumbent, candidate, incumbent -- all three behind the copy: the pass is power-bound, and the first launches after a quiet spell (a copy
+    // is one) run 1-2 % fast; timing the candidate alone there would favour it
+    double ms = 0.0, inc_a = 0.0, inc_b = 0.0;
+    if (e == hipSuccess) rc = time_fde_batch_pass(ix, ix->fde, n, 4, 5, &inc_a);
+    if (e == hipSuccess && !rc) rc = time_fde_batch_pass(ix, (const uint16_t*)cand, n, 2, 5, &ms);
+    if (e == hipSuccess && !rc) rc = time_fde_batch_pass(ix, ix->fde, n, 2, 5, &inc_b);
+    if (e != hipSuccess || rc) { (void)hipStreamSynchronize(ix->stream); (void)hipFree(cand); if (e != hipSuccess) { set_error("hip: %s", hipGetErrorString(e)); return MV_ERR_HIP; } return rc; }
+    const double inc = 0.5 * (inc_a + inc_b);
+    if (ms < inc * 0.985) {  // (1.5 %: the measurement scatters by 0.2-0.3 %, a move costs a slab copy -- only a clear win is taken)
+      held = ix->fde; ix->fde = (uint16_t*)cand; best = ms; ++moves;
+    } else {
+      held = cand; best = inc;
+    }
+  }
+  MV_HIP(hipStreamSynchronize(ix->stream));
+  if (held) (void)hipFree(held);
+  if (out_after_ms) *out_after_ms = best;
+  if (out_moves) *out_moves = moves;
+  return MV_OK;
+}
+
 int mv_index_set_option(mv_index* ix, int option, int64_t value) {
   if (!ix) { set_error("null index"); return MV_ERR_INVALID; }
   std::lock_guard<std::mutex> lk(ix->q_mu);
@@ -1418,6 +1495,29 @@ int mv_index_set_option(mv_index* ix, int option, int64_t value) {
     case MV_OPT_EXACT_TIER:
       if (value < 0 || value > 2) { set_error("EXACT_TIER must be 0 (HBM slab), 1 (pinned-host tier) or 2 (e4m3 slab)"); return MV_ERR_INVALID; }
       ix->exact_tier = (int)value; return MV_OK;
+    case 1000: {  // (diagnostic, not in the header's option list) drop the lazily allocated batch workspaces: the next batched query allocates
+      // them afresh -- tools/fde_batch_*_probe.py use it to tell which allocation the batched FDE pass's time follows.  value: 0 = free them all;
+      // bit 0 = set them aside instead (freed with the index: the next ones cannot get the same memory back); bits 1 / 2 / 3 = only the score
+      // vectors / only the query image / only the rest.
+      DeviceGuard g(ix->cfg.device);
+      if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+      const bool park = value & 1;
+      const int sel = (int)(value >> 1) & 7;
+      auto drop = [&](void** w) { if (*w) { if (park) ix->parked.push_back(*w); else (void)hipFree(*w); *w = nullptr; } };
+      if (!sel || (sel & 1)) { ix->d_bscores = nullptr; drop(&ix->d_bscores_raw); }
+      if (!sel || (sel & 2)) { ix->d_bqimage = nullptr; drop(&ix->d_bqimage_raw); }
+      if (ix->h_bcand) { (void)hipHostFree(ix->h_bcand); ix->h_bcand = nullptr; }  // the "workspace complete" mark: the next query re-runs the ensure
+      if (!sel || (sel & 4)) {
+        void** ws[] = {(void**)&ix->d_bqfde, (void**)&ix->d_bqf32, (void**)&ix->d_btopk_ws, (void**)&ix->d_bsel_s,
+                       (void**)&ix->d_bsel_id, (void**)&ix->d_bcand, (void**)&ix->d_bcand_pads, (void**)&ix->d_bcand_scores, (void**)&ix->d_bout_s, (void**)&ix->d_bout_id,
+                       (void**)&ix->d_bq, (void**)&ix->d_bqlo, (void**)&ix->d_bq8hi, (void**)&ix->d_bq8lo, (void**)&ix->d_bq8fac};
+        for (void** w : ws) drop(w);
+        void** hs[] = {(void**)&ix->h_bout_s, (void**)&ix->h_bout_id};
+        for (void** h : hs) if (*h) { (void)hipHostFree(*h); *h = nullptr; }
+        ix->bq_lo_valid = ix->bq_has_lo = false;
+      }
+      return MV_OK;
+    }
     case MV_OPT_FLOAT_LO_SCAN:
       if (value < 0 || value > 2) { set_error("FLOAT_LO_SCAN must be 0 (hi slab only), 1 (hi + lo) or 2 (hi-only scan, split-bf16 re-score of the best)"); return MV_ERR_INVALID; }
       ix->float_lo_scan = (int)value; return MV_OK;
@@ -2166,6 +2266,27 @@ int mv_index_read_fde(mv_index* ix, int64_t page0, int64_t n_pages, float* out) 
   return MV_OK;
 }
 
+// A device buffer whose address sits `off` bytes behind a 2 MiB boundary.  The batched FDE pass runs in a fast or a slow mode (4-7 % apart)
+// depending on where its score vectors / query image start relative to the 2 MiB fragments the driver maps device memory with (DESIGN 3.20:
+// with the slabs untouched, re-allocating these two buffers flips the mode); plain hipMalloc returns whatever the heap has next.
+// env_name (diagnostic): overrides `off`; "-1" = plain hipMalloc.
+static int alloc_at_2mib_offset(void** raw, void** out, size_t bytes, int64_t off, const char* env_name) {
+  if (const char* e = getenv(env_name)) off = (int64_t)strtoll(e, nullptr, 10);
+  constexpr size_t kAl = (size_t)2 << 20;
+  if (off < 0) {
+    hipError_t er = hipMalloc(raw, bytes);
+    if (er != hipSuccess) { *raw = nullptr; return MV_ERR_NOMEM; }
+    *out = *raw;
+    return MV_OK;
+  }
+  hipError_t er = hipMalloc(raw, bytes + 2 * kAl);
+  if (er != hipSuccess) { *raw = nullptr; return MV_ERR_NOMEM; }
+  const uintptr_t b = ((uintptr_t)*raw + kAl - 1) / kAl * kAl;
+  *out = (void*)(b + (uintptr_t)((size_t)off % kAl));
+  return MV_OK;
+}
+constexpr int64_t kBwsScoresOff = 0, kBwsImageOff = 0;  // (measured: tools/fde_batch_realloc_probe.py)
+
 // Selection workspace of the batched entry point: one top-k workspace, result row and pinned read-back row per query of a
 // group (q_mu held).
 int mv_internal_ensure_batch_select_ws(mv_index* ix) {
@@ -2191,12 +2312,15 @@ int mv_internal_ensure_fde_batch_ws(mv_index* ix) {
   const size_t lists = (size_t)kFdeBatchMaxQueries * kTopkMaxDeviceK;
   if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)kBatchQRows * kRowBytes));
   if (!ix->d_bscores) {
-    hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->bscore_stride * 4);
-    if (e != hipSuccess) { ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->bscore_stride * 4); return MV_ERR_NOMEM; }
+    if (alloc_at_2mib_offset(&ix->d_bscores_raw, (void**)&ix->d_bscores, (size_t)32 * ix->bscore_stride * 4, kBwsScoresOff, "MV_BWS_SCORES_OFF")) {
+      ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->bscore_stride * 4); return MV_ERR_NOMEM;
+    }
   }
   if (!ix->d_bqf32) MV_HIP(hipMalloc(&ix->d_bqf32, (size_t)kBatchQRows * kDim * 4));
   if (!ix->d_bqfde) MV_HIP(hipMalloc(&ix->d_bqfde, (size_t)kFdeBatchMaxQueries * out_dim * 4));
-  if (!ix->d_bqimage) MV_HIP(hipMalloc(&ix->d_bqimage, mv::fde_scan_batch_image_bytes(out_dim)));
+  if (!ix->d_bqimage && alloc_at_2mib_offset(&ix->d_bqimage_raw, (void**)&ix->d_bqimage, mv::fde_scan_batch_image_bytes(out_dim), kBwsImageOff, "MV_BWS_IMAGE_OFF")) {
+    ix->d_bqimage = nullptr; set_error("hipMalloc of the query image failed"); return MV_ERR_NOMEM;
+  }
   if (ix->cfg.flags & MV_WITH_FP8) {
     if (!ix->d_bq8hi) MV_HIP(hipMalloc(&ix->d_bq8hi, (size_t)kBatchQRows * kDim));
     if (!ix->d_bq8lo) MV_HIP(hipMalloc(&ix->d_bq8lo, (size_t)kBatchQRows * kDim));
@@ -2216,8 +2340,9 @@ int mv_internal_ensure_fp8_batch_ws(mv_index* ix) {
   int rc = mv_internal_ensure_batch_select_ws(ix);
   if (rc) return rc;
   if (!ix->d_bscores) {
-    hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->bscore_stride * 4);
-    if (e != hipSuccess) { ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->bscore_stride * 4); return MV_ERR_NOMEM; }
+    if (alloc_at_2mib_offset(&ix->d_bscores_raw, (void**)&ix->d_bscores, (size_t)32 * ix->bscore_stride * 4, kBwsScoresOff, "MV_BWS_SCORES_OFF")) {
+      ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->bscore_stride * 4); return MV_ERR_NOMEM;
+    }
   }
   const size_t lists = (size_t)kFdeBatchMaxQueries * kTopkMaxDeviceK;
   if (!ix->d_bqf32) MV_HIP(hipMalloc(&ix->d_bqf32, (size_t)kBatchQRows * kDim * 4));
@@ -2650,8 +2775,9 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
   const int group = std::min(group_rows / rpq, 32);
   if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)kBatchQRows * kRowBytes));
   if (!ix->d_bscores) {
-    hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->bscore_stride * 4);
-    if (e != hipSuccess) { ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->bscore_stride * 4); return MV_ERR_NOMEM; }
+    if (alloc_at_2mib_offset(&ix->d_bscores_raw, (void**)&ix->d_bscores, (size_t)32 * ix->bscore_stride * 4, kBwsScoresOff, "MV_BWS_SCORES_OFF")) {
+      ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->bscore_stride * 4); return MV_ERR_NOMEM;
+    }
   }
   const bool per_query = allow_bits && allow_per_query;
   const uint32_t* d_allow = nullptr;

@@ -223,6 +223,13 @@ class MvIndex:
         check(lib().mv_index_exact_tier_hits(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
+    def fde_placement_trial(self, trials: int = 3) -> Tuple[float, float, int]:
+        """Try up to `trials` other allocations for the FDE slab and keep the one the batched coarse pass reads fastest (mvmaxsim.h:
+        mv_index_fde_placement_trial; peak memory three slabs).  -> (pass ms before, pass ms after, times a candidate won)."""
+        a, b, m = C.c_double(), C.c_double(), C.c_int32()
+        check(lib().mv_index_fde_placement_trial(self._h, int(trials), C.byref(a), C.byref(b), C.byref(m)))
+        return float(a.value), float(b.value), int(m.value)
+
     # -- lifecycle
     def close(self) -> None:
         if getattr(self, "_h", None):

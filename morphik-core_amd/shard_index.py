@@ -163,6 +163,10 @@ class ShardedIndex:
         """Every shard re-places the hot pages of ITS split exact tier (MvIndex.rebalance_exact_tier).  -> pages moved in all."""
         return sum(int(s.rebalance_exact_tier(max_moves)) for s in self.shards if hasattr(s, "rebalance_exact_tier"))
 
+    def fde_placement_trial(self, trials: int = 3):
+        """Every shard tries other allocations for ITS FDE slab (MvIndex.fde_placement_trial).  -> [(ms before, ms after, moves)] per shard."""
+        return [tuple(s.fde_placement_trial(trials)) for s in self.shards if hasattr(s, "fde_placement_trial")]
+
     # -- query
     def query(self, q: Any, k: int, mode: str = "float", allow: Optional[np.ndarray] = None, want_stats: bool = False, q_fde: Any = None):
         if q_fde is not None:

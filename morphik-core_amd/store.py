@@ -824,6 +824,19 @@ class MI355XMultiVectorStore(BaseVectorStore):
             f = getattr(ix, "rebalance_exact_tier", None)
             return int(f(max_moves)) if f is not None else 0
 
+    def place_fde_slab(self, trials: int = 3):
+        """FDE modes only: try up to `trials` other device allocations for the FDE slab and keep the one the batched coarse pass reads
+        fastest (mv_index_fde_placement_trial, DESIGN 3.20: the pass's time follows the slab's allocation, up to 10 % apart).  ->
+        [(pass ms before, pass ms after, moves)] per shard; [] when the index has no FDE slab.  Answers do not change.  Peak device memory
+        three slabs; writers and queries wait for its duration (seconds): call it once after a bulk load or a checkpoint load."""
+        with self._write_gate, self._lock:
+            ix = self._require_index()
+            f = getattr(ix, "fde_placement_trial", None)
+            if f is None or "fde" not in self.mode:
+                return []
+            r = f(trials)
+            return [tuple(r)] if r and not isinstance(r[0], tuple) else list(r)
+
     # ------------------------------------------------------------------ checkpoint / resume
     def _book(self) -> Dict[str, Any]:
         return {

@@ -927,6 +927,47 @@ def test_fde_batched_coarse_scan_forms_agree_on_a_corpus_of_many_tiles_per_workg
     ix.close()
 
 
+def test_fde_placement_trial_changes_where_the_slab_lives_and_nothing_else(mv):
+    """mv_index_fde_placement_trial: candidates for the FDE slab are timed under the batched pass and the fastest kept.  Whatever it keeps,
+    the batched and the single-query answers are the same bit for bit, later appends land in the slab it kept, an empty index and an
+    index without an FDE slab behave as the header says."""
+    n = 9_000
+    ix = _idx(mv, capacity_pages=n + 500, stride_rows=16, with_fde=True, with_float=True)
+    ix.fill_synthetic(1234, 0, n, pages_per_doc=3)
+    ix.remove_doc(5)
+    queries = [orc.synth_rows(4321, b, 0, 24) for b in range(20)]
+    want = ix.query_batch(queries, 30, mode="fde")
+    want1 = ix.query(queries[3], 30, mode="fde_then_float")
+    moved_total = 0
+    for trials in (0, 1, 4):
+        before, after, moves = ix.fde_placement_trial(trials)
+        assert before > 0 and after > 0 and 0 <= moves <= trials and (moves == 0 or after < before)
+        moved_total += moves
+        got = ix.query_batch(queries, 30, mode="fde")
+        for (s0, i0), (s1, i1) in zip(want, got):
+            assert i0.tolist() == i1.tolist() and s0.tolist() == s1.tolist()
+        s1, i1 = ix.query(queries[3], 30, mode="fde_then_float")
+        assert i1.tolist() == want1[1].tolist() and s1.tolist() == want1[0].tolist()
+    ix.fill_synthetic(1234, n, 500, pages_per_doc=3)  # appends encode into the slab the trial kept
+    ref = _idx(mv, capacity_pages=n + 500, stride_rows=16, with_fde=True, with_float=True)
+    ref.fill_synthetic(1234, 0, n + 500, pages_per_doc=3)
+    ref.remove_doc(5)
+    for (s0, i0), (s1, i1) in zip(ref.query_batch(queries, 30, mode="fde"), ix.query_batch(queries, 30, mode="fde")):
+        assert i0.tolist() == i1.tolist() and s0.tolist() == s1.tolist()
+    ref.close()
+    ix.close()
+    empty = _idx(mv, capacity_pages=4096, stride_rows=16, with_fde=True, with_float=False)
+    before, after, moves = empty.fde_placement_trial(2)  # timed over the whole (empty) slab
+    assert before > 0 and after > 0
+    empty.close()
+    from morphik_core_amd._lib import MvError
+
+    nofde = _idx(mv, capacity_pages=64, stride_rows=16)
+    with pytest.raises(MvError):
+        nofde.fde_placement_trial(1)
+    nofde.close()
+
+
 @pytest.mark.parametrize("n,stride", [(40, 16), (64, 16), (700, 32), (5000, 16)])
 def test_fde_batched_coarse_scan_matches_the_single_query_scan(mv, n, stride):
     """mv_query_topk_batch in FDE mode: ONE pass over the FDE slab per 32 queries (bf16 MFMA, query FDE as bf16 hi + lo;

@@ -252,6 +252,28 @@ def test_request_coalescing_on_the_fast_store_rides_the_batched_fde_pipeline():
             assert {c.document_id for c in g} <= set(d)
 
 
+def test_place_fde_slab_keeps_every_answer_single_and_sharded():
+    """store.place_fde_slab(): the FDE slab may move to another device allocation (mv_index_fde_placement_trial); answers, scores and
+    later writes are untouched; a store without an FDE slab answers []."""
+    from tests import store_scenarios as sc2
+
+    rng = np.random.default_rng(5)
+    chunks = sc2.make_chunks(rng, n_docs=7, chunks_per_doc=3)
+    for make in (lambda: _store("fde_then_float"), lambda: _sharded(2, "fde_then_float")):
+        s = make()
+        sc2.run(s.store_embeddings(chunks[:15]))
+        want = [sc2.run(s.query_similar(c.embedding, k=4)) for c in chunks[:6]]
+        rep = s.place_fde_slab(2)
+        assert rep and all(b > 0 and a > 0 and 0 <= m <= 2 for b, a, m in rep)
+        got = [sc2.run(s.query_similar(c.embedding, k=4)) for c in chunks[:6]]
+        for w, g in zip(want, got):
+            assert [(c.document_id, c.chunk_number, c.score) for c in g] == [(c.document_id, c.chunk_number, c.score) for c in w]
+        sc2.run(s.store_embeddings(chunks[15:]))
+        top = sc2.run(s.query_similar(chunks[-1].embedding, k=1))[0]
+        assert (top.document_id, top.chunk_number) == (chunks[-1].document_id, chunks[-1].chunk_number)
+    assert _store("float").place_fde_slab(1) == []
+
+
 def test_store_checkpoint_and_resume(tmp_path):
     """save() -> a fresh process-like load(): same answers, same payloads, deletes and filters still work."""
     from morphik_core_amd.store import MI355XFastMultiVectorStore
