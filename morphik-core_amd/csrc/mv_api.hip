@@ -1156,9 +1156,9 @@ void mv_index_destroy(mv_index* ix) {
   DeviceGuard g(ix->cfg.device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
   if (ix->w_stream) (void)hipStreamSynchronize(ix->w_stream);
-  void* ptrs[] = {ix->d_xloc, ix->d_xoff, ix->d_xhits, ix->d_row_off, ix->slab_lo, ix->d_qlo, ix->d_bqlo, ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores_raw, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
+  void* ptrs[] = {ix->d_xloc, ix->d_xoff, ix->d_xhits, ix->d_row_off, ix->slab_lo, ix->d_qlo, ix->d_bqlo, ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
                   ix->d_topk_ws, ix->d_q, ix->d_qf32, ix->d_qbits, ix->d_qpop, ix->d_qfde, ix->d_qoff, ix->d_allow, ix->d_out_s,
-                  ix->d_out_id, ix->d_cand, ix->d_cand_scores, ix->d_bqf32, ix->d_bqfde, ix->d_bqimage_raw, ix->d_btopk_ws, ix->d_bsel_s,
+                  ix->d_out_id, ix->d_cand, ix->d_cand_scores, ix->d_bqf32, ix->d_bqfde, ix->d_bqimage, ix->d_btopk_ws, ix->d_bsel_s,
                   ix->d_bsel_id, ix->d_bcand, ix->d_bcand_pads, ix->d_bcand_scores, ix->d_bout_s, ix->d_bout_id, ix->d_bq8hi, ix->d_bq8lo, ix->d_bq8fac};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1504,8 +1504,8 @@ int mv_index_set_option(mv_index* ix, int option, int64_t value) {
       const bool park = value & 1;
       const int sel = (int)(value >> 1) & 7;
       auto drop = [&](void** w) { if (*w) { if (park) ix->parked.push_back(*w); else (void)hipFree(*w); *w = nullptr; } };
-      if (!sel || (sel & 1)) { ix->d_bscores = nullptr; drop(&ix->d_bscores_raw); }
-      if (!sel || (sel & 2)) { ix->d_bqimage = nullptr; drop(&ix->d_bqimage_raw); }
+      if (!sel || (sel & 1)) drop((void**)&ix->d_bscores);
+      if (!sel || (sel & 2)) drop((void**)&ix->d_bqimage);
       if (ix->h_bcand) { (void)hipHostFree(ix->h_bcand); ix->h_bcand = nullptr; }  // the "workspace complete" mark: the next query re-runs the ensure
       if (!sel || (sel & 4)) {
         void** ws[] = {(void**)&ix->d_bqfde, (void**)&ix->d_bqf32, (void**)&ix->d_btopk_ws, (void**)&ix->d_bsel_s,
@@ -2266,27 +2266,6 @@ int mv_index_read_fde(mv_index* ix, int64_t page0, int64_t n_pages, float* out) 
   return MV_OK;
 }
 
-// A device buffer whose address sits `off` bytes behind a 2 MiB boundary.  The batched FDE pass runs in a fast or a slow mode (4-7 % apart)
-// depending on where its score vectors / query image start relative to the 2 MiB fragments the driver maps device memory with (DESIGN 3.20:
-// with the slabs untouched, re-allocating these two buffers flips the mode); plain hipMalloc returns whatever the heap has next.
-// env_name (diagnostic): overrides `off`; "-1" = plain hipMalloc.
-static int alloc_at_2mib_offset(void** raw, void** out, size_t bytes, int64_t off, const char* env_name) {
-  if (const char* e = getenv(env_name)) off = (int64_t)strtoll(e, nullptr, 10);
-  constexpr size_t kAl = (size_t)2 << 20;
-  if (off < 0) {
-    hipError_t er = hipMalloc(raw, bytes);
-    if (er != hipSuccess) { *raw = nullptr; return MV_ERR_NOMEM; }
-    *out = *raw;
-    return MV_OK;
-  }
-  hipError_t er = hipMalloc(raw, bytes + 2 * kAl);
-  if (er != hipSuccess) { *raw = nullptr; return MV_ERR_NOMEM; }
-  const uintptr_t b = ((uintptr_t)*raw + kAl - 1) / kAl * kAl;
-  *out = (void*)(b + (uintptr_t)((size_t)off % kAl));
-  return MV_OK;
-}
-constexpr int64_t kBwsScoresOff = 0, kBwsImageOff = 0;  // (measured: tools/fde_batch_realloc_probe.py)
-
 // Selection workspace of the batched entry point: one top-k workspace, result row and pinned read-back row per query of a
 // group (q_mu held).
 int mv_internal_ensure_batch_select_ws(mv_index* ix) {
@@ -2312,15 +2291,12 @@ int mv_internal_ensure_fde_batch_ws(mv_index* ix) {
   const size_t lists = (size_t)kFdeBatchMaxQueries * kTopkMaxDeviceK;
   if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)kBatchQRows * kRowBytes));
   if (!ix->d_bscores) {
-    if (alloc_at_2mib_offset(&ix->d_bscores_raw, (void**)&ix->d_bscores, (size_t)32 * ix->bscore_stride * 4, kBwsScoresOff, "MV_BWS_SCORES_OFF")) {
-      ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->bscore_stride * 4); return MV_ERR_NOMEM;
-    }
+    hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->bscore_stride * 4);
+    if (e != hipSuccess) { ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->bscore_stride * 4); return MV_ERR_NOMEM; }
   }
   if (!ix->d_bqf32) MV_HIP(hipMalloc(&ix->d_bqf32, (size_t)kBatchQRows * kDim * 4));
   if (!ix->d_bqfde) MV_HIP(hipMalloc(&ix->d_bqfde, (size_t)kFdeBatchMaxQueries * out_dim * 4));
-  if (!ix->d_bqimage && alloc_at_2mib_offset(&ix->d_bqimage_raw, (void**)&ix->d_bqimage, mv::fde_scan_batch_image_bytes(out_dim), kBwsImageOff, "MV_BWS_IMAGE_OFF")) {
-    ix->d_bqimage = nullptr; set_error("hipMalloc of the query image failed"); return MV_ERR_NOMEM;
-  }
+  if (!ix->d_bqimage) MV_HIP(hipMalloc(&ix->d_bqimage, mv::fde_scan_batch_image_bytes(out_dim)));
   if (ix->cfg.flags & MV_WITH_FP8) {
     if (!ix->d_bq8hi) MV_HIP(hipMalloc(&ix->d_bq8hi, (size_t)kBatchQRows * kDim));
     if (!ix->d_bq8lo) MV_HIP(hipMalloc(&ix->d_bq8lo, (size_t)kBatchQRows * kDim));
@@ -2340,9 +2316,8 @@ int mv_internal_ensure_fp8_batch_ws(mv_index* ix) {
   int rc = mv_internal_ensure_batch_select_ws(ix);
   if (rc) return rc;
   if (!ix->d_bscores) {
-    if (alloc_at_2mib_offset(&ix->d_bscores_raw, (void**)&ix->d_bscores, (size_t)32 * ix->bscore_stride * 4, kBwsScoresOff, "MV_BWS_SCORES_OFF")) {
-      ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->bscore_stride * 4); return MV_ERR_NOMEM;
-    }
+    hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->bscore_stride * 4);
+    if (e != hipSuccess) { ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->bscore_stride * 4); return MV_ERR_NOMEM; }
   }
   const size_t lists = (size_t)kFdeBatchMaxQueries * kTopkMaxDeviceK;
   if (!ix->d_bqf32) MV_HIP(hipMalloc(&ix->d_bqf32, (size_t)kBatchQRows * kDim * 4));
@@ -2775,9 +2750,8 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
   const int group = std::min(group_rows / rpq, 32);
   if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)kBatchQRows * kRowBytes));
   if (!ix->d_bscores) {
-    if (alloc_at_2mib_offset(&ix->d_bscores_raw, (void**)&ix->d_bscores, (size_t)32 * ix->bscore_stride * 4, kBwsScoresOff, "MV_BWS_SCORES_OFF")) {
-      ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->bscore_stride * 4); return MV_ERR_NOMEM;
-    }
+    hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->bscore_stride * 4);
+    if (e != hipSuccess) { ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->bscore_stride * 4); return MV_ERR_NOMEM; }
   }
   const bool per_query = allow_bits && allow_per_query;
   const uint32_t* d_allow = nullptr;

@@ -87,8 +87,6 @@ struct mv_index {
   float* d_q8fac = nullptr;    // 2^-s per query row
   uint16_t* d_bq = nullptr;    // [kBatchQRows][128] bf16 query block of the batched scans
   float* d_bscores = nullptr;  // [32][bscore_stride] per-query score vectors of the batched scan (lazily allocated)
-  void* d_bscores_raw = nullptr;   // the allocations behind d_bscores / d_bqimage (placed at a chosen offset from a 2 MiB boundary: DESIGN 3.20)
-  void* d_bqimage_raw = nullptr;
   std::vector<void*> parked;       // (diagnostic option 1000) workspaces set aside instead of freed, so that the next ones get other memory
   int64_t bscore_stride = 0;   // elements between two requests' score vectors: capacity_pages (+ MV_BSCORE_STRIDE_PAD from the environment)
   // batched FDE pipeline (mv_query_topk_batch in the FDE modes; lazily allocated, up to 32 queries per slab pass)

@@ -76,26 +76,6 @@ def main():
             rows.append(measure(ix, qs, rounds=9))
         res["same_slabs_workspace_part_replaced"][name] = rows
         print(f"replaced {name}: " + " ".join(f"{r['B16_ms']}/{r['B32_ms']}" for r in rows), file=sys.stderr, flush=True)
-    # the two buffers of the workspace the kernel touches per tile -- the [32][capacity] score vectors and the query image -- placed at chosen
-    # offsets behind a 2 MiB boundary (MV_BWS_SCORES_OFF / MV_BWS_IMAGE_OFF, read when the workspace is allocated; -1 = plain hipMalloc).
-    # Every setting twice, a filler in between: a mode that follows the offset and not the filler names the buffer and the alignment.
-    res["workspace_offset_sweep"] = []
-    K, M = 1 << 10, 1 << 20
-    sweep = [("scores", o) for o in (0, 4 * K, 64 * K, 256 * K, 512 * K, M, M + 512 * K, M + 4 * K)] + \
-            [("image", o) for o in (0, 4 * K, 64 * K, 512 * K, M, M + 512 * K)] + [("plain", -1)]
-    for which, off in (sweep if "offsets" in sys.argv[3:] else []):
-        for rep_i in range(2):
-            os.environ["MV_BWS_SCORES_OFF"] = str(off if which == "scores" else (-1 if which == "plain" else 0))
-            os.environ["MV_BWS_IMAGE_OFF"] = str(off if which == "image" else (-1 if which == "plain" else 0))
-            ix.set_option(1000, 0)
-            keep.append(torch.empty((5 + 6 * rep_i + len(keep) % 3) << 20, dtype=torch.uint8, device="cuda"))
-            m = measure(ix, qs, rounds=11)
-            m.update(buffer=which, offset_bytes=off)
-            res["workspace_offset_sweep"].append(m)
-            print(f"offset {which} {off}: {m}", file=sys.stderr, flush=True)
-    os.environ.pop("MV_BWS_SCORES_OFF", None)
-    os.environ.pop("MV_BWS_IMAGE_OFF", None)
-    ix.set_option(1000, 0)
     # the last build, measured again and again: does the mode drift inside one set of allocations?
     t0 = time.time()
     rep = []
