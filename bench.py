@@ -456,6 +456,14 @@ def full_shard(args, device, qs):
     ix.set_option(L.MV_OPT_BATCH_VARIANT, -1)
     # ---- FDE -> top-n -> rerank on the e4m3 slab (what an index WITHOUT an exact tier does), one request and 32 per slab pass
     res["fde_then_fp8_rerank"] = {cn_key: ent for cn_key, ent in fde_pipeline_timings(ix, qs, n, (75, 1000)).items()}
+    # ---- the batched pass's time follows the FDE slab's allocation: up to three other allocations tried, the fastest kept
+    t0 = time.time()
+    before, after, moves = ix.fde_placement_trial(3)
+    trial = {"pass_ms_32_requests_before": round(before, 4), "after": round(after, 4), "moves": moves, "wall_s": round(time.time() - t0, 2)}
+    if moves:
+        b32 = fde_pipeline_timings(ix, qs, n, (75,))["coarse75"]["batch_of_32"]
+        trial["coarse75_batch_of_32_after"] = {k: b32[k] for k in ("device_ms_per_batch", "requests_per_s", "coarse_pass_frac_hbm_8TBps", "same_ids_as_single_query")}
+    res["fde_placement_trial"] = trial
     ix.close()
     return res
 
@@ -899,6 +907,7 @@ def aux_summary(out, aux):
         "sign_bit_frac": g("full_shard", "sign_bit_scan", "frac_hbm_8TBps"),
         "fde_scan_frac": g("full_shard", "fde_coarse_scan", "frac_hbm_8TBps"),
         "fde_batch32_frac": g("full_shard", "fde_then_fp8_rerank", "coarse75", "batch_of_32", "coarse_pass_frac_hbm_8TBps"),
+        "fde_batch32_frac_placed": g("full_shard", "fde_placement_trial", "coarse75_batch_of_32_after", "coarse_pass_frac_hbm_8TBps"),
         "batched_bf16_B16_PF": (lambda v: None if v is None else round(v / 1000.0, 3))(g("batched_float", "B16", "TFLOPs")),
         "batched_bf16_B16_frac_2500TF": g("batched_float", "B16", "frac_mfma_bf16_2500TF"),
         "fde_request_ms": g("exact_shard", "fde_then_exact_rerank", "coarse75", "one_request", "device_ms"),
