@@ -48,7 +48,6 @@ struct ScanBatchArgs {
   int32_t n_tiles;     // ceil(n / 64)
   const float* inv_norm;    // FIN kernels: the cosine rule and the tombstones are applied where the scores are written
   const int32_t* doc_ord;   // nullable (no tombstones)
-  int32_t tiled_timing;     // EXPERIMENT (MV_FDE_TILED_TIMING=1): read the slab as if it were laid out [tile][K chunk][64 pages][512 B] -- wrong scores, right traffic
 };
 
 constexpr int kFbPages = 64;
@@ -321,9 +320,7 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
   const int KC = a.out_dim >> 8;
   const int total = n_groups * KC * T;     // ring slots of this phase; a multiple of 4 * T
   if (total == 0) return;
-  const uint32_t row_bytes = a.tiled_timing ? 512u : (uint32_t)a.out_dim * 2u;
-  const size_t kc_bytes = a.tiled_timing ? (size_t)kFbSlotBytes : (size_t)512;
-  const size_t tile_bytes = a.tiled_timing ? (size_t)KC * kFbSlotBytes : (size_t)kFbPages * a.out_dim * 2u;
+  const uint32_t row_bytes = (uint32_t)a.out_dim * 2u;
   const uint32_t q_off = (uint32_t)lane * 16u;
 
   bf16x8 qf[4][NF];  // [K chunk & 3][(e*NQT + qt)*2 + (0 = hi, 1 = lo)]
@@ -343,7 +340,7 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
   auto issue_dma = [&](int slot_idx) {
     const int64_t tile = (int64_t)b + (int64_t)(i0 + i_grp * T + i_j) * G;
     const int64_t page0 = tile * kFbPages;
-    const char* tp = a.fde + (size_t)tile * tile_bytes + (size_t)i_kc * kc_bytes - 4096;
+    const char* tp = a.fde + (size_t)page0 * row_bytes + (size_t)i_kc * 512 - 4096;
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tp);
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)tp >> 32));
     const uint64_t tpu = ((uint64_t)hi << 32) | lo;
@@ -562,7 +559,7 @@ __global__ __launch_bounds__(256) void fde_scan_batch2_kernel(ScanBatchArgs a) {
   const int p = lane & 15, g = lane >> 4;
   const int G = gridDim.x, b = blockIdx.x;
   const int n_my = (a.n_tiles - b + G - 1) / G;  // tiles b, b + G, ...  (grid <= n_tiles)
-  const uint32_t row_bytes = a.tiled_timing ? 512u : (uint32_t)a.out_dim * 2u;
+  const uint32_t row_bytes = (uint32_t)a.out_dim * 2u;
   uint32_t src_off[8];  // see fde_scan_batch_kernel
   uint32_t rd_off[2];
 #pragma unroll
@@ -693,9 +690,7 @@ int launch_fde_scan_batch(const FdeScanBatchArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(fde_batch_qprep_kernel, dim3((unsigned)(KC * 2 * nqt)), dim3(256), 0, s, a.q, a.n_queries, (int)a.out_dim, nqt, a.image);
   const int64_t n_tiles = (a.n + kFbPages - 1) / kFbPages;
   ScanBatchArgs k{reinterpret_cast<const char*>(a.fde), reinterpret_cast<const char*>(a.image), a.scores, a.score_stride, a.n,
-                  (int32_t)a.out_dim, a.n_queries, (int32_t)n_tiles, a.inv_norm, a.doc_ord, 0};
-  static const int tiled_timing = getenv("MV_FDE_TILED_TIMING") ? atoi(getenv("MV_FDE_TILED_TIMING")) : 0;
-  k.tiled_timing = tiled_timing;
+                  (int32_t)a.out_dim, a.n_queries, (int32_t)n_tiles, a.inv_norm, a.doc_ord};
   const bool fin = fde_scan_batch_fuses_finish(a);  // the paired-tile kernel applies the cosine rule and the tombstones itself
   const dim3 grid((unsigned)std::min<int64_t>(n_tiles, ncu));
   if (a.single_tile) {  // one page tile per query fragment (MV_OPT_FDE_BATCH_VARIANT = 3: the cross-check of the paired form)
