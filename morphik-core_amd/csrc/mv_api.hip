@@ -839,6 +839,9 @@ int run_scan(mv_index* ix, const void* q, int q_dtype, int n_q, int mode, const 
 
 int finish_stats(mv_index* ix, mv_query_stats* st, bool had_topk) {
   if (!st) return MV_OK;
+  // a deferred query that had nothing to enqueue, or whose zero-result early return finished it already (empty shard, no allowed page): the
+  // record is complete and no event of it may be read -- every caller (mv_query_stats_finish, mv_comm's per-shard loop) comes through here
+  if (st->reserved & kStatsDoneTag) { st->reserved = 0; return MV_OK; }
   st->reserved &= ~(kStatsDeferredTag | kStatsParityBit);  // a deferred record's routing bits are not stage flags
   MV_HIP(hipEventSynchronize(ix->ev[had_topk ? 2 : 1]));
   if (st->reserved) {  // stage split of the FDE modes (events recorded by run_scan)
@@ -2703,21 +2706,28 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
   const size_t esz = q_dtype == MV_F32 ? 4 : 2;
   const int rpq = ((n_q_rows + 15) / 16) * 16;
   mv_query_stats total{};
+  // the options that ROUTE a batch are read once, under the lock mv_index_set_option writes them under (a concurrent set_option takes
+  // effect for the next batch; TSan run of round 6: the unlocked reads below raced with it)
+  int opt_fde_batch_variant, opt_batch_variant, opt_float_lo_scan;
+  {
+    std::lock_guard<std::mutex> lk(ix->q_mu);
+    opt_fde_batch_variant = ix->fde_batch_variant; opt_batch_variant = ix->batch_variant; opt_float_lo_scan = ix->float_lo_scan;
+  }
   // FDE modes: the batched pipeline (rerank on the bf16 slab, or on the fp8 slab of an index without one: queries of <= 64 rows)
   if ((mode == MV_MODE_FDE_THEN_FLOAT || mode == MV_MODE_FDE_ONLY) && n_queries > 1 && k >= 1 && k <= kTopkMaxDeviceK && rpq <= 512 &&
-      ix->fde_batch_variant != 1 && (ix->cfg.flags & MV_WITH_FDE) &&
+      opt_fde_batch_variant != 1 && (ix->cfg.flags & MV_WITH_FDE) &&
       (mode == MV_MODE_FDE_ONLY || (ix->cfg.flags & (MV_WITH_FLOAT | MV_WITH_HOST_EXACT)) || ((ix->cfg.flags & MV_WITH_FP8) && rpq <= 64)) &&
       mv::fde_scan_batch_supported(ix->fde_t.out_dim) && ix->fde_t.cfg.projection_dimension <= 16)
     return fde_batch_query(ix, q, q_dtype, n_queries, n_q_rows, k, mode, allow_bits, n_allow_words, allow_per_query, out_scores, out_ids, out_n, stats);
   // e4m3 slab: the batched block-scaled MFMA scan (<= 512 query rows per slab pass); MV_OPT_BATCH_VARIANT 8 = query by query
   if ((mode == MV_MODE_FLOAT_FP8 || (mode == MV_MODE_FP8_THEN_FLOAT && rpq <= kMaxQRowsPerPass && (ix->cfg.flags & (MV_WITH_FLOAT | MV_WITH_HOST_EXACT)))) &&
-      n_queries > 1 && rpq <= 512 && k >= 1 && k <= kTopkMaxDeviceK && (ix->cfg.flags & MV_WITH_FP8) && ix->batch_variant != 8)
+      n_queries > 1 && rpq <= 512 && k >= 1 && k <= kTopkMaxDeviceK && (ix->cfg.flags & MV_WITH_FP8) && opt_batch_variant != 8)
     return fp8_batch_query(ix, q, q_dtype, n_queries, n_q_rows, k, mode == MV_MODE_FP8_THEN_FLOAT, allow_bits, n_allow_words, allow_per_query, out_scores,
                            out_ids, out_n, stats);
   // Split-bf16 operands (fp32 queries that are not bf16-representable; an index with a lo slab scanned with it): the batched MFMA
   // kernel multiplies ONE bf16 term per operand -- such batches are served query by query by the single-query kernels, which carry
   // the lo halves (the batch stays one call; bf16 queries on a plain index keep the one-pass form).
-  bool batch_lo = mode == MV_MODE_FLOAT && ix->slab_lo && ix->float_lo_scan != 0;
+  bool batch_lo = mode == MV_MODE_FLOAT && ix->slab_lo && opt_float_lo_scan != 0;
   if (mode == MV_MODE_FLOAT && !batch_lo && q_dtype == MV_F32) {
     const float* qf = (const float*)q;
     const size_t ne = (size_t)n_queries * n_q_rows * kDim;

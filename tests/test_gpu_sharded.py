@@ -226,6 +226,52 @@ def test_shard_comm_equals_single_index_all_modes(R, transport):
     one.close()
 
 
+@pytest.mark.parametrize("transport", ["p2p", "host"])
+def test_shard_comm_collects_stats_when_a_doc_filter_leaves_shards_without_a_page(transport):
+    """A doc filter that selects documents of ONE shard: the other shards return from their query before anything is selected and mark
+    their timing records as finished; mv_comm's per-shard stats loop must not read events that were never recorded for them (found by the
+    host stress run under the HIP stub in round 6: hipEventElapsedTime on a never-recorded stage event = MV_ERR_HIP on the real runtime).
+    Answers == one index holding every page, in every mode with and without the stage split, single and batched."""
+    from morphik_core_amd import _lib
+    from morphik_core_amd.index import ShardComm
+
+    R, per, stride, k = 3, 40, 32, 6
+    pages = [orc.synth_rows(31, i, 0, 6 + (i * 5) % 26) for i in range(R * per)]
+    ords = [(i // per) * 10 + i % 10 for i in range(R * per)]  # shard r owns documents 10 r .. 10 r + 9
+    kw = dict(stride_rows=stride, with_float=True, with_binary=True, with_fde=True, with_fp8=True)
+    one = _idx(capacity_pages=R * per, **kw)
+    one.add(pages, doc_ordinals=ords)
+    shards = []
+    for r in range(R):
+        sh = _idx(capacity_pages=per, id_base=r * per, **kw)
+        sh.add(pages[r * per : (r + 1) * per], doc_ordinals=ords[r * per : (r + 1) * per])
+        shards.append(sh)
+    for ix in [one] + shards:
+        ix.set_option(_lib.MV_OPT_FDE_COARSE_N, 30)
+        ix.set_option(_lib.MV_OPT_RERANK_N, 16)
+    comm = ShardComm(shards, transport=transport)
+    allow = np.array([0b1011010110 << 10], np.uint32)  # documents of shard 1 only
+    q = orc.synth_rows(4321, 77, 0, 18)
+    qs = [orc.synth_rows(4321, 80 + j, 0, 18) for j in range(5)]
+    for mode in ("float", "float_fp8", "binary", "fde_then_float", "fp8_then_float", "fde"):
+        ws, wi = one.query(q, k, mode=mode, allow=allow)
+        for _ in range(2):  # twice: the second call meets the event sets the first one left behind
+            s, i, st = comm.query(q, k, mode=mode, allow=allow, want_stats=True)
+            assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist(), mode
+            assert len(wi) > 0 and all(per <= x < 2 * per for x in i.tolist())
+            assert len(st) == R
+        if mode in ("float", "fde_then_float", "fp8_then_float"):
+            want = one.query_batch(qs, k, mode=mode, allow=allow)
+            got, _st = comm.query_batch(qs, k, mode=mode, allow=allow, want_stats=True)
+            for (s0, i0), (s1, i1) in zip(want, got):
+                assert i0.tolist() == i1.tolist(), mode
+                np.testing.assert_allclose(s1, s0, rtol=2e-6, err_msg=mode)  # (the one index may serve the batch with another kernel than a shard does)
+    comm.close()
+    for sh in shards:
+        sh.close()
+    one.close()
+
+
 def test_sharded_index_batch_runs_every_shard_batched_and_merges_exactly():
     """ShardedIndex.query_batch in the single-stage modes: each shard serves the whole batch through mv_query_topk_batch (a
     host thread per shard), merged per request with the communicator's rule == the communicator's answers."""

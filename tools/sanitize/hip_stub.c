@@ -16,6 +16,7 @@
  * abort the process with a message naming the call.  Test infrastructure only: it is never loaded by the product path
  * (tools/sanitize/run.sh puts it in front of the real runtime with LD_LIBRARY_PATH). */
 #define _GNU_SOURCE
+#include <execinfo.h>
 #include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -42,6 +43,7 @@ static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, 
   do {                                                                \
     fprintf(stderr, "HIP STUB AFFINITY VIOLATION: " __VA_ARGS__);     \
     fprintf(stderr, " (current device %d)\n", cur_dev);               \
+    { void* bt_[24]; int n_ = backtrace(bt_, 24); backtrace_symbols_fd(bt_, n_, 2); } /* who called: the library is built with -g */ \
     abort();                                                          \
   } while (0)
 

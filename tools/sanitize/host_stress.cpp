@@ -213,6 +213,10 @@ int main(int argc, char** argv) {
       mv_index_destroy(re);
       remove("/tmp/mv_split_stress.idx");
       unsetenv("MV_EXACT_HBM_MAX_PAGES");
+      // round 6: hot-page placement (the stub's kernels count nothing, so nothing moves: the tables, the counters' read-back and the locks are exercised)
+      int64_t moved = -1, hb = -1, hh = -1;
+      CHECK(mv_index_exact_tier_rebalance(s8[7], 0, &moved));
+      CHECK(mv_index_exact_tier_hits(s8[7], &hb, &hh));
     }
     for (int transport : {MV_COMM_RCCL, MV_COMM_P2P, MV_COMM_HOST}) {
       mv_comm* c = nullptr;
@@ -258,13 +262,70 @@ int main(int argc, char** argv) {
     }
     for (int r = 0; r < 8; ++r) mv_index_destroy(s8[r]);
   }
+  // ---- round 6: the PACKED layout (row-offset table) with split-bf16 pages (hi + lo slabs) under readers and a writer of ragged pages,
+  // compaction and checkpoints of it; the FDE slab's placement trial (exclusive) against running readers
+  std::atomic<long> n_packed{0};
+  {
+    mv_config c{};
+    c.dim = 128; c.stride_rows = 32; c.capacity_pages = 1024; c.capacity_rows = 1024 * 24; c.device = 1; c.id_base = 0;
+    c.flags = MV_WITH_FLOAT | MV_WITH_FLOAT_LO | MV_WITH_BINARY | MV_WITH_FDE | MV_WITH_FP8 | MV_LAYOUT_PACKED;
+    c.fde = mv_fde_config{128, 20, 5, 16, 1};
+    mv_index* px = nullptr;
+    CHECK(mv_index_create(&c, &px));
+    CHECK(mv_index_fill_synthetic_ragged(px, 1, 0, 256, 5, 32, 4));
+    if (mv_index_rows_used(px) <= 0 || mv_index_rows_used(px) > mv_index_capacity_rows(px)) { fprintf(stderr, "FAIL packed rows_used\n"); std::abort(); }
+    auto preader = [&](int tid) {
+      const int modes[] = {MV_MODE_FLOAT, MV_MODE_BINARY, MV_MODE_FDE_THEN_FLOAT, MV_MODE_FLOAT_FP8, MV_MODE_FP8_THEN_FLOAT, MV_MODE_FDE_ONLY};
+      std::vector<float> q = rows(20, 300 + tid), qb = rows(5 * 20, 400 + tid);
+      float s[64 * 5]; int64_t id[64 * 5]; int32_t n = 0, nb[5];
+      for (int it = 0; it < iters; ++it) {
+        CHECK(mv_query_topk(px, q.data(), MV_F32, 20, 10, modes[(it + tid) % 6], nullptr, 0, s, id, &n, nullptr));
+        if (it % 5 == 0) CHECK(mv_query_topk_batch(px, qb.data(), MV_F32, 5, 20, 7, (it % 10) ? MV_MODE_FLOAT : MV_MODE_FDE_THEN_FLOAT, nullptr, 0, 0, s, id, nb, nullptr));
+        if (it % 13 == 6 && tid == 0) { double b = 0, a = 0; int32_t m = 0; CHECK(mv_index_fde_placement_trial(px, 1, &b, &a, &m)); }
+        if (it % 17 == 3) CHECK(mv_index_set_option(px, MV_OPT_FLOAT_LO_SCAN, it % 3));  // options change under running queries of the other threads
+        if (it % 19 == 4) CHECK(mv_index_set_option(px, MV_OPT_FDE_COARSE_N, (it & 1) ? 40 : 0));
+        if (it % 23 == 5) CHECK(mv_index_set_option(px, MV_OPT_RERANK_N, 16 + it % 32));
+        if (it % 29 == 6) CHECK(mv_index_set_option(px, MV_OPT_BATCH_VARIANT, (it & 1) ? 8 : -1));
+        n_packed.fetch_add(1);
+      }
+    };
+    auto pwriter = [&]() {
+      std::vector<float> emb = rows(8 * 32, 17), back((size_t)4 * 32 * 128);
+      std::vector<uint16_t> pg(32 * 128, 0x3c00);
+      int32_t nr[8], ords[8];
+      for (int it = 0; it < iters / 2; ++it) {
+        int32_t total = 0;
+        for (int i = 0; i < 8; ++i) { nr[i] = 3 + (it * 7 + i * 5) % 30; ords[i] = 2000 + it; total += (nr[i] + 15) / 16 * 16; }
+        // emb holds 8 x 32 rows; a ragged batch is packed back to back as mv_index_add expects
+        if (mv_index_size(px) + 8 <= mv_index_capacity(px) && mv_index_rows_used(px) + total <= mv_index_capacity_rows(px))
+          CHECK(mv_index_add(px, emb.data(), MV_F32, nr, 8, ords, nullptr));
+        if (it % 3 == 1) { int64_t gone = 0; CHECK(mv_index_remove_doc(px, 2000 + it - 1, &gone)); }
+        if (it % 9 == 4) CHECK(mv_index_replace_page(px, 7, pg.data(), 5 + it % 20 > 32 ? 32 : 5 + it % 20));  // a shorter / longer page in place or at the slab's end
+        if (it % 11 == 5) CHECK(mv_index_write_rows(px, 9, 1, 2, pg.data()));
+        if (it % 25 == 12) { int64_t m = 0; CHECK(mv_index_compact(px, nullptr, &m)); }
+        if (it % 7 == 2) CHECK(mv_index_read_pages_f32(px, 3, 4, back.data()));
+        if (it % 40 == 20) CHECK(mv_index_save(px, "/tmp/mv_packed_stress.idx"));
+      }
+    };
+    for (int t = 0; t < 3; ++t) th.emplace_back(preader, t);
+    th.emplace_back(pwriter);
+    for (auto& t : th) t.join();
+    th.clear();
+    CHECK(mv_index_save(px, "/tmp/mv_packed_stress.idx"));
+    mv_index* pb = nullptr;
+    CHECK(mv_index_load("/tmp/mv_packed_stress.idx", 2, &pb));
+    if (mv_index_size(pb) != mv_index_size(px) || mv_index_rows_used(pb) != mv_index_rows_used(px)) { fprintf(stderr, "FAIL reload of the packed index\n"); std::abort(); }
+    mv_index_destroy(pb);
+    remove("/tmp/mv_packed_stress.idx");
+    mv_index_destroy(px);
+  }
   mv_index_destroy(ix);
   long copies = 0, launches = 0, events = 0, gathers = -1;
   hipstub_counters(&copies, &launches, &events);
   if (void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD))
     if (auto f = (long (*)())dlsym(h, "rcclstub_gathers")) gathers = f();
   printf("host_stress ok: %ld queries, %ld write rounds, %ld queries through the 8-shard communicators, %d iterations per thread; "
-         "stub checked %ld copies, %ld kernel launches, %ld event records for device affinity, %ld grouped RCCL all-gathers\n",
-         n_queries.load(), n_writes.load(), n_comm8.load(), iters, copies, launches, events, gathers);
+         "%ld queries on the packed split-bf16 index; stub checked %ld copies, %ld kernel launches, %ld event records for device affinity, %ld grouped RCCL all-gathers\n",
+         n_queries.load(), n_writes.load(), n_comm8.load(), iters, n_packed.load(), copies, launches, events, gathers);
   return 0;
 }

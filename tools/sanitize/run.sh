@@ -1,12 +1,12 @@
 #!/bin/bash
 # Host-side sanitizer runs WITHOUT a GPU: libmvmaxsim_{tsan,asan}.so (csrc/Makefile) + the host-only HIP stub + host_stress.cpp.
-#   bash tools/sanitize/run.sh [iterations]      -> profiles/r5/sanitize_{tsan,asan}_host_8dev.log (PROFILE_DIR)
+#   bash tools/sanitize/run.sh [iterations]      -> profiles/r6/sanitize_{tsan,asan}_host_8dev.log (PROFILE_DIR)
 set -u
 R=$(cd "$(dirname "$0")/../.." && pwd)
 ITERS=${1:-200}
 CLANG=/opt/rocm/lib/llvm/bin/clang
 CLANGXX=/opt/rocm/lib/llvm/bin/clang++
-P=${PROFILE_DIR:-$R/profiles/r5}
+P=${PROFILE_DIR:-$R/profiles/r6}
 B=$R/tools/sanitize/build; mkdir -p $B $P
 make -C $R/morphik-core_amd/csrc -s -j8 tsan asan || exit 1
 for SAN in thread address; do
