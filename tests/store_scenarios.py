@@ -124,7 +124,7 @@ ALL = [scenario_store_query_roundtrip, scenario_doc_filter, scenario_empty_and_m
        scenario_input_tolerance]
 
 
-async def scenario_random_ops_against_model(store, seed=0, n_ops=60, mode="float", capacity=64):
+async def scenario_random_ops_against_model(store, seed=0, n_ops=60, mode="float", capacity=64, fp32_pages=False):
     """Model-based check of the store's bookkeeping: a random sequence of store (incl. upserts), delete, compact and
     filtered queries; after every query the answer must be the brute-force top-k of the LIVE chunks (a plain dict is the
     model), scored by the oracle.  Catches id remapping / tombstone / ordinal-reuse mistakes that fixed scenarios miss."""
@@ -136,6 +136,8 @@ async def scenario_random_ops_against_model(store, seed=0, n_ops=60, mode="float
     used_slots = 0
 
     def bf16r(x):
+        if fp32_pages:  # a store with fp32_pages keeps hi + lo halves: the page scores as the fp32 input does (to 2^-18)
+            return np.asarray(x, np.float32)
         return orc.bf16_to_f32(orc.f32_to_bf16(x))
 
     for step in range(n_ops):

@@ -480,6 +480,26 @@ def test_random_op_sequences_match_a_brute_force_model_on_gpu(seed, mode):
         s.close()
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+@pytest.mark.parametrize("layout", ["packed", "fp32_pages", "packed_fp32_pages"])
+def test_random_op_sequences_on_the_packed_layout_and_with_fp32_pages_match_the_model(seed, layout):
+    """The same model-based sequences (upserts of pages with another row count, deletes, compaction, filtered queries) on the round-6
+    layouts: ragged pages back to back behind the row-offset table, pages kept as bf16 hi + lo, and both."""
+    from morphik_core_amd.store import MI355XMultiVectorStore
+
+    kw = {}
+    if "packed" in layout:
+        kw.update(packed_layout=True, capacity_rows=64 * 32)
+    if "fp32" in layout:
+        kw.update(fp32_pages=True)
+    s = MI355XMultiVectorStore(capacity_pages=64, stride_rows=32, mode="float", **kw)
+    assert s.initialize() is True
+    try:
+        sc.run(sc.scenario_random_ops_against_model(s, seed=seed, n_ops=90, mode="float", capacity=64, fp32_pages="fp32" in layout))
+    finally:
+        s.close()
+
+
 # ------------------------------------------------------------------ one store object over R shards (mv_comm)
 def _sharded(R, mode, transport="auto", **kw):
     from morphik_core_amd.store import MI355XShardedFastMultiVectorStore, MI355XShardedMultiVectorStore
@@ -512,6 +532,27 @@ def test_sharded_store_random_ops_match_the_model_on_gpu(R, mode):
         sc.run(sc.scenario_random_ops_against_model(s, seed=10 + R, n_ops=60, mode=mode, capacity=40))
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("R", [2, 3])
+@pytest.mark.parametrize("layout", ["packed", "packed_fp32_pages"])
+def test_sharded_store_random_ops_on_the_packed_layout_match_the_model_on_gpu(R, layout):
+    """The model-based sequences on a store whose R shards each pack THEIR pages (the row budget split like the page budget), with and
+    without fp32 pages; the FDE store on packed shards runs the reference scenarios."""
+    kw = dict(packed_layout=True, capacity_rows=64 * 32)
+    if "fp32" in layout:
+        kw.update(fp32_pages=True)
+    s = _sharded(R, "float", transport="host" if R == 2 else "p2p", **kw)
+    try:
+        sc.run(sc.scenario_random_ops_against_model(s, seed=20 + R, n_ops=70, mode="float", capacity=40, fp32_pages="fp32" in layout))
+    finally:
+        s.close()
+    for scenario in sc.ALL:
+        f = _sharded(R, "fde_then_float", **kw)
+        try:
+            sc.run(scenario(f))
+        finally:
+            f.close()
 
 
 @pytest.mark.parametrize("mode", ["float", "binary", "fde_then_float", "float_fp8"])
