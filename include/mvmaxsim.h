@@ -80,7 +80,7 @@ enum {
                              index without the flag.  (Independently of the flag, an MV_F32 QUERY is always split into hi + lo
                              and both halves are scored -- free where the scan is HBM-bound; a bf16-representable query takes
                              the one-term kernels, bit for bit as before.) */
-  MV_LAYOUT_PACKED = 128   /* PACKED page layout for ragged corpora (the reference's real encoder, ColQwen2.5, emits a different token
+  MV_LAYOUT_PACKED = 128,  /* PACKED page layout for ragged corpora (the reference's real encoder, ColQwen2.5, emits a different token
                              count per page: core/embedding/colpali_embedding_model.py:47-52): pages lie back to back in whole 16-row
                              tiles instead of one stride_rows slot each.  A table of row offsets (int64 per page, on the device) replaces
                              `page * stride_rows` in every kernel; the row-indexed slabs (bf16, its lo half, e4m3, sign bits) share it.
@@ -88,6 +88,15 @@ enum {
                              stride_rows remains the longest page the index accepts.  Appends publish as before; a page may be replaced
                              in place only by one that fits its tiles; mv_index_compact closes the holes of removed pages.  Same scores,
                              bit for bit, as the fixed-stride layout.  Not combinable with MV_WITH_HOST_EXACT. */
+  MV_WITH_FDE_E4M3 = 256   /* with MV_WITH_FDE: keep an e4m3 COPY of the FDE slab (out_dim bytes per page + one power-of-two scale) and run
+                             the COARSE stage of the FDE modes on it -- half the bytes of the pass that is nine tenths of every
+                             MV_MODE_FDE_THEN_FLOAT request.  The reference's coarse stage is an ANN index (TurboPuffer,
+                             fast_multivector_store.py:527-533): approximate by contract; what the stage owes is the candidates.  Row
+                             quantisation as the e4m3 page slab's (amax -> 2^e, RNE, saturating at 448; oracle: orc_quantize_page_fp8 on
+                             the row viewed as out_dim / 128 rows of 128); the query FDE stays fp32 (single request) or enters as two e4m3
+                             terms (batched).  Coarse scores differ from the bf16 slab's by ~1e-3 relative -- candidate sets by a page or
+                             two at the cut (recall unchanged on every corpus of the bench).  MV_OPT_FDE_COARSE_SLAB selects
+                             the slab per query.  Needs an FDE width of 10 240 (the reference's), 4 096 or 2 048; out_dim bytes per page more HBM. */
 };
 
 /* fixed_dimensional_encoding.FixedDimensionalEncodingConfig as constructed at
@@ -177,6 +186,7 @@ typedef enum {
                                     max(MV_OPT_RERANK_N, k) -> split-bf16 re-score of those -> top-k (fp32-faithful scores at the
                                     hi-only scan's speed; a page whose hi-only score misses the candidate cut by rounding alone --
                                     ~1e-4 relative -- would be lost: same caveat as MV_MODE_FP8_THEN_FLOAT, three orders smaller) */
+  MV_OPT_FDE_COARSE_SLAB = 16,   /* an index with MV_WITH_FDE_E4M3: 1 = the coarse stage reads the e4m3 copy (default), 0 = the bf16 slab */
   MV_OPT_FDE_BATCH_VARIANT = 12  /* mv_query_topk_batch in the FDE modes: 0 = batched pipeline (default): up to 32 queries per pass
                                     over the FDE slab (bf16 MFMA, query FDE as bf16 hi + lo), batched selection, every query's
                                     candidates reranked in one launch, one read-back; 1 = query by query; 2 = as 0 with the query
@@ -367,6 +377,8 @@ MV_API int mv_index_import_fde(mv_index* ix, int64_t page0, int64_t n_pages, con
 /* the FDE slab's rows of pages [page0, page0 + n_pages) as fp32 (the bf16 values the scan reads; host buffer of n_pages x out_dim floats):
  * the library's own document encodings, or what was imported -- for export to another store and for tests */
 MV_API int mv_index_read_fde(mv_index* ix, int64_t page0, int64_t n_pages, float* out);
+/* the e4m3 copy of the same rows (MV_WITH_FDE_E4M3): n_pages x out_dim codes and one scale per page -- value = decode(code) * scale */
+MV_API int mv_index_read_fde_e4m3(mv_index* ix, int64_t page0, int64_t n_pages, void* out_codes, float* out_scale);
 MV_API int mv_query_topk_fde(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const float* q_fde, int32_t k, int mode,
                              const uint32_t* allow_bits, int64_t n_allow_words, float* out_scores, int64_t* out_ids, int32_t* out_n,
                              mv_query_stats* stats);

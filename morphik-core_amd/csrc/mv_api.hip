@@ -357,6 +357,14 @@ int fp8_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_wor
   return MV_OK;
 }
 
+// MV_WITH_FDE_E4M3: the e4m3 copy of FDE rows [first, first + n), derived from the bf16 rows just written (every writer of ix->fde calls it).
+// A row is quantised like a page of the e4m3 slab: out_dim / 128 "rows" of 128 under ONE power-of-two scale (orc_quantize_page_fp8).
+static int fde8_requantize(mv_index* ix, int64_t first, int64_t n, hipStream_t st) {
+  if (!ix->fde8 || n <= 0) return MV_OK;
+  const int64_t od = ix->fde_t.out_dim;
+  return launch_quantize_pages_fp8(ix->fde + (size_t)first * od, nullptr, (int32_t)(od / kDim), n, ix->fde8 + (size_t)first * od, ix->fde8_scale + first, st);
+}
+
 // FDE coarse stage: encode the query already uploaded to d_qf32 (SUM aggregation) and scan the FDE slab -> d_scores[n].
 int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_words, int64_t n, int* launches, bool stage_events, int32_t k_next,
                     bool* hist0_done) {
@@ -376,6 +384,17 @@ int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_wo
   s.fde = ix->fde; s.inv_norm = ix->fde_cosine ? ix->fde_inv_norm : nullptr; s.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
   s.allow = d_allow; s.n_allow_bits = n_words * 32; s.q = ix->d_qfde; s.scores = ix->d_scores; s.n = n;
   s.out_dim = ix->fde_t.out_dim;
+  if (ix->fde8 && ix->fde_coarse_e4m3) {  // MV_WITH_FDE_E4M3: the same stage over half the bytes (the selection bins the scores itself)
+    FdeScan8Args s8{};
+    s8.fde8 = ix->fde8; s8.scale = ix->fde8_scale; s8.inv_norm = s.inv_norm; s8.doc_ord = s.doc_ord; s8.allow = s.allow; s8.n_allow_bits = s.n_allow_bits;
+    s8.q = s.q; s8.scores = s.scores; s8.n = n; s8.out_dim = s.out_dim;
+    if (hist0_done) *hist0_done = false;
+    rc = launch_fde_scan8(s8, ix->stream);
+    if (rc) return rc;
+    if (stage_events) MV_HIP(hipEventRecord(ix->ev_st[1], ix->stream));
+    *launches += 2;
+    return MV_OK;
+  }
   const bool prebin = k_next > 0 && hist0_done && topk_uses_radix(n, k_next) && fde_scan_prebins(ix->fde_scan_variant, s.out_dim);
   s.hist0 = prebin ? topk_radix_hist0(ix->d_topk_ws) : nullptr;  // zero between selections (cleared by the previous one's last kernel)
   if (hist0_done) *hist0_done = prebin;
@@ -993,6 +1012,7 @@ int add_pages_common(mv_index* ix, const void* d_src, int dtype, const int32_t* 
     e.out_bf16 = ix->fde + (size_t)first * ix->fde_t.out_dim;
     e.out_inv_norm = ix->fde_inv_norm + first;
     rc = launch_fde_encode(ix->fde_t, e, ws);
+    if (!rc) rc = fde8_requantize(ix, first, n_pages, ws);
   }
   if (!rc && (ix->cfg.flags & MV_WITH_FP8))
     rc = launch_quantize_pages_fp8(img, ix->d_n_rows + first, stride, n_pages, packed ? ix->slab8 : ix->slab8 + (size_t)row0 * kDim,
@@ -1159,7 +1179,7 @@ void mv_index_destroy(mv_index* ix) {
   DeviceGuard g(ix->cfg.device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
   if (ix->w_stream) (void)hipStreamSynchronize(ix->w_stream);
-  void* ptrs[] = {ix->d_xloc, ix->d_xoff, ix->d_xhits, ix->d_row_off, ix->slab_lo, ix->d_qlo, ix->d_bqlo, ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
+  void* ptrs[] = {ix->d_xloc, ix->d_xoff, ix->d_xhits, ix->d_row_off, ix->slab_lo, ix->d_qlo, ix->d_bqlo, ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->fde8, ix->fde8_scale, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
                   ix->d_topk_ws, ix->d_q, ix->d_qf32, ix->d_qbits, ix->d_qpop, ix->d_qfde, ix->d_qoff, ix->d_allow, ix->d_out_s,
                   ix->d_out_id, ix->d_cand, ix->d_cand_scores, ix->d_bqf32, ix->d_bqfde, ix->d_bqimage, ix->d_btopk_ws, ix->d_bsel_s,
                   ix->d_bsel_id, ix->d_bcand, ix->d_bcand_pads, ix->d_bcand_scores, ix->d_bout_s, ix->d_bout_id, ix->d_bq8hi, ix->d_bq8lo, ix->d_bq8fac};
@@ -1191,6 +1211,10 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   if (cfg->stride_rows < 16 || cfg->stride_rows % 16) { set_error("stride_rows must be a positive multiple of 16 (got %d)", cfg->stride_rows); return MV_ERR_INVALID; }
   if (cfg->capacity_pages < 1 || cfg->capacity_pages > 0x7fffffffLL) { set_error("capacity_pages out of range"); return MV_ERR_INVALID; }
   if (!(cfg->flags & (MV_WITH_FLOAT | MV_WITH_BINARY | MV_WITH_FDE | MV_WITH_FP8))) { set_error("flags select no slab"); return MV_ERR_INVALID; }
+  if (cfg->flags & MV_WITH_FDE_E4M3) {
+    if (!(cfg->flags & MV_WITH_FDE)) { set_error("MV_WITH_FDE_E4M3 needs MV_WITH_FDE (it is a copy of that slab)"); return MV_ERR_INVALID; }
+    if (!fde_scan8_supported(mv_fde_output_dim(&cfg->fde))) { set_error("MV_WITH_FDE_E4M3 needs an FDE width of 10240, 4096 or 2048 (got %lld)", (long long)mv_fde_output_dim(&cfg->fde)); return MV_ERR_INVALID; }
+  }
   if (cfg->flags & MV_LAYOUT_PACKED) {
     if (cfg->flags & MV_WITH_HOST_EXACT) { set_error("MV_LAYOUT_PACKED cannot be combined with MV_WITH_HOST_EXACT (the host exact tier keeps fixed-stride pages)"); return MV_ERR_INVALID; }
     if (cfg->capacity_rows < 0 || cfg->capacity_rows % 16 || (cfg->capacity_rows > 0 && cfg->capacity_rows < cfg->stride_rows)) {
@@ -1258,6 +1282,10 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
     rc = fde_tables_create(cfg->fde, &ix->fde_t);
     alloc((void**)&ix->fde, (size_t)cap * ix->fde_t.out_dim * 2, "FDE slab");
     alloc((void**)&ix->fde_inv_norm, (size_t)cap * 4, "FDE norms");
+    if (cfg->flags & MV_WITH_FDE_E4M3) {
+      alloc((void**)&ix->fde8, (size_t)cap * ix->fde_t.out_dim, "e4m3 copy of the FDE slab");
+      alloc((void**)&ix->fde8_scale, (size_t)cap * 4, "e4m3 FDE scales");
+    }
     alloc((void**)&ix->d_qfde, (size_t)std::max<int64_t>(ix->fde_t.out_dim, 1) * 4, "query FDE");
   }
   if (ix->packed) {
@@ -1521,6 +1549,10 @@ int mv_index_set_option(mv_index* ix, int option, int64_t value) {
       }
       return MV_OK;
     }
+    case MV_OPT_FDE_COARSE_SLAB:
+      if (value != 0 && value != 1) { set_error("FDE_COARSE_SLAB must be 0 (bf16 slab) or 1 (e4m3 copy)"); return MV_ERR_INVALID; }
+      if (value == 1 && !ix->fde8) { set_error("FDE_COARSE_SLAB 1 needs an index with MV_WITH_FDE_E4M3"); return MV_ERR_STATE; }
+      ix->fde_coarse_e4m3 = (int)value; return MV_OK;
     case MV_OPT_FLOAT_LO_SCAN:
       if (value < 0 || value > 2) { set_error("FLOAT_LO_SCAN must be 0 (hi slab only), 1 (hi + lo) or 2 (hi-only scan, split-bf16 re-score of the best)"); return MV_ERR_INVALID; }
       ix->float_lo_scan = (int)value; return MV_OK;
@@ -1770,6 +1802,7 @@ static int derive_slabs_from_bf16(mv_index* ix, const uint16_t* rows_ptr, int64_
       rc = launch_fde_encode(ix->fde_t, e, st);
       done += c;
     }
+    if (!rc) rc = fde8_requantize(ix, first, n, st);
   }
   return rc;
 }
@@ -1937,6 +1970,7 @@ int mv_index_compact(mv_index* ix, int64_t* out_old_to_new, int64_t* out_new_siz
   if (ix->cfg.flags & MV_WITH_FP8) { slabs.push_back({(char*)ix->slab8, stride * kDim, (size_t)kDim}); slabs.push_back({(char*)ix->inv_scale8, 16, 0}); }
   if (ix->cfg.flags & MV_WITH_BINARY) slabs.push_back({(char*)ix->bits, stride * kSignBytes, (size_t)kSignBytes});
   if (ix->cfg.flags & MV_WITH_FDE) { slabs.push_back({(char*)ix->fde, (size_t)ix->fde_t.out_dim * 2, 0}); slabs.push_back({(char*)ix->fde_inv_norm, 16, 0}); }
+  if (ix->fde8) { slabs.push_back({(char*)ix->fde8, (size_t)ix->fde_t.out_dim, 0}); slabs.push_back({(char*)ix->fde8_scale, 16, 0}); }
   int rc = MV_OK;
   // packed layout: the new row offsets (live pages keep their slots, back to back) and, per moved page, (old first row, new first row, rows)
   std::vector<int64_t> new_off;
@@ -2249,6 +2283,7 @@ int mv_index_import_fde(mv_index* ix, int64_t page0, int64_t n_pages, const floa
     const int64_t c = std::min(chunk, n_pages - done);
     MV_HIP(hipMemcpyAsync(ix->w_tmp, fde + (size_t)done * out_dim, (size_t)c * out_dim * 4, hipMemcpyHostToDevice, ix->w_stream));
     rc = launch_fde_import((const float*)ix->w_tmp, c, out_dim, ix->fde + (size_t)(page0 + done) * out_dim, ix->fde_inv_norm + page0 + done, ix->w_stream);
+    if (!rc) rc = fde8_requantize(ix, page0 + done, c, ix->w_stream);
     MV_HIP(hipStreamSynchronize(ix->w_stream));  // the staging buffer is reused; the caller's buffer may be pageable
   }
   return rc;
@@ -2266,6 +2301,16 @@ int mv_index_read_fde(mv_index* ix, int64_t page0, int64_t n_pages, float* out) 
     const uint32_t u = (uint32_t)h[i] << 16;
     memcpy(&out[i], &u, 4);
   }
+  return MV_OK;
+}
+
+int mv_index_read_fde_e4m3(mv_index* ix, int64_t page0, int64_t n_pages, void* out_codes, float* out_scale) {
+  if (!ix || !out_codes || !out_scale || page0 < 0 || n_pages < 0 || page0 + n_pages > ix->size.load()) { set_error("read_fde_e4m3: range"); return MV_ERR_INVALID; }
+  if (!ix->fde8) { set_error("index has no e4m3 copy of the FDE slab (MV_WITH_FDE_E4M3)"); return MV_ERR_STATE; }
+  std::lock_guard<std::mutex> lk(ix->q_mu);
+  DeviceGuard g(ix->cfg.device);
+  MV_HIP(hipMemcpy(out_codes, ix->fde8 + (size_t)page0 * ix->fde_t.out_dim, (size_t)n_pages * ix->fde_t.out_dim, hipMemcpyDeviceToHost));
+  MV_HIP(hipMemcpy(out_scale, ix->fde8_scale + page0, (size_t)n_pages * 4, hipMemcpyDeviceToHost));
   return MV_OK;
 }
 
@@ -3331,6 +3376,10 @@ int mv_index_load(const char* path, int32_t device, mv_index** out) {
   if (h.cfg.flags & MV_WITH_FDE) {
     fill(ix->fde, (size_t)h.size * ix->fde_t.out_dim * 2);
     fill(ix->fde_inv_norm, (size_t)h.size * 4);
+    if (!rc && ix->fde8) {  // the e4m3 copy is not in the file: derived again (the quantiser is deterministic)
+      rc = fde8_requantize(ix, 0, h.size, nullptr);
+      if (!rc && hipDeviceSynchronize() != hipSuccess) { set_error("%s: quantising the FDE slab failed", path); rc = MV_ERR_HIP; }
+    }
   }
   if (h.cfg.flags & MV_WITH_FP8) {
     fill(ix->slab8, rows * kDim);

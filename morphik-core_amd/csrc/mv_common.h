@@ -208,6 +208,21 @@ struct FdeScanArgs {
 };
 // variant: -1 / 5 = row quarters through the nt LDS-DMA ring (default), 0 = query in registers, one wave per row, nt loads (cross-check)
 int launch_fde_scan(const FdeScanArgs& a, int variant, hipStream_t s);
+// The same stage on the e4m3 copy of the slab (mv_fde8.hip): score = (sum_i q_i * decode(code_i)) * scale[page] (* inv_norm[page]).
+struct FdeScan8Args {
+  const uint8_t* fde8;      // [pages][out_dim] e4m3fn
+  const float* scale;       // [pages]
+  const float* inv_norm;    // [pages] (nullable -> dot)
+  const int32_t* doc_ord;
+  const uint32_t* allow;
+  int64_t n_allow_bits;
+  const float* q;           // [out_dim] fp32
+  float* scores;            // [n]
+  int64_t n;
+  int64_t out_dim;
+};
+bool fde_scan8_supported(int64_t out_dim);
+int launch_fde_scan8(const FdeScan8Args& a, hipStream_t s);
 bool fde_scan_prebins(int variant, int64_t out_dim);  // the form launch_fde_scan would run fills FdeScanArgs::hist0
 constexpr int kFdeBatchMaxQueries = 32;
 // Up to 32 queries per pass over the FDE slab (bf16 MFMA, fp32 queries as bf16 hi + lo): scores[q][page] at

@@ -165,6 +165,9 @@ struct mv_index {
   int64_t rerank_n = 128;  // MV_MODE_FP8_THEN_FLOAT: candidates re-scored on the exact tier
   int exact_tier = 0;      // 0 = the bf16 slab in HBM when the index has one, else the pinned-host tier; 1 = the host tier when present
   int fde_cosine = 1;
+  uint8_t* fde8 = nullptr;         // MV_WITH_FDE_E4M3: [capacity][out_dim] e4m3 copy of the FDE slab (derived after every write of `fde`)
+  float* fde8_scale = nullptr;     // [capacity] value = decode(code) * scale (a power of two)
+  int fde_coarse_e4m3 = 1;         // MV_OPT_FDE_COARSE_SLAB
   int pad_semantics = -1;  // -1: mode default (reference batch rule for FDE_THEN_FLOAT / candidates, none for full scan)
   int float_lo_scan = 1;   // MV_MODE_FLOAT full scans on an index with a lo slab: 1 = read both halves (fp32-faithful scores, 2 x the bytes),
                            // 0 = the hi half only (the bf16-rounded pages), 2 = hi-only scan -> top max(MV_OPT_RERANK_N, k) -> split-bf16 re-score

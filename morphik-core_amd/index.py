@@ -29,6 +29,7 @@ from ._lib import (
     MV_WITH_EXACT_SPLIT,
     MV_WITH_FLOAT_LO,
     MV_LAYOUT_PACKED,
+    MV_WITH_FDE_E4M3,
     ConfigC,
     FdeConfigC,
     QueryStatsC,
@@ -180,6 +181,7 @@ class MvIndex:
         with_float_lo: bool = False,
         packed: bool = False,
         capacity_rows: int = 0,
+        with_fde_e4m3: bool = False,
     ):
         """with_host_exact: keep the exact bf16 rows in PINNED HOST memory (no HBM) as the exact tier of mode
         "fp8_then_float" -- for shards whose bf16 slab does not fit beside the fp8 slab.
@@ -191,11 +193,13 @@ class MvIndex:
         packed (MV_LAYOUT_PACKED): ragged pages lie back to back in whole 16-row tiles instead of one stride_rows slot each -- a
         ColQwen2.5-like corpus (dynamic token counts, colpali_embedding_model.py:47-52) then takes the HBM of its valid rows, not of
         its longest page; capacity_rows = rows the row-indexed slabs hold in all (0 = capacity_pages * stride_rows); stride_rows stays
-        the longest page accepted.  Same scores as the fixed layout, bit for bit."""
+        the longest page accepted.  Same scores as the fixed layout, bit for bit.
+        with_fde_e4m3 (with with_fde): an e4m3 copy of the FDE slab (out_dim bytes per page) that the COARSE stage of the FDE modes reads
+        instead of the bf16 slab -- half the bytes of the pass that dominates every request; set_option(MV_OPT_FDE_COARSE_SLAB, 0) goes back."""
         self.fde_config = fde or FdeConfig()
         flags = ((MV_WITH_FLOAT if with_float else 0) | (MV_WITH_BINARY if with_binary else 0) | (MV_WITH_FDE if with_fde else 0)
                  | (MV_WITH_FP8 if with_fp8 else 0) | (MV_WITH_HOST_EXACT if with_host_exact else 0) | (MV_WITH_EXACT_SPLIT if with_exact_split else 0)
-                 | (MV_WITH_FLOAT_LO if with_float_lo else 0) | (MV_LAYOUT_PACKED if packed else 0))
+                 | (MV_WITH_FLOAT_LO if with_float_lo else 0) | (MV_LAYOUT_PACKED if packed else 0) | (MV_WITH_FDE_E4M3 if with_fde_e4m3 else 0))
         cfg = ConfigC(128, int(stride_rows), int(capacity_pages), int(device), flags, int(id_base), self.fde_config.to_c(), int(capacity_rows) if packed else 0)
         h = C.c_void_p()
         check(lib().mv_index_create(C.byref(cfg), C.byref(h)))
@@ -342,6 +346,13 @@ class MvIndex:
         out = np.empty((int(n_pages), self.fde_config.output_dim), np.float32)
         check(lib().mv_index_read_fde(self._h, int(page0), int(n_pages), out.ctypes.data))
         return out
+
+    def read_fde_e4m3(self, page0: int, n_pages: int) -> Tuple[np.ndarray, np.ndarray]:
+        """-> (e4m3 codes [n_pages][output_dim] uint8, scales [n_pages] float32) of the FDE slab's e4m3 copy: value = decode(code) * scale."""
+        codes = np.empty((int(n_pages), self.fde_config.output_dim), np.uint8)
+        sc = np.empty(int(n_pages), np.float32)
+        check(lib().mv_index_read_fde_e4m3(self._h, int(page0), int(n_pages), codes.ctypes.data, sc.ctypes.data))
+        return codes, sc
 
     def read_fp8(self, page0: int, n_pages: int) -> Tuple[np.ndarray, np.ndarray]:
         """-> (e4m3 codes [n, stride_rows, 128] uint8, per-page inverse scales [n] float32)."""

@@ -31,7 +31,7 @@ def _checkpoint_has_exact_split(shard_path: str) -> bool:
 class ShardedIndex:
     def __init__(self, capacity_pages: int, stride_rows: int, devices: Sequence[int], with_float: bool = True, with_binary: bool = False,
                  with_fde: bool = False, with_fp8: bool = False, fde=None, transport: str = "auto", id_base: int = 0,
-                 index_cls=None, comm_cls=None, with_host_exact: bool = False, with_exact_split: bool = False, with_float_lo: bool = False, packed: bool = False, capacity_rows: int = 0):
+                 index_cls=None, comm_cls=None, with_host_exact: bool = False, with_exact_split: bool = False, with_float_lo: bool = False, packed: bool = False, capacity_rows: int = 0, with_fde_e4m3: bool = False):
         from .index import MvIndex, ShardComm
 
         index_cls = index_cls or MvIndex
@@ -48,6 +48,8 @@ class ShardedIndex:
         if packed:
             extra["packed"] = True  # every shard packs ITS pages; the row budget is split like the page budget
             extra["capacity_rows"] = (-(-int(capacity_rows) // self.n_shards) + 15) // 16 * 16 if capacity_rows else 0
+        if with_fde_e4m3:
+            extra["with_fde_e4m3"] = True  # every shard's coarse stage reads the e4m3 copy of ITS FDE slab
         if with_float_lo:
             extra["with_float_lo"] = True  # every shard keeps the lo half of its bf16 slab (fp32-faithful rerank / scan)
         if with_exact_split:

@@ -1,0 +1,208 @@
+"""MV_WITH_FDE_E4M3 (round 6): the coarse stage of the FDE modes on an e4m3 copy of the FDE slab.
+
+The reference's coarse stage is a TurboPuffer ANN query over the documents' FDE vectors (core/vector_store/fast_multivector_store.py:527-533):
+approximate by contract.  What is held here: the copy is the oracle's quantisation of the bf16 rows bit for bit (orc_quantize_page_fp8 on a row
+viewed as out_dim / 128 rows of 128); the scan's scores are the fp32 dot products of those codes (all 256 of them pass through the hardware
+conversion); every writer of the FDE slab keeps the copy in step; the pipeline's answers are those of the bf16 coarse stage wherever the
+candidates decide nothing (planted neighbours), and its recall on hard negatives is the bf16 stage's."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as orc  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _idx(**kw):
+    from morphik_core_amd.index import MvIndex
+
+    return MvIndex(**kw)
+
+
+def _requantize(fde_f32):
+    """oracle: bf16 FDE rows (given widened to fp32) -> (codes [n][out_dim], scale [n])"""
+    n, od = fde_f32.shape
+    codes = np.empty((n, od), np.uint8)
+    scale = np.empty(n, np.float32)
+    for i in range(n):
+        c, inv = orc.quantize_page_fp8(orc.f32_to_bf16(fde_f32[i]).reshape(-1, 128), od // 128)
+        codes[i] = c.reshape(-1)
+        scale[i] = inv
+    return codes, scale
+
+
+def _assert_copy_in_step(ix, n):
+    want_c, want_s = _requantize(ix.read_fde(0, n))
+    got_c, got_s = ix.read_fde_e4m3(0, n)
+    assert got_s.tolist() == want_s.tolist()
+    assert np.array_equal(got_c, want_c)
+
+
+def _pages(n, stride, seed=5):
+    return [orc.synth_rows(seed, i, 0, 3 + (i * 7) % (stride - 2)) for i in range(n)]
+
+
+def test_copy_is_the_oracles_quantisation_and_every_writer_keeps_it_in_step(tmp_path):
+    from morphik_core_amd.index import MvIndex
+
+    N, stride = 90, 32
+    ix = _idx(capacity_pages=N + 10, stride_rows=stride, with_float=True, with_fde=True, with_fde_e4m3=True)
+    ix.add(_pages(N, stride), doc_ordinals=np.arange(N, dtype=np.int32) // 3)
+    _assert_copy_in_step(ix, N)
+    # all-zero row: scale 1, codes 0
+    ix.add([np.zeros((4, 128), np.float32)], doc_ordinals=[500])
+    c, s = ix.read_fde_e4m3(N, 1)
+    assert s.tolist() == [1.0] and not c.any()
+    ix.replace_page(7, orc.synth_rows(77, 0, 0, 19))
+    rng = np.random.default_rng(3)
+    ix.import_fde(11, rng.standard_normal((3, ix.fde_config.output_dim)).astype(np.float32) * 37.0)
+    _assert_copy_in_step(ix, N + 1)
+    ix.remove_doc(2)
+    ix.remove_page(40)
+    ix.compact()
+    n = len(ix)
+    assert n == N + 1 - 4
+    _assert_copy_in_step(ix, n)
+    path = str(tmp_path / "e4m3.idx")
+    ix.save(path)
+    re = MvIndex.load(path, device=0)
+    assert np.array_equal(re.read_fde_e4m3(0, n)[0], ix.read_fde_e4m3(0, n)[0]) and re.read_fde_e4m3(0, n)[1].tolist() == ix.read_fde_e4m3(0, n)[1].tolist()
+    q = orc.synth_rows(4321, 1, 0, 20)
+    assert re.query(q, 5, mode="fde_then_float")[1].tolist() == ix.query(q, 5, mode="fde_then_float")[1].tolist()
+    re.close()
+    ix.close()
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 33, 700, 5003])
+def test_scan_scores_are_the_fp32_dot_products_of_the_codes(n):
+    """Rows that hold EVERY e4m3 code (imported, so the codes are known), a caller-supplied query FDE: the scan's score of a page is
+    (sum_i q_i decode(code_i)) * scale / |d| to fp32 summation accuracy -- i.e. v_cvt_pk_f32_fp8 decodes what the oracle's table decodes --
+    for page counts around the 32-row unit, with tombstones and a doc filter, cosine on and off."""
+    from morphik_core_amd import _lib
+    from morphik_core_amd.index import allow_bitmap
+
+    stride = 16
+    ix = _idx(capacity_pages=n, stride_rows=stride, with_float=False, with_fde=True, with_fde_e4m3=True)
+    od = ix.fde_config.output_dim
+    ix.add([orc.synth_rows(9, i, 0, 5) for i in range(n)], doc_ordinals=np.arange(n, dtype=np.int32) // 2)
+    lut = orc.e4m3_decode(np.arange(256, dtype=np.uint8)).astype(np.float32)
+    finite = np.array([c for c in range(256) if (c & 0x7F) != 0x7F], np.uint8)  # 0x7f / 0xff are e4m3fn's NaN: the quantiser never writes them
+    rng = np.random.default_rng(n)
+    m = min(n, 40)
+    codes = finite[rng.integers(0, finite.size, size=(m, od))]
+    codes[:, 0] = 0x7E  # 448: the row's amax -> scale 1, the imported values ARE the decoded codes
+    rows = lut[codes] * np.float32(0.5) ** rng.integers(0, 3, size=(m, 1)).astype(np.float32)  # other scales too
+    ix.import_fde(0, rows)
+    got_c, got_s = ix.read_fde_e4m3(0, m)
+    assert np.array_equal(got_c, codes)
+    if n > 3:
+        ix.remove_page(2)
+    qf = rng.standard_normal(od).astype(np.float32)
+    full_c, full_s = ix.read_fde_e4m3(0, n)
+    deq = lut[full_c].astype(np.float64)
+    norms = np.linalg.norm(ix.read_fde(0, n).astype(np.float64), axis=1)
+    allow = allow_bitmap([d for d in range((n + 1) // 2) if d % 3 != 1], (n + 1) // 2)
+    for cosine in (1, 0):
+        ix.set_option(_lib.MV_OPT_FDE_COSINE, cosine)
+        want = (deq @ qf.astype(np.float64)) * full_s
+        if cosine:
+            want = want / np.where(norms > 0, norms, 1.0)
+        for al in (None, allow):
+            s, i = ix.query(orc.synth_rows(1, 0, 0, 4), min(n, 1000), mode="fde", q_fde=qf, allow=al)
+            live = [p for p in range(n) if not (n > 3 and p == 2) and (al is None or (p // 2) % 3 != 1)]
+            assert set(i.tolist()) <= set(live) and len(i) == min(len(live), 1000)
+            if n <= 1000:
+                assert sorted(i.tolist()) == live
+            else:  # the best 1000 of the live pages
+                assert float(s.min()) >= float(np.sort(want[live])[-1000]) - 1e-4 * float(np.abs(want).max())
+            np.testing.assert_allclose(s, want[i], rtol=2e-5, atol=1e-4 * float(np.abs(want).max()))
+    ix.close()
+
+
+def test_pipeline_on_the_e4m3_coarse_stage_equals_the_bf16_stage_where_candidates_decide_nothing():
+    """Planted neighbours: both coarse stages put them among the candidates, the exact rerank returns the same ids and scores; the option
+    switches the slab per query; coarse scores of the two slabs agree to the quantisation's ~1e-2."""
+    from morphik_core_amd import _lib, synth
+
+    N, stride = 3000, 64
+    q = orc.synth_rows(4321, 0, 0, 32)
+    ix = _idx(capacity_pages=N, stride_rows=stride, with_fde=True, with_fde_e4m3=True)
+    ix.fill_synthetic(1234, 0, N)
+    spec = synth.planted_spec([q], N, stride, n_ranks=10)
+    for (_, _, p, row0, rows) in spec:
+        page = ix.read_pages(p, 1)[0]
+        page[row0 : row0 + rows.shape[0]] = rows
+        ix.replace_page(p, page)
+    planted = [p for (_, _, p, _, _) in spec]
+    s8, i8 = ix.query(q, 10, mode="fde_then_float")
+    c8 = ix.score_all(q, mode="fde")
+    ix.set_option(_lib.MV_OPT_FDE_COARSE_SLAB, 0)
+    s16, i16 = ix.query(q, 10, mode="fde_then_float")
+    c16 = ix.score_all(q, mode="fde")
+    ix.set_option(_lib.MV_OPT_FDE_COARSE_SLAB, 1)
+    assert i8.tolist() == i16.tolist() == planted and s8.tolist() == s16.tolist()
+    assert not np.array_equal(c8, c16)
+    np.testing.assert_allclose(c8, c16, rtol=0, atol=2e-2 * float(np.abs(c16).max()))
+    # a batch: the planted query's answer is the single query's whatever slab the batched pass reads
+    qs = [q] + [orc.synth_rows(4321, j, 0, 32) for j in range(1, 6)]
+    sb, ib = ix.query_batch(qs, 10, mode="fde_then_float")[0]
+    assert ib.tolist() == planted and sb.tolist() == s8.tolist()
+    ix.close()
+
+
+def test_recall_of_the_e4m3_coarse_stage_on_hard_negatives_is_the_bf16_stages():
+    """64 near-tied pages per query (exact scores 3e-4 apart per rank): of the exact top-10, how many does each coarse stage keep among its 75
+    candidates?  The e4m3 stage may not lose more than one page in all against the bf16 stage."""
+    from morphik_core_amd import _lib, synth
+
+    N, stride, NQ = 20_000, 64, 12
+    qs = [orc.synth_rows(4321, j, 0, 32) for j in range(NQ)]
+    ix = _idx(capacity_pages=N, stride_rows=stride, with_float=True, with_fde=True, with_fde_e4m3=True)
+    ix.fill_synthetic(1234, 0, N)
+    spec = synth.hard_spec(qs, N, stride)
+    for (_qi, _j, p, row0, rows) in spec:
+        page = ix.read_pages(p, 1)[0]
+        page[row0 : row0 + rows.shape[0]] = rows
+        ix.replace_page(p, page)
+    ix.set_option(_lib.MV_OPT_FDE_COARSE_N, 75)
+    kept = {0: 0, 1: 0}
+    for q in qs:
+        truth = set(ix.query(q, 10, mode="float")[1].tolist())
+        for slab in (0, 1):
+            ix.set_option(_lib.MV_OPT_FDE_COARSE_SLAB, slab)
+            cand = set(ix.query(q, 75, mode="fde")[1].tolist())
+            kept[slab] += len(truth & cand)
+    assert kept[0] >= 0.95 * 10 * NQ
+    assert kept[1] >= kept[0] - 1, kept
+    ix.close()
+
+
+def test_flag_and_option_errors():
+    from morphik_core_amd import _lib
+    from morphik_core_amd._lib import MvError
+    from morphik_core_amd.index import FdeConfig
+
+    with pytest.raises(MvError):
+        _idx(capacity_pages=16, stride_rows=16, with_fde=False, with_fde_e4m3=True)
+    with pytest.raises(MvError):  # 20 x 32 x 8 = 5120: no row-half kernel for this width
+        _idx(capacity_pages=16, stride_rows=16, with_fde=True, with_fde_e4m3=True, fde=FdeConfig(projection_dimension=8))
+    plain = _idx(capacity_pages=16, stride_rows=16, with_fde=True)
+    with pytest.raises(MvError):
+        plain.set_option(_lib.MV_OPT_FDE_COARSE_SLAB, 1)
+    plain.set_option(_lib.MV_OPT_FDE_COARSE_SLAB, 0)
+    with pytest.raises(MvError):
+        plain.read_fde_e4m3(0, 0)
+    plain.close()
+    small = _idx(capacity_pages=40, stride_rows=16, with_fde=True, with_fde_e4m3=True, fde=FdeConfig(num_repetitions=8, projection_dimension=16))  # 8 x 32 x 16 = 4096
+    small.add(_pages(40, 16))
+    _assert_copy_in_step(small, 40)
+    q = orc.synth_rows(4321, 0, 0, 12)
+    s8 = small.score_all(q, mode="fde")
+    small.set_option(_lib.MV_OPT_FDE_COARSE_SLAB, 0)
+    s16 = small.score_all(q, mode="fde")
+    np.testing.assert_allclose(s8, s16, rtol=0, atol=3e-2 * float(np.abs(s16).max()))
+    small.close()
