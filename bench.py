@@ -394,7 +394,7 @@ def exact_shard_pages(args, stride, device):
         return max(min(args.exact_shard_pages, fit), 0), budget, False
     _free, total_b = torch.cuda.mem_get_info(device)
     hbm = total_b - (3 << 30)  # what is free once the headline's bf16 slab is gone (context, torch's own blocks)
-    slab_b = stride * 128 + stride * 16 + 20480 + 64 + 33 * 4  # e4m3 + sign bits + FDE + metadata + the batched score vectors
+    slab_b = stride * 128 + stride * 16 + 20480 + 10240 + 72 + 33 * 4  # e4m3 + sign bits + FDE (+ its e4m3 copy) + metadata + the batched score vectors
     n = int(min(args.exact_shard_pages, (hbm - (14 << 30)) // slab_b))
     while n > 0:
         in_hbm = max(0, (hbm - n * slab_b - (13 << 30)) // page_b)  # the library keeps 12 GiB back (MV_EXACT_HBM_RESERVE_BYTES)
@@ -417,7 +417,7 @@ def full_shard(args, device, qs):
     import torch
 
     stride = ((args.patches + 15) // 16) * 16
-    per_page = stride * 128 + stride * 16 + 20480 + 16 + 32 * 4  # slabs + metadata + the batched score vectors
+    per_page = stride * 128 + stride * 16 + 20480 + 10240 + 24 + 32 * 4  # slabs (+ the FDE slab's e4m3 copy) + metadata + the batched score vectors
     free_b, _tot = torch.cuda.mem_get_info(device)
     n = int(min(args.full_shard_pages, (free_b - (8 << 30)) // per_page))
     res = {"pages": n, "slabs": "e4m3 + FDE(10240 bf16) + sign bits, no bf16 slab, no exact tier", "resident_GB": round(n * per_page / 1e9, 1),
@@ -425,7 +425,8 @@ def full_shard(args, device, qs):
            "note": "kernel-only HIP-event times (median of 9 after 0.25 s of warm-up queries); unstructured corpus (timing only: recall and the exact "
                    "pipelines are on aux_paths.exact_shard)"}
     t0 = time.time()
-    ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=False, with_binary=True, with_fde=True, with_fp8=True)
+    ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=False, with_binary=True, with_fde=True, with_fp8=True, with_fde_e4m3=True)
+    ix.set_option(L.MV_OPT_FDE_COARSE_SLAB, 0)  # the bf16 FDE slab first (the figures of rounds 2-5); its e4m3 copy below
     res["create_s"] = round(time.time() - t0, 1)
     t0 = time.time()
     ix.fill_synthetic(synth.SEED_CORPUS, 0, n, n_rows=args.patches)
@@ -464,11 +465,17 @@ def full_shard(args, device, qs):
         b32 = fde_pipeline_timings(ix, qs, n, (75,))["coarse75"]["batch_of_32"]
         trial["coarse75_batch_of_32_after"] = {k: b32[k] for k in ("device_ms_per_batch", "requests_per_s", "coarse_pass_frac_hbm_8TBps", "same_ids_as_single_query")}
     res["fde_placement_trial"] = trial
+    # ---- round 6: the coarse stage on the e4m3 COPY of the FDE slab (MV_WITH_FDE_E4M3: 10 240 B per page instead of 20 480)
+    ix.set_option(L.MV_OPT_FDE_COARSE_SLAB, 1)
+    t = timed_mode(ix, qs, "fde")
+    res["fde_coarse_scan_e4m3"] = dict(scan_entry(n, 10240, t["coarse_ms"]), query_encode_ms=round(t["encode_ms"], 4))
+    e8 = fde_pipeline_timings(ix, qs, n, (75, 1000), bytes_per_page=10240)
+    res["fde_e4m3_then_fp8_rerank"] = e8
     ix.close()
     return res
 
 
-def fde_pipeline_timings(ix, qs, n, coarse_ns):
+def fde_pipeline_timings(ix, qs, n, coarse_ns, bytes_per_page=20480):
     """Device times of MV_MODE_FDE_THEN_FLOAT on `ix` for every coarse list length: one request (stage split) and 32 requests per
     pass over the FDE slab (mv_query_topk_batch)."""
     from morphik_core_amd import _lib as L
@@ -489,13 +496,13 @@ def fde_pipeline_timings(ix, qs, n, coarse_ns):
         out[f"coarse{cn}"] = {
             "one_request": {"device_ms": round(t["total_device_ms"], 4), "pages_searched_per_s": round(n / t["total_device_ms"] * 1e3, 1),
                             "stage_ms": {k: round(t[k], 4) for k in ("encode_ms", "coarse_ms", "select_ms", "rerank_ms", "topk_ms")},
-                            "coarse_scan_GBps": round(n * 20480 / t["coarse_ms"] / 1e6, 1),
-                            "coarse_scan_frac_hbm_8TBps": round(n * 20480 / t["coarse_ms"] / 1e6 / HBM_PEAK_GBPS, 4)},
+                            "coarse_scan_GBps": round(n * bytes_per_page / t["coarse_ms"] / 1e6, 1),
+                            "coarse_scan_frac_hbm_8TBps": round(n * bytes_per_page / t["coarse_ms"] / 1e6 / HBM_PEAK_GBPS, 4)},
             "batch_of_32": {"device_ms_per_batch": round(d, 4), "device_us_per_request": round(d * 1e3 / 32, 2), "requests_per_s": round(32 / d * 1e3, 1),
                             "throughput_vs_one_request_per_pass": round(t["total_device_ms"] * 32 / d, 2),
                             "stage_ms": {k: round(float(v), 4) for k, v in zip(("encode_32_queries", "coarse_gemm_one_slab_pass", "select", "rerank", "topk"), sb)},
-                            "coarse_pass_GBps": round(n * 20480 / float(sb[1]) / 1e6, 1),
-                            "coarse_pass_frac_hbm_8TBps": round(n * 20480 / float(sb[1]) / 1e6 / HBM_PEAK_GBPS, 4),
+                            "coarse_pass_GBps": round(n * bytes_per_page / float(sb[1]) / 1e6, 1),
+                            "coarse_pass_frac_hbm_8TBps": round(n * bytes_per_page / float(sb[1]) / 1e6 / HBM_PEAK_GBPS, 4),
                             "same_ids_as_single_query": same}}
     return out
 
@@ -528,7 +535,8 @@ def exact_shard(args, device, n, n_truth, budget, split, sets, truths, gaps):
                    "float scan (doc filter over the first n pages) before the bf16 slab was freed"}
     t0 = time.time()
     ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=False, with_binary=True, with_fde=True, with_fp8=True, with_host_exact=True,
-                 with_exact_split=split)
+                 with_exact_split=split, with_fde_e4m3=True)
+    ix.set_option(L.MV_OPT_FDE_COARSE_SLAB, 0)  # every figure below reads the bf16 FDE slab unless its name says e4m3
     res["create_and_pin_s"] = round(time.time() - t0, 1)
     in_hbm = ix.exact_hbm_pages
     res["exact_tier_pages_in_hbm"] = in_hbm
@@ -563,6 +571,10 @@ def exact_shard(args, device, n, n_truth, budget, split, sets, truths, gaps):
         one = ent["one_request"]
         one["added_ms_over_coarse_scan_and_encode"] = round(one["device_ms"] - base_fde["total_device_ms"], 4)
         one["exact_stage_GBps_over_pcie_upper_bound"] = round(read / max(one["stage_ms"]["rerank_ms"], 1e-6) / 1e6, 1)
+    # ---- the same pipeline with the coarse stage on the e4m3 copy of the FDE slab (round 6)
+    ix.set_option(L.MV_OPT_FDE_COARSE_SLAB, 1)
+    res["fde_e4m3_coarse_then_exact_rerank"] = fde_pipeline_timings(ix, qs, n, (75,), bytes_per_page=10240)
+    ix.set_option(L.MV_OPT_FDE_COARSE_SLAB, 0)
     # ---- configs[4]: e4m3 scan of every page -> top-128 -> exact re-score out of the pinned-host tier
     base = timed_mode(ix, qs, "float_fp8")
     t = timed_mode(ix, qs, "fp8_then_float")
@@ -599,9 +611,19 @@ def exact_shard(args, device, n, n_truth, budget, split, sets, truths, gaps):
             return ix.query(q, k, mode=mode, allow=al)[1].tolist()
         return f
 
+    def on_e4m3(f):  # the same path with the coarse stage on the e4m3 copy of the FDE slab
+        def g(q, al):
+            ix.set_option(L.MV_OPT_FDE_COARSE_SLAB, 1)
+            try:
+                return f(q, al)
+            finally:
+                ix.set_option(L.MV_OPT_FDE_COARSE_SLAB, 0)
+        return g
+
     modes = [("fp8_scan", ids_of("float_fp8")), ("fp8_then_float_n128", ids_of("fp8_then_float")), ("sign_bit_scan", ids_of("binary")),
              ("fde_top75_then_exact", ids_of("fde_then_float", cn=75)), ("fde_top1000_then_exact", ids_of("fde_then_float", cn=1000)),
-             ("fde_coarse_recall_at_75", ids_of("fde", k=75)), ("fde_coarse_recall_at_1000", ids_of("fde", k=1000))]
+             ("fde_coarse_recall_at_75", ids_of("fde", k=75)), ("fde_coarse_recall_at_1000", ids_of("fde", k=1000)),
+             ("fde_e4m3_top75_then_exact", on_e4m3(ids_of("fde_then_float", cn=75))), ("fde_e4m3_coarse_recall_at_75", on_e4m3(ids_of("fde", k=75)))]
     t0 = time.time()
     res["recall_at_10_vs_exact_bf16"] = recall_of(ix, rsets, truths, gaps, modes, allow_truth)
     # the e4m3 rerank an index WITHOUT an exact tier falls back to (MV_OPT_EXACT_TIER 2), on the same candidates: what the exact tier buys
@@ -911,6 +933,10 @@ def aux_summary(out, aux):
         "batched_bf16_B16_PF": (lambda v: None if v is None else round(v / 1000.0, 3))(g("batched_float", "B16", "TFLOPs")),
         "batched_bf16_B16_frac_2500TF": g("batched_float", "B16", "frac_mfma_bf16_2500TF"),
         "fde_request_ms": g("exact_shard", "fde_then_exact_rerank", "coarse75", "one_request", "device_ms"),
+        "fde8_scan_frac": g("full_shard", "fde_coarse_scan_e4m3", "frac_hbm_8TBps"),
+        "fde8_request_ms": g("exact_shard", "fde_e4m3_coarse_then_exact_rerank", "coarse75", "one_request", "device_ms"),
+        "fde8_batch32_ms": g("full_shard", "fde_e4m3_then_fp8_rerank", "coarse75", "batch_of_32", "device_ms_per_batch"),
+        "fde8_75_recall_hard": g("exact_shard", "recall_at_10_vs_exact_bf16", "hard_negatives", "fde_e4m3_top75_then_exact"),
         "fde_batch32_exact_ms": g("exact_shard", "fde_then_exact_rerank", "coarse1000", "batch_of_32", "device_ms_per_batch"),
         "hot_pages_batch32_ms": [g("exact_shard", "hot_pages_in_hbm", "batch_of_32_device_ms", "train_before"), g("exact_shard", "hot_pages_in_hbm", "batch_of_32_device_ms", "train_after"),
                                  g("exact_shard", "hot_pages_in_hbm", "batch_of_32_device_ms", "unseen_after")] if g("exact_shard", "hot_pages_in_hbm", "batch_of_32_device_ms") else None,

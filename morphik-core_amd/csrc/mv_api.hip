@@ -357,12 +357,22 @@ int fp8_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_allow_wor
   return MV_OK;
 }
 
+__global__ void fde8_cfac_kernel(const float* scale, const float* inv_norm, int64_t n, float* out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = scale[i] * inv_norm[i];
+}
+
 // MV_WITH_FDE_E4M3: the e4m3 copy of FDE rows [first, first + n), derived from the bf16 rows just written (every writer of ix->fde calls it).
 // A row is quantised like a page of the e4m3 slab: out_dim / 128 "rows" of 128 under ONE power-of-two scale (orc_quantize_page_fp8).
 static int fde8_requantize(mv_index* ix, int64_t first, int64_t n, hipStream_t st) {
   if (!ix->fde8 || n <= 0) return MV_OK;
   const int64_t od = ix->fde_t.out_dim;
-  return launch_quantize_pages_fp8(ix->fde + (size_t)first * od, nullptr, (int32_t)(od / kDim), n, ix->fde8 + (size_t)first * od, ix->fde8_scale + first, st);
+  int rc = launch_quantize_pages_fp8(ix->fde + (size_t)first * od, nullptr, (int32_t)(od / kDim), n, ix->fde8 + (size_t)first * od, ix->fde8_scale + first, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(fde8_cfac_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)(ix->fde8_scale + first), (const float*)(ix->fde_inv_norm + first), n,
+                     ix->fde8_cfac + first);
+  MV_HIP(hipGetLastError());
+  return MV_OK;
 }
 
 // FDE coarse stage: encode the query already uploaded to d_qf32 (SUM aggregation) and scan the FDE slab -> d_scores[n].
@@ -1179,7 +1189,7 @@ void mv_index_destroy(mv_index* ix) {
   DeviceGuard g(ix->cfg.device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
   if (ix->w_stream) (void)hipStreamSynchronize(ix->w_stream);
-  void* ptrs[] = {ix->d_xloc, ix->d_xoff, ix->d_xhits, ix->d_row_off, ix->slab_lo, ix->d_qlo, ix->d_bqlo, ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->fde8, ix->fde8_scale, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
+  void* ptrs[] = {ix->d_xloc, ix->d_xoff, ix->d_xhits, ix->d_row_off, ix->slab_lo, ix->d_qlo, ix->d_bqlo, ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->fde8, ix->fde8_scale, ix->fde8_cfac, ix->d_bqfac, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
                   ix->d_topk_ws, ix->d_q, ix->d_qf32, ix->d_qbits, ix->d_qpop, ix->d_qfde, ix->d_qoff, ix->d_allow, ix->d_out_s,
                   ix->d_out_id, ix->d_cand, ix->d_cand_scores, ix->d_bqf32, ix->d_bqfde, ix->d_bqimage, ix->d_btopk_ws, ix->d_bsel_s,
                   ix->d_bsel_id, ix->d_bcand, ix->d_bcand_pads, ix->d_bcand_scores, ix->d_bout_s, ix->d_bout_id, ix->d_bq8hi, ix->d_bq8lo, ix->d_bq8fac};
@@ -1285,6 +1295,7 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
     if (cfg->flags & MV_WITH_FDE_E4M3) {
       alloc((void**)&ix->fde8, (size_t)cap * ix->fde_t.out_dim, "e4m3 copy of the FDE slab");
       alloc((void**)&ix->fde8_scale, (size_t)cap * 4, "e4m3 FDE scales");
+      alloc((void**)&ix->fde8_cfac, (size_t)cap * 4, "e4m3 FDE cosine factors");
     }
     alloc((void**)&ix->d_qfde, (size_t)std::max<int64_t>(ix->fde_t.out_dim, 1) * 4, "query FDE");
   }
@@ -1421,10 +1432,18 @@ int mv_index_exact_tier_rebalance(mv_index* ix, int64_t max_moves, int64_t* out_
   return MV_OK;
 }
 
+// MV_WITH_FDE_E4M3 + MV_OPT_FDE_COARSE_SLAB 1: the batched pass reads the slab's e4m3 copy (the launcher falls back to the bf16 slab for the
+// cross-check forms and widths the e4m3 kernel is not built for).  q_mu held.
+void mv_internal_fde_batch_e4m3_args(mv_index* ix, mv::FdeScanBatchArgs* sa) {
+  if (!ix->fde8 || !ix->fde_coarse_e4m3 || !ix->d_bqfac) return;
+  sa->fde8 = ix->fde8; sa->fde8_fac = ix->fde_cosine ? ix->fde8_cfac : ix->fde8_scale; sa->qfac = ix->d_bqfac;
+}
+
 // One batched coarse pass (32 requests, a fixed pseudo-random query encoding) over `slab`, median of `reps` timed launches behind `warm` untimed ones.
-static int time_fde_batch_pass(mv_index* ix, const uint16_t* slab, int64_t n, int warm, int reps, double* out_ms) {
+static int time_fde_batch_pass(mv_index* ix, const void* slab, bool e4m3, int64_t n, int warm, int reps, double* out_ms) {
   FdeScanBatchArgs sa{};
-  sa.fde = slab; sa.inv_norm = ix->fde_cosine ? ix->fde_inv_norm : nullptr; sa.doc_ord = nullptr;
+  sa.fde = e4m3 ? ix->fde : (const uint16_t*)slab; sa.inv_norm = ix->fde_cosine ? ix->fde_inv_norm : nullptr; sa.doc_ord = nullptr;
+  if (e4m3) { mv_internal_fde_batch_e4m3_args(ix, &sa); sa.fde8 = (const uint8_t*)slab; }
   sa.q = ix->d_bqfde; sa.image = ix->d_bqimage; sa.scores = ix->d_bscores; sa.score_stride = ix->bscore_stride; sa.n = n; sa.out_dim = ix->fde_t.out_dim;
   sa.n_queries = kFdeBatchMaxQueries;
   std::vector<float> ms;
@@ -1457,7 +1476,10 @@ int mv_index_fde_placement_trial(mv_index* ix, int32_t trials, double* out_befor
   if (rc) return rc;
   const int64_t cap = ix->cfg.capacity_pages, out_dim = ix->fde_t.out_dim;
   const int64_t n = ix->size.load() > 0 ? ix->size.load() : cap;  // an empty index is timed over its whole slab (the pass's time does not depend on what it reads)
-  const size_t bytes = (size_t)cap * out_dim * 2;
+  // the slab the batched pass reads: the e4m3 copy of an index that has one (MV_OPT_FDE_COARSE_SLAB 1), else the bf16 slab
+  const bool e4 = ix->fde8 && ix->fde_coarse_e4m3 && ix->d_bqfac && fde_scan_batch8_supported(out_dim);
+  void** slab_pp = e4 ? (void**)&ix->fde8 : (void**)&ix->fde;
+  const size_t bytes = (size_t)cap * out_dim * (e4 ? 1 : 2);
   {  // the requests of the timing passes: fixed pseudo-random encodings (the next real batch overwrites them)
     std::vector<float> q((size_t)kFdeBatchMaxQueries * out_dim);
     uint64_t z = 0x9E3779B97F4A7C15ull;
@@ -1466,7 +1488,7 @@ int mv_index_fde_placement_trial(mv_index* ix, int32_t trials, double* out_befor
     MV_HIP(hipMemcpy(ix->d_bqfde, q.data(), q.size() * 4, hipMemcpyHostToDevice));
   }
   double best = 0.0;
-  rc = time_fde_batch_pass(ix, ix->fde, n, 4, 5, &best);
+  rc = time_fde_batch_pass(ix, *slab_pp, e4, n, 4, 5, &best);
   if (rc) return rc;
   if (out_before_ms) *out_before_ms = best;
   void* held = nullptr;  // the loser of the last comparison stays allocated while the next candidate is taken, so that the candidate is OTHER memory
@@ -1475,17 +1497,17 @@ int mv_index_fde_placement_trial(mv_index* ix, int32_t trials, double* out_befor
     void* cand = nullptr;
     if (hipMalloc(&cand, bytes) != hipSuccess) { (void)hipGetLastError(); break; }  // no room for another candidate: keep what we have
     if (held) { (void)hipFree(held); held = nullptr; }
-    hipError_t e = hipMemcpyAsync(cand, ix->fde, bytes, hipMemcpyDeviceToDevice, ix->stream);
+    hipError_t e = hipMemcpyAsync(cand, *slab_pp, bytes, hipMemcpyDeviceToDevice, ix->stream);
     // incumbent, candidate, incumbent -- all three behind the copy: the pass is power-bound, and the first launches after a quiet spell (a copy
     // is one) run 1-2 % fast; timing the candidate alone there would favour it
     double ms = 0.0, inc_a = 0.0, inc_b = 0.0;
-    if (e == hipSuccess) rc = time_fde_batch_pass(ix, ix->fde, n, 4, 5, &inc_a);
-    if (e == hipSuccess && !rc) rc = time_fde_batch_pass(ix, (const uint16_t*)cand, n, 2, 5, &ms);
-    if (e == hipSuccess && !rc) rc = time_fde_batch_pass(ix, ix->fde, n, 2, 5, &inc_b);
+    if (e == hipSuccess) rc = time_fde_batch_pass(ix, *slab_pp, e4, n, 4, 5, &inc_a);
+    if (e == hipSuccess && !rc) rc = time_fde_batch_pass(ix, cand, e4, n, 2, 5, &ms);
+    if (e == hipSuccess && !rc) rc = time_fde_batch_pass(ix, *slab_pp, e4, n, 2, 5, &inc_b);
     if (e != hipSuccess || rc) { (void)hipStreamSynchronize(ix->stream); (void)hipFree(cand); if (e != hipSuccess) { set_error("hip: %s", hipGetErrorString(e)); return MV_ERR_HIP; } return rc; }
     const double inc = 0.5 * (inc_a + inc_b);
     if (ms < inc * 0.985) {  // (1.5 %: the measurement scatters by 0.2-0.3 %, a move costs a slab copy -- only a clear win is taken)
-      held = ix->fde; ix->fde = (uint16_t*)cand; best = ms; ++moves;
+      held = *slab_pp; *slab_pp = cand; best = ms; ++moves;
     } else {
       held = cand; best = inc;
     }
@@ -1541,7 +1563,7 @@ int mv_index_set_option(mv_index* ix, int option, int64_t value) {
       if (!sel || (sel & 4)) {
         void** ws[] = {(void**)&ix->d_bqfde, (void**)&ix->d_bqf32, (void**)&ix->d_btopk_ws, (void**)&ix->d_bsel_s,
                        (void**)&ix->d_bsel_id, (void**)&ix->d_bcand, (void**)&ix->d_bcand_pads, (void**)&ix->d_bcand_scores, (void**)&ix->d_bout_s, (void**)&ix->d_bout_id,
-                       (void**)&ix->d_bq, (void**)&ix->d_bqlo, (void**)&ix->d_bq8hi, (void**)&ix->d_bq8lo, (void**)&ix->d_bq8fac};
+                       (void**)&ix->d_bq, (void**)&ix->d_bqlo, (void**)&ix->d_bqfac, (void**)&ix->d_bq8hi, (void**)&ix->d_bq8lo, (void**)&ix->d_bq8fac};
         for (void** w : ws) drop(w);
         void** hs[] = {(void**)&ix->h_bout_s, (void**)&ix->h_bout_id};
         for (void** h : hs) if (*h) { (void)hipHostFree(*h); *h = nullptr; }
@@ -1970,7 +1992,7 @@ int mv_index_compact(mv_index* ix, int64_t* out_old_to_new, int64_t* out_new_siz
   if (ix->cfg.flags & MV_WITH_FP8) { slabs.push_back({(char*)ix->slab8, stride * kDim, (size_t)kDim}); slabs.push_back({(char*)ix->inv_scale8, 16, 0}); }
   if (ix->cfg.flags & MV_WITH_BINARY) slabs.push_back({(char*)ix->bits, stride * kSignBytes, (size_t)kSignBytes});
   if (ix->cfg.flags & MV_WITH_FDE) { slabs.push_back({(char*)ix->fde, (size_t)ix->fde_t.out_dim * 2, 0}); slabs.push_back({(char*)ix->fde_inv_norm, 16, 0}); }
-  if (ix->fde8) { slabs.push_back({(char*)ix->fde8, (size_t)ix->fde_t.out_dim, 0}); slabs.push_back({(char*)ix->fde8_scale, 16, 0}); }
+  if (ix->fde8) { slabs.push_back({(char*)ix->fde8, (size_t)ix->fde_t.out_dim, 0}); slabs.push_back({(char*)ix->fde8_scale, 16, 0}); slabs.push_back({(char*)ix->fde8_cfac, 16, 0}); }
   int rc = MV_OK;
   // packed layout: the new row offsets (live pages keep their slots, back to back) and, per moved page, (old first row, new first row, rows)
   std::vector<int64_t> new_off;
@@ -2345,6 +2367,7 @@ int mv_internal_ensure_fde_batch_ws(mv_index* ix) {
   if (!ix->d_bqf32) MV_HIP(hipMalloc(&ix->d_bqf32, (size_t)kBatchQRows * kDim * 4));
   if (!ix->d_bqfde) MV_HIP(hipMalloc(&ix->d_bqfde, (size_t)kFdeBatchMaxQueries * out_dim * 4));
   if (!ix->d_bqimage) MV_HIP(hipMalloc(&ix->d_bqimage, mv::fde_scan_batch_image_bytes(out_dim)));
+  if (ix->fde8 && !ix->d_bqfac) MV_HIP(hipMalloc(&ix->d_bqfac, kFdeBatchMaxQueries * 4));
   if (ix->cfg.flags & MV_WITH_FP8) {
     if (!ix->d_bq8hi) MV_HIP(hipMalloc(&ix->d_bq8hi, (size_t)kBatchQRows * kDim));
     if (!ix->d_bq8lo) MV_HIP(hipMalloc(&ix->d_bq8lo, (size_t)kBatchQRows * kDim));
@@ -2556,6 +2579,7 @@ static int fde_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
     sa.hi_only = ix->fde_batch_variant == 2;
     sa.single_tile = ix->fde_batch_variant == 3;
     sa.separate_finish = ix->fde_batch_variant == 5;
+    mv_internal_fde_batch_e4m3_args(ix, &sa);
     // Default: the scan kernel applies the cosine rule / tombstones itself (no finish pass) and the selection runs its three
     // vectorised passes.  Where a finish pass runs anyway (variants 3 / 4, or a dot-product index with masks) it also bins every
     // request's scores for the selection's first radix pass; variant 5 is the round-2 pipeline (separate finish, three passes).

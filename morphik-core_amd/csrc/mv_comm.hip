@@ -364,6 +364,7 @@ int mv_internal_two_stage_batch_coarse(mv_index* ix, const void* q, int q_dtype,
     sa.hi_only = ix->fde_batch_variant == 2;
     sa.single_tile = ix->fde_batch_variant == 3;
     sa.separate_finish = ix->fde_batch_variant == 5;
+    mv_internal_fde_batch_e4m3_args(ix, &sa);
     if (ix->fde_batch_variant != 5 && topk_uses_radix(n, n_coarse)) {  // the finish pass bins the scores for the selection (mv_api.hip)
       sa.hist0 = topk_radix_hist0(ix->d_btopk_ws);
       sa.hist0_stride_bytes = (int64_t)ix->topk_ws_bytes;

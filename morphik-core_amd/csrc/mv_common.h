@@ -249,13 +249,23 @@ struct FdeScanBatchArgs {
   uint32_t* hist0;
   int64_t hist0_stride_bytes;
   int32_t separate_finish;    // 1: keep the finish a pass of its own even where the scan kernel could apply it (MV_OPT_FDE_BATCH_VARIANT 5)
+  // MV_WITH_FDE_E4M3 (nullable): the slab's e4m3 copy [n][out_dim], its per-page factor (scale, or scale / |d| under the cosine rule) and a
+  // 32-float scratch for the queries' scales.  Given (and the default form selected), the pass reads THIS slab: half the bytes.
+  const uint8_t* fde8;
+  const float* fde8_fac;
+  float* qfac;
 };
+bool fde_scan_batch8_supported(int64_t out_dim);
 // the default (paired-tile) kernel applies the cosine rule and the tombstones where it writes a tile's scores: no finish pass
 inline bool fde_scan_batch_fuses_finish(const FdeScanBatchArgs& a) {
   return a.inv_norm != nullptr && !a.single_tile && !a.separate_finish;
 }
+// the pass reads the slab's e4m3 copy (its kernel always writes finished scores: nothing is binned on the way)
+inline bool fde_scan_batch_uses_e4m3(const FdeScanBatchArgs& a) {
+  return a.fde8 != nullptr && !a.single_tile && !a.hi_only && !a.separate_finish && fde_scan_batch8_supported(a.out_dim);
+}
 inline bool fde_scan_batch_prebins(const FdeScanBatchArgs& a) {
-  return a.hist0 != nullptr && (a.inv_norm != nullptr || a.doc_ord != nullptr) && !fde_scan_batch_fuses_finish(a);
+  return a.hist0 != nullptr && (a.inv_norm != nullptr || a.doc_ord != nullptr) && !fde_scan_batch_fuses_finish(a) && !fde_scan_batch_uses_e4m3(a);
 }
 bool fde_scan_batch_supported(int64_t out_dim);
 size_t fde_scan_batch_image_bytes(int64_t out_dim);

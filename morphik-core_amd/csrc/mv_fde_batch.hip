@@ -7,6 +7,7 @@
 #include <utility>
 
 #include "mv_common.h"
+#include "mv_e4m3.h"
 
 namespace mv {
 namespace {
@@ -48,6 +49,7 @@ struct ScanBatchArgs {
   int32_t n_tiles;     // ceil(n / 64)
   const float* inv_norm;    // FIN kernels: the cosine rule and the tombstones are applied where the scores are written
   const int32_t* doc_ord;   // nullable (no tombstones)
+  const float* qfac;        // E4 kernels: 32 per-query factors 2^-e (the scale the query's e4m3 terms were taken at); else unused
 };
 
 constexpr int kFbPages = 64;
@@ -76,6 +78,54 @@ __global__ __launch_bounds__(256) void fde_batch_qprep_kernel(const float* q, in
   uint16_t* dst = image + ((size_t)(((kc * 4 + w) * 2 + e) * nqt + qt) * 2) * 512 + lane * 8;  // 512 bf16 = 1 KiB per fragment
 #pragma unroll
   for (int i = 0; i < 8; ++i) { dst[i] = hi[i]; dst[512 + i] = lo[i]; }
+}
+
+// ---- the e4m3 form of the pass (MV_WITH_FDE_E4M3: the slab's e4m3 copy, 512 codes per page and ring slot)
+// Queries enter as TWO e4m3 terms under one power-of-two scale per query (amax -> 448, as the rows of the copy): hi = e4m3(x 2^e),
+// lo = e4m3(x 2^e - hi) -- the rounding residual, at most 2^-4 of its value's binade, keeps three more mantissa bits wherever it stays
+// above e4m3's subnormal floor 2^-9, i.e. for every |x 2^e| >= 2^-5: the entries that carry the dot product.  Both terms accumulate in
+// the same fp32 register.  qfac[b] = 2^-e (1 for an all-zero query; 0 beyond nb).
+__global__ __launch_bounds__(256) void fde_batch_qscale8_kernel(const float* q, int nb, int out_dim, float* qfac) {
+  __shared__ uint32_t red[4];
+  const int b = blockIdx.x;
+  if (b >= nb) { if (threadIdx.x == 0) qfac[b] = 0.0f; return; }
+  uint32_t amax = 0;
+  for (int i = threadIdx.x; i < out_dim; i += 256) amax = max(amax, __float_as_uint(q[(size_t)b * out_dim + i]) & 0x7fffffffu);
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, sft));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    amax = max(max(red[0], red[1]), max(red[2], red[3]));
+    if (amax > 0x7f7fffffu) amax = 0x7f7fffffu;
+    qfac[b] = pow2f(-pow2_scale_exp(amax));
+  }
+}
+// image8[kc][wave][query tile][hi.0 | hi.1 | lo.0 | lo.1][lane] of 16-byte pieces: lane (query qt*16 + (l&15), group l>>4) holds the codes of
+// dims kc*512 + wave*128 + 32*(l>>4) .. +32 of its query -- .0 the first sixteen, .1 the second (four 8-byte MFMA operands per term).
+__global__ __launch_bounds__(256) void fde_batch_qprep8_kernel(const float* q, const float* qfac, int nb, int out_dim, int nqt, uint8_t* image) {
+  const int t = blockIdx.x * 256 + threadIdx.x;  // (kc, wave, qt, lane)
+  const int lane = t & 63;
+  int r = t >> 6;
+  const int qt = r % nqt; r /= nqt;
+  const int w = r & 3, kc = r >> 2;
+  if (kc * 512 >= out_dim) return;
+  const int ql = qt * 16 + (lane & 15), g = lane >> 4;
+  const int d0 = kc * 512 + w * 128 + g * 32;
+  const float fac = ql < nb ? qfac[ql] : 0.0f;
+  const float sc = fac > 0.0f ? 1.0f / fac : 0.0f;  // a power of two: exact
+  uint32_t hi[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lo[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const float x = ql < nb ? q[(size_t)ql * out_dim + d0 + i] * sc : 0.0f;
+    const uint32_t ch = e4m3_encode(x);
+    const uint32_t cl = e4m3_encode(x - e4m3_decode(ch));  // the residual in its own binade (no common 2^-4: the K = 32 MFMA has no scale operand)
+    hi[i >> 2] |= ch << (8 * (i & 3));
+    lo[i >> 2] |= cl << (8 * (i & 3));
+  }
+  uint32_t* dst = reinterpret_cast<uint32_t*>(image + ((size_t)((kc * 4 + w) * nqt + qt) * 4) * 1024 + lane * 16);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { dst[i] = hi[i]; dst[256 + i] = hi[4 + i]; dst[512 + i] = lo[i]; dst[768 + i] = lo[4 + i]; }
 }
 
 // NQT query tiles of 16 (16 or 32 queries per pass).
@@ -305,22 +355,31 @@ __device__ __forceinline__ void fb_static_for(F&& f) {
 // slot's own wait returns, read with ds_read at the tile's end.  Every wave issues them (same data, same place: the per-wave
 // counts stay uniform).  Records are double-buffered by group parity: the next group's first slots are issued before this group's
 // epilogue runs.  The arithmetic is the finish kernel's (one fp32 multiply of the same sum): identical scores.
-template <int NQT, bool LO, int T, bool FIN = false>
+template <int NQT, bool LO, int T, bool FIN = false, bool E4 = false>
 __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, float* red, const int lane, const int wave, const int i0,
                                          const int n_groups, const uint32_t (&src_off)[8], const uint32_t (&rd_off)[2]) {
   using bf16x8 = __attribute__((ext_vector_type(8))) short;
   using f32x4 = __attribute__((ext_vector_type(4))) float;
-  constexpr int NF = 4 * NQT;              // query fragments per K chunk and wave: (e, qt, hi|lo)
+  static_assert(!E4 || (LO && FIN), "the e4m3 form always carries both query terms and applies the page factor itself");
+  constexpr int NF = 4 * NQT;              // query fragments per K chunk and wave: (e, qt, hi|lo); E4: (qt, hi|lo, half)
   constexpr int QOPS = LO ? NF : NF / 2;   // fragment loads per K chunk and wave
   constexpr int MOPS = FIN ? 2 : 0;        // metadata loads per slot of a K chunk with kc & 3 == 0
   char* meta = reinterpret_cast<char*>(red) + 4 * 16 * kFbRedStride * 4;  // FIN: [group parity][tile of the group][64 x 1/|d| | 64 x doc ordinal]
   if constexpr (FIN) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the previous phase's last epilogue has read its records
   const int p = lane & 15, g = lane >> 4;
   const int G = gridDim.x, b = blockIdx.x;
-  const int KC = a.out_dim >> 8;
+  const int KC = E4 ? a.out_dim >> 9 : a.out_dim >> 8;  // E4: a slot holds 512 codes per page
   const int total = n_groups * KC * T;     // ring slots of this phase; a multiple of 4 * T
   if (total == 0) return;
-  const uint32_t row_bytes = (uint32_t)a.out_dim * 2u;
+  const uint32_t row_bytes = E4 ? (uint32_t)a.out_dim : (uint32_t)a.out_dim * 2u;
+  // E4: this thread's per-query factors for the tile ends (queries qt*16 + wave + 4x), loaded before the ring starts
+  float qfac[E4 ? NQT * 4 : 1];
+  if constexpr (E4) {
+#pragma unroll
+    for (int x = 0; x < NQT * 4; ++x) qfac[x] = a.qfac[(x >> 2) * 16 + (threadIdx.x >> 6) + 4 * (x & 3)];
+#pragma unroll
+    for (int x = 0; x < NQT * 4; ++x) asm volatile("" : "+v"(qfac[x]));
+  }
   const uint32_t q_off = (uint32_t)lane * 16u;
 
   bf16x8 qf[4][NF];  // [K chunk & 3][(e*NQT + qt)*2 + (0 = hi, 1 = lo)]
@@ -484,6 +543,26 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
         issue_dma(u & 3);
         if constexpr (FIN && ((((u + 4) % (4 * T)) / T) & 3) == 0) issue_meta();
       }
+      if constexpr (E4) {
+        // four K = 32 fp8 MFMAs per (page tile, query tile) and term: every 16-byte piece a lane read / loaded is two 8-byte operands, used
+        // in place (the K = 128 block-scaled form wants 32 consecutive bytes per lane: building them from the ring's 16-byte registers cost
+        // copies and 200 spilled registers).  Any K-slot order is valid as long as A and B agree: operand jj of piece e = codes
+        // 32 g + 16 e + 8 jj .. + 8 of the wave's 128.
+        using i64x2 = __attribute__((ext_vector_type(2))) long;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const long a8 = __builtin_bit_cast(i64x2, af[e][t])[jj];
+#pragma unroll
+              for (int qt = 0; qt < NQT; ++qt) {
+                acc[j][t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a8, __builtin_bit_cast(i64x2, qf[kcs][qt * 4 + e])[jj], acc[j][t][qt], 0, 0, 0);
+                acc[j][t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a8, __builtin_bit_cast(i64x2, qf[kcs][qt * 4 + 2 + e])[jj], acc[j][t][qt], 0, 0, 0);
+              }
+            }
+      } else {
 #pragma unroll
       for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -493,6 +572,7 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
             acc[j][t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[e][t], qf[kcs][(e * NQT + qt) * 2 + 0], acc[j][t][qt], 0, 0, 0);
             if (LO) acc[j][t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[e][t], qf[kcs][(e * NQT + qt) * 2 + 1], acc[j][t][qt], 0, 0, 0);
           }
+      }
       if (s + 4 < total) {
         if constexpr (j == 0) {  // slot s + 4 opens K chunk (u + 4) / T: its fragments go into that chunk's register set
           // (T = 1: the set the MFMAs above just read; at most 63 VMEM operations may be outstanding)
@@ -535,6 +615,7 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
                 float v = (red[(0 * 16 + ql) * kFbRedStride + pg] + red[(1 * 16 + ql) * kFbRedStride + pg]) +
                           (red[(2 * 16 + ql) * kFbRedStride + pg] + red[(3 * 16 + ql) * kFbRedStride + pg]);
                 if constexpr (FIN) v = dead ? -INFINITY : v * inv;
+                if constexpr (E4) v *= qfac[qt * 4 + x];
                 a.scores[(size_t)(qt * 16 + ql) * a.score_stride + page] = v;
               }
             }
@@ -549,7 +630,7 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
   }
 }
 
-template <int NQT, bool LO, bool FIN = false>
+template <int NQT, bool LO, bool FIN = false, bool E4 = false>
 __global__ __launch_bounds__(256) void fde_scan_batch2_kernel(ScanBatchArgs a) {
   // one __shared__ object only (a second one makes hipcc drain vmcnt before every ds_read)
   __shared__ __attribute__((aligned(16))) char lds[kFbSlots * kFbSlotBytes + 4 * 16 * kFbRedStride * 4 + (FIN ? 2 * 2 * 512 : 0)];
@@ -559,7 +640,7 @@ __global__ __launch_bounds__(256) void fde_scan_batch2_kernel(ScanBatchArgs a) {
   const int p = lane & 15, g = lane >> 4;
   const int G = gridDim.x, b = blockIdx.x;
   const int n_my = (a.n_tiles - b + G - 1) / G;  // tiles b, b + G, ...  (grid <= n_tiles)
-  const uint32_t row_bytes = (uint32_t)a.out_dim * 2u;
+  const uint32_t row_bytes = E4 ? (uint32_t)a.out_dim : (uint32_t)a.out_dim * 2u;
   uint32_t src_off[8];  // see fde_scan_batch_kernel
   uint32_t rd_off[2];
 #pragma unroll
@@ -568,9 +649,10 @@ __global__ __launch_bounds__(256) void fde_scan_batch2_kernel(ScanBatchArgs a) {
     src_off[i] = pl * row_bytes + ((((uint32_t)lane & 31u) ^ (pl & 15u)) << 4) + 4096u - (uint32_t)(i & 3) * 1024u;
   }
 #pragma unroll
-  for (int e = 0; e < 2; ++e) rd_off[e] = (uint32_t)p * 512u + (((uint32_t)((2 * wave + e) * 4 + g) ^ (uint32_t)p) << 4);
-  fb_phase<NQT, LO, 2, FIN>(a, lds, red, lane, wave, 0, n_my / 2, src_off, rd_off);
-  fb_phase<NQT, LO, 1, FIN>(a, lds, red, lane, wave, (n_my / 2) * 2, n_my & 1, src_off, rd_off);
+  for (int e = 0; e < 2; ++e)  // bf16: the wave's dims [64 w, 64 w + 64) of the slot's 256 in two K = 32 operands; E4: its codes [128 w, 128 w + 128) of 512 in one
+    rd_off[e] = (uint32_t)p * 512u + (((uint32_t)(E4 ? wave * 8 + g * 2 + e : (2 * wave + e) * 4 + g) ^ (uint32_t)p) << 4);
+  fb_phase<NQT, LO, 2, FIN, E4>(a, lds, red, lane, wave, 0, n_my / 2, src_off, rd_off);
+  fb_phase<NQT, LO, 1, FIN, E4>(a, lds, red, lane, wave, (n_my / 2) * 2, n_my & 1, src_off, rd_off);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -674,6 +756,7 @@ __global__ __launch_bounds__(256) void fde_batch_finish_hist_kernel(float* score
 }  // namespace
 
 bool fde_scan_batch_supported(int64_t out_dim) { return out_dim >= 1024 && out_dim <= 65536 && out_dim % 1024 == 0; }
+bool fde_scan_batch8_supported(int64_t out_dim) { return out_dim >= 2048 && out_dim <= 65536 && out_dim % 2048 == 0; }  // whole groups of four 512-code chunks
 size_t fde_scan_batch_image_bytes(int64_t out_dim) { return (size_t)(out_dim / 256) * 16384 * 2; }  // two query tiles
 
 int launch_fde_scan_batch(const FdeScanBatchArgs& a, hipStream_t s) {
@@ -687,10 +770,27 @@ int launch_fde_scan_batch(const FdeScanBatchArgs& a, hipStream_t s) {
   }
   const int KC = (int)(a.out_dim / 256);
   const int nqt = a.n_queries > 16 ? 2 : 1;
+  if (fde_scan_batch_uses_e4m3(a)) {
+    // the e4m3 copy of the slab: half the bytes per page; page factor (scale, or scale / |d|) and tombstones applied where the scores are written
+    hipLaunchKernelGGL(fde_batch_qscale8_kernel, dim3(kFdeBatchMaxQueries), dim3(256), 0, s, a.q, a.n_queries, (int)a.out_dim, a.qfac);
+    hipLaunchKernelGGL(fde_batch_qprep8_kernel, dim3((unsigned)((a.out_dim / 512) * nqt)), dim3(256), 0, s, a.q, (const float*)a.qfac, a.n_queries, (int)a.out_dim, nqt,
+                       reinterpret_cast<uint8_t*>(a.image));
+    const int64_t n_tiles8 = (a.n + kFbPages - 1) / kFbPages;
+    ScanBatchArgs k8{reinterpret_cast<const char*>(a.fde8), reinterpret_cast<const char*>(a.image), a.scores, a.score_stride, a.n,
+                     (int32_t)a.out_dim, a.n_queries, (int32_t)n_tiles8, a.fde8_fac, a.doc_ord, a.qfac};
+    const dim3 grid8((unsigned)std::min<int64_t>(n_tiles8, ncu));
+    if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch2_kernel<1, true, true, true>), grid8, dim3(256), 0, s, k8);
+    else hipLaunchKernelGGL((fde_scan_batch2_kernel<2, true, true, true>), grid8, dim3(256), 0, s, k8);
+    if (a.allow && a.doc_ord)  // per-request doc filters: masks only, a pass of their own (as behind the bf16 form)
+      hipLaunchKernelGGL(fde_batch_finish_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a.scores, a.score_stride, a.n, a.n_queries,
+                         (const float*)nullptr, a.doc_ord, a.allow, a.n_allow_bits, a.allow_stride_bits);
+    MV_HIP(hipGetLastError());
+    return MV_OK;
+  }
   hipLaunchKernelGGL(fde_batch_qprep_kernel, dim3((unsigned)(KC * 2 * nqt)), dim3(256), 0, s, a.q, a.n_queries, (int)a.out_dim, nqt, a.image);
   const int64_t n_tiles = (a.n + kFbPages - 1) / kFbPages;
   ScanBatchArgs k{reinterpret_cast<const char*>(a.fde), reinterpret_cast<const char*>(a.image), a.scores, a.score_stride, a.n,
-                  (int32_t)a.out_dim, a.n_queries, (int32_t)n_tiles, a.inv_norm, a.doc_ord};
+                  (int32_t)a.out_dim, a.n_queries, (int32_t)n_tiles, a.inv_norm, a.doc_ord, nullptr};
   const bool fin = fde_scan_batch_fuses_finish(a);  // the paired-tile kernel applies the cosine rule and the tombstones itself
   const dim3 grid((unsigned)std::min<int64_t>(n_tiles, ncu));
   if (a.single_tile) {  // one page tile per query fragment (MV_OPT_FDE_BATCH_VARIANT = 3: the cross-check of the paired form)

@@ -167,6 +167,8 @@ struct mv_index {
   int fde_cosine = 1;
   uint8_t* fde8 = nullptr;         // MV_WITH_FDE_E4M3: [capacity][out_dim] e4m3 copy of the FDE slab (derived after every write of `fde`)
   float* fde8_scale = nullptr;     // [capacity] value = decode(code) * scale (a power of two)
+  float* fde8_cfac = nullptr;      // [capacity] scale / |d|: the page factor of the batched pass under the cosine rule (one load per page)
+  float* d_bqfac = nullptr;        // [32] the batched pass's per-query scales (lazily, with the batch workspace)
   int fde_coarse_e4m3 = 1;         // MV_OPT_FDE_COARSE_SLAB
   int pad_semantics = -1;  // -1: mode default (reference batch rule for FDE_THEN_FLOAT / candidates, none for full scan)
   int float_lo_scan = 1;   // MV_MODE_FLOAT full scans on an index with a lo slab: 1 = read both halves (fp32-faithful scores, 2 x the bytes),
@@ -287,6 +289,7 @@ int check_query_finite(const void* q, int q_dtype, size_t n_elems, int mode);
 // Batch workspace and stages of mv_api.hip shared with the batched two-stage communicator (mv_comm.hip).  Callers hold q_mu.
 extern "C" int mv_internal_ensure_batch_select_ws(mv_index* ix);
 extern "C" int mv_internal_ensure_fde_batch_ws(mv_index* ix);
+extern "C" void mv_internal_fde_batch_e4m3_args(mv_index* ix, mv::FdeScanBatchArgs* sa);  // the pass reads the e4m3 copy when the index has one (q_mu held)
 extern "C" int mv_internal_ensure_fp8_batch_ws(mv_index* ix);
 extern "C" int mv_internal_batch_upload_queries(mv_index* ix, const void* q, int q_dtype, int nb, int n_q_rows, bool want_f32, bool want_bf16, bool want_fp8);
 // tier: kTierSlab / kTierHost (bf16 rerank on the slab / the exact host tier) or kTierFp8 (e4m3 rerank).  d_out null -> d_bcand_scores.

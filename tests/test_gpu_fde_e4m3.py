@@ -181,6 +181,101 @@ def test_recall_of_the_e4m3_coarse_stage_on_hard_negatives_is_the_bf16_stages():
     ix.close()
 
 
+def _two_term_query(qf):
+    """numpy restatement of fde_batch_qscale8 / qprep8: one power-of-two scale per query (amax -> 448), hi = e4m3(x 2^e), lo = e4m3(x 2^e - hi)
+    -> the fp64 vector the batched pass multiplies, already divided by 2^e"""
+    qf = np.asarray(qf, np.float32)
+    amax = np.float32(np.abs(qf).max())
+    if amax == 0:
+        return qf.astype(np.float64)
+    bits = int(np.array([amax], np.float32).view(np.uint32)[0])
+    ea, mant = ((bits >> 23) & 0xFF) - 127, bits & 0x7FFFFF
+    e = 8 - ea - (1 if mant > 0x600000 else 0)
+    x = qf * np.float32(2.0) ** np.float32(e)
+    hi = orc.e4m3_decode(orc.e4m3_encode(x)).astype(np.float32)
+    lo = orc.e4m3_decode(orc.e4m3_encode(x - hi)).astype(np.float32)
+    return (hi.astype(np.float64) + lo.astype(np.float64)) * 2.0 ** (-e)
+
+
+@pytest.mark.parametrize("n,B", [(40, 5), (64, 16), (129, 20), (3000, 32), (70_001, 9)])
+def test_batched_pass_on_the_e4m3_copy_scores_the_codes_against_two_term_queries(n, B):
+    """mv_query_topk_batch(mode "fde") on an index with the e4m3 copy: ONE pass over the copy per 32 requests on the fp8 MFMA
+    (v_mfma_f32_16x16x32_fp8_fp8; queries as two e4m3 terms under one scale).  Every returned score is the fp64 dot product of the page's codes
+    with the query's two-term value times scale / |d| (to fp32 accumulation accuracy); the ranking is that model's; tombstones, a shared
+    filter and per-request filters hold; corpus sizes around the 64-page tile, one and two query tiles."""
+    from morphik_core_amd import _lib
+    from morphik_core_amd.index import allow_bitmap
+
+    ix = _idx(capacity_pages=n, stride_rows=16, with_float=False, with_fde=True, with_fde_e4m3=True)
+    od = ix.fde_config.output_dim
+    ix.fill_synthetic(1234, 0, n, pages_per_doc=3)
+    ix.remove_doc(1)
+    rng = np.random.default_rng(n + B)
+    qfdes = (rng.standard_normal((B, od)) * rng.uniform(0.01, 30.0, size=(B, 1))).astype(np.float32)
+    qfdes[B - 1, : od // 2] = 0.0
+    queries = [orc.synth_rows(4321, b, 0, 8) for b in range(B)]
+    m = min(n, 4000)  # the model is checked on the first m pages (a doc filter keeps the answers inside them)
+    codes, scale = ix.read_fde_e4m3(0, m)
+    lut = orc.e4m3_decode(np.arange(256, dtype=np.uint8)).astype(np.float64)
+    deq = lut[codes]
+    norms = np.linalg.norm(ix.read_fde(0, m).astype(np.float64), axis=1)
+    n_docs = (n + 2) // 3
+    docs_m = [d for d in range((m + 2) // 3) if d != 1 and (d + 1) * 3 <= m]
+    shared = allow_bitmap(docs_m, n_docs)
+    per_req = [allow_bitmap([d for d in docs_m if (d + b) % 4 != 0], n_docs) for b in range(B)]
+    k = 25
+    for cosine in (1, 0):
+        ix.set_option(_lib.MV_OPT_FDE_COSINE, cosine)
+        fac = scale.astype(np.float64) / (norms if cosine else 1.0)
+        for kind in ("shared", "per_request"):
+            kw = dict(allow=shared) if kind == "shared" else dict(allows=per_req, n_docs=n_docs)
+            got = ix.query_batch(queries, k, mode="fde", q_fdes=qfdes, **kw)
+            for b in range(B):
+                want = (deq @ _two_term_query(qfdes[b])) * fac
+                ok_docs = set(docs_m) if kind == "shared" else {d for d in docs_m if (d + b) % 4 != 0}
+                live = np.array([p for p in range(m) if p // 3 in ok_docs], np.int64)
+                s, i = got[b]
+                assert len(i) == min(k, live.size) and set(i.tolist()) <= set(live.tolist())
+                tol = 3e-5 * float(np.abs(want[live]).max()) + 1e-30
+                np.testing.assert_allclose(s, want[i], rtol=0, atol=tol)
+                assert float(s.min()) >= float(np.sort(want[live])[-len(i)]) - 2 * tol  # nothing better was left out
+    # the same batch through the bf16 slab: other scores, (nearly) the same candidates
+    ix.set_option(_lib.MV_OPT_FDE_COARSE_SLAB, 0)
+    got16 = ix.query_batch(queries, k, mode="fde", q_fdes=qfdes, allow=shared)
+    ix.set_option(_lib.MV_OPT_FDE_COARSE_SLAB, 1)
+    got8 = ix.query_batch(queries, k, mode="fde", q_fdes=qfdes, allow=shared)
+    overlap = np.mean([len(set(a[1].tolist()) & set(b[1].tolist())) / max(len(a[1]), 1) for a, b in zip(got16, got8)])
+    assert overlap >= 0.8
+    ix.close()
+
+
+def test_batched_pipeline_on_the_e4m3_copy_and_its_placement_trial():
+    """fde_then_float batches on the e4m3 coarse pass: planted neighbours come back with the exact scores of the single query; the
+    placement trial moves the e4m3 copy (the slab the pass reads) and changes nothing."""
+    from morphik_core_amd import synth
+
+    N, stride, B = 5000, 32, 12
+    qs = [orc.synth_rows(4321, j, 0, 16) for j in range(B)]
+    ix = _idx(capacity_pages=N, stride_rows=stride, with_fde=True, with_fde_e4m3=True)
+    ix.fill_synthetic(1234, 0, N)
+    spec = synth.planted_spec(qs, N, stride, n_ranks=10)
+    for (_, _, p, row0, rows) in spec:
+        page = ix.read_pages(p, 1)[0]
+        page[row0 : row0 + rows.shape[0]] = rows
+        ix.replace_page(p, page)
+    want = [ix.query(q, 10, mode="fde_then_float") for q in qs]
+    got = ix.query_batch(qs, 10, mode="fde_then_float")
+    for qi, ((ws, wi), (s, i)) in enumerate(zip(want, got)):
+        assert i.tolist() == wi.tolist() == [p for (qq, _r, p, _a, _b) in spec if qq == qi] and s.tolist() == ws.tolist()
+    codes0 = ix.read_fde_e4m3(0, N)[0]
+    before, after, moves = ix.fde_placement_trial(2)
+    assert before > 0 and after > 0 and 0 <= moves <= 2
+    assert np.array_equal(ix.read_fde_e4m3(0, N)[0], codes0)
+    for (ws, wi), (s, i) in zip(want, ix.query_batch(qs, 10, mode="fde_then_float")):
+        assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist()
+    ix.close()
+
+
 def test_flag_and_option_errors():
     from morphik_core_amd import _lib
     from morphik_core_amd._lib import MvError
