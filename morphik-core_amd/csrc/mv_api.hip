@@ -3402,7 +3402,7 @@ int mv_index_load(const char* path, int32_t device, mv_index** out) {
     fill(ix->fde_inv_norm, (size_t)h.size * 4);
     if (!rc && ix->fde8) {  // the e4m3 copy is not in the file: derived again (the quantiser is deterministic)
       rc = fde8_requantize(ix, 0, h.size, nullptr);
-      if (!rc && hipDeviceSynchronize() != hipSuccess) { set_error("%s: quantising the FDE slab failed", path); rc = MV_ERR_HIP; }
+      if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) { set_error("%s: quantising the FDE slab failed", path); rc = MV_ERR_HIP; }
     }
   }
   if (h.cfg.flags & MV_WITH_FP8) {

@@ -262,7 +262,7 @@ inline bool fde_scan_batch_fuses_finish(const FdeScanBatchArgs& a) {
 }
 // the pass reads the slab's e4m3 copy (its kernel always writes finished scores: nothing is binned on the way)
 inline bool fde_scan_batch_uses_e4m3(const FdeScanBatchArgs& a) {
-  return a.fde8 != nullptr && !a.single_tile && !a.hi_only && !a.separate_finish && fde_scan_batch8_supported(a.out_dim);
+  return a.fde8 != nullptr && !a.single_tile && !a.separate_finish && fde_scan_batch8_supported(a.out_dim);
 }
 inline bool fde_scan_batch_prebins(const FdeScanBatchArgs& a) {
   return a.hist0 != nullptr && (a.inv_norm != nullptr || a.doc_ord != nullptr) && !fde_scan_batch_fuses_finish(a) && !fde_scan_batch_uses_e4m3(a);

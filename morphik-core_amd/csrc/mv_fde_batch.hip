@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void fde_batch_qscale8_kernel(const float* q, 
     qfac[b] = pow2f(-pow2_scale_exp(amax));
   }
 }
-// image8[kc][wave][query tile][hi.0 | hi.1 | lo.0 | lo.1][lane] of 16-byte pieces: lane (query qt*16 + (l&15), group l>>4) holds the codes of
+// image8[kc][wave][query tile][hi.0 | lo.0 | hi.1 | lo.1][lane] of 16-byte pieces (the order of the bf16 image: a one-term pass loads pieces 0 and 2): lane (query qt*16 + (l&15), group l>>4) holds the codes of
 // dims kc*512 + wave*128 + 32*(l>>4) .. +32 of its query -- .0 the first sixteen, .1 the second (four 8-byte MFMA operands per term).
 __global__ __launch_bounds__(256) void fde_batch_qprep8_kernel(const float* q, const float* qfac, int nb, int out_dim, int nqt, uint8_t* image) {
   const int t = blockIdx.x * 256 + threadIdx.x;  // (kc, wave, qt, lane)
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void fde_batch_qprep8_kernel(const float* q, c
   }
   uint32_t* dst = reinterpret_cast<uint32_t*>(image + ((size_t)((kc * 4 + w) * nqt + qt) * 4) * 1024 + lane * 16);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { dst[i] = hi[i]; dst[256 + i] = hi[4 + i]; dst[512 + i] = lo[i]; dst[768 + i] = lo[4 + i]; }
+  for (int i = 0; i < 4; ++i) { dst[i] = hi[i]; dst[256 + i] = lo[i]; dst[512 + i] = hi[4 + i]; dst[768 + i] = lo[4 + i]; }
 }
 
 // NQT query tiles of 16 (16 or 32 queries per pass).
@@ -360,8 +360,8 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
                                          const int n_groups, const uint32_t (&src_off)[8], const uint32_t (&rd_off)[2]) {
   using bf16x8 = __attribute__((ext_vector_type(8))) short;
   using f32x4 = __attribute__((ext_vector_type(4))) float;
-  static_assert(!E4 || (LO && FIN), "the e4m3 form always carries both query terms and applies the page factor itself");
-  constexpr int NF = 4 * NQT;              // query fragments per K chunk and wave: (e, qt, hi|lo); E4: (qt, hi|lo, half)
+  static_assert(!E4 || FIN, "the e4m3 form applies the page factor itself");
+  constexpr int NF = 4 * NQT;              // query fragments per K chunk and wave: (e, qt, hi|lo); E4: (qt, half, hi|lo)
   constexpr int QOPS = LO ? NF : NF / 2;   // fragment loads per K chunk and wave
   constexpr int MOPS = FIN ? 2 : 0;        // metadata loads per slot of a K chunk with kc & 3 == 0
   char* meta = reinterpret_cast<char*>(red) + 4 * 16 * kFbRedStride * 4;  // FIN: [group parity][tile of the group][64 x 1/|d| | 64 x doc ordinal]
@@ -558,8 +558,8 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
               const long a8 = __builtin_bit_cast(i64x2, af[e][t])[jj];
 #pragma unroll
               for (int qt = 0; qt < NQT; ++qt) {
-                acc[j][t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a8, __builtin_bit_cast(i64x2, qf[kcs][qt * 4 + e])[jj], acc[j][t][qt], 0, 0, 0);
-                acc[j][t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a8, __builtin_bit_cast(i64x2, qf[kcs][qt * 4 + 2 + e])[jj], acc[j][t][qt], 0, 0, 0);
+                acc[j][t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a8, __builtin_bit_cast(i64x2, qf[kcs][qt * 4 + 2 * e])[jj], acc[j][t][qt], 0, 0, 0);
+                if (LO) acc[j][t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a8, __builtin_bit_cast(i64x2, qf[kcs][qt * 4 + 2 * e + 1])[jj], acc[j][t][qt], 0, 0, 0);
               }
             }
       } else {
@@ -779,7 +779,10 @@ int launch_fde_scan_batch(const FdeScanBatchArgs& a, hipStream_t s) {
     ScanBatchArgs k8{reinterpret_cast<const char*>(a.fde8), reinterpret_cast<const char*>(a.image), a.scores, a.score_stride, a.n,
                      (int32_t)a.out_dim, a.n_queries, (int32_t)n_tiles8, a.fde8_fac, a.doc_ord, a.qfac};
     const dim3 grid8((unsigned)std::min<int64_t>(n_tiles8, ncu));
-    if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch2_kernel<1, true, true, true>), grid8, dim3(256), 0, s, k8);
+    if (a.hi_only) {  // MV_OPT_FDE_BATCH_VARIANT 2: the queries' hi term only (half the matrix work; the query as coarse as the pages)
+      if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch2_kernel<1, false, true, true>), grid8, dim3(256), 0, s, k8);
+      else hipLaunchKernelGGL((fde_scan_batch2_kernel<2, false, true, true>), grid8, dim3(256), 0, s, k8);
+    } else if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch2_kernel<1, true, true, true>), grid8, dim3(256), 0, s, k8);
     else hipLaunchKernelGGL((fde_scan_batch2_kernel<2, true, true, true>), grid8, dim3(256), 0, s, k8);
     if (a.allow && a.doc_ord)  // per-request doc filters: masks only, a pass of their own (as behind the bf16 form)
       hipLaunchKernelGGL(fde_batch_finish_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a.scores, a.score_stride, a.n, a.n_queries,

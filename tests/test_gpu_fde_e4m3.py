@@ -276,6 +276,45 @@ def test_batched_pipeline_on_the_e4m3_copy_and_its_placement_trial():
     ix.close()
 
 
+@pytest.mark.parametrize("sharded", [False, True])
+def test_store_with_fde_e4m3_runs_the_reference_scenarios_and_survives_a_checkpoint(sharded, tmp_path):
+    """store option fde_e4m3 (single store and one store over three shards): the reference's store scenarios, the model-based random
+    sequences' float twin is not needed -- the rerank is exact, so the planted answers of the scenarios must come back -- and a checkpoint
+    round trip keeps the option and the answers."""
+    from morphik_core_amd.store import MI355XFastMultiVectorStore, MI355XShardedFastMultiVectorStore
+    from tests import store_scenarios as sc
+
+    def make(**kw):
+        if sharded:
+            s = MI355XShardedFastMultiVectorStore(devices=[0, 0, 0], transport="p2p", capacity_pages=96, stride_rows=32, mode="fde_then_float", fde_e4m3=True, **kw)
+        else:
+            s = MI355XFastMultiVectorStore(capacity_pages=96, stride_rows=32, mode="fde_then_float", fde_e4m3=True, **kw)
+        assert s.initialize() is True
+        return s
+
+    for scenario in sc.ALL:
+        s = make()
+        try:
+            sc.run(scenario(s))
+        finally:
+            s.close()
+    s = make()
+    rng = np.random.default_rng(11)
+    chunks = sc.make_chunks(rng, n_docs=6, chunks_per_doc=4)
+    sc.run(s.store_embeddings(chunks))
+    want = [[(c.document_id, c.chunk_number, c.score) for c in sc.run(s.query_similar(ch.embedding, k=3))] for ch in chunks[:5]]
+    assert all(w[0][:2] == (ch.document_id, ch.chunk_number) for w, ch in zip(want, chunks[:5]))
+    path = str(tmp_path / "ckpt")
+    s.save(path)
+    s.close()
+    cls = MI355XShardedFastMultiVectorStore if sharded else MI355XFastMultiVectorStore
+    r = cls.load(path, **(dict(devices=[0, 0, 0], transport="p2p") if sharded else {}))
+    assert r.fde_e4m3 is True
+    got = [[(c.document_id, c.chunk_number, c.score) for c in sc.run(r.query_similar(ch.embedding, k=3))] for ch in chunks[:5]]
+    assert got == want
+    r.close()
+
+
 def test_flag_and_option_errors():
     from morphik_core_amd import _lib
     from morphik_core_amd._lib import MvError

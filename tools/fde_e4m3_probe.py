@@ -46,6 +46,15 @@ def main():
                     _r, st = ix.query_batch(qs[:B], 10, mode="fde", want_stats=True)
                     tb.append(st.coarse_ms)
                 row[name][f"batch{B}_coarse_ms"] = round(float(np.median(tb)), 4)
+                if slab:  # the queries' hi term only (MV_OPT_FDE_BATCH_VARIANT 2)
+                    ix.set_option(L.MV_OPT_FDE_BATCH_VARIANT, 2)
+                    tb = []
+                    for r2 in range(9):
+                        _r, st = ix.query_batch(qs[:B], 10, mode="fde", want_stats=True)
+                        if r2 >= 2:
+                            tb.append(st.coarse_ms)
+                    row[name][f"batch{B}_one_term_coarse_ms"] = round(float(np.median(tb)), 4)
+                    ix.set_option(L.MV_OPT_FDE_BATCH_VARIANT, 0)
         res["rounds"].append(row)
         print(f"round {r}: {row}", file=sys.stderr, flush=True)
     same = 0

@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
     return 0;
   }
   const int iters = argc > 1 ? atoi(argv[1]) : 200;
-  const int all = MV_WITH_FLOAT | MV_WITH_BINARY | MV_WITH_FDE | MV_WITH_FP8 | MV_WITH_HOST_EXACT;
+  const int all = MV_WITH_FLOAT | MV_WITH_BINARY | MV_WITH_FDE | MV_WITH_FP8 | MV_WITH_HOST_EXACT | MV_WITH_FDE_E4M3;  // (round 6: + the e4m3 copy of the FDE slab)
   mv_index* ix = make_index(0, 4096, 0, all);
   CHECK(mv_index_fill_synthetic(ix, 1, 0, 512, 32, 4));
   std::atomic<bool> stop{false};
@@ -268,7 +268,7 @@ int main(int argc, char** argv) {
   {
     mv_config c{};
     c.dim = 128; c.stride_rows = 32; c.capacity_pages = 1024; c.capacity_rows = 1024 * 24; c.device = 1; c.id_base = 0;
-    c.flags = MV_WITH_FLOAT | MV_WITH_FLOAT_LO | MV_WITH_BINARY | MV_WITH_FDE | MV_WITH_FP8 | MV_LAYOUT_PACKED;
+    c.flags = MV_WITH_FLOAT | MV_WITH_FLOAT_LO | MV_WITH_BINARY | MV_WITH_FDE | MV_WITH_FP8 | MV_LAYOUT_PACKED | MV_WITH_FDE_E4M3;
     c.fde = mv_fde_config{128, 20, 5, 16, 1};
     mv_index* px = nullptr;
     CHECK(mv_index_create(&c, &px));
@@ -286,6 +286,7 @@ int main(int argc, char** argv) {
         if (it % 19 == 4) CHECK(mv_index_set_option(px, MV_OPT_FDE_COARSE_N, (it & 1) ? 40 : 0));
         if (it % 23 == 5) CHECK(mv_index_set_option(px, MV_OPT_RERANK_N, 16 + it % 32));
         if (it % 29 == 6) CHECK(mv_index_set_option(px, MV_OPT_BATCH_VARIANT, (it & 1) ? 8 : -1));
+        if (it % 31 == 7) CHECK(mv_index_set_option(px, MV_OPT_FDE_COARSE_SLAB, it & 1));
         n_packed.fetch_add(1);
       }
     };
