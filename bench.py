@@ -467,6 +467,10 @@ def full_shard(args, device, qs):
     res["fde_placement_trial"] = trial
     # ---- round 6: the coarse stage on the e4m3 COPY of the FDE slab (MV_WITH_FDE_E4M3: 10 240 B per page instead of 20 480)
     ix.set_option(L.MV_OPT_FDE_COARSE_SLAB, 1)
+    ix.query_batch([qs[i % len(qs)] for i in range(32)], K, mode="fde")  # (allocates the batch workspace's e4m3 part: the trial times the pass the index would run)
+    t0 = time.time()
+    before, after, moves = ix.fde_placement_trial(3)  # the pass's time follows the allocation of THIS slab too
+    res["fde_placement_trial_e4m3"] = {"pass_ms_32_requests_before": round(before, 4), "after": round(after, 4), "moves": moves, "wall_s": round(time.time() - t0, 2)}
     t = timed_mode(ix, qs, "fde")
     res["fde_coarse_scan_e4m3"] = dict(scan_entry(n, 10240, t["coarse_ms"]), query_encode_ms=round(t["encode_ms"], 4))
     e8 = fde_pipeline_timings(ix, qs, n, (75, 1000), bytes_per_page=10240)
