@@ -10,6 +10,7 @@
 #   pmc_traffic_aux [pages]  the same two passes over the secondary scans (e4m3, sign-bit, FDE)   -> pmc_traffic_aux_scans_<round>.json
 #   batch_sq [pages] SQ counters (two counter-only passes) of the batched bf16 scan at B = 16 -> pmc_sq_batched_bf16_B16.json, batch_scan_probe.jsonl
 #   fde_batch_sq [pages]  SQ / TCC counters of the batched FDE coarse pass, one process per placement -> pmc_fde_batch_modes.json (tools/fde_batch_mode_probe.py)
+#   fde_e4m3_sq [pages]  SQ counters of the FDE scans on both slabs (single-query and batched)  -> pmc_sq_fde_scans_bf16_and_e4m3.json
 #   binary_sq [pages] SQ counters of the sign-bit scan                                -> pmc_sq_sign_bit_scan.json
 #   probe <script.py> [args...]   any tools/*.py probe, stdout -> <script>.jsonl
 #   pmc <name> <counters...> -- <cmd...>   a counter-only rocprofv3 pass of any command -> pmc_<name>.json
@@ -72,6 +73,11 @@ case $what in
     pmc_pass binary_set1 "$SQ1" python $R/tools/binary_probe.py $pages 4
     pmc_pass binary_set2 "$SQ2" python $R/tools/binary_probe.py $pages 4
     python $R/tools/sq_summary.py $OUT/pmc_binary_set1.raw.json $OUT/pmc_binary_set2.raw.json maxsim_binary $OUT/pmc_sq_sign_bit_scan.json ;;
+  fde_e4m3_sq)
+    pages=${1:-1250000}
+    pmc_pass fde8_set1 "$SQ1" python $R/tools/fde_e4m3_probe.py $pages 1
+    pmc_pass fde8_set2 "$SQ2" python $R/tools/fde_e4m3_probe.py $pages 1
+    python $R/tools/sq_summary.py $OUT/pmc_fde8_set1.raw.json $OUT/pmc_fde8_set2.raw.json fde_scan $OUT/pmc_sq_fde_scans_bf16_and_e4m3.json ;;
   probe)
     s=$1; shift
     (cd $R && python tools/$s "$@" > $OUT/${s%.py}.jsonl 2> $OUT/${s%.py}.err; cat $OUT/${s%.py}.jsonl | cut -c1-600) ;;
