@@ -151,8 +151,9 @@ typedef enum {
   MV_OPT_BINARY_VARIANT = 5, /* sign-bit scan: 0 = popcount on the VALU (the independent cross-check), 4 = FP4 MFMA with in-place bit
                                 operands and a 4-slot ring (default); the same integers.  (1-3, 5, 6 lost by measurement and were
                                 removed in round 5: MV_ERR_INVALID.) */
-  MV_OPT_FDE_SCAN_VARIANT = 6, /* FDE coarse scan: 5 = row quarters through the nt LDS-DMA ring, one fresh workgroup per 16 rows (default),
-                                * 0 = one wave per row on plain nt loads (the same arithmetic order: bit-identical scores) */
+  MV_OPT_FDE_SCAN_VARIANT = 6, /* FDE coarse scan: 6 = row quarters through the nt LDS-DMA ring, one fresh workgroup per 256 KiB-aligned block
+                                * of the slab (default), 5 = the same with a workgroup per 16 consecutive rows,
+                                * 0 = one wave per row on plain nt loads (the same arithmetic order in all three: bit-identical scores) */
   MV_OPT_BATCH_VARIANT = 7,   /* batched float scan: -1 / 0 = auto (default): page-split form (wave-private rings, no barrier) up to 128
                                  query rows in the group, row-split workgroup above; both with transposed MFMA roles (one running
                                  max per query tile, v_max3).  3 = row-split form always, 4 = page-split form (<= 128 rows): each is

@@ -1535,7 +1535,7 @@ int mv_index_set_option(mv_index* ix, int option, int64_t value) {
       if (value != -1 && value != 0 && value != 4) { set_error("sign-bit scan variant %lld does not exist (-1 / 4 FP4 MFMA, 0 popcount; 1-3, 5, 6 were removed in round 5)", (long long)value); return MV_ERR_INVALID; }
       ix->binary_variant = (int)value; return MV_OK;
     case MV_OPT_FDE_SCAN_VARIANT:
-      if (value != -1 && value != 0 && value != 5) { set_error("FDE scan variant %lld does not exist (-1 / 5 row quarters on the ring, 0 register form; 1-4 were removed in round 5)", (long long)value); return MV_ERR_INVALID; }
+      if (value != -1 && value != 0 && value != 5 && value != 6) { set_error("FDE scan variant %lld does not exist (-1 / 6 row quarters on the ring over 256 KiB-aligned blocks, 5 the same over 16-row units, 0 register form; 1-4 were removed in round 5)", (long long)value); return MV_ERR_INVALID; }
       ix->fde_scan_variant = (int)value; return MV_OK;
     case MV_OPT_BATCH_VARIANT: ix->batch_variant = (int)value; return MV_OK;
     case MV_OPT_LONG_QUERY_VARIANT: ix->long_query_variant = (int)value; return MV_OK;

@@ -347,4 +347,24 @@ int launch_scatter_rows(const void* d_src, int dtype, const int64_t* d_row_offse
                         uint16_t* d_slab_pages, hipStream_t s, int32_t* d_nonfinite = nullptr, uint16_t* d_slab_lo_pages = nullptr,
                         const int64_t* d_dst_row_off = nullptr);
 
+
+// Units of a row scan that follow the slab's 256 KiB-aligned blocks: unit `blk` = the rows that START in the blk-th aligned
+// block the slab touches; its `G` groups split them in halves.  Workgroup b runs on XCD b % 8, so with one block per workgroup every
+// XCD's successive workgroups stay 2 MiB apart -- the float scan's 256 KiB pages have that shape by construction.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void block_unit_rows(const void* slab, int64_t row_bytes, int64_t blk, int groups, int group, int64_t* first, int* count) {
+  const int64_t off0 = (int64_t)(reinterpret_cast<uintptr_t>(slab) & 262143u);
+  const int64_t lo_b = blk * 262144 - off0, hi_b = lo_b + 262144;
+  const int64_t r0 = lo_b <= 0 ? 0 : (lo_b + row_bytes - 1) / row_bytes;
+  const int n = (int)((hi_b + row_bytes - 1) / row_bytes - r0);
+  const int per = (n + groups - 1) / groups;
+  *first = r0 + (int64_t)group * per;
+  *count = max(0, min(per, n - group * per));
+}
+#endif
+inline int64_t block_unit_count(const void* slab, int64_t row_bytes, int64_t n_rows) {
+  const int64_t span = (int64_t)(reinterpret_cast<uintptr_t>(slab) & 262143u) + n_rows * row_bytes;
+  return (span + 262143) / 262144;
+}
+
 }  // namespace mv

@@ -840,7 +840,10 @@ __global__ __launch_bounds__(256) void fde_scan_rowq_kernel(ScanArgs a, int ru) 
   using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
   // ---- unit prologue: lane i <-> the unit's i-th row
-  const int64_t base = ((int64_t)blockIdx.x * G + group) * (int64_t)ru;
+  // ru > 0: units of ru consecutive rows; ru == 0: one 256 KiB-aligned block of the slab per workgroup (block_unit_rows)
+  int64_t base;
+  if (ru > 0) base = ((int64_t)blockIdx.x * G + group) * (int64_t)ru;
+  else block_unit_rows(a.fde, (int64_t)a.out_dim * 2, (int64_t)blockIdx.x, G, group, &base, &ru);
   const int64_t myrow = base + lane;
   const bool valid = lane < ru && myrow < a.n;
   bool masked = false;
@@ -1197,20 +1200,24 @@ int launch_fde_encode(const FdeTables& t, const FdeEncodeArgs& a, hipStream_t s)
 // form the radix selection takes its own first pass over the n scores (4 bytes per page against 20 480).
 bool fde_scan_prebins(int variant, int64_t out_dim) { return variant == 0 && (out_dim == 10240 || out_dim == 5120); }
 
-// variant: -1 / 5 = row quarters on the nt LDS-DMA ring, one fresh workgroup per 16 rows (default at 10 240 / 5 120 dims);
+// variant: -1 / 6 = row quarters on the nt LDS-DMA ring, one fresh workgroup per 256 KiB-aligned block of the slab (default at 10 240 /
+//          5 120 dims; round 6: +1.2 .. 1.6 % over 5);  5 = the same with a workgroup per 16 consecutive rows (320 KiB);
 //          0 = one wave per row on plain nt loads, the query FDE in registers (the same arithmetic order: bit-identical scores);
 //          other widths: the generic kernel
 int launch_fde_scan(const FdeScanArgs& a, int variant, hipStream_t s) {
   if (a.n <= 0) return MV_OK;
   ScanArgs k{a.fde, a.inv_norm, a.doc_ord, a.allow, a.n_allow_bits, a.q, a.scores, a.n, (int32_t)a.out_dim, nullptr};
   const bool shaped = a.out_dim == 10240 || a.out_dim == 5120;
-  if (variant < 0) variant = 5;
+  if (variant < 0) variant = 6;
+  const bool want_blocks = variant == 6;
+  if (variant == 6) variant = 5;
   if (variant != 0 && variant != 5) { set_error("unknown FDE scan variant %d (5 = row quarters / LDS-DMA, 0 = register form)", variant); return MV_ERR_INVALID; }
   if (variant == 5 && shaped) {
     static int env_ru = -1;
-    if (env_ru < 0) { const char* e = getenv("MV_FDE_SCAN_RU"); env_ru = e ? atoi(e) : 0; }  // tuning hook (tools/scan_ceiling_probe.py)
-    const int ru = env_ru > 0 ? (env_ru > 64 ? 64 : env_ru) : 16;  // 8 / 16 / 32 rows per workgroup measured equal within the noise
-    const int64_t units = (a.n + ru - 1) / ru;
+    if (env_ru == -1) { const char* e = getenv("MV_FDE_SCAN_RU"); env_ru = e ? atoi(e) : 0; }  // tuning hook (tools/scan_ceiling_probe.py)
+    const bool blocks = want_blocks && env_ru <= 0;
+    const int ru = blocks ? 0 : (env_ru > 0 ? (env_ru > 64 ? 64 : env_ru) : 16);  // 8 / 16 / 32 rows per workgroup measured equal within the noise
+    const int64_t units = blocks ? block_unit_count(a.fde, a.out_dim * 2, a.n) * (a.out_dim == 10240 ? 1 : 2) : (a.n + ru - 1) / ru;  // (5 120 dims: two groups per workgroup)
     if (units > ((int64_t)1 << 23)) { set_error("FDE scan: more than 2^27 rows per launch is not supported"); return MV_ERR_INVALID; }
     if (a.out_dim == 10240) hipLaunchKernelGGL((fde_scan_rowq_kernel<5, 4, 3>), dim3((unsigned)units), dim3(256), 0, s, k, ru);
     else hipLaunchKernelGGL((fde_scan_rowq_kernel<5, 2, 3>), dim3((unsigned)((units + 1) / 2)), dim3(256), 0, s, k, ru);

@@ -803,7 +803,7 @@ def test_fde_scan_row_quarters_bit_identical_to_the_register_scan(mv, n):
     allow = allow_bitmap([d for d in range(n_docs) if d % 5 != 1], n_docs)
     q = orc.synth_rows(4321, 7, 0, 32)
     got = {}
-    for v in (0, 5, -1):
+    for v in (0, 5, 6, -1):  # 6 (= -1, round 6): the row-quarter form with one 256 KiB-aligned block of the slab per workgroup (12 / 13 rows)
         ix.set_option(_lib.MV_OPT_FDE_SCAN_VARIANT, v)
         for cosine in (1, 0):
             ix.set_option(_lib.MV_OPT_FDE_COSINE, cosine)
@@ -812,7 +812,7 @@ def test_fde_scan_row_quarters_bit_identical_to_the_register_scan(mv, n):
         ix.set_option(_lib.MV_OPT_FDE_COSINE, 1)
         got[v, "top"] = ix.query(q, min(200, n), mode="fde", allow=allow)
         got[v, "top_all"] = ix.query(q, min(1000, n), mode="fde")
-    for v in (5, -1):
+    for v in (5, 6, -1):
         for cosine in (1, 0):
             for key in ("all", "flt"):
                 a, b = got[0, cosine, key], got[v, cosine, key]
