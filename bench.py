@@ -908,6 +908,17 @@ def fp32_split_block(args, device):
         res[key] = dict(scan_entry(n, bpp, t["score_kernel_ms"] if lo_scan != 2 else t["coarse_ms"]), total_device_ms=round(t["total_device_ms"], 4))
         if lo_scan == 2:
             res[key]["rerank_ms"] = round(t["rerank_ms"], 4)
+    # a batch of fp32 requests in cascade mode: ONE batched hi scan per group + the one-launch split rerank of all lists (== the single requests)
+    ix.set_option(L.MV_OPT_FLOAT_LO_SCAN, 2)
+    bqs = [unit(args.qtokens) for _ in range(16)]
+    singles = [ix.query(q, K) for q in bqs]
+    ms = []
+    for r in range(5):
+        got_b, st_b = ix.query_batch(bqs, K, want_stats=True)
+        if r >= 2:
+            ms.append(st_b.total_device_ms)
+    res["cascade_batch_of_16"] = {"device_ms_per_batch": round(float(np.median(ms)), 4), "sixteen_single_requests_device_ms": round(16 * res["cascade_hi_scan_then_rescore_128"]["total_device_ms"], 4),
+                                  "same_ids_and_scores_as_the_single_requests": all(a[1].tolist() == b[1].tolist() and np.array_equal(a[0], b[0]) for a, b in zip(got_b, singles))}
     # the same queries rounded to bf16 (RNE): the one-term kernel on the hi slab -- what the query's lo chain adds to an HBM-bound scan
     bq = [((q.view(np.uint32) + 0x7FFF + ((q.view(np.uint32) >> 16) & 1)) >> 16).astype(np.uint16) for q in qs]
     ix.set_option(L.MV_OPT_FLOAT_LO_SCAN, 0)
@@ -949,6 +960,7 @@ def aux_summary(out, aux):
         "fde75_recall_hard": g("exact_shard", "recall_at_10_vs_exact_bf16", "hard_negatives", "fde_top75_then_exact"),
         "fp32_split_max_rel_err": g("fp32_split_bf16", "max_rel_score_err_vs_fp32_reference"),
         "fp32_hi_lo_scan_frac": g("fp32_split_bf16", "scan_hi_plus_lo", "frac_hbm_8TBps"),
+        "fp32_batch16_ms": [g("fp32_split_bf16", "cascade_batch_of_16", "device_ms_per_batch"), g("fp32_split_bf16", "cascade_batch_of_16", "sixteen_single_requests_device_ms")] if g("fp32_split_bf16", "cascade_batch_of_16") else None,
         "ragged_packed_valid_frac": g("ragged_corpus", "packed", "frac_hbm_8TBps_valid_bytes"),
         "ragged_fixed_valid_frac": g("ragged_corpus", "fixed_stride", "frac_hbm_8TBps_valid_bytes"),
         "ragged_capacity_gain": g("ragged_corpus", "capacity_gain_packed_over_fixed"),

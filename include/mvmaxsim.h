@@ -353,7 +353,10 @@ MV_API int mv_query_stats_finish(mv_index* ix, mv_query_stats* stats);
  *   allow_bits n_allow_words words shared by all queries (allow_per_query = 0) or n_queries bitmaps of n_allow_words
  *              words back to back (allow_per_query = 1: every request keeps its own doc_ids / auth filter)
  *   out_*      n_queries x k entries (row b = results of query b), out_n[b] = results of query b
- * MV_MODE_FLOAT runs the batched MFMA kernel (up to 512 query rows per slab pass: B x Q flop/byte).
+ * MV_MODE_FLOAT runs the batched MFMA kernel (up to 512 query rows per slab pass: B x Q flop/byte); on an index with
+ * MV_WITH_FLOAT_LO in cascade mode (MV_OPT_FLOAT_LO_SCAN 2) that pass nominates every request's max(MV_OPT_RERANK_N, k) pages
+ * and ONE launch re-scores all lists with split-bf16 operands (the single request's answers); with MV_OPT_FLOAT_LO_SCAN 1, or
+ * fp32 queries on a plain index, the requests of the call are served one by one by the split-bf16 scan.
  * MV_MODE_FLOAT_FP8 runs its e4m3 form (block-scaled MFMA, K = 128 per instruction): half the page bytes per pass.
  * MV_MODE_FP8_THEN_FLOAT runs that pass, then re-scores every request's fp8 top-n exactly from the exact tier in ONE launch.
  * MV_MODE_FDE_THEN_FLOAT / MV_MODE_FDE_ONLY run the batched FDE pipeline: one pass over the FDE slab per 32 queries

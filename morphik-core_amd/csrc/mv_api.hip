@@ -2766,6 +2766,98 @@ static int fp8_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_q
   return MV_OK;
 }
 
+// mv_query_topk_batch(MV_MODE_FLOAT) on an index with a lo slab in cascade mode (MV_OPT_FLOAT_LO_SCAN 2): the single query's rule --
+// hi-only scan of every page -> the best max(MV_OPT_RERANK_N, k) -> split-bf16 re-score of those (fp32-faithful scores) -> top-k --
+// for a GROUP of requests per slab pass: the batched bf16 MFMA scan (queries' hi rows), one batched selection, the one-launch rerank
+// of all lists on the hi + lo slabs (mv_internal_batch_rerank_lists), one batched final selection, one read-back.  (Round 6: such
+// batches ran query by query -- B passes over the slab.)
+static int float_cascade_batch_query(mv_index* ix, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, int32_t k,
+                                     const uint32_t* allow_bits, int64_t n_allow_words, int32_t allow_per_query, float* out_scores, int64_t* out_ids,
+                                     int32_t* out_n, mv_query_stats* stats) {
+  std::lock_guard<std::mutex> lk(ix->q_mu);
+  DeviceGuard g(ix->cfg.device);
+  for (int32_t b = 0; b < n_queries; ++b) out_n[b] = 0;
+  mv_query_stats total{};
+  const int64_t n = ix->size.load(std::memory_order_acquire);
+  if (n == 0) { if (stats) *stats = total; return MV_OK; }
+  const size_t esz = q_dtype == MV_F32 ? 4 : 2;
+  const int rpq = ((n_q_rows + 15) / 16) * 16;
+  const int group = std::min(512 / rpq, 32);
+  int rc = mv_internal_ensure_batch_select_ws(ix);
+  if (rc) return rc;
+  const size_t lists = (size_t)kFdeBatchMaxQueries * kTopkMaxDeviceK;
+  if (!ix->d_bscores) {
+    hipError_t e = hipMalloc(&ix->d_bscores, (size_t)32 * ix->bscore_stride * 4);
+    if (e != hipSuccess) { ix->d_bscores = nullptr; set_error("hipMalloc of the batched score vectors (%lld B) failed", (long long)32 * ix->bscore_stride * 4); return MV_ERR_NOMEM; }
+  }
+  if (!ix->d_bq) MV_HIP(hipMalloc(&ix->d_bq, (size_t)kBatchQRows * kRowBytes));
+  if (!ix->d_bsel_s) MV_HIP(hipMalloc(&ix->d_bsel_s, lists * 4));
+  if (!ix->d_bsel_id) MV_HIP(hipMalloc(&ix->d_bsel_id, lists * 8));
+  if (!ix->d_bcand) MV_HIP(hipMalloc(&ix->d_bcand, lists * 4));
+  if (!ix->d_bcand_pads) MV_HIP(hipMalloc(&ix->d_bcand_pads, lists * 4));
+  if (!ix->d_bcand_scores) MV_HIP(hipMalloc(&ix->d_bcand_scores, lists * 4));
+  const int64_t nc = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(std::max<int64_t>(ix->rerank_n, k), n), kTopkMaxDeviceK));
+  const bool per_query = allow_bits && allow_per_query;
+  const uint32_t* d_allow = nullptr;
+  rc = upload_allow(ix, allow_bits, per_query ? n_allow_words * (int64_t)n_queries : n_allow_words, &d_allow);
+  if (rc) return rc;
+  const bool need_meta = ix->tombstones.load() || d_allow != nullptr;
+  const bool ragged = ix->ragged.load();
+  int64_t pages = 0;
+  const int64_t rows = stats ? count_allowed_rows(ix, n, per_query ? nullptr : allow_bits, n_allow_words, &pages) : 0;
+  for (int32_t b0 = 0; b0 < n_queries; b0 += group) {
+    const int nb = std::min(group, n_queries - b0);
+    rc = mv_internal_batch_upload_queries(ix, (const char*)q + (size_t)b0 * n_q_rows * kDim * esz, q_dtype, nb, n_q_rows, false, true, false);
+    if (rc) return rc;
+    MV_HIP(hipEventRecord(ix->ev[0], ix->stream));
+    BatchArgs a{};
+    a.slab = ix->slab; a.n_rows = ragged ? ix->d_n_rows : nullptr; a.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
+    a.allow = per_query ? d_allow + (size_t)b0 * n_allow_words : d_allow; a.n_allow_bits = n_allow_words * 32;
+    a.allow_stride_bits = per_query ? n_allow_words * 32 : 0; a.q = ix->d_bq; a.scores = ix->d_bscores; a.n = n;
+    a.score_stride = ix->bscore_stride; a.stride = ix->cfg.stride_rows; a.n_queries = nb; a.rows_per_query = rpq; a.row_off = ix->d_row_off;
+    a.variant = (ix->batch_variant == 3 || ix->batch_variant == 4) ? ix->batch_variant : 0;
+    rc = launch_maxsim_batch(a, ix->stream);
+    if (rc) return rc;
+    // every request's best nc pages of the hi scan (local page ids) -> rerank lists -> split-bf16 scores from the hi + lo slabs
+    rc = launch_topk_batch(ix->d_bscores, ix->bscore_stride, n, (int32_t)nc, nullptr, 0, 0, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bsel_s,
+                           ix->d_bsel_id, nc, nb, ix->stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cand_prepare_kernel, dim3((unsigned)((nc + kRerankBatch - 1) / kRerankBatch), (unsigned)nb), dim3(kRerankBatch), 0, ix->stream,
+                       (const int64_t*)ix->d_bsel_id, (const int32_t*)nullptr, (int)nc, (const int32_t*)ix->d_n_rows, ix->cfg.stride_rows, /*pad_sem=*/0,
+                       ix->d_bcand, ix->d_bcand_pads, nc);
+    MV_HIP(hipGetLastError());
+    int launches = 0;
+    rc = mv_internal_batch_rerank_lists(ix, nb, n_q_rows, nc, &launches, kTierSlab, nullptr);
+    if (rc) return rc;
+    MV_HIP(hipEventRecord(ix->ev[1], ix->stream));
+    rc = launch_topk_batch(ix->d_bcand_scores, nc, nc, k, ix->d_bcand, nc, ix->cfg.id_base, ix->d_btopk_ws, ix->topk_ws_bytes, ix->d_bout_s, ix->d_bout_id,
+                           k, nb, ix->stream);
+    if (rc) return rc;
+    MV_HIP(hipEventRecord(ix->ev[2], ix->stream));
+    MV_HIP(hipMemcpyAsync(ix->h_bout_s, ix->d_bout_s, (size_t)nb * k * 4, hipMemcpyDeviceToHost, ix->stream));
+    MV_HIP(hipMemcpyAsync(ix->h_bout_id, ix->d_bout_id, (size_t)nb * k * 8, hipMemcpyDeviceToHost, ix->stream));
+    MV_HIP(hipStreamSynchronize(ix->stream));
+    for (int b = 0; b < nb; ++b) {
+      const float* hs = ix->h_bout_s + (size_t)b * k;
+      const int64_t* hi = ix->h_bout_id + (size_t)b * k;
+      int32_t m = 0;
+      while (m < k && hi[m] >= 0) ++m;
+      memcpy(out_scores + (size_t)(b0 + b) * k, hs, (size_t)m * 4);
+      memcpy(out_ids + (size_t)(b0 + b) * k, hi, (size_t)m * 8);
+      out_n[b0 + b] = m;
+    }
+    if (stats) {
+      float ms_scan = 0, ms_sel = 0;
+      MV_HIP(hipEventElapsedTime(&ms_scan, ix->ev[0], ix->ev[1]));
+      MV_HIP(hipEventElapsedTime(&ms_sel, ix->ev[1], ix->ev[2]));
+      total.score_kernel_ms += ms_scan; total.topk_ms += ms_sel; total.total_device_ms += ms_scan + ms_sel;
+      total.score_launches += 1 + launches; total.pages_scored += pages * nb; total.bytes_scanned += rows * (int64_t)kRowBytes;
+    }
+  }
+  if (stats) *stats = total;
+  return MV_OK;
+}
+
 int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_queries, int32_t n_q_rows, int32_t k, int mode,
                         const uint32_t* allow_bits, int64_t n_allow_words, int32_t allow_per_query, float* out_scores,
                         int64_t* out_ids, int32_t* out_n, mv_query_stats* stats) {
@@ -2796,6 +2888,10 @@ int mv_query_topk_batch(mv_index* ix, const void* q, int q_dtype, int32_t n_quer
   // Split-bf16 operands (fp32 queries that are not bf16-representable; an index with a lo slab scanned with it): the batched MFMA
   // kernel multiplies ONE bf16 term per operand -- such batches are served query by query by the single-query kernels, which carry
   // the lo halves (the batch stays one call; bf16 queries on a plain index keep the one-pass form).
+  // cascade mode of an index with a lo slab: the batched hi scan nominates, the split-bf16 rerank of every list scores (one slab pass per group)
+  if (mode == MV_MODE_FLOAT && ix->slab_lo && opt_float_lo_scan == 2 && n_queries > 1 && k >= 1 && k <= kTopkMaxDeviceK && rpq <= 512 &&
+      (ix->cfg.flags & MV_WITH_FLOAT) && opt_batch_variant != 8)
+    return float_cascade_batch_query(ix, q, q_dtype, n_queries, n_q_rows, k, allow_bits, n_allow_words, allow_per_query, out_scores, out_ids, out_n, stats);
   bool batch_lo = mode == MV_MODE_FLOAT && ix->slab_lo && opt_float_lo_scan != 0;
   if (mode == MV_MODE_FLOAT && !batch_lo && q_dtype == MV_F32) {
     const float* qf = (const float*)q;

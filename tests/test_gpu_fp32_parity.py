@@ -263,3 +263,52 @@ def test_float_lo_flag_needs_the_float_slab():
 
     with pytest.raises(MvError):
         _idx(capacity_pages=4, stride_rows=16, with_float=False, with_fp8=True, with_float_lo=True)
+
+
+@pytest.mark.parametrize("stride,n_pages", [(64, 300), (1024, 150)])
+def test_fp32_batches_in_cascade_mode_take_one_slab_pass_per_group_and_equal_the_single_requests(stride, n_pages):
+    """MV_OPT_FLOAT_LO_SCAN 2 (hi scan -> best max(MV_OPT_RERANK_N, k) -> split-bf16 re-score): a BATCH of fp32 requests is served by the
+    batched bf16 MFMA scan + the one-launch split rerank of all lists (round 6; such batches ran query by query) and returns what
+    the single requests return -- same ids, same fp32-faithful scores, the oracle's top-k -- with a shared filter, per-request
+    filters, tombstones, ragged pages, more queries than one group holds, and queries longer than the one-launch rerank takes."""
+    from morphik_core_amd import _lib
+    from morphik_core_amd.index import allow_bitmap
+
+    rng = np.random.default_rng(stride + n_pages)
+    lens = [int(x) for x in rng.integers(max(1, stride // 3), stride + 1, size=n_pages)]
+    pages = [_unit(rng, n) for n in lens]
+    ix = _idx(capacity_pages=n_pages, stride_rows=stride, with_float_lo=True)
+    ix.add(pages, doc_ordinals=[i // 2 for i in range(n_pages)])
+    ix.set_option(_lib.MV_OPT_FLOAT_LO_SCAN, 2)
+    ix.set_option(_lib.MV_OPT_RERANK_N, 40)
+    k = 9
+    for nq, B in ((32, 5), (9, 20), (80, 3)):
+        qs = [_unit(rng, nq) for _ in range(B)]
+        singles = [ix.query(q, k) for q in qs]
+        for q, (s, i) in zip(qs[:2], singles[:2]):
+            ws, wi = orc.topk(_want(q, pages), k)
+            assert i.tolist() == wi.tolist()
+            _close(s, ws)
+        got, st = ix.query_batch(qs, k, want_stats=True)
+        groups = -(-B // min(512 // (-(-nq // 16) * 16), 32))
+        if nq <= 64:
+            assert st.score_launches == groups * 2  # ONE scan over the slab and ONE rerank launch per group of requests
+        else:
+            assert groups * 2 <= st.score_launches <= groups + 2 * B  # one scan per group; the lists of longer queries are re-scored per request, in passes of 64 rows
+        for (bs, bi), (s, i) in zip(got, singles):
+            assert bi.tolist() == i.tolist()
+            assert np.array_equal(bs, s)
+    # filters and tombstones
+    ix.remove_doc(3)
+    n_docs = (n_pages + 1) // 2
+    shared = allow_bitmap([d for d in range(n_docs) if d % 4 != 1], n_docs)
+    qs = [_unit(rng, 24) for _ in range(6)]
+    per_req = [allow_bitmap([d for d in range(n_docs) if (d + b) % 3 != 0], n_docs) for b in range(6)]
+    for (bs, bi), q in zip(ix.query_batch(qs, k, allow=shared), qs):
+        s, i = ix.query(q, k, allow=shared)
+        assert bi.tolist() == i.tolist() and np.array_equal(bs, s)
+    for (bs, bi), q, ab in zip(ix.query_batch(qs, k, allows=per_req, n_docs=n_docs), qs, per_req):
+        s, i = ix.query(q, k, allow=ab)
+        assert bi.tolist() == i.tolist() and np.array_equal(bs, s)
+        assert not (set(i.tolist()) & {6, 7})
+    ix.close()
