@@ -122,6 +122,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         prune_slab: bool = True,
         fde_module: Any = None,
         fp32_pages: bool = False,
+        fp32_scan: str = "both_halves",
         fde_e4m3: bool = False,
         packed_layout: bool = False,
         capacity_rows: int = 0,
@@ -153,6 +154,12 @@ class MI355XMultiVectorStore(BaseVectorStore):
         # the float scan return that fp32 score to ~1e-6 -- for encoders whose output is not bf16 to begin with.  (A bf16 encoder under
         # autocast -- the reference's own, colpali_embedding_model.py:251-262 -- emits bf16 values: False loses nothing there.)
         self.fp32_pages = bool(fp32_pages)
+        # mode "float" on fp32 pages: "both_halves" = every page scored from hi + lo (twice the bytes per page; MV_OPT_FLOAT_LO_SCAN 1),
+        # "cascade" = the hi halves scanned, the best max(rerank_n, k) pages re-scored from both halves (the speed of a bf16 index, the
+        # same fp32-faithful top-k scores; a batch of requests then takes ONE pass over the slab: MV_OPT_FLOAT_LO_SCAN 2)
+        if fp32_scan not in ("both_halves", "cascade"):
+            raise ValueError(f"unknown fp32_scan {fp32_scan!r} (\"both_halves\" or \"cascade\")")
+        self.fp32_scan = fp32_scan
         # "fde_then_float": keep an e4m3 copy of the FDE slab (10 KiB per page at the reference's FDE width) and run the COARSE stage on it --
         # half the bytes of the pass that is nine tenths of a request.  The reference's coarse stage is an ANN index (approximate by contract);
         # the rerank and its scores are untouched (MV_WITH_FDE_E4M3)
@@ -265,6 +272,10 @@ class MI355XMultiVectorStore(BaseVectorStore):
             from ._lib import MV_OPT_RERANK_N
 
             ix.set_option(MV_OPT_RERANK_N, self.rerank_n)
+        if self.fp32_pages and self.fp32_scan == "cascade" and self.mode == "float":
+            from ._lib import MV_OPT_FLOAT_LO_SCAN
+
+            ix.set_option(MV_OPT_FLOAT_LO_SCAN, 2)
 
     def initialize(self) -> bool:
         """Allocate the HBM slabs. Returns False on failure, never raises (multi_vector_store.py:325-327)."""
@@ -846,7 +857,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
     def _book(self) -> Dict[str, Any]:
         return {
             "version": 3, "mode": self.mode, "capacity_pages": self.capacity_pages, "stride_rows": self.stride_rows,
-            "id_base": self.id_base, "fde_coarse_n": self.fde_coarse_n, "exact_tier": self.exact_tier, "rerank_n": self.rerank_n, "prune_slab": self.prune_slab, "fp32_pages": self.fp32_pages, "fde_e4m3": self.fde_e4m3, "packed_layout": self.packed_layout, "capacity_rows": self.capacity_rows, "fde_external": self.fde_module is not None, "next_ord": self._next_ord,
+            "id_base": self.id_base, "fde_coarse_n": self.fde_coarse_n, "exact_tier": self.exact_tier, "rerank_n": self.rerank_n, "prune_slab": self.prune_slab, "fp32_pages": self.fp32_pages, "fp32_scan": self.fp32_scan, "fde_e4m3": self.fde_e4m3, "packed_layout": self.packed_layout, "capacity_rows": self.capacity_rows, "fde_external": self.fde_module is not None, "next_ord": self._next_ord,
             "rows": [[p, r[0], r[1], r[2], r[3], r[4], row_origin(r)] for p, r in self._rows.items()],
             "doc_ord": self._doc_ord, "doc_app": {str(k): v for k, v in self._doc_app.items()},
         }
@@ -947,7 +958,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
             raise RuntimeError(f"{directory}: this checkpoint " + ("holds document FDE vectors of an external encoder: pass fde_module= to load()"
                                                                      if book.get("fde_external") else "was encoded by the library itself: load it without fde_module"))
         self = cls(capacity_pages=book["capacity_pages"], stride_rows=book["stride_rows"], device=device, mode=book["mode"], storage=storage,
-                   id_base=book["id_base"], fde_coarse_n=book.get("fde_coarse_n", 0), exact_tier=book.get("exact_tier", "hbm"), rerank_n=book.get("rerank_n", 0), prune_slab=book.get("prune_slab", True), **{"fp32_pages": book.get("fp32_pages", False), "fde_e4m3": book.get("fde_e4m3", False), "packed_layout": book.get("packed_layout", False), "capacity_rows": book.get("capacity_rows", 0), **kw})
+                   id_base=book["id_base"], fde_coarse_n=book.get("fde_coarse_n", 0), exact_tier=book.get("exact_tier", "hbm"), rerank_n=book.get("rerank_n", 0), prune_slab=book.get("prune_slab", True), **{"fp32_pages": book.get("fp32_pages", False), "fp32_scan": book.get("fp32_scan", "both_halves"), "fde_e4m3": book.get("fde_e4m3", False), "packed_layout": book.get("packed_layout", False), "capacity_rows": book.get("capacity_rows", 0), **kw})
         self._index = cls._load_index(self, directory, book, device)
         self._apply_options(self._index)
         for p, doc, chunk_no, content, meta_json, app, *rest in book["rows"]:

@@ -481,7 +481,7 @@ def test_random_op_sequences_match_a_brute_force_model_on_gpu(seed, mode):
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
-@pytest.mark.parametrize("layout", ["packed", "fp32_pages", "packed_fp32_pages"])
+@pytest.mark.parametrize("layout", ["packed", "fp32_pages", "packed_fp32_pages", "fp32_pages_cascade"])
 def test_random_op_sequences_on_the_packed_layout_and_with_fp32_pages_match_the_model(seed, layout):
     """The same model-based sequences (upserts of pages with another row count, deletes, compaction, filtered queries) on the round-6
     layouts: ragged pages back to back behind the row-offset table, pages kept as bf16 hi + lo, and both."""
@@ -492,6 +492,8 @@ def test_random_op_sequences_on_the_packed_layout_and_with_fp32_pages_match_the_
         kw.update(packed_layout=True, capacity_rows=64 * 32)
     if "fp32" in layout:
         kw.update(fp32_pages=True)
+    if "cascade" in layout:  # hi scan -> split re-score of the best pages (MV_OPT_FLOAT_LO_SCAN 2): the same fp32-faithful answers
+        kw.update(fp32_scan="cascade")
     s = MI355XMultiVectorStore(capacity_pages=64, stride_rows=32, mode="float", **kw)
     assert s.initialize() is True
     try:
