@@ -312,3 +312,44 @@ def test_fp32_batches_in_cascade_mode_take_one_slab_pass_per_group_and_equal_the
         assert bi.tolist() == i.tolist() and np.array_equal(bs, s)
         assert not (set(i.tolist()) & {6, 7})
     ix.close()
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_fp32_cascade_batches_with_fewer_allowed_pages_than_the_rerank_list(packed):
+    """The corners of the batched cascade (`float_cascade_batch_query`): filters that admit fewer pages than MV_OPT_RERANK_N and
+    fewer than k (the hi scan's selection hands -1 entries to the rerank lists), a request whose filter admits nothing, a corpus
+    smaller than k, the packed layout -- every request answers as it does alone and as the fp32 oracle does."""
+    from morphik_core_amd import _lib
+    from morphik_core_amd.index import allow_bitmap
+
+    rng = np.random.default_rng(77 + packed)
+    n_pages, stride, k = 60, 48, 10
+    lens = [int(x) for x in rng.integers(5, stride + 1, size=n_pages)]
+    pages = [_unit(rng, n) for n in lens]
+    ix = _idx(capacity_pages=n_pages, stride_rows=stride, with_float_lo=True, packed=packed)
+    ix.add(pages, doc_ordinals=list(range(n_pages)))
+    ix.set_option(_lib.MV_OPT_FLOAT_LO_SCAN, 2)
+    ix.set_option(_lib.MV_OPT_RERANK_N, 40)
+    qs = [_unit(rng, 20) for _ in range(5)]
+    allowed = [[3, 17, 41], list(range(0, 60, 9)), [], [59], list(range(60))]
+    per_req = [allow_bitmap(a, n_pages) for a in allowed]
+    got = ix.query_batch(qs, k, allows=per_req, n_docs=n_pages)
+    for (bs, bi), q, a, ab in zip(got, qs, allowed, per_req):
+        s, i = ix.query(q, k, allow=ab)
+        assert bi.tolist() == i.tolist() and np.array_equal(bs, s)
+        assert len(bi) == min(k, len(a)) and set(bi.tolist()) <= set(a)
+        if a:
+            ws, wi = orc.topk(_want(q, [pages[p] for p in a]), k)
+            assert bi.tolist() == [a[j] for j in wi.tolist()]
+            _close(bs, ws)
+    # a shared filter that leaves 4 pages, then tombstones that leave fewer pages than k in the whole index
+    shared = allow_bitmap([1, 2, 30, 31], n_pages)
+    for (bs, bi), q in zip(ix.query_batch(qs, k, allow=shared), qs):
+        s, i = ix.query(q, k, allow=shared)
+        assert bi.tolist() == i.tolist() and np.array_equal(bs, s) and sorted(bi.tolist()) == [1, 2, 30, 31]
+    for d in range(7, n_pages):
+        ix.remove_doc(d)
+    for (bs, bi), q in zip(ix.query_batch(qs, k), qs):
+        s, i = ix.query(q, k)
+        assert bi.tolist() == i.tolist() and np.array_equal(bs, s) and sorted(bi.tolist()) == list(range(7))
+    ix.close()
