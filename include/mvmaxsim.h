@@ -88,7 +88,7 @@ enum {
                              stride_rows remains the longest page the index accepts.  Appends publish as before; a page may be replaced
                              in place only by one that fits its tiles; mv_index_compact closes the holes of removed pages.  Same scores,
                              bit for bit, as the fixed-stride layout.  Not combinable with MV_WITH_HOST_EXACT. */
-  MV_WITH_FDE_E4M3 = 256   /* with MV_WITH_FDE: keep an e4m3 COPY of the FDE slab (out_dim bytes per page + one power-of-two scale) and run
+  MV_WITH_FDE_E4M3 = 256,  /* with MV_WITH_FDE: keep an e4m3 COPY of the FDE slab (out_dim bytes per page + one power-of-two scale) and run
                              the COARSE stage of the FDE modes on it -- half the bytes of the pass that is nine tenths of every
                              MV_MODE_FDE_THEN_FLOAT request.  The reference's coarse stage is an ANN index (TurboPuffer,
                              fast_multivector_store.py:527-533): approximate by contract; what the stage owes is the candidates.  Row
@@ -97,6 +97,13 @@ enum {
                              terms (batched).  Coarse scores differ from the bf16 slab's by ~1e-3 relative -- candidate sets by a page or
                              two at the cut (recall unchanged on every corpus of the bench).  MV_OPT_FDE_COARSE_SLAB selects
                              the slab per query.  Needs an FDE width of 10 240 (the reference's), 4 096 or 2 048; out_dim bytes per page more HBM. */
+  MV_WITH_FDE_FP4 = 512    /* with MV_WITH_FDE, instead of MV_WITH_FDE_E4M3: the copy is FP4 (e2m1: sign + {0, 0.5, 1, 1.5, 2, 3, 4, 6}) under one
+                             power-of-two scale per row -- out_dim / 2 bytes per page, a QUARTER of the bf16 slab's -- and the coarse stage of a
+                             SINGLE request reads it (mv_fde4.hip; the query FDE stays fp32).  Batches of requests keep reading the bf16 slab
+                             (one pass per 32 requests).  Candidate lists differ from the bf16 slab's at the cut; recall@10 behind the exact
+                             rerank, priced before it was built (tools/fde_4bit_recall_probe.py) and measured by the bench: within 0.005 of the
+                             bf16 slab's on hard negatives at 75 candidates, equal at 1000.  Quantiser: oracle
+                             orc_quantize_fde_fp4, bit for bit.  Same widths as MV_WITH_FDE_E4M3.  MV_OPT_FDE_COARSE_SLAB 2 / 0 selects it per query. */
 };
 
 /* fixed_dimensional_encoding.FixedDimensionalEncodingConfig as constructed at
@@ -187,7 +194,8 @@ typedef enum {
                                     max(MV_OPT_RERANK_N, k) -> split-bf16 re-score of those -> top-k (fp32-faithful scores at the
                                     hi-only scan's speed; a page whose hi-only score misses the candidate cut by rounding alone --
                                     ~1e-4 relative -- would be lost: same caveat as MV_MODE_FP8_THEN_FLOAT, three orders smaller) */
-  MV_OPT_FDE_COARSE_SLAB = 16,   /* an index with MV_WITH_FDE_E4M3: 1 = the coarse stage reads the e4m3 copy (default), 0 = the bf16 slab */
+  MV_OPT_FDE_COARSE_SLAB = 16,   /* which slab the coarse stage reads: 0 = the bf16 slab, 1 = the e4m3 copy (default on an index with MV_WITH_FDE_E4M3),
+                                    2 = the fp4 copy (default on an index with MV_WITH_FDE_FP4; single requests) */
   MV_OPT_FDE_BATCH_VARIANT = 12  /* mv_query_topk_batch in the FDE modes: 0 = batched pipeline (default): up to 32 queries per pass
                                     over the FDE slab (bf16 MFMA, query FDE as bf16 hi + lo), batched selection, every query's
                                     candidates reranked in one launch, one read-back; 1 = query by query; 2 = as 0 with the query
@@ -383,6 +391,8 @@ MV_API int mv_index_import_fde(mv_index* ix, int64_t page0, int64_t n_pages, con
 MV_API int mv_index_read_fde(mv_index* ix, int64_t page0, int64_t n_pages, float* out);
 /* the e4m3 copy of the same rows (MV_WITH_FDE_E4M3): n_pages x out_dim codes and one scale per page -- value = decode(code) * scale */
 MV_API int mv_index_read_fde_e4m3(mv_index* ix, int64_t page0, int64_t n_pages, void* out_codes, float* out_scale);
+/* the fp4 copy of the same rows (MV_WITH_FDE_FP4): n_pages x out_dim / 2 bytes of e2m1 codes (element 2i in the low nibble) and one scale per page */
+MV_API int mv_index_read_fde_fp4(mv_index* ix, int64_t page0, int64_t n_pages, void* out_codes, float* out_scale);
 MV_API int mv_query_topk_fde(mv_index* ix, const void* q, int q_dtype, int32_t n_q_rows, const float* q_fde, int32_t k, int mode,
                              const uint32_t* allow_bits, int64_t n_allow_words, float* out_scores, int64_t* out_ids, int32_t* out_n,
                              mv_query_stats* stats);

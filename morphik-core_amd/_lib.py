@@ -78,6 +78,7 @@ MV_WITH_FLOAT, MV_WITH_BINARY, MV_WITH_FDE, MV_WITH_FP8, MV_WITH_HOST_EXACT, MV_
 MV_WITH_FLOAT_LO = 64
 MV_LAYOUT_PACKED = 128
 MV_WITH_FDE_E4M3 = 256
+MV_WITH_FDE_FP4 = 512
 MV_OPT_MAXSIM_VARIANT, MV_OPT_FDE_COARSE_N, MV_OPT_FDE_COSINE, MV_OPT_PAD_SEMANTICS, MV_OPT_BINARY_VARIANT, MV_OPT_FDE_SCAN_VARIANT = 1, 2, 3, 4, 5, 6
 MV_OPT_BATCH_VARIANT = 7
 MV_OPT_FDE_ENCODE_VARIANT = 8
@@ -103,7 +104,7 @@ class CandRecC(C.Structure):
 MV_ABI_VERSION = 7  # include/mvmaxsim.h: the header revision this binding's argument lists were written against
 
 EXPORTS = [
-    "mv_abi_version", "mv_last_error", "mv_version", "mv_device_count", "mv_host_pin_budget_bytes", "mv_index_exact_hbm_pages", "mv_index_exact_tier_rebalance", "mv_index_exact_tier_hits", "mv_index_fde_placement_trial", "mv_index_read_fde_e4m3", "mv_index_create", "mv_index_destroy", "mv_index_set_option",
+    "mv_abi_version", "mv_last_error", "mv_version", "mv_device_count", "mv_host_pin_budget_bytes", "mv_index_exact_hbm_pages", "mv_index_exact_tier_rebalance", "mv_index_exact_tier_hits", "mv_index_fde_placement_trial", "mv_index_read_fde_e4m3", "mv_index_read_fde_fp4", "mv_index_create", "mv_index_destroy", "mv_index_set_option",
     "mv_index_size", "mv_index_capacity", "mv_index_rows_used", "mv_index_capacity_rows", "mv_index_add", "mv_index_add_device", "mv_index_add_bits", "mv_index_remove_doc",
     "mv_index_remove_page", "mv_index_compact", "mv_index_read_pages", "mv_index_read_pages_f32", "mv_index_write_rows", "mv_index_replace_page", "mv_index_read_fp8", "mv_index_fill_synthetic", "mv_index_fill_synthetic_ragged", "mv_synth_rows",
     "mv_query_topk", "mv_query_topk_device", "mv_query_topk_device_async", "mv_query_stats_finish", "mv_query_topk_batch", "mv_merge_topk", "mv_topk_block_bytes", "mv_merge_topk_blocks", "mv_score_all", "mv_score_candidates", "mv_score_candidates_pads", "mv_index_page_rows",
@@ -164,6 +165,7 @@ def lib() -> C.CDLL:
         L.mv_index_exact_tier_rebalance.argtypes = [vp, C.c_int64, C.POINTER(C.c_int64)]
         L.mv_index_exact_tier_hits.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mv_index_read_fde_e4m3.argtypes = [vp, C.c_int64, C.c_int64, vp, vp]
+        L.mv_index_read_fde_fp4.argtypes = [vp, C.c_int64, C.c_int64, vp, vp]
         L.mv_index_fde_placement_trial.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
         L.mv_index_create.argtypes = [C.POINTER(ConfigC), C.POINTER(vp)]
         L.mv_index_destroy.argtypes = [vp]

@@ -365,8 +365,14 @@ __global__ void fde8_cfac_kernel(const float* scale, const float* inv_norm, int6
 // MV_WITH_FDE_E4M3: the e4m3 copy of FDE rows [first, first + n), derived from the bf16 rows just written (every writer of ix->fde calls it).
 // A row is quantised like a page of the e4m3 slab: out_dim / 128 "rows" of 128 under ONE power-of-two scale (orc_quantize_page_fp8).
 static int fde8_requantize(mv_index* ix, int64_t first, int64_t n, hipStream_t st) {
-  if (!ix->fde8 || n <= 0) return MV_OK;
+  if (n <= 0) return MV_OK;
   const int64_t od = ix->fde_t.out_dim;
+  if (ix->fde4) {  // MV_WITH_FDE_FP4: the e2m1 copy (mv_fde4.hip; oracle orc_quantize_fde_fp4), one workgroup per row
+    int rc4 = launch_fde_quantize_fp4(ix->fde + (size_t)first * od, od, n, ix->fde4 + (size_t)first * (od / 2), ix->fde4_scale + first, ix->fde_inv_norm + first,
+                                      ix->fde4_cfac + first, st);
+    if (rc4) return rc4;
+  }
+  if (!ix->fde8) return MV_OK;
   int rc = launch_quantize_pages_fp8(ix->fde + (size_t)first * od, nullptr, (int32_t)(od / kDim), n, ix->fde8 + (size_t)first * od, ix->fde8_scale + first, st);
   if (rc) return rc;
   hipLaunchKernelGGL(fde8_cfac_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)(ix->fde8_scale + first), (const float*)(ix->fde_inv_norm + first), n,
@@ -394,7 +400,18 @@ int fde_coarse_scan(mv_index* ix, int n_q, const uint32_t* d_allow, int64_t n_wo
   s.fde = ix->fde; s.inv_norm = ix->fde_cosine ? ix->fde_inv_norm : nullptr; s.doc_ord = need_meta ? ix->d_doc_ord : nullptr;
   s.allow = d_allow; s.n_allow_bits = n_words * 32; s.q = ix->d_qfde; s.scores = ix->d_scores; s.n = n;
   s.out_dim = ix->fde_t.out_dim;
-  if (ix->fde8 && ix->fde_coarse_e4m3) {  // MV_WITH_FDE_E4M3: the same stage over half the bytes (the selection bins the scores itself)
+  if (ix->fde4 && ix->fde_coarse_e4m3 == 2) {  // MV_WITH_FDE_FP4: the same stage over a quarter of the bytes (the selection bins the scores itself)
+    FdeScan8Args s4{};
+    s4.fde8 = ix->fde4; s4.scale = ix->fde_cosine ? ix->fde4_cfac : ix->fde4_scale; s4.inv_norm = nullptr; s4.doc_ord = s.doc_ord; s4.allow = s.allow;
+    s4.n_allow_bits = s.n_allow_bits; s4.q = s.q; s4.scores = s.scores; s4.n = n; s4.out_dim = s.out_dim;
+    if (hist0_done) *hist0_done = false;
+    rc = launch_fde_scan4(s4, ix->stream);
+    if (rc) return rc;
+    if (stage_events) MV_HIP(hipEventRecord(ix->ev_st[1], ix->stream));
+    *launches += 2;
+    return MV_OK;
+  }
+  if (ix->fde8 && ix->fde_coarse_e4m3 == 1) {  // MV_WITH_FDE_E4M3: the same stage over half the bytes (the selection bins the scores itself)
     FdeScan8Args s8{};
     s8.fde8 = ix->fde8; s8.scale = ix->fde8_scale; s8.inv_norm = s.inv_norm; s8.doc_ord = s.doc_ord; s8.allow = s.allow; s8.n_allow_bits = s.n_allow_bits;
     s8.q = s.q; s8.scores = s.scores; s8.n = n; s8.out_dim = s.out_dim;
@@ -1189,7 +1206,7 @@ void mv_index_destroy(mv_index* ix) {
   DeviceGuard g(ix->cfg.device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
   if (ix->w_stream) (void)hipStreamSynchronize(ix->w_stream);
-  void* ptrs[] = {ix->d_xloc, ix->d_xoff, ix->d_xhits, ix->d_row_off, ix->slab_lo, ix->d_qlo, ix->d_bqlo, ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->fde8, ix->fde8_scale, ix->fde8_cfac, ix->d_bqfac, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
+  void* ptrs[] = {ix->d_xloc, ix->d_xoff, ix->d_xhits, ix->d_row_off, ix->slab_lo, ix->d_qlo, ix->d_bqlo, ix->slab_x, ix->d_xcand, ix->d_xscores, ix->w_stage, ix->w_aux, ix->w_tmp, ix->d_w_flag, ix->d_cand_pads, ix->d_recs, ix->d_sel_pos, ix->d_gscores, ix->slab, ix->bits, ix->fde, ix->fde_inv_norm, ix->fde8, ix->fde8_scale, ix->fde8_cfac, ix->fde4, ix->fde4_scale, ix->fde4_cfac, ix->d_bqfac, ix->slab8, ix->inv_scale8, ix->d_q8hi, ix->d_q8lo, ix->d_q8fac, ix->d_bq, ix->d_bscores, ix->d_fcand, ix->d_fcounts, ix->d_n_rows, ix->d_doc_ord, ix->d_scores, ix->d_scores2,
                   ix->d_topk_ws, ix->d_q, ix->d_qf32, ix->d_qbits, ix->d_qpop, ix->d_qfde, ix->d_qoff, ix->d_allow, ix->d_out_s,
                   ix->d_out_id, ix->d_cand, ix->d_cand_scores, ix->d_bqf32, ix->d_bqfde, ix->d_bqimage, ix->d_btopk_ws, ix->d_bsel_s,
                   ix->d_bsel_id, ix->d_bcand, ix->d_bcand_pads, ix->d_bcand_scores, ix->d_bout_s, ix->d_bout_id, ix->d_bq8hi, ix->d_bq8lo, ix->d_bq8fac};
@@ -1224,6 +1241,11 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   if (cfg->flags & MV_WITH_FDE_E4M3) {
     if (!(cfg->flags & MV_WITH_FDE)) { set_error("MV_WITH_FDE_E4M3 needs MV_WITH_FDE (it is a copy of that slab)"); return MV_ERR_INVALID; }
     if (!fde_scan8_supported(mv_fde_output_dim(&cfg->fde))) { set_error("MV_WITH_FDE_E4M3 needs an FDE width of 10240, 4096 or 2048 (got %lld)", (long long)mv_fde_output_dim(&cfg->fde)); return MV_ERR_INVALID; }
+  }
+  if (cfg->flags & MV_WITH_FDE_FP4) {
+    if (!(cfg->flags & MV_WITH_FDE)) { set_error("MV_WITH_FDE_FP4 needs MV_WITH_FDE (it is a copy of that slab)"); return MV_ERR_INVALID; }
+    if (cfg->flags & MV_WITH_FDE_E4M3) { set_error("MV_WITH_FDE_FP4 and MV_WITH_FDE_E4M3 are two forms of the same copy: choose one"); return MV_ERR_INVALID; }
+    if (!fde_scan4_supported(mv_fde_output_dim(&cfg->fde))) { set_error("MV_WITH_FDE_FP4 needs an FDE width of 10240, 4096 or 2048 (got %lld)", (long long)mv_fde_output_dim(&cfg->fde)); return MV_ERR_INVALID; }
   }
   if (cfg->flags & MV_LAYOUT_PACKED) {
     if (cfg->flags & MV_WITH_HOST_EXACT) { set_error("MV_LAYOUT_PACKED cannot be combined with MV_WITH_HOST_EXACT (the host exact tier keeps fixed-stride pages)"); return MV_ERR_INVALID; }
@@ -1296,6 +1318,12 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
       alloc((void**)&ix->fde8, (size_t)cap * ix->fde_t.out_dim, "e4m3 copy of the FDE slab");
       alloc((void**)&ix->fde8_scale, (size_t)cap * 4, "e4m3 FDE scales");
       alloc((void**)&ix->fde8_cfac, (size_t)cap * 4, "e4m3 FDE cosine factors");
+    }
+    if (cfg->flags & MV_WITH_FDE_FP4) {
+      alloc((void**)&ix->fde4, (size_t)cap * (ix->fde_t.out_dim / 2), "fp4 copy of the FDE slab");
+      alloc((void**)&ix->fde4_scale, (size_t)cap * 4, "fp4 FDE scales");
+      alloc((void**)&ix->fde4_cfac, (size_t)cap * 4, "fp4 FDE cosine factors");
+      ix->fde_coarse_e4m3 = 2;  // MV_OPT_FDE_COARSE_SLAB: the copy the index was built with is the one the coarse stage reads
     }
     alloc((void**)&ix->d_qfde, (size_t)std::max<int64_t>(ix->fde_t.out_dim, 1) * 4, "query FDE");
   }
@@ -1435,7 +1463,7 @@ int mv_index_exact_tier_rebalance(mv_index* ix, int64_t max_moves, int64_t* out_
 // MV_WITH_FDE_E4M3 + MV_OPT_FDE_COARSE_SLAB 1: the batched pass reads the slab's e4m3 copy (the launcher falls back to the bf16 slab for the
 // cross-check forms and widths the e4m3 kernel is not built for).  q_mu held.
 void mv_internal_fde_batch_e4m3_args(mv_index* ix, mv::FdeScanBatchArgs* sa) {
-  if (!ix->fde8 || !ix->fde_coarse_e4m3 || !ix->d_bqfac) return;
+  if (!ix->fde8 || ix->fde_coarse_e4m3 != 1 || !ix->d_bqfac) return;
   sa->fde8 = ix->fde8; sa->fde8_fac = ix->fde_cosine ? ix->fde8_cfac : ix->fde8_scale; sa->qfac = ix->d_bqfac;
 }
 
@@ -1477,7 +1505,7 @@ int mv_index_fde_placement_trial(mv_index* ix, int32_t trials, double* out_befor
   const int64_t cap = ix->cfg.capacity_pages, out_dim = ix->fde_t.out_dim;
   const int64_t n = ix->size.load() > 0 ? ix->size.load() : cap;  // an empty index is timed over its whole slab (the pass's time does not depend on what it reads)
   // the slab the batched pass reads: the e4m3 copy of an index that has one (MV_OPT_FDE_COARSE_SLAB 1), else the bf16 slab
-  const bool e4 = ix->fde8 && ix->fde_coarse_e4m3 && ix->d_bqfac && fde_scan_batch8_supported(out_dim);
+  const bool e4 = ix->fde8 && ix->fde_coarse_e4m3 == 1 && ix->d_bqfac && fde_scan_batch8_supported(out_dim);
   void** slab_pp = e4 ? (void**)&ix->fde8 : (void**)&ix->fde;
   const size_t bytes = (size_t)cap * out_dim * (e4 ? 1 : 2);
   {  // the requests of the timing passes: fixed pseudo-random encodings (the next real batch overwrites them)
@@ -1572,8 +1600,9 @@ int mv_index_set_option(mv_index* ix, int option, int64_t value) {
       return MV_OK;
     }
     case MV_OPT_FDE_COARSE_SLAB:
-      if (value != 0 && value != 1) { set_error("FDE_COARSE_SLAB must be 0 (bf16 slab) or 1 (e4m3 copy)"); return MV_ERR_INVALID; }
+      if (value != 0 && value != 1 && value != 2) { set_error("FDE_COARSE_SLAB must be 0 (bf16 slab), 1 (e4m3 copy) or 2 (fp4 copy)"); return MV_ERR_INVALID; }
       if (value == 1 && !ix->fde8) { set_error("FDE_COARSE_SLAB 1 needs an index with MV_WITH_FDE_E4M3"); return MV_ERR_STATE; }
+      if (value == 2 && !ix->fde4) { set_error("FDE_COARSE_SLAB 2 needs an index with MV_WITH_FDE_FP4"); return MV_ERR_STATE; }
       ix->fde_coarse_e4m3 = (int)value; return MV_OK;
     case MV_OPT_FLOAT_LO_SCAN:
       if (value < 0 || value > 2) { set_error("FLOAT_LO_SCAN must be 0 (hi slab only), 1 (hi + lo) or 2 (hi-only scan, split-bf16 re-score of the best)"); return MV_ERR_INVALID; }
@@ -1992,6 +2021,7 @@ int mv_index_compact(mv_index* ix, int64_t* out_old_to_new, int64_t* out_new_siz
   if (ix->cfg.flags & MV_WITH_FP8) { slabs.push_back({(char*)ix->slab8, stride * kDim, (size_t)kDim}); slabs.push_back({(char*)ix->inv_scale8, 16, 0}); }
   if (ix->cfg.flags & MV_WITH_BINARY) slabs.push_back({(char*)ix->bits, stride * kSignBytes, (size_t)kSignBytes});
   if (ix->cfg.flags & MV_WITH_FDE) { slabs.push_back({(char*)ix->fde, (size_t)ix->fde_t.out_dim * 2, 0}); slabs.push_back({(char*)ix->fde_inv_norm, 16, 0}); }
+  if (ix->fde4) { slabs.push_back({(char*)ix->fde4, (size_t)ix->fde_t.out_dim / 2, 0}); slabs.push_back({(char*)ix->fde4_scale, 16, 0}); slabs.push_back({(char*)ix->fde4_cfac, 16, 0}); }
   if (ix->fde8) { slabs.push_back({(char*)ix->fde8, (size_t)ix->fde_t.out_dim, 0}); slabs.push_back({(char*)ix->fde8_scale, 16, 0}); slabs.push_back({(char*)ix->fde8_cfac, 16, 0}); }
   int rc = MV_OK;
   // packed layout: the new row offsets (live pages keep their slots, back to back) and, per moved page, (old first row, new first row, rows)
@@ -2323,6 +2353,17 @@ int mv_index_read_fde(mv_index* ix, int64_t page0, int64_t n_pages, float* out) 
     const uint32_t u = (uint32_t)h[i] << 16;
     memcpy(&out[i], &u, 4);
   }
+  return MV_OK;
+}
+
+int mv_index_read_fde_fp4(mv_index* ix, int64_t page0, int64_t n_pages, void* out_codes, float* out_scale) {
+  if (!ix || !out_codes || !out_scale || page0 < 0 || n_pages < 0 || page0 + n_pages > ix->size.load()) { set_error("read_fde_fp4: range"); return MV_ERR_INVALID; }
+  if (!ix->fde4) { set_error("index has no fp4 copy of the FDE slab (MV_WITH_FDE_FP4)"); return MV_ERR_STATE; }
+  std::lock_guard<std::mutex> lk(ix->q_mu);
+  DeviceGuard g(ix->cfg.device);
+  const size_t rb = (size_t)ix->fde_t.out_dim / 2;
+  MV_HIP(hipMemcpy(out_codes, ix->fde4 + (size_t)page0 * rb, (size_t)n_pages * rb, hipMemcpyDeviceToHost));
+  MV_HIP(hipMemcpy(out_scale, ix->fde4_scale + page0, (size_t)n_pages * 4, hipMemcpyDeviceToHost));
   return MV_OK;
 }
 
@@ -3496,7 +3537,7 @@ int mv_index_load(const char* path, int32_t device, mv_index** out) {
   if (h.cfg.flags & MV_WITH_FDE) {
     fill(ix->fde, (size_t)h.size * ix->fde_t.out_dim * 2);
     fill(ix->fde_inv_norm, (size_t)h.size * 4);
-    if (!rc && ix->fde8) {  // the e4m3 copy is not in the file: derived again (the quantiser is deterministic)
+    if (!rc && (ix->fde8 || ix->fde4)) {  // the e4m3 / fp4 copy is not in the file: derived again (the quantisers are deterministic)
       rc = fde8_requantize(ix, 0, h.size, nullptr);
       if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) { set_error("%s: quantising the FDE slab failed", path); rc = MV_ERR_HIP; }
     }

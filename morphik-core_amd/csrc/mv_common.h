@@ -223,6 +223,11 @@ struct FdeScan8Args {
 };
 bool fde_scan8_supported(int64_t out_dim);
 int launch_fde_scan8(const FdeScan8Args& a, hipStream_t s);
+// ... and on the FP4 (e2m1) copy (mv_fde4.hip): a.fde8 = the codes [pages][out_dim / 2], a.scale = the per-page factor (scale, or scale / |d|)
+bool fde_scan4_supported(int64_t out_dim);
+int launch_fde_scan4(const FdeScan8Args& a, hipStream_t s);
+int launch_fde_quantize_fp4(const uint16_t* d_fde_rows, int64_t out_dim, int64_t n, uint8_t* d_codes, float* d_scale, const float* d_inv_norm, float* d_cfac,
+                            hipStream_t s);
 bool fde_scan_prebins(int variant, int64_t out_dim);  // the form launch_fde_scan would run fills FdeScanArgs::hist0
 constexpr int kFdeBatchMaxQueries = 32;
 // Up to 32 queries per pass over the FDE slab (bf16 MFMA, fp32 queries as bf16 hi + lo): scores[q][page] at

@@ -168,6 +168,9 @@ struct mv_index {
   uint8_t* fde8 = nullptr;         // MV_WITH_FDE_E4M3: [capacity][out_dim] e4m3 copy of the FDE slab (derived after every write of `fde`)
   float* fde8_scale = nullptr;     // [capacity] value = decode(code) * scale (a power of two)
   float* fde8_cfac = nullptr;      // [capacity] scale / |d|: the page factor of the batched pass under the cosine rule (one load per page)
+  uint8_t* fde4 = nullptr;         // MV_WITH_FDE_FP4: [capacity][out_dim / 2] e2m1 copy of the FDE slab (derived after every write of `fde`; mv_fde4.hip)
+  float* fde4_scale = nullptr;     // [capacity] value = decode(code) * scale (a power of two)
+  float* fde4_cfac = nullptr;      // [capacity] scale / |d|
   float* d_bqfac = nullptr;        // [32] the batched pass's per-query scales (lazily, with the batch workspace)
   int fde_coarse_e4m3 = 1;         // MV_OPT_FDE_COARSE_SLAB
   int pad_semantics = -1;  // -1: mode default (reference batch rule for FDE_THEN_FLOAT / candidates, none for full scan)

@@ -30,6 +30,7 @@ from ._lib import (
     MV_WITH_FLOAT_LO,
     MV_LAYOUT_PACKED,
     MV_WITH_FDE_E4M3,
+    MV_WITH_FDE_FP4,
     ConfigC,
     FdeConfigC,
     QueryStatsC,
@@ -182,6 +183,7 @@ class MvIndex:
         packed: bool = False,
         capacity_rows: int = 0,
         with_fde_e4m3: bool = False,
+        with_fde_fp4: bool = False,
     ):
         """with_host_exact: keep the exact bf16 rows in PINNED HOST memory (no HBM) as the exact tier of mode
         "fp8_then_float" -- for shards whose bf16 slab does not fit beside the fp8 slab.
@@ -195,11 +197,13 @@ class MvIndex:
         its longest page; capacity_rows = rows the row-indexed slabs hold in all (0 = capacity_pages * stride_rows); stride_rows stays
         the longest page accepted.  Same scores as the fixed layout, bit for bit.
         with_fde_e4m3 (with with_fde): an e4m3 copy of the FDE slab (out_dim bytes per page) that the COARSE stage of the FDE modes reads
-        instead of the bf16 slab -- half the bytes of the pass that dominates every request; set_option(MV_OPT_FDE_COARSE_SLAB, 0) goes back."""
+        instead of the bf16 slab -- half the bytes of the pass that dominates every request; set_option(MV_OPT_FDE_COARSE_SLAB, 0) goes back.
+        with_fde_fp4 (with with_fde, instead of with_fde_e4m3): the copy is FP4 (e2m1, one power-of-two scale per row): out_dim / 2 bytes per
+        page, read by the coarse stage of SINGLE requests (batches read the bf16 slab); MV_OPT_FDE_COARSE_SLAB 2 / 0."""
         self.fde_config = fde or FdeConfig()
         flags = ((MV_WITH_FLOAT if with_float else 0) | (MV_WITH_BINARY if with_binary else 0) | (MV_WITH_FDE if with_fde else 0)
                  | (MV_WITH_FP8 if with_fp8 else 0) | (MV_WITH_HOST_EXACT if with_host_exact else 0) | (MV_WITH_EXACT_SPLIT if with_exact_split else 0)
-                 | (MV_WITH_FLOAT_LO if with_float_lo else 0) | (MV_LAYOUT_PACKED if packed else 0) | (MV_WITH_FDE_E4M3 if with_fde_e4m3 else 0))
+                 | (MV_WITH_FLOAT_LO if with_float_lo else 0) | (MV_LAYOUT_PACKED if packed else 0) | (MV_WITH_FDE_E4M3 if with_fde_e4m3 else 0) | (MV_WITH_FDE_FP4 if with_fde_fp4 else 0))
         cfg = ConfigC(128, int(stride_rows), int(capacity_pages), int(device), flags, int(id_base), self.fde_config.to_c(), int(capacity_rows) if packed else 0)
         h = C.c_void_p()
         check(lib().mv_index_create(C.byref(cfg), C.byref(h)))
@@ -352,6 +356,13 @@ class MvIndex:
         codes = np.empty((int(n_pages), self.fde_config.output_dim), np.uint8)
         sc = np.empty(int(n_pages), np.float32)
         check(lib().mv_index_read_fde_e4m3(self._h, int(page0), int(n_pages), codes.ctypes.data, sc.ctypes.data))
+        return codes, sc
+
+    def read_fde_fp4(self, page0: int, n_pages: int) -> Tuple[np.ndarray, np.ndarray]:
+        """-> (e2m1 code bytes [n_pages][output_dim / 2] uint8 -- element 2i in the low nibble --, scales [n_pages] float32) of the FDE slab's fp4 copy."""
+        codes = np.empty((int(n_pages), self.fde_config.output_dim // 2), np.uint8)
+        sc = np.empty(int(n_pages), np.float32)
+        check(lib().mv_index_read_fde_fp4(self._h, int(page0), int(n_pages), codes.ctypes.data, sc.ctypes.data))
         return codes, sc
 
     def read_fp8(self, page0: int, n_pages: int) -> Tuple[np.ndarray, np.ndarray]:

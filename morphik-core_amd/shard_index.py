@@ -31,7 +31,7 @@ def _checkpoint_has_exact_split(shard_path: str) -> bool:
 class ShardedIndex:
     def __init__(self, capacity_pages: int, stride_rows: int, devices: Sequence[int], with_float: bool = True, with_binary: bool = False,
                  with_fde: bool = False, with_fp8: bool = False, fde=None, transport: str = "auto", id_base: int = 0,
-                 index_cls=None, comm_cls=None, with_host_exact: bool = False, with_exact_split: bool = False, with_float_lo: bool = False, packed: bool = False, capacity_rows: int = 0, with_fde_e4m3: bool = False):
+                 index_cls=None, comm_cls=None, with_host_exact: bool = False, with_exact_split: bool = False, with_float_lo: bool = False, packed: bool = False, capacity_rows: int = 0, with_fde_e4m3: bool = False, with_fde_fp4: bool = False):
         from .index import MvIndex, ShardComm
 
         index_cls = index_cls or MvIndex
@@ -50,6 +50,8 @@ class ShardedIndex:
             extra["capacity_rows"] = (-(-int(capacity_rows) // self.n_shards) + 15) // 16 * 16 if capacity_rows else 0
         if with_fde_e4m3:
             extra["with_fde_e4m3"] = True  # every shard's coarse stage reads the e4m3 copy of ITS FDE slab
+        if with_fde_fp4:
+            extra["with_fde_fp4"] = True  # ... or the fp4 copy (single requests)
         if with_float_lo:
             extra["with_float_lo"] = True  # every shard keeps the lo half of its bf16 slab (fp32-faithful rerank / scan)
         if with_exact_split:

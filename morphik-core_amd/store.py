@@ -124,6 +124,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
         fp32_pages: bool = False,
         fp32_scan: str = "both_halves",
         fde_e4m3: bool = False,
+        fde_fp4: bool = False,
         packed_layout: bool = False,
         capacity_rows: int = 0,
         **_ignored: Any,
@@ -164,6 +165,11 @@ class MI355XMultiVectorStore(BaseVectorStore):
         # half the bytes of the pass that is nine tenths of a request.  The reference's coarse stage is an ANN index (approximate by contract);
         # the rerank and its scores are untouched (MV_WITH_FDE_E4M3)
         self.fde_e4m3 = bool(fde_e4m3)
+        # ... or an FP4 (e2m1) copy: out_dim / 2 bytes per page, a quarter of the bf16 slab's, read by the coarse stage of SINGLE requests (coalesced
+        # batches keep reading the bf16 slab, one pass per 32 requests).  MV_WITH_FDE_FP4; not together with fde_e4m3
+        self.fde_fp4 = bool(fde_fp4)
+        if self.fde_fp4 and self.fde_e4m3:
+            raise ValueError("fde_e4m3 and fde_fp4 are two forms of the same copy of the FDE slab: choose one")
         # MV_LAYOUT_PACKED: pages of different lengths (ColQwen2.5's dynamic token counts, colpali_embedding_model.py:47-52) lie back to back
         # in whole 16-row tiles instead of one stride_rows slot each; capacity_rows sizes the row-indexed slabs (0 = capacity_pages *
         # stride_rows: no saving, only the layout).  Not with the host / split exact tiers.
@@ -249,7 +255,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
             raise ValueError("packed_layout cannot be combined with a host / split exact tier")
         return dict(with_float=with_float, with_binary=self.mode == "binary", **({"with_float_lo": True} if with_float and self.fp32_pages else {}),
                     **({"packed": True, "capacity_rows": self.capacity_rows} if self.packed_layout else {}),
-                    with_fde=self.mode == "fde_then_float", **({"with_fde_e4m3": True} if self.mode == "fde_then_float" and self.fde_e4m3 else {}), with_fp8=self.mode in ("float_fp8", "fp8_then_float") or (self.mode == "fde_then_float" and host and self.prune_slab),
+                    with_fde=self.mode == "fde_then_float", **({"with_fde_e4m3": True} if self.mode == "fde_then_float" and self.fde_e4m3 else {}), **({"with_fde_fp4": True} if self.mode == "fde_then_float" and self.fde_fp4 else {}), with_fp8=self.mode in ("float_fp8", "fp8_then_float") or (self.mode == "fde_then_float" and host and self.prune_slab),
                     **({"with_host_exact": True} if host else {}), **({"with_exact_split": True} if host and self.exact_tier == "split" else {}))
 
     def _make_index(self):
@@ -857,7 +863,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
     def _book(self) -> Dict[str, Any]:
         return {
             "version": 3, "mode": self.mode, "capacity_pages": self.capacity_pages, "stride_rows": self.stride_rows,
-            "id_base": self.id_base, "fde_coarse_n": self.fde_coarse_n, "exact_tier": self.exact_tier, "rerank_n": self.rerank_n, "prune_slab": self.prune_slab, "fp32_pages": self.fp32_pages, "fp32_scan": self.fp32_scan, "fde_e4m3": self.fde_e4m3, "packed_layout": self.packed_layout, "capacity_rows": self.capacity_rows, "fde_external": self.fde_module is not None, "next_ord": self._next_ord,
+            "id_base": self.id_base, "fde_coarse_n": self.fde_coarse_n, "exact_tier": self.exact_tier, "rerank_n": self.rerank_n, "prune_slab": self.prune_slab, "fp32_pages": self.fp32_pages, "fp32_scan": self.fp32_scan, "fde_e4m3": self.fde_e4m3, "fde_fp4": self.fde_fp4, "packed_layout": self.packed_layout, "capacity_rows": self.capacity_rows, "fde_external": self.fde_module is not None, "next_ord": self._next_ord,
             "rows": [[p, r[0], r[1], r[2], r[3], r[4], row_origin(r)] for p, r in self._rows.items()],
             "doc_ord": self._doc_ord, "doc_app": {str(k): v for k, v in self._doc_app.items()},
         }
@@ -958,7 +964,7 @@ class MI355XMultiVectorStore(BaseVectorStore):
             raise RuntimeError(f"{directory}: this checkpoint " + ("holds document FDE vectors of an external encoder: pass fde_module= to load()"
                                                                      if book.get("fde_external") else "was encoded by the library itself: load it without fde_module"))
         self = cls(capacity_pages=book["capacity_pages"], stride_rows=book["stride_rows"], device=device, mode=book["mode"], storage=storage,
-                   id_base=book["id_base"], fde_coarse_n=book.get("fde_coarse_n", 0), exact_tier=book.get("exact_tier", "hbm"), rerank_n=book.get("rerank_n", 0), prune_slab=book.get("prune_slab", True), **{"fp32_pages": book.get("fp32_pages", False), "fp32_scan": book.get("fp32_scan", "both_halves"), "fde_e4m3": book.get("fde_e4m3", False), "packed_layout": book.get("packed_layout", False), "capacity_rows": book.get("capacity_rows", 0), **kw})
+                   id_base=book["id_base"], fde_coarse_n=book.get("fde_coarse_n", 0), exact_tier=book.get("exact_tier", "hbm"), rerank_n=book.get("rerank_n", 0), prune_slab=book.get("prune_slab", True), **{"fp32_pages": book.get("fp32_pages", False), "fp32_scan": book.get("fp32_scan", "both_halves"), "fde_e4m3": book.get("fde_e4m3", False), "fde_fp4": book.get("fde_fp4", False), "packed_layout": book.get("packed_layout", False), "capacity_rows": book.get("capacity_rows", 0), **kw})
         self._index = cls._load_index(self, directory, book, device)
         self._apply_options(self._index)
         for p, doc, chunk_no, content, meta_json, app, *rest in book["rows"]:

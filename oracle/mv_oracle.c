@@ -451,6 +451,53 @@ ORC_API void orc_quantize_page_fp8(const uint16_t* rows, int32_t n_rows, int32_t
   for (int64_t i = 0; i < (int64_t)n_rows * 128; ++i) codes[i] = orc_e4m3_encode(orc_bf16_to_f32(rows[i]) * sc);
 }
 
+/* ---- FP4 (e2m1) copy of an FDE row (MV_WITH_FDE_FP4; not a reference function: the coarse stage of
+ * fast_multivector_store.py:526-532 is an ANN index, approximate by contract -- this is the library's own compressed copy of the
+ * document FDE vectors, restated so the tests can check the device quantiser bit for bit).
+ * value = decode(code) * scale, scale = 2^e the smallest power of two with 6 * 2^e >= max|x| over the row;
+ * codes: bit 3 = sign, bits 2..0 index the magnitudes {0, 0.5, 1, 1.5, 2, 3, 4, 6}, round to nearest, ties to the even index;
+ * two codes per byte, element 2i in the LOW nibble. */
+static const float orc_fp4_mag[8] = {0.0f, 0.5f, 1.0f, 1.5f, 2.0f, 3.0f, 4.0f, 6.0f};
+
+ORC_API float orc_fp4_decode(uint32_t code) { return (code & 8u) ? -orc_fp4_mag[code & 7u] : orc_fp4_mag[code & 7u]; }
+
+ORC_API uint32_t orc_fp4_encode(float y /* already divided by the scale */) {
+  const float a = y < 0.0f ? -y : y;
+  uint32_t c;
+  if (a <= 0.25f) c = 0;        /* tie 0.25 -> 0 (even) */
+  else if (a < 0.75f) c = 1;    /* tie 0.75 -> 2 */
+  else if (a <= 1.25f) c = 2;   /* tie 1.25 -> 2 */
+  else if (a < 1.75f) c = 3;    /* tie 1.75 -> 4 */
+  else if (a <= 2.5f) c = 4;    /* tie 2.5 -> 4 */
+  else if (a < 3.5f) c = 5;     /* tie 3.5 -> 6 */
+  else if (a <= 5.0f) c = 6;    /* tie 5.0 -> 6 */
+  else c = 7;
+  return c | ((orc_f32_bits(y) >> 31) << 3);
+}
+
+/* row: bf16 values [n] (n even) -> n / 2 bytes of codes + the scale */
+ORC_API void orc_quantize_fde_fp4(const uint16_t* row, int32_t n, uint8_t* codes, float* scale) {
+  uint32_t amax = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    const uint32_t m = row[i] & 0x7fffu;
+    if (m > amax) amax = m;
+  }
+  int e = 0;
+  if (amax >= 0x0080u && amax < 0x7f80u) {  /* a normal bf16 value: e0 = floor(log2 amax); 6 * 2^(e0-2) = 1.5 * 2^e0 */
+    const int e0 = (int)(amax >> 7) - 127;
+    e = ((amax & 0x7fu) <= 0x40u) ? e0 - 2 : e0 - 1;
+    if (e < -120) e = -120;
+    if (e > 120) e = 120;
+  }
+  *scale = orc_pow2f(e);
+  const float inv = orc_pow2f(-e);
+  for (int32_t i = 0; i < n; i += 2) {
+    const uint32_t lo = orc_fp4_encode(orc_bf16_to_f32(row[i]) * inv);
+    const uint32_t hi = orc_fp4_encode(orc_bf16_to_f32(row[i + 1]) * inv);
+    codes[i >> 1] = (uint8_t)(lo | (hi << 4));
+  }
+}
+
 /* query: fp32 rows [n_q][128] -> hi, lo codes and 2^-s per row */
 ORC_API void orc_fp8_query_prep(const float* q, int32_t n_q, uint8_t* hi, uint8_t* lo, float* fac) {
   for (int32_t r = 0; r < n_q; ++r) {

@@ -85,6 +85,11 @@ def lib() -> C.CDLL:
         L.orc_e4m3_decode.restype = f32
         L.orc_quantize_page_fp8.argtypes = [vp, i32, i32, vp, vp]
         L.orc_fp8_query_prep.argtypes = [vp, i32, vp, vp, vp]
+        L.orc_quantize_fde_fp4.argtypes = [vp, i32, vp, vp]
+        L.orc_fp4_decode.argtypes = [C.c_uint32]
+        L.orc_fp4_decode.restype = f32
+        L.orc_fp4_encode.argtypes = [f32]
+        L.orc_fp4_encode.restype = C.c_uint32
         L.orc_maxsim_fp8.argtypes = [vp, vp, vp, i32, vp, i32, f32, i32]
         L.orc_maxsim_fp8.restype = f32
         _lib = L
@@ -332,6 +337,32 @@ def quantize_page_fp8(rows_bf16, stride: int) -> Tuple[np.ndarray, float]:
     inv = C.c_float()
     lib().orc_quantize_page_fp8(_p(r), r.shape[0], stride, _p(codes), C.byref(inv))
     return codes, float(inv.value)
+
+
+def quantize_fde_fp4(rows_bf16) -> Tuple[np.ndarray, np.ndarray]:
+    """bf16 FDE rows [n, od] (uint16) -> (e2m1 codes [n, od / 2] uint8: element 2i in the low nibble, scales [n] float32)."""
+    r = _c(rows_bf16, np.uint16)
+    r = r.reshape(-1, r.shape[-1])
+    codes = np.empty((r.shape[0], r.shape[1] // 2), np.uint8)
+    sc = np.empty(r.shape[0], np.float32)
+    one = C.c_float()
+    for i in range(r.shape[0]):
+        row = np.ascontiguousarray(r[i])
+        out = np.empty(r.shape[1] // 2, np.uint8)
+        lib().orc_quantize_fde_fp4(_p(row), r.shape[1], _p(out), C.byref(one))
+        codes[i] = out
+        sc[i] = one.value
+    return codes, sc
+
+
+def fp4_decode(codes) -> np.ndarray:
+    """e2m1 code bytes [..., m] -> float32 [..., 2 m] (low nibble first)."""
+    c = _c(codes, np.uint8)
+    lut = np.array([lib().orc_fp4_decode(i) for i in range(16)], np.float32)
+    out = np.empty(c.shape[:-1] + (c.shape[-1] * 2,), np.float32)
+    out[..., 0::2] = lut[c & 15]
+    out[..., 1::2] = lut[c >> 4]
+    return out
 
 
 def fp8_query_prep(q_f32):

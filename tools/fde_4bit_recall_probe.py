@@ -69,6 +69,9 @@ FORMATS = [
     ("int4_per_block_of_128", lambda x: q_int(x, 4, 128), 5120 + 80),
     ("fp4_e2m1_per_block_of_32_mxfp4", lambda x: q_fp4(x, 32), 5120 + 320),
     ("int3_per_block_of_128", lambda x: q_int(x, 3, 128), 3840 + 80),
+    ("fp4_e2m1_per_row", lambda x: q_fp4(x, x.shape[1]), 5120 + 4),
+    ("fp4_e2m1_per_block_of_512", lambda x: q_fp4(x, 512), 5120 + 20),
+    ("fp4_e2m1_per_block_of_128", lambda x: q_fp4(x, 128), 5120 + 80),
 ]
 
 
