@@ -394,7 +394,7 @@ def exact_shard_pages(args, stride, device):
         return max(min(args.exact_shard_pages, fit), 0), budget, False
     _free, total_b = torch.cuda.mem_get_info(device)
     hbm = total_b - (3 << 30)  # what is free once the headline's bf16 slab is gone (context, torch's own blocks)
-    slab_b = stride * 128 + stride * 16 + 20480 + 10240 + 72 + 33 * 4  # e4m3 + sign bits + FDE (+ its e4m3 copy) + metadata + the batched score vectors
+    slab_b = stride * 128 + stride * 16 + 20480 + 10240 + 5120 + 80 + 33 * 4  # e4m3 + sign bits + FDE (+ its e4m3 and fp4 copies) + metadata + the batched score vectors
     n = int(min(args.exact_shard_pages, (hbm - (14 << 30)) // slab_b))
     while n > 0:
         in_hbm = max(0, (hbm - n * slab_b - (13 << 30)) // page_b)  # the library keeps 12 GiB back (MV_EXACT_HBM_RESERVE_BYTES)
@@ -425,7 +425,7 @@ def full_shard(args, device, qs):
            "note": "kernel-only HIP-event times (median of 9 after 0.25 s of warm-up queries); unstructured corpus (timing only: recall and the exact "
                    "pipelines are on aux_paths.exact_shard)"}
     t0 = time.time()
-    ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=False, with_binary=True, with_fde=True, with_fp8=True, with_fde_e4m3=True)
+    ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=False, with_binary=True, with_fde=True, with_fp8=True, with_fde_e4m3=True, with_fde_fp4=True)
     ix.set_option(L.MV_OPT_FDE_COARSE_SLAB, 0)  # the bf16 FDE slab first (the figures of rounds 2-5); its e4m3 copy below
     res["create_s"] = round(time.time() - t0, 1)
     t0 = time.time()
@@ -475,6 +475,10 @@ def full_shard(args, device, qs):
     res["fde_coarse_scan_e4m3"] = dict(scan_entry(n, 10240, t["coarse_ms"]), query_encode_ms=round(t["encode_ms"], 4))
     e8 = fde_pipeline_timings(ix, qs, n, (75, 1000), bytes_per_page=10240)
     res["fde_e4m3_then_fp8_rerank"] = e8
+    # ---- closing session of round 6: the coarse stage of a SINGLE request on the FP4 copy (MV_WITH_FDE_FP4: 5 120 B per page)
+    ix.set_option(L.MV_OPT_FDE_COARSE_SLAB, 2)
+    t = timed_mode(ix, qs, "fde")
+    res["fde_coarse_scan_fp4"] = dict(scan_entry(n, 5120, t["coarse_ms"]), query_encode_ms=round(t["encode_ms"], 4), request_device_ms=round(t["total_device_ms"], 4))
     ix.close()
     return res
 
@@ -539,7 +543,7 @@ def exact_shard(args, device, n, n_truth, budget, split, sets, truths, gaps):
                    "float scan (doc filter over the first n pages) before the bf16 slab was freed"}
     t0 = time.time()
     ix = MvIndex(capacity_pages=n, stride_rows=stride, device=device, with_float=False, with_binary=True, with_fde=True, with_fp8=True, with_host_exact=True,
-                 with_exact_split=split, with_fde_e4m3=True)
+                 with_exact_split=split, with_fde_e4m3=True, with_fde_fp4=True)
     ix.set_option(L.MV_OPT_FDE_COARSE_SLAB, 0)  # every figure below reads the bf16 FDE slab unless its name says e4m3
     res["create_and_pin_s"] = round(time.time() - t0, 1)
     in_hbm = ix.exact_hbm_pages
@@ -578,6 +582,11 @@ def exact_shard(args, device, n, n_truth, budget, split, sets, truths, gaps):
     # ---- the same pipeline with the coarse stage on the e4m3 copy of the FDE slab (round 6)
     ix.set_option(L.MV_OPT_FDE_COARSE_SLAB, 1)
     res["fde_e4m3_coarse_then_exact_rerank"] = fde_pipeline_timings(ix, qs, n, (75,), bytes_per_page=10240)
+    # ---- ... and on the fp4 copy (single requests; a batch reads the bf16 slab whatever the option says)
+    ix.set_option(L.MV_OPT_FDE_COARSE_SLAB, 2)
+    ix.set_option(L.MV_OPT_FDE_COARSE_N, 75)
+    t4 = timed_mode(ix, qs, "fde_then_float", n_timed=12)
+    res["fde_fp4_coarse_then_exact_rerank"] = {"coarse75": {"one_request": {"device_ms": round(t4["total_device_ms"], 4), "stage_ms": {k_: round(t4[k_], 4) for k_ in ("encode_ms", "coarse_ms", "select_ms", "rerank_ms", "topk_ms")}}}}
     ix.set_option(L.MV_OPT_FDE_COARSE_SLAB, 0)
     # ---- configs[4]: e4m3 scan of every page -> top-128 -> exact re-score out of the pinned-host tier
     base = timed_mode(ix, qs, "float_fp8")
@@ -615,9 +624,9 @@ def exact_shard(args, device, n, n_truth, budget, split, sets, truths, gaps):
             return ix.query(q, k, mode=mode, allow=al)[1].tolist()
         return f
 
-    def on_e4m3(f):  # the same path with the coarse stage on the e4m3 copy of the FDE slab
+    def on_e4m3(f, slab=1):  # the same path with the coarse stage on the e4m3 (1) / fp4 (2) copy of the FDE slab
         def g(q, al):
-            ix.set_option(L.MV_OPT_FDE_COARSE_SLAB, 1)
+            ix.set_option(L.MV_OPT_FDE_COARSE_SLAB, slab)
             try:
                 return f(q, al)
             finally:
@@ -627,7 +636,8 @@ def exact_shard(args, device, n, n_truth, budget, split, sets, truths, gaps):
     modes = [("fp8_scan", ids_of("float_fp8")), ("fp8_then_float_n128", ids_of("fp8_then_float")), ("sign_bit_scan", ids_of("binary")),
              ("fde_top75_then_exact", ids_of("fde_then_float", cn=75)), ("fde_top1000_then_exact", ids_of("fde_then_float", cn=1000)),
              ("fde_coarse_recall_at_75", ids_of("fde", k=75)), ("fde_coarse_recall_at_1000", ids_of("fde", k=1000)),
-             ("fde_e4m3_top75_then_exact", on_e4m3(ids_of("fde_then_float", cn=75))), ("fde_e4m3_coarse_recall_at_75", on_e4m3(ids_of("fde", k=75)))]
+             ("fde_e4m3_top75_then_exact", on_e4m3(ids_of("fde_then_float", cn=75))), ("fde_e4m3_coarse_recall_at_75", on_e4m3(ids_of("fde", k=75))),
+             ("fde_fp4_top75_then_exact", on_e4m3(ids_of("fde_then_float", cn=75), 2)), ("fde_fp4_top1000_then_exact", on_e4m3(ids_of("fde_then_float", cn=1000), 2))]
     t0 = time.time()
     res["recall_at_10_vs_exact_bf16"] = recall_of(ix, rsets, truths, gaps, modes, allow_truth)
     # the e4m3 rerank an index WITHOUT an exact tier falls back to (MV_OPT_EXACT_TIER 2), on the same candidates: what the exact tier buys
@@ -952,6 +962,9 @@ def aux_summary(out, aux):
         "fde8_request_ms": g("exact_shard", "fde_e4m3_coarse_then_exact_rerank", "coarse75", "one_request", "device_ms"),
         "fde8_batch32_ms": g("full_shard", "fde_e4m3_then_fp8_rerank", "coarse75", "batch_of_32", "device_ms_per_batch"),
         "fde8_75_recall_hard": g("exact_shard", "recall_at_10_vs_exact_bf16", "hard_negatives", "fde_e4m3_top75_then_exact"),
+        "fde4_scan_frac": g("full_shard", "fde_coarse_scan_fp4", "frac_hbm_8TBps"),
+        "fde4_request_ms": g("exact_shard", "fde_fp4_coarse_then_exact_rerank", "coarse75", "one_request", "device_ms"),
+        "fde4_75_recall_hard": g("exact_shard", "recall_at_10_vs_exact_bf16", "hard_negatives", "fde_fp4_top75_then_exact"),
         "fde_batch32_exact_ms": g("exact_shard", "fde_then_exact_rerank", "coarse1000", "batch_of_32", "device_ms_per_batch"),
         "hot_pages_batch32_ms": [g("exact_shard", "hot_pages_in_hbm", "batch_of_32_device_ms", "train_before"), g("exact_shard", "hot_pages_in_hbm", "batch_of_32_device_ms", "train_after"),
                                  g("exact_shard", "hot_pages_in_hbm", "batch_of_32_device_ms", "unseen_after")] if g("exact_shard", "hot_pages_in_hbm", "batch_of_32_device_ms") else None,

@@ -1244,7 +1244,6 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
   }
   if (cfg->flags & MV_WITH_FDE_FP4) {
     if (!(cfg->flags & MV_WITH_FDE)) { set_error("MV_WITH_FDE_FP4 needs MV_WITH_FDE (it is a copy of that slab)"); return MV_ERR_INVALID; }
-    if (cfg->flags & MV_WITH_FDE_E4M3) { set_error("MV_WITH_FDE_FP4 and MV_WITH_FDE_E4M3 are two forms of the same copy: choose one"); return MV_ERR_INVALID; }
     if (!fde_scan4_supported(mv_fde_output_dim(&cfg->fde))) { set_error("MV_WITH_FDE_FP4 needs an FDE width of 10240, 4096 or 2048 (got %lld)", (long long)mv_fde_output_dim(&cfg->fde)); return MV_ERR_INVALID; }
   }
   if (cfg->flags & MV_LAYOUT_PACKED) {

@@ -109,6 +109,11 @@ __device__ __forceinline__ void f4_wait_left(int left) {  // all rows issued; `l
   else f4_wait_vmcnt<0>();
 }
 
+template <int CTRL>
+__device__ __forceinline__ float f4_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
 template <int CPW, int D>  // a row is CPW KiB of codes (out_dim = 2048 CPW); ring of D row slots per wave
 __global__ __launch_bounds__(256) void fde_scan_row4_kernel(Scan4K a, int ru) {
   static_assert(CPW >= 1 && CPW <= 5 && D >= 2 && D <= 4 && CPW * (D - 1) <= 63, "row shape");
@@ -232,10 +237,16 @@ __global__ __launch_bounds__(256) void fde_scan_row4_kernel(Scan4K a, int ru) {
         acc2 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_scalef32_pk_f32_fp4(v[k], 1.0f, 3), q[c][4 * k + 3], acc2);
       }
     }
+    // wave sum without LDS traffic: four DPP rotations inside every 16-lane row, then the four row sums through v_readlane
     float acc = acc2[0] + acc2[1];
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) acc += __shfl_xor(acc, s);
-    if (lane == i) my_score = acc;
+    acc += f4_dpp<0x128>(acc);  // row_ror:8
+    acc += f4_dpp<0x124>(acc);  // row_ror:4
+    acc += f4_dpp<0x122>(acc);  // row_ror:2
+    acc += f4_dpp<0x121>(acc);  // row_ror:1
+    const int ab = __float_as_int(acc);
+    const float tot = (__int_as_float(__builtin_amdgcn_readlane(ab, 0)) + __int_as_float(__builtin_amdgcn_readlane(ab, 16))) +
+                      (__int_as_float(__builtin_amdgcn_readlane(ab, 32)) + __int_as_float(__builtin_amdgcn_readlane(ab, 48)));
+    if (lane == i) my_score = tot;
   }
   if (valid) a.scores[myrow] = masked ? -INFINITY : my_score * my_fac;
 }

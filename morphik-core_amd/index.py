@@ -198,7 +198,7 @@ class MvIndex:
         the longest page accepted.  Same scores as the fixed layout, bit for bit.
         with_fde_e4m3 (with with_fde): an e4m3 copy of the FDE slab (out_dim bytes per page) that the COARSE stage of the FDE modes reads
         instead of the bf16 slab -- half the bytes of the pass that dominates every request; set_option(MV_OPT_FDE_COARSE_SLAB, 0) goes back.
-        with_fde_fp4 (with with_fde, instead of with_fde_e4m3): the copy is FP4 (e2m1, one power-of-two scale per row): out_dim / 2 bytes per
+        with_fde_fp4 (with with_fde; beside or instead of with_fde_e4m3): a copy in FP4 (e2m1, one power-of-two scale per row): out_dim / 2 bytes per
         page, read by the coarse stage of SINGLE requests (batches read the bf16 slab); MV_OPT_FDE_COARSE_SLAB 2 / 0."""
         self.fde_config = fde or FdeConfig()
         flags = ((MV_WITH_FLOAT if with_float else 0) | (MV_WITH_BINARY if with_binary else 0) | (MV_WITH_FDE if with_fde else 0)

@@ -189,8 +189,13 @@ def test_flag_and_option_errors():
 
     with pytest.raises(MvError):
         _idx(capacity_pages=4, stride_rows=16, with_float=True, with_fde=False, with_fde_fp4=True)
-    with pytest.raises(MvError):
-        _idx(capacity_pages=4, stride_rows=16, with_float=True, with_fde=True, with_fde_fp4=True, with_fde_e4m3=True)
+    both = _idx(capacity_pages=4, stride_rows=16, with_float=True, with_fde=True, with_fde_fp4=True, with_fde_e4m3=True)  # the index may hold both copies
+    both.add([orc.synth_rows(3, 0, 0, 9)], doc_ordinals=[0])
+    q = orc.synth_rows(4321, 0, 0, 8)
+    for slab in (2, 1, 0):  # default 2; every slab answers
+        both.set_option(_lib.MV_OPT_FDE_COARSE_SLAB, slab)
+        assert both.query(q, 1, mode="fde_then_float")[1].tolist() == [0]
+    both.close()
     ix = _idx(capacity_pages=4, stride_rows=16, with_float=True, with_fde=True)
     with pytest.raises(MvError):
         ix.set_option(_lib.MV_OPT_FDE_COARSE_SLAB, 2)
