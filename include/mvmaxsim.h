@@ -98,11 +98,12 @@ enum {
                              two at the cut (recall unchanged on every corpus of the bench).  MV_OPT_FDE_COARSE_SLAB selects
                              the slab per query.  Needs an FDE width of 10 240 (the reference's), 4 096 or 2 048; out_dim bytes per page more HBM. */
   MV_WITH_FDE_FP4 = 512    /* with MV_WITH_FDE (beside or instead of MV_WITH_FDE_E4M3): a copy in FP4 (e2m1: sign + {0, 0.5, 1, 1.5, 2, 3, 4, 6}) under one
-                             power-of-two scale per row -- out_dim / 2 bytes per page, a QUARTER of the bf16 slab's -- and the coarse stage of a
+                             power-of-two scale per row (half the scale that covers the row's largest element: those saturate, the bulk gets a finer grid)
+                             -- out_dim / 2 bytes per page, a QUARTER of the bf16 slab's -- and the coarse stage of a
                              SINGLE request reads it (mv_fde4.hip; the query FDE stays fp32).  Batches of requests keep reading the bf16 slab
                              (one pass per 32 requests).  Candidate lists differ from the bf16 slab's at the cut; recall@10 behind the exact
-                             rerank, priced before it was built (tools/fde_4bit_recall_probe.py) and measured by the bench: within 0.005 of the
-                             bf16 slab's on hard negatives at 75 candidates, equal at 1000.  Quantiser: oracle
+                             rerank, priced before it was built (tools/fde_4bit_recall_probe.py) and measured by the bench (aux_summary.fde4_75_recall_hard
+                             beside fde75_recall_hard): DESIGN 3.23; equal to the bf16 slab's at 1000 candidates.  Quantiser: oracle
                              orc_quantize_fde_fp4, bit for bit.  Same widths as MV_WITH_FDE_E4M3.  MV_OPT_FDE_COARSE_SLAB 2 / 1 / 0 selects the slab per query
                              (default on an index with this flag: 2). */
 };

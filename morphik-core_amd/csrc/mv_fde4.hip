@@ -4,11 +4,13 @@
 // core/vector_store/fast_multivector_store.py:526-532 -- approximate by contract) is nine tenths of a request and reads
 // out_dim x 2 bytes per page from the bf16 slab, out_dim from its e4m3 copy (mv_fde8.hip).  What the stage owes is a candidate list; priced through
 // mv_index_import_fde before anything was built (tools/fde_4bit_recall_probe.py, profiles/r6/fde_4bit_copy_recall_priced_r6.json), a 4-bit copy
-// under one power-of-two scale per row keeps the recall of the bf16 slab on the bench's hard negatives (0.9875 against 0.9922 at 75
-// candidates, 1.0 at 1000).  So every FDE row is kept a third time as out_dim / 2 bytes:
+// under one power-of-two scale per row keeps the recall of the bf16 slab on the bench's hard negatives (0.9922 = the bf16 slab's at 75
+// candidates with the saturating scale below, 1.0 at 1000).  So every FDE row is kept a third time as out_dim / 2 bytes:
 //
 //     value_i = decode(code_i) * scale[page]      code: bit 3 sign, bits 2..0 -> {0, 0.5, 1, 1.5, 2, 3, 4, 6}; element 2i in the LOW nibble
-//     scale   = 2^e, the smallest power of two with 6 * 2^e >= max|x| over the row       (oracle: orc_quantize_fde_fp4)
+//     scale   = 2^e, the smallest power of two with 12 * 2^e >= max|x| over the row: half the covering scale -- elements beyond 6 * scale
+//               saturate at the top code, the bulk gets a grid twice as fine (priced: no page lost on the hard negatives against 3 of 640
+//               with the covering scale)                                                   (oracle: orc_quantize_fde_fp4)
 //     score[page] = (sum_i q_i * decode(code[page][i])) * scale[page] (* 1 / |d| for the cosine rule)
 //
 // Scan kernel: fde_scan_rowq8_kernel's transport (mv_fde8.hip) on 5 KiB rows -- one fresh workgroup per 64 consecutive rows
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void fde4_quantize_kernel(const uint16_t* src,
   int e = 0;
   if (amax >= 0x0080u && amax < 0x7f80u) {
     const int e0 = (int)(amax >> 7) - 127;
-    e = ((amax & 0x7fu) <= 0x40u) ? e0 - 2 : e0 - 1;
+    e = ((amax & 0x7fu) <= 0x40u) ? e0 - 3 : e0 - 2;  // 12 * 2^e >= amax: half the covering scale (the largest elements saturate)
     e = min(max(e, -120), 120);
   }
   const float sc = __uint_as_float((uint32_t)(127 + e) << 23);

@@ -454,7 +454,9 @@ ORC_API void orc_quantize_page_fp8(const uint16_t* rows, int32_t n_rows, int32_t
 /* ---- FP4 (e2m1) copy of an FDE row (MV_WITH_FDE_FP4; not a reference function: the coarse stage of
  * fast_multivector_store.py:526-532 is an ANN index, approximate by contract -- this is the library's own compressed copy of the
  * document FDE vectors, restated so the tests can check the device quantiser bit for bit).
- * value = decode(code) * scale, scale = 2^e the smallest power of two with 6 * 2^e >= max|x| over the row;
+ * value = decode(code) * scale, scale = 2^e the smallest power of two with 12 * 2^e >= max|x| over the row: HALF the scale that would cover
+ * the row's largest element -- elements beyond 6 * scale saturate at the top code, the bulk of the row gets a grid twice as fine
+ * (tools/fde_4bit_recall_probe.py: the covering scale loses 3 pages of 640 on the bench's hard negatives, this one none; a quarter: 3);
  * codes: bit 3 = sign, bits 2..0 index the magnitudes {0, 0.5, 1, 1.5, 2, 3, 4, 6}, round to nearest, ties to the even index;
  * two codes per byte, element 2i in the LOW nibble. */
 static const float orc_fp4_mag[8] = {0.0f, 0.5f, 1.0f, 1.5f, 2.0f, 3.0f, 4.0f, 6.0f};
@@ -483,9 +485,9 @@ ORC_API void orc_quantize_fde_fp4(const uint16_t* row, int32_t n, uint8_t* codes
     if (m > amax) amax = m;
   }
   int e = 0;
-  if (amax >= 0x0080u && amax < 0x7f80u) {  /* a normal bf16 value: e0 = floor(log2 amax); 6 * 2^(e0-2) = 1.5 * 2^e0 */
+  if (amax >= 0x0080u && amax < 0x7f80u) {  /* a normal bf16 value: e0 = floor(log2 amax) */
     const int e0 = (int)(amax >> 7) - 127;
-    e = ((amax & 0x7fu) <= 0x40u) ? e0 - 2 : e0 - 1;
+    e = ((amax & 0x7fu) <= 0x40u) ? e0 - 3 : e0 - 2;  /* 12 * 2^(e0-3) = 1.5 * 2^e0 */
     if (e < -120) e = -120;
     if (e > 120) e = 120;
   }

@@ -2,7 +2,7 @@
 
 The reference's coarse stage is a TurboPuffer ANN query over the documents' FDE vectors (core/vector_store/fast_multivector_store.py:526-532):
 approximate by contract.  What is held here: the copy is the oracle's quantisation of the bf16 rows bit for bit (orc_quantize_fde_fp4: one
-power-of-two scale per row, round to nearest with ties to the even code, element 2i in the low nibble); the scan's scores are the fp32 dot
+power-of-two scale per row -- half the covering one: the largest elements saturate --, round to nearest with ties to the even code, element 2i in the low nibble); the scan's scores are the fp32 dot
 products of those codes (all 16 of them pass through v_cvt_scalef32_pk_f32_fp4, in both nibbles of all four bytes of a dword); every writer of
 the FDE slab keeps the copy in step; batches of requests read the bf16 slab and answer as on an index without the copy; the pipeline's answers are
 those of the bf16 coarse stage wherever the candidates decide nothing (planted neighbours)."""
@@ -83,8 +83,10 @@ def test_scan_scores_are_the_fp32_dot_products_of_the_codes(n):
     rng = np.random.default_rng(n)
     m = min(n, 40)
     nib = rng.integers(0, 16, size=(m, od)).astype(np.uint8)
-    nib[:, 0] = 7  # 6.0: the row's amax -> scale 1, the imported values ARE the decoded codes
-    rows = lut[nib] * np.float32(0.5) ** rng.integers(0, 3, size=(m, 1)).astype(np.float32)  # other scales too
+    nib[:, 0] = 7
+    vals = lut[nib]
+    vals[:, 0] = 12.0  # the row's amax = 12 -> scale 1 (12 * scale >= amax): element 0 saturates to code 7, every other value IS its decoded code
+    rows = vals * np.float32(0.5) ** rng.integers(0, 3, size=(m, 1)).astype(np.float32)  # other scales too
     ix.import_fde(0, rows)
     got_c, got_s = ix.read_fde_fp4(0, m)
     got_nib = np.empty((m, od), np.uint8)

@@ -348,7 +348,7 @@ def test_fde_pin_recipe_runs_end_to_end_on_a_stand_in_extension(tmp_path, monkey
 def test_fp4_quantiser_of_the_fde_copy_known_answers():
     """orc_quantize_fde_fp4 / orc_fp4_encode (the checker of MV_WITH_FDE_FP4; not a reference function -- the reference's coarse stage is an
     ANN index): the e2m1 grid {0, 0.5, 1, 1.5, 2, 3, 4, 6}, round to nearest with ties to the even code, sign in bit 3, element 2i in the
-    low nibble, and the scale = the smallest power of two with 6 * scale >= max|x|."""
+    low nibble, and the scale = the smallest power of two with 12 * scale >= max|x| (elements beyond 6 * scale saturate)."""
     L = orc.lib()
     for v, c in [(0.0, 0), (0.25, 0), (0.26, 1), (0.5, 1), (0.75, 2), (1.0, 2), (1.25, 2), (1.26, 3), (1.75, 4), (2.5, 4), (2.51, 5), (3.5, 6),
                  (5.0, 6), (5.01, 7), (6.0, 7), (100.0, 7), (-6.0, 15), (-0.5, 9), (-0.0, 8)]:
@@ -356,10 +356,12 @@ def test_fp4_quantiser_of_the_fde_copy_known_answers():
     assert [L.orc_fp4_decode(c) for c in range(16)] == [0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0, -0.0, -0.5, -1.0, -1.5, -2.0, -3.0, -4.0, -6.0]
     row = orc.f32_to_bf16(np.array([[6.0, -3.0, 0.5, 0.2, 1.5, -1.5, 0.0, 4.0]], np.float32))
     codes, sc = orc.quantize_fde_fp4(row)
-    assert sc.tolist() == [1.0] and codes.tolist() == [[0x07 | (0x0D << 4), 0x01 | (0x00 << 4), 0x03 | (0x0B << 4), 0x00 | (0x06 << 4)]]
-    # amax 6.5 needs the next scale: 6 * 1 < 6.5 <= 6 * 2; amax 3.0 = 6 * 0.5 exactly keeps 0.5; an all-zero row: scale 1
-    assert orc.quantize_fde_fp4(orc.f32_to_bf16(np.array([[6.5, 1.0]], np.float32)))[1].tolist() == [2.0]
-    assert orc.quantize_fde_fp4(orc.f32_to_bf16(np.array([[3.0, -0.25]], np.float32)))[1].tolist() == [0.5]
+    # scale = the smallest power of two with 12 * scale >= amax (HALF the covering scale): amax 6 -> 0.5; 6.0 / 0.5 = 12 saturates at code 7,
+    # -3.0 -> -6 (15), 0.5 -> 1.0 (2), 0.2 -> 0.4 (1), 1.5 -> 3 (5), -1.5 -> -3 (13), 0 -> 0, 4.0 -> 8 saturates (7)
+    assert sc.tolist() == [0.5] and codes.tolist() == [[0x07 | (0x0F << 4), 0x02 | (0x01 << 4), 0x05 | (0x0D << 4), 0x00 | (0x07 << 4)]]
+    # amax 6.5: 12 * 0.5 < 6.5 <= 12 * 1; amax 3.0 = 12 * 0.25 exactly keeps 0.25; an all-zero row: scale 1
+    assert orc.quantize_fde_fp4(orc.f32_to_bf16(np.array([[6.5, 1.0]], np.float32)))[1].tolist() == [1.0]
+    assert orc.quantize_fde_fp4(orc.f32_to_bf16(np.array([[3.0, -0.25]], np.float32)))[1].tolist() == [0.25]
     assert orc.quantize_fde_fp4(orc.f32_to_bf16(np.zeros((1, 4), np.float32)))[1].tolist() == [1.0]
     # decode(codes) * scale reproduces a row to the grid's half-step everywhere
     rng = np.random.default_rng(4)
@@ -367,5 +369,7 @@ def test_fp4_quantiser_of_the_fde_copy_known_answers():
     codes, sc = orc.quantize_fde_fp4(x)
     back = orc.fp4_decode(codes) * sc[:, None]
     xf = orc.bf16_to_f32(x)
-    assert np.all(np.abs(back - xf) <= sc[:, None] * 1.0 + 1e-12)  # the widest gap of the grid is 2 (between 4 and 6): half of it
+    inside = np.abs(xf) <= 6.0 * sc[:, None]
+    assert np.all(np.abs(back - xf)[inside] <= sc[:, None].repeat(xf.shape[1], 1)[inside] * 1.0 + 1e-12)  # the widest gap of the grid is 2 (between 4 and 6): half of it
+    assert np.all(np.abs(back)[~inside] == (6.0 * sc[:, None]).repeat(xf.shape[1], 1)[~inside])  # beyond 6 * scale: saturated at the top code
     assert float(np.median(np.linalg.norm(back - xf, axis=1) / np.linalg.norm(xf, axis=1))) < 0.15

@@ -50,13 +50,14 @@ def q_int(x, bits, block):
     return (torch.clamp(torch.round(b / s), -qmax, qmax) * s).reshape(n, d).cpu().numpy()
 
 
-def q_fp4(x, block):
-    """e2m1 (the f8f6f4 MFMA's FP4) with one power-of-two scale per `block` elements (block 32 = MXFP4)"""
+def q_fp4(x, block, shrink=1.0):
+    """e2m1 (the f8f6f4 MFMA's FP4) with one power-of-two scale per `block` elements (block 32 = MXFP4); shrink > 1: a scale that many
+    times smaller than the one that covers the largest element -- the largest elements saturate at 6 * scale, the bulk gets a finer grid"""
     import torch
 
     n, d = x.shape
     b = _t(x).reshape(n, d // block, block)
-    s = pow2_ceil(b.abs().amax(dim=2, keepdim=True) / 6.0)
+    s = pow2_ceil(b.abs().amax(dim=2, keepdim=True) / 6.0) / shrink
     grid = torch.tensor(FP4_GRID, device=b.device)
     idx = torch.bucketize(b.abs() / s, torch.tensor(FP4_MIDS, device=b.device), right=True)
     return (torch.sign(b) * grid[idx] * s).reshape(n, d).cpu().numpy()
@@ -72,6 +73,8 @@ FORMATS = [
     ("fp4_e2m1_per_row", lambda x: q_fp4(x, x.shape[1]), 5120 + 4),
     ("fp4_e2m1_per_block_of_512", lambda x: q_fp4(x, 512), 5120 + 20),
     ("fp4_e2m1_per_block_of_128", lambda x: q_fp4(x, 128), 5120 + 80),
+    ("fp4_e2m1_per_row_scale_halved_saturating", lambda x: q_fp4(x, x.shape[1], 2.0), 5120 + 4),
+    ("fp4_e2m1_per_row_scale_quartered_saturating", lambda x: q_fp4(x, x.shape[1], 4.0), 5120 + 4),
 ]
 
 
