@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
     return 0;
   }
   const int iters = argc > 1 ? atoi(argv[1]) : 200;
-  const int all = MV_WITH_FLOAT | MV_WITH_BINARY | MV_WITH_FDE | MV_WITH_FP8 | MV_WITH_HOST_EXACT | MV_WITH_FDE_E4M3;  // (round 6: + the e4m3 copy of the FDE slab)
+  const int all = MV_WITH_FLOAT | MV_WITH_BINARY | MV_WITH_FDE | MV_WITH_FP8 | MV_WITH_HOST_EXACT | MV_WITH_FDE_E4M3 | MV_WITH_FDE_FP4;  // (round 6: + the e4m3 and fp4 copies of the FDE slab)
   mv_index* ix = make_index(0, 4096, 0, all);
   CHECK(mv_index_fill_synthetic(ix, 1, 0, 512, 32, 4));
   std::atomic<bool> stop{false};
