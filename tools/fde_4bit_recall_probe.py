@@ -127,6 +127,47 @@ def main():
                "recall_at_10_vs_exact_bf16": {s: {m: r[s][m] for m, _f in modes} for s in sets}, "seconds": round(time.time() - t0, 1)}
         res["formats"][name] = ent
         print(name, json.dumps(ent["recall_at_10_vs_exact_bf16"]), file=sys.stderr, flush=True)
+    # ---- the QUERY side of a batched pass on the fp4 codes (both MFMA operands FP4): the query FDE as two e2m1 terms under one power-of-two
+    # scale per query -- hi = fp4(x / s), lo = fp4(4 (x / s - hi)) / 4 -- against the fp32 query, documents in the form that was built
+    import torch
+
+    from morphik_core_amd.index import fde_encode
+
+    def orc_bf16_to_f32(a):
+        return (a.astype(np.uint32) << 16).view(np.float32)
+
+    def two_term_fp4(qf):
+        t = torch.from_numpy(qf).cuda()
+        s = pow2_ceil(t.abs().amax() / 6.0)
+        grid = torch.tensor(FP4_GRID, device=t.device)
+        mids = torch.tensor(FP4_MIDS, device=t.device)
+        def enc(v):
+            return torch.sign(v) * grid[torch.bucketize(v.abs(), mids, right=True)]
+        hi = enc(t / s)
+        lo = enc((t / s - hi) * 4.0) / 4.0
+        return ((hi + lo) * s).cpu().numpy()
+
+    built = dict((n_, q_) for n_, q_, _b in FORMATS)["fp4_e2m1_per_row_scale_halved_saturating"]
+    for j, blk in enumerate(original):
+        ix.import_fde(j * CH, built(blk))
+    qerr = []
+
+    def ids_q4(mode, k=bench.K, cn=None):
+        def f(q, al):
+            if cn is not None:
+                ix.set_option(L.MV_OPT_FDE_COARSE_N, cn)
+            qa = np.asarray(q)
+            qf = fde_encode(orc_bf16_to_f32(qa) if qa.dtype == np.uint16 else qa, ix.fde_config, is_query=True)  # synth rows are bf16 bit patterns
+            q4 = two_term_fp4(qf)
+            qerr.append(float(np.linalg.norm(q4 - qf) / max(np.linalg.norm(qf), 1e-30)))
+            return ix.query(q, k, mode=mode, allow=al, q_fde=q4)[1].tolist()
+        return f
+
+    modes4 = [("fde_top75_then_exact", ids_q4("fde_then_float", cn=75)), ("fde_top1000_then_exact", ids_q4("fde_then_float", cn=1000))]
+    r = bench.recall_of(ix, sets, truths, gaps, modes4)
+    res["fp4_documents_and_two_term_fp4_query"] = {"recall_at_10_vs_exact_bf16": {s_: {m: r[s_][m] for m, _f in modes4} for s_ in sets},
+                                                   "median_relative_l2_error_of_a_query_vector": float(np.median(qerr))}
+    print("fp4 docs + two-term fp4 query", json.dumps(res["fp4_documents_and_two_term_fp4_query"]), file=sys.stderr, flush=True)
     ix.close()
     print(json.dumps(res, indent=1))
 
