@@ -1319,7 +1319,7 @@ int mv_index_create(const mv_config* cfg, mv_index** out) {
       alloc((void**)&ix->fde8_cfac, (size_t)cap * 4, "e4m3 FDE cosine factors");
     }
     if (cfg->flags & MV_WITH_FDE_FP4) {
-      alloc((void**)&ix->fde4, (size_t)cap * (ix->fde_t.out_dim / 2), "fp4 copy of the FDE slab");
+      alloc((void**)&ix->fde4, (size_t)cap * (ix->fde_t.out_dim / 2) + 4096, "fp4 copy of the FDE slab");  // +4 KiB: the batched pass pads the chunk count to a multiple of four (reads <= 1 KiB past a row)
       alloc((void**)&ix->fde4_scale, (size_t)cap * 4, "fp4 FDE scales");
       alloc((void**)&ix->fde4_cfac, (size_t)cap * 4, "fp4 FDE cosine factors");
       ix->fde_coarse_e4m3 = 2;  // MV_OPT_FDE_COARSE_SLAB: the copy the index was built with is the one the coarse stage reads
@@ -1462,6 +1462,10 @@ int mv_index_exact_tier_rebalance(mv_index* ix, int64_t max_moves, int64_t* out_
 // MV_WITH_FDE_E4M3 + MV_OPT_FDE_COARSE_SLAB 1: the batched pass reads the slab's e4m3 copy (the launcher falls back to the bf16 slab for the
 // cross-check forms and widths the e4m3 kernel is not built for).  q_mu held.
 void mv_internal_fde_batch_e4m3_args(mv_index* ix, mv::FdeScanBatchArgs* sa) {
+  if (ix->fde4 && ix->fde_coarse_e4m3 == 2 && ix->d_bqfac) {  // MV_WITH_FDE_FP4 + MV_OPT_FDE_COARSE_SLAB 2: the FP4 form of the pass (both MFMA operands FP4)
+    sa->fde8 = ix->fde4; sa->fde8_fac = ix->fde_cosine ? ix->fde4_cfac : ix->fde4_scale; sa->qfac = ix->d_bqfac; sa->copy_fp4 = 1;
+    return;
+  }
   if (!ix->fde8 || ix->fde_coarse_e4m3 != 1 || !ix->d_bqfac) return;
   sa->fde8 = ix->fde8; sa->fde8_fac = ix->fde_cosine ? ix->fde8_cfac : ix->fde8_scale; sa->qfac = ix->d_bqfac;
 }
@@ -1504,9 +1508,10 @@ int mv_index_fde_placement_trial(mv_index* ix, int32_t trials, double* out_befor
   const int64_t cap = ix->cfg.capacity_pages, out_dim = ix->fde_t.out_dim;
   const int64_t n = ix->size.load() > 0 ? ix->size.load() : cap;  // an empty index is timed over its whole slab (the pass's time does not depend on what it reads)
   // the slab the batched pass reads: the e4m3 copy of an index that has one (MV_OPT_FDE_COARSE_SLAB 1), else the bf16 slab
-  const bool e4 = ix->fde8 && ix->fde_coarse_e4m3 == 1 && ix->d_bqfac && fde_scan_batch8_supported(out_dim);
-  void** slab_pp = e4 ? (void**)&ix->fde8 : (void**)&ix->fde;
-  const size_t bytes = (size_t)cap * out_dim * (e4 ? 1 : 2);
+  const bool f4 = ix->fde4 && ix->fde_coarse_e4m3 == 2 && ix->d_bqfac && fde_scan_batch4_supported(out_dim);
+  const bool e4 = f4 || (ix->fde8 && ix->fde_coarse_e4m3 == 1 && ix->d_bqfac && fde_scan_batch8_supported(out_dim));
+  void** slab_pp = f4 ? (void**)&ix->fde4 : (e4 ? (void**)&ix->fde8 : (void**)&ix->fde);
+  const size_t bytes = f4 ? (size_t)cap * (out_dim / 2) + 4096 : (size_t)cap * out_dim * (e4 ? 1 : 2);
   {  // the requests of the timing passes: fixed pseudo-random encodings (the next real batch overwrites them)
     std::vector<float> q((size_t)kFdeBatchMaxQueries * out_dim);
     uint64_t z = 0x9E3779B97F4A7C15ull;
@@ -2407,7 +2412,7 @@ int mv_internal_ensure_fde_batch_ws(mv_index* ix) {
   if (!ix->d_bqf32) MV_HIP(hipMalloc(&ix->d_bqf32, (size_t)kBatchQRows * kDim * 4));
   if (!ix->d_bqfde) MV_HIP(hipMalloc(&ix->d_bqfde, (size_t)kFdeBatchMaxQueries * out_dim * 4));
   if (!ix->d_bqimage) MV_HIP(hipMalloc(&ix->d_bqimage, mv::fde_scan_batch_image_bytes(out_dim)));
-  if (ix->fde8 && !ix->d_bqfac) MV_HIP(hipMalloc(&ix->d_bqfac, kFdeBatchMaxQueries * 4));
+  if ((ix->fde8 || ix->fde4) && !ix->d_bqfac) MV_HIP(hipMalloc(&ix->d_bqfac, kFdeBatchMaxQueries * 4));
   if (ix->cfg.flags & MV_WITH_FP8) {
     if (!ix->d_bq8hi) MV_HIP(hipMalloc(&ix->d_bq8hi, (size_t)kBatchQRows * kDim));
     if (!ix->d_bq8lo) MV_HIP(hipMalloc(&ix->d_bq8lo, (size_t)kBatchQRows * kDim));

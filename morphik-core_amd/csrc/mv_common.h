@@ -259,15 +259,17 @@ struct FdeScanBatchArgs {
   const uint8_t* fde8;
   const float* fde8_fac;
   float* qfac;
+  int32_t copy_fp4;           // 1: fde8 / fde8_fac are the FP4 copy (MV_WITH_FDE_FP4: [n][out_dim / 2] e2m1 codes) -- both MFMA operands FP4, the queries as two e2m1 terms
 };
 bool fde_scan_batch8_supported(int64_t out_dim);
+bool fde_scan_batch4_supported(int64_t out_dim);
 // the default (paired-tile) kernel applies the cosine rule and the tombstones where it writes a tile's scores: no finish pass
 inline bool fde_scan_batch_fuses_finish(const FdeScanBatchArgs& a) {
   return a.inv_norm != nullptr && !a.single_tile && !a.separate_finish;
 }
 // the pass reads the slab's e4m3 copy (its kernel always writes finished scores: nothing is binned on the way)
 inline bool fde_scan_batch_uses_e4m3(const FdeScanBatchArgs& a) {
-  return a.fde8 != nullptr && !a.single_tile && !a.separate_finish && fde_scan_batch8_supported(a.out_dim);
+  return a.fde8 != nullptr && !a.single_tile && !a.separate_finish && (a.copy_fp4 ? fde_scan_batch4_supported(a.out_dim) : fde_scan_batch8_supported(a.out_dim));
 }
 inline bool fde_scan_batch_prebins(const FdeScanBatchArgs& a) {
   return a.hist0 != nullptr && (a.inv_norm != nullptr || a.doc_ord != nullptr) && !fde_scan_batch_fuses_finish(a) && !fde_scan_batch_uses_e4m3(a);

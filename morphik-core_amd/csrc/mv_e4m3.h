@@ -41,5 +41,26 @@ __device__ __forceinline__ int pow2_scale_exp(uint32_t amax_bits) {
 }
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((uint32_t)(127 + e) << 23); }
 
+// ---- FP4 (e2m1) codec of the FDE slab's 4-bit copy (mv_fde4.hip, the F4 form of mv_fde_batch.hip; oracle: orc_fp4_encode / _decode):
+// bit 3 sign, bits 2..0 -> {0, 0.5, 1, 1.5, 2, 3, 4, 6}; round to nearest, ties to the even code, saturating at 6.
+__device__ __forceinline__ uint32_t fp4_encode(float y) {
+  const float a = fabsf(y);
+  uint32_t c;
+  if (a <= 0.25f) c = 0;
+  else if (a < 0.75f) c = 1;
+  else if (a <= 1.25f) c = 2;
+  else if (a < 1.75f) c = 3;
+  else if (a <= 2.5f) c = 4;
+  else if (a < 3.5f) c = 5;
+  else if (a <= 5.0f) c = 6;
+  else c = 7;
+  return c | ((__float_as_uint(y) >> 31) << 3);
+}
+__device__ __forceinline__ float fp4_decode(uint32_t c) {
+  const uint32_t m = c & 7u;
+  const float mag = m < 4u ? 0.5f * (float)m : (m == 4u ? 2.0f : (m == 5u ? 3.0f : (m == 6u ? 4.0f : 6.0f)));
+  return (c & 8u) ? -mag : mag;
+}
+
 }  // namespace
 }  // namespace mv

@@ -22,6 +22,7 @@
 #include <algorithm>
 
 #include "mv_common.h"
+#include "mv_e4m3.h"
 
 namespace mv {
 namespace {
@@ -30,20 +31,6 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
 // ------------------------------------------------------------------------------------------------ quantiser
-__device__ __forceinline__ uint32_t fp4_encode(float y) {  // y = x / scale; oracle: orc_fp4_encode
-  const float a = fabsf(y);
-  uint32_t c;
-  if (a <= 0.25f) c = 0;
-  else if (a < 0.75f) c = 1;
-  else if (a <= 1.25f) c = 2;
-  else if (a < 1.75f) c = 3;
-  else if (a <= 2.5f) c = 4;
-  else if (a < 3.5f) c = 5;
-  else if (a <= 5.0f) c = 6;
-  else c = 7;
-  return c | ((__float_as_uint(y) >> 31) << 3);
-}
-
 // one workgroup per row: bf16 values [od] -> od / 2 code bytes + scale (+ scale / |d|)
 __global__ __launch_bounds__(256) void fde4_quantize_kernel(const uint16_t* src, int64_t od, uint8_t* codes, float* scale, const float* inv_norm, float* cfac) {
   __shared__ uint32_t wmax[4];

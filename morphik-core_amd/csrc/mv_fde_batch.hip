@@ -128,6 +128,64 @@ __global__ __launch_bounds__(256) void fde_batch_qprep8_kernel(const float* q, c
   for (int i = 0; i < 4; ++i) { dst[i] = hi[i]; dst[256 + i] = lo[i]; dst[512 + i] = hi[4 + i]; dst[768 + i] = lo[4 + i]; }
 }
 
+// ---- the FP4 form of the pass (MV_WITH_FDE_FP4: the slab's e2m1 copy, 1024 codes per page and ring slot).  BOTH MFMA operands
+// are FP4 (v_mfma_scale_f32_16x16x128_f8f6f4, cbsz = blgp = 4: a lane's 16-byte ring register IS one A operand, a 16-byte fragment one B
+// operand).  Queries enter as TWO e2m1 terms under one power-of-two scale per query (the smallest s with 6 s >= max|x|): hi = fp4(x / s),
+// lo = fp4(4 (x / s - hi)) -- the second MFMA takes the factor 1/4 as its block scale (E8M0 125).  Priced before it was built
+// (tools/fde_4bit_recall_probe.py: recall with two-term fp4 queries = recall with fp32 queries on the fp4 documents).  qfac[b] = s.
+__global__ __launch_bounds__(256) void fde_batch_qscale4_kernel(const float* q, int nb, int out_dim, float* qfac) {
+  __shared__ uint32_t red[4];
+  const int b = blockIdx.x;
+  if (b >= nb) { if (threadIdx.x == 0) qfac[b] = 0.0f; return; }
+  uint32_t amax = 0;
+  for (int i = threadIdx.x; i < out_dim; i += 256) amax = max(amax, __float_as_uint(q[(size_t)b * out_dim + i]) & 0x7fffffffu);
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, sft));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    amax = max(max(red[0], red[1]), max(red[2], red[3]));
+    int e = 0;
+    if (amax >= 0x00800000u && amax < 0x7f800000u) {  // a normal fp32 value: 6 * 2^(e0-2) = 1.5 * 2^e0
+      const int e0 = (int)(amax >> 23) - 127;
+      e = ((amax & 0x7fffffu) <= 0x400000u) ? e0 - 2 : e0 - 1;
+      e = min(max(e, -100), 100);
+    }
+    qfac[b] = pow2f(e);
+  }
+}
+// image4[kc][wave][query tile][hi.0 | lo.0 | hi.1 | lo.1][lane] of 16-byte pieces: lane (query qt*16 + (l&15), group g = l>>4) holds, in piece e,
+// the 32 codes of dims kc*1024 + 32 (wave*8 + 2 g + e) .. + 32 of its query, two per byte, the lower dim in the LOW nibble -- the order of the
+// slab's bytes, so K slot j of the page operand meets K slot j of the query operand.  Dims >= out_dim (the chunks that pad KC to a multiple of
+// four) are zero: whatever the ring reads there is multiplied by 0 (every FP4 code is finite).
+__global__ __launch_bounds__(256) void fde_batch_qprep4_kernel(const float* q, const float* qfac, int nb, int out_dim, int kc_padded, int nqt, uint8_t* image) {
+  const int t = blockIdx.x * 256 + threadIdx.x;  // (kc, wave, qt, lane)
+  const int lane = t & 63;
+  int r = t >> 6;
+  const int qt = r % nqt; r /= nqt;
+  const int w = r & 3, kc = r >> 2;
+  if (kc >= kc_padded) return;
+  const int ql = qt * 16 + (lane & 15), g = lane >> 4;
+  const float fac = ql < nb ? qfac[ql] : 0.0f;
+  const float sc = fac > 0.0f ? 1.0f / fac : 0.0f;  // a power of two: exact
+  uint32_t* dst = reinterpret_cast<uint32_t*>(image + ((size_t)((kc * 4 + w) * nqt + qt) * 4) * 1024 + lane * 16);
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int d0 = kc * 1024 + 32 * (w * 8 + 2 * g + e);
+    uint32_t hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const float x = (ql < nb && d0 + i < out_dim) ? q[(size_t)ql * out_dim + d0 + i] * sc : 0.0f;
+      const uint32_t ch = fp4_encode(x);
+      const uint32_t cl = fp4_encode((x - fp4_decode(ch)) * 4.0f);
+      hi[i >> 3] |= ch << (4 * (i & 7));
+      lo[i >> 3] |= cl << (4 * (i & 7));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dst[(2 * e) * 256 + i] = hi[i]; dst[(2 * e + 1) * 256 + i] = lo[i]; }
+  }
+}
+
 // NQT query tiles of 16 (16 or 32 queries per pass).
 template <int NQT, bool LO = true>
 __global__ __launch_bounds__(256) void fde_scan_batch_kernel(ScanBatchArgs a) {
@@ -355,12 +413,13 @@ __device__ __forceinline__ void fb_static_for(F&& f) {
 // slot's own wait returns, read with ds_read at the tile's end.  Every wave issues them (same data, same place: the per-wave
 // counts stay uniform).  Records are double-buffered by group parity: the next group's first slots are issued before this group's
 // epilogue runs.  The arithmetic is the finish kernel's (one fp32 multiply of the same sum): identical scores.
-template <int NQT, bool LO, int T, bool FIN = false, bool E4 = false>
+template <int NQT, bool LO, int T, bool FIN = false, bool E4 = false, bool F4 = false>
 __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, float* red, const int lane, const int wave, const int i0,
                                          const int n_groups, const uint32_t (&src_off)[8], const uint32_t (&rd_off)[2]) {
   using bf16x8 = __attribute__((ext_vector_type(8))) short;
   using f32x4 = __attribute__((ext_vector_type(4))) float;
   static_assert(!E4 || FIN, "the e4m3 form applies the page factor itself");
+  static_assert(!F4 || E4, "the fp4 form is the e4m3 form with other codes: page factor, query factor and tombstones as there");
   constexpr int NF = 4 * NQT;              // query fragments per K chunk and wave: (e, qt, hi|lo); E4: (qt, half, hi|lo)
   constexpr int QOPS = LO ? NF : NF / 2;   // fragment loads per K chunk and wave
   constexpr int MOPS = FIN ? 2 : 0;        // metadata loads per slot of a K chunk with kc & 3 == 0
@@ -368,10 +427,11 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
   if constexpr (FIN) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the previous phase's last epilogue has read its records
   const int p = lane & 15, g = lane >> 4;
   const int G = gridDim.x, b = blockIdx.x;
-  const int KC = E4 ? a.out_dim >> 9 : a.out_dim >> 8;  // E4: a slot holds 512 codes per page
+  // E4: a slot holds 512 codes per page; F4: 1024, and the chunk count is padded to a multiple of four (the padding chunks meet zero query fragments)
+  const int KC = F4 ? (((a.out_dim >> 10) + 3) & ~3) : (E4 ? a.out_dim >> 9 : a.out_dim >> 8);
   const int total = n_groups * KC * T;     // ring slots of this phase; a multiple of 4 * T
   if (total == 0) return;
-  const uint32_t row_bytes = E4 ? (uint32_t)a.out_dim : (uint32_t)a.out_dim * 2u;
+  const uint32_t row_bytes = F4 ? (uint32_t)a.out_dim >> 1 : (E4 ? (uint32_t)a.out_dim : (uint32_t)a.out_dim * 2u);
   // E4: this thread's per-query factors for the tile ends (queries qt*16 + wave + 4x), loaded before the ring starts
   float qfac[E4 ? NQT * 4 : 1];
   if constexpr (E4) {
@@ -381,6 +441,8 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
     for (int x = 0; x < NQT * 4; ++x) asm volatile("" : "+v"(qfac[x]));
   }
   const uint32_t q_off = (uint32_t)lane * 16u;
+  uint32_t f4_one = 0x7f7f7f7fu, f4_quarter = 0x7d7d7d7du;  // E8M0 block scales of the F4 MFMAs: 2^0, 2^-2
+  asm volatile("" : "+v"(f4_one), "+v"(f4_quarter));
 
   bf16x8 qf[4][NF];  // [K chunk & 3][(e*NQT + qt)*2 + (0 = hi, 1 = lo)]
 #pragma unroll
@@ -543,7 +605,24 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
         issue_dma(u & 3);
         if constexpr (FIN && ((((u + 4) % (4 * T)) / T) & 3) == 0) issue_meta();
       }
-      if constexpr (E4) {
+      if constexpr (F4) {
+        // ONE K = 128 FP4 x FP4 MFMA per (piece, page tile, query tile) and term, written as inline assembly: operands pinned to the VGPRs the ring
+        // and the fragment loads wrote (the compiler's own allocation of the builtin's operands moved the fragment sets through AGPRs, and an
+        // asynchronous fragment load that lands in a register the allocator has reused corrupts an address); the lo term carries its 1/4 as the B
+        // block scale (E8M0 125 = 2^-2).  Accumulators in VGPRs; consecutive MFMAs on one accumulator forward srcC in hardware.
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt) {
+              asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4"
+                           : "+v"(acc[j][t][qt]) : "v"(af[e][t]), "v"(qf[kcs][qt * 4 + 2 * e]), "v"(f4_one));
+              if (LO)
+                asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:4"
+                             : "+v"(acc[j][t][qt]) : "v"(af[e][t]), "v"(qf[kcs][qt * 4 + 2 * e + 1]), "v"(f4_one), "v"(f4_quarter));
+            }
+      } else if constexpr (E4) {
         // four K = 32 fp8 MFMAs per (page tile, query tile) and term: every 16-byte piece a lane read / loaded is two 8-byte operands, used
         // in place (the K = 128 block-scaled form wants 32 consecutive bytes per lane: building them from the ring's 16-byte registers cost
         // copies and 200 spilled registers).  Any K-slot order is valid as long as A and B agree: operand jj of piece e = codes
@@ -587,7 +666,8 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
       // time keeps the finish out of the other 3 T slots -- round 6: the body was 38 / 55 KB of code (16 / 32 requests) in front of a
       // 64 KB instruction cache shared by two CUs, and the pass ran in a fast or a slow mode depending on the process.
       if constexpr (kcs == 3)
-      if (c_kc == KC - 1) {  // tile j of the group is done: acc[j][t][qt][i] = partial dot of page t*16 + 4g + i with query qt*16 + p
+      if (c_kc == KC - 1) {
+        if constexpr (F4) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the inline-assembly MFMAs above: their results are read below (the compiler does not see the latency)  // tile j of the group is done: acc[j][t][qt][i] = partial dot of page t*16 + 4g + i with query qt*16 + p
         const int pg = threadIdx.x & 63;
         const int64_t tile = (int64_t)b + (int64_t)(i0 + c_grp * T + j) * G;
         const int64_t page = tile * kFbPages + pg;
@@ -630,7 +710,7 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
   }
 }
 
-template <int NQT, bool LO, bool FIN = false, bool E4 = false>
+template <int NQT, bool LO, bool FIN = false, bool E4 = false, bool F4 = false>
 __global__ __launch_bounds__(256) void fde_scan_batch2_kernel(ScanBatchArgs a) {
   // one __shared__ object only (a second one makes hipcc drain vmcnt before every ds_read)
   __shared__ __attribute__((aligned(16))) char lds[kFbSlots * kFbSlotBytes + 4 * 16 * kFbRedStride * 4 + (FIN ? 2 * 2 * 512 : 0)];
@@ -640,7 +720,7 @@ __global__ __launch_bounds__(256) void fde_scan_batch2_kernel(ScanBatchArgs a) {
   const int p = lane & 15, g = lane >> 4;
   const int G = gridDim.x, b = blockIdx.x;
   const int n_my = (a.n_tiles - b + G - 1) / G;  // tiles b, b + G, ...  (grid <= n_tiles)
-  const uint32_t row_bytes = E4 ? (uint32_t)a.out_dim : (uint32_t)a.out_dim * 2u;
+  const uint32_t row_bytes = F4 ? (uint32_t)a.out_dim >> 1 : (E4 ? (uint32_t)a.out_dim : (uint32_t)a.out_dim * 2u);
   uint32_t src_off[8];  // see fde_scan_batch_kernel
   uint32_t rd_off[2];
 #pragma unroll
@@ -651,8 +731,8 @@ __global__ __launch_bounds__(256) void fde_scan_batch2_kernel(ScanBatchArgs a) {
 #pragma unroll
   for (int e = 0; e < 2; ++e)  // bf16: the wave's dims [64 w, 64 w + 64) of the slot's 256 in two K = 32 operands; E4: its codes [128 w, 128 w + 128) of 512 in one
     rd_off[e] = (uint32_t)p * 512u + (((uint32_t)(E4 ? wave * 8 + g * 2 + e : (2 * wave + e) * 4 + g) ^ (uint32_t)p) << 4);
-  fb_phase<NQT, LO, 2, FIN, E4>(a, lds, red, lane, wave, 0, n_my / 2, src_off, rd_off);
-  fb_phase<NQT, LO, 1, FIN, E4>(a, lds, red, lane, wave, (n_my / 2) * 2, n_my & 1, src_off, rd_off);
+  fb_phase<NQT, LO, 2, FIN, E4, F4>(a, lds, red, lane, wave, 0, n_my / 2, src_off, rd_off);
+  fb_phase<NQT, LO, 1, FIN, E4, F4>(a, lds, red, lane, wave, (n_my / 2) * 2, n_my & 1, src_off, rd_off);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -757,6 +837,12 @@ __global__ __launch_bounds__(256) void fde_batch_finish_hist_kernel(float* score
 
 bool fde_scan_batch_supported(int64_t out_dim) { return out_dim >= 1024 && out_dim <= 65536 && out_dim % 1024 == 0; }
 bool fde_scan_batch8_supported(int64_t out_dim) { return out_dim >= 2048 && out_dim <= 65536 && out_dim % 2048 == 0; }  // whole groups of four 512-code chunks
+// FP4 copy: 1024-code chunks, their count padded to a multiple of four -- supported where the padding reads at most a quarter more (10 240: 12 for 10)
+bool fde_scan_batch4_supported(int64_t out_dim) {
+  if (out_dim < 4096 || out_dim > 65536 || out_dim % 1024) return false;
+  const int64_t kc = out_dim / 1024, kcp = (kc + 3) & ~(int64_t)3;
+  return kcp * 4 <= kc * 5;
+}
 size_t fde_scan_batch_image_bytes(int64_t out_dim) { return (size_t)(out_dim / 256) * 16384 * 2; }  // two query tiles
 
 int launch_fde_scan_batch(const FdeScanBatchArgs& a, hipStream_t s) {
@@ -770,6 +856,27 @@ int launch_fde_scan_batch(const FdeScanBatchArgs& a, hipStream_t s) {
   }
   const int KC = (int)(a.out_dim / 256);
   const int nqt = a.n_queries > 16 ? 2 : 1;
+  if (fde_scan_batch_uses_e4m3(a) && a.copy_fp4) {
+    // the FP4 copy of the slab: a quarter of the bytes per page (+ the padding chunks); factors and tombstones as in the e4m3 form
+    const int kcp = (int)(((a.out_dim / 1024) + 3) & ~(int64_t)3);
+    hipLaunchKernelGGL(fde_batch_qscale4_kernel, dim3(kFdeBatchMaxQueries), dim3(256), 0, s, a.q, a.n_queries, (int)a.out_dim, a.qfac);
+    hipLaunchKernelGGL(fde_batch_qprep4_kernel, dim3((unsigned)(kcp * nqt)), dim3(256), 0, s, a.q, (const float*)a.qfac, a.n_queries, (int)a.out_dim, kcp, nqt,
+                       reinterpret_cast<uint8_t*>(a.image));
+    const int64_t n_tiles4 = (a.n + kFbPages - 1) / kFbPages;
+    ScanBatchArgs k4{reinterpret_cast<const char*>(a.fde8), reinterpret_cast<const char*>(a.image), a.scores, a.score_stride, a.n,
+                     (int32_t)a.out_dim, a.n_queries, (int32_t)n_tiles4, a.fde8_fac, a.doc_ord, a.qfac};
+    const dim3 grid4((unsigned)std::min<int64_t>(n_tiles4, ncu));
+    if (a.hi_only) {
+      if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch2_kernel<1, false, true, true, true>), grid4, dim3(256), 0, s, k4);
+      else hipLaunchKernelGGL((fde_scan_batch2_kernel<2, false, true, true, true>), grid4, dim3(256), 0, s, k4);
+    } else if (nqt == 1) hipLaunchKernelGGL((fde_scan_batch2_kernel<1, true, true, true, true>), grid4, dim3(256), 0, s, k4);
+    else hipLaunchKernelGGL((fde_scan_batch2_kernel<2, true, true, true, true>), grid4, dim3(256), 0, s, k4);
+    if (a.allow && a.doc_ord)
+      hipLaunchKernelGGL(fde_batch_finish_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a.scores, a.score_stride, a.n, a.n_queries,
+                         (const float*)nullptr, a.doc_ord, a.allow, a.n_allow_bits, a.allow_stride_bits);
+    MV_HIP(hipGetLastError());
+    return MV_OK;
+  }
   if (fde_scan_batch_uses_e4m3(a)) {
     // the e4m3 copy of the slab: half the bytes per page; page factor (scale, or scale / |d|) and tombstones applied where the scores are written
     hipLaunchKernelGGL(fde_batch_qscale8_kernel, dim3(kFdeBatchMaxQueries), dim3(256), 0, s, a.q, a.n_queries, (int)a.out_dim, a.qfac);

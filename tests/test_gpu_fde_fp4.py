@@ -4,7 +4,8 @@ The reference's coarse stage is a TurboPuffer ANN query over the documents' FDE 
 approximate by contract.  What is held here: the copy is the oracle's quantisation of the bf16 rows bit for bit (orc_quantize_fde_fp4: one
 power-of-two scale per row -- half the covering one: the largest elements saturate --, round to nearest with ties to the even code, element 2i in the low nibble); the scan's scores are the fp32 dot
 products of those codes (all 16 of them pass through v_cvt_scalef32_pk_f32_fp4, in both nibbles of all four bytes of a dword); every writer of
-the FDE slab keeps the copy in step; batches of requests read the bf16 slab and answer as on an index without the copy; the pipeline's answers are
+the FDE slab keeps the copy in step; the batched pass (both MFMA operands FP4, the queries as two e2m1 terms) scores the codes against that two-term
+query; the pipeline's answers are
 those of the bf16 coarse stage wherever the candidates decide nothing (planted neighbours)."""
 import os
 import sys
@@ -118,10 +119,10 @@ def test_scan_scores_are_the_fp32_dot_products_of_the_codes(n):
     ix.close()
 
 
-def test_pipeline_on_the_fp4_coarse_stage_finds_the_planted_pages_and_batches_read_the_bf16_slab():
+def test_pipeline_on_the_fp4_coarse_stage_finds_the_planted_pages_single_and_batched():
     """Planted neighbours: both coarse stages put them among the candidates, the exact rerank returns the same ids and scores;
     MV_OPT_FDE_COARSE_SLAB switches the slab per query; coarse scores of the two slabs agree to the quantisation's few per cent of the
-    largest score; a BATCH of requests reads the bf16 slab and answers bit for bit like an index without the copy."""
+    largest score; a BATCH of requests on the fp4 copy returns the planted pages with the single request's exact scores."""
     from morphik_core_amd import _lib, synth
 
     N, stride = 3000, 64
@@ -147,12 +148,16 @@ def test_pipeline_on_the_fp4_coarse_stage_finds_the_planted_pages_and_batches_re
     assert not np.array_equal(c4, c16)
     np.testing.assert_allclose(c4, c16, rtol=0, atol=6e-2 * float(np.abs(c16).max()))
     assert float(np.corrcoef(c4, c16)[0, 1]) > 0.98
+    # a batch: the batched pass reads the fp4 copy too (both MFMA operands FP4); the planted query's answer is the single query's, and with
+    # MV_OPT_FDE_COARSE_SLAB 0 the batch reads the bf16 slab and answers bit for bit like an index without the copy
     qs = [q] + [orc.synth_rows(4321, j, 0, 32) for j in range(1, 6)]
+    sb, ib = ix.query_batch(qs, 10, mode="fde_then_float")[0]
+    assert ib.tolist() == planted and sb.tolist() == s4.tolist()
+    ix.set_option(_lib.MV_OPT_FDE_COARSE_SLAB, 0)
     got = ix.query_batch(qs, 10, mode="fde_then_float")
     want = plain.query_batch(qs, 10, mode="fde_then_float")
     for (gs, gi), (ws, wi) in zip(got, want):
         assert gi.tolist() == wi.tolist() and np.array_equal(gs, ws)
-    assert got[0][1].tolist() == planted
     ix.close()
     plain.close()
 
@@ -182,6 +187,103 @@ def test_recall_of_the_fp4_coarse_stage_on_hard_negatives_is_close_to_the_bf16_s
             kept[slab] += len(truth & cand)
     assert kept[0] >= 0.95 * 10 * NQ
     assert kept[2] >= kept[0] - 3, kept
+    ix.close()
+
+
+def _two_term_fp4_query(qf):
+    """numpy restatement of fde_batch_qscale4 / qprep4: one power-of-two scale s per query (the smallest with 6 s >= max|x|), hi = fp4(x / s),
+    lo = fp4(4 (x / s - hi)) -> the fp64 vector the batched pass multiplies: (hi + lo / 4) s"""
+    qf = np.asarray(qf, np.float32)
+    amax = np.float32(np.abs(qf).max())
+    if amax == 0:
+        return qf.astype(np.float64)
+    bits = int(np.array([amax], np.float32).view(np.uint32)[0])
+    e0, mant = ((bits >> 23) & 0xFF) - 127, bits & 0x7FFFFF
+    e = e0 - 2 if mant <= 0x400000 else e0 - 1
+    x = (qf * np.float32(2.0) ** np.float32(-e)).astype(np.float32)
+    enc = np.vectorize(lambda v: orc.lib().orc_fp4_decode(orc.lib().orc_fp4_encode(float(v))), otypes=[np.float32])
+    hi = enc(x)
+    lo = enc(((x - hi) * np.float32(4.0)).astype(np.float32))
+    return (hi.astype(np.float64) + lo.astype(np.float64) / 4.0) * 2.0 ** e
+
+
+@pytest.mark.parametrize("n,B", [(40, 5), (64, 16), (129, 20), (3000, 32), (70_001, 9)])
+def test_batched_pass_on_the_fp4_copy_scores_the_codes_against_two_term_fp4_queries(n, B):
+    """mv_query_topk_batch(mode "fde") on an index with the fp4 copy: ONE pass over the copy per 32 requests, both MFMA operands FP4
+    (v_mfma_scale_f32_16x16x128_f8f6f4; queries as two e2m1 terms under one scale, the second at a block scale of 1/4; the chunk count padded from
+    10 to 12 with zero query fragments).  Every returned score is the fp64 dot product of the page's codes with the query's two-term value times
+    scale / |d| (to fp32 accumulation accuracy); the ranking is that model's; tombstones, a shared filter and per-request filters hold; corpus
+    sizes around the 64-page tile, one and two query tiles."""
+    from morphik_core_amd import _lib
+    from morphik_core_amd.index import allow_bitmap
+
+    ix = _idx(capacity_pages=n, stride_rows=16, with_float=False, with_fde=True, with_fde_fp4=True)
+    od = ix.fde_config.output_dim
+    ix.fill_synthetic(1234, 0, n, pages_per_doc=3)
+    ix.remove_doc(1)
+    rng = np.random.default_rng(n + B)
+    qfdes = (rng.standard_normal((B, od)) * rng.uniform(0.01, 30.0, size=(B, 1))).astype(np.float32)
+    qfdes[B - 1, : od // 2] = 0.0
+    queries = [orc.synth_rows(4321, b, 0, 8) for b in range(B)]
+    m = min(n, 4000)  # the model is checked on the first m pages (a doc filter keeps the answers inside them)
+    codes, scale = ix.read_fde_fp4(0, m)
+    deq = orc.fp4_decode(codes).astype(np.float64)
+    norms = np.linalg.norm(ix.read_fde(0, m).astype(np.float64), axis=1)
+    n_docs = (n + 2) // 3
+    docs_m = [d for d in range((m + 2) // 3) if d != 1 and (d + 1) * 3 <= m]
+    shared = allow_bitmap(docs_m, n_docs)
+    per_req = [allow_bitmap([d for d in docs_m if (d + b) % 4 != 0], n_docs) for b in range(B)]
+    q2 = [_two_term_fp4_query(qfdes[b]) for b in range(B)]
+    k = 25
+    for cosine in (1, 0):
+        ix.set_option(_lib.MV_OPT_FDE_COSINE, cosine)
+        fac = scale.astype(np.float64) / (norms if cosine else 1.0)
+        for kind in ("shared", "per_request"):
+            kw = dict(allow=shared) if kind == "shared" else dict(allows=per_req, n_docs=n_docs)
+            got = ix.query_batch(queries, k, mode="fde", q_fdes=qfdes, **kw)
+            for b in range(B):
+                want = (deq @ q2[b]) * fac
+                ok_docs = set(docs_m) if kind == "shared" else {d for d in docs_m if (d + b) % 4 != 0}
+                live = np.array([p for p in range(m) if p // 3 in ok_docs], np.int64)
+                s, i = got[b]
+                assert len(i) == min(k, live.size) and set(i.tolist()) <= set(live.tolist())
+                tol = 3e-5 * float(np.abs(want[live]).max()) + 1e-30
+                np.testing.assert_allclose(s, want[i], rtol=0, atol=tol)
+                assert float(s.min()) >= float(np.sort(want[live])[-len(i)]) - 2 * tol  # nothing better was left out
+    # the same batch through the bf16 slab: other scores, (nearly) the same candidates
+    ix.set_option(_lib.MV_OPT_FDE_COARSE_SLAB, 0)
+    got16 = ix.query_batch(queries, k, mode="fde", q_fdes=qfdes, allow=shared)
+    ix.set_option(_lib.MV_OPT_FDE_COARSE_SLAB, 2)
+    got4 = ix.query_batch(queries, k, mode="fde", q_fdes=qfdes, allow=shared)
+    overlap = np.mean([len(set(a[1].tolist()) & set(b[1].tolist())) / max(len(a[1]), 1) for a, b in zip(got16, got4)])
+    assert overlap >= 0.6
+    ix.close()
+
+
+def test_batched_pipeline_on_the_fp4_copy_and_its_placement_trial():
+    """fde_then_float batches on the fp4 coarse pass: planted neighbours come back with the exact scores of the single query; the placement
+    trial moves the fp4 copy (the slab the pass reads) and changes nothing."""
+    from morphik_core_amd import synth
+
+    N, stride, B = 5000, 32, 12
+    qs = [orc.synth_rows(4321, j, 0, 16) for j in range(B)]
+    ix = _idx(capacity_pages=N, stride_rows=stride, with_fde=True, with_fde_fp4=True)
+    ix.fill_synthetic(1234, 0, N)
+    spec = synth.planted_spec(qs, N, stride, n_ranks=10)
+    for (_, _, p, row0, rows) in spec:
+        page = ix.read_pages(p, 1)[0]
+        page[row0 : row0 + rows.shape[0]] = rows
+        ix.replace_page(p, page)
+    want = [ix.query(q, 10, mode="fde_then_float") for q in qs]
+    got = ix.query_batch(qs, 10, mode="fde_then_float")
+    for qi, ((ws, wi), (s, i)) in enumerate(zip(want, got)):
+        assert i.tolist() == wi.tolist() == [p for (qq, _r, p, _a, _b) in spec if qq == qi] and s.tolist() == ws.tolist()
+    codes0 = ix.read_fde_fp4(0, N)[0]
+    before, after, moves = ix.fde_placement_trial(2)
+    assert before > 0 and after > 0 and 0 <= moves <= 2
+    assert np.array_equal(ix.read_fde_fp4(0, N)[0], codes0)
+    for (ws, wi), (s, i) in zip(want, ix.query_batch(qs, 10, mode="fde_then_float")):
+        assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist()
     ix.close()
 
 
