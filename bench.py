@@ -479,6 +479,7 @@ def full_shard(args, device, qs):
     ix.set_option(L.MV_OPT_FDE_COARSE_SLAB, 2)
     t = timed_mode(ix, qs, "fde")
     res["fde_coarse_scan_fp4"] = dict(scan_entry(n, 5120, t["coarse_ms"]), query_encode_ms=round(t["encode_ms"], 4), request_device_ms=round(t["total_device_ms"], 4))
+    res["fde_fp4_then_fp8_rerank"] = fde_pipeline_timings(ix, qs, n, (75,), bytes_per_page=5120)  # 32 requests per pass: both MFMA operands FP4, 12 chunks read for 10
     ix.close()
     return res
 
@@ -582,11 +583,10 @@ def exact_shard(args, device, n, n_truth, budget, split, sets, truths, gaps):
     # ---- the same pipeline with the coarse stage on the e4m3 copy of the FDE slab (round 6)
     ix.set_option(L.MV_OPT_FDE_COARSE_SLAB, 1)
     res["fde_e4m3_coarse_then_exact_rerank"] = fde_pipeline_timings(ix, qs, n, (75,), bytes_per_page=10240)
-    # ---- ... and on the fp4 copy (single requests; a batch reads the bf16 slab whatever the option says)
+    # ---- ... and on the fp4 copy (single requests: the conversion scan of mv_fde4.hip; batches: the FP4 x FP4 MFMA form of the batched pass)
     ix.set_option(L.MV_OPT_FDE_COARSE_SLAB, 2)
     ix.set_option(L.MV_OPT_FDE_COARSE_N, 75)
-    t4 = timed_mode(ix, qs, "fde_then_float", n_timed=12)
-    res["fde_fp4_coarse_then_exact_rerank"] = {"coarse75": {"one_request": {"device_ms": round(t4["total_device_ms"], 4), "stage_ms": {k_: round(t4[k_], 4) for k_ in ("encode_ms", "coarse_ms", "select_ms", "rerank_ms", "topk_ms")}}}}
+    res["fde_fp4_coarse_then_exact_rerank"] = fde_pipeline_timings(ix, qs, n, (75,), bytes_per_page=5120)
     ix.set_option(L.MV_OPT_FDE_COARSE_SLAB, 0)
     # ---- configs[4]: e4m3 scan of every page -> top-128 -> exact re-score out of the pinned-host tier
     base = timed_mode(ix, qs, "float_fp8")
@@ -964,6 +964,7 @@ def aux_summary(out, aux):
         "fde8_75_recall_hard": g("exact_shard", "recall_at_10_vs_exact_bf16", "hard_negatives", "fde_e4m3_top75_then_exact"),
         "fde4_scan_frac": g("full_shard", "fde_coarse_scan_fp4", "frac_hbm_8TBps"),
         "fde4_request_ms": g("exact_shard", "fde_fp4_coarse_then_exact_rerank", "coarse75", "one_request", "device_ms"),
+        "fde4_batch32_ms": g("full_shard", "fde_fp4_then_fp8_rerank", "coarse75", "batch_of_32", "device_ms_per_batch"),
         "fde4_75_recall_hard": g("exact_shard", "recall_at_10_vs_exact_bf16", "hard_negatives", "fde_fp4_top75_then_exact"),
         "fde_batch32_exact_ms": g("exact_shard", "fde_then_exact_rerank", "coarse1000", "batch_of_32", "device_ms_per_batch"),
         "hot_pages_batch32_ms": [g("exact_shard", "hot_pages_in_hbm", "batch_of_32_device_ms", "train_before"), g("exact_shard", "hot_pages_in_hbm", "batch_of_32_device_ms", "train_after"),

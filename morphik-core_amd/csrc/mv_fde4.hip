@@ -18,7 +18,7 @@
 // slots (nt LDS-DMA) and keeps the whole fp32 query FDE in registers (160 VGPRs at the reference's width).  A lane reads back the 16
 // bytes it requested (32 codes), converts them two at a time with v_cvt_scalef32_pk_f32_fp4 and multiplies in fp32 with packed FMAs:
 // 16 conversions + 16 v_pk_fma_f32 per 16 bytes.  The query stays fp32: only the documents are quantised.
-// Batches of requests keep reading the bf16 slab (the batched pass, mv_fde_batch.hip): this copy serves the single-request path.
+// Batches of requests read the same codes through the F4 form of the batched pass (mv_fde_batch.hip: both MFMA operands FP4).
 #include <algorithm>
 
 #include "mv_common.h"

@@ -610,18 +610,24 @@ __device__ __forceinline__ void fb_phase(const ScanBatchArgs& a, char* lds, floa
         // and the fragment loads wrote (the compiler's own allocation of the builtin's operands moved the fragment sets through AGPRs, and an
         // asynchronous fragment load that lands in a register the allocator has reused corrupts an address); the lo term carries its 1/4 as the B
         // block scale (E8M0 125 = 2^-2).  Accumulators in VGPRs; consecutive MFMAs on one accumulator forward srcC in hardware.
+        // (the hi terms of all 4 NQT accumulators first, then the lo terms: a dependent pair is 4 NQT instructions apart, not back to back)
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
+        for (int e = 0; e < 2; ++e) {
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int qt = 0; qt < NQT; ++qt) {
+            for (int qt = 0; qt < NQT; ++qt)
               asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4"
                            : "+v"(acc[j][t][qt]) : "v"(af[e][t]), "v"(qf[kcs][qt * 4 + 2 * e]), "v"(f4_one));
-              if (LO)
+          if (LO) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int qt = 0; qt < NQT; ++qt)
                 asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:4"
                              : "+v"(acc[j][t][qt]) : "v"(af[e][t]), "v"(qf[kcs][qt * 4 + 2 * e + 1]), "v"(f4_one), "v"(f4_quarter));
-            }
+          }
+        }
       } else if constexpr (E4) {
         // four K = 32 fp8 MFMAs per (page tile, query tile) and term: every 16-byte piece a lane read / loaded is two 8-byte operands, used
         // in place (the K = 128 block-scaled form wants 32 consecutive bytes per lane: building them from the ring's 16-byte registers cost

@@ -199,7 +199,8 @@ class MvIndex:
         with_fde_e4m3 (with with_fde): an e4m3 copy of the FDE slab (out_dim bytes per page) that the COARSE stage of the FDE modes reads
         instead of the bf16 slab -- half the bytes of the pass that dominates every request; set_option(MV_OPT_FDE_COARSE_SLAB, 0) goes back.
         with_fde_fp4 (with with_fde; beside or instead of with_fde_e4m3): a copy in FP4 (e2m1, one power-of-two scale per row): out_dim / 2 bytes per
-        page, read by the coarse stage of SINGLE requests (batches read the bf16 slab); MV_OPT_FDE_COARSE_SLAB 2 / 0."""
+        page, read by the coarse stage (single requests: a conversion scan with the fp32 query; batches: both MFMA operands FP4, the queries as two
+        e2m1 terms); MV_OPT_FDE_COARSE_SLAB 2 / 0."""
         self.fde_config = fde or FdeConfig()
         flags = ((MV_WITH_FLOAT if with_float else 0) | (MV_WITH_BINARY if with_binary else 0) | (MV_WITH_FDE if with_fde else 0)
                  | (MV_WITH_FP8 if with_fp8 else 0) | (MV_WITH_HOST_EXACT if with_host_exact else 0) | (MV_WITH_EXACT_SPLIT if with_exact_split else 0)

@@ -165,8 +165,8 @@ class MI355XMultiVectorStore(BaseVectorStore):
         # half the bytes of the pass that is nine tenths of a request.  The reference's coarse stage is an ANN index (approximate by contract);
         # the rerank and its scores are untouched (MV_WITH_FDE_E4M3)
         self.fde_e4m3 = bool(fde_e4m3)
-        # ... or an FP4 (e2m1) copy: out_dim / 2 bytes per page, a quarter of the bf16 slab's, read by the coarse stage of SINGLE requests (coalesced
-        # batches keep reading the bf16 slab, one pass per 32 requests).  MV_WITH_FDE_FP4; not together with fde_e4m3
+        # ... or an FP4 (e2m1) copy: out_dim / 2 bytes per page, a quarter of the bf16 slab's, read by the coarse stage of single requests and of
+        # coalesced batches (one pass per 32 requests on the FP4 matrix path).  MV_WITH_FDE_FP4; not together with fde_e4m3
         self.fde_fp4 = bool(fde_fp4)
         if self.fde_fp4 and self.fde_e4m3:
             raise ValueError("fde_e4m3 and fde_fp4 are two forms of the same copy of the FDE slab: choose one")
