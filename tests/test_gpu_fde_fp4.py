@@ -287,6 +287,49 @@ def test_batched_pipeline_on_the_fp4_copy_and_its_placement_trial():
     ix.close()
 
 
+@pytest.mark.parametrize("R", [2, 3])
+def test_shards_with_the_fp4_copy_answer_like_one_index(R):
+    """mv_comm over R shards that each hold the fp4 copy of THEIR FDE rows: a row's codes and scale do not depend on its neighbours, so the
+    staged pipeline (global candidate rule across shards) returns what one index with the copy returns -- single requests (fp32 query against
+    the codes) and batches (two-term FP4 queries, both MFMA operands FP4), coarse-only and with the exact rerank, with a doc filter."""
+    from morphik_core_amd import _lib
+    from morphik_core_amd.index import ShardComm, allow_bitmap
+
+    N, stride, k = 360, 32, 8
+    per = N // R
+    pages = _pages(N, stride, seed=21)
+    ords = [i % 13 for i in range(N)]
+    kw = dict(stride_rows=stride, with_float=True, with_fde=True, with_fde_fp4=True)
+    one = _idx(capacity_pages=N, **kw)
+    one.add(pages, doc_ordinals=ords)
+    shards = []
+    for r in range(R):
+        sh = _idx(capacity_pages=per, id_base=r * per, **kw)
+        sh.add(pages[r * per : (r + 1) * per], doc_ordinals=ords[r * per : (r + 1) * per])
+        shards.append(sh)
+    for ix in [one] + shards:
+        ix.set_option(_lib.MV_OPT_FDE_COARSE_N, 60)
+    one.remove_page(100)
+    shards[100 // per].remove_page(100 % per)
+    comm = ShardComm(shards, transport="p2p")
+    allow = allow_bitmap([0, 2, 3, 5, 7, 11, 12], 13)
+    qs = [orc.synth_rows(4321, 40 + j, 0, 14) for j in range(7)]
+    for al in (None, allow):
+        for mode in ("fde_then_float", "fde"):
+            for q in qs[:3]:
+                ws, wi = one.query(q, k, mode=mode, allow=al)
+                s, i = comm.query(q, k, mode=mode, allow=al)
+                assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist(), (mode, R)
+        want = one.query_batch(qs, k, mode="fde_then_float", allow=al)
+        got = comm.query_batch(qs, k, mode="fde_then_float", allow=al)
+        for (ws, wi), (s, i) in zip(want, got):
+            assert i.tolist() == wi.tolist() and s.tolist() == ws.tolist(), ("batch", R)
+    comm.close()
+    for sh in shards:
+        sh.close()
+    one.close()
+
+
 def test_flag_and_option_errors():
     from morphik_core_amd import _lib
     from morphik_core_amd._lib import MvError
